@@ -1,0 +1,324 @@
+"""Host-side lowering of an application's actors to the flat transition table of
+include/demi_gpu.h, plus the synthetic applications the benchmarks run.
+
+The reference schedules real Akka actors (NetSys/demi-applications: akka-raft, Spark) whose
+`receive` functions are arbitrary JVM code outside /root/reference.  On the GPU path the Scala
+adapter lowers each (actor class, message type) handler to a micro-program of guarded rows;
+`Asm` below is that lowering's assembler.
+"""
+import ctypes as C
+import json
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional
+
+import numpy as np
+
+from . import types as T
+
+
+class Reg(int):
+    """Register operand r0..r15 of a handler's 16 x u8 window."""
+    def __repr__(self):
+        return "r%d" % int(self)
+
+
+F = [Reg(i) for i in range(8)]          # receiving actor's persisted state fields
+T0, T1, T2, T3 = Reg(8), Reg(9), Reg(10), Reg(11)   # temporaries, zero at handler entry
+P0, P1 = Reg(12), Reg(13)               # message payload
+SRC, ME = Reg(14), Reg(15)              # sender id (15 = deadLetters), own id
+
+OPS = dict(HALT=0, MOV=1, ADD=2, SUB=3, AND=4, OR=5, XOR=6, SHL=7, SHR=8, BITSET=9, POPC=10,
+           EQ=11, NE=12, LT=13, GE=14, LE=15, GT=16, MIN=17, MAX=18, SKIPZ=20, SKIPNZ=21, SKIP=22,
+           SEND=24, BCAST=25, TSET=26, TREP=27, TCANCEL=28)
+
+
+def row(op, dst=0, a=0, bimm=0, aux=0, b=0):
+    assert 0 <= dst < 16 and 0 <= a < 16 and 0 <= aux < 128 and 0 <= b < 256
+    return op | (dst << 8) | (a << 12) | (bimm << 16) | (aux << 17) | (b << 24)
+
+
+class Asm:
+    """Assembler for one handler (forward-only control flow)."""
+
+    def __init__(self):
+        self.rows: List[int] = []
+        self._fix = []       # (row index, label)
+        self._labels: Dict[str, int] = {}
+
+    def _b(self, b):
+        if isinstance(b, Reg):
+            return 0, int(b)
+        assert 0 <= int(b) < 256
+        return 1, int(b)
+
+    def alu(self, name, dst, a, b):
+        assert isinstance(dst, Reg) and isinstance(a, Reg)
+        bimm, bv = self._b(b)
+        self.rows.append(row(OPS[name], int(dst), int(a), bimm, 0, bv))
+        return self
+
+    def mov(self, dst, b):
+        bimm, bv = self._b(b)
+        self.rows.append(row(OPS["MOV"], int(dst), 0, bimm, 0, bv))
+        return self
+
+    def popc(self, dst, b):
+        bimm, bv = self._b(b)
+        self.rows.append(row(OPS["POPC"], int(dst), 0, bimm, 0, bv))
+        return self
+
+    def _skip(self, name, a, label):
+        self._fix.append((len(self.rows), label))
+        self.rows.append(row(OPS[name], 0, int(a), 1, 0, 0))
+        return self
+
+    def skipz(self, a, label):
+        return self._skip("SKIPZ", a, label)
+
+    def skipnz(self, a, label):
+        return self._skip("SKIPNZ", a, label)
+
+    def skip(self, label):
+        return self._skip("SKIP", Reg(0), label)
+
+    def label(self, name):
+        assert name not in self._labels
+        self._labels[name] = len(self.rows)
+        return self
+
+    def send(self, msg_type, target, p0=0, p1=0):
+        """`target ! Msg(p0, p1)`; p0 must be a register (use a temp for constants)."""
+        assert isinstance(target, Reg) and isinstance(p0, Reg)
+        bimm, bv = self._b(p1)
+        self.rows.append(row(OPS["SEND"], int(p0), int(target), bimm, msg_type, bv))
+        return self
+
+    def bcast(self, msg_type, p0, p1=0):
+        assert isinstance(p0, Reg)
+        bimm, bv = self._b(p1)
+        self.rows.append(row(OPS["BCAST"], int(p0), 0, bimm, msg_type, bv))
+        return self
+
+    def tset(self, msg_type):
+        self.rows.append(row(OPS["TSET"], 0, 0, 1, msg_type, 0))
+        return self
+
+    def trep(self, msg_type):
+        self.rows.append(row(OPS["TREP"], 0, 0, 1, msg_type, 0))
+        return self
+
+    def tcancel(self, msg_type):
+        self.rows.append(row(OPS["TCANCEL"], 0, 0, 1, msg_type, 0))
+        return self
+
+    def halt(self):
+        self.rows.append(row(OPS["HALT"]))
+        return self
+
+    def finish(self) -> List[int]:
+        if not self.rows or (self.rows[-1] & 0xFF) != OPS["HALT"]:
+            self.halt()
+        for idx, label in self._fix:
+            dist = self._labels[label] - (idx + 1)
+            assert 0 <= dist < 256, "skip must be forward, < 256 rows"
+            self.rows[idx] |= dist << 24
+        return self.rows
+
+
+for _n in ("ADD", "SUB", "AND", "OR", "XOR", "SHL", "SHR", "BITSET", "EQ", "NE", "LT", "GE", "LE", "GT",
+           "MIN", "MAX"):
+    def _mk(n):
+        def f(self, dst, a, b):
+            return self.alu(n, dst, a, b)
+        return f
+    setattr(Asm, _n.lower() if _n not in ("AND", "OR") else _n.lower() + "_", _mk(_n))
+
+
+@dataclass
+class Model:
+    """The application lowered to a table (demi_model)."""
+    name: str
+    n_actors: int
+    msg_names: List[str]
+    msg_class: List[int]
+    actor_class: List[int]
+    n_classes: int
+    handler_start: List[int]          # [n_classes * n_msg_types]
+    code: List[int]
+    init_state: List[int]             # u64 per actor
+    inv_kind: int = T.INV_NONE
+    inv_fa: int = 0
+    inv_va: int = 0
+    inv_fb: int = 0
+    fp_match_mask: int = 0xFFFFFFFF
+    _keep: list = field(default_factory=list, repr=False, compare=False)
+
+    @property
+    def n_msg_types(self):
+        return len(self.msg_names)
+
+    def to_struct(self) -> T.ModelStruct:
+        mc = (C.c_uint8 * len(self.msg_class))(*self.msg_class)
+        ac = (C.c_uint8 * len(self.actor_class))(*self.actor_class)
+        hs = (C.c_uint16 * len(self.handler_start))(*self.handler_start)
+        code = (C.c_uint32 * len(self.code))(*self.code)
+        init = (C.c_uint64 * len(self.init_state))(*self.init_state)
+        s = T.ModelStruct(self.n_actors, self.n_msg_types, self.n_classes, len(self.code),
+                          C.cast(mc, C.POINTER(C.c_uint8)), C.cast(ac, C.POINTER(C.c_uint8)),
+                          C.cast(hs, C.POINTER(C.c_uint16)), C.cast(code, C.POINTER(C.c_uint32)),
+                          C.cast(init, C.POINTER(C.c_uint64)),
+                          self.inv_kind, self.inv_fa, self.inv_va, self.inv_fb, self.fp_match_mask)
+        self._keep = [mc, ac, hs, code, init]   # keep the buffers alive as long as the Model
+        return s
+
+    def to_json(self) -> dict:
+        d = {k: getattr(self, k) for k in ("name", "n_actors", "msg_names", "msg_class", "actor_class",
+                                            "n_classes", "handler_start", "code", "init_state", "inv_kind",
+                                            "inv_fa", "inv_va", "inv_fb", "fp_match_mask")}
+        return d
+
+    @staticmethod
+    def from_json(d: dict) -> "Model":
+        return Model(**d)
+
+
+def pack_state(fields: List[int]) -> int:
+    assert len(fields) <= 8
+    s = 0
+    for i, v in enumerate(fields):
+        assert 0 <= v < 256
+        s |= v << (8 * i)
+    return s
+
+
+def build_model(name, n_actors, msgs, handlers, init_fields, invariant, actor_class=None, n_classes=1,
+                fp_match_mask=0xFFFFFFFF) -> Model:
+    """msgs: list of (name, class); handlers: {(actor_class, msg name): Asm}."""
+    names = [m[0] for m in msgs]
+    code: List[int] = []
+    hs = [0xFFFF] * (n_classes * len(msgs))
+    for (cls, mname), asm in handlers.items():
+        hs[cls * len(msgs) + names.index(mname)] = len(code)
+        code.extend(asm.finish())
+    if not code:
+        code = [row(OPS["HALT"])]
+    inv_kind, fa, va, fb = invariant
+    return Model(name=name, n_actors=n_actors, msg_names=names, msg_class=[m[1] for m in msgs],
+                 actor_class=list(actor_class or [0] * n_actors), n_classes=n_classes, handler_start=hs,
+                 code=code, init_state=[pack_state(f) for f in init_fields],
+                 inv_kind=inv_kind, inv_fa=fa, inv_va=va, inv_fb=fb, fp_match_mask=fp_match_mask)
+
+
+# --------------------------------------------------------------------------- raft-synth
+# Raft-like leader election + log replication with one seeded protocol bug, standing in for
+# akka-raft (NetSys/demi-applications, branches raft-45 ... raft-66), which is not in the reference.
+ROLE, TERM, VOTED, VOTES, BUDGET, LOGLEN, COMMIT, BOOTED = F
+FOLLOWER, CANDIDATE, LEADER = 0, 1, 2
+NOBODY = 0xFF
+
+RAFT_MSGS = [("Bootstrap", T.MSG_EXTERNAL), ("ClientCommand", T.MSG_EXTERNAL),
+             ("ElectionTimeout", T.MSG_TIMER), ("RequestVote", T.MSG_INTERNAL),
+             ("VoteReply", T.MSG_INTERNAL), ("AppendEntries", T.MSG_INTERNAL),
+             ("AppendReply", T.MSG_INTERNAL), ("Heartbeat", T.MSG_TIMER)]
+(M_BOOTSTRAP, M_CLIENT, M_ELECTION_TIMEOUT, M_REQUEST_VOTE, M_VOTE_REPLY, M_APPEND_ENTRIES,
+ M_APPEND_REPLY, M_HEARTBEAT) = range(8)
+
+
+def raft_model(n_actors=5, election_budget=1, buggy=True) -> Model:
+    majority = n_actors // 2 + 1
+    h = {}
+
+    # Bootstrap (the ChangeConfiguration the DEMi raft runner Sends after Start): begin as follower.
+    a = Asm()
+    a.skipnz(BOOTED, "done").mov(BOOTED, 1).tset(M_ELECTION_TIMEOUT).label("done")
+    h[(0, "Bootstrap")] = a
+
+    # ClientCommand: a leader appends and replicates; everyone else ignores it.
+    a = Asm()
+    a.eq(T0, ROLE, LEADER).skipz(T0, "done")
+    a.add(LOGLEN, LOGLEN, 1).bcast(M_APPEND_ENTRIES, TERM, LOGLEN).label("done")
+    h[(0, "ClientCommand")] = a
+
+    # ElectionTimeout: start an election (bounded number per node so that executions quiesce).
+    a = Asm()
+    a.eq(T0, ROLE, LEADER).skipnz(T0, "done")
+    a.eq(T0, BUDGET, 0).skipnz(T0, "done")
+    a.sub(BUDGET, BUDGET, 1).mov(ROLE, CANDIDATE).add(TERM, TERM, 1).mov(VOTED, ME)
+    a.mov(VOTES, 0).bitset(VOTES, VOTES, ME)
+    a.bcast(M_REQUEST_VOTE, TERM, 0).tset(M_ELECTION_TIMEOUT).label("done")
+    h[(0, "ElectionTimeout")] = a
+
+    # RequestVote(term) from SRC.
+    a = Asm()
+    a.gt(T0, P0, TERM).skipz(T0, "same")
+    a.eq(T1, ROLE, LEADER).skipz(T1, "nl").tcancel(M_HEARTBEAT).label("nl")
+    a.mov(TERM, P0).mov(ROLE, FOLLOWER).mov(VOTED, NOBODY)
+    a.label("same")
+    a.eq(T0, P0, TERM)
+    a.eq(T1, VOTED, NOBODY).eq(T2, VOTED, SRC).or_(T1, T1, T2)
+    if buggy:
+        # seeded bug: a candidate forgets its own vote when its right-hand neighbour (id + 1)
+        # asks for a vote in the same term -> two leaders can be elected in one term
+        a.eq(T2, ROLE, CANDIDATE).sub(T3, SRC, 1).eq(T3, T3, ME).and_(T2, T2, T3).or_(T1, T1, T2)
+    a.and_(T0, T0, T1).skipz(T0, "deny")
+    a.mov(VOTED, SRC).tcancel(M_ELECTION_TIMEOUT).tset(M_ELECTION_TIMEOUT)
+    a.mov(T3, 1).send(M_VOTE_REPLY, SRC, TERM, T3).halt()
+    a.label("deny").send(M_VOTE_REPLY, SRC, TERM, 0)
+    h[(0, "RequestVote")] = a
+
+    # VoteReply(term, granted) from SRC.
+    a = Asm()
+    a.gt(T0, P0, TERM).skipz(T0, "cur")
+    a.eq(T1, ROLE, LEADER).skipz(T1, "nl").tcancel(M_HEARTBEAT).label("nl")
+    a.mov(TERM, P0).mov(ROLE, FOLLOWER).mov(VOTED, NOBODY).halt()
+    a.label("cur")
+    a.eq(T0, ROLE, CANDIDATE).eq(T1, P0, TERM).and_(T0, T0, T1).and_(T0, T0, P1).skipz(T0, "done")
+    a.bitset(VOTES, VOTES, SRC).popc(T1, VOTES).ge(T1, T1, majority).skipz(T1, "done")
+    a.mov(ROLE, LEADER).tcancel(M_ELECTION_TIMEOUT).trep(M_HEARTBEAT)
+    a.bcast(M_APPEND_ENTRIES, TERM, LOGLEN).label("done")
+    h[(0, "VoteReply")] = a
+
+    # AppendEntries(term, loglen) from SRC.
+    a = Asm()
+    a.lt(T0, P0, TERM).skipz(T0, "ok").send(M_APPEND_REPLY, SRC, TERM, 0).halt()
+    a.label("ok")
+    a.gt(T0, P0, TERM).skipz(T0, "sameterm").mov(VOTED, NOBODY).label("sameterm")
+    a.gt(T0, P0, TERM).ne(T1, ROLE, LEADER).or_(T0, T0, T1).skipz(T0, "keep")
+    a.eq(T1, ROLE, LEADER).skipz(T1, "nl").tcancel(M_HEARTBEAT).label("nl")
+    a.mov(ROLE, FOLLOWER)
+    a.label("keep")
+    a.mov(TERM, P0).max(LOGLEN, LOGLEN, P1)
+    a.tcancel(M_ELECTION_TIMEOUT).tset(M_ELECTION_TIMEOUT)
+    a.send(M_APPEND_REPLY, SRC, TERM, P1)
+    h[(0, "AppendEntries")] = a
+
+    # AppendReply(term, acked) from SRC.
+    a = Asm()
+    a.gt(T0, P0, TERM).skipz(T0, "cur")
+    a.eq(T1, ROLE, LEADER).skipz(T1, "nl").tcancel(M_HEARTBEAT).label("nl")
+    a.mov(TERM, P0).mov(ROLE, FOLLOWER).mov(VOTED, NOBODY).halt()
+    a.label("cur")
+    a.eq(T0, ROLE, LEADER).eq(T1, P0, TERM).and_(T0, T0, T1).skipz(T0, "done")
+    a.max(COMMIT, COMMIT, P1).label("done")
+    h[(0, "AppendReply")] = a
+
+    # Heartbeat (repeating timer): a leader re-sends uncommitted entries.
+    a = Asm()
+    a.eq(T0, ROLE, LEADER).skipnz(T0, "lead").tcancel(M_HEARTBEAT).halt()
+    a.label("lead").gt(T0, LOGLEN, COMMIT).skipz(T0, "done")
+    a.bcast(M_APPEND_ENTRIES, TERM, LOGLEN).label("done")
+    h[(0, "Heartbeat")] = a
+
+    init = [[FOLLOWER, 0, NOBODY, 0, election_budget, 0, 0, 0] for _ in range(n_actors)]
+    return build_model("raft%d-synth%s" % (n_actors, "" if buggy else "-fixed"), n_actors, RAFT_MSGS, h, init,
+                       invariant=(T.INV_AT_MOST_ONE, int(ROLE), LEADER, int(TERM)))
+
+
+def save_model(model: Model, path: str):
+    with open(path, "w") as f:
+        json.dump(model.to_json(), f)
+
+
+def load_model(path: str) -> Model:
+    with open(path) as f:
+        return Model.from_json(json.load(f))

@@ -1,0 +1,97 @@
+"""ctypes mirrors of include/demi_gpu.h (flat data formats crossing the C ABI)."""
+import ctypes as C
+
+MAX_ACTORS = 8
+DEADLETTERS = 15
+MAX_MSG_TYPES = 32
+MAX_CLASSES = 4
+MAX_CODE = 1024
+MAX_TIMER_TYPES = 4
+MAX_EXT_EVENTS = 255
+MAX_REC_EVENTS = 4096
+
+# demi_status
+OK = 0
+ERR_INVALID_ARG = -1
+ERR_INVALID_MODEL = -2
+ERR_INVALID_TRACE = -3
+ERR_NO_MODEL = -4
+ERR_NO_TRACE = -5
+ERR_DEVICE = -6
+ERR_CAPACITY = -7
+
+# demi_ext_kind  (ExternalEvents.scala:62-91)
+EV_START, EV_KILL, EV_SEND, EV_PARTITION, EV_UNPARTITION, EV_WAIT_QUIESCENCE = range(6)
+EV_NAMES = ["Start", "Kill", "Send", "Partition", "UnPartition", "WaitQuiescence"]
+
+# demi_msg_class
+MSG_INTERNAL, MSG_EXTERNAL, MSG_TIMER = 0, 1, 2
+
+# demi_inv_kind
+INV_NONE, INV_AT_MOST_ONE, INV_NEVER, INV_AGREE = 0, 1, 2, 3
+
+# verdict flags
+V_VIOLATION = 0x1
+V_MAXMSG = 0x2
+V_PENDING_OVF = 0x4
+V_QUEUE_OVF = 0x8
+V_DIVERGED = 0x10
+
+# demi_rec_kind
+(REC_SPAWN, REC_KILL, REC_PARTITION, REC_UNPARTITION, REC_BEGIN_WAIT_QUIESCENCE, REC_QUIESCENCE,
+ REC_MSG_SEND, REC_MSG_EVENT) = range(8)
+
+
+class ExtEvent(C.Structure):
+    _fields_ = [("kind", C.c_uint8), ("a", C.c_uint8), ("b", C.c_uint8), ("msg_type", C.c_uint8),
+                ("p0", C.c_uint8), ("p1", C.c_uint8), ("pad", C.c_uint8 * 2)]
+
+
+class ModelStruct(C.Structure):
+    _fields_ = [("n_actors", C.c_uint32), ("n_msg_types", C.c_uint32), ("n_classes", C.c_uint32),
+                ("code_len", C.c_uint32),
+                ("msg_class", C.POINTER(C.c_uint8)), ("actor_class", C.POINTER(C.c_uint8)),
+                ("handler_start", C.POINTER(C.c_uint16)), ("code", C.POINTER(C.c_uint32)),
+                ("init_state", C.POINTER(C.c_uint64)),
+                ("inv_kind", C.c_uint32), ("inv_fa", C.c_uint32), ("inv_va", C.c_uint32),
+                ("inv_fb", C.c_uint32), ("fp_match_mask", C.c_uint32)]
+
+
+class Limits(C.Structure):
+    _fields_ = [("max_messages", C.c_uint32), ("invariant_check_interval", C.c_uint32),
+                ("p_max", C.c_uint32), ("looking_for_valid", C.c_uint32), ("looking_for", C.c_uint32),
+                ("populate_all", C.c_uint32)]
+
+
+class Verdict(C.Structure):
+    _fields_ = [("flags", C.c_uint32), ("fingerprint", C.c_uint32), ("hash", C.c_uint64)]
+
+
+class RecEvent(C.Structure):
+    _fields_ = [("kind", C.c_uint8), ("snd", C.c_uint8), ("rcv", C.c_uint8), ("msg_type", C.c_uint8),
+                ("p0", C.c_uint8), ("p1", C.c_uint8), ("flags", C.c_uint8), ("ext_idx", C.c_uint8),
+                ("id", C.c_uint32)]
+
+
+assert C.sizeof(ExtEvent) == 8 and C.sizeof(Verdict) == 16 and C.sizeof(RecEvent) == 12
+
+import numpy as np  # noqa: E402
+
+VERDICT_DTYPE = np.dtype([("flags", "<u4"), ("fingerprint", "<u4"), ("hash", "<u8")])
+EXT_EVENT_DTYPE = np.dtype([("kind", "u1"), ("a", "u1"), ("b", "u1"), ("msg_type", "u1"),
+                            ("p0", "u1"), ("p1", "u1"), ("pad", "u1", (2,))])
+REC_EVENT_DTYPE = np.dtype([("kind", "u1"), ("snd", "u1"), ("rcv", "u1"), ("msg_type", "u1"),
+                            ("p0", "u1"), ("p1", "u1"), ("flags", "u1"), ("ext_idx", "u1"), ("id", "<u4")])
+assert VERDICT_DTYPE.itemsize == 16 and EXT_EVENT_DTYPE.itemsize == 8 and REC_EVENT_DTYPE.itemsize == 12
+
+
+def verdict_violation(flags):
+    return (flags & V_VIOLATION) != 0
+
+
+def verdict_deliveries(flags):
+    return (flags >> 16) & 0xFFFF
+
+
+def verdict_trace_idx(flags):
+    return (flags >> 8) & 0xFF

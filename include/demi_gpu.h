@@ -1,0 +1,198 @@
+/*
+ * demi_gpu.h — C ABI of libdemi_gpu.so, the MI355X schedule-exploration engine for DEMi.
+ *
+ * The reference (NetSys/demi) has no FFI: its plugin boundary is the Scala traits
+ *   trait Scheduler   (src/main/scala/verification/schedulers/Scheduler.scala:13-104)
+ *   trait TestOracle  (src/main/scala/verification/minification/TestOracle.scala:30-55)
+ * driven by RunnerUtils (src/main/scala/verification/RunnerUtils.scala:62-147, 601-707, 881-911).
+ * A Scala adapter class `GpuRandomScheduler extends Scheduler with TestOracle`
+ * lowers the closures of that boundary (Props, message constructors, Invariant) to the flat
+ * tables below and calls these entry points through a 1:1 JNI shim.  Every entry point names the
+ * reference method(s) it replaces.
+ *
+ * Conventions: plain C, caller-allocated buffers, `int` return (0 = ok, <0 = demi_status),
+ * no callbacks into the host from device code (the transition function and the invariant are
+ * data, not closures), one ctx per host thread, the ctx owns its device memory.
+ * Pointers named d_* are DEVICE pointers; all others are host pointers.
+ */
+#ifndef DEMI_GPU_H
+#define DEMI_GPU_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ limits */
+#define DEMI_MAX_ACTORS      8      /* actor ids 0..7 */
+#define DEMI_DEADLETTERS     15     /* sender id of externals and timers ("deadLetters") */
+#define DEMI_MAX_MSG_TYPES   32
+#define DEMI_MAX_CLASSES     4
+#define DEMI_MAX_CODE        1024   /* delta-table rows */
+#define DEMI_MAX_TIMER_TYPES 4      /* timer-class message types per model */
+#define DEMI_MAX_EXT_EVENTS  255    /* external events per trace */
+#define DEMI_TQ_CAP          8      /* messagesToSend timers between two scheduling steps */
+#define DEMI_RESEND_CAP      8      /* timersToResend */
+#define DEMI_MAX_REC_EVENTS  4096   /* recorded events of one execution */
+
+/* ------------------------------------------------------------------ status */
+typedef enum {
+  DEMI_OK = 0,
+  DEMI_ERR_INVALID_ARG = -1,
+  DEMI_ERR_INVALID_MODEL = -2,   /* model rejected by validation (see demi_last_error) */
+  DEMI_ERR_INVALID_TRACE = -3,   /* e.g. WaitCondition / CodeBlock / HardKill: JVM fallback */
+  DEMI_ERR_NO_MODEL = -4,        /* IllegalArgumentException("Must invoke setInvariant...") analogue */
+  DEMI_ERR_NO_TRACE = -5,
+  DEMI_ERR_DEVICE = -6,          /* HIP runtime error */
+  DEMI_ERR_CAPACITY = -7         /* caller buffer too small */
+} demi_status;
+
+/* ------------------------------------------------------ external events
+ * ExternalEvent ADT, src/main/scala/verification/ExternalEvents.scala:62-91.          */
+typedef enum {
+  DEMI_EV_START = 0,            /* Start(propCtor, name)       a = actor            */
+  DEMI_EV_KILL = 1,             /* Kill(name)                  a = actor            */
+  DEMI_EV_SEND = 2,             /* Send(name, messageCtor)     a = receiver, msg    */
+  DEMI_EV_PARTITION = 3,        /* Partition(a, b)                                  */
+  DEMI_EV_UNPARTITION = 4,      /* UnPartition(a, b)                                */
+  DEMI_EV_WAIT_QUIESCENCE = 5   /* WaitQuiescence()                                 */
+  /* WaitCondition, CodeBlock, HardKill are closures / real actor stops: rejected.   */
+} demi_ext_kind;
+
+typedef struct {
+  uint8_t kind;       /* demi_ext_kind */
+  uint8_t a, b;       /* actors */
+  uint8_t msg_type;   /* SEND: message type (class EXTERNAL) */
+  uint8_t p0, p1;     /* SEND: payload */
+  uint8_t pad[2];
+} demi_ext_event;     /* 8 bytes */
+
+/* ------------------------------------------------------ transition table
+ * The application's actors (NOT in the reference: NetSys/demi-applications) lowered to
+ * a table: one micro-program ("handler") per (actor class, message type), each row one
+ * guarded micro-op over a 16 x u8 register window:
+ *   r0..r7  = the receiving actor's state fields F0..F7 (persisted across deliveries)
+ *   r8..r11 = temporaries T0..T3 (zero at handler entry)
+ *   r12,r13 = message payload P0,P1     r14 = sender id (15 = deadLetters)   r15 = own id
+ * Row word: op[7:0] | dst[11:8] | a[15:12] | bimm[16] | aux[23:17] | b[31:24]
+ *   (bimm=1: b is an 8-bit immediate, else b[3:0] is a register).  All arithmetic mod 256,
+ *   comparisons unsigned.  Control flow is forward-only (SKIP*), so a handler terminates.   */
+typedef enum {
+  DEMI_OP_HALT = 0,
+  DEMI_OP_MOV = 1,  DEMI_OP_ADD = 2,  DEMI_OP_SUB = 3,  DEMI_OP_AND = 4,  DEMI_OP_OR = 5,
+  DEMI_OP_XOR = 6,  DEMI_OP_SHL = 7,  DEMI_OP_SHR = 8,  DEMI_OP_BITSET = 9, /* dst = a | 1<<(b&7) */
+  DEMI_OP_POPC = 10, /* dst = popcount(b) */
+  DEMI_OP_EQ = 11,  DEMI_OP_NE = 12,  DEMI_OP_LT = 13,  DEMI_OP_GE = 14,  DEMI_OP_LE = 15,
+  DEMI_OP_GT = 16,  DEMI_OP_MIN = 17, DEMI_OP_MAX = 18,
+  DEMI_OP_SKIPZ = 20,   /* if reg a == 0 skip the next b rows  (b immediate) */
+  DEMI_OP_SKIPNZ = 21,  /* if reg a != 0 skip the next b rows */
+  DEMI_OP_SKIP = 22,    /* skip the next b rows */
+  DEMI_OP_SEND = 24,    /* `target ! msg`: type = aux, target = reg a, p0 = reg dst, p1 = b    */
+  DEMI_OP_BCAST = 25,   /* SEND to every other created actor, ascending id: p0 = reg dst, p1 = b */
+  DEMI_OP_TSET = 26,    /* scheduler.scheduleOnce(self, msg type aux)                          */
+  DEMI_OP_TREP = 27,    /* scheduler.schedule(self, msg type aux)  (repeating)                 */
+  DEMI_OP_TCANCEL = 28  /* cancellable.cancel() of timer (self, type aux)                      */
+} demi_op;
+
+#define DEMI_ROW(op, dst, a, bimm, aux, b) \
+  ((uint32_t)(op) | ((uint32_t)(dst) << 8) | ((uint32_t)(a) << 12) | ((uint32_t)(bimm) << 16) | \
+   ((uint32_t)(aux) << 17) | ((uint32_t)(b) << 24))
+
+typedef enum { DEMI_MSG_INTERNAL = 0, DEMI_MSG_EXTERNAL = 1, DEMI_MSG_TIMER = 2 } demi_msg_class;
+
+/* Invariant (TestOracle.scala:9-28 `Invariant`) as a descriptor evaluated on simulated state. */
+typedef enum {
+  DEMI_INV_NONE = 0,
+  DEMI_INV_AT_MOST_ONE = 1, /* no two created actors with F[fa]==va and equal F[fb]               */
+  DEMI_INV_NEVER = 2,       /* no created actor with F[fa]==va                                     */
+  DEMI_INV_AGREE = 3        /* created actors with F[fa]!=0 agree on F[fb]                         */
+} demi_inv_kind;
+
+typedef struct {
+  uint32_t n_actors;        /* 1..DEMI_MAX_ACTORS */
+  uint32_t n_msg_types;     /* 1..DEMI_MAX_MSG_TYPES */
+  uint32_t n_classes;       /* 1..DEMI_MAX_CLASSES */
+  uint32_t code_len;        /* rows in `code` */
+  const uint8_t*  msg_class;     /* [n_msg_types] demi_msg_class */
+  const uint8_t*  actor_class;   /* [n_actors] */
+  const uint16_t* handler_start; /* [n_classes * n_msg_types] row index, 0xFFFF = message ignored */
+  const uint32_t* code;          /* [code_len] */
+  const uint64_t* init_state;    /* [n_actors] F0 in bits 0..7 ... F7 in bits 56..63 */
+  uint32_t inv_kind, inv_fa, inv_va, inv_fb;
+  uint32_t fp_match_mask;   /* ViolationFingerprint.matches: ((x ^ y) & mask) == 0 */
+} demi_model;
+
+typedef struct {
+  uint32_t max_messages;              /* RandomScheduler.setMaxMessages (RandomScheduler.scala:54-57); 0 = unbounded */
+  uint32_t invariant_check_interval;  /* RandomScheduler ctor arg (RandomScheduler.scala:43); 0 = only at the end */
+  uint32_t p_max;                     /* capacity of the pending set per schedule: 32, 64 or 128 */
+  uint32_t looking_for_valid;         /* explore(_trace, _lookingFor) (RandomScheduler.scala:234-237) */
+  uint32_t looking_for;               /* target fingerprint code */
+  uint32_t populate_all;              /* setActorNamePropPairs: create all actors, not only Start()ed ones */
+} demi_limits;
+
+/* One verdict per candidate schedule. */
+#define DEMI_V_VIOLATION     0x1u  /* invariant violated (and matching looking_for when set)         */
+#define DEMI_V_MAXMSG        0x2u  /* messagesScheduledSoFar > maxMessages: not bug-checked (:256)   */
+#define DEMI_V_PENDING_OVF   0x4u  /* pending set exceeded p_max: schedule aborted, verdict invalid   */
+#define DEMI_V_QUEUE_OVF     0x8u  /* timer queues exceeded their caps: aborted, verdict invalid      */
+#define DEMI_V_DIVERGED      0x10u /* replay kernels: an expected delivery was absent (ignored)       */
+typedef struct {
+  uint32_t flags;        /* bits 0..7 DEMI_V_*; bits 8..15 traceIdx at the end; bits 16..31 deliveries */
+  uint32_t fingerprint;  /* ViolationFingerprint code, 0 if none */
+  uint64_t hash;         /* FNV-1a over every delivered message word, then every actor's final state */
+} demi_verdict;          /* 16 bytes */
+
+/* Recorded EventTrace of one execution (EventTrace.scala:20, AuxilaryTypes.scala:34-69). */
+typedef enum {
+  DEMI_REC_SPAWN = 0, DEMI_REC_KILL = 1, DEMI_REC_PARTITION = 2, DEMI_REC_UNPARTITION = 3,
+  DEMI_REC_BEGIN_WAIT_QUIESCENCE = 4, DEMI_REC_QUIESCENCE = 5,
+  DEMI_REC_MSG_SEND = 6,   /* UniqueMsgSend(MsgSend(snd, rcv, msg), id) */
+  DEMI_REC_MSG_EVENT = 7   /* UniqueMsgEvent(MsgEvent(snd, rcv, msg), id) */
+} demi_rec_kind;
+
+typedef struct {
+  uint8_t kind;            /* demi_rec_kind */
+  uint8_t snd, rcv;        /* MSG_*: sender (15 = deadLetters; timers are recorded as "Timer"), receiver;
+                              SPAWN/KILL: rcv = actor; (UN)PARTITION: snd = a, rcv = b */
+  uint8_t msg_type, p0, p1;
+  uint8_t flags;           /* bit0: external message, bit1: timer, bit2: dropped at send (crosses_partition) */
+  uint8_t ext_idx;         /* index of the ExternalEvent that caused this record, 255 = none */
+  uint32_t id;             /* Uniq id pairing a MSG_SEND with its MSG_EVENT */
+} demi_rec_event;          /* 12 bytes */
+
+typedef struct demi_ctx demi_ctx;
+
+/* ---------------------------------------------------------- lifecycle */
+int demi_ctx_create(int device_ordinal, demi_ctx** out);
+void demi_ctx_destroy(demi_ctx* ctx);
+const char* demi_last_error(const demi_ctx* ctx);
+const char* demi_version(void);
+
+/* SchedulerConfig (SchedulerConfig.scala:9-37) + the application actors lowered to a table. */
+int demi_model_load(demi_ctx* ctx, const demi_model* model);
+/* The external-event trace handed to explore()/test() (RandomScheduler.scala:226-237). */
+int demi_trace_load(demi_ctx* ctx, const demi_ext_event* events, uint32_t n_events);
+
+/* ---------------------------------------------------------- K1: RandomScheduler
+ * Replaces the loop of RandomScheduler.explore (RandomScheduler.scala:234-272) in the
+ * fresh-scheduler-per-execution shape of RunnerUtils.fuzz (RunnerUtils.scala:75-90): schedule i
+ * is one full execution with `new FullyRandom(seed = seeds[i])` (RandomScheduler.scala:635-697).
+ * `seeds == NULL` means seeds[i] = seed_base + i.  Host-buffer form (what JNI binds).          */
+int demi_random_explore(demi_ctx* ctx, uint64_t seed_base, const uint64_t* seeds, uint64_t n,
+                        const demi_limits* limits, demi_verdict* out);
+/* Device-resident form: d_seeds (or NULL) and d_out are device pointers, the launch is enqueued
+ * on `hip_stream` (a hipStream_t, NULL = default stream) and not synchronised.                 */
+int demi_random_explore_dev(demi_ctx* ctx, uint64_t seed_base, const uint64_t* d_seeds, uint64_t n,
+                            const demi_limits* limits, demi_verdict* d_out, void* hip_stream);
+/* The EventTrace of one execution (what explore() returns for a violating schedule,
+ * RandomScheduler.scala:156-180), recorded on the GPU by re-running that seed.                 */
+int demi_random_get_trace(demi_ctx* ctx, uint64_t seed, const demi_limits* limits,
+                          demi_verdict* verdict, demi_rec_event* out, uint32_t cap, uint32_t* n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEMI_GPU_H */

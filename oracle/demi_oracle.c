@@ -1,0 +1,635 @@
+/*
+ * demi_oracle.c — CPU restatement of DEMi's RandomScheduler hot path.  TEST INFRASTRUCTURE,
+ * see demi_oracle.h (PARITY UNPINNED vs the JVM reference; java.util.Random is pinned by KATs).
+ *
+ * Paths cited as V/... are /root/reference/src/main/scala/verification/...
+ */
+#include "demi_oracle.h"
+
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ===================================================================== java.util.Random
+ * JDK javadoc: seed scrambling, 48-bit LCG, next(bits), nextInt(bound) with the power-of-two
+ * fast path and the rejection loop.  Call sites: V/schedulers/Util.scala:115,172.             */
+#define JR_MULT 0x5DEECE66DULL
+#define JR_MASK ((1ULL << 48) - 1)
+
+void orc_jrandom_seed(orc_jrandom* r, uint64_t seed) { r->s = (seed ^ JR_MULT) & JR_MASK; }
+
+int32_t orc_jrandom_next(orc_jrandom* r, int bits) {
+  r->s = (r->s * JR_MULT + 0xBULL) & JR_MASK;
+  return (int32_t)(uint32_t)(r->s >> (48 - bits));
+}
+
+int32_t orc_jrandom_next_int(orc_jrandom* r) { return orc_jrandom_next(r, 32); }
+
+int32_t orc_jrandom_next_int_bound(orc_jrandom* r, int32_t bound) {
+  int32_t v = orc_jrandom_next(r, 31);
+  int32_t m = bound - 1;
+  if ((bound & m) == 0) return (int32_t)(((int64_t)bound * (int64_t)v) >> 31);
+  /* for (u = v; u - (v = u % bound) + m < 0; u = next(31)) with int32 wrap-around */
+  int32_t u = v;
+  for (;;) {
+    v = u % bound;
+    int32_t t = (int32_t)((uint32_t)u - (uint32_t)v + (uint32_t)m);
+    if (t >= 0) break;
+    u = orc_jrandom_next(r, 31);
+  }
+  return v;
+}
+
+double orc_jrandom_next_double(orc_jrandom* r) {
+  int64_t hi = (int64_t)orc_jrandom_next(r, 26);
+  int64_t lo = (int64_t)orc_jrandom_next(r, 27);
+  return (double)((hi << 27) + lo) * (1.0 / (double)(1LL << 53));
+}
+
+/* ===================================================================== model helpers */
+static int timer_index(const demi_model* m, uint32_t type) {
+  /* dense index of a TIMER-class type among the model's timer types, ascending */
+  int k = 0;
+  for (uint32_t t = 0; t < type; t++)
+    if (m->msg_class[t] == DEMI_MSG_TIMER) k++;
+  return k;
+}
+
+static uint32_t timer_bit(const demi_model* m, uint32_t rcv, uint32_t type) {
+  return 1u << (rcv * DEMI_MAX_TIMER_TYPES + (uint32_t)timer_index(m, type));
+}
+
+#define FAIL(...)                                  \
+  do {                                             \
+    if (err) snprintf(err, err_cap, __VA_ARGS__);  \
+    return DEMI_ERR_INVALID_MODEL;                 \
+  } while (0)
+
+int orc_model_validate(const demi_model* m, char* err, size_t err_cap) {
+  if (!m) FAIL("null model");
+  if (m->n_actors < 1 || m->n_actors > DEMI_MAX_ACTORS) FAIL("n_actors out of range");
+  if (m->n_msg_types < 1 || m->n_msg_types > DEMI_MAX_MSG_TYPES) FAIL("n_msg_types out of range");
+  if (m->n_classes < 1 || m->n_classes > DEMI_MAX_CLASSES) FAIL("n_classes out of range");
+  if (m->code_len < 1 || m->code_len > DEMI_MAX_CODE) FAIL("code_len out of range");
+  if (!m->msg_class || !m->actor_class || !m->handler_start || !m->code || !m->init_state)
+    FAIL("null table pointer");
+  uint32_t n_timers = 0;
+  for (uint32_t t = 0; t < m->n_msg_types; t++) {
+    if (m->msg_class[t] > DEMI_MSG_TIMER) FAIL("msg_class[%u] invalid", t);
+    if (m->msg_class[t] == DEMI_MSG_TIMER) n_timers++;
+  }
+  if (n_timers > DEMI_MAX_TIMER_TYPES) FAIL("more than %d timer types", DEMI_MAX_TIMER_TYPES);
+  for (uint32_t a = 0; a < m->n_actors; a++)
+    if (m->actor_class[a] >= m->n_classes) FAIL("actor_class[%u] out of range", a);
+  for (uint32_t i = 0; i < m->n_classes * m->n_msg_types; i++)
+    if (m->handler_start[i] != 0xFFFF && m->handler_start[i] >= m->code_len)
+      FAIL("handler_start[%u] out of range", i);
+  for (uint32_t pc = 0; pc < m->code_len; pc++) {
+    uint32_t w = m->code[pc];
+    uint32_t op = w & 0xFF, bimm = (w >> 16) & 1, aux = (w >> 17) & 0x7F, b = w >> 24;
+    if (!bimm && b > 15) FAIL("row %u: register operand b out of range", pc);
+    switch (op) {
+      case DEMI_OP_HALT: case DEMI_OP_MOV: case DEMI_OP_ADD: case DEMI_OP_SUB: case DEMI_OP_AND:
+      case DEMI_OP_OR: case DEMI_OP_XOR: case DEMI_OP_SHL: case DEMI_OP_SHR: case DEMI_OP_BITSET:
+      case DEMI_OP_POPC: case DEMI_OP_EQ: case DEMI_OP_NE: case DEMI_OP_LT: case DEMI_OP_GE:
+      case DEMI_OP_LE: case DEMI_OP_GT: case DEMI_OP_MIN: case DEMI_OP_MAX:
+        break;
+      case DEMI_OP_SKIPZ: case DEMI_OP_SKIPNZ: case DEMI_OP_SKIP:
+        if (!bimm) FAIL("row %u: skip distance must be an immediate", pc);
+        if (pc + 1 + b > m->code_len) FAIL("row %u: skip past the end of the table", pc);
+        break;
+      case DEMI_OP_SEND: case DEMI_OP_BCAST:
+        /* the reference assumes "external message objects never == internal message objects"
+           (V/schedulers/ExternalEventInjector.scala:101-104); timers are only ever produced by
+           the akka scheduler.  Actors may therefore only `!` INTERNAL-class types. */
+        if (aux >= m->n_msg_types || m->msg_class[aux] != DEMI_MSG_INTERNAL)
+          FAIL("row %u: SEND/BCAST of a non-internal message type %u", pc, aux);
+        break;
+      case DEMI_OP_TSET: case DEMI_OP_TREP: case DEMI_OP_TCANCEL:
+        if (aux >= m->n_msg_types || m->msg_class[aux] != DEMI_MSG_TIMER)
+          FAIL("row %u: timer op on a non-timer message type %u", pc, aux);
+        break;
+      default:
+        FAIL("row %u: unknown op %u", pc, op);
+    }
+  }
+  if (m->inv_kind > DEMI_INV_AGREE) FAIL("inv_kind invalid");
+  if (m->inv_fa > 7 || m->inv_fb > 7 || m->inv_va > 255) FAIL("invariant field out of range");
+  return DEMI_OK;
+}
+
+#undef FAIL
+#define FAIL(...)                                  \
+  do {                                             \
+    if (err) snprintf(err, err_cap, __VA_ARGS__);  \
+    return DEMI_ERR_INVALID_TRACE;                 \
+  } while (0)
+
+int orc_trace_validate(const demi_model* m, const demi_ext_event* ev, uint32_t n, char* err, size_t err_cap) {
+  if (n > DEMI_MAX_EXT_EVENTS) FAIL("more than %d external events", DEMI_MAX_EXT_EVENTS);
+  for (uint32_t i = 0; i < n; i++) {
+    const demi_ext_event* e = &ev[i];
+    switch (e->kind) {
+      case DEMI_EV_START: case DEMI_EV_KILL:
+        if (e->a >= m->n_actors) FAIL("event %u: actor out of range", i);
+        break;
+      case DEMI_EV_SEND:
+        if (e->a >= m->n_actors) FAIL("event %u: receiver out of range", i);
+        /* MessageTypes.sanityCheckTrace analogue (V/ExternalEvents.scala:138-149) */
+        if (e->msg_type >= m->n_msg_types || m->msg_class[e->msg_type] != DEMI_MSG_EXTERNAL)
+          FAIL("event %u: Send of a non-external message type", i);
+        break;
+      case DEMI_EV_PARTITION: case DEMI_EV_UNPARTITION:
+        if (e->a >= m->n_actors || e->b >= m->n_actors) FAIL("event %u: actor out of range", i);
+        break;
+      case DEMI_EV_WAIT_QUIESCENCE:
+        break;
+      default:
+        FAIL("event %u: unsupported external event kind %u (WaitCondition/CodeBlock/HardKill "
+             "need the JVM scheduler)", i, e->kind);
+    }
+  }
+  return DEMI_OK;
+}
+#undef FAIL
+
+/* ===================================================================== delta-table VM
+ * The application's `receive` (not in the reference; see include/demi_gpu.h for the row
+ * format).  Effects are returned in program order; the scheduler applies them in that order,
+ * as Akka would call `!` / scheduleOnce / cancel inside receive (WeaveActor.aj:224-279).       */
+int orc_vm_run(const demi_model* m, uint32_t me, uint64_t* state, uint8_t msg_type, uint8_t src,
+               uint8_t p0, uint8_t p1, uint32_t exists_mask, orc_effect* fx, uint32_t fx_cap) {
+  uint32_t nfx = 0;
+  uint16_t start = m->handler_start[m->actor_class[me] * m->n_msg_types + msg_type];
+  if (start == 0xFFFF) return 0;
+  uint8_t r[16];
+  for (int i = 0; i < 8; i++) r[i] = (uint8_t)(*state >> (8 * i));
+  r[8] = r[9] = r[10] = r[11] = 0;
+  r[12] = p0; r[13] = p1; r[14] = src; r[15] = (uint8_t)me;
+  uint32_t pc = start;
+  while (pc < m->code_len) {
+    uint32_t w = m->code[pc++];
+    uint32_t op = w & 0xFF, dst = (w >> 8) & 15, ai = (w >> 12) & 15, bimm = (w >> 16) & 1;
+    uint32_t aux = (w >> 17) & 0x7F, braw = w >> 24;
+    uint8_t a = r[ai];
+    uint8_t b = bimm ? (uint8_t)braw : r[braw & 15];
+    if (op == DEMI_OP_HALT) break;
+    switch (op) {
+      case DEMI_OP_MOV: r[dst] = b; break;
+      case DEMI_OP_ADD: r[dst] = (uint8_t)(a + b); break;
+      case DEMI_OP_SUB: r[dst] = (uint8_t)(a - b); break;
+      case DEMI_OP_AND: r[dst] = a & b; break;
+      case DEMI_OP_OR: r[dst] = a | b; break;
+      case DEMI_OP_XOR: r[dst] = a ^ b; break;
+      case DEMI_OP_SHL: r[dst] = (uint8_t)(a << (b & 7)); break;
+      case DEMI_OP_SHR: r[dst] = (uint8_t)(a >> (b & 7)); break;
+      case DEMI_OP_BITSET: r[dst] = (uint8_t)(a | (1u << (b & 7))); break;
+      case DEMI_OP_POPC: r[dst] = (uint8_t)__builtin_popcount(b); break;
+      case DEMI_OP_EQ: r[dst] = a == b; break;
+      case DEMI_OP_NE: r[dst] = a != b; break;
+      case DEMI_OP_LT: r[dst] = a < b; break;
+      case DEMI_OP_GE: r[dst] = a >= b; break;
+      case DEMI_OP_LE: r[dst] = a <= b; break;
+      case DEMI_OP_GT: r[dst] = a > b; break;
+      case DEMI_OP_MIN: r[dst] = a < b ? a : b; break;
+      case DEMI_OP_MAX: r[dst] = a > b ? a : b; break;
+      case DEMI_OP_SKIPZ: if (a == 0) pc += braw; break;
+      case DEMI_OP_SKIPNZ: if (a != 0) pc += braw; break;
+      case DEMI_OP_SKIP: pc += braw; break;
+      case DEMI_OP_SEND:
+        /* a message to a name that was never created reaches no scheduler (deadLetters) */
+        if (a < m->n_actors && ((exists_mask >> a) & 1)) {
+          if (nfx >= fx_cap) return -1;
+          fx[nfx++] = (orc_effect){0, a, (uint8_t)aux, r[dst], b};
+        }
+        break;
+      case DEMI_OP_BCAST:
+        for (uint32_t j = 0; j < m->n_actors; j++) {
+          if (j == me || !((exists_mask >> j) & 1)) continue;
+          if (nfx >= fx_cap) return -1;
+          fx[nfx++] = (orc_effect){0, (uint8_t)j, (uint8_t)aux, r[dst], b};
+        }
+        break;
+      case DEMI_OP_TSET: case DEMI_OP_TREP: case DEMI_OP_TCANCEL:
+        if (nfx >= fx_cap) return -1;
+        fx[nfx++] = (orc_effect){(uint8_t)(1 + (op - DEMI_OP_TSET)), (uint8_t)me, (uint8_t)aux, 0, 0};
+        break;
+      default: break;
+    }
+  }
+  uint64_t s = 0;
+  for (int i = 0; i < 8; i++) s |= (uint64_t)r[i] << (8 * i);
+  *state = s;
+  return (int)nfx;
+}
+
+/* ===================================================================== invariant
+ * `Invariant` closure (V/minification/TestOracle.scala:27) as a descriptor; evaluated on the
+ * simulated actor state instead of CheckpointReply maps (checkpointing is off by default,
+ * V/SchedulerConfig.scala:11-12).  Returns the ViolationFingerprint code.                      */
+static inline uint32_t fld(uint64_t s, uint32_t f) { return (uint32_t)(s >> (8 * f)) & 0xFF; }
+
+uint32_t orc_invariant(const demi_model* m, const uint64_t* st, uint32_t exists) {
+  uint32_t A = m->n_actors, fa = m->inv_fa, va = m->inv_va, fb = m->inv_fb;
+  switch (m->inv_kind) {
+    case DEMI_INV_AT_MOST_ONE:
+      for (uint32_t i = 0; i < A; i++) {
+        if (!((exists >> i) & 1) || fld(st[i], fa) != va) continue;
+        for (uint32_t j = i + 1; j < A; j++) {
+          if (!((exists >> j) & 1) || fld(st[j], fa) != va) continue;
+          if (fld(st[i], fb) != fld(st[j], fb)) continue;
+          uint32_t key = fld(st[i], fb), mask = 0;
+          for (uint32_t k = 0; k < A; k++)
+            if (((exists >> k) & 1) && fld(st[k], fa) == va && fld(st[k], fb) == key) mask |= 1u << k;
+          return (1u << 24) | (key << 8) | mask;
+        }
+      }
+      return 0;
+    case DEMI_INV_NEVER: {
+      uint32_t mask = 0;
+      for (uint32_t k = 0; k < A; k++)
+        if (((exists >> k) & 1) && fld(st[k], fa) == va) mask |= 1u << k;
+      return mask ? (2u << 24) | mask : 0;
+    }
+    case DEMI_INV_AGREE: {
+      uint32_t mask = 0, first = 0xFFFFFFFFu, bad = 0;
+      for (uint32_t k = 0; k < A; k++) {
+        if (!((exists >> k) & 1) || fld(st[k], fa) == 0) continue;
+        mask |= 1u << k;
+        if (first == 0xFFFFFFFFu) first = fld(st[k], fb);
+        else if (fld(st[k], fb) != first) bad = 1;
+      }
+      return bad ? (3u << 24) | mask : 0;
+    }
+    default:
+      return 0;
+  }
+}
+
+/* ===================================================================== one execution */
+#define PEND_HARD_CAP 128
+#define MTS_CAP 512
+
+typedef struct { uint32_t word; uint32_t id; } pend_entry;
+
+static inline uint32_t msg_word(uint32_t type, uint32_t src, uint32_t dst, uint32_t p0, uint32_t p1) {
+  return type | (dst << 5) | (src << 8) | (p0 << 16) | (p1 << 24);
+}
+#define W_TYPE(w) ((w) & 31u)
+#define W_DST(w) (((w) >> 5) & 7u)
+#define W_SRC(w) (((w) >> 8) & 15u)
+#define W_P0(w) (((w) >> 16) & 255u)
+#define W_P1(w) ((w) >> 24)
+
+typedef struct { uint8_t rcv, type, p0, p1, is_external, ext_idx; } mts_entry; /* messagesToSend */
+
+typedef struct {
+  const demi_model* m;
+  const demi_ext_event* trace;
+  uint32_t n_ev;
+  const demi_limits* lim;
+  orc_jrandom rng;
+  uint64_t state[DEMI_MAX_ACTORS];
+  uint32_t exists, inaccessible, killed;
+  uint64_t partitioned; /* bit a*8+b : ordered pair (a,b), V/schedulers/EventOrchestrator.scala:51 */
+  uint32_t trace_idx;
+  pend_entry pend[PEND_HARD_CAP]; /* RandomizedHashSet.arr, V/schedulers/Util.scala:112 */
+  uint32_t n_pend, p_max;
+  mts_entry mts[MTS_CAP]; /* messagesToSend, V/schedulers/ExternalEventInjector.scala:109 */
+  uint32_t n_mts;
+  uint32_t just_scheduled; /* justScheduledTimers, V/schedulers/RandomScheduler.scala:109 */
+  uint32_t repeating;      /* timerToCancellable of ongoing timers, V/Instrumenter.scala:141 */
+  uint8_t resend[DEMI_RESEND_CAP][2]; /* timersToResend (rcv, type), RandomScheduler.scala:113 */
+  uint32_t n_resend;
+  uint32_t count;     /* messagesScheduledSoFar */
+  uint32_t violation; /* violationFound fingerprint code, 0 = None */
+  uint32_t flags;
+  uint32_t next_id;   /* Uniq ids of produced messages, per execution, from 1 */
+  uint64_t hash;
+  demi_rec_event* rec;
+  uint32_t rec_cap, n_rec;
+} exec_t;
+
+static void rec_push(exec_t* x, uint8_t kind, uint8_t snd, uint8_t rcv, uint8_t type, uint8_t p0, uint8_t p1,
+                     uint8_t flags, uint8_t ext_idx, uint32_t id) {
+  if (!x->rec) return;
+  if (x->n_rec < x->rec_cap) {
+    demi_rec_event* e = &x->rec[x->n_rec];
+    e->kind = kind; e->snd = snd; e->rcv = rcv; e->msg_type = type; e->p0 = p0; e->p1 = p1;
+    e->flags = flags; e->ext_idx = ext_idx; e->id = id;
+  }
+  x->n_rec++;
+}
+
+/* V/schedulers/EventOrchestrator.scala:345-351 */
+static int crosses_partition(const exec_t* x, uint32_t snd, uint32_t rcv) {
+  if (snd == rcv && !((x->killed >> snd) & 1)) return 0;
+  int part = 0;
+  if (snd < DEMI_MAX_ACTORS && rcv < DEMI_MAX_ACTORS)
+    part = (int)(((x->partitioned >> (snd * 8 + rcv)) | (x->partitioned >> (rcv * 8 + snd))) & 1);
+  int inacc_r = rcv < DEMI_MAX_ACTORS ? (int)((x->inaccessible >> rcv) & 1) : 0;
+  int inacc_s = snd < DEMI_MAX_ACTORS ? (int)((x->inaccessible >> snd) & 1) : 0;
+  return part || inacc_r || inacc_s;
+}
+
+/* RandomizedHashSet.insert, V/schedulers/Util.scala:126-136 */
+#define OVF_ANY (DEMI_V_PENDING_OVF | DEMI_V_QUEUE_OVF)
+static void pend_insert(exec_t* x, uint32_t word, uint32_t id) {
+  if (x->flags & OVF_ANY) return; /* only the first capacity overflow is reported */
+  if (x->n_pend >= x->p_max) { x->flags |= DEMI_V_PENDING_OVF; return; }
+  x->pend[x->n_pend].word = word;
+  x->pend[x->n_pend].id = id;
+  x->n_pend++;
+}
+
+/* RandomizedHashSet.remove: swap with last, V/schedulers/Util.scala:146-163 */
+static pend_entry pend_remove_at(exec_t* x, uint32_t i) {
+  pend_entry v = x->pend[i];
+  x->pend[i] = x->pend[x->n_pend - 1];
+  x->n_pend--;
+  return v;
+}
+
+/* ExternalEventInjector.handle_timer, V/schedulers/ExternalEventInjector.scala:282-297 */
+static void handle_timer(exec_t* x, uint32_t rcv, uint32_t type) {
+  if (x->flags & OVF_ANY) return;
+  if (x->n_mts >= MTS_CAP) { x->flags |= DEMI_V_QUEUE_OVF; return; }
+  x->mts[x->n_mts++] = (mts_entry){(uint8_t)rcv, (uint8_t)type, 0, 0, 0, 255};
+}
+
+/* RandomScheduler.enqueue_timer, V/schedulers/RandomScheduler.scala:549-559 */
+static void enqueue_timer(exec_t* x, uint32_t rcv, uint32_t type) {
+  if (x->flags & OVF_ANY) return;
+  if (x->just_scheduled & timer_bit(x->m, rcv, type)) {
+    if (x->n_resend >= DEMI_RESEND_CAP) { x->flags |= DEMI_V_QUEUE_OVF; return; }
+    x->resend[x->n_resend][0] = (uint8_t)rcv;
+    x->resend[x->n_resend][1] = (uint8_t)type;
+    x->n_resend++;
+    return;
+  }
+  handle_timer(x, rcv, type);
+}
+
+/* Instrumenter.registerCancellable + handleTick, V/Instrumenter.scala:1145-1200
+ * (WeaveActor.aj:234-279: scheduleOnce -> ongoing=false, schedule -> ongoing=true).            */
+static void register_cancellable(exec_t* x, int ongoing, uint32_t rcv, uint32_t type) {
+  uint32_t bit = timer_bit(x->m, rcv, type);
+  if (x->repeating & bit) return; /* "Non-unique timer" (:1154-1157) */
+  if (ongoing) x->repeating |= bit;
+  enqueue_timer(x, rcv, type);    /* "Schedule it immediately!" */
+  /* one-shot: removeCancellable right after the tick (:1194-1196), i.e. never registered */
+}
+
+/* Instrumenter.cancelTimer (V/Instrumenter.scala:159-168) -> RandomScheduler.notify_timer_cancel
+ * (V/schedulers/RandomScheduler.scala:525-534) -> handle_timer_cancel
+ * (V/schedulers/ExternalEventInjector.scala:601-610) / FullyRandom.remove (:653-664).          */
+static void cancel_timer(exec_t* x, uint32_t rcv, uint32_t type) {
+  x->repeating &= ~timer_bit(x->m, rcv, type);
+  for (uint32_t i = 0; i < x->n_mts; i++) {
+    if (!x->mts[i].is_external && x->mts[i].rcv == rcv && x->mts[i].type == type) {
+      memmove(&x->mts[i], &x->mts[i + 1], (x->n_mts - i - 1) * sizeof(mts_entry));
+      x->n_mts--;
+      return;
+    }
+  }
+  for (uint32_t i = 0; i < x->n_pend; i++) {
+    uint32_t w = x->pend[i].word;
+    if (W_SRC(w) == DEMI_DEADLETTERS && W_DST(w) == rcv && W_TYPE(w) == type && W_P0(w) == 0 && W_P1(w) == 0) {
+      pend_remove_at(x, i);
+      return;
+    }
+  }
+}
+
+/* RandomScheduler.event_produced(cell, envelope), V/schedulers/RandomScheduler.scala:274-321 */
+static void event_produced(exec_t* x, uint32_t snd, uint32_t rcv, uint32_t type, uint32_t p0, uint32_t p1,
+                           int is_external, uint8_t ext_idx) {
+  uint32_t id = x->next_id++;
+  int is_timer = 0, dropped = 0;
+  if (!is_external) {
+    if (snd == DEMI_DEADLETTERS) is_timer = 1;
+    if (!crosses_partition(x, snd, rcv)) pend_insert(x, msg_word(type, snd, rcv, p0, p1), id);
+    else dropped = 1;
+  } else {
+    pend_insert(x, msg_word(type, snd, rcv, p0, p1), id); /* externals: no partition check (:298-308) */
+  }
+  rec_push(x, DEMI_REC_MSG_SEND, (uint8_t)snd, (uint8_t)rcv, (uint8_t)type, (uint8_t)p0, (uint8_t)p1,
+           (uint8_t)((is_external ? 1 : 0) | (is_timer ? 2 : 0) | (dropped ? 4 : 0)), ext_idx, id);
+}
+
+/* ExternalEventInjector.send_external_messages, V/schedulers/ExternalEventInjector.scala:306-365 */
+static void send_external_messages(exec_t* x) {
+  for (uint32_t i = 0; i < x->n_mts; i++) {
+    mts_entry* e = &x->mts[i];
+    event_produced(x, DEMI_DEADLETTERS, e->rcv, e->type, e->p0, e->p1, e->is_external, e->ext_idx);
+  }
+  x->n_mts = 0;
+}
+
+/* EventOrchestrator.inject_until_quiescence, V/schedulers/EventOrchestrator.scala:132-189 */
+static void inject_until_quiescence(exec_t* x) {
+  int loop = 1;
+  while (loop && x->trace_idx < x->n_ev) {
+    const demi_ext_event* e = &x->trace[x->trace_idx];
+    uint8_t idx = (uint8_t)x->trace_idx;
+    switch (e->kind) {
+      case DEMI_EV_START: /* trigger_start :219-231 -> unisolate_node :211-217 */
+        rec_push(x, DEMI_REC_SPAWN, 0, e->a, 0, 0, 0, 0, idx, 0);
+        x->inaccessible &= ~(1u << e->a);
+        x->killed &= ~(1u << e->a);
+        break;
+      case DEMI_EV_KILL: /* trigger_kill :233-241 */
+        rec_push(x, DEMI_REC_KILL, 0, e->a, 0, 0, 0, 0, idx, 0);
+        x->killed |= 1u << e->a;
+        x->inaccessible |= 1u << e->a;
+        break;
+      case DEMI_EV_SEND: /* enqueue_message, V/schedulers/ExternalEventInjector.scala:250-279 */
+        if ((x->exists >> e->a) & 1) {
+          if (x->n_mts >= MTS_CAP) { x->flags |= DEMI_V_QUEUE_OVF; break; }
+          x->mts[x->n_mts++] = (mts_entry){e->a, e->msg_type, e->p0, e->p1, 1, idx};
+        } /* else: "Unknown message receiver" (:254) */
+        break;
+      case DEMI_EV_PARTITION: /* trigger_partition :314-322 */
+        rec_push(x, DEMI_REC_PARTITION, e->a, e->b, 0, 0, 0, 0, idx, 0);
+        x->partitioned |= 1ULL << (e->a * 8 + e->b);
+        break;
+      case DEMI_EV_UNPARTITION: /* trigger_unpartition :324-332 (ordered pair as given) */
+        rec_push(x, DEMI_REC_UNPARTITION, e->a, e->b, 0, 0, 0, 0, idx, 0);
+        x->partitioned &= ~(1ULL << (e->a * 8 + e->b));
+        break;
+      case DEMI_EV_WAIT_QUIESCENCE: /* :182-184 */
+        rec_push(x, DEMI_REC_BEGIN_WAIT_QUIESCENCE, 0, 0, 0, 0, 0, 0, idx, 0);
+        loop = 0;
+        break;
+      default: break;
+    }
+    x->trace_idx++; /* trace_advanced :186 */
+  }
+}
+
+/* test_invariant + violationMatches, V/schedulers/RandomScheduler.scala:138-154 */
+static uint32_t check_invariant(exec_t* x) {
+  uint32_t fp = orc_invariant(x->m, x->state, x->exists);
+  if (!fp) return 0;
+  if (x->lim->looking_for_valid) {
+    if (((fp ^ x->lim->looking_for) & x->m->fp_match_mask) == 0) return x->lim->looking_for;
+    return 0;
+  }
+  return fp;
+}
+
+static inline void hash_step(uint64_t* h, uint64_t v) { *h = (*h ^ v) * 0x100000001B3ULL; }
+
+/* Apply delta to the delivered message and its effects in program order. */
+static void deliver(exec_t* x, uint32_t word) {
+  uint32_t me = W_DST(word);
+  orc_effect fx[64];
+  int n = orc_vm_run(x->m, me, &x->state[me], (uint8_t)W_TYPE(word), (uint8_t)W_SRC(word), (uint8_t)W_P0(word),
+                     (uint8_t)W_P1(word), x->exists, fx, 64);
+  if (n < 0) { x->flags |= DEMI_V_QUEUE_OVF; return; }
+  for (int i = 0; i < n; i++) {
+    switch (fx[i].kind) {
+      case 0: event_produced(x, me, fx[i].target, fx[i].msg_type, fx[i].p0, fx[i].p1, 0, 255); break;
+      case 1: register_cancellable(x, 0, me, fx[i].msg_type); break;
+      case 2: register_cancellable(x, 1, me, fx[i].msg_type); break;
+      case 3: cancel_timer(x, me, fx[i].msg_type); break;
+    }
+  }
+}
+
+/* RandomScheduler.schedule_new_message (V/schedulers/RandomScheduler.scala:352-485) fused with the
+ * Instrumenter dispatch it feeds (V/Instrumenter.scala:913-1017).  Returns 0 on `None`.        */
+static int schedule_new_message(exec_t* x) {
+  uint32_t max_messages = x->lim->max_messages ? x->lim->max_messages : 0x7FFFFFFFu;
+  uint32_t interval = x->lim->invariant_check_interval;
+  if (x->violation) return 0;                                   /* :354-360 */
+  if (x->count > max_messages) {                                /* :369-373 */
+    x->flags |= DEMI_V_MAXMSG;
+    x->trace_idx = x->n_ev;                                     /* finish_early */
+    return 0;
+  }
+  if (interval > 0 && (x->count % interval) == 0 && x->count != 0 /* lastCheckpoint == 0 */) {
+    x->violation = check_invariant(x);                          /* :376-394 */
+    if (x->violation) return 0;
+  }
+  send_external_messages(x);                                    /* :424 */
+  if (x->flags & (DEMI_V_PENDING_OVF | DEMI_V_QUEUE_OVF)) return 0;
+  if (x->n_pend == 0) return 0;                                 /* find_non_blocked_message, Util.scala:474 */
+  /* FullyRandom.removeRandomElement (:666-684) -> RandomizedHashSet.removeRandomElement
+     (V/schedulers/Util.scala:171-176); blockedActors is empty (no crashes / ask in the model). */
+  uint32_t idx = (uint32_t)orc_jrandom_next_int_bound(&x->rng, (int32_t)x->n_pend);
+  pend_entry e = pend_remove_at(x, idx);
+  x->count++;                                                   /* :462 */
+  uint32_t w = e.word;
+  rec_push(x, DEMI_REC_MSG_EVENT, (uint8_t)W_SRC(w), (uint8_t)W_DST(w), (uint8_t)W_TYPE(w), (uint8_t)W_P0(w),
+           (uint8_t)W_P1(w), 0, 255, e.id);
+  hash_step(&x->hash, w);
+  /* updateRepeatingTimer :405-421; isTimer = timerToCancellable contains (rcv, msg) */
+  int is_rep = x->m->msg_class[W_TYPE(w)] == DEMI_MSG_TIMER &&
+               (x->repeating & timer_bit(x->m, W_DST(w), W_TYPE(w))) != 0;
+  if (is_rep) {
+    x->just_scheduled |= timer_bit(x->m, W_DST(w), W_TYPE(w));
+  } else {
+    for (uint32_t i = 0; i < x->n_resend; i++) handle_timer(x, x->resend[i][0], x->resend[i][1]);
+    x->n_resend = 0;
+    x->just_scheduled = 0;
+  }
+  /* dispatch_new_message: "Check if it was a repeating timer. If so, retrigger it"
+     (V/Instrumenter.scala:1008-1016).  The retrigger races with the actor's receive in the
+     reference; this restatement pins it BEFORE the receive. */
+  if (is_rep) enqueue_timer(x, W_DST(w), W_TYPE(w));
+  deliver(x, w);
+  return 1;
+}
+
+int orc_random_execute(const demi_model* m, const demi_ext_event* trace, uint32_t n_ev, uint64_t seed,
+                       const demi_limits* lim, demi_verdict* out, demi_rec_event* rec, uint32_t rec_cap,
+                       uint32_t* n_rec, uint64_t* final_states) {
+  exec_t* x = (exec_t*)calloc(1, sizeof(exec_t));
+  if (!x) return DEMI_ERR_INVALID_ARG;
+  x->m = m; x->trace = trace; x->n_ev = n_ev; x->lim = lim;
+  x->rec = rec; x->rec_cap = rec_cap;
+  x->p_max = lim->p_max ? lim->p_max : 64;
+  if (x->p_max > PEND_HARD_CAP) x->p_max = PEND_HARD_CAP;
+  orc_jrandom_seed(&x->rng, seed); /* new FullyRandom(seed = ...) */
+  /* populateActorSystem (V/schedulers/ExternalEventInjector.scala:371-378, 397-406):
+     every actor that is ever Start()ed is created up front and isolated. */
+  for (uint32_t i = 0; i < n_ev; i++)
+    if (trace[i].kind == DEMI_EV_START) x->exists |= 1u << trace[i].a;
+  if (lim->populate_all) x->exists = (1u << m->n_actors) - 1;
+  x->inaccessible = x->exists;
+  for (uint32_t a = 0; a < m->n_actors; a++) x->state[a] = m->init_state[a];
+  x->next_id = 1;
+  x->hash = 0xCBF29CE484222325ULL;
+
+  /* execute_trace -> advanceTrace -> start_dispatch ... handle_quiescence
+     (V/schedulers/ExternalEventInjector.scala:382-441, 541-580) */
+  for (;;) {
+    inject_until_quiescence(x);
+    while (schedule_new_message(x)) {
+      if (x->flags & (DEMI_V_PENDING_OVF | DEMI_V_QUEUE_OVF)) break;
+    }
+    if (x->flags & (DEMI_V_PENDING_OVF | DEMI_V_QUEUE_OVF)) break;
+    if (x->violation) break;                 /* notify_quiescence :487-500 */
+    if (x->trace_idx < n_ev) {
+      rec_push(x, DEMI_REC_QUIESCENCE, 0, 0, 0, 0, 0, 0, 255, 0);
+      continue;
+    }
+    break;
+  }
+  /* explore(): `if (messagesScheduledSoFar <= maxMessages) checkIfBugFound` (:256-262, 156-180) */
+  if (!(x->flags & (DEMI_V_PENDING_OVF | DEMI_V_QUEUE_OVF | DEMI_V_MAXMSG)) && !x->violation)
+    x->violation = check_invariant(x);
+  for (uint32_t a = 0; a < m->n_actors; a++) hash_step(&x->hash, x->state[a]);
+
+  if (x->flags & (DEMI_V_PENDING_OVF | DEMI_V_QUEUE_OVF)) {
+    /* capacity abort: only the overflow bits are defined (the schedule must be re-run on the
+       JVM scheduler or with a larger p_max) */
+    out->flags = x->flags & (DEMI_V_PENDING_OVF | DEMI_V_QUEUE_OVF);
+    out->fingerprint = 0;
+    out->hash = 0;
+  } else {
+    out->flags = (x->flags & 0xFF) | (x->violation ? DEMI_V_VIOLATION : 0) | ((x->trace_idx & 0xFF) << 8) |
+                 ((x->count & 0xFFFF) << 16);
+    out->fingerprint = x->violation;
+    out->hash = x->hash;
+  }
+  if (n_rec) *n_rec = x->n_rec;
+  if (final_states) memcpy(final_states, x->state, sizeof(uint64_t) * m->n_actors);
+  free(x);
+  return DEMI_OK;
+}
+
+/* ===================================================================== batch driver */
+typedef struct {
+  const demi_model* m; const demi_ext_event* trace; uint32_t n_ev; uint64_t seed_base;
+  const uint64_t* seeds; uint64_t lo, hi; const demi_limits* lim; demi_verdict* out;
+} job_t;
+
+static void* job_main(void* p) {
+  job_t* j = (job_t*)p;
+  for (uint64_t i = j->lo; i < j->hi; i++) {
+    uint64_t seed = j->seeds ? j->seeds[i] : j->seed_base + i;
+    orc_random_execute(j->m, j->trace, j->n_ev, seed, j->lim, &j->out[i], NULL, 0, NULL, NULL);
+  }
+  return NULL;
+}
+
+int orc_random_explore(const demi_model* m, const demi_ext_event* trace, uint32_t n_ev, uint64_t seed_base,
+                       const uint64_t* seeds, uint64_t n, const demi_limits* lim, demi_verdict* out,
+                       int n_threads) {
+  if (n_threads < 1) n_threads = 1;
+  if (n_threads > 256) n_threads = 256;
+  pthread_t th[256];
+  job_t jobs[256];
+  for (int t = 0; t < n_threads; t++) {
+    jobs[t] = (job_t){m, trace, n_ev, seed_base, seeds, n * (uint64_t)t / (uint64_t)n_threads,
+                      n * (uint64_t)(t + 1) / (uint64_t)n_threads, lim, out};
+    if (n_threads == 1) job_main(&jobs[t]);
+    else pthread_create(&th[t], NULL, job_main, &jobs[t]);
+  }
+  if (n_threads > 1)
+    for (int t = 0; t < n_threads; t++) pthread_join(th[t], NULL);
+  return DEMI_OK;
+}

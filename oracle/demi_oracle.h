@@ -1,0 +1,61 @@
+/*
+ * demi_oracle.h — CPU restatement of DEMi's schedule-exploration hot path.  TEST INFRASTRUCTURE.
+ *
+ * This is the parity oracle and the timed CPU baseline ("port").  It is NOT part of the product:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.
+ *
+ * PARITY UNPINNED versus the JVM reference: NetSys/demi has no tests, golden vectors or
+ * known-answer fixtures, cannot be built here (no JVM / sbt / AspectJ / Akka 2.3.6), and the
+ * transition function it schedules (akka-raft, Spark actors) lives in another repository.  The
+ * only externally pinned arithmetic is java.util.Random (JDK javadoc LCG; known answers in
+ * tests/golden/jrandom_kat.json).  Everything else restates the Scala sources function by
+ * function; each function below cites the file:line it follows (paths relative to
+ * /root/reference/src/main/scala/verification/).
+ */
+#ifndef DEMI_ORACLE_H
+#define DEMI_ORACLE_H
+
+#include "../include/demi_gpu.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* java.util.Random */
+typedef struct { uint64_t s; } orc_jrandom;
+void    orc_jrandom_seed(orc_jrandom* r, uint64_t seed);
+int32_t orc_jrandom_next(orc_jrandom* r, int bits);
+int32_t orc_jrandom_next_int(orc_jrandom* r);
+int32_t orc_jrandom_next_int_bound(orc_jrandom* r, int32_t bound);
+double  orc_jrandom_next_double(orc_jrandom* r);
+
+/* Model validation; returns 0 or DEMI_ERR_INVALID_MODEL and writes a reason into err. */
+int orc_model_validate(const demi_model* m, char* err, size_t err_cap);
+int orc_trace_validate(const demi_model* m, const demi_ext_event* ev, uint32_t n, char* err, size_t err_cap);
+
+/* One handler application: delta(state of `me`, message) -> new state + effects appended to `fx`. */
+typedef struct {
+  uint8_t kind;   /* 0 send, 1 tset, 2 trep, 3 tcancel */
+  uint8_t target; /* send: receiver */
+  uint8_t msg_type, p0, p1;
+} orc_effect;
+int orc_vm_run(const demi_model* m, uint32_t me, uint64_t* state, uint8_t msg_type, uint8_t src,
+               uint8_t p0, uint8_t p1, uint32_t exists_mask, orc_effect* fx, uint32_t fx_cap);
+
+/* Invariant: returns the fingerprint code (0 = holds). */
+uint32_t orc_invariant(const demi_model* m, const uint64_t* states, uint32_t exists_mask);
+
+/* One RandomScheduler execution.  rec may be NULL. */
+int orc_random_execute(const demi_model* m, const demi_ext_event* trace, uint32_t n_ev, uint64_t seed,
+                       const demi_limits* lim, demi_verdict* out, demi_rec_event* rec, uint32_t rec_cap,
+                       uint32_t* n_rec, uint64_t* final_states);
+
+/* n executions; seeds == NULL -> seed_base + i.  n_threads > 1 splits the index range. */
+int orc_random_explore(const demi_model* m, const demi_ext_event* trace, uint32_t n_ev, uint64_t seed_base,
+                       const uint64_t* seeds, uint64_t n, const demi_limits* lim, demi_verdict* out,
+                       int n_threads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,105 @@
+"""ctypes binding of the CPU oracle (oracle/_build/liboracle.so).  TEST INFRASTRUCTURE ONLY:
+importable from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, never from the
+product package (demi_amd/)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from demi_amd import types as T
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "_build", "liboracle.so")
+    if force or not os.path.exists(so):
+        subprocess.check_call(["make", "-s", "-C", _HERE])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        L.orc_jrandom_seed.argtypes = [C.c_void_p, C.c_uint64]
+        L.orc_jrandom_next_int.argtypes = [C.c_void_p]
+        L.orc_jrandom_next_int.restype = C.c_int32
+        L.orc_jrandom_next_int_bound.argtypes = [C.c_void_p, C.c_int32]
+        L.orc_jrandom_next_int_bound.restype = C.c_int32
+        L.orc_jrandom_next_double.argtypes = [C.c_void_p]
+        L.orc_jrandom_next_double.restype = C.c_double
+        L.orc_model_validate.argtypes = [C.POINTER(T.ModelStruct), C.c_char_p, C.c_size_t]
+        L.orc_trace_validate.argtypes = [C.POINTER(T.ModelStruct), C.c_void_p, C.c_uint32, C.c_char_p, C.c_size_t]
+        L.orc_invariant.argtypes = [C.POINTER(T.ModelStruct), C.c_void_p, C.c_uint32]
+        L.orc_invariant.restype = C.c_uint32
+        L.orc_random_execute.argtypes = [C.POINTER(T.ModelStruct), C.c_void_p, C.c_uint32, C.c_uint64,
+                                         C.POINTER(T.Limits), C.POINTER(T.Verdict), C.c_void_p, C.c_uint32,
+                                         C.POINTER(C.c_uint32), C.c_void_p]
+        L.orc_random_explore.argtypes = [C.POINTER(T.ModelStruct), C.c_void_p, C.c_uint32, C.c_uint64,
+                                         C.c_void_p, C.c_uint64, C.POINTER(T.Limits), C.c_void_p, C.c_int]
+        L.orc_vm_run.argtypes = [C.POINTER(T.ModelStruct), C.c_uint32, C.POINTER(C.c_uint64), C.c_uint8, C.c_uint8,
+                                 C.c_uint8, C.c_uint8, C.c_uint32, C.c_void_p, C.c_uint32]
+        _LIB = L
+    return _LIB
+
+
+class JRandom:
+    def __init__(self, seed):
+        self._s = C.c_uint64(0)
+        lib().orc_jrandom_seed(C.byref(self._s), C.c_uint64(seed & 0xFFFFFFFFFFFFFFFF))
+
+    def next_int(self, bound=None):
+        if bound is None:
+            return lib().orc_jrandom_next_int(C.byref(self._s))
+        return lib().orc_jrandom_next_int_bound(C.byref(self._s), bound)
+
+    def next_double(self):
+        return lib().orc_jrandom_next_double(C.byref(self._s))
+
+
+def model_validate(model):
+    err = C.create_string_buffer(256)
+    ms = model.to_struct()
+    rc = lib().orc_model_validate(C.byref(ms), err, 256)
+    return rc, err.value.decode()
+
+
+def trace_validate(model, events):
+    err = C.create_string_buffer(256)
+    ms = model.to_struct()
+    ev = np.ascontiguousarray(events)
+    rc = lib().orc_trace_validate(C.byref(ms), ev.ctypes.data, len(ev), err, 256)
+    return rc, err.value.decode()
+
+
+def random_explore(model, events, n, seed_base=0, seeds=None, limits=None, n_threads=1):
+    """n RandomScheduler executions on the CPU; returns a VERDICT_DTYPE array."""
+    ms = model.to_struct()
+    ev = np.ascontiguousarray(events)
+    out = np.zeros(n, dtype=T.VERDICT_DTYPE)
+    sp = None
+    if seeds is not None:
+        seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
+        sp = seeds.ctypes.data
+    rc = lib().orc_random_explore(C.byref(ms), ev.ctypes.data, len(ev), C.c_uint64(seed_base), sp, n,
+                                  C.byref(limits), out.ctypes.data, n_threads)
+    assert rc == 0
+    return out
+
+
+def random_execute(model, events, seed, limits, record=True):
+    """One execution; returns (verdict, recorded events array, final states)."""
+    ms = model.to_struct()
+    ev = np.ascontiguousarray(events)
+    v = T.Verdict()
+    rec = np.zeros(T.MAX_REC_EVENTS, dtype=T.REC_EVENT_DTYPE)
+    n_rec = C.c_uint32(0)
+    states = np.zeros(model.n_actors, dtype=np.uint64)
+    rc = lib().orc_random_execute(C.byref(ms), ev.ctypes.data, len(ev), C.c_uint64(seed), C.byref(limits),
+                                  C.byref(v), rec.ctypes.data if record else None, len(rec), C.byref(n_rec),
+                                  states.ctypes.data)
+    assert rc == 0
+    return v, rec[:min(n_rec.value, len(rec))].copy(), states
