@@ -1,0 +1,106 @@
+"""ctypes binding of libdemi_gpu.so (the C ABI of include/demi_gpu.h).
+
+There is no fallback: if the shared library is missing or no MI355X is visible, the product path
+raises.  Build with `python -c "import __graft_entry__ as g; g.build()"` or `make -C demi_amd/csrc`.
+"""
+import ctypes as C
+import os
+
+from . import types as T
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdemi_gpu.so")
+
+EXPORTS = ["demi_ctx_create", "demi_ctx_destroy", "demi_last_error", "demi_version", "demi_model_load",
+           "demi_trace_load", "demi_random_explore", "demi_random_explore_dev", "demi_random_get_trace"]
+
+_lib = None
+
+
+class DemiError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("demi_gpu error %d: %s" % (code, msg))
+        self.code = code
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libdemi_gpu.so is not built (%s); run __graft_entry__.build()" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    L.demi_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    L.demi_ctx_destroy.argtypes = [C.c_void_p]
+    L.demi_ctx_destroy.restype = None
+    L.demi_last_error.argtypes = [C.c_void_p]
+    L.demi_last_error.restype = C.c_char_p
+    L.demi_version.restype = C.c_char_p
+    L.demi_model_load.argtypes = [C.c_void_p, C.POINTER(T.ModelStruct)]
+    L.demi_trace_load.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+    L.demi_random_explore.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(T.Limits), C.c_void_p]
+    L.demi_random_explore_dev.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(T.Limits),
+                                          C.c_void_p, C.c_void_p]
+    L.demi_random_get_trace.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(T.Limits), C.POINTER(T.Verdict),
+                                        C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+    _lib = L
+    return L
+
+
+class Context:
+    """demi_ctx: one per host thread, owns the device copies of the model and the trace."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        rc = lib().demi_ctx_create(device, C.byref(self._h))
+        if rc != 0:
+            raise DemiError(rc, "demi_ctx_create failed (no MI355X visible? the GPU path has no CPU fallback)")
+        self.device = device
+
+    def close(self):
+        if self._h:
+            lib().demi_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise DemiError(rc, lib().demi_last_error(self._h).decode())
+
+    def model_load(self, model_struct):
+        self._check(lib().demi_model_load(self._h, C.byref(model_struct)))
+
+    def trace_load(self, events):
+        import numpy as np
+        ev = np.ascontiguousarray(events, dtype=T.EXT_EVENT_DTYPE)
+        self._check(lib().demi_trace_load(self._h, ev.ctypes.data if len(ev) else None, len(ev)))
+
+    def random_explore(self, n, limits, seed_base=0, seeds=None):
+        import numpy as np
+        out = np.zeros(n, dtype=T.VERDICT_DTYPE)
+        sp = None
+        if seeds is not None:
+            seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
+            assert len(seeds) == n
+            sp = seeds.ctypes.data
+        self._check(lib().demi_random_explore(self._h, C.c_uint64(seed_base), sp, n, C.byref(limits),
+                                              out.ctypes.data if n else None))
+        return out
+
+    def random_explore_dev(self, n, limits, d_out_ptr, seed_base=0, d_seeds_ptr=None, stream=None):
+        self._check(lib().demi_random_explore_dev(self._h, C.c_uint64(seed_base), d_seeds_ptr, n, C.byref(limits),
+                                                  d_out_ptr, stream))
+
+    def random_get_trace(self, seed, limits):
+        import numpy as np
+        rec = np.zeros(T.MAX_REC_EVENTS, dtype=T.REC_EVENT_DTYPE)
+        v = T.Verdict()
+        n = C.c_uint32(0)
+        self._check(lib().demi_random_get_trace(self._h, C.c_uint64(seed), C.byref(limits), C.byref(v),
+                                                rec.ctypes.data, len(rec), C.byref(n)))
+        return v, rec[:n.value].copy()

@@ -1,0 +1,126 @@
+// demi_device.hpp — device-side building blocks shared by the schedule-exploration kernels
+// (gfx950 / CDNA4, wave64).  One lane simulates one candidate schedule; every per-lane array that
+// needs dynamic indexing lives in LDS in [slot][lane] order, so any per-lane slot index maps lane l
+// to bank l mod 32 (b32) / 2l mod 64 (b64): conflict-free by construction.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/demi_gpu.h"
+
+namespace demi {
+
+// Flat model blob uploaded once per demi_model_load (host fills it from demi_model).
+struct DevModel {
+  uint32_t n_actors, n_msg_types, n_classes, code_len;
+  uint32_t inv_kind, inv_fa, inv_va, inv_fb;
+  uint32_t fp_match_mask, pad0, pad1, pad2;
+  uint32_t meta[DEMI_MAX_MSG_TYPES];                           // msg_class | timer_idx << 8
+  uint32_t handler_start[DEMI_MAX_CLASSES * DEMI_MAX_MSG_TYPES];  // 0xFFFF = ignored
+  uint32_t actor_class[DEMI_MAX_ACTORS];
+  uint64_t init_state[DEMI_MAX_ACTORS];
+  uint32_t divmagic[129];  // ceil(2^(31+L)/d), L = ceil(log2 d): exact floor(r/d) for r < 2^31
+  uint32_t pad3;
+  uint32_t code[DEMI_MAX_CODE];
+};
+
+// ------------------------------------------------------------------ message word
+// type[4:0] | dst[7:5] | src[11:8] | p0[23:16] | p1[31:24]   (identical to the oracle's)
+__device__ __forceinline__ uint32_t msg_word(uint32_t type, uint32_t src, uint32_t dst, uint32_t p0, uint32_t p1) {
+  return type | (dst << 5) | (src << 8) | (p0 << 16) | (p1 << 24);
+}
+__device__ __forceinline__ uint32_t w_type(uint32_t w) { return w & 31u; }
+__device__ __forceinline__ uint32_t w_dst(uint32_t w) { return (w >> 5) & 7u; }
+__device__ __forceinline__ uint32_t w_src(uint32_t w) { return (w >> 8) & 15u; }
+__device__ __forceinline__ uint32_t w_p0(uint32_t w) { return (w >> 16) & 255u; }
+__device__ __forceinline__ uint32_t w_p1(uint32_t w) { return w >> 24; }
+
+// ------------------------------------------------------------------ java.util.Random
+// 48-bit LCG of the JDK javadoc; call sites schedulers/Util.scala:115,172.
+__device__ __forceinline__ uint64_t jr_seed(uint64_t seed) { return (seed ^ 0x5DEECE66DULL) & ((1ULL << 48) - 1); }
+__device__ __forceinline__ uint32_t jr_next31(uint64_t& s) {
+  s = (s * 0x5DEECE66DULL + 0xBULL) & ((1ULL << 48) - 1);
+  return (uint32_t)(s >> 17);
+}
+// nextInt(bound), 1 <= bound <= 128: power-of-two fast path, else modulo with the rejection loop;
+// floor(r / bound) by multiply-high with a precomputed magic (no integer divide on the GPU).
+__device__ __forceinline__ uint32_t jr_next_int(uint64_t& s, uint32_t bound, const uint32_t* magic) {
+  uint32_t r = jr_next31(s);
+  if ((bound & (bound - 1)) == 0) return r >> (__builtin_clz(bound));  // (bound * r) >> 31
+  const uint32_t m = magic[bound];
+  const uint32_t sh = 31 - __builtin_clz(bound - 1);  // L - 1
+  for (;;) {
+    const uint32_t q = __umulhi(r, m) >> sh;
+    const uint32_t qd = q * bound;
+    if ((qd + bound - 1) < 0x80000000u) return r - qd;  // u - (u % bound) + (bound-1) >= 0 as int32
+    r = jr_next31(s);
+  }
+}
+
+// ------------------------------------------------------------------ partitions
+// EventOrchestrator.crosses_partition (schedulers/EventOrchestrator.scala:345-351)
+struct Net {
+  uint32_t inaccessible, killed;
+  uint64_t partitioned;  // bit a*8+b = ordered pair (a,b)
+};
+__device__ __forceinline__ bool crosses_partition(const Net& n, uint32_t snd, uint32_t rcv) {
+  // snd, rcv < 8 (actor-to-actor)
+  if (snd == rcv && !((n.killed >> snd) & 1)) return false;
+  const uint32_t part = (uint32_t)((n.partitioned >> (snd * 8 + rcv)) | (n.partitioned >> (rcv * 8 + snd))) & 1u;
+  return (part | (n.inaccessible >> rcv) | (n.inaccessible >> snd)) & 1u;
+}
+
+__device__ __forceinline__ void hash_step(uint64_t& h, uint64_t v) { h = (h ^ v) * 0x100000001B3ULL; }
+
+// ------------------------------------------------------------------ invariant
+// Invariant descriptor (TestOracle.scala:27 `Invariant`) on the simulated state; returns the
+// ViolationFingerprint code.  st: this lane's actor states in LDS, stride 64 u64.
+__device__ __forceinline__ uint32_t fld(uint64_t s, uint32_t f) { return (uint32_t)(s >> (8 * f)) & 0xFF; }
+
+__device__ inline uint32_t invariant_code(const DevModel* __restrict__ gm, const uint64_t* st, uint32_t exists,
+                                          uint32_t A, uint32_t kind, uint32_t fa, uint32_t va, uint32_t fb) {
+  uint32_t vmask = 0;       // actors with F[fa] == va   (kinds 1, 2) / F[fa] != 0 (kind 3)
+  uint32_t key[DEMI_MAX_ACTORS];
+#pragma unroll
+  for (uint32_t i = 0; i < DEMI_MAX_ACTORS; i++) {
+    uint64_t s = (i < A) ? st[i * 64] : 0;
+    const uint32_t a = fld(s, fa);
+    const bool hit = (kind == DEMI_INV_AGREE) ? (a != 0) : (a == va);
+    if (i < A && ((exists >> i) & 1) && hit) vmask |= 1u << i;
+    key[i] = fld(s, fb);
+  }
+  if (kind == DEMI_INV_NEVER) return vmask ? ((2u << 24) | vmask) : 0u;
+  if (kind == DEMI_INV_AGREE) {
+    bool have = false, bad = false;
+    uint32_t first = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < DEMI_MAX_ACTORS; i++) {
+      if ((vmask >> i) & 1) {
+        if (!have) { have = true; first = key[i]; }
+        else if (key[i] != first) bad = true;
+      }
+    }
+    return bad ? ((3u << 24) | vmask) : 0u;
+  }
+  if (kind == DEMI_INV_AT_MOST_ONE) {
+    bool found = false;
+    uint32_t k = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < DEMI_MAX_ACTORS; i++) {
+#pragma unroll
+      for (uint32_t j = i + 1; j < DEMI_MAX_ACTORS; j++) {
+        if (!found && ((vmask >> i) & 1) && ((vmask >> j) & 1) && key[i] == key[j]) { found = true; k = key[i]; }
+      }
+    }
+    if (!found) return 0u;
+    uint32_t mask = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < DEMI_MAX_ACTORS; i++)
+      if (((vmask >> i) & 1) && key[i] == k) mask |= 1u << i;
+    return (1u << 24) | (k << 8) | mask;
+  }
+  return 0u;
+}
+
+}  // namespace demi

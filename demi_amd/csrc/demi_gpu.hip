@@ -1,0 +1,340 @@
+// demi_gpu.hip — C-ABI host side of libdemi_gpu.so (see include/demi_gpu.h).
+// Owns the device copies of the transition table and the external-event trace, validates what
+// crosses the boundary, and launches the gfx950 kernels.  No CPU execution path exists here: if
+// HIP is unavailable every entry point fails with DEMI_ERR_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/demi_gpu.h"
+#include "k1_random_explore.hpp"
+
+using namespace demi;
+
+struct demi_ctx {
+  int device = 0;
+  int num_cu = 0;
+  std::string err;
+  // model
+  bool have_model = false;
+  DevModel hmodel;
+  DevModel* d_model = nullptr;
+  // trace
+  bool have_trace = false;
+  std::vector<demi_ext_event> trace;
+  uint64_t* d_trace = nullptr;
+  uint32_t started_mask = 0;
+  // scratch
+  unsigned long long* d_counter = nullptr;
+  demi_verdict* d_out = nullptr;
+  size_t out_cap = 0;
+  uint64_t* d_seeds = nullptr;
+  size_t seeds_cap = 0;
+  demi_rec_event* d_rec = nullptr;
+  uint32_t* d_rec_count = nullptr;
+};
+
+static int fail(demi_ctx* ctx, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (ctx) ctx->err = buf;
+  return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                       \
+  do {                                                                                           \
+    hipError_t e_ = (expr);                                                                      \
+    if (e_ != hipSuccess) return fail(ctx, DEMI_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+extern "C" const char* demi_version(void) { return "demi_gpu 0.1 (gfx950)"; }
+
+extern "C" const char* demi_last_error(const demi_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+
+extern "C" int demi_ctx_create(int device_ordinal, demi_ctx** out) {
+  if (!out) return DEMI_ERR_INVALID_ARG;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device_ordinal < 0 || device_ordinal >= n)
+    return DEMI_ERR_DEVICE;  // the product path has no CPU fallback
+  demi_ctx* ctx = new demi_ctx();
+  ctx->device = device_ordinal;
+  if (hipSetDevice(device_ordinal) != hipSuccess) { delete ctx; return DEMI_ERR_DEVICE; }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_ordinal) != hipSuccess) { delete ctx; return DEMI_ERR_DEVICE; }
+  ctx->num_cu = prop.multiProcessorCount;
+  if (hipMalloc(&ctx->d_model, sizeof(DevModel)) != hipSuccess ||
+      hipMalloc(&ctx->d_trace, sizeof(uint64_t) * (DEMI_MAX_EXT_EVENTS + 1)) != hipSuccess ||
+      hipMalloc(&ctx->d_counter, sizeof(unsigned long long)) != hipSuccess ||
+      hipMalloc(&ctx->d_rec, sizeof(demi_rec_event) * DEMI_MAX_REC_EVENTS) != hipSuccess ||
+      hipMalloc(&ctx->d_rec_count, sizeof(uint32_t)) != hipSuccess) {
+    demi_ctx_destroy(ctx);
+    return DEMI_ERR_DEVICE;
+  }
+  *out = ctx;
+  return DEMI_OK;
+}
+
+extern "C" void demi_ctx_destroy(demi_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->d_model) (void)hipFree(ctx->d_model);
+  if (ctx->d_trace) (void)hipFree(ctx->d_trace);
+  if (ctx->d_counter) (void)hipFree(ctx->d_counter);
+  if (ctx->d_out) (void)hipFree(ctx->d_out);
+  if (ctx->d_seeds) (void)hipFree(ctx->d_seeds);
+  if (ctx->d_rec) (void)hipFree(ctx->d_rec);
+  if (ctx->d_rec_count) (void)hipFree(ctx->d_rec_count);
+  delete ctx;
+}
+
+// ----------------------------------------------------------------------------- model
+// Validation of what the adapter lowered (rules are part of the boundary's spec).
+static int validate_model(demi_ctx* ctx, const demi_model* m) {
+  if (!m) return fail(ctx, DEMI_ERR_INVALID_MODEL, "null model");
+  if (m->n_actors < 1 || m->n_actors > DEMI_MAX_ACTORS) return fail(ctx, DEMI_ERR_INVALID_MODEL, "n_actors out of range");
+  if (m->n_msg_types < 1 || m->n_msg_types > DEMI_MAX_MSG_TYPES) return fail(ctx, DEMI_ERR_INVALID_MODEL, "n_msg_types out of range");
+  if (m->n_classes < 1 || m->n_classes > DEMI_MAX_CLASSES) return fail(ctx, DEMI_ERR_INVALID_MODEL, "n_classes out of range");
+  if (m->code_len < 1 || m->code_len > DEMI_MAX_CODE) return fail(ctx, DEMI_ERR_INVALID_MODEL, "code_len out of range");
+  if (!m->msg_class || !m->actor_class || !m->handler_start || !m->code || !m->init_state)
+    return fail(ctx, DEMI_ERR_INVALID_MODEL, "null table pointer");
+  uint32_t timers = 0;
+  for (uint32_t t = 0; t < m->n_msg_types; t++) {
+    if (m->msg_class[t] > DEMI_MSG_TIMER) return fail(ctx, DEMI_ERR_INVALID_MODEL, "msg_class[%u] invalid", t);
+    timers += m->msg_class[t] == DEMI_MSG_TIMER;
+  }
+  if (timers > DEMI_MAX_TIMER_TYPES) return fail(ctx, DEMI_ERR_INVALID_MODEL, "more than %d timer types", DEMI_MAX_TIMER_TYPES);
+  for (uint32_t a = 0; a < m->n_actors; a++)
+    if (m->actor_class[a] >= m->n_classes) return fail(ctx, DEMI_ERR_INVALID_MODEL, "actor_class[%u] out of range", a);
+  for (uint32_t i = 0; i < m->n_classes * m->n_msg_types; i++)
+    if (m->handler_start[i] != 0xFFFF && m->handler_start[i] >= m->code_len)
+      return fail(ctx, DEMI_ERR_INVALID_MODEL, "handler_start[%u] out of range", i);
+  for (uint32_t pc = 0; pc < m->code_len; pc++) {
+    const uint32_t w = m->code[pc], op = w & 0xFF, bimm = (w >> 16) & 1, aux = (w >> 17) & 0x7F, b = w >> 24;
+    if (!bimm && b > 15) return fail(ctx, DEMI_ERR_INVALID_MODEL, "row %u: register operand b out of range", pc);
+    if (op <= DEMI_OP_MAX && op != 19) continue;
+    if (op >= DEMI_OP_SKIPZ && op <= DEMI_OP_SKIP) {
+      if (!bimm) return fail(ctx, DEMI_ERR_INVALID_MODEL, "row %u: skip distance must be an immediate", pc);
+      if (pc + 1 + b > m->code_len) return fail(ctx, DEMI_ERR_INVALID_MODEL, "row %u: skip past the end of the table", pc);
+    } else if (op == DEMI_OP_SEND || op == DEMI_OP_BCAST) {
+      if (aux >= m->n_msg_types || m->msg_class[aux] != DEMI_MSG_INTERNAL)
+        return fail(ctx, DEMI_ERR_INVALID_MODEL, "row %u: SEND/BCAST of a non-internal message type %u", pc, aux);
+    } else if (op >= DEMI_OP_TSET && op <= DEMI_OP_TCANCEL) {
+      if (aux >= m->n_msg_types || m->msg_class[aux] != DEMI_MSG_TIMER)
+        return fail(ctx, DEMI_ERR_INVALID_MODEL, "row %u: timer op on a non-timer message type %u", pc, aux);
+    } else {
+      return fail(ctx, DEMI_ERR_INVALID_MODEL, "row %u: unknown op %u", pc, op);
+    }
+  }
+  if (m->inv_kind > DEMI_INV_AGREE) return fail(ctx, DEMI_ERR_INVALID_MODEL, "inv_kind invalid");
+  if (m->inv_fa > 7 || m->inv_fb > 7 || m->inv_va > 255) return fail(ctx, DEMI_ERR_INVALID_MODEL, "invariant field out of range");
+  return DEMI_OK;
+}
+
+static int validate_trace(demi_ctx* ctx, const DevModel& hm, const demi_ext_event* ev, uint32_t n) {
+  if (n > DEMI_MAX_EXT_EVENTS) return fail(ctx, DEMI_ERR_INVALID_TRACE, "more than %d external events", DEMI_MAX_EXT_EVENTS);
+  for (uint32_t i = 0; i < n; i++) {
+    const demi_ext_event& e = ev[i];
+    switch (e.kind) {
+      case DEMI_EV_START: case DEMI_EV_KILL:
+        if (e.a >= hm.n_actors) return fail(ctx, DEMI_ERR_INVALID_TRACE, "event %u: actor out of range", i);
+        break;
+      case DEMI_EV_SEND:
+        if (e.a >= hm.n_actors) return fail(ctx, DEMI_ERR_INVALID_TRACE, "event %u: receiver out of range", i);
+        if (e.msg_type >= hm.n_msg_types || (hm.meta[e.msg_type] & 0xFF) != DEMI_MSG_EXTERNAL)
+          return fail(ctx, DEMI_ERR_INVALID_TRACE, "event %u: Send of a non-external message type", i);
+        break;
+      case DEMI_EV_PARTITION: case DEMI_EV_UNPARTITION:
+        if (e.a >= hm.n_actors || e.b >= hm.n_actors) return fail(ctx, DEMI_ERR_INVALID_TRACE, "event %u: actor out of range", i);
+        break;
+      case DEMI_EV_WAIT_QUIESCENCE:
+        break;
+      default:
+        return fail(ctx, DEMI_ERR_INVALID_TRACE,
+                    "event %u: unsupported external event kind %u (WaitCondition/CodeBlock/HardKill need the JVM scheduler)",
+                    i, e.kind);
+    }
+  }
+  return DEMI_OK;
+}
+
+extern "C" int demi_model_load(demi_ctx* ctx, const demi_model* m) {
+  if (!ctx) return DEMI_ERR_INVALID_ARG;
+  int rc = validate_model(ctx, m);
+  if (rc) return rc;
+  DevModel& h = ctx->hmodel;
+  memset(&h, 0, sizeof h);
+  h.n_actors = m->n_actors; h.n_msg_types = m->n_msg_types; h.n_classes = m->n_classes; h.code_len = m->code_len;
+  h.inv_kind = m->inv_kind; h.inv_fa = m->inv_fa; h.inv_va = m->inv_va; h.inv_fb = m->inv_fb;
+  h.fp_match_mask = m->fp_match_mask;
+  uint32_t tix = 0;
+  for (uint32_t t = 0; t < m->n_msg_types; t++) {
+    h.meta[t] = m->msg_class[t] | (tix << 8);
+    if (m->msg_class[t] == DEMI_MSG_TIMER) tix++;
+  }
+  for (uint32_t i = 0; i < DEMI_MAX_CLASSES * DEMI_MAX_MSG_TYPES; i++) h.handler_start[i] = 0xFFFF;
+  for (uint32_t i = 0; i < m->n_classes * m->n_msg_types; i++) h.handler_start[i] = m->handler_start[i];
+  for (uint32_t a = 0; a < m->n_actors; a++) { h.actor_class[a] = m->actor_class[a]; h.init_state[a] = m->init_state[a]; }
+  for (uint32_t d = 1; d <= 128; d++) {
+    uint32_t L = 0;
+    while ((1u << L) < d) L++;
+    const unsigned __int128 num = (unsigned __int128)1 << (31 + L);
+    h.divmagic[d] = (uint32_t)((num + d - 1) / d);  // only read for non-powers of two (fits 32 bits)
+  }
+  memcpy(h.code, m->code, sizeof(uint32_t) * m->code_len);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipMemcpy(ctx->d_model, &h, sizeof h, hipMemcpyHostToDevice));
+  ctx->have_model = true;
+  ctx->have_trace = false;  // a trace is validated against the model it was loaded after
+  return DEMI_OK;
+}
+
+extern "C" int demi_trace_load(demi_ctx* ctx, const demi_ext_event* events, uint32_t n_events) {
+  if (!ctx) return DEMI_ERR_INVALID_ARG;
+  if (!ctx->have_model) return fail(ctx, DEMI_ERR_NO_MODEL, "demi_model_load must precede demi_trace_load");
+  if (!events && n_events) return fail(ctx, DEMI_ERR_INVALID_ARG, "null events");
+  int rc = validate_trace(ctx, ctx->hmodel, events, n_events);
+  if (rc) return rc;
+  ctx->trace.assign(events, events + n_events);
+  ctx->started_mask = 0;
+  for (uint32_t i = 0; i < n_events; i++)
+    if (events[i].kind == DEMI_EV_START) ctx->started_mask |= 1u << events[i].a;
+  static_assert(sizeof(demi_ext_event) == 8, "event is one 8-byte word");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (n_events)
+    HIP_TRY(ctx, hipMemcpy(ctx->d_trace, events, sizeof(demi_ext_event) * n_events, hipMemcpyHostToDevice));
+  ctx->have_trace = true;
+  return DEMI_OK;
+}
+
+// ----------------------------------------------------------------------------- K1 launch
+template <int PMAX, bool REC>
+static int launch_k1_t(demi_ctx* ctx, const K1Args& a, hipStream_t stream) {
+  const DevModel& h = ctx->hmodel;
+  const size_t lds = k1_lds_shared_bytes(h.code_len, a.n_ev, h.n_classes * h.n_msg_types) +
+                     K1_WAVES * k1_lds_wave_bytes<PMAX, REC>(h.n_actors);
+  if (lds > 160 * 1024) return fail(ctx, DEMI_ERR_INVALID_ARG, "LDS budget exceeded (%zu bytes)", lds);
+  auto kern = k1_random_explore<PMAX, REC>;
+  HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  int per_cu = 0;
+  HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, K1_WAVES * 64, lds));
+  if (per_cu < 1) per_cu = 1;
+  // persistent-style grid: every wave keeps claiming 64-schedule batches until the range is done
+  uint64_t blocks = (a.n + (uint64_t)K1_WAVES * 64 - 1) / ((uint64_t)K1_WAVES * 64);
+  const uint64_t resident = (uint64_t)ctx->num_cu * (uint64_t)per_cu;
+  if (blocks > resident) blocks = resident;
+  if (blocks < 1) blocks = 1;
+  HIP_TRY(ctx, hipMemsetAsync(a.work_counter, 0, sizeof(unsigned long long), stream));
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(K1_WAVES * 64), lds, stream, a);
+  HIP_TRY(ctx, hipGetLastError());
+  return DEMI_OK;
+}
+
+template <bool REC>
+static int launch_k1(demi_ctx* ctx, uint32_t p_max, const K1Args& a, hipStream_t stream) {
+  switch (p_max) {
+    case 32: return launch_k1_t<32, REC>(ctx, a, stream);
+    case 0: case 64: return launch_k1_t<64, REC>(ctx, a, stream);
+    case 128: return launch_k1_t<128, REC>(ctx, a, stream);
+    default: return fail(ctx, DEMI_ERR_INVALID_ARG, "p_max must be 32, 64 or 128");
+  }
+}
+
+static int make_k1_args(demi_ctx* ctx, uint64_t seed_base, const uint64_t* d_seeds, uint64_t n,
+                        const demi_limits* lim, demi_verdict* d_out, K1Args* a) {
+  if (!ctx->have_model) return fail(ctx, DEMI_ERR_NO_MODEL, "no model loaded (setInvariant / model_load must precede explore)");
+  if (!ctx->have_trace) return fail(ctx, DEMI_ERR_NO_TRACE, "no trace loaded");
+  if (!lim) return fail(ctx, DEMI_ERR_INVALID_ARG, "null limits");
+  memset(a, 0, sizeof *a);
+  a->model = ctx->d_model;
+  a->trace = ctx->d_trace;
+  a->n_ev = (uint32_t)ctx->trace.size();
+  a->exists = lim->populate_all ? ((1u << ctx->hmodel.n_actors) - 1) : ctx->started_mask;
+  a->seed_base = seed_base;
+  a->seeds = d_seeds;
+  a->n = n;
+  a->max_messages = lim->max_messages;
+  a->interval = lim->invariant_check_interval;
+  a->looking_for_valid = lim->looking_for_valid;
+  a->looking_for = lim->looking_for;
+  a->out = d_out;
+  a->work_counter = ctx->d_counter;
+  return DEMI_OK;
+}
+
+extern "C" int demi_random_explore_dev(demi_ctx* ctx, uint64_t seed_base, const uint64_t* d_seeds, uint64_t n,
+                                       const demi_limits* limits, demi_verdict* d_out, void* hip_stream) {
+  if (!ctx) return DEMI_ERR_INVALID_ARG;
+  if (n == 0) return DEMI_OK;
+  if (!d_out) return fail(ctx, DEMI_ERR_INVALID_ARG, "null output");
+  K1Args a;
+  int rc = make_k1_args(ctx, seed_base, d_seeds, n, limits, d_out, &a);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  return launch_k1<false>(ctx, limits->p_max, a, static_cast<hipStream_t>(hip_stream));
+}
+
+extern "C" int demi_random_explore(demi_ctx* ctx, uint64_t seed_base, const uint64_t* seeds, uint64_t n,
+                                   const demi_limits* limits, demi_verdict* out) {
+  if (!ctx) return DEMI_ERR_INVALID_ARG;
+  if (n == 0) return DEMI_OK;
+  if (!out) return fail(ctx, DEMI_ERR_INVALID_ARG, "null output");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (ctx->out_cap < n) {
+    if (ctx->d_out) (void)hipFree(ctx->d_out);
+    ctx->d_out = nullptr; ctx->out_cap = 0;
+    HIP_TRY(ctx, hipMalloc(&ctx->d_out, sizeof(demi_verdict) * n));
+    ctx->out_cap = n;
+  }
+  const uint64_t* d_seeds = nullptr;
+  if (seeds) {
+    if (ctx->seeds_cap < n) {
+      if (ctx->d_seeds) (void)hipFree(ctx->d_seeds);
+      ctx->d_seeds = nullptr; ctx->seeds_cap = 0;
+      HIP_TRY(ctx, hipMalloc(&ctx->d_seeds, sizeof(uint64_t) * n));
+      ctx->seeds_cap = n;
+    }
+    HIP_TRY(ctx, hipMemcpy(ctx->d_seeds, seeds, sizeof(uint64_t) * n, hipMemcpyHostToDevice));
+    d_seeds = ctx->d_seeds;
+  }
+  int rc = demi_random_explore_dev(ctx, seed_base, d_seeds, n, limits, ctx->d_out, nullptr);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  HIP_TRY(ctx, hipMemcpy(out, ctx->d_out, sizeof(demi_verdict) * n, hipMemcpyDeviceToHost));
+  return DEMI_OK;
+}
+
+extern "C" int demi_random_get_trace(demi_ctx* ctx, uint64_t seed, const demi_limits* limits, demi_verdict* verdict,
+                                     demi_rec_event* out, uint32_t cap, uint32_t* n_out) {
+  if (!ctx) return DEMI_ERR_INVALID_ARG;
+  if (!verdict || !n_out || (!out && cap)) return fail(ctx, DEMI_ERR_INVALID_ARG, "null output");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (ctx->out_cap < 1) {
+    HIP_TRY(ctx, hipMalloc(&ctx->d_out, sizeof(demi_verdict)));
+    ctx->out_cap = 1;
+  }
+  K1Args a;
+  int rc = make_k1_args(ctx, seed, nullptr, 1, limits, ctx->d_out, &a);
+  if (rc) return rc;
+  a.rec_out = ctx->d_rec;
+  a.rec_count = ctx->d_rec_count;
+  a.rec_cap = DEMI_MAX_REC_EVENTS;
+  rc = launch_k1<true>(ctx, limits->p_max, a, nullptr);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  uint32_t n_rec = 0;
+  HIP_TRY(ctx, hipMemcpy(verdict, ctx->d_out, sizeof(demi_verdict), hipMemcpyDeviceToHost));
+  HIP_TRY(ctx, hipMemcpy(&n_rec, ctx->d_rec_count, sizeof n_rec, hipMemcpyDeviceToHost));
+  *n_out = n_rec;
+  if (n_rec > DEMI_MAX_REC_EVENTS) return fail(ctx, DEMI_ERR_CAPACITY, "execution recorded %u events (> %d)", n_rec, DEMI_MAX_REC_EVENTS);
+  if (n_rec > cap) return fail(ctx, DEMI_ERR_CAPACITY, "caller buffer holds %u events, %u recorded", cap, n_rec);
+  if (n_rec) HIP_TRY(ctx, hipMemcpy(out, ctx->d_rec, sizeof(demi_rec_event) * n_rec, hipMemcpyDeviceToHost));
+  return DEMI_OK;
+}

@@ -1,0 +1,429 @@
+// k1_random_explore.hpp — K1: one RandomScheduler execution per wavefront lane.
+//
+// Restates, per lane, RandomScheduler.explore / schedule_new_message / event_produced
+// (schedulers/RandomScheduler.scala:234-272, 352-485, 274-321), FullyRandom + RandomizedHashSet
+// (RandomScheduler.scala:635-697, schedulers/Util.scala:110-185), the ExternalEventInjector /
+// EventOrchestrator trace driver (schedulers/ExternalEventInjector.scala:306-365, 382-441, 541-580;
+// schedulers/EventOrchestrator.scala:132-189) and the Instrumenter's timer bookkeeping
+// (Instrumenter.scala:159-168, 1008-1016, 1145-1200) over a table-encoded transition function.
+//
+// Execution shape: a wave is a pool of 64 independent simulators.  Each loop iteration every live
+// lane performs one scheduling step (guards, flush, random pick, swap-remove) and runs the picked
+// message's handler rows.  A lane whose execution ends writes its 16-byte verdict and immediately
+// refills with the next schedule index (wave ballot + prefix count; batches are claimed from one
+// global counter), so variable execution lengths do not idle lanes until the very tail.
+#pragma once
+
+#include "demi_device.hpp"
+
+namespace demi {
+
+struct K1Args {
+  const DevModel* model;
+  const uint64_t* trace;    // demi_ext_event[n_ev] as 8-byte words
+  uint32_t n_ev;
+  uint32_t exists;          // actors created by populateActorSystem
+  uint64_t seed_base;
+  const uint64_t* seeds;    // optional explicit seeds
+  uint64_t n;
+  uint32_t max_messages, interval, looking_for_valid, looking_for;
+  demi_verdict* out;
+  unsigned long long* work_counter;  // zeroed before every launch
+  demi_rec_event* rec_out;  // REC only: [n][rec_cap]
+  uint32_t* rec_count;      // REC only: [n]
+  uint32_t rec_cap;
+};
+
+enum : int { PH_IDLE = 0, PH_INJECT = 1, PH_DISPATCH = 2, PH_FINISH = 3 };
+
+constexpr int K1_WAVES = 4;          // waves per workgroup
+constexpr int K1_BATCH = 64;         // schedule indices claimed per atomic
+
+// dynamic LDS bytes for a launch
+__host__ __device__ inline size_t k1_lds_shared_bytes(uint32_t code_len, uint32_t n_ev, uint32_t n_hs) {
+  size_t b = 0;
+  b += (size_t)n_ev * 8;            // trace
+  b += DEMI_MAX_ACTORS * 8;         // init states
+  b += (size_t)code_len * 4;        // code
+  b += (size_t)n_hs * 4;            // handler_start
+  b += DEMI_MAX_MSG_TYPES * 4;      // meta
+  b += 132 * 4;                     // divmagic (padded)
+  return (b + 15) & ~(size_t)15;
+}
+template <int PMAX, bool REC>
+__host__ __device__ inline size_t k1_lds_wave_bytes(uint32_t n_actors) {
+  return (size_t)n_actors * 64 * 8 + (size_t)PMAX * 64 * 4 * (REC ? 2 : 1);
+}
+
+template <int PMAX, bool REC>
+__global__ __launch_bounds__(K1_WAVES * 64) void k1_random_explore(const K1Args args) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const DevModel* __restrict__ gm = args.model;
+  const uint32_t A = gm->n_actors, NT = gm->n_msg_types, code_len = gm->code_len;
+  const uint32_t n_hs = gm->n_classes * NT;
+  const uint32_t E = args.n_ev;
+
+  // ---- carve the workgroup-shared tables (16-byte aligned base, 8-byte items first)
+  uint64_t* s_trace = reinterpret_cast<uint64_t*>(smem);
+  uint64_t* s_init = s_trace + E;
+  uint32_t* s_code = reinterpret_cast<uint32_t*>(s_init + DEMI_MAX_ACTORS);
+  uint32_t* s_hs = s_code + code_len;
+  uint32_t* s_meta = s_hs + n_hs;
+  uint32_t* s_magic = s_meta + DEMI_MAX_MSG_TYPES;
+  unsigned char* wave_base = smem + k1_lds_shared_bytes(code_len, E, n_hs);
+
+  // the trace and the tables are streamed in once per workgroup with coalesced loads
+  for (uint32_t i = threadIdx.x; i < E; i += blockDim.x) s_trace[i] = args.trace[i];
+  for (uint32_t i = threadIdx.x; i < DEMI_MAX_ACTORS; i += blockDim.x) s_init[i] = gm->init_state[i];
+  for (uint32_t i = threadIdx.x; i < code_len; i += blockDim.x) s_code[i] = gm->code[i];
+  for (uint32_t i = threadIdx.x; i < n_hs; i += blockDim.x) s_hs[i] = gm->handler_start[i];
+  for (uint32_t i = threadIdx.x; i < DEMI_MAX_MSG_TYPES; i += blockDim.x) s_meta[i] = gm->meta[i];
+  for (uint32_t i = threadIdx.x; i < 129; i += blockDim.x) s_magic[i] = gm->divmagic[i];
+  __syncthreads();
+
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned char* wb = wave_base + (size_t)wave * k1_lds_wave_bytes<PMAX, REC>(A);
+  uint64_t* st = reinterpret_cast<uint64_t*>(wb) + lane;               // st[actor * 64]
+  uint32_t* pend = reinterpret_cast<uint32_t*>(wb + (size_t)A * 64 * 8) + lane;  // pend[slot * 64]
+  uint32_t* pend_id = pend + (REC ? PMAX * 64 : 0);                    // REC: ids, same layout
+
+  const uint32_t inv_kind = gm->inv_kind, inv_fa = gm->inv_fa, inv_va = gm->inv_va, inv_fb = gm->inv_fb;
+  const uint32_t fp_mask = gm->fp_match_mask;
+  const uint32_t max_messages = args.max_messages ? args.max_messages : 0x7FFFFFFFu;
+  const uint32_t interval = args.interval;
+  const uint32_t exists = args.exists;
+
+  // ---- per-lane simulator state
+  int ph = PH_IDLE;
+  uint64_t sched = 0, rng = 0, hash = 0;
+  uint32_t n_pend = 0, count = 0, cnt_mod = 0, tidx = 0, inj_lo = 0, inj_hi = 0;
+  Net net = {0, 0, 0};
+  uint64_t tq = 0, resend = 0;        // messagesToSend timers / timersToResend: 1 byte each (rcv<<5 | type)
+  uint32_t n_tq = 0, n_resend = 0;
+  uint32_t just = 0, rep = 0;         // justScheduledTimers / registered repeating timers (bit rcv*4+tidx)
+  uint32_t viol = 0, flags = 0;
+  uint32_t next_id = 1, n_rec = 0;    // REC only
+  demi_rec_event* rec = nullptr;
+
+  bool fresh = false;
+  // wave-uniform work cursor: [b_next, b_end) is the unassigned rest of the last claimed batch
+  uint64_t b_next = 0, b_end = 0;
+  bool exhausted = false;
+  uint32_t ac_packed = 0;             // actor_class, 4 bits per actor
+  for (uint32_t a = 0; a < A; a++) ac_packed |= gm->actor_class[a] << (4 * a);
+
+#define REC_PUSH(KIND, SND, RCV, TYPE, P0, P1, FL, EXT, ID)                                   \
+  do {                                                                                        \
+    if (REC) {                                                                                \
+      if (n_rec < args.rec_cap) {                                                             \
+        demi_rec_event e_;                                                                    \
+        e_.kind = (uint8_t)(KIND); e_.snd = (uint8_t)(SND); e_.rcv = (uint8_t)(RCV);          \
+        e_.msg_type = (uint8_t)(TYPE); e_.p0 = (uint8_t)(P0); e_.p1 = (uint8_t)(P1);          \
+        e_.flags = (uint8_t)(FL); e_.ext_idx = (uint8_t)(EXT); e_.id = (ID);                  \
+        rec[n_rec] = e_;                                                                      \
+      }                                                                                       \
+      n_rec++;                                                                                \
+    }                                                                                         \
+  } while (0)
+
+#define PEND_APPEND(WORD, ID)                                         \
+  do {                                                                \
+    if (n_pend >= (uint32_t)PMAX) { flags |= DEMI_V_PENDING_OVF; }    \
+    else {                                                            \
+      pend[n_pend * 64] = (WORD);                                     \
+      if (REC) pend_id[n_pend * 64] = (ID);                           \
+      n_pend++;                                                       \
+    }                                                                 \
+  } while (0)
+
+#define OVF_ANY (DEMI_V_PENDING_OVF | DEMI_V_QUEUE_OVF)
+#define TIMER_BIT(RCV, TYPE) (1u << ((RCV) * DEMI_MAX_TIMER_TYPES + (s_meta[(TYPE)] >> 8)))
+
+  // RandomScheduler.enqueue_timer (:549-559) -> handle_timer (ExternalEventInjector.scala:282-297)
+  auto enqueue_timer = [&](uint32_t rcv, uint32_t type) {
+    const uint64_t b = (uint64_t)((rcv << 5) | type);
+    if (just & TIMER_BIT(rcv, type)) {
+      if (n_resend >= DEMI_RESEND_CAP) { flags |= DEMI_V_QUEUE_OVF; return; }
+      resend |= b << (8 * n_resend);
+      n_resend++;
+    } else {
+      if (n_tq >= DEMI_TQ_CAP) { flags |= DEMI_V_QUEUE_OVF; return; }
+      tq |= b << (8 * n_tq);
+      n_tq++;
+    }
+  };
+
+  auto check_invariant = [&]() -> uint32_t {
+    const uint32_t fp = invariant_code(gm, st, exists, A, inv_kind, inv_fa, inv_va, inv_fb);
+    if (!fp) return 0u;
+    if (args.looking_for_valid) return (((fp ^ args.looking_for) & fp_mask) == 0) ? args.looking_for : 0u;
+    return fp;
+  };
+
+  for (;;) {
+    // ------------------------------------------------------------ refill idle lanes
+    {
+      const uint64_t idle = __ballot(ph == PH_IDLE);
+      if (idle != 0 && !exhausted) {                     // wave-uniform
+        const uint32_t want = (uint32_t)__popcll(idle);
+        const uint64_t have = b_end - b_next;
+        uint64_t got = 0;
+        if (have < want) {
+          // one claim always suffices: at most 64 lanes ask and a batch holds 64 indices
+          if (lane == 0) got = atomicAdd(args.work_counter, (unsigned long long)K1_BATCH);
+          got = __shfl(got, 0);
+        }
+        if (ph == PH_IDLE) {
+          const uint32_t rank = (uint32_t)__popcll(idle & ((1ULL << lane) - 1));
+          const uint64_t my = (rank < have) ? (b_next + rank) : (got + (rank - have));
+          if (my < args.n) { sched = my; ph = PH_INJECT; fresh = true; }
+        }
+        if (have < want) { b_next = got + (want - have); b_end = got + K1_BATCH; }
+        else b_next += want;
+        if (b_next >= args.n) exhausted = true;
+      }
+      if (__ballot(ph != PH_IDLE) == 0) break;           // nothing running and nothing left to claim
+    }
+
+    // ------------------------------------------------------------ (re)initialise + inject
+    if (ph == PH_INJECT) {
+      if (fresh) {
+        fresh = false;
+        // new execution: `new FullyRandom(seed)`; populateActorSystem isolates every created actor
+        // (ExternalEventInjector.scala:371-378)
+        const uint64_t seed = args.seeds ? args.seeds[sched] : args.seed_base + sched;
+        rng = jr_seed(seed);
+        hash = 0xCBF29CE484222325ULL;
+        net.inaccessible = exists; net.killed = 0; net.partitioned = 0;
+        for (uint32_t a = 0; a < A; a++) st[a * 64] = s_init[a];
+        if (REC) { rec = args.rec_out + sched * (uint64_t)args.rec_cap; n_rec = 0; next_id = 1; }
+      }
+      // EventOrchestrator.inject_until_quiescence (:132-189).  Send events are not materialised:
+      // messagesToSend's external part is the index range [inj_lo, inj_hi) of the trace.
+      inj_lo = tidx;
+      bool loop = true;
+      while (loop && tidx < E) {
+        const uint64_t ev = s_trace[tidx];
+        const uint32_t kind = (uint32_t)ev & 0xFF, a = (uint32_t)(ev >> 8) & 0xFF, b = (uint32_t)(ev >> 16) & 0xFF;
+        if (kind == DEMI_EV_START) {
+          REC_PUSH(DEMI_REC_SPAWN, 0, a, 0, 0, 0, 0, tidx, 0);
+          net.inaccessible &= ~(1u << a); net.killed &= ~(1u << a);
+        } else if (kind == DEMI_EV_KILL) {
+          REC_PUSH(DEMI_REC_KILL, 0, a, 0, 0, 0, 0, tidx, 0);
+          net.killed |= 1u << a; net.inaccessible |= 1u << a;
+        } else if (kind == DEMI_EV_PARTITION) {
+          REC_PUSH(DEMI_REC_PARTITION, a, b, 0, 0, 0, 0, tidx, 0);
+          net.partitioned |= 1ULL << (a * 8 + b);
+        } else if (kind == DEMI_EV_UNPARTITION) {
+          REC_PUSH(DEMI_REC_UNPARTITION, a, b, 0, 0, 0, 0, tidx, 0);
+          net.partitioned &= ~(1ULL << (a * 8 + b));
+        } else if (kind == DEMI_EV_WAIT_QUIESCENCE) {
+          REC_PUSH(DEMI_REC_BEGIN_WAIT_QUIESCENCE, 0, 0, 0, 0, 0, 0, tidx, 0);
+          loop = false;
+        }
+        tidx++;
+      }
+      inj_hi = tidx;
+      ph = PH_DISPATCH;
+    }
+
+    // ------------------------------------------------------------ one scheduling step + delivery
+    if (ph == PH_DISPATCH) {
+      bool none = false;
+      if (viol) {
+        none = true;                                            // :354-360
+      } else if (count > max_messages) {                        // :369-373 finish_early
+        flags |= DEMI_V_MAXMSG; tidx = E; none = true;
+      } else {
+        if (interval > 0 && cnt_mod == 0 && count != 0) {       // :376-394 (lastCheckpoint == 0)
+          viol = check_invariant();
+          if (viol) none = true;
+        }
+        if (!none) {
+          // send_external_messages (:424): injected Sends first (no partition check, :298-308) ...
+          for (uint32_t i = inj_lo; i < inj_hi; i++) {
+            const uint64_t ev = s_trace[i];
+            const uint32_t kind = (uint32_t)ev & 0xFF, a = (uint32_t)(ev >> 8) & 0xFF;
+            if (kind == DEMI_EV_SEND && ((exists >> a) & 1)) {
+              const uint32_t type = (uint32_t)(ev >> 24) & 0xFF, p0 = (uint32_t)(ev >> 32) & 0xFF,
+                             p1 = (uint32_t)(ev >> 40) & 0xFF;
+              const uint32_t id = next_id; if (REC) next_id++;
+              PEND_APPEND(msg_word(type, DEMI_DEADLETTERS, a, p0, p1), id);
+              REC_PUSH(DEMI_REC_MSG_SEND, DEMI_DEADLETTERS, a, type, p0, p1, 1, i, id);
+            }
+          }
+          inj_lo = inj_hi;
+          // ... then timers: internal messages from deadLetters, dropped when the receiver is
+          // inaccessible (crosses_partition(deadLetters, rcv), :287-297)
+          for (uint32_t k = 0; k < n_tq; k++) {
+            const uint32_t bt = (uint32_t)(tq >> (8 * k)) & 0xFF, rcv = bt >> 5, type = bt & 31;
+            const uint32_t id = next_id; if (REC) next_id++;
+            const bool drop = (net.inaccessible >> rcv) & 1;
+            if (!drop) PEND_APPEND(msg_word(type, DEMI_DEADLETTERS, rcv, 0, 0), id);
+            REC_PUSH(DEMI_REC_MSG_SEND, DEMI_DEADLETTERS, rcv, type, 0, 0, 2 | (drop ? 4 : 0), 255, id);
+          }
+          tq = 0; n_tq = 0;
+          if ((flags & OVF_ANY) || n_pend == 0) none = true;
+        }
+      }
+
+      if (!none) {
+        // FullyRandom.removeRandomElement -> RandomizedHashSet: nextInt(arr.length), swap with last
+        const uint32_t idx = jr_next_int(rng, n_pend, s_magic);
+        const uint32_t w = pend[idx * 64];
+        const uint32_t last = pend[(n_pend - 1) * 64];
+        pend[idx * 64] = last;
+        uint32_t wid = 0;
+        if (REC) { wid = pend_id[idx * 64]; pend_id[idx * 64] = pend_id[(n_pend - 1) * 64]; }
+        n_pend--;
+        count++;
+        cnt_mod++; if (cnt_mod == interval) cnt_mod = 0;
+        const uint32_t type = w_type(w), me = w_dst(w), src = w_src(w);
+        REC_PUSH(DEMI_REC_MSG_EVENT, src, me, type, w_p0(w), w_p1(w), 0, 255, wid);
+        hash_step(hash, w);
+        // updateRepeatingTimer (:405-421) and the Instrumenter's retrigger (Instrumenter.scala:1008-1016)
+        const uint32_t meta = s_meta[type];
+        const uint32_t tbit = 1u << (me * DEMI_MAX_TIMER_TYPES + (meta >> 8));
+        const bool is_rep = ((meta & 0xFF) == DEMI_MSG_TIMER) && (rep & tbit);
+        if (is_rep) {
+          just |= tbit;
+          enqueue_timer(me, type);      // parked in timersToResend (it is in justScheduledTimers)
+        } else {
+          for (uint32_t k = 0; k < n_resend; k++) {
+            if (n_tq >= DEMI_TQ_CAP) { flags |= DEMI_V_QUEUE_OVF; break; }
+            tq |= ((resend >> (8 * k)) & 0xFFull) << (8 * n_tq);
+            n_tq++;
+          }
+          resend = 0; n_resend = 0; just = 0;
+        }
+
+        // ---- the handler rows: r0..7 = state (lo), r8..15 = T0..T3, P0, P1, SRC, ME (hi)
+        const uint32_t hs = s_hs[((ac_packed >> (4 * me)) & 15u) * NT + type];
+        if (hs != 0xFFFFu && !(flags & OVF_ANY)) {
+          uint64_t lo = st[me * 64];
+          uint64_t hi = ((uint64_t)w_p0(w) << 32) | ((uint64_t)w_p1(w) << 40) | ((uint64_t)src << 48) |
+                        ((uint64_t)me << 56);
+          uint32_t pc = hs;
+          while (pc < code_len) {
+            const uint32_t row = s_code[pc++];
+            const uint32_t op = row & 0xFF;
+            if (op == DEMI_OP_HALT) break;
+            const uint32_t dsti = (row >> 8) & 15, ai = (row >> 12) & 15, aux = (row >> 17) & 0x7F, braw = row >> 24;
+            const uint32_t a = (uint32_t)(((ai & 8) ? hi : lo) >> ((ai & 7) * 8)) & 0xFF;
+            const uint32_t breg = (uint32_t)(((braw & 8) ? hi : lo) >> ((braw & 7) * 8)) & 0xFF;
+            const uint32_t b = (row & 0x10000u) ? braw : breg;
+            if (op < DEMI_OP_SKIPZ) {
+              uint32_t r;
+              switch (op) {
+                case DEMI_OP_MOV: r = b; break;
+                case DEMI_OP_ADD: r = a + b; break;
+                case DEMI_OP_SUB: r = a - b; break;
+                case DEMI_OP_AND: r = a & b; break;
+                case DEMI_OP_OR: r = a | b; break;
+                case DEMI_OP_XOR: r = a ^ b; break;
+                case DEMI_OP_SHL: r = a << (b & 7); break;
+                case DEMI_OP_SHR: r = a >> (b & 7); break;
+                case DEMI_OP_BITSET: r = a | (1u << (b & 7)); break;
+                case DEMI_OP_POPC: r = __popc(b); break;
+                case DEMI_OP_EQ: r = a == b; break;
+                case DEMI_OP_NE: r = a != b; break;
+                case DEMI_OP_LT: r = a < b; break;
+                case DEMI_OP_GE: r = a >= b; break;
+                case DEMI_OP_LE: r = a <= b; break;
+                case DEMI_OP_GT: r = a > b; break;
+                case DEMI_OP_MIN: r = a < b ? a : b; break;
+                default: r = a > b ? a : b; break;   // MAX
+              }
+              const uint32_t shft = (dsti & 7) * 8;
+              const uint64_t msk = 0xFFull << shft, val = (uint64_t)(r & 0xFF) << shft;
+              if (dsti & 8) hi = (hi & ~msk) | val; else lo = (lo & ~msk) | val;
+            } else if (op <= DEMI_OP_SKIP) {
+              const bool take = (op == DEMI_OP_SKIP) || ((op == DEMI_OP_SKIPZ) == (a == 0));
+              if (take) pc += braw;
+            } else if (op == DEMI_OP_SEND || op == DEMI_OP_BCAST) {
+              // event_produced for internal messages (:287-297): dropped at send time when
+              // crosses_partition, else appended to the pending set
+              const uint32_t p0 = (uint32_t)(((dsti & 8) ? hi : lo) >> ((dsti & 7) * 8)) & 0xFF;
+              const uint32_t first = (op == DEMI_OP_SEND) ? a : 0u;
+              const uint32_t lastp1 = (op == DEMI_OP_SEND) ? a + 1 : A;
+              for (uint32_t t = first; t < lastp1 && t < A; t++) {
+                if (op == DEMI_OP_BCAST && t == me) continue;
+                if (!((exists >> t) & 1)) continue;
+                const uint32_t id = next_id; if (REC) next_id++;
+                const bool drop = crosses_partition(net, me, t);
+                if (!drop) PEND_APPEND(msg_word(aux, me, t, p0, b), id);
+                REC_PUSH(DEMI_REC_MSG_SEND, me, t, aux, p0, b, drop ? 4 : 0, 255, id);
+              }
+            } else if (op == DEMI_OP_TSET || op == DEMI_OP_TREP) {
+              // registerCancellable + handleTick (Instrumenter.scala:1145-1200)
+              const uint32_t bit = TIMER_BIT(me, aux);
+              if (!(rep & bit)) {               // else "Non-unique timer" (:1154-1157)
+                if (op == DEMI_OP_TREP) rep |= bit;
+                enqueue_timer(me, aux);
+              }
+            } else if (op == DEMI_OP_TCANCEL) {
+              // cancelTimer (Instrumenter.scala:159-168) -> notify_timer_cancel (:525-534)
+              rep &= ~TIMER_BIT(me, aux);
+              const uint32_t want = (me << 5) | aux;
+              bool found = false;
+              for (uint32_t k = 0; k < n_tq; k++) {          // handle_timer_cancel: messagesToSend first
+                if (((uint32_t)(tq >> (8 * k)) & 0xFF) == want) {
+                  const uint64_t lowm = (k == 0) ? 0ull : (~0ull >> (64 - 8 * k));
+                  tq = (tq & lowm) | ((tq >> 8) & ~lowm);
+                  n_tq--; found = true; break;
+                }
+              }
+              if (!found) {
+                const uint32_t wantw = msg_word(aux, DEMI_DEADLETTERS, me, 0, 0);
+                for (uint32_t k = 0; k < n_pend; k++) {      // FullyRandom.remove: first match, swap-remove
+                  if (pend[k * 64] == wantw) {
+                    pend[k * 64] = pend[(n_pend - 1) * 64];
+                    if (REC) pend_id[k * 64] = pend_id[(n_pend - 1) * 64];
+                    n_pend--; break;
+                  }
+                }
+              }
+            }
+            if (flags & OVF_ANY) break;
+          }
+          st[me * 64] = lo;
+        }
+        if (flags & OVF_ANY) ph = PH_FINISH;
+      } else {
+        // quiescence: notify_quiescence (:487-500) / handle_quiescence (ExternalEventInjector.scala:541-580)
+        if ((flags & OVF_ANY) || viol || tidx >= E) {
+          ph = PH_FINISH;
+        } else {
+          REC_PUSH(DEMI_REC_QUIESCENCE, 0, 0, 0, 0, 0, 0, 255, 0);
+          ph = PH_INJECT;
+        }
+      }
+    }
+
+    // ------------------------------------------------------------ verdict
+    if (ph == PH_FINISH) {
+      // explore(): `if (messagesScheduledSoFar <= maxMessages) checkIfBugFound` (:256-262, 156-180)
+      if (!(flags & (OVF_ANY | DEMI_V_MAXMSG)) && !viol) viol = check_invariant();
+      for (uint32_t a = 0; a < A; a++) hash_step(hash, st[a * 64]);
+      uint4 v;
+      if (flags & OVF_ANY) {
+        v.x = flags & OVF_ANY; v.y = 0; v.z = 0; v.w = 0;
+      } else {
+        v.x = (flags & 0xFF) | (viol ? DEMI_V_VIOLATION : 0u) | ((tidx & 0xFF) << 8) | ((count & 0xFFFF) << 16);
+        v.y = viol; v.z = (uint32_t)hash; v.w = (uint32_t)(hash >> 32);
+      }
+      *reinterpret_cast<uint4*>(&args.out[sched]) = v;
+      if (REC) args.rec_count[sched] = n_rec;
+      // reset the simulator for the next schedule
+      ph = PH_IDLE;
+      n_pend = 0; count = 0; cnt_mod = 0; tidx = 0; inj_lo = 0; inj_hi = 0;
+      tq = 0; resend = 0; n_tq = 0; n_resend = 0; just = 0; rep = 0; viol = 0; flags = 0; hash = 0;
+    }
+  }
+#undef REC_PUSH
+#undef PEND_APPEND
+#undef OVF_ANY
+#undef TIMER_BIT
+}
+
+}  // namespace demi

@@ -298,6 +298,7 @@ typedef struct {
   uint32_t n_pend, p_max;
   mts_entry mts[MTS_CAP]; /* messagesToSend, V/schedulers/ExternalEventInjector.scala:109 */
   uint32_t n_mts;
+  uint32_t n_mts_timers;  /* timers among them; capacity DEMI_TQ_CAP is part of the spec */
   uint32_t just_scheduled; /* justScheduledTimers, V/schedulers/RandomScheduler.scala:109 */
   uint32_t repeating;      /* timerToCancellable of ongoing timers, V/Instrumenter.scala:141 */
   uint8_t resend[DEMI_RESEND_CAP][2]; /* timersToResend (rcv, type), RandomScheduler.scala:113 */
@@ -309,6 +310,7 @@ typedef struct {
   uint64_t hash;
   demi_rec_event* rec;
   uint32_t rec_cap, n_rec;
+  orc_effect fx[DEMI_MAX_CODE * DEMI_MAX_ACTORS];
 } exec_t;
 
 static void rec_push(exec_t* x, uint8_t kind, uint8_t snd, uint8_t rcv, uint8_t type, uint8_t p0, uint8_t p1,
@@ -354,8 +356,9 @@ static pend_entry pend_remove_at(exec_t* x, uint32_t i) {
 /* ExternalEventInjector.handle_timer, V/schedulers/ExternalEventInjector.scala:282-297 */
 static void handle_timer(exec_t* x, uint32_t rcv, uint32_t type) {
   if (x->flags & OVF_ANY) return;
-  if (x->n_mts >= MTS_CAP) { x->flags |= DEMI_V_QUEUE_OVF; return; }
+  if (x->n_mts >= MTS_CAP || x->n_mts_timers >= DEMI_TQ_CAP) { x->flags |= DEMI_V_QUEUE_OVF; return; }
   x->mts[x->n_mts++] = (mts_entry){(uint8_t)rcv, (uint8_t)type, 0, 0, 0, 255};
+  x->n_mts_timers++;
 }
 
 /* RandomScheduler.enqueue_timer, V/schedulers/RandomScheduler.scala:549-559 */
@@ -390,6 +393,7 @@ static void cancel_timer(exec_t* x, uint32_t rcv, uint32_t type) {
     if (!x->mts[i].is_external && x->mts[i].rcv == rcv && x->mts[i].type == type) {
       memmove(&x->mts[i], &x->mts[i + 1], (x->n_mts - i - 1) * sizeof(mts_entry));
       x->n_mts--;
+      x->n_mts_timers--;
       return;
     }
   }
@@ -425,6 +429,7 @@ static void send_external_messages(exec_t* x) {
     event_produced(x, DEMI_DEADLETTERS, e->rcv, e->type, e->p0, e->p1, e->is_external, e->ext_idx);
   }
   x->n_mts = 0;
+  x->n_mts_timers = 0;
 }
 
 /* EventOrchestrator.inject_until_quiescence, V/schedulers/EventOrchestrator.scala:132-189 */
@@ -484,9 +489,9 @@ static inline void hash_step(uint64_t* h, uint64_t v) { *h = (*h ^ v) * 0x100000
 /* Apply delta to the delivered message and its effects in program order. */
 static void deliver(exec_t* x, uint32_t word) {
   uint32_t me = W_DST(word);
-  orc_effect fx[64];
+  orc_effect* fx = x->fx; /* DEMI_MAX_CODE rows x at most DEMI_MAX_ACTORS effects each: never full */
   int n = orc_vm_run(x->m, me, &x->state[me], (uint8_t)W_TYPE(word), (uint8_t)W_SRC(word), (uint8_t)W_P0(word),
-                     (uint8_t)W_P1(word), x->exists, fx, 64);
+                     (uint8_t)W_P1(word), x->exists, fx, DEMI_MAX_CODE * DEMI_MAX_ACTORS);
   if (n < 0) { x->flags |= DEMI_V_QUEUE_OVF; return; }
   for (int i = 0; i < n; i++) {
     switch (fx[i].kind) {
