@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdemi_gpu.so")
 
 EXPORTS = ["demi_ctx_create", "demi_ctx_destroy", "demi_last_error", "demi_version", "demi_model_load",
-           "demi_trace_load", "demi_random_explore", "demi_random_explore_dev", "demi_random_get_trace"]
+           "demi_trace_load", "demi_random_explore", "demi_random_explore_dev", "demi_random_get_trace", "demi_collect_violations_dev"]
 
 _lib = None
 
@@ -43,6 +43,8 @@ def lib():
                                           C.c_void_p, C.c_void_p]
     L.demi_random_get_trace.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(T.Limits), C.POINTER(T.Verdict),
                                         C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+    L.demi_collect_violations_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p,
+                                              C.c_uint32, C.c_void_p, C.c_void_p]
     _lib = L
     return L
 
@@ -95,6 +97,10 @@ class Context:
     def random_explore_dev(self, n, limits, d_out_ptr, seed_base=0, d_seeds_ptr=None, stream=None):
         self._check(lib().demi_random_explore_dev(self._h, C.c_uint64(seed_base), d_seeds_ptr, n, C.byref(limits),
                                                   d_out_ptr, stream))
+
+    def collect_violations_dev(self, d_verdicts_ptr, n, index_base, d_out_ptr, cap, d_count_ptr, stream=None):
+        self._check(lib().demi_collect_violations_dev(self._h, d_verdicts_ptr, n, C.c_uint64(index_base), d_out_ptr,
+                                                      cap, d_count_ptr, stream))
 
     def random_get_trace(self, seed, limits):
         import numpy as np

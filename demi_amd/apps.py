@@ -1,0 +1,29 @@
+"""The synthetic applications and frozen inputs restating BASELINE.json's configs.
+
+The reference's applications (akka-raft, Spark: NetSys/demi-applications) are not part of
+/root/reference; these table-encoded stand-ins are defined here and frozen under tests/golden/.
+"""
+from . import types as T
+from .fuzzer import events_to_array, raft_trace
+from .model import raft_model
+
+SEED_BASE = 0x5EED0000     # schedule i uses java.util.Random(SEED_BASE + i)
+TRACE_SEED = 0xDE31        # the frozen external traces are generated from this seed
+
+
+def raft5_config2():
+    """BASELINE config 2: akka-raft-like, 5 actors, 50-event trace, maxMessages 200, invariant
+    every 30 deliveries (RunnerUtils.scala:65), pending capacity 64."""
+    model = raft_model(5)
+    events = events_to_array(raft_trace(5, 50, TRACE_SEED))
+    limits = T.Limits(200, 30, 64, 0, 0, 0)
+    return model, events, limits
+
+
+def raft3_config1():
+    """BASELINE config 1 restated: 3 actors, 20 events, 100 schedules (the reference's own
+    CPU-runnable case; runs on the oracle, never reported as "DEMi JVM")."""
+    model = raft_model(3)
+    events = events_to_array(raft_trace(3, 20, TRACE_SEED))
+    limits = T.Limits(200, 30, 64, 0, 0, 0)
+    return model, events, limits

@@ -12,6 +12,7 @@
 
 #include "../../include/demi_gpu.h"
 #include "k1_random_explore.hpp"
+#include "k_collect.hpp"
 
 using namespace demi;
 
@@ -336,5 +337,24 @@ extern "C" int demi_random_get_trace(demi_ctx* ctx, uint64_t seed, const demi_li
   if (n_rec > DEMI_MAX_REC_EVENTS) return fail(ctx, DEMI_ERR_CAPACITY, "execution recorded %u events (> %d)", n_rec, DEMI_MAX_REC_EVENTS);
   if (n_rec > cap) return fail(ctx, DEMI_ERR_CAPACITY, "caller buffer holds %u events, %u recorded", cap, n_rec);
   if (n_rec) HIP_TRY(ctx, hipMemcpy(out, ctx->d_rec, sizeof(demi_rec_event) * n_rec, hipMemcpyDeviceToHost));
+  return DEMI_OK;
+}
+
+// ----------------------------------------------------------------------------- violation set
+extern "C" int demi_collect_violations_dev(demi_ctx* ctx, const demi_verdict* d_verdicts, uint64_t n,
+                                           uint64_t index_base, demi_violation* d_out, uint32_t cap,
+                                           unsigned long long* d_count, void* hip_stream) {
+  if (!ctx) return DEMI_ERR_INVALID_ARG;
+  if (!d_count || (!d_verdicts && n) || (!d_out && cap)) return fail(ctx, DEMI_ERR_INVALID_ARG, "null pointer");
+  hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipMemsetAsync(d_count, 0, sizeof(unsigned long long), stream));
+  if (n == 0) return DEMI_OK;
+  uint64_t blocks = (n + 255) / 256;
+  const uint64_t maxb = (uint64_t)ctx->num_cu * 8;
+  if (blocks > maxb) blocks = maxb;
+  hipLaunchKernelGGL(k_collect_violations, dim3((unsigned)blocks), dim3(256), 0, stream, d_verdicts, n, index_base, d_out,
+                     cap, d_count);
+  HIP_TRY(ctx, hipGetLastError());
   return DEMI_OK;
 }

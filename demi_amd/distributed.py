@@ -1,0 +1,55 @@
+"""Sharding of the schedule-index space across the GPUs of one node.
+
+K1 executions are independent given per-execution seeds, so rank r of W takes the contiguous index
+range shard_range(n, r, W) with the transition table and the trace replicated; there is no
+data-path collective.  The only exchange is the found-violation set: one fixed-size all-gather
+(RCCL over xGMI when the tensors live on GPUs, gloo in the CPU tests) of each rank's compacted
+`demi_violation` list, [count row] + cap entries, so every rank ends with the merged set.
+Payloads are tens of KB: latency-bound, link bandwidth is irrelevant here.
+"""
+from typing import List, Tuple
+
+import numpy as np
+
+from . import types as T
+
+
+def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
+    """[lo, hi) of rank's slice of n schedule indices (strong scaling of a fixed range)."""
+    return n * rank // world, n * (rank + 1) // world
+
+
+def pack_violation_list(entries: np.ndarray, cap: int) -> np.ndarray:
+    """Host-side equivalent of the device layout: int64[(cap+1), 2], row 0 = [count, 0]."""
+    buf = np.zeros((cap + 1, 2), dtype=np.int64)
+    k = min(len(entries), cap)
+    buf[0, 0] = len(entries)
+    if k:
+        buf[1:k + 1] = np.ascontiguousarray(entries[:k]).view(np.int64).reshape(k, 2)
+    return buf
+
+
+def merge_violation_sets(parts: List[np.ndarray], cap: int) -> np.ndarray:
+    """Merge per-rank lists (device layout) into one VIOLATION_DTYPE array sorted by index."""
+    out = []
+    for p in parts:
+        p = np.ascontiguousarray(p, dtype=np.int64)
+        count = int(p[0, 0])
+        k = min(count, cap)
+        if k:
+            out.append(p[1:k + 1].copy().view(T.VIOLATION_DTYPE).reshape(-1))
+    if not out:
+        return np.zeros(0, dtype=T.VIOLATION_DTYPE)
+    all_ = np.concatenate(out)
+    return all_[np.argsort(all_["index"], kind="stable")]
+
+
+def allgather_violation_sets(local: "torch.Tensor", cap: int) -> np.ndarray:
+    """all_gather the fixed-size per-rank list and merge (works on nccl/RCCL and gloo)."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return merge_violation_sets([local.cpu().numpy()], cap)
+    parts = [torch.empty_like(local) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, local)
+    return merge_violation_sets([p.cpu().numpy() for p in parts], cap)

@@ -1,0 +1,166 @@
+"""Host-side mirror of the reference's scheduler plugin surface for the GPU path.
+
+Mirrors (same names, argument meaning and error behaviour):
+  SchedulerConfig      src/main/scala/verification/SchedulerConfig.scala:9-37
+  ViolationFingerprint src/main/scala/verification/minification/TestOracle.scala:9-22
+  TestOracle.test      src/main/scala/verification/minification/TestOracle.scala:30-55
+  RandomScheduler      src/main/scala/verification/schedulers/RandomScheduler.scala:41-613
+  FullyRandom          src/main/scala/verification/schedulers/RandomScheduler.scala:635-697
+  MinimizationStats    src/main/scala/verification/minification/Minimizer.scala:30-217 (replay counter only)
+
+In production the host is the Scala adapter of INTEGRATION.md calling the same C ABI through JNI;
+this Python mirror exists so tests and bench.py drive the kernels the way RunnerUtils would.
+Every compute call goes to libdemi_gpu.so; nothing here simulates an execution on the CPU.
+"""
+from dataclasses import dataclass, field
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+from . import _native
+from . import types as T
+from .model import Model
+
+
+@dataclass
+class SchedulerConfig:
+    """SchedulerConfig.scala:9-37.  On the GPU path the message fingerprinter, the actors and the
+    invariant are all carried by the lowered `model`; failure detector and checkpointing are off
+    (their defaults, :11-12)."""
+    model: Optional[Model] = None
+    enableFailureDetector: bool = False
+    enableCheckpointing: bool = False
+    shouldShutdownActorSystem: bool = True
+    filterKnownAbsents: bool = False
+    ignoreTimers: bool = False
+    abortUponDivergence: bool = False
+    populate_all_actors: bool = False    # setActorNamePropPairs
+
+
+@dataclass(frozen=True)
+class ViolationFingerprint:
+    """TestOracle.scala:9-22.  `code` is the invariant descriptor's fingerprint word."""
+    code: int
+    match_mask: int = 0xFFFFFFFF
+
+    def matches(self, other: "ViolationFingerprint") -> bool:
+        return ((self.code ^ other.code) & self.match_mask) == 0
+
+    def affectedNodes(self) -> List[int]:
+        return [i for i in range(T.MAX_ACTORS) if (self.code >> i) & 1]
+
+
+@dataclass
+class EventTrace:
+    """EventTrace.scala:20: the recorded events of one execution + the externals that drove it."""
+    events: np.ndarray                 # REC_EVENT_DTYPE
+    original_externals: np.ndarray     # EXT_EVENT_DTYPE
+
+
+class MinimizationStats:
+    """Minimizer.scala:30-217, replay counter only (`increment_replays` is the reference's own
+    'schedules evaluated' counter, RandomScheduler.scala:251-253)."""
+
+    def __init__(self):
+        self.total_replays = 0
+
+    def increment_replays(self, n=1):
+        self.total_replays += n
+
+
+@dataclass
+class FullyRandom:
+    """RandomizationStrategy with a seed (RandomScheduler.scala:635-637); the user-defined filter
+    is not supported on the GPU path."""
+    seed: int = 0
+
+
+class RandomScheduler:
+    """RandomScheduler(schedulerConfig, max_executions, invariant_check_interval, strategy).
+
+    Execution i of explore() is one full run with a fresh `FullyRandom(seed = seed_base + i)`:
+    the per-execution-seed shape of RunnerUtils.fuzz (RunnerUtils.scala:75-90), which is the
+    parallelisable contract (the carried-RNG mode of one scheduler instance is sequential)."""
+
+    def __init__(self, schedulerConfig: SchedulerConfig, max_executions: int = 1,
+                 invariant_check_interval: int = 0, randomizationStrategy: Optional[FullyRandom] = None,
+                 seed_base: Optional[int] = None, device: int = 0, p_max: int = 64):
+        self.schedulerConfig = schedulerConfig
+        self.max_executions = max_executions
+        self.invariant_check_interval = invariant_check_interval
+        self.seed_base = seed_base if seed_base is not None else (randomizationStrategy or FullyRandom()).seed
+        self.maxMessages = 0x7FFFFFFF            # Int.MaxValue (:54)
+        self.p_max = p_max
+        self.stats: Optional[MinimizationStats] = None
+        self._model: Optional[Model] = schedulerConfig.model
+        self._ctx = _native.Context(device)
+        self._loaded_model = False
+        self._loaded_trace = None
+
+    def getName(self) -> str:
+        return "RandomScheduler"
+
+    def setMaxMessages(self, _maxMessages: int):
+        self.maxMessages = _maxMessages
+
+    def setInvariant(self, model: Model):
+        """setInvariant (:521-523): on the GPU path the invariant descriptor travels with the model."""
+        self._model = model
+        self._loaded_model = False
+
+    # -- internals
+    def _limits(self, lookingFor: Optional[ViolationFingerprint]) -> T.Limits:
+        mm = 0 if self.maxMessages >= 0x7FFFFFFF else self.maxMessages
+        return T.Limits(mm, max(0, self.invariant_check_interval), self.p_max,
+                        1 if lookingFor is not None else 0, lookingFor.code if lookingFor is not None else 0,
+                        1 if self.schedulerConfig.populate_all_actors else 0)
+
+    def _prepare(self, trace):
+        if self._model is None or self._model.inv_kind == T.INV_NONE:
+            # IllegalArgumentException("Must invoke setInvariant before test()") (:244-246)
+            raise ValueError("Must invoke setInvariant before test()")
+        if not self._loaded_model:
+            self._ctx.model_load(self._model.to_struct())
+            self._loaded_model = True
+            self._loaded_trace = None
+        ev = np.ascontiguousarray(trace, dtype=T.EXT_EVENT_DTYPE)
+        key = ev.tobytes()
+        if self._loaded_trace != key:
+            self._ctx.trace_load(ev)
+            self._loaded_trace = key
+        return ev
+
+    # -- GPU extension: the full verdict set of max_executions schedules
+    def explore_all(self, _trace, _lookingFor: Optional[ViolationFingerprint] = None) -> np.ndarray:
+        self._prepare(_trace)
+        if self.stats is not None:
+            self.stats.increment_replays(self.max_executions)
+        return self._ctx.random_explore(self.max_executions, self._limits(_lookingFor), seed_base=self.seed_base)
+
+    def explore(self, _trace, _lookingFor: Optional[ViolationFingerprint] = None
+                ) -> Optional[Tuple[EventTrace, ViolationFingerprint]]:
+        """explore (:234-272): the first violating execution, or None.  The GPU evaluates all
+        max_executions schedules; the reference-compatible answer is the lowest index."""
+        ev = self._prepare(_trace)
+        verdicts = self.explore_all(ev, _lookingFor)
+        hits = np.nonzero(verdicts["flags"] & T.V_VIOLATION)[0]
+        if len(hits) == 0:
+            return None
+        i = int(hits[0])
+        v, rec = self._ctx.random_get_trace(self.seed_base + i, self._limits(_lookingFor))
+        assert v.flags == int(verdicts["flags"][i]) and v.hash == int(verdicts["hash"][i])
+        # checkIfBugFound prunes the externals that were never injected (:160-163)
+        used = ev[:T.verdict_trace_idx(v.flags)]
+        mask = self._model.fp_match_mask if self._model else 0xFFFFFFFF
+        return EventTrace(rec, used), ViolationFingerprint(int(v.fingerprint), mask)
+
+    def test(self, events, violation_fingerprint: ViolationFingerprint, _stats: Optional[MinimizationStats] = None
+             ) -> Optional[EventTrace]:
+        """TestOracle.test (:597-612): Some(trace) iff the violation is reproduced within
+        max_executions random interleavings of `events`."""
+        self.stats = _stats
+        r = self.explore(events, violation_fingerprint)
+        return r[0] if r is not None else None
+
+    def shutdown(self):
+        self._ctx.close()

@@ -82,7 +82,8 @@ EXT_EVENT_DTYPE = np.dtype([("kind", "u1"), ("a", "u1"), ("b", "u1"), ("msg_type
                             ("p0", "u1"), ("p1", "u1"), ("pad", "u1", (2,))])
 REC_EVENT_DTYPE = np.dtype([("kind", "u1"), ("snd", "u1"), ("rcv", "u1"), ("msg_type", "u1"),
                             ("p0", "u1"), ("p1", "u1"), ("flags", "u1"), ("ext_idx", "u1"), ("id", "<u4")])
-assert VERDICT_DTYPE.itemsize == 16 and EXT_EVENT_DTYPE.itemsize == 8 and REC_EVENT_DTYPE.itemsize == 12
+VIOLATION_DTYPE = np.dtype([("index", "<u8"), ("fingerprint", "<u4"), ("flags", "<u4")])
+assert VERDICT_DTYPE.itemsize == 16 and VIOLATION_DTYPE.itemsize == 16 and EXT_EVENT_DTYPE.itemsize == 8 and REC_EVENT_DTYPE.itemsize == 12
 
 
 def verdict_violation(flags):

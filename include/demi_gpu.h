@@ -192,6 +192,21 @@ int demi_random_explore_dev(demi_ctx* ctx, uint64_t seed_base, const uint64_t* d
 int demi_random_get_trace(demi_ctx* ctx, uint64_t seed, const demi_limits* limits,
                           demi_verdict* verdict, demi_rec_event* out, uint32_t cap, uint32_t* n_out);
 
+/* ---------------------------------------------------------- found-violation set
+ * One entry per violating schedule (what RunnerUtils.fuzz keeps: the violating execution's
+ * index + fingerprint, RunnerUtils.scala:91-128).  Compacts a device verdict array into a device
+ * list; *d_count receives the number of violations (may exceed cap: the list is then truncated).
+ * Entry order is unspecified: it is a set (sort by index on the host if an order is needed).     */
+typedef struct {
+  uint64_t index;        /* index_base + position in the verdict array */
+  uint32_t fingerprint;
+  uint32_t flags;
+} demi_violation;        /* 16 bytes */
+
+int demi_collect_violations_dev(demi_ctx* ctx, const demi_verdict* d_verdicts, uint64_t n, uint64_t index_base,
+                                demi_violation* d_out, uint32_t cap, unsigned long long* d_count,
+                                void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,6 +7,7 @@
 #include "demi_oracle.h"
 
 #include <pthread.h>
+#include <stddef.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -548,11 +549,10 @@ static int schedule_new_message(exec_t* x) {
   return 1;
 }
 
-int orc_random_execute(const demi_model* m, const demi_ext_event* trace, uint32_t n_ev, uint64_t seed,
-                       const demi_limits* lim, demi_verdict* out, demi_rec_event* rec, uint32_t rec_cap,
-                       uint32_t* n_rec, uint64_t* final_states) {
-  exec_t* x = (exec_t*)calloc(1, sizeof(exec_t));
-  if (!x) return DEMI_ERR_INVALID_ARG;
+static int random_execute_in(exec_t* x, const demi_model* m, const demi_ext_event* trace, uint32_t n_ev,
+                             uint64_t seed, const demi_limits* lim, demi_verdict* out, demi_rec_event* rec,
+                             uint32_t rec_cap, uint32_t* n_rec, uint64_t* final_states) {
+  memset(x, 0, offsetof(exec_t, fx));
   x->m = m; x->trace = trace; x->n_ev = n_ev; x->lim = lim;
   x->rec = rec; x->rec_cap = rec_cap;
   x->p_max = lim->p_max ? lim->p_max : 64;
@@ -602,8 +602,17 @@ int orc_random_execute(const demi_model* m, const demi_ext_event* trace, uint32_
   }
   if (n_rec) *n_rec = x->n_rec;
   if (final_states) memcpy(final_states, x->state, sizeof(uint64_t) * m->n_actors);
-  free(x);
   return DEMI_OK;
+}
+
+int orc_random_execute(const demi_model* m, const demi_ext_event* trace, uint32_t n_ev, uint64_t seed,
+                       const demi_limits* lim, demi_verdict* out, demi_rec_event* rec, uint32_t rec_cap,
+                       uint32_t* n_rec, uint64_t* final_states) {
+  exec_t* x = (exec_t*)malloc(sizeof(exec_t));
+  if (!x) return DEMI_ERR_INVALID_ARG;
+  int rc = random_execute_in(x, m, trace, n_ev, seed, lim, out, rec, rec_cap, n_rec, final_states);
+  free(x);
+  return rc;
 }
 
 /* ===================================================================== batch driver */
@@ -614,10 +623,13 @@ typedef struct {
 
 static void* job_main(void* p) {
   job_t* j = (job_t*)p;
+  exec_t* x = (exec_t*)malloc(sizeof(exec_t)); /* one simulator per thread, reset per execution */
+  if (!x) return NULL;
   for (uint64_t i = j->lo; i < j->hi; i++) {
     uint64_t seed = j->seeds ? j->seeds[i] : j->seed_base + i;
-    orc_random_execute(j->m, j->trace, j->n_ev, seed, j->lim, &j->out[i], NULL, 0, NULL, NULL);
+    random_execute_in(x, j->m, j->trace, j->n_ev, seed, j->lim, &j->out[i], NULL, 0, NULL, NULL);
   }
+  free(x);
   return NULL;
 }
 
