@@ -29,6 +29,14 @@ def lib():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise ImportError("libdemi_gpu.so is not built (%s); run __graft_entry__.build()" % LIB_PATH)
+    if not os.environ.get("DEMI_NO_TORCH"):
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64; loading it first makes
+        # libdemi_gpu.so bind to the same runtime, so torch tensors / streams and our kernels share a
+        # device context (loading the system runtime first leaves torch with "No HIP GPUs").
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     L = C.CDLL(LIB_PATH)
     L.demi_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
     L.demi_ctx_destroy.argtypes = [C.c_void_p]

@@ -180,8 +180,9 @@ def generate_fuzz_test(num_events: int, weights: FuzzerWeights, message_gen: Cal
     return out
 
 
-def raft_trace(n_actors: int, n_events: int, seed: int, weights: FuzzerWeights = None) -> List[Event]:
-    """Start x A, Bootstrap x A, then Fuzzer-distributed events; exactly n_events long."""
+def raft_trace(n_actors: int, n_events: int, seed: int, weights: FuzzerWeights = None, exact: bool = True) -> List[Event]:
+    """Start x A, Bootstrap x A, then Fuzzer-distributed events; exactly n_events long (exact=False: at
+    most n_events + 1; the Fuzzer stops early once every node is killed)."""
     from .model import M_BOOTSTRAP, M_CLIENT
     weights = weights or FuzzerWeights()
     prefix = [start(a) for a in range(n_actors)] + [send(a, M_BOOTSTRAP) for a in range(n_actors)]
@@ -192,9 +193,14 @@ def raft_trace(n_actors: int, n_events: int, seed: int, weights: FuzzerWeights =
         target = alive.get_random() if len(alive) else 0
         return send(target, M_CLIENT, counter[0] & 0xFF, 0)
 
-    for k in range(n_events - len(prefix), 0, -1):
-        counter[0] = 0
-        tr = generate_fuzz_test(k, weights, gen, prefix, seed)
-        if len(tr) == n_events:
-            return tr
+    if not exact:
+        return generate_fuzz_test(n_events - len(prefix), weights, gen, prefix, seed)
+    # the Fuzzer appends a final WaitQuiescence only when the last event is not one, so a given seed
+    # may not hit the requested length exactly: retry with a derived seed (deterministic)
+    for attempt in range(64):
+        for k in (n_events - len(prefix), n_events - len(prefix) - 1):
+            counter[0] = 0
+            tr = generate_fuzz_test(k, weights, gen, prefix, seed + attempt * 0x9E3779B9)
+            if len(tr) == n_events:
+                return tr
     raise ValueError("cannot build a trace of exactly %d events" % n_events)

@@ -1,0 +1,275 @@
+"""GPU parity suite for K1 (RandomScheduler executions).  Every call goes through the C ABI of
+libdemi_gpu.so; the CPU oracle is only the checker.  Bit-exact bar: the 16-byte verdict (flags,
+delivery count, traceIdx, fingerprint, FNV hash of every delivered message and every final actor
+state) must be identical for every schedule."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from demi_amd import types as T
+from demi_amd import model as M
+from demi_amd.apps import SEED_BASE, raft3_config1, raft5_config2
+from demi_amd.fuzzer import (FuzzerWeights, events_to_array, kill, partition, raft_trace, send, start, unpartition,
+                             wait_quiescence)
+from demi_amd.model import Asm, build_model, load_model
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def both(gpu_ctx, oracle, model, events, n, lim, seed_base=SEED_BASE, seeds=None):
+    gpu_ctx.model_load(model.to_struct())
+    gpu_ctx.trace_load(events)
+    g = gpu_ctx.random_explore(n, lim, seed_base=seed_base, seeds=seeds)
+    c = oracle.random_explore(model, events, n, seed_base=seed_base, seeds=seeds, limits=lim, n_threads=os.cpu_count())
+    return g, c
+
+
+def assert_same(g, c):
+    if not (g == c).all():
+        bad = np.nonzero(g != c)[0]
+        raise AssertionError("%d of %d verdicts differ; first at %d: gpu=%s cpu=%s" % (len(bad), len(g), bad[0], g[bad[0]], c[bad[0]]))
+
+
+def test_native_library_is_the_one_running(gpu_ctx):
+    import ctypes
+    from demi_amd import _native
+    assert os.path.samefile(_native.LIB_PATH, os.path.join(os.path.dirname(_native.__file__), "libdemi_gpu.so"))
+    maps = open("/proc/self/maps").read()
+    assert "libdemi_gpu.so" in maps
+
+
+@pytest.mark.parametrize("name", ["raft5_config2", "raft3_config1"])
+def test_golden_fixtures_on_gpu(gpu_ctx, name):
+    model = load_model(os.path.join(G, name + "_model.json"))
+    meta = json.load(open(os.path.join(G, name + "_trace.json")))
+    events = events_to_array([tuple(e) for e in meta["events"]])
+    want = np.load(os.path.join(G, name + "_verdicts.npy"))
+    gpu_ctx.model_load(model.to_struct())
+    gpu_ctx.trace_load(events)
+    got = gpu_ctx.random_explore(len(want), T.Limits(*meta["limits"]), seed_base=meta["seed_base"])
+    assert_same(got, want)
+
+
+@pytest.mark.parametrize("p_max", [32, 64, 128])
+def test_raft5_parity_all_capacities(gpu_ctx, oracle, p_max):
+    model, events, lim = raft5_config2()
+    lim.p_max = p_max
+    g, c = both(gpu_ctx, oracle, model, events, 50000, lim)
+    assert_same(g, c)
+    assert (g["flags"] & T.V_VIOLATION).sum() > 100
+    if p_max == 32:
+        assert (g["flags"] & T.V_PENDING_OVF).sum() > 0      # overflow is a verdict, identical on both sides
+
+
+def test_raft3_config1_and_fixed_model(gpu_ctx, oracle):
+    model, events, lim = raft3_config1()
+    g, c = both(gpu_ctx, oracle, model, events, 100, lim)
+    assert_same(g, c)
+    model5, events5, lim5 = raft5_config2()
+    g, c = both(gpu_ctx, oracle, M.raft_model(5, buggy=False), events5, 20000, lim5)
+    assert_same(g, c)
+    assert not (g["flags"] & T.V_VIOLATION).any()
+
+
+@pytest.mark.parametrize("limits", [(0, 0, 64), (0, 7, 64), (50, 1, 64), (1000, 30, 128), (200, 30, 64)])
+def test_limits_matrix(gpu_ctx, oracle, limits):
+    model, events, _ = raft5_config2()
+    lim = T.Limits(limits[0], limits[1], limits[2], 0, 0, 0)
+    g, c = both(gpu_ctx, oracle, M.raft_model(5, election_budget=2), events, 8000, lim)
+    assert_same(g, c)
+
+
+def test_looking_for_and_populate_all(gpu_ctx, oracle):
+    model, events, lim = raft5_config2()
+    g, c = both(gpu_ctx, oracle, model, events, 20000, lim)
+    fps, counts = np.unique(g["fingerprint"][g["fingerprint"] != 0], return_counts=True)
+    target = int(fps[np.argmax(counts)])
+    lim2 = T.Limits(lim.max_messages, lim.invariant_check_interval, lim.p_max, 1, target, 0)
+    g2, c2 = both(gpu_ctx, oracle, model, events, 20000, lim2)
+    assert_same(g2, c2)
+    hit = (g2["flags"] & T.V_VIOLATION) != 0
+    assert hit.sum() > 0 and (g2["fingerprint"][hit] == target).all()
+    # a schedule that violated with another fingerprint keeps running under lookingFor
+    assert hit.sum() < ((g["flags"] & T.V_VIOLATION) != 0).sum()
+    # populate_all: a trace that never Starts actor 4 still creates it (setActorNamePropPairs)
+    ev = events_to_array([start(a) for a in range(4)] + [send(a, M.M_BOOTSTRAP) for a in range(5)] + [wait_quiescence()])
+    for pa in (0, 1):
+        lim3 = T.Limits(200, 30, 64, 0, 0, pa)
+        g3, c3 = both(gpu_ctx, oracle, model, ev, 4000, lim3)
+        assert_same(g3, c3)
+
+
+def test_explicit_seeds_ragged_sizes_and_partitioned_batches(gpu_ctx, oracle):
+    model, events, lim = raft5_config2()
+    rng = np.random.default_rng(5)
+    seeds = rng.integers(0, 2 ** 63, size=3001, dtype=np.uint64)
+    g, c = both(gpu_ctx, oracle, model, events, len(seeds), lim, seeds=seeds)
+    assert_same(g, c)
+    for n in (0, 1, 63, 64, 65, 255, 257, 1025):
+        g, c = both(gpu_ctx, oracle, model, events, n, lim)
+        assert len(g) == n
+        assert_same(g, c)
+    # verdict i depends only on (seed_base + i): any split of the index range gives the same array
+    gpu_ctx.model_load(model.to_struct())
+    gpu_ctx.trace_load(events)
+    whole = gpu_ctx.random_explore(10000, lim, seed_base=SEED_BASE)
+    parts = [gpu_ctx.random_explore(hi - lo, lim, seed_base=SEED_BASE + lo) for lo, hi in ((0, 1), (1, 4097), (4097, 10000))]
+    assert_same(np.concatenate(parts), whole)
+
+
+def test_fault_heavy_and_edge_traces(gpu_ctx, oracle):
+    model = M.raft_model(5, election_budget=2)
+    lim = T.Limits(300, 10, 128, 0, 0, 0)
+    w = FuzzerWeights(kill=0.15, send=0.3, wait_quiescence=0.15, partition=0.25, unpartition=0.15)
+    for seed in (1, 2, 3):
+        events = events_to_array(raft_trace(5, 80, seed, w, exact=False))
+        g, c = both(gpu_ctx, oracle, model, events, 6000, lim)
+        assert_same(g, c)
+    edge = [[], [wait_quiescence()], [start(0)], [send(0, M.M_BOOTSTRAP)],
+            [start(0), kill(0), start(0), send(0, M.M_BOOTSTRAP), wait_quiescence(), kill(0), wait_quiescence()],
+            [start(a) for a in range(5)] + [partition(0, 1), partition(1, 0), unpartition(0, 1)] +
+            [send(a, M.M_BOOTSTRAP) for a in range(5)],
+            [start(a) for a in range(5)] + [send(a, M.M_BOOTSTRAP) for a in range(5)] * 6]
+    for ev in edge:
+        g, c = both(gpu_ctx, oracle, model, events_to_array(ev), 500, lim)
+        assert_same(g, c)
+    # the longest trace the boundary accepts
+    long_ev = [start(a) for a in range(5)] + [send(a, M.M_BOOTSTRAP) for a in range(5)]
+    k = 0
+    while len(long_ev) < T.MAX_EXT_EVENTS:
+        long_ev.append(send(k % 5, M.M_CLIENT, k & 255) if k % 7 else wait_quiescence())
+        k += 1
+    g, c = both(gpu_ctx, oracle, model, events_to_array(long_ev), 3000, T.Limits(1000, 30, 128, 0, 0, 0))
+    assert_same(g, c)
+
+
+def test_timer_semantics_models_on_gpu(gpu_ctx, oracle):
+    """Repeating timers, cancels, queue capacities: the tiny models of the CPU suite, in bulk."""
+    MSGS = [("Kick", T.MSG_EXTERNAL), ("Ping", T.MSG_INTERNAL), ("Tick", T.MSG_TIMER), ("RTick", T.MSG_TIMER)]
+    K, PI, TI, RT = range(4)
+    CNT = M.F[0]
+    kick = Asm().eq(M.T0, M.P0, 0).skipz(M.T0, "a").trep(RT).tset(TI).halt().label("a")
+    kick.eq(M.T0, M.P0, 1).skipz(M.T0, "b").tcancel(RT).tset(TI).tset(TI).halt().label("b")
+    kick.eq(M.T0, M.P0, 2).skipz(M.T0, "c").tcancel(TI).bcast(PI, M.P0, 1).halt().label("c")
+    kick.trep(RT).trep(RT).tcancel(TI).tset(TI)
+    h = {(0, "Kick"): kick,
+         (0, "Ping"): Asm().add(CNT, CNT, 1).lt(M.T0, CNT, 6).skipz(M.T0, "x").send(PI, M.SRC, CNT, 0).tset(TI).label("x"),
+         (0, "Tick"): Asm().add(M.F[1], M.F[1], 1).and_(M.T0, M.F[1], 3).skipnz(M.T0, "y").tcancel(RT).label("y"),
+         (0, "RTick"): Asm().add(M.F[2], M.F[2], 1).ge(M.T0, M.F[2], 14).skipz(M.T0, "z").mov(M.F[3], 1).label("z")}
+    model = build_model("timers", 4, MSGS, h, [[0] * 8 for _ in range(4)], (T.INV_NEVER, 3, 1, 0))
+    rng = np.random.default_rng(11)
+    ev = [start(a) for a in range(4)]
+    for i in range(120):
+        r = rng.integers(0, 10)
+        ev.append(wait_quiescence() if (r < 3 and ev[-1][0] != T.EV_WAIT_QUIESCENCE) else
+                  send(int(rng.integers(0, 4)), K, int(rng.integers(0, 4))))
+    for lim in (T.Limits(400, 5, 64, 0, 0, 0), T.Limits(250, 0, 32, 0, 0, 0), T.Limits(0, 0, 64, 0, 0, 0)):
+        g, c = both(gpu_ctx, oracle, model, events_to_array(ev), 8000, lim)
+        assert_same(g, c)
+        assert len(np.unique(g["hash"])) > 7000
+        if lim.max_messages != 250:
+            assert (g["flags"] & T.V_VIOLATION).any()
+    # a model that overflows the timer queue: 9 distinct sets in one handler is impossible with 4 timer
+    # types, so overflow comes from duplicates of one-shot timers
+    many = Asm()
+    for _ in range(9):
+        many.tset(TI)
+    model2 = build_model("tq", 2, MSGS, {(0, "Kick"): many}, [[0] * 8] * 2, (T.INV_NEVER, 3, 1, 0))
+    g, c = both(gpu_ctx, oracle, model2, events_to_array([start(0), send(0, K)]), 64, T.Limits(0, 0, 64, 0, 0, 0))
+    assert_same(g, c)
+    assert (g["flags"] == T.V_QUEUE_OVF).all()
+
+
+def test_recorded_event_traces_are_identical(gpu_ctx, oracle):
+    model, events, lim = raft5_config2()
+    gpu_ctx.model_load(model.to_struct())
+    gpu_ctx.trace_load(events)
+    v = gpu_ctx.random_explore(2000, lim, seed_base=SEED_BASE)
+    hits = np.nonzero(v["flags"] & T.V_VIOLATION)[0][:6]
+    for i in list(hits) + [0, 1, 2, 1999]:
+        gv, grec = gpu_ctx.random_get_trace(SEED_BASE + int(i), lim)
+        cv, crec, _ = oracle.random_execute(model, events, SEED_BASE + int(i), lim)
+        assert (gv.flags, gv.fingerprint, gv.hash) == (cv.flags, cv.fingerprint, cv.hash)
+        assert (gv.flags, gv.hash) == (int(v["flags"][i]), int(v["hash"][i]))
+        assert len(grec) == len(crec) and (grec == crec).all()
+        # every delivery pairs with an earlier send of the same id; dropped sends are never delivered
+        sends = {int(e["id"]): e for e in grec if e["kind"] == T.REC_MSG_SEND}
+        for e in grec:
+            if e["kind"] == T.REC_MSG_EVENT:
+                s = sends[int(e["id"])]
+                assert not (s["flags"] & 4) and (s["rcv"], s["msg_type"], s["p0"], s["p1"]) == (e["rcv"], e["msg_type"], e["p0"], e["p1"])
+
+
+def test_scheduler_mirror_explore_and_test(oracle):
+    from demi_amd.schedulers import MinimizationStats, RandomScheduler, SchedulerConfig, ViolationFingerprint
+    model, events, lim = raft5_config2()
+    with pytest.raises(ValueError):
+        s0 = RandomScheduler(SchedulerConfig(model=None), max_executions=4)
+        try:
+            s0.explore(events)
+        finally:
+            s0.shutdown()
+    sched = RandomScheduler(SchedulerConfig(model=model), max_executions=2000, invariant_check_interval=30, seed_base=SEED_BASE)
+    sched.setMaxMessages(200)
+    found = sched.explore(events)
+    assert found is not None
+    trace, fp = found
+    want = oracle.random_explore(model, events, 2000, seed_base=SEED_BASE, limits=lim)
+    first = int(np.nonzero(want["flags"] & T.V_VIOLATION)[0][0])
+    assert fp.code == int(want["fingerprint"][first])
+    assert len(trace.original_externals) == T.verdict_trace_idx(int(want["flags"][first]))
+    # TestOracle.test: reproduces the same violation, counts replays like increment_replays()
+    stats = MinimizationStats()
+    assert sched.test(events, fp, stats) is not None and stats.total_replays == 2000
+    other = ViolationFingerprint(fp.code ^ 0x0100)       # same nodes, another term: never matches here
+    got = sched.test(events, other, stats)
+    want2 = oracle.random_explore(model, events, 2000, seed_base=SEED_BASE,
+                                  limits=T.Limits(200, 30, 64, 1, other.code, 0))
+    assert (got is not None) == bool((want2["flags"] & T.V_VIOLATION).any())
+    sched.shutdown()
+
+
+def test_full_size_properties_1m(gpu_ctx, oracle):
+    """BASELINE config 2 at full size (2^20 schedules): properties that do not need the oracle for
+    every index, plus an oracle spot check on random windows."""
+    import ctypes as C
+    import torch
+    model, events, lim = raft5_config2()
+    n = 1 << 20
+    gpu_ctx.model_load(model.to_struct())
+    gpu_ctx.trace_load(events)
+    dev = torch.device("cuda", 0)
+    out = torch.empty((n, 2), dtype=torch.int64, device=dev)
+    sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    gpu_ctx.random_explore_dev(n, lim, out.data_ptr(), seed_base=SEED_BASE, stream=sp)
+    torch.cuda.synchronize()
+    a = out.cpu().numpy().view(T.VERDICT_DTYPE).reshape(-1).copy()
+    out.zero_()
+    gpu_ctx.random_explore_dev(n, lim, out.data_ptr(), seed_base=SEED_BASE, stream=sp)   # idempotent / deterministic
+    torch.cuda.synchronize()
+    b = out.cpu().numpy().view(T.VERDICT_DTYPE).reshape(-1)
+    assert_same(a, b)
+    flags = a["flags"]
+    assert not (flags & (T.V_PENDING_OVF | T.V_QUEUE_OVF)).any()
+    deliveries = (flags >> 16) & 0xFFFF
+    assert deliveries.max() == 201 and ((deliveries == 201) == ((flags & T.V_MAXMSG) != 0)).all()
+    viol = (flags & T.V_VIOLATION) != 0
+    assert ((a["fingerprint"] != 0) == viol).all() and not (viol & ((flags & T.V_MAXMSG) != 0)).any()
+    assert len(np.unique(a["hash"])) > 0.999 * n            # every schedule is a distinct interleaving
+    # the device compaction kernel returns exactly the violating set
+    cap = 1 << 16
+    lst = torch.zeros((cap + 1, 2), dtype=torch.int64, device=dev)
+    gpu_ctx.collect_violations_dev(out.data_ptr(), n, 7_000_000, lst[1:].data_ptr(), cap, lst[0:1].data_ptr(), stream=sp)
+    torch.cuda.synchronize()
+    from demi_amd.distributed import merge_violation_sets
+    got = merge_violation_sets([lst.cpu().numpy()], cap)
+    idx = np.nonzero(viol)[0]
+    assert len(got) == len(idx) and (got["index"] == idx + 7_000_000).all() and (got["fingerprint"] == a["fingerprint"][idx]).all()
+    # oracle spot check on 8 random windows of 4096
+    rng = np.random.default_rng(0)
+    for lo in rng.integers(0, n - 4096, size=8):
+        c = oracle.random_explore(model, events, 4096, seed_base=SEED_BASE + int(lo), limits=lim, n_threads=os.cpu_count())
+        assert_same(a[lo:lo + 4096], c)

@@ -1,0 +1,410 @@
+"""CPU suite, part 1: the oracle (oracle/demi_oracle.c) against the only externally pinned
+arithmetic (java.util.Random known answers), against hand-computed executions of tiny models
+(each one a semantic rule of SURVEY 9.1 / the cited Scala lines), and against the frozen fixtures.
+Parity versus the JVM reference is UNPINNED (the reference has no tests or vectors)."""
+import ctypes as C
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+from demi_amd import types as T
+from demi_amd import model as M
+from demi_amd.fuzzer import (JavaRandom, events_to_array, kill, partition, raft_trace, send, start, unpartition,
+                             wait_quiescence)
+from demi_amd.model import Asm, Model, build_model, load_model
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+# --------------------------------------------------------------------------- java.util.Random
+def test_jrandom_known_answers(oracle):
+    kat = json.load(open(os.path.join(G, "jrandom_kat.json")))
+    for impl in (oracle.JRandom, JavaRandom):
+        for row in kat["next_int"]:
+            assert impl(row["seed"]).next_int() == row["value"]
+        for row in kat["next_int_bound"]:
+            r = impl(row["seed"])
+            assert [r.next_int(row["bound"]) for _ in row["values"]] == row["values"]
+        r = impl(kat["next_double"]["seed"])
+        assert [r.next_double() for _ in kat["next_double"]["values"]] == kat["next_double"]["values"]
+
+
+def test_jrandom_c_equals_python_port(oracle):
+    rnd = random.Random(1)
+    for _ in range(200):
+        seed = rnd.getrandbits(64)
+        a, b = oracle.JRandom(seed), JavaRandom(seed)
+        for _ in range(50):
+            bound = rnd.choice([1, 2, 3, 5, 7, 31, 32, 33, 63, 64, 65, 100, 127, 128, (1 << 30) + 1, (1 << 31) - 1])
+            assert a.next_int(bound) == b.next_int(bound)
+
+
+def test_divmagic_exact():
+    """floor(r / d) by multiply-high with ceil(2^(31+L)/d) (the GPU's nextInt path) is exact for
+    every 31-bit r: checked at all multiples' boundaries that can flip the quotient."""
+    rnd = random.Random(7)
+    for d in range(1, 129):
+        if d & (d - 1) == 0:
+            continue
+        L = (d - 1).bit_length()
+        m = -(-(1 << (31 + L)) // d)
+        assert m < (1 << 32)
+        rs = [0, 1, d - 1, d, d + 1, (1 << 31) - 1, (1 << 31) - d, ((1 << 31) - 1) // d * d, ((1 << 31) - 1) // d * d - 1]
+        rs += [rnd.randrange(1 << 31) for _ in range(300)]
+        rs += [q * d + o for q in (rnd.randrange((1 << 31) // d) for _ in range(300)) for o in (-1, 0, 1)]
+        for r in rs:
+            if 0 <= r < (1 << 31):
+                assert ((r * m) >> 32) >> (L - 1) == r // d, (r, d)
+
+
+# --------------------------------------------------------------------------- validation
+def test_model_validation_rules(oracle):
+    base = M.raft_model(5)
+    assert oracle.model_validate(base)[0] == 0
+
+    def variant(**kw):
+        d = base.to_json()
+        d.update(kw)
+        return Model.from_json(d)
+
+    bad_send = list(base.code)
+    bad_send[0] = M.row(M.OPS["SEND"], 0, 0, 1, M.M_CLIENT, 0)          # `!` of an external type
+    bad_timer = list(base.code)
+    bad_timer[0] = M.row(M.OPS["TSET"], 0, 0, 1, M.M_REQUEST_VOTE, 0)   # timer op on a non-timer type
+    bad_skip = list(base.code)
+    bad_skip[-1] = M.row(M.OPS["SKIP"], 0, 0, 1, 0, 5)                  # skip past the end
+    bad_op = list(base.code)
+    bad_op[0] = 99
+    for m in (variant(n_actors=9, actor_class=[0] * 9, init_state=[0] * 9), variant(code=bad_send),
+              variant(code=bad_timer), variant(code=bad_skip), variant(code=bad_op), variant(inv_fa=8),
+              variant(actor_class=[0, 0, 0, 0, 1]), variant(handler_start=[9999] + base.handler_start[1:])):
+        rc, msg = oracle.model_validate(m)
+        assert rc == T.ERR_INVALID_MODEL and msg
+
+
+def test_trace_validation_rules(oracle):
+    m = M.raft_model(3)
+    ok = events_to_array([start(0), send(0, M.M_BOOTSTRAP), wait_quiescence()])
+    assert oracle.trace_validate(m, ok)[0] == 0
+    for bad in ([(T.EV_START, 3, 0, 0, 0, 0)], [send(0, M.M_REQUEST_VOTE)], [(6, 0, 0, 0, 0, 0)],   # 6 = WaitCondition
+                [partition(0, 7)]):
+        rc, msg = oracle.trace_validate(m, events_to_array(bad))
+        assert rc == T.ERR_INVALID_TRACE and msg
+
+
+# --------------------------------------------------------------------------- transition table vs a plain reference
+def raft_reference(n_actors, buggy, me, fields, msg, src, p0, p1):
+    """The raft-synth `receive` written directly in Python; returns (fields, effects)."""
+    role, term, voted, votes, budget, loglen, commit, booted = fields
+    fx = []
+    others = [j for j in range(n_actors) if j != me]
+    maj = n_actors // 2 + 1
+
+    def step_down_timers():
+        if role == M.LEADER:
+            fx.append(("tcancel", M.M_HEARTBEAT))
+
+    if msg == M.M_BOOTSTRAP:
+        if not booted:
+            booted = 1
+            fx.append(("tset", M.M_ELECTION_TIMEOUT))
+    elif msg == M.M_CLIENT:
+        if role == M.LEADER:
+            loglen = (loglen + 1) & 255
+            fx += [("send", j, M.M_APPEND_ENTRIES, term, loglen) for j in others]
+    elif msg == M.M_ELECTION_TIMEOUT:
+        if role != M.LEADER and budget != 0:
+            budget -= 1
+            role, term, voted = M.CANDIDATE, (term + 1) & 255, me
+            votes = 1 << me
+            fx += [("send", j, M.M_REQUEST_VOTE, term, 0) for j in others]
+            fx.append(("tset", M.M_ELECTION_TIMEOUT))
+    elif msg == M.M_REQUEST_VOTE:
+        if p0 > term:
+            step_down_timers()
+            term, role, voted = p0, M.FOLLOWER, M.NOBODY
+        ok = voted == M.NOBODY or voted == src
+        if buggy and role == M.CANDIDATE and ((src - 1) & 255) == me:
+            ok = True
+        if p0 == term and ok:
+            voted = src
+            fx += [("tcancel", M.M_ELECTION_TIMEOUT), ("tset", M.M_ELECTION_TIMEOUT),
+                   ("send", src, M.M_VOTE_REPLY, term, 1)]
+        else:
+            fx.append(("send", src, M.M_VOTE_REPLY, term, 0))
+    elif msg == M.M_VOTE_REPLY:
+        if p0 > term:
+            step_down_timers()
+            term, role, voted = p0, M.FOLLOWER, M.NOBODY
+        elif role == M.CANDIDATE and p0 == term and (p1 & 1 if p1 in (0, 1) else (1 & p1)):
+            votes = (votes | (1 << (src & 7))) & 255
+            if bin(votes).count("1") >= maj:
+                role = M.LEADER
+                fx += [("tcancel", M.M_ELECTION_TIMEOUT), ("trep", M.M_HEARTBEAT)]
+                fx += [("send", j, M.M_APPEND_ENTRIES, term, loglen) for j in others]
+    elif msg == M.M_APPEND_ENTRIES:
+        if p0 < term:
+            fx.append(("send", src, M.M_APPEND_REPLY, term, 0))
+        else:
+            if p0 > term:
+                voted = M.NOBODY
+            if p0 > term or role != M.LEADER:
+                step_down_timers()
+                role = M.FOLLOWER
+            term, loglen = p0, max(loglen, p1)
+            fx += [("tcancel", M.M_ELECTION_TIMEOUT), ("tset", M.M_ELECTION_TIMEOUT),
+                   ("send", src, M.M_APPEND_REPLY, term, p1)]
+    elif msg == M.M_APPEND_REPLY:
+        if p0 > term:
+            step_down_timers()
+            term, role, voted = p0, M.FOLLOWER, M.NOBODY
+        elif role == M.LEADER and p0 == term:
+            commit = max(commit, p1)
+    elif msg == M.M_HEARTBEAT:
+        if role != M.LEADER:
+            fx.append(("tcancel", M.M_HEARTBEAT))
+        elif loglen > commit:
+            fx += [("send", j, M.M_APPEND_ENTRIES, term, loglen) for j in others]
+    return [role, term, voted, votes, budget, loglen, commit, booted], fx
+
+
+class _Effect(C.Structure):
+    _fields_ = [("kind", C.c_uint8), ("target", C.c_uint8), ("msg_type", C.c_uint8), ("p0", C.c_uint8), ("p1", C.c_uint8)]
+
+
+@pytest.mark.parametrize("buggy", [True, False])
+def test_raft_table_equals_plain_reference(oracle, buggy):
+    A = 5
+    model = M.raft_model(A, buggy=buggy)
+    ms = model.to_struct()
+    rnd = random.Random(3)
+    fx = (_Effect * 64)()
+    for _ in range(4000):
+        me = rnd.randrange(A)
+        msg = rnd.randrange(8)
+        src = T.DEADLETTERS if model.msg_class[msg] != T.MSG_INTERNAL else rnd.choice([j for j in range(A) if j != me])
+        fields = [rnd.randrange(3), rnd.randrange(6), rnd.choice([M.NOBODY] + list(range(A))), rnd.randrange(32),
+                  rnd.randrange(3), rnd.randrange(4), rnd.randrange(4), rnd.randrange(2)]
+        p0, p1 = rnd.randrange(6), rnd.randrange(4)
+        if msg == M.M_VOTE_REPLY:
+            p1 = rnd.randrange(2)
+        st = C.c_uint64(M.pack_state(fields))
+        n = oracle.lib().orc_vm_run(C.byref(ms), me, C.byref(st), msg, src, p0, p1, (1 << A) - 1, fx, 64)
+        want_fields, want_fx = raft_reference(A, buggy, me, fields, msg, src, p0, p1)
+        got_fx = []
+        for e in fx[:n]:
+            got_fx.append(("send", e.target, e.msg_type, e.p0, e.p1) if e.kind == 0 else
+                          (["", "tset", "trep", "tcancel"][e.kind], e.msg_type))
+        assert st.value == M.pack_state(want_fields), (fields, msg, src, p0, p1)
+        assert got_fx == want_fx, (fields, msg, src, p0, p1)
+
+
+# --------------------------------------------------------------------------- tiny models: one semantic rule each
+PING, PONG, KICK, TICK, RTICK = "Ping", "Pong", "Kick", "Tick", "RTick"
+MSGS = [(KICK, T.MSG_EXTERNAL), (PING, T.MSG_INTERNAL), (PONG, T.MSG_INTERNAL), (TICK, T.MSG_TIMER), (RTICK, T.MSG_TIMER)]
+K, PI, PO, TI, RT = range(5)
+CNT, SEEN, FLAG = M.F[0], M.F[1], M.F[2]
+
+
+def tiny_model(handlers, n=3, invariant=(T.INV_NEVER, int(FLAG), 1, 0)):
+    return build_model("tiny", n, MSGS, handlers, [[0] * 8 for _ in range(n)], invariant)
+
+
+def run(oracle, model, events, seed=0, max_messages=0, interval=0, p_max=64, looking_for=None, populate_all=0):
+    lim = T.Limits(max_messages, interval, p_max, 1 if looking_for is not None else 0, looking_for or 0, populate_all)
+    v, rec, st = oracle.random_execute(model, events_to_array(events), seed, lim)
+    return v, rec, st
+
+
+def deliveries(rec):
+    return [(int(e["snd"]), int(e["rcv"]), int(e["msg_type"]), int(e["p0"])) for e in rec if e["kind"] == T.REC_MSG_EVENT]
+
+
+def test_swap_remove_order_matches_hand_computation(oracle):
+    """RandomizedHashSet: idx = nextInt(len); arr[idx] = arr[last]; drop last (Util.scala:146-176)."""
+    h = {(0, KICK): Asm().add(CNT, CNT, 1)}
+    model = tiny_model(h)
+    ev = [start(0)] + [send(0, K, i) for i in range(6)] + [wait_quiescence()]
+    for seed in (0, 1, 42, 12345):
+        v, rec, st = run(oracle, model, ev, seed=seed)
+        r, arr, want = JavaRandom(seed), list(range(6)), []
+        while arr:
+            i = r.next_int(len(arr))
+            want.append(arr[i])
+            arr[i] = arr[-1]
+            arr.pop()
+        assert [d[3] for d in deliveries(rec)] == want
+        assert T.verdict_deliveries(v.flags) == 6 and int(st[0]) & 255 == 6
+
+
+def test_partition_is_checked_at_send_time_only_and_externals_bypass_it(oracle):
+    # actor 0 on Kick: Ping -> 1.   actor 1 on Ping: count.
+    h = {(0, KICK): Asm().mov(M.T0, 1).send(PI, M.T0, M.T1, 0), (0, PING): Asm().add(CNT, CNT, 1)}
+    model = tiny_model(h)
+    # partitioned at send time: dropped (RandomScheduler.scala:292), either order of the pair
+    for pa in (partition(0, 1), partition(1, 0)):
+        v, rec, st = run(oracle, model, [start(0), start(1), pa, send(0, K), wait_quiescence()])
+        assert int(st[1]) & 255 == 0
+        assert any(e["kind"] == T.REC_MSG_SEND and e["flags"] & 4 for e in rec)
+    # UnPartition removes only the ordered pair as given (EventOrchestrator.scala:197-199)
+    v, rec, st = run(oracle, model, [start(0), start(1), partition(0, 1), unpartition(1, 0), send(0, K), wait_quiescence()])
+    assert int(st[1]) & 255 == 0
+    v, rec, st = run(oracle, model, [start(0), start(1), partition(0, 1), unpartition(0, 1), send(0, K), wait_quiescence()])
+    assert int(st[1]) & 255 == 1
+    # a message already pending when the Partition is injected is still delivered
+    v, rec, st = run(oracle, model, [start(0), start(1), send(0, K), wait_quiescence(), partition(0, 1), wait_quiescence()])
+    assert int(st[1]) & 255 == 1
+    # externals bypass the partition check: a Send to a killed / not-yet-started actor is delivered (:298-308)
+    hk = {(0, KICK): Asm().add(CNT, CNT, 1)}
+    v, rec, st = run(oracle, tiny_model(hk), [start(0), kill(0), send(0, K), wait_quiescence()])
+    assert int(st[0]) & 255 == 1
+    v, rec, st = run(oracle, tiny_model(hk), [send(0, K), start(0), wait_quiescence()])
+    assert int(st[0]) & 255 == 1
+    # ... but not to an actor that is never created ("Unknown message receiver")
+    v, rec, st = run(oracle, tiny_model(hk), [start(1), send(0, K), wait_quiescence()])
+    assert int(st[0]) & 255 == 0 and T.verdict_deliveries(v.flags) == 0
+    v, rec, st = run(oracle, tiny_model(hk), [start(1), send(0, K), wait_quiescence()], populate_all=1)
+    assert int(st[0]) & 255 == 1
+
+
+def test_kill_isolates_but_keeps_state_and_self_sends(oracle):
+    # Kick: count, send Ping to self and to actor 1
+    h = {(0, KICK): Asm().add(CNT, CNT, 1).send(PI, M.ME, M.T0, 0).mov(M.T1, 1).send(PI, M.T1, M.T0, 0),
+         (0, PING): Asm().add(SEEN, SEEN, 1)}
+    model = tiny_model(h)
+    # not killed, merely not started (inaccessible): self-send passes (snd == rcv && !killed), the other is dropped
+    v, rec, st = run(oracle, model, [start(1), send(0, K), wait_quiescence()], populate_all=1)
+    assert (int(st[0]) >> 8) & 255 == 1 and (int(st[1]) >> 8) & 255 == 0
+    # killed: even the self-send is dropped; state survives; Start revives it
+    v, rec, st = run(oracle, model, [start(0), start(1), send(0, K), wait_quiescence(), kill(0), send(0, K),
+                                     wait_quiescence(), start(0), send(0, K), wait_quiescence()])
+    assert int(st[0]) & 255 == 3 and (int(st[0]) >> 8) & 255 == 2 and (int(st[1]) >> 8) & 255 == 2
+
+
+def test_one_shot_timer_set_cancel_and_drop_when_inaccessible(oracle):
+    # Kick(p0): p0==0 -> TSET; p0==1 -> TCANCEL; Tick -> count
+    h = {(0, KICK): Asm().skipnz(M.P0, "c").tset(TI).halt().label("c").tcancel(TI),
+         (0, TICK): Asm().add(CNT, CNT, 1)}
+    model = tiny_model(h)
+    v, rec, st = run(oracle, model, [start(0), send(0, K, 0), wait_quiescence()])
+    assert int(st[0]) & 255 == 1
+    d = [e for e in rec if e["kind"] == T.REC_MSG_SEND and e["flags"] & 2]
+    assert len(d) == 1 and d[0]["snd"] == T.DEADLETTERS          # timers come from deadLetters, recorded as "Timer"
+    # two identical one-shot timers may be pending at once; cancel removes the first match only
+    for seed in range(8):
+        v, rec, st = run(oracle, model, [start(0), send(0, K, 0), send(0, K, 0), send(0, K, 1), wait_quiescence()], seed=seed)
+        order = [d[3] for d in deliveries(rec) if d[2] == K]
+        ticks_before_cancel = 0
+        for d in deliveries(rec):
+            if d[2] == K and d[3] == 1:
+                break
+            ticks_before_cancel += d[2] == TI
+        sets_before_cancel = order.index(1)
+        pending_at_cancel = sets_before_cancel - ticks_before_cancel
+        assert int(st[0]) & 255 == 2 - (1 if pending_at_cancel > 0 else 0)
+    # a timer to an inaccessible receiver is dropped at the flush (crosses_partition(deadLetters, rcv))
+    v, rec, st = run(oracle, model, [send(0, K, 0), wait_quiescence(), start(0), wait_quiescence()])
+    assert int(st[0]) & 255 == 0 and any(e["flags"] & 4 for e in rec if e["kind"] == T.REC_MSG_SEND)
+
+
+def test_repeating_timer_is_parked_until_a_non_timer_is_delivered(oracle):
+    # Kick(0): TREP RTick.  Kick(1): nothing.  Kick(2): TCANCEL.  RTick: count.
+    a = Asm().eq(M.T0, M.P0, 0).skipz(M.T0, "n").trep(RT).halt().label("n")
+    a.eq(M.T0, M.P0, 2).skipz(M.T0, "d").tcancel(RT).label("d")
+    h = {(0, KICK): a, (0, RTICK): Asm().add(CNT, CNT, 1)}
+    model = tiny_model(h)
+    # alone: fires once, the retrigger is parked in timersToResend, the system quiesces
+    v, rec, st = run(oracle, model, [start(0), send(0, K, 0), wait_quiescence()])
+    assert int(st[0]) & 255 == 1
+    # a later non-timer delivery re-sends it: fires again (and is parked again)
+    v, rec, st = run(oracle, model, [start(0), send(0, K, 0), wait_quiescence(), send(0, K, 1), wait_quiescence(),
+                                     send(0, K, 1), wait_quiescence()])
+    assert int(st[0]) & 255 == 3
+    # a cancel issued from a non-timer delivery finds the copy that was just re-sent into messagesToSend
+    v, rec, st = run(oracle, model, [start(0), send(0, K, 0), wait_quiescence(), send(0, K, 2), wait_quiescence(),
+                                     send(0, K, 1), wait_quiescence()])
+    assert int(st[0]) & 255 == 1
+    # ... but a cancel issued while the timer itself is being delivered does not reach the copy parked in
+    # timersToResend (reference quirk): it fires once more after the next non-timer delivery
+    h2 = {(0, KICK): a, (0, RTICK): Asm().add(CNT, CNT, 1).tcancel(RT)}
+    v, rec, st = run(oracle, tiny_model(h2), [start(0), send(0, K, 0), wait_quiescence(), send(0, K, 1),
+                                              wait_quiescence(), send(0, K, 1), wait_quiescence()])
+    assert int(st[0]) & 255 == 2
+    # schedule() of an already registered timer is rejected ("Non-unique timer")
+    v, rec, st = run(oracle, model, [start(0), send(0, K, 0), wait_quiescence(), send(0, K, 0), wait_quiescence()])
+    assert int(st[0]) & 255 == 2
+
+
+def test_max_messages_suppresses_final_check_and_interval_check_fires(oracle):
+    # Kick: send Ping to self forever; set FLAG (=violation) after 5 pings
+    h = {(0, KICK): Asm().send(PI, M.ME, M.T0, 0),
+         (0, PING): Asm().add(CNT, CNT, 1).ge(M.T1, CNT, 5).skipz(M.T1, "x").mov(FLAG, 1).label("x").send(PI, M.ME, M.T0, 0)}
+    model = tiny_model(h)
+    ev = [start(0), send(0, K), wait_quiescence()]
+    v, _, _ = run(oracle, model, ev, max_messages=20, interval=0)
+    # count runs to 21 > maxMessages: finish_early, and the execution is NOT bug-checked (:256, :369-373)
+    assert v.flags & T.V_MAXMSG and not (v.flags & T.V_VIOLATION) and T.verdict_deliveries(v.flags) == 21
+    v, _, _ = run(oracle, model, ev, max_messages=20, interval=4)
+    # the periodic check sees it at the first multiple of 4 with CNT >= 5: count = 8 (Kick + 7 Pings)
+    assert v.flags & T.V_VIOLATION and T.verdict_deliveries(v.flags) == 8
+    assert v.fingerprint == (2 << 24) | 1
+    # lookingFor a different fingerprint: not a match, keeps running
+    v, _, _ = run(oracle, model, ev, max_messages=20, interval=4, looking_for=(2 << 24) | 2)
+    assert not (v.flags & T.V_VIOLATION) and v.flags & T.V_MAXMSG
+
+
+def test_pending_overflow_is_a_verdict_not_ub(oracle):
+    h = {(0, KICK): Asm().bcast(PI, M.T0, 0).bcast(PI, M.T0, 0).bcast(PI, M.T0, 0).bcast(PI, M.T0, 0)}
+    model = build_model("ovf", 8, MSGS, h, [[0] * 8 for _ in range(8)], (T.INV_NEVER, 2, 1, 0))
+    ev = [start(a) for a in range(8)] + [send(0, K), send(1, K), wait_quiescence()]
+    v, _, _ = run(oracle, model, ev, p_max=32)
+    assert v.flags == T.V_PENDING_OVF and v.hash == 0 and v.fingerprint == 0
+    v, _, _ = run(oracle, model, ev, p_max=64)
+    assert not (v.flags & T.V_PENDING_OVF) and T.verdict_deliveries(v.flags) == 58
+
+
+def test_quiescence_advances_trace_and_empty_traces(oracle):
+    h = {(0, KICK): Asm().add(CNT, CNT, 1)}
+    model = tiny_model(h)
+    v, rec, st = run(oracle, model, [])
+    assert v.flags == 0 and len(rec) == 0
+    v, rec, st = run(oracle, model, [wait_quiescence()])
+    assert T.verdict_trace_idx(v.flags) == 1 and [int(e["kind"]) for e in rec] == [T.REC_BEGIN_WAIT_QUIESCENCE]
+    v, rec, st = run(oracle, model, [start(0), send(0, K), wait_quiescence(), send(0, K), send(0, K)])
+    kinds = [int(e["kind"]) for e in rec]
+    assert kinds.count(T.REC_QUIESCENCE) == 1 and T.verdict_deliveries(v.flags) == 3 and T.verdict_trace_idx(v.flags) == 5
+
+
+# --------------------------------------------------------------------------- frozen fixtures + properties
+@pytest.mark.parametrize("name", ["raft5_config2", "raft3_config1"])
+def test_golden_fixtures(oracle, name):
+    model = load_model(os.path.join(G, name + "_model.json"))
+    meta = json.load(open(os.path.join(G, name + "_trace.json")))
+    events = events_to_array([tuple(e) for e in meta["events"]])
+    want = np.load(os.path.join(G, name + "_verdicts.npy"))
+    lim = T.Limits(*meta["limits"])
+    got = oracle.random_explore(model, events, len(want), seed_base=meta["seed_base"], limits=lim, n_threads=4)
+    assert (got == want).all()
+    # the frozen model/trace are what the generators produce today
+    from demi_amd import apps
+    m2, ev2, _ = getattr(apps, name)()
+    assert m2.to_json() == model.to_json() and (ev2 == events).all()
+
+
+def test_explicit_seeds_threads_and_determinism(oracle):
+    from demi_amd.apps import SEED_BASE, raft5_config2
+    model, events, lim = raft5_config2()
+    a = oracle.random_explore(model, events, 3000, seed_base=SEED_BASE, limits=lim, n_threads=1)
+    b = oracle.random_explore(model, events, 3000, seeds=np.arange(3000, dtype=np.uint64) + np.uint64(SEED_BASE),
+                              limits=lim, n_threads=7)
+    assert (a == b).all()
+    # a fixed raft never violates; the buggy one does, and every violating fingerprint names >= 2 leaders of one term
+    fixed = oracle.random_explore(M.raft_model(5, buggy=False), events, 3000, seed_base=SEED_BASE, limits=lim, n_threads=4)
+    assert not (fixed["flags"] & T.V_VIOLATION).any()
+    hits = a[(a["flags"] & T.V_VIOLATION) != 0]
+    assert len(hits) > 0
+    for fp in hits["fingerprint"]:
+        assert fp >> 24 == 1 and bin(int(fp) & 0xFF).count("1") >= 2
