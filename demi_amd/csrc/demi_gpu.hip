@@ -37,6 +37,8 @@ struct demi_ctx {
   size_t seeds_cap = 0;
   demi_rec_event* d_rec = nullptr;
   uint32_t* d_rec_count = nullptr;
+  uint32_t* d_spill = nullptr;
+  size_t spill_bytes = 0;
 };
 
 static int fail(demi_ctx* ctx, int code, const char* fmt, ...) {
@@ -93,6 +95,7 @@ extern "C" void demi_ctx_destroy(demi_ctx* ctx) {
   if (ctx->d_seeds) (void)hipFree(ctx->d_seeds);
   if (ctx->d_rec) (void)hipFree(ctx->d_rec);
   if (ctx->d_rec_count) (void)hipFree(ctx->d_rec_count);
+  if (ctx->d_spill) (void)hipFree(ctx->d_spill);
   delete ctx;
 }
 
@@ -124,6 +127,8 @@ static int validate_model(demi_ctx* ctx, const demi_model* m) {
     if (op >= DEMI_OP_SKIPZ && op <= DEMI_OP_SKIP) {
       if (!bimm) return fail(ctx, DEMI_ERR_INVALID_MODEL, "row %u: skip distance must be an immediate", pc);
       if (pc + 1 + b > m->code_len) return fail(ctx, DEMI_ERR_INVALID_MODEL, "row %u: skip past the end of the table", pc);
+    } else if (op >= DEMI_OP_IFEQ && op <= DEMI_OP_IFGT) {
+      if (pc + 1 + aux > m->code_len) return fail(ctx, DEMI_ERR_INVALID_MODEL, "row %u: skip past the end of the table", pc);
     } else if (op == DEMI_OP_SEND || op == DEMI_OP_BCAST) {
       if (aux >= m->n_msg_types || m->msg_class[aux] != DEMI_MSG_INTERNAL)
         return fail(ctx, DEMI_ERR_INVALID_MODEL, "row %u: SEND/BCAST of a non-internal message type %u", pc, aux);
@@ -216,13 +221,15 @@ extern "C" int demi_trace_load(demi_ctx* ctx, const demi_ext_event* events, uint
 }
 
 // ----------------------------------------------------------------------------- K1 launch
-template <int PMAX, bool REC>
-static int launch_k1_t(demi_ctx* ctx, const K1Args& a, hipStream_t stream) {
+template <bool REC>
+static int launch_k1(demi_ctx* ctx, uint32_t p_max, K1Args a, hipStream_t stream) {
   const DevModel& h = ctx->hmodel;
-  const size_t lds = k1_lds_shared_bytes(h.code_len, a.n_ev, h.n_classes * h.n_msg_types) +
-                     K1_WAVES * k1_lds_wave_bytes<PMAX, REC>(h.n_actors);
+  if (p_max == 0) p_max = 64;
+  if (p_max > DEMI_MAX_PENDING) return fail(ctx, DEMI_ERR_INVALID_ARG, "p_max must be 1..%d", DEMI_MAX_PENDING);
+  a.p_max = p_max;
+  const size_t lds = k1_lds_bytes<REC>(h.code_len, a.n_ev, h.n_classes * h.n_msg_types, h.n_actors);
   if (lds > 160 * 1024) return fail(ctx, DEMI_ERR_INVALID_ARG, "LDS budget exceeded (%zu bytes)", lds);
-  auto kern = k1_random_explore<PMAX, REC>;
+  auto kern = k1_random_explore<REC>;
   HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int per_cu = 0;
   HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, K1_WAVES * 64, lds));
@@ -232,20 +239,19 @@ static int launch_k1_t(demi_ctx* ctx, const K1Args& a, hipStream_t stream) {
   const uint64_t resident = (uint64_t)ctx->num_cu * (uint64_t)per_cu;
   if (blocks > resident) blocks = resident;
   if (blocks < 1) blocks = 1;
+  // HBM scratch for the (rare) pending slots beyond the PEND_HOT kept in LDS
+  const size_t need = spill_words(blocks * K1_WAVES * 64) * (REC ? 2 : 1) * sizeof(uint32_t);
+  if (ctx->spill_bytes < need) {
+    if (ctx->d_spill) (void)hipFree(ctx->d_spill);
+    ctx->d_spill = nullptr; ctx->spill_bytes = 0;
+    HIP_TRY(ctx, hipMalloc(&ctx->d_spill, need));
+    ctx->spill_bytes = need;
+  }
+  a.spill = ctx->d_spill;
   HIP_TRY(ctx, hipMemsetAsync(a.work_counter, 0, sizeof(unsigned long long), stream));
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(K1_WAVES * 64), lds, stream, a);
   HIP_TRY(ctx, hipGetLastError());
   return DEMI_OK;
-}
-
-template <bool REC>
-static int launch_k1(demi_ctx* ctx, uint32_t p_max, const K1Args& a, hipStream_t stream) {
-  switch (p_max) {
-    case 32: return launch_k1_t<32, REC>(ctx, a, stream);
-    case 0: case 64: return launch_k1_t<64, REC>(ctx, a, stream);
-    case 128: return launch_k1_t<128, REC>(ctx, a, stream);
-    default: return fail(ctx, DEMI_ERR_INVALID_ARG, "p_max must be 32, 64 or 128");
-  }
 }
 
 static int make_k1_args(demi_ctx* ctx, uint64_t seed_base, const uint64_t* d_seeds, uint64_t n,

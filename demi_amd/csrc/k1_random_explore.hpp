@@ -7,14 +7,15 @@
 // schedulers/EventOrchestrator.scala:132-189) and the Instrumenter's timer bookkeeping
 // (Instrumenter.scala:159-168, 1008-1016, 1145-1200) over a table-encoded transition function.
 //
-// Execution shape: a wave is a pool of 64 independent simulators.  Each loop iteration every live
-// lane performs one scheduling step (guards, flush, random pick, swap-remove) and runs the picked
-// message's handler rows.  A lane whose execution ends writes its 16-byte verdict and immediately
-// refills with the next schedule index (wave ballot + prefix count; batches are claimed from one
-// global counter), so variable execution lengths do not idle lanes until the very tail.
+// Execution shape: each loop iteration every live lane performs one scheduling step (guards,
+// flush, random pick, swap-remove), runs the picked message's handler rows (branch-free
+// interpreter, sim_core.hpp) and applies the recorded effects.  A lane whose execution ends writes
+// its 16-byte verdict and immediately refills with the next schedule index (wave ballot + prefix
+// count; 64-index batches are claimed from one global counter), so variable execution lengths do
+// not idle lanes until the very tail of the launch.
 #pragma once
 
-#include "demi_device.hpp"
+#include "sim_core.hpp"
 
 namespace demi {
 
@@ -29,6 +30,8 @@ struct K1Args {
   uint32_t max_messages, interval, looking_for_valid, looking_for;
   demi_verdict* out;
   unsigned long long* work_counter;  // zeroed before every launch
+  uint32_t p_max;           // pending-set capacity of the spec (<= DEMI_MAX_PENDING)
+  uint32_t* spill;          // HBM scratch for pending slots >= PEND_HOT: spill_words(total lanes) (x2 for REC)
   demi_rec_event* rec_out;  // REC only: [n][rec_cap]
   uint32_t* rec_count;      // REC only: [n]
   uint32_t rec_cap;
@@ -39,62 +42,29 @@ enum : int { PH_IDLE = 0, PH_INJECT = 1, PH_DISPATCH = 2, PH_FINISH = 3 };
 constexpr int K1_WAVES = 4;          // waves per workgroup
 constexpr int K1_BATCH = 64;         // schedule indices claimed per atomic
 
-// dynamic LDS bytes for a launch
-__host__ __device__ inline size_t k1_lds_shared_bytes(uint32_t code_len, uint32_t n_ev, uint32_t n_hs) {
-  size_t b = 0;
-  b += (size_t)n_ev * 8;            // trace
-  b += DEMI_MAX_ACTORS * 8;         // init states
-  b += (size_t)code_len * 4;        // code
-  b += (size_t)n_hs * 4;            // handler_start
-  b += DEMI_MAX_MSG_TYPES * 4;      // meta
-  b += 132 * 4;                     // divmagic (padded)
-  return (b + 15) & ~(size_t)15;
-}
-template <int PMAX, bool REC>
-__host__ __device__ inline size_t k1_lds_wave_bytes(uint32_t n_actors) {
-  return (size_t)n_actors * 64 * 8 + (size_t)PMAX * 64 * 4 * (REC ? 2 : 1);
+template <bool REC>
+__host__ __device__ inline size_t k1_lds_bytes(uint32_t code_len, uint32_t n_ev, uint32_t n_hs, uint32_t n_actors) {
+  return tables_lds_bytes(code_len, n_ev, n_hs) + K1_WAVES * lane_mem_wave_bytes(n_actors, REC);
 }
 
-template <int PMAX, bool REC>
+template <bool REC>
 __global__ __launch_bounds__(K1_WAVES * 64) void k1_random_explore(const K1Args args) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const DevModel* __restrict__ gm = args.model;
-  const uint32_t A = gm->n_actors, NT = gm->n_msg_types, code_len = gm->code_len;
-  const uint32_t n_hs = gm->n_classes * NT;
-  const uint32_t E = args.n_ev;
-
-  // ---- carve the workgroup-shared tables (16-byte aligned base, 8-byte items first)
-  uint64_t* s_trace = reinterpret_cast<uint64_t*>(smem);
-  uint64_t* s_init = s_trace + E;
-  uint32_t* s_code = reinterpret_cast<uint32_t*>(s_init + DEMI_MAX_ACTORS);
-  uint32_t* s_hs = s_code + code_len;
-  uint32_t* s_meta = s_hs + n_hs;
-  uint32_t* s_magic = s_meta + DEMI_MAX_MSG_TYPES;
-  unsigned char* wave_base = smem + k1_lds_shared_bytes(code_len, E, n_hs);
-
-  // the trace and the tables are streamed in once per workgroup with coalesced loads
-  for (uint32_t i = threadIdx.x; i < E; i += blockDim.x) s_trace[i] = args.trace[i];
-  for (uint32_t i = threadIdx.x; i < DEMI_MAX_ACTORS; i += blockDim.x) s_init[i] = gm->init_state[i];
-  for (uint32_t i = threadIdx.x; i < code_len; i += blockDim.x) s_code[i] = gm->code[i];
-  for (uint32_t i = threadIdx.x; i < n_hs; i += blockDim.x) s_hs[i] = gm->handler_start[i];
-  for (uint32_t i = threadIdx.x; i < DEMI_MAX_MSG_TYPES; i += blockDim.x) s_meta[i] = gm->meta[i];
-  for (uint32_t i = threadIdx.x; i < 129; i += blockDim.x) s_magic[i] = gm->divmagic[i];
-  __syncthreads();
-
+  Tables t;
+  unsigned char* wave_base = tables_load(t, smem, args.model, args.trace, args.n_ev, args.exists);
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  unsigned char* wb = wave_base + (size_t)wave * k1_lds_wave_bytes<PMAX, REC>(A);
-  uint64_t* st = reinterpret_cast<uint64_t*>(wb) + lane;               // st[actor * 64]
-  uint32_t* pend = reinterpret_cast<uint32_t*>(wb + (size_t)A * 64 * 8) + lane;  // pend[slot * 64]
-  uint32_t* pend_id = pend + (REC ? PMAX * 64 : 0);                    // REC: ids, same layout
+  const LaneMem mem = lane_mem_carve(wave_base + (size_t)wave * lane_mem_wave_bytes(t.A, REC), t.A, REC, lane, args.spill,
+                                     (size_t)blockIdx.x * blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x);
+  uint64_t* const st = mem.st;
+  const uint32_t PMAX = args.p_max;
 
-  const uint32_t inv_kind = gm->inv_kind, inv_fa = gm->inv_fa, inv_va = gm->inv_va, inv_fb = gm->inv_fb;
-  const uint32_t fp_mask = gm->fp_match_mask;
+  const uint32_t A = t.A, E = t.E, exists = t.exists;
   const uint32_t max_messages = args.max_messages ? args.max_messages : 0x7FFFFFFFu;
   const uint32_t interval = args.interval;
-  const uint32_t exists = args.exists;
 
   // ---- per-lane simulator state
   int ph = PH_IDLE;
+  bool fresh = false;
   uint64_t sched = 0, rng = 0, hash = 0;
   uint32_t n_pend = 0, count = 0, cnt_mod = 0, tidx = 0, inj_lo = 0, inj_hi = 0;
   Net net = {0, 0, 0};
@@ -105,12 +75,9 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k1_random_explore(const K1Args 
   uint32_t next_id = 1, n_rec = 0;    // REC only
   demi_rec_event* rec = nullptr;
 
-  bool fresh = false;
   // wave-uniform work cursor: [b_next, b_end) is the unassigned rest of the last claimed batch
   uint64_t b_next = 0, b_end = 0;
   bool exhausted = false;
-  uint32_t ac_packed = 0;             // actor_class, 4 bits per actor
-  for (uint32_t a = 0; a < A; a++) ac_packed |= gm->actor_class[a] << (4 * a);
 
 #define REC_PUSH(KIND, SND, RCV, TYPE, P0, P1, FL, EXT, ID)                                   \
   do {                                                                                        \
@@ -128,16 +95,15 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k1_random_explore(const K1Args 
 
 #define PEND_APPEND(WORD, ID)                                         \
   do {                                                                \
-    if (n_pend >= (uint32_t)PMAX) { flags |= DEMI_V_PENDING_OVF; }    \
+    if (n_pend >= PMAX) { flags |= DEMI_V_PENDING_OVF; }              \
     else {                                                            \
-      pend[n_pend * 64] = (WORD);                                     \
-      if (REC) pend_id[n_pend * 64] = (ID);                           \
+      pend_store(mem, n_pend, (WORD));                                \
+      if (REC) aux_store(mem, n_pend, (ID));                          \
       n_pend++;                                                       \
     }                                                                 \
   } while (0)
 
-#define OVF_ANY (DEMI_V_PENDING_OVF | DEMI_V_QUEUE_OVF)
-#define TIMER_BIT(RCV, TYPE) (1u << ((RCV) * DEMI_MAX_TIMER_TYPES + (s_meta[(TYPE)] >> 8)))
+#define TIMER_BIT(RCV, TYPE) (1u << ((RCV) * DEMI_MAX_TIMER_TYPES + (t.meta[(TYPE)] >> 8)))
 
   // RandomScheduler.enqueue_timer (:549-559) -> handle_timer (ExternalEventInjector.scala:282-297)
   auto enqueue_timer = [&](uint32_t rcv, uint32_t type) {
@@ -154,9 +120,9 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k1_random_explore(const K1Args 
   };
 
   auto check_invariant = [&]() -> uint32_t {
-    const uint32_t fp = invariant_code(gm, st, exists, A, inv_kind, inv_fa, inv_va, inv_fb);
+    const uint32_t fp = invariant_code(args.model, st, exists, A, t.inv_kind, t.inv_fa, t.inv_va, t.inv_fb);
     if (!fp) return 0u;
-    if (args.looking_for_valid) return (((fp ^ args.looking_for) & fp_mask) == 0) ? args.looking_for : 0u;
+    if (args.looking_for_valid) return (((fp ^ args.looking_for) & t.fp_mask) == 0) ? args.looking_for : 0u;
     return fp;
   };
 
@@ -195,7 +161,7 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k1_random_explore(const K1Args 
         rng = jr_seed(seed);
         hash = 0xCBF29CE484222325ULL;
         net.inaccessible = exists; net.killed = 0; net.partitioned = 0;
-        for (uint32_t a = 0; a < A; a++) st[a * 64] = s_init[a];
+        for (uint32_t a = 0; a < A; a++) st[a * 64] = t.init[a];
         if (REC) { rec = args.rec_out + sched * (uint64_t)args.rec_cap; n_rec = 0; next_id = 1; }
       }
       // EventOrchestrator.inject_until_quiescence (:132-189).  Send events are not materialised:
@@ -203,7 +169,7 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k1_random_explore(const K1Args 
       inj_lo = tidx;
       bool loop = true;
       while (loop && tidx < E) {
-        const uint64_t ev = s_trace[tidx];
+        const uint64_t ev = t.trace[tidx];
         const uint32_t kind = (uint32_t)ev & 0xFF, a = (uint32_t)(ev >> 8) & 0xFF, b = (uint32_t)(ev >> 16) & 0xFF;
         if (kind == DEMI_EV_START) {
           REC_PUSH(DEMI_REC_SPAWN, 0, a, 0, 0, 0, 0, tidx, 0);
@@ -227,7 +193,9 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k1_random_explore(const K1Args 
       ph = PH_DISPATCH;
     }
 
-    // ------------------------------------------------------------ one scheduling step + delivery
+    // ------------------------------------------------------------ one scheduling step
+    uint32_t w = 0;            // the message picked by this step
+    bool deliver = false;
     if (ph == PH_DISPATCH) {
       bool none = false;
       if (viol) {
@@ -242,7 +210,7 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k1_random_explore(const K1Args 
         if (!none) {
           // send_external_messages (:424): injected Sends first (no partition check, :298-308) ...
           for (uint32_t i = inj_lo; i < inj_hi; i++) {
-            const uint64_t ev = s_trace[i];
+            const uint64_t ev = t.trace[i];
             const uint32_t kind = (uint32_t)ev & 0xFF, a = (uint32_t)(ev >> 8) & 0xFF;
             if (kind == DEMI_EV_SEND && ((exists >> a) & 1)) {
               const uint32_t type = (uint32_t)(ev >> 24) & 0xFF, p0 = (uint32_t)(ev >> 32) & 0xFF,
@@ -263,26 +231,25 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k1_random_explore(const K1Args 
             REC_PUSH(DEMI_REC_MSG_SEND, DEMI_DEADLETTERS, rcv, type, 0, 0, 2 | (drop ? 4 : 0), 255, id);
           }
           tq = 0; n_tq = 0;
-          if ((flags & OVF_ANY) || n_pend == 0) none = true;
+          if ((flags & DEMI_OVF_ANY) || n_pend == 0) none = true;
         }
       }
 
       if (!none) {
         // FullyRandom.removeRandomElement -> RandomizedHashSet: nextInt(arr.length), swap with last
-        const uint32_t idx = jr_next_int(rng, n_pend, s_magic);
-        const uint32_t w = pend[idx * 64];
-        const uint32_t last = pend[(n_pend - 1) * 64];
-        pend[idx * 64] = last;
+        const uint32_t idx = jr_next_int(rng, n_pend, t.magic);
+        w = pend_load(mem, idx);
+        pend_store(mem, idx, pend_load(mem, n_pend - 1));
         uint32_t wid = 0;
-        if (REC) { wid = pend_id[idx * 64]; pend_id[idx * 64] = pend_id[(n_pend - 1) * 64]; }
+        if (REC) { wid = aux_load(mem, idx); aux_store(mem, idx, aux_load(mem, n_pend - 1)); }
         n_pend--;
         count++;
         cnt_mod++; if (cnt_mod == interval) cnt_mod = 0;
-        const uint32_t type = w_type(w), me = w_dst(w), src = w_src(w);
-        REC_PUSH(DEMI_REC_MSG_EVENT, src, me, type, w_p0(w), w_p1(w), 0, 255, wid);
+        const uint32_t type = w_type(w), me = w_dst(w);
+        REC_PUSH(DEMI_REC_MSG_EVENT, w_src(w), me, type, w_p0(w), w_p1(w), 0, 255, wid);
         hash_step(hash, w);
         // updateRepeatingTimer (:405-421) and the Instrumenter's retrigger (Instrumenter.scala:1008-1016)
-        const uint32_t meta = s_meta[type];
+        const uint32_t meta = t.meta[type];
         const uint32_t tbit = 1u << (me * DEMI_MAX_TIMER_TYPES + (meta >> 8));
         const bool is_rep = ((meta & 0xFF) == DEMI_MSG_TIMER) && (rep & tbit);
         if (is_rep) {
@@ -296,102 +263,11 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k1_random_explore(const K1Args 
           }
           resend = 0; n_resend = 0; just = 0;
         }
-
-        // ---- the handler rows: r0..7 = state (lo), r8..15 = T0..T3, P0, P1, SRC, ME (hi)
-        const uint32_t hs = s_hs[((ac_packed >> (4 * me)) & 15u) * NT + type];
-        if (hs != 0xFFFFu && !(flags & OVF_ANY)) {
-          uint64_t lo = st[me * 64];
-          uint64_t hi = ((uint64_t)w_p0(w) << 32) | ((uint64_t)w_p1(w) << 40) | ((uint64_t)src << 48) |
-                        ((uint64_t)me << 56);
-          uint32_t pc = hs;
-          while (pc < code_len) {
-            const uint32_t row = s_code[pc++];
-            const uint32_t op = row & 0xFF;
-            if (op == DEMI_OP_HALT) break;
-            const uint32_t dsti = (row >> 8) & 15, ai = (row >> 12) & 15, aux = (row >> 17) & 0x7F, braw = row >> 24;
-            const uint32_t a = (uint32_t)(((ai & 8) ? hi : lo) >> ((ai & 7) * 8)) & 0xFF;
-            const uint32_t breg = (uint32_t)(((braw & 8) ? hi : lo) >> ((braw & 7) * 8)) & 0xFF;
-            const uint32_t b = (row & 0x10000u) ? braw : breg;
-            if (op < DEMI_OP_SKIPZ) {
-              uint32_t r;
-              switch (op) {
-                case DEMI_OP_MOV: r = b; break;
-                case DEMI_OP_ADD: r = a + b; break;
-                case DEMI_OP_SUB: r = a - b; break;
-                case DEMI_OP_AND: r = a & b; break;
-                case DEMI_OP_OR: r = a | b; break;
-                case DEMI_OP_XOR: r = a ^ b; break;
-                case DEMI_OP_SHL: r = a << (b & 7); break;
-                case DEMI_OP_SHR: r = a >> (b & 7); break;
-                case DEMI_OP_BITSET: r = a | (1u << (b & 7)); break;
-                case DEMI_OP_POPC: r = __popc(b); break;
-                case DEMI_OP_EQ: r = a == b; break;
-                case DEMI_OP_NE: r = a != b; break;
-                case DEMI_OP_LT: r = a < b; break;
-                case DEMI_OP_GE: r = a >= b; break;
-                case DEMI_OP_LE: r = a <= b; break;
-                case DEMI_OP_GT: r = a > b; break;
-                case DEMI_OP_MIN: r = a < b ? a : b; break;
-                default: r = a > b ? a : b; break;   // MAX
-              }
-              const uint32_t shft = (dsti & 7) * 8;
-              const uint64_t msk = 0xFFull << shft, val = (uint64_t)(r & 0xFF) << shft;
-              if (dsti & 8) hi = (hi & ~msk) | val; else lo = (lo & ~msk) | val;
-            } else if (op <= DEMI_OP_SKIP) {
-              const bool take = (op == DEMI_OP_SKIP) || ((op == DEMI_OP_SKIPZ) == (a == 0));
-              if (take) pc += braw;
-            } else if (op == DEMI_OP_SEND || op == DEMI_OP_BCAST) {
-              // event_produced for internal messages (:287-297): dropped at send time when
-              // crosses_partition, else appended to the pending set
-              const uint32_t p0 = (uint32_t)(((dsti & 8) ? hi : lo) >> ((dsti & 7) * 8)) & 0xFF;
-              const uint32_t first = (op == DEMI_OP_SEND) ? a : 0u;
-              const uint32_t lastp1 = (op == DEMI_OP_SEND) ? a + 1 : A;
-              for (uint32_t t = first; t < lastp1 && t < A; t++) {
-                if (op == DEMI_OP_BCAST && t == me) continue;
-                if (!((exists >> t) & 1)) continue;
-                const uint32_t id = next_id; if (REC) next_id++;
-                const bool drop = crosses_partition(net, me, t);
-                if (!drop) PEND_APPEND(msg_word(aux, me, t, p0, b), id);
-                REC_PUSH(DEMI_REC_MSG_SEND, me, t, aux, p0, b, drop ? 4 : 0, 255, id);
-              }
-            } else if (op == DEMI_OP_TSET || op == DEMI_OP_TREP) {
-              // registerCancellable + handleTick (Instrumenter.scala:1145-1200)
-              const uint32_t bit = TIMER_BIT(me, aux);
-              if (!(rep & bit)) {               // else "Non-unique timer" (:1154-1157)
-                if (op == DEMI_OP_TREP) rep |= bit;
-                enqueue_timer(me, aux);
-              }
-            } else if (op == DEMI_OP_TCANCEL) {
-              // cancelTimer (Instrumenter.scala:159-168) -> notify_timer_cancel (:525-534)
-              rep &= ~TIMER_BIT(me, aux);
-              const uint32_t want = (me << 5) | aux;
-              bool found = false;
-              for (uint32_t k = 0; k < n_tq; k++) {          // handle_timer_cancel: messagesToSend first
-                if (((uint32_t)(tq >> (8 * k)) & 0xFF) == want) {
-                  const uint64_t lowm = (k == 0) ? 0ull : (~0ull >> (64 - 8 * k));
-                  tq = (tq & lowm) | ((tq >> 8) & ~lowm);
-                  n_tq--; found = true; break;
-                }
-              }
-              if (!found) {
-                const uint32_t wantw = msg_word(aux, DEMI_DEADLETTERS, me, 0, 0);
-                for (uint32_t k = 0; k < n_pend; k++) {      // FullyRandom.remove: first match, swap-remove
-                  if (pend[k * 64] == wantw) {
-                    pend[k * 64] = pend[(n_pend - 1) * 64];
-                    if (REC) pend_id[k * 64] = pend_id[(n_pend - 1) * 64];
-                    n_pend--; break;
-                  }
-                }
-              }
-            }
-            if (flags & OVF_ANY) break;
-          }
-          st[me * 64] = lo;
-        }
-        if (flags & OVF_ANY) ph = PH_FINISH;
+        deliver = !(flags & DEMI_OVF_ANY);
+        if (!deliver) ph = PH_FINISH;
       } else {
         // quiescence: notify_quiescence (:487-500) / handle_quiescence (ExternalEventInjector.scala:541-580)
-        if ((flags & OVF_ANY) || viol || tidx >= E) {
+        if ((flags & DEMI_OVF_ANY) || viol || tidx >= E) {
           ph = PH_FINISH;
         } else {
           REC_PUSH(DEMI_REC_QUIESCENCE, 0, 0, 0, 0, 0, 0, 255, 0);
@@ -400,14 +276,71 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k1_random_explore(const K1Args 
       }
     }
 
+    // ------------------------------------------------------------ the receiver's handler rows
+    uint32_t nfx = 0;
+    if (deliver) nfx = vm_run(t, mem, w, flags);
+
+    // ------------------------------------------------------------ apply the recorded effects, in program order
+    if (deliver) {
+      const uint32_t me = w_dst(w);
+      for (uint32_t k = 0; k < nfx && !(flags & DEMI_OVF_ANY); k++) {
+        const uint32_t fx = mem.fxq[k * 64];
+        const uint32_t op = fx & 31u, type = (fx >> 5) & 31u, target = (fx >> 10) & 15u, p0 = (fx >> 14) & 0xFFu,
+                       p1 = (fx >> 22) & 0xFFu;
+        if (op <= DEMI_OP_BCAST) {
+          // event_produced for internal messages (:287-297): dropped at send time when
+          // crosses_partition, else appended to the pending set
+          const bool bc = (op == DEMI_OP_BCAST);
+          const uint32_t first = bc ? 0u : target, last = bc ? A : (target < A ? target + 1 : 0u);
+          for (uint32_t r = first; r < last; r++) {
+            if ((bc && r == me) || !((exists >> r) & 1)) continue;
+            const uint32_t id = next_id; if (REC) next_id++;
+            const bool drop = crosses_partition(net, me, r);
+            if (!drop) PEND_APPEND(msg_word(type, me, r, p0, p1), id);
+            REC_PUSH(DEMI_REC_MSG_SEND, me, r, type, p0, p1, drop ? 4 : 0, 255, id);
+          }
+        } else if (op == DEMI_OP_TCANCEL) {
+          // cancelTimer (Instrumenter.scala:159-168) -> notify_timer_cancel (:525-534)
+          rep &= ~TIMER_BIT(me, type);
+          const uint32_t want = (me << 5) | type;
+          bool found = false;
+          for (uint32_t q = 0; q < n_tq; q++) {          // handle_timer_cancel: messagesToSend first
+            if (((uint32_t)(tq >> (8 * q)) & 0xFF) == want) {
+              const uint64_t lowm = (q == 0) ? 0ull : (~0ull >> (64 - 8 * q));
+              tq = (tq & lowm) | ((tq >> 8) & ~lowm);
+              n_tq--; found = true; break;
+            }
+          }
+          if (!found) {
+            const uint32_t wantw = msg_word(type, DEMI_DEADLETTERS, me, 0, 0);
+            for (uint32_t q = 0; q < n_pend; q++) {      // FullyRandom.remove: first match, swap-remove
+              if (pend_load(mem, q) == wantw) {
+                pend_store(mem, q, pend_load(mem, n_pend - 1));
+                if (REC) aux_store(mem, q, aux_load(mem, n_pend - 1));
+                n_pend--; break;
+              }
+            }
+          }
+        } else {
+          // TSET / TREP: registerCancellable + handleTick (Instrumenter.scala:1145-1200)
+          const uint32_t bit = TIMER_BIT(me, type);
+          if (!(rep & bit)) {               // else "Non-unique timer" (:1154-1157)
+            if (op == DEMI_OP_TREP) rep |= bit;
+            enqueue_timer(me, type);
+          }
+        }
+      }
+      if (flags & DEMI_OVF_ANY) ph = PH_FINISH;
+    }
+
     // ------------------------------------------------------------ verdict
     if (ph == PH_FINISH) {
       // explore(): `if (messagesScheduledSoFar <= maxMessages) checkIfBugFound` (:256-262, 156-180)
-      if (!(flags & (OVF_ANY | DEMI_V_MAXMSG)) && !viol) viol = check_invariant();
+      if (!(flags & (DEMI_OVF_ANY | DEMI_V_MAXMSG)) && !viol) viol = check_invariant();
       for (uint32_t a = 0; a < A; a++) hash_step(hash, st[a * 64]);
       uint4 v;
-      if (flags & OVF_ANY) {
-        v.x = flags & OVF_ANY; v.y = 0; v.z = 0; v.w = 0;
+      if (flags & DEMI_OVF_ANY) {
+        v.x = flags & DEMI_OVF_ANY; v.y = 0; v.z = 0; v.w = 0;
       } else {
         v.x = (flags & 0xFF) | (viol ? DEMI_V_VIOLATION : 0u) | ((tidx & 0xFF) << 8) | ((count & 0xFFFF) << 16);
         v.y = viol; v.z = (uint32_t)hash; v.w = (uint32_t)(hash >> 32);
@@ -422,7 +355,6 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k1_random_explore(const K1Args 
   }
 #undef REC_PUSH
 #undef PEND_APPEND
-#undef OVF_ANY
 #undef TIMER_BIT
 }
 

@@ -1,0 +1,198 @@
+// sim_core.hpp — the per-lane actor-system simulator shared by the exploration kernels.
+//
+// A wavefront is a pool of 64 independent simulators.  Everything that needs a per-lane dynamic
+// index lives in LDS as [slot][lane] (stride 64 elements), so lane l always hits bank l mod 32
+// (b32) / banks 2l,2l+1 mod 64 (b64): no conflicts for ANY combination of per-lane slots.
+//
+// The row interpreter is branch-free: every lane fetches its own row (per-lane pc) and computes
+// all result classes with selects, so lanes sitting in different handlers of the transition
+// table do not serialise.  Rows with effects (SEND/BCAST/TSET/TREP/TCANCEL) are only recorded
+// while the rows run; they are applied afterwards in program order, slot k of every lane at the
+// same time (apply phase), so the expensive bodies are paid once per slot and not once per row.
+#pragma once
+
+#include "demi_device.hpp"
+
+namespace demi {
+
+#define DEMI_OVF_ANY (DEMI_V_PENDING_OVF | DEMI_V_QUEUE_OVF)
+
+// ------------------------------------------------------------------ workgroup-shared tables
+struct Tables {
+  const uint64_t* trace;  // [E] external events, one 8-byte word each
+  const uint64_t* init;   // [8] initial actor states
+  const uint32_t* code;   // [code_len] transition-table rows
+  const uint32_t* hs;     // [n_classes * NT] handler starts
+  const uint32_t* meta;   // [32] msg_class | timer_idx << 8
+  const uint32_t* magic;  // [129] nextInt multiply-high magics
+  uint32_t A, NT, code_len, E, exists, ac_packed;
+  uint32_t inv_kind, inv_fa, inv_va, inv_fb, fp_mask;
+};
+
+__host__ __device__ inline size_t tables_lds_bytes(uint32_t code_len, uint32_t n_ev, uint32_t n_hs) {
+  size_t b = (size_t)n_ev * 8 + DEMI_MAX_ACTORS * 8 + (size_t)code_len * 4 + (size_t)n_hs * 4 +
+             DEMI_MAX_MSG_TYPES * 4 + 132 * 4;
+  return (b + 15) & ~(size_t)15;
+}
+
+// Streams the trace and the tables from HBM into LDS once per workgroup (coalesced); ends with a
+// workgroup barrier.  Returns the first byte after the tables.
+__device__ inline unsigned char* tables_load(Tables& t, unsigned char* smem, const DevModel* __restrict__ gm,
+                                             const uint64_t* __restrict__ g_trace, uint32_t n_ev, uint32_t exists) {
+  t.A = gm->n_actors; t.NT = gm->n_msg_types; t.code_len = gm->code_len; t.E = n_ev; t.exists = exists;
+  t.inv_kind = gm->inv_kind; t.inv_fa = gm->inv_fa; t.inv_va = gm->inv_va; t.inv_fb = gm->inv_fb;
+  t.fp_mask = gm->fp_match_mask;
+  const uint32_t n_hs = gm->n_classes * t.NT;
+  uint64_t* s_trace = reinterpret_cast<uint64_t*>(smem);
+  uint64_t* s_init = s_trace + n_ev;
+  uint32_t* s_code = reinterpret_cast<uint32_t*>(s_init + DEMI_MAX_ACTORS);
+  uint32_t* s_hs = s_code + t.code_len;
+  uint32_t* s_meta = s_hs + n_hs;
+  uint32_t* s_magic = s_meta + DEMI_MAX_MSG_TYPES;
+  for (uint32_t i = threadIdx.x; i < n_ev; i += blockDim.x) s_trace[i] = g_trace[i];
+  for (uint32_t i = threadIdx.x; i < DEMI_MAX_ACTORS; i += blockDim.x) s_init[i] = gm->init_state[i];
+  for (uint32_t i = threadIdx.x; i < t.code_len; i += blockDim.x) s_code[i] = gm->code[i];
+  for (uint32_t i = threadIdx.x; i < n_hs; i += blockDim.x) s_hs[i] = gm->handler_start[i];
+  for (uint32_t i = threadIdx.x; i < DEMI_MAX_MSG_TYPES; i += blockDim.x) s_meta[i] = gm->meta[i];
+  for (uint32_t i = threadIdx.x; i < 129; i += blockDim.x) s_magic[i] = gm->divmagic[i];
+  t.ac_packed = 0;
+  for (uint32_t a = 0; a < t.A; a++) t.ac_packed |= gm->actor_class[a] << (4 * a);
+  t.trace = s_trace; t.init = s_init; t.code = s_code; t.hs = s_hs; t.meta = s_meta; t.magic = s_magic;
+  __syncthreads();
+  return smem + tables_lds_bytes(t.code_len, n_ev, n_hs);
+}
+
+// ------------------------------------------------------------------ per-lane arrays
+// All LDS pointers are already offset by the lane id; element k of an array is p[k * 64].
+// The pending set keeps its PEND_HOT lowest slots in LDS; deeper slots (rare: <1% of raft
+// schedules ever hold more than 32 pending messages) spill to an HBM scratch laid out
+// [slot - PEND_HOT][global lane], so a wave's spill accesses to one slot are coalesced.
+constexpr uint32_t PEND_HOT = 32;
+
+struct LaneMem {
+  uint64_t* st;        // [A]          actor states (LDS)
+  uint32_t* pend;      // [PEND_HOT]   pending message words (LDS)
+  uint32_t* pend_aux;  // [PEND_HOT]   optional parallel array (ids / sequence numbers), may be null
+  uint32_t* fxq;       // [FX_CAP]     effect rows recorded by the current delivery (LDS)
+  uint32_t* spill;     // global: slot s >= PEND_HOT lives at spill[(s - PEND_HOT) * spill_stride]
+  uint32_t* spill_aux; // global, parallel to spill (may be null)
+  uint32_t spill_stride;
+};
+
+__host__ __device__ inline size_t lane_mem_wave_bytes(uint32_t n_actors, bool aux) {
+  return (size_t)n_actors * 64 * 8 + (size_t)PEND_HOT * 64 * 4 * (aux ? 2 : 1) + (size_t)DEMI_FX_CAP * 64 * 4;
+}
+// HBM scratch words for `lanes` simulators (per array)
+__host__ __device__ inline size_t spill_words(size_t lanes) { return lanes * (DEMI_MAX_PENDING - PEND_HOT); }
+
+__device__ inline LaneMem lane_mem_carve(unsigned char* wave_base, uint32_t n_actors, bool aux, uint32_t lane,
+                                         uint32_t* g_spill, size_t global_lane, size_t total_lanes) {
+  LaneMem m;
+  m.st = reinterpret_cast<uint64_t*>(wave_base) + lane;
+  uint32_t* p = reinterpret_cast<uint32_t*>(wave_base + (size_t)n_actors * 64 * 8);
+  m.pend = p + lane;
+  p += (size_t)PEND_HOT * 64;
+  m.pend_aux = aux ? p + lane : nullptr;
+  if (aux) p += (size_t)PEND_HOT * 64;
+  m.fxq = p + lane;
+  m.spill = g_spill + global_lane;
+  m.spill_aux = aux ? g_spill + spill_words(total_lanes) + global_lane : nullptr;
+  m.spill_stride = (uint32_t)total_lanes;
+  return m;
+}
+
+__device__ __forceinline__ uint32_t pend_load(const LaneMem& m, uint32_t slot) {
+  if (slot < PEND_HOT) return m.pend[slot * 64];
+  return m.spill[(size_t)(slot - PEND_HOT) * m.spill_stride];
+}
+__device__ __forceinline__ void pend_store(const LaneMem& m, uint32_t slot, uint32_t v) {
+  if (slot < PEND_HOT) m.pend[slot * 64] = v;
+  else m.spill[(size_t)(slot - PEND_HOT) * m.spill_stride] = v;
+}
+__device__ __forceinline__ uint32_t aux_load(const LaneMem& m, uint32_t slot) {
+  if (slot < PEND_HOT) return m.pend_aux[slot * 64];
+  return m.spill_aux[(size_t)(slot - PEND_HOT) * m.spill_stride];
+}
+__device__ __forceinline__ void aux_store(const LaneMem& m, uint32_t slot, uint32_t v) {
+  if (slot < PEND_HOT) m.pend_aux[slot * 64] = v;
+  else m.spill_aux[(size_t)(slot - PEND_HOT) * m.spill_stride] = v;
+}
+
+// ------------------------------------------------------------------ row interpreter
+// effect word recorded per effect row: op[4:0] | type[9:5] | target[13:10] | p0[21:14] | p1[29:22]
+__device__ __forceinline__ uint32_t fx_pack(uint32_t op, uint32_t type, uint32_t target, uint32_t p0, uint32_t p1) {
+  return (op & 31u) | (type << 5) | (target << 10) | (p0 << 14) | (p1 << 22);
+}
+
+__device__ __forceinline__ uint32_t reg_get(uint64_t lo, uint64_t hi, uint32_t i) {
+  const uint64_t v = (i & 8u) ? hi : lo;
+  return (uint32_t)(v >> ((i & 7u) * 8u)) & 0xFFu;
+}
+
+// Runs the handler of message word `w` on its receiver.  State is read from / written to
+// mem.st; effect rows are recorded into mem.fxq.  Returns the number of recorded effect rows
+// (sets DEMI_V_QUEUE_OVF in flags when more than DEMI_FX_CAP would be recorded).
+__device__ inline uint32_t vm_run(const Tables& t, const LaneMem& mem, uint32_t w, uint32_t& flags) {
+  const uint32_t type = w_type(w), me = w_dst(w);
+  uint32_t pc = t.hs[((t.ac_packed >> (4 * me)) & 15u) * t.NT + type];
+  if (pc == 0xFFFFu) return 0;
+  uint64_t lo = mem.st[me * 64];
+  uint64_t hi = ((uint64_t)w_p0(w) << 32) | ((uint64_t)w_p1(w) << 40) | ((uint64_t)w_src(w) << 48) | ((uint64_t)me << 56);
+  uint32_t nfx = 0;
+  const uint32_t code_len = t.code_len;
+  while (pc < code_len) {
+    const uint32_t row = t.code[pc];
+    pc++;
+    const uint32_t op = row & 0xFFu;
+    if (op == DEMI_OP_HALT) break;
+    const uint32_t dsti = (row >> 8) & 15u, ai = (row >> 12) & 15u, aux = (row >> 17) & 0x7Fu, braw = row >> 24;
+    const uint32_t a = reg_get(lo, hi, ai);
+    const uint32_t breg = reg_get(lo, hi, braw & 15u);
+    const uint32_t b = (row & 0x10000u) ? braw : breg;
+    // ---- relation of a and b: 0 (a<b), 1 (a==b), 2 (a>b); accepted-relation masks per compare kind
+    const int32_t d = (int32_t)a - (int32_t)b;
+    const uint32_t rel = (uint32_t)(min(max(d, -1), 1) + 1);                 // v_med3_i32
+    // kinds in the order EQ NE LT GE LE GT: masks over {lt=1, eq=2, gt=4}
+    const bool is_if = op >= DEMI_OP_IFEQ;
+    const uint32_t ck = is_if ? op - DEMI_OP_IFEQ : op - DEMI_OP_EQ;         // only meaningful for compares
+    constexpr uint32_t kRelMasks = 2u | (5u << 3) | (1u << 6) | (6u << 9) | (3u << 12) | (4u << 15);
+    const uint32_t relmask = (kRelMasks >> ((ck & 7u) * 3u)) & 7u;
+    const uint32_t cond = (relmask >> rel) & 1u;
+    // ---- ALU result classes (all computed, one selected)
+    const uint32_t sh = b & 7u;
+    uint32_t r = b;                                                          // MOV
+    r = (op == DEMI_OP_ADD) ? a + b : r;
+    r = (op == DEMI_OP_SUB) ? a - b : r;
+    r = (op == DEMI_OP_AND) ? (a & b) : r;
+    r = (op == DEMI_OP_OR) ? (a | b) : r;
+    r = (op == DEMI_OP_XOR) ? (a ^ b) : r;
+    r = (op == DEMI_OP_SHL) ? (a << sh) : r;
+    r = (op == DEMI_OP_SHR) ? (a >> sh) : r;
+    r = (op == DEMI_OP_BITSET) ? (a | (1u << sh)) : r;
+    r = (op == DEMI_OP_POPC) ? (uint32_t)__popc(b) : r;
+    r = (op >= DEMI_OP_EQ && op <= DEMI_OP_GT) ? cond : r;
+    r = (op == DEMI_OP_MIN) ? ((rel == 0) ? a : b) : r;
+    r = (op == DEMI_OP_MAX) ? ((rel == 2) ? a : b) : r;
+    const bool is_alu = op <= DEMI_OP_MAX;
+    if (is_alu) {
+      const uint32_t shft = (dsti & 7u) * 8u;
+      const uint64_t msk = 0xFFull << shft, val = (uint64_t)(r & 0xFFu) << shft;
+      if (dsti & 8u) hi = (hi & ~msk) | val; else lo = (lo & ~msk) | val;
+    }
+    // ---- forward skips
+    const bool skip = (op == DEMI_OP_SKIP) | ((op == DEMI_OP_SKIPZ) & (a == 0)) | ((op == DEMI_OP_SKIPNZ) & (a != 0)) |
+                      (is_if & (cond == 0));
+    pc += skip ? (is_if ? aux : braw) : 0u;
+    // ---- effect rows: recorded now, applied after the rows have run
+    if (op >= DEMI_OP_SEND && op <= DEMI_OP_TCANCEL) {
+      if (nfx >= DEMI_FX_CAP) { flags |= DEMI_V_QUEUE_OVF; break; }
+      const uint32_t p0 = reg_get(lo, hi, dsti);
+      mem.fxq[nfx * 64] = fx_pack(op, aux, a > 15u ? 15u : a, p0, b);   // target 15 = nobody
+      nfx++;
+    }
+  }
+  mem.st[me * 64] = lo;
+  return nfx;
+}
+
+}  // namespace demi

@@ -29,7 +29,7 @@ SRC, ME = Reg(14), Reg(15)              # sender id (15 = deadLetters), own id
 
 OPS = dict(HALT=0, MOV=1, ADD=2, SUB=3, AND=4, OR=5, XOR=6, SHL=7, SHR=8, BITSET=9, POPC=10,
            EQ=11, NE=12, LT=13, GE=14, LE=15, GT=16, MIN=17, MAX=18, SKIPZ=20, SKIPNZ=21, SKIP=22,
-           SEND=24, BCAST=25, TSET=26, TREP=27, TCANCEL=28)
+           SEND=24, BCAST=25, TSET=26, TREP=27, TCANCEL=28, IFEQ=32, IFNE=33, IFLT=34, IFGE=35, IFLE=36, IFGT=37)
 
 
 def row(op, dst=0, a=0, bimm=0, aux=0, b=0):
@@ -70,6 +70,14 @@ class Asm:
     def _skip(self, name, a, label):
         self._fix.append((len(self.rows), label))
         self.rows.append(row(OPS[name], 0, int(a), 1, 0, 0))
+        return self
+
+    def _if(self, name, a, b, label):
+        """Fused guard: rows up to `label` execute only if (a OP b)."""
+        assert isinstance(a, Reg)
+        bimm, bv = self._b(b)
+        self._fix.append((len(self.rows), label))
+        self.rows.append(row(OPS[name], 0, int(a), bimm, 0, bv))
         return self
 
     def skipz(self, a, label):
@@ -120,8 +128,12 @@ class Asm:
             self.halt()
         for idx, label in self._fix:
             dist = self._labels[label] - (idx + 1)
-            assert 0 <= dist < 256, "skip must be forward, < 256 rows"
-            self.rows[idx] |= dist << 24
+            if (self.rows[idx] & 0xFF) >= OPS["IFEQ"]:
+                assert 0 <= dist < 128, "guarded block must be forward, < 128 rows"
+                self.rows[idx] |= dist << 17
+            else:
+                assert 0 <= dist < 256, "skip must be forward, < 256 rows"
+                self.rows[idx] |= dist << 24
         return self.rows
 
 
@@ -132,6 +144,14 @@ for _n in ("ADD", "SUB", "AND", "OR", "XOR", "SHL", "SHR", "BITSET", "EQ", "NE",
             return self.alu(n, dst, a, b)
         return f
     setattr(Asm, _n.lower() if _n not in ("AND", "OR") else _n.lower() + "_", _mk(_n))
+
+
+for _n in ("IFEQ", "IFNE", "IFLT", "IFGE", "IFLE", "IFGT"):
+    def _mk2(n):
+        def f(self, a, b, label):
+            return self._if(n, a, b, label)
+        return f
+    setattr(Asm, "if_" + _n[2:].lower(), _mk2(_n))
 
 
 @dataclass
@@ -230,19 +250,19 @@ def raft_model(n_actors=5, election_budget=1, buggy=True) -> Model:
 
     # Bootstrap (the ChangeConfiguration the DEMi raft runner Sends after Start): begin as follower.
     a = Asm()
-    a.skipnz(BOOTED, "done").mov(BOOTED, 1).tset(M_ELECTION_TIMEOUT).label("done")
+    a.if_eq(BOOTED, 0, "done").mov(BOOTED, 1).tset(M_ELECTION_TIMEOUT).label("done")
     h[(0, "Bootstrap")] = a
 
     # ClientCommand: a leader appends and replicates; everyone else ignores it.
     a = Asm()
-    a.eq(T0, ROLE, LEADER).skipz(T0, "done")
+    a.if_eq(ROLE, LEADER, "done")
     a.add(LOGLEN, LOGLEN, 1).bcast(M_APPEND_ENTRIES, TERM, LOGLEN).label("done")
     h[(0, "ClientCommand")] = a
 
     # ElectionTimeout: start an election (bounded number per node so that executions quiesce).
     a = Asm()
-    a.eq(T0, ROLE, LEADER).skipnz(T0, "done")
-    a.eq(T0, BUDGET, 0).skipnz(T0, "done")
+    a.if_ne(ROLE, LEADER, "done")
+    a.if_ne(BUDGET, 0, "done")
     a.sub(BUDGET, BUDGET, 1).mov(ROLE, CANDIDATE).add(TERM, TERM, 1).mov(VOTED, ME)
     a.mov(VOTES, 0).bitset(VOTES, VOTES, ME)
     a.bcast(M_REQUEST_VOTE, TERM, 0).tset(M_ELECTION_TIMEOUT).label("done")
@@ -250,17 +270,16 @@ def raft_model(n_actors=5, election_budget=1, buggy=True) -> Model:
 
     # RequestVote(term) from SRC.
     a = Asm()
-    a.gt(T0, P0, TERM).skipz(T0, "same")
-    a.eq(T1, ROLE, LEADER).skipz(T1, "nl").tcancel(M_HEARTBEAT).label("nl")
+    a.if_gt(P0, TERM, "same")
+    a.if_eq(ROLE, LEADER, "nl").tcancel(M_HEARTBEAT).label("nl")
     a.mov(TERM, P0).mov(ROLE, FOLLOWER).mov(VOTED, NOBODY)
     a.label("same")
-    a.eq(T0, P0, TERM)
     a.eq(T1, VOTED, NOBODY).eq(T2, VOTED, SRC).or_(T1, T1, T2)
     if buggy:
         # seeded bug: a candidate forgets its own vote when its right-hand neighbour (id + 1)
         # asks for a vote in the same term -> two leaders can be elected in one term
         a.eq(T2, ROLE, CANDIDATE).sub(T3, SRC, 1).eq(T3, T3, ME).and_(T2, T2, T3).or_(T1, T1, T2)
-    a.and_(T0, T0, T1).skipz(T0, "deny")
+    a.eq(T0, P0, TERM).and_(T0, T0, T1).if_ne(T0, 0, "deny")
     a.mov(VOTED, SRC).tcancel(M_ELECTION_TIMEOUT).tset(M_ELECTION_TIMEOUT)
     a.mov(T3, 1).send(M_VOTE_REPLY, SRC, TERM, T3).halt()
     a.label("deny").send(M_VOTE_REPLY, SRC, TERM, 0)
@@ -268,23 +287,23 @@ def raft_model(n_actors=5, election_budget=1, buggy=True) -> Model:
 
     # VoteReply(term, granted) from SRC.
     a = Asm()
-    a.gt(T0, P0, TERM).skipz(T0, "cur")
-    a.eq(T1, ROLE, LEADER).skipz(T1, "nl").tcancel(M_HEARTBEAT).label("nl")
+    a.if_gt(P0, TERM, "cur")
+    a.if_eq(ROLE, LEADER, "nl").tcancel(M_HEARTBEAT).label("nl")
     a.mov(TERM, P0).mov(ROLE, FOLLOWER).mov(VOTED, NOBODY).halt()
     a.label("cur")
-    a.eq(T0, ROLE, CANDIDATE).eq(T1, P0, TERM).and_(T0, T0, T1).and_(T0, T0, P1).skipz(T0, "done")
-    a.bitset(VOTES, VOTES, SRC).popc(T1, VOTES).ge(T1, T1, majority).skipz(T1, "done")
+    a.if_eq(ROLE, CANDIDATE, "done").if_eq(P0, TERM, "done").and_(T0, P1, 1).if_ne(T0, 0, "done")
+    a.bitset(VOTES, VOTES, SRC).popc(T1, VOTES).if_ge(T1, majority, "done")
     a.mov(ROLE, LEADER).tcancel(M_ELECTION_TIMEOUT).trep(M_HEARTBEAT)
     a.bcast(M_APPEND_ENTRIES, TERM, LOGLEN).label("done")
     h[(0, "VoteReply")] = a
 
     # AppendEntries(term, loglen) from SRC.
     a = Asm()
-    a.lt(T0, P0, TERM).skipz(T0, "ok").send(M_APPEND_REPLY, SRC, TERM, 0).halt()
+    a.if_lt(P0, TERM, "ok").send(M_APPEND_REPLY, SRC, TERM, 0).halt()
     a.label("ok")
-    a.gt(T0, P0, TERM).skipz(T0, "sameterm").mov(VOTED, NOBODY).label("sameterm")
-    a.gt(T0, P0, TERM).ne(T1, ROLE, LEADER).or_(T0, T0, T1).skipz(T0, "keep")
-    a.eq(T1, ROLE, LEADER).skipz(T1, "nl").tcancel(M_HEARTBEAT).label("nl")
+    a.if_gt(P0, TERM, "sameterm").mov(VOTED, NOBODY).label("sameterm")
+    a.gt(T0, P0, TERM).ne(T1, ROLE, LEADER).or_(T0, T0, T1).if_ne(T0, 0, "keep")
+    a.if_eq(ROLE, LEADER, "nl").tcancel(M_HEARTBEAT).label("nl")
     a.mov(ROLE, FOLLOWER)
     a.label("keep")
     a.mov(TERM, P0).max(LOGLEN, LOGLEN, P1)
@@ -294,18 +313,18 @@ def raft_model(n_actors=5, election_budget=1, buggy=True) -> Model:
 
     # AppendReply(term, acked) from SRC.
     a = Asm()
-    a.gt(T0, P0, TERM).skipz(T0, "cur")
-    a.eq(T1, ROLE, LEADER).skipz(T1, "nl").tcancel(M_HEARTBEAT).label("nl")
+    a.if_gt(P0, TERM, "cur")
+    a.if_eq(ROLE, LEADER, "nl").tcancel(M_HEARTBEAT).label("nl")
     a.mov(TERM, P0).mov(ROLE, FOLLOWER).mov(VOTED, NOBODY).halt()
     a.label("cur")
-    a.eq(T0, ROLE, LEADER).eq(T1, P0, TERM).and_(T0, T0, T1).skipz(T0, "done")
+    a.if_eq(ROLE, LEADER, "done").if_eq(P0, TERM, "done")
     a.max(COMMIT, COMMIT, P1).label("done")
     h[(0, "AppendReply")] = a
 
     # Heartbeat (repeating timer): a leader re-sends uncommitted entries.
     a = Asm()
-    a.eq(T0, ROLE, LEADER).skipnz(T0, "lead").tcancel(M_HEARTBEAT).halt()
-    a.label("lead").gt(T0, LOGLEN, COMMIT).skipz(T0, "done")
+    a.if_ne(ROLE, LEADER, "lead").tcancel(M_HEARTBEAT).halt()
+    a.label("lead").if_gt(LOGLEN, COMMIT, "done")
     a.bcast(M_APPEND_ENTRIES, TERM, LOGLEN).label("done")
     h[(0, "Heartbeat")] = a
 

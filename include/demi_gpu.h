@@ -35,7 +35,9 @@ extern "C" {
 #define DEMI_MAX_EXT_EVENTS  255    /* external events per trace */
 #define DEMI_TQ_CAP          8      /* messagesToSend timers between two scheduling steps */
 #define DEMI_RESEND_CAP      8      /* timersToResend */
+#define DEMI_FX_CAP          8      /* effect rows (SEND/BCAST/TSET/TREP/TCANCEL) executed per delivery */
 #define DEMI_MAX_REC_EVENTS  4096   /* recorded events of one execution */
+#define DEMI_MAX_PENDING     128    /* largest p_max */
 
 /* ------------------------------------------------------------------ status */
 typedef enum {
@@ -89,6 +91,8 @@ typedef enum {
   DEMI_OP_SKIPZ = 20,   /* if reg a == 0 skip the next b rows  (b immediate) */
   DEMI_OP_SKIPNZ = 21,  /* if reg a != 0 skip the next b rows */
   DEMI_OP_SKIP = 22,    /* skip the next b rows */
+  /* fused guard: if !(reg a OP b) skip the next `aux` rows */
+  DEMI_OP_IFEQ = 32, DEMI_OP_IFNE = 33, DEMI_OP_IFLT = 34, DEMI_OP_IFGE = 35, DEMI_OP_IFLE = 36, DEMI_OP_IFGT = 37,
   DEMI_OP_SEND = 24,    /* `target ! msg`: type = aux, target = reg a, p0 = reg dst, p1 = b    */
   DEMI_OP_BCAST = 25,   /* SEND to every other created actor, ascending id: p0 = reg dst, p1 = b */
   DEMI_OP_TSET = 26,    /* scheduler.scheduleOnce(self, msg type aux)                          */
@@ -127,7 +131,7 @@ typedef struct {
 typedef struct {
   uint32_t max_messages;              /* RandomScheduler.setMaxMessages (RandomScheduler.scala:54-57); 0 = unbounded */
   uint32_t invariant_check_interval;  /* RandomScheduler ctor arg (RandomScheduler.scala:43); 0 = only at the end */
-  uint32_t p_max;                     /* capacity of the pending set per schedule: 32, 64 or 128 */
+  uint32_t p_max;                     /* capacity of the pending set per schedule, 1..128 (0 = 64) */
   uint32_t looking_for_valid;         /* explore(_trace, _lookingFor) (RandomScheduler.scala:234-237) */
   uint32_t looking_for;               /* target fingerprint code */
   uint32_t populate_all;              /* setActorNamePropPairs: create all actors, not only Start()ed ones */
@@ -137,7 +141,7 @@ typedef struct {
 #define DEMI_V_VIOLATION     0x1u  /* invariant violated (and matching looking_for when set)         */
 #define DEMI_V_MAXMSG        0x2u  /* messagesScheduledSoFar > maxMessages: not bug-checked (:256)   */
 #define DEMI_V_PENDING_OVF   0x4u  /* pending set exceeded p_max: schedule aborted, verdict invalid   */
-#define DEMI_V_QUEUE_OVF     0x8u  /* timer queues exceeded their caps: aborted, verdict invalid      */
+#define DEMI_V_QUEUE_OVF     0x8u  /* timer queues / DEMI_FX_CAP exceeded: aborted, verdict invalid       */
 #define DEMI_V_DIVERGED      0x10u /* replay kernels: an expected delivery was absent (ignored)       */
 typedef struct {
   uint32_t flags;        /* bits 0..7 DEMI_V_*; bits 8..15 traceIdx at the end; bits 16..31 deliveries */

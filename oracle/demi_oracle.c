@@ -100,6 +100,10 @@ int orc_model_validate(const demi_model* m, char* err, size_t err_cap) {
         if (!bimm) FAIL("row %u: skip distance must be an immediate", pc);
         if (pc + 1 + b > m->code_len) FAIL("row %u: skip past the end of the table", pc);
         break;
+      case DEMI_OP_IFEQ: case DEMI_OP_IFNE: case DEMI_OP_IFLT: case DEMI_OP_IFGE: case DEMI_OP_IFLE:
+      case DEMI_OP_IFGT:
+        if (pc + 1 + aux > m->code_len) FAIL("row %u: skip past the end of the table", pc);
+        break;
       case DEMI_OP_SEND: case DEMI_OP_BCAST:
         /* the reference assumes "external message objects never == internal message objects"
            (V/schedulers/ExternalEventInjector.scala:101-104); timers are only ever produced by
@@ -161,7 +165,7 @@ int orc_trace_validate(const demi_model* m, const demi_ext_event* ev, uint32_t n
  * as Akka would call `!` / scheduleOnce / cancel inside receive (WeaveActor.aj:224-279).       */
 int orc_vm_run(const demi_model* m, uint32_t me, uint64_t* state, uint8_t msg_type, uint8_t src,
                uint8_t p0, uint8_t p1, uint32_t exists_mask, orc_effect* fx, uint32_t fx_cap) {
-  uint32_t nfx = 0;
+  uint32_t nfx = 0, n_fx_rows = 0;
   uint16_t start = m->handler_start[m->actor_class[me] * m->n_msg_types + msg_type];
   if (start == 0xFFFF) return 0;
   uint8_t r[16];
@@ -198,7 +202,14 @@ int orc_vm_run(const demi_model* m, uint32_t me, uint64_t* state, uint8_t msg_ty
       case DEMI_OP_SKIPZ: if (a == 0) pc += braw; break;
       case DEMI_OP_SKIPNZ: if (a != 0) pc += braw; break;
       case DEMI_OP_SKIP: pc += braw; break;
+      case DEMI_OP_IFEQ: if (!(a == b)) pc += aux; break;
+      case DEMI_OP_IFNE: if (!(a != b)) pc += aux; break;
+      case DEMI_OP_IFLT: if (!(a < b)) pc += aux; break;
+      case DEMI_OP_IFGE: if (!(a >= b)) pc += aux; break;
+      case DEMI_OP_IFLE: if (!(a <= b)) pc += aux; break;
+      case DEMI_OP_IFGT: if (!(a > b)) pc += aux; break;
       case DEMI_OP_SEND:
+        if (++n_fx_rows > DEMI_FX_CAP) return -1;
         /* a message to a name that was never created reaches no scheduler (deadLetters) */
         if (a < m->n_actors && ((exists_mask >> a) & 1)) {
           if (nfx >= fx_cap) return -1;
@@ -206,6 +217,7 @@ int orc_vm_run(const demi_model* m, uint32_t me, uint64_t* state, uint8_t msg_ty
         }
         break;
       case DEMI_OP_BCAST:
+        if (++n_fx_rows > DEMI_FX_CAP) return -1;
         for (uint32_t j = 0; j < m->n_actors; j++) {
           if (j == me || !((exists_mask >> j) & 1)) continue;
           if (nfx >= fx_cap) return -1;
@@ -213,6 +225,7 @@ int orc_vm_run(const demi_model* m, uint32_t me, uint64_t* state, uint8_t msg_ty
         }
         break;
       case DEMI_OP_TSET: case DEMI_OP_TREP: case DEMI_OP_TCANCEL:
+        if (++n_fx_rows > DEMI_FX_CAP) return -1;
         if (nfx >= fx_cap) return -1;
         fx[nfx++] = (orc_effect){(uint8_t)(1 + (op - DEMI_OP_TSET)), (uint8_t)me, (uint8_t)aux, 0, 0};
         break;
@@ -269,7 +282,7 @@ uint32_t orc_invariant(const demi_model* m, const uint64_t* st, uint32_t exists)
 }
 
 /* ===================================================================== one execution */
-#define PEND_HARD_CAP 128
+#define PEND_HARD_CAP DEMI_MAX_PENDING
 #define MTS_CAP 512
 
 typedef struct { uint32_t word; uint32_t id; } pend_entry;
