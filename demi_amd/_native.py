@@ -12,7 +12,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdemi_gpu.so")
 
 EXPORTS = ["demi_ctx_create", "demi_ctx_destroy", "demi_last_error", "demi_version", "demi_model_load",
-           "demi_trace_load", "demi_random_explore", "demi_random_explore_dev", "demi_random_get_trace", "demi_collect_violations_dev"]
+           "demi_trace_load", "demi_random_explore", "demi_random_explore_dev", "demi_random_get_trace", "demi_collect_violations_dev",
+           "demi_replay_load", "demi_replay_batch", "demi_replay_batch_dev"]
 
 _lib = None
 
@@ -53,6 +54,9 @@ def lib():
                                         C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
     L.demi_collect_violations_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p,
                                               C.c_uint32, C.c_void_p, C.c_void_p]
+    L.demi_replay_load.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
+    L.demi_replay_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(T.Limits), C.c_void_p]
+    L.demi_replay_batch_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(T.Limits), C.c_void_p, C.c_void_p]
     _lib = L
     return L
 
@@ -109,6 +113,22 @@ class Context:
     def collect_violations_dev(self, d_verdicts_ptr, n, index_base, d_out_ptr, cap, d_count_ptr, stream=None):
         self._check(lib().demi_collect_violations_dev(self._h, d_verdicts_ptr, n, C.c_uint64(index_base), d_out_ptr,
                                                       cap, d_count_ptr, stream))
+
+    def replay_load(self, original_externals, original_trace):
+        import numpy as np
+        ev = np.ascontiguousarray(original_externals, dtype=T.EXT_EVENT_DTYPE)
+        rec = np.ascontiguousarray(original_trace, dtype=T.REC_EVENT_DTYPE)
+        self._check(lib().demi_replay_load(self._h, ev.ctypes.data if len(ev) else None, len(ev),
+                                           rec.ctypes.data if len(rec) else None, len(rec)))
+
+    def replay_batch(self, masks, limits):
+        """masks: uint64[n, 4] (bit i of the 256-bit row = external event i kept)."""
+        import numpy as np
+        masks = np.ascontiguousarray(masks, dtype=np.uint64).reshape(-1, 4)
+        out = np.zeros(len(masks), dtype=T.VERDICT_DTYPE)
+        self._check(lib().demi_replay_batch(self._h, masks.ctypes.data if len(masks) else None, len(masks),
+                                            C.byref(limits), out.ctypes.data if len(masks) else None))
+        return out
 
     def random_get_trace(self, seed, limits):
         import numpy as np

@@ -27,3 +27,15 @@ def raft3_config1():
     events = events_to_array(raft_trace(3, 20, TRACE_SEED))
     limits = T.Limits(200, 30, 64, 0, 0, 0)
     return model, events, limits
+
+
+def raft5_config4(n_events=200):
+    """BASELINE config 4: DDMin of a failing Raft-5 execution with 200 external events.  The failing
+    execution is the first violating schedule of the frozen 200-event trace (found by K1, recorded
+    on the GPU); callers minimise its externals with DDMin over the STSSched (no-peek) oracle.
+    The invariant is only checked at the end (interval 0) so the failing execution consumes the
+    whole trace."""
+    model = raft_model(5)
+    events = events_to_array(raft_trace(5, n_events, TRACE_SEED + 4))
+    limits = T.Limits(4000, 0, 128, 0, 0, 0)
+    return model, events, limits

@@ -12,6 +12,7 @@
 
 #include "../../include/demi_gpu.h"
 #include "k1_random_explore.hpp"
+#include "k2_replay.hpp"
 #include "k_collect.hpp"
 
 using namespace demi;
@@ -39,6 +40,15 @@ struct demi_ctx {
   uint32_t* d_rec_count = nullptr;
   uint32_t* d_spill = nullptr;
   size_t spill_bytes = 0;
+  // K2 (replay of an original execution)
+  bool have_replay = false;
+  uint64_t* d_rext = nullptr;       // original externals
+  uint32_t n_rext = 0;
+  uint64_t* d_expected = nullptr;   // lowered original trace
+  uint32_t n_expected = 0;
+  uint32_t replay_spawned = 0;      // actors with a SpawnEvent in the original trace
+  uint64_t* d_masks = nullptr;
+  size_t masks_cap = 0;
 };
 
 static int fail(demi_ctx* ctx, int code, const char* fmt, ...) {
@@ -96,6 +106,9 @@ extern "C" void demi_ctx_destroy(demi_ctx* ctx) {
   if (ctx->d_rec) (void)hipFree(ctx->d_rec);
   if (ctx->d_rec_count) (void)hipFree(ctx->d_rec_count);
   if (ctx->d_spill) (void)hipFree(ctx->d_spill);
+  if (ctx->d_rext) (void)hipFree(ctx->d_rext);
+  if (ctx->d_expected) (void)hipFree(ctx->d_expected);
+  if (ctx->d_masks) (void)hipFree(ctx->d_masks);
   delete ctx;
 }
 
@@ -199,6 +212,7 @@ extern "C" int demi_model_load(demi_ctx* ctx, const demi_model* m) {
   HIP_TRY(ctx, hipMemcpy(ctx->d_model, &h, sizeof h, hipMemcpyHostToDevice));
   ctx->have_model = true;
   ctx->have_trace = false;  // a trace is validated against the model it was loaded after
+  ctx->have_replay = false;
   return DEMI_OK;
 }
 
@@ -243,6 +257,9 @@ static int launch_k1(demi_ctx* ctx, uint32_t p_max, K1Args a, hipStream_t stream
   const size_t need = spill_words(blocks * K1_WAVES * 64) * (REC ? 2 : 1) * sizeof(uint32_t);
   if (ctx->spill_bytes < need) {
     if (ctx->d_spill) (void)hipFree(ctx->d_spill);
+  if (ctx->d_rext) (void)hipFree(ctx->d_rext);
+  if (ctx->d_expected) (void)hipFree(ctx->d_expected);
+  if (ctx->d_masks) (void)hipFree(ctx->d_masks);
     ctx->d_spill = nullptr; ctx->spill_bytes = 0;
     HIP_TRY(ctx, hipMalloc(&ctx->d_spill, need));
     ctx->spill_bytes = need;
@@ -362,5 +379,144 @@ extern "C" int demi_collect_violations_dev(demi_ctx* ctx, const demi_verdict* d_
   hipLaunchKernelGGL(k_collect_violations, dim3((unsigned)blocks), dim3(256), 0, stream, d_verdicts, n, index_base, d_out,
                      cap, d_count);
   HIP_TRY(ctx, hipGetLastError());
+  return DEMI_OK;
+}
+
+// ----------------------------------------------------------------------------- K2: replay
+static int ensure_spill(demi_ctx* ctx, size_t lanes, int arrays) {
+  const size_t need = spill_words(lanes) * (size_t)arrays * sizeof(uint32_t);
+  if (ctx->spill_bytes < need) {
+    if (ctx->d_spill) (void)hipFree(ctx->d_spill);
+    ctx->d_spill = nullptr; ctx->spill_bytes = 0;
+    HIP_TRY(ctx, hipMalloc(&ctx->d_spill, need));
+    ctx->spill_bytes = need;
+  }
+  return DEMI_OK;
+}
+
+extern "C" int demi_replay_load(demi_ctx* ctx, const demi_ext_event* ext, uint32_t n_ext, const demi_rec_event* rec,
+                                uint32_t n_rec) {
+  if (!ctx) return DEMI_ERR_INVALID_ARG;
+  if (!ctx->have_model) return fail(ctx, DEMI_ERR_NO_MODEL, "demi_model_load must precede demi_replay_load");
+  if ((!ext && n_ext) || (!rec && n_rec)) return fail(ctx, DEMI_ERR_INVALID_ARG, "null pointer");
+  if (n_rec > DEMI_MAX_REC_EVENTS) return fail(ctx, DEMI_ERR_INVALID_TRACE, "more than %d recorded events", DEMI_MAX_REC_EVENTS);
+  int rc = validate_trace(ctx, ctx->hmodel, ext, n_ext);
+  if (rc) return rc;
+  const DevModel& h = ctx->hmodel;
+  // id -> index of the Send that enqueued it: filterSends pairs the k-th external MsgSend with the
+  // k-th Send; our recorder stores that index explicitly (ext_idx)
+  std::vector<uint8_t> send_of_id(2 * DEMI_MAX_REC_EVENTS + 2, 255);
+  std::vector<uint64_t> expd;
+  uint32_t spawned = 0;
+  for (uint32_t i = 0; i < n_rec; i++) {
+    const demi_rec_event& e = rec[i];
+    auto pack = [](uint32_t kind, uint32_t a, uint32_t b, uint32_t type, uint32_t p0, uint32_t p1, uint32_t x) {
+      return (uint64_t)kind | ((uint64_t)a << 8) | ((uint64_t)b << 16) | ((uint64_t)type << 24) | ((uint64_t)p0 << 32) |
+             ((uint64_t)p1 << 40) | ((uint64_t)x << 48);
+    };
+    switch (e.kind) {
+      case DEMI_REC_SPAWN: case DEMI_REC_KILL:
+        if (e.rcv >= h.n_actors) return fail(ctx, DEMI_ERR_INVALID_TRACE, "recorded event %u: actor out of range", i);
+        if (e.kind == DEMI_REC_SPAWN) spawned |= 1u << e.rcv;
+        expd.push_back(pack(e.kind, e.rcv, 0, 0, 0, 0, e.ext_idx));
+        break;
+      case DEMI_REC_PARTITION: case DEMI_REC_UNPARTITION:
+        if (e.snd >= h.n_actors || e.rcv >= h.n_actors) return fail(ctx, DEMI_ERR_INVALID_TRACE, "recorded event %u: actor out of range", i);
+        expd.push_back(pack(e.kind, e.snd, e.rcv, 0, 0, 0, e.ext_idx));
+        break;
+      case DEMI_REC_MSG_SEND:
+        if (e.rcv >= h.n_actors || e.msg_type >= h.n_msg_types) return fail(ctx, DEMI_ERR_INVALID_TRACE, "recorded event %u: bad message", i);
+        if (e.flags & 1) {  // external
+          if (e.ext_idx >= n_ext || ext[e.ext_idx].kind != DEMI_EV_SEND)
+            return fail(ctx, DEMI_ERR_INVALID_TRACE, "recorded event %u: external MsgSend without its Send", i);
+          if (e.id < send_of_id.size()) send_of_id[e.id] = e.ext_idx;
+          expd.push_back(pack(e.kind, 0, e.rcv, e.msg_type, e.p0, e.p1, e.ext_idx));
+        }
+        break;
+      case DEMI_REC_MSG_EVENT: {
+        if (e.rcv >= h.n_actors || e.msg_type >= h.n_msg_types || (e.snd >= h.n_actors && e.snd != DEMI_DEADLETTERS))
+          return fail(ctx, DEMI_ERR_INVALID_TRACE, "recorded event %u: bad message", i);
+        const uint8_t s = e.id < send_of_id.size() ? send_of_id[e.id] : 255;
+        expd.push_back(pack(e.kind, e.snd, e.rcv, e.msg_type, e.p0, e.p1, s));
+        break;
+      }
+      case DEMI_REC_BEGIN_WAIT_QUIESCENCE: case DEMI_REC_QUIESCENCE:
+        break;  // nops in advanceReplay (:530-538)
+      default:
+        return fail(ctx, DEMI_ERR_INVALID_TRACE, "recorded event %u: unknown kind %u", i, e.kind);
+    }
+  }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (!ctx->d_rext) HIP_TRY(ctx, hipMalloc(&ctx->d_rext, sizeof(uint64_t) * (DEMI_MAX_EXT_EVENTS + 1)));
+  if (!ctx->d_expected) HIP_TRY(ctx, hipMalloc(&ctx->d_expected, sizeof(uint64_t) * (DEMI_MAX_REC_EVENTS + 1)));
+  if (n_ext) HIP_TRY(ctx, hipMemcpy(ctx->d_rext, ext, sizeof(demi_ext_event) * n_ext, hipMemcpyHostToDevice));
+  if (!expd.empty()) HIP_TRY(ctx, hipMemcpy(ctx->d_expected, expd.data(), sizeof(uint64_t) * expd.size(), hipMemcpyHostToDevice));
+  ctx->n_rext = n_ext;
+  ctx->n_expected = (uint32_t)expd.size();
+  ctx->replay_spawned = spawned;
+  ctx->have_replay = true;
+  return DEMI_OK;
+}
+
+extern "C" int demi_replay_batch_dev(demi_ctx* ctx, const uint64_t* d_masks, uint64_t n, const demi_limits* lim,
+                                     demi_verdict* d_out, void* hip_stream) {
+  if (!ctx) return DEMI_ERR_INVALID_ARG;
+  if (n == 0) return DEMI_OK;
+  if (!ctx->have_model) return fail(ctx, DEMI_ERR_NO_MODEL, "no model loaded");
+  if (!ctx->have_replay) return fail(ctx, DEMI_ERR_NO_TRACE, "demi_replay_load must precede demi_replay_batch");
+  if (!lim || !d_masks || !d_out) return fail(ctx, DEMI_ERR_INVALID_ARG, "null pointer");
+  if (!lim->looking_for_valid) return fail(ctx, DEMI_ERR_INVALID_ARG, "replay needs the target fingerprint (looking_for)");
+  uint32_t p_max = lim->p_max ? lim->p_max : 64;
+  if (p_max > DEMI_MAX_PENDING) return fail(ctx, DEMI_ERR_INVALID_ARG, "p_max must be 1..%d", DEMI_MAX_PENDING);
+  hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+  const DevModel& h = ctx->hmodel;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const size_t lds = k2_lds_bytes(h.code_len, ctx->n_rext, h.n_classes * h.n_msg_types, h.n_actors);
+  HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k2_replay), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  int per_cu = 0;
+  HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k2_replay, K2_WAVES * 64, lds));
+  if (per_cu < 1) per_cu = 1;
+  // candidates are few (a DDMin frontier): spread them over as many CUs as possible, one wave each
+  uint64_t blocks = (n + 63) / 64;
+  const uint64_t resident = (uint64_t)ctx->num_cu * (uint64_t)per_cu;
+  if (blocks > resident) blocks = resident;
+  int rc = ensure_spill(ctx, blocks * K2_WAVES * 64, 1);
+  if (rc) return rc;
+  K2Args a;
+  memset(&a, 0, sizeof a);
+  a.model = ctx->d_model; a.ext = ctx->d_rext; a.n_ext = ctx->n_rext;
+  a.exists = lim->populate_all ? ((1u << h.n_actors) - 1) : ctx->replay_spawned;
+  a.expected = ctx->d_expected; a.n_exp = ctx->n_expected;
+  a.p_max = p_max; a.looking_for = lim->looking_for;
+  a.masks = d_masks; a.n = n; a.out = d_out; a.work_counter = ctx->d_counter; a.spill = ctx->d_spill;
+  HIP_TRY(ctx, hipMemsetAsync(a.work_counter, 0, sizeof(unsigned long long), stream));
+  hipLaunchKernelGGL(k2_replay, dim3((unsigned)blocks), dim3(K2_WAVES * 64), lds, stream, a);
+  HIP_TRY(ctx, hipGetLastError());
+  return DEMI_OK;
+}
+
+extern "C" int demi_replay_batch(demi_ctx* ctx, const uint64_t* masks, uint64_t n, const demi_limits* lim,
+                                 demi_verdict* out) {
+  if (!ctx) return DEMI_ERR_INVALID_ARG;
+  if (n == 0) return DEMI_OK;
+  if (!masks || !out) return fail(ctx, DEMI_ERR_INVALID_ARG, "null pointer");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (ctx->out_cap < n) {
+    if (ctx->d_out) (void)hipFree(ctx->d_out);
+    ctx->d_out = nullptr; ctx->out_cap = 0;
+    HIP_TRY(ctx, hipMalloc(&ctx->d_out, sizeof(demi_verdict) * n));
+    ctx->out_cap = n;
+  }
+  if (ctx->masks_cap < n) {
+    if (ctx->d_masks) (void)hipFree(ctx->d_masks);
+    ctx->d_masks = nullptr; ctx->masks_cap = 0;
+    HIP_TRY(ctx, hipMalloc(&ctx->d_masks, sizeof(uint64_t) * 4 * n));
+    ctx->masks_cap = n;
+  }
+  HIP_TRY(ctx, hipMemcpy(ctx->d_masks, masks, sizeof(uint64_t) * 4 * n, hipMemcpyHostToDevice));
+  int rc = demi_replay_batch_dev(ctx, ctx->d_masks, n, lim, ctx->d_out, nullptr);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  HIP_TRY(ctx, hipMemcpy(out, ctx->d_out, sizeof(demi_verdict) * n, hipMemcpyDeviceToHost));
   return DEMI_OK;
 }

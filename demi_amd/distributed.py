@@ -53,3 +53,31 @@ def allgather_violation_sets(local: "torch.Tensor", cap: int) -> np.ndarray:
     parts = [torch.empty_like(local) for _ in range(dist.get_world_size())]
     dist.all_gather(parts, local)
     return merge_violation_sets([p.cpu().numpy() for p in parts], cap)
+
+
+def sharded_map(items: list, fn) -> list:
+    """Evaluate fn(list) -> list of bool over `items`, dealt round-robin to the ranks of the default
+    process group, and all-gather the result bits so every rank returns the full list.  Without a
+    process group this is fn(items).  Used for DDMin frontiers and DPOR rounds: payloads are a few
+    hundred bytes, i.e. latency-bound."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+        return list(fn(items))
+    world, rank = dist.get_world_size(), dist.get_rank()
+    mine = items[rank::world]
+    res = list(fn(mine)) if mine else []
+    per = (len(items) + world - 1) // world
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    buf = torch.zeros(per, dtype=torch.uint8, device=dev)
+    if res:
+        buf[:len(res)] = torch.tensor([1 if r else 0 for r in res], dtype=torch.uint8, device=dev)
+    parts = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(parts, buf)
+    parts = [p.cpu().numpy() for p in parts]
+    out = [False] * len(items)
+    for r in range(world):
+        n_r = len(items[r::world])
+        for k in range(n_r):
+            out[r + k * world] = bool(parts[r][k])
+    return out

@@ -8,7 +8,7 @@ MAX_CLASSES = 4
 MAX_CODE = 1024
 MAX_TIMER_TYPES = 4
 MAX_EXT_EVENTS = 255
-MAX_REC_EVENTS = 4096
+MAX_REC_EVENTS = 16384
 
 # demi_status
 OK = 0

@@ -36,7 +36,7 @@ extern "C" {
 #define DEMI_TQ_CAP          8      /* messagesToSend timers between two scheduling steps */
 #define DEMI_RESEND_CAP      8      /* timersToResend */
 #define DEMI_FX_CAP          8      /* effect rows (SEND/BCAST/TSET/TREP/TCANCEL) executed per delivery */
-#define DEMI_MAX_REC_EVENTS  4096   /* recorded events of one execution */
+#define DEMI_MAX_REC_EVENTS  16384  /* recorded events of one execution */
 #define DEMI_MAX_PENDING     128    /* largest p_max */
 
 /* ------------------------------------------------------------------ status */
@@ -195,6 +195,22 @@ int demi_random_explore_dev(demi_ctx* ctx, uint64_t seed_base, const uint64_t* d
  * RandomScheduler.scala:156-180), recorded on the GPU by re-running that seed.                 */
 int demi_random_get_trace(demi_ctx* ctx, uint64_t seed, const demi_limits* limits,
                           demi_verdict* verdict, demi_rec_event* out, uint32_t cap, uint32_t* n_out);
+
+/* ---------------------------------------------------------- K2: DDMin's replay oracle
+ * Replaces STSScheduler.test without peek (STSScheduler.scala:199-310) as called by DDMin.ddmin2
+ * (minification/DeltaDebugging.scala:73-109) once per candidate: the original failing execution
+ * (its external events + its recorded EventTrace, e.g. from demi_random_get_trace) is loaded once;
+ * every candidate subsequence is a 256-bit mask over the external events (bit i = event i kept;
+ * WaitQuiescence bits are ignored, RunnerUtils.scala:680-684).  limits->looking_for is the target
+ * ViolationFingerprint (limits->looking_for_valid must be 1); p_max and populate_all as in K1.
+ * Verdict: DEMI_V_VIOLATION = "the subsequence still triggers the violation" (test() returned Some),
+ * DEMI_V_DIVERGED = at least one expected delivery was absent and ignored.                      */
+int demi_replay_load(demi_ctx* ctx, const demi_ext_event* original_externals, uint32_t n_ext,
+                     const demi_rec_event* original_trace, uint32_t n_rec);
+int demi_replay_batch(demi_ctx* ctx, const uint64_t* masks /* [n][4] */, uint64_t n, const demi_limits* limits,
+                      demi_verdict* out);
+int demi_replay_batch_dev(demi_ctx* ctx, const uint64_t* d_masks, uint64_t n, const demi_limits* limits,
+                          demi_verdict* d_out, void* hip_stream);
 
 /* ---------------------------------------------------------- found-violation set
  * One entry per violating schedule (what RunnerUtils.fuzz keeps: the violating execution's

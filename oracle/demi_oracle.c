@@ -663,3 +663,250 @@ int orc_random_explore(const demi_model* m, const demi_ext_event* trace, uint32_
     for (int t = 0; t < n_threads; t++) pthread_join(th[t], NULL);
   return DEMI_OK;
 }
+
+/* ===================================================================== K2: STSScheduler replay
+ * One candidate = one STSScheduler.test (V/schedulers/STSScheduler.scala:199-310, no peek,
+ * abortUponDivergence off, filterKnownAbsents off): project the original trace onto the
+ * subsequence (EventTrace.subsequenceIntersection + filterSends, V/EventTrace.scala:290-452),
+ * walk the expected events (advanceReplay :405-559), deliver an expected MsgEvent iff a message
+ * with the same (snd, rcv, fingerprint) is pending (messagePending :381-403, oldest first
+ * :709-737), else ignore it (:528-529); at the end evaluate the invariant and match the target
+ * fingerprint (:278-300).                                                                        */
+typedef struct { uint32_t word; uint32_t seq; } sts_pend;
+
+typedef struct {
+  const demi_model* m;
+  uint64_t state[DEMI_MAX_ACTORS];
+  uint32_t exists, inaccessible, killed;
+  uint64_t partitioned;
+  sts_pend pend[PEND_HARD_CAP];   /* pendingEvents: (snd,rcv) -> fingerprint -> FIFO; seq keeps FIFO order */
+  uint32_t n_pend, p_max, next_seq;
+  uint8_t mts[DEMI_TQ_CAP][2];    /* messagesToSend timers (rcv, type) */
+  uint32_t n_mts;
+  uint32_t repeating, flags, count, ignored;
+  uint64_t hash;
+  orc_effect fx[DEMI_MAX_CODE * DEMI_MAX_ACTORS];
+} sts_t;
+
+static int sts_crosses(const sts_t* x, uint32_t snd, uint32_t rcv) {
+  if (snd == rcv && !((x->killed >> snd) & 1)) return 0;
+  int part = 0;
+  if (snd < DEMI_MAX_ACTORS && rcv < DEMI_MAX_ACTORS)
+    part = (int)(((x->partitioned >> (snd * 8 + rcv)) | (x->partitioned >> (rcv * 8 + snd))) & 1);
+  int ir = rcv < DEMI_MAX_ACTORS ? (int)((x->inaccessible >> rcv) & 1) : 0;
+  int is = snd < DEMI_MAX_ACTORS ? (int)((x->inaccessible >> snd) & 1) : 0;
+  return part || ir || is;
+}
+
+static void sts_pend_add(sts_t* x, uint32_t word) {
+  if (x->flags & OVF_ANY) return;
+  if (x->n_pend >= x->p_max) { x->flags |= DEMI_V_PENDING_OVF; return; }
+  x->pend[x->n_pend].word = word;
+  x->pend[x->n_pend].seq = x->next_seq++;
+  x->n_pend++;
+}
+
+/* oldest pending message with this (snd, rcv, fingerprint); -1 if none */
+static int sts_pend_find(const sts_t* x, uint32_t word) {
+  int best = -1;
+  for (uint32_t i = 0; i < x->n_pend; i++)
+    if (x->pend[i].word == word && (best < 0 || x->pend[i].seq < x->pend[best].seq)) best = (int)i;
+  return best;
+}
+
+static void sts_pend_remove(sts_t* x, int i) {
+  x->pend[i] = x->pend[x->n_pend - 1];
+  x->n_pend--;
+}
+
+/* STSScheduler.enqueue_timer = handle_timer (:857), no justScheduledTimers parking */
+static void sts_handle_timer(sts_t* x, uint32_t rcv, uint32_t type) {
+  if (x->flags & OVF_ANY) return;
+  if (x->n_mts >= DEMI_TQ_CAP) { x->flags |= DEMI_V_QUEUE_OVF; return; }
+  x->mts[x->n_mts][0] = (uint8_t)rcv;
+  x->mts[x->n_mts][1] = (uint8_t)type;
+  x->n_mts++;
+}
+
+/* send_external_messages for timers: internal messages from deadLetters (:583-607) */
+static void sts_flush(sts_t* x) {
+  for (uint32_t i = 0; i < x->n_mts; i++) {
+    uint32_t rcv = x->mts[i][0], type = x->mts[i][1];
+    if (!((x->inaccessible >> rcv) & 1)) sts_pend_add(x, msg_word(type, DEMI_DEADLETTERS, rcv, 0, 0));
+  }
+  x->n_mts = 0;
+}
+
+static void sts_deliver(sts_t* x, uint32_t w) {
+  const demi_model* m = x->m;
+  uint32_t me = W_DST(w);
+  x->count++;
+  hash_step(&x->hash, w);
+  /* Instrumenter retrigger of repeating timers (V/Instrumenter.scala:1008-1016), pinned before receive */
+  if (m->msg_class[W_TYPE(w)] == DEMI_MSG_TIMER && (x->repeating & timer_bit(m, me, W_TYPE(w))))
+    sts_handle_timer(x, me, W_TYPE(w));
+  int n = orc_vm_run(m, me, &x->state[me], (uint8_t)W_TYPE(w), (uint8_t)W_SRC(w), (uint8_t)W_P0(w), (uint8_t)W_P1(w),
+                     x->exists, x->fx, DEMI_MAX_CODE * DEMI_MAX_ACTORS);
+  if (n < 0) { x->flags |= DEMI_V_QUEUE_OVF; return; }
+  for (int i = 0; i < n && !(x->flags & OVF_ANY); i++) {
+    const orc_effect* e = &x->fx[i];
+    uint32_t bit = e->kind ? timer_bit(m, me, e->msg_type) : 0;
+    switch (e->kind) {
+      case 0: /* event_produced, internal (:590-607) */
+        if (!sts_crosses(x, me, e->target)) sts_pend_add(x, msg_word(e->msg_type, me, e->target, e->p0, e->p1));
+        break;
+      case 1: case 2: /* registerCancellable + handleTick (V/Instrumenter.scala:1145-1200) */
+        if (x->repeating & bit) break;
+        if (e->kind == 2) x->repeating |= bit;
+        sts_handle_timer(x, me, e->msg_type);
+        break;
+      case 3: { /* notify_timer_cancel (:828-855) */
+        x->repeating &= ~bit;
+        int found = 0;
+        for (uint32_t k = 0; k < x->n_mts; k++) {
+          if (x->mts[k][0] == me && x->mts[k][1] == e->msg_type) {
+            memmove(&x->mts[k], &x->mts[k + 1], (x->n_mts - k - 1) * 2);
+            x->n_mts--; found = 1; break;
+          }
+        }
+        if (!found) {
+          int k = sts_pend_find(x, msg_word(e->msg_type, DEMI_DEADLETTERS, me, 0, 0));
+          if (k >= 0) sts_pend_remove(x, k);
+        }
+        break;
+      }
+    }
+  }
+  sts_flush(x); /* schedule_new_message begins with send_external_messages (:655) */
+}
+
+static int ext_equal(const demi_ext_event* e, uint32_t kind, uint32_t a, uint32_t b) {
+  if (kind == DEMI_REC_SPAWN) return e->kind == DEMI_EV_START && e->a == a;
+  if (kind == DEMI_REC_KILL) return e->kind == DEMI_EV_KILL && e->a == a;
+  if (kind == DEMI_REC_PARTITION) return e->kind == DEMI_EV_PARTITION && e->a == a && e->b == b;
+  if (kind == DEMI_REC_UNPARTITION) return e->kind == DEMI_EV_UNPARTITION && e->a == a && e->b == b;
+  return 0;
+}
+
+static int sts_replay_in(sts_t* x, const demi_model* m, const demi_ext_event* ext, uint32_t n_ext,
+                         const demi_rec_event* rec, uint32_t n_rec, const uint64_t mask[4], const demi_limits* lim,
+                         demi_verdict* out, uint32_t* n_ignored) {
+  memset(x, 0, offsetof(sts_t, fx));
+  x->m = m;
+  x->p_max = lim->p_max ? lim->p_max : 64;
+  if (x->p_max > PEND_HARD_CAP) x->p_max = PEND_HARD_CAP;
+  x->hash = 0xCBF29CE484222325ULL;
+  /* populateActorSystem from the ORIGINAL trace's SpawnEvents (:231-236) */
+  for (uint32_t i = 0; i < n_rec; i++)
+    if (rec[i].kind == DEMI_REC_SPAWN) x->exists |= 1u << rec[i].rcv;
+  if (lim->populate_all) x->exists = (1u << m->n_actors) - 1;
+  x->inaccessible = x->exists;
+  for (uint32_t a = 0; a < m->n_actors; a++) x->state[a] = m->init_state[a];
+
+#define IN_MASK(i) ((mask[(i) >> 6] >> ((i) & 63)) & 1)
+  /* id -> index of the Send that enqueued it (external messages only): filterSends (:382-452) */
+  static _Thread_local uint8_t send_of_id[DEMI_MAX_REC_EVENTS * 2];
+  memset(send_of_id, 255, sizeof send_of_id);
+  for (uint32_t i = 0; i < n_rec; i++)
+    if (rec[i].kind == DEMI_REC_MSG_SEND && (rec[i].flags & 1) && rec[i].id < sizeof send_of_id)
+      send_of_id[rec[i].id] = rec[i].ext_idx;
+
+  /* cursor over the subsequence's non-Send externals (subsequenceIntersection :299-304) */
+  uint32_t cur = 0;
+#define CUR_SKIP() while (cur < n_ext && (!IN_MASK(cur) || ext[cur].kind == DEMI_EV_SEND || \
+                                          ext[cur].kind == DEMI_EV_WAIT_QUIESCENCE)) cur++
+  CUR_SKIP();
+  for (uint32_t idx = 0; idx < n_rec && !(x->flags & OVF_ANY); idx++) {
+    const demi_rec_event* e = &rec[idx];
+    switch (e->kind) {
+      case DEMI_REC_SPAWN: case DEMI_REC_KILL: case DEMI_REC_PARTITION: case DEMI_REC_UNPARTITION: {
+        /* kept iff it equals the cursor head (by name, not identity); dropped once the cursor is exhausted */
+        uint32_t a = (e->kind <= DEMI_REC_KILL) ? e->rcv : e->snd, b = e->rcv;
+        if (cur >= n_ext || !ext_equal(&ext[cur], e->kind, a, b)) break;
+        cur++;
+        CUR_SKIP();
+        if (e->kind == DEMI_REC_SPAWN) { x->inaccessible &= ~(1u << a); x->killed &= ~(1u << a); }
+        else if (e->kind == DEMI_REC_KILL) { x->killed |= 1u << a; x->inaccessible |= 1u << a; }
+        else if (e->kind == DEMI_REC_PARTITION) x->partitioned |= 1ULL << (a * 8 + b);
+        else x->partitioned &= ~(1ULL << (a * 8 + b));
+        break;
+      }
+      case DEMI_REC_MSG_SEND:
+        /* external MsgSend: enqueue_message (:509-511) unless its Send was pruned; internal: nothing */
+        if ((e->flags & 1) && IN_MASK(e->ext_idx) && ((x->exists >> e->rcv) & 1))
+          sts_pend_add(x, msg_word(e->msg_type, DEMI_DEADLETTERS, e->rcv, e->p0, e->p1));
+        break;
+      case DEMI_REC_MSG_EVENT: {
+        uint8_t s = e->id < sizeof send_of_id ? send_of_id[e->id] : 255;
+        if (s != 255 && !IN_MASK(s)) break; /* pruned together with its Send */
+        uint32_t w = msg_word(e->msg_type, e->snd, e->rcv, e->p0, e->p1);
+        int k = sts_pend_find(x, w);
+        if (k < 0) { x->ignored++; break; } /* "Ignoring message" (:528-529) */
+        sts_pend_remove(x, k);
+        sts_deliver(x, w);
+        break;
+      }
+      default: break; /* Quiescence, BeginWaitQuiescence: nop */
+    }
+  }
+#undef CUR_SKIP
+#undef IN_MASK
+  uint32_t viol = 0;
+  if (!(x->flags & OVF_ANY)) {
+    uint32_t fp = orc_invariant(m, x->state, x->exists);
+    if (fp && ((fp ^ lim->looking_for) & m->fp_match_mask) == 0) viol = lim->looking_for;
+  }
+  for (uint32_t a = 0; a < m->n_actors; a++) hash_step(&x->hash, x->state[a]);
+  if (x->flags & OVF_ANY) {
+    out->flags = x->flags & OVF_ANY; out->fingerprint = 0; out->hash = 0;
+  } else {
+    out->flags = (viol ? DEMI_V_VIOLATION : 0) | (x->ignored ? DEMI_V_DIVERGED : 0) | ((x->count & 0xFFFF) << 16);
+    out->fingerprint = viol;
+    out->hash = x->hash;
+  }
+  if (n_ignored) *n_ignored = x->ignored;
+  return DEMI_OK;
+}
+
+int orc_sts_replay(const demi_model* m, const demi_ext_event* ext, uint32_t n_ext, const demi_rec_event* rec,
+                   uint32_t n_rec, const uint64_t mask[4], const demi_limits* lim, demi_verdict* out,
+                   uint32_t* n_ignored) {
+  sts_t* x = (sts_t*)malloc(sizeof(sts_t));
+  if (!x) return DEMI_ERR_INVALID_ARG;
+  int rc = sts_replay_in(x, m, ext, n_ext, rec, n_rec, mask, lim, out, n_ignored);
+  free(x);
+  return rc;
+}
+
+typedef struct {
+  const demi_model* m; const demi_ext_event* ext; uint32_t n_ext; const demi_rec_event* rec; uint32_t n_rec;
+  const uint64_t* masks; uint64_t lo, hi; const demi_limits* lim; demi_verdict* out;
+} sts_job_t;
+
+static void* sts_job_main(void* p) {
+  sts_job_t* j = (sts_job_t*)p;
+  sts_t* x = (sts_t*)malloc(sizeof(sts_t));
+  if (!x) return NULL;
+  for (uint64_t i = j->lo; i < j->hi; i++)
+    sts_replay_in(x, j->m, j->ext, j->n_ext, j->rec, j->n_rec, &j->masks[4 * i], j->lim, &j->out[i], NULL);
+  free(x);
+  return NULL;
+}
+
+int orc_sts_replay_batch(const demi_model* m, const demi_ext_event* ext, uint32_t n_ext, const demi_rec_event* rec,
+                         uint32_t n_rec, const uint64_t* masks, uint64_t n, const demi_limits* lim, demi_verdict* out,
+                         int n_threads) {
+  if (n_threads < 1) n_threads = 1;
+  if (n_threads > 256) n_threads = 256;
+  pthread_t th[256];
+  sts_job_t jobs[256];
+  for (int t = 0; t < n_threads; t++) {
+    jobs[t] = (sts_job_t){m, ext, n_ext, rec, n_rec, masks, n * (uint64_t)t / (uint64_t)n_threads,
+                          n * (uint64_t)(t + 1) / (uint64_t)n_threads, lim, out};
+    if (n_threads == 1) sts_job_main(&jobs[t]);
+    else pthread_create(&th[t], NULL, sts_job_main, &jobs[t]);
+  }
+  if (n_threads > 1)
+    for (int t = 0; t < n_threads; t++) pthread_join(th[t], NULL);
+  return DEMI_OK;
+}

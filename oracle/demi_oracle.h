@@ -55,6 +55,17 @@ int orc_random_explore(const demi_model* m, const demi_ext_event* trace, uint32_
                        const uint64_t* seeds, uint64_t n, const demi_limits* lim, demi_verdict* out,
                        int n_threads);
 
+/* ---- K2: DDMin's replay oracle, STSScheduler.test without peek (V/schedulers/STSScheduler.scala:199-310).
+ * original_ext/original_rec: the externals and the recorded EventTrace of the failing execution.
+ * mask: bit i set = external event i is in the candidate subsequence (WaitQuiescence bits are ignored:
+ * RunnerUtils.stsSchedDDMin strips them, V/RunnerUtils.scala:680-684).  lim->looking_for is the target. */
+int orc_sts_replay(const demi_model* m, const demi_ext_event* original_ext, uint32_t n_ext,
+                   const demi_rec_event* original_rec, uint32_t n_rec, const uint64_t mask[4],
+                   const demi_limits* lim, demi_verdict* out, uint32_t* n_ignored);
+int orc_sts_replay_batch(const demi_model* m, const demi_ext_event* original_ext, uint32_t n_ext,
+                         const demi_rec_event* original_rec, uint32_t n_rec, const uint64_t* masks, uint64_t n,
+                         const demi_limits* lim, demi_verdict* out, int n_threads);
+
 #ifdef __cplusplus
 }
 #endif

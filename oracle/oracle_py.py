@@ -42,6 +42,8 @@ def lib():
                                          C.c_void_p, C.c_uint64, C.POINTER(T.Limits), C.c_void_p, C.c_int]
         L.orc_vm_run.argtypes = [C.POINTER(T.ModelStruct), C.c_uint32, C.POINTER(C.c_uint64), C.c_uint8, C.c_uint8,
                                  C.c_uint8, C.c_uint8, C.c_uint32, C.c_void_p, C.c_uint32]
+        L.orc_sts_replay_batch.argtypes = [C.POINTER(T.ModelStruct), C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
+                                           C.c_void_p, C.c_uint64, C.POINTER(T.Limits), C.c_void_p, C.c_int]
         _LIB = L
     return _LIB
 
@@ -103,3 +105,16 @@ def random_execute(model, events, seed, limits, record=True):
                                   states.ctypes.data)
     assert rc == 0
     return v, rec[:min(n_rec.value, len(rec))].copy(), states
+
+
+def sts_replay_batch(model, original_externals, original_trace, masks, limits, n_threads=1):
+    """STSScheduler.test (no peek) for every candidate mask (uint64[n, 4]); VERDICT_DTYPE array."""
+    ms = model.to_struct()
+    ev = np.ascontiguousarray(original_externals, dtype=T.EXT_EVENT_DTYPE)
+    rec = np.ascontiguousarray(original_trace, dtype=T.REC_EVENT_DTYPE)
+    masks = np.ascontiguousarray(masks, dtype=np.uint64).reshape(-1, 4)
+    out = np.zeros(len(masks), dtype=T.VERDICT_DTYPE)
+    rc = lib().orc_sts_replay_batch(C.byref(ms), ev.ctypes.data, len(ev), rec.ctypes.data, len(rec),
+                                    masks.ctypes.data, len(masks), C.byref(limits), out.ctypes.data, n_threads)
+    assert rc == 0
+    return out

@@ -1,0 +1,141 @@
+"""GPU parity suite for K2 (STSScheduler replay of candidate subsequences) and DDMin end to end."""
+import os
+
+import numpy as np
+import pytest
+
+from demi_amd import types as T
+from demi_amd import model as M
+from demi_amd.apps import SEED_BASE, raft5_config2, raft5_config4
+from demi_amd.fuzzer import FuzzerWeights, events_to_array, raft_trace
+from demi_amd.minification import (DDMin, EventDagView, SpeculativeDDMin, UnmodifiedEventDag, events_to_mask, stsSchedDDMin)
+from demi_amd.schedulers import EventTrace, MinimizationStats, STSScheduler, SchedulerConfig, ViolationFingerprint
+
+pytestmark = pytest.mark.gpu
+
+
+def record(gpu_ctx, model, events, lim, want_violation=True, skip=0, n=4000):
+    gpu_ctx.model_load(model.to_struct())
+    gpu_ctx.trace_load(events)
+    v = gpu_ctx.random_explore(n, lim, seed_base=SEED_BASE)
+    hits = np.nonzero(v["flags"] & T.V_VIOLATION)[0] if want_violation else np.arange(n)
+    i = int(hits[skip])
+    vv, rec = gpu_ctx.random_get_trace(SEED_BASE + i, lim)
+    return vv, rec, events[:T.verdict_trace_idx(vv.flags)]
+
+
+def random_masks(rng, n_ext, n):
+    masks = np.zeros((n, 4), dtype=np.uint64)
+    for r in range(n):
+        p = rng.choice([0.1, 0.5, 0.8, 0.95])
+        keep = np.nonzero(rng.random(n_ext) < p)[0]
+        if r == 0:
+            keep = np.arange(n_ext)
+        if r == 1:
+            keep = np.arange(0)
+        masks[r] = events_to_mask(keep)
+    return masks
+
+
+def assert_same(g, c):
+    if not (g == c).all():
+        bad = np.nonzero(g != c)[0]
+        raise AssertionError("%d of %d verdicts differ; first at %d: gpu=%s cpu=%s" % (len(bad), len(g), bad[0], g[bad[0]], c[bad[0]]))
+
+
+def test_replay_parity_random_subsequences_raft5(gpu_ctx, oracle):
+    model, events, lim = raft5_config2()
+    rng = np.random.default_rng(2)
+    for skip in range(4):
+        vv, rec, used = record(gpu_ctx, model, events, lim, skip=skip)
+        masks = random_masks(rng, len(used), 3000)
+        target = T.Limits(0, 0, 64, 1, vv.fingerprint, 0)
+        gpu_ctx.replay_load(used, rec)
+        g = gpu_ctx.replay_batch(masks, target)
+        c = oracle.sts_replay_batch(model, used, rec, masks, target, n_threads=os.cpu_count())
+        assert_same(g, c)
+        # the unmodified trace replays the recorded schedule exactly
+        assert g[0]["flags"] & T.V_VIOLATION and not g[0]["flags"] & T.V_DIVERGED and int(g[0]["hash"]) == vv.hash
+        assert T.verdict_deliveries(int(g[1]["flags"])) == 0
+        assert (g["flags"] & T.V_VIOLATION).sum() > 1 and (g["flags"] & T.V_DIVERGED).sum() > 100
+
+
+def test_replay_parity_fault_heavy_traces_and_capacities(gpu_ctx, oracle):
+    """Kills / partitions (paired atoms, name-based Spawn/Kill matching), non-violating originals,
+    small pending capacity (overflow verdicts), populate_all."""
+    model = M.raft_model(5, election_budget=2)
+    w = FuzzerWeights(kill=0.12, send=0.35, wait_quiescence=0.13, partition=0.25, unpartition=0.15)
+    rng = np.random.default_rng(3)
+    for seed in (1, 2, 3, 4):
+        events = events_to_array(raft_trace(5, 90, seed, w, exact=False))
+        lim = T.Limits(400, 10, 128, 0, 0, 0)
+        vv, rec, used = record(gpu_ctx, model, events, lim, want_violation=False, skip=seed, n=64)
+        masks = random_masks(rng, len(used), 1500)
+        for p_max, pa in ((128, 0), (16, 0), (64, 1)):
+            target = T.Limits(0, 0, p_max, 1, vv.fingerprint if vv.fingerprint else 0x1000103, pa)
+            gpu_ctx.replay_load(used, rec)
+            g = gpu_ctx.replay_batch(masks, target)
+            c = oracle.sts_replay_batch(model, used, rec, masks, target, n_threads=os.cpu_count())
+            assert_same(g, c)
+            if p_max == 16:
+                assert (g["flags"] & T.V_PENDING_OVF).any()
+
+
+def test_replay_api_errors(gpu_ctx):
+    from demi_amd._native import DemiError
+    model, events, lim = raft5_config2()
+    gpu_ctx.model_load(model.to_struct())          # resets any loaded replay
+    with pytest.raises(DemiError) as e:
+        gpu_ctx.replay_batch(np.zeros((1, 4), dtype=np.uint64), T.Limits(0, 0, 64, 1, 5, 0))
+    assert e.value.code == T.ERR_NO_TRACE
+    vv, rec, used = record(gpu_ctx, model, events, lim)
+    gpu_ctx.replay_load(used, rec)
+    with pytest.raises(DemiError) as e:
+        gpu_ctx.replay_batch(np.zeros((1, 4), dtype=np.uint64), T.Limits(0, 0, 64, 0, 0, 0))   # no target fingerprint
+    assert e.value.code == T.ERR_INVALID_ARG
+    bad = rec.copy()
+    bad[0]["kind"] = 99
+    with pytest.raises(DemiError) as e:
+        gpu_ctx.replay_load(used, bad)
+    assert e.value.code == T.ERR_INVALID_TRACE
+
+
+def test_ddmin_end_to_end_matches_the_oracle_backed_run(gpu_ctx, oracle):
+    from tests.test_minification_cpu import OracleSTS
+    model, events, lim = raft5_config2()
+    for skip in (0, 3):
+        vv, rec, used = record(gpu_ctx, model, events, lim, skip=skip)
+        fp = ViolationFingerprint(vv.fingerprint)
+        sts = STSScheduler(SchedulerConfig(model=model), EventTrace(rec, used))
+        stats = MinimizationStats()
+        mcs_g, d_g, ver_g = stsSchedDDMin(sts, used, fp, speculative_depth=3, stats=stats)
+        mcs_s, d_s, _ = stsSchedDDMin(sts, used, fp, speculative_depth=0)
+        mcs_c, d_c, ver_c = stsSchedDDMin(OracleSTS(oracle, model, used, rec, vv.fingerprint), used, fp, speculative_depth=0)
+        assert mcs_g == mcs_s == mcs_c and d_g.consulted == d_s.consulted == d_c.consulted
+        assert ver_g is not None and stats.total_replays == len(d_c.consulted)
+        assert len(d_g.batches) < len(d_c.consulted)          # fewer launches than sequential oracle calls
+        sts.shutdown()
+
+
+def test_config4_ddmin_200_external_events(gpu_ctx, oracle):
+    """BASELINE config 4 (single GPU leg): 200 external events, DDMin over the STSSched oracle with a
+    speculative frontier; every consulted verdict is checked against the oracle."""
+    model, events, lim = raft5_config4()
+    assert len(events) == 200
+    vv, rec, used = record(gpu_ctx, model, events, lim, n=4000)
+    assert len(used) == 200 and len(rec) <= T.MAX_REC_EVENTS
+    fp = ViolationFingerprint(vv.fingerprint)
+    sts = STSScheduler(SchedulerConfig(model=model), EventTrace(rec, used), p_max=128)
+    mcs, d, ver = stsSchedDDMin(sts, used, fp, speculative_depth=4)
+    assert ver is not None and len(mcs) < len(used) // 4
+    cands = [c for c, _ in d.consulted]
+    masks = np.array([events_to_mask(c) for c in cands], dtype=np.uint64).reshape(-1, 4)
+    c = oracle.sts_replay_batch(model, used, rec, masks, T.Limits(0, 0, 128, 1, vv.fingerprint, 0), n_threads=os.cpu_count())
+    assert [not bool(f & T.V_VIOLATION) for f in c["flags"]] == [p for _, p in d.consulted]
+    # 1-minimality over atoms (what ddmin guarantees): dropping any one atom of the MCS stops reproducing
+    dag = UnmodifiedEventDag(used)
+    atoms = EventDagView(dag, mcs).get_atomic_events()
+    singles = [tuple(e for e in mcs if e not in a) for a in atoms]
+    res = sts.test_batch([s for s in singles if s], fp)
+    assert not any(res)
+    sts.shutdown()

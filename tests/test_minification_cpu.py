@@ -1,0 +1,213 @@
+"""CPU suite, part 3: delta debugging host logic (EventDag atoms, split_list, ddmin2, speculation)
+and the STS replay restatement in the oracle."""
+import itertools
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from demi_amd import types as T
+from demi_amd import model as M
+from demi_amd.apps import SEED_BASE, raft5_config2
+from demi_amd.fuzzer import (events_to_array, kill, partition, send, start, unpartition, wait_quiescence)
+from demi_amd.minification import (DDMin, EventDagView, SpeculativeDDMin, UnmodifiedEventDag, events_to_mask, split_list,
+                                   stsSchedDDMin)
+from demi_amd.schedulers import MinimizationStats, ViolationFingerprint
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_split_list_matches_reference_chunking():
+    assert split_list(list(range(5)), 2) == [[0, 1, 2], [3, 4]]
+    assert split_list(list(range(4)), 2) == [[0, 1], [2, 3]]
+    assert split_list([7], 2) == [[7], []]
+    assert split_list(list(range(7)), 3) == [[0, 1, 2], [3, 4], [5, 6]]
+    with pytest.raises(ValueError):
+        split_list([1], 0)
+
+
+def test_atoms_pair_kill_with_start_and_unpartition_with_partition():
+    ev = events_to_array([start(0), start(1), send(0, M.M_BOOTSTRAP), partition(0, 1), kill(1), send(0, M.M_CLIENT, 1),
+                          unpartition(0, 1), start(1), partition(1, 0), wait_quiescence()])
+    dag = UnmodifiedEventDag(ev)
+    assert dag.get_atomic_events() == [(0,), (1, 4), (2,), (3, 6), (5,), (7,), (8,), (9,)]
+    view = dag.remove_events([(1, 4), (5,)])
+    assert view.get_all_events() == (0, 2, 3, 6, 7, 8, 9)
+    assert view.get_atomic_events() == [(0,), (2,), (3, 6), (7,), (8,), (9,)]
+    u = view.remove_events([(3, 6)]).union(EventDagView(dag, (3, 6)))
+    assert u.get_all_events() == view.get_all_events()      # union re-sorts by original index
+    with pytest.raises(RuntimeError):
+        UnmodifiedEventDag(events_to_array([kill(0)])).get_atomic_events()
+    with pytest.raises(RuntimeError):
+        UnmodifiedEventDag(events_to_array([unpartition(0, 1)])).get_atomic_events()
+    with pytest.raises(AssertionError):      # two Starts of one actor without a Kill: the reference's assume() fails
+        UnmodifiedEventDag(events_to_array([start(0), start(0)])).get_atomic_events()
+    explicit = UnmodifiedEventDag(events_to_array([start(0), send(0, M.M_BOOTSTRAP), send(0, M.M_CLIENT)]))
+    explicit.conjoinAtoms(1, 2)
+    assert explicit.get_atomic_events() == [(0,), (1, 2)]
+
+
+class SetOracle:
+    """Fails (reproduces) iff the candidate contains every index of one of the `cores`."""
+
+    def __init__(self, cores):
+        self.cores = [set(c) for c in cores]
+        self.calls = 0
+
+    def _rep(self, sub):
+        return any(c <= set(sub) for c in self.cores)
+
+    def test(self, sub, fp, stats):
+        self.calls += 1
+        if stats is not None:
+            stats.increment_replays()
+        return True if self._rep(sub) else None
+
+    def test_batch(self, subs, fp, stats):
+        return [self._rep(s) for s in subs]
+
+    def getName(self):
+        return "SetOracle"
+
+
+@pytest.mark.parametrize("cores", [[{3}], [{0, 9}], [{2, 5, 11}], [{1, 2}, {7}], [{0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11}], [{4, 6}, {4, 7}]])
+@pytest.mark.parametrize("depth", [1, 2, 4])
+def test_speculative_ddmin_equals_sequential(cores, depth):
+    ev = events_to_array([send(0, M.M_CLIENT, i) for i in range(12)])
+    fp = ViolationFingerprint(1)
+    d1 = DDMin(SetOracle(cores))
+    m1 = d1.minimize(UnmodifiedEventDag(ev), fp)
+    d2 = SpeculativeDDMin(SetOracle(cores), depth=depth)
+    m2 = d2.minimize(UnmodifiedEventDag(ev), fp)
+    assert m1.get_all_events() == m2.get_all_events()
+    assert d1.consulted == d2.consulted                    # same verdict consulted at every step
+    assert d1._stats.total_replays == d2._stats.total_replays == len(d1.consulted)
+    assert d2.speculative_replays >= len({c for c, _ in d2.consulted})
+    assert len(d2.batches) <= len(d1.consulted)
+    # ddmin's result is 1-minimal: removing any single atom no longer reproduces
+    mcs = set(m1.get_all_events())
+    assert SetOracle(cores)._rep(mcs)
+    for e in mcs:
+        assert not SetOracle(cores)._rep(mcs - {e})
+    # the reference's accounting assert
+    assert d1.original_num_events - d1.total_inputs_pruned == m1.length
+
+
+def _violating_execution(oracle, model, events, lim, skip=0):
+    v = oracle.random_explore(model, events, 4000, seed_base=SEED_BASE, limits=lim, n_threads=4)
+    i = int(np.nonzero(v["flags"] & T.V_VIOLATION)[0][skip])
+    vv, rec, _ = oracle.random_execute(model, events, SEED_BASE + i, lim)
+    return vv, rec, events[:T.verdict_trace_idx(vv.flags)]
+
+
+class OracleSTS:
+    def __init__(self, oracle, model, used, rec, fp):
+        self.o, self.model, self.used, self.rec, self.fp = oracle, model, used, rec, fp
+
+    def _v(self, subs):
+        masks = np.array([events_to_mask(s) for s in subs], dtype=np.uint64).reshape(-1, 4)
+        return self.o.sts_replay_batch(self.model, self.used, self.rec, masks, T.Limits(0, 0, 64, 1, self.fp, 0))
+
+    def test(self, sub, fp, stats):
+        if stats is not None:
+            stats.increment_replays()
+        r = self._v([sub])[0]
+        return r if r["flags"] & T.V_VIOLATION else None
+
+    def test_batch(self, subs, fp, stats):
+        return [bool(f & T.V_VIOLATION) for f in self._v(subs)["flags"]]
+
+
+def test_sts_replay_of_the_unmodified_trace_reproduces_the_execution(oracle):
+    """Replaying ALL externals follows the recorded schedule exactly: nothing is ignored, the same
+    messages are delivered in the same order (equal delivery hash), the violation reappears."""
+    model, events, lim = raft5_config2()
+    for skip in range(5):
+        vv, rec, used = _violating_execution(oracle, model, events, lim, skip)
+        full = np.array([events_to_mask(range(len(used)))], dtype=np.uint64)
+        r = oracle.sts_replay_batch(model, used, rec, full, T.Limits(0, 0, 64, 1, vv.fingerprint, 0))[0]
+        assert r["flags"] & T.V_VIOLATION and not (r["flags"] & T.V_DIVERGED)
+        assert T.verdict_deliveries(int(r["flags"])) == T.verdict_deliveries(vv.flags)
+        assert int(r["hash"]) == vv.hash and int(r["fingerprint"]) == vv.fingerprint
+        # the empty subsequence delivers nothing; a wrong target never matches
+        none = oracle.sts_replay_batch(model, used, rec, np.zeros((1, 4), dtype=np.uint64), T.Limits(0, 0, 64, 1, vv.fingerprint, 0))[0]
+        assert T.verdict_deliveries(int(none["flags"])) == 0 and not (none["flags"] & T.V_VIOLATION)
+        wrong = oracle.sts_replay_batch(model, used, rec, full, T.Limits(0, 0, 64, 1, vv.fingerprint ^ 0x100, 0))[0]
+        assert not (wrong["flags"] & T.V_VIOLATION)
+
+
+def test_sts_projection_rules(oracle):
+    """Pruned Sends drop their MsgSend and MsgEvent; pruned Starts leave the actor isolated; absent
+    deliveries are ignored; name-based matching of Spawn/Kill against the cursor head."""
+    MSGS = [("Kick", T.MSG_EXTERNAL), ("Ping", T.MSG_INTERNAL)]
+    h = {(0, "Kick"): M.Asm().add(M.F[0], M.F[0], 1).mov(M.T0, 1).if_eq(M.ME, 0, "x").send(1, M.T0, M.T1, 0).label("x"),
+         (0, "Ping"): M.Asm().add(M.F[1], M.F[1], 1)}
+    model = M.build_model("p", 2, MSGS, h, [[0] * 8] * 2, (T.INV_NEVER, 1, 3, 0))    # violation: actor 1 saw 3 Pings
+    ev = events_to_array([start(0), start(1), send(0, 0, 1), send(0, 0, 2), wait_quiescence(), kill(1), start(1), send(0, 0, 3)])
+    lim = T.Limits(0, 0, 64, 0, 0, 0)
+    vv, rec, st = oracle.random_execute(model, ev, 5, lim)
+    assert vv.flags & T.V_VIOLATION
+    target = T.Limits(0, 0, 64, 1, vv.fingerprint, 0)
+
+    def run(keep):
+        return oracle.sts_replay_batch(model, ev, rec, np.array([events_to_mask(keep)], dtype=np.uint64), target)[0]
+
+    full = run(range(8))
+    assert full["flags"] & T.V_VIOLATION and not full["flags"] & T.V_DIVERGED and T.verdict_deliveries(int(full["flags"])) == 6
+    # drop one Kick: its delivery and its Ping disappear (the Ping's expected delivery is ignored)
+    r = run([0, 1, 2, 4, 5, 6, 7])
+    assert T.verdict_deliveries(int(r["flags"])) == 4 and r["flags"] & T.V_DIVERGED
+    # drop the first Start(1) and, as its atom, Kill(1): the later Start(1) is matched BY NAME against the
+    # first recorded SpawnEvent of actor 1 (EventTrace.scala:345-354), so actor 1 is up from the beginning,
+    # every Ping arrives and the violation is reproduced
+    r = run([0, 2, 3, 4, 6, 7])
+    assert T.verdict_deliveries(int(r["flags"])) == 6 and r["flags"] & T.V_VIOLATION
+    # without any Start(1) the actor stays isolated: every Ping is dropped at send time
+    r = run([0, 2, 3, 4, 7])
+    assert T.verdict_deliveries(int(r["flags"])) == 3 and not r["flags"] & T.V_VIOLATION and r["flags"] & T.V_DIVERGED
+
+
+def test_ddmin_over_the_sts_oracle_raft(oracle):
+    model, events, lim = raft5_config2()
+    vv, rec, used = _violating_execution(oracle, model, events, lim)
+    fp = ViolationFingerprint(vv.fingerprint)
+    sts = OracleSTS(oracle, model, used, rec, vv.fingerprint)
+    mcs1, d1, ver1 = stsSchedDDMin(sts, used, fp, speculative_depth=0)
+    mcs2, d2, ver2 = stsSchedDDMin(sts, used, fp, speculative_depth=3)
+    assert mcs1 == mcs2 and d1.consulted == d2.consulted and ver1 is not None and ver2 is not None
+    assert len(mcs1) < len(used)
+    assert all(int(used[i]["kind"]) != T.EV_WAIT_QUIESCENCE for i in mcs1)
+
+
+_GLOO_WORKER = r'''
+import os, sys
+import torch.distributed as dist
+sys.path.insert(0, %(root)r)
+from demi_amd.distributed import sharded_map
+rank = int(os.environ["RANK"])
+dist.init_process_group("gloo")
+calls = []
+def fn(part):
+    calls.append(list(part))
+    return [x %% 3 == 0 for x in part]
+for n in (0, 1, 2, 7, 64):
+    items = list(range(n))
+    out = sharded_map(items, fn)
+    assert out == [x %% 3 == 0 for x in items], (n, out)
+assert all(all(x %% 2 == rank for x in c) for c in calls)      # each rank only evaluated its own share
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_sharded_frontier_evaluation_gloo_world2(tmp_path):
+    script = tmp_path / "w.py"
+    script.write_text(_GLOO_WORKER % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0 and "ok" in o, o
