@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libdemi_gpu.so")
 
 EXPORTS = ["demi_ctx_create", "demi_ctx_destroy", "demi_last_error", "demi_version", "demi_model_load",
            "demi_trace_load", "demi_random_explore", "demi_random_explore_dev", "demi_random_get_trace", "demi_collect_violations_dev",
-           "demi_replay_load", "demi_replay_batch", "demi_replay_batch_dev"]
+           "demi_replay_load", "demi_replay_batch", "demi_replay_batch_dev", "demi_dpor_load", "demi_dpor_batch"]
 
 _lib = None
 
@@ -57,6 +57,9 @@ def lib():
     L.demi_replay_load.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
     L.demi_replay_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(T.Limits), C.c_void_p]
     L.demi_replay_batch_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(T.Limits), C.c_void_p, C.c_void_p]
+    L.demi_dpor_load.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+    L.demi_dpor_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.POINTER(T.DporParams),
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     _lib = L
     return L
 
@@ -129,6 +132,33 @@ class Context:
         self._check(lib().demi_replay_batch(self._h, masks.ctypes.data if len(masks) else None, len(masks),
                                             C.byref(limits), out.ctypes.data if len(masks) else None))
         return out
+
+    def dpor_load(self, externals):
+        import numpy as np
+        ev = np.ascontiguousarray(externals, dtype=T.EXT_EVENT_DTYPE)
+        self._check(lib().demi_dpor_load(self._h, ev.ctypes.data if len(ev) else None, len(ev)))
+
+    def dpor_batch(self, prefixes, params):
+        """prefixes: list of DPOR_TRACE_DTYPE arrays (nextTrace of each interleaving).  Returns
+        (verdicts, [trace arrays], [pair arrays])."""
+        import numpy as np
+        n = len(prefixes)
+        stride = max([len(p) for p in prefixes] + [1])
+        pf = np.zeros((n, stride), dtype=T.DPOR_TRACE_DTYPE)
+        pl = np.zeros(n, dtype=np.uint32)
+        for i, p in enumerate(prefixes):
+            pf[i, :len(p)] = p
+            pl[i] = len(p)
+        verdicts = np.zeros(n, dtype=T.VERDICT_DTYPE)
+        traces = np.zeros((n, T.DPOR_MAX_TRACE), dtype=T.DPOR_TRACE_DTYPE)
+        tl = np.zeros(n, dtype=np.uint32)
+        pairs = np.zeros((n, max(1, params.max_pairs)), dtype=T.DPOR_PAIR_DTYPE)
+        npairs = np.zeros(n, dtype=np.uint32)
+        if n:
+            self._check(lib().demi_dpor_batch(self._h, pf.ctypes.data, pl.ctypes.data, stride, n, C.byref(params),
+                                              verdicts.ctypes.data, traces.ctypes.data, tl.ctypes.data,
+                                              pairs.ctypes.data, npairs.ctypes.data))
+        return verdicts, [traces[i, :tl[i]].copy() for i in range(n)], [pairs[i, :npairs[i]].copy() for i in range(n)]
 
     def random_get_trace(self, seed, limits):
         import numpy as np

@@ -39,3 +39,13 @@ def raft5_config4(n_events=200):
     events = events_to_array(raft_trace(5, n_events, TRACE_SEED + 4))
     limits = T.Limits(4000, 0, 128, 0, 0, 0)
     return model, events, limits
+
+
+def raft5_config3(n_sends=5):
+    """BASELINE config 3: DPORwHeuristics, depth_bound 30, Start x 5 + Send x k (DPOR supports only
+    Start / Send / WaitQuiescence), stopIfViolationFound=false, trackHistory=true."""
+    from .fuzzer import send, start
+    from .model import M_BOOTSTRAP
+    model = raft_model(5)
+    events = events_to_array([start(a) for a in range(5)] + [send(a % 5, M_BOOTSTRAP) for a in range(n_sends)])
+    return model, events, 30

@@ -13,6 +13,7 @@
 #include "../../include/demi_gpu.h"
 #include "k1_random_explore.hpp"
 #include "k2_replay.hpp"
+#include "k3_dpor.hpp"
 #include "k_collect.hpp"
 
 using namespace demi;
@@ -49,6 +50,12 @@ struct demi_ctx {
   uint32_t replay_spawned = 0;      // actors with a SpawnEvent in the original trace
   uint64_t* d_masks = nullptr;
   size_t masks_cap = 0;
+  // K3 (DPOR)
+  bool have_dpor = false;
+  uint64_t* d_dext = nullptr;
+  uint32_t n_dext = 0;
+  void* d_dpor = nullptr;           // one arena for a batch's inputs and outputs
+  size_t dpor_bytes = 0;
 };
 
 static int fail(demi_ctx* ctx, int code, const char* fmt, ...) {
@@ -109,6 +116,8 @@ extern "C" void demi_ctx_destroy(demi_ctx* ctx) {
   if (ctx->d_rext) (void)hipFree(ctx->d_rext);
   if (ctx->d_expected) (void)hipFree(ctx->d_expected);
   if (ctx->d_masks) (void)hipFree(ctx->d_masks);
+  if (ctx->d_dext) (void)hipFree(ctx->d_dext);
+  if (ctx->d_dpor) (void)hipFree(ctx->d_dpor);
   delete ctx;
 }
 
@@ -213,6 +222,7 @@ extern "C" int demi_model_load(demi_ctx* ctx, const demi_model* m) {
   ctx->have_model = true;
   ctx->have_trace = false;  // a trace is validated against the model it was loaded after
   ctx->have_replay = false;
+  ctx->have_dpor = false;
   return DEMI_OK;
 }
 
@@ -260,6 +270,8 @@ static int launch_k1(demi_ctx* ctx, uint32_t p_max, K1Args a, hipStream_t stream
   if (ctx->d_rext) (void)hipFree(ctx->d_rext);
   if (ctx->d_expected) (void)hipFree(ctx->d_expected);
   if (ctx->d_masks) (void)hipFree(ctx->d_masks);
+  if (ctx->d_dext) (void)hipFree(ctx->d_dext);
+  if (ctx->d_dpor) (void)hipFree(ctx->d_dpor);
     ctx->d_spill = nullptr; ctx->spill_bytes = 0;
     HIP_TRY(ctx, hipMalloc(&ctx->d_spill, need));
     ctx->spill_bytes = need;
@@ -509,6 +521,8 @@ extern "C" int demi_replay_batch(demi_ctx* ctx, const uint64_t* masks, uint64_t 
   }
   if (ctx->masks_cap < n) {
     if (ctx->d_masks) (void)hipFree(ctx->d_masks);
+  if (ctx->d_dext) (void)hipFree(ctx->d_dext);
+  if (ctx->d_dpor) (void)hipFree(ctx->d_dpor);
     ctx->d_masks = nullptr; ctx->masks_cap = 0;
     HIP_TRY(ctx, hipMalloc(&ctx->d_masks, sizeof(uint64_t) * 4 * n));
     ctx->masks_cap = n;
@@ -518,5 +532,96 @@ extern "C" int demi_replay_batch(demi_ctx* ctx, const uint64_t* masks, uint64_t 
   if (rc) return rc;
   HIP_TRY(ctx, hipDeviceSynchronize());
   HIP_TRY(ctx, hipMemcpy(out, ctx->d_out, sizeof(demi_verdict) * n, hipMemcpyDeviceToHost));
+  return DEMI_OK;
+}
+
+// ----------------------------------------------------------------------------- K3: DPOR
+extern "C" int demi_dpor_load(demi_ctx* ctx, const demi_ext_event* ext, uint32_t n_ext) {
+  if (!ctx) return DEMI_ERR_INVALID_ARG;
+  if (!ctx->have_model) return fail(ctx, DEMI_ERR_NO_MODEL, "demi_model_load must precede demi_dpor_load");
+  if (!ext && n_ext) return fail(ctx, DEMI_ERR_INVALID_ARG, "null pointer");
+  int rc = validate_trace(ctx, ctx->hmodel, ext, n_ext);
+  if (rc) return rc;
+  for (uint32_t i = 0; i < n_ext; i++)
+    if (ext[i].kind != DEMI_EV_START && ext[i].kind != DEMI_EV_SEND && ext[i].kind != DEMI_EV_WAIT_QUIESCENCE)
+      return fail(ctx, DEMI_ERR_INVALID_TRACE, "event %u: unsuported external event for DPOR", i);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (!ctx->d_dext) HIP_TRY(ctx, hipMalloc(&ctx->d_dext, sizeof(uint64_t) * (DEMI_MAX_EXT_EVENTS + 1)));
+  if (n_ext) HIP_TRY(ctx, hipMemcpy(ctx->d_dext, ext, sizeof(demi_ext_event) * n_ext, hipMemcpyHostToDevice));
+  ctx->n_dext = n_ext;
+  ctx->have_dpor = true;
+  return DEMI_OK;
+}
+
+extern "C" int demi_dpor_batch(demi_ctx* ctx, const demi_dpor_trace_entry* prefixes, const uint32_t* prefix_len,
+                               uint32_t stride, uint64_t n, const demi_dpor_params* par, demi_verdict* out_verdicts,
+                               demi_dpor_trace_entry* out_traces, uint32_t* out_trace_len, demi_dpor_pair* out_pairs,
+                               uint32_t* out_n_pairs) {
+  if (!ctx) return DEMI_ERR_INVALID_ARG;
+  if (n == 0) return DEMI_OK;
+  if (!ctx->have_model) return fail(ctx, DEMI_ERR_NO_MODEL, "no model loaded");
+  if (!ctx->have_dpor) return fail(ctx, DEMI_ERR_NO_TRACE, "demi_dpor_load must precede demi_dpor_batch");
+  if (!par || !prefix_len || !out_verdicts || !out_traces || !out_trace_len || !out_n_pairs || (!prefixes && stride) ||
+      (!out_pairs && par->max_pairs))
+    return fail(ctx, DEMI_ERR_INVALID_ARG, "null pointer");
+  uint32_t p_max = par->p_max ? par->p_max : 64;
+  if (p_max > DEMI_MAX_PENDING) return fail(ctx, DEMI_ERR_INVALID_ARG, "p_max must be 1..%d", DEMI_MAX_PENDING);
+  for (uint64_t i = 0; i < n; i++)
+    if (prefix_len[i] > stride) return fail(ctx, DEMI_ERR_INVALID_ARG, "prefix %llu longer than stride", (unsigned long long)i);
+  const DevModel& h = ctx->hmodel;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  // arena: prefixes | prefix_len | verdicts | traces | trace_len | pairs | n_pairs
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  const size_t o_pfx = 0, s_pfx = al(sizeof(demi_dpor_trace_entry) * (size_t)stride * n);
+  const size_t o_pl = o_pfx + s_pfx, s_pl = al(4 * n);
+  const size_t o_v = o_pl + s_pl, s_v = al(sizeof(demi_verdict) * n);
+  const size_t o_t = o_v + s_v, s_t = al(sizeof(demi_dpor_trace_entry) * DEMI_DPOR_MAX_TRACE * n);
+  const size_t o_tl = o_t + s_t, s_tl = al(4 * n);
+  const size_t o_p = o_tl + s_tl, s_p = al(sizeof(demi_dpor_pair) * (size_t)par->max_pairs * n);
+  const size_t o_np = o_p + s_p, s_np = al(4 * n);
+  const size_t total = o_np + s_np;
+  if (ctx->dpor_bytes < total) {
+    if (ctx->d_dpor) (void)hipFree(ctx->d_dpor);
+    ctx->d_dpor = nullptr; ctx->dpor_bytes = 0;
+    HIP_TRY(ctx, hipMalloc(&ctx->d_dpor, total));
+    ctx->dpor_bytes = total;
+  }
+  unsigned char* base = static_cast<unsigned char*>(ctx->d_dpor);
+  if (stride) HIP_TRY(ctx, hipMemcpy(base + o_pfx, prefixes, sizeof(demi_dpor_trace_entry) * (size_t)stride * n, hipMemcpyHostToDevice));
+  HIP_TRY(ctx, hipMemcpy(base + o_pl, prefix_len, 4 * n, hipMemcpyHostToDevice));
+  const size_t lds = k3_lds_bytes(h.code_len, ctx->n_dext, h.n_classes * h.n_msg_types, h.n_actors);
+  HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k3_dpor), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  int per_cu = 0;
+  HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k3_dpor, K3_WAVES * 64, lds));
+  if (per_cu < 1) per_cu = 1;
+  uint64_t blocks = (n + 63) / 64;   // a round of the backtrack queue is small: one wave per 64 interleavings
+  const uint64_t resident = (uint64_t)ctx->num_cu * (uint64_t)per_cu;
+  if (blocks > resident) blocks = resident;
+  int rc = ensure_spill(ctx, blocks * K3_WAVES * 64, 2);
+  if (rc) return rc;
+  K3Args a;
+  memset(&a, 0, sizeof a);
+  a.model = ctx->d_model; a.ext = ctx->d_dext; a.n_ext = ctx->n_dext;
+  a.prefixes = reinterpret_cast<const demi_dpor_trace_entry*>(base + o_pfx);
+  a.prefix_len = reinterpret_cast<const uint32_t*>(base + o_pl);
+  a.stride = stride; a.n = n;
+  a.depth_bound = par->depth_bound; a.max_messages = par->max_messages;
+  a.looking_for_valid = par->looking_for_valid; a.looking_for = par->looking_for; a.p_max = p_max;
+  a.max_pairs = par->max_pairs;
+  a.out = reinterpret_cast<demi_verdict*>(base + o_v);
+  a.traces = reinterpret_cast<demi_dpor_trace_entry*>(base + o_t);
+  a.trace_len = reinterpret_cast<uint32_t*>(base + o_tl);
+  a.pairs = reinterpret_cast<demi_dpor_pair*>(base + o_p);
+  a.n_pairs = reinterpret_cast<uint32_t*>(base + o_np);
+  a.work_counter = ctx->d_counter; a.spill = ctx->d_spill;
+  HIP_TRY(ctx, hipMemsetAsync(a.work_counter, 0, sizeof(unsigned long long), nullptr));
+  hipLaunchKernelGGL(k3_dpor, dim3((unsigned)blocks), dim3(K3_WAVES * 64), lds, nullptr, a);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  HIP_TRY(ctx, hipMemcpy(out_verdicts, base + o_v, sizeof(demi_verdict) * n, hipMemcpyDeviceToHost));
+  HIP_TRY(ctx, hipMemcpy(out_traces, base + o_t, sizeof(demi_dpor_trace_entry) * DEMI_DPOR_MAX_TRACE * n, hipMemcpyDeviceToHost));
+  HIP_TRY(ctx, hipMemcpy(out_trace_len, base + o_tl, 4 * n, hipMemcpyDeviceToHost));
+  if (par->max_pairs) HIP_TRY(ctx, hipMemcpy(out_pairs, base + o_p, sizeof(demi_dpor_pair) * (size_t)par->max_pairs * n, hipMemcpyDeviceToHost));
+  HIP_TRY(ctx, hipMemcpy(out_n_pairs, base + o_np, 4 * n, hipMemcpyDeviceToHost));
   return DEMI_OK;
 }

@@ -1,0 +1,333 @@
+// k3_dpor.hpp — K3: one DPORwHeuristics interleaving per wavefront lane, plus its racing pairs.
+//
+// Restates DPORwHeuristics.schedule_new_message / getMatchingMessage / getPendingEvent /
+// event_produced / getMessage / runExternal / notify_quiescence / notify_timer_cancel
+// (schedulers/DPORwHeuristics.scala:421-648, 803-847, 773-801, 684-721, 855-942, 961-984) and
+// the pair loop of dpor() with isCoEnabeled / analyze_dep / getCommonPrefix (:1020-1139, 994-1018).
+//
+// lane = one interleaving = one `nextTrace` prefix popped from the host's backtrack queue.
+// The dep-graph is a tree, so a node is the hash chain of its causal path (include/demi_gpu.h);
+// the lane keeps, for every delivered event, the trace index of the delivery that produced it.
+// "earlier happens-before later" (later.pathTo(earlier)) is a walk up those parent indices and the
+// branch point (getCommonPrefix(...).last) is the lowest common ancestor of the two trace indices.
+// The lane writes its trace (16 B per event) straight into the output array and re-reads it for
+// the walks; pending messages live in the LDS hot slots / HBM spill of sim_core.hpp with a packed
+// side word (producer index, quiescent period, FIFO sequence number).
+#pragma once
+
+#include "sim_core.hpp"
+
+namespace demi {
+
+constexpr uint64_t DPOR_ROOT_KEY = 0xCBF29CE484222325ULL;
+constexpr uint64_t DPOR_PRIME = 0x100000001B3ULL;
+__host__ __device__ inline uint64_t dpor_marker_key(uint32_t ext_idx) {
+  return DPOR_ROOT_KEY ^ (0x5155494553434500ULL | (uint64_t)ext_idx);
+}
+
+struct K3Args {
+  const DevModel* model;
+  const uint64_t* ext;               // external events (Start / Send / WaitQuiescence)
+  uint32_t n_ext;
+  const demi_dpor_trace_entry* prefixes;  // [n][stride]
+  const uint32_t* prefix_len;        // [n]
+  uint32_t stride;
+  uint64_t n;
+  uint32_t depth_bound, max_messages, looking_for_valid, looking_for, p_max, max_pairs;
+  demi_verdict* out;
+  demi_dpor_trace_entry* traces;     // [n][DEMI_DPOR_MAX_TRACE]
+  uint32_t* trace_len;               // [n]
+  demi_dpor_pair* pairs;             // [n][max_pairs]
+  uint32_t* n_pairs;                 // [n]
+  unsigned long long* work_counter;
+  uint32_t* spill;
+};
+
+constexpr int K3_WAVES = 4;
+
+__host__ __device__ inline size_t k3_lds_bytes(uint32_t code_len, uint32_t n_ext, uint32_t n_hs, uint32_t n_actors) {
+  return tables_lds_bytes(code_len, n_ext, n_hs) + K3_WAVES * lane_mem_wave_bytes(n_actors, true);
+}
+
+__global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  Tables t;
+  unsigned char* wave_base = tables_load(t, smem, args.model, args.ext, args.n_ext, (1u << args.model->n_actors) - 1);
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const LaneMem mem = lane_mem_carve(wave_base + (size_t)wave * lane_mem_wave_bytes(t.A, true), t.A, true, lane,
+                                     args.spill, (size_t)blockIdx.x * blockDim.x + threadIdx.x,
+                                     (size_t)gridDim.x * blockDim.x);
+  uint64_t* const st = mem.st;
+  const uint32_t A = t.A, NE = t.E, PMAX = args.p_max;
+  const uint32_t max_messages = args.max_messages ? args.max_messages : 0x7FFFFFFFu;
+
+  bool active = false, fresh = false;
+  uint64_t sched = 0, hash = 0, parent_key = 0;
+  demi_dpor_trace_entry* tr = nullptr;
+  const demi_dpor_trace_entry* pf = nullptr;
+  uint32_t pfx = 0, pfx_len = 0;
+  uint32_t n_pend = 0, next_seq = 0, parent = 0, parent_depth = 0, cur_root = 0, qperiod = 0, next_qperiod = 0;
+  uint32_t marker_ext = 0, qmarker_ext = 0, isolated = 0, rep = 0, flags = 0, count = 0, deliveries = 0;
+  uint32_t n_trace = 0, ext_idx = 0;
+  bool awaiting = false, marker_pending = false;
+  uint64_t b_next = 0, b_end = 0;
+  bool exhausted = false;
+
+#define K3_ABORT (DEMI_OVF_ANY | DEMI_V_TRACE_OVF | DEMI_V_SELFMSG)
+#define TIMER_BIT(RCV, TYPE) (1u << ((RCV) * DEMI_MAX_TIMER_TYPES + (t.meta[(TYPE)] >> 8)))
+
+  // event_produced + getMessage: the node is a child of the current parentEvent; enqueued unless
+  // the depth bound is hit (:832-838)
+  auto produce = [&](uint32_t word) {
+    if (args.depth_bound && parent_depth + 1 >= args.depth_bound) return;
+    if (flags & DEMI_OVF_ANY) return;
+    if (n_pend >= PMAX) { flags |= DEMI_V_PENDING_OVF; return; }
+    pend_store(mem, n_pend, word);
+    aux_store(mem, n_pend, parent | (qperiod << 8) | (next_seq << 16));
+    next_seq++;
+    n_pend++;
+  };
+  auto trace_push = [&](uint64_t key, uint32_t word, uint32_t par, uint32_t qp, uint32_t kind) -> int {
+    if (n_trace >= DEMI_DPOR_MAX_TRACE) { flags |= DEMI_V_TRACE_OVF; return -1; }
+    demi_dpor_trace_entry e;
+    e.key = key; e.word = word; e.parent = (uint8_t)par; e.qperiod = (uint8_t)qp;
+    e.depth = (uint8_t)(n_trace == 0 ? 0 : tr[par].depth + 1);
+    e.kind = (uint8_t)kind;
+    tr[n_trace] = e;
+    return (int)n_trace++;
+  };
+  // runExternal (:684-721)
+  auto run_external = [&]() {
+    bool await = false;
+    while (ext_idx < NE && !await) {
+      const uint64_t ev = t.trace[ext_idx];
+      const uint32_t kind = (uint32_t)ev & 0xFF, a = (uint32_t)(ev >> 8) & 0xFF;
+      if (kind == DEMI_EV_START) isolated &= ~(1u << a);
+      else if (kind == DEMI_EV_SEND)
+        produce(msg_word((uint32_t)(ev >> 24) & 0xFF, DEMI_DEADLETTERS, a, (uint32_t)(ev >> 32) & 0xFF, (uint32_t)(ev >> 40) & 0xFF));
+      else if (kind == DEMI_EV_WAIT_QUIESCENCE) { marker_pending = true; marker_ext = ext_idx; await = true; }
+      ext_idx++;
+    }
+  };
+
+  for (;;) {
+    {
+      const uint64_t idle = __ballot(!active);
+      if (idle != 0 && !exhausted) {
+        const uint32_t want = (uint32_t)__popcll(idle);
+        const uint64_t have = b_end - b_next;
+        uint64_t got = 0;
+        if (have < want) {
+          if (lane == 0) got = atomicAdd(args.work_counter, 64ull);
+          got = __shfl(got, 0);
+        }
+        if (!active) {
+          const uint32_t rank = (uint32_t)__popcll(idle & ((1ULL << lane) - 1));
+          const uint64_t my = (rank < have) ? (b_next + rank) : (got + (rank - have));
+          if (my < args.n) { sched = my; active = true; fresh = true; }
+        }
+        if (have < want) { b_next = got + (want - have); b_end = got + 64; }
+        else b_next += want;
+        if (b_next >= args.n) exhausted = true;
+      }
+      if (__ballot(active) == 0) break;
+    }
+
+    uint32_t w = 0;
+    bool deliver = false, finish = false;
+    if (active) {
+      if (fresh) {
+        fresh = false;
+        tr = args.traces + sched * DEMI_DPOR_MAX_TRACE;
+        pf = args.prefixes + sched * (uint64_t)args.stride;
+        pfx = 0; pfx_len = args.prefix_len[sched];
+        hash = 0xCBF29CE484222325ULL;
+        isolated = (1u << A) - 1;      // maybeStartActors: every actor exists and is isolated (:666-679)
+        for (uint32_t a = 0; a < A; a++) st[a * 64] = t.init[a];
+        n_pend = 0; next_seq = 0; qperiod = 0; next_qperiod = 0; rep = 0; flags = 0; count = 0; deliveries = 0;
+        n_trace = 0; ext_idx = 0; awaiting = false; marker_pending = false;
+        trace_push(DPOR_ROOT_KEY, 0, 0, 0, 0);   // currentTrace += getRootEvent (:336-343)
+        parent = 0; parent_key = DPOR_ROOT_KEY; parent_depth = 0; cur_root = 0;
+        run_external();
+      }
+      if (flags & K3_ABORT) {
+        finish = true;
+      } else {
+        // ------------------------------------------------------ schedule_new_message (:421-648)
+        int chosen = -1;
+        bool chose_marker = false, none = false;
+        count++;                                         // messagesScheduledSoFar += 1 (:583)
+        if (count > max_messages) none = true;           // (:584-586)
+        if (!none && !awaiting) {
+          // getMatchingMessage: skip root / id-0 heads (:363-372), then match the head by identity
+          while (pfx < pfx_len && pf[pfx].kind == 0) pfx++;
+          if (pfx < pfx_len) {
+            const demi_dpor_trace_entry want = pf[pfx];
+            pfx++;
+            if (want.kind == 2) {
+              if (marker_pending && want.key == dpor_marker_key(marker_ext)) chose_marker = true;
+            } else {
+              uint32_t best_seq = 0xFFFFFFFFu;
+              for (uint32_t k = 0; k < n_pend; k++) {
+                if (pend_load(mem, k) != want.word) continue;
+                const uint32_t aux = aux_load(mem, k);
+                const uint64_t key = (tr[aux & 0xFF].key ^ (uint64_t)want.word) * DPOR_PRIME;
+                if (key == want.key && (aux >> 16) < best_seq) { best_seq = aux >> 16; chosen = (int)k; }
+              }
+            }
+          }
+        }
+        if (!none && chosen < 0 && !chose_marker) {
+          // getPendingEvent (:452-472), iteration order pinned: (snd, rcv) ascending, FIFO inside
+          uint32_t best = 0xFFFFFFFFu;
+          for (uint32_t k = 0; k < n_pend; k++) {
+            const uint32_t pw = pend_load(mem, k);
+            const uint32_t ord = (((w_src(pw) << 4) | w_dst(pw)) << 16) | (aux_load(mem, k) >> 16);
+            if (ord < best) { best = ord; chosen = (int)k; }
+          }
+          if (chosen < 0 && marker_pending) chose_marker = true;
+          if (chosen < 0 && !chose_marker) none = true;
+        }
+        if (chose_marker) {                              // awaitQuiescenceUpdate (:256-266)
+          marker_pending = false; awaiting = true; next_qperiod = marker_ext + 1; qmarker_ext = marker_ext;
+        } else if (!none) {
+          const uint32_t pw = pend_load(mem, (uint32_t)chosen), aux = aux_load(mem, (uint32_t)chosen);
+          pend_store(mem, (uint32_t)chosen, pend_load(mem, n_pend - 1));
+          aux_store(mem, (uint32_t)chosen, aux_load(mem, n_pend - 1));
+          n_pend--;
+          const uint32_t snd = w_src(pw), rcv = w_dst(pw);
+          if ((snd < DEMI_MAX_ACTORS && ((isolated >> snd) & 1)) || ((isolated >> rcv) & 1)) {
+            if (snd == rcv) { flags |= DEMI_V_SELFMSG; finish = true; }   // (:631-633)
+            // else: discarded, schedule again (:626-635)
+          } else {
+            const uint32_t par = aux & 0xFF;
+            const uint64_t key = (tr[par].key ^ (uint64_t)pw) * DPOR_PRIME;
+            const int ti = trace_push(key, pw, par, (aux >> 8) & 0xFF, 1);
+            if (ti < 0) finish = true;
+            else {
+              parent = (uint32_t)ti; parent_key = key; parent_depth = tr[ti].depth;   // setParentEvent
+              w = pw; deliver = true;
+              deliveries++;
+              hash_step(hash, w);
+              const uint32_t type = w_type(w), meta = t.meta[type];
+              if (((meta & 0xFF) == DEMI_MSG_TIMER) && (rep & (1u << (rcv * DEMI_MAX_TIMER_TYPES + (meta >> 8)))))
+                produce(msg_word(type, DEMI_DEADLETTERS, rcv, 0, 0));   // retrigger: enqueue_timer = `!`
+            }
+          }
+        } else {
+          // ---------------------------------------------------- notify_quiescence (:855-942)
+          if (awaiting) {
+            awaiting = false;
+            qperiod = next_qperiod; next_qperiod = 0;
+            const int ti = trace_push(dpor_marker_key(qmarker_ext), 0, cur_root, qperiod, 2);
+            if (ti < 0) finish = true;
+            else {
+              cur_root = (uint32_t)ti; parent = (uint32_t)ti; parent_key = tr[ti].key; parent_depth = tr[ti].depth;
+              run_external();
+            }
+          } else {
+            finish = true;
+          }
+        }
+      }
+    }
+
+    uint32_t nfx = 0;
+    if (deliver) nfx = vm_run(t, mem, w, flags);
+    if (deliver) {
+      const uint32_t me = w_dst(w);
+      for (uint32_t k = 0; k < nfx && !(flags & DEMI_OVF_ANY); k++) {
+        const uint32_t fx = mem.fxq[k * 64];
+        const uint32_t op = fx & 31u, type = (fx >> 5) & 31u, target = (fx >> 10) & 15u, p0 = (fx >> 14) & 0xFFu,
+                       p1 = (fx >> 22) & 0xFFu;
+        if (op <= DEMI_OP_BCAST) {
+          const bool bc = (op == DEMI_OP_BCAST);
+          const uint32_t first = bc ? 0u : target, last = bc ? A : (target < A ? target + 1 : 0u);
+          for (uint32_t r = first; r < last; r++) {
+            if (bc && r == me) continue;
+            produce(msg_word(type, me, r, p0, p1));
+          }
+        } else if (op == DEMI_OP_TCANCEL) {
+          // notify_timer_cancel (:961-984): first of the (deadLetters, rcv) queue with this message
+          rep &= ~TIMER_BIT(me, type);
+          const uint32_t wantw = msg_word(type, DEMI_DEADLETTERS, me, 0, 0);
+          int best = -1;
+          uint32_t best_seq = 0xFFFFFFFFu;
+          for (uint32_t q = 0; q < n_pend; q++) {
+            if (pend_load(mem, q) != wantw) continue;
+            const uint32_t sq = aux_load(mem, q) >> 16;
+            if (sq < best_seq) { best_seq = sq; best = (int)q; }
+          }
+          if (best >= 0) {
+            pend_store(mem, (uint32_t)best, pend_load(mem, n_pend - 1));
+            aux_store(mem, (uint32_t)best, aux_load(mem, n_pend - 1));
+            n_pend--;
+          }
+        } else {
+          const uint32_t bit = TIMER_BIT(me, type);
+          if (!(rep & bit)) {
+            if (op == DEMI_OP_TREP) rep |= bit;
+            produce(msg_word(type, DEMI_DEADLETTERS, me, 0, 0));
+          }
+        }
+      }
+    }
+
+    if (active && finish) {
+      const bool aborted = (flags & K3_ABORT) != 0;
+      uint32_t viol = 0;
+      if (!aborted) {   // checkInvariant (:394-418)
+        const uint32_t fp = invariant_code(args.model, st, (1u << A) - 1, A, t.inv_kind, t.inv_fa, t.inv_va, t.inv_fb);
+        if (fp) {
+          if (!args.looking_for_valid) viol = fp;
+          else if (((fp ^ args.looking_for) & t.fp_mask) == 0) viol = args.looking_for;
+        }
+      }
+      for (uint32_t a = 0; a < A; a++) hash_step(hash, st[a * 64]);
+      // -------------------------------------------------------- dpor(): racing pairs (:1122-1139)
+      uint32_t np = 0;
+      bool pairs_ovf = false;
+      if (!aborted) {
+        demi_dpor_pair* po = args.pairs + sched * (uint64_t)args.max_pairs;
+        for (uint32_t l = 1; l < n_trace; l++) {
+          const demi_dpor_trace_entry L = tr[l];
+          if (L.kind != 1) continue;
+          for (uint32_t e = 1; e < l; e++) {
+            const demi_dpor_trace_entry E = tr[e];
+            // isCoEnabeled (:1091-1110): same receiver, same quiescent period, no causal path
+            if (E.kind != 1 || w_dst(E.word) != w_dst(L.word) || E.qperiod != L.qperiod) continue;
+            bool anc = false;
+            for (uint32_t k = L.parent;; k = tr[k].parent) {
+              if (k == e) { anc = true; break; }
+              if (k < e) break;                 // parents have smaller indices: e cannot be above k
+            }
+            if (anc) continue;
+            // analyze_dep (:1043-1077): branch point = deepest common ancestor, as a trace index
+            uint32_t a = E.parent, b = L.parent;
+            while (a != b) { if (a > b) a = tr[a].parent; else b = tr[b].parent; }
+            if (np < args.max_pairs) {
+              demi_dpor_pair p; p.branch = (uint8_t)a; p.later = (uint8_t)l; p.earlier = (uint8_t)e; p.pad = 0;
+              po[np] = p; np++;
+            } else pairs_ovf = true;
+          }
+        }
+      }
+      uint4 v;
+      if (aborted) {
+        v.x = flags & K3_ABORT; v.y = 0; v.z = 0; v.w = 0;
+        args.trace_len[sched] = 0; args.n_pairs[sched] = 0;
+      } else {
+        v.x = (viol ? DEMI_V_VIOLATION : 0u) | (pairs_ovf ? DEMI_V_PAIRS_OVF : 0u) |
+              ((count > max_messages) ? DEMI_V_MAXMSG : 0u) | ((deliveries & 0xFFFF) << 16);
+        v.y = viol; v.z = (uint32_t)hash; v.w = (uint32_t)(hash >> 32);
+        args.trace_len[sched] = n_trace; args.n_pairs[sched] = np;
+      }
+      *reinterpret_cast<uint4*>(&args.out[sched]) = v;
+      active = false;
+    }
+  }
+#undef K3_ABORT
+#undef TIMER_BIT
+}
+
+}  // namespace demi

@@ -81,3 +81,48 @@ def sharded_map(items: list, fn) -> list:
         for k in range(n_r):
             out[r + k * world] = bool(parts[r][k])
     return out
+
+
+def sharded_batch(items: list, fn):
+    """fn(list of prefixes) -> (verdicts ndarray, [trace arrays], [pair arrays]); items are dealt
+    round-robin to the ranks and the results all-gathered (as one fixed-size byte row per item:
+    verdict 16 B | trace_len 4 B | n_pairs 4 B | trace 256 x 16 B | pairs), so every rank keeps an
+    identical backtrack queue and explored set while the interleavings themselves are sharded."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+        return fn(items)
+    world, rank = dist.get_world_size(), dist.get_rank()
+    mine = items[rank::world]
+    v, tr, pr = fn(mine) if mine else (np.zeros(0, dtype=T.VERDICT_DTYPE), [], [])
+    max_pairs = max([len(p) for p in pr] + [0])
+    mp = torch.tensor([max_pairs], dtype=torch.int64)
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    mp = mp.to(dev)
+    dist.all_reduce(mp, op=dist.ReduceOp.MAX)
+    max_pairs = int(mp.item())
+    row = 24 + T.DPOR_MAX_TRACE * 16 + max_pairs * 4
+    per = (len(items) + world - 1) // world
+    buf = np.zeros((per, row), dtype=np.uint8)
+    for k in range(len(mine)):
+        buf[k, :16] = np.frombuffer(v[k:k + 1].tobytes(), dtype=np.uint8)
+        buf[k, 16:24] = np.frombuffer(np.array([len(tr[k]), len(pr[k])], dtype=np.uint32).tobytes(), dtype=np.uint8)
+        buf[k, 24:24 + 16 * len(tr[k])] = np.frombuffer(tr[k].tobytes(), dtype=np.uint8)
+        o = 24 + T.DPOR_MAX_TRACE * 16
+        buf[k, o:o + 4 * len(pr[k])] = np.frombuffer(pr[k].tobytes(), dtype=np.uint8)
+    tb = torch.from_numpy(buf).to(dev)
+    parts = [torch.empty_like(tb) for _ in range(world)]
+    dist.all_gather(parts, tb)
+    parts = [p.cpu().numpy() for p in parts]
+    verdicts = np.zeros(len(items), dtype=T.VERDICT_DTYPE)
+    traces, pairs = [None] * len(items), [None] * len(items)
+    for r in range(world):
+        for k in range(len(items[r::world])):
+            i = r + k * world
+            rowb = parts[r][k]
+            verdicts[i] = np.frombuffer(rowb[:16].tobytes(), dtype=T.VERDICT_DTYPE)[0]
+            tl, npr = np.frombuffer(rowb[16:24].tobytes(), dtype=np.uint32)
+            traces[i] = np.frombuffer(rowb[24:24 + 16 * int(tl)].tobytes(), dtype=T.DPOR_TRACE_DTYPE).copy()
+            o = 24 + T.DPOR_MAX_TRACE * 16
+            pairs[i] = np.frombuffer(rowb[o:o + 4 * int(npr)].tobytes(), dtype=T.DPOR_PAIR_DTYPE).copy()
+    return verdicts, traces, pairs

@@ -36,6 +36,16 @@ V_MAXMSG = 0x2
 V_PENDING_OVF = 0x4
 V_QUEUE_OVF = 0x8
 V_DIVERGED = 0x10
+V_TRACE_OVF = 0x20
+V_PAIRS_OVF = 0x40
+V_SELFMSG = 0x80
+DPOR_MAX_TRACE = 256
+DPOR_ROOT_KEY = 0xCBF29CE484222325
+DPOR_PRIME = 0x100000001B3
+
+
+def dpor_marker_key(ext_idx):
+    return DPOR_ROOT_KEY ^ (0x5155494553434500 | ext_idx)
 
 # demi_rec_kind
 (REC_SPAWN, REC_KILL, REC_PARTITION, REC_UNPARTITION, REC_BEGIN_WAIT_QUIESCENCE, REC_QUIESCENCE,
@@ -73,6 +83,11 @@ class RecEvent(C.Structure):
                 ("id", C.c_uint32)]
 
 
+class DporParams(C.Structure):
+    _fields_ = [("depth_bound", C.c_uint32), ("max_messages", C.c_uint32), ("looking_for_valid", C.c_uint32),
+                ("looking_for", C.c_uint32), ("p_max", C.c_uint32), ("max_pairs", C.c_uint32)]
+
+
 assert C.sizeof(ExtEvent) == 8 and C.sizeof(Verdict) == 16 and C.sizeof(RecEvent) == 12
 
 import numpy as np  # noqa: E402
@@ -82,6 +97,10 @@ EXT_EVENT_DTYPE = np.dtype([("kind", "u1"), ("a", "u1"), ("b", "u1"), ("msg_type
                             ("p0", "u1"), ("p1", "u1"), ("pad", "u1", (2,))])
 REC_EVENT_DTYPE = np.dtype([("kind", "u1"), ("snd", "u1"), ("rcv", "u1"), ("msg_type", "u1"),
                             ("p0", "u1"), ("p1", "u1"), ("flags", "u1"), ("ext_idx", "u1"), ("id", "<u4")])
+DPOR_TRACE_DTYPE = np.dtype([("key", "<u8"), ("word", "<u4"), ("parent", "u1"), ("qperiod", "u1"), ("depth", "u1"),
+                             ("kind", "u1")])
+DPOR_PAIR_DTYPE = np.dtype([("branch", "u1"), ("later", "u1"), ("earlier", "u1"), ("pad", "u1")])
+assert DPOR_TRACE_DTYPE.itemsize == 16 and DPOR_PAIR_DTYPE.itemsize == 4
 VIOLATION_DTYPE = np.dtype([("index", "<u8"), ("fingerprint", "<u4"), ("flags", "<u4")])
 assert VERDICT_DTYPE.itemsize == 16 and VIOLATION_DTYPE.itemsize == 16 and EXT_EVENT_DTYPE.itemsize == 8 and REC_EVENT_DTYPE.itemsize == 12
 

@@ -212,6 +212,56 @@ int demi_replay_batch(demi_ctx* ctx, const uint64_t* masks /* [n][4] */, uint64_
 int demi_replay_batch_dev(demi_ctx* ctx, const uint64_t* d_masks, uint64_t n, const demi_limits* limits,
                           demi_verdict* d_out, void* hip_stream);
 
+/* ---------------------------------------------------------- K3: DPORwHeuristics interleavings
+ * Replaces, per interleaving, DPORwHeuristics.schedule_new_message / event_produced / getMessage /
+ * runExternal / notify_quiescence (DPORwHeuristics.scala:421-648, 803-847, 773-801, 684-721,
+ * 855-942) and the racing-pair analysis of dpor() (:1020-1139: isCoEnabeled, analyze_dep,
+ * getCommonPrefix).  The backtrack priority queue, the ExploredTacker and getNext() (:1142-1185)
+ * stay on the host (demi_amd/dpor.py here, the Scala DPORwHeuristics in production); a round of the
+ * queue is one batch: lane = one interleaving = one `nextTrace` prefix.
+ *
+ * Message identity across interleavings: the dep-graph is a tree (every node has one out-edge,
+ * :844-845) and getMessage() collapses equal (snd, rcv, fingerprint) children of one parent
+ * (:773-801), so a node is identified by the 64-bit hash chain of its path,
+ *   key(child) = (key(parent) ^ word) * FNV_PRIME,   key(root) = FNV_OFFSET,
+ *   key(WaitQuiescence marker of external event i) = FNV_OFFSET ^ (0x5155494553434500 | i)
+ * which needs no global id counter and is identical on every GPU.
+ * External events: Start, Send, WaitQuiescence only (:692-710); all actors exist and start isolated
+ * (setActorNameProps, :666-679).                                                                   */
+#define DEMI_DPOR_MAX_TRACE 256   /* root + deliveries + quiescence markers of one interleaving */
+typedef struct {
+  uint32_t depth_bound;        /* depth_bound ctor arg / setDepthBound (:81, 108-115); 0 = unbounded */
+  uint32_t max_messages;       /* setMaxMessagesToSchedule (:118-122); 0 = unbounded; counts scheduler calls */
+  uint32_t looking_for_valid;  /* 0: any violation counts */
+  uint32_t looking_for;
+  uint32_t p_max;              /* pending capacity, 1..128 (0 = 64) */
+  uint32_t max_pairs;          /* capacity of the racing-pair list per interleaving */
+} demi_dpor_params;
+
+typedef struct {
+  uint64_t key;      /* node identity (see above) */
+  uint32_t word;     /* message word (0 for root and markers) */
+  uint8_t parent;    /* trace index of the delivery (or root / marker) that produced it */
+  uint8_t qperiod;   /* quiescentPeriod(node): 0, or 1 + index of the WaitQuiescence that opened it */
+  uint8_t depth;     /* getPathLength(node) */
+  uint8_t kind;      /* 0 root, 1 message delivery, 2 WaitQuiescence marker */
+} demi_dpor_trace_entry; /* 16 bytes */
+
+typedef struct { uint8_t branch, later, earlier, pad; } demi_dpor_pair;  /* trace indices (:1043-1077) */
+
+#define DEMI_V_TRACE_OVF 0x20u  /* interleaving longer than DEMI_DPOR_MAX_TRACE: aborted           */
+#define DEMI_V_PAIRS_OVF 0x40u  /* more racing pairs than max_pairs: list truncated                 */
+#define DEMI_V_SELFMSG   0x80u  /* "self message without prior messages!" (:631-633): aborted       */
+
+int demi_dpor_load(demi_ctx* ctx, const demi_ext_event* externals, uint32_t n_ext);
+/* prefixes: [n][stride] entries of nextTrace (root and markers included, as getNext builds them,
+ * :1180; only key, word and kind are read); outputs are [n], [n][DEMI_DPOR_MAX_TRACE], [n],
+ * [n][max_pairs], [n].  All host pointers.                                                         */
+int demi_dpor_batch(demi_ctx* ctx, const demi_dpor_trace_entry* prefixes, const uint32_t* prefix_len, uint32_t stride,
+                    uint64_t n, const demi_dpor_params* params, demi_verdict* out_verdicts,
+                    demi_dpor_trace_entry* out_traces, uint32_t* out_trace_len, demi_dpor_pair* out_pairs,
+                    uint32_t* out_n_pairs);
+
 /* ---------------------------------------------------------- found-violation set
  * One entry per violating schedule (what RunnerUtils.fuzz keeps: the violating execution's
  * index + fingerprint, RunnerUtils.scala:91-128).  Compacts a device verdict array into a device

@@ -910,3 +910,247 @@ int orc_sts_replay_batch(const demi_model* m, const demi_ext_event* ext, uint32_
     for (int t = 0; t < n_threads; t++) pthread_join(th[t], NULL);
   return DEMI_OK;
 }
+
+/* ===================================================================== K3: DPORwHeuristics
+ * One interleaving of V/schedulers/DPORwHeuristics.scala (checkpointing off, FD off,
+ * prioritizePendingUponDivergence=false, invariant at the end of the interleaving :877-902).
+ * Pinned where the reference depends on Scala HashMap iteration order (:454-456): the divergent
+ * choice iterates the (snd, rcv) queues in ascending (snd, rcv) order with the scheduler's
+ * WaitQuiescence queue last.                                                                     */
+#define DPOR_ROOT_KEY 0xCBF29CE484222325ULL
+#define DPOR_MARKER_KEY(i) (DPOR_ROOT_KEY ^ (0x5155494553434500ULL | (uint64_t)(i)))
+#define DPOR_PRIME 0x100000001B3ULL
+
+typedef struct { uint32_t word; uint32_t seq; uint8_t parent; uint8_t qperiod; } dpor_pend;
+
+typedef struct {
+  const demi_model* m;
+  const demi_dpor_params* par;
+  uint64_t state[DEMI_MAX_ACTORS];
+  uint32_t isolated;
+  dpor_pend pend[PEND_HARD_CAP];
+  uint32_t n_pend, p_max, next_seq;
+  int marker_pending;        /* the (SCHEDULER, SCHEDULER) queue holds at most one marker */
+  uint32_t marker_ext;
+  demi_dpor_trace_entry* trace;
+  uint32_t n_trace;
+  uint32_t parent, cur_root, qperiod, next_qperiod, awaiting, quiescent_marker_ext;
+  uint32_t repeating, flags, count, deliveries;
+  uint64_t hash;
+  orc_effect fx[DEMI_MAX_CODE * DEMI_MAX_ACTORS];
+} dpor_t;
+
+int orc_dpor_trace_validate(const demi_model* m, const demi_ext_event* ev, uint32_t n, char* err, size_t err_cap) {
+  int rc = orc_trace_validate(m, ev, n, err, err_cap);
+  if (rc) return rc;
+  for (uint32_t i = 0; i < n; i++)
+    if (ev[i].kind != DEMI_EV_START && ev[i].kind != DEMI_EV_SEND && ev[i].kind != DEMI_EV_WAIT_QUIESCENCE) {
+      if (err) snprintf(err, err_cap, "event %u: unsuported external event for DPOR", i); /* :709 */
+      return DEMI_ERR_INVALID_TRACE;
+    }
+  return DEMI_OK;
+}
+
+/* event_produced + getMessage (:803-847, 773-801): the node always exists in the graph; it is only
+ * enqueued when the depth bound allows (:832-838) */
+static void dpor_produce(dpor_t* x, uint32_t word) {
+  uint32_t cur_depth = (uint32_t)x->trace[x->parent].depth + 1; /* currentDepth = pathLength(parent)+1 */
+  if (x->par->depth_bound && cur_depth >= x->par->depth_bound) return;
+  if (x->flags & OVF_ANY) return;
+  if (x->n_pend >= x->p_max) { x->flags |= DEMI_V_PENDING_OVF; return; }
+  x->pend[x->n_pend].word = word;
+  x->pend[x->n_pend].seq = x->next_seq++;
+  x->pend[x->n_pend].parent = (uint8_t)x->parent;
+  x->pend[x->n_pend].qperiod = (uint8_t)x->qperiod; /* quiescentPeriod(node) = period at production (:284-288) */
+  x->n_pend++;
+}
+
+static uint64_t dpor_key_of(const dpor_t* x, const dpor_pend* p) {
+  return (x->trace[p->parent].key ^ (uint64_t)p->word) * DPOR_PRIME;
+}
+
+/* runExternal (:684-721) */
+static uint32_t dpor_run_external(dpor_t* x, const demi_ext_event* ext, uint32_t n_ext, uint32_t idx) {
+  int await = 0;
+  while (idx < n_ext && !await) {
+    const demi_ext_event* e = &ext[idx];
+    if (e->kind == DEMI_EV_START) x->isolated &= ~(1u << e->a);
+    else if (e->kind == DEMI_EV_SEND) dpor_produce(x, msg_word(e->msg_type, DEMI_DEADLETTERS, e->a, e->p0, e->p1));
+    else if (e->kind == DEMI_EV_WAIT_QUIESCENCE) { x->marker_pending = 1; x->marker_ext = idx; await = 1; }
+    idx++;
+  }
+  return idx;
+}
+
+static int dpor_trace_push(dpor_t* x, uint64_t key, uint32_t word, uint32_t parent, uint32_t kind) {
+  if (x->n_trace >= DEMI_DPOR_MAX_TRACE) { x->flags |= DEMI_V_TRACE_OVF; return -1; }
+  demi_dpor_trace_entry* t = &x->trace[x->n_trace];
+  t->key = key; t->word = word; t->parent = (uint8_t)parent; t->qperiod = (uint8_t)x->qperiod;
+  t->depth = (uint8_t)(x->n_trace == 0 ? 0 : x->trace[parent].depth + 1);
+  t->kind = (uint8_t)kind;
+  return (int)x->n_trace++;
+}
+
+static int dpor_cmp_queue(const dpor_pend* a, const dpor_pend* b) {
+  /* pinned iteration order of pendingEvents: (snd, rcv) ascending, FIFO inside a queue */
+  uint32_t ka = (W_SRC(a->word) << 4) | W_DST(a->word), kb = (W_SRC(b->word) << 4) | W_DST(b->word);
+  if (ka != kb) return ka < kb ? -1 : 1;
+  return a->seq < b->seq ? -1 : (a->seq > b->seq ? 1 : 0);
+}
+
+static void dpor_deliver(dpor_t* x, uint32_t w) {
+  const demi_model* m = x->m;
+  uint32_t me = W_DST(w);
+  x->deliveries++;
+  hash_step(&x->hash, w);
+  if (m->msg_class[W_TYPE(w)] == DEMI_MSG_TIMER && (x->repeating & timer_bit(m, me, W_TYPE(w))))
+    dpor_produce(x, msg_word(W_TYPE(w), DEMI_DEADLETTERS, me, 0, 0)); /* retrigger -> enqueue_timer = `!` (Scheduler.scala:73) */
+  int n = orc_vm_run(m, me, &x->state[me], (uint8_t)W_TYPE(w), (uint8_t)W_SRC(w), (uint8_t)W_P0(w), (uint8_t)W_P1(w),
+                     (1u << m->n_actors) - 1, x->fx, DEMI_MAX_CODE * DEMI_MAX_ACTORS);
+  if (n < 0) { x->flags |= DEMI_V_QUEUE_OVF; return; }
+  for (int i = 0; i < n && !(x->flags & OVF_ANY); i++) {
+    const orc_effect* e = &x->fx[i];
+    uint32_t bit = e->kind ? timer_bit(m, me, e->msg_type) : 0;
+    switch (e->kind) {
+      case 0: dpor_produce(x, msg_word(e->msg_type, me, e->target, e->p0, e->p1)); break;
+      case 1: case 2:
+        if (x->repeating & bit) break; /* Non-unique timer */
+        if (e->kind == 2) x->repeating |= bit;
+        dpor_produce(x, msg_word(e->msg_type, DEMI_DEADLETTERS, me, 0, 0));
+        break;
+      case 3: { /* notify_timer_cancel (:961-984): first in the (deadLetters, rcv) queue with this msg */
+        x->repeating &= ~bit;
+        uint32_t want = msg_word(e->msg_type, DEMI_DEADLETTERS, me, 0, 0);
+        int best = -1;
+        for (uint32_t k = 0; k < x->n_pend; k++)
+          if (x->pend[k].word == want && (best < 0 || x->pend[k].seq < x->pend[best].seq)) best = (int)k;
+        if (best >= 0) { x->pend[best] = x->pend[x->n_pend - 1]; x->n_pend--; }
+        break;
+      }
+    }
+  }
+}
+
+int orc_dpor_execute(const demi_model* m, const demi_ext_event* ext, uint32_t n_ext, const uint64_t* prefix,
+                     uint32_t prefix_len, const demi_dpor_params* par, demi_verdict* out,
+                     demi_dpor_trace_entry* trace, uint32_t* trace_len, demi_dpor_pair* pairs, uint32_t* n_pairs) {
+  dpor_t* x = (dpor_t*)calloc(1, sizeof(dpor_t));
+  if (!x) return DEMI_ERR_INVALID_ARG;
+  x->m = m; x->par = par; x->trace = trace;
+  x->p_max = par->p_max ? par->p_max : 64;
+  if (x->p_max > PEND_HARD_CAP) x->p_max = PEND_HARD_CAP;
+  x->hash = 0xCBF29CE484222325ULL;
+  x->isolated = (1u << m->n_actors) - 1; /* maybeStartActors: isolatedActors ++= actorNames (:666-679) */
+  for (uint32_t a = 0; a < m->n_actors; a++) x->state[a] = m->init_state[a];
+  dpor_trace_push(x, DPOR_ROOT_KEY, 0, 0, 0); /* start_trace: currentTrace += getRootEvent (:336-343) */
+  x->parent = 0; x->cur_root = 0;
+  uint32_t ext_idx = dpor_run_external(x, ext, n_ext, 0);
+  uint32_t pfx = 0;
+  uint32_t max_messages = par->max_messages ? par->max_messages : 0x7FFFFFFFu;
+  uint32_t viol = 0;
+
+  for (;;) {
+    if (x->flags & (OVF_ANY | DEMI_V_TRACE_OVF | DEMI_V_SELFMSG)) break;
+    /* ---- schedule_new_message (:421-648) */
+    int chosen = -1, chose_marker = 0, none = 0;
+    x->count++;                                       /* messagesScheduledSoFar += 1 (:583) */
+    if (x->count > max_messages) none = 1;            /* (:584-586) */
+    if (!none && !x->awaiting) {
+      /* getMatchingMessage: pop nextTrace heads that are root / id 0 (:363-372), then look the head up */
+      while (pfx < prefix_len && prefix[pfx] == DPOR_ROOT_KEY) pfx++;
+      if (pfx < prefix_len) {
+        uint64_t want = prefix[pfx++];
+        if (x->marker_pending && want == DPOR_MARKER_KEY(x->marker_ext)) chose_marker = 1;
+        else {
+          for (uint32_t k = 0; k < x->n_pend; k++)
+            if (dpor_key_of(x, &x->pend[k]) == want && (chosen < 0 || x->pend[k].seq < x->pend[chosen].seq)) chosen = (int)k;
+        }
+      }
+    }
+    if (!none && chosen < 0 && !chose_marker) {
+      /* divergent / first run / awaiting quiescence: getPendingEvent (:452-472), pinned order */
+      for (uint32_t k = 0; k < x->n_pend; k++)
+        if (chosen < 0 || dpor_cmp_queue(&x->pend[k], &x->pend[chosen]) < 0) chosen = (int)k;
+      if (chosen < 0 && x->marker_pending) chose_marker = 1;
+      if (chosen < 0 && !chose_marker) none = 1;
+    }
+    if (chose_marker) {                               /* awaitQuiescenceUpdate (:256-266) */
+      x->marker_pending = 0;
+      x->awaiting = 1; x->next_qperiod = x->marker_ext + 1; x->quiescent_marker_ext = x->marker_ext;
+      continue;
+    }
+    if (!none) {
+      dpor_pend p = x->pend[chosen];
+      x->pend[chosen] = x->pend[x->n_pend - 1];
+      x->n_pend--;
+      uint32_t snd = W_SRC(p.word), rcv = W_DST(p.word);
+      if ((snd < DEMI_MAX_ACTORS && ((x->isolated >> snd) & 1)) || ((x->isolated >> rcv) & 1)) {
+        if (snd == rcv) { x->flags |= DEMI_V_SELFMSG; break; }  /* (:631-633) */
+        continue;                                     /* discarded, schedule again (:626-635) */
+      }
+      uint64_t key = dpor_key_of(x, &p);
+      int ti = dpor_trace_push(x, key, p.word, p.parent, 1);
+      if (ti < 0) break;
+      x->trace[ti].qperiod = p.qperiod;
+      x->parent = (uint32_t)ti;                       /* setParentEvent (:636-639) */
+      dpor_deliver(x, p.word);
+      continue;
+    }
+    /* ---- notify_quiescence (:855-942) */
+    if (x->awaiting) {
+      x->awaiting = 0;
+      x->qperiod = x->next_qperiod; x->next_qperiod = 0;
+      int ti = dpor_trace_push(x, DPOR_MARKER_KEY(x->quiescent_marker_ext), 0, x->cur_root, 2);
+      if (ti < 0) break;
+      x->trace[ti].qperiod = (uint8_t)x->qperiod;
+      x->cur_root = (uint32_t)ti; x->parent = (uint32_t)ti;
+      ext_idx = dpor_run_external(x, ext, n_ext, ext_idx);
+      continue;
+    }
+    break; /* end of this interleaving */
+  }
+
+  int aborted = (x->flags & (OVF_ANY | DEMI_V_TRACE_OVF | DEMI_V_SELFMSG)) != 0;
+  if (!aborted) { /* checkInvariant (:394-418) */
+    uint32_t fp = orc_invariant(m, x->state, (1u << m->n_actors) - 1);
+    if (fp) {
+      if (!par->looking_for_valid) viol = fp;
+      else if (((fp ^ par->looking_for) & m->fp_match_mask) == 0) viol = par->looking_for;
+    }
+  }
+  for (uint32_t a = 0; a < m->n_actors; a++) hash_step(&x->hash, x->state[a]);
+
+  /* ---- dpor(): racing pairs (:1122-1139) with isCoEnabeled (:1091-1110) and analyze_dep (:1043-1077) */
+  uint32_t np = 0, pairs_ovf = 0;
+  if (!aborted) {
+    for (uint32_t l = 0; l < x->n_trace; l++) {
+      if (trace[l].kind != 1) continue;
+      for (uint32_t e = 0; e < l; e++) {
+        if (trace[e].kind != 1) continue;
+        if (W_DST(trace[e].word) != W_DST(trace[l].word)) continue;
+        if (trace[e].qperiod != trace[l].qperiod) continue;
+        /* later.pathTo(earlier): is `e` an ancestor of `l`?  also collect l's ancestors for the LCA */
+        int anc = 0;
+        for (uint32_t k = l; k != 0;) { k = trace[k].parent; if (k == e) { anc = 1; break; } }
+        if (anc) continue;
+        /* getCommonPrefix(earlier, later).last: deepest common ancestor, as a trace index */
+        uint32_t a = e, b = l;
+        while (a != b) { if (a > b) a = trace[a].parent; else b = trace[b].parent; }
+        if (np < par->max_pairs) { pairs[np].branch = (uint8_t)a; pairs[np].later = (uint8_t)l; pairs[np].earlier = (uint8_t)e; pairs[np].pad = 0; np++; }
+        else pairs_ovf = 1;
+      }
+    }
+  }
+
+  if (aborted) {
+    out->flags = x->flags & (OVF_ANY | DEMI_V_TRACE_OVF | DEMI_V_SELFMSG); out->fingerprint = 0; out->hash = 0;
+    *trace_len = 0; *n_pairs = 0;
+  } else {
+    out->flags = (viol ? DEMI_V_VIOLATION : 0) | (pairs_ovf ? DEMI_V_PAIRS_OVF : 0) |
+                 ((x->count > max_messages) ? DEMI_V_MAXMSG : 0) | ((x->deliveries & 0xFFFF) << 16);
+    out->fingerprint = viol; out->hash = x->hash;
+    *trace_len = x->n_trace; *n_pairs = np;
+  }
+  free(x);
+  return DEMI_OK;
+}

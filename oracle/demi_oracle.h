@@ -66,6 +66,13 @@ int orc_sts_replay_batch(const demi_model* m, const demi_ext_event* original_ext
                          const demi_rec_event* original_rec, uint32_t n_rec, const uint64_t* masks, uint64_t n,
                          const demi_limits* lim, demi_verdict* out, int n_threads);
 
+/* ---- K3: one DPORwHeuristics interleaving (V/schedulers/DPORwHeuristics.scala:421-942) + the racing-pair
+ * analysis of dpor() (:1020-1139).  prefix: nextTrace as node keys.  trace: [DEMI_DPOR_MAX_TRACE]. */
+int orc_dpor_execute(const demi_model* m, const demi_ext_event* ext, uint32_t n_ext, const uint64_t* prefix,
+                     uint32_t prefix_len, const demi_dpor_params* par, demi_verdict* out,
+                     demi_dpor_trace_entry* trace, uint32_t* trace_len, demi_dpor_pair* pairs, uint32_t* n_pairs);
+int orc_dpor_trace_validate(const demi_model* m, const demi_ext_event* ev, uint32_t n, char* err, size_t err_cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -44,6 +44,9 @@ def lib():
                                  C.c_uint8, C.c_uint8, C.c_uint32, C.c_void_p, C.c_uint32]
         L.orc_sts_replay_batch.argtypes = [C.POINTER(T.ModelStruct), C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
                                            C.c_void_p, C.c_uint64, C.POINTER(T.Limits), C.c_void_p, C.c_int]
+        L.orc_dpor_execute.argtypes = [C.POINTER(T.ModelStruct), C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
+                                       C.POINTER(T.DporParams), C.POINTER(T.Verdict), C.c_void_p, C.POINTER(C.c_uint32),
+                                       C.c_void_p, C.POINTER(C.c_uint32)]
         _LIB = L
     return _LIB
 
@@ -118,3 +121,24 @@ def sts_replay_batch(model, original_externals, original_trace, masks, limits, n
                                     masks.ctypes.data, len(masks), C.byref(limits), out.ctypes.data, n_threads)
     assert rc == 0
     return out
+
+
+def dpor_batch(model, externals, prefixes, params):
+    """One DPORwHeuristics interleaving per prefix on the CPU; same return shape as Context.dpor_batch."""
+    ms = model.to_struct()
+    ev = np.ascontiguousarray(externals, dtype=T.EXT_EVENT_DTYPE)
+    verdicts = np.zeros(len(prefixes), dtype=T.VERDICT_DTYPE)
+    traces, pairs = [], []
+    for i, p in enumerate(prefixes):
+        keys = np.ascontiguousarray(np.asarray(p, dtype=T.DPOR_TRACE_DTYPE)["key"], dtype=np.uint64)
+        v = T.Verdict()
+        tr = np.zeros(T.DPOR_MAX_TRACE, dtype=T.DPOR_TRACE_DTYPE)
+        pr = np.zeros(max(1, params.max_pairs), dtype=T.DPOR_PAIR_DTYPE)
+        tl, npr = C.c_uint32(0), C.c_uint32(0)
+        rc = lib().orc_dpor_execute(C.byref(ms), ev.ctypes.data, len(ev), keys.ctypes.data if len(keys) else None, len(keys),
+                                    C.byref(params), C.byref(v), tr.ctypes.data, C.byref(tl), pr.ctypes.data, C.byref(npr))
+        assert rc == 0
+        verdicts[i] = (v.flags, v.fingerprint, v.hash)
+        traces.append(tr[:tl.value].copy())
+        pairs.append(pr[:npr.value].copy())
+    return verdicts, traces, pairs

@@ -1,0 +1,94 @@
+"""GPU parity suite for K3 (DPORwHeuristics interleavings + racing pairs): per-interleaving
+outputs (verdict, trace, pair list) bit-exact vs the oracle, and whole explorations identical."""
+import numpy as np
+import pytest
+
+from demi_amd import types as T
+from demi_amd import model as M
+from demi_amd.apps import raft5_config3
+from demi_amd.dpor import DPORwHeuristics
+from demi_amd.fuzzer import events_to_array, send, start, wait_quiescence
+from demi_amd.schedulers import SchedulerConfig, ViolationFingerprint
+
+pytestmark = pytest.mark.gpu
+
+
+def same_batch(g, c):
+    gv, gt, gp = g
+    cv, ct, cp = c
+    assert (gv == cv).all(), (gv[gv != cv][:3], cv[gv != cv][:3])
+    for a, b in zip(gt, ct):
+        assert len(a) == len(b) and (a == b).all()
+    for a, b in zip(gp, cp):
+        assert len(a) == len(b) and (a == b).all()
+
+
+def collect_prefixes(oracle, model, ev, depth, batch, budget):
+    """Run an oracle-backed exploration and keep every prefix it launched."""
+    launched = []
+
+    def backend(m, e, prefixes, params):
+        launched.extend(prefixes)
+        return oracle.dpor_batch(m, e, prefixes, params)
+
+    d = DPORwHeuristics(SchedulerConfig(model=model), depth_bound=depth, stopIfViolationFound=False, batch=batch, backend=backend)
+    res = d.explore(ev, max_interleavings=budget)
+    return launched, res, d
+
+
+@pytest.mark.parametrize("cfg", ["raft3", "raft5", "quiescence"])
+def test_per_interleaving_outputs_match_the_oracle(gpu_ctx, oracle, cfg):
+    if cfg == "raft3":
+        model = M.raft_model(3)
+        ev = events_to_array([start(a) for a in range(3)] + [send(a, M.M_BOOTSTRAP) for a in range(3)])
+    elif cfg == "raft5":
+        model, ev, _ = raft5_config3()
+    else:
+        model = M.raft_model(3)
+        ev = events_to_array([start(0), start(1), send(0, M.M_BOOTSTRAP), send(1, M.M_BOOTSTRAP), wait_quiescence(), start(2),
+                              send(2, M.M_BOOTSTRAP), send(0, M.M_CLIENT, 1), wait_quiescence(), send(1, M.M_CLIENT, 2)])
+    prefixes, res, _ = collect_prefixes(oracle, model, ev, 30, 32, 160)
+    assert len(prefixes) >= 128
+    gpu_ctx.model_load(model.to_struct())
+    gpu_ctx.dpor_load(ev)
+    for par in (T.DporParams(30, 0, 0, 0, 64, 4096), T.DporParams(12, 0, 0, 0, 64, 4096), T.DporParams(30, 40, 0, 0, 64, 64),
+                T.DporParams(30, 0, 0, 0, 3, 4096), T.DporParams(30, 0, 1, 0x1000103, 64, 4096)):
+        g = gpu_ctx.dpor_batch(prefixes, par)
+        c = oracle.dpor_batch(model, ev, prefixes, par)
+        same_batch(g, c)
+    # capacity verdicts appear and agree
+    tiny = gpu_ctx.dpor_batch(prefixes[:64], T.DporParams(30, 0, 0, 0, 3, 4096))[0]
+    assert (tiny["flags"] & T.V_PENDING_OVF).any()
+    unbounded = gpu_ctx.dpor_batch(prefixes[:8], T.DporParams(0, 0, 0, 0, 64, 16))
+    same_batch(unbounded, oracle.dpor_batch(model, ev, prefixes[:8], T.DporParams(0, 0, 0, 0, 64, 16)))
+
+
+@pytest.mark.parametrize("batch", [1, 64])
+def test_whole_exploration_identical_gpu_vs_oracle_backend(oracle, batch):
+    model = M.raft_model(3)
+    ev = events_to_array([start(a) for a in range(3)] + [send(a, M.M_BOOTSTRAP) for a in range(2)])
+    budget = 100 if batch == 1 else 800
+    dg = DPORwHeuristics(SchedulerConfig(model=model), depth_bound=30, stopIfViolationFound=False, batch=batch)
+    rg = dg.explore(ev, max_interleavings=budget)
+    dc = DPORwHeuristics(SchedulerConfig(model=model), depth_bound=30, stopIfViolationFound=False, batch=batch, backend=oracle.dpor_batch)
+    rc = dc.explore(ev, max_interleavings=budget)
+    assert rg.rounds == rc.rounds and rg.exhausted == rc.exhausted and rg.violations == rc.violations
+    assert len(rg.interleavings) == len(rc.interleavings)
+    for a, b in zip(rg.interleavings, rc.interleavings):
+        assert a.verdict == b.verdict and (a.trace == b.trace).all() and a.prefix_len == b.prefix_len
+    dg.shutdown()
+
+
+def test_config3_bounded_exploration_raft5(oracle):
+    """BASELINE config 3 (depth 30, Start x 5 + Bootstrap x 5), a budgeted slice of it: every explored
+    interleaving is a distinct backtrack point, and sampled interleavings replay identically on the oracle."""
+    model, ev, depth = raft5_config3()
+    d = DPORwHeuristics(SchedulerConfig(model=model), depth_bound=depth, stopIfViolationFound=False, batch=512)
+    res = d.explore(ev, max_interleavings=1500)
+    assert len(res.interleavings) == 1500 and not res.exhausted and len(res.rounds) <= 5
+    assert len(res.schedule_hashes()) > 500
+    for k in (0, 1, 700, 1499):
+        il = res.interleavings[k]
+        v, t, _ = oracle.dpor_batch(model, ev, [il.trace], T.DporParams(depth, 0, 0, 0, 64, 4096))
+        assert v[0] == il.verdict and (t[0] == il.trace).all()
+    d.shutdown()
