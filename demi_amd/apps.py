@@ -49,3 +49,16 @@ def raft5_config3(n_sends=5):
     model = raft_model(5)
     events = events_to_array([start(a) for a in range(5)] + [send(a % 5, M_BOOTSTRAP) for a in range(n_sends)])
     return model, events, 30
+
+
+def shuffle8_config5():
+    """BASELINE config 5: the Spark-like 2-stage shuffle job (8 actors, 3 actor classes) for bounded
+    DPOR exploration (Start / Send only) and for fuzzing.  Spark's actors are not in the reference:
+    synthetic only, parity vs real Spark unpinned."""
+    from .fuzzer import send, start, wait_quiescence
+    from .model import SH_SPECULATE, SH_SUBMIT, shuffle_model
+    model = shuffle_model()
+    dpor_events = events_to_array([start(a) for a in range(8)] + [send(0, SH_SUBMIT), send(0, SH_SPECULATE, 1)])
+    fuzz_events = events_to_array([start(a) for a in range(8)] + [send(0, SH_SUBMIT), send(0, SH_SPECULATE, 1),
+                                                                  send(0, SH_SPECULATE, 3), wait_quiescence()])
+    return model, dpor_events, fuzz_events, T.Limits(400, 0, 64, 0, 0, 0)

@@ -341,3 +341,88 @@ def save_model(model: Model, path: str):
 def load_model(path: str) -> Model:
     with open(path) as f:
         return Model.from_json(json.load(f))
+
+
+# --------------------------------------------------------------------------- shuffle-synth
+# A 2-stage shuffle job standing in for the Spark application of NetSys/demi-applications
+# (branches spark-2294/3150/9256), which is not in the reference: one driver, two stage
+# coordinators, five workers, three actor classes.  Seeded bug: the driver starts stage 2 as soon
+# as it has counted `n_workers` MapDone reports, and counts a duplicate report from a re-launched
+# task twice, so stage 2 can start while a map output is still missing.
+SH_MSGS = [("Submit", T.MSG_EXTERNAL), ("Speculate", T.MSG_EXTERNAL), ("LaunchStage", T.MSG_INTERNAL),
+           ("RunTask", T.MSG_INTERNAL), ("MapDone", T.MSG_INTERNAL), ("StageDone", T.MSG_INTERNAL),
+           ("Fetch", T.MSG_INTERNAL), ("FetchReply", T.MSG_INTERNAL), ("TaskTimeout", T.MSG_TIMER)]
+(SH_SUBMIT, SH_SPECULATE, SH_LAUNCH, SH_RUN, SH_MAPDONE, SH_STAGEDONE, SH_FETCH, SH_FETCHREPLY, SH_TIMEOUT) = range(9)
+CLS_DRIVER, CLS_COORD, CLS_WORKER = 0, 1, 2
+
+
+def shuffle_model(buggy=True) -> Model:
+    """Actors: 0 driver, 1 map-stage coordinator, 2 reduce-stage coordinator, 3..7 workers."""
+    n_workers = 5
+    h = {}
+    # ---- driver: F0 phase (0 idle, 1 map, 2 reduce, 3 done), F1 reports counted, F2 bitmask of workers reported
+    a = Asm()
+    a.if_eq(F[0], 0, "x").mov(F[0], 1).mov(T0, 1).send(SH_LAUNCH, T0, T1, 0).label("x")
+    h[(CLS_DRIVER, "Submit")] = a
+    a = Asm()          # Speculate(w): ask the map coordinator to re-launch worker w's task
+    a.if_eq(F[0], 1, "x").mov(T0, 1).send(SH_LAUNCH, T0, P0, 1).label("x")
+    h[(CLS_DRIVER, "Speculate")] = a
+    a = Asm()          # StageDone(stage) from a coordinator
+    a.if_eq(P0, 1, "s2")
+    a.if_eq(F[0], 1, "x").mov(F[0], 2).mov(T0, 2).send(SH_LAUNCH, T0, T1, 0).halt()
+    a.label("s2").if_eq(F[0], 2, "x").mov(F[0], 3).label("x")
+    h[(CLS_DRIVER, "StageDone")] = a
+    # ---- map coordinator (actor 1): F0 started, F1 done count, F2 done mask
+    a = Asm()          # LaunchStage(w, relaunch): relaunch=0 -> all workers; relaunch=1 -> worker 3+w only
+    a.if_eq(P1, 0, "re").if_eq(F[0], 0, "x").mov(F[0], 1)
+    for w in range(n_workers):
+        a.mov(T0, 3 + w).mov(T1, 1).send(SH_RUN, T0, T1, 0)
+    a.halt()
+    a.label("re").lt(T2, P0, n_workers).if_ne(T2, 0, "x").add(T0, P0, 3).mov(T1, 1).send(SH_RUN, T0, T1, 0).label("x")
+    h[(CLS_COORD, "LaunchStage")] = a
+    a = Asm()          # MapDone from worker SRC
+    a.sub(T0, SRC, 3).mov(T1, 1).shl(T1, T1, T0)            # bit of the reporting worker
+    if buggy:
+        a.add(F[1], F[1], 1).or_(F[2], F[2], T1)            # bug: duplicates are counted
+    else:
+        a.and_(T2, F[2], T1).if_eq(T2, 0, "x").add(F[1], F[1], 1).or_(F[2], F[2], T1)
+    a.if_eq(F[1], n_workers, "x").if_eq(F[3], 0, "x").mov(F[3], 1).mov(T0, 0).mov(T1, 1).send(SH_STAGEDONE, T0, T1, 0).label("x")
+    h[(CLS_COORD, "MapDone")] = a
+    # ---- reduce coordinator (actor 2) shares the class: LaunchStage(_, 0) on actor 2 starts the reducers;
+    # distinguish by ME inside the handlers above is avoided by giving the reducer its own rows via SRC
+    # (stage 2 launch arrives from the driver with P1 == 0 and ME == 2): handled by RunTask kind 2 below
+    # ---- workers: F0 has map output, F1 fetched count, F2 fetch-missing flag (violation), F3 ran reduce
+    a = Asm()          # RunTask(kind): 1 = map (arm a task timeout, produce output, report); 2 = reduce (fetch from all)
+    a.if_eq(P0, 1, "red").mov(F[0], 1).tcancel(SH_TIMEOUT).tset(SH_TIMEOUT).mov(T0, 1).send(SH_MAPDONE, T0, T1, 0).halt()
+    a.label("red").if_eq(F[3], 0, "x").mov(F[3], 1).bcast(SH_FETCH, T1, 0).label("x")
+    h[(CLS_WORKER, "RunTask")] = a
+    a = Asm()          # Fetch from a reducer: reply with whether the map output exists
+    a.send(SH_FETCHREPLY, SRC, F[0], 0)
+    h[(CLS_WORKER, "Fetch")] = a
+    a = Asm()          # FetchReply(has_output)
+    a.add(F[1], F[1], 1).if_eq(P0, 0, "x").mov(F[2], 1).label("x")
+    h[(CLS_WORKER, "FetchReply")] = a
+    a = Asm()          # TaskTimeout: a straggler detector re-reports (duplicate MapDone)
+    a.if_eq(F[0], 1, "x").if_lt(F[4], 1, "x").add(F[4], F[4], 1).mov(T0, 1).send(SH_MAPDONE, T0, T1, 0).label("x")
+    h[(CLS_WORKER, "TaskTimeout")] = a
+    # coordinators ignore worker-only messages and vice versa (handler_start 0xFFFF)
+    # reduce coordinator: LaunchStage on actor 2 -> RunTask(2) to all workers
+    red = Asm()
+    red.if_eq(ME, 2, "map")
+    for w in range(n_workers):
+        red.mov(T0, 3 + w).mov(T1, 2).send(SH_RUN, T0, T1, 0)
+    red.halt()
+    red.label("map")
+    # fall through into the map coordinator's LaunchStage rows
+    base = h[(CLS_COORD, "LaunchStage")].finish()
+    fix_rows = red.rows
+    for idx, label in red._fix:
+        dist = red._labels[label] - (idx + 1)
+        fix_rows[idx] |= dist << 17
+    merged = Asm()
+    merged.rows = fix_rows + base
+    h[(CLS_COORD, "LaunchStage")] = merged
+    init = [[0] * 8 for _ in range(8)]
+    return build_model("shuffle8-synth%s" % ("" if buggy else "-fixed"), 8, SH_MSGS, h, init,
+                       invariant=(T.INV_NEVER, 2, 1, 0), actor_class=[CLS_DRIVER, CLS_COORD, CLS_COORD] + [CLS_WORKER] * 5,
+                       n_classes=3)

@@ -273,3 +273,15 @@ def test_full_size_properties_1m(gpu_ctx, oracle):
     for lo in rng.integers(0, n - 4096, size=8):
         c = oracle.random_explore(model, events, 4096, seed_base=SEED_BASE + int(lo), limits=lim, n_threads=os.cpu_count())
         assert_same(a[lo:lo + 4096], c)
+
+
+def test_shuffle8_three_actor_classes(gpu_ctx, oracle):
+    """BASELINE config 5's application (8 actors, 3 classes): class-indexed handler lookup."""
+    from demi_amd.apps import shuffle8_config5
+    model, _, events, lim = shuffle8_config5()
+    g, c = both(gpu_ctx, oracle, model, events, 30000, lim)
+    assert_same(g, c)
+    assert (g["flags"] & T.V_VIOLATION).sum() > 500
+    g, c = both(gpu_ctx, oracle, M.shuffle_model(buggy=False), events, 30000, lim)
+    assert_same(g, c)
+    assert not (g["flags"] & T.V_VIOLATION).any()

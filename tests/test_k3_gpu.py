@@ -92,3 +92,18 @@ def test_config3_bounded_exploration_raft5(oracle):
         v, t, _ = oracle.dpor_batch(model, ev, [il.trace], T.DporParams(depth, 0, 0, 0, 64, 4096))
         assert v[0] == il.verdict and (t[0] == il.trace).all()
     d.shutdown()
+
+
+def test_config5_shuffle8_bounded_dpor(oracle):
+    """BASELINE config 5 (single GPU leg): bounded exhaustive DPOR over the 8-actor, 3-class shuffle job
+    runs to an empty backtrack queue; the exploration is identical with the oracle backend."""
+    from demi_amd.apps import shuffle8_config5
+    model, ev, _, _ = shuffle8_config5()
+    d = DPORwHeuristics(SchedulerConfig(model=model), depth_bound=30, stopIfViolationFound=False, batch=256)
+    res = d.explore(ev, max_interleavings=4000)
+    dc = DPORwHeuristics(SchedulerConfig(model=model), depth_bound=30, stopIfViolationFound=False, batch=256, backend=oracle.dpor_batch)
+    rc = dc.explore(ev, max_interleavings=4000)
+    assert res.exhausted and rc.exhausted and res.rounds == rc.rounds and res.violations == rc.violations
+    assert len(res.interleavings) > 1000
+    assert all(a.verdict == b.verdict and (a.trace == b.trace).all() for a, b in zip(res.interleavings, rc.interleavings))
+    d.shutdown()
