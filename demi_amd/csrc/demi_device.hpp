@@ -80,17 +80,23 @@ __device__ __forceinline__ uint32_t fld(uint64_t s, uint32_t f) { return (uint32
 
 __device__ inline uint32_t invariant_code(const DevModel* __restrict__ gm, const uint64_t* st, uint32_t exists,
                                           uint32_t A, uint32_t kind, uint32_t fa, uint32_t va, uint32_t fb) {
-  uint32_t vmask = 0;       // actors with F[fa] == va   (kinds 1, 2) / F[fa] != 0 (kind 3)
+  // fast path first: which created actors "hit" (F[fa] == va, or F[fa] != 0 for AGREE).  Almost every
+  // check ends here (fewer than two hits), so the pair logic below is rarely entered by any lane.
+  uint32_t vmask = 0;
+  const uint32_t sa = 8 * fa;
+  for (uint32_t i = 0; i < A; i++) {
+    const uint32_t a = (uint32_t)(st[i * 64] >> sa) & 0xFF;
+    const bool hit = (kind == DEMI_INV_AGREE) ? (a != 0) : (a == va);
+    vmask |= (uint32_t)hit << i;
+  }
+  vmask &= exists;
+  if (kind == DEMI_INV_NEVER) return vmask ? ((2u << 24) | vmask) : 0u;
+  if (kind == DEMI_INV_NONE || (vmask & (vmask - 1)) == 0) return 0u;   // needs at least two hits
+  // slow path: group keys of the hit actors
+  const uint32_t sb = 8 * fb;
   uint32_t key[DEMI_MAX_ACTORS];
 #pragma unroll
-  for (uint32_t i = 0; i < DEMI_MAX_ACTORS; i++) {
-    uint64_t s = (i < A) ? st[i * 64] : 0;
-    const uint32_t a = fld(s, fa);
-    const bool hit = (kind == DEMI_INV_AGREE) ? (a != 0) : (a == va);
-    if (i < A && ((exists >> i) & 1) && hit) vmask |= 1u << i;
-    key[i] = fld(s, fb);
-  }
-  if (kind == DEMI_INV_NEVER) return vmask ? ((2u << 24) | vmask) : 0u;
+  for (uint32_t i = 0; i < DEMI_MAX_ACTORS; i++) key[i] = (i < A) ? ((uint32_t)(st[i * 64] >> sb) & 0xFF) : 0u;
   if (kind == DEMI_INV_AGREE) {
     bool have = false, bad = false;
     uint32_t first = 0;
@@ -103,24 +109,22 @@ __device__ inline uint32_t invariant_code(const DevModel* __restrict__ gm, const
     }
     return bad ? ((3u << 24) | vmask) : 0u;
   }
-  if (kind == DEMI_INV_AT_MOST_ONE) {
-    bool found = false;
-    uint32_t k = 0;
+  // AT_MOST_ONE: lowest (i, j) pair of hits with equal keys
+  bool found = false;
+  uint32_t k = 0;
 #pragma unroll
-    for (uint32_t i = 0; i < DEMI_MAX_ACTORS; i++) {
+  for (uint32_t i = 0; i < DEMI_MAX_ACTORS; i++) {
 #pragma unroll
-      for (uint32_t j = i + 1; j < DEMI_MAX_ACTORS; j++) {
-        if (!found && ((vmask >> i) & 1) && ((vmask >> j) & 1) && key[i] == key[j]) { found = true; k = key[i]; }
-      }
+    for (uint32_t j = i + 1; j < DEMI_MAX_ACTORS; j++) {
+      if (!found && ((vmask >> i) & 1) && ((vmask >> j) & 1) && key[i] == key[j]) { found = true; k = key[i]; }
     }
-    if (!found) return 0u;
-    uint32_t mask = 0;
-#pragma unroll
-    for (uint32_t i = 0; i < DEMI_MAX_ACTORS; i++)
-      if (((vmask >> i) & 1) && key[i] == k) mask |= 1u << i;
-    return (1u << 24) | (k << 8) | mask;
   }
-  return 0u;
+  if (!found) return 0u;
+  uint32_t mask = 0;
+#pragma unroll
+  for (uint32_t i = 0; i < DEMI_MAX_ACTORS; i++)
+    if (((vmask >> i) & 1) && key[i] == k) mask |= 1u << i;
+  return (1u << 24) | (k << 8) | mask;
 }
 
 }  // namespace demi

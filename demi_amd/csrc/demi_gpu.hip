@@ -31,6 +31,7 @@ struct demi_ctx {
   std::vector<demi_ext_event> trace;
   uint64_t* d_trace = nullptr;
   uint32_t started_mask = 0;
+  uint32_t n_batches = 1;           // injection batches: WaitQuiescence events + 1
   // scratch
   unsigned long long* d_counter = nullptr;
   demi_verdict* d_out = nullptr;
@@ -234,8 +235,11 @@ extern "C" int demi_trace_load(demi_ctx* ctx, const demi_ext_event* events, uint
   if (rc) return rc;
   ctx->trace.assign(events, events + n_events);
   ctx->started_mask = 0;
-  for (uint32_t i = 0; i < n_events; i++)
+  ctx->n_batches = 1;
+  for (uint32_t i = 0; i < n_events; i++) {
     if (events[i].kind == DEMI_EV_START) ctx->started_mask |= 1u << events[i].a;
+    if (events[i].kind == DEMI_EV_WAIT_QUIESCENCE) ctx->n_batches++;
+  }
   static_assert(sizeof(demi_ext_event) == 8, "event is one 8-byte word");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   if (n_events)
@@ -251,7 +255,8 @@ static int launch_k1(demi_ctx* ctx, uint32_t p_max, K1Args a, hipStream_t stream
   if (p_max == 0) p_max = 64;
   if (p_max > DEMI_MAX_PENDING) return fail(ctx, DEMI_ERR_INVALID_ARG, "p_max must be 1..%d", DEMI_MAX_PENDING);
   a.p_max = p_max;
-  const size_t lds = k1_lds_bytes<REC>(h.code_len, a.n_ev, h.n_classes * h.n_msg_types, h.n_actors);
+  a.n_batches = ctx->n_batches;
+  const size_t lds = k1_lds_bytes<REC>(h.code_len, a.n_ev, h.n_classes * h.n_msg_types, h.n_actors, a.n_batches);
   if (lds > 160 * 1024) return fail(ctx, DEMI_ERR_INVALID_ARG, "LDS budget exceeded (%zu bytes)", lds);
   auto kern = k1_random_explore<REC>;
   HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -278,8 +283,32 @@ static int launch_k1(demi_ctx* ctx, uint32_t p_max, K1Args a, hipStream_t stream
   }
   a.spill = ctx->d_spill;
   HIP_TRY(ctx, hipMemsetAsync(a.work_counter, 0, sizeof(unsigned long long), stream));
+#ifdef DEMI_K1_PHASES
+  // diagnostic build only (tools/k1_phases.sh): per-phase cycle totals of every wave
+  static unsigned long long* d_ph = nullptr;
+  const size_t n_ph = (size_t)blocks * K1_WAVES * 8;
+  if (!d_ph) HIP_TRY(ctx, hipMalloc(&d_ph, sizeof(unsigned long long) * 8 * 4096 * K1_WAVES));
+  HIP_TRY(ctx, hipMemsetAsync(d_ph, 0, sizeof(unsigned long long) * n_ph, stream));
+  a.phase_out = d_ph;
+#endif
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(K1_WAVES * 64), lds, stream, a);
   HIP_TRY(ctx, hipGetLastError());
+#ifdef DEMI_K1_PHASES
+  {
+    HIP_TRY(ctx, hipStreamSynchronize(stream));
+    std::vector<unsigned long long> h(n_ph);
+    HIP_TRY(ctx, hipMemcpy(h.data(), d_ph, sizeof(unsigned long long) * n_ph, hipMemcpyDeviceToHost));
+    unsigned long long tot[8] = {0};
+    for (size_t i = 0; i < n_ph; i++) tot[i & 7] += h[i];
+    double all = 0;
+    for (int i = 0; i < 6; i++) all += (double)tot[i];
+    const char* names[6] = {"refill+finish", "inject", "sched", "rows", "apply", "tail"};
+    fprintf(stderr, "[k1 phases] waves=%zu", n_ph / 8);
+    for (int i = 0; i < 6; i++) fprintf(stderr, " %s=%.1f%%", names[i], 100.0 * (double)tot[i] / all);
+    fprintf(stderr, " iters/wave=%.0f active-lanes/iter=%.1f cycles/iter=%.0f\n", (double)tot[6] / (n_ph / 8),
+            (double)tot[7] / (double)tot[6], all / (double)tot[6]);
+  }
+#endif
   return DEMI_OK;
 }
 

@@ -35,6 +35,8 @@ struct K1Args {
   demi_rec_event* rec_out;  // REC only: [n][rec_cap]
   uint32_t* rec_count;      // REC only: [n]
   uint32_t rec_cap;
+  uint32_t n_batches;       // WaitQuiescence events + 1
+  unsigned long long* phase_out;   // -DDEMI_K1_PHASES builds only: [waves][8] cycle totals per phase
 };
 
 enum : int { PH_IDLE = 0, PH_INJECT = 1, PH_DISPATCH = 2, PH_FINISH = 3 };
@@ -42,16 +44,52 @@ enum : int { PH_IDLE = 0, PH_INJECT = 1, PH_DISPATCH = 2, PH_FINISH = 3 };
 constexpr int K1_WAVES = 4;          // waves per workgroup
 constexpr int K1_BATCH = 64;         // schedule indices claimed per atomic
 
+// K1 keeps two more workgroup-shared tables derived from the trace: the network state after every
+// injection batch (inject_until_quiescence is schedule-independent: the events are applied in trace
+// order whatever the interleaving, so the state after batch j is a function of j alone) and the
+// message word of every Send (0 = not a deliverable Send).
+constexpr uint32_t K1_BATCH_WORDS = 6;   // end index, inaccessible, killed, partitioned lo/hi, pad
+__host__ __device__ inline size_t k1_extra_lds_bytes(uint32_t n_ev, uint32_t n_batches) {
+  return (((size_t)n_batches * K1_BATCH_WORDS + n_ev) * 4 + 15) & ~(size_t)15;
+}
 template <bool REC>
-__host__ __device__ inline size_t k1_lds_bytes(uint32_t code_len, uint32_t n_ev, uint32_t n_hs, uint32_t n_actors) {
-  return tables_lds_bytes(code_len, n_ev, n_hs) + K1_WAVES * lane_mem_wave_bytes(n_actors, REC);
+__host__ __device__ inline size_t k1_lds_bytes(uint32_t code_len, uint32_t n_ev, uint32_t n_hs, uint32_t n_actors,
+                                               uint32_t n_batches) {
+  return tables_lds_bytes(code_len, n_ev, n_hs) + k1_extra_lds_bytes(n_ev, n_batches) +
+         K1_WAVES * lane_mem_wave_bytes(n_actors, REC);
 }
 
 template <bool REC>
 __global__ __launch_bounds__(K1_WAVES * 64) void k1_random_explore(const K1Args args) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Tables t;
-  unsigned char* wave_base = tables_load(t, smem, args.model, args.trace, args.n_ev, args.exists);
+  unsigned char* extra = tables_load(t, smem, args.model, args.trace, args.n_ev, args.exists);
+  uint32_t* const s_batch = reinterpret_cast<uint32_t*>(extra);
+  uint32_t* const s_sendw = s_batch + (size_t)args.n_batches * K1_BATCH_WORDS;
+  unsigned char* wave_base = extra + k1_extra_lds_bytes(args.n_ev, args.n_batches);
+  if (threadIdx.x == 0) {
+    // EventOrchestrator.inject_until_quiescence (:132-189) once per workgroup, for every batch
+    uint32_t inacc = t.exists, killed = 0, b_no = 0;
+    uint64_t part = 0;
+    if (t.E == 0) { s_batch[0] = 0; s_batch[1] = inacc; s_batch[2] = 0; s_batch[3] = 0; s_batch[4] = 0; s_batch[5] = 0; }
+    for (uint32_t i = 0; i < t.E; i++) {
+      const uint64_t ev = t.trace[i];
+      const uint32_t kind = (uint32_t)ev & 0xFF, a = (uint32_t)(ev >> 8) & 0xFF, b = (uint32_t)(ev >> 16) & 0xFF;
+      s_sendw[i] = (kind == DEMI_EV_SEND && ((t.exists >> a) & 1))
+                       ? msg_word((uint32_t)(ev >> 24) & 0xFF, DEMI_DEADLETTERS, a, (uint32_t)(ev >> 32) & 0xFF, (uint32_t)(ev >> 40) & 0xFF)
+                       : 0u;
+      if (kind == DEMI_EV_START) { inacc &= ~(1u << a); killed &= ~(1u << a); }
+      else if (kind == DEMI_EV_KILL) { killed |= 1u << a; inacc |= 1u << a; }
+      else if (kind == DEMI_EV_PARTITION) part |= 1ULL << (a * 8 + b);
+      else if (kind == DEMI_EV_UNPARTITION) part &= ~(1ULL << (a * 8 + b));
+      if (kind == DEMI_EV_WAIT_QUIESCENCE || i + 1 == t.E) {
+        uint32_t* o = s_batch + (size_t)b_no * K1_BATCH_WORDS;
+        o[0] = i + 1; o[1] = inacc; o[2] = killed; o[3] = (uint32_t)part; o[4] = (uint32_t)(part >> 32); o[5] = 0;
+        b_no++;
+      }
+    }
+  }
+  __syncthreads();
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const LaneMem mem = lane_mem_carve(wave_base + (size_t)wave * lane_mem_wave_bytes(t.A, REC), t.A, REC, lane, args.spill,
                                      (size_t)blockIdx.x * blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x);
@@ -66,7 +104,7 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k1_random_explore(const K1Args 
   int ph = PH_IDLE;
   bool fresh = false;
   uint64_t sched = 0, rng = 0, hash = 0;
-  uint32_t n_pend = 0, count = 0, cnt_mod = 0, tidx = 0, inj_lo = 0, inj_hi = 0;
+  uint32_t n_pend = 0, count = 0, cnt_mod = 0, tidx = 0, inj_lo = 0, inj_hi = 0, batch_no = 0;
   Net net = {0, 0, 0};
   uint64_t tq = 0, resend = 0;        // messagesToSend timers / timersToResend: 1 byte each (rcv<<5 | type)
   uint32_t n_tq = 0, n_resend = 0;
@@ -126,6 +164,13 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k1_random_explore(const K1Args 
     return fp;
   };
 
+#ifdef DEMI_K1_PHASES
+  uint64_t ph_t[6] = {0, 0, 0, 0, 0, 0}, ph_iters = 0, ph_rows = 0, ph_active = 0;
+#define PH_MARK(I) do { const uint64_t now_ = __builtin_readcyclecounter(); ph_t[I] += now_ - ph_last; ph_last = now_; } while (0)
+  uint64_t ph_last = __builtin_readcyclecounter();
+#else
+#define PH_MARK(I) do {} while (0)
+#endif
   for (;;) {
     // ------------------------------------------------------------ refill idle lanes
     {
@@ -150,6 +195,7 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k1_random_explore(const K1Args 
       }
       if (__ballot(ph != PH_IDLE) == 0) break;           // nothing running and nothing left to claim
     }
+    PH_MARK(0);
 
     // ------------------------------------------------------------ (re)initialise + inject
     if (ph == PH_INJECT) {
@@ -163,11 +209,19 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k1_random_explore(const K1Args 
         net.inaccessible = exists; net.killed = 0; net.partitioned = 0;
         for (uint32_t a = 0; a < A; a++) st[a * 64] = t.init[a];
         if (REC) { rec = args.rec_out + sched * (uint64_t)args.rec_cap; n_rec = 0; next_id = 1; }
+        batch_no = 0;
       }
       // EventOrchestrator.inject_until_quiescence (:132-189).  Send events are not materialised:
       // messagesToSend's external part is the index range [inj_lo, inj_hi) of the trace.
       inj_lo = tidx;
-      bool loop = true;
+      if (!REC) {
+        // the batch's effect on the network state is a table lookup (computed once per workgroup)
+        const uint32_t* bt = s_batch + (size_t)batch_no * K1_BATCH_WORDS;
+        batch_no++;
+        tidx = bt[0];
+        net.inaccessible = bt[1]; net.killed = bt[2]; net.partitioned = (uint64_t)bt[3] | ((uint64_t)bt[4] << 32);
+      }
+      bool loop = REC;     // the recording variant walks the events to emit their records
       while (loop && tidx < E) {
         const uint64_t ev = t.trace[tidx];
         const uint32_t kind = (uint32_t)ev & 0xFF, a = (uint32_t)(ev >> 8) & 0xFF, b = (uint32_t)(ev >> 16) & 0xFF;
@@ -193,6 +247,7 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k1_random_explore(const K1Args 
       ph = PH_DISPATCH;
     }
 
+    PH_MARK(1);
     // ------------------------------------------------------------ one scheduling step
     uint32_t w = 0;            // the message picked by this step
     bool deliver = false;
@@ -210,14 +265,11 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k1_random_explore(const K1Args 
         if (!none) {
           // send_external_messages (:424): injected Sends first (no partition check, :298-308) ...
           for (uint32_t i = inj_lo; i < inj_hi; i++) {
-            const uint64_t ev = t.trace[i];
-            const uint32_t kind = (uint32_t)ev & 0xFF, a = (uint32_t)(ev >> 8) & 0xFF;
-            if (kind == DEMI_EV_SEND && ((exists >> a) & 1)) {
-              const uint32_t type = (uint32_t)(ev >> 24) & 0xFF, p0 = (uint32_t)(ev >> 32) & 0xFF,
-                             p1 = (uint32_t)(ev >> 40) & 0xFF;
+            const uint32_t sw = s_sendw[i];
+            if (sw != 0) {
               const uint32_t id = next_id; if (REC) next_id++;
-              PEND_APPEND(msg_word(type, DEMI_DEADLETTERS, a, p0, p1), id);
-              REC_PUSH(DEMI_REC_MSG_SEND, DEMI_DEADLETTERS, a, type, p0, p1, 1, i, id);
+              PEND_APPEND(sw, id);
+              REC_PUSH(DEMI_REC_MSG_SEND, DEMI_DEADLETTERS, w_dst(sw), w_type(sw), w_p0(sw), w_p1(sw), 1, i, id);
             }
           }
           inj_lo = inj_hi;
@@ -276,9 +328,14 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k1_random_explore(const K1Args 
       }
     }
 
+    PH_MARK(2);
     // ------------------------------------------------------------ the receiver's handler rows
     uint32_t nfx = 0;
     if (deliver) nfx = vm_run(t, mem, w, flags);
+    PH_MARK(3);
+#ifdef DEMI_K1_PHASES
+    ph_iters++; ph_active += __popcll(__ballot(deliver));
+#endif
 
     // ------------------------------------------------------------ apply the recorded effects, in program order
     if (deliver) {
@@ -333,6 +390,7 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k1_random_explore(const K1Args 
       if (flags & DEMI_OVF_ANY) ph = PH_FINISH;
     }
 
+    PH_MARK(4);
     // ------------------------------------------------------------ verdict
     if (ph == PH_FINISH) {
       // explore(): `if (messagesScheduledSoFar <= maxMessages) checkIfBugFound` (:256-262, 156-180)
@@ -349,10 +407,19 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k1_random_explore(const K1Args 
       if (REC) args.rec_count[sched] = n_rec;
       // reset the simulator for the next schedule
       ph = PH_IDLE;
-      n_pend = 0; count = 0; cnt_mod = 0; tidx = 0; inj_lo = 0; inj_hi = 0;
+      n_pend = 0; count = 0; cnt_mod = 0; tidx = 0; inj_lo = 0; inj_hi = 0; batch_no = 0;
       tq = 0; resend = 0; n_tq = 0; n_resend = 0; just = 0; rep = 0; viol = 0; flags = 0; hash = 0;
     }
   }
+#ifdef DEMI_K1_PHASES
+  PH_MARK(5);
+  if (lane == 0 && args.phase_out) {
+    unsigned long long* o = args.phase_out + ((size_t)blockIdx.x * K1_WAVES + wave) * 8;
+    for (int i = 0; i < 6; i++) o[i] = ph_t[i];
+    o[6] = ph_iters; o[7] = ph_active;
+  }
+#endif
+#undef PH_MARK
 #undef REC_PUSH
 #undef PEND_APPEND
 #undef TIMER_BIT

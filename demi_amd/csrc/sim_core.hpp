@@ -124,9 +124,13 @@ __device__ __forceinline__ uint32_t fx_pack(uint32_t op, uint32_t type, uint32_t
   return (op & 31u) | (type << 5) | (target << 10) | (p0 << 14) | (p1 << 22);
 }
 
-__device__ __forceinline__ uint32_t reg_get(uint64_t lo, uint64_t hi, uint32_t i) {
-  const uint64_t v = (i & 8u) ? hi : lo;
-  return (uint32_t)(v >> ((i & 7u) * 8u)) & 0xFFu;
+// 16 x u8 register window held in four VGPRs: w0,w1 = r0..r7 (state), w2,w3 = r8..r15 (temps, payload,
+// sender, self).  v_perm_b32 extracts / inserts one byte without variable 64-bit shifts.
+__device__ __forceinline__ uint32_t reg_get4(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t i) {
+  const uint32_t sel = (i & 7u) | 0x0C0C0C00u;                 // byte i&7 of the 64-bit pair, upper bytes zero
+  const uint32_t lo = __builtin_amdgcn_perm(w1, w0, sel);
+  const uint32_t hi = __builtin_amdgcn_perm(w3, w2, sel);
+  return (i & 8u) ? hi : lo;
 }
 
 // Runs the handler of message word `w` on its receiver.  State is read from / written to
@@ -136,28 +140,29 @@ __device__ inline uint32_t vm_run(const Tables& t, const LaneMem& mem, uint32_t 
   const uint32_t type = w_type(w), me = w_dst(w);
   uint32_t pc = t.hs[((t.ac_packed >> (4 * me)) & 15u) * t.NT + type];
   if (pc == 0xFFFFu) return 0;
-  uint64_t lo = mem.st[me * 64];
-  uint64_t hi = ((uint64_t)w_p0(w) << 32) | ((uint64_t)w_p1(w) << 40) | ((uint64_t)w_src(w) << 48) | ((uint64_t)me << 56);
+  const uint64_t st0 = mem.st[me * 64];
+  uint32_t w0 = (uint32_t)st0, w1 = (uint32_t)(st0 >> 32);
+  uint32_t w2 = 0;                                                      // T0..T3
+  uint32_t w3 = w_p0(w) | (w_p1(w) << 8) | (w_src(w) << 16) | (me << 24);  // P0 P1 SRC ME
   uint32_t nfx = 0;
   const uint32_t code_len = t.code_len;
-  while (pc < code_len) {
+  bool running = true;
+  while (running) {
     const uint32_t row = t.code[pc];
     pc++;
     const uint32_t op = row & 0xFFu;
-    if (op == DEMI_OP_HALT) break;
     const uint32_t dsti = (row >> 8) & 15u, ai = (row >> 12) & 15u, aux = (row >> 17) & 0x7Fu, braw = row >> 24;
-    const uint32_t a = reg_get(lo, hi, ai);
-    const uint32_t breg = reg_get(lo, hi, braw & 15u);
+    const uint32_t a = reg_get4(w0, w1, w2, w3, ai);
+    const uint32_t breg = reg_get4(w0, w1, w2, w3, braw);
     const uint32_t b = (row & 0x10000u) ? braw : breg;
     // ---- relation of a and b: 0 (a<b), 1 (a==b), 2 (a>b); accepted-relation masks per compare kind
     const int32_t d = (int32_t)a - (int32_t)b;
     const uint32_t rel = (uint32_t)(min(max(d, -1), 1) + 1);                 // v_med3_i32
-    // kinds in the order EQ NE LT GE LE GT: masks over {lt=1, eq=2, gt=4}
     const bool is_if = op >= DEMI_OP_IFEQ;
-    const uint32_t ck = is_if ? op - DEMI_OP_IFEQ : op - DEMI_OP_EQ;         // only meaningful for compares
+    // compare kinds in the order EQ NE LT GE LE GT (ops 11..16 and 32..37): masks over {lt=1, eq=2, gt=4}
     constexpr uint32_t kRelMasks = 2u | (5u << 3) | (1u << 6) | (6u << 9) | (3u << 12) | (4u << 15);
-    const uint32_t relmask = (kRelMasks >> ((ck & 7u) * 3u)) & 7u;
-    const uint32_t cond = (relmask >> rel) & 1u;
+    const uint32_t ck = (op + (is_if ? 32u - DEMI_OP_IFEQ : 32u - DEMI_OP_EQ)) & 7u;
+    const uint32_t cond = (kRelMasks >> (ck * 3u + rel)) & 1u;
     // ---- ALU result classes (all computed, one selected)
     const uint32_t sh = b & 7u;
     uint32_t r = b;                                                          // MOV
@@ -170,28 +175,35 @@ __device__ inline uint32_t vm_run(const Tables& t, const LaneMem& mem, uint32_t 
     r = (op == DEMI_OP_SHR) ? (a >> sh) : r;
     r = (op == DEMI_OP_BITSET) ? (a | (1u << sh)) : r;
     r = (op == DEMI_OP_POPC) ? (uint32_t)__popc(b) : r;
-    r = (op >= DEMI_OP_EQ && op <= DEMI_OP_GT) ? cond : r;
+    r = (op - DEMI_OP_EQ <= DEMI_OP_GT - DEMI_OP_EQ) ? cond : r;
     r = (op == DEMI_OP_MIN) ? ((rel == 0) ? a : b) : r;
     r = (op == DEMI_OP_MAX) ? ((rel == 2) ? a : b) : r;
-    const bool is_alu = op <= DEMI_OP_MAX;
-    if (is_alu) {
-      const uint32_t shft = (dsti & 7u) * 8u;
-      const uint64_t msk = 0xFFull << shft, val = (uint64_t)(r & 0xFFu) << shft;
-      if (dsti & 8u) hi = (hi & ~msk) | val; else lo = (lo & ~msk) | val;
-    }
+    // ---- write-back, branch-free: insert byte r into word dsti>>2 when the row is an ALU row (1..18)
+    const bool is_alu = (op - 1u) < DEMI_OP_MAX;
+    const uint32_t k8 = (dsti & 3u) * 8u;
+    const uint32_t ins = 0x03020100u ^ ((((dsti & 3u) ^ 4u)) << k8);         // selector: byte k := S0.byte0
+    const uint32_t wsel = is_alu ? (dsti >> 2) : 4u;
+    w0 = __builtin_amdgcn_perm(r, w0, wsel == 0 ? ins : 0x03020100u);
+    w1 = __builtin_amdgcn_perm(r, w1, wsel == 1 ? ins : 0x03020100u);
+    w2 = __builtin_amdgcn_perm(r, w2, wsel == 2 ? ins : 0x03020100u);
+    w3 = __builtin_amdgcn_perm(r, w3, wsel == 3 ? ins : 0x03020100u);
     // ---- forward skips
     const bool skip = (op == DEMI_OP_SKIP) | ((op == DEMI_OP_SKIPZ) & (a == 0)) | ((op == DEMI_OP_SKIPNZ) & (a != 0)) |
                       (is_if & (cond == 0));
     pc += skip ? (is_if ? aux : braw) : 0u;
     // ---- effect rows: recorded now, applied after the rows have run
-    if (op >= DEMI_OP_SEND && op <= DEMI_OP_TCANCEL) {
-      if (nfx >= DEMI_FX_CAP) { flags |= DEMI_V_QUEUE_OVF; break; }
-      const uint32_t p0 = reg_get(lo, hi, dsti);
-      mem.fxq[nfx * 64] = fx_pack(op, aux, a > 15u ? 15u : a, p0, b);   // target 15 = nobody
-      nfx++;
+    const bool is_fx = (op - DEMI_OP_SEND) <= (DEMI_OP_TCANCEL - DEMI_OP_SEND);
+    if (is_fx) {
+      if (nfx >= DEMI_FX_CAP) { flags |= DEMI_V_QUEUE_OVF; }
+      else {
+        const uint32_t p0 = reg_get4(w0, w1, w2, w3, dsti);
+        mem.fxq[nfx * 64] = fx_pack(op, aux, a > 15u ? 15u : a, p0, b);     // target 15 = nobody
+        nfx++;
+      }
     }
+    running = (op != DEMI_OP_HALT) & (pc < code_len) & !(flags & DEMI_V_QUEUE_OVF);
   }
-  mem.st[me * 64] = lo;
+  mem.st[me * 64] = (uint64_t)w0 | ((uint64_t)w1 << 32);
   return nfx;
 }
 
