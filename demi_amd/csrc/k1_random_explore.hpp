@@ -110,6 +110,7 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k1_random_explore(const K1Args 
   uint32_t n_tq = 0, n_resend = 0;
   uint32_t just = 0, rep = 0;         // justScheduledTimers / registered repeating timers (bit rcv*4+tidx)
   uint32_t viol = 0, flags = 0;
+  uint64_t tmask = 0;
   uint32_t next_id = 1, n_rec = 0;    // REC only
   demi_rec_event* rec = nullptr;
 
@@ -131,12 +132,14 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k1_random_explore(const K1Args 
     }                                                                                         \
   } while (0)
 
-#define PEND_APPEND(WORD, ID)                                         \
+// tmask: bit s = pending slot s (< 64) holds a timer message; lets TCANCEL probe only those slots
+#define PEND_APPEND(WORD, ID, IS_TIMER)                               \
   do {                                                                \
     if (n_pend >= PMAX) { flags |= DEMI_V_PENDING_OVF; }              \
     else {                                                            \
       pend_store(mem, n_pend, (WORD));                                \
       if (REC) aux_store(mem, n_pend, (ID));                          \
+      if ((IS_TIMER) && n_pend < 64) tmask |= 1ull << n_pend;         \
       n_pend++;                                                       \
     }                                                                 \
   } while (0)
@@ -155,6 +158,20 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k1_random_explore(const K1Args 
       tq |= b << (8 * n_tq);
       n_tq++;
     }
+  };
+
+  // RandomizedHashSet.remove (Util.scala:146-163): the last element moves into the hole
+  auto pend_remove = [&](uint32_t idx) {
+    const uint32_t last = n_pend - 1;
+    const uint32_t lw = pend_load(mem, last);
+    pend_store(mem, idx, lw);
+    if (REC) aux_store(mem, idx, aux_load(mem, last));
+    bool last_is_timer;
+    if (last < 64) last_is_timer = (tmask >> last) & 1;
+    else last_is_timer = (w_src(lw) == DEMI_DEADLETTERS) && ((t.meta[w_type(lw)] & 0xFF) == DEMI_MSG_TIMER);
+    if (idx < 64) tmask = (tmask & ~(1ull << idx)) | ((uint64_t)(last_is_timer && idx != last) << idx);
+    if (last < 64) tmask &= ~(1ull << last);
+    n_pend = last;
   };
 
   auto check_invariant = [&]() -> uint32_t {
@@ -268,7 +285,7 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k1_random_explore(const K1Args 
             const uint32_t sw = s_sendw[i];
             if (sw != 0) {
               const uint32_t id = next_id; if (REC) next_id++;
-              PEND_APPEND(sw, id);
+              PEND_APPEND(sw, id, false);
               REC_PUSH(DEMI_REC_MSG_SEND, DEMI_DEADLETTERS, w_dst(sw), w_type(sw), w_p0(sw), w_p1(sw), 1, i, id);
             }
           }
@@ -279,7 +296,7 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k1_random_explore(const K1Args 
             const uint32_t bt = (uint32_t)(tq >> (8 * k)) & 0xFF, rcv = bt >> 5, type = bt & 31;
             const uint32_t id = next_id; if (REC) next_id++;
             const bool drop = (net.inaccessible >> rcv) & 1;
-            if (!drop) PEND_APPEND(msg_word(type, DEMI_DEADLETTERS, rcv, 0, 0), id);
+            if (!drop) PEND_APPEND(msg_word(type, DEMI_DEADLETTERS, rcv, 0, 0), id, true);
             REC_PUSH(DEMI_REC_MSG_SEND, DEMI_DEADLETTERS, rcv, type, 0, 0, 2 | (drop ? 4 : 0), 255, id);
           }
           tq = 0; n_tq = 0;
@@ -291,10 +308,9 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k1_random_explore(const K1Args 
         // FullyRandom.removeRandomElement -> RandomizedHashSet: nextInt(arr.length), swap with last
         const uint32_t idx = jr_next_int(rng, n_pend, t.magic);
         w = pend_load(mem, idx);
-        pend_store(mem, idx, pend_load(mem, n_pend - 1));
         uint32_t wid = 0;
-        if (REC) { wid = aux_load(mem, idx); aux_store(mem, idx, aux_load(mem, n_pend - 1)); }
-        n_pend--;
+        if (REC) wid = aux_load(mem, idx);
+        pend_remove(idx);
         count++;
         cnt_mod++; if (cnt_mod == interval) cnt_mod = 0;
         const uint32_t type = w_type(w), me = w_dst(w);
@@ -348,13 +364,30 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k1_random_explore(const K1Args 
           // event_produced for internal messages (:287-297): dropped at send time when
           // crosses_partition, else appended to the pending set
           const bool bc = (op == DEMI_OP_BCAST);
-          const uint32_t first = bc ? 0u : target, last = bc ? A : (target < A ? target + 1 : 0u);
-          for (uint32_t r = first; r < last; r++) {
-            if ((bc && r == me) || !((exists >> r) & 1)) continue;
-            const uint32_t id = next_id; if (REC) next_id++;
-            const bool drop = crosses_partition(net, me, r);
-            if (!drop) PEND_APPEND(msg_word(type, me, r, p0, p1), id);
-            REC_PUSH(DEMI_REC_MSG_SEND, me, r, type, p0, p1, drop ? 4 : 0, 255, id);
+          if (REC) {
+            const uint32_t first = bc ? 0u : target, last = bc ? A : (target < A ? target + 1 : 0u);
+            for (uint32_t r = first; r < last; r++) {
+              if ((bc && r == me) || !((exists >> r) & 1)) continue;
+              const uint32_t id = next_id; next_id++;
+              const bool drop = crosses_partition(net, me, r);
+              if (!drop) PEND_APPEND(msg_word(type, me, r, p0, p1), id, false);
+              REC_PUSH(DEMI_REC_MSG_SEND, me, r, type, p0, p1, drop ? 4 : 0, 255, id);
+            }
+          } else {
+            // receivers as a bitmask; crosses_partition(me, .) for all receivers at once: row and column of
+            // the ordered-pair matrix (column gathered by multiply), inaccessible receivers, isolated sender
+            uint32_t tm = bc ? (exists & ~(1u << me)) : ((1u << target) & exists & 0xFFu);
+            const uint32_t row = (uint32_t)(net.partitioned >> (me * 8)) & 0xFFu;
+            const uint32_t col = (uint32_t)((((net.partitioned >> me) & 0x0101010101010101ULL) * 0x0102040810204080ULL) >> 56);
+            uint32_t blocked = row | col | net.inaccessible | (((net.inaccessible >> me) & 1u) ? 0xFFu : 0u);
+            if (!((net.killed >> me) & 1u)) blocked &= ~(1u << me);      // snd == rcv && !killed: never crosses
+            tm &= ~blocked;
+            const uint32_t base = msg_word(type, me, 0, p0, p1);
+            while (tm) {
+              const uint32_t r = (uint32_t)__builtin_ctz(tm);
+              tm &= tm - 1;
+              PEND_APPEND(base | (r << 5), 0u, false);
+            }
           }
         } else if (op == DEMI_OP_TCANCEL) {
           // cancelTimer (Instrumenter.scala:159-168) -> notify_timer_cancel (:525-534)
@@ -369,14 +402,16 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k1_random_explore(const K1Args 
             }
           }
           if (!found) {
+            // FullyRandom.remove (:653-664): first match in arr order, then swap-remove.  Only slots that
+            // hold timer messages are probed (ascending = arr order); slots >= 64 are scanned linearly.
             const uint32_t wantw = msg_word(type, DEMI_DEADLETTERS, me, 0, 0);
-            for (uint32_t q = 0; q < n_pend; q++) {      // FullyRandom.remove: first match, swap-remove
-              if (pend_load(mem, q) == wantw) {
-                pend_store(mem, q, pend_load(mem, n_pend - 1));
-                if (REC) aux_store(mem, q, aux_load(mem, n_pend - 1));
-                n_pend--; break;
-              }
+            bool gone = false;
+            for (uint64_t m = tmask; m != 0; m &= m - 1) {
+              const uint32_t q = (uint32_t)__builtin_ctzll(m);
+              if (pend_load(mem, q) == wantw) { pend_remove(q); gone = true; break; }
             }
+            for (uint32_t q = 64; !gone && q < n_pend; q++)
+              if (pend_load(mem, q) == wantw) { pend_remove(q); gone = true; }
           }
         } else {
           // TSET / TREP: registerCancellable + handleTick (Instrumenter.scala:1145-1200)
@@ -408,7 +443,7 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k1_random_explore(const K1Args 
       // reset the simulator for the next schedule
       ph = PH_IDLE;
       n_pend = 0; count = 0; cnt_mod = 0; tidx = 0; inj_lo = 0; inj_hi = 0; batch_no = 0;
-      tq = 0; resend = 0; n_tq = 0; n_resend = 0; just = 0; rep = 0; viol = 0; flags = 0; hash = 0;
+      tq = 0; resend = 0; n_tq = 0; n_resend = 0; just = 0; rep = 0; viol = 0; flags = 0; hash = 0; tmask = 0;
     }
   }
 #ifdef DEMI_K1_PHASES
