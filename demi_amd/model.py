@@ -264,24 +264,29 @@ def raft_model(n_actors=5, election_budget=1, buggy=True) -> Model:
     a.if_ne(ROLE, LEADER, "done")
     a.if_ne(BUDGET, 0, "done")
     a.sub(BUDGET, BUDGET, 1).mov(ROLE, CANDIDATE).add(TERM, TERM, 1).mov(VOTED, ME)
-    a.mov(VOTES, 0).bitset(VOTES, VOTES, ME)
+    a.bitset(VOTES, T0, ME)                                  # votes = {self}  (T0 is zero at entry)
     a.bcast(M_REQUEST_VOTE, TERM, 0).tset(M_ELECTION_TIMEOUT).label("done")
     h[(0, "ElectionTimeout")] = a
 
-    # RequestVote(term) from SRC.
+    # RequestVote(term) from SRC, lowered as a decision tree (guards skip forward):
+    #   newer term -> step down;  grant iff same term and (not voted | voted for SRC | <seeded bug>)
     a = Asm()
     a.if_gt(P0, TERM, "same")
     a.if_eq(ROLE, LEADER, "nl").tcancel(M_HEARTBEAT).label("nl")
     a.mov(TERM, P0).mov(ROLE, FOLLOWER).mov(VOTED, NOBODY)
     a.label("same")
-    a.eq(T1, VOTED, NOBODY).eq(T2, VOTED, SRC).or_(T1, T1, T2)
+    a.if_eq(P0, TERM, "deny")
+    a.if_ne(VOTED, NOBODY, "grant")                          # already voted for somebody ...
+    a.if_ne(VOTED, SRC, "grant")                             # ... else than SRC
     if buggy:
         # seeded bug: a candidate forgets its own vote when its right-hand neighbour (id + 1)
         # asks for a vote in the same term -> two leaders can be elected in one term
-        a.eq(T2, ROLE, CANDIDATE).sub(T3, SRC, 1).eq(T3, T3, ME).and_(T2, T2, T3).or_(T1, T1, T2)
-    a.eq(T0, P0, TERM).and_(T0, T0, T1).if_ne(T0, 0, "deny")
+        a.if_eq(ROLE, CANDIDATE, "deny").sub(T3, SRC, 1).if_eq(T3, ME, "deny")
+    else:
+        a.skip("deny")
+    a.label("grant")
     a.mov(VOTED, SRC).tcancel(M_ELECTION_TIMEOUT).tset(M_ELECTION_TIMEOUT)
-    a.mov(T3, 1).send(M_VOTE_REPLY, SRC, TERM, T3).halt()
+    a.send(M_VOTE_REPLY, SRC, TERM, 1).halt()
     a.label("deny").send(M_VOTE_REPLY, SRC, TERM, 0)
     h[(0, "RequestVote")] = a
 
@@ -301,10 +306,12 @@ def raft_model(n_actors=5, election_budget=1, buggy=True) -> Model:
     a = Asm()
     a.if_lt(P0, TERM, "ok").send(M_APPEND_REPLY, SRC, TERM, 0).halt()
     a.label("ok")
-    a.if_gt(P0, TERM, "sameterm").mov(VOTED, NOBODY).label("sameterm")
-    a.gt(T0, P0, TERM).ne(T1, ROLE, LEADER).or_(T0, T0, T1).if_ne(T0, 0, "keep")
+    a.if_gt(P0, TERM, "sameterm")                            # newer term: forget the vote, step down
+    a.mov(VOTED, NOBODY)
     a.if_eq(ROLE, LEADER, "nl").tcancel(M_HEARTBEAT).label("nl")
-    a.mov(ROLE, FOLLOWER)
+    a.mov(ROLE, FOLLOWER).skip("keep")
+    a.label("sameterm")
+    a.if_ne(ROLE, LEADER, "keep").mov(ROLE, FOLLOWER)       # same term: a candidate steps down, a leader stays
     a.label("keep")
     a.mov(TERM, P0).max(LOGLEN, LOGLEN, P1)
     a.tcancel(M_ELECTION_TIMEOUT).tset(M_ELECTION_TIMEOUT)
