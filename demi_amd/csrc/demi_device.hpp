@@ -22,6 +22,7 @@ struct DevModel {
   uint64_t init_state[DEMI_MAX_ACTORS];
   uint32_t divmagic[129];  // ceil(2^(31+L)/d), L = ceil(log2 d): exact floor(r/d) for r < 2^31
   uint32_t pad3;
+  uint32_t optab[64];      // per-op control words (sim_core.hpp op_control), filled by the host
   uint32_t code[DEMI_MAX_CODE];
 };
 

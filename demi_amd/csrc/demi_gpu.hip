@@ -217,6 +217,7 @@ extern "C" int demi_model_load(demi_ctx* ctx, const demi_model* m) {
     const unsigned __int128 num = (unsigned __int128)1 << (31 + L);
     h.divmagic[d] = (uint32_t)((num + d - 1) / d);  // only read for non-powers of two (fits 32 bits)
   }
+  for (uint32_t op = 0; op < 64; op++) h.optab[op] = op_control(op);
   memcpy(h.code, m->code, sizeof(uint32_t) * m->code_len);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipMemcpy(ctx->d_model, &h, sizeof h, hipMemcpyHostToDevice));

@@ -17,6 +17,47 @@ namespace demi {
 
 #define DEMI_OVF_ANY (DEMI_V_PENDING_OVF | DEMI_V_QUEUE_OVF)
 
+// Per-op control word (what the row does), looked up instead of decoded with compare chains.
+// The masks make the ALU a sum of mutually exclusive (candidate & mask) terms: no VCC selects.
+enum : uint32_t {
+  CW_ADDSUB = 1u << 0,   // r = (a & am) + (b ^ nm) + n1   (MOV: am = 0; SUB: nm = ~0, n1 = 1)
+  CW_KEEP_A = 1u << 1,   //   am = ~0
+  CW_NEG_B = 1u << 2,    //   nm = ~0, n1 = 1
+  CW_AND = 1u << 3, CW_OR = 1u << 4, CW_BITB = 1u << 5 /* OR with b := 1 << (b & 7) */, CW_XOR = 1u << 6,
+  CW_SHL = 1u << 7, CW_SHR = 1u << 8, CW_POPC = 1u << 9, CW_CMP = 1u << 10,
+  CW_MINMAX = 1u << 11, CW_IS_MIN = 1u << 12,
+  CW_ALU = 1u << 13,     // writes dst
+  CW_IF = 1u << 14,      // fused guard: skip aux rows unless the relation holds
+  CW_SKIPZ = 1u << 15, CW_SKIPNZ = 1u << 16, CW_SKIP = 1u << 17,
+  CW_FX = 1u << 18, CW_HALT = 1u << 19,
+  CW_REL_SHIFT = 20      // bits 20..22: accepted relations {lt, eq, gt} of compare / guard rows
+};
+
+inline uint32_t op_control(uint32_t op) {   // host side: fills DevModel::optab
+  // accepted-relation masks in the order EQ NE LT GE LE GT
+  const uint32_t rels[6] = {2u, 5u, 1u, 6u, 3u, 4u};
+  if (op == DEMI_OP_HALT) return CW_HALT;
+  if (op == DEMI_OP_MOV) return CW_ALU | CW_ADDSUB;
+  if (op == DEMI_OP_ADD) return CW_ALU | CW_ADDSUB | CW_KEEP_A;
+  if (op == DEMI_OP_SUB) return CW_ALU | CW_ADDSUB | CW_KEEP_A | CW_NEG_B;
+  if (op == DEMI_OP_AND) return CW_ALU | CW_AND;
+  if (op == DEMI_OP_OR) return CW_ALU | CW_OR;
+  if (op == DEMI_OP_XOR) return CW_ALU | CW_XOR;
+  if (op == DEMI_OP_SHL) return CW_ALU | CW_SHL;
+  if (op == DEMI_OP_SHR) return CW_ALU | CW_SHR;
+  if (op == DEMI_OP_BITSET) return CW_ALU | CW_OR | CW_BITB;
+  if (op == DEMI_OP_POPC) return CW_ALU | CW_POPC;
+  if (op >= DEMI_OP_EQ && op <= DEMI_OP_GT) return CW_ALU | CW_CMP | (rels[op - DEMI_OP_EQ] << CW_REL_SHIFT);
+  if (op == DEMI_OP_MIN) return CW_ALU | CW_MINMAX | CW_IS_MIN;
+  if (op == DEMI_OP_MAX) return CW_ALU | CW_MINMAX;
+  if (op == DEMI_OP_SKIPZ) return CW_SKIPZ;
+  if (op == DEMI_OP_SKIPNZ) return CW_SKIPNZ;
+  if (op == DEMI_OP_SKIP) return CW_SKIP;
+  if (op >= DEMI_OP_SEND && op <= DEMI_OP_TCANCEL) return CW_FX;
+  if (op >= DEMI_OP_IFEQ && op <= DEMI_OP_IFGT) return CW_IF | (rels[op - DEMI_OP_IFEQ] << CW_REL_SHIFT);
+  return CW_HALT;   // unknown ops are rejected by validation
+}
+
 // ------------------------------------------------------------------ workgroup-shared tables
 struct Tables {
   const uint64_t* trace;  // [E] external events, one 8-byte word each
@@ -25,13 +66,14 @@ struct Tables {
   const uint32_t* hs;     // [n_classes * NT] handler starts
   const uint32_t* meta;   // [32] msg_class | timer_idx << 8
   const uint32_t* magic;  // [129] nextInt multiply-high magics
+  const uint32_t* optab;  // [64] per-op control words (op_control)
   uint32_t A, NT, code_len, E, exists, ac_packed;
   uint32_t inv_kind, inv_fa, inv_va, inv_fb, fp_mask;
 };
 
 __host__ __device__ inline size_t tables_lds_bytes(uint32_t code_len, uint32_t n_ev, uint32_t n_hs) {
   size_t b = (size_t)n_ev * 8 + DEMI_MAX_ACTORS * 8 + (size_t)code_len * 4 + (size_t)n_hs * 4 +
-             DEMI_MAX_MSG_TYPES * 4 + 132 * 4;
+             DEMI_MAX_MSG_TYPES * 4 + 132 * 4 + 64 * 4;
   return (b + 15) & ~(size_t)15;
 }
 
@@ -49,15 +91,17 @@ __device__ inline unsigned char* tables_load(Tables& t, unsigned char* smem, con
   uint32_t* s_hs = s_code + t.code_len;
   uint32_t* s_meta = s_hs + n_hs;
   uint32_t* s_magic = s_meta + DEMI_MAX_MSG_TYPES;
+  uint32_t* s_optab = s_magic + 132;
   for (uint32_t i = threadIdx.x; i < n_ev; i += blockDim.x) s_trace[i] = g_trace[i];
   for (uint32_t i = threadIdx.x; i < DEMI_MAX_ACTORS; i += blockDim.x) s_init[i] = gm->init_state[i];
   for (uint32_t i = threadIdx.x; i < t.code_len; i += blockDim.x) s_code[i] = gm->code[i];
   for (uint32_t i = threadIdx.x; i < n_hs; i += blockDim.x) s_hs[i] = gm->handler_start[i];
   for (uint32_t i = threadIdx.x; i < DEMI_MAX_MSG_TYPES; i += blockDim.x) s_meta[i] = gm->meta[i];
   for (uint32_t i = threadIdx.x; i < 129; i += blockDim.x) s_magic[i] = gm->divmagic[i];
+  for (uint32_t i = threadIdx.x; i < 64; i += blockDim.x) s_optab[i] = gm->optab[i];
   t.ac_packed = 0;
   for (uint32_t a = 0; a < t.A; a++) t.ac_packed |= gm->actor_class[a] << (4 * a);
-  t.trace = s_trace; t.init = s_init; t.code = s_code; t.hs = s_hs; t.meta = s_meta; t.magic = s_magic;
+  t.trace = s_trace; t.init = s_init; t.code = s_code; t.hs = s_hs; t.meta = s_meta; t.magic = s_magic; t.optab = s_optab;
   __syncthreads();
   return smem + tables_lds_bytes(t.code_len, n_ev, n_hs);
 }
@@ -133,6 +177,10 @@ __device__ __forceinline__ uint32_t reg_get4(uint32_t w0, uint32_t w1, uint32_t 
   return (i & 8u) ? hi : lo;
 }
 
+__device__ __forceinline__ uint32_t mask_of(uint32_t cw, uint32_t bit_index) {
+  return (uint32_t)__builtin_amdgcn_sbfe(cw, bit_index, 1);   // v_bfe_i32: 0 or ~0
+}
+
 // Runs the handler of message word `w` on its receiver.  State is read from / written to
 // mem.st; effect rows are recorded into mem.fxq.  Returns the number of recorded effect rows
 // (sets DEMI_V_QUEUE_OVF in flags when more than DEMI_FX_CAP would be recorded).
@@ -150,58 +198,53 @@ __device__ inline uint32_t vm_run(const Tables& t, const LaneMem& mem, uint32_t 
   while (running) {
     const uint32_t row = t.code[pc];
     pc++;
-    const uint32_t op = row & 0xFFu;
+    const uint32_t cw = t.optab[row & 0x3Fu];
     const uint32_t dsti = (row >> 8) & 15u, ai = (row >> 12) & 15u, aux = (row >> 17) & 0x7Fu, braw = row >> 24;
     const uint32_t a = reg_get4(w0, w1, w2, w3, ai);
     const uint32_t breg = reg_get4(w0, w1, w2, w3, braw);
     const uint32_t b = (row & 0x10000u) ? braw : breg;
-    // ---- relation of a and b: 0 (a<b), 1 (a==b), 2 (a>b); accepted-relation masks per compare kind
+    // ---- relation of a and b: 0 (a<b), 1 (a==b), 2 (a>b), tested against the row's accepted set
     const int32_t d = (int32_t)a - (int32_t)b;
     const uint32_t rel = (uint32_t)(min(max(d, -1), 1) + 1);                 // v_med3_i32
-    const bool is_if = op >= DEMI_OP_IFEQ;
-    // compare kinds in the order EQ NE LT GE LE GT (ops 11..16 and 32..37): masks over {lt=1, eq=2, gt=4}
-    constexpr uint32_t kRelMasks = 2u | (5u << 3) | (1u << 6) | (6u << 9) | (3u << 12) | (4u << 15);
-    const uint32_t ck = (op + (is_if ? 32u - DEMI_OP_IFEQ : 32u - DEMI_OP_EQ)) & 7u;
-    const uint32_t cond = (kRelMasks >> (ck * 3u + rel)) & 1u;
-    // ---- ALU result classes (all computed, one selected)
+    const uint32_t cond = (cw >> (CW_REL_SHIFT + rel)) & 1u;
+    const uint32_t ltm = (uint32_t)(d >> 31);                                // ~0 iff a < b
+    // ---- ALU: mutually exclusive (candidate & mask) terms
     const uint32_t sh = b & 7u;
-    uint32_t r = b;                                                          // MOV
-    r = (op == DEMI_OP_ADD) ? a + b : r;
-    r = (op == DEMI_OP_SUB) ? a - b : r;
-    r = (op == DEMI_OP_AND) ? (a & b) : r;
-    r = (op == DEMI_OP_OR) ? (a | b) : r;
-    r = (op == DEMI_OP_XOR) ? (a ^ b) : r;
-    r = (op == DEMI_OP_SHL) ? (a << sh) : r;
-    r = (op == DEMI_OP_SHR) ? (a >> sh) : r;
-    r = (op == DEMI_OP_BITSET) ? (a | (1u << sh)) : r;
-    r = (op == DEMI_OP_POPC) ? (uint32_t)__popc(b) : r;
-    r = (op - DEMI_OP_EQ <= DEMI_OP_GT - DEMI_OP_EQ) ? cond : r;
-    r = (op == DEMI_OP_MIN) ? ((rel == 0) ? a : b) : r;
-    r = (op == DEMI_OP_MAX) ? ((rel == 2) ? a : b) : r;
-    // ---- write-back, branch-free: insert byte r into word dsti>>2 when the row is an ALU row (1..18)
-    const bool is_alu = (op - 1u) < DEMI_OP_MAX;
+    const uint32_t nm = mask_of(cw, 2);
+    uint32_t r = ((a & mask_of(cw, 1)) + (b ^ nm) + (nm & 1u)) & mask_of(cw, 0);                 // MOV ADD SUB
+    r |= (a & b) & mask_of(cw, 3);                                                                // AND
+    const uint32_t bm = mask_of(cw, 5);
+    r |= (a | ((b & ~bm) | ((1u << sh) & bm))) & mask_of(cw, 4);                                  // OR BITSET
+    r |= (a ^ b) & mask_of(cw, 6);                                                                // XOR
+    r |= (a << sh) & mask_of(cw, 7);                                                              // SHL
+    r |= (a >> sh) & mask_of(cw, 8);                                                              // SHR
+    r |= (uint32_t)__popc(b) & mask_of(cw, 9);                                                    // POPC
+    r |= cond & mask_of(cw, 10);                                                                  // EQ..GT
+    const uint32_t mn = mask_of(cw, 12);                 // MIN: b ^ ((a^b) & lt)   MAX: a ^ ((a^b) & lt)
+    r |= (((b & mn) | (a & ~mn)) ^ ((a ^ b) & ltm)) & mask_of(cw, 11);
+    // ---- write-back, branch-free: insert byte r into word dsti>>2 when the row is an ALU row
     const uint32_t k8 = (dsti & 3u) * 8u;
     const uint32_t ins = 0x03020100u ^ ((((dsti & 3u) ^ 4u)) << k8);         // selector: byte k := S0.byte0
-    const uint32_t wsel = is_alu ? (dsti >> 2) : 4u;
+    const uint32_t wsel = (cw & CW_ALU) ? (dsti >> 2) : 4u;
     w0 = __builtin_amdgcn_perm(r, w0, wsel == 0 ? ins : 0x03020100u);
     w1 = __builtin_amdgcn_perm(r, w1, wsel == 1 ? ins : 0x03020100u);
     w2 = __builtin_amdgcn_perm(r, w2, wsel == 2 ? ins : 0x03020100u);
     w3 = __builtin_amdgcn_perm(r, w3, wsel == 3 ? ins : 0x03020100u);
     // ---- forward skips
-    const bool skip = (op == DEMI_OP_SKIP) | ((op == DEMI_OP_SKIPZ) & (a == 0)) | ((op == DEMI_OP_SKIPNZ) & (a != 0)) |
-                      (is_if & (cond == 0));
-    pc += skip ? (is_if ? aux : braw) : 0u;
+    const uint32_t zf = (a == 0) ? CW_SKIPZ : CW_SKIPNZ;
+    const bool skip_if = (cw & CW_IF) && (cond == 0);
+    const bool skip = skip_if | ((cw & (zf | CW_SKIP)) != 0);
+    pc += skip ? (skip_if ? aux : braw) : 0u;
     // ---- effect rows: recorded now, applied after the rows have run
-    const bool is_fx = (op - DEMI_OP_SEND) <= (DEMI_OP_TCANCEL - DEMI_OP_SEND);
-    if (is_fx) {
+    if (cw & CW_FX) {
       if (nfx >= DEMI_FX_CAP) { flags |= DEMI_V_QUEUE_OVF; }
       else {
         const uint32_t p0 = reg_get4(w0, w1, w2, w3, dsti);
-        mem.fxq[nfx * 64] = fx_pack(op, aux, a > 15u ? 15u : a, p0, b);     // target 15 = nobody
+        mem.fxq[nfx * 64] = fx_pack(row & 0xFFu, aux, a > 15u ? 15u : a, p0, b);     // target 15 = nobody
         nfx++;
       }
     }
-    running = (op != DEMI_OP_HALT) & (pc < code_len) & !(flags & DEMI_V_QUEUE_OVF);
+    running = !(cw & CW_HALT) & (pc < code_len) & !(flags & DEMI_V_QUEUE_OVF);
   }
   mem.st[me * 64] = (uint64_t)w0 | ((uint64_t)w1 << 32);
   return nfx;
