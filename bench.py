@@ -114,8 +114,9 @@ def main():
         value = total / dt
         # algorithmic bytes of one K1 launch: 16 B verdict per schedule out, plus the
         # trace and the transition table streamed once per workgroup
-        blocks = min((n + 255) // 256, 256 * 2)
-        shared = 8 * len(events) + 4 * len(model.code) + 4 * len(model.handler_start) + 8 * 8 + 32 * 4 + 129 * 4
+        # the trace and the tables are streamed once per resident workgroup (3 per CU at this LDS footprint)
+        blocks = min((n + 255) // 256, torch.cuda.get_device_properties(dev).multi_processor_count * 3)
+        shared = 8 * len(events) + 4 * len(model.code) + 4 * len(model.handler_start) + 8 * 8 + 32 * 4 + 132 * 4 + 64 * 4
         alg_bytes = 16 * n + blocks * shared
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
         traffic = None
@@ -138,7 +139,7 @@ def main():
             "bugs_per_hr": float(len(vset)) / (dt / args.steps) * 3600.0,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k1_random_explore<%d,false>" % args.p_max, "kernel_ms": kernel_ms,
+                         "kernel": "k1_random_explore<false>", "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "integer/LDS-bound simulation: algorithmic HBM traffic is 16 B per schedule, so the "
                                  "HBM fraction is tiny by construction (SURVEY 8d); see DESIGN.md for the issue-rate model"},
