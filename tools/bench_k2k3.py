@@ -1,0 +1,59 @@
+#!/usr/bin/env python
+"""Throughput of K2 (STSSched replays/s) and K3 (DPOR interleavings/s, kernel + host loop) on one
+MI355X, for DESIGN.md §5.  Not the headline bench (that is bench.py / K1)."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from demi_amd import _native, types as T  # noqa: E402
+from demi_amd.apps import SEED_BASE, raft5_config3, raft5_config4  # noqa: E402
+from demi_amd.dpor import DPORwHeuristics  # noqa: E402
+from demi_amd.minification import events_to_mask, stsSchedDDMin  # noqa: E402
+from demi_amd.schedulers import EventTrace, STSScheduler, SchedulerConfig, ViolationFingerprint  # noqa: E402
+
+out = {}
+ctx = _native.Context(0)
+model, events, lim = raft5_config4()
+ctx.model_load(model.to_struct()); ctx.trace_load(events)
+v = ctx.random_explore(4000, lim, seed_base=SEED_BASE)
+i = int(np.nonzero(v["flags"] & T.V_VIOLATION)[0][0])
+vv, rec = ctx.random_get_trace(SEED_BASE + i, lim)
+used = events[:T.verdict_trace_idx(vv.flags)]
+ctx.replay_load(used, rec)
+rng = np.random.default_rng(0)
+for n in (1024, 65536, 1 << 20):
+    masks = np.zeros((n, 4), dtype=np.uint64)
+    keep = rng.random((n, len(used))) < 0.7
+    for w in range(4):
+        bits = keep[:, 64 * w:64 * (w + 1)]
+        masks[:, w] = (bits.astype(np.uint64) << np.arange(bits.shape[1], dtype=np.uint64)).sum(axis=1)
+    target = T.Limits(0, 0, 128, 1, vv.fingerprint, 0)
+    ctx.replay_batch(masks[:64], target)
+    t = time.perf_counter(); r = ctx.replay_batch(masks, target); dt = time.perf_counter() - t
+    out["k2_replays_per_s_n%d" % n] = n / dt
+out["k2_original_trace"] = {"externals": int(len(used)), "recorded_events": int(len(rec)), "deliveries": T.verdict_deliveries(vv.flags)}
+# DDMin end to end (config 4)
+sts = STSScheduler(SchedulerConfig(model=model), EventTrace(rec, used), p_max=128)
+t = time.perf_counter()
+mcs, d, ver = stsSchedDDMin(sts, used, ViolationFingerprint(vv.fingerprint), speculative_depth=4)
+out["ddmin_config4"] = {"seconds": time.perf_counter() - t, "mcs_len": len(mcs), "oracle_consultations": len(d.consulted),
+                        "launches": len(d.batches), "replays_launched": d.speculative_replays}
+sts.shutdown()
+# K3: kernel-only rate on a fixed batch of prefixes, then the whole loop
+model3, ev3, depth = raft5_config3()
+d = DPORwHeuristics(SchedulerConfig(model=model3), depth_bound=depth, stopIfViolationFound=False, batch=2048)
+t = time.perf_counter(); res = d.explore(ev3, max_interleavings=8192); dt = time.perf_counter() - t
+out["k3_loop_interleavings_per_s"] = len(res.interleavings) / dt
+pref = [il.trace[:max(1, il.prefix_len)] for il in res.interleavings[:8192]]
+par = T.DporParams(depth, 0, 0, 0, 64, 4096)
+d._ctx.dpor_batch(pref[:64], par)
+t = time.perf_counter(); d._ctx.dpor_batch(pref, par); dt = time.perf_counter() - t
+out["k3_batch_interleavings_per_s_incl_copies"] = len(pref) / dt
+out["k3_mean_trace_len"] = float(np.mean([len(il.trace) for il in res.interleavings]))
+d.shutdown()
+print(json.dumps(out, indent=1))
