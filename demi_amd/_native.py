@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libdemi_gpu.so")
 
 EXPORTS = ["demi_ctx_create", "demi_ctx_destroy", "demi_last_error", "demi_version", "demi_model_load",
            "demi_trace_load", "demi_random_explore", "demi_random_explore_dev", "demi_random_get_trace", "demi_collect_violations_dev",
-           "demi_replay_load", "demi_replay_batch", "demi_replay_batch_dev", "demi_dpor_load", "demi_dpor_batch"]
+           "demi_replay_load", "demi_replay_batch", "demi_replay_batch_dev", "demi_dpor_load", "demi_dpor_batch", "demi_dpor_explore"]
 
 _lib = None
 
@@ -60,6 +60,8 @@ def lib():
     L.demi_dpor_load.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
     L.demi_dpor_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.POINTER(T.DporParams),
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.demi_dpor_explore.argtypes = [C.c_void_p, C.POINTER(T.DporParams), C.POINTER(T.DporSearch), C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(T.DporStats)]
     _lib = L
     return L
 
@@ -159,6 +161,21 @@ class Context:
                                               verdicts.ctypes.data, traces.ctypes.data, tl.ctypes.data,
                                               pairs.ctypes.data, npairs.ctypes.data))
         return verdicts, [traces[i, :tl[i]].copy() for i in range(n)], [pairs[i, :npairs[i]].copy() for i in range(n)]
+
+    def dpor_explore(self, params, search):
+        """The whole exploration natively: returns (verdicts, prefix_len, rounds, first violating trace, stats)."""
+        import numpy as np
+        cap = search.max_interleavings
+        verdicts = np.zeros(cap, dtype=T.VERDICT_DTYPE)
+        plen = np.zeros(cap, dtype=np.uint32)
+        rounds = np.zeros(cap, dtype=np.uint32)
+        vt = np.zeros(T.DPOR_MAX_TRACE, dtype=T.DPOR_TRACE_DTYPE)
+        vl = C.c_uint32(0)
+        stats = T.DporStats()
+        self._check(lib().demi_dpor_explore(self._h, C.byref(params), C.byref(search), verdicts.ctypes.data,
+                                            plen.ctypes.data, rounds.ctypes.data, vt.ctypes.data, C.byref(vl), C.byref(stats)))
+        n = int(stats.interleavings)
+        return verdicts[:n].copy(), plen[:n].copy(), rounds[:int(stats.launches)].copy(), vt[:vl.value].copy(), stats
 
     def random_get_trace(self, seed, limits):
         import numpy as np

@@ -179,6 +179,33 @@ class DPORwHeuristics:
         res.exhausted = not self.backTrack and not frontier
         return res
 
+    def explore_native(self, externals, lookingFor: Optional[ViolationFingerprint] = None, max_interleavings: int = 100000):
+        """The same exploration with the queue / explored-set bookkeeping run natively inside
+        libdemi_gpu.so (demi_dpor_explore): identical rounds, verdicts and prefix lengths, two orders of
+        magnitude less host time per interleaving than this Python loop.  Single rank only."""
+        from . import _native
+        externals = np.ascontiguousarray(externals, dtype=T.EXT_EVENT_DTYPE)
+        if self._ctx is None:
+            self._ctx = _native.Context(self._device)
+            self._ctx.model_load(self.schedulerConfig.model.to_struct())
+            self._ctx.dpor_load(externals)
+        search = T.DporSearch(self.batch, max_interleavings, 1 if self.stopIfViolationFound else 0,
+                              1 if self.trackHistory else 0)
+        verdicts, plen, rounds, vtrace, stats = self._ctx.dpor_explore(self._params(lookingFor), search)
+        res = Exploration()
+        res.rounds = [int(r) for r in rounds]
+        res.exhausted = bool(stats.exhausted)
+        empty = np.zeros(0, dtype=T.DPOR_TRACE_DTYPE)
+        for k in range(len(verdicts)):
+            res.interleavings.append(Interleaving(verdicts[k], empty, int(plen[k])))
+            if int(verdicts[k]["flags"]) & T.V_VIOLATION:
+                res.violations.append(k)
+        if len(vtrace):
+            res.interleavings[int(stats.first_violation)].trace = vtrace
+            self.shortestTraceSoFar = vtrace
+        self.interleavingCounter += len(verdicts)
+        return res
+
     def test(self, events, violation_fingerprint: ViolationFingerprint, _stats: Optional[MinimizationStats] = None):
         """TestOracle.test (:1193-1242): Some(trace of a matching violation) or None."""
         if self.stopIfViolationFound and self.shortestTraceSoFar is not None:

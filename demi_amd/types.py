@@ -88,6 +88,17 @@ class DporParams(C.Structure):
                 ("looking_for", C.c_uint32), ("p_max", C.c_uint32), ("max_pairs", C.c_uint32)]
 
 
+class DporSearch(C.Structure):
+    _fields_ = [("batch", C.c_uint32), ("max_interleavings", C.c_uint32), ("stop_if_violation", C.c_uint32),
+                ("track_history", C.c_uint32)]
+
+
+class DporStats(C.Structure):
+    _fields_ = [("interleavings", C.c_uint64), ("launches", C.c_uint64), ("violations", C.c_uint64),
+                ("first_violation", C.c_uint64), ("queue_len", C.c_uint64), ("exhausted", C.c_uint32),
+                ("pad", C.c_uint32)]
+
+
 assert C.sizeof(ExtEvent) == 8 and C.sizeof(Verdict) == 16 and C.sizeof(RecEvent) == 12
 
 import numpy as np  # noqa: E402

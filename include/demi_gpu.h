@@ -262,6 +262,36 @@ int demi_dpor_batch(demi_ctx* ctx, const demi_dpor_trace_entry* prefixes, const 
                     demi_dpor_trace_entry* out_traces, uint32_t* out_trace_len, demi_dpor_pair* out_pairs,
                     uint32_t* out_n_pairs);
 
+/* The whole bounded exploration in one call: the backtrack priority queue with
+ * DefaultBacktrackOrdering (BacktrackOrdering.scala:58-69), the ExploredTacker
+ * (AuxilaryTypes.scala:209-246), dpor()'s bookkeeping (:1068-1070, 1134) and getNext() (:1142-1185)
+ * run natively on the host around demi_dpor_batch-sized launches.  A round pops up to `batch`
+ * unexplored backtrack points (batch = 1 is the reference's one-at-a-time order; PriorityQueue ties
+ * pop in creation order) and each point carries its own next trace.                                */
+typedef struct {
+  uint32_t batch;               /* backtrack points per launch (>= 1) */
+  uint32_t max_interleavings;   /* budget; also the capacity of the output arrays */
+  uint32_t stop_if_violation;   /* stopIfViolationFound */
+  uint32_t track_history;       /* trackHistory */
+} demi_dpor_search;
+
+typedef struct {
+  uint64_t interleavings;       /* executed */
+  uint64_t launches;
+  uint64_t violations;
+  uint64_t first_violation;     /* index into out_verdicts, ~0 if none */
+  uint64_t queue_len;           /* backtrack points still queued at return */
+  uint32_t exhausted;           /* the queue ran empty */
+  uint32_t pad;
+} demi_dpor_stats;
+
+/* out_verdicts / out_prefix_len: [max_interleavings], in execution order.  first_violation_trace:
+ * [DEMI_DPOR_MAX_TRACE] (may be NULL).  out_rounds: launch sizes, [max_interleavings] (may be NULL). */
+int demi_dpor_explore(demi_ctx* ctx, const demi_dpor_params* params, const demi_dpor_search* search,
+                      demi_verdict* out_verdicts, uint32_t* out_prefix_len, uint32_t* out_rounds,
+                      demi_dpor_trace_entry* first_violation_trace, uint32_t* first_violation_len,
+                      demi_dpor_stats* stats);
+
 /* ---------------------------------------------------------- found-violation set
  * One entry per violating schedule (what RunnerUtils.fuzz keeps: the violating execution's
  * index + fingerprint, RunnerUtils.scala:91-128).  Compacts a device verdict array into a device

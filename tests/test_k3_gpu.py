@@ -107,3 +107,21 @@ def test_config5_shuffle8_bounded_dpor(oracle):
     assert len(res.interleavings) > 1000
     assert all(a.verdict == b.verdict and (a.trace == b.trace).all() for a, b in zip(res.interleavings, rc.interleavings))
     d.shutdown()
+
+
+@pytest.mark.parametrize("batch,budget", [(1, 150), (64, 3000), (1024, 20000)])
+def test_native_exploration_loop_equals_the_python_loop(batch, budget):
+    """demi_dpor_explore (queue + explored set in C++) walks exactly the Python mirror's exploration."""
+    model = M.raft_model(3)
+    ev = events_to_array([start(a) for a in range(3)] + [send(a, M.M_BOOTSTRAP) for a in range(2)])
+    if batch == 1024:
+        model, ev, _ = raft5_config3(n_sends=3)
+        budget = 4000
+    dp = DPORwHeuristics(SchedulerConfig(model=model), depth_bound=30, stopIfViolationFound=False, batch=batch)
+    rp = dp.explore(ev, max_interleavings=budget)
+    dn = DPORwHeuristics(SchedulerConfig(model=model), depth_bound=30, stopIfViolationFound=False, batch=batch)
+    rn = dn.explore_native(ev, max_interleavings=budget)
+    assert rn.rounds == rp.rounds and rn.exhausted == rp.exhausted and rn.violations == rp.violations
+    assert len(rn.interleavings) == len(rp.interleavings)
+    assert all(a.verdict == b.verdict and a.prefix_len == b.prefix_len for a, b in zip(rn.interleavings, rp.interleavings))
+    dp.shutdown(); dn.shutdown()
