@@ -183,8 +183,10 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k1_random_explore(const K1Args 
 
 #ifdef DEMI_K1_PHASES
   uint64_t ph_t[6] = {0, 0, 0, 0, 0, 0}, ph_iters = 0, ph_rows = 0, ph_active = 0;
-#define PH_MARK(I) do { const uint64_t now_ = __builtin_readcyclecounter(); ph_t[I] += now_ - ph_last; ph_last = now_; } while (0)
-  uint64_t ph_last = __builtin_readcyclecounter();
+  // volatile asm with a memory clobber: keeps loads/stores and control flow on their side of the mark
+#define PH_NOW(V) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(V) : : "memory")
+#define PH_MARK(I) do { uint64_t now_; PH_NOW(now_); ph_t[I] += now_ - ph_last; ph_last = now_; } while (0)
+  uint64_t ph_last; PH_NOW(ph_last);
 #else
 #define PH_MARK(I) do {} while (0)
 #endif

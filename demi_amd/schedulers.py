@@ -223,3 +223,42 @@ class STSScheduler:
 
     def shutdown(self):
         self._ctx.close()
+
+
+class ReplayException(Exception):
+    """ReplayScheduler.scala:24-25: the recorded execution could not be followed exactly."""
+
+
+class ReplayScheduler:
+    """Strict replay of a full EventTrace (schedulers/ReplayScheduler.scala:71-140, 256-342), used by
+    RunnerUtils.fuzz to validate that a found violation is deterministic before it is kept
+    (RunnerUtils.scala:101-128).  On the GPU path a strict replay is K2 with the full mask: every
+    expected delivery must be present (no DEMI_V_DIVERGED), otherwise ReplayException."""
+
+    def __init__(self, schedulerConfig: SchedulerConfig, device: int = 0, p_max: int = 128):
+        if schedulerConfig.model is None or schedulerConfig.model.inv_kind == T.INV_NONE:
+            raise ValueError("Must invoke setInvariant before test()")
+        self.schedulerConfig = schedulerConfig
+        self.p_max = p_max
+        self._ctx = _native.Context(device)
+        self._ctx.model_load(schedulerConfig.model.to_struct())
+
+    def replay(self, trace: EventTrace, expected: Optional[ViolationFingerprint] = None):
+        """Returns the replay's verdict row; raises ReplayException on divergence."""
+        n = len(trace.original_externals)
+        self._ctx.replay_load(trace.original_externals, trace.events)
+        mask = np.zeros((1, 4), dtype=np.uint64)
+        for e in range(n):
+            mask[0, e >> 6] |= np.uint64(1) << np.uint64(e & 63)
+        lim = T.Limits(0, 0, self.p_max, 1, expected.code if expected is not None else 0,
+                       1 if self.schedulerConfig.populate_all_actors else 0)
+        v = self._ctx.replay_batch(mask, lim)[0]
+        flags = int(v["flags"])
+        if flags & (T.V_PENDING_OVF | T.V_QUEUE_OVF):
+            raise ReplayException("capacity exceeded during replay")
+        if flags & T.V_DIVERGED:
+            raise ReplayException("expected message was not pending: the recorded execution is not reproducible")
+        return v
+
+    def shutdown(self):
+        self._ctx.close()

@@ -140,3 +140,17 @@ def test_sharded_violation_set_allgather_gloo_world2(tmp_path, oracle):
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
         assert "ok" in o
+
+
+def test_experiment_dir_roundtrip(tmp_path, oracle):
+    from demi_amd.apps import SEED_BASE, raft3_config1
+    from demi_amd.schedulers import EventTrace, ViolationFingerprint
+    from demi_amd.serialization import load_experiment, save_experiment
+    model, events, lim = raft3_config1()
+    v, rec, _ = oracle.random_execute(model, events, SEED_BASE + 1, lim)
+    tr = EventTrace(rec, events[:T.verdict_trace_idx(v.flags)])
+    save_experiment(str(tmp_path / "e"), model, tr, ViolationFingerprint(0x1000103), limits=lim, seed=SEED_BASE + 1, mcs=[0, 2, 5])
+    m2, t2, fp2, meta, mcs = load_experiment(str(tmp_path / "e"))
+    assert m2.to_json() == model.to_json() and (t2.events == rec).all() and (t2.original_externals == tr.original_externals).all()
+    assert fp2.code == 0x1000103 and meta["seed"] == SEED_BASE + 1 and list(mcs) == [0, 2, 5]
+    assert os.path.getsize(str(tmp_path / "e" / "event_trace.bin")) == 12 * len(rec)

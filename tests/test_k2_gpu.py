@@ -139,3 +139,34 @@ def test_config4_ddmin_200_external_events(gpu_ctx, oracle):
     res = sts.test_batch([s for s in singles if s], fp)
     assert not any(res)
     sts.shutdown()
+
+
+def test_fuzz_validate_minimize_roundtrip_through_an_experiment_dir(gpu_ctx, tmp_path):
+    """RunnerUtils.fuzz -> validate_replay -> save -> load -> stsSchedDDMin -> verify_mcs, all on the GPU."""
+    from demi_amd.schedulers import RandomScheduler, ReplayException, ReplayScheduler
+    from demi_amd.serialization import load_experiment, save_experiment
+    model, events, lim = raft5_config2()
+    sched = RandomScheduler(SchedulerConfig(model=model), max_executions=2000, invariant_check_interval=30, seed_base=SEED_BASE)
+    sched.setMaxMessages(200)
+    trace, fp = sched.explore(events)
+    sched.shutdown()
+    # a found violation is only kept if a strict replay reproduces it (RunnerUtils.scala:101-128)
+    rs = ReplayScheduler(SchedulerConfig(model=model))
+    v = rs.replay(trace, fp)
+    assert int(v["flags"]) & T.V_VIOLATION
+    # a tampered trace (one delivery that never happened) is rejected
+    bad = EventTrace(trace.events.copy(), trace.original_externals)
+    k = int(np.nonzero(bad.events["kind"] == T.REC_MSG_EVENT)[0][3])
+    bad.events[k]["p0"] ^= 0x55
+    with pytest.raises(ReplayException):
+        rs.replay(bad, fp)
+    rs.shutdown()
+    save_experiment(str(tmp_path / "exp"), model, trace, fp, limits=lim, seed=SEED_BASE)
+    m2, t2, fp2, meta, mcs0 = load_experiment(str(tmp_path / "exp"))
+    assert m2.to_json() == model.to_json() and (t2.events == trace.events).all() and fp2 == fp and mcs0 is None
+    sts = STSScheduler(SchedulerConfig(model=m2), t2)
+    mcs, d, ver = stsSchedDDMin(sts, t2.original_externals, fp2)
+    assert ver is not None and 0 < len(mcs) < len(t2.original_externals)
+    save_experiment(str(tmp_path / "exp"), m2, t2, fp2, mcs=mcs)
+    assert list(load_experiment(str(tmp_path / "exp"))[4]) == list(mcs)
+    sts.shutdown()
