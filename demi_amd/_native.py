@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libdemi_gpu.so")
 
 EXPORTS = ["demi_ctx_create", "demi_ctx_destroy", "demi_last_error", "demi_version", "demi_model_load",
            "demi_trace_load", "demi_random_explore", "demi_random_explore_dev", "demi_random_get_trace", "demi_collect_violations_dev",
-           "demi_replay_load", "demi_replay_batch", "demi_replay_batch_dev", "demi_dpor_load", "demi_dpor_batch", "demi_dpor_explore"]
+           "demi_replay_load", "demi_replay_batch", "demi_replay_batch_dev", "demi_dpor_load", "demi_dpor_batch", "demi_dpor_explore", "demi_random_explore_violations"]
 
 _lib = None
 
@@ -62,6 +62,8 @@ def lib():
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.demi_dpor_explore.argtypes = [C.c_void_p, C.POINTER(T.DporParams), C.POINTER(T.DporSearch), C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(T.DporStats)]
+    L.demi_random_explore_violations.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(T.Limits), C.c_void_p,
+                                                 C.c_uint32, C.POINTER(C.c_uint64)]
     _lib = L
     return L
 
@@ -110,6 +112,15 @@ class Context:
         self._check(lib().demi_random_explore(self._h, C.c_uint64(seed_base), sp, n, C.byref(limits),
                                               out.ctypes.data if n else None))
         return out
+
+    def random_explore_violations(self, n, limits, seed_base=0, cap=1 << 16):
+        """n schedules; only the violating ones come back (VIOLATION_DTYPE, sorted by index) + their count."""
+        import numpy as np
+        out = np.zeros(cap, dtype=T.VIOLATION_DTYPE)
+        cnt = C.c_uint64(0)
+        self._check(lib().demi_random_explore_violations(self._h, C.c_uint64(seed_base), n, C.byref(limits),
+                                                         out.ctypes.data, cap, C.byref(cnt)))
+        return out[:min(cnt.value, cap)].copy(), int(cnt.value)
 
     def random_explore_dev(self, n, limits, d_out_ptr, seed_base=0, d_seeds_ptr=None, stream=None):
         self._check(lib().demi_random_explore_dev(self._h, C.c_uint64(seed_base), d_seeds_ptr, n, C.byref(limits),

@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
 #include <memory>
 #include <queue>
 #include <string>
@@ -60,6 +61,9 @@ struct demi_ctx {
   uint32_t n_dext = 0;
   void* d_dpor = nullptr;           // one arena for a batch's inputs and outputs
   size_t dpor_bytes = 0;
+  demi_violation* d_viol = nullptr; // demi_random_explore_violations: list
+  unsigned long long* d_viol_count = nullptr;
+  size_t viol_cap = 0;
 };
 
 static int fail(demi_ctx* ctx, int code, const char* fmt, ...) {
@@ -97,6 +101,7 @@ extern "C" int demi_ctx_create(int device_ordinal, demi_ctx** out) {
   if (hipMalloc(&ctx->d_model, sizeof(DevModel)) != hipSuccess ||
       hipMalloc(&ctx->d_trace, sizeof(uint64_t) * (DEMI_MAX_EXT_EVENTS + 1)) != hipSuccess ||
       hipMalloc(&ctx->d_counter, sizeof(unsigned long long)) != hipSuccess ||
+      hipMalloc(&ctx->d_viol_count, sizeof(unsigned long long)) != hipSuccess ||
       hipMalloc(&ctx->d_rec, sizeof(demi_rec_event) * DEMI_MAX_REC_EVENTS) != hipSuccess ||
       hipMalloc(&ctx->d_rec_count, sizeof(uint32_t)) != hipSuccess) {
     demi_ctx_destroy(ctx);
@@ -122,6 +127,8 @@ extern "C" void demi_ctx_destroy(demi_ctx* ctx) {
   if (ctx->d_masks) (void)hipFree(ctx->d_masks);
   if (ctx->d_dext) (void)hipFree(ctx->d_dext);
   if (ctx->d_dpor) (void)hipFree(ctx->d_dpor);
+  if (ctx->d_viol) (void)hipFree(ctx->d_viol);
+  if (ctx->d_viol_count) (void)hipFree(ctx->d_viol_count);
   delete ctx;
 }
 
@@ -276,11 +283,6 @@ static int launch_k1(demi_ctx* ctx, uint32_t p_max, K1Args a, hipStream_t stream
   const size_t need = spill_words(blocks * K1_WAVES * 64) * (REC ? 2 : 1) * sizeof(uint32_t);
   if (ctx->spill_bytes < need) {
     if (ctx->d_spill) (void)hipFree(ctx->d_spill);
-  if (ctx->d_rext) (void)hipFree(ctx->d_rext);
-  if (ctx->d_expected) (void)hipFree(ctx->d_expected);
-  if (ctx->d_masks) (void)hipFree(ctx->d_masks);
-  if (ctx->d_dext) (void)hipFree(ctx->d_dext);
-  if (ctx->d_dpor) (void)hipFree(ctx->d_dpor);
     ctx->d_spill = nullptr; ctx->spill_bytes = 0;
     HIP_TRY(ctx, hipMalloc(&ctx->d_spill, need));
     ctx->spill_bytes = need;
@@ -554,8 +556,6 @@ extern "C" int demi_replay_batch(demi_ctx* ctx, const uint64_t* masks, uint64_t 
   }
   if (ctx->masks_cap < n) {
     if (ctx->d_masks) (void)hipFree(ctx->d_masks);
-  if (ctx->d_dext) (void)hipFree(ctx->d_dext);
-  if (ctx->d_dpor) (void)hipFree(ctx->d_dpor);
     ctx->d_masks = nullptr; ctx->masks_cap = 0;
     HIP_TRY(ctx, hipMalloc(&ctx->d_masks, sizeof(uint64_t) * 4 * n));
     ctx->masks_cap = n;
@@ -775,5 +775,40 @@ extern "C" int demi_dpor_explore(demi_ctx* ctx, const demi_dpor_params* par, con
   }
   stats->queue_len = back_track.size();
   stats->exhausted = exhausted ? 1u : 0u;
+  return DEMI_OK;
+}
+
+extern "C" int demi_random_explore_violations(demi_ctx* ctx, uint64_t seed_base, uint64_t n, const demi_limits* limits,
+                                              demi_violation* out, uint32_t cap, uint64_t* n_violations) {
+  if (!ctx) return DEMI_ERR_INVALID_ARG;
+  if (!n_violations || (!out && cap)) return fail(ctx, DEMI_ERR_INVALID_ARG, "null output");
+  *n_violations = 0;
+  if (n == 0) return DEMI_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (ctx->out_cap < n) {
+    if (ctx->d_out) (void)hipFree(ctx->d_out);
+    ctx->d_out = nullptr; ctx->out_cap = 0;
+    HIP_TRY(ctx, hipMalloc(&ctx->d_out, sizeof(demi_verdict) * n));
+    ctx->out_cap = n;
+  }
+  if (ctx->viol_cap < cap || !ctx->d_viol) {
+    if (ctx->d_viol) (void)hipFree(ctx->d_viol);
+    ctx->d_viol = nullptr; ctx->viol_cap = 0;
+    HIP_TRY(ctx, hipMalloc(&ctx->d_viol, sizeof(demi_violation) * (size_t)(cap ? cap : 1)));
+    ctx->viol_cap = cap;
+  }
+  unsigned long long* d_count = ctx->d_viol_count;
+  int rc = demi_random_explore_dev(ctx, seed_base, nullptr, n, limits, ctx->d_out, nullptr);
+  if (rc) return rc;
+  rc = demi_collect_violations_dev(ctx, ctx->d_out, n, 0, ctx->d_viol, cap, d_count, nullptr);
+  if (rc) return rc;
+  unsigned long long cnt = 0;
+  HIP_TRY(ctx, hipMemcpy(&cnt, d_count, sizeof cnt, hipMemcpyDeviceToHost));   // synchronises the stream
+  *n_violations = cnt;
+  const size_t k = cnt < cap ? (size_t)cnt : (size_t)cap;
+  if (k) {
+    HIP_TRY(ctx, hipMemcpy(out, ctx->d_viol, sizeof(demi_violation) * k, hipMemcpyDeviceToHost));
+    std::sort(out, out + k, [](const demi_violation& a, const demi_violation& b) { return a.index < b.index; });
+  }
   return DEMI_OK;
 }

@@ -303,6 +303,14 @@ typedef struct {
   uint32_t flags;
 } demi_violation;        /* 16 bytes */
 
+/* explore() only ever needs the violating executions (RandomScheduler.scala:257-261 returns the first
+ * one): run n schedules, keep the verdicts on the device, and copy back just the compacted violation
+ * set (entries sorted by index; *n_violations may exceed cap, the list is then the `cap` lowest...
+ * no order guarantee beyond "sorted among those returned").  16 bytes per violation cross PCIe
+ * instead of 16 bytes per schedule.                                                                */
+int demi_random_explore_violations(demi_ctx* ctx, uint64_t seed_base, uint64_t n, const demi_limits* limits,
+                                   demi_violation* out, uint32_t cap, uint64_t* n_violations);
+
 int demi_collect_violations_dev(demi_ctx* ctx, const demi_verdict* d_verdicts, uint64_t n, uint64_t index_base,
                                 demi_violation* d_out, uint32_t cap, unsigned long long* d_count,
                                 void* hip_stream);

@@ -285,3 +285,18 @@ def test_shuffle8_three_actor_classes(gpu_ctx, oracle):
     g, c = both(gpu_ctx, oracle, M.shuffle_model(buggy=False), events, 30000, lim)
     assert_same(g, c)
     assert not (g["flags"] & T.V_VIOLATION).any()
+
+
+def test_violation_set_entry_point(gpu_ctx, oracle):
+    model, events, lim = raft5_config2()
+    gpu_ctx.model_load(model.to_struct())
+    gpu_ctx.trace_load(events)
+    want = oracle.random_explore(model, events, 50000, seed_base=SEED_BASE, limits=lim, n_threads=os.cpu_count())
+    idx = np.nonzero(want["flags"] & T.V_VIOLATION)[0]
+    got, n = gpu_ctx.random_explore_violations(50000, lim, seed_base=SEED_BASE)
+    assert n == len(idx) == len(got) and (got["index"] == idx).all()
+    assert (got["fingerprint"] == want["fingerprint"][idx]).all() and (got["flags"] == want["flags"][idx]).all()
+    few, n2 = gpu_ctx.random_explore_violations(50000, lim, seed_base=SEED_BASE, cap=8)
+    assert n2 == len(idx) and len(few) == 8 and set(few["index"]) <= set(idx)
+    none, n3 = gpu_ctx.random_explore_violations(0, lim, seed_base=SEED_BASE)
+    assert n3 == 0 and len(none) == 0

@@ -36,6 +36,16 @@ for n in (1024, 65536, 1 << 20):
     ctx.replay_batch(masks[:64], target)
     t = time.perf_counter(); r = ctx.replay_batch(masks, target); dt = time.perf_counter() - t
     out["k2_replays_per_s_n%d" % n] = n / dt
+# CPU baseline beside it: the oracle's STSSched restatement on the host cores, same candidates (bounded sample)
+from oracle import oracle_py as O  # noqa: E402
+cores = os.cpu_count() or 1
+sample = masks[:262144]
+t = time.perf_counter(); c = O.sts_replay_batch(model, used, rec, sample, target, n_threads=cores); dt = time.perf_counter() - t
+out["k2_cpu_baseline"] = {"value": len(sample) / dt, "unit": "replays/s", "cores": cores, "kind": "port",
+                          "sample": "first %d of the same candidate masks" % len(sample),
+                          "bit_identical_to_gpu": bool((c == r[:len(sample)]).all())}
+# algorithmic bytes per replay: 32 B mask in + 16 B verdict out + the expected events (8 B each) read once per lane
+out["k2_algorithmic_bytes_per_replay"] = 48 + 8 * int(sum(1 for e in rec if e["kind"] in (0, 1, 2, 3, 7) or (e["kind"] == 6 and e["flags"] & 1)))
 out["k2_original_trace"] = {"externals": int(len(used)), "recorded_events": int(len(rec)), "deliveries": T.verdict_deliveries(vv.flags)}
 # DDMin end to end (config 4)
 sts = STSScheduler(SchedulerConfig(model=model), EventTrace(rec, used), p_max=128)
@@ -60,6 +70,9 @@ par = T.DporParams(depth, 0, 0, 0, 64, 4096)
 d._ctx.dpor_batch(pref[:64], par)
 t = time.perf_counter(); d._ctx.dpor_batch(pref, par); dt = time.perf_counter() - t
 out["k3_batch_interleavings_per_s_incl_copies"] = len(pref) / dt
+t = time.perf_counter(); cb = O.dpor_batch(model3, ev3, pref[:512], par); dt = time.perf_counter() - t
+out["k3_cpu_baseline"] = {"value": 512 / dt, "unit": "interleavings/s", "cores": 1, "kind": "port",
+                          "sample": "first 512 of the same prefixes, oracle via ctypes (one call per interleaving)"}
 out["k3_mean_trace_len"] = float(np.mean([len(il.trace) for il in res.interleavings]))
 d.shutdown()
 print(json.dumps(out, indent=1))
