@@ -19,6 +19,7 @@
 #include "k2_replay.hpp"
 #include "k3_dpor.hpp"
 #include "k_collect.hpp"
+#include "dpor_host.hpp"
 
 using namespace demi;
 
@@ -660,24 +661,6 @@ extern "C" int demi_dpor_batch(demi_ctx* ctx, const demi_dpor_trace_entry* prefi
 }
 
 // ----------------------------------------------------------------------------- K3: native exploration loop
-namespace {
-struct BtPoint {          // one entry of the backTrack priority queue (DPORwHeuristics.BacktrackKey)
-  int32_t branch;
-  uint64_t seq;
-  uint64_t k_later, k_earlier;
-  uint32_t trace_id;
-  uint8_t later, earlier;
-};
-struct BtLess {           // DefaultBacktrackOrdering: deepest branch first; ties in creation order
-  bool operator()(const BtPoint& a, const BtPoint& b) const {
-    if (a.branch != b.branch) return a.branch < b.branch;
-    return a.seq > b.seq;
-  }
-};
-struct PairKey { uint64_t a, b; bool operator==(const PairKey& o) const { return a == o.a && b == o.b; } };
-struct PairHash { size_t operator()(const PairKey& p) const { return (size_t)((p.a * 0x9E3779B97F4A7C15ULL) ^ (p.b + 0x7F4A7C159E3779B9ULL + (p.a << 6))); } };
-}  // namespace
-
 extern "C" int demi_dpor_explore(demi_ctx* ctx, const demi_dpor_params* par, const demi_dpor_search* srch,
                                  demi_verdict* out_verdicts, uint32_t* out_prefix_len, uint32_t* out_rounds,
                                  demi_dpor_trace_entry* first_violation_trace, uint32_t* first_violation_len,
@@ -685,16 +668,12 @@ extern "C" int demi_dpor_explore(demi_ctx* ctx, const demi_dpor_params* par, con
   if (!ctx) return DEMI_ERR_INVALID_ARG;
   if (!par || !srch || !out_verdicts || !out_prefix_len || !stats) return fail(ctx, DEMI_ERR_INVALID_ARG, "null pointer");
   if (srch->batch < 1 || srch->max_interleavings < 1) return fail(ctx, DEMI_ERR_INVALID_ARG, "batch and max_interleavings must be >= 1");
-  using Trace = std::vector<demi_dpor_trace_entry>;
-  std::vector<std::shared_ptr<Trace>> traces;        // trace_id -> trace (kept while points refer to it)
-  std::priority_queue<BtPoint, std::vector<BtPoint>, BtLess> back_track;
-  std::unordered_set<PairKey, PairHash> explored;    // ExploredTacker: union over all indices
-  uint64_t seq = 0;
+  demi_host::DporBook book(srch->track_history != 0);
   memset(stats, 0, sizeof *stats);
   stats->first_violation = ~0ull;
   if (first_violation_len) *first_violation_len = 0;
 
-  std::vector<Trace> frontier(1);                    // first run: nextTrace is empty
+  std::vector<demi_host::Trace> frontier(1);         // first run: nextTrace is empty
   const uint32_t max_pairs = par->max_pairs;
   std::vector<demi_dpor_trace_entry> pf, tr;
   std::vector<uint32_t> pl, tl, np;
@@ -722,58 +701,30 @@ extern "C" int demi_dpor_explore(demi_ctx* ctx, const demi_dpor_params* par, con
       const uint64_t idx = stats->interleavings++;
       out_verdicts[idx] = vd[i];
       out_prefix_len[idx] = pl[i];
-      const demi_dpor_trace_entry* t = &tr[i * DEMI_DPOR_MAX_TRACE];
       if (vd[i].flags & DEMI_V_VIOLATION) {
         stats->violations++;
         found = true;
         if (stats->first_violation == ~0ull) {
           stats->first_violation = idx;
-          if (first_violation_trace) memcpy(first_violation_trace, t, sizeof(demi_dpor_trace_entry) * tl[i]);
+          if (first_violation_trace) memcpy(first_violation_trace, &tr[i * DEMI_DPOR_MAX_TRACE], sizeof(demi_dpor_trace_entry) * tl[i]);
           if (first_violation_len) *first_violation_len = tl[i];
         }
       }
-      // dpor(): bookkeeping for this interleaving's racing pairs (:1122-1139)
-      if (np[i]) {
-        auto tp = std::make_shared<Trace>(t, t + tl[i]);
-        bool used = false;
-        const demi_dpor_pair* pp = &pr[i * (size_t)max_pairs];
-        for (uint32_t k = 0; k < np[i]; k++) {
-          const uint64_t ke = t[pp[k].earlier].key, kl = t[pp[k].later].key;
-          if (srch->track_history) {
-            explored.insert(PairKey{ke, kl});                       // setExplored(branchI, (earlier, later))
-            if (explored.count(PairKey{kl, ke})) continue;           // getNext would skip it (:1153-1157)
-          }
-          if (!used) { traces.push_back(tp); used = true; }
-          back_track.push(BtPoint{(int32_t)pp[k].branch, seq++, kl, ke, (uint32_t)(traces.size() - 1), pp[k].later, pp[k].earlier});
-        }
-      }
     }
+    // dpor(): bookkeeping for the racing pairs of the whole round (:1122-1139), sharded over host threads
+    book.absorb(tr.data(), tl.data(), pr.data(), np.data(), n, max_pairs);
     frontier.clear();
     if (srch->stop_if_violation && found) break;
     if (stats->interleavings >= srch->max_interleavings) break;
     // getNext (:1142-1162) for up to `batch` points
     while (frontier.size() < srch->batch && stats->interleavings + frontier.size() < srch->max_interleavings) {
-      bool got = false;
-      while (!back_track.empty()) {
-        const BtPoint p = back_track.top();
-        back_track.pop();
-        if (srch->track_history) {
-          if (explored.count(PairKey{p.k_later, p.k_earlier})) continue;
-          explored.insert(PairKey{p.k_later, p.k_earlier});          // setExplored(maxIndex, (e1, e2)) (:1170-1172)
-        }
-        const Trace& src = *traces[p.trace_id];
-        Trace nxt(src.begin(), src.begin() + p.branch + 1);          // trace.take(maxIndex + 1) ++ needToReplay
-        for (int k = p.branch + 1; k <= (int)p.later; k++)
-          if (k != (int)p.earlier) nxt.push_back(src[k]);
-        frontier.push_back(std::move(nxt));
-        got = true;
-        break;
-      }
-      if (!got) break;
+      demi_host::Trace nxt;
+      if (!book.get_next(nxt)) break;
+      frontier.push_back(std::move(nxt));
     }
-    if (frontier.empty() && back_track.empty()) exhausted = true;
+    if (frontier.empty() && book.empty()) exhausted = true;
   }
-  stats->queue_len = back_track.size();
+  stats->queue_len = book.queue_len();
   stats->exhausted = exhausted ? 1u : 0u;
   return DEMI_OK;
 }

@@ -4,6 +4,6 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 cp demi_amd/libdemi_gpu.so /tmp/libdemi_gpu.so.keep
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -DDEMI_K1_PHASES -o demi_amd/libdemi_gpu.so demi_amd/csrc/demi_gpu.hip
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -pthread -DDEMI_K1_PHASES -o demi_amd/libdemi_gpu.so demi_amd/csrc/demi_gpu.hip
 python bench.py --steps 2 --warmup 1 --no-cpu-baseline ${BENCH_ARGS} 2>&1 | grep -E "k1 phases|value" | cut -c1-400
 cp /tmp/libdemi_gpu.so.keep demi_amd/libdemi_gpu.so
