@@ -13,7 +13,8 @@ LIB_PATH = os.path.join(_HERE, "libdemi_gpu.so")
 
 EXPORTS = ["demi_ctx_create", "demi_ctx_destroy", "demi_last_error", "demi_version", "demi_model_load",
            "demi_trace_load", "demi_random_explore", "demi_random_explore_dev", "demi_random_get_trace", "demi_collect_violations_dev",
-           "demi_replay_load", "demi_replay_batch", "demi_replay_batch_dev", "demi_dpor_load", "demi_dpor_batch", "demi_dpor_explore", "demi_random_explore_violations"]
+           "demi_replay_load", "demi_replay_batch", "demi_replay_batch_dev", "demi_dpor_load", "demi_dpor_batch", "demi_dpor_explore", "demi_random_explore_violations",
+           "demi_replay_removal_batch", "demi_replay_get_kept"]
 
 _lib = None
 
@@ -57,6 +58,9 @@ def lib():
     L.demi_replay_load.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
     L.demi_replay_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(T.Limits), C.c_void_p]
     L.demi_replay_batch_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(T.Limits), C.c_void_p, C.c_void_p]
+    L.demi_replay_removal_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(T.Limits), C.c_void_p]
+    L.demi_replay_get_kept.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(T.Limits), C.POINTER(T.Verdict),
+                                       C.c_void_p]
     L.demi_dpor_load.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
     L.demi_dpor_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.POINTER(T.DporParams),
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -145,6 +149,37 @@ class Context:
         self._check(lib().demi_replay_batch(self._h, masks.ctypes.data if len(masks) else None, len(masks),
                                             C.byref(limits), out.ctypes.data if len(masks) else None))
         return out
+
+    def replay_removal_batch(self, skips, limits, masks=None):
+        """One STSScheduler.test per entry of skips: the loaded trace minus the delivery at that recorded-event
+        index (0xFFFFFFFF = nothing removed); masks (uint64[n, 4]) default to every external kept."""
+        import numpy as np
+        skips = np.ascontiguousarray(skips, dtype=np.uint32)
+        out = np.zeros(len(skips), dtype=T.VERDICT_DTYPE)
+        if len(skips) == 0:
+            return out
+        mp = None
+        if masks is not None:
+            masks = np.ascontiguousarray(masks, dtype=np.uint64).reshape(-1, 4)
+            if len(masks) != len(skips):
+                raise ValueError("one mask per removal candidate")
+            mp = masks.ctypes.data
+        self._check(lib().demi_replay_removal_batch(self._h, mp, skips.ctypes.data, len(skips), C.byref(limits),
+                                                    out.ctypes.data))
+        return out
+
+    def replay_get_kept(self, n_rec, skip, limits, mask=None):
+        """(Verdict, uint8[n_rec]) of one candidate: which recorded events make up its executed trace."""
+        import numpy as np
+        mp = None
+        if mask is not None:
+            mask = np.ascontiguousarray(mask, dtype=np.uint64).reshape(4)
+            mp = mask.ctypes.data
+        v = T.Verdict()
+        kept = np.zeros(max(int(n_rec), 1), dtype=np.uint8)
+        self._check(lib().demi_replay_get_kept(self._h, mp, C.c_uint32(int(skip) & 0xFFFFFFFF), C.byref(limits),
+                                               C.byref(v), kept.ctypes.data))
+        return v, kept[:int(n_rec)]
 
     def dpor_load(self, externals):
         import numpy as np

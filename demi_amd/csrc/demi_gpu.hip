@@ -56,6 +56,10 @@ struct demi_ctx {
   uint32_t replay_spawned = 0;      // actors with a SpawnEvent in the original trace
   uint64_t* d_masks = nullptr;
   size_t masks_cap = 0;
+  std::vector<int32_t> exp_of_rec;  // recorded-event index -> index in d_expected (-1: not lowered, a nop in replay)
+  uint32_t* d_skip = nullptr;       // removal candidates (demi_replay_removal_batch)
+  size_t skip_cap = 0;
+  uint8_t* d_kept = nullptr;        // executed-trace marks of one candidate (demi_replay_get_kept)
   // K3 (DPOR)
   bool have_dpor = false;
   uint64_t* d_dext = nullptr;
@@ -126,6 +130,8 @@ extern "C" void demi_ctx_destroy(demi_ctx* ctx) {
   if (ctx->d_rext) (void)hipFree(ctx->d_rext);
   if (ctx->d_expected) (void)hipFree(ctx->d_expected);
   if (ctx->d_masks) (void)hipFree(ctx->d_masks);
+  if (ctx->d_skip) (void)hipFree(ctx->d_skip);
+  if (ctx->d_kept) (void)hipFree(ctx->d_kept);
   if (ctx->d_dext) (void)hipFree(ctx->d_dext);
   if (ctx->d_dpor) (void)hipFree(ctx->d_dpor);
   if (ctx->d_viol) (void)hipFree(ctx->d_viol);
@@ -455,9 +461,11 @@ extern "C" int demi_replay_load(demi_ctx* ctx, const demi_ext_event* ext, uint32
   // k-th Send; our recorder stores that index explicitly (ext_idx)
   std::vector<uint8_t> send_of_id(2 * DEMI_MAX_REC_EVENTS + 2, 255);
   std::vector<uint64_t> expd;
+  std::vector<int32_t> exp_of_rec(n_rec, -1);
   uint32_t spawned = 0;
   for (uint32_t i = 0; i < n_rec; i++) {
     const demi_rec_event& e = rec[i];
+    const size_t before = expd.size();
     auto pack = [](uint32_t kind, uint32_t a, uint32_t b, uint32_t type, uint32_t p0, uint32_t p1, uint32_t x) {
       return (uint64_t)kind | ((uint64_t)a << 8) | ((uint64_t)b << 16) | ((uint64_t)type << 24) | ((uint64_t)p0 << 32) |
              ((uint64_t)p1 << 40) | ((uint64_t)x << 48);
@@ -493,6 +501,7 @@ extern "C" int demi_replay_load(demi_ctx* ctx, const demi_ext_event* ext, uint32
       default:
         return fail(ctx, DEMI_ERR_INVALID_TRACE, "recorded event %u: unknown kind %u", i, e.kind);
     }
+    if (expd.size() != before) exp_of_rec[i] = (int32_t)before;
   }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   if (!ctx->d_rext) HIP_TRY(ctx, hipMalloc(&ctx->d_rext, sizeof(uint64_t) * (DEMI_MAX_EXT_EVENTS + 1)));
@@ -502,17 +511,17 @@ extern "C" int demi_replay_load(demi_ctx* ctx, const demi_ext_event* ext, uint32
   ctx->n_rext = n_ext;
   ctx->n_expected = (uint32_t)expd.size();
   ctx->replay_spawned = spawned;
+  ctx->exp_of_rec.swap(exp_of_rec);
   ctx->have_replay = true;
   return DEMI_OK;
 }
 
-extern "C" int demi_replay_batch_dev(demi_ctx* ctx, const uint64_t* d_masks, uint64_t n, const demi_limits* lim,
-                                     demi_verdict* d_out, void* hip_stream) {
-  if (!ctx) return DEMI_ERR_INVALID_ARG;
-  if (n == 0) return DEMI_OK;
+// d_masks == nullptr: every external kept; d_skip / d_kept: see K2Args
+static int replay_launch(demi_ctx* ctx, const uint64_t* d_masks, const uint32_t* d_skip, uint8_t* d_kept, uint64_t n,
+                         const demi_limits* lim, demi_verdict* d_out, void* hip_stream) {
   if (!ctx->have_model) return fail(ctx, DEMI_ERR_NO_MODEL, "no model loaded");
   if (!ctx->have_replay) return fail(ctx, DEMI_ERR_NO_TRACE, "demi_replay_load must precede demi_replay_batch");
-  if (!lim || !d_masks || !d_out) return fail(ctx, DEMI_ERR_INVALID_ARG, "null pointer");
+  if (!lim || !d_out) return fail(ctx, DEMI_ERR_INVALID_ARG, "null pointer");
   if (!lim->looking_for_valid) return fail(ctx, DEMI_ERR_INVALID_ARG, "replay needs the target fingerprint (looking_for)");
   uint32_t p_max = lim->p_max ? lim->p_max : 64;
   if (p_max > DEMI_MAX_PENDING) return fail(ctx, DEMI_ERR_INVALID_ARG, "p_max must be 1..%d", DEMI_MAX_PENDING);
@@ -536,10 +545,102 @@ extern "C" int demi_replay_batch_dev(demi_ctx* ctx, const uint64_t* d_masks, uin
   a.exists = lim->populate_all ? ((1u << h.n_actors) - 1) : ctx->replay_spawned;
   a.expected = ctx->d_expected; a.n_exp = ctx->n_expected;
   a.p_max = p_max; a.looking_for = lim->looking_for;
-  a.masks = d_masks; a.n = n; a.out = d_out; a.work_counter = ctx->d_counter; a.spill = ctx->d_spill;
+  a.masks = d_masks; a.skip = d_skip; a.kept = d_kept;
+  a.n = n; a.out = d_out; a.work_counter = ctx->d_counter; a.spill = ctx->d_spill;
   HIP_TRY(ctx, hipMemsetAsync(a.work_counter, 0, sizeof(unsigned long long), stream));
   hipLaunchKernelGGL(k2_replay, dim3((unsigned)blocks), dim3(K2_WAVES * 64), lds, stream, a);
   HIP_TRY(ctx, hipGetLastError());
+  return DEMI_OK;
+}
+
+extern "C" int demi_replay_batch_dev(demi_ctx* ctx, const uint64_t* d_masks, uint64_t n, const demi_limits* lim,
+                                     demi_verdict* d_out, void* hip_stream) {
+  if (!ctx) return DEMI_ERR_INVALID_ARG;
+  if (n == 0) return DEMI_OK;
+  if (!d_masks) return fail(ctx, DEMI_ERR_INVALID_ARG, "null pointer");
+  return replay_launch(ctx, d_masks, nullptr, nullptr, n, lim, d_out, hip_stream);
+}
+
+static int ensure_replay_buffers(demi_ctx* ctx, uint64_t n, bool masks) {
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (ctx->out_cap < n) {
+    if (ctx->d_out) (void)hipFree(ctx->d_out);
+    ctx->d_out = nullptr; ctx->out_cap = 0;
+    HIP_TRY(ctx, hipMalloc(&ctx->d_out, sizeof(demi_verdict) * n));
+    ctx->out_cap = n;
+  }
+  if (masks && ctx->masks_cap < n) {
+    if (ctx->d_masks) (void)hipFree(ctx->d_masks);
+    ctx->d_masks = nullptr; ctx->masks_cap = 0;
+    HIP_TRY(ctx, hipMalloc(&ctx->d_masks, sizeof(uint64_t) * 4 * n));
+    ctx->masks_cap = n;
+  }
+  return DEMI_OK;
+}
+
+// recorded-event index of a removal candidate -> index in the lowered trace (must be a MsgEvent)
+static int skip_to_expected(demi_ctx* ctx, uint32_t skip, uint32_t* out) {
+  if (skip == 0xFFFFFFFFu) { *out = skip; return DEMI_OK; }
+  if (skip >= ctx->exp_of_rec.size() || ctx->exp_of_rec[skip] < 0)
+    return fail(ctx, DEMI_ERR_INVALID_ARG, "removal candidate %u is not a delivery of the loaded trace", skip);
+  *out = (uint32_t)ctx->exp_of_rec[skip];
+  return DEMI_OK;
+}
+
+extern "C" int demi_replay_removal_batch(demi_ctx* ctx, const uint64_t* masks, const uint32_t* skip, uint64_t n,
+                                         const demi_limits* lim, demi_verdict* out) {
+  if (!ctx) return DEMI_ERR_INVALID_ARG;
+  if (n == 0) return DEMI_OK;
+  if (!skip || !out) return fail(ctx, DEMI_ERR_INVALID_ARG, "null pointer");
+  if (!ctx->have_replay) return fail(ctx, DEMI_ERR_NO_TRACE, "demi_replay_load must precede demi_replay_removal_batch");
+  int rc = ensure_replay_buffers(ctx, n, masks != nullptr);
+  if (rc) return rc;
+  if (ctx->skip_cap < n) {
+    if (ctx->d_skip) (void)hipFree(ctx->d_skip);
+    ctx->d_skip = nullptr; ctx->skip_cap = 0;
+    HIP_TRY(ctx, hipMalloc(&ctx->d_skip, sizeof(uint32_t) * n));
+    ctx->skip_cap = n;
+  }
+  std::vector<uint32_t> sk(n);
+  for (uint64_t i = 0; i < n; i++) {
+    rc = skip_to_expected(ctx, skip[i], &sk[i]);
+    if (rc) return rc;
+  }
+  HIP_TRY(ctx, hipMemcpy(ctx->d_skip, sk.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice));
+  if (masks) HIP_TRY(ctx, hipMemcpy(ctx->d_masks, masks, sizeof(uint64_t) * 4 * n, hipMemcpyHostToDevice));
+  rc = replay_launch(ctx, masks ? ctx->d_masks : nullptr, ctx->d_skip, nullptr, n, lim, ctx->d_out, nullptr);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  HIP_TRY(ctx, hipMemcpy(out, ctx->d_out, sizeof(demi_verdict) * n, hipMemcpyDeviceToHost));
+  return DEMI_OK;
+}
+
+extern "C" int demi_replay_get_kept(demi_ctx* ctx, const uint64_t* mask, uint32_t skip, const demi_limits* lim,
+                                    demi_verdict* verdict, uint8_t* kept) {
+  if (!ctx) return DEMI_ERR_INVALID_ARG;
+  if (!verdict || !kept) return fail(ctx, DEMI_ERR_INVALID_ARG, "null pointer");
+  if (!ctx->have_replay) return fail(ctx, DEMI_ERR_NO_TRACE, "demi_replay_load must precede demi_replay_get_kept");
+  int rc = ensure_replay_buffers(ctx, 1, true);
+  if (rc) return rc;
+  if (ctx->skip_cap < 1) {
+    HIP_TRY(ctx, hipMalloc(&ctx->d_skip, sizeof(uint32_t)));
+    ctx->skip_cap = 1;
+  }
+  if (!ctx->d_kept) HIP_TRY(ctx, hipMalloc(&ctx->d_kept, DEMI_MAX_REC_EVENTS + 1));
+  uint32_t sk = 0;
+  rc = skip_to_expected(ctx, skip, &sk);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipMemcpy(ctx->d_skip, &sk, sizeof sk, hipMemcpyHostToDevice));
+  if (mask) HIP_TRY(ctx, hipMemcpy(ctx->d_masks, mask, sizeof(uint64_t) * 4, hipMemcpyHostToDevice));
+  HIP_TRY(ctx, hipMemset(ctx->d_kept, 0, DEMI_MAX_REC_EVENTS + 1));
+  rc = replay_launch(ctx, mask ? ctx->d_masks : nullptr, ctx->d_skip, ctx->d_kept, 1, lim, ctx->d_out, nullptr);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  HIP_TRY(ctx, hipMemcpy(verdict, ctx->d_out, sizeof(demi_verdict), hipMemcpyDeviceToHost));
+  std::vector<uint8_t> ke(ctx->n_expected + 1);
+  if (ctx->n_expected) HIP_TRY(ctx, hipMemcpy(ke.data(), ctx->d_kept, ctx->n_expected, hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < ctx->exp_of_rec.size(); i++)
+    kept[i] = ctx->exp_of_rec[i] >= 0 ? ke[ctx->exp_of_rec[i]] : 0;
   return DEMI_OK;
 }
 
@@ -548,21 +649,10 @@ extern "C" int demi_replay_batch(demi_ctx* ctx, const uint64_t* masks, uint64_t 
   if (!ctx) return DEMI_ERR_INVALID_ARG;
   if (n == 0) return DEMI_OK;
   if (!masks || !out) return fail(ctx, DEMI_ERR_INVALID_ARG, "null pointer");
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
-  if (ctx->out_cap < n) {
-    if (ctx->d_out) (void)hipFree(ctx->d_out);
-    ctx->d_out = nullptr; ctx->out_cap = 0;
-    HIP_TRY(ctx, hipMalloc(&ctx->d_out, sizeof(demi_verdict) * n));
-    ctx->out_cap = n;
-  }
-  if (ctx->masks_cap < n) {
-    if (ctx->d_masks) (void)hipFree(ctx->d_masks);
-    ctx->d_masks = nullptr; ctx->masks_cap = 0;
-    HIP_TRY(ctx, hipMalloc(&ctx->d_masks, sizeof(uint64_t) * 4 * n));
-    ctx->masks_cap = n;
-  }
+  int rc = ensure_replay_buffers(ctx, n, true);
+  if (rc) return rc;
   HIP_TRY(ctx, hipMemcpy(ctx->d_masks, masks, sizeof(uint64_t) * 4 * n, hipMemcpyHostToDevice));
-  int rc = demi_replay_batch_dev(ctx, ctx->d_masks, n, lim, ctx->d_out, nullptr);
+  rc = demi_replay_batch_dev(ctx, ctx->d_masks, n, lim, ctx->d_out, nullptr);
   if (rc) return rc;
   HIP_TRY(ctx, hipDeviceSynchronize());
   HIP_TRY(ctx, hipMemcpy(out, ctx->d_out, sizeof(demi_verdict) * n, hipMemcpyDeviceToHost));

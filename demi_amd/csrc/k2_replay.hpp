@@ -32,7 +32,9 @@ struct K2Args {
   const uint64_t* expected; // lowered original trace [n_exp]
   uint32_t n_exp;
   uint32_t p_max, looking_for;
-  const uint64_t* masks;    // [n][4]
+  const uint64_t* masks;    // [n][4]; null = every external kept
+  const uint32_t* skip;     // [n] index (in `expected`) of one MSG_EVENT removed from the trace, or null
+  uint8_t* kept;            // [n][n_exp] (pre-zeroed) 1 where the expected event took effect, or null
   uint64_t n;
   demi_verdict* out;
   unsigned long long* work_counter;
@@ -60,7 +62,7 @@ __global__ __launch_bounds__(K2_WAVES * 64) void k2_replay(const K2Args args) {
   bool active = false, fresh = false;
   uint64_t sched = 0, hash = 0;
   uint64_t m0 = 0, m1 = 0, m2 = 0, m3 = 0;   // candidate mask
-  uint32_t idx = 0, cur = 0, n_pend = 0, count = 0, ignored = 0, flags = 0, rep = 0;
+  uint32_t idx = 0, cur = 0, n_pend = 0, count = 0, ignored = 0, flags = 0, rep = 0, skip = 0xFFFFFFFFu;
   Net net = {0, 0, 0};
   uint64_t tq = 0;
   uint32_t n_tq = 0;
@@ -119,8 +121,13 @@ __global__ __launch_bounds__(K2_WAVES * 64) void k2_replay(const K2Args args) {
     if (active) {
       if (fresh) {
         fresh = false;
-        const uint64_t* mk = args.masks + sched * 4;
-        m0 = mk[0]; m1 = mk[1]; m2 = mk[2]; m3 = mk[3];
+        if (args.masks) {
+          const uint64_t* mk = args.masks + sched * 4;
+          m0 = mk[0]; m1 = mk[1]; m2 = mk[2]; m3 = mk[3];
+        } else {
+          m0 = m1 = m2 = m3 = ~0ull;
+        }
+        skip = args.skip ? args.skip[sched] : 0xFFFFFFFFu;
         hash = 0xCBF29CE484222325ULL;
         net.inaccessible = exists; net.killed = 0; net.partitioned = 0;
         for (uint32_t a = 0; a < A; a++) st[a * 64] = t.init[a];
@@ -145,16 +152,20 @@ __global__ __launch_bounds__(K2_WAVES * 64) void k2_replay(const K2Args args) {
           if (xk != want_kind || xa != a || (two && xb != b)) continue;
           cur++;
           cur_skip();
+          if (args.kept) args.kept[sched * NX + idx - 1] = 1;
           if (kind == DEMI_REC_SPAWN) { net.inaccessible &= ~(1u << a); net.killed &= ~(1u << a); }
           else if (kind == DEMI_REC_KILL) { net.killed |= 1u << a; net.inaccessible |= 1u << a; }
           else if (kind == DEMI_REC_PARTITION) net.partitioned |= 1ULL << (a * 8 + b);
           else net.partitioned &= ~(1ULL << (a * 8 + b));
         } else if (kind == DEMI_REC_MSG_SEND) {
           // external MsgSend -> enqueue_message (:509-511) unless its Send was pruned
-          if (IN_MASK(ext) && ((exists >> b) & 1))
+          if (IN_MASK(ext) && ((exists >> b) & 1)) {
             PEND_APPEND(msg_word((uint32_t)(e >> 24) & 0xFF, DEMI_DEADLETTERS, b, (uint32_t)(e >> 32) & 0xFF,
                                  (uint32_t)(e >> 40) & 0xFF));
+            if (args.kept && !(flags & DEMI_OVF_ANY)) args.kept[sched * NX + idx - 1] = 1;
+          }
         } else {  // MSG_EVENT
+          if (idx - 1 == skip) continue;               // the delivery this candidate removes (OneAtATimeRemoval.scala:57-124)
           if (ext != 255 && !IN_MASK(ext)) continue;   // pruned together with its Send (filterSends)
           const uint32_t want = msg_word((uint32_t)(e >> 24) & 0xFF, a, b, (uint32_t)(e >> 32) & 0xFF,
                                          (uint32_t)(e >> 40) & 0xFF);
@@ -164,6 +175,7 @@ __global__ __launch_bounds__(K2_WAVES * 64) void k2_replay(const K2Args args) {
           if (k == n_pend) { ignored++; continue; }     // "Ignoring message" (:528-529)
           pend_store(mem, k, pend_load(mem, n_pend - 1));
           n_pend--;
+          if (args.kept) args.kept[sched * NX + idx - 1] = 1;
           w = want;
           deliver = true;
           break;

@@ -228,6 +228,18 @@ class STSScheduler:
         v = self.verdicts([tuple(subseq)], violationFingerprint)[0]
         return v if (int(v["flags"]) & T.V_VIOLATION) else None
 
+    def executed_trace(self, subseq, violationFingerprint: ViolationFingerprint) -> Optional[EventTrace]:
+        """test() with the EventTrace it returns on success (:286-292), re-based on `subseq`
+        (trace.setOriginalExternalEvents(mcs), RunnerUtils.scala:698): DDMin.verify_mcs's verified_mcs,
+        the input of internal-event minimization."""
+        from .internal_minimization import executed_trace
+        subseq = tuple(subseq)
+        v, kept = self._ctx.replay_get_kept(len(self.original_trace.events), 0xFFFFFFFF,
+                                            self._limits(violationFingerprint), mask=self._masks([subseq])[0])
+        if not (int(v.flags) & T.V_VIOLATION):
+            return None
+        return executed_trace(self.original_trace, kept, subseq=subseq)
+
     def shutdown(self):
         self._ctx.close()
 

@@ -212,6 +212,23 @@ int demi_replay_batch(demi_ctx* ctx, const uint64_t* masks /* [n][4] */, uint64_
 int demi_replay_batch_dev(demi_ctx* ctx, const uint64_t* d_masks, uint64_t n, const demi_limits* limits,
                           demi_verdict* d_out, void* hip_stream);
 
+/* ---------------------------------------------------------- K2 for internal-event minimization
+ * Replaces RunnerUtils.testWithStsSched (RunnerUtils.scala:913-943) as called by
+ * STSSchedMinimizer.minimize (minification/internal_minimization/ScheduleCheckers.scala:50-57) on the
+ * traces a OneAtATimeStrategy proposes (OneAtATimeRemoval.scala:57-124): candidate i is the loaded trace
+ * (demi_replay_load, normally the verified MCS execution and its externals) minus the one MsgEvent /
+ * TimerDelivery at index skip[i] of original_trace (0xFFFFFFFF removes nothing).  A removed delivery is
+ * not "ignored": it does not set DEMI_V_DIVERGED.  masks == NULL keeps every external (test(mcs)).
+ * A removal strategy proposes its candidates one after another assuming each fails; the mirror
+ * (demi_amd/internal_minimization.py) enumerates that whole sequence and evaluates it in one launch.  */
+int demi_replay_removal_batch(demi_ctx* ctx, const uint64_t* masks /* [n][4] or NULL */, const uint32_t* skip /* [n] */,
+                              uint64_t n, const demi_limits* limits, demi_verdict* out);
+/* The executed trace of one candidate, i.e. what test() returns on success (STSScheduler.scala:286-292):
+ * kept[i] = 1 iff original_trace[i] took effect in the replay (external event applied, external MsgSend
+ * enqueued, MsgEvent delivered); absent deliveries, pruned events and replay nops are 0.  kept: [n_rec]. */
+int demi_replay_get_kept(demi_ctx* ctx, const uint64_t* mask /* [4] or NULL */, uint32_t skip,
+                         const demi_limits* limits, demi_verdict* verdict, uint8_t* kept);
+
 /* ---------------------------------------------------------- K3: DPORwHeuristics interleavings
  * Replaces, per interleaving, DPORwHeuristics.schedule_new_message / event_produced / getMessage /
  * runExternal / notify_quiescence (DPORwHeuristics.scala:421-648, 803-847, 773-801, 684-721,

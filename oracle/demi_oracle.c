@@ -790,8 +790,12 @@ static int ext_equal(const demi_ext_event* e, uint32_t kind, uint32_t a, uint32_
 
 static int sts_replay_in(sts_t* x, const demi_model* m, const demi_ext_event* ext, uint32_t n_ext,
                          const demi_rec_event* rec, uint32_t n_rec, const uint64_t mask[4], const demi_limits* lim,
-                         demi_verdict* out, uint32_t* n_ignored) {
+                         demi_verdict* out, uint32_t* n_ignored, uint32_t skip, uint8_t* kept) {
+  /* skip: index of one MsgEvent removed from the trace before the replay (STSSchedMinimizer's candidate,
+   * V/minification/internal_minimization/OneAtATimeRemoval.scala:57-124); kept[i] = 1 iff rec[i] took effect
+   * in the replay, i.e. is part of the executed trace test() returns (V/schedulers/STSScheduler.scala:286-292) */
   memset(x, 0, offsetof(sts_t, fx));
+  if (kept) memset(kept, 0, n_rec);
   x->m = m;
   x->p_max = lim->p_max ? lim->p_max : 64;
   if (x->p_max > PEND_HARD_CAP) x->p_max = PEND_HARD_CAP;
@@ -825,6 +829,7 @@ static int sts_replay_in(sts_t* x, const demi_model* m, const demi_ext_event* ex
         if (cur >= n_ext || !ext_equal(&ext[cur], e->kind, a, b)) break;
         cur++;
         CUR_SKIP();
+        if (kept) kept[idx] = 1;
         if (e->kind == DEMI_REC_SPAWN) { x->inaccessible &= ~(1u << a); x->killed &= ~(1u << a); }
         else if (e->kind == DEMI_REC_KILL) { x->killed |= 1u << a; x->inaccessible |= 1u << a; }
         else if (e->kind == DEMI_REC_PARTITION) x->partitioned |= 1ULL << (a * 8 + b);
@@ -833,16 +838,20 @@ static int sts_replay_in(sts_t* x, const demi_model* m, const demi_ext_event* ex
       }
       case DEMI_REC_MSG_SEND:
         /* external MsgSend: enqueue_message (:509-511) unless its Send was pruned; internal: nothing */
-        if ((e->flags & 1) && IN_MASK(e->ext_idx) && ((x->exists >> e->rcv) & 1))
+        if ((e->flags & 1) && IN_MASK(e->ext_idx) && ((x->exists >> e->rcv) & 1)) {
           sts_pend_add(x, msg_word(e->msg_type, DEMI_DEADLETTERS, e->rcv, e->p0, e->p1));
+          if (kept && !(x->flags & OVF_ANY)) kept[idx] = 1;
+        }
         break;
       case DEMI_REC_MSG_EVENT: {
         uint8_t s = e->id < sizeof send_of_id ? send_of_id[e->id] : 255;
+        if (idx == skip) break;             /* the delivery this candidate removes */
         if (s != 255 && !IN_MASK(s)) break; /* pruned together with its Send */
         uint32_t w = msg_word(e->msg_type, e->snd, e->rcv, e->p0, e->p1);
         int k = sts_pend_find(x, w);
         if (k < 0) { x->ignored++; break; } /* "Ignoring message" (:528-529) */
         sts_pend_remove(x, k);
+        if (kept) kept[idx] = 1;
         sts_deliver(x, w);
         break;
       }
@@ -873,14 +882,26 @@ int orc_sts_replay(const demi_model* m, const demi_ext_event* ext, uint32_t n_ex
                    uint32_t* n_ignored) {
   sts_t* x = (sts_t*)malloc(sizeof(sts_t));
   if (!x) return DEMI_ERR_INVALID_ARG;
-  int rc = sts_replay_in(x, m, ext, n_ext, rec, n_rec, mask, lim, out, n_ignored);
+  int rc = sts_replay_in(x, m, ext, n_ext, rec, n_rec, mask, lim, out, n_ignored, 0xFFFFFFFFu, NULL);
+  free(x);
+  return rc;
+}
+
+static const uint64_t STS_ALL[4] = {~0ULL, ~0ULL, ~0ULL, ~0ULL};
+
+int orc_sts_removal(const demi_model* m, const demi_ext_event* ext, uint32_t n_ext, const demi_rec_event* rec,
+                    uint32_t n_rec, const uint64_t* mask, uint32_t skip, const demi_limits* lim, demi_verdict* out,
+                    uint8_t* kept) {
+  sts_t* x = (sts_t*)malloc(sizeof(sts_t));
+  if (!x) return DEMI_ERR_INVALID_ARG;
+  int rc = sts_replay_in(x, m, ext, n_ext, rec, n_rec, mask ? mask : STS_ALL, lim, out, NULL, skip, kept);
   free(x);
   return rc;
 }
 
 typedef struct {
   const demi_model* m; const demi_ext_event* ext; uint32_t n_ext; const demi_rec_event* rec; uint32_t n_rec;
-  const uint64_t* masks; uint64_t lo, hi; const demi_limits* lim; demi_verdict* out;
+  const uint64_t* masks; uint64_t lo, hi; const demi_limits* lim; demi_verdict* out; const uint32_t* skip;
 } sts_job_t;
 
 static void* sts_job_main(void* p) {
@@ -888,27 +909,40 @@ static void* sts_job_main(void* p) {
   sts_t* x = (sts_t*)malloc(sizeof(sts_t));
   if (!x) return NULL;
   for (uint64_t i = j->lo; i < j->hi; i++)
-    sts_replay_in(x, j->m, j->ext, j->n_ext, j->rec, j->n_rec, &j->masks[4 * i], j->lim, &j->out[i], NULL);
+    sts_replay_in(x, j->m, j->ext, j->n_ext, j->rec, j->n_rec, j->masks ? &j->masks[4 * i] : STS_ALL, j->lim, &j->out[i],
+                  NULL, j->skip ? j->skip[i] : 0xFFFFFFFFu, NULL);
   free(x);
   return NULL;
 }
 
-int orc_sts_replay_batch(const demi_model* m, const demi_ext_event* ext, uint32_t n_ext, const demi_rec_event* rec,
-                         uint32_t n_rec, const uint64_t* masks, uint64_t n, const demi_limits* lim, demi_verdict* out,
-                         int n_threads) {
+static int sts_batch(const demi_model* m, const demi_ext_event* ext, uint32_t n_ext, const demi_rec_event* rec,
+                     uint32_t n_rec, const uint64_t* masks, const uint32_t* skip, uint64_t n, const demi_limits* lim,
+                     demi_verdict* out, int n_threads) {
   if (n_threads < 1) n_threads = 1;
   if (n_threads > 256) n_threads = 256;
   pthread_t th[256];
   sts_job_t jobs[256];
   for (int t = 0; t < n_threads; t++) {
     jobs[t] = (sts_job_t){m, ext, n_ext, rec, n_rec, masks, n * (uint64_t)t / (uint64_t)n_threads,
-                          n * (uint64_t)(t + 1) / (uint64_t)n_threads, lim, out};
+                          n * (uint64_t)(t + 1) / (uint64_t)n_threads, lim, out, skip};
     if (n_threads == 1) sts_job_main(&jobs[t]);
     else pthread_create(&th[t], NULL, sts_job_main, &jobs[t]);
   }
   if (n_threads > 1)
     for (int t = 0; t < n_threads; t++) pthread_join(th[t], NULL);
   return DEMI_OK;
+}
+
+int orc_sts_replay_batch(const demi_model* m, const demi_ext_event* ext, uint32_t n_ext, const demi_rec_event* rec,
+                         uint32_t n_rec, const uint64_t* masks, uint64_t n, const demi_limits* lim, demi_verdict* out,
+                         int n_threads) {
+  return sts_batch(m, ext, n_ext, rec, n_rec, masks, NULL, n, lim, out, n_threads);
+}
+
+int orc_sts_removal_batch(const demi_model* m, const demi_ext_event* ext, uint32_t n_ext, const demi_rec_event* rec,
+                          uint32_t n_rec, const uint64_t* masks, const uint32_t* skip, uint64_t n,
+                          const demi_limits* lim, demi_verdict* out, int n_threads) {
+  return sts_batch(m, ext, n_ext, rec, n_rec, masks, skip, n, lim, out, n_threads);
 }
 
 /* ===================================================================== K3: DPORwHeuristics

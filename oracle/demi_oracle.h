@@ -66,6 +66,17 @@ int orc_sts_replay_batch(const demi_model* m, const demi_ext_event* original_ext
                          const demi_rec_event* original_rec, uint32_t n_rec, const uint64_t* masks, uint64_t n,
                          const demi_limits* lim, demi_verdict* out, int n_threads);
 
+/* ---- K2 with one removed delivery per candidate: the replay STSSchedMinimizer asks for
+ * (V/minification/internal_minimization/ScheduleCheckers.scala:54-57, OneAtATimeRemoval.scala:57-124).
+ * skip = index in original_rec of the MsgEvent removed (0xFFFFFFFF = none); masks == NULL keeps every external.
+ * kept (optional, [n_rec]): 1 where the recorded event took effect = the executed trace test() returns. */
+int orc_sts_removal(const demi_model* m, const demi_ext_event* original_ext, uint32_t n_ext,
+                    const demi_rec_event* original_rec, uint32_t n_rec, const uint64_t* mask, uint32_t skip,
+                    const demi_limits* lim, demi_verdict* out, uint8_t* kept);
+int orc_sts_removal_batch(const demi_model* m, const demi_ext_event* original_ext, uint32_t n_ext,
+                          const demi_rec_event* original_rec, uint32_t n_rec, const uint64_t* masks,
+                          const uint32_t* skip, uint64_t n, const demi_limits* lim, demi_verdict* out, int n_threads);
+
 /* ---- K3: one DPORwHeuristics interleaving (V/schedulers/DPORwHeuristics.scala:421-942) + the racing-pair
  * analysis of dpor() (:1020-1139).  prefix: nextTrace as node keys.  trace: [DEMI_DPOR_MAX_TRACE]. */
 int orc_dpor_execute(const demi_model* m, const demi_ext_event* ext, uint32_t n_ext, const uint64_t* prefix,

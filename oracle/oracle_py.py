@@ -44,6 +44,10 @@ def lib():
                                  C.c_uint8, C.c_uint8, C.c_uint32, C.c_void_p, C.c_uint32]
         L.orc_sts_replay_batch.argtypes = [C.POINTER(T.ModelStruct), C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
                                            C.c_void_p, C.c_uint64, C.POINTER(T.Limits), C.c_void_p, C.c_int]
+        L.orc_sts_removal_batch.argtypes = [C.POINTER(T.ModelStruct), C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
+                                            C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(T.Limits), C.c_void_p, C.c_int]
+        L.orc_sts_removal.argtypes = [C.POINTER(T.ModelStruct), C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
+                                      C.c_void_p, C.c_uint32, C.POINTER(T.Limits), C.POINTER(T.Verdict), C.c_void_p]
         L.orc_dpor_execute.argtypes = [C.POINTER(T.ModelStruct), C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
                                        C.POINTER(T.DporParams), C.POINTER(T.Verdict), C.c_void_p, C.POINTER(C.c_uint32),
                                        C.c_void_p, C.POINTER(C.c_uint32)]
@@ -121,6 +125,40 @@ def sts_replay_batch(model, original_externals, original_trace, masks, limits, n
                                     masks.ctypes.data, len(masks), C.byref(limits), out.ctypes.data, n_threads)
     assert rc == 0
     return out
+
+
+def sts_removal_batch(model, original_externals, original_trace, skips, limits, masks=None, n_threads=1):
+    """STSScheduler.test of the trace minus the MsgEvent at index skips[i] (0xFFFFFFFF = none), all externals
+    kept unless masks is given; VERDICT_DTYPE array."""
+    ms = model.to_struct()
+    ev = np.ascontiguousarray(original_externals, dtype=T.EXT_EVENT_DTYPE)
+    rec = np.ascontiguousarray(original_trace, dtype=T.REC_EVENT_DTYPE)
+    skips = np.ascontiguousarray(skips, dtype=np.uint32)
+    if masks is not None:
+        masks = np.ascontiguousarray(masks, dtype=np.uint64).reshape(-1, 4)
+        assert len(masks) == len(skips)
+    out = np.zeros(len(skips), dtype=T.VERDICT_DTYPE)
+    rc = lib().orc_sts_removal_batch(C.byref(ms), ev.ctypes.data, len(ev), rec.ctypes.data, len(rec),
+                                     masks.ctypes.data if masks is not None else None, skips.ctypes.data, len(skips),
+                                     C.byref(limits), out.ctypes.data, n_threads)
+    assert rc == 0
+    return out
+
+
+def sts_removal_kept(model, original_externals, original_trace, skip, limits, mask=None):
+    """(verdict, kept uint8[n_rec]) of one removal candidate: kept marks the executed trace."""
+    ms = model.to_struct()
+    ev = np.ascontiguousarray(original_externals, dtype=T.EXT_EVENT_DTYPE)
+    rec = np.ascontiguousarray(original_trace, dtype=T.REC_EVENT_DTYPE)
+    if mask is not None:
+        mask = np.ascontiguousarray(mask, dtype=np.uint64).reshape(4)
+    v = T.Verdict()
+    kept = np.zeros(max(len(rec), 1), dtype=np.uint8)
+    rc = lib().orc_sts_removal(C.byref(ms), ev.ctypes.data, len(ev), rec.ctypes.data, len(rec),
+                               mask.ctypes.data if mask is not None else None, C.c_uint32(int(skip) & 0xFFFFFFFF),
+                               C.byref(limits), C.byref(v), kept.ctypes.data)
+    assert rc == 0
+    return v, kept[:len(rec)]
 
 
 def dpor_batch(model, externals, prefixes, params):

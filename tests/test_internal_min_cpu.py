@@ -1,0 +1,205 @@
+"""CPU suite, part 5: internal-event minimization (removal strategies, STSSchedMinimizer with and without
+speculation) over the oracle's restatement of the STS replay with one removed delivery."""
+from collections import Counter
+
+import numpy as np
+import pytest
+
+from demi_amd import types as T
+from demi_amd import model as M
+from demi_amd.apps import SEED_BASE, raft5_config2
+from demi_amd.fuzzer import events_to_array, send, start, wait_quiescence
+from demi_amd.internal_minimization import (LeftToRightOneAtATime, SrcDstFIFORemoval, STSSchedMinimizer, countMsgEvents,
+                                            deliveries, executed_trace, getFingerprintedDeliveries)
+from demi_amd.minification import events_to_mask, stsSchedDDMin
+from demi_amd.schedulers import EventTrace, MinimizationStats, ViolationFingerprint
+
+from .test_minification_cpu import OracleSTS, _violating_execution
+
+NO_SKIP = 0xFFFFFFFF
+
+
+class OracleRemoval:
+    """The oracle standing in for StsRemovalOracle (same interface), CPU tests only."""
+
+    def __init__(self, oracle, model):
+        self.o, self.model = oracle, model
+        self.launches = 0
+
+    def _lim(self, fp):
+        return T.Limits(0, 0, 64, 1, fp.code, 0)
+
+    def test_removals(self, trace, skips, violation):
+        self.launches += 1
+        v = self.o.sts_removal_batch(self.model, trace.original_externals, trace.events, skips, self._lim(violation))
+        return [bool(f & T.V_VIOLATION) for f in v["flags"]]
+
+    def executed(self, trace, skip, violation):
+        v, kept = self.o.sts_removal_kept(self.model, trace.original_externals, trace.events, skip, self._lim(violation))
+        if not (v.flags & T.V_VIOLATION):
+            return None
+        return executed_trace(trace, kept)
+
+
+def _verified_mcs(oracle, model, events, lim, skip=0):
+    """fuzz -> DDMin -> verified MCS trace re-based on the MCS (what RunnerUtils.stsSchedDDMin returns)."""
+    vv, rec, used = _violating_execution(oracle, model, events, lim, skip)
+    fp = ViolationFingerprint(vv.fingerprint)
+    mcs, _, ver = stsSchedDDMin(OracleSTS(oracle, model, used, rec, vv.fingerprint), used, fp, speculative_depth=2)
+    assert ver is not None
+    mask = np.array(events_to_mask(mcs), dtype=np.uint64)
+    v, kept = oracle.sts_removal_kept(model, used, rec, NO_SKIP, T.Limits(0, 0, 64, 1, fp.code, 0), mask=mask)
+    assert v.flags & T.V_VIOLATION
+    trace = executed_trace(EventTrace(rec, used), kept, subseq=mcs)
+    return trace, fp
+
+
+def test_removal_batch_without_a_removal_is_the_plain_replay(oracle):
+    model, events, lim = raft5_config2()
+    vv, rec, used = _violating_execution(oracle, model, events, lim)
+    target = T.Limits(0, 0, 64, 1, vv.fingerprint, 0)
+    rng = np.random.default_rng(5)
+    masks = rng.integers(0, 1 << 63, size=(16, 4), dtype=np.uint64)
+    masks[0] = ~np.uint64(0)
+    plain = oracle.sts_replay_batch(model, used, rec, masks, target)
+    none = oracle.sts_removal_batch(model, used, rec, np.full(16, NO_SKIP, dtype=np.uint32), target, masks=masks)
+    assert (plain == none).all()
+    # masks == None keeps every external
+    allk = oracle.sts_removal_batch(model, used, rec, [NO_SKIP], target)
+    assert allk[0] == plain[0]
+
+
+def test_kept_marks_are_the_executed_trace(oracle):
+    """Full replay: every Spawn, external MsgSend and MsgEvent is kept, internal MsgSends and quiescence records
+    are not; the executed trace replays to the same verdict (hash over deliveries and final states)."""
+    model, events, lim = raft5_config2()
+    vv, rec, used = _violating_execution(oracle, model, events, lim)
+    target = T.Limits(0, 0, 64, 1, vv.fingerprint, 0)
+    v, kept = oracle.sts_removal_kept(model, used, rec, NO_SKIP, target)
+    assert v.flags & T.V_VIOLATION and v.hash == vv.hash
+    kinds = rec["kind"]
+    expect = (kinds <= T.REC_UNPARTITION) | (kinds == T.REC_MSG_EVENT) | ((kinds == T.REC_MSG_SEND) & ((rec["flags"] & 1) == 1))
+    assert (kept.astype(bool) == expect).all()
+    tr = executed_trace(EventTrace(rec, used), kept)
+    v2, kept2 = oracle.sts_removal_kept(model, tr.original_externals, tr.events, NO_SKIP, target)
+    assert v2.flags == v.flags and v2.hash == v.hash and kept2.all()
+    # removing one delivery: it is not delivered, is not counted as "ignored" by itself, and whatever it caused
+    # is now absent (those expected deliveries are ignored -> DIVERGED) or the run is simply one shorter
+    dl = deliveries(EventTrace(rec, used))
+    for idx, key, _ in dl[:12]:
+        v3, kept3 = oracle.sts_removal_kept(model, used, rec, idx, target)
+        assert not kept3[idx]
+        assert T.verdict_deliveries(v3.flags) <= T.verdict_deliveries(v.flags) - 1
+        absent = int(expect.sum()) - 1 - int(kept3.sum())
+        assert bool(v3.flags & T.V_DIVERGED) == (absent > 0)
+        b = oracle.sts_removal_batch(model, used, rec, [idx], target)[0]
+        assert int(b["flags"]) == v3.flags and int(b["hash"]) == v3.hash
+
+
+def test_rebased_verified_mcs_replays_identically(oracle):
+    model, events, lim = raft5_config2()
+    trace, fp = _verified_mcs(oracle, model, events, lim)
+    assert len(trace.original_externals) < 50
+    assert not (trace.original_externals["kind"] == T.EV_WAIT_QUIESCENCE).any()
+    ext_sends = trace.events[(trace.events["kind"] == T.REC_MSG_SEND)]
+    assert ((ext_sends["flags"] & 1) == 1).all()
+    assert (trace.original_externals["kind"][ext_sends["ext_idx"]] == T.EV_SEND).all()
+    v, kept = oracle.sts_removal_kept(model, trace.original_externals, trace.events, NO_SKIP, T.Limits(0, 0, 64, 1, fp.code, 0))
+    assert v.flags & T.V_VIOLATION and not (v.flags & T.V_DIVERGED) and kept.all()
+
+
+def _literal_get_next_trace(strategy, trace, alreadyRemoved):
+    """OneAtATimeStrategy.getNextTrace transliterated with the full flatMap (no early return), LeftToRight filter."""
+    keys = Counter(alreadyRemoved)
+    found = [None]
+
+    def check(key):
+        keys[key] += 1
+        if found[0] is not None:
+            return True
+        if keys[key] > strategy[key]:
+            found[0] = key
+            strategy[key] += 1
+            return False
+        return True
+
+    out = []
+    for i, e in enumerate(trace.events):
+        if e["kind"] == T.REC_MSG_EVENT:
+            key = (int(e["snd"]), int(e["rcv"]), (int(e["msg_type"]), int(e["p0"]), int(e["p1"])))
+            if not check(key):
+                continue
+        out.append(i)
+    return out if found[0] is not None else None
+
+
+def test_left_to_right_proposals_match_the_literal_transliteration(oracle):
+    model, events, lim = raft5_config2()
+    trace, fp = _verified_mcs(oracle, model, events, lim)
+    s = LeftToRightOneAtATime(trace, model)
+    tried = Counter(s.triedIgnoring)
+    assert s.unignorable == sum(1 for _, k, _ in deliveries(trace) if model.msg_class[k[2][0]] == T.MSG_EXTERNAL)
+    n = 0
+    while True:
+        kept_idx = _literal_get_next_trace(tried, trace, Counter())
+        nxt = s.getNextTrace(trace, Counter(), False)
+        if kept_idx is None:
+            assert nxt is None
+            break
+        assert (nxt.events == trace.events[kept_idx]).all()
+        n += 1
+    assert n == countMsgEvents(trace) - s.unignorable
+
+
+@pytest.mark.parametrize("strategy_cls", [LeftToRightOneAtATime, SrcDstFIFORemoval])
+@pytest.mark.parametrize("skip", [0, 1, 2])
+def test_speculative_minimizer_equals_the_sequential_loop(oracle, strategy_cls, skip):
+    model, events, lim = raft5_config2()
+    trace, fp = _verified_mcs(oracle, model, events, lim, skip)
+    mcs = trace.original_externals
+    seq_or, spec_or = OracleRemoval(oracle, model), OracleRemoval(oracle, model)
+    seq = STSSchedMinimizer(mcs, trace, fp, strategy_cls(trace, model), seq_or, max_batch=1)
+    s1, t1 = seq.minimize()
+    spec = STSSchedMinimizer(mcs, trace, fp, strategy_cls(trace, model), spec_or)
+    s2, t2 = spec.minimize()
+    mid = STSSchedMinimizer(mcs, trace, fp, strategy_cls(trace, model), OracleRemoval(oracle, model), max_batch=7)
+    s3, t3 = mid.minimize()
+    assert (t1.events == t2.events).all() and (t1.events == t3.events).all()
+    assert s1.total_replays == s2.total_replays == s3.total_replays
+    assert seq.internal_sizes == spec.internal_sizes == mid.internal_sizes
+    assert spec_or.launches < seq_or.launches or s1.total_replays <= 1
+    # the minimized schedule still triggers the violation, follows exactly (nothing absent), and is no longer
+    v, kept = oracle.sts_removal_kept(model, mcs, t1.events, NO_SKIP, T.Limits(0, 0, 64, 1, fp.code, 0))
+    assert v.flags & T.V_VIOLATION and not (v.flags & T.V_DIVERGED) and kept.all()
+    assert countMsgEvents(t1) <= countMsgEvents(trace)
+    # externals' deliveries are never removed
+    ext = [k for k in getFingerprintedDeliveries(trace) if model.msg_class[k[2][0]] == T.MSG_EXTERNAL]
+    left = Counter(getFingerprintedDeliveries(t1))
+    for k, c in Counter(ext).items():
+        assert left[k] >= c or countMsgEvents(t1) < countMsgEvents(trace)
+
+
+def test_left_to_right_result_is_one_pass_minimal_on_a_chain(oracle):
+    """Two independent Kick->Ping chains; the violation needs only the Pings of one of them, so the other chain's
+    Ping delivery is removable, while the needed ones are not."""
+    MSGS = [("Kick", T.MSG_EXTERNAL), ("Ping", T.MSG_INTERNAL), ("Noise", T.MSG_INTERNAL)]
+    h = {(0, "Kick"): M.Asm().mov(M.T0, 1).mov(M.T1, 2).if_eq(M.ME, 0, "x").send(1, M.T0, M.P0, 0).send(2, M.T1, M.P0, 0).label("x"),
+         (0, "Ping"): M.Asm().add(M.F[1], M.F[1], 1),
+         (0, "Noise"): M.Asm().add(M.F[2], M.F[2], 1)}
+    model = M.build_model("chain", 3, MSGS, h, [[0] * 8] * 3, (T.INV_NEVER, 1, 2, 0))     # actor saw 2 Pings
+    ev = events_to_array([start(0), start(1), start(2), send(0, 0, 1), send(0, 0, 2), wait_quiescence()])
+    lim = T.Limits(0, 0, 64, 0, 0, 0)
+    vv, rec, _ = oracle.random_execute(model, ev, 3, lim)
+    assert vv.flags & T.V_VIOLATION
+    fp = ViolationFingerprint(vv.fingerprint)
+    mcs = [0, 1, 2, 3, 4]
+    v, kept = oracle.sts_removal_kept(model, ev, rec, NO_SKIP, T.Limits(0, 0, 64, 1, fp.code, 0),
+                                      mask=np.array(events_to_mask(mcs), dtype=np.uint64))
+    trace = executed_trace(EventTrace(rec, ev), kept, subseq=mcs)
+    before = Counter(k[2][0] for k in getFingerprintedDeliveries(trace))
+    assert before == Counter({0: 2, 1: 2, 2: 2})
+    stats, out = STSSchedMinimizer(trace.original_externals, trace, fp, LeftToRightOneAtATime(trace, model),
+                                   OracleRemoval(oracle, model)).minimize()
+    after = Counter(k[2][0] for k in getFingerprintedDeliveries(out))
+    assert after == Counter({0: 2, 1: 2})            # both Noise deliveries pruned, Kicks (external) and Pings stay
+    assert stats.total_replays == 4                   # 2 Pings tried and kept, 2 Noises tried and dropped

@@ -170,3 +170,83 @@ def test_fuzz_validate_minimize_roundtrip_through_an_experiment_dir(gpu_ctx, tmp
     save_experiment(str(tmp_path / "exp"), m2, t2, fp2, mcs=mcs)
     assert list(load_experiment(str(tmp_path / "exp"))[4]) == list(mcs)
     sts.shutdown()
+
+
+# ----------------------------------------------------------------------------------------------
+# internal-event minimization: K2 with one removed delivery per candidate
+NO_SKIP = 0xFFFFFFFF
+
+
+def test_removal_batch_and_kept_parity(gpu_ctx, oracle):
+    """Every delivery of the recorded execution removed in turn (with and without pruned externals), small
+    pending capacity included: verdicts and executed-trace marks bit-identical to the oracle's."""
+    from demi_amd.internal_minimization import deliveries
+    rng = np.random.default_rng(11)
+    for cfg, skip in ((raft5_config2, 0), (raft5_config2, 3), (raft5_config4, 0)):
+        model, events, lim = cfg()
+        vv, rec, used = record(gpu_ctx, model, events, lim, skip=skip)
+        gpu_ctx.replay_load(used, rec)
+        dl = [i for i, _, _ in deliveries(EventTrace(rec, used))]
+        skips = np.array(dl + [NO_SKIP], dtype=np.uint32)
+        for p_max in (64, 12):
+            target = T.Limits(0, 0, p_max, 1, vv.fingerprint, 0)
+            g = gpu_ctx.replay_removal_batch(skips, target)
+            c = oracle.sts_removal_batch(model, used, rec, skips, target, n_threads=os.cpu_count())
+            assert_same(g, c)
+        target = T.Limits(0, 0, 64, 1, vv.fingerprint, 0)
+        full = gpu_ctx.replay_batch(np.array([events_to_mask(range(len(used)))], dtype=np.uint64), target)[0]
+        assert gpu_ctx.replay_removal_batch([NO_SKIP], target)[0] == full
+        # removal combined with pruned externals
+        masks = random_masks(rng, len(used), 512)
+        sk = rng.choice(skips, size=512)
+        g = gpu_ctx.replay_removal_batch(sk, target, masks=masks)
+        c = oracle.sts_removal_batch(model, used, rec, sk, target, masks=masks, n_threads=os.cpu_count())
+        assert_same(g, c)
+        assert (g["flags"] & T.V_VIOLATION).sum() > 0
+        # executed-trace marks
+        for s, m in [(NO_SKIP, None)] + [(int(sk[i]), masks[i]) for i in range(0, 512, 37)] + [(d, None) for d in dl[:8]]:
+            gv, gk = gpu_ctx.replay_get_kept(len(rec), s, target, mask=m)
+            cv, ck = oracle.sts_removal_kept(model, used, rec, s, target, mask=m)
+            assert gv.flags == cv.flags and gv.hash == cv.hash and gv.fingerprint == cv.fingerprint
+            assert (gk == ck).all()
+    # a removal candidate must be a delivery of the loaded trace
+    from demi_amd._native import DemiError
+    not_delivery = int(np.nonzero(rec["kind"] != T.REC_MSG_EVENT)[0][0])
+    for bad in (not_delivery, len(rec) + 5):
+        with pytest.raises(DemiError):
+            gpu_ctx.replay_removal_batch([bad], target)
+
+
+@pytest.mark.parametrize("strategy", ["LeftToRightOneAtATime", "SrcDstFIFORemoval"])
+def test_minimize_internals_end_to_end(gpu_ctx, oracle, strategy):
+    """fuzz -> DDMin -> verified MCS -> internal minimization, all replays on the GPU; identical (final trace,
+    replay count, sizes) to the same host loop driven by the CPU oracle, sequentially."""
+    from demi_amd import internal_minimization as IM
+    from .test_internal_min_cpu import OracleRemoval
+    cls = getattr(IM, strategy)
+    model, events, lim = raft5_config4()
+    cfg = SchedulerConfig(model=model)
+    vv, rec, used = record(gpu_ctx, model, events, lim)
+    fp = ViolationFingerprint(vv.fingerprint)
+    sts = STSScheduler(cfg, EventTrace(rec, used))
+    mcs, ddmin, ver = stsSchedDDMin(sts, used, fp)
+    verified = sts.executed_trace(mcs, fp)
+    sts.shutdown()
+    assert ver is not None and verified is not None and len(mcs) < len(used)
+    # the verified MCS trace is what the oracle computes for the same projection
+    cv, ck = oracle.sts_removal_kept(model, used, rec, NO_SKIP, T.Limits(0, 0, 64, 1, fp.code, 0),
+                                     mask=np.array(events_to_mask(mcs), dtype=np.uint64))
+    want = IM.executed_trace(EventTrace(rec, used), ck, subseq=mcs)
+    assert (verified.events == want.events).all() and (verified.original_externals == want.original_externals).all()
+    stats, out = IM.minimizeInternals(cfg, verified.original_externals, verified, fp,
+                                      removalStrategyCtor=lambda: cls(verified, model))
+    ref = IM.STSSchedMinimizer(verified.original_externals, verified, fp, cls(verified, model),
+                               OracleRemoval(oracle, model), max_batch=1)
+    rstats, rout = ref.minimize()
+    assert (out.events == rout.events).all() and stats.total_replays == rstats.total_replays
+    assert IM.countMsgEvents(out) < IM.countMsgEvents(verified)
+    # the minimized schedule replays strictly (nothing absent) to the violation
+    gpu_ctx.replay_load(out.original_externals, out.events)
+    v = gpu_ctx.replay_removal_batch([NO_SKIP], T.Limits(0, 0, 64, 1, fp.code, 0))[0]
+    assert v["flags"] & T.V_VIOLATION and not v["flags"] & T.V_DIVERGED
+    assert T.verdict_deliveries(int(v["flags"])) == IM.countMsgEvents(out)

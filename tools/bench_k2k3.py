@@ -53,7 +53,19 @@ t = time.perf_counter()
 mcs, d, ver = stsSchedDDMin(sts, used, ViolationFingerprint(vv.fingerprint), speculative_depth=4)
 out["ddmin_config4"] = {"seconds": time.perf_counter() - t, "mcs_len": len(mcs), "oracle_consultations": len(d.consulted),
                         "launches": len(d.batches), "replays_launched": d.speculative_replays}
+verified = sts.executed_trace(mcs, ViolationFingerprint(vv.fingerprint))
 sts.shutdown()
+# internal-event minimization of the verified MCS execution (config 4), both removal strategies
+from demi_amd import internal_minimization as IM  # noqa: E402
+for name in ("LeftToRightOneAtATime", "SrcDstFIFORemoval"):
+    orc = IM.StsRemovalOracle(SchedulerConfig(model=model), p_max=128)
+    mz = IM.STSSchedMinimizer(verified.original_externals, verified, ViolationFingerprint(vv.fingerprint),
+                              getattr(IM, name)(verified, model), orc)
+    t = time.perf_counter(); st, tr = mz.minimize(); dt = time.perf_counter() - t
+    out["intmin_config4_" + name] = {"seconds": dt, "deliveries_before": IM.countMsgEvents(verified),
+                                     "deliveries_after": IM.countMsgEvents(tr), "sequential_replays": st.total_replays,
+                                     "replays_launched": mz.speculative_replays, "launches": len(mz.batches)}
+    orc.shutdown()
 # K3: kernel-only rate on a fixed batch of prefixes, then the whole loop
 model3, ev3, depth = raft5_config3()
 d = DPORwHeuristics(SchedulerConfig(model=model3), depth_bound=depth, stopIfViolationFound=False, batch=2048)
