@@ -758,65 +758,12 @@ extern "C" int demi_dpor_explore(demi_ctx* ctx, const demi_dpor_params* par, con
   if (!ctx) return DEMI_ERR_INVALID_ARG;
   if (!par || !srch || !out_verdicts || !out_prefix_len || !stats) return fail(ctx, DEMI_ERR_INVALID_ARG, "null pointer");
   if (srch->batch < 1 || srch->max_interleavings < 1) return fail(ctx, DEMI_ERR_INVALID_ARG, "batch and max_interleavings must be >= 1");
-  demi_host::DporBook book(srch->track_history != 0);
-  memset(stats, 0, sizeof *stats);
-  stats->first_violation = ~0ull;
-  if (first_violation_len) *first_violation_len = 0;
-
-  std::vector<demi_host::Trace> frontier(1);         // first run: nextTrace is empty
-  const uint32_t max_pairs = par->max_pairs;
-  std::vector<demi_dpor_trace_entry> pf, tr;
-  std::vector<uint32_t> pl, tl, np;
-  std::vector<demi_verdict> vd;
-  std::vector<demi_dpor_pair> pr;
-  bool exhausted = false;
-  while (!frontier.empty()) {
-    const size_t n = frontier.size();
-    size_t stride = 1;
-    for (auto& f : frontier) stride = f.size() > stride ? f.size() : stride;
-    pf.assign(n * stride, demi_dpor_trace_entry{});
-    pl.resize(n); tl.resize(n); np.resize(n); vd.resize(n);
-    tr.resize(n * DEMI_DPOR_MAX_TRACE);
-    pr.resize(n * (size_t)(max_pairs ? max_pairs : 1));
-    for (size_t i = 0; i < n; i++) {
-      pl[i] = (uint32_t)frontier[i].size();
-      if (pl[i]) memcpy(&pf[i * stride], frontier[i].data(), sizeof(demi_dpor_trace_entry) * pl[i]);
-    }
-    int rc = demi_dpor_batch(ctx, pf.data(), pl.data(), (uint32_t)stride, n, par, vd.data(), tr.data(), tl.data(), pr.data(), np.data());
-    if (rc) return rc;
-    if (out_rounds) out_rounds[stats->launches] = (uint32_t)n;
-    stats->launches++;
-    bool found = false;
-    for (size_t i = 0; i < n; i++) {
-      const uint64_t idx = stats->interleavings++;
-      out_verdicts[idx] = vd[i];
-      out_prefix_len[idx] = pl[i];
-      if (vd[i].flags & DEMI_V_VIOLATION) {
-        stats->violations++;
-        found = true;
-        if (stats->first_violation == ~0ull) {
-          stats->first_violation = idx;
-          if (first_violation_trace) memcpy(first_violation_trace, &tr[i * DEMI_DPOR_MAX_TRACE], sizeof(demi_dpor_trace_entry) * tl[i]);
-          if (first_violation_len) *first_violation_len = tl[i];
-        }
-      }
-    }
-    // dpor(): bookkeeping for the racing pairs of the whole round (:1122-1139), sharded over host threads
-    book.absorb(tr.data(), tl.data(), pr.data(), np.data(), n, max_pairs);
-    frontier.clear();
-    if (srch->stop_if_violation && found) break;
-    if (stats->interleavings >= srch->max_interleavings) break;
-    // getNext (:1142-1162) for up to `batch` points
-    while (frontier.size() < srch->batch && stats->interleavings + frontier.size() < srch->max_interleavings) {
-      demi_host::Trace nxt;
-      if (!book.get_next(nxt)) break;
-      frontier.push_back(std::move(nxt));
-    }
-    if (frontier.empty() && book.empty()) exhausted = true;
-  }
-  stats->queue_len = book.queue_len();
-  stats->exhausted = exhausted ? 1u : 0u;
-  return DEMI_OK;
+  auto run = [&](const demi_dpor_trace_entry* pf, const uint32_t* pl, uint32_t stride, uint64_t n, demi_verdict* vd,
+                 demi_dpor_trace_entry* tr, uint32_t* tl, demi_dpor_pair* pr, uint32_t* np) {
+    return demi_dpor_batch(ctx, pf, pl, stride, n, par, vd, tr, tl, pr, np);
+  };
+  return demi_host::explore_loop(run, par->max_pairs, srch, out_verdicts, out_prefix_len, out_rounds, first_violation_trace,
+                                 first_violation_len, stats, nullptr);
 }
 
 extern "C" int demi_random_explore_violations(demi_ctx* ctx, uint64_t seed_base, uint64_t n, const demi_limits* limits,

@@ -2,21 +2,24 @@
 // priority queue with DefaultBacktrackOrdering (BacktrackOrdering.scala:58-69), the ExploredTacker
 // (AuxilaryTypes.scala:209-246), dpor()'s enqueue (:1068-1070, 1134) and getNext() (:1142-1185).
 //
-// A raft5 interleaving yields ~1.7 k racing pairs, so this bookkeeping, not the kernel, bounds the
-// exploration rate.  Three things keep it cheap and exactly equal to the one-at-a-time loop:
-//  * every operation on a racing pair touches only the explored-set entries (a, b) and (b, a), so the
-//    state is sharded by the unordered pair {a, b}; a round's pairs are bucketed by shard (in
-//    parallel, by contiguous ranges of interleavings) and each shard is then processed by one thread
-//    in global pair order;
-//  * the explored set is an open-addressing table of 16-byte keys (no allocation per insert);
-//  * DefaultBacktrackOrdering only compares the branch index (< 256) and PriorityQueue ties are pinned
-//    to creation order, so the queue is 256 FIFO buckets per shard: push O(1); the global pop takes,
-//    in the highest non-empty branch, the front with the smallest global pair ordinal.
+// A raft5 interleaving yields ~2 k racing pairs, so this bookkeeping, not the kernel, bounds the
+// exploration rate.  What keeps it cheap and exactly equal to the one-at-a-time loop:
+//  * every operation on a racing pair touches only the entries (a, b) and (b, a), so the state is sharded by
+//    the unordered pair {a, b}; a round's pairs are bucketed by shard (in parallel, by contiguous ranges of
+//    interleavings) and each shard is then processed by one thread in global pair order;
+//  * the explored set is an open-addressing table (no allocation per insert);
+//  * DefaultBacktrackOrdering only compares the branch index (< 256) and PriorityQueue ties are pinned to
+//    creation order, so the queue is 256 FIFO buckets per shard (chunks from a per-shard pool: no malloc
+//    traffic); the global pop takes, in the highest non-empty branch, the front with the smallest ordinal;
+//  * getNext() skips a popped point whose flipped pair is explored (:1153-1157) and the explored set only
+//    grows, so a point that can never be popped live is dropped early: when its flipped pair is already
+//    explored, when a queued point of the same flipped pair precedes it in pop order (branch >= and created
+//    earlier: that one is popped first and explores the pair), or when it reaches its shard's front dead.
 #pragma once
 
+#include <chrono>
 #include <cstdint>
 #include <cstring>
-#include <deque>
 #include <memory>
 #include <thread>
 #include <vector>
@@ -33,42 +36,92 @@ struct BtPoint {          // one entry of the backTrack queue (DPORwHeuristics.B
   uint8_t branch, later, earlier, pad;
 };
 
-// open addressing, linear probing; key (0, 0) is the empty slot (node keys are FNV hash chains: never 0, 0)
-class FlatPairSet {
+// (a, b) -> 32-bit value; open addressing, linear probing; key (0, 0) is the empty slot (node keys are FNV
+// hash chains: never 0, 0)
+class FlatPairMap {
  public:
-  FlatPairSet() { resize(1u << 12); }
-  bool contains(uint64_t a, uint64_t b) const {
+  FlatPairMap() { resize(1u << 12); }
+  const uint32_t* find(uint64_t a, uint64_t b) const {
     for (size_t i = slot(a, b);; i = (i + 1) & mask_) {
-      const Key& k = tab_[i];
-      if (k.a == a && k.b == b) return true;
-      if (k.a == 0 && k.b == 0) return false;
+      const Entry& k = tab_[i];
+      if (k.a == a && k.b == b) return &k.val;
+      if (k.a == 0 && k.b == 0) return nullptr;
     }
   }
-  void insert(uint64_t a, uint64_t b) {
+  // find or insert (value 0); the reference is valid until the next at()
+  uint32_t& at(uint64_t a, uint64_t b) {
     if ((n_ + 1) * 5 > (mask_ + 1) * 3) grow();
     for (size_t i = slot(a, b);; i = (i + 1) & mask_) {
-      Key& k = tab_[i];
-      if (k.a == a && k.b == b) return;
-      if (k.a == 0 && k.b == 0) { k.a = a; k.b = b; n_++; return; }
+      Entry& k = tab_[i];
+      if (k.a == a && k.b == b) return k.val;
+      if (k.a == 0 && k.b == 0) { k.a = a; k.b = b; n_++; return k.val; }
     }
   }
   size_t size() const { return n_; }
 
  private:
-  struct Key { uint64_t a, b; };
+  struct Entry { uint64_t a, b; uint32_t val, pad; };
   size_t slot(uint64_t a, uint64_t b) const {
     return (size_t)(((a * 0x9E3779B97F4A7C15ULL) ^ (b * 0xC2B2AE3D27D4EB4FULL) ^ (a >> 29)) >> 7) & mask_;
   }
-  void resize(size_t cap) { tab_.assign(cap, Key{0, 0}); mask_ = cap - 1; n_ = 0; }
+  void resize(size_t cap) { tab_.assign(cap, Entry{0, 0, 0, 0}); mask_ = cap - 1; n_ = 0; }
   void grow() {
-    std::vector<Key> old;
+    std::vector<Entry> old;
     old.swap(tab_);
     resize((mask_ + 1) * 2);
-    for (const Key& k : old)
-      if (k.a || k.b) insert(k.a, k.b);
+    for (const Entry& k : old)
+      if (k.a || k.b) at(k.a, k.b) = k.val;
   }
-  std::vector<Key> tab_;
+  std::vector<Entry> tab_;
   size_t mask_ = 0, n_ = 0;
+};
+
+// FIFO of BtPoints in 4 KB chunks taken from (and returned to) a pool owned by the shard
+struct Chunk {
+  Chunk* next;
+  uint32_t head, tail;
+  BtPoint item[255];
+};
+class ChunkPool {
+ public:
+  Chunk* get() {
+    if (!free_) {
+      slabs_.emplace_back(new Chunk[SLAB]);
+      Chunk* c = slabs_.back().get();
+      for (size_t i = 0; i < SLAB; i++) { c[i].next = free_; free_ = &c[i]; }
+    }
+    Chunk* c = free_;
+    free_ = c->next;
+    c->next = nullptr; c->head = c->tail = 0;
+    return c;
+  }
+  void put(Chunk* c) { c->next = free_; free_ = c; }
+
+ private:
+  static constexpr size_t SLAB = 256;
+  std::vector<std::unique_ptr<Chunk[]>> slabs_;
+  Chunk* free_ = nullptr;
+};
+struct Fifo {
+  Chunk *head = nullptr, *tail = nullptr;
+  bool empty() const { return head == nullptr; }
+  const BtPoint& front() const { return head->item[head->head]; }
+  void push_back(ChunkPool& pool, const BtPoint& p) {
+    if (!tail || tail->tail == 255) {
+      Chunk* c = pool.get();
+      if (tail) tail->next = c; else head = c;
+      tail = c;
+    }
+    tail->item[tail->tail++] = p;
+  }
+  void pop_front(ChunkPool& pool) {
+    Chunk* c = head;
+    if (++c->head == c->tail) {
+      head = c->next;
+      if (!head) tail = nullptr;
+      pool.put(c);
+    }
+  }
 };
 
 class DporBook {
@@ -106,7 +159,7 @@ class DporBook {
         const demi_dpor_pair* pp = pr + i * (size_t)max_pairs;
         for (uint32_t k = 0; k < np[i]; k++) {
           const uint64_t ke = tt[pp[k].earlier].key, kl = tt[pp[k].later].key;
-          pieces_[t * S + shard_of(ke, kl)].push_back(BtPoint{base[i] + k, tid[i], pp[k].branch, pp[k].later, pp[k].earlier, 0});
+          pieces_[t * S + shard_of(ke, kl)].push_back(Piece{ke, kl, BtPoint{base[i] + k, tid[i], pp[k].branch, pp[k].later, pp[k].earlier, 0}});
         }
       }
     };
@@ -114,15 +167,18 @@ class DporBook {
     auto process = [&](unsigned t) {
       for (size_t s = t; s < S; s += threads_) {
         Shard& sh = shards_[s];
+        sh.front_valid = false;                                   // newly explored pairs may kill the front point
         for (unsigned src = 0; src < threads_; src++) {
-          for (const BtPoint& p : pieces_[src * S + s]) {
+          for (const Piece& pc : pieces_[src * S + s]) {
+            const BtPoint& p = pc.p;
             if (track_) {
-              const Trace& trc = *traces_[p.trace_id];
-              const uint64_t ke = trc[p.earlier].key, kl = trc[p.later].key;
-              sh.explored.insert(ke, kl);                        // setExplored(branchI, (earlier, later))
-              if (sh.explored.contains(kl, ke)) continue;         // getNext would skip it (:1153-1157)
+              sh.map.at(pc.ke, pc.kl) |= EXPLORED;               // setExplored(branchI, (earlier, later)) (:1068-1070)
+              uint32_t& flipped = sh.map.at(pc.kl, pc.ke);
+              if (flipped & EXPLORED) continue;                   // getNext would skip it (:1153-1157)
+              if ((flipped & QUEUED_MASK) > p.branch) continue;   // a queued point of this pair pops before it
+              flipped = (flipped & ~QUEUED_MASK) | ((uint32_t)p.branch + 1);
             }
-            sh.bucket[p.branch].push_back(p);
+            sh.bucket[p.branch].push_back(sh.pool, p);
             if ((int)p.branch > sh.top) sh.top = (int)p.branch;
             sh.queued++;
           }
@@ -135,32 +191,26 @@ class DporBook {
 
   // getNext (:1142-1162) + the next trace `trace.take(maxIndex + 1) ++ needToReplay` (:1054-1057, 1180)
   bool get_next(Trace& out) {
-    for (;;) {
-      int best = -1, best_branch = -1;
-      uint64_t best_seq = 0;
-      for (size_t s = 0; s < shards_.size(); s++) {
-        Shard& sh = shards_[s];
-        while (sh.top >= 0 && sh.bucket[sh.top].empty()) sh.top--;
-        if (sh.top < 0) continue;
-        const uint64_t sq = sh.bucket[sh.top].front().seq;
-        if (sh.top > best_branch || (sh.top == best_branch && sq < best_seq)) { best = (int)s; best_branch = sh.top; best_seq = sq; }
-      }
-      if (best < 0) return false;
-      Shard& sh = shards_[best];
-      const BtPoint p = sh.bucket[best_branch].front();
-      sh.bucket[best_branch].pop_front();
-      sh.queued--;
-      const Trace& src = *traces_[p.trace_id];
-      if (track_) {
-        const uint64_t ke = src[p.earlier].key, kl = src[p.later].key;
-        if (sh.explored.contains(kl, ke)) continue;
-        sh.explored.insert(kl, ke);                              // setExplored(maxIndex, (e1, e2)) (:1170-1172)
-      }
-      out.assign(src.begin(), src.begin() + p.branch + 1);
-      for (int k = (int)p.branch + 1; k <= (int)p.later; k++)
-        if (k != (int)p.earlier) out.push_back(src[k]);
-      return true;
+    int best = -1;
+    for (size_t s = 0; s < shards_.size(); s++) {
+      Shard& sh = shards_[s];
+      if (!sh.front_valid) settle(sh);
+      if (sh.top < 0) continue;
+      if (best < 0 || sh.top > shards_[best].top || (sh.top == shards_[best].top && sh.front_seq < shards_[best].front_seq))
+        best = (int)s;
     }
+    if (best < 0) return false;
+    Shard& sh = shards_[best];
+    const BtPoint p = sh.bucket[sh.top].front();
+    sh.bucket[sh.top].pop_front(sh.pool);
+    sh.queued--;
+    sh.front_valid = false;
+    const Trace& src = *traces_[p.trace_id];
+    if (track_) sh.map.at(src[p.later].key, src[p.earlier].key) |= EXPLORED;   // setExplored(maxIndex, (e1, e2)) (:1170-1172)
+    out.assign(src.begin(), src.begin() + p.branch + 1);
+    for (int k = (int)p.branch + 1; k <= (int)p.later; k++)
+      if (k != (int)p.earlier) out.push_back(src[k]);
+    return true;
   }
 
   bool empty() const { return queue_len() == 0; }
@@ -171,12 +221,34 @@ class DporBook {
   }
 
  private:
+  static constexpr uint32_t EXPLORED = 0x80000000u;   // the pair is in the ExploredTacker
+  static constexpr uint32_t QUEUED_MASK = 0x1FFu;     // 1 + highest branch of a queued point that flips INTO this pair
+  struct Piece { uint64_t ke, kl; BtPoint p; };
   struct Shard {
-    FlatPairSet explored;                    // ExploredTacker restricted to this shard's pairs
-    std::deque<BtPoint> bucket[256];         // backTrack, one FIFO per branch index
-    int top = -1;
+    FlatPairMap map;                         // ExploredTacker (+ queued marks) restricted to this shard's pairs
+    ChunkPool pool;
+    Fifo bucket[256];                        // backTrack, one FIFO per branch index
+    int top = -1;                            // highest non-empty bucket once settled
     uint64_t queued = 0;
+    bool front_valid = false;                // top / front_seq describe a live (unexplored) point
+    uint64_t front_seq = 0;
   };
+  // drop dead points from the front of the shard's queue until a live one (or nothing) is at the front
+  void settle(Shard& sh) {
+    while (sh.top >= 0) {
+      Fifo& b = sh.bucket[sh.top];
+      if (b.empty()) { sh.top--; continue; }
+      const BtPoint& p = b.front();
+      if (track_) {
+        const Trace& src = *traces_[p.trace_id];
+        const uint32_t* v = sh.map.find(src[p.later].key, src[p.earlier].key);
+        if (v && (*v & EXPLORED)) { b.pop_front(sh.pool); sh.queued--; continue; }
+      }
+      sh.front_seq = p.seq;
+      break;
+    }
+    sh.front_valid = true;
+  }
   size_t shard_of(uint64_t a, uint64_t b) const {      // unordered pair: (a, b) and (b, a) share a shard
     const uint64_t lo = a < b ? a : b, hi = a < b ? b : a;
     return (size_t)(((lo * 0x9E3779B97F4A7C15ULL) ^ (hi * 0xC2B2AE3D27D4EB4FULL)) >> 40) % shards_.size();
@@ -193,8 +265,80 @@ class DporBook {
   unsigned threads_;
   uint64_t seq_ = 0;
   std::vector<Shard> shards_;
-  std::vector<std::vector<BtPoint>> pieces_;            // [thread][shard] buckets of the current round
+  std::vector<std::vector<Piece>> pieces_;              // [thread][shard] buckets of the current round
   std::vector<std::shared_ptr<Trace>> traces_;
 };
+
+// The exploration loop of DPORwHeuristics.test (:1193-1242) in rounds: run(...) executes one batch of next-traces
+// (demi_dpor_batch's argument order; the GPU in the library, anything with the same contract in a test harness).
+// seconds (optional): [0] run, [1] absorb, [2] get_next.
+template <class Run>
+int explore_loop(Run&& run, uint32_t max_pairs, const demi_dpor_search* srch, demi_verdict* out_verdicts,
+                 uint32_t* out_prefix_len, uint32_t* out_rounds, demi_dpor_trace_entry* first_violation_trace,
+                 uint32_t* first_violation_len, demi_dpor_stats* stats, double* seconds) {
+  DporBook book(srch->track_history != 0);
+  memset(stats, 0, sizeof *stats);
+  stats->first_violation = ~0ull;
+  if (first_violation_len) *first_violation_len = 0;
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+
+  std::vector<Trace> frontier(1);         // first run: nextTrace is empty
+  std::vector<demi_dpor_trace_entry> pf, tr;
+  std::vector<uint32_t> pl, tl, np;
+  std::vector<demi_verdict> vd;
+  std::vector<demi_dpor_pair> pr;
+  bool exhausted = false;
+  while (!frontier.empty()) {
+    const size_t n = frontier.size();
+    size_t stride = 1;
+    for (auto& f : frontier) stride = f.size() > stride ? f.size() : stride;
+    pf.assign(n * stride, demi_dpor_trace_entry{});
+    pl.resize(n); tl.resize(n); np.resize(n); vd.resize(n);
+    tr.resize(n * DEMI_DPOR_MAX_TRACE);
+    pr.resize(n * (size_t)(max_pairs ? max_pairs : 1));
+    for (size_t i = 0; i < n; i++) {
+      pl[i] = (uint32_t)frontier[i].size();
+      if (pl[i]) memcpy(&pf[i * stride], frontier[i].data(), sizeof(demi_dpor_trace_entry) * pl[i]);
+    }
+    double t0 = now();
+    int rc = run(pf.data(), pl.data(), (uint32_t)stride, (uint64_t)n, vd.data(), tr.data(), tl.data(), pr.data(), np.data());
+    if (rc) return rc;
+    double t1 = now();
+    if (out_rounds) out_rounds[stats->launches] = (uint32_t)n;
+    stats->launches++;
+    bool found = false;
+    for (size_t i = 0; i < n; i++) {
+      const uint64_t idx = stats->interleavings++;
+      out_verdicts[idx] = vd[i];
+      out_prefix_len[idx] = pl[i];
+      if (vd[i].flags & DEMI_V_VIOLATION) {
+        stats->violations++;
+        found = true;
+        if (stats->first_violation == ~0ull) {
+          stats->first_violation = idx;
+          if (first_violation_trace) memcpy(first_violation_trace, &tr[i * DEMI_DPOR_MAX_TRACE], sizeof(demi_dpor_trace_entry) * tl[i]);
+          if (first_violation_len) *first_violation_len = tl[i];
+        }
+      }
+    }
+    // dpor(): bookkeeping for the racing pairs of the whole round (:1122-1139), sharded over host threads
+    book.absorb(tr.data(), tl.data(), pr.data(), np.data(), n, max_pairs);
+    double t2 = now();
+    frontier.clear();
+    if (srch->stop_if_violation && found) break;
+    if (stats->interleavings >= srch->max_interleavings) break;
+    // getNext (:1142-1162) for up to `batch` points
+    while (frontier.size() < srch->batch && stats->interleavings + frontier.size() < srch->max_interleavings) {
+      Trace nxt;
+      if (!book.get_next(nxt)) break;
+      frontier.push_back(std::move(nxt));
+    }
+    if (frontier.empty() && book.empty()) exhausted = true;
+    if (seconds) { seconds[0] += t1 - t0; seconds[1] += t2 - t1; seconds[2] += now() - t2; }
+  }
+  stats->queue_len = book.queue_len();
+  stats->exhausted = exhausted ? 1u : 0u;
+  return 0;
+}
 
 }  // namespace demi_host
