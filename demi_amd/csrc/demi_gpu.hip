@@ -762,8 +762,14 @@ extern "C" int demi_dpor_explore(demi_ctx* ctx, const demi_dpor_params* par, con
                  demi_dpor_trace_entry* tr, uint32_t* tl, demi_dpor_pair* pr, uint32_t* np) {
     return demi_dpor_batch(ctx, pf, pl, stride, n, par, vd, tr, tl, pr, np);
   };
+  // pinned result buffers: a round returns up to (4 KB trace + 4 B x max_pairs) per interleaving
+  auto pinned_alloc = [](size_t bytes) -> void* {
+    void* p = nullptr;
+    return hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess ? p : nullptr;
+  };
+  auto pinned_free = [](void* p) { (void)hipHostFree(p); };
   return demi_host::explore_loop(run, par->max_pairs, srch, out_verdicts, out_prefix_len, out_rounds, first_violation_trace,
-                                 first_violation_len, stats, nullptr);
+                                 first_violation_len, stats, nullptr, pinned_alloc, pinned_free);
 }
 
 extern "C" int demi_random_explore_violations(demi_ctx* ctx, uint64_t seed_base, uint64_t n, const demi_limits* limits,

@@ -19,6 +19,7 @@
 
 #include <chrono>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <thread>
@@ -272,10 +273,34 @@ class DporBook {
 // The exploration loop of DPORwHeuristics.test (:1193-1242) in rounds: run(...) executes one batch of next-traces
 // (demi_dpor_batch's argument order; the GPU in the library, anything with the same contract in a test harness).
 // seconds (optional): [0] run, [1] absorb, [2] get_next.
+// The two large per-round result arrays (traces, pairs) live in buffers from `alloc`/`release` (the library passes
+// pinned host memory so the device-to-host copies run at full PCIe rate; malloc/free elsewhere).
+struct RawBuf {
+  void* (*alloc)(size_t);
+  void (*release)(void*);
+  void* p = nullptr;
+  size_t cap = 0;
+  RawBuf(void* (*a)(size_t), void (*r)(void*)) : alloc(a), release(r) {}
+  ~RawBuf() { if (p) release(p); }
+  RawBuf(const RawBuf&) = delete;
+  RawBuf& operator=(const RawBuf&) = delete;
+  void* reserve(size_t bytes) {
+    if (bytes > cap) {
+      if (p) release(p);
+      p = alloc(bytes);
+      cap = p ? bytes : 0;
+    }
+    return p;
+  }
+};
+
 template <class Run>
 int explore_loop(Run&& run, uint32_t max_pairs, const demi_dpor_search* srch, demi_verdict* out_verdicts,
                  uint32_t* out_prefix_len, uint32_t* out_rounds, demi_dpor_trace_entry* first_violation_trace,
-                 uint32_t* first_violation_len, demi_dpor_stats* stats, double* seconds) {
+                 uint32_t* first_violation_len, demi_dpor_stats* stats, double* seconds,
+                 void* (*alloc)(size_t) = nullptr, void (*release)(void*) = nullptr) {
+  if (!alloc || !release) { alloc = [](size_t b) { return malloc(b); }; release = [](void* q) { free(q); }; }
+  RawBuf tr_buf(alloc, release), pr_buf(alloc, release);
   DporBook book(srch->track_history != 0);
   memset(stats, 0, sizeof *stats);
   stats->first_violation = ~0ull;
@@ -283,10 +308,9 @@ int explore_loop(Run&& run, uint32_t max_pairs, const demi_dpor_search* srch, de
   auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 
   std::vector<Trace> frontier(1);         // first run: nextTrace is empty
-  std::vector<demi_dpor_trace_entry> pf, tr;
+  std::vector<demi_dpor_trace_entry> pf;
   std::vector<uint32_t> pl, tl, np;
   std::vector<demi_verdict> vd;
-  std::vector<demi_dpor_pair> pr;
   bool exhausted = false;
   while (!frontier.empty()) {
     const size_t n = frontier.size();
@@ -294,14 +318,15 @@ int explore_loop(Run&& run, uint32_t max_pairs, const demi_dpor_search* srch, de
     for (auto& f : frontier) stride = f.size() > stride ? f.size() : stride;
     pf.assign(n * stride, demi_dpor_trace_entry{});
     pl.resize(n); tl.resize(n); np.resize(n); vd.resize(n);
-    tr.resize(n * DEMI_DPOR_MAX_TRACE);
-    pr.resize(n * (size_t)(max_pairs ? max_pairs : 1));
+    auto* tr = static_cast<demi_dpor_trace_entry*>(tr_buf.reserve(sizeof(demi_dpor_trace_entry) * DEMI_DPOR_MAX_TRACE * n));
+    auto* pr = static_cast<demi_dpor_pair*>(pr_buf.reserve(sizeof(demi_dpor_pair) * (size_t)(max_pairs ? max_pairs : 1) * n));
+    if (!tr || !pr) return DEMI_ERR_INVALID_ARG;
     for (size_t i = 0; i < n; i++) {
       pl[i] = (uint32_t)frontier[i].size();
       if (pl[i]) memcpy(&pf[i * stride], frontier[i].data(), sizeof(demi_dpor_trace_entry) * pl[i]);
     }
     double t0 = now();
-    int rc = run(pf.data(), pl.data(), (uint32_t)stride, (uint64_t)n, vd.data(), tr.data(), tl.data(), pr.data(), np.data());
+    int rc = run(pf.data(), pl.data(), (uint32_t)stride, (uint64_t)n, vd.data(), tr, tl.data(), pr, np.data());
     if (rc) return rc;
     double t1 = now();
     if (out_rounds) out_rounds[stats->launches] = (uint32_t)n;
@@ -322,7 +347,7 @@ int explore_loop(Run&& run, uint32_t max_pairs, const demi_dpor_search* srch, de
       }
     }
     // dpor(): bookkeeping for the racing pairs of the whole round (:1122-1139), sharded over host threads
-    book.absorb(tr.data(), tl.data(), pr.data(), np.data(), n, max_pairs);
+    book.absorb(tr, tl.data(), pr, np.data(), n, max_pairs);
     double t2 = now();
     frontier.clear();
     if (srch->stop_if_violation && found) break;

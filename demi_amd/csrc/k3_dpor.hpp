@@ -10,9 +10,16 @@
 // the lane keeps, for every delivered event, the trace index of the delivery that produced it.
 // "earlier happens-before later" (later.pathTo(earlier)) is a walk up those parent indices and the
 // branch point (getCommonPrefix(...).last) is the lowest common ancestor of the two trace indices.
-// The lane writes its trace (16 B per event) straight into the output array and re-reads it for
-// the walks; pending messages live in the LDS hot slots / HBM spill of sim_core.hpp with a packed
-// side word (producer index, quiescent period, FIFO sequence number).
+// The lane writes its trace (16 B per event) straight into the output array; pending messages live in
+// the LDS hot slots / HBM spill of sim_core.hpp with a packed side word (producer index, quiescent
+// period, FIFO sequence number).
+//
+// The racing-pair analysis of a finished interleaving is done by the WHOLE wave (k3_racing_pairs): the
+// trace's (parent, period, receiver) words and one 256-bit ancestor set per event are staged in LDS
+// (9 KB per wave); lane i owns the candidates "later = i, i + 64, ..." and all lanes walk `earlier`
+// together, so every LDS read of the inner loop is a broadcast.  happens-before is one bit test, the
+// branch point is the highest common bit of two ancestor sets.  Pairs are written in the sequential
+// (later, earlier) order via a count pass, a wave prefix sum and a write pass.
 #pragma once
 
 #include "sim_core.hpp"
@@ -44,9 +51,105 @@ struct K3Args {
 };
 
 constexpr int K3_WAVES = 4;
+constexpr size_t K3_ANALYSIS_BYTES = DEMI_DPOR_MAX_TRACE * 4 + DEMI_DPOR_MAX_TRACE * 32;   // meta words + ancestor sets
 
 __host__ __device__ inline size_t k3_lds_bytes(uint32_t code_len, uint32_t n_ext, uint32_t n_hs, uint32_t n_actors) {
-  return tables_lds_bytes(code_len, n_ext, n_hs) + K3_WAVES * lane_mem_wave_bytes(n_actors, true);
+  return tables_lds_bytes(code_len, n_ext, n_hs) + K3_WAVES * (lane_mem_wave_bytes(n_actors, true) + K3_ANALYSIS_BYTES);
+}
+
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v, uint32_t lane) {
+#pragma unroll
+  for (uint32_t d = 1; d < 64; d <<= 1) {
+    const uint32_t u = __shfl_up(v, d);
+    if (lane >= d) v += u;
+  }
+  return v;
+}
+
+// dpor()'s pair loop (:1122-1139) for one finished trace T[0..n), executed by all 64 lanes of the wave.
+// Returns the number of racing pairs (wave-uniform); the first max_pairs of them are written to `po` in the
+// order of the sequential loop (later ascending, earlier ascending).
+__device__ inline uint32_t k3_racing_pairs(const demi_dpor_trace_entry* __restrict__ T, uint32_t n, uint32_t* s_meta,
+                                           uint64_t* s_anc, demi_dpor_pair* __restrict__ po, uint32_t max_pairs,
+                                           uint32_t lane) {
+  constexpr uint32_t MSG = 1u << 19;
+  // meta word: parent | qperiod << 8 | receiver << 16 | (kind == message delivery) << 19
+  for (uint32_t i = lane; i < n; i += 64) {
+    const demi_dpor_trace_entry e = T[i];
+    s_meta[i] = (uint32_t)e.parent | ((uint32_t)e.qperiod << 8) | (w_dst(e.word) << 16) | (e.kind == 1 ? MSG : 0u);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  // ancestor set of event i: every trace index on the path from its producer up to the root (parents have
+  // smaller indices, the root is its own parent)
+  for (uint32_t i = lane; i < n; i += 64) {
+    uint64_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    uint32_t k = s_meta[i] & 0xFF;
+    for (;;) {
+      const uint64_t bit = 1ull << (k & 63);
+      const uint32_t q = k >> 6;
+      a0 |= (q == 0) ? bit : 0ull; a1 |= (q == 1) ? bit : 0ull; a2 |= (q == 2) ? bit : 0ull; a3 |= (q == 3) ? bit : 0ull;
+      if (k == 0) break;
+      k = s_meta[k] & 0xFF;
+    }
+    s_anc[i * 4 + 0] = a0; s_anc[i * 4 + 1] = a1; s_anc[i * 4 + 2] = a2; s_anc[i * 4 + 3] = a3;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+
+  uint32_t cnt[4] = {0, 0, 0, 0}, off[4] = {0, 0, 0, 0};
+  uint32_t total = 0;
+#pragma unroll
+  for (int pass = 0; pass < 2; pass++) {
+#pragma unroll
+    for (uint32_t g = 0; g < 4; g++) {
+      if (g * 64 >= n) continue;
+      const uint32_t l = g * 64 + lane;
+      const bool lv = l < n;
+      const uint32_t ml = lv ? s_meta[l] : 0u;
+      const bool lmsg = (ml & MSG) != 0;
+      const uint64_t l0 = lv ? s_anc[l * 4 + 0] : 0ull, l1 = lv ? s_anc[l * 4 + 1] : 0ull,
+                     l2 = lv ? s_anc[l * 4 + 2] : 0ull, l3 = lv ? s_anc[l * 4 + 3] : 0ull;
+      const uint32_t e_end = (g * 64 + 64 < n) ? g * 64 + 64 : n;
+      uint32_t c = 0;
+      for (uint32_t e = 1; e < e_end; e++) {
+        const uint32_t me = s_meta[e];
+        if (!(me & MSG)) continue;
+        // isCoEnabeled (:1091-1110): same receiver, same quiescent period, no causal path earlier -> later
+        const uint64_t sel = (e < 64) ? l0 : (e < 128) ? l1 : (e < 192) ? l2 : l3;
+        const bool race = lmsg && e < l && (((me ^ ml) & 0x7FF00u) == 0) && !((sel >> (e & 63)) & 1ull);
+        if (pass == 0) {
+          c += race ? 1u : 0u;
+        } else if (__ballot(race) != 0) {
+          // analyze_dep (:1043-1077): branch point = deepest common ancestor of the two producers
+          const uint64_t x3 = l3 & s_anc[e * 4 + 3], x2 = l2 & s_anc[e * 4 + 2], x1 = l1 & s_anc[e * 4 + 1],
+                         x0 = l0 & s_anc[e * 4 + 0];
+          if (race) {
+            const uint32_t branch = x3 ? 255u - (uint32_t)__builtin_clzll(x3) : x2 ? 191u - (uint32_t)__builtin_clzll(x2)
+                                  : x1 ? 127u - (uint32_t)__builtin_clzll(x1) : 63u - (uint32_t)__builtin_clzll(x0 | 1ull);
+            const uint32_t idx = off[g] + c;
+            if (idx < max_pairs) {
+              demi_dpor_pair p; p.branch = (uint8_t)branch; p.later = (uint8_t)l; p.earlier = (uint8_t)e; p.pad = 0;
+              po[idx] = p;
+            }
+            c++;
+          }
+        }
+      }
+      if (pass == 0) cnt[g] = c;
+    }
+    if (pass == 0) {
+      uint32_t base = 0;
+#pragma unroll
+      for (uint32_t g = 0; g < 4; g++) {
+        const uint32_t incl = wave_inclusive_sum(cnt[g], lane);
+        off[g] = base + incl - cnt[g];
+        base += __shfl(incl, 63);
+      }
+      total = base;
+    }
+  }
+  return total;
 }
 
 __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
@@ -58,6 +161,9 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
                                      args.spill, (size_t)blockIdx.x * blockDim.x + threadIdx.x,
                                      (size_t)gridDim.x * blockDim.x);
   uint64_t* const st = mem.st;
+  unsigned char* const an = wave_base + (size_t)K3_WAVES * lane_mem_wave_bytes(t.A, true) + (size_t)wave * K3_ANALYSIS_BYTES;
+  uint64_t* const s_anc = reinterpret_cast<uint64_t*>(an);
+  uint32_t* const s_meta = reinterpret_cast<uint32_t*>(an + DEMI_DPOR_MAX_TRACE * 32);
   const uint32_t A = t.A, NE = t.E, PMAX = args.p_max;
   const uint32_t max_messages = args.max_messages ? args.max_messages : 0x7FFFFFFFu;
 
@@ -273,8 +379,27 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
       }
     }
 
-    if (active && finish) {
-      const bool aborted = (flags & K3_ABORT) != 0;
+    // ---------------------------------------------------------- finished interleavings
+    const bool fin = active && finish;
+    const bool aborted = (flags & K3_ABORT) != 0;
+    uint32_t np = 0;
+    bool pairs_ovf = false;
+    {
+      // dpor(): racing pairs (:1122-1139), one finished trace at a time, all lanes helping
+      uint64_t todo = __ballot(fin && !aborted);
+      if (todo) __threadfence();            // the owner lane's trace stores are read back by the other lanes
+      while (todo) {
+        const int src = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const uint64_t s_sched = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(sched >> 32), src) << 32) |
+                                 (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)sched, src);
+        const uint32_t s_n = (uint32_t)__builtin_amdgcn_readlane((int)n_trace, src);
+        const uint32_t total = k3_racing_pairs(args.traces + s_sched * DEMI_DPOR_MAX_TRACE, s_n, s_meta, s_anc,
+                                               args.pairs + s_sched * (uint64_t)args.max_pairs, args.max_pairs, lane);
+        if ((int)lane == src) { np = total < args.max_pairs ? total : args.max_pairs; pairs_ovf = total > args.max_pairs; }
+      }
+    }
+    if (fin) {
       uint32_t viol = 0;
       if (!aborted) {   // checkInvariant (:394-418)
         const uint32_t fp = invariant_code(args.model, st, (1u << A) - 1, A, t.inv_kind, t.inv_fa, t.inv_va, t.inv_fb);
@@ -284,34 +409,6 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
         }
       }
       for (uint32_t a = 0; a < A; a++) hash_step(hash, st[a * 64]);
-      // -------------------------------------------------------- dpor(): racing pairs (:1122-1139)
-      uint32_t np = 0;
-      bool pairs_ovf = false;
-      if (!aborted) {
-        demi_dpor_pair* po = args.pairs + sched * (uint64_t)args.max_pairs;
-        for (uint32_t l = 1; l < n_trace; l++) {
-          const demi_dpor_trace_entry L = tr[l];
-          if (L.kind != 1) continue;
-          for (uint32_t e = 1; e < l; e++) {
-            const demi_dpor_trace_entry E = tr[e];
-            // isCoEnabeled (:1091-1110): same receiver, same quiescent period, no causal path
-            if (E.kind != 1 || w_dst(E.word) != w_dst(L.word) || E.qperiod != L.qperiod) continue;
-            bool anc = false;
-            for (uint32_t k = L.parent;; k = tr[k].parent) {
-              if (k == e) { anc = true; break; }
-              if (k < e) break;                 // parents have smaller indices: e cannot be above k
-            }
-            if (anc) continue;
-            // analyze_dep (:1043-1077): branch point = deepest common ancestor, as a trace index
-            uint32_t a = E.parent, b = L.parent;
-            while (a != b) { if (a > b) a = tr[a].parent; else b = tr[b].parent; }
-            if (np < args.max_pairs) {
-              demi_dpor_pair p; p.branch = (uint8_t)a; p.later = (uint8_t)l; p.earlier = (uint8_t)e; p.pad = 0;
-              po[np] = p; np++;
-            } else pairs_ovf = true;
-          }
-        }
-      }
       uint4 v;
       if (aborted) {
         v.x = flags & K3_ABORT; v.y = 0; v.z = 0; v.w = 0;
