@@ -71,12 +71,17 @@ model3, ev3, depth = raft5_config3()
 d = DPORwHeuristics(SchedulerConfig(model=model3), depth_bound=depth, stopIfViolationFound=False, batch=2048)
 t = time.perf_counter(); res = d.explore(ev3, max_interleavings=8192); dt = time.perf_counter() - t
 out["k3_python_loop_interleavings_per_s"] = len(res.interleavings) / dt
-dn = DPORwHeuristics(SchedulerConfig(model=model3), depth_bound=depth, stopIfViolationFound=False, batch=2048)
-t = time.perf_counter(); rn = dn.explore_native(ev3, max_interleavings=65536); dt = time.perf_counter() - t
-out["k3_native_loop_interleavings_per_s"] = len(rn.interleavings) / dt
-out["k3_native_loop"] = {"interleavings": len(rn.interleavings), "launches": len(rn.rounds), "seconds": dt,
-                         "distinct_schedules": len(rn.schedule_hashes())}
-dn.shutdown()
+for nb in (2048, 16384):
+    dn = DPORwHeuristics(SchedulerConfig(model=model3), depth_bound=depth, stopIfViolationFound=False, batch=nb)
+    dn.explore_native(ev3, max_interleavings=64)         # context + first launch out of the timing
+    dn.shutdown()
+    dn = DPORwHeuristics(SchedulerConfig(model=model3), depth_bound=depth, stopIfViolationFound=False, batch=nb)
+    t = time.perf_counter(); rn = dn.explore_native(ev3, max_interleavings=1 << 17); dt = time.perf_counter() - t
+    out["k3_native_loop_batch%d" % nb] = {"interleavings_per_s": len(rn.interleavings) / dt, "interleavings": len(rn.interleavings),
+                                          "launches": len(rn.rounds), "seconds": dt, "exhausted": rn.exhausted,
+                                          "distinct_schedules": len(rn.schedule_hashes())}
+    dn.shutdown()
+out["k3_native_loop_interleavings_per_s"] = out["k3_native_loop_batch2048"]["interleavings_per_s"]
 pref = [il.trace[:max(1, il.prefix_len)] for il in res.interleavings[:8192]]
 par = T.DporParams(depth, 0, 0, 0, 64, 4096)
 d._ctx.dpor_batch(pref[:64], par)
