@@ -57,6 +57,7 @@ struct demi_ctx {
   uint64_t* d_masks = nullptr;
   size_t masks_cap = 0;
   std::vector<int32_t> exp_of_rec;  // recorded-event index -> index in d_expected (-1: not lowered, a nop in replay)
+  std::vector<uint8_t> rec_is_delivery;  // recorded event is a MsgEvent / TimerDelivery
   uint32_t* d_skip = nullptr;       // removal candidates (demi_replay_removal_batch)
   size_t skip_cap = 0;
   uint8_t* d_kept = nullptr;        // executed-trace marks of one candidate (demi_replay_get_kept)
@@ -462,6 +463,7 @@ extern "C" int demi_replay_load(demi_ctx* ctx, const demi_ext_event* ext, uint32
   std::vector<uint8_t> send_of_id(2 * DEMI_MAX_REC_EVENTS + 2, 255);
   std::vector<uint64_t> expd;
   std::vector<int32_t> exp_of_rec(n_rec, -1);
+  std::vector<uint8_t> rec_is_delivery(n_rec, 0);
   uint32_t spawned = 0;
   for (uint32_t i = 0; i < n_rec; i++) {
     const demi_rec_event& e = rec[i];
@@ -502,6 +504,7 @@ extern "C" int demi_replay_load(demi_ctx* ctx, const demi_ext_event* ext, uint32
         return fail(ctx, DEMI_ERR_INVALID_TRACE, "recorded event %u: unknown kind %u", i, e.kind);
     }
     if (expd.size() != before) exp_of_rec[i] = (int32_t)before;
+    rec_is_delivery[i] = e.kind == DEMI_REC_MSG_EVENT;
   }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   if (!ctx->d_rext) HIP_TRY(ctx, hipMalloc(&ctx->d_rext, sizeof(uint64_t) * (DEMI_MAX_EXT_EVENTS + 1)));
@@ -512,6 +515,7 @@ extern "C" int demi_replay_load(demi_ctx* ctx, const demi_ext_event* ext, uint32
   ctx->n_expected = (uint32_t)expd.size();
   ctx->replay_spawned = spawned;
   ctx->exp_of_rec.swap(exp_of_rec);
+  ctx->rec_is_delivery.swap(rec_is_delivery);
   ctx->have_replay = true;
   return DEMI_OK;
 }
@@ -581,7 +585,7 @@ static int ensure_replay_buffers(demi_ctx* ctx, uint64_t n, bool masks) {
 // recorded-event index of a removal candidate -> index in the lowered trace (must be a MsgEvent)
 static int skip_to_expected(demi_ctx* ctx, uint32_t skip, uint32_t* out) {
   if (skip == 0xFFFFFFFFu) { *out = skip; return DEMI_OK; }
-  if (skip >= ctx->exp_of_rec.size() || ctx->exp_of_rec[skip] < 0)
+  if (skip >= ctx->exp_of_rec.size() || ctx->exp_of_rec[skip] < 0 || !ctx->rec_is_delivery[skip])
     return fail(ctx, DEMI_ERR_INVALID_ARG, "removal candidate %u is not a delivery of the loaded trace", skip);
   *out = (uint32_t)ctx->exp_of_rec[skip];
   return DEMI_OK;
