@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--schedules", type=int, default=N_PER_GPU, help="schedules per GPU per step")
     ap.add_argument("--p-max", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-specialize", action="store_true", help="interpret the transition table instead of compiling it")
     ap.add_argument("--cpu-sample", type=int, default=1 << 20)
     args = ap.parse_args()
 
@@ -64,6 +65,15 @@ def main():
     ctx = _native.Context(local_rank)
     ctx.model_load(model.to_struct())
     ctx.trace_load(events)
+    specialized = False
+    if not args.no_specialize:
+        # compile the loaded table to native code once (hiprtc, ~1 s, outside the timed region); a failure leaves
+        # the table interpreter in place and is reported in the JSON line
+        try:
+            ctx.model_specialize()
+            specialized = ctx.is_specialized()
+        except _native.DemiError as e:
+            print("bench: specialisation unavailable, interpreting the table: %s" % e, file=sys.stderr)
 
     verdicts = torch.empty((n, 2), dtype=torch.int64, device=dev)          # demi_verdict[n]
     viol = torch.zeros((VIOL_CAP + 1, 2), dtype=torch.int64, device=dev)  # row 0 = count, then demi_violation[]
@@ -133,13 +143,14 @@ def main():
                                    "Fuzzer-distribution trace, %d random interleavings per GPU per step" % n,
                        "schedules_per_gpu_per_step": n, "max_messages": int(limits.max_messages),
                        "invariant_check_interval": int(limits.invariant_check_interval), "p_max": int(limits.p_max),
-                       "seed_base": SEED_BASE, "parallelism": "schedule-index range sharded, %d rank(s)" % world},
+                       "table_compiled_to_native_code": specialized, "seed_base": SEED_BASE, "parallelism": "schedule-index range sharded, %d rank(s)" % world},
             "violations_last_step": int(len(vset)),
             "distinct_fingerprints_last_step": int(len(np.unique(vset["fingerprint"]))) if len(vset) else 0,
             "bugs_per_hr": float(len(vset)) / (dt / args.steps) * 3600.0,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k1_random_explore<false>", "kernel_ms": kernel_ms,
+                         "kernel": "k1_random_explore<false>" + (" (specialised, hiprtc)" if specialized else ""),
+                         "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "integer/LDS-bound simulation: algorithmic HBM traffic is 16 B per schedule, so the "
                                  "HBM fraction is tiny by construction (SURVEY 8d); see DESIGN.md for the issue-rate model"},

@@ -14,7 +14,8 @@ LIB_PATH = os.path.join(_HERE, "libdemi_gpu.so")
 EXPORTS = ["demi_ctx_create", "demi_ctx_destroy", "demi_last_error", "demi_version", "demi_model_load",
            "demi_trace_load", "demi_random_explore", "demi_random_explore_dev", "demi_random_get_trace", "demi_collect_violations_dev",
            "demi_replay_load", "demi_replay_batch", "demi_replay_batch_dev", "demi_dpor_load", "demi_dpor_batch", "demi_dpor_explore", "demi_random_explore_violations",
-           "demi_replay_removal_batch", "demi_replay_get_kept"]
+           "demi_replay_removal_batch", "demi_replay_get_kept", "demi_model_specialize", "demi_model_is_specialized",
+           "demi_specialize_check", "demi_specialize_source"]
 
 _lib = None
 
@@ -47,6 +48,12 @@ def lib():
     L.demi_last_error.restype = C.c_char_p
     L.demi_version.restype = C.c_char_p
     L.demi_model_load.argtypes = [C.c_void_p, C.POINTER(T.ModelStruct)]
+    L.demi_model_specialize.argtypes = [C.c_void_p, C.c_int]
+    L.demi_model_is_specialized.argtypes = [C.c_void_p]
+    L.demi_specialize_check.argtypes = [C.POINTER(T.ModelStruct), C.c_char_p, C.c_size_t]
+    L.demi_specialize_check.restype = C.c_long
+    L.demi_specialize_source.argtypes = [C.POINTER(T.ModelStruct), C.c_char_p, C.c_size_t]
+    L.demi_specialize_source.restype = C.c_long
     L.demi_trace_load.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
     L.demi_random_explore.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(T.Limits), C.c_void_p]
     L.demi_random_explore_dev.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(T.Limits),
@@ -70,6 +77,24 @@ def lib():
                                                  C.c_uint32, C.POINTER(C.c_uint64)]
     _lib = L
     return L
+
+
+def specialize_check(model_struct):
+    """Generate + compile the specialised K1 kernel for a model without a device: (code size, kernel name)."""
+    log = C.create_string_buffer(4096)
+    n = lib().demi_specialize_check(C.byref(model_struct), log, len(log))
+    if n < 0:
+        raise DemiError(-n, log.value.decode(errors="replace"))
+    return int(n), log.value.decode()
+
+
+def specialize_source(model_struct):
+    """The C++ the specialiser generates for the model's handlers."""
+    buf = C.create_string_buffer(1 << 20)
+    n = lib().demi_specialize_source(C.byref(model_struct), buf, len(buf))
+    if n < 0:
+        raise DemiError(-n, buf.value.decode(errors="replace"))
+    return buf.value.decode()
 
 
 class Context:
@@ -99,6 +124,13 @@ class Context:
 
     def model_load(self, model_struct):
         self._check(lib().demi_model_load(self._h, C.byref(model_struct)))
+
+    def model_specialize(self, enable=True):
+        """Compile the loaded table to native code (hiprtc) for the following random_explore launches."""
+        self._check(lib().demi_model_specialize(self._h, 1 if enable else 0))
+
+    def is_specialized(self):
+        return bool(lib().demi_model_is_specialized(self._h))
 
     def trace_load(self, events):
         import numpy as np

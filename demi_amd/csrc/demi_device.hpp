@@ -4,8 +4,10 @@
 // to bank l mod 32 (b32) / 2l mod 64 (b64): conflict-free by construction.
 #pragma once
 
+#ifndef __HIPCC_RTC__   // hiprtc (jit.hpp) has the device runtime built in
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#endif
 
 #include "../../include/demi_gpu.h"
 

@@ -1,0 +1,207 @@
+// jit.hpp — host side: compile the loaded transition table to native gfx950 code (hiprtc).
+//
+// The generic kernels interpret the table row by row: every lane decodes its own row and computes every
+// result class with selects (sim_core.hpp vm_run, ~150 VALU instructions per row) so that lanes sitting in
+// different handlers do not serialise.  Once a model is loaded its rows are constants, so the same handlers
+// can be emitted as straight-line code over 16 named byte registers with real branches: a row becomes 1-4
+// instructions, and a wave pays only for the rows some lane actually takes.  demi_model_specialize()
+// generates that source (generate_vm below), compiles the K1 kernel with it through hiprtc and the launch
+// path then uses the module's kernel; everything else (scheduling step, pending set, effects, verdict) is
+// the same code as the generic kernel, and the results stay bit-identical (tests run both).
+//
+// hiprtc is resolved with dlopen at specialisation time, next to the HIP runtime this process already uses
+// (PyTorch bundles its own), so the library has no link-time dependency on it and keeps working without it.
+#pragma once
+
+#include <dlfcn.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "sim_core.hpp"
+
+namespace demi_jit {
+
+// ------------------------------------------------------------------ code generation
+// One statement block per row; forward skips become gotos (the table has no backward edges, validation
+// guarantees it), handler entry is a switch over the distinct handler starts.
+inline std::string generate_vm(const demi::DevModel& h) {
+  using namespace demi;
+  std::string s;
+  char buf[512];
+  auto emit = [&](const char* fmt, auto... a) { snprintf(buf, sizeof buf, fmt, a...); s += buf; };
+  s += "namespace demi {\n";
+  s += "__device__ inline uint32_t vm_run_jit(const Tables& t, const LaneMem& mem, uint32_t w, uint32_t& flags) {\n";
+  s += "  const uint32_t type = w_type(w), me = w_dst(w);\n";
+  s += "  const uint32_t entry = t.hs[((t.ac_packed >> (4 * me)) & 15u) * t.NT + type];\n";
+  s += "  if (entry == 0xFFFFu) return 0;\n";
+  s += "  const uint64_t st0 = mem.st[me * 64];\n";
+  s += "  uint32_t r0 = (uint32_t)st0 & 255u, r1 = (uint32_t)(st0 >> 8) & 255u, r2 = (uint32_t)(st0 >> 16) & 255u, "
+       "r3 = (uint32_t)(st0 >> 24) & 255u,\n           r4 = (uint32_t)(st0 >> 32) & 255u, r5 = (uint32_t)(st0 >> 40) & 255u, "
+       "r6 = (uint32_t)(st0 >> 48) & 255u, r7 = (uint32_t)(st0 >> 56) & 255u;\n";
+  s += "  uint32_t r8 = 0, r9 = 0, r10 = 0, r11 = 0, r12 = w_p0(w), r13 = w_p1(w), r14 = w_src(w), r15 = me;\n";
+  s += "  uint32_t nfx = 0;\n";
+  s += "  (void)r8; (void)r9; (void)r10; (void)r11; (void)r12; (void)r13; (void)r14; (void)r15;\n";
+  // distinct handler starts
+  std::vector<uint32_t> starts;
+  for (uint32_t i = 0; i < h.n_classes * h.n_msg_types; i++) {
+    const uint32_t st = h.handler_start[i];
+    if (st == 0xFFFF || st >= h.code_len) continue;
+    bool seen = false;
+    for (uint32_t x : starts) seen |= (x == st);
+    if (!seen) starts.push_back(st);
+  }
+  s += "  switch (entry) {\n";
+  for (uint32_t st : starts) emit("    case %uu: goto L%u;\n", st, st);
+  s += "    default: goto done;\n  }\n";
+  auto target = [&](uint32_t pc) -> std::string {
+    if (pc >= h.code_len) return "done";
+    return "L" + std::to_string(pc);
+  };
+  const char* relop[6] = {"==", "!=", "<", ">=", "<=", ">"};     // EQ NE LT GE LE GT
+  for (uint32_t pc = 0; pc < h.code_len; pc++) {
+    const uint32_t row = h.code[pc];
+    const uint32_t op = row & 0x3Fu, dsti = (row >> 8) & 15u, ai = (row >> 12) & 15u, aux = (row >> 17) & 0x7Fu,
+                   braw = row >> 24;
+    const bool bimm = (row & 0x10000u) != 0;
+    char a[8], b[16], d[8];
+    snprintf(a, sizeof a, "r%u", ai);
+    snprintf(d, sizeof d, "r%u", dsti);
+    if (bimm) snprintf(b, sizeof b, "%uu", braw); else snprintf(b, sizeof b, "r%u", braw & 15u);
+    emit("  L%u: ", pc);
+    const uint32_t cw = op_control(op);
+    if (cw & CW_HALT) {
+      s += "goto done;\n";
+      continue;
+    }
+    if (cw & CW_ALU) {
+      switch (op) {
+        case DEMI_OP_MOV: emit("%s = %s & 255u;", d, b); break;
+        case DEMI_OP_ADD: emit("%s = (%s + %s) & 255u;", d, a, b); break;
+        case DEMI_OP_SUB: emit("%s = (%s - %s) & 255u;", d, a, b); break;
+        case DEMI_OP_AND: emit("%s = %s & %s & 255u;", d, a, b); break;
+        case DEMI_OP_OR: emit("%s = (%s | %s) & 255u;", d, a, b); break;
+        case DEMI_OP_XOR: emit("%s = (%s ^ %s) & 255u;", d, a, b); break;
+        case DEMI_OP_SHL: emit("%s = (%s << (%s & 7u)) & 255u;", d, a, b); break;
+        case DEMI_OP_SHR: emit("%s = (%s >> (%s & 7u)) & 255u;", d, a, b); break;
+        case DEMI_OP_BITSET: emit("%s = (%s | (1u << (%s & 7u))) & 255u;", d, a, b); break;
+        case DEMI_OP_POPC: emit("%s = (uint32_t)__popc(%s);", d, b); break;
+        case DEMI_OP_MIN: emit("%s = %s < %s ? %s : %s;", d, a, b, a, b); break;
+        case DEMI_OP_MAX: emit("%s = %s < %s ? %s : %s;", d, a, b, b, a); break;
+        default: emit("%s = (%s %s %s) ? 1u : 0u;", d, a, relop[op - DEMI_OP_EQ], b); break;   // EQ .. GT
+      }
+      s += "\n";
+    } else if (cw & CW_IF) {
+      emit("if (!(%s %s %s)) goto %s;\n", a, relop[op - DEMI_OP_IFEQ], b, target(pc + 1 + aux).c_str());
+    } else if (cw & CW_SKIPZ) {
+      emit("if (%s == 0u) goto %s;\n", a, target(pc + 1 + braw).c_str());
+    } else if (cw & CW_SKIPNZ) {
+      emit("if (%s != 0u) goto %s;\n", a, target(pc + 1 + braw).c_str());
+    } else if (cw & CW_SKIP) {
+      emit("goto %s;\n", target(pc + 1 + braw).c_str());
+    } else {   // CW_FX: recorded now, applied after the rows have run (same record as vm_run)
+      emit("if (nfx >= DEMI_FX_CAP) { flags |= DEMI_V_QUEUE_OVF; goto done; } "
+           "mem.fxq[nfx * 64] = fx_pack(%uu, %uu, %s > 15u ? 15u : %s, %s, %s); nfx++;\n",
+           row & 0xFFu, aux, a, a, d, b);
+    }
+  }
+  s += "  done:\n";
+  s += "  mem.st[me * 64] = (uint64_t)(r0 | (r1 << 8) | (r2 << 16) | (r3 << 24)) | "
+       "((uint64_t)(r4 | (r5 << 8) | (r6 << 16) | (r7 << 24)) << 32);\n";
+  s += "  return nfx;\n}\n}  // namespace demi\n";
+  return s;
+}
+
+// ------------------------------------------------------------------ hiprtc through dlopen
+struct Rtc {
+  void* lib = nullptr;
+  int (*create)(void**, const char*, const char*, int, const char* const*, const char* const*) = nullptr;
+  int (*compile)(void*, int, const char* const*) = nullptr;
+  int (*log_size)(void*, size_t*) = nullptr;
+  int (*log)(void*, char*) = nullptr;
+  int (*code_size)(void*, size_t*) = nullptr;
+  int (*code)(void*, char*) = nullptr;
+  int (*destroy)(void**) = nullptr;
+  int (*add_name)(void*, const char*) = nullptr;
+  int (*lowered)(void*, const char*, const char**) = nullptr;
+
+  bool open(std::string& err) {
+    if (lib) return true;
+    // prefer the hiprtc that ships next to the HIP runtime already mapped into this process
+    std::vector<std::string> cands;
+    Dl_info info;
+    if (dladdr(reinterpret_cast<void*>(&hipGetDeviceCount), &info) && info.dli_fname) {
+      std::string p(info.dli_fname);
+      const size_t slash = p.rfind('/');
+      if (slash != std::string::npos) cands.push_back(p.substr(0, slash) + "/libhiprtc.so");
+    }
+    cands.push_back("libhiprtc.so.7");
+    cands.push_back("libhiprtc.so");
+    for (const std::string& c : cands) {
+      lib = dlopen(c.c_str(), RTLD_NOW | RTLD_LOCAL);
+      if (lib) break;
+    }
+    if (!lib) { err = "hiprtc not found (dlopen libhiprtc.so failed)"; return false; }
+    auto sym = [&](const char* n) { return dlsym(lib, n); };
+    create = reinterpret_cast<decltype(create)>(sym("hiprtcCreateProgram"));
+    compile = reinterpret_cast<decltype(compile)>(sym("hiprtcCompileProgram"));
+    log_size = reinterpret_cast<decltype(log_size)>(sym("hiprtcGetProgramLogSize"));
+    log = reinterpret_cast<decltype(log)>(sym("hiprtcGetProgramLog"));
+    code_size = reinterpret_cast<decltype(code_size)>(sym("hiprtcGetCodeSize"));
+    code = reinterpret_cast<decltype(code)>(sym("hiprtcGetCode"));
+    destroy = reinterpret_cast<decltype(destroy)>(sym("hiprtcDestroyProgram"));
+    add_name = reinterpret_cast<decltype(add_name)>(sym("hiprtcAddNameExpression"));
+    lowered = reinterpret_cast<decltype(lowered)>(sym("hiprtcGetLoweredName"));
+    if (!create || !compile || !log_size || !log || !code_size || !code || !destroy || !add_name || !lowered) {
+      err = "hiprtc entry points missing";
+      dlclose(lib); lib = nullptr;
+      return false;
+    }
+    return true;
+  }
+};
+
+struct Header { const char* name; const char* text; };
+
+// Compiles `source` (with the embedded headers) for gfx950; on success `image` is the code object and
+// `lowered_names[i]` the mangled name of name_exprs[i].
+inline bool compile(Rtc& rtc, const std::string& source, const std::vector<Header>& headers,
+                    const std::vector<std::string>& name_exprs, std::vector<char>& image,
+                    std::vector<std::string>& lowered_names, std::string& err) {
+  if (!rtc.open(err)) return false;
+  std::vector<const char*> hn, ht;
+  for (const Header& h : headers) { hn.push_back(h.name); ht.push_back(h.text); }
+  void* prog = nullptr;
+  if (rtc.create(&prog, source.c_str(), "demi_k1_jit.hip", (int)headers.size(), ht.data(), hn.data()) != 0) {
+    err = "hiprtcCreateProgram failed";
+    return false;
+  }
+  for (const std::string& n : name_exprs) rtc.add_name(prog, n.c_str());
+  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-label"};
+  const int rc = rtc.compile(prog, 4, opts);
+  if (rc != 0) {
+    size_t ls = 0;
+    rtc.log_size(prog, &ls);
+    std::string lg(ls + 1, '\0');
+    if (ls) rtc.log(prog, &lg[0]);
+    err = "hiprtcCompileProgram failed: " + lg.substr(0, 1500);
+    rtc.destroy(&prog);
+    return false;
+  }
+  lowered_names.clear();
+  for (const std::string& n : name_exprs) {
+    const char* ln = nullptr;
+    if (rtc.lowered(prog, n.c_str(), &ln) != 0 || !ln) { err = "hiprtcGetLoweredName failed for " + n; rtc.destroy(&prog); return false; }
+    lowered_names.push_back(ln);
+  }
+  size_t cs = 0;
+  rtc.code_size(prog, &cs);
+  image.resize(cs);
+  if (cs == 0 || rtc.code(prog, image.data()) != 0) { err = "hiprtcGetCode failed"; rtc.destroy(&prog); return false; }
+  rtc.destroy(&prog);
+  return true;
+}
+
+}  // namespace demi_jit

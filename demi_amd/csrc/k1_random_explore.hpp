@@ -17,6 +17,12 @@
 
 #include "sim_core.hpp"
 
+// The handler-row engine: the table interpreter, or the native code generated from the loaded table when the
+// kernel is compiled by demi_model_specialize (jit.hpp defines DEMI_VM_RUN before including this file).
+#ifndef DEMI_VM_RUN
+#define DEMI_VM_RUN vm_run
+#endif
+
 namespace demi {
 
 struct K1Args {
@@ -349,7 +355,7 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k1_random_explore(const K1Args 
     PH_MARK(2);
     // ------------------------------------------------------------ the receiver's handler rows
     uint32_t nfx = 0;
-    if (deliver) nfx = vm_run(t, mem, w, flags);
+    if (deliver) nfx = DEMI_VM_RUN(t, mem, w, flags);
     PH_MARK(3);
 #ifdef DEMI_K1_PHASES
     ph_iters++; ph_active += __popcll(__ballot(deliver));

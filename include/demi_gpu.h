@@ -18,8 +18,10 @@
 #ifndef DEMI_GPU_H
 #define DEMI_GPU_H
 
+#ifndef __HIPCC_RTC__   /* the run-time compiler (demi_model_specialize) supplies the fixed-width types */
 #include <stdint.h>
 #include <stddef.h>
+#endif
 
 #ifdef __cplusplus
 extern "C" {
@@ -177,6 +179,19 @@ const char* demi_version(void);
 
 /* SchedulerConfig (SchedulerConfig.scala:9-37) + the application actors lowered to a table. */
 int demi_model_load(demi_ctx* ctx, const demi_model* model);
+/* Compile the loaded transition table to native gfx950 code (hiprtc, ~1 s) and use that kernel for the
+ * following demi_random_explore* launches instead of the table interpreter: the reference runs the
+ * application's own (JIT-compiled) receive methods, this is the same step for the lowered table.  Verdicts are
+ * bit-identical with and without it.  enable = 0 returns to the interpreter.  A failure (no hiprtc, compile
+ * error) leaves the interpreter in place and returns the reason through demi_last_error.  demi_model_load
+ * drops the specialisation of the previous model.                                                         */
+int demi_model_specialize(demi_ctx* ctx, int enable);
+int demi_model_is_specialized(const demi_ctx* ctx);
+/* Device-free check of the same code generation + compilation (build / CI): code-object size in bytes, or
+ * -demi_status with the reason in `log`.                                                                   */
+long demi_specialize_check(const demi_model* model, char* log, size_t log_cap);
+/* The generated handler source (C++), NUL-terminated, truncated to cap; returns its full length. */
+long demi_specialize_source(const demi_model* model, char* out, size_t cap);
 /* The external-event trace handed to explore()/test() (RandomScheduler.scala:226-237). */
 int demi_trace_load(demi_ctx* ctx, const demi_ext_event* events, uint32_t n_events);
 

@@ -1,0 +1,19 @@
+// Host stand-ins for the few device definitions the generated handler code (demi_specialize_source) uses,
+// so that the CPU suite can compile it with g++ and compare it with the oracle's row interpreter.
+#include <cstdint>
+#define __device__
+#define DEMI_FX_CAP 8
+#define DEMI_V_QUEUE_OVF 0x8u
+namespace demi {
+struct Tables { const uint32_t* hs; uint32_t ac_packed, NT; };
+struct LaneMem { uint64_t* st; uint32_t* fxq; };
+static inline uint32_t w_type(uint32_t w) { return w & 31u; }
+static inline uint32_t w_dst(uint32_t w) { return (w >> 5) & 7u; }
+static inline uint32_t w_src(uint32_t w) { return (w >> 8) & 15u; }
+static inline uint32_t w_p0(uint32_t w) { return (w >> 16) & 255u; }
+static inline uint32_t w_p1(uint32_t w) { return w >> 24; }
+static inline uint32_t fx_pack(uint32_t op, uint32_t type, uint32_t target, uint32_t p0, uint32_t p1) {
+  return (op & 31u) | (type << 5) | (target << 10) | (p0 << 14) | (p1 << 22);
+}
+static inline int __popc(uint32_t x) { return __builtin_popcount(x); }
+}  // namespace demi

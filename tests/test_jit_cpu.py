@@ -1,0 +1,105 @@
+"""CPU suite, part 6: the table -> native code specialiser (demi_model_specialize).  Without a GPU we can still
+(a) run the code generator and the hiprtc compilation for gfx950 and (b) compile the generated handler code
+for the host and compare it, delivery by delivery, with the oracle's row interpreter."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from demi_amd import _native, types as T
+from demi_amd import model as M
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FX_CAP = 8            # DEMI_FX_CAP
+MODELS = [("raft5", lambda: M.raft_model(5)), ("raft3_fixed", lambda: M.raft_model(3, election_budget=2, buggy=False)),
+          ("shuffle8", lambda: M.shuffle_model(True))]
+
+
+@pytest.mark.parametrize("name,mk", MODELS)
+def test_specialised_kernel_compiles_for_gfx950(name, mk):
+    try:
+        size, kernel = _native.specialize_check(mk().to_struct())
+    except _native.DemiError as e:
+        if "hiprtc not found" in str(e):
+            pytest.skip("no hiprtc in this environment")
+        raise
+    assert size > 10000 and "k1_random_explore" in kernel
+
+
+def test_generated_source_shape():
+    m = M.raft_model(5)
+    src = _native.specialize_source(m.to_struct())
+    assert src.count("\n  L") == len(m.code)                 # one labelled statement per row
+    assert "vm_run_jit" in src and "goto done;" in src
+    for st in {s for s in m.handler_start if s != 0xFFFF}:
+        assert "case %du: goto L%d;" % (st, st) in src
+
+
+def _host_vm(model, tmp_path):
+    src = _native.specialize_source(model.to_struct())
+    cpp = tmp_path / "vm_host.cpp"
+    cpp.write_text('#include "%s"\n%s\nextern "C" uint32_t run(const uint32_t* hs, uint32_t ac, uint32_t nt, uint64_t* st, '
+                   'uint32_t* fxq, uint32_t w, uint32_t* flags) {\n  demi::Tables t{hs, ac, nt}; demi::LaneMem m{st, fxq};\n'
+                   '  uint32_t f = *flags; uint32_t n = demi::vm_run_jit(t, m, w, f); *flags = f; return n; }\n'
+                   % (os.path.join(ROOT, "tests", "jit_host_shim.hpp"), src))
+    so = tmp_path / "vm_host.so"
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-label", "-o", str(so), str(cpp)])
+    L = C.CDLL(str(so))
+    L.run.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+    L.run.restype = C.c_uint32
+    return L
+
+
+@pytest.mark.parametrize("name,mk", MODELS)
+def test_generated_handlers_equal_the_row_interpreter(oracle, tmp_path, name, mk):
+    """Random states x random messages: same new state, same effect rows (after expanding SEND / BCAST the way the
+    apply phase does), same FX_CAP overflow."""
+    model = mk()
+    L = _host_vm(model, tmp_path)
+    ms = model.to_struct()
+    A, NT = model.n_actors, len(model.msg_names)
+    hs = np.full(T.MAX_CLASSES * T.MAX_MSG_TYPES, 0xFFFF, dtype=np.uint32)
+    hs[:len(model.handler_start)] = model.handler_start
+    ac = sum((c & 15) << (4 * i) for i, c in enumerate(model.actor_class))
+    exists = (1 << A) - 1
+    rng = np.random.default_rng(7)
+    st = np.zeros(8 * 64, dtype=np.uint64)
+    fxq = np.zeros(FX_CAP * 64, dtype=np.uint32)
+    fx = (C.c_uint8 * (5 * 64))()
+    n_fx_seen = n_ovf = 0
+    for it in range(30000):
+        me = int(rng.integers(A))
+        typ = int(rng.integers(NT))
+        src = int(rng.choice([int(rng.integers(A)), T.DEADLETTERS]))
+        p0, p1 = int(rng.integers(256)), int(rng.integers(256))
+        # states near the reachable region (small field values) and fully random ones
+        state = int.from_bytes(bytes(int(x) for x in (rng.integers(0, 6, 8) if it % 3 else rng.integers(0, 256, 8))), "little")
+        w = typ | (me << 5) | (src << 8) | (p0 << 16) | (p1 << 24)
+        st[me * 64] = state
+        flags = C.c_uint32(0)
+        n = L.run(hs.ctypes.data, ac, NT, st.ctypes.data, fxq.ctypes.data, w, C.byref(flags))
+        want_state = C.c_uint64(state)
+        wn = oracle.lib().orc_vm_run(C.byref(ms), me, C.byref(want_state), typ, src, p0, p1, exists, fx, 64)
+        if wn < 0:
+            assert flags.value & T.V_QUEUE_OVF
+            n_ovf += 1
+            continue
+        assert not flags.value
+        assert int(st[me * 64]) == want_state.value, (it, me, typ, hex(state))
+        got = []
+        for k in range(n):
+            f = int(fxq[k * 64])
+            op, t_, target, q0, q1 = f & 31, (f >> 5) & 31, (f >> 10) & 15, (f >> 14) & 255, (f >> 22) & 255
+            if op == M.OPS["SEND"]:
+                if target < A:
+                    got.append((0, target, t_, q0, q1))
+            elif op == M.OPS["BCAST"]:
+                got += [(0, r, t_, q0, q1) for r in range(A) if r != me]
+            else:
+                got.append((1 + op - M.OPS["TSET"], me, t_, 0, 0))
+        want = [tuple(fx[5 * k + j] for j in range(5)) for k in range(wn)]
+        assert got == want, (it, me, typ, hex(state), got, want)
+        n_fx_seen += len(got)
+    assert n_fx_seen > 1000

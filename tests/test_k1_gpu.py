@@ -19,10 +19,20 @@ pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(__file__), "golden")
 
 
-def both(gpu_ctx, oracle, model, events, n, lim, seed_base=SEED_BASE, seeds=None):
+def both(gpu_ctx, oracle, model, events, n, lim, seed_base=SEED_BASE, seeds=None, jit=False):
+    """GPU verdicts and oracle verdicts of the same schedules.  jit=True also runs the kernel compiled for the
+    model's table (demi_model_specialize) and requires it to agree with the table interpreter bit for bit."""
     gpu_ctx.model_load(model.to_struct())
     gpu_ctx.trace_load(events)
     g = gpu_ctx.random_explore(n, lim, seed_base=seed_base, seeds=seeds)
+    if jit:
+        assert not gpu_ctx.is_specialized()
+        gpu_ctx.model_specialize()
+        assert gpu_ctx.is_specialized()
+        gj = gpu_ctx.random_explore(n, lim, seed_base=seed_base, seeds=seeds)
+        assert_same(gj, g)
+        gpu_ctx.model_specialize(False)
+        assert not gpu_ctx.is_specialized()
     c = oracle.random_explore(model, events, n, seed_base=seed_base, seeds=seeds, limits=lim, n_threads=os.cpu_count())
     return g, c
 
@@ -57,7 +67,7 @@ def test_golden_fixtures_on_gpu(gpu_ctx, name):
 def test_raft5_parity_all_capacities(gpu_ctx, oracle, p_max):
     model, events, lim = raft5_config2()
     lim.p_max = p_max
-    g, c = both(gpu_ctx, oracle, model, events, 50000, lim)
+    g, c = both(gpu_ctx, oracle, model, events, 50000, lim, jit=True)
     assert_same(g, c)
     assert (g["flags"] & T.V_VIOLATION).sum() > 100
     if p_max == 32:
@@ -78,7 +88,7 @@ def test_raft3_config1_and_fixed_model(gpu_ctx, oracle):
 def test_limits_matrix(gpu_ctx, oracle, limits):
     model, events, _ = raft5_config2()
     lim = T.Limits(limits[0], limits[1], limits[2], 0, 0, 0)
-    g, c = both(gpu_ctx, oracle, M.raft_model(5, election_budget=2), events, 8000, lim)
+    g, c = both(gpu_ctx, oracle, M.raft_model(5, election_budget=2), events, 8000, lim, jit=(limits[1] in (0, 30)))
     assert_same(g, c)
 
 
@@ -126,7 +136,7 @@ def test_fault_heavy_and_edge_traces(gpu_ctx, oracle):
     w = FuzzerWeights(kill=0.15, send=0.3, wait_quiescence=0.15, partition=0.25, unpartition=0.15)
     for seed in (1, 2, 3):
         events = events_to_array(raft_trace(5, 80, seed, w, exact=False))
-        g, c = both(gpu_ctx, oracle, model, events, 6000, lim)
+        g, c = both(gpu_ctx, oracle, model, events, 6000, lim, jit=True)
         assert_same(g, c)
     edge = [[], [wait_quiescence()], [start(0)], [send(0, M.M_BOOTSTRAP)],
             [start(0), kill(0), start(0), send(0, M.M_BOOTSTRAP), wait_quiescence(), kill(0), wait_quiescence()],
@@ -142,7 +152,7 @@ def test_fault_heavy_and_edge_traces(gpu_ctx, oracle):
     while len(long_ev) < T.MAX_EXT_EVENTS:
         long_ev.append(send(k % 5, M.M_CLIENT, k & 255) if k % 7 else wait_quiescence())
         k += 1
-    g, c = both(gpu_ctx, oracle, model, events_to_array(long_ev), 3000, T.Limits(1000, 30, 128, 0, 0, 0))
+    g, c = both(gpu_ctx, oracle, model, events_to_array(long_ev), 3000, T.Limits(1000, 30, 128, 0, 0, 0), jit=True)
     assert_same(g, c)
 
 
@@ -167,7 +177,7 @@ def test_timer_semantics_models_on_gpu(gpu_ctx, oracle):
         ev.append(wait_quiescence() if (r < 3 and ev[-1][0] != T.EV_WAIT_QUIESCENCE) else
                   send(int(rng.integers(0, 4)), K, int(rng.integers(0, 4))))
     for lim in (T.Limits(400, 5, 64, 0, 0, 0), T.Limits(250, 0, 32, 0, 0, 0), T.Limits(0, 0, 64, 0, 0, 0)):
-        g, c = both(gpu_ctx, oracle, model, events_to_array(ev), 8000, lim)
+        g, c = both(gpu_ctx, oracle, model, events_to_array(ev), 8000, lim, jit=True)
         assert_same(g, c)
         assert len(np.unique(g["hash"])) > 7000
         if lim.max_messages != 250:
@@ -178,7 +188,7 @@ def test_timer_semantics_models_on_gpu(gpu_ctx, oracle):
     for _ in range(9):
         many.tset(TI)
     model2 = build_model("tq", 2, MSGS, {(0, "Kick"): many}, [[0] * 8] * 2, (T.INV_NEVER, 3, 1, 0))
-    g, c = both(gpu_ctx, oracle, model2, events_to_array([start(0), send(0, K)]), 64, T.Limits(0, 0, 64, 0, 0, 0))
+    g, c = both(gpu_ctx, oracle, model2, events_to_array([start(0), send(0, K)]), 64, T.Limits(0, 0, 64, 0, 0, 0), jit=True)
     assert_same(g, c)
     assert (g["flags"] == T.V_QUEUE_OVF).all()
 
@@ -250,8 +260,15 @@ def test_full_size_properties_1m(gpu_ctx, oracle):
     out.zero_()
     gpu_ctx.random_explore_dev(n, lim, out.data_ptr(), seed_base=SEED_BASE, stream=sp)   # idempotent / deterministic
     torch.cuda.synchronize()
+    b = out.cpu().numpy().view(T.VERDICT_DTYPE).reshape(-1).copy()
+    assert_same(a, b)
+    out.zero_()
+    gpu_ctx.model_specialize()           # the same 2^20 schedules through the kernel compiled for this table
+    gpu_ctx.random_explore_dev(n, lim, out.data_ptr(), seed_base=SEED_BASE, stream=sp)
+    torch.cuda.synchronize()
     b = out.cpu().numpy().view(T.VERDICT_DTYPE).reshape(-1)
     assert_same(a, b)
+    gpu_ctx.model_specialize(False)
     flags = a["flags"]
     assert not (flags & (T.V_PENDING_OVF | T.V_QUEUE_OVF)).any()
     deliveries = (flags >> 16) & 0xFFFF
@@ -279,10 +296,10 @@ def test_shuffle8_three_actor_classes(gpu_ctx, oracle):
     """BASELINE config 5's application (8 actors, 3 classes): class-indexed handler lookup."""
     from demi_amd.apps import shuffle8_config5
     model, _, events, lim = shuffle8_config5()
-    g, c = both(gpu_ctx, oracle, model, events, 30000, lim)
+    g, c = both(gpu_ctx, oracle, model, events, 30000, lim, jit=True)
     assert_same(g, c)
     assert (g["flags"] & T.V_VIOLATION).sum() > 500
-    g, c = both(gpu_ctx, oracle, M.shuffle_model(buggy=False), events, 30000, lim)
+    g, c = both(gpu_ctx, oracle, M.shuffle_model(buggy=False), events, 30000, lim, jit=True)
     assert_same(g, c)
     assert not (g["flags"] & T.V_VIOLATION).any()
 
