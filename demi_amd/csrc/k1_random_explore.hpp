@@ -42,7 +42,7 @@ struct K1Args {
   uint32_t* rec_count;      // REC only: [n]
   uint32_t rec_cap;
   uint32_t n_batches;       // WaitQuiescence events + 1
-  unsigned long long* phase_out;   // -DDEMI_K1_PHASES builds only: [waves][8] cycle totals per phase
+  unsigned long long* phase_out;   // -DDEMI_K1_PHASES builds only: [waves][16] cycle totals per phase
 };
 
 enum : int { PH_IDLE = 0, PH_INJECT = 1, PH_DISPATCH = 2, PH_FINISH = 3 };
@@ -54,9 +54,9 @@ constexpr int K1_BATCH = 64;         // schedule indices claimed per atomic
 // injection batch (inject_until_quiescence is schedule-independent: the events are applied in trace
 // order whatever the interleaving, so the state after batch j is a function of j alone) and the
 // message word of every Send (0 = not a deliverable Send).
-constexpr uint32_t K1_BATCH_WORDS = 6;   // end index, inaccessible, killed, partitioned lo/hi, pad
+constexpr uint32_t K1_BATCH_WORDS = 6;   // end index, inaccessible, killed, partitioned lo/hi, sends (offset | count << 16)
 __host__ __device__ inline size_t k1_extra_lds_bytes(uint32_t n_ev, uint32_t n_batches) {
-  return (((size_t)n_batches * K1_BATCH_WORDS + n_ev) * 4 + 15) & ~(size_t)15;
+  return (((size_t)n_batches * K1_BATCH_WORDS + 2 * (size_t)n_ev) * 4 + 15) & ~(size_t)15;
 }
 template <bool REC>
 __host__ __device__ inline size_t k1_lds_bytes(uint32_t code_len, uint32_t n_ev, uint32_t n_hs, uint32_t n_actors,
@@ -72,25 +72,30 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k1_random_explore(const K1Args 
   unsigned char* extra = tables_load(t, smem, args.model, args.trace, args.n_ev, args.exists);
   uint32_t* const s_batch = reinterpret_cast<uint32_t*>(extra);
   uint32_t* const s_sendw = s_batch + (size_t)args.n_batches * K1_BATCH_WORDS;
+  uint32_t* const s_bsend = s_sendw + args.n_ev;     // the deliverable Send words, batch after batch, compacted
   unsigned char* wave_base = extra + k1_extra_lds_bytes(args.n_ev, args.n_batches);
   if (threadIdx.x == 0) {
     // EventOrchestrator.inject_until_quiescence (:132-189) once per workgroup, for every batch
-    uint32_t inacc = t.exists, killed = 0, b_no = 0;
+    uint32_t inacc = t.exists, killed = 0, b_no = 0, n_bs = 0, bs_lo = 0;
     uint64_t part = 0;
     if (t.E == 0) { s_batch[0] = 0; s_batch[1] = inacc; s_batch[2] = 0; s_batch[3] = 0; s_batch[4] = 0; s_batch[5] = 0; }
     for (uint32_t i = 0; i < t.E; i++) {
       const uint64_t ev = t.trace[i];
       const uint32_t kind = (uint32_t)ev & 0xFF, a = (uint32_t)(ev >> 8) & 0xFF, b = (uint32_t)(ev >> 16) & 0xFF;
-      s_sendw[i] = (kind == DEMI_EV_SEND && ((t.exists >> a) & 1))
-                       ? msg_word((uint32_t)(ev >> 24) & 0xFF, DEMI_DEADLETTERS, a, (uint32_t)(ev >> 32) & 0xFF, (uint32_t)(ev >> 40) & 0xFF)
-                       : 0u;
+      const uint32_t sw = (kind == DEMI_EV_SEND && ((t.exists >> a) & 1))
+                              ? msg_word((uint32_t)(ev >> 24) & 0xFF, DEMI_DEADLETTERS, a, (uint32_t)(ev >> 32) & 0xFF, (uint32_t)(ev >> 40) & 0xFF)
+                              : 0u;
+      s_sendw[i] = sw;
+      if (sw != 0) s_bsend[n_bs++] = sw;
       if (kind == DEMI_EV_START) { inacc &= ~(1u << a); killed &= ~(1u << a); }
       else if (kind == DEMI_EV_KILL) { killed |= 1u << a; inacc |= 1u << a; }
       else if (kind == DEMI_EV_PARTITION) part |= 1ULL << (a * 8 + b);
       else if (kind == DEMI_EV_UNPARTITION) part &= ~(1ULL << (a * 8 + b));
       if (kind == DEMI_EV_WAIT_QUIESCENCE || i + 1 == t.E) {
         uint32_t* o = s_batch + (size_t)b_no * K1_BATCH_WORDS;
-        o[0] = i + 1; o[1] = inacc; o[2] = killed; o[3] = (uint32_t)part; o[4] = (uint32_t)(part >> 32); o[5] = 0;
+        o[0] = i + 1; o[1] = inacc; o[2] = killed; o[3] = (uint32_t)part; o[4] = (uint32_t)(part >> 32);
+        o[5] = bs_lo | ((n_bs - bs_lo) << 16);
+        bs_lo = n_bs;
         b_no++;
       }
     }
@@ -102,7 +107,13 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k1_random_explore(const K1Args 
   uint64_t* const st = mem.st;
   const uint32_t PMAX = args.p_max;
 
-  const uint32_t A = t.A, E = t.E, exists = t.exists;
+  // a specialised build (jit.hpp) knows the model's constants at compile time
+#ifdef DEMI_JIT_A
+  const uint32_t A = DEMI_JIT_A;
+#else
+  const uint32_t A = t.A;
+#endif
+  const uint32_t E = t.E, exists = t.exists;
   const uint32_t max_messages = args.max_messages ? args.max_messages : 0x7FFFFFFFu;
   const uint32_t interval = args.interval;
 
@@ -111,6 +122,7 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k1_random_explore(const K1Args 
   bool fresh = false;
   uint64_t sched = 0, rng = 0, hash = 0;
   uint32_t n_pend = 0, count = 0, cnt_mod = 0, tidx = 0, inj_lo = 0, inj_hi = 0, batch_no = 0;
+  uint32_t fl_off = 0, fl_cnt = 0;    // !REC: the injected batch's Sends as a range of s_bsend, flushed by the whole wave
   Net net = {0, 0, 0};
   uint64_t tq = 0, resend = 0;        // messagesToSend timers / timersToResend: 1 byte each (rcv<<5 | type)
   uint32_t n_tq = 0, n_resend = 0;
@@ -181,14 +193,20 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k1_random_explore(const K1Args 
   };
 
   auto check_invariant = [&]() -> uint32_t {
+#ifdef DEMI_JIT_A
+    const uint32_t fp = invariant_code(args.model, st, exists, A, DEMI_JIT_INV_KIND, DEMI_JIT_INV_FA, DEMI_JIT_INV_VA, DEMI_JIT_INV_FB);
+    const uint32_t fp_mask = DEMI_JIT_FP_MASK;
+#else
     const uint32_t fp = invariant_code(args.model, st, exists, A, t.inv_kind, t.inv_fa, t.inv_va, t.inv_fb);
+    const uint32_t fp_mask = t.fp_mask;
+#endif
     if (!fp) return 0u;
-    if (args.looking_for_valid) return (((fp ^ args.looking_for) & t.fp_mask) == 0) ? args.looking_for : 0u;
+    if (args.looking_for_valid) return (((fp ^ args.looking_for) & fp_mask) == 0) ? args.looking_for : 0u;
     return fp;
   };
 
 #ifdef DEMI_K1_PHASES
-  uint64_t ph_t[6] = {0, 0, 0, 0, 0, 0}, ph_iters = 0, ph_rows = 0, ph_active = 0;
+  uint64_t ph_t[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ph_iters = 0, ph_active = 0;
   // volatile asm with a memory clobber: keeps loads/stores and control flow on their side of the mark
 #define PH_NOW(V) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(V) : : "memory")
 #define PH_MARK(I) do { uint64_t now_; PH_NOW(now_); ph_t[I] += now_ - ph_last; ph_last = now_; } while (0)
@@ -245,6 +263,7 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k1_random_explore(const K1Args 
         batch_no++;
         tidx = bt[0];
         net.inaccessible = bt[1]; net.killed = bt[2]; net.partitioned = (uint64_t)bt[3] | ((uint64_t)bt[4] << 32);
+        fl_off = bt[5] & 0xFFFFu; fl_cnt = bt[5] >> 16;
       }
       bool loop = REC;     // the recording variant walks the events to emit their records
       while (loop && tidx < E) {
@@ -276,8 +295,9 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k1_random_explore(const K1Args 
     // ------------------------------------------------------------ one scheduling step
     uint32_t w = 0;            // the message picked by this step
     bool deliver = false;
-    if (ph == PH_DISPATCH) {
-      bool none = false;
+    const bool disp = (ph == PH_DISPATCH);
+    bool none = false, step = false;
+    if (disp) {
       if (viol) {
         none = true;                                            // :354-360
       } else if (count > max_messages) {                        // :369-373 finish_early
@@ -287,31 +307,63 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k1_random_explore(const K1Args 
           viol = check_invariant();
           if (viol) none = true;
         }
-        if (!none) {
-          // send_external_messages (:424): injected Sends first (no partition check, :298-308) ...
-          for (uint32_t i = inj_lo; i < inj_hi; i++) {
-            const uint32_t sw = s_sendw[i];
-            if (sw != 0) {
-              const uint32_t id = next_id; if (REC) next_id++;
-              PEND_APPEND(sw, id, false);
-              REC_PUSH(DEMI_REC_MSG_SEND, DEMI_DEADLETTERS, w_dst(sw), w_type(sw), w_p0(sw), w_p1(sw), 1, i, id);
-            }
-          }
-          inj_lo = inj_hi;
-          // ... then timers: internal messages from deadLetters, dropped when the receiver is
-          // inaccessible (crosses_partition(deadLetters, rcv), :287-297)
-          for (uint32_t k = 0; k < n_tq; k++) {
-            const uint32_t bt = (uint32_t)(tq >> (8 * k)) & 0xFF, rcv = bt >> 5, type = bt & 31;
-            const uint32_t id = next_id; if (REC) next_id++;
-            const bool drop = (net.inaccessible >> rcv) & 1;
-            if (!drop) PEND_APPEND(msg_word(type, DEMI_DEADLETTERS, rcv, 0, 0), id, true);
-            REC_PUSH(DEMI_REC_MSG_SEND, DEMI_DEADLETTERS, rcv, type, 0, 0, 2 | (drop ? 4 : 0), 255, id);
-          }
-          tq = 0; n_tq = 0;
-          if ((flags & DEMI_OVF_ANY) || n_pend == 0) none = true;
+        step = !none;
+      }
+    }
+    PH_MARK(2);
+    // send_external_messages (:424): injected Sends first (no partition check, :298-308).  The Sends of an
+    // injection batch are the same words for every schedule, so the wave appends them together: for each lane
+    // that has a batch to flush, lane i stores the batch's i-th word into that lane's pending slot n_pend + i.
+    if (!REC) {
+      uint64_t need = __ballot(step && fl_cnt != 0);
+      bool spilled = false;
+      while (need) {
+        const int src = __builtin_ctzll(need);
+        need &= need - 1;
+        const uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)fl_cnt, src);
+        const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)fl_off, src);
+        const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)n_pend, src);
+        for (uint32_t i = lane; i < cnt; i += 64) {
+          const uint32_t slot = base + i;
+          if (slot >= PMAX) break;
+          const uint32_t sw = s_bsend[off + i];
+          if (slot < PEND_HOT) (mem.pend - lane + src)[slot * 64] = sw;
+          else { (mem.spill - lane + src)[(size_t)(slot - PEND_HOT) * mem.spill_stride] = sw; spilled = true; }
         }
       }
-
+      if (__ballot(spilled) != 0) __threadfence_block();        // another lane's spill slots were written
+      if (step && fl_cnt != 0) {
+        if (n_pend + fl_cnt > PMAX) { flags |= DEMI_V_PENDING_OVF; n_pend = PMAX; }
+        else n_pend += fl_cnt;
+        fl_cnt = 0;
+      }
+    }
+    if (step) {
+      if (REC) {
+        for (uint32_t i = inj_lo; i < inj_hi; i++) {
+          const uint32_t sw = s_sendw[i];
+          if (sw != 0) {
+            const uint32_t id = next_id; next_id++;
+            PEND_APPEND(sw, id, false);
+            REC_PUSH(DEMI_REC_MSG_SEND, DEMI_DEADLETTERS, w_dst(sw), w_type(sw), w_p0(sw), w_p1(sw), 1, i, id);
+          }
+        }
+        inj_lo = inj_hi;
+      }
+      // ... then timers: internal messages from deadLetters, dropped when the receiver is
+      // inaccessible (crosses_partition(deadLetters, rcv), :287-297)
+      for (uint32_t k = 0; k < n_tq; k++) {
+        const uint32_t bt = (uint32_t)(tq >> (8 * k)) & 0xFF, rcv = bt >> 5, type = bt & 31;
+        const uint32_t id = next_id; if (REC) next_id++;
+        const bool drop = (net.inaccessible >> rcv) & 1;
+        if (!drop) PEND_APPEND(msg_word(type, DEMI_DEADLETTERS, rcv, 0, 0), id, true);
+        REC_PUSH(DEMI_REC_MSG_SEND, DEMI_DEADLETTERS, rcv, type, 0, 0, 2 | (drop ? 4 : 0), 255, id);
+      }
+      tq = 0; n_tq = 0;
+      if ((flags & DEMI_OVF_ANY) || n_pend == 0) none = true;
+    }
+    PH_MARK(3);
+    if (disp) {
       if (!none) {
         // FullyRandom.removeRandomElement -> RandomizedHashSet: nextInt(arr.length), swap with last
         const uint32_t idx = jr_next_int(rng, n_pend, t.magic);
@@ -352,11 +404,11 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k1_random_explore(const K1Args 
       }
     }
 
-    PH_MARK(2);
+    PH_MARK(4);
     // ------------------------------------------------------------ the receiver's handler rows
     uint32_t nfx = 0;
     if (deliver) nfx = DEMI_VM_RUN(t, mem, w, flags);
-    PH_MARK(3);
+    PH_MARK(5);
 #ifdef DEMI_K1_PHASES
     ph_iters++; ph_active += __popcll(__ballot(deliver));
 #endif
@@ -368,6 +420,7 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k1_random_explore(const K1Args 
         const uint32_t fx = mem.fxq[k * 64];
         const uint32_t op = fx & 31u, type = (fx >> 5) & 31u, target = (fx >> 10) & 15u, p0 = (fx >> 14) & 0xFFu,
                        p1 = (fx >> 22) & 0xFFu;
+        PH_MARK(9);
         if (op <= DEMI_OP_BCAST) {
           // event_produced for internal messages (:287-297): dropped at send time when
           // crosses_partition, else appended to the pending set
@@ -397,6 +450,7 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k1_random_explore(const K1Args 
               PEND_APPEND(base | (r << 5), 0u, false);
             }
           }
+          PH_MARK(6);
         } else if (op == DEMI_OP_TCANCEL) {
           // cancelTimer (Instrumenter.scala:159-168) -> notify_timer_cancel (:525-534)
           rep &= ~TIMER_BIT(me, type);
@@ -421,6 +475,7 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k1_random_explore(const K1Args 
             for (uint32_t q = 64; !gone && q < n_pend; q++)
               if (pend_load(mem, q) == wantw) { pend_remove(q); gone = true; }
           }
+          PH_MARK(7);
         } else {
           // TSET / TREP: registerCancellable + handleTick (Instrumenter.scala:1145-1200)
           const uint32_t bit = TIMER_BIT(me, type);
@@ -428,12 +483,13 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k1_random_explore(const K1Args 
             if (op == DEMI_OP_TREP) rep |= bit;
             enqueue_timer(me, type);
           }
+          PH_MARK(8);
         }
       }
       if (flags & DEMI_OVF_ANY) ph = PH_FINISH;
     }
 
-    PH_MARK(4);
+    PH_MARK(9);
     // ------------------------------------------------------------ verdict
     if (ph == PH_FINISH) {
       // explore(): `if (messagesScheduledSoFar <= maxMessages) checkIfBugFound` (:256-262, 156-180)
@@ -453,13 +509,14 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k1_random_explore(const K1Args 
       n_pend = 0; count = 0; cnt_mod = 0; tidx = 0; inj_lo = 0; inj_hi = 0; batch_no = 0;
       tq = 0; resend = 0; n_tq = 0; n_resend = 0; just = 0; rep = 0; viol = 0; flags = 0; hash = 0; tmask = 0;
     }
+    PH_MARK(10);
   }
 #ifdef DEMI_K1_PHASES
-  PH_MARK(5);
+  PH_MARK(11);
   if (lane == 0 && args.phase_out) {
-    unsigned long long* o = args.phase_out + ((size_t)blockIdx.x * K1_WAVES + wave) * 8;
-    for (int i = 0; i < 6; i++) o[i] = ph_t[i];
-    o[6] = ph_iters; o[7] = ph_active;
+    unsigned long long* o = args.phase_out + ((size_t)blockIdx.x * K1_WAVES + wave) * 16;
+    for (int i = 0; i < 12; i++) o[i] = ph_t[i];
+    o[14] = ph_iters; o[15] = ph_active;
   }
 #endif
 #undef PH_MARK

@@ -1,9 +1,11 @@
 #!/bin/bash
-# Diagnostic: build a -DDEMI_K1_PHASES copy of the library, run the bench workload once, print the
-# per-phase cycle split of K1 (s_memtime deltas summed over waves).  Does not touch the product .so.
+# Diagnostic: build a -DDEMI_K1_PHASES copy of the library, run the bench workload once with the specialised
+# kernel and once with the table interpreter, print the per-phase cycle split of K1 (s_memtime deltas summed
+# over waves).  Does not touch the product .so.
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 cp demi_amd/libdemi_gpu.so /tmp/libdemi_gpu.so.keep
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -pthread -DDEMI_K1_PHASES -o demi_amd/libdemi_gpu.so demi_amd/csrc/demi_gpu.hip
-python bench.py --steps 2 --warmup 1 --no-cpu-baseline ${BENCH_ARGS} 2>&1 | grep -E "k1 phases|value" | cut -c1-400
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -pthread -ldl -DDEMI_K1_PHASES -o demi_amd/libdemi_gpu.so demi_amd/csrc/demi_gpu.hip
+python bench.py --steps 2 --warmup 1 --no-cpu-baseline ${BENCH_ARGS} 2>&1 | grep -E "k1 phases|value" | tail -2 | cut -c1-700
+python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-specialize ${BENCH_ARGS} 2>&1 | grep -E "k1 phases|value" | tail -2 | cut -c1-700
 cp /tmp/libdemi_gpu.so.keep demi_amd/libdemi_gpu.so
