@@ -84,8 +84,11 @@ class RandomScheduler:
 
     def __init__(self, schedulerConfig: SchedulerConfig, max_executions: int = 1,
                  invariant_check_interval: int = 0, randomizationStrategy: Optional[FullyRandom] = None,
-                 seed_base: Optional[int] = None, device: int = 0, p_max: int = 64):
+                 seed_base: Optional[int] = None, device: int = 0, p_max: int = 64, specialize: Optional[bool] = None):
+        """specialize: compile the model's transition table to native code before exploring (demi_model_specialize,
+        about a second); None = only when max_executions is large enough to amortise it."""
         self.schedulerConfig = schedulerConfig
+        self.specialize = (max_executions >= (1 << 18)) if specialize is None else specialize
         self.max_executions = max_executions
         self.invariant_check_interval = invariant_check_interval
         self.seed_base = seed_base if seed_base is not None else (randomizationStrategy or FullyRandom()).seed
@@ -123,6 +126,11 @@ class RandomScheduler:
             self._ctx.model_load(self._model.to_struct())
             self._loaded_model = True
             self._loaded_trace = None
+            if self.specialize:
+                try:
+                    self._ctx.model_specialize()
+                except _native.DemiError:
+                    pass                     # no run-time compiler here: the table interpreter is used
         ev = np.ascontiguousarray(trace, dtype=T.EXT_EVENT_DTYPE)
         key = ev.tobytes()
         if self._loaded_trace != key:
