@@ -19,6 +19,10 @@
 
 #include "sim_core.hpp"
 
+#ifndef DEMI_VM_RUN   // the table interpreter, unless a specialised build supplies the compiled handlers (jit.hpp)
+#define DEMI_VM_RUN vm_run
+#endif
+
 namespace demi {
 
 // expected event, 8 bytes: kind | a<<8 | b<<16 | type<<24 | p0<<32 | p1<<40 | ext<<48 | flags<<56
@@ -195,7 +199,7 @@ __global__ __launch_bounds__(K2_WAVES * 64) void k2_replay(const K2Args args) {
     }
 
     uint32_t nfx = 0;
-    if (deliver) nfx = vm_run(t, mem, w, flags);
+    if (deliver) nfx = DEMI_VM_RUN(t, mem, w, flags);
 
     if (deliver) {
       const uint32_t me = w_dst(w);

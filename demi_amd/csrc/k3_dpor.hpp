@@ -24,6 +24,10 @@
 
 #include "sim_core.hpp"
 
+#ifndef DEMI_VM_RUN   // the table interpreter, unless a specialised build supplies the compiled handlers (jit.hpp)
+#define DEMI_VM_RUN vm_run
+#endif
+
 namespace demi {
 
 constexpr uint64_t DPOR_ROOT_KEY = 0xCBF29CE484222325ULL;
@@ -339,7 +343,7 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
     }
 
     uint32_t nfx = 0;
-    if (deliver) nfx = vm_run(t, mem, w, flags);
+    if (deliver) nfx = DEMI_VM_RUN(t, mem, w, flags);
     if (deliver) {
       const uint32_t me = w_dst(w);
       for (uint32_t k = 0; k < nfx && !(flags & DEMI_OVF_ANY); k++) {

@@ -63,7 +63,8 @@ class DPORwHeuristics:
 
     def __init__(self, schedulerConfig: SchedulerConfig, depth_bound: Optional[int] = None,
                  stopIfViolationFound: bool = True, trackHistory: bool = True, batch: int = 256,
-                 max_pairs: int = 4096, p_max: int = 64, device: int = 0, backend: Optional[Callable] = None):
+                 max_pairs: int = 4096, p_max: int = 64, device: int = 0, backend: Optional[Callable] = None,
+                 specialize: bool = False):
         if schedulerConfig.model is None or schedulerConfig.model.inv_kind == T.INV_NONE:
             raise ValueError("Must invoke setInvariant before test()")
         self.schedulerConfig = schedulerConfig
@@ -75,6 +76,7 @@ class DPORwHeuristics:
         self.p_max = p_max
         self.max_messages = 0
         self._backend = backend          # tests inject the CPU oracle here
+        self.specialize = specialize     # compile the model's table to native code first (pays off on long explorations)
         self._device = device
         self._ctx = None
         self.backTrack: list = []        # heap of (-branch, seq, (later key, earlier key), trace, later, earlier)
@@ -106,6 +108,8 @@ class DPORwHeuristics:
                 from . import _native
                 self._ctx = _native.Context(self._device)
                 self._ctx.model_load(self.schedulerConfig.model.to_struct())
+                if self.specialize:
+                    self._ctx.model_specialize()
                 self._ctx.dpor_load(externals)
             fn = lambda part: self._ctx.dpor_batch(part, params)
         return sharded_batch(prefixes, fn)
@@ -188,6 +192,8 @@ class DPORwHeuristics:
         if self._ctx is None:
             self._ctx = _native.Context(self._device)
             self._ctx.model_load(self.schedulerConfig.model.to_struct())
+            if self.specialize:
+                self._ctx.model_specialize()
             self._ctx.dpor_load(externals)
         search = T.DporSearch(self.batch, max_interleavings, 1 if self.stopIfViolationFound else 0,
                               1 if self.trackHistory else 0)

@@ -250,3 +250,29 @@ def test_minimize_internals_end_to_end(gpu_ctx, oracle, strategy):
     v = gpu_ctx.replay_removal_batch([NO_SKIP], T.Limits(0, 0, 64, 1, fp.code, 0))[0]
     assert v["flags"] & T.V_VIOLATION and not v["flags"] & T.V_DIVERGED
     assert T.verdict_deliveries(int(v["flags"])) == IM.countMsgEvents(out)
+
+
+def test_specialised_replay_kernel_is_bit_identical(gpu_ctx, oracle):
+    """K2 compiled for the model's table (demi_model_specialize, compiled at the first replay launch) against the
+    table interpreter and the oracle: subsequence masks, removal candidates, executed-trace marks."""
+    from demi_amd.internal_minimization import deliveries
+    rng = np.random.default_rng(21)
+    for cfg in (raft5_config2, raft5_config4):
+        model, events, lim = cfg()
+        vv, rec, used = record(gpu_ctx, model, events, lim)
+        gpu_ctx.replay_load(used, rec)
+        masks = random_masks(rng, len(used), 4000)
+        dl = np.array([i for i, _, _ in deliveries(EventTrace(rec, used))] + [NO_SKIP], dtype=np.uint32)
+        sk = rng.choice(dl, size=4000)
+        target = T.Limits(0, 0, 64, 1, vv.fingerprint, 0)
+        plain = gpu_ctx.replay_batch(masks, target)
+        rem = gpu_ctx.replay_removal_batch(sk, target, masks=masks)
+        kept = [gpu_ctx.replay_get_kept(len(rec), int(sk[i]), target, mask=masks[i])[1] for i in range(0, 4000, 401)]
+        gpu_ctx.model_specialize()
+        assert gpu_ctx.is_specialized()
+        assert_same(gpu_ctx.replay_batch(masks, target), plain)
+        assert_same(gpu_ctx.replay_removal_batch(sk, target, masks=masks), rem)
+        for j, i in enumerate(range(0, 4000, 401)):
+            assert (gpu_ctx.replay_get_kept(len(rec), int(sk[i]), target, mask=masks[i])[1] == kept[j]).all()
+        gpu_ctx.model_specialize(False)
+        assert_same(plain, oracle.sts_replay_batch(model, used, rec, masks, target, n_threads=os.cpu_count()))

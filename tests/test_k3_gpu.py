@@ -56,6 +56,11 @@ def test_per_interleaving_outputs_match_the_oracle(gpu_ctx, oracle, cfg):
         g = gpu_ctx.dpor_batch(prefixes, par)
         c = oracle.dpor_batch(model, ev, prefixes, par)
         same_batch(g, c)
+    # the kernel compiled for this model's table (demi_model_specialize; K3 is compiled at its first launch)
+    gpu_ctx.model_specialize()
+    for par in (T.DporParams(30, 0, 0, 0, 64, 4096), T.DporParams(30, 40, 0, 0, 64, 64)):
+        same_batch(gpu_ctx.dpor_batch(prefixes, par), oracle.dpor_batch(model, ev, prefixes, par))
+    gpu_ctx.model_specialize(False)
     # capacity verdicts appear and agree
     tiny = gpu_ctx.dpor_batch(prefixes[:64], T.DporParams(30, 0, 0, 0, 3, 4096))[0]
     assert (tiny["flags"] & T.V_PENDING_OVF).any()
@@ -125,3 +130,17 @@ def test_native_exploration_loop_equals_the_python_loop(batch, budget):
     assert len(rn.interleavings) == len(rp.interleavings)
     assert all(a.verdict == b.verdict and a.prefix_len == b.prefix_len for a, b in zip(rn.interleavings, rp.interleavings))
     dp.shutdown(); dn.shutdown()
+
+
+def test_specialised_native_exploration_is_the_same_exploration():
+    model, ev, depth = raft5_config3(n_sends=3)
+    runs = []
+    for spec in (False, True):
+        d = DPORwHeuristics(SchedulerConfig(model=model), depth_bound=depth, stopIfViolationFound=False, batch=512, specialize=spec)
+        r = d.explore_native(ev, max_interleavings=5000)
+        assert d._ctx.is_specialized() == spec
+        runs.append(r)
+        d.shutdown()
+    a, b = runs
+    assert a.rounds == b.rounds and a.exhausted == b.exhausted and len(a.interleavings) == len(b.interleavings)
+    assert all(x.verdict == y.verdict and x.prefix_len == y.prefix_len for x, y in zip(a.interleavings, b.interleavings))

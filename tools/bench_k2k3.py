@@ -36,6 +36,12 @@ for n in (1024, 65536, 1 << 20):
     ctx.replay_batch(masks[:64], target)
     t = time.perf_counter(); r = ctx.replay_batch(masks, target); dt = time.perf_counter() - t
     out["k2_replays_per_s_n%d" % n] = n / dt
+ctx.model_specialize()
+ctx.replay_batch(masks[:64], target)          # compiles K2 for this table
+t = time.perf_counter(); rj = ctx.replay_batch(masks, target); dt = time.perf_counter() - t
+out["k2_replays_per_s_n%d_specialised" % n] = n / dt
+out["k2_specialised_bit_identical"] = bool((rj == r).all())
+ctx.model_specialize(False)
 # CPU baseline beside it: the oracle's STSSched restatement on the host cores, same candidates (bounded sample)
 from oracle import oracle_py as O  # noqa: E402
 cores = os.cpu_count() or 1
@@ -82,6 +88,13 @@ for nb in (2048, 16384):
                                           "distinct_schedules": len(rn.schedule_hashes())}
     dn.shutdown()
 out["k3_native_loop_interleavings_per_s"] = out["k3_native_loop_batch2048"]["interleavings_per_s"]
+# the same exploration with the kernel compiled for the model's table (compilation outside the timing)
+dn = DPORwHeuristics(SchedulerConfig(model=model3), depth_bound=depth, stopIfViolationFound=False, batch=16384, specialize=True)
+dn.explore_native(ev3, max_interleavings=64)
+t = time.perf_counter(); rn = dn.explore_native(ev3, max_interleavings=1 << 17); dt = time.perf_counter() - t
+out["k3_native_loop_batch16384_specialised"] = {"interleavings_per_s": len(rn.interleavings) / dt, "interleavings": len(rn.interleavings),
+                                                "seconds": dt}
+dn.shutdown()
 pref = [il.trace[:max(1, il.prefix_len)] for il in res.interleavings[:8192]]
 par = T.DporParams(depth, 0, 0, 0, 64, 4096)
 d._ctx.dpor_batch(pref[:64], par)
