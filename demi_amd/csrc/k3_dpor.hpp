@@ -44,7 +44,7 @@ struct K3Args {
   const uint32_t* prefix_len;        // [n]
   uint32_t stride;
   uint64_t n;
-  uint32_t depth_bound, max_messages, looking_for_valid, looking_for, p_max, max_pairs;
+  uint32_t depth_bound, max_messages, looking_for_valid, looking_for, p_max, max_pairs, prioritize;
   demi_verdict* out;
   demi_dpor_trace_entry* traces;     // [n][DEMI_DPOR_MAX_TRACE]
   uint32_t* trace_len;               // [n]
@@ -269,9 +269,11 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
         count++;                                         // messagesScheduledSoFar += 1 (:583)
         if (count > max_messages) none = true;           // (:584-586)
         if (!none && !awaiting) {
-          // getMatchingMessage: skip root / id-0 heads (:363-372), then match the head by identity
-          while (pfx < pfx_len && pf[pfx].kind == 0) pfx++;
-          if (pfx < pfx_len) {
+          // getMatchingMessage: skip root / id-0 heads (:363-372), then match the head by identity; with
+          // prioritizePendingUponDivergence keep popping heads until one is pending (getNextMatchingMessage :537-550)
+          do {
+            while (pfx < pfx_len && pf[pfx].kind == 0) pfx++;
+            if (pfx >= pfx_len) break;
             const demi_dpor_trace_entry want = pf[pfx];
             pfx++;
             if (want.kind == 2) {
@@ -285,7 +287,7 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
                 if (key == want.key && (aux >> 16) < best_seq) { best_seq = aux >> 16; chosen = (int)k; }
               }
             }
-          }
+          } while (args.prioritize && chosen < 0 && !chose_marker);
         }
         if (!none && chosen < 0 && !chose_marker) {
           // getPendingEvent (:452-472), iteration order pinned: (snd, rcv) ascending, FIFO inside

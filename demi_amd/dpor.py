@@ -58,13 +58,72 @@ class ExploredTacker:
         return pair in self._any
 
 
+class DefaultBacktrackOrdering:
+    """BacktrackOrdering.scala:58-69: deeper branch first; no notion of distance."""
+
+    def init(self, sched, originalTrace):
+        pass
+
+    def priority(self, trace: np.ndarray, branch: int, later: int, earlier: int) -> Tuple[int, ...]:
+        return (branch,)                       # compared as a tuple, larger = dequeued first
+
+    def getDistance(self, priority: Tuple[int, ...]) -> int:
+        return 0
+
+
+class StopImmediatelyOrdering(DefaultBacktrackOrdering):
+    """BacktrackOrdering.scala:71-81: combine with setMaxDistance(0)."""
+
+    def getDistance(self, priority):
+        return 0x7FFFFFFF
+
+
+class ArvindDistanceOrdering:
+    """BacktrackOrdering.scala:99-173.  Distance of a backtrack point from the original execution: events of its
+    path that the original did not contain, plus misordered pairs among those it did.  The path is the one the
+    reference builds (:117-123): the causal chain root..later, the events to replay, then (later, earlier).
+    Higher distance compares greater, i.e. is dequeued FIRST, ties by depth (:155-165) — and getNext() stops as soon
+    as the head's distance reaches the cap (DPORwHeuristics.scala:1145-1146)."""
+
+    def __init__(self):
+        self.originalIndices: Dict[int, int] = {}
+
+    def init(self, sched, originalTrace: np.ndarray):
+        self.originalIndices = {int(k): i for i, k in enumerate(np.asarray(originalTrace)["key"].tolist())}
+
+    def arvindDistance(self, trace: np.ndarray, branch: int, later: int, earlier: int) -> int:
+        keys = trace["key"].tolist()
+        parent = trace["parent"].tolist()
+        chain = [later]                                     # getCommonPrefix(later, later): root .. later
+        while chain[-1] != 0:
+            chain.append(parent[chain[-1]])
+        path = [keys[i] for i in reversed(chain)]
+        path += [keys[i] for i in range(branch + 1, later + 1) if i != earlier]      # needToReplay (:1054-1057)
+        path += [keys[later], keys[earlier]]
+        idx = np.array([self.originalIndices.get(k, -1) for k in path], dtype=np.int64)
+        present = idx >= 0
+        distance = int((~present).sum())
+        pi = idx[present]
+        if len(pi) > 1:
+            distance += int(np.triu(pi[:, None] > pi[None, :], 1).sum())    # pred before e with a larger original index
+        return distance
+
+    def priority(self, trace, branch, later, earlier):
+        return (self.arvindDistance(trace, branch, later, earlier), branch)
+
+    def getDistance(self, priority):
+        return priority[0]
+
+
 class DPORwHeuristics:
-    """DPORwHeuristics(schedulerConfig, depth_bound=..., stopIfViolationFound=..., trackHistory=...)."""
+    """DPORwHeuristics(schedulerConfig, prioritizePendingUponDivergence=..., backtrackHeuristic=..., depth_bound=...,
+    stopIfViolationFound=..., startFromBackTrackPoints=..., trackHistory=...) (DPORwHeuristics.scala:63-90)."""
 
     def __init__(self, schedulerConfig: SchedulerConfig, depth_bound: Optional[int] = None,
                  stopIfViolationFound: bool = True, trackHistory: bool = True, batch: int = 256,
                  max_pairs: int = 4096, p_max: int = 64, device: int = 0, backend: Optional[Callable] = None,
-                 specialize: bool = False):
+                 specialize: bool = False, prioritizePendingUponDivergence: bool = False, backtrackHeuristic=None,
+                 startFromBackTrackPoints: bool = True):
         if schedulerConfig.model is None or schedulerConfig.model.inv_kind == T.INV_NONE:
             raise ValueError("Must invoke setInvariant before test()")
         self.schedulerConfig = schedulerConfig
@@ -79,7 +138,17 @@ class DPORwHeuristics:
         self.specialize = specialize     # compile the model's table to native code first (pays off on long explorations)
         self._device = device
         self._ctx = None
-        self.backTrack: list = []        # heap of (-branch, seq, (later key, earlier key), trace, later, earlier)
+        self.prioritizePendingUponDivergence = prioritizePendingUponDivergence
+        self.backtrackHeuristic = backtrackHeuristic or DefaultBacktrackOrdering()
+        self.startFromBackTrackPoints = startFromBackTrackPoints
+        self.should_cap_distance = False
+        self.stop_at_distance = 0
+        self._initialTrace: Optional[np.ndarray] = None
+        self._started = False            # test()/explore() has run before on this instance (ResumableDPOR)
+        # dropping a point whose flipped pair is already explored when it is CREATED is only the same exploration
+        # if nothing looks at the queue's head before popping: not with a distance cap or a custom ordering
+        self._early_drop = backtrackHeuristic is None
+        self.backTrack: list = []        # heap of (negated priority..., seq, (later key, earlier key), trace, later, earlier)
         self._seq = 0
         self.exploredTracker = ExploredTacker()
         self.interleavingCounter = 0
@@ -94,10 +163,21 @@ class DPORwHeuristics:
     def setDepthBound(self, d: int):
         self.depth_bound = d
 
+    def setMaxDistance(self, _stop_at_distance: int):
+        """:131-134: getNext() gives up once the head of the queue is at least this far from the original."""
+        self.should_cap_distance = True
+        self.stop_at_distance = _stop_at_distance
+        self._early_drop = False
+
+    def setInitialTrace(self, t: np.ndarray):
+        """:211-213: the first interleaving replays this trace (DPOR_TRACE_DTYPE: key, word, kind)."""
+        self._initialTrace = np.ascontiguousarray(t, dtype=T.DPOR_TRACE_DTYPE)
+
     # -- one launch
     def _params(self, lookingFor: Optional[ViolationFingerprint]) -> T.DporParams:
         return T.DporParams(self.depth_bound or 0, self.max_messages, 1 if lookingFor is not None else 0,
-                            lookingFor.code if lookingFor is not None else 0, self.p_max, self.max_pairs)
+                            lookingFor.code if lookingFor is not None else 0, self.p_max, self.max_pairs,
+                            1 if self.prioritizePendingUponDivergence else 0)
 
     def _run(self, externals, prefixes, params):
         from .distributed import sharded_batch
@@ -114,13 +194,16 @@ class DPORwHeuristics:
             fn = lambda part: self._ctx.dpor_batch(part, params)
         return sharded_batch(prefixes, fn)
 
-    # -- getNext (:1142-1162): pop the deepest unexplored backtrack point
+    # -- getNext (:1142-1162): pop the highest-priority unexplored backtrack point
     def _get_next(self):
         while self.backTrack:
-            neg_branch, _, pair, trace, later, earlier = heapq.heappop(self.backTrack)
+            head = self.backTrack[0]
+            if self.should_cap_distance and self.backtrackHeuristic.getDistance(tuple(-x for x in head[0])) >= self.stop_at_distance:
+                return None                                  # "Tutto finito!" (:1144-1150); the queue is kept
+            neg_prio, _, pair, trace, later, earlier = heapq.heappop(self.backTrack)
             if self.trackHistory and pair in self.exploredTracker._any:
                 continue
-            branch = -neg_branch
+            branch = -neg_prio[-1]
             if self.trackHistory:
                 self.exploredTracker.setExplored(branch, pair)
             # next trace = trace.take(branch + 1) ++ needToReplay (:1054-1057, 1180), built on demand
@@ -142,11 +225,12 @@ class DPORwHeuristics:
             if self.trackHistory:
                 stack.setdefault(branch, set()).add((ke, kl))        # setExplored(branchI, (earlier, later)) (:1068-1070)
                 explored.add((ke, kl))
-                if (kl, ke) in explored:
+                if self._early_drop and (kl, ke) in explored:
                     # getNext would skip this point when it is popped (:1153-1157): isExplored only ever grows,
                     # so dropping it now is the same exploration with a shorter queue
                     continue
-            push(self.backTrack, (-branch, self._seq, (kl, ke), trace, later, earlier))
+            prio = self.backtrackHeuristic.priority(trace, branch, later, earlier)
+            push(self.backTrack, (tuple(-x for x in prio), self._seq, (kl, ke), trace, later, earlier))
             self._seq += 1
 
     def explore(self, externals, lookingFor: Optional[ViolationFingerprint] = None,
@@ -154,7 +238,15 @@ class DPORwHeuristics:
         externals = np.ascontiguousarray(externals, dtype=T.EXT_EVENT_DTYPE)
         params = self._params(lookingFor)
         res = Exploration()
-        frontier = [np.zeros(0, dtype=T.DPOR_TRACE_DTYPE)]            # first run: nextTrace is empty
+        if self._started and self.startFromBackTrackPoints and self.backTrack:
+            # test() again on the same instance (ResumableDPOR): continue from the backtrack queue (:1219-1220)
+            nxt = self._get_next()
+            frontier = [nxt] if nxt is not None else []
+        elif self._initialTrace is not None:
+            frontier = [self._initialTrace]                           # setInitialTrace (:1220-1221)
+        else:
+            frontier = [np.zeros(0, dtype=T.DPOR_TRACE_DTYPE)]        # first run: nextTrace is empty
+        self._started = True
         while frontier:
             verdicts, traces, pairs = self._run(externals, frontier, params)
             res.rounds.append(len(frontier))
@@ -188,6 +280,10 @@ class DPORwHeuristics:
         libdemi_gpu.so (demi_dpor_explore): identical rounds, verdicts and prefix lengths, two orders of
         magnitude less host time per interleaving than this Python loop.  Single rank only."""
         from . import _native
+        if not isinstance(self.backtrackHeuristic, DefaultBacktrackOrdering) or self.should_cap_distance or \
+                self._initialTrace is not None:
+            raise NotImplementedError("demi_dpor_explore implements DefaultBacktrackOrdering without a distance cap; "
+                                      "use explore() for ArvindDistanceOrdering / setMaxDistance / setInitialTrace")
         externals = np.ascontiguousarray(externals, dtype=T.EXT_EVENT_DTYPE)
         if self._ctx is None:
             self._ctx = _native.Context(self._device)

@@ -85,7 +85,8 @@ class RecEvent(C.Structure):
 
 class DporParams(C.Structure):
     _fields_ = [("depth_bound", C.c_uint32), ("max_messages", C.c_uint32), ("looking_for_valid", C.c_uint32),
-                ("looking_for", C.c_uint32), ("p_max", C.c_uint32), ("max_pairs", C.c_uint32)]
+                ("looking_for", C.c_uint32), ("p_max", C.c_uint32), ("max_pairs", C.c_uint32),
+                ("prioritize_pending", C.c_uint32)]
 
 
 class DporSearch(C.Structure):

@@ -268,6 +268,8 @@ typedef struct {
   uint32_t looking_for;
   uint32_t p_max;              /* pending capacity, 1..128 (0 = 64) */
   uint32_t max_pairs;          /* capacity of the racing-pair list per interleaving */
+  uint32_t prioritize_pending; /* prioritizePendingUponDivergence (:65-68, 537-550, 594-597): when the expected head of
+                                  nextTrace is not pending, keep popping heads until one is, before diverging */
 } demi_dpor_params;
 
 typedef struct {

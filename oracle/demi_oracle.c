@@ -1091,15 +1091,18 @@ int orc_dpor_execute(const demi_model* m, const demi_ext_event* ext, uint32_t n_
     if (x->count > max_messages) none = 1;            /* (:584-586) */
     if (!none && !x->awaiting) {
       /* getMatchingMessage: pop nextTrace heads that are root / id 0 (:363-372), then look the head up */
-      while (pfx < prefix_len && prefix[pfx] == DPOR_ROOT_KEY) pfx++;
-      if (pfx < prefix_len) {
+      /* prioritizePendingUponDivergence: getNextMatchingMessage keeps popping heads until one is pending
+       * (:537-550); otherwise exactly one head is tried (:594-597) */
+      do {
+        while (pfx < prefix_len && prefix[pfx] == DPOR_ROOT_KEY) pfx++;
+        if (pfx >= prefix_len) break;
         uint64_t want = prefix[pfx++];
         if (x->marker_pending && want == DPOR_MARKER_KEY(x->marker_ext)) chose_marker = 1;
         else {
           for (uint32_t k = 0; k < x->n_pend; k++)
             if (dpor_key_of(x, &x->pend[k]) == want && (chosen < 0 || x->pend[k].seq < x->pend[chosen].seq)) chosen = (int)k;
         }
-      }
+      } while (par->prioritize_pending && chosen < 0 && !chose_marker);
     }
     if (!none && chosen < 0 && !chose_marker) {
       /* divergent / first run / awaiting quiescence: getPendingEvent (:452-472), pinned order */

@@ -1,0 +1,139 @@
+"""CPU suite, part 7: DDMin over DPOR with a growing edit-distance bound (IncrementalDDMin, ResumableDPOR,
+ArvindDistanceOrdering, prioritizePendingUponDivergence), with the oracle standing in for the K3 kernel."""
+import numpy as np
+import pytest
+
+from demi_amd import types as T
+from demi_amd import model as M
+from demi_amd.dpor import ArvindDistanceOrdering, DPORwHeuristics, DefaultBacktrackOrdering, StopImmediatelyOrdering
+from demi_amd.fuzzer import events_to_array, kill, partition, send, start, wait_quiescence
+from demi_amd.incremental_ddmin import (IncrementalDDMin, ResumableDPOR, convertToDPORTrace, dpor_initial_trace,
+                                        editDistanceDporDDMin)
+from demi_amd.minification import EventDagView, UnmodifiedEventDag
+from demi_amd.model import Asm, build_model
+from demi_amd.schedulers import EventTrace, SchedulerConfig, ViolationFingerprint
+
+from .test_dpor_cpu import two_writers_model
+
+
+def _execution(oracle, model, ev, want_violation=True, lim=None):
+    lim = lim or T.Limits(0, 0, 64, 0, 0, 0)
+    for seed in range(200):
+        v, rec, _ = oracle.random_execute(model, ev, seed, lim)
+        if bool(v.flags & T.V_VIOLATION) == want_violation:
+            return v, EventTrace(rec, ev)
+    raise AssertionError("no execution with the wanted outcome")
+
+
+def test_initial_trace_of_a_random_execution_replays_under_dpor(oracle):
+    """The deliveries of a RandomScheduler execution, re-identified by causal-path keys, are exactly the nodes DPOR
+    generates: replaying them as nextTrace reproduces the same delivery sequence and the same verdict hash."""
+    model = two_writers_model()
+    ev = events_to_array([start(0), start(1), start(2), send(1, 0), send(2, 0), send(1, 0)])
+    v, trace = _execution(oracle, model, ev)
+    init = dpor_initial_trace(trace)
+    assert init[0]["kind"] == 0 and int(init[0]["key"]) == T.DPOR_ROOT_KEY
+    assert len(init) == 1 + T.verdict_deliveries(v.flags)
+    out = oracle.dpor_batch(model, ev, [init], T.DporParams(0, 0, 0, 0, 64, 4096, 0))
+    dv, dt = out[0][0], out[1][0]
+    assert (dt["key"] == init["key"]).all() and (dt["word"] == init["word"]).all()
+    assert (dt["parent"] == init["parent"]).all() and (dt["depth"] == init["depth"]).all()
+    assert int(dv["hash"]) == v.hash and int(dv["fingerprint"]) == v.fingerprint
+    # raft (no repeating timer before a leader exists): same property on a longer execution
+    model = M.raft_model(3)
+    ev = events_to_array([start(a) for a in range(3)] + [send(a, M.M_BOOTSTRAP) for a in range(3)])
+    v, trace = _execution(oracle, model, ev, want_violation=False, lim=T.Limits(12, 0, 64, 0, 0, 0))
+    init = dpor_initial_trace(trace)
+    dt = oracle.dpor_batch(model, ev, [init], T.DporParams(0, len(init), 0, 0, 64, 4096, 0))[1][0]
+    n = min(len(dt), len(init))
+    assert n >= 8 and (dt["key"][:8] == init["key"][:8]).all()
+
+
+def test_prioritize_pending_upon_divergence(oracle):
+    """Expected heads that are not pending are popped until one is (getNextMatchingMessage); without the option
+    only one head is tried and the scheduler then diverges to the first pending message."""
+    model = two_writers_model()
+    ev = events_to_array([start(0), start(1), start(2), send(1, 0), send(2, 0)])
+    base = oracle.dpor_batch(model, ev, [np.zeros(0, dtype=T.DPOR_TRACE_DTYPE)], T.DporParams(0, 0, 0, 0, 64, 4096, 0))[1][0]
+    deliveries = base[base["kind"] == 1]
+    go2 = deliveries[[int(w) >> 5 & 7 == 2 and int(w) & 31 == 0 for w in deliveries["word"]]][0]
+    bogus = np.zeros(2, dtype=T.DPOR_TRACE_DTYPE)
+    bogus["kind"] = 1; bogus["key"] = [12345, 67890]; bogus["word"] = [int(go2["word"])] * 2
+    prefix = np.concatenate([base[:1], bogus, np.array([go2])])
+    with_p = oracle.dpor_batch(model, ev, [prefix], T.DporParams(0, 0, 0, 0, 64, 4096, 1))[1][0]
+    without = oracle.dpor_batch(model, ev, [prefix], T.DporParams(0, 0, 0, 0, 64, 4096, 0))[1][0]
+    assert int(with_p[1]["key"]) == int(go2["key"])                 # skipped both absent heads, then matched
+    assert int(without[1]["key"]) == int(base[1]["key"]) != int(go2["key"])   # diverged to the pinned first pending
+
+
+def test_arvind_distance_is_the_literal_path_computation():
+    def tr(rows):      # (key, parent)
+        a = np.zeros(len(rows), dtype=T.DPOR_TRACE_DTYPE)
+        a["key"] = [r[0] for r in rows]; a["parent"] = [r[1] for r in rows]; a["kind"] = [0] + [1] * (len(rows) - 1)
+        return a
+
+    orig = tr([(1, 0), (10, 0), (20, 0), (30, 1), (40, 2)])
+    h = ArvindDistanceOrdering()
+    h.init(None, orig)
+    # the original order itself: path(later=3 (key 30, parent 1), earlier=2, branch 0) = [1, 10, 30] ++ [10, 30] ++ [30, 20]
+    # inversions: (30 before 10): 1, (30,20): three 30s before the final 20 -> 3  => 4
+    assert h.arvindDistance(orig, 0, 3, 2) == 4
+    # unknown events cost 1 each and do not take part in the inversion count
+    other = tr([(1, 0), (10, 0), (99, 0), (30, 1)])
+    assert h.arvindDistance(other, 0, 3, 2) == h.arvindDistance(tr([(1, 0), (10, 0), (20, 0), (30, 1)]), 0, 3, 2) + 1 - 3
+    assert h.priority(orig, 0, 3, 2) == (4, 0) and h.getDistance((4, 0)) == 4
+    assert DefaultBacktrackOrdering().getDistance((7,)) == 0 and StopImmediatelyOrdering().getDistance((7,)) > 1 << 30
+
+
+def test_distance_cap_and_resumption(oracle):
+    """setMaxDistance(0) runs the initial trace only (every queued point is >= 0 away); raising the cap resumes from
+    the queue without re-running the initial trace; the farthest point is dequeued first."""
+    model = two_writers_model()
+    ev = events_to_array([start(0), start(1), start(2), send(1, 0), send(2, 0), send(1, 0)])
+    _, trace = _execution(oracle, model, ev, want_violation=False)
+    init = dpor_initial_trace(trace)
+    h = ArvindDistanceOrdering()
+    d = DPORwHeuristics(SchedulerConfig(model=model), prioritizePendingUponDivergence=True, backtrackHeuristic=h,
+                        stopIfViolationFound=False, batch=4, backend=oracle.dpor_batch)
+    d.setInitialTrace(init)
+    h.init(d, init)
+    d.setMaxDistance(0)
+    r0 = d.explore(ev)
+    assert len(r0.interleavings) == 1 and (r0.interleavings[0].trace["key"] == init["key"]).all()
+    queued = len(d.backTrack)
+    assert queued > 0 and not r0.exhausted
+    head_distance = -d.backTrack[0][0][0]
+    assert head_distance == max(-e[0][0] for e in d.backTrack)
+    d.setMaxDistance(head_distance)              # still capped: the head is exactly at the bound
+    assert len(d.explore(ev).interleavings) == 0
+    d.setMaxDistance(1 << 20)
+    r2 = d.explore(ev)
+    assert len(r2.interleavings) >= 1 and r2.interleavings[0].prefix_len > 0      # resumed, not restarted
+    assert r2.exhausted
+
+
+def test_convert_to_dpor_trace_drops_faults():
+    ev = events_to_array([start(0), kill(0), start(0), send(0, 0), partition(0, 1), wait_quiescence(), send(0, 0)])
+    assert [int(k) for k in convertToDPORTrace(ev)["kind"]] == [T.EV_START, T.EV_START, T.EV_SEND, T.EV_SEND]
+    assert len(convertToDPORTrace(ev, ignoreQuiescence=False)) == 5
+
+
+def test_edit_distance_dpor_ddmin_end_to_end(oracle):
+    """two writers + noise: the violation (actor 0's last writer is 1) needs Start(0), Start(1) and one Go to actor 1;
+    the second writer, the duplicate Go and the idle actor are pruned."""
+    MSGS = [("Go", T.MSG_EXTERNAL), ("Write", T.MSG_INTERNAL)]
+    hnd = {(0, "Go"): Asm().mov(M.T0, 0).send(1, M.T0, M.ME, 0),
+           (0, "Write"): Asm().mov(M.F[0], M.P0).add(M.F[1], M.F[1], 1)}
+    model = build_model("race4", 4, MSGS, hnd, [[0] * 8] * 4, (T.INV_NEVER, 0, 1, 0))
+    ev = events_to_array([start(0), start(1), start(2), start(3), send(2, 0), send(1, 0), send(3, 0), send(2, 0)])
+    v, trace = _execution(oracle, model, ev)
+    fp = ViolationFingerprint(v.fingerprint)
+    mcs, ddmin, verified, _ = editDistanceDporDDMin(SchedulerConfig(model=model), trace, fp, stopAtSize=2, maxMaxDistance=8,
+                                                    batch=8, backend=oracle.dpor_batch)
+    assert verified is not None
+    kinds = [(int(ev[i]["kind"]), int(ev[i]["a"])) for i in mcs]
+    assert (T.EV_START, 0) in kinds and (T.EV_START, 1) in kinds and (T.EV_SEND, 1) in kinds
+    assert len(mcs) < len(ev) and len(mcs) <= 4
+    assert ddmin.distances[0][0] == 0 and ddmin._stats.total_replays > 0
+    # one DPOR instance per consulted subsequence, reused across distance rounds
+    assert len(ddmin.oracle.subseqToDPOR) >= len({c for c, _ in ddmin.ddmin.consulted})

@@ -56,6 +56,21 @@ def test_per_interleaving_outputs_match_the_oracle(gpu_ctx, oracle, cfg):
         g = gpu_ctx.dpor_batch(prefixes, par)
         c = oracle.dpor_batch(model, ev, prefixes, par)
         same_batch(g, c)
+    # prioritizePendingUponDivergence: prefixes with expected heads that are never pending (keys of other prefixes'
+    # events spliced in), with and without the option
+    rng = np.random.default_rng(5)
+    noisy = []
+    for k, pfx in enumerate(prefixes[:96]):
+        other = prefixes[(k * 7 + 3) % len(prefixes)]
+        if len(pfx) < 2 or len(other) < 2:
+            noisy.append(pfx)
+            continue
+        cut = int(rng.integers(1, len(pfx)))
+        junk = other[rng.integers(1, len(other), size=int(rng.integers(1, 4)))]
+        noisy.append(np.concatenate([pfx[:cut], junk, pfx[cut:]]))
+    for prio in (0, 1):
+        par = T.DporParams(30, 0, 0, 0, 64, 4096, prio)
+        same_batch(gpu_ctx.dpor_batch(noisy, par), oracle.dpor_batch(model, ev, noisy, par))
     # the kernel compiled for this model's table (demi_model_specialize; K3 is compiled at its first launch)
     gpu_ctx.model_specialize()
     for par in (T.DporParams(30, 0, 0, 0, 64, 4096), T.DporParams(30, 40, 0, 0, 64, 64)):
@@ -144,3 +159,24 @@ def test_specialised_native_exploration_is_the_same_exploration():
     a, b = runs
     assert a.rounds == b.rounds and a.exhausted == b.exhausted and len(a.interleavings) == len(b.interleavings)
     assert all(x.verdict == y.verdict and x.prefix_len == y.prefix_len for x, y in zip(a.interleavings, b.interleavings))
+
+
+def test_edit_distance_dpor_ddmin_on_the_gpu(oracle):
+    """DDMin over DPOR with a growing edit-distance bound (IncrementalDDMin + ResumableDPOR + ArvindDistanceOrdering):
+    every oracle consultation is a bounded K3 exploration; same MCS and consultation sequence as the same host
+    logic over the CPU oracle."""
+    from demi_amd.incremental_ddmin import editDistanceDporDDMin
+    from demi_amd.schedulers import EventTrace
+    from .test_incremental_ddmin_cpu import _execution
+    model = M.raft_model(3)
+    ev = events_to_array([start(a) for a in range(3)] + [send(a, M.M_BOOTSTRAP) for a in range(3)] +
+                         [send(0, M.M_CLIENT, 1), send(1, M.M_CLIENT, 2)])
+    v, trace = _execution(oracle, model, ev, lim=T.Limits(60, 0, 64, 0, 0, 0))
+    fp = ViolationFingerprint(v.fingerprint, model.fp_match_mask)
+    runs = []
+    for backend in (None, oracle.dpor_batch):
+        mcs, ddmin, verified, _ = editDistanceDporDDMin(SchedulerConfig(model=model), trace, fp, stopAtSize=2,
+                                                        maxMaxDistance=4, batch=64, backend=backend)
+        runs.append((mcs, ddmin.ddmin.consulted, ddmin.distances, verified is not None, ddmin._stats.total_replays))
+    assert runs[0] == runs[1]
+    assert runs[0][3] and len(runs[0][0]) < len(ev)
