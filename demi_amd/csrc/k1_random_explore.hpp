@@ -58,14 +58,26 @@ constexpr uint32_t K1_BATCH_WORDS = 6;   // end index, inaccessible, killed, par
 __host__ __device__ inline size_t k1_extra_lds_bytes(uint32_t n_ev, uint32_t n_batches) {
   return (((size_t)n_batches * K1_BATCH_WORDS + 2 * (size_t)n_ev) * 4 + 15) & ~(size_t)15;
 }
-template <bool REC>
+// SrcDstFIFO (RandomScheduler.scala:702-909) keeps the actor-to-actor messages apart from the timers / externals:
+// one array in arrival order (a pair's queue is the sub-sequence with that (src, dst)); its NORM_HOT first slots in
+// LDS, the rest in the HBM spill after the timers-and-externals arrays; srcDsts as a byte list (src * 8 + dst).
+constexpr uint32_t NORM_HOT = 16;
+__host__ __device__ inline uint32_t k1_pair_words(uint32_t n_actors) { return (n_actors * n_actors + 3) / 4; }
+__host__ __device__ inline size_t k1_fifo_wave_bytes(uint32_t n_actors, bool rec) {
+  return ((size_t)NORM_HOT * (rec ? 2 : 1) + k1_pair_words(n_actors)) * 64 * 4;
+}
+// HBM scratch words per simulator lane: pending slots beyond the LDS-resident ones, every array of the variant
+__host__ __device__ inline size_t k1_spill_words_per_lane(bool rec, bool fifo) {
+  return (size_t)((DEMI_MAX_PENDING - PEND_HOT) + (fifo ? (DEMI_MAX_PENDING - NORM_HOT) : 0)) * (rec ? 2 : 1);
+}
+template <bool REC, bool FIFO>
 __host__ __device__ inline size_t k1_lds_bytes(uint32_t code_len, uint32_t n_ev, uint32_t n_hs, uint32_t n_actors,
                                                uint32_t n_batches) {
   return tables_lds_bytes(code_len, n_ev, n_hs) + k1_extra_lds_bytes(n_ev, n_batches) +
-         K1_WAVES * lane_mem_wave_bytes(n_actors, REC);
+         K1_WAVES * (lane_mem_wave_bytes(n_actors, REC) + (FIFO ? k1_fifo_wave_bytes(n_actors, REC) : 0));
 }
 
-template <bool REC>
+template <bool REC, bool FIFO = false>
 __global__ __launch_bounds__(K1_WAVES * 64) void k1_random_explore(const K1Args args) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Tables t;
@@ -106,6 +118,36 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k1_random_explore(const K1Args 
                                      (size_t)blockIdx.x * blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x);
   uint64_t* const st = mem.st;
   const uint32_t PMAX = args.p_max;
+  // SrcDstFIFO arrays of this lane (FIFO builds only)
+  uint32_t* f_norm = nullptr, *f_norm_aux = nullptr, *f_pairs = nullptr, *f_spill = nullptr, *f_spill_aux = nullptr;
+  if (FIFO) {
+    unsigned char* fb = wave_base + (size_t)K1_WAVES * lane_mem_wave_bytes(t.A, REC) + (size_t)wave * k1_fifo_wave_bytes(t.A, REC);
+    f_norm = reinterpret_cast<uint32_t*>(fb) + lane;
+    if (REC) f_norm_aux = f_norm + (size_t)NORM_HOT * 64;
+    f_pairs = f_norm + (size_t)NORM_HOT * 64 * (REC ? 2 : 1);
+    const size_t lanes = (size_t)gridDim.x * blockDim.x, gl = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    f_spill = args.spill + spill_words(lanes) * (REC ? 2 : 1) + gl;
+    if (REC) f_spill_aux = f_spill + lanes * (DEMI_MAX_PENDING - NORM_HOT);
+  }
+  const uint32_t f_stride = (uint32_t)((size_t)gridDim.x * blockDim.x);
+  auto norm_load = [&](uint32_t slot) -> uint32_t {
+    return slot < NORM_HOT ? f_norm[slot * 64] : f_spill[(size_t)(slot - NORM_HOT) * f_stride];
+  };
+  auto norm_store = [&](uint32_t slot, uint32_t v) {
+    if (slot < NORM_HOT) f_norm[slot * 64] = v; else f_spill[(size_t)(slot - NORM_HOT) * f_stride] = v;
+  };
+  auto norm_aux_load = [&](uint32_t slot) -> uint32_t {
+    return slot < NORM_HOT ? f_norm_aux[slot * 64] : f_spill_aux[(size_t)(slot - NORM_HOT) * f_stride];
+  };
+  auto norm_aux_store = [&](uint32_t slot, uint32_t v) {
+    if (slot < NORM_HOT) f_norm_aux[slot * 64] = v; else f_spill_aux[(size_t)(slot - NORM_HOT) * f_stride] = v;
+  };
+  auto pair_get = [&](uint32_t i) -> uint32_t { return (f_pairs[(i >> 2) * 64] >> (8 * (i & 3))) & 0xFFu; };
+  auto pair_set = [&](uint32_t i, uint32_t v) {
+    uint32_t* q = f_pairs + (size_t)(i >> 2) * 64;
+    const uint32_t sh = 8 * (i & 3);
+    *q = (*q & ~(0xFFu << sh)) | (v << sh);
+  };
 
   // a specialised build (jit.hpp) knows the model's constants at compile time
 #ifdef DEMI_JIT_A
@@ -123,6 +165,10 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k1_random_explore(const K1Args 
   uint64_t sched = 0, rng = 0, hash = 0;
   uint32_t n_pend = 0, count = 0, cnt_mod = 0, tidx = 0, inj_lo = 0, inj_hi = 0, batch_no = 0;
   uint32_t fl_off = 0, fl_cnt = 0;    // !REC: the injected batch's Sends as a range of s_bsend, flushed by the whole wave
+  // SrcDstFIFO: n_pend counts timersAndExternals, n_norm the actor-to-actor messages, n_pairs = srcDsts.size,
+  // pairmask bit (src * 8 + dst) = that pair has a queue; te_rng is timersAndExternals' own generator
+  uint32_t n_norm = 0, n_pairs = 0;
+  uint64_t pairmask = 0, te_rng = 0;
   Net net = {0, 0, 0};
   uint64_t tq = 0, resend = 0;        // messagesToSend timers / timersToResend: 1 byte each (rcv<<5 | type)
   uint32_t n_tq = 0, n_resend = 0;
@@ -153,12 +199,27 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k1_random_explore(const K1Args 
 // tmask: bit s = pending slot s (< 64) holds a timer message; lets TCANCEL probe only those slots
 #define PEND_APPEND(WORD, ID, IS_TIMER)                               \
   do {                                                                \
-    if (n_pend >= PMAX) { flags |= DEMI_V_PENDING_OVF; }              \
+    if (n_pend + n_norm >= PMAX) { flags |= DEMI_V_PENDING_OVF; }     \
     else {                                                            \
       pend_store(mem, n_pend, (WORD));                                \
       if (REC) aux_store(mem, n_pend, (ID));                          \
       if ((IS_TIMER) && n_pend < 64) tmask |= 1ull << n_pend;         \
       n_pend++;                                                       \
+    }                                                                 \
+  } while (0)
+
+// SrcDstFIFO.+= for an actor-to-actor message (:791-811): append to the pair's queue, creating the queue (and its
+// srcDsts entry) when the pair has none
+#define NORM_APPEND(WORD, ID)                                         \
+  do {                                                                \
+    if (n_pend + n_norm >= PMAX) { flags |= DEMI_V_PENDING_OVF; }     \
+    else {                                                            \
+      const uint32_t w_ = (WORD);                                     \
+      const uint32_t pr_ = w_src(w_) * 8 + w_dst(w_);                 \
+      norm_store(n_norm, w_);                                         \
+      if (REC) norm_aux_store(n_norm, (ID));                          \
+      if (!((pairmask >> pr_) & 1ull)) { pair_set(n_pairs, pr_); n_pairs++; pairmask |= 1ull << pr_; } \
+      n_norm++;                                                       \
     }                                                                 \
   } while (0)
 
@@ -248,6 +309,7 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k1_random_explore(const K1Args 
         // (ExternalEventInjector.scala:371-378)
         const uint64_t seed = args.seeds ? args.seeds[sched] : args.seed_base + sched;
         rng = jr_seed(seed);
+        te_rng = rng;                  // SrcDstFIFO: both generators are `new Random(seed)`
         hash = 0xCBF29CE484222325ULL;
         net.inaccessible = exists; net.killed = 0; net.partitioned = 0;
         for (uint32_t a = 0; a < A; a++) st[a * 64] = t.init[a];
@@ -323,9 +385,10 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k1_random_explore(const K1Args 
         const uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)fl_cnt, src);
         const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)fl_off, src);
         const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)n_pend, src);
+        const uint32_t other = (uint32_t)__builtin_amdgcn_readlane((int)n_norm, src);
         for (uint32_t i = lane; i < cnt; i += 64) {
           const uint32_t slot = base + i;
-          if (slot >= PMAX) break;
+          if (slot + other >= PMAX) break;
           const uint32_t sw = s_bsend[off + i];
           if (slot < PEND_HOT) (mem.pend - lane + src)[slot * 64] = sw;
           else { (mem.spill - lane + src)[(size_t)(slot - PEND_HOT) * mem.spill_stride] = sw; spilled = true; }
@@ -333,7 +396,7 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k1_random_explore(const K1Args 
       }
       if (__ballot(spilled) != 0) __threadfence_block();        // another lane's spill slots were written
       if (step && fl_cnt != 0) {
-        if (n_pend + fl_cnt > PMAX) { flags |= DEMI_V_PENDING_OVF; n_pend = PMAX; }
+        if (n_pend + n_norm + fl_cnt > PMAX) { flags |= DEMI_V_PENDING_OVF; n_pend = PMAX - n_norm; }
         else n_pend += fl_cnt;
         fl_cnt = 0;
       }
@@ -360,17 +423,52 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k1_random_explore(const K1Args 
         REC_PUSH(DEMI_REC_MSG_SEND, DEMI_DEADLETTERS, rcv, type, 0, 0, 2 | (drop ? 4 : 0), 255, id);
       }
       tq = 0; n_tq = 0;
-      if ((flags & DEMI_OVF_ANY) || n_pend == 0) none = true;
+      if ((flags & DEMI_OVF_ANY) || n_pend + n_norm == 0) none = true;
     }
     PH_MARK(3);
     if (disp) {
       if (!none) {
-        // FullyRandom.removeRandomElement -> RandomizedHashSet: nextInt(arr.length), swap with last
-        const uint32_t idx = jr_next_int(rng, n_pend, t.magic);
-        w = pend_load(mem, idx);
         uint32_t wid = 0;
-        if (REC) wid = aux_load(mem, idx);
-        pend_remove(idx);
+        bool from_te = true;
+        uint32_t idx = 0;
+        if (!FIFO) {
+          // FullyRandom.removeRandomElement -> RandomizedHashSet: nextInt(arr.length), swap with last
+          idx = jr_next_int(rng, n_pend, t.magic);
+        } else if (n_pairs == 0) {
+          // SrcDstFIFO.getNonBlockedMessage (:716-729): only timers / externals left
+          idx = jr_next_int(te_rng, n_pend, t.magic);
+        } else {
+          // (:731-759) a timer / external with probability |timersAndExternals| / |allMessages|, else a random pair's head
+          from_te = jr_next_int(rng, n_pend + n_norm, t.magic) < n_pend;
+          if (from_te) idx = jr_next_int(te_rng, n_pend, t.magic);
+        }
+        if (from_te) {
+          w = pend_load(mem, idx);
+          if (REC) wid = aux_load(mem, idx);
+          pend_remove(idx);
+        } else {
+          const uint32_t pi = jr_next_int(rng, n_pairs, t.magic);
+          const uint32_t pr = pair_get(pi);
+          uint32_t k = 0;
+          uint32_t cur = norm_load(0);
+          while (w_src(cur) * 8 + w_dst(cur) != pr) { k++; cur = norm_load(k); }      // queue.head
+          w = cur;
+          if (REC) wid = norm_aux_load(k);
+          // dequeue (:764-774): close the gap (arrival order is the FIFO order) and see whether the pair has more
+          bool more = false;
+          for (uint32_t j = k; j + 1 < n_norm; j++) {
+            const uint32_t nx = norm_load(j + 1);
+            more |= (w_src(nx) * 8 + w_dst(nx) == pr);
+            norm_store(j, nx);
+            if (REC) norm_aux_store(j, norm_aux_load(j + 1));
+          }
+          n_norm--;
+          if (!more) {                                     // srcDstToMessages -= srcDst; srcDsts.remove(idx)
+            for (uint32_t j = pi; j + 1 < n_pairs; j++) pair_set(j, pair_get(j + 1));
+            n_pairs--;
+            pairmask &= ~(1ull << pr);
+          }
+        }
         count++;
         cnt_mod++; if (cnt_mod == interval) cnt_mod = 0;
         const uint32_t type = w_type(w), me = w_dst(w);
@@ -431,7 +529,10 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k1_random_explore(const K1Args 
               if ((bc && r == me) || !((exists >> r) & 1)) continue;
               const uint32_t id = next_id; next_id++;
               const bool drop = crosses_partition(net, me, r);
-              if (!drop) PEND_APPEND(msg_word(type, me, r, p0, p1), id, false);
+              if (!drop) {
+                if (FIFO) NORM_APPEND(msg_word(type, me, r, p0, p1), id);
+                else PEND_APPEND(msg_word(type, me, r, p0, p1), id, false);
+              }
               REC_PUSH(DEMI_REC_MSG_SEND, me, r, type, p0, p1, drop ? 4 : 0, 255, id);
             }
           } else {
@@ -447,7 +548,8 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k1_random_explore(const K1Args 
             while (tm) {
               const uint32_t r = (uint32_t)__builtin_ctz(tm);
               tm &= tm - 1;
-              PEND_APPEND(base | (r << 5), 0u, false);
+              if (FIFO) NORM_APPEND(base | (r << 5), 0u);
+              else PEND_APPEND(base | (r << 5), 0u, false);
             }
           }
           PH_MARK(6);
@@ -508,6 +610,7 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k1_random_explore(const K1Args 
       ph = PH_IDLE;
       n_pend = 0; count = 0; cnt_mod = 0; tidx = 0; inj_lo = 0; inj_hi = 0; batch_no = 0;
       tq = 0; resend = 0; n_tq = 0; n_resend = 0; just = 0; rep = 0; viol = 0; flags = 0; hash = 0; tmask = 0;
+      n_norm = 0; n_pairs = 0; pairmask = 0;
     }
     PH_MARK(10);
   }
@@ -522,6 +625,7 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k1_random_explore(const K1Args 
 #undef PH_MARK
 #undef REC_PUSH
 #undef PEND_APPEND
+#undef NORM_APPEND
 #undef TIMER_BIT
 }
 

@@ -75,6 +75,14 @@ class FullyRandom:
     seed: int = 0
 
 
+@dataclass
+class SrcDstFIFO:
+    """RandomizationStrategy SrcDstFIFO (RandomScheduler.scala:702-909): per (src, dst) FIFO delivery, timers and
+    externals at random.  Both of its generators are seeded with the execution's seed (the reference uses the wall
+    clock for both)."""
+    seed: int = 0
+
+
 class RandomScheduler:
     """RandomScheduler(schedulerConfig, max_executions, invariant_check_interval, strategy).
 
@@ -92,6 +100,7 @@ class RandomScheduler:
         self.max_executions = max_executions
         self.invariant_check_interval = invariant_check_interval
         self.seed_base = seed_base if seed_base is not None else (randomizationStrategy or FullyRandom()).seed
+        self.strategy = T.STRATEGY_SRC_DST_FIFO if isinstance(randomizationStrategy, SrcDstFIFO) else T.STRATEGY_FULLY_RANDOM
         self.maxMessages = 0x7FFFFFFF            # Int.MaxValue (:54)
         self.p_max = p_max
         self.stats: Optional[MinimizationStats] = None
@@ -116,7 +125,7 @@ class RandomScheduler:
         mm = 0 if self.maxMessages >= 0x7FFFFFFF else self.maxMessages
         return T.Limits(mm, max(0, self.invariant_check_interval), self.p_max,
                         1 if lookingFor is not None else 0, lookingFor.code if lookingFor is not None else 0,
-                        1 if self.schedulerConfig.populate_all_actors else 0)
+                        1 if self.schedulerConfig.populate_all_actors else 0, self.strategy)
 
     def _prepare(self, trace):
         if self._model is None or self._model.inv_kind == T.INV_NONE:

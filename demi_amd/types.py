@@ -27,6 +27,9 @@ EV_NAMES = ["Start", "Kill", "Send", "Partition", "UnPartition", "WaitQuiescence
 # demi_msg_class
 MSG_INTERNAL, MSG_EXTERNAL, MSG_TIMER = 0, 1, 2
 
+# demi_strategy
+STRATEGY_FULLY_RANDOM, STRATEGY_SRC_DST_FIFO = 0, 1
+
 # demi_inv_kind
 INV_NONE, INV_AT_MOST_ONE, INV_NEVER, INV_AGREE = 0, 1, 2, 3
 
@@ -70,7 +73,7 @@ class ModelStruct(C.Structure):
 class Limits(C.Structure):
     _fields_ = [("max_messages", C.c_uint32), ("invariant_check_interval", C.c_uint32),
                 ("p_max", C.c_uint32), ("looking_for_valid", C.c_uint32), ("looking_for", C.c_uint32),
-                ("populate_all", C.c_uint32)]
+                ("populate_all", C.c_uint32), ("strategy", C.c_uint32)]
 
 
 class Verdict(C.Structure):

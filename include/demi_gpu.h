@@ -137,7 +137,16 @@ typedef struct {
   uint32_t looking_for_valid;         /* explore(_trace, _lookingFor) (RandomScheduler.scala:234-237) */
   uint32_t looking_for;               /* target fingerprint code */
   uint32_t populate_all;              /* setActorNamePropPairs: create all actors, not only Start()ed ones */
+  uint32_t strategy;                  /* RandomizationStrategy (RandomScheduler.scala:614-633): demi_strategy */
 } demi_limits;
+
+/* The pending-message container of RandomScheduler.
+ * FULLY_RANDOM: FullyRandom (RandomScheduler.scala:635-697), one RandomizedHashSet seeded with the execution's seed.
+ * SRC_DST_FIFO: SrcDstFIFO (:702-909): TCP-like delivery, one FIFO per (src, dst) pair of actors, an ordered list of
+ *   the pairs that currently have a queue, timers and external messages (sender deadLetters) in a FullyRandom of
+ *   their own; RandomScheduler asks it through getNonBlockedMessage (:443-449, 716-760).  The reference seeds both of
+ *   its generators with System.currentTimeMillis(); here both are `new Random(seed)` of the execution's seed.  K1 only. */
+typedef enum { DEMI_STRATEGY_FULLY_RANDOM = 0, DEMI_STRATEGY_SRC_DST_FIFO = 1 } demi_strategy;
 
 /* One verdict per candidate schedule. */
 #define DEMI_V_VIOLATION     0x1u  /* invariant violated (and matching looking_for when set)         */

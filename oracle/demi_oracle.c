@@ -308,8 +308,16 @@ typedef struct {
   uint32_t exists, inaccessible, killed;
   uint64_t partitioned; /* bit a*8+b : ordered pair (a,b), V/schedulers/EventOrchestrator.scala:51 */
   uint32_t trace_idx;
-  pend_entry pend[PEND_HARD_CAP]; /* RandomizedHashSet.arr, V/schedulers/Util.scala:112 */
+  pend_entry pend[PEND_HARD_CAP]; /* RandomizedHashSet.arr, V/schedulers/Util.scala:112 (SrcDstFIFO: timersAndExternals) */
   uint32_t n_pend, p_max;
+  /* SrcDstFIFO (V/schedulers/RandomScheduler.scala:702-909): the actor-to-actor messages in arrival order (the
+   * per-pair queues are the sub-sequences with equal (src, dst)), srcDsts, the second generator */
+  int fifo;
+  pend_entry norm[PEND_HARD_CAP];
+  uint32_t n_norm;
+  uint8_t pairs[64];              /* srcDsts: src * 8 + dst, in queue-creation order */
+  uint32_t n_pairs;
+  orc_jrandom te_rng;             /* timersAndExternals' RandomizedHashSet generator */
   mts_entry mts[MTS_CAP]; /* messagesToSend, V/schedulers/ExternalEventInjector.scala:109 */
   uint32_t n_mts;
   uint32_t n_mts_timers;  /* timers among them; capacity DEMI_TQ_CAP is part of the spec */
@@ -353,10 +361,38 @@ static int crosses_partition(const exec_t* x, uint32_t snd, uint32_t rcv) {
 #define OVF_ANY (DEMI_V_PENDING_OVF | DEMI_V_QUEUE_OVF)
 static void pend_insert(exec_t* x, uint32_t word, uint32_t id) {
   if (x->flags & OVF_ANY) return; /* only the first capacity overflow is reported */
-  if (x->n_pend >= x->p_max) { x->flags |= DEMI_V_PENDING_OVF; return; }
+  if (x->n_pend + x->n_norm >= x->p_max) { x->flags |= DEMI_V_PENDING_OVF; return; }
+  if (x->fifo && W_SRC(word) != DEMI_DEADLETTERS) {
+    /* SrcDstFIFO.+= (:791-811): append to the pair's queue, creating it (and its srcDsts entry) if absent */
+    uint8_t pair = (uint8_t)(W_SRC(word) * 8 + W_DST(word));
+    int have = 0;
+    for (uint32_t i = 0; i < x->n_pairs; i++) have |= (x->pairs[i] == pair);
+    if (!have) x->pairs[x->n_pairs++] = pair;
+    x->norm[x->n_norm].word = word;
+    x->norm[x->n_norm].id = id;
+    x->n_norm++;
+    return;
+  }
   x->pend[x->n_pend].word = word;
   x->pend[x->n_pend].id = id;
   x->n_pend++;
+}
+
+/* SrcDstFIFO.dequeue (:764-774): the head of the pair's queue; the queue and its srcDsts entry go when it empties */
+static pend_entry fifo_dequeue(exec_t* x, uint32_t pi) {
+  const uint8_t pair = x->pairs[pi];
+  uint32_t k = 0;
+  while (W_SRC(x->norm[k].word) * 8 + W_DST(x->norm[k].word) != pair) k++;
+  pend_entry v = x->norm[k];
+  memmove(&x->norm[k], &x->norm[k + 1], (x->n_norm - k - 1) * sizeof(pend_entry));
+  x->n_norm--;
+  int more = 0;
+  for (uint32_t i = k; i < x->n_norm; i++) more |= (W_SRC(x->norm[i].word) * 8 + W_DST(x->norm[i].word) == pair);
+  if (!more) {
+    memmove(&x->pairs[pi], &x->pairs[pi + 1], x->n_pairs - pi - 1);   /* ArrayList.remove(idx) */
+    x->n_pairs--;
+  }
+  return v;
 }
 
 /* RandomizedHashSet.remove: swap with last, V/schedulers/Util.scala:146-163 */
@@ -534,11 +570,25 @@ static int schedule_new_message(exec_t* x) {
   }
   send_external_messages(x);                                    /* :424 */
   if (x->flags & (DEMI_V_PENDING_OVF | DEMI_V_QUEUE_OVF)) return 0;
-  if (x->n_pend == 0) return 0;                                 /* find_non_blocked_message, Util.scala:474 */
-  /* FullyRandom.removeRandomElement (:666-684) -> RandomizedHashSet.removeRandomElement
-     (V/schedulers/Util.scala:171-176); blockedActors is empty (no crashes / ask in the model). */
-  uint32_t idx = (uint32_t)orc_jrandom_next_int_bound(&x->rng, (int32_t)x->n_pend);
-  pend_entry e = pend_remove_at(x, idx);
+  if (x->n_pend + x->n_norm == 0) return 0;                     /* find_non_blocked_message, Util.scala:474 */
+  pend_entry e;
+  if (!x->fifo) {
+    /* FullyRandom.removeRandomElement (:666-684) -> RandomizedHashSet.removeRandomElement
+       (V/schedulers/Util.scala:171-176); blockedActors is empty (no crashes / ask in the model). */
+    uint32_t idx = (uint32_t)orc_jrandom_next_int_bound(&x->rng, (int32_t)x->n_pend);
+    e = pend_remove_at(x, idx);
+  } else if (x->n_pairs == 0) {
+    /* SrcDstFIFO.getNonBlockedMessage (:716-729): only timers / externals left */
+    e = pend_remove_at(x, (uint32_t)orc_jrandom_next_int_bound(&x->te_rng, (int32_t)x->n_pend));
+  } else {
+    /* (:731-759) first decide whether to deliver a timer / external, in proportion to their share */
+    int timer = 0;
+    if ((uint32_t)orc_jrandom_next_int_bound(&x->rng, (int32_t)(x->n_pend + x->n_norm)) < x->n_pend) {
+      e = pend_remove_at(x, (uint32_t)orc_jrandom_next_int_bound(&x->te_rng, (int32_t)x->n_pend));
+      timer = 1;
+    }
+    if (!timer) e = fifo_dequeue(x, (uint32_t)orc_jrandom_next_int_bound(&x->rng, (int32_t)x->n_pairs));
+  }
   x->count++;                                                   /* :462 */
   uint32_t w = e.word;
   rec_push(x, DEMI_REC_MSG_EVENT, (uint8_t)W_SRC(w), (uint8_t)W_DST(w), (uint8_t)W_TYPE(w), (uint8_t)W_P0(w),
@@ -570,7 +620,9 @@ static int random_execute_in(exec_t* x, const demi_model* m, const demi_ext_even
   x->rec = rec; x->rec_cap = rec_cap;
   x->p_max = lim->p_max ? lim->p_max : 64;
   if (x->p_max > PEND_HARD_CAP) x->p_max = PEND_HARD_CAP;
-  orc_jrandom_seed(&x->rng, seed); /* new FullyRandom(seed = ...) */
+  orc_jrandom_seed(&x->rng, seed); /* new FullyRandom(seed = ...) / SrcDstFIFO.rand */
+  orc_jrandom_seed(&x->te_rng, seed);
+  x->fifo = lim->strategy == DEMI_STRATEGY_SRC_DST_FIFO;
   /* populateActorSystem (V/schedulers/ExternalEventInjector.scala:371-378, 397-406):
      every actor that is ever Start()ed is created up front and isolated. */
   for (uint32_t i = 0; i < n_ev; i++)

@@ -317,3 +317,71 @@ def test_violation_set_entry_point(gpu_ctx, oracle):
     assert n2 == len(idx) and len(few) == 8 and set(few["index"]) <= set(idx)
     none, n3 = gpu_ctx.random_explore_violations(0, lim, seed_base=SEED_BASE)
     assert n3 == 0 and len(none) == 0
+
+
+# ----------------------------------------------------------------------------------------------
+# SrcDstFIFO randomization strategy (RandomScheduler.scala:702-909)
+def _fifo(lim):
+    return T.Limits(lim.max_messages, lim.invariant_check_interval, lim.p_max, lim.looking_for_valid, lim.looking_for,
+                    lim.populate_all, T.STRATEGY_SRC_DST_FIFO)
+
+
+@pytest.mark.parametrize("p_max", [24, 64, 128])
+def test_srcdst_fifo_parity_raft5(gpu_ctx, oracle, p_max):
+    model, events, lim = raft5_config2()
+    lim.p_max = p_max
+    g, c = both(gpu_ctx, oracle, model, events, 40000, _fifo(lim), jit=True)
+    assert_same(g, c)
+    plain = gpu_ctx.random_explore(40000, lim, seed_base=SEED_BASE)
+    assert (g["hash"] != plain["hash"]).mean() > 0.9              # a different delivery discipline
+    assert (g["flags"] & T.V_VIOLATION).sum() > 10
+    if p_max == 24:
+        assert (g["flags"] & T.V_PENDING_OVF).sum() > 0
+
+
+def test_srcdst_fifo_parity_other_models_and_traces(gpu_ctx, oracle):
+    from .test_srcdst_fifo_cpu import gossip_model
+    rng = np.random.default_rng(1)
+    ev = [start(a) for a in range(4)]
+    for i in range(60):
+        ev.append(wait_quiescence() if rng.integers(0, 6) == 0 and ev[-1][0] != T.EV_WAIT_QUIESCENCE
+                  else send(int(rng.integers(0, 4)), 0, int(rng.integers(0, 8))))
+    for lim in (T.Limits(300, 0, 128, 0, 0, 0), T.Limits(120, 7, 40, 0, 0, 0)):
+        g, c = both(gpu_ctx, oracle, gossip_model(), events_to_array(ev), 12000, _fifo(lim), jit=True)
+        assert_same(g, c)
+    # kills / partitions, the 8-actor 3-class application, explicit seeds
+    model = M.raft_model(5, election_budget=2)
+    w = FuzzerWeights(kill=0.15, send=0.3, wait_quiescence=0.15, partition=0.25, unpartition=0.15)
+    for seed in (1, 2):
+        events = events_to_array(raft_trace(5, 80, seed, w, exact=False))
+        g, c = both(gpu_ctx, oracle, model, events, 6000, _fifo(T.Limits(300, 10, 128, 0, 0, 0)))
+        assert_same(g, c)
+    from demi_amd.apps import shuffle8_config5
+    model, _, events, lim = shuffle8_config5()
+    g, c = both(gpu_ctx, oracle, model, events, 20000, _fifo(lim), jit=True)
+    assert_same(g, c)
+    seeds = rng.integers(0, 1 << 62, size=3001, dtype=np.uint64)
+    g, c = both(gpu_ctx, oracle, model, events, 3001, _fifo(lim), seeds=seeds)
+    assert_same(g, c)
+
+
+def test_srcdst_fifo_recorded_traces_and_scheduler_mirror(gpu_ctx, oracle):
+    """The recording variant under SrcDstFIFO: identical EventTrace, deliveries in per-pair send order; the
+    RandomScheduler mirror takes the strategy object."""
+    from demi_amd.schedulers import RandomScheduler, SchedulerConfig, SrcDstFIFO
+    model, events, lim = raft5_config2()
+    fl = _fifo(lim)
+    gpu_ctx.model_load(model.to_struct())
+    gpu_ctx.trace_load(events)
+    v = gpu_ctx.random_explore(3000, fl, seed_base=SEED_BASE)
+    idx = list(np.nonzero(v["flags"] & T.V_VIOLATION)[0][:3]) + [0, 1, 2999]
+    for i in idx:
+        gv, grec = gpu_ctx.random_get_trace(SEED_BASE + int(i), fl)
+        cv, crec, _ = oracle.random_execute(model, events, SEED_BASE + int(i), fl)
+        assert gv.flags == cv.flags and gv.hash == cv.hash == int(v[i]["hash"])
+        assert len(grec) == len(crec) and (grec == crec).all()
+    sched = RandomScheduler(SchedulerConfig(model=model), max_executions=3000, invariant_check_interval=30,
+                            randomizationStrategy=SrcDstFIFO(SEED_BASE))
+    sched.setMaxMessages(200)
+    assert_same(sched.explore_all(events), v)
+    sched.shutdown()
