@@ -451,7 +451,7 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k1_random_explore(const K1Args 
           const uint32_t pr = pair_get(pi);
           uint32_t k = 0;
           uint32_t cur = norm_load(0);
-          while (w_src(cur) * 8 + w_dst(cur) != pr) { k++; cur = norm_load(k); }      // queue.head
+          while (k + 1 < n_norm && w_src(cur) * 8 + w_dst(cur) != pr) { k++; cur = norm_load(k); }   // queue.head
           w = cur;
           if (REC) wid = norm_aux_load(k);
           // dequeue (:764-774): close the gap (arrival order is the FIFO order) and see whether the pair has more
