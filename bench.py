@@ -37,6 +37,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-specialize", action="store_true", help="interpret the transition table instead of compiling it")
     ap.add_argument("--cpu-sample", type=int, default=1 << 20)
+    ap.add_argument("--strategy", choices=["random", "fifo"], default="random",
+                    help="RandomizationStrategy: FullyRandom (the headline workload) or SrcDstFIFO")
     args = ap.parse_args()
 
     import numpy as np
@@ -61,6 +63,7 @@ def main():
 
     model, events, limits = raft5_config2()
     limits.p_max = args.p_max
+    limits.strategy = T.STRATEGY_SRC_DST_FIFO if args.strategy == "fifo" else T.STRATEGY_FULLY_RANDOM
     n = args.schedules
     ctx = _native.Context(local_rank)
     ctx.model_load(model.to_struct())
@@ -125,7 +128,7 @@ def main():
         # algorithmic bytes of one K1 launch: 16 B verdict per schedule out, plus the
         # trace and the transition table streamed once per workgroup
         # the trace and the tables are streamed once per resident workgroup (3 per CU at this LDS footprint)
-        blocks = min((n + 255) // 256, torch.cuda.get_device_properties(dev).multi_processor_count * 3)
+        blocks = min((n + 255) // 256, torch.cuda.get_device_properties(dev).multi_processor_count * (2 if args.strategy == "fifo" else 3))
         shared = 8 * len(events) + 4 * len(model.code) + 4 * len(model.handler_start) + 8 * 8 + 32 * 4 + 132 * 4 + 64 * 4
         alg_bytes = 16 * n + blocks * shared
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
@@ -143,13 +146,15 @@ def main():
                                    "Fuzzer-distribution trace, %d random interleavings per GPU per step" % n,
                        "schedules_per_gpu_per_step": n, "max_messages": int(limits.max_messages),
                        "invariant_check_interval": int(limits.invariant_check_interval), "p_max": int(limits.p_max),
+                       "randomization_strategy": "SrcDstFIFO" if args.strategy == "fifo" else "FullyRandom",
                        "table_compiled_to_native_code": specialized, "seed_base": SEED_BASE, "parallelism": "schedule-index range sharded, %d rank(s)" % world},
             "violations_last_step": int(len(vset)),
             "distinct_fingerprints_last_step": int(len(np.unique(vset["fingerprint"]))) if len(vset) else 0,
             "bugs_per_hr": float(len(vset)) / (dt / args.steps) * 3600.0,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k1_random_explore<false>" + (" (specialised, hiprtc)" if specialized else ""),
+                         "kernel": ("k1_random_explore<false, true>" if args.strategy == "fifo" else "k1_random_explore<false, false>") +
+                                   (" (specialised, hiprtc)" if specialized else ""),
                          "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "integer/LDS-bound simulation: algorithmic HBM traffic is 16 B per schedule, so the "
