@@ -482,10 +482,10 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k1_random_explore(const K1Args 
           just |= tbit;
           enqueue_timer(me, type);      // parked in timersToResend (it is in justScheduledTimers)
         } else {
-          for (uint32_t k = 0; k < n_resend; k++) {
-            if (n_tq >= DEMI_TQ_CAP) { flags |= DEMI_V_QUEUE_OVF; break; }
-            tq |= ((resend >> (8 * k)) & 0xFFull) << (8 * n_tq);
-            n_tq++;
+          // timersToResend re-enter messagesToSend in order (RandomScheduler.scala:416-419): one shifted OR
+          if (n_resend != 0) {
+            if (n_tq + n_resend > DEMI_TQ_CAP) flags |= DEMI_V_QUEUE_OVF;
+            else { tq |= resend << (8 * n_tq); n_tq += n_resend; }
           }
           resend = 0; n_resend = 0; just = 0;
         }
@@ -557,12 +557,18 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k1_random_explore(const K1Args 
           // cancelTimer (Instrumenter.scala:159-168) -> notify_timer_cancel (:525-534)
           rep &= ~TIMER_BIT(me, type);
           const uint32_t want = (me << 5) | type;
+          // handle_timer_cancel: messagesToSend first.  The first of its n_tq bytes equal to `want`, all eight
+          // compared at once (zero-byte test on tq ^ want...want; its lowest hit is exact)
           bool found = false;
-          for (uint32_t q = 0; q < n_tq; q++) {          // handle_timer_cancel: messagesToSend first
-            if (((uint32_t)(tq >> (8 * q)) & 0xFF) == want) {
-              const uint64_t lowm = (q == 0) ? 0ull : (~0ull >> (64 - 8 * q));
+          {
+            const uint64_t x = tq ^ (0x0101010101010101ull * (uint64_t)want);
+            uint64_t z = (x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull;
+            z &= (n_tq >= 8) ? ~0ull : ((1ull << (8 * n_tq)) - 1ull);
+            if (z != 0) {
+              const uint32_t q = (uint32_t)__builtin_ctzll(z) >> 3;
+              const uint64_t lowm = (1ull << (8 * q)) - 1ull;
               tq = (tq & lowm) | ((tq >> 8) & ~lowm);
-              n_tq--; found = true; break;
+              n_tq--; found = true;
             }
           }
           if (!found) {

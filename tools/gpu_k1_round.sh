@@ -1,5 +1,5 @@
 #!/bin/bash
-# K1 parity (interpreter and specialised kernel) + the bench line both ways, one GPU call
+# K1 parity (interpreter and specialised kernel) + the bench line both ways + the SrcDstFIFO line + the phase split
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out
@@ -10,6 +10,9 @@ rc=$?
 tail -25 $OUT/k1_tests.log
 if [ $rc -ne 0 ]; then exit $rc; fi
 timeout 200 python bench.py --steps 10 --warmup 2 > $OUT/bench_jit.json 2> $OUT/bench_jit.err
-echo "bench(jit) rc $?"; tail -3 $OUT/bench_jit.err; cat $OUT/bench_jit.json
+echo "bench(jit) rc $?"; tail -3 $OUT/bench_jit.err
 timeout 200 python bench.py --steps 10 --warmup 2 --no-specialize --no-cpu-baseline > $OUT/bench_interp.json 2> $OUT/bench_interp.err
-echo "bench(interp) rc $?"; cat $OUT/bench_interp.json
+echo "bench(interp) rc $?"
+timeout 200 python bench.py --steps 10 --warmup 2 --strategy fifo > $OUT/bench_fifo.json 2> $OUT/bench_fifo.err
+echo "bench(fifo) rc $?"; tail -3 $OUT/bench_fifo.err
+if [ -n "$PHASES" ]; then bash tools/k1_phases.sh; fi
