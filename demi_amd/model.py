@@ -379,8 +379,13 @@ def shuffle_model(buggy=True) -> Model:
     a.if_eq(F[0], 1, "x").mov(F[0], 2).mov(T0, 2).send(SH_LAUNCH, T0, T1, 0).halt()
     a.label("s2").if_eq(F[0], 2, "x").mov(F[0], 3).label("x")
     h[(CLS_DRIVER, "StageDone")] = a
-    # ---- map coordinator (actor 1): F0 started, F1 done count, F2 done mask
-    a = Asm()          # LaunchStage(w, relaunch): relaunch=0 -> all workers; relaunch=1 -> worker 3+w only
+    # ---- stage coordinators (actors 1 and 2 share a class): F0 started, F1 done count, F2 done mask
+    a = Asm()          # LaunchStage(w, relaunch)
+    a.if_eq(ME, 2, "map")            # on the reduce coordinator: RunTask(reduce) to every worker
+    for w in range(n_workers):
+        a.mov(T0, 3 + w).mov(T1, 2).send(SH_RUN, T0, T1, 0)
+    a.halt()
+    a.label("map")                   # on the map coordinator: relaunch=0 -> all workers; relaunch=1 -> worker 3+w only
     a.if_eq(P1, 0, "re").if_eq(F[0], 0, "x").mov(F[0], 1)
     for w in range(n_workers):
         a.mov(T0, 3 + w).mov(T1, 1).send(SH_RUN, T0, T1, 0)
@@ -395,9 +400,6 @@ def shuffle_model(buggy=True) -> Model:
         a.and_(T2, F[2], T1).if_eq(T2, 0, "x").add(F[1], F[1], 1).or_(F[2], F[2], T1)
     a.if_eq(F[1], n_workers, "x").if_eq(F[3], 0, "x").mov(F[3], 1).mov(T0, 0).mov(T1, 1).send(SH_STAGEDONE, T0, T1, 0).label("x")
     h[(CLS_COORD, "MapDone")] = a
-    # ---- reduce coordinator (actor 2) shares the class: LaunchStage(_, 0) on actor 2 starts the reducers;
-    # distinguish by ME inside the handlers above is avoided by giving the reducer its own rows via SRC
-    # (stage 2 launch arrives from the driver with P1 == 0 and ME == 2): handled by RunTask kind 2 below
     # ---- workers: F0 has map output, F1 fetched count, F2 fetch-missing flag (violation), F3 ran reduce
     a = Asm()          # RunTask(kind): 1 = map (arm a task timeout, produce output, report); 2 = reduce (fetch from all)
     a.if_eq(P0, 1, "red").mov(F[0], 1).tcancel(SH_TIMEOUT).tset(SH_TIMEOUT).mov(T0, 1).send(SH_MAPDONE, T0, T1, 0).halt()
@@ -413,22 +415,6 @@ def shuffle_model(buggy=True) -> Model:
     a.if_eq(F[0], 1, "x").if_lt(F[4], 1, "x").add(F[4], F[4], 1).mov(T0, 1).send(SH_MAPDONE, T0, T1, 0).label("x")
     h[(CLS_WORKER, "TaskTimeout")] = a
     # coordinators ignore worker-only messages and vice versa (handler_start 0xFFFF)
-    # reduce coordinator: LaunchStage on actor 2 -> RunTask(2) to all workers
-    red = Asm()
-    red.if_eq(ME, 2, "map")
-    for w in range(n_workers):
-        red.mov(T0, 3 + w).mov(T1, 2).send(SH_RUN, T0, T1, 0)
-    red.halt()
-    red.label("map")
-    # fall through into the map coordinator's LaunchStage rows
-    base = h[(CLS_COORD, "LaunchStage")].finish()
-    fix_rows = red.rows
-    for idx, label in red._fix:
-        dist = red._labels[label] - (idx + 1)
-        fix_rows[idx] |= dist << 17
-    merged = Asm()
-    merged.rows = fix_rows + base
-    h[(CLS_COORD, "LaunchStage")] = merged
     init = [[0] * 8 for _ in range(8)]
     return build_model("shuffle8-synth%s" % ("" if buggy else "-fixed"), 8, SH_MSGS, h, init,
                        invariant=(T.INV_NEVER, 2, 1, 0), actor_class=[CLS_DRIVER, CLS_COORD, CLS_COORD] + [CLS_WORKER] * 5,
