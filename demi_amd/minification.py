@@ -293,3 +293,37 @@ def stsSchedDDMin(oracle, externals: np.ndarray, violation: ViolationFingerprint
     mcs = ddmin.minimize(view, violation)
     verified = ddmin.verify_mcs(mcs, violation)
     return mcs.get_all_events(), ddmin, verified
+
+
+class _SubsequenceOracle:
+    """DDMin hands the oracle index tuples (EventDag events); a scheduler's test() wants the events themselves."""
+
+    def __init__(self, sched, externals: np.ndarray):
+        self.sched = sched
+        self.externals = externals
+
+    def getName(self) -> str:
+        return self.sched.getName()
+
+    def test(self, events, violation_fingerprint: ViolationFingerprint, stats: Optional[MinimizationStats] = None):
+        return self.sched.test(self.externals[list(events)], violation_fingerprint, stats)
+
+
+def randomDDMin(schedulerConfig, trace, violation: ViolationFingerprint, max_executions: int = 100, seed_base: int = 0,
+                stats: Optional[MinimizationStats] = None, device: int = 0, p_max: int = 64):
+    """RunnerUtils.randomDDMin (RunnerUtils.scala:601-623): DDMin whose oracle is the RandomScheduler itself —
+    a candidate subsequence "fails" iff one of `max_executions` random interleavings of it (one K1 launch; the
+    reference constructs the scheduler with max_executions = 1) reproduces the violation fingerprint.  maxMessages is
+    the length of the recorded trace, as in the reference.  Returns (mcs indices, ddmin, verified trace or None)."""
+    from .schedulers import RandomScheduler
+    sched = RandomScheduler(schedulerConfig, max_executions, 0, seed_base=seed_base, device=device, p_max=p_max,
+                            specialize=False)
+    sched.setMaxMessages(len(trace.events))
+    try:
+        externals = trace.original_externals
+        ddmin = DDMin(_SubsequenceOracle(sched, externals), checkUnmodifed=False, stats=stats)
+        mcs = ddmin.minimize(UnmodifiedEventDag(externals), violation)
+        verified = ddmin.verify_mcs(mcs, violation) if mcs.length < len(externals) else trace
+    finally:
+        sched.shutdown()
+    return mcs.get_all_events(), ddmin, verified

@@ -276,3 +276,21 @@ def test_specialised_replay_kernel_is_bit_identical(gpu_ctx, oracle):
             assert (gpu_ctx.replay_get_kept(len(rec), int(sk[i]), target, mask=masks[i])[1] == kept[j]).all()
         gpu_ctx.model_specialize(False)
         assert_same(plain, oracle.sts_replay_batch(model, used, rec, masks, target, n_threads=os.cpu_count()))
+
+
+def test_random_ddmin_with_the_random_scheduler_as_oracle(gpu_ctx):
+    """RunnerUtils.randomDDMin: every DDMin consultation is a K1 launch of R random interleavings of the candidate."""
+    from demi_amd.minification import randomDDMin
+    model, events, lim = raft5_config2()
+    vv, rec, used = record(gpu_ctx, model, events, lim)
+    fp = ViolationFingerprint(vv.fingerprint, model.fp_match_mask)
+    stats = MinimizationStats()
+    mcs, ddmin, verified = randomDDMin(SchedulerConfig(model=model), EventTrace(rec, used), fp, max_executions=256,
+                                       seed_base=SEED_BASE, stats=stats)
+    assert verified is not None and 0 < len(mcs) < len(used)
+    assert stats.total_replays == 256 * len(ddmin.consulted)
+    # the MCS is 1-minimal with respect to this (randomised, seeded) oracle: the consultations that removed an atom passed
+    assert any(passes for _, passes in ddmin.consulted) and any(not passes for _, passes in ddmin.consulted)
+    # deterministic: same seeds, same answer
+    mcs2, _, _ = randomDDMin(SchedulerConfig(model=model), EventTrace(rec, used), fp, max_executions=256, seed_base=SEED_BASE)
+    assert mcs2 == mcs
