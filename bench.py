@@ -137,6 +137,23 @@ def main():
         if os.path.exists(tp):
             with open(tp) as f:
                 traffic = json.load(f).get("hbm_bytes_per_launch")
+        # the bound that actually binds: VALU / SALU issue.  Instruction counts per launch come from the
+        # committed rocprofv3 --pmc pass of this same workload and kernel flavour, the duration is this run's.
+        issue = None
+        cp = os.path.join(ROOT, "profiles", "r01_k1_final_counters.json")
+        if os.path.exists(cp) and specialized and args.strategy == "random" and n == N_PER_GPU:
+            with open(cp) as f:
+                ctr = json.load(f)
+            k1 = next((v for k, v in ctr.items() if "k1_random_explore" in k), None)
+            if k1 and "SQ_INSTS_VALU" in k1:
+                props = torch.cuda.get_device_properties(dev)
+                simds, clk = props.multi_processor_count * 4, props.clock_rate * 1e3
+                valu, salu = k1["SQ_INSTS_VALU"]["avg_per_dispatch"], k1["SQ_INSTS_SALU"]["avg_per_dispatch"]
+                issue = {"valu_insts_per_launch": valu, "salu_insts_per_launch": salu,
+                         "valu_issue_frac": valu * 4.0 / simds / (kernel_ms * 1e-3 * clk),
+                         "salu_issue_frac": salu / props.multi_processor_count / (kernel_ms * 1e-3 * clk),
+                         "clock_hz": clk, "source": "profiles/r01_k1_final_counters.json (SQ_INSTS_VALU / SQ_INSTS_SALU); a wave64 "
+                         "VALU instruction occupies its SIMD for 4 cycles, the scalar unit is one per CU"}
         out = {
             "metric": "candidate schedules evaluated/sec on Raft-5 fuzz (RandomScheduler executions)",
             "value": value, "unit": "schedules/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -158,7 +175,8 @@ def main():
                          "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "integer/LDS-bound simulation: algorithmic HBM traffic is 16 B per schedule, so the "
-                                 "HBM fraction is tiny by construction (SURVEY 8d); see DESIGN.md for the issue-rate model"},
+                                 "HBM fraction is tiny by construction (SURVEY 8d); see DESIGN.md for the issue-rate model",
+                         "issue_model": issue},
         }
         if not args.no_cpu_baseline and world == 1:
             from oracle import oracle_py as O

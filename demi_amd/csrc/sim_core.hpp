@@ -111,7 +111,10 @@ __device__ inline unsigned char* tables_load(Tables& t, unsigned char* smem, con
 // The pending set keeps its PEND_HOT lowest slots in LDS; deeper slots (rare: <1% of raft
 // schedules ever hold more than 32 pending messages) spill to an HBM scratch laid out
 // [slot - PEND_HOT][global lane], so a wave's spill accesses to one slot are coalesced.
-constexpr uint32_t PEND_HOT = 32;
+#ifndef DEMI_PEND_HOT
+#define DEMI_PEND_HOT 32
+#endif
+constexpr uint32_t PEND_HOT = DEMI_PEND_HOT;
 
 struct LaneMem {
   uint64_t* st;        // [A]          actor states (LDS)
