@@ -147,7 +147,8 @@ def main():
             k1 = next((v for k, v in ctr.items() if "k1_random_explore" in k), None)
             if k1 and "SQ_INSTS_VALU" in k1:
                 props = torch.cuda.get_device_properties(dev)
-                simds, clk = props.multi_processor_count * 4, props.clock_rate * 1e3
+                simds = props.multi_processor_count * 4
+                clk = float(getattr(props, "clock_rate", 2400000)) * 1e3          # kHz -> Hz (MI355X: 2.4 GHz)
                 valu, salu = k1["SQ_INSTS_VALU"]["avg_per_dispatch"], k1["SQ_INSTS_SALU"]["avg_per_dispatch"]
                 issue = {"valu_insts_per_launch": valu, "salu_insts_per_launch": salu,
                          "valu_issue_frac": valu * 4.0 / simds / (kernel_ms * 1e-3 * clk),
