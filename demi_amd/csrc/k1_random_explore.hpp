@@ -48,6 +48,13 @@ struct K1Args {
 enum : int { PH_IDLE = 0, PH_INJECT = 1, PH_DISPATCH = 2, PH_FINISH = 3 };
 
 constexpr int K1_WAVES = 4;          // waves per workgroup
+// LDS-resident pending slots per lane in K1.  The interpreter is VALU-bound and wants residency (32: 12 waves/CU);
+// the specialised build issues as many scalar as vector instructions and gains more from a fourth workgroup per CU
+// (16 waves: VALU and SALU of different waves issue together) than it loses to spills: jit.hpp sets it to 16.
+#ifndef DEMI_K1_HOT
+#define DEMI_K1_HOT DEMI_PEND_HOT
+#endif
+constexpr uint32_t K1_HOT = DEMI_K1_HOT;
 constexpr int K1_BATCH = 64;         // schedule indices claimed per atomic
 
 // K1 keeps two more workgroup-shared tables derived from the trace: the network state after every
@@ -67,14 +74,14 @@ __host__ __device__ inline size_t k1_fifo_wave_bytes(uint32_t n_actors, bool rec
   return ((size_t)NORM_HOT * (rec ? 2 : 1) + k1_pair_words(n_actors)) * 64 * 4;
 }
 // HBM scratch words per simulator lane: pending slots beyond the LDS-resident ones, every array of the variant
-__host__ __device__ inline size_t k1_spill_words_per_lane(bool rec, bool fifo) {
-  return (size_t)((DEMI_MAX_PENDING - PEND_HOT) + (fifo ? (DEMI_MAX_PENDING - NORM_HOT) : 0)) * (rec ? 2 : 1);
+__host__ __device__ inline size_t k1_spill_words_per_lane(bool rec, bool fifo, uint32_t hot = K1_HOT) {
+  return (size_t)((DEMI_MAX_PENDING - hot) + (fifo ? (DEMI_MAX_PENDING - NORM_HOT) : 0)) * (rec ? 2 : 1);
 }
 template <bool REC, bool FIFO>
 __host__ __device__ inline size_t k1_lds_bytes(uint32_t code_len, uint32_t n_ev, uint32_t n_hs, uint32_t n_actors,
-                                               uint32_t n_batches) {
+                                               uint32_t n_batches, uint32_t hot = K1_HOT) {
   return tables_lds_bytes(code_len, n_ev, n_hs) + k1_extra_lds_bytes(n_ev, n_batches) +
-         K1_WAVES * (lane_mem_wave_bytes(n_actors, REC) + (FIFO ? k1_fifo_wave_bytes(n_actors, REC) : 0));
+         K1_WAVES * (lane_mem_wave_bytes(n_actors, REC, hot) + (FIFO ? k1_fifo_wave_bytes(n_actors, REC) : 0));
 }
 
 template <bool REC, bool FIFO = false>
@@ -114,19 +121,19 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k1_random_explore(const K1Args 
   }
   __syncthreads();
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const LaneMem mem = lane_mem_carve(wave_base + (size_t)wave * lane_mem_wave_bytes(t.A, REC), t.A, REC, lane, args.spill,
-                                     (size_t)blockIdx.x * blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x);
+  const LaneMem mem = lane_mem_carve(wave_base + (size_t)wave * lane_mem_wave_bytes(t.A, REC, K1_HOT), t.A, REC, lane, args.spill,
+                                     (size_t)blockIdx.x * blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x, K1_HOT);
   uint64_t* const st = mem.st;
   const uint32_t PMAX = args.p_max;
   // SrcDstFIFO arrays of this lane (FIFO builds only)
   uint32_t* f_norm = nullptr, *f_norm_aux = nullptr, *f_pairs = nullptr, *f_spill = nullptr, *f_spill_aux = nullptr;
   if (FIFO) {
-    unsigned char* fb = wave_base + (size_t)K1_WAVES * lane_mem_wave_bytes(t.A, REC) + (size_t)wave * k1_fifo_wave_bytes(t.A, REC);
+    unsigned char* fb = wave_base + (size_t)K1_WAVES * lane_mem_wave_bytes(t.A, REC, K1_HOT) + (size_t)wave * k1_fifo_wave_bytes(t.A, REC);
     f_norm = reinterpret_cast<uint32_t*>(fb) + lane;
     if (REC) f_norm_aux = f_norm + (size_t)NORM_HOT * 64;
     f_pairs = f_norm + (size_t)NORM_HOT * 64 * (REC ? 2 : 1);
     const size_t lanes = (size_t)gridDim.x * blockDim.x, gl = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    f_spill = args.spill + spill_words(lanes) * (REC ? 2 : 1) + gl;
+    f_spill = args.spill + spill_words(lanes, K1_HOT) * (REC ? 2 : 1) + gl;
     if (REC) f_spill_aux = f_spill + lanes * (DEMI_MAX_PENDING - NORM_HOT);
   }
   const uint32_t f_stride = (uint32_t)((size_t)gridDim.x * blockDim.x);
@@ -390,8 +397,8 @@ __global__ __launch_bounds__(K1_WAVES * 64) void k1_random_explore(const K1Args 
           const uint32_t slot = base + i;
           if (slot + other >= PMAX) break;
           const uint32_t sw = s_bsend[off + i];
-          if (slot < PEND_HOT) (mem.pend - lane + src)[slot * 64] = sw;
-          else { (mem.spill - lane + src)[(size_t)(slot - PEND_HOT) * mem.spill_stride] = sw; spilled = true; }
+          if (slot < K1_HOT) (mem.pend - lane + src)[slot * 64] = sw;
+          else { (mem.spill - lane + src)[(size_t)(slot - K1_HOT) * mem.spill_stride] = sw; spilled = true; }
         }
       }
       if (__ballot(spilled) != 0) __threadfence_block();        // another lane's spill slots were written

@@ -124,45 +124,48 @@ struct LaneMem {
   uint32_t* spill;     // global: slot s >= PEND_HOT lives at spill[(s - PEND_HOT) * spill_stride]
   uint32_t* spill_aux; // global, parallel to spill (may be null)
   uint32_t spill_stride;
+  uint32_t hot;        // slots below `hot` live in LDS (PEND_HOT, or less where occupancy is worth more than residency)
 };
 
-__host__ __device__ inline size_t lane_mem_wave_bytes(uint32_t n_actors, bool aux) {
-  return (size_t)n_actors * 64 * 8 + (size_t)PEND_HOT * 64 * 4 * (aux ? 2 : 1) + (size_t)DEMI_FX_CAP * 64 * 4;
+__host__ __device__ inline size_t lane_mem_wave_bytes(uint32_t n_actors, bool aux, uint32_t hot = PEND_HOT) {
+  return (size_t)n_actors * 64 * 8 + (size_t)hot * 64 * 4 * (aux ? 2 : 1) + (size_t)DEMI_FX_CAP * 64 * 4;
 }
 // HBM scratch words for `lanes` simulators (per array)
-__host__ __device__ inline size_t spill_words(size_t lanes) { return lanes * (DEMI_MAX_PENDING - PEND_HOT); }
+__host__ __device__ inline size_t spill_words(size_t lanes, uint32_t hot = PEND_HOT) { return lanes * (DEMI_MAX_PENDING - hot); }
 
 __device__ inline LaneMem lane_mem_carve(unsigned char* wave_base, uint32_t n_actors, bool aux, uint32_t lane,
-                                         uint32_t* g_spill, size_t global_lane, size_t total_lanes) {
+                                         uint32_t* g_spill, size_t global_lane, size_t total_lanes,
+                                         uint32_t hot = PEND_HOT) {
   LaneMem m;
   m.st = reinterpret_cast<uint64_t*>(wave_base) + lane;
   uint32_t* p = reinterpret_cast<uint32_t*>(wave_base + (size_t)n_actors * 64 * 8);
   m.pend = p + lane;
-  p += (size_t)PEND_HOT * 64;
+  p += (size_t)hot * 64;
   m.pend_aux = aux ? p + lane : nullptr;
-  if (aux) p += (size_t)PEND_HOT * 64;
+  if (aux) p += (size_t)hot * 64;
   m.fxq = p + lane;
   m.spill = g_spill + global_lane;
-  m.spill_aux = aux ? g_spill + spill_words(total_lanes) + global_lane : nullptr;
+  m.spill_aux = aux ? g_spill + spill_words(total_lanes, hot) + global_lane : nullptr;
   m.spill_stride = (uint32_t)total_lanes;
+  m.hot = hot;
   return m;
 }
 
 __device__ __forceinline__ uint32_t pend_load(const LaneMem& m, uint32_t slot) {
-  if (slot < PEND_HOT) return m.pend[slot * 64];
-  return m.spill[(size_t)(slot - PEND_HOT) * m.spill_stride];
+  if (slot < m.hot) return m.pend[slot * 64];
+  return m.spill[(size_t)(slot - m.hot) * m.spill_stride];
 }
 __device__ __forceinline__ void pend_store(const LaneMem& m, uint32_t slot, uint32_t v) {
-  if (slot < PEND_HOT) m.pend[slot * 64] = v;
-  else m.spill[(size_t)(slot - PEND_HOT) * m.spill_stride] = v;
+  if (slot < m.hot) m.pend[slot * 64] = v;
+  else m.spill[(size_t)(slot - m.hot) * m.spill_stride] = v;
 }
 __device__ __forceinline__ uint32_t aux_load(const LaneMem& m, uint32_t slot) {
-  if (slot < PEND_HOT) return m.pend_aux[slot * 64];
-  return m.spill_aux[(size_t)(slot - PEND_HOT) * m.spill_stride];
+  if (slot < m.hot) return m.pend_aux[slot * 64];
+  return m.spill_aux[(size_t)(slot - m.hot) * m.spill_stride];
 }
 __device__ __forceinline__ void aux_store(const LaneMem& m, uint32_t slot, uint32_t v) {
-  if (slot < PEND_HOT) m.pend_aux[slot * 64] = v;
-  else m.spill_aux[(size_t)(slot - PEND_HOT) * m.spill_stride] = v;
+  if (slot < m.hot) m.pend_aux[slot * 64] = v;
+  else m.spill_aux[(size_t)(slot - m.hot) * m.spill_stride] = v;
 }
 
 // ------------------------------------------------------------------ row interpreter
