@@ -176,7 +176,9 @@ def main():
                          "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "integer/LDS-bound simulation: algorithmic HBM traffic is 16 B per schedule, so the "
-                                 "HBM fraction is tiny by construction (SURVEY 8d); see DESIGN.md for the issue-rate model",
+                                 "HBM fraction is tiny by construction (SURVEY 8d); see DESIGN.md for the issue-rate model. "
+                                 "traffic above the algorithmic bytes is the pending-set spill of the specialised build "
+                                 "(8 LDS-resident slots per lane for 20 waves/CU), not re-reads of inputs",
                          "issue_model": issue},
         }
         if not args.no_cpu_baseline and world == 1:
