@@ -385,3 +385,11 @@ def test_srcdst_fifo_recorded_traces_and_scheduler_mirror(gpu_ctx, oracle):
     sched.setMaxMessages(200)
     assert_same(sched.explore_all(events), v)
     sched.shutdown()
+
+
+def test_fifo_golden_fixture_on_gpu(gpu_ctx):
+    model, events, lim = raft5_config2()
+    want = np.load(os.path.join(G, "raft5_config2_fifo_verdicts.npy"))
+    gpu_ctx.model_load(model.to_struct())
+    gpu_ctx.trace_load(events)
+    assert_same(gpu_ctx.random_explore(len(want), _fifo(lim), seed_base=SEED_BASE), want)

@@ -294,3 +294,20 @@ def test_random_ddmin_with_the_random_scheduler_as_oracle(gpu_ctx):
     # deterministic: same seeds, same answer
     mcs2, _, _ = randomDDMin(SchedulerConfig(model=model), EventTrace(rec, used), fp, max_executions=256, seed_base=SEED_BASE)
     assert mcs2 == mcs
+
+
+def test_replay_golden_fixture_on_gpu(gpu_ctx):
+    """The committed fixture (tools/make_golden.py): recorded execution, masks, removal candidates and executed-trace
+    marks with the verdicts the oracle gave them."""
+    model, events, lim = raft5_config2()
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "raft5_config2_replay.npz"))
+    gpu_ctx.model_load(model.to_struct())
+    gpu_ctx.trace_load(events)
+    vv, rec = gpu_ctx.random_get_trace(SEED_BASE + int(z["index"]), lim)
+    assert vv.fingerprint == int(z["fingerprint"]) and (rec == z["rec"]).all()
+    target = T.Limits(0, 0, 64, 1, int(z["fingerprint"]), 0)
+    gpu_ctx.replay_load(z["used"], z["rec"])
+    assert_same(gpu_ctx.replay_batch(z["masks"], target), z["mask_verdicts"])
+    assert_same(gpu_ctx.replay_removal_batch(z["skips"], target), z["skip_verdicts"])
+    for k in range(len(z["kept"])):
+        assert (gpu_ctx.replay_get_kept(len(z["rec"]), int(z["skips"][k]), target)[1] == z["kept"][k]).all()

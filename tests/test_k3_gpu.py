@@ -180,3 +180,16 @@ def test_edit_distance_dpor_ddmin_on_the_gpu(oracle):
         runs.append((mcs, ddmin.ddmin.consulted, ddmin.distances, verified is not None, ddmin._stats.total_replays))
     assert runs[0] == runs[1]
     assert runs[0][3] and len(runs[0][0]) < len(ev)
+
+
+def test_dpor_golden_fixture_on_gpu(gpu_ctx):
+    import hashlib
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "raft3_dpor.npz"))
+    prefixes = [z["prefixes"][k, :int(n)] for k, n in enumerate(z["prefix_len"])]
+    gpu_ctx.model_load(M.raft_model(3).to_struct())
+    gpu_ctx.dpor_load(z["externals"])
+    dv, dt, dp = gpu_ctx.dpor_batch(prefixes, T.DporParams(30, 0, 0, 0, 64, 4096, 0))
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    assert (dv == z["verdicts"]).all()
+    assert [sha(t) for t in dt] == list(z["trace_sha"]) and [sha(p) for p in dp] == list(z["pairs_sha"])

@@ -48,3 +48,60 @@ for name, cfg, n in (("raft5_config2", raft5_config2, 4096), ("raft3_config1", r
     v = O.random_explore(model, events, n, seed_base=SEED_BASE, limits=limits)
     np.save(os.path.join(G, name + "_verdicts.npy"), v)
     print(name, "violations", int((v["flags"] & T.V_VIOLATION).sum()), "of", n)
+
+# ---------------------------------------------------------------------------------------------
+# Regression pins for the other paths (again: the CPU oracle's outputs on frozen inputs, not JVM outputs)
+import hashlib  # noqa: E402
+
+from demi_amd.fuzzer import events_to_array, send, start  # noqa: E402
+from demi_amd import model as M  # noqa: E402
+from demi_amd.dpor import DPORwHeuristics  # noqa: E402
+from demi_amd.internal_minimization import deliveries  # noqa: E402
+from demi_amd.minification import events_to_mask  # noqa: E402
+from demi_amd.schedulers import EventTrace, SchedulerConfig  # noqa: E402
+
+model, events, limits = raft5_config2()
+# K1 with the SrcDstFIFO strategy
+fifo = T.Limits(limits.max_messages, limits.invariant_check_interval, limits.p_max, 0, 0, 0, T.STRATEGY_SRC_DST_FIFO)
+np.save(os.path.join(G, "raft5_config2_fifo_verdicts.npy"), O.random_explore(model, events, 1024, seed_base=SEED_BASE, limits=fifo))
+# K2: the first violating execution of the frozen workload, subsequence masks, removal candidates, executed-trace marks
+v = np.load(os.path.join(G, "raft5_config2_verdicts.npy"))
+i0 = int(np.nonzero(v["flags"] & T.V_VIOLATION)[0][0])
+vv, rec, _ = O.random_execute(model, events, SEED_BASE + i0, limits)
+used = events[:T.verdict_trace_idx(vv.flags)]
+rng = np.random.default_rng(2024)
+masks = np.zeros((96, 4), dtype=np.uint64)
+for r in range(96):
+    keep = np.arange(len(used)) if r == 0 else np.nonzero(rng.random(len(used)) < rng.choice([0.3, 0.6, 0.9]))[0]
+    masks[r] = events_to_mask(keep)
+target = T.Limits(0, 0, 64, 1, vv.fingerprint, 0)
+dl = np.array([i for i, _, _ in deliveries(EventTrace(rec, used))], dtype=np.uint32)
+skips = np.concatenate([dl[::3], [0xFFFFFFFF]]).astype(np.uint32)
+kept = np.stack([O.sts_removal_kept(model, used, rec, int(s), target)[1] for s in skips[:4]])
+np.savez(os.path.join(G, "raft5_config2_replay.npz"), index=i0, fingerprint=vv.fingerprint, rec=rec, used=used, masks=masks,
+         mask_verdicts=O.sts_replay_batch(model, used, rec, masks, target), skips=skips,
+         skip_verdicts=O.sts_removal_batch(model, used, rec, skips, target), kept=kept)
+# K3: prefixes of a bounded exploration of raft3, per-interleaving outputs as verdicts + digests
+m3 = M.raft_model(3)
+ev3 = events_to_array([start(a) for a in range(3)] + [send(a, M.M_BOOTSTRAP) for a in range(3)])
+launched = []
+
+
+def backend(m, e, prefixes, params):
+    launched.extend(prefixes)
+    return O.dpor_batch(m, e, prefixes, params)
+
+
+DPORwHeuristics(SchedulerConfig(model=m3), depth_bound=30, stopIfViolationFound=False, batch=16, backend=backend).explore(
+    ev3, max_interleavings=64)
+par = T.DporParams(30, 0, 0, 0, 64, 4096, 0)
+dv, dt, dp = O.dpor_batch(m3, ev3, launched, par)
+stride = max(len(p) for p in launched)
+pf = np.zeros((len(launched), stride), dtype=T.DPOR_TRACE_DTYPE)
+for k, p in enumerate(launched):
+    pf[k, :len(p)] = p
+np.savez(os.path.join(G, "raft3_dpor.npz"), externals=ev3, prefixes=pf, prefix_len=np.array([len(p) for p in launched]),
+         verdicts=dv, trace_len=np.array([len(t) for t in dt]), n_pairs=np.array([len(p) for p in dp]),
+         trace_sha=np.array([hashlib.sha256(np.ascontiguousarray(t).tobytes()).hexdigest() for t in dt]),
+         pairs_sha=np.array([hashlib.sha256(np.ascontiguousarray(p).tobytes()).hexdigest() for p in dp]))
+print("extra fixtures written")
