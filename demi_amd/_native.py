@@ -84,7 +84,7 @@ def specialize_check(model_struct):
     log = C.create_string_buffer(4096)
     n = lib().demi_specialize_check(C.byref(model_struct), log, len(log))
     if n < 0:
-        raise DemiError(-n, log.value.decode(errors="replace"))
+        raise DemiError(n, log.value.decode(errors="replace"))
     return int(n), log.value.decode()
 
 
@@ -93,7 +93,7 @@ def specialize_source(model_struct):
     buf = C.create_string_buffer(1 << 20)
     n = lib().demi_specialize_source(C.byref(model_struct), buf, len(buf))
     if n < 0:
-        raise DemiError(-n, buf.value.decode(errors="replace"))
+        raise DemiError(n, buf.value.decode(errors="replace"))
     return buf.value.decode()
 
 

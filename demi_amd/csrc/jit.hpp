@@ -16,6 +16,7 @@
 #include <dlfcn.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -131,6 +132,10 @@ struct Rtc {
     if (lib) return true;
     // prefer the hiprtc that ships next to the HIP runtime already mapped into this process
     std::vector<std::string> cands;
+    if (const char* only = getenv("DEMI_HIPRTC_LIB")) {      // an explicit library (tests use a bogus path to see the fallback)
+      lib = dlopen(only, RTLD_NOW | RTLD_LOCAL);
+      if (!lib) { err = std::string("hiprtc not found (DEMI_HIPRTC_LIB=") + only + ")"; return false; }
+    }
     Dl_info info;
     if (dladdr(reinterpret_cast<void*>(&hipGetDeviceCount), &info) && info.dli_fname) {
       std::string p(info.dli_fname);
@@ -140,8 +145,8 @@ struct Rtc {
     cands.push_back("libhiprtc.so.7");
     cands.push_back("libhiprtc.so");
     for (const std::string& c : cands) {
-      lib = dlopen(c.c_str(), RTLD_NOW | RTLD_LOCAL);
       if (lib) break;
+      lib = dlopen(c.c_str(), RTLD_NOW | RTLD_LOCAL);
     }
     if (!lib) { err = "hiprtc not found (dlopen libhiprtc.so failed)"; return false; }
     auto sym = [&](const char* n) { return dlsym(lib, n); };

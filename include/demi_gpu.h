@@ -196,8 +196,8 @@ int demi_model_load(demi_ctx* ctx, const demi_model* model);
  * drops the specialisation of the previous model.                                                         */
 int demi_model_specialize(demi_ctx* ctx, int enable);
 int demi_model_is_specialized(const demi_ctx* ctx);
-/* Device-free check of the same code generation + compilation (build / CI): code-object size in bytes, or
- * -demi_status with the reason in `log`.                                                                   */
+/* Device-free check of the same code generation + compilation (build / CI): code-object size in bytes, or the
+ * (negative) demi_status with the reason in `log`.                                                         */
 long demi_specialize_check(const demi_model* model, char* log, size_t log_cap);
 /* The generated handler source (C++), NUL-terminated, truncated to cap; returns its full length. */
 long demi_specialize_source(const demi_model* model, char* out, size_t cap);

@@ -103,3 +103,15 @@ def test_generated_handlers_equal_the_row_interpreter(oracle, tmp_path, name, mk
         assert got == want, (it, me, typ, hex(state), got, want)
         n_fx_seen += len(got)
     assert n_fx_seen > 1000
+
+
+def test_missing_runtime_compiler_is_reported_not_fatal(tmp_path):
+    """Without hiprtc the specialiser says so (the launch paths then keep the table interpreter); checked in a fresh
+    process because the hiprtc handle is opened once per process."""
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from demi_amd import _native, model as M\n"
+            "try:\n    _native.specialize_check(M.raft_model(3).to_struct())\n"
+            "except _native.DemiError as e:\n    print('ERR', e)\n" % ROOT)
+    env = dict(os.environ, DEMI_HIPRTC_LIB=str(tmp_path / "no_such_libhiprtc.so"))
+    out = subprocess.run([os.sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert "ERR" in out.stdout and "hiprtc not found" in out.stdout, out.stdout + out.stderr
