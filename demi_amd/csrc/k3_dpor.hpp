@@ -45,6 +45,9 @@ struct K3Args {
   uint32_t stride;
   uint64_t n;
   uint32_t depth_bound, max_messages, looking_for_valid, looking_for, p_max, max_pairs, prioritize;
+  uint32_t lanes_per_wave;           // simulators a wave runs at a time (8..64): a round of the backtrack queue is far
+                                     // smaller than the chip, and a wave analyses its finished traces one after the
+                                     // other, so few interleavings per wave on many waves finish sooner
   demi_verdict* out;
   demi_dpor_trace_entry* traces;     // [n][DEMI_DPOR_MAX_TRACE]
   uint32_t* trace_len;               // [n]
@@ -222,21 +225,21 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
 
   for (;;) {
     {
-      const uint64_t idle = __ballot(!active);
+      const uint64_t idle = __ballot(!active && lane < args.lanes_per_wave);
       if (idle != 0 && !exhausted) {
         const uint32_t want = (uint32_t)__popcll(idle);
         const uint64_t have = b_end - b_next;
         uint64_t got = 0;
         if (have < want) {
-          if (lane == 0) got = atomicAdd(args.work_counter, 64ull);
+          if (lane == 0) got = atomicAdd(args.work_counter, (unsigned long long)args.lanes_per_wave);
           got = __shfl(got, 0);
         }
-        if (!active) {
+        if (!active && lane < args.lanes_per_wave) {
           const uint32_t rank = (uint32_t)__popcll(idle & ((1ULL << lane) - 1));
           const uint64_t my = (rank < have) ? (b_next + rank) : (got + (rank - have));
           if (my < args.n) { sched = my; active = true; fresh = true; }
         }
-        if (have < want) { b_next = got + (want - have); b_end = got + 64; }
+        if (have < want) { b_next = got + (want - have); b_end = got + args.lanes_per_wave; }
         else b_next += want;
         if (b_next >= args.n) exhausted = true;
       }
