@@ -287,8 +287,9 @@ struct RawBuf {
   void* reserve(size_t bytes) {
     if (bytes > cap) {
       if (p) release(p);
-      p = alloc(bytes);
-      cap = p ? bytes : 0;
+      const size_t want = bytes + bytes / 2;      // grow geometrically: pinned allocations are expensive
+      p = alloc(want);
+      cap = p ? want : 0;
     }
     return p;
   }
@@ -298,9 +299,12 @@ template <class Run>
 int explore_loop(Run&& run, uint32_t max_pairs, const demi_dpor_search* srch, demi_verdict* out_verdicts,
                  uint32_t* out_prefix_len, uint32_t* out_rounds, demi_dpor_trace_entry* first_violation_trace,
                  uint32_t* first_violation_len, demi_dpor_stats* stats, double* seconds,
-                 void* (*alloc)(size_t) = nullptr, void (*release)(void*) = nullptr) {
-  if (!alloc || !release) { alloc = [](size_t b) { return malloc(b); }; release = [](void* q) { free(q); }; }
-  RawBuf tr_buf(alloc, release), pr_buf(alloc, release);
+                 RawBuf* trace_buf = nullptr, RawBuf* pair_buf = nullptr) {
+  // result buffers: the caller's (the library keeps pinned ones across calls) or malloc'ed ones for this call
+  RawBuf own_tr([](size_t b) { return malloc(b); }, [](void* q) { free(q); });
+  RawBuf own_pr([](size_t b) { return malloc(b); }, [](void* q) { free(q); });
+  RawBuf& tr_buf = trace_buf ? *trace_buf : own_tr;
+  RawBuf& pr_buf = pair_buf ? *pair_buf : own_pr;
   DporBook book(srch->track_history != 0);
   memset(stats, 0, sizeof *stats);
   stats->first_violation = ~0ull;
@@ -316,7 +320,7 @@ int explore_loop(Run&& run, uint32_t max_pairs, const demi_dpor_search* srch, de
     const size_t n = frontier.size();
     size_t stride = 1;
     for (auto& f : frontier) stride = f.size() > stride ? f.size() : stride;
-    pf.assign(n * stride, demi_dpor_trace_entry{});
+    pf.resize(n * stride);             // rows are read up to their prefix length only: the padding is never looked at
     pl.resize(n); tl.resize(n); np.resize(n); vd.resize(n);
     auto* tr = static_cast<demi_dpor_trace_entry*>(tr_buf.reserve(sizeof(demi_dpor_trace_entry) * DEMI_DPOR_MAX_TRACE * n));
     auto* pr = static_cast<demi_dpor_pair*>(pr_buf.reserve(sizeof(demi_dpor_pair) * (size_t)(max_pairs ? max_pairs : 1) * n));
