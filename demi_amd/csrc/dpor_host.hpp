@@ -270,11 +270,19 @@ class DporBook {
   std::vector<std::shared_ptr<Trace>> traces_;
 };
 
-// The exploration loop of DPORwHeuristics.test (:1193-1242) in rounds: run(...) executes one batch of next-traces
-// (demi_dpor_batch's argument order; the GPU in the library, anything with the same contract in a test harness).
-// seconds (optional): [0] run, [1] absorb, [2] get_next.
-// The two large per-round result arrays (traces, pairs) live in buffers from `alloc`/`release` (the library passes
-// pinned host memory so the device-to-host copies run at full PCIe rate; malloc/free elsewhere).
+// The exploration loop of DPORwHeuristics.test (:1193-1242) in rounds.
+//   run(prefixes, prefix_len, stride, n, verdicts, trace_len, n_pairs)  executes one batch of next-traces and returns the
+//       per-interleaving scalars (demi_dpor_batch's meaning; the GPU in the library, anything with the same contract in
+//       a test harness);
+//   fetch(lo, cnt, traces, pairs)  delivers the traces ([cnt][DEMI_DPOR_MAX_TRACE]) and racing pairs ([cnt][max_pairs])
+//       of interleavings lo .. lo + cnt of the last batch.
+// The bulky results are consumed chunk by chunk (bookkeeping is order-preserving, so a round absorbed in chunks is the
+// round absorbed at once): the staging buffers stay small, pinned and allocated once.
+// seconds (optional): [0] run, [1] fetch + absorb, [2] get_next.
+constexpr size_t EXPLORE_CHUNK = 1024;
+
+// A buffer from `alloc` / `release` (the library passes pinned host memory so the device-to-host copies run at full
+// PCIe rate; malloc / free elsewhere), grown geometrically.
 struct RawBuf {
   void* (*alloc)(size_t);
   void (*release)(void*);
@@ -287,24 +295,26 @@ struct RawBuf {
   void* reserve(size_t bytes) {
     if (bytes > cap) {
       if (p) release(p);
-      const size_t want = bytes + bytes / 2;      // grow geometrically: pinned allocations are expensive
-      p = alloc(want);
-      cap = p ? want : 0;
+      p = alloc(bytes);
+      cap = p ? bytes : 0;
     }
     return p;
   }
 };
 
-template <class Run>
-int explore_loop(Run&& run, uint32_t max_pairs, const demi_dpor_search* srch, demi_verdict* out_verdicts,
+template <class Run, class Fetch>
+int explore_loop(Run&& run, Fetch&& fetch, uint32_t max_pairs, const demi_dpor_search* srch, demi_verdict* out_verdicts,
                  uint32_t* out_prefix_len, uint32_t* out_rounds, demi_dpor_trace_entry* first_violation_trace,
                  uint32_t* first_violation_len, demi_dpor_stats* stats, double* seconds,
                  RawBuf* trace_buf = nullptr, RawBuf* pair_buf = nullptr) {
-  // result buffers: the caller's (the library keeps pinned ones across calls) or malloc'ed ones for this call
+  // staging buffers: the caller's (the library keeps pinned ones across calls) or malloc'ed ones for this call
   RawBuf own_tr([](size_t b) { return malloc(b); }, [](void* q) { free(q); });
   RawBuf own_pr([](size_t b) { return malloc(b); }, [](void* q) { free(q); });
   RawBuf& tr_buf = trace_buf ? *trace_buf : own_tr;
   RawBuf& pr_buf = pair_buf ? *pair_buf : own_pr;
+  auto* tr = static_cast<demi_dpor_trace_entry*>(tr_buf.reserve(sizeof(demi_dpor_trace_entry) * DEMI_DPOR_MAX_TRACE * EXPLORE_CHUNK));
+  auto* pr = static_cast<demi_dpor_pair*>(pr_buf.reserve(sizeof(demi_dpor_pair) * (size_t)(max_pairs ? max_pairs : 1) * EXPLORE_CHUNK));
+  if (!tr || !pr) return DEMI_ERR_INVALID_ARG;
   DporBook book(srch->track_history != 0);
   memset(stats, 0, sizeof *stats);
   stats->first_violation = ~0ull;
@@ -322,20 +332,18 @@ int explore_loop(Run&& run, uint32_t max_pairs, const demi_dpor_search* srch, de
     for (auto& f : frontier) stride = f.size() > stride ? f.size() : stride;
     pf.resize(n * stride);             // rows are read up to their prefix length only: the padding is never looked at
     pl.resize(n); tl.resize(n); np.resize(n); vd.resize(n);
-    auto* tr = static_cast<demi_dpor_trace_entry*>(tr_buf.reserve(sizeof(demi_dpor_trace_entry) * DEMI_DPOR_MAX_TRACE * n));
-    auto* pr = static_cast<demi_dpor_pair*>(pr_buf.reserve(sizeof(demi_dpor_pair) * (size_t)(max_pairs ? max_pairs : 1) * n));
-    if (!tr || !pr) return DEMI_ERR_INVALID_ARG;
     for (size_t i = 0; i < n; i++) {
       pl[i] = (uint32_t)frontier[i].size();
       if (pl[i]) memcpy(&pf[i * stride], frontier[i].data(), sizeof(demi_dpor_trace_entry) * pl[i]);
     }
     double t0 = now();
-    int rc = run(pf.data(), pl.data(), (uint32_t)stride, (uint64_t)n, vd.data(), tr, tl.data(), pr, np.data());
+    int rc = run(pf.data(), pl.data(), (uint32_t)stride, (uint64_t)n, vd.data(), tl.data(), np.data());
     if (rc) return rc;
     double t1 = now();
     if (out_rounds) out_rounds[stats->launches] = (uint32_t)n;
     stats->launches++;
     bool found = false;
+    size_t first_here = n;             // position in this round of the overall first violation, if it is in this round
     for (size_t i = 0; i < n; i++) {
       const uint64_t idx = stats->interleavings++;
       out_verdicts[idx] = vd[i];
@@ -343,15 +351,21 @@ int explore_loop(Run&& run, uint32_t max_pairs, const demi_dpor_search* srch, de
       if (vd[i].flags & DEMI_V_VIOLATION) {
         stats->violations++;
         found = true;
-        if (stats->first_violation == ~0ull) {
-          stats->first_violation = idx;
-          if (first_violation_trace) memcpy(first_violation_trace, &tr[i * DEMI_DPOR_MAX_TRACE], sizeof(demi_dpor_trace_entry) * tl[i]);
-          if (first_violation_len) *first_violation_len = tl[i];
-        }
+        if (stats->first_violation == ~0ull) { stats->first_violation = idx; first_here = i; }
       }
     }
-    // dpor(): bookkeeping for the racing pairs of the whole round (:1122-1139), sharded over host threads
-    book.absorb(tr, tl.data(), pr, np.data(), n, max_pairs);
+    // dpor(): bookkeeping for the racing pairs of the round (:1122-1139), chunk by chunk, sharded over host threads
+    for (size_t lo = 0; lo < n; lo += EXPLORE_CHUNK) {
+      const size_t cnt = n - lo < EXPLORE_CHUNK ? n - lo : EXPLORE_CHUNK;
+      rc = fetch(lo, cnt, tr, pr);
+      if (rc) return rc;
+      if (first_here >= lo && first_here < lo + cnt) {
+        const size_t k = first_here - lo;
+        if (first_violation_trace) memcpy(first_violation_trace, &tr[k * DEMI_DPOR_MAX_TRACE], sizeof(demi_dpor_trace_entry) * tl[first_here]);
+        if (first_violation_len) *first_violation_len = tl[first_here];
+      }
+      book.absorb(tr, tl.data() + lo, pr, np.data() + lo, cnt, max_pairs);
+    }
     double t2 = now();
     frontier.clear();
     if (srch->stop_if_violation && found) break;
