@@ -279,7 +279,7 @@ class DporBook {
 // The bulky results are consumed chunk by chunk (bookkeeping is order-preserving, so a round absorbed in chunks is the
 // round absorbed at once): the staging buffers stay small, pinned and allocated once.
 // seconds (optional): [0] run, [1] fetch + absorb, [2] get_next.
-constexpr size_t EXPLORE_CHUNK = 1024;
+constexpr size_t EXPLORE_CHUNK = 4096;
 
 // A buffer from `alloc` / `release` (the library passes pinned host memory so the device-to-host copies run at full
 // PCIe rate; malloc / free elsewhere), grown geometrically.
