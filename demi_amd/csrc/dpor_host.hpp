@@ -279,7 +279,10 @@ class DporBook {
 // The bulky results are consumed chunk by chunk (bookkeeping is order-preserving, so a round absorbed in chunks is the
 // round absorbed at once): the staging buffers stay small, pinned and allocated once.
 // seconds (optional): [0] run, [1] fetch + absorb, [2] get_next.
-constexpr size_t EXPLORE_CHUNK = 4096;
+#ifndef DEMI_EXPLORE_CHUNK
+#define DEMI_EXPLORE_CHUNK 4096
+#endif
+constexpr size_t EXPLORE_CHUNK = DEMI_EXPLORE_CHUNK;
 
 // A buffer from `alloc` / `release` (the library passes pinned host memory so the device-to-host copies run at full
 // PCIe rate; malloc / free elsewhere), grown geometrically.
