@@ -85,8 +85,13 @@ __host__ __device__ inline size_t k1_lds_bytes(uint32_t code_len, uint32_t n_ev,
          K1_WAVES * (lane_mem_wave_bytes(n_actors, REC, hot) + (FIFO ? k1_fifo_wave_bytes(n_actors, REC) : 0));
 }
 
+#ifdef DEMI_K1_MIN_WAVES_PER_EU    // experiment knob of the specialised build: ask for more waves per SIMD (fewer VGPRs)
+#define K1_LAUNCH_BOUNDS __launch_bounds__(K1_WAVES * 64, DEMI_K1_MIN_WAVES_PER_EU)
+#else
+#define K1_LAUNCH_BOUNDS __launch_bounds__(K1_WAVES * 64)
+#endif
 template <bool REC, bool FIFO = false>
-__global__ __launch_bounds__(K1_WAVES * 64) void k1_random_explore(const K1Args args) {
+__global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Tables t;
   unsigned char* extra = tables_load(t, smem, args.model, args.trace, args.n_ev, args.exists);
