@@ -2,7 +2,7 @@
 # Experiment: LDS-resident pending slots x requested waves per SIMD of the specialised K1 (bench line per setting)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
-for cfg in "8 0" "4 6" "5 6" "8 6" "4 0"; do
+for cfg in "0 0" "0 6" "2 0" "2 6" "5 6"; do
   set -- $cfg
   export DEMI_JIT_K1_HOT=$1
   if [ "$2" != "0" ]; then export DEMI_JIT_K1_WAVES_PER_EU=$2; else unset DEMI_JIT_K1_WAVES_PER_EU; fi
