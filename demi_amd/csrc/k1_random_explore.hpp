@@ -48,10 +48,11 @@ struct K1Args {
 enum : int { PH_IDLE = 0, PH_INJECT = 1, PH_DISPATCH = 2, PH_FINISH = 3 };
 
 constexpr int K1_WAVES = 4;          // waves per workgroup
-// LDS-resident pending slots per lane in K1.  The interpreter is VALU-bound and wants residency (32: 12 waves/CU);
-// the specialised build issues as many scalar as vector instructions and gains more from five workgroups per CU
-// (20 waves: VALU and SALU of different waves issue together) than it loses to spills: the host sets it to 8 there
-// (measured on raft5: 8 -> 5.64 ms, 12 -> 6.14, 16 -> 6.02, 20 / 24 -> 6.6 per 2^20 schedules).
+// LDS-resident pending slots per lane in K1.  The interpreter is VALU-bound and wants residency (32: 12 waves/CU).  The
+// specialised build issues as many scalar as vector instructions: it gains from more waves per CU (VALU and SALU of
+// different waves issue together) and loses on every `slot < hot ? LDS : scratch` branch that splits a wave, so the host
+// gives it none at all: every pending slot then lives in the coalesced [slot][lane] scratch, which the L2 serves
+// (measured on raft5, ms per 2^20 schedules: 0 -> 4.84, 2 -> 5.41, 4 -> 5.35, 8 -> 5.62, 16 -> 6.02, 24 / 32 -> 6.6).
 #ifndef DEMI_K1_HOT
 #define DEMI_K1_HOT DEMI_PEND_HOT
 #endif
