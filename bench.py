@@ -128,7 +128,8 @@ def main():
         # algorithmic bytes of one K1 launch: 16 B verdict per schedule out, plus the
         # trace and the transition table streamed once per workgroup
         # the trace and the tables are streamed once per resident workgroup (3 per CU at this LDS footprint)
-        blocks = min((n + 255) // 256, torch.cuda.get_device_properties(dev).multi_processor_count * (2 if args.strategy == "fifo" else 3))
+        blocks = min((n + 255) // 256, torch.cuda.get_device_properties(dev).multi_processor_count *
+                     ((3 if specialized else 2) if args.strategy == "fifo" else (6 if specialized else 3)))
         shared = 8 * len(events) + 4 * len(model.code) + 4 * len(model.handler_start) + 8 * 8 + 32 * 4 + 132 * 4 + 64 * 4
         alg_bytes = 16 * n + blocks * shared
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
@@ -177,8 +178,9 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "integer/LDS-bound simulation: algorithmic HBM traffic is 16 B per schedule, so the "
                                  "HBM fraction is tiny by construction (SURVEY 8d); see DESIGN.md for the issue-rate model. "
-                                 "traffic above the algorithmic bytes is the pending-set spill of the specialised build "
-                                 "(8 LDS-resident slots per lane for 20 waves/CU), not re-reads of inputs",
+                                 "traffic above the algorithmic bytes is the pending sets of the specialised build, kept in "
+                                 "an HBM scratch instead of LDS (24 waves/CU, no divergent LDS/scratch branch): a measured "
+                                 "trade, DESIGN.md section 4 K1; it is working-set traffic, not re-reads of inputs",
                          "issue_model": issue},
         }
         if not args.no_cpu_baseline and world == 1:
