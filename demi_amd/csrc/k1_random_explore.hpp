@@ -37,7 +37,7 @@ struct K1Args {
   demi_verdict* out;
   unsigned long long* work_counter;  // zeroed before every launch
   uint32_t p_max;           // pending-set capacity of the spec (<= DEMI_MAX_PENDING)
-  uint32_t* spill;          // HBM scratch for pending slots >= PEND_HOT: spill_words(total lanes) (x2 for REC)
+  uint32_t* spill;          // HBM scratch for pending slots >= K1_HOT (and the SrcDstFIFO arrays): k1_spill_words_per_lane
   demi_rec_event* rec_out;  // REC only: [n][rec_cap]
   uint32_t* rec_count;      // REC only: [n]
   uint32_t rec_cap;
@@ -51,8 +51,9 @@ constexpr int K1_WAVES = 4;          // waves per workgroup
 // LDS-resident pending slots per lane in K1.  The interpreter is VALU-bound and wants residency (32: 12 waves/CU).  The
 // specialised build issues as many scalar as vector instructions: it gains from more waves per CU (VALU and SALU of
 // different waves issue together) and loses on every `slot < hot ? LDS : scratch` branch that splits a wave, so the host
-// gives it none at all: every pending slot then lives in the coalesced [slot][lane] scratch, which the L2 serves
-// (measured on raft5, ms per 2^20 schedules: 0 -> 4.84, 2 -> 5.41, 4 -> 5.35, 8 -> 5.62, 16 -> 6.02, 24 / 32 -> 6.6).
+// gives it none at all: every pending slot then lives in the coalesced [slot][lane] HBM scratch.  That is the fastest
+// setting and the one with the most HBM traffic (DESIGN.md section 4 has the table; measured on raft5, ms per 2^20
+// schedules: 0 -> 4.84, 2 -> 5.41, 4 -> 5.35, 8 -> 5.62, 16 -> 6.02, 24 / 32 -> 6.6).
 #ifndef DEMI_K1_HOT
 #define DEMI_K1_HOT DEMI_PEND_HOT
 #endif
