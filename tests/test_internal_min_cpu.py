@@ -203,3 +203,102 @@ def test_left_to_right_result_is_one_pass_minimal_on_a_chain(oracle):
     after = Counter(k[2][0] for k in getFingerprintedDeliveries(out))
     assert after == Counter({0: 2, 1: 2})            # both Noise deliveries pruned, Kicks (external) and Pings stay
     assert stats.total_replays == 4                   # 2 Pings tried and kept, 2 Noises tried and dropped
+
+
+class _ScalaSrcDstFIFORemoval:
+    """OneAtATimeRemoval.scala:141-251 transliterated with the reference's own data structures (HashMap of Vectors,
+    MultiSets as Counters, flatMap over the whole trace), to cross-check demi_amd's index-returning version."""
+
+    def __init__(self, verified, model):
+        self.verified = verified
+        self.tried = Counter()
+        for e in verified.events:
+            if e["kind"] == T.REC_MSG_EVENT and model.msg_class[int(e["msg_type"])] == T.MSG_EXTERNAL:
+                self.tried[self._key(e)] += 1
+        self.srcDstToMessages = {}
+        for e in verified.events:
+            if e["kind"] == T.REC_MSG_EVENT and int(e["snd"]) != T.DEADLETTERS:
+                self.srcDstToMessages.setdefault((int(e["snd"]), int(e["rcv"])), []).append(self._key(e)[2])
+        self.previouslyChosenSrcDst = None
+        self.srcDstToCurrentIdx = {}
+        self._reset()
+
+    @staticmethod
+    def _key(e):
+        return (int(e["snd"]), int(e["rcv"]), (int(e["msg_type"]), int(e["p0"]), int(e["p1"])))
+
+    def _reset(self):
+        for k in self.srcDstToMessages:
+            self.srcDstToCurrentIdx[k] = -1
+
+    def choiceFilter(self, snd, rcv, fp):
+        if (snd, rcv) in self.srcDstToMessages:
+            self.srcDstToCurrentIdx[(snd, rcv)] += 1
+            idx = self.srcDstToCurrentIdx[(snd, rcv)]
+            lst = self.srcDstToMessages[(snd, rcv)]
+            if idx == len(lst) - 1:
+                self.srcDstToMessages[(snd, rcv)] = lst[:-1]
+                if not self.srcDstToMessages[(snd, rcv)]:
+                    del self.srcDstToMessages[(snd, rcv)]
+                self.previouslyChosenSrcDst = (snd, rcv)
+                return True
+        self.previouslyChosenSrcDst = None
+        return snd == T.DEADLETTERS
+
+    def getNextTrace(self, trace, alreadyRemoved, violationTriggeredLastRun):
+        if not violationTriggeredLastRun and self.previouslyChosenSrcDst is not None:
+            self.srcDstToMessages.pop(self.previouslyChosenSrcDst, None)
+        if violationTriggeredLastRun:
+            self.srcDstToMessages.clear()
+            copy = Counter(alreadyRemoved)
+            for e in self.verified.events[::-1]:
+                if e["kind"] != T.REC_MSG_EVENT or int(e["snd"]) == T.DEADLETTERS:
+                    continue
+                t = self._key(e)
+                if copy[t] > 0:
+                    copy[t] -= 1
+                else:
+                    self.srcDstToMessages[(t[0], t[1])] = [t[2]] + self.srcDstToMessages.get((t[0], t[1]), [])
+        self._reset()
+        keysThisIteration = Counter(alreadyRemoved)
+        found = [False]
+
+        def checkDelivery(key):
+            keysThisIteration[key] += 1
+            if found[0]:
+                return True
+            if keysThisIteration[key] > self.tried[key] and self.choiceFilter(*key):
+                found[0] = True
+                self.tried[key] += 1
+                return False
+            return True
+
+        kept = [i for i, e in enumerate(trace.events) if e["kind"] != T.REC_MSG_EVENT or checkDelivery(self._key(e))]
+        return kept if found[0] else None
+
+
+@pytest.mark.parametrize("skip", [0, 1])
+def test_srcdst_fifo_removal_matches_the_scala_transliteration(oracle, skip):
+    """Drive both versions through a whole minimization (successes and failures as the oracle decides them) and
+    compare every proposed trace."""
+    model, events, lim = raft5_config2()
+    trace, fp = _verified_mcs(oracle, model, events, lim, skip)
+    ours, ref = SrcDstFIFORemoval(trace, model), _ScalaSrcDstFIFORemoval(trace, model)
+    orc = OracleRemoval(oracle, model)
+    last, pruned, triggered, steps = EventTrace(trace.events, trace.original_externals), Counter(), False, 0
+    while True:
+        kept = ref.getNextTrace(last, pruned, triggered)
+        nxt = ours.getNextTrace(last, pruned, triggered)
+        if kept is None:
+            assert nxt is None
+            break
+        assert (nxt.events == last.events[kept]).all()
+        removed = [i for i in range(len(last.events)) if i not in set(kept)]
+        assert len(removed) == 1
+        executed = orc.executed(last, removed[0], fp)
+        triggered = executed is not None
+        if triggered:
+            pruned += Counter(getFingerprintedDeliveries(last)) - Counter(getFingerprintedDeliveries(executed))
+            last = EventTrace(executed.events, trace.original_externals)
+        steps += 1
+    assert steps > 10
