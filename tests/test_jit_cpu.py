@@ -115,3 +115,108 @@ def test_missing_runtime_compiler_is_reported_not_fatal(tmp_path):
     env = dict(os.environ, DEMI_HIPRTC_LIB=str(tmp_path / "no_such_libhiprtc.so"))
     out = subprocess.run([os.sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert "ERR" in out.stdout and "hiprtc not found" in out.stdout, out.stdout + out.stderr
+
+
+def _random_handler(rng, n_rows, n_types):
+    """A random valid handler: every op of the table, forward skips / guards of random length, registers and
+    immediates mixed."""
+    a = M.Asm()
+    regs = [M.Reg(i) for i in range(16)]
+    alu = ["add", "sub", "and_", "or_", "xor", "shl", "shr", "bitset", "eq", "ne", "lt", "ge", "le", "gt", "min", "max"]
+    pending = []                      # labels that must still be placed
+    for i in range(n_rows):
+        for lab in [l for l in pending if l[1] == i]:
+            a.label(lab[0]); pending.remove(lab)
+        k = int(rng.integers(0, 100))
+        breg = lambda: regs[int(rng.integers(16))] if rng.integers(2) else int(rng.integers(256))
+        if k < 45:
+            getattr(a, alu[int(rng.integers(len(alu)))])(regs[int(rng.integers(12))], regs[int(rng.integers(16))], breg())
+        elif k < 52:
+            a.mov(regs[int(rng.integers(12))], breg())
+        elif k < 56:
+            a.popc(regs[int(rng.integers(12))], breg())
+        elif k < 78:
+            name = "L%d" % i
+            tgt = i + 1 + int(rng.integers(0, min(6, n_rows - i)))
+            pending.append((name, tgt))
+            c = int(rng.integers(0, 9))
+            if c < 6:
+                getattr(a, ["if_eq", "if_ne", "if_lt", "if_ge", "if_le", "if_gt"][c])(regs[int(rng.integers(16))], breg(), name)
+            elif c == 6:
+                a.skipz(regs[int(rng.integers(16))], name)
+            elif c == 7:
+                a.skipnz(regs[int(rng.integers(16))], name)
+            else:
+                a.skip(name)
+        elif k < 88:
+            a.send(int(rng.integers(1, 3)), regs[int(rng.integers(16))], regs[int(rng.integers(16))], breg())   # internal types
+        elif k < 92:
+            a.bcast(int(rng.integers(1, 3)), regs[int(rng.integers(16))], breg())
+        elif k < 95:
+            a.tset(n_types - 1)
+        elif k < 97:
+            a.trep(n_types - 1)
+        elif k < 99:
+            a.tcancel(n_types - 1)
+        else:
+            a.halt()
+    for lab in pending:
+        if lab[0] not in a._labels:
+            a.label(lab[0])
+    return a
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_random_programs_through_the_code_generator(oracle, tmp_path, seed):
+    """Every op, random control flow, two actor classes: generated C++ == the oracle's row interpreter, delivery by
+    delivery (state, effect rows, FX_CAP overflow)."""
+    rng = np.random.default_rng(seed)
+    MSGS = [("E", T.MSG_EXTERNAL), ("A", T.MSG_INTERNAL), ("B", T.MSG_INTERNAL), ("Tm", T.MSG_TIMER)]
+    h = {}
+    for cls in range(2):
+        for name, _ in MSGS:
+            if rng.integers(5):
+                h[(cls, name)] = _random_handler(rng, int(rng.integers(3, 40)), len(MSGS))
+    A = 5
+    model = M.build_model("rand%d" % seed, A, MSGS, h, [[0] * 8] * A, (T.INV_NEVER, 0, 200, 0),
+                          actor_class=[0, 1, 0, 1, 1], n_classes=2)
+    L = _host_vm(model, tmp_path)
+    ms = model.to_struct()
+    NT = len(MSGS)
+    hs = np.full(T.MAX_CLASSES * T.MAX_MSG_TYPES, 0xFFFF, dtype=np.uint32)
+    hs[:len(model.handler_start)] = model.handler_start
+    ac = sum((c & 15) << (4 * i) for i, c in enumerate(model.actor_class))
+    st = np.zeros(8 * 64, dtype=np.uint64)
+    fxq = np.zeros(FX_CAP * 64, dtype=np.uint32)
+    fx = (C.c_uint8 * (5 * 64))()
+    seen_ovf = seen_fx = 0
+    for it in range(6000):
+        me, typ = int(rng.integers(A)), int(rng.integers(NT))
+        src = int(rng.choice([int(rng.integers(A)), T.DEADLETTERS]))
+        p0, p1 = int(rng.integers(256)), int(rng.integers(256))
+        state = int.from_bytes(bytes(int(x) for x in rng.integers(0, 256, 8)), "little")
+        w = typ | (me << 5) | (src << 8) | (p0 << 16) | (p1 << 24)
+        st[me * 64] = state
+        flags = C.c_uint32(0)
+        n = L.run(hs.ctypes.data, ac, NT, st.ctypes.data, fxq.ctypes.data, w, C.byref(flags))
+        want_state = C.c_uint64(state)
+        wn = oracle.lib().orc_vm_run(C.byref(ms), me, C.byref(want_state), typ, src, p0, p1, (1 << A) - 1, fx, 64)
+        if wn < 0:
+            assert flags.value & T.V_QUEUE_OVF
+            seen_ovf += 1
+            continue
+        assert not flags.value and int(st[me * 64]) == want_state.value, (it, me, typ, hex(state))
+        got = []
+        for k in range(n):
+            f = int(fxq[k * 64])
+            op, t_, target, q0, q1 = f & 31, (f >> 5) & 31, (f >> 10) & 15, (f >> 14) & 255, (f >> 22) & 255
+            if op == M.OPS["SEND"]:
+                if target < A:
+                    got.append((0, target, t_, q0, q1))
+            elif op == M.OPS["BCAST"]:
+                got += [(0, r, t_, q0, q1) for r in range(A) if r != me]
+            else:
+                got.append((1 + op - M.OPS["TSET"], me, t_, 0, 0))
+        assert got == [tuple(fx[5 * k + j] for j in range(5)) for k in range(wn)], (it, me, typ)
+        seen_fx += len(got)
+    assert seen_fx > 200
