@@ -117,9 +117,9 @@ def test_missing_runtime_compiler_is_reported_not_fatal(tmp_path):
     assert "ERR" in out.stdout and "hiprtc not found" in out.stdout, out.stdout + out.stderr
 
 
-def _random_handler(rng, n_rows, n_types):
+def _random_handler(rng, n_rows, n_types, few_effects=False):
     """A random valid handler: every op of the table, forward skips / guards of random length, registers and
-    immediates mixed."""
+    immediates mixed.  few_effects: effect rows are rare (whole executions then stay within the capacities)."""
     a = M.Asm()
     regs = [M.Reg(i) for i in range(16)]
     alu = ["add", "sub", "and_", "or_", "xor", "shl", "shr", "bitset", "eq", "ne", "lt", "ge", "le", "gt", "min", "max"]
@@ -128,6 +128,8 @@ def _random_handler(rng, n_rows, n_types):
         for lab in [l for l in pending if l[1] == i]:
             a.label(lab[0]); pending.remove(lab)
         k = int(rng.integers(0, 100))
+        if few_effects and k >= 78 and rng.integers(0, 4):
+            k = int(rng.integers(0, 78))
         breg = lambda: regs[int(rng.integers(16))] if rng.integers(2) else int(rng.integers(256))
         if k < 45:
             getattr(a, alu[int(rng.integers(len(alu)))])(regs[int(rng.integers(12))], regs[int(rng.integers(16))], breg())

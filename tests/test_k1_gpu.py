@@ -393,3 +393,28 @@ def test_fifo_golden_fixture_on_gpu(gpu_ctx):
     gpu_ctx.model_load(model.to_struct())
     gpu_ctx.trace_load(events)
     assert_same(gpu_ctx.random_explore(len(want), _fifo(lim), seed_base=SEED_BASE), want)
+
+
+@pytest.mark.parametrize("seed", [1, 3, 13])
+def test_random_programs_interpreter_specialised_and_oracle_agree(gpu_ctx, oracle, seed):
+    """Random transition tables (every op, random forward control flow, two actor classes, timers): the table
+    interpreter, the kernel compiled from the table and the oracle give the same verdict for every schedule."""
+    from .test_jit_cpu import _random_handler
+    rng = np.random.default_rng(seed)
+    MSGS = [("E", T.MSG_EXTERNAL), ("A", T.MSG_INTERNAL), ("B", T.MSG_INTERNAL), ("Tm", T.MSG_TIMER)]
+    h = {}
+    for cls in range(2):
+        for name, _ in MSGS:
+            if rng.integers(5):
+                h[(cls, name)] = _random_handler(rng, int(rng.integers(3, 30)), len(MSGS), few_effects=True)
+    model = M.build_model("rand%d" % seed, 5, MSGS, h, [[0] * 8] * 5, (T.INV_NEVER, 0, 200, 0),
+                          actor_class=[0, 1, 0, 1, 1], n_classes=2)
+    ev = [start(a) for a in range(5)]
+    for i in range(40):
+        ev.append(wait_quiescence() if rng.integers(0, 7) == 0 and ev[-1][0] != T.EV_WAIT_QUIESCENCE
+                  else send(int(rng.integers(0, 5)), 0, int(rng.integers(0, 256))))
+    g, c = both(gpu_ctx, oracle, model, events_to_array(ev), 4000, T.Limits(150, 9, 64, 0, 0, 0), jit=True)
+    assert_same(g, c)
+    assert len(np.unique(g["hash"])) > 900
+    gf, cf = both(gpu_ctx, oracle, model, events_to_array(ev), 2000, _fifo(T.Limits(60, 0, 20, 0, 0, 0)), jit=True)
+    assert_same(gf, cf)
