@@ -211,3 +211,88 @@ def test_sharded_frontier_evaluation_gloo_world2(tmp_path):
     outs = [p.communicate(timeout=300)[0].decode() for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0 and "ok" in o, o
+
+
+def _scala_subsequence_intersection(rec, externals, subseq, model):
+    """EventTrace.subsequenceIntersection + filterSends (EventTrace.scala:290-452, filterKnownAbsents = false)
+    transliterated over the recorded-event array; returns the indices of the events that survive."""
+    EXT_OF_REC = {T.REC_SPAWN: T.EV_START, T.REC_KILL: T.EV_KILL, T.REC_PARTITION: T.EV_PARTITION,
+                  T.REC_UNPARTITION: T.EV_UNPARTITION}
+    remaining = [i for i in subseq if int(externals[i]["kind"]) != T.EV_SEND]
+    result = []
+    for idx, e in enumerate(rec):
+        kind = int(e["kind"])
+        is_msg = kind in (T.REC_MSG_SEND, T.REC_MSG_EVENT)
+        is_external_kind = kind in EXT_OF_REC
+        if not remaining:
+            if is_msg or not is_external_kind:
+                result.append(idx)
+            continue
+        if is_external_kind:
+            x = externals[remaining[0]]
+            if kind in (T.REC_SPAWN, T.REC_KILL):
+                same = int(x["kind"]) == EXT_OF_REC[kind] and int(x["a"]) == int(e["rcv"])
+            else:
+                same = int(x["kind"]) == EXT_OF_REC[kind] and int(x["a"]) == int(e["snd"]) and int(x["b"]) == int(e["rcv"])
+            if same:
+                result.append(idx)
+                remaining = remaining[1:]
+        else:
+            result.append(idx)
+    # filterSends: the k-th external MsgSend belongs to the k-th Send of the original externals
+    original_sends = [i for i in range(len(externals)) if int(externals[i]["kind"]) == T.EV_SEND]
+    subseq_sends = {i for i in subseq if int(externals[i]["kind"]) == T.EV_SEND}
+    missing = {k for k, i in enumerate(original_sends) if i not in subseq_sends}
+    msg_send_idx, pruned_ids, out = -1, set(), []
+    for idx in result:
+        e = rec[idx]
+        kind = int(e["kind"])
+        if kind == T.REC_MSG_SEND:
+            if model.msg_class[int(e["msg_type"])] == T.MSG_EXTERNAL:
+                msg_send_idx += 1
+                if msg_send_idx in missing:
+                    pruned_ids.add(int(e["id"]))
+                    continue
+            out.append(idx)
+        elif kind == T.REC_MSG_EVENT:
+            if int(e["id"]) not in pruned_ids:
+                out.append(idx)
+        else:
+            out.append(idx)
+    return out
+
+
+def test_projection_equals_the_scala_transliteration(oracle):
+    """For random subsequences (atoms respected or not): what the oracle's replay keeps is exactly what
+    subsequenceIntersection + filterSends let through — external events and external MsgSends one for one, and every
+    delivered MsgEvent is a projected one (projected but absent ones are the ignored deliveries)."""
+    model = M.raft_model(5, election_budget=2)
+    from demi_amd.fuzzer import FuzzerWeights, raft_trace
+    w = FuzzerWeights(kill=0.12, send=0.4, wait_quiescence=0.13, partition=0.2, unpartition=0.15)
+    rng = np.random.default_rng(9)
+    checked = 0
+    for seed in (1, 2, 3):
+        events = events_to_array(raft_trace(5, 70, seed, w, exact=False))
+        lim = T.Limits(300, 10, 128, 0, 0, 0)
+        vv, rec, _ = oracle.random_execute(model, events, SEED_BASE + seed, lim)
+        used = events[:T.verdict_trace_idx(vv.flags)]
+        target = T.Limits(0, 0, 128, 1, vv.fingerprint if vv.fingerprint else 0x1000103, 0)
+        noq = [i for i in range(len(used)) if int(used[i]["kind"]) != T.EV_WAIT_QUIESCENCE]
+        for _ in range(40):
+            subseq = [i for i in noq if rng.random() < rng.choice([0.4, 0.7, 0.95])]
+            mask = np.array(events_to_mask(subseq), dtype=np.uint64)
+            v, kept = oracle.sts_removal_kept(model, used, rec, 0xFFFFFFFF, target, mask=mask)
+            if v.flags & (T.V_PENDING_OVF | T.V_QUEUE_OVF):
+                continue
+            proj = set(_scala_subsequence_intersection(rec, used, subseq, model))
+            kinds = rec["kind"]
+            ext_events = set(np.nonzero(kinds <= T.REC_UNPARTITION)[0].tolist())
+            ext_sends = set(np.nonzero((kinds == T.REC_MSG_SEND) & ((rec["flags"] & 1) == 1))[0].tolist())
+            msg_events = set(np.nonzero(kinds == T.REC_MSG_EVENT)[0].tolist())
+            kept_set = set(np.nonzero(kept)[0].tolist())
+            assert kept_set & ext_events == proj & ext_events
+            assert kept_set & ext_sends == proj & ext_sends
+            assert kept_set & msg_events <= proj & msg_events
+            assert bool(v.flags & T.V_DIVERGED) == (len(proj & msg_events) > len(kept_set & msg_events))
+            checked += 1
+    assert checked > 80
