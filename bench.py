@@ -121,6 +121,17 @@ def main():
     parts = gathered if world > 1 else [viol]
     vset = merge_violation_sets([p.cpu().numpy() for p in parts], VIOL_CAP)
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
+    # distinct violating schedules by delivery-sequence hash: this rank's shard of the last step
+    distinct_hashes = None
+    try:
+        mine = vset[(vset["index"] >= index_base) & (vset["index"] < index_base + n)]
+        if len(mine):
+            sel = torch.as_tensor((mine["index"] - index_base).astype(np.int64), device=dev)
+            distinct_hashes = int(torch.unique(verdicts[sel, 1]).numel())
+        else:
+            distinct_hashes = 0
+    except Exception as e:           # never let a statistic break the bench line
+        print("bench: delivery-hash statistic unavailable: %s" % e, file=sys.stderr)
 
     if rank == 0:
         total = world * n * args.steps
@@ -169,6 +180,7 @@ def main():
                        "table_compiled_to_native_code": specialized, "seed_base": SEED_BASE, "parallelism": "schedule-index range sharded, %d rank(s)" % world},
             "violations_last_step": int(len(vset)),
             "distinct_fingerprints_last_step": int(len(np.unique(vset["fingerprint"]))) if len(vset) else 0,
+            "distinct_violating_delivery_hashes_last_step_rank0_shard": distinct_hashes,
             "bugs_per_hr": float(len(vset)) / (dt / args.steps) * 3600.0,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
