@@ -62,6 +62,40 @@ inline std::string generate_vm(const demi::DevModel& h) {
     return "L" + std::to_string(pc);
   };
   const char* relop[6] = {"==", "!=", "<", ">=", "<=", ">"};     // EQ NE LT GE LE GT
+  // Optional if-conversion (DEMI_JIT_IFCONVERT = longest guarded run, 0 / unset = off): a fused guard over a short
+  // run of pure ALU rows, none of which is a jump target or a handler entry, becomes selects instead of a branch
+  // (fewer exec-mask manipulations on the scalar unit).  Same semantics: a skipped ALU row leaves its register alone.
+  uint32_t ifconv = 0;
+  if (const char* e = getenv("DEMI_JIT_IFCONVERT")) { const long x = strtol(e, nullptr, 10); ifconv = x > 0 && x < 16 ? (uint32_t)x : 0; }
+  std::vector<uint8_t> is_target(h.code_len + 1, 0);
+  for (uint32_t st : starts) is_target[st] = 1;
+  for (uint32_t pc = 0; pc < h.code_len; pc++) {
+    const uint32_t row = h.code[pc], cw = op_control(row & 0x3Fu);
+    uint32_t t = h.code_len;
+    if (cw & CW_IF) t = pc + 1 + ((row >> 17) & 0x7Fu);
+    else if (cw & (CW_SKIPZ | CW_SKIPNZ | CW_SKIP)) t = pc + 1 + (row >> 24);
+    if (t < h.code_len) is_target[t] = 1;
+  }
+  std::vector<int32_t> pred_of(h.code_len, -1);      // row -> the guard row whose predicate it runs under, if converted
+  for (uint32_t pc = 0; ifconv && pc < h.code_len; pc++) {
+    const uint32_t row = h.code[pc];
+    if (!(op_control(row & 0x3Fu) & CW_IF) || pred_of[pc] >= 0) continue;
+    const uint32_t len = (row >> 17) & 0x7Fu;
+    if (len == 0 || len > ifconv || pc + 1 + len > h.code_len) continue;
+    bool ok = true;
+    for (uint32_t q = pc + 1; q <= pc + len && ok; q++)
+      ok = (op_control(h.code[q] & 0x3Fu) & CW_ALU) && !is_target[q] && pred_of[q] < 0;
+    if (!ok) continue;
+    for (uint32_t q = pc + 1; q <= pc + len; q++) pred_of[q] = (int32_t)pc;
+  }
+  // the predicates are declared before the dispatch switch: no goto may cross an initialisation
+  std::string preds;
+  for (uint32_t pc = 0; pc + 1 < h.code_len; pc++)
+    if (pred_of[pc + 1] == (int32_t)pc) preds += "  bool c" + std::to_string(pc) + " = false;\n";
+  if (!preds.empty()) {
+    const size_t at = s.find("  switch (entry) {");
+    s.insert(at, preds);
+  }
   for (uint32_t pc = 0; pc < h.code_len; pc++) {
     const uint32_t row = h.code[pc];
     const uint32_t op = row & 0x3Fu, dsti = (row >> 8) & 15u, ai = (row >> 12) & 15u, aux = (row >> 17) & 0x7Fu,
@@ -78,24 +112,29 @@ inline std::string generate_vm(const demi::DevModel& h) {
       continue;
     }
     if (cw & CW_ALU) {
+      char val[96];
       switch (op) {
-        case DEMI_OP_MOV: emit("%s = %s & 255u;", d, b); break;
-        case DEMI_OP_ADD: emit("%s = (%s + %s) & 255u;", d, a, b); break;
-        case DEMI_OP_SUB: emit("%s = (%s - %s) & 255u;", d, a, b); break;
-        case DEMI_OP_AND: emit("%s = %s & %s & 255u;", d, a, b); break;
-        case DEMI_OP_OR: emit("%s = (%s | %s) & 255u;", d, a, b); break;
-        case DEMI_OP_XOR: emit("%s = (%s ^ %s) & 255u;", d, a, b); break;
-        case DEMI_OP_SHL: emit("%s = (%s << (%s & 7u)) & 255u;", d, a, b); break;
-        case DEMI_OP_SHR: emit("%s = (%s >> (%s & 7u)) & 255u;", d, a, b); break;
-        case DEMI_OP_BITSET: emit("%s = (%s | (1u << (%s & 7u))) & 255u;", d, a, b); break;
-        case DEMI_OP_POPC: emit("%s = (uint32_t)__popc(%s);", d, b); break;
-        case DEMI_OP_MIN: emit("%s = %s < %s ? %s : %s;", d, a, b, a, b); break;
-        case DEMI_OP_MAX: emit("%s = %s < %s ? %s : %s;", d, a, b, b, a); break;
-        default: emit("%s = (%s %s %s) ? 1u : 0u;", d, a, relop[op - DEMI_OP_EQ], b); break;   // EQ .. GT
+        case DEMI_OP_MOV: snprintf(val, sizeof val, "%s & 255u", b); break;
+        case DEMI_OP_ADD: snprintf(val, sizeof val, "(%s + %s) & 255u", a, b); break;
+        case DEMI_OP_SUB: snprintf(val, sizeof val, "(%s - %s) & 255u", a, b); break;
+        case DEMI_OP_AND: snprintf(val, sizeof val, "%s & %s & 255u", a, b); break;
+        case DEMI_OP_OR: snprintf(val, sizeof val, "(%s | %s) & 255u", a, b); break;
+        case DEMI_OP_XOR: snprintf(val, sizeof val, "(%s ^ %s) & 255u", a, b); break;
+        case DEMI_OP_SHL: snprintf(val, sizeof val, "(%s << (%s & 7u)) & 255u", a, b); break;
+        case DEMI_OP_SHR: snprintf(val, sizeof val, "(%s >> (%s & 7u)) & 255u", a, b); break;
+        case DEMI_OP_BITSET: snprintf(val, sizeof val, "(%s | (1u << (%s & 7u))) & 255u", a, b); break;
+        case DEMI_OP_POPC: snprintf(val, sizeof val, "(uint32_t)__popc(%s)", b); break;
+        case DEMI_OP_MIN: snprintf(val, sizeof val, "%s < %s ? %s : %s", a, b, a, b); break;
+        case DEMI_OP_MAX: snprintf(val, sizeof val, "%s < %s ? %s : %s", a, b, b, a); break;
+        default: snprintf(val, sizeof val, "(%s %s %s) ? 1u : 0u", a, relop[op - DEMI_OP_EQ], b); break;   // EQ .. GT
       }
-      s += "\n";
+      if (pred_of[pc] >= 0) emit("%s = c%d ? (%s) : %s;\n", d, pred_of[pc], val, d);
+      else emit("%s = %s;\n", d, val);
     } else if (cw & CW_IF) {
-      emit("if (!(%s %s %s)) goto %s;\n", a, relop[op - DEMI_OP_IFEQ], b, target(pc + 1 + aux).c_str());
+      if (pc + 1 < h.code_len && pred_of[pc + 1] == (int32_t)pc)
+        emit("c%u = (%s %s %s);\n", pc, a, relop[op - DEMI_OP_IFEQ], b);
+      else
+        emit("if (!(%s %s %s)) goto %s;\n", a, relop[op - DEMI_OP_IFEQ], b, target(pc + 1 + aux).c_str());
     } else if (cw & CW_SKIPZ) {
       emit("if (%s == 0u) goto %s;\n", a, target(pc + 1 + braw).c_str());
     } else if (cw & CW_SKIPNZ) {

@@ -168,10 +168,13 @@ def _random_handler(rng, n_rows, n_types, few_effects=False):
     return a
 
 
+@pytest.mark.parametrize("ifconvert", [0, 4])
 @pytest.mark.parametrize("seed", [1, 2, 3, 4])
-def test_random_programs_through_the_code_generator(oracle, tmp_path, seed):
+def test_random_programs_through_the_code_generator(oracle, tmp_path, seed, ifconvert, monkeypatch):
     """Every op, random control flow, two actor classes: generated C++ == the oracle's row interpreter, delivery by
     delivery (state, effect rows, FX_CAP overflow)."""
+    # ifconvert: the experimental select-based emission of short guarded ALU runs (DEMI_JIT_IFCONVERT), same semantics
+    monkeypatch.setenv("DEMI_JIT_IFCONVERT", str(ifconvert))
     rng = np.random.default_rng(seed)
     MSGS = [("E", T.MSG_EXTERNAL), ("A", T.MSG_INTERNAL), ("B", T.MSG_INTERNAL), ("Tm", T.MSG_TIMER)]
     h = {}
@@ -222,3 +225,35 @@ def test_random_programs_through_the_code_generator(oracle, tmp_path, seed):
         assert got == [tuple(fx[5 * k + j] for j in range(5)) for k in range(wn)], (it, me, typ)
         seen_fx += len(got)
     assert seen_fx > 200
+
+
+def test_if_conversion_knob_converts_short_guarded_alu_runs(oracle, tmp_path, monkeypatch):
+    """DEMI_JIT_IFCONVERT: `if (cond) { two ALU rows }` becomes two selects (no branch); a guard over an effect row, or
+    one whose body is a jump target, stays a branch; results are the interpreter's either way."""
+    MSGS = [("E", T.MSG_EXTERNAL), ("A", T.MSG_INTERNAL)]
+    a = M.Asm()
+    a.if_eq(M.F[0], 1, "x").add(M.F[1], M.F[1], 1).mov(M.F[2], 7).label("x")          # convertible
+    a.if_gt(M.P0, 9, "y").mov(M.T0, 1).send(1, M.T0, M.F[1], 0).label("y")             # effect row inside: stays a branch
+    a.skipz(M.P1, "in").if_ne(M.F[3], 0, "z").add(M.F[4], M.F[4], 2).label("in").add(M.F[5], M.F[5], 1).label("z")   # target inside
+    model = M.build_model("ifc", 2, MSGS, {(0, "E"): a}, [[0] * 8] * 2, (T.INV_NEVER, 0, 200, 0))
+    monkeypatch.setenv("DEMI_JIT_IFCONVERT", "3")
+    src = _native.specialize_source(model.to_struct())
+    assert src.count(" ? (") == 2 and "bool c0 = false;" in src and src.count("bool c") == 1
+    L = _host_vm(model, tmp_path)
+    ms = model.to_struct()
+    hs = np.full(T.MAX_CLASSES * T.MAX_MSG_TYPES, 0xFFFF, dtype=np.uint32)
+    hs[:len(model.handler_start)] = model.handler_start
+    st = np.zeros(8 * 64, dtype=np.uint64)
+    fxq = np.zeros(FX_CAP * 64, dtype=np.uint32)
+    fx = (C.c_uint8 * (5 * 64))()
+    rng = np.random.default_rng(0)
+    for _ in range(3000):
+        state = int.from_bytes(bytes(int(x) for x in rng.integers(0, 3, 8)), "little")
+        p0, p1 = int(rng.integers(0, 20)), int(rng.integers(0, 2))
+        w = 0 | (0 << 5) | (T.DEADLETTERS << 8) | (p0 << 16) | (p1 << 24)
+        st[0] = state
+        flags = C.c_uint32(0)
+        n = L.run(hs.ctypes.data, 0, len(MSGS), st.ctypes.data, fxq.ctypes.data, w, C.byref(flags))
+        want = C.c_uint64(state)
+        wn = oracle.lib().orc_vm_run(C.byref(ms), 0, C.byref(want), 0, T.DEADLETTERS, p0, p1, 3, fx, 64)
+        assert int(st[0]) == want.value and n == wn
