@@ -311,3 +311,24 @@ def test_replay_golden_fixture_on_gpu(gpu_ctx):
     assert_same(gpu_ctx.replay_removal_batch(z["skips"], target), z["skip_verdicts"])
     for k in range(len(z["kept"])):
         assert (gpu_ctx.replay_get_kept(len(z["rec"]), int(z["skips"][k]), target)[1] == z["kept"][k]).all()
+
+
+def test_fuzz_then_the_gamut_end_to_end():
+    """RunnerUtils.fuzz -> validate by strict replay -> provenance -> stsSchedDDMin -> minimizeInternals, every
+    execution and replay on the GPU."""
+    from demi_amd.fuzzer import FuzzerWeights
+    from demi_amd.runner_utils import fuzz, run_the_gamut
+    from demi_amd.schedulers import ReplayScheduler
+    from demi_amd.internal_minimization import countMsgEvents
+    model = M.raft_model(5)
+    cfg = SchedulerConfig(model=model)
+    w = FuzzerWeights()
+    gen = lambda i: events_to_array(raft_trace(5, 50, 0xF022 + i, w, exact=False))
+    res = fuzz(gen, cfg, validate_replay=lambda: ReplayScheduler(cfg), maxMessages=200, executions_per_test=2048, max_tests=8)
+    assert res is not None
+    trace, violation, initial, filtered = res
+    assert len(initial) == 1 + countMsgEvents(trace) and 0 < len(filtered) <= len(initial)
+    out = run_the_gamut(cfg, trace, violation)
+    assert out["verified_mcs"] is not None and len(out["mcs"]) < out["original_externals"]
+    assert out["minimized_deliveries"] <= countMsgEvents(out["verified_mcs"]) <= out["original_deliveries"]
+    assert out["ddmin_replays"] > 0 and out["intmin_replays"] > 0
