@@ -175,7 +175,7 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
   const uint32_t max_messages = args.max_messages ? args.max_messages : 0x7FFFFFFFu;
 
   bool active = false, fresh = false;
-  uint64_t sched = 0, hash = 0, parent_key = 0;
+  uint64_t sched = 0, hash = 0;
   demi_dpor_trace_entry* tr = nullptr;
   const demi_dpor_trace_entry* pf = nullptr;
   uint32_t pfx = 0, pfx_len = 0;
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
         n_pend = 0; next_seq = 0; qperiod = 0; next_qperiod = 0; rep = 0; flags = 0; count = 0; deliveries = 0;
         n_trace = 0; ext_idx = 0; awaiting = false; marker_pending = false;
         trace_push(DPOR_ROOT_KEY, 0, 0, 0, 0);   // currentTrace += getRootEvent (:336-343)
-        parent = 0; parent_key = DPOR_ROOT_KEY; parent_depth = 0; cur_root = 0;
+        parent = 0; parent_depth = 0; cur_root = 0;
         run_external();
       }
       if (flags & K3_ABORT) {
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
             const int ti = trace_push(key, pw, par, (aux >> 8) & 0xFF, 1);
             if (ti < 0) finish = true;
             else {
-              parent = (uint32_t)ti; parent_key = key; parent_depth = tr[ti].depth;   // setParentEvent
+              parent = (uint32_t)ti; parent_depth = tr[ti].depth;   // setParentEvent
               w = pw; deliver = true;
               deliveries++;
               hash_step(hash, w);
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
             const int ti = trace_push(dpor_marker_key(qmarker_ext), 0, cur_root, qperiod, 2);
             if (ti < 0) finish = true;
             else {
-              cur_root = (uint32_t)ti; parent = (uint32_t)ti; parent_key = tr[ti].key; parent_depth = tr[ti].depth;
+              cur_root = (uint32_t)ti; parent = (uint32_t)ti; parent_depth = tr[ti].depth;
               run_external();
             }
           } else {
