@@ -189,8 +189,10 @@ const char* demi_version(void);
 /* SchedulerConfig (SchedulerConfig.scala:9-37) + the application actors lowered to a table. */
 int demi_model_load(demi_ctx* ctx, const demi_model* model);
 /* Compile the loaded transition table to native gfx950 code (hiprtc, ~1 s) and use that kernel for the
- * following demi_random_explore* launches instead of the table interpreter: the reference runs the
- * application's own (JIT-compiled) receive methods, this is the same step for the lowered table.  Verdicts are
+ * following demi_random_explore* launches (and, compiled at their first launch, demi_replay_* / demi_dpor_*) instead
+ * of the table interpreter: the reference hands every delivery to the application's own JVM-compiled `receive`
+ * (Instrumenter.dispatch_new_message, Instrumenter.scala:913-1017; WeaveActor.aj around-advice on receive), this is
+ * the same step for the lowered table.  Verdicts are
  * bit-identical with and without it.  enable = 0 returns to the interpreter.  A failure (no hiprtc, compile
  * error) leaves the interpreter in place and returns the reason through demi_last_error.  demi_model_load
  * drops the specialisation of the previous model.                                                         */
