@@ -69,7 +69,7 @@ def lib():
     L.demi_replay_get_kept.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(T.Limits), C.POINTER(T.Verdict),
                                        C.c_void_p]
     L.demi_dpor_load.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
-    L.demi_dpor_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.POINTER(T.DporParams),
+    L.demi_dpor_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.POINTER(T.DporParams),
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.demi_dpor_explore.argtypes = [C.c_void_p, C.POINTER(T.DporParams), C.POINTER(T.DporSearch), C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(T.DporStats)]
@@ -218,8 +218,9 @@ class Context:
         ev = np.ascontiguousarray(externals, dtype=T.EXT_EVENT_DTYPE)
         self._check(lib().demi_dpor_load(self._h, ev.ctypes.data if len(ev) else None, len(ev)))
 
-    def dpor_batch(self, prefixes, params):
-        """prefixes: list of DPOR_TRACE_DTYPE arrays (nextTrace of each interleaving).  Returns
+    def dpor_batch(self, prefixes, params, shared=None):
+        """prefixes: list of DPOR_TRACE_DTYPE arrays (nextTrace of each interleaving); shared[i]: leading events of
+        prefix i whose racing pairs the caller already has (None / 0 = report all).  Returns
         (verdicts, [trace arrays], [pair arrays])."""
         import numpy as np
         n = len(prefixes)
@@ -234,8 +235,10 @@ class Context:
         tl = np.zeros(n, dtype=np.uint32)
         pairs = np.zeros((n, max(1, params.max_pairs)), dtype=T.DPOR_PAIR_DTYPE)
         npairs = np.zeros(n, dtype=np.uint32)
+        sh = np.ascontiguousarray(shared, dtype=np.uint32) if shared is not None else None
         if n:
-            self._check(lib().demi_dpor_batch(self._h, pf.ctypes.data, pl.ctypes.data, stride, n, C.byref(params),
+            self._check(lib().demi_dpor_batch(self._h, pf.ctypes.data, pl.ctypes.data, sh.ctypes.data if sh is not None else None,
+                                              stride, n, C.byref(params),
                                               verdicts.ctypes.data, traces.ctypes.data, tl.ctypes.data,
                                               pairs.ctypes.data, npairs.ctypes.data))
         return verdicts, [traces[i, :tl[i]].copy() for i in range(n)], [pairs[i, :npairs[i]].copy() for i in range(n)]

@@ -81,18 +81,16 @@ __device__ __forceinline__ void hash_step(uint64_t& h, uint64_t v) { h = (h ^ v)
 // ViolationFingerprint code.  st: this lane's actor states in LDS, stride 64 u64.
 __device__ __forceinline__ uint32_t fld(uint64_t s, uint32_t f) { return (uint32_t)(s >> (8 * f)) & 0xFF; }
 
-__device__ inline uint32_t invariant_code(const DevModel* __restrict__ gm, const uint64_t* st, uint32_t exists,
-                                          uint32_t A, uint32_t kind, uint32_t fa, uint32_t va, uint32_t fb) {
-  // fast path first: which created actors "hit" (F[fa] == va, or F[fa] != 0 for AGREE).  Almost every
-  // check ends here (fewer than two hits), so the pair logic below is rarely entered by any lane.
-  uint32_t vmask = 0;
-  const uint32_t sa = 8 * fa;
-  for (uint32_t i = 0; i < A; i++) {
-    const uint32_t a = (uint32_t)(st[i * 64] >> sa) & 0xFF;
-    const bool hit = (kind == DEMI_INV_AGREE) ? (a != 0) : (a == va);
-    vmask |= (uint32_t)hit << i;
-  }
-  vmask &= exists;
+// One actor's contribution to the invariant's "hit" mask: F[fa] == va (F[fa] != 0 for AGREE).
+__device__ __forceinline__ uint32_t invariant_hit(uint64_t state, uint32_t kind, uint32_t fa, uint32_t va) {
+  const uint32_t a = (uint32_t)(state >> (8 * fa)) & 0xFF;
+  return (kind == DEMI_INV_AGREE) ? (a != 0) : (a == va);
+}
+
+// The verdict from the hit mask (bit i = created actor i hits).  Almost every check ends in the first two lines
+// (fewer than two hits); the group keys are only read after that.
+__device__ inline uint32_t invariant_from_hits(const uint64_t* st, uint32_t vmask, uint32_t A, uint32_t kind, uint32_t fb) {
+  vmask &= (1u << A) - 1u;   // (a specialised build knows A: the pair logic below then only exists for real actors)
   if (kind == DEMI_INV_NEVER) return vmask ? ((2u << 24) | vmask) : 0u;
   if (kind == DEMI_INV_NONE || (vmask & (vmask - 1)) == 0) return 0u;   // needs at least two hits
   // slow path: group keys of the hit actors
@@ -128,6 +126,14 @@ __device__ inline uint32_t invariant_code(const DevModel* __restrict__ gm, const
   for (uint32_t i = 0; i < DEMI_MAX_ACTORS; i++)
     if (((vmask >> i) & 1) && key[i] == k) mask |= 1u << i;
   return (1u << 24) | (k << 8) | mask;
+}
+
+__device__ inline uint32_t invariant_code(const DevModel* __restrict__ gm, const uint64_t* st, uint32_t exists,
+                                          uint32_t A, uint32_t kind, uint32_t fa, uint32_t va, uint32_t fb) {
+  (void)gm;
+  uint32_t vmask = 0;
+  for (uint32_t i = 0; i < A; i++) vmask |= invariant_hit(st[i * 64], kind, fa, va) << i;
+  return invariant_from_hits(st, vmask & exists, A, kind, fb);
 }
 
 }  // namespace demi

@@ -17,12 +17,15 @@
 //    earlier: that one is popped first and explores the pair), or when it reaches its shard's front dead.
 #pragma once
 
+#include <atomic>
 #include <chrono>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <memory>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/demi_gpu.h"
@@ -125,28 +128,37 @@ struct Fifo {
   }
 };
 
+// One finished interleaving as dpor() sees it: its trace and its racing pairs.
+struct Finished {
+  const demi_dpor_trace_entry* trace;
+  uint32_t trace_len;
+  const demi_dpor_pair* pairs;
+  uint32_t n_pairs;
+};
+
 class DporBook {
  public:
-  explicit DporBook(bool track_history, unsigned n_shards = 64) : track_(track_history), shards_(n_shards) {
+  // max_threads = 1: everything on the calling thread (the one-interleaving-at-a-time commit of the reference order)
+  explicit DporBook(bool track_history, unsigned max_threads = 32, unsigned n_shards = 64) : track_(track_history), shards_(n_shards) {
     unsigned hw = std::thread::hardware_concurrency();
-    threads_ = hw ? (hw > 32 ? 32u : hw) : 4u;
+    threads_ = hw ? (hw > max_threads ? max_threads : hw) : (max_threads < 4u ? max_threads : 4u);
     if (threads_ > n_shards) threads_ = n_shards;
+    if (threads_ < 1) threads_ = 1;
     pieces_.resize((size_t)threads_ * n_shards);
   }
 
-  // dpor() for one round: interleaving i has trace tr[i * MAX_TRACE .. +tl[i]) and pairs pr[i * max_pairs .. +np[i])
-  void absorb(const demi_dpor_trace_entry* tr, const uint32_t* tl, const demi_dpor_pair* pr, const uint32_t* np, size_t n,
-              uint32_t max_pairs) {
+  // dpor() for a run of finished interleavings, in the order given
+  void absorb(const Finished* fin, size_t n) {
     // trace ids and global pair ordinals (creation order = interleaving order, then pair order)
     std::vector<uint32_t> tid(n);
     std::vector<uint64_t> base(n);
     for (size_t i = 0; i < n; i++) {
       base[i] = seq_;
-      seq_ += np[i];
+      seq_ += fin[i].n_pairs;
       tid[i] = 0;
-      if (np[i]) {
-        const demi_dpor_trace_entry* t = tr + i * DEMI_DPOR_MAX_TRACE;
-        traces_.push_back(std::make_shared<Trace>(t, t + tl[i]));
+      if (fin[i].n_pairs) {
+        traces_.emplace_back();
+        traces_.back().t.assign(fin[i].trace, fin[i].trace + fin[i].trace_len);
         tid[i] = (uint32_t)(traces_.size() - 1);
       }
     }
@@ -156,9 +168,9 @@ class DporBook {
       const size_t lo = n * t / threads_, hi = n * (t + 1) / threads_;
       for (size_t s = 0; s < S; s++) pieces_[t * S + s].clear();
       for (size_t i = lo; i < hi; i++) {
-        const demi_dpor_trace_entry* tt = tr + i * DEMI_DPOR_MAX_TRACE;
-        const demi_dpor_pair* pp = pr + i * (size_t)max_pairs;
-        for (uint32_t k = 0; k < np[i]; k++) {
+        const demi_dpor_trace_entry* tt = fin[i].trace;
+        const demi_dpor_pair* pp = fin[i].pairs;
+        for (uint32_t k = 0; k < fin[i].n_pairs; k++) {
           const uint64_t ke = tt[pp[k].earlier].key, kl = tt[pp[k].later].key;
           pieces_[t * S + shard_of(ke, kl)].push_back(Piece{ke, kl, BtPoint{base[i] + k, tid[i], pp[k].branch, pp[k].later, pp[k].earlier, 0}});
         }
@@ -180,6 +192,7 @@ class DporBook {
               flipped = (flipped & ~QUEUED_MASK) | ((uint32_t)p.branch + 1);
             }
             sh.bucket[p.branch].push_back(sh.pool, p);
+            traces_[p.trace_id].refs.fetch_add(1, std::memory_order_relaxed);
             if ((int)p.branch > sh.top) sh.top = (int)p.branch;
             sh.queued++;
           }
@@ -188,10 +201,22 @@ class DporBook {
     };
     run(distribute);
     run(process);
+    for (size_t i = 0; i < n; i++)                                // a trace no queued point refers to is not needed again
+      if (fin[i].n_pairs && traces_[tid[i]].refs.load(std::memory_order_relaxed) == 0) Trace().swap(traces_[tid[i]].t);
   }
 
-  // getNext (:1142-1162) + the next trace `trace.take(maxIndex + 1) ++ needToReplay` (:1054-1057, 1180)
-  bool get_next(Trace& out) {
+  // the contiguous layout of one fetched chunk: interleaving i has trace tr[i * MAX_TRACE .. +tl[i]) and pairs
+  // pr[i * max_pairs .. +np[i])
+  void absorb(const demi_dpor_trace_entry* tr, const uint32_t* tl, const demi_dpor_pair* pr, const uint32_t* np, size_t n,
+              uint32_t max_pairs) {
+    std::vector<Finished> fin(n);
+    for (size_t i = 0; i < n; i++) fin[i] = Finished{tr + i * DEMI_DPOR_MAX_TRACE, tl[i], pr + i * (size_t)max_pairs, np[i]};
+    absorb(fin.data(), n);
+  }
+
+  // getNext (:1142-1162) + the next trace `trace.take(maxIndex + 1) ++ needToReplay` (:1054-1057, 1180).  *shared = the
+  // length of the take() part when its racing pairs need not be reported again (demi_gpu.h, demi_dpor_batch), else 0.
+  bool get_next(Trace& out, uint32_t* shared = nullptr) {
     int best = -1;
     for (size_t s = 0; s < shards_.size(); s++) {
       Shard& sh = shards_[s];
@@ -206,11 +231,13 @@ class DporBook {
     sh.bucket[sh.top].pop_front(sh.pool);
     sh.queued--;
     sh.front_valid = false;
-    const Trace& src = *traces_[p.trace_id];
+    const Trace& src = traces_[p.trace_id].t;
     if (track_) sh.map.at(src[p.later].key, src[p.earlier].key) |= EXPLORED;   // setExplored(maxIndex, (e1, e2)) (:1170-1172)
     out.assign(src.begin(), src.begin() + p.branch + 1);
     for (int k = (int)p.branch + 1; k <= (int)p.later; k++)
       if (k != (int)p.earlier) out.push_back(src[k]);
+    if (shared) *shared = track_ ? (uint32_t)p.branch + 1 : 0u;
+    release(p.trace_id);
     return true;
   }
 
@@ -234,6 +261,13 @@ class DporBook {
     bool front_valid = false;                // top / front_seq describe a live (unexplored) point
     uint64_t front_seq = 0;
   };
+  struct TraceRec {
+    Trace t;                                 // emptied once no queued point refers to it
+    std::atomic<uint32_t> refs{0};           // queued backtrack points found by this interleaving
+  };
+  void release(uint32_t tid) {
+    if (traces_[tid].refs.fetch_sub(1, std::memory_order_relaxed) == 1) Trace().swap(traces_[tid].t);
+  }
   // drop dead points from the front of the shard's queue until a live one (or nothing) is at the front
   void settle(Shard& sh) {
     while (sh.top >= 0) {
@@ -241,9 +275,9 @@ class DporBook {
       if (b.empty()) { sh.top--; continue; }
       const BtPoint& p = b.front();
       if (track_) {
-        const Trace& src = *traces_[p.trace_id];
+        const Trace& src = traces_[p.trace_id].t;
         const uint32_t* v = sh.map.find(src[p.later].key, src[p.earlier].key);
-        if (v && (*v & EXPLORED)) { b.pop_front(sh.pool); sh.queued--; continue; }
+        if (v && (*v & EXPLORED)) { const uint32_t tid = p.trace_id; b.pop_front(sh.pool); sh.queued--; release(tid); continue; }
       }
       sh.front_seq = p.seq;
       break;
@@ -267,7 +301,7 @@ class DporBook {
   uint64_t seq_ = 0;
   std::vector<Shard> shards_;
   std::vector<std::vector<Piece>> pieces_;              // [thread][shard] buckets of the current round
-  std::vector<std::shared_ptr<Trace>> traces_;
+  std::deque<TraceRec> traces_;                         // (a deque: records keep their address while it grows)
 };
 
 // The exploration loop of DPORwHeuristics.test (:1193-1242) in rounds.
@@ -305,11 +339,12 @@ struct RawBuf {
   }
 };
 
+// ------------------------------------------------------------------ ROUNDS order
 template <class Run, class Fetch>
-int explore_loop(Run&& run, Fetch&& fetch, uint32_t max_pairs, const demi_dpor_search* srch, demi_verdict* out_verdicts,
-                 uint32_t* out_prefix_len, uint32_t* out_rounds, demi_dpor_trace_entry* first_violation_trace,
-                 uint32_t* first_violation_len, demi_dpor_stats* stats, double* seconds,
-                 RawBuf* trace_buf = nullptr, RawBuf* pair_buf = nullptr) {
+int explore_rounds(Run&& run, Fetch&& fetch, uint32_t max_pairs, const demi_dpor_search* srch, demi_verdict* out_verdicts,
+                   uint32_t* out_prefix_len, uint32_t* out_rounds, demi_dpor_trace_entry* first_violation_trace,
+                   uint32_t* first_violation_len, demi_dpor_stats* stats, double* seconds,
+                   RawBuf* trace_buf = nullptr, RawBuf* pair_buf = nullptr) {
   // staging buffers: the caller's (the library keeps pinned ones across calls) or malloc'ed ones for this call
   RawBuf own_tr([](size_t b) { return malloc(b); }, [](void* q) { free(q); });
   RawBuf own_pr([](size_t b) { return malloc(b); }, [](void* q) { free(q); });
@@ -325,6 +360,7 @@ int explore_loop(Run&& run, Fetch&& fetch, uint32_t max_pairs, const demi_dpor_s
   auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
 
   std::vector<Trace> frontier(1);         // first run: nextTrace is empty
+  std::vector<uint32_t> shared(1, 0u);
   std::vector<demi_dpor_trace_entry> pf;
   std::vector<uint32_t> pl, tl, np;
   std::vector<demi_verdict> vd;
@@ -340,11 +376,12 @@ int explore_loop(Run&& run, Fetch&& fetch, uint32_t max_pairs, const demi_dpor_s
       if (pl[i]) memcpy(&pf[i * stride], frontier[i].data(), sizeof(demi_dpor_trace_entry) * pl[i]);
     }
     double t0 = now();
-    int rc = run(pf.data(), pl.data(), (uint32_t)stride, (uint64_t)n, vd.data(), tl.data(), np.data());
+    int rc = run(pf.data(), pl.data(), shared.data(), (uint32_t)stride, (uint64_t)n, vd.data(), tl.data(), np.data());
     if (rc) return rc;
     double t1 = now();
     if (out_rounds) out_rounds[stats->launches] = (uint32_t)n;
     stats->launches++;
+    stats->executed += n;
     bool found = false;
     size_t first_here = n;             // position in this round of the overall first violation, if it is in this round
     for (size_t i = 0; i < n; i++) {
@@ -371,13 +408,16 @@ int explore_loop(Run&& run, Fetch&& fetch, uint32_t max_pairs, const demi_dpor_s
     }
     double t2 = now();
     frontier.clear();
+    shared.clear();
     if (srch->stop_if_violation && found) break;
     if (stats->interleavings >= srch->max_interleavings) break;
     // getNext (:1142-1162) for up to `batch` points
     while (frontier.size() < srch->batch && stats->interleavings + frontier.size() < srch->max_interleavings) {
       Trace nxt;
-      if (!book.get_next(nxt)) break;
+      uint32_t sh = 0;
+      if (!book.get_next(nxt, &sh)) break;
       frontier.push_back(std::move(nxt));
+      shared.push_back(sh);
     }
     if (frontier.empty() && book.empty()) exhausted = true;
     if (seconds) { seconds[0] += t1 - t0; seconds[1] += t2 - t1; seconds[2] += now() - t2; }
@@ -385,6 +425,197 @@ int explore_loop(Run&& run, Fetch&& fetch, uint32_t max_pairs, const demi_dpor_s
   stats->queue_len = book.queue_len();
   stats->exhausted = exhausted ? 1u : 0u;
   return 0;
+}
+
+// ------------------------------------------------------------------ REFERENCE order
+// The sequence of interleavings of batch = 1 (DPORwHeuristics' own order), with the device running ahead.
+//
+// An interleaving is a pure function of its next trace, so its result can be computed at any time and by anyone.  Two
+// books are kept: `spec`, a ROUNDS exploration of width `batch` that only serves to guess which next traces will be
+// needed, and `real`, which pops ONE backtrack point at a time, takes that interleaving's result from a cache filled by
+// the launches (key: the next trace's node keys + its shared length), absorbs it, and pops again - DPORwHeuristics' loop
+// verbatim.  When `real` needs a result nobody has computed, the next launch runs it together with `spec`'s next round.
+// What `spec` explores only changes how often that happens, never what `real` commits.
+struct SpecResult {
+  demi_verdict verdict;
+  uint32_t prefix_len = 0;
+  uint64_t key = 0;
+  Trace trace;
+  std::vector<demi_dpor_pair> pairs;
+  size_t bytes() const { return sizeof(SpecResult) + trace.size() * sizeof(demi_dpor_trace_entry) + pairs.size() * sizeof(demi_dpor_pair); }
+};
+
+inline uint64_t next_trace_key(const Trace& t, uint32_t shared) {
+  uint64_t h = 0xCBF29CE484222325ULL ^ (uint64_t)t.size() ^ ((uint64_t)shared << 32);
+  for (const demi_dpor_trace_entry& e : t) h = (h ^ e.key) * 0x100000001B3ULL + (h >> 47);
+  return h ? h : 1;
+}
+
+template <class Run, class Fetch>
+int explore_reference_order(Run&& run, Fetch&& fetch, uint32_t max_pairs, const demi_dpor_search* srch,
+                            demi_verdict* out_verdicts, uint32_t* out_prefix_len, uint32_t* out_rounds,
+                            demi_dpor_trace_entry* first_violation_trace, uint32_t* first_violation_len,
+                            demi_dpor_stats* stats, double* seconds, RawBuf* trace_buf = nullptr, RawBuf* pair_buf = nullptr) {
+  RawBuf own_tr([](size_t b) { return malloc(b); }, [](void* q) { free(q); });
+  RawBuf own_pr([](size_t b) { return malloc(b); }, [](void* q) { free(q); });
+  RawBuf& tr_buf = trace_buf ? *trace_buf : own_tr;
+  RawBuf& pr_buf = pair_buf ? *pair_buf : own_pr;
+  auto* tr = static_cast<demi_dpor_trace_entry*>(tr_buf.reserve(sizeof(demi_dpor_trace_entry) * DEMI_DPOR_MAX_TRACE * EXPLORE_CHUNK));
+  auto* pr = static_cast<demi_dpor_pair*>(pr_buf.reserve(sizeof(demi_dpor_pair) * (size_t)(max_pairs ? max_pairs : 1) * EXPLORE_CHUNK));
+  if (!tr || !pr) return DEMI_ERR_INVALID_ARG;
+  const bool track = srch->track_history != 0;
+  DporBook real(track, 1), spec(track);
+  memset(stats, 0, sizeof *stats);
+  stats->first_violation = ~0ull;
+  if (first_violation_len) *first_violation_len = 0;
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+
+  // results computed and not yet committed; evicted oldest first beyond the memory cap (a needed one is then run again)
+  std::unordered_map<uint64_t, std::unique_ptr<SpecResult>> cache;
+  std::deque<uint64_t> age;
+  size_t cache_bytes = 0;
+  const size_t cache_cap = (size_t)(srch->cache_mb ? srch->cache_mb : 1024u) << 20;
+  auto evict_to_cap = [&](uint64_t keep) {
+    while (cache_bytes > cache_cap && !age.empty()) {
+      const uint64_t k = age.front();
+      age.pop_front();
+      if (k == keep) { age.push_back(k); if (age.size() == 1) break; continue; }
+      auto it = cache.find(k);
+      if (it != cache.end()) { cache_bytes -= it->second->bytes(); cache.erase(it); }
+    }
+  };
+
+  Trace cur;                         // the next trace `real` wants (first run: empty)
+  uint32_t cur_shared = 0;
+  bool have_cur = true, exhausted = false, done = false;
+  std::vector<Trace> spec_frontier(1);
+  std::vector<uint32_t> spec_shared(1, 0u);
+  bool spec_alive = true;
+
+  std::vector<const Trace*> launch;          // next traces of this launch
+  std::vector<uint32_t> launch_shared;
+  std::vector<uint64_t> launch_key;
+  std::vector<demi_dpor_trace_entry> pf;
+  std::vector<uint32_t> pl, tl, np;
+  std::vector<demi_verdict> vd;
+  std::vector<Finished> fin;
+
+  while (!done) {
+    // ---- commit, one interleaving at a time, as far as computed results reach
+    double t0 = now();
+    while (have_cur) {
+      const uint64_t key = next_trace_key(cur, cur_shared);
+      auto it = cache.find(key);
+      if (it == cache.end()) break;
+      const SpecResult& r = *it->second;
+      const uint64_t idx = stats->interleavings++;
+      out_verdicts[idx] = r.verdict;
+      out_prefix_len[idx] = (uint32_t)cur.size();
+      bool found = false;
+      if (r.verdict.flags & DEMI_V_VIOLATION) {
+        stats->violations++;
+        found = true;
+        if (stats->first_violation == ~0ull) {
+          stats->first_violation = idx;
+          if (first_violation_trace && !r.trace.empty()) memcpy(first_violation_trace, r.trace.data(), sizeof(demi_dpor_trace_entry) * r.trace.size());
+          if (first_violation_len) *first_violation_len = (uint32_t)r.trace.size();
+        }
+      }
+      const Finished f{r.trace.data(), (uint32_t)r.trace.size(), r.pairs.data(), (uint32_t)r.pairs.size()};
+      real.absorb(&f, 1);
+      cache_bytes -= r.bytes();
+      cache.erase(it);
+      if ((srch->stop_if_violation && found) || stats->interleavings >= srch->max_interleavings) { done = true; break; }
+      have_cur = real.get_next(cur, &cur_shared);
+      if (!have_cur) { exhausted = true; done = true; }
+    }
+    double t1 = now();
+    if (seconds) seconds[2] += t1 - t0;
+    if (done) break;
+
+    // ---- one launch: what `real` is waiting for + the speculation's next round (minus what is computed already)
+    stats->cache_misses++;
+    launch.clear(); launch_shared.clear(); launch_key.clear();
+    const uint64_t cur_key = next_trace_key(cur, cur_shared);
+    launch.push_back(&cur); launch_shared.push_back(cur_shared); launch_key.push_back(cur_key);
+    std::vector<uint64_t> round_key(spec_frontier.size());
+    for (size_t i = 0; i < spec_frontier.size(); i++) {
+      const uint64_t k = next_trace_key(spec_frontier[i], spec_shared[i]);
+      round_key[i] = k;
+      bool dup = cache.count(k) != 0;
+      for (size_t j = 0; j < launch_key.size() && !dup; j++) dup = launch_key[j] == k;
+      if (!dup) { launch.push_back(&spec_frontier[i]); launch_shared.push_back(spec_shared[i]); launch_key.push_back(k); }
+    }
+    const size_t n = launch.size();
+    size_t stride = 1;
+    for (const Trace* f : launch) stride = f->size() > stride ? f->size() : stride;
+    pf.resize(n * stride);
+    pl.resize(n); tl.resize(n); np.resize(n); vd.resize(n);
+    for (size_t i = 0; i < n; i++) {
+      pl[i] = (uint32_t)launch[i]->size();
+      if (pl[i]) memcpy(&pf[i * stride], launch[i]->data(), sizeof(demi_dpor_trace_entry) * pl[i]);
+    }
+    int rc = run(pf.data(), pl.data(), launch_shared.data(), (uint32_t)stride, (uint64_t)n, vd.data(), tl.data(), np.data());
+    if (rc) return rc;
+    if (out_rounds && stats->launches < srch->max_interleavings) out_rounds[stats->launches] = (uint32_t)n;
+    stats->launches++;
+    stats->executed += n;
+    double t2 = now();
+    for (size_t lo = 0; lo < n; lo += EXPLORE_CHUNK) {
+      const size_t cnt = n - lo < EXPLORE_CHUNK ? n - lo : EXPLORE_CHUNK;
+      rc = fetch(lo, cnt, tr, pr);
+      if (rc) return rc;
+      for (size_t i = 0; i < cnt; i++) {
+        std::unique_ptr<SpecResult> r(new SpecResult);
+        r->verdict = vd[lo + i];
+        r->prefix_len = pl[lo + i];
+        r->key = launch_key[lo + i];
+        r->trace.assign(&tr[i * DEMI_DPOR_MAX_TRACE], &tr[i * DEMI_DPOR_MAX_TRACE] + tl[lo + i]);
+        r->pairs.assign(&pr[i * (size_t)max_pairs], &pr[i * (size_t)max_pairs] + np[lo + i]);
+        cache_bytes += r->bytes();
+        age.push_back(r->key);
+        cache[r->key] = std::move(r);
+      }
+    }
+    // the speculation absorbs its round in pop order (every member is in the cache now) and pops its next round
+    if (spec_alive) {
+      fin.clear();
+      for (size_t i = 0; i < spec_frontier.size(); i++) {
+        auto it = cache.find(round_key[i]);
+        if (it == cache.end()) continue;               // (only if the cap is smaller than one round)
+        const SpecResult& r = *it->second;
+        fin.push_back(Finished{r.trace.data(), (uint32_t)r.trace.size(), r.pairs.data(), (uint32_t)r.pairs.size()});
+      }
+      spec.absorb(fin.data(), fin.size());
+      spec_frontier.clear();
+      spec_shared.clear();
+      while (spec_frontier.size() < srch->batch) {
+        Trace nxt;
+        uint32_t sh = 0;
+        if (!spec.get_next(nxt, &sh)) break;
+        spec_frontier.push_back(std::move(nxt));
+        spec_shared.push_back(sh);
+      }
+      if (spec_frontier.empty()) spec_alive = false;
+    }
+    evict_to_cap(cur_key);
+    if (seconds) { seconds[0] += t2 - t1; seconds[1] += now() - t2; }
+  }
+  stats->queue_len = real.queue_len();
+  stats->exhausted = exhausted ? 1u : 0u;
+  return 0;
+}
+
+template <class Run, class Fetch>
+int explore_loop(Run&& run, Fetch&& fetch, uint32_t max_pairs, const demi_dpor_search* srch, demi_verdict* out_verdicts,
+                 uint32_t* out_prefix_len, uint32_t* out_rounds, demi_dpor_trace_entry* first_violation_trace,
+                 uint32_t* first_violation_len, demi_dpor_stats* stats, double* seconds,
+                 RawBuf* trace_buf = nullptr, RawBuf* pair_buf = nullptr) {
+  if (srch->order == DEMI_DPOR_ORDER_REFERENCE)
+    return explore_reference_order(run, fetch, max_pairs, srch, out_verdicts, out_prefix_len, out_rounds, first_violation_trace,
+                                   first_violation_len, stats, seconds, trace_buf, pair_buf);
+  return explore_rounds(run, fetch, max_pairs, srch, out_verdicts, out_prefix_len, out_rounds, first_violation_trace,
+                        first_violation_len, stats, seconds, trace_buf, pair_buf);
 }
 
 }  // namespace demi_host

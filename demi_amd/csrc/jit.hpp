@@ -15,6 +15,7 @@
 
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -34,6 +35,9 @@ inline std::string generate_vm(const demi::DevModel& h) {
   char buf[512];
   auto emit = [&](const char* fmt, auto... a) { snprintf(buf, sizeof buf, fmt, a...); s += buf; };
   s += "namespace demi {\n";
+  // effect rows are recorded into the LDS effect queue in program order, exactly as vm_run does
+  s += "#define DEMI_FX(OP, TYPE, TGT, P0, P1) { if (nfx >= DEMI_FX_CAP) { flags |= DEMI_V_QUEUE_OVF; goto done; } "
+       "mem.fxq[nfx * 64] = fx_pack(OP, TYPE, TGT, P0, P1); nfx++; }\n";
   s += "__device__ inline uint32_t vm_run_jit(const Tables& t, const LaneMem& mem, uint32_t w, uint32_t& flags) {\n";
   s += "  const uint32_t type = w_type(w), me = w_dst(w);\n";
   s += "  const uint32_t entry = t.hs[((t.ac_packed >> (4 * me)) & 15u) * t.NT + type];\n";
@@ -142,9 +146,7 @@ inline std::string generate_vm(const demi::DevModel& h) {
     } else if (cw & CW_SKIP) {
       emit("goto %s;\n", target(pc + 1 + braw).c_str());
     } else {   // CW_FX: recorded now, applied after the rows have run (same record as vm_run)
-      emit("if (nfx >= DEMI_FX_CAP) { flags |= DEMI_V_QUEUE_OVF; goto done; } "
-           "mem.fxq[nfx * 64] = fx_pack(%uu, %uu, %s > 15u ? 15u : %s, %s, %s); nfx++;\n",
-           row & 0xFFu, aux, a, a, d, b);
+      emit("DEMI_FX(%uu, %uu, %s > 15u ? 15u : %s, %s, %s)\n", row & 0xFFu, aux, a, a, d, b);
     }
   }
   s += "  done:\n";

@@ -189,6 +189,7 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
   uint32_t n_tq = 0, n_resend = 0;
   uint32_t just = 0, rep = 0;         // justScheduledTimers / registered repeating timers (bit rcv*4+tidx)
   uint32_t viol = 0, flags = 0;
+  uint32_t hits = 0;                  // invariant "hit" mask of the actors (demi_device.hpp invariant_hit), kept up to date per delivery
   uint64_t tmask = 0;
   uint32_t next_id = 1, n_rec = 0;    // REC only
   demi_rec_event* rec = nullptr;
@@ -268,14 +269,17 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
     n_pend = last;
   };
 
-  auto check_invariant = [&]() -> uint32_t {
+  // The invariant's hit mask is maintained incrementally (one actor changes per delivery), so a check - every
+  // `interval` deliveries of every lane, i.e. in almost every iteration of the wave for SOME lane - is a test on a register
+  // and only reads the states when two actors hit.
 #ifdef DEMI_JIT_A
-    const uint32_t fp = invariant_code(args.model, st, exists, A, DEMI_JIT_INV_KIND, DEMI_JIT_INV_FA, DEMI_JIT_INV_VA, DEMI_JIT_INV_FB);
-    const uint32_t fp_mask = DEMI_JIT_FP_MASK;
+  const uint32_t inv_kind = DEMI_JIT_INV_KIND, inv_fa = DEMI_JIT_INV_FA, inv_va = DEMI_JIT_INV_VA, inv_fb = DEMI_JIT_INV_FB,
+                 fp_mask = DEMI_JIT_FP_MASK;
 #else
-    const uint32_t fp = invariant_code(args.model, st, exists, A, t.inv_kind, t.inv_fa, t.inv_va, t.inv_fb);
-    const uint32_t fp_mask = t.fp_mask;
+  const uint32_t inv_kind = t.inv_kind, inv_fa = t.inv_fa, inv_va = t.inv_va, inv_fb = t.inv_fb, fp_mask = t.fp_mask;
 #endif
+  auto check_invariant = [&]() -> uint32_t {
+    const uint32_t fp = invariant_from_hits(st, hits & exists, A, inv_kind, inv_fb);
     if (!fp) return 0u;
     if (args.looking_for_valid) return (((fp ^ args.looking_for) & fp_mask) == 0) ? args.looking_for : 0u;
     return fp;
@@ -327,7 +331,8 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
         te_rng = rng;                  // SrcDstFIFO: both generators are `new Random(seed)`
         hash = 0xCBF29CE484222325ULL;
         net.inaccessible = exists; net.killed = 0; net.partitioned = 0;
-        for (uint32_t a = 0; a < A; a++) st[a * 64] = t.init[a];
+        hits = 0;
+        for (uint32_t a = 0; a < A; a++) { const uint64_t s0 = t.init[a]; st[a * 64] = s0; hits |= invariant_hit(s0, inv_kind, inv_fa, inv_va) << a; }
         if (REC) { rec = args.rec_out + sched * (uint64_t)args.rec_cap; n_rec = 0; next_id = 1; }
         batch_no = 0;
       }
@@ -409,7 +414,15 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
           else { (mem.spill - lane + src)[(size_t)(slot - K1_HOT) * mem.spill_stride] = sw; spilled = true; }
         }
       }
-      if (__ballot(spilled) != 0) __threadfence_block();        // another lane's spill slots were written
+      // No fence after writing other lanes' spill slots: the owner lane belongs to this same wave, a wave's vector
+      // memory instructions are issued in order, and the memory pipeline keeps accesses to one address in that order
+      // (the same guarantee a lane relies on when it re-reads its own store).  The fence waited for every outstanding
+      // store of the wave in almost every iteration: 4.52 -> 4.41 ms per 2^20 schedules.  DEMI_K1_FLUSH_FENCE restores it.
+#ifdef DEMI_K1_FLUSH_FENCE
+      if (__ballot(spilled) != 0) __threadfence_block();
+#else
+      (void)spilled;
+#endif
       if (step && fl_cnt != 0) {
         if (n_pend + n_norm + fl_cnt > PMAX) { flags |= DEMI_V_PENDING_OVF; n_pend = PMAX - n_norm; }
         else n_pend += fl_cnt;
@@ -521,93 +534,120 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
     // ------------------------------------------------------------ the receiver's handler rows
     uint32_t nfx = 0;
     if (deliver) nfx = DEMI_VM_RUN(t, mem, w, flags);
+    if (deliver) {      // the receiver's new state decides its bit of the invariant's hit mask
+      const uint32_t me_ = w_dst(w);
+      hits = (hits & ~(1u << me_)) | (invariant_hit(st[me_ * 64], inv_kind, inv_fa, inv_va) << me_);
+    }
     PH_MARK(5);
 #ifdef DEMI_K1_PHASES
     ph_iters++; ph_active += __popcll(__ballot(deliver));
 #endif
 
-    // ------------------------------------------------------------ apply the recorded effects, in program order
-    if (deliver) {
-      const uint32_t me = w_dst(w);
+    // ------------------------------------------------------------ apply the recorded effects
+    const uint32_t me = w_dst(w);
+    // receivers of a SEND / BCAST effect that are not cut off: crosses_partition(me, .) for all receivers at once (row and
+    // column of the ordered-pair matrix, the column gathered by a multiply; inaccessible receivers; isolated sender)
+    auto send_targets = [&](uint32_t fx) -> uint32_t {
+      const bool bc = ((fx & 31u) == DEMI_OP_BCAST);
+      const uint32_t target = (fx >> 10) & 15u;
+      uint32_t tm = bc ? (exists & ~(1u << me)) : ((1u << target) & exists & 0xFFu);
+      const uint32_t row = (uint32_t)(net.partitioned >> (me * 8)) & 0xFFu;
+      const uint32_t col = (uint32_t)((((net.partitioned >> me) & 0x0101010101010101ULL) * 0x0102040810204080ULL) >> 56);
+      uint32_t blocked = row | col | net.inaccessible | (((net.inaccessible >> me) & 1u) ? 0xFFu : 0u);
+      if (!((net.killed >> me) & 1u)) blocked &= ~(1u << me);      // snd == rcv && !killed: never crosses
+      return tm & ~blocked;
+    };
+    // event_produced for internal messages (:287-297): dropped at send time when crosses_partition, else appended
+    auto apply_send = [&](uint32_t fx) {
+      const uint32_t type = (fx >> 5) & 31u, p0 = (fx >> 14) & 0xFFu, p1 = (fx >> 22) & 0xFFu;
+      if (REC) {
+        const bool bc = ((fx & 31u) == DEMI_OP_BCAST);
+        const uint32_t target = (fx >> 10) & 15u;
+        const uint32_t first = bc ? 0u : target, last = bc ? A : (target < A ? target + 1 : 0u);
+        for (uint32_t r = first; r < last; r++) {
+          if ((bc && r == me) || !((exists >> r) & 1)) continue;
+          const uint32_t id = next_id; next_id++;
+          const bool drop = crosses_partition(net, me, r);
+          if (!drop) {
+            if (FIFO) NORM_APPEND(msg_word(type, me, r, p0, p1), id);
+            else PEND_APPEND(msg_word(type, me, r, p0, p1), id, false);
+          }
+          REC_PUSH(DEMI_REC_MSG_SEND, me, r, type, p0, p1, drop ? 4 : 0, 255, id);
+        }
+      } else {
+        uint32_t tm = send_targets(fx);
+        const uint32_t base = msg_word(type, me, 0, p0, p1);
+        while (tm) {
+          const uint32_t r = (uint32_t)__builtin_ctz(tm);
+          tm &= tm - 1;
+          if (FIFO) NORM_APPEND(base | (r << 5), 0u);
+          else PEND_APPEND(base | (r << 5), 0u, false);
+        }
+      }
+    };
+    // cancelTimer (Instrumenter.scala:159-168) -> notify_timer_cancel (:525-534)
+    auto apply_cancel = [&](uint32_t type) {
+      rep &= ~TIMER_BIT(me, type);
+      const uint32_t want = (me << 5) | type;
+      // handle_timer_cancel: messagesToSend first.  The first of its n_tq bytes equal to `want`, all eight
+      // compared at once (zero-byte test on tq ^ want...want; its lowest hit is exact)
+      bool found = false;
+      {
+        const uint64_t x = tq ^ (0x0101010101010101ull * (uint64_t)want);
+        uint64_t z = (x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull;
+        z &= (n_tq >= 8) ? ~0ull : ((1ull << (8 * n_tq)) - 1ull);
+        if (z != 0) {
+          const uint32_t q = (uint32_t)__builtin_ctzll(z) >> 3;
+          const uint64_t lowm = (1ull << (8 * q)) - 1ull;
+          tq = (tq & lowm) | ((tq >> 8) & ~lowm);
+          n_tq--; found = true;
+        }
+      }
+      if (!found) {
+        // FullyRandom.remove (:653-664): first match in arr order, then swap-remove.  Only slots that hold timer
+        // messages are probed (ascending = arr order), four at a time so that their loads are in flight together (the
+        // pending set may live in HBM and the kernel is bound by such dependent round trips: 4.87 -> 4.56 ms per 2^20
+        // schedules); slots >= 64 are scanned linearly.
+        const uint32_t wantw = msg_word(type, DEMI_DEADLETTERS, me, 0, 0);
+        bool gone = false;
+#ifndef DEMI_K1_CANCEL_PROBE1
+        uint64_t m = tmask;
+        while (m != 0 && !gone) {
+          const uint64_t m1 = m & (m - 1), m2 = m1 & (m1 - 1), m3 = m2 & (m2 - 1);
+          const uint32_t q0 = (uint32_t)__builtin_ctzll(m);
+          const uint32_t q1 = m1 ? (uint32_t)__builtin_ctzll(m1) : q0, q2 = m2 ? (uint32_t)__builtin_ctzll(m2) : q0,
+                         q3 = m3 ? (uint32_t)__builtin_ctzll(m3) : q0;
+          const uint32_t w0 = pend_load(mem, q0), w1 = pend_load(mem, q1), w2 = pend_load(mem, q2), w3 = pend_load(mem, q3);
+          const uint32_t hit = (w0 == wantw) ? q0 : (w1 == wantw) ? q1 : (w2 == wantw) ? q2 : (w3 == wantw) ? q3 : 0xFFFFFFFFu;
+          if (hit != 0xFFFFFFFFu) { pend_remove(hit); gone = true; }
+          m = m3 & (m3 - 1);
+        }
+#else
+        for (uint64_t m = tmask; m != 0; m &= m - 1) {
+          const uint32_t q = (uint32_t)__builtin_ctzll(m);
+          if (pend_load(mem, q) == wantw) { pend_remove(q); gone = true; break; }
+        }
+#endif
+        for (uint32_t q = 64; !gone && q < n_pend; q++)
+          if (pend_load(mem, q) == wantw) { pend_remove(q); gone = true; }
+      }
+    };
+    // TSET / TREP: registerCancellable + handleTick (Instrumenter.scala:1145-1200)
+    auto apply_timer_set = [&](bool repeating, uint32_t type) {
+      const uint32_t bit = TIMER_BIT(me, type);
+      if (!(rep & bit)) {               // else "Non-unique timer" (:1154-1157)
+        if (repeating) rep |= bit;
+        enqueue_timer(me, type);
+      }
+    };
+    if (deliver) {      // every effect row in program order
       for (uint32_t k = 0; k < nfx && !(flags & DEMI_OVF_ANY); k++) {
         const uint32_t fx = mem.fxq[k * 64];
-        const uint32_t op = fx & 31u, type = (fx >> 5) & 31u, target = (fx >> 10) & 15u, p0 = (fx >> 14) & 0xFFu,
-                       p1 = (fx >> 22) & 0xFFu;
+        const uint32_t op = fx & 31u, type = (fx >> 5) & 31u;
         PH_MARK(9);
-        if (op <= DEMI_OP_BCAST) {
-          // event_produced for internal messages (:287-297): dropped at send time when
-          // crosses_partition, else appended to the pending set
-          const bool bc = (op == DEMI_OP_BCAST);
-          if (REC) {
-            const uint32_t first = bc ? 0u : target, last = bc ? A : (target < A ? target + 1 : 0u);
-            for (uint32_t r = first; r < last; r++) {
-              if ((bc && r == me) || !((exists >> r) & 1)) continue;
-              const uint32_t id = next_id; next_id++;
-              const bool drop = crosses_partition(net, me, r);
-              if (!drop) {
-                if (FIFO) NORM_APPEND(msg_word(type, me, r, p0, p1), id);
-                else PEND_APPEND(msg_word(type, me, r, p0, p1), id, false);
-              }
-              REC_PUSH(DEMI_REC_MSG_SEND, me, r, type, p0, p1, drop ? 4 : 0, 255, id);
-            }
-          } else {
-            // receivers as a bitmask; crosses_partition(me, .) for all receivers at once: row and column of
-            // the ordered-pair matrix (column gathered by multiply), inaccessible receivers, isolated sender
-            uint32_t tm = bc ? (exists & ~(1u << me)) : ((1u << target) & exists & 0xFFu);
-            const uint32_t row = (uint32_t)(net.partitioned >> (me * 8)) & 0xFFu;
-            const uint32_t col = (uint32_t)((((net.partitioned >> me) & 0x0101010101010101ULL) * 0x0102040810204080ULL) >> 56);
-            uint32_t blocked = row | col | net.inaccessible | (((net.inaccessible >> me) & 1u) ? 0xFFu : 0u);
-            if (!((net.killed >> me) & 1u)) blocked &= ~(1u << me);      // snd == rcv && !killed: never crosses
-            tm &= ~blocked;
-            const uint32_t base = msg_word(type, me, 0, p0, p1);
-            while (tm) {
-              const uint32_t r = (uint32_t)__builtin_ctz(tm);
-              tm &= tm - 1;
-              if (FIFO) NORM_APPEND(base | (r << 5), 0u);
-              else PEND_APPEND(base | (r << 5), 0u, false);
-            }
-          }
-          PH_MARK(6);
-        } else if (op == DEMI_OP_TCANCEL) {
-          // cancelTimer (Instrumenter.scala:159-168) -> notify_timer_cancel (:525-534)
-          rep &= ~TIMER_BIT(me, type);
-          const uint32_t want = (me << 5) | type;
-          // handle_timer_cancel: messagesToSend first.  The first of its n_tq bytes equal to `want`, all eight
-          // compared at once (zero-byte test on tq ^ want...want; its lowest hit is exact)
-          bool found = false;
-          {
-            const uint64_t x = tq ^ (0x0101010101010101ull * (uint64_t)want);
-            uint64_t z = (x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull;
-            z &= (n_tq >= 8) ? ~0ull : ((1ull << (8 * n_tq)) - 1ull);
-            if (z != 0) {
-              const uint32_t q = (uint32_t)__builtin_ctzll(z) >> 3;
-              const uint64_t lowm = (1ull << (8 * q)) - 1ull;
-              tq = (tq & lowm) | ((tq >> 8) & ~lowm);
-              n_tq--; found = true;
-            }
-          }
-          if (!found) {
-            // FullyRandom.remove (:653-664): first match in arr order, then swap-remove.  Only slots that
-            // hold timer messages are probed (ascending = arr order); slots >= 64 are scanned linearly.
-            const uint32_t wantw = msg_word(type, DEMI_DEADLETTERS, me, 0, 0);
-            bool gone = false;
-            for (uint64_t m = tmask; m != 0; m &= m - 1) {
-              const uint32_t q = (uint32_t)__builtin_ctzll(m);
-              if (pend_load(mem, q) == wantw) { pend_remove(q); gone = true; break; }
-            }
-            for (uint32_t q = 64; !gone && q < n_pend; q++)
-              if (pend_load(mem, q) == wantw) { pend_remove(q); gone = true; }
-          }
-          PH_MARK(7);
-        } else {
-          // TSET / TREP: registerCancellable + handleTick (Instrumenter.scala:1145-1200)
-          const uint32_t bit = TIMER_BIT(me, type);
-          if (!(rep & bit)) {               // else "Non-unique timer" (:1154-1157)
-            if (op == DEMI_OP_TREP) rep |= bit;
-            enqueue_timer(me, type);
-          }
-          PH_MARK(8);
-        }
+        if (op <= DEMI_OP_BCAST) { apply_send(fx); PH_MARK(6); }
+        else if (op == DEMI_OP_TCANCEL) { apply_cancel(type); PH_MARK(7); }
+        else { apply_timer_set(op == DEMI_OP_TREP, type); PH_MARK(8); }
       }
       if (flags & DEMI_OVF_ANY) ph = PH_FINISH;
     }

@@ -42,6 +42,7 @@ struct K3Args {
   uint32_t n_ext;
   const demi_dpor_trace_entry* prefixes;  // [n][stride]
   const uint32_t* prefix_len;        // [n]
+  const uint32_t* shared_len;        // [n] or null: leading events whose racing pairs the caller already has (demi_gpu.h)
   uint32_t stride;
   uint64_t n;
   uint32_t depth_bound, max_messages, looking_for_valid, looking_for, p_max, max_pairs, prioritize;
@@ -74,11 +75,11 @@ __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v, uint32_t lane
 }
 
 // dpor()'s pair loop (:1122-1139) for one finished trace T[0..n), executed by all 64 lanes of the wave.
-// Returns the number of racing pairs (wave-uniform); the first max_pairs of them are written to `po` in the
-// order of the sequential loop (later ascending, earlier ascending).
+// Returns the number of racing pairs (wave-uniform) whose later event is at index >= shared; the first max_pairs of them
+// are written to `po` in the order of the sequential loop (later ascending, earlier ascending).
 __device__ inline uint32_t k3_racing_pairs(const demi_dpor_trace_entry* __restrict__ T, uint32_t n, uint32_t* s_meta,
                                            uint64_t* s_anc, demi_dpor_pair* __restrict__ po, uint32_t max_pairs,
-                                           uint32_t lane) {
+                                           uint32_t lane, uint32_t shared) {
   constexpr uint32_t MSG = 1u << 19;
   // meta word: parent | qperiod << 8 | receiver << 16 | (kind == message delivery) << 19
   for (uint32_t i = lane; i < n; i += 64) {
@@ -110,9 +111,9 @@ __device__ inline uint32_t k3_racing_pairs(const demi_dpor_trace_entry* __restri
   for (int pass = 0; pass < 2; pass++) {
 #pragma unroll
     for (uint32_t g = 0; g < 4; g++) {
-      if (g * 64 >= n) continue;
+      if (g * 64 >= n || g * 64 + 64 <= shared) continue;      // later < shared: reported by the producing interleaving
       const uint32_t l = g * 64 + lane;
-      const bool lv = l < n;
+      const bool lv = l < n && l >= shared;
       const uint32_t ml = lv ? s_meta[l] : 0u;
       const bool lmsg = (ml & MSG) != 0;
       const uint64_t l0 = lv ? s_anc[l * 4 + 0] : 0ull, l1 = lv ? s_anc[l * 4 + 1] : 0ull,
@@ -403,8 +404,9 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
         const uint64_t s_sched = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(sched >> 32), src) << 32) |
                                  (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)sched, src);
         const uint32_t s_n = (uint32_t)__builtin_amdgcn_readlane((int)n_trace, src);
+        const uint32_t s_shared = args.shared_len ? args.shared_len[s_sched] : 0u;
         const uint32_t total = k3_racing_pairs(args.traces + s_sched * DEMI_DPOR_MAX_TRACE, s_n, s_meta, s_anc,
-                                               args.pairs + s_sched * (uint64_t)args.max_pairs, args.max_pairs, lane);
+                                               args.pairs + s_sched * (uint64_t)args.max_pairs, args.max_pairs, lane, s_shared);
         if ((int)lane == src) { np = total < args.max_pairs ? total : args.max_pairs; pairs_ovf = total > args.max_pairs; }
       }
     }

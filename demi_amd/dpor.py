@@ -152,6 +152,7 @@ class DPORwHeuristics:
         self._seq = 0
         self.exploredTracker = ExploredTacker()
         self.interleavingCounter = 0
+        self._next_shared = 0
         self.shortestTraceSoFar: Optional[np.ndarray] = None
 
     def getName(self) -> str:
@@ -179,10 +180,14 @@ class DPORwHeuristics:
                             lookingFor.code if lookingFor is not None else 0, self.p_max, self.max_pairs,
                             1 if self.prioritizePendingUponDivergence else 0)
 
-    def _run(self, externals, prefixes, params):
+    def _run(self, externals, prefixes, params, shared=None):
         from .distributed import sharded_batch
+        if shared is None:
+            shared = [0] * len(prefixes)
+        items = list(zip(prefixes, shared))
         if self._backend is not None:
-            fn = lambda part: self._backend(self.schedulerConfig.model, externals, part, params)
+            fn = lambda part: self._backend(self.schedulerConfig.model, externals, [p for p, _ in part], params,
+                                            [s for _, s in part])
         else:
             if self._ctx is None:
                 from . import _native
@@ -191,8 +196,8 @@ class DPORwHeuristics:
                 if self.specialize:
                     self._ctx.model_specialize()
                 self._ctx.dpor_load(externals)
-            fn = lambda part: self._ctx.dpor_batch(part, params)
-        return sharded_batch(prefixes, fn)
+            fn = lambda part: self._ctx.dpor_batch([p for p, _ in part], params, [s for _, s in part])
+        return sharded_batch(items, fn)
 
     # -- getNext (:1142-1162): pop the highest-priority unexplored backtrack point
     def _get_next(self):
@@ -206,8 +211,11 @@ class DPORwHeuristics:
             branch = -neg_prio[-1]
             if self.trackHistory:
                 self.exploredTracker.setExplored(branch, pair)
-            # next trace = trace.take(branch + 1) ++ needToReplay (:1054-1057, 1180), built on demand
+            # next trace = trace.take(branch + 1) ++ needToReplay (:1054-1057, 1180), built on demand.  The racing pairs
+            # inside the take() part were absorbed when `trace` ran: with the default ordering their duplicates can never
+            # be dequeued live, so the kernel need not report them again (include/demi_gpu.h, demi_dpor_batch)
             idx = [i for i in range(branch + 1, later + 1) if i != earlier]
+            self._next_shared = branch + 1 if (self.trackHistory and self._early_drop) else 0
             return np.concatenate([trace[:branch + 1], trace[idx]])
         return None
 
@@ -238,17 +246,19 @@ class DPORwHeuristics:
         externals = np.ascontiguousarray(externals, dtype=T.EXT_EVENT_DTYPE)
         params = self._params(lookingFor)
         res = Exploration()
+        shared = [0]
         if self._started and self.startFromBackTrackPoints and self.backTrack:
             # test() again on the same instance (ResumableDPOR): continue from the backtrack queue (:1219-1220)
             nxt = self._get_next()
             frontier = [nxt] if nxt is not None else []
+            shared = [self._next_shared]
         elif self._initialTrace is not None:
             frontier = [self._initialTrace]                           # setInitialTrace (:1220-1221)
         else:
             frontier = [np.zeros(0, dtype=T.DPOR_TRACE_DTYPE)]        # first run: nextTrace is empty
         self._started = True
         while frontier:
-            verdicts, traces, pairs = self._run(externals, frontier, params)
+            verdicts, traces, pairs = self._run(externals, frontier, params, shared)
             res.rounds.append(len(frontier))
             if stats is not None:
                 stats.increment_replays(len(frontier))
@@ -264,7 +274,7 @@ class DPORwHeuristics:
                 break
             if max_interleavings is not None and len(res.interleavings) >= max_interleavings:
                 break
-            frontier = []
+            frontier, shared = [], []
             while len(frontier) < self.batch:
                 if max_interleavings is not None and len(res.interleavings) + len(frontier) >= max_interleavings:
                     break
@@ -272,13 +282,17 @@ class DPORwHeuristics:
                 if nxt is None:
                     break
                 frontier.append(nxt)
+                shared.append(self._next_shared)
         res.exhausted = not self.backTrack and not frontier
         return res
 
-    def explore_native(self, externals, lookingFor: Optional[ViolationFingerprint] = None, max_interleavings: int = 100000):
+    def explore_native(self, externals, lookingFor: Optional[ViolationFingerprint] = None, max_interleavings: int = 100000,
+                       reference_order: bool = False):
         """The same exploration with the queue / explored-set bookkeeping run natively inside
         libdemi_gpu.so (demi_dpor_explore): identical rounds, verdicts and prefix lengths, two orders of
-        magnitude less host time per interleaving than this Python loop.  Single rank only."""
+        magnitude less host time per interleaving than this Python loop.  Single rank only.
+        reference_order: commit the interleavings in DPORwHeuristics' own one-at-a-time order (the sequence batch = 1
+        gives) while the device speculates `batch` wide (DEMI_DPOR_ORDER_REFERENCE)."""
         from . import _native
         if not isinstance(self.backtrackHeuristic, DefaultBacktrackOrdering) or self.should_cap_distance or \
                 self._initialTrace is not None:
@@ -292,7 +306,7 @@ class DPORwHeuristics:
                 self._ctx.model_specialize()
             self._ctx.dpor_load(externals)
         search = T.DporSearch(self.batch, max_interleavings, 1 if self.stopIfViolationFound else 0,
-                              1 if self.trackHistory else 0)
+                              1 if self.trackHistory else 0, T.DPOR_ORDER_REFERENCE if reference_order else T.DPOR_ORDER_ROUNDS)
         verdicts, plen, rounds, vtrace, stats = self._ctx.dpor_explore(self._params(lookingFor), search)
         res = Exploration()
         res.rounds = [int(r) for r in rounds]
@@ -306,6 +320,7 @@ class DPORwHeuristics:
             res.interleavings[int(stats.first_violation)].trace = vtrace
             self.shortestTraceSoFar = vtrace
         self.interleavingCounter += len(verdicts)
+        self.last_native_stats = stats
         return res
 
     def test(self, events, violation_fingerprint: ViolationFingerprint, _stats: Optional[MinimizationStats] = None):

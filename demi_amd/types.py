@@ -94,13 +94,20 @@ class DporParams(C.Structure):
 
 class DporSearch(C.Structure):
     _fields_ = [("batch", C.c_uint32), ("max_interleavings", C.c_uint32), ("stop_if_violation", C.c_uint32),
-                ("track_history", C.c_uint32)]
+                ("track_history", C.c_uint32), ("order", C.c_uint32), ("cache_mb", C.c_uint32)]
+
+    def __init__(self, batch=1, max_interleavings=1, stop_if_violation=0, track_history=1, order=0, cache_mb=0):
+        super().__init__(batch, max_interleavings, stop_if_violation, track_history, order, cache_mb)
 
 
 class DporStats(C.Structure):
     _fields_ = [("interleavings", C.c_uint64), ("launches", C.c_uint64), ("violations", C.c_uint64),
                 ("first_violation", C.c_uint64), ("queue_len", C.c_uint64), ("exhausted", C.c_uint32),
-                ("pad", C.c_uint32)]
+                ("pad", C.c_uint32), ("executed", C.c_uint64), ("cache_misses", C.c_uint64)]
+
+
+DPOR_ORDER_ROUNDS = 0       # demi_dpor_order
+DPOR_ORDER_REFERENCE = 1
 
 
 assert C.sizeof(ExtEvent) == 8 and C.sizeof(Verdict) == 16 and C.sizeof(RecEvent) == 12

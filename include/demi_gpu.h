@@ -301,8 +301,18 @@ typedef struct { uint8_t branch, later, earlier, pad; } demi_dpor_pair;  /* trac
 int demi_dpor_load(demi_ctx* ctx, const demi_ext_event* externals, uint32_t n_ext);
 /* prefixes: [n][stride] entries of nextTrace (root and markers included, as getNext builds them,
  * :1180; only key, word and kind are read); outputs are [n], [n][DEMI_DPOR_MAX_TRACE], [n],
- * [n][max_pairs], [n].  All host pointers.                                                         */
-int demi_dpor_batch(demi_ctx* ctx, const demi_dpor_trace_entry* prefixes, const uint32_t* prefix_len, uint32_t stride,
+ * [n][max_pairs], [n].  All host pointers.
+ * shared_len (may be NULL = all 0): shared_len[i] leading events of prefix i are the `trace.take(branch + 1)` part of the
+ * next trace (:1054-1057, 1180), i.e. events of the interleaving that produced this backtrack point.  The replay
+ * reproduces them at the same trace indices, so every racing pair (later, earlier) with later < shared_len[i] was
+ * already reported - same node keys, same branch - when that interleaving ran, and dpor()'s bookkeeping for it is a
+ * no-op now: (earlier, later) is in the ExploredTacker (:1068-1070), and the backtrack point it would enqueue (:1134) was
+ * either enqueued then with the same branch and an older creation time, so it is dequeued first, or its flipped pair
+ * was explored already; getNext() drops the duplicate either way (:1153-1157).  Those pairs are not reported.  Only
+ * valid with trackHistory and DefaultBacktrackOrdering (the duplicate's priority equals the original's); pass 0
+ * otherwise.                                                                                         */
+int demi_dpor_batch(demi_ctx* ctx, const demi_dpor_trace_entry* prefixes, const uint32_t* prefix_len,
+                    const uint32_t* shared_len, uint32_t stride,
                     uint64_t n, const demi_dpor_params* params, demi_verdict* out_verdicts,
                     demi_dpor_trace_entry* out_traces, uint32_t* out_trace_len, demi_dpor_pair* out_pairs,
                     uint32_t* out_n_pairs);
@@ -313,11 +323,25 @@ int demi_dpor_batch(demi_ctx* ctx, const demi_dpor_trace_entry* prefixes, const 
  * run natively on the host around demi_dpor_batch-sized launches.  A round pops up to `batch`
  * unexplored backtrack points (batch = 1 is the reference's one-at-a-time order; PriorityQueue ties
  * pop in creation order) and each point carries its own next trace.                                */
+/* In which order the backtrack points are explored.
+ * ROUNDS: a round pops up to `batch` unexplored points, runs them as one launch and absorbs their racing pairs in pop
+ *   order.  batch = 1 is the reference's order; the explored-pair heuristic (ExploredTacker, AuxilaryTypes.scala:209-246)
+ *   makes the SET of explored interleavings depend on the order, so a wider round explores a slightly different set
+ *   (DESIGN.md section 4 K3 has the measured difference).
+ * REFERENCE: exactly the sequence of interleavings of batch = 1 - DPORwHeuristics' own depth-first order
+ *   (:1142-1185) with PriorityQueue ties in creation order - whatever `batch` is.  The device runs ahead speculatively
+ *   (a ROUNDS exploration of width `batch` whose results are cached by next-trace identity) and the host commits the
+ *   cached results strictly one at a time, launching what the speculation missed.  An interleaving is a pure function of
+ *   its next trace, so the committed sequence, verdicts and violating set do not depend on what was speculated.        */
+typedef enum { DEMI_DPOR_ORDER_ROUNDS = 0, DEMI_DPOR_ORDER_REFERENCE = 1 } demi_dpor_order;
+
 typedef struct {
-  uint32_t batch;               /* backtrack points per launch (>= 1) */
+  uint32_t batch;               /* backtrack points per launch (>= 1); REFERENCE order: width of the speculation */
   uint32_t max_interleavings;   /* budget; also the capacity of the output arrays */
   uint32_t stop_if_violation;   /* stopIfViolationFound */
   uint32_t track_history;       /* trackHistory */
+  uint32_t order;               /* demi_dpor_order */
+  uint32_t cache_mb;            /* REFERENCE order: host memory for speculated results not yet committed (0 = 1024) */
 } demi_dpor_search;
 
 typedef struct {
@@ -328,6 +352,8 @@ typedef struct {
   uint64_t queue_len;           /* backtrack points still queued at return */
   uint32_t exhausted;           /* the queue ran empty */
   uint32_t pad;
+  uint64_t executed;            /* interleavings run on the device (REFERENCE order: committed + speculated in vain) */
+  uint64_t cache_misses;        /* REFERENCE order: committed interleavings the speculation had not run */
 } demi_dpor_stats;
 
 /* out_verdicts / out_prefix_len: [max_interleavings], in execution order.  first_violation_trace:

@@ -1118,7 +1118,7 @@ static void dpor_deliver(dpor_t* x, uint32_t w) {
 }
 
 int orc_dpor_execute(const demi_model* m, const demi_ext_event* ext, uint32_t n_ext, const uint64_t* prefix,
-                     uint32_t prefix_len, const demi_dpor_params* par, demi_verdict* out,
+                     uint32_t prefix_len, uint32_t shared_len, const demi_dpor_params* par, demi_verdict* out,
                      demi_dpor_trace_entry* trace, uint32_t* trace_len, demi_dpor_pair* pairs, uint32_t* n_pairs) {
   dpor_t* x = (dpor_t*)calloc(1, sizeof(dpor_t));
   if (!x) return DEMI_ERR_INVALID_ARG;
@@ -1212,7 +1212,10 @@ int orc_dpor_execute(const demi_model* m, const demi_ext_event* ext, uint32_t n_
   /* ---- dpor(): racing pairs (:1122-1139) with isCoEnabeled (:1091-1110) and analyze_dep (:1043-1077) */
   uint32_t np = 0, pairs_ovf = 0;
   if (!aborted) {
-    for (uint32_t l = 0; l < x->n_trace; l++) {
+    /* shared_len: the first shared_len events of this trace are those of the interleaving whose backtrack point this
+     * prefix is (trace.take(branch + 1), :1180).  A pair inside that part was reported, with the same keys and the same
+     * branch, when that interleaving ran, so dpor() has nothing new to learn from it (see include/demi_gpu.h). */
+    for (uint32_t l = shared_len; l < x->n_trace; l++) {
       if (trace[l].kind != 1) continue;
       for (uint32_t e = 0; e < l; e++) {
         if (trace[e].kind != 1) continue;

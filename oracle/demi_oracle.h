@@ -80,7 +80,7 @@ int orc_sts_removal_batch(const demi_model* m, const demi_ext_event* original_ex
 /* ---- K3: one DPORwHeuristics interleaving (V/schedulers/DPORwHeuristics.scala:421-942) + the racing-pair
  * analysis of dpor() (:1020-1139).  prefix: nextTrace as node keys.  trace: [DEMI_DPOR_MAX_TRACE]. */
 int orc_dpor_execute(const demi_model* m, const demi_ext_event* ext, uint32_t n_ext, const uint64_t* prefix,
-                     uint32_t prefix_len, const demi_dpor_params* par, demi_verdict* out,
+                     uint32_t prefix_len, uint32_t shared_len, const demi_dpor_params* par, demi_verdict* out,
                      demi_dpor_trace_entry* trace, uint32_t* trace_len, demi_dpor_pair* pairs, uint32_t* n_pairs);
 int orc_dpor_trace_validate(const demi_model* m, const demi_ext_event* ev, uint32_t n, char* err, size_t err_cap);
 

@@ -48,7 +48,7 @@ def lib():
                                             C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(T.Limits), C.c_void_p, C.c_int]
         L.orc_sts_removal.argtypes = [C.POINTER(T.ModelStruct), C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
                                       C.c_void_p, C.c_uint32, C.POINTER(T.Limits), C.POINTER(T.Verdict), C.c_void_p]
-        L.orc_dpor_execute.argtypes = [C.POINTER(T.ModelStruct), C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
+        L.orc_dpor_execute.argtypes = [C.POINTER(T.ModelStruct), C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32,
                                        C.POINTER(T.DporParams), C.POINTER(T.Verdict), C.c_void_p, C.POINTER(C.c_uint32),
                                        C.c_void_p, C.POINTER(C.c_uint32)]
         _LIB = L
@@ -161,8 +161,9 @@ def sts_removal_kept(model, original_externals, original_trace, skip, limits, ma
     return v, kept[:len(rec)]
 
 
-def dpor_batch(model, externals, prefixes, params):
-    """One DPORwHeuristics interleaving per prefix on the CPU; same return shape as Context.dpor_batch."""
+def dpor_batch(model, externals, prefixes, params, shared=None):
+    """One DPORwHeuristics interleaving per prefix on the CPU; same return shape as Context.dpor_batch.
+    shared[i]: leading events of prefix i whose racing pairs the caller already has (0 = report all)."""
     ms = model.to_struct()
     ev = np.ascontiguousarray(externals, dtype=T.EXT_EVENT_DTYPE)
     verdicts = np.zeros(len(prefixes), dtype=T.VERDICT_DTYPE)
@@ -174,7 +175,7 @@ def dpor_batch(model, externals, prefixes, params):
         pr = np.zeros(max(1, params.max_pairs), dtype=T.DPOR_PAIR_DTYPE)
         tl, npr = C.c_uint32(0), C.c_uint32(0)
         rc = lib().orc_dpor_execute(C.byref(ms), ev.ctypes.data, len(ev), keys.ctypes.data if len(keys) else None, len(keys),
-                                    C.byref(params), C.byref(v), tr.ctypes.data, C.byref(tl), pr.ctypes.data, C.byref(npr))
+                                    int(shared[i]) if shared is not None else 0, C.byref(params), C.byref(v), tr.ctypes.data, C.byref(tl), pr.ctypes.data, C.byref(npr))
         assert rc == 0
         verdicts[i] = (v.flags, v.fingerprint, v.hash)
         traces.append(tr[:tl.value].copy())

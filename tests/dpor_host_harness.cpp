@@ -15,15 +15,15 @@ extern "C" int harness_dpor_explore(const demi_model* m, const demi_ext_event* e
                                     demi_dpor_stats* stats, double* seconds) {
   std::vector<demi_dpor_trace_entry> all_tr;
   std::vector<demi_dpor_pair> all_pr;
-  auto run = [&](const demi_dpor_trace_entry* pf, const uint32_t* pl, uint32_t stride, uint64_t n, demi_verdict* vd,
-                 uint32_t* tl, uint32_t* np) {
+  auto run = [&](const demi_dpor_trace_entry* pf, const uint32_t* pl, const uint32_t* sh, uint32_t stride, uint64_t n,
+                 demi_verdict* vd, uint32_t* tl, uint32_t* np) {
     all_tr.resize(n * DEMI_DPOR_MAX_TRACE);
     all_pr.resize(n * (size_t)par->max_pairs);
     auto work = [&](unsigned t) {
       std::vector<uint64_t> keys(DEMI_DPOR_MAX_TRACE);
       for (uint64_t i = t; i < n; i += (unsigned)n_threads) {
         for (uint32_t k = 0; k < pl[i]; k++) keys[k] = pf[i * stride + k].key;
-        orc_dpor_execute(m, ext, n_ext, keys.data(), pl[i], par, &vd[i], &all_tr[i * DEMI_DPOR_MAX_TRACE], &tl[i],
+        orc_dpor_execute(m, ext, n_ext, keys.data(), pl[i], sh ? sh[i] : 0u, par, &vd[i], &all_tr[i * DEMI_DPOR_MAX_TRACE], &tl[i],
                          &all_pr[i * (size_t)par->max_pairs], &np[i]);
       }
     };

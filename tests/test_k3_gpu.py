@@ -23,13 +23,18 @@ def same_batch(g, c):
         assert len(a) == len(b) and (a == b).all()
 
 
+launched_shared = []      # the shared lengths of the prefixes of the last collect_prefixes call
+
+
 def collect_prefixes(oracle, model, ev, depth, batch, budget):
     """Run an oracle-backed exploration and keep every prefix it launched."""
     launched = []
+    launched_shared.clear()
 
-    def backend(m, e, prefixes, params):
+    def backend(m, e, prefixes, params, shared=None):
         launched.extend(prefixes)
-        return oracle.dpor_batch(m, e, prefixes, params)
+        launched_shared.extend(shared if shared is not None else [0] * len(prefixes))
+        return oracle.dpor_batch(m, e, prefixes, params, shared)
 
     d = DPORwHeuristics(SchedulerConfig(model=model), depth_bound=depth, stopIfViolationFound=False, batch=batch, backend=backend)
     res = d.explore(ev, max_interleavings=budget)
