@@ -10,6 +10,13 @@ Inputs (transition table, trace) and outputs (verdicts) are resident in HBM duri
   python bench.py --gpus 1 --steps 10 --warmup 2
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
       --master-port P bench.py --gpus N --steps K --warmup W
+
+The one JSON line also carries, under "secondary" (N = 1 only, after the timed region), the other two loops of the
+hot path on their BASELINE configurations, each with its own roofline and CPU baseline:
+  dpor   config 3: DPORwHeuristics, raft5, depth 30 — the whole bounded exploration (interleavings/s), in ROUNDS order and
+         in the reference's own order;
+  ddmin  config 4: STSSched replays of candidate subsequences of a 200-event failing execution (replays/s).
+`--workload dpor|ddmin` prints that record alone as the line (same contract fields).
 """
 import argparse
 import ctypes as C
@@ -25,6 +32,145 @@ if ROOT not in sys.path:
 N_PER_GPU = 1 << 20           # "1M random interleavings on 1 MI355X"
 VIOL_CAP = 1 << 16            # found-violation list capacity per rank and step
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
+PREWARM_S = 1.5               # untimed launches before the warmup steps: the shader clock ramps over ~1 s (DVFS)
+K1_COUNTERS = os.path.join(ROOT, "profiles", "k1_counters.json")   # rocprofv3 --pmc passes of this workload (tools/profile_k1.sh)
+
+
+def roofline(bound_bytes, kernel_ms, traffic, kernel, note, extra=None):
+    achieved = bound_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms else 0.0
+    r = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+         "traffic": traffic, "kernel": kernel, "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": bound_bytes, "note": note}
+    if extra:
+        r.update(extra)
+    return r
+
+
+def bench_dpor(ctx_device, cpu_baseline=True, batch=16384):
+    """BASELINE config 3: the whole bounded DPOR exploration of raft5 (depth 30, Start x 5 + Send x 5)."""
+    import numpy as np
+    from demi_amd import types as T
+    from demi_amd.apps import raft5_config3
+    from demi_amd.dpor import DPORwHeuristics
+    from demi_amd.schedulers import SchedulerConfig
+    model, ev, depth = raft5_config3()
+    out = {"metric": "interleavings explored/sec, DPORwHeuristics bounded exploration (raft5, depth 30)", "unit": "interleavings/s",
+           "config": {"workload": "raft5-synth, Start x 5 + Send(Bootstrap) x 5, depth_bound 30, trackHistory, stopIfViolationFound = false, "
+                                  "explored until the backtrack queue is empty", "batch": batch}}
+    runs = {}
+    for name, ref in (("rounds", False), ("reference_order", True)):
+        d2 = DPORwHeuristics(SchedulerConfig(model=model), depth_bound=depth, stopIfViolationFound=False, batch=batch,
+                             device=ctx_device, specialize=True)
+        d2.explore_native(ev, max_interleavings=64)          # context, compilation for this table, first launches
+        t = time.perf_counter()                              # (every explore_native call is a fresh exploration)
+        res = d2.explore_native(ev, max_interleavings=1 << 17, reference_order=ref)
+        dt = time.perf_counter() - t
+        st = d2.last_native_stats
+        runs[name] = {"value": len(res.interleavings) / dt, "seconds": dt, "interleavings": len(res.interleavings),
+                      "executed_on_device": int(st.executed), "launches": int(st.launches), "exhausted": bool(res.exhausted),
+                      "violations": len(res.violations), "distinct_schedules": len(res.schedule_hashes()),
+                      "kernel_ms_total": float(st.kernel_ms), "h2d_bytes": int(st.h2d_bytes), "d2h_bytes": int(st.d2h_bytes)}
+        if ref:
+            runs[name]["launches_for_results_the_speculation_lacked"] = int(st.cache_misses)
+        d2.shutdown()
+    out["value"] = runs["rounds"]["value"]
+    out["orders"] = runs
+    r = runs["rounds"]
+    # algorithmic bytes of the K3 launches: next traces in, verdicts + traces + racing pairs out (what the bookkeeping consumes)
+    alg = r["h2d_bytes"] + r["d2h_bytes"]
+    out["roofline"] = roofline(alg, r["kernel_ms_total"], None, "k3_dpor (specialised, hiprtc), %d launches" % r["launches"],
+                               "bytes = next traces uploaded + verdicts, traces and racing pairs fetched over the whole exploration "
+                               "(the output arrays are strided by capacity on the device; only the used part crosses PCIe); "
+                               "kernel_ms = sum of the launches (HIP events in the library). K3 is latency / issue bound: a round of "
+                               "the backtrack queue is far smaller than the chip")
+    if cpu_baseline:
+        from oracle import oracle_py as O
+        cores = os.cpu_count() or 1
+        par = T.DporParams(depth, 0, 0, 0, 64, 4096)
+        base = {}
+        for name, ref in (("rounds", False), ("reference_order", True)):
+            srch = T.DporSearch(batch, 1 << 17, 0, 1, T.DPOR_ORDER_REFERENCE if ref else T.DPOR_ORDER_ROUNDS)
+            t = time.perf_counter()
+            v, plen, rounds, vt, st, secs = O.dpor_explore(model, ev, par, srch, n_threads=cores)
+            dt = time.perf_counter() - t
+            base[name] = {"value": len(v) / dt, "seconds": dt, "interleavings": len(v)}
+        out["cpu_baseline"] = {"value": base["rounds"]["value"], "unit": "interleavings/s", "cores": cores, "kind": "port",
+                               "sample": "the same whole exploration: oracle/demi_oracle.c interleavings on %d host threads (one next "
+                                         "trace per thread) under the same host bookkeeping (demi_amd/csrc/dpor_host.hpp)" % cores,
+                               "orders": base,
+                               "same_interleaving_count_as_gpu": {k: base[k]["interleavings"] == runs[k]["interleavings"] for k in base}}
+    return out
+
+
+def bench_ddmin(ctx_device, cpu_baseline=True, n=1 << 20):
+    """BASELINE config 4: STSSched (no peek) replays of candidate subsequences of a 200-event failing Raft-5 execution."""
+    import numpy as np
+    import torch
+    from demi_amd import _native, types as T
+    from demi_amd.apps import SEED_BASE, raft5_config4
+    model, events, lim = raft5_config4()
+    ctx = _native.Context(ctx_device)
+    ctx.model_load(model.to_struct())
+    ctx.trace_load(events)
+    v = ctx.random_explore(4000, lim, seed_base=SEED_BASE)
+    i = int(np.nonzero(v["flags"] & T.V_VIOLATION)[0][0])
+    vv, rec = ctx.random_get_trace(SEED_BASE + i, lim)
+    used = events[:T.verdict_trace_idx(vv.flags)]
+    ctx.replay_load(used, rec)
+    ctx.model_specialize()
+    rng = np.random.default_rng(0)
+    masks = np.zeros((n, 4), dtype=np.uint64)
+    keep = rng.random((n, len(used))) < 0.7
+    for w in range(4):
+        bits = keep[:, 64 * w:64 * (w + 1)]
+        masks[:, w] = (bits.astype(np.uint64) << np.arange(bits.shape[1], dtype=np.uint64)).sum(axis=1)
+    target = T.Limits(0, 0, 128, 1, vv.fingerprint, 0)
+    dev = torch.device("cuda", ctx_device)
+    d_masks = torch.from_numpy(masks.view(np.int64)).to(dev)
+    d_out = torch.empty((n, 2), dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream(dev)
+    sp = C.c_void_p(stream.cuda_stream)
+    ctx.replay_batch_dev(d_masks.data_ptr(), 256, target, d_out.data_ptr(), stream=sp)      # compiles K2 for this table
+    torch.cuda.synchronize(dev)
+    res = {}
+    for m, reps in ((256, 50), (n, 5)):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ctx.replay_batch_dev(d_masks.data_ptr(), m, target, d_out.data_ptr(), stream=sp)
+        torch.cuda.synchronize(dev)
+        t = time.perf_counter()
+        e0.record(stream)
+        for _ in range(reps):
+            ctx.replay_batch_dev(d_masks.data_ptr(), m, target, d_out.data_ptr(), stream=sp)
+        e1.record(stream)
+        torch.cuda.synchronize(dev)
+        res[m] = {"kernel_ms": e0.elapsed_time(e1) / reps, "wall_ms": (time.perf_counter() - t) * 1e3 / reps}
+    got = d_out.cpu().numpy().view(T.VERDICT_DTYPE).reshape(-1)
+    n_exp = int(sum(1 for e in rec if e["kind"] in (0, 1, 2, 3, 7) or (e["kind"] == 6 and e["flags"] & 1)))
+    kms = res[n]["kernel_ms"]
+    out = {"metric": "candidate subsequences replayed/sec (STSScheduler.test without peek, DDMin's oracle)", "unit": "replays/s",
+           "value": n / (res[n]["wall_ms"] * 1e-3),
+           "config": {"workload": "raft5-synth, 200-event failing execution (%d externals used, %d recorded events, %d deliveries), "
+                                  "%d random candidate subsequences per launch, masks and verdicts resident in HBM" %
+                                  (len(used), len(rec), T.verdict_deliveries(vv.flags), n), "candidates_per_launch": n},
+           "launch_floor": {"candidates": 256, "kernel_us": res[256]["kernel_ms"] * 1e3, "wall_us": res[256]["wall_ms"] * 1e3},
+           "still_violating": int((got["flags"] & T.V_VIOLATION).sum())}
+    # algorithmic HBM bytes per candidate: 32 B mask in + 16 B verdict out; the lowered original trace (8 B x expected events)
+    # is shared by every lane (read once per workgroup into LDS)
+    alg = 48 * n + 8 * n_exp * ((n + 255) // 256)
+    out["roofline"] = roofline(alg, kms, None, "k2_replay (specialised, hiprtc)",
+                               "32 B mask + 16 B verdict per candidate, the lowered original trace (%d x 8 B) once per workgroup; "
+                               "the replay itself is integer / LDS work" % n_exp)
+    ctx.close()
+    if cpu_baseline:
+        from oracle import oracle_py as O
+        cores = os.cpu_count() or 1
+        sample = masks[:262144]
+        t = time.perf_counter()
+        c = O.sts_replay_batch(model, used, rec, sample, target, n_threads=cores)
+        dt = time.perf_counter() - t
+        out["cpu_baseline"] = {"value": len(sample) / dt, "unit": "replays/s", "cores": cores, "kind": "port",
+                               "sample": "first %d of the same candidate masks, oracle/demi_oracle.c on %d pthreads" % (len(sample), cores),
+                               "seconds": dt, "bit_identical_to_gpu": bool((c == got[:len(sample)]).all())}
+    return out
 
 
 def main():
@@ -32,10 +178,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", choices=["fuzz", "dpor", "ddmin"], default="fuzz")
     ap.add_argument("--schedules", type=int, default=N_PER_GPU, help="schedules per GPU per step")
     ap.add_argument("--p-max", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="fuzz line only (no dpor / ddmin records)")
     ap.add_argument("--no-specialize", action="store_true", help="interpret the transition table instead of compiling it")
+    ap.add_argument("--no-prewarm", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=1 << 20)
     ap.add_argument("--strategy", choices=["random", "fifo"], default="random",
                     help="RandomizationStrategy: FullyRandom (the headline workload) or SrcDstFIFO")
@@ -60,6 +209,16 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+
+    if args.workload != "fuzz":
+        assert world == 1, "the dpor / ddmin records are single-GPU"
+        fn = bench_dpor if args.workload == "dpor" else bench_ddmin
+        t = time.perf_counter()
+        rec = fn(local_rank, cpu_baseline=not args.no_cpu_baseline)
+        rec.update({"n_gpus": 1, "steps": 1, "warmup": 1, "ms_per_step": (time.perf_counter() - t) * 1e3, "higher_is_better": True,
+                    "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic"})
+        print(json.dumps(rec))
+        return
 
     model, events, limits = raft5_config2()
     limits.p_max = args.p_max
@@ -104,6 +263,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # a freshly leased GPU idles at a low shader clock and ramps over about a second of load: run the same launches
+    # untimed first so that the W warmup steps and the K timed steps see the clock a long-running job sees
+    prewarm_s = 0.0
+    if not args.no_prewarm:
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < PREWARM_S:
+            ctx.random_explore_dev(n, limits, verdicts.data_ptr(), seed_base=SEED_BASE + index_base, stream=sp)
+            torch.cuda.synchronize()
+        prewarm_s = time.perf_counter() - t0
     for _ in range(args.warmup):
         step()
     sync()
@@ -137,36 +305,44 @@ def main():
         total = world * n * args.steps
         value = total / dt
         # algorithmic bytes of one K1 launch: 16 B verdict per schedule out, plus the
-        # trace and the transition table streamed once per workgroup
-        # the trace and the tables are streamed once per resident workgroup (3 per CU at this LDS footprint)
+        # trace and the transition table streamed once per resident workgroup
         blocks = min((n + 255) // 256, torch.cuda.get_device_properties(dev).multi_processor_count *
                      ((3 if specialized else 2) if args.strategy == "fifo" else (6 if specialized else 3)))
         shared = 8 * len(events) + 4 * len(model.code) + 4 * len(model.handler_start) + 8 * 8 + 32 * 4 + 132 * 4 + 64 * 4
         alg_bytes = 16 * n + blocks * shared
-        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-        traffic = None
-        tp = os.path.join(ROOT, "profiles", "k1_hbm_traffic.json")
-        if os.path.exists(tp):
-            with open(tp) as f:
-                traffic = json.load(f).get("hbm_bytes_per_launch")
-        # the bound that actually binds: VALU / SALU issue.  Instruction counts per launch come from the
-        # committed rocprofv3 --pmc pass of this same workload and kernel flavour, the duration is this run's.
-        issue = None
-        cp = os.path.join(ROOT, "profiles", "r01_k1_final_counters.json")
-        if os.path.exists(cp) and specialized and args.strategy == "random" and n == N_PER_GPU:
-            with open(cp) as f:
+        # measured on this box, right after the timed region: the shader clock under load and the SIMD cycles per wave64
+        # integer VALU instruction (alone on the SIMD / with 6 waves competing as in K1)
+        probe = None
+        try:
+            p1, p6 = ctx.device_probe(1, 20000), ctx.device_probe(6, 6000)
+            probe = {"shader_clock_ghz": p6.shader_clock_ghz, "simd_cycles_per_int_valu_1_wave": p1.cycles_per_valu,
+                     "simd_cycles_per_int_valu_6_waves": p6.cycles_per_valu,
+                     "how": "demi_device_probe: s_memtime cycles per 100 MHz wall_clock64 tick; 64-instruction unrolled "
+                            "v_mad_u32_u24 / v_add / v_xor passes on 8 independent accumulators"}
+        except Exception as e:
+            print("bench: device probe failed: %s" % e, file=sys.stderr)
+        # rocprofv3 counters of THIS kernel build on this workload (tools/profile_k1.sh writes profiles/k1_counters.json with
+        # the duration it saw): used only when that duration is within 10 % of this run's, i.e. the same kernel
+        traffic, issue, stale = None, None, None
+        if os.path.exists(K1_COUNTERS) and specialized and args.strategy == "random" and n == N_PER_GPU:
+            with open(K1_COUNTERS) as f:
                 ctr = json.load(f)
-            k1 = next((v for k, v in ctr.items() if "k1_random_explore" in k), None)
-            if k1 and "SQ_INSTS_VALU" in k1:
-                props = torch.cuda.get_device_properties(dev)
-                simds = props.multi_processor_count * 4
-                clk = float(getattr(props, "clock_rate", 2400000)) * 1e3          # kHz -> Hz (MI355X: 2.4 GHz)
-                valu, salu = k1["SQ_INSTS_VALU"]["avg_per_dispatch"], k1["SQ_INSTS_SALU"]["avg_per_dispatch"]
-                issue = {"valu_insts_per_launch": valu, "salu_insts_per_launch": salu,
-                         "valu_issue_frac": valu * 4.0 / simds / (kernel_ms * 1e-3 * clk),
-                         "salu_issue_frac": salu / props.multi_processor_count / (kernel_ms * 1e-3 * clk),
-                         "clock_hz": clk, "source": "profiles/r01_k1_final_counters.json (SQ_INSTS_VALU / SQ_INSTS_SALU); a wave64 "
-                         "VALU instruction occupies its SIMD for 4 cycles, the scalar unit is one per CU"}
+            pms = float(ctr.get("kernel_ms", 0.0))
+            if pms > 0 and abs(pms - kernel_ms) / pms <= 0.10:
+                traffic = ctr.get("fabric_bytes_per_launch")
+                if probe and "SQ_INSTS_VALU" in ctr:
+                    props = torch.cuda.get_device_properties(dev)
+                    cus = props.multi_processor_count
+                    clk = probe["shader_clock_ghz"] * 1e9
+                    valu, salu = ctr["SQ_INSTS_VALU"], ctr["SQ_INSTS_SALU"]
+                    issue = {"valu_insts_per_launch": valu, "salu_insts_per_launch": salu,
+                             "active_lanes_per_valu_inst": ctr.get("SQ_THREAD_CYCLES_VALU", 0) / valu if valu else None,
+                             "valu_issue_frac": valu * probe["simd_cycles_per_int_valu_6_waves"] / (cus * 4) / (kernel_ms * 1e-3 * clk),
+                             "salu_issue_frac": salu / cus / (kernel_ms * 1e-3 * clk),
+                             "clock_hz": clk, "source": "profiles/k1_counters.json (rocprofv3 --pmc, kernel_ms %.3f there); clock and "
+                             "cycles per VALU instruction measured in this run; one scalar unit per CU assumed" % pms}
+            else:
+                stale = "profiles/k1_counters.json describes a %.3f ms kernel, this run measured %.3f ms: counters not quoted" % (pms, kernel_ms)
         out = {
             "metric": "candidate schedules evaluated/sec on Raft-5 fuzz (RandomScheduler executions)",
             "value": value, "unit": "schedules/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -177,23 +353,21 @@ def main():
                        "schedules_per_gpu_per_step": n, "max_messages": int(limits.max_messages),
                        "invariant_check_interval": int(limits.invariant_check_interval), "p_max": int(limits.p_max),
                        "randomization_strategy": "SrcDstFIFO" if args.strategy == "fifo" else "FullyRandom",
-                       "table_compiled_to_native_code": specialized, "seed_base": SEED_BASE, "parallelism": "schedule-index range sharded, %d rank(s)" % world},
+                       "table_compiled_to_native_code": specialized, "seed_base": SEED_BASE, "parallelism": "schedule-index range sharded, %d rank(s)" % world,
+                       "untimed_prewarm_s": prewarm_s},
             "violations_last_step": int(len(vset)),
             "distinct_fingerprints_last_step": int(len(np.unique(vset["fingerprint"]))) if len(vset) else 0,
             "distinct_violating_delivery_hashes_last_step_rank0_shard": distinct_hashes,
             "bugs_per_hr": float(len(vset)) / (dt / args.steps) * 3600.0,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": ("k1_random_explore<false, true>" if args.strategy == "fifo" else "k1_random_explore<false, false>") +
-                                   (" (specialised, hiprtc)" if specialized else ""),
-                         "kernel_ms": kernel_ms,
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "integer/LDS-bound simulation: algorithmic HBM traffic is 16 B per schedule, so the "
-                                 "HBM fraction is tiny by construction (SURVEY 8d); see DESIGN.md for the issue-rate model. "
-                                 "traffic above the algorithmic bytes is the pending sets of the specialised build, kept in "
-                                 "an HBM scratch instead of LDS (24 waves/CU, no divergent LDS/scratch branch): a measured "
-                                 "trade, DESIGN.md section 4 K1; it is working-set traffic, not re-reads of inputs",
-                         "issue_model": issue},
+            "roofline": roofline(alg_bytes, kernel_ms, traffic,
+                                 ("k1_random_explore<false, true>" if args.strategy == "fifo" else "k1_random_explore<false, false>") +
+                                 (" (specialised, hiprtc)" if specialized else ""),
+                                 "integer / latency-bound simulation: algorithmic HBM traffic is 16 B per schedule, so the HBM "
+                                 "fraction is tiny by construction (SURVEY 8d). `traffic` = fabric-side bytes (L2 <-> Infinity Cache / "
+                                 "HBM; FETCH_SIZE x 2 + WRITE_SIZE as calibrated in profiles/), dominated by the pending sets the "
+                                 "specialised build keeps in a [slot][lane] scratch instead of LDS (24 waves per CU): a measured trade, "
+                                 "DESIGN.md section 4 K1; that working set (~47 MB) fits the 256 MiB Infinity Cache",
+                                 {"issue_model": issue, "probe": probe, "counters_stale": stale}),
         }
         if not args.no_cpu_baseline and world == 1:
             from oracle import oracle_py as O
@@ -207,8 +381,17 @@ def main():
                                    "sample": "first %d schedules of the same workload, oracle/demi_oracle.c with %d "
                                              "pthreads (restated CPU oracle, not the DEMi JVM)" % (m, cores),
                                    "seconds": tcpu, "bit_identical_to_gpu": same}
-        print(json.dumps(out))
     ctx.close()
+    if rank == 0:
+        if world == 1 and not args.no_secondary:
+            sec = {}
+            for name, fn in (("dpor", bench_dpor), ("ddmin", bench_ddmin)):
+                try:
+                    sec[name] = fn(local_rank, cpu_baseline=not args.no_cpu_baseline)
+                except Exception as e:          # a secondary record must never cost the headline line
+                    sec[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+            out["secondary"] = sec
+        print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
 

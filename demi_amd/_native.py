@@ -15,7 +15,7 @@ EXPORTS = ["demi_ctx_create", "demi_ctx_destroy", "demi_last_error", "demi_versi
            "demi_trace_load", "demi_random_explore", "demi_random_explore_dev", "demi_random_get_trace", "demi_collect_violations_dev",
            "demi_replay_load", "demi_replay_batch", "demi_replay_batch_dev", "demi_dpor_load", "demi_dpor_batch", "demi_dpor_explore", "demi_random_explore_violations",
            "demi_replay_removal_batch", "demi_replay_get_kept", "demi_model_specialize", "demi_model_is_specialized",
-           "demi_specialize_check", "demi_specialize_source"]
+           "demi_specialize_check", "demi_specialize_source", "demi_device_probe", "demi_calib_rw", "demi_random_explore_flagged", "demi_collect_flagged_dev"]
 
 _lib = None
 
@@ -158,6 +158,16 @@ class Context:
                                                          out.ctypes.data, cap, C.byref(cnt)))
         return out[:min(cnt.value, cap)].copy(), int(cnt.value)
 
+    def random_explore_flagged(self, n, limits, flag_mask, seed_base=0, cap=1 << 16):
+        """n schedules; the entries whose verdict flags intersect flag_mask (sorted by index), their count and the lowest
+        such index (exact even when the list is truncated to `cap`)."""
+        import numpy as np
+        out = np.zeros(cap, dtype=T.VIOLATION_DTYPE)
+        cnt, first = C.c_uint64(0), C.c_uint64(0)
+        self._check(lib().demi_random_explore_flagged(self._h, C.c_uint64(seed_base), n, C.byref(limits), flag_mask,
+                                                      out.ctypes.data, cap, C.byref(cnt), C.byref(first)))
+        return out[:min(cnt.value, cap)].copy(), int(cnt.value), int(first.value)
+
     def random_explore_dev(self, n, limits, d_out_ptr, seed_base=0, d_seeds_ptr=None, stream=None):
         self._check(lib().demi_random_explore_dev(self._h, C.c_uint64(seed_base), d_seeds_ptr, n, C.byref(limits),
                                                   d_out_ptr, stream))
@@ -181,6 +191,11 @@ class Context:
         self._check(lib().demi_replay_batch(self._h, masks.ctypes.data if len(masks) else None, len(masks),
                                             C.byref(limits), out.ctypes.data if len(masks) else None))
         return out
+
+    def replay_batch_dev(self, d_masks_ptr, n, limits, d_out_ptr, stream=None):
+        """Device-resident form: masks [n][4] u64 and verdicts [n] stay in HBM; enqueued on `stream`, not synchronised."""
+        self._check(lib().demi_replay_batch_dev(self._h, C.c_void_p(d_masks_ptr), C.c_uint64(n), C.byref(limits),
+                                                C.c_void_p(d_out_ptr), stream))
 
     def replay_removal_batch(self, skips, limits, masks=None):
         """One STSScheduler.test per entry of skips: the loaded trace minus the delivery at that recorded-event
@@ -257,6 +272,15 @@ class Context:
                                             plen.ctypes.data, rounds.ctypes.data, vt.ctypes.data, C.byref(vl), C.byref(stats)))
         n = int(stats.interleavings)
         return verdicts[:n].copy(), plen[:n].copy(), rounds[:int(stats.launches)].copy(), vt[:vl.value].copy(), stats
+
+    def device_probe(self, waves_per_simd=1, iters=20000):
+        """Shader clock under load (GHz) and SIMD cycles per wave64 integer VALU instruction (demi_device_probe)."""
+        r = T.ProbeResult()
+        self._check(lib().demi_device_probe(self._h, waves_per_simd, iters, C.byref(r)))
+        return r
+
+    def calib_rw(self, mode, nbytes, repeats=1):
+        self._check(lib().demi_calib_rw(self._h, mode, nbytes, repeats))
 
     def random_get_trace(self, seed, limits):
         import numpy as np

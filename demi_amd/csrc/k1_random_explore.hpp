@@ -256,9 +256,10 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
   };
 
   // RandomizedHashSet.remove (Util.scala:146-163): the last element moves into the hole
-  auto pend_remove = [&](uint32_t idx) {
+  // (lw = the word in the last slot: callers load it together with the words they inspect, one round trip to the
+  // pending set instead of two when it lives in HBM)
+  auto pend_remove = [&](uint32_t idx, uint32_t lw) {
     const uint32_t last = n_pend - 1;
-    const uint32_t lw = pend_load(mem, last);
     pend_store(mem, idx, lw);
     if (REC) aux_store(mem, idx, aux_load(mem, last));
     bool last_is_timer;
@@ -472,8 +473,9 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
         }
         if (from_te) {
           w = pend_load(mem, idx);
+          const uint32_t lastw = pend_load(mem, n_pend - 1);
           if (REC) wid = aux_load(mem, idx);
-          pend_remove(idx);
+          pend_remove(idx, lastw);
         } else {
           const uint32_t pi = jr_next_int(rng, n_pairs, t.magic);
           const uint32_t pr = pair_get(pi);
@@ -618,18 +620,19 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
           const uint32_t q1 = m1 ? (uint32_t)__builtin_ctzll(m1) : q0, q2 = m2 ? (uint32_t)__builtin_ctzll(m2) : q0,
                          q3 = m3 ? (uint32_t)__builtin_ctzll(m3) : q0;
           const uint32_t w0 = pend_load(mem, q0), w1 = pend_load(mem, q1), w2 = pend_load(mem, q2), w3 = pend_load(mem, q3);
+          const uint32_t lastw = pend_load(mem, n_pend - 1);
           const uint32_t hit = (w0 == wantw) ? q0 : (w1 == wantw) ? q1 : (w2 == wantw) ? q2 : (w3 == wantw) ? q3 : 0xFFFFFFFFu;
-          if (hit != 0xFFFFFFFFu) { pend_remove(hit); gone = true; }
+          if (hit != 0xFFFFFFFFu) { pend_remove(hit, lastw); gone = true; }
           m = m3 & (m3 - 1);
         }
 #else
         for (uint64_t m = tmask; m != 0; m &= m - 1) {
           const uint32_t q = (uint32_t)__builtin_ctzll(m);
-          if (pend_load(mem, q) == wantw) { pend_remove(q); gone = true; break; }
+          if (pend_load(mem, q) == wantw) { pend_remove(q, pend_load(mem, n_pend - 1)); gone = true; break; }
         }
 #endif
         for (uint32_t q = 64; !gone && q < n_pend; q++)
-          if (pend_load(mem, q) == wantw) { pend_remove(q); gone = true; }
+          if (pend_load(mem, q) == wantw) { pend_remove(q, pend_load(mem, n_pend - 1)); gone = true; }
       }
     };
     // TSET / TREP: registerCancellable + handleTick (Instrumenter.scala:1145-1200)

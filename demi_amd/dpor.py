@@ -25,6 +25,10 @@ from . import types as T
 from .schedulers import MinimizationStats, SchedulerConfig, ViolationFingerprint
 
 
+# verdict flags of an interleaving whose racing pairs are missing or truncated
+K3_INCOMPLETE = T.V_PENDING_OVF | T.V_QUEUE_OVF | T.V_TRACE_OVF | T.V_SELFMSG | T.V_PAIRS_OVF
+
+
 @dataclass
 class Interleaving:
     verdict: np.void            # VERDICT_DTYPE row
@@ -37,7 +41,10 @@ class Exploration:
     interleavings: List[Interleaving] = field(default_factory=list)
     violations: List[int] = field(default_factory=list)      # indices into interleavings
     rounds: List[int] = field(default_factory=list)          # batch size of every launch
-    exhausted: bool = False                                  # the backtrack queue ran empty
+    exhausted: bool = False                                  # the backtrack queue ran empty and no interleaving was cut short
+    aborted: int = 0                                         # interleavings without a valid result (a capacity of the engine:
+                                                             # pending set, trace length, racing-pair list; SELFMSG): their
+                                                             # backtrack points are missing, the exploration is incomplete
 
     def schedule_hashes(self) -> Set[int]:
         return {int(i.verdict["hash"]) for i in self.interleavings}
@@ -265,6 +272,8 @@ class DPORwHeuristics:
             for k in range(len(frontier)):
                 il = Interleaving(verdicts[k], traces[k], len(frontier[k]))
                 res.interleavings.append(il)
+                if int(verdicts[k]["flags"]) & K3_INCOMPLETE:
+                    res.aborted += 1
                 if int(verdicts[k]["flags"]) & T.V_VIOLATION:
                     res.violations.append(len(res.interleavings) - 1)
                     if self.shortestTraceSoFar is None or len(traces[k]) < len(self.shortestTraceSoFar):
@@ -283,7 +292,7 @@ class DPORwHeuristics:
                     break
                 frontier.append(nxt)
                 shared.append(self._next_shared)
-        res.exhausted = not self.backTrack and not frontier
+        res.exhausted = not self.backTrack and not frontier and res.aborted == 0
         return res
 
     def explore_native(self, externals, lookingFor: Optional[ViolationFingerprint] = None, max_interleavings: int = 100000,
@@ -310,7 +319,8 @@ class DPORwHeuristics:
         verdicts, plen, rounds, vtrace, stats = self._ctx.dpor_explore(self._params(lookingFor), search)
         res = Exploration()
         res.rounds = [int(r) for r in rounds]
-        res.exhausted = bool(stats.exhausted)
+        res.aborted = int(np.count_nonzero(verdicts["flags"] & K3_INCOMPLETE))
+        res.exhausted = bool(stats.exhausted) and res.aborted == 0
         empty = np.zeros(0, dtype=T.DPOR_TRACE_DTYPE)
         for k in range(len(verdicts)):
             res.interleavings.append(Interleaving(verdicts[k], empty, int(plen[k])))

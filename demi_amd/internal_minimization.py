@@ -229,13 +229,32 @@ class StsRemovalOracle:
         from .distributed import sharded_map
         self._load(trace)
         lim = self._limits(violation)
-        return sharded_map(list(skips), lambda part: [bool(f & T.V_VIOLATION) for f in
-                                                      self._ctx.replay_removal_batch(part, lim)["flags"]])
+
+        def run(part):
+            # a replay aborted on a capacity is no answer: repeat it with the largest pending set, else give up loudly
+            from .schedulers import CapacityExceeded, OVF_FLAGS
+            v = self._ctx.replay_removal_batch(part, lim)
+            bad = np.nonzero(v["flags"] & OVF_FLAGS)[0]
+            if len(bad):
+                big = self._limits(violation)
+                big.p_max = T.MAX_PENDING
+                v[bad] = self._ctx.replay_removal_batch([part[i] for i in bad], big)
+                if (v["flags"] & OVF_FLAGS).any():
+                    raise CapacityExceeded("a removal candidate's replay exceeds the engine's capacities")
+            return [bool(f & T.V_VIOLATION) for f in v["flags"]]
+        return sharded_map(list(skips), run)
 
     def executed(self, trace: EventTrace, skip: int, violation: ViolationFingerprint) -> Optional[EventTrace]:
         """test() of one candidate: Some(executed trace) iff it triggers the violation."""
+        from .schedulers import CapacityExceeded, OVF_FLAGS
         self._load(trace)
-        v, kept = self._ctx.replay_get_kept(len(trace.events), skip, self._limits(violation))
+        lim = self._limits(violation)
+        v, kept = self._ctx.replay_get_kept(len(trace.events), skip, lim)
+        if (int(v.flags) & OVF_FLAGS) and lim.p_max < T.MAX_PENDING:
+            lim.p_max = T.MAX_PENDING
+            v, kept = self._ctx.replay_get_kept(len(trace.events), skip, lim)
+        if int(v.flags) & OVF_FLAGS:
+            raise CapacityExceeded("the replay exceeds the engine's capacities")
         if not (int(v.flags) & T.V_VIOLATION):
             return None
         return executed_trace(trace, kept)

@@ -282,14 +282,18 @@ class SpeculativeDDMin(DDMin):
 
 
 def stsSchedDDMin(oracle, externals: np.ndarray, violation: ViolationFingerprint, speculative_depth: int = 3,
-                  stats: Optional[MinimizationStats] = None):
+                  stats: Optional[MinimizationStats] = None, checkUnmodified: bool = True):
     """RunnerUtils.stsSchedDDMin (:642-707): strip WaitQuiescence from the externals, minimise with
-    DDMin over the STSSched oracle, verify the MCS.  Returns (mcs indices, ddmin, verified trace)."""
+    DDMin over the STSSched oracle, verify the MCS.  Returns (mcs indices, ddmin, verified trace).
+    checkUnmodified (default true, as in the reference, :653, 671): the unmodified trace must reproduce the violation under
+    STSSched, else ValueError - a non-reproducing input would otherwise "minimise" to an arbitrary single atom.  (The
+    reference validates the MCS only when it is smaller than the input, :689; here it is always replayed once: the
+    verified trace is what the later stages start from.)"""
     dag = UnmodifiedEventDag(externals)
     keep = tuple(i for i in dag.events if int(externals[i]["kind"]) != T.EV_WAIT_QUIESCENCE)
     view = EventDagView(dag, keep)
-    ddmin = SpeculativeDDMin(oracle, depth=speculative_depth, stats=stats) if speculative_depth > 0 else \
-        DDMin(oracle, stats=stats)
+    ddmin = SpeculativeDDMin(oracle, depth=speculative_depth, checkUnmodifed=checkUnmodified, stats=stats) if speculative_depth > 0 else \
+        DDMin(oracle, checkUnmodifed=checkUnmodified, stats=stats)
     mcs = ddmin.minimize(view, violation)
     verified = ddmin.verify_mcs(mcs, violation)
     return mcs.get_all_events(), ddmin, verified

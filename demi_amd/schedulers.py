@@ -152,7 +152,9 @@ class RandomScheduler:
         self._prepare(_trace)
         if self.stats is not None:
             self.stats.increment_replays(self.max_executions)
-        return self._ctx.random_explore(self.max_executions, self._limits(_lookingFor), seed_base=self.seed_base)
+        v = self._ctx.random_explore(self.max_executions, self._limits(_lookingFor), seed_base=self.seed_base)
+        self.last_aborted = int(((v["flags"] & OVF_FLAGS) != 0).sum())      # verdicts without a valid answer (capacity)
+        return v
 
     def explore(self, _trace, _lookingFor: Optional[ViolationFingerprint] = None
                 ) -> Optional[Tuple[EventTrace, ViolationFingerprint]]:
@@ -161,17 +163,44 @@ class RandomScheduler:
         ev = self._prepare(_trace)
         if self.stats is not None:
             self.stats.increment_replays(self.max_executions)
-        # only the violation set crosses PCIe (16 B per violation instead of 16 B per schedule)
-        hits, n_hits = self._ctx.random_explore_violations(self.max_executions, self._limits(_lookingFor),
-                                                           seed_base=self.seed_base)
-        if n_hits == 0:
+        # only the violating and the aborted executions cross PCIe (16 B each instead of 16 B per schedule).  An execution
+        # aborted on a capacity has no valid verdict: it is re-run alone with the largest pending set before any
+        # higher index is believed (the reference has no capacities; its answer is the lowest violating index)
+        lim = self._limits(_lookingFor)
+        start, i = 0, None
+        self.last_aborted_reruns = 0
+        while start < self.max_executions and i is None:
+            hits, n_hits, first = self._ctx.random_explore_flagged(self.max_executions - start, lim, T.V_VIOLATION | OVF_FLAGS,
+                                                                   seed_base=self.seed_base + start)
+            if n_hits == 0:
+                return None
+            # a truncated list is an arbitrary subset: only the lowest index (computed on the device) is certain then
+            cand = [(int(h["index"]), int(h["flags"])) for h in hits] if n_hits <= len(hits) else [(first, None)]
+            nxt = self.max_executions
+            for idx, flags in cand:
+                if flags is not None and not (flags & OVF_FLAGS):
+                    i = start + idx
+                    break
+                # aborted (or unknown): decide this execution alone
+                self.last_aborted_reruns += 1
+                big = self._limits(_lookingFor)
+                big.p_max = T.MAX_PENDING
+                v1, _ = self._ctx.random_get_trace(self.seed_base + start + idx, big)
+                if v1.flags & OVF_FLAGS:
+                    raise CapacityExceeded("schedule %d exceeds the engine's capacities (flags 0x%x)" % (start + idx, v1.flags & 0xFF))
+                if v1.flags & T.V_VIOLATION:
+                    i = start + idx
+                    lim = big
+                    break
+                if flags is None:
+                    nxt = start + idx + 1
+            else:
+                if n_hits <= len(hits):
+                    return None           # every flagged execution was an abort that turned out clean
+            start = nxt
+        if i is None:
             return None
-        if n_hits > len(hits):       # list truncated: fall back to the full verdict array for the lowest index
-            verdicts = self._ctx.random_explore(self.max_executions, self._limits(_lookingFor), seed_base=self.seed_base)
-            i = int(np.nonzero(verdicts["flags"] & T.V_VIOLATION)[0][0])
-        else:
-            i = int(hits["index"][0])
-        v, rec = self._ctx.random_get_trace(self.seed_base + i, self._limits(_lookingFor))
+        v, rec = self._ctx.random_get_trace(self.seed_base + i, lim)
         assert v.flags & T.V_VIOLATION
         # checkIfBugFound prunes the externals that were never injected (:160-163)
         used = ev[:T.verdict_trace_idx(v.flags)]
@@ -224,7 +253,20 @@ class STSScheduler:
         return masks
 
     def verdicts(self, subseqs, violationFingerprint: ViolationFingerprint) -> np.ndarray:
-        return self._ctx.replay_batch(self._masks(subseqs), self._limits(violationFingerprint))
+        """One verdict per candidate.  A replay aborted on a capacity is no verdict: it is repeated with the largest
+        pending set, and if it still does not fit the candidate cannot be decided here (CapacityExceeded) - never
+        reported as "does not reproduce"."""
+        masks = self._masks(subseqs)
+        lim = self._limits(violationFingerprint)
+        v = self._ctx.replay_batch(masks, lim)
+        bad = np.nonzero(v["flags"] & OVF_FLAGS)[0]
+        if len(bad):
+            if lim.p_max < T.MAX_PENDING:
+                lim.p_max = T.MAX_PENDING
+                v[bad] = self._ctx.replay_batch(masks[bad], lim)
+            if (v["flags"] & OVF_FLAGS).any():
+                raise CapacityExceeded("%d candidate replay(s) exceed the engine's capacities" % int(((v["flags"] & OVF_FLAGS) != 0).sum()))
+        return v
 
     def test_batch(self, subseqs, violationFingerprint: ViolationFingerprint,
                    stats: Optional[MinimizationStats] = None) -> List[bool]:
@@ -251,14 +293,28 @@ class STSScheduler:
         the input of internal-event minimization."""
         from .internal_minimization import executed_trace
         subseq = tuple(subseq)
-        v, kept = self._ctx.replay_get_kept(len(self.original_trace.events), 0xFFFFFFFF,
-                                            self._limits(violationFingerprint), mask=self._masks([subseq])[0])
+        lim = self._limits(violationFingerprint)
+        v, kept = self._ctx.replay_get_kept(len(self.original_trace.events), 0xFFFFFFFF, lim, mask=self._masks([subseq])[0])
+        if (int(v.flags) & OVF_FLAGS) and lim.p_max < T.MAX_PENDING:
+            lim.p_max = T.MAX_PENDING
+            v, kept = self._ctx.replay_get_kept(len(self.original_trace.events), 0xFFFFFFFF, lim, mask=self._masks([subseq])[0])
+        if int(v.flags) & OVF_FLAGS:
+            raise CapacityExceeded("the replay exceeds the engine's capacities")
         if not (int(v.flags) & T.V_VIOLATION):
             return None
         return executed_trace(self.original_trace, kept, subseq=subseq)
 
     def shutdown(self):
         self._ctx.close()
+
+
+class CapacityExceeded(RuntimeError):
+    """An execution needed more than the engine's largest capacities (pending set of DEMI_MAX_PENDING messages, the
+    timer queues, DEMI_FX_CAP effects per delivery): its verdict is invalid (DEMI_V_PENDING_OVF / DEMI_V_QUEUE_OVF) and the
+    reference, which has no such capacities, must decide it (JVM fallback)."""
+
+
+OVF_FLAGS = T.V_PENDING_OVF | T.V_QUEUE_OVF
 
 
 class ReplayException(Exception):

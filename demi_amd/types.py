@@ -9,6 +9,7 @@ MAX_CODE = 1024
 MAX_TIMER_TYPES = 4
 MAX_EXT_EVENTS = 255
 MAX_REC_EVENTS = 16384
+MAX_PENDING = 128          # DEMI_MAX_PENDING
 
 # demi_status
 OK = 0
@@ -103,7 +104,13 @@ class DporSearch(C.Structure):
 class DporStats(C.Structure):
     _fields_ = [("interleavings", C.c_uint64), ("launches", C.c_uint64), ("violations", C.c_uint64),
                 ("first_violation", C.c_uint64), ("queue_len", C.c_uint64), ("exhausted", C.c_uint32),
-                ("pad", C.c_uint32), ("executed", C.c_uint64), ("cache_misses", C.c_uint64)]
+                ("pad", C.c_uint32), ("executed", C.c_uint64), ("cache_misses", C.c_uint64), ("kernel_ms", C.c_double),
+                ("h2d_bytes", C.c_uint64), ("d2h_bytes", C.c_uint64)]
+
+
+class ProbeResult(C.Structure):
+    _fields_ = [("shader_clock_ghz", C.c_double), ("cycles_per_valu", C.c_double), ("waves_per_simd", C.c_uint32),
+                ("num_cu", C.c_uint32)]
 
 
 DPOR_ORDER_ROUNDS = 0       # demi_dpor_order

@@ -251,7 +251,8 @@ int demi_replay_removal_batch(demi_ctx* ctx, const uint64_t* masks /* [n][4] or 
                               uint64_t n, const demi_limits* limits, demi_verdict* out);
 /* The executed trace of one candidate, i.e. what test() returns on success (STSScheduler.scala:286-292):
  * kept[i] = 1 iff original_trace[i] took effect in the replay (external event applied, external MsgSend
- * enqueued, MsgEvent delivered); absent deliveries, pruned events and replay nops are 0.  kept: [n_rec]. */
+ * enqueued, MsgEvent delivered, internal / timer MsgSend whose delivery took effect); absent deliveries, pruned
+ * events, sends of messages that were never delivered and the quiescence markers are 0.  kept: [n_rec].  */
 int demi_replay_get_kept(demi_ctx* ctx, const uint64_t* mask /* [4] or NULL */, uint32_t skip,
                          const demi_limits* limits, demi_verdict* verdict, uint8_t* kept);
 
@@ -354,6 +355,9 @@ typedef struct {
   uint32_t pad;
   uint64_t executed;            /* interleavings run on the device (REFERENCE order: committed + speculated in vain) */
   uint64_t cache_misses;        /* REFERENCE order: committed interleavings the speculation had not run */
+  double kernel_ms;             /* sum of the K3 launches' durations (HIP events on the launch stream) */
+  uint64_t h2d_bytes;           /* next traces uploaded */
+  uint64_t d2h_bytes;           /* verdicts, traces and racing pairs fetched */
 } demi_dpor_stats;
 
 /* out_verdicts / out_prefix_len: [max_interleavings], in execution order.  first_violation_trace:
@@ -374,17 +378,41 @@ typedef struct {
   uint32_t flags;
 } demi_violation;        /* 16 bytes */
 
-/* explore() only ever needs the violating executions (RandomScheduler.scala:257-261 returns the first
- * one): run n schedules, keep the verdicts on the device, and copy back just the compacted violation
- * set (entries sorted by index; *n_violations may exceed cap, the list is then the `cap` lowest...
- * no order guarantee beyond "sorted among those returned").  16 bytes per violation cross PCIe
- * instead of 16 bytes per schedule.                                                                */
+/* explore() only ever needs the violating executions (RandomScheduler.scala:257-261 returns the first one): run n
+ * schedules, keep the verdicts on the device, and copy back just the compacted violation set.  The entries returned
+ * are sorted by index; when *n_violations exceeds cap the list is truncated to an arbitrary subset of `cap` entries.
+ * 16 bytes per violation cross PCIe instead of 16 bytes per schedule.                                              */
 int demi_random_explore_violations(demi_ctx* ctx, uint64_t seed_base, uint64_t n, const demi_limits* limits,
                                    demi_violation* out, uint32_t cap, uint64_t* n_violations);
+/* The same with a caller-chosen selection: entries whose verdict flags intersect flag_mask.  With
+ * DEMI_V_VIOLATION | DEMI_V_PENDING_OVF | DEMI_V_QUEUE_OVF the list also names the executions that were ABORTED on a
+ * capacity (their verdicts are invalid): the reference has no such capacities, so a driver re-runs those seeds with a
+ * larger p_max (demi_random_get_trace) before it trusts "no violation at a lower index".  *first_index (may be NULL) is
+ * the lowest selected index, computed on the device: exact even when the list is truncated.                        */
+int demi_random_explore_flagged(demi_ctx* ctx, uint64_t seed_base, uint64_t n, const demi_limits* limits, uint32_t flag_mask,
+                                demi_violation* out, uint32_t cap, uint64_t* n_flagged, uint64_t* first_index);
 
 int demi_collect_violations_dev(demi_ctx* ctx, const demi_verdict* d_verdicts, uint64_t n, uint64_t index_base,
                                 demi_violation* d_out, uint32_t cap, unsigned long long* d_count,
                                 void* hip_stream);
+int demi_collect_flagged_dev(demi_ctx* ctx, const demi_verdict* d_verdicts, uint64_t n, uint64_t index_base,
+                             uint32_t flag_mask, demi_violation* d_out, uint32_t cap, unsigned long long* d_count,
+                             void* hip_stream);
+
+/* ---------------------------------------------------------- measurement helpers (no reference counterpart)
+ * Used by bench.py and the profiling scripts so that the figures beside the throughput are measured on the box that
+ * prints them: the shader clock under load (s_memtime cycles per 100 MHz wall_clock64 tick) and the cycles one SIMD spends
+ * per wave64 integer VALU instruction with `waves_per_simd` waves issuing (the unit of K1's issue-rate model).          */
+typedef struct {
+  double shader_clock_ghz;
+  double cycles_per_valu;
+  uint32_t waves_per_simd;
+  uint32_t num_cu;
+} demi_probe_result;
+int demi_device_probe(demi_ctx* ctx, uint32_t waves_per_simd, uint32_t iters, demi_probe_result* out);
+/* A kernel with a known byte count for calibrating rocprofv3's FETCH_SIZE / WRITE_SIZE: mode 0 writes / 1 reads `bytes`
+ * with 4 B per lane (K1's scratch rows), 2 writes / 3 reads with 16 B per lane (the verdict array's pattern).          */
+int demi_calib_rw(demi_ctx* ctx, uint32_t mode, uint64_t bytes, uint32_t repeats);
 
 #ifdef __cplusplus
 }

@@ -948,6 +948,17 @@ int orc_sts_removal(const demi_model* m, const demi_ext_event* ext, uint32_t n_e
   if (!x) return DEMI_ERR_INVALID_ARG;
   int rc = sts_replay_in(x, m, ext, n_ext, rec, n_rec, mask ? mask : STS_ALL, lim, out, NULL, skip, kept);
   free(x);
+  if (rc == DEMI_OK && kept) {
+    /* the executed trace holds the MsgSend of every message it delivered (event_produced records the send of each
+     * produced message, V/schedulers/STSScheduler.scala:561-623; the recorded internal / timer MsgSends themselves are nops of
+     * the replay, :530-538): such a send is kept iff the delivery with its id took effect */
+    for (uint32_t i = 0; i < n_rec; i++) {
+      if (rec[i].kind != DEMI_REC_MSG_SEND || (rec[i].flags & 1)) continue;
+      kept[i] = 0;
+      for (uint32_t k = i + 1; k < n_rec; k++)
+        if (rec[k].kind == DEMI_REC_MSG_EVENT && rec[k].id == rec[i].id) { kept[i] = kept[k]; break; }
+    }
+  }
   return rc;
 }
 

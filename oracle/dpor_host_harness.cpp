@@ -6,7 +6,7 @@
 #include <vector>
 
 #include "../demi_amd/csrc/dpor_host.hpp"
-#include "../oracle/demi_oracle.h"
+#include "demi_oracle.h"
 
 extern "C" int harness_dpor_explore(const demi_model* m, const demi_ext_event* ext, uint32_t n_ext,
                                     const demi_dpor_params* par, const demi_dpor_search* srch, int n_threads,

@@ -14,10 +14,37 @@ _LIB = None
 
 
 def build(force=False):
+    """make decides what is stale (the oracle itself and the DPOR bookkeeping harness)."""
     so = os.path.join(_HERE, "_build", "liboracle.so")
-    if force or not os.path.exists(so):
-        subprocess.check_call(["make", "-s", "-C", _HERE])
+    subprocess.check_call(["make", "-s", "-C", _HERE] + (["-B"] if force else []))
     return so
+
+
+def dpor_explore(model, externals, params, search, n_threads=None):
+    """The whole DPOR exploration on the CPU: the product's host bookkeeping (demi_amd/csrc/dpor_host.hpp) around this
+    oracle's interleavings, `n_threads` of them at a time.  Returns (verdicts, prefix_len, rounds, first violating trace,
+    stats, seconds[run, fetch + absorb, get_next])."""
+    build()
+    H = C.CDLL(os.path.join(_HERE, "_build", "dpor_host_harness.so"))
+    H.harness_dpor_explore.argtypes = [C.POINTER(T.ModelStruct), C.c_void_p, C.c_uint32, C.POINTER(T.DporParams),
+                                       C.POINTER(T.DporSearch), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.POINTER(C.c_uint32), C.POINTER(T.DporStats), C.c_void_p]
+    ms = model.to_struct()
+    ev = np.ascontiguousarray(externals, dtype=T.EXT_EVENT_DTYPE)
+    cap = search.max_interleavings
+    verdicts = np.zeros(cap, dtype=T.VERDICT_DTYPE)
+    plen = np.zeros(cap, dtype=np.uint32)
+    rounds = np.zeros(cap, dtype=np.uint32)
+    vt = np.zeros(T.DPOR_MAX_TRACE, dtype=T.DPOR_TRACE_DTYPE)
+    vl = C.c_uint32(0)
+    stats = T.DporStats()
+    secs = np.zeros(3, dtype=np.float64)
+    rc = H.harness_dpor_explore(C.byref(ms), ev.ctypes.data, len(ev), C.byref(params), C.byref(search),
+                                n_threads or (os.cpu_count() or 1), verdicts.ctypes.data, plen.ctypes.data, rounds.ctypes.data,
+                                vt.ctypes.data, C.byref(vl), C.byref(stats), secs.ctypes.data)
+    assert rc == 0
+    n = int(stats.interleavings)
+    return verdicts[:n], plen[:n], rounds[:int(stats.launches)], vt[:vl.value], stats, secs
 
 
 def lib():

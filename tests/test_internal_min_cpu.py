@@ -70,16 +70,24 @@ def test_removal_batch_without_a_removal_is_the_plain_replay(oracle):
 
 
 def test_kept_marks_are_the_executed_trace(oracle):
-    """Full replay: every Spawn, external MsgSend and MsgEvent is kept, internal MsgSends and quiescence records
-    are not; the executed trace replays to the same verdict (hash over deliveries and final states)."""
+    """Full replay: every Spawn, external MsgSend and MsgEvent is kept, and so is the internal / timer MsgSend of every
+    delivered message (the trace test() returns pairs each delivery with its send: DepTracker and the DPOR initial
+    trace need that); sends of messages that were never delivered and quiescence records are not.  The executed trace
+    replays to the same verdict (hash over deliveries and final states)."""
     model, events, lim = raft5_config2()
     vv, rec, used = _violating_execution(oracle, model, events, lim)
     target = T.Limits(0, 0, 64, 1, vv.fingerprint, 0)
     v, kept = oracle.sts_removal_kept(model, used, rec, NO_SKIP, target)
     assert v.flags & T.V_VIOLATION and v.hash == vv.hash
     kinds = rec["kind"]
-    expect = (kinds <= T.REC_UNPARTITION) | (kinds == T.REC_MSG_EVENT) | ((kinds == T.REC_MSG_SEND) & ((rec["flags"] & 1) == 1))
-    assert (kept.astype(bool) == expect).all()
+    core = (kinds <= T.REC_UNPARTITION) | (kinds == T.REC_MSG_EVENT) | ((kinds == T.REC_MSG_SEND) & ((rec["flags"] & 1) == 1))
+    delivered_ids = set(rec["id"][kinds == T.REC_MSG_EVENT].tolist())
+    internal_send = (kinds == T.REC_MSG_SEND) & ((rec["flags"] & 1) == 0)
+    expect = core | (internal_send & np.isin(rec["id"], list(delivered_ids)))
+    assert (kept.astype(bool) == expect).all() and (internal_send & expect).any() and (internal_send & ~expect).any()
+    # every delivery of the executed trace has its send in it
+    tr0 = executed_trace(EventTrace(rec, used), kept).events
+    assert set(tr0["id"][tr0["kind"] == T.REC_MSG_EVENT].tolist()) <= set(tr0["id"][tr0["kind"] == T.REC_MSG_SEND].tolist())
     tr = executed_trace(EventTrace(rec, used), kept)
     v2, kept2 = oracle.sts_removal_kept(model, tr.original_externals, tr.events, NO_SKIP, target)
     assert v2.flags == v.flags and v2.hash == v.hash and kept2.all()
@@ -90,10 +98,28 @@ def test_kept_marks_are_the_executed_trace(oracle):
         v3, kept3 = oracle.sts_removal_kept(model, used, rec, idx, target)
         assert not kept3[idx]
         assert T.verdict_deliveries(v3.flags) <= T.verdict_deliveries(v.flags) - 1
-        absent = int(expect.sum()) - 1 - int(kept3.sum())
+        absent = int(core.sum()) - 1 - int(kept3[core].sum())
         assert bool(v3.flags & T.V_DIVERGED) == (absent > 0)
         b = oracle.sts_removal_batch(model, used, rec, [idx], target)[0]
         assert int(b["flags"]) == v3.flags and int(b["hash"]) == v3.hash
+
+
+def test_executed_traces_feed_the_dpor_initial_trace(oracle):
+    """A trace returned by an STSSched replay (DDMin's verified MCS, every lastFailingTrace of internal minimization) is
+    consumed by later stages that pair each delivery with its send (DepTracker / editDistanceDporDDMin): every MsgEvent of
+    it must find its MsgSend."""
+    from demi_amd.incremental_ddmin import dpor_initial_trace
+    model, events, lim = raft5_config2()
+    trace, fp = _verified_mcs(oracle, model, events, lim)
+    it = dpor_initial_trace(trace)
+    assert len(it) == 1 + int((trace.events["kind"] == T.REC_MSG_EVENT).sum())
+    # ... and after a removal (internal minimization's candidate that still fails)
+    dl = deliveries(trace)
+    target = T.Limits(0, 0, 64, 1, fp.code, 0)
+    for idx, _, _ in dl[:6]:
+        v, kept = oracle.sts_removal_kept(model, trace.original_externals, trace.events, idx, target)
+        sub = executed_trace(trace, kept)
+        assert len(dpor_initial_trace(sub)) == 1 + int((sub.events["kind"] == T.REC_MSG_EVENT).sum())
 
 
 def test_rebased_verified_mcs_replays_identically(oracle):
@@ -101,8 +127,8 @@ def test_rebased_verified_mcs_replays_identically(oracle):
     trace, fp = _verified_mcs(oracle, model, events, lim)
     assert len(trace.original_externals) < 50
     assert not (trace.original_externals["kind"] == T.EV_WAIT_QUIESCENCE).any()
-    ext_sends = trace.events[(trace.events["kind"] == T.REC_MSG_SEND)]
-    assert ((ext_sends["flags"] & 1) == 1).all()
+    ext_sends = trace.events[(trace.events["kind"] == T.REC_MSG_SEND) & ((trace.events["flags"] & 1) == 1)]
+    assert len(ext_sends) > 0
     assert (trace.original_externals["kind"][ext_sends["ext_idx"]] == T.EV_SEND).all()
     v, kept = oracle.sts_removal_kept(model, trace.original_externals, trace.events, NO_SKIP, T.Limits(0, 0, 64, 1, fp.code, 0))
     assert v.flags & T.V_VIOLATION and not (v.flags & T.V_DIVERGED) and kept.all()

@@ -198,3 +198,62 @@ def test_dpor_golden_fixture_on_gpu(gpu_ctx):
     sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
     assert (dv == z["verdicts"]).all()
     assert [sha(t) for t in dt] == list(z["trace_sha"]) and [sha(p) for p in dp] == list(z["pairs_sha"])
+
+
+# ------------------------------------------------------------------ shared-prefix pair filter, reference order
+def test_shared_prefix_pairs_are_not_reported_again(gpu_ctx, oracle):
+    """demi_dpor_batch(shared_len): racing pairs whose later event lies in the take() part of the next trace are left
+    out, identically on the kernel and on the oracle, and they are exactly the pairs the full list has there."""
+    model, ev, _ = raft5_config3()
+    prefixes, res, _ = collect_prefixes(oracle, model, ev, 30, 64, 400)
+    shared = list(launched_shared)
+    assert len(prefixes) == len(shared) and max(shared) > 20
+    gpu_ctx.model_load(model.to_struct())
+    gpu_ctx.dpor_load(ev)
+    par = T.DporParams(30, 0, 0, 0, 64, 4096)
+    g = gpu_ctx.dpor_batch(prefixes, par, shared)
+    c = oracle.dpor_batch(model, ev, prefixes, par, shared)
+    same_batch(g, c)
+    full = gpu_ctx.dpor_batch(prefixes, par)
+    for k in range(len(prefixes)):
+        want = full[2][k][full[2][k]["later"] >= shared[k]]
+        assert len(want) == len(g[2][k]) and (want == g[2][k]).all()
+        assert (g[0][k] == full[0][k]) and (g[1][k] == full[1][k]).all()       # verdict and trace do not depend on it
+
+
+@pytest.mark.parametrize("jit", [False, True])
+def test_reference_order_on_the_gpu_is_the_batch1_sequence(oracle, jit):
+    """demi_dpor_explore with DEMI_DPOR_ORDER_REFERENCE: the device speculates 256 wide, the committed sequence is the one
+    the CPU oracle produces one backtrack point at a time (DPORwHeuristics' own loop); with a violating set that depends
+    on the order (writers model) and with raft3."""
+    from tests.test_dpor_cpu import native_explore, writers_model
+    cases = [(M.raft_model(3), events_to_array([start(a) for a in range(3)] + [send(a, M.M_BOOTSTRAP) for a in range(3)]), 30),
+             (writers_model(4), events_to_array([start(a) for a in range(5)] + [send(a, 0) for a in range(1, 5)]), 0)]
+    for model, ev, depth in cases:
+        one = native_explore(model, ev, T.DporParams(depth, 0, 0, 0, 64, 4096), 1, 20000)
+        d = DPORwHeuristics(SchedulerConfig(model=model), depth_bound=depth or None, stopIfViolationFound=False, batch=256, specialize=jit)
+        res = d.explore_native(ev, max_interleavings=20000, reference_order=True)
+        got = np.array([il.verdict for il in res.interleavings], dtype=T.VERDICT_DTYPE)
+        assert len(got) == len(one[0]) and (got == one[0]).all() and res.exhausted
+        assert [il.prefix_len for il in res.interleavings] == [int(x) for x in one[1]]
+        st = d.last_native_stats
+        assert st.executed >= len(got) and (len(got) < 100 or st.launches < len(got) / 4)
+        d.shutdown()
+
+
+def test_config3_reference_order_matches_the_golden_batch1_record():
+    """BASELINE config 3 to exhaustion in the reference's order on the GPU: the verdict sequence (60 332 interleavings)
+    hashes to the record the CPU oracle produced at batch = 1 (tools/make_golden_dpor.py)."""
+    import hashlib, json, os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dpor_config3_reference_order.json")) as f:
+        want = json.load(f)
+    model, ev, depth = raft5_config3()
+    d = DPORwHeuristics(SchedulerConfig(model=model), depth_bound=depth, stopIfViolationFound=False, batch=4096, specialize=True)
+    res = d.explore_native(ev, max_interleavings=1 << 17, reference_order=True)
+    got = np.array([il.verdict for il in res.interleavings], dtype=T.VERDICT_DTYPE)
+    plen = np.array([il.prefix_len for il in res.interleavings], dtype=np.uint32)
+    assert len(got) == want["interleavings"] and res.exhausted == want["exhausted"]
+    assert hashlib.sha256(got.tobytes()).hexdigest() == want["sha256_verdicts"]
+    assert hashlib.sha256(plen.tobytes()).hexdigest() == want["sha256_prefix_lens"]
+    assert len(res.violations) == want["violations"] and len(res.schedule_hashes()) == want["distinct_schedules"]
+    d.shutdown()

@@ -87,9 +87,9 @@ ev3 = events_to_array([start(a) for a in range(3)] + [send(a, M.M_BOOTSTRAP) for
 launched = []
 
 
-def backend(m, e, prefixes, params):
+def backend(m, e, prefixes, params, shared=None):
     launched.extend(prefixes)
-    return O.dpor_batch(m, e, prefixes, params)
+    return O.dpor_batch(m, e, prefixes, params, shared)
 
 
 DPORwHeuristics(SchedulerConfig(model=m3), depth_bound=30, stopIfViolationFound=False, batch=16, backend=backend).explore(

@@ -1,46 +1,100 @@
 #!/usr/bin/env python
-"""Condense rocprofv3 rocpd databases (gpurun_out/prof_*/*.db) into the small text/JSON summaries
-committed under profiles/.  Usage: summarize_prof.py <tag> [gpurun_out]"""
+"""Condense rocprofv3 rocpd databases (<src>/prof_*/, <src>/calib_*/) into small text / JSON summaries:
+  <out>/<tag>_k1.txt             kernel-trace stats + PMC averages per dispatch
+  <out>/<tag>_k1_counters.json   the K1 kernel's figures in the form bench.py reads (profiles/k1_counters.json)
+  <out>/<tag>_dpor.txt, <tag>_ddmin.txt   kernel-trace stats of the secondary workloads, when profiled
+Usage: summarize_prof.py <tag> <src dir> <out dir>; copy what should be judged into profiles/."""
 import glob
 import json
 import os
 import sqlite3
 import sys
 
-tag = sys.argv[1]
-root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = sys.argv[2] if len(sys.argv) > 2 else os.path.join(root, "gpurun_out")
-out_dir = os.path.join(root, "profiles")
+tag, src, out_dir = sys.argv[1], sys.argv[2], sys.argv[3]
 os.makedirs(out_dir, exist_ok=True)
-lines, counters = [], {}
-for d in sorted(glob.glob(os.path.join(src, "prof_*"))):
-    if not os.path.isdir(d):
+CALIB_BYTES = 1 << 30
+
+
+def db_of(d):
+    dbs = glob.glob(os.path.join(src, d, "*.db"))
+    return sqlite3.connect(dbs[0]).cursor() if dbs else None
+
+
+def stats_lines(cur, title):
+    lines = ["# %s: rocprofv3 --kernel-trace --stats  (durations in ns)" % title,
+             "%-90s %8s %14s %12s %7s" % ("kernel", "calls", "total_ns", "avg_ns", "pct")]
+    for r in cur.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
+        lines.append("%-90s %8d %14.0f %12.0f %7.2f" % (r[0][:90], r[1], r[2] * 1000, r[3] * 1000, r[4]))
+    return lines
+
+
+lines, counters, k1 = [], {}, {}
+cur = db_of("prof_stats")
+if cur:
+    lines += stats_lines(cur, "python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-secondary") + [""]
+    # the timed launches are the last 30 of the run (pre-warm and warm-up launches come first)
+    rows = [r[0] for r in cur.execute("select duration from kernels where name like '%k1_random_explore%' order by start")]
+    if rows:
+        tail = rows[-30:]
+        k1["kernel_ms"] = sum(tail) / len(tail) / 1e6
+        k1["kernel_ms_all_launches"] = sum(rows) / len(rows) / 1e6
+        k1["launches_profiled"] = len(rows)
+for d in ("prof_fetch", "prof_write", "prof_sq", "prof_sq2"):
+    cur = db_of(d)
+    if not cur:
         continue
-    dbs = glob.glob(os.path.join(d, "*.db"))
-    if not dbs:
+    q = ("select kernel_name, counter_name, count(*), avg(value) from counters_collection "
+         "where kernel_name like '%demi%' group by kernel_name, counter_name")
+    for kn, cn, cnt, avg in cur.execute(q):
+        counters.setdefault(kn, {})[cn] = {"dispatches": cnt, "avg_per_dispatch": avg}
+# calibration: bytes per counter unit for the four access patterns
+calib = {}
+for d, cn in (("calib_fetch", "FETCH_SIZE"), ("calib_write", "WRITE_SIZE")):
+    cur = db_of(d)
+    if not cur:
         continue
-    cur = sqlite3.connect(dbs[0]).cursor()
-    name = os.path.basename(d)
-    if name == "prof_stats":
-        lines.append("# rocprofv3 --kernel-trace --stats  (durations in ns)")
-        lines.append("%-90s %8s %14s %12s %7s" % ("kernel", "calls", "total_ns", "avg_ns", "pct"))
-        for r in cur.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
-            lines.append("%-90s %8d %14.0f %12.0f %7.2f" % (r[0][:90], r[1], r[2] * 1000, r[3] * 1000, r[4]))
-        lines.append("")
-    else:
-        q = ("select kernel_name, counter_name, count(*), avg(value) from counters_collection "
-             "where kernel_name like '%demi%' group by kernel_name, counter_name")
-        for kn, cn, cnt, avg in cur.execute(q):
-            counters.setdefault(kn, {})[cn] = {"dispatches": cnt, "avg_per_dispatch": avg}
+    vals = [r[0] for r in cur.execute("select value from counters_collection where kernel_name like '%k_calib_rw%' and counter_name = ? "
+                                      "order by dispatch_id", (cn,))]
+    if len(vals) == 4:
+        names = ["write_4B_per_lane", "read_4B_per_lane", "write_16B_per_lane", "read_16B_per_lane"]
+        calib[cn] = {n: {"counter": v, "bytes_per_unit": (CALIB_BYTES / v) if v else None} for n, v in zip(names, vals)}
 if counters:
     lines.append("# rocprofv3 --pmc (separate passes), average per dispatch")
     for kn in sorted(counters):
         lines.append(kn)
         for cn in sorted(counters[kn]):
             lines.append("    %-28s %20.1f   (%d dispatches)" % (cn, counters[kn][cn]["avg_per_dispatch"], counters[kn][cn]["dispatches"]))
-txt = os.path.join(out_dir, tag + ".txt")
-with open(txt, "w") as f:
+if calib:
+    lines += ["", "# counter calibration: demi::k_calib_rw over %d bytes per dispatch (tools/calib_counters.py)" % CALIB_BYTES]
+    for cn in calib:
+        for n, v in calib[cn].items():
+            lines.append("    %-12s %-20s counter %16.1f   bytes per unit %s" % (cn, n, v["counter"], "%.1f" % v["bytes_per_unit"] if v["bytes_per_unit"] else "-"))
+k1name = next((k for k in counters if "k1_random_explore" in k), None)
+if k1name:
+    c = {cn: v["avg_per_dispatch"] for cn, v in counters[k1name].items()}
+    k1.update(c)
+    k1["kernel"] = k1name
+    # fabric-side bytes per launch.  FETCH_SIZE / WRITE_SIZE are reported in KB by rocprofv3; the calibration gives the
+    # real bytes per unit for 4-byte-per-lane rows (K1's scratch pattern) - the guide's "x2 for reads" on gfx950 is what
+    # the 16-byte pattern should reproduce.
+    f_unit = (calib.get("FETCH_SIZE", {}).get("read_4B_per_lane", {}) or {}).get("bytes_per_unit") or 2048.0
+    w_unit = (calib.get("WRITE_SIZE", {}).get("write_4B_per_lane", {}) or {}).get("bytes_per_unit") or 1024.0
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        k1["fetch_bytes_per_launch"] = c["FETCH_SIZE"] * f_unit
+        k1["write_bytes_per_launch"] = c["WRITE_SIZE"] * w_unit
+        k1["fabric_bytes_per_launch"] = k1["fetch_bytes_per_launch"] + k1["write_bytes_per_launch"]
+        k1["bytes_per_counter_unit"] = {"FETCH_SIZE": f_unit, "WRITE_SIZE": w_unit,
+                                        "source": "calibrated (4 B per lane)" if calib else "guide default (FETCH x2, WRITE as reported)"}
+    k1["calibration"] = calib
+    with open(os.path.join(out_dir, tag + "_k1_counters.json"), "w") as f:
+        json.dump(k1, f, indent=1, sort_keys=True)
+with open(os.path.join(out_dir, tag + "_k1.txt"), "w") as f:
     f.write("\n".join(lines) + "\n")
-with open(os.path.join(out_dir, tag + "_counters.json"), "w") as f:
-    json.dump(counters, f, indent=1, sort_keys=True)
-print(open(txt).read())
+print("\n".join(lines))
+for d, name in (("prof_stats_dpor", "dpor"), ("prof_stats_ddmin", "ddmin")):
+    cur = db_of(d)
+    if cur:
+        txt = "\n".join(stats_lines(cur, "python bench.py --workload %s --no-cpu-baseline" % name)) + "\n"
+        with open(os.path.join(out_dir, "%s_%s.txt" % (tag, name)), "w") as f:
+            f.write(txt)
+        print(txt)
