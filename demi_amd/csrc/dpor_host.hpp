@@ -24,11 +24,14 @@
 #include <cstring>
 #include <deque>
 #include <memory>
+#include <algorithm>
 #include <thread>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 #include "../../include/demi_gpu.h"
+#include "dpor_types.hpp"
 
 namespace demi_host {
 
@@ -602,6 +605,97 @@ int explore_reference_order(Run&& run, Fetch&& fetch, uint32_t max_pairs, const 
     if (seconds) { seconds[0] += t2 - t1; seconds[1] += now() - t2; }
   }
   stats->queue_len = real.queue_len();
+  stats->exhausted = exhausted ? 1u : 0u;
+  return 0;
+}
+
+// ------------------------------------------------------------------ ROUNDS order, bookkeeping on the device
+// The same exploration as explore_rounds (track_history, DefaultBacktrackOrdering) when the ExploredTacker and dpor()'s
+// enqueue decision live on the device (k3_pairs.hpp): per round the host sends the dequeued points (8 bytes each - the
+// traces they refer to stayed in the device's arena) and gets back one verdict per interleaving, the backtrack points
+// that can still be dequeued live, and the pairs that became explored while points flipping into them were queued.
+// What is left here is the queue itself: 256 FIFO buckets by branch index and getNext()'s skip of explored pairs.
+//   dev.round(items, n, round, base_id, verdicts, points, kills)   one launch; interleaving i gets arena id base_id + i
+//   dev.fetch_trace(id, out, &len)                                 one finished trace (the first violation's)
+struct PairKeyHash {
+  size_t operator()(const std::pair<uint64_t, uint64_t>& k) const {
+    return (size_t)((k.first * 0x9E3779B97F4A7C15ULL) ^ (k.second * 0xC2B2AE3D27D4EB4FULL) ^ (k.first >> 29));
+  }
+};
+
+template <class Dev>
+int explore_rounds_resident(Dev&& dev, const demi_dpor_search* srch, demi_verdict* out_verdicts, uint32_t* out_prefix_len,
+                            uint32_t* out_rounds, demi_dpor_trace_entry* first_violation_trace, uint32_t* first_violation_len,
+                            demi_dpor_stats* stats, double* seconds) {
+  memset(stats, 0, sizeof *stats);
+  stats->first_violation = ~0ull;
+  if (first_violation_len) *first_violation_len = 0;
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  std::deque<demi::DporPoint> bucket[256];
+  int top = -1;
+  uint64_t queued = 0;
+  std::unordered_set<std::pair<uint64_t, uint64_t>, PairKeyHash> dead;     // flipped pairs getNext() would skip
+  std::vector<demi::DporItem> items(1, demi::DporItem{0xFFFFFFFFu, 0, 0, 0, 0});   // first run: nextTrace is empty
+  std::vector<demi_verdict> vd;
+  std::vector<demi::DporPoint> pts;
+  std::vector<demi::DporKill> kills;
+  uint32_t base_id = 0, round = 0;
+  uint64_t first_id = ~0ull;
+  bool exhausted = false;
+  while (!items.empty()) {
+    const uint32_t n = (uint32_t)items.size();
+    vd.resize(n);
+    pts.clear(); kills.clear();
+    round++;
+    double t0 = now();
+    int rc = dev.round(items.data(), n, round, base_id, vd.data(), pts, kills);
+    if (rc) return rc;
+    double t1 = now();
+    if (out_rounds) out_rounds[stats->launches] = n;
+    stats->launches++;
+    stats->executed += n;
+    bool found = false;
+    for (uint32_t i = 0; i < n; i++) {
+      const uint64_t idx = stats->interleavings++;
+      out_verdicts[idx] = vd[i];
+      out_prefix_len[idx] = items[i].src == 0xFFFFFFFFu ? 0u : (uint32_t)items[i].later;
+      if (vd[i].flags & DEMI_V_VIOLATION) {
+        stats->violations++;
+        found = true;
+        if (stats->first_violation == ~0ull) { stats->first_violation = idx; first_id = base_id + i; }
+      }
+    }
+    base_id += n;
+    for (const demi::DporKill& k : kills) dead.insert({k.a, k.b});
+    std::sort(pts.begin(), pts.end(), [](const demi::DporPoint& x, const demi::DporPoint& y) { return x.ordinal < y.ordinal; });
+    for (const demi::DporPoint& p : pts) {        // creation order: the round's interleavings in pop order, then pair order
+      bucket[p.branch].push_back(p);
+      if ((int)p.branch > top) top = (int)p.branch;
+      queued++;
+    }
+    items.clear();
+    double t2 = now();
+    if (seconds) { seconds[0] += t1 - t0; seconds[1] += t2 - t1; }
+    if (srch->stop_if_violation && found) break;
+    if (stats->interleavings >= srch->max_interleavings) break;
+    // getNext (:1142-1162): deepest branch first, creation order within a branch, explored pairs skipped
+    while (items.size() < srch->batch && stats->interleavings + items.size() < srch->max_interleavings) {
+      while (top >= 0 && bucket[top].empty()) top--;
+      if (top < 0) break;
+      const demi::DporPoint p = bucket[top].front();
+      bucket[top].pop_front();
+      queued--;
+      if (!dead.insert({p.flip_a, p.flip_b}).second) continue;     // isExplored: skip; else setExplored (:1170-1172)
+      items.push_back(demi::DporItem{p.src, p.branch, p.later, p.earlier, 0});
+    }
+    if (items.empty() && queued == 0) exhausted = true;
+    if (seconds) seconds[2] += now() - t2;
+  }
+  if (first_id != ~0ull && first_violation_trace && first_violation_len) {
+    int rc = dev.fetch_trace((uint32_t)first_id, first_violation_trace, first_violation_len);
+    if (rc) return rc;
+  }
+  stats->queue_len = queued;
   stats->exhausted = exhausted ? 1u : 0u;
   return 0;
 }

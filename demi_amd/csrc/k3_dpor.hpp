@@ -23,6 +23,7 @@
 #pragma once
 
 #include "sim_core.hpp"
+#include "k3_pairs.hpp"
 
 #ifndef DEMI_VM_RUN   // the table interpreter, unless a specialised build supplies the compiled handlers (jit.hpp)
 #define DEMI_VM_RUN vm_run
@@ -56,6 +57,12 @@ struct K3Args {
   uint32_t* n_pairs;                 // [n]
   unsigned long long* work_counter;
   uint32_t* spill;
+  // device-resident exploration (demi_dpor_explore, ROUNDS order): the next trace of interleaving i is not uploaded but
+  // read from the trace of the interleaving that found the backtrack point, which stayed in the arena:
+  // trace.take(branch + 1) ++ trace(branch + 1 .. later) minus `earlier` (:1054-1057, 1180).  `traces` then points at this
+  // round's slots of the same arena.
+  const DporItem* items;             // [n] or null (then prefixes / prefix_len / shared_len are used)
+  const demi_dpor_trace_entry* arena;
 };
 
 constexpr int K3_WAVES = 4;
@@ -180,6 +187,10 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
   demi_dpor_trace_entry* tr = nullptr;
   const demi_dpor_trace_entry* pf = nullptr;
   uint32_t pfx = 0, pfx_len = 0;
+  uint32_t it_branch = 0, it_earlier = 0;      // device-resident next trace: position i is pf[i] up to the branch, then
+  auto pf_at = [&](uint32_t i) -> const demi_dpor_trace_entry& {      // pf[i] or pf[i + 1]: `earlier` is left out
+    return pf[(args.items && i > it_branch && i >= it_earlier) ? i + 1 : i];
+  };
   uint32_t n_pend = 0, next_seq = 0, parent = 0, parent_depth = 0, cur_root = 0, qperiod = 0, next_qperiod = 0;
   uint32_t marker_ext = 0, qmarker_ext = 0, isolated = 0, rep = 0, flags = 0, count = 0, deliveries = 0;
   uint32_t n_trace = 0, ext_idx = 0;
@@ -253,8 +264,17 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
       if (fresh) {
         fresh = false;
         tr = args.traces + sched * DEMI_DPOR_MAX_TRACE;
-        pf = args.prefixes + sched * (uint64_t)args.stride;
-        pfx = 0; pfx_len = args.prefix_len[sched];
+        if (args.items) {
+          const DporItem it = args.items[sched];
+          const bool first = it.src == 0xFFFFFFFFu;
+          pf = args.arena + (size_t)(first ? 0u : it.src) * DEMI_DPOR_MAX_TRACE;
+          it_branch = it.branch; it_earlier = it.earlier;
+          pfx_len = first ? 0u : (uint32_t)it.later;
+        } else {
+          pf = args.prefixes + sched * (uint64_t)args.stride;
+          pfx_len = args.prefix_len[sched];
+        }
+        pfx = 0;
         hash = 0xCBF29CE484222325ULL;
         isolated = (1u << A) - 1;      // maybeStartActors: every actor exists and is isolated (:666-679)
         for (uint32_t a = 0; a < A; a++) st[a * 64] = t.init[a];
@@ -276,9 +296,9 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
           // getMatchingMessage: skip root / id-0 heads (:363-372), then match the head by identity; with
           // prioritizePendingUponDivergence keep popping heads until one is pending (getNextMatchingMessage :537-550)
           do {
-            while (pfx < pfx_len && pf[pfx].kind == 0) pfx++;
+            while (pfx < pfx_len && pf_at(pfx).kind == 0) pfx++;
             if (pfx >= pfx_len) break;
-            const demi_dpor_trace_entry want = pf[pfx];
+            const demi_dpor_trace_entry want = pf_at(pfx);
             pfx++;
             if (want.kind == 2) {
               if (marker_pending && want.key == dpor_marker_key(marker_ext)) chose_marker = true;
@@ -404,7 +424,8 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
         const uint64_t s_sched = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(sched >> 32), src) << 32) |
                                  (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)sched, src);
         const uint32_t s_n = (uint32_t)__builtin_amdgcn_readlane((int)n_trace, src);
-        const uint32_t s_shared = args.shared_len ? args.shared_len[s_sched] : 0u;
+        const uint32_t s_shared = args.shared_len ? args.shared_len[s_sched]
+                                  : (args.items && args.items[s_sched].src != 0xFFFFFFFFu) ? (uint32_t)args.items[s_sched].branch + 1u : 0u;
         const uint32_t total = k3_racing_pairs(args.traces + s_sched * DEMI_DPOR_MAX_TRACE, s_n, s_meta, s_anc,
                                                args.pairs + s_sched * (uint64_t)args.max_pairs, args.max_pairs, lane, s_shared);
         if ((int)lane == src) { np = total < args.max_pairs ? total : args.max_pairs; pairs_ovf = total > args.max_pairs; }

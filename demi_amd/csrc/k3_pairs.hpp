@@ -1,0 +1,147 @@
+// k3_pairs.hpp — dpor()'s bookkeeping on the device: the ExploredTacker (AuxilaryTypes.scala:209-246) as a
+// device-resident hash table over ordered pairs of node keys, and the enqueue decision of dpor() (:1068-1070, 1134) and
+// getNext()'s skip (:1153-1157) taken there, so that of the ~10^3 racing pairs of an interleaving only the backtrack
+// points that can still be dequeued live ever leave the GPU.
+//
+// What is decided here, per round (one launch of k3_dpor = the interleavings popped together):
+//   mark    every backtrack point popped for this round: setExplored(branch, (later, earlier)) (:1170-1172);
+//   insert  every racing pair (earlier, later) of the round: setExplored(branch, (earlier, later)) (:1068-1070); a pair that
+//           becomes explored while backtrack points that flip INTO it are queued is reported to the host ("kill"), whose
+//           queue then skips them exactly as getNext() would; and every pair proposes itself as this round's candidate for
+//           its flipped pair (later, earlier): highest branch first, then creation order - DefaultBacktrackOrdering's
+//           dequeue order, so the candidate is the one point of the round that getNext() would reach first;
+//   decide  a pair's backtrack point is emitted iff its flipped pair is unexplored after the round (else getNext() would
+//           skip it: the explored set only grows and nothing is dequeued during a round), it is the round's candidate
+//           for that flipped pair (else the candidate is dequeued before it and explores the pair), and no point of an
+//           earlier round with the same flipped pair and an equal or higher branch is queued (that one is dequeued first).
+// Every point dropped here is one the reference would enqueue and later skip; the points it dequeues live, and their
+// order, are unchanged (tests: the exploration equals the host-side bookkeeping's, round by round).
+#pragma once
+
+#include "demi_device.hpp"
+#include "dpor_types.hpp"
+
+namespace demi {
+
+struct PairEntry {           // 32 bytes; key (0, 0) = empty slot (node keys are FNV chains, never both 0)
+  unsigned long long a, b;   // ordered pair of node keys
+  unsigned long long cand;   // this round's candidate for the points flipping INTO (a, b): round | branch + 1 | ~ordinal
+  uint32_t state;            // bit 31: explored; bits 0..8: 1 + highest branch of a queued point flipping into (a, b)
+  uint32_t pad;
+};
+constexpr uint32_t PE_EXPLORED = 0x80000000u, PE_QMASK = 0x1FFu;
+
+__device__ __forceinline__ uint64_t pair_hash(uint64_t a, uint64_t b) {
+  uint64_t h = (a * 0x9E3779B97F4A7C15ULL) ^ (b * 0xC2B2AE3D27D4EB4FULL) ^ (a >> 29);
+  h ^= h >> 32; h *= 0xD6E8FEB86659FD93ULL; h ^= h >> 32;
+  return h;
+}
+
+// find or insert (a, b); returns the slot, or 0xFFFFFFFF when the table is full (64 probes).  An inserter claims the
+// slot by CAS on `a` and publishes `b` right after, in the same iteration; a reader that sees the claim but not yet `b`
+// simply repeats the iteration (no spinning inside a divergent branch: the publishing lane may be in the same wave).
+__device__ inline uint32_t pair_slot(PairEntry* tab, uint32_t mask, uint64_t a, uint64_t b) {
+  uint32_t i = (uint32_t)pair_hash(a, b) & mask;
+  for (uint32_t probes = 0; probes < 4096;) {
+    PairEntry* e = tab + i;
+    unsigned long long ea = __atomic_load_n(&e->a, __ATOMIC_RELAXED);
+    if (ea == 0) {
+      const unsigned long long seen = atomicCAS(&e->a, 0ull, (unsigned long long)a);
+      if (seen == 0) { __atomic_store_n(&e->b, (unsigned long long)b, __ATOMIC_RELEASE); return i; }
+      ea = seen;
+    }
+    if (ea == a) {
+      const unsigned long long eb = __atomic_load_n(&e->b, __ATOMIC_ACQUIRE);
+      if (eb == b) return i;
+      if (eb == 0) { probes++; continue; }      // claimed, key not published yet: look again
+    }
+    i = (i + 1) & mask;
+    probes++;
+  }
+  return 0xFFFFFFFFu;
+}
+
+struct K3PairArgs {
+  PairEntry* table;
+  uint32_t mask;                       // table size - 1
+  const demi_dpor_trace_entry* arena;  // [ids][DEMI_DPOR_MAX_TRACE]
+  const DporItem* items;               // [n] the round's dequeued points
+  uint32_t base_id;                    // arena id of item 0's interleaving
+  uint32_t n;
+  const demi_dpor_pair* pairs;         // [n][max_pairs] racing pairs of the round's interleavings
+  const uint32_t* n_pairs;             // [n]
+  uint32_t max_pairs;
+  uint32_t round;                      // 1, 2, ...: stamps the candidates
+  uint32_t* pair_slot_of;              // [n][max_pairs] slot of the flipped pair (insert -> decide)
+  DporPoint* points; uint32_t points_cap;
+  DporKill* kills; uint32_t kills_cap;
+  unsigned long long* counters;        // [0] points, [1] kills, [2] table-full errors, [3] table entries
+};
+
+__device__ __forceinline__ unsigned long long cand_pack(uint32_t round, uint32_t branch, unsigned long long ordinal) {
+  // round < 2^24, branch + 1 < 2^9, ordinal < 2^31 (the host keeps n * max_pairs below that)
+  return ((unsigned long long)round << 40) | ((unsigned long long)(branch + 1) << 31) | (0x7FFFFFFFull - ordinal);
+}
+
+// mark: the dequeued points' flipped pairs are explored (getNext, :1170-1172)
+__global__ __launch_bounds__(256) void k3_pairs_mark(const K3PairArgs a) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  const DporItem it = a.items[i];
+  if (it.src == 0xFFFFFFFFu) return;
+  const demi_dpor_trace_entry* T = a.arena + (size_t)it.src * DEMI_DPOR_MAX_TRACE;
+  const uint32_t s = pair_slot(a.table, a.mask, T[it.later].key, T[it.earlier].key);
+  if (s == 0xFFFFFFFFu) { atomicAdd(&a.counters[2], 1ull); return; }
+  atomicOr(&a.table[s].state, PE_EXPLORED);
+}
+
+// insert: one workgroup per finished interleaving, its threads stride over the racing pairs
+__global__ __launch_bounds__(256) void k3_pairs_insert(const K3PairArgs a) {
+  const uint32_t it = blockIdx.x;
+  const demi_dpor_trace_entry* T = a.arena + (size_t)(a.base_id + it) * DEMI_DPOR_MAX_TRACE;
+  const demi_dpor_pair* P = a.pairs + (size_t)it * a.max_pairs;
+  const uint32_t np = a.n_pairs[it];
+  for (uint32_t k = threadIdx.x; k < np; k += blockDim.x) {
+    const demi_dpor_pair p = P[k];
+    const uint64_t ke = T[p.earlier].key, kl = T[p.later].key;
+    const uint32_t s1 = pair_slot(a.table, a.mask, ke, kl);
+    const uint32_t s2 = pair_slot(a.table, a.mask, kl, ke);
+    a.pair_slot_of[(size_t)it * a.max_pairs + k] = s2;
+    if (s1 == 0xFFFFFFFFu || s2 == 0xFFFFFFFFu) { atomicAdd(&a.counters[2], 1ull); continue; }
+    const uint32_t old = atomicOr(&a.table[s1].state, PE_EXPLORED);        // setExplored(branch, (earlier, later))
+    if (!(old & PE_EXPLORED) && (old & PE_QMASK)) {                        // queued points flip into this pair: dead now
+      const unsigned long long q = atomicAdd(&a.counters[1], 1ull);
+      if (q < a.kills_cap) { DporKill kk; kk.a = ke; kk.b = kl; a.kills[q] = kk; }
+    }
+    atomicMax(&a.table[s2].cand, cand_pack(a.round, p.branch, (unsigned long long)it * a.max_pairs + k));
+  }
+}
+
+// decide: which pairs' backtrack points can still be dequeued live
+__global__ __launch_bounds__(256) void k3_pairs_decide(const K3PairArgs a) {
+  const uint32_t it = blockIdx.x;
+  const demi_dpor_trace_entry* T = a.arena + (size_t)(a.base_id + it) * DEMI_DPOR_MAX_TRACE;
+  const demi_dpor_pair* P = a.pairs + (size_t)it * a.max_pairs;
+  const uint32_t np = a.n_pairs[it];
+  for (uint32_t k = threadIdx.x; k < np; k += blockDim.x) {
+    const uint32_t s2 = a.pair_slot_of[(size_t)it * a.max_pairs + k];
+    if (s2 == 0xFFFFFFFFu) continue;
+    const demi_dpor_pair p = P[k];
+    PairEntry* e = a.table + s2;
+    const unsigned long long ord = (unsigned long long)it * a.max_pairs + k;
+    const uint32_t st = e->state;
+    if (st & PE_EXPLORED) continue;                                        // getNext would skip it (:1153-1157)
+    if (e->cand != cand_pack(a.round, p.branch, ord)) continue;            // another point of this round is dequeued first
+    if ((st & PE_QMASK) > p.branch) continue;                              // so is a queued point of an earlier round
+    e->state = (st & ~PE_QMASK) | ((uint32_t)p.branch + 1);                // (the only writer of this entry this round)
+    const unsigned long long q = atomicAdd(&a.counters[0], 1ull);
+    if (q < a.points_cap) {
+      DporPoint o;
+      o.flip_a = T[p.later].key; o.flip_b = T[p.earlier].key; o.ordinal = ord; o.src = a.base_id + it;
+      o.branch = p.branch; o.later = p.later; o.earlier = p.earlier; o.pad = 0; o.pad2 = 0;
+      a.points[q] = o;
+    }
+  }
+}
+
+}  // namespace demi

@@ -3,6 +3,7 @@
 // host time can be profiled.  Built by tests/test_dpor_cpu.py with g++, linked against oracle/_build/liboracle.so.
 #include <cstring>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "../demi_amd/csrc/dpor_host.hpp"
@@ -40,4 +41,103 @@ extern "C" int harness_dpor_explore(const demi_model* m, const demi_ext_event* e
   };
   return demi_host::explore_loop(run, fetch, par->max_pairs, srch, out_verdicts, out_prefix_len, out_rounds,
                                  first_violation_trace, first_violation_len, stats, seconds);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The device-resident bookkeeping (demi_amd/csrc/k3_pairs.hpp: mark / insert / decide over a pair table, next traces
+// read from an arena of finished traces) restated sequentially on the host, under the same host loop
+// (explore_rounds_resident).  It is the CPU check of that loop and the reference the kernels are compared with.
+namespace {
+struct SimEntry { uint32_t state = 0; unsigned long long cand = 0; };
+constexpr uint32_t SIM_EXPLORED = 0x80000000u, SIM_QMASK = 0x1FFu;
+unsigned long long sim_cand(uint32_t round, uint32_t branch, unsigned long long ord) {
+  return ((unsigned long long)round << 40) | ((unsigned long long)(branch + 1) << 31) | (0x7FFFFFFFull - ord);
+}
+struct SimDev {
+  const demi_model* m; const demi_ext_event* ext; uint32_t n_ext; const demi_dpor_params* par; int n_threads;
+  std::vector<demi_host::Trace> arena;
+  std::unordered_map<std::pair<uint64_t, uint64_t>, SimEntry, demi_host::PairKeyHash> table;
+
+  int round(const demi::DporItem* items, uint32_t n, uint32_t round_no, uint32_t base_id, demi_verdict* vd,
+            std::vector<demi::DporPoint>& pts, std::vector<demi::DporKill>& kills) {
+    if (arena.size() < (size_t)base_id + n) arena.resize((size_t)base_id + n);
+    const uint32_t mp = par->max_pairs;
+    std::vector<std::vector<demi_dpor_pair>> pairs(n);
+    // mark
+    for (uint32_t i = 0; i < n; i++) {
+      if (items[i].src == 0xFFFFFFFFu) continue;
+      const demi_host::Trace& T = arena[items[i].src];
+      table[{T[items[i].later].key, T[items[i].earlier].key}].state |= SIM_EXPLORED;
+    }
+    // the interleavings (next trace = take(branch + 1) ++ replay, from the arena)
+    auto work = [&](unsigned t) {
+      std::vector<uint64_t> keys(DEMI_DPOR_MAX_TRACE);
+      std::vector<demi_dpor_trace_entry> tr(DEMI_DPOR_MAX_TRACE);
+      std::vector<demi_dpor_pair> pr(mp ? mp : 1);
+      for (uint32_t i = t; i < n; i += (unsigned)n_threads) {
+        uint32_t pl = 0, shared = 0;
+        if (items[i].src != 0xFFFFFFFFu) {
+          const demi_host::Trace& T = arena[items[i].src];
+          for (uint32_t k = 0; k <= items[i].branch; k++) keys[pl++] = T[k].key;
+          for (uint32_t k = items[i].branch + 1u; k <= items[i].later; k++) if (k != items[i].earlier) keys[pl++] = T[k].key;
+          shared = items[i].branch + 1u;
+        }
+        uint32_t tl = 0, np = 0;
+        orc_dpor_execute(m, ext, n_ext, keys.data(), pl, shared, par, &vd[i], tr.data(), &tl, pr.data(), &np);
+        arena[(size_t)base_id + i].assign(tr.begin(), tr.begin() + tl);
+        pairs[i].assign(pr.begin(), pr.begin() + np);
+      }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < n_threads; t++) pool.emplace_back(work, (unsigned)t);
+    work(0u);
+    for (auto& th : pool) th.join();
+    // insert
+    for (uint32_t i = 0; i < n; i++) {
+      const demi_host::Trace& T = arena[(size_t)base_id + i];
+      for (uint32_t k = 0; k < pairs[i].size(); k++) {
+        const demi_dpor_pair p = pairs[i][k];
+        const uint64_t ke = T[p.earlier].key, kl = T[p.later].key;
+        SimEntry& e1 = table[{ke, kl}];
+        if (!(e1.state & SIM_EXPLORED) && (e1.state & SIM_QMASK)) kills.push_back(demi::DporKill{ke, kl});
+        e1.state |= SIM_EXPLORED;
+        SimEntry& e2 = table[{kl, ke}];
+        const unsigned long long c = sim_cand(round_no, p.branch, (unsigned long long)i * mp + k);
+        if (c > e2.cand) e2.cand = c;
+      }
+    }
+    // decide
+    for (uint32_t i = 0; i < n; i++) {
+      const demi_host::Trace& T = arena[(size_t)base_id + i];
+      for (uint32_t k = 0; k < pairs[i].size(); k++) {
+        const demi_dpor_pair p = pairs[i][k];
+        SimEntry& e = table[{T[p.later].key, T[p.earlier].key}];
+        const unsigned long long ord = (unsigned long long)i * mp + k;
+        if (e.state & SIM_EXPLORED) continue;
+        if (e.cand != sim_cand(round_no, p.branch, ord)) continue;
+        if ((e.state & SIM_QMASK) > p.branch) continue;
+        e.state = (e.state & ~SIM_QMASK) | ((uint32_t)p.branch + 1);
+        pts.push_back(demi::DporPoint{T[p.later].key, T[p.earlier].key, ord, base_id + i, p.branch, p.later, p.earlier, 0, 0});
+      }
+    }
+    return 0;
+  }
+  int fetch_trace(uint32_t id, demi_dpor_trace_entry* out, uint32_t* len) {
+    memcpy(out, arena[id].data(), sizeof(demi_dpor_trace_entry) * arena[id].size());
+    *len = (uint32_t)arena[id].size();
+    return 0;
+  }
+};
+}  // namespace
+
+extern "C" int harness_dpor_explore_resident(const demi_model* m, const demi_ext_event* ext, uint32_t n_ext,
+                                             const demi_dpor_params* par, const demi_dpor_search* srch, int n_threads,
+                                             demi_verdict* out_verdicts, uint32_t* out_prefix_len, uint32_t* out_rounds,
+                                             demi_dpor_trace_entry* first_violation_trace, uint32_t* first_violation_len,
+                                             demi_dpor_stats* stats, double* seconds, uint64_t* table_entries) {
+  SimDev dev{m, ext, n_ext, par, n_threads, {}, {}};
+  const int rc = demi_host::explore_rounds_resident(dev, srch, out_verdicts, out_prefix_len, out_rounds, first_violation_trace,
+                                                    first_violation_len, stats, seconds);
+  if (table_entries) *table_entries = dev.table.size();
+  return rc;
 }

@@ -20,10 +20,12 @@ def build(force=False):
     return so
 
 
-def dpor_explore(model, externals, params, search, n_threads=None):
+def dpor_explore(model, externals, params, search, n_threads=None, resident=False):
     """The whole DPOR exploration on the CPU: the product's host bookkeeping (demi_amd/csrc/dpor_host.hpp) around this
     oracle's interleavings, `n_threads` of them at a time.  Returns (verdicts, prefix_len, rounds, first violating trace,
-    stats, seconds[run, fetch + absorb, get_next])."""
+    stats, seconds[run, fetch + absorb, get_next]).
+    resident: the device-resident bookkeeping (explored-pair table, enqueue decision, trace arena: k3_pairs.hpp) restated
+    sequentially, under the host loop that drives the kernels (explore_rounds_resident)."""
     build()
     H = C.CDLL(os.path.join(_HERE, "_build", "dpor_host_harness.so"))
     H.harness_dpor_explore.argtypes = [C.POINTER(T.ModelStruct), C.c_void_p, C.c_uint32, C.POINTER(T.DporParams),
@@ -39,9 +41,16 @@ def dpor_explore(model, externals, params, search, n_threads=None):
     vl = C.c_uint32(0)
     stats = T.DporStats()
     secs = np.zeros(3, dtype=np.float64)
-    rc = H.harness_dpor_explore(C.byref(ms), ev.ctypes.data, len(ev), C.byref(params), C.byref(search),
-                                n_threads or (os.cpu_count() or 1), verdicts.ctypes.data, plen.ctypes.data, rounds.ctypes.data,
-                                vt.ctypes.data, C.byref(vl), C.byref(stats), secs.ctypes.data)
+    args = [C.byref(ms), ev.ctypes.data, len(ev), C.byref(params), C.byref(search),
+            n_threads or (os.cpu_count() or 1), verdicts.ctypes.data, plen.ctypes.data, rounds.ctypes.data,
+            vt.ctypes.data, C.byref(vl), C.byref(stats), secs.ctypes.data]
+    if resident:
+        H.harness_dpor_explore_resident.argtypes = H.harness_dpor_explore.argtypes + [C.POINTER(C.c_uint64)]
+        entries = C.c_uint64(0)
+        rc = H.harness_dpor_explore_resident(*args, C.byref(entries))
+        stats.table_entries = int(entries.value)
+    else:
+        rc = H.harness_dpor_explore(*args)
     assert rc == 0
     n = int(stats.interleavings)
     return verdicts[:n], plen[:n], rounds[:int(stats.launches)], vt[:vl.value], stats, secs

@@ -257,3 +257,23 @@ def test_config3_reference_order_matches_the_golden_batch1_record():
     assert hashlib.sha256(plen.tobytes()).hexdigest() == want["sha256_prefix_lens"]
     assert len(res.violations) == want["violations"] and len(res.schedule_hashes()) == want["distinct_schedules"]
     d.shutdown()
+
+
+def test_device_resident_bookkeeping_equals_the_host_bookkeeping_config3(monkeypatch):
+    """BASELINE config 3 to exhaustion in ROUNDS order: explored set + enqueue decision on the device (the default) against
+    the path that fetches every racing pair and absorbs it on the host (DEMI_DPOR_HOST_BOOKKEEPING): the same rounds and
+    verdicts, a fraction of the bytes over PCIe."""
+    model, ev, depth = raft5_config3()
+    out = {}
+    for host in (False, True):
+        if host:
+            monkeypatch.setenv("DEMI_DPOR_HOST_BOOKKEEPING", "1")
+        d = DPORwHeuristics(SchedulerConfig(model=model), depth_bound=depth, stopIfViolationFound=False, batch=2048, specialize=True)
+        res = d.explore_native(ev, max_interleavings=1 << 17)
+        st = d.last_native_stats
+        out[host] = (np.array([il.verdict for il in res.interleavings], dtype=T.VERDICT_DTYPE), res.rounds, res.exhausted,
+                     int(st.d2h_bytes) + int(st.h2d_bytes))
+        d.shutdown()
+    assert len(out[False][0]) == len(out[True][0]) == 62902 and (out[False][0] == out[True][0]).all()
+    assert out[False][1] == out[True][1] and out[False][2] and out[True][2]
+    assert out[False][3] * 20 < out[True][3]
