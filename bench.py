@@ -246,7 +246,26 @@ def main():
 
     verdicts = torch.empty((n, 2), dtype=torch.int64, device=dev)          # demi_verdict[n]
     viol = torch.zeros((VIOL_CAP + 1, 2), dtype=torch.int64, device=dev)  # row 0 = count, then demi_violation[]
-    gathered = [torch.empty_like(viol) for _ in range(world)] if world > 1 else None
+    gathered = torch.empty((world, VIOL_CAP + 1, 2), dtype=torch.int64, device=dev) if world > 1 else None
+    # the found-violation sets are all-gathered by the library's own communicator (demi_comm_*: ncclAllGather over xGMI
+    # behind the C ABI, what a JVM host would call); its unique id travels over torch.distributed, which also provides the
+    # barrier.  If RCCL cannot be initialised there, torch.distributed's all_gather does the exchange (and the line says so).
+    collective = "none (1 rank)"
+    if world > 1:
+        try:
+            uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+            if rank == 0:
+                uid = torch.tensor(list(_native.Context.comm_unique_id()), dtype=torch.uint8, device=dev)
+            dist.broadcast(uid, 0)
+            ctx.comm_create(bytes(uid.cpu().tolist()), rank, world)
+            collective = "demi_comm_allgather_dev (RCCL ncclAllGather inside libdemi_gpu.so)"
+        except Exception as e:
+            collective = "torch.distributed.all_gather (library communicator unavailable: %s)" % e
+        flag = torch.tensor([1 if collective.startswith("demi_comm") else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)          # all ranks take the same path
+        if int(flag.item()) == 0 and collective.startswith("demi_comm"):
+            collective = "torch.distributed.all_gather (library communicator unavailable on another rank)"
+    use_lib_comm = collective.startswith("demi_comm")
     stream = torch.cuda.current_stream()
     sp = C.c_void_p(stream.cuda_stream)
     index_base = rank * n      # weak scaling: rank r evaluates schedules [r*n, (r+1)*n)
@@ -263,7 +282,10 @@ def main():
         ctx.collect_violations_dev(verdicts.data_ptr(), n, index_base, viol[1:].data_ptr(), VIOL_CAP,
                                    viol[0:1].data_ptr(), stream=sp)
         if world > 1:
-            dist.all_gather(gathered, viol)
+            if use_lib_comm:
+                ctx.comm_allgather_dev(viol.data_ptr(), gathered.data_ptr(), viol.numel() * 8, stream=sp)
+            else:
+                dist.all_gather_into_tensor(gathered.view(-1, 2), viol)
 
     def sync():
         if world > 1:
@@ -293,7 +315,7 @@ def main():
         dt = float(t.item())
 
     # ---- found-violation set of the last step (all ranks)
-    parts = gathered if world > 1 else [viol]
+    parts = [gathered[r] for r in range(world)] if world > 1 else [viol]
     vset = merge_violation_sets([p.cpu().numpy() for p in parts], VIOL_CAP)
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
     # distinct violating schedules by delivery-sequence hash: this rank's shard of the last step
@@ -360,7 +382,7 @@ def main():
                        "schedules_per_gpu_per_step": n, "max_messages": int(limits.max_messages),
                        "invariant_check_interval": int(limits.invariant_check_interval), "p_max": int(limits.p_max),
                        "randomization_strategy": "SrcDstFIFO" if args.strategy == "fifo" else "FullyRandom",
-                       "table_compiled_to_native_code": specialized, "seed_base": SEED_BASE, "parallelism": "schedule-index range sharded, %d rank(s)" % world,
+                       "table_compiled_to_native_code": specialized, "seed_base": SEED_BASE, "parallelism": "schedule-index range sharded, %d rank(s)" % world, "collective": collective,
                        "untimed_prewarm_s": prewarm_s},
             "violations_last_step": int(len(vset)),
             "distinct_fingerprints_last_step": int(len(np.unique(vset["fingerprint"]))) if len(vset) else 0,

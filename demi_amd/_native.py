@@ -15,9 +15,12 @@ EXPORTS = ["demi_ctx_create", "demi_ctx_destroy", "demi_last_error", "demi_versi
            "demi_trace_load", "demi_random_explore", "demi_random_explore_dev", "demi_random_get_trace", "demi_collect_violations_dev",
            "demi_replay_load", "demi_replay_batch", "demi_replay_batch_dev", "demi_dpor_load", "demi_dpor_batch", "demi_dpor_explore", "demi_random_explore_violations",
            "demi_replay_removal_batch", "demi_replay_get_kept", "demi_model_specialize", "demi_model_is_specialized",
-           "demi_specialize_check", "demi_specialize_source", "demi_device_probe", "demi_calib_rw", "demi_random_explore_flagged", "demi_collect_flagged_dev"]
+           "demi_specialize_check", "demi_specialize_source", "demi_device_probe", "demi_calib_rw", "demi_random_explore_flagged", "demi_collect_flagged_dev",
+           "demi_comm_unique_id", "demi_comm_create", "demi_comm_create_host", "demi_comm_destroy", "demi_comm_rank",
+           "demi_comm_allgather_dev", "demi_random_explore_sharded", "demi_replay_batch_sharded"]
 
 _lib = None
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)     # demi_allgather_fn
 
 
 class DemiError(RuntimeError):
@@ -75,6 +78,25 @@ def lib():
                                     C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(T.DporStats)]
     L.demi_random_explore_violations.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(T.Limits), C.c_void_p,
                                                  C.c_uint32, C.POINTER(C.c_uint64)]
+    L.demi_random_explore_flagged.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(T.Limits), C.c_uint32, C.c_void_p,
+                                              C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.demi_collect_flagged_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint32,
+                                           C.c_void_p, C.c_void_p]
+    L.demi_comm_unique_id.argtypes = [C.c_void_p]
+    L.demi_comm_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    L.demi_comm_create_host.argtypes = [C.c_void_p, C.c_int, C.c_int, ALLGATHER_FN, C.c_void_p]
+    L.demi_comm_destroy.argtypes = [C.c_void_p]
+    L.demi_comm_rank.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.demi_comm_allgather_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.demi_random_explore_sharded.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(T.Limits), C.c_void_p, C.c_uint32,
+                                              C.POINTER(C.c_uint64)]
+    L.demi_replay_batch_sharded.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(T.Limits), C.c_void_p]
+    L.demi_device_probe.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(T.ProbeResult)]
+    L.demi_calib_rw.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint32]
+    # every export has its argument types declared: an undeclared one would silently truncate pointers to 32 bits
+    for name in EXPORTS:
+        fn = getattr(L, name)
+        assert fn.argtypes is not None or name in ("demi_version",), "no argtypes for %s" % name
     _lib = L
     return L
 
@@ -272,6 +294,62 @@ class Context:
                                             plen.ctypes.data, rounds.ctypes.data, vt.ctypes.data, C.byref(vl), C.byref(stats)))
         n = int(stats.interleavings)
         return verdicts[:n].copy(), plen[:n].copy(), rounds[:int(stats.launches)].copy(), vt[:vl.value].copy(), stats
+
+    # ---- multi-GPU (one process and one Context per GPU)
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """Rank 0: the RCCL unique id (128 bytes) every rank passes to comm_create."""
+        buf = C.create_string_buffer(128)
+        rc = lib().demi_comm_unique_id(buf)
+        if rc != 0:
+            raise DemiError(rc, "RCCL unavailable")
+        return buf.raw
+
+    def comm_create(self, unique_id: bytes, rank: int, world: int):
+        """RCCL communicator over xGMI (ncclCommInitRank: collective over the ranks)."""
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        self._check(lib().demi_comm_create(self._h, buf, rank, world))
+
+    def comm_create_host(self, rank: int, world: int, allgather):
+        """A communicator whose all-gather the host supplies: allgather(send: bytes) -> bytes of every rank's block in rank
+        order (e.g. torch.distributed over gloo).  Blocks are staged through host memory."""
+        def thunk(_user, send, recv, nbytes):
+            try:
+                out = allgather(C.string_at(send, nbytes))
+                C.memmove(recv, out, len(out))
+                return 0
+            except Exception:        # reported as DEMI_ERR_DEVICE by the library
+                return 1
+        self._allgather_cb = ALLGATHER_FN(thunk)          # keep the callback alive as long as the communicator
+        self._check(lib().demi_comm_create_host(self._h, rank, world, self._allgather_cb, None))
+
+    def comm_destroy(self):
+        self._check(lib().demi_comm_destroy(self._h))
+
+    def comm_rank(self):
+        r, w = C.c_int(0), C.c_int(1)
+        self._check(lib().demi_comm_rank(self._h, C.byref(r), C.byref(w)))
+        return r.value, w.value
+
+    def comm_allgather_dev(self, d_send_ptr, d_recv_ptr, nbytes, stream=None):
+        self._check(lib().demi_comm_allgather_dev(self._h, C.c_void_p(d_send_ptr), C.c_void_p(d_recv_ptr), nbytes, stream))
+
+    def random_explore_sharded(self, n_total, limits, seed_base=0, cap=1 << 16):
+        """n_total schedules split by index range over the communicator's ranks; the merged violation set on every rank."""
+        import numpy as np
+        out = np.zeros(cap, dtype=T.VIOLATION_DTYPE)
+        cnt = C.c_uint64(0)
+        self._check(lib().demi_random_explore_sharded(self._h, C.c_uint64(seed_base), n_total, C.byref(limits), out.ctypes.data,
+                                                      cap, C.byref(cnt)))
+        return out[:min(cnt.value, cap)].copy(), int(cnt.value)
+
+    def replay_batch_sharded(self, masks, limits):
+        import numpy as np
+        masks = np.ascontiguousarray(masks, dtype=np.uint64).reshape(-1, 4)
+        out = np.zeros(len(masks), dtype=T.VERDICT_DTYPE)
+        if len(masks):
+            self._check(lib().demi_replay_batch_sharded(self._h, masks.ctypes.data, len(masks), C.byref(limits), out.ctypes.data))
+        return out
 
     def device_probe(self, waves_per_simd=1, iters=20000):
         """Shader clock under load (GHz) and SIMD cycles per wave64 integer VALU instruction (demi_device_probe)."""

@@ -15,6 +15,20 @@
 //     pending, otherwise it is ignored ("Ignoring message", STSScheduler.scala:528-529).
 // Messages with equal (snd, rcv, fingerprint) are interchangeable, so the per-key FIFO of the
 // reference is realised as "any pending entry with this word" + swap-remove.
+//
+// k2_replay<true> goes one step further: which messages can ever be delivered is known when the original execution is
+// loaded - the distinct message words of its MsgEvents (a few hundred) - so the pending set of a lane is not an array
+// that every expected delivery scans (O(pending) loads, most of them in the HBM spill at p_max = 128) but one byte
+// counter per such word: "is a message with this fingerprint pending" is one read, a produced message finds its
+// counter through a workgroup-shared hash of the words, and a message nobody will ever ask for only counts against the
+// capacity.  The lowered original trace is staged in LDS as well.  Same verdicts, bit for bit.  Where the counters live:
+//   K2_FP_LDS   [word][lane] bytes in LDS: shortest dependent chain per delivery, but ~17 KB per wave for a 400-delivery
+//               execution, i.e. one workgroup per CU - the choice for a DDMin frontier (10^2 - 10^4 candidates), whose
+//               launch time is the serial chain of one replay and not throughput;
+//   K2_FP_HBM   [word][global lane] bytes in an HBM scratch, incremented / decremented with fire-and-forget 32-bit
+//               atomics on the dword that holds four lanes' counters, read with one load per expected delivery (the
+//               same one round trip per delivery as K1's random pick): 4.6 KB of LDS per wave, 16-20 waves per CU -
+//               the choice when there are more candidates than the LDS variant can hold at once.
 #pragma once
 
 #include "sim_core.hpp"
@@ -43,25 +57,104 @@ struct K2Args {
   demi_verdict* out;
   unsigned long long* work_counter;
   uint32_t* spill;
+  // k2_replay<true>: the deliverable message words of the loaded execution
+  const uint16_t* exp_fp;   // [n_exp] word id of a MSG_EVENT's message / of the message an external MSG_SEND enqueues (0xFFFF: none)
+  const uint64_t* fp_hash;  // [fp_hash_mask + 1] open addressing: word | (id + 1) << 32, 0 = empty
+  uint32_t fp_hash_mask;
+  uint32_t n_fp;            // word ids 0 .. n_fp - 1
+  uint8_t* fp_counts;       // K2_FP_HBM: [n_fp][resident lanes] counters
 };
 
 constexpr int K2_WAVES = 4;
+constexpr uint32_t K2_FP_NONE = 0xFFFFu;
+enum : int { K2_SCAN = 0, K2_FP_LDS = 1, K2_FP_HBM = 2 };
+
+// LDS of k2_replay<true>: tables | expected (8 B each) | exp_fp (2 B each) | word hash | per wave: states, effect queue, counters
+__host__ __device__ inline size_t k2_fp_shared_bytes(uint32_t n_exp, uint32_t hash_slots) {
+  return (((size_t)n_exp * 8 + (size_t)n_exp * 2 + 15) & ~(size_t)15) + (size_t)hash_slots * 8;
+}
+__host__ __device__ inline size_t k2_fp_wave_bytes(uint32_t n_actors, uint32_t n_fp, bool counters_in_lds) {
+  return (size_t)n_actors * 64 * 8 + (size_t)DEMI_FX_CAP * 64 * 4 + (counters_in_lds ? (((size_t)n_fp * 64 + 15) & ~(size_t)15) : 0);
+}
+__host__ __device__ inline size_t k2_fp_lds_bytes(uint32_t code_len, uint32_t n_ext, uint32_t n_hs, uint32_t n_actors,
+                                                  uint32_t n_exp, uint32_t hash_slots, uint32_t n_fp, bool counters_in_lds) {
+  return tables_lds_bytes(code_len, n_ext, n_hs) + k2_fp_shared_bytes(n_exp, hash_slots) +
+         K2_WAVES * k2_fp_wave_bytes(n_actors, n_fp, counters_in_lds);
+}
 
 __host__ __device__ inline size_t k2_lds_bytes(uint32_t code_len, uint32_t n_ext, uint32_t n_hs, uint32_t n_actors) {
   return tables_lds_bytes(code_len, n_ext, n_hs) + K2_WAVES * lane_mem_wave_bytes(n_actors, false);
 }
 
-__global__ __launch_bounds__(K2_WAVES * 64) void k2_replay(const K2Args args) {
+template <int MODE>
+__device__ __forceinline__ void k2_replay_body(const K2Args& args) {
+  constexpr bool FP = MODE != K2_SCAN;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Tables t;
   unsigned char* wave_base = tables_load(t, smem, args.model, args.ext, args.n_ext, args.exists);
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const LaneMem mem = lane_mem_carve(wave_base + (size_t)wave * lane_mem_wave_bytes(t.A, false), t.A, false, lane,
-                                     args.spill, (size_t)blockIdx.x * blockDim.x + threadIdx.x,
-                                     (size_t)gridDim.x * blockDim.x);
+  const uint32_t NX = args.n_exp;
+  const uint64_t* expected = args.expected;
+  const uint16_t* exp_fp = nullptr;
+  const uint64_t* fp_hash = nullptr;
+  uint8_t* cnt = nullptr;                 // FP: this lane's counters, cnt[id * cnt_stride]
+  size_t cnt_stride = 64;
+  LaneMem mem;
+  if (FP) {
+    // stage the lowered trace, the word ids and the word hash once per workgroup
+    uint64_t* s_exp = reinterpret_cast<uint64_t*>(wave_base);
+    uint16_t* s_fp = reinterpret_cast<uint16_t*>(s_exp + NX);
+    uint64_t* s_hash = reinterpret_cast<uint64_t*>(wave_base + (((size_t)NX * 10 + 15) & ~(size_t)15));
+    for (uint32_t i = threadIdx.x; i < NX; i += blockDim.x) { s_exp[i] = args.expected[i]; s_fp[i] = args.exp_fp[i]; }
+    for (uint32_t i = threadIdx.x; i <= args.fp_hash_mask; i += blockDim.x) s_hash[i] = args.fp_hash[i];
+    __syncthreads();
+    expected = s_exp; exp_fp = s_fp; fp_hash = s_hash;
+    unsigned char* wb = wave_base + k2_fp_shared_bytes(NX, args.fp_hash_mask + 1) +
+                        (size_t)wave * k2_fp_wave_bytes(t.A, args.n_fp, MODE == K2_FP_LDS);
+    mem.st = reinterpret_cast<uint64_t*>(wb) + lane;
+    mem.fxq = reinterpret_cast<uint32_t*>(wb + (size_t)t.A * 64 * 8) + lane;
+    mem.pend = nullptr; mem.pend_aux = nullptr; mem.spill = nullptr; mem.spill_aux = nullptr; mem.spill_stride = 0; mem.hot = 0;
+    if (MODE == K2_FP_LDS) cnt = wb + (size_t)t.A * 64 * 8 + (size_t)DEMI_FX_CAP * 64 * 4 + lane;
+    else { cnt_stride = (size_t)gridDim.x * blockDim.x; cnt = args.fp_counts + (size_t)blockIdx.x * blockDim.x + threadIdx.x; }
+  } else {
+    mem = lane_mem_carve(wave_base + (size_t)wave * lane_mem_wave_bytes(t.A, false), t.A, false, lane,
+                         args.spill, (size_t)blockIdx.x * blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x);
+  }
   uint64_t* const st = mem.st;
-  const uint32_t A = t.A, NE = t.E, exists = t.exists, PMAX = args.p_max, NX = args.n_exp;
-  const uint64_t* __restrict__ expected = args.expected;
+  const uint32_t A = t.A, NE = t.E, exists = t.exists, PMAX = args.p_max;
+  // counter of word id `f` of this lane: read; +1 / -1 (K2_FP_HBM: a 32-bit atomic on the dword shared with three other
+  // lanes - their bytes are untouched as a count never leaves 0..255 - with no return value, so nothing waits for it)
+  // (the HBM read goes to the L2, where the atomics are performed: an L1 line could predate this lane's own atomic)
+  auto cnt_get = [&](uint32_t f) -> uint32_t {
+    const uint8_t* c = cnt + (size_t)f * cnt_stride;
+    if (MODE == K2_FP_HBM) {
+      const uintptr_t ad = reinterpret_cast<uintptr_t>(c);
+      const uint32_t w32 = __hip_atomic_load(reinterpret_cast<const uint32_t*>(ad & ~(uintptr_t)3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return (w32 >> (8u * (uint32_t)(ad & 3u))) & 0xFFu;
+    }
+    return *c;
+  };
+  auto cnt_add = [&](uint32_t f, bool up) {
+    uint8_t* c = cnt + (size_t)f * cnt_stride;
+    if (MODE == K2_FP_HBM) {
+      const uintptr_t ad = reinterpret_cast<uintptr_t>(c);
+      uint32_t* w32 = reinterpret_cast<uint32_t*>(ad & ~(uintptr_t)3);
+      const uint32_t one = 1u << (8u * (uint32_t)(ad & 3u));
+      if (up) atomicAdd(w32, one); else atomicSub(w32, one);
+    } else {
+      *c = (uint8_t)(*c + (up ? 1 : -1));
+    }
+  };
+  // the word id of a message produced at run time (FP): a probe or two of the workgroup's hash
+  auto fp_of = [&](uint32_t word) -> uint32_t {
+    uint32_t i = (word * 0x9E3779B1u) >> 7 & args.fp_hash_mask;
+    for (;;) {
+      const uint64_t e = fp_hash[i];
+      if (e == 0) return K2_FP_NONE;
+      if ((uint32_t)e == word) return (uint32_t)(e >> 32) - 1u;
+      i = (i + 1) & args.fp_hash_mask;
+    }
+  };
 
   bool active = false, fresh = false;
   uint64_t sched = 0, hash = 0;
@@ -75,11 +168,17 @@ __global__ __launch_bounds__(K2_WAVES * 64) void k2_replay(const K2Args args) {
 
 #define IN_MASK(I) ((uint32_t)((((I) & 128u) ? (((I) & 64u) ? m3 : m2) : (((I) & 64u) ? m1 : m0)) >> ((I) & 63u)) & 1u)
 #define TIMER_BIT(RCV, TYPE) (1u << ((RCV) * DEMI_MAX_TIMER_TYPES + (t.meta[(TYPE)] >> 8)))
-#define PEND_APPEND(WORD)                                              \
+// FP: FPID is the word's id if the caller knows it, else it is looked up; a word without an id only takes up capacity
+#define PEND_APPEND_ID(WORD, FPID)                                     \
   do {                                                                 \
     if (n_pend >= PMAX) { flags |= DEMI_V_PENDING_OVF; }               \
-    else { pend_store(mem, n_pend, (WORD)); n_pend++; }                \
+    else if (FP) {                                                     \
+      const uint32_t id_ = (FPID);                                     \
+      if (id_ != K2_FP_NONE) cnt_add(id_, true);                       \
+      n_pend++;                                                        \
+    } else { pend_store(mem, n_pend, (WORD)); n_pend++; }              \
   } while (0)
+#define PEND_APPEND(WORD) PEND_APPEND_ID(WORD, fp_of(WORD))
 
   // cursor over the candidate's non-Send, non-WaitQuiescence externals (subsequenceIntersection :299-304)
   auto cur_skip = [&]() {
@@ -135,6 +234,7 @@ __global__ __launch_bounds__(K2_WAVES * 64) void k2_replay(const K2Args args) {
         hash = 0xCBF29CE484222325ULL;
         net.inaccessible = exists; net.killed = 0; net.partitioned = 0;
         for (uint32_t a = 0; a < A; a++) st[a * 64] = t.init[a];
+        if (FP) for (uint32_t f = 0; f < args.n_fp; f++) cnt[(size_t)f * cnt_stride] = 0;
         idx = 0; cur = 0; n_pend = 0; count = 0; ignored = 0; flags = 0; rep = 0; tq = 0; n_tq = 0;
         cur_skip();
       }
@@ -164,8 +264,8 @@ __global__ __launch_bounds__(K2_WAVES * 64) void k2_replay(const K2Args args) {
         } else if (kind == DEMI_REC_MSG_SEND) {
           // external MsgSend -> enqueue_message (:509-511) unless its Send was pruned
           if (IN_MASK(ext) && ((exists >> b) & 1)) {
-            PEND_APPEND(msg_word((uint32_t)(e >> 24) & 0xFF, DEMI_DEADLETTERS, b, (uint32_t)(e >> 32) & 0xFF,
-                                 (uint32_t)(e >> 40) & 0xFF));
+            PEND_APPEND_ID(msg_word((uint32_t)(e >> 24) & 0xFF, DEMI_DEADLETTERS, b, (uint32_t)(e >> 32) & 0xFF,
+                                    (uint32_t)(e >> 40) & 0xFF), (uint32_t)exp_fp[idx - 1]);
             if (args.kept && !(flags & DEMI_OVF_ANY)) args.kept[sched * NX + idx - 1] = 1;
           }
         } else {  // MSG_EVENT
@@ -173,11 +273,17 @@ __global__ __launch_bounds__(K2_WAVES * 64) void k2_replay(const K2Args args) {
           if (ext != 255 && !IN_MASK(ext)) continue;   // pruned together with its Send (filterSends)
           const uint32_t want = msg_word((uint32_t)(e >> 24) & 0xFF, a, b, (uint32_t)(e >> 32) & 0xFF,
                                          (uint32_t)(e >> 40) & 0xFF);
-          uint32_t k = 0;
-          for (; k < n_pend; k++)
-            if (pend_load(mem, k) == want) break;
-          if (k == n_pend) { ignored++; continue; }     // "Ignoring message" (:528-529)
-          pend_store(mem, k, pend_load(mem, n_pend - 1));
+          if (FP) {
+            const uint32_t f = exp_fp[idx - 1];
+            if (cnt_get(f) == 0) { ignored++; continue; }     // "Ignoring message" (:528-529)
+            cnt_add(f, false);
+          } else {
+            uint32_t k = 0;
+            for (; k < n_pend; k++)
+              if (pend_load(mem, k) == want) break;
+            if (k == n_pend) { ignored++; continue; }     // "Ignoring message" (:528-529)
+            pend_store(mem, k, pend_load(mem, n_pend - 1));
+          }
           n_pend--;
           if (args.kept) args.kept[sched * NX + idx - 1] = 1;
           w = want;
@@ -228,10 +334,15 @@ __global__ __launch_bounds__(K2_WAVES * 64) void k2_replay(const K2Args args) {
           }
           if (!found) {
             const uint32_t wantw = msg_word(type, DEMI_DEADLETTERS, me, 0, 0);
-            for (uint32_t q = 0; q < n_pend; q++) {
-              if (pend_load(mem, q) == wantw) {
-                pend_store(mem, q, pend_load(mem, n_pend - 1));
-                n_pend--; break;
+            if (FP) {
+              const uint32_t f = fp_of(wantw);                   // every timer word has an id
+              if (cnt_get(f)) { cnt_add(f, false); n_pend--; }
+            } else {
+              for (uint32_t q = 0; q < n_pend; q++) {
+                if (pend_load(mem, q) == wantw) {
+                  pend_store(mem, q, pend_load(mem, n_pend - 1));
+                  n_pend--; break;
+                }
               }
             }
           }
@@ -275,6 +386,11 @@ __global__ __launch_bounds__(K2_WAVES * 64) void k2_replay(const K2Args args) {
 #undef IN_MASK
 #undef TIMER_BIT
 #undef PEND_APPEND
+#undef PEND_APPEND_ID
 }
+
+__global__ __launch_bounds__(K2_WAVES * 64) void k2_replay(const K2Args args) { k2_replay_body<K2_SCAN>(args); }
+__global__ __launch_bounds__(K2_WAVES * 64) void k2_replay_fp(const K2Args args) { k2_replay_body<K2_FP_LDS>(args); }
+__global__ __launch_bounds__(K2_WAVES * 64) void k2_replay_fp_hbm(const K2Args args) { k2_replay_body<K2_FP_HBM>(args); }
 
 }  // namespace demi

@@ -399,6 +399,31 @@ int demi_collect_flagged_dev(demi_ctx* ctx, const demi_verdict* d_verdicts, uint
                              uint32_t flag_mask, demi_violation* d_out, uint32_t cap, unsigned long long* d_count,
                              void* hip_stream);
 
+/* ---------------------------------------------------------- multi-GPU (no reference counterpart)
+ * The reference evaluates one execution at a time in one JVM (Instrumenter.scala:1289-1296).  Here the candidates of
+ * each loop are split over the GPUs of a node, one process (and one demi_ctx) per GPU; what the ranks exchange is always
+ * an all-gather of fixed-size blocks: RCCL over xGMI when the communicator is created from an RCCL unique id (rank 0
+ * calls demi_comm_unique_id and hands the 128 bytes to the other ranks by whatever means the host has - a JVM would use
+ * its own control channel), or a host-supplied all-gather (demi_comm_create_host: any transport; blocks are staged
+ * through host memory).  Without a communicator every sharded entry point degenerates to its single-GPU form.       */
+typedef struct { char bytes[128]; } demi_comm_id;                 /* = ncclUniqueId */
+typedef int (*demi_allgather_fn)(void* user, const void* send, void* recv /* world * bytes */, size_t bytes);
+int demi_comm_unique_id(demi_comm_id* out);
+int demi_comm_create(demi_ctx* ctx, const demi_comm_id* id, int rank, int world);
+int demi_comm_create_host(demi_ctx* ctx, int rank, int world, demi_allgather_fn fn, void* user);
+int demi_comm_destroy(demi_ctx* ctx);
+int demi_comm_rank(const demi_ctx* ctx, int* rank, int* world);
+/* every rank's `bytes` at d_send -> world * bytes at d_recv (rank r's block at r * bytes), device pointers, on hip_stream */
+int demi_comm_allgather_dev(demi_ctx* ctx, const void* d_send, void* d_recv, size_t bytes, void* hip_stream);
+/* RandomScheduler executions [0, n_total) split by index range over the ranks (RunnerUtils.fuzz's executions are
+ * independent given per-execution seeds); every rank returns the merged found-violation set, sorted by schedule index
+ * (*n_violations counts all of them; at most `cap` per rank are listed).                                           */
+int demi_random_explore_sharded(demi_ctx* ctx, uint64_t seed_base, uint64_t n_total, const demi_limits* limits,
+                                demi_violation* out, uint32_t cap, uint64_t* n_violations);
+/* demi_replay_batch with the candidates in contiguous blocks over the ranks; every rank receives all n verdicts. */
+int demi_replay_batch_sharded(demi_ctx* ctx, const uint64_t* masks /* [n][4] */, uint64_t n, const demi_limits* limits,
+                              demi_verdict* out);
+
 /* ---------------------------------------------------------- measurement helpers (no reference counterpart)
  * Used by bench.py and the profiling scripts so that the figures beside the throughput are measured on the box that
  * prints them: the shader clock under load (s_memtime cycles per 100 MHz wall_clock64 tick) and the cycles one SIMD spends

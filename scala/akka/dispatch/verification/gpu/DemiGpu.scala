@@ -1,0 +1,43 @@
+package akka.dispatch.verification.gpu
+
+/** JNI declarations, 1:1 with jni/demi_jni.c (which is 1:1 with include/demi_gpu.h).  Array layouts are documented at the
+ *  top of demi_jni.c.  Every call returns 0 or a negative demi_status unless stated otherwise; lastError(h) has the text. */
+object DemiGpu {
+  System.loadLibrary("demi_jni")
+
+  // DEMI_V_* verdict flags (include/demi_gpu.h)
+  val V_VIOLATION = 0x1; val V_MAXMSG = 0x2; val V_PENDING_OVF = 0x4; val V_QUEUE_OVF = 0x8; val V_DIVERGED = 0x10
+  val V_TRACE_OVF = 0x20; val V_PAIRS_OVF = 0x40; val V_SELFMSG = 0x80
+  val MAX_PENDING = 128
+  val DPOR_ORDER_ROUNDS = 0; val DPOR_ORDER_REFERENCE = 1
+
+  @native def ctxCreate(device: Int): Long
+  @native def ctxDestroy(h: Long): Unit
+  @native def lastError(h: Long): String
+  @native def modelLoad(h: Long, nActors: Int, msgClass: Array[Byte], actorClass: Array[Byte], nClasses: Int,
+                        handlerStart: Array[Short], code: Array[Int], initState: Array[Long], inv: Array[Int]): Int
+  @native def modelSpecialize(h: Long, enable: Boolean): Int
+  @native def traceLoad(h: Long, events: Array[Byte]): Int
+  @native def randomExplore(h: Long, seedBase: Long, n: Long, limits: Array[Int], verdicts: Array[Long]): Int
+  @native def randomExploreFlagged(h: Long, seedBase: Long, n: Long, limits: Array[Int], flagMask: Int,
+                                   out: Array[Long], counts: Array[Long]): Int
+  /** returns the number of recorded events (12 bytes each in `recorded`), or a negative status */
+  @native def randomGetTrace(h: Long, seed: Long, limits: Array[Int], verdict: Array[Long], recorded: Array[Byte]): Int
+  @native def replayLoad(h: Long, externals: Array[Byte], recorded: Array[Byte]): Int
+  @native def replayBatch(h: Long, masks: Array[Long], limits: Array[Int], verdicts: Array[Long]): Int
+  @native def replayRemovalBatch(h: Long, masksOrNull: Array[Long], skip: Array[Int], limits: Array[Int], verdicts: Array[Long]): Int
+  @native def replayGetKept(h: Long, maskOrNull: Array[Long], skip: Int, limits: Array[Int], verdict: Array[Long], kept: Array[Byte]): Int
+  @native def dporLoad(h: Long, externals: Array[Byte]): Int
+  /** returns the length of the first violating trace (entries of 16 bytes in firstViolationTrace), or a negative status */
+  @native def dporExplore(h: Long, params: Array[Int], search: Array[Int], verdicts: Array[Long], prefixLen: Array[Int],
+                          rounds: Array[Int], firstViolationTrace: Array[Byte], stats: Array[Long]): Int
+  @native def commUniqueId(id128: Array[Byte]): Int
+  @native def commCreate(h: Long, id128: Array[Byte], rank: Int, world: Int): Int
+  @native def commDestroy(h: Long): Int
+  @native def randomExploreSharded(h: Long, seedBase: Long, nTotal: Long, limits: Array[Int], out: Array[Long], count: Array[Long]): Int
+
+  def check(h: Long, rc: Int): Int = { if (rc < 0) throw new RuntimeException("demi_gpu error " + rc + ": " + lastError(h)); rc }
+  def flags(verdicts: Array[Long], i: Int): Int = (verdicts(2 * i) & 0xFFFFFFFFL).toInt
+  def fingerprint(verdicts: Array[Long], i: Int): Int = (verdicts(2 * i) >>> 32).toInt
+  def hash(verdicts: Array[Long], i: Int): Long = verdicts(2 * i + 1)
+}

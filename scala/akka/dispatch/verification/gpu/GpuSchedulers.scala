@@ -1,0 +1,226 @@
+package akka.dispatch.verification.gpu
+
+import akka.dispatch.verification._
+import DemiGpu._
+
+/** RandomScheduler on the GPU: the same constructor shape as RandomScheduler (RandomScheduler.scala:41-44) plus the
+ *  lowering.  Execution i of explore() is one full execution with `new FullyRandom(seed + i)`, i.e. the shape of
+ *  RunnerUtils.fuzz, which builds a fresh scheduler and strategy per execution (RunnerUtils.scala:75-90).
+ *
+ *  NOT result-compatible with `new RandomScheduler(config, max_executions = N)` for N > 1: one RandomScheduler instance
+ *  never reseeds between its executions (RandomScheduler.scala:584, 649-651: execution k + 1 continues the generator where
+ *  execution k left it), a sequential dependence that cannot be evaluated in parallel.  The contract here is
+ *  "N independent executions with seeds seed, seed + 1, ...", and explore() returns the lowest violating index. */
+class GpuRandomScheduler(val schedulerConfig: SchedulerConfig, max_executions: Int = 1, invariant_check_interval: Int = 0,
+                         seed: Long = System.currentTimeMillis(), lowering: TableLowering, device: Int = 0,
+                         srcDstFifo: Boolean = false, pMax: Int = 64) extends TestOracle {
+  private val h = ctxCreate(device)
+  if (h == 0) throw new IllegalStateException("no MI355X visible: use RandomScheduler")
+  private var maxMessages = Int.MaxValue
+  private var modelLoaded = false
+  var stats: MinimizationStats = null
+  def getName = "GpuRandomScheduler"
+  def setMaxMessages(m: Int) { maxMessages = m }
+  def setInvariant(i: TestOracle.Invariant) {}        // the invariant descriptor travels with lowering.model
+
+  private def limits(lookingFor: Option[ViolationFingerprint], p: Int = pMax) = Array(
+    if (maxMessages == Int.MaxValue) 0 else maxMessages, math.max(0, invariant_check_interval), p,
+    if (lookingFor.isDefined) 1 else 0, lookingFor.map(lowering.fingerprintCode).getOrElse(0), 0, if (srcDstFifo) 1 else 0)
+
+  private def prepare(trace: Seq[ExternalEvent]) {
+    if (!modelLoaded) {
+      val m = lowering.model
+      check(h, modelLoad(h, m.nActors, m.msgClass, m.actorClass, m.nClasses, m.handlerStart, m.code, m.initState,
+                         Array(m.invKind, m.invFa, m.invVa, m.invFb, m.fpMatchMask)))
+      if (max_executions >= (1 << 16)) modelSpecialize(h, true)   // optional: a failure keeps the table interpreter
+      modelLoaded = true
+    }
+    check(h, traceLoad(h, FlatEvents.pack(trace, lowering)))
+  }
+
+  /** explore (RandomScheduler.scala:234-272): Some((trace, fingerprint)) of the lowest violating execution.  Executions
+   *  that were aborted on an engine capacity are re-run alone with the largest pending set before a higher index is
+   *  believed; if one still does not fit, the JVM scheduler has to decide it (UnsupportedOnGpu). */
+  def explore(trace: Seq[ExternalEvent], lookingFor: Option[ViolationFingerprint] = None)
+      : Option[(EventTrace, ViolationFingerprint)] = {
+    prepare(trace)
+    if (stats != null) (1 to max_executions).foreach(_ => stats.increment_replays())
+    val OVF = V_PENDING_OVF | V_QUEUE_OVF
+    var start = 0L
+    while (start < max_executions) {
+      val out = new Array[Long](2 * 65536); val counts = new Array[Long](2)
+      check(h, randomExploreFlagged(h, seed + start, max_executions - start, limits(lookingFor), V_VIOLATION | OVF, out, counts))
+      if (counts(0) == 0) return None
+      // (index, flags) in index order; a truncated list is an arbitrary subset: then only the lowest index is certain
+      val cand = if (counts(0) <= 65536) (0 until counts(0).toInt).map(i => (out(2 * i), ((out(2 * i + 1) >>> 32) & 0xFF).toInt))
+                 else Seq((counts(1), -1))
+      var next = max_executions.toLong
+      for ((idx, fl) <- cand) {
+        var lim = limits(lookingFor)
+        if (fl < 0 || (fl & OVF) != 0) lim = limits(lookingFor, MAX_PENDING)
+        val v = new Array[Long](2); val rec = new Array[Byte](12 * 16384)
+        val n = check(h, randomGetTrace(h, seed + start + idx, lim, v, rec))
+        val f = flags(v, 0)
+        if ((f & OVF) != 0) throw new UnsupportedOnGpu("schedule " + (start + idx) + " exceeds the engine's capacities")
+        if ((f & V_VIOLATION) != 0) {
+          val used = trace.take((f >> 8) & 0xFF)        // checkIfBugFound prunes the externals never injected (:160-163)
+          return Some((FlatEvents.toEventTrace(rec, n, used, lowering), lowering.fingerprintOf(fingerprint(v, 0))))
+        }
+        if (fl < 0) next = start + idx + 1
+      }
+      if (counts(0) <= 65536) return None
+      start = next
+    }
+    None
+  }
+
+  /** TestOracle.test (RandomScheduler.scala:597-612). */
+  def test(events: Seq[ExternalEvent], fp: ViolationFingerprint, _stats: MinimizationStats,
+           init: Option[() => Any] = None): Option[EventTrace] = {
+    stats = _stats
+    explore(events, Some(fp)).map(_._1)
+  }
+  def shutdown() { ctxDestroy(h) }
+}
+
+/** STSScheduler(schedulerConfig, original_trace, allowPeek = false) as DDMin's oracle (STSScheduler.scala:199-310). */
+class GpuSTSScheduler(val schedulerConfig: SchedulerConfig, original_trace: EventTrace, lowering: TableLowering,
+                      device: Int = 0, pMax: Int = 64) extends TestOracle {
+  private val h = ctxCreate(device)
+  if (h == 0) throw new IllegalStateException("no MI355X visible: use STSScheduler")
+  private val externals = original_trace.original_externals
+  private val indexOf = externals.zipWithIndex.map { case (e, i) => e._id -> i }.toMap      // ExternalEvent._id (ExternalEvents.scala:14-31)
+  private val recorded = FlatEvents.packRecorded(original_trace, lowering)
+  locally {
+    val m = lowering.model
+    check(h, modelLoad(h, m.nActors, m.msgClass, m.actorClass, m.nClasses, m.handlerStart, m.code, m.initState,
+                       Array(m.invKind, m.invFa, m.invVa, m.invFb, m.fpMatchMask)))
+    check(h, replayLoad(h, FlatEvents.pack(externals, lowering), recorded))
+  }
+  def getName = "GpuSTSSchedNoPeek"
+  def setInvariant(i: TestOracle.Invariant) {}
+  private def limits(fp: ViolationFingerprint, p: Int = pMax) = Array(0, 0, p, 1, lowering.fingerprintCode(fp), 0, 0)
+  private def mask(subseq: Seq[ExternalEvent]): Array[Long] = {
+    val m = new Array[Long](4)
+    for (e <- subseq) { val i = indexOf(e._id); m(i >> 6) |= 1L << (i & 63) }
+    m
+  }
+
+  /** one launch for a whole DDMin frontier: element i is Some(executed trace) iff subseqs(i) reproduces the violation */
+  def testBatch(subseqs: Seq[Seq[ExternalEvent]], fp: ViolationFingerprint, stats: MinimizationStats): Seq[Option[EventTrace]] = {
+    if (stats != null) subseqs.foreach(_ => stats.increment_replays())
+    val masks = subseqs.flatMap(mask).toArray
+    val v = new Array[Long](2 * subseqs.size)
+    check(h, replayBatch(h, masks, limits(fp), v))
+    val OVF = V_PENDING_OVF | V_QUEUE_OVF
+    subseqs.indices.map { i =>
+      var f = flags(v, i)
+      if ((f & OVF) != 0) {                                 // aborted on a capacity: once more with the largest pending set
+        val v1 = new Array[Long](2)
+        check(h, replayBatch(h, mask(subseqs(i)), limits(fp, MAX_PENDING), v1))
+        f = flags(v1, 0)
+        if ((f & OVF) != 0) throw new UnsupportedOnGpu("a candidate replay exceeds the engine's capacities")
+      }
+      if ((f & V_VIOLATION) != 0) Some(executed(subseqs(i), fp)) else None
+    }
+  }
+
+  /** the EventTrace test() returns on success (:286-292): the recorded events that took effect in the replay */
+  private def executed(subseq: Seq[ExternalEvent], fp: ViolationFingerprint): EventTrace = {
+    val v = new Array[Long](2); val kept = new Array[Byte](original_trace.events.size)
+    check(h, replayGetKept(h, mask(subseq), -1, limits(fp, MAX_PENDING), v, kept))
+    val t = new EventTrace(subseq)
+    for ((e, k) <- original_trace.events.zip(kept) if k != 0) t += e
+    t
+  }
+
+  def test(subseq: Seq[ExternalEvent], fp: ViolationFingerprint, stats: MinimizationStats,
+           init: Option[() => Any] = None): Option[EventTrace] = testBatch(Seq(subseq), fp, stats).head
+  def shutdown() { ctxDestroy(h) }
+}
+
+/** RunnerUtils.testWithStsSched (RunnerUtils.scala:913-943) for STSSchedMinimizer: the candidates are "the last failing
+ *  trace minus the delivery at index skip(i)" (OneAtATimeRemoval.scala:57-124). */
+class GpuStsRemovalOracle(schedulerConfig: SchedulerConfig, mcs: Seq[ExternalEvent], lowering: TableLowering,
+                          device: Int = 0, pMax: Int = 64) {
+  private val h = ctxCreate(device)
+  private var loaded: EventTrace = null
+  private var modelLoaded = false
+  private def limits(fp: ViolationFingerprint, p: Int = pMax) = Array(0, 0, p, 1, lowering.fingerprintCode(fp), 0, 0)
+  private def load(trace: EventTrace) {
+    if (!modelLoaded) {
+      val m = lowering.model
+      check(h, modelLoad(h, m.nActors, m.msgClass, m.actorClass, m.nClasses, m.handlerStart, m.code, m.initState,
+                         Array(m.invKind, m.invFa, m.invVa, m.invFb, m.fpMatchMask)))
+      modelLoaded = true
+    }
+    if (!(loaded eq trace)) { check(h, replayLoad(h, FlatEvents.pack(mcs, lowering), FlatEvents.packRecorded(trace, lowering))); loaded = trace }
+  }
+  /** one launch for the whole proposal sequence of a RemovalStrategy (each proposal assumes the previous one failed) */
+  def testRemovals(trace: EventTrace, skip: Array[Int], fp: ViolationFingerprint): Array[Boolean] = {
+    load(trace)
+    val out = new Array[Long](2 * skip.length)
+    check(h, replayRemovalBatch(h, null, skip, limits(fp, MAX_PENDING), out))
+    Array.tabulate(skip.length) { i =>
+      if ((flags(out, i) & (V_PENDING_OVF | V_QUEUE_OVF)) != 0) throw new UnsupportedOnGpu("a removal candidate exceeds the engine's capacities")
+      (flags(out, i) & V_VIOLATION) != 0
+    }
+  }
+  /** Some(executed trace) iff the candidate still triggers the violation */
+  def executed(trace: EventTrace, skip: Int, fp: ViolationFingerprint): Option[EventTrace] = {
+    load(trace)
+    val v = new Array[Long](2); val kept = new Array[Byte](trace.events.size)
+    check(h, replayGetKept(h, null, skip, limits(fp, MAX_PENDING), v, kept))
+    if ((flags(v, 0) & V_VIOLATION) == 0) None
+    else { val t = new EventTrace(trace.original_externals); for ((e, k) <- trace.events.zip(kept) if k != 0) t += e; Some(t) }
+  }
+  def shutdown() { ctxDestroy(h) }
+}
+
+/** RunnerUtils.boundedDPOR (RunnerUtils.scala:881-911) / DPORwHeuristics.test over the whole exploration in the library:
+ *  backtrack queue, ExploredTacker and getNext() run natively, the explored set and the traces stay on the GPU.
+ *  referenceOrder = true commits the interleavings in DPORwHeuristics' own one-at-a-time order (same sequence, same
+ *  "first violation found"); false explores in rounds of `batch` (a slightly different explored set, much faster). */
+class GpuDPOR(val schedulerConfig: SchedulerConfig, lowering: TableLowering, depthBound: Int = 0, batch: Int = 4096,
+              stopIfViolationFound: Boolean = true, referenceOrder: Boolean = true, maxInterleavings: Int = 1 << 17,
+              device: Int = 0) extends TestOracle {
+  private val h = ctxCreate(device)
+  if (h == 0) throw new IllegalStateException("no MI355X visible: use DPORwHeuristics")
+  def getName = "GpuDPORwHeuristics"
+  def setInvariant(i: TestOracle.Invariant) {}
+  def test(events: Seq[ExternalEvent], fp: ViolationFingerprint, stats: MinimizationStats,
+           init: Option[() => Any] = None): Option[EventTrace] = {
+    val m = lowering.model
+    check(h, modelLoad(h, m.nActors, m.msgClass, m.actorClass, m.nClasses, m.handlerStart, m.code, m.initState,
+                       Array(m.invKind, m.invFa, m.invVa, m.invFb, m.fpMatchMask)))
+    modelSpecialize(h, true)
+    check(h, dporLoad(h, FlatEvents.pack(events, lowering)))      // Start / Send / WaitQuiescence only (DPORwHeuristics.scala:692-710)
+    val params = Array(depthBound, 0, 1, lowering.fingerprintCode(fp), 64, 4096, 0)
+    val search = Array(batch, maxInterleavings, if (stopIfViolationFound) 1 else 0, 1,
+                       if (referenceOrder) DPOR_ORDER_REFERENCE else DPOR_ORDER_ROUNDS, 0)
+    val verdicts = new Array[Long](2 * maxInterleavings); val plen = new Array[Int](maxInterleavings)
+    val rounds = new Array[Int](maxInterleavings); val vt = new Array[Byte](16 * 256); val st = new Array[Long](11)
+    val vlen = check(h, dporExplore(h, params, search, verdicts, plen, rounds, vt, st))
+    if (stats != null) (0L until st(0)).foreach(_ => stats.increment_replays())
+    if (st(2) == 0) None
+    else Some(GpuDPOR.traceOf(vt, vlen, events, lowering))
+  }
+  def shutdown() { ctxDestroy(h) }
+}
+
+object GpuDPOR {
+  /** demi_dpor_trace_entry[] (key 8, word 4, parent, qperiod, depth, kind) -> the MsgEvents of the violating interleaving */
+  def traceOf(vt: Array[Byte], n: Int, externals: Seq[ExternalEvent], lo: TableLowering): EventTrace = {
+    val t = new EventTrace(externals)
+    for (i <- 0 until n) {
+      val o = 16 * i
+      val kind = vt(o + 15) & 0xFF
+      if (kind == 1) {
+        val w = (vt(o + 8) & 0xFF) | ((vt(o + 9) & 0xFF) << 8) | ((vt(o + 10) & 0xFF) << 16) | ((vt(o + 11) & 0xFF) << 24)
+        val (ty, dst, src, p0, p1) = (w & 31, (w >> 5) & 7, (w >> 8) & 15, (w >> 16) & 255, (w >>> 24) & 255)
+        t += MsgEvent(if (src == FlatEvents.DEADLETTERS) "deadLetters" else lo.actorName(src), lo.actorName(dst), lo.decode(ty, p0, p1))
+      } else if (kind == 2) t += Quiescence
+    }
+    t
+  }
+}

@@ -1,0 +1,107 @@
+package akka.dispatch.verification.gpu
+
+import akka.dispatch.verification._
+
+/** The flat arrays of demi_model (include/demi_gpu.h): the application's actors as a transition table. */
+case class FlatModel(nActors: Int, msgClass: Array[Byte], actorClass: Array[Byte], nClasses: Int,
+                     handlerStart: Array[Short], code: Array[Int], initState: Array[Long],
+                     invKind: Int, invFa: Int, invVa: Int, invFb: Int, fpMatchMask: Int = 0xFFFFFFFF)
+
+/** What an application supplies next to its MessageFingerprinter (MessageFingerprints.scala:14-32): how its actors,
+ *  messages and invariant lower to the table.  The row vocabulary is DEMI_OP_* in include/demi_gpu.h; demi_amd/model.py
+ *  (raft_model) is a complete example in the Python mirror.  Closures cannot cross the boundary (Props, message
+ *  constructors, Invariant: SURVEY 8b), which is exactly what this trait replaces. */
+trait TableLowering {
+  def model: FlatModel
+  def actorId(name: String): Int                      // 0 .. nActors - 1
+  def actorName(id: Int): String
+  def encode(msg: Any): (Int, Int, Int)               // (msg_type, p0, p1) = the message's fingerprint
+  def decode(msgType: Int, p0: Int, p1: Int): Any     // a message equal to the original under the app's fingerprinter
+  def fingerprintCode(fp: ViolationFingerprint): Int  // 32-bit code of demi_verdict.fingerprint
+  def fingerprintOf(code: Int): ViolationFingerprint
+}
+
+class UnsupportedOnGpu(what: String) extends RuntimeException(what + " cannot run on the GPU path: use the JVM scheduler")
+
+/** ExternalEvent <-> demi_ext_event (8 bytes) and demi_rec_event (12 bytes) <-> the EventTrace records. */
+object FlatEvents {
+  val EV_START = 0; val EV_KILL = 1; val EV_SEND = 2; val EV_PARTITION = 3; val EV_UNPARTITION = 4; val EV_WAIT_QUIESCENCE = 5
+  val REC_SPAWN = 0; val REC_KILL = 1; val REC_PARTITION = 2; val REC_UNPARTITION = 3; val REC_BEGIN_WAIT_QUIESCENCE = 4
+  val REC_QUIESCENCE = 5; val REC_MSG_SEND = 6; val REC_MSG_EVENT = 7
+  val DEADLETTERS = 15
+
+  def pack(trace: Seq[ExternalEvent], lo: TableLowering): Array[Byte] = {
+    val out = new Array[Byte](8 * trace.size)
+    for ((ev, i) <- trace.zipWithIndex) {
+      val (kind, a, b, t, p0, p1) = ev match {
+        case Start(_, name) => (EV_START, lo.actorId(name), 0, 0, 0, 0)
+        case Kill(name) => (EV_KILL, lo.actorId(name), 0, 0, 0, 0)
+        case Send(name, ctor) => val (t, p0, p1) = lo.encode(ctor()); (EV_SEND, lo.actorId(name), 0, t, p0, p1)
+        case Partition(x, y) => (EV_PARTITION, lo.actorId(x), lo.actorId(y), 0, 0, 0)
+        case UnPartition(x, y) => (EV_UNPARTITION, lo.actorId(x), lo.actorId(y), 0, 0, 0)
+        case WaitQuiescence() => (EV_WAIT_QUIESCENCE, 0, 0, 0, 0, 0)
+        case other => throw new UnsupportedOnGpu(other.getClass.getSimpleName)   // WaitCondition, CodeBlock, HardKill
+      }
+      val o = 8 * i
+      out(o) = kind.toByte; out(o + 1) = a.toByte; out(o + 2) = b.toByte; out(o + 3) = t.toByte
+      out(o + 4) = p0.toByte; out(o + 5) = p1.toByte
+    }
+    out
+  }
+
+  private def name(id: Int, lo: TableLowering) = if (id == DEADLETTERS) "deadLetters" else lo.actorName(id)
+
+  /** demi_rec_event[] -> the records an EventTrace holds (EventTrace.scala:16-18, AuxilaryTypes.scala:34-69). */
+  def toEventTrace(rec: Array[Byte], nRec: Int, externals: Seq[ExternalEvent], lo: TableLowering): EventTrace = {
+    val trace = new EventTrace(externals)
+    for (i <- 0 until nRec) {
+      val o = 12 * i
+      def u(k: Int) = rec(o + k) & 0xFF
+      val id = (u(8)) | (u(9) << 8) | (u(10) << 16) | (u(11) << 24)
+      u(0) match {
+        case REC_SPAWN => externals(u(7)) match { case Start(ctor, n) => trace += SpawnEvent("", ctor(), n, null) }
+        case REC_KILL => trace += KillEvent(lo.actorName(u(2)))
+        case REC_PARTITION => trace += PartitionEvent((lo.actorName(u(1)), lo.actorName(u(2))))
+        case REC_UNPARTITION => trace += UnPartitionEvent((lo.actorName(u(1)), lo.actorName(u(2))))
+        case REC_BEGIN_WAIT_QUIESCENCE => trace += BeginWaitQuiescence
+        case REC_QUIESCENCE => trace += Quiescence
+        case REC_MSG_SEND => trace += UniqueMsgSend(MsgSend(name(u(1), lo), lo.actorName(u(2)), lo.decode(u(3), u(4), u(5))), id)
+        case REC_MSG_EVENT => trace += UniqueMsgEvent(MsgEvent(name(u(1), lo), lo.actorName(u(2)), lo.decode(u(3), u(4), u(5))), id)
+      }
+    }
+    trace
+  }
+
+  /** EventTrace -> demi_rec_event[] (for replayLoad): the inverse of toEventTrace for the records the GPU path produces. */
+  def packRecorded(trace: EventTrace, lo: TableLowering): Array[Byte] = {
+    val evs = trace.events.toSeq
+    val out = new Array[Byte](12 * evs.size)
+    val sends = trace.original_externals.zipWithIndex.collect { case (Send(_, _), i) => i }.iterator
+    val spawns = scala.collection.mutable.Map[String, Int]() ++
+      trace.original_externals.zipWithIndex.collect { case (Start(_, n), i) => n -> i }
+    def put(i: Int, kind: Int, snd: Int, rcv: Int, t: Int, p0: Int, p1: Int, fl: Int, ext: Int, id: Int) {
+      val o = 12 * i
+      out(o) = kind.toByte; out(o + 1) = snd.toByte; out(o + 2) = rcv.toByte; out(o + 3) = t.toByte; out(o + 4) = p0.toByte
+      out(o + 5) = p1.toByte; out(o + 6) = fl.toByte; out(o + 7) = ext.toByte
+      out(o + 8) = id.toByte; out(o + 9) = (id >> 8).toByte; out(o + 10) = (id >> 16).toByte; out(o + 11) = (id >> 24).toByte
+    }
+    def actor(n: String) = if (n == "deadLetters" || n == "Timer") DEADLETTERS else lo.actorId(n)
+    for ((e, i) <- evs.zipWithIndex) e match {
+      case SpawnEvent(_, _, n, _) => put(i, REC_SPAWN, 0, lo.actorId(n), 0, 0, 0, 0, spawns.getOrElse(n, 255), 0)
+      case KillEvent(n) => put(i, REC_KILL, 0, lo.actorId(n), 0, 0, 0, 0, 255, 0)
+      case PartitionEvent((a, b)) => put(i, REC_PARTITION, lo.actorId(a), lo.actorId(b), 0, 0, 0, 0, 255, 0)
+      case UnPartitionEvent((a, b)) => put(i, REC_UNPARTITION, lo.actorId(a), lo.actorId(b), 0, 0, 0, 0, 255, 0)
+      case BeginWaitQuiescence => put(i, REC_BEGIN_WAIT_QUIESCENCE, 0, 0, 0, 0, 0, 0, 255, 0)
+      case Quiescence => put(i, REC_QUIESCENCE, 0, 0, 0, 0, 0, 0, 255, 0)
+      case UniqueMsgSend(MsgSend(s, r, m), id) =>
+        val (t, p0, p1) = lo.encode(m)
+        val external = EventTypes.isExternal(e)       // the k-th external MsgSend belongs to the k-th Send (EventTrace.scala:382-452)
+        put(i, REC_MSG_SEND, actor(s), lo.actorId(r), t, p0, p1, if (external) 1 else 0, if (external) sends.next() else 255, id)
+      case UniqueMsgEvent(MsgEvent(s, r, m), id) =>
+        val (t, p0, p1) = lo.encode(m)
+        put(i, REC_MSG_EVENT, actor(s), lo.actorId(r), t, p0, p1, 0, 255, id)
+      case other => throw new UnsupportedOnGpu(other.getClass.getSimpleName)
+    }
+    out
+  }
+}

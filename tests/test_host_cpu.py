@@ -155,3 +155,35 @@ def test_experiment_dir_roundtrip(tmp_path, oracle):
     assert m2.to_json() == model.to_json() and (t2.events == rec).all() and (t2.original_externals == tr.original_externals).all()
     assert fp2.code == 0x1000103 and meta["seed"] == SEED_BASE + 1 and list(mcs) == [0, 2, 5]
     assert os.path.getsize(str(tmp_path / "e" / "event_trace.bin")) == 12 * len(rec)
+
+
+def test_jni_shim_compiles_against_the_stub_header_and_covers_the_adapter():
+    """jni/demi_jni.c must stay in step with include/demi_gpu.h (no JDK here: a compile-only <jni.h> stands in), and every
+    @native method the Scala adapter declares has its Java_..._DemiGpu_<name> function."""
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "jni"), "check"])
+    shim = open(os.path.join(root, "jni", "demi_jni.c")).read()
+    scala = open(os.path.join(root, "scala", "akka", "dispatch", "verification", "gpu", "DemiGpu.scala")).read()
+    natives = set(re.findall(r"@native def (\w+)\(", scala))
+    shims = set(re.findall(r"FN\((\w+)\)\(JNIEnv", shim))
+    assert natives and natives == shims, (natives - shims, shims - natives)
+
+
+def test_verdict_dump_for_the_deferred_jvm_check(tmp_path):
+    """tools/dump_verdicts.py writes the file set a JVM box diffs against RandomScheduler + FullyRandom(seed) (SURVEY 8c ii)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "dump"
+    subprocess.check_call([sys.executable, os.path.join(root, "tools", "dump_verdicts.py"), str(out), "--n", "128", "--traces", "3",
+                           "--source", "oracle"])
+    meta = json.load(open(out / "meta.json"))
+    v = np.fromfile(out / "verdicts.bin", dtype=T.VERDICT_DTYPE)
+    seeds = np.fromfile(out / "seeds.bin", dtype=np.uint64)
+    assert len(v) == len(seeds) == 128 and meta["violations"] == int((v["flags"] & T.V_VIOLATION != 0).sum())
+    for k in meta["recorded"]:
+        rec = np.fromfile(out / ("deliveries_%d.bin" % k), dtype=T.REC_EVENT_DTYPE)
+        assert int((rec["kind"] == T.REC_MSG_EVENT).sum()) == T.verdict_deliveries(int(v["flags"][k]))
