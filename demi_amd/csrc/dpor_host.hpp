@@ -616,7 +616,11 @@ int explore_reference_order(Run&& run, Fetch&& fetch, uint32_t max_pairs, const 
 // that can still be dequeued live, and the pairs that became explored while points flipping into them were queued.
 // What is left here is the queue itself: 256 FIFO buckets by branch index and getNext()'s skip of explored pairs.
 //   dev.round(items, n, round, base_id, verdicts, points, kills)   one launch; interleaving i gets arena id base_id + i
+//   dev.ids_used(n)                                                arena ids a round of n items consumes (n; with several
+//                                                                  GPUs the ranks' equal-sized blocks: world * ceil(n / world))
 //   dev.fetch_trace(id, out, &len)                                 one finished trace (the first violation's)
+// With several GPUs every rank runs this same loop on identical queues (SPMD): dev.round() returns the same verdicts,
+// points and kills on every rank, whatever part of the round and of the explored-pair table that rank worked on.
 struct PairKeyHash {
   size_t operator()(const std::pair<uint64_t, uint64_t>& k) const {
     return (size_t)((k.first * 0x9E3779B97F4A7C15ULL) ^ (k.second * 0xC2B2AE3D27D4EB4FULL) ^ (k.first >> 29));
@@ -665,7 +669,7 @@ int explore_rounds_resident(Dev&& dev, const demi_dpor_search* srch, demi_verdic
         if (stats->first_violation == ~0ull) { stats->first_violation = idx; first_id = base_id + i; }
       }
     }
-    base_id += n;
+    base_id += dev.ids_used(n);
     for (const demi::DporKill& k : kills) dead.insert({k.a, k.b});
     std::sort(pts.begin(), pts.end(), [](const demi::DporPoint& x, const demi::DporPoint& y) { return x.ordinal < y.ordinal; });
     for (const demi::DporPoint& p : pts) {        // creation order: the round's interleavings in pop order, then pair order

@@ -23,4 +23,25 @@ struct DporPoint {           // a backtrack point that may still be dequeued liv
 
 struct DporKill { unsigned long long a, b; };   // this pair is explored now: queued points flipping into it are dead
 
+// One racing pair as it travels between GPUs (multi-GPU rounds): everything insert / decide need, so that the rank that
+// owns the pair's table entries does not need the trace it came from.  32 bytes.
+struct DporPairRec {
+  unsigned long long ke, kl;   // node keys of the earlier / later event
+  uint32_t ordinal;            // creation order within the round: (item index in the round) * max_pairs + pair index
+  uint32_t src;                // arena id of the interleaving that found it
+  uint8_t branch, later, earlier, pad;
+  uint32_t pad2;
+};
+
+// which rank owns the table entries of the unordered pair {a, b}: (a, b) and (b, a) live together
+#if defined(__HIPCC__) || defined(__HIPCC_RTC__)
+__host__ __device__
+#endif
+inline uint32_t dpor_pair_owner(unsigned long long a, unsigned long long b, uint32_t world) {
+  const unsigned long long lo = a < b ? a : b, hi = a < b ? b : a;
+  unsigned long long h = (lo * 0x9E3779B97F4A7C15ULL) ^ (hi * 0xC2B2AE3D27D4EB4FULL);
+  h ^= h >> 31;
+  return (uint32_t)(h % world);
+}
+
 }  // namespace demi

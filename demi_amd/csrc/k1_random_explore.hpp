@@ -665,7 +665,7 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
       if (flags & DEMI_OVF_ANY) {
         v.x = flags & DEMI_OVF_ANY; v.y = 0; v.z = 0; v.w = 0;
       } else {
-        v.x = (flags & 0xFF) | (viol ? DEMI_V_VIOLATION : 0u) | ((tidx & 0xFF) << 8) | ((count & 0xFFFF) << 16);
+        v.x = (flags & 0xFF) | (viol ? DEMI_V_VIOLATION : 0u) | ((tidx & 0xFF) << 8) | ((count < 0xFFFFu ? count : 0xFFFFu) << 16);
         v.y = viol; v.z = (uint32_t)hash; v.w = (uint32_t)(hash >> 32);
       }
       *reinterpret_cast<uint4*>(&args.out[sched]) = v;

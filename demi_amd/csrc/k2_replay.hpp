@@ -376,7 +376,7 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
       if (flags & DEMI_OVF_ANY) {
         v.x = flags & DEMI_OVF_ANY; v.y = 0; v.z = 0; v.w = 0;
       } else {
-        v.x = (viol ? DEMI_V_VIOLATION : 0u) | (ignored ? DEMI_V_DIVERGED : 0u) | ((count & 0xFFFF) << 16);
+        v.x = (viol ? DEMI_V_VIOLATION : 0u) | (ignored ? DEMI_V_DIVERGED : 0u) | ((count < 0xFFFFu ? count : 0xFFFFu) << 16);
         v.y = viol; v.z = (uint32_t)hash; v.w = (uint32_t)(hash >> 32);
       }
       *reinterpret_cast<uint4*>(&args.out[sched]) = v;

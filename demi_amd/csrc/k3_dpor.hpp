@@ -447,7 +447,7 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
         args.trace_len[sched] = 0; args.n_pairs[sched] = 0;
       } else {
         v.x = (viol ? DEMI_V_VIOLATION : 0u) | (pairs_ovf ? DEMI_V_PAIRS_OVF : 0u) |
-              ((count > max_messages) ? DEMI_V_MAXMSG : 0u) | ((deliveries & 0xFFFF) << 16);
+              ((count > max_messages) ? DEMI_V_MAXMSG : 0u) | ((deliveries < 0xFFFFu ? deliveries : 0xFFFFu) << 16);
         v.y = viol; v.z = (uint32_t)hash; v.w = (uint32_t)(hash >> 32);
         args.trace_len[sched] = n_trace; args.n_pairs[sched] = np;
       }

@@ -75,7 +75,14 @@ struct K3PairArgs {
   uint32_t* pair_slot_of;              // [n][max_pairs] slot of the flipped pair (insert -> decide)
   DporPoint* points; uint32_t points_cap;
   DporKill* kills; uint32_t kills_cap;
-  unsigned long long* counters;        // [0] points, [1] kills, [2] table-full errors, [3] table entries
+  unsigned long long* counters;        // [0] points, [1] kills, [2] table-full errors, [3] pair records
+  // multi-GPU rounds: every rank runs a contiguous block of the round's items and owns the table entries of the pairs
+  // with dpor_pair_owner(...) == rank; racing pairs travel as records (all-gathered), see k3_pairs_records
+  uint32_t rank, world;
+  uint32_t item_base;                  // index in the round of this rank's first item (ordinals are global)
+  DporPairRec* recs;                   // k3_pairs_records out: [recs_cap]; insert_rec / decide_rec in: [world][recs_stride]
+  uint32_t recs_cap, recs_stride;
+  const unsigned long long* rec_counts;   // [world] valid records per rank segment
 };
 
 __device__ __forceinline__ unsigned long long cand_pack(uint32_t round, uint32_t branch, unsigned long long ordinal) {
@@ -90,6 +97,7 @@ __global__ __launch_bounds__(256) void k3_pairs_mark(const K3PairArgs a) {
   const DporItem it = a.items[i];
   if (it.src == 0xFFFFFFFFu) return;
   const demi_dpor_trace_entry* T = a.arena + (size_t)it.src * DEMI_DPOR_MAX_TRACE;
+  if (a.world > 1 && dpor_pair_owner(T[it.later].key, T[it.earlier].key, a.world) != a.rank) return;   // another rank's entry
   const uint32_t s = pair_slot(a.table, a.mask, T[it.later].key, T[it.earlier].key);
   if (s == 0xFFFFFFFFu) { atomicAdd(&a.counters[2], 1ull); return; }
   atomicOr(&a.table[s].state, PE_EXPLORED);
@@ -139,6 +147,72 @@ __global__ __launch_bounds__(256) void k3_pairs_decide(const K3PairArgs a) {
       DporPoint o;
       o.flip_a = T[p.later].key; o.flip_b = T[p.earlier].key; o.ordinal = ord; o.src = a.base_id + it;
       o.branch = p.branch; o.later = p.later; o.earlier = p.earlier; o.pad = 0; o.pad2 = 0;
+      a.points[q] = o;
+    }
+  }
+}
+
+}  // namespace demi
+
+namespace demi {
+
+// ------------------------------------------------------------------ multi-GPU rounds: racing pairs as records
+// this rank's racing pairs of the round, compacted (any order: the ordinal travels with the record)
+__global__ __launch_bounds__(256) void k3_pairs_records(const K3PairArgs a) {
+  const uint32_t it = blockIdx.x;
+  const demi_dpor_trace_entry* T = a.arena + (size_t)(a.base_id + it) * DEMI_DPOR_MAX_TRACE;
+  const demi_dpor_pair* P = a.pairs + (size_t)it * a.max_pairs;
+  const uint32_t np = a.n_pairs[it];
+  for (uint32_t k = threadIdx.x; k < np; k += blockDim.x) {
+    const demi_dpor_pair p = P[k];
+    const unsigned long long q = atomicAdd(&a.counters[3], 1ull);
+    if (q >= a.recs_cap) continue;
+    DporPairRec r;
+    r.ke = T[p.earlier].key; r.kl = T[p.later].key;
+    r.ordinal = (a.item_base + it) * a.max_pairs + k; r.src = a.base_id + it;
+    r.branch = p.branch; r.later = p.later; r.earlier = p.earlier; r.pad = 0; r.pad2 = 0;
+    a.recs[q] = r;
+  }
+}
+
+// insert / decide over the gathered records [world][recs_stride], each rank only for the pairs it owns
+__global__ __launch_bounds__(256) void k3_pairs_insert_rec(const K3PairArgs a) {
+  const uint64_t total = (uint64_t)a.world * a.recs_stride;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+    a.pair_slot_of[i] = 0xFFFFFFFFu;
+    if ((i % a.recs_stride) >= a.rec_counts[i / a.recs_stride]) continue;
+    const DporPairRec r = a.recs[i];
+    if (dpor_pair_owner(r.ke, r.kl, a.world) != a.rank) continue;
+    const uint32_t s1 = pair_slot(a.table, a.mask, r.ke, r.kl);
+    const uint32_t s2 = pair_slot(a.table, a.mask, r.kl, r.ke);
+    if (s1 == 0xFFFFFFFFu || s2 == 0xFFFFFFFFu) { atomicAdd(&a.counters[2], 1ull); continue; }
+    a.pair_slot_of[i] = s2;
+    const uint32_t old = atomicOr(&a.table[s1].state, PE_EXPLORED);
+    if (!(old & PE_EXPLORED) && (old & PE_QMASK)) {
+      const unsigned long long q = atomicAdd(&a.counters[1], 1ull);
+      if (q < a.kills_cap) { DporKill kk; kk.a = r.ke; kk.b = r.kl; a.kills[q] = kk; }
+    }
+    atomicMax(&a.table[s2].cand, cand_pack(a.round, r.branch, r.ordinal));
+  }
+}
+
+__global__ __launch_bounds__(256) void k3_pairs_decide_rec(const K3PairArgs a) {
+  const uint64_t total = (uint64_t)a.world * a.recs_stride;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t s2 = a.pair_slot_of[i];
+    if (s2 == 0xFFFFFFFFu) continue;
+    const DporPairRec r = a.recs[i];
+    PairEntry* e = a.table + s2;
+    const uint32_t st = e->state;
+    if (st & PE_EXPLORED) continue;
+    if (e->cand != cand_pack(a.round, r.branch, r.ordinal)) continue;
+    if ((st & PE_QMASK) > r.branch) continue;
+    e->state = (st & ~PE_QMASK) | ((uint32_t)r.branch + 1);
+    const unsigned long long q = atomicAdd(&a.counters[0], 1ull);
+    if (q < a.points_cap) {
+      DporPoint o;
+      o.flip_a = r.kl; o.flip_b = r.ke; o.ordinal = r.ordinal; o.src = r.src;
+      o.branch = r.branch; o.later = r.later; o.earlier = r.earlier; o.pad = 0; o.pad2 = 0;
       a.points[q] = o;
     }
   }

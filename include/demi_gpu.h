@@ -155,7 +155,8 @@ typedef enum { DEMI_STRATEGY_FULLY_RANDOM = 0, DEMI_STRATEGY_SRC_DST_FIFO = 1 } 
 #define DEMI_V_QUEUE_OVF     0x8u  /* timer queues / DEMI_FX_CAP exceeded: aborted, verdict invalid       */
 #define DEMI_V_DIVERGED      0x10u /* replay kernels: an expected delivery was absent (ignored)       */
 typedef struct {
-  uint32_t flags;        /* bits 0..7 DEMI_V_*; bits 8..15 traceIdx at the end; bits 16..31 deliveries */
+  uint32_t flags;        /* bits 0..7 DEMI_V_*; bits 8..15 traceIdx at the end; bits 16..31 deliveries, saturating at 65535
+                            (max_messages = 0 is unbounded: a longer execution reports 65535, never a wrapped count) */
   uint32_t fingerprint;  /* ViolationFingerprint code, 0 if none */
   uint64_t hash;         /* FNV-1a over every delivered message word, then every actor's final state */
 } demi_verdict;          /* 16 bytes */

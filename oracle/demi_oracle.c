@@ -661,7 +661,7 @@ static int random_execute_in(exec_t* x, const demi_model* m, const demi_ext_even
     out->hash = 0;
   } else {
     out->flags = (x->flags & 0xFF) | (x->violation ? DEMI_V_VIOLATION : 0) | ((x->trace_idx & 0xFF) << 8) |
-                 ((x->count & 0xFFFF) << 16);
+                 ((x->count < 0xFFFFu ? x->count : 0xFFFFu) << 16);
     out->fingerprint = x->violation;
     out->hash = x->hash;
   }
@@ -921,7 +921,7 @@ static int sts_replay_in(sts_t* x, const demi_model* m, const demi_ext_event* ex
   if (x->flags & OVF_ANY) {
     out->flags = x->flags & OVF_ANY; out->fingerprint = 0; out->hash = 0;
   } else {
-    out->flags = (viol ? DEMI_V_VIOLATION : 0) | (x->ignored ? DEMI_V_DIVERGED : 0) | ((x->count & 0xFFFF) << 16);
+    out->flags = (viol ? DEMI_V_VIOLATION : 0) | (x->ignored ? DEMI_V_DIVERGED : 0) | ((x->count < 0xFFFFu ? x->count : 0xFFFFu) << 16);
     out->fingerprint = viol;
     out->hash = x->hash;
   }
@@ -1250,7 +1250,7 @@ int orc_dpor_execute(const demi_model* m, const demi_ext_event* ext, uint32_t n_
     *trace_len = 0; *n_pairs = 0;
   } else {
     out->flags = (viol ? DEMI_V_VIOLATION : 0) | (pairs_ovf ? DEMI_V_PAIRS_OVF : 0) |
-                 ((x->count > max_messages) ? DEMI_V_MAXMSG : 0) | ((x->deliveries & 0xFFFF) << 16);
+                 ((x->count > max_messages) ? DEMI_V_MAXMSG : 0) | ((x->deliveries < 0xFFFFu ? x->deliveries : 0xFFFFu) << 16);
     out->fingerprint = viol; out->hash = x->hash;
     *trace_len = x->n_trace; *n_pairs = np;
   }

@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "../demi_amd/csrc/dpor_host.hpp"
+#include "../demi_amd/csrc/comm.hpp"
 #include "demi_oracle.h"
 
 extern "C" int harness_dpor_explore(const demi_model* m, const demi_ext_event* ext, uint32_t n_ext,
@@ -122,6 +123,113 @@ struct SimDev {
     }
     return 0;
   }
+  uint32_t ids_used(uint32_t n) const { return n; }
+  int fetch_trace(uint32_t id, demi_dpor_trace_entry* out, uint32_t* len) {
+    memcpy(out, arena[id].data(), sizeof(demi_dpor_trace_entry) * arena[id].size());
+    *len = (uint32_t)arena[id].size();
+    return 0;
+  }
+};
+
+// The multi-GPU round (ResidentDev::round_sharded in demi_gpu.hip) restated for host "ranks": this rank runs its block of
+// the round's items, all-gathers traces / verdicts / racing-pair records, owns the table entries with
+// dpor_pair_owner == rank, and all-gathers what it decided.  Every rank must return the same verdicts, points and kills.
+struct SimShardDev {
+  const demi_model* m; const demi_ext_event* ext; uint32_t n_ext; const demi_dpor_params* par;
+  demi_comm::Comm* comm;
+  std::vector<demi_host::Trace> arena;          // replicated
+  std::unordered_map<std::pair<uint64_t, uint64_t>, SimEntry, demi_host::PairKeyHash> table;     // this rank's shard
+
+  uint32_t ids_used(uint32_t n) const { const uint32_t W = (uint32_t)comm->world; return W * ((n + W - 1) / W); }
+
+  template <class T>
+  std::vector<T> gather_var(const std::vector<T>& mine) {       // counts, then blocks padded to the largest
+    const uint32_t W = (uint32_t)comm->world;
+    unsigned long long c = mine.size();
+    std::vector<unsigned long long> counts(W);
+    comm->allgather(&c, counts.data(), sizeof c, nullptr);
+    unsigned long long mx = 0;
+    for (auto x : counts) mx = x > mx ? x : mx;
+    std::vector<T> out;
+    if (!mx) return out;
+    std::vector<T> send(mx), recv((size_t)mx * W);
+    std::copy(mine.begin(), mine.end(), send.begin());
+    comm->allgather(send.data(), recv.data(), sizeof(T) * (size_t)mx, nullptr);
+    for (uint32_t k = 0; k < W; k++) out.insert(out.end(), recv.begin() + (size_t)k * mx, recv.begin() + (size_t)k * mx + counts[k]);
+    return out;
+  }
+
+  int round(const demi::DporItem* items, uint32_t n, uint32_t round_no, uint32_t base_id, demi_verdict* vd,
+            std::vector<demi::DporPoint>& pts, std::vector<demi::DporKill>& kills) {
+    const uint32_t W = (uint32_t)comm->world, r = (uint32_t)comm->rank, mp = par->max_pairs;
+    const uint32_t blk = (n + W - 1) / W;
+    const uint32_t lo = r * blk < n ? r * blk : n, hi = lo + blk < n ? lo + blk : n;
+    if (arena.size() < (size_t)base_id + (size_t)W * blk) arena.resize((size_t)base_id + (size_t)W * blk);
+    for (uint32_t i = 0; i < n; i++) {        // mark (owner only)
+      if (items[i].src == 0xFFFFFFFFu) continue;
+      const demi_host::Trace& T = arena[items[i].src];
+      const uint64_t a = T[items[i].later].key, b = T[items[i].earlier].key;
+      if (demi::dpor_pair_owner(a, b, W) == r) table[{a, b}].state |= SIM_EXPLORED;
+    }
+    // my block: interleavings, records
+    std::vector<demi_dpor_trace_entry> my_tr((size_t)blk * DEMI_DPOR_MAX_TRACE);
+    std::vector<uint32_t> my_tl(blk, 0);
+    std::vector<demi_verdict> my_vd(blk);
+    memset(my_vd.data(), 0, sizeof(demi_verdict) * blk);
+    std::vector<demi::DporPairRec> my_recs;
+    std::vector<uint64_t> keys(DEMI_DPOR_MAX_TRACE);
+    std::vector<demi_dpor_pair> pr(mp ? mp : 1);
+    for (uint32_t i = lo; i < hi; i++) {
+      uint32_t pl = 0, shared = 0;
+      if (items[i].src != 0xFFFFFFFFu) {
+        const demi_host::Trace& T = arena[items[i].src];
+        for (uint32_t k = 0; k <= items[i].branch; k++) keys[pl++] = T[k].key;
+        for (uint32_t k = items[i].branch + 1u; k <= items[i].later; k++) if (k != items[i].earlier) keys[pl++] = T[k].key;
+        shared = items[i].branch + 1u;
+      }
+      uint32_t np = 0;
+      demi_dpor_trace_entry* tr = &my_tr[(size_t)(i - lo) * DEMI_DPOR_MAX_TRACE];
+      orc_dpor_execute(m, ext, n_ext, keys.data(), pl, shared, par, &my_vd[i - lo], tr, &my_tl[i - lo], pr.data(), &np);
+      for (uint32_t k = 0; k < np; k++)
+        my_recs.push_back(demi::DporPairRec{tr[pr[k].earlier].key, tr[pr[k].later].key, i * mp + k, base_id + i, pr[k].branch, pr[k].later,
+                                            pr[k].earlier, 0, 0});
+    }
+    // exchange: traces, lengths, verdicts (equal blocks), records (variable)
+    std::vector<demi_dpor_trace_entry> all_tr((size_t)blk * W * DEMI_DPOR_MAX_TRACE);
+    std::vector<uint32_t> all_tl((size_t)blk * W);
+    std::vector<demi_verdict> all_vd((size_t)blk * W);
+    comm->allgather(my_tr.data(), all_tr.data(), sizeof(demi_dpor_trace_entry) * DEMI_DPOR_MAX_TRACE * (size_t)blk, nullptr);
+    comm->allgather(my_tl.data(), all_tl.data(), 4 * (size_t)blk, nullptr);
+    comm->allgather(my_vd.data(), all_vd.data(), sizeof(demi_verdict) * (size_t)blk, nullptr);
+    for (uint32_t i = 0; i < W * blk; i++)
+      arena[(size_t)base_id + i].assign(&all_tr[(size_t)i * DEMI_DPOR_MAX_TRACE], &all_tr[(size_t)i * DEMI_DPOR_MAX_TRACE] + all_tl[i]);
+    memcpy(vd, all_vd.data(), sizeof(demi_verdict) * n);
+    std::vector<demi::DporPairRec> recs = gather_var(my_recs);
+    // insert + decide for the pairs this rank owns
+    std::vector<demi::DporPoint> my_pts;
+    std::vector<demi::DporKill> my_kills;
+    for (const demi::DporPairRec& x : recs) {
+      if (demi::dpor_pair_owner(x.ke, x.kl, W) != r) continue;
+      SimEntry& e1 = table[{x.ke, x.kl}];
+      if (!(e1.state & SIM_EXPLORED) && (e1.state & SIM_QMASK)) my_kills.push_back(demi::DporKill{x.ke, x.kl});
+      e1.state |= SIM_EXPLORED;
+      SimEntry& e2 = table[{x.kl, x.ke}];
+      const unsigned long long c = sim_cand(round_no, x.branch, x.ordinal);
+      if (c > e2.cand) e2.cand = c;
+    }
+    for (const demi::DporPairRec& x : recs) {
+      if (demi::dpor_pair_owner(x.ke, x.kl, W) != r) continue;
+      SimEntry& e = table[{x.kl, x.ke}];
+      if (e.state & SIM_EXPLORED) continue;
+      if (e.cand != sim_cand(round_no, x.branch, x.ordinal)) continue;
+      if ((e.state & SIM_QMASK) > x.branch) continue;
+      e.state = (e.state & ~SIM_QMASK) | ((uint32_t)x.branch + 1);
+      my_pts.push_back(demi::DporPoint{x.kl, x.ke, x.ordinal, x.src, x.branch, x.later, x.earlier, 0, 0});
+    }
+    pts = gather_var(my_pts);
+    kills = gather_var(my_kills);
+    return 0;
+  }
   int fetch_trace(uint32_t id, demi_dpor_trace_entry* out, uint32_t* len) {
     memcpy(out, arena[id].data(), sizeof(demi_dpor_trace_entry) * arena[id].size());
     *len = (uint32_t)arena[id].size();
@@ -129,6 +237,30 @@ struct SimDev {
   }
 };
 }  // namespace
+
+// `world` ranks as threads of this process (LocalComm): every rank runs the whole host loop; outputs are [world][...]
+extern "C" int harness_dpor_explore_sharded(const demi_model* m, const demi_ext_event* ext, uint32_t n_ext,
+                                            const demi_dpor_params* par, const demi_dpor_search* srch, int world,
+                                            demi_verdict* out_verdicts, uint32_t* out_prefix_len, uint32_t* out_rounds,
+                                            demi_dpor_trace_entry* first_violation_trace, uint32_t* first_violation_len,
+                                            demi_dpor_stats* stats) {
+  demi_comm::LocalGroup group(world);
+  std::vector<int> rcs((size_t)world, 0);
+  const size_t cap = srch->max_interleavings;
+  auto run = [&](int r) {
+    demi_comm::LocalComm comm(&group, r);
+    SimShardDev dev{m, ext, n_ext, par, &comm, {}, {}};
+    rcs[(size_t)r] = demi_host::explore_rounds_resident(dev, srch, out_verdicts + (size_t)r * cap, out_prefix_len + (size_t)r * cap,
+                                                        out_rounds + (size_t)r * cap, first_violation_trace + (size_t)r * DEMI_DPOR_MAX_TRACE,
+                                                        first_violation_len + r, stats + r, nullptr);
+  };
+  std::vector<std::thread> pool;
+  for (int r = 1; r < world; r++) pool.emplace_back(run, r);
+  run(0);
+  for (auto& th : pool) th.join();
+  for (int rc : rcs) if (rc) return rc;
+  return 0;
+}
 
 extern "C" int harness_dpor_explore_resident(const demi_model* m, const demi_ext_event* ext, uint32_t n_ext,
                                              const demi_dpor_params* par, const demi_dpor_search* srch, int n_threads,

@@ -217,3 +217,32 @@ def dpor_batch(model, externals, prefixes, params, shared=None):
         traces.append(tr[:tl.value].copy())
         pairs.append(pr[:npr.value].copy())
     return verdicts, traces, pairs
+
+
+def dpor_explore_sharded(model, externals, params, search, world):
+    """The multi-GPU rounds of the device-resident exploration restated for `world` host ranks (threads exchanging their
+    blocks through an in-process all-gather): returns one (verdicts, prefix_len, rounds, first violating trace, stats)
+    per rank - they must all be equal, and equal to the single-rank exploration."""
+    build()
+    H = C.CDLL(os.path.join(_HERE, "_build", "dpor_host_harness.so"))
+    H.harness_dpor_explore_sharded.argtypes = [C.POINTER(T.ModelStruct), C.c_void_p, C.c_uint32, C.POINTER(T.DporParams),
+                                               C.POINTER(T.DporSearch), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                               C.c_void_p, C.c_void_p]
+    ms = model.to_struct()
+    ev = np.ascontiguousarray(externals, dtype=T.EXT_EVENT_DTYPE)
+    cap = search.max_interleavings
+    verdicts = np.zeros((world, cap), dtype=T.VERDICT_DTYPE)
+    plen = np.zeros((world, cap), dtype=np.uint32)
+    rounds = np.zeros((world, cap), dtype=np.uint32)
+    vt = np.zeros((world, T.DPOR_MAX_TRACE), dtype=T.DPOR_TRACE_DTYPE)
+    vl = np.zeros(world, dtype=np.uint32)
+    stats = (T.DporStats * world)()
+    rc = H.harness_dpor_explore_sharded(C.byref(ms), ev.ctypes.data, len(ev), C.byref(params), C.byref(search), world,
+                                        verdicts.ctypes.data, plen.ctypes.data, rounds.ctypes.data, vt.ctypes.data, vl.ctypes.data,
+                                        C.cast(stats, C.c_void_p))
+    assert rc == 0
+    out = []
+    for r in range(world):
+        n = int(stats[r].interleavings)
+        out.append((verdicts[r, :n], plen[r, :n], rounds[r, :int(stats[r].launches)], vt[r, :vl[r]], stats[r]))
+    return out

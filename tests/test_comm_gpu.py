@@ -52,6 +52,23 @@ single = ctx.replay_batch(masks, target)
 ctx.comm_create_host(rank, world, allgather)
 sharded = ctx.replay_batch_sharded(masks, target)
 assert (sharded == single).all()
+# K3: the whole bounded exploration, rounds split over the ranks, explored-pair table owner-sharded
+from demi_amd import model as M
+from demi_amd.fuzzer import events_to_array, send, start
+m3 = M.raft_model(3)
+ev3 = events_to_array([start(a) for a in range(3)] + [send(a, M.M_BOOTSTRAP) for a in range(3)])
+ctx.comm_destroy()
+ctx.model_load(m3.to_struct()); ctx.dpor_load(ev3)
+par = T.DporParams(30, 0, 0, 0, 64, 4096)
+for batch in (5, 256):
+    srch = T.DporSearch(batch, 5000, 0, 1)
+    ctx.comm_destroy()
+    one = ctx.dpor_explore(par, srch)
+    ctx.comm_create_host(rank, world, allgather)
+    two = ctx.dpor_explore(par, srch)
+    assert len(one[0]) == len(two[0]) and (one[0] == two[0]).all() and (one[1] == two[1]).all() and (one[2] == two[2]).all(), batch
+    assert one[4].exhausted and two[4].exhausted
+ctx.comm_destroy()
 dist.barrier(); dist.destroy_process_group()
 ctx.close()
 print("rank", rank, "ok", n)

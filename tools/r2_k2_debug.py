@@ -21,3 +21,12 @@ print("oracle                 :", O.sts_replay_batch(model, used, rec, full, tar
 print("removal NO_SKIP        :", ctx.replay_removal_batch([0xFFFFFFFF], target))
 print("removal NO_SKIP x3     :", ctx.replay_removal_batch([0xFFFFFFFF] * 3, target))
 print("removal NO_SKIP + mask :", ctx.replay_removal_batch([0xFFFFFFFF], target, masks=full))
+from demi_amd.internal_minimization import deliveries
+from demi_amd.schedulers import EventTrace
+dl = [i for i, _, _ in deliveries(EventTrace(rec, used))]
+for skips in ([0xFFFFFFFF] * 61, dl[:3] + [0xFFFFFFFF], dl + [0xFFFFFFFF]):
+    skips = np.array(skips, dtype=np.uint32)
+    g = ctx.replay_removal_batch(skips, target)
+    c = O.sts_removal_batch(model, used, rec, skips, target, n_threads=8)
+    bad = np.nonzero(g != c)[0]
+    print("n", len(skips), "differ", len(bad), "first gpu", g[bad[0]] if len(bad) else None, "cpu", c[bad[0]] if len(bad) else None, "last gpu", g[-1], "cpu", c[-1])
