@@ -111,7 +111,7 @@ inline std::string generate_vm(const demi::DevModel& h) {
     if (bimm) snprintf(b, sizeof b, "%uu", braw); else snprintf(b, sizeof b, "r%u", braw & 15u);
     emit("  L%u: ", pc);
     const uint32_t cw = op_control(op);
-    if (cw & CW_HALT) {
+    if ((cw & CW_HALT) && !(cw & CW_FX)) {
       s += "goto done;\n";
       continue;
     }
@@ -146,7 +146,7 @@ inline std::string generate_vm(const demi::DevModel& h) {
     } else if (cw & CW_SKIP) {
       emit("goto %s;\n", target(pc + 1 + braw).c_str());
     } else {   // CW_FX: recorded now, applied after the rows have run (same record as vm_run)
-      emit("DEMI_FX(%uu, %uu, %s > 15u ? 15u : %s, %s, %s)\n", row & 0xFFu, aux, a, a, d, b);
+      emit("DEMI_FX(%uu, %uu, %s > 15u ? 15u : %s, %s, %s)%s\n", row & 0xFFu, aux, a, a, d, b, (cw & CW_HALT) ? " goto done;" : "");
     }
   }
   s += "  done:\n";

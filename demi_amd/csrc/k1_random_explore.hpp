@@ -64,7 +64,7 @@ constexpr int K1_BATCH = 64;         // schedule indices claimed per atomic
 // injection batch (inject_until_quiescence is schedule-independent: the events are applied in trace
 // order whatever the interleaving, so the state after batch j is a function of j alone) and the
 // message word of every Send (0 = not a deliverable Send).
-constexpr uint32_t K1_BATCH_WORDS = 6;   // end index, inaccessible, killed, partitioned lo/hi, sends (offset | count << 16)
+constexpr uint32_t K1_BATCH_WORDS = 7;   // end index, inaccessible, killed, partitioned lo/hi, sends (offset | count << 16), actors Start()ed
 __host__ __device__ inline size_t k1_extra_lds_bytes(uint32_t n_ev, uint32_t n_batches) {
   return (((size_t)n_batches * K1_BATCH_WORDS + 2 * (size_t)n_ev) * 4 + 15) & ~(size_t)15;
 }
@@ -103,9 +103,9 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
   unsigned char* wave_base = extra + k1_extra_lds_bytes(args.n_ev, args.n_batches);
   if (threadIdx.x == 0) {
     // EventOrchestrator.inject_until_quiescence (:132-189) once per workgroup, for every batch
-    uint32_t inacc = t.exists, killed = 0, b_no = 0, n_bs = 0, bs_lo = 0;
+    uint32_t inacc = t.exists, killed = 0, b_no = 0, n_bs = 0, bs_lo = 0, started = 0;
     uint64_t part = 0;
-    if (t.E == 0) { s_batch[0] = 0; s_batch[1] = inacc; s_batch[2] = 0; s_batch[3] = 0; s_batch[4] = 0; s_batch[5] = 0; }
+    if (t.E == 0) { s_batch[0] = 0; s_batch[1] = inacc; s_batch[2] = 0; s_batch[3] = 0; s_batch[4] = 0; s_batch[5] = 0; s_batch[6] = 0; }
     for (uint32_t i = 0; i < t.E; i++) {
       const uint64_t ev = t.trace[i];
       const uint32_t kind = (uint32_t)ev & 0xFF, a = (uint32_t)(ev >> 8) & 0xFF, b = (uint32_t)(ev >> 16) & 0xFF;
@@ -114,7 +114,7 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
                               : 0u;
       s_sendw[i] = sw;
       if (sw != 0) s_bsend[n_bs++] = sw;
-      if (kind == DEMI_EV_START) { inacc &= ~(1u << a); killed &= ~(1u << a); }
+      if (kind == DEMI_EV_START) { inacc &= ~(1u << a); killed &= ~(1u << a); started |= 1u << a; }
       else if (kind == DEMI_EV_KILL) { killed |= 1u << a; inacc |= 1u << a; }
       else if (kind == DEMI_EV_PARTITION) part |= 1ULL << (a * 8 + b);
       else if (kind == DEMI_EV_UNPARTITION) part &= ~(1ULL << (a * 8 + b));
@@ -122,7 +122,8 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
         uint32_t* o = s_batch + (size_t)b_no * K1_BATCH_WORDS;
         o[0] = i + 1; o[1] = inacc; o[2] = killed; o[3] = (uint32_t)part; o[4] = (uint32_t)(part >> 32);
         o[5] = bs_lo | ((n_bs - bs_lo) << 16);
-        bs_lo = n_bs;
+        o[6] = started;
+        bs_lo = n_bs; started = 0;
         b_no++;
       }
     }
@@ -189,6 +190,7 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
   uint32_t n_tq = 0, n_resend = 0;
   uint32_t just = 0, rep = 0;         // justScheduledTimers / registered repeating timers (bit rcv*4+tidx)
   uint32_t viol = 0, flags = 0;
+  uint32_t blocked = 0;               // Instrumenter().blockedActors: actors that crashed (DEMI_OP_CRASH) and were not Start()ed since
   uint32_t hits = 0;                  // invariant "hit" mask of the actors (demi_device.hpp invariant_hit), kept up to date per delivery
   uint64_t tmask = 0;
   uint32_t next_id = 1, n_rec = 0;    // REC only
@@ -332,6 +334,7 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
         te_rng = rng;                  // SrcDstFIFO: both generators are `new Random(seed)`
         hash = 0xCBF29CE484222325ULL;
         net.inaccessible = exists; net.killed = 0; net.partitioned = 0;
+        blocked = 0;
         hits = 0;
         for (uint32_t a = 0; a < A; a++) { const uint64_t s0 = t.init[a]; st[a * 64] = s0; hits |= invariant_hit(s0, inv_kind, inv_fa, inv_va) << a; }
         if (REC) { rec = args.rec_out + sched * (uint64_t)args.rec_cap; n_rec = 0; next_id = 1; }
@@ -347,6 +350,7 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
         tidx = bt[0];
         net.inaccessible = bt[1]; net.killed = bt[2]; net.partitioned = (uint64_t)bt[3] | ((uint64_t)bt[4] << 32);
         fl_off = bt[5] & 0xFFFFu; fl_cnt = bt[5] >> 16;
+        blocked &= ~bt[6];            // trigger_start: "allow scheduler to send messages to it again" (EventOrchestrator.scala:224-227)
       }
       bool loop = REC;     // the recording variant walks the events to emit their records
       while (loop && tidx < E) {
@@ -354,7 +358,7 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
         const uint32_t kind = (uint32_t)ev & 0xFF, a = (uint32_t)(ev >> 8) & 0xFF, b = (uint32_t)(ev >> 16) & 0xFF;
         if (kind == DEMI_EV_START) {
           REC_PUSH(DEMI_REC_SPAWN, 0, a, 0, 0, 0, 0, tidx, 0);
-          net.inaccessible &= ~(1u << a); net.killed &= ~(1u << a);
+          net.inaccessible &= ~(1u << a); net.killed &= ~(1u << a); blocked &= ~(1u << a);
         } else if (kind == DEMI_EV_KILL) {
           REC_PUSH(DEMI_REC_KILL, 0, a, 0, 0, 0, 0, tidx, 0);
           net.killed |= 1u << a; net.inaccessible |= 1u << a;
@@ -456,47 +460,119 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
     }
     PH_MARK(3);
     if (disp) {
-      if (!none) {
-        uint32_t wid = 0;
-        bool from_te = true;
-        uint32_t idx = 0;
-        if (!FIFO) {
-          // FullyRandom.removeRandomElement -> RandomizedHashSet: nextInt(arr.length), swap with last
-          idx = jr_next_int(rng, n_pend, t.magic);
-        } else if (n_pairs == 0) {
-          // SrcDstFIFO.getNonBlockedMessage (:716-729): only timers / externals left
-          idx = jr_next_int(te_rng, n_pend, t.magic);
-        } else {
-          // (:731-759) a timer / external with probability |timersAndExternals| / |allMessages|, else a random pair's head
-          from_te = jr_next_int(rng, n_pend + n_norm, t.magic) < n_pend;
-          if (from_te) idx = jr_next_int(te_rng, n_pend, t.magic);
+      uint32_t wid = 0;
+      // SrcDstFIFO.dequeue (:764-774) of pair number pi of srcDsts: the head of its queue; the gap closes (arrival order is the
+      // FIFO order) and the pair leaves srcDsts when its queue is empty
+      auto fifo_dequeue = [&](uint32_t pi) {
+        const uint32_t pr = pair_get(pi);
+        uint32_t k = 0;
+        uint32_t cur = norm_load(0);
+        while (k + 1 < n_norm && w_src(cur) * 8 + w_dst(cur) != pr) { k++; cur = norm_load(k); }   // queue.head
+        w = cur;
+        if (REC) wid = norm_aux_load(k);
+        bool more = false;
+        for (uint32_t j = k; j + 1 < n_norm; j++) {
+          const uint32_t nx = norm_load(j + 1);
+          more |= (w_src(nx) * 8 + w_dst(nx) == pr);
+          norm_store(j, nx);
+          if (REC) norm_aux_store(j, norm_aux_load(j + 1));
         }
-        if (from_te) {
-          w = pend_load(mem, idx);
-          const uint32_t lastw = pend_load(mem, n_pend - 1);
-          if (REC) wid = aux_load(mem, idx);
-          pend_remove(idx, lastw);
-        } else {
-          const uint32_t pi = jr_next_int(rng, n_pairs, t.magic);
-          const uint32_t pr = pair_get(pi);
+        n_norm--;
+        if (!more) {                                     // srcDstToMessages -= srcDst; srcDsts.remove(idx)
+          for (uint32_t j = pi; j + 1 < n_pairs; j++) pair_set(j, pair_get(j + 1));
+          n_pairs--;
+          pairmask &= ~(1ull << pr);
+        }
+      };
+      bool picked = false;          // the message was already chosen (and removed) by the blocked-actor path
+      if (!none && blocked != 0) {
+        // Some actor crashed: Util.find_non_blocked_message (Util.scala:470-489).  Draw until the receiver is not blocked;
+        // what was drawn for a blocked actor is set aside and re-appended afterwards in draw order - which permutes
+        // arr, so it is replayed literally.  Rare (only executions with a crashed actor come here), hence simple.
+        auto find_non_blocked = [&](uint64_t& g) -> bool {
+          const uint32_t n0 = n_pend;
           uint32_t k = 0;
-          uint32_t cur = norm_load(0);
-          while (k + 1 < n_norm && w_src(cur) * 8 + w_dst(cur) != pr) { k++; cur = norm_load(k); }   // queue.head
-          w = cur;
-          if (REC) wid = norm_aux_load(k);
-          // dequeue (:764-774): close the gap (arrival order is the FIFO order) and see whether the pair has more
-          bool more = false;
-          for (uint32_t j = k; j + 1 < n_norm; j++) {
-            const uint32_t nx = norm_load(j + 1);
-            more |= (w_src(nx) * 8 + w_dst(nx) == pr);
-            norm_store(j, nx);
-            if (REC) norm_aux_store(j, norm_aux_load(j + 1));
+          bool found = false;
+          while (n_pend > 0) {
+            const uint32_t i = jr_next_int(g, n_pend, t.magic);
+            const uint32_t cw = pend_load(mem, i);
+            const uint32_t cid = REC ? aux_load(mem, i) : 0u;
+            pend_remove(i, pend_load(mem, n_pend - 1));
+            if ((blocked >> w_dst(cw)) & 1u) {           // set aside in the slot this removal just freed
+              pend_store(mem, n0 - 1 - k, cw);
+              if (REC) aux_store(mem, n0 - 1 - k, cid);
+              k++;
+              continue;
+            }
+            w = cw; wid = cid; found = true;
+            break;
           }
-          n_norm--;
-          if (!more) {                                     // srcDstToMessages -= srcDst; srcDsts.remove(idx)
-            for (uint32_t j = pi; j + 1 < n_pairs; j++) pair_set(j, pair_get(j + 1));
-            n_pairs--;
-            pairmask &= ~(1ull << pr);
+          // the rejected ones sit in slots n0 - 1 down to n0 - k in draw order: reverse them in place, then close the gap
+          // the accepted element left, so that arr = remaining ++ rejected (collection ++= blocked)
+          if (k > 1) {
+            for (uint32_t lo = n0 - k, hi = n0 - 1; lo < hi; lo++, hi--) {
+              const uint32_t x = pend_load(mem, lo), y = pend_load(mem, hi);
+              pend_store(mem, lo, y); pend_store(mem, hi, x);
+              if (REC) { const uint32_t ax = aux_load(mem, lo), ay = aux_load(mem, hi); aux_store(mem, lo, ay); aux_store(mem, hi, ax); }
+            }
+          }
+          if (found)
+            for (uint32_t j = 0; j < k; j++) {
+              pend_store(mem, n0 - k - 1 + j, pend_load(mem, n0 - k + j));
+              if (REC) aux_store(mem, n0 - k - 1 + j, aux_load(mem, n0 - k + j));
+            }
+          n_pend = n0 - (found ? 1u : 0u);
+          tmask = 0;                                     // which slots hold timer messages, from scratch
+          for (uint32_t q = 0; q < n_pend && q < 64; q++) {
+            const uint32_t pw = pend_load(mem, q);
+            if (w_src(pw) == DEMI_DEADLETTERS && (t.meta[w_type(pw)] & 0xFF) == DEMI_MSG_TIMER) tmask |= 1ull << q;
+          }
+          return found;
+        };
+        bool found = false;
+        if (!FIFO) {
+          found = find_non_blocked(rng);
+        } else {
+          // SrcDstFIFO.getNonBlockedMessage (:716-760) with blocked receivers
+          bool open_pair = false;                        // a pair queue whose receiver is not blocked
+          for (uint32_t i = 0; i < n_pairs; i++) open_pair |= !((blocked >> (pair_get(i) & 7u)) & 1u);
+          if (!open_pair) {
+            found = find_non_blocked(te_rng);            // (:717-729) "only timers left"
+          } else {
+            if (jr_next_int(rng, n_pend + n_norm, t.magic) < n_pend) found = find_non_blocked(te_rng);
+            if (!found) {
+              uint32_t pi = jr_next_int(rng, n_pairs, t.magic);
+              while ((blocked >> (pair_get(pi) & 7u)) & 1u) pi = jr_next_int(rng, n_pairs, t.magic);
+              fifo_dequeue(pi);
+              found = true;
+            }
+          }
+        }
+        picked = found;
+        if (!found) none = true;
+      }
+      if (!none) {
+        if (!picked) {
+          bool from_te = true;
+          uint32_t idx = 0;
+          if (!FIFO) {
+            // FullyRandom.removeRandomElement -> RandomizedHashSet: nextInt(arr.length), swap with last
+            idx = jr_next_int(rng, n_pend, t.magic);
+          } else if (n_pairs == 0) {
+            // SrcDstFIFO.getNonBlockedMessage (:716-729): only timers / externals left
+            idx = jr_next_int(te_rng, n_pend, t.magic);
+          } else {
+            // (:731-759) a timer / external with probability |timersAndExternals| / |allMessages|, else a random pair's head
+            from_te = jr_next_int(rng, n_pend + n_norm, t.magic) < n_pend;
+            if (from_te) idx = jr_next_int(te_rng, n_pend, t.magic);
+          }
+          if (from_te) {
+            w = pend_load(mem, idx);
+            const uint32_t lastw = pend_load(mem, n_pend - 1);
+            if (REC) wid = aux_load(mem, idx);
+            pend_remove(idx, lastw);
+          } else {
+            fifo_dequeue(jr_next_int(rng, n_pairs, t.magic));
           }
         }
         count++;
@@ -649,6 +725,7 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
         const uint32_t op = fx & 31u, type = (fx >> 5) & 31u;
         PH_MARK(9);
         if (op <= DEMI_OP_BCAST) { apply_send(fx); PH_MARK(6); }
+        else if (op == DEMI_OP_CRASH) blocked |= 1u << me;        // actorCrashed (Instrumenter.scala:184-199)
         else if (op == DEMI_OP_TCANCEL) { apply_cancel(type); PH_MARK(7); }
         else { apply_timer_set(op == DEMI_OP_TREP, type); PH_MARK(8); }
       }

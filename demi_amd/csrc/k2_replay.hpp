@@ -160,6 +160,7 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
   uint64_t sched = 0, hash = 0;
   uint64_t m0 = 0, m1 = 0, m2 = 0, m3 = 0;   // candidate mask
   uint32_t idx = 0, cur = 0, n_pend = 0, count = 0, ignored = 0, flags = 0, rep = 0, skip = 0xFFFFFFFFu;
+  uint32_t blocked = 0;     // crashed actors (DEMI_OP_CRASH): an expected delivery to one is not "pending" (STSScheduler.scala:392-402)
   Net net = {0, 0, 0};
   uint64_t tq = 0;
   uint32_t n_tq = 0;
@@ -235,7 +236,7 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
         net.inaccessible = exists; net.killed = 0; net.partitioned = 0;
         for (uint32_t a = 0; a < A; a++) st[a * 64] = t.init[a];
         if (FP) for (uint32_t f = 0; f < args.n_fp; f++) cnt[(size_t)f * cnt_stride] = 0;
-        idx = 0; cur = 0; n_pend = 0; count = 0; ignored = 0; flags = 0; rep = 0; tq = 0; n_tq = 0;
+        idx = 0; cur = 0; n_pend = 0; count = 0; ignored = 0; flags = 0; rep = 0; tq = 0; n_tq = 0; blocked = 0;
         cur_skip();
       }
       // -------------------------------------------------------- advanceReplay (:405-559)
@@ -257,7 +258,7 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
           cur++;
           cur_skip();
           if (args.kept) args.kept[sched * NX + idx - 1] = 1;
-          if (kind == DEMI_REC_SPAWN) { net.inaccessible &= ~(1u << a); net.killed &= ~(1u << a); }
+          if (kind == DEMI_REC_SPAWN) { net.inaccessible &= ~(1u << a); net.killed &= ~(1u << a); blocked &= ~(1u << a); }
           else if (kind == DEMI_REC_KILL) { net.killed |= 1u << a; net.inaccessible |= 1u << a; }
           else if (kind == DEMI_REC_PARTITION) net.partitioned |= 1ULL << (a * 8 + b);
           else net.partitioned &= ~(1ULL << (a * 8 + b));
@@ -271,6 +272,7 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
         } else {  // MSG_EVENT
           if (idx - 1 == skip) continue;               // the delivery this candidate removes (OneAtATimeRemoval.scala:57-124)
           if (ext != 255 && !IN_MASK(ext)) continue;   // pruned together with its Send (filterSends)
+          if ((blocked >> b) & 1u) { ignored++; continue; }   // the destination is blocked: not deliverable (:392-402), ignored
           const uint32_t want = msg_word((uint32_t)(e >> 24) & 0xFF, a, b, (uint32_t)(e >> 32) & 0xFF,
                                          (uint32_t)(e >> 40) & 0xFF);
           if (FP) {
@@ -320,6 +322,8 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
             if ((bc && r == me) || !((exists >> r) & 1)) continue;
             if (!crosses_partition(net, me, r)) PEND_APPEND(msg_word(type, me, r, p0, p1));
           }
+        } else if (op == DEMI_OP_CRASH) {
+          blocked |= 1u << me;                 // actorCrashed (Instrumenter.scala:184-199)
         } else if (op == DEMI_OP_TCANCEL) {
           // notify_timer_cancel (:828-855): messagesToSend first, then the (deadLetters, rcv) queue
           rep &= ~TIMER_BIT(me, type);

@@ -193,6 +193,7 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
   };
   uint32_t n_pend = 0, next_seq = 0, parent = 0, parent_depth = 0, cur_root = 0, qperiod = 0, next_qperiod = 0;
   uint32_t marker_ext = 0, qmarker_ext = 0, isolated = 0, rep = 0, flags = 0, count = 0, deliveries = 0;
+  uint32_t blocked = 0;     // crashed actors (DEMI_OP_CRASH): skipped by getMatchingMessage (:478, 518) and getPendingEvent (:455)
   uint32_t n_trace = 0, ext_idx = 0;
   bool awaiting = false, marker_pending = false;
   uint64_t b_next = 0, b_end = 0;
@@ -278,7 +279,7 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
         hash = 0xCBF29CE484222325ULL;
         isolated = (1u << A) - 1;      // maybeStartActors: every actor exists and is isolated (:666-679)
         for (uint32_t a = 0; a < A; a++) st[a * 64] = t.init[a];
-        n_pend = 0; next_seq = 0; qperiod = 0; next_qperiod = 0; rep = 0; flags = 0; count = 0; deliveries = 0;
+        n_pend = 0; next_seq = 0; qperiod = 0; next_qperiod = 0; rep = 0; flags = 0; count = 0; deliveries = 0; blocked = 0;
         n_trace = 0; ext_idx = 0; awaiting = false; marker_pending = false;
         trace_push(DPOR_ROOT_KEY, 0, 0, 0, 0);   // currentTrace += getRootEvent (:336-343)
         parent = 0; parent_depth = 0; cur_root = 0;
@@ -304,7 +305,7 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
               if (marker_pending && want.key == dpor_marker_key(marker_ext)) chose_marker = true;
             } else {
               uint32_t best_seq = 0xFFFFFFFFu;
-              for (uint32_t k = 0; k < n_pend; k++) {
+              for (uint32_t k = 0; k < n_pend && !((blocked >> w_dst(want.word)) & 1u); k++) {
                 if (pend_load(mem, k) != want.word) continue;
                 const uint32_t aux = aux_load(mem, k);
                 const uint64_t key = (tr[aux & 0xFF].key ^ (uint64_t)want.word) * DPOR_PRIME;
@@ -318,6 +319,7 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
           uint32_t best = 0xFFFFFFFFu;
           for (uint32_t k = 0; k < n_pend; k++) {
             const uint32_t pw = pend_load(mem, k);
+            if ((blocked >> w_dst(pw)) & 1u) continue;           // !(blockedActors contains k._2) (:455)
             const uint32_t ord = (((w_src(pw) << 4) | w_dst(pw)) << 16) | (aux_load(mem, k) >> 16);
             if (ord < best) { best = ord; chosen = (int)k; }
           }
@@ -383,6 +385,8 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
             if (bc && r == me) continue;
             produce(msg_word(type, me, r, p0, p1));
           }
+        } else if (op == DEMI_OP_CRASH) {
+          blocked |= 1u << me;                 // actorCrashed (Instrumenter.scala:184-199)
         } else if (op == DEMI_OP_TCANCEL) {
           // notify_timer_cancel (:961-984): first of the (deadLetters, rcv) queue with this message
           rep &= ~TIMER_BIT(me, type);

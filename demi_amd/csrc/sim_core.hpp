@@ -54,6 +54,7 @@ inline uint32_t op_control(uint32_t op) {   // host side: fills DevModel::optab
   if (op == DEMI_OP_SKIPNZ) return CW_SKIPNZ;
   if (op == DEMI_OP_SKIP) return CW_SKIP;
   if (op >= DEMI_OP_SEND && op <= DEMI_OP_TCANCEL) return CW_FX;
+  if (op == DEMI_OP_CRASH) return CW_FX | CW_HALT;     // recorded as the delivery's last effect, then the rows stop
   if (op >= DEMI_OP_IFEQ && op <= DEMI_OP_IFGT) return CW_IF | (rels[op - DEMI_OP_IFEQ] << CW_REL_SHIFT);
   return CW_HALT;   // unknown ops are rejected by validation
 }

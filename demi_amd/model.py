@@ -29,7 +29,7 @@ SRC, ME = Reg(14), Reg(15)              # sender id (15 = deadLetters), own id
 
 OPS = dict(HALT=0, MOV=1, ADD=2, SUB=3, AND=4, OR=5, XOR=6, SHL=7, SHR=8, BITSET=9, POPC=10,
            EQ=11, NE=12, LT=13, GE=14, LE=15, GT=16, MIN=17, MAX=18, SKIPZ=20, SKIPNZ=21, SKIP=22,
-           SEND=24, BCAST=25, TSET=26, TREP=27, TCANCEL=28, IFEQ=32, IFNE=33, IFLT=34, IFGE=35, IFLE=36, IFGT=37)
+           SEND=24, BCAST=25, TSET=26, TREP=27, TCANCEL=28, CRASH=29, IFEQ=32, IFNE=33, IFLT=34, IFGE=35, IFLE=36, IFGT=37)
 
 
 def row(op, dst=0, a=0, bimm=0, aux=0, b=0):
@@ -117,6 +117,11 @@ class Asm:
 
     def tcancel(self, msg_type):
         self.rows.append(row(OPS["TCANCEL"], 0, 0, 1, msg_type, 0))
+        return self
+
+    def crash(self):
+        """The receive throws here (Instrumenter.actorCrashed): the actor is blocked until a Start() of its name."""
+        self.rows.append(row(OPS["CRASH"], 0, 0, 1, 0, 0))
         return self
 
     def halt(self):

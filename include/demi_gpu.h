@@ -99,7 +99,13 @@ typedef enum {
   DEMI_OP_BCAST = 25,   /* SEND to every other created actor, ascending id: p0 = reg dst, p1 = b */
   DEMI_OP_TSET = 26,    /* scheduler.scheduleOnce(self, msg type aux)                          */
   DEMI_OP_TREP = 27,    /* scheduler.schedule(self, msg type aux)  (repeating)                 */
-  DEMI_OP_TCANCEL = 28  /* cancellable.cancel() of timer (self, type aux)                      */
+  DEMI_OP_TCANCEL = 28, /* cancellable.cancel() of timer (self, type aux)                      */
+  DEMI_OP_CRASH = 29    /* the receive throws: Instrumenter.actorCrashed (Instrumenter.scala:184-199).  The handler
+                           stops here (state changes and effects so far stand) and the actor joins blockedActors: the
+                           schedulers no longer deliver to it (Util.find_non_blocked_message, Util.scala:470-489: a
+                           drawn message for a blocked receiver is set aside, the draw repeated, and the rejected
+                           ones re-appended in draw order) until a Start() of the same name (EventOrchestrator
+                           trigger_start :219-231).  Counts as an effect row.                                      */
 } demi_op;
 
 #define DEMI_ROW(op, dst, a, bimm, aux, b) \

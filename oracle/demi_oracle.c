@@ -115,6 +115,8 @@ int orc_model_validate(const demi_model* m, char* err, size_t err_cap) {
         if (aux >= m->n_msg_types || m->msg_class[aux] != DEMI_MSG_TIMER)
           FAIL("row %u: timer op on a non-timer message type %u", pc, aux);
         break;
+      case DEMI_OP_CRASH:
+        break;
       default:
         FAIL("row %u: unknown op %u", pc, op);
     }
@@ -229,6 +231,12 @@ int orc_vm_run(const demi_model* m, uint32_t me, uint64_t* state, uint8_t msg_ty
         if (nfx >= fx_cap) return -1;
         fx[nfx++] = (orc_effect){(uint8_t)(1 + (op - DEMI_OP_TSET)), (uint8_t)me, (uint8_t)aux, 0, 0};
         break;
+      case DEMI_OP_CRASH: /* the receive throws (V/Instrumenter.scala:184-199): recorded as the last effect, rows stop */
+        if (++n_fx_rows > DEMI_FX_CAP) return -1;
+        if (nfx >= fx_cap) return -1;
+        fx[nfx++] = (orc_effect){4, (uint8_t)me, 0, 0, 0};
+        pc = m->code_len;
+        break;
       default: break;
     }
   }
@@ -306,6 +314,7 @@ typedef struct {
   orc_jrandom rng;
   uint64_t state[DEMI_MAX_ACTORS];
   uint32_t exists, inaccessible, killed;
+  uint32_t blocked;     /* Instrumenter().blockedActors (crashed actors), V/Instrumenter.scala:116, 184-199 */
   uint64_t partitioned; /* bit a*8+b : ordered pair (a,b), V/schedulers/EventOrchestrator.scala:51 */
   uint32_t trace_idx;
   pend_entry pend[PEND_HARD_CAP]; /* RandomizedHashSet.arr, V/schedulers/Util.scala:112 (SrcDstFIFO: timersAndExternals) */
@@ -493,6 +502,7 @@ static void inject_until_quiescence(exec_t* x) {
         rec_push(x, DEMI_REC_SPAWN, 0, e->a, 0, 0, 0, 0, idx, 0);
         x->inaccessible &= ~(1u << e->a);
         x->killed &= ~(1u << e->a);
+        x->blocked &= ~(1u << e->a);     /* "allow scheduler to send messages to it again" (:224-227) */
         break;
       case DEMI_EV_KILL: /* trigger_kill :233-241 */
         rec_push(x, DEMI_REC_KILL, 0, e->a, 0, 0, 0, 0, idx, 0);
@@ -549,8 +559,27 @@ static void deliver(exec_t* x, uint32_t word) {
       case 1: register_cancellable(x, 0, me, fx[i].msg_type); break;
       case 2: register_cancellable(x, 1, me, fx[i].msg_type); break;
       case 3: cancel_timer(x, me, fx[i].msg_type); break;
+      case 4: x->blocked |= 1u << me; break;    /* actorCrashed: blockedActors += name */
     }
   }
+}
+
+/* Util.find_non_blocked_message (V/schedulers/Util.scala:470-489) over a RandomizedHashSet: draw until the receiver is
+ * not blocked; the rejected elements are re-appended in draw order (which permutes arr).  Returns 0 when every pending
+ * message is for a blocked actor (all of them re-appended, `None`). */
+static int find_non_blocked(exec_t* x, orc_jrandom* rng, pend_entry* out) {
+  pend_entry rejected[PEND_HARD_CAP];
+  uint32_t n_rej = 0;
+  int found = 0;
+  while (x->n_pend > 0) {
+    pend_entry e = pend_remove_at(x, (uint32_t)orc_jrandom_next_int_bound(rng, (int32_t)x->n_pend));
+    if ((x->blocked >> W_DST(e.word)) & 1) { rejected[n_rej++] = e; continue; }
+    *out = e;
+    found = 1;
+    break;
+  }
+  for (uint32_t i = 0; i < n_rej; i++) x->pend[x->n_pend++] = rejected[i];      /* collection ++= blocked */
+  return found;
 }
 
 /* RandomScheduler.schedule_new_message (V/schedulers/RandomScheduler.scala:352-485) fused with the
@@ -573,21 +602,27 @@ static int schedule_new_message(exec_t* x) {
   if (x->n_pend + x->n_norm == 0) return 0;                     /* find_non_blocked_message, Util.scala:474 */
   pend_entry e;
   if (!x->fifo) {
-    /* FullyRandom.removeRandomElement (:666-684) -> RandomizedHashSet.removeRandomElement
-       (V/schedulers/Util.scala:171-176); blockedActors is empty (no crashes / ask in the model). */
-    uint32_t idx = (uint32_t)orc_jrandom_next_int_bound(&x->rng, (int32_t)x->n_pend);
-    e = pend_remove_at(x, idx);
-  } else if (x->n_pairs == 0) {
-    /* SrcDstFIFO.getNonBlockedMessage (:716-729): only timers / externals left */
-    e = pend_remove_at(x, (uint32_t)orc_jrandom_next_int_bound(&x->te_rng, (int32_t)x->n_pend));
+    /* Util.find_non_blocked_message over FullyRandom.removeRandomElement (:443-458, :666-684) ->
+       RandomizedHashSet.removeRandomElement (V/schedulers/Util.scala:171-176) */
+    if (!find_non_blocked(x, &x->rng, &e)) return 0;
   } else {
-    /* (:731-759) first decide whether to deliver a timer / external, in proportion to their share */
-    int timer = 0;
-    if ((uint32_t)orc_jrandom_next_int_bound(&x->rng, (int32_t)(x->n_pend + x->n_norm)) < x->n_pend) {
-      e = pend_remove_at(x, (uint32_t)orc_jrandom_next_int_bound(&x->te_rng, (int32_t)x->n_pend));
-      timer = 1;
+    /* SrcDstFIFO.getNonBlockedMessage (:716-760) */
+    int open_pair = 0;                      /* a pair queue whose receiver is not blocked */
+    for (uint32_t i = 0; i < x->n_pairs; i++) open_pair |= !((x->blocked >> (x->pairs[i] & 7)) & 1);
+    if (!open_pair) {
+      /* (:717-729) "only timers left" */
+      if (!find_non_blocked(x, &x->te_rng, &e)) return 0;
+    } else {
+      /* (:731-759) first decide whether to deliver a timer / external, in proportion to their share */
+      int timer = 0;
+      if ((uint32_t)orc_jrandom_next_int_bound(&x->rng, (int32_t)(x->n_pend + x->n_norm)) < x->n_pend)
+        timer = find_non_blocked(x, &x->te_rng, &e);
+      if (!timer) {
+        uint32_t pi = (uint32_t)orc_jrandom_next_int_bound(&x->rng, (int32_t)x->n_pairs);
+        while ((x->blocked >> (x->pairs[pi] & 7)) & 1) pi = (uint32_t)orc_jrandom_next_int_bound(&x->rng, (int32_t)x->n_pairs);
+        e = fifo_dequeue(x, pi);
+      }
     }
-    if (!timer) e = fifo_dequeue(x, (uint32_t)orc_jrandom_next_int_bound(&x->rng, (int32_t)x->n_pairs));
   }
   x->count++;                                                   /* :462 */
   uint32_t w = e.word;
@@ -730,6 +765,7 @@ typedef struct {
   const demi_model* m;
   uint64_t state[DEMI_MAX_ACTORS];
   uint32_t exists, inaccessible, killed;
+  uint32_t blocked;   /* crashed actors (Instrumenter().blockedActors): an expected delivery to one is not "pending" (:392-402) */
   uint64_t partitioned;
   sts_pend pend[PEND_HARD_CAP];   /* pendingEvents: (snd,rcv) -> fingerprint -> FIFO; seq keeps FIFO order */
   uint32_t n_pend, p_max, next_seq;
@@ -827,6 +863,8 @@ static void sts_deliver(sts_t* x, uint32_t w) {
         }
         break;
       }
+      case 4: { x->blocked |= 1u << me; /* actorCrashed (V/Instrumenter.scala:184-199) */
+      }
     }
   }
   sts_flush(x); /* schedule_new_message begins with send_external_messages (:655) */
@@ -882,7 +920,7 @@ static int sts_replay_in(sts_t* x, const demi_model* m, const demi_ext_event* ex
         cur++;
         CUR_SKIP();
         if (kept) kept[idx] = 1;
-        if (e->kind == DEMI_REC_SPAWN) { x->inaccessible &= ~(1u << a); x->killed &= ~(1u << a); }
+        if (e->kind == DEMI_REC_SPAWN) { x->inaccessible &= ~(1u << a); x->killed &= ~(1u << a); x->blocked &= ~(1u << a); }
         else if (e->kind == DEMI_REC_KILL) { x->killed |= 1u << a; x->inaccessible |= 1u << a; }
         else if (e->kind == DEMI_REC_PARTITION) x->partitioned |= 1ULL << (a * 8 + b);
         else x->partitioned &= ~(1ULL << (a * 8 + b));
@@ -900,7 +938,7 @@ static int sts_replay_in(sts_t* x, const demi_model* m, const demi_ext_event* ex
         if (idx == skip) break;             /* the delivery this candidate removes */
         if (s != 255 && !IN_MASK(s)) break; /* pruned together with its Send */
         uint32_t w = msg_word(e->msg_type, e->snd, e->rcv, e->p0, e->p1);
-        int k = sts_pend_find(x, w);
+        int k = ((x->blocked >> e->rcv) & 1) ? -1 : sts_pend_find(x, w);   /* messagePending: "double check that the destination isn't currently blocked" (:392-402) */
         if (k < 0) { x->ignored++; break; } /* "Ignoring message" (:528-529) */
         sts_pend_remove(x, k);
         if (kept) kept[idx] = 1;
@@ -1025,6 +1063,7 @@ typedef struct {
   const demi_dpor_params* par;
   uint64_t state[DEMI_MAX_ACTORS];
   uint32_t isolated;
+  uint32_t blocked;    /* crashed actors: skipped by getPendingEvent (:455) and by getMatchingMessage (:478, 518) */
   dpor_pend pend[PEND_HARD_CAP];
   uint32_t n_pend, p_max, next_seq;
   int marker_pending;        /* the (SCHEDULER, SCHEDULER) queue holds at most one marker */
@@ -1124,6 +1163,7 @@ static void dpor_deliver(dpor_t* x, uint32_t w) {
         if (best >= 0) { x->pend[best] = x->pend[x->n_pend - 1]; x->n_pend--; }
         break;
       }
+      case 4: x->blocked |= 1u << me; break;   /* actorCrashed (V/Instrumenter.scala:184-199) */
     }
   }
 }
@@ -1163,14 +1203,17 @@ int orc_dpor_execute(const demi_model* m, const demi_ext_event* ext, uint32_t n_
         if (x->marker_pending && want == DPOR_MARKER_KEY(x->marker_ext)) chose_marker = 1;
         else {
           for (uint32_t k = 0; k < x->n_pend; k++)
-            if (dpor_key_of(x, &x->pend[k]) == want && (chosen < 0 || x->pend[k].seq < x->pend[chosen].seq)) chosen = (int)k;
+            if (dpor_key_of(x, &x->pend[k]) == want && !((x->blocked >> W_DST(x->pend[k].word)) & 1) &&
+                (chosen < 0 || x->pend[k].seq < x->pend[chosen].seq)) chosen = (int)k;
         }
       } while (par->prioritize_pending && chosen < 0 && !chose_marker);
     }
     if (!none && chosen < 0 && !chose_marker) {
       /* divergent / first run / awaiting quiescence: getPendingEvent (:452-472), pinned order */
-      for (uint32_t k = 0; k < x->n_pend; k++)
+      for (uint32_t k = 0; k < x->n_pend; k++) {
+        if ((x->blocked >> W_DST(x->pend[k].word)) & 1) continue;       /* !(blockedActors contains k._2) (:455) */
         if (chosen < 0 || dpor_cmp_queue(&x->pend[k], &x->pend[chosen]) < 0) chosen = (int)k;
+      }
       if (chosen < 0 && x->marker_pending) chose_marker = 1;
       if (chosen < 0 && !chose_marker) none = 1;
     }
