@@ -22,8 +22,8 @@ struct DevModel {
   uint32_t handler_start[DEMI_MAX_CLASSES * DEMI_MAX_MSG_TYPES];  // 0xFFFF = ignored
   uint32_t actor_class[DEMI_MAX_ACTORS];
   uint64_t init_state[DEMI_MAX_ACTORS];
-  uint32_t divmagic[129];  // ceil(2^(31+L)/d), L = ceil(log2 d): exact floor(r/d) for r < 2^31
-  uint32_t pad3;
+  uint32_t divmagic[257];  // ceil(2^(31+L)/d), L = ceil(log2 d): exact floor(r/d) for r < 2^31 (d <= 128: the pending
+  uint32_t pad3;           //  set's nextInt; d <= 255: DEMI_OP_RND bounds)
   uint32_t optab[64];      // per-op control words (sim_core.hpp op_control), filled by the host
   uint32_t code[DEMI_MAX_CODE];
 };
@@ -46,7 +46,7 @@ __device__ __forceinline__ uint32_t jr_next31(uint64_t& s) {
   s = (s * 0x5DEECE66DULL + 0xBULL) & ((1ULL << 48) - 1);
   return (uint32_t)(s >> 17);
 }
-// nextInt(bound), 1 <= bound <= 128: power-of-two fast path, else modulo with the rejection loop;
+// nextInt(bound), 1 <= bound <= 256: power-of-two fast path, else modulo with the rejection loop;
 // floor(r / bound) by multiply-high with a precomputed magic (no integer divide on the GPU).
 __device__ __forceinline__ uint32_t jr_next_int(uint64_t& s, uint32_t bound, const uint32_t* magic) {
   uint32_t r = jr_next31(s);

@@ -38,7 +38,7 @@ inline std::string generate_vm(const demi::DevModel& h) {
   // effect rows are recorded into the LDS effect queue in program order, exactly as vm_run does
   s += "#define DEMI_FX(OP, TYPE, TGT, P0, P1) { if (nfx >= DEMI_FX_CAP) { flags |= DEMI_V_QUEUE_OVF; goto done; } "
        "mem.fxq[nfx * 64] = fx_pack(OP, TYPE, TGT, P0, P1); nfx++; }\n";
-  s += "__device__ inline uint32_t vm_run_jit(const Tables& t, const LaneMem& mem, uint32_t w, uint32_t& flags) {\n";
+  s += "__device__ inline uint32_t vm_run_jit(const Tables& t, const LaneMem& mem, uint32_t w, uint32_t& flags, uint64_t& app_rng) {\n";
   s += "  const uint32_t type = w_type(w), me = w_dst(w);\n";
   s += "  const uint32_t entry = t.hs[((t.ac_packed >> (4 * me)) & 15u) * t.NT + type];\n";
   s += "  if (entry == 0xFFFFu) return 0;\n";
@@ -88,7 +88,7 @@ inline std::string generate_vm(const demi::DevModel& h) {
     if (len == 0 || len > ifconv || pc + 1 + len > h.code_len) continue;
     bool ok = true;
     for (uint32_t q = pc + 1; q <= pc + len && ok; q++)
-      ok = (op_control(h.code[q] & 0x3Fu) & CW_ALU) && !is_target[q] && pred_of[q] < 0;
+      ok = (op_control(h.code[q] & 0x3Fu) & CW_ALU) && !(op_control(h.code[q] & 0x3Fu) & CW_RND) && !is_target[q] && pred_of[q] < 0;
     if (!ok) continue;
     for (uint32_t q = pc + 1; q <= pc + len; q++) pred_of[q] = (int32_t)pc;
   }
@@ -130,6 +130,7 @@ inline std::string generate_vm(const demi::DevModel& h) {
         case DEMI_OP_POPC: snprintf(val, sizeof val, "(uint32_t)__popc(%s)", b); break;
         case DEMI_OP_MIN: snprintf(val, sizeof val, "%s < %s ? %s : %s", a, b, a, b); break;
         case DEMI_OP_MAX: snprintf(val, sizeof val, "%s < %s ? %s : %s", a, b, b, a); break;
+        case DEMI_OP_RND: snprintf(val, sizeof val, "app_next_int(app_rng, %s, t.magic)", b); break;
         default: snprintf(val, sizeof val, "(%s %s %s) ? 1u : 0u", a, relop[op - DEMI_OP_EQ], b); break;   // EQ .. GT
       }
       if (pred_of[pc] >= 0) emit("%s = c%d ? (%s) : %s;\n", d, pred_of[pc], val, d);

@@ -179,6 +179,7 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
   int ph = PH_IDLE;
   bool fresh = false;
   uint64_t sched = 0, rng = 0, hash = 0;
+  uint64_t app_rng = 0;               // Instrumenter().seededRandom: scala.util.Random(0), new with every execution (DEMI_OP_RND)
   uint32_t n_pend = 0, count = 0, cnt_mod = 0, tidx = 0, inj_lo = 0, inj_hi = 0, batch_no = 0;
   uint32_t fl_off = 0, fl_cnt = 0;    // !REC: the injected batch's Sends as a range of s_bsend, flushed by the whole wave
   // SrcDstFIFO: n_pend counts timersAndExternals, n_norm the actor-to-actor messages, n_pairs = srcDsts.size,
@@ -191,6 +192,13 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
   uint32_t just = 0, rep = 0;         // justScheduledTimers / registered repeating timers (bit rcv*4+tidx)
   uint32_t viol = 0, flags = 0;
   uint32_t blocked = 0;               // Instrumenter().blockedActors: actors that crashed (DEMI_OP_CRASH) and were not Start()ed since
+  // a specialised build knows whether the table has a CRASH row at all (jit: DEMI_JIT_NO_CRASH): without one `blocked` is
+  // provably 0 and the find_non_blocked_message path below is not even compiled
+#ifdef DEMI_JIT_NO_CRASH
+  constexpr bool CRASHES = false;
+#else
+  constexpr bool CRASHES = true;
+#endif
   uint32_t hits = 0;                  // invariant "hit" mask of the actors (demi_device.hpp invariant_hit), kept up to date per delivery
   uint64_t tmask = 0;
   uint32_t next_id = 1, n_rec = 0;    // REC only
@@ -332,6 +340,7 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
         const uint64_t seed = args.seeds ? args.seeds[sched] : args.seed_base + sched;
         rng = jr_seed(seed);
         te_rng = rng;                  // SrcDstFIFO: both generators are `new Random(seed)`
+        app_rng = jr_seed(0);
         hash = 0xCBF29CE484222325ULL;
         net.inaccessible = exists; net.killed = 0; net.partitioned = 0;
         blocked = 0;
@@ -485,7 +494,7 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
         }
       };
       bool picked = false;          // the message was already chosen (and removed) by the blocked-actor path
-      if (!none && blocked != 0) {
+      if (CRASHES && !none && blocked != 0) {
         // Some actor crashed: Util.find_non_blocked_message (Util.scala:470-489).  Draw until the receiver is not blocked;
         // what was drawn for a blocked actor is set aside and re-appended afterwards in draw order - which permutes
         // arr, so it is replayed literally.  Rare (only executions with a crashed actor come here), hence simple.
@@ -611,7 +620,7 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
     PH_MARK(4);
     // ------------------------------------------------------------ the receiver's handler rows
     uint32_t nfx = 0;
-    if (deliver) nfx = DEMI_VM_RUN(t, mem, w, flags);
+    if (deliver) nfx = DEMI_VM_RUN(t, mem, w, flags, app_rng);
     if (deliver) {      // the receiver's new state decides its bit of the invariant's hit mask
       const uint32_t me_ = w_dst(w);
       hits = (hits & ~(1u << me_)) | (invariant_hit(st[me_ * 64], inv_kind, inv_fa, inv_va) << me_);
@@ -725,7 +734,7 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
         const uint32_t op = fx & 31u, type = (fx >> 5) & 31u;
         PH_MARK(9);
         if (op <= DEMI_OP_BCAST) { apply_send(fx); PH_MARK(6); }
-        else if (op == DEMI_OP_CRASH) blocked |= 1u << me;        // actorCrashed (Instrumenter.scala:184-199)
+        else if (op == DEMI_OP_CRASH) { if (CRASHES) blocked |= 1u << me; }   // actorCrashed (Instrumenter.scala:184-199)
         else if (op == DEMI_OP_TCANCEL) { apply_cancel(type); PH_MARK(7); }
         else { apply_timer_set(op == DEMI_OP_TREP, type); PH_MARK(8); }
       }

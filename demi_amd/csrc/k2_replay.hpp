@@ -159,6 +159,7 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
   bool active = false, fresh = false;
   uint64_t sched = 0, hash = 0;
   uint64_t m0 = 0, m1 = 0, m2 = 0, m3 = 0;   // candidate mask
+  uint64_t app_rng = 0;                      // Instrumenter().seededRandom, restarted with every replay (DEMI_OP_RND)
   uint32_t idx = 0, cur = 0, n_pend = 0, count = 0, ignored = 0, flags = 0, rep = 0, skip = 0xFFFFFFFFu;
   uint32_t blocked = 0;     // crashed actors (DEMI_OP_CRASH): an expected delivery to one is not "pending" (STSScheduler.scala:392-402)
   Net net = {0, 0, 0};
@@ -233,6 +234,7 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
         }
         skip = args.skip ? args.skip[sched] : 0xFFFFFFFFu;
         hash = 0xCBF29CE484222325ULL;
+        app_rng = jr_seed(0);
         net.inaccessible = exists; net.killed = 0; net.partitioned = 0;
         for (uint32_t a = 0; a < A; a++) st[a * 64] = t.init[a];
         if (FP) for (uint32_t f = 0; f < args.n_fp; f++) cnt[(size_t)f * cnt_stride] = 0;
@@ -307,7 +309,7 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
     }
 
     uint32_t nfx = 0;
-    if (deliver) nfx = DEMI_VM_RUN(t, mem, w, flags);
+    if (deliver) nfx = DEMI_VM_RUN(t, mem, w, flags, app_rng);
 
     if (deliver) {
       const uint32_t me = w_dst(w);

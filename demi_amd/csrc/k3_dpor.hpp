@@ -184,6 +184,7 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
 
   bool active = false, fresh = false;
   uint64_t sched = 0, hash = 0;
+  uint64_t app_rng = 0;     // Instrumenter().seededRandom, restarted with every interleaving (DEMI_OP_RND)
   demi_dpor_trace_entry* tr = nullptr;
   const demi_dpor_trace_entry* pf = nullptr;
   uint32_t pfx = 0, pfx_len = 0;
@@ -277,6 +278,7 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
         }
         pfx = 0;
         hash = 0xCBF29CE484222325ULL;
+        app_rng = jr_seed(0);
         isolated = (1u << A) - 1;      // maybeStartActors: every actor exists and is isolated (:666-679)
         for (uint32_t a = 0; a < A; a++) st[a * 64] = t.init[a];
         n_pend = 0; next_seq = 0; qperiod = 0; next_qperiod = 0; rep = 0; flags = 0; count = 0; deliveries = 0; blocked = 0;
@@ -371,7 +373,7 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
     }
 
     uint32_t nfx = 0;
-    if (deliver) nfx = DEMI_VM_RUN(t, mem, w, flags);
+    if (deliver) nfx = DEMI_VM_RUN(t, mem, w, flags, app_rng);
     if (deliver) {
       const uint32_t me = w_dst(w);
       for (uint32_t k = 0; k < nfx && !(flags & DEMI_OVF_ANY); k++) {

@@ -30,7 +30,8 @@ enum : uint32_t {
   CW_IF = 1u << 14,      // fused guard: skip aux rows unless the relation holds
   CW_SKIPZ = 1u << 15, CW_SKIPNZ = 1u << 16, CW_SKIP = 1u << 17,
   CW_FX = 1u << 18, CW_HALT = 1u << 19,
-  CW_REL_SHIFT = 20      // bits 20..22: accepted relations {lt, eq, gt} of compare / guard rows
+  CW_REL_SHIFT = 20,     // bits 20..22: accepted relations {lt, eq, gt} of compare / guard rows
+  CW_RND = 1u << 23      // dst = seededRandom.nextInt(b)
 };
 
 inline uint32_t op_control(uint32_t op) {   // host side: fills DevModel::optab
@@ -55,6 +56,7 @@ inline uint32_t op_control(uint32_t op) {   // host side: fills DevModel::optab
   if (op == DEMI_OP_SKIP) return CW_SKIP;
   if (op >= DEMI_OP_SEND && op <= DEMI_OP_TCANCEL) return CW_FX;
   if (op == DEMI_OP_CRASH) return CW_FX | CW_HALT;     // recorded as the delivery's last effect, then the rows stop
+  if (op == DEMI_OP_RND) return CW_ALU | CW_RND;
   if (op >= DEMI_OP_IFEQ && op <= DEMI_OP_IFGT) return CW_IF | (rels[op - DEMI_OP_IFEQ] << CW_REL_SHIFT);
   return CW_HALT;   // unknown ops are rejected by validation
 }
@@ -66,7 +68,7 @@ struct Tables {
   const uint32_t* code;   // [code_len] transition-table rows
   const uint32_t* hs;     // [n_classes * NT] handler starts
   const uint32_t* meta;   // [32] msg_class | timer_idx << 8
-  const uint32_t* magic;  // [129] nextInt multiply-high magics
+  const uint32_t* magic;  // [257] nextInt multiply-high magics
   const uint32_t* optab;  // [64] per-op control words (op_control)
   uint32_t A, NT, code_len, E, exists, ac_packed;
   uint32_t inv_kind, inv_fa, inv_va, inv_fb, fp_mask;
@@ -74,7 +76,7 @@ struct Tables {
 
 __host__ __device__ inline size_t tables_lds_bytes(uint32_t code_len, uint32_t n_ev, uint32_t n_hs) {
   size_t b = (size_t)n_ev * 8 + DEMI_MAX_ACTORS * 8 + (size_t)code_len * 4 + (size_t)n_hs * 4 +
-             DEMI_MAX_MSG_TYPES * 4 + 132 * 4 + 64 * 4;
+             DEMI_MAX_MSG_TYPES * 4 + 260 * 4 + 64 * 4;
   return (b + 15) & ~(size_t)15;
 }
 
@@ -92,13 +94,13 @@ __device__ inline unsigned char* tables_load(Tables& t, unsigned char* smem, con
   uint32_t* s_hs = s_code + t.code_len;
   uint32_t* s_meta = s_hs + n_hs;
   uint32_t* s_magic = s_meta + DEMI_MAX_MSG_TYPES;
-  uint32_t* s_optab = s_magic + 132;
+  uint32_t* s_optab = s_magic + 260;
   for (uint32_t i = threadIdx.x; i < n_ev; i += blockDim.x) s_trace[i] = g_trace[i];
   for (uint32_t i = threadIdx.x; i < DEMI_MAX_ACTORS; i += blockDim.x) s_init[i] = gm->init_state[i];
   for (uint32_t i = threadIdx.x; i < t.code_len; i += blockDim.x) s_code[i] = gm->code[i];
   for (uint32_t i = threadIdx.x; i < n_hs; i += blockDim.x) s_hs[i] = gm->handler_start[i];
   for (uint32_t i = threadIdx.x; i < DEMI_MAX_MSG_TYPES; i += blockDim.x) s_meta[i] = gm->meta[i];
-  for (uint32_t i = threadIdx.x; i < 129; i += blockDim.x) s_magic[i] = gm->divmagic[i];
+  for (uint32_t i = threadIdx.x; i < 257; i += blockDim.x) s_magic[i] = gm->divmagic[i];
   for (uint32_t i = threadIdx.x; i < 64; i += blockDim.x) s_optab[i] = gm->optab[i];
   t.ac_packed = 0;
   for (uint32_t a = 0; a < t.A; a++) t.ac_packed |= gm->actor_class[a] << (4 * a);
@@ -145,9 +147,19 @@ __device__ inline LaneMem lane_mem_carve(unsigned char* wave_base, uint32_t n_ac
   m.pend_aux = aux ? p + lane : nullptr;
   if (aux) p += (size_t)hot * 64;
   m.fxq = p + lane;
+#ifdef DEMI_SPILL_LANE_MAJOR
+  // one [slot][lane] matrix over every lane of the launch (slot stride = all lanes): the layout of rounds 1-2, kept for A/B runs
   m.spill = g_spill + global_lane;
   m.spill_aux = aux ? g_spill + spill_words(total_lanes, hot) + global_lane : nullptr;
   m.spill_stride = (uint32_t)total_lanes;
+#else
+  // one contiguous [slot][64] block per wave: a wave's pending sets stay inside (MAX_PENDING - hot) * 256 B of address space
+  // (one translation, neighbouring DRAM pages) instead of one 256 B row in each of MAX_PENDING launch-wide planes
+  const size_t block = (global_lane >> 6) * ((size_t)(DEMI_MAX_PENDING - hot) * 64);
+  m.spill = g_spill + block + lane;
+  m.spill_aux = aux ? g_spill + spill_words(total_lanes, hot) + block + lane : nullptr;
+  m.spill_stride = 64;
+#endif
   m.hot = hot;
   return m;
 }
@@ -191,7 +203,12 @@ __device__ __forceinline__ uint32_t mask_of(uint32_t cw, uint32_t bit_index) {
 // Runs the handler of message word `w` on its receiver.  State is read from / written to
 // mem.st; effect rows are recorded into mem.fxq.  Returns the number of recorded effect rows
 // (sets DEMI_V_QUEUE_OVF in flags when more than DEMI_FX_CAP would be recorded).
-__device__ inline uint32_t vm_run(const Tables& t, const LaneMem& mem, uint32_t w, uint32_t& flags) {
+// DEMI_OP_RND: the application's generator (Instrumenter().seededRandom, restarted at seed 0 by every execution)
+__device__ __forceinline__ uint32_t app_next_int(uint64_t& app_rng, uint32_t bound, const uint32_t* magic) {
+  return bound == 0 ? 0u : jr_next_int(app_rng, bound, magic);
+}
+
+__device__ inline uint32_t vm_run(const Tables& t, const LaneMem& mem, uint32_t w, uint32_t& flags, uint64_t& app_rng) {
   const uint32_t type = w_type(w), me = w_dst(w);
   uint32_t pc = t.hs[((t.ac_packed >> (4 * me)) & 15u) * t.NT + type];
   if (pc == 0xFFFFu) return 0;
@@ -229,6 +246,7 @@ __device__ inline uint32_t vm_run(const Tables& t, const LaneMem& mem, uint32_t 
     r |= cond & mask_of(cw, 10);                                                                  // EQ..GT
     const uint32_t mn = mask_of(cw, 12);                 // MIN: b ^ ((a^b) & lt)   MAX: a ^ ((a^b) & lt)
     r |= (((b & mn) | (a & ~mn)) ^ ((a ^ b) & ltm)) & mask_of(cw, 11);
+    if (cw & CW_RND) r = app_next_int(app_rng, b, t.magic);                                       // RND (rare: a real branch)
     // ---- write-back, branch-free: insert byte r into word dsti>>2 when the row is an ALU row
     const uint32_t k8 = (dsti & 3u) * 8u;
     const uint32_t ins = 0x03020100u ^ ((((dsti & 3u) ^ 4u)) << k8);         // selector: byte k := S0.byte0

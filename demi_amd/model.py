@@ -29,7 +29,7 @@ SRC, ME = Reg(14), Reg(15)              # sender id (15 = deadLetters), own id
 
 OPS = dict(HALT=0, MOV=1, ADD=2, SUB=3, AND=4, OR=5, XOR=6, SHL=7, SHR=8, BITSET=9, POPC=10,
            EQ=11, NE=12, LT=13, GE=14, LE=15, GT=16, MIN=17, MAX=18, SKIPZ=20, SKIPNZ=21, SKIP=22,
-           SEND=24, BCAST=25, TSET=26, TREP=27, TCANCEL=28, CRASH=29, IFEQ=32, IFNE=33, IFLT=34, IFGE=35, IFLE=36, IFGT=37)
+           SEND=24, BCAST=25, TSET=26, TREP=27, TCANCEL=28, CRASH=29, RND=30, IFEQ=32, IFNE=33, IFLT=34, IFGE=35, IFLE=36, IFGT=37)
 
 
 def row(op, dst=0, a=0, bimm=0, aux=0, b=0):
@@ -60,6 +60,13 @@ class Asm:
     def mov(self, dst, b):
         bimm, bv = self._b(b)
         self.rows.append(row(OPS["MOV"], int(dst), 0, bimm, 0, bv))
+        return self
+
+    def rnd(self, dst, bound):
+        """dst = Instrumenter().seededRandom.nextInt(bound): the application's own generator (restarts at seed 0 with every
+        execution); bound 1..255, an immediate or a register."""
+        bimm, bv = self._b(bound)
+        self.rows.append(row(OPS["RND"], int(dst), 0, bimm, 0, bv))
         return self
 
     def popc(self, dst, b):

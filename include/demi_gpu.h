@@ -100,12 +100,17 @@ typedef enum {
   DEMI_OP_TSET = 26,    /* scheduler.scheduleOnce(self, msg type aux)                          */
   DEMI_OP_TREP = 27,    /* scheduler.schedule(self, msg type aux)  (repeating)                 */
   DEMI_OP_TCANCEL = 28, /* cancellable.cancel() of timer (self, type aux)                      */
-  DEMI_OP_CRASH = 29    /* the receive throws: Instrumenter.actorCrashed (Instrumenter.scala:184-199).  The handler
+  DEMI_OP_CRASH = 29,   /* the receive throws: Instrumenter.actorCrashed (Instrumenter.scala:184-199).  The handler
                            stops here (state changes and effects so far stand) and the actor joins blockedActors: the
                            schedulers no longer deliver to it (Util.find_non_blocked_message, Util.scala:470-489: a
                            drawn message for a blocked receiver is set aside, the draw repeated, and the rejected
                            ones re-appended in draw order) until a Start() of the same name (EventOrchestrator
                            trigger_start :219-231).  Counts as an effect row.                                      */
+  DEMI_OP_RND = 30      /* dst = Instrumenter().seededRandom.nextInt(b), b = bound 1..255 (0: dst = 0, nothing drawn).
+                           Applications draw their randomness (akka-raft: election timeouts) from this generator, a
+                           scala.util.Random(0) - the same JDK LCG - recreated with every ActorSystem, i.e. a second
+                           deterministic stream that restarts at seed 0 in every execution (Instrumenter.scala:212,
+                           226-229, 570).                                                                          */
 } demi_op;
 
 #define DEMI_ROW(op, dst, a, bimm, aux, b) \
@@ -144,7 +149,16 @@ typedef struct {
   uint32_t looking_for;               /* target fingerprint code */
   uint32_t populate_all;              /* setActorNamePropPairs: create all actors, not only Start()ed ones */
   uint32_t strategy;                  /* RandomizationStrategy (RandomScheduler.scala:614-633): demi_strategy */
+  uint32_t filter_known_absents;      /* replays only: SchedulerConfig.filterKnownAbsents (SchedulerConfig.scala:14) ->
+                                         EventTrace.filterKnownAbsentInternals (EventTrace.scala:458-534): demi_filter_absents */
 } demi_limits;
+
+/* EventTrace.filterKnownAbsentInternals drops from the projected trace every internal MsgSend whose sender is not alive or
+ * is "partitioned" from the receiver, the MsgEvents of those sends, and every MsgEvent whose receiver is not alive or is
+ * "partitioned" from the sender.  The reference's partition bookkeeping is inverted (EventTrace.scala:523-528: a
+ * PartitionEvent stores false, an UnPartitionEvent true, under the ordered pair of the event): LITERAL reproduces exactly
+ * that, CORRECTED treats a pair as cut off between Partition and UnPartition, in either direction. */
+typedef enum { DEMI_FILTER_ABSENTS_OFF = 0, DEMI_FILTER_ABSENTS_LITERAL = 1, DEMI_FILTER_ABSENTS_CORRECTED = 2 } demi_filter_absents;
 
 /* The pending-message container of RandomScheduler.
  * FULLY_RANDOM: FullyRandom (RandomScheduler.scala:635-697), one RandomizedHashSet seeded with the execution's seed.

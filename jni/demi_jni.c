@@ -25,6 +25,7 @@ static demi_limits limits_of(const jint* l) {
   demi_limits x;
   x.max_messages = (uint32_t)l[0]; x.invariant_check_interval = (uint32_t)l[1]; x.p_max = (uint32_t)l[2];
   x.looking_for_valid = (uint32_t)l[3]; x.looking_for = (uint32_t)l[4]; x.populate_all = (uint32_t)l[5]; x.strategy = (uint32_t)l[6];
+  x.filter_known_absents = (uint32_t)l[7];
   return x;
 }
 static demi_dpor_params dpor_params_of(const jint* p) {

@@ -94,7 +94,7 @@ int orc_model_validate(const demi_model* m, char* err, size_t err_cap) {
       case DEMI_OP_HALT: case DEMI_OP_MOV: case DEMI_OP_ADD: case DEMI_OP_SUB: case DEMI_OP_AND:
       case DEMI_OP_OR: case DEMI_OP_XOR: case DEMI_OP_SHL: case DEMI_OP_SHR: case DEMI_OP_BITSET:
       case DEMI_OP_POPC: case DEMI_OP_EQ: case DEMI_OP_NE: case DEMI_OP_LT: case DEMI_OP_GE:
-      case DEMI_OP_LE: case DEMI_OP_GT: case DEMI_OP_MIN: case DEMI_OP_MAX:
+      case DEMI_OP_LE: case DEMI_OP_GT: case DEMI_OP_MIN: case DEMI_OP_MAX: case DEMI_OP_RND:
         break;
       case DEMI_OP_SKIPZ: case DEMI_OP_SKIPNZ: case DEMI_OP_SKIP:
         if (!bimm) FAIL("row %u: skip distance must be an immediate", pc);
@@ -166,7 +166,7 @@ int orc_trace_validate(const demi_model* m, const demi_ext_event* ev, uint32_t n
  * format).  Effects are returned in program order; the scheduler applies them in that order,
  * as Akka would call `!` / scheduleOnce / cancel inside receive (WeaveActor.aj:224-279).       */
 int orc_vm_run(const demi_model* m, uint32_t me, uint64_t* state, uint8_t msg_type, uint8_t src,
-               uint8_t p0, uint8_t p1, uint32_t exists_mask, orc_effect* fx, uint32_t fx_cap) {
+               uint8_t p0, uint8_t p1, uint32_t exists_mask, orc_effect* fx, uint32_t fx_cap, orc_jrandom* app) {
   uint32_t nfx = 0, n_fx_rows = 0;
   uint16_t start = m->handler_start[m->actor_class[me] * m->n_msg_types + msg_type];
   if (start == 0xFFFF) return 0;
@@ -201,6 +201,9 @@ int orc_vm_run(const demi_model* m, uint32_t me, uint64_t* state, uint8_t msg_ty
       case DEMI_OP_GT: r[dst] = a > b; break;
       case DEMI_OP_MIN: r[dst] = a < b ? a : b; break;
       case DEMI_OP_MAX: r[dst] = a > b ? a : b; break;
+      case DEMI_OP_RND: /* Instrumenter().seededRandom.nextInt(bound) (V/Instrumenter.scala:212, 226-229) */
+        r[dst] = b ? (uint8_t)orc_jrandom_next_int_bound(app, (int32_t)b) : 0;
+        break;
       case DEMI_OP_SKIPZ: if (a == 0) pc += braw; break;
       case DEMI_OP_SKIPNZ: if (a != 0) pc += braw; break;
       case DEMI_OP_SKIP: pc += braw; break;
@@ -327,6 +330,7 @@ typedef struct {
   uint8_t pairs[64];              /* srcDsts: src * 8 + dst, in queue-creation order */
   uint32_t n_pairs;
   orc_jrandom te_rng;             /* timersAndExternals' RandomizedHashSet generator */
+  orc_jrandom app_rng;            /* Instrumenter().seededRandom = scala.util.Random(0), new per ActorSystem (V/Instrumenter.scala:226-229) */
   mts_entry mts[MTS_CAP]; /* messagesToSend, V/schedulers/ExternalEventInjector.scala:109 */
   uint32_t n_mts;
   uint32_t n_mts_timers;  /* timers among them; capacity DEMI_TQ_CAP is part of the spec */
@@ -551,7 +555,7 @@ static void deliver(exec_t* x, uint32_t word) {
   uint32_t me = W_DST(word);
   orc_effect* fx = x->fx; /* DEMI_MAX_CODE rows x at most DEMI_MAX_ACTORS effects each: never full */
   int n = orc_vm_run(x->m, me, &x->state[me], (uint8_t)W_TYPE(word), (uint8_t)W_SRC(word), (uint8_t)W_P0(word),
-                     (uint8_t)W_P1(word), x->exists, fx, DEMI_MAX_CODE * DEMI_MAX_ACTORS);
+                     (uint8_t)W_P1(word), x->exists, fx, DEMI_MAX_CODE * DEMI_MAX_ACTORS, &x->app_rng);
   if (n < 0) { x->flags |= DEMI_V_QUEUE_OVF; return; }
   for (int i = 0; i < n; i++) {
     switch (fx[i].kind) {
@@ -657,6 +661,7 @@ static int random_execute_in(exec_t* x, const demi_model* m, const demi_ext_even
   if (x->p_max > PEND_HARD_CAP) x->p_max = PEND_HARD_CAP;
   orc_jrandom_seed(&x->rng, seed); /* new FullyRandom(seed = ...) / SrcDstFIFO.rand */
   orc_jrandom_seed(&x->te_rng, seed);
+  orc_jrandom_seed(&x->app_rng, 0);
   x->fifo = lim->strategy == DEMI_STRATEGY_SRC_DST_FIFO;
   /* populateActorSystem (V/schedulers/ExternalEventInjector.scala:371-378, 397-406):
      every actor that is ever Start()ed is created up front and isolated. */
@@ -766,6 +771,7 @@ typedef struct {
   uint64_t state[DEMI_MAX_ACTORS];
   uint32_t exists, inaccessible, killed;
   uint32_t blocked;   /* crashed actors (Instrumenter().blockedActors): an expected delivery to one is not "pending" (:392-402) */
+  orc_jrandom app_rng; /* Instrumenter().seededRandom, new with every replay */
   uint64_t partitioned;
   sts_pend pend[PEND_HARD_CAP];   /* pendingEvents: (snd,rcv) -> fingerprint -> FIFO; seq keeps FIFO order */
   uint32_t n_pend, p_max, next_seq;
@@ -834,7 +840,7 @@ static void sts_deliver(sts_t* x, uint32_t w) {
   if (m->msg_class[W_TYPE(w)] == DEMI_MSG_TIMER && (x->repeating & timer_bit(m, me, W_TYPE(w))))
     sts_handle_timer(x, me, W_TYPE(w));
   int n = orc_vm_run(m, me, &x->state[me], (uint8_t)W_TYPE(w), (uint8_t)W_SRC(w), (uint8_t)W_P0(w), (uint8_t)W_P1(w),
-                     x->exists, x->fx, DEMI_MAX_CODE * DEMI_MAX_ACTORS);
+                     x->exists, x->fx, DEMI_MAX_CODE * DEMI_MAX_ACTORS, &x->app_rng);
   if (n < 0) { x->flags |= DEMI_V_QUEUE_OVF; return; }
   for (int i = 0; i < n && !(x->flags & OVF_ANY); i++) {
     const orc_effect* e = &x->fx[i];
@@ -885,6 +891,7 @@ static int sts_replay_in(sts_t* x, const demi_model* m, const demi_ext_event* ex
    * V/minification/internal_minimization/OneAtATimeRemoval.scala:57-124); kept[i] = 1 iff rec[i] took effect
    * in the replay, i.e. is part of the executed trace test() returns (V/schedulers/STSScheduler.scala:286-292) */
   memset(x, 0, offsetof(sts_t, fx));
+  orc_jrandom_seed(&x->app_rng, 0);
   if (kept) memset(kept, 0, n_rec);
   x->m = m;
   x->p_max = lim->p_max ? lim->p_max : 64;
@@ -905,6 +912,22 @@ static int sts_replay_in(sts_t* x, const demi_model* m, const demi_ext_event* ex
     if (rec[i].kind == DEMI_REC_MSG_SEND && (rec[i].flags & 1) && rec[i].id < sizeof send_of_id)
       send_of_id[rec[i].id] = rec[i].ext_idx;
 
+  /* EventTrace.filterKnownAbsentInternals (EventTrace.scala:458-534), the last stage of the projection when
+   * SchedulerConfig.filterKnownAbsents is set.  actorToAlive: default false, deadLetters / Timer true, SpawnEvent true,
+   * KillEvent false.  actorsToPartitioned: default false, and as written PartitionEvent((a,b)) stores FALSE and
+   * UnPartitionEvent((a,b)) stores TRUE under the ordered key (a,b) (:523-528) - DEMI_FILTER_ABSENTS_LITERAL keeps that;
+   * _CORRECTED is the evident intent (cut off between Partition and UnPartition, either direction).  prunedMessageSends:
+   * ids of MsgSends that were not sendable; their MsgEvents go too.                                                   */
+  const uint32_t fka = lim->filter_known_absents;
+  uint32_t fk_alive = 0;
+  uint64_t fk_part = 0;
+  static _Thread_local uint8_t fk_pruned[DEMI_MAX_REC_EVENTS * 2];
+  if (fka) memset(fk_pruned, 0, sizeof fk_pruned);
+#define FK_ALIVE(who) ((who) >= DEMI_MAX_ACTORS ? 1u : ((fk_alive >> (who)) & 1u))
+#define FK_PART(s, r) (((s) >= DEMI_MAX_ACTORS || (r) >= DEMI_MAX_ACTORS) ? 0u                                       \
+                       : (fka == DEMI_FILTER_ABSENTS_LITERAL) ? (uint32_t)((fk_part >> ((s) * 8 + (r))) & 1u)         \
+                       : (uint32_t)(((fk_part >> ((s) * 8 + (r))) | (fk_part >> ((r) * 8 + (s)))) & 1u))
+
   /* cursor over the subsequence's non-Send externals (subsequenceIntersection :299-304) */
   uint32_t cur = 0;
 #define CUR_SKIP() while (cur < n_ext && (!IN_MASK(cur) || ext[cur].kind == DEMI_EV_SEND || \
@@ -924,9 +947,22 @@ static int sts_replay_in(sts_t* x, const demi_model* m, const demi_ext_event* ex
         else if (e->kind == DEMI_REC_KILL) { x->killed |= 1u << a; x->inaccessible |= 1u << a; }
         else if (e->kind == DEMI_REC_PARTITION) x->partitioned |= 1ULL << (a * 8 + b);
         else x->partitioned &= ~(1ULL << (a * 8 + b));
+        if (e->kind == DEMI_REC_SPAWN) fk_alive |= 1u << a;
+        else if (e->kind == DEMI_REC_KILL) fk_alive &= ~(1u << a);
+        else {
+          /* literal: Partition -> false, UnPartition -> true (sic); corrected: the other way round */
+          const int set = (fka == DEMI_FILTER_ABSENTS_LITERAL) ? (e->kind == DEMI_REC_UNPARTITION) : (e->kind == DEMI_REC_PARTITION);
+          if (set) fk_part |= 1ULL << (a * 8 + b); else fk_part &= ~(1ULL << (a * 8 + b));
+        }
         break;
       }
       case DEMI_REC_MSG_SEND:
+        /* filterKnownAbsentInternals: `if (messageSendable(m.sender, m.receiver)) result += event else prunedMessageSends += id`
+         * (an external MsgSend is from deadLetters: always sendable) */
+        if (fka && !(FK_ALIVE(e->snd) && !FK_PART(e->snd, e->rcv))) {
+          if (e->id < sizeof fk_pruned) fk_pruned[e->id] = 1;
+          break;
+        }
         /* external MsgSend: enqueue_message (:509-511) unless its Send was pruned; internal: nothing */
         if ((e->flags & 1) && IN_MASK(e->ext_idx) && ((x->exists >> e->rcv) & 1)) {
           sts_pend_add(x, msg_word(e->msg_type, DEMI_DEADLETTERS, e->rcv, e->p0, e->p1));
@@ -937,6 +973,8 @@ static int sts_replay_in(sts_t* x, const demi_model* m, const demi_ext_event* ex
         uint8_t s = e->id < sizeof send_of_id ? send_of_id[e->id] : 255;
         if (idx == skip) break;             /* the delivery this candidate removes */
         if (s != 255 && !IN_MASK(s)) break; /* pruned together with its Send */
+        /* filterKnownAbsentInternals: messageDeliverable(snd, rcv, id) or the event is not part of the projected trace */
+        if (fka && !(FK_ALIVE(e->rcv) && !FK_PART(e->snd, e->rcv) && !(e->id < sizeof fk_pruned && fk_pruned[e->id]))) break;
         uint32_t w = msg_word(e->msg_type, e->snd, e->rcv, e->p0, e->p1);
         int k = ((x->blocked >> e->rcv) & 1) ? -1 : sts_pend_find(x, w);   /* messagePending: "double check that the destination isn't currently blocked" (:392-402) */
         if (k < 0) { x->ignored++; break; } /* "Ignoring message" (:528-529) */
@@ -950,6 +988,8 @@ static int sts_replay_in(sts_t* x, const demi_model* m, const demi_ext_event* ex
   }
 #undef CUR_SKIP
 #undef IN_MASK
+#undef FK_ALIVE
+#undef FK_PART
   uint32_t viol = 0;
   if (!(x->flags & OVF_ANY)) {
     uint32_t fp = orc_invariant(m, x->state, x->exists);
@@ -1064,6 +1104,7 @@ typedef struct {
   uint64_t state[DEMI_MAX_ACTORS];
   uint32_t isolated;
   uint32_t blocked;    /* crashed actors: skipped by getPendingEvent (:455) and by getMatchingMessage (:478, 518) */
+  orc_jrandom app_rng; /* Instrumenter().seededRandom, new with every interleaving */
   dpor_pend pend[PEND_HARD_CAP];
   uint32_t n_pend, p_max, next_seq;
   int marker_pending;        /* the (SCHEDULER, SCHEDULER) queue holds at most one marker */
@@ -1142,7 +1183,7 @@ static void dpor_deliver(dpor_t* x, uint32_t w) {
   if (m->msg_class[W_TYPE(w)] == DEMI_MSG_TIMER && (x->repeating & timer_bit(m, me, W_TYPE(w))))
     dpor_produce(x, msg_word(W_TYPE(w), DEMI_DEADLETTERS, me, 0, 0)); /* retrigger -> enqueue_timer = `!` (Scheduler.scala:73) */
   int n = orc_vm_run(m, me, &x->state[me], (uint8_t)W_TYPE(w), (uint8_t)W_SRC(w), (uint8_t)W_P0(w), (uint8_t)W_P1(w),
-                     (1u << m->n_actors) - 1, x->fx, DEMI_MAX_CODE * DEMI_MAX_ACTORS);
+                     (1u << m->n_actors) - 1, x->fx, DEMI_MAX_CODE * DEMI_MAX_ACTORS, &x->app_rng);
   if (n < 0) { x->flags |= DEMI_V_QUEUE_OVF; return; }
   for (int i = 0; i < n && !(x->flags & OVF_ANY); i++) {
     const orc_effect* e = &x->fx[i];
@@ -1178,6 +1219,7 @@ int orc_dpor_execute(const demi_model* m, const demi_ext_event* ext, uint32_t n_
   if (x->p_max > PEND_HARD_CAP) x->p_max = PEND_HARD_CAP;
   x->hash = 0xCBF29CE484222325ULL;
   x->isolated = (1u << m->n_actors) - 1; /* maybeStartActors: isolatedActors ++= actorNames (:666-679) */
+  orc_jrandom_seed(&x->app_rng, 0);
   for (uint32_t a = 0; a < m->n_actors; a++) x->state[a] = m->init_state[a];
   dpor_trace_push(x, DPOR_ROOT_KEY, 0, 0, 0); /* start_trace: currentTrace += getRootEvent (:336-343) */
   x->parent = 0; x->cur_root = 0;

@@ -40,7 +40,7 @@ typedef struct {
   uint8_t msg_type, p0, p1;
 } orc_effect;
 int orc_vm_run(const demi_model* m, uint32_t me, uint64_t* state, uint8_t msg_type, uint8_t src,
-               uint8_t p0, uint8_t p1, uint32_t exists_mask, orc_effect* fx, uint32_t fx_cap);
+               uint8_t p0, uint8_t p1, uint32_t exists_mask, orc_effect* fx, uint32_t fx_cap, orc_jrandom* app);
 
 /* Invariant: returns the fingerprint code (0 = holds). */
 uint32_t orc_invariant(const demi_model* m, const uint64_t* states, uint32_t exists_mask);

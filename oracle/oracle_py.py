@@ -77,7 +77,7 @@ def lib():
         L.orc_random_explore.argtypes = [C.POINTER(T.ModelStruct), C.c_void_p, C.c_uint32, C.c_uint64,
                                          C.c_void_p, C.c_uint64, C.POINTER(T.Limits), C.c_void_p, C.c_int]
         L.orc_vm_run.argtypes = [C.POINTER(T.ModelStruct), C.c_uint32, C.POINTER(C.c_uint64), C.c_uint8, C.c_uint8,
-                                 C.c_uint8, C.c_uint8, C.c_uint32, C.c_void_p, C.c_uint32]
+                                 C.c_uint8, C.c_uint8, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
         L.orc_sts_replay_batch.argtypes = [C.POINTER(T.ModelStruct), C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
                                            C.c_void_p, C.c_uint64, C.POINTER(T.Limits), C.c_void_p, C.c_int]
         L.orc_sts_removal_batch.argtypes = [C.POINTER(T.ModelStruct), C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,

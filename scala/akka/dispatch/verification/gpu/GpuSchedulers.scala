@@ -25,7 +25,7 @@ class GpuRandomScheduler(val schedulerConfig: SchedulerConfig, max_executions: I
 
   private def limits(lookingFor: Option[ViolationFingerprint], p: Int = pMax) = Array(
     if (maxMessages == Int.MaxValue) 0 else maxMessages, math.max(0, invariant_check_interval), p,
-    if (lookingFor.isDefined) 1 else 0, lookingFor.map(lowering.fingerprintCode).getOrElse(0), 0, if (srcDstFifo) 1 else 0)
+    if (lookingFor.isDefined) 1 else 0, lookingFor.map(lowering.fingerprintCode).getOrElse(0), 0, if (srcDstFifo) 1 else 0, 0)
 
   private def prepare(trace: Seq[ExternalEvent]) {
     if (!modelLoaded) {
@@ -99,7 +99,9 @@ class GpuSTSScheduler(val schedulerConfig: SchedulerConfig, original_trace: Even
   }
   def getName = "GpuSTSSchedNoPeek"
   def setInvariant(i: TestOracle.Invariant) {}
-  private def limits(fp: ViolationFingerprint, p: Int = pMax) = Array(0, 0, p, 1, lowering.fingerprintCode(fp), 0, 0)
+  // the last entry is demi_limits.filter_known_absents: SchedulerConfig.filterKnownAbsents, as the reference computes it
+  private def limits(fp: ViolationFingerprint, p: Int = pMax) =
+    Array(0, 0, p, 1, lowering.fingerprintCode(fp), 0, 0, if (schedulerConfig.filterKnownAbsents) 1 else 0)
   private def mask(subseq: Seq[ExternalEvent]): Array[Long] = {
     val m = new Array[Long](4)
     for (e <- subseq) { val i = indexOf(e._id); m(i >> 6) |= 1L << (i & 63) }
@@ -146,7 +148,9 @@ class GpuStsRemovalOracle(schedulerConfig: SchedulerConfig, mcs: Seq[ExternalEve
   private val h = ctxCreate(device)
   private var loaded: EventTrace = null
   private var modelLoaded = false
-  private def limits(fp: ViolationFingerprint, p: Int = pMax) = Array(0, 0, p, 1, lowering.fingerprintCode(fp), 0, 0)
+  // the last entry is demi_limits.filter_known_absents: SchedulerConfig.filterKnownAbsents, as the reference computes it
+  private def limits(fp: ViolationFingerprint, p: Int = pMax) =
+    Array(0, 0, p, 1, lowering.fingerprintCode(fp), 0, 0, if (schedulerConfig.filterKnownAbsents) 1 else 0)
   private def load(trace: EventTrace) {
     if (!modelLoaded) {
       val m = lowering.model

@@ -5,7 +5,7 @@
 #define DEMI_FX_CAP 8
 #define DEMI_V_QUEUE_OVF 0x8u
 namespace demi {
-struct Tables { const uint32_t* hs; uint32_t ac_packed, NT; };
+struct Tables { const uint32_t* hs; uint32_t ac_packed, NT; const uint32_t* magic; };
 struct LaneMem { uint64_t* st; uint32_t* fxq; };
 static inline uint32_t w_type(uint32_t w) { return w & 31u; }
 static inline uint32_t w_dst(uint32_t w) { return (w >> 5) & 7u; }
@@ -16,4 +16,15 @@ static inline uint32_t fx_pack(uint32_t op, uint32_t type, uint32_t target, uint
   return (op & 31u) | (type << 5) | (target << 10) | (p0 << 14) | (p1 << 22);
 }
 static inline int __popc(uint32_t x) { return __builtin_popcount(x); }
+// DEMI_OP_RND: java.util.Random.nextInt(bound) on the application's generator (the device uses multiply-high magics for the
+// modulo; here the plain JDK algorithm - the results must agree)
+static inline uint32_t app_next_int(uint64_t& s, uint32_t bound, const uint32_t*) {
+  if (bound == 0) return 0;
+  auto next31 = [&]() { s = (s * 0x5DEECE66DULL + 0xBULL) & ((1ULL << 48) - 1); return (uint32_t)(s >> 17); };
+  uint32_t r = next31();
+  if ((bound & (bound - 1)) == 0) return (uint32_t)(((uint64_t)bound * r) >> 31);
+  uint32_t u = r;
+  while ((int32_t)(u - (r = u % bound) + (bound - 1)) < 0) u = next31();
+  return r;
+}
 }  // namespace demi

@@ -146,3 +146,29 @@ def test_crash_in_replay_and_dpor(oracle):
         dv, traces, pairs = oracle.dpor_batch(model, events_to_array(events), [np.zeros(0, dtype=T.DPOR_TRACE_DTYPE)],
                                               T.DporParams(0, 0, 0, 0, 64, 256))
         assert len(traces[0]) == 1 + n_deliveries
+
+
+# ------------------------------------------------------------------ application randomness (DEMI_OP_RND)
+def test_rnd_draws_from_a_second_generator_that_restarts_at_seed_zero(oracle):
+    """Instrumenter().seededRandom = scala.util.Random(0), recreated with every ActorSystem (Instrumenter.scala:212, 226-229,
+    570): the values an actor draws are java.util.Random(0).nextInt(bound) in delivery order, the same in every execution
+    whatever the scheduler's own seed, and independent of the scheduler's generator."""
+    msgs = [("Draw", T.MSG_EXTERNAL)]
+    h = {(0, "Draw"): Asm().rnd(M.T0, M.P0).shl(M.F[1], M.F[1], 0).add(M.F[2], M.F[2], 1).mov(M.F[0], M.T0).rnd(M.F[3], 0)}
+    model = build_model("dice", 1, msgs, h, [[0] * 8], (T.INV_NEVER, 4, 9, 0))
+    bounds = [10, 5, 7, 255, 1, 128, 3]
+    ev = events_to_array([start(0)] + [send(0, 0, b) for b in bounds])
+    for seed in (1, 99, 0x5EED0000):
+        v, rec, states = oracle.random_execute(model, ev, seed, T.Limits(0, 0, 64, 0, 0, 0))
+        order = [int(e["p0"]) for e in rec if e["kind"] == T.REC_MSG_EVENT]
+        assert sorted(order) == sorted(bounds)
+        jr = JavaRandom(0)
+        drawn = [jr.next_int(b) for b in order]           # one draw per delivery, in delivery order (bound 0 draws nothing)
+        assert int(states[0]) & 0xFF == drawn[-1] and (int(states[0]) >> 24) & 0xFF == 0
+    # the JDK known answers: new Random(0).nextInt(5) x 10 = 0,3,4,2,0,3,1,1,4,4 (SURVEY 8c)
+    ev5 = events_to_array([start(0), send(0, 0, 5)])
+    got = []
+    model_acc = build_model("dice5", 1, msgs, {(0, "Draw"): Asm().rnd(M.F[0], 5).rnd(M.F[1], 5).rnd(M.F[2], 5).rnd(M.F[3], 5).rnd(M.F[4], 5)
+                                               .rnd(M.F[5], 5).rnd(M.F[6], 5).rnd(M.F[7], 5)}, [[0] * 8], (T.INV_NEVER, 0, 9, 0))
+    v, rec, states = oracle.random_execute(model_acc, ev5, 7, T.Limits(0, 0, 64, 0, 0, 0))
+    assert [(int(states[0]) >> (8 * i)) & 0xFF for i in range(8)] == [0, 3, 4, 2, 0, 3, 1, 1]

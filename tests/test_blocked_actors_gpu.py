@@ -93,3 +93,53 @@ def test_k3_parity_with_crashed_actors(gpu_ctx, oracle):
         for a, b in zip(rg.interleavings, rc.interleavings):
             assert a.verdict == b.verdict and (a.trace == b.trace).all()
         dg.shutdown()
+
+
+def jittery_model():
+    """Raft-like randomized timeouts: an actor draws its next timeout budget from the application's generator
+    (Instrumenter().seededRandom) and acts when the budget runs out - the schedule decides who draws which number."""
+    msgs = [("Go", T.MSG_EXTERNAL), ("Ping", T.MSG_INTERNAL), ("Tick", T.MSG_TIMER)]
+    go = Asm().rnd(M.F[0], 7).add(M.F[0], M.F[0], 1).trep(2)
+    tick = (Asm().sub(M.F[0], M.F[0], 1).if_eq(M.F[0], 0, "end").rnd(M.F[0], M.F[2]).add(M.F[0], M.F[0], 1).add(M.F[1], M.F[1], 1)
+            .mov(M.T1, 0).bcast(1, M.F[1], 3).if_ge(M.F[1], 4, "end").tcancel(2).label("end"))
+    ping = Asm().add(M.F[3], M.F[3], 1).rnd(M.T0, 200).max(M.F[4], M.F[4], M.T0).add(M.F[2], M.F[2], 1)
+    h = {(0, "Go"): go, (0, "Ping"): ping, (0, "Tick"): tick}
+    return build_model("jittery", 4, msgs, h, [[0, 0, 5, 0, 0, 0, 0, 0]] * 4, (T.INV_AT_MOST_ONE, 1, 4, 4))
+
+
+def test_application_randomness_parity_on_every_kernel(gpu_ctx, oracle, monkeypatch):
+    model = jittery_model()
+    ev = events_to_array([start(a) for a in range(4)] + [send(a, 0) for a in range(4)] + [wait_quiescence(), send(1, 0), send(2, 0)])
+    for strategy in (T.STRATEGY_FULLY_RANDOM, T.STRATEGY_SRC_DST_FIFO):
+        lim = T.Limits(150, 11, 64, 0, 0, 0, strategy)
+        g, c = both(gpu_ctx, oracle, model, ev, 8192, lim, seed_base=0x7E57AB1E0000, jit=True)
+        assert_same(g, c)
+        assert len(set(g["hash"].tolist())) > 2000
+    lim = T.Limits(150, 0, 64, 0, 0, 0)
+    gv, grec = gpu_ctx.random_get_trace(0x7E57AB1E0000 + 5, lim)
+    cv, crec, _ = oracle.random_execute(model, ev, 0x7E57AB1E0000 + 5, lim)
+    assert gv.hash == cv.hash and (grec == crec).all()
+    # K2: replays of candidate subsequences draw the same numbers in the same deliveries
+    used = ev[:T.verdict_trace_idx(gv.flags)]
+    rng = np.random.default_rng(5)
+    masks = np.zeros((1024, 4), dtype=np.uint64)
+    masks[:, 0] = rng.integers(0, 1 << len(used), size=1024, dtype=np.uint64)
+    masks[0, 0] = (1 << len(used)) - 1
+    target = T.Limits(0, 0, 64, 1, 0x7FFFFFFF, 0)
+    want = oracle.sts_replay_batch(model, used, grec, masks, target, n_threads=os.cpu_count())
+    for mode in ("lds", "hbm"):
+        monkeypatch.setenv("DEMI_K2_MODE", mode)
+        gpu_ctx.replay_load(used, grec)
+        assert_same(gpu_ctx.replay_batch(masks, target), want)
+    monkeypatch.delenv("DEMI_K2_MODE")
+    assert int(want[0]["hash"]) == gv.hash
+    # K3
+    from demi_amd.dpor import DPORwHeuristics
+    from demi_amd.schedulers import SchedulerConfig
+    ev3 = events_to_array([start(a) for a in range(4)] + [send(0, 0), send(1, 0)])
+    dg = DPORwHeuristics(SchedulerConfig(model=model), depth_bound=20, stopIfViolationFound=False, batch=64, specialize=True)
+    rg = dg.explore(ev3, max_interleavings=300)
+    dc = DPORwHeuristics(SchedulerConfig(model=model), depth_bound=20, stopIfViolationFound=False, batch=64, backend=oracle.dpor_batch)
+    rc = dc.explore(ev3, max_interleavings=300)
+    assert rg.rounds == rc.rounds and all(a.verdict == b.verdict for a, b in zip(rg.interleavings, rc.interleavings))
+    dg.shutdown()

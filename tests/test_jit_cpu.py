@@ -40,15 +40,18 @@ def test_generated_source_shape():
 def _host_vm(model, tmp_path):
     src = _native.specialize_source(model.to_struct())
     cpp = tmp_path / "vm_host.cpp"
-    cpp.write_text('#include "%s"\n%s\nextern "C" uint32_t run(const uint32_t* hs, uint32_t ac, uint32_t nt, uint64_t* st, '
-                   'uint32_t* fxq, uint32_t w, uint32_t* flags) {\n  demi::Tables t{hs, ac, nt}; demi::LaneMem m{st, fxq};\n'
-                   '  uint32_t f = *flags; uint32_t n = demi::vm_run_jit(t, m, w, f); *flags = f; return n; }\n'
+    cpp.write_text('#include "%s"\n%s\nstatic uint64_t g_app = 0x5DEECE66DULL;   // Instrumenter().seededRandom: seed 0\n'
+                   'extern "C" void app_reset() { g_app = 0x5DEECE66DULL; }\n'
+                   'extern "C" uint32_t run(const uint32_t* hs, uint32_t ac, uint32_t nt, uint64_t* st, '
+                   'uint32_t* fxq, uint32_t w, uint32_t* flags) {\n  demi::Tables t{hs, ac, nt, nullptr}; demi::LaneMem m{st, fxq};\n'
+                   '  uint32_t f = *flags; uint32_t n = demi::vm_run_jit(t, m, w, f, g_app); *flags = f; return n; }\n'
                    % (os.path.join(ROOT, "tests", "jit_host_shim.hpp"), src))
     so = tmp_path / "vm_host.so"
     subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-label", "-o", str(so), str(cpp)])
     L = C.CDLL(str(so))
     L.run.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
     L.run.restype = C.c_uint32
+    L.app_rng = C.c_uint64(0x5DEECE66D)          # the oracle's copy of the application generator (seed 0), advanced in step
     return L
 
 
@@ -81,7 +84,7 @@ def test_generated_handlers_equal_the_row_interpreter(oracle, tmp_path, name, mk
         flags = C.c_uint32(0)
         n = L.run(hs.ctypes.data, ac, NT, st.ctypes.data, fxq.ctypes.data, w, C.byref(flags))
         want_state = C.c_uint64(state)
-        wn = oracle.lib().orc_vm_run(C.byref(ms), me, C.byref(want_state), typ, src, p0, p1, exists, fx, 64)
+        wn = oracle.lib().orc_vm_run(C.byref(ms), me, C.byref(want_state), typ, src, p0, p1, exists, fx, 64, C.byref(L.app_rng))
         if wn < 0:
             assert flags.value & T.V_QUEUE_OVF
             n_ovf += 1
@@ -154,6 +157,8 @@ def _random_handler(rng, n_rows, n_types, few_effects=False):
             a.send(int(rng.integers(1, 3)), regs[int(rng.integers(16))], regs[int(rng.integers(16))], breg())   # internal types
         elif k < 92:
             a.bcast(int(rng.integers(1, 3)), regs[int(rng.integers(16))], breg())
+        elif k < 93:
+            a.rnd(regs[int(rng.integers(12))], breg() if rng.integers(2) else int(rng.integers(0, 256)))
         elif k < 95:
             a.tset(n_types - 1)
         elif k < 97:
@@ -205,7 +210,7 @@ def test_random_programs_through_the_code_generator(oracle, tmp_path, seed, ifco
         flags = C.c_uint32(0)
         n = L.run(hs.ctypes.data, ac, NT, st.ctypes.data, fxq.ctypes.data, w, C.byref(flags))
         want_state = C.c_uint64(state)
-        wn = oracle.lib().orc_vm_run(C.byref(ms), me, C.byref(want_state), typ, src, p0, p1, (1 << A) - 1, fx, 64)
+        wn = oracle.lib().orc_vm_run(C.byref(ms), me, C.byref(want_state), typ, src, p0, p1, (1 << A) - 1, fx, 64, C.byref(L.app_rng))
         if wn < 0:
             assert flags.value & T.V_QUEUE_OVF
             seen_ovf += 1
@@ -255,5 +260,5 @@ def test_if_conversion_knob_converts_short_guarded_alu_runs(oracle, tmp_path, mo
         flags = C.c_uint32(0)
         n = L.run(hs.ctypes.data, 0, len(MSGS), st.ctypes.data, fxq.ctypes.data, w, C.byref(flags))
         want = C.c_uint64(state)
-        wn = oracle.lib().orc_vm_run(C.byref(ms), 0, C.byref(want), 0, T.DEADLETTERS, p0, p1, 3, fx, 64)
+        wn = oracle.lib().orc_vm_run(C.byref(ms), 0, C.byref(want), 0, T.DEADLETTERS, p0, p1, 3, fx, 64, C.byref(L.app_rng))
         assert int(st[0]) == want.value and n == wn

@@ -395,7 +395,7 @@ def test_fifo_golden_fixture_on_gpu(gpu_ctx):
     assert_same(gpu_ctx.random_explore(len(want), _fifo(lim), seed_base=SEED_BASE), want)
 
 
-@pytest.mark.parametrize("seed", [1, 3, 13])
+@pytest.mark.parametrize("seed", [1, 11, 13])
 def test_random_programs_interpreter_specialised_and_oracle_agree(gpu_ctx, oracle, seed):
     """Random transition tables (every op, random forward control flow, two actor classes, timers): the table
     interpreter, the kernel compiled from the table and the oracle give the same verdict for every schedule."""

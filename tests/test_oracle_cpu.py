@@ -192,7 +192,7 @@ def test_raft_table_equals_plain_reference(oracle, buggy):
         if msg == M.M_VOTE_REPLY:
             p1 = rnd.randrange(2)
         st = C.c_uint64(M.pack_state(fields))
-        n = oracle.lib().orc_vm_run(C.byref(ms), me, C.byref(st), msg, src, p0, p1, (1 << A) - 1, fx, 64)
+        n = oracle.lib().orc_vm_run(C.byref(ms), me, C.byref(st), msg, src, p0, p1, (1 << A) - 1, fx, 64, C.byref(C.c_uint64(0x5DEECE66D)))
         want_fields, want_fx = raft_reference(A, buggy, me, fields, msg, src, p0, p1)
         got_fx = []
         for e in fx[:n]:
