@@ -39,9 +39,11 @@
 
 namespace demi {
 
-// expected event, 8 bytes: kind | a<<8 | b<<16 | type<<24 | p0<<32 | p1<<40 | ext<<48 | flags<<56
-//   SPAWN/KILL: a = actor;  (UN)PARTITION: a, b;  MSG_SEND (external only): b = rcv, ext = Send index
+// expected event, 8 bytes: kind | a<<8 | b<<16 | type<<24 | p0<<32 | p1<<40 | ext<<48 | slot<<56
+//   SPAWN/KILL: a = actor;  (UN)PARTITION: a, b;  MSG_SEND of an external: b = rcv, ext = Send index
 //   MSG_EVENT: a = snd, b = rcv, ext = index of the Send that enqueued it (255 = internal / timer)
+//   only in the lowering for filter_absents != 0: MSG_SEND of an actor (ext = 255): a = snd, b = rcv, slot = the bit of the lane's
+//   pruned-sends mask that stands for this message until its MSG_EVENT (which carries the same slot; 255 = none) has passed
 struct K2Args {
   const DevModel* model;
   const uint64_t* ext;      // original external events [n_ext]
@@ -50,6 +52,9 @@ struct K2Args {
   const uint64_t* expected; // lowered original trace [n_exp]
   uint32_t n_exp;
   uint32_t p_max, looking_for;
+  uint32_t lanes_per_wave;  // candidates a wave replays at once (1..64): a DDMin frontier is small next to the chip, and a wave's
+                            // step costs the union of its lanes' paths - spread thin, every candidate walks only its own
+  uint32_t filter_absents;  // demi_filter_absents: EventTrace.filterKnownAbsentInternals as the last stage of the projection
   const uint64_t* masks;    // [n][4]; null = every external kept
   const uint32_t* skip;     // [n] index (in `expected`) of one MSG_EVENT removed from the trace, or null
   uint8_t* kept;            // [n][n_exp] (pre-zeroed) 1 where the expected event took effect, or null
@@ -161,8 +166,21 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
   uint64_t m0 = 0, m1 = 0, m2 = 0, m3 = 0;   // candidate mask
   uint64_t app_rng = 0;                      // Instrumenter().seededRandom, restarted with every replay (DEMI_OP_RND)
   uint32_t idx = 0, cur = 0, n_pend = 0, count = 0, ignored = 0, flags = 0, rep = 0, skip = 0xFFFFFFFFu;
-  uint32_t blocked = 0;     // crashed actors (DEMI_OP_CRASH): an expected delivery to one is not "pending" (STSScheduler.scala:392-402)
   Net net = {0, 0, 0};
+  uint32_t blocked = 0;     // crashed actors (DEMI_OP_CRASH): an expected delivery to one is not "pending" (STSScheduler.scala:392-402)
+  // EventTrace.filterKnownAbsentInternals (EventTrace.scala:458-534) on the fly.  actorToAlive is exists & ~inaccessible (a
+  // kept SpawnEvent sets it, a kept KillEvent clears it, default false; deadLetters always alive).  actorsToPartitioned as the
+  // reference wrote it - PartitionEvent((a,b)) -> false, UnPartitionEvent((a,b)) -> true under the ordered key (:523-528) - is
+  // fk_part (LITERAL); CORRECTED reads net.partitioned in both directions.  prunedMessageSends is a mask over the slots the
+  // lowering gave the in-flight internal messages.
+  const uint32_t FK = args.filter_absents;
+  uint64_t fk_part = 0, fk_pruned0 = 0, fk_pruned1 = 0;
+  auto fk_cut = [&](uint32_t s_, uint32_t r_) -> bool {
+    if (s_ >= DEMI_MAX_ACTORS || r_ >= DEMI_MAX_ACTORS) return false;
+    if (FK == DEMI_FILTER_ABSENTS_LITERAL) return (fk_part >> (s_ * 8 + r_)) & 1ull;
+    return ((net.partitioned >> (s_ * 8 + r_)) | (net.partitioned >> (r_ * 8 + s_))) & 1ull;
+  };
+  auto fk_alive = [&](uint32_t who) -> bool { return who >= DEMI_MAX_ACTORS || (((exists & ~net.inaccessible) >> who) & 1u); };
   uint64_t tq = 0;
   uint32_t n_tq = 0;
   uint64_t b_next = 0, b_end = 0;
@@ -200,21 +218,21 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
   for (;;) {
     // ---------------------------------------------------------- refill (same protocol as K1)
     {
-      const uint64_t idle = __ballot(!active);
+      const uint64_t idle = __ballot(!active && lane < args.lanes_per_wave);
       if (idle != 0 && !exhausted) {
         const uint32_t want = (uint32_t)__popcll(idle);
         const uint64_t have = b_end - b_next;
         uint64_t got = 0;
         if (have < want) {
-          if (lane == 0) got = atomicAdd(args.work_counter, 64ull);
+          if (lane == 0) got = atomicAdd(args.work_counter, (unsigned long long)args.lanes_per_wave);
           got = __shfl(got, 0);
         }
-        if (!active) {
+        if (!active && lane < args.lanes_per_wave) {
           const uint32_t rank = (uint32_t)__popcll(idle & ((1ULL << lane) - 1));
           const uint64_t my = (rank < have) ? (b_next + rank) : (got + (rank - have));
           if (my < args.n) { sched = my; active = true; fresh = true; }
         }
-        if (have < want) { b_next = got + (want - have); b_end = got + 64; }
+        if (have < want) { b_next = got + (want - have); b_end = got + args.lanes_per_wave; }
         else b_next += want;
         if (b_next >= args.n) exhausted = true;
       }
@@ -239,6 +257,7 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
         for (uint32_t a = 0; a < A; a++) st[a * 64] = t.init[a];
         if (FP) for (uint32_t f = 0; f < args.n_fp; f++) cnt[(size_t)f * cnt_stride] = 0;
         idx = 0; cur = 0; n_pend = 0; count = 0; ignored = 0; flags = 0; rep = 0; tq = 0; n_tq = 0; blocked = 0;
+        fk_part = 0; fk_pruned0 = 0; fk_pruned1 = 0;
         cur_skip();
       }
       // -------------------------------------------------------- advanceReplay (:405-559)
@@ -262,8 +281,16 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
           if (args.kept) args.kept[sched * NX + idx - 1] = 1;
           if (kind == DEMI_REC_SPAWN) { net.inaccessible &= ~(1u << a); net.killed &= ~(1u << a); blocked &= ~(1u << a); }
           else if (kind == DEMI_REC_KILL) { net.killed |= 1u << a; net.inaccessible |= 1u << a; }
-          else if (kind == DEMI_REC_PARTITION) net.partitioned |= 1ULL << (a * 8 + b);
-          else net.partitioned &= ~(1ULL << (a * 8 + b));
+          else if (kind == DEMI_REC_PARTITION) { net.partitioned |= 1ULL << (a * 8 + b); fk_part &= ~(1ULL << (a * 8 + b)); }
+          else { net.partitioned &= ~(1ULL << (a * 8 + b)); fk_part |= 1ULL << (a * 8 + b); }
+        } else if (kind == DEMI_REC_MSG_SEND && ext == 255) {
+          // an actor's MsgSend (only lowered for the filter): `if (messageSendable(snd, rcv)) result += event else
+          // prunedMessageSends += id`; the slot is reused, so a sendable one clears the bit
+          const uint32_t slot = (uint32_t)(e >> 56);
+          const bool pruned = FK && !(fk_alive(a) && !fk_cut(a, b));
+          const uint64_t bit = 1ull << (slot & 63u);
+          if (slot & 64u) fk_pruned1 = pruned ? (fk_pruned1 | bit) : (fk_pruned1 & ~bit);
+          else fk_pruned0 = pruned ? (fk_pruned0 | bit) : (fk_pruned0 & ~bit);
         } else if (kind == DEMI_REC_MSG_SEND) {
           // external MsgSend -> enqueue_message (:509-511) unless its Send was pruned
           if (IN_MASK(ext) && ((exists >> b) & 1)) {
@@ -274,6 +301,11 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
         } else {  // MSG_EVENT
           if (idx - 1 == skip) continue;               // the delivery this candidate removes (OneAtATimeRemoval.scala:57-124)
           if (ext != 255 && !IN_MASK(ext)) continue;   // pruned together with its Send (filterSends)
+          if (FK) {                                    // messageDeliverable(snd, rcv, id), else not part of the projected trace
+            const uint32_t slot = (uint32_t)(e >> 56);
+            const bool sent = slot == 255u || !(((slot & 64u) ? fk_pruned1 : fk_pruned0) >> (slot & 63u) & 1ull);
+            if (!(fk_alive(b) && !fk_cut(a, b) && sent)) continue;
+          }
           if ((blocked >> b) & 1u) { ignored++; continue; }   // the destination is blocked: not deliverable (:392-402), ignored
           const uint32_t want = msg_word((uint32_t)(e >> 24) & 0xFF, a, b, (uint32_t)(e >> 32) & 0xFF,
                                          (uint32_t)(e >> 40) & 0xFF);

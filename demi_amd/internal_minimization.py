@@ -217,7 +217,8 @@ class StsRemovalOracle:
         self._loaded = None
 
     def _limits(self, fp: ViolationFingerprint) -> T.Limits:
-        return T.Limits(0, 0, self.p_max, 1, fp.code, 1 if self.schedulerConfig.populate_all_actors else 0)
+        return T.Limits(0, 0, self.p_max, 1, fp.code, 1 if self.schedulerConfig.populate_all_actors else 0, 0,
+                        int(self.schedulerConfig.filterKnownAbsents))
 
     def _load(self, trace: EventTrace):
         if self._loaded is not trace:

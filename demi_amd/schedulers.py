@@ -31,7 +31,8 @@ class SchedulerConfig:
     enableFailureDetector: bool = False
     enableCheckpointing: bool = False
     shouldShutdownActorSystem: bool = True
-    filterKnownAbsents: bool = False
+    filterKnownAbsents: int = False      # SchedulerConfig.scala:14; True / 1 = as the reference computes it (types.FILTER_ABSENTS_LITERAL),
+                                         # 2 = FILTER_ABSENTS_CORRECTED (see include/demi_gpu.h demi_filter_absents)
     ignoreTimers: bool = False
     abortUponDivergence: bool = False
     populate_all_actors: bool = False    # setActorNamePropPairs
@@ -243,7 +244,8 @@ class STSScheduler:
         return "STSSchedNoPeek"
 
     def _limits(self, fp: ViolationFingerprint) -> T.Limits:
-        return T.Limits(0, 0, self.p_max, 1, fp.code, 1 if self.schedulerConfig.populate_all_actors else 0)
+        return T.Limits(0, 0, self.p_max, 1, fp.code, 1 if self.schedulerConfig.populate_all_actors else 0, 0,
+                        int(self.schedulerConfig.filterKnownAbsents))
 
     def _masks(self, subseqs) -> np.ndarray:
         masks = np.zeros((len(subseqs), 4), dtype=np.uint64)
@@ -343,7 +345,7 @@ class ReplayScheduler:
         for e in range(n):
             mask[0, e >> 6] |= np.uint64(1) << np.uint64(e & 63)
         lim = T.Limits(0, 0, self.p_max, 1, expected.code if expected is not None else 0,
-                       1 if self.schedulerConfig.populate_all_actors else 0)
+                       1 if self.schedulerConfig.populate_all_actors else 0, 0, int(self.schedulerConfig.filterKnownAbsents))
         v = self._ctx.replay_batch(mask, lim)[0]
         flags = int(v["flags"])
         if flags & (T.V_PENDING_OVF | T.V_QUEUE_OVF):

@@ -71,6 +71,9 @@ class ModelStruct(C.Structure):
                 ("inv_fb", C.c_uint32), ("fp_match_mask", C.c_uint32)]
 
 
+FILTER_ABSENTS_OFF, FILTER_ABSENTS_LITERAL, FILTER_ABSENTS_CORRECTED = 0, 1, 2     # demi_filter_absents
+
+
 class Limits(C.Structure):
     _fields_ = [("max_messages", C.c_uint32), ("invariant_check_interval", C.c_uint32),
                 ("p_max", C.c_uint32), ("looking_for_valid", C.c_uint32), ("looking_for", C.c_uint32),

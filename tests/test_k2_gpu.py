@@ -332,3 +332,50 @@ def test_fuzz_then_the_gamut_end_to_end():
     assert out["verified_mcs"] is not None and len(out["mcs"]) < out["original_externals"]
     assert out["minimized_deliveries"] <= countMsgEvents(out["verified_mcs"]) <= out["original_deliveries"]
     assert out["ddmin_replays"] > 0 and out["intmin_replays"] > 0
+
+
+@pytest.mark.parametrize("k2_mode", ["auto", "hbm", "scan"])
+def test_filter_known_absents_parity(gpu_ctx, oracle, k2_mode, monkeypatch):
+    """SchedulerConfig.filterKnownAbsents (EventTrace.filterKnownAbsentInternals as the last stage of the projection),
+    as the reference computes it and corrected: verdicts, removal candidates and executed-trace marks against the
+    oracle on fault-heavy traces, switching between the two lowerings of one loaded execution, in every kernel variant."""
+    from demi_amd.internal_minimization import deliveries
+    if k2_mode == "scan":
+        monkeypatch.setenv("DEMI_K2_SCAN", "1")
+    elif k2_mode == "hbm":
+        monkeypatch.setenv("DEMI_K2_MODE", "hbm")
+    model = M.raft_model(5, election_budget=2)
+    w = FuzzerWeights(kill=0.12, send=0.35, wait_quiescence=0.13, partition=0.25, unpartition=0.15)
+    rng = np.random.default_rng(5)
+    differs = 0
+    for seed in (1, 2, 3):
+        events = events_to_array(raft_trace(5, 90, seed, w, exact=False))
+        lim = T.Limits(400, 10, 128, 0, 0, 0)
+        vv, rec, used = record(gpu_ctx, model, events, lim, want_violation=False, skip=seed, n=64)
+        masks = random_masks(rng, len(used), 1200)
+        fpc = vv.fingerprint if vv.fingerprint else 0x1000103
+        gpu_ctx.replay_load(used, rec)
+        dl = np.array([i for i, _, _ in deliveries(EventTrace(rec, used))] + [NO_SKIP], dtype=np.uint32)
+        sk = rng.choice(dl, size=len(masks))
+        res = {}
+        for mode in (T.FILTER_ABSENTS_LITERAL, T.FILTER_ABSENTS_OFF, T.FILTER_ABSENTS_CORRECTED, T.FILTER_ABSENTS_LITERAL):
+            target = T.Limits(0, 0, 128, 1, fpc, 0, 0, mode)
+            g = gpu_ctx.replay_batch(masks, target)
+            assert_same(g, oracle.sts_replay_batch(model, used, rec, masks, target, n_threads=os.cpu_count()))
+            res[mode] = g
+            g = gpu_ctx.replay_removal_batch(sk, target, masks=masks)
+            assert_same(g, oracle.sts_removal_batch(model, used, rec, sk, target, masks=masks, n_threads=os.cpu_count()))
+            for i in range(0, len(masks), 173):
+                gv, gk = gpu_ctx.replay_get_kept(len(rec), int(sk[i]), target, mask=masks[i])
+                cv, ck = oracle.sts_removal_kept(model, used, rec, int(sk[i]), target, mask=masks[i])
+                assert gv.flags == cv.flags and gv.hash == cv.hash and (gk == ck).all()
+        differs += int((res[T.FILTER_ABSENTS_LITERAL] != res[T.FILTER_ABSENTS_OFF]).sum())
+        differs += int((res[T.FILTER_ABSENTS_LITERAL] != res[T.FILTER_ABSENTS_CORRECTED]).sum())
+        if k2_mode == "auto" and seed == 1:      # the kernel compiled from the table as well
+            gpu_ctx.model_specialize()
+            for mode in (T.FILTER_ABSENTS_LITERAL, T.FILTER_ABSENTS_CORRECTED):
+                assert_same(gpu_ctx.replay_batch(masks, T.Limits(0, 0, 128, 1, fpc, 0, 0, mode)), res[mode])
+            gpu_ctx.model_specialize(False)
+    assert differs > 0
+    with pytest.raises(Exception):
+        gpu_ctx.replay_batch(masks, T.Limits(0, 0, 128, 1, fpc, 0, 0, 3))

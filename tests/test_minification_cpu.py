@@ -296,3 +296,101 @@ def test_projection_equals_the_scala_transliteration(oracle):
             assert bool(v.flags & T.V_DIVERGED) == (len(proj & msg_events) > len(kept_set & msg_events))
             checked += 1
     assert checked > 80
+
+
+def _scala_filter_known_absent_internals(rec, indices, corrected=False):
+    """EventTrace.filterKnownAbsentInternals (EventTrace.scala:458-534) transliterated over the recorded-event array:
+    `indices` is what subsequenceIntersection + filterSends let through, the result what survives the filter.  As in the
+    Scala, a PartitionEvent stores false and an UnPartitionEvent true (:523-528); corrected=True swaps the two and
+    looks the pair up in either direction (DEMI_FILTER_ABSENTS_CORRECTED)."""
+    alive = {"deadLetters": True, "Timer": True}                 # default false
+    partitioned = {}                                               # default false
+    pruned_sends = set()
+
+    def name(x):
+        return "deadLetters" if int(x) == T.DEADLETTERS else int(x)
+
+    def is_partitioned(snd, rcv):
+        if corrected:
+            return partitioned.get((snd, rcv), False) or partitioned.get((rcv, snd), False)
+        return partitioned.get((snd, rcv), False)
+
+    def sendable(snd, rcv):
+        if not alive.get(snd, False):
+            return False
+        return not is_partitioned(snd, rcv)
+
+    def deliverable(snd, rcv, mid):
+        if not alive.get(rcv, False):
+            return False
+        return not is_partitioned(snd, rcv) and mid not in pruned_sends
+
+    result = []
+    for idx in indices:
+        e = rec[idx]
+        kind = int(e["kind"])
+        if kind == T.REC_MSG_SEND:
+            if sendable(name(e["snd"]), name(e["rcv"])):
+                result.append(idx)
+            else:
+                pruned_sends.add(int(e["id"]))
+        elif kind == T.REC_MSG_EVENT:
+            if deliverable(name(e["snd"]), name(e["rcv"]), int(e["id"])):
+                result.append(idx)
+        elif kind == T.REC_SPAWN:
+            alive[name(e["rcv"])] = True
+            result.append(idx)
+        elif kind == T.REC_KILL:
+            alive[name(e["rcv"])] = False
+            result.append(idx)
+        elif kind == T.REC_PARTITION:
+            partitioned[(name(e["snd"]), name(e["rcv"]))] = corrected
+            result.append(idx)
+        elif kind == T.REC_UNPARTITION:
+            partitioned[(name(e["snd"]), name(e["rcv"]))] = not corrected
+            result.append(idx)
+        else:
+            result.append(idx)
+    return result
+
+
+@pytest.mark.parametrize("mode", [T.FILTER_ABSENTS_LITERAL, T.FILTER_ABSENTS_CORRECTED])
+def test_filter_known_absent_internals_equals_the_scala_transliteration(oracle, mode):
+    """SchedulerConfig.filterKnownAbsents: the replay walks exactly the trace that subsequenceIntersection + filterSends
+    + filterKnownAbsentInternals produce - the reference's inverted Partition / UnPartition bookkeeping included (LITERAL)."""
+    model = M.raft_model(5, election_budget=2)
+    from demi_amd.fuzzer import FuzzerWeights, raft_trace
+    w = FuzzerWeights(kill=0.12, send=0.4, wait_quiescence=0.13, partition=0.2, unpartition=0.15)
+    rng = np.random.default_rng(17)
+    checked = filtered = changed = 0
+    for seed in (1, 2, 3, 4):
+        events = events_to_array(raft_trace(5, 70, seed, w, exact=False))
+        lim = T.Limits(300, 10, 128, 0, 0, 0)
+        vv, rec, _ = oracle.random_execute(model, events, SEED_BASE + seed, lim)
+        used = events[:T.verdict_trace_idx(vv.flags)]
+        fpc = vv.fingerprint if vv.fingerprint else 0x1000103
+        target = T.Limits(0, 0, 128, 1, fpc, 0, 0, mode)
+        plain = T.Limits(0, 0, 128, 1, fpc, 0, 0, 0)
+        noq = [i for i in range(len(used)) if int(used[i]["kind"]) != T.EV_WAIT_QUIESCENCE]
+        kinds = rec["kind"]
+        ext_events = set(np.nonzero(kinds <= T.REC_UNPARTITION)[0].tolist())
+        ext_sends = set(np.nonzero((kinds == T.REC_MSG_SEND) & ((rec["flags"] & 1) == 1))[0].tolist())
+        msg_events = set(np.nonzero(kinds == T.REC_MSG_EVENT)[0].tolist())
+        for _ in range(40):
+            subseq = [i for i in noq if rng.random() < rng.choice([0.4, 0.7, 0.95, 1.0])]
+            mask = np.array(events_to_mask(subseq), dtype=np.uint64)
+            v, kept = oracle.sts_removal_kept(model, used, rec, 0xFFFFFFFF, target, mask=mask)
+            if v.flags & (T.V_PENDING_OVF | T.V_QUEUE_OVF):
+                continue
+            proj = _scala_subsequence_intersection(rec, used, subseq, model)
+            proj_f = set(_scala_filter_known_absent_internals(rec, proj, corrected=(mode == T.FILTER_ABSENTS_CORRECTED)))
+            kept_set = set(np.nonzero(kept)[0].tolist())
+            assert kept_set & ext_events == proj_f & ext_events
+            assert kept_set & ext_sends == proj_f & ext_sends
+            assert kept_set & msg_events <= proj_f & msg_events
+            assert bool(v.flags & T.V_DIVERGED) == (len(proj_f & msg_events) > len(kept_set & msg_events))
+            filtered += len(set(proj) & msg_events) - len(proj_f & msg_events)
+            v0 = oracle.sts_replay_batch(model, used, rec, mask[None, :], plain)[0]
+            changed += int(v0["hash"] != v.hash or (int(v0["flags"]) ^ int(v.flags)) & T.V_DIVERGED != 0)
+            checked += 1
+    assert checked > 100 and filtered > 100 and changed > 0
