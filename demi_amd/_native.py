@@ -15,7 +15,7 @@ EXPORTS = ["demi_ctx_create", "demi_ctx_destroy", "demi_last_error", "demi_versi
            "demi_trace_load", "demi_random_explore", "demi_random_explore_dev", "demi_random_get_trace", "demi_collect_violations_dev",
            "demi_replay_load", "demi_replay_batch", "demi_replay_batch_dev", "demi_dpor_load", "demi_dpor_batch", "demi_dpor_explore", "demi_random_explore_violations",
            "demi_replay_removal_batch", "demi_replay_get_kept", "demi_model_specialize", "demi_model_is_specialized",
-           "demi_specialize_check", "demi_specialize_source", "demi_device_probe", "demi_calib_rw", "demi_random_explore_flagged", "demi_collect_flagged_dev",
+           "demi_specialize_check", "demi_specialize_source", "demi_device_probe", "demi_device_probe_mix", "demi_calib_rw", "demi_random_explore_flagged", "demi_collect_flagged_dev",
            "demi_comm_unique_id", "demi_comm_create", "demi_comm_create_host", "demi_comm_destroy", "demi_comm_rank",
            "demi_comm_allgather_dev", "demi_random_explore_sharded", "demi_replay_batch_sharded"]
 
@@ -92,6 +92,7 @@ def lib():
                                               C.POINTER(C.c_uint64)]
     L.demi_replay_batch_sharded.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(T.Limits), C.c_void_p]
     L.demi_device_probe.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(T.ProbeResult)]
+    L.demi_device_probe_mix.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(T.ProbeResult)]
     L.demi_calib_rw.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint32]
     # every export has its argument types declared: an undeclared one would silently truncate pointers to 32 bits
     for name in EXPORTS:
@@ -351,10 +352,11 @@ class Context:
             self._check(lib().demi_replay_batch_sharded(self._h, masks.ctypes.data, len(masks), C.byref(limits), out.ctypes.data))
         return out
 
-    def device_probe(self, waves_per_simd=1, iters=20000):
-        """Shader clock under load (GHz) and SIMD cycles per wave64 integer VALU instruction (demi_device_probe)."""
+    def device_probe(self, waves_per_simd=1, iters=20000, kind=0):
+        """Shader clock under load (GHz) and SIMD cycles per wave64 instruction of the probe's kind: 0 integer VALU,
+        1 SALU, 2 VALU / SALU alternating, 3 a divergent `if` (demi_device_probe_mix)."""
         r = T.ProbeResult()
-        self._check(lib().demi_device_probe(self._h, waves_per_simd, iters, C.byref(r)))
+        self._check(lib().demi_device_probe_mix(self._h, waves_per_simd, iters, kind, C.byref(r)))
         return r
 
     def calib_rw(self, mode, nbytes, repeats=1):

@@ -456,6 +456,10 @@ typedef struct {
   uint32_t num_cu;
 } demi_probe_result;
 int demi_device_probe(demi_ctx* ctx, uint32_t waves_per_simd, uint32_t iters, demi_probe_result* out);
+/* The same for other instruction kinds (cycles_per_valu is then SIMD cycles per instruction of the probe's mix): kind 0 =
+ * integer VALU (demi_device_probe), 1 = SALU only, 2 = VALU and SALU alternating, 3 = the code of a divergent two-instruction
+ * `if` (saveexec / branch / body / restore).                                                                             */
+int demi_device_probe_mix(demi_ctx* ctx, uint32_t waves_per_simd, uint32_t iters, uint32_t kind, demi_probe_result* out);
 /* A kernel with a known byte count for calibrating rocprofv3's FETCH_SIZE / WRITE_SIZE: mode 0 writes / 1 reads `bytes`
  * with 4 B per lane (K1's scratch rows), 2 writes / 3 reads with 16 B per lane (the verdict array's pattern).          */
 int demi_calib_rw(demi_ctx* ctx, uint32_t mode, uint64_t bytes, uint32_t repeats);

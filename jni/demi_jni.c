@@ -8,7 +8,7 @@
  *   events    byte[8 * n]     demi_ext_event          recorded  byte[12 * n]  demi_rec_event
  *   verdicts  long[2 * n]     demi_verdict (long 0 = flags | fingerprint << 32, long 1 = hash)
  *   masks     long[4 * n]     candidate subsequences  violations long[2 * n]  demi_violation (index, fingerprint | flags << 32)
- *   limits    int[7]          demi_limits             dporParams int[7]  demi_dpor_params     dporSearch int[6]  demi_dpor_search
+ *   limits    int[8]          demi_limits             dporParams int[7]  demi_dpor_params     dporSearch int[6]  demi_dpor_search
  *   dporStats long[11]        demi_dpor_stats (kernel_ms as raw double bits)                                       */
 #include <jni.h>
 #include <stdint.h>
