@@ -15,7 +15,7 @@ EXPORTS = ["demi_ctx_create", "demi_ctx_destroy", "demi_last_error", "demi_versi
            "demi_trace_load", "demi_random_explore", "demi_random_explore_dev", "demi_random_get_trace", "demi_collect_violations_dev",
            "demi_replay_load", "demi_replay_batch", "demi_replay_batch_dev", "demi_dpor_load", "demi_dpor_batch", "demi_dpor_explore", "demi_random_explore_violations",
            "demi_replay_removal_batch", "demi_replay_get_kept", "demi_model_specialize", "demi_model_is_specialized",
-           "demi_specialize_check", "demi_specialize_source", "demi_device_probe", "demi_device_probe_mix", "demi_calib_rw", "demi_random_explore_flagged", "demi_collect_flagged_dev",
+           "demi_specialize_check", "demi_specialize_source", "demi_provenance_prune", "demi_device_probe", "demi_device_probe_mix", "demi_calib_rw", "demi_random_explore_flagged", "demi_collect_flagged_dev",
            "demi_comm_unique_id", "demi_comm_create", "demi_comm_create_host", "demi_comm_destroy", "demi_comm_rank",
            "demi_comm_allgather_dev", "demi_random_explore_sharded", "demi_replay_batch_sharded"]
 
@@ -92,6 +92,7 @@ def lib():
                                               C.POINTER(C.c_uint64)]
     L.demi_replay_batch_sharded.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(T.Limits), C.c_void_p]
     L.demi_device_probe.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(T.ProbeResult)]
+    L.demi_provenance_prune.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p]
     L.demi_device_probe_mix.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(T.ProbeResult)]
     L.demi_calib_rw.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint32]
     # every export has its argument types declared: an undeclared one would silently truncate pointers to 32 bits
@@ -350,6 +351,30 @@ class Context:
         out = np.zeros(len(masks), dtype=T.VERDICT_DTYPE)
         if len(masks):
             self._check(lib().demi_replay_batch_sharded(self._h, masks.ctypes.data, len(masks), C.byref(limits), out.ctypes.data))
+        return out
+
+    def provenance_prune(self, traces, affected_masks):
+        """demi_provenance_prune: traces = sequence of DPOR_TRACE_DTYPE arrays, affected_masks = one actor bitmask per trace;
+        returns a list of index arrays (the kept events of every trace)."""
+        import numpy as np
+        n = len(traces)
+        if n == 0:
+            return []
+        stride = max(1, max(len(t) for t in traces))
+        buf = np.zeros((n, stride), dtype=T.DPOR_TRACE_DTYPE)
+        lens = np.zeros(n, dtype=np.uint32)
+        for i, t in enumerate(traces):
+            buf[i, :len(t)] = t
+            lens[i] = len(t)
+        aff = np.ascontiguousarray(affected_masks, dtype=np.uint32)
+        assert len(aff) == n
+        words = T.DPOR_MAX_TRACE // 64
+        keep = np.zeros((n, words), dtype=np.uint64)
+        self._check(lib().demi_provenance_prune(self._h, buf.ctypes.data, lens.ctypes.data, aff.ctypes.data, stride, n, keep.ctypes.data))
+        out = []
+        for i in range(n):
+            bits = np.unpackbits(keep[i].view(np.uint8), bitorder="little")[:int(lens[i])]
+            out.append(np.nonzero(bits)[0].astype(np.int64))
         return out
 
     def device_probe(self, waves_per_simd=1, iters=20000, kind=0):

@@ -2,8 +2,11 @@
 
 Mirror of schedulers/Util.scala:267-376 (ProvenanceTracker) and RunnerUtils.pruneConcurrentEvents
 (RunnerUtils.scala:149-163), over the delivery trace of one execution as `dpor_initial_trace` produces it (root
-followed by the deliveries, each with the trace index of the delivery that sent it).  This runs once per found
-violation on a few hundred events, so it is host code (numpy bit matrix), not a kernel.
+followed by the deliveries, each with the trace index of the delivery that sent it).  Two forms: the class below (host,
+numpy bit matrix - the shape of the reference's own class, one trace at a time) and `pruneConcurrentEventsBatch`, which
+hands any number of traces to the library's bitset kernel (demi_provenance_prune, demi_amd/csrc/k_provenance.hpp: one
+wavefront per trace) - what RunnerUtils.fuzz uses when it runs on a device, and the way to prune every violating
+execution of a fuzz run at once.
 
 happens-before, first order (:283-299): every earlier receive on the same machine precedes a receive (the pair
 (u, u) included, as in the reference), and a receive precedes the messages sent while it was handled (its
@@ -70,7 +73,18 @@ class ProvenanceTracker:
         return np.nonzero(~removed)[0]
 
 
-def pruneConcurrentEvents(initialTrace: np.ndarray, affectedNodes: Sequence[int]) -> np.ndarray:
-    """RunnerUtils.pruneConcurrentEvents: the initial trace restricted to the provenance of the violation."""
+def pruneConcurrentEvents(initialTrace: np.ndarray, affectedNodes: Sequence[int], ctx=None) -> np.ndarray:
+    """RunnerUtils.pruneConcurrentEvents: the initial trace restricted to the provenance of the violation.
+    ctx: a demi_amd._native.Context - the closure and the pruning then run on its device."""
+    if ctx is not None:
+        return pruneConcurrentEventsBatch(ctx, [initialTrace], [affectedNodes])[0]
     keep = ProvenanceTracker(initialTrace).pruneConcurrentEvents(affectedNodes)
     return np.ascontiguousarray(initialTrace)[keep]
+
+
+def pruneConcurrentEventsBatch(ctx, initialTraces: Sequence[np.ndarray], affectedNodes: Sequence[Sequence[int]]) -> List[np.ndarray]:
+    """pruneConcurrentEvents for many executions in one launch (one wavefront per trace)."""
+    traces = [np.ascontiguousarray(t, dtype=T.DPOR_TRACE_DTYPE) for t in initialTraces]
+    masks = [sum(1 << int(a) for a in set(nodes) if 0 <= int(a) < T.MAX_ACTORS) for nodes in affectedNodes]
+    kept = ctx.provenance_prune(traces, masks)
+    return [t[k] for t, k in zip(traces, kept)]

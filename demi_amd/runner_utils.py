@@ -17,7 +17,8 @@ def fuzz(generateFuzzTest: Callable[[int], np.ndarray], schedulerConfig: Schedul
          validate_replay: Optional[Callable[[], ReplayScheduler]] = None, invariant_check_interval: int = 30,
          maxMessages: Optional[int] = None, randomizationStrategyCtor: Callable[[], object] = FullyRandom,
          computeProvenance: bool = True, violationWereLookingFor: Callable[[ViolationFingerprint], bool] = lambda f: True,
-         executions_per_test: int = 4096, max_tests: int = 64, scheduler_ctor=RandomScheduler
+         executions_per_test: int = 4096, max_tests: int = 64, scheduler_ctor=RandomScheduler,
+         provenance_device: Optional[int] = None
          ) -> Optional[Tuple[EventTrace, ViolationFingerprint, np.ndarray, np.ndarray]]:
     """RunnerUtils.fuzz: generate a fuzz test, explore it, keep the first violation that (optionally) replays
     deterministically, then prune the deliveries outside the violation's provenance.
@@ -27,7 +28,8 @@ def fuzz(generateFuzzTest: Callable[[int], np.ndarray], schedulerConfig: Schedul
     violating one.  generateFuzzTest(i) is Fuzzer.generateFuzzTest for the i-th attempt (fuzzer.generate_fuzz_test /
     raft_trace with a seed derived from i).  Returns (trace, violation, initialTrace, filtered) — the depGraph of the
     reference is implicit in the causal-path keys of initialTrace — or None after max_tests tests without a violation
-    (the reference loops forever)."""
+    (the reference loops forever).  provenance_device: run ProvenanceTracker on that GPU (demi_provenance_prune)
+    instead of the host class."""
     for attempt in range(max_tests):
         fuzzTest = np.ascontiguousarray(generateFuzzTest(attempt), dtype=T.EXT_EVENT_DTYPE)
         sched = scheduler_ctor(schedulerConfig, executions_per_test, invariant_check_interval,
@@ -57,7 +59,17 @@ def fuzz(generateFuzzTest: Callable[[int], np.ndarray], schedulerConfig: Schedul
             if not deterministic:
                 continue
         initialTrace = dpor_initial_trace(trace)
-        filtered = pruneConcurrentEvents(initialTrace, violation.affectedNodes()) if computeProvenance else initialTrace[:0]
+        if not computeProvenance:
+            filtered = initialTrace[:0]
+        elif provenance_device is not None:
+            from . import _native
+            pctx = _native.Context(provenance_device)
+            try:
+                filtered = pruneConcurrentEvents(initialTrace, violation.affectedNodes(), ctx=pctx)
+            finally:
+                pctx.close()
+        else:
+            filtered = pruneConcurrentEvents(initialTrace, violation.affectedNodes())
         return trace, violation, initialTrace, filtered
     return None
 

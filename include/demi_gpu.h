@@ -388,6 +388,16 @@ int demi_dpor_explore(demi_ctx* ctx, const demi_dpor_params* params, const demi_
                       demi_dpor_trace_entry* first_violation_trace, uint32_t* first_violation_len,
                       demi_dpor_stats* stats);
 
+/* ---------------------------------------------------------- provenance of a violation
+ * ProvenanceTracker.pruneConcurrentEvents (schedulers/Util.scala:267-376; RunnerUtils.pruneConcurrentEvents,
+ * RunnerUtils.scala:149-163) for n delivery traces at once: happens-before (same-machine receive order + "sent while
+ * handling") closed transitively, then an event is kept iff it strictly precedes the last receive of at least one actor
+ * of affected[i] (bit a = actor a, ViolationFingerprint.affectedNodes).  traces: [n][stride] entries as K3 /
+ * dpor_initial_trace produce them (word, parent and kind are read; trace_len[i] <= DEMI_DPOR_MAX_TRACE);
+ * out_keep: [n][DEMI_DPOR_MAX_TRACE / 64] words, bit u = event u of trace i is kept.  All host pointers.          */
+int demi_provenance_prune(demi_ctx* ctx, const demi_dpor_trace_entry* traces, const uint32_t* trace_len,
+                          const uint32_t* affected, uint32_t stride, uint64_t n, uint64_t* out_keep);
+
 /* ---------------------------------------------------------- found-violation set
  * One entry per violating schedule (what RunnerUtils.fuzz keeps: the violating execution's
  * index + fingerprint, RunnerUtils.scala:91-128).  Compacts a device verdict array into a device

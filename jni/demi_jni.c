@@ -226,6 +226,25 @@ JNIEXPORT jint JNICALL FN(dporExplore)(JNIEnv* e, jclass c, jlong h, jintArray p
   return rc == DEMI_OK ? (jint)vlen : rc;
 }
 
+/* ---- ProvenanceTracker.pruneConcurrentEvents for a batch of traces: traces byte[16 * stride * n] (demi_dpor_trace_entry),
+ *      traceLen int[n], affected int[n] (actor bitmasks), keep long[4 * n] */
+JNIEXPORT jint JNICALL FN(provenancePrune)(JNIEnv* e, jclass c, jlong h, jbyteArray traces, jintArray traceLen, jintArray affected,
+                                          jint stride, jlongArray keep) {
+  (void)c;
+  const jsize n = (*e)->GetArrayLength(e, traceLen);
+  void* t = PIN(traces);
+  void* l = PIN(traceLen);
+  void* a = PIN(affected);
+  void* k = PIN(keep);
+  jint rc = demi_provenance_prune(CTX(h), (const demi_dpor_trace_entry*)t, (const uint32_t*)l, (const uint32_t*)a, (uint32_t)stride,
+                                  (uint64_t)n, (uint64_t*)k);
+  UNPIN(keep, k, 0);
+  UNPIN(affected, a, JNI_ABORT);
+  UNPIN(traceLen, l, JNI_ABORT);
+  UNPIN(traces, t, JNI_ABORT);
+  return rc;
+}
+
 /* ---- multi-GPU: one JVM (and one ctx) per GPU; rank 0 obtains the id and sends the 128 bytes to the others */
 JNIEXPORT jint JNICALL FN(commUniqueId)(JNIEnv* e, jclass c, jbyteArray id128) {
   (void)c;

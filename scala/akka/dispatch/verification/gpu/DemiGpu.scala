@@ -31,6 +31,8 @@ object DemiGpu {
   /** returns the length of the first violating trace (entries of 16 bytes in firstViolationTrace), or a negative status */
   @native def dporExplore(h: Long, params: Array[Int], search: Array[Int], verdicts: Array[Long], prefixLen: Array[Int],
                           rounds: Array[Int], firstViolationTrace: Array[Byte], stats: Array[Long]): Int
+  /** ProvenanceTracker.pruneConcurrentEvents for n traces (16-byte entries, `stride` per trace); keep: 4 longs (256 bits) per trace */
+  @native def provenancePrune(h: Long, traces: Array[Byte], traceLen: Array[Int], affected: Array[Int], stride: Int, keep: Array[Long]): Int
   @native def commUniqueId(id128: Array[Byte]): Int
   @native def commCreate(h: Long, id128: Array[Byte], rank: Int, world: Int): Int
   @native def commDestroy(h: Long): Int

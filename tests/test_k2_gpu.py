@@ -324,10 +324,13 @@ def test_fuzz_then_the_gamut_end_to_end():
     cfg = SchedulerConfig(model=model)
     w = FuzzerWeights()
     gen = lambda i: events_to_array(raft_trace(5, 50, 0xF022 + i, w, exact=False))
-    res = fuzz(gen, cfg, validate_replay=lambda: ReplayScheduler(cfg), maxMessages=200, executions_per_test=2048, max_tests=8)
+    res = fuzz(gen, cfg, validate_replay=lambda: ReplayScheduler(cfg), maxMessages=200, executions_per_test=2048, max_tests=8,
+               provenance_device=0)
     assert res is not None
     trace, violation, initial, filtered = res
     assert len(initial) == 1 + countMsgEvents(trace) and 0 < len(filtered) <= len(initial)
+    from demi_amd.provenance import pruneConcurrentEvents
+    assert (filtered == pruneConcurrentEvents(initial, violation.affectedNodes())).all()      # device kernel == host class
     out = run_the_gamut(cfg, trace, violation)
     assert out["verified_mcs"] is not None and len(out["mcs"]) < out["original_externals"]
     assert out["minimized_deliveries"] <= countMsgEvents(out["verified_mcs"]) <= out["original_deliveries"]
