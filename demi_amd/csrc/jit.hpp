@@ -226,8 +226,17 @@ inline bool compile(Rtc& rtc, const std::string& source, const std::vector<Heade
     return false;
   }
   for (const std::string& n : name_exprs) rtc.add_name(prog, n.c_str());
-  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-label"};
-  const int rc = rtc.compile(prog, 4, opts);
+  std::vector<const char*> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-label"};
+  std::vector<std::string> extra;                            // experiment knob: DEMI_JIT_FLAGS = extra compiler options, space separated
+  if (const char* f = getenv("DEMI_JIT_FLAGS")) {
+    std::string item;
+    for (const char* c = f;; c++) {
+      if (*c == ' ' || *c == '\0') { if (!item.empty()) extra.push_back(item); item.clear(); if (*c == '\0') break; }
+      else item += *c;
+    }
+  }
+  for (const std::string& x : extra) opts.push_back(x.c_str());
+  const int rc = rtc.compile(prog, (int)opts.size(), opts.data());
   if (rc != 0) {
     size_t ls = 0;
     rtc.log_size(prog, &ls);
