@@ -362,10 +362,15 @@ def main():
         probe = None
         try:
             p1, p6 = ctx.device_probe(1, 20000), ctx.device_probe(6, 6000)
+            s6, m6, d6 = ctx.device_probe(6, 6000, 1), ctx.device_probe(6, 6000, 2), ctx.device_probe(6, 6000, 3)
             probe = {"shader_clock_ghz": p6.shader_clock_ghz, "simd_cycles_per_int_valu_1_wave": p1.cycles_per_valu,
                      "simd_cycles_per_int_valu_6_waves": p6.cycles_per_valu,
-                     "how": "demi_device_probe: s_memtime cycles per 100 MHz wall_clock64 tick; 64-instruction unrolled "
-                            "v_mad_u32_u24 / v_add / v_xor passes on 8 independent accumulators"}
+                     "simd_cycles_per_salu_6_waves": s6.cycles_per_valu,
+                     "simd_cycles_per_inst_valu_salu_alternating_6_waves": m6.cycles_per_valu,
+                     "simd_cycles_per_inst_divergent_if_6_waves": d6.cycles_per_valu,
+                     "how": "demi_device_probe_mix: s_memtime cycles per 100 MHz wall_clock64 tick; unrolled passes of "
+                            "independent integer VALU instructions / SALU instructions / the two alternating / the code of a "
+                            "divergent two-instruction if, with 6 waves per SIMD as in K1"}
         except Exception as e:
             print("bench: device probe failed: %s" % e, file=sys.stderr)
         # rocprofv3 counters of THIS kernel build on this workload (tools/profile_k1.sh writes profiles/k1_counters.json with
@@ -382,12 +387,18 @@ def main():
                     cus = props.multi_processor_count
                     clk = probe["shader_clock_ghz"] * 1e9
                     valu, salu = ctr["SQ_INSTS_VALU"], ctr["SQ_INSTS_SALU"]
+                    other = ctr.get("SQ_INSTS_LDS", 0) + ctr.get("SQ_INSTS_VMEM_RD", 0) + ctr.get("SQ_INSTS_VMEM_WR", 0)
+                    cyc = kernel_ms * 1e-3 * clk
                     issue = {"valu_insts_per_launch": valu, "salu_insts_per_launch": salu,
                              "active_lanes_per_valu_inst": ctr.get("SQ_THREAD_CYCLES_VALU", 0) / valu if valu else None,
-                             "valu_issue_frac": valu * probe["simd_cycles_per_int_valu_6_waves"] / (cus * 4) / (kernel_ms * 1e-3 * clk),
-                             "salu_issue_frac": salu / cus / (kernel_ms * 1e-3 * clk),
-                             "clock_hz": clk, "source": "profiles/k1_counters.json (rocprofv3 --pmc, kernel_ms %.3f there); clock and "
-                             "cycles per VALU instruction measured in this run; one scalar unit per CU assumed" % pms}
+                             "valu_alone_frac": valu * probe["simd_cycles_per_int_valu_6_waves"] / (cus * 4) / cyc,
+                             "salu_alone_frac": salu * probe["simd_cycles_per_salu_6_waves"] / (cus * 4) / cyc,
+                             "issue_frac_straight_line": (valu + salu + other) * probe["simd_cycles_per_inst_valu_salu_alternating_6_waves"] / (cus * 4) / cyc,
+                             "issue_frac_branchy": (valu + salu + other) * probe["simd_cycles_per_inst_divergent_if_6_waves"] / (cus * 4) / cyc,
+                             "clock_hz": clk, "source": "profiles/k1_counters.json (rocprofv3 --pmc, kernel_ms %.3f there); the clock and "
+                             "the SIMD cycles per instruction of each kind are measured in this run (roofline.probe): the share "
+                             "of the kernel's duration that issuing its instructions takes lies between the straight-line and "
+                             "the branchy figure" % pms}
             else:
                 stale = "profiles/k1_counters.json describes a %.3f ms kernel, this run measured %.3f ms: counters not quoted" % (pms, kernel_ms)
         out = {
