@@ -39,6 +39,8 @@ if cur:
         k1["kernel_ms"] = sum(tail) / len(tail) / 1e6
         k1["kernel_ms_all_launches"] = sum(rows) / len(rows) / 1e6
         k1["launches_profiled"] = len(rows)
+        lines += ["# K1 launches in trace order: all %d avg %.4f ms; the timed ones (last %d) avg %.4f ms" %
+                  (len(rows), k1["kernel_ms_all_launches"], len(tail), k1["kernel_ms"]), ""]
 for d in ("prof_fetch", "prof_write", "prof_sq", "prof_sq2"):
     cur = db_of(d)
     if not cur:
