@@ -270,15 +270,23 @@ def main():
     # barrier.  If RCCL cannot be initialised there, torch.distributed's all_gather does the exchange (and the line says so).
     collective = "none (1 rank)"
     if world > 1:
-        try:
-            uid = torch.zeros(128, dtype=torch.uint8, device=dev)
-            if rank == 0:
-                uid = torch.tensor(list(_native.Context.comm_unique_id()), dtype=torch.uint8, device=dev)
-            dist.broadcast(uid, 0)
-            ctx.comm_create(bytes(uid.cpu().tolist()), rank, world)
-            collective = "demi_comm_allgather_dev (RCCL ncclAllGather inside libdemi_gpu.so)"
-        except Exception as e:
-            collective = "torch.distributed.all_gather (library communicator unavailable: %s)" % e
+        # (every rank takes part in both broadcasts whatever happens on rank 0: a failure there must not leave the others waiting)
+        uid = torch.zeros(129, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            try:
+                uid[:128] = torch.tensor(list(_native.Context.comm_unique_id()), dtype=torch.uint8, device=dev)
+                uid[128] = 1
+            except Exception as e:
+                print("bench: no RCCL unique id: %s" % e, file=sys.stderr)
+        dist.broadcast(uid, 0)
+        if int(uid[128].item()) == 1:
+            try:
+                ctx.comm_create(bytes(uid[:128].cpu().tolist()), rank, world)
+                collective = "demi_comm_allgather_dev (RCCL ncclAllGather inside libdemi_gpu.so)"
+            except Exception as e:
+                collective = "torch.distributed.all_gather (library communicator unavailable: %s)" % e
+        else:
+            collective = "torch.distributed.all_gather (library communicator unavailable: no unique id on rank 0)"
         flag = torch.tensor([1 if collective.startswith("demi_comm") else 0], dtype=torch.int32, device=dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)          # all ranks take the same path
         if int(flag.item()) == 0 and collective.startswith("demi_comm"):
