@@ -1,0 +1,354 @@
+"""CPU suite: one RandomScheduler execution transliterated from the Scala, against the oracle (K1's restatement).
+
+What is transliterated, with the reference's own data structures (queues of tuples, hash sets, the multiset of enqueued
+external messages, RandomizedHashSet with its swap-with-last removal):
+  RandomScheduler.explore / event_produced / schedule_new_message / updateRepeatingTimer / notify_quiescence /
+    notify_timer_cancel / enqueue_timer                        (schedulers/RandomScheduler.scala:234-272, 282-321, 352-485, 487-500, 525-559)
+  FullyRandom (+=, remove, removeRandomElement)                (:631-684)
+  ExternalEventInjector.enqueue_message / handle_timer / send_external_messages / execute_trace / advanceTrace /
+    handle_event_produced / handle_event_consumed / handle_quiescence / handle_timer_cancel
+                                                               (schedulers/ExternalEventInjector.scala:250-297, 299-365, 382-441, 492-512, 529-580, 601-610)
+  EventOrchestrator.inject_until_quiescence / trigger_* / isolate / unisolate / crosses_partition
+                                                               (schedulers/EventOrchestrator.scala:132-189, 192-241, 314-330, 345-351)
+  Instrumenter: the dispatch step with the repeating-timer retrigger, registerCancellable / handleTick / removeCancellable /
+    cancelTimer / actorCrashed / seededRandom                  (Instrumenter.scala:159-168, 184-199, 212-229, 1008-1016, 1145-1200)
+  Util.find_non_blocked_message, RandomizedHashSet            (schedulers/Util.scala:110-185, 470-489; literal classes of
+                                                                tests/test_blocked_actors_cpu.py)
+The actors' `receive` is the table (oracle's row interpreter, one call per delivery): what is pinned here is the scheduler.
+Pinned as in the oracle: a repeating timer's retrigger runs before the receive it races with."""
+import ctypes as C
+from collections import Counter
+
+import numpy as np
+import pytest
+
+from demi_amd import model as M
+from demi_amd import types as T
+from demi_amd.fuzzer import FuzzerWeights, JavaRandom, events_to_array, raft_trace, send, start, wait_quiescence
+
+from .test_blocked_actors_cpu import RandomizedHashSet, find_non_blocked_message
+
+MASK64 = (1 << 64) - 1
+DEAD = "deadLetters"
+
+
+class _Effect(C.Structure):
+    _fields_ = [("kind", C.c_uint8), ("target", C.c_uint8), ("msg_type", C.c_uint8), ("p0", C.c_uint8), ("p1", C.c_uint8)]
+
+
+class FullyRandom:
+    """RandomScheduler.scala:631-684 over the literal RandomizedHashSet; an element is (snd, rcv, msg, uniq id)."""
+
+    def __init__(self, seed):
+        self.pendingEvents = RandomizedHashSet(seed)
+
+    def add(self, e):
+        self.pendingEvents.insert(e)
+
+    def isEmpty(self):
+        return self.pendingEvents.isEmpty()
+
+    def insert(self, e):                      # Growable.+= (find_non_blocked_message's `collection ++= blocked`)
+        self.pendingEvents.insert(e)
+
+    def remove(self, snd, rcv, msg):
+        arr = self.pendingEvents.arr
+        for i, e in enumerate(arr):
+            if snd == e[0] and rcv == e[1] and msg == e[2]:
+                arr[i] = arr[-1]              # RandomizedHashSet.remove: A[i] = d, drop the last cell
+                arr.pop()
+                return e
+        return None
+
+    def removeRandomElement(self):
+        # userDefinedFilter is the default (always true): the rejection loop never runs
+        return self.pendingEvents.removeRandomElement()
+
+
+class ScalaRandomScheduler:
+    def __init__(self, oracle, model, trace, seed, maxMessages, invariant_check_interval):
+        self.oracle, self.model, self.ms = oracle, model, model.to_struct()
+        self.trace = [tuple(int(x) for x in (e["kind"], e["a"], e["b"], e["msg_type"], e["p0"], e["p1"])) for e in trace]
+        self.maxMessages = maxMessages if maxMessages else (1 << 31) - 1
+        self.invariant_check_interval = invariant_check_interval
+        A = model.n_actors
+        # ---- EventOrchestrator
+        self.traceIdx = 0
+        self.partitioned, self.inaccessible, self.killed = set(), set(), set()
+        self.actorToActorRef = set()
+        # ---- ExternalEventInjector
+        self.enqueuedExternalMessages = Counter()
+        self.messagesToSend = []                      # (senderOpt, receiver, msg)
+        # ---- RandomScheduler
+        self.pendingEvents = FullyRandom(seed)
+        self.justScheduledTimers, self.timersToResend = set(), []
+        self.violationFound = None
+        self.messagesScheduledSoFar = 0
+        self.finished_early = False
+        # ---- Instrumenter
+        self.timerToCancellable, self.ongoingCancellableTasks, self.registeredCancellableTasks = {}, set(), set()
+        self.next_cancellable = 0
+        self.blockedActors = set()
+        self.seededRandom = C.c_uint64((0 ^ 0x5DEECE66D) & ((1 << 48) - 1))       # new Random(0)
+        # ---- the application
+        self.state = [int(s) for s in model.init_state[:A]]
+        self.deliveries = []
+        self.next_uniq = 1
+        # populateActorSystem: every actor that is ever Start()ed is created and isolated (:371-378, 397-406)
+        for kind, a, *_ in self.trace:
+            if kind == T.EV_START:
+                self.actorToActorRef.add(a)
+                self.inaccessible.add(a)
+        self.exists = sum(1 << a for a in self.actorToActorRef)
+
+    # ------------------------------------------------------------------ EventOrchestrator
+    def trace_finished(self):
+        return self.traceIdx >= len(self.trace)
+
+    def crosses_partition(self, snd, rcv):
+        if snd == rcv and snd not in self.killed:
+            return False
+        return ((snd, rcv) in self.partitioned or (rcv, snd) in self.partitioned or rcv in self.inaccessible
+                or snd in self.inaccessible)
+
+    def inject_until_quiescence(self):
+        loop = True
+        while loop and not self.trace_finished():
+            kind, a, b, mtype, p0, p1 = self.trace[self.traceIdx]
+            if kind == T.EV_START:                    # trigger_start: unisolate_node + blockedActors -= name
+                self.inaccessible.discard(a)
+                self.killed.discard(a)
+                self.blockedActors.discard(a)
+            elif kind == T.EV_KILL:                   # trigger_kill
+                self.killed.add(a)
+                self.inaccessible.add(a)
+            elif kind == T.EV_SEND:
+                self.enqueue_message(None, a, (mtype, p0, p1))
+            elif kind == T.EV_PARTITION:
+                self.partitioned.add((a, b))
+            elif kind == T.EV_UNPARTITION:
+                self.partitioned.discard((a, b))
+            elif kind == T.EV_WAIT_QUIESCENCE:
+                loop = False
+            self.traceIdx += 1                        # trace_advanced()
+
+    # ------------------------------------------------------------------ ExternalEventInjector
+    def enqueue_message(self, sender, receiver, msg):
+        if receiver not in self.actorToActorRef:      # "Unknown message receiver"
+            return
+        self.enqueuedExternalMessages[msg] += 1
+        self.messagesToSend.append((sender, receiver, msg))
+
+    def handle_timer(self, receiver, msg):
+        if receiver in self.actorToActorRef:
+            self.messagesToSend.append((None, receiver, msg))
+
+    def send_external_messages(self):
+        for senderOpt, receiver, msg in self.messagesToSend:
+            # Instrumenter().receiverIsAlive(receiver): the actor exists
+            if receiver in self.actorToActorRef:
+                self.tell(DEAD if senderOpt is None else senderOpt, receiver, msg)        # receiver ! msg
+        self.messagesToSend = []
+
+    def handle_timer_cancel(self, rcv, msg):
+        for i, (s, r, m) in enumerate(self.messagesToSend):     # dequeueFirst
+            if r == rcv and m == msg:
+                del self.messagesToSend[i]
+                return True
+        return False
+
+    # ------------------------------------------------------------------ RandomScheduler
+    def tell(self, snd, rcv, msg):
+        """`rcv ! msg` under the instrumentation: event_produced (:282-321)."""
+        uniq = self.next_uniq
+        self.next_uniq += 1
+        if self.enqueuedExternalMessages[msg] > 0:                  # handle_event_produced -> ExternalMessage
+            self.pendingEvents.add((snd, rcv, msg, uniq))
+        else:                                                        # InternalMessage (a timer when snd == deadLetters)
+            if not self.crosses_partition(snd, rcv):
+                self.pendingEvents.add((snd, rcv, msg, uniq))
+
+    def test_invariant(self):
+        states = (C.c_uint64 * T.MAX_ACTORS)(*self.state)
+        return int(self.oracle.lib().orc_invariant(C.byref(self.ms), states, self.exists))
+
+    def isTimer(self, rcv, msg):
+        return (rcv, msg) in self.timerToCancellable
+
+    def updateRepeatingTimer(self, rcv, msg):
+        if self.isTimer(rcv, msg):
+            self.justScheduledTimers.add((rcv, msg))
+        else:
+            for r, t in self.timersToResend:
+                self.handle_timer(r, t)
+            self.timersToResend = []
+            self.justScheduledTimers.clear()
+
+    def schedule_new_message(self):
+        if self.violationFound:
+            return None
+        if self.messagesScheduledSoFar > self.maxMessages:
+            self.traceIdx = len(self.trace)                          # event_orchestrator.finish_early
+            self.finished_early = True
+            return None
+        if (self.invariant_check_interval > 0 and self.messagesScheduledSoFar % self.invariant_check_interval == 0
+                and 0 != self.messagesScheduledSoFar):               # lastCheckpoint (= 0) != messagesScheduledSoFar
+            self.violationFound = self.test_invariant() or None
+            if self.violationFound:
+                return None
+        self.send_external_messages()
+        toSchedule = find_non_blocked_message(self.blockedActors, self.pendingEvents, lambda e: e[1])
+        if toSchedule is None:
+            return None
+        self.messagesScheduledSoFar += 1
+        snd, rcv, msg, _uniq = toSchedule
+        self.updateRepeatingTimer(rcv, msg)
+        return toSchedule
+
+    def notify_timer_cancel(self, rcv, msg):
+        if self.handle_timer_cancel(rcv, msg):
+            return
+        self.pendingEvents.remove(DEAD, rcv, msg)
+
+    def enqueue_timer(self, receiver, msg):
+        if (receiver, msg) in self.justScheduledTimers:
+            self.timersToResend.append((receiver, msg))
+            return
+        self.handle_timer(receiver, msg)
+
+    # ------------------------------------------------------------------ Instrumenter
+    def registerCancellable(self, ongoingTimer, receiver, msg):
+        if (receiver, msg) in self.timerToCancellable:              # "Non-unique timer"
+            return
+        c = self.next_cancellable
+        self.next_cancellable += 1
+        self.registeredCancellableTasks.add(c)
+        if ongoingTimer:
+            self.ongoingCancellableTasks.add(c)
+        self.timerToCancellable[(receiver, msg)] = c
+        self.handleTick(receiver, msg, c)
+
+    def removeCancellable(self, c):
+        self.registeredCancellableTasks.discard(c)
+        for k, v in list(self.timerToCancellable.items()):
+            if v == c:
+                del self.timerToCancellable[k]
+
+    def handleTick(self, receiver, msg, c):
+        assert c in self.registeredCancellableTasks
+        self.enqueue_timer(receiver, msg)
+        if c not in self.ongoingCancellableTasks:
+            self.removeCancellable(c)
+
+    def cancelTimer(self, rcv, msg):
+        c = self.timerToCancellable.get((rcv, msg))
+        if c is not None:
+            self.ongoingCancellableTasks.discard(c)
+            self.removeCancellable(c)
+        self.notify_timer_cancel(rcv, msg)
+
+    def dispatch_new_message(self, snd, rcv, msg):
+        mtype, p0, p1 = msg
+        self.deliveries.append((15 if snd == DEAD else snd, rcv, mtype, p0, p1))
+        if self.enqueuedExternalMessages[msg] > 0:                  # handle_event_consumed
+            self.enqueuedExternalMessages[msg] -= 1
+        # "Check if it was a repeating timer. If so, retrigger it" (pinned before the receive)
+        c = self.timerToCancellable.get((rcv, msg))
+        if c is not None and c in self.ongoingCancellableTasks:
+            self.handleTick(rcv, msg, c)
+        # the actor's receive
+        st = C.c_uint64(self.state[rcv])
+        fx = (_Effect * 64)()
+        n = self.oracle.lib().orc_vm_run(C.byref(self.ms), rcv, C.byref(st), mtype, 15 if snd == DEAD else snd, p0, p1,
+                                         self.exists, fx, 64, C.byref(self.seededRandom))
+        assert n >= 0
+        self.state[rcv] = int(st.value)
+        for e in fx[:n]:
+            if e.kind == 0:
+                self.tell(rcv, int(e.target), (int(e.msg_type), int(e.p0), int(e.p1)))
+            elif e.kind in (1, 2):                                  # scheduleOnce / schedule: the timer message has no payload
+                self.registerCancellable(e.kind == 2, rcv, (int(e.msg_type), 0, 0))
+            elif e.kind == 3:
+                self.cancelTimer(rcv, (int(e.msg_type), 0, 0))
+            elif e.kind == 4:                                       # actorCrashed
+                self.blockedActors.add(rcv)
+
+    # ------------------------------------------------------------------ explore(): one execution
+    def execute(self):
+        while True:
+            self.inject_until_quiescence()                          # advanceTrace
+            while True:                                             # start_dispatch ... after every receive
+                nxt = self.schedule_new_message()
+                if nxt is None:
+                    break
+                self.dispatch_new_message(nxt[0], nxt[1], nxt[2])
+            # notify_quiescence
+            if self.violationFound:
+                break
+            if not self.trace_finished():                           # handle_quiescence: events += Quiescence; advanceTrace()
+                continue
+            break
+        if self.messagesScheduledSoFar <= self.maxMessages and not self.violationFound:
+            self.violationFound = self.test_invariant() or None     # checkIfBugFound
+        return self.violationFound
+
+    def verdict(self):
+        h = 0xCBF29CE484222325
+        for snd, rcv, mtype, p0, p1 in self.deliveries:
+            w = mtype | (rcv << 5) | (snd << 8) | (p0 << 16) | (p1 << 24)
+            h = ((h ^ w) * 0x100000001B3) & MASK64
+        for a in range(self.model.n_actors):
+            h = ((h ^ self.state[a]) * 0x100000001B3) & MASK64
+        flags = (T.V_VIOLATION if self.violationFound else 0) | (T.V_MAXMSG if self.finished_early else 0)
+        flags |= (self.traceIdx & 0xFF) << 8 | min(self.messagesScheduledSoFar, 0xFFFF) << 16
+        return flags, int(self.violationFound or 0), h
+
+
+def _compare(oracle, model, events, seeds, max_messages, interval, p_max=128):
+    lim = T.Limits(max_messages, interval, p_max, 0, 0, 0)
+    checked = violations = 0
+    for seed in seeds:
+        v, rec, _states = oracle.random_execute(model, events, seed, lim)
+        if v.flags & (T.V_PENDING_OVF | T.V_QUEUE_OVF):
+            continue                                    # a capacity of the restatement, not a behaviour of the reference
+        s = ScalaRandomScheduler(oracle, model, events, seed, max_messages, interval)
+        s.execute()
+        got = [(int(e["snd"]), int(e["rcv"]), int(e["msg_type"]), int(e["p0"]), int(e["p1"])) for e in rec if e["kind"] == T.REC_MSG_EVENT]
+        assert got == s.deliveries, "seed %d: delivery sequences differ at %d" % (
+            seed, next((i for i, (x, y) in enumerate(zip(got, s.deliveries)) if x != y), min(len(got), len(s.deliveries))))
+        assert (int(v.flags), int(v.fingerprint), int(v.hash)) == s.verdict(), "seed %d" % seed
+        checked += 1
+        violations += int(bool(v.flags & T.V_VIOLATION))
+    return checked, violations
+
+
+def test_raft5_fuzz_executions_equal_the_scala_transliteration(oracle):
+    from demi_amd.apps import SEED_BASE, raft5_config2
+    model, events, lim = raft5_config2()
+    checked, violations = _compare(oracle, model, events, [SEED_BASE + i for i in range(70)], lim.max_messages, lim.invariant_check_interval)
+    assert checked == 70 and violations >= 1            # (index 61 is the first violating execution of the frozen workload)
+    checked, _ = _compare(oracle, model, events, [7, 8, 9], 0, 0)              # unbounded, invariant only at the end
+    assert checked == 3
+    checked, _ = _compare(oracle, model, events, [3, 4, 5, 6], 25, 7)          # maxMessages cuts the execution short
+    assert checked == 4
+
+
+def test_kills_partitions_and_restarts_equal_the_scala_transliteration(oracle):
+    model = M.raft_model(5, election_budget=2)
+    w = FuzzerWeights(kill=0.12, send=0.35, wait_quiescence=0.13, partition=0.25, unpartition=0.15)
+    total = violations = 0
+    for tseed in (1, 2, 3, 4, 5, 6):
+        events = events_to_array(raft_trace(5, 60, tseed, w, exact=False))
+        c, v = _compare(oracle, model, events, [1000 * tseed + i * 7919 for i in range(12)], 300, 10)
+        total += c
+        violations += v
+    assert total >= 60
+
+
+def test_crashing_and_randomised_applications_equal_the_scala_transliteration(oracle):
+    from .test_blocked_actors_gpu import crashy_model, crashy_trace, jittery_model
+    c, _ = _compare(oracle, crashy_model(), crashy_trace(), [11 + 104729 * i for i in range(40)], 300, 0, p_max=64)
+    assert c >= 30
+    ev = events_to_array([start(a) for a in range(4)] + [send(a, 0) for a in range(4)] + [wait_quiescence(), send(1, 0), send(2, 0)])
+    c, _ = _compare(oracle, jittery_model(), ev, [0x7E57AB1E0000 + 31 * i for i in range(40)], 150, 11, p_max=64)
+    assert c >= 30
