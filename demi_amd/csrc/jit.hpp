@@ -130,7 +130,7 @@ inline std::string generate_vm(const demi::DevModel& h) {
         case DEMI_OP_POPC: snprintf(val, sizeof val, "(uint32_t)__popc(%s)", b); break;
         case DEMI_OP_MIN: snprintf(val, sizeof val, "%s < %s ? %s : %s", a, b, a, b); break;
         case DEMI_OP_MAX: snprintf(val, sizeof val, "%s < %s ? %s : %s", a, b, b, a); break;
-        case DEMI_OP_RND: snprintf(val, sizeof val, "app_next_int(app_rng, %s, t.magic)", b); break;
+        case DEMI_OP_RND: snprintf(val, sizeof val, "app_next_int(app_rng, %s, t.gmagic)", b); break;
         default: snprintf(val, sizeof val, "(%s %s %s) ? 1u : 0u", a, relop[op - DEMI_OP_EQ], b); break;   // EQ .. GT
       }
       if (pred_of[pc] >= 0) emit("%s = c%d ? (%s) : %s;\n", d, pred_of[pc], val, d);

@@ -68,7 +68,8 @@ struct Tables {
   const uint32_t* code;   // [code_len] transition-table rows
   const uint32_t* hs;     // [n_classes * NT] handler starts
   const uint32_t* meta;   // [32] msg_class | timer_idx << 8
-  const uint32_t* magic;  // [257] nextInt multiply-high magics
+  const uint32_t* magic;  // [129] nextInt multiply-high magics of the scheduler's bounds (<= p_max <= 128), in LDS
+  const uint32_t* gmagic; // [257] the whole table in the model blob (global memory): DEMI_OP_RND's bounds go up to 255 and are rare
   const uint32_t* optab;  // [64] per-op control words (op_control)
   uint32_t A, NT, code_len, E, exists, ac_packed;
   uint32_t inv_kind, inv_fa, inv_va, inv_fb, fp_mask;
@@ -76,7 +77,7 @@ struct Tables {
 
 __host__ __device__ inline size_t tables_lds_bytes(uint32_t code_len, uint32_t n_ev, uint32_t n_hs) {
   size_t b = (size_t)n_ev * 8 + DEMI_MAX_ACTORS * 8 + (size_t)code_len * 4 + (size_t)n_hs * 4 +
-             DEMI_MAX_MSG_TYPES * 4 + 260 * 4 + 64 * 4;
+             DEMI_MAX_MSG_TYPES * 4 + 132 * 4 + 64 * 4;
   return (b + 15) & ~(size_t)15;
 }
 
@@ -94,17 +95,17 @@ __device__ inline unsigned char* tables_load(Tables& t, unsigned char* smem, con
   uint32_t* s_hs = s_code + t.code_len;
   uint32_t* s_meta = s_hs + n_hs;
   uint32_t* s_magic = s_meta + DEMI_MAX_MSG_TYPES;
-  uint32_t* s_optab = s_magic + 260;
+  uint32_t* s_optab = s_magic + 132;
   for (uint32_t i = threadIdx.x; i < n_ev; i += blockDim.x) s_trace[i] = g_trace[i];
   for (uint32_t i = threadIdx.x; i < DEMI_MAX_ACTORS; i += blockDim.x) s_init[i] = gm->init_state[i];
   for (uint32_t i = threadIdx.x; i < t.code_len; i += blockDim.x) s_code[i] = gm->code[i];
   for (uint32_t i = threadIdx.x; i < n_hs; i += blockDim.x) s_hs[i] = gm->handler_start[i];
   for (uint32_t i = threadIdx.x; i < DEMI_MAX_MSG_TYPES; i += blockDim.x) s_meta[i] = gm->meta[i];
-  for (uint32_t i = threadIdx.x; i < 257; i += blockDim.x) s_magic[i] = gm->divmagic[i];
+  for (uint32_t i = threadIdx.x; i < 129; i += blockDim.x) s_magic[i] = gm->divmagic[i];
   for (uint32_t i = threadIdx.x; i < 64; i += blockDim.x) s_optab[i] = gm->optab[i];
   t.ac_packed = 0;
   for (uint32_t a = 0; a < t.A; a++) t.ac_packed |= gm->actor_class[a] << (4 * a);
-  t.trace = s_trace; t.init = s_init; t.code = s_code; t.hs = s_hs; t.meta = s_meta; t.magic = s_magic; t.optab = s_optab;
+  t.trace = s_trace; t.init = s_init; t.code = s_code; t.hs = s_hs; t.meta = s_meta; t.magic = s_magic; t.gmagic = gm->divmagic; t.optab = s_optab;
   __syncthreads();
   return smem + tables_lds_bytes(t.code_len, n_ev, n_hs);
 }
@@ -246,7 +247,7 @@ __device__ inline uint32_t vm_run(const Tables& t, const LaneMem& mem, uint32_t 
     r |= cond & mask_of(cw, 10);                                                                  // EQ..GT
     const uint32_t mn = mask_of(cw, 12);                 // MIN: b ^ ((a^b) & lt)   MAX: a ^ ((a^b) & lt)
     r |= (((b & mn) | (a & ~mn)) ^ ((a ^ b) & ltm)) & mask_of(cw, 11);
-    if (cw & CW_RND) r = app_next_int(app_rng, b, t.magic);                                       // RND (rare: a real branch)
+    if (cw & CW_RND) r = app_next_int(app_rng, b, t.gmagic);                                       // RND (rare: a real branch)
     // ---- write-back, branch-free: insert byte r into word dsti>>2 when the row is an ALU row
     const uint32_t k8 = (dsti & 3u) * 8u;
     const uint32_t ins = 0x03020100u ^ ((((dsti & 3u) ^ 4u)) << k8);         // selector: byte k := S0.byte0

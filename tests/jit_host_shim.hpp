@@ -5,7 +5,7 @@
 #define DEMI_FX_CAP 8
 #define DEMI_V_QUEUE_OVF 0x8u
 namespace demi {
-struct Tables { const uint32_t* hs; uint32_t ac_packed, NT; const uint32_t* magic; };
+struct Tables { const uint32_t* hs; uint32_t ac_packed, NT; const uint32_t* magic; const uint32_t* gmagic; };
 struct LaneMem { uint64_t* st; uint32_t* fxq; };
 static inline uint32_t w_type(uint32_t w) { return w & 31u; }
 static inline uint32_t w_dst(uint32_t w) { return (w >> 5) & 7u; }
