@@ -1,5 +1,5 @@
 // k3_pairs.hpp — dpor()'s bookkeeping on the device: the ExploredTacker (AuxilaryTypes.scala:209-246) as a
-// device-resident hash table over ordered pairs of node keys, and the enqueue decision of dpor() (:1068-1070, 1134) and
+// device-resident hash table over pairs of node keys (one 64-byte entry per unordered pair, a side per orientation), and the enqueue decision of dpor() (:1068-1070, 1134) and
 // getNext()'s skip (:1153-1157) taken there, so that of the ~10^3 racing pairs of an interleaving only the backtrack
 // points that can still be dequeued live ever leave the GPU.
 //
@@ -23,11 +23,12 @@
 
 namespace demi {
 
-struct PairEntry {           // 32 bytes; key (0, 0) = empty slot (node keys are FNV chains, never both 0)
-  unsigned long long a, b;   // ordered pair of node keys
-  unsigned long long cand;   // this round's candidate for the points flipping INTO (a, b): round | branch + 1 | ~ordinal
-  uint32_t state;            // bit 31: explored; bits 0..8: 1 + highest branch of a queued point flipping into (a, b)
-  uint32_t pad;
+struct PairEntry {           // 64 bytes, one per UNORDERED pair of node keys: everything dpor() does with a racing pair touches
+                             // the ordered pair and its flip, so both live in one line.  Side 0 is (lo, hi), side 1 is (hi, lo).
+  unsigned long long lo, hi; // lo < hi; lo == 0 = empty slot (node keys are FNV chains, never 0)
+  unsigned long long cand[2];   // per side: this round's candidate for the points flipping INTO it: round | branch + 1 | ~ordinal
+  uint32_t state[2];         // per side: bit 31 explored; bits 0..8: 1 + highest branch of a queued point flipping into it
+  uint32_t pad[6];
 };
 constexpr uint32_t PE_EXPLORED = 0x80000000u, PE_QMASK = 0x1FFu;
 
@@ -37,23 +38,26 @@ __device__ __forceinline__ uint64_t pair_hash(uint64_t a, uint64_t b) {
   return h;
 }
 
-// find or insert (a, b); returns the slot, or 0xFFFFFFFF when the table is full (64 probes).  An inserter claims the
-// slot by CAS on `a` and publishes `b` right after, in the same iteration; a reader that sees the claim but not yet `b`
-// simply repeats the iteration (no spinning inside a divergent branch: the publishing lane may be in the same wave).
+// find or insert the entry of {a, b}; returns slot * 2 + side of the ORDERED pair (a, b) - `ref ^ 1` is its flip - or
+// 0xFFFFFFFF when the table is full.  An inserter claims the slot by CAS on `lo` and publishes `hi` right after, in the
+// same iteration; a reader that sees the claim but not yet `hi` simply repeats the iteration (no spinning inside a
+// divergent branch: the publishing lane may be in the same wave).
 __device__ inline uint32_t pair_slot(PairEntry* tab, uint32_t mask, uint64_t a, uint64_t b) {
-  uint32_t i = (uint32_t)pair_hash(a, b) & mask;
+  const uint64_t lo = a < b ? a : b, hi = a < b ? b : a;
+  const uint32_t side = a < b ? 0u : 1u;
+  uint32_t i = (uint32_t)pair_hash(lo, hi) & mask;
   for (uint32_t probes = 0; probes < 4096;) {
     PairEntry* e = tab + i;
-    unsigned long long ea = __atomic_load_n(&e->a, __ATOMIC_RELAXED);
-    if (ea == 0) {
-      const unsigned long long seen = atomicCAS(&e->a, 0ull, (unsigned long long)a);
-      if (seen == 0) { __atomic_store_n(&e->b, (unsigned long long)b, __ATOMIC_RELEASE); return i; }
-      ea = seen;
+    unsigned long long el = __atomic_load_n(&e->lo, __ATOMIC_RELAXED);
+    if (el == 0) {
+      const unsigned long long seen = atomicCAS(&e->lo, 0ull, (unsigned long long)lo);
+      if (seen == 0) { __atomic_store_n(&e->hi, (unsigned long long)hi, __ATOMIC_RELEASE); return i * 2 + side; }
+      el = seen;
     }
-    if (ea == a) {
-      const unsigned long long eb = __atomic_load_n(&e->b, __ATOMIC_ACQUIRE);
-      if (eb == b) return i;
-      if (eb == 0) { probes++; continue; }      // claimed, key not published yet: look again
+    if (el == lo) {
+      const unsigned long long eh = __atomic_load_n(&e->hi, __ATOMIC_ACQUIRE);
+      if (eh == hi) return i * 2 + side;
+      if (eh == 0) { probes++; continue; }      // claimed, key not published yet: look again
     }
     i = (i + 1) & mask;
     probes++;
@@ -100,7 +104,7 @@ __global__ __launch_bounds__(256) void k3_pairs_mark(const K3PairArgs a) {
   if (a.world > 1 && dpor_pair_owner(T[it.later].key, T[it.earlier].key, a.world) != a.rank) return;   // another rank's entry
   const uint32_t s = pair_slot(a.table, a.mask, T[it.later].key, T[it.earlier].key);
   if (s == 0xFFFFFFFFu) { atomicAdd(&a.counters[2], 1ull); return; }
-  atomicOr(&a.table[s].state, PE_EXPLORED);
+  atomicOr(&a.table[s >> 1].state[s & 1], PE_EXPLORED);
 }
 
 // insert: one workgroup per finished interleaving, its threads stride over the racing pairs
@@ -112,16 +116,16 @@ __global__ __launch_bounds__(256) void k3_pairs_insert(const K3PairArgs a) {
   for (uint32_t k = threadIdx.x; k < np; k += blockDim.x) {
     const demi_dpor_pair p = P[k];
     const uint64_t ke = T[p.earlier].key, kl = T[p.later].key;
-    const uint32_t s1 = pair_slot(a.table, a.mask, ke, kl);
-    const uint32_t s2 = pair_slot(a.table, a.mask, kl, ke);
+    const uint32_t s1 = pair_slot(a.table, a.mask, ke, kl);                // (earlier, later); its flip is the other side
+    const uint32_t s2 = s1 == 0xFFFFFFFFu ? s1 : (s1 ^ 1u);
     a.pair_slot_of[(size_t)it * a.max_pairs + k] = s2;
-    if (s1 == 0xFFFFFFFFu || s2 == 0xFFFFFFFFu) { atomicAdd(&a.counters[2], 1ull); continue; }
-    const uint32_t old = atomicOr(&a.table[s1].state, PE_EXPLORED);        // setExplored(branch, (earlier, later))
+    if (s1 == 0xFFFFFFFFu) { atomicAdd(&a.counters[2], 1ull); continue; }
+    const uint32_t old = atomicOr(&a.table[s1 >> 1].state[s1 & 1], PE_EXPLORED);   // setExplored(branch, (earlier, later))
     if (!(old & PE_EXPLORED) && (old & PE_QMASK)) {                        // queued points flip into this pair: dead now
       const unsigned long long q = atomicAdd(&a.counters[1], 1ull);
       if (q < a.kills_cap) { DporKill kk; kk.a = ke; kk.b = kl; a.kills[q] = kk; }
     }
-    atomicMax(&a.table[s2].cand, cand_pack(a.round, p.branch, (unsigned long long)it * a.max_pairs + k));
+    atomicMax(&a.table[s2 >> 1].cand[s2 & 1], cand_pack(a.round, p.branch, (unsigned long long)it * a.max_pairs + k));
   }
 }
 
@@ -135,13 +139,14 @@ __global__ __launch_bounds__(256) void k3_pairs_decide(const K3PairArgs a) {
     const uint32_t s2 = a.pair_slot_of[(size_t)it * a.max_pairs + k];
     if (s2 == 0xFFFFFFFFu) continue;
     const demi_dpor_pair p = P[k];
-    PairEntry* e = a.table + s2;
+    PairEntry* e = a.table + (s2 >> 1);
+    const uint32_t sd = s2 & 1;
     const unsigned long long ord = (unsigned long long)it * a.max_pairs + k;
-    const uint32_t st = e->state;
+    const uint32_t st = e->state[sd];
     if (st & PE_EXPLORED) continue;                                        // getNext would skip it (:1153-1157)
-    if (e->cand != cand_pack(a.round, p.branch, ord)) continue;            // another point of this round is dequeued first
+    if (e->cand[sd] != cand_pack(a.round, p.branch, ord)) continue;        // another point of this round is dequeued first
     if ((st & PE_QMASK) > p.branch) continue;                              // so is a queued point of an earlier round
-    e->state = (st & ~PE_QMASK) | ((uint32_t)p.branch + 1);                // (the only writer of this entry this round)
+    e->state[sd] = (st & ~PE_QMASK) | ((uint32_t)p.branch + 1);            // (the only writer of this side this round)
     const unsigned long long q = atomicAdd(&a.counters[0], 1ull);
     if (q < a.points_cap) {
       DporPoint o;
@@ -184,15 +189,15 @@ __global__ __launch_bounds__(256) void k3_pairs_insert_rec(const K3PairArgs a) {
     const DporPairRec r = a.recs[i];
     if (dpor_pair_owner(r.ke, r.kl, a.world) != a.rank) continue;
     const uint32_t s1 = pair_slot(a.table, a.mask, r.ke, r.kl);
-    const uint32_t s2 = pair_slot(a.table, a.mask, r.kl, r.ke);
-    if (s1 == 0xFFFFFFFFu || s2 == 0xFFFFFFFFu) { atomicAdd(&a.counters[2], 1ull); continue; }
+    if (s1 == 0xFFFFFFFFu) { atomicAdd(&a.counters[2], 1ull); continue; }
+    const uint32_t s2 = s1 ^ 1u;
     a.pair_slot_of[i] = s2;
-    const uint32_t old = atomicOr(&a.table[s1].state, PE_EXPLORED);
+    const uint32_t old = atomicOr(&a.table[s1 >> 1].state[s1 & 1], PE_EXPLORED);
     if (!(old & PE_EXPLORED) && (old & PE_QMASK)) {
       const unsigned long long q = atomicAdd(&a.counters[1], 1ull);
       if (q < a.kills_cap) { DporKill kk; kk.a = r.ke; kk.b = r.kl; a.kills[q] = kk; }
     }
-    atomicMax(&a.table[s2].cand, cand_pack(a.round, r.branch, r.ordinal));
+    atomicMax(&a.table[s2 >> 1].cand[s2 & 1], cand_pack(a.round, r.branch, r.ordinal));
   }
 }
 
@@ -202,12 +207,13 @@ __global__ __launch_bounds__(256) void k3_pairs_decide_rec(const K3PairArgs a) {
     const uint32_t s2 = a.pair_slot_of[i];
     if (s2 == 0xFFFFFFFFu) continue;
     const DporPairRec r = a.recs[i];
-    PairEntry* e = a.table + s2;
-    const uint32_t st = e->state;
+    PairEntry* e = a.table + (s2 >> 1);
+    const uint32_t sd = s2 & 1;
+    const uint32_t st = e->state[sd];
     if (st & PE_EXPLORED) continue;
-    if (e->cand != cand_pack(a.round, r.branch, r.ordinal)) continue;
+    if (e->cand[sd] != cand_pack(a.round, r.branch, r.ordinal)) continue;
     if ((st & PE_QMASK) > r.branch) continue;
-    e->state = (st & ~PE_QMASK) | ((uint32_t)r.branch + 1);
+    e->state[sd] = (st & ~PE_QMASK) | ((uint32_t)r.branch + 1);
     const unsigned long long q = atomicAdd(&a.counters[0], 1ull);
     if (q < a.points_cap) {
       DporPoint o;
