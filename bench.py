@@ -57,32 +57,39 @@ def bench_dpor(ctx_device, cpu_baseline=True, batch=16384):
            "config": {"workload": "raft5-synth, Start x 5 + Send(Bootstrap) x 5, depth_bound 30, trackHistory, stopIfViolationFound = false, "
                                   "explored until the backtrack queue is empty", "batch": batch}}
     runs = {}
+    from demi_amd import _native
+    par = T.DporParams(depth, 0, 0, 0, 64, 4096)
     for name, ref in (("rounds", False), ("reference_order", True)):
-        d2 = DPORwHeuristics(SchedulerConfig(model=model), depth_bound=depth, stopIfViolationFound=False, batch=batch,
-                             device=ctx_device, specialize=True)
-        # a first whole exploration outside the timing: context, compilation for this table, the device arenas (a
-        # long-lived demi_ctx keeps them); every explore_native call is a fresh exploration
-        d2.explore_native(ev, max_interleavings=1 << 17, reference_order=ref)
+        # timed: demi_dpor_explore itself, the C entry point a JVM host binds (the Python mirror DPORwHeuristics.explore_native
+        # wraps the same call and then builds one object per interleaving, which is not the library's time)
+        ctx = _native.Context(ctx_device)
+        ctx.model_load(model.to_struct())
+        ctx.model_specialize()
+        ctx.dpor_load(ev)
+        srch = T.DporSearch(batch, 1 << 17, 0, 1, T.DPOR_ORDER_REFERENCE if ref else T.DPOR_ORDER_ROUNDS)
+        # a first whole exploration outside the timing: compilation for this table, the device arenas (a long-lived demi_ctx
+        # keeps them); every call is a fresh exploration
+        ctx.dpor_explore(par, srch)
         t = time.perf_counter()
-        res = d2.explore_native(ev, max_interleavings=1 << 17, reference_order=ref)
+        verdicts, plen, rounds, vtrace, st = ctx.dpor_explore(par, srch)
         dt = time.perf_counter() - t
-        st = d2.last_native_stats
-        runs[name] = {"value": len(res.interleavings) / dt, "seconds": dt, "interleavings": len(res.interleavings),
-                      "executed_on_device": int(st.executed), "launches": int(st.launches), "exhausted": bool(res.exhausted),
-                      "violations": len(res.violations), "distinct_schedules": len(res.schedule_hashes()),
+        runs[name] = {"value": len(verdicts) / dt, "seconds": dt, "interleavings": len(verdicts),
+                      "executed_on_device": int(st.executed), "launches": int(st.launches), "exhausted": bool(st.exhausted),
+                      "violations": int(np.count_nonzero(verdicts["flags"] & T.V_VIOLATION)),
+                      "distinct_schedules": int(len(np.unique(verdicts["hash"]))),
                       "kernel_ms_total": float(st.kernel_ms), "h2d_bytes": int(st.h2d_bytes), "d2h_bytes": int(st.d2h_bytes)}
         if ref:
             runs[name]["launches_for_results_the_speculation_lacked"] = int(st.cache_misses)
-        d2.shutdown()
+        ctx.close()
     out["value"] = runs["rounds"]["value"]
     out["orders"] = runs
     r = runs["rounds"]
     # algorithmic HBM bytes of a round's kernels (k3_dpor + k3_pairs_mark / insert / decide), summed over the exploration:
     # per interleaving the finished trace written to the arena (16 B x ~190 events) and read back by the pair kernels, its
-    # racing pairs written and read twice (4 B each, ~600 after the shared-prefix filter), 2 x 32 B table entries touched
+    # racing pairs written and read twice (4 B each, ~600 after the shared-prefix filter), one 64 B table entry touched
     # per pair by insert and one by decide, 8 B item in, 16 B verdict out
     n_il = r["interleavings"]
-    alg = n_il * (2 * 16 * 190 + 600 * (3 * 4 + 3 * 32) + 8 + 16)
+    alg = n_il * (2 * 16 * 190 + 600 * (3 * 4 + 2 * 64) + 8 + 16)
     out["roofline"] = roofline(alg, r["kernel_ms_total"], None,
                                "k3_dpor + k3_pairs_mark/insert/decide (specialised, hiprtc), %d rounds" % r["launches"],
                                "ROUNDS order, bookkeeping on the device: explored-pair table, enqueue decision and the traces stay in "
@@ -92,7 +99,6 @@ def bench_dpor(ctx_device, cpu_baseline=True, batch=16384):
     if cpu_baseline:
         from oracle import oracle_py as O
         cores = os.cpu_count() or 1
-        par = T.DporParams(depth, 0, 0, 0, 64, 4096)
         base = {}
         for name, ref in (("rounds", False), ("reference_order", True)):
             srch = T.DporSearch(batch, 1 << 17, 0, 1, T.DPOR_ORDER_REFERENCE if ref else T.DPOR_ORDER_ROUNDS)
