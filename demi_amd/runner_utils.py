@@ -18,7 +18,7 @@ def fuzz(generateFuzzTest: Callable[[int], np.ndarray], schedulerConfig: Schedul
          maxMessages: Optional[int] = None, randomizationStrategyCtor: Callable[[], object] = FullyRandom,
          computeProvenance: bool = True, violationWereLookingFor: Callable[[ViolationFingerprint], bool] = lambda f: True,
          executions_per_test: int = 4096, max_tests: int = 64, scheduler_ctor=RandomScheduler,
-         provenance_device: Optional[int] = None
+         provenance_device: Optional[int] = -1
          ) -> Optional[Tuple[EventTrace, ViolationFingerprint, np.ndarray, np.ndarray]]:
     """RunnerUtils.fuzz: generate a fuzz test, explore it, keep the first violation that (optionally) replays
     deterministically, then prune the deliveries outside the violation's provenance.
@@ -28,8 +28,11 @@ def fuzz(generateFuzzTest: Callable[[int], np.ndarray], schedulerConfig: Schedul
     violating one.  generateFuzzTest(i) is Fuzzer.generateFuzzTest for the i-th attempt (fuzzer.generate_fuzz_test /
     raft_trace with a seed derived from i).  Returns (trace, violation, initialTrace, filtered) — the depGraph of the
     reference is implicit in the causal-path keys of initialTrace — or None after max_tests tests without a violation
-    (the reference loops forever).  provenance_device: run ProvenanceTracker on that GPU (demi_provenance_prune)
-    instead of the host class."""
+    (the reference loops forever).  provenance_device: the GPU ProvenanceTracker runs on (demi_provenance_prune); -1 = device
+    0 when the executions ran on the GPU scheduler (the default scheduler_ctor), the host class (demi_amd/provenance.py)
+    for a caller-supplied scheduler; None = always the host class."""
+    if provenance_device == -1:
+        provenance_device = 0 if scheduler_ctor is RandomScheduler else None
     for attempt in range(max_tests):
         fuzzTest = np.ascontiguousarray(generateFuzzTest(attempt), dtype=T.EXT_EVENT_DTYPE)
         sched = scheduler_ctor(schedulerConfig, executions_per_test, invariant_check_interval,
