@@ -177,6 +177,19 @@ def bench_ddmin(ctx_device, cpu_baseline=True, n=1 << 20):
                                "32 B mask + 16 B verdict per candidate, the lowered original trace (%d x 8 B) once per workgroup; "
                                "the replay itself is integer / LDS work" % n_exp)
     ctx.close()
+    # what the replays are for: RunnerUtils.stsSchedDDMin on this execution, end to end (DDMin's decision tree on the host,
+    # every frontier one launch), through the Python mirror of the reference's classes
+    from demi_amd.minification import stsSchedDDMin
+    from demi_amd.schedulers import EventTrace, STSScheduler, SchedulerConfig, ViolationFingerprint
+    fp = ViolationFingerprint(vv.fingerprint)
+    sts = STSScheduler(SchedulerConfig(model=model), EventTrace(rec, used), p_max=128, device=ctx_device)
+    stsSchedDDMin(sts, used, fp, speculative_depth=4)            # (compilation, buffers)
+    t = time.perf_counter()
+    mcs, dd, _ver = stsSchedDDMin(sts, used, fp, speculative_depth=4)
+    out["ddmin_end_to_end"] = {"seconds": time.perf_counter() - t, "externals": int(len(used)), "mcs_len": len(mcs),
+                               "oracle_consultations": len(dd.consulted), "launches": len(dd.batches),
+                               "replays_launched": int(dd.speculative_replays)}
+    sts.shutdown()
     if cpu_baseline:
         from oracle import oracle_py as O
         cores = os.cpu_count() or 1
@@ -198,7 +211,34 @@ def bench_ddmin(ctx_device, cpu_baseline=True, n=1 << 20):
                 O.sts_replay_batch(model, used, rec, sample[:m], target, n_threads=min(cores, m))
                 ts.append(time.perf_counter() - t)
             fr[str(m)] = {"wall_us": sorted(ts)[2] * 1e6}
+        # the same minimization with the oracle as DDMin's TestOracle: one replay at a time on one core (what the reference's
+        # loop does), and the same speculative frontiers on all host threads
+        class _OracleSTS:
+            def __init__(self, threads):
+                self.threads = threads
+
+            def getName(self):
+                return "OracleSTS"
+
+            def _v(self, subs):
+                from demi_amd.minification import events_to_mask
+                mk = np.array([events_to_mask(x) for x in subs], dtype=np.uint64).reshape(-1, 4)
+                return O.sts_replay_batch(model, used, rec, mk, target, n_threads=min(self.threads, max(1, len(subs))))
+
+            def test(self, sub, fpx, stats):
+                r = self._v([sub])[0]
+                return r if r["flags"] & T.V_VIOLATION else None
+
+            def test_batch(self, subs, fpx, stats):
+                return [bool(f & T.V_VIOLATION) for f in self._v(subs)["flags"]]
+
+        e2e = {}
+        for name, depth_, threads in (("sequential_one_core", 0, 1), ("speculative_all_threads", 4, cores)):
+            t = time.perf_counter()
+            m2, d2, _ = stsSchedDDMin(_OracleSTS(threads), used, fp, speculative_depth=depth_)
+            e2e[name] = {"seconds": time.perf_counter() - t, "mcs_len": len(m2), "same_mcs_as_gpu": list(m2) == list(mcs)}
         out["cpu_baseline"] = {"value": len(sample) * reps / dt, "unit": "replays/s", "cores": cores, "kind": "port",
+                               "ddmin_end_to_end": e2e,
                                "sample": "first %d of the same candidate masks x %d passes, oracle/demi_oracle.c on %d pthreads" % (len(sample), reps, cores),
                                "seconds": dt, "frontiers": fr, "bit_identical_to_gpu": bool((c == got[:len(sample)]).all())}
     return out
