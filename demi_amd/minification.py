@@ -53,11 +53,16 @@ class UnmodifiedEventDag:
         self.externals = np.ascontiguousarray(externals, dtype=T.EXT_EVENT_DTYPE)
         self._events: Tuple[int, ...] = tuple(range(len(self.externals)))
         self._conjoined: Dict[int, int] = {}
+        # (kind, a, b) of every event as plain ints, and the atoms of every subsequence asked for so far: DDMin's frontier
+        # enumeration asks for the atoms of hundreds of views of this one dag
+        self._kab = list(zip(self.externals["kind"].tolist(), self.externals["a"].tolist(), self.externals["b"].tolist()))
+        self._atoms_of: Dict[Tuple[int, ...], List[Atom]] = {}
 
     def conjoinAtoms(self, e1: int, e2: int):
         assert e1 not in self._conjoined and e2 not in self._conjoined
         self._conjoined[e1] = e2
         self._conjoined[e2] = e1
+        self._atoms_of.clear()
 
     # -- EventDag trait
     def remove_events(self, to_remove: Sequence[Atom]) -> "EventDagView":
@@ -73,6 +78,9 @@ class UnmodifiedEventDag:
         actor, UnPartition with the remembered Partition of the same ordered pair; the rest are
         singletons; sorted by the index of the first event."""
         given = self._events if given is None else tuple(given)
+        cached = self._atoms_of.get(given)
+        if cached is not None:
+            return list(cached)
         atoms: List[Atom] = []
         done = set()
         for e in given:
@@ -85,8 +93,7 @@ class UnmodifiedEventDag:
         for e in given:
             if e in self._conjoined:
                 continue
-            ev = self.externals[e]
-            kind, a, b = int(ev["kind"]), int(ev["a"]), int(ev["b"])
+            kind, a, b = self._kab[e]
             if kind == T.EV_KILL:
                 if ("n", a) not in prev:
                     raise RuntimeError("Kill without preceding Start")
@@ -106,7 +113,10 @@ class UnmodifiedEventDag:
         # map (two Starts of one actor with no Kill between them) trips the reference's assumption
         if sum(len(a) for a in atoms) != len(given):
             raise AssertionError("assumption failed: atoms do not partition the events")
-        return sorted(atoms, key=lambda a: a[0])
+        atoms = sorted(atoms, key=lambda a: a[0])
+        if len(self._atoms_of) < 65536:
+            self._atoms_of[given] = atoms
+        return list(atoms)
 
     def get_all_events(self) -> Tuple[int, ...]:
         return self._events
@@ -154,10 +164,16 @@ def _remove(to_remove: Sequence[Atom], events: Sequence[int]) -> Tuple[int, ...]
 
 
 def events_to_mask(events: Sequence[int]) -> np.ndarray:
-    m = np.zeros(4, dtype=np.uint64)
-    for e in events:
-        m[e >> 6] |= np.uint64(1) << np.uint64(e & 63)
-    return m
+    return events_to_masks([events])[0]
+
+
+def events_to_masks(subseqs) -> np.ndarray:
+    """[n][4] u64: bit e of row r = external event e is part of candidate r (the 256-bit masks K2 takes)."""
+    bits = np.zeros((len(subseqs), 256), dtype=np.uint8)
+    for r, sub in enumerate(subseqs):
+        if len(sub):
+            bits[r, np.fromiter(sub, dtype=np.int64, count=len(sub))] = 1
+    return np.packbits(bits, axis=1, bitorder="little").view(np.uint64).reshape(len(subseqs), 4)
 
 
 class DDMin:

@@ -248,11 +248,8 @@ class STSScheduler:
                         int(self.schedulerConfig.filterKnownAbsents))
 
     def _masks(self, subseqs) -> np.ndarray:
-        masks = np.zeros((len(subseqs), 4), dtype=np.uint64)
-        for r, sub in enumerate(subseqs):
-            for e in sub:
-                masks[r, e >> 6] |= np.uint64(1) << np.uint64(e & 63)
-        return masks
+        from .minification import events_to_masks
+        return events_to_masks(subseqs)
 
     def verdicts(self, subseqs, violationFingerprint: ViolationFingerprint) -> np.ndarray:
         """One verdict per candidate.  A replay aborted on a capacity is no verdict: it is repeated with the largest
