@@ -216,7 +216,7 @@ struct Header { const char* name; const char* text; };
 // `lowered_names[i]` the mangled name of name_exprs[i].
 inline bool compile(Rtc& rtc, const std::string& source, const std::vector<Header>& headers,
                     const std::vector<std::string>& name_exprs, std::vector<char>& image,
-                    std::vector<std::string>& lowered_names, std::string& err) {
+                    std::vector<std::string>& lowered_names, std::string& err, const char* opt_level = "-O3") {
   if (!rtc.open(err)) return false;
   std::vector<const char*> hn, ht;
   for (const Header& h : headers) { hn.push_back(h.name); ht.push_back(h.text); }
@@ -226,7 +226,7 @@ inline bool compile(Rtc& rtc, const std::string& source, const std::vector<Heade
     return false;
   }
   for (const std::string& n : name_exprs) rtc.add_name(prog, n.c_str());
-  std::vector<const char*> opts = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-label"};
+  std::vector<const char*> opts = {"--offload-arch=gfx950", opt_level, "-std=c++17", "-Wno-unused-label"};
   std::vector<std::string> extra;                            // experiment knob: DEMI_JIT_FLAGS = extra compiler options, space separated
   if (const char* f = getenv("DEMI_JIT_FLAGS")) {
     std::string item;

@@ -148,14 +148,16 @@ __device__ inline LaneMem lane_mem_carve(unsigned char* wave_base, uint32_t n_ac
   m.pend_aux = aux ? p + lane : nullptr;
   if (aux) p += (size_t)hot * 64;
   m.fxq = p + lane;
-#ifdef DEMI_SPILL_LANE_MAJOR
-  // one [slot][lane] matrix over every lane of the launch (slot stride = all lanes): the layout of rounds 1-2, kept for A/B runs
+#ifndef DEMI_SPILL_WAVE_BLOCKS
+  // one [slot][lane] matrix over every lane of the launch (slot stride = all lanes): the live part of the pending sets
+  // (the low slots of every wave) is one contiguous region.  Measured over 8 processes each: 4.37-4.39 ms per 2^20 every
+  // time, where one [slot][64] block per wave (DEMI_SPILL_WAVE_BLOCKS, kept for A/B runs: 32 KB stride with only the first
+  // few KB of each block live) is 4.37 ms in some processes and 4.58 ms in others with the same binary, depending on
+  // where the allocation happens to lie physically
   m.spill = g_spill + global_lane;
   m.spill_aux = aux ? g_spill + spill_words(total_lanes, hot) + global_lane : nullptr;
   m.spill_stride = (uint32_t)total_lanes;
 #else
-  // one contiguous [slot][64] block per wave: a wave's pending sets stay inside (MAX_PENDING - hot) * 256 B of address space
-  // (one translation, neighbouring DRAM pages) instead of one 256 B row in each of MAX_PENDING launch-wide planes
   const size_t block = (global_lane >> 6) * ((size_t)(DEMI_MAX_PENDING - hot) * 64);
   m.spill = g_spill + block + lane;
   m.spill_aux = aux ? g_spill + spill_words(total_lanes, hot) + block + lane : nullptr;
