@@ -20,6 +20,7 @@
 #include <atomic>
 #include <chrono>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
@@ -43,41 +44,48 @@ struct BtPoint {          // one entry of the backTrack queue (DPORwHeuristics.B
   uint8_t branch, later, earlier, pad;
 };
 
-// (a, b) -> 32-bit value; open addressing, linear probing; key (0, 0) is the empty slot (node keys are FNV
-// hash chains: never 0, 0)
+// Ordered pair (a, b) -> 32-bit value, with both orientations of a pair in ONE entry: everything dpor() and getNext() do
+// with a racing pair touches (a, b) and its flip (b, a), so a pair costs one probe and one cache line.  Open addressing,
+// linear probing, keyed by the unordered pair (lo, hi); key (0, 0) is the empty slot (node keys are FNV hash chains:
+// never 0, 0).
 class FlatPairMap {
  public:
+  struct Ref { uint32_t* fwd; uint32_t* rev; };     // the values of (a, b) and of (b, a)
   FlatPairMap() { resize(1u << 12); }
   const uint32_t* find(uint64_t a, uint64_t b) const {
-    for (size_t i = slot(a, b);; i = (i + 1) & mask_) {
+    const bool sw = b < a;
+    const uint64_t lo = sw ? b : a, hi = sw ? a : b;
+    for (size_t i = slot(lo, hi);; i = (i + 1) & mask_) {
       const Entry& k = tab_[i];
-      if (k.a == a && k.b == b) return &k.val;
-      if (k.a == 0 && k.b == 0) return nullptr;
+      if (k.lo == lo && k.hi == hi) return &k.val[sw];
+      if (k.lo == 0 && k.hi == 0) return nullptr;
     }
   }
-  // find or insert (value 0); the reference is valid until the next at()
-  uint32_t& at(uint64_t a, uint64_t b) {
+  // find or insert (values 0); the pointers are valid until the next at()
+  Ref at(uint64_t a, uint64_t b) {
     if ((n_ + 1) * 5 > (mask_ + 1) * 3) grow();
-    for (size_t i = slot(a, b);; i = (i + 1) & mask_) {
+    const bool sw = b < a;
+    const uint64_t lo = sw ? b : a, hi = sw ? a : b;
+    for (size_t i = slot(lo, hi);; i = (i + 1) & mask_) {
       Entry& k = tab_[i];
-      if (k.a == a && k.b == b) return k.val;
-      if (k.a == 0 && k.b == 0) { k.a = a; k.b = b; n_++; return k.val; }
+      if (k.lo == 0 && k.hi == 0) { k.lo = lo; k.hi = hi; n_++; }
+      if (k.lo == lo && k.hi == hi) return Ref{&k.val[sw], &k.val[!sw]};
     }
   }
   size_t size() const { return n_; }
 
  private:
-  struct Entry { uint64_t a, b; uint32_t val, pad; };
-  size_t slot(uint64_t a, uint64_t b) const {
-    return (size_t)(((a * 0x9E3779B97F4A7C15ULL) ^ (b * 0xC2B2AE3D27D4EB4FULL) ^ (a >> 29)) >> 7) & mask_;
+  struct Entry { uint64_t lo, hi; uint32_t val[2]; };
+  size_t slot(uint64_t lo, uint64_t hi) const {
+    return (size_t)(((lo * 0x9E3779B97F4A7C15ULL) ^ (hi * 0xC2B2AE3D27D4EB4FULL) ^ (lo >> 29)) >> 7) & mask_;
   }
-  void resize(size_t cap) { tab_.assign(cap, Entry{0, 0, 0, 0}); mask_ = cap - 1; n_ = 0; }
+  void resize(size_t cap) { tab_.assign(cap, Entry{0, 0, {0, 0}}); mask_ = cap - 1; n_ = 0; }
   void grow() {
     std::vector<Entry> old;
     old.swap(tab_);
     resize((mask_ + 1) * 2);
     for (const Entry& k : old)
-      if (k.a || k.b) at(k.a, k.b) = k.val;
+      if (k.lo || k.hi) { const Ref r = at(k.lo, k.hi); *r.fwd = k.val[0]; *r.rev = k.val[1]; }
   }
   std::vector<Entry> tab_;
   size_t mask_ = 0, n_ = 0;
@@ -137,6 +145,7 @@ struct Finished {
   uint32_t trace_len;
   const demi_dpor_pair* pairs;
   uint32_t n_pairs;
+  bool complete = true;    // every racing pair of the trace was applied by this or an earlier absorb (see ParentFilter)
 };
 
 class DporBook {
@@ -162,6 +171,7 @@ class DporBook {
       if (fin[i].n_pairs) {
         traces_.emplace_back();
         traces_.back().t.assign(fin[i].trace, fin[i].trace + fin[i].trace_len);
+        traces_.back().complete = fin[i].complete;
         tid[i] = (uint32_t)(traces_.size() - 1);
       }
     }
@@ -179,31 +189,50 @@ class DporBook {
         }
       }
     };
+    // what dpor() does with one racing pair, in the shard that owns it
+    auto apply = [&](Shard& sh, uint64_t ke, uint64_t kl, const BtPoint& p) {
+      if (track_) {
+#ifdef DEMI_DPOR_PROFILE
+        { const uint32_t* a_ = sh.map.find(ke, kl); const uint32_t* b_ = sh.map.find(kl, ke);
+          prof_all++; if (a_ && (*a_ & EXPLORED)) { prof_fwd++; if (b_ && (*b_ & EXPLORED)) prof_both++; } }
+#endif
+        const FlatPairMap::Ref r = sh.map.at(ke, kl);
+        *r.fwd |= EXPLORED;                                 // setExplored(branchI, (earlier, later)) (:1068-1070)
+        uint32_t& flipped = *r.rev;
+        if (flipped & EXPLORED) return;                     // getNext would skip it (:1153-1157)
+        if ((flipped & QUEUED_MASK) > p.branch) return;     // a queued point of this pair pops before it
+        flipped = (flipped & ~QUEUED_MASK) | ((uint32_t)p.branch + 1);
+      }
+      sh.bucket[p.branch].push_back(sh.pool, p);
+      traces_[p.trace_id].refs.fetch_add(1, std::memory_order_relaxed);
+      if ((int)p.branch > sh.top) sh.top = (int)p.branch;
+      sh.queued++;
+    };
     // phase 2: thread t processes its shards; the pieces of a shard are read in thread (= interleaving) order
     auto process = [&](unsigned t) {
       for (size_t s = t; s < S; s += threads_) {
         Shard& sh = shards_[s];
         sh.front_valid = false;                                   // newly explored pairs may kill the front point
-        for (unsigned src = 0; src < threads_; src++) {
-          for (const Piece& pc : pieces_[src * S + s]) {
-            const BtPoint& p = pc.p;
-            if (track_) {
-              sh.map.at(pc.ke, pc.kl) |= EXPLORED;               // setExplored(branchI, (earlier, later)) (:1068-1070)
-              uint32_t& flipped = sh.map.at(pc.kl, pc.ke);
-              if (flipped & EXPLORED) continue;                   // getNext would skip it (:1153-1157)
-              if ((flipped & QUEUED_MASK) > p.branch) continue;   // a queued point of this pair pops before it
-              flipped = (flipped & ~QUEUED_MASK) | ((uint32_t)p.branch + 1);
-            }
-            sh.bucket[p.branch].push_back(sh.pool, p);
-            traces_[p.trace_id].refs.fetch_add(1, std::memory_order_relaxed);
-            if ((int)p.branch > sh.top) sh.top = (int)p.branch;
-            sh.queued++;
-          }
-        }
+        for (unsigned src = 0; src < threads_; src++)
+          for (const Piece& pc : pieces_[src * S + s]) apply(sh, pc.ke, pc.kl, pc.p);
       }
     };
-    run(distribute);
-    run(process);
+    if (threads_ == 1) {
+      // one thread (the reference order's commit): the pairs in the order given, no staging copy
+      for (Shard& sh : shards_) sh.front_valid = false;
+      for (size_t i = 0; i < n; i++) {
+        const demi_dpor_trace_entry* tt = fin[i].trace;
+        const demi_dpor_pair* pp = fin[i].pairs;
+        for (uint32_t k = 0; k < fin[i].n_pairs; k++) {
+          const uint64_t ke = tt[pp[k].earlier].key, kl = tt[pp[k].later].key;
+          apply(S == 1 ? shards_[0] : shards_[shard_of(ke, kl)], ke, kl,
+                BtPoint{base[i] + k, tid[i], pp[k].branch, pp[k].later, pp[k].earlier, 0});
+        }
+      }
+    } else {
+      run(distribute);
+      run(process);
+    }
     for (size_t i = 0; i < n; i++)                                // a trace no queued point refers to is not needed again
       if (fin[i].n_pairs && traces_[tid[i]].refs.load(std::memory_order_relaxed) == 0) Trace().swap(traces_[tid[i]].t);
   }
@@ -219,7 +248,9 @@ class DporBook {
 
   // getNext (:1142-1162) + the next trace `trace.take(maxIndex + 1) ++ needToReplay` (:1054-1057, 1180).  *shared = the
   // length of the take() part when its racing pairs need not be reported again (demi_gpu.h, demi_dpor_batch), else 0.
-  bool get_next(Trace& out, uint32_t* shared = nullptr) {
+  // *parent (optional) = the whole trace of the interleaving that found the point, when all of its racing pairs have
+  // been applied (else left empty): what ParentFilter needs.
+  bool get_next(Trace& out, uint32_t* shared = nullptr, Trace* parent = nullptr) {
     int best = -1;
     for (size_t s = 0; s < shards_.size(); s++) {
       Shard& sh = shards_[s];
@@ -235,11 +266,12 @@ class DporBook {
     sh.queued--;
     sh.front_valid = false;
     const Trace& src = traces_[p.trace_id].t;
-    if (track_) sh.map.at(src[p.later].key, src[p.earlier].key) |= EXPLORED;   // setExplored(maxIndex, (e1, e2)) (:1170-1172)
+    if (track_) *sh.map.at(src[p.later].key, src[p.earlier].key).fwd |= EXPLORED;   // setExplored(maxIndex, (e1, e2)) (:1170-1172)
     out.assign(src.begin(), src.begin() + p.branch + 1);
     for (int k = (int)p.branch + 1; k <= (int)p.later; k++)
       if (k != (int)p.earlier) out.push_back(src[k]);
     if (shared) *shared = track_ ? (uint32_t)p.branch + 1 : 0u;
+    if (parent) { if (track_ && traces_[p.trace_id].complete) *parent = src; else parent->clear(); }
     release(p.trace_id);
     return true;
   }
@@ -267,6 +299,7 @@ class DporBook {
   struct TraceRec {
     Trace t;                                 // emptied once no queued point refers to it
     std::atomic<uint32_t> refs{0};           // queued backtrack points found by this interleaving
+    bool complete = true;
   };
   void release(uint32_t tid) {
     if (traces_[tid].refs.fetch_sub(1, std::memory_order_relaxed) == 1) Trace().swap(traces_[tid].t);
@@ -299,6 +332,11 @@ class DporBook {
     f(0u);
     for (auto& th : pool) th.join();
   }
+#ifdef DEMI_DPOR_PROFILE
+ public:
+  unsigned long long prof_all = 0, prof_fwd = 0, prof_both = 0;
+ private:
+#endif
   bool track_;
   unsigned threads_;
   uint64_t seq_ = 0;
@@ -448,11 +486,92 @@ struct SpecResult {
   size_t bytes() const { return sizeof(SpecResult) + trace.size() * sizeof(demi_dpor_trace_entry) + pairs.size() * sizeof(demi_dpor_pair); }
 };
 
-inline uint64_t next_trace_key(const Trace& t, uint32_t shared) {
+// `parent` = the trace of the interleaving whose racing pair made this next trace (empty: none / unknown).  It is part of the
+// key because the result's pair list is filtered against it (ParentFilter).
+inline uint64_t next_trace_key(const Trace& t, uint32_t shared, const Trace& parent) {
   uint64_t h = 0xCBF29CE484222325ULL ^ (uint64_t)t.size() ^ ((uint64_t)shared << 32);
   for (const demi_dpor_trace_entry& e : t) h = (h ^ e.key) * 0x100000001B3ULL + (h >> 47);
+  for (const demi_dpor_trace_entry& e : parent) h = (h ^ e.key ^ ((uint64_t)e.qperiod << 56)) * 0x100000001B3ULL + (h >> 47);
   return h ? h : 1;
 }
+
+// Which racing pairs of an interleaving C need not be absorbed, because its PARENT P - the interleaving whose racing pair
+// produced C's next trace, P.take(branch + 1) ++ replayed events - or one of P's ancestors has applied the same pair already.
+//
+// Invariant (I): when an interleaving T has been absorbed, every racing pair (e, l) of its trace, with branch index b_T,
+// has been applied - by T or by an interleaving absorbed before it - as (key(e), key(l), b') with b' >= b_T.
+// Applying (ke, kl, b) when (ke, kl, b') with b' >= b was applied before changes nothing: the explored bit of (ke, kl) is
+// set, and the flipped pair is either explored or carries a queued mark >= b' + 1 > b; both only ever grow (absorb()).
+//
+// A racing pair is a property of its two nodes: both message deliveries, same receiver, no causal path from the earlier
+// to the later one (all three read off the node keys, which ARE causal paths) and equal quiescent periods; its branch is
+// the trace index of the last common ancestor of the two producers.  So if the nodes of a pair (e, l) of C also occur in
+// P, in the same order and in the same quiescent periods, P's dpor() saw the same racing pair with b_P = P's index of the
+// same ancestor node, and by (I) for P it was applied with a branch >= b_P.  If b_P >= b_C, C may drop the pair and (I)
+// still holds for C.  P is absorbed before C is dequeued (C's backtrack point is created by absorbing P).  The device's
+// shared-prefix filter is the special case l < shared (same indices in P and C).  Because equal (parent, message)
+// children collapse into one key, the argument needs the three keys involved (e, l, the ancestor) to be unique in P and
+// in C; a pair touching a duplicated key is kept.  (I) fails for an interleaving whose pair list was truncated
+// (DEMI_V_PAIRS_OVF) or whose parent's did: get_next() then hands out no parent and nothing is dropped.
+// Config 3: 109 M reported pairs -> 8.9 M absorbed.
+class ParentFilter {
+ public:
+  explicit ParentFilter(const Trace& parent) {
+    if (parent.empty() || parent.size() > DEMI_DPOR_MAX_TRACE) return;
+    on_ = true;
+    n_ = (uint32_t)parent.size();
+    memset(slot_, 0xFF, sizeof slot_);
+    for (uint32_t i = 0; i < n_; i++) {
+      key_[i] = parent[i].key; qp_[i] = parent[i].qperiod; dup_[i] = 0;
+      size_t h = hash(key_[i]);
+      for (; slot_[h] != 0xFFFFu; h = (h + 1) & (SLOTS - 1))
+        if (key_[slot_[h]] == key_[i]) { dup_[slot_[h]] = 1; dup_[i] = 1; }
+      slot_[h] = (uint16_t)i;
+    }
+  }
+  bool active() const { return on_; }
+  // keeps the pairs that still have to be absorbed
+  void filter(const demi_dpor_trace_entry* tr, uint32_t n_tr, const demi_dpor_pair* pr, uint32_t n_pr,
+              std::vector<demi_dpor_pair>& out) const {
+    if (n_tr > DEMI_DPOR_MAX_TRACE) { out.assign(pr, pr + n_pr); return; }
+    // idx[i] = where C's event i sits in the parent (same key, same quiescent period, key unique on both sides), or -1
+    int idx[DEMI_DPOR_MAX_TRACE];
+    uint16_t own[SLOTS];
+    memset(own, 0xFF, sizeof own);
+    for (uint32_t i = 0; i < n_tr; i++) {
+      idx[i] = index_of(tr[i]);
+      size_t h = hash(tr[i].key);
+      for (; own[h] != 0xFFFFu; h = (h + 1) & (SLOTS - 1))
+        if (tr[own[h]].key == tr[i].key) { idx[own[h]] = -1; idx[i] = -1; }
+      own[h] = (uint16_t)i;
+    }
+    uint32_t keep = 0;
+    for (uint32_t k = 0; k < n_pr; k++) keep += !redundant(idx, pr[k]);
+    out.clear();
+    out.reserve(keep);
+    for (uint32_t k = 0; k < n_pr; k++)
+      if (!redundant(idx, pr[k])) out.push_back(pr[k]);
+  }
+
+ private:
+  static constexpr size_t SLOTS = 1024;             // > 2 x DEMI_DPOR_MAX_TRACE
+  static size_t hash(uint64_t k) { return (size_t)((k * 0x9E3779B97F4A7C15ULL) >> 54) & (SLOTS - 1); }
+  int index_of(const demi_dpor_trace_entry& e) const {
+    for (size_t h = hash(e.key);; h = (h + 1) & (SLOTS - 1)) {
+      const uint16_t i = slot_[h];
+      if (i == 0xFFFFu) return -1;
+      if (key_[i] == e.key) return (!dup_[i] && qp_[i] == e.qperiod) ? (int)i : -1;
+    }
+  }
+  static bool redundant(const int* idx, const demi_dpor_pair& p) {
+    return idx[p.earlier] >= 0 && idx[p.later] >= 0 && idx[p.earlier] < idx[p.later] && idx[p.branch] >= (int)p.branch;
+  }
+  bool on_ = false;
+  uint32_t n_ = 0;
+  uint64_t key_[DEMI_DPOR_MAX_TRACE];
+  uint8_t qp_[DEMI_DPOR_MAX_TRACE], dup_[DEMI_DPOR_MAX_TRACE];
+  uint16_t slot_[SLOTS];
+};
 
 template <class Run, class Fetch>
 int explore_reference_order(Run&& run, Fetch&& fetch, uint32_t max_pairs, const demi_dpor_search* srch,
@@ -467,7 +586,7 @@ int explore_reference_order(Run&& run, Fetch&& fetch, uint32_t max_pairs, const 
   auto* pr = static_cast<demi_dpor_pair*>(pr_buf.reserve(sizeof(demi_dpor_pair) * (size_t)(max_pairs ? max_pairs : 1) * EXPLORE_CHUNK));
   if (!tr || !pr) return DEMI_ERR_INVALID_ARG;
   const bool track = srch->track_history != 0;
-  DporBook real(track, 1), spec(track);
+  DporBook real(track, 1, 1), spec(track);   // the one-at-a-time book: one shard, so getNext() settles one queue front per pop instead of 64
   memset(stats, 0, sizeof *stats);
   stats->first_violation = ~0ull;
   if (first_violation_len) *first_violation_len = 0;
@@ -488,26 +607,33 @@ int explore_reference_order(Run&& run, Fetch&& fetch, uint32_t max_pairs, const 
     }
   };
 
-  Trace cur;                         // the next trace `real` wants (first run: empty)
+#ifdef DEMI_DPOR_PROFILE
+  double prof[3] = {0, 0, 0};
+  unsigned long long prof_pairs = 0;
+#endif
+  Trace cur, cur_parent;             // the next trace `real` wants (first run: empty) and the trace it was derived from
   uint32_t cur_shared = 0;
   bool have_cur = true, exhausted = false, done = false;
-  std::vector<Trace> spec_frontier(1);
+  std::vector<Trace> spec_frontier(1), spec_parent(1);
   std::vector<uint32_t> spec_shared(1, 0u);
   bool spec_alive = true;
 
-  std::vector<const Trace*> launch;          // next traces of this launch
+  std::vector<const Trace*> launch, launch_parent;   // next traces of this launch (and what each was derived from)
   std::vector<uint32_t> launch_shared;
   std::vector<uint64_t> launch_key;
   std::vector<demi_dpor_trace_entry> pf;
   std::vector<uint32_t> pl, tl, np;
   std::vector<demi_verdict> vd;
   std::vector<Finished> fin;
+  std::vector<std::unique_ptr<SpecResult>> made;
+  const bool no_parent_filter = getenv("DEMI_DPOR_NO_PARENT_FILTER") != nullptr;   // A/B and tests: absorb every reported pair
+  unsigned long long stats_pairs_reported = 0, stats_pairs_kept = 0;
 
   while (!done) {
     // ---- commit, one interleaving at a time, as far as computed results reach
     double t0 = now();
     while (have_cur) {
-      const uint64_t key = next_trace_key(cur, cur_shared);
+      const uint64_t key = next_trace_key(cur, cur_shared, cur_parent);
       auto it = cache.find(key);
       if (it == cache.end()) break;
       const SpecResult& r = *it->second;
@@ -524,12 +650,28 @@ int explore_reference_order(Run&& run, Fetch&& fetch, uint32_t max_pairs, const 
           if (first_violation_len) *first_violation_len = (uint32_t)r.trace.size();
         }
       }
-      const Finished f{r.trace.data(), (uint32_t)r.trace.size(), r.pairs.data(), (uint32_t)r.pairs.size()};
+      // invariant (I) of ParentFilter holds for this interleaving if its own pair list is whole and (I) held for its parent
+      const Finished f{r.trace.data(), (uint32_t)r.trace.size(), r.pairs.data(), (uint32_t)r.pairs.size(),
+                       !(r.verdict.flags & DEMI_V_PAIRS_OVF) && (cur.empty() || !cur_parent.empty())};
+#ifdef DEMI_DPOR_PROFILE
+      const double p0 = now();
+      prof_pairs += r.pairs.size();
+#endif
       real.absorb(&f, 1);
+#ifdef DEMI_DPOR_PROFILE
+      const double p1 = now();
+#endif
       cache_bytes -= r.bytes();
       cache.erase(it);
       if ((srch->stop_if_violation && found) || stats->interleavings >= srch->max_interleavings) { done = true; break; }
-      have_cur = real.get_next(cur, &cur_shared);
+#ifdef DEMI_DPOR_PROFILE
+      const double p2 = now();
+#endif
+      have_cur = real.get_next(cur, &cur_shared, &cur_parent);
+#ifdef DEMI_DPOR_PROFILE
+      const double p3 = now();
+      prof[0] += p1 - p0; prof[1] += p2 - p1; prof[2] += p3 - p2;
+#endif
       if (!have_cur) { exhausted = true; done = true; }
     }
     double t1 = now();
@@ -538,16 +680,20 @@ int explore_reference_order(Run&& run, Fetch&& fetch, uint32_t max_pairs, const 
 
     // ---- one launch: what `real` is waiting for + the speculation's next round (minus what is computed already)
     stats->cache_misses++;
-    launch.clear(); launch_shared.clear(); launch_key.clear();
-    const uint64_t cur_key = next_trace_key(cur, cur_shared);
-    launch.push_back(&cur); launch_shared.push_back(cur_shared); launch_key.push_back(cur_key);
+    launch.clear(); launch_parent.clear(); launch_shared.clear(); launch_key.clear();
+    const uint64_t cur_key = next_trace_key(cur, cur_shared, cur_parent);
+    launch.push_back(&cur); launch_parent.push_back(&cur_parent); launch_shared.push_back(cur_shared); launch_key.push_back(cur_key);
     std::vector<uint64_t> round_key(spec_frontier.size());
-    for (size_t i = 0; i < spec_frontier.size(); i++) {
-      const uint64_t k = next_trace_key(spec_frontier[i], spec_shared[i]);
-      round_key[i] = k;
-      bool dup = cache.count(k) != 0;
-      for (size_t j = 0; j < launch_key.size() && !dup; j++) dup = launch_key[j] == k;
-      if (!dup) { launch.push_back(&spec_frontier[i]); launch_shared.push_back(spec_shared[i]); launch_key.push_back(k); }
+    {
+      std::unordered_map<uint64_t, char> in_launch;
+      in_launch[cur_key] = 1;
+      for (size_t i = 0; i < spec_frontier.size(); i++) {
+        const uint64_t k = next_trace_key(spec_frontier[i], spec_shared[i], spec_parent[i]);
+        round_key[i] = k;
+        if (cache.count(k) != 0 || !in_launch.emplace(k, 1).second) continue;
+        launch.push_back(&spec_frontier[i]); launch_parent.push_back(&spec_parent[i]);
+        launch_shared.push_back(spec_shared[i]); launch_key.push_back(k);
+      }
     }
     const size_t n = launch.size();
     size_t stride = 1;
@@ -568,16 +714,40 @@ int explore_reference_order(Run&& run, Fetch&& fetch, uint32_t max_pairs, const 
       const size_t cnt = n - lo < EXPLORE_CHUNK ? n - lo : EXPLORE_CHUNK;
       rc = fetch(lo, cnt, tr, pr);
       if (rc) return rc;
+      // the results are built by several threads; each keeps only the racing pairs its parent has not applied already
+      made.clear();
+      made.resize(cnt);
+      auto build = [&](unsigned t, unsigned nt) {
+        for (size_t i = cnt * t / nt; i < cnt * (t + 1) / nt; i++) {
+          std::unique_ptr<SpecResult> r(new SpecResult);
+          r->verdict = vd[lo + i];
+          r->prefix_len = pl[lo + i];
+          r->key = launch_key[lo + i];
+          const demi_dpor_trace_entry* tt = &tr[i * DEMI_DPOR_MAX_TRACE];
+          const demi_dpor_pair* pp = &pr[i * (size_t)max_pairs];
+          const uint32_t n_pp = np[lo + i] < max_pairs ? np[lo + i] : max_pairs;
+          r->trace.assign(tt, tt + tl[lo + i]);
+          const ParentFilter pf_(track && !no_parent_filter ? *launch_parent[lo + i] : Trace());
+          if (pf_.active()) pf_.filter(tt, tl[lo + i], pp, n_pp, r->pairs);
+          else r->pairs.assign(pp, pp + n_pp);
+          made[i] = std::move(r);
+        }
+      };
+      {
+        unsigned nt = std::thread::hardware_concurrency();
+        nt = nt ? (nt > 32u ? 32u : nt) : 4u;
+        if (cnt < 64) nt = 1;
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < nt; t++) pool.emplace_back(build, t, nt);
+        build(0u, nt);
+        for (auto& th : pool) th.join();
+      }
       for (size_t i = 0; i < cnt; i++) {
-        std::unique_ptr<SpecResult> r(new SpecResult);
-        r->verdict = vd[lo + i];
-        r->prefix_len = pl[lo + i];
-        r->key = launch_key[lo + i];
-        r->trace.assign(&tr[i * DEMI_DPOR_MAX_TRACE], &tr[i * DEMI_DPOR_MAX_TRACE] + tl[lo + i]);
-        r->pairs.assign(&pr[i * (size_t)max_pairs], &pr[i * (size_t)max_pairs] + np[lo + i]);
-        cache_bytes += r->bytes();
-        age.push_back(r->key);
-        cache[r->key] = std::move(r);
+        stats_pairs_reported += np[lo + i];
+        stats_pairs_kept += made[i]->pairs.size();
+        cache_bytes += made[i]->bytes();
+        age.push_back(made[i]->key);
+        cache[made[i]->key] = std::move(made[i]);
       }
     }
     // the speculation absorbs its round in pop order (every member is in the cache now) and pops its next round
@@ -587,16 +757,19 @@ int explore_reference_order(Run&& run, Fetch&& fetch, uint32_t max_pairs, const 
         auto it = cache.find(round_key[i]);
         if (it == cache.end()) continue;               // (only if the cap is smaller than one round)
         const SpecResult& r = *it->second;
-        fin.push_back(Finished{r.trace.data(), (uint32_t)r.trace.size(), r.pairs.data(), (uint32_t)r.pairs.size()});
+        fin.push_back(Finished{r.trace.data(), (uint32_t)r.trace.size(), r.pairs.data(), (uint32_t)r.pairs.size(),
+                               !(r.verdict.flags & DEMI_V_PAIRS_OVF)});
       }
       spec.absorb(fin.data(), fin.size());
       spec_frontier.clear();
+      spec_parent.clear();
       spec_shared.clear();
       while (spec_frontier.size() < srch->batch) {
-        Trace nxt;
+        Trace nxt, par;
         uint32_t sh = 0;
-        if (!spec.get_next(nxt, &sh)) break;
+        if (!spec.get_next(nxt, &sh, &par)) break;
         spec_frontier.push_back(std::move(nxt));
+        spec_parent.push_back(std::move(par));
         spec_shared.push_back(sh);
       }
       if (spec_frontier.empty()) spec_alive = false;
@@ -606,6 +779,14 @@ int explore_reference_order(Run&& run, Fetch&& fetch, uint32_t max_pairs, const 
   }
   stats->queue_len = real.queue_len();
   stats->exhausted = exhausted ? 1u : 0u;
+  if (getenv("DEMI_DPOR_TIMING"))
+    fprintf(stderr, "[reference order] racing pairs reported %llu, kept after the parent filter %llu\n", stats_pairs_reported, stats_pairs_kept);
+#ifdef DEMI_DPOR_PROFILE
+  fprintf(stderr, "[reference order commit] absorb %.3f s, cache erase %.3f s, get_next %.3f s, %llu pairs\n", prof[0], prof[1], prof[2],
+          (unsigned long long)prof_pairs);
+  fprintf(stderr, "[reference order commit] pairs %llu, forward orientation already explored %llu, both orientations explored %llu, table entries ?\n",
+          real.prof_all, real.prof_fwd, real.prof_both);
+#endif
   return 0;
 }
 
