@@ -3,7 +3,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_k3_gpu.py tests/test_comm_gpu.py -x -q --timeout 600 2>&1 | tail -3
+timeout 900 python -m pytest tests/test_k3_gpu.py tests/test_comm_gpu.py -x -q --timeout 600 2>&1 | grep -E "passed|failed|error" | tail -3
 DEMI_DPOR_TIMING=1 timeout 600 python bench.py --workload dpor > gpurun_out/r2_q_dpor.json 2> gpurun_out/r2_q_dpor.err
 grep -i "dpor\|timing" gpurun_out/r2_q_dpor.err | tail -8
 python - <<'PY'
