@@ -88,13 +88,16 @@ def wait_quiescence():
 def events_to_array(events: List[Event]) -> np.ndarray:
     arr = np.zeros(len(events), dtype=T.EXT_EVENT_DTYPE)
     for i, e in enumerate(events):
-        arr[i]["kind"], arr[i]["a"], arr[i]["b"], arr[i]["msg_type"], arr[i]["p0"], arr[i]["p1"] = e
+        kind, a, b, msg_type, p0, p1 = e
+        arr[i]["kind"], arr[i]["a"], arr[i]["b"], arr[i]["msg_type"] = kind, a, b, msg_type
+        arr[i]["p0"], arr[i]["p1"] = p0 & 0xFF, p1 & 0xFF
+        arr[i]["p0_hi"], arr[i]["p1_hi"] = p0 >> 8, p1 >> 8          # 16-bit payloads: wide models only
     return arr
 
 
 def array_to_events(arr: np.ndarray) -> List[Event]:
-    return [(int(e["kind"]), int(e["a"]), int(e["b"]), int(e["msg_type"]), int(e["p0"]), int(e["p1"]))
-            for e in arr]
+    return [(int(e["kind"]), int(e["a"]), int(e["b"]), int(e["msg_type"]), int(e["p0"]) | (int(e["p0_hi"]) << 8),
+             int(e["p1"]) | (int(e["p1_hi"]) << 8)) for e in arr]
 
 
 class _RandSet:

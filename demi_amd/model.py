@@ -28,7 +28,7 @@ P0, P1 = Reg(12), Reg(13)               # message payload
 SRC, ME = Reg(14), Reg(15)              # sender id (15 = deadLetters), own id
 
 OPS = dict(HALT=0, MOV=1, ADD=2, SUB=3, AND=4, OR=5, XOR=6, SHL=7, SHR=8, BITSET=9, POPC=10,
-           EQ=11, NE=12, LT=13, GE=14, LE=15, GT=16, MIN=17, MAX=18, SKIPZ=20, SKIPNZ=21, SKIP=22,
+           EQ=11, NE=12, LT=13, GE=14, LE=15, GT=16, MIN=17, MAX=18, MOVHI=19, SKIPZ=20, SKIPNZ=21, SKIP=22,
            SEND=24, BCAST=25, TSET=26, TREP=27, TCANCEL=28, CRASH=29, RND=30, IFEQ=32, IFNE=33, IFLT=34, IFGE=35, IFLE=36, IFGT=37)
 
 
@@ -60,6 +60,20 @@ class Asm:
     def mov(self, dst, b):
         bimm, bv = self._b(b)
         self.rows.append(row(OPS["MOV"], int(dst), 0, bimm, 0, bv))
+        return self
+
+    def movhi(self, dst, a, hi):
+        """DEMI_MODEL_WIDE only: dst = (a & 0xFF) | (hi << 8)."""
+        assert isinstance(dst, Reg) and isinstance(a, Reg) and 0 <= int(hi) < 256
+        self.rows.append(row(OPS["MOVHI"], int(dst), int(a), 1, 0, int(hi)))
+        return self
+
+    def ldi16(self, dst, value):
+        """dst = a 16-bit constant (wide models): MOV of the lower half, MOVHI of the upper one when it is not zero."""
+        assert 0 <= int(value) < 65536
+        self.mov(dst, int(value) & 0xFF)
+        if int(value) >> 8:
+            self.movhi(dst, dst, int(value) >> 8)
         return self
 
     def rnd(self, dst, bound):
@@ -177,12 +191,13 @@ class Model:
     n_classes: int
     handler_start: List[int]          # [n_classes * n_msg_types]
     code: List[int]
-    init_state: List[int]             # u64 per actor
+    init_state: List[int]             # u64 per actor (wide: two per actor, F0..F3 then F4..F7, 16 bits each)
     inv_kind: int = T.INV_NONE
     inv_fa: int = 0
     inv_va: int = 0
     inv_fb: int = 0
     fp_match_mask: int = 0xFFFFFFFF
+    wide: bool = False                # DEMI_MODEL_WIDE: 16 x u16 register window
     _keep: list = field(default_factory=list, repr=False, compare=False)
 
     @property
@@ -199,7 +214,8 @@ class Model:
                           C.cast(mc, C.POINTER(C.c_uint8)), C.cast(ac, C.POINTER(C.c_uint8)),
                           C.cast(hs, C.POINTER(C.c_uint16)), C.cast(code, C.POINTER(C.c_uint32)),
                           C.cast(init, C.POINTER(C.c_uint64)),
-                          self.inv_kind, self.inv_fa, self.inv_va, self.inv_fb, self.fp_match_mask)
+                          self.inv_kind, self.inv_fa, self.inv_va, self.inv_fb, self.fp_match_mask,
+                          T.MODEL_WIDE if self.wide else 0)
         self._keep = [mc, ac, hs, code, init]   # keep the buffers alive as long as the Model
         return s
 
@@ -207,6 +223,8 @@ class Model:
         d = {k: getattr(self, k) for k in ("name", "n_actors", "msg_names", "msg_class", "actor_class",
                                             "n_classes", "handler_start", "code", "init_state", "inv_kind",
                                             "inv_fa", "inv_va", "inv_fb", "fp_match_mask")}
+        if self.wide:
+            d["wide"] = True
         return d
 
     @staticmethod
@@ -223,8 +241,15 @@ def pack_state(fields: List[int]) -> int:
     return s
 
 
+def pack_state_wide(fields: List[int]) -> List[int]:
+    """The two state words of an actor of a wide model: F0..F3 and F4..F7, 16 bits each."""
+    f = list(fields) + [0] * (8 - len(fields))
+    assert len(f) == 8 and all(0 <= v < 65536 for v in f)
+    return [sum(v << (16 * i) for i, v in enumerate(f[:4])), sum(v << (16 * i) for i, v in enumerate(f[4:]))]
+
+
 def build_model(name, n_actors, msgs, handlers, init_fields, invariant, actor_class=None, n_classes=1,
-                fp_match_mask=0xFFFFFFFF) -> Model:
+                fp_match_mask=0xFFFFFFFF, wide=False) -> Model:
     """msgs: list of (name, class); handlers: {(actor_class, msg name): Asm}."""
     names = [m[0] for m in msgs]
     code: List[int] = []
@@ -237,8 +262,9 @@ def build_model(name, n_actors, msgs, handlers, init_fields, invariant, actor_cl
     inv_kind, fa, va, fb = invariant
     return Model(name=name, n_actors=n_actors, msg_names=names, msg_class=[m[1] for m in msgs],
                  actor_class=list(actor_class or [0] * n_actors), n_classes=n_classes, handler_start=hs,
-                 code=code, init_state=[pack_state(f) for f in init_fields],
-                 inv_kind=inv_kind, inv_fa=fa, inv_va=va, inv_fb=fb, fp_match_mask=fp_match_mask)
+                 code=code, init_state=([w for f in init_fields for w in pack_state_wide(f)] if wide else
+                                        [pack_state(f) for f in init_fields]),
+                 inv_kind=inv_kind, inv_fa=fa, inv_va=va, inv_fb=fb, fp_match_mask=fp_match_mask, wide=wide)
 
 
 # --------------------------------------------------------------------------- raft-synth
@@ -256,7 +282,10 @@ RAFT_MSGS = [("Bootstrap", T.MSG_EXTERNAL), ("ClientCommand", T.MSG_EXTERNAL),
  M_APPEND_REPLY, M_HEARTBEAT) = range(8)
 
 
-def raft_model(n_actors=5, election_budget=1, buggy=True) -> Model:
+def raft_model(n_actors=5, election_budget=1, buggy=True, term0=0, loglen0=0) -> Model:
+    """term0 / loglen0: the term and the log length every node starts with.  Values above 255 (a cluster that has been
+    running for a while) need 16-bit fields and payloads: the model is then lowered as DEMI_MODEL_WIDE, same handlers."""
+    wide = max(term0, loglen0) > 200
     majority = n_actors // 2 + 1
     h = {}
 
@@ -347,9 +376,9 @@ def raft_model(n_actors=5, election_budget=1, buggy=True) -> Model:
     a.bcast(M_APPEND_ENTRIES, TERM, LOGLEN).label("done")
     h[(0, "Heartbeat")] = a
 
-    init = [[FOLLOWER, 0, NOBODY, 0, election_budget, 0, 0, 0] for _ in range(n_actors)]
-    return build_model("raft%d-synth%s" % (n_actors, "" if buggy else "-fixed"), n_actors, RAFT_MSGS, h, init,
-                       invariant=(T.INV_AT_MOST_ONE, int(ROLE), LEADER, int(TERM)))
+    init = [[FOLLOWER, term0, NOBODY, 0, election_budget, loglen0, loglen0, 0] for _ in range(n_actors)]
+    return build_model("raft%d-synth%s%s" % (n_actors, "" if buggy else "-fixed", "-wide" if wide else ""), n_actors, RAFT_MSGS,
+                       h, init, invariant=(T.INV_AT_MOST_ONE, int(ROLE), LEADER, int(TERM)), wide=wide)
 
 
 def save_model(model: Model, path: str):

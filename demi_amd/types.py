@@ -58,7 +58,7 @@ def dpor_marker_key(ext_idx):
 
 class ExtEvent(C.Structure):
     _fields_ = [("kind", C.c_uint8), ("a", C.c_uint8), ("b", C.c_uint8), ("msg_type", C.c_uint8),
-                ("p0", C.c_uint8), ("p1", C.c_uint8), ("pad", C.c_uint8 * 2)]
+                ("p0", C.c_uint8), ("p1", C.c_uint8), ("p0_hi", C.c_uint8), ("p1_hi", C.c_uint8)]
 
 
 class ModelStruct(C.Structure):
@@ -68,7 +68,10 @@ class ModelStruct(C.Structure):
                 ("handler_start", C.POINTER(C.c_uint16)), ("code", C.POINTER(C.c_uint32)),
                 ("init_state", C.POINTER(C.c_uint64)),
                 ("inv_kind", C.c_uint32), ("inv_fa", C.c_uint32), ("inv_va", C.c_uint32),
-                ("inv_fb", C.c_uint32), ("fp_match_mask", C.c_uint32)]
+                ("inv_fb", C.c_uint32), ("fp_match_mask", C.c_uint32), ("flags", C.c_uint32)]
+
+
+MODEL_WIDE = 0x1            # demi_model.flags: 16 x u16 register window (include/demi_gpu.h, DEMI_MODEL_WIDE)
 
 
 FILTER_ABSENTS_OFF, FILTER_ABSENTS_LITERAL, FILTER_ABSENTS_CORRECTED = 0, 1, 2     # demi_filter_absents
@@ -127,7 +130,7 @@ import numpy as np  # noqa: E402
 
 VERDICT_DTYPE = np.dtype([("flags", "<u4"), ("fingerprint", "<u4"), ("hash", "<u8")])
 EXT_EVENT_DTYPE = np.dtype([("kind", "u1"), ("a", "u1"), ("b", "u1"), ("msg_type", "u1"),
-                            ("p0", "u1"), ("p1", "u1"), ("pad", "u1", (2,))])
+                            ("p0", "u1"), ("p1", "u1"), ("p0_hi", "u1"), ("p1_hi", "u1")])
 REC_EVENT_DTYPE = np.dtype([("kind", "u1"), ("snd", "u1"), ("rcv", "u1"), ("msg_type", "u1"),
                             ("p0", "u1"), ("p1", "u1"), ("flags", "u1"), ("ext_idx", "u1"), ("id", "<u4")])
 DPOR_TRACE_DTYPE = np.dtype([("key", "<u8"), ("word", "<u4"), ("parent", "u1"), ("qperiod", "u1"), ("depth", "u1"),

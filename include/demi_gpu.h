@@ -69,8 +69,8 @@ typedef struct {
   uint8_t kind;       /* demi_ext_kind */
   uint8_t a, b;       /* actors */
   uint8_t msg_type;   /* SEND: message type (class EXTERNAL) */
-  uint8_t p0, p1;     /* SEND: payload */
-  uint8_t pad[2];
+  uint8_t p0, p1;     /* SEND: payload (low bytes) */
+  uint8_t p0_hi, p1_hi; /* SEND, DEMI_MODEL_WIDE only: bits 8..15 of the payload fields; must be 0 for other models */
 } demi_ext_event;     /* 8 bytes */
 
 /* ------------------------------------------------------ transition table
@@ -90,6 +90,8 @@ typedef enum {
   DEMI_OP_POPC = 10, /* dst = popcount(b) */
   DEMI_OP_EQ = 11,  DEMI_OP_NE = 12,  DEMI_OP_LT = 13,  DEMI_OP_GE = 14,  DEMI_OP_LE = 15,
   DEMI_OP_GT = 16,  DEMI_OP_MIN = 17, DEMI_OP_MAX = 18,
+  DEMI_OP_MOVHI = 19,   /* DEMI_MODEL_WIDE only: dst = (a & 0xFF) | (b << 8), b an 8-bit immediate: the upper half of a
+                           16-bit constant (MOV loads the lower half)                                               */
   DEMI_OP_SKIPZ = 20,   /* if reg a == 0 skip the next b rows  (b immediate) */
   DEMI_OP_SKIPNZ = 21,  /* if reg a != 0 skip the next b rows */
   DEMI_OP_SKIP = 22,    /* skip the next b rows */
@@ -139,7 +141,26 @@ typedef struct {
   const uint64_t* init_state;    /* [n_actors] F0 in bits 0..7 ... F7 in bits 56..63 */
   uint32_t inv_kind, inv_fa, inv_va, inv_fb;
   uint32_t fp_match_mask;   /* ViolationFingerprint.matches: ((x ^ y) & mask) == 0 */
+  uint32_t flags;           /* DEMI_MODEL_*; occupies what used to be the struct's tail padding (sizeof is unchanged) */
 } demi_model;
+
+/* DEMI_MODEL_WIDE: the register window is 16 x u16 instead of 16 x u8 - state fields F0..F7, temporaries and the two
+ * payload fields are 16 bits wide, all arithmetic is mod 65536, shifts / BITSET use b & 15, POPC counts 16 bits, sender
+ * and own id are unchanged - so that a protocol whose terms and log indices exceed 255 lowers without multi-byte
+ * arithmetic.  What changes at the boundary:
+ *   init_state       [2 * n_actors]: word 2i holds F0..F3 of actor i (16 bits each, F0 lowest), word 2i + 1 holds F4..F7;
+ *   row immediates   stay 8 bits; DEMI_OP_MOVHI supplies the upper half of a constant;
+ *   DEMI_OP_RND      the bound is b & 0xFF;
+ *   external Sends   carry 16-bit payloads (demi_ext_event.p0_hi / p1_hi);
+ *   inv_va           up to 65535; the fingerprint of DEMI_INV_AT_MOST_ONE keeps the layout 1 << 24 | key << 8 | mask with a
+ *                    16-bit key;
+ *   the message word hashed into demi_verdict.hash is 64 bits: type[4:0] | dst[7:5] | src[11:8] | p0[31:16] | p1[47:32], and
+ *                    an actor's final state enters the hash as its two words.
+ * A wide model runs only as a compiled table (demi_model_specialize must succeed: there is no interpreter for it) and
+ * only through the RandomScheduler entry points with DEMI_STRATEGY_FULLY_RANDOM (demi_random_explore* except
+ * demi_random_get_trace); the replay, DPOR and provenance entry points return DEMI_ERR_INVALID_MODEL for it.  The
+ * 8-bit layout is untouched by the option (same code, same verdict hashes as before). */
+#define DEMI_MODEL_WIDE 0x1u
 
 typedef struct {
   uint32_t max_messages;              /* RandomScheduler.setMaxMessages (RandomScheduler.scala:54-57); 0 = unbounded */

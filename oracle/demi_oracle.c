@@ -96,6 +96,10 @@ int orc_model_validate(const demi_model* m, char* err, size_t err_cap) {
       case DEMI_OP_POPC: case DEMI_OP_EQ: case DEMI_OP_NE: case DEMI_OP_LT: case DEMI_OP_GE:
       case DEMI_OP_LE: case DEMI_OP_GT: case DEMI_OP_MIN: case DEMI_OP_MAX: case DEMI_OP_RND:
         break;
+      case DEMI_OP_MOVHI:
+        if (!(m->flags & DEMI_MODEL_WIDE)) FAIL("row %u: MOVHI in a model without DEMI_MODEL_WIDE", pc);
+        if (!bimm) FAIL("row %u: MOVHI takes an immediate", pc);
+        break;
       case DEMI_OP_SKIPZ: case DEMI_OP_SKIPNZ: case DEMI_OP_SKIP:
         if (!bimm) FAIL("row %u: skip distance must be an immediate", pc);
         if (pc + 1 + b > m->code_len) FAIL("row %u: skip past the end of the table", pc);
@@ -122,7 +126,8 @@ int orc_model_validate(const demi_model* m, char* err, size_t err_cap) {
     }
   }
   if (m->inv_kind > DEMI_INV_AGREE) FAIL("inv_kind invalid");
-  if (m->inv_fa > 7 || m->inv_fb > 7 || m->inv_va > 255) FAIL("invariant field out of range");
+  if (m->flags & ~DEMI_MODEL_WIDE) FAIL("unknown model flags 0x%x", m->flags);
+  if (m->inv_fa > 7 || m->inv_fb > 7 || m->inv_va > ((m->flags & DEMI_MODEL_WIDE) ? 65535u : 255u)) FAIL("invariant field out of range");
   return DEMI_OK;
 }
 
@@ -146,6 +151,8 @@ int orc_trace_validate(const demi_model* m, const demi_ext_event* ev, uint32_t n
         /* MessageTypes.sanityCheckTrace analogue (V/ExternalEvents.scala:138-149) */
         if (e->msg_type >= m->n_msg_types || m->msg_class[e->msg_type] != DEMI_MSG_EXTERNAL)
           FAIL("event %u: Send of a non-external message type", i);
+        if (!(m->flags & DEMI_MODEL_WIDE) && (e->p0_hi | e->p1_hi))
+          FAIL("event %u: 16-bit payload in a model without DEMI_MODEL_WIDE", i);
         break;
       case DEMI_EV_PARTITION: case DEMI_EV_UNPARTITION:
         if (e->a >= m->n_actors || e->b >= m->n_actors) FAIL("event %u: actor out of range", i);
@@ -166,33 +173,37 @@ int orc_trace_validate(const demi_model* m, const demi_ext_event* ev, uint32_t n
  * format).  Effects are returned in program order; the scheduler applies them in that order,
  * as Akka would call `!` / scheduleOnce / cancel inside receive (WeaveActor.aj:224-279).       */
 int orc_vm_run(const demi_model* m, uint32_t me, uint64_t* state, uint8_t msg_type, uint8_t src,
-               uint8_t p0, uint8_t p1, uint32_t exists_mask, orc_effect* fx, uint32_t fx_cap, orc_jrandom* app) {
+               uint16_t p0, uint16_t p1, uint32_t exists_mask, orc_effect* fx, uint32_t fx_cap, orc_jrandom* app) {
   uint32_t nfx = 0, n_fx_rows = 0;
   uint16_t start = m->handler_start[m->actor_class[me] * m->n_msg_types + msg_type];
   if (start == 0xFFFF) return 0;
-  uint8_t r[16];
-  for (int i = 0; i < 8; i++) r[i] = (uint8_t)(*state >> (8 * i));
+  /* the register window: 16 x u8, or 16 x u16 for DEMI_MODEL_WIDE (state = two words, four 16-bit fields each) */
+  const int wide = (m->flags & DEMI_MODEL_WIDE) != 0;
+  const uint32_t M = wide ? 0xFFFFu : 0xFFu, SH = wide ? 15u : 7u;
+  uint16_t r[16];
+  for (int i = 0; i < 8; i++) r[i] = wide ? (uint16_t)(state[i >> 2] >> (16 * (i & 3))) : (uint16_t)((*state >> (8 * i)) & 0xFF);
   r[8] = r[9] = r[10] = r[11] = 0;
-  r[12] = p0; r[13] = p1; r[14] = src; r[15] = (uint8_t)me;
+  r[12] = (uint16_t)(p0 & M); r[13] = (uint16_t)(p1 & M); r[14] = src; r[15] = (uint16_t)me;
   uint32_t pc = start;
   while (pc < m->code_len) {
     uint32_t w = m->code[pc++];
     uint32_t op = w & 0xFF, dst = (w >> 8) & 15, ai = (w >> 12) & 15, bimm = (w >> 16) & 1;
     uint32_t aux = (w >> 17) & 0x7F, braw = w >> 24;
-    uint8_t a = r[ai];
-    uint8_t b = bimm ? (uint8_t)braw : r[braw & 15];
+    uint32_t a = r[ai];
+    uint32_t b = bimm ? braw : r[braw & 15];
     if (op == DEMI_OP_HALT) break;
     switch (op) {
-      case DEMI_OP_MOV: r[dst] = b; break;
-      case DEMI_OP_ADD: r[dst] = (uint8_t)(a + b); break;
-      case DEMI_OP_SUB: r[dst] = (uint8_t)(a - b); break;
-      case DEMI_OP_AND: r[dst] = a & b; break;
-      case DEMI_OP_OR: r[dst] = a | b; break;
-      case DEMI_OP_XOR: r[dst] = a ^ b; break;
-      case DEMI_OP_SHL: r[dst] = (uint8_t)(a << (b & 7)); break;
-      case DEMI_OP_SHR: r[dst] = (uint8_t)(a >> (b & 7)); break;
-      case DEMI_OP_BITSET: r[dst] = (uint8_t)(a | (1u << (b & 7))); break;
-      case DEMI_OP_POPC: r[dst] = (uint8_t)__builtin_popcount(b); break;
+      case DEMI_OP_MOV: r[dst] = (uint16_t)b; break;
+      case DEMI_OP_MOVHI: r[dst] = (uint16_t)(((a & 0xFFu) | (b << 8)) & M); break;   /* (wide models only: validation) */
+      case DEMI_OP_ADD: r[dst] = (uint16_t)((a + b) & M); break;
+      case DEMI_OP_SUB: r[dst] = (uint16_t)((a - b) & M); break;
+      case DEMI_OP_AND: r[dst] = (uint16_t)(a & b); break;
+      case DEMI_OP_OR: r[dst] = (uint16_t)(a | b); break;
+      case DEMI_OP_XOR: r[dst] = (uint16_t)(a ^ b); break;
+      case DEMI_OP_SHL: r[dst] = (uint16_t)((a << (b & SH)) & M); break;
+      case DEMI_OP_SHR: r[dst] = (uint16_t)(a >> (b & SH)); break;
+      case DEMI_OP_BITSET: r[dst] = (uint16_t)((a | (1u << (b & SH))) & M); break;
+      case DEMI_OP_POPC: r[dst] = (uint16_t)__builtin_popcount(b); break;
       case DEMI_OP_EQ: r[dst] = a == b; break;
       case DEMI_OP_NE: r[dst] = a != b; break;
       case DEMI_OP_LT: r[dst] = a < b; break;
@@ -202,7 +213,7 @@ int orc_vm_run(const demi_model* m, uint32_t me, uint64_t* state, uint8_t msg_ty
       case DEMI_OP_MIN: r[dst] = a < b ? a : b; break;
       case DEMI_OP_MAX: r[dst] = a > b ? a : b; break;
       case DEMI_OP_RND: /* Instrumenter().seededRandom.nextInt(bound) (V/Instrumenter.scala:212, 226-229) */
-        r[dst] = b ? (uint8_t)orc_jrandom_next_int_bound(app, (int32_t)b) : 0;
+        r[dst] = (b & 0xFFu) ? (uint16_t)orc_jrandom_next_int_bound(app, (int32_t)(b & 0xFFu)) : 0;   /* bound = b & 0xFF */
         break;
       case DEMI_OP_SKIPZ: if (a == 0) pc += braw; break;
       case DEMI_OP_SKIPNZ: if (a != 0) pc += braw; break;
@@ -218,7 +229,7 @@ int orc_vm_run(const demi_model* m, uint32_t me, uint64_t* state, uint8_t msg_ty
         /* a message to a name that was never created reaches no scheduler (deadLetters) */
         if (a < m->n_actors && ((exists_mask >> a) & 1)) {
           if (nfx >= fx_cap) return -1;
-          fx[nfx++] = (orc_effect){0, a, (uint8_t)aux, r[dst], b};
+          fx[nfx++] = (orc_effect){0, (uint8_t)a, (uint8_t)aux, r[dst], (uint16_t)b};
         }
         break;
       case DEMI_OP_BCAST:
@@ -226,7 +237,7 @@ int orc_vm_run(const demi_model* m, uint32_t me, uint64_t* state, uint8_t msg_ty
         for (uint32_t j = 0; j < m->n_actors; j++) {
           if (j == me || !((exists_mask >> j) & 1)) continue;
           if (nfx >= fx_cap) return -1;
-          fx[nfx++] = (orc_effect){0, (uint8_t)j, (uint8_t)aux, r[dst], b};
+          fx[nfx++] = (orc_effect){0, (uint8_t)j, (uint8_t)aux, r[dst], (uint16_t)b};
         }
         break;
       case DEMI_OP_TSET: case DEMI_OP_TREP: case DEMI_OP_TCANCEL:
@@ -243,9 +254,14 @@ int orc_vm_run(const demi_model* m, uint32_t me, uint64_t* state, uint8_t msg_ty
       default: break;
     }
   }
-  uint64_t s = 0;
-  for (int i = 0; i < 8; i++) s |= (uint64_t)r[i] << (8 * i);
-  *state = s;
+  if (wide) {
+    state[0] = (uint64_t)r[0] | ((uint64_t)r[1] << 16) | ((uint64_t)r[2] << 32) | ((uint64_t)r[3] << 48);
+    state[1] = (uint64_t)r[4] | ((uint64_t)r[5] << 16) | ((uint64_t)r[6] << 32) | ((uint64_t)r[7] << 48);
+  } else {
+    uint64_t s = 0;
+    for (int i = 0; i < 8; i++) s |= (uint64_t)r[i] << (8 * i);
+    *state = s;
+  }
   return (int)nfx;
 }
 
@@ -253,20 +269,24 @@ int orc_vm_run(const demi_model* m, uint32_t me, uint64_t* state, uint8_t msg_ty
  * `Invariant` closure (V/minification/TestOracle.scala:27) as a descriptor; evaluated on the
  * simulated actor state instead of CheckpointReply maps (checkpointing is off by default,
  * V/SchedulerConfig.scala:11-12).  Returns the ViolationFingerprint code.                      */
-static inline uint32_t fld(uint64_t s, uint32_t f) { return (uint32_t)(s >> (8 * f)) & 0xFF; }
+/* field f of actor i: 8 bits of its one state word, or 16 bits of its two (DEMI_MODEL_WIDE) */
+static inline uint32_t fldw(int wide, const uint64_t* st, uint32_t i, uint32_t f) {
+  return wide ? (uint32_t)(st[2 * i + (f >> 2)] >> (16 * (f & 3))) & 0xFFFFu : (uint32_t)(st[i] >> (8 * f)) & 0xFFu;
+}
 
 uint32_t orc_invariant(const demi_model* m, const uint64_t* st, uint32_t exists) {
   uint32_t A = m->n_actors, fa = m->inv_fa, va = m->inv_va, fb = m->inv_fb;
+  const int wide = (m->flags & DEMI_MODEL_WIDE) != 0;
   switch (m->inv_kind) {
     case DEMI_INV_AT_MOST_ONE:
       for (uint32_t i = 0; i < A; i++) {
-        if (!((exists >> i) & 1) || fld(st[i], fa) != va) continue;
+        if (!((exists >> i) & 1) || fldw(wide, st, i, fa) != va) continue;
         for (uint32_t j = i + 1; j < A; j++) {
-          if (!((exists >> j) & 1) || fld(st[j], fa) != va) continue;
-          if (fld(st[i], fb) != fld(st[j], fb)) continue;
-          uint32_t key = fld(st[i], fb), mask = 0;
+          if (!((exists >> j) & 1) || fldw(wide, st, j, fa) != va) continue;
+          if (fldw(wide, st, i, fb) != fldw(wide, st, j, fb)) continue;
+          uint32_t key = fldw(wide, st, i, fb), mask = 0;
           for (uint32_t k = 0; k < A; k++)
-            if (((exists >> k) & 1) && fld(st[k], fa) == va && fld(st[k], fb) == key) mask |= 1u << k;
+            if (((exists >> k) & 1) && fldw(wide, st, k, fa) == va && fldw(wide, st, k, fb) == key) mask |= 1u << k;
           return (1u << 24) | (key << 8) | mask;
         }
       }
@@ -274,16 +294,16 @@ uint32_t orc_invariant(const demi_model* m, const uint64_t* st, uint32_t exists)
     case DEMI_INV_NEVER: {
       uint32_t mask = 0;
       for (uint32_t k = 0; k < A; k++)
-        if (((exists >> k) & 1) && fld(st[k], fa) == va) mask |= 1u << k;
+        if (((exists >> k) & 1) && fldw(wide, st, k, fa) == va) mask |= 1u << k;
       return mask ? (2u << 24) | mask : 0;
     }
     case DEMI_INV_AGREE: {
       uint32_t mask = 0, first = 0xFFFFFFFFu, bad = 0;
       for (uint32_t k = 0; k < A; k++) {
-        if (!((exists >> k) & 1) || fld(st[k], fa) == 0) continue;
+        if (!((exists >> k) & 1) || fldw(wide, st, k, fa) == 0) continue;
         mask |= 1u << k;
-        if (first == 0xFFFFFFFFu) first = fld(st[k], fb);
-        else if (fld(st[k], fb) != first) bad = 1;
+        if (first == 0xFFFFFFFFu) first = fldw(wide, st, k, fb);
+        else if (fldw(wide, st, k, fb) != first) bad = 1;
       }
       return bad ? (3u << 24) | mask : 0;
     }
@@ -296,18 +316,25 @@ uint32_t orc_invariant(const demi_model* m, const uint64_t* st, uint32_t exists)
 #define PEND_HARD_CAP DEMI_MAX_PENDING
 #define MTS_CAP 512
 
-typedef struct { uint32_t word; uint32_t id; } pend_entry;
+typedef struct { uint64_t word; uint32_t id; } pend_entry;
 
+/* message word: type[4:0] | dst[7:5] | src[11:8] | p0[23:16] | p1[31:24]; DEMI_MODEL_WIDE: p0[31:16] | p1[47:32] */
 static inline uint32_t msg_word(uint32_t type, uint32_t src, uint32_t dst, uint32_t p0, uint32_t p1) {
   return type | (dst << 5) | (src << 8) | (p0 << 16) | (p1 << 24);
 }
-#define W_TYPE(w) ((w) & 31u)
-#define W_DST(w) (((w) >> 5) & 7u)
-#define W_SRC(w) (((w) >> 8) & 15u)
+static inline uint64_t msg_word_x(int wide, uint32_t type, uint32_t src, uint32_t dst, uint32_t p0, uint32_t p1) {
+  if (!wide) return msg_word(type, src, dst, p0 & 0xFFu, p1 & 0xFFu);
+  return (uint64_t)(type | (dst << 5) | (src << 8) | ((p0 & 0xFFFFu) << 16)) | ((uint64_t)(p1 & 0xFFFFu) << 32);
+}
+#define W_TYPE(w) ((uint32_t)(w) & 31u)
+#define W_DST(w) (((uint32_t)(w) >> 5) & 7u)
+#define W_SRC(w) (((uint32_t)(w) >> 8) & 15u)
 #define W_P0(w) (((w) >> 16) & 255u)
 #define W_P1(w) ((w) >> 24)
+#define WX_P0(wide, w) ((wide) ? (uint32_t)((w) >> 16) & 0xFFFFu : (uint32_t)((w) >> 16) & 255u)
+#define WX_P1(wide, w) ((wide) ? (uint32_t)((w) >> 32) & 0xFFFFu : (uint32_t)((w) >> 24) & 255u)
 
-typedef struct { uint8_t rcv, type, p0, p1, is_external, ext_idx; } mts_entry; /* messagesToSend */
+typedef struct { uint8_t rcv, type; uint16_t p0, p1; uint8_t is_external, ext_idx; } mts_entry; /* messagesToSend */
 
 typedef struct {
   const demi_model* m;
@@ -315,7 +342,8 @@ typedef struct {
   uint32_t n_ev;
   const demi_limits* lim;
   orc_jrandom rng;
-  uint64_t state[DEMI_MAX_ACTORS];
+  int wide;                             /* DEMI_MODEL_WIDE */
+  uint64_t state[2 * DEMI_MAX_ACTORS];  /* one word per actor; two for a wide model */
   uint32_t exists, inaccessible, killed;
   uint32_t blocked;     /* Instrumenter().blockedActors (crashed actors), V/Instrumenter.scala:116, 184-199 */
   uint64_t partitioned; /* bit a*8+b : ordered pair (a,b), V/schedulers/EventOrchestrator.scala:51 */
@@ -372,7 +400,7 @@ static int crosses_partition(const exec_t* x, uint32_t snd, uint32_t rcv) {
 
 /* RandomizedHashSet.insert, V/schedulers/Util.scala:126-136 */
 #define OVF_ANY (DEMI_V_PENDING_OVF | DEMI_V_QUEUE_OVF)
-static void pend_insert(exec_t* x, uint32_t word, uint32_t id) {
+static void pend_insert(exec_t* x, uint64_t word, uint32_t id) {
   if (x->flags & OVF_ANY) return; /* only the first capacity overflow is reported */
   if (x->n_pend + x->n_norm >= x->p_max) { x->flags |= DEMI_V_PENDING_OVF; return; }
   if (x->fifo && W_SRC(word) != DEMI_DEADLETTERS) {
@@ -461,8 +489,8 @@ static void cancel_timer(exec_t* x, uint32_t rcv, uint32_t type) {
     }
   }
   for (uint32_t i = 0; i < x->n_pend; i++) {
-    uint32_t w = x->pend[i].word;
-    if (W_SRC(w) == DEMI_DEADLETTERS && W_DST(w) == rcv && W_TYPE(w) == type && W_P0(w) == 0 && W_P1(w) == 0) {
+    uint64_t w = x->pend[i].word;
+    if (W_SRC(w) == DEMI_DEADLETTERS && W_DST(w) == rcv && W_TYPE(w) == type && (w >> 16) == 0) {
       pend_remove_at(x, i);
       return;
     }
@@ -476,10 +504,10 @@ static void event_produced(exec_t* x, uint32_t snd, uint32_t rcv, uint32_t type,
   int is_timer = 0, dropped = 0;
   if (!is_external) {
     if (snd == DEMI_DEADLETTERS) is_timer = 1;
-    if (!crosses_partition(x, snd, rcv)) pend_insert(x, msg_word(type, snd, rcv, p0, p1), id);
+    if (!crosses_partition(x, snd, rcv)) pend_insert(x, msg_word_x(x->wide, type, snd, rcv, p0, p1), id);
     else dropped = 1;
   } else {
-    pend_insert(x, msg_word(type, snd, rcv, p0, p1), id); /* externals: no partition check (:298-308) */
+    pend_insert(x, msg_word_x(x->wide, type, snd, rcv, p0, p1), id); /* externals: no partition check (:298-308) */
   }
   rec_push(x, DEMI_REC_MSG_SEND, (uint8_t)snd, (uint8_t)rcv, (uint8_t)type, (uint8_t)p0, (uint8_t)p1,
            (uint8_t)((is_external ? 1 : 0) | (is_timer ? 2 : 0) | (dropped ? 4 : 0)), ext_idx, id);
@@ -516,7 +544,7 @@ static void inject_until_quiescence(exec_t* x) {
       case DEMI_EV_SEND: /* enqueue_message, V/schedulers/ExternalEventInjector.scala:250-279 */
         if ((x->exists >> e->a) & 1) {
           if (x->n_mts >= MTS_CAP) { x->flags |= DEMI_V_QUEUE_OVF; break; }
-          x->mts[x->n_mts++] = (mts_entry){e->a, e->msg_type, e->p0, e->p1, 1, idx};
+          x->mts[x->n_mts++] = (mts_entry){e->a, e->msg_type, (uint16_t)(e->p0 | (e->p0_hi << 8)), (uint16_t)(e->p1 | (e->p1_hi << 8)), 1, idx};
         } /* else: "Unknown message receiver" (:254) */
         break;
       case DEMI_EV_PARTITION: /* trigger_partition :314-322 */
@@ -551,11 +579,12 @@ static uint32_t check_invariant(exec_t* x) {
 static inline void hash_step(uint64_t* h, uint64_t v) { *h = (*h ^ v) * 0x100000001B3ULL; }
 
 /* Apply delta to the delivered message and its effects in program order. */
-static void deliver(exec_t* x, uint32_t word) {
+static void deliver(exec_t* x, uint64_t word) {
   uint32_t me = W_DST(word);
   orc_effect* fx = x->fx; /* DEMI_MAX_CODE rows x at most DEMI_MAX_ACTORS effects each: never full */
-  int n = orc_vm_run(x->m, me, &x->state[me], (uint8_t)W_TYPE(word), (uint8_t)W_SRC(word), (uint8_t)W_P0(word),
-                     (uint8_t)W_P1(word), x->exists, fx, DEMI_MAX_CODE * DEMI_MAX_ACTORS, &x->app_rng);
+  int n = orc_vm_run(x->m, me, &x->state[x->wide ? 2 * me : me], (uint8_t)W_TYPE(word), (uint8_t)W_SRC(word),
+                     (uint16_t)WX_P0(x->wide, word), (uint16_t)WX_P1(x->wide, word), x->exists, fx,
+                     DEMI_MAX_CODE * DEMI_MAX_ACTORS, &x->app_rng);
   if (n < 0) { x->flags |= DEMI_V_QUEUE_OVF; return; }
   for (int i = 0; i < n; i++) {
     switch (fx[i].kind) {
@@ -629,7 +658,7 @@ static int schedule_new_message(exec_t* x) {
     }
   }
   x->count++;                                                   /* :462 */
-  uint32_t w = e.word;
+  uint64_t w = e.word;
   rec_push(x, DEMI_REC_MSG_EVENT, (uint8_t)W_SRC(w), (uint8_t)W_DST(w), (uint8_t)W_TYPE(w), (uint8_t)W_P0(w),
            (uint8_t)W_P1(w), 0, 255, e.id);
   hash_step(&x->hash, w);
@@ -656,6 +685,9 @@ static int random_execute_in(exec_t* x, const demi_model* m, const demi_ext_even
                              uint32_t rec_cap, uint32_t* n_rec, uint64_t* final_states) {
   memset(x, 0, offsetof(exec_t, fx));
   x->m = m; x->trace = trace; x->n_ev = n_ev; x->lim = lim;
+  x->wide = (m->flags & DEMI_MODEL_WIDE) != 0;
+  /* a wide model has no recorded-trace format (demi_rec_event carries 8-bit payloads) and no SrcDstFIFO variant */
+  if (x->wide && (rec || lim->strategy != DEMI_STRATEGY_FULLY_RANDOM)) return DEMI_ERR_INVALID_MODEL;
   x->rec = rec; x->rec_cap = rec_cap;
   x->p_max = lim->p_max ? lim->p_max : 64;
   if (x->p_max > PEND_HARD_CAP) x->p_max = PEND_HARD_CAP;
@@ -669,7 +701,8 @@ static int random_execute_in(exec_t* x, const demi_model* m, const demi_ext_even
     if (trace[i].kind == DEMI_EV_START) x->exists |= 1u << trace[i].a;
   if (lim->populate_all) x->exists = (1u << m->n_actors) - 1;
   x->inaccessible = x->exists;
-  for (uint32_t a = 0; a < m->n_actors; a++) x->state[a] = m->init_state[a];
+  const uint32_t n_state = m->n_actors * (x->wide ? 2u : 1u);
+  for (uint32_t a = 0; a < n_state; a++) x->state[a] = m->init_state[a];
   x->next_id = 1;
   x->hash = 0xCBF29CE484222325ULL;
 
@@ -691,7 +724,7 @@ static int random_execute_in(exec_t* x, const demi_model* m, const demi_ext_even
   /* explore(): `if (messagesScheduledSoFar <= maxMessages) checkIfBugFound` (:256-262, 156-180) */
   if (!(x->flags & (DEMI_V_PENDING_OVF | DEMI_V_QUEUE_OVF | DEMI_V_MAXMSG)) && !x->violation)
     x->violation = check_invariant(x);
-  for (uint32_t a = 0; a < m->n_actors; a++) hash_step(&x->hash, x->state[a]);
+  for (uint32_t a = 0; a < n_state; a++) hash_step(&x->hash, x->state[a]);
 
   if (x->flags & (DEMI_V_PENDING_OVF | DEMI_V_QUEUE_OVF)) {
     /* capacity abort: only the overflow bits are defined (the schedule must be re-run on the
@@ -706,7 +739,7 @@ static int random_execute_in(exec_t* x, const demi_model* m, const demi_ext_even
     out->hash = x->hash;
   }
   if (n_rec) *n_rec = x->n_rec;
-  if (final_states) memcpy(final_states, x->state, sizeof(uint64_t) * m->n_actors);
+  if (final_states) memcpy(final_states, x->state, sizeof(uint64_t) * n_state);
   return DEMI_OK;
 }
 
@@ -1010,6 +1043,7 @@ static int sts_replay_in(sts_t* x, const demi_model* m, const demi_ext_event* ex
 int orc_sts_replay(const demi_model* m, const demi_ext_event* ext, uint32_t n_ext, const demi_rec_event* rec,
                    uint32_t n_rec, const uint64_t mask[4], const demi_limits* lim, demi_verdict* out,
                    uint32_t* n_ignored) {
+  if (m->flags & DEMI_MODEL_WIDE) return DEMI_ERR_INVALID_MODEL;   /* wide models: the RandomScheduler path only (include/demi_gpu.h) */
   sts_t* x = (sts_t*)malloc(sizeof(sts_t));
   if (!x) return DEMI_ERR_INVALID_ARG;
   int rc = sts_replay_in(x, m, ext, n_ext, rec, n_rec, mask, lim, out, n_ignored, 0xFFFFFFFFu, NULL);
@@ -1022,6 +1056,7 @@ static const uint64_t STS_ALL[4] = {~0ULL, ~0ULL, ~0ULL, ~0ULL};
 int orc_sts_removal(const demi_model* m, const demi_ext_event* ext, uint32_t n_ext, const demi_rec_event* rec,
                     uint32_t n_rec, const uint64_t* mask, uint32_t skip, const demi_limits* lim, demi_verdict* out,
                     uint8_t* kept) {
+  if (m->flags & DEMI_MODEL_WIDE) return DEMI_ERR_INVALID_MODEL;   /* wide models: the RandomScheduler path only (include/demi_gpu.h) */
   sts_t* x = (sts_t*)malloc(sizeof(sts_t));
   if (!x) return DEMI_ERR_INVALID_ARG;
   int rc = sts_replay_in(x, m, ext, n_ext, rec, n_rec, mask ? mask : STS_ALL, lim, out, NULL, skip, kept);
@@ -1059,6 +1094,7 @@ static void* sts_job_main(void* p) {
 static int sts_batch(const demi_model* m, const demi_ext_event* ext, uint32_t n_ext, const demi_rec_event* rec,
                      uint32_t n_rec, const uint64_t* masks, const uint32_t* skip, uint64_t n, const demi_limits* lim,
                      demi_verdict* out, int n_threads) {
+  if (m->flags & DEMI_MODEL_WIDE) return DEMI_ERR_INVALID_MODEL;   /* wide models: the RandomScheduler path only (include/demi_gpu.h) */
   if (n_threads < 1) n_threads = 1;
   if (n_threads > 256) n_threads = 256;
   pthread_t th[256];
@@ -1212,6 +1248,7 @@ static void dpor_deliver(dpor_t* x, uint32_t w) {
 int orc_dpor_execute(const demi_model* m, const demi_ext_event* ext, uint32_t n_ext, const uint64_t* prefix,
                      uint32_t prefix_len, uint32_t shared_len, const demi_dpor_params* par, demi_verdict* out,
                      demi_dpor_trace_entry* trace, uint32_t* trace_len, demi_dpor_pair* pairs, uint32_t* n_pairs) {
+  if (m->flags & DEMI_MODEL_WIDE) return DEMI_ERR_INVALID_MODEL;   /* wide models: the RandomScheduler path only (include/demi_gpu.h) */
   dpor_t* x = (dpor_t*)calloc(1, sizeof(dpor_t));
   if (!x) return DEMI_ERR_INVALID_ARG;
   x->m = m; x->par = par; x->trace = trace;

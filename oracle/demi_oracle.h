@@ -37,10 +37,12 @@ int orc_trace_validate(const demi_model* m, const demi_ext_event* ev, uint32_t n
 typedef struct {
   uint8_t kind;   /* 0 send, 1 tset, 2 trep, 3 tcancel */
   uint8_t target; /* send: receiver */
-  uint8_t msg_type, p0, p1;
+  uint8_t msg_type;
+  uint16_t p0, p1; /* 8 bits used unless the model is DEMI_MODEL_WIDE */
 } orc_effect;
+/* state: the actor's one word, or its two words for a DEMI_MODEL_WIDE model */
 int orc_vm_run(const demi_model* m, uint32_t me, uint64_t* state, uint8_t msg_type, uint8_t src,
-               uint8_t p0, uint8_t p1, uint32_t exists_mask, orc_effect* fx, uint32_t fx_cap, orc_jrandom* app);
+               uint16_t p0, uint16_t p1, uint32_t exists_mask, orc_effect* fx, uint32_t fx_cap, orc_jrandom* app);
 
 /* Invariant: returns the fingerprint code (0 = holds). */
 uint32_t orc_invariant(const demi_model* m, const uint64_t* states, uint32_t exists_mask);

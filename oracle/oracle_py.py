@@ -76,8 +76,8 @@ def lib():
                                          C.POINTER(C.c_uint32), C.c_void_p]
         L.orc_random_explore.argtypes = [C.POINTER(T.ModelStruct), C.c_void_p, C.c_uint32, C.c_uint64,
                                          C.c_void_p, C.c_uint64, C.POINTER(T.Limits), C.c_void_p, C.c_int]
-        L.orc_vm_run.argtypes = [C.POINTER(T.ModelStruct), C.c_uint32, C.POINTER(C.c_uint64), C.c_uint8, C.c_uint8,
-                                 C.c_uint8, C.c_uint8, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.orc_vm_run.argtypes = [C.POINTER(T.ModelStruct), C.c_uint32, C.c_void_p, C.c_uint8, C.c_uint8,
+                                 C.c_uint16, C.c_uint16, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
         L.orc_sts_replay_batch.argtypes = [C.POINTER(T.ModelStruct), C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
                                            C.c_void_p, C.c_uint64, C.POINTER(T.Limits), C.c_void_p, C.c_int]
         L.orc_sts_removal_batch.argtypes = [C.POINTER(T.ModelStruct), C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
@@ -89,6 +89,11 @@ def lib():
                                        C.c_void_p, C.POINTER(C.c_uint32)]
         _LIB = L
     return _LIB
+
+
+class Effect(C.Structure):
+    """orc_effect (demi_oracle.h): kind 0 send, 1 tset, 2 trep, 3 tcancel, 4 crash."""
+    _fields_ = [("kind", C.c_uint8), ("target", C.c_uint8), ("msg_type", C.c_uint8), ("p0", C.c_uint16), ("p1", C.c_uint16)]
 
 
 class JRandom:
@@ -142,7 +147,7 @@ def random_execute(model, events, seed, limits, record=True):
     v = T.Verdict()
     rec = np.zeros(T.MAX_REC_EVENTS, dtype=T.REC_EVENT_DTYPE)
     n_rec = C.c_uint32(0)
-    states = np.zeros(model.n_actors, dtype=np.uint64)
+    states = np.zeros(model.n_actors * (2 if getattr(model, "wide", False) else 1), dtype=np.uint64)
     rc = lib().orc_random_execute(C.byref(ms), ev.ctypes.data, len(ev), C.c_uint64(seed), C.byref(limits),
                                   C.byref(v), rec.ctypes.data if record else None, len(rec), C.byref(n_rec),
                                   states.ctypes.data)

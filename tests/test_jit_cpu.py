@@ -10,6 +10,7 @@ import pytest
 
 from demi_amd import _native, types as T
 from demi_amd import model as M
+from oracle.oracle_py import Effect
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FX_CAP = 8            # DEMI_FX_CAP
@@ -70,7 +71,7 @@ def test_generated_handlers_equal_the_row_interpreter(oracle, tmp_path, name, mk
     rng = np.random.default_rng(7)
     st = np.zeros(8 * 64, dtype=np.uint64)
     fxq = np.zeros(FX_CAP * 64, dtype=np.uint32)
-    fx = (C.c_uint8 * (5 * 64))()
+    fx = (Effect * 64)()
     n_fx_seen = n_ovf = 0
     for it in range(30000):
         me = int(rng.integers(A))
@@ -102,7 +103,7 @@ def test_generated_handlers_equal_the_row_interpreter(oracle, tmp_path, name, mk
                 got += [(0, r, t_, q0, q1) for r in range(A) if r != me]
             else:
                 got.append((1 + op - M.OPS["TSET"], me, t_, 0, 0))
-        want = [tuple(fx[5 * k + j] for j in range(5)) for k in range(wn)]
+        want = [(e.kind, e.target, e.msg_type, e.p0, e.p1) for e in fx[:wn]]
         assert got == want, (it, me, typ, hex(state), got, want)
         n_fx_seen += len(got)
     assert n_fx_seen > 1000
@@ -198,7 +199,7 @@ def test_random_programs_through_the_code_generator(oracle, tmp_path, seed, ifco
     ac = sum((c & 15) << (4 * i) for i, c in enumerate(model.actor_class))
     st = np.zeros(8 * 64, dtype=np.uint64)
     fxq = np.zeros(FX_CAP * 64, dtype=np.uint32)
-    fx = (C.c_uint8 * (5 * 64))()
+    fx = (Effect * 64)()
     seen_ovf = seen_fx = 0
     for it in range(6000):
         me, typ = int(rng.integers(A)), int(rng.integers(NT))
@@ -227,7 +228,7 @@ def test_random_programs_through_the_code_generator(oracle, tmp_path, seed, ifco
                 got += [(0, r, t_, q0, q1) for r in range(A) if r != me]
             else:
                 got.append((1 + op - M.OPS["TSET"], me, t_, 0, 0))
-        assert got == [tuple(fx[5 * k + j] for j in range(5)) for k in range(wn)], (it, me, typ)
+        assert got == [(e.kind, e.target, e.msg_type, e.p0, e.p1) for e in fx[:wn]], (it, me, typ)
         seen_fx += len(got)
     assert seen_fx > 200
 
@@ -250,7 +251,7 @@ def test_if_conversion_knob_converts_short_guarded_alu_runs(oracle, tmp_path, mo
     hs[:len(model.handler_start)] = model.handler_start
     st = np.zeros(8 * 64, dtype=np.uint64)
     fxq = np.zeros(FX_CAP * 64, dtype=np.uint32)
-    fx = (C.c_uint8 * (5 * 64))()
+    fx = (Effect * 64)()
     rng = np.random.default_rng(0)
     for _ in range(3000):
         state = int.from_bytes(bytes(int(x) for x in rng.integers(0, 3, 8)), "little")

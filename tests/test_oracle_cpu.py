@@ -96,8 +96,9 @@ def test_trace_validation_rules(oracle):
 
 
 # --------------------------------------------------------------------------- transition table vs a plain reference
-def raft_reference(n_actors, buggy, me, fields, msg, src, p0, p1):
-    """The raft-synth `receive` written directly in Python; returns (fields, effects)."""
+def raft_reference(n_actors, buggy, me, fields, msg, src, p0, p1, mask=255):
+    """The raft-synth `receive` written directly in Python; returns (fields, effects).  mask: 255 for the 8-bit register
+    window, 65535 for a wide model."""
     role, term, voted, votes, budget, loglen, commit, booted = fields
     fx = []
     others = [j for j in range(n_actors) if j != me]
@@ -113,12 +114,12 @@ def raft_reference(n_actors, buggy, me, fields, msg, src, p0, p1):
             fx.append(("tset", M.M_ELECTION_TIMEOUT))
     elif msg == M.M_CLIENT:
         if role == M.LEADER:
-            loglen = (loglen + 1) & 255
+            loglen = (loglen + 1) & mask
             fx += [("send", j, M.M_APPEND_ENTRIES, term, loglen) for j in others]
     elif msg == M.M_ELECTION_TIMEOUT:
         if role != M.LEADER and budget != 0:
             budget -= 1
-            role, term, voted = M.CANDIDATE, (term + 1) & 255, me
+            role, term, voted = M.CANDIDATE, (term + 1) & mask, me
             votes = 1 << me
             fx += [("send", j, M.M_REQUEST_VOTE, term, 0) for j in others]
             fx.append(("tset", M.M_ELECTION_TIMEOUT))
@@ -127,7 +128,7 @@ def raft_reference(n_actors, buggy, me, fields, msg, src, p0, p1):
             step_down_timers()
             term, role, voted = p0, M.FOLLOWER, M.NOBODY
         ok = voted == M.NOBODY or voted == src
-        if buggy and role == M.CANDIDATE and ((src - 1) & 255) == me:
+        if buggy and role == M.CANDIDATE and ((src - 1) & mask) == me:
             ok = True
         if p0 == term and ok:
             voted = src
@@ -140,7 +141,7 @@ def raft_reference(n_actors, buggy, me, fields, msg, src, p0, p1):
             step_down_timers()
             term, role, voted = p0, M.FOLLOWER, M.NOBODY
         elif role == M.CANDIDATE and p0 == term and (p1 & 1 if p1 in (0, 1) else (1 & p1)):
-            votes = (votes | (1 << (src & 7))) & 255
+            votes = (votes | (1 << (src & (15 if mask > 255 else 7)))) & mask
             if bin(votes).count("1") >= maj:
                 role = M.LEADER
                 fx += [("tcancel", M.M_ELECTION_TIMEOUT), ("trep", M.M_HEARTBEAT)]
@@ -171,8 +172,8 @@ def raft_reference(n_actors, buggy, me, fields, msg, src, p0, p1):
     return [role, term, voted, votes, budget, loglen, commit, booted], fx
 
 
-class _Effect(C.Structure):
-    _fields_ = [("kind", C.c_uint8), ("target", C.c_uint8), ("msg_type", C.c_uint8), ("p0", C.c_uint8), ("p1", C.c_uint8)]
+class _Effect(C.Structure):      # orc_effect (oracle/demi_oracle.h)
+    _fields_ = [("kind", C.c_uint8), ("target", C.c_uint8), ("msg_type", C.c_uint8), ("p0", C.c_uint16), ("p1", C.c_uint16)]
 
 
 @pytest.mark.parametrize("buggy", [True, False])
@@ -200,6 +201,66 @@ def test_raft_table_equals_plain_reference(oracle, buggy):
                           (["", "tset", "trep", "tcancel"][e.kind], e.msg_type))
         assert st.value == M.pack_state(want_fields), (fields, msg, src, p0, p1)
         assert got_fx == want_fx, (fields, msg, src, p0, p1)
+
+
+def test_wide_raft_table_equals_plain_reference(oracle):
+    """DEMI_MODEL_WIDE: the same handlers over 16-bit fields and payloads (terms around 1000, log lengths around 300)."""
+    A = 5
+    model = M.raft_model(A, term0=1000, loglen0=300)
+    assert model.wide and len(model.init_state) == 2 * A
+    ms = model.to_struct()
+    rnd = random.Random(5)
+    fx = (_Effect * 64)()
+    st = (C.c_uint64 * 2)()
+    for _ in range(4000):
+        me = rnd.randrange(A)
+        msg = rnd.randrange(8)
+        src = T.DEADLETTERS if model.msg_class[msg] != T.MSG_INTERNAL else rnd.choice([j for j in range(A) if j != me])
+        fields = [rnd.randrange(3), 998 + rnd.randrange(6), rnd.choice([M.NOBODY] + list(range(A))), rnd.randrange(32),
+                  rnd.randrange(3), 298 + rnd.randrange(4), 298 + rnd.randrange(4), rnd.randrange(2)]
+        p0, p1 = 998 + rnd.randrange(6), 298 + rnd.randrange(4)
+        if msg == M.M_VOTE_REPLY:
+            p1 = rnd.randrange(2)
+        if rnd.randrange(20) == 0:
+            fields[1], p0 = 65535, rnd.choice([0, 65535])          # wrap-around at 2^16, not at 2^8
+        st[0], st[1] = M.pack_state_wide(fields)
+        n = oracle.lib().orc_vm_run(C.byref(ms), me, st, msg, src, p0, p1, (1 << A) - 1, fx, 64, C.byref(C.c_uint64(0x5DEECE66D)))
+        want_fields, want_fx = raft_reference(A, True, me, fields, msg, src, p0, p1, mask=65535)
+        got_fx = [("send", e.target, e.msg_type, e.p0, e.p1) if e.kind == 0 else (["", "tset", "trep", "tcancel"][e.kind], e.msg_type)
+                  for e in fx[:n]]
+        assert [st[0], st[1]] == M.pack_state_wide(want_fields), (fields, msg, src, p0, p1)
+        assert got_fx == want_fx, (fields, msg, src, p0, p1)
+
+
+def test_wide_model_rules(oracle):
+    """MOVHI and 16-bit payloads belong to wide models only; a wide model executes under the RandomScheduler oracle (terms
+    above 255 reach the verdict hash) and is refused by the recording, SrcDstFIFO, replay and DPOR paths."""
+    narrow = M.raft_model(3)
+    a = Asm().ldi16(M.T0, 0x1234).mov(M.F[0], M.T0)
+    bad = build_model("bad", 2, [("E", T.MSG_EXTERNAL)], {(0, "E"): a}, [[0] * 8] * 2, (T.INV_NONE, 0, 0, 0))
+    rc, msg = oracle.model_validate(bad)
+    assert rc == T.ERR_INVALID_MODEL and "MOVHI" in msg
+    wide = build_model("ok", 2, [("E", T.MSG_EXTERNAL)], {(0, "E"): a}, [[0] * 8] * 2, (T.INV_NEVER, 0, 0x1234, 0), wide=True)
+    assert oracle.model_validate(wide)[0] == 0
+    ev = events_to_array([start(0), start(1), send(0, 0, 7, 9)])
+    v = oracle.random_explore(wide, ev, 4, limits=T.Limits(0, 0, 16, 0, 0, 0))
+    assert (v["flags"] & T.V_VIOLATION).all() and (v["fingerprint"] == ((2 << 24) | 1)).all()
+    rc, msg = oracle.trace_validate(narrow, events_to_array([start(0), send(0, M.M_BOOTSTRAP, 300, 0)]))
+    assert rc == T.ERR_INVALID_TRACE and "16-bit" in msg
+    # the wide raft: same protocol, terms from 1000 on; a different execution hash than the narrow model, same verdict counts
+    ev = events_to_array([start(a) for a in range(3)] + [send(a, M.M_BOOTSTRAP) for a in range(3)])
+    lim = T.Limits(100, 10, 64, 0, 0, 0)
+    vn = oracle.random_explore(M.raft_model(3), ev, 300, limits=lim)
+    vw = oracle.random_explore(M.raft_model(3, term0=1000), ev, 300, limits=lim)
+    assert (T.verdict_deliveries(vn["flags"]) == T.verdict_deliveries(vw["flags"])).all()        # same protocol, same schedules
+    assert ((vn["flags"] & T.V_VIOLATION) == (vw["flags"] & T.V_VIOLATION)).all() and (vn["hash"] != vw["hash"]).all()
+    viol = vw[(vw["flags"] & T.V_VIOLATION) != 0]
+    assert len(viol) and (((viol["fingerprint"] >> 8) & 0xFFFF) > 1000).all()                  # the term two leaders share
+    fifo = T.Limits(100, 10, 64, 0, 0, 0)
+    fifo.strategy = T.STRATEGY_SRC_DST_FIFO
+    assert (oracle.random_explore(M.raft_model(3, term0=1000), ev, 2, limits=fifo)["hash"] == 0).all()   # (refused: nothing computed)
+    with pytest.raises(AssertionError):
+        oracle.random_execute(M.raft_model(3, term0=1000), ev, 1, lim, record=True)          # no recorded-trace format
 
 
 # --------------------------------------------------------------------------- tiny models: one semantic rule each

@@ -32,8 +32,8 @@ MASK64 = (1 << 64) - 1
 DEAD = "deadLetters"
 
 
-class _Effect(C.Structure):
-    _fields_ = [("kind", C.c_uint8), ("target", C.c_uint8), ("msg_type", C.c_uint8), ("p0", C.c_uint8), ("p1", C.c_uint8)]
+class _Effect(C.Structure):      # orc_effect (oracle/demi_oracle.h)
+    _fields_ = [("kind", C.c_uint8), ("target", C.c_uint8), ("msg_type", C.c_uint8), ("p0", C.c_uint16), ("p1", C.c_uint16)]
 
 
 class FullyRandom:
