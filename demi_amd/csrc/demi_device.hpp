@@ -17,7 +17,7 @@ namespace demi {
 struct DevModel {
   uint32_t n_actors, n_msg_types, n_classes, code_len;
   uint32_t inv_kind, inv_fa, inv_va, inv_fb;
-  uint32_t fp_match_mask, pad0, pad1, pad2;
+  uint32_t fp_match_mask, wide /* DEMI_MODEL_WIDE */, pad1, pad2;
   uint32_t meta[DEMI_MAX_MSG_TYPES];                           // msg_class | timer_idx << 8
   uint32_t handler_start[DEMI_MAX_CLASSES * DEMI_MAX_MSG_TYPES];  // 0xFFFF = ignored
   uint32_t actor_class[DEMI_MAX_ACTORS];
@@ -26,10 +26,34 @@ struct DevModel {
   uint32_t pad3;           //  set's nextInt; d <= 255: DEMI_OP_RND bounds)
   uint32_t optab[64];      // per-op control words (sim_core.hpp op_control), filled by the host
   uint32_t code[DEMI_MAX_CODE];
+  uint64_t init_state_wide[2 * DEMI_MAX_ACTORS];   // DEMI_MODEL_WIDE: two words per actor (init_state is unused then)
 };
+
+// A translation unit compiled for a DEMI_MODEL_WIDE table (-DDEMI_WIDE, only ever by demi_model_specialize) sees 64-bit
+// message words and two state words per actor; everything else sees the 8-bit layout, unchanged.
+#ifdef DEMI_WIDE
+typedef uint64_t word_t;
+constexpr uint32_t ST_WORDS = 2;
+constexpr bool WIDE_TU = true;
+#else
+typedef uint32_t word_t;
+constexpr uint32_t ST_WORDS = 1;
+constexpr bool WIDE_TU = false;
+#endif
 
 // ------------------------------------------------------------------ message word
 // type[4:0] | dst[7:5] | src[11:8] | p0[23:16] | p1[31:24]   (identical to the oracle's)
+// wide: type[4:0] | dst[7:5] | src[11:8] | p0[31:16] | p1[47:32]
+#ifdef DEMI_WIDE
+__device__ __forceinline__ word_t msg_word(uint32_t type, uint32_t src, uint32_t dst, uint32_t p0, uint32_t p1) {
+  return (word_t)(type | (dst << 5) | (src << 8) | (p0 << 16)) | ((word_t)p1 << 32);
+}
+__device__ __forceinline__ uint32_t w_type(word_t w) { return (uint32_t)w & 31u; }
+__device__ __forceinline__ uint32_t w_dst(word_t w) { return ((uint32_t)w >> 5) & 7u; }
+__device__ __forceinline__ uint32_t w_src(word_t w) { return ((uint32_t)w >> 8) & 15u; }
+__device__ __forceinline__ uint32_t w_p0(word_t w) { return (uint32_t)w >> 16; }
+__device__ __forceinline__ uint32_t w_p1(word_t w) { return (uint32_t)(w >> 32) & 0xFFFFu; }
+#else
 __device__ __forceinline__ uint32_t msg_word(uint32_t type, uint32_t src, uint32_t dst, uint32_t p0, uint32_t p1) {
   return type | (dst << 5) | (src << 8) | (p0 << 16) | (p1 << 24);
 }
@@ -38,6 +62,7 @@ __device__ __forceinline__ uint32_t w_dst(uint32_t w) { return (w >> 5) & 7u; }
 __device__ __forceinline__ uint32_t w_src(uint32_t w) { return (w >> 8) & 15u; }
 __device__ __forceinline__ uint32_t w_p0(uint32_t w) { return (w >> 16) & 255u; }
 __device__ __forceinline__ uint32_t w_p1(uint32_t w) { return w >> 24; }
+#endif
 
 // ------------------------------------------------------------------ java.util.Random
 // 48-bit LCG of the JDK javadoc; call sites schedulers/Util.scala:115,172.
@@ -80,10 +105,23 @@ __device__ __forceinline__ void hash_step(uint64_t& h, uint64_t v) { h = (h ^ v)
 // Invariant descriptor (TestOracle.scala:27 `Invariant`) on the simulated state; returns the
 // ViolationFingerprint code.  st: this lane's actor states in LDS, stride 64 u64.
 __device__ __forceinline__ uint32_t fld(uint64_t s, uint32_t f) { return (uint32_t)(s >> (8 * f)) & 0xFF; }
+// field f of actor a in a lane's state array (stride 64 words): 8 bits of its one word, or 16 bits of its two (wide)
+__device__ __forceinline__ uint32_t state_field(const uint64_t* st, uint32_t a, uint32_t f) {
+#ifdef DEMI_WIDE
+  return (uint32_t)(st[(2 * a + (f >> 2)) * 64] >> (16 * (f & 3))) & 0xFFFFu;
+#else
+  return (uint32_t)(st[a * 64] >> (8 * f)) & 0xFFu;
+#endif
+}
 
 // One actor's contribution to the invariant's "hit" mask: F[fa] == va (F[fa] != 0 for AGREE).
 __device__ __forceinline__ uint32_t invariant_hit(uint64_t state, uint32_t kind, uint32_t fa, uint32_t va) {
   const uint32_t a = (uint32_t)(state >> (8 * fa)) & 0xFF;
+  return (kind == DEMI_INV_AGREE) ? (a != 0) : (a == va);
+}
+// the same from the lane's state array (what K1 uses: also right for a wide table)
+__device__ __forceinline__ uint32_t invariant_hit_at(const uint64_t* st, uint32_t actor, uint32_t kind, uint32_t fa, uint32_t va) {
+  const uint32_t a = state_field(st, actor, fa);
   return (kind == DEMI_INV_AGREE) ? (a != 0) : (a == va);
 }
 
@@ -94,10 +132,9 @@ __device__ inline uint32_t invariant_from_hits(const uint64_t* st, uint32_t vmas
   if (kind == DEMI_INV_NEVER) return vmask ? ((2u << 24) | vmask) : 0u;
   if (kind == DEMI_INV_NONE || (vmask & (vmask - 1)) == 0) return 0u;   // needs at least two hits
   // slow path: group keys of the hit actors
-  const uint32_t sb = 8 * fb;
   uint32_t key[DEMI_MAX_ACTORS];
 #pragma unroll
-  for (uint32_t i = 0; i < DEMI_MAX_ACTORS; i++) key[i] = (i < A) ? ((uint32_t)(st[i * 64] >> sb) & 0xFF) : 0u;
+  for (uint32_t i = 0; i < DEMI_MAX_ACTORS; i++) key[i] = (i < A) ? state_field(st, i, fb) : 0u;
   if (kind == DEMI_INV_AGREE) {
     bool have = false, bad = false;
     uint32_t first = 0;

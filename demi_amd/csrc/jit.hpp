@@ -38,14 +38,26 @@ inline std::string generate_vm(const demi::DevModel& h) {
   // effect rows are recorded into the LDS effect queue in program order, exactly as vm_run does
   s += "#define DEMI_FX(OP, TYPE, TGT, P0, P1) { if (nfx >= DEMI_FX_CAP) { flags |= DEMI_V_QUEUE_OVF; goto done; } "
        "mem.fxq[nfx * 64] = fx_pack(OP, TYPE, TGT, P0, P1); nfx++; }\n";
-  s += "__device__ inline uint32_t vm_run_jit(const Tables& t, const LaneMem& mem, uint32_t w, uint32_t& flags, uint64_t& app_rng) {\n";
+  // A wide table (DevModel::wide) has 16-bit registers: the same statements with the masks of the wider window, the
+  // state in two words, and 64-bit message / effect words (word_t of a -DDEMI_WIDE translation unit).
+  const bool wide = h.wide != 0;
+  const unsigned RM = wide ? 65535u : 255u, SM = wide ? 15u : 7u;
+  emit("__device__ inline uint32_t vm_run_jit(const Tables& t, const LaneMem& mem, %s w, uint32_t& flags, uint64_t& app_rng) {\n",
+       wide ? "word_t" : "uint32_t");
   s += "  const uint32_t type = w_type(w), me = w_dst(w);\n";
   s += "  const uint32_t entry = t.hs[((t.ac_packed >> (4 * me)) & 15u) * t.NT + type];\n";
   s += "  if (entry == 0xFFFFu) return 0;\n";
-  s += "  const uint64_t st0 = mem.st[me * 64];\n";
-  s += "  uint32_t r0 = (uint32_t)st0 & 255u, r1 = (uint32_t)(st0 >> 8) & 255u, r2 = (uint32_t)(st0 >> 16) & 255u, "
-       "r3 = (uint32_t)(st0 >> 24) & 255u,\n           r4 = (uint32_t)(st0 >> 32) & 255u, r5 = (uint32_t)(st0 >> 40) & 255u, "
-       "r6 = (uint32_t)(st0 >> 48) & 255u, r7 = (uint32_t)(st0 >> 56) & 255u;\n";
+  if (wide) {
+    s += "  const uint64_t st0 = mem.st[(2 * me) * 64], st1 = mem.st[(2 * me + 1) * 64];\n";
+    s += "  uint32_t r0 = (uint32_t)st0 & 65535u, r1 = (uint32_t)(st0 >> 16) & 65535u, r2 = (uint32_t)(st0 >> 32) & 65535u, "
+         "r3 = (uint32_t)(st0 >> 48) & 65535u,\n           r4 = (uint32_t)st1 & 65535u, r5 = (uint32_t)(st1 >> 16) & 65535u, "
+         "r6 = (uint32_t)(st1 >> 32) & 65535u, r7 = (uint32_t)(st1 >> 48) & 65535u;\n";
+  } else {
+    s += "  const uint64_t st0 = mem.st[me * 64];\n";
+    s += "  uint32_t r0 = (uint32_t)st0 & 255u, r1 = (uint32_t)(st0 >> 8) & 255u, r2 = (uint32_t)(st0 >> 16) & 255u, "
+         "r3 = (uint32_t)(st0 >> 24) & 255u,\n           r4 = (uint32_t)(st0 >> 32) & 255u, r5 = (uint32_t)(st0 >> 40) & 255u, "
+         "r6 = (uint32_t)(st0 >> 48) & 255u, r7 = (uint32_t)(st0 >> 56) & 255u;\n";
+  }
   s += "  uint32_t r8 = 0, r9 = 0, r10 = 0, r11 = 0, r12 = w_p0(w), r13 = w_p1(w), r14 = w_src(w), r15 = me;\n";
   s += "  uint32_t nfx = 0;\n";
   s += "  (void)r8; (void)r9; (void)r10; (void)r11; (void)r12; (void)r13; (void)r14; (void)r15;\n";
@@ -118,19 +130,23 @@ inline std::string generate_vm(const demi::DevModel& h) {
     if (cw & CW_ALU) {
       char val[96];
       switch (op) {
-        case DEMI_OP_MOV: snprintf(val, sizeof val, "%s & 255u", b); break;
-        case DEMI_OP_ADD: snprintf(val, sizeof val, "(%s + %s) & 255u", a, b); break;
-        case DEMI_OP_SUB: snprintf(val, sizeof val, "(%s - %s) & 255u", a, b); break;
-        case DEMI_OP_AND: snprintf(val, sizeof val, "%s & %s & 255u", a, b); break;
-        case DEMI_OP_OR: snprintf(val, sizeof val, "(%s | %s) & 255u", a, b); break;
-        case DEMI_OP_XOR: snprintf(val, sizeof val, "(%s ^ %s) & 255u", a, b); break;
-        case DEMI_OP_SHL: snprintf(val, sizeof val, "(%s << (%s & 7u)) & 255u", a, b); break;
-        case DEMI_OP_SHR: snprintf(val, sizeof val, "(%s >> (%s & 7u)) & 255u", a, b); break;
-        case DEMI_OP_BITSET: snprintf(val, sizeof val, "(%s | (1u << (%s & 7u))) & 255u", a, b); break;
+        case DEMI_OP_MOV: snprintf(val, sizeof val, "%s & %uu", b, RM); break;
+        case DEMI_OP_MOVHI: snprintf(val, sizeof val, "((%s & 255u) | (%s << 8)) & %uu", a, b, RM); break;   // (wide tables only)
+        case DEMI_OP_ADD: snprintf(val, sizeof val, "(%s + %s) & %uu", a, b, RM); break;
+        case DEMI_OP_SUB: snprintf(val, sizeof val, "(%s - %s) & %uu", a, b, RM); break;
+        case DEMI_OP_AND: snprintf(val, sizeof val, "%s & %s & %uu", a, b, RM); break;
+        case DEMI_OP_OR: snprintf(val, sizeof val, "(%s | %s) & %uu", a, b, RM); break;
+        case DEMI_OP_XOR: snprintf(val, sizeof val, "(%s ^ %s) & %uu", a, b, RM); break;
+        case DEMI_OP_SHL: snprintf(val, sizeof val, "(%s << (%s & %uu)) & %uu", a, b, SM, RM); break;
+        case DEMI_OP_SHR: snprintf(val, sizeof val, "(%s >> (%s & %uu)) & %uu", a, b, SM, RM); break;
+        case DEMI_OP_BITSET: snprintf(val, sizeof val, "(%s | (1u << (%s & %uu))) & %uu", a, b, SM, RM); break;
         case DEMI_OP_POPC: snprintf(val, sizeof val, "(uint32_t)__popc(%s)", b); break;
         case DEMI_OP_MIN: snprintf(val, sizeof val, "%s < %s ? %s : %s", a, b, a, b); break;
         case DEMI_OP_MAX: snprintf(val, sizeof val, "%s < %s ? %s : %s", a, b, b, a); break;
-        case DEMI_OP_RND: snprintf(val, sizeof val, "app_next_int(app_rng, %s, t.gmagic)", b); break;
+        case DEMI_OP_RND:      // (a wide table's bound is b & 0xFF: the magics cover 1..256)
+          if (wide) snprintf(val, sizeof val, "app_next_int(app_rng, %s & 255u, t.gmagic)", b);
+          else snprintf(val, sizeof val, "app_next_int(app_rng, %s, t.gmagic)", b);
+          break;
         default: snprintf(val, sizeof val, "(%s %s %s) ? 1u : 0u", a, relop[op - DEMI_OP_EQ], b); break;   // EQ .. GT
       }
       if (pred_of[pc] >= 0) emit("%s = c%d ? (%s) : %s;\n", d, pred_of[pc], val, d);
@@ -151,8 +167,12 @@ inline std::string generate_vm(const demi::DevModel& h) {
     }
   }
   s += "  done:\n";
-  s += "  mem.st[me * 64] = (uint64_t)(r0 | (r1 << 8) | (r2 << 16) | (r3 << 24)) | "
-       "((uint64_t)(r4 | (r5 << 8) | (r6 << 16) | (r7 << 24)) << 32);\n";
+  if (wide)
+    s += "  mem.st[(2 * me) * 64] = (uint64_t)(r0 | (r1 << 16)) | ((uint64_t)(r2 | (r3 << 16)) << 32);\n"
+         "  mem.st[(2 * me + 1) * 64] = (uint64_t)(r4 | (r5 << 16)) | ((uint64_t)(r6 | (r7 << 16)) << 32);\n";
+  else
+    s += "  mem.st[me * 64] = (uint64_t)(r0 | (r1 << 8) | (r2 << 16) | (r3 << 24)) | "
+         "((uint64_t)(r4 | (r5 << 8) | (r6 << 16) | (r7 << 24)) << 32);\n";
   s += "  return nfx;\n}\n}  // namespace demi\n";
   return s;
 }

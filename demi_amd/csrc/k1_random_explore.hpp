@@ -65,8 +65,8 @@ constexpr int K1_BATCH = 64;         // schedule indices claimed per atomic
 // order whatever the interleaving, so the state after batch j is a function of j alone) and the
 // message word of every Send (0 = not a deliverable Send).
 constexpr uint32_t K1_BATCH_WORDS = 7;   // end index, inaccessible, killed, partitioned lo/hi, sends (offset | count << 16), actors Start()ed
-__host__ __device__ inline size_t k1_extra_lds_bytes(uint32_t n_ev, uint32_t n_batches) {
-  return (((size_t)n_batches * K1_BATCH_WORDS + 2 * (size_t)n_ev) * 4 + 15) & ~(size_t)15;
+__host__ __device__ inline size_t k1_extra_lds_bytes(uint32_t n_ev, uint32_t n_batches, bool wide = WIDE_TU) {
+  return ((size_t)n_batches * K1_BATCH_WORDS * 4 + 2 * (size_t)n_ev * (wide ? 8 : 4) + 15) & ~(size_t)15;
 }
 // SrcDstFIFO (RandomScheduler.scala:702-909) keeps the actor-to-actor messages apart from the timers / externals:
 // one array in arrival order (a pair's queue is the sub-sequence with that (src, dst)); its NORM_HOT first slots in
@@ -82,9 +82,9 @@ __host__ __device__ inline size_t k1_spill_words_per_lane(bool rec, bool fifo, u
 }
 template <bool REC, bool FIFO>
 __host__ __device__ inline size_t k1_lds_bytes(uint32_t code_len, uint32_t n_ev, uint32_t n_hs, uint32_t n_actors,
-                                               uint32_t n_batches, uint32_t hot = K1_HOT) {
-  return tables_lds_bytes(code_len, n_ev, n_hs) + k1_extra_lds_bytes(n_ev, n_batches) +
-         K1_WAVES * (lane_mem_wave_bytes(n_actors, REC, hot) + (FIFO ? k1_fifo_wave_bytes(n_actors, REC) : 0));
+                                               uint32_t n_batches, uint32_t hot = K1_HOT, bool wide = WIDE_TU) {
+  return tables_lds_bytes(code_len, n_ev, n_hs, wide) + k1_extra_lds_bytes(n_ev, n_batches, wide) +
+         K1_WAVES * (lane_mem_wave_bytes(n_actors, REC, hot, wide) + (FIFO ? k1_fifo_wave_bytes(n_actors, REC) : 0));
 }
 
 #ifdef DEMI_K1_MIN_WAVES_PER_EU    // experiment knob of the specialised build: ask for more waves per SIMD (fewer VGPRs)
@@ -97,9 +97,10 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Tables t;
   unsigned char* extra = tables_load(t, smem, args.model, args.trace, args.n_ev, args.exists);
-  uint32_t* const s_batch = reinterpret_cast<uint32_t*>(extra);
-  uint32_t* const s_sendw = s_batch + (size_t)args.n_batches * K1_BATCH_WORDS;
-  uint32_t* const s_bsend = s_sendw + args.n_ev;     // the deliverable Send words, batch after batch, compacted
+  // (the word arrays first: 8-byte words in a wide build, and `extra` is 16-byte aligned)
+  word_t* const s_sendw = reinterpret_cast<word_t*>(extra);
+  word_t* const s_bsend = s_sendw + args.n_ev;       // the deliverable Send words, batch after batch, compacted
+  uint32_t* const s_batch = reinterpret_cast<uint32_t*>(s_bsend + args.n_ev);
   unsigned char* wave_base = extra + k1_extra_lds_bytes(args.n_ev, args.n_batches);
   if (threadIdx.x == 0) {
     // EventOrchestrator.inject_until_quiescence (:132-189) once per workgroup, for every batch
@@ -109,9 +110,12 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
     for (uint32_t i = 0; i < t.E; i++) {
       const uint64_t ev = t.trace[i];
       const uint32_t kind = (uint32_t)ev & 0xFF, a = (uint32_t)(ev >> 8) & 0xFF, b = (uint32_t)(ev >> 16) & 0xFF;
-      const uint32_t sw = (kind == DEMI_EV_SEND && ((t.exists >> a) & 1))
-                              ? msg_word((uint32_t)(ev >> 24) & 0xFF, DEMI_DEADLETTERS, a, (uint32_t)(ev >> 32) & 0xFF, (uint32_t)(ev >> 40) & 0xFF)
-                              : 0u;
+      // (a wide table's Sends carry 16-bit payloads: demi_ext_event.p0_hi / p1_hi, zero otherwise)
+      const uint32_t ep0 = ((uint32_t)(ev >> 32) & 0xFF) | (WIDE_TU ? ((uint32_t)(ev >> 48) & 0xFF) << 8 : 0u);
+      const uint32_t ep1 = ((uint32_t)(ev >> 40) & 0xFF) | (WIDE_TU ? ((uint32_t)(ev >> 56) & 0xFF) << 8 : 0u);
+      const word_t sw = (kind == DEMI_EV_SEND && ((t.exists >> a) & 1))
+                            ? msg_word((uint32_t)(ev >> 24) & 0xFF, DEMI_DEADLETTERS, a, ep0, ep1)
+                            : (word_t)0;
       s_sendw[i] = sw;
       if (sw != 0) s_bsend[n_bs++] = sw;
       if (kind == DEMI_EV_START) { inacc &= ~(1u << a); killed &= ~(1u << a); started |= 1u << a; }
@@ -268,7 +272,7 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
   // RandomizedHashSet.remove (Util.scala:146-163): the last element moves into the hole
   // (lw = the word in the last slot: callers load it together with the words they inspect, one round trip to the
   // pending set instead of two when it lives in HBM)
-  auto pend_remove = [&](uint32_t idx, uint32_t lw) {
+  auto pend_remove = [&](uint32_t idx, word_t lw) {
     const uint32_t last = n_pend - 1;
     pend_store(mem, idx, lw);
     if (REC) aux_store(mem, idx, aux_load(mem, last));
@@ -345,7 +349,8 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
         net.inaccessible = exists; net.killed = 0; net.partitioned = 0;
         blocked = 0;
         hits = 0;
-        for (uint32_t a = 0; a < A; a++) { const uint64_t s0 = t.init[a]; st[a * 64] = s0; hits |= invariant_hit(s0, inv_kind, inv_fa, inv_va) << a; }
+        for (uint32_t i = 0; i < A * ST_WORDS; i++) st[i * 64] = t.init[i];
+        for (uint32_t a = 0; a < A; a++) hits |= invariant_hit_at(st, a, inv_kind, inv_fa, inv_va) << a;
         if (REC) { rec = args.rec_out + sched * (uint64_t)args.rec_cap; n_rec = 0; next_id = 1; }
         batch_no = 0;
       }
@@ -389,7 +394,7 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
 
     PH_MARK(1);
     // ------------------------------------------------------------ one scheduling step
-    uint32_t w = 0;            // the message picked by this step
+    word_t w = 0;              // the message picked by this step
     bool deliver = false;
     const bool disp = (ph == PH_DISPATCH);
     bool none = false, step = false;
@@ -423,7 +428,7 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
         for (uint32_t i = lane; i < cnt; i += 64) {
           const uint32_t slot = base + i;
           if (slot + other >= PMAX) break;
-          const uint32_t sw = s_bsend[off + i];
+          const word_t sw = s_bsend[off + i];
           if (slot < K1_HOT) (mem.pend - lane + src)[slot * 64] = sw;
           else { (mem.spill - lane + src)[(size_t)(slot - K1_HOT) * mem.spill_stride] = sw; spilled = true; }
         }
@@ -446,7 +451,7 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
     if (step) {
       if (REC) {
         for (uint32_t i = inj_lo; i < inj_hi; i++) {
-          const uint32_t sw = s_sendw[i];
+          const word_t sw = s_sendw[i];
           if (sw != 0) {
             const uint32_t id = next_id; next_id++;
             PEND_APPEND(sw, id, false);
@@ -475,7 +480,7 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
       auto fifo_dequeue = [&](uint32_t pi) {
         const uint32_t pr = pair_get(pi);
         uint32_t k = 0;
-        uint32_t cur = norm_load(0);
+        word_t cur = norm_load(0);
         while (k + 1 < n_norm && w_src(cur) * 8 + w_dst(cur) != pr) { k++; cur = norm_load(k); }   // queue.head
         w = cur;
         if (REC) wid = norm_aux_load(k);
@@ -504,7 +509,7 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
           bool found = false;
           while (n_pend > 0) {
             const uint32_t i = jr_next_int(g, n_pend, t.magic);
-            const uint32_t cw = pend_load(mem, i);
+            const word_t cw = pend_load(mem, i);
             const uint32_t cid = REC ? aux_load(mem, i) : 0u;
             pend_remove(i, pend_load(mem, n_pend - 1));
             if ((blocked >> w_dst(cw)) & 1u) {           // set aside in the slot this removal just freed
@@ -520,7 +525,7 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
           // the accepted element left, so that arr = remaining ++ rejected (collection ++= blocked)
           if (k > 1) {
             for (uint32_t lo = n0 - k, hi = n0 - 1; lo < hi; lo++, hi--) {
-              const uint32_t x = pend_load(mem, lo), y = pend_load(mem, hi);
+              const word_t x = pend_load(mem, lo), y = pend_load(mem, hi);
               pend_store(mem, lo, y); pend_store(mem, hi, x);
               if (REC) { const uint32_t ax = aux_load(mem, lo), ay = aux_load(mem, hi); aux_store(mem, lo, ay); aux_store(mem, hi, ax); }
             }
@@ -533,7 +538,7 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
           n_pend = n0 - (found ? 1u : 0u);
           tmask = 0;                                     // which slots hold timer messages, from scratch
           for (uint32_t q = 0; q < n_pend && q < 64; q++) {
-            const uint32_t pw = pend_load(mem, q);
+            const word_t pw = pend_load(mem, q);
             if (w_src(pw) == DEMI_DEADLETTERS && (t.meta[w_type(pw)] & 0xFF) == DEMI_MSG_TIMER) tmask |= 1ull << q;
           }
           return found;
@@ -577,7 +582,7 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
           }
           if (from_te) {
             w = pend_load(mem, idx);
-            const uint32_t lastw = pend_load(mem, n_pend - 1);
+            const word_t lastw = pend_load(mem, n_pend - 1);
             if (REC) wid = aux_load(mem, idx);
             pend_remove(idx, lastw);
           } else {
@@ -623,7 +628,7 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
     if (deliver) nfx = DEMI_VM_RUN(t, mem, w, flags, app_rng);
     if (deliver) {      // the receiver's new state decides its bit of the invariant's hit mask
       const uint32_t me_ = w_dst(w);
-      hits = (hits & ~(1u << me_)) | (invariant_hit(st[me_ * 64], inv_kind, inv_fa, inv_va) << me_);
+      hits = (hits & ~(1u << me_)) | (invariant_hit_at(st, me_, inv_kind, inv_fa, inv_va) << me_);
     }
     PH_MARK(5);
 #ifdef DEMI_K1_PHASES
@@ -634,7 +639,7 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
     const uint32_t me = w_dst(w);
     // receivers of a SEND / BCAST effect that are not cut off: crosses_partition(me, .) for all receivers at once (row and
     // column of the ordered-pair matrix, the column gathered by a multiply; inaccessible receivers; isolated sender)
-    auto send_targets = [&](uint32_t fx) -> uint32_t {
+    auto send_targets = [&](uint32_t fx) -> uint32_t {    // (the low word of the effect: op, type, target)
       const bool bc = ((fx & 31u) == DEMI_OP_BCAST);
       const uint32_t target = (fx >> 10) & 15u;
       uint32_t tm = bc ? (exists & ~(1u << me)) : ((1u << target) & exists & 0xFFu);
@@ -645,8 +650,9 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
       return tm & ~blocked;
     };
     // event_produced for internal messages (:287-297): dropped at send time when crosses_partition, else appended
-    auto apply_send = [&](uint32_t fx) {
-      const uint32_t type = (fx >> 5) & 31u, p0 = (fx >> 14) & 0xFFu, p1 = (fx >> 22) & 0xFFu;
+    auto apply_send = [&](word_t fxw) {
+      const uint32_t fx = (uint32_t)fxw;
+      const uint32_t type = (fx >> 5) & 31u, p0 = fx_p0(fxw), p1 = fx_p1(fxw);
       if (REC) {
         const bool bc = ((fx & 31u) == DEMI_OP_BCAST);
         const uint32_t target = (fx >> 10) & 15u;
@@ -663,7 +669,7 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
         }
       } else {
         uint32_t tm = send_targets(fx);
-        const uint32_t base = msg_word(type, me, 0, p0, p1);
+        const word_t base = msg_word(type, me, 0, p0, p1);
         while (tm) {
           const uint32_t r = (uint32_t)__builtin_ctz(tm);
           tm &= tm - 1;
@@ -695,7 +701,7 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
         // messages are probed (ascending = arr order), four at a time so that their loads are in flight together (the
         // pending set may live in HBM and the kernel is bound by such dependent round trips: 4.87 -> 4.56 ms per 2^20
         // schedules); slots >= 64 are scanned linearly.
-        const uint32_t wantw = msg_word(type, DEMI_DEADLETTERS, me, 0, 0);
+        const word_t wantw = msg_word(type, DEMI_DEADLETTERS, me, 0, 0);
         bool gone = false;
 #ifndef DEMI_K1_CANCEL_PROBE1
         uint64_t m = tmask;
@@ -704,8 +710,8 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
           const uint32_t q0 = (uint32_t)__builtin_ctzll(m);
           const uint32_t q1 = m1 ? (uint32_t)__builtin_ctzll(m1) : q0, q2 = m2 ? (uint32_t)__builtin_ctzll(m2) : q0,
                          q3 = m3 ? (uint32_t)__builtin_ctzll(m3) : q0;
-          const uint32_t w0 = pend_load(mem, q0), w1 = pend_load(mem, q1), w2 = pend_load(mem, q2), w3 = pend_load(mem, q3);
-          const uint32_t lastw = pend_load(mem, n_pend - 1);
+          const word_t w0 = pend_load(mem, q0), w1 = pend_load(mem, q1), w2 = pend_load(mem, q2), w3 = pend_load(mem, q3);
+          const word_t lastw = pend_load(mem, n_pend - 1);
           const uint32_t hit = (w0 == wantw) ? q0 : (w1 == wantw) ? q1 : (w2 == wantw) ? q2 : (w3 == wantw) ? q3 : 0xFFFFFFFFu;
           if (hit != 0xFFFFFFFFu) { pend_remove(hit, lastw); gone = true; }
           m = m3 & (m3 - 1);
@@ -730,10 +736,11 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
     };
     if (deliver) {      // every effect row in program order
       for (uint32_t k = 0; k < nfx && !(flags & DEMI_OVF_ANY); k++) {
-        const uint32_t fx = mem.fxq[k * 64];
+        const word_t fxw = mem.fxq[k * 64];
+        const uint32_t fx = (uint32_t)fxw;
         const uint32_t op = fx & 31u, type = (fx >> 5) & 31u;
         PH_MARK(9);
-        if (op <= DEMI_OP_BCAST) { apply_send(fx); PH_MARK(6); }
+        if (op <= DEMI_OP_BCAST) { apply_send(fxw); PH_MARK(6); }
         else if (op == DEMI_OP_CRASH) { if (CRASHES) blocked |= 1u << me; }   // actorCrashed (Instrumenter.scala:184-199)
         else if (op == DEMI_OP_TCANCEL) { apply_cancel(type); PH_MARK(7); }
         else { apply_timer_set(op == DEMI_OP_TREP, type); PH_MARK(8); }
@@ -746,7 +753,7 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
     if (ph == PH_FINISH) {
       // explore(): `if (messagesScheduledSoFar <= maxMessages) checkIfBugFound` (:256-262, 156-180)
       if (!(flags & (DEMI_OVF_ANY | DEMI_V_MAXMSG)) && !viol) viol = check_invariant();
-      for (uint32_t a = 0; a < A; a++) hash_step(hash, st[a * 64]);
+      for (uint32_t i = 0; i < A * ST_WORDS; i++) hash_step(hash, st[i * 64]);
       uint4 v;
       if (flags & DEMI_OVF_ANY) {
         v.x = flags & DEMI_OVF_ANY; v.y = 0; v.z = 0; v.w = 0;

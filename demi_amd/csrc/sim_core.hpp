@@ -57,6 +57,7 @@ inline uint32_t op_control(uint32_t op) {   // host side: fills DevModel::optab
   if (op >= DEMI_OP_SEND && op <= DEMI_OP_TCANCEL) return CW_FX;
   if (op == DEMI_OP_CRASH) return CW_FX | CW_HALT;     // recorded as the delivery's last effect, then the rows stop
   if (op == DEMI_OP_RND) return CW_ALU | CW_RND;
+  if (op == DEMI_OP_MOVHI) return CW_ALU;     // wide tables only, and those are never interpreted (jit.hpp emits it)
   if (op >= DEMI_OP_IFEQ && op <= DEMI_OP_IFGT) return CW_IF | (rels[op - DEMI_OP_IFEQ] << CW_REL_SHIFT);
   return CW_HALT;   // unknown ops are rejected by validation
 }
@@ -64,7 +65,7 @@ inline uint32_t op_control(uint32_t op) {   // host side: fills DevModel::optab
 // ------------------------------------------------------------------ workgroup-shared tables
 struct Tables {
   const uint64_t* trace;  // [E] external events, one 8-byte word each
-  const uint64_t* init;   // [8] initial actor states
+  const uint64_t* init;   // [8 * ST_WORDS] initial actor states
   const uint32_t* code;   // [code_len] transition-table rows
   const uint32_t* hs;     // [n_classes * NT] handler starts
   const uint32_t* meta;   // [32] msg_class | timer_idx << 8
@@ -75,8 +76,8 @@ struct Tables {
   uint32_t inv_kind, inv_fa, inv_va, inv_fb, fp_mask;
 };
 
-__host__ __device__ inline size_t tables_lds_bytes(uint32_t code_len, uint32_t n_ev, uint32_t n_hs) {
-  size_t b = (size_t)n_ev * 8 + DEMI_MAX_ACTORS * 8 + (size_t)code_len * 4 + (size_t)n_hs * 4 +
+__host__ __device__ inline size_t tables_lds_bytes(uint32_t code_len, uint32_t n_ev, uint32_t n_hs, bool wide = WIDE_TU) {
+  size_t b = (size_t)n_ev * 8 + DEMI_MAX_ACTORS * 8 * (wide ? 2 : 1) + (size_t)code_len * 4 + (size_t)n_hs * 4 +
              DEMI_MAX_MSG_TYPES * 4 + 132 * 4 + 64 * 4;
   return (b + 15) & ~(size_t)15;
 }
@@ -91,13 +92,14 @@ __device__ inline unsigned char* tables_load(Tables& t, unsigned char* smem, con
   const uint32_t n_hs = gm->n_classes * t.NT;
   uint64_t* s_trace = reinterpret_cast<uint64_t*>(smem);
   uint64_t* s_init = s_trace + n_ev;
-  uint32_t* s_code = reinterpret_cast<uint32_t*>(s_init + DEMI_MAX_ACTORS);
+  uint32_t* s_code = reinterpret_cast<uint32_t*>(s_init + DEMI_MAX_ACTORS * ST_WORDS);
   uint32_t* s_hs = s_code + t.code_len;
   uint32_t* s_meta = s_hs + n_hs;
   uint32_t* s_magic = s_meta + DEMI_MAX_MSG_TYPES;
   uint32_t* s_optab = s_magic + 132;
   for (uint32_t i = threadIdx.x; i < n_ev; i += blockDim.x) s_trace[i] = g_trace[i];
-  for (uint32_t i = threadIdx.x; i < DEMI_MAX_ACTORS; i += blockDim.x) s_init[i] = gm->init_state[i];
+  for (uint32_t i = threadIdx.x; i < DEMI_MAX_ACTORS * ST_WORDS; i += blockDim.x)
+    s_init[i] = WIDE_TU ? gm->init_state_wide[i] : gm->init_state[i];
   for (uint32_t i = threadIdx.x; i < t.code_len; i += blockDim.x) s_code[i] = gm->code[i];
   for (uint32_t i = threadIdx.x; i < n_hs; i += blockDim.x) s_hs[i] = gm->handler_start[i];
   for (uint32_t i = threadIdx.x; i < DEMI_MAX_MSG_TYPES; i += blockDim.x) s_meta[i] = gm->meta[i];
@@ -121,33 +123,37 @@ __device__ inline unsigned char* tables_load(Tables& t, unsigned char* smem, con
 constexpr uint32_t PEND_HOT = DEMI_PEND_HOT;
 
 struct LaneMem {
-  uint64_t* st;        // [A]          actor states (LDS)
-  uint32_t* pend;      // [PEND_HOT]   pending message words (LDS)
+  uint64_t* st;        // [A * ST_WORDS] actor states (LDS)
+  word_t* pend;        // [PEND_HOT]   pending message words (LDS)
   uint32_t* pend_aux;  // [PEND_HOT]   optional parallel array (ids / sequence numbers), may be null
-  uint32_t* fxq;       // [FX_CAP]     effect rows recorded by the current delivery (LDS)
-  uint32_t* spill;     // global: slot s >= PEND_HOT lives at spill[(s - PEND_HOT) * spill_stride]
+  word_t* fxq;         // [FX_CAP]     effect rows recorded by the current delivery (LDS)
+  word_t* spill;       // global: slot s >= PEND_HOT lives at spill[(s - PEND_HOT) * spill_stride]
   uint32_t* spill_aux; // global, parallel to spill (may be null)
   uint32_t spill_stride;
   uint32_t hot;        // slots below `hot` live in LDS (PEND_HOT, or less where occupancy is worth more than residency)
 };
 
-__host__ __device__ inline size_t lane_mem_wave_bytes(uint32_t n_actors, bool aux, uint32_t hot = PEND_HOT) {
-  return (size_t)n_actors * 64 * 8 + (size_t)hot * 64 * 4 * (aux ? 2 : 1) + (size_t)DEMI_FX_CAP * 64 * 4;
+__host__ __device__ inline size_t lane_mem_wave_bytes(uint32_t n_actors, bool aux, uint32_t hot = PEND_HOT, bool wide = WIDE_TU) {
+  const size_t wb = wide ? 8 : 4;     // bytes per message / effect word
+  return (size_t)n_actors * 64 * 8 * (wide ? 2 : 1) + (size_t)hot * 64 * (wb + (aux ? 4 : 0)) + (size_t)DEMI_FX_CAP * 64 * wb;
 }
 // HBM scratch words for `lanes` simulators (per array)
 __host__ __device__ inline size_t spill_words(size_t lanes, uint32_t hot = PEND_HOT) { return lanes * (DEMI_MAX_PENDING - hot); }
 
 __device__ inline LaneMem lane_mem_carve(unsigned char* wave_base, uint32_t n_actors, bool aux, uint32_t lane,
-                                         uint32_t* g_spill, size_t global_lane, size_t total_lanes,
+                                         uint32_t* g_spill_words, size_t global_lane, size_t total_lanes,
                                          uint32_t hot = PEND_HOT) {
+  word_t* const g_spill = reinterpret_cast<word_t*>(g_spill_words);
+  // (the aux arrays behind the message words are 32-bit: only the recording variants have them, and those never run wide)
+  uint32_t* const g_aux = reinterpret_cast<uint32_t*>(g_spill + spill_words(total_lanes, hot));
   LaneMem m;
   m.st = reinterpret_cast<uint64_t*>(wave_base) + lane;
-  uint32_t* p = reinterpret_cast<uint32_t*>(wave_base + (size_t)n_actors * 64 * 8);
-  m.pend = p + lane;
-  p += (size_t)hot * 64;
-  m.pend_aux = aux ? p + lane : nullptr;
-  if (aux) p += (size_t)hot * 64;
-  m.fxq = p + lane;
+  unsigned char* q = wave_base + (size_t)n_actors * ST_WORDS * 64 * 8;
+  m.pend = reinterpret_cast<word_t*>(q) + lane;
+  q += (size_t)hot * 64 * sizeof(word_t);
+  m.pend_aux = aux ? reinterpret_cast<uint32_t*>(q) + lane : nullptr;
+  if (aux) q += (size_t)hot * 64 * 4;
+  m.fxq = reinterpret_cast<word_t*>(q) + lane;
 #ifndef DEMI_SPILL_WAVE_BLOCKS
   // one [slot][lane] matrix over every lane of the launch (slot stride = all lanes): the live part of the pending sets
   // (the low slots of every wave) is one contiguous region.  Measured over 8 processes each: 4.37-4.39 ms per 2^20 every
@@ -155,23 +161,23 @@ __device__ inline LaneMem lane_mem_carve(unsigned char* wave_base, uint32_t n_ac
   // few KB of each block live) is 4.37 ms in some processes and 4.58 ms in others with the same binary, depending on
   // where the allocation happens to lie physically
   m.spill = g_spill + global_lane;
-  m.spill_aux = aux ? g_spill + spill_words(total_lanes, hot) + global_lane : nullptr;
+  m.spill_aux = aux ? g_aux + global_lane : nullptr;
   m.spill_stride = (uint32_t)total_lanes;
 #else
   const size_t block = (global_lane >> 6) * ((size_t)(DEMI_MAX_PENDING - hot) * 64);
   m.spill = g_spill + block + lane;
-  m.spill_aux = aux ? g_spill + spill_words(total_lanes, hot) + block + lane : nullptr;
+  m.spill_aux = aux ? g_aux + block + lane : nullptr;
   m.spill_stride = 64;
 #endif
   m.hot = hot;
   return m;
 }
 
-__device__ __forceinline__ uint32_t pend_load(const LaneMem& m, uint32_t slot) {
+__device__ __forceinline__ word_t pend_load(const LaneMem& m, uint32_t slot) {
   if (slot < m.hot) return m.pend[slot * 64];
   return m.spill[(size_t)(slot - m.hot) * m.spill_stride];
 }
-__device__ __forceinline__ void pend_store(const LaneMem& m, uint32_t slot, uint32_t v) {
+__device__ __forceinline__ void pend_store(const LaneMem& m, uint32_t slot, word_t v) {
   if (slot < m.hot) m.pend[slot * 64] = v;
   else m.spill[(size_t)(slot - m.hot) * m.spill_stride] = v;
 }
@@ -186,9 +192,20 @@ __device__ __forceinline__ void aux_store(const LaneMem& m, uint32_t slot, uint3
 
 // ------------------------------------------------------------------ row interpreter
 // effect word recorded per effect row: op[4:0] | type[9:5] | target[13:10] | p0[21:14] | p1[29:22]
+// wide: the same with p0[29:14] | p1[45:30]
+#ifdef DEMI_WIDE
+__device__ __forceinline__ word_t fx_pack(uint32_t op, uint32_t type, uint32_t target, uint32_t p0, uint32_t p1) {
+  return (word_t)((op & 31u) | (type << 5) | (target << 10)) | ((word_t)(p0 & 0xFFFFu) << 14) | ((word_t)(p1 & 0xFFFFu) << 30);
+}
+__device__ __forceinline__ uint32_t fx_p0(word_t fx) { return (uint32_t)(fx >> 14) & 0xFFFFu; }
+__device__ __forceinline__ uint32_t fx_p1(word_t fx) { return (uint32_t)(fx >> 30) & 0xFFFFu; }
+#else
 __device__ __forceinline__ uint32_t fx_pack(uint32_t op, uint32_t type, uint32_t target, uint32_t p0, uint32_t p1) {
   return (op & 31u) | (type << 5) | (target << 10) | (p0 << 14) | (p1 << 22);
 }
+__device__ __forceinline__ uint32_t fx_p0(uint32_t fx) { return (fx >> 14) & 0xFFu; }
+__device__ __forceinline__ uint32_t fx_p1(uint32_t fx) { return (fx >> 22) & 0xFFu; }
+#endif
 
 // 16 x u8 register window held in four VGPRs: w0,w1 = r0..r7 (state), w2,w3 = r8..r15 (temps, payload,
 // sender, self).  v_perm_b32 extracts / inserts one byte without variable 64-bit shifts.
@@ -211,6 +228,7 @@ __device__ __forceinline__ uint32_t app_next_int(uint64_t& app_rng, uint32_t bou
   return bound == 0 ? 0u : jr_next_int(app_rng, bound, magic);
 }
 
+#ifndef DEMI_WIDE     // the row interpreter exists for the 8-bit window only: a wide table always runs as generated code
 __device__ inline uint32_t vm_run(const Tables& t, const LaneMem& mem, uint32_t w, uint32_t& flags, uint64_t& app_rng) {
   const uint32_t type = w_type(w), me = w_dst(w);
   uint32_t pc = t.hs[((t.ac_packed >> (4 * me)) & 15u) * t.NT + type];
@@ -277,5 +295,6 @@ __device__ inline uint32_t vm_run(const Tables& t, const LaneMem& mem, uint32_t 
   mem.st[me * 64] = (uint64_t)w0 | ((uint64_t)w1 << 32);
   return nfx;
 }
+#endif  // !DEMI_WIDE
 
 }  // namespace demi

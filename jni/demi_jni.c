@@ -43,7 +43,7 @@ JNIEXPORT jlong JNICALL FN(ctxCreate)(JNIEnv* e, jclass c, jint device) {
 JNIEXPORT void JNICALL FN(ctxDestroy)(JNIEnv* e, jclass c, jlong h) { (void)e; (void)c; demi_ctx_destroy(CTX(h)); }
 JNIEXPORT jstring JNICALL FN(lastError)(JNIEnv* e, jclass c, jlong h) { (void)c; return (*e)->NewStringUTF(e, demi_last_error(CTX(h))); }
 
-/* demi_model_load: inv = { inv_kind, inv_fa, inv_va, inv_fb, fp_match_mask } */
+/* demi_model_load: inv = { inv_kind, inv_fa, inv_va, inv_fb, fp_match_mask [, flags (DEMI_MODEL_WIDE)] } */
 JNIEXPORT jint JNICALL FN(modelLoad)(JNIEnv* e, jclass c, jlong h, jint nActors, jbyteArray msgClass, jbyteArray actorClass,
                                      jint nClasses, jshortArray handlerStart, jintArray code, jlongArray initState, jintArray inv) {
   demi_model m;
@@ -55,6 +55,7 @@ JNIEXPORT jint JNICALL FN(modelLoad)(JNIEnv* e, jclass c, jlong h, jint nActors,
   jint* iv = (jint*)PIN(inv);
   m.inv_kind = (uint32_t)iv[0]; m.inv_fa = (uint32_t)iv[1]; m.inv_va = (uint32_t)iv[2]; m.inv_fb = (uint32_t)iv[3];
   m.fp_match_mask = (uint32_t)iv[4];
+  m.flags = (*e)->GetArrayLength(e, inv) > 5 ? (uint32_t)iv[5] : 0u;     /* a wide model: initState holds two words per actor */
   UNPIN(inv, iv, JNI_ABORT);
   m.msg_class = (const uint8_t*)PIN(msgClass);
   m.actor_class = (const uint8_t*)PIN(actorClass);

@@ -31,7 +31,7 @@ class GpuRandomScheduler(val schedulerConfig: SchedulerConfig, max_executions: I
     if (!modelLoaded) {
       val m = lowering.model
       check(h, modelLoad(h, m.nActors, m.msgClass, m.actorClass, m.nClasses, m.handlerStart, m.code, m.initState,
-                         Array(m.invKind, m.invFa, m.invVa, m.invFb, m.fpMatchMask)))
+                         Array(m.invKind, m.invFa, m.invVa, m.invFb, m.fpMatchMask, m.flags)))
       if (max_executions >= (1 << 16)) modelSpecialize(h, true)   // optional: a failure keeps the table interpreter
       modelLoaded = true
     }
@@ -94,7 +94,7 @@ class GpuSTSScheduler(val schedulerConfig: SchedulerConfig, original_trace: Even
   locally {
     val m = lowering.model
     check(h, modelLoad(h, m.nActors, m.msgClass, m.actorClass, m.nClasses, m.handlerStart, m.code, m.initState,
-                       Array(m.invKind, m.invFa, m.invVa, m.invFb, m.fpMatchMask)))
+                       Array(m.invKind, m.invFa, m.invVa, m.invFb, m.fpMatchMask, m.flags)))
     check(h, replayLoad(h, FlatEvents.pack(externals, lowering), recorded))
   }
   def getName = "GpuSTSSchedNoPeek"
@@ -155,7 +155,7 @@ class GpuStsRemovalOracle(schedulerConfig: SchedulerConfig, mcs: Seq[ExternalEve
     if (!modelLoaded) {
       val m = lowering.model
       check(h, modelLoad(h, m.nActors, m.msgClass, m.actorClass, m.nClasses, m.handlerStart, m.code, m.initState,
-                         Array(m.invKind, m.invFa, m.invVa, m.invFb, m.fpMatchMask)))
+                         Array(m.invKind, m.invFa, m.invVa, m.invFb, m.fpMatchMask, m.flags)))
       modelLoaded = true
     }
     if (!(loaded eq trace)) { check(h, replayLoad(h, FlatEvents.pack(mcs, lowering), FlatEvents.packRecorded(trace, lowering))); loaded = trace }
@@ -196,7 +196,7 @@ class GpuDPOR(val schedulerConfig: SchedulerConfig, lowering: TableLowering, dep
            init: Option[() => Any] = None): Option[EventTrace] = {
     val m = lowering.model
     check(h, modelLoad(h, m.nActors, m.msgClass, m.actorClass, m.nClasses, m.handlerStart, m.code, m.initState,
-                       Array(m.invKind, m.invFa, m.invVa, m.invFb, m.fpMatchMask)))
+                       Array(m.invKind, m.invFa, m.invVa, m.invFb, m.fpMatchMask, m.flags)))
     modelSpecialize(h, true)
     check(h, dporLoad(h, FlatEvents.pack(events, lowering)))      // Start / Send / WaitQuiescence only (DPORwHeuristics.scala:692-710)
     val params = Array(depthBound, 0, 1, lowering.fingerprintCode(fp), 64, 4096, 0)

@@ -5,7 +5,12 @@ import akka.dispatch.verification._
 /** The flat arrays of demi_model (include/demi_gpu.h): the application's actors as a transition table. */
 case class FlatModel(nActors: Int, msgClass: Array[Byte], actorClass: Array[Byte], nClasses: Int,
                      handlerStart: Array[Short], code: Array[Int], initState: Array[Long],
-                     invKind: Int, invFa: Int, invVa: Int, invFb: Int, fpMatchMask: Int = 0xFFFFFFFF)
+                     invKind: Int, invFa: Int, invVa: Int, invFb: Int, fpMatchMask: Int = 0xFFFFFFFF,
+                     wide: Boolean = false) {
+  /** demi_model.flags.  wide = DEMI_MODEL_WIDE: 16-bit state fields and payloads (terms / log indices above 255); initState then
+   *  holds two words per actor (F0..F3, F4..F7) and the model runs through GpuRandomScheduler only (include/demi_gpu.h). */
+  def flags: Int = if (wide) 1 else 0
+}
 
 /** What an application supplies next to its MessageFingerprinter (MessageFingerprints.scala:14-32): how its actors,
  *  messages and invariant lower to the table.  The row vocabulary is DEMI_OP_* in include/demi_gpu.h; demi_amd/model.py
@@ -45,6 +50,7 @@ object FlatEvents {
       val o = 8 * i
       out(o) = kind.toByte; out(o + 1) = a.toByte; out(o + 2) = b.toByte; out(o + 3) = t.toByte
       out(o + 4) = p0.toByte; out(o + 5) = p1.toByte
+      out(o + 6) = (p0 >> 8).toByte; out(o + 7) = (p1 >> 8).toByte       // 16-bit payloads: wide models only (else 0)
     }
     out
   }

@@ -6,6 +6,19 @@
 #define DEMI_V_QUEUE_OVF 0x8u
 namespace demi {
 struct Tables { const uint32_t* hs; uint32_t ac_packed, NT; const uint32_t* magic; const uint32_t* gmagic; };
+#ifdef DEMI_WIDE      // a DEMI_MODEL_WIDE table: 64-bit message / effect words, two state words per actor
+typedef uint64_t word_t;
+struct LaneMem { uint64_t* st; word_t* fxq; };
+static inline uint32_t w_type(word_t w) { return (uint32_t)w & 31u; }
+static inline uint32_t w_dst(word_t w) { return ((uint32_t)w >> 5) & 7u; }
+static inline uint32_t w_src(word_t w) { return ((uint32_t)w >> 8) & 15u; }
+static inline uint32_t w_p0(word_t w) { return (uint32_t)w >> 16; }
+static inline uint32_t w_p1(word_t w) { return (uint32_t)(w >> 32) & 0xFFFFu; }
+static inline word_t fx_pack(uint32_t op, uint32_t type, uint32_t target, uint32_t p0, uint32_t p1) {
+  return (word_t)((op & 31u) | (type << 5) | (target << 10)) | ((word_t)(p0 & 0xFFFFu) << 14) | ((word_t)(p1 & 0xFFFFu) << 30);
+}
+#else
+typedef uint32_t word_t;
 struct LaneMem { uint64_t* st; uint32_t* fxq; };
 static inline uint32_t w_type(uint32_t w) { return w & 31u; }
 static inline uint32_t w_dst(uint32_t w) { return (w >> 5) & 7u; }
@@ -15,6 +28,7 @@ static inline uint32_t w_p1(uint32_t w) { return w >> 24; }
 static inline uint32_t fx_pack(uint32_t op, uint32_t type, uint32_t target, uint32_t p0, uint32_t p1) {
   return (op & 31u) | (type << 5) | (target << 10) | (p0 << 14) | (p1 << 22);
 }
+#endif
 static inline int __popc(uint32_t x) { return __builtin_popcount(x); }
 // DEMI_OP_RND: java.util.Random.nextInt(bound) on the application's generator (the device uses multiply-high magics for the
 // modulo; here the plain JDK algorithm - the results must agree)

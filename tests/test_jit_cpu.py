@@ -40,17 +40,19 @@ def test_generated_source_shape():
 
 def _host_vm(model, tmp_path):
     src = _native.specialize_source(model.to_struct())
-    cpp = tmp_path / "vm_host.cpp"
+    wide = getattr(model, "wide", False)
+    cpp = tmp_path / ("vm_host_wide.cpp" if wide else "vm_host.cpp")
     cpp.write_text('#include "%s"\n%s\nstatic uint64_t g_app = 0x5DEECE66DULL;   // Instrumenter().seededRandom: seed 0\n'
                    'extern "C" void app_reset() { g_app = 0x5DEECE66DULL; }\n'
                    'extern "C" uint32_t run(const uint32_t* hs, uint32_t ac, uint32_t nt, uint64_t* st, '
-                   'uint32_t* fxq, uint32_t w, uint32_t* flags) {\n  demi::Tables t{hs, ac, nt, nullptr}; demi::LaneMem m{st, fxq};\n'
+                   'demi::word_t* fxq, demi::word_t w, uint32_t* flags) {\n  demi::Tables t{hs, ac, nt, nullptr}; demi::LaneMem m{st, fxq};\n'
                    '  uint32_t f = *flags; uint32_t n = demi::vm_run_jit(t, m, w, f, g_app); *flags = f; return n; }\n'
                    % (os.path.join(ROOT, "tests", "jit_host_shim.hpp"), src))
-    so = tmp_path / "vm_host.so"
-    subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-label", "-o", str(so), str(cpp)])
+    so = tmp_path / ("vm_host_wide.so" if wide else "vm_host.so")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-label"] + (["-DDEMI_WIDE"] if wide else []) +
+                          ["-o", str(so), str(cpp)])
     L = C.CDLL(str(so))
-    L.run.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+    L.run.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64 if wide else C.c_uint32, C.POINTER(C.c_uint32)]
     L.run.restype = C.c_uint32
     L.app_rng = C.c_uint64(0x5DEECE66D)          # the oracle's copy of the application generator (seed 0), advanced in step
     return L
@@ -263,3 +265,84 @@ def test_if_conversion_knob_converts_short_guarded_alu_runs(oracle, tmp_path, mo
         want = C.c_uint64(state)
         wn = oracle.lib().orc_vm_run(C.byref(ms), 0, C.byref(want), 0, T.DEADLETTERS, p0, p1, 3, fx, 64, C.byref(L.app_rng))
         assert int(st[0]) == want.value and n == wn
+
+
+def _random_handler_wide(rng, n_rows, n_types):
+    """_random_handler plus 16-bit constants (LDI16 / MOVHI): a wide table's rows."""
+    a = _random_handler(rng, n_rows, n_types, few_effects=True)
+    b = M.Asm()
+    regs = [M.Reg(i) for i in range(12)]
+    for _ in range(int(rng.integers(1, 4))):
+        b.ldi16(regs[int(rng.integers(12))], int(rng.integers(0, 65536)))
+    b.movhi(regs[int(rng.integers(12))], M.Reg(int(rng.integers(16))), int(rng.integers(256)))
+    b.rows += a.rows
+    b._fix = [(i + len(b.rows) - len(a.rows), lab) for i, lab in a._fix]
+    b._labels = {k: v + len(b.rows) - len(a.rows) for k, v in a._labels.items()}
+    return b
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_wide_tables_through_the_code_generator(oracle, tmp_path, seed):
+    """DEMI_MODEL_WIDE: the generated handlers over the 16 x u16 window (masks, shifts by b & 15, 16-bit POPC, MOVHI, state in
+    two words, 64-bit message / effect words) equal the oracle's wide row interpreter on random rows and on the raft lowered
+    with terms above 255; the kernel source compiles for gfx950."""
+    rng = np.random.default_rng(seed)
+    if seed == 1:
+        model = M.raft_model(5, term0=1000, loglen0=300)
+        A, NT = 5, model.n_msg_types
+    else:
+        MSGS = [("E", T.MSG_EXTERNAL), ("A", T.MSG_INTERNAL), ("B", T.MSG_INTERNAL), ("Tm", T.MSG_TIMER)]
+        h = {(0, name): _random_handler_wide(rng, int(rng.integers(4, 40)), len(MSGS)) for name, _ in MSGS}
+        A, NT = 4, len(MSGS)
+        model = M.build_model("rand_wide%d" % seed, A, MSGS, h, [[0] * 8] * A, (T.INV_NEVER, 0, 60000, 0), wide=True)
+    assert oracle.model_validate(model)[0] == 0
+    try:
+        size, kernel = _native.specialize_check(model.to_struct())
+        assert size > 10000 and "k1_random_explore" in kernel
+    except _native.DemiError as e:
+        if "hiprtc not found" not in str(e):
+            raise
+    L = _host_vm(model, tmp_path)
+    ms = model.to_struct()
+    hs = np.full(T.MAX_CLASSES * T.MAX_MSG_TYPES, 0xFFFF, dtype=np.uint32)
+    hs[:len(model.handler_start)] = model.handler_start
+    st = np.zeros(16 * 64, dtype=np.uint64)
+    fxq = np.zeros(FX_CAP * 64, dtype=np.uint64)
+    fx = (Effect * 64)()
+    want_state = (C.c_uint64 * 2)()
+    seen_fx = seen_big = 0
+    for it in range(6000):
+        me, typ = int(rng.integers(A)), int(rng.integers(NT))
+        src = int(rng.choice([int(rng.integers(A)), T.DEADLETTERS]))
+        hi = 65536 if it % 2 else 1200
+        p0, p1 = int(rng.integers(hi)), int(rng.integers(hi))
+        fields = [int(x) for x in rng.integers(0, hi, 8)]
+        if seed == 1:
+            fields[0], fields[2] = int(rng.integers(3)), int(rng.choice([M.NOBODY, int(rng.integers(A))]))
+        w0, w1 = M.pack_state_wide(fields)
+        st[(2 * me) * 64], st[(2 * me + 1) * 64] = w0, w1
+        w = typ | (me << 5) | (src << 8) | (p0 << 16) | (p1 << 32)
+        flags = C.c_uint32(0)
+        n = L.run(hs.ctypes.data, 0, NT, st.ctypes.data, fxq.ctypes.data, w, C.byref(flags))
+        want_state[0], want_state[1] = w0, w1
+        wn = oracle.lib().orc_vm_run(C.byref(ms), me, want_state, typ, src, p0, p1, (1 << A) - 1, fx, 64, C.byref(L.app_rng))
+        if wn < 0:
+            assert flags.value & T.V_QUEUE_OVF
+            continue
+        assert not flags.value
+        assert (int(st[(2 * me) * 64]), int(st[(2 * me + 1) * 64])) == (want_state[0], want_state[1]), (it, me, typ, fields)
+        got = []
+        for k in range(n):
+            f = int(fxq[k * 64])
+            op, t_, target, q0, q1 = f & 31, (f >> 5) & 31, (f >> 10) & 15, (f >> 14) & 0xFFFF, (f >> 30) & 0xFFFF
+            if op == M.OPS["SEND"]:
+                if target < A:
+                    got.append((0, target, t_, q0, q1))
+            elif op == M.OPS["BCAST"]:
+                got += [(0, r, t_, q0, q1) for r in range(A) if r != me]
+            else:
+                got.append((1 + op - M.OPS["TSET"], me, t_, 0, 0))
+        assert got == [(e.kind, e.target, e.msg_type, e.p0, e.p1) for e in fx[:wn]], (it, me, typ)
+        seen_fx += len(got)
+        seen_big += any(v > 255 for v in (int(st[(2 * me) * 64]) >> 16 & 0xFFFF, *[g[3] for g in got]))
+    assert seen_fx > 200 and seen_big > 100
