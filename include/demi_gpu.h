@@ -13,6 +13,10 @@
  * Conventions: plain C, caller-allocated buffers, `int` return (0 = ok, <0 = demi_status),
  * no callbacks into the host from device code (the transition function and the invariant are
  * data, not closures), one ctx per host thread, the ctx owns its device memory.
+ * The *_dev entry points enqueue on the caller's stream and return without synchronising; a ctx runs ONE launch at a
+ * time (its work counter and scratch are shared): a launch on a different stream than the ctx's previous one waits for
+ * that one on the device, and demi_model_load / demi_trace_load / demi_replay_load wait for the last launch before they
+ * replace what the kernels read.  Concurrent launches need one ctx each.
  * Pointers named d_* are DEVICE pointers; all others are host pointers.
  */
 #ifndef DEMI_GPU_H

@@ -418,3 +418,30 @@ def test_random_programs_interpreter_specialised_and_oracle_agree(gpu_ctx, oracl
     assert len(np.unique(g["hash"])) > 900
     gf, cf = both(gpu_ctx, oracle, model, events_to_array(ev), 2000, _fifo(T.Limits(60, 0, 20, 0, 0, 0)), jit=True)
     assert_same(gf, cf)
+
+
+def test_launches_of_one_ctx_on_two_streams_are_ordered(oracle):
+    """The *_dev entry points do not synchronise and a ctx's launches share its work counter and scratch: launches that
+    alternate between two streams must still each evaluate exactly their own schedules (include/demi_gpu.h: a launch on
+    another stream waits for the ctx's previous one), and a trace (re)load waits for the launch in flight."""
+    import ctypes as C
+    import torch
+    from demi_amd import _native
+    model, events, lim = raft5_config2()
+    ctx = _native.Context(0)
+    try:
+        ctx.model_load(model.to_struct())
+        ctx.trace_load(events)
+        ctx.model_specialize()
+        n, k = 1 << 17, 6
+        want = [ctx.random_explore(n, lim, seed_base=SEED_BASE + j * n) for j in range(k)]
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        outs = [torch.zeros((n, 2), dtype=torch.int64, device="cuda") for _ in range(k)]
+        for j in range(k):
+            ctx.random_explore_dev(n, lim, outs[j].data_ptr(), seed_base=SEED_BASE + j * n, stream=C.c_void_p(streams[j % 2].cuda_stream))
+        ctx.trace_load(events[:10])                 # must not disturb the launches in flight
+        torch.cuda.synchronize()
+        for j in range(k):
+            assert_same(outs[j].cpu().numpy().view(T.VERDICT_DTYPE).reshape(-1), want[j])
+    finally:
+        ctx.close()
