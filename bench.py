@@ -433,13 +433,17 @@ def main():
         except Exception as e:
             print("bench: device probe failed: %s" % e, file=sys.stderr)
         # rocprofv3 counters of THIS kernel build on this workload (tools/profile_k1.sh writes profiles/k1_counters.json with
-        # the duration it saw): used only when that duration is within 10 % of this run's, i.e. the same kernel
+        # the duration it saw): used only for the SAME kernel build - the profile records the code object's identity
+        # (demi_model_code_id); a profile without one is accepted when its duration is within 10 % of this run's.  A process
+        # traced by rocprofv3 runs this kernel ~10 % slower than an untraced one, so durations alone do not identify it.
         traffic, issue, stale = None, None, None
+        code_id = "%016x" % ctx.code_id() if specialized else None
         if os.path.exists(K1_COUNTERS) and specialized and args.strategy == "random" and n == N_PER_GPU:
             with open(K1_COUNTERS) as f:
                 ctr = json.load(f)
             pms = float(ctr.get("kernel_ms", 0.0))
-            if pms > 0 and abs(pms - kernel_ms) / pms <= 0.10:
+            same = (ctr["code_id"] == code_id) if ctr.get("code_id") else (pms > 0 and abs(pms - kernel_ms) / pms <= 0.10)
+            if same:
                 traffic = ctr.get("fabric_bytes_per_launch")
                 if probe and "SQ_INSTS_VALU" in ctr:
                     props = torch.cuda.get_device_properties(dev)
@@ -459,7 +463,7 @@ def main():
                              "of the kernel's duration that issuing its instructions takes lies between the straight-line and "
                              "the branchy figure" % pms}
             else:
-                stale = "profiles/k1_counters.json describes a %.3f ms kernel, this run measured %.3f ms: counters not quoted" % (pms, kernel_ms)
+                stale = "profiles/k1_counters.json describes another kernel build (code id %s, %.3f ms there; this run: %s, %.3f ms): counters not quoted" % (ctr.get("code_id"), pms, code_id, kernel_ms)
         out = {
             "metric": "candidate schedules evaluated/sec on Raft-5 fuzz (RandomScheduler executions)",
             "value": value, "unit": "schedules/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -484,7 +488,7 @@ def main():
                                  "HBM; FETCH_SIZE x 2 + WRITE_SIZE as calibrated in profiles/), dominated by the pending sets the "
                                  "specialised build keeps in a [slot][lane] scratch instead of LDS (24 waves per CU): a measured trade, "
                                  "DESIGN.md section 4 K1; that working set (~47 MB) fits the 256 MiB Infinity Cache",
-                                 {"issue_model": issue, "probe": probe, "counters_stale": stale}),
+                                 {"issue_model": issue, "probe": probe, "counters_stale": stale, "kernel_code_id": code_id}),
         }
         if not args.no_cpu_baseline and world == 1:
             from oracle import oracle_py as O

@@ -244,6 +244,9 @@ int demi_model_load(demi_ctx* ctx, const demi_model* model);
  * drops the specialisation of the previous model.                                                         */
 int demi_model_specialize(demi_ctx* ctx, int enable);
 int demi_model_is_specialized(const demi_ctx* ctx);
+/* Identity of the compiled RandomScheduler kernel of the loaded model: a 64-bit hash of its code object, 0 when the table is
+ * interpreted.  Measurement aid: bench.py quotes hardware counters from profiles/ only for the build they were taken on. */
+uint64_t demi_model_code_id(const demi_ctx* ctx);
 /* Device-free check of the same code generation + compilation (build / CI): code-object size in bytes, or the
  * (negative) demi_status with the reason in `log`.                                                         */
 long demi_specialize_check(const demi_model* model, char* log, size_t log_cap);

@@ -445,3 +445,23 @@ def test_launches_of_one_ctx_on_two_streams_are_ordered(oracle):
             assert_same(outs[j].cpu().numpy().view(T.VERDICT_DTYPE).reshape(-1), want[j])
     finally:
         ctx.close()
+
+
+def test_code_id_names_the_compiled_kernel(oracle):
+    """demi_model_code_id: 0 while the table is interpreted, the same value for the same table in two contexts, another one
+    for another table (bench.py quotes hardware counters only for the build they were taken on)."""
+    from demi_amd import _native
+    model, events, lim = raft5_config2()
+    ids = []
+    for m in (model, model, M.raft_model(3)):
+        ctx = _native.Context(0)
+        try:
+            ctx.model_load(m.to_struct())
+            assert ctx.code_id() == 0
+            ctx.model_specialize()
+            ids.append(ctx.code_id())
+            ctx.model_specialize(False)
+            assert ctx.code_id() == 0
+        finally:
+            ctx.close()
+    assert ids[0] != 0 and ids[0] == ids[1] and ids[2] not in (0, ids[0])

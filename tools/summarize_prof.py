@@ -41,6 +41,18 @@ if cur:
         k1["launches_profiled"] = len(rows)
         lines += ["# K1 launches in trace order: all %d avg %.4f ms; the timed ones (last %d) avg %.4f ms" %
                   (len(rows), k1["kernel_ms_all_launches"], len(tail), k1["kernel_ms"]), ""]
+# the bench line of the traced run itself: the kernel's identity (demi_model_code_id) and its duration by bench.py's own HIP
+# events, which agrees with the trace - a traced process runs this kernel slower than an untraced one
+try:
+    for line in open(os.path.join(out_dir, "%s_prof_stats.log" % tag)):
+        if line.startswith('{"metric"'):
+            rl = json.loads(line)["roofline"]
+            k1["code_id"] = rl.get("kernel_code_id")
+            k1["kernel_ms_by_bench_events_in_the_traced_run"] = rl.get("kernel_ms")
+            lines += ["# the same traced run timed by bench.py's HIP events: %.4f ms per launch; kernel code id %s" %
+                      (rl.get("kernel_ms"), rl.get("kernel_code_id")), ""]
+except OSError:
+    pass
 for d in ("prof_fetch", "prof_write", "prof_sq", "prof_sq2"):
     cur = db_of(d)
     if not cur:
