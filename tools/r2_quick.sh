@@ -1,12 +1,21 @@
 #!/bin/bash
-# Optimisation level of the specialised K1 (each twice, own process), and the wide raft on the bench trace
+# Code-layout / scheduling options of the specialised K1 on top of -Os (one process each)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 mkdir -p gpurun_out
-run() {  # name, bench args..., -- flags
+run() {  # name, flags...
   name=$1; shift
-  timeout 300 python bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-secondary $BARGS 2>gpurun_out/r2_q_$name.err | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$name', 'kernel_ms', round(d['roofline']['kernel_ms'],3), 'value %.4g' % d['value'], 'clock', round(d['roofline']['probe']['shader_clock_ghz'],3), d['config'].get('wide_register_window'))"
+  DEMI_JIT_FLAGS="$*" timeout 300 python bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-secondary 2>gpurun_out/r2_q_$name.err | python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('$name', 'kernel_ms', round(r['kernel_ms'],3), 'value %.4g' % d['value'])" || tail -2 gpurun_out/r2_q_$name.err
 }
-for f in -Oz -O2 -O1; do DEMI_JIT_FLAGS=$f run ${f}_1; DEMI_JIT_FLAGS=$f run ${f}_2; done
-DEMI_K1_VERBOSE=1 BARGS="--wide-term0 1000" run wide1; BARGS="--wide-term0 1000" run wide2
-grep -m1 "k1 launch" gpurun_out/r2_q_wide1.err
+run base
+run wavepri -mllvm -amdgpu-set-wave-priority
+run noloopalign -mllvm -amdgpu-disable-loop-alignment
+run exttsp -mllvm -enable-ext-tsp-block-placement
+run align5 -mllvm -align-all-nofallthru-blocks=5
+run align6 -mllvm -align-all-nofallthru-blocks=6
+run notaildup -mllvm -disable-tail-duplicate
+run noplacement -mllvm -disable-block-placement
+run bias100 -mllvm -amdgpu-schedule-metric-bias=100
+run maxilp -mllvm -amdgpu-sched-strategy=max-ilp
+run maxmem -mllvm -amdgpu-sched-strategy=max-memory-clause
+run nobranchfold -mllvm -disable-branch-fold
