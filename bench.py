@@ -490,6 +490,27 @@ def main():
                                  "DESIGN.md section 4 K1; that working set (~47 MB) fits the 256 MiB Infinity Cache",
                                  {"issue_model": issue, "probe": probe, "counters_stale": stale, "kernel_code_id": code_id}),
         }
+        if world == 1:
+            # what a JVM host sees through demi_random_explore (caller's pageable host buffer for the verdicts): the same
+            # launch plus the copy over PCIe.  Never `value` (inputs / outputs resident in HBM); reported beside it.
+            try:
+                hv = np.zeros(n, dtype=T.VERDICT_DTYPE)
+                hv["hash"] = 1                        # (pages touched: the caller's buffer exists before the call)
+
+                def host_call():
+                    rc = _native.lib().demi_random_explore(ctx._h, C.c_uint64(SEED_BASE + index_base), None, n, C.byref(limits), hv.ctypes.data)
+                    assert rc == 0
+                host_call()
+                th = time.perf_counter()
+                for _ in range(3):
+                    host_call()
+                th = (time.perf_counter() - th) / 3
+                out["pcie_inclusive"] = {"entry_point": "demi_random_explore (16 B verdict per schedule into a pageable host buffer, "
+                                                        "through two pinned staging buffers)",
+                                         "ms_per_step": th * 1e3, "value": n / th, "unit": "schedules/s",
+                                         "same_verdicts_as_the_resident_path": bool((hv == verdicts.cpu().numpy().view(T.VERDICT_DTYPE).reshape(-1)).all())}
+            except Exception as e:           # never let a side measurement break the bench line
+                print("bench: host-buffer measurement unavailable: %s" % e, file=sys.stderr)
         if not args.no_cpu_baseline and world == 1:
             from oracle import oracle_py as O
             cores = os.cpu_count() or 1

@@ -1,21 +1,11 @@
 #!/bin/bash
-# Code-layout / scheduling options of the specialised K1 on top of -Os (one process each)
+# Host-buffer path (demi_random_explore / demi_replay_batch) with and without the pinned staging buffers; the tests that use it
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 mkdir -p gpurun_out
-run() {  # name, flags...
-  name=$1; shift
-  DEMI_JIT_FLAGS="$*" timeout 300 python bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-secondary 2>gpurun_out/r2_q_$name.err | python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('$name', 'kernel_ms', round(r['kernel_ms'],3), 'value %.4g' % d['value'])" || tail -2 gpurun_out/r2_q_$name.err
-}
-run base
-run wavepri -mllvm -amdgpu-set-wave-priority
-run noloopalign -mllvm -amdgpu-disable-loop-alignment
-run exttsp -mllvm -enable-ext-tsp-block-placement
-run align5 -mllvm -align-all-nofallthru-blocks=5
-run align6 -mllvm -align-all-nofallthru-blocks=6
-run notaildup -mllvm -disable-tail-duplicate
-run noplacement -mllvm -disable-block-placement
-run bias100 -mllvm -amdgpu-schedule-metric-bias=100
-run maxilp -mllvm -amdgpu-sched-strategy=max-ilp
-run maxmem -mllvm -amdgpu-sched-strategy=max-memory-clause
-run nobranchfold -mllvm -disable-branch-fold
+for v in staged plain; do
+  if [ $v = plain ]; then export DEMI_NO_STAGED_COPY=1; fi
+  timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary 2>gpurun_out/r2_q_$v.err | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$v', 'kernel_ms', round(d['roofline']['kernel_ms'],3), 'value %.4g' % d['value'], d.get('pcie_inclusive'))"
+done
+unset DEMI_NO_STAGED_COPY
+timeout 600 python -m pytest tests/test_k1_gpu.py tests/test_k2_gpu.py -x -q --timeout 300 2>&1 | grep -E "passed|failed|rror" | tail -3
