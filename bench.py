@@ -505,8 +505,7 @@ def main():
                 for _ in range(3):
                     host_call()
                 th = (time.perf_counter() - th) / 3
-                out["pcie_inclusive"] = {"entry_point": "demi_random_explore (16 B verdict per schedule into a pageable host buffer, "
-                                                        "through two pinned staging buffers)",
+                out["pcie_inclusive"] = {"entry_point": "demi_random_explore (16 B verdict per schedule copied into a pageable host buffer)",
                                          "ms_per_step": th * 1e3, "value": n / th, "unit": "schedules/s",
                                          "same_verdicts_as_the_resident_path": bool((hv == verdicts.cpu().numpy().view(T.VERDICT_DTYPE).reshape(-1)).all())}
             except Exception as e:           # never let a side measurement break the bench line
