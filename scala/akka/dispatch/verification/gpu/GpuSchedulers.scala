@@ -32,7 +32,8 @@ class GpuRandomScheduler(val schedulerConfig: SchedulerConfig, max_executions: I
       val m = lowering.model
       check(h, modelLoad(h, m.nActors, m.msgClass, m.actorClass, m.nClasses, m.handlerStart, m.code, m.initState,
                          Array(m.invKind, m.invFa, m.invVa, m.invFb, m.fpMatchMask, m.flags)))
-      if (max_executions >= (1 << 16)) modelSpecialize(h, true)   // optional: a failure keeps the table interpreter
+      if (m.wide) check(h, modelSpecialize(h, true))             // a wide table runs only as compiled code
+      else if (max_executions >= (1 << 16)) modelSpecialize(h, true)   // optional: a failure keeps the table interpreter
       modelLoaded = true
     }
     check(h, traceLoad(h, FlatEvents.pack(trace, lowering)))

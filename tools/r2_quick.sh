@@ -1,11 +1,9 @@
 #!/bin/bash
-# Host-buffer path (demi_random_explore / demi_replay_batch) with and without the pinned staging buffers; the tests that use it
+# -Os for the specialised K2 / K3 as well? (K1 gained 8 % from it)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 mkdir -p gpurun_out
-for v in staged plain; do
-  if [ $v = plain ]; then export DEMI_NO_STAGED_COPY=1; fi
-  timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary 2>gpurun_out/r2_q_$v.err | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$v', 'kernel_ms', round(d['roofline']['kernel_ms'],3), 'value %.4g' % d['value'], d.get('pcie_inclusive'))"
+for v in O3 Os O2; do
+  DEMI_JIT_FLAGS=-$v timeout 300 python bench.py --workload ddmin --no-cpu-baseline 2>gpurun_out/r2_q_dd_$v.err | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('ddmin $v', {k: round(v['kernel_us']) for k,v in d['frontiers'].items()}, 'value %.4g' % d['value'])"
+  DEMI_JIT_FLAGS=-$v timeout 300 python bench.py --workload dpor --no-cpu-baseline 2>gpurun_out/r2_q_dp_$v.err | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('dpor $v', {k: (round(v['value']), round(v['kernel_ms_total'],1)) for k,v in d['orders'].items()})"
 done
-unset DEMI_NO_STAGED_COPY
-timeout 600 python -m pytest tests/test_k1_gpu.py tests/test_k2_gpu.py -x -q --timeout 300 2>&1 | grep -E "passed|failed|rror" | tail -3
