@@ -1,9 +1,13 @@
 #!/bin/bash
-# -Os for the specialised K2 / K3 as well? (K1 gained 8 % from it)
+# The evidence run with the traced process on the same compiler as the bench, then the bench lines; and K1 under the system's
+# ROCm 7.2 compiler (what a host without PyTorch gets) at three optimisation levels
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 mkdir -p gpurun_out
-for v in O3 Os O2; do
-  DEMI_JIT_FLAGS=-$v timeout 300 python bench.py --workload ddmin --no-cpu-baseline 2>gpurun_out/r2_q_dd_$v.err | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('ddmin $v', {k: round(v['kernel_us']) for k,v in d['frontiers'].items()}, 'value %.4g' % d['value'])"
-  DEMI_JIT_FLAGS=-$v timeout 300 python bench.py --workload dpor --no-cpu-baseline 2>gpurun_out/r2_q_dp_$v.err | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('dpor $v', {k: (round(v['value']), round(v['kernel_ms_total'],1)) for k,v in d['orders'].items()})"
+timeout 1500 bash tools/profile_r2.sh all > gpurun_out/r02_profile.log 2>&1; tail -3 gpurun_out/r02_profile.log
+grep -h "the same traced run\|timed ones" gpurun_out/r02_k1.txt
+cp gpurun_out/r02_k1_counters.json profiles/k1_counters.json
+bash tools/r2_extra_lines.sh
+for f in Os O3 O2; do
+  LD_PRELOAD=/opt/rocm/lib/libamd_comgr.so.3 DEMI_JIT_FLAGS=-$f timeout 300 python bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-secondary 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('llvm22 $f', 'kernel_ms', round(r['kernel_ms'],3), 'value %.4g' % d['value'], r['kernel_code_id'])"
 done
