@@ -1,13 +1,34 @@
 #!/bin/bash
-# The evidence run with the traced process on the same compiler as the bench, then the bench lines; and K1 under the system's
-# ROCm 7.2 compiler (what a host without PyTorch gets) at three optimisation levels
+# Issue counters of the K2 (ddmin) and K3 (dpor) kernels: instructions per launch, active lanes per VALU instruction
+export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
-cd $R
-mkdir -p gpurun_out
-timeout 1500 bash tools/profile_r2.sh all > gpurun_out/r02_profile.log 2>&1; tail -3 gpurun_out/r02_profile.log
-grep -h "the same traced run\|timed ones" gpurun_out/r02_k1.txt
-cp gpurun_out/r02_k1_counters.json profiles/k1_counters.json
-bash tools/r2_extra_lines.sh
-for f in Os O3 O2; do
-  LD_PRELOAD=/opt/rocm/lib/libamd_comgr.so.3 DEMI_JIT_FLAGS=-$f timeout 300 python bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-secondary 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('llvm22 $f', 'kernel_ms', round(r['kernel_ms'],3), 'value %.4g' % d['value'], r['kernel_code_id'])"
+OUT=$R/gpurun_out
+P=/tmp/prof23
+rm -rf $P; mkdir -p $OUT $P
+cd /tmp
+COMGR=$(python -c "import torch, os; print(os.path.join(os.path.dirname(torch.__file__), 'lib', 'libamd_comgr.so'))")
+for w in ddmin dpor; do
+  rocprofv3 --preload $COMGR --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE -d $P/$w -o c -- python $R/bench.py --workload $w --no-cpu-baseline > $OUT/r02_pmc_$w.log 2>&1
 done
+python - <<'PY'
+import glob, sqlite3, os
+for w in ("ddmin", "dpor"):
+    dbs = glob.glob("/tmp/prof23/%s/*.db" % w)
+    if not dbs:
+        print(w, "no db"); continue
+    cur = sqlite3.connect(dbs[0]).cursor()
+    q = ("select kernel_name, counter_name, count(*), avg(value), sum(value) from counters_collection "
+         "where kernel_name like '%demi%' group by kernel_name, counter_name")
+    rows = {}
+    for kn, cn, cnt, avg, tot in cur.execute(q):
+        rows.setdefault(kn, {})[cn] = (cnt, avg, tot)
+    lines = ["# python bench.py --workload %s --no-cpu-baseline under rocprofv3 --pmc: per kernel, dispatches, average and total per counter" % w]
+    for kn, cs in rows.items():
+        lines.append(kn[:100])
+        for cn, (cnt, avg, tot) in sorted(cs.items()):
+            lines.append("    %-24s %6d dispatches  avg %16.1f  total %18.1f" % (cn, cnt, avg, tot))
+        if "SQ_INSTS_VALU" in cs and "SQ_THREAD_CYCLES_VALU" in cs and cs["SQ_INSTS_VALU"][2]:
+            lines.append("    active lanes per VALU instruction: %.1f" % (cs["SQ_THREAD_CYCLES_VALU"][2] / cs["SQ_INSTS_VALU"][2]))
+    open(os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "gpurun_out", "r02_%s_counters.txt" % w), "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines[:40]))
+PY
