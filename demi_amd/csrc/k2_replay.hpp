@@ -7,7 +7,8 @@
 //
 // lane = candidate subsequence of the external events (a 256-bit mask).  The recorded original
 // execution is lowered once on the host to a flat array of "expected" events (8 bytes each) that
-// every lane walks with its own cursor; the per-candidate projection is evaluated on the fly:
+// the lanes of a wave walk together, one event per step (the lock-step loop; DEMI_K2_LOCKSTEP=0 selects the older loop with a
+// cursor per lane); the per-candidate projection is evaluated on the fly:
 //   * a recorded Spawn/Kill/Partition/UnPartition is kept iff it equals (by name) the head of the
 //     candidate's remaining non-Send externals, and dropped once those are exhausted;
 //   * an external MsgSend, and the MsgEvent with the same id, are kept iff their Send is in the mask;
@@ -68,6 +69,7 @@ struct K2Args {
   uint32_t fp_hash_mask;
   uint32_t n_fp;            // word ids 0 .. n_fp - 1
   uint8_t* fp_counts;       // K2_FP_HBM: [n_fp][resident lanes] counters
+  uint32_t lockstep;        // 1: the lanes of a wave walk the expected events together (k2 lock-step loop below)
 };
 
 constexpr int K2_WAVES = 4;
@@ -214,6 +216,207 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
     tq |= (uint64_t)((rcv << 5) | type) << (8 * n_tq);
     n_tq++;
   };
+
+  // ------------------------------------------------------------ lock-step walk
+  // Every lane of the wave looks at the SAME expected event in every step.  With a cursor per lane (the loop further
+  // down) a lane whose candidate lost an ancestor of the next recorded deliveries skips a run of events while the lanes
+  // that found theirs wait: 3.6 of 64 lanes active per VALU instruction on 2^20 random candidates, 1.65 M wave
+  // instructions per 64 candidates (profiles/r02_ddmin_counters.txt).  In lock step the event is decoded once per wave
+  // (scalar), the cheap "does it apply to my candidate" test runs full-width, and when some lane delivers, all of them
+  // deliver the same message to the same receiver: one handler per step instead of up to eight.  A wave takes
+  // lanes_per_wave candidates, walks the trace once, writes their verdicts and claims the next batch.  Per lane the
+  // sequence of operations is exactly the one of the per-lane loop (same verdicts, kept marks and flags; the GPU suite runs
+  // every K2 test in all three counter modes on it).  Measured on the ddmin record: 2^20 candidates 61.5 -> 10.8 ms,
+  // 65 536: 7.2 -> 1.8 ms, 4 096: 1.33 -> 1.20 ms, 256: 0.81 -> 0.72 ms.
+  if (args.lockstep) {
+    for (;;) {
+      uint64_t base = 0;
+      if (lane == 0) base = atomicAdd(args.work_counter, (unsigned long long)args.lanes_per_wave);
+      base = __shfl(base, 0);
+      if (base >= args.n) break;
+      sched = base + lane;
+      const bool mine = lane < args.lanes_per_wave && sched < args.n;
+      active = mine;                                   // still replaying (no capacity abort so far)
+      if (mine) {
+        if (args.masks) {
+          const uint64_t* mk = args.masks + sched * 4;
+          m0 = mk[0]; m1 = mk[1]; m2 = mk[2]; m3 = mk[3];
+        } else {
+          m0 = m1 = m2 = m3 = ~0ull;
+        }
+        skip = args.skip ? args.skip[sched] : 0xFFFFFFFFu;
+        hash = 0xCBF29CE484222325ULL;
+        app_rng = jr_seed(0);
+        net.inaccessible = exists; net.killed = 0; net.partitioned = 0;
+        for (uint32_t a = 0; a < A; a++) st[a * 64] = t.init[a];
+        if (FP) for (uint32_t f = 0; f < args.n_fp; f++) cnt[(size_t)f * cnt_stride] = 0;
+        cur = 0; n_pend = 0; count = 0; ignored = 0; flags = 0; rep = 0; tq = 0; n_tq = 0; blocked = 0;
+        fk_part = 0; fk_pruned0 = 0; fk_pruned1 = 0;
+        cur_skip();
+      }
+      for (idx = 1; idx <= NX; idx++) {                // (idx - 1 is the event's index, as in the per-lane loop)
+        if (__ballot(active) == 0) break;
+        const uint64_t ev = expected[idx - 1];
+        // the event is the same for every lane: keep it in scalar registers, so that its kind, the handler it selects
+        // and the receiver are wave-uniform for the compiler too
+        const uint64_t e = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ev) |
+                           ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(ev >> 32)) << 32);
+        const uint32_t kind = (uint32_t)e & 0xFF, a = (uint32_t)(e >> 8) & 0xFF, b = (uint32_t)(e >> 16) & 0xFF;
+        const uint32_t ext = (uint32_t)(e >> 48) & 0xFF;
+        if (kind <= DEMI_REC_UNPARTITION) {
+          if (active && cur < NE) {
+            const uint64_t x = t.trace[cur];
+            const uint32_t xk = (uint32_t)x & 0xFF, xa = (uint32_t)(x >> 8) & 0xFF, xb = (uint32_t)(x >> 16) & 0xFF;
+            const bool two = kind >= DEMI_REC_PARTITION;
+            const uint32_t want_kind = (kind == DEMI_REC_SPAWN) ? DEMI_EV_START : (kind == DEMI_REC_KILL) ? DEMI_EV_KILL
+                                     : (kind == DEMI_REC_PARTITION) ? DEMI_EV_PARTITION : DEMI_EV_UNPARTITION;
+            if (xk == want_kind && xa == a && (!two || xb == b)) {
+              cur++;
+              cur_skip();
+              if (args.kept) args.kept[sched * NX + idx - 1] = 1;
+              if (kind == DEMI_REC_SPAWN) { net.inaccessible &= ~(1u << a); net.killed &= ~(1u << a); blocked &= ~(1u << a); }
+              else if (kind == DEMI_REC_KILL) { net.killed |= 1u << a; net.inaccessible |= 1u << a; }
+              else if (kind == DEMI_REC_PARTITION) { net.partitioned |= 1ULL << (a * 8 + b); fk_part &= ~(1ULL << (a * 8 + b)); }
+              else { net.partitioned &= ~(1ULL << (a * 8 + b)); fk_part |= 1ULL << (a * 8 + b); }
+            }
+          }
+          continue;
+        }
+        if (kind == DEMI_REC_MSG_SEND && ext == 255) {
+          if (active) {
+            const uint32_t slot = (uint32_t)(e >> 56);
+            const bool pruned = FK && !(fk_alive(a) && !fk_cut(a, b));
+            const uint64_t bit = 1ull << (slot & 63u);
+            if (slot & 64u) fk_pruned1 = pruned ? (fk_pruned1 | bit) : (fk_pruned1 & ~bit);
+            else fk_pruned0 = pruned ? (fk_pruned0 | bit) : (fk_pruned0 & ~bit);
+          }
+          continue;
+        }
+        if (kind == DEMI_REC_MSG_SEND) {
+          if (active && IN_MASK(ext) && ((exists >> b) & 1)) {
+            PEND_APPEND_ID(msg_word((uint32_t)(e >> 24) & 0xFF, DEMI_DEADLETTERS, b, (uint32_t)(e >> 32) & 0xFF,
+                                    (uint32_t)(e >> 40) & 0xFF), (uint32_t)exp_fp[idx - 1]);
+            if (args.kept && !(flags & DEMI_OVF_ANY)) args.kept[sched * NX + idx - 1] = 1;
+            if (flags & DEMI_OVF_ANY) active = false;
+          }
+          continue;
+        }
+        // ---- MSG_EVENT: which lanes deliver it
+        const uint32_t want = msg_word((uint32_t)(e >> 24) & 0xFF, a, b, (uint32_t)(e >> 32) & 0xFF, (uint32_t)(e >> 40) & 0xFF);
+        bool deliver = false;
+        if (active) {
+          do {
+            if (idx - 1 == skip) break;                  // the delivery this candidate removes
+            if (ext != 255 && !IN_MASK(ext)) break;      // pruned together with its Send (filterSends)
+            if (FK) {
+              const uint32_t slot = (uint32_t)(e >> 56);
+              const bool sent = slot == 255u || !(((slot & 64u) ? fk_pruned1 : fk_pruned0) >> (slot & 63u) & 1ull);
+              if (!(fk_alive(b) && !fk_cut(a, b) && sent)) break;
+            }
+            if ((blocked >> b) & 1u) { ignored++; break; }
+            if (FP) {
+              const uint32_t f = exp_fp[idx - 1];
+              if (cnt_get(f) == 0) { ignored++; break; }       // "Ignoring message" (:528-529)
+              cnt_add(f, false);
+            } else {
+              uint32_t k = 0;
+              for (; k < n_pend; k++)
+                if (pend_load(mem, k) == want) break;
+              if (k == n_pend) { ignored++; break; }
+              pend_store(mem, k, pend_load(mem, n_pend - 1));
+            }
+            n_pend--;
+            if (args.kept) args.kept[sched * NX + idx - 1] = 1;
+            deliver = true;
+          } while (0);
+        }
+        if (__ballot(deliver) == 0) continue;            // nobody's candidate has this message pending
+        const uint32_t w = want;
+        const uint32_t type = w_type(w), me = w_dst(w);
+        if (deliver) {
+          count++;
+          hash_step(hash, w);
+          const uint32_t meta = t.meta[type];
+          if (((meta & 0xFF) == DEMI_MSG_TIMER) && (rep & (1u << (me * DEMI_MAX_TIMER_TYPES + (meta >> 8)))))
+            handle_timer(me, type);
+          if (flags & DEMI_OVF_ANY) { deliver = false; active = false; }
+        }
+        uint32_t nfx = 0;
+        if (deliver) nfx = DEMI_VM_RUN(t, mem, w, flags, app_rng);
+        if (deliver) {
+          for (uint32_t k = 0; k < nfx && !(flags & DEMI_OVF_ANY); k++) {
+            const uint32_t fx = mem.fxq[k * 64];
+            const uint32_t op = fx & 31u, ftype = (fx >> 5) & 31u, target = (fx >> 10) & 15u, p0 = (fx >> 14) & 0xFFu,
+                           p1 = (fx >> 22) & 0xFFu;
+            if (op <= DEMI_OP_BCAST) {
+              const bool bc = (op == DEMI_OP_BCAST);
+              const uint32_t first = bc ? 0u : target, last = bc ? A : (target < A ? target + 1 : 0u);
+              for (uint32_t r = first; r < last; r++) {
+                if ((bc && r == me) || !((exists >> r) & 1)) continue;
+                if (!crosses_partition(net, me, r)) PEND_APPEND(msg_word(ftype, me, r, p0, p1));
+              }
+            } else if (op == DEMI_OP_CRASH) {
+              blocked |= 1u << me;
+            } else if (op == DEMI_OP_TCANCEL) {
+              rep &= ~TIMER_BIT(me, ftype);
+              const uint32_t wantt = (me << 5) | ftype;
+              bool found = false;
+              for (uint32_t q = 0; q < n_tq; q++) {
+                if (((uint32_t)(tq >> (8 * q)) & 0xFF) == wantt) {
+                  const uint64_t lowm = (q == 0) ? 0ull : (~0ull >> (64 - 8 * q));
+                  tq = (tq & lowm) | ((tq >> 8) & ~lowm);
+                  n_tq--; found = true; break;
+                }
+              }
+              if (!found) {
+                const uint32_t wantw = msg_word(ftype, DEMI_DEADLETTERS, me, 0, 0);
+                if (FP) {
+                  const uint32_t f = fp_of(wantw);
+                  if (cnt_get(f)) { cnt_add(f, false); n_pend--; }
+                } else {
+                  for (uint32_t q = 0; q < n_pend; q++) {
+                    if (pend_load(mem, q) == wantw) {
+                      pend_store(mem, q, pend_load(mem, n_pend - 1));
+                      n_pend--; break;
+                    }
+                  }
+                }
+              }
+            } else {
+              const uint32_t bit = TIMER_BIT(me, ftype);
+              if (!(rep & bit)) {
+                if (op == DEMI_OP_TREP) rep |= bit;
+                handle_timer(me, ftype);
+              }
+            }
+          }
+          for (uint32_t k = 0; k < n_tq && !(flags & DEMI_OVF_ANY); k++) {
+            const uint32_t bt = (uint32_t)(tq >> (8 * k)) & 0xFF, rcv = bt >> 5, ttype = bt & 31;
+            if (!((net.inaccessible >> rcv) & 1)) PEND_APPEND(msg_word(ttype, DEMI_DEADLETTERS, rcv, 0, 0));
+          }
+          tq = 0; n_tq = 0;
+          if (flags & DEMI_OVF_ANY) active = false;
+        }
+      }
+      if (mine) {
+        uint32_t viol = 0;
+        if (!(flags & DEMI_OVF_ANY)) {
+          const uint32_t fp = invariant_code(args.model, st, exists, A, t.inv_kind, t.inv_fa, t.inv_va, t.inv_fb);
+          if (fp && (((fp ^ args.looking_for) & t.fp_mask) == 0)) viol = args.looking_for;
+        }
+        for (uint32_t a = 0; a < A; a++) hash_step(hash, st[a * 64]);
+        uint4 v;
+        if (flags & DEMI_OVF_ANY) {
+          v.x = flags & DEMI_OVF_ANY; v.y = 0; v.z = 0; v.w = 0;
+        } else {
+          v.x = (viol ? DEMI_V_VIOLATION : 0u) | (ignored ? DEMI_V_DIVERGED : 0u) | ((count < 0xFFFFu ? count : 0xFFFFu) << 16);
+          v.y = viol; v.z = (uint32_t)hash; v.w = (uint32_t)(hash >> 32);
+        }
+        *reinterpret_cast<uint4*>(&args.out[sched]) = v;
+      }
+    }
+    return;
+  }
 
   for (;;) {
     // ---------------------------------------------------------- refill (same protocol as K1)

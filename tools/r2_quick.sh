@@ -1,34 +1,16 @@
 #!/bin/bash
-# Issue counters of the K2 (ddmin) and K3 (dpor) kernels: instructions per launch, active lanes per VALU instruction
+# After the K2 lock-step default: the bench line again (its ddmin record changes) and the ddmin kernel-trace stats
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$R/gpurun_out
-P=/tmp/prof23
-rm -rf $P; mkdir -p $OUT $P
-cd /tmp
+cd $R
+mkdir -p gpurun_out
+timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/r02_bench_1gpu.json 2> gpurun_out/r02_bench_1gpu.err
+python -c "
+import json; d=json.loads(open('gpurun_out/r02_bench_1gpu.json').read().strip().splitlines()[-1]); s=d['secondary']; r=d['roofline']
+print('fuzz', 'value %.4g' % d['value'], 'kernel_ms %.3f' % r['kernel_ms'], 'stale', r['counters_stale'])
+print('ddmin', round(s['ddmin']['value']), {k: round(v['kernel_us']) for k,v in s['ddmin']['frontiers'].items()}, 'cpu', round(s['ddmin']['cpu_baseline']['value']), s['ddmin']['cpu_baseline']['bit_identical_to_gpu'], s['ddmin']['ddmin_end_to_end']['seconds'])
+print('dpor', {k: round(v['value']) for k,v in s['dpor']['orders'].items()})"
+P=/tmp/profdd; rm -rf $P; mkdir -p $P; cd /tmp
 COMGR=$(python -c "import torch, os; print(os.path.join(os.path.dirname(torch.__file__), 'lib', 'libamd_comgr.so'))")
-for w in ddmin dpor; do
-  rocprofv3 --preload $COMGR --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE -d $P/$w -o c -- python $R/bench.py --workload $w --no-cpu-baseline > $OUT/r02_pmc_$w.log 2>&1
-done
-python - <<'PY'
-import glob, sqlite3, os
-for w in ("ddmin", "dpor"):
-    dbs = glob.glob("/tmp/prof23/%s/*.db" % w)
-    if not dbs:
-        print(w, "no db"); continue
-    cur = sqlite3.connect(dbs[0]).cursor()
-    q = ("select kernel_name, counter_name, count(*), avg(value), sum(value) from counters_collection "
-         "where kernel_name like '%demi%' group by kernel_name, counter_name")
-    rows = {}
-    for kn, cn, cnt, avg, tot in cur.execute(q):
-        rows.setdefault(kn, {})[cn] = (cnt, avg, tot)
-    lines = ["# python bench.py --workload %s --no-cpu-baseline under rocprofv3 --pmc: per kernel, dispatches, average and total per counter" % w]
-    for kn, cs in rows.items():
-        lines.append(kn[:100])
-        for cn, (cnt, avg, tot) in sorted(cs.items()):
-            lines.append("    %-24s %6d dispatches  avg %16.1f  total %18.1f" % (cn, cnt, avg, tot))
-        if "SQ_INSTS_VALU" in cs and "SQ_THREAD_CYCLES_VALU" in cs and cs["SQ_INSTS_VALU"][2]:
-            lines.append("    active lanes per VALU instruction: %.1f" % (cs["SQ_THREAD_CYCLES_VALU"][2] / cs["SQ_INSTS_VALU"][2]))
-    open(os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "gpurun_out", "r02_%s_counters.txt" % w), "w").write("\n".join(lines) + "\n")
-    print("\n".join(lines[:40]))
-PY
+rocprofv3 --preload $COMGR --kernel-trace --stats -d $P/prof_stats_ddmin -o k2 -- python $R/bench.py --workload ddmin --no-cpu-baseline > $R/gpurun_out/r02_prof_stats_ddmin.log 2>&1
+python $R/tools/summarize_prof.py r02dd $P $R/gpurun_out > /dev/null 2>&1; head -6 $R/gpurun_out/r02dd_ddmin.txt
