@@ -52,10 +52,11 @@ JNIEXPORT jint JNICALL FN(modelLoad)(JNIEnv* e, jclass c, jlong h, jint nActors,
   m.n_actors = (uint32_t)nActors; m.n_classes = (uint32_t)nClasses;
   m.n_msg_types = (uint32_t)(*e)->GetArrayLength(e, msgClass);
   m.code_len = (uint32_t)(*e)->GetArrayLength(e, code);
+  const jsize n_inv = (*e)->GetArrayLength(e, inv);     /* (before the critical section: no JNI calls inside one) */
   jint* iv = (jint*)PIN(inv);
   m.inv_kind = (uint32_t)iv[0]; m.inv_fa = (uint32_t)iv[1]; m.inv_va = (uint32_t)iv[2]; m.inv_fb = (uint32_t)iv[3];
   m.fp_match_mask = (uint32_t)iv[4];
-  m.flags = (*e)->GetArrayLength(e, inv) > 5 ? (uint32_t)iv[5] : 0u;     /* a wide model: initState holds two words per actor */
+  m.flags = n_inv > 5 ? (uint32_t)iv[5] : 0u;            /* a wide model: initState holds two words per actor */
   UNPIN(inv, iv, JNI_ABORT);
   m.msg_class = (const uint8_t*)PIN(msgClass);
   m.actor_class = (const uint8_t*)PIN(actorClass);
