@@ -413,7 +413,7 @@ def main():
         # algorithmic bytes of one K1 launch: 16 B verdict per schedule out, plus the
         # trace and the transition table streamed once per resident workgroup
         blocks = min((n + 255) // 256, torch.cuda.get_device_properties(dev).multi_processor_count *
-                     ((3 if specialized else 2) if args.strategy == "fifo" else (6 if specialized else 3)))
+                     ((3 if specialized else 2) if args.strategy == "fifo" else 4 if getattr(model, "wide", False) else (6 if specialized else 3)))
         shared = 8 * len(events) + 4 * len(model.code) + 4 * len(model.handler_start) + 8 * 8 + 32 * 4 + 132 * 4 + 64 * 4
         alg_bytes = 16 * n + blocks * shared
         # measured on this box, right after the timed region: the shader clock under load and the SIMD cycles per wave64
