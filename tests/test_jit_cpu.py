@@ -374,7 +374,7 @@ def test_specialised_k1_keeps_six_waves_per_simd_with_either_compiler(tmp_path, 
             "    print('SIZE', _native.specialize_check(M.raft_model(5).to_struct())[0])\n"
             "except _native.DemiError as e:\n"
             "    print('ERR', e)\n" % ROOT)
-    env = dict(os.environ, DEMI_JIT_DUMP=str(tmp_path / "img"))
+    env = dict(os.environ, DEMI_JIT_DUMP=str(tmp_path / "img"), DEMI_SPECIALIZE_CHECK_K1_ONLY="1")
     if system_comgr:
         env["LD_PRELOAD"] = comgr
     out = subprocess.run([os.sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
