@@ -136,7 +136,9 @@ class RandomScheduler:
             self._ctx.model_load(self._model.to_struct())
             self._loaded_model = True
             self._loaded_trace = None
-            if self.specialize:
+            if getattr(self._model, "wide", False):
+                self._ctx.model_specialize()     # a wide table (DEMI_MODEL_WIDE) runs only as compiled code: a failure is an error
+            elif self.specialize:
                 try:
                     self._ctx.model_specialize()
                 except _native.DemiError:
