@@ -15,7 +15,7 @@ EXPORTS = ["demi_ctx_create", "demi_ctx_destroy", "demi_last_error", "demi_versi
            "demi_trace_load", "demi_random_explore", "demi_random_explore_dev", "demi_random_get_trace", "demi_collect_violations_dev",
            "demi_replay_load", "demi_replay_batch", "demi_replay_batch_dev", "demi_dpor_load", "demi_dpor_batch", "demi_dpor_explore", "demi_random_explore_violations",
            "demi_replay_removal_batch", "demi_replay_get_kept", "demi_model_specialize", "demi_model_is_specialized", "demi_model_code_id",
-           "demi_specialize_check", "demi_specialize_source", "demi_provenance_prune", "demi_device_probe", "demi_device_probe_mix", "demi_calib_rw", "demi_random_explore_flagged", "demi_collect_flagged_dev",
+           "demi_specialize_check", "demi_specialize_source", "demi_specialize_source_k1", "demi_provenance_prune", "demi_device_probe", "demi_device_probe_mix", "demi_calib_rw", "demi_random_explore_flagged", "demi_collect_flagged_dev",
            "demi_comm_unique_id", "demi_comm_create", "demi_comm_create_host", "demi_comm_destroy", "demi_comm_rank",
            "demi_comm_allgather_dev", "demi_random_explore_sharded", "demi_replay_batch_sharded"]
 
@@ -59,6 +59,8 @@ def lib():
     L.demi_specialize_check.restype = C.c_long
     L.demi_specialize_source.argtypes = [C.POINTER(T.ModelStruct), C.c_char_p, C.c_size_t]
     L.demi_specialize_source.restype = C.c_long
+    L.demi_specialize_source_k1.argtypes = [C.POINTER(T.ModelStruct), C.c_char_p, C.c_size_t]
+    L.demi_specialize_source_k1.restype = C.c_long
     L.demi_trace_load.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
     L.demi_random_explore.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(T.Limits), C.c_void_p]
     L.demi_random_explore_dev.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(T.Limits),
@@ -114,10 +116,11 @@ def specialize_check(model_struct):
     return int(n), log.value.decode()
 
 
-def specialize_source(model_struct):
-    """The C++ the specialiser generates for the model's handlers."""
+def specialize_source(model_struct, k1=False):
+    """The C++ the specialiser generates for the model's handlers (k1: the RandomScheduler kernel's flavour, with the
+    table's effect-slot schedule when it has one)."""
     buf = C.create_string_buffer(1 << 20)
-    n = lib().demi_specialize_source(C.byref(model_struct), buf, len(buf))
+    n = (lib().demi_specialize_source_k1 if k1 else lib().demi_specialize_source)(C.byref(model_struct), buf, len(buf))
     if n < 0:
         raise DemiError(n, buf.value.decode(errors="replace"))
     return buf.value.decode()

@@ -17,7 +17,9 @@ namespace demi {
 struct DevModel {
   uint32_t n_actors, n_msg_types, n_classes, code_len;
   uint32_t inv_kind, inv_fa, inv_va, inv_fb;
-  uint32_t fp_match_mask, wide /* DEMI_MODEL_WIDE */, pad1, pad2;
+  uint32_t fp_match_mask, wide /* DEMI_MODEL_WIDE */;
+  uint32_t n_timer_types;   // TIMER-class message types of the model (their timer indices are 0 .. n_timer_types - 1)
+  uint32_t timer_types;     // bit t = message type t is TIMER-class
   uint32_t meta[DEMI_MAX_MSG_TYPES];                           // msg_class | timer_idx << 8
   uint32_t handler_start[DEMI_MAX_CLASSES * DEMI_MAX_MSG_TYPES];  // 0xFFFF = ignored
   uint32_t actor_class[DEMI_MAX_ACTORS];
@@ -27,6 +29,7 @@ struct DevModel {
   uint32_t optab[64];      // per-op control words (sim_core.hpp op_control), filled by the host
   uint32_t code[DEMI_MAX_CODE];
   uint64_t init_state_wide[2 * DEMI_MAX_ACTORS];   // DEMI_MODEL_WIDE: two words per actor (init_state is unused then)
+  uint64_t tix_packed;      // timer index of message type t in bits 2t, 2t + 1 (what meta[t] >> 8 holds, without the table read)
 };
 
 // A translation unit compiled for a DEMI_MODEL_WIDE table (-DDEMI_WIDE, only ever by demi_model_specialize) sees 64-bit

@@ -26,18 +26,225 @@
 
 namespace demi_jit {
 
+// ------------------------------------------------------------------ static effect-slot schedule (K1)
+// The generic kernels record a delivery's effect rows into a queue and apply entry k of every lane together; at entry k
+// some lane of the wave has a SEND, another a TCANCEL, a third a TSET, so the wave pays for every body at every entry.
+// For a loaded table the effect rows are known: each one gets a FIXED slot in a short schedule of effect classes
+// (all SEND / BCAST rows are one class; timer rows are a class per (op, timer type)) such that along every control-flow
+// path of every handler the slots increase - program order is kept - and slot j of all lanes is the same class: the
+// apply phase becomes one straight pass over the schedule, each body once, with the class constants folded in.
+// The schedule is a common supersequence of the handlers' effect-class sequences (majority merge over the distinct paths,
+// then one pass over the row DAG that fixes every row's slot and extends the schedule where the paths of one row disagree).
+// Not applicable (the dynamic queue is kept) when some path holds more than DEMI_FX_CAP effect rows - the queue overflow
+// is then a possible verdict - or the schedule needs more than DEMI_FX_CAP slots.
+struct FxSchedule {
+  bool ok = false;
+  std::vector<uint32_t> cls;        // per slot: kind << 16 | op << 8 | type   (kind 0: send, op / type unused)
+  std::vector<int32_t> slot;        // per row: its slot, -1 for rows that are not effect rows
+};
+enum : uint32_t { FXK_SEND = 0, FXK_CANCEL = 1, FXK_TSET = 2, FXK_CRASH = 3 };
+inline uint32_t fx_class_of(uint32_t row) {
+  const uint32_t op = row & 0x3Fu, type = (row >> 17) & 0x7Fu;
+  if (op == DEMI_OP_SEND || op == DEMI_OP_BCAST) return FXK_SEND << 16;
+  if (op == DEMI_OP_TCANCEL) return (FXK_CANCEL << 16) | (op << 8) | type;
+  if (op == DEMI_OP_TSET || op == DEMI_OP_TREP) return (FXK_TSET << 16) | (op << 8) | type;
+  return FXK_CRASH << 16;
+}
+inline FxSchedule fx_schedule(const demi::DevModel& h) {
+  using namespace demi;
+  FxSchedule S;
+  const uint32_t n = h.code_len;
+  S.slot.assign(n, -1);
+  // successors of a row (n = the handler is done)
+  auto succ = [&](uint32_t pc, uint32_t out[2]) -> int {
+    const uint32_t row = h.code[pc], cw = op_control(row & 0x3Fu);
+    auto clip = [&](uint32_t t) { return t < n ? t : n; };
+    if (cw & CW_HALT) return 0;                                   // HALT, CRASH
+    if (cw & CW_IF) { out[0] = clip(pc + 1); out[1] = clip(pc + 1 + ((row >> 17) & 0x7Fu)); return 2; }
+    if (cw & (CW_SKIPZ | CW_SKIPNZ)) { out[0] = clip(pc + 1); out[1] = clip(pc + 1 + (row >> 24)); return 2; }
+    if (cw & CW_SKIP) { out[0] = clip(pc + 1 + (row >> 24)); return 1; }
+    out[0] = clip(pc + 1);
+    return 1;
+  };
+  auto is_fx = [&](uint32_t pc) { return (op_control(h.code[pc] & 0x3Fu) & CW_FX) != 0; };
+  std::vector<uint32_t> starts;
+  for (uint32_t i = 0; i < h.n_classes * h.n_msg_types; i++) {
+    const uint32_t st = h.handler_start[i];
+    if (st == 0xFFFF || st >= n) continue;
+    if (std::find(starts.begin(), starts.end(), st) == starts.end()) starts.push_back(st);
+  }
+  // most effect rows on any path from a row (the DAG has forward edges only)
+  std::vector<uint32_t> most(n + 1, 0);
+  for (uint32_t pc = n; pc-- > 0;) {
+    uint32_t o[2], m = 0;
+    const int k = succ(pc, o);
+    for (int i = 0; i < k; i++) m = std::max(m, most[o[i]]);
+    most[pc] = m + (is_fx(pc) ? 1u : 0u);
+  }
+  for (uint32_t st : starts) if (most[st] > DEMI_FX_CAP) return S;
+  // the distinct effect-class sequences of the handlers' paths (bounded enumeration; beyond the bound the DAG pass below
+  // still produces a valid schedule, only a longer one)
+  std::vector<std::vector<uint32_t>> seqs;
+  {
+    size_t budget = 20000;
+    std::vector<uint32_t> cur;
+    struct Frame { uint32_t pc; int next; size_t depth; };
+    for (uint32_t st : starts) {
+      std::vector<Frame> stack;
+      stack.push_back({st, 0, 0});
+      cur.clear();
+      while (!stack.empty() && budget) {
+        Frame& f = stack.back();
+        if (f.pc >= n) {
+          if (!cur.empty() && std::find(seqs.begin(), seqs.end(), cur) == seqs.end()) seqs.push_back(cur);
+          budget--;
+          stack.pop_back();
+          continue;
+        }
+        uint32_t o[2];
+        const int k = succ(f.pc, o);
+        if (f.next == 0) {
+          f.depth = cur.size();
+          if (is_fx(f.pc)) cur.push_back(fx_class_of(h.code[f.pc]));
+          if (k == 0) {
+            if (!cur.empty() && std::find(seqs.begin(), seqs.end(), cur) == seqs.end()) seqs.push_back(cur);
+            budget--;
+          }
+        }
+        if (f.next < k) {
+          const uint32_t to = o[f.next];
+          f.next++;
+          cur.resize(f.depth + (is_fx(f.pc) ? 1 : 0));
+          stack.push_back({to, 0, 0});
+        } else {
+          cur.resize(f.depth);
+          stack.pop_back();
+        }
+      }
+    }
+  }
+  // a cheap common supersequence of those sequences.  First guess: majority merge (the class at the front of the most
+  // remaining sequences comes next); then a bounded branch-and-bound over "which front class next" looks for a cheaper one
+  // (cost = the bodies the kernel will execute per delivery: a send or a cancel body is about twice a timer-set body)
+  auto weight = [](uint32_t c) -> uint32_t { const uint32_t k = c >> 16; return k == FXK_TSET ? 2u : (k == FXK_CRASH ? 1u : 4u); };
+  {
+    std::vector<size_t> at(seqs.size(), 0);
+    for (;;) {
+      std::vector<std::pair<uint32_t, uint32_t>> votes;          // class, count
+      for (size_t i = 0; i < seqs.size(); i++) {
+        if (at[i] >= seqs[i].size()) continue;
+        const uint32_t c = seqs[i][at[i]];
+        bool hit = false;
+        for (auto& v : votes) if (v.first == c) { v.second++; hit = true; }
+        if (!hit) votes.push_back({c, 1u});
+      }
+      if (votes.empty()) break;
+      uint32_t best = 0;
+      for (uint32_t i = 1; i < votes.size(); i++) if (votes[i].second > votes[best].second) best = i;
+      const uint32_t c = votes[best].first;
+      S.cls.push_back(c);
+      for (size_t i = 0; i < seqs.size(); i++) if (at[i] < seqs[i].size() && seqs[i][at[i]] == c) at[i]++;
+      if (S.cls.size() > 4 * DEMI_FX_CAP) return S;
+    }
+    uint32_t best_cost = 0;
+    for (uint32_t c : S.cls) best_cost += weight(c);
+    size_t nodes = 200000;
+    std::vector<uint32_t> cur;
+    std::vector<size_t> pos(seqs.size(), 0);
+    // (plain recursion: the depth is at most the length of the first guess)
+    struct Rec {
+      const std::vector<std::vector<uint32_t>>& seqs; std::vector<uint32_t>& best; uint32_t& best_cost; size_t& nodes;
+      decltype(weight)& w;
+      void go(std::vector<size_t>& pos, std::vector<uint32_t>& cur, uint32_t cost) {
+        if (nodes == 0) return;
+        nodes--;
+        std::vector<uint32_t> fronts;
+        uint32_t need = 0;                                       // lower bound: the most expensive remaining single sequence
+        for (size_t i = 0; i < seqs.size(); i++) {
+          if (pos[i] >= seqs[i].size()) continue;
+          if (std::find(fronts.begin(), fronts.end(), seqs[i][pos[i]]) == fronts.end()) fronts.push_back(seqs[i][pos[i]]);
+          uint32_t rest = 0;
+          for (size_t k = pos[i]; k < seqs[i].size(); k++) rest += w(seqs[i][k]);
+          need = std::max(need, rest);
+        }
+        if (fronts.empty()) {
+          if (cost < best_cost || (cost == best_cost && cur.size() < best.size())) { best = cur; best_cost = cost; }
+          return;
+        }
+        if (cost + need > best_cost || (cost + need == best_cost && cur.size() + 1 >= best.size())) return;
+        for (uint32_t c : fronts) {
+          std::vector<size_t> saved = pos;
+          for (size_t i = 0; i < seqs.size(); i++) if (pos[i] < seqs[i].size() && seqs[i][pos[i]] == c) pos[i]++;
+          cur.push_back(c);
+          go(pos, cur, cost + w(c));
+          cur.pop_back();
+          pos = saved;
+        }
+      }
+    } rec{seqs, S.cls, best_cost, nodes, weight};
+    rec.go(pos, cur, 0);
+  }
+  // fix every row's slot: the first slot of its class after the slots of every effect row that can precede it
+  std::vector<int32_t> lo(n + 1, -1);                            // -1: not reachable
+  for (uint32_t st : starts) lo[st] = 0;
+  for (uint32_t pc = 0; pc < n; pc++) {
+    if (lo[pc] < 0) continue;
+    int32_t next = lo[pc];
+    if (is_fx(pc)) {
+      const uint32_t c = fx_class_of(h.code[pc]);
+      int32_t j = next;
+      while (j < (int32_t)S.cls.size() && S.cls[j] != c) j++;
+      if (j >= (int32_t)S.cls.size()) { S.cls.push_back(c); j = (int32_t)S.cls.size() - 1; }
+      S.slot[pc] = j;
+      next = j + 1;
+    }
+    uint32_t o[2];
+    const int k = succ(pc, o);
+    for (int i = 0; i < k; i++) if (o[i] < n) lo[o[i]] = std::max(lo[o[i]], next);
+  }
+  // slots nobody uses (the merge saw a path the DAG pass placed elsewhere) are dropped
+  {
+    std::vector<int32_t> used(S.cls.size(), 0), remap(S.cls.size(), -1);
+    for (uint32_t pc = 0; pc < n; pc++) if (S.slot[pc] >= 0) used[S.slot[pc]] = 1;
+    std::vector<uint32_t> cls2;
+    for (size_t j = 0; j < S.cls.size(); j++) if (used[j]) { remap[j] = (int32_t)cls2.size(); cls2.push_back(S.cls[j]); }
+    for (uint32_t pc = 0; pc < n; pc++) if (S.slot[pc] >= 0) S.slot[pc] = remap[S.slot[pc]];
+    S.cls.swap(cls2);
+  }
+  S.ok = S.cls.size() <= DEMI_FX_CAP;
+  return S;
+}
+
 // ------------------------------------------------------------------ code generation
 // One statement block per row; forward skips become gotos (the table has no backward edges, validation
 // guarantees it), handler entry is a switch over the distinct handler starts.
-inline std::string generate_vm(const demi::DevModel& h) {
+// `sched`: K1's flavour with the static effect-slot schedule above (vm_run_jit then returns the mask of filled slots);
+// without it, or when no schedule exists, effect rows are queued in program order as vm_run does (K2 / K3).
+inline std::string generate_vm(const demi::DevModel& h, bool sched = false) {
   using namespace demi;
   std::string s;
   char buf[512];
   auto emit = [&](const char* fmt, auto... a) { snprintf(buf, sizeof buf, fmt, a...); s += buf; };
+  FxSchedule fxs;
+  if (sched) fxs = fx_schedule(h);
+  if (fxs.ok) {
+    // the schedule for the kernel's apply phase: one DEMI_FX_SLOT(slot, kind, op, type, timer index) per slot, in order
+    s += "#define DEMI_JIT_FX_SCHED 1\n#define DEMI_JIT_FX_APPLY";
+    for (size_t j = 0; j < fxs.cls.size(); j++) {
+      const uint32_t c = fxs.cls[j], type = c & 0xFFu;
+      emit(" DEMI_FX_SLOT(%zu, %uu, %uu, %uu, %uu)", j, c >> 16, (c >> 8) & 0xFFu, type, (c >> 16) == FXK_SEND ? 0u : (h.meta[type & 31u] >> 8));
+    }
+    s += "\n";
+  }
   s += "namespace demi {\n";
-  // effect rows are recorded into the LDS effect queue in program order, exactly as vm_run does
-  s += "#define DEMI_FX(OP, TYPE, TGT, P0, P1) { if (nfx >= DEMI_FX_CAP) { flags |= DEMI_V_QUEUE_OVF; goto done; } "
-       "mem.fxq[nfx * 64] = fx_pack(OP, TYPE, TGT, P0, P1); nfx++; }\n";
+  if (fxs.ok)
+    // an effect row fills its own slot of the schedule; only SEND / BCAST rows carry data (a timer row IS its slot)
+    s += "#define DEMI_FX_AT(SLOT, OP, TYPE, TGT, P0, P1) { mem.fxq[(SLOT) * 64] = fx_pack(OP, TYPE, TGT, P0, P1); nfx |= 1u << (SLOT); }\n"
+         "#define DEMI_FX_MARK(SLOT) { nfx |= 1u << (SLOT); }\n";
+  else
+    // effect rows are recorded into the LDS effect queue in program order, exactly as vm_run does
+    s += "#define DEMI_FX(OP, TYPE, TGT, P0, P1) { if (nfx >= DEMI_FX_CAP) { flags |= DEMI_V_QUEUE_OVF; goto done; } "
+         "mem.fxq[nfx * 64] = fx_pack(OP, TYPE, TGT, P0, P1); nfx++; }\n";
   // A wide table (DevModel::wide) has 16-bit registers: the same statements with the masks of the wider window, the
   // state in two words, and 64-bit message / effect words (word_t of a -DDEMI_WIDE translation unit).
   const bool wide = h.wide != 0;
@@ -163,7 +370,12 @@ inline std::string generate_vm(const demi::DevModel& h) {
     } else if (cw & CW_SKIP) {
       emit("goto %s;\n", target(pc + 1 + braw).c_str());
     } else {   // CW_FX: recorded now, applied after the rows have run (same record as vm_run)
-      emit("DEMI_FX(%uu, %uu, %s > 15u ? 15u : %s, %s, %s)%s\n", row & 0xFFu, aux, a, a, d, b, (cw & CW_HALT) ? " goto done;" : "");
+      if (fxs.ok && (fxs.cls[fxs.slot[pc]] >> 16) != FXK_SEND)
+        emit("DEMI_FX_MARK(%d)%s\n", fxs.slot[pc], (cw & CW_HALT) ? " goto done;" : "");
+      else if (fxs.ok)
+        emit("DEMI_FX_AT(%d, %uu, %uu, %s > 15u ? 15u : %s, %s, %s)\n", fxs.slot[pc], row & 0xFFu, aux, a, a, d, b);
+      else
+        emit("DEMI_FX(%uu, %uu, %s > 15u ? 15u : %s, %s, %s)%s\n", row & 0xFFu, aux, a, a, d, b, (cw & CW_HALT) ? " goto done;" : "");
     }
   }
   s += "  done:\n";

@@ -80,11 +80,22 @@ __host__ __device__ inline size_t k1_fifo_wave_bytes(uint32_t n_actors, bool rec
 __host__ __device__ inline size_t k1_spill_words_per_lane(bool rec, bool fifo, uint32_t hot = K1_HOT) {
   return (size_t)((DEMI_MAX_PENDING - hot) + (fifo ? (DEMI_MAX_PENDING - NORM_HOT) : 0)) * (rec ? 2 : 1);
 }
+// The timer directory: one byte per (actor, timer type) and lane = the pending slot that holds the ONLY pending copy of that
+// timer message (TD_NONE: no copy pending, TD_MANY: there were several at some point - the cancel path then scans).  A
+// cancellable.cancel() (notify_timer_cancel -> FullyRandom.remove, RandomScheduler.scala:525-534, 653-664) removes the
+// first copy in array order; with the directory that is one byte read instead of probing the pending set, which lives in HBM
+// for the specialised kernel.  Four entries share a word; word j of a lane is at [j][lane].
+constexpr uint32_t TD_NONE = 0xFFu, TD_MANY = 0xFEu;
+__host__ __device__ inline uint32_t k1_tdir_words(uint32_t n_actors, uint32_t n_timer_types) { return (n_actors * n_timer_types + 3) / 4; }
+__host__ __device__ inline size_t k1_tdir_wave_bytes(uint32_t n_actors, uint32_t n_timer_types) {
+  return (size_t)k1_tdir_words(n_actors, n_timer_types) * 64 * 4;
+}
 template <bool REC, bool FIFO>
 __host__ __device__ inline size_t k1_lds_bytes(uint32_t code_len, uint32_t n_ev, uint32_t n_hs, uint32_t n_actors,
-                                               uint32_t n_batches, uint32_t hot = K1_HOT, bool wide = WIDE_TU) {
+                                               uint32_t n_batches, uint32_t n_timer_types, uint32_t hot = K1_HOT, bool wide = WIDE_TU) {
   return tables_lds_bytes(code_len, n_ev, n_hs, wide) + k1_extra_lds_bytes(n_ev, n_batches, wide) +
-         K1_WAVES * (lane_mem_wave_bytes(n_actors, REC, hot, wide) + (FIFO ? k1_fifo_wave_bytes(n_actors, REC) : 0));
+         K1_WAVES * (lane_mem_wave_bytes(n_actors, REC, hot, wide) + (FIFO ? k1_fifo_wave_bytes(n_actors, REC) : 0) +
+                     k1_tdir_wave_bytes(n_actors, n_timer_types));
 }
 
 #ifdef DEMI_K1_MIN_WAVES_PER_EU    // experiment knob of the specialised build: ask for more waves per SIMD (fewer VGPRs)
@@ -172,9 +183,24 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
   // a specialised build (jit.hpp) knows the model's constants at compile time
 #ifdef DEMI_JIT_A
   const uint32_t A = DEMI_JIT_A;
+  const uint32_t NTT = DEMI_JIT_NTT, timer_types = DEMI_JIT_TIMER_TYPES;
+  const uint64_t tix_packed = DEMI_JIT_TIX_PACKED;
 #else
   const uint32_t A = t.A;
+  const uint32_t NTT = t.n_timer_types, timer_types = t.timer_types;
+  const uint64_t tix_packed = t.tix_packed;
 #endif
+  // the timer directory of this lane (k1_tdir_words above): entry e = rcv * NTT + timer index is byte (e & 3) of word e >> 2
+  unsigned char* const tdir = wave_base + (size_t)K1_WAVES * (lane_mem_wave_bytes(t.A, REC, K1_HOT) + (FIFO ? k1_fifo_wave_bytes(t.A, REC) : 0)) +
+                              (size_t)wave * k1_tdir_wave_bytes(t.A, t.n_timer_types) + (size_t)lane * 4;
+  auto td_ptr = [&](uint32_t e) -> unsigned char* { return tdir + ((e >> 2) << 8) + (e & 3u); };
+  auto tix_of = [&](uint32_t type) -> uint32_t { return (uint32_t)(tix_packed >> (2 * type)) & 3u; };
+  // is `pw` a timer message (sender deadLetters, TIMER-class type; externals share the sender), and which entry is its
+  auto timer_entry = [&](word_t pw, uint32_t& e) -> bool {
+    const uint32_t ty = w_type(pw);
+    e = w_dst(pw) * NTT + tix_of(ty);
+    return w_src(pw) == DEMI_DEADLETTERS && ((timer_types >> ty) & 1u);
+  };
   const uint32_t E = t.E, exists = t.exists;
   const uint32_t max_messages = args.max_messages ? args.max_messages : 0x7FFFFFFFu;
   const uint32_t interval = args.interval;
@@ -204,7 +230,6 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
   constexpr bool CRASHES = true;
 #endif
   uint32_t hits = 0;                  // invariant "hit" mask of the actors (demi_device.hpp invariant_hit), kept up to date per delivery
-  uint64_t tmask = 0;
   uint32_t next_id = 1, n_rec = 0;    // REC only
   demi_rec_event* rec = nullptr;
 
@@ -226,14 +251,17 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
     }                                                                                         \
   } while (0)
 
-// tmask: bit s = pending slot s (< 64) holds a timer message; lets TCANCEL probe only those slots
-#define PEND_APPEND(WORD, ID, IS_TIMER)                               \
+// TD_ENTRY: the timer directory entry of a timer message (>= 0: it now has a copy in slot n_pend), -1 for anything else
+#define PEND_APPEND(WORD, ID, TD_ENTRY)                               \
   do {                                                                \
     if (n_pend + n_norm >= PMAX) { flags |= DEMI_V_PENDING_OVF; }     \
     else {                                                            \
       pend_store(mem, n_pend, (WORD));                                \
       if (REC) aux_store(mem, n_pend, (ID));                          \
-      if ((IS_TIMER) && n_pend < 64) tmask |= 1ull << n_pend;         \
+      if ((TD_ENTRY) >= 0) {                                          \
+        unsigned char* const p_ = td_ptr((uint32_t)(TD_ENTRY));       \
+        *p_ = (unsigned char)((*p_ == TD_NONE) ? n_pend : TD_MANY);   \
+      }                                                               \
       n_pend++;                                                       \
     }                                                                 \
   } while (0)
@@ -272,16 +300,25 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
   // RandomizedHashSet.remove (Util.scala:146-163): the last element moves into the hole
   // (lw = the word in the last slot: callers load it together with the words they inspect, one round trip to the
   // pending set instead of two when it lives in HBM)
-  auto pend_remove = [&](uint32_t idx, word_t lw) {
+  // rw = the word that leaves slot idx.  The timer directory follows: a removed timer whose entry points at idx has no
+  // copy left (an entry only points somewhere while that copy is the single one), a timer moved out of the last slot
+  // takes its entry along.
+  auto pend_remove = [&](uint32_t idx, word_t rw, word_t lw) {
     const uint32_t last = n_pend - 1;
     pend_store(mem, idx, lw);
     if (REC) aux_store(mem, idx, aux_load(mem, last));
-    bool last_is_timer;
-    if (last < 64) last_is_timer = (tmask >> last) & 1;
-    else last_is_timer = (w_src(lw) == DEMI_DEADLETTERS) && ((t.meta[w_type(lw)] & 0xFF) == DEMI_MSG_TIMER);
-    if (idx < 64) tmask = (tmask & ~(1ull << idx)) | ((uint64_t)(last_is_timer && idx != last) << idx);
-    if (last < 64) tmask &= ~(1ull << last);
+    uint32_t e;
+    if (timer_entry(rw, e)) { unsigned char* const p = td_ptr(e); if (*p == idx) *p = (unsigned char)TD_NONE; }
+    if (idx != last && timer_entry(lw, e)) { unsigned char* const p = td_ptr(e); if (*p == last) *p = (unsigned char)idx; }
     n_pend = last;
+  };
+  // the directory from scratch (after the blocked-actor path has permuted the array)
+  auto tdir_rebuild = [&]() {
+    for (uint32_t j = 0; j < k1_tdir_words(A, NTT); j++) *reinterpret_cast<uint32_t*>(tdir + (j << 8)) = 0xFFFFFFFFu;
+    for (uint32_t q = 0; q < n_pend; q++) {
+      uint32_t e;
+      if (timer_entry(pend_load(mem, q), e)) { unsigned char* const p = td_ptr(e); *p = (unsigned char)((*p == TD_NONE) ? q : TD_MANY); }
+    }
   };
 
   // The invariant's hit mask is maintained incrementally (one actor changes per delivery), so a check - every
@@ -349,6 +386,7 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
         net.inaccessible = exists; net.killed = 0; net.partitioned = 0;
         blocked = 0;
         hits = 0;
+        for (uint32_t j = 0; j < k1_tdir_words(A, NTT); j++) *reinterpret_cast<uint32_t*>(tdir + (j << 8)) = 0xFFFFFFFFu;   // no timer pending
         for (uint32_t i = 0; i < A * ST_WORDS; i++) st[i * 64] = t.init[i];
         for (uint32_t a = 0; a < A; a++) hits |= invariant_hit_at(st, a, inv_kind, inv_fa, inv_va) << a;
         if (REC) { rec = args.rec_out + sched * (uint64_t)args.rec_cap; n_rec = 0; next_id = 1; }
@@ -454,7 +492,7 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
           const word_t sw = s_sendw[i];
           if (sw != 0) {
             const uint32_t id = next_id; next_id++;
-            PEND_APPEND(sw, id, false);
+            PEND_APPEND(sw, id, -1);
             REC_PUSH(DEMI_REC_MSG_SEND, DEMI_DEADLETTERS, w_dst(sw), w_type(sw), w_p0(sw), w_p1(sw), 1, i, id);
           }
         }
@@ -466,7 +504,7 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
         const uint32_t bt = (uint32_t)(tq >> (8 * k)) & 0xFF, rcv = bt >> 5, type = bt & 31;
         const uint32_t id = next_id; if (REC) next_id++;
         const bool drop = (net.inaccessible >> rcv) & 1;
-        if (!drop) PEND_APPEND(msg_word(type, DEMI_DEADLETTERS, rcv, 0, 0), id, true);
+        if (!drop) PEND_APPEND(msg_word(type, DEMI_DEADLETTERS, rcv, 0, 0), id, (int32_t)(rcv * NTT + tix_of(type)));
         REC_PUSH(DEMI_REC_MSG_SEND, DEMI_DEADLETTERS, rcv, type, 0, 0, 2 | (drop ? 4 : 0), 255, id);
       }
       tq = 0; n_tq = 0;
@@ -511,7 +549,7 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
             const uint32_t i = jr_next_int(g, n_pend, t.magic);
             const word_t cw = pend_load(mem, i);
             const uint32_t cid = REC ? aux_load(mem, i) : 0u;
-            pend_remove(i, pend_load(mem, n_pend - 1));
+            pend_remove(i, cw, pend_load(mem, n_pend - 1));
             if ((blocked >> w_dst(cw)) & 1u) {           // set aside in the slot this removal just freed
               pend_store(mem, n0 - 1 - k, cw);
               if (REC) aux_store(mem, n0 - 1 - k, cid);
@@ -536,11 +574,7 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
               if (REC) aux_store(mem, n0 - k - 1 + j, aux_load(mem, n0 - k + j));
             }
           n_pend = n0 - (found ? 1u : 0u);
-          tmask = 0;                                     // which slots hold timer messages, from scratch
-          for (uint32_t q = 0; q < n_pend && q < 64; q++) {
-            const word_t pw = pend_load(mem, q);
-            if (w_src(pw) == DEMI_DEADLETTERS && (t.meta[w_type(pw)] & 0xFF) == DEMI_MSG_TIMER) tmask |= 1ull << q;
-          }
+          tdir_rebuild();                                // which slot holds which timer message, from scratch
           return found;
         };
         bool found = false;
@@ -584,7 +618,7 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
             w = pend_load(mem, idx);
             const word_t lastw = pend_load(mem, n_pend - 1);
             if (REC) wid = aux_load(mem, idx);
-            pend_remove(idx, lastw);
+            pend_remove(idx, w, lastw);
           } else {
             fifo_dequeue(jr_next_int(rng, n_pairs, t.magic));
           }
@@ -663,7 +697,7 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
           const bool drop = crosses_partition(net, me, r);
           if (!drop) {
             if (FIFO) NORM_APPEND(msg_word(type, me, r, p0, p1), id);
-            else PEND_APPEND(msg_word(type, me, r, p0, p1), id, false);
+            else PEND_APPEND(msg_word(type, me, r, p0, p1), id, -1);
           }
           REC_PUSH(DEMI_REC_MSG_SEND, me, r, type, p0, p1, drop ? 4 : 0, 255, id);
         }
@@ -674,18 +708,18 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
           const uint32_t r = (uint32_t)__builtin_ctz(tm);
           tm &= tm - 1;
           if (FIFO) NORM_APPEND(base | (r << 5), 0u);
-          else PEND_APPEND(base | (r << 5), 0u, false);
+          else PEND_APPEND(base | (r << 5), 0u, -1);
         }
       }
     };
     // cancelTimer (Instrumenter.scala:159-168) -> notify_timer_cancel (:525-534)
-    auto apply_cancel = [&](uint32_t type) {
-      rep &= ~TIMER_BIT(me, type);
+    auto apply_cancel = [&](uint32_t type, uint32_t tbit, uint32_t tix) {      // tbit = TIMER_BIT(me, type), tix = its timer index
+      rep &= ~tbit;
       const uint32_t want = (me << 5) | type;
       // handle_timer_cancel: messagesToSend first.  The first of its n_tq bytes equal to `want`, all eight
       // compared at once (zero-byte test on tq ^ want...want; its lowest hit is exact)
       bool found = false;
-      {
+      if (n_tq != 0) {
         const uint64_t x = tq ^ (0x0101010101010101ull * (uint64_t)want);
         uint64_t z = (x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull;
         z &= (n_tq >= 8) ? ~0ull : ((1ull << (8 * n_tq)) - 1ull);
@@ -697,44 +731,57 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
         }
       }
       if (!found) {
-        // FullyRandom.remove (:653-664): first match in arr order, then swap-remove.  Only slots that hold timer
-        // messages are probed (ascending = arr order), four at a time so that their loads are in flight together (the
-        // pending set may live in HBM and the kernel is bound by such dependent round trips: 4.87 -> 4.56 ms per 2^20
-        // schedules); slots >= 64 are scanned linearly.
-        const word_t wantw = msg_word(type, DEMI_DEADLETTERS, me, 0, 0);
-        bool gone = false;
-#ifndef DEMI_K1_CANCEL_PROBE1
-        uint64_t m = tmask;
-        while (m != 0 && !gone) {
-          const uint64_t m1 = m & (m - 1), m2 = m1 & (m1 - 1), m3 = m2 & (m2 - 1);
-          const uint32_t q0 = (uint32_t)__builtin_ctzll(m);
-          const uint32_t q1 = m1 ? (uint32_t)__builtin_ctzll(m1) : q0, q2 = m2 ? (uint32_t)__builtin_ctzll(m2) : q0,
-                         q3 = m3 ? (uint32_t)__builtin_ctzll(m3) : q0;
-          const word_t w0 = pend_load(mem, q0), w1 = pend_load(mem, q1), w2 = pend_load(mem, q2), w3 = pend_load(mem, q3);
-          const word_t lastw = pend_load(mem, n_pend - 1);
-          const uint32_t hit = (w0 == wantw) ? q0 : (w1 == wantw) ? q1 : (w2 == wantw) ? q2 : (w3 == wantw) ? q3 : 0xFFFFFFFFu;
-          if (hit != 0xFFFFFFFFu) { pend_remove(hit, lastw); gone = true; }
-          m = m3 & (m3 - 1);
+        // FullyRandom.remove (:653-664): first match in arr order, then swap-remove.  The timer directory knows the slot
+        // when the message has exactly one pending copy (the usual case: a timer is cancelled and set again), and that
+        // there is nothing to remove when it has none - no access to the pending set (HBM in the specialised kernel)
+        // beyond the word of the last slot, which the swap-remove needs anyway.
+        unsigned char* const p = td_ptr(me * NTT + tix);
+        const uint32_t d = *p;
+        if (d != TD_NONE) {
+          const word_t wantw = msg_word(type, DEMI_DEADLETTERS, me, 0, 0);
+          if (d != TD_MANY) {
+            pend_remove(d, wantw, pend_load(mem, n_pend - 1));
+          } else {
+            // several copies were pending at some point: scan.  The scan also counts the copies, so the entry becomes exact
+            // again when at most one is left after this removal.
+            uint32_t first = 0xFFFFFFFFu, second = 0xFFFFFFFFu, copies = 0;
+            for (uint32_t q = 0; q < n_pend; q++)
+              if (pend_load(mem, q) == wantw) {
+                if (copies == 0) first = q; else if (copies == 1) second = q;
+                copies++;
+              }
+            if (copies != 0) {
+              const uint32_t last = n_pend - 1;
+              pend_remove(first, wantw, pend_load(mem, last));   // (the entry is TD_MANY: pend_remove leaves it alone)
+              if (copies == 2) *p = (unsigned char)(second == last ? first : second);
+            }
+            if (copies <= 1) *p = (unsigned char)TD_NONE;
+          }
         }
-#else
-        for (uint64_t m = tmask; m != 0; m &= m - 1) {
-          const uint32_t q = (uint32_t)__builtin_ctzll(m);
-          if (pend_load(mem, q) == wantw) { pend_remove(q, pend_load(mem, n_pend - 1)); gone = true; break; }
-        }
-#endif
-        for (uint32_t q = 64; !gone && q < n_pend; q++)
-          if (pend_load(mem, q) == wantw) { pend_remove(q, pend_load(mem, n_pend - 1)); gone = true; }
       }
     };
     // TSET / TREP: registerCancellable + handleTick (Instrumenter.scala:1145-1200)
-    auto apply_timer_set = [&](bool repeating, uint32_t type) {
-      const uint32_t bit = TIMER_BIT(me, type);
+    auto apply_timer_set = [&](bool repeating, uint32_t type, uint32_t bit) {      // bit = TIMER_BIT(me, type)
       if (!(rep & bit)) {               // else "Non-unique timer" (:1154-1157)
         if (repeating) rep |= bit;
         enqueue_timer(me, type);
       }
     };
     if (deliver) {      // every effect row in program order
+#ifdef DEMI_JIT_FX_SCHED
+      // A table compiled with an effect schedule (jit.hpp fx_schedule): every effect row has a fixed slot whose class -
+      // send, or (timer op, timer type) - is a compile-time constant, slots increase along every path of every handler
+      // (program order), and `nfx` is the mask of the slots this delivery filled: one straight pass, each body once.
+#define DEMI_FX_SLOT(J, KIND, OP, TYPE, TIDX)                                                                         \
+      if (((nfx >> (J)) & 1u) && !(flags & DEMI_OVF_ANY)) {                                                           \
+        if ((KIND) == 0u) { apply_send(mem.fxq[(J) * 64]); PH_MARK(6); }                                               \
+        else if ((KIND) == 1u) { apply_cancel((TYPE), 1u << (me * DEMI_MAX_TIMER_TYPES + (TIDX)), (TIDX)); PH_MARK(7); } \
+        else if ((KIND) == 2u) { apply_timer_set((OP) == DEMI_OP_TREP, (TYPE), 1u << (me * DEMI_MAX_TIMER_TYPES + (TIDX))); PH_MARK(8); } \
+        else if (CRASHES) blocked |= 1u << me;                                                                        \
+      }
+      DEMI_JIT_FX_APPLY
+#undef DEMI_FX_SLOT
+#else
       for (uint32_t k = 0; k < nfx && !(flags & DEMI_OVF_ANY); k++) {
         const word_t fxw = mem.fxq[k * 64];
         const uint32_t fx = (uint32_t)fxw;
@@ -742,9 +789,10 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
         PH_MARK(9);
         if (op <= DEMI_OP_BCAST) { apply_send(fxw); PH_MARK(6); }
         else if (op == DEMI_OP_CRASH) { if (CRASHES) blocked |= 1u << me; }   // actorCrashed (Instrumenter.scala:184-199)
-        else if (op == DEMI_OP_TCANCEL) { apply_cancel(type); PH_MARK(7); }
-        else { apply_timer_set(op == DEMI_OP_TREP, type); PH_MARK(8); }
+        else if (op == DEMI_OP_TCANCEL) { apply_cancel(type, TIMER_BIT(me, type), tix_of(type)); PH_MARK(7); }
+        else { apply_timer_set(op == DEMI_OP_TREP, type, TIMER_BIT(me, type)); PH_MARK(8); }
       }
+#endif
       if (flags & DEMI_OVF_ANY) ph = PH_FINISH;
     }
 
@@ -766,7 +814,7 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
       // reset the simulator for the next schedule
       ph = PH_IDLE;
       n_pend = 0; count = 0; cnt_mod = 0; tidx = 0; inj_lo = 0; inj_hi = 0; batch_no = 0;
-      tq = 0; resend = 0; n_tq = 0; n_resend = 0; just = 0; rep = 0; viol = 0; flags = 0; hash = 0; tmask = 0;
+      tq = 0; resend = 0; n_tq = 0; n_resend = 0; just = 0; rep = 0; viol = 0; flags = 0; hash = 0;
       n_norm = 0; n_pairs = 0; pairmask = 0;
     }
     PH_MARK(10);

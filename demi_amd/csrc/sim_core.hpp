@@ -74,6 +74,8 @@ struct Tables {
   const uint32_t* optab;  // [64] per-op control words (op_control)
   uint32_t A, NT, code_len, E, exists, ac_packed;
   uint32_t inv_kind, inv_fa, inv_va, inv_fb, fp_mask;
+  uint32_t n_timer_types, timer_types;   // TIMER-class message types: how many, and which (bit t)
+  uint64_t tix_packed;                   // their timer indices, two bits per message type
 };
 
 __host__ __device__ inline size_t tables_lds_bytes(uint32_t code_len, uint32_t n_ev, uint32_t n_hs, bool wide = WIDE_TU) {
@@ -89,6 +91,7 @@ __device__ inline unsigned char* tables_load(Tables& t, unsigned char* smem, con
   t.A = gm->n_actors; t.NT = gm->n_msg_types; t.code_len = gm->code_len; t.E = n_ev; t.exists = exists;
   t.inv_kind = gm->inv_kind; t.inv_fa = gm->inv_fa; t.inv_va = gm->inv_va; t.inv_fb = gm->inv_fb;
   t.fp_mask = gm->fp_match_mask;
+  t.n_timer_types = gm->n_timer_types; t.timer_types = gm->timer_types; t.tix_packed = gm->tix_packed;
   const uint32_t n_hs = gm->n_classes * t.NT;
   uint64_t* s_trace = reinterpret_cast<uint64_t*>(smem);
   uint64_t* s_init = s_trace + n_ev;

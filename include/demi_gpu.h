@@ -252,6 +252,10 @@ uint64_t demi_model_code_id(const demi_ctx* ctx);
 long demi_specialize_check(const demi_model* model, char* log, size_t log_cap);
 /* The generated handler source (C++), NUL-terminated, truncated to cap; returns its full length. */
 long demi_specialize_source(const demi_model* model, char* out, size_t cap);
+/* The same for the RandomScheduler kernel's flavour of it: when the table admits one, every effect row is given a fixed slot
+ * of a per-table schedule of effect classes (program order kept along every path), so that the kernel applies slot j of all
+ * its lanes as one class; the handler then returns the mask of filled slots instead of a count. */
+long demi_specialize_source_k1(const demi_model* model, char* out, size_t cap);
 /* The external-event trace handed to explore()/test() (RandomScheduler.scala:226-237). */
 int demi_trace_load(demi_ctx* ctx, const demi_ext_event* events, uint32_t n_events);
 

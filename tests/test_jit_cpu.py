@@ -38,32 +38,48 @@ def test_generated_source_shape():
         assert "case %du: goto L%d;" % (st, st) in src
 
 
-def _host_vm(model, tmp_path):
-    src = _native.specialize_source(model.to_struct())
+def _fx_schedule(src):
+    """The effect-slot schedule of a K1-flavoured source: [(kind, op, type)] per slot, None when the table has none."""
+    import re
+    line = [l for l in src.splitlines() if l.startswith("#define DEMI_JIT_FX_APPLY")]
+    if not line:
+        return None
+    return [(int(k), int(op), int(t)) for _, k, op, t, _ in re.findall(r"DEMI_FX_SLOT\((\d+), (\d+)u, (\d+)u, (\d+)u, (\d+)u\)", line[0])]
+
+
+def _host_vm(model, tmp_path, k1=False):
+    src = _native.specialize_source(model.to_struct(), k1=k1)
     wide = getattr(model, "wide", False)
-    cpp = tmp_path / ("vm_host_wide.cpp" if wide else "vm_host.cpp")
+    cpp = tmp_path / (("vm_host_wide" if wide else "vm_host") + ("_k1.cpp" if k1 else ".cpp"))
     cpp.write_text('#include "%s"\n%s\nstatic uint64_t g_app = 0x5DEECE66DULL;   // Instrumenter().seededRandom: seed 0\n'
                    'extern "C" void app_reset() { g_app = 0x5DEECE66DULL; }\n'
                    'extern "C" uint32_t run(const uint32_t* hs, uint32_t ac, uint32_t nt, uint64_t* st, '
                    'demi::word_t* fxq, demi::word_t w, uint32_t* flags) {\n  demi::Tables t{hs, ac, nt, nullptr}; demi::LaneMem m{st, fxq};\n'
                    '  uint32_t f = *flags; uint32_t n = demi::vm_run_jit(t, m, w, f, g_app); *flags = f; return n; }\n'
                    % (os.path.join(ROOT, "tests", "jit_host_shim.hpp"), src))
-    so = tmp_path / ("vm_host_wide.so" if wide else "vm_host.so")
+    so = tmp_path / (("vm_host_wide" if wide else "vm_host") + ("_k1.so" if k1 else ".so"))
     subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-label"] + (["-DDEMI_WIDE"] if wide else []) +
                           ["-o", str(so), str(cpp)])
     L = C.CDLL(str(so))
     L.run.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64 if wide else C.c_uint32, C.POINTER(C.c_uint32)]
     L.run.restype = C.c_uint32
     L.app_rng = C.c_uint64(0x5DEECE66D)          # the oracle's copy of the application generator (seed 0), advanced in step
+    L.fx_schedule = _fx_schedule(src) if k1 else None
     return L
 
 
+@pytest.mark.parametrize("k1", [False, True], ids=["queue", "k1-schedule"])
 @pytest.mark.parametrize("name,mk", MODELS)
-def test_generated_handlers_equal_the_row_interpreter(oracle, tmp_path, name, mk):
+def test_generated_handlers_equal_the_row_interpreter(oracle, tmp_path, name, mk, k1):
     """Random states x random messages: same new state, same effect rows (after expanding SEND / BCAST the way the
-    apply phase does), same FX_CAP overflow."""
+    apply phase does), same FX_CAP overflow.  k1: the RandomScheduler kernel's flavour, where an effect row fills a fixed
+    slot of the table's effect schedule and the apply phase walks the schedule - the filled slots in schedule order must be
+    the rows in program order."""
     model = mk()
-    L = _host_vm(model, tmp_path)
+    L = _host_vm(model, tmp_path, k1)
+    sched = L.fx_schedule
+    if k1:
+        assert sched is not None and len(sched) <= FX_CAP, "these tables have an effect schedule"
     ms = model.to_struct()
     A, NT = model.n_actors, len(model.msg_names)
     hs = np.full(T.MAX_CLASSES * T.MAX_MSG_TYPES, 0xFFFF, dtype=np.uint32)
@@ -95,9 +111,13 @@ def test_generated_handlers_equal_the_row_interpreter(oracle, tmp_path, name, mk
         assert not flags.value
         assert int(st[me * 64]) == want_state.value, (it, me, typ, hex(state))
         got = []
-        for k in range(n):
+        for k in (range(n) if sched is None else [j for j in range(len(sched)) if (n >> j) & 1]):
             f = int(fxq[k * 64])
             op, t_, target, q0, q1 = f & 31, (f >> 5) & 31, (f >> 10) & 15, (f >> 14) & 255, (f >> 22) & 255
+            if sched is not None and sched[k][0] != 0:       # a timer slot carries no data: the slot is the row
+                op, t_ = sched[k][1], sched[k][2]
+            elif sched is not None:
+                assert op in (M.OPS["SEND"], M.OPS["BCAST"])
             if op == M.OPS["SEND"]:
                 if target < A:
                     got.append((0, target, t_, q0, q1))
@@ -176,11 +196,12 @@ def _random_handler(rng, n_rows, n_types, few_effects=False):
     return a
 
 
-@pytest.mark.parametrize("ifconvert", [0, 4])
-@pytest.mark.parametrize("seed", [1, 2, 3, 4])
-def test_random_programs_through_the_code_generator(oracle, tmp_path, seed, ifconvert, monkeypatch):
+@pytest.mark.parametrize("seed,ifconvert,k1", [(s, c, False) for s in (1, 2, 3, 4) for c in (0, 4)] + [(s, 0, True) for s in (1, 2, 3, 11, 12, 13, 14)])
+def test_random_programs_through_the_code_generator(oracle, tmp_path, seed, ifconvert, k1, monkeypatch):
     """Every op, random control flow, two actor classes: generated C++ == the oracle's row interpreter, delivery by
-    delivery (state, effect rows, FX_CAP overflow)."""
+    delivery (state, effect rows, FX_CAP overflow).  k1: the RandomScheduler kernel's flavour of the generated code; seeds
+    above 10 build tables with few effect rows, which have an effect-slot schedule (jit.hpp fx_schedule) - the filled slots
+    in schedule order must then be the effect rows in program order, on every path the random control flow takes."""
     # ifconvert: the experimental select-based emission of short guarded ALU runs (DEMI_JIT_IFCONVERT), same semantics
     monkeypatch.setenv("DEMI_JIT_IFCONVERT", str(ifconvert))
     rng = np.random.default_rng(seed)
@@ -189,11 +210,14 @@ def test_random_programs_through_the_code_generator(oracle, tmp_path, seed, ifco
     for cls in range(2):
         for name, _ in MSGS:
             if rng.integers(5):
-                h[(cls, name)] = _random_handler(rng, int(rng.integers(3, 40)), len(MSGS))
+                h[(cls, name)] = _random_handler(rng, int(rng.integers(3, 40)), len(MSGS), few_effects=seed > 10)
     A = 5
     model = M.build_model("rand%d" % seed, A, MSGS, h, [[0] * 8] * A, (T.INV_NEVER, 0, 200, 0),
                           actor_class=[0, 1, 0, 1, 1], n_classes=2)
-    L = _host_vm(model, tmp_path)
+    L = _host_vm(model, tmp_path, k1)
+    sched = L.fx_schedule
+    if seed > 10:
+        assert sched is not None and 2 <= len(sched) <= FX_CAP, "a table with few effect rows has a schedule"
     ms = model.to_struct()
     NT = len(MSGS)
     hs = np.full(T.MAX_CLASSES * T.MAX_MSG_TYPES, 0xFFFF, dtype=np.uint32)
@@ -220,9 +244,13 @@ def test_random_programs_through_the_code_generator(oracle, tmp_path, seed, ifco
             continue
         assert not flags.value and int(st[me * 64]) == want_state.value, (it, me, typ, hex(state))
         got = []
-        for k in range(n):
+        for k in (range(n) if sched is None else [j for j in range(len(sched)) if (n >> j) & 1]):
             f = int(fxq[k * 64])
             op, t_, target, q0, q1 = f & 31, (f >> 5) & 31, (f >> 10) & 15, (f >> 14) & 255, (f >> 22) & 255
+            if sched is not None and sched[k][0] != 0:       # a timer slot carries no data: the slot is the row
+                op, t_ = sched[k][1], sched[k][2]
+            elif sched is not None:
+                assert op in (M.OPS["SEND"], M.OPS["BCAST"])
             if op == M.OPS["SEND"]:
                 if target < A:
                     got.append((0, target, t_, q0, q1))
@@ -362,9 +390,10 @@ def _vgpr_count(image):
 
 @pytest.mark.parametrize("system_comgr", [False, True])
 def test_specialised_k1_keeps_six_waves_per_simd_with_either_compiler(tmp_path, system_comgr):
-    """The specialised K1 needs <= 80 VGPRs for 6 waves per SIMD (with 5 it is 11 % slower).  PyTorch's bundled compiler
-    (ROCm 7.0.2) stays within that on its own; /opt/rocm's (7.2) allocates 83 for the same source, and jit_compile then
-    compiles once more with the occupancy stated.  Either way the code object that would be loaded has <= 80 and no spills."""
+    """The specialised K1 needs <= 80 VGPRs for 6 waves per SIMD (with 5 it is 11 % slower).  Round 2's kernel sat at 79
+    with PyTorch's bundled compiler (ROCm 7.0.2) and at 83 with /opt/rocm's (7.2), and a second compilation with the occupancy
+    stated pulled the latter back; round 3's kernel (effect-slot schedule, timer directory instead of a 64-bit timer mask)
+    needs 72 / 74, so the rule is gone and this test pins the margin: <= 80 and no spills with either compiler."""
     comgr = "/opt/rocm/lib/libamd_comgr.so.3"
     if system_comgr and not os.path.exists(comgr):
         pytest.skip("no system comgr next to the bundled one")
