@@ -215,6 +215,16 @@ inline FxSchedule fx_schedule(const demi::DevModel& h) {
   return S;
 }
 
+// effect-queue entries the scheduled K1 of a table needs (its SEND / BCAST slots), DEMI_FX_CAP without a schedule
+inline uint32_t k1_fxq_slots(const demi::DevModel& h, bool sched) {
+  if (!sched) return DEMI_FX_CAP;
+  const FxSchedule fxs = fx_schedule(h);
+  if (!fxs.ok) return DEMI_FX_CAP;
+  uint32_t nq = 0;
+  for (uint32_t c : fxs.cls) nq += (c >> 16) == FXK_SEND;
+  return nq ? nq : 1u;
+}
+
 // ------------------------------------------------------------------ code generation
 // One statement block per row; forward skips become gotos (the table has no backward edges, validation
 // guarantees it), handler entry is a switch over the distinct handler starts.
@@ -226,20 +236,26 @@ inline std::string generate_vm(const demi::DevModel& h, bool sched = false) {
   char buf[512];
   auto emit = [&](const char* fmt, auto... a) { snprintf(buf, sizeof buf, fmt, a...); s += buf; };
   FxSchedule fxs;
+  std::vector<uint32_t> fxq_of_slot;
   if (sched) fxs = fx_schedule(h);
   if (fxs.ok) {
     // the schedule for the kernel's apply phase: one DEMI_FX_SLOT(slot, kind, op, type, timer index) per slot, in order
+    // (only the SEND / BCAST slots carry data: they get the entries 0, 1, ... of the effect queue, DEMI_JIT_FXQ_SLOTS in all)
     s += "#define DEMI_JIT_FX_SCHED 1\n#define DEMI_JIT_FX_APPLY";
+    uint32_t nq = 0;
     for (size_t j = 0; j < fxs.cls.size(); j++) {
       const uint32_t c = fxs.cls[j], type = c & 0xFFu;
-      emit(" DEMI_FX_SLOT(%zu, %uu, %uu, %uu, %uu)", j, c >> 16, (c >> 8) & 0xFFu, type, (c >> 16) == FXK_SEND ? 0u : (h.meta[type & 31u] >> 8));
+      const bool snd = (c >> 16) == FXK_SEND;
+      emit(" DEMI_FX_SLOT(%zu, %uu, %uu, %uu, %uu, %uu)", j, c >> 16, (c >> 8) & 0xFFu, type, snd ? 0u : (h.meta[type & 31u] >> 8), snd ? nq : 0u);
+      fxq_of_slot.push_back(snd ? nq : 0u);
+      if (snd) nq++;
     }
-    s += "\n";
+    emit("\n#define DEMI_JIT_FXQ_SLOTS %uu\n", nq ? nq : 1u);
   }
   s += "namespace demi {\n";
   if (fxs.ok)
     // an effect row fills its own slot of the schedule; only SEND / BCAST rows carry data (a timer row IS its slot)
-    s += "#define DEMI_FX_AT(SLOT, OP, TYPE, TGT, P0, P1) { mem.fxq[(SLOT) * 64] = fx_pack(OP, TYPE, TGT, P0, P1); nfx |= 1u << (SLOT); }\n"
+    s += "#define DEMI_FX_AT(SLOT, Q, OP, TYPE, TGT, P0, P1) { mem.fxq[(Q) * 64] = fx_pack(OP, TYPE, TGT, P0, P1); nfx |= 1u << (SLOT); }\n"
          "#define DEMI_FX_MARK(SLOT) { nfx |= 1u << (SLOT); }\n";
   else
     // effect rows are recorded into the LDS effect queue in program order, exactly as vm_run does
@@ -373,7 +389,7 @@ inline std::string generate_vm(const demi::DevModel& h, bool sched = false) {
       if (fxs.ok && (fxs.cls[fxs.slot[pc]] >> 16) != FXK_SEND)
         emit("DEMI_FX_MARK(%d)%s\n", fxs.slot[pc], (cw & CW_HALT) ? " goto done;" : "");
       else if (fxs.ok)
-        emit("DEMI_FX_AT(%d, %uu, %uu, %s > 15u ? 15u : %s, %s, %s)\n", fxs.slot[pc], row & 0xFFu, aux, a, a, d, b);
+        emit("DEMI_FX_AT(%d, %uu, %uu, %uu, %s > 15u ? 15u : %s, %s, %s)\n", fxs.slot[pc], fxq_of_slot[fxs.slot[pc]], row & 0xFFu, aux, a, a, d, b);
       else
         emit("DEMI_FX(%uu, %uu, %s > 15u ? 15u : %s, %s, %s)%s\n", row & 0xFFu, aux, a, a, d, b, (cw & CW_HALT) ? " goto done;" : "");
     }

@@ -64,7 +64,9 @@ constexpr int K1_BATCH = 64;         // schedule indices claimed per atomic
 // injection batch (inject_until_quiescence is schedule-independent: the events are applied in trace
 // order whatever the interleaving, so the state after batch j is a function of j alone) and the
 // message word of every Send (0 = not a deliverable Send).
-constexpr uint32_t K1_BATCH_WORDS = 7;   // end index, inaccessible, killed, partitioned lo/hi, sends (offset | count << 16), actors Start()ed
+constexpr uint32_t K1_BATCH_WORDS = 9;   // end index, inaccessible, killed, partitioned lo/hi, sends (offset | count << 16), actors Start()ed, reach lo/hi
+// reach: byte `snd` = the created actors a message sent by `snd` reaches, i.e. NOT crosses_partition(snd, .)
+// (EventOrchestrator.scala:345-351) under the batch's network state - what every SEND / BCAST of the batch's deliveries asks
 __host__ __device__ inline size_t k1_extra_lds_bytes(uint32_t n_ev, uint32_t n_batches, bool wide = WIDE_TU) {
   return ((size_t)n_batches * K1_BATCH_WORDS * 4 + 2 * (size_t)n_ev * (wide ? 8 : 4) + 15) & ~(size_t)15;
 }
@@ -90,11 +92,18 @@ __host__ __device__ inline uint32_t k1_tdir_words(uint32_t n_actors, uint32_t n_
 __host__ __device__ inline size_t k1_tdir_wave_bytes(uint32_t n_actors, uint32_t n_timer_types) {
   return (size_t)k1_tdir_words(n_actors, n_timer_types) * 64 * 4;
 }
+// effect-queue entries of this translation unit's K1: the SEND / BCAST slots of the table's effect schedule, or the whole queue
+#ifdef DEMI_JIT_FXQ_SLOTS
+constexpr uint32_t K1_FXQ_SLOTS = DEMI_JIT_FXQ_SLOTS;
+#else
+constexpr uint32_t K1_FXQ_SLOTS = DEMI_FX_CAP;
+#endif
 template <bool REC, bool FIFO>
 __host__ __device__ inline size_t k1_lds_bytes(uint32_t code_len, uint32_t n_ev, uint32_t n_hs, uint32_t n_actors,
-                                               uint32_t n_batches, uint32_t n_timer_types, uint32_t hot = K1_HOT, bool wide = WIDE_TU) {
+                                               uint32_t n_batches, uint32_t n_timer_types, uint32_t hot = K1_HOT, bool wide = WIDE_TU,
+                                               uint32_t fxq_slots = K1_FXQ_SLOTS) {
   return tables_lds_bytes(code_len, n_ev, n_hs, wide) + k1_extra_lds_bytes(n_ev, n_batches, wide) +
-         K1_WAVES * (lane_mem_wave_bytes(n_actors, REC, hot, wide) + (FIFO ? k1_fifo_wave_bytes(n_actors, REC) : 0) +
+         K1_WAVES * (lane_mem_wave_bytes(n_actors, REC, hot, wide, fxq_slots) + (FIFO ? k1_fifo_wave_bytes(n_actors, REC) : 0) +
                      k1_tdir_wave_bytes(n_actors, n_timer_types));
 }
 
@@ -117,7 +126,22 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
     // EventOrchestrator.inject_until_quiescence (:132-189) once per workgroup, for every batch
     uint32_t inacc = t.exists, killed = 0, b_no = 0, n_bs = 0, bs_lo = 0, started = 0;
     uint64_t part = 0;
-    if (t.E == 0) { s_batch[0] = 0; s_batch[1] = inacc; s_batch[2] = 0; s_batch[3] = 0; s_batch[4] = 0; s_batch[5] = 0; s_batch[6] = 0; }
+    auto reach_of = [&](uint32_t inacc_, uint32_t killed_, uint64_t part_) -> uint64_t {
+      uint64_t r = 0;
+      for (uint32_t snd = 0; snd < DEMI_MAX_ACTORS; snd++) {
+        const uint32_t row = (uint32_t)(part_ >> (snd * 8)) & 0xFFu;
+        const uint32_t col = (uint32_t)((((part_ >> snd) & 0x0101010101010101ULL) * 0x0102040810204080ULL) >> 56);
+        uint32_t cut = row | col | inacc_ | (((inacc_ >> snd) & 1u) ? 0xFFu : 0u);
+        if (!((killed_ >> snd) & 1u)) cut &= ~(1u << snd);        // snd == rcv && !killed: never crosses
+        r |= (uint64_t)(t.exists & ~cut & 0xFFu) << (8 * snd);
+      }
+      return r;
+    };
+    if (t.E == 0) {
+      const uint64_t r0 = reach_of(inacc, 0, 0);
+      s_batch[0] = 0; s_batch[1] = inacc; s_batch[2] = 0; s_batch[3] = 0; s_batch[4] = 0; s_batch[5] = 0; s_batch[6] = 0;
+      s_batch[7] = (uint32_t)r0; s_batch[8] = (uint32_t)(r0 >> 32);
+    }
     for (uint32_t i = 0; i < t.E; i++) {
       const uint64_t ev = t.trace[i];
       const uint32_t kind = (uint32_t)ev & 0xFF, a = (uint32_t)(ev >> 8) & 0xFF, b = (uint32_t)(ev >> 16) & 0xFF;
@@ -138,6 +162,7 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
         o[0] = i + 1; o[1] = inacc; o[2] = killed; o[3] = (uint32_t)part; o[4] = (uint32_t)(part >> 32);
         o[5] = bs_lo | ((n_bs - bs_lo) << 16);
         o[6] = started;
+        { const uint64_t r = reach_of(inacc, killed, part); o[7] = (uint32_t)r; o[8] = (uint32_t)(r >> 32); }
         bs_lo = n_bs; started = 0;
         b_no++;
       }
@@ -145,14 +170,14 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
   }
   __syncthreads();
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const LaneMem mem = lane_mem_carve(wave_base + (size_t)wave * lane_mem_wave_bytes(t.A, REC, K1_HOT), t.A, REC, lane, args.spill,
+  const LaneMem mem = lane_mem_carve(wave_base + (size_t)wave * lane_mem_wave_bytes(t.A, REC, K1_HOT, WIDE_TU, K1_FXQ_SLOTS), t.A, REC, lane, args.spill,
                                      (size_t)blockIdx.x * blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x, K1_HOT);
   uint64_t* const st = mem.st;
   const uint32_t PMAX = args.p_max;
   // SrcDstFIFO arrays of this lane (FIFO builds only)
   uint32_t* f_norm = nullptr, *f_norm_aux = nullptr, *f_pairs = nullptr, *f_spill = nullptr, *f_spill_aux = nullptr;
   if (FIFO) {
-    unsigned char* fb = wave_base + (size_t)K1_WAVES * lane_mem_wave_bytes(t.A, REC, K1_HOT) + (size_t)wave * k1_fifo_wave_bytes(t.A, REC);
+    unsigned char* fb = wave_base + (size_t)K1_WAVES * lane_mem_wave_bytes(t.A, REC, K1_HOT, WIDE_TU, K1_FXQ_SLOTS) + (size_t)wave * k1_fifo_wave_bytes(t.A, REC);
     f_norm = reinterpret_cast<uint32_t*>(fb) + lane;
     if (REC) f_norm_aux = f_norm + (size_t)NORM_HOT * 64;
     f_pairs = f_norm + (size_t)NORM_HOT * 64 * (REC ? 2 : 1);
@@ -191,10 +216,18 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
   const uint64_t tix_packed = t.tix_packed;
 #endif
   // the timer directory of this lane (k1_tdir_words above): entry e = rcv * NTT + timer index is byte (e & 3) of word e >> 2
-  unsigned char* const tdir = wave_base + (size_t)K1_WAVES * (lane_mem_wave_bytes(t.A, REC, K1_HOT) + (FIFO ? k1_fifo_wave_bytes(t.A, REC) : 0)) +
+  unsigned char* const tdir = wave_base + (size_t)K1_WAVES * (lane_mem_wave_bytes(t.A, REC, K1_HOT, WIDE_TU, K1_FXQ_SLOTS) + (FIFO ? k1_fifo_wave_bytes(t.A, REC) : 0)) +
                               (size_t)wave * k1_tdir_wave_bytes(t.A, t.n_timer_types) + (size_t)lane * 4;
   auto td_ptr = [&](uint32_t e) -> unsigned char* { return tdir + ((e >> 2) << 8) + (e & 3u); };
-  auto tix_of = [&](uint32_t type) -> uint32_t { return (uint32_t)(tix_packed >> (2 * type)) & 3u; };
+  // (two bits per message type: one 32-bit shift when the table has at most 16 message types, which a specialised build knows)
+#ifdef DEMI_JIT_NT
+  constexpr bool TIX32 = DEMI_JIT_NT <= 16u;
+#else
+  constexpr bool TIX32 = false;
+#endif
+  auto tix_of = [&](uint32_t type) -> uint32_t {
+    return TIX32 ? (((uint32_t)tix_packed >> (2 * type)) & 3u) : ((uint32_t)(tix_packed >> (2 * type)) & 3u);
+  };
   // is `pw` a timer message (sender deadLetters, TIMER-class type; externals share the sender), and which entry is its
   auto timer_entry = [&](word_t pw, uint32_t& e) -> bool {
     const uint32_t ty = w_type(pw);
@@ -217,6 +250,7 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
   uint32_t n_norm = 0, n_pairs = 0;
   uint64_t pairmask = 0, te_rng = 0;
   Net net = {0, 0, 0};
+  uint64_t reach = 0;                 // !REC: the batch's reach matrix (K1_BATCH_WORDS above)
   uint64_t tq = 0, resend = 0;        // messagesToSend timers / timersToResend: 1 byte each (rcv<<5 | type)
   uint32_t n_tq = 0, n_resend = 0;
   uint32_t just = 0, rep = 0;         // justScheduledTimers / registered repeating timers (bit rcv*4+tidx)
@@ -230,6 +264,19 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
   constexpr bool CRASHES = true;
 #endif
   uint32_t hits = 0;                  // invariant "hit" mask of the actors (demi_device.hpp invariant_hit), kept up to date per delivery
+  // The word in the LAST pending slot, kept in a register: every swap-remove needs it, and the pending set of the specialised
+  // kernel lives in HBM.  An append knows it for free; a removal issues the load of the new last word right away and nobody
+  // waits for it before the next removal, so the round trip is off the path of a delivery (DEMI_K1_NO_LASTW: load on demand).
+  word_t lastw = 0;
+#ifdef DEMI_K1_NO_LASTW
+#define LASTW() pend_load(mem, n_pend - 1)
+#define LASTW_SET(W) do {} while (0)
+#define LASTW_RELOAD() do {} while (0)
+#else
+#define LASTW() lastw
+#define LASTW_SET(W) do { lastw = (W); } while (0)
+#define LASTW_RELOAD() do { if (n_pend != 0) lastw = pend_load(mem, n_pend - 1); } while (0)
+#endif
   uint32_t next_id = 1, n_rec = 0;    // REC only
   demi_rec_event* rec = nullptr;
 
@@ -257,6 +304,7 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
     if (n_pend + n_norm >= PMAX) { flags |= DEMI_V_PENDING_OVF; }     \
     else {                                                            \
       pend_store(mem, n_pend, (WORD));                                \
+      LASTW_SET(WORD);                                                \
       if (REC) aux_store(mem, n_pend, (ID));                          \
       if ((TD_ENTRY) >= 0) {                                          \
         unsigned char* const p_ = td_ptr((uint32_t)(TD_ENTRY));       \
@@ -281,12 +329,12 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
     }                                                                 \
   } while (0)
 
-#define TIMER_BIT(RCV, TYPE) (1u << ((RCV) * DEMI_MAX_TIMER_TYPES + (t.meta[(TYPE)] >> 8)))
+#define TIMER_BIT(RCV, TYPE) (1u << ((RCV) * DEMI_MAX_TIMER_TYPES + tix_of(TYPE)))
 
   // RandomScheduler.enqueue_timer (:549-559) -> handle_timer (ExternalEventInjector.scala:282-297)
-  auto enqueue_timer = [&](uint32_t rcv, uint32_t type) {
+  auto enqueue_timer = [&](uint32_t rcv, uint32_t type, uint32_t tbit) {      // tbit = TIMER_BIT(rcv, type)
     const uint64_t b = (uint64_t)((rcv << 5) | type);
-    if (just & TIMER_BIT(rcv, type)) {
+    if (just & tbit) {
       if (n_resend >= DEMI_RESEND_CAP) { flags |= DEMI_V_QUEUE_OVF; return; }
       resend |= b << (8 * n_resend);
       n_resend++;
@@ -311,6 +359,7 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
     if (timer_entry(rw, e)) { unsigned char* const p = td_ptr(e); if (*p == idx) *p = (unsigned char)TD_NONE; }
     if (idx != last && timer_entry(lw, e)) { unsigned char* const p = td_ptr(e); if (*p == last) *p = (unsigned char)idx; }
     n_pend = last;
+    LASTW_RELOAD();          // (after the store above: when idx is the new last slot the load returns lw, same lane, same address)
   };
   // the directory from scratch (after the blocked-actor path has permuted the array)
   auto tdir_rebuild = [&]() {
@@ -346,89 +395,133 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
 #else
 #define PH_MARK(I) do {} while (0)
 #endif
+  // Service iterations.  Ending an execution (verdict), claiming the next one and injecting a batch of external events are
+  // things a lane does a handful of times per execution, but with 64 lanes some lane needs one of them in almost every
+  // iteration, and the wave pays for the whole block each time.  A lane that reaches such a point therefore WAITS (it is inert:
+  // its execution is its own) until the wave's next service iteration: when SVC_LANES lanes are waiting, SVC_PERIOD iterations
+  // after the last one, or when nobody is left delivering.  The other iterations skip these blocks as a whole (a scalar
+  // branch).  DEMI_K1_SVC_PERIOD 0 = every iteration is a service iteration (the order of events of a lane is unchanged either
+  // way, so are the verdicts).
+#ifndef DEMI_K1_SVC_PERIOD
+#define DEMI_K1_SVC_PERIOD 0
+#endif
+#ifndef DEMI_K1_SVC_LANES
+#define DEMI_K1_SVC_LANES 16
+#endif
+  uint32_t svc_age = 0;
   for (;;) {
-    // ------------------------------------------------------------ refill idle lanes
-    {
-      const uint64_t idle = __ballot(ph == PH_IDLE);
-      if (idle != 0 && !exhausted) {                     // wave-uniform
-        const uint32_t want = (uint32_t)__popcll(idle);
-        const uint64_t have = b_end - b_next;
-        uint64_t got = 0;
-        if (have < want) {
-          // one claim always suffices: at most 64 lanes ask and a batch holds 64 indices
-          if (lane == 0) got = atomicAdd(args.work_counter, (unsigned long long)K1_BATCH);
-          got = __shfl(got, 0);
-        }
-        if (ph == PH_IDLE) {
-          const uint32_t rank = (uint32_t)__popcll(idle & ((1ULL << lane) - 1));
-          const uint64_t my = (rank < have) ? (b_next + rank) : (got + (rank - have));
-          if (my < args.n) { sched = my; ph = PH_INJECT; fresh = true; }
-        }
-        if (have < want) { b_next = got + (want - have); b_end = got + K1_BATCH; }
-        else b_next += want;
-        if (b_next >= args.n) exhausted = true;
-      }
-      if (__ballot(ph != PH_IDLE) == 0) break;           // nothing running and nothing left to claim
+    bool service = true;
+    if (DEMI_K1_SVC_PERIOD != 0) {
+      const uint64_t waiting = __ballot(ph != PH_DISPATCH);
+      service = (uint32_t)__popcll(waiting) >= (uint32_t)DEMI_K1_SVC_LANES || svc_age >= (uint32_t)DEMI_K1_SVC_PERIOD || waiting == ~0ull;
+      svc_age = service ? 0u : svc_age + 1u;
     }
-    PH_MARK(0);
+    if (service) {
+      // ------------------------------------------------------------ verdict
+      if (ph == PH_FINISH) {
+        // explore(): `if (messagesScheduledSoFar <= maxMessages) checkIfBugFound` (:256-262, 156-180)
+        if (!(flags & (DEMI_OVF_ANY | DEMI_V_MAXMSG)) && !viol) viol = check_invariant();
+        for (uint32_t i = 0; i < A * ST_WORDS; i++) hash_step(hash, st[i * 64]);
+        uint4 v;
+        if (flags & DEMI_OVF_ANY) {
+          v.x = flags & DEMI_OVF_ANY; v.y = 0; v.z = 0; v.w = 0;
+        } else {
+          v.x = (flags & 0xFF) | (viol ? DEMI_V_VIOLATION : 0u) | ((tidx & 0xFF) << 8) | ((count < 0xFFFFu ? count : 0xFFFFu) << 16);
+          v.y = viol; v.z = (uint32_t)hash; v.w = (uint32_t)(hash >> 32);
+        }
+        *reinterpret_cast<uint4*>(&args.out[sched]) = v;
+        if (REC) args.rec_count[sched] = n_rec;
+        // reset the simulator for the next schedule
+        ph = PH_IDLE;
+        n_pend = 0; count = 0; cnt_mod = 0; tidx = 0; inj_lo = 0; inj_hi = 0; batch_no = 0;
+        tq = 0; resend = 0; n_tq = 0; n_resend = 0; just = 0; rep = 0; viol = 0; flags = 0; hash = 0;
+        n_norm = 0; n_pairs = 0; pairmask = 0;
+      }
+      PH_MARK(10);
+      // ------------------------------------------------------------ refill idle lanes
+      {
+        const uint64_t idle = __ballot(ph == PH_IDLE);
+        if (idle != 0 && !exhausted) {                     // wave-uniform
+          const uint32_t want = (uint32_t)__popcll(idle);
+          const uint64_t have = b_end - b_next;
+          uint64_t got = 0;
+          if (have < want) {
+            // one claim always suffices: at most 64 lanes ask and a batch holds 64 indices
+            if (lane == 0) got = atomicAdd(args.work_counter, (unsigned long long)K1_BATCH);
+            got = __shfl(got, 0);
+          }
+          if (ph == PH_IDLE) {
+            const uint32_t rank = (uint32_t)__popcll(idle & ((1ULL << lane) - 1));
+            const uint64_t my = (rank < have) ? (b_next + rank) : (got + (rank - have));
+            if (my < args.n) { sched = my; ph = PH_INJECT; fresh = true; }
+          }
+          if (have < want) { b_next = got + (want - have); b_end = got + K1_BATCH; }
+          else b_next += want;
+          if (b_next >= args.n) exhausted = true;
+        }
+        if (__ballot(ph != PH_IDLE) == 0) break;           // nothing running and nothing left to claim
+      }
+      PH_MARK(0);
 
-    // ------------------------------------------------------------ (re)initialise + inject
-    if (ph == PH_INJECT) {
-      if (fresh) {
-        fresh = false;
-        // new execution: `new FullyRandom(seed)`; populateActorSystem isolates every created actor
-        // (ExternalEventInjector.scala:371-378)
-        const uint64_t seed = args.seeds ? args.seeds[sched] : args.seed_base + sched;
-        rng = jr_seed(seed);
-        te_rng = rng;                  // SrcDstFIFO: both generators are `new Random(seed)`
-        app_rng = jr_seed(0);
-        hash = 0xCBF29CE484222325ULL;
-        net.inaccessible = exists; net.killed = 0; net.partitioned = 0;
-        blocked = 0;
-        hits = 0;
-        for (uint32_t j = 0; j < k1_tdir_words(A, NTT); j++) *reinterpret_cast<uint32_t*>(tdir + (j << 8)) = 0xFFFFFFFFu;   // no timer pending
-        for (uint32_t i = 0; i < A * ST_WORDS; i++) st[i * 64] = t.init[i];
-        for (uint32_t a = 0; a < A; a++) hits |= invariant_hit_at(st, a, inv_kind, inv_fa, inv_va) << a;
-        if (REC) { rec = args.rec_out + sched * (uint64_t)args.rec_cap; n_rec = 0; next_id = 1; }
-        batch_no = 0;
-      }
-      // EventOrchestrator.inject_until_quiescence (:132-189).  Send events are not materialised:
-      // messagesToSend's external part is the index range [inj_lo, inj_hi) of the trace.
-      inj_lo = tidx;
-      if (!REC) {
-        // the batch's effect on the network state is a table lookup (computed once per workgroup)
-        const uint32_t* bt = s_batch + (size_t)batch_no * K1_BATCH_WORDS;
-        batch_no++;
-        tidx = bt[0];
-        net.inaccessible = bt[1]; net.killed = bt[2]; net.partitioned = (uint64_t)bt[3] | ((uint64_t)bt[4] << 32);
-        fl_off = bt[5] & 0xFFFFu; fl_cnt = bt[5] >> 16;
-        blocked &= ~bt[6];            // trigger_start: "allow scheduler to send messages to it again" (EventOrchestrator.scala:224-227)
-      }
-      bool loop = REC;     // the recording variant walks the events to emit their records
-      while (loop && tidx < E) {
-        const uint64_t ev = t.trace[tidx];
-        const uint32_t kind = (uint32_t)ev & 0xFF, a = (uint32_t)(ev >> 8) & 0xFF, b = (uint32_t)(ev >> 16) & 0xFF;
-        if (kind == DEMI_EV_START) {
-          REC_PUSH(DEMI_REC_SPAWN, 0, a, 0, 0, 0, 0, tidx, 0);
-          net.inaccessible &= ~(1u << a); net.killed &= ~(1u << a); blocked &= ~(1u << a);
-        } else if (kind == DEMI_EV_KILL) {
-          REC_PUSH(DEMI_REC_KILL, 0, a, 0, 0, 0, 0, tidx, 0);
-          net.killed |= 1u << a; net.inaccessible |= 1u << a;
-        } else if (kind == DEMI_EV_PARTITION) {
-          REC_PUSH(DEMI_REC_PARTITION, a, b, 0, 0, 0, 0, tidx, 0);
-          net.partitioned |= 1ULL << (a * 8 + b);
-        } else if (kind == DEMI_EV_UNPARTITION) {
-          REC_PUSH(DEMI_REC_UNPARTITION, a, b, 0, 0, 0, 0, tidx, 0);
-          net.partitioned &= ~(1ULL << (a * 8 + b));
-        } else if (kind == DEMI_EV_WAIT_QUIESCENCE) {
-          REC_PUSH(DEMI_REC_BEGIN_WAIT_QUIESCENCE, 0, 0, 0, 0, 0, 0, tidx, 0);
-          loop = false;
+      // ------------------------------------------------------------ (re)initialise + inject
+      if (ph == PH_INJECT) {
+        if (fresh) {
+          fresh = false;
+          // new execution: `new FullyRandom(seed)`; populateActorSystem isolates every created actor
+          // (ExternalEventInjector.scala:371-378)
+          const uint64_t seed = args.seeds ? args.seeds[sched] : args.seed_base + sched;
+          rng = jr_seed(seed);
+          te_rng = rng;                  // SrcDstFIFO: both generators are `new Random(seed)`
+          app_rng = jr_seed(0);
+          hash = 0xCBF29CE484222325ULL;
+          net.inaccessible = exists; net.killed = 0; net.partitioned = 0;
+          blocked = 0;
+          hits = 0;
+          for (uint32_t j = 0; j < k1_tdir_words(A, NTT); j++) *reinterpret_cast<uint32_t*>(tdir + (j << 8)) = 0xFFFFFFFFu;   // no timer pending
+          for (uint32_t i = 0; i < A * ST_WORDS; i++) st[i * 64] = t.init[i];
+          for (uint32_t a = 0; a < A; a++) hits |= invariant_hit_at(st, a, inv_kind, inv_fa, inv_va) << a;
+          if (REC) { rec = args.rec_out + sched * (uint64_t)args.rec_cap; n_rec = 0; next_id = 1; }
+          batch_no = 0;
         }
-        tidx++;
+        // EventOrchestrator.inject_until_quiescence (:132-189).  Send events are not materialised:
+        // messagesToSend's external part is the index range [inj_lo, inj_hi) of the trace.
+        inj_lo = tidx;
+        if (!REC) {
+          // the batch's effect on the network state is a table lookup (computed once per workgroup)
+          const uint32_t* bt = s_batch + (size_t)batch_no * K1_BATCH_WORDS;
+          batch_no++;
+          tidx = bt[0];
+          net.inaccessible = bt[1]; net.killed = bt[2]; net.partitioned = (uint64_t)bt[3] | ((uint64_t)bt[4] << 32);
+          reach = (uint64_t)bt[7] | ((uint64_t)bt[8] << 32);
+          fl_off = bt[5] & 0xFFFFu; fl_cnt = bt[5] >> 16;
+          blocked &= ~bt[6];            // trigger_start: "allow scheduler to send messages to it again" (EventOrchestrator.scala:224-227)
+        }
+        bool loop = REC;     // the recording variant walks the events to emit their records
+        while (loop && tidx < E) {
+          const uint64_t ev = t.trace[tidx];
+          const uint32_t kind = (uint32_t)ev & 0xFF, a = (uint32_t)(ev >> 8) & 0xFF, b = (uint32_t)(ev >> 16) & 0xFF;
+          if (kind == DEMI_EV_START) {
+            REC_PUSH(DEMI_REC_SPAWN, 0, a, 0, 0, 0, 0, tidx, 0);
+            net.inaccessible &= ~(1u << a); net.killed &= ~(1u << a); blocked &= ~(1u << a);
+          } else if (kind == DEMI_EV_KILL) {
+            REC_PUSH(DEMI_REC_KILL, 0, a, 0, 0, 0, 0, tidx, 0);
+            net.killed |= 1u << a; net.inaccessible |= 1u << a;
+          } else if (kind == DEMI_EV_PARTITION) {
+            REC_PUSH(DEMI_REC_PARTITION, a, b, 0, 0, 0, 0, tidx, 0);
+            net.partitioned |= 1ULL << (a * 8 + b);
+          } else if (kind == DEMI_EV_UNPARTITION) {
+            REC_PUSH(DEMI_REC_UNPARTITION, a, b, 0, 0, 0, 0, tidx, 0);
+            net.partitioned &= ~(1ULL << (a * 8 + b));
+          } else if (kind == DEMI_EV_WAIT_QUIESCENCE) {
+            REC_PUSH(DEMI_REC_BEGIN_WAIT_QUIESCENCE, 0, 0, 0, 0, 0, 0, tidx, 0);
+            loop = false;
+          }
+          tidx++;
+        }
+        inj_hi = tidx;
+        ph = PH_DISPATCH;
       }
-      inj_hi = tidx;
-      ph = PH_DISPATCH;
-    }
+    }   // service
 
     PH_MARK(1);
     // ------------------------------------------------------------ one scheduling step
@@ -468,7 +561,7 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
           if (slot + other >= PMAX) break;
           const word_t sw = s_bsend[off + i];
           if (slot < K1_HOT) (mem.pend - lane + src)[slot * 64] = sw;
-          else { (mem.spill - lane + src)[(size_t)(slot - K1_HOT) * mem.spill_stride] = sw; spilled = true; }
+          else { *spill_at(mem.spill, __umul24(slot - K1_HOT, mem.spill_stride) + (mem.spill_lane - lane + (uint32_t)src)) = sw; spilled = true; }
         }
       }
       // No fence after writing other lanes' spill slots: the owner lane belongs to this same wave, a wave's vector
@@ -482,7 +575,7 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
 #endif
       if (step && fl_cnt != 0) {
         if (n_pend + n_norm + fl_cnt > PMAX) { flags |= DEMI_V_PENDING_OVF; n_pend = PMAX - n_norm; }
-        else n_pend += fl_cnt;
+        else { n_pend += fl_cnt; LASTW_SET(s_bsend[fl_off + fl_cnt - 1]); }     // (an overflowing execution ends here)
         fl_cnt = 0;
       }
     }
@@ -549,7 +642,7 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
             const uint32_t i = jr_next_int(g, n_pend, t.magic);
             const word_t cw = pend_load(mem, i);
             const uint32_t cid = REC ? aux_load(mem, i) : 0u;
-            pend_remove(i, cw, pend_load(mem, n_pend - 1));
+            pend_remove(i, cw, LASTW());
             if ((blocked >> w_dst(cw)) & 1u) {           // set aside in the slot this removal just freed
               pend_store(mem, n0 - 1 - k, cw);
               if (REC) aux_store(mem, n0 - 1 - k, cid);
@@ -574,6 +667,7 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
               if (REC) aux_store(mem, n0 - k - 1 + j, aux_load(mem, n0 - k + j));
             }
           n_pend = n0 - (found ? 1u : 0u);
+          LASTW_RELOAD();
           tdir_rebuild();                                // which slot holds which timer message, from scratch
           return found;
         };
@@ -616,9 +710,8 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
           }
           if (from_te) {
             w = pend_load(mem, idx);
-            const word_t lastw = pend_load(mem, n_pend - 1);
             if (REC) wid = aux_load(mem, idx);
-            pend_remove(idx, w, lastw);
+            pend_remove(idx, w, LASTW());
           } else {
             fifo_dequeue(jr_next_int(rng, n_pairs, t.magic));
           }
@@ -629,12 +722,11 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
         REC_PUSH(DEMI_REC_MSG_EVENT, w_src(w), me, type, w_p0(w), w_p1(w), 0, 255, wid);
         hash_step(hash, w);
         // updateRepeatingTimer (:405-421) and the Instrumenter's retrigger (Instrumenter.scala:1008-1016)
-        const uint32_t meta = t.meta[type];
-        const uint32_t tbit = 1u << (me * DEMI_MAX_TIMER_TYPES + (meta >> 8));
-        const bool is_rep = ((meta & 0xFF) == DEMI_MSG_TIMER) && (rep & tbit);
+        const uint32_t tbit = TIMER_BIT(me, type);
+        const bool is_rep = ((timer_types >> type) & 1u) && (rep & tbit);
         if (is_rep) {
           just |= tbit;
-          enqueue_timer(me, type);      // parked in timersToResend (it is in justScheduledTimers)
+          enqueue_timer(me, type, tbit);      // parked in timersToResend (it is in justScheduledTimers)
         } else {
           // timersToResend re-enter messagesToSend in order (RandomScheduler.scala:416-419): one shifted OR
           if (n_resend != 0) {
@@ -676,12 +768,8 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
     auto send_targets = [&](uint32_t fx) -> uint32_t {    // (the low word of the effect: op, type, target)
       const bool bc = ((fx & 31u) == DEMI_OP_BCAST);
       const uint32_t target = (fx >> 10) & 15u;
-      uint32_t tm = bc ? (exists & ~(1u << me)) : ((1u << target) & exists & 0xFFu);
-      const uint32_t row = (uint32_t)(net.partitioned >> (me * 8)) & 0xFFu;
-      const uint32_t col = (uint32_t)((((net.partitioned >> me) & 0x0101010101010101ULL) * 0x0102040810204080ULL) >> 56);
-      uint32_t blocked = row | col | net.inaccessible | (((net.inaccessible >> me) & 1u) ? 0xFFu : 0u);
-      if (!((net.killed >> me) & 1u)) blocked &= ~(1u << me);      // snd == rcv && !killed: never crosses
-      return tm & ~blocked;
+      const uint32_t tm = bc ? ~(1u << me) : (1u << target);       // (target 15 = nobody: outside the matrix row)
+      return tm & (uint32_t)(reach >> (me * 8)) & 0xFFu;           // created, and not cut off from `me` (reach_of above)
     };
     // event_produced for internal messages (:287-297): dropped at send time when crosses_partition, else appended
     auto apply_send = [&](word_t fxw) {
@@ -740,7 +828,7 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
         if (d != TD_NONE) {
           const word_t wantw = msg_word(type, DEMI_DEADLETTERS, me, 0, 0);
           if (d != TD_MANY) {
-            pend_remove(d, wantw, pend_load(mem, n_pend - 1));
+            pend_remove(d, wantw, LASTW());
           } else {
             // several copies were pending at some point: scan.  The scan also counts the copies, so the entry becomes exact
             // again when at most one is left after this removal.
@@ -752,7 +840,7 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
               }
             if (copies != 0) {
               const uint32_t last = n_pend - 1;
-              pend_remove(first, wantw, pend_load(mem, last));   // (the entry is TD_MANY: pend_remove leaves it alone)
+              pend_remove(first, wantw, LASTW());   // (the entry is TD_MANY: pend_remove leaves it alone)
               if (copies == 2) *p = (unsigned char)(second == last ? first : second);
             }
             if (copies <= 1) *p = (unsigned char)TD_NONE;
@@ -764,7 +852,7 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
     auto apply_timer_set = [&](bool repeating, uint32_t type, uint32_t bit) {      // bit = TIMER_BIT(me, type)
       if (!(rep & bit)) {               // else "Non-unique timer" (:1154-1157)
         if (repeating) rep |= bit;
-        enqueue_timer(me, type);
+        enqueue_timer(me, type, bit);
       }
     };
     if (deliver) {      // every effect row in program order
@@ -772,9 +860,9 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
       // A table compiled with an effect schedule (jit.hpp fx_schedule): every effect row has a fixed slot whose class -
       // send, or (timer op, timer type) - is a compile-time constant, slots increase along every path of every handler
       // (program order), and `nfx` is the mask of the slots this delivery filled: one straight pass, each body once.
-#define DEMI_FX_SLOT(J, KIND, OP, TYPE, TIDX)                                                                         \
+#define DEMI_FX_SLOT(J, KIND, OP, TYPE, TIDX, Q)                                                                      \
       if (((nfx >> (J)) & 1u) && !(flags & DEMI_OVF_ANY)) {                                                           \
-        if ((KIND) == 0u) { apply_send(mem.fxq[(J) * 64]); PH_MARK(6); }                                               \
+        if ((KIND) == 0u) { apply_send(mem.fxq[(Q) * 64]); PH_MARK(6); }     /* (Q: the slot's entry of the effect queue) */ \
         else if ((KIND) == 1u) { apply_cancel((TYPE), 1u << (me * DEMI_MAX_TIMER_TYPES + (TIDX)), (TIDX)); PH_MARK(7); } \
         else if ((KIND) == 2u) { apply_timer_set((OP) == DEMI_OP_TREP, (TYPE), 1u << (me * DEMI_MAX_TIMER_TYPES + (TIDX))); PH_MARK(8); } \
         else if (CRASHES) blocked |= 1u << me;                                                                        \
@@ -797,27 +885,6 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
     }
 
     PH_MARK(9);
-    // ------------------------------------------------------------ verdict
-    if (ph == PH_FINISH) {
-      // explore(): `if (messagesScheduledSoFar <= maxMessages) checkIfBugFound` (:256-262, 156-180)
-      if (!(flags & (DEMI_OVF_ANY | DEMI_V_MAXMSG)) && !viol) viol = check_invariant();
-      for (uint32_t i = 0; i < A * ST_WORDS; i++) hash_step(hash, st[i * 64]);
-      uint4 v;
-      if (flags & DEMI_OVF_ANY) {
-        v.x = flags & DEMI_OVF_ANY; v.y = 0; v.z = 0; v.w = 0;
-      } else {
-        v.x = (flags & 0xFF) | (viol ? DEMI_V_VIOLATION : 0u) | ((tidx & 0xFF) << 8) | ((count < 0xFFFFu ? count : 0xFFFFu) << 16);
-        v.y = viol; v.z = (uint32_t)hash; v.w = (uint32_t)(hash >> 32);
-      }
-      *reinterpret_cast<uint4*>(&args.out[sched]) = v;
-      if (REC) args.rec_count[sched] = n_rec;
-      // reset the simulator for the next schedule
-      ph = PH_IDLE;
-      n_pend = 0; count = 0; cnt_mod = 0; tidx = 0; inj_lo = 0; inj_hi = 0; batch_no = 0;
-      tq = 0; resend = 0; n_tq = 0; n_resend = 0; just = 0; rep = 0; viol = 0; flags = 0; hash = 0;
-      n_norm = 0; n_pairs = 0; pairmask = 0;
-    }
-    PH_MARK(10);
   }
 #ifdef DEMI_K1_PHASES
   PH_MARK(11);
@@ -831,6 +898,9 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
 #undef REC_PUSH
 #undef PEND_APPEND
 #undef NORM_APPEND
+#undef LASTW
+#undef LASTW_SET
+#undef LASTW_RELOAD
 #undef TIMER_BIT
 }
 

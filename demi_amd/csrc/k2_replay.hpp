@@ -120,7 +120,7 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
                         (size_t)wave * k2_fp_wave_bytes(t.A, args.n_fp, MODE == K2_FP_LDS);
     mem.st = reinterpret_cast<uint64_t*>(wb) + lane;
     mem.fxq = reinterpret_cast<uint32_t*>(wb + (size_t)t.A * 64 * 8) + lane;
-    mem.pend = nullptr; mem.pend_aux = nullptr; mem.spill = nullptr; mem.spill_aux = nullptr; mem.spill_stride = 0; mem.hot = 0;
+    mem.pend = nullptr; mem.pend_aux = nullptr; mem.spill = nullptr; mem.spill_aux = nullptr; mem.spill_stride = 0; mem.spill_lane = 0; mem.hot = 0;
     if (MODE == K2_FP_LDS) cnt = wb + (size_t)t.A * 64 * 8 + (size_t)DEMI_FX_CAP * 64 * 4 + lane;
     else { cnt_stride = (size_t)gridDim.x * blockDim.x; cnt = args.fp_counts + (size_t)blockIdx.x * blockDim.x + threadIdx.x; }
   } else {

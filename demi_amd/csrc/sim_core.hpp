@@ -130,15 +130,21 @@ struct LaneMem {
   word_t* pend;        // [PEND_HOT]   pending message words (LDS)
   uint32_t* pend_aux;  // [PEND_HOT]   optional parallel array (ids / sequence numbers), may be null
   word_t* fxq;         // [FX_CAP]     effect rows recorded by the current delivery (LDS)
-  word_t* spill;       // global: slot s >= PEND_HOT lives at spill[(s - PEND_HOT) * spill_stride]
-  uint32_t* spill_aux; // global, parallel to spill (may be null)
-  uint32_t spill_stride;
+  // global scratch: slot s >= hot of this lane is spill[(s - hot) * spill_stride + spill_lane].  The base pointers are the
+  // same for every lane (scalar registers) and the index is 32 bits (128 slots x < 2^24 lanes), so an access is one
+  // multiply-add for the offset instead of a 64-bit multiply and a 64-bit add
+  word_t* spill;
+  uint32_t* spill_aux; // parallel to spill (may be null)
+  uint32_t spill_stride, spill_lane;
   uint32_t hot;        // slots below `hot` live in LDS (PEND_HOT, or less where occupancy is worth more than residency)
 };
 
-__host__ __device__ inline size_t lane_mem_wave_bytes(uint32_t n_actors, bool aux, uint32_t hot = PEND_HOT, bool wide = WIDE_TU) {
+// fxq_slots: entries of the effect queue (DEMI_FX_CAP; a K1 compiled with an effect-slot schedule only stores its SEND /
+// BCAST slots, jit.hpp fx_schedule)
+__host__ __device__ inline size_t lane_mem_wave_bytes(uint32_t n_actors, bool aux, uint32_t hot = PEND_HOT, bool wide = WIDE_TU,
+                                                      uint32_t fxq_slots = DEMI_FX_CAP) {
   const size_t wb = wide ? 8 : 4;     // bytes per message / effect word
-  return (size_t)n_actors * 64 * 8 * (wide ? 2 : 1) + (size_t)hot * 64 * (wb + (aux ? 4 : 0)) + (size_t)DEMI_FX_CAP * 64 * wb;
+  return (size_t)n_actors * 64 * 8 * (wide ? 2 : 1) + (size_t)hot * 64 * (wb + (aux ? 4 : 0)) + (size_t)fxq_slots * 64 * wb;
 }
 // HBM scratch words for `lanes` simulators (per array)
 __host__ __device__ inline size_t spill_words(size_t lanes, uint32_t hot = PEND_HOT) { return lanes * (DEMI_MAX_PENDING - hot); }
@@ -163,34 +169,44 @@ __device__ inline LaneMem lane_mem_carve(unsigned char* wave_base, uint32_t n_ac
   // time, where one [slot][64] block per wave (DEMI_SPILL_WAVE_BLOCKS, kept for A/B runs: 32 KB stride with only the first
   // few KB of each block live) is 4.37 ms in some processes and 4.58 ms in others with the same binary, depending on
   // where the allocation happens to lie physically
-  m.spill = g_spill + global_lane;
-  m.spill_aux = aux ? g_aux + global_lane : nullptr;
+  m.spill = g_spill;
+  m.spill_aux = aux ? g_aux : nullptr;
   m.spill_stride = (uint32_t)total_lanes;
+  m.spill_lane = (uint32_t)global_lane;
 #else
-  const size_t block = (global_lane >> 6) * ((size_t)(DEMI_MAX_PENDING - hot) * 64);
-  m.spill = g_spill + block + lane;
-  m.spill_aux = aux ? g_aux + block + lane : nullptr;
+  m.spill = g_spill;
+  m.spill_aux = aux ? g_aux : nullptr;
   m.spill_stride = 64;
+  m.spill_lane = (uint32_t)((global_lane >> 6) * ((size_t)(DEMI_MAX_PENDING - hot) * 64) + lane);
 #endif
   m.hot = hot;
   return m;
 }
 
+// (slot < 2^7, stride < 2^24: the 24-bit multiply-add is exact and full rate; the BYTE offset stays below 2^32 - 128 slots x
+// < 2^22 lanes x 8 bytes - and is formed in 32 bits so that the access is scalar base + 32-bit vector offset)
+__device__ __forceinline__ uint32_t spill_index(const LaneMem& m, uint32_t slot) {
+  return __umul24(slot - m.hot, m.spill_stride) + m.spill_lane;
+}
+template <typename T>
+__device__ __forceinline__ T* spill_at(T* base, uint32_t index) {
+  return reinterpret_cast<T*>(reinterpret_cast<unsigned char*>(base) + (uint32_t)(index * (uint32_t)sizeof(T)));
+}
 __device__ __forceinline__ word_t pend_load(const LaneMem& m, uint32_t slot) {
   if (slot < m.hot) return m.pend[slot * 64];
-  return m.spill[(size_t)(slot - m.hot) * m.spill_stride];
+  return *spill_at(m.spill, spill_index(m, slot));
 }
 __device__ __forceinline__ void pend_store(const LaneMem& m, uint32_t slot, word_t v) {
   if (slot < m.hot) m.pend[slot * 64] = v;
-  else m.spill[(size_t)(slot - m.hot) * m.spill_stride] = v;
+  else *spill_at(m.spill, spill_index(m, slot)) = v;
 }
 __device__ __forceinline__ uint32_t aux_load(const LaneMem& m, uint32_t slot) {
   if (slot < m.hot) return m.pend_aux[slot * 64];
-  return m.spill_aux[(size_t)(slot - m.hot) * m.spill_stride];
+  return *spill_at(m.spill_aux, spill_index(m, slot));
 }
 __device__ __forceinline__ void aux_store(const LaneMem& m, uint32_t slot, uint32_t v) {
   if (slot < m.hot) m.pend_aux[slot * 64] = v;
-  else m.spill_aux[(size_t)(slot - m.hot) * m.spill_stride] = v;
+  else *spill_at(m.spill_aux, spill_index(m, slot)) = v;
 }
 
 // ------------------------------------------------------------------ row interpreter

@@ -44,7 +44,7 @@ def _fx_schedule(src):
     line = [l for l in src.splitlines() if l.startswith("#define DEMI_JIT_FX_APPLY")]
     if not line:
         return None
-    return [(int(k), int(op), int(t)) for _, k, op, t, _ in re.findall(r"DEMI_FX_SLOT\((\d+), (\d+)u, (\d+)u, (\d+)u, (\d+)u\)", line[0])]
+    return [(int(k), int(op), int(t), int(q)) for _, k, op, t, _, q in re.findall(r"DEMI_FX_SLOT\((\d+), (\d+)u, (\d+)u, (\d+)u, (\d+)u, (\d+)u\)", line[0])]
 
 
 def _host_vm(model, tmp_path, k1=False):
@@ -112,7 +112,7 @@ def test_generated_handlers_equal_the_row_interpreter(oracle, tmp_path, name, mk
         assert int(st[me * 64]) == want_state.value, (it, me, typ, hex(state))
         got = []
         for k in (range(n) if sched is None else [j for j in range(len(sched)) if (n >> j) & 1]):
-            f = int(fxq[k * 64])
+            f = int(fxq[(k if sched is None else sched[k][3]) * 64])     # (a send slot's entry of the effect queue)
             op, t_, target, q0, q1 = f & 31, (f >> 5) & 31, (f >> 10) & 15, (f >> 14) & 255, (f >> 22) & 255
             if sched is not None and sched[k][0] != 0:       # a timer slot carries no data: the slot is the row
                 op, t_ = sched[k][1], sched[k][2]
@@ -245,7 +245,7 @@ def test_random_programs_through_the_code_generator(oracle, tmp_path, seed, ifco
         assert not flags.value and int(st[me * 64]) == want_state.value, (it, me, typ, hex(state))
         got = []
         for k in (range(n) if sched is None else [j for j in range(len(sched)) if (n >> j) & 1]):
-            f = int(fxq[k * 64])
+            f = int(fxq[(k if sched is None else sched[k][3]) * 64])     # (a send slot's entry of the effect queue)
             op, t_, target, q0, q1 = f & 31, (f >> 5) & 31, (f >> 10) & 15, (f >> 14) & 255, (f >> 22) & 255
             if sched is not None and sched[k][0] != 0:       # a timer slot carries no data: the slot is the row
                 op, t_ = sched[k][1], sched[k][2]

@@ -6,6 +6,9 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 cp demi_amd/libdemi_gpu.so /tmp/libdemi_gpu.so.keep
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -pthread -ldl -DDEMI_K1_PHASES -o demi_amd/libdemi_gpu.so demi_amd/csrc/demi_gpu.hip
-python bench.py --steps 2 --warmup 1 --no-cpu-baseline ${BENCH_ARGS} 2>&1 | grep -E "k1 phases|value" | tail -2 | cut -c1-700
-python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-specialize ${BENCH_ARGS} 2>&1 | grep -E "k1 phases|value" | tail -2 | cut -c1-700
+# (the headline launches only: --no-secondary, and of those the last one)
+python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-prewarm ${BENCH_ARGS} 2>&1 | grep -E "k1 phases" | grep -v "waves=4 " | tail -1 | cut -c1-700
+if [ -z "$PHASES_JIT_ONLY" ]; then
+python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-prewarm --no-specialize ${BENCH_ARGS} 2>&1 | grep -E "k1 phases" | grep -v "waves=4 " | tail -1 | cut -c1-700
+fi
 cp /tmp/libdemi_gpu.so.keep demi_amd/libdemi_gpu.so
