@@ -45,7 +45,19 @@ def roofline(bound_bytes, kernel_ms, traffic, kernel, note, extra=None):
     return r
 
 
-def bench_dpor(ctx_device, cpu_baseline=True, batch=16384):
+def _seq_digest(verdicts):
+    """Order-sensitive 64-bit digest of a verdict array (flags, fingerprint, hash of every entry in sequence)."""
+    import numpy as np
+    if not len(verdicts):
+        return 0
+    idx = np.arange(1, len(verdicts) + 1, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        x = (verdicts["hash"] ^ (verdicts["flags"].astype(np.uint64) << np.uint64(32)) ^ verdicts["fingerprint"].astype(np.uint64)) * \
+            (idx * np.uint64(0x9E3779B97F4A7C15) | np.uint64(1))
+    return int(np.bitwise_xor.reduce(x))
+
+
+def bench_dpor(ctx_device, cpu_baseline=True, batch=16384, orders=("rounds", "reference_order")):
     """BASELINE config 3: the whole bounded DPOR exploration of raft5 (depth 30, Start x 5 + Send x 5)."""
     import numpy as np
     from demi_amd import types as T
@@ -60,6 +72,8 @@ def bench_dpor(ctx_device, cpu_baseline=True, batch=16384):
     from demi_amd import _native
     par = T.DporParams(depth, 0, 0, 0, 64, 4096)
     for name, ref in (("rounds", False), ("reference_order", True)):
+        if name not in orders:
+            continue
         # timed: demi_dpor_explore itself, the C entry point a JVM host binds (the Python mirror DPORwHeuristics.explore_native
         # wraps the same call and then builds one object per interleaving, which is not the library's time)
         ctx = _native.Context(ctx_device)
@@ -74,6 +88,8 @@ def bench_dpor(ctx_device, cpu_baseline=True, batch=16384):
         verdicts, plen, rounds, vtrace, st = ctx.dpor_explore(par, srch)
         dt = time.perf_counter() - t
         runs[name] = {"value": len(verdicts) / dt, "seconds": dt, "interleavings": len(verdicts),
+                      "mean_prefix_len": float(np.mean(plen)) if len(plen) else 0.0, "backtrack_points": int(st.backtrack_points),
+                      "sequence_digest": "%016x" % _seq_digest(verdicts),
                       "executed_on_device": int(st.executed), "launches": int(st.launches), "exhausted": bool(st.exhausted),
                       "violations": int(np.count_nonzero(verdicts["flags"] & T.V_VIOLATION)),
                       "distinct_schedules": int(len(np.unique(verdicts["hash"]))),
@@ -81,36 +97,140 @@ def bench_dpor(ctx_device, cpu_baseline=True, batch=16384):
         if ref:
             runs[name]["launches_for_results_the_speculation_lacked"] = int(st.cache_misses)
         ctx.close()
-    out["value"] = runs["rounds"]["value"]
+    first = "rounds" if "rounds" in runs else next(iter(runs))
+    out["value"] = runs[first]["value"]
     out["orders"] = runs
-    r = runs["rounds"]
-    # algorithmic HBM bytes of a round's kernels (k3_dpor + k3_pairs_mark / insert / decide), summed over the exploration:
-    # per interleaving the finished trace written to the arena (16 B x ~190 events) and read back by the pair kernels, its
-    # racing pairs written and read twice (4 B each, ~600 after the shared-prefix filter), one 64 B table entry touched
-    # per pair by insert and one by decide, 8 B item in, 16 B verdict out
+    r = runs[first]
+    # algorithmic bytes per interleaving = 4 x depth (its prefix in) + 8 (verdict out) + 12 x r (its r new
+    # backtrack points out), with the MEASURED mean prefix length and r = backtrack points enqueued / interleavings.  What the
+    # kernels additionally move inside HBM (finished traces into the arena and back into the pair kernels, racing pairs, one
+    # 64-byte explored-pair entry per pair) is working-set traffic, reported beside it as a model and, when a counters profile of
+    # this workload exists (tools/profile_r3.sh dpor passes), as measured `traffic` - never as algorithmic bytes.
     n_il = r["interleavings"]
-    alg = n_il * (2 * 16 * 190 + 600 * (3 * 4 + 2 * 64) + 8 + 16)
-    out["roofline"] = roofline(alg, r["kernel_ms_total"], None,
+    per_il = 4.0 * r["mean_prefix_len"] + 8.0 + 12.0 * (r["backtrack_points"] / max(1, n_il))
+    alg = n_il * per_il
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r03_dpor_counters.json")) as f:
+            traffic = json.load(f).get("fabric_bytes_per_exploration")
+    except (OSError, ValueError):
+        pass
+    out["roofline"] = roofline(alg, r["kernel_ms_total"], traffic,
                                "k3_dpor + k3_pairs_mark/insert/decide (specialised, hiprtc), %d rounds" % r["launches"],
-                               "ROUNDS order, bookkeeping on the device: explored-pair table, enqueue decision and the traces stay in "
-                               "HBM; %d B up and %d B down over PCIe for the whole exploration. kernel_ms = sum over the rounds (HIP "
-                               "events in the library). Latency / issue bound: a round of the backtrack queue is far smaller than the "
-                               "chip" % (r["h2d_bytes"], r["d2h_bytes"]))
+                               "ROUNDS order. Algorithmic bytes per SURVEY 8(d): 4 x mean prefix length (%.1f events) + 8 + 12 x r "
+                               "(r = %.2f backtrack points per interleaving) = %.0f B per interleaving. kernel_ms = sum over the "
+                               "rounds (HIP events in the library). Latency / issue bound: a round of the backtrack queue is far "
+                               "smaller than the chip" % (r["mean_prefix_len"], r["backtrack_points"] / max(1, n_il), per_il),
+                               {"working_set_bytes_model": n_il * (2 * 16 * 190 + 600 * (3 * 4 + 2 * 64) + 8 + 16),
+                                "working_set_note": "model of what the round's kernels move inside HBM per interleaving: the finished trace "
+                                                    "(16 B x ~190 events) written to the arena and read by the pair kernels, ~600 racing pairs "
+                                                    "written and read twice (4 B), one 64 B explored-pair entry per pair in insert and in decide",
+                                "pcie_bytes": {"h2d": r["h2d_bytes"], "d2h": r["d2h_bytes"]},
+                                "reference_order": None if "reference_order" not in runs else
+                                {"algorithmic_bytes": runs["reference_order"]["interleavings"] *
+                                 (4.0 * runs["reference_order"]["mean_prefix_len"] + 8.0 + 12.0 * runs["reference_order"]["backtrack_points"] /
+                                  max(1, runs["reference_order"]["interleavings"])),
+                                 "kernel_ms_total": runs["reference_order"]["kernel_ms_total"],
+                                 "pcie_bytes": {"h2d": runs["reference_order"]["h2d_bytes"], "d2h": runs["reference_order"]["d2h_bytes"]}}})
     if cpu_baseline:
         from oracle import oracle_py as O
         cores = os.cpu_count() or 1
         base = {}
         for name, ref in (("rounds", False), ("reference_order", True)):
+            if name not in orders:
+                continue
             srch = T.DporSearch(batch, 1 << 17, 0, 1, T.DPOR_ORDER_REFERENCE if ref else T.DPOR_ORDER_ROUNDS)
             t = time.perf_counter()
             v, plen, rounds, vt, st, secs = O.dpor_explore(model, ev, par, srch, n_threads=cores)
             dt = time.perf_counter() - t
-            base[name] = {"value": len(v) / dt, "seconds": dt, "interleavings": len(v)}
-        out["cpu_baseline"] = {"value": base["rounds"]["value"], "unit": "interleavings/s", "cores": cores, "kind": "port",
+            base[name] = {"value": len(v) / dt, "seconds": dt, "interleavings": len(v), "sequence_digest": "%016x" % _seq_digest(v)}
+        out["cpu_baseline"] = {"value": base[first]["value"], "unit": "interleavings/s", "cores": cores, "kind": "port",
                                "sample": "the same whole exploration: oracle/demi_oracle.c interleavings on %d host threads (one next "
                                          "trace per thread) under the same host bookkeeping (demi_amd/csrc/dpor_host.hpp)" % cores,
                                "orders": base,
-                               "same_interleaving_count_as_gpu": {k: base[k]["interleavings"] == runs[k]["interleavings"] for k in base}}
+                               "same_interleaving_count_as_gpu": {k: base[k]["interleavings"] == runs[k]["interleavings"] for k in base},
+                               # every verdict (flags, fingerprint, delivery hash) in exploration order, GPU = oracle
+                               "same_verdict_sequence_as_gpu": {k: base[k]["sequence_digest"] == runs[k]["sequence_digest"] for k in base}}
+    return out
+
+
+def bench_config1(ctx_device, cpu_baseline=True):
+    """BASELINE config 1 restated: raft3-synth, 20-event trace, RandomScheduler, 100 schedules - the reference's own
+    CPU-runnable case.  The reference's akka-raft / JVM cannot run here: the oracle on ONE thread stands in for it and is
+    labelled as such; the same 100 schedules through the GPU path are checked bit for bit and timed beside it (a launch of
+    100 schedules is launch-latency, not throughput)."""
+    import numpy as np
+    from demi_amd import _native, types as T
+    from demi_amd.apps import SEED_BASE, raft3_config1
+    model, events, limits = raft3_config1()
+    n = 100
+    ctx = _native.Context(ctx_device)
+    ctx.model_load(model.to_struct())
+    ctx.trace_load(events)
+    ctx.model_specialize()
+    got = ctx.random_explore(n, limits, seed_base=SEED_BASE)
+    reps = 20
+    t = time.perf_counter()
+    for _ in range(reps):
+        got = ctx.random_explore(n, limits, seed_base=SEED_BASE)
+    dt = (time.perf_counter() - t) / reps
+    ctx.close()
+    out = {"metric": "candidate schedules evaluated/sec, config 1 (raft3-synth, RandomScheduler, 100 schedules)", "unit": "schedules/s",
+           "value": n / dt, "seconds_per_100_schedules": dt,
+           "config": {"workload": "raft3-synth, 3 actors, frozen 20-event trace, 100 schedules per call through demi_random_explore "
+                                  "(host buffers: what a JVM caller gets)", "max_messages": int(limits.max_messages)},
+           "violations": int(np.count_nonzero(got["flags"] & T.V_VIOLATION))}
+    if cpu_baseline:
+        from oracle import oracle_py as O
+        O.random_explore(model, events, n, seed_base=SEED_BASE, limits=limits, n_threads=1)
+        t = time.perf_counter()
+        for _ in range(reps):
+            cpu = O.random_explore(model, events, n, seed_base=SEED_BASE, limits=limits, n_threads=1)
+        dc = (time.perf_counter() - t) / reps
+        out["cpu_baseline"] = {"value": n / dc, "unit": "schedules/s", "cores": 1, "kind": "port",
+                               "sample": "the same 100 schedules, oracle/demi_oracle.c on one thread (restated CPU baseline, never "
+                                         "'DEMi JVM': no JVM / akka-raft in this image)", "seconds": dc,
+                               "bit_identical_to_gpu": bool((cpu == got).all())}
+    return out
+
+
+def bench_config5(ctx_device, cpu_baseline=True, max_interleavings=1 << 17, batch=16384):
+    """BASELINE config 5: shuffle8-synth (8 actors, 3 classes), bounded DPOR exploration - single GPU here (the 8-GPU form is
+    demi_dpor_explore with a communicator: the explored-pair table sharded by owner)."""
+    import numpy as np
+    from demi_amd import _native, types as T
+    from demi_amd.apps import shuffle8_config5
+    model, dpor_events, _fuzz_events, _lim = shuffle8_config5()
+    par = T.DporParams(40, 0, 0, 0, 64, 4096)
+    srch = T.DporSearch(batch, max_interleavings, 0, 1, T.DPOR_ORDER_ROUNDS)
+    ctx = _native.Context(ctx_device)
+    ctx.model_load(model.to_struct())
+    ctx.model_specialize()
+    ctx.dpor_load(dpor_events)
+    ctx.dpor_explore(par, srch)
+    t = time.perf_counter()
+    verdicts, plen, rounds, vtrace, st = ctx.dpor_explore(par, srch)
+    dt = time.perf_counter() - t
+    ctx.close()
+    n_il = len(verdicts)
+    per_il = 4.0 * float(np.mean(plen)) + 8.0 + 12.0 * (int(st.backtrack_points) / max(1, n_il))
+    out = {"metric": "interleavings explored/sec, bounded DPOR (shuffle8-synth, depth 40)", "unit": "interleavings/s",
+           "value": n_il / dt, "seconds": dt, "interleavings": n_il, "exhausted": bool(st.exhausted), "launches": int(st.launches),
+           "violations": int(np.count_nonzero(verdicts["flags"] & T.V_VIOLATION)), "sequence_digest": "%016x" % _seq_digest(verdicts),
+           "config": {"workload": "shuffle8-synth (2-stage shuffle stand-in, 8 actors, 3 actor classes), Start x 8 + Submit + Speculate, "
+                                  "depth_bound 40, ROUNDS of %d, at most %d interleavings" % (batch, max_interleavings)},
+           "roofline": roofline(n_il * per_il, float(st.kernel_ms), None, "k3_dpor + k3_pairs_* (specialised)",
+                                "SURVEY 8(d): 4 x mean prefix (%.1f) + 8 + 12 x r (%.2f) B per interleaving" %
+                                (float(np.mean(plen)), int(st.backtrack_points) / max(1, n_il)))}
+    if cpu_baseline:
+        from oracle import oracle_py as O
+        cores = os.cpu_count() or 1
+        t = time.perf_counter()
+        v, _pl, _r, _vt, _st, _s = O.dpor_explore(model, dpor_events, par, srch, n_threads=cores)
+        dc = time.perf_counter() - t
+        out["cpu_baseline"] = {"value": len(v) / dc, "unit": "interleavings/s", "cores": cores, "kind": "port", "seconds": dc,
+                               "sample": "the same exploration, oracle interleavings on %d host threads under the same host bookkeeping" % cores,
+                               "same_verdict_sequence_as_gpu": "%016x" % _seq_digest(v) == out["sequence_digest"]}
     return out
 
 
@@ -190,6 +310,19 @@ def bench_ddmin(ctx_device, cpu_baseline=True, n=1 << 20):
                                "oracle_consultations": len(dd.consulted), "launches": len(dd.batches),
                                "replays_launched": int(dd.speculative_replays)}
     sts.shutdown()
+    # RunnerUtils.randomDDMin (RunnerUtils.scala:601-623): DDMin whose oracle is the RandomScheduler itself, R = 100 random
+    # interleavings per candidate: every consultation is one K1 launch of R executions
+    try:
+        from demi_amd.minification import randomDDMin
+        randomDDMin(SchedulerConfig(model=model), EventTrace(rec, used), fp, max_executions=100, seed_base=SEED_BASE)
+        t = time.perf_counter()
+        mcs_r, dd_r, _v = randomDDMin(SchedulerConfig(model=model), EventTrace(rec, used), fp, max_executions=100, seed_base=SEED_BASE)
+        dtr = time.perf_counter() - t
+        n_cons = len(dd_r.consulted) if hasattr(dd_r, "consulted") else None
+        out["random_ddmin_R100"] = {"seconds": dtr, "mcs_len": len(mcs_r), "oracle_consultations": n_cons,
+                                    "executions": (n_cons or 0) * 100, "executions_per_s": ((n_cons or 0) * 100 / dtr) if dtr else None}
+    except Exception as e:           # never let a side measurement cost the record
+        out["random_ddmin_R100"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if cpu_baseline:
         from oracle import oracle_py as O
         cores = os.cpu_count() or 1
@@ -249,7 +382,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", choices=["fuzz", "dpor", "ddmin"], default="fuzz")
+    ap.add_argument("--workload", choices=["fuzz", "dpor", "ddmin", "config1", "config5"], default="fuzz")
+    ap.add_argument("--dpor-order", choices=["both", "rounds", "reference_order"], default="both",
+                    help="--workload dpor: which exploration order(s) to run (profiling passes use one)")
     ap.add_argument("--schedules", type=int, default=N_PER_GPU, help="schedules per GPU per step")
     ap.add_argument("--p-max", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -285,9 +420,12 @@ def main():
 
     if args.workload != "fuzz":
         assert world == 1, "the dpor / ddmin records are single-GPU"
-        fn = bench_dpor if args.workload == "dpor" else bench_ddmin
+        fn = {"dpor": bench_dpor, "ddmin": bench_ddmin, "config1": bench_config1, "config5": bench_config5}[args.workload]
         t = time.perf_counter()
-        rec = fn(local_rank, cpu_baseline=not args.no_cpu_baseline)
+        if args.workload == "dpor" and args.dpor_order != "both":
+            rec = fn(local_rank, cpu_baseline=not args.no_cpu_baseline, orders=(args.dpor_order,))
+        else:
+            rec = fn(local_rank, cpu_baseline=not args.no_cpu_baseline)
         rec.update({"n_gpus": 1, "steps": 1, "warmup": 1, "ms_per_step": (time.perf_counter() - t) * 1e3, "higher_is_better": True,
                     "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic"})
         print(json.dumps(rec))
@@ -518,15 +656,24 @@ def main():
             cpu = O.random_explore(model, events, m, seed_base=SEED_BASE, limits=limits, n_threads=cores)
             tcpu = time.perf_counter() - tc
             same = bool((cpu == verdicts[:m].cpu().numpy().view(T.VERDICT_DTYPE).reshape(-1)).all())
+            # the oracle on ONE thread as well (what a single JVM scheduler corresponds to: the reference cannot
+            # use more than one core for executions, Instrumenter.scala:1289-1296)
+            m1 = min(m, 1 << 15)
+            t1 = time.perf_counter()
+            cpu1 = O.random_explore(model, events, m1, seed_base=SEED_BASE, limits=limits, n_threads=1)
+            t1 = time.perf_counter() - t1
             out["cpu_baseline"] = {"value": m / tcpu, "unit": "schedules/s", "cores": cores, "kind": "port",
                                    "sample": "first %d schedules of the same workload, oracle/demi_oracle.c with %d "
                                              "pthreads (restated CPU oracle, not the DEMi JVM)" % (m, cores),
-                                   "seconds": tcpu, "bit_identical_to_gpu": same}
+                                   "seconds": tcpu, "bit_identical_to_gpu": same,
+                                   "single_thread": {"value": m1 / t1, "unit": "schedules/s", "cores": 1, "seconds": t1,
+                                                     "sample": "first %d schedules, one thread" % m1,
+                                                     "bit_identical_to_gpu": bool((cpu1 == verdicts[:m1].cpu().numpy().view(T.VERDICT_DTYPE).reshape(-1)).all())}}
     ctx.close()
     if rank == 0:
         if world == 1 and not args.no_secondary:
             sec = {}
-            for name, fn in (("dpor", bench_dpor), ("ddmin", bench_ddmin)):
+            for name, fn in (("config1", bench_config1), ("dpor", bench_dpor), ("ddmin", bench_ddmin), ("config5", bench_config5)):
                 try:
                     sec[name] = fn(local_rank, cpu_baseline=not args.no_cpu_baseline)
                 except Exception as e:          # a secondary record must never cost the headline line

@@ -207,6 +207,7 @@ class DporBook {
       traces_[p.trace_id].refs.fetch_add(1, std::memory_order_relaxed);
       if ((int)p.branch > sh.top) sh.top = (int)p.branch;
       sh.queued++;
+      sh.enqueued++;
     };
     // phase 2: thread t processes its shards; the pieces of a shard are read in thread (= interleaving) order
     auto process = [&](unsigned t) {
@@ -276,6 +277,11 @@ class DporBook {
     return true;
   }
 
+  uint64_t enqueued() const {          // backtrack points ever enqueued (demi_dpor_stats.backtrack_points)
+    uint64_t n = 0;
+    for (auto& s : shards_) n += s.enqueued;
+    return n;
+  }
   bool empty() const { return queue_len() == 0; }
   uint64_t queue_len() const {
     uint64_t n = 0;
@@ -292,7 +298,7 @@ class DporBook {
     ChunkPool pool;
     Fifo bucket[256];                        // backTrack, one FIFO per branch index
     int top = -1;                            // highest non-empty bucket once settled
-    uint64_t queued = 0;
+    uint64_t queued = 0, enqueued = 0;
     bool front_valid = false;                // top / front_seq describe a live (unexplored) point
     uint64_t front_seq = 0;
   };
@@ -464,6 +470,7 @@ int explore_rounds(Run&& run, Fetch&& fetch, uint32_t max_pairs, const demi_dpor
     if (seconds) { seconds[0] += t1 - t0; seconds[1] += t2 - t1; seconds[2] += now() - t2; }
   }
   stats->queue_len = book.queue_len();
+  stats->backtrack_points = book.enqueued();
   stats->exhausted = exhausted ? 1u : 0u;
   return 0;
 }
@@ -778,6 +785,7 @@ int explore_reference_order(Run&& run, Fetch&& fetch, uint32_t max_pairs, const 
     if (seconds) { seconds[0] += t2 - t1; seconds[1] += now() - t2; }
   }
   stats->queue_len = real.queue_len();
+  stats->backtrack_points = real.enqueued();
   stats->exhausted = exhausted ? 1u : 0u;
   if (getenv("DEMI_DPOR_TIMING"))
     fprintf(stderr, "[reference order] racing pairs reported %llu, kept after the parent filter %llu\n", stats_pairs_reported, stats_pairs_kept);
@@ -853,6 +861,7 @@ int explore_rounds_resident(Dev&& dev, const demi_dpor_search* srch, demi_verdic
     base_id += dev.ids_used(n);
     for (const demi::DporKill& k : kills) dead.insert({k.a, k.b});
     std::sort(pts.begin(), pts.end(), [](const demi::DporPoint& x, const demi::DporPoint& y) { return x.ordinal < y.ordinal; });
+    stats->backtrack_points += pts.size();
     for (const demi::DporPoint& p : pts) {        // creation order: the round's interleavings in pop order, then pair order
       bucket[p.branch].push_back(p);
       if ((int)p.branch > top) top = (int)p.branch;

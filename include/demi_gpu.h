@@ -308,6 +308,9 @@ int demi_replay_removal_batch(demi_ctx* ctx, const uint64_t* masks /* [n][4] or 
  * events, sends of messages that were never delivered and the quiescence markers are 0.  kept: [n_rec].  */
 int demi_replay_get_kept(demi_ctx* ctx, const uint64_t* mask /* [4] or NULL */, uint32_t skip,
                          const demi_limits* limits, demi_verdict* verdict, uint8_t* kept);
+/* Number of recorded events of the execution loaded by demi_replay_load (0 without one): the size demi_replay_get_kept's
+ * out_kept needs.  Lets a binding check its buffer before the call. */
+uint32_t demi_replay_recorded_len(const demi_ctx* ctx);
 
 /* ---------------------------------------------------------- K3: DPORwHeuristics interleavings
  * Replaces, per interleaving, DPORwHeuristics.schedule_new_message / event_produced / getMessage /
@@ -411,6 +414,8 @@ typedef struct {
   double kernel_ms;             /* sum of the K3 launches' durations (HIP events on the launch stream) */
   uint64_t h2d_bytes;           /* next traces uploaded */
   uint64_t d2h_bytes;           /* verdicts, traces and racing pairs fetched */
+  uint64_t backtrack_points;    /* backtrack points the bookkeeping enqueued (dpor() :1134 after the drops that getNext() would make
+                                   anyway): the "r new backtrack points out" of an interleaving, summed */
 } demi_dpor_stats;
 
 /* out_verdicts / out_prefix_len: [max_interleavings], in execution order.  first_violation_trace:

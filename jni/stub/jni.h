@@ -16,8 +16,18 @@ struct JNINativeInterface_;
 typedef const struct JNINativeInterface_* JNIEnv;
 struct JNINativeInterface_ {
   jsize (*GetArrayLength)(JNIEnv*, jarray);
-  void* (*GetPrimitiveArrayCritical)(JNIEnv*, jarray, jboolean*);
-  void (*ReleasePrimitiveArrayCritical)(JNIEnv*, jarray, void*, jint);
   jstring (*NewStringUTF)(JNIEnv*, const char*);
+  jbyte* (*GetByteArrayElements)(JNIEnv*, jbyteArray, jboolean*);
+  jshort* (*GetShortArrayElements)(JNIEnv*, jshortArray, jboolean*);
+  jint* (*GetIntArrayElements)(JNIEnv*, jintArray, jboolean*);
+  jlong* (*GetLongArrayElements)(JNIEnv*, jlongArray, jboolean*);
+  void (*ReleaseByteArrayElements)(JNIEnv*, jbyteArray, jbyte*, jint);
+  void (*ReleaseShortArrayElements)(JNIEnv*, jshortArray, jshort*, jint);
+  void (*ReleaseIntArrayElements)(JNIEnv*, jintArray, jint*, jint);
+  void (*ReleaseLongArrayElements)(JNIEnv*, jlongArray, jlong*, jint);
+  void (*GetByteArrayRegion)(JNIEnv*, jbyteArray, jsize, jsize, jbyte*);
+  void (*GetIntArrayRegion)(JNIEnv*, jintArray, jsize, jsize, jint*);
+  void (*SetByteArrayRegion)(JNIEnv*, jbyteArray, jsize, jsize, const jbyte*);
+  void (*SetLongArrayRegion)(JNIEnv*, jlongArray, jsize, jsize, const jlong*);
 };
 #endif

@@ -1,7 +1,71 @@
 package akka.dispatch.verification.gpu
 
+import akka.actor.{ActorRef, Cell}
+import akka.dispatch.Envelope
 import akka.dispatch.verification._
 import DemiGpu._
+
+/** What `trait Scheduler` (schedulers/Scheduler.scala:13-104) asks of a class, for schedulers that evaluate their executions on
+ *  the GPU.  The reference's drivers assign every scheduler to the Instrumenter before using it (`Instrumenter().scheduler =
+ *  sched`: RunnerUtils.scala:89, 666; StatelessTestOracle, TestOracle.scala:79-83), so the GPU schedulers ARE Schedulers.  They
+ *  never start an ActorSystem - an execution is simulated from the lowered table - so the Instrumenter has nothing to call
+ *  back about: the notification members are no-ops, and the members through which a LIVE system would ask this scheduler what
+ *  to deliver next throw (a live system under a GPU scheduler is a wiring error, not something to paper over). */
+trait GpuSchedulerBase extends Scheduler {
+  protected def notLive(what: String): Nothing =
+    throw new IllegalStateException(getClass.getSimpleName + "." + what + ": the GPU schedulers do not drive a live ActorSystem " +
+                                    "(executions are simulated from the lowered table); use the JVM scheduler for that")
+  // ---- classification (Scheduler.scala:15, 27): nothing is system traffic, there is no failure detector / checkpointer here
+  def isSystemCommunication(sender: ActorRef, receiver: ActorRef): Boolean = false
+  def isSystemMessage(src: String, dst: String): Boolean = false
+  // ---- the Instrumenter's questions to a live scheduler (Scheduler.scala:38-45)
+  def start_trace(): Unit = {}                                                   // nothing to restart
+  def schedule_new_message(blockedActors: Set[String]): Option[(Cell, Envelope)] = notLive("schedule_new_message")
+  def next_event(): Event = notLive("next_event")
+  def notify_quiescence(): Unit = {}
+  // ---- notifications (Scheduler.scala:48-70)
+  def before_receive(cell: Cell): Unit = {}
+  def after_receive(cell: Cell): Unit = {}
+  def event_produced(event: Event): Unit = {}
+  def event_produced(cell: Cell, envelope: Envelope): Unit = notLive("event_produced")
+  def event_consumed(event: Event): Unit = {}
+  def event_consumed(cell: Cell, envelope: Envelope) { }
+  def notify_timer_cancel(receiver: String, msg: Any) { }
+  def enqueue_message(sender: Option[ActorRef], receiver: String, msg: Any) { notLive("enqueue_message") }
+  // shutdown() is each class's own (it frees the demi_ctx)
+
+  // ---- TestOracle's contract: "Throws an IllegalArgumentException if setInvariant has not been invoked"
+  // (TestOracle.scala:45; RandomScheduler.scala:244-246).  The invariant the kernels evaluate is the DESCRIPTOR in
+  // lowering.model (closures do not cross the boundary); the closure is kept so that the contract holds and so that a
+  // lowering can check on sample checkpoints that the descriptor is the lowering of this very closure.
+  protected var invariant: TestOracle.Invariant = null
+  def setInvariant(i: TestOracle.Invariant) { invariant = i }
+  protected def requireInvariant() {
+    if (invariant == null) throw new IllegalArgumentException("Must invoke setInvariant before test / explore")
+  }
+}
+
+/** sched.depTracker (RunnerUtils.scala:99-100 reads getGraph / getInitialTrace after a violating explore()): the reference's
+ *  own DepTracker, fed from the recorded EventTrace with exactly the calls RandomScheduler makes while it runs -
+ *  reportNewlyEnabled / reportNewlyEnabledExternal for every produced message (RandomScheduler.scala:291, 303),
+ *  reportNewlyDelivered for every delivery (:468), reportKill / reportPartition / reportUnPartition from the orchestrator's
+ *  callbacks (:127-129).  Unique ids are the DepTracker's own, as in the reference. */
+object GpuDepTracker {
+  def fromTrace(schedulerConfig: SchedulerConfig, trace: EventTrace, allActors: Set[String]): DepTracker = {
+    val dep = new DepTracker(schedulerConfig)
+    val enabled = scala.collection.mutable.HashMap[Int, Unique]()        // Uniq id of the MsgSend -> the DepTracker's node
+    for (e <- trace.events) e match {
+      case UniqueMsgSend(MsgSend(snd, rcv, msg), id) =>
+        enabled(id) = if (EventTypes.isExternal(e)) dep.reportNewlyEnabledExternal(snd, rcv, msg) else dep.reportNewlyEnabled(snd, rcv, msg)
+      case UniqueMsgEvent(_, id) => enabled.get(id).foreach(dep.reportNewlyDelivered)
+      case KillEvent(n) => dep.reportKill(n, allActors, 0)
+      case PartitionEvent((a, b)) => dep.reportPartition(a, b, 0)
+      case UnPartitionEvent((a, b)) => dep.reportUnPartition(a, b, 0)
+      case _ =>
+    }
+    dep
+  }
+}
 
 /** RandomScheduler on the GPU: the same constructor shape as RandomScheduler (RandomScheduler.scala:41-44) plus the
  *  lowering.  Execution i of explore() is one full execution with `new FullyRandom(seed + i)`, i.e. the shape of
@@ -13,15 +77,16 @@ import DemiGpu._
  *  "N independent executions with seeds seed, seed + 1, ...", and explore() returns the lowest violating index. */
 class GpuRandomScheduler(val schedulerConfig: SchedulerConfig, max_executions: Int = 1, invariant_check_interval: Int = 0,
                          seed: Long = System.currentTimeMillis(), lowering: TableLowering, device: Int = 0,
-                         srcDstFifo: Boolean = false, pMax: Int = 64) extends TestOracle {
+                         srcDstFifo: Boolean = false, pMax: Int = 64) extends GpuSchedulerBase with TestOracle {
   private val h = ctxCreate(device)
   if (h == 0) throw new IllegalStateException("no MI355X visible: use RandomScheduler")
   private var maxMessages = Int.MaxValue
   private var modelLoaded = false
   var stats: MinimizationStats = null
+  /** filled by a violating explore(): what RunnerUtils.fuzz reads as sched.depTracker.getGraph / getInitialTrace (:99-100) */
+  var depTracker = new DepTracker(schedulerConfig)
   def getName = "GpuRandomScheduler"
   def setMaxMessages(m: Int) { maxMessages = m }
-  def setInvariant(i: TestOracle.Invariant) {}        // the invariant descriptor travels with lowering.model
 
   private def limits(lookingFor: Option[ViolationFingerprint], p: Int = pMax) = Array(
     if (maxMessages == Int.MaxValue) 0 else maxMessages, math.max(0, invariant_check_interval), p,
@@ -44,6 +109,7 @@ class GpuRandomScheduler(val schedulerConfig: SchedulerConfig, max_executions: I
    *  believed; if one still does not fit, the JVM scheduler has to decide it (UnsupportedOnGpu). */
   def explore(trace: Seq[ExternalEvent], lookingFor: Option[ViolationFingerprint] = None)
       : Option[(EventTrace, ViolationFingerprint)] = {
+    requireInvariant()
     prepare(trace)
     if (stats != null) (1 to max_executions).foreach(_ => stats.increment_replays())
     val OVF = V_PENDING_OVF | V_QUEUE_OVF
@@ -65,7 +131,9 @@ class GpuRandomScheduler(val schedulerConfig: SchedulerConfig, max_executions: I
         if ((f & OVF) != 0) throw new UnsupportedOnGpu("schedule " + (start + idx) + " exceeds the engine's capacities")
         if ((f & V_VIOLATION) != 0) {
           val used = trace.take((f >> 8) & 0xFF)        // checkIfBugFound prunes the externals never injected (:160-163)
-          return Some((FlatEvents.toEventTrace(rec, n, used, lowering), lowering.fingerprintOf(fingerprint(v, 0))))
+          val found = FlatEvents.toEventTrace(rec, n, used, lowering)
+          depTracker = GpuDepTracker.fromTrace(schedulerConfig, found, (0 until lowering.model.nActors).map(lowering.actorName).toSet)
+          return Some((found, lowering.fingerprintOf(fingerprint(v, 0))))
         }
         if (fl < 0) next = start + idx + 1
       }
@@ -86,9 +154,18 @@ class GpuRandomScheduler(val schedulerConfig: SchedulerConfig, max_executions: I
 
 /** STSScheduler(schedulerConfig, original_trace, allowPeek = false) as DDMin's oracle (STSScheduler.scala:199-310). */
 class GpuSTSScheduler(val schedulerConfig: SchedulerConfig, original_trace: EventTrace, lowering: TableLowering,
-                      device: Int = 0, pMax: Int = 64) extends TestOracle {
+                      device: Int = 0, pMax: Int = 64) extends GpuSchedulerBase with TestOracle {
   private val h = ctxCreate(device)
   if (h == 0) throw new IllegalStateException("no MI355X visible: use STSScheduler")
+  // what RunnerUtils.stsSchedDDMin sets on its scheduler before minimising (RunnerUtils.scala:655-667): the callbacks run around
+  // every test() as in STSScheduler.test (:206-214, 300-305); the actor Props are what populateActorSystem would create - the
+  // lowering already names every actor, so they are only remembered
+  private var preTest: Option[STSScheduler.PreTestCallback] = None
+  private var postTest: Option[STSScheduler.PostTestCallback] = None
+  def setPreTestCallback(c: STSScheduler.PreTestCallback) { preTest = Some(c) }
+  def setPostTestCallback(c: STSScheduler.PostTestCallback) { postTest = Some(c) }
+  var actorNamePropPairs: Seq[Tuple2[akka.actor.Props, String]] = Seq.empty
+  def setActorNamePropPairs(pairs: Seq[Tuple2[akka.actor.Props, String]]) { actorNamePropPairs = pairs }
   private val externals = original_trace.original_externals
   private val indexOf = externals.zipWithIndex.map { case (e, i) => e._id -> i }.toMap      // ExternalEvent._id (ExternalEvents.scala:14-31)
   private val recorded = FlatEvents.packRecorded(original_trace, lowering)
@@ -99,7 +176,6 @@ class GpuSTSScheduler(val schedulerConfig: SchedulerConfig, original_trace: Even
     check(h, replayLoad(h, FlatEvents.pack(externals, lowering), recorded))
   }
   def getName = "GpuSTSSchedNoPeek"
-  def setInvariant(i: TestOracle.Invariant) {}
   // the last entry is demi_limits.filter_known_absents: SchedulerConfig.filterKnownAbsents, as the reference computes it
   private def limits(fp: ViolationFingerprint, p: Int = pMax) =
     Array(0, 0, p, 1, lowering.fingerprintCode(fp), 0, 0, if (schedulerConfig.filterKnownAbsents) 1 else 0)
@@ -111,6 +187,7 @@ class GpuSTSScheduler(val schedulerConfig: SchedulerConfig, original_trace: Even
 
   /** one launch for a whole DDMin frontier: element i is Some(executed trace) iff subseqs(i) reproduces the violation */
   def testBatch(subseqs: Seq[Seq[ExternalEvent]], fp: ViolationFingerprint, stats: MinimizationStats): Seq[Option[EventTrace]] = {
+    requireInvariant()
     if (stats != null) subseqs.foreach(_ => stats.increment_replays())
     val masks = subseqs.flatMap(mask).toArray
     val v = new Array[Long](2 * subseqs.size)
@@ -138,7 +215,12 @@ class GpuSTSScheduler(val schedulerConfig: SchedulerConfig, original_trace: Even
   }
 
   def test(subseq: Seq[ExternalEvent], fp: ViolationFingerprint, stats: MinimizationStats,
-           init: Option[() => Any] = None): Option[EventTrace] = testBatch(Seq(subseq), fp, stats).head
+           init: Option[() => Any] = None): Option[EventTrace] = {
+    preTest.foreach(_())
+    val r = testBatch(Seq(subseq), fp, stats).head
+    postTest.foreach(_())
+    r
+  }
   def shutdown() { ctxDestroy(h) }
 }
 
@@ -188,23 +270,28 @@ class GpuStsRemovalOracle(schedulerConfig: SchedulerConfig, mcs: Seq[ExternalEve
  *  "first violation found"); false explores in rounds of `batch` (a slightly different explored set, much faster). */
 class GpuDPOR(val schedulerConfig: SchedulerConfig, lowering: TableLowering, depthBound: Int = 0, batch: Int = 4096,
               stopIfViolationFound: Boolean = true, referenceOrder: Boolean = true, maxInterleavings: Int = 1 << 17,
-              device: Int = 0) extends TestOracle {
+              device: Int = 0) extends GpuSchedulerBase with TestOracle {
   private val h = ctxCreate(device)
   if (h == 0) throw new IllegalStateException("no MI355X visible: use DPORwHeuristics")
   def getName = "GpuDPORwHeuristics"
-  def setInvariant(i: TestOracle.Invariant) {}
+  // what RunnerUtils.boundedDPOR sets before test() (RunnerUtils.scala:889-900)
+  private var maxMessagesToSchedule = 0
+  def setMaxMessagesToSchedule(m: Int) { maxMessagesToSchedule = m }                       // DPORwHeuristics.scala:136-139
+  var actorNameProps: Seq[Tuple2[akka.actor.Props, String]] = Seq.empty
+  def setActorNameProps(pairs: Seq[Tuple2[akka.actor.Props, String]]) { actorNameProps = pairs }
   def test(events: Seq[ExternalEvent], fp: ViolationFingerprint, stats: MinimizationStats,
            init: Option[() => Any] = None): Option[EventTrace] = {
+    requireInvariant()
     val m = lowering.model
     check(h, modelLoad(h, m.nActors, m.msgClass, m.actorClass, m.nClasses, m.handlerStart, m.code, m.initState,
                        Array(m.invKind, m.invFa, m.invVa, m.invFb, m.fpMatchMask, m.flags)))
     modelSpecialize(h, true)
     check(h, dporLoad(h, FlatEvents.pack(events, lowering)))      // Start / Send / WaitQuiescence only (DPORwHeuristics.scala:692-710)
-    val params = Array(depthBound, 0, 1, lowering.fingerprintCode(fp), 64, 4096, 0)
+    val params = Array(depthBound, maxMessagesToSchedule, 1, lowering.fingerprintCode(fp), 64, 4096, 0)
     val search = Array(batch, maxInterleavings, if (stopIfViolationFound) 1 else 0, 1,
                        if (referenceOrder) DPOR_ORDER_REFERENCE else DPOR_ORDER_ROUNDS, 0)
     val verdicts = new Array[Long](2 * maxInterleavings); val plen = new Array[Int](maxInterleavings)
-    val rounds = new Array[Int](maxInterleavings); val vt = new Array[Byte](16 * 256); val st = new Array[Long](11)
+    val rounds = new Array[Int](maxInterleavings); val vt = new Array[Byte](16 * 256); val st = new Array[Long](12)
     val vlen = check(h, dporExplore(h, params, search, verdicts, plen, rounds, vt, st))
     if (stats != null) (0L until st(0)).foreach(_ => stats.increment_replays())
     if (st(2) == 0) None

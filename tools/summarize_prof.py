@@ -105,10 +105,25 @@ if k1name:
 with open(os.path.join(out_dir, tag + "_k1.txt"), "w") as f:
     f.write("\n".join(lines) + "\n")
 print("\n".join(lines))
+def by_grid_lines(cur, like):
+    """Per (kernel, grid size): launches and average duration - a frontier of 256 candidates and one of 2^20 are different
+    launches of the same kernel, and the stats table above lumps them."""
+    cols = [c[1] for c in cur.execute("pragma table_info(kernels)")]
+    gcols = [c for c in cols if "grid" in c.lower()]
+    if not gcols:
+        return ["# (no grid-size column in this rocpd schema: %s)" % ", ".join(cols)]
+    g = " || 'x' || ".join(gcols)
+    out = ["# per launch shape (%s): kernel, grid, launches, avg_ns, min_ns, max_ns" % ", ".join(gcols)]
+    q = "select name, %s as g, count(*), avg(duration), min(duration), max(duration) from kernels where name like ? group by name, g order by name, avg(duration)" % g
+    for r in cur.execute(q, (like,)):
+        out.append("%-60s %-18s %6d %12.0f %12.0f %12.0f" % (r[0][:60], r[1], r[2], r[3], r[4], r[5]))
+    return out
+
+
 for d, name in (("prof_stats_dpor", "dpor"), ("prof_stats_ddmin", "ddmin")):
     cur = db_of(d)
     if cur:
-        txt = "\n".join(stats_lines(cur, "python bench.py --workload %s --no-cpu-baseline" % name)) + "\n"
+        txt = "\n".join(stats_lines(cur, "python bench.py --workload %s --no-cpu-baseline" % name) + [""] + by_grid_lines(cur, "%demi%")) + "\n"
         with open(os.path.join(out_dir, "%s_%s.txt" % (tag, name)), "w") as f:
             f.write(txt)
         print(txt)
