@@ -70,6 +70,8 @@ def lib():
     L.demi_collect_violations_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p,
                                               C.c_uint32, C.c_void_p, C.c_void_p]
     L.demi_replay_load.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
+    L.demi_replay_recorded_len.argtypes = [C.c_void_p]
+    L.demi_replay_recorded_len.restype = C.c_uint32
     L.demi_replay_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(T.Limits), C.c_void_p]
     L.demi_replay_batch_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(T.Limits), C.c_void_p, C.c_void_p]
     L.demi_replay_removal_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(T.Limits), C.c_void_p]

@@ -571,7 +571,9 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
 #ifdef DEMI_K1_FLUSH_FENCE
       if (__ballot(spilled) != 0) __threadfence_block();
 #else
-      (void)spilled;
+      // what stays is the COMPILER's side of that order: a wavefront-scope release fence constrains the reordering of the
+      // stores above against the owner lane's later loads and costs no s_waitcnt on this target
+      if (__ballot(spilled) != 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 #endif
       if (step && fl_cnt != 0) {
         if (n_pend + n_norm + fl_cnt > PMAX) { flags |= DEMI_V_PENDING_OVF; n_pend = PMAX - n_norm; }
