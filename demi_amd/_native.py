@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libdemi_gpu.so")
 
 EXPORTS = ["demi_ctx_create", "demi_ctx_destroy", "demi_last_error", "demi_version", "demi_model_load",
            "demi_trace_load", "demi_random_explore", "demi_random_explore_dev", "demi_random_get_trace", "demi_collect_violations_dev",
-           "demi_replay_load", "demi_replay_batch", "demi_replay_batch_dev", "demi_dpor_load", "demi_dpor_batch", "demi_dpor_explore", "demi_random_explore_violations",
+           "demi_replay_load", "demi_replay_batch", "demi_replay_batch_dev", "demi_dpor_load", "demi_dpor_batch", "demi_dpor_explore", "demi_random_explore_violations", "demi_random_get_trace_carried",
            "demi_replay_removal_batch", "demi_replay_get_kept", "demi_replay_recorded_len", "demi_model_specialize", "demi_model_is_specialized", "demi_model_code_id",
            "demi_specialize_check", "demi_specialize_source", "demi_specialize_source_k1", "demi_provenance_prune", "demi_device_probe", "demi_device_probe_mix", "demi_calib_rw", "demi_random_explore_flagged", "demi_collect_flagged_dev",
            "demi_comm_unique_id", "demi_comm_create", "demi_comm_create_host", "demi_comm_destroy", "demi_comm_rank",
@@ -67,6 +67,8 @@ def lib():
                                           C.c_void_p, C.c_void_p]
     L.demi_random_get_trace.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(T.Limits), C.POINTER(T.Verdict),
                                         C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+    L.demi_random_get_trace_carried.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(T.Limits), C.POINTER(T.Verdict),
+                                                C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.demi_collect_violations_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p,
                                               C.c_uint32, C.c_void_p, C.c_void_p]
     L.demi_replay_load.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
@@ -397,6 +399,16 @@ class Context:
 
     def calib_rw(self, mode, nbytes, repeats=1):
         self._check(lib().demi_calib_rw(self._h, mode, nbytes, repeats))
+
+    def random_get_trace_carried(self, seed, exec_index, limits):
+        """(verdict, recorded events, executed index) of execution `exec_index` of the carried-generator instance seeded `seed`."""
+        import numpy as np
+        rec = np.zeros(T.MAX_REC_EVENTS, dtype=T.REC_EVENT_DTYPE)
+        v = T.Verdict()
+        n, ran = C.c_uint32(0), C.c_uint32(0)
+        self._check(lib().demi_random_get_trace_carried(self._h, C.c_uint64(seed), exec_index, C.byref(limits), C.byref(v),
+                                                        rec.ctypes.data, len(rec), C.byref(n), C.byref(ran)))
+        return v, rec[:n.value].copy(), ran.value
 
     def random_get_trace(self, seed, limits):
         import numpy as np

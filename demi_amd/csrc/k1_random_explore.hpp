@@ -43,6 +43,8 @@ struct K1Args {
   uint32_t rec_cap;
   uint32_t n_batches;       // WaitQuiescence events + 1
   unsigned long long* phase_out;   // -DDEMI_K1_PHASES builds only: [waves][16] cycle totals per phase
+  uint32_t epi;             // CARRY variants: executions per RandomScheduler instance (demi_limits.executions_per_instance)
+  uint32_t rec_shared;      // CARRY + REC: every execution of the instance records into rec_out[0 ..] (the last one stays)
 };
 
 enum : int { PH_IDLE = 0, PH_INJECT = 1, PH_DISPATCH = 2, PH_FINISH = 3 };
@@ -112,7 +114,13 @@ __host__ __device__ inline size_t k1_lds_bytes(uint32_t code_len, uint32_t n_ev,
 #else
 #define K1_LAUNCH_BOUNDS __launch_bounds__(K1_WAVES * 64)
 #endif
-template <bool REC, bool FIFO = false>
+// CARRY: the unit of work is a RandomScheduler INSTANCE that runs args.epi executions one after the other without reseeding
+// its generator(s) (explore() with max_executions > 1, RandomScheduler.scala:248-269: reset_all_state :575-595 clears the
+// pending set but keeps the FullyRandom / SrcDstFIFO objects and therefore their Random).  Work index = instance, verdict
+// index = instance * epi + execution; lookingFor only applies to the first execution (:586 sets it to None); the instance
+// stops at its first violating execution (:257-261) - the verdicts behind it stay as the host zeroed them.  The executions of
+// an instance are a sequential chain on one lane; instances run in parallel like the executions of the default mode.
+template <bool REC, bool FIFO = false, bool CARRY = false>
 __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Tables t;
@@ -242,6 +250,8 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
   int ph = PH_IDLE;
   bool fresh = false;
   uint64_t sched = 0, rng = 0, hash = 0;
+  uint64_t inst = 0, inst_end = 0;    // CARRY: this lane's instance and the end of its verdict range
+  uint32_t exec_no = 0;               // CARRY: number of the running execution within the instance
   uint64_t app_rng = 0;               // Instrumenter().seededRandom: scala.util.Random(0), new with every execution (DEMI_OP_RND)
   uint32_t n_pend = 0, count = 0, cnt_mod = 0, tidx = 0, inj_lo = 0, inj_hi = 0, batch_no = 0;
   uint32_t fl_off = 0, fl_cnt = 0;    // !REC: the injected batch's Sends as a range of s_bsend, flushed by the whole wave
@@ -382,7 +392,7 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
   auto check_invariant = [&]() -> uint32_t {
     const uint32_t fp = invariant_from_hits(st, hits & exists, A, inv_kind, inv_fb);
     if (!fp) return 0u;
-    if (args.looking_for_valid) return (((fp ^ args.looking_for) & fp_mask) == 0) ? args.looking_for : 0u;
+    if (args.looking_for_valid && (!CARRY || exec_no == 0)) return (((fp ^ args.looking_for) & fp_mask) == 0) ? args.looking_for : 0u;
     return fp;
   };
 
@@ -408,6 +418,7 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
 #ifndef DEMI_K1_SVC_LANES
 #define DEMI_K1_SVC_LANES 16
 #endif
+  const uint64_t n_units = CARRY ? (args.n + args.epi - 1) / args.epi : args.n;    // work units: executions, or instances
   uint32_t svc_age = 0;
   for (;;) {
     bool service = true;
@@ -433,6 +444,11 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
         if (REC) args.rec_count[sched] = n_rec;
         // reset the simulator for the next schedule
         ph = PH_IDLE;
+        if (CARRY && !(v.x & DEMI_V_VIOLATION) && sched + 1 < inst_end) {
+          // the instance's next execution: reset_all_state + execute_trace again, the generators as they are
+          sched++; exec_no++;
+          ph = PH_INJECT; fresh = true;
+        }
         n_pend = 0; count = 0; cnt_mod = 0; tidx = 0; inj_lo = 0; inj_hi = 0; batch_no = 0;
         tq = 0; resend = 0; n_tq = 0; n_resend = 0; just = 0; rep = 0; viol = 0; flags = 0; hash = 0;
         n_norm = 0; n_pairs = 0; pairmask = 0;
@@ -453,11 +469,17 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
           if (ph == PH_IDLE) {
             const uint32_t rank = (uint32_t)__popcll(idle & ((1ULL << lane) - 1));
             const uint64_t my = (rank < have) ? (b_next + rank) : (got + (rank - have));
-            if (my < args.n) { sched = my; ph = PH_INJECT; fresh = true; }
+            if (my < n_units) {
+              ph = PH_INJECT; fresh = true;
+              if (CARRY) {
+                inst = my; exec_no = 0; sched = my * (uint64_t)args.epi;
+                inst_end = sched + args.epi < args.n ? sched + args.epi : args.n;
+              } else sched = my;
+            }
           }
           if (have < want) { b_next = got + (want - have); b_end = got + K1_BATCH; }
           else b_next += want;
-          if (b_next >= args.n) exhausted = true;
+          if (b_next >= n_units) exhausted = true;
         }
         if (__ballot(ph != PH_IDLE) == 0) break;           // nothing running and nothing left to claim
       }
@@ -469,9 +491,12 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
           fresh = false;
           // new execution: `new FullyRandom(seed)`; populateActorSystem isolates every created actor
           // (ExternalEventInjector.scala:371-378)
-          const uint64_t seed = args.seeds ? args.seeds[sched] : args.seed_base + sched;
-          rng = jr_seed(seed);
-          te_rng = rng;                  // SrcDstFIFO: both generators are `new Random(seed)`
+          if (!CARRY || exec_no == 0) {
+            const uint64_t unit = CARRY ? inst : sched;
+            const uint64_t seed = args.seeds ? args.seeds[unit] : args.seed_base + unit;
+            rng = jr_seed(seed);
+            te_rng = rng;                // SrcDstFIFO: both generators are `new Random(seed)`
+          }
           app_rng = jr_seed(0);
           hash = 0xCBF29CE484222325ULL;
           net.inaccessible = exists; net.killed = 0; net.partitioned = 0;
@@ -480,7 +505,7 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
           for (uint32_t j = 0; j < k1_tdir_words(A, NTT); j++) *reinterpret_cast<uint32_t*>(tdir + (j << 8)) = 0xFFFFFFFFu;   // no timer pending
           for (uint32_t i = 0; i < A * ST_WORDS; i++) st[i * 64] = t.init[i];
           for (uint32_t a = 0; a < A; a++) hits |= invariant_hit_at(st, a, inv_kind, inv_fa, inv_va) << a;
-          if (REC) { rec = args.rec_out + sched * (uint64_t)args.rec_cap; n_rec = 0; next_id = 1; }
+          if (REC) { rec = args.rec_out + (args.rec_shared ? 0ull : sched * (uint64_t)args.rec_cap); n_rec = 0; next_id = 1; }
           batch_no = 0;
         }
         // EventOrchestrator.inject_until_quiescence (:132-189).  Send events are not materialised:

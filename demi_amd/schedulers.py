@@ -93,9 +93,16 @@ class RandomScheduler:
 
     def __init__(self, schedulerConfig: SchedulerConfig, max_executions: int = 1,
                  invariant_check_interval: int = 0, randomizationStrategy: Optional[FullyRandom] = None,
-                 seed_base: Optional[int] = None, device: int = 0, p_max: int = 64, specialize: Optional[bool] = None):
+                 seed_base: Optional[int] = None, device: int = 0, p_max: int = 64, specialize: Optional[bool] = None,
+                 carried_generator: bool = False):
         """specialize: compile the model's transition table to native code before exploring (demi_model_specialize,
-        about a second); None = only when max_executions is large enough to amortise it."""
+        about a second); None = only when max_executions is large enough to amortise it.
+        carried_generator: exactly one reference instance `new RandomScheduler(config, max_executions)` with
+        `new FullyRandom(seed_base)`: the generator is NOT reseeded between the executions (reset_all_state only clears the
+        pending set, RandomScheduler.scala:575-595, 649-651), lookingFor applies to the first execution only (:586) and the
+        executions behind the first violating one are not run (explore() returns there, :257-261).  A sequential chain: for
+        comparisons with a JVM run, not for throughput (demi_limits.executions_per_instance)."""
+        self.carried_generator = carried_generator
         self.schedulerConfig = schedulerConfig
         self.specialize = (max_executions >= (1 << 18)) if specialize is None else specialize
         self.max_executions = max_executions
@@ -126,7 +133,8 @@ class RandomScheduler:
         mm = 0 if self.maxMessages >= 0x7FFFFFFF else self.maxMessages
         return T.Limits(mm, max(0, self.invariant_check_interval), self.p_max,
                         1 if lookingFor is not None else 0, lookingFor.code if lookingFor is not None else 0,
-                        1 if self.schedulerConfig.populate_all_actors else 0, self.strategy)
+                        1 if self.schedulerConfig.populate_all_actors else 0, self.strategy, 0,
+                        self.max_executions if self.carried_generator and self.max_executions > 1 else 0)
 
     def _prepare(self, trace):
         if self._model is None or self._model.inv_kind == T.INV_NONE:
@@ -166,6 +174,21 @@ class RandomScheduler:
         ev = self._prepare(_trace)
         if self.stats is not None:
             self.stats.increment_replays(self.max_executions)
+        if self.carried_generator and self.max_executions > 1:
+            # one instance: the chain of executions runs on one lane; the first violating execution ends it
+            lim = self._limits(_lookingFor)
+            v = self._ctx.random_explore(self.max_executions, lim, seed_base=self.seed_base)
+            if (v["flags"] & OVF_FLAGS).any():
+                raise CapacityExceeded("an execution of the instance exceeds the engine's capacities")
+            hit = np.nonzero(v["flags"] & T.V_VIOLATION)[0]
+            if not len(hit):
+                return None
+            i = int(hit[0])
+            v1, rec, ran = self._ctx.random_get_trace_carried(self.seed_base, i, lim)
+            assert ran == i and v1.flags & T.V_VIOLATION
+            used = ev[:T.verdict_trace_idx(v1.flags)]
+            mask = self._model.fp_match_mask if self._model else 0xFFFFFFFF
+            return EventTrace(rec, used), ViolationFingerprint(int(v1.fingerprint), mask)
         # only the violating and the aborted executions cross PCIe (16 B each instead of 16 B per schedule).  An execution
         # aborted on a capacity has no valid verdict: it is re-run alone with the largest pending set before any
         # higher index is believed (the reference has no capacities; its answer is the lowest violating index)

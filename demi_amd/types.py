@@ -81,7 +81,7 @@ class Limits(C.Structure):
     _fields_ = [("max_messages", C.c_uint32), ("invariant_check_interval", C.c_uint32),
                 ("p_max", C.c_uint32), ("looking_for_valid", C.c_uint32), ("looking_for", C.c_uint32),
                 ("populate_all", C.c_uint32), ("strategy", C.c_uint32),
-                ("filter_known_absents", C.c_uint32)]
+                ("filter_known_absents", C.c_uint32), ("executions_per_instance", C.c_uint32)]
 
 
 class Verdict(C.Structure):

@@ -176,6 +176,16 @@ typedef struct {
   uint32_t strategy;                  /* RandomizationStrategy (RandomScheduler.scala:614-633): demi_strategy */
   uint32_t filter_known_absents;      /* replays only: SchedulerConfig.filterKnownAbsents (SchedulerConfig.scala:14) ->
                                          EventTrace.filterKnownAbsentInternals (EventTrace.scala:458-534): demi_filter_absents */
+  uint32_t executions_per_instance;   /* RandomScheduler entry points: 0 / 1 = every execution is a scheduler of its own, seeded
+                                         seed_base + i (RunnerUtils.fuzz's shape).  k > 1 = the carried-generator mode of ONE
+                                         `new RandomScheduler(config, max_executions = k)`: verdict index i belongs to instance
+                                         i / k, seeded seed_base + i / k (seeds[i / k]), and is its execution number i % k; the
+                                         instance's generator(s) are NOT reseeded between its executions (reset_all_state only
+                                         clears the pending set, RandomScheduler.scala:575-595, 649-651), the application's
+                                         seededRandom restarts at 0 with every execution as always, lookingFor only applies to
+                                         execution 0 (reset_all_state sets it to None, :586), and explore() returns at the first
+                                         violating execution (:257-261): the instance's later verdicts are all-zero ("not run").
+                                         An instance is a sequential chain; instances run in parallel. */
 } demi_limits;
 
 /* EventTrace.filterKnownAbsentInternals drops from the projected trace every internal MsgSend whose sender is not alive or
@@ -274,6 +284,12 @@ int demi_random_explore_dev(demi_ctx* ctx, uint64_t seed_base, const uint64_t* d
  * RandomScheduler.scala:156-180), recorded on the GPU by re-running that seed.                 */
 int demi_random_get_trace(demi_ctx* ctx, uint64_t seed, const demi_limits* limits,
                           demi_verdict* verdict, demi_rec_event* out, uint32_t cap, uint32_t* n_out);
+/* The same for execution number exec_index of the instance seeded `seed` in the carried-generator mode
+ * (demi_limits.executions_per_instance): the chain is re-run from its first execution; *executed_index (may be NULL) is the
+ * execution the instance stopped at - exec_index, or an earlier one that violated, whose verdict and trace are then returned. */
+int demi_random_get_trace_carried(demi_ctx* ctx, uint64_t seed, uint32_t exec_index, const demi_limits* limits,
+                                  demi_verdict* verdict, demi_rec_event* out, uint32_t cap, uint32_t* n_out,
+                                  uint32_t* executed_index);
 
 /* ---------------------------------------------------------- K2: DDMin's replay oracle
  * Replaces STSScheduler.test without peek (STSScheduler.scala:199-310) as called by DDMin.ddmin2

@@ -14,7 +14,7 @@
  *   events    byte[8 * n]     demi_ext_event          recorded  byte[12 * n]  demi_rec_event
  *   verdicts  long[2 * n]     demi_verdict (long 0 = flags | fingerprint << 32, long 1 = hash)
  *   masks     long[4 * n]     candidate subsequences  violations long[2 * n]  demi_violation (index, fingerprint | flags << 32)
- *   limits    int[8]          demi_limits             dporParams int[7]  demi_dpor_params     dporSearch int[6]  demi_dpor_search
+ *   limits    int[9]          demi_limits             dporParams int[7]  demi_dpor_params     dporSearch int[6]  demi_dpor_search
  *   dporStats long[12]        demi_dpor_stats (kernel_ms as raw double bits)                                       */
 #include <jni.h>
 #include <stdint.h>
@@ -35,14 +35,14 @@
 #define PUT_INTS(arr, p, mode) do { if ((arr) && (p)) (*e)->ReleaseIntArrayElements(e, (arr), (jint*)(p), (mode)); } while (0)
 #define PUT_LONGS(arr, p, mode) do { if ((arr) && (p)) (*e)->ReleaseLongArrayElements(e, (arr), (jlong*)(p), (mode)); } while (0)
 
-/* demi_limits from int[8] (a 7-entry array of an older adapter is refused, not read out of bounds) */
+/* demi_limits from int[9] (a shorter array of an older adapter is refused, not read out of bounds) */
 static int limits_of(JNIEnv* e, jintArray limits, demi_limits* x) {
-  jint l[8];
-  if (LEN(limits) != 8) return DEMI_ERR_INVALID_ARG;
-  (*e)->GetIntArrayRegion(e, limits, 0, 8, l);
+  jint l[9];
+  if (LEN(limits) != 9) return DEMI_ERR_INVALID_ARG;
+  (*e)->GetIntArrayRegion(e, limits, 0, 9, l);
   x->max_messages = (uint32_t)l[0]; x->invariant_check_interval = (uint32_t)l[1]; x->p_max = (uint32_t)l[2];
   x->looking_for_valid = (uint32_t)l[3]; x->looking_for = (uint32_t)l[4]; x->populate_all = (uint32_t)l[5]; x->strategy = (uint32_t)l[6];
-  x->filter_known_absents = (uint32_t)l[7];
+  x->filter_known_absents = (uint32_t)l[7]; x->executions_per_instance = (uint32_t)l[8];
   return DEMI_OK;
 }
 static int dpor_params_of(JNIEnv* e, jintArray params, demi_dpor_params* x) {
@@ -148,6 +148,24 @@ JNIEXPORT jint JNICALL FN(randomGetTrace)(JNIEnv* e, jclass c, jlong h, jlong se
   jint rc = demi_random_get_trace(CTX(h), (uint64_t)seed, &lim, &v, (demi_rec_event*)r, cap, &n_out);
   PUT_BYTES(recorded, r, 0);
   (*e)->SetLongArrayRegion(e, verdict, 0, 2, (const jlong*)(const void*)&v);
+  return rc == DEMI_OK ? (jint)n_out : rc;
+}
+
+/* the same for execution number execIndex of the carried-generator instance seeded `seed` */
+JNIEXPORT jint JNICALL FN(randomGetTraceCarried)(JNIEnv* e, jclass c, jlong h, jlong seed, jint execIndex, jintArray limits, jlongArray verdict,
+                                                jbyteArray recorded) {
+  demi_limits lim;
+  demi_verdict v;
+  (void)c;
+  if (limits_of(e, limits, &lim) || execIndex < 0 || LEN(verdict) != 2 || LEN(recorded) < 0 || LEN(recorded) % 12) return DEMI_ERR_INVALID_ARG;
+  const uint32_t cap = (uint32_t)(LEN(recorded) / 12);
+  uint32_t n_out = 0, ran = 0;
+  memset(&v, 0, sizeof v);
+  void* r = BYTES(recorded);
+  jint rc = demi_random_get_trace_carried(CTX(h), (uint64_t)seed, (uint32_t)execIndex, &lim, &v, (demi_rec_event*)r, cap, &n_out, &ran);
+  PUT_BYTES(recorded, r, 0);
+  (*e)->SetLongArrayRegion(e, verdict, 0, 2, (const jlong*)(const void*)&v);
+  if (rc == DEMI_OK && ran != (uint32_t)execIndex) return DEMI_ERR_INVALID_ARG;      /* an earlier execution of the chain already violated */
   return rc == DEMI_OK ? (jint)n_out : rc;
 }
 

@@ -680,9 +680,20 @@ static int schedule_new_message(exec_t* x) {
   return 1;
 }
 
+/* carried: NULL, or the generators an earlier execution of the same RandomScheduler instance left behind ([0] FullyRandom's /
+   SrcDstFIFO.rand, [1] SrcDstFIFO's timersAndExternals): reset_all_state only clears the pending containers, it does not
+   reseed them (V/schedulers/RandomScheduler.scala:575-595, 649-651).  On return they hold this execution's final states. */
+static int random_execute_in2(exec_t* x, const demi_model* m, const demi_ext_event* trace, uint32_t n_ev,
+                              uint64_t seed, const demi_limits* lim, demi_verdict* out, demi_rec_event* rec,
+                              uint32_t rec_cap, uint32_t* n_rec, uint64_t* final_states, orc_jrandom* carried, int carried_valid);
 static int random_execute_in(exec_t* x, const demi_model* m, const demi_ext_event* trace, uint32_t n_ev,
                              uint64_t seed, const demi_limits* lim, demi_verdict* out, demi_rec_event* rec,
                              uint32_t rec_cap, uint32_t* n_rec, uint64_t* final_states) {
+  return random_execute_in2(x, m, trace, n_ev, seed, lim, out, rec, rec_cap, n_rec, final_states, NULL, 0);
+}
+static int random_execute_in2(exec_t* x, const demi_model* m, const demi_ext_event* trace, uint32_t n_ev,
+                              uint64_t seed, const demi_limits* lim, demi_verdict* out, demi_rec_event* rec,
+                              uint32_t rec_cap, uint32_t* n_rec, uint64_t* final_states, orc_jrandom* carried, int carried_valid) {
   memset(x, 0, offsetof(exec_t, fx));
   x->m = m; x->trace = trace; x->n_ev = n_ev; x->lim = lim;
   x->wide = (m->flags & DEMI_MODEL_WIDE) != 0;
@@ -693,6 +704,7 @@ static int random_execute_in(exec_t* x, const demi_model* m, const demi_ext_even
   if (x->p_max > PEND_HARD_CAP) x->p_max = PEND_HARD_CAP;
   orc_jrandom_seed(&x->rng, seed); /* new FullyRandom(seed = ...) / SrcDstFIFO.rand */
   orc_jrandom_seed(&x->te_rng, seed);
+  if (carried && carried_valid) { x->rng = carried[0]; x->te_rng = carried[1]; }   /* a later execution of the same instance */
   orc_jrandom_seed(&x->app_rng, 0);
   x->fifo = lim->strategy == DEMI_STRATEGY_SRC_DST_FIFO;
   /* populateActorSystem (V/schedulers/ExternalEventInjector.scala:371-378, 397-406):
@@ -740,6 +752,7 @@ static int random_execute_in(exec_t* x, const demi_model* m, const demi_ext_even
   }
   if (n_rec) *n_rec = x->n_rec;
   if (final_states) memcpy(final_states, x->state, sizeof(uint64_t) * n_state);
+  if (carried) { carried[0] = x->rng; carried[1] = x->te_rng; }
   return DEMI_OK;
 }
 
@@ -753,22 +766,73 @@ int orc_random_execute(const demi_model* m, const demi_ext_event* trace, uint32_
   return rc;
 }
 
+/* Execution number `exec_index` of the instance seeded `seed` (demi_limits.executions_per_instance mode), recorded: the chain
+   is run from its first execution; *ran = the execution the instance stopped at (exec_index, or an earlier violating one). */
+int orc_random_execute_carried(const demi_model* m, const demi_ext_event* trace, uint32_t n_ev, uint64_t seed, uint32_t exec_index,
+                               const demi_limits* lim, demi_verdict* out, demi_rec_event* rec, uint32_t rec_cap,
+                               uint32_t* n_rec, uint32_t* ran);
+
 /* ===================================================================== batch driver */
 typedef struct {
   const demi_model* m; const demi_ext_event* trace; uint32_t n_ev; uint64_t seed_base;
-  const uint64_t* seeds; uint64_t lo, hi; const demi_limits* lim; demi_verdict* out;
+  const uint64_t* seeds; uint64_t lo, hi; const demi_limits* lim; demi_verdict* out; uint64_t n;
 } job_t;
+
+/* One RandomScheduler instance with max_executions = k (explore(), V/schedulers/RandomScheduler.scala:248-269): executions
+   first .. first + k - 1 of the verdict array (clipped to n), the generators carried from one to the next, lookingFor only
+   for the first (reset_all_state sets it to None, :586), and the loop returns at the first violating execution: the
+   instance's remaining verdicts stay all-zero ("not run").  rec / n_rec (optional): the recorded trace of the LAST execution
+   that ran. */
+static uint64_t instance_run(exec_t* x, const demi_model* m, const demi_ext_event* trace, uint32_t n_ev, uint64_t seed,
+                             const demi_limits* lim, uint64_t first, uint64_t k, uint64_t n, demi_verdict* out,
+                             demi_rec_event* rec, uint32_t rec_cap, uint32_t* n_rec) {
+  orc_jrandom carried[2];
+  demi_limits l = *lim;
+  uint64_t last = first;
+  for (uint64_t e = 0; e < k && first + e < n; e++) {
+    if (e == 1) l.looking_for_valid = 0;
+    random_execute_in2(x, m, trace, n_ev, seed, &l, &out[first + e], rec, rec_cap, n_rec, NULL, carried, e > 0);
+    last = first + e;
+    if (out[first + e].flags & DEMI_V_VIOLATION) {
+      for (uint64_t r = e + 1; r < k && first + r < n; r++) memset(&out[first + r], 0, sizeof(demi_verdict));
+      break;
+    }
+  }
+  return last;
+}
 
 static void* job_main(void* p) {
   job_t* j = (job_t*)p;
   exec_t* x = (exec_t*)malloc(sizeof(exec_t)); /* one simulator per thread, reset per execution */
   if (!x) return NULL;
-  for (uint64_t i = j->lo; i < j->hi; i++) {
-    uint64_t seed = j->seeds ? j->seeds[i] : j->seed_base + i;
-    random_execute_in(x, j->m, j->trace, j->n_ev, seed, j->lim, &j->out[i], NULL, 0, NULL, NULL);
+  const uint64_t k = j->lim->executions_per_instance > 1 ? j->lim->executions_per_instance : 1;
+  if (k > 1) {
+    /* (lo, hi are INSTANCE indices here; instance i owns the verdicts [i * k, (i + 1) * k)) */
+    for (uint64_t i = j->lo; i < j->hi; i++) {
+      uint64_t seed = j->seeds ? j->seeds[i] : j->seed_base + i;
+      instance_run(x, j->m, j->trace, j->n_ev, seed, j->lim, i * k, k, j->n, j->out, NULL, 0, NULL);
+    }
+  } else {
+    for (uint64_t i = j->lo; i < j->hi; i++) {
+      uint64_t seed = j->seeds ? j->seeds[i] : j->seed_base + i;
+      random_execute_in(x, j->m, j->trace, j->n_ev, seed, j->lim, &j->out[i], NULL, 0, NULL, NULL);
+    }
   }
   free(x);
   return NULL;
+}
+
+int orc_random_execute_carried(const demi_model* m, const demi_ext_event* trace, uint32_t n_ev, uint64_t seed, uint32_t exec_index,
+                               const demi_limits* lim, demi_verdict* out, demi_rec_event* rec, uint32_t rec_cap,
+                               uint32_t* n_rec, uint32_t* ran) {
+  exec_t* x = (exec_t*)malloc(sizeof(exec_t));
+  demi_verdict* v = (demi_verdict*)calloc((size_t)exec_index + 1, sizeof(demi_verdict));
+  if (!x || !v) { free(x); free(v); return DEMI_ERR_INVALID_ARG; }
+  const uint64_t last = instance_run(x, m, trace, n_ev, seed, lim, 0, (uint64_t)exec_index + 1, (uint64_t)exec_index + 1, v, rec, rec_cap, n_rec);
+  *out = v[last];
+  if (ran) *ran = (uint32_t)last;
+  free(x); free(v);
+  return DEMI_OK;
 }
 
 int orc_random_explore(const demi_model* m, const demi_ext_event* trace, uint32_t n_ev, uint64_t seed_base,
@@ -778,9 +842,11 @@ int orc_random_explore(const demi_model* m, const demi_ext_event* trace, uint32_
   if (n_threads > 256) n_threads = 256;
   pthread_t th[256];
   job_t jobs[256];
+  const uint64_t k = lim->executions_per_instance > 1 ? lim->executions_per_instance : 1;
+  const uint64_t units = (n + k - 1) / k;                 /* executions, or instances in the carried-generator mode */
   for (int t = 0; t < n_threads; t++) {
-    jobs[t] = (job_t){m, trace, n_ev, seed_base, seeds, n * (uint64_t)t / (uint64_t)n_threads,
-                      n * (uint64_t)(t + 1) / (uint64_t)n_threads, lim, out};
+    jobs[t] = (job_t){m, trace, n_ev, seed_base, seeds, units * (uint64_t)t / (uint64_t)n_threads,
+                      units * (uint64_t)(t + 1) / (uint64_t)n_threads, lim, out, n};
     if (n_threads == 1) job_main(&jobs[t]);
     else pthread_create(&th[t], NULL, job_main, &jobs[t]);
   }

@@ -53,6 +53,9 @@ int orc_random_execute(const demi_model* m, const demi_ext_event* trace, uint32_
                        uint32_t* n_rec, uint64_t* final_states);
 
 /* n executions; seeds == NULL -> seed_base + i.  n_threads > 1 splits the index range. */
+int orc_random_execute_carried(const demi_model* m, const demi_ext_event* trace, uint32_t n_ev, uint64_t seed, uint32_t exec_index,
+                               const demi_limits* lim, demi_verdict* out, demi_rec_event* rec, uint32_t rec_cap,
+                               uint32_t* n_rec, uint32_t* ran);
 int orc_random_explore(const demi_model* m, const demi_ext_event* trace, uint32_t n_ev, uint64_t seed_base,
                        const uint64_t* seeds, uint64_t n, const demi_limits* lim, demi_verdict* out,
                        int n_threads);

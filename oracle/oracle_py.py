@@ -155,6 +155,24 @@ def random_execute(model, events, seed, limits, record=True):
     return v, rec[:min(n_rec.value, len(rec))].copy(), states
 
 
+def random_execute_carried(model, events, seed, exec_index, limits):
+    """Execution number exec_index of the RandomScheduler instance seeded `seed` (limits.executions_per_instance mode: one
+    generator through the instance's executions); returns (verdict, recorded events, index of the execution the instance
+    stopped at - exec_index, or an earlier violating one)."""
+    ms = model.to_struct()
+    ev = np.ascontiguousarray(events)
+    v = T.Verdict()
+    rec = np.zeros(T.MAX_REC_EVENTS, dtype=T.REC_EVENT_DTYPE)
+    n_rec, ran = C.c_uint32(0), C.c_uint32(0)
+    L = lib()
+    L.orc_random_execute_carried.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    rc = L.orc_random_execute_carried(C.byref(ms), ev.ctypes.data, len(ev), C.c_uint64(seed), exec_index, C.byref(limits),
+                                      C.byref(v), rec.ctypes.data, len(rec), C.byref(n_rec), C.byref(ran))
+    assert rc == 0
+    return v, rec[:min(n_rec.value, len(rec))].copy(), ran.value
+
+
 def sts_replay_batch(model, original_externals, original_trace, masks, limits, n_threads=1):
     """STSScheduler.test (no peek) for every candidate mask (uint64[n, 4]); VERDICT_DTYPE array."""
     ms = model.to_struct()

@@ -23,6 +23,8 @@ object DemiGpu {
                                    out: Array[Long], counts: Array[Long]): Int
   /** returns the number of recorded events (12 bytes each in `recorded`), or a negative status */
   @native def randomGetTrace(h: Long, seed: Long, limits: Array[Int], verdict: Array[Long], recorded: Array[Byte]): Int
+  /** the same for execution number `execIndex` of the instance seeded `seed` (demi_limits.executions_per_instance > 1) */
+  @native def randomGetTraceCarried(h: Long, seed: Long, execIndex: Int, limits: Array[Int], verdict: Array[Long], recorded: Array[Byte]): Int
   @native def replayLoad(h: Long, externals: Array[Byte], recorded: Array[Byte]): Int
   @native def replayBatch(h: Long, masks: Array[Long], limits: Array[Int], verdicts: Array[Long]): Int
   @native def replayRemovalBatch(h: Long, masksOrNull: Array[Long], skip: Array[Int], limits: Array[Int], verdicts: Array[Long]): Int

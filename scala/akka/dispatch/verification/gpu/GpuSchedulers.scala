@@ -71,13 +71,16 @@ object GpuDepTracker {
  *  lowering.  Execution i of explore() is one full execution with `new FullyRandom(seed + i)`, i.e. the shape of
  *  RunnerUtils.fuzz, which builds a fresh scheduler and strategy per execution (RunnerUtils.scala:75-90).
  *
- *  NOT result-compatible with `new RandomScheduler(config, max_executions = N)` for N > 1: one RandomScheduler instance
- *  never reseeds between its executions (RandomScheduler.scala:584, 649-651: execution k + 1 continues the generator where
- *  execution k left it), a sequential dependence that cannot be evaluated in parallel.  The contract here is
- *  "N independent executions with seeds seed, seed + 1, ...", and explore() returns the lowest violating index. */
+ *  One RandomScheduler instance never reseeds between its executions (RandomScheduler.scala:584, 649-651: execution k + 1
+ *  continues the generator where execution k left it).  carriedGenerator = true reproduces exactly that -
+ *  `new RandomScheduler(config, max_executions, ..., new FullyRandom(seed))`: one lane runs the chain of executions, the
+ *  first violating one is returned - and is what a JVM run with the same seed can be compared with execution by execution
+ *  (sequential by nature: use it for that comparison, not for throughput).  The default is "N independent executions with
+ *  seeds seed, seed + 1, ...", the lowest violating index returned: RunnerUtils.fuzz's shape, and the parallel one. */
 class GpuRandomScheduler(val schedulerConfig: SchedulerConfig, max_executions: Int = 1, invariant_check_interval: Int = 0,
                          seed: Long = System.currentTimeMillis(), lowering: TableLowering, device: Int = 0,
-                         srcDstFifo: Boolean = false, pMax: Int = 64) extends GpuSchedulerBase with TestOracle {
+                         srcDstFifo: Boolean = false, pMax: Int = 64, carriedGenerator: Boolean = false)
+    extends GpuSchedulerBase with TestOracle {
   private val h = ctxCreate(device)
   if (h == 0) throw new IllegalStateException("no MI355X visible: use RandomScheduler")
   private var maxMessages = Int.MaxValue
@@ -90,7 +93,10 @@ class GpuRandomScheduler(val schedulerConfig: SchedulerConfig, max_executions: I
 
   private def limits(lookingFor: Option[ViolationFingerprint], p: Int = pMax) = Array(
     if (maxMessages == Int.MaxValue) 0 else maxMessages, math.max(0, invariant_check_interval), p,
-    if (lookingFor.isDefined) 1 else 0, lookingFor.map(lowering.fingerprintCode).getOrElse(0), 0, if (srcDstFifo) 1 else 0, 0)
+    if (lookingFor.isDefined) 1 else 0, lookingFor.map(lowering.fingerprintCode).getOrElse(0), 0, if (srcDstFifo) 1 else 0, 0,
+    // demi_limits.executions_per_instance: carriedGenerator = exactly `new RandomScheduler(config, max_executions)` with
+    // `new FullyRandom(seed)` - ONE generator through all executions, the first violating one returned
+    if (carriedGenerator) max_executions else 1)
 
   private def prepare(trace: Seq[ExternalEvent]) {
     if (!modelLoaded) {
@@ -126,7 +132,9 @@ class GpuRandomScheduler(val schedulerConfig: SchedulerConfig, max_executions: I
         var lim = limits(lookingFor)
         if (fl < 0 || (fl & OVF) != 0) lim = limits(lookingFor, MAX_PENDING)
         val v = new Array[Long](2); val rec = new Array[Byte](12 * 16384)
-        val n = check(h, randomGetTrace(h, seed + start + idx, lim, v, rec))
+        // (carried generator: `idx` is the execution number within the one instance; the recording kernel re-runs the chain)
+        val n = if (carriedGenerator) check(h, randomGetTraceCarried(h, seed, (start + idx).toInt, lim, v, rec))
+                else check(h, randomGetTrace(h, seed + start + idx, lim, v, rec))
         val f = flags(v, 0)
         if ((f & OVF) != 0) throw new UnsupportedOnGpu("schedule " + (start + idx) + " exceeds the engine's capacities")
         if ((f & V_VIOLATION) != 0) {
@@ -178,7 +186,7 @@ class GpuSTSScheduler(val schedulerConfig: SchedulerConfig, original_trace: Even
   def getName = "GpuSTSSchedNoPeek"
   // the last entry is demi_limits.filter_known_absents: SchedulerConfig.filterKnownAbsents, as the reference computes it
   private def limits(fp: ViolationFingerprint, p: Int = pMax) =
-    Array(0, 0, p, 1, lowering.fingerprintCode(fp), 0, 0, if (schedulerConfig.filterKnownAbsents) 1 else 0)
+    Array(0, 0, p, 1, lowering.fingerprintCode(fp), 0, 0, if (schedulerConfig.filterKnownAbsents) 1 else 0, 1)
   private def mask(subseq: Seq[ExternalEvent]): Array[Long] = {
     val m = new Array[Long](4)
     for (e <- subseq) { val i = indexOf(e._id); m(i >> 6) |= 1L << (i & 63) }
@@ -233,7 +241,7 @@ class GpuStsRemovalOracle(schedulerConfig: SchedulerConfig, mcs: Seq[ExternalEve
   private var modelLoaded = false
   // the last entry is demi_limits.filter_known_absents: SchedulerConfig.filterKnownAbsents, as the reference computes it
   private def limits(fp: ViolationFingerprint, p: Int = pMax) =
-    Array(0, 0, p, 1, lowering.fingerprintCode(fp), 0, 0, if (schedulerConfig.filterKnownAbsents) 1 else 0)
+    Array(0, 0, p, 1, lowering.fingerprintCode(fp), 0, 0, if (schedulerConfig.filterKnownAbsents) 1 else 0, 1)
   private def load(trace: EventTrace) {
     if (!modelLoaded) {
       val m = lowering.model

@@ -465,3 +465,46 @@ def test_code_id_names_the_compiled_kernel(oracle):
         finally:
             ctx.close()
     assert ids[0] != 0 and ids[0] == ids[1] and ids[2] not in (0, ids[0])
+
+
+@pytest.mark.parametrize("strategy", [T.STRATEGY_FULLY_RANDOM, T.STRATEGY_SRC_DST_FIFO])
+def test_carried_generator_instances(gpu_ctx, oracle, strategy):
+    """demi_limits.executions_per_instance = k: one lane = one `new RandomScheduler(config, max_executions = k)` whose
+    generator(s) run on through its executions (RandomScheduler.scala:248-269, 575-595, 649-651), lookingFor on the first
+    execution only (:586), nothing run behind the first violating execution.  Kernel = oracle on every verdict (the oracle's
+    chain is pinned to the Scala explore loop in tests/test_random_scheduler_transliteration_cpu.py), with a verdict count
+    that is not a multiple of k, explicit per-instance seeds, a lookingFor, and the recorded trace of a chained execution."""
+    model, events, lim0 = raft5_config2()
+    k, n = 7, 20003
+    for looking in (0, 1):
+        fp = 0
+        if looking:                                   # a fingerprint that occurs: from the independent executions
+            ind = oracle.random_explore(model, events, 400, seed_base=SEED_BASE, limits=lim0, n_threads=os.cpu_count())
+            fp = int(ind["fingerprint"][np.nonzero(ind["flags"] & T.V_VIOLATION)[0][0]])
+        lim = T.Limits(lim0.max_messages, lim0.invariant_check_interval, 64, looking, fp, 0, strategy, 0, k)
+        g, c = both(gpu_ctx, oracle, model, events, n, lim)
+        assert_same(g, c)
+        viol = np.nonzero(g["flags"] & T.V_VIOLATION)[0]
+        assert len(viol) > 20
+        not_run = (g["flags"] == 0) & (g["hash"] == 0)
+        assert not_run.sum() > 0                      # executions behind a violating one
+        for i in viol[:50]:                           # ... and exactly those
+            end = min((i // k + 1) * k, n)
+            assert not_run[i + 1:end].all() and not not_run[(i // k) * k:i + 1].any()
+    # explicit seeds are per instance
+    seeds = np.arange(1000, 1000 + (n + k - 1) // k, dtype=np.uint64) * np.uint64(7919)
+    lim = T.Limits(lim0.max_messages, lim0.invariant_check_interval, 64, 0, 0, 0, strategy, 0, k)
+    g, c = both(gpu_ctx, oracle, model, events, n, lim, seeds=seeds)
+    assert_same(g, c)
+    # a chained execution differs from the independent execution of the same index
+    lim1 = T.Limits(lim0.max_messages, lim0.invariant_check_interval, 64, 0, 0, 0, strategy)
+    ind = gpu_ctx.random_explore(2 * k, lim1, seed_base=SEED_BASE)
+    lim = T.Limits(lim0.max_messages, lim0.invariant_check_interval, 64, 0, 0, 0, strategy, 0, k)
+    chained = gpu_ctx.random_explore(2 * k, lim, seed_base=SEED_BASE)
+    assert chained[0] == ind[0] and chained[k] == ind[1] and chained[1] != ind[1]
+    # the recorded trace of execution e of an instance
+    for e in (0, 3):
+        v, rec, ran = gpu_ctx.random_get_trace_carried(SEED_BASE + 2, e, lim)
+        vo, reco, rano = oracle.random_execute_carried(model, events, SEED_BASE + 2, e, lim)
+        assert ran == rano and (int(v.flags), int(v.fingerprint), int(v.hash)) == (int(vo.flags), int(vo.fingerprint), int(vo.hash))
+        assert len(rec) == len(reco) and (rec == reco).all()

@@ -66,7 +66,9 @@ class FullyRandom:
 
 
 class ScalaRandomScheduler:
-    def __init__(self, oracle, model, trace, seed, maxMessages, invariant_check_interval):
+    def __init__(self, oracle, model, trace, seed, maxMessages, invariant_check_interval, strategy=None):
+        """strategy: the FullyRandom of an earlier execution of the same scheduler instance (reset_all_state keeps the object
+        and calls pendingEvents.clear(), RandomScheduler.scala:584: its Random is not reseeded)."""
         self.oracle, self.model, self.ms = oracle, model, model.to_struct()
         self.trace = [tuple(int(x) for x in (e["kind"], e["a"], e["b"], e["msg_type"], e["p0"], e["p1"])) for e in trace]
         self.maxMessages = maxMessages if maxMessages else (1 << 31) - 1
@@ -80,7 +82,7 @@ class ScalaRandomScheduler:
         self.enqueuedExternalMessages = Counter()
         self.messagesToSend = []                      # (senderOpt, receiver, msg)
         # ---- RandomScheduler
-        self.pendingEvents = FullyRandom(seed)
+        self.pendingEvents = strategy if strategy is not None else FullyRandom(seed)
         self.justScheduledTimers, self.timersToResend = set(), []
         self.violationFound = None
         self.messagesScheduledSoFar = 0
@@ -352,3 +354,41 @@ def test_crashing_and_randomised_applications_equal_the_scala_transliteration(or
     ev = events_to_array([start(a) for a in range(4)] + [send(a, 0) for a in range(4)] + [wait_quiescence(), send(1, 0), send(2, 0)])
     c, _ = _compare(oracle, jittery_model(), ev, [0x7E57AB1E0000 + 31 * i for i in range(40)], 150, 11, p_max=64)
     assert c >= 30
+
+
+def test_carried_generator_instances_equal_the_scala_explore_loop(oracle):
+    """explore() with max_executions = k on ONE scheduler instance (RandomScheduler.scala:248-269): reset_all_state (:575-595)
+    clears the pending set - RandomizedHashSet.clear, the restatement's true clear - but keeps the FullyRandom and its
+    java.util.Random, so execution e + 1 continues the generator where e stopped; lookingFor is None from the second
+    execution on (:586); the loop returns at the first violating execution.  The oracle's executions_per_instance mode,
+    execution by execution, against the transliteration driven through that loop."""
+    from demi_amd.apps import SEED_BASE, raft5_config2
+    model, events, lim = raft5_config2()
+    k, n_inst = 12, 10
+    limc = T.Limits(lim.max_messages, lim.invariant_check_interval, 128, 0, 0, 0, 0, 0, k)
+    got = oracle.random_explore(model, events, k * n_inst, seed_base=SEED_BASE, limits=limc)
+    stopped_early = 0
+    for j in range(n_inst):
+        strategy = None
+        for e in range(k):
+            s = ScalaRandomScheduler(oracle, model, events, SEED_BASE + j, lim.max_messages, lim.invariant_check_interval, strategy=strategy)
+            s.execute()
+            v = got[j * k + e]
+            assert (int(v["flags"]), int(v["fingerprint"]), int(v["hash"])) == s.verdict(), (j, e)
+            # reset_all_state: pendingEvents.clear() (the array empties, the generator stays)
+            strategy = s.pendingEvents
+            del strategy.pendingEvents.arr[:]
+            if s.violationFound:
+                rest = got[j * k + e + 1:(j + 1) * k]
+                assert not rest["flags"].any() and not rest["hash"].any(), "executions behind the first violation are not run"
+                stopped_early += e + 1 < k
+                break
+    assert stopped_early >= 1, "the sample holds an instance that stops at a violation"
+    # the chain differs from independent executions: execution 1 of instance 0 is NOT the execution seeded SEED_BASE + 1
+    ind = oracle.random_explore(model, events, 2, seed_base=SEED_BASE, limits=T.Limits(lim.max_messages, lim.invariant_check_interval, 128, 0, 0, 0))
+    assert int(got[1]["hash"]) != int(ind[1]["hash"]) and int(got[0]["hash"]) == int(ind[0]["hash"])
+    # the recorded trace of a chained execution: same verdict as the batch, deliveries counted in its flags
+    v, rec, ran = oracle.random_execute_carried(model, events, SEED_BASE, 3, limc)
+    first_stop = next((e for e in range(4) if got[e]["flags"] & T.V_VIOLATION), 3)
+    assert ran == first_stop and int(v.hash) == int(got[first_stop]["hash"])
+    assert int((rec["kind"] == T.REC_MSG_EVENT).sum()) == T.verdict_deliveries(int(v.flags))
