@@ -180,7 +180,8 @@ class Context:
         sp = None
         if seeds is not None:
             seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
-            assert len(seeds) == n
+            k = max(1, int(limits.executions_per_instance))           # carried-generator mode: one seed per instance
+            assert len(seeds) == (n + k - 1) // k
             sp = seeds.ctypes.data
         self._check(lib().demi_random_explore(self._h, C.c_uint64(seed_base), sp, n, C.byref(limits),
                                               out.ctypes.data if n else None))

@@ -117,6 +117,13 @@ def by_grid_lines(cur, like):
     q = "select name, %s as g, count(*), avg(duration), min(duration), max(duration) from kernels where name like ? group by name, g order by name, avg(duration)" % g
     for r in cur.execute(q, (like,)):
         out.append("%-60s %-18s %6d %12.0f %12.0f %12.0f" % (r[0][:60], r[1], r[2], r[3], r[4], r[5]))
+    # persistent grids cap the launch shape at the resident workgroups, so the big frontiers share one shape: the ten longest
+    # launches of each kernel, in ns (bench.py --workload ddmin ends with 1 + 5 launches of 2^20 candidates)
+    out.append("# the ten longest launches per kernel (ns)")
+    names = [r[0] for r in cur.execute("select distinct name from kernels where name like ?", (like,))]
+    for nm in names:
+        d = [r[0] for r in cur.execute("select duration from kernels where name = ? order by duration desc limit 10", (nm,))]
+        out.append("%-60s %s" % (nm[:60], " ".join("%d" % x for x in d)))
     return out
 
 
