@@ -409,14 +409,26 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # Plumbing test of the N > 1 path on a box with ONE GPU (tests/test_comm_gpu.py): DEMI_BENCH_BACKEND=gloo,
+    # DEMI_BENCH_ONE_GPU=1 (every rank on cuda:0) and DEMI_BENCH_COMM=host (the library's communicator over a host all-gather
+    # callback instead of RCCL, which refuses two ranks on one device).  The driver's 8-GPU run uses none of them.
+    backend = os.environ.get("DEMI_BENCH_BACKEND", "nccl")
+    one_gpu = os.environ.get("DEMI_BENCH_ONE_GPU") == "1"
+    host_comm = os.environ.get("DEMI_BENCH_COMM") == "host"
+    if one_gpu:
+        local_rank = 0
     if args.gpus > 1 or world > 1:
         assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = dev if backend == "nccl" else torch.device("cpu")       # where torch.distributed's own small tensors live
 
     if args.workload != "fuzz":
         assert world == 1, "the dpor / ddmin records are single-GPU"
@@ -458,7 +470,15 @@ def main():
     # behind the C ABI, what a JVM host would call); its unique id travels over torch.distributed, which also provides the
     # barrier.  If RCCL cannot be initialised there, torch.distributed's all_gather does the exchange (and the line says so).
     collective = "none (1 rank)"
-    if world > 1:
+    if world > 1 and host_comm:
+        def _host_allgather(block: bytes) -> bytes:
+            mine = torch.frombuffer(bytearray(block), dtype=torch.uint8)
+            parts = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(parts, mine)
+            return b"".join(bytes(q.numpy().tobytes()) for q in parts)
+        ctx.comm_create_host(rank, world, _host_allgather)
+        collective = "demi_comm_allgather_dev (host all-gather callback over torch.distributed %s: plumbing test)" % backend
+    elif world > 1:
         # (every rank takes part in both broadcasts whatever happens on rank 0: a failure there must not leave the others waiting)
         uid = torch.zeros(129, dtype=torch.uint8, device=dev)
         if rank == 0:
@@ -525,7 +545,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 

@@ -894,6 +894,235 @@ int explore_rounds_resident(Dev&& dev, const demi_dpor_search* srch, demi_verdic
   return 0;
 }
 
+// ------------------------------------------------------------------ REFERENCE order, results resident on the device
+// The same committed sequence as explore_reference_order (DPORwHeuristics' own one-at-a-time order), with what made that
+// path slow taken out: every finished trace used to cross PCIe together with all of its racing pairs (1.3 GB for config 3),
+// to be filtered and absorbed on the host.  Here
+//   * traces stay in the device's arena; a backtrack point is {arena id of the interleaving that found it, branch, later,
+//     earlier} and the device builds the next trace from it (as in the ROUNDS path), so the item IS the identity of an
+//     interleaving: results are cached under it, no trace hashing;
+//   * the SPECULATION - which interleavings to run before the commit asks for them - is the device-resident ROUNDS
+//     exploration itself (explored-pair table, candidates and enqueue decision on the device, explore_rounds_resident's
+//     queue here): it costs 3.5 MB of PCIe for the whole of config 3;
+//   * the COMMIT (`real`: pop one point, absorb that interleaving's racing pairs, pop again - getNext() / dpor() verbatim)
+//     only ever sees the racing pairs that can still change its state.  The device drops, per interleaving and in pair
+//     order, (a) the pairs its parent provably applied (ParentFilter's rule, evaluated against the parent's trace in the
+//     arena) and (b) the pairs that are no-ops under a SNAPSHOT of the commit's own explored-pair table, which the host
+//     mirrors to the device as deltas before every launch.  (b) is sound because the state a no-op tests only grows: a pair
+//     (ke, kl, b) is a no-op iff (ke, kl) is explored and its flip is explored or carries a queued mark above b; explored
+//     bits are never cleared and a mark is only replaced by a higher one or superseded by the explored bit - so a pair that
+//     is a no-op under an OLDER state of the table is a no-op when the commit reaches it.  What remains travels as 24-byte
+//     records (keys + indices), in pair order.
+// Committed sequence, verdicts, prefix lengths, first violation: those of batch = 1 (tests: the CPU harness restates the
+// device rules sequentially under this same loop; the GPU suite holds config 3 against the committed golden sequence).
+struct RefRec {              // one racing pair the commit still has to absorb (device -> host), 24 bytes
+  unsigned long long ke, kl;
+  uint8_t branch, later, earlier, pad;
+  uint32_t pad2;
+};
+struct RefDelta {            // one entry of the commit's explored-pair table that changed since the last launch (host -> device)
+  unsigned long long lo, hi; // the unordered pair, lo < hi
+  uint32_t state[2];         // side 0 = (lo, hi), side 1 = (hi, lo): bit 31 explored, bits 0..8 = 1 + highest queued branch
+};
+
+// The commit's bookkeeping over records: one queue (256 FIFO buckets by branch, creation order within one), one table.
+class RefBook {
+ public:
+  struct Point { unsigned long long flip_a, flip_b; uint32_t src; uint8_t branch, later, earlier, pad; };
+  // dpor() for one committed interleaving (arena id `src`): its surviving racing pairs in pair order
+  void absorb(const RefRec* r, uint32_t n, uint32_t src) {
+    front_valid_ = false;
+    for (uint32_t k = 0; k < n; k++) {
+      const FlatPairMap::Ref e = map_.at(r[k].ke, r[k].kl);
+      uint32_t* const side0 = r[k].ke < r[k].kl ? e.fwd : e.rev;      // (the entry's first value: where the dirty mark lives)
+      if (!(*e.fwd & EXPLORED)) touch(side0, r[k].ke, r[k].kl);
+      *e.fwd |= EXPLORED;                                  // setExplored(branchI, (earlier, later)) (:1068-1070)
+      uint32_t& flipped = *e.rev;
+      if (flipped & EXPLORED) continue;                    // getNext would skip it (:1153-1157)
+      if ((flipped & QUEUED_MASK) > r[k].branch) continue; // a queued point of this pair pops before it
+      flipped = (flipped & ~QUEUED_MASK) | ((uint32_t)r[k].branch + 1);
+      touch(side0, r[k].ke, r[k].kl);
+      bucket_[r[k].branch].push_back(Point{r[k].kl, r[k].ke, src, r[k].branch, r[k].later, r[k].earlier, 0});
+      if ((int)r[k].branch > top_) top_ = (int)r[k].branch;
+      queued_++; enqueued_++;
+    }
+  }
+  // getNext (:1142-1162): deepest branch first, creation order within a branch, explored flips skipped; marks it explored
+  bool get_next(Point& out) {
+    while (top_ >= 0) {
+      std::deque<Point>& b = bucket_[top_];
+      if (b.empty()) { top_--; continue; }
+      const Point p = b.front();
+      b.pop_front();
+      queued_--;
+      const FlatPairMap::Ref e = map_.at(p.flip_a, p.flip_b);
+      if (*e.fwd & EXPLORED) continue;                     // isExplored: skip
+      *e.fwd |= EXPLORED;                                  // setExplored(maxIndex, (e1, e2)) (:1170-1172)
+      touch(p.flip_a < p.flip_b ? e.fwd : e.rev, p.flip_a, p.flip_b);
+      out = p;
+      return true;
+    }
+    return false;
+  }
+  uint64_t queue_len() const { return queued_; }
+  uint64_t enqueued() const { return enqueued_; }
+  // the entries that changed since the last call, with their current states
+  void take_deltas(std::vector<RefDelta>& out) {
+    out.clear();
+    out.reserve(dirty_.size());
+    for (const std::pair<uint64_t, uint64_t>& k : dirty_) {
+      const FlatPairMap::Ref e = map_.at(k.first, k.second);      // (lo, hi): fwd = side 0
+      *e.fwd &= ~DIRTY;
+      out.push_back(RefDelta{k.first, k.second, {*e.fwd & ~DIRTY, *e.rev & ~DIRTY}});
+    }
+    dirty_.clear();
+  }
+
+ private:
+  static constexpr uint32_t EXPLORED = 0x80000000u, QUEUED_MASK = 0x1FFu, DIRTY = 0x40000000u;   // DIRTY lives on side 0 only
+  // (no second table lookup here: a lookup may grow the table and move the entry the caller is still pointing at)
+  void touch(uint32_t* side0, uint64_t a, uint64_t b) {
+    if (!(*side0 & DIRTY)) { *side0 |= DIRTY; dirty_.push_back({a < b ? a : b, a < b ? b : a}); }
+  }
+  FlatPairMap map_;
+  std::deque<Point> bucket_[256];
+  int top_ = -1;
+  bool front_valid_ = false;
+  uint64_t queued_ = 0, enqueued_ = 0;
+  std::vector<std::pair<uint64_t, uint64_t>> dirty_;
+};
+
+// dev.round_ref(items, use_parent, n, round, base_id, deltas, n_deltas, verdicts, points, kills, rec_off, rec_cnt, recs):
+//   one launch like dev.round() of the ROUNDS path (K3 + the speculation's mark / insert / decide), plus: the deltas applied to
+//   the device's copy of the commit's table first, and afterwards the commit filter - interleaving i's surviving racing pairs
+//   are recs[rec_off[i] .. + rec_cnt[i]) in pair order; use_parent[i] says whether its parent's trace may be used for (a).
+template <class Dev>
+int explore_reference_resident(Dev&& dev, const demi_dpor_search* srch, demi_verdict* out_verdicts, uint32_t* out_prefix_len,
+                               uint32_t* out_rounds, demi_dpor_trace_entry* first_violation_trace, uint32_t* first_violation_len,
+                               demi_dpor_stats* stats, double* seconds) {
+  memset(stats, 0, sizeof *stats);
+  stats->first_violation = ~0ull;
+  if (first_violation_len) *first_violation_len = 0;
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  auto key_of = [](const demi::DporItem& it) -> uint64_t {
+    return ((uint64_t)it.src << 24) | ((uint64_t)it.branch << 16) | ((uint64_t)it.later << 8) | (uint64_t)it.earlier;
+  };
+  struct Result { uint32_t id; demi_verdict verdict; uint64_t rec_off; uint32_t rec_cnt; };
+  std::unordered_map<uint64_t, Result> results;          // every interleaving run so far, by its item
+  std::vector<RefRec> pool;                              // their surviving racing pairs
+  std::vector<uint8_t> complete;                         // per arena id: invariant (I) of ParentFilter holds (see there)
+  RefBook real;
+  // the speculation's queue (explore_rounds_resident's)
+  std::deque<demi::DporPoint> bucket[256];
+  int top = -1;
+  std::unordered_set<std::pair<uint64_t, uint64_t>, PairKeyHash> dead;
+
+  const demi::DporItem first{0xFFFFFFFFu, 0, 0, 0, 0};
+  demi::DporItem cur = first;
+  bool have_cur = true, exhausted = false, done = false;
+  std::vector<demi::DporItem> spec_items(1, first), items;
+  std::vector<uint8_t> use_parent;
+  std::vector<demi_verdict> vd;
+  std::vector<demi::DporPoint> pts;
+  std::vector<demi::DporKill> kills;
+  std::vector<uint64_t> rec_off;
+  std::vector<uint32_t> rec_cnt;
+  std::vector<RefRec> recs;
+  std::vector<RefDelta> deltas;
+  uint32_t base_id = 0, round = 0;
+  uint64_t first_id = ~0ull;
+
+  while (!done) {
+    // ---- commit, one interleaving at a time, as far as computed results reach
+    double t0 = now();
+    while (have_cur) {
+      auto it = results.find(key_of(cur));
+      if (it == results.end()) break;
+      const Result& r = it->second;
+      const uint64_t idx = stats->interleavings++;
+      out_verdicts[idx] = r.verdict;
+      out_prefix_len[idx] = cur.src == 0xFFFFFFFFu ? 0u : (uint32_t)cur.later;
+      bool found = false;
+      if (r.verdict.flags & DEMI_V_VIOLATION) {
+        stats->violations++;
+        found = true;
+        if (stats->first_violation == ~0ull) { stats->first_violation = idx; first_id = r.id; }
+      }
+      real.absorb(pool.data() + r.rec_off, r.rec_cnt, r.id);
+      if ((srch->stop_if_violation && found) || stats->interleavings >= srch->max_interleavings) { done = true; break; }
+      RefBook::Point p;
+      have_cur = real.get_next(p);
+      if (!have_cur) { exhausted = true; done = true; break; }
+      cur = demi::DporItem{p.src, p.branch, p.later, p.earlier, 0};
+    }
+    double t1 = now();
+    if (seconds) seconds[2] += t1 - t0;
+    if (done) break;
+
+    // ---- one launch: what the commit is waiting for + the speculation's next round (minus what has been run already)
+    stats->cache_misses++;
+    items.clear();
+    items.push_back(cur);
+    {
+      std::unordered_set<uint64_t> in_launch;
+      in_launch.insert(key_of(cur));
+      for (const demi::DporItem& s : spec_items) {
+        const uint64_t k = key_of(s);
+        if (results.count(k) || !in_launch.insert(k).second) continue;
+        items.push_back(s);
+      }
+    }
+    const uint32_t n = (uint32_t)items.size();
+    use_parent.resize(n);
+    for (uint32_t i = 0; i < n; i++) use_parent[i] = items[i].src != 0xFFFFFFFFu && items[i].src < complete.size() && complete[items[i].src];
+    real.take_deltas(deltas);
+    vd.resize(n); rec_off.resize(n); rec_cnt.resize(n);
+    pts.clear(); kills.clear(); recs.clear();
+    round++;
+    int rc = dev.round_ref(items.data(), use_parent.data(), n, round, base_id, deltas.data(), (uint32_t)deltas.size(), vd.data(), pts, kills,
+                           rec_off.data(), rec_cnt.data(), recs);
+    if (rc) return rc;
+    if (out_rounds && stats->launches < srch->max_interleavings) out_rounds[stats->launches] = n;
+    stats->launches++;
+    stats->executed += n;
+    double t2 = now();
+    const uint64_t pool_base = pool.size();
+    pool.insert(pool.end(), recs.begin(), recs.end());
+    if (complete.size() < (size_t)base_id + n) complete.resize((size_t)base_id + n, 0);
+    for (uint32_t i = 0; i < n; i++) {
+      results[key_of(items[i])] = Result{base_id + i, vd[i], pool_base + rec_off[i], rec_cnt[i]};
+      // (I) holds for this interleaving once it is absorbed iff its own pair list is whole and (I) held for its parent
+      complete[(size_t)base_id + i] = !(vd[i].flags & DEMI_V_PAIRS_OVF) && (items[i].src == 0xFFFFFFFFu || use_parent[i]);
+    }
+    base_id += dev.ids_used(n);
+    // the speculation: this round's live points and kills into its queue, then its next round
+    for (const demi::DporKill& k : kills) dead.insert({k.a, k.b});
+    std::sort(pts.begin(), pts.end(), [](const demi::DporPoint& x, const demi::DporPoint& y) { return x.ordinal < y.ordinal; });
+    for (const demi::DporPoint& p : pts) {
+      bucket[p.branch].push_back(p);
+      if ((int)p.branch > top) top = (int)p.branch;
+    }
+    spec_items.clear();
+    while (spec_items.size() < srch->batch) {
+      while (top >= 0 && bucket[top].empty()) top--;
+      if (top < 0) break;
+      const demi::DporPoint p = bucket[top].front();
+      bucket[top].pop_front();
+      if (!dead.insert({p.flip_a, p.flip_b}).second) continue;
+      spec_items.push_back(demi::DporItem{p.src, p.branch, p.later, p.earlier, 0});
+    }
+    if (seconds) { seconds[0] += t2 - t1; seconds[1] += now() - t2; }
+  }
+  if (first_id != ~0ull && first_violation_trace && first_violation_len) {
+    int rc = dev.fetch_trace((uint32_t)first_id, first_violation_trace, first_violation_len);
+    if (rc) return rc;
+  }
+  stats->queue_len = real.queue_len();
+  stats->backtrack_points = real.enqueued();
+  stats->exhausted = exhausted ? 1u : 0u;
+  return 0;
+}
+
 template <class Run, class Fetch>
 int explore_loop(Run&& run, Fetch&& fetch, uint32_t max_pairs, const demi_dpor_search* srch, demi_verdict* out_verdicts,
                  uint32_t* out_prefix_len, uint32_t* out_rounds, demi_dpor_trace_entry* first_violation_trace,

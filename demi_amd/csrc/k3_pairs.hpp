@@ -225,3 +225,148 @@ __global__ __launch_bounds__(256) void k3_pairs_decide_rec(const K3PairArgs a) {
 }
 
 }  // namespace demi
+
+namespace demi {
+
+// ------------------------------------------------------------------ REFERENCE order: the commit filter
+// (dpor_host.hpp explore_reference_resident.)  The commit absorbs an interleaving's racing pairs one interleaving at a time on
+// the host; of the ~10^3 pairs an interleaving reports only those that can still change the commit's state need to get
+// there.  One workgroup per interleaving drops, in pair order,
+//   (a) what its PARENT provably applied - ParentFilter's rule (dpor_host.hpp): both events also occur in the parent, with
+//       unique keys on both sides and equal quiescent periods, in the same order, and the branch event sits at least as deep
+//       there - evaluated against the parent's trace in the arena through a hash of its node keys in LDS;
+//   (b) what is a no-op under the device's copy of the commit's explored-pair table (a SNAPSHOT: the host sends the entries
+//       that changed before every launch): (ke, kl) explored and its flip explored or marked above the pair's branch.  The
+//       state only grows, so a no-op under an older state is a no-op when the commit reaches the pair.
+// The survivors are written as 24-byte records, contiguous per interleaving and in pair order.
+struct RefRecDev { unsigned long long ke, kl; uint8_t branch, later, earlier, pad; uint32_t pad2; };        // = demi_host::RefRec
+struct RefDeltaDev { unsigned long long lo, hi; uint32_t state[2]; };                                       // = demi_host::RefDelta
+
+struct K3RefArgs {
+  PairEntry* real_table; uint32_t real_mask;          // the commit's table as of the last launch
+  const RefDeltaDev* deltas; uint32_t n_deltas;
+  const demi_dpor_trace_entry* arena;
+  const uint32_t* arena_len;
+  const DporItem* items; const uint8_t* use_parent;   // [n]
+  uint32_t base_id, n;
+  const demi_dpor_pair* pairs; const uint32_t* n_pairs; uint32_t max_pairs;
+  RefRecDev* recs; unsigned long long recs_cap;
+  unsigned long long* rec_off; uint32_t* rec_cnt;     // [n]
+  unsigned long long* counters;                       // [0] records wanted (may exceed recs_cap: the host grows and re-runs), [1] table full
+};
+
+// the commit's table: entries are written by k3_ref_apply (one writer per entry and launch) and read by k3_ref_filter
+__global__ __launch_bounds__(256) void k3_ref_apply(const K3RefArgs a) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n_deltas) return;
+  const RefDeltaDev d = a.deltas[i];
+  const uint32_t s = pair_slot(a.real_table, a.real_mask, d.lo, d.hi);        // lo < hi: side 0
+  if (s == 0xFFFFFFFFu) { atomicAdd(&a.counters[1], 1ull); return; }
+  a.real_table[s >> 1].state[0] = d.state[0];
+  a.real_table[s >> 1].state[1] = d.state[1];
+}
+
+// read-only lookup: the states of (a, b) and of its flip, 0 / 0 when the pair has no entry
+__device__ inline void pair_states(const PairEntry* tab, uint32_t mask, uint64_t a, uint64_t b, uint32_t& fwd, uint32_t& rev) {
+  const uint64_t lo = a < b ? a : b, hi = a < b ? b : a;
+  const uint32_t side = a < b ? 0u : 1u;
+  fwd = 0; rev = 0;
+  uint32_t i = (uint32_t)pair_hash(lo, hi) & mask;
+  for (uint32_t probes = 0; probes < 4096; probes++, i = (i + 1) & mask) {
+    const PairEntry* e = tab + i;
+    const unsigned long long el = e->lo;
+    if (el == 0) return;
+    if (el == lo && e->hi == hi) { fwd = e->state[side]; rev = e->state[side ^ 1u]; return; }
+  }
+}
+
+constexpr uint32_t REF_SLOTS = 1024;       // > 2 x DEMI_DPOR_MAX_TRACE
+
+__device__ __forceinline__ uint32_t ref_key_hash(uint64_t k) { return (uint32_t)((k * 0x9E3779B97F4A7C15ULL) >> 54) & (REF_SLOTS - 1); }
+
+__global__ __launch_bounds__(256) void k3_ref_filter(const K3RefArgs a) {
+  __shared__ unsigned long long s_pkey[DEMI_DPOR_MAX_TRACE], s_okey[DEMI_DPOR_MAX_TRACE];
+  __shared__ uint32_t s_pslot[REF_SLOTS], s_oslot[REF_SLOTS];      // 0xFFFFFFFF = empty, else an event index
+  __shared__ uint32_t s_pdup[DEMI_DPOR_MAX_TRACE], s_odup[DEMI_DPOR_MAX_TRACE];
+  __shared__ int s_idx[DEMI_DPOR_MAX_TRACE];
+  __shared__ uint8_t s_pq[DEMI_DPOR_MAX_TRACE];
+  __shared__ uint32_t s_keep[128], s_pre[129];                     // keep bits of up to 4096 pairs; exclusive prefix per word
+  __shared__ unsigned long long s_off;
+  const uint32_t it = blockIdx.x, t = threadIdx.x;
+  const demi_dpor_trace_entry* T = a.arena + (size_t)(a.base_id + it) * DEMI_DPOR_MAX_TRACE;
+  const uint32_t n_tr = min(a.arena_len[a.base_id + it], (uint32_t)DEMI_DPOR_MAX_TRACE);
+  const DporItem item = a.items[it];
+  const bool par = a.use_parent[it] != 0 && item.src != 0xFFFFFFFFu;
+  const demi_dpor_trace_entry* TP = par ? a.arena + (size_t)item.src * DEMI_DPOR_MAX_TRACE : nullptr;
+  const uint32_t n_par = par ? min(a.arena_len[item.src], (uint32_t)DEMI_DPOR_MAX_TRACE) : 0u;
+  for (uint32_t i = t; i < REF_SLOTS; i += blockDim.x) { s_pslot[i] = 0xFFFFFFFFu; s_oslot[i] = 0xFFFFFFFFu; }
+  for (uint32_t i = t; i < 128; i += blockDim.x) s_keep[i] = 0;
+  if (t < DEMI_DPOR_MAX_TRACE) {
+    s_pdup[t] = 0; s_odup[t] = 0; s_idx[t] = -1;
+    if (t < n_par) { s_pkey[t] = TP[t].key; s_pq[t] = TP[t].qperiod; }
+    if (t < n_tr) s_okey[t] = T[t].key;
+  }
+  __syncthreads();
+  // hashes of the parent's and of the own node keys; equal keys mark each other as duplicates (collapsed siblings)
+  if (t < n_par) {
+    const unsigned long long k = s_pkey[t];
+    for (uint32_t h = ref_key_hash(k);; h = (h + 1) & (REF_SLOTS - 1)) {
+      const uint32_t old = atomicCAS(&s_pslot[h], 0xFFFFFFFFu, t);
+      if (old == 0xFFFFFFFFu) break;
+      if (s_pkey[old] == k) { s_pdup[old] = 1; s_pdup[t] = 1; break; }
+    }
+  }
+  if (par && t < n_tr) {
+    const unsigned long long k = s_okey[t];
+    for (uint32_t h = ref_key_hash(k);; h = (h + 1) & (REF_SLOTS - 1)) {
+      const uint32_t old = atomicCAS(&s_oslot[h], 0xFFFFFFFFu, t);
+      if (old == 0xFFFFFFFFu) break;
+      if (s_okey[old] == k) { s_odup[old] = 1; s_odup[t] = 1; break; }
+    }
+  }
+  __syncthreads();
+  // where the own event t sits in the parent: same key, unique on both sides, same quiescent period
+  if (par && t < n_tr && !s_odup[t]) {
+    const unsigned long long k = s_okey[t];
+    for (uint32_t h = ref_key_hash(k);; h = (h + 1) & (REF_SLOTS - 1)) {
+      const uint32_t j = s_pslot[h];
+      if (j == 0xFFFFFFFFu) break;
+      if (s_pkey[j] == k) { if (!s_pdup[j] && s_pq[j] == T[t].qperiod) s_idx[t] = (int)j; break; }
+    }
+  }
+  __syncthreads();
+  const demi_dpor_pair* P = a.pairs + (size_t)it * a.max_pairs;
+  const uint32_t np = min(a.n_pairs[it], a.max_pairs);
+  for (uint32_t k = t; k < np; k += blockDim.x) {
+    const demi_dpor_pair p = P[k];
+    const int ie = s_idx[p.earlier], il = s_idx[p.later], ib = s_idx[p.branch];
+    if (par && ie >= 0 && il >= 0 && ie < il && ib >= (int)p.branch) continue;           // (a) the parent applied it
+    uint32_t sf, sr;
+    pair_states(a.real_table, a.real_mask, s_okey[p.earlier], s_okey[p.later], sf, sr);
+    if ((sf & PE_EXPLORED) && ((sr & PE_EXPLORED) || (sr & PE_QMASK) > p.branch)) continue;   // (b) a no-op for the commit
+    atomicOr(&s_keep[k >> 5], 1u << (k & 31));
+  }
+  __syncthreads();
+  if (t == 0) {
+    uint32_t tot = 0;
+    for (uint32_t w = 0; w < 128; w++) { s_pre[w] = tot; tot += (uint32_t)__popc(s_keep[w]); }
+    s_pre[128] = tot;
+    s_off = atomicAdd(&a.counters[0], (unsigned long long)tot);
+    a.rec_off[it] = s_off;
+    a.rec_cnt[it] = tot;
+  }
+  __syncthreads();
+  const unsigned long long off = s_off;
+  if (off + s_pre[128] > a.recs_cap) return;              // the host sees counters[0] > recs_cap, grows the buffer and runs this again
+  for (uint32_t k = t; k < np; k += blockDim.x) {
+    const uint32_t w = s_keep[k >> 5];
+    if (!((w >> (k & 31)) & 1u)) continue;
+    const demi_dpor_pair p = P[k];
+    RefRecDev r;
+    r.ke = s_okey[p.earlier]; r.kl = s_okey[p.later];
+    r.branch = p.branch; r.later = p.later; r.earlier = p.earlier; r.pad = 0; r.pad2 = 0;
+    a.recs[off + s_pre[k >> 5] + (uint32_t)__popc(w & ((1u << (k & 31)) - 1u))] = r;
+  }
+}
+
+}  // namespace demi

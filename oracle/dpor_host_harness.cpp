@@ -58,12 +58,51 @@ struct SimDev {
   const demi_model* m; const demi_ext_event* ext; uint32_t n_ext; const demi_dpor_params* par; int n_threads;
   std::vector<demi_host::Trace> arena;
   std::unordered_map<std::pair<uint64_t, uint64_t>, SimEntry, demi_host::PairKeyHash> table;
+  std::vector<std::vector<demi_dpor_pair>> pairs;       // racing pairs of the last round's interleavings
+  // the device's copy of the COMMIT's explored-pair table (REFERENCE order, explore_reference_resident): ordered pair -> state
+  std::unordered_map<std::pair<uint64_t, uint64_t>, uint32_t, demi_host::PairKeyHash> real_tab;
+  unsigned long long pairs_reported = 0, pairs_after_parent = 0, pairs_kept = 0;
+
+  // ResidentDev::round_ref restated: the ROUNDS machinery for the speculation, then the commit filter per interleaving -
+  // (a) ParentFilter against the parent's trace in the arena, (b) no-ops under the snapshot of the commit's table
+  int round_ref(const demi::DporItem* items, const uint8_t* use_parent, uint32_t n, uint32_t round_no, uint32_t base_id,
+                const demi_host::RefDelta* deltas, uint32_t n_deltas, demi_verdict* vd, std::vector<demi::DporPoint>& pts,
+                std::vector<demi::DporKill>& kills, uint64_t* rec_off, uint32_t* rec_cnt, std::vector<demi_host::RefRec>& recs) {
+    for (uint32_t i = 0; i < n_deltas; i++) {
+      real_tab[{deltas[i].lo, deltas[i].hi}] = deltas[i].state[0];
+      real_tab[{deltas[i].hi, deltas[i].lo}] = deltas[i].state[1];
+    }
+    const int rc = round(items, n, round_no, base_id, vd, pts, kills);
+    if (rc) return rc;
+    std::vector<demi_dpor_pair> kept;
+    for (uint32_t i = 0; i < n; i++) {
+      const demi_host::Trace& T = arena[(size_t)base_id + i];
+      const std::vector<demi_dpor_pair>& P = pairs[i];
+      pairs_reported += P.size();
+      const demi_host::ParentFilter pf(use_parent[i] ? arena[items[i].src] : demi_host::Trace());
+      if (pf.active()) pf.filter(T.data(), (uint32_t)T.size(), P.data(), (uint32_t)P.size(), kept);
+      else kept.assign(P.begin(), P.end());
+      pairs_after_parent += kept.size();
+      rec_off[i] = recs.size();
+      for (const demi_dpor_pair& p : kept) {
+        const uint64_t ke = T[p.earlier].key, kl = T[p.later].key;
+        auto f = real_tab.find({ke, kl});
+        auto r = real_tab.find({kl, ke});
+        const uint32_t sf = f == real_tab.end() ? 0u : f->second, sr = r == real_tab.end() ? 0u : r->second;
+        if ((sf & SIM_EXPLORED) && ((sr & SIM_EXPLORED) || (sr & SIM_QMASK) > p.branch)) continue;    // a no-op for the commit
+        recs.push_back(demi_host::RefRec{ke, kl, p.branch, p.later, p.earlier, 0, 0});
+      }
+      rec_cnt[i] = (uint32_t)(recs.size() - rec_off[i]);
+      pairs_kept += rec_cnt[i];
+    }
+    return 0;
+  }
 
   int round(const demi::DporItem* items, uint32_t n, uint32_t round_no, uint32_t base_id, demi_verdict* vd,
             std::vector<demi::DporPoint>& pts, std::vector<demi::DporKill>& kills) {
     if (arena.size() < (size_t)base_id + n) arena.resize((size_t)base_id + n);
     const uint32_t mp = par->max_pairs;
-    std::vector<std::vector<demi_dpor_pair>> pairs(n);
+    pairs.assign(n, std::vector<demi_dpor_pair>());
     // mark
     for (uint32_t i = 0; i < n; i++) {
       if (items[i].src == 0xFFFFFFFFu) continue;
@@ -262,12 +301,27 @@ extern "C" int harness_dpor_explore_sharded(const demi_model* m, const demi_ext_
   return 0;
 }
 
+// REFERENCE order with the results resident (explore_reference_resident) over the restated device: the committed sequence must
+// be the one of harness_dpor_explore with order = REFERENCE (and of batch = 1).  pair_counts (optional): racing pairs
+// reported / left by the parent filter / left by the snapshot filter as well (= what would cross PCIe).
+extern "C" int harness_dpor_explore_reference_resident(const demi_model* m, const demi_ext_event* ext, uint32_t n_ext,
+                                                       const demi_dpor_params* par, const demi_dpor_search* srch, int n_threads,
+                                                       demi_verdict* out_verdicts, uint32_t* out_prefix_len, uint32_t* out_rounds,
+                                                       demi_dpor_trace_entry* first_violation_trace, uint32_t* first_violation_len,
+                                                       demi_dpor_stats* stats, double* seconds, uint64_t* pair_counts) {
+  SimDev dev{m, ext, n_ext, par, n_threads, {}, {}, {}, {}};
+  const int rc = demi_host::explore_reference_resident(dev, srch, out_verdicts, out_prefix_len, out_rounds, first_violation_trace,
+                                                       first_violation_len, stats, seconds);
+  if (pair_counts) { pair_counts[0] = dev.pairs_reported; pair_counts[1] = dev.pairs_after_parent; pair_counts[2] = dev.pairs_kept; }
+  return rc;
+}
+
 extern "C" int harness_dpor_explore_resident(const demi_model* m, const demi_ext_event* ext, uint32_t n_ext,
                                              const demi_dpor_params* par, const demi_dpor_search* srch, int n_threads,
                                              demi_verdict* out_verdicts, uint32_t* out_prefix_len, uint32_t* out_rounds,
                                              demi_dpor_trace_entry* first_violation_trace, uint32_t* first_violation_len,
                                              demi_dpor_stats* stats, double* seconds, uint64_t* table_entries) {
-  SimDev dev{m, ext, n_ext, par, n_threads, {}, {}};
+  SimDev dev{m, ext, n_ext, par, n_threads, {}, {}, {}, {}};
   const int rc = demi_host::explore_rounds_resident(dev, srch, out_verdicts, out_prefix_len, out_rounds, first_violation_trace,
                                                     first_violation_len, stats, seconds);
   if (table_entries) *table_entries = dev.table.size();

@@ -20,6 +20,33 @@ def build(force=False):
     return so
 
 
+def dpor_explore_reference_resident(model, externals, params, search, n_threads=None):
+    """REFERENCE order with the results resident on the (restated) device: explore_reference_resident of dpor_host.hpp over the
+    CPU stand-in of ResidentDev::round_ref.  Returns (verdicts, prefix_len, rounds, first violating trace, stats, pair counts
+    [reported, after the parent filter, after the snapshot filter])."""
+    build()
+    H = C.CDLL(os.path.join(_HERE, "_build", "dpor_host_harness.so"))
+    H.harness_dpor_explore_reference_resident.argtypes = [C.POINTER(T.ModelStruct), C.c_void_p, C.c_uint32, C.POINTER(T.DporParams),
+                                                          C.POINTER(T.DporSearch), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                          C.POINTER(C.c_uint32), C.POINTER(T.DporStats), C.c_void_p, C.c_void_p]
+    ms = model.to_struct()
+    ev = np.ascontiguousarray(externals, dtype=T.EXT_EVENT_DTYPE)
+    cap = search.max_interleavings
+    verdicts = np.zeros(cap, dtype=T.VERDICT_DTYPE)
+    plen = np.zeros(cap, dtype=np.uint32)
+    rounds = np.zeros(cap, dtype=np.uint32)
+    vtrace = np.zeros(T.DPOR_MAX_TRACE, dtype=T.DPOR_TRACE_DTYPE)
+    vlen = C.c_uint32(0)
+    stats = T.DporStats()
+    counts = np.zeros(3, dtype=np.uint64)
+    rc = H.harness_dpor_explore_reference_resident(C.byref(ms), ev.ctypes.data, len(ev), C.byref(params), C.byref(search),
+                                                   n_threads or (os.cpu_count() or 1), verdicts.ctypes.data, plen.ctypes.data,
+                                                   rounds.ctypes.data, vtrace.ctypes.data, C.byref(vlen), C.byref(stats), None, counts.ctypes.data)
+    assert rc == 0, rc
+    n = int(stats.interleavings)
+    return verdicts[:n].copy(), plen[:n].copy(), rounds[:int(stats.launches)].copy(), vtrace[:vlen.value].copy(), stats, counts
+
+
 def dpor_explore(model, externals, params, search, n_threads=None, resident=False):
     """The whole DPOR exploration on the CPU: the product's host bookkeeping (demi_amd/csrc/dpor_host.hpp) around this
     oracle's interleavings, `n_threads` of them at a time.  Returns (verdicts, prefix_len, rounds, first violating trace,

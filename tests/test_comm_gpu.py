@@ -109,3 +109,29 @@ def test_rccl_communicator_world_of_one(gpu_ctx):
     gpu_ctx.comm_destroy()
     want, n1 = gpu_ctx.random_explore_violations(20000, lim, seed_base=SEED_BASE)
     assert n == n1 and (got == want).all()
+
+
+def test_bench_py_two_ranks_on_one_gpu(tmp_path):
+    """The command the driver runs for its multi-GPU scaling bench - torch.distributed.run ... bench.py --gpus N - with N = 2
+    on this box's one GPU: gloo for torch.distributed, both ranks on cuda:0, the library's communicator over the host
+    all-gather callback (RCCL refuses two ranks on one device).  Everything but the RCCL transport itself: rank / world
+    plumbing, index-range sharding, the all-gather of the violation sets through demi_comm_allgather_dev, the max over ranks,
+    the one JSON line from rank 0."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DEMI_BENCH_BACKEND="gloo", DEMI_BENCH_ONE_GPU="1", DEMI_BENCH_COMM="host")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29547", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--schedules", "65536", "--no-prewarm"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["value"] > 0
+    assert "demi_comm_allgather_dev" in d["config"]["collective"]
+    # both ranks' violations are in the merged set: rank 1 evaluates the indices [65536, 131072)
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0", "--schedules", "65536",
+                          "--no-prewarm", "--no-cpu-baseline", "--no-secondary"], capture_output=True, text=True, timeout=600)
+    d1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][0])
+    assert d["violations_last_step"] > d1["violations_last_step"] > 0

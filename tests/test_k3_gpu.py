@@ -277,3 +277,36 @@ def test_device_resident_bookkeeping_equals_the_host_bookkeeping_config3(monkeyp
     assert len(out[False][0]) == len(out[True][0]) == 62902 and (out[False][0] == out[True][0]).all()
     assert out[False][1] == out[True][1] and out[False][2] and out[True][2]
     assert out[False][3] * 20 < out[True][3]
+
+
+def test_reference_order_resident_equals_the_host_commit(monkeypatch):
+    """REFERENCE order, both implementations on the GPU: the round-3 path - traces, the speculation's bookkeeping and the commit's
+    pair filter on the device, the commit fed with 24-byte records (explore_reference_resident) - against the round-2 path that
+    fetched every trace and every racing pair (DEMI_DPOR_HOST_BOOKKEEPING): the same committed sequence on a budgeted config 3,
+    a fraction of the bytes over PCIe, and the first violating trace of the writers model."""
+    from tests.test_dpor_cpu import writers_model
+    model, ev, depth = raft5_config3()
+
+    def run(model, ev, depth, budget, host, stop=False):
+        if host:
+            monkeypatch.setenv("DEMI_DPOR_HOST_BOOKKEEPING", "1")
+        else:
+            monkeypatch.delenv("DEMI_DPOR_HOST_BOOKKEEPING", raising=False)
+        d = DPORwHeuristics(SchedulerConfig(model=model), depth_bound=depth or None, stopIfViolationFound=stop, batch=1024, specialize=True)
+        res = d.explore_native(ev, max_interleavings=budget, reference_order=True)
+        got = np.array([il.verdict for il in res.interleavings], dtype=T.VERDICT_DTYPE)
+        plen = [il.prefix_len for il in res.interleavings]
+        st = d.last_native_stats
+        out = (got, plen, int(st.d2h_bytes), int(st.executed), res)
+        d.shutdown()
+        return out
+    new = run(model, ev, depth, 12000, host=False)
+    old = run(model, ev, depth, 12000, host=True)
+    assert len(new[0]) == 12000 and (new[0] == old[0]).all() and new[1] == old[1]
+    assert new[2] * 4 < old[2], (new[2], old[2])                      # PCIe: records instead of traces + every pair
+    wm = writers_model(4)
+    wev = events_to_array([start(a) for a in range(5)] + [send(a, 0) for a in range(1, 5)])
+    a, b = run(wm, wev, 0, 5000, host=False, stop=True), run(wm, wev, 0, 5000, host=True, stop=True)
+    assert (a[0] == b[0]).all() and a[1] == b[1] and len(a[4].violations) == len(b[4].violations) == 1
+    ta, tb = a[4].interleavings[a[4].violations[0]].trace, b[4].interleavings[b[4].violations[0]].trace
+    assert len(ta) == len(tb) and (np.asarray(ta) == np.asarray(tb)).all()
