@@ -966,6 +966,19 @@ class RefBook {
   }
   uint64_t queue_len() const { return queued_; }
   uint64_t enqueued() const { return enqueued_; }
+  // up to `k` points in dequeue order that are live right now, without dequeuing them: what the commit will most likely ask
+  // for next (a speculation: a point may still die before its turn, and new points may get ahead of it)
+  template <class F>
+  void peek(size_t k, F&& f) const {
+    for (int b = top_; b >= 0 && k; b--)
+      for (const Point& p : bucket_[b]) {
+        if (!k) break;
+        const uint32_t* v = map_.find(p.flip_a, p.flip_b);
+        if (v && (*v & EXPLORED)) continue;
+        f(p);
+        k--;
+      }
+  }
   // the entries that changed since the last call, with their current states
   void take_deltas(std::vector<RefDelta>& out) {
     out.clear();
@@ -992,10 +1005,11 @@ class RefBook {
   std::vector<std::pair<uint64_t, uint64_t>> dirty_;
 };
 
-// dev.round_ref(items, use_parent, n, round, base_id, deltas, n_deltas, verdicts, points, kills, rec_off, rec_cnt, recs):
+// dev.round_ref(items, use_parent, n, round, base_id, deltas, n_deltas, verdicts, points, kills, rec_off, rec_cnt, &recs):
 //   one launch like dev.round() of the ROUNDS path (K3 + the speculation's mark / insert / decide), plus: the deltas applied to
 //   the device's copy of the commit's table first, and afterwards the commit filter - interleaving i's surviving racing pairs
-//   are recs[rec_off[i] .. + rec_cnt[i]) in pair order; use_parent[i] says whether its parent's trace may be used for (a).
+//   are recs[rec_off[i] .. + rec_cnt[i]) in pair order (memory owned by dev, valid until the exploration ends: the records are
+//   copied from the device ONCE, into where they stay); use_parent[i] says whether its parent's trace may be used for (a).
 template <class Dev>
 int explore_reference_resident(Dev&& dev, const demi_dpor_search* srch, demi_verdict* out_verdicts, uint32_t* out_prefix_len,
                                uint32_t* out_rounds, demi_dpor_trace_entry* first_violation_trace, uint32_t* first_violation_len,
@@ -1007,9 +1021,9 @@ int explore_reference_resident(Dev&& dev, const demi_dpor_search* srch, demi_ver
   auto key_of = [](const demi::DporItem& it) -> uint64_t {
     return ((uint64_t)it.src << 24) | ((uint64_t)it.branch << 16) | ((uint64_t)it.later << 8) | (uint64_t)it.earlier;
   };
-  struct Result { uint32_t id; demi_verdict verdict; uint64_t rec_off; uint32_t rec_cnt; };
-  std::unordered_map<uint64_t, Result> results;          // every interleaving run so far, by its item
-  std::vector<RefRec> pool;                              // their surviving racing pairs
+  struct Result { uint32_t id; demi_verdict verdict; const RefRec* recs; uint32_t rec_cnt; };
+  std::unordered_map<uint64_t, Result> results;          // every interleaving run so far, by its item; its surviving racing
+                                                         // pairs stay where the device's copy put them (dev owns that memory)
   std::vector<uint8_t> complete;                         // per arena id: invariant (I) of ParentFilter holds (see there)
   RefBook real;
   // the speculation's queue (explore_rounds_resident's)
@@ -1027,7 +1041,6 @@ int explore_reference_resident(Dev&& dev, const demi_dpor_search* srch, demi_ver
   std::vector<demi::DporKill> kills;
   std::vector<uint64_t> rec_off;
   std::vector<uint32_t> rec_cnt;
-  std::vector<RefRec> recs;
   std::vector<RefDelta> deltas;
   uint32_t base_id = 0, round = 0;
   uint64_t first_id = ~0ull;
@@ -1048,7 +1061,7 @@ int explore_reference_resident(Dev&& dev, const demi_dpor_search* srch, demi_ver
         found = true;
         if (stats->first_violation == ~0ull) { stats->first_violation = idx; first_id = r.id; }
       }
-      real.absorb(pool.data() + r.rec_off, r.rec_cnt, r.id);
+      real.absorb(r.recs, r.rec_cnt, r.id);
       if ((srch->stop_if_violation && found) || stats->interleavings >= srch->max_interleavings) { done = true; break; }
       RefBook::Point p;
       have_cur = real.get_next(p);
@@ -1066,6 +1079,13 @@ int explore_reference_resident(Dev&& dev, const demi_dpor_search* srch, demi_ver
     {
       std::unordered_set<uint64_t> in_launch;
       in_launch.insert(key_of(cur));
+      // the commit's own queue front: what it will most likely dequeue next (the speculation below explores in rounds and
+      // runs out long before the commit does; without this every later interleaving would be a launch of its own)
+      real.peek(srch->batch / 4 + 1, [&](const RefBook::Point& p) {
+        const demi::DporItem q{p.src, p.branch, p.later, p.earlier, 0};
+        const uint64_t k = key_of(q);
+        if (!results.count(k) && in_launch.insert(k).second) items.push_back(q);
+      });
       for (const demi::DporItem& s : spec_items) {
         const uint64_t k = key_of(s);
         if (results.count(k) || !in_launch.insert(k).second) continue;
@@ -1077,20 +1097,19 @@ int explore_reference_resident(Dev&& dev, const demi_dpor_search* srch, demi_ver
     for (uint32_t i = 0; i < n; i++) use_parent[i] = items[i].src != 0xFFFFFFFFu && items[i].src < complete.size() && complete[items[i].src];
     real.take_deltas(deltas);
     vd.resize(n); rec_off.resize(n); rec_cnt.resize(n);
-    pts.clear(); kills.clear(); recs.clear();
+    pts.clear(); kills.clear();
     round++;
+    const RefRec* recs = nullptr;          // this launch's records: valid until the exploration ends (dev keeps them)
     int rc = dev.round_ref(items.data(), use_parent.data(), n, round, base_id, deltas.data(), (uint32_t)deltas.size(), vd.data(), pts, kills,
-                           rec_off.data(), rec_cnt.data(), recs);
+                           rec_off.data(), rec_cnt.data(), &recs);
     if (rc) return rc;
     if (out_rounds && stats->launches < srch->max_interleavings) out_rounds[stats->launches] = n;
     stats->launches++;
     stats->executed += n;
     double t2 = now();
-    const uint64_t pool_base = pool.size();
-    pool.insert(pool.end(), recs.begin(), recs.end());
     if (complete.size() < (size_t)base_id + n) complete.resize((size_t)base_id + n, 0);
     for (uint32_t i = 0; i < n; i++) {
-      results[key_of(items[i])] = Result{base_id + i, vd[i], pool_base + rec_off[i], rec_cnt[i]};
+      results[key_of(items[i])] = Result{base_id + i, vd[i], recs + rec_off[i], rec_cnt[i]};
       // (I) holds for this interleaving once it is absorbed iff its own pair list is whole and (I) held for its parent
       complete[(size_t)base_id + i] = !(vd[i].flags & DEMI_V_PAIRS_OVF) && (items[i].src == 0xFFFFFFFFu || use_parent[i]);
     }

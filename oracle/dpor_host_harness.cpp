@@ -55,7 +55,7 @@ unsigned long long sim_cand(uint32_t round, uint32_t branch, unsigned long long 
   return ((unsigned long long)round << 40) | ((unsigned long long)(branch + 1) << 31) | (0x7FFFFFFFull - ord);
 }
 struct SimDev {
-  const demi_model* m; const demi_ext_event* ext; uint32_t n_ext; const demi_dpor_params* par; int n_threads;
+  const demi_model* m; const demi_ext_event* ext; uint32_t n_ext; const demi_dpor_params* par; int n_threads = 1;
   std::vector<demi_host::Trace> arena;
   std::unordered_map<std::pair<uint64_t, uint64_t>, SimEntry, demi_host::PairKeyHash> table;
   std::vector<std::vector<demi_dpor_pair>> pairs;       // racing pairs of the last round's interleavings
@@ -67,7 +67,9 @@ struct SimDev {
   // (a) ParentFilter against the parent's trace in the arena, (b) no-ops under the snapshot of the commit's table
   int round_ref(const demi::DporItem* items, const uint8_t* use_parent, uint32_t n, uint32_t round_no, uint32_t base_id,
                 const demi_host::RefDelta* deltas, uint32_t n_deltas, demi_verdict* vd, std::vector<demi::DporPoint>& pts,
-                std::vector<demi::DporKill>& kills, uint64_t* rec_off, uint32_t* rec_cnt, std::vector<demi_host::RefRec>& recs) {
+                std::vector<demi::DporKill>& kills, uint64_t* rec_off, uint32_t* rec_cnt, const demi_host::RefRec** recs_out) {
+    rec_chunks.emplace_back();
+    std::vector<demi_host::RefRec>& recs = rec_chunks.back();
     for (uint32_t i = 0; i < n_deltas; i++) {
       real_tab[{deltas[i].lo, deltas[i].hi}] = deltas[i].state[0];
       real_tab[{deltas[i].hi, deltas[i].lo}] = deltas[i].state[1];
@@ -95,8 +97,10 @@ struct SimDev {
       rec_cnt[i] = (uint32_t)(recs.size() - rec_off[i]);
       pairs_kept += rec_cnt[i];
     }
+    *recs_out = recs.data();
     return 0;
   }
+  std::deque<std::vector<demi_host::RefRec>> rec_chunks;      // one per launch, alive until the exploration ends
 
   int round(const demi::DporItem* items, uint32_t n, uint32_t round_no, uint32_t base_id, demi_verdict* vd,
             std::vector<demi::DporPoint>& pts, std::vector<demi::DporKill>& kills) {
@@ -309,7 +313,7 @@ extern "C" int harness_dpor_explore_reference_resident(const demi_model* m, cons
                                                        demi_verdict* out_verdicts, uint32_t* out_prefix_len, uint32_t* out_rounds,
                                                        demi_dpor_trace_entry* first_violation_trace, uint32_t* first_violation_len,
                                                        demi_dpor_stats* stats, double* seconds, uint64_t* pair_counts) {
-  SimDev dev{m, ext, n_ext, par, n_threads, {}, {}, {}, {}};
+  SimDev dev{m, ext, n_ext, par, n_threads};
   const int rc = demi_host::explore_reference_resident(dev, srch, out_verdicts, out_prefix_len, out_rounds, first_violation_trace,
                                                        first_violation_len, stats, seconds);
   if (pair_counts) { pair_counts[0] = dev.pairs_reported; pair_counts[1] = dev.pairs_after_parent; pair_counts[2] = dev.pairs_kept; }
@@ -321,7 +325,7 @@ extern "C" int harness_dpor_explore_resident(const demi_model* m, const demi_ext
                                              demi_verdict* out_verdicts, uint32_t* out_prefix_len, uint32_t* out_rounds,
                                              demi_dpor_trace_entry* first_violation_trace, uint32_t* first_violation_len,
                                              demi_dpor_stats* stats, double* seconds, uint64_t* table_entries) {
-  SimDev dev{m, ext, n_ext, par, n_threads, {}, {}, {}, {}};
+  SimDev dev{m, ext, n_ext, par, n_threads};
   const int rc = demi_host::explore_rounds_resident(dev, srch, out_verdicts, out_prefix_len, out_rounds, first_violation_trace,
                                                     first_violation_len, stats, seconds);
   if (table_entries) *table_entries = dev.table.size();
