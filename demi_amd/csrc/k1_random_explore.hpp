@@ -56,8 +56,10 @@ constexpr int K1_WAVES = 4;          // waves per workgroup
 // gives it none at all: every pending slot then lives in the coalesced [slot][lane] HBM scratch.  That is the fastest
 // setting and the one with the most HBM traffic (DESIGN.md section 4 has the table; measured on raft5, ms per 2^20
 // schedules: 0 -> 4.84, 2 -> 5.41, 4 -> 5.35, 8 -> 5.62, 16 -> 6.02, 24 / 32 -> 6.6).
+// (the generic kernel: 28 - with the timer directory and the reach words of round 3 in LDS, 32 resident slots would leave
+// two workgroups per CU where 28 leave three)
 #ifndef DEMI_K1_HOT
-#define DEMI_K1_HOT DEMI_PEND_HOT
+#define DEMI_K1_HOT 28
 #endif
 constexpr uint32_t K1_HOT = DEMI_K1_HOT;
 constexpr int K1_BATCH = 64;         // schedule indices claimed per atomic

@@ -17,15 +17,15 @@ CMD="python $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-secondary"
 COMGR=$(python -c "import torch, os; print(os.path.join(os.path.dirname(torch.__file__), 'lib', 'libamd_comgr.so'))")
 PRE=""
 if [ -f "$COMGR" ] && [ -z "$DEMI_PROFILE_SYSTEM_COMGR" ]; then PRE="--preload $COMGR"; fi
-rocprofv3 $PRE --kernel-trace --stats -d $P/prof_stats -o k1 -- $CMD > $OUT/r03_prof_stats.log 2>&1
-rocprofv3 $PRE --pmc FETCH_SIZE -d $P/prof_fetch -o k1 -- $CMD > $OUT/r03_prof_fetch.log 2>&1
-rocprofv3 $PRE --pmc WRITE_SIZE -d $P/prof_write -o k1 -- $CMD > $OUT/r03_prof_write.log 2>&1
-rocprofv3 $PRE --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY -d $P/prof_sq -o k1 -- $CMD > $OUT/r03_prof_sq.log 2>&1
-rocprofv3 $PRE --pmc SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE SQ_THREAD_CYCLES_VALU -d $P/prof_sq2 -o k1 -- $CMD > $OUT/r03_prof_sq2.log 2>&1
-rocprofv3 --pmc FETCH_SIZE -d $P/calib_fetch -o c -- python $R/tools/calib_counters.py > $OUT/r03_calib_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE -d $P/calib_write -o c -- python $R/tools/calib_counters.py > $OUT/r03_calib_write.log 2>&1
+timeout 300 rocprofv3 $PRE --kernel-trace --stats -d $P/prof_stats -o k1 -- $CMD > $OUT/r03_prof_stats.log 2>&1
+timeout 300 rocprofv3 $PRE --pmc FETCH_SIZE -d $P/prof_fetch -o k1 -- $CMD > $OUT/r03_prof_fetch.log 2>&1
+timeout 300 rocprofv3 $PRE --pmc WRITE_SIZE -d $P/prof_write -o k1 -- $CMD > $OUT/r03_prof_write.log 2>&1
+timeout 300 rocprofv3 $PRE --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY -d $P/prof_sq -o k1 -- $CMD > $OUT/r03_prof_sq.log 2>&1
+timeout 300 rocprofv3 $PRE --pmc SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE SQ_THREAD_CYCLES_VALU -d $P/prof_sq2 -o k1 -- $CMD > $OUT/r03_prof_sq2.log 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE -d $P/calib_fetch -o c -- python $R/tools/calib_counters.py > $OUT/r03_calib_fetch.log 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE -d $P/calib_write -o c -- python $R/tools/calib_counters.py > $OUT/r03_calib_write.log 2>&1
 if [ "$1" = "all" ]; then
-  rocprofv3 $PRE --kernel-trace --stats -d $P/prof_stats_dpor -o k3 -- python $R/bench.py --workload dpor --no-cpu-baseline > $OUT/r03_prof_stats_dpor.log 2>&1
-  rocprofv3 $PRE --kernel-trace --stats -d $P/prof_stats_ddmin -o k2 -- python $R/bench.py --workload ddmin --no-cpu-baseline > $OUT/r03_prof_stats_ddmin.log 2>&1
+  timeout 300 rocprofv3 $PRE --kernel-trace --stats -d $P/prof_stats_dpor -o k3 -- python $R/bench.py --workload dpor --no-cpu-baseline > $OUT/r03_prof_stats_dpor.log 2>&1
+  timeout 300 rocprofv3 $PRE --kernel-trace --stats -d $P/prof_stats_ddmin -o k2 -- python $R/bench.py --workload ddmin --no-cpu-baseline > $OUT/r03_prof_stats_ddmin.log 2>&1
 fi
 python $R/tools/summarize_prof.py r03 $P $OUT
