@@ -891,11 +891,12 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
       // (program order), and `nfx` is the mask of the slots this delivery filled: one straight pass, each body once.
 #define DEMI_FX_SLOT(J, KIND, OP, TYPE, TIDX, Q)                                                                      \
       if (((nfx >> (J)) & 1u) && !(flags & DEMI_OVF_ANY)) {                                                           \
-        if ((KIND) == 0u) { apply_send(mem.fxq[(Q) * 64]); PH_MARK(6); }     /* (Q: the slot's entry of the effect queue) */ \
-        else if ((KIND) == 1u) { apply_cancel((TYPE), 1u << (me * DEMI_MAX_TIMER_TYPES + (TIDX)), (TIDX)); PH_MARK(7); } \
-        else if ((KIND) == 2u) { apply_timer_set((OP) == DEMI_OP_TREP, (TYPE), 1u << (me * DEMI_MAX_TIMER_TYPES + (TIDX))); PH_MARK(8); } \
+        if ((KIND) == 0u) apply_send(mem.fxq[(Q) * 64]);                     /* (Q: the slot's entry of the effect queue) */ \
+        else if ((KIND) == 1u) apply_cancel((TYPE), 1u << (me * DEMI_MAX_TIMER_TYPES + (TIDX)), (TIDX));               \
+        else if ((KIND) == 2u) apply_timer_set((OP) == DEMI_OP_TREP, (TYPE), 1u << (me * DEMI_MAX_TIMER_TYPES + (TIDX))); \
         else if (CRASHES) blocked |= 1u << me;                                                                        \
-      }
+      }                                                                                                               \
+      PH_MARK((KIND) == 0u ? 6 : (KIND) == 1u ? 7 : 8);      /* (after the slot, where the wave has reconverged: every lane's clock) */
       DEMI_JIT_FX_APPLY
 #undef DEMI_FX_SLOT
 #else
