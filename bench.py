@@ -96,6 +96,7 @@ def bench_dpor(ctx_device, cpu_baseline=True, batch=16384, orders=("rounds", "re
                       "kernel_ms_total": float(st.kernel_ms), "h2d_bytes": int(st.h2d_bytes), "d2h_bytes": int(st.d2h_bytes)}
         if ref:
             runs[name]["launches_for_results_the_speculation_lacked"] = int(st.cache_misses)
+            runs[name]["record_fetches"] = int(st.fetches)
         ctx.close()
     first = "rounds" if "rounds" in runs else next(iter(runs))
     out["value"] = runs[first]["value"]

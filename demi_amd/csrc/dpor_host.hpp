@@ -1005,11 +1005,24 @@ class RefBook {
   std::vector<std::pair<uint64_t, uint64_t>> dirty_;
 };
 
-// dev.round_ref(items, use_parent, n, round, base_id, deltas, n_deltas, verdicts, points, kills, rec_off, rec_cnt, &recs):
+// dev.round_ref(items, use_parent, n, round, base_id, deltas, n_deltas, verdicts, points, kills, rec_cnt):
 //   one launch like dev.round() of the ROUNDS path (K3 + the speculation's mark / insert / decide), plus: the deltas applied to
-//   the device's copy of the commit's table first, and afterwards the commit filter - interleaving i's surviving racing pairs
-//   are recs[rec_off[i] .. + rec_cnt[i]) in pair order (memory owned by dev, valid until the exploration ends: the records are
-//   copied from the device ONCE, into where they stay); use_parent[i] says whether its parent's trace may be used for (a).
+//   the device's copy of the commit's table first, and afterwards the commit filter - interleaving i keeps rec_cnt[i] racing
+//   pairs as records, in pair order, WITH THE DEVICE (keyed by its arena id base_id + i); use_parent[i] says whether its
+//   parent's trace may be used for (a).
+// dev.ref_fetch(ids, m, deltas, n_deltas, rec_off, rec_cnt, &recs):
+//   the commit is about to absorb the interleavings `ids` (arena ids, the first one right now, the others probably next):
+//   their records, filtered AGAIN under the table as it is now (the deltas first) - rule (b) holds for any older state, and a
+//   launch is 10^4 interleavings wide, most of whose pairs the commit has made no-ops by the time it reaches them: a
+//   16 384-wide launch keeps 83 % of the pairs, the fetch a few per cent of those.  recs[rec_off[j] .. + rec_cnt[j]) are
+//   interleaving ids[j]'s survivors, in pair order (memory owned by dev, valid until the exploration ends).
+// how many interleavings of the commit's queue front a record fetch covers besides the one the commit stands at
+inline size_t ref_fetch_width() {
+  const char* e = getenv("DEMI_DPOR_FETCH_WIDTH");
+  const long v = e ? atol(e) : 0;
+  return v > 0 ? (size_t)v : 64u;
+}
+
 template <class Dev>
 int explore_reference_resident(Dev&& dev, const demi_dpor_search* srch, demi_verdict* out_verdicts, uint32_t* out_prefix_len,
                                uint32_t* out_rounds, demi_dpor_trace_entry* first_violation_trace, uint32_t* first_violation_len,
@@ -1021,7 +1034,7 @@ int explore_reference_resident(Dev&& dev, const demi_dpor_search* srch, demi_ver
   auto key_of = [](const demi::DporItem& it) -> uint64_t {
     return ((uint64_t)it.src << 24) | ((uint64_t)it.branch << 16) | ((uint64_t)it.later << 8) | (uint64_t)it.earlier;
   };
-  struct Result { uint32_t id; demi_verdict verdict; const RefRec* recs; uint32_t rec_cnt; };
+  struct Result { uint32_t id; demi_verdict verdict; const RefRec* recs; uint32_t rec_cnt; bool fetched; };
   std::unordered_map<uint64_t, Result> results;          // every interleaving run so far, by its item; its surviving racing
                                                          // pairs stay where the device's copy put them (dev owns that memory)
   std::vector<uint8_t> complete;                         // per arena id: invariant (I) of ParentFilter holds (see there)
@@ -1042,15 +1055,20 @@ int explore_reference_resident(Dev&& dev, const demi_dpor_search* srch, demi_ver
   std::vector<uint64_t> rec_off;
   std::vector<uint32_t> rec_cnt;
   std::vector<RefDelta> deltas;
+  std::vector<uint32_t> fetch_ids;
+  std::vector<Result*> fetch_res;
   uint32_t base_id = 0, round = 0;
   uint64_t first_id = ~0ull;
+  const size_t fetch_width = ref_fetch_width();
 
   while (!done) {
     // ---- commit, one interleaving at a time, as far as computed results reach
     double t0 = now();
+    bool need_fetch = false;
     while (have_cur) {
       auto it = results.find(key_of(cur));
       if (it == results.end()) break;
+      if (!it->second.fetched) { need_fetch = true; break; }
       const Result& r = it->second;
       const uint64_t idx = stats->interleavings++;
       out_verdicts[idx] = r.verdict;
@@ -1071,6 +1089,30 @@ int explore_reference_resident(Dev&& dev, const demi_dpor_search* srch, demi_ver
     double t1 = now();
     if (seconds) seconds[2] += t1 - t0;
     if (done) break;
+
+    if (need_fetch) {
+      // ---- the records of the interleaving the commit stands at, and of those its queue will most likely hand out next
+      fetch_ids.clear(); fetch_res.clear();
+      Result* r0 = &results.find(key_of(cur))->second;         // (no insertion below: the pointers stay valid)
+      fetch_ids.push_back(r0->id); fetch_res.push_back(r0);
+      r0->fetched = true;
+      real.peek(fetch_width, [&](const RefBook::Point& p) {
+        auto it = results.find(key_of(demi::DporItem{p.src, p.branch, p.later, p.earlier, 0}));
+        if (it == results.end() || it->second.fetched) return;
+        it->second.fetched = true;
+        fetch_ids.push_back(it->second.id); fetch_res.push_back(&it->second);
+      });
+      real.take_deltas(deltas);
+      const uint32_t m = (uint32_t)fetch_ids.size();
+      rec_off.resize(m); rec_cnt.resize(m);
+      const RefRec* recs = nullptr;
+      int rc = dev.ref_fetch(fetch_ids.data(), m, deltas.data(), (uint32_t)deltas.size(), rec_off.data(), rec_cnt.data(), &recs);
+      if (rc) return rc;
+      for (uint32_t j = 0; j < m; j++) { fetch_res[j]->recs = recs + rec_off[j]; fetch_res[j]->rec_cnt = rec_cnt[j]; }
+      stats->fetches++;
+      if (seconds) seconds[1] += now() - t1;
+      continue;
+    }
 
     // ---- one launch: what the commit is waiting for + the speculation's next round (minus what has been run already)
     stats->cache_misses++;
@@ -1099,9 +1141,8 @@ int explore_reference_resident(Dev&& dev, const demi_dpor_search* srch, demi_ver
     vd.resize(n); rec_off.resize(n); rec_cnt.resize(n);
     pts.clear(); kills.clear();
     round++;
-    const RefRec* recs = nullptr;          // this launch's records: valid until the exploration ends (dev keeps them)
     int rc = dev.round_ref(items.data(), use_parent.data(), n, round, base_id, deltas.data(), (uint32_t)deltas.size(), vd.data(), pts, kills,
-                           rec_off.data(), rec_cnt.data(), &recs);
+                           rec_cnt.data());
     if (rc) return rc;
     if (out_rounds && stats->launches < srch->max_interleavings) out_rounds[stats->launches] = n;
     stats->launches++;
@@ -1109,7 +1150,7 @@ int explore_reference_resident(Dev&& dev, const demi_dpor_search* srch, demi_ver
     double t2 = now();
     if (complete.size() < (size_t)base_id + n) complete.resize((size_t)base_id + n, 0);
     for (uint32_t i = 0; i < n; i++) {
-      results[key_of(items[i])] = Result{base_id + i, vd[i], recs + rec_off[i], rec_cnt[i]};
+      results[key_of(items[i])] = Result{base_id + i, vd[i], nullptr, 0u, rec_cnt[i] == 0};   // (nothing to fetch: as good as fetched)
       // (I) holds for this interleaving once it is absorbed iff its own pair list is whole and (I) held for its parent
       complete[(size_t)base_id + i] = !(vd[i].flags & DEMI_V_PAIRS_OVF) && (items[i].src == 0xFFFFFFFFu || use_parent[i]);
     }

@@ -48,6 +48,13 @@ __device__ inline uint32_t pair_slot(PairEntry* tab, uint32_t mask, uint64_t a, 
   uint32_t i = (uint32_t)pair_hash(lo, hi) & mask;
   for (uint32_t probes = 0; probes < 4096;) {
     PairEntry* e = tab + i;
+    // Most lookups of a round find a pair that an earlier interleaving inserted: an ordinary (cacheable) load of the key
+    // answers those from the CU's own cache.  Keys are written once and never change, so a match is final; anything else
+    // (empty, half-published, another key - possibly a stale line) takes the coherent path below.
+    {
+      const ulonglong2 k = *reinterpret_cast<const ulonglong2*>(&e->lo);
+      if (k.x == lo && k.y == hi) return i * 2 + side;
+    }
     unsigned long long el = __atomic_load_n(&e->lo, __ATOMIC_RELAXED);
     if (el == 0) {
       const unsigned long long seen = atomicCAS(&e->lo, 0ull, (unsigned long long)lo);
@@ -120,12 +127,19 @@ __global__ __launch_bounds__(256) void k3_pairs_insert(const K3PairArgs a) {
     const uint32_t s2 = s1 == 0xFFFFFFFFu ? s1 : (s1 ^ 1u);
     a.pair_slot_of[(size_t)it * a.max_pairs + k] = s2;
     if (s1 == 0xFFFFFFFFu) { atomicAdd(&a.counters[2], 1ull); continue; }
-    const uint32_t old = atomicOr(&a.table[s1 >> 1].state[s1 & 1], PE_EXPLORED);   // setExplored(branch, (earlier, later))
-    if (!(old & PE_EXPLORED) && (old & PE_QMASK)) {                        // queued points flip into this pair: dead now
-      const unsigned long long q = atomicAdd(&a.counters[1], 1ull);
-      if (q < a.kills_cap) { DporKill kk; kk.a = ke; kk.b = kl; a.kills[q] = kk; }
+    // Thousands of interleavings of a round report the same few pairs, and a read-modify-write on one address is serialised
+    // where it executes.  Both updates are monotone (the explored bit is only ever set, the candidate only ever raised), so
+    // an ordinary load that already shows the result makes the atomic redundant; a stale line only means one atomic more.
+    PairEntry* const e1 = a.table + (s1 >> 1);
+    if (!(e1->state[s1 & 1] & PE_EXPLORED)) {
+      const uint32_t old = atomicOr(&e1->state[s1 & 1], PE_EXPLORED);      // setExplored(branch, (earlier, later))
+      if (!(old & PE_EXPLORED) && (old & PE_QMASK)) {                      // queued points flip into this pair: dead now
+        const unsigned long long q = atomicAdd(&a.counters[1], 1ull);
+        if (q < a.kills_cap) { DporKill kk; kk.a = ke; kk.b = kl; a.kills[q] = kk; }
+      }
     }
-    atomicMax(&a.table[s2 >> 1].cand[s2 & 1], cand_pack(a.round, p.branch, (unsigned long long)it * a.max_pairs + k));
+    const unsigned long long mine = cand_pack(a.round, p.branch, (unsigned long long)it * a.max_pairs + k);
+    if (e1->cand[(s2 & 1)] < mine) atomicMax(&e1->cand[s2 & 1], mine);   // (s2 is the other side of the same entry)
   }
 }
 
@@ -192,12 +206,16 @@ __global__ __launch_bounds__(256) void k3_pairs_insert_rec(const K3PairArgs a) {
     if (s1 == 0xFFFFFFFFu) { atomicAdd(&a.counters[2], 1ull); continue; }
     const uint32_t s2 = s1 ^ 1u;
     a.pair_slot_of[i] = s2;
-    const uint32_t old = atomicOr(&a.table[s1 >> 1].state[s1 & 1], PE_EXPLORED);
-    if (!(old & PE_EXPLORED) && (old & PE_QMASK)) {
-      const unsigned long long q = atomicAdd(&a.counters[1], 1ull);
-      if (q < a.kills_cap) { DporKill kk; kk.a = r.ke; kk.b = r.kl; a.kills[q] = kk; }
+    PairEntry* const e1 = a.table + (s1 >> 1);                             // (ordinary loads first: see k3_pairs_insert)
+    if (!(e1->state[s1 & 1] & PE_EXPLORED)) {
+      const uint32_t old = atomicOr(&e1->state[s1 & 1], PE_EXPLORED);
+      if (!(old & PE_EXPLORED) && (old & PE_QMASK)) {
+        const unsigned long long q = atomicAdd(&a.counters[1], 1ull);
+        if (q < a.kills_cap) { DporKill kk; kk.a = r.ke; kk.b = r.kl; a.kills[q] = kk; }
+      }
     }
-    atomicMax(&a.table[s2 >> 1].cand[s2 & 1], cand_pack(a.round, r.branch, r.ordinal));
+    const unsigned long long mine = cand_pack(a.round, r.branch, r.ordinal);
+    if (e1->cand[s2 & 1] < mine) atomicMax(&e1->cand[s2 & 1], mine);
   }
 }
 
@@ -251,7 +269,8 @@ struct K3RefArgs {
   uint32_t base_id, n;
   const demi_dpor_pair* pairs; const uint32_t* n_pairs; uint32_t max_pairs;
   RefRecDev* recs; unsigned long long recs_cap;
-  unsigned long long* rec_off; uint32_t* rec_cnt;     // [n]
+  unsigned long long* rec_off; uint32_t* rec_cnt;     // [n]: where interleaving i's records start (rec_base + its offset in recs) / how many
+  unsigned long long rec_base;
   unsigned long long* counters;                       // [0] records wanted (may exceed recs_cap: the host grows and re-runs), [1] table full
 };
 
@@ -352,7 +371,7 @@ __global__ __launch_bounds__(256) void k3_ref_filter(const K3RefArgs a) {
     for (uint32_t w = 0; w < 128; w++) { s_pre[w] = tot; tot += (uint32_t)__popc(s_keep[w]); }
     s_pre[128] = tot;
     s_off = atomicAdd(&a.counters[0], (unsigned long long)tot);
-    a.rec_off[it] = s_off;
+    a.rec_off[it] = a.rec_base + s_off;
     a.rec_cnt[it] = tot;
   }
   __syncthreads();
@@ -368,5 +387,60 @@ __global__ __launch_bounds__(256) void k3_ref_filter(const K3RefArgs a) {
     a.recs[off + s_pre[k >> 5] + (uint32_t)__popc(w & ((1u << (k & 31)) - 1u))] = r;
   }
 }
+
+// ------------------------------------------------------------------ REFERENCE order: the commit fetches records
+// (dpor_host.hpp explore_reference_resident, dev.ref_fetch.)  The records k3_ref_filter kept stay in a pool on the device.
+// When the commit reaches an interleaving it asks for that one's records and for those of the interleavings its queue will
+// most likely hand out next; rule (b) is applied AGAIN, under the table as the commit has made it by now (the host sends the
+// entries that changed first).  The same monotonicity argument holds, so what is dropped here is a no-op for the commit too -
+// and by now that is most of what a wide launch had to keep.  One workgroup per interleaving; survivors in pair order.
+// ids / out / out_off / out_cnt are pinned host memory mapped into the device's address space: the launch reads its request
+// and writes its answer across PCIe itself, so a fetch costs two launches and one synchronisation, no copies.
+struct K3FetchArgs {
+  const PairEntry* real_table; uint32_t real_mask;
+  const uint32_t* ids; uint32_t m;                          // arena ids of the interleavings asked for
+  const RefRecDev* pool;                                    // every record kept so far
+  const unsigned long long* pool_off; const uint32_t* pool_cnt;   // per arena id
+  RefRecDev* out;                                           // room for the sum of pool_cnt[ids]
+  unsigned long long* out_off; uint32_t* out_cnt;           // [m]
+  unsigned long long* counter; unsigned long long counter_base;   // [0] running total of records handed out, [1] k3_ref_apply's
+                                                                  // "table full" count (device memory)
+  unsigned long long* table_full_out;                       // counter[1], passed on to the host
+};
+
+__global__ __launch_bounds__(256) void k3_ref_fetch(const K3FetchArgs a) {
+  __shared__ uint32_t s_keep[128], s_pre[129];
+  __shared__ unsigned long long s_off;
+  const uint32_t j = blockIdx.x, t = threadIdx.x;
+  if (j == 0 && t == 0) *a.table_full_out = a.counter[1];
+  const uint32_t id = a.ids[j];
+  const RefRecDev* R = a.pool + a.pool_off[id];
+  const uint32_t n = min(a.pool_cnt[id], 4096u);
+  for (uint32_t i = t; i < 128; i += blockDim.x) s_keep[i] = 0;
+  __syncthreads();
+  for (uint32_t k = t; k < n; k += blockDim.x) {
+    uint32_t sf, sr;
+    pair_states(a.real_table, a.real_mask, R[k].ke, R[k].kl, sf, sr);
+    if ((sf & PE_EXPLORED) && ((sr & PE_EXPLORED) || (sr & PE_QMASK) > R[k].branch)) continue;     // a no-op for the commit by now
+    atomicOr(&s_keep[k >> 5], 1u << (k & 31));
+  }
+  __syncthreads();
+  if (t == 0) {
+    uint32_t tot = 0;
+    for (uint32_t w = 0; w < 128; w++) { s_pre[w] = tot; tot += (uint32_t)__popc(s_keep[w]); }
+    s_pre[128] = tot;
+    s_off = atomicAdd(a.counter, (unsigned long long)tot) - a.counter_base;
+    a.out_off[j] = s_off;
+    a.out_cnt[j] = tot;
+  }
+  __syncthreads();
+  const unsigned long long off = s_off;
+  for (uint32_t k = t; k < n; k += blockDim.x) {
+    const uint32_t w = s_keep[k >> 5];
+    if (!((w >> (k & 31)) & 1u)) continue;
+    a.out[off + s_pre[k >> 5] + (uint32_t)__popc(w & ((1u << (k & 31)) - 1u))] = R[k];
+  }
+}
+
 
 }  // namespace demi

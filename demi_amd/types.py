@@ -111,7 +111,7 @@ class DporSearch(C.Structure):
 class DporStats(C.Structure):
     _fields_ = [("interleavings", C.c_uint64), ("launches", C.c_uint64), ("violations", C.c_uint64),
                 ("first_violation", C.c_uint64), ("queue_len", C.c_uint64), ("exhausted", C.c_uint32),
-                ("pad", C.c_uint32), ("executed", C.c_uint64), ("cache_misses", C.c_uint64), ("kernel_ms", C.c_double),
+                ("fetches", C.c_uint32), ("executed", C.c_uint64), ("cache_misses", C.c_uint64), ("kernel_ms", C.c_double),
                 ("h2d_bytes", C.c_uint64), ("d2h_bytes", C.c_uint64), ("backtrack_points", C.c_uint64)]
 
 

@@ -64,18 +64,27 @@ struct SimDev {
   unsigned long long pairs_reported = 0, pairs_after_parent = 0, pairs_kept = 0;
 
   // ResidentDev::round_ref restated: the ROUNDS machinery for the speculation, then the commit filter per interleaving -
-  // (a) ParentFilter against the parent's trace in the arena, (b) no-ops under the snapshot of the commit's table
-  int round_ref(const demi::DporItem* items, const uint8_t* use_parent, uint32_t n, uint32_t round_no, uint32_t base_id,
-                const demi_host::RefDelta* deltas, uint32_t n_deltas, demi_verdict* vd, std::vector<demi::DporPoint>& pts,
-                std::vector<demi::DporKill>& kills, uint64_t* rec_off, uint32_t* rec_cnt, const demi_host::RefRec** recs_out) {
-    rec_chunks.emplace_back();
-    std::vector<demi_host::RefRec>& recs = rec_chunks.back();
+  // (a) ParentFilter against the parent's trace in the arena, (b) no-ops under the snapshot of the commit's table; the
+  // survivors stay "with the device", per arena id
+  void apply_deltas(const demi_host::RefDelta* deltas, uint32_t n_deltas) {
     for (uint32_t i = 0; i < n_deltas; i++) {
       real_tab[{deltas[i].lo, deltas[i].hi}] = deltas[i].state[0];
       real_tab[{deltas[i].hi, deltas[i].lo}] = deltas[i].state[1];
     }
+  }
+  bool noop(uint64_t ke, uint64_t kl, uint32_t branch) const {
+    auto f = real_tab.find({ke, kl});
+    auto r = real_tab.find({kl, ke});
+    const uint32_t sf = f == real_tab.end() ? 0u : f->second, sr = r == real_tab.end() ? 0u : r->second;
+    return (sf & SIM_EXPLORED) && ((sr & SIM_EXPLORED) || (sr & SIM_QMASK) > branch);
+  }
+  int round_ref(const demi::DporItem* items, const uint8_t* use_parent, uint32_t n, uint32_t round_no, uint32_t base_id,
+                const demi_host::RefDelta* deltas, uint32_t n_deltas, demi_verdict* vd, std::vector<demi::DporPoint>& pts,
+                std::vector<demi::DporKill>& kills, uint32_t* rec_cnt) {
+    apply_deltas(deltas, n_deltas);
     const int rc = round(items, n, round_no, base_id, vd, pts, kills);
     if (rc) return rc;
+    if (held.size() < (size_t)base_id + n) held.resize((size_t)base_id + n);
     std::vector<demi_dpor_pair> kept;
     for (uint32_t i = 0; i < n; i++) {
       const demi_host::Trace& T = arena[(size_t)base_id + i];
@@ -85,22 +94,37 @@ struct SimDev {
       if (pf.active()) pf.filter(T.data(), (uint32_t)T.size(), P.data(), (uint32_t)P.size(), kept);
       else kept.assign(P.begin(), P.end());
       pairs_after_parent += kept.size();
-      rec_off[i] = recs.size();
+      std::vector<demi_host::RefRec>& H = held[(size_t)base_id + i];
       for (const demi_dpor_pair& p : kept) {
         const uint64_t ke = T[p.earlier].key, kl = T[p.later].key;
-        auto f = real_tab.find({ke, kl});
-        auto r = real_tab.find({kl, ke});
-        const uint32_t sf = f == real_tab.end() ? 0u : f->second, sr = r == real_tab.end() ? 0u : r->second;
-        if ((sf & SIM_EXPLORED) && ((sr & SIM_EXPLORED) || (sr & SIM_QMASK) > p.branch)) continue;    // a no-op for the commit
-        recs.push_back(demi_host::RefRec{ke, kl, p.branch, p.later, p.earlier, 0, 0});
+        if (noop(ke, kl, p.branch)) continue;                                      // a no-op for the commit
+        H.push_back(demi_host::RefRec{ke, kl, p.branch, p.later, p.earlier, 0, 0});
       }
-      rec_cnt[i] = (uint32_t)(recs.size() - rec_off[i]);
+      rec_cnt[i] = (uint32_t)H.size();
       pairs_kept += rec_cnt[i];
     }
+    return 0;
+  }
+  // ResidentDev::ref_fetch restated: the held records of `ids`, filtered again under the table as of now
+  int ref_fetch(const uint32_t* ids, uint32_t m, const demi_host::RefDelta* deltas, uint32_t n_deltas, uint64_t* rec_off,
+                uint32_t* rec_cnt, const demi_host::RefRec** recs_out) {
+    apply_deltas(deltas, n_deltas);
+    rec_chunks.emplace_back();
+    std::vector<demi_host::RefRec>& recs = rec_chunks.back();
+    for (uint32_t j = 0; j < m; j++) {
+      rec_off[j] = recs.size();
+      for (const demi_host::RefRec& r : held[ids[j]]) if (!noop(r.ke, r.kl, r.branch)) recs.push_back(r);
+      rec_cnt[j] = (uint32_t)(recs.size() - rec_off[j]);
+      pairs_fetched += rec_cnt[j];
+      std::vector<demi_host::RefRec>().swap(held[ids[j]]);
+    }
+    fetches++; fetched_ids += m;
     *recs_out = recs.data();
     return 0;
   }
-  std::deque<std::vector<demi_host::RefRec>> rec_chunks;      // one per launch, alive until the exploration ends
+  std::vector<std::vector<demi_host::RefRec>> held;           // per arena id: the first filter's survivors
+  std::deque<std::vector<demi_host::RefRec>> rec_chunks;      // one per fetch, alive until the exploration ends
+  unsigned long long pairs_fetched = 0, fetches = 0, fetched_ids = 0;
 
   int round(const demi::DporItem* items, uint32_t n, uint32_t round_no, uint32_t base_id, demi_verdict* vd,
             std::vector<demi::DporPoint>& pts, std::vector<demi::DporKill>& kills) {
@@ -316,7 +340,7 @@ extern "C" int harness_dpor_explore_reference_resident(const demi_model* m, cons
   SimDev dev{m, ext, n_ext, par, n_threads};
   const int rc = demi_host::explore_reference_resident(dev, srch, out_verdicts, out_prefix_len, out_rounds, first_violation_trace,
                                                        first_violation_len, stats, seconds);
-  if (pair_counts) { pair_counts[0] = dev.pairs_reported; pair_counts[1] = dev.pairs_after_parent; pair_counts[2] = dev.pairs_kept; }
+  if (pair_counts) { pair_counts[0] = dev.pairs_reported; pair_counts[1] = dev.pairs_after_parent; pair_counts[2] = dev.pairs_kept; pair_counts[3] = dev.pairs_fetched; pair_counts[4] = dev.fetches; pair_counts[5] = dev.fetched_ids; }
   return rc;
 }
 

@@ -23,7 +23,8 @@ def build(force=False):
 def dpor_explore_reference_resident(model, externals, params, search, n_threads=None):
     """REFERENCE order with the results resident on the (restated) device: explore_reference_resident of dpor_host.hpp over the
     CPU stand-in of ResidentDev::round_ref.  Returns (verdicts, prefix_len, rounds, first violating trace, stats, pair counts
-    [reported, after the parent filter, after the snapshot filter])."""
+    [reported, after the parent filter, after the snapshot filter = held by the device, after the fetch's second filter =
+    what crosses PCIe, record fetches, interleavings fetched])."""
     build()
     H = C.CDLL(os.path.join(_HERE, "_build", "dpor_host_harness.so"))
     H.harness_dpor_explore_reference_resident.argtypes = [C.POINTER(T.ModelStruct), C.c_void_p, C.c_uint32, C.POINTER(T.DporParams),
@@ -38,10 +39,11 @@ def dpor_explore_reference_resident(model, externals, params, search, n_threads=
     vtrace = np.zeros(T.DPOR_MAX_TRACE, dtype=T.DPOR_TRACE_DTYPE)
     vlen = C.c_uint32(0)
     stats = T.DporStats()
-    counts = np.zeros(3, dtype=np.uint64)
+    counts = np.zeros(6, dtype=np.uint64)
+    secs = np.zeros(3, dtype=np.float64)
     rc = H.harness_dpor_explore_reference_resident(C.byref(ms), ev.ctypes.data, len(ev), C.byref(params), C.byref(search),
                                                    n_threads or (os.cpu_count() or 1), verdicts.ctypes.data, plen.ctypes.data,
-                                                   rounds.ctypes.data, vtrace.ctypes.data, C.byref(vlen), C.byref(stats), None, counts.ctypes.data)
+                                                   rounds.ctypes.data, vtrace.ctypes.data, C.byref(vlen), C.byref(stats), secs.ctypes.data, counts.ctypes.data)
     assert rc == 0, rc
     n = int(stats.interleavings)
     return verdicts[:n].copy(), plen[:n].copy(), rounds[:int(stats.launches)].copy(), vtrace[:vlen.value].copy(), stats, counts

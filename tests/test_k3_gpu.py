@@ -297,13 +297,19 @@ def test_reference_order_resident_equals_the_host_commit(monkeypatch):
         got = np.array([il.verdict for il in res.interleavings], dtype=T.VERDICT_DTYPE)
         plen = [il.prefix_len for il in res.interleavings]
         st = d.last_native_stats
-        out = (got, plen, int(st.d2h_bytes), int(st.executed), res)
+        out = (got, plen, int(st.d2h_bytes), int(st.executed), res, int(st.fetches))
         d.shutdown()
         return out
     new = run(model, ev, depth, 12000, host=False)
     old = run(model, ev, depth, 12000, host=True)
     assert len(new[0]) == 12000 and (new[0] == old[0]).all() and new[1] == old[1]
-    assert new[2] * 4 < old[2], (new[2], old[2])                      # PCIe: records instead of traces + every pair
+    assert new[2] * 20 < old[2], (new[2], old[2])                     # PCIe: records the commit can still use, fetched when it
+    assert 0 < new[5] < 12000 and old[5] == 0                          # gets there, instead of traces + every pair
+    for width in ("1", "4096"):                                        # whatever the fetch covers, the commit is the same
+        monkeypatch.setenv("DEMI_DPOR_FETCH_WIDTH", width)
+        w = run(model, ev, depth, 3000, host=False)
+        assert (w[0] == old[0][:3000]).all() and w[1] == old[1][:3000]
+    monkeypatch.delenv("DEMI_DPOR_FETCH_WIDTH")
     wm = writers_model(4)
     wev = events_to_array([start(a) for a in range(5)] + [send(a, 0) for a in range(1, 5)])
     a, b = run(wm, wev, 0, 5000, host=False, stop=True), run(wm, wev, 0, 5000, host=True, stop=True)
