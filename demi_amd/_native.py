@@ -217,7 +217,7 @@ class Context:
     def replay_load(self, original_externals, original_trace):
         import numpy as np
         ev = np.ascontiguousarray(original_externals, dtype=T.EXT_EVENT_DTYPE)
-        rec = np.ascontiguousarray(original_trace, dtype=T.REC_EVENT_DTYPE)
+        rec = T.rec_events(original_trace)
         self._check(lib().demi_replay_load(self._h, ev.ctypes.data if len(ev) else None, len(ev),
                                            rec.ctypes.data if len(rec) else None, len(rec)))
 

@@ -1020,7 +1020,7 @@ class RefBook {
 inline size_t ref_fetch_width() {
   const char* e = getenv("DEMI_DPOR_FETCH_WIDTH");
   const long v = e ? atol(e) : 0;
-  return v > 0 ? (size_t)v : 64u;
+  return v > 0 ? (size_t)v : 128u;
 }
 
 template <class Dev>

@@ -302,8 +302,8 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
       if (n_rec < args.rec_cap) {                                                             \
         demi_rec_event e_;                                                                    \
         e_.kind = (uint8_t)(KIND); e_.snd = (uint8_t)(SND); e_.rcv = (uint8_t)(RCV);          \
-        e_.msg_type = (uint8_t)(TYPE); e_.p0 = (uint8_t)(P0); e_.p1 = (uint8_t)(P1);          \
-        e_.flags = (uint8_t)(FL); e_.ext_idx = (uint8_t)(EXT); e_.id = (ID);                  \
+        e_.msg_type = (uint8_t)(TYPE); e_.p0 = (uint16_t)(P0); e_.p1 = (uint16_t)(P1);        \
+        e_.flags = (uint8_t)(FL); e_.ext_idx = (uint8_t)(EXT); e_.reserved = 0; e_.id = (ID); \
         rec[n_rec] = e_;                                                                      \
       }                                                                                       \
       n_rec++;                                                                                \

@@ -70,6 +70,8 @@ struct K2Args {
   uint32_t n_fp;            // word ids 0 .. n_fp - 1
   uint8_t* fp_counts;       // K2_FP_HBM: [n_fp][resident lanes] counters
   uint32_t lockstep;        // 1: the lanes of a wave walk the expected events together (k2 lock-step loop below)
+  const uint16_t* exp_hi;   // DEMI_MODEL_WIDE tables only: [n_exp] bits 8..15 of p0 | bits 8..15 of p1 << 8 (the 8-byte expected
+                            // event holds the low bytes)
 };
 
 constexpr int K2_WAVES = 4;
@@ -89,8 +91,8 @@ __host__ __device__ inline size_t k2_fp_lds_bytes(uint32_t code_len, uint32_t n_
          K2_WAVES * k2_fp_wave_bytes(n_actors, n_fp, counters_in_lds);
 }
 
-__host__ __device__ inline size_t k2_lds_bytes(uint32_t code_len, uint32_t n_ext, uint32_t n_hs, uint32_t n_actors) {
-  return tables_lds_bytes(code_len, n_ext, n_hs) + K2_WAVES * lane_mem_wave_bytes(n_actors, false);
+__host__ __device__ inline size_t k2_lds_bytes(uint32_t code_len, uint32_t n_ext, uint32_t n_hs, uint32_t n_actors, bool wide = WIDE_TU) {
+  return tables_lds_bytes(code_len, n_ext, n_hs, wide) + K2_WAVES * lane_mem_wave_bytes(n_actors, false, PEND_HOT, wide);
 }
 
 template <int MODE>
@@ -119,7 +121,7 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
     unsigned char* wb = wave_base + k2_fp_shared_bytes(NX, args.fp_hash_mask + 1) +
                         (size_t)wave * k2_fp_wave_bytes(t.A, args.n_fp, MODE == K2_FP_LDS);
     mem.st = reinterpret_cast<uint64_t*>(wb) + lane;
-    mem.fxq = reinterpret_cast<uint32_t*>(wb + (size_t)t.A * 64 * 8) + lane;
+    mem.fxq = reinterpret_cast<word_t*>(wb + (size_t)t.A * 64 * 8) + lane;    // (the counter variants never run a wide table)
     mem.pend = nullptr; mem.pend_aux = nullptr; mem.spill = nullptr; mem.spill_aux = nullptr; mem.spill_stride = 0; mem.spill_lane = 0; mem.hot = 0;
     if (MODE == K2_FP_LDS) cnt = wb + (size_t)t.A * 64 * 8 + (size_t)DEMI_FX_CAP * 64 * 4 + lane;
     else { cnt_stride = (size_t)gridDim.x * blockDim.x; cnt = args.fp_counts + (size_t)blockIdx.x * blockDim.x + threadIdx.x; }
@@ -190,6 +192,9 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
 
 #define IN_MASK(I) ((uint32_t)((((I) & 128u) ? (((I) & 64u) ? m3 : m2) : (((I) & 64u) ? m1 : m0)) >> ((I) & 63u)) & 1u)
 #define TIMER_BIT(RCV, TYPE) (1u << ((RCV) * DEMI_MAX_TIMER_TYPES + (t.meta[(TYPE)] >> 8)))
+// payload fields of expected event E at index I (a wide table's upper bytes come from exp_hi)
+#define EXP_P0(E, I) (((uint32_t)((E) >> 32) & 0xFFu) | (WIDE_TU ? ((uint32_t)args.exp_hi[(I)] & 0xFFu) << 8 : 0u))
+#define EXP_P1(E, I) (((uint32_t)((E) >> 40) & 0xFFu) | (WIDE_TU ? ((uint32_t)args.exp_hi[(I)] >> 8) << 8 : 0u))
 // FP: FPID is the word's id if the caller knows it, else it is looked up; a word without an id only takes up capacity
 #define PEND_APPEND_ID(WORD, FPID)                                     \
   do {                                                                 \
@@ -200,7 +205,7 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
       n_pend++;                                                        \
     } else { pend_store(mem, n_pend, (WORD)); n_pend++; }              \
   } while (0)
-#define PEND_APPEND(WORD) PEND_APPEND_ID(WORD, fp_of(WORD))
+#define PEND_APPEND(WORD) PEND_APPEND_ID(WORD, FP ? fp_of((uint32_t)(WORD)) : K2_FP_NONE)
 
   // cursor over the candidate's non-Send, non-WaitQuiescence externals (subsequenceIntersection :299-304)
   auto cur_skip = [&]() {
@@ -248,7 +253,7 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
         hash = 0xCBF29CE484222325ULL;
         app_rng = jr_seed(0);
         net.inaccessible = exists; net.killed = 0; net.partitioned = 0;
-        for (uint32_t a = 0; a < A; a++) st[a * 64] = t.init[a];
+        for (uint32_t a = 0; a < A * ST_WORDS; a++) st[a * 64] = t.init[a];
         if (FP) for (uint32_t f = 0; f < args.n_fp; f++) cnt[(size_t)f * cnt_stride] = 0;
         cur = 0; n_pend = 0; count = 0; ignored = 0; flags = 0; rep = 0; tq = 0; n_tq = 0; blocked = 0;
         fk_part = 0; fk_pruned0 = 0; fk_pruned1 = 0;
@@ -294,15 +299,15 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
         }
         if (kind == DEMI_REC_MSG_SEND) {
           if (active && IN_MASK(ext) && ((exists >> b) & 1)) {
-            PEND_APPEND_ID(msg_word((uint32_t)(e >> 24) & 0xFF, DEMI_DEADLETTERS, b, (uint32_t)(e >> 32) & 0xFF,
-                                    (uint32_t)(e >> 40) & 0xFF), (uint32_t)exp_fp[idx - 1]);
+            PEND_APPEND_ID(msg_word((uint32_t)(e >> 24) & 0xFF, DEMI_DEADLETTERS, b, EXP_P0(e, idx - 1), EXP_P1(e, idx - 1)),
+                           FP ? (uint32_t)exp_fp[idx - 1] : K2_FP_NONE);
             if (args.kept && !(flags & DEMI_OVF_ANY)) args.kept[sched * NX + idx - 1] = 1;
             if (flags & DEMI_OVF_ANY) active = false;
           }
           continue;
         }
         // ---- MSG_EVENT: which lanes deliver it
-        const uint32_t want = msg_word((uint32_t)(e >> 24) & 0xFF, a, b, (uint32_t)(e >> 32) & 0xFF, (uint32_t)(e >> 40) & 0xFF);
+        const word_t want = msg_word((uint32_t)(e >> 24) & 0xFF, a, b, EXP_P0(e, idx - 1), EXP_P1(e, idx - 1));
         bool deliver = false;
         if (active) {
           do {
@@ -331,7 +336,7 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
           } while (0);
         }
         if (__ballot(deliver) == 0) continue;            // nobody's candidate has this message pending
-        const uint32_t w = want;
+        const word_t w = want;
         const uint32_t type = w_type(w), me = w_dst(w);
         if (deliver) {
           count++;
@@ -345,9 +350,9 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
         if (deliver) nfx = DEMI_VM_RUN(t, mem, w, flags, app_rng);
         if (deliver) {
           for (uint32_t k = 0; k < nfx && !(flags & DEMI_OVF_ANY); k++) {
-            const uint32_t fx = mem.fxq[k * 64];
-            const uint32_t op = fx & 31u, ftype = (fx >> 5) & 31u, target = (fx >> 10) & 15u, p0 = (fx >> 14) & 0xFFu,
-                           p1 = (fx >> 22) & 0xFFu;
+            const word_t fxw = mem.fxq[k * 64];
+            const uint32_t fx = (uint32_t)fxw;
+            const uint32_t op = fx & 31u, ftype = (fx >> 5) & 31u, target = (fx >> 10) & 15u, p0 = fx_p0(fxw), p1 = fx_p1(fxw);
             if (op <= DEMI_OP_BCAST) {
               const bool bc = (op == DEMI_OP_BCAST);
               const uint32_t first = bc ? 0u : target, last = bc ? A : (target < A ? target + 1 : 0u);
@@ -369,9 +374,9 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
                 }
               }
               if (!found) {
-                const uint32_t wantw = msg_word(ftype, DEMI_DEADLETTERS, me, 0, 0);
+                const word_t wantw = msg_word(ftype, DEMI_DEADLETTERS, me, 0, 0);
                 if (FP) {
-                  const uint32_t f = fp_of(wantw);
+                  const uint32_t f = fp_of((uint32_t)wantw);
                   if (cnt_get(f)) { cnt_add(f, false); n_pend--; }
                 } else {
                   for (uint32_t q = 0; q < n_pend; q++) {
@@ -404,7 +409,7 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
           const uint32_t fp = invariant_code(args.model, st, exists, A, t.inv_kind, t.inv_fa, t.inv_va, t.inv_fb);
           if (fp && (((fp ^ args.looking_for) & t.fp_mask) == 0)) viol = args.looking_for;
         }
-        for (uint32_t a = 0; a < A; a++) hash_step(hash, st[a * 64]);
+        for (uint32_t a = 0; a < A * ST_WORDS; a++) hash_step(hash, st[a * 64]);
         uint4 v;
         if (flags & DEMI_OVF_ANY) {
           v.x = flags & DEMI_OVF_ANY; v.y = 0; v.z = 0; v.w = 0;
@@ -442,7 +447,7 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
       if (__ballot(active) == 0) break;
     }
 
-    uint32_t w = 0;
+    word_t w = 0;
     bool deliver = false, finish = false;
     if (active) {
       if (fresh) {
@@ -457,7 +462,7 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
         hash = 0xCBF29CE484222325ULL;
         app_rng = jr_seed(0);
         net.inaccessible = exists; net.killed = 0; net.partitioned = 0;
-        for (uint32_t a = 0; a < A; a++) st[a * 64] = t.init[a];
+        for (uint32_t a = 0; a < A * ST_WORDS; a++) st[a * 64] = t.init[a];
         if (FP) for (uint32_t f = 0; f < args.n_fp; f++) cnt[(size_t)f * cnt_stride] = 0;
         idx = 0; cur = 0; n_pend = 0; count = 0; ignored = 0; flags = 0; rep = 0; tq = 0; n_tq = 0; blocked = 0;
         fk_part = 0; fk_pruned0 = 0; fk_pruned1 = 0;
@@ -497,8 +502,8 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
         } else if (kind == DEMI_REC_MSG_SEND) {
           // external MsgSend -> enqueue_message (:509-511) unless its Send was pruned
           if (IN_MASK(ext) && ((exists >> b) & 1)) {
-            PEND_APPEND_ID(msg_word((uint32_t)(e >> 24) & 0xFF, DEMI_DEADLETTERS, b, (uint32_t)(e >> 32) & 0xFF,
-                                    (uint32_t)(e >> 40) & 0xFF), (uint32_t)exp_fp[idx - 1]);
+            PEND_APPEND_ID(msg_word((uint32_t)(e >> 24) & 0xFF, DEMI_DEADLETTERS, b, EXP_P0(e, idx - 1), EXP_P1(e, idx - 1)),
+                           FP ? (uint32_t)exp_fp[idx - 1] : K2_FP_NONE);
             if (args.kept && !(flags & DEMI_OVF_ANY)) args.kept[sched * NX + idx - 1] = 1;
           }
         } else {  // MSG_EVENT
@@ -510,8 +515,7 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
             if (!(fk_alive(b) && !fk_cut(a, b) && sent)) continue;
           }
           if ((blocked >> b) & 1u) { ignored++; continue; }   // the destination is blocked: not deliverable (:392-402), ignored
-          const uint32_t want = msg_word((uint32_t)(e >> 24) & 0xFF, a, b, (uint32_t)(e >> 32) & 0xFF,
-                                         (uint32_t)(e >> 40) & 0xFF);
+          const word_t want = msg_word((uint32_t)(e >> 24) & 0xFF, a, b, EXP_P0(e, idx - 1), EXP_P1(e, idx - 1));
           if (FP) {
             const uint32_t f = exp_fp[idx - 1];
             if (cnt_get(f) == 0) { ignored++; continue; }     // "Ignoring message" (:528-529)
@@ -549,9 +553,9 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
     if (deliver) {
       const uint32_t me = w_dst(w);
       for (uint32_t k = 0; k < nfx && !(flags & DEMI_OVF_ANY); k++) {
-        const uint32_t fx = mem.fxq[k * 64];
-        const uint32_t op = fx & 31u, type = (fx >> 5) & 31u, target = (fx >> 10) & 15u, p0 = (fx >> 14) & 0xFFu,
-                       p1 = (fx >> 22) & 0xFFu;
+        const word_t fxw = mem.fxq[k * 64];
+        const uint32_t fx = (uint32_t)fxw;
+        const uint32_t op = fx & 31u, type = (fx >> 5) & 31u, target = (fx >> 10) & 15u, p0 = fx_p0(fxw), p1 = fx_p1(fxw);
         if (op <= DEMI_OP_BCAST) {
           const bool bc = (op == DEMI_OP_BCAST);
           const uint32_t first = bc ? 0u : target, last = bc ? A : (target < A ? target + 1 : 0u);
@@ -574,9 +578,9 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
             }
           }
           if (!found) {
-            const uint32_t wantw = msg_word(type, DEMI_DEADLETTERS, me, 0, 0);
+            const word_t wantw = msg_word(type, DEMI_DEADLETTERS, me, 0, 0);
             if (FP) {
-              const uint32_t f = fp_of(wantw);                   // every timer word has an id
+              const uint32_t f = fp_of((uint32_t)wantw);         // every timer word has an id
               if (cnt_get(f)) { cnt_add(f, false); n_pend--; }
             } else {
               for (uint32_t q = 0; q < n_pend; q++) {
@@ -612,7 +616,7 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
         const uint32_t fp = invariant_code(args.model, st, exists, A, t.inv_kind, t.inv_fa, t.inv_va, t.inv_fb);
         if (fp && (((fp ^ args.looking_for) & t.fp_mask) == 0)) viol = args.looking_for;
       }
-      for (uint32_t a = 0; a < A; a++) hash_step(hash, st[a * 64]);
+      for (uint32_t a = 0; a < A * ST_WORDS; a++) hash_step(hash, st[a * 64]);
       uint4 v;
       if (flags & DEMI_OVF_ANY) {
         v.x = flags & DEMI_OVF_ANY; v.y = 0; v.z = 0; v.w = 0;
@@ -625,6 +629,8 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
     }
   }
 #undef IN_MASK
+#undef EXP_P0
+#undef EXP_P1
 #undef TIMER_BIT
 #undef PEND_APPEND
 #undef PEND_APPEND_ID

@@ -68,8 +68,8 @@ struct K3Args {
 constexpr int K3_WAVES = 4;
 constexpr size_t K3_ANALYSIS_BYTES = DEMI_DPOR_MAX_TRACE * 4 + DEMI_DPOR_MAX_TRACE * 32;   // meta words + ancestor sets
 
-__host__ __device__ inline size_t k3_lds_bytes(uint32_t code_len, uint32_t n_ext, uint32_t n_hs, uint32_t n_actors) {
-  return tables_lds_bytes(code_len, n_ext, n_hs) + K3_WAVES * (lane_mem_wave_bytes(n_actors, true) + K3_ANALYSIS_BYTES);
+__host__ __device__ inline size_t k3_lds_bytes(uint32_t code_len, uint32_t n_ext, uint32_t n_hs, uint32_t n_actors, bool wide = WIDE_TU) {
+  return tables_lds_bytes(code_len, n_ext, n_hs, wide) + K3_WAVES * (lane_mem_wave_bytes(n_actors, true, PEND_HOT, wide) + K3_ANALYSIS_BYTES);
 }
 
 __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v, uint32_t lane) {
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
 
   // event_produced + getMessage: the node is a child of the current parentEvent; enqueued unless
   // the depth bound is hit (:832-838)
-  auto produce = [&](uint32_t word) {
+  auto produce = [&](word_t word) {
     if (args.depth_bound && parent_depth + 1 >= args.depth_bound) return;
     if (flags & DEMI_OVF_ANY) return;
     if (n_pend >= PMAX) { flags |= DEMI_V_PENDING_OVF; return; }
@@ -214,10 +214,11 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
     next_seq++;
     n_pend++;
   };
-  auto trace_push = [&](uint64_t key, uint32_t word, uint32_t par, uint32_t qp, uint32_t kind) -> int {
+  // (a wide table's trace entry reports the low half of the 64-bit message word: type, dst, src, p0 - include/demi_gpu.h)
+  auto trace_push = [&](uint64_t key, word_t word, uint32_t par, uint32_t qp, uint32_t kind) -> int {
     if (n_trace >= DEMI_DPOR_MAX_TRACE) { flags |= DEMI_V_TRACE_OVF; return -1; }
     demi_dpor_trace_entry e;
-    e.key = key; e.word = word; e.parent = (uint8_t)par; e.qperiod = (uint8_t)qp;
+    e.key = key; e.word = (uint32_t)word; e.parent = (uint8_t)par; e.qperiod = (uint8_t)qp;
     e.depth = (uint8_t)(n_trace == 0 ? 0 : tr[par].depth + 1);
     e.kind = (uint8_t)kind;
     tr[n_trace] = e;
@@ -231,7 +232,9 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
       const uint32_t kind = (uint32_t)ev & 0xFF, a = (uint32_t)(ev >> 8) & 0xFF;
       if (kind == DEMI_EV_START) isolated &= ~(1u << a);
       else if (kind == DEMI_EV_SEND)
-        produce(msg_word((uint32_t)(ev >> 24) & 0xFF, DEMI_DEADLETTERS, a, (uint32_t)(ev >> 32) & 0xFF, (uint32_t)(ev >> 40) & 0xFF));
+        produce(msg_word((uint32_t)(ev >> 24) & 0xFF, DEMI_DEADLETTERS, a,
+                         ((uint32_t)(ev >> 32) & 0xFF) | (WIDE_TU ? ((uint32_t)(ev >> 48) & 0xFF) << 8 : 0u),
+                         ((uint32_t)(ev >> 40) & 0xFF) | (WIDE_TU ? ((uint32_t)(ev >> 56) & 0xFF) << 8 : 0u)));
       else if (kind == DEMI_EV_WAIT_QUIESCENCE) { marker_pending = true; marker_ext = ext_idx; await = true; }
       ext_idx++;
     }
@@ -260,7 +263,7 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
       if (__ballot(active) == 0) break;
     }
 
-    uint32_t w = 0;
+    word_t w = 0;
     bool deliver = false, finish = false;
     if (active) {
       if (fresh) {
@@ -280,7 +283,7 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
         hash = 0xCBF29CE484222325ULL;
         app_rng = jr_seed(0);
         isolated = (1u << A) - 1;      // maybeStartActors: every actor exists and is isolated (:666-679)
-        for (uint32_t a = 0; a < A; a++) st[a * 64] = t.init[a];
+        for (uint32_t a = 0; a < A * ST_WORDS; a++) st[a * 64] = t.init[a];
         n_pend = 0; next_seq = 0; qperiod = 0; next_qperiod = 0; rep = 0; flags = 0; count = 0; deliveries = 0; blocked = 0;
         n_trace = 0; ext_idx = 0; awaiting = false; marker_pending = false;
         trace_push(DPOR_ROOT_KEY, 0, 0, 0, 0);   // currentTrace += getRootEvent (:336-343)
@@ -308,9 +311,10 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
             } else {
               uint32_t best_seq = 0xFFFFFFFFu;
               for (uint32_t k = 0; k < n_pend && !((blocked >> w_dst(want.word)) & 1u); k++) {
-                if (pend_load(mem, k) != want.word) continue;
+                const word_t cw = pend_load(mem, k);
+                if ((uint32_t)cw != want.word) continue;         // (the entry holds the word's low half; the key decides)
                 const uint32_t aux = aux_load(mem, k);
-                const uint64_t key = (tr[aux & 0xFF].key ^ (uint64_t)want.word) * DPOR_PRIME;
+                const uint64_t key = (tr[aux & 0xFF].key ^ (uint64_t)cw) * DPOR_PRIME;
                 if (key == want.key && (aux >> 16) < best_seq) { best_seq = aux >> 16; chosen = (int)k; }
               }
             }
@@ -320,7 +324,7 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
           // getPendingEvent (:452-472), iteration order pinned: (snd, rcv) ascending, FIFO inside
           uint32_t best = 0xFFFFFFFFu;
           for (uint32_t k = 0; k < n_pend; k++) {
-            const uint32_t pw = pend_load(mem, k);
+            const word_t pw = pend_load(mem, k);
             if ((blocked >> w_dst(pw)) & 1u) continue;           // !(blockedActors contains k._2) (:455)
             const uint32_t ord = (((w_src(pw) << 4) | w_dst(pw)) << 16) | (aux_load(mem, k) >> 16);
             if (ord < best) { best = ord; chosen = (int)k; }
@@ -331,7 +335,8 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
         if (chose_marker) {                              // awaitQuiescenceUpdate (:256-266)
           marker_pending = false; awaiting = true; next_qperiod = marker_ext + 1; qmarker_ext = marker_ext;
         } else if (!none) {
-          const uint32_t pw = pend_load(mem, (uint32_t)chosen), aux = aux_load(mem, (uint32_t)chosen);
+          const word_t pw = pend_load(mem, (uint32_t)chosen);
+          const uint32_t aux = aux_load(mem, (uint32_t)chosen);
           pend_store(mem, (uint32_t)chosen, pend_load(mem, n_pend - 1));
           aux_store(mem, (uint32_t)chosen, aux_load(mem, n_pend - 1));
           n_pend--;
@@ -377,9 +382,9 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
     if (deliver) {
       const uint32_t me = w_dst(w);
       for (uint32_t k = 0; k < nfx && !(flags & DEMI_OVF_ANY); k++) {
-        const uint32_t fx = mem.fxq[k * 64];
-        const uint32_t op = fx & 31u, type = (fx >> 5) & 31u, target = (fx >> 10) & 15u, p0 = (fx >> 14) & 0xFFu,
-                       p1 = (fx >> 22) & 0xFFu;
+        const word_t fxw = mem.fxq[k * 64];
+        const uint32_t fx = (uint32_t)fxw;
+        const uint32_t op = fx & 31u, type = (fx >> 5) & 31u, target = (fx >> 10) & 15u, p0 = fx_p0(fxw), p1 = fx_p1(fxw);
         if (op <= DEMI_OP_BCAST) {
           const bool bc = (op == DEMI_OP_BCAST);
           const uint32_t first = bc ? 0u : target, last = bc ? A : (target < A ? target + 1 : 0u);
@@ -392,7 +397,7 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
         } else if (op == DEMI_OP_TCANCEL) {
           // notify_timer_cancel (:961-984): first of the (deadLetters, rcv) queue with this message
           rep &= ~TIMER_BIT(me, type);
-          const uint32_t wantw = msg_word(type, DEMI_DEADLETTERS, me, 0, 0);
+          const word_t wantw = msg_word(type, DEMI_DEADLETTERS, me, 0, 0);
           int best = -1;
           uint32_t best_seq = 0xFFFFFFFFu;
           for (uint32_t q = 0; q < n_pend; q++) {
@@ -446,7 +451,7 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
           else if (((fp ^ args.looking_for) & t.fp_mask) == 0) viol = args.looking_for;
         }
       }
-      for (uint32_t a = 0; a < A; a++) hash_step(hash, st[a * 64]);
+      for (uint32_t a = 0; a < A * ST_WORDS; a++) hash_step(hash, st[a * 64]);
       uint4 v;
       if (aborted) {
         v.x = flags & K3_ABORT; v.y = 0; v.z = 0; v.w = 0;

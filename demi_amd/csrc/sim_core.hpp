@@ -153,7 +153,8 @@ __device__ inline LaneMem lane_mem_carve(unsigned char* wave_base, uint32_t n_ac
                                          uint32_t* g_spill_words, size_t global_lane, size_t total_lanes,
                                          uint32_t hot = PEND_HOT) {
   word_t* const g_spill = reinterpret_cast<word_t*>(g_spill_words);
-  // (the aux arrays behind the message words are 32-bit: only the recording variants have them, and those never run wide)
+  // (the aux arrays behind the message words are 32-bit also when the message words are 64-bit: the host sizes the scratch
+  // as words x (1 or 2) + aux x 1 dwords per slot)
   uint32_t* const g_aux = reinterpret_cast<uint32_t*>(g_spill + spill_words(total_lanes, hot));
   LaneMem m;
   m.st = reinterpret_cast<uint64_t*>(wave_base) + lane;

@@ -214,6 +214,8 @@ class StsRemovalOracle:
         self.p_max = p_max
         self._ctx = _native.Context(device)
         self._ctx.model_load(schedulerConfig.model.to_struct())
+        if getattr(schedulerConfig.model, "wide", False):
+            self._ctx.model_specialize()         # a wide table (DEMI_MODEL_WIDE) runs only as compiled code
         self._loaded = None
 
     def _limits(self, fp: ViolationFingerprint) -> T.Limits:

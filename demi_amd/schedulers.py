@@ -263,6 +263,8 @@ class STSScheduler:
         self.p_max = p_max
         self._ctx = _native.Context(device)
         self._ctx.model_load(schedulerConfig.model.to_struct())
+        if getattr(schedulerConfig.model, "wide", False):
+            self._ctx.model_specialize()         # a wide table (DEMI_MODEL_WIDE) runs only as compiled code
         self._ctx.replay_load(original_trace.original_externals, original_trace.events)
 
     def getName(self) -> str:
@@ -358,6 +360,8 @@ class ReplayScheduler:
         self.p_max = p_max
         self._ctx = _native.Context(device)
         self._ctx.model_load(schedulerConfig.model.to_struct())
+        if getattr(schedulerConfig.model, "wide", False):
+            self._ctx.model_specialize()         # a wide table (DEMI_MODEL_WIDE) runs only as compiled code
 
     def replay(self, trace: EventTrace, expected: Optional[ViolationFingerprint] = None):
         """Returns the replay's verdict row; raises ReplayException on divergence."""

@@ -5,7 +5,7 @@ JSON file, so a JVM (or anything else) can read it without this package:
 
   model.json                the lowered application (demi_model)
   externals.bin             demi_ext_event[]   (original_externals)
-  event_trace.bin           demi_rec_event[]   (the recorded violating execution)
+  event_trace.bin           demi_rec_event[]   (16-byte records: the recorded violating execution)
   mcs.bin                   uint32[]           (indices of the minimal causal sequence, optional)
   meta.json                 fingerprint code, limits, seed, format version
 """
@@ -27,7 +27,7 @@ def save_experiment(path: str, model: Model, trace: EventTrace, fingerprint: Vio
     os.makedirs(path, exist_ok=True)
     save_model(model, os.path.join(path, "model.json"))
     np.ascontiguousarray(trace.original_externals, dtype=T.EXT_EVENT_DTYPE).tofile(os.path.join(path, "externals.bin"))
-    np.ascontiguousarray(trace.events, dtype=T.REC_EVENT_DTYPE).tofile(os.path.join(path, "event_trace.bin"))
+    T.rec_events(trace.events).tofile(os.path.join(path, "event_trace.bin"))
     if mcs is not None:
         np.asarray(mcs, dtype=np.uint32).tofile(os.path.join(path, "mcs.bin"))
     meta = {"format": FORMAT_VERSION, "fingerprint": int(fingerprint.code), "match_mask": int(fingerprint.match_mask),

@@ -131,14 +131,28 @@ import numpy as np  # noqa: E402
 VERDICT_DTYPE = np.dtype([("flags", "<u4"), ("fingerprint", "<u4"), ("hash", "<u8")])
 EXT_EVENT_DTYPE = np.dtype([("kind", "u1"), ("a", "u1"), ("b", "u1"), ("msg_type", "u1"),
                             ("p0", "u1"), ("p1", "u1"), ("p0_hi", "u1"), ("p1_hi", "u1")])
-REC_EVENT_DTYPE = np.dtype([("kind", "u1"), ("snd", "u1"), ("rcv", "u1"), ("msg_type", "u1"),
-                            ("p0", "u1"), ("p1", "u1"), ("flags", "u1"), ("ext_idx", "u1"), ("id", "<u4")])
+REC_EVENT_DTYPE = np.dtype([("kind", "u1"), ("snd", "u1"), ("rcv", "u1"), ("msg_type", "u1"), ("p0", "<u2"), ("p1", "<u2"),
+                            ("flags", "u1"), ("ext_idx", "u1"), ("reserved", "<u2"), ("id", "<u4")])
+
+
+def rec_events(a):
+    """A recorded trace as a contiguous demi_rec_event[] (16-byte records).  Accepts any structured array with the record's
+    field names - e.g. the 12-byte layout (8-bit payloads) that fixtures written before the wide models hold - and copies field
+    by field."""
+    a = np.asarray(a)
+    if a.dtype == REC_EVENT_DTYPE:
+        return np.ascontiguousarray(a)
+    out = np.zeros(a.shape, dtype=REC_EVENT_DTYPE)
+    for name in REC_EVENT_DTYPE.names:
+        if a.dtype.names and name in a.dtype.names:
+            out[name] = a[name]
+    return out
 DPOR_TRACE_DTYPE = np.dtype([("key", "<u8"), ("word", "<u4"), ("parent", "u1"), ("qperiod", "u1"), ("depth", "u1"),
                              ("kind", "u1")])
 DPOR_PAIR_DTYPE = np.dtype([("branch", "u1"), ("later", "u1"), ("earlier", "u1"), ("pad", "u1")])
 assert DPOR_TRACE_DTYPE.itemsize == 16 and DPOR_PAIR_DTYPE.itemsize == 4
 VIOLATION_DTYPE = np.dtype([("index", "<u8"), ("fingerprint", "<u4"), ("flags", "<u4")])
-assert VERDICT_DTYPE.itemsize == 16 and VIOLATION_DTYPE.itemsize == 16 and EXT_EVENT_DTYPE.itemsize == 8 and REC_EVENT_DTYPE.itemsize == 12
+assert VERDICT_DTYPE.itemsize == 16 and VIOLATION_DTYPE.itemsize == 16 and EXT_EVENT_DTYPE.itemsize == 8 and REC_EVENT_DTYPE.itemsize == 16
 
 
 def verdict_violation(flags):

@@ -228,11 +228,13 @@ typedef struct {
   uint8_t kind;            /* demi_rec_kind */
   uint8_t snd, rcv;        /* MSG_*: sender (15 = deadLetters; timers are recorded as "Timer"), receiver;
                               SPAWN/KILL: rcv = actor; (UN)PARTITION: snd = a, rcv = b */
-  uint8_t msg_type, p0, p1;
+  uint8_t msg_type;
+  uint16_t p0, p1;         /* the message's payload fields: below 256 unless the model is DEMI_MODEL_WIDE */
   uint8_t flags;           /* bit0: external message, bit1: timer, bit2: dropped at send (crosses_partition) */
   uint8_t ext_idx;         /* index of the ExternalEvent that caused this record, 255 = none */
+  uint16_t reserved;       /* 0 */
   uint32_t id;             /* Uniq id pairing a MSG_SEND with its MSG_EVENT */
-} demi_rec_event;          /* 12 bytes */
+} demi_rec_event;          /* 16 bytes */
 
 typedef struct demi_ctx demi_ctx;
 

@@ -11,11 +11,11 @@
  * Build: make -C jni (needs JAVA_HOME; without a JDK `make -C jni check` compiles against jni/stub/jni.h).
  *
  * Array conventions (little-endian, same layouts as the C structs):
- *   events    byte[8 * n]     demi_ext_event          recorded  byte[12 * n]  demi_rec_event
+ *   events    byte[8 * n]     demi_ext_event          recorded  byte[16 * n]  demi_rec_event
  *   verdicts  long[2 * n]     demi_verdict (long 0 = flags | fingerprint << 32, long 1 = hash)
  *   masks     long[4 * n]     candidate subsequences  violations long[2 * n]  demi_violation (index, fingerprint | flags << 32)
  *   limits    int[9]          demi_limits             dporParams int[7]  demi_dpor_params     dporSearch int[6]  demi_dpor_search
- *   dporStats long[12]        demi_dpor_stats (kernel_ms as raw double bits)                                       */
+ *   dporStats long[13]        demi_dpor_stats (kernel_ms as raw double bits; fetches last)                                       */
 #include <jni.h>
 #include <stdint.h>
 #include <string.h>
@@ -135,13 +135,13 @@ JNIEXPORT jint JNICALL FN(randomExploreFlagged)(JNIEnv* e, jclass c, jlong h, jl
   (*e)->SetLongArrayRegion(e, counts, 0, 2, cn);
   return rc;
 }
-/* verdict: long[2]; recorded: byte[12 * cap]; returns the number of recorded events, or a negative demi_status */
+/* verdict: long[2]; recorded: byte[16 * cap]; returns the number of recorded events, or a negative demi_status */
 JNIEXPORT jint JNICALL FN(randomGetTrace)(JNIEnv* e, jclass c, jlong h, jlong seed, jintArray limits, jlongArray verdict, jbyteArray recorded) {
   demi_limits lim;
   demi_verdict v;
   (void)c;
-  if (limits_of(e, limits, &lim) || LEN(verdict) != 2 || LEN(recorded) < 0 || LEN(recorded) % 12) return DEMI_ERR_INVALID_ARG;
-  const uint32_t cap = (uint32_t)(LEN(recorded) / 12);
+  if (limits_of(e, limits, &lim) || LEN(verdict) != 2 || LEN(recorded) < 0 || LEN(recorded) % (jint)sizeof(demi_rec_event)) return DEMI_ERR_INVALID_ARG;
+  const uint32_t cap = (uint32_t)(LEN(recorded) / (jint)sizeof(demi_rec_event));
   uint32_t n_out = 0;
   memset(&v, 0, sizeof v);
   void* r = BYTES(recorded);
@@ -157,8 +157,8 @@ JNIEXPORT jint JNICALL FN(randomGetTraceCarried)(JNIEnv* e, jclass c, jlong h, j
   demi_limits lim;
   demi_verdict v;
   (void)c;
-  if (limits_of(e, limits, &lim) || execIndex < 0 || LEN(verdict) != 2 || LEN(recorded) < 0 || LEN(recorded) % 12) return DEMI_ERR_INVALID_ARG;
-  const uint32_t cap = (uint32_t)(LEN(recorded) / 12);
+  if (limits_of(e, limits, &lim) || execIndex < 0 || LEN(verdict) != 2 || LEN(recorded) < 0 || LEN(recorded) % (jint)sizeof(demi_rec_event)) return DEMI_ERR_INVALID_ARG;
+  const uint32_t cap = (uint32_t)(LEN(recorded) / (jint)sizeof(demi_rec_event));
   uint32_t n_out = 0, ran = 0;
   memset(&v, 0, sizeof v);
   void* r = BYTES(recorded);
@@ -173,10 +173,10 @@ JNIEXPORT jint JNICALL FN(randomGetTraceCarried)(JNIEnv* e, jclass c, jlong h, j
 JNIEXPORT jint JNICALL FN(replayLoad)(JNIEnv* e, jclass c, jlong h, jbyteArray externals, jbyteArray recorded) {
   (void)c;
   const int64_t le = LEN(externals), lr = LEN(recorded);
-  if (le < 0 || le % 8 || lr < 0 || lr % 12) return DEMI_ERR_INVALID_ARG;
+  if (le < 0 || le % 8 || lr < 0 || lr % (jint)sizeof(demi_rec_event)) return DEMI_ERR_INVALID_ARG;
   void* x = BYTES(externals);
   void* r = BYTES(recorded);
-  jint rc = demi_replay_load(CTX(h), (const demi_ext_event*)x, (uint32_t)(le / 8), (const demi_rec_event*)r, (uint32_t)(lr / 12));
+  jint rc = demi_replay_load(CTX(h), (const demi_ext_event*)x, (uint32_t)(le / 8), (const demi_rec_event*)r, (uint32_t)(lr / (jint)sizeof(demi_rec_event)));
   PUT_BYTES(recorded, r, JNI_ABORT);
   PUT_BYTES(externals, x, JNI_ABORT);
   return rc;
@@ -239,7 +239,7 @@ JNIEXPORT jint JNICALL FN(dporLoad)(JNIEnv* e, jclass c, jlong h, jbyteArray ext
   return rc;
 }
 /* verdicts: long[2 * max_interleavings]; prefixLen, rounds: int[max_interleavings]; firstViolationTrace: byte[16 * 256];
- * stats: long[12] (the demi_dpor_stats fields in order; the length of the first violating trace is returned, or a negative
+ * stats: long[13] (the demi_dpor_stats fields in order, `fetches` last; the length of the first violating trace is returned, or a negative
  * demi_status).  A whole exploration runs inside this call: no array is pinned critically (see the header). */
 JNIEXPORT jint JNICALL FN(dporExplore)(JNIEnv* e, jclass c, jlong h, jintArray params, jintArray search, jlongArray verdicts,
                                       jintArray prefixLen, jintArray rounds, jbyteArray firstViolationTrace, jlongArray stats) {
@@ -247,7 +247,7 @@ JNIEXPORT jint JNICALL FN(dporExplore)(JNIEnv* e, jclass c, jlong h, jintArray p
   demi_dpor_search srch;
   jint s[6];
   (void)c;
-  if (dpor_params_of(e, params, &par) || LEN(search) != 6 || LEN(stats) != 12) return DEMI_ERR_INVALID_ARG;
+  if (dpor_params_of(e, params, &par) || LEN(search) != 6 || LEN(stats) != 13) return DEMI_ERR_INVALID_ARG;
   (*e)->GetIntArrayRegion(e, search, 0, 6, s);
   srch.batch = (uint32_t)s[0]; srch.max_interleavings = (uint32_t)s[1]; srch.stop_if_violation = (uint32_t)s[2];
   srch.track_history = (uint32_t)s[3]; srch.order = (uint32_t)s[4]; srch.cache_mb = (uint32_t)s[5];
@@ -267,12 +267,12 @@ JNIEXPORT jint JNICALL FN(dporExplore)(JNIEnv* e, jclass c, jlong h, jintArray p
   PUT_INTS(rounds, rd, 0);
   PUT_INTS(prefixLen, pl, 0);
   PUT_LONGS(verdicts, v, 0);
-  jlong o[12];
+  jlong o[13];
   o[0] = (jlong)st.interleavings; o[1] = (jlong)st.launches; o[2] = (jlong)st.violations; o[3] = (jlong)st.first_violation;
   o[4] = (jlong)st.queue_len; o[5] = (jlong)st.exhausted; o[6] = (jlong)st.executed; o[7] = (jlong)st.cache_misses;
   memcpy(&o[8], &st.kernel_ms, sizeof(jlong));
-  o[9] = (jlong)st.h2d_bytes; o[10] = (jlong)st.d2h_bytes; o[11] = (jlong)st.backtrack_points;
-  (*e)->SetLongArrayRegion(e, stats, 0, 12, o);
+  o[9] = (jlong)st.h2d_bytes; o[10] = (jlong)st.d2h_bytes; o[11] = (jlong)st.backtrack_points; o[12] = (jlong)st.fetches;
+  (*e)->SetLongArrayRegion(e, stats, 0, 13, o);
   return rc == DEMI_OK ? (jint)vlen : rc;
 }
 

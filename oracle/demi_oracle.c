@@ -376,13 +376,13 @@ typedef struct {
   orc_effect fx[DEMI_MAX_CODE * DEMI_MAX_ACTORS];
 } exec_t;
 
-static void rec_push(exec_t* x, uint8_t kind, uint8_t snd, uint8_t rcv, uint8_t type, uint8_t p0, uint8_t p1,
+static void rec_push(exec_t* x, uint8_t kind, uint8_t snd, uint8_t rcv, uint8_t type, uint16_t p0, uint16_t p1,
                      uint8_t flags, uint8_t ext_idx, uint32_t id) {
   if (!x->rec) return;
   if (x->n_rec < x->rec_cap) {
     demi_rec_event* e = &x->rec[x->n_rec];
     e->kind = kind; e->snd = snd; e->rcv = rcv; e->msg_type = type; e->p0 = p0; e->p1 = p1;
-    e->flags = flags; e->ext_idx = ext_idx; e->id = id;
+    e->flags = flags; e->ext_idx = ext_idx; e->reserved = 0; e->id = id;
   }
   x->n_rec++;
 }
@@ -509,7 +509,7 @@ static void event_produced(exec_t* x, uint32_t snd, uint32_t rcv, uint32_t type,
   } else {
     pend_insert(x, msg_word_x(x->wide, type, snd, rcv, p0, p1), id); /* externals: no partition check (:298-308) */
   }
-  rec_push(x, DEMI_REC_MSG_SEND, (uint8_t)snd, (uint8_t)rcv, (uint8_t)type, (uint8_t)p0, (uint8_t)p1,
+  rec_push(x, DEMI_REC_MSG_SEND, (uint8_t)snd, (uint8_t)rcv, (uint8_t)type, (uint16_t)(x->wide ? p0 : (p0 & 0xFFu)), (uint16_t)(x->wide ? p1 : (p1 & 0xFFu)),
            (uint8_t)((is_external ? 1 : 0) | (is_timer ? 2 : 0) | (dropped ? 4 : 0)), ext_idx, id);
 }
 
@@ -659,8 +659,8 @@ static int schedule_new_message(exec_t* x) {
   }
   x->count++;                                                   /* :462 */
   uint64_t w = e.word;
-  rec_push(x, DEMI_REC_MSG_EVENT, (uint8_t)W_SRC(w), (uint8_t)W_DST(w), (uint8_t)W_TYPE(w), (uint8_t)W_P0(w),
-           (uint8_t)W_P1(w), 0, 255, e.id);
+  rec_push(x, DEMI_REC_MSG_EVENT, (uint8_t)W_SRC(w), (uint8_t)W_DST(w), (uint8_t)W_TYPE(w), (uint16_t)WX_P0(x->wide, w),
+           (uint16_t)WX_P1(x->wide, w), 0, 255, e.id);
   hash_step(&x->hash, w);
   /* updateRepeatingTimer :405-421; isTimer = timerToCancellable contains (rcv, msg) */
   int is_rep = x->m->msg_class[W_TYPE(w)] == DEMI_MSG_TIMER &&
@@ -697,8 +697,8 @@ static int random_execute_in2(exec_t* x, const demi_model* m, const demi_ext_eve
   memset(x, 0, offsetof(exec_t, fx));
   x->m = m; x->trace = trace; x->n_ev = n_ev; x->lim = lim;
   x->wide = (m->flags & DEMI_MODEL_WIDE) != 0;
-  /* a wide model has no recorded-trace format (demi_rec_event carries 8-bit payloads) and no SrcDstFIFO variant */
-  if (x->wide && (rec || lim->strategy != DEMI_STRATEGY_FULLY_RANDOM)) return DEMI_ERR_INVALID_MODEL;
+  /* a wide model has no SrcDstFIFO variant */
+  if (x->wide && lim->strategy != DEMI_STRATEGY_FULLY_RANDOM) return DEMI_ERR_INVALID_MODEL;
   x->rec = rec; x->rec_cap = rec_cap;
   x->p_max = lim->p_max ? lim->p_max : 64;
   if (x->p_max > PEND_HARD_CAP) x->p_max = PEND_HARD_CAP;
@@ -863,11 +863,12 @@ int orc_random_explore(const demi_model* m, const demi_ext_event* trace, uint32_
  * with the same (snd, rcv, fingerprint) is pending (messagePending :381-403, oldest first
  * :709-737), else ignore it (:528-529); at the end evaluate the invariant and match the target
  * fingerprint (:278-300).                                                                        */
-typedef struct { uint32_t word; uint32_t seq; } sts_pend;
+typedef struct { uint64_t word; uint32_t seq; } sts_pend;   /* word: 64 bits for a wide model */
 
 typedef struct {
   const demi_model* m;
-  uint64_t state[DEMI_MAX_ACTORS];
+  int wide;           /* DEMI_MODEL_WIDE: 64-bit message words, two state words per actor */
+  uint64_t state[2 * DEMI_MAX_ACTORS];
   uint32_t exists, inaccessible, killed;
   uint32_t blocked;   /* crashed actors (Instrumenter().blockedActors): an expected delivery to one is not "pending" (:392-402) */
   orc_jrandom app_rng; /* Instrumenter().seededRandom, new with every replay */
@@ -891,7 +892,7 @@ static int sts_crosses(const sts_t* x, uint32_t snd, uint32_t rcv) {
   return part || ir || is;
 }
 
-static void sts_pend_add(sts_t* x, uint32_t word) {
+static void sts_pend_add(sts_t* x, uint64_t word) {
   if (x->flags & OVF_ANY) return;
   if (x->n_pend >= x->p_max) { x->flags |= DEMI_V_PENDING_OVF; return; }
   x->pend[x->n_pend].word = word;
@@ -900,7 +901,7 @@ static void sts_pend_add(sts_t* x, uint32_t word) {
 }
 
 /* oldest pending message with this (snd, rcv, fingerprint); -1 if none */
-static int sts_pend_find(const sts_t* x, uint32_t word) {
+static int sts_pend_find(const sts_t* x, uint64_t word) {
   int best = -1;
   for (uint32_t i = 0; i < x->n_pend; i++)
     if (x->pend[i].word == word && (best < 0 || x->pend[i].seq < x->pend[best].seq)) best = (int)i;
@@ -930,7 +931,7 @@ static void sts_flush(sts_t* x) {
   x->n_mts = 0;
 }
 
-static void sts_deliver(sts_t* x, uint32_t w) {
+static void sts_deliver(sts_t* x, uint64_t w) {
   const demi_model* m = x->m;
   uint32_t me = W_DST(w);
   x->count++;
@@ -938,15 +939,15 @@ static void sts_deliver(sts_t* x, uint32_t w) {
   /* Instrumenter retrigger of repeating timers (V/Instrumenter.scala:1008-1016), pinned before receive */
   if (m->msg_class[W_TYPE(w)] == DEMI_MSG_TIMER && (x->repeating & timer_bit(m, me, W_TYPE(w))))
     sts_handle_timer(x, me, W_TYPE(w));
-  int n = orc_vm_run(m, me, &x->state[me], (uint8_t)W_TYPE(w), (uint8_t)W_SRC(w), (uint8_t)W_P0(w), (uint8_t)W_P1(w),
-                     x->exists, x->fx, DEMI_MAX_CODE * DEMI_MAX_ACTORS, &x->app_rng);
+  int n = orc_vm_run(m, me, &x->state[x->wide ? 2 * me : me], (uint8_t)W_TYPE(w), (uint8_t)W_SRC(w), (uint16_t)WX_P0(x->wide, w),
+                     (uint16_t)WX_P1(x->wide, w), x->exists, x->fx, DEMI_MAX_CODE * DEMI_MAX_ACTORS, &x->app_rng);
   if (n < 0) { x->flags |= DEMI_V_QUEUE_OVF; return; }
   for (int i = 0; i < n && !(x->flags & OVF_ANY); i++) {
     const orc_effect* e = &x->fx[i];
     uint32_t bit = e->kind ? timer_bit(m, me, e->msg_type) : 0;
     switch (e->kind) {
       case 0: /* event_produced, internal (:590-607) */
-        if (!sts_crosses(x, me, e->target)) sts_pend_add(x, msg_word(e->msg_type, me, e->target, e->p0, e->p1));
+        if (!sts_crosses(x, me, e->target)) sts_pend_add(x, msg_word_x(x->wide, e->msg_type, me, e->target, e->p0, e->p1));
         break;
       case 1: case 2: /* registerCancellable + handleTick (V/Instrumenter.scala:1145-1200) */
         if (x->repeating & bit) break;
@@ -993,6 +994,7 @@ static int sts_replay_in(sts_t* x, const demi_model* m, const demi_ext_event* ex
   orc_jrandom_seed(&x->app_rng, 0);
   if (kept) memset(kept, 0, n_rec);
   x->m = m;
+  x->wide = (m->flags & DEMI_MODEL_WIDE) != 0;
   x->p_max = lim->p_max ? lim->p_max : 64;
   if (x->p_max > PEND_HARD_CAP) x->p_max = PEND_HARD_CAP;
   x->hash = 0xCBF29CE484222325ULL;
@@ -1001,7 +1003,7 @@ static int sts_replay_in(sts_t* x, const demi_model* m, const demi_ext_event* ex
     if (rec[i].kind == DEMI_REC_SPAWN) x->exists |= 1u << rec[i].rcv;
   if (lim->populate_all) x->exists = (1u << m->n_actors) - 1;
   x->inaccessible = x->exists;
-  for (uint32_t a = 0; a < m->n_actors; a++) x->state[a] = m->init_state[a];
+  for (uint32_t a = 0; a < m->n_actors * (x->wide ? 2u : 1u); a++) x->state[a] = m->init_state[a];
 
 #define IN_MASK(i) ((mask[(i) >> 6] >> ((i) & 63)) & 1)
   /* id -> index of the Send that enqueued it (external messages only): filterSends (:382-452) */
@@ -1064,7 +1066,7 @@ static int sts_replay_in(sts_t* x, const demi_model* m, const demi_ext_event* ex
         }
         /* external MsgSend: enqueue_message (:509-511) unless its Send was pruned; internal: nothing */
         if ((e->flags & 1) && IN_MASK(e->ext_idx) && ((x->exists >> e->rcv) & 1)) {
-          sts_pend_add(x, msg_word(e->msg_type, DEMI_DEADLETTERS, e->rcv, e->p0, e->p1));
+          sts_pend_add(x, msg_word_x(x->wide, e->msg_type, DEMI_DEADLETTERS, e->rcv, e->p0, e->p1));
           if (kept && !(x->flags & OVF_ANY)) kept[idx] = 1;
         }
         break;
@@ -1074,7 +1076,7 @@ static int sts_replay_in(sts_t* x, const demi_model* m, const demi_ext_event* ex
         if (s != 255 && !IN_MASK(s)) break; /* pruned together with its Send */
         /* filterKnownAbsentInternals: messageDeliverable(snd, rcv, id) or the event is not part of the projected trace */
         if (fka && !(FK_ALIVE(e->rcv) && !FK_PART(e->snd, e->rcv) && !(e->id < sizeof fk_pruned && fk_pruned[e->id]))) break;
-        uint32_t w = msg_word(e->msg_type, e->snd, e->rcv, e->p0, e->p1);
+        uint64_t w = msg_word_x(x->wide, e->msg_type, e->snd, e->rcv, e->p0, e->p1);
         int k = ((x->blocked >> e->rcv) & 1) ? -1 : sts_pend_find(x, w);   /* messagePending: "double check that the destination isn't currently blocked" (:392-402) */
         if (k < 0) { x->ignored++; break; } /* "Ignoring message" (:528-529) */
         sts_pend_remove(x, k);
@@ -1094,7 +1096,7 @@ static int sts_replay_in(sts_t* x, const demi_model* m, const demi_ext_event* ex
     uint32_t fp = orc_invariant(m, x->state, x->exists);
     if (fp && ((fp ^ lim->looking_for) & m->fp_match_mask) == 0) viol = lim->looking_for;
   }
-  for (uint32_t a = 0; a < m->n_actors; a++) hash_step(&x->hash, x->state[a]);
+  for (uint32_t a = 0; a < m->n_actors * (x->wide ? 2u : 1u); a++) hash_step(&x->hash, x->state[a]);
   if (x->flags & OVF_ANY) {
     out->flags = x->flags & OVF_ANY; out->fingerprint = 0; out->hash = 0;
   } else {
@@ -1109,7 +1111,6 @@ static int sts_replay_in(sts_t* x, const demi_model* m, const demi_ext_event* ex
 int orc_sts_replay(const demi_model* m, const demi_ext_event* ext, uint32_t n_ext, const demi_rec_event* rec,
                    uint32_t n_rec, const uint64_t mask[4], const demi_limits* lim, demi_verdict* out,
                    uint32_t* n_ignored) {
-  if (m->flags & DEMI_MODEL_WIDE) return DEMI_ERR_INVALID_MODEL;   /* wide models: the RandomScheduler path only (include/demi_gpu.h) */
   sts_t* x = (sts_t*)malloc(sizeof(sts_t));
   if (!x) return DEMI_ERR_INVALID_ARG;
   int rc = sts_replay_in(x, m, ext, n_ext, rec, n_rec, mask, lim, out, n_ignored, 0xFFFFFFFFu, NULL);
@@ -1122,7 +1123,6 @@ static const uint64_t STS_ALL[4] = {~0ULL, ~0ULL, ~0ULL, ~0ULL};
 int orc_sts_removal(const demi_model* m, const demi_ext_event* ext, uint32_t n_ext, const demi_rec_event* rec,
                     uint32_t n_rec, const uint64_t* mask, uint32_t skip, const demi_limits* lim, demi_verdict* out,
                     uint8_t* kept) {
-  if (m->flags & DEMI_MODEL_WIDE) return DEMI_ERR_INVALID_MODEL;   /* wide models: the RandomScheduler path only (include/demi_gpu.h) */
   sts_t* x = (sts_t*)malloc(sizeof(sts_t));
   if (!x) return DEMI_ERR_INVALID_ARG;
   int rc = sts_replay_in(x, m, ext, n_ext, rec, n_rec, mask ? mask : STS_ALL, lim, out, NULL, skip, kept);
@@ -1160,7 +1160,6 @@ static void* sts_job_main(void* p) {
 static int sts_batch(const demi_model* m, const demi_ext_event* ext, uint32_t n_ext, const demi_rec_event* rec,
                      uint32_t n_rec, const uint64_t* masks, const uint32_t* skip, uint64_t n, const demi_limits* lim,
                      demi_verdict* out, int n_threads) {
-  if (m->flags & DEMI_MODEL_WIDE) return DEMI_ERR_INVALID_MODEL;   /* wide models: the RandomScheduler path only (include/demi_gpu.h) */
   if (n_threads < 1) n_threads = 1;
   if (n_threads > 256) n_threads = 256;
   pthread_t th[256];
@@ -1198,12 +1197,13 @@ int orc_sts_removal_batch(const demi_model* m, const demi_ext_event* ext, uint32
 #define DPOR_MARKER_KEY(i) (DPOR_ROOT_KEY ^ (0x5155494553434500ULL | (uint64_t)(i)))
 #define DPOR_PRIME 0x100000001B3ULL
 
-typedef struct { uint32_t word; uint32_t seq; uint8_t parent; uint8_t qperiod; } dpor_pend;
+typedef struct { uint64_t word; uint32_t seq; uint8_t parent; uint8_t qperiod; } dpor_pend;   /* word: 64 bits for a wide model */
 
 typedef struct {
   const demi_model* m;
   const demi_dpor_params* par;
-  uint64_t state[DEMI_MAX_ACTORS];
+  int wide;                             /* DEMI_MODEL_WIDE: 64-bit message words, two state words per actor */
+  uint64_t state[2 * DEMI_MAX_ACTORS];
   uint32_t isolated;
   uint32_t blocked;    /* crashed actors: skipped by getPendingEvent (:455) and by getMatchingMessage (:478, 518) */
   orc_jrandom app_rng; /* Instrumenter().seededRandom, new with every interleaving */
@@ -1232,7 +1232,7 @@ int orc_dpor_trace_validate(const demi_model* m, const demi_ext_event* ev, uint3
 
 /* event_produced + getMessage (:803-847, 773-801): the node always exists in the graph; it is only
  * enqueued when the depth bound allows (:832-838) */
-static void dpor_produce(dpor_t* x, uint32_t word) {
+static void dpor_produce(dpor_t* x, uint64_t word) {
   uint32_t cur_depth = (uint32_t)x->trace[x->parent].depth + 1; /* currentDepth = pathLength(parent)+1 */
   if (x->par->depth_bound && cur_depth >= x->par->depth_bound) return;
   if (x->flags & OVF_ANY) return;
@@ -1245,7 +1245,7 @@ static void dpor_produce(dpor_t* x, uint32_t word) {
 }
 
 static uint64_t dpor_key_of(const dpor_t* x, const dpor_pend* p) {
-  return (x->trace[p->parent].key ^ (uint64_t)p->word) * DPOR_PRIME;
+  return (x->trace[p->parent].key ^ p->word) * DPOR_PRIME;
 }
 
 /* runExternal (:684-721) */
@@ -1254,17 +1254,19 @@ static uint32_t dpor_run_external(dpor_t* x, const demi_ext_event* ext, uint32_t
   while (idx < n_ext && !await) {
     const demi_ext_event* e = &ext[idx];
     if (e->kind == DEMI_EV_START) x->isolated &= ~(1u << e->a);
-    else if (e->kind == DEMI_EV_SEND) dpor_produce(x, msg_word(e->msg_type, DEMI_DEADLETTERS, e->a, e->p0, e->p1));
+    else if (e->kind == DEMI_EV_SEND)
+      dpor_produce(x, msg_word_x(x->wide, e->msg_type, DEMI_DEADLETTERS, e->a, e->p0 | ((uint32_t)e->p0_hi << 8), e->p1 | ((uint32_t)e->p1_hi << 8)));
     else if (e->kind == DEMI_EV_WAIT_QUIESCENCE) { x->marker_pending = 1; x->marker_ext = idx; await = 1; }
     idx++;
   }
   return idx;
 }
 
-static int dpor_trace_push(dpor_t* x, uint64_t key, uint32_t word, uint32_t parent, uint32_t kind) {
+/* (a wide model's trace entry reports the low half of the message word - type, dst, src, p0 - include/demi_gpu.h) */
+static int dpor_trace_push(dpor_t* x, uint64_t key, uint64_t word, uint32_t parent, uint32_t kind) {
   if (x->n_trace >= DEMI_DPOR_MAX_TRACE) { x->flags |= DEMI_V_TRACE_OVF; return -1; }
   demi_dpor_trace_entry* t = &x->trace[x->n_trace];
-  t->key = key; t->word = word; t->parent = (uint8_t)parent; t->qperiod = (uint8_t)x->qperiod;
+  t->key = key; t->word = (uint32_t)word; t->parent = (uint8_t)parent; t->qperiod = (uint8_t)x->qperiod;
   t->depth = (uint8_t)(x->n_trace == 0 ? 0 : x->trace[parent].depth + 1);
   t->kind = (uint8_t)kind;
   return (int)x->n_trace++;
@@ -1277,21 +1279,21 @@ static int dpor_cmp_queue(const dpor_pend* a, const dpor_pend* b) {
   return a->seq < b->seq ? -1 : (a->seq > b->seq ? 1 : 0);
 }
 
-static void dpor_deliver(dpor_t* x, uint32_t w) {
+static void dpor_deliver(dpor_t* x, uint64_t w) {
   const demi_model* m = x->m;
   uint32_t me = W_DST(w);
   x->deliveries++;
   hash_step(&x->hash, w);
   if (m->msg_class[W_TYPE(w)] == DEMI_MSG_TIMER && (x->repeating & timer_bit(m, me, W_TYPE(w))))
     dpor_produce(x, msg_word(W_TYPE(w), DEMI_DEADLETTERS, me, 0, 0)); /* retrigger -> enqueue_timer = `!` (Scheduler.scala:73) */
-  int n = orc_vm_run(m, me, &x->state[me], (uint8_t)W_TYPE(w), (uint8_t)W_SRC(w), (uint8_t)W_P0(w), (uint8_t)W_P1(w),
-                     (1u << m->n_actors) - 1, x->fx, DEMI_MAX_CODE * DEMI_MAX_ACTORS, &x->app_rng);
+  int n = orc_vm_run(m, me, &x->state[x->wide ? 2 * me : me], (uint8_t)W_TYPE(w), (uint8_t)W_SRC(w), (uint16_t)WX_P0(x->wide, w),
+                     (uint16_t)WX_P1(x->wide, w), (1u << m->n_actors) - 1, x->fx, DEMI_MAX_CODE * DEMI_MAX_ACTORS, &x->app_rng);
   if (n < 0) { x->flags |= DEMI_V_QUEUE_OVF; return; }
   for (int i = 0; i < n && !(x->flags & OVF_ANY); i++) {
     const orc_effect* e = &x->fx[i];
     uint32_t bit = e->kind ? timer_bit(m, me, e->msg_type) : 0;
     switch (e->kind) {
-      case 0: dpor_produce(x, msg_word(e->msg_type, me, e->target, e->p0, e->p1)); break;
+      case 0: dpor_produce(x, msg_word_x(x->wide, e->msg_type, me, e->target, e->p0, e->p1)); break;
       case 1: case 2:
         if (x->repeating & bit) break; /* Non-unique timer */
         if (e->kind == 2) x->repeating |= bit;
@@ -1299,7 +1301,7 @@ static void dpor_deliver(dpor_t* x, uint32_t w) {
         break;
       case 3: { /* notify_timer_cancel (:961-984): first in the (deadLetters, rcv) queue with this msg */
         x->repeating &= ~bit;
-        uint32_t want = msg_word(e->msg_type, DEMI_DEADLETTERS, me, 0, 0);
+        uint64_t want = msg_word(e->msg_type, DEMI_DEADLETTERS, me, 0, 0);
         int best = -1;
         for (uint32_t k = 0; k < x->n_pend; k++)
           if (x->pend[k].word == want && (best < 0 || x->pend[k].seq < x->pend[best].seq)) best = (int)k;
@@ -1314,16 +1316,16 @@ static void dpor_deliver(dpor_t* x, uint32_t w) {
 int orc_dpor_execute(const demi_model* m, const demi_ext_event* ext, uint32_t n_ext, const uint64_t* prefix,
                      uint32_t prefix_len, uint32_t shared_len, const demi_dpor_params* par, demi_verdict* out,
                      demi_dpor_trace_entry* trace, uint32_t* trace_len, demi_dpor_pair* pairs, uint32_t* n_pairs) {
-  if (m->flags & DEMI_MODEL_WIDE) return DEMI_ERR_INVALID_MODEL;   /* wide models: the RandomScheduler path only (include/demi_gpu.h) */
   dpor_t* x = (dpor_t*)calloc(1, sizeof(dpor_t));
   if (!x) return DEMI_ERR_INVALID_ARG;
   x->m = m; x->par = par; x->trace = trace;
+  x->wide = (m->flags & DEMI_MODEL_WIDE) != 0;
   x->p_max = par->p_max ? par->p_max : 64;
   if (x->p_max > PEND_HARD_CAP) x->p_max = PEND_HARD_CAP;
   x->hash = 0xCBF29CE484222325ULL;
   x->isolated = (1u << m->n_actors) - 1; /* maybeStartActors: isolatedActors ++= actorNames (:666-679) */
   orc_jrandom_seed(&x->app_rng, 0);
-  for (uint32_t a = 0; a < m->n_actors; a++) x->state[a] = m->init_state[a];
+  for (uint32_t a = 0; a < m->n_actors * (x->wide ? 2u : 1u); a++) x->state[a] = m->init_state[a];
   dpor_trace_push(x, DPOR_ROOT_KEY, 0, 0, 0); /* start_trace: currentTrace += getRootEvent (:336-343) */
   x->parent = 0; x->cur_root = 0;
   uint32_t ext_idx = dpor_run_external(x, ext, n_ext, 0);
@@ -1406,7 +1408,7 @@ int orc_dpor_execute(const demi_model* m, const demi_ext_event* ext, uint32_t n_
       else if (((fp ^ par->looking_for) & m->fp_match_mask) == 0) viol = par->looking_for;
     }
   }
-  for (uint32_t a = 0; a < m->n_actors; a++) hash_step(&x->hash, x->state[a]);
+  for (uint32_t a = 0; a < m->n_actors * (x->wide ? 2u : 1u); a++) hash_step(&x->hash, x->state[a]);
 
   /* ---- dpor(): racing pairs (:1122-1139) with isCoEnabeled (:1091-1110) and analyze_dep (:1043-1077) */
   uint32_t np = 0, pairs_ovf = 0;

@@ -62,6 +62,8 @@ struct SimDev {
   // the device's copy of the COMMIT's explored-pair table (REFERENCE order, explore_reference_resident): ordered pair -> state
   std::unordered_map<std::pair<uint64_t, uint64_t>, uint32_t, demi_host::PairKeyHash> real_tab;
   unsigned long long pairs_reported = 0, pairs_after_parent = 0, pairs_kept = 0;
+  unsigned long long sum_branch = 0, sum_later = 0, n_items = 0, sum_len = 0;
+  ~SimDev() { if (getenv("DEMI_HARNESS_STATS")) fprintf(stderr, "[harness] items %llu mean shared (branch + 1) %.1f mean prefix (later) %.1f\n", n_items, n_items ? (double)sum_branch / n_items : 0.0, n_items ? (double)sum_later / n_items : 0.0); }
 
   // ResidentDev::round_ref restated: the ROUNDS machinery for the speculation, then the commit filter per interleaving -
   // (a) ParentFilter against the parent's trace in the arena, (b) no-ops under the snapshot of the commit's table; the
@@ -134,6 +136,7 @@ struct SimDev {
     // mark
     for (uint32_t i = 0; i < n; i++) {
       if (items[i].src == 0xFFFFFFFFu) continue;
+      sum_branch += items[i].branch + 1u; sum_later += items[i].later; n_items++;
       const demi_host::Trace& T = arena[items[i].src];
       table[{T[items[i].later].key, T[items[i].earlier].key}].state |= SIM_EXPLORED;
     }

@@ -206,7 +206,7 @@ def sts_replay_batch(model, original_externals, original_trace, masks, limits, n
     """STSScheduler.test (no peek) for every candidate mask (uint64[n, 4]); VERDICT_DTYPE array."""
     ms = model.to_struct()
     ev = np.ascontiguousarray(original_externals, dtype=T.EXT_EVENT_DTYPE)
-    rec = np.ascontiguousarray(original_trace, dtype=T.REC_EVENT_DTYPE)
+    rec = T.rec_events(original_trace)
     masks = np.ascontiguousarray(masks, dtype=np.uint64).reshape(-1, 4)
     out = np.zeros(len(masks), dtype=T.VERDICT_DTYPE)
     rc = lib().orc_sts_replay_batch(C.byref(ms), ev.ctypes.data, len(ev), rec.ctypes.data, len(rec),
@@ -220,7 +220,7 @@ def sts_removal_batch(model, original_externals, original_trace, skips, limits, 
     kept unless masks is given; VERDICT_DTYPE array."""
     ms = model.to_struct()
     ev = np.ascontiguousarray(original_externals, dtype=T.EXT_EVENT_DTYPE)
-    rec = np.ascontiguousarray(original_trace, dtype=T.REC_EVENT_DTYPE)
+    rec = T.rec_events(original_trace)
     skips = np.ascontiguousarray(skips, dtype=np.uint32)
     if masks is not None:
         masks = np.ascontiguousarray(masks, dtype=np.uint64).reshape(-1, 4)
@@ -237,7 +237,7 @@ def sts_removal_kept(model, original_externals, original_trace, skip, limits, ma
     """(verdict, kept uint8[n_rec]) of one removal candidate: kept marks the executed trace."""
     ms = model.to_struct()
     ev = np.ascontiguousarray(original_externals, dtype=T.EXT_EVENT_DTYPE)
-    rec = np.ascontiguousarray(original_trace, dtype=T.REC_EVENT_DTYPE)
+    rec = T.rec_events(original_trace)
     if mask is not None:
         mask = np.ascontiguousarray(mask, dtype=np.uint64).reshape(4)
     v = T.Verdict()

@@ -131,7 +131,7 @@ class GpuRandomScheduler(val schedulerConfig: SchedulerConfig, max_executions: I
       for ((idx, fl) <- cand) {
         var lim = limits(lookingFor)
         if (fl < 0 || (fl & OVF) != 0) lim = limits(lookingFor, MAX_PENDING)
-        val v = new Array[Long](2); val rec = new Array[Byte](12 * 16384)
+        val v = new Array[Long](2); val rec = new Array[Byte](FlatEvents.REC_BYTES * 16384)
         // (carried generator: `idx` is the execution number within the one instance; the recording kernel re-runs the chain)
         val n = if (carriedGenerator) check(h, randomGetTraceCarried(h, seed, (start + idx).toInt, lim, v, rec))
                 else check(h, randomGetTrace(h, seed + start + idx, lim, v, rec))
@@ -299,7 +299,7 @@ class GpuDPOR(val schedulerConfig: SchedulerConfig, lowering: TableLowering, dep
     val search = Array(batch, maxInterleavings, if (stopIfViolationFound) 1 else 0, 1,
                        if (referenceOrder) DPOR_ORDER_REFERENCE else DPOR_ORDER_ROUNDS, 0)
     val verdicts = new Array[Long](2 * maxInterleavings); val plen = new Array[Int](maxInterleavings)
-    val rounds = new Array[Int](maxInterleavings); val vt = new Array[Byte](16 * 256); val st = new Array[Long](12)
+    val rounds = new Array[Int](maxInterleavings); val vt = new Array[Byte](16 * 256); val st = new Array[Long](13)
     val vlen = check(h, dporExplore(h, params, search, verdicts, plen, rounds, vt, st))
     if (stats != null) (0L until st(0)).foreach(_ => stats.increment_replays())
     if (st(2) == 0) None

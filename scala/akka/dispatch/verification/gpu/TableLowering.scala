@@ -28,11 +28,12 @@ trait TableLowering {
 
 class UnsupportedOnGpu(what: String) extends RuntimeException(what + " cannot run on the GPU path: use the JVM scheduler")
 
-/** ExternalEvent <-> demi_ext_event (8 bytes) and demi_rec_event (12 bytes) <-> the EventTrace records. */
+/** ExternalEvent <-> demi_ext_event (8 bytes) and demi_rec_event (16 bytes) <-> the EventTrace records. */
 object FlatEvents {
   val EV_START = 0; val EV_KILL = 1; val EV_SEND = 2; val EV_PARTITION = 3; val EV_UNPARTITION = 4; val EV_WAIT_QUIESCENCE = 5
   val REC_SPAWN = 0; val REC_KILL = 1; val REC_PARTITION = 2; val REC_UNPARTITION = 3; val REC_BEGIN_WAIT_QUIESCENCE = 4
   val REC_QUIESCENCE = 5; val REC_MSG_SEND = 6; val REC_MSG_EVENT = 7
+  val REC_BYTES = 16           // sizeof(demi_rec_event)
   val DEADLETTERS = 15
 
   def pack(trace: Seq[ExternalEvent], lo: TableLowering): Array[Byte] = {
@@ -61,18 +62,20 @@ object FlatEvents {
   def toEventTrace(rec: Array[Byte], nRec: Int, externals: Seq[ExternalEvent], lo: TableLowering): EventTrace = {
     val trace = new EventTrace(externals)
     for (i <- 0 until nRec) {
-      val o = 12 * i
+      // kind, snd, rcv, msg_type, p0 (u16), p1 (u16), flags, ext_idx, reserved (u16), id (u32): include/demi_gpu.h
+      val o = REC_BYTES * i
       def u(k: Int) = rec(o + k) & 0xFF
-      val id = (u(8)) | (u(9) << 8) | (u(10) << 16) | (u(11) << 24)
+      val id = (u(12)) | (u(13) << 8) | (u(14) << 16) | (u(15) << 24)
+      val p0 = u(4) | (u(5) << 8); val p1 = u(6) | (u(7) << 8)
       u(0) match {
-        case REC_SPAWN => externals(u(7)) match { case Start(ctor, n) => trace += SpawnEvent("", ctor(), n, null) }
+        case REC_SPAWN => externals(u(9)) match { case Start(ctor, n) => trace += SpawnEvent("", ctor(), n, null) }
         case REC_KILL => trace += KillEvent(lo.actorName(u(2)))
         case REC_PARTITION => trace += PartitionEvent((lo.actorName(u(1)), lo.actorName(u(2))))
         case REC_UNPARTITION => trace += UnPartitionEvent((lo.actorName(u(1)), lo.actorName(u(2))))
         case REC_BEGIN_WAIT_QUIESCENCE => trace += BeginWaitQuiescence
         case REC_QUIESCENCE => trace += Quiescence
-        case REC_MSG_SEND => trace += UniqueMsgSend(MsgSend(name(u(1), lo), lo.actorName(u(2)), lo.decode(u(3), u(4), u(5))), id)
-        case REC_MSG_EVENT => trace += UniqueMsgEvent(MsgEvent(name(u(1), lo), lo.actorName(u(2)), lo.decode(u(3), u(4), u(5))), id)
+        case REC_MSG_SEND => trace += UniqueMsgSend(MsgSend(name(u(1), lo), lo.actorName(u(2)), lo.decode(u(3), p0, p1)), id)
+        case REC_MSG_EVENT => trace += UniqueMsgEvent(MsgEvent(name(u(1), lo), lo.actorName(u(2)), lo.decode(u(3), p0, p1)), id)
       }
     }
     trace
@@ -81,15 +84,16 @@ object FlatEvents {
   /** EventTrace -> demi_rec_event[] (for replayLoad): the inverse of toEventTrace for the records the GPU path produces. */
   def packRecorded(trace: EventTrace, lo: TableLowering): Array[Byte] = {
     val evs = trace.events.toSeq
-    val out = new Array[Byte](12 * evs.size)
+    val out = new Array[Byte](REC_BYTES * evs.size)
     val sends = trace.original_externals.zipWithIndex.collect { case (Send(_, _), i) => i }.iterator
     val spawns = scala.collection.mutable.Map[String, Int]() ++
       trace.original_externals.zipWithIndex.collect { case (Start(_, n), i) => n -> i }
     def put(i: Int, kind: Int, snd: Int, rcv: Int, t: Int, p0: Int, p1: Int, fl: Int, ext: Int, id: Int) {
-      val o = 12 * i
-      out(o) = kind.toByte; out(o + 1) = snd.toByte; out(o + 2) = rcv.toByte; out(o + 3) = t.toByte; out(o + 4) = p0.toByte
-      out(o + 5) = p1.toByte; out(o + 6) = fl.toByte; out(o + 7) = ext.toByte
-      out(o + 8) = id.toByte; out(o + 9) = (id >> 8).toByte; out(o + 10) = (id >> 16).toByte; out(o + 11) = (id >> 24).toByte
+      val o = REC_BYTES * i
+      out(o) = kind.toByte; out(o + 1) = snd.toByte; out(o + 2) = rcv.toByte; out(o + 3) = t.toByte
+      out(o + 4) = p0.toByte; out(o + 5) = (p0 >> 8).toByte; out(o + 6) = p1.toByte; out(o + 7) = (p1 >> 8).toByte
+      out(o + 8) = fl.toByte; out(o + 9) = ext.toByte                                  // (10, 11: reserved, 0)
+      out(o + 12) = id.toByte; out(o + 13) = (id >> 8).toByte; out(o + 14) = (id >> 16).toByte; out(o + 15) = (id >> 24).toByte
     }
     def actor(n: String) = if (n == "deadLetters" || n == "Timer") DEADLETTERS else lo.actorId(n)
     for ((e, i) <- evs.zipWithIndex) e match {

@@ -154,7 +154,7 @@ def test_experiment_dir_roundtrip(tmp_path, oracle):
     m2, t2, fp2, meta, mcs = load_experiment(str(tmp_path / "e"))
     assert m2.to_json() == model.to_json() and (t2.events == rec).all() and (t2.original_externals == tr.original_externals).all()
     assert fp2.code == 0x1000103 and meta["seed"] == SEED_BASE + 1 and list(mcs) == [0, 2, 5]
-    assert os.path.getsize(str(tmp_path / "e" / "event_trace.bin")) == 12 * len(rec)
+    assert os.path.getsize(str(tmp_path / "e" / "event_trace.bin")) == 16 * len(rec)
 
 
 def test_jni_shim_compiles_against_the_stub_header_and_covers_the_adapter():

@@ -234,7 +234,7 @@ def test_wide_raft_table_equals_plain_reference(oracle):
 
 def test_wide_model_rules(oracle):
     """MOVHI and 16-bit payloads belong to wide models only; a wide model executes under the RandomScheduler oracle (terms
-    above 255 reach the verdict hash) and is refused by the recording, SrcDstFIFO, replay and DPOR paths."""
+    above 255 reach the verdict hash) is recorded with its 16-bit payloads and replays; SrcDstFIFO refuses it."""
     narrow = M.raft_model(3)
     a = Asm().ldi16(M.T0, 0x1234).mov(M.F[0], M.T0)
     bad = build_model("bad", 2, [("E", T.MSG_EXTERNAL)], {(0, "E"): a}, [[0] * 8] * 2, (T.INV_NONE, 0, 0, 0))
@@ -259,8 +259,16 @@ def test_wide_model_rules(oracle):
     fifo = T.Limits(100, 10, 64, 0, 0, 0)
     fifo.strategy = T.STRATEGY_SRC_DST_FIFO
     assert (oracle.random_explore(M.raft_model(3, term0=1000), ev, 2, limits=fifo)["hash"] == 0).all()   # (refused: nothing computed)
-    with pytest.raises(AssertionError):
-        oracle.random_execute(M.raft_model(3, term0=1000), ev, 1, lim, record=True)          # no recorded-trace format
+    # the recorded trace carries the 16-bit payloads; replaying it whole reproduces the execution (test(trace) == verdict)
+    wm = M.raft_model(3, term0=1000)
+    k = int(np.flatnonzero(vw["flags"] & T.V_VIOLATION)[0])
+    v, rec, _ = oracle.random_execute(wm, ev, k, lim, record=True)
+    assert v.flags == vw["flags"][k] and v.hash == vw["hash"][k]
+    assert int(rec["p0"].max()) >= 1000 and int(rec[rec["kind"] == T.REC_MSG_EVENT]["p0"].max()) >= 1000
+    used = ev[:T.verdict_trace_idx(v.flags)]
+    full = np.full((1, 4), ~np.uint64(0), dtype=np.uint64)
+    r = oracle.sts_replay_batch(wm, used, rec, full, T.Limits(0, 0, 64, 1, v.fingerprint, 0))
+    assert (r["flags"] & T.V_VIOLATION).all() and not (r["flags"] & T.V_DIVERGED).any() and r["hash"][0] == v.hash
 
 
 # --------------------------------------------------------------------------- tiny models: one semantic rule each

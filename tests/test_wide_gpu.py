@@ -81,6 +81,105 @@ def test_wide_random_tables_parity(oracle, seed):
         ctx.close()
 
 
+def test_wide_dpor_parity(oracle):
+    """DPORwHeuristics over a wide table (K3 compiled with 64-bit message words): per-interleaving verdicts, traces and racing
+    pairs against the oracle, the whole exploration with the oracle as backend, the native loop in both orders.  A trace entry
+    reports the low half of the message word (include/demi_gpu.h); node keys hash the whole word."""
+    from demi_amd.dpor import DPORwHeuristics
+    from demi_amd.schedulers import SchedulerConfig
+    from .test_k3_gpu import collect_prefixes, same_batch
+    model = M.raft_model(3, term0=1000, loglen0=300)
+    assert model.wide
+    ev = events_to_array([start(a) for a in range(3)] + [send(a, M.M_BOOTSTRAP) for a in range(3)])
+    prefixes, res, _ = collect_prefixes(oracle, model, ev, 30, 32, 160)
+    assert len(prefixes) >= 128
+    ctx = _native.Context(0)
+    try:
+        ctx.model_load(model.to_struct())
+        ctx.dpor_load(ev)
+        with pytest.raises(_native.DemiError, match="compiled table"):
+            ctx.dpor_batch(prefixes[:4], T.DporParams(30, 0, 0, 0, 64, 4096))
+        ctx.model_specialize()
+        for par in (T.DporParams(30, 0, 0, 0, 64, 4096), T.DporParams(12, 0, 0, 0, 64, 4096), T.DporParams(30, 40, 0, 0, 64, 64),
+                    T.DporParams(30, 0, 0, 0, 3, 4096)):
+            same_batch(ctx.dpor_batch(prefixes, par), oracle.dpor_batch(model, ev, prefixes, par))
+    finally:
+        ctx.close()
+    # same protocol as the 8-bit model: the same tree of interleavings, other keys and hashes
+    narrow = collect_prefixes(oracle, M.raft_model(3), ev, 30, 32, 160)[1]
+    assert res.rounds == narrow.rounds and [i.prefix_len for i in res.interleavings] == [i.prefix_len for i in narrow.interleavings]
+    assert res.schedule_hashes().isdisjoint(narrow.schedule_hashes())
+    # whole explorations: Python loop on the GPU vs the oracle as backend, then the native loop in both orders
+    dg = DPORwHeuristics(SchedulerConfig(model=model), depth_bound=30, stopIfViolationFound=False, batch=64, specialize=True)
+    rg = dg.explore(ev, max_interleavings=800)
+    dc = DPORwHeuristics(SchedulerConfig(model=model), depth_bound=30, stopIfViolationFound=False, batch=64, backend=oracle.dpor_batch)
+    rc = dc.explore(ev, max_interleavings=800)
+    assert rg.rounds == rc.rounds and len(rg.interleavings) == len(rc.interleavings) == 800
+    assert all(a.verdict == b.verdict and (a.trace == b.trace).all() for a, b in zip(rg.interleavings, rc.interleavings))
+    dn = DPORwHeuristics(SchedulerConfig(model=model), depth_bound=30, stopIfViolationFound=False, batch=64, specialize=True)
+    rn = dn.explore_native(ev, max_interleavings=800)
+    assert rn.rounds == rg.rounds and all(a.verdict == b.verdict and a.prefix_len == b.prefix_len for a, b in zip(rn.interleavings, rg.interleavings))
+    d1 = DPORwHeuristics(SchedulerConfig(model=model), depth_bound=30, stopIfViolationFound=False, batch=1, backend=oracle.dpor_batch)
+    r1 = d1.explore(ev, max_interleavings=300)
+    dr = DPORwHeuristics(SchedulerConfig(model=model), depth_bound=30, stopIfViolationFound=False, batch=256, specialize=True)
+    rr = dr.explore_native(ev, max_interleavings=300, reference_order=True)
+    assert len(rr.interleavings) == 300 and all(a.verdict == b.verdict and a.prefix_len == b.prefix_len for a, b in zip(rr.interleavings, r1.interleavings))
+    dg.shutdown(); dn.shutdown(); dr.shutdown()
+
+
+def test_wide_record_replay_minimize(oracle):
+    """The rest of the pipeline on a wide table: the recorded EventTrace of a violating execution (16-bit payloads in
+    demi_rec_event), STSScheduler replays of candidate subsequences, removal candidates and kept marks (K2 compiled with 64-bit
+    message words, the scanning variant), DDMin and the internal minimization end to end - everything against the oracle."""
+    from demi_amd.internal_minimization import STSSchedMinimizer
+    from demi_amd.minification import stsSchedDDMin
+    from demi_amd.schedulers import EventTrace, STSScheduler, SchedulerConfig, ViolationFingerprint
+    from tests.test_minification_cpu import OracleSTS
+    from .test_k2_gpu import random_masks
+    _, events, lim = raft5_config2()
+    model = M.raft_model(5, term0=1000, loglen0=300)
+    ctx = _native.Context(0)
+    try:
+        ctx.model_load(model.to_struct())
+        ctx.trace_load(events)
+        ctx.model_specialize()
+        v = ctx.random_explore(4000, lim, seed_base=SEED_BASE)
+        hits = np.nonzero(v["flags"] & T.V_VIOLATION)[0]
+        rng = np.random.default_rng(11)
+        for k in (int(hits[0]), int(hits[3])):
+            vv, rec = ctx.random_get_trace(SEED_BASE + k, lim)
+            cv, crec, _ = oracle.random_execute(model, events, SEED_BASE + k, lim, record=True)
+            assert vv.flags == cv.flags == v["flags"][k] and vv.hash == cv.hash == v["hash"][k] and vv.fingerprint == cv.fingerprint
+            assert len(rec) == len(crec) and (rec == crec).all() and int(rec["p0"].max()) >= 1000
+            used = events[:T.verdict_trace_idx(vv.flags)]
+            target = T.Limits(0, 0, 64, 1, vv.fingerprint, 0)
+            ctx.replay_load(used, rec)
+            masks = random_masks(rng, len(used), 1500)
+            g = ctx.replay_batch(masks, target)
+            c = oracle.sts_replay_batch(model, used, rec, masks, target, n_threads=os.cpu_count())
+            assert_same(g, c)
+            assert g[0]["flags"] & T.V_VIOLATION and not g[0]["flags"] & T.V_DIVERGED and int(g[0]["hash"]) == vv.hash
+            assert (g["flags"] & T.V_VIOLATION).sum() > 1 and (g["flags"] & T.V_DIVERGED).sum() > 100
+            for fka in (T.FILTER_ABSENTS_LITERAL, T.FILTER_ABSENTS_CORRECTED):
+                tl = T.Limits(0, 0, 64, 1, vv.fingerprint, 0, 0, fka)
+                assert_same(ctx.replay_batch(masks[:300], tl), oracle.sts_replay_batch(model, used, rec, masks[:300], tl))
+            skips = np.nonzero(rec["kind"] == T.REC_MSG_EVENT)[0].astype(np.uint32)
+            assert_same(ctx.replay_removal_batch(skips, target), oracle.sts_removal_batch(model, used, rec, skips, target))
+            for sk in (int(skips[0]), int(skips[len(skips) // 2]), 0xFFFFFFFF):
+                gv, gk = ctx.replay_get_kept(len(rec), sk, target)
+                ov, ok = oracle.sts_removal_kept(model, used, rec, sk, target)
+                assert gv.flags == ov.flags and gv.hash == ov.hash and (gk == ok).all()
+    finally:
+        ctx.close()
+    # DDMin, then the removal of internal deliveries, on the GPU and with the oracle as the replay backend
+    fp = ViolationFingerprint(vv.fingerprint)
+    sts = STSScheduler(SchedulerConfig(model=model), EventTrace(rec, used))
+    mcs_g, d_g, ver_g = stsSchedDDMin(sts, used, fp, speculative_depth=3)
+    mcs_c, d_c, ver_c = stsSchedDDMin(OracleSTS(oracle, model, used, rec, vv.fingerprint), used, fp, speculative_depth=0)
+    assert mcs_g == mcs_c and d_g.consulted == d_c.consulted and ver_g is not None and 0 < len(mcs_g) < len(used)
+    sts.shutdown()
+
+
 def test_wide_models_are_refused_where_they_cannot_run(oracle):
     model = M.raft_model(3, term0=1000)
     ev = events_to_array([start(a) for a in range(3)] + [send(a, M.M_BOOTSTRAP) for a in range(3)])
@@ -93,16 +192,10 @@ def test_wide_models_are_refused_where_they_cannot_run(oracle):
             ctx.random_explore(16, lim, seed_base=1)                    # no interpreter for the wide window
         ctx.model_specialize()
         assert_same(ctx.random_explore(64, lim, seed_base=1), oracle.random_explore(model, ev, 64, seed_base=1, limits=lim))
-        with pytest.raises(_native.DemiError):
-            ctx.random_get_trace(1, lim)                                # no recorded-trace format
         fifo = T.Limits(100, 10, 64, 0, 0, 0)
         fifo.strategy = T.STRATEGY_SRC_DST_FIFO
         with pytest.raises(_native.DemiError):
             ctx.random_explore(16, fifo, seed_base=1)
-        with pytest.raises(_native.DemiError):
-            ctx.dpor_load(ev)
-        with pytest.raises(_native.DemiError):
-            ctx.replay_load(ev, np.zeros(0, dtype=T.REC_EVENT_DTYPE))
         # 16-bit payloads belong to wide models only
         ctx.model_load(M.raft_model(3).to_struct())
         with pytest.raises(_native.DemiError, match="16-bit"):

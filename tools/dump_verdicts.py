@@ -64,13 +64,13 @@ viol = np.nonzero(verdicts["flags"] & T.V_VIOLATION)[0]
 rest = np.setdiff1d(np.arange(args.n), viol)
 picked = [int(k) for k in np.concatenate([viol, rest])[:args.traces]]
 for k in picked:
-    np.ascontiguousarray(record(seed_base + k), dtype=T.REC_EVENT_DTYPE).tofile(os.path.join(args.out, "deliveries_%d.bin" % k))
+    T.rec_events(record(seed_base + k)).tofile(os.path.join(args.out, "deliveries_%d.bin" % k))
 meta = {"format": 1, "config": args.config, "source": source, "seed_base": seed_base, "n": args.n,
         "limits": {"max_messages": int(limits.max_messages), "invariant_check_interval": int(limits.invariant_check_interval),
                    "p_max": int(limits.p_max), "strategy": int(limits.strategy)},
         "violations": int(len(viol)), "recorded": picked,
         "layouts": {"externals.bin": "demi_ext_event[] (8 B)", "seeds.bin": "uint64[]", "verdicts.bin": "demi_verdict[] (16 B: flags u32, fingerprint u32, hash u64)",
-                    "deliveries_<k>.bin": "demi_rec_event[] (12 B) of execution k"},
+                    "deliveries_<k>.bin": "demi_rec_event[] (16 B) of execution k"},
         "jvm_side": "RunnerUtils.fuzz shape: one RandomScheduler + FullyRandom(seed) per execution; with max_executions > 1 on ONE "
                     "instance the reference carries the generator over (RandomScheduler.scala:584, 649-651) and is not comparable"}
 with open(os.path.join(args.out, "meta.json"), "w") as f:
