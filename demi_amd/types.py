@@ -90,8 +90,8 @@ class Verdict(C.Structure):
 
 class RecEvent(C.Structure):
     _fields_ = [("kind", C.c_uint8), ("snd", C.c_uint8), ("rcv", C.c_uint8), ("msg_type", C.c_uint8),
-                ("p0", C.c_uint8), ("p1", C.c_uint8), ("flags", C.c_uint8), ("ext_idx", C.c_uint8),
-                ("id", C.c_uint32)]
+                ("p0", C.c_uint16), ("p1", C.c_uint16), ("flags", C.c_uint8), ("ext_idx", C.c_uint8),
+                ("reserved", C.c_uint16), ("id", C.c_uint32)]
 
 
 class DporParams(C.Structure):
@@ -124,7 +124,7 @@ DPOR_ORDER_ROUNDS = 0       # demi_dpor_order
 DPOR_ORDER_REFERENCE = 1
 
 
-assert C.sizeof(ExtEvent) == 8 and C.sizeof(Verdict) == 16 and C.sizeof(RecEvent) == 12
+assert C.sizeof(ExtEvent) == 8 and C.sizeof(Verdict) == 16 and C.sizeof(RecEvent) == 16
 
 import numpy as np  # noqa: E402
 

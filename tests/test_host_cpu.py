@@ -37,7 +37,7 @@ def test_c_abi_library_exports_every_declared_symbol():
 
 
 def test_struct_layouts_match_the_header():
-    assert C.sizeof(T.ExtEvent) == 8 and C.sizeof(T.Verdict) == 16 and C.sizeof(T.RecEvent) == 12
+    assert C.sizeof(T.ExtEvent) == 8 and C.sizeof(T.Verdict) == 16 and C.sizeof(T.RecEvent) == 16 and T.REC_EVENT_DTYPE.itemsize == 16
     assert C.sizeof(T.Limits) == 36 and T.Limits.strategy.offset == 24 and T.Limits.filter_known_absents.offset == 28 and T.Limits.executions_per_instance.offset == 32
     assert C.sizeof(T.DporParams) == 28 and T.DporParams.prioritize_pending.offset == 24
     assert T.ModelStruct.msg_class.offset == 16 and T.ModelStruct.inv_kind.offset == 56 and C.sizeof(T.ModelStruct) == 80
