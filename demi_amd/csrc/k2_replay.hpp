@@ -91,8 +91,9 @@ __host__ __device__ inline size_t k2_fp_lds_bytes(uint32_t code_len, uint32_t n_
          K2_WAVES * k2_fp_wave_bytes(n_actors, n_fp, counters_in_lds);
 }
 
-__host__ __device__ inline size_t k2_lds_bytes(uint32_t code_len, uint32_t n_ext, uint32_t n_hs, uint32_t n_actors, bool wide = WIDE_TU) {
-  return tables_lds_bytes(code_len, n_ext, n_hs, wide) + K2_WAVES * lane_mem_wave_bytes(n_actors, false, PEND_HOT, wide);
+__host__ __device__ inline size_t k2_lds_bytes(uint32_t code_len, uint32_t n_ext, uint32_t n_hs, uint32_t n_actors, bool wide = WIDE_TU,
+                                               uint32_t hot = PEND_HOT) {
+  return tables_lds_bytes(code_len, n_ext, n_hs, wide) + K2_WAVES * lane_mem_wave_bytes(n_actors, false, hot, wide);
 }
 
 template <int MODE>

@@ -68,8 +68,9 @@ struct K3Args {
 constexpr int K3_WAVES = 4;
 constexpr size_t K3_ANALYSIS_BYTES = DEMI_DPOR_MAX_TRACE * 4 + DEMI_DPOR_MAX_TRACE * 32;   // meta words + ancestor sets
 
-__host__ __device__ inline size_t k3_lds_bytes(uint32_t code_len, uint32_t n_ext, uint32_t n_hs, uint32_t n_actors, bool wide = WIDE_TU) {
-  return tables_lds_bytes(code_len, n_ext, n_hs, wide) + K3_WAVES * (lane_mem_wave_bytes(n_actors, true, PEND_HOT, wide) + K3_ANALYSIS_BYTES);
+__host__ __device__ inline size_t k3_lds_bytes(uint32_t code_len, uint32_t n_ext, uint32_t n_hs, uint32_t n_actors, bool wide = WIDE_TU,
+                                               uint32_t hot = PEND_HOT) {
+  return tables_lds_bytes(code_len, n_ext, n_hs, wide) + K3_WAVES * (lane_mem_wave_bytes(n_actors, true, hot, wide) + K3_ANALYSIS_BYTES);
 }
 
 __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v, uint32_t lane) {
