@@ -172,7 +172,7 @@ __device__ inline uint32_t invariant_code(const DevModel* __restrict__ gm, const
                                           uint32_t A, uint32_t kind, uint32_t fa, uint32_t va, uint32_t fb) {
   (void)gm;
   uint32_t vmask = 0;
-  for (uint32_t i = 0; i < A; i++) vmask |= invariant_hit(st[i * 64], kind, fa, va) << i;
+  for (uint32_t i = 0; i < A; i++) vmask |= invariant_hit_at(st, i, kind, fa, va) << i;     // (also right for a wide table)
   return invariant_from_hits(st, vmask & exists, A, kind, fb);
 }
 

@@ -125,6 +125,21 @@ def test_wide_dpor_parity(oracle):
     rr = dr.explore_native(ev, max_interleavings=300, reference_order=True)
     assert len(rr.interleavings) == 300 and all(a.verdict == b.verdict and a.prefix_len == b.prefix_len for a, b in zip(rr.interleavings, r1.interleavings))
     dg.shutdown(); dn.shutdown(); dr.shutdown()
+    # violations found by the exploration (the invariant reads 16-bit fields): writers whose ids start at 1000
+    from demi_amd.model import Asm, build_model
+    k = 4
+    MSGS = [("Go", T.MSG_EXTERNAL), ("Write", T.MSG_INTERNAL)]
+    h = {(0, "Go"): Asm().ldi16(M.T0, 1000).add(M.T0, M.T0, M.ME).mov(M.T1, 0).send(1, M.T1, M.T0, 0),
+         (0, "Write"): Asm().mov(M.F[0], M.P0).add(M.F[1], M.F[1], 1)}
+    wm = build_model("wide_writers", k + 1, MSGS, h, [[0] * 8] * (k + 1), (T.INV_NEVER, 0, 1001, 0), wide=True)
+    wev = events_to_array([start(a) for a in range(k + 1)] + [send(a, 0) for a in range(1, k + 1)])
+    dw = DPORwHeuristics(SchedulerConfig(model=wm), stopIfViolationFound=False, batch=16, specialize=True)
+    rw = dw.explore(wev, max_interleavings=400)
+    do = DPORwHeuristics(SchedulerConfig(model=wm), stopIfViolationFound=False, batch=16, backend=oracle.dpor_batch)
+    ro = do.explore(wev, max_interleavings=400)
+    assert rw.rounds == ro.rounds and rw.violations == ro.violations and 0 < len(rw.violations) < len(rw.interleavings)
+    assert all(a.verdict == b.verdict and (a.trace == b.trace).all() for a, b in zip(rw.interleavings, ro.interleavings))
+    dw.shutdown()
 
 
 def test_wide_record_replay_minimize(oracle):
