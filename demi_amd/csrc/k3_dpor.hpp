@@ -68,9 +68,10 @@ struct K3Args {
 constexpr int K3_WAVES = 4;
 constexpr size_t K3_ANALYSIS_BYTES = DEMI_DPOR_MAX_TRACE * 4 + DEMI_DPOR_MAX_TRACE * 32;   // meta words + ancestor sets
 
+// (waves: wavefronts per workgroup of the launch, at most K3_WAVES; the kernel reads it from blockDim)
 __host__ __device__ inline size_t k3_lds_bytes(uint32_t code_len, uint32_t n_ext, uint32_t n_hs, uint32_t n_actors, bool wide = WIDE_TU,
-                                               uint32_t hot = PEND_HOT) {
-  return tables_lds_bytes(code_len, n_ext, n_hs, wide) + K3_WAVES * (lane_mem_wave_bytes(n_actors, true, hot, wide) + K3_ANALYSIS_BYTES);
+                                               uint32_t hot = PEND_HOT, uint32_t waves = 4) {
+  return tables_lds_bytes(code_len, n_ext, n_hs, wide) + waves * (lane_mem_wave_bytes(n_actors, true, hot, wide) + K3_ANALYSIS_BYTES);
 }
 
 __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v, uint32_t lane) {
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
                                      args.spill, (size_t)blockIdx.x * blockDim.x + threadIdx.x,
                                      (size_t)gridDim.x * blockDim.x);
   uint64_t* const st = mem.st;
-  unsigned char* const an = wave_base + (size_t)K3_WAVES * lane_mem_wave_bytes(t.A, true) + (size_t)wave * K3_ANALYSIS_BYTES;
+  unsigned char* const an = wave_base + (size_t)(blockDim.x >> 6) * lane_mem_wave_bytes(t.A, true) + (size_t)wave * K3_ANALYSIS_BYTES;
   uint64_t* const s_anc = reinterpret_cast<uint64_t*>(an);
   uint32_t* const s_meta = reinterpret_cast<uint32_t*>(an + DEMI_DPOR_MAX_TRACE * 32);
   const uint32_t A = t.A, NE = t.E, PMAX = args.p_max;
@@ -438,8 +439,12 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
         const uint32_t s_n = (uint32_t)__builtin_amdgcn_readlane((int)n_trace, src);
         const uint32_t s_shared = args.shared_len ? args.shared_len[s_sched]
                                   : (args.items && args.items[s_sched].src != 0xFFFFFFFFu) ? (uint32_t)args.items[s_sched].branch + 1u : 0u;
+#ifdef DEMI_K3_NO_PAIRS      // timing experiments only (DEMI_JIT_DEFINES): the interleavings without their racing-pair analysis
+        const uint32_t total = 0; (void)s_n; (void)s_shared;
+#else
         const uint32_t total = k3_racing_pairs(args.traces + s_sched * DEMI_DPOR_MAX_TRACE, s_n, s_meta, s_anc,
                                                args.pairs + s_sched * (uint64_t)args.max_pairs, args.max_pairs, lane, s_shared);
+#endif
         if ((int)lane == src) { np = total < args.max_pairs ? total : args.max_pairs; pairs_ovf = total > args.max_pairs; }
       }
     }

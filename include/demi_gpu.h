@@ -160,10 +160,15 @@ typedef struct {
  *                    16-bit key;
  *   the message word hashed into demi_verdict.hash is 64 bits: type[4:0] | dst[7:5] | src[11:8] | p0[31:16] | p1[47:32], and
  *                    an actor's final state enters the hash as its two words.
- * A wide model runs only as a compiled table (demi_model_specialize must succeed: there is no interpreter for it) and
- * only through the RandomScheduler entry points with DEMI_STRATEGY_FULLY_RANDOM (demi_random_explore* except
- * demi_random_get_trace); the replay, DPOR and provenance entry points return DEMI_ERR_INVALID_MODEL for it.  The
- * 8-bit layout is untouched by the option (same code, same verdict hashes as before). */
+ *   demi_rec_event   carries the 16-bit payloads (p0, p1 are uint16_t for every model);
+ *   demi_dpor_trace_entry.word  is the LOW half of the 64-bit message word (type, dst, src, p0): enough to build next traces
+ *                    from (only key, word and kind of a prefix entry are read, and the node key hashes the whole word);
+ *                    p1 is not reported there.
+ * A wide model runs only as a compiled table (demi_model_specialize must succeed: there is no interpreter for it; the kernels
+ * are compiled for it at their first launch and a failure is an error, never a fallback): the RandomScheduler entry points
+ * with DEMI_STRATEGY_FULLY_RANDOM incl. demi_random_get_trace, the replay entry points (the pending-set scan variant of the
+ * kernel) and the DPOR entry points.  DEMI_STRATEGY_SRC_DST_FIFO and executions_per_instance > 1 return
+ * DEMI_ERR_INVALID_MODEL for it.  The 8-bit layout is untouched by the option (same code, same verdict hashes as before). */
 #define DEMI_MODEL_WIDE 0x1u
 
 typedef struct {

@@ -1,0 +1,22 @@
+#!/bin/bash
+# k3_dpor residency: LDS-resident pending slots x waves per workgroup (ROUNDS order, config 3); parity first
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd $R
+timeout 900 python -m pytest tests/test_k3_gpu.py tests/test_wide_gpu.py -x -q --timeout 600 2>&1 | tail -4
+run() {
+  timeout 300 python bench.py --workload dpor --dpor-order rounds --no-cpu-baseline 2> gpurun_out/r3_k3d.err | python -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+for k, v in d['orders'].items(): print('$1', k, round(v['value']), 'sec %.4f' % v['seconds'], 'il', v['interleavings'], 'launches', v['launches'], 'kernel_ms %.1f' % v['kernel_ms_total'], v['sequence_digest'])
+"
+  grep "k3 launch" gpurun_out/r3_k3d.err | sort | uniq -c | sort -rn | head -2
+}
+export DEMI_K3_VERBOSE=1
+run default
+DEMI_JIT_K3_HOT=32 DEMI_K3_WAVES=4 run hot32w4
+DEMI_JIT_K3_HOT=16 DEMI_K3_WAVES=2 run hot16w2
+DEMI_JIT_K3_HOT=8 DEMI_K3_WAVES=2 run hot8w2
+DEMI_JIT_K3_HOT=8 DEMI_K3_WAVES=4 run hot8w4
+DEMI_JIT_K3_HOT=4 DEMI_K3_WAVES=1 run hot4w1
+DEMI_JIT_K3_HOT=12 DEMI_K3_WAVES=1 run hot12w1
+DEMI_JIT_K3_HOT=24 DEMI_K3_WAVES=2 run hot24w2
