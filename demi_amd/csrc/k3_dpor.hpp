@@ -63,6 +63,7 @@ struct K3Args {
   // round's slots of the same arena.
   const DporItem* items;             // [n] or null (then prefixes / prefix_len / shared_len are used)
   const demi_dpor_trace_entry* arena;
+  unsigned long long* phase_out;     // -DDEMI_K3_PHASES builds only (tools/k3_phases.sh): [waves][16] cycle totals per phase
 };
 
 constexpr int K3_WAVES = 4;
@@ -114,56 +115,73 @@ __device__ inline uint32_t k3_racing_pairs(const demi_dpor_trace_entry* __restri
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
 
-  uint32_t cnt[4] = {0, 0, 0, 0}, off[4] = {0, 0, 0, 0};
+  // Which pairs race is a matter of 256-bit masks, not of a loop over `earlier`: later = l races with every message delivery
+  // e < l that has l's receiver and quiescent period (isCoEnabeled, :1091-1110) and is not an ancestor of l, i.e.
+  //   race(l) = SAME[class(l)] & ~anc(l) & below(l),     class = (receiver, quiescent period, is-a-delivery) of the meta word.
+  // SAME[c] is one ballot per 64 events and distinct class (a handful: actors x quiescent periods), taken once for all the
+  // lanes of that class.  The lane then owns its set of racing `earlier`s as bits, counts them with popcounts (the offsets of
+  // the sequential order - later ascending, earlier ascending - are a wave prefix sum per group of 64 laters, groups in
+  // order) and walks only ITS set bits to compute the branch points (analyze_dep, :1043-1077: the highest common bit of two
+  // ancestor sets) and write the pairs.  The loop over every (later group, earlier) with its dependent LDS read per step that
+  // this replaces took 60-75 % of k3_dpor (tools/k3_phases.sh).
+  constexpr uint32_t CLS = 0xFFF00u;        // quiescent period | receiver | MSG
+  uint32_t mg[4];
+#pragma unroll
+  for (uint32_t k = 0; k < 4; k++) mg[k] = (k * 64 + lane < n) ? s_meta[k * 64 + lane] : 0u;
   uint32_t total = 0;
 #pragma unroll
-  for (int pass = 0; pass < 2; pass++) {
+  for (uint32_t g = 0; g < 4; g++) {
+    if (g * 64 >= n || g * 64 + 64 <= shared) continue;        // later < shared: reported by the producing interleaving
+    const uint32_t l = g * 64 + lane;
+    const bool lv = l < n && l >= shared && (mg[g] & MSG) != 0;
+    const uint32_t cls = mg[g] & CLS;
+    uint64_t same[4] = {0, 0, 0, 0};
+    uint64_t todo = __ballot(lv);
+    while (todo) {
+      const int lead = __builtin_ctzll(todo);
+      const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cls, lead);
+      const bool mine = lv && cls == c;
+      uint64_t m[4];
 #pragma unroll
-    for (uint32_t g = 0; g < 4; g++) {
-      if (g * 64 >= n || g * 64 + 64 <= shared) continue;      // later < shared: reported by the producing interleaving
-      const uint32_t l = g * 64 + lane;
-      const bool lv = l < n && l >= shared;
-      const uint32_t ml = lv ? s_meta[l] : 0u;
-      const bool lmsg = (ml & MSG) != 0;
-      const uint64_t l0 = lv ? s_anc[l * 4 + 0] : 0ull, l1 = lv ? s_anc[l * 4 + 1] : 0ull,
-                     l2 = lv ? s_anc[l * 4 + 2] : 0ull, l3 = lv ? s_anc[l * 4 + 3] : 0ull;
-      const uint32_t e_end = (g * 64 + 64 < n) ? g * 64 + 64 : n;
-      uint32_t c = 0;
-      for (uint32_t e = 1; e < e_end; e++) {
-        const uint32_t me = s_meta[e];
-        if (!(me & MSG)) continue;
-        // isCoEnabeled (:1091-1110): same receiver, same quiescent period, no causal path earlier -> later
-        const uint64_t sel = (e < 64) ? l0 : (e < 128) ? l1 : (e < 192) ? l2 : l3;
-        const bool race = lmsg && e < l && (((me ^ ml) & 0x7FF00u) == 0) && !((sel >> (e & 63)) & 1ull);
-        if (pass == 0) {
-          c += race ? 1u : 0u;
-        } else if (__ballot(race) != 0) {
-          // analyze_dep (:1043-1077): branch point = deepest common ancestor of the two producers
-          const uint64_t x3 = l3 & s_anc[e * 4 + 3], x2 = l2 & s_anc[e * 4 + 2], x1 = l1 & s_anc[e * 4 + 1],
-                         x0 = l0 & s_anc[e * 4 + 0];
-          if (race) {
-            const uint32_t branch = x3 ? 255u - (uint32_t)__builtin_clzll(x3) : x2 ? 191u - (uint32_t)__builtin_clzll(x2)
-                                  : x1 ? 127u - (uint32_t)__builtin_clzll(x1) : 63u - (uint32_t)__builtin_clzll(x0 | 1ull);
-            const uint32_t idx = off[g] + c;
-            if (idx < max_pairs) {
-              demi_dpor_pair p; p.branch = (uint8_t)branch; p.later = (uint8_t)l; p.earlier = (uint8_t)e; p.pad = 0;
-              po[idx] = p;
-            }
-            c++;
-          }
-        }
-      }
-      if (pass == 0) cnt[g] = c;
+      for (uint32_t k = 0; k < 4; k++) m[k] = (k <= g) ? __ballot((mg[k] & CLS) == c) : 0ull;     // (c has the MSG bit: deliveries only)
+      if (mine) { same[0] = m[0]; same[1] = m[1]; same[2] = m[2]; same[3] = m[3]; }
+      todo &= ~__ballot(mine);
     }
-    if (pass == 0) {
-      uint32_t base = 0;
+    uint64_t la[4] = {0, 0, 0, 0}, r[4] = {0, 0, 0, 0};
+    uint32_t cnt = 0;
+    if (lv) {
 #pragma unroll
-      for (uint32_t g = 0; g < 4; g++) {
-        const uint32_t incl = wave_inclusive_sum(cnt[g], lane);
-        off[g] = base + incl - cnt[g];
-        base += __shfl(incl, 63);
+      for (uint32_t k = 0; k < 4; k++) {
+        la[k] = s_anc[l * 4 + k];
+        const uint64_t below = (k < g) ? ~0ull : (k == g) ? ((1ull << lane) - 1ull) : 0ull;      // e < l
+        r[k] = same[k] & ~la[k] & below;
+        cnt += (uint32_t)__popcll(r[k]);
       }
-      total = base;
+    }
+    const uint32_t incl = wave_inclusive_sum(cnt, lane);
+    uint32_t idx = total + incl - cnt;
+    total += __shfl(incl, 63);
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) {
+      if (k > g) continue;
+      uint64_t bits = r[k];
+      while (bits) {
+        const uint32_t e = k * 64 + (uint32_t)__builtin_ctzll(bits);
+        bits &= bits - 1;
+        if (idx < max_pairs) {
+          // analyze_dep (:1043-1077): branch point = deepest common ancestor of the two producers (ancestors of e are below e)
+          uint32_t branch = 0;
+#pragma unroll
+          for (int q = 3; q >= 0; q--) {
+            if ((uint32_t)q > k) continue;
+            const uint64_t x = la[q] & s_anc[e * 4 + q];
+            if (x && branch == 0) branch = (uint32_t)q * 64u + 63u - (uint32_t)__builtin_clzll(x);
+          }
+          demi_dpor_pair p; p.branch = (uint8_t)branch; p.later = (uint8_t)l; p.earlier = (uint8_t)e; p.pad = 0;
+          po[idx] = p;
+        }
+        idx++;
+      }
     }
   }
   return total;
@@ -202,6 +220,14 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
   uint64_t b_next = 0, b_end = 0;
   bool exhausted = false;
 
+#ifdef DEMI_K3_PHASES
+  uint64_t ph_t[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ph_iters = 0, ph_active = 0;
+#define K3_NOW(V) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(V) : : "memory")
+#define K3_MARK(I) do { uint64_t now_; K3_NOW(now_); ph_t[I] += now_ - ph_last; ph_last = now_; } while (0)
+  uint64_t ph_last; K3_NOW(ph_last);
+#else
+#define K3_MARK(I) do {} while (0)
+#endif
 #define K3_ABORT (DEMI_OVF_ANY | DEMI_V_TRACE_OVF | DEMI_V_SELFMSG)
 #define TIMER_BIT(RCV, TYPE) (1u << ((RCV) * DEMI_MAX_TIMER_TYPES + (t.meta[(TYPE)] >> 8)))
 
@@ -264,6 +290,10 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
       }
       if (__ballot(active) == 0) break;
     }
+    K3_MARK(0);
+#ifdef DEMI_K3_PHASES
+    ph_iters++; ph_active += __popcll(__ballot(active));
+#endif
 
     word_t w = 0;
     bool deliver = false, finish = false;
@@ -291,6 +321,7 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
         trace_push(DPOR_ROOT_KEY, 0, 0, 0, 0);   // currentTrace += getRootEvent (:336-343)
         parent = 0; parent_depth = 0; cur_root = 0;
         run_external();
+        K3_MARK(1);
       }
       if (flags & K3_ABORT) {
         finish = true;
@@ -322,6 +353,7 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
             }
           } while (args.prioritize && chosen < 0 && !chose_marker);
         }
+        K3_MARK(2);
         if (!none && chosen < 0 && !chose_marker) {
           // getPendingEvent (:452-472), iteration order pinned: (snd, rcv) ascending, FIFO inside
           uint32_t best = 0xFFFFFFFFu;
@@ -334,6 +366,7 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
           if (chosen < 0 && marker_pending) chose_marker = true;
           if (chosen < 0 && !chose_marker) none = true;
         }
+        K3_MARK(3);
         if (chose_marker) {                              // awaitQuiescenceUpdate (:256-266)
           marker_pending = false; awaiting = true; next_qperiod = marker_ext + 1; qmarker_ext = marker_ext;
         } else if (!none) {
@@ -379,8 +412,10 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
       }
     }
 
+    K3_MARK(4);
     uint32_t nfx = 0;
     if (deliver) nfx = DEMI_VM_RUN(t, mem, w, flags, app_rng);
+    K3_MARK(5);
     if (deliver) {
       const uint32_t me = w_dst(w);
       for (uint32_t k = 0; k < nfx && !(flags & DEMI_OVF_ANY); k++) {
@@ -422,6 +457,7 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
       }
     }
 
+    K3_MARK(6);
     // ---------------------------------------------------------- finished interleavings
     const bool fin = active && finish;
     const bool aborted = (flags & K3_ABORT) != 0;
@@ -448,6 +484,7 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
         if ((int)lane == src) { np = total < args.max_pairs ? total : args.max_pairs; pairs_ovf = total > args.max_pairs; }
       }
     }
+    K3_MARK(7);
     if (fin) {
       uint32_t viol = 0;
       if (!aborted) {   // checkInvariant (:394-418)
@@ -471,7 +508,15 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
       *reinterpret_cast<uint4*>(&args.out[sched]) = v;
       active = false;
     }
+    K3_MARK(8);
   }
+#ifdef DEMI_K3_PHASES
+  if (lane == 0 && args.phase_out) {
+    unsigned long long* o = args.phase_out + ((size_t)blockIdx.x * (blockDim.x >> 6) + wave) * 16;
+    for (int i = 0; i < 9; i++) o[i] = ph_t[i];
+    o[14] = ph_iters; o[15] = ph_active;
+  }
+#endif
 #undef K3_ABORT
 #undef TIMER_BIT
 }
