@@ -164,23 +164,38 @@ __device__ inline uint32_t k3_racing_pairs(const demi_dpor_trace_entry* __restri
 #pragma unroll
     for (uint32_t k = 0; k < 4; k++) {
       if (k > g) continue;
+      // two earliers per step: the ancestor sets of both are requested from LDS before either is used (one wave, nothing
+      // else to hide the latency behind)
       uint64_t bits = r[k];
       while (bits) {
-        const uint32_t e = k * 64 + (uint32_t)__builtin_ctzll(bits);
+        const uint32_t e0 = k * 64 + (uint32_t)__builtin_ctzll(bits);
         bits &= bits - 1;
-        if (idx < max_pairs) {
-          // analyze_dep (:1043-1077): branch point = deepest common ancestor of the two producers (ancestors of e are below e)
-          uint32_t branch = 0;
+        const bool two = bits != 0;
+        const uint32_t e1 = two ? k * 64 + (uint32_t)__builtin_ctzll(bits) : e0;
+        bits &= bits - 1;                       // (0 & anything stays 0)
+        uint64_t x0[4], x1[4];
 #pragma unroll
-          for (int q = 3; q >= 0; q--) {
-            if ((uint32_t)q > k) continue;
-            const uint64_t x = la[q] & s_anc[e * 4 + q];
-            if (x && branch == 0) branch = (uint32_t)q * 64u + 63u - (uint32_t)__builtin_clzll(x);
-          }
-          demi_dpor_pair p; p.branch = (uint8_t)branch; p.later = (uint8_t)l; p.earlier = (uint8_t)e; p.pad = 0;
+        for (uint32_t q = 0; q < 4; q++) {
+          x0[q] = (q <= k) ? (la[q] & s_anc[e0 * 4 + q]) : 0ull;
+          x1[q] = (q <= k) ? (la[q] & s_anc[e1 * 4 + q]) : 0ull;
+        }
+        // analyze_dep (:1043-1077): branch point = deepest common ancestor of the two producers (ancestors of e are below e)
+        const uint32_t b0 = x0[3] ? 255u - (uint32_t)__builtin_clzll(x0[3]) : x0[2] ? 191u - (uint32_t)__builtin_clzll(x0[2])
+                          : x0[1] ? 127u - (uint32_t)__builtin_clzll(x0[1]) : 63u - (uint32_t)__builtin_clzll(x0[0] | 1ull);
+        const uint32_t b1 = x1[3] ? 255u - (uint32_t)__builtin_clzll(x1[3]) : x1[2] ? 191u - (uint32_t)__builtin_clzll(x1[2])
+                          : x1[1] ? 127u - (uint32_t)__builtin_clzll(x1[1]) : 63u - (uint32_t)__builtin_clzll(x1[0] | 1ull);
+        if (idx < max_pairs) {
+          demi_dpor_pair p; p.branch = (uint8_t)b0; p.later = (uint8_t)l; p.earlier = (uint8_t)e0; p.pad = 0;
           po[idx] = p;
         }
         idx++;
+        if (two) {
+          if (idx < max_pairs) {
+            demi_dpor_pair p; p.branch = (uint8_t)b1; p.later = (uint8_t)l; p.earlier = (uint8_t)e1; p.pad = 0;
+            po[idx] = p;
+          }
+          idx++;
+        }
       }
     }
   }
@@ -243,6 +258,7 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
     n_pend++;
   };
   // (a wide table's trace entry reports the low half of the 64-bit message word: type, dst, src, p0 - include/demi_gpu.h)
+  uint32_t pushed_depth = 0;
   auto trace_push = [&](uint64_t key, word_t word, uint32_t par, uint32_t qp, uint32_t kind) -> int {
     if (n_trace >= DEMI_DPOR_MAX_TRACE) { flags |= DEMI_V_TRACE_OVF; return -1; }
     demi_dpor_trace_entry e;
@@ -250,6 +266,7 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
     e.depth = (uint8_t)(n_trace == 0 ? 0 : tr[par].depth + 1);
     e.kind = (uint8_t)kind;
     tr[n_trace] = e;
+    pushed_depth = e.depth;                    // (the caller's setParentEvent: not read back from the trace)
     return (int)n_trace++;
   };
   // runExternal (:684-721)
@@ -342,10 +359,21 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
             if (want.kind == 2) {
               if (marker_pending && want.key == dpor_marker_key(marker_ext)) chose_marker = true;
             } else {
+              // first which pending slots hold this message word (a branch-free pass: its LDS / scratch reads do not wait for
+              // one another), then the identity test - producer's key, FIFO order - for those few
               uint32_t best_seq = 0xFFFFFFFFu;
-              for (uint32_t k = 0; k < n_pend && !((blocked >> w_dst(want.word)) & 1u); k++) {
+              uint64_t hit0 = 0, hit1 = 0;
+              if (!((blocked >> w_dst(want.word)) & 1u)) {
+#pragma unroll 4
+                for (uint32_t k = 0; k < n_pend; k++) {
+                  const uint64_t h = ((uint32_t)pend_load(mem, k) == want.word) ? 1ull : 0ull;   // (the entry holds the word's low half)
+                  if (k < 64) hit0 |= h << k; else hit1 |= h << (k - 64);
+                }
+              }
+              while (hit0 | hit1) {
+                const uint32_t k = hit0 ? (uint32_t)__builtin_ctzll(hit0) : 64u + (uint32_t)__builtin_ctzll(hit1);
+                if (hit0) hit0 &= hit0 - 1; else hit1 &= hit1 - 1;
                 const word_t cw = pend_load(mem, k);
-                if ((uint32_t)cw != want.word) continue;         // (the entry holds the word's low half; the key decides)
                 const uint32_t aux = aux_load(mem, k);
                 const uint64_t key = (tr[aux & 0xFF].key ^ (uint64_t)cw) * DPOR_PRIME;
                 if (key == want.key && (aux >> 16) < best_seq) { best_seq = aux >> 16; chosen = (int)k; }
@@ -357,11 +385,13 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
         if (!none && chosen < 0 && !chose_marker) {
           // getPendingEvent (:452-472), iteration order pinned: (snd, rcv) ascending, FIFO inside
           uint32_t best = 0xFFFFFFFFu;
-          for (uint32_t k = 0; k < n_pend; k++) {
+#pragma unroll 4
+          for (uint32_t k = 0; k < n_pend; k++) {                // (branch-free body: the reads of consecutive slots overlap)
             const word_t pw = pend_load(mem, k);
-            if ((blocked >> w_dst(pw)) & 1u) continue;           // !(blockedActors contains k._2) (:455)
             const uint32_t ord = (((w_src(pw) << 4) | w_dst(pw)) << 16) | (aux_load(mem, k) >> 16);
-            if (ord < best) { best = ord; chosen = (int)k; }
+            const bool ok = !((blocked >> w_dst(pw)) & 1u) && ord < best;      // !(blockedActors contains k._2) (:455)
+            best = ok ? ord : best;
+            chosen = ok ? (int)k : chosen;
           }
           if (chosen < 0 && marker_pending) chose_marker = true;
           if (chosen < 0 && !chose_marker) none = true;
@@ -385,7 +415,7 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
             const int ti = trace_push(key, pw, par, (aux >> 8) & 0xFF, 1);
             if (ti < 0) finish = true;
             else {
-              parent = (uint32_t)ti; parent_depth = tr[ti].depth;   // setParentEvent
+              parent = (uint32_t)ti; parent_depth = pushed_depth;   // setParentEvent
               w = pw; deliver = true;
               deliveries++;
               hash_step(hash, w);
@@ -402,7 +432,7 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
             const int ti = trace_push(dpor_marker_key(qmarker_ext), 0, cur_root, qperiod, 2);
             if (ti < 0) finish = true;
             else {
-              cur_root = (uint32_t)ti; parent = (uint32_t)ti; parent_depth = tr[ti].depth;
+              cur_root = (uint32_t)ti; parent = (uint32_t)ti; parent_depth = pushed_depth;
               run_external();
             }
           } else {
