@@ -307,10 +307,31 @@ def bench_ddmin(ctx_device, cpu_baseline=True, n=1 << 20):
     stsSchedDDMin(sts, used, fp, speculative_depth=4)            # (compilation, buffers)
     t = time.perf_counter()
     mcs, dd, _ver = stsSchedDDMin(sts, used, fp, speculative_depth=4)
-    out["ddmin_end_to_end"] = {"seconds": time.perf_counter() - t, "externals": int(len(used)), "mcs_len": len(mcs),
-                               "oracle_consultations": len(dd.consulted), "launches": len(dd.batches),
-                               "replays_launched": int(dd.speculative_replays)}
+    out["ddmin_end_to_end_python_mirror"] = {"seconds": time.perf_counter() - t, "externals": int(len(used)), "mcs_len": len(mcs),
+                                             "oracle_consultations": len(dd.consulted), "launches": len(dd.batches),
+                                             "replays_launched": int(dd.speculative_replays),
+                                             "note": "the same search with DDMin's decision tree enumerated by demi_amd/minification.py"}
     sts.shutdown()
+    # the same minimization in ONE call of the library (demi_ddmin: atoms, ddmin2, the speculative frontier and the K2 launches
+    # natively - what a JVM host binds); the best of a few launch budgets, each timed as the best of 5
+    ctx = _native.Context(ctx_device)
+    ctx.model_load(model.to_struct())
+    ctx.model_specialize()
+    ctx.replay_load(used, rec)
+    best = None
+    for budget in (256, 1024, 4096):
+        par = T.DdminParams(0, budget, 1, 1)
+        ctx.ddmin(target, par)
+        for _ in range(5):
+            t = time.perf_counter()
+            mcs_n, cons_n, batches_n, st = ctx.ddmin(target, par)
+            dt = time.perf_counter() - t
+            if best is None or dt < best["seconds"]:
+                best = {"seconds": dt, "externals": int(len(used)), "mcs_len": len(mcs_n), "oracle_consultations": int(st.consultations),
+                        "launches": int(st.launches), "replays_launched": int(st.replays), "candidates_per_launch": batches_n,
+                        "max_candidates": budget, "same_mcs_as_the_python_mirror": tuple(mcs_n) == tuple(mcs)}
+    out["ddmin_end_to_end"] = best
+    ctx.close()
     # RunnerUtils.randomDDMin (RunnerUtils.scala:601-623): DDMin whose oracle is the RandomScheduler itself, R = 100 random
     # interleavings per candidate: every consultation is one K1 launch of R executions
     try:
@@ -371,6 +392,17 @@ def bench_ddmin(ctx_device, cpu_baseline=True, n=1 << 20):
             t = time.perf_counter()
             m2, d2, _ = stsSchedDDMin(_OracleSTS(threads), used, fp, speculative_depth=depth_)
             e2e[name] = {"seconds": time.perf_counter() - t, "mcs_len": len(m2), "same_mcs_as_gpu": list(m2) == list(mcs)}
+        # and the library's own DDMin loop (demi_amd/csrc/ddmin_host.hpp) around the oracle's replays, one at a time on one core
+        try:
+            ts = []
+            for _ in range(5):
+                t = time.perf_counter()
+                m3, _c3, _b3, st3 = O.ddmin(model, used, rec, target, T.DdminParams(1, 0, 1, 1), n_threads=1)
+                ts.append(time.perf_counter() - t)
+            e2e["native_loop_one_core"] = {"seconds": min(ts), "mcs_len": len(m3), "same_mcs_as_gpu": list(m3) == list(mcs),
+                                           "replays": int(st3.replays)}
+        except Exception as e:
+            e2e["native_loop_one_core"] = {"error": "%s: %s" % (type(e).__name__, e)}
         out["cpu_baseline"] = {"value": len(sample) * reps / dt, "unit": "replays/s", "cores": cores, "kind": "port",
                                "ddmin_end_to_end": e2e,
                                "sample": "first %d of the same candidate masks x %d passes, oracle/demi_oracle.c on %d pthreads" % (len(sample), reps, cores),

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libdemi_gpu.so")
 EXPORTS = ["demi_ctx_create", "demi_ctx_destroy", "demi_last_error", "demi_version", "demi_model_load",
            "demi_trace_load", "demi_random_explore", "demi_random_explore_dev", "demi_random_get_trace", "demi_collect_violations_dev",
            "demi_replay_load", "demi_replay_batch", "demi_replay_batch_dev", "demi_dpor_load", "demi_dpor_batch", "demi_dpor_explore", "demi_random_explore_violations", "demi_random_get_trace_carried",
-           "demi_replay_removal_batch", "demi_replay_get_kept", "demi_replay_recorded_len", "demi_model_specialize", "demi_model_is_specialized", "demi_model_code_id",
+           "demi_replay_removal_batch", "demi_replay_get_kept", "demi_replay_recorded_len", "demi_ddmin", "demi_model_specialize", "demi_model_is_specialized", "demi_model_code_id",
            "demi_specialize_check", "demi_specialize_source", "demi_specialize_source_k1", "demi_provenance_prune", "demi_device_probe", "demi_device_probe_mix", "demi_calib_rw", "demi_random_explore_flagged", "demi_collect_flagged_dev",
            "demi_comm_unique_id", "demi_comm_create", "demi_comm_create_host", "demi_comm_destroy", "demi_comm_rank",
            "demi_comm_allgather_dev", "demi_random_explore_sharded", "demi_replay_batch_sharded"]
@@ -57,6 +57,9 @@ def lib():
     L.demi_model_code_id.restype = C.c_uint64
     L.demi_specialize_check.argtypes = [C.POINTER(T.ModelStruct), C.c_char_p, C.c_size_t]
     L.demi_specialize_check.restype = C.c_long
+    L.demi_ddmin.argtypes = [C.c_void_p, C.POINTER(T.Limits), C.POINTER(T.DdminParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                             C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(T.DdminStats)]
+    L.demi_ddmin.restype = C.c_int
     L.demi_specialize_source.argtypes = [C.POINTER(T.ModelStruct), C.c_char_p, C.c_size_t]
     L.demi_specialize_source.restype = C.c_long
     L.demi_specialize_source_k1.argtypes = [C.POINTER(T.ModelStruct), C.c_char_p, C.c_size_t]
@@ -252,6 +255,23 @@ class Context:
         self._check(lib().demi_replay_removal_batch(self._h, mp, skips.ctypes.data, len(skips), C.byref(limits),
                                                     out.ctypes.data))
         return out
+
+    def ddmin(self, limits, params=None, conjoined=None, cap=4096):
+        """RunnerUtils.stsSchedDDMin on the loaded replay, natively (demi_ddmin): (mcs indices, [(candidate indices, passes)] in
+        consultation order, candidates per launch, stats)."""
+        import numpy as np
+        params = params or T.DdminParams()
+        mcs = np.zeros(4, dtype=np.uint64)
+        consulted = np.zeros((cap, 4), dtype=np.uint64)
+        passed = np.zeros(cap, dtype=np.uint8)
+        batches = np.zeros(cap, dtype=np.uint32)
+        st = T.DdminStats()
+        conj = np.ascontiguousarray(conjoined, dtype=np.uint8) if conjoined is not None else None
+        self._check(lib().demi_ddmin(self._h, C.byref(limits), C.byref(params), conj.ctypes.data if conj is not None else None,
+                                     mcs.ctypes.data, consulted.ctypes.data, passed.ctypes.data, cap, batches.ctypes.data, cap,
+                                     C.byref(st)))
+        return T.mask_to_events(mcs), [(T.mask_to_events(consulted[i]), bool(passed[i])) for i in range(min(cap, st.consultations))], \
+            [int(b) for b in batches[:st.launches]], st
 
     def replay_get_kept(self, n_rec, skip, limits, mask=None):
         """(Verdict, uint8[n_rec]) of one candidate: which recorded events make up its executed trace."""

@@ -252,7 +252,9 @@ class STSScheduler:
     original_trace.original_externals."""
 
     def __init__(self, schedulerConfig: SchedulerConfig, original_trace: EventTrace, allowPeek: bool = False,
-                 device: int = 0, p_max: int = 64):
+                 device: int = 0, p_max: int = 64, specialize: bool = False):
+        """specialize: compile the model's table to native code first (demi_model_specialize): a minimization consults the
+        oracle in many small launches whose time is the serial chain of one replay, which the compiled handlers shorten."""
         if allowPeek:
             raise NotImplementedError("IntervalPeek is not on the GPU path (allowPeek=false, RunnerUtils.scala:332)")
         if schedulerConfig.model is None or schedulerConfig.model.inv_kind == T.INV_NONE:
@@ -265,6 +267,11 @@ class STSScheduler:
         self._ctx.model_load(schedulerConfig.model.to_struct())
         if getattr(schedulerConfig.model, "wide", False):
             self._ctx.model_specialize()         # a wide table (DEMI_MODEL_WIDE) runs only as compiled code
+        elif specialize:
+            try:
+                self._ctx.model_specialize()
+            except _native.DemiError:
+                pass                             # no run-time compiler here: the table interpreter is used
         self._ctx.replay_load(original_trace.original_externals, original_trace.events)
 
     def getName(self) -> str:

@@ -94,6 +94,20 @@ class RecEvent(C.Structure):
                 ("reserved", C.c_uint16), ("id", C.c_uint32)]
 
 
+class DdminParams(C.Structure):
+    """demi_ddmin_params"""
+    _fields_ = [("depth", C.c_uint32), ("max_candidates", C.c_uint32), ("check_unmodified", C.c_uint32), ("verify_mcs", C.c_uint32)]
+
+    def __init__(self, depth=0, max_candidates=0, check_unmodified=1, verify_mcs=1):
+        super().__init__(depth, max_candidates, check_unmodified, verify_mcs)
+
+
+class DdminStats(C.Structure):
+    """demi_ddmin_stats"""
+    _fields_ = [("consultations", C.c_uint32), ("launches", C.c_uint32), ("mcs_len", C.c_uint32), ("verified", C.c_uint32),
+                ("replays", C.c_uint64)]
+
+
 class DporParams(C.Structure):
     _fields_ = [("depth_bound", C.c_uint32), ("max_messages", C.c_uint32), ("looking_for_valid", C.c_uint32),
                 ("looking_for", C.c_uint32), ("p_max", C.c_uint32), ("max_pairs", C.c_uint32),
@@ -165,3 +179,9 @@ def verdict_deliveries(flags):
 
 def verdict_trace_idx(flags):
     return (flags >> 8) & 0xFF
+
+
+def mask_to_events(mask) -> tuple:
+    """The external-event indices of a 256-bit candidate mask (uint64[4])."""
+    bits = np.unpackbits(np.ascontiguousarray(mask, dtype=np.uint64).view(np.uint8), bitorder="little")
+    return tuple(int(i) for i in np.flatnonzero(bits))

@@ -335,6 +335,38 @@ int demi_replay_get_kept(demi_ctx* ctx, const uint64_t* mask /* [4] or NULL */, 
  * out_kept needs.  Lets a binding check its buffer before the call. */
 uint32_t demi_replay_recorded_len(const demi_ctx* ctx);
 
+/* ---------------------------------------------------------- DDMin over the replay oracle, in one call
+ * Replaces RunnerUtils.stsSchedDDMin (RunnerUtils.scala:642-707): DDMin.minimize / ddmin2 (minification/DeltaDebugging.scala:27-109)
+ * over the EventDag of the loaded execution's external events (demi_replay_load), WaitQuiescence events stripped (:680-684), atomic
+ * events as EventDag.get_atomic_events builds them (minification/Util.scala:197-265: a Kill with the Start of its actor, an
+ * UnPartition with its Partition, pairs given in `conjoined`, singletons), MinificationUtil.split_list (:9-37), with
+ * STSScheduler.test as the oracle (demi_replay_batch).  ddmin2 consults its oracle once per node of a sequential decision
+ * tree; here the candidates the next levels could ask for, whatever the outcomes, are replayed together in one launch, and
+ * the real path walks through the verdicts - the MCS and the sequence of consultations are those of the sequential algorithm.
+ * A candidate whose replay exceeds limits->p_max is replayed with the largest pending set; DEMI_ERR_CAPACITY if it still does
+ * not fit (never "does not reproduce").  DEMI_ERR_INVALID_ARG: the unmodified trace does not trigger the violation
+ * (check_unmodified).  DEMI_ERR_INVALID_TRACE: the externals' atoms do not partition them (e.g. a Kill without its Start). */
+typedef struct {
+  uint32_t depth;            /* levels of the decision tree tested ahead per launch; 0 = as many as fit max_candidates */
+  uint32_t max_candidates;   /* per launch when depth = 0 (0 = 4096) */
+  uint32_t check_unmodified; /* DDMin(checkUnmodifed): test the whole trace first */
+  uint32_t verify_mcs;       /* DDMin.verify_mcs: replay the MCS once more */
+} demi_ddmin_params;
+typedef struct {
+  uint32_t consultations;    /* oracle.test calls of the sequential algorithm (MinimizationStats.total_replays) */
+  uint32_t launches;         /* K2 launches, the two optional single replays included */
+  uint32_t mcs_len;
+  uint32_t verified;         /* verify_mcs: the MCS reproduces the violation */
+  uint64_t replays;          /* candidates replayed, speculation included */
+} demi_ddmin_stats;
+/* conjoined (may be NULL): [n_ext] index of the event this one is conjoined with (UnmodifiedEventDag.conjoinAtoms), 255 = none.
+ * out_mcs: the minimal causal sequence as a mask over the external events.  out_consulted [cap][4] / out_passed [cap] (may be
+ * NULL): the candidates in consultation order and whether each "passed" (did not reproduce).  out_batches [batches_cap] (may be
+ * NULL): candidates per launch. */
+int demi_ddmin(demi_ctx* ctx, const demi_limits* limits, const demi_ddmin_params* params, const uint8_t* conjoined,
+               uint64_t out_mcs[4], uint64_t* out_consulted, uint8_t* out_passed, uint32_t cap, uint32_t* out_batches,
+               uint32_t batches_cap, demi_ddmin_stats* stats);
+
 /* ---------------------------------------------------------- K3: DPORwHeuristics interleavings
  * Replaces, per interleaving, DPORwHeuristics.schedule_new_message / event_produced / getMessage /
  * runExternal / notify_quiescence (DPORwHeuristics.scala:421-648, 803-847, 773-801, 684-721,

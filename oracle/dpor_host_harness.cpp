@@ -358,3 +358,26 @@ extern "C" int harness_dpor_explore_resident(const demi_model* m, const demi_ext
   if (table_entries) *table_entries = dev.table.size();
   return rc;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// DDMin in one call (demi_amd/csrc/ddmin_host.hpp, what demi_ddmin runs around K2 launches) over the CPU oracle's
+// STSScheduler replays: the CPU check of that loop against the Python mirror (demi_amd/minification.py).
+#include "../demi_amd/csrc/ddmin_host.hpp"
+
+extern "C" int harness_ddmin(const demi_model* m, const demi_ext_event* ext, uint32_t n_ext, const demi_rec_event* rec, uint32_t n_rec,
+                             const demi_limits* lim, const demi_ddmin_params* par, const uint8_t* conjoined, int n_threads,
+                             uint64_t* out_mcs, uint64_t* out_consulted, uint8_t* out_passed, uint32_t cap, uint32_t* out_batches,
+                             uint32_t batches_cap, demi_ddmin_stats* stats) {
+  std::vector<demi_verdict> vd;
+  auto test = [&](const uint64_t* masks, uint32_t n, uint8_t* reproduced) -> int {
+    vd.resize(n);
+    int rc = orc_sts_replay_batch(m, ext, n_ext, rec, n_rec, masks, n, lim, vd.data(), n_threads);
+    if (rc) return rc;
+    for (uint32_t i = 0; i < n; i++) {
+      if (vd[i].flags & (DEMI_V_PENDING_OVF | DEMI_V_QUEUE_OVF)) return DEMI_ERR_CAPACITY;
+      reproduced[i] = (vd[i].flags & DEMI_V_VIOLATION) ? 1 : 0;
+    }
+    return DEMI_OK;
+  };
+  return demi_host::sts_sched_ddmin(ext, n_ext, conjoined, par, test, out_mcs, out_consulted, out_passed, cap, out_batches, batches_cap, stats);
+}

@@ -298,3 +298,32 @@ def dpor_explore_sharded(model, externals, params, search, world):
         n = int(stats[r].interleavings)
         out.append((verdicts[r, :n], plen[r, :n], rounds[r, :int(stats[r].launches)], vt[r, :vl[r]], stats[r]))
     return out
+
+
+def ddmin(model, original_externals, original_trace, limits, params=None, conjoined=None, n_threads=1, cap=4096):
+    """demi_ddmin's host loop (demi_amd/csrc/ddmin_host.hpp) over this oracle's STSScheduler replays.  Returns (mcs indices,
+    [(candidate indices, passes)] in consultation order, candidates per launch, stats)."""
+    build()
+    H = C.CDLL(os.path.join(_HERE, "_build", "dpor_host_harness.so"))
+    ms = model.to_struct()
+    ev = np.ascontiguousarray(original_externals, dtype=T.EXT_EVENT_DTYPE)
+    rec = T.rec_events(original_trace)
+    params = params or T.DdminParams()
+    mcs = np.zeros(4, dtype=np.uint64)
+    consulted = np.zeros((cap, 4), dtype=np.uint64)
+    passed = np.zeros(cap, dtype=np.uint8)
+    batches = np.zeros(cap, dtype=np.uint32)
+    st = T.DdminStats()
+    conj = None
+    if conjoined is not None:
+        conj = np.ascontiguousarray(conjoined, dtype=np.uint8)
+    H.harness_ddmin.argtypes = [C.POINTER(T.ModelStruct), C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(T.Limits),
+                                C.POINTER(T.DdminParams), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
+                                C.c_void_p, C.c_uint32, C.POINTER(T.DdminStats)]
+    rc = H.harness_ddmin(C.byref(ms), ev.ctypes.data, len(ev), rec.ctypes.data, len(rec), C.byref(limits), C.byref(params),
+                         conj.ctypes.data if conj is not None else None, n_threads, mcs.ctypes.data, consulted.ctypes.data,
+                         passed.ctypes.data, cap, batches.ctypes.data, cap, C.byref(st))
+    if rc:
+        raise RuntimeError("harness_ddmin: %d" % rc)
+    return T.mask_to_events(mcs), [(T.mask_to_events(consulted[i]), bool(passed[i])) for i in range(min(cap, st.consultations))], \
+        [int(b) for b in batches[:st.launches]], st

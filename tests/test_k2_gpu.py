@@ -117,6 +117,31 @@ def test_ddmin_end_to_end_matches_the_oracle_backed_run(gpu_ctx, oracle):
         sts.shutdown()
 
 
+def test_native_ddmin_equals_the_python_mirror_on_the_gpu(gpu_ctx, oracle):
+    """demi_ddmin (the whole stsSchedDDMin in one call: atoms, ddmin2, the speculative frontier, K2 launches) against the Python
+    mirror over the same GPU oracle and against the mirror over the CPU oracle: the same MCS and consultations; with a launch
+    budget the search needs a handful of launches."""
+    from tests.test_minification_cpu import OracleSTS
+    for cfg, skip in ((raft5_config2, 0), (raft5_config2, 3), (raft5_config4, 0)):
+        model, events, lim = cfg()
+        vv, rec, used = record(gpu_ctx, model, events, lim, skip=skip)
+        fp = ViolationFingerprint(vv.fingerprint)
+        target = T.Limits(0, 0, 128, 1, vv.fingerprint, 0)
+        o = OracleSTS(oracle, model, used, rec, vv.fingerprint)
+        o._v = lambda subs, m=model, u=used, r=rec: oracle.sts_replay_batch(
+            m, u, r, np.array([events_to_mask(s) for s in subs], dtype=np.uint64).reshape(-1, 4), target)
+        mcs_c, d_c, _ = stsSchedDDMin(o, used, fp, speculative_depth=0)
+        gpu_ctx.replay_load(used, rec)
+        for par in (T.DdminParams(3, 0, 1, 1), T.DdminParams(0, 1024, 1, 1), T.DdminParams(0, 0, 1, 1)):
+            mcs_n, cons_n, batches_n, st = gpu_ctx.ddmin(target, par)
+            assert tuple(mcs_n) == tuple(mcs_c) and cons_n == [(tuple(c), p) for c, p in d_c.consulted]
+            assert st.verified == 1 and st.consultations == len(d_c.consulted) and st.launches == len(batches_n)
+            if par.depth == 0:
+                assert st.launches <= 4 and st.launches < st.consultations
+        with pytest.raises(Exception, match="does not trigger"):
+            gpu_ctx.ddmin(T.Limits(0, 0, 128, 1, 0x7777, 0), T.DdminParams(0, 0, 1, 1))
+
+
 def test_config4_ddmin_200_external_events(gpu_ctx, oracle):
     """BASELINE config 4 (single GPU leg): 200 external events, DDMin over the STSSched oracle with a
     speculative frontier; every consulted verdict is checked against the oracle."""

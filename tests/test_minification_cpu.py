@@ -394,3 +394,50 @@ def test_filter_known_absent_internals_equals_the_scala_transliteration(oracle, 
             changed += int(v0["hash"] != v.hash or (int(v0["flags"]) ^ int(v.flags)) & T.V_DIVERGED != 0)
             checked += 1
     assert checked > 100 and filtered > 100 and changed > 0
+
+
+def test_native_ddmin_loop_equals_the_python_mirror(oracle):
+    """demi_ddmin's host loop (demi_amd/csrc/ddmin_host.hpp: atoms, split_list, ddmin2, the speculative frontier) over the CPU
+    oracle's replays against SpeculativeDDMin / DDMin of the Python mirror: the same MCS, the same consultations in the same
+    order with the same outcomes, the same candidates per launch at a fixed depth - on raft5 executions and on fault-heavy
+    traces with Kill / Partition atoms - and with a launch budget instead of a depth only the launches differ."""
+    from demi_amd.fuzzer import FuzzerWeights, raft_trace
+    from oracle import oracle_py
+    cases = []
+    model, events, lim = raft5_config2()
+    for skip in (0, 2):
+        cases.append((model,) + _violating_execution(oracle, model, events, lim, skip))
+    fm = M.raft_model(5, election_budget=2)
+    w = FuzzerWeights(kill=0.12, send=0.35, wait_quiescence=0.13, partition=0.25, unpartition=0.15)
+    for seed in (2, 7):
+        ev = events_to_array(raft_trace(5, 90, seed, w, exact=False))
+        v = oracle.random_explore(fm, ev, 2000, seed_base=SEED_BASE, limits=T.Limits(400, 10, 128, 0, 0, 0), n_threads=4)
+        hits = np.nonzero(v["flags"] & T.V_VIOLATION)[0]
+        if not len(hits):
+            continue
+        vv, rec, _ = oracle.random_execute(fm, ev, SEED_BASE + int(hits[0]), T.Limits(400, 10, 128, 0, 0, 0))
+        cases.append((fm, vv, rec, ev[:T.verdict_trace_idx(vv.flags)]))
+    assert len(cases) == 4
+    for model, vv, rec, used in cases:
+        fp = ViolationFingerprint(vv.fingerprint)
+        target = T.Limits(0, 0, 128, 1, vv.fingerprint, 0)
+        sts = OracleSTS(oracle, model, used, rec, vv.fingerprint)
+        sts._v = lambda subs, o=oracle, m=model, u=used, r=rec: o.sts_replay_batch(
+            m, u, r, np.array([events_to_mask(s) for s in subs], dtype=np.uint64).reshape(-1, 4), target)
+        for depth in (1, 3):
+            mcs_p, dd_p, _ = stsSchedDDMin(sts, used, fp, speculative_depth=depth)
+            mcs_n, cons_n, batches_n, st = oracle_py.ddmin(model, used, rec, target, T.DdminParams(depth, 0, 1, 1))
+            assert tuple(mcs_n) == tuple(mcs_p) and st.mcs_len == len(mcs_p) and st.verified == 1
+            assert cons_n == [(tuple(c), p) for c, p in dd_p.consulted] and st.consultations == len(dd_p.consulted)
+            assert batches_n[1:-1] == dd_p.batches and batches_n[0] == batches_n[-1] == 1        # (the check and the verification)
+            assert st.launches == len(dd_p.batches) + 2 and st.replays == dd_p.speculative_replays + 2
+        mcs_s, dd_s, _ = stsSchedDDMin(sts, used, fp, speculative_depth=0)
+        for budget in (16, 4096):
+            mcs_n, cons_n, batches_n, st = oracle_py.ddmin(model, used, rec, target, T.DdminParams(0, budget, 1, 1))
+            assert tuple(mcs_n) == tuple(mcs_s) and cons_n == [(tuple(c), p) for c, p in dd_s.consulted]
+            assert all(b <= max(budget, 4) * 4 for b in batches_n)
+        assert st.launches <= 6                                                                  # a few wide launches instead of one per consultation
+    # an unmodified trace that does not reproduce, and a Kill whose Start is not among the events
+    model, vv, rec, used = cases[0]
+    with pytest.raises(RuntimeError, match="-1"):
+        oracle_py.ddmin(model, used, rec, T.Limits(0, 0, 128, 1, 0x7777, 0), T.DdminParams(2, 0, 1, 1))
