@@ -70,6 +70,7 @@ struct K2Args {
   uint32_t n_fp;            // word ids 0 .. n_fp - 1
   uint8_t* fp_counts;       // K2_FP_HBM: [n_fp][resident lanes] counters
   uint32_t lockstep;        // 1: the lanes of a wave walk the expected events together (k2 lock-step loop below)
+  unsigned long long* phase_out;   // -DDEMI_K2_PHASES builds only (tools/k2_phases.sh): [waves][16] cycle totals per phase
   const uint16_t* exp_hi;   // DEMI_MODEL_WIDE tables only: [n_exp] bits 8..15 of p0 | bits 8..15 of p1 << 8 (the 8-byte expected
                             // event holds the low bytes)
 };
@@ -152,7 +153,12 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
       const uint32_t one = 1u << (8u * (uint32_t)(ad & 3u));
       if (up) atomicAdd(w32, one); else atomicSub(w32, one);
     } else {
-      *c = (uint8_t)(*c + (up ? 1 : -1));
+      // (LDS: the same trick - an add on the dword that holds four lanes' counters, without a return value, instead of a byte
+      // read-modify-write whose read the lane would have to wait for)
+      const uint32_t ad = (uint32_t)reinterpret_cast<uintptr_t>(c);
+      uint32_t* w32 = reinterpret_cast<uint32_t*>(c - (ad & 3u));
+      const uint32_t one = 1u << (8u * (ad & 3u));
+      (void)__hip_atomic_fetch_add(w32, up ? one : (0u - one), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
   };
   // the word id of a message produced at run time (FP): a probe or two of the workgroup's hash
@@ -234,6 +240,14 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
   // sequence of operations is exactly the one of the per-lane loop (same verdicts, kept marks and flags; the GPU suite runs
   // every K2 test in all three counter modes on it).  Measured on the ddmin record: 2^20 candidates 61.5 -> 10.8 ms,
   // 65 536: 7.2 -> 1.8 ms, 4 096: 1.33 -> 1.20 ms, 256: 0.81 -> 0.72 ms.
+#ifdef DEMI_K2_PHASES
+  uint64_t ph_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_ev = 0;
+#define K2_NOW(V) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(V) : : "memory")
+#define K2_MARK(I) do { uint64_t now_; K2_NOW(now_); ph_t[I] += now_ - ph_last; ph_last = now_; } while (0)
+  uint64_t ph_last; K2_NOW(ph_last);
+#else
+#define K2_MARK(I) do {} while (0)
+#endif
   if (args.lockstep) {
     for (;;) {
       uint64_t base = 0;
@@ -260,9 +274,20 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
         fk_part = 0; fk_pruned0 = 0; fk_pruned1 = 0;
         cur_skip();
       }
+      K2_MARK(0);
+      // the next event and its word id are requested one step ahead: with one wave per SIMD there is nothing else to hide
+      // the LDS round trip behind, and the walk is a chain of them
+      uint64_t ev_next = NX ? expected[0] : 0ull;
+      uint32_t fp_next = (FP && NX) ? (uint32_t)exp_fp[0] : 0u;
       for (idx = 1; idx <= NX; idx++) {                // (idx - 1 is the event's index, as in the per-lane loop)
+        K2_MARK(1);
+#ifdef DEMI_K2_PHASES
+        ph_ev++;
+#endif
         if (__ballot(active) == 0) break;
-        const uint64_t ev = expected[idx - 1];
+        const uint64_t ev = ev_next;
+        const uint32_t fp_cur = fp_next;
+        if (idx < NX) { ev_next = expected[idx]; if (FP) fp_next = (uint32_t)exp_fp[idx]; }
         // the event is the same for every lane: keep it in scalar registers, so that its kind, the handler it selects
         // and the receiver are wave-uniform for the compiler too
         const uint64_t e = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ev) |
@@ -301,7 +326,7 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
         if (kind == DEMI_REC_MSG_SEND) {
           if (active && IN_MASK(ext) && ((exists >> b) & 1)) {
             PEND_APPEND_ID(msg_word((uint32_t)(e >> 24) & 0xFF, DEMI_DEADLETTERS, b, EXP_P0(e, idx - 1), EXP_P1(e, idx - 1)),
-                           FP ? (uint32_t)exp_fp[idx - 1] : K2_FP_NONE);
+                           FP ? fp_cur : K2_FP_NONE);
             if (args.kept && !(flags & DEMI_OVF_ANY)) args.kept[sched * NX + idx - 1] = 1;
             if (flags & DEMI_OVF_ANY) active = false;
           }
@@ -321,7 +346,7 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
             }
             if ((blocked >> b) & 1u) { ignored++; break; }
             if (FP) {
-              const uint32_t f = exp_fp[idx - 1];
+              const uint32_t f = fp_cur;
               if (cnt_get(f) == 0) { ignored++; break; }       // "Ignoring message" (:528-529)
               cnt_add(f, false);
             } else {
@@ -336,6 +361,7 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
             deliver = true;
           } while (0);
         }
+        K2_MARK(2);
         if (__ballot(deliver) == 0) continue;            // nobody's candidate has this message pending
         const word_t w = want;
         const uint32_t type = w_type(w), me = w_dst(w);
@@ -347,8 +373,10 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
             handle_timer(me, type);
           if (flags & DEMI_OVF_ANY) { deliver = false; active = false; }
         }
+        K2_MARK(3);
         uint32_t nfx = 0;
         if (deliver) nfx = DEMI_VM_RUN(t, mem, w, flags, app_rng);
+        K2_MARK(4);
         if (deliver) {
           for (uint32_t k = 0; k < nfx && !(flags & DEMI_OVF_ANY); k++) {
             const word_t fxw = mem.fxq[k * 64];
@@ -403,6 +431,7 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
           tq = 0; n_tq = 0;
           if (flags & DEMI_OVF_ANY) active = false;
         }
+        K2_MARK(5);
       }
       if (mine) {
         uint32_t viol = 0;
@@ -420,7 +449,15 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
         }
         *reinterpret_cast<uint4*>(&args.out[sched]) = v;
       }
+      K2_MARK(6);
     }
+#ifdef DEMI_K2_PHASES
+    if (lane == 0 && args.phase_out) {
+      unsigned long long* o = args.phase_out + ((size_t)blockIdx.x * K2_WAVES + wave) * 16;
+      for (int i = 0; i < 7; i++) o[i] = ph_t[i];
+      o[15] = ph_ev;
+    }
+#endif
     return;
   }
 
