@@ -133,10 +133,12 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
   }
   uint64_t* const st = mem.st;
   const uint32_t A = t.A, NE = t.E, exists = t.exists, PMAX = args.p_max;
+  // (every lambda below is force-inlined: one that stays a call keeps the variables it captures - the candidate mask, the
+  // cursor, the counters' base - in the stack frame, i.e. in scratch memory, and the walk then waits for HBM at every step)
   // counter of word id `f` of this lane: read; +1 / -1 (K2_FP_HBM: a 32-bit atomic on the dword shared with three other
   // lanes - their bytes are untouched as a count never leaves 0..255 - with no return value, so nothing waits for it)
   // (the HBM read goes to the L2, where the atomics are performed: an L1 line could predate this lane's own atomic)
-  auto cnt_get = [&](uint32_t f) -> uint32_t {
+  auto cnt_get = [&](uint32_t f) __attribute__((always_inline)) -> uint32_t {
     const uint8_t* c = cnt + (size_t)f * cnt_stride;
     if (MODE == K2_FP_HBM) {
       const uintptr_t ad = reinterpret_cast<uintptr_t>(c);
@@ -145,7 +147,7 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
     }
     return *c;
   };
-  auto cnt_add = [&](uint32_t f, bool up) {
+  auto cnt_add = [&](uint32_t f, bool up) __attribute__((always_inline)) {
     uint8_t* c = cnt + (size_t)f * cnt_stride;
     if (MODE == K2_FP_HBM) {
       const uintptr_t ad = reinterpret_cast<uintptr_t>(c);
@@ -162,7 +164,7 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
     }
   };
   // the word id of a message produced at run time (FP): a probe or two of the workgroup's hash
-  auto fp_of = [&](uint32_t word) -> uint32_t {
+  auto fp_of = [&](uint32_t word) __attribute__((always_inline)) -> uint32_t {
     uint32_t i = (word * 0x9E3779B1u) >> 7 & args.fp_hash_mask;
     for (;;) {
       const uint64_t e = fp_hash[i];
@@ -186,18 +188,22 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
   // lowering gave the in-flight internal messages.
   const uint32_t FK = args.filter_absents;
   uint64_t fk_part = 0, fk_pruned0 = 0, fk_pruned1 = 0;
-  auto fk_cut = [&](uint32_t s_, uint32_t r_) -> bool {
+  auto fk_cut = [&](uint32_t s_, uint32_t r_) __attribute__((always_inline)) -> bool {
     if (s_ >= DEMI_MAX_ACTORS || r_ >= DEMI_MAX_ACTORS) return false;
     if (FK == DEMI_FILTER_ABSENTS_LITERAL) return (fk_part >> (s_ * 8 + r_)) & 1ull;
     return ((net.partitioned >> (s_ * 8 + r_)) | (net.partitioned >> (r_ * 8 + s_))) & 1ull;
   };
-  auto fk_alive = [&](uint32_t who) -> bool { return who >= DEMI_MAX_ACTORS || (((exists & ~net.inaccessible) >> who) & 1u); };
+  auto fk_alive = [&](uint32_t who) __attribute__((always_inline)) -> bool { return who >= DEMI_MAX_ACTORS || (((exists & ~net.inaccessible) >> who) & 1u); };
   uint64_t tq = 0;
   uint32_t n_tq = 0;
   uint64_t b_next = 0, b_end = 0;
   bool exhausted = false;
 
-#define IN_MASK(I) ((uint32_t)((((I) & 128u) ? (((I) & 64u) ? m3 : m2) : (((I) & 64u) ? m1 : m0)) >> ((I) & 63u)) & 1u)
+// bit I of the candidate mask.  Selected by VALUE: written as a choice between the four variables, the compiler turns it into a
+// table of their addresses, which pins the mask, the cursor and the kernel arguments in the stack frame (scratch memory) - every
+// step of the walk then waits for two memory round trips (round 3: 240 bytes of scratch per lane, 2 500 cycles per event)
+#define IN_MASK(I) ((uint32_t)((((((I) >> 6) & 3u) == 0u ? m0 : 0ull) | ((((I) >> 6) & 3u) == 1u ? m1 : 0ull) | \
+                                ((((I) >> 6) & 3u) == 2u ? m2 : 0ull) | ((((I) >> 6) & 3u) == 3u ? m3 : 0ull)) >> ((I) & 63u)) & 1u)
 #define TIMER_BIT(RCV, TYPE) (1u << ((RCV) * DEMI_MAX_TIMER_TYPES + (t.meta[(TYPE)] >> 8)))
 // payload fields of expected event E at index I (a wide table's upper bytes come from exp_hi)
 #define EXP_P0(E, I) (((uint32_t)((E) >> 32) & 0xFFu) | (WIDE_TU ? ((uint32_t)args.exp_hi[(I)] & 0xFFu) << 8 : 0u))
@@ -215,7 +221,7 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
 #define PEND_APPEND(WORD) PEND_APPEND_ID(WORD, FP ? fp_of((uint32_t)(WORD)) : K2_FP_NONE)
 
   // cursor over the candidate's non-Send, non-WaitQuiescence externals (subsequenceIntersection :299-304)
-  auto cur_skip = [&]() {
+  auto cur_skip = [&]() __attribute__((always_inline)) {
     while (cur < NE) {
       const uint32_t kind = (uint32_t)t.trace[cur] & 0xFF;
       if (IN_MASK(cur) && kind != DEMI_EV_SEND && kind != DEMI_EV_WAIT_QUIESCENCE) break;
@@ -223,7 +229,7 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
     }
   };
   // STSScheduler.enqueue_timer = handle_timer: straight into messagesToSend (no parking)
-  auto handle_timer = [&](uint32_t rcv, uint32_t type) {
+  auto handle_timer = [&](uint32_t rcv, uint32_t type) __attribute__((always_inline)) {
     if (n_tq >= DEMI_TQ_CAP) { flags |= DEMI_V_QUEUE_OVF; return; }
     tq |= (uint64_t)((rcv << 5) | type) << (8 * n_tq);
     n_tq++;

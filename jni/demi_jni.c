@@ -228,6 +228,39 @@ JNIEXPORT jint JNICALL FN(replayGetKept)(JNIEnv* e, jclass c, jlong h, jlongArra
   return rc;
 }
 
+/* ---- DDMin in one call (demi_ddmin).  params: int[4] (demi_ddmin_params); conjoinedOrNull: byte[n externals]; mcs: long[4];
+ *      consultedOrNull: long[4 * cap] with passedOrNull: byte[cap]; stats: long[5] = consultations, launches, mcs_len, verified, replays */
+JNIEXPORT jint JNICALL FN(ddmin)(JNIEnv* e, jclass c, jlong h, jintArray limits, jintArray params, jbyteArray conjoinedOrNull, jlongArray mcs,
+                                jlongArray consultedOrNull, jbyteArray passedOrNull, jlongArray stats) {
+  demi_limits lim;
+  demi_ddmin_params par;
+  demi_ddmin_stats st;
+  jint pr[4];
+  uint64_t out[4] = {0, 0, 0, 0};
+  (void)c;
+  if (limits_of(e, limits, &lim) || LEN(params) != 4 || LEN(mcs) != 4 || LEN(stats) != 5) return DEMI_ERR_INVALID_ARG;
+  (*e)->GetIntArrayRegion(e, params, 0, 4, pr);
+  par.depth = (uint32_t)pr[0]; par.max_candidates = (uint32_t)pr[1]; par.check_unmodified = (uint32_t)pr[2]; par.verify_mcs = (uint32_t)pr[3];
+  uint32_t cap = 0;
+  if (consultedOrNull) {
+    if (LEN(consultedOrNull) % 4 || !passedOrNull || LEN(passedOrNull) < LEN(consultedOrNull) / 4) return DEMI_ERR_INVALID_ARG;
+    cap = (uint32_t)(LEN(consultedOrNull) / 4);
+  }
+  memset(&st, 0, sizeof st);
+  void* cj = BYTES(conjoinedOrNull);
+  void* co = LONGS(consultedOrNull);
+  void* pa = BYTES(passedOrNull);
+  jint rc = demi_ddmin(CTX(h), &lim, &par, (const uint8_t*)cj, out, (uint64_t*)co, (uint8_t*)pa, cap, NULL, 0, &st);
+  PUT_BYTES(passedOrNull, pa, 0);
+  PUT_LONGS(consultedOrNull, co, 0);
+  PUT_BYTES(conjoinedOrNull, cj, JNI_ABORT);
+  (*e)->SetLongArrayRegion(e, mcs, 0, 4, (const jlong*)(const void*)out);
+  jlong o[5];
+  o[0] = (jlong)st.consultations; o[1] = (jlong)st.launches; o[2] = (jlong)st.mcs_len; o[3] = (jlong)st.verified; o[4] = (jlong)st.replays;
+  (*e)->SetLongArrayRegion(e, stats, 0, 5, o);
+  return rc;
+}
+
 /* ---- K3 */
 JNIEXPORT jint JNICALL FN(dporLoad)(JNIEnv* e, jclass c, jlong h, jbyteArray externals) {
   (void)c;

@@ -28,6 +28,10 @@ object DemiGpu {
   @native def replayLoad(h: Long, externals: Array[Byte], recorded: Array[Byte]): Int
   @native def replayBatch(h: Long, masks: Array[Long], limits: Array[Int], verdicts: Array[Long]): Int
   @native def replayRemovalBatch(h: Long, masksOrNull: Array[Long], skip: Array[Int], limits: Array[Int], verdicts: Array[Long]): Int
+  /** RunnerUtils.stsSchedDDMin in one call (demi_ddmin): params = int[4] (depth, max_candidates, check_unmodified, verify_mcs), mcs = long[4],
+   *  stats = long[5] (consultations, launches, mcs_len, verified, replays) */
+  @native def ddmin(h: Long, limits: Array[Int], params: Array[Int], conjoinedOrNull: Array[Byte], mcs: Array[Long],
+                    consultedOrNull: Array[Long], passedOrNull: Array[Byte], stats: Array[Long]): Int
   @native def replayGetKept(h: Long, maskOrNull: Array[Long], skip: Int, limits: Array[Int], verdict: Array[Long], kept: Array[Byte]): Int
   @native def dporLoad(h: Long, externals: Array[Byte]): Int
   /** returns the length of the first violating trace (entries of 16 bytes in firstViolationTrace), or a negative status */

@@ -213,6 +213,22 @@ class GpuSTSScheduler(val schedulerConfig: SchedulerConfig, original_trace: Even
     }
   }
 
+  /** RunnerUtils.stsSchedDDMin (:642-707) in ONE native call (demi_ddmin): DDMin.minimize / ddmin2 over the loaded execution's
+   *  external events with this scheduler as the oracle - the atoms, the splits, the speculative frontiers and their launches all
+   *  inside the library.  Returns (the MCS as a subsequence of the original externals, the verified trace if the MCS reproduces
+   *  the violation); the consultations are added to `stats` as DDMin would.  maxCandidates = 0 leaves the launch width to the
+   *  library.  Same MCS as `new DDMin(this).minimize(...)` (the same decision tree, consulted through cached verdicts). */
+  def ddmin(fp: ViolationFingerprint, stats: MinimizationStats, checkUnmodified: Boolean = true,
+            maxCandidates: Int = 0): (Seq[ExternalEvent], Option[EventTrace]) = {
+    requireInvariant()
+    val mcs = new Array[Long](4); val st = new Array[Long](5)
+    check(h, DemiGpu.ddmin(h, limits(fp), Array(0, maxCandidates, if (checkUnmodified) 1 else 0, 1), null, mcs, null, null, st))
+    if (stats != null) (0L until st(0)).foreach(_ => stats.increment_replays())
+    val ext = original_trace.original_externals
+    val kept = ext.indices.filter(i => ((mcs(i >> 6) >>> (i & 63)) & 1L) != 0).map(ext)
+    (kept, if (st(3) != 0) Some(executed(kept, fp)) else None)
+  }
+
   /** the EventTrace test() returns on success (:286-292): the recorded events that took effect in the replay */
   private def executed(subseq: Seq[ExternalEvent], fp: ViolationFingerprint): EventTrace = {
     val v = new Array[Long](2); val kept = new Array[Byte](original_trace.events.size)

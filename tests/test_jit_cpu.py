@@ -413,3 +413,47 @@ def test_specialised_k1_keeps_six_waves_per_simd_with_either_compiler(tmp_path, 
     image = open(str(tmp_path / "img") + ".0", "rb").read()          # kernel 0 = K1 (FullyRandom)
     assert 0 < _vgpr_count(image) <= 80
     assert b".vgpr_spill_count" in image and image[image.find(b".vgpr_spill_count") + len(b".vgpr_spill_count")] == 0
+
+
+def _meta_values(image, key):
+    """every value of msgpack key `key` in a code object's metadata note (fixint / uint8 / uint16 / uint32)"""
+    vals, k = [], key.encode()
+    i = image.find(k)
+    while i >= 0:
+        p = i + len(k)
+        t = image[p]
+        vals.append(t if t <= 0x7F else image[p + 1] if t == 0xCC else int.from_bytes(image[p + 1:p + 3], "big") if t == 0xCD
+                    else int.from_bytes(image[p + 1:p + 5], "big") if t == 0xCE else -1)
+        i = image.find(k, i + 1)
+    return vals
+
+
+@pytest.mark.parametrize("wide", [False, True])
+def test_no_specialised_kernel_touches_scratch_memory(tmp_path, wide):
+    """None of the compiled kernels may keep anything in the stack frame (scratch = HBM-backed private memory): the replay and
+    DPOR kernels are latency-bound chains, and a variable that lives there costs a memory round trip per use.  Round 3 found
+    K2 with 240 bytes of it - the candidate mask, the cursor and the kernel arguments, pinned by ONE expression that selected
+    among four variables and was compiled into a table of their addresses."""
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from demi_amd import _native, model as M\n"
+            "m = M.raft_model(5, term0=1000, loglen0=300) if %r else M.raft_model(5)\n"
+            "try:\n"
+            "    print('SIZE', _native.specialize_check(m.to_struct())[0])\n"
+            "except _native.DemiError as e:\n"
+            "    print('ERR', e)\n" % (ROOT, wide))
+    env = dict(os.environ, DEMI_JIT_DUMP=str(tmp_path / "img"))
+    out = subprocess.run([os.sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    if "hiprtc not found" in out.stdout:
+        pytest.skip("no hiprtc in this environment")
+    assert "SIZE" in out.stdout, out.stdout + out.stderr
+    seen = 0
+    for k in range(8):
+        path = str(tmp_path / "img") + ".%d" % k
+        if not os.path.exists(path):
+            continue
+        image = open(path, "rb").read()
+        sizes = _meta_values(image, ".private_segment_fixed_size")
+        assert sizes and all(v == 0 for v in sizes), (k, sizes)
+        assert all(v == 0 for v in _meta_values(image, ".vgpr_spill_count")), k
+        seen += 1
+    assert seen >= 4
