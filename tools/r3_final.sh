@@ -32,3 +32,6 @@ if 'value' in r:
 else: print('ddmin', r)
 PY
 timeout 1200 bash tools/profile_r3_k2k3.sh > gpurun_out/r03_profile_k2k3.log 2>&1; tail -2 gpurun_out/r03_profile_k2k3.log
+# the latency-bound kernels' phase splits (diagnostic builds of the compiled kernels; proportions only)
+timeout 300 bash tools/k3_phases.sh > gpurun_out/r03_k3_phases.txt 2>&1; tail -2 gpurun_out/r03_k3_phases.txt
+timeout 300 bash tools/k2_phases.sh > gpurun_out/r03_k2_phases.txt 2>&1; tail -2 gpurun_out/r03_k2_phases.txt
