@@ -117,63 +117,6 @@ __device__ __forceinline__ uint32_t state_field(const uint64_t* st, uint32_t a, 
 #endif
 }
 
-// One actor's contribution to the invariant's "hit" mask: F[fa] == va (F[fa] != 0 for AGREE).
-__device__ __forceinline__ uint32_t invariant_hit(uint64_t state, uint32_t kind, uint32_t fa, uint32_t va) {
-  const uint32_t a = (uint32_t)(state >> (8 * fa)) & 0xFF;
-  return (kind == DEMI_INV_AGREE) ? (a != 0) : (a == va);
-}
-// the same from the lane's state array (what K1 uses: also right for a wide table)
-__device__ __forceinline__ uint32_t invariant_hit_at(const uint64_t* st, uint32_t actor, uint32_t kind, uint32_t fa, uint32_t va) {
-  const uint32_t a = state_field(st, actor, fa);
-  return (kind == DEMI_INV_AGREE) ? (a != 0) : (a == va);
-}
-
-// The verdict from the hit mask (bit i = created actor i hits).  Almost every check ends in the first two lines
-// (fewer than two hits); the group keys are only read after that.
-__device__ inline uint32_t invariant_from_hits(const uint64_t* st, uint32_t vmask, uint32_t A, uint32_t kind, uint32_t fb) {
-  vmask &= (1u << A) - 1u;   // (a specialised build knows A: the pair logic below then only exists for real actors)
-  if (kind == DEMI_INV_NEVER) return vmask ? ((2u << 24) | vmask) : 0u;
-  if (kind == DEMI_INV_NONE || (vmask & (vmask - 1)) == 0) return 0u;   // needs at least two hits
-  // slow path: group keys of the hit actors
-  uint32_t key[DEMI_MAX_ACTORS];
-#pragma unroll
-  for (uint32_t i = 0; i < DEMI_MAX_ACTORS; i++) key[i] = (i < A) ? state_field(st, i, fb) : 0u;
-  if (kind == DEMI_INV_AGREE) {
-    bool have = false, bad = false;
-    uint32_t first = 0;
-#pragma unroll
-    for (uint32_t i = 0; i < DEMI_MAX_ACTORS; i++) {
-      if ((vmask >> i) & 1) {
-        if (!have) { have = true; first = key[i]; }
-        else if (key[i] != first) bad = true;
-      }
-    }
-    return bad ? ((3u << 24) | vmask) : 0u;
-  }
-  // AT_MOST_ONE: lowest (i, j) pair of hits with equal keys
-  bool found = false;
-  uint32_t k = 0;
-#pragma unroll
-  for (uint32_t i = 0; i < DEMI_MAX_ACTORS; i++) {
-#pragma unroll
-    for (uint32_t j = i + 1; j < DEMI_MAX_ACTORS; j++) {
-      if (!found && ((vmask >> i) & 1) && ((vmask >> j) & 1) && key[i] == key[j]) { found = true; k = key[i]; }
-    }
-  }
-  if (!found) return 0u;
-  uint32_t mask = 0;
-#pragma unroll
-  for (uint32_t i = 0; i < DEMI_MAX_ACTORS; i++)
-    if (((vmask >> i) & 1) && key[i] == k) mask |= 1u << i;
-  return (1u << 24) | (k << 8) | mask;
-}
-
-__device__ inline uint32_t invariant_code(const DevModel* __restrict__ gm, const uint64_t* st, uint32_t exists,
-                                          uint32_t A, uint32_t kind, uint32_t fa, uint32_t va, uint32_t fb) {
-  (void)gm;
-  uint32_t vmask = 0;
-  for (uint32_t i = 0; i < A; i++) vmask |= invariant_hit_at(st, i, kind, fa, va) << i;     // (also right for a wide table)
-  return invariant_from_hits(st, vmask & exists, A, kind, fb);
-}
+// (the invariant itself - per-actor hit / key, the combining kinds - lives in sim_core.hpp: a DEMI_INV_PROGRAM invariant runs rows)
 
 }  // namespace demi

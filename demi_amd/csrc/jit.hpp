@@ -335,6 +335,29 @@ inline std::string generate_vm(const demi::DevModel& h, bool sched = false) {
     const size_t at = s.find("  switch (entry) {");
     s.insert(at, preds);
   }
+  // the value an ALU row assigns, as an expression over the register names a, b
+  auto alu_value = [&](uint32_t op, const char* a, const char* b, char* val, size_t cap) {
+    switch (op) {
+      case DEMI_OP_MOV: snprintf(val, cap, "%s & %uu", b, RM); break;
+      case DEMI_OP_MOVHI: snprintf(val, cap, "((%s & 255u) | (%s << 8)) & %uu", a, b, RM); break;   // (wide tables only)
+      case DEMI_OP_ADD: snprintf(val, cap, "(%s + %s) & %uu", a, b, RM); break;
+      case DEMI_OP_SUB: snprintf(val, cap, "(%s - %s) & %uu", a, b, RM); break;
+      case DEMI_OP_AND: snprintf(val, cap, "%s & %s & %uu", a, b, RM); break;
+      case DEMI_OP_OR: snprintf(val, cap, "(%s | %s) & %uu", a, b, RM); break;
+      case DEMI_OP_XOR: snprintf(val, cap, "(%s ^ %s) & %uu", a, b, RM); break;
+      case DEMI_OP_SHL: snprintf(val, cap, "(%s << (%s & %uu)) & %uu", a, b, SM, RM); break;
+      case DEMI_OP_SHR: snprintf(val, cap, "(%s >> (%s & %uu)) & %uu", a, b, SM, RM); break;
+      case DEMI_OP_BITSET: snprintf(val, cap, "(%s | (1u << (%s & %uu))) & %uu", a, b, SM, RM); break;
+      case DEMI_OP_POPC: snprintf(val, cap, "(uint32_t)__popc(%s)", b); break;
+      case DEMI_OP_MIN: snprintf(val, cap, "%s < %s ? %s : %s", a, b, a, b); break;
+      case DEMI_OP_MAX: snprintf(val, cap, "%s < %s ? %s : %s", a, b, b, a); break;
+      case DEMI_OP_RND:      // (a wide table's bound is b & 0xFF: the magics cover 1..256)
+        if (wide) snprintf(val, cap, "app_next_int(app_rng, %s & 255u, t.gmagic)", b);
+        else snprintf(val, cap, "app_next_int(app_rng, %s, t.gmagic)", b);
+        break;
+      default: snprintf(val, cap, "(%s %s %s) ? 1u : 0u", a, relop[op - DEMI_OP_EQ], b); break;   // EQ .. GT
+    }
+  };
   for (uint32_t pc = 0; pc < h.code_len; pc++) {
     const uint32_t row = h.code[pc];
     const uint32_t op = row & 0x3Fu, dsti = (row >> 8) & 15u, ai = (row >> 12) & 15u, aux = (row >> 17) & 0x7Fu,
@@ -352,26 +375,7 @@ inline std::string generate_vm(const demi::DevModel& h, bool sched = false) {
     }
     if (cw & CW_ALU) {
       char val[96];
-      switch (op) {
-        case DEMI_OP_MOV: snprintf(val, sizeof val, "%s & %uu", b, RM); break;
-        case DEMI_OP_MOVHI: snprintf(val, sizeof val, "((%s & 255u) | (%s << 8)) & %uu", a, b, RM); break;   // (wide tables only)
-        case DEMI_OP_ADD: snprintf(val, sizeof val, "(%s + %s) & %uu", a, b, RM); break;
-        case DEMI_OP_SUB: snprintf(val, sizeof val, "(%s - %s) & %uu", a, b, RM); break;
-        case DEMI_OP_AND: snprintf(val, sizeof val, "%s & %s & %uu", a, b, RM); break;
-        case DEMI_OP_OR: snprintf(val, sizeof val, "(%s | %s) & %uu", a, b, RM); break;
-        case DEMI_OP_XOR: snprintf(val, sizeof val, "(%s ^ %s) & %uu", a, b, RM); break;
-        case DEMI_OP_SHL: snprintf(val, sizeof val, "(%s << (%s & %uu)) & %uu", a, b, SM, RM); break;
-        case DEMI_OP_SHR: snprintf(val, sizeof val, "(%s >> (%s & %uu)) & %uu", a, b, SM, RM); break;
-        case DEMI_OP_BITSET: snprintf(val, sizeof val, "(%s | (1u << (%s & %uu))) & %uu", a, b, SM, RM); break;
-        case DEMI_OP_POPC: snprintf(val, sizeof val, "(uint32_t)__popc(%s)", b); break;
-        case DEMI_OP_MIN: snprintf(val, sizeof val, "%s < %s ? %s : %s", a, b, a, b); break;
-        case DEMI_OP_MAX: snprintf(val, sizeof val, "%s < %s ? %s : %s", a, b, b, a); break;
-        case DEMI_OP_RND:      // (a wide table's bound is b & 0xFF: the magics cover 1..256)
-          if (wide) snprintf(val, sizeof val, "app_next_int(app_rng, %s & 255u, t.gmagic)", b);
-          else snprintf(val, sizeof val, "app_next_int(app_rng, %s, t.gmagic)", b);
-          break;
-        default: snprintf(val, sizeof val, "(%s %s %s) ? 1u : 0u", a, relop[op - DEMI_OP_EQ], b); break;   // EQ .. GT
-      }
+      alu_value(op, a, b, val, sizeof val);
       if (pred_of[pc] >= 0) emit("%s = c%d ? (%s) : %s;\n", d, pred_of[pc], val, d);
       else emit("%s = %s;\n", d, val);
     } else if (cw & CW_IF) {
@@ -401,7 +405,56 @@ inline std::string generate_vm(const demi::DevModel& h, bool sched = false) {
   else
     s += "  mem.st[me * 64] = (uint64_t)(r0 | (r1 << 8) | (r2 << 16) | (r3 << 24)) | "
          "((uint64_t)(r4 | (r5 << 8) | (r6 << 16) | (r7 << 24)) << 32);\n";
-  s += "  return nfx;\n}\n}  // namespace demi\n";
+  s += "  return nfx;\n}\n";
+  if (h.inv_kind & DEMI_INV_PROGRAM) {
+    // the invariant's per-actor program (include/demi_gpu.h DEMI_INV_PROGRAM): the rows from inv_fa on, run on one actor's
+    // state - r0..r7 its fields, r15 its id, everything else 0; T0 = hit, T1 = key; what it writes to the fields is discarded
+    // (jit_source defines DEMI_JIT_INV_PROG ahead of sim_core.hpp, whose inv_prog() then calls this)
+    s += "__device__ inline uint32_t inv_prog_jit(const uint64_t* st, uint32_t actor, uint32_t& key) {\n";
+    if (wide) {
+      s += "  const uint64_t st0 = st[(2 * actor) * 64], st1 = st[(2 * actor + 1) * 64];\n";
+      s += "  uint32_t r0 = (uint32_t)st0 & 65535u, r1 = (uint32_t)(st0 >> 16) & 65535u, r2 = (uint32_t)(st0 >> 32) & 65535u, "
+           "r3 = (uint32_t)(st0 >> 48) & 65535u,\n           r4 = (uint32_t)st1 & 65535u, r5 = (uint32_t)(st1 >> 16) & 65535u, "
+           "r6 = (uint32_t)(st1 >> 32) & 65535u, r7 = (uint32_t)(st1 >> 48) & 65535u;\n";
+    } else {
+      s += "  const uint64_t st0 = st[actor * 64];\n";
+      s += "  uint32_t r0 = (uint32_t)st0 & 255u, r1 = (uint32_t)(st0 >> 8) & 255u, r2 = (uint32_t)(st0 >> 16) & 255u, "
+           "r3 = (uint32_t)(st0 >> 24) & 255u,\n           r4 = (uint32_t)(st0 >> 32) & 255u, r5 = (uint32_t)(st0 >> 40) & 255u, "
+           "r6 = (uint32_t)(st0 >> 48) & 255u, r7 = (uint32_t)(st0 >> 56) & 255u;\n";
+    }
+    s += "  uint32_t r8 = 0, r9 = 0, r10 = 0, r11 = 0, r12 = 0, r13 = 0, r14 = 0, r15 = actor;\n";
+    s += "  (void)r0; (void)r1; (void)r2; (void)r3; (void)r4; (void)r5; (void)r6; (void)r7; (void)r10; (void)r11; (void)r12; (void)r13; (void)r14; (void)r15;\n";
+    auto itarget = [&](uint32_t pc) -> std::string { return pc >= h.code_len ? "idone" : "I" + std::to_string(pc); };
+    for (uint32_t pc = h.inv_fa; pc < h.code_len; pc++) {
+      const uint32_t row = h.code[pc];
+      const uint32_t op = row & 0x3Fu, dsti = (row >> 8) & 15u, ai = (row >> 12) & 15u, aux = (row >> 17) & 0x7Fu, braw = row >> 24;
+      const bool bimm = (row & 0x10000u) != 0;
+      char a[8], b[16], d[8];
+      snprintf(a, sizeof a, "r%u", ai);
+      snprintf(d, sizeof d, "r%u", dsti);
+      if (bimm) snprintf(b, sizeof b, "%uu", braw); else snprintf(b, sizeof b, "r%u", braw & 15u);
+      emit("  I%u: ", pc);
+      const uint32_t cw = op_control(op);
+      if (cw & CW_HALT) { s += "goto idone;\n"; continue; }
+      if ((cw & CW_ALU) && !(cw & CW_RND)) {
+        char val[96];
+        alu_value(op, a, b, val, sizeof val);
+        emit("%s = %s;\n", d, val);
+      } else if (cw & CW_IF) {
+        emit("if (!(%s %s %s)) goto %s;\n", a, relop[op - DEMI_OP_IFEQ], b, itarget(pc + 1 + aux).c_str());
+      } else if (cw & CW_SKIPZ) {
+        emit("if (%s == 0u) goto %s;\n", a, itarget(pc + 1 + braw).c_str());
+      } else if (cw & CW_SKIPNZ) {
+        emit("if (%s != 0u) goto %s;\n", a, itarget(pc + 1 + braw).c_str());
+      } else if (cw & CW_SKIP) {
+        emit("goto %s;\n", itarget(pc + 1 + braw).c_str());
+      } else {
+        s += ";   /* (refused at load: an invariant program has no effects) */\n";
+      }
+    }
+    s += "  idone:\n  key = r9;\n  return r8;\n}\n";
+  }
+  s += "}  // namespace demi\n";
   return s;
 }
 

@@ -392,7 +392,7 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
   const uint32_t inv_kind = t.inv_kind, inv_fa = t.inv_fa, inv_va = t.inv_va, inv_fb = t.inv_fb, fp_mask = t.fp_mask;
 #endif
   auto check_invariant = [&]() -> uint32_t {
-    const uint32_t fp = invariant_from_hits(st, hits & exists, A, inv_kind, inv_fb);
+    const uint32_t fp = invariant_from_hits(t, st, hits & exists, A, inv_kind, inv_fb);
     if (!fp) return 0u;
     if (args.looking_for_valid && (!CARRY || exec_no == 0)) return (((fp ^ args.looking_for) & fp_mask) == 0) ? args.looking_for : 0u;
     return fp;
@@ -506,7 +506,7 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
           hits = 0;
           for (uint32_t j = 0; j < k1_tdir_words(A, NTT); j++) *reinterpret_cast<uint32_t*>(tdir + (j << 8)) = 0xFFFFFFFFu;   // no timer pending
           for (uint32_t i = 0; i < A * ST_WORDS; i++) st[i * 64] = t.init[i];
-          for (uint32_t a = 0; a < A; a++) hits |= invariant_hit_at(st, a, inv_kind, inv_fa, inv_va) << a;
+          for (uint32_t a = 0; a < A; a++) hits |= invariant_hit_at(t, st, a, inv_kind, inv_fa, inv_va) << a;
           if (REC) { rec = args.rec_out + (args.rec_shared ? 0ull : sched * (uint64_t)args.rec_cap); n_rec = 0; next_id = 1; }
           batch_no = 0;
         }
@@ -783,7 +783,7 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
     if (deliver) nfx = DEMI_VM_RUN(t, mem, w, flags, app_rng);
     if (deliver) {      // the receiver's new state decides its bit of the invariant's hit mask
       const uint32_t me_ = w_dst(w);
-      hits = (hits & ~(1u << me_)) | (invariant_hit_at(st, me_, inv_kind, inv_fa, inv_va) << me_);
+      hits = (hits & ~(1u << me_)) | (invariant_hit_at(t, st, me_, inv_kind, inv_fa, inv_va) << me_);
     }
     PH_MARK(5);
 #ifdef DEMI_K1_PHASES

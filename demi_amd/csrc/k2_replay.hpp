@@ -442,7 +442,7 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
       if (mine) {
         uint32_t viol = 0;
         if (!(flags & DEMI_OVF_ANY)) {
-          const uint32_t fp = invariant_code(args.model, st, exists, A, t.inv_kind, t.inv_fa, t.inv_va, t.inv_fb);
+          const uint32_t fp = invariant_code(t, st, exists, A, DEMI_INV_KIND_OF(t), t.inv_fa, t.inv_va, t.inv_fb);
           if (fp && (((fp ^ args.looking_for) & t.fp_mask) == 0)) viol = args.looking_for;
         }
         for (uint32_t a = 0; a < A * ST_WORDS; a++) hash_step(hash, st[a * 64]);
@@ -657,7 +657,7 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
       // the invariant on the final state; verdict = fingerprint.matches(target) (:278-300)
       uint32_t viol = 0;
       if (!(flags & DEMI_OVF_ANY)) {
-        const uint32_t fp = invariant_code(args.model, st, exists, A, t.inv_kind, t.inv_fa, t.inv_va, t.inv_fb);
+        const uint32_t fp = invariant_code(t, st, exists, A, DEMI_INV_KIND_OF(t), t.inv_fa, t.inv_va, t.inv_fb);
         if (fp && (((fp ^ args.looking_for) & t.fp_mask) == 0)) viol = args.looking_for;
       }
       for (uint32_t a = 0; a < A * ST_WORDS; a++) hash_step(hash, st[a * 64]);

@@ -518,7 +518,7 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
     if (fin) {
       uint32_t viol = 0;
       if (!aborted) {   // checkInvariant (:394-418)
-        const uint32_t fp = invariant_code(args.model, st, (1u << A) - 1, A, t.inv_kind, t.inv_fa, t.inv_va, t.inv_fb);
+        const uint32_t fp = invariant_code(t, st, (1u << A) - 1, A, DEMI_INV_KIND_OF(t), t.inv_fa, t.inv_va, t.inv_fb);
         if (fp) {
           if (!args.looking_for_valid) viol = fp;
           else if (((fp ^ args.looking_for) & t.fp_mask) == 0) viol = args.looking_for;

@@ -317,4 +317,143 @@ __device__ inline uint32_t vm_run(const Tables& t, const LaneMem& mem, uint32_t 
 }
 #endif  // !DEMI_WIDE
 
+// ------------------------------------------------------------------ invariant
+// Invariant descriptor (TestOracle.scala:27 `Invariant`) on the simulated state; returns the ViolationFingerprint code.
+// st: this lane's actor states in LDS, stride 64 u64.  Per actor: does it count ("hit"), and under which key; the kinds
+// combine the actors (include/demi_gpu.h).  With DEMI_INV_PROGRAM the per-actor part is a row program (first row inv_fa)
+// run on that actor's state: r0..r7 = its fields, r15 = its id, everything else 0; hit = T0 != 0, key = T1.  A compiled table
+// brings it as generated code (jit.hpp: inv_prog_jit); the interpreter below runs it for the others.
+#if defined(DEMI_JIT_INV_PROG)
+__device__ inline uint32_t inv_prog_jit(const uint64_t* st, uint32_t actor, uint32_t& key);     // (generated: jit.hpp)
+#endif
+// the invariant's kind: a compile-time constant in a translation unit compiled for one table (the other kinds' code is not
+// even generated there), the loaded model's otherwise
+#ifdef DEMI_JIT_INV_KIND
+#define DEMI_INV_KIND_OF(T) DEMI_JIT_INV_KIND
+#else
+#define DEMI_INV_KIND_OF(T) ((T).inv_kind)
+#endif
+#ifndef DEMI_WIDE
+// the pure part of vm_run: ALU / SKIP / IF rows from `pc` until HALT or the end of the table
+__device__ inline uint32_t inv_prog_interp(const Tables& t, const uint64_t* st, uint32_t actor, uint32_t& key) {
+  uint32_t pc = t.inv_fa;
+  const uint64_t st0 = st[actor * 64];
+  uint32_t w0 = (uint32_t)st0, w1 = (uint32_t)(st0 >> 32), w2 = 0, w3 = actor << 24;
+  bool running = pc < t.code_len;
+  while (running) {
+    const uint32_t row = t.code[pc];
+    pc++;
+    const uint32_t cw = t.optab[row & 0x3Fu];
+    const uint32_t dsti = (row >> 8) & 15u, ai = (row >> 12) & 15u, aux = (row >> 17) & 0x7Fu, braw = row >> 24;
+    const uint32_t a = reg_get4(w0, w1, w2, w3, ai);
+    const uint32_t breg = reg_get4(w0, w1, w2, w3, braw);
+    const uint32_t b = (row & 0x10000u) ? braw : breg;
+    const int32_t d = (int32_t)a - (int32_t)b;
+    const uint32_t rel = (uint32_t)(min(max(d, -1), 1) + 1);
+    const uint32_t cond = (cw >> (CW_REL_SHIFT + rel)) & 1u;
+    const uint32_t ltm = (uint32_t)(d >> 31);
+    const uint32_t sh = b & 7u;
+    const uint32_t nm = mask_of(cw, 2);
+    uint32_t r = ((a & mask_of(cw, 1)) + (b ^ nm) + (nm & 1u)) & mask_of(cw, 0);
+    r |= (a & b) & mask_of(cw, 3);
+    const uint32_t bm = mask_of(cw, 5);
+    r |= (a | ((b & ~bm) | ((1u << sh) & bm))) & mask_of(cw, 4);
+    r |= (a ^ b) & mask_of(cw, 6);
+    r |= (a << sh) & mask_of(cw, 7);
+    r |= (a >> sh) & mask_of(cw, 8);
+    r |= (uint32_t)__popc(b) & mask_of(cw, 9);
+    r |= cond & mask_of(cw, 10);
+    const uint32_t mn = mask_of(cw, 12);
+    r |= (((b & mn) | (a & ~mn)) ^ ((a ^ b) & ltm)) & mask_of(cw, 11);
+    const uint32_t k8 = (dsti & 3u) * 8u;
+    const uint32_t ins = 0x03020100u ^ ((((dsti & 3u) ^ 4u)) << k8);
+    const uint32_t wsel = (cw & CW_ALU) ? (dsti >> 2) : 4u;
+    w0 = __builtin_amdgcn_perm(r, w0, wsel == 0 ? ins : 0x03020100u);
+    w1 = __builtin_amdgcn_perm(r, w1, wsel == 1 ? ins : 0x03020100u);
+    w2 = __builtin_amdgcn_perm(r, w2, wsel == 2 ? ins : 0x03020100u);
+    w3 = __builtin_amdgcn_perm(r, w3, wsel == 3 ? ins : 0x03020100u);
+    const uint32_t zf = (a == 0) ? CW_SKIPZ : CW_SKIPNZ;
+    const bool skip_if = (cw & CW_IF) && (cond == 0);
+    const bool skip = skip_if | ((cw & (zf | CW_SKIP)) != 0);
+    pc += skip ? (skip_if ? aux : braw) : 0u;
+    running = !(cw & CW_HALT) & (pc < t.code_len);
+  }
+  key = (w2 >> 8) & 0xFFu;      // T1
+  return w2 & 0xFFu;            // T0
+}
+#endif
+// hit (non-zero = the actor counts) and key of one actor under a DEMI_INV_PROGRAM invariant
+__device__ __forceinline__ uint32_t inv_prog(const Tables& t, const uint64_t* st, uint32_t actor, uint32_t& key) {
+#if defined(DEMI_JIT_INV_PROG)
+  (void)t;
+  return inv_prog_jit(st, actor, key);
+#elif !defined(DEMI_WIDE)
+  return inv_prog_interp(t, st, actor, key);
+#else
+  (void)t; (void)st; (void)actor; key = 0;
+  return 0u;                    // (a wide table always runs as generated code)
+#endif
+}
+
+// One actor's contribution to the invariant's "hit" mask: F[fa] == va (F[fa] != 0 for AGREE), or its program's T0
+__device__ __forceinline__ uint32_t invariant_hit_at(const Tables& t, const uint64_t* st, uint32_t actor, uint32_t kind, uint32_t fa, uint32_t va) {
+  if (kind & DEMI_INV_PROGRAM) { uint32_t key; return inv_prog(t, st, actor, key) != 0u; }
+  const uint32_t a = state_field(st, actor, fa);
+  return ((kind & 0xFFu) == DEMI_INV_AGREE) ? (a != 0) : (a == va);
+}
+
+// The verdict from the hit mask (bit i = created actor i hits).  Almost every check ends in the first two lines
+// (fewer than two hits); the group keys are only read after that.
+__device__ inline uint32_t invariant_from_hits(const Tables& t, const uint64_t* st, uint32_t vmask, uint32_t A, uint32_t kind, uint32_t fb) {
+  vmask &= (1u << A) - 1u;   // (a specialised build knows A: the pair logic below then only exists for real actors)
+  const uint32_t comb = kind & 0xFFu;
+  if (comb == DEMI_INV_NEVER) return vmask ? ((2u << 24) | vmask) : 0u;
+  if (comb == DEMI_INV_NONE || (vmask & (vmask - 1)) == 0) return 0u;   // needs at least two hits
+  // slow path: group keys of the hit actors
+  uint32_t key[DEMI_MAX_ACTORS];
+#pragma unroll
+  for (uint32_t i = 0; i < DEMI_MAX_ACTORS; i++) {
+    key[i] = 0u;
+    if (i < A) {
+      if (kind & DEMI_INV_PROGRAM) { if ((vmask >> i) & 1u) (void)inv_prog(t, st, i, key[i]); }
+      else key[i] = state_field(st, i, fb);
+    }
+  }
+  if (comb == DEMI_INV_AGREE) {
+    bool have = false, bad = false;
+    uint32_t first = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < DEMI_MAX_ACTORS; i++) {
+      if ((vmask >> i) & 1) {
+        if (!have) { have = true; first = key[i]; }
+        else if (key[i] != first) bad = true;
+      }
+    }
+    return bad ? ((3u << 24) | vmask) : 0u;
+  }
+  // AT_MOST_ONE: lowest (i, j) pair of hits with equal keys
+  bool found = false;
+  uint32_t k = 0;
+#pragma unroll
+  for (uint32_t i = 0; i < DEMI_MAX_ACTORS; i++) {
+#pragma unroll
+    for (uint32_t j = i + 1; j < DEMI_MAX_ACTORS; j++) {
+      if (!found && ((vmask >> i) & 1) && ((vmask >> j) & 1) && key[i] == key[j]) { found = true; k = key[i]; }
+    }
+  }
+  if (!found) return 0u;
+  uint32_t mask = 0;
+#pragma unroll
+  for (uint32_t i = 0; i < DEMI_MAX_ACTORS; i++)
+    if (((vmask >> i) & 1) && key[i] == k) mask |= 1u << i;
+  return (1u << 24) | (k << 8) | mask;
+}
+
+__device__ inline uint32_t invariant_code(const Tables& t, const uint64_t* st, uint32_t exists,
+                                          uint32_t A, uint32_t kind, uint32_t fa, uint32_t va, uint32_t fb) {
+  uint32_t vmask = 0;
+  for (uint32_t i = 0; i < A; i++) if ((exists >> i) & 1u) vmask |= invariant_hit_at(t, st, i, kind, fa, va) << i;
+  return invariant_from_hits(t, st, vmask & exists, A, kind, fb);
+}
+
 }  // namespace demi

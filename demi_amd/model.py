@@ -259,7 +259,14 @@ def build_model(name, n_actors, msgs, handlers, init_fields, invariant, actor_cl
         code.extend(asm.finish())
     if not code:
         code = [row(OPS["HALT"])]
-    inv_kind, fa, va, fb = invariant
+    if len(invariant) == 2:
+        # (combining kind, Asm): DEMI_INV_PROGRAM - the per-actor predicate / key as rows after the handlers (T0 = counts,
+        # T1 = key; include/demi_gpu.h)
+        kind, prog = invariant
+        inv_kind, fa, va, fb = kind | T.INV_PROGRAM, len(code), 0, 0
+        code.extend(prog.finish())
+    else:
+        inv_kind, fa, va, fb = invariant
     return Model(name=name, n_actors=n_actors, msg_names=names, msg_class=[m[1] for m in msgs],
                  actor_class=list(actor_class or [0] * n_actors), n_classes=n_classes, handler_start=hs,
                  code=code, init_state=([w for f in init_fields for w in pack_state_wide(f)] if wide else
@@ -282,9 +289,11 @@ RAFT_MSGS = [("Bootstrap", T.MSG_EXTERNAL), ("ClientCommand", T.MSG_EXTERNAL),
  M_APPEND_REPLY, M_HEARTBEAT) = range(8)
 
 
-def raft_model(n_actors=5, election_budget=1, buggy=True, term0=0, loglen0=0) -> Model:
+def raft_model(n_actors=5, election_budget=1, buggy=True, term0=0, loglen0=0, invariant=None) -> Model:
     """term0 / loglen0: the term and the log length every node starts with.  Values above 255 (a cluster that has been
-    running for a while) need 16-bit fields and payloads: the model is then lowered as DEMI_MODEL_WIDE, same handlers."""
+    running for a while) need 16-bit fields and payloads: the model is then lowered as DEMI_MODEL_WIDE, same handlers.
+    invariant: None = "at most one leader per term" as a descriptor; or what build_model takes, e.g. (kind, Asm) for a
+    DEMI_INV_PROGRAM invariant over the fields ROLE, TERM, ... of this module."""
     wide = max(term0, loglen0) > 200
     majority = n_actors // 2 + 1
     h = {}
@@ -378,7 +387,7 @@ def raft_model(n_actors=5, election_budget=1, buggy=True, term0=0, loglen0=0) ->
 
     init = [[FOLLOWER, term0, NOBODY, 0, election_budget, loglen0, loglen0, 0] for _ in range(n_actors)]
     return build_model("raft%d-synth%s%s" % (n_actors, "" if buggy else "-fixed", "-wide" if wide else ""), n_actors, RAFT_MSGS,
-                       h, init, invariant=(T.INV_AT_MOST_ONE, int(ROLE), LEADER, int(TERM)), wide=wide)
+                       h, init, invariant=invariant or (T.INV_AT_MOST_ONE, int(ROLE), LEADER, int(TERM)), wide=wide)
 
 
 def save_model(model: Model, path: str):

@@ -33,6 +33,7 @@ STRATEGY_FULLY_RANDOM, STRATEGY_SRC_DST_FIFO = 0, 1
 
 # demi_inv_kind
 INV_NONE, INV_AT_MOST_ONE, INV_NEVER, INV_AGREE = 0, 1, 2, 3
+INV_PROGRAM = 0x100          # OR-ed into inv_kind: the per-actor predicate / key is a row program starting at row inv_fa
 
 # verdict flags
 V_VIOLATION = 0x1

@@ -132,6 +132,15 @@ typedef enum {
   DEMI_INV_NEVER = 2,       /* no created actor with F[fa]==va                                     */
   DEMI_INV_AGREE = 3        /* created actors with F[fa]!=0 agree on F[fb]                         */
 } demi_inv_kind;
+/* DEMI_INV_PROGRAM, OR-ed into inv_kind: the per-actor part of the invariant - "does this actor count" and "under which key" -
+ * is a ROW PROGRAM instead of the two field tests.  inv_fa = its first row in `code` (inv_va, inv_fb: 0).  It is run on every
+ * created actor with the register window r0..r7 = that actor's F0..F7, r15 = its id, everything else 0, and ends (HALT, or the
+ * end of the table) with T0 (r8) != 0 = the actor counts ("hit"), T1 (r9) = its key; what it writes to r0..r7 is discarded.
+ * Only ALU, SKIP* and IF* rows (no effects, no RND).  inv_kind & 0xFF combines the actors as before: NEVER = some actor
+ * counts; AT_MOST_ONE = two counting actors have equal keys; AGREE = the counting actors' keys differ - with the same
+ * fingerprint layouts.  So an arbitrary predicate over one actor's state (ranges, bit tests, several fields, its id) and a
+ * computed key replace `F[fa] == va` / `F[fb]`; relations between two actors beyond "equal keys" still need the JVM. */
+#define DEMI_INV_PROGRAM 0x100u
 
 typedef struct {
   uint32_t n_actors;        /* 1..DEMI_MAX_ACTORS */

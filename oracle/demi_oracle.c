@@ -125,9 +125,18 @@ int orc_model_validate(const demi_model* m, char* err, size_t err_cap) {
         FAIL("row %u: unknown op %u", pc, op);
     }
   }
-  if (m->inv_kind > DEMI_INV_AGREE) FAIL("inv_kind invalid");
+  if ((m->inv_kind & ~DEMI_INV_PROGRAM) > DEMI_INV_AGREE) FAIL("inv_kind invalid");
   if (m->flags & ~DEMI_MODEL_WIDE) FAIL("unknown model flags 0x%x", m->flags);
-  if (m->inv_fa > 7 || m->inv_fb > 7 || m->inv_va > ((m->flags & DEMI_MODEL_WIDE) ? 65535u : 255u)) FAIL("invariant field out of range");
+  if (m->inv_kind & DEMI_INV_PROGRAM) {
+    /* the per-actor predicate / key as rows (include/demi_gpu.h): pure rows only, from inv_fa to the end of the table */
+    if ((m->inv_kind & 0xFFu) == DEMI_INV_NONE) FAIL("DEMI_INV_PROGRAM needs a combining kind");
+    if (m->inv_fa >= m->code_len) FAIL("invariant program starts past the end of the table");
+    for (uint32_t pc = m->inv_fa; pc < m->code_len; pc++) {
+      const uint32_t op = m->code[pc] & 0xFF;
+      if ((op >= DEMI_OP_SEND && op <= DEMI_OP_RND))
+        FAIL("row %u: an invariant program has no effects and draws no random numbers", pc);
+    }
+  } else if (m->inv_fa > 7 || m->inv_fb > 7 || m->inv_va > ((m->flags & DEMI_MODEL_WIDE) ? 65535u : 255u)) FAIL("invariant field out of range");
   return DEMI_OK;
 }
 
@@ -172,11 +181,18 @@ int orc_trace_validate(const demi_model* m, const demi_ext_event* ev, uint32_t n
  * The application's `receive` (not in the reference; see include/demi_gpu.h for the row
  * format).  Effects are returned in program order; the scheduler applies them in that order,
  * as Akka would call `!` / scheduleOnce / cancel inside receive (WeaveActor.aj:224-279).       */
+static int vm_run_at(const demi_model* m, uint32_t start, uint32_t me, uint64_t* state, uint8_t src, uint16_t p0, uint16_t p1,
+                     uint32_t exists_mask, orc_effect* fx, uint32_t fx_cap, orc_jrandom* app, uint16_t* regs_out);
 int orc_vm_run(const demi_model* m, uint32_t me, uint64_t* state, uint8_t msg_type, uint8_t src,
                uint16_t p0, uint16_t p1, uint32_t exists_mask, orc_effect* fx, uint32_t fx_cap, orc_jrandom* app) {
-  uint32_t nfx = 0, n_fx_rows = 0;
   uint16_t start = m->handler_start[m->actor_class[me] * m->n_msg_types + msg_type];
   if (start == 0xFFFF) return 0;
+  return vm_run_at(m, start, me, state, src, p0, p1, exists_mask, fx, fx_cap, app, NULL);
+}
+/* the rows from `start` on; regs_out (may be NULL) receives the final register window */
+static int vm_run_at(const demi_model* m, uint32_t start, uint32_t me, uint64_t* state, uint8_t src, uint16_t p0, uint16_t p1,
+                     uint32_t exists_mask, orc_effect* fx, uint32_t fx_cap, orc_jrandom* app, uint16_t* regs_out) {
+  uint32_t nfx = 0, n_fx_rows = 0;
   /* the register window: 16 x u8, or 16 x u16 for DEMI_MODEL_WIDE (state = two words, four 16-bit fields each) */
   const int wide = (m->flags & DEMI_MODEL_WIDE) != 0;
   const uint32_t M = wide ? 0xFFFFu : 0xFFu, SH = wide ? 15u : 7u;
@@ -262,6 +278,7 @@ int orc_vm_run(const demi_model* m, uint32_t me, uint64_t* state, uint8_t msg_ty
     for (int i = 0; i < 8; i++) s |= (uint64_t)r[i] << (8 * i);
     *state = s;
   }
+  if (regs_out) memcpy(regs_out, r, sizeof r);
   return (int)nfx;
 }
 
@@ -274,38 +291,58 @@ static inline uint32_t fldw(int wide, const uint64_t* st, uint32_t i, uint32_t f
   return wide ? (uint32_t)(st[2 * i + (f >> 2)] >> (16 * (f & 3))) & 0xFFFFu : (uint32_t)(st[i] >> (8 * f)) & 0xFFu;
 }
 
-uint32_t orc_invariant(const demi_model* m, const uint64_t* st, uint32_t exists) {
-  uint32_t A = m->n_actors, fa = m->inv_fa, va = m->inv_va, fb = m->inv_fb;
+/* per actor: does it count ("hit") and under which key.  Descriptor: F[fa] == va (AGREE: F[fa] != 0), key F[fb].
+ * DEMI_INV_PROGRAM: the rows from inv_fa on, run on a COPY of the actor's state with r15 = its id and everything else 0;
+ * hit = T0 != 0, key = T1 (include/demi_gpu.h). */
+static void inv_actor(const demi_model* m, const uint64_t* st, uint32_t i, uint32_t* hit, uint32_t* key) {
   const int wide = (m->flags & DEMI_MODEL_WIDE) != 0;
-  switch (m->inv_kind) {
+  if (m->inv_kind & DEMI_INV_PROGRAM) {
+    uint64_t copy[2] = {wide ? st[2 * i] : st[i], wide ? st[2 * i + 1] : 0};
+    uint16_t r[16];
+    orc_jrandom none;
+    orc_jrandom_seed(&none, 0);
+    vm_run_at(m, m->inv_fa, i, copy, 0, 0, 0, 0, NULL, 0, &none, r);
+    *hit = r[8] != 0;
+    *key = r[9];
+    return;
+  }
+  const uint32_t a = fldw(wide, st, i, m->inv_fa);
+  *hit = ((m->inv_kind & 0xFFu) == DEMI_INV_AGREE) ? (a != 0) : (a == m->inv_va);
+  *key = fldw(wide, st, i, m->inv_fb);
+}
+
+uint32_t orc_invariant(const demi_model* m, const uint64_t* st, uint32_t exists) {
+  const uint32_t A = m->n_actors;
+  uint32_t hit[DEMI_MAX_ACTORS], key[DEMI_MAX_ACTORS], hits = 0;
+  if ((m->inv_kind & 0xFFu) == DEMI_INV_NONE) return 0;
+  for (uint32_t i = 0; i < A; i++) {
+    hit[i] = 0; key[i] = 0;
+    if ((exists >> i) & 1) inv_actor(m, st, i, &hit[i], &key[i]);
+    hits |= hit[i] << i;
+  }
+  switch (m->inv_kind & 0xFFu) {
     case DEMI_INV_AT_MOST_ONE:
       for (uint32_t i = 0; i < A; i++) {
-        if (!((exists >> i) & 1) || fldw(wide, st, i, fa) != va) continue;
+        if (!hit[i]) continue;
         for (uint32_t j = i + 1; j < A; j++) {
-          if (!((exists >> j) & 1) || fldw(wide, st, j, fa) != va) continue;
-          if (fldw(wide, st, i, fb) != fldw(wide, st, j, fb)) continue;
-          uint32_t key = fldw(wide, st, i, fb), mask = 0;
+          if (!hit[j] || key[i] != key[j]) continue;
+          uint32_t mask = 0;
           for (uint32_t k = 0; k < A; k++)
-            if (((exists >> k) & 1) && fldw(wide, st, k, fa) == va && fldw(wide, st, k, fb) == key) mask |= 1u << k;
-          return (1u << 24) | (key << 8) | mask;
+            if (hit[k] && key[k] == key[i]) mask |= 1u << k;
+          return (1u << 24) | (key[i] << 8) | mask;
         }
       }
       return 0;
-    case DEMI_INV_NEVER: {
-      uint32_t mask = 0;
-      for (uint32_t k = 0; k < A; k++)
-        if (((exists >> k) & 1) && fldw(wide, st, k, fa) == va) mask |= 1u << k;
-      return mask ? (2u << 24) | mask : 0;
-    }
+    case DEMI_INV_NEVER:
+      return hits ? (2u << 24) | hits : 0;
     case DEMI_INV_AGREE: {
-      uint32_t mask = 0, first = 0xFFFFFFFFu, bad = 0;
+      uint32_t first = 0xFFFFFFFFu, bad = 0;
       for (uint32_t k = 0; k < A; k++) {
-        if (!((exists >> k) & 1) || fldw(wide, st, k, fa) == 0) continue;
-        mask |= 1u << k;
-        if (first == 0xFFFFFFFFu) first = fldw(wide, st, k, fb);
-        else if (fldw(wide, st, k, fb) != first) bad = 1;
+        if (!hit[k]) continue;
+        if (first == 0xFFFFFFFFu) first = key[k];
+        else if (key[k] != first) bad = 1;
       }
-      return bad ? (3u << 24) | mask : 0;
+      return bad ? (3u << 24) | hits : 0;
     }
     default:
       return 0;

@@ -477,3 +477,146 @@ def test_explicit_seeds_threads_and_determinism(oracle):
     assert len(hits) > 0
     for fp in hits["fingerprint"]:
         assert fp >> 24 == 1 and bin(int(fp) & 0xFF).count("1") >= 2
+
+
+# --------------------------------------------------------------------------- DEMI_INV_PROGRAM
+def _py_rows(code, start, regs, mask, sh):
+    """plain-Python run of pure rows (ALU / SKIP / IF) from `start`: the semantics include/demi_gpu.h states"""
+    r = list(regs)
+    pc = start
+    while pc < len(code):
+        w = code[pc]; pc += 1
+        op, dst, ai, bimm, aux, braw = w & 0xFF, (w >> 8) & 15, (w >> 12) & 15, (w >> 16) & 1, (w >> 17) & 0x7F, w >> 24
+        a, b = r[ai], (braw if bimm else r[braw & 15])
+        O = M.OPS
+        if op == O["HALT"]:
+            break
+        rel = {O["EQ"]: a == b, O["NE"]: a != b, O["LT"]: a < b, O["GE"]: a >= b, O["LE"]: a <= b, O["GT"]: a > b}
+        ifs = {O["IFEQ"]: a == b, O["IFNE"]: a != b, O["IFLT"]: a < b, O["IFGE"]: a >= b, O["IFLE"]: a <= b, O["IFGT"]: a > b}
+        if op == O["MOV"]: r[dst] = b & mask
+        elif op == O["MOVHI"]: r[dst] = ((a & 0xFF) | (b << 8)) & mask
+        elif op == O["ADD"]: r[dst] = (a + b) & mask
+        elif op == O["SUB"]: r[dst] = (a - b) & mask
+        elif op == O["AND"]: r[dst] = a & b & mask
+        elif op == O["OR"]: r[dst] = (a | b) & mask
+        elif op == O["XOR"]: r[dst] = (a ^ b) & mask
+        elif op == O["SHL"]: r[dst] = (a << (b & sh)) & mask
+        elif op == O["SHR"]: r[dst] = (a >> (b & sh)) & mask
+        elif op == O["BITSET"]: r[dst] = (a | (1 << (b & sh))) & mask
+        elif op == O["POPC"]: r[dst] = bin(b).count("1")
+        elif op == O["MIN"]: r[dst] = min(a, b)
+        elif op == O["MAX"]: r[dst] = max(a, b)
+        elif op in rel: r[dst] = int(rel[op])
+        elif op in ifs: pc += 0 if ifs[op] else aux
+        elif op == O["SKIPZ"]: pc += braw if a == 0 else 0
+        elif op == O["SKIPNZ"]: pc += braw if a != 0 else 0
+        elif op == O["SKIP"]: pc += braw
+        else: raise AssertionError("op %d in a pure program" % op)
+    return r
+
+
+def _py_invariant(model, fields, exists):
+    """the invariant of a DEMI_INV_PROGRAM model on per-actor field lists, in plain Python"""
+    wide = model.wide
+    mask, sh = (0xFFFF, 15) if wide else (0xFF, 7)
+    hit, key = [], []
+    for i in range(model.n_actors):
+        if not (exists >> i) & 1:
+            hit.append(0); key.append(0); continue
+        r = _py_rows(model.code, model.inv_fa, list(fields[i]) + [0] * 7 + [i], mask, sh)
+        hit.append(int(r[8] != 0)); key.append(r[9])
+    hits = sum(h << i for i, h in enumerate(hit))
+    kind = model.inv_kind & 0xFF
+    if kind == T.INV_NEVER:
+        return ((2 << 24) | hits) if hits else 0
+    if kind == T.INV_AGREE:
+        ks = {key[i] for i in range(model.n_actors) if hit[i]}
+        return ((3 << 24) | hits) if len(ks) > 1 else 0
+    for i in range(model.n_actors):
+        for j in range(i + 1, model.n_actors):
+            if hit[i] and hit[j] and key[i] == key[j]:
+                return (1 << 24) | (key[i] << 8) | sum(1 << k for k in range(model.n_actors) if hit[k] and key[k] == key[i])
+    return 0
+
+
+def _random_pure_program(rng, n_rows):
+    """random ALU / SKIP / IF rows that end with values in T0 (hit) and T1 (key)"""
+    from tests.test_jit_cpu import _random_handler
+    a = Asm()
+    regs = [M.Reg(i) for i in range(16)]
+    alu = ["add", "sub", "and_", "or_", "xor", "shl", "shr", "bitset", "eq", "ne", "lt", "ge", "le", "gt", "min", "max"]
+    pending = []
+    for i in range(n_rows):
+        for lab in [l for l in pending if l[1] == i]:
+            a.label(lab[0]); pending.remove(lab)
+        k = int(rng.integers(0, 100))
+        breg = lambda: regs[int(rng.integers(16))] if rng.integers(2) else int(rng.integers(256))
+        if k < 60:
+            getattr(a, alu[int(rng.integers(len(alu)))])(regs[int(rng.integers(8, 12))] if rng.integers(3) else regs[int(rng.integers(12))],
+                                                         regs[int(rng.integers(16))], breg())
+        elif k < 70:
+            a.mov(regs[int(rng.integers(8, 10))], breg())
+        elif k < 75:
+            a.popc(regs[int(rng.integers(8, 12))], breg())
+        else:
+            name = "L%d" % i
+            pending.append((name, i + 1 + int(rng.integers(0, min(5, n_rows - i)))))
+            c = int(rng.integers(0, 9))
+            if c < 6:
+                getattr(a, ["if_eq", "if_ne", "if_lt", "if_ge", "if_le", "if_gt"][c])(regs[int(rng.integers(16))], breg(), name)
+            elif c == 6:
+                a.skipz(regs[int(rng.integers(16))], name)
+            elif c == 7:
+                a.skipnz(regs[int(rng.integers(16))], name)
+            else:
+                a.skip(name)
+    for lab in pending:
+        a.label(lab[0])
+    a.and_(M.T1, M.T1, 15)               # few distinct keys: groups form
+    return a.halt()
+
+
+@pytest.mark.parametrize("wide", [False, True])
+def test_program_invariants_equal_a_plain_python_evaluation(oracle, wide):
+    """DEMI_INV_PROGRAM: the per-actor predicate and key as a row program, under each combining kind - hand-written programs
+    with known answers, then random programs on random states against a plain-Python run of the rows."""
+    ROLE, TERM, LOG = M.F[0], M.F[1], M.F[2]
+    # "a leader (role 2) of a term >= 3 whose log is shorter than 2": a conjunction over three fields, key = term
+    prog = Asm().if_eq(ROLE, 2, "no").if_ge(TERM, 3, "no").if_lt(LOG, 2, "no").mov(M.T0, 1).mov(M.T1, TERM).label("no").halt()
+    msgs = [("E", T.MSG_EXTERNAL), ("I", T.MSG_INTERNAL)]
+    h = {(0, "E"): Asm().add(M.F[3], M.F[3], 1)}
+    m = build_model("prog", 4, msgs, h, [[0] * 8] * 4, (T.INV_AT_MOST_ONE, prog), wide=wide)
+    assert m.inv_kind == (T.INV_AT_MOST_ONE | T.INV_PROGRAM) and oracle.model_validate(m)[0] == 0
+    pack = (lambda f: M.pack_state_wide(f)) if wide else (lambda f: [M.pack_state(f)])
+    def inv(model, fields, exists):
+        st = np.array([w for f in fields for w in pack(f)], dtype=np.uint64)
+        return int(oracle.lib().orc_invariant(C.byref(model.to_struct()), st.ctypes.data, exists))
+    S = lambda role, term, log: [role, term, log, 0, 0, 0, 0, 0]
+    assert inv(m, [S(2, 3, 1), S(2, 3, 0), S(1, 3, 0), S(2, 3, 5)], 15) == (1 << 24) | (3 << 8) | 0b0011      # two such leaders of term 3
+    assert inv(m, [S(2, 3, 1), S(2, 4, 0), S(2, 2, 0), S(2, 3, 2)], 15) == 0                                   # other terms / long log / term 2
+    assert inv(m, [S(2, 3, 1), S(2, 3, 0), S(0, 0, 0), S(0, 0, 0)], 0b0001) == 0                               # the second one does not exist
+    never = build_model("prog", 4, msgs, h, [[0] * 8] * 4, (T.INV_NEVER, prog), wide=wide)
+    assert inv(never, [S(2, 3, 1), S(2, 9, 0), S(1, 3, 0), S(2, 3, 5)], 15) == (2 << 24) | 0b0011
+    agree = build_model("prog", 4, msgs, h, [[0] * 8] * 4, (T.INV_AGREE, prog), wide=wide)
+    assert inv(agree, [S(2, 3, 1), S(2, 9, 0), S(1, 3, 0), S(2, 3, 5)], 15) == (3 << 24) | 0b0011
+    assert inv(agree, [S(2, 3, 1), S(2, 3, 0), S(1, 3, 0), S(2, 3, 5)], 15) == 0
+    # rules: effects / RND are refused, a combining kind is needed
+    bad = build_model("bad", 2, msgs, h, [[0] * 8] * 2, (T.INV_NEVER, Asm().send(1, M.ME, M.T0, 0).halt()), wide=wide)
+    assert oracle.model_validate(bad)[0] == T.ERR_INVALID_MODEL and "invariant program" in oracle.model_validate(bad)[1]
+    bad = build_model("bad", 2, msgs, h, [[0] * 8] * 2, (T.INV_NONE, prog), wide=wide)
+    assert oracle.model_validate(bad)[0] == T.ERR_INVALID_MODEL
+    # random programs, random states
+    rng = np.random.default_rng(5 + wide)
+    hi = 65536 if wide else 256
+    nonzero = 0
+    for trial in range(60):
+        kind = [T.INV_AT_MOST_ONE, T.INV_NEVER, T.INV_AGREE][trial % 3]
+        mm = build_model("rp", 5, msgs, h, [[0] * 8] * 5, (kind, _random_pure_program(rng, int(rng.integers(3, 25)))), wide=wide)
+        assert oracle.model_validate(mm)[0] == 0
+        for _ in range(40):
+            fields = [[int(x) for x in rng.integers(0, hi if rng.integers(2) else 4, 8)] for _ in range(5)]
+            exists = int(rng.integers(0, 32))
+            got, want = inv(mm, fields, exists), _py_invariant(mm, fields, exists)
+            assert got == want, (trial, fields, exists, hex(got), hex(want))
+            nonzero += got != 0
+    assert nonzero > 200
