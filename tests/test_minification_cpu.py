@@ -437,6 +437,26 @@ def test_native_ddmin_loop_equals_the_python_mirror(oracle):
             assert tuple(mcs_n) == tuple(mcs_s) and cons_n == [(tuple(c), p) for c, p in dd_s.consulted]
             assert all(b <= max(budget, 4) * 4 for b in batches_n)
         assert st.launches <= 6                                                                  # a few wide launches instead of one per consultation
+    # explicitly conjoined atoms (UnmodifiedEventDag.conjoinAtoms): two pairs of Sends that may only be removed together
+    model, vv, rec, used = cases[0]
+    fp = ViolationFingerprint(vv.fingerprint)
+    target = T.Limits(0, 0, 128, 1, vv.fingerprint, 0)
+    sends = [i for i in range(len(used)) if int(used[i]["kind"]) == T.EV_SEND]
+    pairs = [(sends[1], sends[6]), (sends[3], sends[4])]
+    dag = UnmodifiedEventDag(used)
+    conj = np.full(len(used), 255, dtype=np.uint8)
+    for a, b in pairs:
+        dag.conjoinAtoms(a, b)
+        conj[a], conj[b] = b, a
+    sts = OracleSTS(oracle, model, used, rec, vv.fingerprint)
+    sts._v = lambda subs: oracle.sts_replay_batch(model, used, rec, np.array([events_to_mask(x) for x in subs], dtype=np.uint64).reshape(-1, 4), target)
+    keep = tuple(i for i in dag.events if int(used[i]["kind"]) != T.EV_WAIT_QUIESCENCE)
+    dd = DDMin(sts, checkUnmodifed=True)
+    mcs_p = dd.minimize(EventDagView(dag, keep), fp).get_all_events()
+    mcs_n, cons_n, _, st = oracle_py.ddmin(model, used, rec, target, T.DdminParams(0, 64, 1, 1), conjoined=conj)
+    assert tuple(mcs_n) == tuple(mcs_p) and cons_n == [(tuple(c), p) for c, p in dd.consulted]
+    for a, b in pairs:
+        assert (a in mcs_n) == (b in mcs_n)
     # an unmodified trace that does not reproduce, and a Kill whose Start is not among the events
     model, vv, rec, used = cases[0]
     with pytest.raises(RuntimeError, match="-1"):

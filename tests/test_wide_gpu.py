@@ -192,10 +192,47 @@ def test_wide_record_replay_minimize(oracle):
     mcs_g, d_g, ver_g = stsSchedDDMin(sts, used, fp, speculative_depth=3)
     mcs_c, d_c, ver_c = stsSchedDDMin(OracleSTS(oracle, model, used, rec, vv.fingerprint), used, fp, speculative_depth=0)
     assert mcs_g == mcs_c and d_g.consulted == d_c.consulted and ver_g is not None and 0 < len(mcs_g) < len(used)
+    verified = sts.executed_trace(mcs_g, fp)
     sts.shutdown()
+    # ... and the removal of internal deliveries from the verified MCS trace: same final trace and replay count as the
+    # one-replay-at-a-time loop over the oracle
+    from demi_amd import internal_minimization as IM
+    from .test_internal_min_cpu import OracleRemoval
+    cfg = SchedulerConfig(model=model)
+    stats, out = IM.minimizeInternals(cfg, verified.original_externals, verified, fp,
+                                      removalStrategyCtor=lambda: IM.LeftToRightOneAtATime(verified, model))
+    rstats, rout = IM.STSSchedMinimizer(verified.original_externals, verified, fp, IM.LeftToRightOneAtATime(verified, model),
+                                        OracleRemoval(oracle, model), max_batch=1).minimize()
+    assert (out.events == rout.events).all() and stats.total_replays == rstats.total_replays
+    assert IM.countMsgEvents(out) < IM.countMsgEvents(verified)
+    # the native DDMin on the same execution
+    ctx = _native.Context(0)
+    try:
+        ctx.model_load(model.to_struct()); ctx.model_specialize(); ctx.replay_load(used, rec)
+        mcs_n, cons_n, _, st = ctx.ddmin(T.Limits(0, 0, 64, 1, vv.fingerprint, 0), T.DdminParams(0, 1024, 1, 1))
+        assert tuple(mcs_n) == tuple(mcs_c) and cons_n == [(tuple(c), p) for c, p in d_c.consulted] and st.verified == 1
+    finally:
+        ctx.close()
+    # DPOR over the wide raft5 of config 3: a budgeted exploration natively in both orders equals the oracle-backed loop
+    from demi_amd.apps import raft5_config3
+    from demi_amd.dpor import DPORwHeuristics
+    _, dev, depth = raft5_config3()
+    d1 = DPORwHeuristics(cfg, depth_bound=depth, stopIfViolationFound=False, batch=1, backend=oracle.dpor_batch)
+    r1 = d1.explore(dev, max_interleavings=120)
+    dr = DPORwHeuristics(cfg, depth_bound=depth, stopIfViolationFound=False, batch=512, specialize=True)
+    rr = dr.explore_native(dev, max_interleavings=120, reference_order=True)
+    assert len(rr.interleavings) == 120 and all(a.verdict == b.verdict and a.prefix_len == b.prefix_len for a, b in zip(rr.interleavings, r1.interleavings))
+    db = DPORwHeuristics(cfg, depth_bound=depth, stopIfViolationFound=False, batch=256, backend=oracle.dpor_batch)
+    rb = db.explore(dev, max_interleavings=1500)
+    dn = DPORwHeuristics(cfg, depth_bound=depth, stopIfViolationFound=False, batch=256, specialize=True)
+    rn = dn.explore_native(dev, max_interleavings=1500)
+    assert rn.rounds == rb.rounds and all(a.verdict == b.verdict and a.prefix_len == b.prefix_len for a, b in zip(rn.interleavings, rb.interleavings))
+    dr.shutdown(); dn.shutdown()
 
 
-def test_wide_models_are_refused_where_they_cannot_run(oracle):
+def test_wide_model_rules_at_the_boundary(oracle):
+    """What is left of round 2's list of refusals: a wide table has no interpreter and no SrcDstFIFO kernel, and 16-bit
+    payloads belong to wide models only."""
     model = M.raft_model(3, term0=1000)
     ev = events_to_array([start(a) for a in range(3)] + [send(a, M.M_BOOTSTRAP) for a in range(3)])
     lim = T.Limits(100, 10, 64, 0, 0, 0)
