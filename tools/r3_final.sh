@@ -9,6 +9,9 @@ timeout 1200 python -m pytest tests -m gpu -x -q --timeout 600 > gpurun_out/r03_
 timeout 300 python __graft_entry__.py --smoke 2>&1 | tail -1
 timeout 1500 bash tools/profile_r3.sh > gpurun_out/r03_profile.log 2>&1; tail -3 gpurun_out/r03_profile.log
 cp gpurun_out/r03_k1_counters.json profiles/k1_counters.json
+# the K2 / K3 profiles first: the dpor record quotes its `traffic` from the counters of THIS build
+timeout 1200 bash tools/profile_r3_k2k3.sh > gpurun_out/r03_profile_k2k3.log 2>&1; tail -2 gpurun_out/r03_profile_k2k3.log
+cp gpurun_out/r03_dpor_counters.json profiles/r03_dpor_counters.json
 timeout 900 python bench.py --steps 20 --warmup 5 > gpurun_out/r03_bench_1gpu.json 2> gpurun_out/r03_bench_1gpu.err
 timeout 300 python bench.py --steps 20 --warmup 5 --no-specialize --no-secondary > gpurun_out/r03_bench_1gpu_interpreter.json 2>/dev/null
 timeout 300 python bench.py --steps 20 --warmup 5 --strategy fifo --no-secondary > gpurun_out/r03_bench_1gpu_srcdstfifo.json 2>/dev/null
@@ -31,7 +34,6 @@ if 'value' in r:
     print('ddmin', round(r['value']), 'frac', r['roofline']['frac'], r['ddmin_end_to_end'], r.get('random_ddmin_R100'), r['launch_floor'], 'cpu', round(r['cpu_baseline']['value']), r['cpu_baseline']['ddmin_end_to_end'])
 else: print('ddmin', r)
 PY
-timeout 1200 bash tools/profile_r3_k2k3.sh > gpurun_out/r03_profile_k2k3.log 2>&1; tail -2 gpurun_out/r03_profile_k2k3.log
 # the latency-bound kernels' phase splits (diagnostic builds of the compiled kernels; proportions only)
 timeout 300 bash tools/k3_phases.sh > gpurun_out/r03_k3_phases.txt 2>&1; tail -2 gpurun_out/r03_k3_phases.txt
 timeout 300 bash tools/k2_phases.sh > gpurun_out/r03_k2_phases.txt 2>&1; tail -2 gpurun_out/r03_k2_phases.txt
