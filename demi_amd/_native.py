@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libdemi_gpu.so")
 EXPORTS = ["demi_ctx_create", "demi_ctx_destroy", "demi_last_error", "demi_version", "demi_model_load",
            "demi_trace_load", "demi_random_explore", "demi_random_explore_dev", "demi_random_get_trace", "demi_collect_violations_dev",
            "demi_replay_load", "demi_replay_batch", "demi_replay_batch_dev", "demi_dpor_load", "demi_dpor_batch", "demi_dpor_explore", "demi_random_explore_violations", "demi_random_get_trace_carried",
-           "demi_replay_removal_batch", "demi_replay_get_kept", "demi_replay_recorded_len", "demi_ddmin", "demi_model_specialize", "demi_model_is_specialized", "demi_model_code_id",
+           "demi_replay_removal_batch", "demi_replay_get_kept", "demi_replay_recorded_len", "demi_ddmin", "demi_dpor_set_traces", "demi_model_specialize", "demi_model_is_specialized", "demi_model_code_id",
            "demi_specialize_check", "demi_specialize_source", "demi_specialize_source_k1", "demi_provenance_prune", "demi_device_probe", "demi_device_probe_mix", "demi_calib_rw", "demi_random_explore_flagged", "demi_collect_flagged_dev",
            "demi_comm_unique_id", "demi_comm_create", "demi_comm_create_host", "demi_comm_destroy", "demi_comm_rank",
            "demi_comm_allgather_dev", "demi_random_explore_sharded", "demi_replay_batch_sharded"]
@@ -57,6 +57,8 @@ def lib():
     L.demi_model_code_id.restype = C.c_uint64
     L.demi_specialize_check.argtypes = [C.POINTER(T.ModelStruct), C.c_char_p, C.c_size_t]
     L.demi_specialize_check.restype = C.c_long
+    L.demi_dpor_set_traces.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
+    L.demi_dpor_set_traces.restype = C.c_int
     L.demi_ddmin.argtypes = [C.c_void_p, C.POINTER(T.Limits), C.POINTER(T.DdminParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                              C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(T.DdminStats)]
     L.demi_ddmin.restype = C.c_int
@@ -315,6 +317,15 @@ class Context:
                                               verdicts.ctypes.data, traces.ctypes.data, tl.ctypes.data,
                                               pairs.ctypes.data, npairs.ctypes.data))
         return verdicts, [traces[i, :tl[i]].copy() for i in range(n)], [pairs[i, :npairs[i]].copy() for i in range(n)]
+
+    def dpor_set_traces(self, original_trace=None, initial_trace=None):
+        """ArvindDistanceOrdering.init(sched, originalTrace) and DPORwHeuristics.setInitialTrace for the following dpor_explore
+        calls (DPOR_TRACE_DTYPE arrays; None clears)."""
+        import numpy as np
+        keys = np.ascontiguousarray(np.asarray(original_trace)["key"], dtype=np.uint64) if original_trace is not None else np.zeros(0, dtype=np.uint64)
+        init = np.ascontiguousarray(initial_trace, dtype=T.DPOR_TRACE_DTYPE) if initial_trace is not None else np.zeros(0, dtype=T.DPOR_TRACE_DTYPE)
+        self._check(lib().demi_dpor_set_traces(self._h, keys.ctypes.data if len(keys) else None, len(keys),
+                                               init.ctypes.data if len(init) else None, len(init)))
 
     def dpor_explore(self, params, search):
         """The whole exploration natively: returns (verdicts, prefix_len, rounds, first violating trace, stats)."""

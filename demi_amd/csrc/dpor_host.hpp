@@ -25,6 +25,7 @@
 #include <cstring>
 #include <deque>
 #include <memory>
+#include <queue>
 #include <algorithm>
 #include <thread>
 #include <unordered_map>
@@ -475,6 +476,168 @@ int explore_rounds(Run&& run, Fetch&& fetch, uint32_t max_pairs, const demi_dpor
   return 0;
 }
 
+struct PairKeyHash {
+  size_t operator()(const std::pair<uint64_t, uint64_t>& k) const {
+    return (size_t)((k.first * 0x9E3779B97F4A7C15ULL) ^ (k.second * 0xC2B2AE3D27D4EB4FULL) ^ (k.first >> 29));
+  }
+};
+
+// ------------------------------------------------------------------ other backtrack orderings, distance cap, initial trace
+// DPORwHeuristics with a `backtrackHeuristic` other than DefaultBacktrackOrdering, with setMaxDistance and / or
+// setInitialTrace (DPORwHeuristics.scala:63-90, 131-134, 211-213): what IncrementalDDMin's DPOR consultations use
+// (ArvindDistanceOrdering, BacktrackOrdering.scala:99-173).  The shortcuts of explore_rounds do not hold here - a backtrack
+// point whose flipped pair is already explored may not be dropped when it is created (getNext() looks at the queue's head
+// before it pops: the head's distance against the cap), and the shared-prefix filter assumes the default priority - so this
+// is the plain loop: one priority queue of (priority, creation order), every racing pair enqueued, explored flips skipped
+// at pop time (:1153-1157), the queue kept when the head reaches the cap ("Tutto finito", :1144-1150).  Single-threaded; the
+// interleavings still run `batch` at a time.  Same rounds, verdicts and prefix lengths as the Python mirror
+// (demi_amd/dpor.py DPORwHeuristics.explore with ArvindDistanceOrdering / setMaxDistance / setInitialTrace).
+struct OrderedSearch {
+  uint32_t ordering = 0;                         // demi_dpor_ordering
+  bool capped = false;                           // setMaxDistance called
+  uint32_t max_distance = 0;
+  std::unordered_map<uint64_t, uint32_t> original_index;   // ArvindDistanceOrdering.init: node key -> index in the original trace
+  Trace initial;                                 // setInitialTrace: the first interleaving's next trace
+};
+
+// arvindDistance (BacktrackOrdering.scala:116-143) of the backtrack point (branch, later, earlier) of trace T: events of its
+// path the original did not contain, plus misordered pairs among those it did.  The path: the causal chain root .. later
+// (getCommonPrefix(later, later)), the events to replay, then (later, earlier) (:117-123).
+inline uint32_t arvind_distance(const OrderedSearch& o, const demi_dpor_trace_entry* T, uint32_t branch, uint32_t later, uint32_t earlier) {
+  uint32_t chain[DEMI_DPOR_MAX_TRACE + 1], nc = 0;
+  for (uint32_t k = later;; k = T[k].parent) { chain[nc++] = k; if (k == 0 || nc > DEMI_DPOR_MAX_TRACE) break; }
+  int32_t idx[2 * DEMI_DPOR_MAX_TRACE + 4];
+  uint32_t n = 0;
+  auto at = [&](uint32_t i) { auto it = o.original_index.find(T[i].key); idx[n++] = it == o.original_index.end() ? -1 : (int32_t)it->second; };
+  for (uint32_t k = nc; k-- > 0;) at(chain[k]);
+  for (uint32_t i = branch + 1; i <= later; i++) if (i != earlier) at(i);
+  at(later); at(earlier);
+  uint32_t distance = 0;
+  for (uint32_t i = 0; i < n; i++) {
+    if (idx[i] < 0) { distance++; continue; }
+    for (uint32_t j = 0; j < i; j++) if (idx[j] >= 0 && idx[j] > idx[i]) distance++;
+  }
+  return distance;
+}
+
+template <class Run, class Fetch>
+int explore_rounds_ordered(Run&& run, Fetch&& fetch, uint32_t max_pairs, const demi_dpor_search* srch, const OrderedSearch& ord,
+                           demi_verdict* out_verdicts, uint32_t* out_prefix_len, uint32_t* out_rounds,
+                           demi_dpor_trace_entry* first_violation_trace, uint32_t* first_violation_len, demi_dpor_stats* stats,
+                           RawBuf* trace_buf = nullptr, RawBuf* pair_buf = nullptr) {
+  RawBuf own_tr([](size_t b) { return malloc(b); }, [](void* q) { free(q); });
+  RawBuf own_pr([](size_t b) { return malloc(b); }, [](void* q) { free(q); });
+  RawBuf& tr_buf = trace_buf ? *trace_buf : own_tr;
+  RawBuf& pr_buf = pair_buf ? *pair_buf : own_pr;
+  auto* tr = static_cast<demi_dpor_trace_entry*>(tr_buf.reserve(sizeof(demi_dpor_trace_entry) * DEMI_DPOR_MAX_TRACE * EXPLORE_CHUNK));
+  auto* pr = static_cast<demi_dpor_pair*>(pr_buf.reserve(sizeof(demi_dpor_pair) * (size_t)(max_pairs ? max_pairs : 1) * EXPLORE_CHUNK));
+  if (!tr || !pr) return DEMI_ERR_INVALID_ARG;
+  memset(stats, 0, sizeof *stats);
+  stats->first_violation = ~0ull;
+  if (first_violation_len) *first_violation_len = 0;
+  const bool track = srch->track_history != 0;
+
+  // a queued point: (distance, branch) compares as the reference's Ordered does - the GREATER one is dequeued first
+  // (:155-165 with scala's max-PriorityQueue), ties in creation order; it keeps the trace that found it
+  struct Point { uint32_t distance, branch; uint64_t seq; uint64_t flip_a, flip_b; std::shared_ptr<Trace> trace; uint8_t later, earlier; };
+  auto before = [](const Point& x, const Point& y) {        // "x is dequeued after y"
+    if (x.distance != y.distance) return x.distance < y.distance;
+    if (x.branch != y.branch) return x.branch < y.branch;
+    return x.seq > y.seq;
+  };
+  std::priority_queue<Point, std::vector<Point>, decltype(before)> queue(before);
+  std::unordered_set<std::pair<uint64_t, uint64_t>, PairKeyHash> explored;
+  uint64_t seq = 0;
+
+  auto get_next = [&](Trace& out) -> bool {                 // getNext (:1142-1185)
+    while (!queue.empty()) {
+      const Point& head = queue.top();
+      if (ord.capped && head.distance >= ord.max_distance) return false;      // the queue is kept
+      const Point p = head;
+      queue.pop();
+      if (track && explored.count({p.flip_a, p.flip_b})) continue;
+      if (track) explored.insert({p.flip_a, p.flip_b});
+      const Trace& T = *p.trace;
+      out.assign(T.begin(), T.begin() + p.branch + 1);
+      for (uint32_t i = p.branch + 1; i <= p.later; i++) if (i != p.earlier) out.push_back(T[i]);
+      return true;
+    }
+    return false;
+  };
+
+  std::vector<Trace> frontier(1, ord.initial);              // first run: the initial trace, or empty
+  std::vector<uint32_t> shared(1, 0u);
+  std::vector<demi_dpor_trace_entry> pf;
+  std::vector<uint32_t> pl, tl, np;
+  std::vector<demi_verdict> vd;
+  bool stopped = false;
+  while (!frontier.empty()) {
+    const size_t n = frontier.size();
+    size_t stride = 1;
+    for (auto& f : frontier) stride = f.size() > stride ? f.size() : stride;
+    pf.resize(n * stride);
+    pl.resize(n); tl.resize(n); np.resize(n); vd.resize(n);
+    shared.assign(n, 0u);                                   // (no shared-prefix filter: every racing pair is reported)
+    for (size_t i = 0; i < n; i++) {
+      pl[i] = (uint32_t)frontier[i].size();
+      if (pl[i]) memcpy(&pf[i * stride], frontier[i].data(), sizeof(demi_dpor_trace_entry) * pl[i]);
+    }
+    int rc = run(pf.data(), pl.data(), shared.data(), (uint32_t)stride, (uint64_t)n, vd.data(), tl.data(), np.data());
+    if (rc) return rc;
+    if (out_rounds) out_rounds[stats->launches] = (uint32_t)n;
+    stats->launches++;
+    stats->executed += n;
+    bool found = false;
+    size_t first_here = n;
+    for (size_t i = 0; i < n; i++) {
+      const uint64_t idx = stats->interleavings++;
+      out_verdicts[idx] = vd[i];
+      out_prefix_len[idx] = pl[i];
+      if (vd[i].flags & DEMI_V_VIOLATION) {
+        stats->violations++;
+        found = true;
+        if (stats->first_violation == ~0ull) { stats->first_violation = idx; first_here = i; }
+      }
+    }
+    for (size_t lo = 0; lo < n; lo += EXPLORE_CHUNK) {
+      const size_t cnt = n - lo < EXPLORE_CHUNK ? n - lo : EXPLORE_CHUNK;
+      rc = fetch(lo, cnt, tr, pr);
+      if (rc) return rc;
+      if (first_here >= lo && first_here < lo + cnt) {
+        const size_t k = first_here - lo;
+        if (first_violation_trace) memcpy(first_violation_trace, &tr[k * DEMI_DPOR_MAX_TRACE], sizeof(demi_dpor_trace_entry) * tl[first_here]);
+        if (first_violation_len) *first_violation_len = tl[first_here];
+      }
+      // dpor()'s bookkeeping for each finished interleaving (:1122-1139): setExplored(branch, (earlier, later)), enqueue
+      for (size_t k = 0; k < cnt; k++) {
+        const demi_dpor_trace_entry* T = &tr[k * DEMI_DPOR_MAX_TRACE];
+        const demi_dpor_pair* P = &pr[k * (size_t)(max_pairs ? max_pairs : 1)];
+        if (np[lo + k] == 0) continue;
+        auto keep = std::make_shared<Trace>(T, T + tl[lo + k]);
+        for (uint32_t q = 0; q < np[lo + k]; q++) {
+          const demi_dpor_pair p = P[q];
+          const uint64_t ke = T[p.earlier].key, kl = T[p.later].key;
+          if (track) explored.insert({ke, kl});
+          const uint32_t dist = ord.ordering == DEMI_DPOR_ORDERING_ARVIND ? arvind_distance(ord, T, p.branch, p.later, p.earlier) : 0u;
+          queue.push(Point{dist, p.branch, seq++, kl, ke, keep, p.later, p.earlier});
+          stats->backtrack_points++;
+        }
+      }
+    }
+    frontier.clear();
+    if (srch->stop_if_violation && found) { stopped = true; break; }
+    if (stats->interleavings >= srch->max_interleavings) { stopped = true; break; }
+    while (frontier.size() < srch->batch && stats->interleavings + frontier.size() < srch->max_interleavings) {
+      Trace nxt;
+      if (!get_next(nxt)) break;
+      frontier.push_back(std::move(nxt));
+    }
+  }
+  stats->queue_len = queue.size();
+  stats->exhausted = (!stopped && queue.empty()) ? 1u : 0u;
+  return 0;
+}
+
 // ------------------------------------------------------------------ REFERENCE order
 // The sequence of interleavings of batch = 1 (DPORwHeuristics' own order), with the device running ahead.
 //
@@ -810,11 +973,6 @@ int explore_reference_order(Run&& run, Fetch&& fetch, uint32_t max_pairs, const 
 //   dev.fetch_trace(id, out, &len)                                 one finished trace (the first violation's)
 // With several GPUs every rank runs this same loop on identical queues (SPMD): dev.round() returns the same verdicts,
 // points and kills on every rank, whatever part of the round and of the explored-pair table that rank worked on.
-struct PairKeyHash {
-  size_t operator()(const std::pair<uint64_t, uint64_t>& k) const {
-    return (size_t)((k.first * 0x9E3779B97F4A7C15ULL) ^ (k.second * 0xC2B2AE3D27D4EB4FULL) ^ (k.first >> 29));
-  }
-};
 
 template <class Dev>
 int explore_rounds_resident(Dev&& dev, const demi_dpor_search* srch, demi_verdict* out_verdicts, uint32_t* out_prefix_len,

@@ -96,6 +96,7 @@ class ArvindDistanceOrdering:
         self.originalIndices: Dict[int, int] = {}
 
     def init(self, sched, originalTrace: np.ndarray):
+        self.originalTrace = np.ascontiguousarray(originalTrace, dtype=T.DPOR_TRACE_DTYPE)        # (explore_native hands it to the library)
         self.originalIndices = {int(k): i for i, k in enumerate(np.asarray(originalTrace)["key"].tolist())}
 
     def arvindDistance(self, trace: np.ndarray, branch: int, later: int, earlier: int) -> int:
@@ -303,10 +304,15 @@ class DPORwHeuristics:
         reference_order: commit the interleavings in DPORwHeuristics' own one-at-a-time order (the sequence batch = 1
         gives) while the device speculates `batch` wide (DEMI_DPOR_ORDER_REFERENCE)."""
         from . import _native
-        if not isinstance(self.backtrackHeuristic, DefaultBacktrackOrdering) or self.should_cap_distance or \
-                self._initialTrace is not None:
-            raise NotImplementedError("demi_dpor_explore implements DefaultBacktrackOrdering without a distance cap; "
-                                      "use explore() for ArvindDistanceOrdering / setMaxDistance / setInitialTrace")
+        arvind = isinstance(self.backtrackHeuristic, ArvindDistanceOrdering)
+        if not arvind and type(self.backtrackHeuristic) is not DefaultBacktrackOrdering:
+            raise NotImplementedError("demi_dpor_explore knows DefaultBacktrackOrdering and ArvindDistanceOrdering; use explore()")
+        if self._started and self.backTrack:
+            raise NotImplementedError("demi_dpor_explore starts from the initial trace at every call; a ResumableDPOR that "
+                                      "continues from its queue uses explore()")
+        ordered = arvind or self.should_cap_distance or self._initialTrace is not None
+        if ordered and reference_order:
+            raise NotImplementedError("the reference order runs with DefaultBacktrackOrdering, no cap and no initial trace")
         externals = np.ascontiguousarray(externals, dtype=T.EXT_EVENT_DTYPE)
         if self._ctx is None:
             self._ctx = _native.Context(self._device)
@@ -315,7 +321,11 @@ class DPORwHeuristics:
                 self._ctx.model_specialize()
             self._ctx.dpor_load(externals)
         search = T.DporSearch(self.batch, max_interleavings, 1 if self.stopIfViolationFound else 0,
-                              1 if self.trackHistory else 0, T.DPOR_ORDER_REFERENCE if reference_order else T.DPOR_ORDER_ROUNDS)
+                              1 if self.trackHistory else 0, T.DPOR_ORDER_REFERENCE if reference_order else T.DPOR_ORDER_ROUNDS, 0,
+                              T.DPOR_ORDERING_ARVIND if arvind else T.DPOR_ORDERING_DEFAULT,
+                              self.stop_at_distance if self.should_cap_distance else None)
+        if ordered:
+            self._ctx.dpor_set_traces(getattr(self.backtrackHeuristic, "originalTrace", None) if arvind else None, self._initialTrace)
         verdicts, plen, rounds, vtrace, stats = self._ctx.dpor_explore(self._params(lookingFor), search)
         res = Exploration()
         res.rounds = [int(r) for r in rounds]

@@ -117,10 +117,14 @@ class DporParams(C.Structure):
 
 class DporSearch(C.Structure):
     _fields_ = [("batch", C.c_uint32), ("max_interleavings", C.c_uint32), ("stop_if_violation", C.c_uint32),
-                ("track_history", C.c_uint32), ("order", C.c_uint32), ("cache_mb", C.c_uint32)]
+                ("track_history", C.c_uint32), ("order", C.c_uint32), ("cache_mb", C.c_uint32),
+                ("ordering", C.c_uint32), ("max_distance_plus1", C.c_uint32)]
 
-    def __init__(self, batch=1, max_interleavings=1, stop_if_violation=0, track_history=1, order=0, cache_mb=0):
-        super().__init__(batch, max_interleavings, stop_if_violation, track_history, order, cache_mb)
+    def __init__(self, batch=1, max_interleavings=1, stop_if_violation=0, track_history=1, order=0, cache_mb=0, ordering=0,
+                 max_distance=None):
+        """ordering: DPOR_ORDERING_*; max_distance: None = no cap, k = setMaxDistance(k)"""
+        super().__init__(batch, max_interleavings, stop_if_violation, track_history, order, cache_mb, ordering,
+                         0 if max_distance is None else int(max_distance) + 1)
 
 
 class DporStats(C.Structure):
@@ -135,6 +139,7 @@ class ProbeResult(C.Structure):
                 ("num_cu", C.c_uint32)]
 
 
+DPOR_ORDERING_DEFAULT, DPOR_ORDERING_ARVIND = 0, 1      # demi_dpor_ordering (BacktrackOrdering.scala)
 DPOR_ORDER_ROUNDS = 0       # demi_dpor_order
 DPOR_ORDER_REFERENCE = 1
 

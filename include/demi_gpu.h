@@ -463,7 +463,24 @@ typedef struct {
   uint32_t track_history;       /* trackHistory */
   uint32_t order;               /* demi_dpor_order */
   uint32_t cache_mb;            /* REFERENCE order: host memory for speculated results not yet committed (0 = 1024) */
+  uint32_t ordering;            /* demi_dpor_ordering: the backtrackHeuristic (DPORwHeuristics.scala:69) */
+  uint32_t max_distance_plus1;  /* 0 = no cap; k + 1 = setMaxDistance(k) (:131-134): getNext() gives up - the queue is kept - once its
+                                   head is at least k away from the original execution */
 } demi_dpor_search;
+
+/* BacktrackOrdering.scala: DEFAULT = DefaultBacktrackOrdering (:58-69, deepest branch first, distance 0);
+ * ARVIND = ArvindDistanceOrdering (:99-173): a backtrack point's priority is (distance from the original execution, branch) -
+ * events of its path the original trace lacks + misordered pairs among those it has; needs demi_dpor_set_traces.
+ * With ARVIND, a distance cap or an initial trace, demi_dpor_explore runs the plain loop of the reference (ROUNDS order,
+ * host bookkeeping, every racing pair enqueued and explored flips skipped at pop time) - the shortcuts of the default path
+ * assume the default priority.  Single rank; DEMI_DPOR_ORDER_REFERENCE is refused with them.  Every call starts from the
+ * initial trace (the Python mirror's ResumableDPOR, which continues from the queue of an earlier call, stays the mirror's). */
+typedef enum { DEMI_DPOR_ORDERING_DEFAULT = 0, DEMI_DPOR_ORDERING_ARVIND = 1 } demi_dpor_ordering;
+/* ArvindDistanceOrdering.init(sched, originalTrace) (:115-123) and DPORwHeuristics.setInitialTrace (:211-213): the node keys of
+ * the original execution, and the next trace of the first interleaving (key, word, kind are read).  (NULL, 0) clears either.
+ * Kept until the next demi_dpor_load. */
+int demi_dpor_set_traces(demi_ctx* ctx, const uint64_t* original_keys, uint32_t n_original,
+                         const demi_dpor_trace_entry* initial_trace, uint32_t n_initial);
 
 typedef struct {
   uint64_t interleavings;       /* executed */

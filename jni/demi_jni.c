@@ -14,7 +14,7 @@
  *   events    byte[8 * n]     demi_ext_event          recorded  byte[16 * n]  demi_rec_event
  *   verdicts  long[2 * n]     demi_verdict (long 0 = flags | fingerprint << 32, long 1 = hash)
  *   masks     long[4 * n]     candidate subsequences  violations long[2 * n]  demi_violation (index, fingerprint | flags << 32)
- *   limits    int[9]          demi_limits             dporParams int[7]  demi_dpor_params     dporSearch int[6]  demi_dpor_search
+ *   limits    int[9]          demi_limits             dporParams int[7]  demi_dpor_params     dporSearch int[8]  demi_dpor_search
  *   dporStats long[13]        demi_dpor_stats (kernel_ms as raw double bits; fetches last)                                       */
 #include <jni.h>
 #include <stdint.h>
@@ -278,12 +278,13 @@ JNIEXPORT jint JNICALL FN(dporExplore)(JNIEnv* e, jclass c, jlong h, jintArray p
                                       jintArray prefixLen, jintArray rounds, jbyteArray firstViolationTrace, jlongArray stats) {
   demi_dpor_params par;
   demi_dpor_search srch;
-  jint s[6];
+  jint s[8];
   (void)c;
-  if (dpor_params_of(e, params, &par) || LEN(search) != 6 || LEN(stats) != 13) return DEMI_ERR_INVALID_ARG;
-  (*e)->GetIntArrayRegion(e, search, 0, 6, s);
+  if (dpor_params_of(e, params, &par) || LEN(search) != 8 || LEN(stats) != 13) return DEMI_ERR_INVALID_ARG;
+  (*e)->GetIntArrayRegion(e, search, 0, 8, s);
   srch.batch = (uint32_t)s[0]; srch.max_interleavings = (uint32_t)s[1]; srch.stop_if_violation = (uint32_t)s[2];
   srch.track_history = (uint32_t)s[3]; srch.order = (uint32_t)s[4]; srch.cache_mb = (uint32_t)s[5];
+  srch.ordering = (uint32_t)s[6]; srch.max_distance_plus1 = (uint32_t)s[7];
   const int64_t cap = (int64_t)srch.max_interleavings;
   if (LEN(verdicts) < 2 * cap || LEN(prefixLen) < cap || (rounds && LEN(rounds) < cap) ||
       (firstViolationTrace && LEN(firstViolationTrace) < (int64_t)sizeof(demi_dpor_trace_entry) * DEMI_DPOR_MAX_TRACE))
@@ -328,6 +329,21 @@ JNIEXPORT jint JNICALL FN(provenancePrune)(JNIEnv* e, jclass c, jlong h, jbyteAr
   PUT_INTS(affected, a, JNI_ABORT);
   PUT_INTS(traceLen, l, JNI_ABORT);
   PUT_BYTES(traces, t, JNI_ABORT);
+  return rc;
+}
+
+/* ArvindDistanceOrdering.init / setInitialTrace for the following dporExplore calls: originalKeys long[n] (node keys) or null,
+ * initialTrace byte[16 * m] (demi_dpor_trace_entry) or null */
+JNIEXPORT jint JNICALL FN(dporSetTraces)(JNIEnv* e, jclass c, jlong h, jlongArray originalKeysOrNull, jbyteArray initialTraceOrNull) {
+  (void)c;
+  const int64_t lk = originalKeysOrNull ? LEN(originalKeysOrNull) : 0, lt = initialTraceOrNull ? LEN(initialTraceOrNull) : 0;
+  if (lk < 0 || lt < 0 || lt % (int64_t)sizeof(demi_dpor_trace_entry)) return DEMI_ERR_INVALID_ARG;
+  void* k = LONGS(originalKeysOrNull);
+  void* t = BYTES(initialTraceOrNull);
+  jint rc = demi_dpor_set_traces(CTX(h), (const uint64_t*)k, (uint32_t)lk, (const demi_dpor_trace_entry*)t,
+                                 (uint32_t)(lt / (int64_t)sizeof(demi_dpor_trace_entry)));
+  PUT_BYTES(initialTraceOrNull, t, JNI_ABORT);
+  PUT_LONGS(originalKeysOrNull, k, JNI_ABORT);
   return rc;
 }
 

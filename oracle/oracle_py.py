@@ -327,3 +327,32 @@ def ddmin(model, original_externals, original_trace, limits, params=None, conjoi
         raise RuntimeError("harness_ddmin: %d" % rc)
     return T.mask_to_events(mcs), [(T.mask_to_events(consulted[i]), bool(passed[i])) for i in range(min(cap, st.consultations))], \
         [int(b) for b in batches[:st.launches]], st
+
+
+def dpor_explore_ordered(model, externals, params, search, original_trace=None, initial_trace=None, n_threads=None):
+    """DPORwHeuristics with ArvindDistanceOrdering / setMaxDistance / setInitialTrace natively (dpor_host.hpp explore_rounds_ordered,
+    what demi_dpor_explore runs for them) around this oracle's interleavings.  Returns (verdicts, prefix_len, rounds, first
+    violating trace, stats)."""
+    build()
+    H = C.CDLL(os.path.join(_HERE, "_build", "dpor_host_harness.so"))
+    H.harness_dpor_explore_ordered.argtypes = [C.POINTER(T.ModelStruct), C.c_void_p, C.c_uint32, C.POINTER(T.DporParams), C.POINTER(T.DporSearch),
+                                               C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                               C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(T.DporStats)]
+    ms = model.to_struct()
+    ev = np.ascontiguousarray(externals, dtype=T.EXT_EVENT_DTYPE)
+    keys = np.ascontiguousarray(np.asarray(original_trace)["key"], dtype=np.uint64) if original_trace is not None else np.zeros(0, dtype=np.uint64)
+    init = np.ascontiguousarray(initial_trace, dtype=T.DPOR_TRACE_DTYPE) if initial_trace is not None else np.zeros(0, dtype=T.DPOR_TRACE_DTYPE)
+    cap = search.max_interleavings
+    verdicts = np.zeros(cap, dtype=T.VERDICT_DTYPE)
+    plen = np.zeros(cap, dtype=np.uint32)
+    rounds = np.zeros(cap, dtype=np.uint32)
+    vt = np.zeros(T.DPOR_MAX_TRACE, dtype=T.DPOR_TRACE_DTYPE)
+    vl = C.c_uint32(0)
+    stats = T.DporStats()
+    rc = H.harness_dpor_explore_ordered(C.byref(ms), ev.ctypes.data, len(ev), C.byref(params), C.byref(search),
+                                        keys.ctypes.data if len(keys) else None, len(keys), init.ctypes.data if len(init) else None, len(init),
+                                        n_threads or (os.cpu_count() or 1), verdicts.ctypes.data, plen.ctypes.data, rounds.ctypes.data,
+                                        vt.ctypes.data, C.byref(vl), C.byref(stats))
+    assert rc == 0, rc
+    n = int(stats.interleavings)
+    return verdicts[:n].copy(), plen[:n].copy(), rounds[:int(stats.launches)].copy(), vt[:vl.value].copy(), stats

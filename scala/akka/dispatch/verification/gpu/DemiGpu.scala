@@ -35,6 +35,8 @@ object DemiGpu {
   @native def replayGetKept(h: Long, maskOrNull: Array[Long], skip: Int, limits: Array[Int], verdict: Array[Long], kept: Array[Byte]): Int
   @native def dporLoad(h: Long, externals: Array[Byte]): Int
   /** returns the length of the first violating trace (entries of 16 bytes in firstViolationTrace), or a negative status */
+  /** ArvindDistanceOrdering.init(sched, originalTrace) / setInitialTrace for the following dporExplore calls (node keys; 16-byte trace entries) */
+  @native def dporSetTraces(h: Long, originalKeysOrNull: Array[Long], initialTraceOrNull: Array[Byte]): Int
   @native def dporExplore(h: Long, params: Array[Int], search: Array[Int], verdicts: Array[Long], prefixLen: Array[Int],
                           rounds: Array[Int], firstViolationTrace: Array[Byte], stats: Array[Long]): Int
   /** ProvenanceTracker.pruneConcurrentEvents for n traces (16-byte entries, `stride` per trace); keep: 4 longs (256 bits) per trace */

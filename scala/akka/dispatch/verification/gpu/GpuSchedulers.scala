@@ -313,7 +313,8 @@ class GpuDPOR(val schedulerConfig: SchedulerConfig, lowering: TableLowering, dep
     check(h, dporLoad(h, FlatEvents.pack(events, lowering)))      // Start / Send / WaitQuiescence only (DPORwHeuristics.scala:692-710)
     val params = Array(depthBound, maxMessagesToSchedule, 1, lowering.fingerprintCode(fp), 64, 4096, 0)
     val search = Array(batch, maxInterleavings, if (stopIfViolationFound) 1 else 0, 1,
-                       if (referenceOrder) DPOR_ORDER_REFERENCE else DPOR_ORDER_ROUNDS, 0)
+                       if (referenceOrder) DPOR_ORDER_REFERENCE else DPOR_ORDER_ROUNDS, 0,
+                       0 /* DefaultBacktrackOrdering; 1 = ArvindDistanceOrdering after dporSetTraces */, 0 /* no distance cap */)
     val verdicts = new Array[Long](2 * maxInterleavings); val plen = new Array[Int](maxInterleavings)
     val rounds = new Array[Int](maxInterleavings); val vt = new Array[Byte](16 * 256); val st = new Array[Long](13)
     val vlen = check(h, dporExplore(h, params, search, verdicts, plen, rounds, vt, st))

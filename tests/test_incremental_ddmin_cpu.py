@@ -137,3 +137,48 @@ def test_edit_distance_dpor_ddmin_end_to_end(oracle):
     assert ddmin.distances[0][0] == 0 and ddmin._stats.total_replays > 0
     # one DPOR instance per consulted subsequence, reused across distance rounds
     assert len(ddmin.oracle.subseqToDPOR) >= len({c for c, _ in ddmin.ddmin.consulted})
+
+
+@pytest.mark.parametrize("which", ["two_writers", "raft3"])
+def test_native_ordered_exploration_equals_the_python_mirror(oracle, which):
+    """demi_dpor_explore's plain loop for ArvindDistanceOrdering / setMaxDistance / setInitialTrace (dpor_host.hpp
+    explore_rounds_ordered, here around the oracle's interleavings) against the Python mirror's explore() of a fresh
+    DPORwHeuristics: the same rounds, verdicts (incl. the delivery hashes), prefix lengths and exhaustion - with the Arvind
+    ordering uncapped and capped at several distances, with the default ordering under a cap, with and without an initial
+    trace, one at a time and in rounds."""
+    from oracle import oracle_py
+    if which == "two_writers":
+        model = two_writers_model()
+        ev = events_to_array([start(0), start(1), start(2), send(1, 0), send(2, 0), send(1, 0)])
+        depth, budget = 0, 400
+    else:
+        model = M.raft_model(3)
+        ev = events_to_array([start(a) for a in range(3)] + [send(a, M.M_BOOTSTRAP) for a in range(3)])
+        depth, budget = 30, 300
+    _, trace = _execution(oracle, model, ev, want_violation=False, lim=T.Limits(60, 0, 64, 0, 0, 0))
+    init = dpor_initial_trace(trace)
+    par = T.DporParams(depth, 0, 0, 0, 64, 4096, 1)
+    seen = 0
+    for batch in (1, 8):
+        for arvind, cap, with_init in ((True, None, True), (True, 3, True), (True, 0, True), (True, 6, False), (False, 5, True),
+                                       (False, None, True), (True, None, False)):
+            h = ArvindDistanceOrdering() if arvind else DefaultBacktrackOrdering()
+            d = DPORwHeuristics(SchedulerConfig(model=model), depth_bound=depth or None, prioritizePendingUponDivergence=True,
+                                backtrackHeuristic=h, stopIfViolationFound=False, batch=batch, backend=oracle.dpor_batch)
+            if with_init:
+                d.setInitialTrace(init)
+            h.init(d, init)
+            if cap is not None:
+                d.setMaxDistance(cap)
+            rp = d.explore(ev, max_interleavings=budget)
+            srch = T.DporSearch(batch, budget, 0, 1, T.DPOR_ORDER_ROUNDS, 0, T.DPOR_ORDERING_ARVIND if arvind else T.DPOR_ORDERING_DEFAULT, cap)
+            nv, npl, nr, _, st = oracle_py.dpor_explore_ordered(model, ev, par, srch, original_trace=init if arvind else None,
+                                                                initial_trace=init if with_init else None, n_threads=2)
+            assert [int(x) for x in nr] == rp.rounds, (batch, arvind, cap, with_init)
+            assert len(nv) == len(rp.interleavings)
+            assert all(nv[k] == il.verdict and int(npl[k]) == il.prefix_len for k, il in enumerate(rp.interleavings))
+            assert int(st.queue_len) == len(d.backTrack)
+            if len(nv) < budget:
+                assert bool(st.exhausted) == (rp.exhausted or (not d.backTrack and rp.aborted > 0))
+            seen += len(nv)
+    assert seen > (15 if which == "two_writers" else 500)

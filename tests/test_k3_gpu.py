@@ -187,6 +187,40 @@ def test_edit_distance_dpor_ddmin_on_the_gpu(oracle):
     assert runs[0][3] and len(runs[0][0]) < len(ev)
 
 
+def test_native_arvind_ordering_and_distance_cap_on_the_gpu(oracle):
+    """demi_dpor_explore with ArvindDistanceOrdering / setMaxDistance / setInitialTrace (the plain loop of the reference around
+    K3 launches, dpor_host.hpp explore_rounds_ordered) against the Python mirror's explore() over the CPU oracle: the same
+    rounds, verdicts and prefix lengths."""
+    from demi_amd.dpor import ArvindDistanceOrdering, DefaultBacktrackOrdering
+    from demi_amd.incremental_ddmin import dpor_initial_trace
+    from .test_incremental_ddmin_cpu import _execution
+    model = M.raft_model(3)
+    ev = events_to_array([start(a) for a in range(3)] + [send(a, M.M_BOOTSTRAP) for a in range(3)])
+    _, trace = _execution(oracle, model, ev, want_violation=False, lim=T.Limits(60, 0, 64, 0, 0, 0))
+    init = dpor_initial_trace(trace)
+    seen = 0
+    for batch, arvind, cap, with_init in ((1, True, None, True), (16, True, 4, True), (16, True, None, False), (16, False, 5, True),
+                                          (64, True, None, True)):
+        runs = []
+        for backend in (oracle.dpor_batch, None):
+            h = ArvindDistanceOrdering() if arvind else DefaultBacktrackOrdering()
+            d = DPORwHeuristics(SchedulerConfig(model=model), depth_bound=30, prioritizePendingUponDivergence=True, backtrackHeuristic=h,
+                                stopIfViolationFound=False, batch=batch, backend=backend, specialize=backend is None and batch == 64)
+            if with_init:
+                d.setInitialTrace(init)
+            h.init(d, init)
+            if cap is not None:
+                d.setMaxDistance(cap)
+            runs.append(d.explore(ev, max_interleavings=400) if backend is not None else d.explore_native(ev, max_interleavings=400))
+            if backend is None:
+                d.shutdown()
+        rp, rn = runs
+        assert rn.rounds == rp.rounds and len(rn.interleavings) == len(rp.interleavings), (batch, arvind, cap, with_init)
+        assert all(a.verdict == b.verdict and a.prefix_len == b.prefix_len for a, b in zip(rn.interleavings, rp.interleavings))
+        seen += len(rn.interleavings)
+    assert seen > 300
+
+
 def test_dpor_golden_fixture_on_gpu(gpu_ctx):
     import hashlib
     import os
