@@ -500,6 +500,26 @@ struct OrderedSearch {
   Trace initial;                                 // setInitialTrace: the first interleaving's next trace
 };
 
+// What an exploration leaves behind for the next one on the same instance (ResumableDPOR, IncrementalDeltaDebugging.scala:94-122:
+// a later test() of the same DPORwHeuristics continues from its backtrack queue, DPORwHeuristics.scala:1219-1220): the queue
+// - a point keeps the trace that found it -, the explored pairs, the creation counter.
+struct OrderedState {
+  // (distance, branch) compares as the reference's Ordered does - the GREATER one is dequeued first (:155-165 with scala's
+  // max-PriorityQueue), ties in creation order
+  struct Point { uint32_t distance, branch; uint64_t seq; uint64_t flip_a, flip_b; std::shared_ptr<Trace> trace; uint8_t later, earlier; };
+  struct After {
+    bool operator()(const Point& x, const Point& y) const {        // "x is dequeued after y"
+      if (x.distance != y.distance) return x.distance < y.distance;
+      if (x.branch != y.branch) return x.branch < y.branch;
+      return x.seq > y.seq;
+    }
+  };
+  std::priority_queue<Point, std::vector<Point>, After> queue;
+  std::unordered_set<std::pair<uint64_t, uint64_t>, PairKeyHash> explored;
+  uint64_t seq = 0;
+  bool started = false;                          // an exploration has run on this state
+};
+
 // arvindDistance (BacktrackOrdering.scala:116-143) of the backtrack point (branch, later, earlier) of trace T: events of its
 // path the original did not contain, plus misordered pairs among those it did.  The path: the causal chain root .. later
 // (getCommonPrefix(later, later)), the events to replay, then (later, earlier) (:117-123).
@@ -524,7 +544,8 @@ template <class Run, class Fetch>
 int explore_rounds_ordered(Run&& run, Fetch&& fetch, uint32_t max_pairs, const demi_dpor_search* srch, const OrderedSearch& ord,
                            demi_verdict* out_verdicts, uint32_t* out_prefix_len, uint32_t* out_rounds,
                            demi_dpor_trace_entry* first_violation_trace, uint32_t* first_violation_len, demi_dpor_stats* stats,
-                           RawBuf* trace_buf = nullptr, RawBuf* pair_buf = nullptr) {
+                           RawBuf* trace_buf = nullptr, RawBuf* pair_buf = nullptr, OrderedState* persistent = nullptr) {
+  // persistent + srch->resume: continue from the queue the previous exploration on this state left (startFromBackTrackPoints)
   RawBuf own_tr([](size_t b) { return malloc(b); }, [](void* q) { free(q); });
   RawBuf own_pr([](size_t b) { return malloc(b); }, [](void* q) { free(q); });
   RawBuf& tr_buf = trace_buf ? *trace_buf : own_tr;
@@ -537,17 +558,16 @@ int explore_rounds_ordered(Run&& run, Fetch&& fetch, uint32_t max_pairs, const d
   if (first_violation_len) *first_violation_len = 0;
   const bool track = srch->track_history != 0;
 
-  // a queued point: (distance, branch) compares as the reference's Ordered does - the GREATER one is dequeued first
-  // (:155-165 with scala's max-PriorityQueue), ties in creation order; it keeps the trace that found it
-  struct Point { uint32_t distance, branch; uint64_t seq; uint64_t flip_a, flip_b; std::shared_ptr<Trace> trace; uint8_t later, earlier; };
-  auto before = [](const Point& x, const Point& y) {        // "x is dequeued after y"
-    if (x.distance != y.distance) return x.distance < y.distance;
-    if (x.branch != y.branch) return x.branch < y.branch;
-    return x.seq > y.seq;
-  };
-  std::priority_queue<Point, std::vector<Point>, decltype(before)> queue(before);
-  std::unordered_set<std::pair<uint64_t, uint64_t>, PairKeyHash> explored;
-  uint64_t seq = 0;
+  typedef OrderedState::Point Point;
+  OrderedState local;
+  OrderedState& S = persistent ? *persistent : local;
+  const bool cont = persistent && srch->resume && S.started;       // a later test() of the same instance: its explored pairs stay
+  if (!cont) S = OrderedState();                                  // a fresh instance
+  const bool resume = cont && !S.queue.empty();                   // ... and it continues from its queue if there is one (:1219-1220)
+  S.started = true;
+  auto& queue = S.queue;
+  auto& explored = S.explored;
+  uint64_t& seq = S.seq;
 
   auto get_next = [&](Trace& out) -> bool {                 // getNext (:1142-1185)
     while (!queue.empty()) {
@@ -565,7 +585,13 @@ int explore_rounds_ordered(Run&& run, Fetch&& fetch, uint32_t max_pairs, const d
     return false;
   };
 
-  std::vector<Trace> frontier(1, ord.initial);              // first run: the initial trace, or empty
+  std::vector<Trace> frontier;
+  if (resume) {                                             // (:1219-1220: the first interleaving of a later test() is ONE dequeued point)
+    Trace nxt;
+    if (get_next(nxt)) frontier.push_back(std::move(nxt));
+  } else {
+    frontier.push_back(ord.initial);                        // first run: the initial trace, or empty
+  }
   std::vector<uint32_t> shared(1, 0u);
   std::vector<demi_dpor_trace_entry> pf;
   std::vector<uint32_t> pl, tl, np;

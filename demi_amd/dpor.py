@@ -131,7 +131,10 @@ class DPORwHeuristics:
                  stopIfViolationFound: bool = True, trackHistory: bool = True, batch: int = 256,
                  max_pairs: int = 4096, p_max: int = 64, device: int = 0, backend: Optional[Callable] = None,
                  specialize: bool = False, prioritizePendingUponDivergence: bool = False, backtrackHeuristic=None,
-                 startFromBackTrackPoints: bool = True):
+                 startFromBackTrackPoints: bool = True, native: bool = False):
+        """native: test() runs the whole exploration inside the library (demi_dpor_explore: queue, explored pairs, getNext and
+        - for ArvindDistanceOrdering / a distance cap / an initial trace - the resumable state of this instance) instead of this
+        Python loop; same explorations."""
         if schedulerConfig.model is None or schedulerConfig.model.inv_kind == T.INV_NONE:
             raise ValueError("Must invoke setInvariant before test()")
         self.schedulerConfig = schedulerConfig
@@ -142,6 +145,7 @@ class DPORwHeuristics:
         self.max_pairs = max_pairs
         self.p_max = p_max
         self.max_messages = 0
+        self.native = native and backend is None
         self._backend = backend          # tests inject the CPU oracle here
         self.specialize = specialize     # compile the model's table to native code first (pays off on long explorations)
         self._device = device
@@ -151,6 +155,7 @@ class DPORwHeuristics:
         self.startFromBackTrackPoints = startFromBackTrackPoints
         self.should_cap_distance = False
         self.stop_at_distance = 0
+        self.native_budget = 1 << 16     # interleavings per native test() call (the capacity of its output arrays)
         self._initialTrace: Optional[np.ndarray] = None
         self._started = False            # test()/explore() has run before on this instance (ResumableDPOR)
         # dropping a point whose flipped pair is already explored when it is CREATED is only the same exploration
@@ -307,9 +312,8 @@ class DPORwHeuristics:
         arvind = isinstance(self.backtrackHeuristic, ArvindDistanceOrdering)
         if not arvind and type(self.backtrackHeuristic) is not DefaultBacktrackOrdering:
             raise NotImplementedError("demi_dpor_explore knows DefaultBacktrackOrdering and ArvindDistanceOrdering; use explore()")
-        if self._started and self.backTrack:
-            raise NotImplementedError("demi_dpor_explore starts from the initial trace at every call; a ResumableDPOR that "
-                                      "continues from its queue uses explore()")
+        if self.backTrack:
+            raise NotImplementedError("this instance has explored through the Python loop: its queue is not the library's")
         ordered = arvind or self.should_cap_distance or self._initialTrace is not None
         if ordered and reference_order:
             raise NotImplementedError("the reference order runs with DefaultBacktrackOrdering, no cap and no initial trace")
@@ -323,7 +327,10 @@ class DPORwHeuristics:
         search = T.DporSearch(self.batch, max_interleavings, 1 if self.stopIfViolationFound else 0,
                               1 if self.trackHistory else 0, T.DPOR_ORDER_REFERENCE if reference_order else T.DPOR_ORDER_ROUNDS, 0,
                               T.DPOR_ORDERING_ARVIND if arvind else T.DPOR_ORDERING_DEFAULT,
-                              self.stop_at_distance if self.should_cap_distance else None)
+                              self.stop_at_distance if self.should_cap_distance else None,
+                              # a later test() of this instance continues from the queue the library kept (:1219-1220)
+                              resume=1 if (ordered and self._started and self.startFromBackTrackPoints) else 0)
+        self._started = True
         if ordered:
             self._ctx.dpor_set_traces(getattr(self.backtrackHeuristic, "originalTrace", None) if arvind else None, self._initialTrace)
         verdicts, plen, rounds, vtrace, stats = self._ctx.dpor_explore(self._params(lookingFor), search)
@@ -347,7 +354,12 @@ class DPORwHeuristics:
         """TestOracle.test (:1193-1242): Some(trace of a matching violation) or None."""
         if self.stopIfViolationFound and self.shortestTraceSoFar is not None:
             return self.shortestTraceSoFar
-        res = self.explore(events, violation_fingerprint, stats=_stats)
+        if self.native:
+            res = self.explore_native(events, violation_fingerprint, max_interleavings=self.native_budget)
+            if _stats is not None:
+                _stats.increment_replays(len(res.interleavings))
+        else:
+            res = self.explore(events, violation_fingerprint, stats=_stats)
         return res.interleavings[res.violations[0]].trace if res.violations else None
 
     def shutdown(self):

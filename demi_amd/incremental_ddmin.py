@@ -130,16 +130,19 @@ class IncrementalDDMin:
 
 def editDistanceDporDDMin(schedulerConfig: SchedulerConfig, trace: EventTrace, violation: ViolationFingerprint,
                           ignoreQuiescence: bool = True, stats: Optional[MinimizationStats] = None,
-                          stopAtSize: int = 6, maxMaxDistance: int = 8, batch: int = 256, backend=None, device: int = 0):
+                          stopAtSize: int = 6, maxMaxDistance: int = 8, batch: int = 256, backend=None, device: int = 0,
+                          native: bool = False):
     """RunnerUtils.editDistanceDporDDMin (RunnerUtils.scala:810-879).  `trace` is the violating execution found by
     the fuzzer (its recorded events + the externals that drove it).  Returns (mcs indices into
-    trace.original_externals, stats, the DPOR trace that reproduces the violation on the MCS or None, violation)."""
+    trace.original_externals, stats, the DPOR trace that reproduces the violation on the MCS or None, violation).
+    native: every DPOR consultation runs inside the library (demi_dpor_explore with ArvindDistanceOrdering, the distance cap,
+    the initial trace and - for a subsequence consulted again at a larger distance - its resumable state)."""
     initialTrace = dpor_initial_trace(trace)
 
     def dporConstructor() -> DPORwHeuristics:
         heuristic = ArvindDistanceOrdering()
         dpor = DPORwHeuristics(schedulerConfig, prioritizePendingUponDivergence=True, backtrackHeuristic=heuristic,
-                               batch=batch, backend=backend, device=device)
+                               batch=batch, backend=backend, device=device, native=native)
         dpor.setMaxMessagesToSchedule(len(initialTrace))
         dpor.setInitialTrace(initialTrace)
         heuristic.init(dpor, initialTrace)

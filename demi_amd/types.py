@@ -118,13 +118,14 @@ class DporParams(C.Structure):
 class DporSearch(C.Structure):
     _fields_ = [("batch", C.c_uint32), ("max_interleavings", C.c_uint32), ("stop_if_violation", C.c_uint32),
                 ("track_history", C.c_uint32), ("order", C.c_uint32), ("cache_mb", C.c_uint32),
-                ("ordering", C.c_uint32), ("max_distance_plus1", C.c_uint32)]
+                ("ordering", C.c_uint32), ("max_distance_plus1", C.c_uint32), ("resume", C.c_uint32)]
 
     def __init__(self, batch=1, max_interleavings=1, stop_if_violation=0, track_history=1, order=0, cache_mb=0, ordering=0,
-                 max_distance=None):
-        """ordering: DPOR_ORDERING_*; max_distance: None = no cap, k = setMaxDistance(k)"""
+                 max_distance=None, resume=0):
+        """ordering: DPOR_ORDERING_*; max_distance: None = no cap, k = setMaxDistance(k); resume: continue from the queue the
+        previous ordered exploration of the context left"""
         super().__init__(batch, max_interleavings, stop_if_violation, track_history, order, cache_mb, ordering,
-                         0 if max_distance is None else int(max_distance) + 1)
+                         0 if max_distance is None else int(max_distance) + 1, resume)
 
 
 class DporStats(C.Structure):

@@ -466,6 +466,9 @@ typedef struct {
   uint32_t ordering;            /* demi_dpor_ordering: the backtrackHeuristic (DPORwHeuristics.scala:69) */
   uint32_t max_distance_plus1;  /* 0 = no cap; k + 1 = setMaxDistance(k) (:131-134): getNext() gives up - the queue is kept - once its
                                    head is at least k away from the original execution */
+  uint32_t resume;              /* with an ordering / cap / initial trace: 1 = continue from the backtrack queue the previous such
+                                   exploration of this demi_ctx left (a later test() of the same DPORwHeuristics, :1219-1220:
+                                   ResumableDPOR); 0, or no queue left = start from the initial trace */
 } demi_dpor_search;
 
 /* BacktrackOrdering.scala: DEFAULT = DefaultBacktrackOrdering (:58-69, deepest branch first, distance 0);
@@ -473,8 +476,8 @@ typedef struct {
  * events of its path the original trace lacks + misordered pairs among those it has; needs demi_dpor_set_traces.
  * With ARVIND, a distance cap or an initial trace, demi_dpor_explore runs the plain loop of the reference (ROUNDS order,
  * host bookkeeping, every racing pair enqueued and explored flips skipped at pop time) - the shortcuts of the default path
- * assume the default priority.  Single rank; DEMI_DPOR_ORDER_REFERENCE is refused with them.  Every call starts from the
- * initial trace (the Python mirror's ResumableDPOR, which continues from the queue of an earlier call, stays the mirror's). */
+ * assume the default priority.  Single rank; DEMI_DPOR_ORDER_REFERENCE is refused with them.  The queue and the explored pairs
+ * of such an exploration stay with the demi_ctx until the next demi_dpor_load: demi_dpor_search.resume continues from them. */
 typedef enum { DEMI_DPOR_ORDERING_DEFAULT = 0, DEMI_DPOR_ORDERING_ARVIND = 1 } demi_dpor_ordering;
 /* ArvindDistanceOrdering.init(sched, originalTrace) (:115-123) and DPORwHeuristics.setInitialTrace (:211-213): the node keys of
  * the original execution, and the next trace of the first interleaving (key, word, kind are read).  (NULL, 0) clears either.

@@ -14,7 +14,7 @@
  *   events    byte[8 * n]     demi_ext_event          recorded  byte[16 * n]  demi_rec_event
  *   verdicts  long[2 * n]     demi_verdict (long 0 = flags | fingerprint << 32, long 1 = hash)
  *   masks     long[4 * n]     candidate subsequences  violations long[2 * n]  demi_violation (index, fingerprint | flags << 32)
- *   limits    int[9]          demi_limits             dporParams int[7]  demi_dpor_params     dporSearch int[8]  demi_dpor_search
+ *   limits    int[9]          demi_limits             dporParams int[7]  demi_dpor_params     dporSearch int[9]  demi_dpor_search
  *   dporStats long[13]        demi_dpor_stats (kernel_ms as raw double bits; fetches last)                                       */
 #include <jni.h>
 #include <stdint.h>
@@ -278,13 +278,13 @@ JNIEXPORT jint JNICALL FN(dporExplore)(JNIEnv* e, jclass c, jlong h, jintArray p
                                       jintArray prefixLen, jintArray rounds, jbyteArray firstViolationTrace, jlongArray stats) {
   demi_dpor_params par;
   demi_dpor_search srch;
-  jint s[8];
+  jint s[9];
   (void)c;
-  if (dpor_params_of(e, params, &par) || LEN(search) != 8 || LEN(stats) != 13) return DEMI_ERR_INVALID_ARG;
-  (*e)->GetIntArrayRegion(e, search, 0, 8, s);
+  if (dpor_params_of(e, params, &par) || LEN(search) != 9 || LEN(stats) != 13) return DEMI_ERR_INVALID_ARG;
+  (*e)->GetIntArrayRegion(e, search, 0, 9, s);
   srch.batch = (uint32_t)s[0]; srch.max_interleavings = (uint32_t)s[1]; srch.stop_if_violation = (uint32_t)s[2];
   srch.track_history = (uint32_t)s[3]; srch.order = (uint32_t)s[4]; srch.cache_mb = (uint32_t)s[5];
-  srch.ordering = (uint32_t)s[6]; srch.max_distance_plus1 = (uint32_t)s[7];
+  srch.ordering = (uint32_t)s[6]; srch.max_distance_plus1 = (uint32_t)s[7]; srch.resume = (uint32_t)s[8];
   const int64_t cap = (int64_t)srch.max_interleavings;
   if (LEN(verdicts) < 2 * cap || LEN(prefixLen) < cap || (rounds && LEN(rounds) < cap) ||
       (firstViolationTrace && LEN(firstViolationTrace) < (int64_t)sizeof(demi_dpor_trace_entry) * DEMI_DPOR_MAX_TRACE))

@@ -390,7 +390,7 @@ extern "C" int harness_dpor_explore_ordered(const demi_model* m, const demi_ext_
                                             const demi_dpor_trace_entry* initial, uint32_t n_initial, int n_threads,
                                             demi_verdict* out_verdicts, uint32_t* out_prefix_len, uint32_t* out_rounds,
                                             demi_dpor_trace_entry* first_violation_trace, uint32_t* first_violation_len,
-                                            demi_dpor_stats* stats) {
+                                            demi_dpor_stats* stats, void* state) {
   std::vector<demi_dpor_trace_entry> all_tr;
   std::vector<demi_dpor_pair> all_pr;
   auto run = [&](const demi_dpor_trace_entry* pf, const uint32_t* pl, const uint32_t* sh, uint32_t stride, uint64_t n,
@@ -423,5 +423,9 @@ extern "C" int harness_dpor_explore_ordered(const demi_model* m, const demi_ext_
   for (uint32_t i = 0; i < n_original; i++) ord.original_index[original_keys[i]] = i;
   ord.initial.assign(initial, initial + n_initial);
   return demi_host::explore_rounds_ordered(run, fetch, par->max_pairs, srch, ord, out_verdicts, out_prefix_len, out_rounds,
-                                           first_violation_trace, first_violation_len, stats);
+                                           first_violation_trace, first_violation_len, stats, nullptr, nullptr,
+                                           static_cast<demi_host::OrderedState*>(state));
 }
+// the state one DPORwHeuristics instance keeps between its test() calls (demi_ctx holds one per loaded trace)
+extern "C" void* harness_ordered_state_new() { return new demi_host::OrderedState(); }
+extern "C" void harness_ordered_state_free(void* p) { delete static_cast<demi_host::OrderedState*>(p); }

@@ -329,7 +329,24 @@ def ddmin(model, original_externals, original_trace, limits, params=None, conjoi
         [int(b) for b in batches[:st.launches]], st
 
 
-def dpor_explore_ordered(model, externals, params, search, original_trace=None, initial_trace=None, n_threads=None):
+class OrderedState:
+    """What one DPORwHeuristics instance keeps between its test() calls (queue, explored pairs): hand the same object to
+    consecutive dpor_explore_ordered calls with search.resume = 1."""
+
+    def __init__(self):
+        build()
+        self._H = C.CDLL(os.path.join(_HERE, "_build", "dpor_host_harness.so"))
+        self._H.harness_ordered_state_new.restype = C.c_void_p
+        self._H.harness_ordered_state_free.argtypes = [C.c_void_p]
+        self.ptr = C.c_void_p(self._H.harness_ordered_state_new())
+
+    def __del__(self):
+        if getattr(self, "ptr", None):
+            self._H.harness_ordered_state_free(self.ptr)
+            self.ptr = None
+
+
+def dpor_explore_ordered(model, externals, params, search, original_trace=None, initial_trace=None, n_threads=None, state=None):
     """DPORwHeuristics with ArvindDistanceOrdering / setMaxDistance / setInitialTrace natively (dpor_host.hpp explore_rounds_ordered,
     what demi_dpor_explore runs for them) around this oracle's interleavings.  Returns (verdicts, prefix_len, rounds, first
     violating trace, stats)."""
@@ -337,7 +354,7 @@ def dpor_explore_ordered(model, externals, params, search, original_trace=None, 
     H = C.CDLL(os.path.join(_HERE, "_build", "dpor_host_harness.so"))
     H.harness_dpor_explore_ordered.argtypes = [C.POINTER(T.ModelStruct), C.c_void_p, C.c_uint32, C.POINTER(T.DporParams), C.POINTER(T.DporSearch),
                                                C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
-                                               C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(T.DporStats)]
+                                               C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(T.DporStats), C.c_void_p]
     ms = model.to_struct()
     ev = np.ascontiguousarray(externals, dtype=T.EXT_EVENT_DTYPE)
     keys = np.ascontiguousarray(np.asarray(original_trace)["key"], dtype=np.uint64) if original_trace is not None else np.zeros(0, dtype=np.uint64)
@@ -352,7 +369,7 @@ def dpor_explore_ordered(model, externals, params, search, original_trace=None, 
     rc = H.harness_dpor_explore_ordered(C.byref(ms), ev.ctypes.data, len(ev), C.byref(params), C.byref(search),
                                         keys.ctypes.data if len(keys) else None, len(keys), init.ctypes.data if len(init) else None, len(init),
                                         n_threads or (os.cpu_count() or 1), verdicts.ctypes.data, plen.ctypes.data, rounds.ctypes.data,
-                                        vt.ctypes.data, C.byref(vl), C.byref(stats))
+                                        vt.ctypes.data, C.byref(vl), C.byref(stats), state.ptr if state is not None else None)
     assert rc == 0, rc
     n = int(stats.interleavings)
     return verdicts[:n].copy(), plen[:n].copy(), rounds[:int(stats.launches)].copy(), vt[:vl.value].copy(), stats

@@ -314,7 +314,8 @@ class GpuDPOR(val schedulerConfig: SchedulerConfig, lowering: TableLowering, dep
     val params = Array(depthBound, maxMessagesToSchedule, 1, lowering.fingerprintCode(fp), 64, 4096, 0)
     val search = Array(batch, maxInterleavings, if (stopIfViolationFound) 1 else 0, 1,
                        if (referenceOrder) DPOR_ORDER_REFERENCE else DPOR_ORDER_ROUNDS, 0,
-                       0 /* DefaultBacktrackOrdering; 1 = ArvindDistanceOrdering after dporSetTraces */, 0 /* no distance cap */)
+                       0 /* DefaultBacktrackOrdering; 1 = ArvindDistanceOrdering after dporSetTraces */, 0 /* no distance cap */,
+                       0 /* resume: 1 = continue from the queue the previous ordered exploration of this context left */)
     val verdicts = new Array[Long](2 * maxInterleavings); val plen = new Array[Int](maxInterleavings)
     val rounds = new Array[Int](maxInterleavings); val vt = new Array[Byte](16 * 256); val st = new Array[Long](13)
     val vlen = check(h, dporExplore(h, params, search, verdicts, plen, rounds, vt, st))

@@ -182,3 +182,42 @@ def test_native_ordered_exploration_equals_the_python_mirror(oracle, which):
                 assert bool(st.exhausted) == (rp.exhausted or (not d.backTrack and rp.aborted > 0))
             seen += len(nv)
     assert seen > (15 if which == "two_writers" else 500)
+
+
+@pytest.mark.parametrize("which", ["two_writers", "raft3"])
+def test_native_ordered_exploration_resumes_like_the_mirror(oracle, which):
+    """ResumableDPOR's pattern on one instance: explore under a small distance cap, raise the cap, explore again, ... - a later
+    call continues from the queue the earlier one left (one dequeued point first, DPORwHeuristics.scala:1219-1220), keeps the
+    explored pairs, and restarts from the initial trace only when the queue is empty.  The native loop with
+    demi_dpor_search.resume against the Python mirror, call by call."""
+    from oracle import oracle_py
+    if which == "two_writers":
+        model = two_writers_model()
+        ev = events_to_array([start(0), start(1), start(2), send(1, 0), send(2, 0), send(1, 0)])
+        depth = 0
+    else:
+        model = M.raft_model(3)
+        ev = events_to_array([start(a) for a in range(3)] + [send(a, M.M_BOOTSTRAP) for a in range(3)])
+        depth = 30
+    _, trace = _execution(oracle, model, ev, want_violation=False, lim=T.Limits(60, 0, 64, 0, 0, 0))
+    init = dpor_initial_trace(trace)
+    par = T.DporParams(depth, 0, 0, 0, 64, 4096, 1)
+    for batch in (1, 4):
+        h = ArvindDistanceOrdering()
+        d = DPORwHeuristics(SchedulerConfig(model=model), depth_bound=depth or None, prioritizePendingUponDivergence=True,
+                            backtrackHeuristic=h, stopIfViolationFound=False, batch=batch, backend=oracle.dpor_batch)
+        d.setInitialTrace(init)
+        h.init(d, init)
+        state = oracle_py.OrderedState()
+        total = 0
+        for call, (cap, budget) in enumerate(((0, 50), (2, 50), (2, 50), (5, 40), (9, 60), (1 << 20, 150), (1 << 20, 150))):
+            d.setMaxDistance(cap)
+            rp = d.explore(ev, max_interleavings=budget)
+            srch = T.DporSearch(batch, budget, 0, 1, T.DPOR_ORDER_ROUNDS, 0, T.DPOR_ORDERING_ARVIND, cap, resume=1)
+            nv, npl, nr, _, st = oracle_py.dpor_explore_ordered(model, ev, par, srch, original_trace=init, initial_trace=init,
+                                                                n_threads=2, state=state)
+            assert [int(x) for x in nr] == rp.rounds, (batch, call, cap)
+            assert len(nv) == len(rp.interleavings) and int(st.queue_len) == len(d.backTrack)
+            assert all(nv[k] == il.verdict and int(npl[k]) == il.prefix_len for k, il in enumerate(rp.interleavings))
+            total += len(nv)
+        assert total >= (3 if which == "two_writers" else 200)

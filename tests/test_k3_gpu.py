@@ -179,11 +179,14 @@ def test_edit_distance_dpor_ddmin_on_the_gpu(oracle):
     v, trace = _execution(oracle, model, ev, lim=T.Limits(60, 0, 64, 0, 0, 0))
     fp = ViolationFingerprint(v.fingerprint, model.fp_match_mask)
     runs = []
-    for backend in (None, oracle.dpor_batch):
+    for backend, native in ((None, False), (oracle.dpor_batch, False), (None, True)):
         mcs, ddmin, verified, _ = editDistanceDporDDMin(SchedulerConfig(model=model), trace, fp, stopAtSize=2,
-                                                        maxMaxDistance=4, batch=64, backend=backend)
+                                                        maxMaxDistance=4, batch=64, backend=backend, native=native)
         runs.append((mcs, ddmin.ddmin.consulted, ddmin.distances, verified is not None, ddmin._stats.total_replays))
     assert runs[0] == runs[1]
+    # ... and with every DPOR consultation inside the library (ArvindDistanceOrdering, the cap, the initial trace and the
+    # resumable state of a subsequence consulted again at a larger distance): the same minimization
+    assert runs[2] == runs[0]
     assert runs[0][3] and len(runs[0][0]) < len(ev)
 
 
