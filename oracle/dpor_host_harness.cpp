@@ -429,3 +429,13 @@ extern "C" int harness_dpor_explore_ordered(const demi_model* m, const demi_ext_
 // the state one DPORwHeuristics instance keeps between its test() calls (demi_ctx holds one per loaded trace)
 extern "C" void* harness_ordered_state_new() { return new demi_host::OrderedState(); }
 extern "C" void harness_ordered_state_free(void* p) { delete static_cast<demi_host::OrderedState*>(p); }
+
+// the same loop around an arbitrary oracle (a callback): property tests of the DDMin host logic itself - atoms, splits, the
+// frontier - against the Python mirror, independent of what a replay would say
+extern "C" int harness_ddmin_callback(const demi_ext_event* ext, uint32_t n_ext, const demi_ddmin_params* par, const uint8_t* conjoined,
+                                      int (*cb)(const uint64_t* masks, uint32_t n, uint8_t* reproduced),
+                                      uint64_t* out_mcs, uint64_t* out_consulted, uint8_t* out_passed, uint32_t cap, uint32_t* out_batches,
+                                      uint32_t batches_cap, demi_ddmin_stats* stats) {
+  auto test = [&](const uint64_t* masks, uint32_t n, uint8_t* reproduced) -> int { return cb(masks, n, reproduced); };
+  return demi_host::sts_sched_ddmin(ext, n_ext, conjoined, par, test, out_mcs, out_consulted, out_passed, cap, out_batches, batches_cap, stats);
+}

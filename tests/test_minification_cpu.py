@@ -461,3 +461,93 @@ def test_native_ddmin_loop_equals_the_python_mirror(oracle):
     model, vv, rec, used = cases[0]
     with pytest.raises(RuntimeError, match="-1"):
         oracle_py.ddmin(model, used, rec, T.Limits(0, 0, 128, 1, 0x7777, 0), T.DdminParams(2, 0, 1, 1))
+
+
+def test_native_ddmin_loop_on_arbitrary_oracles(oracle):
+    """The DDMin host loop (ddmin_host.hpp) around an ARBITRARY oracle - a Python callback - against the mirror's DDMin on random
+    external-event lists with Kill / Partition / UnPartition atoms and conjoined pairs: monotone predicates ("contains this
+    set"), non-monotone ones (a hash of the candidate), with a fixed depth and with launch budgets.  Checks in particular that
+    computing the atoms once (a view ddmin2 can reach is a union of whole atoms) gives what the mirror gets by recomputing them
+    for every view, as the reference does."""
+    import ctypes as C
+    from oracle import oracle_py
+    oracle_py.build()
+    H = C.CDLL(os.path.join(os.path.dirname(oracle_py.__file__), "_build", "dpor_host_harness.so"))
+    CB = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_uint64), C.c_uint32, C.POINTER(C.c_uint8))
+    H.harness_ddmin_callback.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(T.DdminParams), C.c_void_p, CB, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(T.DdminStats)]
+    rng = np.random.default_rng(77)
+
+    def random_externals(n):
+        ev, alive, parts = [], set(), set()
+        for a in range(4):
+            ev.append(start(a)); alive.add(a)
+        while len(ev) < n:
+            k = int(rng.integers(0, 10))
+            a, b = int(rng.integers(0, 4)), int(rng.integers(0, 4))
+            if k < 5:
+                ev.append(send(a, 0, int(rng.integers(0, 9))))
+            elif k == 5 and a in alive and len(alive) > 1:
+                ev.append(kill(a)); alive.discard(a)
+            elif k == 6 and a not in alive:
+                ev.append(start(a)); alive.add(a)
+            elif k == 7 and a != b and (a, b) not in parts:
+                ev.append(partition(a, b)); parts.add((a, b))
+            elif k == 8 and parts:
+                p = sorted(parts)[int(rng.integers(0, len(parts)))]
+                ev.append(unpartition(*p)); parts.discard(p)
+            elif k == 9:
+                ev.append(wait_quiescence())
+        return events_to_array(ev)
+
+    class PyOracle:
+        def __init__(self, pred):
+            self.pred = pred
+
+        def test(self, sub, fp, stats):
+            return True if self.pred(tuple(sub)) else None
+
+        def test_batch(self, subs, fp, stats):
+            return [bool(self.pred(tuple(s))) for s in subs]
+
+    checked = 0
+    for trial in range(60):
+        ext = random_externals(int(rng.integers(8, 60)))
+        n = len(ext)
+        dag = UnmodifiedEventDag(ext)
+        keep = tuple(i for i in dag.events if int(ext[i]["kind"]) != T.EV_WAIT_QUIESCENCE)
+        conj = np.full(n, 255, dtype=np.uint8)
+        sends = [i for i in keep if int(ext[i]["kind"]) == T.EV_SEND]
+        if trial % 3 == 0 and len(sends) >= 4:
+            a, b = sorted(rng.choice(sends, 2, replace=False).tolist())
+            dag.conjoinAtoms(int(a), int(b)); conj[a], conj[b] = b, a
+        if trial % 2:
+            need = set(rng.choice(keep, int(rng.integers(1, 4)), replace=False).tolist())
+            pred = lambda s, need=need: need.issubset(s)                      # monotone: the violation needs these events
+        else:
+            salt = int(rng.integers(1, 1 << 30))
+            full = tuple(keep)
+            pred = lambda s, salt=salt, full=full: s == full or (hash((s, salt)) % 3 == 0)      # arbitrary (the whole trace fails)
+        try:
+            view = EventDagView(dag, keep)
+            dd = DDMin(PyOracle(pred), checkUnmodifed=True)
+            mcs_p = dd.minimize(view, ViolationFingerprint(1)).get_all_events()
+        except (RuntimeError, AssertionError, ValueError):
+            continue                                                          # (a list whose atoms the reference rejects)
+        for par in (T.DdminParams(2, 0, 1, 0), T.DdminParams(0, 8, 1, 0), T.DdminParams(0, 4096, 1, 0)):
+            def cb(masks, cnt, reproduced, pred=pred):
+                for i in range(cnt):
+                    m = [masks[4 * i + k] for k in range(4)]
+                    sub = tuple(e for e in range(n) if (m[e >> 6] >> (e & 63)) & 1)
+                    reproduced[i] = 1 if pred(sub) else 0
+                return 0
+            mcs = np.zeros(4, dtype=np.uint64); consulted = np.zeros((4096, 4), dtype=np.uint64); passed = np.zeros(4096, dtype=np.uint8)
+            st = T.DdminStats()
+            rc = H.harness_ddmin_callback(ext.ctypes.data, n, C.byref(par), conj.ctypes.data, CB(cb), mcs.ctypes.data, consulted.ctypes.data,
+                                          passed.ctypes.data, 4096, None, 0, C.byref(st))
+            assert rc == 0, (trial, rc)
+            assert T.mask_to_events(mcs) == tuple(mcs_p), (trial, par.depth, par.max_candidates)
+            got = [(T.mask_to_events(consulted[i]), bool(passed[i])) for i in range(st.consultations)]
+            assert got == [(tuple(c), p) for c, p in dd.consulted], (trial, par.depth, par.max_candidates)
+            checked += 1
+    assert checked > 100
