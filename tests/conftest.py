@@ -25,3 +25,24 @@ def gpu_ctx():
     ctx = _native.Context(0)
     yield ctx
     ctx.close()
+
+
+# ---- the wave64 emulator (tests/emu, TEST INFRASTRUCTURE): DEMI_EMU=1 runs the `gpu` tests that need no torch device against the
+# kernel sources compiled for the CPU (tests/test_emu_suite_cpu.py drives that from the CPU suite).  The product never sees it.
+if os.environ.get("DEMI_EMU") == "1":
+    from tests.emu import build as _emu_build
+    _emu = _emu_build.build()
+    os.environ["DEMI_NO_TORCH"] = "1"
+    os.environ["DEMI_HIPRTC_LIB"] = _emu["hiprtc"]
+    from demi_amd import _native as _n
+    _n.LIB_PATH = _emu["lib"]
+
+
+    # what cannot run there: the tests about the real library file, a torch device, RCCL, or bench.py itself
+    _EMU_SKIP = {"test_native_library_is_the_one_running", "test_full_size_properties_1m", "test_launches_of_one_ctx_on_two_streams_are_ordered",
+                 "test_rccl_communicator_world_of_one", "test_bench_py_two_ranks_on_one_gpu"}
+
+    def pytest_collection_modifyitems(config, items):
+        for it in items:
+            if it.name.split("[")[0] in _EMU_SKIP:
+                it.add_marker(pytest.mark.skip(reason="needs the GPU itself (DEMI_EMU=1 run)"))

@@ -17,6 +17,8 @@ pytestmark = pytest.mark.gpu
 _WORKER = r'''
 import os, sys
 sys.path.insert(0, %(root)r)
+if os.environ.get("DEMI_EMU") == "1":      # the CPU suite's run of this test (tests/test_emu_suite_cpu.py): same worker, emulated device
+    import tests.conftest
 import numpy as np
 import torch
 import torch.distributed as dist

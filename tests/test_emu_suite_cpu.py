@@ -1,0 +1,112 @@
+"""The `gpu` parity tests, run on the CPU against the UNMODIFIED kernel sources (tests/emu: demi_amd/csrc compiled with g++ on
+top of a lock-step wave64 emulator - fibers for lanes, a rendezvous for every cross-lane operation, real atomics between
+workgroups on different OS threads; the specialised kernels go through a stand-in for hiprtc that compiles the generated
+translation unit the same way).  TEST INFRASTRUCTURE: the product never loads any of it; on a GPU box the same tests run on the
+GPU (`-m gpu`) and that run is the parity claim.  What this adds without a GPU:
+
+* the logic of K1 / K2 / K3 / k_provenance as written - interpreter and generated code, narrow and wide tables, every K1
+  variant - is held against the oracle in the CPU suite too;
+* the emulator aborts a launch whose lanes meet at different cross-lane operations (divergent ballot / readlane / shuffle),
+  so wave-uniformity of those sites is checked, not assumed;
+* `W64_LANE_ORDER=reverse` resumes the lanes of every lock-step interval from the last to the first: a kernel whose result
+  depended on which lane's stores another lane sees WITHOUT an ordering point in between would change its answers (this is
+  how the missing ordering point in k_provenance was found: correct in lock step on the GPU, invisible to the compiler).
+
+The selection below is sized for a couple of minutes; `DEMI_EMU=1 python -m pytest tests -m gpu` runs everything that does not
+need a torch device."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_emulated(ids, threads=4, lane_order=None, timeout=1500):
+    env = dict(os.environ, DEMI_EMU="1", W64_THREADS=str(threads))
+    env.pop("DEMI_JIT_DEFINES", None)
+    if lane_order:
+        env["W64_LANE_ORDER"] = lane_order
+    cmd = [sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-p", "no:cacheprovider", "-x"] + ["tests/" + i for i in ids]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    tail = (out.stdout + out.stderr)[-4000:]
+    assert out.returncode == 0, tail
+    m = re.search(r"(\d+) passed", out.stdout)
+    assert m and int(m.group(1)) >= len(ids) and "failed" not in out.stdout and "skipped" not in out.stdout, tail
+
+
+def test_emulator_reports_divergent_cross_lane_operations(tmp_path):
+    """The emulator's own check: a ballot under divergent control flow aborts the launch with both source lines."""
+    from tests.emu import build
+    b = build.build()
+    src = tmp_path / "div.cpp"
+    src.write_text('#include <hip/hip_runtime.h>\n#include <stdio.h>\n'
+                   '__global__ void k(unsigned long long* o) {\n'
+                   '  unsigned long long m = 0;\n'
+                   '  if (threadIdx.x & 1) m = __ballot(true);\n'
+                   '  else m = __ballot(false);\n'
+                   '  o[threadIdx.x] = m;\n}\n'
+                   '__global__ void ok(unsigned long long* o) { o[threadIdx.x] = __ballot(threadIdx.x & 1) + __shfl((int)threadIdx.x, 5); }\n'
+                   'int main(int c, char** v) {\n'
+                   '  static unsigned long long o[64];\n'
+                   '  if (c > 1) { hipLaunchKernelGGL(k, dim3(1), dim3(64), 0, 0, o); return 0; }\n'
+                   '  hipLaunchKernelGGL(ok, dim3(1), dim3(64), 0, 0, o);\n'
+                   '  printf("%llx %llx\\n", o[0], o[63]);\n  return 0;\n}\n')
+    exe = tmp_path / "div"
+    emu = os.path.join(ROOT, "tests", "emu")
+    subprocess.check_call(["g++", "-x", "c++", "-std=c++17", "-O1", "-w", "-I" + emu, str(src), "-o", str(exe), "-L" + os.path.dirname(b["runtime"]),
+                           "-lw64rt", "-pthread", "-Wl,-rpath," + os.path.dirname(b["runtime"])])
+    good = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert good.returncode == 0 and good.stdout.split() == ["aaaaaaaaaaaaaaaf", "aaaaaaaaaaaaaaaf"], good.stdout + good.stderr
+    bad = subprocess.run([str(exe), "x"], capture_output=True, text=True)
+    assert bad.returncode != 0 and "divergent rendezvous" in bad.stderr, bad.stderr
+
+
+def test_k1_sources_against_the_oracle_on_the_cpu():
+    run_emulated(["test_k1_gpu.py::test_raft5_parity_all_capacities[64]",
+                  "test_k1_gpu.py::test_recorded_event_traces_are_identical",
+                  "test_k1_gpu.py::test_srcdst_fifo_parity_raft5[24]",
+                  "test_k1_gpu.py::test_random_programs_interpreter_specialised_and_oracle_agree[1]",
+                  "test_blocked_actors_gpu.py::test_k1_parity_with_crashed_actors[0]",
+                  "test_invariant_gpu.py::test_random_program_invariants_through_every_kernel[1]"])
+
+
+def test_k2_sources_against_the_oracle_on_the_cpu():
+    run_emulated(["test_k2_gpu.py::test_replay_parity_random_subsequences_raft5",
+                  "test_k2_gpu.py::test_filter_known_absents_parity[auto]",
+                  "test_k2_gpu.py::test_removal_batch_and_kept_parity",
+                  "test_k2_gpu.py::test_config4_ddmin_200_external_events",
+                  "test_k2_gpu.py::test_native_ddmin_equals_the_python_mirror_on_the_gpu"])
+
+
+def test_k3_and_provenance_sources_against_the_oracle_on_the_cpu():
+    # (one OS thread: the explored-pair table's bounded wait for a half-published key assumes the publishing wave is running)
+    run_emulated(["test_k3_gpu.py::test_per_interleaving_outputs_match_the_oracle",
+                  "test_k3_gpu.py::test_whole_exploration_identical_gpu_vs_oracle_backend[64]",
+                  "test_k3_gpu.py::test_native_exploration_loop_equals_the_python_loop[64-3000]",
+                  "test_k3_gpu.py::test_reference_order_on_the_gpu_is_the_batch1_sequence[True]",
+                  "test_k3_gpu.py::test_config5_shuffle8_bounded_dpor",
+                  "test_provenance_gpu.py"], threads=1)
+
+
+def test_sharded_entry_points_two_ranks_on_the_cpu():
+    """demi_random_explore_sharded / demi_replay_batch_sharded / the sharded demi_dpor_explore with two processes, gloo and the
+    host all-gather: the worker of tests/test_comm_gpu.py as it is, each rank on an emulated device."""
+    run_emulated(["test_comm_gpu.py::test_sharded_entry_points_two_ranks_on_one_gpu"], threads=1)
+
+
+def test_wide_tables_every_k1_variant_on_the_cpu():
+    run_emulated(["test_wide_gpu.py::test_wide_srcdst_fifo_and_carried_generator",
+                  "test_wide_gpu.py::test_wide_model_rules_at_the_boundary",
+                  "test_wide_gpu.py::test_wide_random_tables_parity[2]"])
+
+
+def test_results_do_not_depend_on_the_order_of_the_lanes_within_an_interval():
+    run_emulated(["test_k1_gpu.py::test_raft5_parity_all_capacities[32]",
+                  "test_k1_gpu.py::test_srcdst_fifo_parity_raft5[64]",
+                  "test_k2_gpu.py::test_replay_parity_random_subsequences_raft5",
+                  "test_k2_gpu.py::test_filter_known_absents_parity[hbm]"], lane_order="reverse")
+    run_emulated(["test_k3_gpu.py::test_per_interleaving_outputs_match_the_oracle",
+                  "test_provenance_gpu.py"], threads=1, lane_order="reverse")
