@@ -79,8 +79,9 @@ __host__ __device__ inline size_t k1_extra_lds_bytes(uint32_t n_ev, uint32_t n_b
 // LDS, the rest in the HBM spill after the timers-and-externals arrays; srcDsts as a byte list (src * 8 + dst).
 constexpr uint32_t NORM_HOT = 16;
 __host__ __device__ inline uint32_t k1_pair_words(uint32_t n_actors) { return (n_actors * n_actors + 3) / 4; }
-__host__ __device__ inline size_t k1_fifo_wave_bytes(uint32_t n_actors, bool rec) {
-  return ((size_t)NORM_HOT * (rec ? 2 : 1) + k1_pair_words(n_actors)) * 64 * 4;
+// (message words are 8 bytes in a wide build; the ids beside them - recording variant - and the pair list stay 32-bit)
+__host__ __device__ inline size_t k1_fifo_wave_bytes(uint32_t n_actors, bool rec, bool wide = WIDE_TU) {
+  return ((size_t)NORM_HOT * ((wide ? 2 : 1) + (rec ? 1 : 0)) + k1_pair_words(n_actors)) * 64 * 4;
 }
 // HBM scratch words per simulator lane: pending slots beyond the LDS-resident ones, every array of the variant
 __host__ __device__ inline size_t k1_spill_words_per_lane(bool rec, bool fifo, uint32_t hot = K1_HOT) {
@@ -107,7 +108,7 @@ __host__ __device__ inline size_t k1_lds_bytes(uint32_t code_len, uint32_t n_ev,
                                                uint32_t n_batches, uint32_t n_timer_types, uint32_t hot = K1_HOT, bool wide = WIDE_TU,
                                                uint32_t fxq_slots = K1_FXQ_SLOTS) {
   return tables_lds_bytes(code_len, n_ev, n_hs, wide) + k1_extra_lds_bytes(n_ev, n_batches, wide) +
-         K1_WAVES * (lane_mem_wave_bytes(n_actors, REC, hot, wide, fxq_slots) + (FIFO ? k1_fifo_wave_bytes(n_actors, REC) : 0) +
+         K1_WAVES * (lane_mem_wave_bytes(n_actors, REC, hot, wide, fxq_slots) + (FIFO ? k1_fifo_wave_bytes(n_actors, REC, wide) : 0) +
                      k1_tdir_wave_bytes(n_actors, n_timer_types));
 }
 
@@ -185,21 +186,25 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
   uint64_t* const st = mem.st;
   const uint32_t PMAX = args.p_max;
   // SrcDstFIFO arrays of this lane (FIFO builds only)
-  uint32_t* f_norm = nullptr, *f_norm_aux = nullptr, *f_pairs = nullptr, *f_spill = nullptr, *f_spill_aux = nullptr;
+  word_t* f_norm = nullptr, *f_spill = nullptr;
+  uint32_t* f_norm_aux = nullptr, *f_pairs = nullptr, *f_spill_aux = nullptr;
   if (FIFO) {
     unsigned char* fb = wave_base + (size_t)K1_WAVES * lane_mem_wave_bytes(t.A, REC, K1_HOT, WIDE_TU, K1_FXQ_SLOTS) + (size_t)wave * k1_fifo_wave_bytes(t.A, REC);
-    f_norm = reinterpret_cast<uint32_t*>(fb) + lane;
-    if (REC) f_norm_aux = f_norm + (size_t)NORM_HOT * 64;
-    f_pairs = f_norm + (size_t)NORM_HOT * 64 * (REC ? 2 : 1);
+    f_norm = reinterpret_cast<word_t*>(fb) + lane;
+    uint32_t* const after = reinterpret_cast<uint32_t*>(fb + (size_t)NORM_HOT * 64 * sizeof(word_t)) + lane;
+    if (REC) f_norm_aux = after;
+    f_pairs = after + (REC ? (size_t)NORM_HOT * 64 : 0);
+    // the scratch behind the timers-and-externals arrays (lane_mem_carve: their words, then - recording variant - their ids)
     const size_t lanes = (size_t)gridDim.x * blockDim.x, gl = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    f_spill = args.spill + spill_words(lanes, K1_HOT) * (REC ? 2 : 1) + gl;
-    if (REC) f_spill_aux = f_spill + lanes * (DEMI_MAX_PENDING - NORM_HOT);
+    unsigned char* const fs = reinterpret_cast<unsigned char*>(args.spill) + spill_words(lanes, K1_HOT) * (sizeof(word_t) + (REC ? 4 : 0));
+    f_spill = reinterpret_cast<word_t*>(fs) + gl;
+    if (REC) f_spill_aux = reinterpret_cast<uint32_t*>(fs + lanes * (DEMI_MAX_PENDING - NORM_HOT) * sizeof(word_t)) + gl;
   }
   const uint32_t f_stride = (uint32_t)((size_t)gridDim.x * blockDim.x);
-  auto norm_load = [&](uint32_t slot) -> uint32_t {
+  auto norm_load = [&](uint32_t slot) -> word_t {
     return slot < NORM_HOT ? f_norm[slot * 64] : f_spill[(size_t)(slot - NORM_HOT) * f_stride];
   };
-  auto norm_store = [&](uint32_t slot, uint32_t v) {
+  auto norm_store = [&](uint32_t slot, word_t v) {
     if (slot < NORM_HOT) f_norm[slot * 64] = v; else f_spill[(size_t)(slot - NORM_HOT) * f_stride] = v;
   };
   auto norm_aux_load = [&](uint32_t slot) -> uint32_t {
@@ -332,7 +337,7 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
   do {                                                                \
     if (n_pend + n_norm >= PMAX) { flags |= DEMI_V_PENDING_OVF; }     \
     else {                                                            \
-      const uint32_t w_ = (WORD);                                     \
+      const word_t w_ = (WORD);                                       \
       const uint32_t pr_ = w_src(w_) * 8 + w_dst(w_);                 \
       norm_store(n_norm, w_);                                         \
       if (REC) norm_aux_store(n_norm, (ID));                          \
@@ -646,7 +651,7 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
         if (REC) wid = norm_aux_load(k);
         bool more = false;
         for (uint32_t j = k; j + 1 < n_norm; j++) {
-          const uint32_t nx = norm_load(j + 1);
+          const word_t nx = norm_load(j + 1);
           more |= (w_src(nx) * 8 + w_dst(nx) == pr);
           norm_store(j, nx);
           if (REC) norm_aux_store(j, norm_aux_load(j + 1));

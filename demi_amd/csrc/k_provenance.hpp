@@ -58,6 +58,10 @@ __global__ __launch_bounds__(PROV_WAVES * 64) void k_provenance(const ProvArgs a
     rcv[u] = (uint8_t)r; par[u] = (uint8_t)p;
     for (uint32_t j = 0; j < PROV_WORDS; j++) M[u * PROV_WORDS + j] = 0;
   }
+  // (the nine lanes below read what every lane has just written: same ordering point as further down - no instruction, it only
+  // says so to the compiler, and to the lock-step emulator of the CPU suite, whose lanes really run one after the other)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
   // prev[u]: by one lane per machine (9 of them), in trace order
   if (lane < 9) {
     uint32_t last = 255;

@@ -734,8 +734,6 @@ static int random_execute_in2(exec_t* x, const demi_model* m, const demi_ext_eve
   memset(x, 0, offsetof(exec_t, fx));
   x->m = m; x->trace = trace; x->n_ev = n_ev; x->lim = lim;
   x->wide = (m->flags & DEMI_MODEL_WIDE) != 0;
-  /* a wide model has no SrcDstFIFO variant */
-  if (x->wide && lim->strategy != DEMI_STRATEGY_FULLY_RANDOM) return DEMI_ERR_INVALID_MODEL;
   x->rec = rec; x->rec_cap = rec_cap;
   x->p_max = lim->p_max ? lim->p_max : 64;
   if (x->p_max > PEND_HARD_CAP) x->p_max = PEND_HARD_CAP;

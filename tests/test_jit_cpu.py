@@ -447,7 +447,7 @@ def test_no_specialised_kernel_touches_scratch_memory(tmp_path, wide):
         pytest.skip("no hiprtc in this environment")
     assert "SIZE" in out.stdout, out.stdout + out.stderr
     seen = 0
-    for k in range(8):
+    for k in range(12):            # (demi_gpu.hip JK_COUNT: a wide table gets every variant of K1 compiled)
         path = str(tmp_path / "img") + ".%d" % k
         if not os.path.exists(path):
             continue
@@ -456,7 +456,7 @@ def test_no_specialised_kernel_touches_scratch_memory(tmp_path, wide):
         assert sizes and all(v == 0 for v in sizes), (k, sizes)
         assert all(v == 0 for v in _meta_values(image, ".vgpr_spill_count")), k
         seen += 1
-    assert seen >= 4
+    assert seen >= (10 if wide else 4)
 
 
 @pytest.mark.parametrize("wide", [False, True])

@@ -230,9 +230,59 @@ def test_wide_record_replay_minimize(oracle):
     dr.shutdown(); dn.shutdown()
 
 
+def test_wide_srcdst_fifo_and_carried_generator(oracle):
+    """The two refusals round 3's first half still listed for a wide table: `SrcDstFIFO` (RandomScheduler.scala:702-909) and
+    the carried-generator mode (`executions_per_instance`, :248-269, 575-595).  Every variant of K1 - recording or not, either
+    strategy, independent or chained executions - is compiled for the table (demi_gpu.hip jk_k1): verdicts and recorded traces
+    against the oracle."""
+    _, events, lim0 = raft5_config2()
+    model = M.raft_model(5, term0=1000, loglen0=300)
+    ctx = _native.Context(0)
+    try:
+        for p_max in (64, 24):
+            fl = T.Limits(lim0.max_messages, lim0.invariant_check_interval, p_max, 0, 0, 0, T.STRATEGY_SRC_DST_FIFO)
+            g, c = wide_both(ctx, oracle, model, events, 20000, fl)
+            assert_same(g, c)
+            assert (g["flags"] & T.V_VIOLATION).sum() > 20
+            if p_max == 24:
+                assert (g["flags"] & T.V_PENDING_OVF).sum() > 0
+        # SrcDstFIFO is another schedule distribution than FullyRandom
+        full = ctx.random_explore(2000, lim0, seed_base=SEED_BASE)
+        assert (full["hash"] != g["hash"][:2000]).mean() > 0.9
+        # recorded traces under SrcDstFIFO
+        fl = T.Limits(lim0.max_messages, lim0.invariant_check_interval, 64, 0, 0, 0, T.STRATEGY_SRC_DST_FIFO)
+        g = ctx.random_explore(300, fl, seed_base=SEED_BASE)
+        hits = np.nonzero(g["flags"] & T.V_VIOLATION)[0]
+        for i in list(hits[:3]) + [0, 1]:
+            gv, grec = ctx.random_get_trace(SEED_BASE + int(i), fl)
+            cv, crec, _ = oracle.random_execute(model, events, SEED_BASE + int(i), fl)
+            assert (int(gv.flags), int(gv.fingerprint), int(gv.hash)) == (int(cv.flags), int(cv.fingerprint), int(cv.hash))
+            assert gv.hash == g[i]["hash"] and len(grec) == len(crec) and (grec == crec).all()
+            assert (grec["p0"] > 255).any()                   # 16-bit payloads in the records (terms above 1000)
+        # carried generators: chains of k executions per instance, both strategies
+        k, n = 5, 6003
+        for strategy in (T.STRATEGY_FULLY_RANDOM, T.STRATEGY_SRC_DST_FIFO):
+            lim = T.Limits(lim0.max_messages, lim0.invariant_check_interval, 64, 0, 0, 0, strategy, 0, k)
+            g, c = wide_both(ctx, oracle, model, events, n, lim)
+            assert_same(g, c)
+            viol = np.nonzero(g["flags"] & T.V_VIOLATION)[0]
+            not_run = (g["flags"] == 0) & (g["hash"] == 0)
+            assert len(viol) > 5 and not_run.sum() > 0
+            lim1 = T.Limits(lim0.max_messages, lim0.invariant_check_interval, 64, 0, 0, 0, strategy)
+            ind = ctx.random_explore(2 * k, lim1, seed_base=SEED_BASE)
+            assert g[0] == ind[0] and g[k] == ind[1] and g[1] != ind[1]
+            for e in (0, 3):
+                v, rec, ran = ctx.random_get_trace_carried(SEED_BASE + 2, e, lim)
+                vo, reco, rano = oracle.random_execute_carried(model, events, SEED_BASE + 2, e, lim)
+                assert ran == rano and (int(v.flags), int(v.fingerprint), int(v.hash)) == (int(vo.flags), int(vo.fingerprint), int(vo.hash))
+                assert len(rec) == len(reco) and (rec == reco).all()
+    finally:
+        ctx.close()
+
+
 def test_wide_model_rules_at_the_boundary(oracle):
-    """What is left of round 2's list of refusals: a wide table has no interpreter and no SrcDstFIFO kernel, and 16-bit
-    payloads belong to wide models only."""
+    """What is left of round 2's list of refusals: a wide table has no interpreter (it runs as compiled code or not at all),
+    and 16-bit payloads belong to wide models only."""
     model = M.raft_model(3, term0=1000)
     ev = events_to_array([start(a) for a in range(3)] + [send(a, M.M_BOOTSTRAP) for a in range(3)])
     lim = T.Limits(100, 10, 64, 0, 0, 0)
@@ -242,12 +292,13 @@ def test_wide_model_rules_at_the_boundary(oracle):
         ctx.trace_load(ev)
         with pytest.raises(_native.DemiError, match="compiled table"):
             ctx.random_explore(16, lim, seed_base=1)                    # no interpreter for the wide window
-        ctx.model_specialize()
-        assert_same(ctx.random_explore(64, lim, seed_base=1), oracle.random_explore(model, ev, 64, seed_base=1, limits=lim))
         fifo = T.Limits(100, 10, 64, 0, 0, 0)
         fifo.strategy = T.STRATEGY_SRC_DST_FIFO
-        with pytest.raises(_native.DemiError):
+        with pytest.raises(_native.DemiError, match="compiled table"):
             ctx.random_explore(16, fifo, seed_base=1)
+        ctx.model_specialize()
+        assert_same(ctx.random_explore(64, lim, seed_base=1), oracle.random_explore(model, ev, 64, seed_base=1, limits=lim))
+        assert_same(ctx.random_explore(64, fifo, seed_base=1), oracle.random_explore(model, ev, 64, seed_base=1, limits=fifo))
         # 16-bit payloads belong to wide models only
         ctx.model_load(M.raft_model(3).to_struct())
         with pytest.raises(_native.DemiError, match="16-bit"):
