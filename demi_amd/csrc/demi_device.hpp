@@ -25,7 +25,7 @@ struct DevModel {
   uint32_t actor_class[DEMI_MAX_ACTORS];
   uint64_t init_state[DEMI_MAX_ACTORS];
   uint32_t divmagic[257];  // ceil(2^(31+L)/d), L = ceil(log2 d): exact floor(r/d) for r < 2^31 (d <= 128: the pending
-  uint32_t pad3;           //  set's nextInt; d <= 255: DEMI_OP_RND bounds)
+  uint32_t arr_len;        //  set's nextInt; d <= 255: DEMI_OP_RND bounds)      arr_len: DEMI_MODEL_ARRAY's length, 0 = none
   uint32_t optab[64];      // per-op control words (sim_core.hpp op_control), filled by the host
   uint32_t code[DEMI_MAX_CODE];
   uint64_t init_state_wide[2 * DEMI_MAX_ACTORS];   // DEMI_MODEL_WIDE: two words per actor (init_state is unused then)
@@ -36,13 +36,25 @@ struct DevModel {
 // message words and two state words per actor; everything else sees the 8-bit layout, unchanged.
 #ifdef DEMI_WIDE
 typedef uint64_t word_t;
-constexpr uint32_t ST_WORDS = 2;
+constexpr uint32_t FLD_WORDS = 2;
 constexpr bool WIDE_TU = true;
 #else
 typedef uint32_t word_t;
-constexpr uint32_t ST_WORDS = 1;
+constexpr uint32_t FLD_WORDS = 1;
 constexpr bool WIDE_TU = false;
 #endif
+// DEMI_MODEL_ARRAY(n): the actors' arrays (rows LDX / STX) are further state words behind the field word(s) - 8 elements to
+// a word, 4 in a wide table - and, like the wide window, exist only in a translation unit compiled for the table
+// (DEMI_JIT_ARR_LEN, from demi_model_specialize).  ST_WORDS = all the 64-bit words of one actor's state: what is initialised,
+// kept per lane in LDS ([word][lane]) and hashed at the end.
+#ifdef DEMI_JIT_ARR_LEN
+constexpr uint32_t ARR_LEN = DEMI_JIT_ARR_LEN;
+#else
+constexpr uint32_t ARR_LEN = 0;
+#endif
+__host__ __device__ constexpr uint32_t arr_words_of(bool wide, uint32_t len) { return (len + (wide ? 4u : 8u) - 1u) / (wide ? 4u : 8u); }
+constexpr uint32_t ARR_WORDS = arr_words_of(WIDE_TU, ARR_LEN);
+constexpr uint32_t ST_WORDS = FLD_WORDS + ARR_WORDS;
 
 // ------------------------------------------------------------------ message word
 // type[4:0] | dst[7:5] | src[11:8] | p0[23:16] | p1[31:24]   (identical to the oracle's)
@@ -111,10 +123,24 @@ __device__ __forceinline__ uint32_t fld(uint64_t s, uint32_t f) { return (uint32
 // field f of actor a in a lane's state array (stride 64 words): 8 bits of its one word, or 16 bits of its two (wide)
 __device__ __forceinline__ uint32_t state_field(const uint64_t* st, uint32_t a, uint32_t f) {
 #ifdef DEMI_WIDE
-  return (uint32_t)(st[(2 * a + (f >> 2)) * 64] >> (16 * (f & 3))) & 0xFFFFu;
+  return (uint32_t)(st[(ST_WORDS * a + (f >> 2)) * 64] >> (16 * (f & 3))) & 0xFFFFu;
 #else
-  return (uint32_t)(st[a * 64] >> (8 * f)) & 0xFFu;
+  return (uint32_t)(st[(ST_WORDS * a) * 64] >> (8 * f)) & 0xFFu;
 #endif
+}
+// element `idx` of actor a's array (DEMI_OP_LDX / DEMI_OP_STX): element k of an array word is its k-th byte (16-bit half in a
+// wide table), so a store is one narrow LDS write, not a read-modify-write of the word; past the end: 0 / nothing
+__device__ __forceinline__ uint32_t arr_load(const uint64_t* st, uint32_t a, uint32_t idx) {
+  if (ARR_LEN == 0 || idx >= ARR_LEN) return 0;
+  const unsigned char* w = reinterpret_cast<const unsigned char*>(st + (size_t)(ST_WORDS * a + FLD_WORDS + idx / (WIDE_TU ? 4u : 8u)) * 64);
+  if (WIDE_TU) return reinterpret_cast<const uint16_t*>(w)[idx & 3u];
+  return w[idx & 7u];
+}
+__device__ __forceinline__ void arr_store(uint64_t* st, uint32_t a, uint32_t idx, uint32_t v) {
+  if (ARR_LEN == 0 || idx >= ARR_LEN) return;
+  unsigned char* w = reinterpret_cast<unsigned char*>(st + (size_t)(ST_WORDS * a + FLD_WORDS + idx / (WIDE_TU ? 4u : 8u)) * 64);
+  if (WIDE_TU) reinterpret_cast<uint16_t*>(w)[idx & 3u] = (uint16_t)v;
+  else w[idx & 7u] = (unsigned char)v;
 }
 
 // (the invariant itself - per-actor hit / key, the combining kinds - lives in sim_core.hpp: a DEMI_INV_PROGRAM invariant runs rows)

@@ -271,12 +271,12 @@ inline std::string generate_vm(const demi::DevModel& h, bool sched = false) {
   s += "  const uint32_t entry = t.hs[((t.ac_packed >> (4 * me)) & 15u) * t.NT + type];\n";
   s += "  if (entry == 0xFFFFu) return 0;\n";
   if (wide) {
-    s += "  const uint64_t st0 = mem.st[(2 * me) * 64], st1 = mem.st[(2 * me + 1) * 64];\n";
+    s += "  const uint64_t st0 = mem.st[(ST_WORDS * me) * 64], st1 = mem.st[(ST_WORDS * me + 1) * 64];\n";
     s += "  uint32_t r0 = (uint32_t)st0 & 65535u, r1 = (uint32_t)(st0 >> 16) & 65535u, r2 = (uint32_t)(st0 >> 32) & 65535u, "
          "r3 = (uint32_t)(st0 >> 48) & 65535u,\n           r4 = (uint32_t)st1 & 65535u, r5 = (uint32_t)(st1 >> 16) & 65535u, "
          "r6 = (uint32_t)(st1 >> 32) & 65535u, r7 = (uint32_t)(st1 >> 48) & 65535u;\n";
   } else {
-    s += "  const uint64_t st0 = mem.st[me * 64];\n";
+    s += "  const uint64_t st0 = mem.st[(ST_WORDS * me) * 64];\n";
     s += "  uint32_t r0 = (uint32_t)st0 & 255u, r1 = (uint32_t)(st0 >> 8) & 255u, r2 = (uint32_t)(st0 >> 16) & 255u, "
          "r3 = (uint32_t)(st0 >> 24) & 255u,\n           r4 = (uint32_t)(st0 >> 32) & 255u, r5 = (uint32_t)(st0 >> 40) & 255u, "
          "r6 = (uint32_t)(st0 >> 48) & 255u, r7 = (uint32_t)(st0 >> 56) & 255u;\n";
@@ -336,8 +336,10 @@ inline std::string generate_vm(const demi::DevModel& h, bool sched = false) {
     s.insert(at, preds);
   }
   // the value an ALU row assigns, as an expression over the register names a, b
+  const char* arr_of = "mem.st, me";      // (whose array an LDX reads: the receiving actor's; the invariant program's actor below)
   auto alu_value = [&](uint32_t op, const char* a, const char* b, char* val, size_t cap) {
     switch (op) {
+      case DEMI_OP_LDX: snprintf(val, cap, "arr_load(%s, %s)", arr_of, b); break;      // DEMI_MODEL_ARRAY (demi_device.hpp)
       case DEMI_OP_MOV: snprintf(val, cap, "%s & %uu", b, RM); break;
       case DEMI_OP_MOVHI: snprintf(val, cap, "((%s & 255u) | (%s << 8)) & %uu", a, b, RM); break;   // (wide tables only)
       case DEMI_OP_ADD: snprintf(val, cap, "(%s + %s) & %uu", a, b, RM); break;
@@ -389,6 +391,8 @@ inline std::string generate_vm(const demi::DevModel& h, bool sched = false) {
       emit("if (%s != 0u) goto %s;\n", a, target(pc + 1 + braw).c_str());
     } else if (cw & CW_SKIP) {
       emit("goto %s;\n", target(pc + 1 + braw).c_str());
+    } else if (cw & CW_STX) {
+      emit("arr_store(mem.st, me, %s, %s);\n", b, a);
     } else {   // CW_FX: recorded now, applied after the rows have run (same record as vm_run)
       if (fxs.ok && (fxs.cls[fxs.slot[pc]] >> 16) != FXK_SEND)
         emit("DEMI_FX_MARK(%d)%s\n", fxs.slot[pc], (cw & CW_HALT) ? " goto done;" : "");
@@ -400,10 +404,10 @@ inline std::string generate_vm(const demi::DevModel& h, bool sched = false) {
   }
   s += "  done:\n";
   if (wide)
-    s += "  mem.st[(2 * me) * 64] = (uint64_t)(r0 | (r1 << 16)) | ((uint64_t)(r2 | (r3 << 16)) << 32);\n"
-         "  mem.st[(2 * me + 1) * 64] = (uint64_t)(r4 | (r5 << 16)) | ((uint64_t)(r6 | (r7 << 16)) << 32);\n";
+    s += "  mem.st[(ST_WORDS * me) * 64] = (uint64_t)(r0 | (r1 << 16)) | ((uint64_t)(r2 | (r3 << 16)) << 32);\n"
+         "  mem.st[(ST_WORDS * me + 1) * 64] = (uint64_t)(r4 | (r5 << 16)) | ((uint64_t)(r6 | (r7 << 16)) << 32);\n";
   else
-    s += "  mem.st[me * 64] = (uint64_t)(r0 | (r1 << 8) | (r2 << 16) | (r3 << 24)) | "
+    s += "  mem.st[(ST_WORDS * me) * 64] = (uint64_t)(r0 | (r1 << 8) | (r2 << 16) | (r3 << 24)) | "
          "((uint64_t)(r4 | (r5 << 8) | (r6 << 16) | (r7 << 24)) << 32);\n";
   s += "  return nfx;\n}\n";
   if (h.inv_kind & DEMI_INV_PROGRAM) {
@@ -412,12 +416,12 @@ inline std::string generate_vm(const demi::DevModel& h, bool sched = false) {
     // (jit_source defines DEMI_JIT_INV_PROG ahead of sim_core.hpp, whose inv_prog() then calls this)
     s += "__device__ inline uint32_t inv_prog_jit(const uint64_t* st, uint32_t actor, uint32_t& key) {\n";
     if (wide) {
-      s += "  const uint64_t st0 = st[(2 * actor) * 64], st1 = st[(2 * actor + 1) * 64];\n";
+      s += "  const uint64_t st0 = st[(ST_WORDS * actor) * 64], st1 = st[(ST_WORDS * actor + 1) * 64];\n";
       s += "  uint32_t r0 = (uint32_t)st0 & 65535u, r1 = (uint32_t)(st0 >> 16) & 65535u, r2 = (uint32_t)(st0 >> 32) & 65535u, "
            "r3 = (uint32_t)(st0 >> 48) & 65535u,\n           r4 = (uint32_t)st1 & 65535u, r5 = (uint32_t)(st1 >> 16) & 65535u, "
            "r6 = (uint32_t)(st1 >> 32) & 65535u, r7 = (uint32_t)(st1 >> 48) & 65535u;\n";
     } else {
-      s += "  const uint64_t st0 = st[actor * 64];\n";
+      s += "  const uint64_t st0 = st[(ST_WORDS * actor) * 64];\n";
       s += "  uint32_t r0 = (uint32_t)st0 & 255u, r1 = (uint32_t)(st0 >> 8) & 255u, r2 = (uint32_t)(st0 >> 16) & 255u, "
            "r3 = (uint32_t)(st0 >> 24) & 255u,\n           r4 = (uint32_t)(st0 >> 32) & 255u, r5 = (uint32_t)(st0 >> 40) & 255u, "
            "r6 = (uint32_t)(st0 >> 48) & 255u, r7 = (uint32_t)(st0 >> 56) & 255u;\n";
@@ -425,6 +429,7 @@ inline std::string generate_vm(const demi::DevModel& h, bool sched = false) {
     s += "  uint32_t r8 = 0, r9 = 0, r10 = 0, r11 = 0, r12 = 0, r13 = 0, r14 = 0, r15 = actor;\n";
     s += "  (void)r0; (void)r1; (void)r2; (void)r3; (void)r4; (void)r5; (void)r6; (void)r7; (void)r10; (void)r11; (void)r12; (void)r13; (void)r14; (void)r15;\n";
     auto itarget = [&](uint32_t pc) -> std::string { return pc >= h.code_len ? "idone" : "I" + std::to_string(pc); };
+    arr_of = "st, actor";
     for (uint32_t pc = h.inv_fa; pc < h.code_len; pc++) {
       const uint32_t row = h.code[pc];
       const uint32_t op = row & 0x3Fu, dsti = (row >> 8) & 15u, ai = (row >> 12) & 15u, aux = (row >> 17) & 0x7Fu, braw = row >> 24;

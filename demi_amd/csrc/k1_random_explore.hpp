@@ -106,9 +106,9 @@ constexpr uint32_t K1_FXQ_SLOTS = DEMI_FX_CAP;
 template <bool REC, bool FIFO>
 __host__ __device__ inline size_t k1_lds_bytes(uint32_t code_len, uint32_t n_ev, uint32_t n_hs, uint32_t n_actors,
                                                uint32_t n_batches, uint32_t n_timer_types, uint32_t hot = K1_HOT, bool wide = WIDE_TU,
-                                               uint32_t fxq_slots = K1_FXQ_SLOTS) {
-  return tables_lds_bytes(code_len, n_ev, n_hs, wide) + k1_extra_lds_bytes(n_ev, n_batches, wide) +
-         K1_WAVES * (lane_mem_wave_bytes(n_actors, REC, hot, wide, fxq_slots) + (FIFO ? k1_fifo_wave_bytes(n_actors, REC, wide) : 0) +
+                                               uint32_t fxq_slots = K1_FXQ_SLOTS, uint32_t arr_words = ARR_WORDS) {
+  return tables_lds_bytes(code_len, n_ev, n_hs, wide, arr_words) + k1_extra_lds_bytes(n_ev, n_batches, wide) +
+         K1_WAVES * (lane_mem_wave_bytes(n_actors, REC, hot, wide, fxq_slots, arr_words) + (FIFO ? k1_fifo_wave_bytes(n_actors, REC, wide) : 0) +
                      k1_tdir_wave_bytes(n_actors, n_timer_types));
 }
 

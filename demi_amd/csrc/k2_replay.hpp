@@ -93,8 +93,8 @@ __host__ __device__ inline size_t k2_fp_lds_bytes(uint32_t code_len, uint32_t n_
 }
 
 __host__ __device__ inline size_t k2_lds_bytes(uint32_t code_len, uint32_t n_ext, uint32_t n_hs, uint32_t n_actors, bool wide = WIDE_TU,
-                                               uint32_t hot = PEND_HOT) {
-  return tables_lds_bytes(code_len, n_ext, n_hs, wide) + K2_WAVES * lane_mem_wave_bytes(n_actors, false, hot, wide);
+                                               uint32_t hot = PEND_HOT, uint32_t arr_words = ARR_WORDS) {
+  return tables_lds_bytes(code_len, n_ext, n_hs, wide, arr_words) + K2_WAVES * lane_mem_wave_bytes(n_actors, false, hot, wide, DEMI_FX_CAP, arr_words);
 }
 
 template <int MODE>

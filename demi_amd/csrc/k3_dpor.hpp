@@ -71,8 +71,9 @@ constexpr size_t K3_ANALYSIS_BYTES = DEMI_DPOR_MAX_TRACE * 4 + DEMI_DPOR_MAX_TRA
 
 // (waves: wavefronts per workgroup of the launch, at most K3_WAVES; the kernel reads it from blockDim)
 __host__ __device__ inline size_t k3_lds_bytes(uint32_t code_len, uint32_t n_ext, uint32_t n_hs, uint32_t n_actors, bool wide = WIDE_TU,
-                                               uint32_t hot = PEND_HOT, uint32_t waves = 4) {
-  return tables_lds_bytes(code_len, n_ext, n_hs, wide) + waves * (lane_mem_wave_bytes(n_actors, true, hot, wide) + K3_ANALYSIS_BYTES);
+                                               uint32_t hot = PEND_HOT, uint32_t waves = 4, uint32_t arr_words = ARR_WORDS) {
+  return tables_lds_bytes(code_len, n_ext, n_hs, wide, arr_words) +
+         waves * (lane_mem_wave_bytes(n_actors, true, hot, wide, DEMI_FX_CAP, arr_words) + K3_ANALYSIS_BYTES);
 }
 
 __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v, uint32_t lane) {

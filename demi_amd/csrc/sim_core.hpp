@@ -31,7 +31,8 @@ enum : uint32_t {
   CW_SKIPZ = 1u << 15, CW_SKIPNZ = 1u << 16, CW_SKIP = 1u << 17,
   CW_FX = 1u << 18, CW_HALT = 1u << 19,
   CW_REL_SHIFT = 20,     // bits 20..22: accepted relations {lt, eq, gt} of compare / guard rows
-  CW_RND = 1u << 23      // dst = seededRandom.nextInt(b)
+  CW_RND = 1u << 23,     // dst = seededRandom.nextInt(b)
+  CW_LDX = 1u << 24, CW_STX = 1u << 25     // dst = ARRAY[b] / ARRAY[b] = a (DEMI_MODEL_ARRAY)
 };
 
 inline uint32_t op_control(uint32_t op) {   // host side: fills DevModel::optab
@@ -58,6 +59,8 @@ inline uint32_t op_control(uint32_t op) {   // host side: fills DevModel::optab
   if (op == DEMI_OP_CRASH) return CW_FX | CW_HALT;     // recorded as the delivery's last effect, then the rows stop
   if (op == DEMI_OP_RND) return CW_ALU | CW_RND;
   if (op == DEMI_OP_MOVHI) return CW_ALU;     // wide tables only, and those are never interpreted (jit.hpp emits it)
+  if (op == DEMI_OP_LDX) return CW_ALU | CW_LDX;   // DEMI_MODEL_ARRAY tables only: compiled, never interpreted (jit.hpp)
+  if (op == DEMI_OP_STX) return CW_STX;
   if (op >= DEMI_OP_IFEQ && op <= DEMI_OP_IFGT) return CW_IF | (rels[op - DEMI_OP_IFEQ] << CW_REL_SHIFT);
   return CW_HALT;   // unknown ops are rejected by validation
 }
@@ -78,8 +81,9 @@ struct Tables {
   uint64_t tix_packed;                   // their timer indices, two bits per message type
 };
 
-__host__ __device__ inline size_t tables_lds_bytes(uint32_t code_len, uint32_t n_ev, uint32_t n_hs, bool wide = WIDE_TU) {
-  size_t b = (size_t)n_ev * 8 + DEMI_MAX_ACTORS * 8 * (wide ? 2 : 1) + (size_t)code_len * 4 + (size_t)n_hs * 4 +
+__host__ __device__ inline size_t tables_lds_bytes(uint32_t code_len, uint32_t n_ev, uint32_t n_hs, bool wide = WIDE_TU,
+                                                   uint32_t arr_words = ARR_WORDS) {
+  size_t b = (size_t)n_ev * 8 + DEMI_MAX_ACTORS * 8 * ((wide ? 2 : 1) + arr_words) + (size_t)code_len * 4 + (size_t)n_hs * 4 +
              DEMI_MAX_MSG_TYPES * 4 + 132 * 4 + 64 * 4;
   return (b + 15) & ~(size_t)15;
 }
@@ -101,8 +105,13 @@ __device__ inline unsigned char* tables_load(Tables& t, unsigned char* smem, con
   uint32_t* s_magic = s_meta + DEMI_MAX_MSG_TYPES;
   uint32_t* s_optab = s_magic + 132;
   for (uint32_t i = threadIdx.x; i < n_ev; i += blockDim.x) s_trace[i] = g_trace[i];
-  for (uint32_t i = threadIdx.x; i < DEMI_MAX_ACTORS * ST_WORDS; i += blockDim.x)
-    s_init[i] = WIDE_TU ? gm->init_state_wide[i] : gm->init_state[i];
+  for (uint32_t i = threadIdx.x; i < DEMI_MAX_ACTORS * ST_WORDS; i += blockDim.x) {
+    if (ARR_WORDS == 0) s_init[i] = WIDE_TU ? gm->init_state_wide[i] : gm->init_state[i];
+    else {                                   // (the fields from the model, the arrays empty)
+      const uint32_t a = i / ST_WORDS, k = i % ST_WORDS;
+      s_init[i] = k >= FLD_WORDS ? 0ull : WIDE_TU ? gm->init_state_wide[a * FLD_WORDS + k] : gm->init_state[a];
+    }
+  }
   for (uint32_t i = threadIdx.x; i < t.code_len; i += blockDim.x) s_code[i] = gm->code[i];
   for (uint32_t i = threadIdx.x; i < n_hs; i += blockDim.x) s_hs[i] = gm->handler_start[i];
   for (uint32_t i = threadIdx.x; i < DEMI_MAX_MSG_TYPES; i += blockDim.x) s_meta[i] = gm->meta[i];
@@ -142,9 +151,9 @@ struct LaneMem {
 // fxq_slots: entries of the effect queue (DEMI_FX_CAP; a K1 compiled with an effect-slot schedule only stores its SEND /
 // BCAST slots, jit.hpp fx_schedule)
 __host__ __device__ inline size_t lane_mem_wave_bytes(uint32_t n_actors, bool aux, uint32_t hot = PEND_HOT, bool wide = WIDE_TU,
-                                                      uint32_t fxq_slots = DEMI_FX_CAP) {
+                                                      uint32_t fxq_slots = DEMI_FX_CAP, uint32_t arr_words = ARR_WORDS) {
   const size_t wb = wide ? 8 : 4;     // bytes per message / effect word
-  return (size_t)n_actors * 64 * 8 * (wide ? 2 : 1) + (size_t)hot * 64 * (wb + (aux ? 4 : 0)) + (size_t)fxq_slots * 64 * wb;
+  return (size_t)n_actors * 64 * 8 * ((wide ? 2 : 1) + arr_words) + (size_t)hot * 64 * (wb + (aux ? 4 : 0)) + (size_t)fxq_slots * 64 * wb;
 }
 // HBM scratch words for `lanes` simulators (per array)
 __host__ __device__ inline size_t spill_words(size_t lanes, uint32_t hot = PEND_HOT) { return lanes * (DEMI_MAX_PENDING - hot); }

@@ -29,7 +29,8 @@ SRC, ME = Reg(14), Reg(15)              # sender id (15 = deadLetters), own id
 
 OPS = dict(HALT=0, MOV=1, ADD=2, SUB=3, AND=4, OR=5, XOR=6, SHL=7, SHR=8, BITSET=9, POPC=10,
            EQ=11, NE=12, LT=13, GE=14, LE=15, GT=16, MIN=17, MAX=18, MOVHI=19, SKIPZ=20, SKIPNZ=21, SKIP=22,
-           SEND=24, BCAST=25, TSET=26, TREP=27, TCANCEL=28, CRASH=29, RND=30, IFEQ=32, IFNE=33, IFLT=34, IFGE=35, IFLE=36, IFGT=37)
+           SEND=24, BCAST=25, TSET=26, TREP=27, TCANCEL=28, CRASH=29, RND=30, IFEQ=32, IFNE=33, IFLT=34, IFGE=35, IFLE=36, IFGT=37,
+           LDX=38, STX=39)
 
 
 def row(op, dst=0, a=0, bimm=0, aux=0, b=0):
@@ -74,6 +75,20 @@ class Asm:
         self.mov(dst, int(value) & 0xFF)
         if int(value) >> 8:
             self.movhi(dst, dst, int(value) >> 8)
+        return self
+
+    def ldx(self, dst, index):
+        """dst = ARRAY[index] (DEMI_MODEL_ARRAY: the actor's array beside its eight fields; index a register or a constant;
+        past the end: 0)."""
+        bimm, bv = self._b(index)
+        self.rows.append(row(OPS["LDX"], int(dst), 0, bimm, 0, bv))
+        return self
+
+    def stx(self, index, value):
+        """ARRAY[index] = value (a register; past the end: nothing)."""
+        assert isinstance(value, Reg)
+        bimm, bv = self._b(index)
+        self.rows.append(row(OPS["STX"], 0, int(value), bimm, 0, bv))
         return self
 
     def rnd(self, dst, bound):
@@ -198,11 +213,18 @@ class Model:
     inv_fb: int = 0
     fp_match_mask: int = 0xFFFFFFFF
     wide: bool = False                # DEMI_MODEL_WIDE: 16 x u16 register window
+    array_len: int = 0                # DEMI_MODEL_ARRAY: elements of every actor's array (LDX / STX), 0 = none
     _keep: list = field(default_factory=list, repr=False, compare=False)
 
     @property
     def n_msg_types(self):
         return len(self.msg_names)
+
+    @property
+    def state_words(self):
+        """64-bit words of one actor's state: its field word(s), then its array (8 elements to a word, 4 when wide)."""
+        per = 4 if self.wide else 8
+        return (2 if self.wide else 1) + (self.array_len + per - 1) // per
 
     def to_struct(self) -> T.ModelStruct:
         mc = (C.c_uint8 * len(self.msg_class))(*self.msg_class)
@@ -215,7 +237,7 @@ class Model:
                           C.cast(hs, C.POINTER(C.c_uint16)), C.cast(code, C.POINTER(C.c_uint32)),
                           C.cast(init, C.POINTER(C.c_uint64)),
                           self.inv_kind, self.inv_fa, self.inv_va, self.inv_fb, self.fp_match_mask,
-                          T.MODEL_WIDE if self.wide else 0)
+                          (T.MODEL_WIDE if self.wide else 0) | T.MODEL_ARRAY(self.array_len))
         self._keep = [mc, ac, hs, code, init]   # keep the buffers alive as long as the Model
         return s
 
@@ -225,6 +247,8 @@ class Model:
                                             "inv_fa", "inv_va", "inv_fb", "fp_match_mask")}
         if self.wide:
             d["wide"] = True
+        if self.array_len:
+            d["array_len"] = self.array_len
         return d
 
     @staticmethod
@@ -249,8 +273,9 @@ def pack_state_wide(fields: List[int]) -> List[int]:
 
 
 def build_model(name, n_actors, msgs, handlers, init_fields, invariant, actor_class=None, n_classes=1,
-                fp_match_mask=0xFFFFFFFF, wide=False) -> Model:
+                fp_match_mask=0xFFFFFFFF, wide=False, array_len=0) -> Model:
     """msgs: list of (name, class); handlers: {(actor_class, msg name): Asm}."""
+    assert 0 <= array_len <= T.MAX_ARRAY
     names = [m[0] for m in msgs]
     code: List[int] = []
     hs = [0xFFFF] * (n_classes * len(msgs))
@@ -271,7 +296,8 @@ def build_model(name, n_actors, msgs, handlers, init_fields, invariant, actor_cl
                  actor_class=list(actor_class or [0] * n_actors), n_classes=n_classes, handler_start=hs,
                  code=code, init_state=([w for f in init_fields for w in pack_state_wide(f)] if wide else
                                         [pack_state(f) for f in init_fields]),
-                 inv_kind=inv_kind, inv_fa=fa, inv_va=va, inv_fb=fb, fp_match_mask=fp_match_mask, wide=wide)
+                 inv_kind=inv_kind, inv_fa=fa, inv_va=va, inv_fb=fb, fp_match_mask=fp_match_mask, wide=wide,
+                 array_len=array_len)
 
 
 # --------------------------------------------------------------------------- raft-synth
@@ -469,3 +495,34 @@ def shuffle_model(buggy=True) -> Model:
     return build_model("shuffle8-synth%s" % ("" if buggy else "-fixed"), 8, SH_MSGS, h, init,
                        invariant=(T.INV_NEVER, 2, 1, 0), actor_class=[CLS_DRIVER, CLS_COORD, CLS_COORD] + [CLS_WORKER] * 5,
                        n_classes=3)
+
+
+# --------------------------------------------------------------------------- replicated log (DEMI_MODEL_ARRAY)
+# Primary-backup log replication with the LOG ITSELF in the actors' state - what raft-synth above abstracts to a length
+# (akka-raft keeps `replicatedLog: Vector[Entry]`; eight fields cannot).  The array of every actor is its log.  Whoever
+# receives a client's Put appends the value and broadcasts Append(index, value); a backup appends the entry that comes next,
+# ignores one it already has, and answers with its length either way; the primary answers an Ack that shows a backup behind
+# with the entry that backup is missing (read from its own log at a computed index: LDX).  Messages overtake each other under
+# the random schedulers, so gaps are the normal case.  The seeded bug: a backup that receives an entry beyond its length stores
+# it where it belongs anyway and advances its length past the gap - a log with a hole.  Invariant (a DEMI_INV_PROGRAM that
+# reads the array): no actor has an empty slot (value 0; clients never Put 0) below its length.
+REPLOG_MSGS = [("Put", T.MSG_EXTERNAL), ("Append", T.MSG_INTERNAL), ("Ack", T.MSG_INTERNAL)]
+RL_PUT, RL_APPEND, RL_ACK = range(3)
+RL_LEN = F[0]
+
+
+def replog_model(n_actors=3, log_len=6, buggy=True, wide=False) -> Model:
+    assert 1 <= log_len <= T.MAX_ARRAY
+    put = Asm().if_lt(RL_LEN, log_len, "x").stx(RL_LEN, P0).mov(T0, RL_LEN).add(RL_LEN, RL_LEN, 1).bcast(RL_APPEND, T0, P0).label("x")
+    ap = Asm().if_eq(P0, RL_LEN, "other").stx(P0, P1).add(RL_LEN, RL_LEN, 1).send(RL_ACK, SRC, RL_LEN, 0).halt()
+    ap.label("other").if_gt(P0, RL_LEN, "x")                     # beyond the end: a gap
+    if buggy:
+        ap.stx(P0, P1).add(RL_LEN, P0, 1)
+    ap.send(RL_ACK, SRC, RL_LEN, 0).label("x")
+    ack = Asm().if_lt(P0, RL_LEN, "x").ldx(T0, P0).send(RL_APPEND, SRC, P0, T0).label("x")
+    inv = Asm()
+    for i in range(log_len):
+        inv.if_gt(RL_LEN, i, "n%d" % i).ldx(T1, i).if_eq(T1, 0, "n%d" % i).mov(T0, 1).label("n%d" % i)
+    h = {(0, "Put"): put, (0, "Append"): ap, (0, "Ack"): ack}
+    return build_model("replog%d-%d%s%s" % (n_actors, log_len, "" if buggy else "-fixed", "-wide" if wide else ""), n_actors,
+                       REPLOG_MSGS, h, [[0] * 8] * n_actors, invariant=(T.INV_NEVER, inv), wide=wide, array_len=log_len)

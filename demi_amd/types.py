@@ -73,6 +73,13 @@ class ModelStruct(C.Structure):
 
 
 MODEL_WIDE = 0x1            # demi_model.flags: 16 x u16 register window (include/demi_gpu.h, DEMI_MODEL_WIDE)
+MAX_ARRAY = 64              # DEMI_MAX_ARRAY
+
+
+def MODEL_ARRAY(n):
+    """demi_model.flags: every actor owns an array of n elements (DEMI_MODEL_ARRAY, rows LDX / STX)."""
+    return (int(n) & 0xFF) << 8
+
 
 
 FILTER_ABSENTS_OFF, FILTER_ABSENTS_LITERAL, FILTER_ABSENTS_CORRECTED = 0, 1, 2     # demi_filter_absents

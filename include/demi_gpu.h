@@ -116,7 +116,10 @@ typedef enum {
                            Applications draw their randomness (akka-raft: election timeouts) from this generator, a
                            scala.util.Random(0) - the same JDK LCG - recreated with every ActorSystem, i.e. a second
                            deterministic stream that restarts at seed 0 in every execution (Instrumenter.scala:212,
-                           226-229, 570).                                                                          */
+                           226-229, 570).                                                                          */,
+  /* Indexed state (DEMI_MODEL_ARRAY below): the actor's array - a log, a vote table - beside its eight fields. */
+  DEMI_OP_LDX = 38,     /* dst = ARRAY[b]  (b register or immediate; an index >= the array's length reads 0)         */
+  DEMI_OP_STX = 39      /* ARRAY[b] = a    (an index >= the array's length stores nothing)                             */
 } demi_op;
 
 #define DEMI_ROW(op, dst, a, bimm, aux, b) \
@@ -175,10 +178,26 @@ typedef struct {
  *                    p1 is not reported there.
  * A wide model runs only as a compiled table (demi_model_specialize must succeed: there is no interpreter for it; the kernels
  * are compiled for it at their first launch and a failure is an error, never a fallback): the RandomScheduler entry points
- * with DEMI_STRATEGY_FULLY_RANDOM incl. demi_random_get_trace, the replay entry points (the pending-set scan variant of the
- * kernel) and the DPOR entry points.  DEMI_STRATEGY_SRC_DST_FIFO and executions_per_instance > 1 return
- * DEMI_ERR_INVALID_MODEL for it.  The 8-bit layout is untouched by the option (same code, same verdict hashes as before). */
+ * (both strategies, independent or carried generators, incl. demi_random_get_trace: every variant of the kernel is compiled
+ * for the table), the replay entry points (the pending-set scan variant of the kernel) and the DPOR entry points.  The 8-bit
+ * layout is untouched by the option (same code, same verdict hashes as before). */
 #define DEMI_MODEL_WIDE 0x1u
+
+/* DEMI_MODEL_ARRAY(n): every actor owns, beside its eight state fields, an ARRAY of n elements (1..DEMI_MAX_ARRAY) of the
+ * register window's width (u8, or u16 with DEMI_MODEL_WIDE) - the part of an actor's state that eight fields cannot hold: a
+ * replicated log (akka-raft's `replicatedLog`), a table of votes, a mailbox of deferred requests.  Rows reach it through
+ * DEMI_OP_LDX / DEMI_OP_STX with a computed index; the arrays start all-zero (a log starts empty; `init_state` keeps its
+ * layout and holds the fields only); they are part of the actor's state in every respect: persisted across deliveries,
+ * hashed into demi_verdict.hash after the actor's field word(s) - element 0 in the lowest bits of the first array word, 8 (wide:
+ * 4) elements per 64-bit word - and visible to a DEMI_INV_PROGRAM (LDX is a pure row; STX is not allowed there).  The length
+ * lives in bits 8..15 of `flags`.  Like a wide table, a table with an array runs only as compiled code
+ * (demi_model_specialize).  Budget: a schedule's actor states live in LDS, n_actors x (1 (wide: 2) + ceil(n / 8 (wide: 4)))
+ * words of 8 bytes per simulated schedule, 256 schedules to a workgroup of the RandomScheduler kernel - 2 KB per state word and
+ * actor next to the tables, within the 160 KB of a CU (5 actors with 64 narrow elements: 90 KB; with 64 wide ones the launch is
+ * refused: DEMI_ERR_INVALID_ARG, "LDS budget exceeded"). */
+#define DEMI_MAX_ARRAY 64
+#define DEMI_MODEL_ARRAY(n) ((uint32_t)(n) << 8)
+#define DEMI_MODEL_ARRAY_LEN(flags) (((flags) >> 8) & 0xFFu)
 
 typedef struct {
   uint32_t max_messages;              /* RandomScheduler.setMaxMessages (RandomScheduler.scala:54-57); 0 = unbounded */

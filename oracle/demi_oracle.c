@@ -61,6 +61,23 @@ static uint32_t timer_bit(const demi_model* m, uint32_t rcv, uint32_t type) {
   return 1u << (rcv * DEMI_MAX_TIMER_TYPES + (uint32_t)timer_index(m, type));
 }
 
+/* state words of one actor: its field word(s) - one, two for DEMI_MODEL_WIDE - then its array (DEMI_MODEL_ARRAY: 8 elements
+ * per word, 4 for a wide model), include/demi_gpu.h */
+#define ORC_MAX_STW (2 + DEMI_MAX_ARRAY / 4)
+static inline uint32_t model_fw(const demi_model* m) { return (m->flags & DEMI_MODEL_WIDE) ? 2u : 1u; }
+static inline uint32_t model_arr_words(const demi_model* m) {
+  const uint32_t per = (m->flags & DEMI_MODEL_WIDE) ? 4u : 8u;
+  return (DEMI_MODEL_ARRAY_LEN(m->flags) + per - 1) / per;
+}
+static inline uint32_t model_stw(const demi_model* m) { return model_fw(m) + model_arr_words(m); }
+uint32_t orc_model_state_words(const demi_model* m) { return model_stw(m); }
+/* the initial state: the fields from init_state, the arrays empty */
+static void state_init(const demi_model* m, uint64_t* st) {
+  const uint32_t fw = model_fw(m), stw = model_stw(m);
+  for (uint32_t a = 0; a < m->n_actors; a++)
+    for (uint32_t k = 0; k < stw; k++) st[a * stw + k] = k < fw ? m->init_state[a * fw + k] : 0;
+}
+
 #define FAIL(...)                                  \
   do {                                             \
     if (err) snprintf(err, err_cap, __VA_ARGS__);  \
@@ -121,19 +138,23 @@ int orc_model_validate(const demi_model* m, char* err, size_t err_cap) {
         break;
       case DEMI_OP_CRASH:
         break;
+      case DEMI_OP_LDX: case DEMI_OP_STX:
+        if (!DEMI_MODEL_ARRAY_LEN(m->flags)) FAIL("row %u: LDX / STX in a model without DEMI_MODEL_ARRAY", pc);
+        break;
       default:
         FAIL("row %u: unknown op %u", pc, op);
     }
   }
   if ((m->inv_kind & ~DEMI_INV_PROGRAM) > DEMI_INV_AGREE) FAIL("inv_kind invalid");
-  if (m->flags & ~DEMI_MODEL_WIDE) FAIL("unknown model flags 0x%x", m->flags);
+  if (m->flags & ~(DEMI_MODEL_WIDE | 0xFF00u)) FAIL("unknown model flags 0x%x", m->flags);
+  if (DEMI_MODEL_ARRAY_LEN(m->flags) > DEMI_MAX_ARRAY) FAIL("DEMI_MODEL_ARRAY: at most %d elements", DEMI_MAX_ARRAY);
   if (m->inv_kind & DEMI_INV_PROGRAM) {
     /* the per-actor predicate / key as rows (include/demi_gpu.h): pure rows only, from inv_fa to the end of the table */
     if ((m->inv_kind & 0xFFu) == DEMI_INV_NONE) FAIL("DEMI_INV_PROGRAM needs a combining kind");
     if (m->inv_fa >= m->code_len) FAIL("invariant program starts past the end of the table");
     for (uint32_t pc = m->inv_fa; pc < m->code_len; pc++) {
       const uint32_t op = m->code[pc] & 0xFF;
-      if ((op >= DEMI_OP_SEND && op <= DEMI_OP_RND))
+      if ((op >= DEMI_OP_SEND && op <= DEMI_OP_RND) || op == DEMI_OP_STX)
         FAIL("row %u: an invariant program has no effects and draws no random numbers", pc);
     }
   } else if (m->inv_fa > 7 || m->inv_fb > 7 || m->inv_va > ((m->flags & DEMI_MODEL_WIDE) ? 65535u : 255u)) FAIL("invariant field out of range");
@@ -196,6 +217,9 @@ static int vm_run_at(const demi_model* m, uint32_t start, uint32_t me, uint64_t*
   /* the register window: 16 x u8, or 16 x u16 for DEMI_MODEL_WIDE (state = two words, four 16-bit fields each) */
   const int wide = (m->flags & DEMI_MODEL_WIDE) != 0;
   const uint32_t M = wide ? 0xFFFFu : 0xFFu, SH = wide ? 15u : 7u;
+  /* the actor's array (DEMI_MODEL_ARRAY): behind its field word(s), `per` elements of `bits` bits to a word */
+  const uint32_t arr_len = DEMI_MODEL_ARRAY_LEN(m->flags), per = wide ? 4u : 8u, bits = wide ? 16u : 8u;
+  uint64_t* const arr = state + (wide ? 2 : 1);
   uint16_t r[16];
   for (int i = 0; i < 8; i++) r[i] = wide ? (uint16_t)(state[i >> 2] >> (16 * (i & 3))) : (uint16_t)((*state >> (8 * i)) & 0xFF);
   r[8] = r[9] = r[10] = r[11] = 0;
@@ -230,6 +254,10 @@ static int vm_run_at(const demi_model* m, uint32_t start, uint32_t me, uint64_t*
       case DEMI_OP_MAX: r[dst] = a > b ? a : b; break;
       case DEMI_OP_RND: /* Instrumenter().seededRandom.nextInt(bound) (V/Instrumenter.scala:212, 226-229) */
         r[dst] = (b & 0xFFu) ? (uint16_t)orc_jrandom_next_int_bound(app, (int32_t)(b & 0xFFu)) : 0;   /* bound = b & 0xFF */
+        break;
+      case DEMI_OP_LDX: r[dst] = b < arr_len ? (uint16_t)((arr[b / per] >> (bits * (b % per))) & M) : 0; break;
+      case DEMI_OP_STX:
+        if (b < arr_len) arr[b / per] = (arr[b / per] & ~((uint64_t)M << (bits * (b % per)))) | ((uint64_t)a << (bits * (b % per)));
         break;
       case DEMI_OP_SKIPZ: if (a == 0) pc += braw; break;
       case DEMI_OP_SKIPNZ: if (a != 0) pc += braw; break;
@@ -287,8 +315,8 @@ static int vm_run_at(const demi_model* m, uint32_t start, uint32_t me, uint64_t*
  * simulated actor state instead of CheckpointReply maps (checkpointing is off by default,
  * V/SchedulerConfig.scala:11-12).  Returns the ViolationFingerprint code.                      */
 /* field f of actor i: 8 bits of its one state word, or 16 bits of its two (DEMI_MODEL_WIDE) */
-static inline uint32_t fldw(int wide, const uint64_t* st, uint32_t i, uint32_t f) {
-  return wide ? (uint32_t)(st[2 * i + (f >> 2)] >> (16 * (f & 3))) & 0xFFFFu : (uint32_t)(st[i] >> (8 * f)) & 0xFFu;
+static inline uint32_t fldw(int wide, const uint64_t* st, uint32_t stw, uint32_t i, uint32_t f) {
+  return wide ? (uint32_t)(st[stw * i + (f >> 2)] >> (16 * (f & 3))) & 0xFFFFu : (uint32_t)(st[stw * i] >> (8 * f)) & 0xFFu;
 }
 
 /* per actor: does it count ("hit") and under which key.  Descriptor: F[fa] == va (AGREE: F[fa] != 0), key F[fb].
@@ -296,8 +324,10 @@ static inline uint32_t fldw(int wide, const uint64_t* st, uint32_t i, uint32_t f
  * hit = T0 != 0, key = T1 (include/demi_gpu.h). */
 static void inv_actor(const demi_model* m, const uint64_t* st, uint32_t i, uint32_t* hit, uint32_t* key) {
   const int wide = (m->flags & DEMI_MODEL_WIDE) != 0;
+  const uint32_t stw = model_stw(m);
   if (m->inv_kind & DEMI_INV_PROGRAM) {
-    uint64_t copy[2] = {wide ? st[2 * i] : st[i], wide ? st[2 * i + 1] : 0};
+    uint64_t copy[ORC_MAX_STW];
+    memcpy(copy, st + (size_t)stw * i, sizeof(uint64_t) * stw);
     uint16_t r[16];
     orc_jrandom none;
     orc_jrandom_seed(&none, 0);
@@ -306,9 +336,9 @@ static void inv_actor(const demi_model* m, const uint64_t* st, uint32_t i, uint3
     *key = r[9];
     return;
   }
-  const uint32_t a = fldw(wide, st, i, m->inv_fa);
+  const uint32_t a = fldw(wide, st, stw, i, m->inv_fa);
   *hit = ((m->inv_kind & 0xFFu) == DEMI_INV_AGREE) ? (a != 0) : (a == m->inv_va);
-  *key = fldw(wide, st, i, m->inv_fb);
+  *key = fldw(wide, st, stw, i, m->inv_fb);
 }
 
 uint32_t orc_invariant(const demi_model* m, const uint64_t* st, uint32_t exists) {
@@ -380,7 +410,7 @@ typedef struct {
   const demi_limits* lim;
   orc_jrandom rng;
   int wide;                             /* DEMI_MODEL_WIDE */
-  uint64_t state[2 * DEMI_MAX_ACTORS];  /* one word per actor; two for a wide model */
+  uint64_t state[ORC_MAX_STW * DEMI_MAX_ACTORS];  /* model_stw words per actor: field word(s), then the array */
   uint32_t exists, inaccessible, killed;
   uint32_t blocked;     /* Instrumenter().blockedActors (crashed actors), V/Instrumenter.scala:116, 184-199 */
   uint64_t partitioned; /* bit a*8+b : ordered pair (a,b), V/schedulers/EventOrchestrator.scala:51 */
@@ -619,7 +649,7 @@ static inline void hash_step(uint64_t* h, uint64_t v) { *h = (*h ^ v) * 0x100000
 static void deliver(exec_t* x, uint64_t word) {
   uint32_t me = W_DST(word);
   orc_effect* fx = x->fx; /* DEMI_MAX_CODE rows x at most DEMI_MAX_ACTORS effects each: never full */
-  int n = orc_vm_run(x->m, me, &x->state[x->wide ? 2 * me : me], (uint8_t)W_TYPE(word), (uint8_t)W_SRC(word),
+  int n = orc_vm_run(x->m, me, &x->state[model_stw(x->m) * me], (uint8_t)W_TYPE(word), (uint8_t)W_SRC(word),
                      (uint16_t)WX_P0(x->wide, word), (uint16_t)WX_P1(x->wide, word), x->exists, fx,
                      DEMI_MAX_CODE * DEMI_MAX_ACTORS, &x->app_rng);
   if (n < 0) { x->flags |= DEMI_V_QUEUE_OVF; return; }
@@ -748,8 +778,8 @@ static int random_execute_in2(exec_t* x, const demi_model* m, const demi_ext_eve
     if (trace[i].kind == DEMI_EV_START) x->exists |= 1u << trace[i].a;
   if (lim->populate_all) x->exists = (1u << m->n_actors) - 1;
   x->inaccessible = x->exists;
-  const uint32_t n_state = m->n_actors * (x->wide ? 2u : 1u);
-  for (uint32_t a = 0; a < n_state; a++) x->state[a] = m->init_state[a];
+  const uint32_t n_state = m->n_actors * model_stw(m);
+  state_init(m, x->state);
   x->next_id = 1;
   x->hash = 0xCBF29CE484222325ULL;
 
@@ -903,7 +933,7 @@ typedef struct { uint64_t word; uint32_t seq; } sts_pend;   /* word: 64 bits for
 typedef struct {
   const demi_model* m;
   int wide;           /* DEMI_MODEL_WIDE: 64-bit message words, two state words per actor */
-  uint64_t state[2 * DEMI_MAX_ACTORS];
+  uint64_t state[ORC_MAX_STW * DEMI_MAX_ACTORS];
   uint32_t exists, inaccessible, killed;
   uint32_t blocked;   /* crashed actors (Instrumenter().blockedActors): an expected delivery to one is not "pending" (:392-402) */
   orc_jrandom app_rng; /* Instrumenter().seededRandom, new with every replay */
@@ -974,7 +1004,7 @@ static void sts_deliver(sts_t* x, uint64_t w) {
   /* Instrumenter retrigger of repeating timers (V/Instrumenter.scala:1008-1016), pinned before receive */
   if (m->msg_class[W_TYPE(w)] == DEMI_MSG_TIMER && (x->repeating & timer_bit(m, me, W_TYPE(w))))
     sts_handle_timer(x, me, W_TYPE(w));
-  int n = orc_vm_run(m, me, &x->state[x->wide ? 2 * me : me], (uint8_t)W_TYPE(w), (uint8_t)W_SRC(w), (uint16_t)WX_P0(x->wide, w),
+  int n = orc_vm_run(m, me, &x->state[model_stw(m) * me], (uint8_t)W_TYPE(w), (uint8_t)W_SRC(w), (uint16_t)WX_P0(x->wide, w),
                      (uint16_t)WX_P1(x->wide, w), x->exists, x->fx, DEMI_MAX_CODE * DEMI_MAX_ACTORS, &x->app_rng);
   if (n < 0) { x->flags |= DEMI_V_QUEUE_OVF; return; }
   for (int i = 0; i < n && !(x->flags & OVF_ANY); i++) {
@@ -1038,7 +1068,7 @@ static int sts_replay_in(sts_t* x, const demi_model* m, const demi_ext_event* ex
     if (rec[i].kind == DEMI_REC_SPAWN) x->exists |= 1u << rec[i].rcv;
   if (lim->populate_all) x->exists = (1u << m->n_actors) - 1;
   x->inaccessible = x->exists;
-  for (uint32_t a = 0; a < m->n_actors * (x->wide ? 2u : 1u); a++) x->state[a] = m->init_state[a];
+  state_init(m, x->state);
 
 #define IN_MASK(i) ((mask[(i) >> 6] >> ((i) & 63)) & 1)
   /* id -> index of the Send that enqueued it (external messages only): filterSends (:382-452) */
@@ -1131,7 +1161,7 @@ static int sts_replay_in(sts_t* x, const demi_model* m, const demi_ext_event* ex
     uint32_t fp = orc_invariant(m, x->state, x->exists);
     if (fp && ((fp ^ lim->looking_for) & m->fp_match_mask) == 0) viol = lim->looking_for;
   }
-  for (uint32_t a = 0; a < m->n_actors * (x->wide ? 2u : 1u); a++) hash_step(&x->hash, x->state[a]);
+  for (uint32_t a = 0; a < m->n_actors * model_stw(m); a++) hash_step(&x->hash, x->state[a]);
   if (x->flags & OVF_ANY) {
     out->flags = x->flags & OVF_ANY; out->fingerprint = 0; out->hash = 0;
   } else {
@@ -1238,7 +1268,7 @@ typedef struct {
   const demi_model* m;
   const demi_dpor_params* par;
   int wide;                             /* DEMI_MODEL_WIDE: 64-bit message words, two state words per actor */
-  uint64_t state[2 * DEMI_MAX_ACTORS];
+  uint64_t state[ORC_MAX_STW * DEMI_MAX_ACTORS];
   uint32_t isolated;
   uint32_t blocked;    /* crashed actors: skipped by getPendingEvent (:455) and by getMatchingMessage (:478, 518) */
   orc_jrandom app_rng; /* Instrumenter().seededRandom, new with every interleaving */
@@ -1321,7 +1351,7 @@ static void dpor_deliver(dpor_t* x, uint64_t w) {
   hash_step(&x->hash, w);
   if (m->msg_class[W_TYPE(w)] == DEMI_MSG_TIMER && (x->repeating & timer_bit(m, me, W_TYPE(w))))
     dpor_produce(x, msg_word(W_TYPE(w), DEMI_DEADLETTERS, me, 0, 0)); /* retrigger -> enqueue_timer = `!` (Scheduler.scala:73) */
-  int n = orc_vm_run(m, me, &x->state[x->wide ? 2 * me : me], (uint8_t)W_TYPE(w), (uint8_t)W_SRC(w), (uint16_t)WX_P0(x->wide, w),
+  int n = orc_vm_run(m, me, &x->state[model_stw(m) * me], (uint8_t)W_TYPE(w), (uint8_t)W_SRC(w), (uint16_t)WX_P0(x->wide, w),
                      (uint16_t)WX_P1(x->wide, w), (1u << m->n_actors) - 1, x->fx, DEMI_MAX_CODE * DEMI_MAX_ACTORS, &x->app_rng);
   if (n < 0) { x->flags |= DEMI_V_QUEUE_OVF; return; }
   for (int i = 0; i < n && !(x->flags & OVF_ANY); i++) {
@@ -1360,7 +1390,7 @@ int orc_dpor_execute(const demi_model* m, const demi_ext_event* ext, uint32_t n_
   x->hash = 0xCBF29CE484222325ULL;
   x->isolated = (1u << m->n_actors) - 1; /* maybeStartActors: isolatedActors ++= actorNames (:666-679) */
   orc_jrandom_seed(&x->app_rng, 0);
-  for (uint32_t a = 0; a < m->n_actors * (x->wide ? 2u : 1u); a++) x->state[a] = m->init_state[a];
+  state_init(m, x->state);
   dpor_trace_push(x, DPOR_ROOT_KEY, 0, 0, 0); /* start_trace: currentTrace += getRootEvent (:336-343) */
   x->parent = 0; x->cur_root = 0;
   uint32_t ext_idx = dpor_run_external(x, ext, n_ext, 0);
@@ -1443,7 +1473,7 @@ int orc_dpor_execute(const demi_model* m, const demi_ext_event* ext, uint32_t n_
       else if (((fp ^ par->looking_for) & m->fp_match_mask) == 0) viol = par->looking_for;
     }
   }
-  for (uint32_t a = 0; a < m->n_actors * (x->wide ? 2u : 1u); a++) hash_step(&x->hash, x->state[a]);
+  for (uint32_t a = 0; a < m->n_actors * model_stw(m); a++) hash_step(&x->hash, x->state[a]);
 
   /* ---- dpor(): racing pairs (:1122-1139) with isCoEnabeled (:1091-1110) and analyze_dep (:1043-1077) */
   uint32_t np = 0, pairs_ovf = 0;

@@ -176,7 +176,7 @@ def random_execute(model, events, seed, limits, record=True):
     v = T.Verdict()
     rec = np.zeros(T.MAX_REC_EVENTS, dtype=T.REC_EVENT_DTYPE)
     n_rec = C.c_uint32(0)
-    states = np.zeros(model.n_actors * (2 if getattr(model, "wide", False) else 1), dtype=np.uint64)
+    states = np.zeros(model.n_actors * model.state_words, dtype=np.uint64)
     rc = lib().orc_random_execute(C.byref(ms), ev.ctypes.data, len(ev), C.c_uint64(seed), C.byref(limits),
                                   C.byref(v), rec.ctypes.data if record else None, len(rec), C.byref(n_rec),
                                   states.ctypes.data)

@@ -103,7 +103,7 @@ class GpuRandomScheduler(val schedulerConfig: SchedulerConfig, max_executions: I
       val m = lowering.model
       check(h, modelLoad(h, m.nActors, m.msgClass, m.actorClass, m.nClasses, m.handlerStart, m.code, m.initState,
                          Array(m.invKind, m.invFa, m.invVa, m.invFb, m.fpMatchMask, m.flags)))
-      if (m.wide) check(h, modelSpecialize(h, true))             // a wide table runs only as compiled code
+      if (m.compiledOnly) check(h, modelSpecialize(h, true))     // a wide table, or one with arrays, runs only as compiled code
       else if (max_executions >= (1 << 16)) modelSpecialize(h, true)   // optional: a failure keeps the table interpreter
       modelLoaded = true
     }
@@ -181,6 +181,7 @@ class GpuSTSScheduler(val schedulerConfig: SchedulerConfig, original_trace: Even
     val m = lowering.model
     check(h, modelLoad(h, m.nActors, m.msgClass, m.actorClass, m.nClasses, m.handlerStart, m.code, m.initState,
                        Array(m.invKind, m.invFa, m.invVa, m.invFb, m.fpMatchMask, m.flags)))
+    if (m.compiledOnly) check(h, modelSpecialize(h, true))
     check(h, replayLoad(h, FlatEvents.pack(externals, lowering), recorded))
   }
   def getName = "GpuSTSSchedNoPeek"
@@ -263,6 +264,7 @@ class GpuStsRemovalOracle(schedulerConfig: SchedulerConfig, mcs: Seq[ExternalEve
       val m = lowering.model
       check(h, modelLoad(h, m.nActors, m.msgClass, m.actorClass, m.nClasses, m.handlerStart, m.code, m.initState,
                          Array(m.invKind, m.invFa, m.invVa, m.invFb, m.fpMatchMask, m.flags)))
+      if (m.compiledOnly) check(h, modelSpecialize(h, true))
       modelLoaded = true
     }
     if (!(loaded eq trace)) { check(h, replayLoad(h, FlatEvents.pack(mcs, lowering), FlatEvents.packRecorded(trace, lowering))); loaded = trace }

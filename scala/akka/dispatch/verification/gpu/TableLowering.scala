@@ -6,10 +6,13 @@ import akka.dispatch.verification._
 case class FlatModel(nActors: Int, msgClass: Array[Byte], actorClass: Array[Byte], nClasses: Int,
                      handlerStart: Array[Short], code: Array[Int], initState: Array[Long],
                      invKind: Int, invFa: Int, invVa: Int, invFb: Int, fpMatchMask: Int = 0xFFFFFFFF,
-                     wide: Boolean = false) {
+                     wide: Boolean = false, arrayLen: Int = 0) {
   /** demi_model.flags.  wide = DEMI_MODEL_WIDE: 16-bit state fields and payloads (terms / log indices above 255); initState then
-   *  holds two words per actor (F0..F3, F4..F7) and the model runs through GpuRandomScheduler only (include/demi_gpu.h). */
-  def flags: Int = if (wide) 1 else 0
+   *  holds two words per actor (F0..F3, F4..F7).  arrayLen = DEMI_MODEL_ARRAY(n): every actor owns an array of n elements
+   *  beside its eight fields (rows LDX / STX: a replicated log, a vote table), empty at the start (include/demi_gpu.h). */
+  def flags: Int = (if (wide) 1 else 0) | ((arrayLen & 0xFF) << 8)
+  /** Such a table has no interpreter on the device: every scheduler compiles it right after loading it. */
+  def compiledOnly: Boolean = wide || arrayLen > 0
 }
 
 /** What an application supplies next to its MessageFingerprinter (MessageFingerprints.scala:14-32): how its actors,

@@ -29,6 +29,27 @@ static inline uint32_t fx_pack(uint32_t op, uint32_t type, uint32_t target, uint
   return (op & 31u) | (type << 5) | (target << 10) | (p0 << 14) | (p1 << 22);
 }
 #endif
+// DEMI_MODEL_ARRAY (demi_device.hpp): the state words of an actor are its field word(s), then its array - here with shifts and
+// masks on the 64-bit words (the device addresses the element's byte / half-word directly)
+#ifndef DEMI_JIT_ARR_LEN
+#define DEMI_JIT_ARR_LEN 0
+#endif
+#ifdef DEMI_WIDE
+constexpr uint32_t FLD_WORDS = 2, ARR_PER = 4, ARR_BITS = 16;
+#else
+constexpr uint32_t FLD_WORDS = 1, ARR_PER = 8, ARR_BITS = 8;
+#endif
+constexpr uint32_t ARR_LEN = DEMI_JIT_ARR_LEN, ST_WORDS = FLD_WORDS + (ARR_LEN + ARR_PER - 1) / ARR_PER;
+static inline uint32_t arr_load(const uint64_t* st, uint32_t a, uint32_t idx) {
+  if (idx >= ARR_LEN) return 0;
+  return (uint32_t)(st[(ST_WORDS * a + FLD_WORDS + idx / ARR_PER) * 64] >> (ARR_BITS * (idx % ARR_PER))) & ((1u << ARR_BITS) - 1u);
+}
+static inline void arr_store(uint64_t* st, uint32_t a, uint32_t idx, uint32_t v) {
+  if (idx >= ARR_LEN) return;
+  uint64_t& w = st[(ST_WORDS * a + FLD_WORDS + idx / ARR_PER) * 64];
+  const uint64_t m = (uint64_t)((1u << ARR_BITS) - 1u) << (ARR_BITS * (idx % ARR_PER));
+  w = (w & ~m) | (((uint64_t)v << (ARR_BITS * (idx % ARR_PER))) & m);
+}
 static inline int __popc(uint32_t x) { return __builtin_popcount(x); }
 // DEMI_OP_RND: java.util.Random.nextInt(bound) on the application's generator (the device uses multiply-high magics for the
 // modulo; here the plain JDK algorithm - the results must agree)

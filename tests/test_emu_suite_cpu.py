@@ -103,6 +103,11 @@ def test_wide_tables_every_k1_variant_on_the_cpu():
                   "test_wide_gpu.py::test_wide_random_tables_parity[2]"])
 
 
+def test_array_tables_through_every_kernel_on_the_cpu():
+    """DEMI_MODEL_ARRAY (LDX / STX, the replicated-log model): K1 in every variant, K2, the native DDMin, K3."""
+    run_emulated(["test_array_gpu.py"])
+
+
 def test_results_do_not_depend_on_the_order_of_the_lanes_within_an_interval():
     run_emulated(["test_k1_gpu.py::test_raft5_parity_all_capacities[32]",
                   "test_k1_gpu.py::test_srcdst_fifo_parity_raft5[64]",

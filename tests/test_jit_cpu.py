@@ -59,7 +59,7 @@ def _host_vm(model, tmp_path, k1=False):
                    % (os.path.join(ROOT, "tests", "jit_host_shim.hpp"), src))
     so = tmp_path / (("vm_host_wide" if wide else "vm_host") + ("_k1.so" if k1 else ".so"))
     subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-label"] + (["-DDEMI_WIDE"] if wide else []) +
-                          ["-o", str(so), str(cpp)])
+                          ["-DDEMI_JIT_ARR_LEN=%d" % getattr(model, "array_len", 0), "-o", str(so), str(cpp)])
     L = C.CDLL(str(so))
     L.run.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64 if wide else C.c_uint32, C.POINTER(C.c_uint32)]
     L.run.restype = C.c_uint32
@@ -309,6 +309,104 @@ def _random_handler_wide(rng, n_rows, n_types):
     return b
 
 
+def _random_handler_array(rng, n_rows, n_types, wide):
+    """A random handler whose rows also load from and store to the actor's array (LDX / STX): indices from registers and
+    constants, in and out of range."""
+    base = _random_handler_wide(rng, n_rows, n_types) if wide else _random_handler(rng, n_rows, n_types, few_effects=True)
+    b = M.Asm()
+    regs = [M.Reg(i) for i in range(16)]
+    pre = int(rng.integers(2, 7))
+    for _ in range(pre):
+        idx = regs[int(rng.integers(16))] if rng.integers(3) else int(rng.integers(0, 80))
+        if rng.integers(2):
+            b.ldx(regs[int(rng.integers(12))], idx)
+        else:
+            b.stx(idx, regs[int(rng.integers(16))])
+    b.rows += base.rows
+    b._fix = [(i + pre, lab) for i, lab in base._fix]
+    b._labels = {k: v + pre for k, v in base._labels.items()}
+    # ... and a few more after the random rows, where the registers hold computed values (reached when no row halts before)
+    for _ in range(int(rng.integers(1, 4))):
+        if rng.integers(2):
+            b.stx(regs[int(rng.integers(16))], regs[int(rng.integers(16))])
+        else:
+            b.ldx(regs[int(rng.integers(8))], regs[int(rng.integers(16))])
+    return b
+
+
+@pytest.mark.parametrize("seed,wide,alen", [(1, False, 20), (2, False, 64), (3, True, 10), (4, True, 64), (5, False, 3)])
+def test_array_tables_through_the_code_generator(oracle, tmp_path, seed, wide, alen):
+    """DEMI_MODEL_ARRAY: the generated LDX / STX statements (a narrow LDS access to the element inside the actor's array
+    words, which lie behind its field words) equal the oracle's row interpreter on random rows x random (fields, array,
+    message), both window widths, lengths that do and do not fill their last word; the kernels compile for gfx950."""
+    rng = np.random.default_rng(100 + seed)
+    MSGS = [("E", T.MSG_EXTERNAL), ("A", T.MSG_INTERNAL), ("B", T.MSG_INTERNAL), ("Tm", T.MSG_TIMER)]
+    h = {(0, name): _random_handler_array(rng, int(rng.integers(4, 30)), len(MSGS), wide) for name, _ in MSGS}
+    A, NT = 4, len(MSGS)
+    model = M.build_model("rand_arr%d" % seed, A, MSGS, h, [[0] * 8] * A, (T.INV_NEVER, 0, 200, 0), wide=wide, array_len=alen)
+    assert oracle.model_validate(model)[0] == 0
+    stw = model.state_words
+    assert stw == (2 if wide else 1) + (alen + (3 if wide else 7)) // (4 if wide else 8)
+    if seed in (1, 3):
+        try:
+            size, kernel = _native.specialize_check(model.to_struct())
+            assert size > 10000 and kernel.count("k1_random_explore") == 8 and "k2_replay" in kernel and "k3_dpor" in kernel
+        except _native.DemiError as e:
+            if "hiprtc not found" not in str(e):
+                raise
+    L = _host_vm(model, tmp_path)
+    ms = model.to_struct()
+    hs = np.full(T.MAX_CLASSES * T.MAX_MSG_TYPES, 0xFFFF, dtype=np.uint32)
+    hs[:len(model.handler_start)] = model.handler_start
+    st = np.zeros(8 * stw * 64, dtype=np.uint64)
+    fxq = np.zeros(FX_CAP * 64, dtype=np.uint64 if wide else np.uint32)
+    fx = (Effect * 64)()
+    want_state = (C.c_uint64 * stw)()
+    hi = 65536 if wide else 256
+    changed = loaded = 0
+    for it in range(5000):
+        me, typ = int(rng.integers(A)), int(rng.integers(NT))
+        src = int(rng.choice([int(rng.integers(A)), T.DEADLETTERS]))
+        p0, p1 = int(rng.integers(hi)), int(rng.integers(hi))
+        fields = [int(x) for x in rng.integers(0, min(hi, 90 if it % 3 else hi), 8)]       # (small values index the array)
+        words = (M.pack_state_wide(fields) if wide else [M.pack_state(fields)]) + [int(x) for x in rng.integers(0, 1 << 63, stw - (2 if wide else 1), dtype=np.uint64)]
+        # the unused tail of the last array word stays zero, as in an execution (no STX reaches it)
+        per, bits = (4, 16) if wide else (8, 8)
+        if alen % per:
+            words[-1] &= (1 << (bits * (alen % per))) - 1
+        for k, wv in enumerate(words):
+            st[(stw * me + k) * 64] = wv
+            want_state[k] = wv
+        w = typ | (me << 5) | (src << 8) | (p0 << 16) | (p1 << (32 if wide else 24))
+        flags = C.c_uint32(0)
+        n = L.run(hs.ctypes.data, 0, NT, st.ctypes.data, fxq.ctypes.data, w, C.byref(flags))
+        wn = oracle.lib().orc_vm_run(C.byref(ms), me, want_state, typ, src, p0, p1, (1 << A) - 1, fx, 64, C.byref(L.app_rng))
+        if wn < 0:
+            assert flags.value & T.V_QUEUE_OVF
+            continue
+        assert not flags.value
+        got_state = [int(st[(stw * me + k) * 64]) for k in range(stw)]
+        assert got_state == [int(x) for x in want_state], (it, me, typ, fields)
+        changed += got_state[(2 if wide else 1):] != words[(2 if wide else 1):]
+        loaded += got_state[:(2 if wide else 1)] != words[:(2 if wide else 1)]
+        got = []
+        for k in range(n):
+            f = int(fxq[k * 64])
+            if wide:
+                op, t_, target, q0, q1 = f & 31, (f >> 5) & 31, (f >> 10) & 15, (f >> 14) & 0xFFFF, (f >> 30) & 0xFFFF
+            else:
+                op, t_, target, q0, q1 = f & 31, (f >> 5) & 31, (f >> 10) & 15, (f >> 14) & 0xFF, (f >> 22) & 0xFF
+            if op == M.OPS["SEND"]:
+                if target < A:
+                    got.append((0, target, t_, q0, q1))
+            elif op == M.OPS["BCAST"]:
+                got += [(0, r, t_, q0, q1) for r in range(A) if r != me]
+            else:
+                got.append((1 + op - M.OPS["TSET"], me, t_, 0, 0))
+        assert got == [(e.kind, e.target, e.msg_type, e.p0, e.p1) for e in fx[:wn]], (it, me, typ)
+    assert changed > 300 and loaded > 300
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_wide_tables_through_the_code_generator(oracle, tmp_path, seed):
     """DEMI_MODEL_WIDE: the generated handlers over the 16 x u16 window (masks, shifts by b & 15, 16-bit POPC, MOVHI, state in
@@ -428,7 +526,7 @@ def _meta_values(image, key):
     return vals
 
 
-@pytest.mark.parametrize("wide", [False, True])
+@pytest.mark.parametrize("wide", [False, True, "array"])
 def test_no_specialised_kernel_touches_scratch_memory(tmp_path, wide):
     """None of the compiled kernels may keep anything in the stack frame (scratch = HBM-backed private memory): the replay and
     DPOR kernels are latency-bound chains, and a variable that lives there costs a memory round trip per use.  Round 3 found
@@ -436,7 +534,8 @@ def test_no_specialised_kernel_touches_scratch_memory(tmp_path, wide):
     among four variables and was compiled into a table of their addresses."""
     code = ("import sys; sys.path.insert(0, %r)\n"
             "from demi_amd import _native, model as M\n"
-            "m = M.raft_model(5, term0=1000, loglen0=300) if %r else M.raft_model(5)\n"
+            "w = %r\n"
+            "m = M.replog_model(5, 16, True, False) if w == 'array' else M.raft_model(5, term0=1000, loglen0=300) if w else M.raft_model(5)\n"
             "try:\n"
             "    print('SIZE', _native.specialize_check(m.to_struct())[0])\n"
             "except _native.DemiError as e:\n"

@@ -624,3 +624,84 @@ def test_program_invariants_equal_a_plain_python_evaluation(oracle, wide):
             assert got == want, (trial, fields, exists, hex(got), hex(want))
             nonzero += got != 0
     assert nonzero > 200
+
+
+# --------------------------------------------------------------------------- DEMI_MODEL_ARRAY: the replicated log
+def replog_reference(L, buggy, me, length, log, msg, src, p0, p1, others, mask):
+    """model.replog_model's protocol in plain Python: (new length, new log, effects)."""
+    log = list(log)
+    fx = []
+    if msg == M.RL_PUT:
+        if length < L:
+            log[length] = p0
+            fx += [("send", j, M.RL_APPEND, length, p0) for j in others]
+            length += 1
+    elif msg == M.RL_APPEND:
+        if p0 == length:
+            if p0 < L:
+                log[p0] = p1
+            length = (length + 1) & mask
+            fx.append(("send", src, M.RL_ACK, length, 0))
+        elif p0 > length:
+            if buggy:
+                if p0 < L:
+                    log[p0] = p1
+                length = (p0 + 1) & mask
+            fx.append(("send", src, M.RL_ACK, length, 0))
+    elif msg == M.RL_ACK:
+        if p0 < length:
+            fx.append(("send", src, M.RL_APPEND, p0, log[p0] if p0 < L else 0))
+    return length, log, fx
+
+
+@pytest.mark.parametrize("wide", [False, True])
+@pytest.mark.parametrize("buggy", [True, False])
+def test_replicated_log_table_equals_plain_reference(oracle, buggy, wide):
+    """LDX / STX (the actor's array, DEMI_MODEL_ARRAY) as the oracle's row interpreter runs them, against the protocol written
+    out in Python: the log in the state words behind the fields (8 elements to a word, 4 when wide), indices from registers,
+    reads and writes past the end, and the invariant program that reads the log."""
+    A, L = 4, 6
+    model = M.replog_model(A, L, buggy, wide)
+    assert model.array_len == L and model.state_words == (2 if wide else 1) + (2 if wide else 1)
+    ms = model.to_struct()
+    rnd = random.Random(7 + wide)
+    fx = (_Effect * 64)()
+    stw, fw = model.state_words, 2 if wide else 1
+    per, bits, mask = (4, 16, 0xFFFF) if wide else (8, 8, 0xFF)
+    st = (C.c_uint64 * stw)()
+    seen_hole = 0
+    for _ in range(6000):
+        me = rnd.randrange(A)
+        msg = rnd.randrange(3)
+        src = T.DEADLETTERS if msg == M.RL_PUT else rnd.choice([j for j in range(A) if j != me])
+        length = rnd.choice([rnd.randrange(L + 1), rnd.randrange(L + 1), rnd.randrange(mask + 1)])
+        log = [rnd.choice([0, rnd.randrange(1, mask + 1)]) for _ in range(L)]
+        p0 = rnd.choice([rnd.randrange(L + 2), length, rnd.randrange(mask + 1)])
+        p1 = rnd.randrange(1, mask + 1)
+        fields = [length] + [rnd.randrange(mask + 1) for _ in range(7)]
+        words = (M.pack_state_wide(fields) if wide else [M.pack_state(fields)]) + [0] * (stw - fw)
+        for i, v in enumerate(log):
+            words[fw + i // per] |= v << (bits * (i % per))
+        for k in range(stw):
+            st[k] = words[k]
+        n = oracle.lib().orc_vm_run(C.byref(ms), me, st, msg, src, p0, p1, (1 << A) - 1, fx, 64, C.byref(C.c_uint64(0x5DEECE66D)))
+        want_len, want_log, want_fx = replog_reference(L, buggy, me, length, log, msg, src, p0, p1, [j for j in range(A) if j != me], mask)
+        got_fields = [(st[i // 4] >> (16 * (i % 4))) & 0xFFFF for i in range(8)] if wide else [(st[0] >> (8 * i)) & 0xFF for i in range(8)]
+        got_log = [(st[fw + i // per] >> (bits * (i % per))) & mask for i in range(L)]
+        assert got_fields == [want_len] + fields[1:] and got_log == want_log, (length, log, msg, p0, p1)
+        assert [("send", e.target, e.msg_type, e.p0, e.p1) for e in fx[:n]] == want_fx, (length, log, msg, p0, p1)
+        # the invariant program: a slot below the length that holds 0
+        full = (C.c_uint64 * (A * stw))()
+        for k in range(stw):
+            full[me * stw + k] = st[k]
+        hole = any(want_log[i] == 0 for i in range(min(want_len, L)))
+        assert oracle.lib().orc_invariant(C.byref(ms), full, 1 << me) == (((2 << 24) | (1 << me)) if hole else 0)
+        seen_hole += hole
+    assert seen_hole > 500
+    # the rules of the option at the boundary
+    bad = build_model("noarr", 2, [("E", T.MSG_EXTERNAL)], {(0, "E"): Asm().ldx(M.T0, 1)}, [[0] * 8] * 2, (T.INV_NONE, 0, 0, 0))
+    rc, msg_ = oracle.model_validate(bad)
+    assert rc == T.ERR_INVALID_MODEL and "DEMI_MODEL_ARRAY" in msg_
+    bad = build_model("stxinv", 2, [("E", T.MSG_EXTERNAL)], {(0, "E"): Asm().mov(M.T0, 1)}, [[0] * 8] * 2,
+                      (T.INV_NEVER, Asm().stx(0, M.T0)), array_len=4)
+    assert oracle.model_validate(bad)[0] == T.ERR_INVALID_MODEL
