@@ -105,7 +105,7 @@ def test_wide_tables_every_k1_variant_on_the_cpu():
 
 def test_array_tables_through_every_kernel_on_the_cpu():
     """DEMI_MODEL_ARRAY (LDX / STX, the replicated-log model): K1 in every variant, K2, the native DDMin, K3."""
-    run_emulated(["test_array_gpu.py"])
+    run_emulated(["test_zz_array_gpu.py"])
 
 
 def test_results_do_not_depend_on_the_order_of_the_lanes_within_an_interval():

@@ -2,7 +2,11 @@
 include/demi_gpu.h): the kernels compiled from the table against the oracle's row interpreter, through the C ABI - the
 RandomScheduler kernel in every variant, recorded traces, STSScheduler replays and DDMin, DPOR.  Bit-exact bar as
 everywhere: the 16-byte verdict incl. the hash over every delivered message word and EVERY state word of every actor, the
-array words included."""
+array words included.
+
+(The file sorts last on purpose: it was written at the end of round 3 with no GPU minutes left - green on the CPU emulator in
+both lane orders, every kernel compiled for gfx950 without scratch - and the round-end GPU run uses `-x`: a surprise here must
+not hide the suites that have run on the MI355X before.)"""
 import os
 
 import numpy as np
