@@ -315,14 +315,37 @@ RAFT_MSGS = [("Bootstrap", T.MSG_EXTERNAL), ("ClientCommand", T.MSG_EXTERNAL),
  M_APPEND_REPLY, M_HEARTBEAT) = range(8)
 
 
-def raft_model(n_actors=5, election_budget=1, buggy=True, term0=0, loglen0=0, invariant=None) -> Model:
+RAFT_LOG_MAX = 15      # log_cap of raft_model: AppendEntries packs index (4 bits), prevLogTerm and the entry's term (6 bits each)
+
+
+def raft_entry_word(idx, prev_term, term):
+    """p1 of an AppendEntries that carries log entry `idx` (1-based; 0 = none) of raft_model(log_cap > 0)."""
+    return idx | (prev_term << 4) | (term << 10)
+
+
+def raft_model(n_actors=5, election_budget=1, buggy=True, term0=0, loglen0=0, invariant=None, log_cap=0) -> Model:
     """term0 / loglen0: the term and the log length every node starts with.  Values above 255 (a cluster that has been
     running for a while) need 16-bit fields and payloads: the model is then lowered as DEMI_MODEL_WIDE, same handlers.
     invariant: None = "at most one leader per term" as a descriptor; or what build_model takes, e.g. (kind, Asm) for a
-    DEMI_INV_PROGRAM invariant over the fields ROLE, TERM, ... of this module."""
-    wide = max(term0, loglen0) > 200
+    DEMI_INV_PROGRAM invariant over the fields ROLE, TERM, ... of this module.
+    log_cap > 0: the nodes keep a REAL log (DEMI_MODEL_ARRAY(log_cap): element i = the term of entry i + 1, 0 = none) instead
+    of its length only - akka-raft's `replicatedLog` - and AppendEntries carries one entry with the consistency check of the
+    protocol: p1 = index | prevLogTerm << 4 | entry term << 10 (raft_entry_word; a wide table).  A follower appends the entry
+    (or overwrites a conflicting suffix) when the entry before it matches, else answers with a hint (0x8000 | where to retry)
+    and the leader backs up, reading its own log at the computed index; an answer that shows a follower behind is followed by
+    the next entry.  Elections (and the seeded bug) are as without a log."""
+    assert 0 <= log_cap <= RAFT_LOG_MAX and not (log_cap and (term0 > 50 or loglen0))
+    wide = max(term0, loglen0) > 200 or log_cap > 0
     majority = n_actors // 2 + 1
     h = {}
+
+    def entry_word(a, k, uniq):
+        """rows: T3 = raft_entry_word(k, log[k - 2] (0 when k < 2), log[k - 1]) for the 1-based index in register k (T0..T2
+        are free to use except k itself); k == 0 gives 0."""
+        a.mov(T3, 0).if_ne(k, 0, "ew%s" % uniq)
+        a.sub(T3, k, 1).ldx(T3, T3).shl(T3, T3, 10).or_(T3, T3, k)              # entry term << 10 | index
+        a.if_ge(k, 2, "ew%s" % uniq).sub(T2, k, 2).ldx(T2, T2).shl(T2, T2, 4).or_(T3, T3, T2)
+        a.label("ew%s" % uniq)
 
     # Bootstrap (the ChangeConfiguration the DEMi raft runner Sends after Start): begin as follower.
     a = Asm()
@@ -332,7 +355,12 @@ def raft_model(n_actors=5, election_budget=1, buggy=True, term0=0, loglen0=0, in
     # ClientCommand: a leader appends and replicates; everyone else ignores it.
     a = Asm()
     a.if_eq(ROLE, LEADER, "done")
-    a.add(LOGLEN, LOGLEN, 1).bcast(M_APPEND_ENTRIES, TERM, LOGLEN).label("done")
+    if log_cap:
+        a.if_lt(LOGLEN, log_cap, "done").stx(LOGLEN, TERM).add(LOGLEN, LOGLEN, 1)
+        entry_word(a, LOGLEN, "c")
+        a.bcast(M_APPEND_ENTRIES, TERM, T3).label("done")
+    else:
+        a.add(LOGLEN, LOGLEN, 1).bcast(M_APPEND_ENTRIES, TERM, LOGLEN).label("done")
     h[(0, "ClientCommand")] = a
 
     # ElectionTimeout: start an election (bounded number per node so that executions quiesce).
@@ -375,7 +403,11 @@ def raft_model(n_actors=5, election_budget=1, buggy=True, term0=0, loglen0=0, in
     a.if_eq(ROLE, CANDIDATE, "done").if_eq(P0, TERM, "done").and_(T0, P1, 1).if_ne(T0, 0, "done")
     a.bitset(VOTES, VOTES, SRC).popc(T1, VOTES).if_ge(T1, majority, "done")
     a.mov(ROLE, LEADER).tcancel(M_ELECTION_TIMEOUT).trep(M_HEARTBEAT)
-    a.bcast(M_APPEND_ENTRIES, TERM, LOGLEN).label("done")
+    if log_cap:
+        entry_word(a, LOGLEN, "v")                           # its last entry (nothing when the log is empty)
+        a.bcast(M_APPEND_ENTRIES, TERM, T3).label("done")
+    else:
+        a.bcast(M_APPEND_ENTRIES, TERM, LOGLEN).label("done")
     h[(0, "VoteReply")] = a
 
     # AppendEntries(term, loglen) from SRC.
@@ -389,9 +421,23 @@ def raft_model(n_actors=5, election_budget=1, buggy=True, term0=0, loglen0=0, in
     a.label("sameterm")
     a.if_ne(ROLE, LEADER, "keep").mov(ROLE, FOLLOWER)       # same term: a candidate steps down, a leader stays
     a.label("keep")
-    a.mov(TERM, P0).max(LOGLEN, LOGLEN, P1)
-    a.tcancel(M_ELECTION_TIMEOUT).tset(M_ELECTION_TIMEOUT)
-    a.send(M_APPEND_REPLY, SRC, TERM, P1)
+    if log_cap:
+        a.mov(TERM, P0).tcancel(M_ELECTION_TIMEOUT).tset(M_ELECTION_TIMEOUT)
+        a.and_(T0, P1, 15).shr(T1, P1, 4).and_(T1, T1, 63).shr(T2, P1, 10)     # T0 = index, T1 = prevLogTerm, T2 = entry term
+        a.if_ne(T0, 0, "none")
+        a.if_ge(T0, 2, "prevok")                                               # the entry before it: there, with that term?
+        a.sub(T3, T0, 1).if_le(T3, LOGLEN, "nack").sub(T3, T0, 2).ldx(T3, T3).if_eq(T3, T1, "nack")
+        a.label("prevok")
+        a.sub(T3, T0, 1).mov(T1, 0).if_le(T0, LOGLEN, "cmp").ldx(T1, T3)       # T1 = what it holds at that index (0 past the end)
+        a.label("cmp").if_ne(T1, T2, "have").stx(T3, T2).mov(LOGLEN, T0)       # append, or overwrite and cut a conflicting suffix
+        a.label("have").send(M_APPEND_REPLY, SRC, TERM, T0).halt()
+        # (the hint: one back, or the end of a shorter log)
+        a.label("nack").sub(T3, T0, 2).min(T3, T3, LOGLEN).movhi(T3, T3, 0x80).send(M_APPEND_REPLY, SRC, TERM, T3).halt()
+        a.label("none").mov(T3, 0).send(M_APPEND_REPLY, SRC, TERM, T3)
+    else:
+        a.mov(TERM, P0).max(LOGLEN, LOGLEN, P1)
+        a.tcancel(M_ELECTION_TIMEOUT).tset(M_ELECTION_TIMEOUT)
+        a.send(M_APPEND_REPLY, SRC, TERM, P1)
     h[(0, "AppendEntries")] = a
 
     # AppendReply(term, acked) from SRC.
@@ -401,19 +447,32 @@ def raft_model(n_actors=5, election_budget=1, buggy=True, term0=0, loglen0=0, in
     a.mov(TERM, P0).mov(ROLE, FOLLOWER).mov(VOTED, NOBODY).halt()
     a.label("cur")
     a.if_eq(ROLE, LEADER, "done").if_eq(P0, TERM, "done")
-    a.max(COMMIT, COMMIT, P1).label("done")
+    if log_cap:
+        a.and_(T0, P1, 255).shr(T1, P1, 15).if_eq(T1, 0, "hint")              # matched up to T0
+        a.if_le(T0, LOGLEN, "done").max(COMMIT, COMMIT, T0).skip("next")
+        a.label("hint")                                                        # refused: retry right after the hinted index
+        a.label("next").if_lt(T0, LOGLEN, "done").add(T0, T0, 1)
+        entry_word(a, T0, "r")
+        a.send(M_APPEND_ENTRIES, SRC, TERM, T3).label("done")
+    else:
+        a.max(COMMIT, COMMIT, P1).label("done")
     h[(0, "AppendReply")] = a
 
     # Heartbeat (repeating timer): a leader re-sends uncommitted entries.
     a = Asm()
     a.if_ne(ROLE, LEADER, "lead").tcancel(M_HEARTBEAT).halt()
     a.label("lead").if_gt(LOGLEN, COMMIT, "done")
-    a.bcast(M_APPEND_ENTRIES, TERM, LOGLEN).label("done")
+    if log_cap:
+        entry_word(a, LOGLEN, "h")
+        a.bcast(M_APPEND_ENTRIES, TERM, T3).label("done")
+    else:
+        a.bcast(M_APPEND_ENTRIES, TERM, LOGLEN).label("done")
     h[(0, "Heartbeat")] = a
 
     init = [[FOLLOWER, term0, NOBODY, 0, election_budget, loglen0, loglen0, 0] for _ in range(n_actors)]
-    return build_model("raft%d-synth%s%s" % (n_actors, "" if buggy else "-fixed", "-wide" if wide else ""), n_actors, RAFT_MSGS,
-                       h, init, invariant=invariant or (T.INV_AT_MOST_ONE, int(ROLE), LEADER, int(TERM)), wide=wide)
+    return build_model("raft%d-synth%s%s%s" % (n_actors, "" if buggy else "-fixed", "-wide" if wide else "", "-log%d" % log_cap if log_cap else ""),
+                       n_actors, RAFT_MSGS, h, init, invariant=invariant or (T.INV_AT_MOST_ONE, int(ROLE), LEADER, int(TERM)), wide=wide,
+                       array_len=log_cap)
 
 
 def save_model(model: Model, path: str):

@@ -172,6 +172,108 @@ def raft_reference(n_actors, buggy, me, fields, msg, src, p0, p1, mask=255):
     return [role, term, voted, votes, budget, loglen, commit, booted], fx
 
 
+def raft_log_reference(n_actors, buggy, me, fields, log, msg, src, p0, p1, cap):
+    """raft_model(log_cap = cap): the handlers that touch the log, written out; everything else is raft_reference (wide)."""
+    role, term, voted, votes, budget, loglen, commit, booted = fields
+    log = list(log)
+    others = [j for j in range(n_actors) if j != me]
+    at = lambda i: log[i] if 0 <= i < cap else 0                    # LDX: past the end reads 0
+
+    def entry(k):
+        k &= 0xFFFF
+        return 0 if k == 0 else (((at(k - 1) << 10) | k | ((at(k - 2) << 4) if k >= 2 else 0)) & 0xFFFF)
+
+    if msg == M.M_CLIENT:
+        fx = []
+        if role == M.LEADER and loglen < cap:
+            log[loglen] = term
+            loglen += 1
+            fx = [("send", j, M.M_APPEND_ENTRIES, term, entry(loglen)) for j in others]
+        return [role, term, voted, votes, budget, loglen, commit, booted], log, fx
+    if msg == M.M_APPEND_ENTRIES and p0 >= term:
+        f2, fx = raft_reference(n_actors, buggy, me, fields, msg, src, p0, 0, mask=65535)      # term / role / timers as without a log
+        role, term, voted, votes, budget, _, commit, booted = f2
+        fx = fx[:-1]                                                                           # (its reply is replaced)
+        idx, pt, et = p1 & 15, (p1 >> 4) & 63, p1 >> 10
+        if idx == 0:
+            fx.append(("send", src, M.M_APPEND_REPLY, term, 0))
+        elif idx >= 2 and not (idx - 1 <= loglen and at(idx - 2) == pt):
+            fx.append(("send", src, M.M_APPEND_REPLY, term, 0x8000 | (min(idx - 2, loglen) & 0xFF)))
+        else:
+            cur = at(idx - 1) if idx <= loglen else 0
+            if cur != et:
+                if idx - 1 < cap:
+                    log[idx - 1] = et
+                loglen = idx
+            fx.append(("send", src, M.M_APPEND_REPLY, term, idx))
+        return [role, term, voted, votes, budget, loglen, commit, booted], log, fx
+    if msg == M.M_APPEND_REPLY and not p0 > term:
+        fx = []
+        if role == M.LEADER and p0 == term:
+            t0, ok = p1 & 255, (p1 >> 15) == 0
+            go = True
+            if ok:
+                if t0 <= loglen:
+                    commit = max(commit, t0)
+                else:
+                    go = False
+            if go and t0 < loglen:
+                fx.append(("send", src, M.M_APPEND_ENTRIES, term, entry(t0 + 1)))
+        return [role, term, voted, votes, budget, loglen, commit, booted], log, fx
+    f2, fx = raft_reference(n_actors, buggy, me, fields, msg, src, p0, p1, mask=65535)
+    # the places where the abstract protocol sends its log LENGTH send the last entry instead
+    fx = [("send", e[1], e[2], e[3], entry(f2[5])) if e[0] == "send" and e[2] == M.M_APPEND_ENTRIES else e for e in fx]
+    return f2, log, fx
+
+
+@pytest.mark.parametrize("buggy", [True, False])
+def test_raft_with_a_real_log_equals_plain_reference(oracle, buggy):
+    """raft_model(log_cap = 8): the log in the nodes' arrays, AppendEntries with the consistency check (one entry, prevLogTerm),
+    hints and back-up - the table's rows (LDX / STX at computed indices, packed payloads) against the protocol in Python."""
+    A, cap = 5, 8
+    model = M.raft_model(A, buggy=buggy, log_cap=cap)
+    assert model.wide and model.array_len == cap and model.state_words == 4
+    ms = model.to_struct()
+    rnd = random.Random(11)
+    fx = (_Effect * 64)()
+    st = (C.c_uint64 * 4)()
+    seen = {"append": 0, "nack": 0, "over": 0, "next": 0}
+    for _ in range(12000):
+        me = rnd.randrange(A)
+        msg = rnd.choice([M.M_CLIENT, M.M_APPEND_ENTRIES, M.M_APPEND_ENTRIES, M.M_APPEND_REPLY, M.M_APPEND_REPLY, rnd.randrange(8)])
+        src = T.DEADLETTERS if model.msg_class[msg] != T.MSG_INTERNAL else rnd.choice([j for j in range(A) if j != me])
+        loglen = rnd.randrange(cap + 1)
+        log = [rnd.randrange(1, 6) for _ in range(loglen)] + [rnd.choice([0, 0, rnd.randrange(1, 6)]) for _ in range(cap - loglen)]
+        fields = [rnd.randrange(3), rnd.randrange(1, 7), rnd.choice([M.NOBODY] + list(range(A))), rnd.randrange(32),
+                  rnd.randrange(3), loglen, rnd.randrange(loglen + 1), rnd.randrange(2)]
+        p0 = rnd.randrange(1, 7)
+        if msg == M.M_APPEND_ENTRIES:
+            idx = rnd.choice([0, loglen + 1, loglen + 1, rnd.randrange(cap + 1), rnd.randrange(16)])
+            pt = rnd.choice([log[idx - 2] if 2 <= idx <= cap else 0, rnd.randrange(6)])
+            p1 = M.raft_entry_word(idx, pt, rnd.randrange(1, 6))
+        elif msg == M.M_APPEND_REPLY:
+            p1 = rnd.choice([rnd.randrange(cap + 2), 0x8000 | rnd.randrange(cap + 1)])
+        else:
+            p1 = rnd.randrange(2) if msg == M.M_VOTE_REPLY else rnd.randrange(4)
+        words = M.pack_state_wide(fields) + [sum(v << (16 * (i % 4)) for i, v in enumerate(log) if i // 4 == k) for k in range(2)]
+        for k in range(4):
+            st[k] = words[k]
+        n = oracle.lib().orc_vm_run(C.byref(ms), me, st, msg, src, p0, p1, (1 << A) - 1, fx, 64, C.byref(C.c_uint64(0x5DEECE66D)))
+        want_fields, want_log, want_fx = raft_log_reference(A, buggy, me, fields, log, msg, src, p0, p1, cap)
+        got_fields = [(st[i // 4] >> (16 * (i % 4))) & 0xFFFF for i in range(8)]
+        got_log = [(st[2 + i // 4] >> (16 * (i % 4))) & 0xFFFF for i in range(cap)]
+        got_fx = [("send", e.target, e.msg_type, e.p0, e.p1) if e.kind == 0 else (["", "tset", "trep", "tcancel"][e.kind], e.msg_type)
+                  for e in fx[:n]]
+        assert got_fields == want_fields and got_log == want_log, (fields, log, msg, src, p0, hex(p1))
+        assert got_fx == want_fx, (fields, log, msg, src, p0, hex(p1))
+        if msg == M.M_APPEND_ENTRIES and p0 >= fields[1]:
+            seen["append"] += want_fields[5] == loglen + 1
+            seen["over"] += want_log != log and want_fields[5] <= loglen
+            seen["nack"] += any(e[0] == "send" and e[4] & 0x8000 for e in want_fx)
+        seen["next"] += msg == M.M_APPEND_REPLY and any(e[0] == "send" for e in want_fx)
+    assert all(v > 50 for v in seen.values()), seen
+
+
 class _Effect(C.Structure):      # orc_effect (oracle/demi_oracle.h)
     _fields_ = [("kind", C.c_uint8), ("target", C.c_uint8), ("msg_type", C.c_uint8), ("p0", C.c_uint16), ("p1", C.c_uint16)]
 

@@ -170,3 +170,45 @@ def test_array_tables_replay_ddmin_and_dpor(oracle, wide):
     assert rn.rounds == rc.rounds and all(a.verdict == b.verdict and a.prefix_len == b.prefix_len for a, b in zip(rn.interleavings, rc.interleavings))
     assert len(rc.interleavings) > 50 and rn.violations == rc.violations      # (per-link FIFO order: DPOR never opens the gap)
     dn.shutdown()
+
+
+def test_raft_with_a_real_log_through_the_kernels(oracle):
+    """raft_model(log_cap = 8): akka-raft's `replicatedLog` as the nodes' arrays, AppendEntries with the consistency check,
+    hints and back-up (tests/test_oracle_cpu.py pins the table to the protocol written out).  The bench workload's trace
+    through K1 (both strategies), the recorded trace of a violating execution, K2 replays of candidate subsequences of it,
+    K3 on the three-node cluster."""
+    from demi_amd.apps import raft5_config2
+    from .test_k2_gpu import random_masks
+    from .test_k3_gpu import collect_prefixes, same_batch
+    _, events, lim = raft5_config2()
+    model = M.raft_model(5, log_cap=8)
+    assert model.wide and model.array_len == 8
+    ctx = _native.Context(0)
+    try:
+        for strategy in (T.STRATEGY_FULLY_RANDOM, T.STRATEGY_SRC_DST_FIFO):
+            l2 = T.Limits(lim.max_messages, lim.invariant_check_interval, 64, 0, 0, 0, strategy)
+            g, c = both(ctx, oracle, model, events, 12000, l2)
+            assert_same(g, c)
+            assert (g["flags"] & T.V_VIOLATION).sum() > 20 and len(np.unique(g["hash"])) > 10000
+        g, c = both(ctx, oracle, model, events, 3000, lim)
+        k = int(np.nonzero(g["flags"] & T.V_VIOLATION)[0][0])
+        vv, rec = ctx.random_get_trace(SEED_BASE + k, lim)
+        cv, crec, states = oracle.random_execute(model, events, SEED_BASE + k, lim)
+        assert vv.hash == cv.hash == g[k]["hash"] and (rec == crec).all()
+        _, _, states = oracle.random_execute(model, events, 5, lim, record=False)
+        assert any(int(w) for a in range(5) for w in states[4 * a + 2:4 * a + 4])          # logs with entries at the end of an execution
+        used = events[:T.verdict_trace_idx(vv.flags)]
+        target = T.Limits(0, 0, 64, 1, vv.fingerprint, 0)
+        ctx.replay_load(used, rec)
+        masks = random_masks(np.random.default_rng(1), len(used), 800)
+        assert_same(ctx.replay_batch(masks, target), oracle.sts_replay_batch(model, used, rec, masks, target, n_threads=os.cpu_count()))
+        m3 = M.raft_model(3, log_cap=4)
+        dev = events_to_array([start(a) for a in range(3)] + [send(a, M.M_BOOTSTRAP) for a in range(3)] + [send(a, M.M_CLIENT) for a in range(3)])
+        prefixes, _, _ = collect_prefixes(oracle, m3, dev, 30, 32, 120)
+        ctx.model_load(m3.to_struct())
+        ctx.dpor_load(dev)
+        ctx.model_specialize()
+        par = T.DporParams(30, 0, 0, 0, 64, 4096)
+        same_batch(ctx.dpor_batch(prefixes, par), oracle.dpor_batch(m3, dev, prefixes, par))
+    finally:
+        ctx.close()
