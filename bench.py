@@ -427,6 +427,9 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=1 << 20)
     ap.add_argument("--wide-term0", type=int, default=0,
                     help="experiment, not the headline: the same raft lowered as DEMI_MODEL_WIDE with terms starting here (> 255)")
+    ap.add_argument("--log-cap", type=int, default=0,
+                    help="experiment, not the headline: the raft with a REAL log of this many entries in the nodes' arrays "
+                         "(DEMI_MODEL_ARRAY, raft_model(log_cap)); not yet measured on a GPU (DESIGN section 8, item 0)")
     ap.add_argument("--strategy", choices=["random", "fifo"], default="random",
                     help="RandomizationStrategy: FullyRandom (the headline workload) or SrcDstFIFO")
     args = ap.parse_args()
@@ -480,6 +483,9 @@ def main():
     if args.wide_term0:
         from demi_amd.model import raft_model
         model = raft_model(5, term0=args.wide_term0, loglen0=300)
+    if args.log_cap:
+        from demi_amd.model import raft_model
+        model = raft_model(5, log_cap=args.log_cap)
     limits.p_max = args.p_max
     limits.strategy = T.STRATEGY_SRC_DST_FIFO if args.strategy == "fifo" else T.STRATEGY_FULLY_RANDOM
     n = args.schedules
@@ -665,7 +671,7 @@ def main():
                        "schedules_per_gpu_per_step": n, "max_messages": int(limits.max_messages),
                        "invariant_check_interval": int(limits.invariant_check_interval), "p_max": int(limits.p_max),
                        "randomization_strategy": "SrcDstFIFO" if args.strategy == "fifo" else "FullyRandom",
-                       "table_compiled_to_native_code": specialized, "wide_register_window": bool(getattr(model, "wide", False)), "seed_base": SEED_BASE, "parallelism": "schedule-index range sharded, %d rank(s)" % world, "collective": collective,
+                       "table_compiled_to_native_code": specialized, "wide_register_window": bool(getattr(model, "wide", False)), "array_elements_per_actor": int(getattr(model, "array_len", 0)), "seed_base": SEED_BASE, "parallelism": "schedule-index range sharded, %d rank(s)" % world, "collective": collective,
                        "untimed_prewarm_s": prewarm_s},
             "violations_last_step": int(len(vset)),
             "distinct_fingerprints_last_step": int(len(np.unique(vset["fingerprint"]))) if len(vset) else 0,
