@@ -429,7 +429,7 @@ def main():
                     help="experiment, not the headline: the same raft lowered as DEMI_MODEL_WIDE with terms starting here (> 255)")
     ap.add_argument("--log-cap", type=int, default=0,
                     help="experiment, not the headline: the raft with a REAL log of this many entries in the nodes' arrays "
-                         "(DEMI_MODEL_ARRAY, raft_model(log_cap)); not yet measured on a GPU (DESIGN section 8, item 0)")
+                         "(DEMI_MODEL_ARRAY, raft_model(log_cap)); parity green on the GPU, not yet timed (DESIGN section 8, item 0)")
     ap.add_argument("--strategy", choices=["random", "fifo"], default="random",
                     help="RandomizationStrategy: FullyRandom (the headline workload) or SrcDstFIFO")
     args = ap.parse_args()

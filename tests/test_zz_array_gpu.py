@@ -4,9 +4,9 @@ RandomScheduler kernel in every variant, recorded traces, STSScheduler replays a
 everywhere: the 16-byte verdict incl. the hash over every delivered message word and EVERY state word of every actor, the
 array words included.
 
-(The file sorts last on purpose: it was written at the end of round 3 with no GPU minutes left - green on the CPU emulator in
-both lane orders, every kernel compiled for gfx950 without scratch - and the round-end GPU run uses `-x`: a surprise here must
-not hide the suites that have run on the MI355X before.)"""
+(Written at the end of round 3: green on the MI355X in the round's last GPU seconds - profiles/r03_array_gpu_tests.log - and on
+the CPU emulator in both lane orders.  The file sorts last because it was written before that run: the round-end GPU run uses
+`-x`, and a surprise here must not hide the suites before it.)"""
 import os
 
 import numpy as np
