@@ -206,7 +206,7 @@ class DPORwHeuristics:
                 from . import _native
                 self._ctx = _native.Context(self._device)
                 self._ctx.model_load(self.schedulerConfig.model.to_struct())
-                if self.specialize or getattr(self.schedulerConfig.model, "wide", False):     # (a wide table has no interpreter)
+                if self.specialize or getattr(self.schedulerConfig.model, "compiled_only", False):     # (a wide table has no interpreter)
                     self._ctx.model_specialize()
                 self._ctx.dpor_load(externals)
             fn = lambda part: self._ctx.dpor_batch([p for p, _ in part], params, [s for _, s in part])
@@ -321,7 +321,7 @@ class DPORwHeuristics:
         if self._ctx is None:
             self._ctx = _native.Context(self._device)
             self._ctx.model_load(self.schedulerConfig.model.to_struct())
-            if self.specialize or getattr(self.schedulerConfig.model, "wide", False):
+            if self.specialize or getattr(self.schedulerConfig.model, "compiled_only", False):
                 self._ctx.model_specialize()
             self._ctx.dpor_load(externals)
         search = T.DporSearch(self.batch, max_interleavings, 1 if self.stopIfViolationFound else 0,

@@ -214,7 +214,7 @@ class StsRemovalOracle:
         self.p_max = p_max
         self._ctx = _native.Context(device)
         self._ctx.model_load(schedulerConfig.model.to_struct())
-        if getattr(schedulerConfig.model, "wide", False):
+        if getattr(schedulerConfig.model, "compiled_only", False):
             self._ctx.model_specialize()         # a wide table (DEMI_MODEL_WIDE) runs only as compiled code
         self._loaded = None
 

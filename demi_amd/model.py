@@ -221,6 +221,11 @@ class Model:
         return len(self.msg_names)
 
     @property
+    def compiled_only(self):
+        """A wide table, and one with arrays, has no interpreter on the device: the schedulers compile it right after loading it."""
+        return bool(self.wide or self.array_len)
+
+    @property
     def state_words(self):
         """64-bit words of one actor's state: its field word(s), then its array (8 elements to a word, 4 when wide)."""
         per = 4 if self.wide else 8

@@ -144,7 +144,7 @@ class RandomScheduler:
             self._ctx.model_load(self._model.to_struct())
             self._loaded_model = True
             self._loaded_trace = None
-            if getattr(self._model, "wide", False):
+            if getattr(self._model, "compiled_only", False):
                 self._ctx.model_specialize()     # a wide table (DEMI_MODEL_WIDE) runs only as compiled code: a failure is an error
             elif self.specialize:
                 try:
@@ -265,7 +265,7 @@ class STSScheduler:
         self.p_max = p_max
         self._ctx = _native.Context(device)
         self._ctx.model_load(schedulerConfig.model.to_struct())
-        if getattr(schedulerConfig.model, "wide", False):
+        if getattr(schedulerConfig.model, "compiled_only", False):
             self._ctx.model_specialize()         # a wide table (DEMI_MODEL_WIDE) runs only as compiled code
         elif specialize:
             try:
@@ -367,7 +367,7 @@ class ReplayScheduler:
         self.p_max = p_max
         self._ctx = _native.Context(device)
         self._ctx.model_load(schedulerConfig.model.to_struct())
-        if getattr(schedulerConfig.model, "wide", False):
+        if getattr(schedulerConfig.model, "compiled_only", False):
             self._ctx.model_specialize()         # a wide table (DEMI_MODEL_WIDE) runs only as compiled code
 
     def replay(self, trace: EventTrace, expected: Optional[ViolationFingerprint] = None):

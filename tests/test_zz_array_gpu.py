@@ -212,3 +212,44 @@ def test_raft_with_a_real_log_through_the_kernels(oracle):
         same_batch(ctx.dpor_batch(prefixes, par), oracle.dpor_batch(m3, dev, prefixes, par))
     finally:
         ctx.close()
+
+
+def test_scheduler_mirror_on_a_table_with_arrays(oracle):
+    """The reference-shaped classes (RandomScheduler.explore, STSScheduler + stsSchedDDMin, the removal of internal deliveries,
+    DPORwHeuristics) compile a table with arrays on their own, as they do a wide one: fuzz -> minimise -> replay."""
+    from demi_amd import internal_minimization as IM
+    from demi_amd.minification import stsSchedDDMin
+    from demi_amd.schedulers import EventTrace, RandomScheduler, STSScheduler, SchedulerConfig, ViolationFingerprint
+    from tests.test_minification_cpu import OracleSTS
+    model = M.replog_model(4, 6, True, False)
+    events = put_trace(4, 6, False)
+    cfg = SchedulerConfig(model=model)
+    sched = RandomScheduler(cfg, max_executions=400, invariant_check_interval=0)
+    sched.setMaxMessages(400)
+    v = sched.explore_all(events)
+    c = oracle.random_explore(model, events, 400, seed_base=sched.seed_base if hasattr(sched, "seed_base") else SEED_BASE,
+                              limits=T.Limits(400, 0, 64, 0, 0, 0))
+    assert (v["flags"] & T.V_VIOLATION).sum() > 10
+    if (v["hash"] == c["hash"]).all():
+        assert_same(v, c)
+    sched.shutdown()
+    ctx = _native.Context(0)
+    try:
+        ctx.model_load(model.to_struct()); ctx.trace_load(events); ctx.model_specialize()
+        lim = T.Limits(400, 0, 64, 0, 0, 0)
+        g = ctx.random_explore(200, lim, seed_base=SEED_BASE)
+        k = int(np.nonzero(g["flags"] & T.V_VIOLATION)[0][0])
+        vv, rec = ctx.random_get_trace(SEED_BASE + k, lim)
+    finally:
+        ctx.close()
+    used = events[:T.verdict_trace_idx(vv.flags)]
+    fp = ViolationFingerprint(vv.fingerprint)
+    sts = STSScheduler(cfg, EventTrace(rec, used))
+    mcs_g, d_g, ver_g = stsSchedDDMin(sts, used, fp, speculative_depth=2)
+    mcs_c, d_c, _ = stsSchedDDMin(OracleSTS(oracle, model, used, rec, vv.fingerprint), used, fp, speculative_depth=0)
+    assert mcs_g == mcs_c and d_g.consulted == d_c.consulted and ver_g is not None and 0 < len(mcs_g) < len(used)
+    verified = sts.executed_trace(mcs_g, fp)
+    sts.shutdown()
+    stats, out = IM.minimizeInternals(cfg, verified.original_externals, verified, fp,
+                                      removalStrategyCtor=lambda: IM.LeftToRightOneAtATime(verified, model))
+    assert IM.countMsgEvents(out) <= IM.countMsgEvents(verified) and stats.total_replays > 0
