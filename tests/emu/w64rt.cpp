@@ -10,6 +10,7 @@
 // can deposit for n + 1 before the slowest lane has read n, never for n + 2.
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <sys/mman.h>
 
 #include <atomic>
@@ -73,6 +74,7 @@ struct Wave {
   Lane* lanes[64];
   unsigned n = 0;
   bool at_barrier = false, done = false;
+  uint64_t shuffle_state = 0;
 };
 struct Group {
   std::vector<Lane> lanes;
@@ -83,6 +85,7 @@ struct Group {
 };
 thread_local Group* g_group = nullptr;
 bool g_reverse = false;
+uint64_t g_shuffle = 0;         // W64_LANE_ORDER=shuffle[:seed]
 uint64_t g_watch = 0;          // W64_WATCH=n: report where a wave is every n rendezvous (finding a loop that never ends)
 thread_local Lane* g_cur = nullptr;
 struct StackPool {
@@ -131,6 +134,7 @@ void run_group(dim3 grid, dim3 block, unsigned bx, unsigned by, unsigned bz, voi
   g.lanes.resize(n);
   g.waves.resize((n + 63) / 64);
   for (Wave& w : g.waves) {
+    w.shuffle_state = g_shuffle * 0x9E3779B97F4A7C15ULL + bx * 1315423911ull + (uint64_t)(&w - &g.waves[0]);
     memset(w.val, 0, sizeof w.val);
     memset(w.lane_seq, 0, sizeof w.lane_seq);
   }
@@ -160,10 +164,19 @@ void run_group(dim3 grid, dim3 block, unsigned bx, unsigned by, unsigned bz, voi
       if (w.at_barrier) { any = true; continue; }
       // one pass: every running lane up to its next rendezvous
       bool running = false;
+      unsigned char order[64];
+      if (g_shuffle) {                          // W64_LANE_ORDER=shuffle[:seed]: a new permutation of the lanes for every interval
+        for (unsigned k = 0; k < w.n; k++) order[k] = (unsigned char)k;
+        for (unsigned k = w.n; k > 1; k--) {
+          w.shuffle_state = w.shuffle_state * 6364136223846793005ULL + 1442695040888963407ULL;
+          const unsigned j = (unsigned)((w.shuffle_state >> 33) % k);
+          const unsigned char t = order[k - 1]; order[k - 1] = order[j]; order[j] = t;
+        }
+      }
       for (unsigned k0 = 0; k0 < w.n; k0++) {
         // W64_LANE_ORDER=reverse resumes the lanes of an interval from the last to the first: a kernel whose result depends on
         // which lane's stores another lane sees WITHOUT a cross-lane operation in between computes something else then
-        Lane* l = w.lanes[g_reverse ? w.n - 1 - k0 : k0];
+        Lane* l = w.lanes[g_shuffle ? order[k0] : g_reverse ? w.n - 1 - k0 : k0];
         if (l->done) continue;
         g_cur = l;
         w64_switch(&g.sched_sp, l->sp);
@@ -253,7 +266,8 @@ extern "C" void w64_launch(dim3 grid, dim3 block, size_t lds_bytes, void (*body)
   if (lds_bytes > sizeof demi::smem) die("dynamic LDS beyond 160 KB", (int)lds_bytes);
   const uint64_t n_groups = (uint64_t)grid.x * grid.y * grid.z;
   if (block.x * block.y * block.z == 0 || block.x * block.y * block.z > 1024) die("workgroup size", (int)block.x);
-  { const char* o = getenv("W64_LANE_ORDER"); g_reverse = o && o[0] == 'r'; }
+  { const char* o = getenv("W64_LANE_ORDER"); g_reverse = o && o[0] == 'r';
+    g_shuffle = (o && o[0] == 's') ? (strchr(o, ':') ? strtoull(strchr(o, ':') + 1, nullptr, 10) : 1) | 1ull : 0; }
   { const char* o = getenv("W64_WATCH"); g_watch = o ? strtoull(o, nullptr, 10) : 0; }
   if (getenv("W64_TRACE")) fprintf(stderr, "[w64 launch] grid %u block %u lds %zu\n", grid.x, block.x, lds_bytes);
   const int n_thr = (int)std::min<uint64_t>((uint64_t)env_int("W64_THREADS", 4, 1, 64), n_groups);

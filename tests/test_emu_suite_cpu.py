@@ -8,7 +8,8 @@ GPU (`-m gpu`) and that run is the parity claim.  What this adds without a GPU:
   variant - is held against the oracle in the CPU suite too;
 * the emulator aborts a launch whose lanes meet at different cross-lane operations (divergent ballot / readlane / shuffle),
   so wave-uniformity of those sites is checked, not assumed;
-* `W64_LANE_ORDER=reverse` resumes the lanes of every lock-step interval from the last to the first: a kernel whose result
+* `W64_LANE_ORDER=reverse` (or `shuffle[:seed]`: a new permutation per interval) resumes the lanes of every lock-step interval
+  in another order than first to last: a kernel whose result
   depended on which lane's stores another lane sees WITHOUT an ordering point in between would change its answers (this is
   how the missing ordering point in k_provenance was found: correct in lock step on the GPU, invisible to the compiler).
 
@@ -114,4 +115,4 @@ def test_results_do_not_depend_on_the_order_of_the_lanes_within_an_interval():
                   "test_k2_gpu.py::test_replay_parity_random_subsequences_raft5",
                   "test_k2_gpu.py::test_filter_known_absents_parity[hbm]"], lane_order="reverse")
     run_emulated(["test_k3_gpu.py::test_per_interleaving_outputs_match_the_oracle",
-                  "test_provenance_gpu.py"], threads=1, lane_order="reverse")
+                  "test_provenance_gpu.py", "test_zz_array_gpu.py::test_raft_with_a_real_log_through_the_kernels"], threads=1, lane_order="shuffle:7")
