@@ -44,3 +44,22 @@ def test_dpor_fixture(oracle):
     assert (dv == z["verdicts"]).all()
     assert [len(t) for t in dt] == list(z["trace_len"]) and [len(p) for p in dp] == list(z["n_pairs"])
     assert [_sha(t) for t in dt] == list(z["trace_sha"]) and [_sha(p) for p in dp] == list(z["pairs_sha"])
+
+
+def test_array_model_fixtures(oracle):
+    """DEMI_MODEL_ARRAY: the committed models (rows with LDX / STX, the array length in `flags`) and the oracle's verdicts on
+    them, both strategies - the raft with a real log on the bench trace, the replicated log with its hole."""
+    import pytest
+    for name in ("raft5_log8", "replog4_6"):
+        model = M.load_model(os.path.join(G, name + "_model.json"))
+        assert model.array_len > 0
+        z = np.load(os.path.join(G, name + "_verdicts.npz"))
+        mm, ic, pm = (int(x) for x in z["limits"])
+        for sname, strat in (("random", T.STRATEGY_FULLY_RANDOM), ("fifo", T.STRATEGY_SRC_DST_FIFO)):
+            lim = T.Limits(mm, ic, pm, 0, 0, 0, strat)
+            got = oracle.random_explore(model, z["events"], len(z[sname]), seed_base=SEED_BASE, limits=lim, n_threads=os.cpu_count())
+            assert (got == z[sname]).all(), (name, sname)
+            assert (got["flags"] & T.V_VIOLATION).sum() > 10
+    # the constructors still produce the committed tables
+    assert M.raft_model(5, log_cap=8).code == M.load_model(os.path.join(G, "raft5_log8_model.json")).code
+    assert M.replog_model(4, 6, True, False).code == M.load_model(os.path.join(G, "replog4_6_model.json")).code

@@ -253,3 +253,19 @@ def test_scheduler_mirror_on_a_table_with_arrays(oracle):
     stats, out = IM.minimizeInternals(cfg, verified.original_externals, verified, fp,
                                       removalStrategyCtor=lambda: IM.LeftToRightOneAtATime(verified, model))
     assert IM.countMsgEvents(out) <= IM.countMsgEvents(verified) and stats.total_replays > 0
+
+
+@pytest.mark.parametrize("name", ["raft5_log8", "replog4_6"])
+def test_array_golden_fixtures_on_gpu(name):
+    """The committed fixtures of tools/make_golden.py (models as JSON, the oracle's verdicts for both strategies)."""
+    G = os.path.join(os.path.dirname(__file__), "golden")
+    model = M.load_model(os.path.join(G, name + "_model.json"))
+    z = np.load(os.path.join(G, name + "_verdicts.npz"))
+    mm, ic, pm = (int(x) for x in z["limits"])
+    ctx = _native.Context(0)
+    try:
+        ctx.model_load(model.to_struct()); ctx.trace_load(z["events"]); ctx.model_specialize()
+        for sname, strat in (("random", T.STRATEGY_FULLY_RANDOM), ("fifo", T.STRATEGY_SRC_DST_FIFO)):
+            assert_same(ctx.random_explore(len(z[sname]), T.Limits(mm, ic, pm, 0, 0, 0, strat), seed_base=SEED_BASE), z[sname])
+    finally:
+        ctx.close()

@@ -105,3 +105,22 @@ np.savez(os.path.join(G, "raft3_dpor.npz"), externals=ev3, prefixes=pf, prefix_l
          trace_sha=np.array([hashlib.sha256(np.ascontiguousarray(t).tobytes()).hexdigest() for t in dt]),
          pairs_sha=np.array([hashlib.sha256(np.ascontiguousarray(p).tobytes()).hexdigest() for p in dp]))
 print("extra fixtures written")
+
+# ---------------------------------------------------------------------------------------------
+# Tables with arrays (DEMI_MODEL_ARRAY): the raft with a real log on the bench trace, the replicated log with its hole - the
+# models as JSON (rows, flags) and the oracle's verdicts, both strategies
+from demi_amd.fuzzer import wait_quiescence  # noqa: E402
+
+_, events, limits = raft5_config2()
+arr = {"raft5_log8": (M.raft_model(5, log_cap=8), events, limits, 2048),
+       "replog4_6": (M.replog_model(4, 6, True, False),
+                     events_to_array([start(a) for a in range(4)] + [send(0 if i % 3 else i % 4, M.RL_PUT, 20 + i, 0) for i in range(6)]),
+                     T.Limits(400, 7, 64, 0, 0, 0), 1024)}
+for name, (m, ev, lim, n) in arr.items():
+    save_model(m, os.path.join(G, name + "_model.json"))
+    out = {}
+    for sname, strat in (("random", T.STRATEGY_FULLY_RANDOM), ("fifo", T.STRATEGY_SRC_DST_FIFO)):
+        l2 = T.Limits(lim.max_messages, lim.invariant_check_interval, lim.p_max, 0, 0, 0, strat)
+        out[sname] = O.random_explore(m, ev, n, seed_base=SEED_BASE, limits=l2)
+    np.savez(os.path.join(G, name + "_verdicts.npz"), events=ev, limits=np.array([lim.max_messages, lim.invariant_check_interval, lim.p_max]), **out)
+    print(name, {k: int((v["flags"] & T.V_VIOLATION).sum()) for k, v in out.items()}, "of", n)
