@@ -111,7 +111,9 @@ class ScalaDPORwHeuristics:
         self.blockedActors = set()
         self.timerToCancellable, self.ongoing, self.registered, self.next_c = {}, set(), set(), 0
         self.seededRandom = C.c_uint64((0 ^ 0x5DEECE66D) & ((1 << 48) - 1))
-        self.state = [int(s) for s in self.model.init_state[:A]]
+        # (an actor's state: its field word, then - DEMI_MODEL_ARRAY - the words of its array, empty at the start)
+        self.stw = getattr(self.model, "state_words", 1)
+        self.state = [[int(self.model.init_state[a])] + [0] * (self.stw - 1) for a in range(A)]
         self.deliveries = []
         self.aborted = False
         self.runExternal()
@@ -238,12 +240,12 @@ class ScalaDPORwHeuristics:
         c = self.timerToCancellable.get((rcv, msg))
         if c is not None and c in self.ongoing:                    # "Check if it was a repeating timer. If so, retrigger it"
             self.handleTick(rcv, msg, c)
-        st = C.c_uint64(self.state[rcv])
+        st = (C.c_uint64 * self.stw)(*self.state[rcv])
         fx = (_Effect * 64)()
-        n = self.oracle.lib().orc_vm_run(C.byref(self.ms), rcv, C.byref(st), mtype, snd, p0, p1, (1 << self.model.n_actors) - 1,
+        n = self.oracle.lib().orc_vm_run(C.byref(self.ms), rcv, st, mtype, snd, p0, p1, (1 << self.model.n_actors) - 1,
                                          fx, 64, C.byref(self.seededRandom))
         assert n >= 0
-        self.state[rcv] = int(st.value)
+        self.state[rcv] = [int(w) for w in st]
         for e in fx[:n]:
             if e.kind == 0:
                 self.event_produced(rcv, int(e.target), (int(e.msg_type), int(e.p0), int(e.p1)))
@@ -322,13 +324,14 @@ class ScalaDPORwHeuristics:
                     continue
                 break
             # checkInvariant + the verdict of this interleaving
-            states = (C.c_uint64 * T.MAX_ACTORS)(*self.state)
+            states = (C.c_uint64 * (T.MAX_ACTORS * self.stw))(*[w for st_ in self.state for w in st_])
             fp = int(self.oracle.lib().orc_invariant(C.byref(self.ms), states, (1 << self.model.n_actors) - 1))
             h = 0xCBF29CE484222325
             for w in self.deliveries:
                 h = ((h ^ w) * 0x100000001B3) & MASK64
             for a in range(self.model.n_actors):
-                h = ((h ^ self.state[a]) * 0x100000001B3) & MASK64
+                for w in self.state[a]:
+                    h = ((h ^ w) * 0x100000001B3) & MASK64
             capped = self.should_cap_messages and self.messagesScheduledSoFar > self.max_messages
             flags = (T.V_VIOLATION if fp else 0) | (T.V_MAXMSG if capped else 0) | min(len(self.deliveries), 0xFFFF) << 16
             self.verdicts.append((flags, fp, h))
@@ -344,6 +347,8 @@ CASES = {
     "raft3": lambda: (M.raft_model(3), events_to_array([start(a) for a in range(3)] + [send(a, M.M_BOOTSTRAP) for a in range(3)]), 30, 0, 300),
     "raft3_two_periods": lambda: (M.raft_model(3), events_to_array([start(a) for a in range(3)] + [send(0, M.M_BOOTSTRAP),
                                   wait_quiescence(), send(1, M.M_BOOTSTRAP), send(2, M.M_BOOTSTRAP)]), 24, 0, 300),
+    # DEMI_MODEL_ARRAY: the replicated log (rows LDX / STX, an invariant program that reads the log)
+    "replog3_arrays": lambda: (M.replog_model(3, 4, True, False), events_to_array([start(a) for a in range(3)] + [send(0, M.RL_PUT, 9, 0), send(1, M.RL_PUT, 8, 0), send(0, M.RL_PUT, 7, 0)]), 40, 0, 400),
     "raft3_late_start_and_cap": lambda: (M.raft_model(3), events_to_array([start(0), start(1), send(0, M.M_BOOTSTRAP), send(1, M.M_BOOTSTRAP),
                                          wait_quiescence(), start(2), send(2, M.M_BOOTSTRAP)]), 20, 40, 300),
 }

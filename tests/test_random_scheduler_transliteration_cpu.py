@@ -93,7 +93,10 @@ class ScalaRandomScheduler:
         self.blockedActors = set()
         self.seededRandom = C.c_uint64((0 ^ 0x5DEECE66D) & ((1 << 48) - 1))       # new Random(0)
         # ---- the application
-        self.state = [int(s) for s in model.init_state[:A]]
+        # (an actor's state: its field word, then - DEMI_MODEL_ARRAY - the words of its array, empty at the start)
+        self.stw = getattr(model, "state_words", 1)
+        assert not getattr(model, "wide", False)
+        self.state = [[int(model.init_state[a])] + [0] * (self.stw - 1) for a in range(A)]
         self.deliveries = []
         self.next_uniq = 1
         # populateActorSystem: every actor that is ever Start()ed is created and isolated (:371-378, 397-406)
@@ -171,7 +174,7 @@ class ScalaRandomScheduler:
                 self.pendingEvents.add((snd, rcv, msg, uniq))
 
     def test_invariant(self):
-        states = (C.c_uint64 * T.MAX_ACTORS)(*self.state)
+        states = (C.c_uint64 * (T.MAX_ACTORS * self.stw))(*[w for st in self.state for w in st])
         return int(self.oracle.lib().orc_invariant(C.byref(self.ms), states, self.exists))
 
     def isTimer(self, rcv, msg):
@@ -259,12 +262,12 @@ class ScalaRandomScheduler:
         if c is not None and c in self.ongoingCancellableTasks:
             self.handleTick(rcv, msg, c)
         # the actor's receive
-        st = C.c_uint64(self.state[rcv])
+        st = (C.c_uint64 * self.stw)(*self.state[rcv])
         fx = (_Effect * 64)()
-        n = self.oracle.lib().orc_vm_run(C.byref(self.ms), rcv, C.byref(st), mtype, 15 if snd == DEAD else snd, p0, p1,
+        n = self.oracle.lib().orc_vm_run(C.byref(self.ms), rcv, st, mtype, 15 if snd == DEAD else snd, p0, p1,
                                          self.exists, fx, 64, C.byref(self.seededRandom))
         assert n >= 0
-        self.state[rcv] = int(st.value)
+        self.state[rcv] = [int(w) for w in st]
         for e in fx[:n]:
             if e.kind == 0:
                 self.tell(rcv, int(e.target), (int(e.msg_type), int(e.p0), int(e.p1)))
@@ -300,7 +303,8 @@ class ScalaRandomScheduler:
             w = mtype | (rcv << 5) | (snd << 8) | (p0 << 16) | (p1 << 24)
             h = ((h ^ w) * 0x100000001B3) & MASK64
         for a in range(self.model.n_actors):
-            h = ((h ^ self.state[a]) * 0x100000001B3) & MASK64
+            for w in self.state[a]:
+                h = ((h ^ w) * 0x100000001B3) & MASK64
         flags = (T.V_VIOLATION if self.violationFound else 0) | (T.V_MAXMSG if self.finished_early else 0)
         flags |= (self.traceIdx & 0xFF) << 8 | min(self.messagesScheduledSoFar, 0xFFFF) << 16
         return flags, int(self.violationFound or 0), h
@@ -392,3 +396,21 @@ def test_carried_generator_instances_equal_the_scala_explore_loop(oracle):
     first_stop = next((e for e in range(4) if got[e]["flags"] & T.V_VIOLATION), 3)
     assert ran == first_stop and int(v.hash) == int(got[first_stop]["hash"])
     assert int((rec["kind"] == T.REC_MSG_EVENT).sum()) == T.verdict_deliveries(int(v.flags))
+
+
+def test_a_table_with_arrays_equals_the_scala_transliteration(oracle):
+    """DEMI_MODEL_ARRAY: whole executions of the replicated-log protocol (rows LDX / STX, an invariant program that reads the
+    log) - the scheduler is the transliteration above, the handlers the oracle's rows, the state an actor's field word and its
+    array words; verdict and hash (every state word) against the oracle's own loop."""
+    from demi_amd import model as M
+    from demi_amd.fuzzer import events_to_array, send, start, wait_quiescence
+    for buggy in (True, False):
+        model = M.replog_model(4, 6, buggy, False)
+        ev = [start(a) for a in range(4)]
+        for i in range(7):
+            ev.append(send(0 if i % 3 else i % 4, M.RL_PUT, 30 + i, 0))
+            if i == 3:
+                ev.append(wait_quiescence())
+        events = events_to_array(ev)
+        checked, violations = _compare(oracle, model, events, list(range(100, 140)), 300, 5)
+        assert checked == 40 and (violations > 5) == buggy

@@ -131,7 +131,8 @@ class ScalaSTSScheduler(ScalaRandomScheduler):
         for snd, rcv, mtype, p0, p1 in self.deliveries:
             h = ((h ^ (mtype | (rcv << 5) | (snd << 8) | (p0 << 16) | (p1 << 24))) * 0x100000001B3) & MASK64
         for a in range(self.model.n_actors):
-            h = ((h ^ self.state[a]) * 0x100000001B3) & MASK64
+            for w in self.state[a]:
+                h = ((h ^ w) * 0x100000001B3) & MASK64
         flags = (T.V_VIOLATION if found else 0) | (T.V_DIVERGED if self.ignored else 0) | min(self.messagesScheduledSoFar, 0xFFFF) << 16
         return flags, found, h
 
@@ -198,3 +199,21 @@ def test_crashing_application_replays_equal_the_scala_transliteration(oracle):
     subseqs = [noq] + [[i for i in noq if rng.random() < p] for p in (0.5, 0.8) for _ in range(10)]
     c, _ = _check(oracle, model, used, rec, vv.fingerprint if vv.fingerprint else 0x1000103, subseqs)
     assert c >= 15
+
+
+def test_replays_on_a_table_with_arrays_equal_the_scala_transliteration(oracle):
+    """DEMI_MODEL_ARRAY: candidate subsequences of a violating execution of the replicated-log protocol (the hole)."""
+    from demi_amd import model as M
+    from demi_amd.fuzzer import events_to_array, send, start
+    model = M.replog_model(4, 6, True, False)
+    events = events_to_array([start(a) for a in range(4)] + [send(0 if i % 3 else i % 4, M.RL_PUT, 30 + i, 0) for i in range(7)])
+    lim = T.Limits(300, 0, 128, 0, 0, 0)
+    v = oracle.random_explore(model, events, 100, seed_base=500, limits=lim)
+    i0 = int(np.nonzero(v["flags"] & T.V_VIOLATION)[0][0])
+    vv, rec, _ = oracle.random_execute(model, events, 500 + i0, lim)
+    used = events[:T.verdict_trace_idx(vv.flags)]
+    rng = np.random.default_rng(9)
+    allx = list(range(len(used)))
+    subseqs = [allx] + [[i for i in allx if rng.random() < p] for p in (0.4, 0.6, 0.8, 0.9) for _ in range(8)]
+    checked, diverged = _check(oracle, model, used, rec, vv.fingerprint, subseqs)
+    assert checked == len(subseqs) and 0 < diverged < checked
