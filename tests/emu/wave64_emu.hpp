@@ -164,13 +164,6 @@ template <class T, class U, class V> static inline T atomicCAS(T* p, U expect, V
 #define __hip_atomic_fetch_add(P, V, ORDER, SCOPE) __atomic_fetch_add((P), (V), __ATOMIC_SEQ_CST)
 #define __hip_atomic_fetch_or(P, V, ORDER, SCOPE) __atomic_fetch_or((P), (V), __ATOMIC_SEQ_CST)
 
-// A bounded wait on another workgroup's progress (the explored-pair table of k3_pairs.hpp retries a half-published key a few
-// thousand times: on the GPU the publishing wave keeps running) must not be outrun by an OS thread that lost its core: every 64th
-// atomic load of a thread yields.  (After the templates above, which use the builtin themselves.)
-#include <sched.h>
-static inline void w64_relax_() { static thread_local unsigned n_ = 0; if ((++n_ & 63u) == 0) sched_yield(); }
-#define __atomic_load_n(P, O) (w64_relax_(), __atomic_load_n((P), (O)))
-
 // ------------------------------------------------------------------ gfx950 inline assembly (cycle counters of the diagnostic builds,
 // the instruction-mix probes of k_probe.hpp): there is nothing to time here, the statements vanish and their outputs stay
 // as they were.  (`asm volatile ( ... )` -> `asm ( ... )` -> nothing; every standard header is in before this point of a
