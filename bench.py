@@ -11,12 +11,23 @@ Inputs (transition table, trace) and outputs (verdicts) are resident in HBM duri
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
       --master-port P bench.py --gpus N --steps K --warmup W
 
-The one JSON line also carries, under "secondary" (N = 1 only, after the timed region), the other two loops of the
-hot path on their BASELINE configurations, each with its own roofline and CPU baseline:
-  dpor   config 3: DPORwHeuristics, raft5, depth 30 — the whole bounded exploration (interleavings/s), in ROUNDS order and
-         in the reference's own order;
-  ddmin  config 4: STSSched replays of candidate subsequences of a 200-event failing execution (replays/s).
-`--workload dpor|ddmin` prints that record alone as the line (same contract fields).
+Every timed step evaluates FRESH seeds: step i of rank r runs the schedule indices [(i * W + r) * n, ... + n), so that
+`bugs_per_hr` counts the distinct violating executions (by the 64-bit hash over every delivered message and every final
+state) found in the timed region per wall-clock hour; one more, untimed, step on the fixed indices [r * n, ...) follows for the
+bit-for-bit comparison with the CPU oracle.
+
+The one JSON line also carries, under "secondary" (after the timed region), the other loops of the hot path on their BASELINE
+configurations, each with its own roofline and CPU baseline:
+  config1  raft3, 100 schedules per call through host buffers (N = 1 only);
+  dpor     config 3: DPORwHeuristics, raft5, depth 30 — the whole bounded exploration (interleavings/s), in ROUNDS order and
+           in the reference's own order (N = 1 only: the reference order's commit is one sequential loop);
+  ddmin    config 4: DDMin of a 200-event failing execution over the STSSched replay oracle.  N = 1: replays/s of 2^20 resident
+           candidates + demi_ddmin end to end.  N > 1: demi_ddmin with every speculative frontier split over the ranks
+           (demi_replay_batch_sharded inside the library: all-gather of the verdicts), and the aggregate replay rate;
+  config5  the 8-actor shuffle pipeline, bounded DPOR exploration with a budget of 2^20 interleavings (apps.shuffle8_config5_large).
+           N > 1: demi_dpor_explore with the communicator (rounds dealt over the ranks, explored-pair table owner-sharded).
+`--workload dpor|ddmin|config1|config5` prints that record alone as the line (same contract fields; ddmin and config5 also
+under torch.distributed.run with N ranks).
 """
 import argparse
 import ctypes as C
@@ -195,43 +206,207 @@ def bench_config1(ctx_device, cpu_baseline=True):
     return out
 
 
-def bench_config5(ctx_device, cpu_baseline=True, max_interleavings=1 << 17, batch=16384):
-    """BASELINE config 5: shuffle8-synth (8 actors, 3 classes), bounded DPOR exploration - single GPU here (the 8-GPU form is
-    demi_dpor_explore with a communicator: the explored-pair table sharded by owner)."""
+class Ranks:
+    """What the records below need from the process group: one instance per process.  world == 1: everything is local."""
+
+    def __init__(self, rank=0, world=1, attach=None, dist=None, cdev=None):
+        self.rank, self.world, self.attach, self.dist, self.cdev = rank, world, attach, dist, cdev
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+
+    def max(self, x):
+        if self.world == 1:
+            return float(x)
+        import torch
+        t = torch.tensor([float(x)], dtype=torch.float64, device=self.cdev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def gather(self, obj):
+        """every rank's (small, picklable) object, in rank order, on every rank"""
+        if self.world == 1:
+            return [obj]
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj)
+        return out
+
+
+def _counters_profile(name):
+    """fabric-side bytes of a secondary record from its FETCH_SIZE / WRITE_SIZE passes (tools/profile_r4.sh), if committed"""
+    try:
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
+
+
+def bench_config5(ctx_device, cpu_baseline=True, max_interleavings=None, batch=16384, ranks=None, small=True):
+    """BASELINE config 5: shuffle8-synth as a pipeline of three jobs (8 actors, 3 classes), bounded DPOR exploration with a budget
+    of 2^20 interleavings (apps.shuffle8_config5_large says why more externals do not enlarge the one-job exploration and
+    chained jobs do).  With N ranks: demi_dpor_explore with the communicator - a round's backtrack points dealt over the ranks
+    in contiguous blocks, the explored-pair table sharded by owner = hash(unordered pair) mod N, three all-gathers per round
+    (DESIGN section 6); every rank ends with the same verdict sequence (checked)."""
     import numpy as np
     from demi_amd import _native, types as T
-    from demi_amd.apps import shuffle8_config5
-    model, dpor_events, _fuzz_events, _lim = shuffle8_config5()
-    par = T.DporParams(40, 0, 0, 0, 64, 4096)
+    from demi_amd.apps import shuffle8_config5, shuffle8_config5_large
+    ranks = ranks or Ranks()
+    model, dpor_events, depth, budget = shuffle8_config5_large()
+    if max_interleavings is None:
+        max_interleavings = budget
+    par = T.DporParams(depth, 0, 0, 0, 64, 4096)
     srch = T.DporSearch(batch, max_interleavings, 0, 1, T.DPOR_ORDER_ROUNDS)
     ctx = _native.Context(ctx_device)
     ctx.model_load(model.to_struct())
+    t = time.perf_counter()
     ctx.model_specialize()
     ctx.dpor_load(dpor_events)
-    ctx.dpor_explore(par, srch)
+    collective = ranks.attach(ctx) if ranks.world > 1 else "none (1 rank)"
+    warm = T.DporSearch(batch, min(max_interleavings, 1 << 16), 0, 1, T.DPOR_ORDER_ROUNDS)
+    ctx.dpor_explore(par, warm)                      # compilation for this table, the device arenas; every call is a fresh exploration
+    setup_s = time.perf_counter() - t
+    ranks.barrier()
     t = time.perf_counter()
     verdicts, plen, rounds, vtrace, st = ctx.dpor_explore(par, srch)
-    dt = time.perf_counter() - t
-    ctx.close()
+    dt = ranks.max(time.perf_counter() - t)
     n_il = len(verdicts)
+    digest = "%016x" % _seq_digest(verdicts)
     per_il = 4.0 * float(np.mean(plen)) + 8.0 + 12.0 * (int(st.backtrack_points) / max(1, n_il))
-    out = {"metric": "interleavings explored/sec, bounded DPOR (shuffle8-synth, depth 40)", "unit": "interleavings/s",
-           "value": n_il / dt, "seconds": dt, "interleavings": n_il, "exhausted": bool(st.exhausted), "launches": int(st.launches),
-           "violations": int(np.count_nonzero(verdicts["flags"] & T.V_VIOLATION)), "sequence_digest": "%016x" % _seq_digest(verdicts),
-           "config": {"workload": "shuffle8-synth (2-stage shuffle stand-in, 8 actors, 3 actor classes), Start x 8 + Submit + Speculate, "
-                                  "depth_bound 40, ROUNDS of %d, at most %d interleavings" % (batch, max_interleavings)},
-           "roofline": roofline(n_il * per_il, float(st.kernel_ms), None, "k3_dpor + k3_pairs_* (specialised)",
-                                "SURVEY 8(d): 4 x mean prefix (%.1f) + 8 + 12 x r (%.2f) B per interleaving" %
+    flags, counts = np.unique(verdicts["flags"] & 0xFF, return_counts=True)
+    prof = _counters_profile("r04_config5_counters.json")
+    out = {"metric": "interleavings explored/sec, bounded DPOR (shuffle8-synth pipeline of 3 jobs, depth 40, budget %d)" % max_interleavings,
+           "unit": "interleavings/s", "value": n_il / dt, "seconds": dt, "interleavings": n_il, "exhausted": bool(st.exhausted),
+           "budget": int(max_interleavings), "backtrack_points_still_queued": int(st.queue_len), "launches": int(st.launches),
+           "n_gpus": ranks.world, "collective": collective, "setup_s_untimed": setup_s,
+           "violations": int(np.count_nonzero(verdicts["flags"] & T.V_VIOLATION)), "sequence_digest": digest,
+           "distinct_schedules": int(len(np.unique(verdicts["hash"]))),
+           "verdict_flag_histogram": {"0x%02x" % int(f): int(c) for f, c in zip(flags, counts)},
+           "mean_prefix_len": float(np.mean(plen)), "kernel_ms_total": float(st.kernel_ms),
+           "pcie_bytes": {"h2d": int(st.h2d_bytes), "d2h": int(st.d2h_bytes)},
+           "config": {"workload": "shuffle8-synth pipeline (2-stage shuffle stand-in, 8 actors, 3 actor classes, 3 jobs back to back), "
+                                  "Start x 8 + Submit + Speculate, depth_bound 40, ROUNDS of %d, budget %d interleavings (not exhausted: "
+                                  "the budget bounds the search, RunnerUtils.boundedDPOR's shape)" % (batch, max_interleavings)},
+           "roofline": roofline(n_il * per_il, float(st.kernel_ms), (prof or {}).get("fabric_bytes_per_exploration"),
+                                "k3_dpor + k3_pairs_* (specialised)",
+                                "SURVEY 8(d): 4 x mean prefix (%.1f) + 8 + 12 x r (%.2f) B per interleaving; kernel_ms = this rank's launches" %
                                 (float(np.mean(plen)), int(st.backtrack_points) / max(1, n_il)))}
-    if cpu_baseline:
+    if ranks.world > 1:
+        per_rank = ranks.gather({"digest": digest, "interleavings": n_il, "kernel_ms": float(st.kernel_ms)})
+        out["per_rank"] = per_rank
+        out["same_verdict_sequence_on_every_rank"] = all(r["digest"] == digest and r["interleavings"] == n_il for r in per_rank)
+    ctx.close()
+    if small and ranks.world == 1:
+        # the one-job table of rounds 1-3 (1 653 interleavings, exhausted in three launches: launch latency, kept for continuity)
+        m1, ev1, _f, _l = shuffle8_config5()
+        c1 = _native.Context(ctx_device)
+        c1.model_load(m1.to_struct()); c1.model_specialize(); c1.dpor_load(ev1)
+        s1 = T.DporSearch(batch, 1 << 17, 0, 1, T.DPOR_ORDER_ROUNDS)
+        c1.dpor_explore(par, s1)
+        t = time.perf_counter()
+        v1, _p1, _r1, _t1, st1 = c1.dpor_explore(par, s1)
+        d1 = time.perf_counter() - t
+        c1.close()
+        out["one_job"] = {"interleavings": len(v1), "seconds": d1, "value": len(v1) / d1, "exhausted": bool(st1.exhausted),
+                          "launches": int(st1.launches), "sequence_digest": "%016x" % _seq_digest(v1)}
+    if cpu_baseline and ranks.rank == 0:
         from oracle import oracle_py as O
         cores = os.cpu_count() or 1
+        m = min(n_il, 1 << 16)          # a bounded sample: the same exploration cut at 2^16 interleavings (same order, same prefix)
+        cs = T.DporSearch(batch, m, 0, 1, T.DPOR_ORDER_ROUNDS)
         t = time.perf_counter()
-        v, _pl, _r, _vt, _st, _s = O.dpor_explore(model, dpor_events, par, srch, n_threads=cores)
+        v, _pl, _r, _vt, _st, _s = O.dpor_explore(model, dpor_events, par, cs, n_threads=cores)
         dc = time.perf_counter() - t
         out["cpu_baseline"] = {"value": len(v) / dc, "unit": "interleavings/s", "cores": cores, "kind": "port", "seconds": dc,
-                               "sample": "the same exploration, oracle interleavings on %d host threads under the same host bookkeeping" % cores,
-                               "same_verdict_sequence_as_gpu": "%016x" % _seq_digest(v) == out["sequence_digest"]}
+                               "sample": "the first %d interleavings of the same exploration (budget %d), oracle interleavings on %d host "
+                                         "threads under the same host bookkeeping" % (len(v), m, cores),
+                               "same_verdict_sequence_as_gpu_prefix": "%016x" % _seq_digest(v) == "%016x" % _seq_digest(verdicts[:len(v)])}
+    return out
+
+
+def bench_ddmin_ranks(ctx_device, ranks, n_per_rank=1 << 18):
+    """BASELINE config 4 with N ranks ("DDMin ... subsequence frontier sharded across 8 GPUs"): demi_ddmin with the communicator -
+    every speculative frontier of the decision tree is split over the ranks in contiguous blocks inside the library
+    (demi_replay_batch_sharded: one all-gather of the verdicts per launch), all ranks walk the same tree; the launch budget
+    grows with N (a frontier N times as wide in the time of one launch).  Beside it the aggregate replay rate: every rank
+    replays its own n_per_rank resident candidates and the verdicts are all-gathered."""
+    import numpy as np
+    import torch
+    from demi_amd import _native, types as T
+    from demi_amd.apps import SEED_BASE, raft5_config4
+    model, events, lim = raft5_config4()
+    ctx = _native.Context(ctx_device)
+    ctx.model_load(model.to_struct())
+    ctx.trace_load(events)
+    v = ctx.random_explore(4000, lim, seed_base=SEED_BASE)
+    i = int(np.nonzero(v["flags"] & T.V_VIOLATION)[0][0])
+    vv, rec = ctx.random_get_trace(SEED_BASE + i, lim)
+    used = events[:T.verdict_trace_idx(vv.flags)]
+    ctx.replay_load(used, rec)
+    ctx.model_specialize()
+    target = T.Limits(0, 0, 128, 1, vv.fingerprint, 0)
+    W = ranks.world
+    # the single-rank call first (no communicator yet): every rank computes the same MCS - the reference for the sharded one
+    par1 = T.DdminParams(0, 1024, 1, 1)
+    ctx.ddmin(target, par1)
+    t = time.perf_counter()
+    mcs1, cons1, batches1, st1 = ctx.ddmin(target, par1)
+    single_s = time.perf_counter() - t
+    collective = ranks.attach(ctx) if W > 1 else "none (1 rank)"
+    best = None
+    for budget in (1024 * W, 4096 * W):
+        parw = T.DdminParams(0, budget, 1, 1)
+        ctx.ddmin(target, parw)
+        for _ in range(3):
+            ranks.barrier()
+            t = time.perf_counter()
+            mcsw, consw, batchesw, stw = ctx.ddmin(target, parw)
+            dt = ranks.max(time.perf_counter() - t)
+            if best is None or dt < best["seconds"]:
+                best = {"seconds": dt, "max_candidates_per_launch_all_ranks": budget, "launches": int(stw.launches),
+                        "replays_launched": int(stw.replays), "candidates_per_launch": batchesw, "mcs_len": len(mcsw),
+                        "oracle_consultations": int(stw.consultations),
+                        "same_mcs_as_single_rank": tuple(mcsw) == tuple(mcs1),
+                        "same_consultation_sequence_as_single_rank": [(tuple(c), p) for c, p in consw] == [(tuple(c), p) for c, p in cons1]}
+    # aggregate replay rate: n_per_rank random candidates per rank, resident in HBM, verdicts all-gathered through the library
+    dev = torch.device("cuda", ctx_device)
+    rng = np.random.default_rng(1000 + ranks.rank)
+    keep = rng.random((n_per_rank, len(used))) < 0.7
+    masks = np.zeros((n_per_rank, 4), dtype=np.uint64)
+    for w in range(4):
+        bits = keep[:, 64 * w:64 * (w + 1)]
+        masks[:, w] = (bits.astype(np.uint64) << np.arange(bits.shape[1], dtype=np.uint64)).sum(axis=1)
+    d_masks = torch.from_numpy(masks.view(np.int64)).to(dev)
+    d_out = torch.empty((n_per_rank, 2), dtype=torch.int64, device=dev)
+    d_all = torch.empty((W, n_per_rank, 2), dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream(dev)
+    sp = C.c_void_p(stream.cuda_stream)
+
+    def one():
+        ctx.replay_batch_dev(d_masks.data_ptr(), n_per_rank, target, d_out.data_ptr(), stream=sp)
+        ctx.comm_allgather_dev(d_out.data_ptr(), d_all.data_ptr(), n_per_rank * 16, stream=sp)
+    one()
+    torch.cuda.synchronize(dev)
+    ranks.barrier()
+    reps = 5
+    t = time.perf_counter()
+    for _ in range(reps):
+        one()
+    torch.cuda.synchronize(dev)
+    ranks.barrier()
+    dt = ranks.max(time.perf_counter() - t)
+    got = d_all.cpu().numpy().view(T.VERDICT_DTYPE).reshape(W, n_per_rank)
+    digests = ranks.gather("%016x" % _seq_digest(got[ranks.rank]))
+    out = {"metric": "candidate subsequences replayed/sec (STSScheduler.test without peek), %d ranks" % W, "unit": "replays/s",
+           "value": W * n_per_rank * reps / dt, "n_gpus": W, "collective": collective,
+           "config": {"workload": "raft5-synth, 200-event failing execution (%d externals), %d random candidates per rank per pass, "
+                                  "resident in HBM, verdicts all-gathered" % (len(used), n_per_rank)},
+           "ms_per_pass": dt / reps * 1e3,
+           "every_ranks_block_arrived_everywhere": all(d == "%016x" % _seq_digest(got[k]) for k, d in enumerate(digests)),
+           "ddmin_end_to_end": dict(best, externals=int(len(used))),
+           "ddmin_end_to_end_single_rank": {"seconds": single_s, "launches": int(st1.launches), "replays_launched": int(st1.replays),
+                                            "mcs_len": len(mcs1), "max_candidates": 1024}}
+    ctx.close()
     return out
 
 
@@ -419,6 +594,8 @@ def main():
     ap.add_argument("--dpor-order", choices=["both", "rounds", "reference_order"], default="both",
                     help="--workload dpor: which exploration order(s) to run (profiling passes use one)")
     ap.add_argument("--schedules", type=int, default=N_PER_GPU, help="schedules per GPU per step")
+    ap.add_argument("--config5-budget", type=int, default=None,
+                    help="interleavings the config 5 record may explore (default: apps.shuffle8_config5_large's 2^20)")
     ap.add_argument("--p-max", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="fuzz line only (no dpor / ddmin records)")
@@ -440,7 +617,6 @@ def main():
 
     from demi_amd import _native, types as T
     from demi_amd.apps import SEED_BASE, raft5_config2
-    from demi_amd.distributed import merge_violation_sets
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -466,17 +642,62 @@ def main():
     dev = torch.device("cuda", local_rank)
     cdev = dev if backend == "nccl" else torch.device("cpu")       # where torch.distributed's own small tensors live
 
+    def attach(ctx):
+        """The library's own communicator for this demi_ctx on every rank (demi_comm_*: ncclAllGather over xGMI behind the C ABI,
+        what a JVM host would call); its unique id travels over torch.distributed.  Returns what carries the collectives; raises
+        on every rank alike when it cannot be created (the sharded entry points need it)."""
+        if host_comm:
+            def _host_allgather(block: bytes) -> bytes:
+                mine = torch.frombuffer(bytearray(block), dtype=torch.uint8)
+                parts = [torch.empty_like(mine) for _ in range(world)]
+                dist.all_gather(parts, mine)
+                return b"".join(bytes(q.numpy().tobytes()) for q in parts)
+            ctx.comm_create_host(rank, world, _host_allgather)
+            return "demi_comm (host all-gather callback over torch.distributed %s: plumbing test)" % backend
+        # (every rank takes part in the broadcast and the agreement whatever happens locally: nobody is left waiting)
+        uid = torch.zeros(129, dtype=torch.uint8, device=dev)
+        err = None
+        if rank == 0:
+            try:
+                uid[:128] = torch.tensor(list(_native.Context.comm_unique_id()), dtype=torch.uint8, device=dev)
+                uid[128] = 1
+            except Exception as e:
+                err = "no RCCL unique id: %s" % e
+        dist.broadcast(uid, 0)
+        ok = int(uid[128].item()) == 1
+        if ok:
+            try:
+                ctx.comm_create(bytes(uid[:128].cpu().tolist()), rank, world)
+            except Exception as e:
+                ok, err = False, "ncclCommInitRank: %s" % e
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            if ok:
+                ctx.comm_destroy()
+            raise RuntimeError("library communicator unavailable (%s)" % (err or "another rank failed"))
+        return "demi_comm (RCCL ncclAllGather inside libdemi_gpu.so)"
+
+    ranks = Ranks(rank, world, attach if world > 1 else None, dist, cdev)
+
     if args.workload != "fuzz":
-        assert world == 1, "the dpor / ddmin records are single-GPU"
-        fn = {"dpor": bench_dpor, "ddmin": bench_ddmin, "config1": bench_config1, "config5": bench_config5}[args.workload]
+        assert world == 1 or args.workload in ("ddmin", "config5"), "the dpor / config1 records are single-GPU"
         t = time.perf_counter()
-        if args.workload == "dpor" and args.dpor_order != "both":
-            rec = fn(local_rank, cpu_baseline=not args.no_cpu_baseline, orders=(args.dpor_order,))
+        if args.workload == "dpor":
+            rec = bench_dpor(local_rank, cpu_baseline=not args.no_cpu_baseline,
+                             orders=("rounds", "reference_order") if args.dpor_order == "both" else (args.dpor_order,))
+        elif args.workload == "config5":
+            rec = bench_config5(local_rank, cpu_baseline=not args.no_cpu_baseline, ranks=ranks, max_interleavings=args.config5_budget)
+        elif args.workload == "ddmin" and world > 1:
+            rec = bench_ddmin_ranks(local_rank, ranks)
         else:
-            rec = fn(local_rank, cpu_baseline=not args.no_cpu_baseline)
-        rec.update({"n_gpus": 1, "steps": 1, "warmup": 1, "ms_per_step": (time.perf_counter() - t) * 1e3, "higher_is_better": True,
-                    "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic"})
-        print(json.dumps(rec))
+            rec = {"ddmin": bench_ddmin, "config1": bench_config1}[args.workload](local_rank, cpu_baseline=not args.no_cpu_baseline)
+        rec.update({"n_gpus": world, "steps": 1, "warmup": 1, "ms_per_step": (time.perf_counter() - t) * 1e3, "higher_is_better": True,
+                    "scaling": "strong" if args.workload == "config5" else "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic"})
+        if rank == 0:
+            print(json.dumps(rec))
+        if world > 1:
+            dist.destroy_process_group()
         return
 
     model, events, limits = raft5_config2()
@@ -493,67 +714,53 @@ def main():
     ctx.model_load(model.to_struct())
     ctx.trace_load(events)
     specialized = False
+    jit_compile_s = None
     if not args.no_specialize:
-        # compile the loaded table to native code once (hiprtc, ~1 s, outside the timed region); a failure leaves
-        # the table interpreter in place and is reported in the JSON line
+        # compile the loaded table to native code once (hiprtc, outside the timed region: reported as config.jit_compile_s); a
+        # failure leaves the table interpreter in place and is reported in the JSON line
         try:
+            tj = time.perf_counter()
             ctx.model_specialize()
+            jit_compile_s = time.perf_counter() - tj
             specialized = ctx.is_specialized()
         except _native.DemiError as e:
             print("bench: specialisation unavailable, interpreting the table: %s" % e, file=sys.stderr)
 
-    verdicts = torch.empty((n, 2), dtype=torch.int64, device=dev)          # demi_verdict[n]
+    # one verdict array per timed step (16 MB each at 2^20 schedules; HBM has 288 GB): the violating executions of the whole
+    # timed region are counted after it, on the device, without a synchronisation inside it
+    keep_steps = min(args.steps, 256)
+    vbuf = torch.empty((max(1, keep_steps), n, 2), dtype=torch.int64, device=dev)     # demi_verdict[n] per step
+    verdicts = torch.empty((n, 2), dtype=torch.int64, device=dev)                     # warm-up / fixed-seed step
     viol = torch.zeros((VIOL_CAP + 1, 2), dtype=torch.int64, device=dev)  # row 0 = count, then demi_violation[]
     gathered = torch.empty((world, VIOL_CAP + 1, 2), dtype=torch.int64, device=dev) if world > 1 else None
-    # the found-violation sets are all-gathered by the library's own communicator (demi_comm_*: ncclAllGather over xGMI
-    # behind the C ABI, what a JVM host would call); its unique id travels over torch.distributed, which also provides the
-    # barrier.  If RCCL cannot be initialised there, torch.distributed's all_gather does the exchange (and the line says so).
+    # the found-violation sets are all-gathered by the library's own communicator; if RCCL cannot be initialised there,
+    # torch.distributed's all_gather does the exchange (and the line says so)
     collective = "none (1 rank)"
-    if world > 1 and host_comm:
-        def _host_allgather(block: bytes) -> bytes:
-            mine = torch.frombuffer(bytearray(block), dtype=torch.uint8)
-            parts = [torch.empty_like(mine) for _ in range(world)]
-            dist.all_gather(parts, mine)
-            return b"".join(bytes(q.numpy().tobytes()) for q in parts)
-        ctx.comm_create_host(rank, world, _host_allgather)
-        collective = "demi_comm_allgather_dev (host all-gather callback over torch.distributed %s: plumbing test)" % backend
-    elif world > 1:
-        # (every rank takes part in both broadcasts whatever happens on rank 0: a failure there must not leave the others waiting)
-        uid = torch.zeros(129, dtype=torch.uint8, device=dev)
-        if rank == 0:
-            try:
-                uid[:128] = torch.tensor(list(_native.Context.comm_unique_id()), dtype=torch.uint8, device=dev)
-                uid[128] = 1
-            except Exception as e:
-                print("bench: no RCCL unique id: %s" % e, file=sys.stderr)
-        dist.broadcast(uid, 0)
-        if int(uid[128].item()) == 1:
-            try:
-                ctx.comm_create(bytes(uid[:128].cpu().tolist()), rank, world)
-                collective = "demi_comm_allgather_dev (RCCL ncclAllGather inside libdemi_gpu.so)"
-            except Exception as e:
-                collective = "torch.distributed.all_gather (library communicator unavailable: %s)" % e
-        else:
-            collective = "torch.distributed.all_gather (library communicator unavailable: no unique id on rank 0)"
-        flag = torch.tensor([1 if collective.startswith("demi_comm") else 0], dtype=torch.int32, device=dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)          # all ranks take the same path
-        if int(flag.item()) == 0 and collective.startswith("demi_comm"):
-            collective = "torch.distributed.all_gather (library communicator unavailable on another rank)"
+    if world > 1:
+        try:
+            collective = attach(ctx) + ": demi_comm_allgather_dev"
+        except RuntimeError as e:
+            collective = "torch.distributed.all_gather (%s)" % e
     use_lib_comm = collective.startswith("demi_comm")
     stream = torch.cuda.current_stream()
     sp = C.c_void_p(stream.cuda_stream)
-    index_base = rank * n      # weak scaling: rank r evaluates schedules [r*n, (r+1)*n)
 
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
 
-    def step(i=None):
+    def step(i=None, out=None, index_base=None):
+        """one pass of the hot path: K1 over n schedules, the found-violation set compacted, all-gathered with N > 1.
+        Timed step i: fresh indices [(i * W + r) * n, ...); otherwise the fixed indices [r * n, ...)."""
+        if index_base is None:
+            index_base = ((i * world + rank) if i is not None else rank) * n
+        if out is None:
+            out = vbuf[i % keep_steps] if i is not None else verdicts
         if i is not None:
             ev0[i].record(stream)
-        ctx.random_explore_dev(n, limits, verdicts.data_ptr(), seed_base=SEED_BASE + index_base, stream=sp)
+        ctx.random_explore_dev(n, limits, out.data_ptr(), seed_base=SEED_BASE + index_base, stream=sp)
         if i is not None:
             ev1[i].record(stream)
-        ctx.collect_violations_dev(verdicts.data_ptr(), n, index_base, viol[1:].data_ptr(), VIOL_CAP,
+        ctx.collect_violations_dev(out.data_ptr(), n, index_base, viol[1:].data_ptr(), VIOL_CAP,
                                    viol[0:1].data_ptr(), stream=sp)
         if world > 1:
             if use_lib_comm:
@@ -572,7 +779,7 @@ def main():
     if not args.no_prewarm:
         t0 = time.perf_counter()
         while time.perf_counter() - t0 < PREWARM_S:
-            ctx.random_explore_dev(n, limits, verdicts.data_ptr(), seed_base=SEED_BASE + index_base, stream=sp)
+            ctx.random_explore_dev(n, limits, verdicts.data_ptr(), seed_base=SEED_BASE + rank * n, stream=sp)
             torch.cuda.synchronize()
         prewarm_s = time.perf_counter() - t0
     for _ in range(args.warmup):
@@ -587,23 +794,31 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-
-    # ---- found-violation set of the last step (all ranks)
-    parts = [gathered[r] for r in range(world)] if world > 1 else [viol]
-    vset = merge_violation_sets([p.cpu().numpy() for p in parts], VIOL_CAP)
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
-    # distinct violating schedules by delivery-sequence hash: this rank's shard of the last step
-    distinct_hashes = None
-    try:
-        mine = vset[(vset["index"] >= index_base) & (vset["index"] < index_base + n)]
-        if len(mine):
-            sel = torch.as_tensor((mine["index"] - index_base).astype(np.int64), device=dev)
-            distinct_hashes = int(torch.unique(verdicts[sel, 1]).numel())
-        else:
-            distinct_hashes = 0
-    except Exception as e:           # never let a statistic break the bench line
-        print("bench: delivery-hash statistic unavailable: %s" % e, file=sys.stderr)
 
+    # ---- what the timed region found: the violating executions of its steps, by delivery-sequence hash and by fingerprint
+    # (bugs/hr = distinct violating schedules per wall-clock hour); counted here, after the timed region
+    kept = vbuf[:keep_steps].reshape(-1, 2)
+    vmask = (kept[:, 0] & T.V_VIOLATION) != 0
+    my_hashes = torch.unique(kept[vmask, 1]).cpu().numpy()
+    my_fps = torch.unique((kept[vmask, 0] >> 32) & 0xFFFFFFFF).cpu().numpy()
+    my_viol = int(vmask.sum().item())
+    parts = ranks.gather((my_viol, my_hashes, my_fps))
+    timed_viol = sum(p[0] for p in parts)
+    timed_hashes = int(len(np.unique(np.concatenate([p[1] for p in parts])))) if parts else 0
+    timed_fps = int(len(np.unique(np.concatenate([p[2] for p in parts])))) if parts else 0
+    counted_frac = keep_steps / float(args.steps)
+
+    # ---- one more, untimed, step on the fixed indices [r * n, ...): the found-violation set every rank ends up with, and the
+    # verdicts the CPU oracle is compared with bit for bit
+    from demi_amd.distributed import merge_violation_sets
+    step()
+    sync()
+    vparts = [gathered[r] for r in range(world)] if world > 1 else [viol]
+    vset = merge_violation_sets([p.cpu().numpy() for p in vparts], VIOL_CAP)
+    index_base = rank * n
+
+    out = None
     if rank == 0:
         total = world * n * args.steps
         value = total / dt
@@ -629,10 +844,9 @@ def main():
                             "divergent two-instruction if, with 6 waves per SIMD as in K1"}
         except Exception as e:
             print("bench: device probe failed: %s" % e, file=sys.stderr)
-        # rocprofv3 counters of THIS kernel build on this workload (tools/profile_k1.sh writes profiles/k1_counters.json with
+        # rocprofv3 counters of THIS kernel build on this workload (tools/profile_r4.sh writes profiles/k1_counters.json with
         # the duration it saw): used only for the SAME kernel build - the profile records the code object's identity
-        # (demi_model_code_id); a profile without one is accepted when its duration is within 10 % of this run's.  A process
-        # traced by rocprofv3 runs this kernel ~10 % slower than an untraced one, so durations alone do not identify it.
+        # (demi_model_code_id); a profile without one is accepted when its duration is within 10 % of this run's.
         traffic, issue, stale = None, None, None
         code_id = "%016x" % ctx.code_id() if specialized else None
         if os.path.exists(K1_COUNTERS) and specialized and args.strategy == "random" and n == N_PER_GPU:
@@ -671,12 +885,21 @@ def main():
                        "schedules_per_gpu_per_step": n, "max_messages": int(limits.max_messages),
                        "invariant_check_interval": int(limits.invariant_check_interval), "p_max": int(limits.p_max),
                        "randomization_strategy": "SrcDstFIFO" if args.strategy == "fifo" else "FullyRandom",
-                       "table_compiled_to_native_code": specialized, "wide_register_window": bool(getattr(model, "wide", False)), "array_elements_per_actor": int(getattr(model, "array_len", 0)), "seed_base": SEED_BASE, "parallelism": "schedule-index range sharded, %d rank(s)" % world, "collective": collective,
+                       "table_compiled_to_native_code": specialized, "jit_compile_s": jit_compile_s,
+                       "wide_register_window": bool(getattr(model, "wide", False)), "array_elements_per_actor": int(getattr(model, "array_len", 0)), "seed_base": SEED_BASE,
+                       "seeds": "timed step i of rank r: schedule indices [(i * %d + r) * n, ... + n) - every timed step evaluates fresh "
+                                "seeds; the untimed last step: [r * n, ... + n)" % world,
+                       "parallelism": "schedule-index range sharded, %d rank(s)" % world, "collective": collective,
                        "untimed_prewarm_s": prewarm_s},
+            # distinct bugs found in the TIMED region per wall-clock hour of it: by delivery-sequence hash - two
+            # executions count once only if every delivered message and every final state agree - and by fingerprint
+            "bugs_per_hr": timed_hashes / counted_frac / dt * 3600.0,
+            "bugs_per_hr_by_fingerprint": timed_fps / dt * 3600.0,
+            "timed_region": {"schedules": total, "seconds": dt, "violating_executions": timed_viol,
+                             "distinct_violating_delivery_hashes": timed_hashes, "distinct_fingerprints": timed_fps,
+                             "steps_counted": keep_steps},
             "violations_last_step": int(len(vset)),
             "distinct_fingerprints_last_step": int(len(np.unique(vset["fingerprint"]))) if len(vset) else 0,
-            "distinct_violating_delivery_hashes_last_step_rank0_shard": distinct_hashes,
-            "bugs_per_hr": float(len(vset)) / (dt / args.steps) * 3600.0,
             "roofline": roofline(alg_bytes, kernel_ms, traffic,
                                  ("k1_random_explore<false, true>" if args.strategy == "fifo" else "k1_random_explore<false, false>") +
                                  (" (specialised, hiprtc)" if specialized else ""),
@@ -722,22 +945,42 @@ def main():
             cpu1 = O.random_explore(model, events, m1, seed_base=SEED_BASE, limits=limits, n_threads=1)
             t1 = time.perf_counter() - t1
             out["cpu_baseline"] = {"value": m / tcpu, "unit": "schedules/s", "cores": cores, "kind": "port",
-                                   "sample": "first %d schedules of the same workload, oracle/demi_oracle.c with %d "
+                                   "sample": "first %d schedules of the untimed fixed-seed step, oracle/demi_oracle.c with %d "
                                              "pthreads (restated CPU oracle, not the DEMi JVM)" % (m, cores),
                                    "seconds": tcpu, "bit_identical_to_gpu": same,
                                    "single_thread": {"value": m1 / t1, "unit": "schedules/s", "cores": 1, "seconds": t1,
                                                      "sample": "first %d schedules, one thread" % m1,
                                                      "bit_identical_to_gpu": bool((cpu1 == verdicts[:m1].cpu().numpy().view(T.VERDICT_DTYPE).reshape(-1)).all())}}
     ctx.close()
-    if rank == 0:
-        if world == 1 and not args.no_secondary:
-            sec = {}
-            for name, fn in (("config1", bench_config1), ("dpor", bench_dpor), ("ddmin", bench_ddmin), ("config5", bench_config5)):
+    del vbuf
+    torch.cuda.empty_cache()
+    if not args.no_secondary:
+        sec = {}
+        if world == 1:
+            for name, fn in (("config1", bench_config1), ("dpor", bench_dpor), ("ddmin", bench_ddmin),
+                             ("config5", lambda d, cpu_baseline: bench_config5(d, cpu_baseline=cpu_baseline, max_interleavings=args.config5_budget))):
                 try:
                     sec[name] = fn(local_rank, cpu_baseline=not args.no_cpu_baseline)
                 except Exception as e:          # a secondary record must never cost the headline line
                     sec[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+        else:
+            # BASELINE configs 4 and 5 over the N ranks.  Every rank runs the record (the sharded entry points are collective);
+            # an exception on one rank is agreed on before anybody enters the record's collectives a second time.
+            for name, fn in (("ddmin", lambda: bench_ddmin_ranks(local_rank, ranks)),
+                             ("config5", lambda: bench_config5(local_rank, cpu_baseline=False, ranks=ranks, small=False,
+                                                               max_interleavings=args.config5_budget))):
+                try:
+                    r = fn()
+                    err = None
+                except Exception as e:
+                    r, err = None, "%s: %s" % (type(e).__name__, e)
+                errs = [x for x in ranks.gather(err) if x]
+                sec[name] = r if not errs else {"error": errs[0], "failed_ranks": len(errs)}
+                if errs:
+                    break                       # (a rank that failed inside a collective may have left the others' communicators unusable)
+        if out is not None:
             out["secondary"] = sec
+    if rank == 0:
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

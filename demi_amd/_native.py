@@ -17,7 +17,7 @@ EXPORTS = ["demi_ctx_create", "demi_ctx_destroy", "demi_last_error", "demi_versi
            "demi_replay_removal_batch", "demi_replay_get_kept", "demi_replay_recorded_len", "demi_ddmin", "demi_dpor_set_traces", "demi_model_specialize", "demi_model_is_specialized", "demi_model_code_id",
            "demi_specialize_check", "demi_specialize_source", "demi_specialize_source_k1", "demi_provenance_prune", "demi_device_probe", "demi_device_probe_mix", "demi_calib_rw", "demi_random_explore_flagged", "demi_collect_flagged_dev",
            "demi_comm_unique_id", "demi_comm_create", "demi_comm_create_host", "demi_comm_destroy", "demi_comm_rank",
-           "demi_comm_allgather_dev", "demi_random_explore_sharded", "demi_replay_batch_sharded"]
+           "demi_comm_allgather_dev", "demi_random_explore_sharded", "demi_replay_batch_sharded", "demi_abi_version", "demi_replay_externals_len"]
 
 _lib = None
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)     # demi_allgather_fn
@@ -50,6 +50,13 @@ def lib():
     L.demi_last_error.argtypes = [C.c_void_p]
     L.demi_last_error.restype = C.c_char_p
     L.demi_version.restype = C.c_char_p
+    L.demi_abi_version.argtypes = []
+    L.demi_abi_version.restype = C.c_uint32
+    if L.demi_abi_version() != T.ABI_VERSION:       # (struct layouts of another generation of include/demi_gpu.h)
+        raise ImportError("libdemi_gpu.so has ABI generation %d, this binding was written for %d: rebuild (__graft_entry__.build())"
+                          % (L.demi_abi_version(), T.ABI_VERSION))
+    L.demi_replay_externals_len.argtypes = [C.c_void_p]
+    L.demi_replay_externals_len.restype = C.c_uint32
     L.demi_model_load.argtypes = [C.c_void_p, C.POINTER(T.ModelStruct)]
     L.demi_model_specialize.argtypes = [C.c_void_p, C.c_int]
     L.demi_model_is_specialized.argtypes = [C.c_void_p]

@@ -62,3 +62,19 @@ def shuffle8_config5():
     fuzz_events = events_to_array([start(a) for a in range(8)] + [send(0, SH_SUBMIT), send(0, SH_SPECULATE, 1),
                                                                   send(0, SH_SPECULATE, 3), wait_quiescence()])
     return model, dpor_events, fuzz_events, T.Limits(400, 0, 64, 0, 0, 0)
+
+
+def shuffle8_config5_large(jobs=3):
+    """BASELINE config 5 at a size worth sharding over 8 GPUs ("bounded exhaustive search across 8 GPUs"): the same 8-actor
+    shuffle application as a PIPELINE of `jobs` shuffle jobs (model.shuffle_model(jobs): the reduce stage reports back and the
+    driver launches the next job itself), explored by DPORwHeuristics with depth_bound 40 until a budget of interleavings is
+    spent.  More Submit / Speculate externals do not enlarge the one-job exploration (1 685 -> 1 787 interleavings with five
+    Speculates: every racing pair is flipped once, ExploredTacker, and the job's causal structure fixes the pairs); chaining
+    jobs does, because the next job's messages descend from whichever delivery completed the previous one and are new DPOR nodes
+    for each way it can end: 2 jobs exhaust after 722 376 interleavings, 3 jobs are not exhausted at 2^20 (the bench line's
+    budget; the backtrack queue still holds millions of points).  Returns (model, externals, depth_bound, budget)."""
+    from .fuzzer import send, start
+    from .model import SH_SPECULATE, SH_SUBMIT, shuffle_model
+    model = shuffle_model(jobs=jobs)
+    dpor_events = events_to_array([start(a) for a in range(8)] + [send(0, SH_SUBMIT), send(0, SH_SPECULATE, 1)])
+    return model, dpor_events, 40, 1 << 20

@@ -12,6 +12,7 @@
 // This is the loop a JVM host would otherwise run around demi_replay_batch; in the Python mirror the enumeration of a few
 // thousand candidates costs more than the launch that replays them.
 #pragma once
+#include "knobs.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -370,7 +371,7 @@ int sts_sched_ddmin(const demi_ext_event* ext, uint32_t n_ext, const uint8_t* co
   SpeculativeDdmin<typename std::remove_reference<TestBatch>::type> dd(dag, test, par->depth, par->max_candidates);
   const double t0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
   int rc = dd.minimize(view, par->check_unmodified != 0, par->verify_mcs != 0, &o);
-  if (getenv("DEMI_DDMIN_TIMING")) {
+  if (demi_host::knob("DEMI_DDMIN_TIMING")) {
     const double t1 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
     fprintf(stderr, "[ddmin] %u consultations, %u launches, %llu replays: oracle %.3f ms, host loop %.3f ms\n", o.consultations, o.launches,
             (unsigned long long)o.replays, dd.oracle_s_ * 1e3, (t1 - t0 - dd.oracle_s_) * 1e3);

@@ -16,6 +16,7 @@
 //    explored, when a queued point of the same flipped pair precedes it in pop order (branch >= and created
 //    earlier: that one is popped first and explores the pair), or when it reaches its shard's front dead.
 #pragma once
+#include "knobs.hpp"
 
 #include <atomic>
 #include <chrono>
@@ -822,7 +823,7 @@ int explore_reference_order(Run&& run, Fetch&& fetch, uint32_t max_pairs, const 
   std::vector<demi_verdict> vd;
   std::vector<Finished> fin;
   std::vector<std::unique_ptr<SpecResult>> made;
-  const bool no_parent_filter = getenv("DEMI_DPOR_NO_PARENT_FILTER") != nullptr;   // A/B and tests: absorb every reported pair
+  const bool no_parent_filter = demi_host::knob("DEMI_DPOR_NO_PARENT_FILTER") != nullptr;   // A/B and tests: absorb every reported pair
   unsigned long long stats_pairs_reported = 0, stats_pairs_kept = 0;
 
   while (!done) {
@@ -976,7 +977,7 @@ int explore_reference_order(Run&& run, Fetch&& fetch, uint32_t max_pairs, const 
   stats->queue_len = real.queue_len();
   stats->backtrack_points = real.enqueued();
   stats->exhausted = exhausted ? 1u : 0u;
-  if (getenv("DEMI_DPOR_TIMING"))
+  if (demi_host::knob("DEMI_DPOR_TIMING"))
     fprintf(stderr, "[reference order] racing pairs reported %llu, kept after the parent filter %llu\n", stats_pairs_reported, stats_pairs_kept);
 #ifdef DEMI_DPOR_PROFILE
   fprintf(stderr, "[reference order commit] absorb %.3f s, cache erase %.3f s, get_next %.3f s, %llu pairs\n", prof[0], prof[1], prof[2],
@@ -1202,7 +1203,7 @@ class RefBook {
 //   interleaving ids[j]'s survivors, in pair order (memory owned by dev, valid until the exploration ends).
 // how many interleavings of the commit's queue front a record fetch covers besides the one the commit stands at
 inline size_t ref_fetch_width() {
-  const char* e = getenv("DEMI_DPOR_FETCH_WIDTH");
+  const char* e = demi_host::knob("DEMI_DPOR_FETCH_WIDTH");
   const long v = e ? atol(e) : 0;
   return v > 0 ? (size_t)v : 128u;
 }

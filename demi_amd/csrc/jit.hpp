@@ -12,6 +12,7 @@
 // hiprtc is resolved with dlopen at specialisation time, next to the HIP runtime this process already uses
 // (PyTorch bundles its own), so the library has no link-time dependency on it and keeps working without it.
 #pragma once
+#include "knobs.hpp"
 
 #include <dlfcn.h>
 
@@ -305,7 +306,7 @@ inline std::string generate_vm(const demi::DevModel& h, bool sched = false) {
   // run of pure ALU rows, none of which is a jump target or a handler entry, becomes selects instead of a branch
   // (fewer exec-mask manipulations on the scalar unit).  Same semantics: a skipped ALU row leaves its register alone.
   uint32_t ifconv = 0;
-  if (const char* e = getenv("DEMI_JIT_IFCONVERT")) { const long x = strtol(e, nullptr, 10); ifconv = x > 0 && x < 16 ? (uint32_t)x : 0; }
+  if (const char* e = demi_host::knob("DEMI_JIT_IFCONVERT")) { const long x = strtol(e, nullptr, 10); ifconv = x > 0 && x < 16 ? (uint32_t)x : 0; }
   std::vector<uint8_t> is_target(h.code_len + 1, 0);
   for (uint32_t st : starts) is_target[st] = 1;
   for (uint32_t pc = 0; pc < h.code_len; pc++) {
@@ -534,7 +535,7 @@ inline bool compile(Rtc& rtc, const std::string& source, const std::vector<Heade
   for (const std::string& n : name_exprs) rtc.add_name(prog, n.c_str());
   std::vector<const char*> opts = {"--offload-arch=gfx950", opt_level, "-std=c++17", "-Wno-unused-label"};
   std::vector<std::string> extra;                            // experiment knob: DEMI_JIT_FLAGS = extra compiler options, space separated
-  if (const char* f = getenv("DEMI_JIT_FLAGS")) {
+  if (const char* f = demi_host::knob("DEMI_JIT_FLAGS")) {
     std::string item;
     for (const char* c = f;; c++) {
       if (*c == ' ' || *c == '\0') { if (!item.empty()) extra.push_back(item); item.clear(); if (*c == '\0') break; }

@@ -30,6 +30,14 @@
 //               atomics on the dword that holds four lanes' counters, read with one load per expected delivery (the
 //               same one round trip per delivery as K1's random pick): 4.6 KB of LDS per wave, 16-20 waves per CU -
 //               the choice when there are more candidates than the LDS variant can hold at once.
+//   K2_FP_WAVE  (round 4) ONE candidate per wave, its counters one byte per word in LDS (no lane dimension: ~5 KB per wave,
+//               5 workgroups per CU).  Where DDMin lives - a frontier of 10^2 .. 10^4 candidates - the launch time is the
+//               serial chain of one replay, and 80 % of the expected events of a candidate do nothing (their message was never
+//               sent, their Send was pruned): the 64 lanes LOOK AHEAD together - lane i tests event pos + i against the
+//               candidate's mask, its cursor head, its counters - and the walk jumps to the first event that acts on the
+//               state (everything before it provably does nothing under the current state, and the state only changes when
+//               an event acts); the skipped "Ignoring message" events are counted by a popcount.  Only the acting events are
+//               stepped through one by one, on lane 0, by the same code as the lock-step walk.
 #pragma once
 
 #include "sim_core.hpp"
@@ -77,19 +85,21 @@ struct K2Args {
 
 constexpr int K2_WAVES = 4;
 constexpr uint32_t K2_FP_NONE = 0xFFFFu;
-enum : int { K2_SCAN = 0, K2_FP_LDS = 1, K2_FP_HBM = 2 };
+enum : int { K2_SCAN = 0, K2_FP_LDS = 1, K2_FP_HBM = 2, K2_FP_WAVE = 3 };
 
 // LDS of k2_replay<true>: tables | expected (8 B each) | exp_fp (2 B each) | word hash | per wave: states, effect queue, counters
 __host__ __device__ inline size_t k2_fp_shared_bytes(uint32_t n_exp, uint32_t hash_slots) {
   return (((size_t)n_exp * 8 + (size_t)n_exp * 2 + 15) & ~(size_t)15) + (size_t)hash_slots * 8;
 }
-__host__ __device__ inline size_t k2_fp_wave_bytes(uint32_t n_actors, uint32_t n_fp, bool counters_in_lds) {
-  return (size_t)n_actors * 64 * 8 + (size_t)DEMI_FX_CAP * 64 * 4 + (counters_in_lds ? (((size_t)n_fp * 64 + 15) & ~(size_t)15) : 0);
+// (mode: K2_FP_LDS counters [word][lane], K2_FP_WAVE one byte per word, K2_FP_HBM none in LDS)
+__host__ __device__ inline size_t k2_fp_wave_bytes(uint32_t n_actors, uint32_t n_fp, int mode) {
+  const size_t counters = mode == K2_FP_LDS ? (size_t)n_fp * 64 : mode == K2_FP_WAVE ? (size_t)n_fp : 0;
+  return (size_t)n_actors * 64 * 8 + (size_t)DEMI_FX_CAP * 64 * 4 + ((counters + 15) & ~(size_t)15);
 }
 __host__ __device__ inline size_t k2_fp_lds_bytes(uint32_t code_len, uint32_t n_ext, uint32_t n_hs, uint32_t n_actors,
-                                                  uint32_t n_exp, uint32_t hash_slots, uint32_t n_fp, bool counters_in_lds) {
+                                                  uint32_t n_exp, uint32_t hash_slots, uint32_t n_fp, int mode) {
   return tables_lds_bytes(code_len, n_ext, n_hs) + k2_fp_shared_bytes(n_exp, hash_slots) +
-         K2_WAVES * k2_fp_wave_bytes(n_actors, n_fp, counters_in_lds);
+         K2_WAVES * k2_fp_wave_bytes(n_actors, n_fp, mode);
 }
 
 __host__ __device__ inline size_t k2_lds_bytes(uint32_t code_len, uint32_t n_ext, uint32_t n_hs, uint32_t n_actors, bool wide = WIDE_TU,
@@ -100,6 +110,7 @@ __host__ __device__ inline size_t k2_lds_bytes(uint32_t code_len, uint32_t n_ext
 template <int MODE>
 __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
   constexpr bool FP = MODE != K2_SCAN;
+  constexpr bool WAVE = MODE == K2_FP_WAVE;       // one candidate per wave, cooperative look-ahead
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Tables t;
   unsigned char* wave_base = tables_load(t, smem, args.model, args.ext, args.n_ext, args.exists);
@@ -121,11 +132,12 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
     __syncthreads();
     expected = s_exp; exp_fp = s_fp; fp_hash = s_hash;
     unsigned char* wb = wave_base + k2_fp_shared_bytes(NX, args.fp_hash_mask + 1) +
-                        (size_t)wave * k2_fp_wave_bytes(t.A, args.n_fp, MODE == K2_FP_LDS);
+                        (size_t)wave * k2_fp_wave_bytes(t.A, args.n_fp, MODE);
     mem.st = reinterpret_cast<uint64_t*>(wb) + lane;
     mem.fxq = reinterpret_cast<word_t*>(wb + (size_t)t.A * 64 * 8) + lane;    // (the counter variants never run a wide table)
     mem.pend = nullptr; mem.pend_aux = nullptr; mem.spill = nullptr; mem.spill_aux = nullptr; mem.spill_stride = 0; mem.spill_lane = 0; mem.hot = 0;
     if (MODE == K2_FP_LDS) cnt = wb + (size_t)t.A * 64 * 8 + (size_t)DEMI_FX_CAP * 64 * 4 + lane;
+    else if (WAVE) { cnt = wb + (size_t)t.A * 64 * 8 + (size_t)DEMI_FX_CAP * 64 * 4; cnt_stride = 1; }    // (every lane sees the wave's one candidate)
     else { cnt_stride = (size_t)gridDim.x * blockDim.x; cnt = args.fp_counts + (size_t)blockIdx.x * blockDim.x + threadIdx.x; }
   } else {
     mem = lane_mem_carve(wave_base + (size_t)wave * lane_mem_wave_bytes(t.A, false), t.A, false, lane,
@@ -172,6 +184,12 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
       if ((uint32_t)e == word) return (uint32_t)(e >> 32) - 1u;
       i = (i + 1) & args.fp_hash_mask;
     }
+  };
+
+  // lane 0's 64-bit value on every lane
+  auto bcast64 = [&](uint64_t x) __attribute__((always_inline)) -> uint64_t {
+    return (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x) |
+           ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x >> 32)) << 32);
   };
 
   bool active = false, fresh = false;
@@ -275,10 +293,16 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
         app_rng = jr_seed(0);
         net.inaccessible = exists; net.killed = 0; net.partitioned = 0;
         for (uint32_t a = 0; a < A * ST_WORDS; a++) st[a * 64] = t.init[a];
-        if (FP) for (uint32_t f = 0; f < args.n_fp; f++) cnt[(size_t)f * cnt_stride] = 0;
+        if (FP && !WAVE) for (uint32_t f = 0; f < args.n_fp; f++) cnt[(size_t)f * cnt_stride] = 0;
         cur = 0; n_pend = 0; count = 0; ignored = 0; flags = 0; rep = 0; tq = 0; n_tq = 0; blocked = 0;
         fk_part = 0; fk_pruned0 = 0; fk_pruned1 = 0;
         cur_skip();
+      }
+      if (WAVE) {
+        // the wave's one candidate (lane 0's): its counters zeroed by all lanes, its mask known to all of them
+        for (uint32_t f = lane; f < args.n_fp; f += 64) cnt[f] = 0;
+        m0 = bcast64(m0); m1 = bcast64(m1); m2 = bcast64(m2); m3 = bcast64(m3);
+        __builtin_amdgcn_wave_barrier();       // (the zeroed counters before lane 0's first increment: LDS operations of a wave complete in order)
       }
       K2_MARK(0);
       // the next event and its word id are requested one step ahead: with one wave per SIMD there is nothing else to hide
@@ -291,9 +315,70 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
         ph_ev++;
 #endif
         if (__ballot(active) == 0) break;
-        const uint64_t ev = ev_next;
-        const uint32_t fp_cur = fp_next;
-        if (idx < NX) { ev_next = expected[idx]; if (FP) fp_next = (uint32_t)exp_fp[idx]; }
+        if (WAVE) {
+          // ---- cooperative look-ahead: lane i looks at expected event pos + i under the candidate's CURRENT state (lane 0's,
+          // broadcast).  An event ACTS when the step below would change the state for it: a network event that equals the
+          // cursor head, a kept external MsgSend, an actor's MsgSend of the filter's lowering, a MsgEvent whose message is
+          // pending.  A MsgEvent that is part of the projected trace but whose message is not pending (or whose receiver is
+          // blocked) is IGNORED (:528-529): it only counts.  Nothing before the first acting event changes anything the tests
+          // read, so the tests of all 64 lanes are the ones the sequential walk would have made.
+          const uint32_t pos = idx - 1, j = pos + lane;
+          const uint32_t cur0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur), skip0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)skip);
+          const uint32_t blocked0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)blocked);
+          // (the filter's state is broadcast here, where control flow is wave-uniform: FK is a kernel argument)
+          uint32_t inacc0 = 0;
+          uint64_t partn0 = 0, part0 = 0, pr0 = 0, pr1 = 0;
+          if (FK) {
+            inacc0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)net.inaccessible);
+            partn0 = bcast64(net.partitioned); part0 = bcast64(fk_part); pr0 = bcast64(fk_pruned0); pr1 = bcast64(fk_pruned1);
+          }
+          bool acts = false, ign = false;
+          if (j < NX) {
+            const uint64_t e_ = expected[j];
+            const uint32_t kind_ = (uint32_t)e_ & 0xFF, a_ = (uint32_t)(e_ >> 8) & 0xFF, b_ = (uint32_t)(e_ >> 16) & 0xFF;
+            const uint32_t ext_ = (uint32_t)(e_ >> 48) & 0xFF;
+            if (kind_ <= DEMI_REC_UNPARTITION) {
+              if (cur0 < NE) {
+                const uint64_t x = t.trace[cur0];
+                const uint32_t xk = (uint32_t)x & 0xFF, xa = (uint32_t)(x >> 8) & 0xFF, xb = (uint32_t)(x >> 16) & 0xFF;
+                const uint32_t want_kind = (kind_ == DEMI_REC_SPAWN) ? DEMI_EV_START : (kind_ == DEMI_REC_KILL) ? DEMI_EV_KILL
+                                         : (kind_ == DEMI_REC_PARTITION) ? DEMI_EV_PARTITION : DEMI_EV_UNPARTITION;
+                acts = xk == want_kind && xa == a_ && (kind_ < DEMI_REC_PARTITION || xb == b_);
+              }
+            } else if (kind_ == DEMI_REC_MSG_SEND && ext_ == 255) {
+              acts = FK != 0;
+            } else if (kind_ == DEMI_REC_MSG_SEND) {
+              acts = IN_MASK(ext_) && ((exists >> b_) & 1);
+            } else {
+              bool in_trace = j != skip0 && (ext_ == 255 || IN_MASK(ext_));
+              if (FK && in_trace) {
+                const uint32_t slot = (uint32_t)(e_ >> 56);
+                const bool sent = slot == 255u || !(((slot & 64u) ? pr1 : pr0) >> (slot & 63u) & 1ull);
+                const bool alive = b_ >= DEMI_MAX_ACTORS || (((exists & ~inacc0) >> b_) & 1u);
+                bool cut = false;
+                if (a_ < DEMI_MAX_ACTORS && b_ < DEMI_MAX_ACTORS)
+                  cut = FK == DEMI_FILTER_ABSENTS_LITERAL ? ((part0 >> (a_ * 8 + b_)) & 1ull)
+                                                          : (((partn0 >> (a_ * 8 + b_)) | (partn0 >> (b_ * 8 + a_))) & 1ull);
+                in_trace = alive && !cut && sent;
+              }
+              if (in_trace) {
+                if ((blocked0 >> b_) & 1u) ign = true;
+                else if (cnt[exp_fp[j]] == 0) ign = true;
+                else acts = true;
+              }
+            }
+          }
+          const uint64_t acting = __ballot(acts);
+          const uint32_t first = acting ? (uint32_t)__builtin_ctzll(acting) : 64u;
+          const uint64_t before = first >= 64u ? ~0ull : ((1ull << first) - 1ull);
+          const uint64_t ignoring = __ballot(ign);
+          if (lane == 0 && active) ignored += (uint32_t)__popcll(ignoring & before);
+          if (first == 64u) { idx += 63; continue; }      // (none of the next 64 events acts; the loop's idx++ completes the jump)
+          idx += first;
+        }
+        const uint64_t ev = WAVE ? expected[idx - 1] : ev_next;
+        const uint32_t fp_cur = WAVE ? (uint32_t)exp_fp[idx - 1] : fp_next;
+        if (!WAVE && idx < NX) { ev_next = expected[idx]; if (FP) fp_next = (uint32_t)exp_fp[idx]; }
         // the event is the same for every lane: keep it in scalar registers, so that its kind, the handler it selects
         // and the receiver are wave-uniform for the compiler too
         const uint64_t e = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ev) |
@@ -683,5 +768,6 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
 __global__ __launch_bounds__(K2_WAVES * 64) void k2_replay(const K2Args args) { k2_replay_body<K2_SCAN>(args); }
 __global__ __launch_bounds__(K2_WAVES * 64) void k2_replay_fp(const K2Args args) { k2_replay_body<K2_FP_LDS>(args); }
 __global__ __launch_bounds__(K2_WAVES * 64) void k2_replay_fp_hbm(const K2Args args) { k2_replay_body<K2_FP_HBM>(args); }
+__global__ __launch_bounds__(K2_WAVES * 64) void k2_replay_fp_wave(const K2Args args) { k2_replay_body<K2_FP_WAVE>(args); }
 
 }  // namespace demi

@@ -500,14 +500,24 @@ SH_MSGS = [("Submit", T.MSG_EXTERNAL), ("Speculate", T.MSG_EXTERNAL), ("LaunchSt
            ("RunTask", T.MSG_INTERNAL), ("MapDone", T.MSG_INTERNAL), ("StageDone", T.MSG_INTERNAL),
            ("Fetch", T.MSG_INTERNAL), ("FetchReply", T.MSG_INTERNAL), ("TaskTimeout", T.MSG_TIMER)]
 (SH_SUBMIT, SH_SPECULATE, SH_LAUNCH, SH_RUN, SH_MAPDONE, SH_STAGEDONE, SH_FETCH, SH_FETCHREPLY, SH_TIMEOUT) = range(9)
+SH_REDUCEDONE = 9      # the pipeline variant only (shuffle_model(jobs > 1))
 CLS_DRIVER, CLS_COORD, CLS_WORKER = 0, 1, 2
 
 
-def shuffle_model(buggy=True) -> Model:
-    """Actors: 0 driver, 1 map-stage coordinator, 2 reduce-stage coordinator, 3..7 workers."""
+def shuffle_model(buggy=True, jobs=1) -> Model:
+    """Actors: 0 driver, 1 map-stage coordinator, 2 reduce-stage coordinator, 3..7 workers.
+
+    jobs > 1 is the PIPELINE variant (BASELINE config 5 at a size worth sharding, apps.shuffle8_config5_large): the reduce stage
+    reports back - a worker that has all its FetchReplies sends ReduceDone, the reduce coordinator counts them and reports
+    StageDone(2) - and the driver then launches the next job itself, `jobs` of them back to back.  The next job's messages
+    descend from the delivery that completed the previous one, so its whole subtree of DPOR nodes is new for every way the
+    previous job can end: the space of racing pairs multiplies per job instead of adding up.  jobs = 1 is the table every
+    fixture of rounds 1-3 was taken on, row for row."""
     n_workers = 5
+    pipeline = jobs > 1
+    assert 1 <= jobs <= 255
     h = {}
-    # ---- driver: F0 phase (0 idle, 1 map, 2 reduce, 3 done), F1 reports counted, F2 bitmask of workers reported
+    # ---- driver: F0 phase (0 idle, 1 map, 2 reduce, 3 done), F1 reports counted, F2 bitmask of workers reported, F6 job number
     a = Asm()
     a.if_eq(F[0], 0, "x").mov(F[0], 1).mov(T0, 1).send(SH_LAUNCH, T0, T1, 0).label("x")
     h[(CLS_DRIVER, "Submit")] = a
@@ -517,16 +527,24 @@ def shuffle_model(buggy=True) -> Model:
     a = Asm()          # StageDone(stage) from a coordinator
     a.if_eq(P0, 1, "s2")
     a.if_eq(F[0], 1, "x").mov(F[0], 2).mov(T0, 2).send(SH_LAUNCH, T0, T1, 0).halt()
-    a.label("s2").if_eq(F[0], 2, "x").mov(F[0], 3).label("x")
+    a.label("s2").if_eq(F[0], 2, "x").mov(F[0], 3)
+    if pipeline:       # the next job: LaunchStage(job number) to the map coordinator
+        a.if_lt(F[6], jobs - 1, "x").add(F[6], F[6], 1).mov(F[0], 1).mov(T0, 1).send(SH_LAUNCH, T0, F[6], 0)
+    a.label("x")
     h[(CLS_DRIVER, "StageDone")] = a
-    # ---- stage coordinators (actors 1 and 2 share a class): F0 started, F1 done count, F2 done mask
+    # ---- stage coordinators (actors 1 and 2 share a class): F0 started, F1 done count, F2 done mask, F3 reported, F4 job number
     a = Asm()          # LaunchStage(w, relaunch)
     a.if_eq(ME, 2, "map")            # on the reduce coordinator: RunTask(reduce) to every worker
+    if pipeline:
+        a.mov(F[1], 0).mov(F[3], 0)
     for w in range(n_workers):
         a.mov(T0, 3 + w).mov(T1, 2).send(SH_RUN, T0, T1, 0)
     a.halt()
     a.label("map")                   # on the map coordinator: relaunch=0 -> all workers; relaunch=1 -> worker 3+w only
-    a.if_eq(P1, 0, "re").if_eq(F[0], 0, "x").mov(F[0], 1)
+    a.if_eq(P1, 0, "re")
+    if pipeline:                     # (a new job number: the coordinator starts over)
+        a.if_ne(P0, F[4], "same").mov(F[4], P0).mov(F[0], 0).mov(F[1], 0).mov(F[2], 0).mov(F[3], 0).label("same")
+    a.if_eq(F[0], 0, "x").mov(F[0], 1)
     for w in range(n_workers):
         a.mov(T0, 3 + w).mov(T1, 1).send(SH_RUN, T0, T1, 0)
     a.halt()
@@ -540,23 +558,33 @@ def shuffle_model(buggy=True) -> Model:
         a.and_(T2, F[2], T1).if_eq(T2, 0, "x").add(F[1], F[1], 1).or_(F[2], F[2], T1)
     a.if_eq(F[1], n_workers, "x").if_eq(F[3], 0, "x").mov(F[3], 1).mov(T0, 0).mov(T1, 1).send(SH_STAGEDONE, T0, T1, 0).label("x")
     h[(CLS_COORD, "MapDone")] = a
+    if pipeline:
+        a = Asm()      # ReduceDone from a worker (at the reduce coordinator): the fifth one ends the stage
+        a.add(F[1], F[1], 1).if_eq(F[1], n_workers, "x").if_eq(F[3], 0, "x").mov(F[3], 1).mov(T0, 0).mov(T1, 2).send(SH_STAGEDONE, T0, T1, 0).label("x")
+        h[(CLS_COORD, "ReduceDone")] = a
     # ---- workers: F0 has map output, F1 fetched count, F2 fetch-missing flag (violation), F3 ran reduce
     a = Asm()          # RunTask(kind): 1 = map (arm a task timeout, produce output, report); 2 = reduce (fetch from all)
-    a.if_eq(P0, 1, "red").mov(F[0], 1).tcancel(SH_TIMEOUT).tset(SH_TIMEOUT).mov(T0, 1).send(SH_MAPDONE, T0, T1, 0).halt()
+    a.if_eq(P0, 1, "red").mov(F[0], 1)
+    if pipeline:
+        a.mov(F[1], 0).mov(F[3], 0)
+    a.tcancel(SH_TIMEOUT).tset(SH_TIMEOUT).mov(T0, 1).send(SH_MAPDONE, T0, T1, 0).halt()
     a.label("red").if_eq(F[3], 0, "x").mov(F[3], 1).bcast(SH_FETCH, T1, 0).label("x")
     h[(CLS_WORKER, "RunTask")] = a
     a = Asm()          # Fetch from a reducer: reply with whether the map output exists
     a.send(SH_FETCHREPLY, SRC, F[0], 0)
     h[(CLS_WORKER, "Fetch")] = a
     a = Asm()          # FetchReply(has_output)
-    a.add(F[1], F[1], 1).if_eq(P0, 0, "x").mov(F[2], 1).label("x")
+    a.add(F[1], F[1], 1).if_eq(P0, 0, "y").mov(F[2], 1).label("y")
+    if pipeline:       # the last of the n_workers - 1 replies: this reducer is done
+        a.if_eq(F[1], n_workers - 1, "x").mov(T0, 2).send(SH_REDUCEDONE, T0, T1, 0).label("x")
     h[(CLS_WORKER, "FetchReply")] = a
     a = Asm()          # TaskTimeout: a straggler detector re-reports (duplicate MapDone)
     a.if_eq(F[0], 1, "x").if_lt(F[4], 1, "x").add(F[4], F[4], 1).mov(T0, 1).send(SH_MAPDONE, T0, T1, 0).label("x")
     h[(CLS_WORKER, "TaskTimeout")] = a
     # coordinators ignore worker-only messages and vice versa (handler_start 0xFFFF)
     init = [[0] * 8 for _ in range(8)]
-    return build_model("shuffle8-synth%s" % ("" if buggy else "-fixed"), 8, SH_MSGS, h, init,
+    return build_model("shuffle8-synth%s%s" % ("" if buggy else "-fixed", "-x%d" % jobs if pipeline else ""), 8,
+                       SH_MSGS + ([("ReduceDone", T.MSG_INTERNAL)] if pipeline else []), h, init,
                        invariant=(T.INV_NEVER, 2, 1, 0), actor_class=[CLS_DRIVER, CLS_COORD, CLS_COORD] + [CLS_WORKER] * 5,
                        n_classes=3)
 

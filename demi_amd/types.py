@@ -9,6 +9,7 @@ MAX_CODE = 1024
 MAX_TIMER_TYPES = 4
 MAX_EXT_EVENTS = 255
 MAX_REC_EVENTS = 16384
+ABI_VERSION = 4             # DEMI_ABI_VERSION of include/demi_gpu.h (struct-layout generation)
 MAX_PENDING = 128          # DEMI_MAX_PENDING
 
 # demi_status

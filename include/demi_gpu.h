@@ -18,6 +18,14 @@
  * that one on the device, and demi_model_load / demi_trace_load / demi_replay_load wait for the last launch before they
  * replace what the kernels read.  Concurrent launches need one ctx each.
  * Pointers named d_* are DEVICE pointers; all others are host pointers.
+ *
+ * Environment.  The library reads exactly two environment variables on its own account:
+ *   DEMI_HIPRTC_LIB   the hiprtc library demi_model_specialize dlopens (default: the one next to the process's HIP runtime);
+ *   DEMI_RCCL_LIB     the RCCL library demi_comm_create dlopens (default: librccl.so next to the HIP runtime, then the loader path).
+ * Every other DEMI_* variable of the source tree (kernel-variant, launch-shape and bookkeeping selectors such as DEMI_K2_MODE,
+ * DEMI_JIT_K1_HOT, DEMI_DPOR_HOST_BOOKKEEPING; diagnostics such as DEMI_K1_VERBOSE, DEMI_DPOR_TIMING, DEMI_JIT_DUMP) is an
+ * experiment knob of the test suites and the profiling scripts and is IGNORED unless DEMI_EXPERIMENT=1 is set as well
+ * (demi_amd/csrc/knobs.hpp): a host process that inherits a stray one runs the default engine.
  */
 #ifndef DEMI_GPU_H
 #define DEMI_GPU_H
@@ -276,6 +284,13 @@ int demi_ctx_create(int device_ordinal, demi_ctx** out);
 void demi_ctx_destroy(demi_ctx* ctx);
 const char* demi_last_error(const demi_ctx* ctx);
 const char* demi_version(void);
+/* The layout generation of this header's structs.  It changes whenever a struct a caller fills or reads changes size or
+ * meaning (4: demi_rec_event is 16 bytes with 16-bit payloads; demi_limits ends with executions_per_instance; demi_dpor_search
+ * ends with ordering / max_distance_plus1 / resume; demi_dpor_stats ends with backtrack_points).  A binding built against
+ * another generation must refuse to run: compare demi_abi_version() with the DEMI_ABI_VERSION it was compiled with right
+ * after loading the library (jni/demi_jni.c does so in JNI_OnLoad, demi_amd/_native.py in lib()). */
+#define DEMI_ABI_VERSION 4u
+uint32_t demi_abi_version(void);
 
 /* SchedulerConfig (SchedulerConfig.scala:9-37) + the application actors lowered to a table. */
 int demi_model_load(demi_ctx* ctx, const demi_model* model);
@@ -362,6 +377,8 @@ int demi_replay_get_kept(demi_ctx* ctx, const uint64_t* mask /* [4] or NULL */, 
 /* Number of recorded events of the execution loaded by demi_replay_load (0 without one): the size demi_replay_get_kept's
  * out_kept needs.  Lets a binding check its buffer before the call. */
 uint32_t demi_replay_recorded_len(const demi_ctx* ctx);
+/* Number of external events of that execution (0 without one): the length demi_ddmin's `conjoined` must have. */
+uint32_t demi_replay_externals_len(const demi_ctx* ctx);
 
 /* ---------------------------------------------------------- DDMin over the replay oracle, in one call
  * Replaces RunnerUtils.stsSchedDDMin (RunnerUtils.scala:642-707): DDMin.minimize / ddmin2 (minification/DeltaDebugging.scala:27-109)
@@ -373,7 +390,11 @@ uint32_t demi_replay_recorded_len(const demi_ctx* ctx);
  * the real path walks through the verdicts - the MCS and the sequence of consultations are those of the sequential algorithm.
  * A candidate whose replay exceeds limits->p_max is replayed with the largest pending set; DEMI_ERR_CAPACITY if it still does
  * not fit (never "does not reproduce").  DEMI_ERR_INVALID_ARG: the unmodified trace does not trigger the violation
- * (check_unmodified).  DEMI_ERR_INVALID_TRACE: the externals' atoms do not partition them (e.g. a Kill without its Start). */
+ * (check_unmodified).  DEMI_ERR_INVALID_TRACE: the externals' atoms do not partition them (e.g. a Kill without its Start).
+ * With a communicator (demi_comm_create*) every rank calls demi_ddmin with the same arguments: the candidates of each launch are
+ * split over the ranks in contiguous blocks (demi_replay_batch_sharded) and one all-gather of the verdicts lets every rank walk
+ * the same decision tree - same MCS, consultations and launch sizes as the single-rank call on every rank; max_candidates is the
+ * width of a launch over ALL ranks, so W ranks test a frontier W times as wide in the time of one. */
 typedef struct {
   uint32_t depth;            /* levels of the decision tree tested ahead per launch; 0 = as many as fit max_candidates */
   uint32_t max_candidates;   /* per launch when depth = 0 (0 = 4096) */

@@ -7,7 +7,11 @@
  *     entry point may run a whole exploration, compile a table with hiprtc, start host thread pools or take part in an
  *     RCCL collective, and a JNI critical region must neither block nor last (it holds off the collector);
  *   - every array length is checked against what the C entry point reads or writes BEFORE the call: a mismatched caller gets
- *     DEMI_ERR_INVALID_ARG instead of a corrupted Java heap.
+ *     DEMI_ERR_INVALID_ARG instead of a corrupted Java heap;
+ *   - a non-null array whose Get<Type>ArrayElements returns NULL (the JVM is out of memory, an exception is pending) is an
+ *     error, never "absent": NULL means something to the C ABI (no conjoined atoms, no masks), so passing it on would silently
+ *     change the call (LOST below);
+ *   - JNI_OnLoad refuses a libdemi_gpu.so of another struct-layout generation (demi_abi_version() != DEMI_ABI_VERSION).
  * Build: make -C jni (needs JAVA_HOME; without a JDK `make -C jni check` compiles against jni/stub/jni.h).
  *
  * Array conventions (little-endian, same layouts as the C structs):
@@ -30,10 +34,17 @@
 #define SHORTS(arr) ((arr) ? (void*)(*e)->GetShortArrayElements(e, (arr), NULL) : NULL)
 #define INTS(arr) ((arr) ? (void*)(*e)->GetIntArrayElements(e, (arr), NULL) : NULL)
 #define LONGS(arr) ((arr) ? (void*)(*e)->GetLongArrayElements(e, (arr), NULL) : NULL)
+#define LOST(arr, p) ((arr) != NULL && (p) == NULL)     /* the array exists and its elements could not be obtained */
 #define PUT_BYTES(arr, p, mode) do { if ((arr) && (p)) (*e)->ReleaseByteArrayElements(e, (arr), (jbyte*)(p), (mode)); } while (0)
 #define PUT_SHORTS(arr, p, mode) do { if ((arr) && (p)) (*e)->ReleaseShortArrayElements(e, (arr), (jshort*)(p), (mode)); } while (0)
 #define PUT_INTS(arr, p, mode) do { if ((arr) && (p)) (*e)->ReleaseIntArrayElements(e, (arr), (jint*)(p), (mode)); } while (0)
 #define PUT_LONGS(arr, p, mode) do { if ((arr) && (p)) (*e)->ReleaseLongArrayElements(e, (arr), (jlong*)(p), (mode)); } while (0)
+
+JNIEXPORT jint JNICALL JNI_OnLoad(JavaVM* vm, void* reserved) {
+  (void)vm; (void)reserved;
+  /* a library built from another generation of demi_gpu.h would read these arrays with other struct layouts */
+  return demi_abi_version() == DEMI_ABI_VERSION ? JNI_VERSION_1_6 : JNI_ERR;
+}
 
 /* demi_limits from int[9] (a shorter array of an older adapter is refused, not read out of bounds) */
 static int limits_of(JNIEnv* e, jintArray limits, demi_limits* x) {
@@ -87,7 +98,8 @@ JNIEXPORT jint JNICALL FN(modelLoad)(JNIEnv* e, jclass c, jlong h, jint nActors,
   m.handler_start = (const uint16_t*)SHORTS(handlerStart);
   m.code = (const uint32_t*)INTS(code);
   m.init_state = (const uint64_t*)LONGS(initState);
-  jint rc = demi_model_load(CTX(h), &m);
+  jint rc = (LOST(msgClass, m.msg_class) || LOST(actorClass, m.actor_class) || LOST(handlerStart, m.handler_start) || LOST(code, m.code) ||
+             LOST(initState, m.init_state)) ? DEMI_ERR_INVALID_ARG : demi_model_load(CTX(h), &m);
   PUT_LONGS(initState, m.init_state, JNI_ABORT);
   PUT_INTS(code, m.code, JNI_ABORT);
   PUT_SHORTS(handlerStart, m.handler_start, JNI_ABORT);
@@ -104,7 +116,7 @@ JNIEXPORT jint JNICALL FN(traceLoad)(JNIEnv* e, jclass c, jlong h, jbyteArray ev
   const int64_t len = LEN(events);
   if (len < 0 || len % 8) return DEMI_ERR_INVALID_ARG;
   void* p = BYTES(events);
-  jint rc = demi_trace_load(CTX(h), (const demi_ext_event*)p, (uint32_t)(len / 8));
+  jint rc = LOST(events, p) ? DEMI_ERR_INVALID_ARG : demi_trace_load(CTX(h), (const demi_ext_event*)p, (uint32_t)(len / 8));
   PUT_BYTES(events, p, JNI_ABORT);
   return rc;
 }
@@ -115,7 +127,7 @@ JNIEXPORT jint JNICALL FN(randomExplore)(JNIEnv* e, jclass c, jlong h, jlong see
   (void)c;
   if (limits_of(e, limits, &lim) || n < 0 || LEN(verdicts) < 2 * (int64_t)n) return DEMI_ERR_INVALID_ARG;
   void* o = LONGS(verdicts);
-  jint rc = demi_random_explore(CTX(h), (uint64_t)seedBase, NULL, (uint64_t)n, &lim, (demi_verdict*)o);
+  jint rc = LOST(verdicts, o) ? DEMI_ERR_INVALID_ARG : demi_random_explore(CTX(h), (uint64_t)seedBase, NULL, (uint64_t)n, &lim, (demi_verdict*)o);
   PUT_LONGS(verdicts, o, 0);
   return rc;
 }
@@ -128,8 +140,9 @@ JNIEXPORT jint JNICALL FN(randomExploreFlagged)(JNIEnv* e, jclass c, jlong h, jl
   const uint32_t cap = (uint32_t)(LEN(out) / 2);
   uint64_t n_flagged = 0, first = 0;
   void* o = LONGS(out);
-  jint rc = demi_random_explore_flagged(CTX(h), (uint64_t)seedBase, (uint64_t)n, &lim, (uint32_t)flagMask, (demi_violation*)o, cap,
-                                        &n_flagged, &first);
+  jint rc = LOST(out, o) ? DEMI_ERR_INVALID_ARG
+                         : demi_random_explore_flagged(CTX(h), (uint64_t)seedBase, (uint64_t)n, &lim, (uint32_t)flagMask, (demi_violation*)o, cap,
+                                                       &n_flagged, &first);
   PUT_LONGS(out, o, 0);
   const jlong cn[2] = {(jlong)n_flagged, (jlong)first};
   (*e)->SetLongArrayRegion(e, counts, 0, 2, cn);
@@ -145,7 +158,7 @@ JNIEXPORT jint JNICALL FN(randomGetTrace)(JNIEnv* e, jclass c, jlong h, jlong se
   uint32_t n_out = 0;
   memset(&v, 0, sizeof v);
   void* r = BYTES(recorded);
-  jint rc = demi_random_get_trace(CTX(h), (uint64_t)seed, &lim, &v, (demi_rec_event*)r, cap, &n_out);
+  jint rc = LOST(recorded, r) ? DEMI_ERR_INVALID_ARG : demi_random_get_trace(CTX(h), (uint64_t)seed, &lim, &v, (demi_rec_event*)r, cap, &n_out);
   PUT_BYTES(recorded, r, 0);
   (*e)->SetLongArrayRegion(e, verdict, 0, 2, (const jlong*)(const void*)&v);
   return rc == DEMI_OK ? (jint)n_out : rc;
@@ -162,7 +175,8 @@ JNIEXPORT jint JNICALL FN(randomGetTraceCarried)(JNIEnv* e, jclass c, jlong h, j
   uint32_t n_out = 0, ran = 0;
   memset(&v, 0, sizeof v);
   void* r = BYTES(recorded);
-  jint rc = demi_random_get_trace_carried(CTX(h), (uint64_t)seed, (uint32_t)execIndex, &lim, &v, (demi_rec_event*)r, cap, &n_out, &ran);
+  jint rc = LOST(recorded, r) ? DEMI_ERR_INVALID_ARG
+                              : demi_random_get_trace_carried(CTX(h), (uint64_t)seed, (uint32_t)execIndex, &lim, &v, (demi_rec_event*)r, cap, &n_out, &ran);
   PUT_BYTES(recorded, r, 0);
   (*e)->SetLongArrayRegion(e, verdict, 0, 2, (const jlong*)(const void*)&v);
   if (rc == DEMI_OK && ran != (uint32_t)execIndex) return DEMI_ERR_INVALID_ARG;      /* an earlier execution of the chain already violated */
@@ -176,7 +190,8 @@ JNIEXPORT jint JNICALL FN(replayLoad)(JNIEnv* e, jclass c, jlong h, jbyteArray e
   if (le < 0 || le % 8 || lr < 0 || lr % (jint)sizeof(demi_rec_event)) return DEMI_ERR_INVALID_ARG;
   void* x = BYTES(externals);
   void* r = BYTES(recorded);
-  jint rc = demi_replay_load(CTX(h), (const demi_ext_event*)x, (uint32_t)(le / 8), (const demi_rec_event*)r, (uint32_t)(lr / (jint)sizeof(demi_rec_event)));
+  jint rc = (LOST(externals, x) || LOST(recorded, r)) ? DEMI_ERR_INVALID_ARG
+            : demi_replay_load(CTX(h), (const demi_ext_event*)x, (uint32_t)(le / 8), (const demi_rec_event*)r, (uint32_t)(lr / (jint)sizeof(demi_rec_event)));
   PUT_BYTES(recorded, r, JNI_ABORT);
   PUT_BYTES(externals, x, JNI_ABORT);
   return rc;
@@ -189,7 +204,8 @@ JNIEXPORT jint JNICALL FN(replayBatch)(JNIEnv* e, jclass c, jlong h, jlongArray 
   if (LEN(verdicts) < 2 * (int64_t)n) return DEMI_ERR_INVALID_ARG;
   void* m = LONGS(masks);
   void* o = LONGS(verdicts);
-  jint rc = demi_replay_batch_sharded(CTX(h), (const uint64_t*)m, n, &lim, (demi_verdict*)o);   /* = demi_replay_batch without a communicator */
+  jint rc = (LOST(masks, m) || LOST(verdicts, o)) ? DEMI_ERR_INVALID_ARG
+            : demi_replay_batch_sharded(CTX(h), (const uint64_t*)m, n, &lim, (demi_verdict*)o);   /* = demi_replay_batch without a communicator */
   PUT_LONGS(verdicts, o, 0);
   PUT_LONGS(masks, m, JNI_ABORT);
   return rc;
@@ -204,7 +220,8 @@ JNIEXPORT jint JNICALL FN(replayRemovalBatch)(JNIEnv* e, jclass c, jlong h, jlon
   void* m = LONGS(masksOrNull);
   void* s = INTS(skip);
   void* o = LONGS(verdicts);
-  jint rc = demi_replay_removal_batch(CTX(h), (const uint64_t*)m, (const uint32_t*)s, n, &lim, (demi_verdict*)o);
+  jint rc = (LOST(masksOrNull, m) || LOST(skip, s) || LOST(verdicts, o)) ? DEMI_ERR_INVALID_ARG
+            : demi_replay_removal_batch(CTX(h), (const uint64_t*)m, (const uint32_t*)s, n, &lim, (demi_verdict*)o);
   PUT_LONGS(verdicts, o, 0);
   PUT_INTS(skip, s, JNI_ABORT);
   PUT_LONGS(masksOrNull, m, JNI_ABORT);
@@ -221,14 +238,15 @@ JNIEXPORT jint JNICALL FN(replayGetKept)(JNIEnv* e, jclass c, jlong h, jlongArra
   memset(&v, 0, sizeof v);
   void* m = LONGS(maskOrNull);
   void* k = BYTES(kept);
-  jint rc = demi_replay_get_kept(CTX(h), (const uint64_t*)m, (uint32_t)skip, &lim, &v, (uint8_t*)k);
+  jint rc = (LOST(maskOrNull, m) || LOST(kept, k)) ? DEMI_ERR_INVALID_ARG
+            : demi_replay_get_kept(CTX(h), (const uint64_t*)m, (uint32_t)skip, &lim, &v, (uint8_t*)k);
   PUT_BYTES(kept, k, 0);
   PUT_LONGS(maskOrNull, m, JNI_ABORT);
   (*e)->SetLongArrayRegion(e, verdict, 0, 2, (const jlong*)(const void*)&v);
   return rc;
 }
 
-/* ---- DDMin in one call (demi_ddmin).  params: int[4] (demi_ddmin_params); conjoinedOrNull: byte[n externals]; mcs: long[4];
+/* ---- DDMin in one call (demi_ddmin).  params: int[4] (demi_ddmin_params); conjoinedOrNull: byte[>= n externals of replayLoad]; mcs: long[4];
  *      consultedOrNull: long[4 * cap] with passedOrNull: byte[cap]; stats: long[5] = consultations, launches, mcs_len, verified, replays */
 JNIEXPORT jint JNICALL FN(ddmin)(JNIEnv* e, jclass c, jlong h, jintArray limits, jintArray params, jbyteArray conjoinedOrNull, jlongArray mcs,
                                 jlongArray consultedOrNull, jbyteArray passedOrNull, jlongArray stats) {
@@ -241,6 +259,8 @@ JNIEXPORT jint JNICALL FN(ddmin)(JNIEnv* e, jclass c, jlong h, jintArray limits,
   if (limits_of(e, limits, &lim) || LEN(params) != 4 || LEN(mcs) != 4 || LEN(stats) != 5) return DEMI_ERR_INVALID_ARG;
   (*e)->GetIntArrayRegion(e, params, 0, 4, pr);
   par.depth = (uint32_t)pr[0]; par.max_candidates = (uint32_t)pr[1]; par.check_unmodified = (uint32_t)pr[2]; par.verify_mcs = (uint32_t)pr[3];
+  /* demi_ddmin reads conjoined[0 .. n externals of the loaded execution): a shorter array is refused */
+  if (conjoinedOrNull && LEN(conjoinedOrNull) < (int64_t)demi_replay_externals_len(CTX(h))) return DEMI_ERR_INVALID_ARG;
   uint32_t cap = 0;
   if (consultedOrNull) {
     if (LEN(consultedOrNull) % 4 || !passedOrNull || LEN(passedOrNull) < LEN(consultedOrNull) / 4) return DEMI_ERR_INVALID_ARG;
@@ -250,7 +270,8 @@ JNIEXPORT jint JNICALL FN(ddmin)(JNIEnv* e, jclass c, jlong h, jintArray limits,
   void* cj = BYTES(conjoinedOrNull);
   void* co = LONGS(consultedOrNull);
   void* pa = BYTES(passedOrNull);
-  jint rc = demi_ddmin(CTX(h), &lim, &par, (const uint8_t*)cj, out, (uint64_t*)co, (uint8_t*)pa, cap, NULL, 0, &st);
+  jint rc = (LOST(conjoinedOrNull, cj) || LOST(consultedOrNull, co) || LOST(passedOrNull, pa)) ? DEMI_ERR_INVALID_ARG
+            : demi_ddmin(CTX(h), &lim, &par, (const uint8_t*)cj, out, (uint64_t*)co, (uint8_t*)pa, cap, NULL, 0, &st);
   PUT_BYTES(passedOrNull, pa, 0);
   PUT_LONGS(consultedOrNull, co, 0);
   PUT_BYTES(conjoinedOrNull, cj, JNI_ABORT);
@@ -267,7 +288,7 @@ JNIEXPORT jint JNICALL FN(dporLoad)(JNIEnv* e, jclass c, jlong h, jbyteArray ext
   const int64_t len = LEN(externals);
   if (len < 0 || len % 8) return DEMI_ERR_INVALID_ARG;
   void* p = BYTES(externals);
-  jint rc = demi_dpor_load(CTX(h), (const demi_ext_event*)p, (uint32_t)(len / 8));
+  jint rc = LOST(externals, p) ? DEMI_ERR_INVALID_ARG : demi_dpor_load(CTX(h), (const demi_ext_event*)p, (uint32_t)(len / 8));
   PUT_BYTES(externals, p, JNI_ABORT);
   return rc;
 }
@@ -296,7 +317,8 @@ JNIEXPORT jint JNICALL FN(dporExplore)(JNIEnv* e, jclass c, jlong h, jintArray p
   void* pl = INTS(prefixLen);
   void* rd = INTS(rounds);
   void* ft = BYTES(firstViolationTrace);
-  jint rc = demi_dpor_explore(CTX(h), &par, &srch, (demi_verdict*)v, (uint32_t*)pl, (uint32_t*)rd, (demi_dpor_trace_entry*)ft, &vlen, &st);
+  jint rc = (LOST(verdicts, v) || LOST(prefixLen, pl) || LOST(rounds, rd) || LOST(firstViolationTrace, ft)) ? DEMI_ERR_INVALID_ARG
+            : demi_dpor_explore(CTX(h), &par, &srch, (demi_verdict*)v, (uint32_t*)pl, (uint32_t*)rd, (demi_dpor_trace_entry*)ft, &vlen, &st);
   PUT_BYTES(firstViolationTrace, ft, 0);
   PUT_INTS(rounds, rd, 0);
   PUT_INTS(prefixLen, pl, 0);
@@ -323,8 +345,9 @@ JNIEXPORT jint JNICALL FN(provenancePrune)(JNIEnv* e, jclass c, jlong h, jbyteAr
   void* l = INTS(traceLen);
   void* a = INTS(affected);
   void* k = LONGS(keep);
-  jint rc = demi_provenance_prune(CTX(h), (const demi_dpor_trace_entry*)t, (const uint32_t*)l, (const uint32_t*)a, (uint32_t)stride,
-                                  (uint64_t)n, (uint64_t*)k);
+  jint rc = (LOST(traces, t) || LOST(traceLen, l) || LOST(affected, a) || LOST(keep, k)) ? DEMI_ERR_INVALID_ARG
+            : demi_provenance_prune(CTX(h), (const demi_dpor_trace_entry*)t, (const uint32_t*)l, (const uint32_t*)a, (uint32_t)stride,
+                                    (uint64_t)n, (uint64_t*)k);
   PUT_LONGS(keep, k, 0);
   PUT_INTS(affected, a, JNI_ABORT);
   PUT_INTS(traceLen, l, JNI_ABORT);
@@ -340,8 +363,9 @@ JNIEXPORT jint JNICALL FN(dporSetTraces)(JNIEnv* e, jclass c, jlong h, jlongArra
   if (lk < 0 || lt < 0 || lt % (int64_t)sizeof(demi_dpor_trace_entry)) return DEMI_ERR_INVALID_ARG;
   void* k = LONGS(originalKeysOrNull);
   void* t = BYTES(initialTraceOrNull);
-  jint rc = demi_dpor_set_traces(CTX(h), (const uint64_t*)k, (uint32_t)lk, (const demi_dpor_trace_entry*)t,
-                                 (uint32_t)(lt / (int64_t)sizeof(demi_dpor_trace_entry)));
+  jint rc = (LOST(originalKeysOrNull, k) || LOST(initialTraceOrNull, t)) ? DEMI_ERR_INVALID_ARG
+            : demi_dpor_set_traces(CTX(h), (const uint64_t*)k, (uint32_t)lk, (const demi_dpor_trace_entry*)t,
+                                   (uint32_t)(lt / (int64_t)sizeof(demi_dpor_trace_entry)));
   PUT_BYTES(initialTraceOrNull, t, JNI_ABORT);
   PUT_LONGS(originalKeysOrNull, k, JNI_ABORT);
   return rc;
@@ -373,7 +397,8 @@ JNIEXPORT jint JNICALL FN(randomExploreSharded)(JNIEnv* e, jclass c, jlong h, jl
   const uint32_t cap = (uint32_t)(LEN(out) / 2);
   uint64_t n = 0;
   void* o = LONGS(out);
-  jint rc = demi_random_explore_sharded(CTX(h), (uint64_t)seedBase, (uint64_t)nTotal, &lim, (demi_violation*)o, cap, &n);
+  jint rc = LOST(out, o) ? DEMI_ERR_INVALID_ARG
+                         : demi_random_explore_sharded(CTX(h), (uint64_t)seedBase, (uint64_t)nTotal, &lim, (demi_violation*)o, cap, &n);
   PUT_LONGS(out, o, 0);
   const jlong cn = (jlong)n;
   (*e)->SetLongArrayRegion(e, count, 0, 1, &cn);

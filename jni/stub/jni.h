@@ -12,6 +12,9 @@ typedef jarray jintArray; typedef jarray jlongArray;
 #define JNIEXPORT __attribute__((visibility("default")))
 #define JNICALL
 #define JNI_ABORT 2
+#define JNI_ERR (-1)
+#define JNI_VERSION_1_6 0x00010006
+struct JavaVM_; typedef struct JavaVM_ JavaVM;
 struct JNINativeInterface_;
 typedef const struct JNINativeInterface_* JNIEnv;
 struct JNINativeInterface_ {

@@ -21,7 +21,7 @@ object DemiGpu {
   @native def randomExplore(h: Long, seedBase: Long, n: Long, limits: Array[Int], verdicts: Array[Long]): Int
   @native def randomExploreFlagged(h: Long, seedBase: Long, n: Long, limits: Array[Int], flagMask: Int,
                                    out: Array[Long], counts: Array[Long]): Int
-  /** returns the number of recorded events (12 bytes each in `recorded`), or a negative status */
+  /** returns the number of recorded events (16 bytes each in `recorded`: demi_rec_event), or a negative status */
   @native def randomGetTrace(h: Long, seed: Long, limits: Array[Int], verdict: Array[Long], recorded: Array[Byte]): Int
   /** the same for execution number `execIndex` of the instance seeded `seed` (demi_limits.executions_per_instance > 1) */
   @native def randomGetTraceCarried(h: Long, seed: Long, execIndex: Int, limits: Array[Int], verdict: Array[Long], recorded: Array[Byte]): Int

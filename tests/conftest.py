@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+# the suites run the library's experiment variants against each other (DEMI_K2_MODE, DEMI_DPOR_HOST_BOOKKEEPING, DEMI_JIT_*):
+# the library reads such variables only with this switch on (demi_amd/csrc/knobs.hpp); tests/test_host_cpu.py checks the
+# gate itself in processes of their own
+os.environ.setdefault("DEMI_EXPERIMENT", "1")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

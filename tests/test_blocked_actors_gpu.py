@@ -69,7 +69,7 @@ def test_k2_parity_with_crashed_actors(gpu_ctx, oracle, monkeypatch):
     masks[0, 0] = (1 << len(used)) - 1
     target = T.Limits(0, 0, 64, 1, 0x7FFFFFFF, 0)
     c = oracle.sts_replay_batch(model, used, rec, masks, target, n_threads=os.cpu_count())
-    for mode in ("lds", "hbm", None):
+    for mode in ("wave", "lds", "hbm", None):
         if mode:
             monkeypatch.setenv("DEMI_K2_MODE", mode)
         else:
@@ -127,7 +127,7 @@ def test_application_randomness_parity_on_every_kernel(gpu_ctx, oracle, monkeypa
     masks[0, 0] = (1 << len(used)) - 1
     target = T.Limits(0, 0, 64, 1, 0x7FFFFFFF, 0)
     want = oracle.sts_replay_batch(model, used, grec, masks, target, n_threads=os.cpu_count())
-    for mode in ("lds", "hbm"):
+    for mode in ("wave", "lds", "hbm"):
         monkeypatch.setenv("DEMI_K2_MODE", mode)
         gpu_ctx.replay_load(used, grec)
         assert_same(gpu_ctx.replay_batch(masks, target), want)

@@ -77,16 +77,38 @@ print("rank", rank, "ok", n)
 '''
 
 
-def test_sharded_entry_points_two_ranks_on_one_gpu(tmp_path):
+def _run_ranks(tmp_path, text, world, port, timeout=900, per_rank_env=None, expect="ok"):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    script = tmp_path / "w.py"
-    script.write_text(_WORKER % {"root": root})
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", WORLD_SIZE="2")
-    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
-    outs = [p.communicate(timeout=500)[0].decode() for p in procs]
+    script = tmp_path / ("w%d.py" % world)
+    script.write_text(text % {"root": root})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world))
+    if os.environ.get("DEMI_EMU") == "1":
+        env["W64_THREADS"] = "1"     # (tests/emu/README: the explored-pair table's bounded wait assumes waves that keep running)
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r), **((per_rank_env or {}).get(r, {}))),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=timeout)[0].decode())
+    finally:
+        for p in procs:          # (a hung rank must not outlive the test)
+            if p.poll() is None:
+                p.kill()
     for p, o in zip(procs, outs):
-        assert p.returncode == 0 and "ok" in o, o
+        assert p.returncode == 0 and expect in o, o
+    return outs
+
+
+def test_sharded_entry_points_two_ranks_on_one_gpu(tmp_path):
+    _run_ranks(tmp_path, _WORKER, 2, 29541)
+
+
+@pytest.mark.parametrize("world", [3, 8])
+def test_sharded_entry_points_odd_and_full_world_sizes(tmp_path, world):
+    """The same worker with 3 and with 8 ranks (the driver's 8-GPU shape, here on one device): an odd world exercises the
+    W * ceil(n / W) padding of every block exchange - empty and ragged last blocks, arena ids that are padding - and the
+    status agreement before each collective with more than two parties."""
+    _run_ranks(tmp_path, _WORKER, world, 29550 + world)
 
 
 def test_rccl_communicator_world_of_one(gpu_ctx):
@@ -124,16 +146,142 @@ def test_bench_py_two_ranks_on_one_gpu(tmp_path):
     env = dict(os.environ, DEMI_BENCH_BACKEND="gloo", DEMI_BENCH_ONE_GPU="1", DEMI_BENCH_COMM="host")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29547", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--schedules", "65536", "--no-prewarm"]
-    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+           "--schedules", "65536", "--no-prewarm", "--config5-budget", "40000"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["value"] > 0
     assert "demi_comm_allgather_dev" in d["config"]["collective"]
+    # every timed step evaluates fresh seeds: 3 steps x 2 ranks x 65536 schedules, their violating executions counted once each
+    tr = d["timed_region"]
+    assert tr["schedules"] == 3 * 2 * 65536 and tr["violating_executions"] >= tr["distinct_violating_delivery_hashes"] > 0
+    assert tr["distinct_violating_delivery_hashes"] > 2 * d["violations_last_step"] and d["bugs_per_hr"] > 0
+    assert d["config"]["jit_compile_s"] > 0
+    # BASELINE configs 4 and 5 as N-rank records of the same line
+    dd, c5 = d["secondary"]["ddmin"], d["secondary"]["config5"]
+    assert "error" not in dd and "error" not in c5, (dd, c5)
+    e2e = dd["ddmin_end_to_end"]
+    assert dd["n_gpus"] == 2 and e2e["same_mcs_as_single_rank"] and e2e["same_consultation_sequence_as_single_rank"] and e2e["mcs_len"] > 0
+    assert dd["every_ranks_block_arrived_everywhere"] and dd["value"] > 0
+    assert c5["n_gpus"] == 2 and c5["interleavings"] == 40000 and not c5["exhausted"] and c5["same_verdict_sequence_on_every_rank"]
     # both ranks' violations are in the merged set: rank 1 evaluates the indices [65536, 131072)
     one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0", "--schedules", "65536",
                           "--no-prewarm", "--no-cpu-baseline", "--no-secondary"], capture_output=True, text=True, timeout=600)
     d1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][0])
     assert d["violations_last_step"] > d1["violations_last_step"] > 0
+
+
+# BASELINE configs 4 and 5 over the ranks, exactly as bench.py --gpus N runs them: demi_ddmin with the communicator (every
+# speculative frontier split over the ranks inside the library) and the bounded DPOR exploration of the shuffle pipeline
+# (apps.shuffle8_config5_large; a smaller budget here), each against the single-rank call on the same inputs.
+_WORKER_CFG45 = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+if os.environ.get("DEMI_EMU") == "1":
+    import tests.conftest
+import numpy as np
+import torch
+import torch.distributed as dist
+from demi_amd import _native, types as T
+from demi_amd.apps import SEED_BASE, raft5_config4, shuffle8_config5_large
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+def allgather(block: bytes) -> bytes:
+    mine = torch.frombuffer(bytearray(block), dtype=torch.uint8)
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine)
+    return b"".join(bytes(p.numpy().tobytes()) for p in parts)
+emu = os.environ.get("DEMI_EMU") == "1"
+# ---- config 4: DDMin of the 200-event failing execution
+n_ev = 60 if emu else 200
+model, events, lim = raft5_config4(n_ev)
+ctx = _native.Context(0)
+ctx.model_load(model.to_struct()); ctx.trace_load(events)
+v = ctx.random_explore(4000, lim, seed_base=SEED_BASE)
+i = int(np.nonzero(v["flags"] & T.V_VIOLATION)[0][0])
+vv, rec = ctx.random_get_trace(SEED_BASE + i, lim)
+used = events[:T.verdict_trace_idx(vv.flags)]
+ctx.replay_load(used, rec)
+if not emu:
+    ctx.model_specialize()
+target = T.Limits(0, 0, 128, 1, vv.fingerprint, 0)
+mcs1, cons1, batches1, st1 = ctx.ddmin(target, T.DdminParams(0, 256, 1, 1))
+ctx.comm_create_host(rank, world, allgather)
+for budget in (256, 256 * world):
+    mcsw, consw, batchesw, stw = ctx.ddmin(target, T.DdminParams(0, budget, 1, 1))
+    assert tuple(mcsw) == tuple(mcs1) and stw.verified == st1.verified and stw.consultations == st1.consultations
+    assert [(tuple(c), p) for c, p in consw] == [(tuple(c), p) for c, p in cons1]
+    if budget == 256:
+        assert batchesw == batches1          # same frontiers, each split over the ranks
+    else:
+        assert len(batchesw) <= len(batches1)
+ctx.comm_destroy()
+# ---- config 5: the shuffle pipeline, bounded DPOR exploration
+model5, ev5, depth, _budget = shuffle8_config5_large()
+budget = int(os.environ.get("CFG5_BUDGET", "3000" if emu else "40000"))
+ctx.model_load(model5.to_struct())
+if not emu:
+    ctx.model_specialize()
+ctx.dpor_load(ev5)
+par = T.DporParams(depth, 0, 0, 0, 64, 4096)
+srch = T.DporSearch(1024 if emu else 4096, budget, 0, 1, T.DPOR_ORDER_ROUNDS)
+one = ctx.dpor_explore(par, srch)
+ctx.comm_create_host(rank, world, allgather)
+two = ctx.dpor_explore(par, srch)
+assert len(one[0]) == len(two[0]) == budget and (one[0] == two[0]).all() and (one[1] == two[1]).all() and (one[2] == two[2]).all()
+assert not one[4].exhausted and not two[4].exhausted and one[4].queue_len == two[4].queue_len
+ctx.comm_destroy()
+dist.barrier(); dist.destroy_process_group()
+ctx.close()
+print("rank", rank, "ok", len(mcs1), len(one[0]))
+'''
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_config4_ddmin_and_config5_dpor_over_the_ranks(tmp_path, world):
+    _run_ranks(tmp_path, _WORKER_CFG45, world, 29560 + world, timeout=1500)
+
+
+# One rank whose share of the explored-pair table is full (a 64-entry table on rank 1 only): every rank must return the
+# capacity error from the same call - nobody is left waiting in the round's next all-gather (comm_agree).
+_WORKER_FAIL = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+if os.environ.get("DEMI_EMU") == "1":
+    import tests.conftest
+import numpy as np
+import torch
+import torch.distributed as dist
+from demi_amd import _native, types as T, model as M
+from demi_amd.fuzzer import events_to_array, send, start
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+def allgather(block: bytes) -> bytes:
+    mine = torch.frombuffer(bytearray(block), dtype=torch.uint8)
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine)
+    return b"".join(bytes(p.numpy().tobytes()) for p in parts)
+m3 = M.raft_model(3)
+ev3 = events_to_array([start(a) for a in range(3)] + [send(a, M.M_BOOTSTRAP) for a in range(3)])
+ctx = _native.Context(0)
+ctx.model_load(m3.to_struct()); ctx.dpor_load(ev3)
+ctx.comm_create_host(rank, world, allgather)
+par = T.DporParams(30, 0, 0, 0, 64, 4096)
+try:
+    ctx.dpor_explore(par, T.DporSearch(64, 5000, 0, 1))
+    print("rank", rank, "no error")
+except _native.DemiError as e:
+    assert e.code == -7, e           # DEMI_ERR_CAPACITY on every rank
+    print("rank", rank, "stopped", "own table" if "table full" in str(e) else "with the failing rank")
+ctx.comm_destroy()
+dist.barrier(); dist.destroy_process_group()
+ctx.close()
+'''
+
+
+def test_one_ranks_full_table_stops_every_rank(tmp_path):
+    outs = _run_ranks(tmp_path, _WORKER_FAIL, 3, 29571, timeout=600, expect="stopped",
+                      per_rank_env={1: {"DEMI_EXPERIMENT": "1", "DEMI_K3_TABLE_ENTRIES": "64"}})
+    assert "own table" in outs[1] and all("with the failing rank" in outs[r] for r in (0, 2)), outs

@@ -187,3 +187,28 @@ def test_verdict_dump_for_the_deferred_jvm_check(tmp_path):
     for k in meta["recorded"]:
         rec = np.fromfile(out / ("deliveries_%d.bin" % k), dtype=T.REC_EVENT_DTYPE)
         assert int((rec["kind"] == T.REC_MSG_EVENT).sum()) == T.verdict_deliveries(int(v["flags"][k]))
+
+
+def test_experiment_knobs_are_ignored_without_the_switch():
+    """csrc/knobs.hpp: the library's experiment variables select an engine only together with DEMI_EXPERIMENT=1.  Checked on a
+    knob whose effect is visible without a GPU: DEMI_JIT_IFCONVERT changes the generated handler source."""
+    import subprocess
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from demi_amd import _native, model as M\n"
+            "print(hash(_native.specialize_source(M.raft_model(5).to_struct())))\n") % ROOT
+    def run(**env):
+        e = {k: v for k, v in os.environ.items() if k not in ("DEMI_EXPERIMENT", "DEMI_JIT_IFCONVERT")}
+        e.update(env, PYTHONHASHSEED="0", DEMI_NO_TORCH="1")
+        return subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, check=True).stdout.strip()
+    plain = run()
+    assert run(DEMI_JIT_IFCONVERT="3") == plain                                # a stray knob: ignored
+    assert run(DEMI_JIT_IFCONVERT="3", DEMI_EXPERIMENT="1") != plain           # with the switch: it acts
+    assert run(DEMI_EXPERIMENT="1") == plain
+
+
+def test_abi_generation_is_checked():
+    from demi_amd import _native
+    L = _native.lib()
+    assert L.demi_abi_version() == T.ABI_VERSION
+    hdr = open(os.path.join(ROOT, "include", "demi_gpu.h")).read()
+    assert "#define DEMI_ABI_VERSION %du" % T.ABI_VERSION in hdr

@@ -546,7 +546,7 @@ def test_no_specialised_kernel_touches_scratch_memory(tmp_path, wide):
         pytest.skip("no hiprtc in this environment")
     assert "SIZE" in out.stdout, out.stdout + out.stderr
     seen = 0
-    for k in range(12):            # (demi_gpu.hip JK_COUNT: a wide table gets every variant of K1 compiled)
+    for k in range(13):            # (demi_gpu.hip JK_COUNT: a wide table gets every variant of K1 compiled)
         path = str(tmp_path / "img") + ".%d" % k
         if not os.path.exists(path):
             continue

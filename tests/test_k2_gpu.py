@@ -362,7 +362,7 @@ def test_fuzz_then_the_gamut_end_to_end():
     assert out["ddmin_replays"] > 0 and out["intmin_replays"] > 0
 
 
-@pytest.mark.parametrize("k2_mode", ["auto", "hbm", "scan"])
+@pytest.mark.parametrize("k2_mode", ["auto", "wave", "lds", "hbm", "scan"])
 def test_filter_known_absents_parity(gpu_ctx, oracle, k2_mode, monkeypatch):
     """SchedulerConfig.filterKnownAbsents (EventTrace.filterKnownAbsentInternals as the last stage of the projection),
     as the reference computes it and corrected: verdicts, removal candidates and executed-trace marks against the
@@ -370,8 +370,8 @@ def test_filter_known_absents_parity(gpu_ctx, oracle, k2_mode, monkeypatch):
     from demi_amd.internal_minimization import deliveries
     if k2_mode == "scan":
         monkeypatch.setenv("DEMI_K2_SCAN", "1")
-    elif k2_mode == "hbm":
-        monkeypatch.setenv("DEMI_K2_MODE", "hbm")
+    elif k2_mode != "auto":
+        monkeypatch.setenv("DEMI_K2_MODE", k2_mode)          # (one candidate per wave with the look-ahead / [word][lane] counters in LDS / in HBM)
     model = M.raft_model(5, election_budget=2)
     w = FuzzerWeights(kill=0.12, send=0.35, wait_quiescence=0.13, partition=0.25, unpartition=0.15)
     rng = np.random.default_rng(5)

@@ -1,4 +1,5 @@
 #!/bin/bash
+export DEMI_EXPERIMENT=1     # the library reads its experiment / diagnostic variables only with this set (csrc/knobs.hpp)
 # tools/isa_diff.sh [<git rev>]  - which gfx950 kernels does the working tree compile to different instructions than <rev> (HEAD)?
 # No GPU needed.  The generic kernels of libdemi_gpu.so are compared symbol by symbol (device-only compilation of demi_gpu.hip,
 # disassembled), the kernels specialised for raft5 by the .text of their code objects (demi_specialize_check under

@@ -45,7 +45,7 @@ def main():
     code = ("import sys; sys.path.insert(0, %r)\nfrom demi_amd import _native, model as M\n"
             "m = M.raft_model(5, log_cap=%d) if %d else M.raft_model(5, term0=1000, loglen0=300) if %r else M.raft_model(5)\n"
             "print(_native.specialize_check(m.to_struct())[0])\n" % (ROOT, args.log_cap, args.log_cap, args.wide))
-    env = dict(os.environ, DEMI_JIT_DUMP=os.path.join(d, "img"))
+    env = dict(os.environ, DEMI_EXPERIMENT="1", DEMI_JIT_DUMP=os.path.join(d, "img"))
     if args.flags:
         env["DEMI_JIT_FLAGS"] = args.flags
     if args.system:

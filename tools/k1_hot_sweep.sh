@@ -1,4 +1,5 @@
 #!/bin/bash
+export DEMI_EXPERIMENT=1     # the library reads its experiment / diagnostic variables only with this set (csrc/knobs.hpp)
 # Experiment: resident workgroups per CU x LDS-resident slots of the specialised K1 (bench line per setting)
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}

@@ -1,4 +1,5 @@
 #!/bin/bash
+export DEMI_EXPERIMENT=1     # the library reads its experiment / diagnostic variables only with this set (csrc/knobs.hpp)
 # Diagnostic: build a -DDEMI_K1_PHASES copy of the library, run the bench workload once with the specialised
 # kernel and once with the table interpreter, print the per-phase cycle split of K1 (s_memtime deltas summed
 # over waves).  Does not touch the product .so.

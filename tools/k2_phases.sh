@@ -1,4 +1,5 @@
 #!/bin/bash
+export DEMI_EXPERIMENT=1     # the library reads its experiment / diagnostic variables only with this set (csrc/knobs.hpp)
 # per-phase s_memtime split of k2_replay's lock-step loop on the native DDMin of config 4 (diagnostic build; proportions only)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R

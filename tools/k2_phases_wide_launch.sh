@@ -1,4 +1,5 @@
 #!/bin/bash
+export DEMI_EXPERIMENT=1     # the library reads its experiment / diagnostic variables only with this set (csrc/knobs.hpp)
 # the same phase split for a THROUGHPUT launch of K2: 2^20 random candidate masks of config 4's execution, 64 per wave
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R

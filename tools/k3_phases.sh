@@ -1,4 +1,5 @@
 #!/bin/bash
+export DEMI_EXPERIMENT=1     # the library reads its experiment / diagnostic variables only with this set (csrc/knobs.hpp)
 # per-phase s_memtime split of k3_dpor (diagnostic build of the compiled kernel; the marks cost time: proportions only)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R

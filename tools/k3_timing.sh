@@ -1,4 +1,5 @@
 #!/bin/bash
+export DEMI_EXPERIMENT=1     # the library reads its experiment / diagnostic variables only with this set (csrc/knobs.hpp)
 # Where the native DPOR loop's wall time goes (BASELINE config 3), for two round sizes
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R

@@ -1,4 +1,5 @@
 #!/bin/bash
+export DEMI_EXPERIMENT=1     # the library reads its experiment / diagnostic variables only with this set (csrc/knobs.hpp)
 # One rocprofv3 --pmc pass over the headline bench; prints the per-dispatch averages of the K1 kernel.
 #   bash tools/pmc_pass.sh <tag> COUNTER [COUNTER ...]         (env is passed through: DEMI_JIT_DEFINES etc.)
 export TMPDIR=/tmp

@@ -1,4 +1,5 @@
 #!/bin/bash
+export DEMI_EXPERIMENT=1     # the library reads its experiment / diagnostic variables only with this set (csrc/knobs.hpp)
 # round-2 K1 experiment: does a scratch working set that fits the L2 (fewer resident workgroups, some slots in LDS) pay?
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R

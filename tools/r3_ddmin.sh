@@ -1,4 +1,5 @@
 #!/bin/bash
+export DEMI_EXPERIMENT=1     # the library reads its experiment / diagnostic variables only with this set (csrc/knobs.hpp)
 # native DDMin (demi_ddmin): parity on the GPU, then the ddmin record
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R

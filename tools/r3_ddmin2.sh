@@ -1,4 +1,5 @@
 #!/bin/bash
+export DEMI_EXPERIMENT=1     # the library reads its experiment / diagnostic variables only with this set (csrc/knobs.hpp)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 timeout 900 python -m pytest tests/test_k2_gpu.py tests/test_wide_gpu.py -x -q --timeout 600 2>&1 | grep -E "passed|failed|rror" | tail -5

@@ -1,4 +1,5 @@
 #!/bin/bash
+export DEMI_EXPERIMENT=1     # the library reads its experiment / diagnostic variables only with this set (csrc/knobs.hpp)
 # Round 3, K1 A/B in one call: parity of the current build (K1 suites), then the bench line's kernel_ms for each prebuilt
 # variant under variants/*.so (base = round 2's kernel), the current build with the effect schedule switched off, the
 # current build compiled by /opt/rocm's LLVM 22, and the phase split.  Writes gpurun_out/r3_ab_*.

@@ -1,4 +1,5 @@
 #!/bin/bash
+export DEMI_EXPERIMENT=1     # the library reads its experiment / diagnostic variables only with this set (csrc/knobs.hpp)
 # Round 3, second K1 A/B: prebuilt variants (variants/*.so), then the current build under JIT defines (last-word register,
 # service iterations), each with the bit-for-bit check of 2^18 schedules against the oracle; phases of two of them.
 R=${GRAFT_REPO_ROOT:-/root/repo}

@@ -1,4 +1,5 @@
 #!/bin/bash
+export DEMI_EXPERIMENT=1     # the library reads its experiment / diagnostic variables only with this set (csrc/knobs.hpp)
 # Round 3: with the effect queue cut to the SEND slots there is LDS for a window of pending slots at full occupancy: sweep
 # the window (DEMI_JIT_K1_HOT) against the resident workgroups per CU.  Parity of the mixed LDS / HBM paths first.
 R=${GRAFT_REPO_ROOT:-/root/repo}

@@ -1,4 +1,5 @@
 #!/bin/bash
+export DEMI_EXPERIMENT=1     # the library reads its experiment / diagnostic variables only with this set (csrc/knobs.hpp)
 # Round 3: where the specialised K1 stands after the effect schedule: counters (issue vs wait), and whether the scratch
 # working set is now what bounds it (fewer resident workgroups, LDS-resident pending slots).
 R=${GRAFT_REPO_ROOT:-/root/repo}

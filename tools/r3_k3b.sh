@@ -1,4 +1,5 @@
 #!/bin/bash
+export DEMI_EXPERIMENT=1     # the library reads its experiment / diagnostic variables only with this set (csrc/knobs.hpp)
 # K3 after the pair-table pre-checks and the commit's record fetch: tests, then the dpor record per fetch width; K1 at 6 / 7 WG per CU
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R

@@ -1,4 +1,5 @@
 #!/bin/bash
+export DEMI_EXPERIMENT=1     # the library reads its experiment / diagnostic variables only with this set (csrc/knobs.hpp)
 # where k3_dpor's time goes: lanes per wave, and the interleavings without the pair analysis (ROUNDS order, config 3)
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R

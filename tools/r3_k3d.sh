@@ -1,4 +1,5 @@
 #!/bin/bash
+export DEMI_EXPERIMENT=1     # the library reads its experiment / diagnostic variables only with this set (csrc/knobs.hpp)
 # k3_dpor residency: LDS-resident pending slots x waves per workgroup (ROUNDS order, config 3); parity first
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R

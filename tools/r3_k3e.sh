@@ -1,4 +1,5 @@
 #!/bin/bash
+export DEMI_EXPERIMENT=1     # the library reads its experiment / diagnostic variables only with this set (csrc/knobs.hpp)
 # after the racing-pair rewrite: parity, then the dpor record in both orders, the phase split, residency variants
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
