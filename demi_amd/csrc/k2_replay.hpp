@@ -214,6 +214,11 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
   auto fk_alive = [&](uint32_t who) __attribute__((always_inline)) -> bool { return who >= DEMI_MAX_ACTORS || (((exists & ~net.inaccessible) >> who) & 1u); };
   uint64_t tq = 0;
   uint32_t n_tq = 0;
+  // K2_FP_WAVE: the look-ahead window (lane i: expected event win_base + i): class 0 network event / 1 actor's MsgSend (filter
+  // lowering) / 2 external MsgSend / 3 MsgEvent / 4 none; the candidate-static test; the word id (class 0: the cursor-head word
+  // it must meet); a | b << 8 | slot << 16
+  uint32_t win_base = 0xFFFFFF00u, w_kind = 4u, w_fp = 0, w_ab = 0;
+  bool w_static = false;
   uint64_t b_next = 0, b_end = 0;
   bool exhausted = false;
 
@@ -302,6 +307,7 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
         // the wave's one candidate (lane 0's): its counters zeroed by all lanes, its mask known to all of them
         for (uint32_t f = lane; f < args.n_fp; f += 64) cnt[f] = 0;
         m0 = bcast64(m0); m1 = bcast64(m1); m2 = bcast64(m2); m3 = bcast64(m3);
+        win_base = 0xFFFFFF00u;                 // (no window yet: its static part depends on the candidate's mask)
         __builtin_amdgcn_wave_barrier();       // (the zeroed counters before lane 0's first increment: LDS operations of a wave complete in order)
       }
       K2_MARK(0);
@@ -316,65 +322,76 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
 #endif
         if (__ballot(active) == 0) break;
         if (WAVE) {
-          // ---- cooperative look-ahead: lane i looks at expected event pos + i under the candidate's CURRENT state (lane 0's,
-          // broadcast).  An event ACTS when the step below would change the state for it: a network event that equals the
-          // cursor head, a kept external MsgSend, an actor's MsgSend of the filter's lowering, a MsgEvent whose message is
-          // pending.  A MsgEvent that is part of the projected trace but whose message is not pending (or whose receiver is
-          // blocked) is IGNORED (:528-529): it only counts.  Nothing before the first acting event changes anything the tests
-          // read, so the tests of all 64 lanes are the ones the sequential walk would have made.
-          const uint32_t pos = idx - 1, j = pos + lane;
-          const uint32_t cur0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur), skip0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)skip);
-          const uint32_t blocked0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)blocked);
-          // (the filter's state is broadcast here, where control flow is wave-uniform: FK is a kernel argument)
-          uint32_t inacc0 = 0;
-          uint64_t partn0 = 0, part0 = 0, pr0 = 0, pr1 = 0;
-          if (FK) {
-            inacc0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)net.inaccessible);
-            partn0 = bcast64(net.partitioned); part0 = bcast64(fk_part); pr0 = bcast64(fk_pruned0); pr1 = bcast64(fk_pruned1);
-          }
-          bool acts = false, ign = false;
-          if (j < NX) {
-            const uint64_t e_ = expected[j];
-            const uint32_t kind_ = (uint32_t)e_ & 0xFF, a_ = (uint32_t)(e_ >> 8) & 0xFF, b_ = (uint32_t)(e_ >> 16) & 0xFF;
-            const uint32_t ext_ = (uint32_t)(e_ >> 48) & 0xFF;
-            if (kind_ <= DEMI_REC_UNPARTITION) {
-              if (cur0 < NE) {
-                const uint64_t x = t.trace[cur0];
-                const uint32_t xk = (uint32_t)x & 0xFF, xa = (uint32_t)(x >> 8) & 0xFF, xb = (uint32_t)(x >> 16) & 0xFF;
+          // ---- cooperative look-ahead over a WINDOW of 64 expected events (lane i holds event win_base + i).  What does not
+          // depend on the replay's state is decoded once per window: the event's class, whether the candidate's mask / removed
+          // delivery keeps it in the projected trace, the word id of its message.  What does depend on it - is the message
+          // pending, is the receiver blocked, does a network event equal the cursor head - is re-evaluated after every event that
+          // acted: one counter read and a handful of instructions per lane.  An event ACTS when the step below would change the
+          // state for it; a MsgEvent of the projected trace whose message is not pending (or whose receiver is blocked) is
+          // IGNORED (:528-529): it only counts.  Nothing before the first acting event changes anything the tests read, so all
+          // 64 tests are the ones the sequential walk would have made.
+          const uint32_t pos = idx - 1;
+          if (pos >= win_base + 64u || pos < win_base) {
+            win_base = pos;
+            const uint32_t j = win_base + lane;
+            const uint32_t skip0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)skip);
+            w_kind = 4u; w_static = false; w_fp = 0; w_ab = 0;
+            if (j < NX) {
+              const uint64_t e_ = expected[j];
+              const uint32_t kind_ = (uint32_t)e_ & 0xFF, a_ = (uint32_t)(e_ >> 8) & 0xFF, b_ = (uint32_t)(e_ >> 16) & 0xFF;
+              const uint32_t ext_ = (uint32_t)(e_ >> 48) & 0xFF;
+              w_ab = a_ | (b_ << 8) | ((uint32_t)(e_ >> 56) << 16);
+              if (kind_ <= DEMI_REC_UNPARTITION) {
+                // (the external-event kind this record must meet at the cursor head, with its actors: compared as one word)
                 const uint32_t want_kind = (kind_ == DEMI_REC_SPAWN) ? DEMI_EV_START : (kind_ == DEMI_REC_KILL) ? DEMI_EV_KILL
                                          : (kind_ == DEMI_REC_PARTITION) ? DEMI_EV_PARTITION : DEMI_EV_UNPARTITION;
-                acts = xk == want_kind && xa == a_ && (kind_ < DEMI_REC_PARTITION || xb == b_);
-              }
-            } else if (kind_ == DEMI_REC_MSG_SEND && ext_ == 255) {
-              acts = FK != 0;
-            } else if (kind_ == DEMI_REC_MSG_SEND) {
-              acts = IN_MASK(ext_) && ((exists >> b_) & 1);
-            } else {
-              bool in_trace = j != skip0 && (ext_ == 255 || IN_MASK(ext_));
-              if (FK && in_trace) {
-                const uint32_t slot = (uint32_t)(e_ >> 56);
-                const bool sent = slot == 255u || !(((slot & 64u) ? pr1 : pr0) >> (slot & 63u) & 1ull);
-                const bool alive = b_ >= DEMI_MAX_ACTORS || (((exists & ~inacc0) >> b_) & 1u);
-                bool cut = false;
-                if (a_ < DEMI_MAX_ACTORS && b_ < DEMI_MAX_ACTORS)
-                  cut = FK == DEMI_FILTER_ABSENTS_LITERAL ? ((part0 >> (a_ * 8 + b_)) & 1ull)
-                                                          : (((partn0 >> (a_ * 8 + b_)) | (partn0 >> (b_ * 8 + a_))) & 1ull);
-                in_trace = alive && !cut && sent;
-              }
-              if (in_trace) {
-                if ((blocked0 >> b_) & 1u) ign = true;
-                else if (cnt[exp_fp[j]] == 0) ign = true;
-                else acts = true;
+                w_kind = 0u; w_fp = want_kind | (a_ << 8) | ((kind_ >= DEMI_REC_PARTITION ? b_ : 0u) << 16);
+              } else if (kind_ == DEMI_REC_MSG_SEND && ext_ == 255) {
+                w_kind = 1u;
+              } else if (kind_ == DEMI_REC_MSG_SEND) {
+                w_kind = 2u; w_static = IN_MASK(ext_) && ((exists >> b_) & 1);
+              } else {
+                w_kind = 3u; w_static = j != skip0 && (ext_ == 255 || IN_MASK(ext_)); w_fp = (uint32_t)exp_fp[j];
               }
             }
           }
-          const uint64_t acting = __ballot(acts);
-          const uint32_t first = acting ? (uint32_t)__builtin_ctzll(acting) : 64u;
-          const uint64_t before = first >= 64u ? ~0ull : ((1ull << first) - 1ull);
-          const uint64_t ignoring = __ballot(ign);
-          if (lane == 0 && active) ignored += (uint32_t)__popcll(ignoring & before);
-          if (first == 64u) { idx += 63; continue; }      // (none of the next 64 events acts; the loop's idx++ completes the jump)
-          idx += first;
+          const uint32_t cur0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur);
+          const uint32_t blocked0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)blocked);
+          // (the cursor head as the word a network event of the window carries: kind | a << 8 | b << 16, b only for partitions)
+          uint32_t head = 0xFFFFFFFFu;
+          if (cur0 < NE) {
+            const uint64_t x = t.trace[cur0];
+            const uint32_t xk = (uint32_t)x & 0xFF;
+            head = xk | (((uint32_t)(x >> 8) & 0xFF) << 8) | ((xk >= DEMI_EV_PARTITION ? (uint32_t)(x >> 16) & 0xFF : 0u) << 16);
+          }
+          bool in_trace = w_static;
+          if (FK) {       // (the filter's state, broadcast where control flow is wave-uniform: FK is a kernel argument)
+            const uint32_t inacc0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)net.inaccessible);
+            const uint64_t partn0 = bcast64(net.partitioned), part0 = bcast64(fk_part), pr0 = bcast64(fk_pruned0), pr1 = bcast64(fk_pruned1);
+            const uint32_t a_ = w_ab & 0xFF, b_ = (w_ab >> 8) & 0xFF, slot = w_ab >> 16;
+            const bool sent = slot == 255u || !(((slot & 64u) ? pr1 : pr0) >> (slot & 63u) & 1ull);
+            const bool alive = b_ >= DEMI_MAX_ACTORS || (((exists & ~inacc0) >> b_) & 1u);
+            bool cut = false;
+            if (a_ < DEMI_MAX_ACTORS && b_ < DEMI_MAX_ACTORS)
+              cut = FK == DEMI_FILTER_ABSENTS_LITERAL ? ((part0 >> (a_ * 8 + b_)) & 1ull)
+                                                      : (((partn0 >> (a_ * 8 + b_)) | (partn0 >> (b_ * 8 + a_))) & 1ull);
+            in_trace = in_trace && alive && !cut && sent;
+          }
+          const bool is_ev = w_kind == 3u;
+          const bool pending = is_ev && in_trace && !((blocked0 >> ((w_ab >> 8) & 0xFF)) & 1u) && cnt[is_ev ? w_fp : 0u] != 0;
+          const bool acts = (w_kind == 0u && w_fp == head) || (w_kind == 1u && FK != 0) || (w_kind == 2u && w_static) || pending;
+          const bool ign = is_ev && in_trace && !pending;
+          const uint32_t off = pos - win_base;                       // the window's events before `pos` are behind the walk
+          const uint64_t ahead = ~0ull << off;
+          const uint64_t acting = __ballot(acts) & ahead, ignoring = __ballot(ign) & ahead;
+          if (acting == 0) {                                         // nothing in the rest of the window acts
+            if (lane == 0 && active) ignored += (uint32_t)__popcll(ignoring);
+            idx = win_base + 64u;                                    // (the loop's idx++ makes the next position win_base + 64)
+            continue;
+          }
+          const uint32_t first = (uint32_t)__builtin_ctzll(acting);
+          if (lane == 0 && active) ignored += (uint32_t)__popcll(ignoring & ((1ull << first) - 1ull));
+          idx = win_base + first + 1u;
         }
         const uint64_t ev = WAVE ? expected[idx - 1] : ev_next;
         const uint32_t fp_cur = WAVE ? (uint32_t)exp_fp[idx - 1] : fp_next;

@@ -355,9 +355,24 @@ class DPORwHeuristics:
         if self.stopIfViolationFound and self.shortestTraceSoFar is not None:
             return self.shortestTraceSoFar
         if self.native:
+            # The reference's test() explores until the queue is empty, its head reaches the distance cap, or a violation is
+            # found - never "until a budget".  One native call explores at most native_budget interleavings; a call that stopped
+            # BECAUSE of the budget (it used all of it, found nothing, points are still queued) is therefore continued from the
+            # queue the library kept (resume, the ordered search) - or refused, where the library keeps no queue between calls:
+            # "budget ran out" must never read as "the subsequence does not reproduce the violation".
             res = self.explore_native(events, violation_fingerprint, max_interleavings=self.native_budget)
+            total = len(res.interleavings)
+            while not res.violations and total and len(res.interleavings) >= self.native_budget and \
+                    int(self.last_native_stats.queue_len) > 0 and not bool(self.last_native_stats.exhausted):
+                ordered = isinstance(self.backtrackHeuristic, ArvindDistanceOrdering) or self.should_cap_distance or self._initialTrace is not None
+                if not (ordered and self.startFromBackTrackPoints):
+                    raise RuntimeError("DPORwHeuristics.test(native=True): %d interleavings explored, no violation, %d backtrack points "
+                                       "still queued - raise native_budget (the search is not resumable without an ordering, a "
+                                       "distance cap or an initial trace)" % (total, int(self.last_native_stats.queue_len)))
+                res = self.explore_native(events, violation_fingerprint, max_interleavings=self.native_budget)
+                total += len(res.interleavings)
             if _stats is not None:
-                _stats.increment_replays(len(res.interleavings))
+                _stats.increment_replays(total)
         else:
             res = self.explore(events, violation_fingerprint, stats=_stats)
         return res.interleavings[res.violations[0]].trace if res.violations else None

@@ -120,16 +120,26 @@ class GpuRandomScheduler(val schedulerConfig: SchedulerConfig, max_executions: I
     if (stats != null) (1 to max_executions).foreach(_ => stats.increment_replays())
     val OVF = V_PENDING_OVF | V_QUEUE_OVF
     var start = 0L
+    // Carried generator: the executions of the instance are ONE chain.  An execution aborted on a capacity leaves the generator
+    // where the reference's instance never is, so every verdict behind it is meaningless (the kernel runs the chain on; the
+    // Python mirror raises CapacityExceeded): the whole chain - exploration AND the recording re-run - is then repeated with the
+    // largest pending set, and if an execution still does not fit the JVM scheduler has to decide the instance.
+    var chainPMax = pMax
     while (start < max_executions) {
       val out = new Array[Long](2 * 65536); val counts = new Array[Long](2)
-      check(h, randomExploreFlagged(h, seed + start, max_executions - start, limits(lookingFor), V_VIOLATION | OVF, out, counts))
+      check(h, randomExploreFlagged(h, seed + start, max_executions - start, limits(lookingFor, chainPMax), V_VIOLATION | OVF, out, counts))
       if (counts(0) == 0) return None
       // (index, flags) in index order; a truncated list is an arbitrary subset: then only the lowest index is certain
-      val cand = if (counts(0) <= 65536) (0 until counts(0).toInt).map(i => (out(2 * i), ((out(2 * i + 1) >>> 32) & 0xFF).toInt))
-                 else Seq((counts(1), -1))
-      var next = max_executions.toLong
+      val cand0 = if (counts(0) <= 65536) (0 until counts(0).toInt).map(i => (out(2 * i), ((out(2 * i + 1) >>> 32) & 0xFF).toInt))
+                  else Seq((counts(1), -1))
+      // (carried: only what precedes the chain's first violating execution was run at all; an OVF there poisons the rest)
+      val chainOvf = carriedGenerator && cand0.exists { case (_, fl) => fl < 0 || (fl & OVF) != 0 }
+      if (chainOvf && chainPMax == MAX_PENDING)
+        throw new UnsupportedOnGpu("an execution of the carried-generator instance exceeds the engine's capacities")
+      val cand = if (chainOvf) { chainPMax = MAX_PENDING; Seq.empty[(Long, Int)] } else cand0
+      var next = if (chainOvf) 0L else max_executions.toLong          // (0: the same chain again, with the largest pending set)
       for ((idx, fl) <- cand) {
-        var lim = limits(lookingFor)
+        var lim = limits(lookingFor, chainPMax)
         if (fl < 0 || (fl & OVF) != 0) lim = limits(lookingFor, MAX_PENDING)
         val v = new Array[Long](2); val rec = new Array[Byte](FlatEvents.REC_BYTES * 16384)
         // (carried generator: `idx` is the execution number within the one instance; the recording kernel re-runs the chain)
@@ -145,7 +155,7 @@ class GpuRandomScheduler(val schedulerConfig: SchedulerConfig, max_executions: I
         }
         if (fl < 0) next = start + idx + 1
       }
-      if (counts(0) <= 65536) return None
+      if (counts(0) <= 65536 && !chainOvf) return None
       start = next
     }
     None
@@ -216,18 +226,29 @@ class GpuSTSScheduler(val schedulerConfig: SchedulerConfig, original_trace: Even
 
   /** RunnerUtils.stsSchedDDMin (:642-707) in ONE native call (demi_ddmin): DDMin.minimize / ddmin2 over the loaded execution's
    *  external events with this scheduler as the oracle - the atoms, the splits, the speculative frontiers and their launches all
-   *  inside the library.  Returns (the MCS as a subsequence of the original externals, the verified trace if the MCS reproduces
-   *  the violation); the consultations are added to `stats` as DDMin would.  maxCandidates = 0 leaves the launch width to the
-   *  library.  Same MCS as `new DDMin(this).minimize(...)` (the same decision tree, consulted through cached verdicts). */
+   *  inside the library.  Returns (the MCS as a subsequence of the original externals, the trace as stsSchedDDMin returns it);
+   *  the consultations are added to `stats` as DDMin would.  maxCandidates = 0 leaves the launch width to the library.  Same MCS
+   *  as `new DDMin(this).minimize(...)` (the same decision tree, consulted through cached verdicts).
+   *  conjoined: UnmodifiedEventDag.conjoinAtoms as one partner index per external event (-1 / 255 = none), or None.
+   *  As in the reference (:689-706): an MCS shorter than the externals is verified - Some(executed trace) if it reproduces the
+   *  violation, None otherwise - and an MCS that removed nothing returns Some(original trace) without a verification.
+   *  Where this differs from the reference's loop, by construction: the preTest / postTest callbacks stsSchedDDMin installs run
+   *  ONCE around the whole native search, not around each of its consultations (those happen inside one library call; a
+   *  callback that must see every replay needs `new DDMin(this)` over test()). */
   def ddmin(fp: ViolationFingerprint, stats: MinimizationStats, checkUnmodified: Boolean = true,
-            maxCandidates: Int = 0): (Seq[ExternalEvent], Option[EventTrace]) = {
+            maxCandidates: Int = 0, conjoined: Option[Array[Byte]] = None): (Seq[ExternalEvent], Option[EventTrace]) = {
     requireInvariant()
     val mcs = new Array[Long](4); val st = new Array[Long](5)
-    check(h, DemiGpu.ddmin(h, limits(fp), Array(0, maxCandidates, if (checkUnmodified) 1 else 0, 1), null, mcs, null, null, st))
-    if (stats != null) (0L until st(0)).foreach(_ => stats.increment_replays())
     val ext = original_trace.original_externals
+    conjoined.foreach(c => require(c.length >= ext.size, "one conjoined-partner index per external event"))
+    preTest.foreach(_())
+    try check(h, DemiGpu.ddmin(h, limits(fp), Array(0, maxCandidates, if (checkUnmodified) 1 else 0, 1), conjoined.orNull, mcs, null, null, st))
+    finally postTest.foreach(_())
+    if (stats != null) (0L until st(0)).foreach(_ => stats.increment_replays())
     val kept = ext.indices.filter(i => ((mcs(i >> 6) >>> (i & 63)) & 1L) != 0).map(ext)
-    (kept, if (st(3) != 0) Some(executed(kept, fp)) else None)
+    val externalsSize = ext.count { case WaitQuiescence() => false; case WaitCondition(_) => false; case _ => true }
+    if (kept.length < externalsSize) (kept, if (st(3) != 0) Some(executed(kept, fp)) else None)
+    else (kept, Some(original_trace))
   }
 
   /** the EventTrace test() returns on success (:286-292): the recorded events that took effect in the replay */

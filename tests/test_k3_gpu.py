@@ -224,6 +224,42 @@ def test_native_arvind_ordering_and_distance_cap_on_the_gpu(oracle):
     assert seen > 300
 
 
+def test_native_test_continues_past_its_budget_instead_of_reporting_no_violation(oracle):
+    """TestOracle.test of the native DPORwHeuristics: one library call explores at most native_budget interleavings; a call that
+    stopped BECAUSE of the budget is continued from the queue the library kept (an ordered, resumable search) until that queue
+    is empty - as one call with a sufficient budget ends (the two explore slightly different sets: a resumed call starts with
+    one dequeued point, so the rounds are cut differently, and the explored-pair heuristic depends on the order of absorption) -
+    and refused where nothing can be resumed (never read as "the subsequence does not reproduce")."""
+    from demi_amd.dpor import ArvindDistanceOrdering
+    from demi_amd.incremental_ddmin import dpor_initial_trace
+    from demi_amd.schedulers import MinimizationStats, ViolationFingerprint
+    from .test_incremental_ddmin_cpu import _execution
+    model = M.raft_model(3)
+    ev = events_to_array([start(a) for a in range(3)] + [send(a, M.M_BOOTSTRAP) for a in range(3)])
+    _, trace = _execution(oracle, model, ev, want_violation=False, lim=T.Limits(60, 0, 64, 0, 0, 0))
+    init = dpor_initial_trace(trace)
+    nothing = ViolationFingerprint(0x7FFFFFF1)        # a fingerprint no interleaving produces: test() explores to the end
+    counts = []
+    for budget in (1 << 16, 37):
+        h = ArvindDistanceOrdering()
+        d = DPORwHeuristics(SchedulerConfig(model=model), depth_bound=30, prioritizePendingUponDivergence=True, backtrackHeuristic=h,
+                            stopIfViolationFound=True, batch=16, native=True)
+        d.setInitialTrace(init)
+        h.init(d, init)
+        d.native_budget = budget
+        st = MinimizationStats()
+        assert d.test(ev, nothing, st) is None
+        counts.append(st.total_replays)
+        assert bool(d.last_native_stats.exhausted) and int(d.last_native_stats.queue_len) == 0      # explored to the end, not to a budget
+        d.shutdown()
+    assert counts[0] > 1000 and counts[1] > 1000 and abs(counts[0] - counts[1]) < counts[0] // 5, counts
+    d = DPORwHeuristics(SchedulerConfig(model=model), depth_bound=30, stopIfViolationFound=True, batch=16, native=True)
+    d.native_budget = 37
+    with pytest.raises(RuntimeError, match="native_budget"):
+        d.test(ev, nothing, MinimizationStats())
+    d.shutdown()
+
+
 def test_dpor_golden_fixture_on_gpu(gpu_ctx):
     import hashlib
     import os
