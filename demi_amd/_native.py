@@ -17,7 +17,7 @@ EXPORTS = ["demi_ctx_create", "demi_ctx_destroy", "demi_last_error", "demi_versi
            "demi_replay_removal_batch", "demi_replay_get_kept", "demi_replay_recorded_len", "demi_ddmin", "demi_dpor_set_traces", "demi_model_specialize", "demi_model_is_specialized", "demi_model_code_id",
            "demi_specialize_check", "demi_specialize_source", "demi_specialize_source_k1", "demi_provenance_prune", "demi_device_probe", "demi_device_probe_mix", "demi_calib_rw", "demi_random_explore_flagged", "demi_collect_flagged_dev",
            "demi_comm_unique_id", "demi_comm_create", "demi_comm_create_host", "demi_comm_destroy", "demi_comm_rank",
-           "demi_comm_allgather_dev", "demi_random_explore_sharded", "demi_replay_batch_sharded", "demi_abi_version", "demi_replay_externals_len"]
+           "demi_comm_allgather_dev", "demi_random_explore_sharded", "demi_replay_batch_sharded", "demi_abi_version", "demi_replay_externals_len", "demi_edit_distance_dpor_ddmin"]
 
 _lib = None
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)     # demi_allgather_fn
@@ -69,6 +69,10 @@ def lib():
     L.demi_ddmin.argtypes = [C.c_void_p, C.POINTER(T.Limits), C.POINTER(T.DdminParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                              C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(T.DdminStats)]
     L.demi_ddmin.restype = C.c_int
+    L.demi_edit_distance_dpor_ddmin.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(T.DporParams),
+                                                C.POINTER(T.IncDdminParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
+                                                C.c_void_p, C.POINTER(T.IncDdminStats)]
+    L.demi_edit_distance_dpor_ddmin.restype = C.c_int
     L.demi_specialize_source.argtypes = [C.POINTER(T.ModelStruct), C.c_char_p, C.c_size_t]
     L.demi_specialize_source.restype = C.c_long
     L.demi_specialize_source_k1.argtypes = [C.POINTER(T.ModelStruct), C.c_char_p, C.c_size_t]
@@ -333,6 +337,28 @@ class Context:
         init = np.ascontiguousarray(initial_trace, dtype=T.DPOR_TRACE_DTYPE) if initial_trace is not None else np.zeros(0, dtype=T.DPOR_TRACE_DTYPE)
         self._check(lib().demi_dpor_set_traces(self._h, keys.ctypes.data if len(keys) else None, len(keys),
                                                init.ctypes.data if len(init) else None, len(init)))
+
+    def edit_distance_dpor_ddmin(self, externals, initial_trace, params, ip=None, cap=4096):
+        """RunnerUtils.editDistanceDporDDMin natively (demi_edit_distance_dpor_ddmin: IncrementalDDMin over ResumableDPOR, every
+        consultation K3 launches): (mcs indices, [(subsequence indices, passes, distance cap)] in consultation order,
+        [(cap, MCS size)] per pass, the reproducing interleaving or None, stats)."""
+        import numpy as np
+        ev = np.ascontiguousarray(externals, dtype=T.EXT_EVENT_DTYPE)
+        init = np.ascontiguousarray(initial_trace, dtype=T.DPOR_TRACE_DTYPE)
+        ip = ip or T.IncDdminParams()
+        mcs = np.zeros(4, dtype=np.uint64)
+        consulted = np.zeros((cap, 4), dtype=np.uint64)
+        passed = np.zeros(cap, dtype=np.uint8)
+        dist = np.zeros(cap, dtype=np.uint32)
+        vt = np.zeros(T.DPOR_MAX_TRACE, dtype=T.DPOR_TRACE_DTYPE)
+        st = T.IncDdminStats()
+        self._check(lib().demi_edit_distance_dpor_ddmin(self._h, ev.ctypes.data if len(ev) else None, len(ev), init.ctypes.data, len(init),
+                                                        C.byref(params), C.byref(ip), mcs.ctypes.data, consulted.ctypes.data, passed.ctypes.data,
+                                                        dist.ctypes.data, cap, vt.ctypes.data, C.byref(st)))
+        n = min(cap, st.consultations)
+        return T.mask_to_events(mcs), [(T.mask_to_events(consulted[i]), bool(passed[i]), int(dist[i])) for i in range(n)], \
+            [(int(st.pass_distance[i]), int(st.pass_mcs_len[i])) for i in range(min(16, st.passes))], \
+            (vt[:st.violation_len].copy() if st.violation_len else None), st
 
     def dpor_explore(self, params, search):
         """The whole exploration natively: returns (verdicts, prefix_len, rounds, first violating trace, stats)."""

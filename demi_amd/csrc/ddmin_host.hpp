@@ -173,8 +173,11 @@ struct DdminOutcome {
 template <class TestBatch>
 class SpeculativeDdmin {
  public:
-  SpeculativeDdmin(const DdminDag& dag, TestBatch& test, uint32_t depth, uint32_t max_candidates)
-      : dag_(dag), test_(test), depth_(depth), budget_(max_candidates ? max_candidates : 4096u) {}
+  // sequential: no speculation and no verdict cache - every consultation of ddmin2 is one call of the oracle with that one
+  // candidate, as the reference's DDMin does it.  For oracles whose consultation is expensive and has a memory of its own
+  // (ResumableDPOR: a DPOR exploration per consultation, continued when the same subsequence is asked again; incddmin_host.hpp)
+  SpeculativeDdmin(const DdminDag& dag, TestBatch& test, uint32_t depth, uint32_t max_candidates, bool sequential = false)
+      : dag_(dag), test_(test), depth_(depth), budget_(max_candidates ? max_candidates : 4096u), sequential_(sequential) {}
   double oracle_s_ = 0;           // time spent inside the oracle (the launches); the rest of minimize() is this loop
 
   // DDMin.minimize (:27-46) on the events `view`, then verify_mcs (:48-51) if asked; returns a demi_status
@@ -293,7 +296,10 @@ class SpeculativeDdmin {
 
   bool passes(const Mask256& cand) {
     if (rc_) return true;
-    if (cache_.get(cand) < 0) {
+    if (sequential_) {
+      rc_ = launch(std::vector<Mask256>(1, cand));
+      if (rc_) return true;
+    } else if (cache_.get(cand) < 0) {
       std::vector<Mask256> cands;
       if (depth_) {
         seen_.clear();
@@ -348,6 +354,7 @@ class SpeculativeDdmin {
   const DdminDag& dag_;
   TestBatch& test_;
   uint32_t depth_, budget_;
+  bool sequential_ = false;
   std::vector<Mask256> atom_events_;             // the external events of atom i
   bool singletons_ = true, pending_check_ = false;
   MaskTable cache_;                              // candidate (atom numbers) -> 1 passes / 0 fails

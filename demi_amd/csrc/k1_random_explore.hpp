@@ -103,13 +103,29 @@ constexpr uint32_t K1_FXQ_SLOTS = DEMI_JIT_FXQ_SLOTS;
 #else
 constexpr uint32_t K1_FXQ_SLOTS = DEMI_FX_CAP;
 #endif
+// REBIN (round 4): the deliveries of a workgroup's 256 simulators are re-dealt over its lanes by handler class in every
+// iteration (see the kernel).  Its LDS: the scheduler state a delivery reads and writes, one 32-bit word per item and
+// simulator ([word][workgroup lane]); per class a list of the simulators that deliver a message of that class in this
+// iteration (one byte each: the lane within the workgroup); two sets of class counters and "somebody is still running" flags
+// (iterations alternate between them, so that one is cleared while the other is in use).
+constexpr uint32_t K1_RB_MAX_CLASSES = 16;
+__host__ __device__ inline uint32_t k1_rb_classes(uint32_t n_msg_types) { return n_msg_types < K1_RB_MAX_CLASSES ? n_msg_types : K1_RB_MAX_CLASSES; }
+// exchanged words per simulator: message word, packed counters, last pending word, tq, resend (2 each), just, rep
+// [+ blocked when the table can crash an actor] [+ the application's generator when it has a RND row]
+__host__ __device__ constexpr uint32_t k1_rb_words(bool wide, bool crashes, bool rnd) {
+  return (wide ? 2u : 1u) * 2u + 1u + 4u + 2u + (crashes ? 1u : 0u) + (rnd ? 2u : 0u);
+}
+__host__ __device__ inline size_t k1_rb_bytes(uint32_t rb_words, uint32_t rb_classes) {
+  return rb_words == 0 ? 0 : (size_t)rb_words * K1_WAVES * 64 * 4 + (size_t)rb_classes * K1_WAVES * 64 + (2 * K1_RB_MAX_CLASSES + 4) * 4;
+}
 template <bool REC, bool FIFO>
 __host__ __device__ inline size_t k1_lds_bytes(uint32_t code_len, uint32_t n_ev, uint32_t n_hs, uint32_t n_actors,
                                                uint32_t n_batches, uint32_t n_timer_types, uint32_t hot = K1_HOT, bool wide = WIDE_TU,
-                                               uint32_t fxq_slots = K1_FXQ_SLOTS, uint32_t arr_words = ARR_WORDS) {
+                                               uint32_t fxq_slots = K1_FXQ_SLOTS, uint32_t arr_words = ARR_WORDS,
+                                               uint32_t rb_words = 0, uint32_t rb_classes = 0) {
   return tables_lds_bytes(code_len, n_ev, n_hs, wide, arr_words) + k1_extra_lds_bytes(n_ev, n_batches, wide) +
          K1_WAVES * (lane_mem_wave_bytes(n_actors, REC, hot, wide, fxq_slots, arr_words) + (FIFO ? k1_fifo_wave_bytes(n_actors, REC, wide) : 0) +
-                     k1_tdir_wave_bytes(n_actors, n_timer_types));
+                     k1_tdir_wave_bytes(n_actors, n_timer_types)) + k1_rb_bytes(rb_words, rb_classes);
 }
 
 #ifdef DEMI_K1_MIN_WAVES_PER_EU    // experiment knob of the specialised build: ask for more waves per SIMD (fewer VGPRs)
@@ -123,8 +139,22 @@ __host__ __device__ inline size_t k1_lds_bytes(uint32_t code_len, uint32_t n_ev,
 // index = instance * epi + execution; lookingFor only applies to the first execution (:586 sets it to None); the instance
 // stops at its first violating execution (:257-261) - the verdicts behind it stay as the host zeroed them.  The executions of
 // an instance are a sequential chain on one lane; instances run in parallel like the executions of the default mode.
-template <bool REC, bool FIFO = false, bool CARRY = false>
+//
+// REBIN: the deliveries of the workgroup's 256 simulators are re-dealt over its lanes by handler class, every iteration.
+// Lanes sitting in eight different handlers with six effect bodies between them is what a wave pays for in the plain kernel
+// (19.5 of 64 lanes active per vector instruction; with 64 copies of ONE execution per wave the same kernel needs 1.57 ms
+// instead of 4.0: tools/r4_k1_ceiling.py).  The scheduling step - guards, flush, the random pick - stays with the OWNER lane
+// (it is the same code for every simulator).  Then every owner that picked a message posts it: the message word and the part
+// of its scheduler state a delivery reads or writes (pending count and last word, the two timer queues, justScheduledTimers,
+// the registered repeating timers, the flags) go to LDS, its workgroup lane goes to the list of the message's class (an LDS
+// counter per class hands out the positions).  After a barrier lane i of the workgroup takes item i of the concatenated
+// lists: it runs the handler rows and applies the effects on the OWNER's state - actor states, effect queue and timer
+// directory are LDS columns, the pending set a column of the HBM scratch, all addressable by any lane - so that the lanes of
+// a wave now run (almost) one handler.  A second barrier, and every owner takes its state back.  Which lane runs a
+// delivery changes nothing about it: verdicts are bit-identical with the plain kernel (tests run both).
+template <bool REC, bool FIFO = false, bool CARRY = false, bool REBIN = false>
 __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
+  static_assert(!REBIN || (!REC && !FIFO), "the re-binned kernel exists for the non-recording FullyRandom variant");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Tables t;
   unsigned char* extra = tables_load(t, smem, args.model, args.trace, args.n_ev, args.exists);
@@ -181,9 +211,11 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
   }
   __syncthreads();
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const LaneMem mem = lane_mem_carve(wave_base + (size_t)wave * lane_mem_wave_bytes(t.A, REC, K1_HOT, WIDE_TU, K1_FXQ_SLOTS), t.A, REC, lane, args.spill,
-                                     (size_t)blockIdx.x * blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x, K1_HOT);
-  uint64_t* const st = mem.st;
+  // (REBIN: `mem`, `st` and `tdir` are the simulator's this lane is WORKING on - its own outside the delivery part)
+  LaneMem mem = lane_mem_carve(wave_base + (size_t)wave * lane_mem_wave_bytes(t.A, REC, K1_HOT, WIDE_TU, K1_FXQ_SLOTS), t.A, REC, lane, args.spill,
+                               (size_t)blockIdx.x * blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x, K1_HOT);
+  const LaneMem own_mem = mem;
+  uint64_t* st = mem.st;
   const uint32_t PMAX = args.p_max;
   // SrcDstFIFO arrays of this lane (FIFO builds only)
   word_t* f_norm = nullptr, *f_spill = nullptr;
@@ -231,8 +263,38 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
   const uint64_t tix_packed = t.tix_packed;
 #endif
   // the timer directory of this lane (k1_tdir_words above): entry e = rcv * NTT + timer index is byte (e & 3) of word e >> 2
-  unsigned char* const tdir = wave_base + (size_t)K1_WAVES * (lane_mem_wave_bytes(t.A, REC, K1_HOT, WIDE_TU, K1_FXQ_SLOTS) + (FIFO ? k1_fifo_wave_bytes(t.A, REC) : 0)) +
-                              (size_t)wave * k1_tdir_wave_bytes(t.A, t.n_timer_types) + (size_t)lane * 4;
+  unsigned char* const tdir_base = wave_base + (size_t)K1_WAVES * (lane_mem_wave_bytes(t.A, REC, K1_HOT, WIDE_TU, K1_FXQ_SLOTS) + (FIFO ? k1_fifo_wave_bytes(t.A, REC) : 0));
+  unsigned char* tdir = tdir_base + (size_t)wave * k1_tdir_wave_bytes(t.A, t.n_timer_types) + (size_t)lane * 4;
+  unsigned char* const own_tdir = tdir;
+  // REBIN's LDS (k1_rb_bytes): exchanged words [word][workgroup lane], class lists [class][position], counters and flags
+#ifdef DEMI_JIT_NO_RND
+  constexpr bool APP_RND = false;
+#else
+  constexpr bool APP_RND = true;
+#endif
+#ifdef DEMI_JIT_NO_CRASH
+  constexpr bool RB_CRASHES = false;
+#else
+  constexpr bool RB_CRASHES = true;
+#endif
+  constexpr uint32_t RB_WG = K1_WAVES * 64, RB_WORDS = k1_rb_words(WIDE_TU, RB_CRASHES, APP_RND);
+#if defined(DEMI_JIT_NT) && !defined(DEMI_K1_RB_CLASS)
+  constexpr uint32_t RB_C = DEMI_JIT_NT < K1_RB_MAX_CLASSES ? DEMI_JIT_NT : K1_RB_MAX_CLASSES;
+#elif defined(DEMI_K1_RB_CLASS)
+  constexpr uint32_t RB_C = K1_RB_MAX_CLASSES;
+#else
+  const uint32_t RB_C = k1_rb_classes(t.NT);
+#endif
+  uint32_t* const rb_x = reinterpret_cast<uint32_t*>(tdir_base + (size_t)K1_WAVES * k1_tdir_wave_bytes(t.A, t.n_timer_types));
+  unsigned char* const rb_list = reinterpret_cast<unsigned char*>(rb_x + (size_t)RB_WORDS * RB_WG);
+  uint32_t* const rb_cnt = reinterpret_cast<uint32_t*>(rb_list + (size_t)RB_C * RB_WG);      // [2][K1_RB_MAX_CLASSES], then flag[2]
+  uint32_t* const rb_flag = rb_cnt + 2 * K1_RB_MAX_CLASSES;
+  uint32_t rb_it = 0;                 // parity of the iteration (workgroup-uniform)
+  bool wave_live = true;              // some lane of this wave still has (or may get) an execution
+  if (REBIN) {
+    if (threadIdx.x < 2 * K1_RB_MAX_CLASSES + 2) rb_cnt[threadIdx.x] = 0;
+    __syncthreads();
+  }
   auto td_ptr = [&](uint32_t e) -> unsigned char* { return tdir + ((e >> 2) << 8) + (e & 3u); };
   // (two bits per message type: one 32-bit shift when the table has at most 16 message types, which a specialised build knows)
 #ifdef DEMI_JIT_NT
@@ -488,7 +550,8 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
           else b_next += want;
           if (b_next >= n_units) exhausted = true;
         }
-        if (__ballot(ph != PH_IDLE) == 0) break;           // nothing running and nothing left to claim
+        if (!REBIN) { if (__ballot(ph != PH_IDLE) == 0) break; }          // nothing running and nothing left to claim
+        else wave_live = __ballot(ph != PH_IDLE) != 0;     // (REBIN: its lanes keep working for the other waves until all are done)
       }
       PH_MARK(0);
 
@@ -783,12 +846,82 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
     }
 
     PH_MARK(4);
+    // ------------------------------------------------------------ REBIN: post the delivery, take somebody's
+    uint32_t rb_me = 0xFFu;           // the receiver of the message THIS lane's simulator posted (0xFF: none)
+    uint32_t rb_owner = 0, rb_hit = 0;
+    if (REBIN) {
+      const uint32_t tid = threadIdx.x;
+      uint32_t* const xo = rb_x + tid;
+      uint32_t* const cnt = rb_cnt + rb_it * K1_RB_MAX_CLASSES;
+      // every lane parks its scheduler state in its own column (the registers are about to hold another simulator's)
+      uint32_t k = 0;
+      {
+        const uint32_t me_ = w_dst(w);
+        xo[k++ * RB_WG] = (flags & 0xFu) | (n_pend << 4) | (n_tq << 12) | (n_resend << 16) | (((uint32_t)(reach >> (me_ * 8)) & 0xFFu) << 20);
+        xo[k++ * RB_WG] = (uint32_t)lastw; if (WIDE_TU) xo[k++ * RB_WG] = (uint32_t)((uint64_t)lastw >> 32);
+        xo[k++ * RB_WG] = (uint32_t)tq; xo[k++ * RB_WG] = (uint32_t)(tq >> 32);
+        xo[k++ * RB_WG] = (uint32_t)resend; xo[k++ * RB_WG] = (uint32_t)(resend >> 32);
+        xo[k++ * RB_WG] = just; xo[k++ * RB_WG] = rep;
+        if (RB_CRASHES) xo[k++ * RB_WG] = blocked;
+        if (APP_RND) { xo[k++ * RB_WG] = (uint32_t)app_rng; xo[k++ * RB_WG] = (uint32_t)(app_rng >> 32); }
+        if (deliver) {
+          xo[k++ * RB_WG] = (uint32_t)w; if (WIDE_TU) xo[k++ * RB_WG] = (uint32_t)((uint64_t)w >> 32);
+          // (any mapping is correct; the default groups by handler.  DEMI_K1_RB_CLASS(message word, low word of the receiver's
+          // state) lets an experiment build try another one)
+#ifdef DEMI_K1_RB_CLASS
+          const uint32_t cls = (uint32_t)(DEMI_K1_RB_CLASS(w, (uint32_t)st[(ST_WORDS * me_) * 64])) & (K1_RB_MAX_CLASSES - 1u);
+#else
+          const uint32_t cls = w_type(w) & (K1_RB_MAX_CLASSES - 1u);
+#endif
+          const uint32_t pos = atomicAdd(&cnt[cls < RB_C ? cls : 0u], 1u);
+          rb_list[(cls < RB_C ? cls : 0u) * RB_WG + pos] = (unsigned char)tid;
+          rb_me = me_;
+        }
+      }
+      if (lane == 0 && wave_live) rb_flag[rb_it] = 1u;
+      __syncthreads();
+      if (rb_flag[rb_it] == 0u) break;                                        // every wave is done (workgroup-uniform)
+      // (the other set of counters / the other flag: last read before the previous iteration's second barrier, next written
+      // after this iteration's)
+      if (tid < K1_RB_MAX_CLASSES) rb_cnt[(rb_it ^ 1u) * K1_RB_MAX_CLASSES + tid] = 0u;
+      if (tid == K1_RB_MAX_CLASSES) rb_flag[rb_it ^ 1u] = 0u;
+      // item `tid` of the concatenated class lists
+      uint32_t acc = 0, base = 0, csel = 0;
+      for (uint32_t c = 0; c < RB_C; c++) {
+        const uint32_t n_c = cnt[c];
+        if (tid >= acc) { csel = c; base = acc; }
+        acc += n_c;
+      }
+      deliver = tid < acc;
+      if (deliver) {
+        const uint32_t o = rb_list[csel * RB_WG + (tid - base)];
+        rb_owner = o;
+        const uint32_t ow = o >> 6, ol = o & 63u;
+        mem = lane_mem_carve(wave_base + (size_t)ow * lane_mem_wave_bytes(t.A, REC, K1_HOT, WIDE_TU, K1_FXQ_SLOTS), t.A, REC, ol, args.spill,
+                             (size_t)blockIdx.x * blockDim.x + o, (size_t)gridDim.x * blockDim.x, K1_HOT);
+        st = mem.st;
+        tdir = tdir_base + (size_t)ow * k1_tdir_wave_bytes(t.A, t.n_timer_types) + (size_t)ol * 4;
+        const uint32_t* const xi = rb_x + o;
+        uint32_t j = 0;
+        const uint32_t pk = xi[j++ * RB_WG];
+        flags = pk & 0xFu; n_pend = (pk >> 4) & 0xFFu; n_tq = (pk >> 12) & 0xFu; n_resend = (pk >> 16) & 0xFu;
+        { uint64_t lw = xi[j++ * RB_WG]; if (WIDE_TU) lw |= (uint64_t)xi[j++ * RB_WG] << 32; lastw = (word_t)lw; }
+        tq = xi[j * RB_WG] | ((uint64_t)xi[(j + 1) * RB_WG] << 32); j += 2;
+        resend = xi[j * RB_WG] | ((uint64_t)xi[(j + 1) * RB_WG] << 32); j += 2;
+        just = xi[j++ * RB_WG]; rep = xi[j++ * RB_WG];
+        if (RB_CRASHES) blocked = xi[j++ * RB_WG];
+        if (APP_RND) { app_rng = xi[j * RB_WG] | ((uint64_t)xi[(j + 1) * RB_WG] << 32); j += 2; }
+        { uint64_t mw = xi[j++ * RB_WG]; if (WIDE_TU) mw |= (uint64_t)xi[j++ * RB_WG] << 32; w = (word_t)mw; }
+        reach = (uint64_t)((pk >> 20) & 0xFFu) << (w_dst(w) * 8);              // (the receiver's row is all a delivery asks)
+      }
+    }
     // ------------------------------------------------------------ the receiver's handler rows
     uint32_t nfx = 0;
     if (deliver) nfx = DEMI_VM_RUN(t, mem, w, flags, app_rng);
     if (deliver) {      // the receiver's new state decides its bit of the invariant's hit mask
       const uint32_t me_ = w_dst(w);
-      hits = (hits & ~(1u << me_)) | (invariant_hit_at(t, st, me_, inv_kind, inv_fa, inv_va) << me_);
+      rb_hit = invariant_hit_at(t, st, me_, inv_kind, inv_fa, inv_va);
+      if (!REBIN) hits = (hits & ~(1u << me_)) | (rb_hit << me_);
     }
     PH_MARK(5);
 #ifdef DEMI_K1_PHASES
@@ -916,7 +1049,44 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
         else { apply_timer_set(op == DEMI_OP_TREP, type, TIMER_BIT(me, type)); PH_MARK(8); }
       }
 #endif
-      if (flags & DEMI_OVF_ANY) ph = PH_FINISH;
+      if (!REBIN && (flags & DEMI_OVF_ANY)) ph = PH_FINISH;
+    }
+    // ------------------------------------------------------------ REBIN: hand the state back, take one's own
+    if (REBIN) {
+      if (deliver) {
+        uint32_t* const xb = rb_x + rb_owner;
+        uint32_t k = 0;
+        xb[k++ * RB_WG] = (flags & 0xFu) | (n_pend << 4) | (n_tq << 12) | (n_resend << 16) | (rb_hit << 28);
+        xb[k++ * RB_WG] = (uint32_t)lastw; if (WIDE_TU) xb[k++ * RB_WG] = (uint32_t)((uint64_t)lastw >> 32);
+        xb[k++ * RB_WG] = (uint32_t)tq; xb[k++ * RB_WG] = (uint32_t)(tq >> 32);
+        xb[k++ * RB_WG] = (uint32_t)resend; xb[k++ * RB_WG] = (uint32_t)(resend >> 32);
+        xb[k++ * RB_WG] = just; xb[k++ * RB_WG] = rep;
+        if (RB_CRASHES) xb[k++ * RB_WG] = blocked;
+        if (APP_RND) { xb[k++ * RB_WG] = (uint32_t)app_rng; xb[k++ * RB_WG] = (uint32_t)(app_rng >> 32); }
+      }
+      __syncthreads();
+      {
+        const uint32_t* const xi = rb_x + threadIdx.x;
+        uint32_t j = 0;
+        const uint32_t pk = xi[j++ * RB_WG];
+        flags = pk & 0xFu; n_pend = (pk >> 4) & 0xFFu; n_tq = (pk >> 12) & 0xFu; n_resend = (pk >> 16) & 0xFu;
+        { uint64_t lw = xi[j++ * RB_WG]; if (WIDE_TU) lw |= (uint64_t)xi[j++ * RB_WG] << 32; lastw = (word_t)lw; }
+        tq = xi[j * RB_WG] | ((uint64_t)xi[(j + 1) * RB_WG] << 32); j += 2;
+        resend = xi[j * RB_WG] | ((uint64_t)xi[(j + 1) * RB_WG] << 32); j += 2;
+        just = xi[j++ * RB_WG]; rep = xi[j++ * RB_WG];
+        if (RB_CRASHES) blocked = xi[j++ * RB_WG];
+        if (APP_RND) { app_rng = xi[j * RB_WG] | ((uint64_t)xi[(j + 1) * RB_WG] << 32); j += 2; }
+        if (rb_me != 0xFFu) {
+          hits = (hits & ~(1u << rb_me)) | (((pk >> 28) & 1u) << rb_me);
+          if (flags & DEMI_OVF_ANY) ph = PH_FINISH;
+        }
+      }
+      mem = own_mem; st = own_mem.st; tdir = own_tdir;
+      if (batch_no != 0) {            // its batch's reach matrix again (the register held the worked-on simulator's row)
+        const uint32_t* bt = s_batch + (size_t)(batch_no - 1) * K1_BATCH_WORDS;
+        reach = (uint64_t)bt[7] | ((uint64_t)bt[8] << 32);
+      }
+      rb_it ^= 1u;
     }
 
     PH_MARK(9);

@@ -106,6 +106,7 @@ class IncrementalDDMin:
         self._stats = stats or MinimizationStats()
         self.ddmin: Optional[DDMin] = None
         self.distances: List[Tuple[int, int]] = []          # (distance, MCS size after the pass)
+        self.consulted_all: List[Tuple[Tuple[int, ...], bool, int]] = []      # every pass's consultations: (events, passes, cap)
 
     def minimize(self, dag, violation_fingerprint: ViolationFingerprint):
         currentDistance = 0
@@ -119,6 +120,7 @@ class IncrementalDDMin:
             self.ddmin = DDMin(self.oracle, checkUnmodifed=False)
             currentMCS = self.ddmin.minimize(currentMCS, violation_fingerprint)
             self._stats.total_replays += self.ddmin._stats.total_replays       # mergeStats (:33-41)
+            self.consulted_all += [(c, p, currentDistance) for c, p in self.ddmin.consulted]
             self.distances.append((currentDistance, currentMCS.length))
             currentDistance = 2 if currentDistance == 0 else currentDistance << 1
             self.oracle.setMaxDistance(currentDistance)
@@ -128,16 +130,45 @@ class IncrementalDDMin:
         return self.oracle.test(mcs.get_all_events(), _violation_fingerprint, MinimizationStats())
 
 
+class NativeIncrementalDDMin:
+    """What editDistanceDporDDMin(native_loop=True) returns in IncrementalDDMin's place: the same read-only facts."""
+
+    def __init__(self, consulted, passes, st):
+        self.consulted_all = [(tuple(c), p, d) for c, p, d in consulted]
+        self.distances = list(passes)
+        self._stats = MinimizationStats()
+        self._stats.total_replays = int(st.replays)
+        self.native_stats = st
+
+
 def editDistanceDporDDMin(schedulerConfig: SchedulerConfig, trace: EventTrace, violation: ViolationFingerprint,
                           ignoreQuiescence: bool = True, stats: Optional[MinimizationStats] = None,
                           stopAtSize: int = 6, maxMaxDistance: int = 8, batch: int = 256, backend=None, device: int = 0,
-                          native: bool = False):
+                          native: bool = False, native_loop: bool = False, specialize: bool = False):
     """RunnerUtils.editDistanceDporDDMin (RunnerUtils.scala:810-879).  `trace` is the violating execution found by
     the fuzzer (its recorded events + the externals that drove it).  Returns (mcs indices into
     trace.original_externals, stats, the DPOR trace that reproduces the violation on the MCS or None, violation).
     native: every DPOR consultation runs inside the library (demi_dpor_explore with ArvindDistanceOrdering, the distance cap,
     the initial trace and - for a subsequence consulted again at a larger distance - its resumable state)."""
     initialTrace = dpor_initial_trace(trace)
+    if native_loop:
+        # the whole of this function inside the library (demi_edit_distance_dpor_ddmin, csrc/incddmin_host.hpp): one call
+        from . import _native
+        ctx = _native.Context(device)
+        try:
+            ctx.model_load(schedulerConfig.model.to_struct())
+            if specialize or getattr(schedulerConfig.model, "compiled_only", False):
+                ctx.model_specialize()
+            par = T.DporParams(0, len(initialTrace), 1, violation.code, 64, 4096, 1)
+            ip = T.IncDdminParams(max_max_distance=maxMaxDistance, stop_at_size=stopAtSize, check_unmodified=0,
+                                  ignore_quiescence=1 if ignoreQuiescence else 0, verify_mcs=1, batch=batch)
+            mcs, consulted, passes, vtrace, st = ctx.edit_distance_dpor_ddmin(trace.original_externals, initialTrace, par, ip)
+        finally:
+            ctx.close()
+        res = NativeIncrementalDDMin(consulted, passes, st)
+        if stats is not None:
+            stats.total_replays = res._stats.total_replays
+        return mcs, res, vtrace, violation
 
     def dporConstructor() -> DPORwHeuristics:
         heuristic = ArvindDistanceOrdering()

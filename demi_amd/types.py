@@ -117,6 +117,23 @@ class DdminStats(C.Structure):
                 ("replays", C.c_uint64)]
 
 
+class IncDdminParams(C.Structure):
+    """demi_incddmin_params"""
+    _fields_ = [("max_max_distance", C.c_uint32), ("stop_at_size", C.c_uint32), ("check_unmodified", C.c_uint32),
+                ("ignore_quiescence", C.c_uint32), ("verify_mcs", C.c_uint32), ("batch", C.c_uint32), ("budget", C.c_uint32),
+                ("reserved", C.c_uint32)]
+
+    def __init__(self, max_max_distance=256, stop_at_size=1, check_unmodified=0, ignore_quiescence=1, verify_mcs=1, batch=256, budget=1 << 16):
+        super().__init__(max_max_distance, stop_at_size, check_unmodified, ignore_quiescence, verify_mcs, batch, budget, 0)
+
+
+class IncDdminStats(C.Structure):
+    """demi_incddmin_stats"""
+    _fields_ = [("replays", C.c_uint64), ("interleavings", C.c_uint64), ("consultations", C.c_uint32), ("instances", C.c_uint32),
+                ("passes", C.c_uint32), ("mcs_len", C.c_uint32), ("verified", C.c_int32), ("violation_len", C.c_uint32),
+                ("pass_distance", C.c_uint32 * 16), ("pass_mcs_len", C.c_uint32 * 16)]
+
+
 class DporParams(C.Structure):
     _fields_ = [("depth_bound", C.c_uint32), ("max_messages", C.c_uint32), ("looking_for_valid", C.c_uint32),
                 ("looking_for", C.c_uint32), ("p_max", C.c_uint32), ("max_pairs", C.c_uint32),

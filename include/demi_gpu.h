@@ -549,6 +549,51 @@ int demi_dpor_explore(demi_ctx* ctx, const demi_dpor_params* params, const demi_
                       demi_dpor_trace_entry* first_violation_trace, uint32_t* first_violation_len,
                       demi_dpor_stats* stats);
 
+/* ---------------------------------------------------------- DDMin over DPOR with a growing edit-distance bound
+ * RunnerUtils.editDistanceDporDDMin (RunnerUtils.scala:810-879) in one call: IncrementalDDMin (minification/
+ * IncrementalDeltaDebugging.scala:20-92) - DDMin with the distance cap 0, then 2, 4, ... < max_max_distance, each pass starting
+ * from the previous pass's MCS, until the MCS has at most stop_at_size events - over ResumableDPOR (:94-122): every
+ * consultation is a DPORwHeuristics exploration (K3 launches) of one subsequence of the external events with
+ * ArvindDistanceOrdering, `initial_trace` (DepTracker.getInitialTrace of the original execution: demi_dpor_trace_entry as K3 /
+ * dpor_initial_trace produce them; also ArvindDistanceOrdering's original trace) as the first interleaving and
+ * setMaxDistance(cap); the backtrack queue and explored pairs of a subsequence are kept, a later consultation of the same
+ * subsequence continues from them.  `externals`: the original execution's; only Start / Send (and WaitQuiescence with
+ * ignore_quiescence = 0) take part (convertToDPORTrace, DPORwHeuristics.scala:1279-1303).  `params` as for demi_dpor_explore
+ * (looking_for = the violation; max_messages = n_initial is what RunnerUtils sets).  Replaces what demi_dpor_load /
+ * demi_dpor_set_traces loaded.  Single rank.  Same MCS, consultations, caps and replay count as the reference's loop
+ * (tests: against the Python mirror demi_amd/incremental_ddmin.py around the CPU oracle and on the GPU).                   */
+typedef struct demi_incddmin_params {
+  uint32_t max_max_distance;    /* IncrementalDDMin.maxMaxDistance (0 = 256, the class's default; RunnerUtils passes its own) */
+  uint32_t stop_at_size;        /* stopAtSize */
+  uint32_t check_unmodified;    /* checkUnmodifed: consult the whole view first (DEMI_ERR_INVALID_ARG if it does not reproduce) */
+  uint32_t ignore_quiescence;   /* RunnerUtils' ignoreQuiescence (1 = WaitQuiescence events are not part of the minimization) */
+  uint32_t verify_mcs;          /* verify_mcs when the MCS is smaller than the view (:868-873) */
+  uint32_t batch;               /* interleavings per K3 launch (0 = 256) */
+  uint32_t budget;              /* interleavings per internal exploration call (0 = 65536); a consultation continues until the
+                                   queue is empty, its head reaches the cap, or a violation is found - never "until the budget" */
+  uint32_t reserved;
+} demi_incddmin_params;
+typedef struct demi_incddmin_stats {
+  uint64_t replays;             /* MinimizationStats.total_replays as IncrementalDDMin merges it (interleavings of the passes) */
+  uint64_t interleavings;       /* every interleaving explored, checks and verification included */
+  uint32_t consultations;       /* DDMin consultations over all passes */
+  uint32_t instances;           /* DPORwHeuristics instances (distinct subsequences consulted) */
+  uint32_t passes;              /* DDMin passes run (distance caps tried) */
+  uint32_t mcs_len;
+  int32_t verified;             /* -1: not verified (the MCS removed nothing, or verify_mcs = 0); 0 / 1: verify_mcs' answer */
+  uint32_t violation_len;       /* entries written to out_violation_trace */
+  uint32_t pass_distance[16];   /* per pass (the first 16): its cap, and the MCS size after it */
+  uint32_t pass_mcs_len[16];
+} demi_incddmin_stats;
+/* out_mcs: bit i = external event i is in the MCS.  out_consulted [cap][4] / out_passed [cap] / out_distance [cap] (may be
+ * NULL): every DDMin consultation in order - the subsequence, whether it "passes" (no violation), the cap it ran under.
+ * out_violation_trace [DEMI_DPOR_MAX_TRACE] (may be NULL): the interleaving that reproduces the violation on the MCS. */
+int demi_edit_distance_dpor_ddmin(demi_ctx* ctx, const demi_ext_event* externals, uint32_t n_ext,
+                                  const demi_dpor_trace_entry* initial_trace, uint32_t n_initial, const demi_dpor_params* params,
+                                  const demi_incddmin_params* ip, uint64_t out_mcs[4], uint64_t* out_consulted, uint8_t* out_passed,
+                                  uint32_t* out_distance, uint32_t cap, demi_dpor_trace_entry* out_violation_trace,
+                                  demi_incddmin_stats* stats);
+
 /* ---------------------------------------------------------- provenance of a violation
  * ProvenanceTracker.pruneConcurrentEvents (schedulers/Util.scala:267-376; RunnerUtils.pruneConcurrentEvents,
  * RunnerUtils.scala:149-163) for n delivery traces at once: happens-before (same-machine receive order + "sent while

@@ -282,6 +282,63 @@ JNIEXPORT jint JNICALL FN(ddmin)(JNIEnv* e, jclass c, jlong h, jintArray limits,
   return rc;
 }
 
+/* ---- RunnerUtils.editDistanceDporDDMin in one call (demi_edit_distance_dpor_ddmin).  externals: byte[8 * n]; initialTrace: byte[16 * m]
+ *      (demi_dpor_trace_entry); dporParams: int[7]; params: int[7] = max_max_distance, stop_at_size, check_unmodified, ignore_quiescence,
+ *      verify_mcs, batch, budget; mcs: long[4]; consultedOrNull: long[4 * cap] with passedOrNull: byte[cap] and distanceOrNull: int[cap];
+ *      violationTraceOrNull: byte[16 * 256]; stats: long[8 + 32] = replays, interleavings, consultations, instances, passes, mcs_len,
+ *      verified, violation_len, pass_distance[16], pass_mcs_len[16] */
+JNIEXPORT jint JNICALL FN(editDistanceDporDDMin)(JNIEnv* e, jclass c, jlong h, jbyteArray externals, jbyteArray initialTrace, jintArray dporParams,
+                                                jintArray params, jlongArray mcs, jlongArray consultedOrNull, jbyteArray passedOrNull,
+                                                jintArray distanceOrNull, jbyteArray violationTraceOrNull, jlongArray stats) {
+  demi_dpor_params par;
+  demi_incddmin_params ip;
+  demi_incddmin_stats st;
+  jint pr[7];
+  uint64_t out[4] = {0, 0, 0, 0};
+  (void)c;
+  const int64_t n_ext = LEN(externals), n_init = LEN(initialTrace);
+  if (dpor_params_of(e, dporParams, &par) || LEN(params) != 7 || LEN(mcs) != 4 || LEN(stats) != 40 || n_ext < 0 || n_ext % 8 ||
+      n_init <= 0 || n_init % (int64_t)sizeof(demi_dpor_trace_entry))
+    return DEMI_ERR_INVALID_ARG;
+  (*e)->GetIntArrayRegion(e, params, 0, 7, pr);
+  memset(&ip, 0, sizeof ip);
+  ip.max_max_distance = (uint32_t)pr[0]; ip.stop_at_size = (uint32_t)pr[1]; ip.check_unmodified = (uint32_t)pr[2];
+  ip.ignore_quiescence = (uint32_t)pr[3]; ip.verify_mcs = (uint32_t)pr[4]; ip.batch = (uint32_t)pr[5]; ip.budget = (uint32_t)pr[6];
+  uint32_t cap = 0;
+  if (consultedOrNull) {
+    if (LEN(consultedOrNull) % 4 || !passedOrNull || LEN(passedOrNull) < LEN(consultedOrNull) / 4 ||
+        (distanceOrNull && LEN(distanceOrNull) < LEN(consultedOrNull) / 4))
+      return DEMI_ERR_INVALID_ARG;
+    cap = (uint32_t)(LEN(consultedOrNull) / 4);
+  }
+  if (violationTraceOrNull && LEN(violationTraceOrNull) < (int64_t)sizeof(demi_dpor_trace_entry) * DEMI_DPOR_MAX_TRACE) return DEMI_ERR_INVALID_ARG;
+  memset(&st, 0, sizeof st);
+  void* ex = BYTES(externals);
+  void* it = BYTES(initialTrace);
+  void* co = LONGS(consultedOrNull);
+  void* pa = BYTES(passedOrNull);
+  void* di = consultedOrNull ? INTS(distanceOrNull) : NULL;
+  void* vt = BYTES(violationTraceOrNull);
+  jint rc = (LOST(externals, ex) || LOST(initialTrace, it) || LOST(consultedOrNull, co) || LOST(passedOrNull, pa) ||
+             (consultedOrNull && LOST(distanceOrNull, di)) || LOST(violationTraceOrNull, vt)) ? DEMI_ERR_INVALID_ARG
+            : demi_edit_distance_dpor_ddmin(CTX(h), (const demi_ext_event*)ex, (uint32_t)(n_ext / 8), (const demi_dpor_trace_entry*)it,
+                                            (uint32_t)(n_init / (int64_t)sizeof(demi_dpor_trace_entry)), &par, &ip, out, (uint64_t*)co,
+                                            (uint8_t*)pa, (uint32_t*)di, cap, (demi_dpor_trace_entry*)vt, &st);
+  PUT_BYTES(violationTraceOrNull, vt, 0);
+  if (consultedOrNull) PUT_INTS(distanceOrNull, di, 0);
+  PUT_BYTES(passedOrNull, pa, 0);
+  PUT_LONGS(consultedOrNull, co, 0);
+  PUT_BYTES(initialTrace, it, JNI_ABORT);
+  PUT_BYTES(externals, ex, JNI_ABORT);
+  (*e)->SetLongArrayRegion(e, mcs, 0, 4, (const jlong*)(const void*)out);
+  jlong o[40];
+  o[0] = (jlong)st.replays; o[1] = (jlong)st.interleavings; o[2] = (jlong)st.consultations; o[3] = (jlong)st.instances;
+  o[4] = (jlong)st.passes; o[5] = (jlong)st.mcs_len; o[6] = (jlong)st.verified; o[7] = (jlong)st.violation_len;
+  for (int i = 0; i < 16; i++) { o[8 + i] = (jlong)st.pass_distance[i]; o[24 + i] = (jlong)st.pass_mcs_len[i]; }
+  (*e)->SetLongArrayRegion(e, stats, 0, 40, o);
+  return rc;
+}
+
 /* ---- K3 */
 JNIEXPORT jint JNICALL FN(dporLoad)(JNIEnv* e, jclass c, jlong h, jbyteArray externals) {
   (void)c;

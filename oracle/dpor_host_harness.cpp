@@ -363,6 +363,7 @@ extern "C" int harness_dpor_explore_resident(const demi_model* m, const demi_ext
 // DDMin in one call (demi_amd/csrc/ddmin_host.hpp, what demi_ddmin runs around K2 launches) over the CPU oracle's
 // STSScheduler replays: the CPU check of that loop against the Python mirror (demi_amd/minification.py).
 #include "../demi_amd/csrc/ddmin_host.hpp"
+#include "../demi_amd/csrc/incddmin_host.hpp"
 
 extern "C" int harness_ddmin(const demi_model* m, const demi_ext_event* ext, uint32_t n_ext, const demi_rec_event* rec, uint32_t n_rec,
                              const demi_limits* lim, const demi_ddmin_params* par, const uint8_t* conjoined, int n_threads,
@@ -429,6 +430,49 @@ extern "C" int harness_dpor_explore_ordered(const demi_model* m, const demi_ext_
 // the state one DPORwHeuristics instance keeps between its test() calls (demi_ctx holds one per loaded trace)
 extern "C" void* harness_ordered_state_new() { return new demi_host::OrderedState(); }
 extern "C" void harness_ordered_state_free(void* p) { delete static_cast<demi_host::OrderedState*>(p); }
+
+// RunnerUtils.editDistanceDporDDMin's native loop (incddmin_host.hpp: IncrementalDDMin over ResumableDPOR) with the CPU oracle's
+// interleavings under every DPOR consultation: the CPU check of demi_edit_distance_dpor_ddmin against the Python mirror.
+extern "C" int harness_edit_distance_dpor_ddmin(const demi_model* m, const demi_ext_event* ext, uint32_t n_ext,
+                                                const demi_dpor_trace_entry* initial, uint32_t n_initial, const demi_dpor_params* par,
+                                                const demi_incddmin_params* ip, int n_threads, uint64_t* out_mcs, uint64_t* out_consulted,
+                                                uint8_t* out_passed, uint32_t* out_distance, uint32_t cap,
+                                                demi_dpor_trace_entry* out_violation_trace, demi_incddmin_stats* stats) {
+  std::vector<uint64_t> keys(n_initial);
+  for (uint32_t i = 0; i < n_initial; i++) keys[i] = initial[i].key;
+  const uint32_t budget = ip->budget ? ip->budget : (1u << 16);
+  std::vector<demi_verdict> verdicts(budget);
+  std::vector<uint32_t> plen(budget), rounds(budget);
+  auto explore = [&](const std::vector<demi_ext_event>& sub, const demi_dpor_search& srch, std::unique_ptr<demi_host::OrderedState>& state,
+                     demi_dpor_stats* st, std::vector<demi_dpor_trace_entry>* vt) -> int {
+    if (!state) state.reset(new demi_host::OrderedState());
+    vt->assign(DEMI_DPOR_MAX_TRACE, demi_dpor_trace_entry{});
+    uint32_t vlen = 0;
+    const int rc = harness_dpor_explore_ordered(m, sub.data(), (uint32_t)sub.size(), par, &srch, keys.data(), n_initial, initial, n_initial, n_threads,
+                                                verdicts.data(), plen.data(), rounds.data(), vt->data(), &vlen, st, state.get());
+    vt->resize(vlen);
+    return rc;
+  };
+  demi_host::IncDdminResult r;
+  const int rc = demi_host::edit_distance_dpor_ddmin(ext, n_ext, ip, explore, &r);
+  if (rc) return rc;
+  memset(stats, 0, sizeof *stats);
+  for (int k = 0; k < 4; k++) out_mcs[k] = r.mcs.w[k];
+  stats->replays = r.replays; stats->interleavings = r.interleavings; stats->consultations = r.consultations;
+  stats->instances = r.instances; stats->passes = (uint32_t)r.distances.size(); stats->mcs_len = r.mcs.count();
+  stats->verified = r.verified;
+  for (size_t i = 0; i < r.distances.size() && i < 16; i++) { stats->pass_distance[i] = r.distances[i].first; stats->pass_mcs_len[i] = r.distances[i].second; }
+  for (size_t i = 0; i < r.consulted.size() && i < cap; i++) {
+    if (out_consulted) memcpy(out_consulted + 4 * i, r.consulted[i].first.w, 32);
+    if (out_passed) out_passed[i] = r.consulted[i].second ? 1 : 0;
+    if (out_distance) out_distance[i] = r.consulted_distance[i];
+  }
+  if (out_violation_trace && !r.violation_trace.empty()) {
+    memcpy(out_violation_trace, r.violation_trace.data(), sizeof(demi_dpor_trace_entry) * r.violation_trace.size());
+    stats->violation_len = (uint32_t)r.violation_trace.size();
+  }
+  return 0;
+}
 
 // the same loop around an arbitrary oracle (a callback): property tests of the DDMin host logic itself - atoms, splits, the
 // frontier - against the Python mirror, independent of what a replay would say

@@ -329,6 +329,35 @@ def ddmin(model, original_externals, original_trace, limits, params=None, conjoi
         [int(b) for b in batches[:st.launches]], st
 
 
+def edit_distance_dpor_ddmin(model, externals, initial_trace, params, ip=None, n_threads=2, cap=4096):
+    """demi_edit_distance_dpor_ddmin's host loop (demi_amd/csrc/incddmin_host.hpp) with this oracle's interleavings under every
+    DPOR consultation.  Returns what demi_amd._native.Context.edit_distance_dpor_ddmin returns."""
+    build()
+    H = C.CDLL(os.path.join(_HERE, "_build", "dpor_host_harness.so"))
+    ms = model.to_struct()
+    ev = np.ascontiguousarray(externals, dtype=T.EXT_EVENT_DTYPE)
+    init = np.ascontiguousarray(initial_trace, dtype=T.DPOR_TRACE_DTYPE)
+    ip = ip or T.IncDdminParams()
+    mcs = np.zeros(4, dtype=np.uint64)
+    consulted = np.zeros((cap, 4), dtype=np.uint64)
+    passed = np.zeros(cap, dtype=np.uint8)
+    dist = np.zeros(cap, dtype=np.uint32)
+    vt = np.zeros(T.DPOR_MAX_TRACE, dtype=T.DPOR_TRACE_DTYPE)
+    st = T.IncDdminStats()
+    H.harness_edit_distance_dpor_ddmin.argtypes = [C.POINTER(T.ModelStruct), C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
+                                                   C.POINTER(T.DporParams), C.POINTER(T.IncDdminParams), C.c_int, C.c_void_p, C.c_void_p,
+                                                   C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(T.IncDdminStats)]
+    rc = H.harness_edit_distance_dpor_ddmin(C.byref(ms), ev.ctypes.data if len(ev) else None, len(ev), init.ctypes.data, len(init),
+                                            C.byref(params), C.byref(ip), n_threads, mcs.ctypes.data, consulted.ctypes.data,
+                                            passed.ctypes.data, dist.ctypes.data, cap, vt.ctypes.data, C.byref(st))
+    if rc:
+        raise RuntimeError("harness_edit_distance_dpor_ddmin: %d" % rc)
+    n = min(cap, st.consultations)
+    return T.mask_to_events(mcs), [(T.mask_to_events(consulted[i]), bool(passed[i]), int(dist[i])) for i in range(n)], \
+        [(int(st.pass_distance[i]), int(st.pass_mcs_len[i])) for i in range(min(16, st.passes))], \
+        (vt[:st.violation_len].copy() if st.violation_len else None), st
+
+
 class OrderedState:
     """What one DPORwHeuristics instance keeps between its test() calls (queue, explored pairs): hand the same object to
     consecutive dpor_explore_ordered calls with search.resume = 1."""

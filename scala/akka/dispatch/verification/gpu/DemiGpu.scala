@@ -39,6 +39,15 @@ object DemiGpu {
   @native def dporSetTraces(h: Long, originalKeysOrNull: Array[Long], initialTraceOrNull: Array[Byte]): Int
   @native def dporExplore(h: Long, params: Array[Int], search: Array[Int], verdicts: Array[Long], prefixLen: Array[Int],
                           rounds: Array[Int], firstViolationTrace: Array[Byte], stats: Array[Long]): Int
+  /** RunnerUtils.editDistanceDporDDMin in one call (demi_edit_distance_dpor_ddmin: IncrementalDDMin over ResumableDPOR, every DPOR
+   *  consultation inside the library).  externals = 8 bytes each; initialTrace = 16-byte entries (FlatEvents.dporInitialTrace);
+   *  dporParams = int[7]; params = int[7] (max_max_distance, stop_at_size, check_unmodified, ignore_quiescence, verify_mcs, batch, budget);
+   *  mcs = long[4]; consultedOrNull = long[4 * cap] with passedOrNull = byte[cap], distanceOrNull = int[cap];
+   *  violationTraceOrNull = byte[16 * 256]; stats = long[40] (replays, interleavings, consultations, instances, passes, mcs_len, verified,
+   *  violation_len, pass_distance[16], pass_mcs_len[16]) */
+  @native def editDistanceDporDDMin(h: Long, externals: Array[Byte], initialTrace: Array[Byte], dporParams: Array[Int], params: Array[Int],
+                                    mcs: Array[Long], consultedOrNull: Array[Long], passedOrNull: Array[Byte], distanceOrNull: Array[Int],
+                                    violationTraceOrNull: Array[Byte], stats: Array[Long]): Int
   /** ProvenanceTracker.pruneConcurrentEvents for n traces (16-byte entries, `stride` per trace); keep: 4 longs (256 bits) per trace */
   @native def provenancePrune(h: Long, traces: Array[Byte], traceLen: Array[Int], affected: Array[Int], stride: Int, keep: Array[Long]): Int
   @native def commUniqueId(id128: Array[Byte]): Int

@@ -349,6 +349,40 @@ class GpuDPOR(val schedulerConfig: SchedulerConfig, lowering: TableLowering, dep
   def shutdown() { ctxDestroy(h) }
 }
 
+/** RunnerUtils.editDistanceDporDDMin (RunnerUtils.scala:810-879) in ONE native call (demi_edit_distance_dpor_ddmin): IncrementalDDMin
+ *  (IncrementalDeltaDebugging.scala:20-92) over ResumableDPOR (:94-122) - every consultation a bounded DPORwHeuristics exploration with
+ *  ArvindDistanceOrdering, the original execution as initial trace and a distance cap that doubles per pass; a subsequence consulted
+ *  again continues from its backtrack queue.  Returns what the reference returns: (mcs externals, stats, the reproducing trace if the
+ *  MCS is smaller than the externals and verifies, the violation).  The preTest / postTest hooks of the reference's schedulers have no
+ *  counterpart: the consultations happen inside one library call. */
+object GpuEditDistanceDporDDMin {
+  def apply(schedulerConfig: SchedulerConfig, lowering: TableLowering, trace: EventTrace, violation: ViolationFingerprint,
+            ignoreQuiescence: Boolean = true, stats: Option[MinimizationStats] = None, stopAtSize: Int = 6, maxMaxDistance: Int = 8,
+            batch: Int = 256, device: Int = 0): (Seq[ExternalEvent], MinimizationStats, Option[EventTrace], ViolationFingerprint) = {
+    if (schedulerConfig.invariant_check.isEmpty) throw new IllegalArgumentException("Must invoke setInvariant before test()")
+    val h = ctxCreate(device)
+    if (h == 0) throw new IllegalStateException("no MI355X visible: use RunnerUtils.editDistanceDporDDMin")
+    try {
+      val m = lowering.model
+      check(h, modelLoad(h, m.nActors, m.msgClass, m.actorClass, m.nClasses, m.handlerStart, m.code, m.initState,
+                         Array(m.invKind, m.invFa, m.invVa, m.invFb, m.fpMatchMask, m.flags)))
+      modelSpecialize(h, true)
+      val ext = trace.original_externals
+      val init = FlatEvents.dporInitialTrace(trace, lowering)
+      // what the reference's dporConstructor sets (:827-839): prioritizePendingUponDivergence, setMaxMessagesToSchedule(initialTrace.size)
+      val dporParams = Array(0, init.length / 16, 1, lowering.fingerprintCode(violation), 64, 4096, 1)
+      val params = Array(maxMaxDistance, stopAtSize, 0, if (ignoreQuiescence) 1 else 0, 1, batch, 0)
+      val mcs = new Array[Long](4); val vt = new Array[Byte](16 * 256); val st = new Array[Long](40)
+      check(h, DemiGpu.editDistanceDporDDMin(h, FlatEvents.pack(ext, lowering), init, dporParams, params, mcs, null, null, null, vt, st))
+      val out = stats.getOrElse(new MinimizationStats)
+      (0L until st(0)).foreach(_ => out.increment_replays())
+      val kept = ext.indices.filter(i => ((mcs(i >> 6) >>> (i & 63)) & 1L) != 0).map(ext)
+      val verified = if (st(6) == 1) Some(GpuDPOR.traceOf(vt, st(7).toInt, kept, lowering)) else None
+      (kept, out, verified, violation)
+    } finally ctxDestroy(h)
+  }
+}
+
 object GpuDPOR {
   /** demi_dpor_trace_entry[] (key 8, word 4, parent, qperiod, depth, kind) -> the MsgEvents of the violating interleaving */
   def traceOf(vt: Array[Byte], n: Int, externals: Seq[ExternalEvent], lo: TableLowering): EventTrace = {

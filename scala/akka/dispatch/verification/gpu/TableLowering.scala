@@ -84,6 +84,38 @@ object FlatEvents {
     trace
   }
 
+  /** DepTracker.getInitialTrace (DepTracker.scala:130-133, 173) of a recorded execution as demi_dpor_trace_entry[] (key u64, word u32,
+   *  parent, qperiod, depth, kind - 16 bytes): the root, then every delivery, each identified by the hash chain of its causal path
+   *  (include/demi_gpu.h: key(child) = (key(parent) ^ word) * FNV prime; the parent is the delivery during which it was sent, the
+   *  root for external messages).  What demi_amd/incremental_ddmin.py dpor_initial_trace computes from the same records. */
+  val DPOR_ROOT_KEY = 0xCBF29CE484222325L
+  val DPOR_PRIME = 0x100000001B3L
+  def dporInitialTrace(trace: EventTrace, lo: TableLowering): Array[Byte] = {
+    def actor(n: String) = if (n == "deadLetters" || n == "Timer") DEADLETTERS else lo.actorId(n)
+    def word(s: String, r: String, m: Any): Int = { val (t, p0, p1) = lo.encode(m); t | (lo.actorId(r) << 5) | (actor(s) << 8) | ((p0 & 255) << 16) | ((p1 & 255) << 24) }
+    val keyOfId = scala.collection.mutable.Map[Int, (Long, Int)]()        // Uniq id -> (node key, trace index of its producer)
+    val entries = scala.collection.mutable.ArrayBuffer[(Long, Int, Int, Int, Int)]((DPOR_ROOT_KEY, 0, 0, 0, 0))    // key, word, parent, depth, kind
+    var curKey = DPOR_ROOT_KEY; var curIdx = 0
+    for (e <- trace.events) e match {
+      case u @ UniqueMsgSend(MsgSend(s, r, m), id) =>
+        val (pk, pi) = if (EventTypes.isExternal(u)) (DPOR_ROOT_KEY, 0) else (curKey, curIdx)
+        keyOfId(id) = (((pk ^ (word(s, r, m).toLong & 0xFFFFFFFFL)) * DPOR_PRIME), pi)
+      case UniqueMsgEvent(MsgEvent(s, r, m), id) =>
+        val (k, pi) = keyOfId(id)
+        entries += ((k, word(s, r, m), pi & 0xFF, (entries(pi)._4 + 1) & 0xFF, 1))
+        curKey = k; curIdx = entries.size - 1
+      case _ =>
+    }
+    val out = new Array[Byte](16 * entries.size)
+    for (((k, w, parent, depth, kind), i) <- entries.zipWithIndex) {
+      val o = 16 * i
+      for (b <- 0 until 8) out(o + b) = (k >>> (8 * b)).toByte
+      for (b <- 0 until 4) out(o + 8 + b) = (w >>> (8 * b)).toByte
+      out(o + 12) = parent.toByte; out(o + 13) = 0; out(o + 14) = depth.toByte; out(o + 15) = kind.toByte
+    }
+    out
+  }
+
   /** EventTrace -> demi_rec_event[] (for replayLoad): the inverse of toEventTrace for the records the GPU path produces. */
   def packRecorded(trace: EventTrace, lo: TableLowering): Array[Byte] = {
     val evs = trace.events.toSeq

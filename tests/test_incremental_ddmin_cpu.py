@@ -221,3 +221,54 @@ def test_native_ordered_exploration_resumes_like_the_mirror(oracle, which):
             assert all(nv[k] == il.verdict and int(npl[k]) == il.prefix_len for k, il in enumerate(rp.interleavings))
             total += len(nv)
         assert total >= (3 if which == "two_writers" else 200)
+
+
+def _race4():
+    MSGS = [("Go", T.MSG_EXTERNAL), ("Write", T.MSG_INTERNAL)]
+    hnd = {(0, "Go"): Asm().mov(M.T0, 0).send(1, M.T0, M.ME, 0),
+           (0, "Write"): Asm().mov(M.F[0], M.P0).add(M.F[1], M.F[1], 1)}
+    model = build_model("race4", 4, MSGS, hnd, [[0] * 8] * 4, (T.INV_NEVER, 0, 1, 0))
+    ev = events_to_array([start(0), start(1), start(2), start(3), send(2, 0), send(1, 0), send(3, 0), send(2, 0)])
+    return model, ev
+
+
+@pytest.mark.parametrize("which", ["race4", "race4_faults", "raft3"])
+def test_native_edit_distance_dpor_ddmin_equals_the_python_mirror(oracle, which):
+    """demi_edit_distance_dpor_ddmin's host loop (csrc/incddmin_host.hpp: IncrementalDDMin over ResumableDPOR, here around the
+    oracle's interleavings) against the Python mirror's editDistanceDporDDMin over the same oracle: the same MCS, the same
+    consultations - subsequence, verdict and distance cap, pass after pass -, the same (cap, MCS size) per pass, the same merged
+    replay count, the same answer of verify_mcs; also with a small budget per internal exploration call (a consultation is then
+    several resumed calls) and one-at-a-time launches."""
+    from oracle import oracle_py
+    if which.startswith("race4"):
+        model, ev = _race4()
+        if which == "race4_faults":      # faults and quiescence markers in the externals: not part of the minimization
+            ev = events_to_array([start(0), start(1), start(2), start(3), partition(2, 3), send(2, 0), wait_quiescence(), send(1, 0),
+                                  kill(3), send(2, 0)])
+        want, stop_at, lim = True, 2, None
+    else:
+        model = M.raft_model(3)
+        ev = events_to_array([start(a) for a in range(3)] + [send(a, M.M_BOOTSTRAP) for a in range(3)] + [send(0, M.M_CLIENT)])
+        want, stop_at, lim = True, 3, T.Limits(40, 0, 64, 0, 0, 0)
+    v, trace = _execution(oracle, model, ev, want_violation=want, lim=lim)
+    fp = ViolationFingerprint(v.fingerprint)
+    init = dpor_initial_trace(trace)
+    for batch, budget in ((8, 1 << 16), (1, 1 << 16), (4, 5)):
+        mcs, dd, verified, _ = editDistanceDporDDMin(SchedulerConfig(model=model), trace, fp, stopAtSize=stop_at, maxMaxDistance=8, batch=batch,
+                                                     backend=oracle.dpor_batch)
+        par = T.DporParams(0, len(init), 1, fp.code, 64, 4096, 1)
+        ip = T.IncDdminParams(max_max_distance=8, stop_at_size=stop_at, check_unmodified=0, ignore_quiescence=1, verify_mcs=1, batch=batch,
+                              budget=budget)
+        n_mcs, n_cons, n_pass, n_vt, st = oracle_py.edit_distance_dpor_ddmin(model, ev, init, par, ip)
+        assert tuple(n_mcs) == tuple(mcs), (which, batch, budget)
+        assert n_pass == dd.distances
+        assert [(tuple(c), p, d) for c, p, d in n_cons] == [(tuple(c), p, d) for c, p, d in dd.consulted_all]
+        assert int(st.replays) == dd._stats.total_replays and int(st.consultations) == len(dd.consulted_all)
+        assert int(st.instances) == len(dd.oracle.subseqToDPOR)
+        if len(mcs) < len([i for i in range(len(ev)) if int(ev[i]["kind"]) in (T.EV_START, T.EV_SEND)]):
+            assert (int(st.verified) == 1) == (verified is not None)
+            if verified is not None:
+                assert n_vt is not None and len(n_vt) == len(verified) and (n_vt["key"] == verified["key"]).all()
+        else:
+            assert int(st.verified) == -1 and verified is None
+    assert len(mcs) < len(ev)

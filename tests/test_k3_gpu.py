@@ -188,6 +188,19 @@ def test_edit_distance_dpor_ddmin_on_the_gpu(oracle):
     # resumable state of a subsequence consulted again at a larger distance): the same minimization
     assert runs[2] == runs[0]
     assert runs[0][3] and len(runs[0][0]) < len(ev)
+    # ... and with the loop itself inside the library too (demi_edit_distance_dpor_ddmin: IncrementalDDMin over ResumableDPOR
+    # in one call), interpreted and with the compiled table: the same MCS, consultations with their caps, passes, replays
+    mcs, dd, verified, _ = editDistanceDporDDMin(SchedulerConfig(model=model), trace, fp, stopAtSize=2, maxMaxDistance=4, batch=64,
+                                                 backend=oracle.dpor_batch)
+    for spec in (False, True):
+        n_mcs, n_dd, n_verified, _ = editDistanceDporDDMin(SchedulerConfig(model=model), trace, fp, stopAtSize=2, maxMaxDistance=4, batch=64,
+                                                           native_loop=True, specialize=spec)
+        assert tuple(n_mcs) == tuple(mcs) and n_dd.distances == dd.distances
+        assert n_dd.consulted_all == [(tuple(c), p, d) for c, p, d in dd.consulted_all]
+        assert n_dd._stats.total_replays == dd._stats.total_replays
+        assert (n_verified is not None) == (verified is not None)
+        if verified is not None:
+            assert len(n_verified) == len(verified) and (n_verified["key"] == verified["key"]).all()
 
 
 def test_native_arvind_ordering_and_distance_cap_on_the_gpu(oracle):

@@ -54,7 +54,7 @@ def main():
     if out.returncode:
         sys.exit(out.stdout + out.stderr)
     objdump, readelf = "/opt/rocm/lib/llvm/bin/llvm-objdump", "/opt/rocm/lib/llvm/bin/llvm-readelf"
-    for k in range(6):
+    for k in list(range(6)) + [13]:
         p = os.path.join(d, "img.%d" % k)
         if not os.path.exists(p) or k in (4, 5):
             continue
@@ -65,7 +65,7 @@ def main():
         meta = [l.strip() for l in notes.splitlines() if any(x in l for x in (".name:", ".vgpr_count", ".sgpr_count", "spill_count", "private_segment_fixed"))
                 and ".name:           hidden" not in l and "value_kind" not in l]
         comp = [l for l in subprocess.run([readelf, "-p", ".comment", p], capture_output=True, text=True).stdout.splitlines() if "clang version" in l]
-        print("== kernel %d: %s" % (k, NAMES[k]))
+        print("== kernel %d: %s" % (k, NAMES[k] if k < len(NAMES) else "k1_random_explore<false,false,false,true> (re-binned)"))
         print("   instructions %d (+ %d s_nop), code id %s, %d bytes" % (sum(1 for i in ins if i != "s_nop"), ins.count("s_nop"), text_hash(b), len(b)))
         print("   " + "  ".join(meta))
         if comp and k == 0:
