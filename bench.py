@@ -121,12 +121,7 @@ def bench_dpor(ctx_device, cpu_baseline=True, batch=16384, orders=("rounds", "re
     n_il = r["interleavings"]
     per_il = 4.0 * r["mean_prefix_len"] + 8.0 + 12.0 * (r["backtrack_points"] / max(1, n_il))
     alg = n_il * per_il
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r03_dpor_counters.json")) as f:
-            traffic = json.load(f).get("fabric_bytes_per_exploration")
-    except (OSError, ValueError):
-        pass
+    traffic = (_counters_profile("r04_dpor_counters.json") or _counters_profile("r03_dpor_counters.json") or {}).get("fabric_bytes_per_exploration")
     out["roofline"] = roofline(alg, r["kernel_ms_total"], traffic,
                                "k3_dpor + k3_pairs_mark/insert/decide (specialised, hiprtc), %d rounds" % r["launches"],
                                "ROUNDS order. Algorithmic bytes per SURVEY 8(d): 4 x mean prefix length (%.1f events) + 8 + 12 x r "
@@ -263,8 +258,11 @@ def bench_config5(ctx_device, cpu_baseline=True, max_interleavings=None, batch=1
     ctx.model_specialize()
     ctx.dpor_load(dpor_events)
     collective = ranks.attach(ctx) if ranks.world > 1 else "none (1 rank)"
-    warm = T.DporSearch(batch, min(max_interleavings, 1 << 16), 0, 1, T.DPOR_ORDER_ROUNDS)
-    ctx.dpor_explore(par, warm)                      # compilation for this table, the device arenas; every call is a fresh exploration
+    # compilation for this table and the device arenas (sized by the budget: 4 KB of trace arena per interleaving and the
+    # explored-pair table are allocated when a call first needs them - the same budget, so that the timed call allocates nothing;
+    # every call is a fresh exploration)
+    warm = T.DporSearch(batch, max_interleavings, 0, 1, T.DPOR_ORDER_ROUNDS)
+    ctx.dpor_explore(par, warm)
     setup_s = time.perf_counter() - t
     ranks.barrier()
     t = time.perf_counter()
@@ -469,7 +467,9 @@ def bench_ddmin(ctx_device, cpu_baseline=True, n=1 << 20):
     # algorithmic HBM bytes per candidate: 32 B mask in + 16 B verdict out; the lowered original trace (8 B x expected events)
     # is shared by every lane (read once per workgroup into LDS)
     alg = 48 * n + 8 * n_exp * ((n + 255) // 256)
-    out["roofline"] = roofline(alg, kms, None, "k2_replay (specialised, hiprtc)",
+    # (measured fabric-side bytes of one 2^20-candidate launch, when the counters of this round are committed: tools/profile_r4_k2k3.sh)
+    k2_traffic = (_counters_profile("r04_ddmin_counters.json") or {}).get("fabric_bytes_per_launch") if n == (1 << 20) else None
+    out["roofline"] = roofline(alg, kms, k2_traffic, "k2_replay (specialised, hiprtc)",
                                "32 B mask + 16 B verdict per candidate, the lowered original trace (%d x 8 B) once per workgroup; "
                                "the replay itself is integer / LDS work" % n_exp)
     ctx.close()

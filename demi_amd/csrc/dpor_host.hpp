@@ -93,6 +93,53 @@ class FlatPairMap {
   size_t mask_ = 0, n_ = 0;
 };
 
+// A set of ORDERED pairs of node keys (the flipped pairs getNext() would skip): open addressing, linear probing, 16-byte
+// entries; (0, 0) is the empty slot.  The resident loops insert a pair per dequeued point and per device-side kill - millions
+// for a budgeted exploration - where a node-based set spends most of its time allocating (config 5: 0.29 s of 1.0 s).
+class FlatPairSet {
+ public:
+  FlatPairSet() { resize(1u << 14); }
+  // true if (a, b) was absent (it is present afterwards)
+  bool insert(uint64_t a, uint64_t b) {
+    if ((n_ + 1) * 5 > (mask_ + 1) * 3) grow();
+    for (size_t i = slot(a, b);; i = (i + 1) & mask_) {
+      Entry& k = tab_[i];
+      if (k.a == 0 && k.b == 0) { k.a = a; k.b = b; n_++; return true; }
+      if (k.a == a && k.b == b) return false;
+    }
+  }
+  size_t size() const { return n_; }
+
+ private:
+  struct Entry { uint64_t a, b; };
+  size_t slot(uint64_t a, uint64_t b) const {
+    return (size_t)(((a * 0x9E3779B97F4A7C15ULL) ^ (b * 0xC2B2AE3D27D4EB4FULL) ^ (a >> 29)) >> 7) & mask_;
+  }
+  void resize(size_t cap) { tab_.assign(cap, Entry{0, 0}); mask_ = cap - 1; n_ = 0; }
+  void grow() {
+    std::vector<Entry> old;
+    old.swap(tab_);
+    resize((mask_ + 1) * 2);
+    for (const Entry& k : old) if (k.a || k.b) insert(k.a, k.b);
+  }
+  std::vector<Entry> tab_;
+  size_t mask_ = 0, n_ = 0;
+};
+
+// the order of `n` 64-bit keys (indices, ascending by key, stable): LSD radix passes of 11 bits over the bits the largest key has
+inline void radix_order(const uint64_t* key, size_t n, std::vector<uint32_t>& order, std::vector<uint32_t>& tmp) {
+  order.resize(n); tmp.resize(n);
+  uint64_t all = 0;
+  for (size_t i = 0; i < n; i++) { order[i] = (uint32_t)i; all |= key[i]; }
+  for (uint32_t shift = 0; shift < 64 && (all >> shift) != 0; shift += 11) {
+    uint32_t cnt[2049] = {0};
+    for (size_t i = 0; i < n; i++) cnt[((key[i] >> shift) & 2047u) + 1]++;
+    for (int b = 0; b < 2048; b++) cnt[b + 1] += cnt[b];
+    for (size_t i = 0; i < n; i++) { const uint32_t j = order[i]; tmp[cnt[(key[j] >> shift) & 2047u]++] = j; }
+    order.swap(tmp);
+  }
+}
+
 // FIFO of BtPoints in 4 KB chunks taken from (and returned to) a pool owned by the shard
 struct Chunk {
   Chunk* next;
@@ -1012,11 +1059,13 @@ int explore_rounds_resident(Dev&& dev, const demi_dpor_search* srch, demi_verdic
   std::deque<demi::DporPoint> bucket[256];
   int top = -1;
   uint64_t queued = 0;
-  std::unordered_set<std::pair<uint64_t, uint64_t>, PairKeyHash> dead;     // flipped pairs getNext() would skip
+  FlatPairSet dead;                                                        // flipped pairs getNext() would skip
   std::vector<demi::DporItem> items(1, demi::DporItem{0xFFFFFFFFu, 0, 0, 0, 0});   // first run: nextTrace is empty
   std::vector<demi_verdict> vd;
   std::vector<demi::DporPoint> pts;
   std::vector<demi::DporKill> kills;
+  std::vector<uint64_t> ord_key;
+  std::vector<uint32_t> ord, ord_tmp;
   uint32_t base_id = 0, round = 0;
   uint64_t first_id = ~0ull;
   bool exhausted = false;
@@ -1044,10 +1093,14 @@ int explore_rounds_resident(Dev&& dev, const demi_dpor_search* srch, demi_verdic
       }
     }
     base_id += dev.ids_used(n);
-    for (const demi::DporKill& k : kills) dead.insert({k.a, k.b});
-    std::sort(pts.begin(), pts.end(), [](const demi::DporPoint& x, const demi::DporPoint& y) { return x.ordinal < y.ordinal; });
+    for (const demi::DporKill& k : kills) dead.insert(k.a, k.b);
+    // creation order: the round's interleavings in pop order, then pair order (ordinals are unique within a round)
+    ord_key.resize(pts.size());
+    for (size_t i = 0; i < pts.size(); i++) ord_key[i] = pts[i].ordinal;
+    radix_order(ord_key.data(), pts.size(), ord, ord_tmp);
     stats->backtrack_points += pts.size();
-    for (const demi::DporPoint& p : pts) {        // creation order: the round's interleavings in pop order, then pair order
+    for (size_t i = 0; i < pts.size(); i++) {
+      const demi::DporPoint& p = pts[ord[i]];
       bucket[p.branch].push_back(p);
       if ((int)p.branch > top) top = (int)p.branch;
       queued++;
@@ -1064,7 +1117,7 @@ int explore_rounds_resident(Dev&& dev, const demi_dpor_search* srch, demi_verdic
       const demi::DporPoint p = bucket[top].front();
       bucket[top].pop_front();
       queued--;
-      if (!dead.insert({p.flip_a, p.flip_b}).second) continue;     // isExplored: skip; else setExplored (:1170-1172)
+      if (!dead.insert(p.flip_a, p.flip_b)) continue;              // isExplored: skip; else setExplored (:1170-1172)
       items.push_back(demi::DporItem{p.src, p.branch, p.later, p.earlier, 0});
     }
     if (items.empty() && queued == 0) exhausted = true;
@@ -1227,7 +1280,7 @@ int explore_reference_resident(Dev&& dev, const demi_dpor_search* srch, demi_ver
   // the speculation's queue (explore_rounds_resident's)
   std::deque<demi::DporPoint> bucket[256];
   int top = -1;
-  std::unordered_set<std::pair<uint64_t, uint64_t>, PairKeyHash> dead;
+  FlatPairSet dead;
 
   const demi::DporItem first{0xFFFFFFFFu, 0, 0, 0, 0};
   demi::DporItem cur = first;
@@ -1341,7 +1394,7 @@ int explore_reference_resident(Dev&& dev, const demi_dpor_search* srch, demi_ver
     }
     base_id += dev.ids_used(n);
     // the speculation: this round's live points and kills into its queue, then its next round
-    for (const demi::DporKill& k : kills) dead.insert({k.a, k.b});
+    for (const demi::DporKill& k : kills) dead.insert(k.a, k.b);
     std::sort(pts.begin(), pts.end(), [](const demi::DporPoint& x, const demi::DporPoint& y) { return x.ordinal < y.ordinal; });
     for (const demi::DporPoint& p : pts) {
       bucket[p.branch].push_back(p);
@@ -1353,7 +1406,7 @@ int explore_reference_resident(Dev&& dev, const demi_dpor_search* srch, demi_ver
       if (top < 0) break;
       const demi::DporPoint p = bucket[top].front();
       bucket[top].pop_front();
-      if (!dead.insert({p.flip_a, p.flip_b}).second) continue;
+      if (!dead.insert(p.flip_a, p.flip_b)) continue;
       spec_items.push_back(demi::DporItem{p.src, p.branch, p.later, p.earlier, 0});
     }
     if (seconds) { seconds[0] += t2 - t1; seconds[1] += now() - t2; }

@@ -354,6 +354,7 @@ inline std::string generate_vm(const demi::DevModel& h, bool sched = false) {
       case DEMI_OP_POPC: snprintf(val, cap, "(uint32_t)__popc(%s)", b); break;
       case DEMI_OP_MIN: snprintf(val, cap, "%s < %s ? %s : %s", a, b, a, b); break;
       case DEMI_OP_MAX: snprintf(val, cap, "%s < %s ? %s : %s", a, b, b, a); break;
+      case DEMI_OP_PEER: snprintf(val, cap, "0u"); break;     // (invariant programs only: their rows are emitted by the loop further down)
       case DEMI_OP_RND:      // (a wide table's bound is b & 0xFF: the magics cover 1..256)
         if (wide) snprintf(val, cap, "app_next_int(app_rng, %s & 255u, t.gmagic)", b);
         else snprintf(val, cap, "app_next_int(app_rng, %s, t.gmagic)", b);
@@ -415,7 +416,8 @@ inline std::string generate_vm(const demi::DevModel& h, bool sched = false) {
     // the invariant's per-actor program (include/demi_gpu.h DEMI_INV_PROGRAM): the rows from inv_fa on, run on one actor's
     // state - r0..r7 its fields, r15 its id, everything else 0; T0 = hit, T1 = key; what it writes to the fields is discarded
     // (jit_source defines DEMI_JIT_INV_PROG ahead of sim_core.hpp, whose inv_prog() then calls this)
-    s += "__device__ inline uint32_t inv_prog_jit(const uint64_t* st, uint32_t actor, uint32_t& key) {\n";
+    s += "__device__ inline uint32_t inv_prog_jit(const uint64_t* st, uint32_t actor, uint32_t& key, uint32_t exists, uint32_t n_actors) {\n"
+         "  (void)exists; (void)n_actors;\n";
     if (wide) {
       s += "  const uint64_t st0 = st[(ST_WORDS * actor) * 64], st1 = st[(ST_WORDS * actor + 1) * 64];\n";
       s += "  uint32_t r0 = (uint32_t)st0 & 65535u, r1 = (uint32_t)(st0 >> 16) & 65535u, r2 = (uint32_t)(st0 >> 32) & 65535u, "
@@ -442,7 +444,9 @@ inline std::string generate_vm(const demi::DevModel& h, bool sched = false) {
       emit("  I%u: ", pc);
       const uint32_t cw = op_control(op);
       if (cw & CW_HALT) { s += "goto idone;\n"; continue; }
-      if ((cw & CW_ALU) && !(cw & CW_RND)) {
+      if (cw & CW_PEER) {
+        emit("%s = peer_field(st, %s, %uu, exists, n_actors);\n", d, a, aux);
+      } else if ((cw & CW_ALU) && !(cw & CW_RND)) {
         char val[96];
         alu_value(op, a, b, val, sizeof val);
         emit("%s = %s;\n", d, val);

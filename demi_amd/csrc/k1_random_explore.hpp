@@ -459,6 +459,10 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
   const uint32_t inv_kind = t.inv_kind, inv_fa = t.inv_fa, inv_va = t.inv_va, inv_fb = t.inv_fb, fp_mask = t.fp_mask;
 #endif
   auto check_invariant = [&]() -> uint32_t {
+    if (inv_kind & DEMI_INV_PEERS) {      // the program reads other actors (DEMI_OP_PEER): every actor's hit, from the states as they are
+      hits = 0;
+      for (uint32_t a = 0; a < A; a++) if ((exists >> a) & 1u) hits |= invariant_hit_at(t, st, a, inv_kind, inv_fa, inv_va) << a;
+    }
     const uint32_t fp = invariant_from_hits(t, st, hits & exists, A, inv_kind, inv_fb);
     if (!fp) return 0u;
     if (args.looking_for_valid && (!CARRY || exec_no == 0)) return (((fp ^ args.looking_for) & fp_mask) == 0) ? args.looking_for : 0u;
@@ -920,8 +924,10 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
     if (deliver) nfx = DEMI_VM_RUN(t, mem, w, flags, app_rng);
     if (deliver) {      // the receiver's new state decides its bit of the invariant's hit mask
       const uint32_t me_ = w_dst(w);
-      rb_hit = invariant_hit_at(t, st, me_, inv_kind, inv_fa, inv_va);
-      if (!REBIN) hits = (hits & ~(1u << me_)) | (rb_hit << me_);
+      if (!(inv_kind & DEMI_INV_PEERS)) {     // (with PEER rows the mask is rebuilt at every check: check_invariant)
+        rb_hit = invariant_hit_at(t, st, me_, inv_kind, inv_fa, inv_va);
+        if (!REBIN) hits = (hits & ~(1u << me_)) | (rb_hit << me_);
+      }
     }
     PH_MARK(5);
 #ifdef DEMI_K1_PHASES

@@ -32,8 +32,12 @@ enum : uint32_t {
   CW_FX = 1u << 18, CW_HALT = 1u << 19,
   CW_REL_SHIFT = 20,     // bits 20..22: accepted relations {lt, eq, gt} of compare / guard rows
   CW_RND = 1u << 23,     // dst = seededRandom.nextInt(b)
-  CW_LDX = 1u << 24, CW_STX = 1u << 25     // dst = ARRAY[b] / ARRAY[b] = a (DEMI_MODEL_ARRAY)
+  CW_LDX = 1u << 24, CW_STX = 1u << 25,    // dst = ARRAY[b] / ARRAY[b] = a (DEMI_MODEL_ARRAY)
+  CW_PEER = 1u << 26                       // dst = a field of another actor (invariant programs only)
 };
+// DevModel::inv_kind, set by the host when the invariant's program has a DEMI_OP_PEER row: an actor's hit depends on the other
+// actors' states, so K1's incrementally maintained hit mask is rebuilt at every check instead
+#define DEMI_INV_PEERS 0x200u
 
 inline uint32_t op_control(uint32_t op) {   // host side: fills DevModel::optab
   // accepted-relation masks in the order EQ NE LT GE LE GT
@@ -61,6 +65,7 @@ inline uint32_t op_control(uint32_t op) {   // host side: fills DevModel::optab
   if (op == DEMI_OP_MOVHI) return CW_ALU;     // wide tables only, and those are never interpreted (jit.hpp emits it)
   if (op == DEMI_OP_LDX) return CW_ALU | CW_LDX;   // DEMI_MODEL_ARRAY tables only: compiled, never interpreted (jit.hpp)
   if (op == DEMI_OP_STX) return CW_STX;
+  if (op == DEMI_OP_PEER) return CW_ALU | CW_PEER;
   if (op >= DEMI_OP_IFEQ && op <= DEMI_OP_IFGT) return CW_IF | (rels[op - DEMI_OP_IFEQ] << CW_REL_SHIFT);
   return CW_HALT;   // unknown ops are rejected by validation
 }
@@ -333,8 +338,18 @@ __device__ inline uint32_t vm_run(const Tables& t, const LaneMem& mem, uint32_t 
 // run on that actor's state: r0..r7 = its fields, r15 = its id, everything else 0; hit = T0 != 0, key = T1.  A compiled table
 // brings it as generated code (jit.hpp: inv_prog_jit); the interpreter below runs it for the others.
 #if defined(DEMI_JIT_INV_PROG)
-__device__ inline uint32_t inv_prog_jit(const uint64_t* st, uint32_t actor, uint32_t& key);     // (generated: jit.hpp)
+__device__ inline uint32_t inv_prog_jit(const uint64_t* st, uint32_t actor, uint32_t& key, uint32_t exists, uint32_t n_actors);     // (generated: jit.hpp)
 #endif
+// DEMI_OP_PEER: field `f` (0..7; 8 = "is created") of actor `who` in this lane's state array; not a created actor: 0
+__device__ __forceinline__ uint32_t peer_field(const uint64_t* st, uint32_t who, uint32_t f, uint32_t exists, uint32_t n_actors) {
+  if (who >= n_actors || !((exists >> who) & 1u)) return 0u;
+  if (f >= 8u) return 1u;
+#ifdef DEMI_WIDE
+  return (uint32_t)(st[(ST_WORDS * who + (f >> 2)) * 64] >> (16 * (f & 3))) & 0xFFFFu;
+#else
+  return (uint32_t)(st[(ST_WORDS * who) * 64] >> (8 * f)) & 0xFFu;
+#endif
+}
 // the invariant's kind: a compile-time constant in a translation unit compiled for one table (the other kinds' code is not
 // even generated there), the loaded model's otherwise
 #ifdef DEMI_JIT_INV_KIND
@@ -374,6 +389,7 @@ __device__ inline uint32_t inv_prog_interp(const Tables& t, const uint64_t* st, 
     r |= cond & mask_of(cw, 10);
     const uint32_t mn = mask_of(cw, 12);
     r |= (((b & mn) | (a & ~mn)) ^ ((a ^ b) & ltm)) & mask_of(cw, 11);
+    if (cw & CW_PEER) r = peer_field(st, a, aux, t.exists, t.A);                                  // PEER (rare: a real branch)
     const uint32_t k8 = (dsti & 3u) * 8u;
     const uint32_t ins = 0x03020100u ^ ((((dsti & 3u) ^ 4u)) << k8);
     const uint32_t wsel = (cw & CW_ALU) ? (dsti >> 2) : 4u;
@@ -394,8 +410,7 @@ __device__ inline uint32_t inv_prog_interp(const Tables& t, const uint64_t* st, 
 // hit (non-zero = the actor counts) and key of one actor under a DEMI_INV_PROGRAM invariant
 __device__ __forceinline__ uint32_t inv_prog(const Tables& t, const uint64_t* st, uint32_t actor, uint32_t& key) {
 #if defined(DEMI_JIT_INV_PROG)
-  (void)t;
-  return inv_prog_jit(st, actor, key);
+  return inv_prog_jit(st, actor, key, t.exists, t.A);
 #elif !defined(DEMI_WIDE)
   return inv_prog_interp(t, st, actor, key);
 #else

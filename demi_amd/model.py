@@ -30,7 +30,10 @@ SRC, ME = Reg(14), Reg(15)              # sender id (15 = deadLetters), own id
 OPS = dict(HALT=0, MOV=1, ADD=2, SUB=3, AND=4, OR=5, XOR=6, SHL=7, SHR=8, BITSET=9, POPC=10,
            EQ=11, NE=12, LT=13, GE=14, LE=15, GT=16, MIN=17, MAX=18, MOVHI=19, SKIPZ=20, SKIPNZ=21, SKIP=22,
            SEND=24, BCAST=25, TSET=26, TREP=27, TCANCEL=28, CRASH=29, RND=30, IFEQ=32, IFNE=33, IFLT=34, IFGE=35, IFLE=36, IFGT=37,
-           LDX=38, STX=39)
+           LDX=38, STX=39, PEER=40)
+
+
+PEER_CREATED = 8     # Asm.peer(dst, actor, PEER_CREATED): is that actor created
 
 
 def row(op, dst=0, a=0, bimm=0, aux=0, b=0):
@@ -89,6 +92,15 @@ class Asm:
         assert isinstance(value, Reg)
         bimm, bv = self._b(index)
         self.rows.append(row(OPS["STX"], 0, int(value), bimm, 0, bv))
+        return self
+
+    def peer(self, dst, actor, field):
+        """DEMI_INV_PROGRAM rows only: dst = field `field` (0..7, or a field register F[k]) of the actor whose id is in register
+        `actor`; field 8 (PEER_CREATED) = 1 if that actor is created, else 0.  An id that is not a created actor reads 0."""
+        assert isinstance(dst, Reg) and isinstance(actor, Reg)
+        f = int(field)
+        assert 0 <= f <= 8
+        self.rows.append(row(OPS["PEER"], int(dst), int(actor), 0, f, 0))
         return self
 
     def rnd(self, dst, bound):

@@ -127,7 +127,10 @@ typedef enum {
                            226-229, 570).                                                                          */,
   /* Indexed state (DEMI_MODEL_ARRAY below): the actor's array - a log, a vote table - beside its eight fields. */
   DEMI_OP_LDX = 38,     /* dst = ARRAY[b]  (b register or immediate; an index >= the array's length reads 0)         */
-  DEMI_OP_STX = 39      /* ARRAY[b] = a    (an index >= the array's length stores nothing)                             */
+  DEMI_OP_STX = 39,     /* ARRAY[b] = a    (an index >= the array's length stores nothing)                             */
+  /* DEMI_INV_PROGRAM rows only: ANOTHER actor's state, so that an invariant can relate two actors by more than equal keys. */
+  DEMI_OP_PEER = 40     /* dst = field F[aux] (aux 0..7) of the actor whose id is in reg a; aux = 8: dst = 1 if that actor is
+                           created, else 0.  An id that is not a created actor reads 0.                                 */
 } demi_op;
 
 #define DEMI_ROW(op, dst, a, bimm, aux, b) \
@@ -150,7 +153,12 @@ typedef enum {
  * Only ALU, SKIP* and IF* rows (no effects, no RND).  inv_kind & 0xFF combines the actors as before: NEVER = some actor
  * counts; AT_MOST_ONE = two counting actors have equal keys; AGREE = the counting actors' keys differ - with the same
  * fingerprint layouts.  So an arbitrary predicate over one actor's state (ranges, bit tests, several fields, its id) and a
- * computed key replace `F[fa] == va` / `F[fb]`; relations between two actors beyond "equal keys" still need the JVM. */
+ * computed key replace `F[fa] == va` / `F[fb]`.  A program may also read the fields of the OTHER actors (DEMI_OP_PEER, actor id
+ * from a register or unrolled over the ids): "this actor is a leader and some created actor has a larger term", "my commit index
+ * exceeds what a majority has logged" - a relation between two (or all) actors, evaluated from each actor's point of view and
+ * combined as before.  (The hit of one actor then depends on the others' states: the kernels re-evaluate every actor at a
+ * check instead of only the receiver of the last delivery.)  What still needs the JVM: invariants over state the table does not
+ * model. */
 #define DEMI_INV_PROGRAM 0x100u
 
 typedef struct {

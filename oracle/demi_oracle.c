@@ -138,6 +138,10 @@ int orc_model_validate(const demi_model* m, char* err, size_t err_cap) {
         break;
       case DEMI_OP_CRASH:
         break;
+      case DEMI_OP_PEER:
+        if (!(m->inv_kind & DEMI_INV_PROGRAM) || pc < m->inv_fa) FAIL("PEER outside an invariant program");
+        if (aux > 8) FAIL("PEER reads field 0..7 or 8 (created)");
+        break;
       case DEMI_OP_LDX: case DEMI_OP_STX:
         if (!DEMI_MODEL_ARRAY_LEN(m->flags)) FAIL("row %u: LDX / STX in a model without DEMI_MODEL_ARRAY", pc);
         break;
@@ -203,16 +207,17 @@ int orc_trace_validate(const demi_model* m, const demi_ext_event* ev, uint32_t n
  * format).  Effects are returned in program order; the scheduler applies them in that order,
  * as Akka would call `!` / scheduleOnce / cancel inside receive (WeaveActor.aj:224-279).       */
 static int vm_run_at(const demi_model* m, uint32_t start, uint32_t me, uint64_t* state, uint8_t src, uint16_t p0, uint16_t p1,
-                     uint32_t exists_mask, orc_effect* fx, uint32_t fx_cap, orc_jrandom* app, uint16_t* regs_out);
+                     uint32_t exists_mask, orc_effect* fx, uint32_t fx_cap, orc_jrandom* app, uint16_t* regs_out, const uint64_t* all_states);
 int orc_vm_run(const demi_model* m, uint32_t me, uint64_t* state, uint8_t msg_type, uint8_t src,
                uint16_t p0, uint16_t p1, uint32_t exists_mask, orc_effect* fx, uint32_t fx_cap, orc_jrandom* app) {
   uint16_t start = m->handler_start[m->actor_class[me] * m->n_msg_types + msg_type];
   if (start == 0xFFFF) return 0;
-  return vm_run_at(m, start, me, state, src, p0, p1, exists_mask, fx, fx_cap, app, NULL);
+  return vm_run_at(m, start, me, state, src, p0, p1, exists_mask, fx, fx_cap, app, NULL, NULL);
 }
-/* the rows from `start` on; regs_out (may be NULL) receives the final register window */
+/* the rows from `start` on; regs_out (may be NULL) receives the final register window; all_states (invariant programs only):
+ * every actor's state, for DEMI_OP_PEER */
 static int vm_run_at(const demi_model* m, uint32_t start, uint32_t me, uint64_t* state, uint8_t src, uint16_t p0, uint16_t p1,
-                     uint32_t exists_mask, orc_effect* fx, uint32_t fx_cap, orc_jrandom* app, uint16_t* regs_out) {
+                     uint32_t exists_mask, orc_effect* fx, uint32_t fx_cap, orc_jrandom* app, uint16_t* regs_out, const uint64_t* all_states) {
   uint32_t nfx = 0, n_fx_rows = 0;
   /* the register window: 16 x u8, or 16 x u16 for DEMI_MODEL_WIDE (state = two words, four 16-bit fields each) */
   const int wide = (m->flags & DEMI_MODEL_WIDE) != 0;
@@ -259,6 +264,16 @@ static int vm_run_at(const demi_model* m, uint32_t start, uint32_t me, uint64_t*
       case DEMI_OP_STX:
         if (b < arr_len) arr[b / per] = (arr[b / per] & ~((uint64_t)M << (bits * (b % per)))) | ((uint64_t)a << (bits * (b % per)));
         break;
+      case DEMI_OP_PEER: {    /* invariant programs: field aux (8 = "is created") of actor a, 0 when a is not a created actor */
+        uint32_t v = 0;
+        if (all_states && a < m->n_actors && ((exists_mask >> a) & 1)) {
+          const uint32_t stw_ = (wide ? 2u : 1u) + (arr_len + per - 1) / per;
+          const uint64_t* ps = all_states + (size_t)stw_ * a;
+          v = aux >= 8 ? 1u : wide ? (uint32_t)(ps[aux >> 2] >> (16 * (aux & 3))) & 0xFFFFu : (uint32_t)(ps[0] >> (8 * aux)) & 0xFFu;
+        }
+        r[dst] = (uint16_t)v;
+        break;
+      }
       case DEMI_OP_SKIPZ: if (a == 0) pc += braw; break;
       case DEMI_OP_SKIPNZ: if (a != 0) pc += braw; break;
       case DEMI_OP_SKIP: pc += braw; break;
@@ -322,7 +337,7 @@ static inline uint32_t fldw(int wide, const uint64_t* st, uint32_t stw, uint32_t
 /* per actor: does it count ("hit") and under which key.  Descriptor: F[fa] == va (AGREE: F[fa] != 0), key F[fb].
  * DEMI_INV_PROGRAM: the rows from inv_fa on, run on a COPY of the actor's state with r15 = its id and everything else 0;
  * hit = T0 != 0, key = T1 (include/demi_gpu.h). */
-static void inv_actor(const demi_model* m, const uint64_t* st, uint32_t i, uint32_t* hit, uint32_t* key) {
+static void inv_actor(const demi_model* m, const uint64_t* st, uint32_t i, uint32_t* hit, uint32_t* key, uint32_t exists) {
   const int wide = (m->flags & DEMI_MODEL_WIDE) != 0;
   const uint32_t stw = model_stw(m);
   if (m->inv_kind & DEMI_INV_PROGRAM) {
@@ -331,7 +346,7 @@ static void inv_actor(const demi_model* m, const uint64_t* st, uint32_t i, uint3
     uint16_t r[16];
     orc_jrandom none;
     orc_jrandom_seed(&none, 0);
-    vm_run_at(m, m->inv_fa, i, copy, 0, 0, 0, 0, NULL, 0, &none, r);
+    vm_run_at(m, m->inv_fa, i, copy, 0, 0, 0, exists, NULL, 0, &none, r, st);
     *hit = r[8] != 0;
     *key = r[9];
     return;
@@ -347,7 +362,7 @@ uint32_t orc_invariant(const demi_model* m, const uint64_t* st, uint32_t exists)
   if ((m->inv_kind & 0xFFu) == DEMI_INV_NONE) return 0;
   for (uint32_t i = 0; i < A; i++) {
     hit[i] = 0; key[i] = 0;
-    if ((exists >> i) & 1) inv_actor(m, st, i, &hit[i], &key[i]);
+    if ((exists >> i) & 1) inv_actor(m, st, i, &hit[i], &key[i], exists);
     hits |= hit[i] << i;
   }
   switch (m->inv_kind & 0xFFu) {

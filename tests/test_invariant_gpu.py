@@ -50,10 +50,37 @@ def test_program_restating_the_descriptor_gives_the_same_verdicts(oracle, wide):
         ctx.close()
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_invariant_relating_two_actors_on_raft5(oracle):
+    """DEMI_OP_PEER: an invariant that relates two actors by more than an equal key - "a leader whose term is below the term of
+    some created actor" (a stale leader, NEVER) - on the bench workload: K1 interpreted and compiled, with interval checks, against
+    the oracle (whose PEER is pinned to a plain-Python evaluation in the CPU suite).  An actor's hit depends on the other actors'
+    states here, so K1 rebuilds its hit mask at every check instead of updating the receiver's bit per delivery."""
+    _, events, lim = raft5_config2()
+    stale = Asm().if_eq(M.ROLE, M.LEADER, "no")
+    for j in range(5):
+        stale.mov(M.T2, j).peer(M.T1, M.T2, M.PEER_CREATED).if_ne(M.T1, 0, "n%d" % j).peer(M.T1, M.T2, M.TERM)
+        stale.if_gt(M.T1, M.TERM, "n%d" % j).mov(M.T0, 1).label("n%d" % j)
+    stale.label("no").mov(M.T1, 0).halt()
+    model = M.raft_model(5, invariant=(T.INV_NEVER, stale))
+    ctx = _native.Context(0)
+    try:
+        for lim_ in (lim, T.Limits(lim.max_messages, 7, lim.p_max, 0, 0, 0)):
+            ref = oracle.random_explore(model, events, 20000, seed_base=SEED_BASE, limits=lim_, n_threads=os.cpu_count())
+            for jit in (False, True):
+                ctx.model_load(model.to_struct()); ctx.trace_load(events)
+                if jit:
+                    ctx.model_specialize()
+                assert_same(ctx.random_explore(20000, lim_, seed_base=SEED_BASE), ref)
+            assert 20 < (ref["flags"] & T.V_VIOLATION).sum() < 20000
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
 def test_random_program_invariants_through_every_kernel(oracle, seed):
     """Random tables with a random invariant program under each combining kind: K1 (interpreter and compiled), a recorded
-    violating execution, its replays (K2) and DPOR interleavings (K3) - verdicts equal the oracle's."""
+    violating execution, its replays (K2) and DPOR interleavings (K3) - verdicts equal the oracle's.  Seeds 5 and 6: programs
+    with DEMI_OP_PEER rows (other actors' fields)."""
     from tests.test_jit_cpu import _random_handler
     from tests.test_oracle_cpu import _random_pure_program
     from tests.test_k2_gpu import random_masks
@@ -62,9 +89,9 @@ def test_random_program_invariants_through_every_kernel(oracle, seed):
     h = {}
     for name, _ in MSGS:
         h[(0, name)] = _random_handler(rng, int(rng.integers(4, 16)), len(MSGS), few_effects=(name != "E"))
-    kind = [T.INV_AT_MOST_ONE, T.INV_NEVER, T.INV_AGREE, T.INV_AT_MOST_ONE][seed - 1]
+    kind = [T.INV_AT_MOST_ONE, T.INV_NEVER, T.INV_AGREE, T.INV_AT_MOST_ONE, T.INV_AT_MOST_ONE, T.INV_AGREE][seed - 1]
     model = M.build_model("rinv%d" % seed, 4, MSGS, h, [[int(x) for x in rng.integers(0, 4, 8)] for _ in range(4)],
-                          (kind, _random_pure_program(rng, int(rng.integers(4, 20)))))
+                          (kind, _random_pure_program(rng, int(rng.integers(4, 20)), peers=seed >= 5)))
     ev = [start(a) for a in range(4)]
     for i in range(10):
         ev.append(wait_quiescence() if i == 5 else send(int(rng.integers(0, 4)), 0, int(rng.integers(0, 256)), int(rng.integers(0, 256))))

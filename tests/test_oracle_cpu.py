@@ -586,8 +586,9 @@ def test_explicit_seeds_threads_and_determinism(oracle):
 
 
 # --------------------------------------------------------------------------- DEMI_INV_PROGRAM
-def _py_rows(code, start, regs, mask, sh):
-    """plain-Python run of pure rows (ALU / SKIP / IF) from `start`: the semantics include/demi_gpu.h states"""
+def _py_rows(code, start, regs, mask, sh, peers=None):
+    """plain-Python run of pure rows (ALU / SKIP / IF, PEER with peers = (per-actor field lists, exists mask)) from `start`: the
+    semantics include/demi_gpu.h states"""
     r = list(regs)
     pc = start
     while pc < len(code):
@@ -617,6 +618,10 @@ def _py_rows(code, start, regs, mask, sh):
         elif op == O["SKIPZ"]: pc += braw if a == 0 else 0
         elif op == O["SKIPNZ"]: pc += braw if a != 0 else 0
         elif op == O["SKIP"]: pc += braw
+        elif op == O["PEER"] and peers is not None:
+            fields, exists = peers
+            ok = a < len(fields) and (exists >> a) & 1
+            r[dst] = 0 if not ok else 1 if aux >= 8 else fields[a][aux]
         else: raise AssertionError("op %d in a pure program" % op)
     return r
 
@@ -629,7 +634,7 @@ def _py_invariant(model, fields, exists):
     for i in range(model.n_actors):
         if not (exists >> i) & 1:
             hit.append(0); key.append(0); continue
-        r = _py_rows(model.code, model.inv_fa, list(fields[i]) + [0] * 7 + [i], mask, sh)
+        r = _py_rows(model.code, model.inv_fa, list(fields[i]) + [0] * 7 + [i], mask, sh, peers=(fields, exists))
         hit.append(int(r[8] != 0)); key.append(r[9])
     hits = sum(h << i for i, h in enumerate(hit))
     kind = model.inv_kind & 0xFF
@@ -645,8 +650,9 @@ def _py_invariant(model, fields, exists):
     return 0
 
 
-def _random_pure_program(rng, n_rows):
-    """random ALU / SKIP / IF rows that end with values in T0 (hit) and T1 (key)"""
+def _random_pure_program(rng, n_rows, peers=False):
+    """random ALU / SKIP / IF rows (peers: and PEER rows - another actor's field, or whether it is created, the actor taken from
+    a register that may hold anything) that end with values in T0 (hit) and T1 (key)"""
     from tests.test_jit_cpu import _random_handler
     a = Asm()
     regs = [M.Reg(i) for i in range(16)]
@@ -657,7 +663,11 @@ def _random_pure_program(rng, n_rows):
             a.label(lab[0]); pending.remove(lab)
         k = int(rng.integers(0, 100))
         breg = lambda: regs[int(rng.integers(16))] if rng.integers(2) else int(rng.integers(256))
-        if k < 60:
+        if peers and k < 18:
+            if rng.integers(2):       # a valid id most of the time: (something) & 3, or the own id
+                a.and_(M.T3, regs[int(rng.integers(16))], 3)
+            a.peer(regs[int(rng.integers(8, 11))], M.T3 if rng.integers(4) else regs[int(rng.integers(16))], int(rng.integers(0, 9)))
+        elif k < 60:
             getattr(a, alu[int(rng.integers(len(alu)))])(regs[int(rng.integers(8, 12))] if rng.integers(3) else regs[int(rng.integers(12))],
                                                          regs[int(rng.integers(16))], breg())
         elif k < 70:
@@ -711,13 +721,25 @@ def test_program_invariants_equal_a_plain_python_evaluation(oracle, wide):
     assert oracle.model_validate(bad)[0] == T.ERR_INVALID_MODEL and "invariant program" in oracle.model_validate(bad)[1]
     bad = build_model("bad", 2, msgs, h, [[0] * 8] * 2, (T.INV_NONE, prog), wide=wide)
     assert oracle.model_validate(bad)[0] == T.ERR_INVALID_MODEL
+    # DEMI_OP_PEER: a relation between two actors - "a leader whose term is below the term of some created actor" (NEVER)
+    stale = Asm().if_eq(ROLE, 2, "no")
+    for j in range(4):
+        stale.mov(M.T2, j).peer(M.T1, M.T2, 8).if_ne(M.T1, 0, "n%d" % j).peer(M.T1, M.T2, 1).if_gt(M.T1, TERM, "n%d" % j).mov(M.T0, 1).label("n%d" % j)
+    stale.label("no").mov(M.T1, 0).halt()
+    pm = build_model("peer", 4, msgs, h, [[0] * 8] * 4, (T.INV_NEVER, stale), wide=wide)
+    assert oracle.model_validate(pm)[0] == 0
+    assert inv(pm, [S(2, 3, 0), S(0, 4, 0), S(0, 1, 0), S(2, 5, 0)], 15) == (2 << 24) | 0b0001       # leader 0 (term 3) sees term 4 / 5
+    assert inv(pm, [S(2, 3, 0), S(0, 4, 0), S(0, 1, 0), S(2, 5, 0)], 0b0101) == 0                    # ... but those actors do not exist
+    assert inv(pm, [S(2, 6, 0), S(0, 4, 0), S(0, 1, 0), S(2, 6, 0)], 15) == 0                        # nobody is ahead of a leader
+    bad = build_model("bad", 2, msgs, {(0, "E"): Asm().peer(M.T0, M.ME, 0)}, [[0] * 8] * 2, (T.INV_NEVER, prog), wide=wide)
+    assert oracle.model_validate(bad)[0] == T.ERR_INVALID_MODEL and "PEER" in oracle.model_validate(bad)[1]
     # random programs, random states
     rng = np.random.default_rng(5 + wide)
     hi = 65536 if wide else 256
     nonzero = 0
-    for trial in range(60):
+    for trial in range(90):
         kind = [T.INV_AT_MOST_ONE, T.INV_NEVER, T.INV_AGREE][trial % 3]
-        mm = build_model("rp", 5, msgs, h, [[0] * 8] * 5, (kind, _random_pure_program(rng, int(rng.integers(3, 25)))), wide=wide)
+        mm = build_model("rp", 5, msgs, h, [[0] * 8] * 5, (kind, _random_pure_program(rng, int(rng.integers(3, 25)), peers=trial >= 60)), wide=wide)
         assert oracle.model_validate(mm)[0] == 0
         for _ in range(40):
             fields = [[int(x) for x in rng.integers(0, hi if rng.integers(2) else 4, 8)] for _ in range(5)]
