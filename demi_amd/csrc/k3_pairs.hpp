@@ -101,6 +101,13 @@ __device__ __forceinline__ unsigned long long cand_pack(uint32_t round, uint32_t
   return ((unsigned long long)round << 40) | ((unsigned long long)(branch + 1) << 31) | (0x7FFFFFFFull - ordinal);
 }
 
+// occupied entries of the table (diagnostics, and what sizes it: DESIGN section 4 K3)
+__global__ __launch_bounds__(256) void k3_pairs_count(const PairEntry* tab, uint32_t mask, unsigned long long* out) {
+  unsigned long long n = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i <= mask; i += (size_t)gridDim.x * blockDim.x) n += tab[i].lo != 0;
+  if (n) atomicAdd(out, n);
+}
+
 // mark: the dequeued points' flipped pairs are explored (getNext, :1170-1172)
 __global__ __launch_bounds__(256) void k3_pairs_mark(const K3PairArgs a) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -50,6 +50,16 @@ static inline void arr_store(uint64_t* st, uint32_t a, uint32_t idx, uint32_t v)
   const uint64_t m = (uint64_t)((1u << ARR_BITS) - 1u) << (ARR_BITS * (idx % ARR_PER));
   w = (w & ~m) | (((uint64_t)v << (ARR_BITS * (idx % ARR_PER))) & m);
 }
+// DEMI_OP_PEER (sim_core.hpp peer_field): field f (8 = "is created") of actor `who`; not a created actor: 0
+static inline uint32_t peer_field(const uint64_t* st, uint32_t who, uint32_t f, uint32_t exists, uint32_t n_actors) {
+  if (who >= n_actors || !((exists >> who) & 1u)) return 0u;
+  if (f >= 8u) return 1u;
+#ifdef DEMI_WIDE
+  return (uint32_t)(st[(ST_WORDS * who + (f >> 2)) * 64] >> (16 * (f & 3))) & 0xFFFFu;
+#else
+  return (uint32_t)(st[(ST_WORDS * who) * 64] >> (8 * f)) & 0xFFu;
+#endif
+}
 static inline int __popc(uint32_t x) { return __builtin_popcount(x); }
 // DEMI_OP_RND: java.util.Random.nextInt(bound) on the application's generator (the device uses multiply-high magics for the
 // modulo; here the plain JDK algorithm - the results must agree)

@@ -350,7 +350,7 @@ def test_array_tables_through_the_code_generator(oracle, tmp_path, seed, wide, a
     if seed in (1, 3):
         try:
             size, kernel = _native.specialize_check(model.to_struct())
-            assert size > 10000 and kernel.count("k1_random_explore") == 8 and "k2_replay" in kernel and "k3_dpor" in kernel
+            assert size > 10000 and kernel.count("k1_random_explore") == 9 and "k2_replay" in kernel and "k3_dpor" in kernel
         except _native.DemiError as e:
             if "hiprtc not found" not in str(e):
                 raise
@@ -561,37 +561,42 @@ def test_no_specialised_kernel_touches_scratch_memory(tmp_path, wide):
 @pytest.mark.parametrize("wide", [False, True])
 def test_generated_invariant_program_equals_the_oracle(oracle, tmp_path, wide):
     """DEMI_INV_PROGRAM: the per-actor program as generated code (jit.hpp inv_prog_jit), compiled for the host, against the
-    oracle's row interpreter - hit and key of every actor on random states, random programs."""
+    oracle's row interpreter - hit and key of every actor on random states, random programs; the later trials with DEMI_OP_PEER
+    rows (the fields of the other actors, some of them not created)."""
     from tests.test_oracle_cpu import _random_pure_program, _py_rows
     rng = np.random.default_rng(21 + wide)
     msgs = [("E", T.MSG_EXTERNAL)]
     h = {(0, "E"): M.Asm().add(M.F[3], M.F[3], 1)}
     hi = 65536 if wide else 256
-    for trial in range(6):
-        model = M.build_model("ip%d" % trial, 5, msgs, h, [[0] * 8] * 5, (T.INV_AT_MOST_ONE, _random_pure_program(rng, int(rng.integers(4, 30)))), wide=wide)
+    for trial in range(9):
+        model = M.build_model("ip%d" % trial, 5, msgs, h, [[0] * 8] * 5,
+                              (T.INV_AT_MOST_ONE, _random_pure_program(rng, int(rng.integers(4, 30)), peers=trial >= 6)), wide=wide)
         src = _native.specialize_source(model.to_struct())
         assert "inv_prog_jit" in src
         cpp = tmp_path / ("inv%d_%d.cpp" % (trial, wide))
-        cpp.write_text('#include "%s"\n%s\nextern "C" uint32_t inv(const uint64_t* st, uint32_t actor, uint32_t* key) {\n'
-                       '  uint32_t k = 0; const uint32_t hit = demi::inv_prog_jit(st, actor, k); *key = k; return hit; }\n'
+        cpp.write_text('#include "%s"\n%s\nextern "C" uint32_t inv(const uint64_t* st, uint32_t actor, uint32_t* key, uint32_t exists) {\n'
+                       '  uint32_t k = 0; const uint32_t hit = demi::inv_prog_jit(st, actor, k, exists, 5); *key = k; return hit; }\n'
                        % (os.path.join(ROOT, "tests", "jit_host_shim.hpp"), src))
         so = tmp_path / ("inv%d_%d.so" % (trial, wide))
         subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-label", "-Wno-unused-variable"] +
                               (["-DDEMI_WIDE"] if wide else []) + ["-o", str(so), str(cpp)])
         L = C.CDLL(str(so))
-        L.inv.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+        L.inv.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32]
         L.inv.restype = C.c_uint32
         st = np.zeros(16 * 64, dtype=np.uint64)
         hits = 0
         for it in range(400):
             actor = int(rng.integers(5))
-            fields = [int(x) for x in rng.integers(0, hi if it % 2 else 5, 8)]
-            words = M.pack_state_wide(fields) if wide else [M.pack_state(fields)]
-            for k, wv in enumerate(words):
-                st[(len(words) * actor + k) * 64] = wv
+            allf = [[int(x) for x in rng.integers(0, hi if it % 2 else 5, 8)] for _ in range(5)]
+            exists = int(rng.integers(0, 32)) | (1 << actor)
+            fields = allf[actor]
+            for a_ in range(5):
+                words = M.pack_state_wide(allf[a_]) if wide else [M.pack_state(allf[a_])]
+                for k, wv in enumerate(words):
+                    st[(len(words) * a_ + k) * 64] = wv
             key = C.c_uint32(0)
-            hit = L.inv(st.ctypes.data, actor, C.byref(key))
-            r = _py_rows(model.code, model.inv_fa, fields + [0] * 7 + [actor], hi - 1, 15 if wide else 7)
+            hit = L.inv(st.ctypes.data, actor, C.byref(key), exists)
+            r = _py_rows(model.code, model.inv_fa, fields + [0] * 7 + [actor], hi - 1, 15 if wide else 7, peers=(allf, exists))
             assert (hit != 0) == (r[8] != 0) and (hit == 0 or key.value == r[9]), (trial, it, fields, hit, key.value, r[8], r[9])
             hits += hit != 0
         assert hits > 20 or trial > 0
