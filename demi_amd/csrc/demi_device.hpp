@@ -30,6 +30,7 @@ struct DevModel {
   uint32_t code[DEMI_MAX_CODE];
   uint64_t init_state_wide[2 * DEMI_MAX_ACTORS];   // DEMI_MODEL_WIDE: two words per actor (init_state is unused then)
   uint64_t tix_packed;      // timer index of message type t in bits 2t, 2t + 1 (what meta[t] >> 8 holds, without the table read)
+  uint32_t npay, pad_;      // DEMI_MODEL_PAYLOADS: payload fields per message (2 unless the table says otherwise)
 };
 
 // A translation unit compiled for a DEMI_MODEL_WIDE table (-DDEMI_WIDE, only ever by demi_model_specialize) sees 64-bit
@@ -58,16 +59,39 @@ constexpr uint32_t ST_WORDS = FLD_WORDS + ARR_WORDS;
 
 // ------------------------------------------------------------------ message word
 // type[4:0] | dst[7:5] | src[11:8] | p0[23:16] | p1[31:24]   (identical to the oracle's)
-// wide: type[4:0] | dst[7:5] | src[11:8] | p0[31:16] | p1[47:32]
+// wide: type[4:0] | dst[7:5] | src[11:8] | payload area[63:16]; field k of the area = bits [k * PAY_BITS, (k + 1) * PAY_BITS)
+// of it, NPAY fields of PAY_BITS = 16, 16, 12, 9, 8 bits for NPAY = 2 ... 6 (DEMI_MODEL_PAYLOADS, include/demi_gpu.h;
+// DEMI_JIT_NPAY from demi_model_specialize; the plain wide table is NPAY = 2: p0[31:16] | p1[47:32])
+#ifdef DEMI_JIT_NPAY
+constexpr uint32_t NPAY = DEMI_JIT_NPAY;
+#else
+constexpr uint32_t NPAY = 2;
+#endif
+constexpr uint32_t PAY_BITS = DEMI_PAYLOAD_BITS(NPAY);
+constexpr uint32_t PAY_MASK = (1u << PAY_BITS) - 1u;
 #ifdef DEMI_WIDE
+// the area of a message with the payload fields p0 .. p5 (each truncated to PAY_BITS; fields past NPAY are dropped)
+__device__ __forceinline__ uint64_t pay_area(uint32_t p0, uint32_t p1, uint32_t p2 = 0, uint32_t p3 = 0, uint32_t p4 = 0, uint32_t p5 = 0) {
+  uint64_t a = (uint64_t)(p0 & PAY_MASK) | ((uint64_t)(p1 & PAY_MASK) << PAY_BITS);
+  if (NPAY > 2) a |= (uint64_t)(p2 & PAY_MASK) << (2 * PAY_BITS);
+  if (NPAY > 3) a |= (uint64_t)(p3 & PAY_MASK) << (3 * PAY_BITS);
+  if (NPAY > 4) a |= (uint64_t)(p4 & PAY_MASK) << (4 * PAY_BITS);
+  if (NPAY > 5) a |= (uint64_t)(p5 & PAY_MASK) << (5 * PAY_BITS);
+  return a;
+}
+__device__ __forceinline__ word_t msg_word_area(uint32_t type, uint32_t src, uint32_t dst, uint64_t area) {
+  return (word_t)(type | (dst << 5) | (src << 8)) | ((word_t)area << 16);
+}
 __device__ __forceinline__ word_t msg_word(uint32_t type, uint32_t src, uint32_t dst, uint32_t p0, uint32_t p1) {
-  return (word_t)(type | (dst << 5) | (src << 8) | (p0 << 16)) | ((word_t)p1 << 32);
+  return msg_word_area(type, src, dst, pay_area(p0, p1));
 }
 __device__ __forceinline__ uint32_t w_type(word_t w) { return (uint32_t)w & 31u; }
 __device__ __forceinline__ uint32_t w_dst(word_t w) { return ((uint32_t)w >> 5) & 7u; }
 __device__ __forceinline__ uint32_t w_src(word_t w) { return ((uint32_t)w >> 8) & 15u; }
-__device__ __forceinline__ uint32_t w_p0(word_t w) { return (uint32_t)w >> 16; }
-__device__ __forceinline__ uint32_t w_p1(word_t w) { return (uint32_t)(w >> 32) & 0xFFFFu; }
+__device__ __forceinline__ uint64_t w_area(word_t w) { return w >> 16; }
+__device__ __forceinline__ uint32_t w_pay(word_t w, uint32_t k) { return k < NPAY ? (uint32_t)(w >> (16 + k * PAY_BITS)) & PAY_MASK : 0u; }
+__device__ __forceinline__ uint32_t w_p0(word_t w) { return w_pay(w, 0); }
+__device__ __forceinline__ uint32_t w_p1(word_t w) { return w_pay(w, 1); }
 #else
 __device__ __forceinline__ uint32_t msg_word(uint32_t type, uint32_t src, uint32_t dst, uint32_t p0, uint32_t p1) {
   return type | (dst << 5) | (src << 8) | (p0 << 16) | (p1 << 24);
@@ -77,6 +101,8 @@ __device__ __forceinline__ uint32_t w_dst(uint32_t w) { return (w >> 5) & 7u; }
 __device__ __forceinline__ uint32_t w_src(uint32_t w) { return (w >> 8) & 15u; }
 __device__ __forceinline__ uint32_t w_p0(uint32_t w) { return (w >> 16) & 255u; }
 __device__ __forceinline__ uint32_t w_p1(uint32_t w) { return w >> 24; }
+// (the "area" of a narrow word, as demi_rec_event stores it: p0 in bits 0..15, p1 in bits 16..31)
+__device__ __forceinline__ uint64_t w_area(uint32_t w) { return (uint64_t)(w_p0(w) | (w_p1(w) << 16)); }
 #endif
 
 // ------------------------------------------------------------------ java.util.Random

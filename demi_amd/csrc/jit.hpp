@@ -254,14 +254,18 @@ inline std::string generate_vm(const demi::DevModel& h, bool sched = false) {
     emit("\n#define DEMI_JIT_FXQ_SLOTS %uu\n", nq ? nq : 1u);
   }
   s += "namespace demi {\n";
+  // (PAY: the two payload operands of the row - or, for a table with DEMI_MODEL_PAYLOADS, the payload area with the staged
+  // fields P2.. packed in: fx_pack_area, sim_core.hpp)
+  const bool long_msg = h.npay > 2;
+  const char* fx_pack_fn = long_msg ? "fx_pack_area" : "fx_pack";
   if (fxs.ok)
     // an effect row fills its own slot of the schedule; only SEND / BCAST rows carry data (a timer row IS its slot)
-    s += "#define DEMI_FX_AT(SLOT, Q, OP, TYPE, TGT, P0, P1) { mem.fxq[(Q) * 64] = fx_pack(OP, TYPE, TGT, P0, P1); nfx |= 1u << (SLOT); }\n"
+    s += std::string("#define DEMI_FX_AT(SLOT, Q, OP, TYPE, TGT, ...) { mem.fxq[(Q) * 64] = ") + fx_pack_fn + "(OP, TYPE, TGT, __VA_ARGS__); nfx |= 1u << (SLOT); }\n"
          "#define DEMI_FX_MARK(SLOT) { nfx |= 1u << (SLOT); }\n";
   else
     // effect rows are recorded into the LDS effect queue in program order, exactly as vm_run does
-    s += "#define DEMI_FX(OP, TYPE, TGT, P0, P1) { if (nfx >= DEMI_FX_CAP) { flags |= DEMI_V_QUEUE_OVF; goto done; } "
-         "mem.fxq[nfx * 64] = fx_pack(OP, TYPE, TGT, P0, P1); nfx++; }\n";
+    s += std::string("#define DEMI_FX(OP, TYPE, TGT, ...) { if (nfx >= DEMI_FX_CAP) { flags |= DEMI_V_QUEUE_OVF; goto done; } "
+         "mem.fxq[nfx * 64] = ") + fx_pack_fn + "(OP, TYPE, TGT, __VA_ARGS__); nfx++; }\n";
   // A wide table (DevModel::wide) has 16-bit registers: the same statements with the masks of the wider window, the
   // state in two words, and 64-bit message / effect words (word_t of a -DDEMI_WIDE translation unit).
   const bool wide = h.wide != 0;
@@ -285,6 +289,8 @@ inline std::string generate_vm(const demi::DevModel& h, bool sched = false) {
   s += "  uint32_t r8 = 0, r9 = 0, r10 = 0, r11 = 0, r12 = w_p0(w), r13 = w_p1(w), r14 = w_src(w), r15 = me;\n";
   s += "  uint32_t nfx = 0;\n";
   s += "  (void)r8; (void)r9; (void)r10; (void)r11; (void)r12; (void)r13; (void)r14; (void)r15;\n";
+  if (long_msg) s += "  uint32_t q2 = 0, q3 = 0, q4 = 0, q5 = 0;   // DEMI_OP_PSET: the staged payload fields of the messages sent next\n"
+                     "  (void)q2; (void)q3; (void)q4; (void)q5;\n";
   // distinct handler starts
   std::vector<uint32_t> starts;
   for (uint32_t i = 0; i < h.n_classes * h.n_msg_types; i++) {
@@ -355,6 +361,7 @@ inline std::string generate_vm(const demi::DevModel& h, bool sched = false) {
       case DEMI_OP_MIN: snprintf(val, cap, "%s < %s ? %s : %s", a, b, a, b); break;
       case DEMI_OP_MAX: snprintf(val, cap, "%s < %s ? %s : %s", a, b, b, a); break;
       case DEMI_OP_PEER: snprintf(val, cap, "0u"); break;     // (invariant programs only: their rows are emitted by the loop further down)
+      case DEMI_OP_LDP: snprintf(val, cap, "w_pay(w, %s)", b); break;       // DEMI_MODEL_PAYLOADS (demi_device.hpp)
       case DEMI_OP_RND:      // (a wide table's bound is b & 0xFF: the magics cover 1..256)
         if (wide) snprintf(val, cap, "app_next_int(app_rng, %s & 255u, t.gmagic)", b);
         else snprintf(val, cap, "app_next_int(app_rng, %s, t.gmagic)", b);
@@ -395,13 +402,18 @@ inline std::string generate_vm(const demi::DevModel& h, bool sched = false) {
       emit("goto %s;\n", target(pc + 1 + braw).c_str());
     } else if (cw & CW_STX) {
       emit("arr_store(mem.st, me, %s, %s);\n", b, a);
+    } else if (cw & CW_PSET) {
+      emit("q%u = %s;\n", aux >= 2 && aux <= 5 ? aux : 2u, b);
     } else {   // CW_FX: recorded now, applied after the rows have run (same record as vm_run)
+      char pay[96];
+      if (long_msg) snprintf(pay, sizeof pay, "pay_area(%s, %s, q2, q3, q4, q5)", d, b);
+      else snprintf(pay, sizeof pay, "%s, %s", d, b);
       if (fxs.ok && (fxs.cls[fxs.slot[pc]] >> 16) != FXK_SEND)
         emit("DEMI_FX_MARK(%d)%s\n", fxs.slot[pc], (cw & CW_HALT) ? " goto done;" : "");
       else if (fxs.ok)
-        emit("DEMI_FX_AT(%d, %uu, %uu, %uu, %s > 15u ? 15u : %s, %s, %s)\n", fxs.slot[pc], fxq_of_slot[fxs.slot[pc]], row & 0xFFu, aux, a, a, d, b);
+        emit("DEMI_FX_AT(%d, %uu, %uu, %uu, %s > 15u ? 15u : %s, %s)\n", fxs.slot[pc], fxq_of_slot[fxs.slot[pc]], row & 0xFFu, aux, a, a, pay);
       else
-        emit("DEMI_FX(%uu, %uu, %s > 15u ? 15u : %s, %s, %s)%s\n", row & 0xFFu, aux, a, a, d, b, (cw & CW_HALT) ? " goto done;" : "");
+        emit("DEMI_FX(%uu, %uu, %s > 15u ? 15u : %s, %s)%s\n", row & 0xFFu, aux, a, a, pay, (cw & CW_HALT) ? " goto done;" : "");
     }
   }
   s += "  done:\n";

@@ -363,14 +363,15 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
   uint64_t b_next = 0, b_end = 0;
   bool exhausted = false;
 
-#define REC_PUSH(KIND, SND, RCV, TYPE, P0, P1, FL, EXT, ID)                                   \
+#define REC_PUSH(KIND, SND, RCV, TYPE, AREA, FL, EXT, ID)  /* AREA: demi_rec_event's p0 | p1 << 16 | p_hi << 32 */ \
   do {                                                                                        \
     if (REC) {                                                                                \
       if (n_rec < args.rec_cap) {                                                             \
         demi_rec_event e_;                                                                    \
         e_.kind = (uint8_t)(KIND); e_.snd = (uint8_t)(SND); e_.rcv = (uint8_t)(RCV);          \
-        e_.msg_type = (uint8_t)(TYPE); e_.p0 = (uint16_t)(P0); e_.p1 = (uint16_t)(P1);        \
-        e_.flags = (uint8_t)(FL); e_.ext_idx = (uint8_t)(EXT); e_.reserved = 0; e_.id = (ID); \
+        const uint64_t ar_ = (uint64_t)(AREA);                                                \
+        e_.msg_type = (uint8_t)(TYPE); e_.p0 = (uint16_t)ar_; e_.p1 = (uint16_t)(ar_ >> 16);  \
+        e_.flags = (uint8_t)(FL); e_.ext_idx = (uint8_t)(EXT); e_.p_hi = (uint16_t)(ar_ >> 32); e_.id = (ID); \
         rec[n_rec] = e_;                                                                      \
       }                                                                                       \
       n_rec++;                                                                                \
@@ -600,19 +601,19 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
           const uint64_t ev = t.trace[tidx];
           const uint32_t kind = (uint32_t)ev & 0xFF, a = (uint32_t)(ev >> 8) & 0xFF, b = (uint32_t)(ev >> 16) & 0xFF;
           if (kind == DEMI_EV_START) {
-            REC_PUSH(DEMI_REC_SPAWN, 0, a, 0, 0, 0, 0, tidx, 0);
+            REC_PUSH(DEMI_REC_SPAWN, 0, a, 0, 0, 0, tidx, 0);
             net.inaccessible &= ~(1u << a); net.killed &= ~(1u << a); blocked &= ~(1u << a);
           } else if (kind == DEMI_EV_KILL) {
-            REC_PUSH(DEMI_REC_KILL, 0, a, 0, 0, 0, 0, tidx, 0);
+            REC_PUSH(DEMI_REC_KILL, 0, a, 0, 0, 0, tidx, 0);
             net.killed |= 1u << a; net.inaccessible |= 1u << a;
           } else if (kind == DEMI_EV_PARTITION) {
-            REC_PUSH(DEMI_REC_PARTITION, a, b, 0, 0, 0, 0, tidx, 0);
+            REC_PUSH(DEMI_REC_PARTITION, a, b, 0, 0, 0, tidx, 0);
             net.partitioned |= 1ULL << (a * 8 + b);
           } else if (kind == DEMI_EV_UNPARTITION) {
-            REC_PUSH(DEMI_REC_UNPARTITION, a, b, 0, 0, 0, 0, tidx, 0);
+            REC_PUSH(DEMI_REC_UNPARTITION, a, b, 0, 0, 0, tidx, 0);
             net.partitioned &= ~(1ULL << (a * 8 + b));
           } else if (kind == DEMI_EV_WAIT_QUIESCENCE) {
-            REC_PUSH(DEMI_REC_BEGIN_WAIT_QUIESCENCE, 0, 0, 0, 0, 0, 0, tidx, 0);
+            REC_PUSH(DEMI_REC_BEGIN_WAIT_QUIESCENCE, 0, 0, 0, 0, 0, tidx, 0);
             loop = false;
           }
           tidx++;
@@ -687,7 +688,7 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
           if (sw != 0) {
             const uint32_t id = next_id; next_id++;
             PEND_APPEND(sw, id, -1);
-            REC_PUSH(DEMI_REC_MSG_SEND, DEMI_DEADLETTERS, w_dst(sw), w_type(sw), w_p0(sw), w_p1(sw), 1, i, id);
+            REC_PUSH(DEMI_REC_MSG_SEND, DEMI_DEADLETTERS, w_dst(sw), w_type(sw), w_area(sw), 1, i, id);
           }
         }
         inj_lo = inj_hi;
@@ -699,7 +700,7 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
         const uint32_t id = next_id; if (REC) next_id++;
         const bool drop = (net.inaccessible >> rcv) & 1;
         if (!drop) PEND_APPEND(msg_word(type, DEMI_DEADLETTERS, rcv, 0, 0), id, (int32_t)(rcv * NTT + tix_of(type)));
-        REC_PUSH(DEMI_REC_MSG_SEND, DEMI_DEADLETTERS, rcv, type, 0, 0, 2 | (drop ? 4 : 0), 255, id);
+        REC_PUSH(DEMI_REC_MSG_SEND, DEMI_DEADLETTERS, rcv, type, 0, 2 | (drop ? 4 : 0), 255, id);
       }
       tq = 0; n_tq = 0;
       if ((flags & DEMI_OVF_ANY) || n_pend + n_norm == 0) none = true;
@@ -820,7 +821,7 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
         count++;
         cnt_mod++; if (cnt_mod == interval) cnt_mod = 0;
         const uint32_t type = w_type(w), me = w_dst(w);
-        REC_PUSH(DEMI_REC_MSG_EVENT, w_src(w), me, type, w_p0(w), w_p1(w), 0, 255, wid);
+        REC_PUSH(DEMI_REC_MSG_EVENT, w_src(w), me, type, w_area(w), 0, 255, wid);
         hash_step(hash, w);
         // updateRepeatingTimer (:405-421) and the Instrumenter's retrigger (Instrumenter.scala:1008-1016)
         const uint32_t tbit = TIMER_BIT(me, type);
@@ -843,7 +844,7 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
         if ((flags & DEMI_OVF_ANY) || viol || tidx >= E) {
           ph = PH_FINISH;
         } else {
-          REC_PUSH(DEMI_REC_QUIESCENCE, 0, 0, 0, 0, 0, 0, 255, 0);
+          REC_PUSH(DEMI_REC_QUIESCENCE, 0, 0, 0, 0, 0, 255, 0);
           ph = PH_INJECT;
         }
       }
@@ -947,7 +948,7 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
     // event_produced for internal messages (:287-297): dropped at send time when crosses_partition, else appended
     auto apply_send = [&](word_t fxw) {
       const uint32_t fx = (uint32_t)fxw;
-      const uint32_t type = (fx >> 5) & 31u, p0 = fx_p0(fxw), p1 = fx_p1(fxw);
+      const uint32_t type = (fx >> 5) & 31u;
       if (REC) {
         const bool bc = ((fx & 31u) == DEMI_OP_BCAST);
         const uint32_t target = (fx >> 10) & 15u;
@@ -957,14 +958,14 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
           const uint32_t id = next_id; next_id++;
           const bool drop = crosses_partition(net, me, r);
           if (!drop) {
-            if (FIFO) NORM_APPEND(msg_word(type, me, r, p0, p1), id);
-            else PEND_APPEND(msg_word(type, me, r, p0, p1), id, -1);
+            if (FIFO) NORM_APPEND(fx_msg_word(fxw, type, me, r), id);
+            else PEND_APPEND(fx_msg_word(fxw, type, me, r), id, -1);
           }
-          REC_PUSH(DEMI_REC_MSG_SEND, me, r, type, p0, p1, drop ? 4 : 0, 255, id);
+          REC_PUSH(DEMI_REC_MSG_SEND, me, r, type, fx_area(fxw), drop ? 4 : 0, 255, id);
         }
       } else {
         uint32_t tm = send_targets(fx);
-        const word_t base = msg_word(type, me, 0, p0, p1);
+        const word_t base = fx_msg_word(fxw, type, me, 0);
         while (tm) {
           const uint32_t r = (uint32_t)__builtin_ctz(tm);
           tm &= tm - 1;

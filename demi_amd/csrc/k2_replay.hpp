@@ -79,8 +79,8 @@ struct K2Args {
   uint8_t* fp_counts;       // K2_FP_HBM: [n_fp][resident lanes] counters
   uint32_t lockstep;        // 1: the lanes of a wave walk the expected events together (k2 lock-step loop below)
   unsigned long long* phase_out;   // -DDEMI_K2_PHASES builds only (tools/k2_phases.sh): [waves][16] cycle totals per phase
-  const uint16_t* exp_hi;   // DEMI_MODEL_WIDE tables only: [n_exp] bits 8..15 of p0 | bits 8..15 of p1 << 8 (the 8-byte expected
-                            // event holds the low bytes)
+  const uint64_t* exp_area; // DEMI_MODEL_WIDE tables only: [n_exp] the 48-bit payload area of the expected event's message
+                            // (demi_rec_event p0 | p1 << 16 | p_hi << 32; the 8-byte expected event has room for two bytes)
 };
 
 constexpr int K2_WAVES = 4;
@@ -228,9 +228,12 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
 #define IN_MASK(I) ((uint32_t)((((((I) >> 6) & 3u) == 0u ? m0 : 0ull) | ((((I) >> 6) & 3u) == 1u ? m1 : 0ull) | \
                                 ((((I) >> 6) & 3u) == 2u ? m2 : 0ull) | ((((I) >> 6) & 3u) == 3u ? m3 : 0ull)) >> ((I) & 63u)) & 1u)
 #define TIMER_BIT(RCV, TYPE) (1u << ((RCV) * DEMI_MAX_TIMER_TYPES + (t.meta[(TYPE)] >> 8)))
-// payload fields of expected event E at index I (a wide table's upper bytes come from exp_hi)
-#define EXP_P0(E, I) (((uint32_t)((E) >> 32) & 0xFFu) | (WIDE_TU ? ((uint32_t)args.exp_hi[(I)] & 0xFFu) << 8 : 0u))
-#define EXP_P1(E, I) (((uint32_t)((E) >> 40) & 0xFFu) | (WIDE_TU ? ((uint32_t)args.exp_hi[(I)] >> 8) << 8 : 0u))
+// the message word of expected event E at index I, from SRC to DST (a wide table's payload area comes from exp_area)
+#ifdef DEMI_WIDE
+#define EXP_WORD(E, I, SRC, DST) msg_word_area((uint32_t)((E) >> 24) & 0xFF, (SRC), (DST), args.exp_area[(I)])
+#else
+#define EXP_WORD(E, I, SRC, DST) msg_word((uint32_t)((E) >> 24) & 0xFF, (SRC), (DST), (uint32_t)((E) >> 32) & 0xFFu, (uint32_t)((E) >> 40) & 0xFFu)
+#endif
 // FP: FPID is the word's id if the caller knows it, else it is looked up; a word without an id only takes up capacity
 #define PEND_APPEND_ID(WORD, FPID)                                     \
   do {                                                                 \
@@ -433,7 +436,7 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
         }
         if (kind == DEMI_REC_MSG_SEND) {
           if (active && IN_MASK(ext) && ((exists >> b) & 1)) {
-            PEND_APPEND_ID(msg_word((uint32_t)(e >> 24) & 0xFF, DEMI_DEADLETTERS, b, EXP_P0(e, idx - 1), EXP_P1(e, idx - 1)),
+            PEND_APPEND_ID(EXP_WORD(e, idx - 1, DEMI_DEADLETTERS, b),
                            FP ? fp_cur : K2_FP_NONE);
             if (args.kept && !(flags & DEMI_OVF_ANY)) args.kept[sched * NX + idx - 1] = 1;
             if (flags & DEMI_OVF_ANY) active = false;
@@ -441,7 +444,7 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
           continue;
         }
         // ---- MSG_EVENT: which lanes deliver it
-        const word_t want = msg_word((uint32_t)(e >> 24) & 0xFF, a, b, EXP_P0(e, idx - 1), EXP_P1(e, idx - 1));
+        const word_t want = EXP_WORD(e, idx - 1, a, b);
         bool deliver = false;
         if (active) {
           do {
@@ -489,13 +492,13 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
           for (uint32_t k = 0; k < nfx && !(flags & DEMI_OVF_ANY); k++) {
             const word_t fxw = mem.fxq[k * 64];
             const uint32_t fx = (uint32_t)fxw;
-            const uint32_t op = fx & 31u, ftype = (fx >> 5) & 31u, target = (fx >> 10) & 15u, p0 = fx_p0(fxw), p1 = fx_p1(fxw);
+            const uint32_t op = fx & 31u, ftype = (fx >> 5) & 31u, target = (fx >> 10) & 15u;
             if (op <= DEMI_OP_BCAST) {
               const bool bc = (op == DEMI_OP_BCAST);
               const uint32_t first = bc ? 0u : target, last = bc ? A : (target < A ? target + 1 : 0u);
               for (uint32_t r = first; r < last; r++) {
                 if ((bc && r == me) || !((exists >> r) & 1)) continue;
-                if (!crosses_partition(net, me, r)) PEND_APPEND(msg_word(ftype, me, r, p0, p1));
+                if (!crosses_partition(net, me, r)) PEND_APPEND(fx_msg_word(fxw, ftype, me, r));
               }
             } else if (op == DEMI_OP_CRASH) {
               blocked |= 1u << me;
@@ -648,7 +651,7 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
         } else if (kind == DEMI_REC_MSG_SEND) {
           // external MsgSend -> enqueue_message (:509-511) unless its Send was pruned
           if (IN_MASK(ext) && ((exists >> b) & 1)) {
-            PEND_APPEND_ID(msg_word((uint32_t)(e >> 24) & 0xFF, DEMI_DEADLETTERS, b, EXP_P0(e, idx - 1), EXP_P1(e, idx - 1)),
+            PEND_APPEND_ID(EXP_WORD(e, idx - 1, DEMI_DEADLETTERS, b),
                            FP ? (uint32_t)exp_fp[idx - 1] : K2_FP_NONE);
             if (args.kept && !(flags & DEMI_OVF_ANY)) args.kept[sched * NX + idx - 1] = 1;
           }
@@ -661,7 +664,7 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
             if (!(fk_alive(b) && !fk_cut(a, b) && sent)) continue;
           }
           if ((blocked >> b) & 1u) { ignored++; continue; }   // the destination is blocked: not deliverable (:392-402), ignored
-          const word_t want = msg_word((uint32_t)(e >> 24) & 0xFF, a, b, EXP_P0(e, idx - 1), EXP_P1(e, idx - 1));
+          const word_t want = EXP_WORD(e, idx - 1, a, b);
           if (FP) {
             const uint32_t f = exp_fp[idx - 1];
             if (cnt_get(f) == 0) { ignored++; continue; }     // "Ignoring message" (:528-529)
@@ -701,13 +704,13 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
       for (uint32_t k = 0; k < nfx && !(flags & DEMI_OVF_ANY); k++) {
         const word_t fxw = mem.fxq[k * 64];
         const uint32_t fx = (uint32_t)fxw;
-        const uint32_t op = fx & 31u, type = (fx >> 5) & 31u, target = (fx >> 10) & 15u, p0 = fx_p0(fxw), p1 = fx_p1(fxw);
+        const uint32_t op = fx & 31u, type = (fx >> 5) & 31u, target = (fx >> 10) & 15u;
         if (op <= DEMI_OP_BCAST) {
           const bool bc = (op == DEMI_OP_BCAST);
           const uint32_t first = bc ? 0u : target, last = bc ? A : (target < A ? target + 1 : 0u);
           for (uint32_t r = first; r < last; r++) {
             if ((bc && r == me) || !((exists >> r) & 1)) continue;
-            if (!crosses_partition(net, me, r)) PEND_APPEND(msg_word(type, me, r, p0, p1));
+            if (!crosses_partition(net, me, r)) PEND_APPEND(fx_msg_word(fxw, type, me, r));
           }
         } else if (op == DEMI_OP_CRASH) {
           blocked |= 1u << me;                 // actorCrashed (Instrumenter.scala:184-199)
@@ -775,8 +778,7 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
     }
   }
 #undef IN_MASK
-#undef EXP_P0
-#undef EXP_P1
+#undef EXP_WORD
 #undef TIMER_BIT
 #undef PEND_APPEND
 #undef PEND_APPEND_ID

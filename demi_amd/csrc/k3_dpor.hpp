@@ -452,13 +452,13 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
       for (uint32_t k = 0; k < nfx && !(flags & DEMI_OVF_ANY); k++) {
         const word_t fxw = mem.fxq[k * 64];
         const uint32_t fx = (uint32_t)fxw;
-        const uint32_t op = fx & 31u, type = (fx >> 5) & 31u, target = (fx >> 10) & 15u, p0 = fx_p0(fxw), p1 = fx_p1(fxw);
+        const uint32_t op = fx & 31u, type = (fx >> 5) & 31u, target = (fx >> 10) & 15u;
         if (op <= DEMI_OP_BCAST) {
           const bool bc = (op == DEMI_OP_BCAST);
           const uint32_t first = bc ? 0u : target, last = bc ? A : (target < A ? target + 1 : 0u);
           for (uint32_t r = first; r < last; r++) {
             if (bc && r == me) continue;
-            produce(msg_word(type, me, r, p0, p1));
+            produce(fx_msg_word(fxw, type, me, r));
           }
         } else if (op == DEMI_OP_CRASH) {
           blocked |= 1u << me;                 // actorCrashed (Instrumenter.scala:184-199)

@@ -33,7 +33,8 @@ enum : uint32_t {
   CW_REL_SHIFT = 20,     // bits 20..22: accepted relations {lt, eq, gt} of compare / guard rows
   CW_RND = 1u << 23,     // dst = seededRandom.nextInt(b)
   CW_LDX = 1u << 24, CW_STX = 1u << 25,    // dst = ARRAY[b] / ARRAY[b] = a (DEMI_MODEL_ARRAY)
-  CW_PEER = 1u << 26                       // dst = a field of another actor (invariant programs only)
+  CW_PEER = 1u << 26,                      // dst = a field of another actor (invariant programs only)
+  CW_LDP = 1u << 27, CW_PSET = 1u << 28    // dst = payload field b / staged payload field aux = b (DEMI_MODEL_PAYLOADS: compiled only)
 };
 // DevModel::inv_kind, set by the host when the invariant's program has a DEMI_OP_PEER row: an actor's hit depends on the other
 // actors' states, so K1's incrementally maintained hit mask is rebuilt at every check instead
@@ -66,6 +67,8 @@ inline uint32_t op_control(uint32_t op) {   // host side: fills DevModel::optab
   if (op == DEMI_OP_LDX) return CW_ALU | CW_LDX;   // DEMI_MODEL_ARRAY tables only: compiled, never interpreted (jit.hpp)
   if (op == DEMI_OP_STX) return CW_STX;
   if (op == DEMI_OP_PEER) return CW_ALU | CW_PEER;
+  if (op == DEMI_OP_LDP) return CW_ALU | CW_LDP;   // (the interpreter never sees one: validation wants DEMI_MODEL_PAYLOADS, a wide table)
+  if (op == DEMI_OP_PSET) return CW_PSET;
   if (op >= DEMI_OP_IFEQ && op <= DEMI_OP_IFGT) return CW_IF | (rels[op - DEMI_OP_IFEQ] << CW_REL_SHIFT);
   return CW_HALT;   // unknown ops are rejected by validation
 }
@@ -226,19 +229,30 @@ __device__ __forceinline__ void aux_store(const LaneMem& m, uint32_t slot, uint3
 
 // ------------------------------------------------------------------ row interpreter
 // effect word recorded per effect row: op[4:0] | type[9:5] | target[13:10] | p0[21:14] | p1[29:22]
-// wide: the same with p0[29:14] | p1[45:30]
+// wide: op[4:0] | type[9:5] | target[13:10] | payload area[61:14] (demi_device.hpp pay_area: p0[29:14] | p1[45:30] for the two
+// fields of a plain wide table)
 #ifdef DEMI_WIDE
-__device__ __forceinline__ word_t fx_pack(uint32_t op, uint32_t type, uint32_t target, uint32_t p0, uint32_t p1) {
-  return (word_t)((op & 31u) | (type << 5) | (target << 10)) | ((word_t)(p0 & 0xFFFFu) << 14) | ((word_t)(p1 & 0xFFFFu) << 30);
+__device__ __forceinline__ word_t fx_pack_area(uint32_t op, uint32_t type, uint32_t target, uint64_t area) {
+  return (word_t)((op & 31u) | (type << 5) | (target << 10)) | ((word_t)area << 14);
 }
-__device__ __forceinline__ uint32_t fx_p0(word_t fx) { return (uint32_t)(fx >> 14) & 0xFFFFu; }
-__device__ __forceinline__ uint32_t fx_p1(word_t fx) { return (uint32_t)(fx >> 30) & 0xFFFFu; }
+__device__ __forceinline__ word_t fx_pack(uint32_t op, uint32_t type, uint32_t target, uint32_t p0, uint32_t p1) {
+  return fx_pack_area(op, type, target, pay_area(p0, p1));
+}
+__device__ __forceinline__ uint64_t fx_area(word_t fx) { return (fx >> 14) & 0xFFFFFFFFFFFFull; }
+// the message an effect word sends: type / payload from the word, sender and receiver from the caller
+__device__ __forceinline__ word_t fx_msg_word(word_t fx, uint32_t type, uint32_t src, uint32_t dst) {
+  return msg_word_area(type, src, dst, fx_area(fx));
+}
 #else
 __device__ __forceinline__ uint32_t fx_pack(uint32_t op, uint32_t type, uint32_t target, uint32_t p0, uint32_t p1) {
   return (op & 31u) | (type << 5) | (target << 10) | (p0 << 14) | (p1 << 22);
 }
 __device__ __forceinline__ uint32_t fx_p0(uint32_t fx) { return (fx >> 14) & 0xFFu; }
 __device__ __forceinline__ uint32_t fx_p1(uint32_t fx) { return (fx >> 22) & 0xFFu; }
+__device__ __forceinline__ uint64_t fx_area(uint32_t fx) { return (uint64_t)(fx_p0(fx) | (fx_p1(fx) << 16)); }
+__device__ __forceinline__ uint32_t fx_msg_word(uint32_t fx, uint32_t type, uint32_t src, uint32_t dst) {
+  return msg_word(type, src, dst, fx_p0(fx), fx_p1(fx));
+}
 #endif
 
 // 16 x u8 register window held in four VGPRs: w0,w1 = r0..r7 (state), w2,w3 = r8..r15 (temps, payload,

@@ -30,7 +30,7 @@ SRC, ME = Reg(14), Reg(15)              # sender id (15 = deadLetters), own id
 OPS = dict(HALT=0, MOV=1, ADD=2, SUB=3, AND=4, OR=5, XOR=6, SHL=7, SHR=8, BITSET=9, POPC=10,
            EQ=11, NE=12, LT=13, GE=14, LE=15, GT=16, MIN=17, MAX=18, MOVHI=19, SKIPZ=20, SKIPNZ=21, SKIP=22,
            SEND=24, BCAST=25, TSET=26, TREP=27, TCANCEL=28, CRASH=29, RND=30, IFEQ=32, IFNE=33, IFLT=34, IFGE=35, IFLE=36, IFGT=37,
-           LDX=38, STX=39, PEER=40)
+           LDX=38, STX=39, PEER=40, LDP=41, PSET=42)
 
 
 PEER_CREATED = 8     # Asm.peer(dst, actor, PEER_CREATED): is that actor created
@@ -142,15 +142,35 @@ class Asm:
         self._labels[name] = len(self.rows)
         return self
 
-    def send(self, msg_type, target, p0=0, p1=0):
-        """`target ! Msg(p0, p1)`; p0 must be a register (use a temp for constants)."""
+    def ldp(self, dst, k):
+        """dst = payload field k (0..5) of the message being handled (DEMI_MODEL_PAYLOADS; P0 / P1 are also registers)."""
+        assert isinstance(dst, Reg) and 0 <= int(k) < T.MAX_PAYLOADS
+        self.rows.append(row(OPS["LDP"], int(dst), 0, 1, 0, int(k)))
+        return self
+
+    def pset(self, k, value):
+        """Payload field k (2..5) of the messages sent next = value (register or immediate); kept until overwritten."""
+        assert 2 <= int(k) < T.MAX_PAYLOADS
+        bimm, bv = self._b(value)
+        self.rows.append(row(OPS["PSET"], 0, 0, bimm, int(k), bv))
+        return self
+
+    def _more(self, more):
+        for k, v in enumerate(more):
+            self.pset(2 + k, v)
+
+    def send(self, msg_type, target, p0=0, p1=0, *more):
+        """`target ! Msg(p0, p1, ...)`; p0 must be a register (use a temp for constants).  Further fields (a table with
+        DEMI_MODEL_PAYLOADS) are staged with PSET rows in front of the SEND."""
         assert isinstance(target, Reg) and isinstance(p0, Reg)
+        self._more(more)
         bimm, bv = self._b(p1)
         self.rows.append(row(OPS["SEND"], int(p0), int(target), bimm, msg_type, bv))
         return self
 
-    def bcast(self, msg_type, p0, p1=0):
+    def bcast(self, msg_type, p0, p1=0, *more):
         assert isinstance(p0, Reg)
+        self._more(more)
         bimm, bv = self._b(p1)
         self.rows.append(row(OPS["BCAST"], int(p0), 0, bimm, msg_type, bv))
         return self
@@ -226,6 +246,7 @@ class Model:
     fp_match_mask: int = 0xFFFFFFFF
     wide: bool = False                # DEMI_MODEL_WIDE: 16 x u16 register window
     array_len: int = 0                # DEMI_MODEL_ARRAY: elements of every actor's array (LDX / STX), 0 = none
+    payloads: int = 2                 # DEMI_MODEL_PAYLOADS: payload fields per message (3..6 need a wide table)
     _keep: list = field(default_factory=list, repr=False, compare=False)
 
     @property
@@ -254,7 +275,7 @@ class Model:
                           C.cast(hs, C.POINTER(C.c_uint16)), C.cast(code, C.POINTER(C.c_uint32)),
                           C.cast(init, C.POINTER(C.c_uint64)),
                           self.inv_kind, self.inv_fa, self.inv_va, self.inv_fb, self.fp_match_mask,
-                          (T.MODEL_WIDE if self.wide else 0) | T.MODEL_ARRAY(self.array_len))
+                          (T.MODEL_WIDE if self.wide else 0) | T.MODEL_ARRAY(self.array_len) | T.MODEL_PAYLOADS(self.payloads))
         self._keep = [mc, ac, hs, code, init]   # keep the buffers alive as long as the Model
         return s
 
@@ -266,6 +287,8 @@ class Model:
             d["wide"] = True
         if self.array_len:
             d["array_len"] = self.array_len
+        if self.payloads != 2:
+            d["payloads"] = self.payloads
         return d
 
     @staticmethod
@@ -290,9 +313,9 @@ def pack_state_wide(fields: List[int]) -> List[int]:
 
 
 def build_model(name, n_actors, msgs, handlers, init_fields, invariant, actor_class=None, n_classes=1,
-                fp_match_mask=0xFFFFFFFF, wide=False, array_len=0) -> Model:
+                fp_match_mask=0xFFFFFFFF, wide=False, array_len=0, payloads=2) -> Model:
     """msgs: list of (name, class); handlers: {(actor_class, msg name): Asm}."""
-    assert 0 <= array_len <= T.MAX_ARRAY
+    assert 0 <= array_len <= T.MAX_ARRAY and (payloads == 2 or (wide and 3 <= payloads <= T.MAX_PAYLOADS))
     names = [m[0] for m in msgs]
     code: List[int] = []
     hs = [0xFFFF] * (n_classes * len(msgs))
@@ -314,7 +337,7 @@ def build_model(name, n_actors, msgs, handlers, init_fields, invariant, actor_cl
                  code=code, init_state=([w for f in init_fields for w in pack_state_wide(f)] if wide else
                                         [pack_state(f) for f in init_fields]),
                  inv_kind=inv_kind, inv_fa=fa, inv_va=va, inv_fb=fb, fp_match_mask=fp_match_mask, wide=wide,
-                 array_len=array_len)
+                 array_len=array_len, payloads=payloads)
 
 
 # --------------------------------------------------------------------------- raft-synth
@@ -340,7 +363,7 @@ def raft_entry_word(idx, prev_term, term):
     return idx | (prev_term << 4) | (term << 10)
 
 
-def raft_model(n_actors=5, election_budget=1, buggy=True, term0=0, loglen0=0, invariant=None, log_cap=0) -> Model:
+def raft_model(n_actors=5, election_budget=1, buggy=True, term0=0, loglen0=0, invariant=None, log_cap=0, real_fields=False) -> Model:
     """term0 / loglen0: the term and the log length every node starts with.  Values above 255 (a cluster that has been
     running for a while) need 16-bit fields and payloads: the model is then lowered as DEMI_MODEL_WIDE, same handlers.
     invariant: None = "at most one leader per term" as a descriptor; or what build_model takes, e.g. (kind, Asm) for a
@@ -350,8 +373,13 @@ def raft_model(n_actors=5, election_budget=1, buggy=True, term0=0, loglen0=0, in
     protocol: p1 = index | prevLogTerm << 4 | entry term << 10 (raft_entry_word; a wide table).  A follower appends the entry
     (or overwrites a conflicting suffix) when the entry before it matches, else answers with a hint (0x8000 | where to retry)
     and the leader backs up, reading its own log at the computed index; an answer that shows a follower behind is followed by
-    the next entry.  Elections (and the seeded bug) are as without a log."""
-    assert 0 <= log_cap <= RAFT_LOG_MAX and not (log_cap and (term0 > 50 or loglen0))
+    the next entry.  Elections (and the seeded bug) are as without a log.
+    real_fields (with log_cap > 0): the messages carry akka-raft's own field sets instead of hand-packed values - a table with
+    DEMI_MODEL_PAYLOADS(5), 9-bit fields: AppendEntries(term, prevLogIndex, prevLogTerm, entry term (0 = no entry), leaderCommit),
+    RequestVote(term, candidateId, lastLogTerm, lastLogIndex) with the up-to-date rule of the protocol (a voter refuses a
+    candidate whose log is behind its own), AppendReply(term, lastIndex / hint, success); a follower that appended advances
+    its commit index to min(leaderCommit, the entry's index)."""
+    assert 0 <= log_cap <= RAFT_LOG_MAX and not (log_cap and (term0 > 50 or loglen0)) and not (real_fields and not log_cap)
     wide = max(term0, loglen0) > 200 or log_cap > 0
     majority = n_actors // 2 + 1
     h = {}
@@ -364,6 +392,29 @@ def raft_model(n_actors=5, election_budget=1, buggy=True, term0=0, loglen0=0, in
         a.if_ge(k, 2, "ew%s" % uniq).sub(T2, k, 2).ldx(T2, T2).shl(T2, T2, 4).or_(T3, T3, T2)
         a.label("ew%s" % uniq)
 
+    def entry_fields(a, k, uniq):
+        """rows (real_fields): T3 = prevLogIndex = k - 1, T1 = prevLogTerm = log[k - 2] (0 when k < 2), T2 = the term of
+        entry k = log[k - 1], for the 1-based index in register k (not T1..T3); k == 0 (an empty log): all 0 = no entry."""
+        a.mov(T1, 0).mov(T2, 0).mov(T3, 0).if_ne(k, 0, "ef%s" % uniq)
+        a.sub(T3, k, 1).ldx(T2, T3)
+        a.if_ge(k, 2, "ef%s" % uniq).sub(T1, k, 2).ldx(T1, T1)
+        a.label("ef%s" % uniq)
+
+    def append_entries(a, k, uniq, target=None):
+        """rows: send (target register) or broadcast the AppendEntries that carries entry k"""
+        if real_fields:
+            entry_fields(a, k, uniq)
+            if target is None:
+                a.bcast(M_APPEND_ENTRIES, TERM, T3, T1, T2, COMMIT)
+            else:
+                a.send(M_APPEND_ENTRIES, target, TERM, T3, T1, T2, COMMIT)
+        else:
+            entry_word(a, k, uniq)
+            if target is None:
+                a.bcast(M_APPEND_ENTRIES, TERM, T3)
+            else:
+                a.send(M_APPEND_ENTRIES, target, TERM, T3)
+
     # Bootstrap (the ChangeConfiguration the DEMi raft runner Sends after Start): begin as follower.
     a = Asm()
     a.if_eq(BOOTED, 0, "done").mov(BOOTED, 1).tset(M_ELECTION_TIMEOUT).label("done")
@@ -374,8 +425,8 @@ def raft_model(n_actors=5, election_budget=1, buggy=True, term0=0, loglen0=0, in
     a.if_eq(ROLE, LEADER, "done")
     if log_cap:
         a.if_lt(LOGLEN, log_cap, "done").stx(LOGLEN, TERM).add(LOGLEN, LOGLEN, 1)
-        entry_word(a, LOGLEN, "c")
-        a.bcast(M_APPEND_ENTRIES, TERM, T3).label("done")
+        append_entries(a, LOGLEN, "c")
+        a.label("done")
     else:
         a.add(LOGLEN, LOGLEN, 1).bcast(M_APPEND_ENTRIES, TERM, LOGLEN).label("done")
     h[(0, "ClientCommand")] = a
@@ -386,7 +437,11 @@ def raft_model(n_actors=5, election_budget=1, buggy=True, term0=0, loglen0=0, in
     a.if_ne(BUDGET, 0, "done")
     a.sub(BUDGET, BUDGET, 1).mov(ROLE, CANDIDATE).add(TERM, TERM, 1).mov(VOTED, ME)
     a.bitset(VOTES, T0, ME)                                  # votes = {self}  (T0 is zero at entry)
-    a.bcast(M_REQUEST_VOTE, TERM, 0).tset(M_ELECTION_TIMEOUT).label("done")
+    if real_fields:                                          # RequestVote(term, candidateId, lastLogTerm, lastLogIndex)
+        a.mov(T1, 0).if_ne(LOGLEN, 0, "lt").sub(T1, LOGLEN, 1).ldx(T1, T1).label("lt")
+        a.bcast(M_REQUEST_VOTE, TERM, ME, T1, LOGLEN).tset(M_ELECTION_TIMEOUT).label("done")
+    else:
+        a.bcast(M_REQUEST_VOTE, TERM, 0).tset(M_ELECTION_TIMEOUT).label("done")
     h[(0, "ElectionTimeout")] = a
 
     # RequestVote(term) from SRC, lowered as a decision tree (guards skip forward):
@@ -397,6 +452,11 @@ def raft_model(n_actors=5, election_budget=1, buggy=True, term0=0, loglen0=0, in
     a.mov(TERM, P0).mov(ROLE, FOLLOWER).mov(VOTED, NOBODY)
     a.label("same")
     a.if_eq(P0, TERM, "deny")
+    if real_fields:
+        # the candidate's log must be at least as up to date as the voter's: a later last term, or the same and no shorter
+        a.mov(T0, 0).if_ne(LOGLEN, 0, "lt").sub(T0, LOGLEN, 1).ldx(T0, T0).label("lt")
+        a.ldp(T1, 2).ldp(T2, 3)
+        a.if_ge(T1, T0, "deny").if_eq(T1, T0, "utd").if_ge(T2, LOGLEN, "deny").label("utd")
     a.if_ne(VOTED, NOBODY, "grant")                          # already voted for somebody ...
     a.if_ne(VOTED, SRC, "grant")                             # ... else than SRC
     if buggy:
@@ -421,15 +481,15 @@ def raft_model(n_actors=5, election_budget=1, buggy=True, term0=0, loglen0=0, in
     a.bitset(VOTES, VOTES, SRC).popc(T1, VOTES).if_ge(T1, majority, "done")
     a.mov(ROLE, LEADER).tcancel(M_ELECTION_TIMEOUT).trep(M_HEARTBEAT)
     if log_cap:
-        entry_word(a, LOGLEN, "v")                           # its last entry (nothing when the log is empty)
-        a.bcast(M_APPEND_ENTRIES, TERM, T3).label("done")
+        append_entries(a, LOGLEN, "v")                       # its last entry (nothing when the log is empty)
+        a.label("done")
     else:
         a.bcast(M_APPEND_ENTRIES, TERM, LOGLEN).label("done")
     h[(0, "VoteReply")] = a
 
     # AppendEntries(term, loglen) from SRC.
     a = Asm()
-    a.if_lt(P0, TERM, "ok").send(M_APPEND_REPLY, SRC, TERM, 0).halt()
+    a.if_lt(P0, TERM, "ok").send(M_APPEND_REPLY, SRC, TERM, 0).halt()          # (real_fields: success = 0, P2 staged as 0)
     a.label("ok")
     a.if_gt(P0, TERM, "sameterm")                            # newer term: forget the vote, step down
     a.mov(VOTED, NOBODY)
@@ -440,17 +500,26 @@ def raft_model(n_actors=5, election_budget=1, buggy=True, term0=0, loglen0=0, in
     a.label("keep")
     if log_cap:
         a.mov(TERM, P0).tcancel(M_ELECTION_TIMEOUT).tset(M_ELECTION_TIMEOUT)
-        a.and_(T0, P1, 15).shr(T1, P1, 4).and_(T1, T1, 63).shr(T2, P1, 10)     # T0 = index, T1 = prevLogTerm, T2 = entry term
+        if real_fields:          # T0 = the entry's index = prevLogIndex + 1 (0: no entry), T1 = prevLogTerm, T2 = entry term
+            a.ldp(T2, 3).if_ne(T2, 0, "noent").add(T0, P1, 1).label("noent").ldp(T1, 2)
+        else:
+            a.and_(T0, P1, 15).shr(T1, P1, 4).and_(T1, T1, 63).shr(T2, P1, 10)     # T0 = index, T1 = prevLogTerm, T2 = entry term
         a.if_ne(T0, 0, "none")
         a.if_ge(T0, 2, "prevok")                                               # the entry before it: there, with that term?
         a.sub(T3, T0, 1).if_le(T3, LOGLEN, "nack").sub(T3, T0, 2).ldx(T3, T3).if_eq(T3, T1, "nack")
         a.label("prevok")
         a.sub(T3, T0, 1).mov(T1, 0).if_le(T0, LOGLEN, "cmp").ldx(T1, T3)       # T1 = what it holds at that index (0 past the end)
         a.label("cmp").if_ne(T1, T2, "have").stx(T3, T2).mov(LOGLEN, T0)       # append, or overwrite and cut a conflicting suffix
-        a.label("have").send(M_APPEND_REPLY, SRC, TERM, T0).halt()
-        # (the hint: one back, or the end of a shorter log)
-        a.label("nack").sub(T3, T0, 2).min(T3, T3, LOGLEN).movhi(T3, T3, 0x80).send(M_APPEND_REPLY, SRC, TERM, T3).halt()
-        a.label("none").mov(T3, 0).send(M_APPEND_REPLY, SRC, TERM, T3)
+        if real_fields:
+            a.label("have").ldp(T3, 4).min(T3, T3, T0).max(COMMIT, COMMIT, T3)     # commitIndex = min(leaderCommit, this entry)
+            a.send(M_APPEND_REPLY, SRC, TERM, T0, 1).halt()
+            a.label("nack").sub(T3, T0, 2).min(T3, T3, LOGLEN).send(M_APPEND_REPLY, SRC, TERM, T3, 0).halt()
+            a.label("none").mov(T3, 0).send(M_APPEND_REPLY, SRC, TERM, T3, 1)
+        else:
+            a.label("have").send(M_APPEND_REPLY, SRC, TERM, T0).halt()
+            # (the hint: one back, or the end of a shorter log)
+            a.label("nack").sub(T3, T0, 2).min(T3, T3, LOGLEN).movhi(T3, T3, 0x80).send(M_APPEND_REPLY, SRC, TERM, T3).halt()
+            a.label("none").mov(T3, 0).send(M_APPEND_REPLY, SRC, TERM, T3)
     else:
         a.mov(TERM, P0).max(LOGLEN, LOGLEN, P1)
         a.tcancel(M_ELECTION_TIMEOUT).tset(M_ELECTION_TIMEOUT)
@@ -465,12 +534,15 @@ def raft_model(n_actors=5, election_budget=1, buggy=True, term0=0, loglen0=0, in
     a.label("cur")
     a.if_eq(ROLE, LEADER, "done").if_eq(P0, TERM, "done")
     if log_cap:
-        a.and_(T0, P1, 255).shr(T1, P1, 15).if_eq(T1, 0, "hint")              # matched up to T0
+        if real_fields:
+            a.mov(T0, P1).ldp(T1, 2).if_ne(T1, 0, "hint")                         # AppendReply(term, index, success): matched up to T0
+        else:
+            a.and_(T0, P1, 255).shr(T1, P1, 15).if_eq(T1, 0, "hint")              # matched up to T0
         a.if_le(T0, LOGLEN, "done").max(COMMIT, COMMIT, T0).skip("next")
         a.label("hint")                                                        # refused: retry right after the hinted index
         a.label("next").if_lt(T0, LOGLEN, "done").add(T0, T0, 1)
-        entry_word(a, T0, "r")
-        a.send(M_APPEND_ENTRIES, SRC, TERM, T3).label("done")
+        append_entries(a, T0, "r", target=SRC)
+        a.label("done")
     else:
         a.max(COMMIT, COMMIT, P1).label("done")
     h[(0, "AppendReply")] = a
@@ -480,16 +552,17 @@ def raft_model(n_actors=5, election_budget=1, buggy=True, term0=0, loglen0=0, in
     a.if_ne(ROLE, LEADER, "lead").tcancel(M_HEARTBEAT).halt()
     a.label("lead").if_gt(LOGLEN, COMMIT, "done")
     if log_cap:
-        entry_word(a, LOGLEN, "h")
-        a.bcast(M_APPEND_ENTRIES, TERM, T3).label("done")
+        append_entries(a, LOGLEN, "h")
+        a.label("done")
     else:
         a.bcast(M_APPEND_ENTRIES, TERM, LOGLEN).label("done")
     h[(0, "Heartbeat")] = a
 
     init = [[FOLLOWER, term0, NOBODY, 0, election_budget, loglen0, loglen0, 0] for _ in range(n_actors)]
-    return build_model("raft%d-synth%s%s%s" % (n_actors, "" if buggy else "-fixed", "-wide" if wide else "", "-log%d" % log_cap if log_cap else ""),
+    return build_model("raft%d-synth%s%s%s%s" % (n_actors, "" if buggy else "-fixed", "-wide" if wide else "", "-log%d" % log_cap if log_cap else "",
+                                                 "-fields" if real_fields else ""),
                        n_actors, RAFT_MSGS, h, init, invariant=invariant or (T.INV_AT_MOST_ONE, int(ROLE), LEADER, int(TERM)), wide=wide,
-                       array_len=log_cap)
+                       array_len=log_cap, payloads=5 if real_fields else 2)
 
 
 def save_model(model: Model, path: str):

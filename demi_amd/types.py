@@ -82,6 +82,37 @@ def MODEL_ARRAY(n):
     return (int(n) & 0xFF) << 8
 
 
+MAX_PAYLOADS = 6            # DEMI_MAX_PAYLOADS
+
+
+def MODEL_PAYLOADS(n):
+    """demi_model.flags: a message carries n = 3..6 payload fields (DEMI_MODEL_PAYLOADS; wide tables only); 2 = the default."""
+    assert n == 2 or 3 <= n <= MAX_PAYLOADS
+    return 0 if n == 2 else int(n) << 16
+
+
+def payload_bits(n):
+    """DEMI_PAYLOAD_BITS: the width of one payload field of a wide table whose messages carry n fields."""
+    return 16 if n <= 3 else 48 // n
+
+
+def payload_area(fields, n):
+    """The 48-bit payload area (demi_rec_event p0 | p1 << 16 | p_hi << 32) of a wide table's message with these field values."""
+    w = payload_bits(n)
+    return sum((int(v) & ((1 << w) - 1)) << (k * w) for k, v in enumerate(list(fields)[:n]))
+
+
+def payload_fields(area, n):
+    """The n payload fields of a 48-bit payload area (DEMI_PAYLOAD_OF)."""
+    w = payload_bits(n)
+    return [(int(area) >> (k * w)) & ((1 << w) - 1) for k in range(n)]
+
+
+def rec_area(e):
+    """DEMI_REC_AREA of one record (numpy record or ctypes RecEvent)."""
+    return int(e["p0"]) | (int(e["p1"]) << 16) | (int(e["p_hi"]) << 32)
+
+
 
 FILTER_ABSENTS_OFF, FILTER_ABSENTS_LITERAL, FILTER_ABSENTS_CORRECTED = 0, 1, 2     # demi_filter_absents
 
@@ -100,7 +131,7 @@ class Verdict(C.Structure):
 class RecEvent(C.Structure):
     _fields_ = [("kind", C.c_uint8), ("snd", C.c_uint8), ("rcv", C.c_uint8), ("msg_type", C.c_uint8),
                 ("p0", C.c_uint16), ("p1", C.c_uint16), ("flags", C.c_uint8), ("ext_idx", C.c_uint8),
-                ("reserved", C.c_uint16), ("id", C.c_uint32)]
+                ("p_hi", C.c_uint16), ("id", C.c_uint32)]
 
 
 class DdminParams(C.Structure):
@@ -178,7 +209,7 @@ VERDICT_DTYPE = np.dtype([("flags", "<u4"), ("fingerprint", "<u4"), ("hash", "<u
 EXT_EVENT_DTYPE = np.dtype([("kind", "u1"), ("a", "u1"), ("b", "u1"), ("msg_type", "u1"),
                             ("p0", "u1"), ("p1", "u1"), ("p0_hi", "u1"), ("p1_hi", "u1")])
 REC_EVENT_DTYPE = np.dtype([("kind", "u1"), ("snd", "u1"), ("rcv", "u1"), ("msg_type", "u1"), ("p0", "<u2"), ("p1", "<u2"),
-                            ("flags", "u1"), ("ext_idx", "u1"), ("reserved", "<u2"), ("id", "<u4")])
+                            ("flags", "u1"), ("ext_idx", "u1"), ("p_hi", "<u2"), ("id", "<u4")])
 
 
 def rec_events(a):
@@ -192,6 +223,8 @@ def rec_events(a):
     for name in REC_EVENT_DTYPE.names:
         if a.dtype.names and name in a.dtype.names:
             out[name] = a[name]
+    if a.dtype.names and "reserved" in a.dtype.names:      # (records written before the field had a meaning: always 0)
+        out["p_hi"] = a["reserved"]
     return out
 DPOR_TRACE_DTYPE = np.dtype([("key", "<u8"), ("word", "<u4"), ("parent", "u1"), ("qperiod", "u1"), ("depth", "u1"),
                              ("kind", "u1")])

@@ -129,8 +129,14 @@ typedef enum {
   DEMI_OP_LDX = 38,     /* dst = ARRAY[b]  (b register or immediate; an index >= the array's length reads 0)         */
   DEMI_OP_STX = 39,     /* ARRAY[b] = a    (an index >= the array's length stores nothing)                             */
   /* DEMI_INV_PROGRAM rows only: ANOTHER actor's state, so that an invariant can relate two actors by more than equal keys. */
-  DEMI_OP_PEER = 40     /* dst = field F[aux] (aux 0..7) of the actor whose id is in reg a; aux = 8: dst = 1 if that actor is
+  DEMI_OP_PEER = 40,    /* dst = field F[aux] (aux 0..7) of the actor whose id is in reg a; aux = 8: dst = 1 if that actor is
                            created, else 0.  An id that is not a created actor reads 0.                                 */
+  /* Messages with more than two payload fields (DEMI_MODEL_PAYLOADS below). */
+  DEMI_OP_LDP = 41,     /* dst = payload field b of the message being handled (b an immediate 0..5; a field the model's
+                           messages do not have reads 0).  P0 / P1 are also r12 / r13 as always.  A pure row.           */
+  DEMI_OP_PSET = 42     /* outgoing payload field aux (2..5) = b (register or immediate): SEND / BCAST rows take P0 / P1 from
+                           their operands and P2..P5 from these staging values - 0 at handler entry, kept until
+                           overwritten (several SENDs may share them).  Not an effect row.                             */
 } demi_op;
 
 #define DEMI_ROW(op, dst, a, bimm, aux, b) \
@@ -215,6 +221,30 @@ typedef struct {
 #define DEMI_MODEL_ARRAY(n) ((uint32_t)(n) << 8)
 #define DEMI_MODEL_ARRAY_LEN(flags) (((flags) >> 8) & 0xFFu)
 
+/* DEMI_MODEL_PAYLOADS(n), n = 3..6 (with DEMI_MODEL_WIDE only: the message word is then 64 bits): a message carries n payload
+ * fields instead of two - akka-raft's AppendEntries(term, prevLogIndex, prevLogTerm, entries, leaderCommit) or
+ * RequestVote(term, candidateId, lastLogTerm, lastLogIndex) lower field by field instead of being packed into two values by
+ * hand.  The reference identifies a message by what its MessageFingerprinter makes of the whole object
+ * (V/MessageFingerprints.scala:83-101); here the identity of a message IS its word, so every field is part of it: of the
+ * pending set's equality (FullyRandom.remove, the replay's messagePending), of the DPOR node key and of demi_verdict.hash.
+ * Layout: the 48 bits above the 16-bit header are the PAYLOAD AREA; field k occupies bits [k * w, (k + 1) * w) of it with
+ * w = DEMI_PAYLOAD_BITS(n) = 16, 12, 9, 8 for n = 3, 4, 5, 6 (and 16 for the two fields of a plain wide table - the same
+ * rule, so nothing changes for those):
+ *     word = type[4:0] | dst[7:5] | src[11:8] | area[63:16],    area = sum of (P_k mod 2^w) << (k * w)
+ * A SEND truncates each field to w bits (the register window stays 16 bits wide; a protocol whose terms outgrow w bits needs a
+ * smaller n).  Rows: P0 / P1 are r12 / r13 and the SEND / BCAST operands as before; DEMI_OP_LDP reads any field, DEMI_OP_PSET
+ * stages P2..P5 of the messages sent next.  At the boundary: external Sends carry P0 and P1 only (demi_ext_event; the other
+ * fields of an external message are 0); demi_rec_event.p0 / p1 / p_hi are bits 0..15 / 16..31 / 32..47 of the area (for n = 3
+ * exactly P0, P1, P2; DEMI_REC_PAYLOAD extracts field k for any n); demi_dpor_trace_entry.word stays the low half of the
+ * word.  Like every wide table it runs only as compiled code.  The count lives in bits 16..18 of `flags` (0 = two fields). */
+#define DEMI_MODEL_PAYLOADS(n) ((uint32_t)(n) << 16)
+#define DEMI_MODEL_PAYLOADS_N(flags) ((((flags) >> 16) & 7u) ? (((flags) >> 16) & 7u) : 2u)
+#define DEMI_MAX_PAYLOADS 6
+#define DEMI_PAYLOAD_BITS(n) ((n) <= 3 ? 16u : 48u / (uint32_t)(n))
+/* field k of a 48-bit payload area for a model with n payload fields */
+#define DEMI_PAYLOAD_OF(area, n, k) \
+  ((k) < (n) ? (uint32_t)(((uint64_t)(area) >> ((k) * DEMI_PAYLOAD_BITS(n))) & ((1u << DEMI_PAYLOAD_BITS(n)) - 1u)) : 0u)
+
 typedef struct {
   uint32_t max_messages;              /* RandomScheduler.setMaxMessages (RandomScheduler.scala:54-57); 0 = unbounded */
   uint32_t invariant_check_interval;  /* RandomScheduler ctor arg (RandomScheduler.scala:43); 0 = only at the end */
@@ -278,12 +308,16 @@ typedef struct {
   uint8_t snd, rcv;        /* MSG_*: sender (15 = deadLetters; timers are recorded as "Timer"), receiver;
                               SPAWN/KILL: rcv = actor; (UN)PARTITION: snd = a, rcv = b */
   uint8_t msg_type;
-  uint16_t p0, p1;         /* the message's payload fields: below 256 unless the model is DEMI_MODEL_WIDE */
+  uint16_t p0, p1;         /* the message's payload fields: below 256 unless the model is DEMI_MODEL_WIDE (with
+                              DEMI_MODEL_PAYLOADS: bits 0..15 / 16..31 of the payload area) */
   uint8_t flags;           /* bit0: external message, bit1: timer, bit2: dropped at send (crosses_partition) */
   uint8_t ext_idx;         /* index of the ExternalEvent that caused this record, 255 = none */
-  uint16_t reserved;       /* 0 */
+  uint16_t p_hi;           /* DEMI_MODEL_PAYLOADS(n >= 3): bits 32..47 of the payload area; otherwise 0 */
   uint32_t id;             /* Uniq id pairing a MSG_SEND with its MSG_EVENT */
 } demi_rec_event;          /* 16 bytes */
+/* payload field k of a recorded message of a model with n payload fields (n = 2: p0 / p1 themselves) */
+#define DEMI_REC_AREA(e) ((uint64_t)(e).p0 | ((uint64_t)(e).p1 << 16) | ((uint64_t)(e).p_hi << 32))
+#define DEMI_REC_PAYLOAD(e, n, k) DEMI_PAYLOAD_OF(DEMI_REC_AREA(e), n, k)
 
 typedef struct demi_ctx demi_ctx;
 

@@ -145,12 +145,23 @@ int orc_model_validate(const demi_model* m, char* err, size_t err_cap) {
       case DEMI_OP_LDX: case DEMI_OP_STX:
         if (!DEMI_MODEL_ARRAY_LEN(m->flags)) FAIL("row %u: LDX / STX in a model without DEMI_MODEL_ARRAY", pc);
         break;
+      case DEMI_OP_LDP: case DEMI_OP_PSET:
+        if (DEMI_MODEL_PAYLOADS_N(m->flags) < 3) FAIL("row %u: LDP / PSET in a model without DEMI_MODEL_PAYLOADS", pc);
+        if (op == DEMI_OP_LDP && (!bimm || b >= DEMI_MAX_PAYLOADS)) FAIL("row %u: LDP takes an immediate field index 0..5", pc);
+        if (op == DEMI_OP_PSET && (aux < 2 || aux >= DEMI_MAX_PAYLOADS)) FAIL("row %u: PSET stages payload field 2..5", pc);
+        if ((m->inv_kind & DEMI_INV_PROGRAM) && pc >= m->inv_fa) FAIL("row %u: LDP / PSET in an invariant program", pc);
+        break;
       default:
         FAIL("row %u: unknown op %u", pc, op);
     }
   }
   if ((m->inv_kind & ~DEMI_INV_PROGRAM) > DEMI_INV_AGREE) FAIL("inv_kind invalid");
-  if (m->flags & ~(DEMI_MODEL_WIDE | 0xFF00u)) FAIL("unknown model flags 0x%x", m->flags);
+  if (m->flags & ~(DEMI_MODEL_WIDE | 0xFF00u | 0x70000u)) FAIL("unknown model flags 0x%x", m->flags);
+  if ((m->flags >> 16) & 7u) {
+    const uint32_t np = (m->flags >> 16) & 7u;
+    if (np < 3 || np > DEMI_MAX_PAYLOADS) FAIL("DEMI_MODEL_PAYLOADS: 3..%d fields", DEMI_MAX_PAYLOADS);
+    if (!(m->flags & DEMI_MODEL_WIDE)) FAIL("DEMI_MODEL_PAYLOADS needs DEMI_MODEL_WIDE (a 64-bit message word)");
+  }
   if (DEMI_MODEL_ARRAY_LEN(m->flags) > DEMI_MAX_ARRAY) FAIL("DEMI_MODEL_ARRAY: at most %d elements", DEMI_MAX_ARRAY);
   if (m->inv_kind & DEMI_INV_PROGRAM) {
     /* the per-actor predicate / key as rows (include/demi_gpu.h): pure rows only, from inv_fa to the end of the table */
@@ -202,21 +213,45 @@ int orc_trace_validate(const demi_model* m, const demi_ext_event* ev, uint32_t n
 }
 #undef FAIL
 
+/* ===================================================================== payload area (include/demi_gpu.h DEMI_MODEL_PAYLOADS)
+ * A message's payload as ONE value, the way demi_rec_event stores it (p0 | p1 << 16 | p_hi << 32): a narrow model's two bytes
+ * sit in bits 0..7 and 16..23; a wide model's area is the 48 bits above the word's header, n fields of DEMI_PAYLOAD_BITS(n). */
+static inline uint64_t pay_area(const demi_model* m, const uint16_t* p /* [DEMI_MAX_PAYLOADS] */) {
+  if (!(m->flags & DEMI_MODEL_WIDE)) return (uint64_t)(p[0] & 0xFFu) | ((uint64_t)(p[1] & 0xFFu) << 16);
+  const uint32_t n = DEMI_MODEL_PAYLOADS_N(m->flags), bits = DEMI_PAYLOAD_BITS(n);
+  uint64_t a = 0;
+  for (uint32_t k = 0; k < n; k++) a |= (uint64_t)(p[k] & ((1u << bits) - 1u)) << (k * bits);
+  return a;
+}
+static inline uint32_t area_field(const demi_model* m, uint64_t area, uint32_t k) {
+  if (!(m->flags & DEMI_MODEL_WIDE)) return k == 0 ? (uint32_t)area & 0xFFu : k == 1 ? (uint32_t)(area >> 16) & 0xFFu : 0u;
+  return DEMI_PAYLOAD_OF(area, DEMI_MODEL_PAYLOADS_N(m->flags), k);
+}
+static inline uint64_t area_of2(const demi_model* m, uint32_t p0, uint32_t p1) {
+  const uint16_t p[DEMI_MAX_PAYLOADS] = {(uint16_t)p0, (uint16_t)p1, 0, 0, 0, 0};
+  return pay_area(m, p);
+}
+
 /* ===================================================================== delta-table VM
  * The application's `receive` (not in the reference; see include/demi_gpu.h for the row
  * format).  Effects are returned in program order; the scheduler applies them in that order,
  * as Akka would call `!` / scheduleOnce / cancel inside receive (WeaveActor.aj:224-279).       */
-static int vm_run_at(const demi_model* m, uint32_t start, uint32_t me, uint64_t* state, uint8_t src, uint16_t p0, uint16_t p1,
+static int vm_run_at(const demi_model* m, uint32_t start, uint32_t me, uint64_t* state, uint8_t src, uint64_t area,
                      uint32_t exists_mask, orc_effect* fx, uint32_t fx_cap, orc_jrandom* app, uint16_t* regs_out, const uint64_t* all_states);
-int orc_vm_run(const demi_model* m, uint32_t me, uint64_t* state, uint8_t msg_type, uint8_t src,
-               uint16_t p0, uint16_t p1, uint32_t exists_mask, orc_effect* fx, uint32_t fx_cap, orc_jrandom* app) {
+int orc_vm_run_area(const demi_model* m, uint32_t me, uint64_t* state, uint8_t msg_type, uint8_t src,
+                    uint64_t area, uint32_t exists_mask, orc_effect* fx, uint32_t fx_cap, orc_jrandom* app) {
   uint16_t start = m->handler_start[m->actor_class[me] * m->n_msg_types + msg_type];
   if (start == 0xFFFF) return 0;
-  return vm_run_at(m, start, me, state, src, p0, p1, exists_mask, fx, fx_cap, app, NULL, NULL);
+  return vm_run_at(m, start, me, state, src, area, exists_mask, fx, fx_cap, app, NULL, NULL);
 }
+int orc_vm_run(const demi_model* m, uint32_t me, uint64_t* state, uint8_t msg_type, uint8_t src,
+               uint16_t p0, uint16_t p1, uint32_t exists_mask, orc_effect* fx, uint32_t fx_cap, orc_jrandom* app) {
+  return orc_vm_run_area(m, me, state, msg_type, src, area_of2(m, p0, p1), exists_mask, fx, fx_cap, app);
+}
+uint64_t orc_pay_area(const demi_model* m, const uint16_t* p) { return pay_area(m, p); }
 /* the rows from `start` on; regs_out (may be NULL) receives the final register window; all_states (invariant programs only):
  * every actor's state, for DEMI_OP_PEER */
-static int vm_run_at(const demi_model* m, uint32_t start, uint32_t me, uint64_t* state, uint8_t src, uint16_t p0, uint16_t p1,
+static int vm_run_at(const demi_model* m, uint32_t start, uint32_t me, uint64_t* state, uint8_t src, uint64_t area,
                      uint32_t exists_mask, orc_effect* fx, uint32_t fx_cap, orc_jrandom* app, uint16_t* regs_out, const uint64_t* all_states) {
   uint32_t nfx = 0, n_fx_rows = 0;
   /* the register window: 16 x u8, or 16 x u16 for DEMI_MODEL_WIDE (state = two words, four 16-bit fields each) */
@@ -228,7 +263,8 @@ static int vm_run_at(const demi_model* m, uint32_t start, uint32_t me, uint64_t*
   uint16_t r[16];
   for (int i = 0; i < 8; i++) r[i] = wide ? (uint16_t)(state[i >> 2] >> (16 * (i & 3))) : (uint16_t)((*state >> (8 * i)) & 0xFF);
   r[8] = r[9] = r[10] = r[11] = 0;
-  r[12] = (uint16_t)(p0 & M); r[13] = (uint16_t)(p1 & M); r[14] = src; r[15] = (uint16_t)me;
+  r[12] = (uint16_t)area_field(m, area, 0); r[13] = (uint16_t)area_field(m, area, 1); r[14] = src; r[15] = (uint16_t)me;
+  uint16_t q[DEMI_MAX_PAYLOADS] = {0, 0, 0, 0, 0, 0};   /* DEMI_OP_PSET: the staged payload fields P2..P5 of the messages sent next */
   uint32_t pc = start;
   while (pc < m->code_len) {
     uint32_t w = m->code[pc++];
@@ -274,6 +310,8 @@ static int vm_run_at(const demi_model* m, uint32_t start, uint32_t me, uint64_t*
         r[dst] = (uint16_t)v;
         break;
       }
+      case DEMI_OP_LDP: r[dst] = (uint16_t)area_field(m, area, b); break;
+      case DEMI_OP_PSET: if (aux >= 2 && aux < DEMI_MAX_PAYLOADS) q[aux] = (uint16_t)b; break;
       case DEMI_OP_SKIPZ: if (a == 0) pc += braw; break;
       case DEMI_OP_SKIPNZ: if (a != 0) pc += braw; break;
       case DEMI_OP_SKIP: pc += braw; break;
@@ -288,7 +326,8 @@ static int vm_run_at(const demi_model* m, uint32_t start, uint32_t me, uint64_t*
         /* a message to a name that was never created reaches no scheduler (deadLetters) */
         if (a < m->n_actors && ((exists_mask >> a) & 1)) {
           if (nfx >= fx_cap) return -1;
-          fx[nfx++] = (orc_effect){0, (uint8_t)a, (uint8_t)aux, r[dst], (uint16_t)b};
+          q[0] = r[dst]; q[1] = (uint16_t)b;
+          fx[nfx++] = (orc_effect){0, (uint8_t)a, (uint8_t)aux, r[dst], (uint16_t)b, pay_area(m, q)};
         }
         break;
       case DEMI_OP_BCAST:
@@ -296,18 +335,19 @@ static int vm_run_at(const demi_model* m, uint32_t start, uint32_t me, uint64_t*
         for (uint32_t j = 0; j < m->n_actors; j++) {
           if (j == me || !((exists_mask >> j) & 1)) continue;
           if (nfx >= fx_cap) return -1;
-          fx[nfx++] = (orc_effect){0, (uint8_t)j, (uint8_t)aux, r[dst], (uint16_t)b};
+          q[0] = r[dst]; q[1] = (uint16_t)b;
+          fx[nfx++] = (orc_effect){0, (uint8_t)j, (uint8_t)aux, r[dst], (uint16_t)b, pay_area(m, q)};
         }
         break;
       case DEMI_OP_TSET: case DEMI_OP_TREP: case DEMI_OP_TCANCEL:
         if (++n_fx_rows > DEMI_FX_CAP) return -1;
         if (nfx >= fx_cap) return -1;
-        fx[nfx++] = (orc_effect){(uint8_t)(1 + (op - DEMI_OP_TSET)), (uint8_t)me, (uint8_t)aux, 0, 0};
+        fx[nfx++] = (orc_effect){(uint8_t)(1 + (op - DEMI_OP_TSET)), (uint8_t)me, (uint8_t)aux, 0, 0, 0};
         break;
       case DEMI_OP_CRASH: /* the receive throws (V/Instrumenter.scala:184-199): recorded as the last effect, rows stop */
         if (++n_fx_rows > DEMI_FX_CAP) return -1;
         if (nfx >= fx_cap) return -1;
-        fx[nfx++] = (orc_effect){4, (uint8_t)me, 0, 0, 0};
+        fx[nfx++] = (orc_effect){4, (uint8_t)me, 0, 0, 0, 0};
         pc = m->code_len;
         break;
       default: break;
@@ -346,7 +386,7 @@ static void inv_actor(const demi_model* m, const uint64_t* st, uint32_t i, uint3
     uint16_t r[16];
     orc_jrandom none;
     orc_jrandom_seed(&none, 0);
-    vm_run_at(m, m->inv_fa, i, copy, 0, 0, 0, exists, NULL, 0, &none, r, st);
+    vm_run_at(m, m->inv_fa, i, copy, 0, 0, exists, NULL, 0, &none, r, st);
     *hit = r[8] != 0;
     *key = r[9];
     return;
@@ -404,19 +444,19 @@ typedef struct { uint64_t word; uint32_t id; } pend_entry;
 static inline uint32_t msg_word(uint32_t type, uint32_t src, uint32_t dst, uint32_t p0, uint32_t p1) {
   return type | (dst << 5) | (src << 8) | (p0 << 16) | (p1 << 24);
 }
-static inline uint64_t msg_word_x(int wide, uint32_t type, uint32_t src, uint32_t dst, uint32_t p0, uint32_t p1) {
-  if (!wide) return msg_word(type, src, dst, p0 & 0xFFu, p1 & 0xFFu);
-  return (uint64_t)(type | (dst << 5) | (src << 8) | ((p0 & 0xFFFFu) << 16)) | ((uint64_t)(p1 & 0xFFFFu) << 32);
-}
 #define W_TYPE(w) ((uint32_t)(w) & 31u)
 #define W_DST(w) (((uint32_t)(w) >> 5) & 7u)
 #define W_SRC(w) (((uint32_t)(w) >> 8) & 15u)
 #define W_P0(w) (((w) >> 16) & 255u)
 #define W_P1(w) ((w) >> 24)
-#define WX_P0(wide, w) ((wide) ? (uint32_t)((w) >> 16) & 0xFFFFu : (uint32_t)((w) >> 16) & 255u)
-#define WX_P1(wide, w) ((wide) ? (uint32_t)((w) >> 32) & 0xFFFFu : (uint32_t)((w) >> 24) & 255u)
+/* the word of a message whose payload is `area`, and the area of a word (see "payload area" above) */
+static inline uint64_t msg_word_a(int wide, uint32_t type, uint32_t src, uint32_t dst, uint64_t area) {
+  if (!wide) return msg_word(type, src, dst, (uint32_t)area & 0xFFu, (uint32_t)(area >> 16) & 0xFFu);
+  return (uint64_t)(type | (dst << 5) | (src << 8)) | (area << 16);
+}
+#define WX_AREA(wide, w) ((wide) ? (uint64_t)(w) >> 16 : (uint64_t)(W_P0(w) | (W_P1(w) << 16)))
 
-typedef struct { uint8_t rcv, type; uint16_t p0, p1; uint8_t is_external, ext_idx; } mts_entry; /* messagesToSend */
+typedef struct { uint8_t rcv, type; uint64_t area; uint8_t is_external, ext_idx; } mts_entry; /* messagesToSend */
 
 typedef struct {
   const demi_model* m;
@@ -458,13 +498,13 @@ typedef struct {
   orc_effect fx[DEMI_MAX_CODE * DEMI_MAX_ACTORS];
 } exec_t;
 
-static void rec_push(exec_t* x, uint8_t kind, uint8_t snd, uint8_t rcv, uint8_t type, uint16_t p0, uint16_t p1,
+static void rec_push(exec_t* x, uint8_t kind, uint8_t snd, uint8_t rcv, uint8_t type, uint64_t area,
                      uint8_t flags, uint8_t ext_idx, uint32_t id) {
   if (!x->rec) return;
   if (x->n_rec < x->rec_cap) {
     demi_rec_event* e = &x->rec[x->n_rec];
-    e->kind = kind; e->snd = snd; e->rcv = rcv; e->msg_type = type; e->p0 = p0; e->p1 = p1;
-    e->flags = flags; e->ext_idx = ext_idx; e->reserved = 0; e->id = id;
+    e->kind = kind; e->snd = snd; e->rcv = rcv; e->msg_type = type; e->p0 = (uint16_t)area; e->p1 = (uint16_t)(area >> 16);
+    e->flags = flags; e->ext_idx = ext_idx; e->p_hi = (uint16_t)(area >> 32); e->id = id;
   }
   x->n_rec++;
 }
@@ -530,7 +570,7 @@ static pend_entry pend_remove_at(exec_t* x, uint32_t i) {
 static void handle_timer(exec_t* x, uint32_t rcv, uint32_t type) {
   if (x->flags & OVF_ANY) return;
   if (x->n_mts >= MTS_CAP || x->n_mts_timers >= DEMI_TQ_CAP) { x->flags |= DEMI_V_QUEUE_OVF; return; }
-  x->mts[x->n_mts++] = (mts_entry){(uint8_t)rcv, (uint8_t)type, 0, 0, 0, 255};
+  x->mts[x->n_mts++] = (mts_entry){(uint8_t)rcv, (uint8_t)type, 0, 0, 255};
   x->n_mts_timers++;
 }
 
@@ -580,18 +620,18 @@ static void cancel_timer(exec_t* x, uint32_t rcv, uint32_t type) {
 }
 
 /* RandomScheduler.event_produced(cell, envelope), V/schedulers/RandomScheduler.scala:274-321 */
-static void event_produced(exec_t* x, uint32_t snd, uint32_t rcv, uint32_t type, uint32_t p0, uint32_t p1,
+static void event_produced(exec_t* x, uint32_t snd, uint32_t rcv, uint32_t type, uint64_t area,
                            int is_external, uint8_t ext_idx) {
   uint32_t id = x->next_id++;
   int is_timer = 0, dropped = 0;
   if (!is_external) {
     if (snd == DEMI_DEADLETTERS) is_timer = 1;
-    if (!crosses_partition(x, snd, rcv)) pend_insert(x, msg_word_x(x->wide, type, snd, rcv, p0, p1), id);
+    if (!crosses_partition(x, snd, rcv)) pend_insert(x, msg_word_a(x->wide, type, snd, rcv, area), id);
     else dropped = 1;
   } else {
-    pend_insert(x, msg_word_x(x->wide, type, snd, rcv, p0, p1), id); /* externals: no partition check (:298-308) */
+    pend_insert(x, msg_word_a(x->wide, type, snd, rcv, area), id); /* externals: no partition check (:298-308) */
   }
-  rec_push(x, DEMI_REC_MSG_SEND, (uint8_t)snd, (uint8_t)rcv, (uint8_t)type, (uint16_t)(x->wide ? p0 : (p0 & 0xFFu)), (uint16_t)(x->wide ? p1 : (p1 & 0xFFu)),
+  rec_push(x, DEMI_REC_MSG_SEND, (uint8_t)snd, (uint8_t)rcv, (uint8_t)type, area,
            (uint8_t)((is_external ? 1 : 0) | (is_timer ? 2 : 0) | (dropped ? 4 : 0)), ext_idx, id);
 }
 
@@ -599,7 +639,7 @@ static void event_produced(exec_t* x, uint32_t snd, uint32_t rcv, uint32_t type,
 static void send_external_messages(exec_t* x) {
   for (uint32_t i = 0; i < x->n_mts; i++) {
     mts_entry* e = &x->mts[i];
-    event_produced(x, DEMI_DEADLETTERS, e->rcv, e->type, e->p0, e->p1, e->is_external, e->ext_idx);
+    event_produced(x, DEMI_DEADLETTERS, e->rcv, e->type, e->area, e->is_external, e->ext_idx);
   }
   x->n_mts = 0;
   x->n_mts_timers = 0;
@@ -613,32 +653,32 @@ static void inject_until_quiescence(exec_t* x) {
     uint8_t idx = (uint8_t)x->trace_idx;
     switch (e->kind) {
       case DEMI_EV_START: /* trigger_start :219-231 -> unisolate_node :211-217 */
-        rec_push(x, DEMI_REC_SPAWN, 0, e->a, 0, 0, 0, 0, idx, 0);
+        rec_push(x, DEMI_REC_SPAWN, 0, e->a, 0, 0, 0, idx, 0);
         x->inaccessible &= ~(1u << e->a);
         x->killed &= ~(1u << e->a);
         x->blocked &= ~(1u << e->a);     /* "allow scheduler to send messages to it again" (:224-227) */
         break;
       case DEMI_EV_KILL: /* trigger_kill :233-241 */
-        rec_push(x, DEMI_REC_KILL, 0, e->a, 0, 0, 0, 0, idx, 0);
+        rec_push(x, DEMI_REC_KILL, 0, e->a, 0, 0, 0, idx, 0);
         x->killed |= 1u << e->a;
         x->inaccessible |= 1u << e->a;
         break;
       case DEMI_EV_SEND: /* enqueue_message, V/schedulers/ExternalEventInjector.scala:250-279 */
         if ((x->exists >> e->a) & 1) {
           if (x->n_mts >= MTS_CAP) { x->flags |= DEMI_V_QUEUE_OVF; break; }
-          x->mts[x->n_mts++] = (mts_entry){e->a, e->msg_type, (uint16_t)(e->p0 | (e->p0_hi << 8)), (uint16_t)(e->p1 | (e->p1_hi << 8)), 1, idx};
+          x->mts[x->n_mts++] = (mts_entry){e->a, e->msg_type, area_of2(x->m, e->p0 | ((uint32_t)e->p0_hi << 8), e->p1 | ((uint32_t)e->p1_hi << 8)), 1, idx};
         } /* else: "Unknown message receiver" (:254) */
         break;
       case DEMI_EV_PARTITION: /* trigger_partition :314-322 */
-        rec_push(x, DEMI_REC_PARTITION, e->a, e->b, 0, 0, 0, 0, idx, 0);
+        rec_push(x, DEMI_REC_PARTITION, e->a, e->b, 0, 0, 0, idx, 0);
         x->partitioned |= 1ULL << (e->a * 8 + e->b);
         break;
       case DEMI_EV_UNPARTITION: /* trigger_unpartition :324-332 (ordered pair as given) */
-        rec_push(x, DEMI_REC_UNPARTITION, e->a, e->b, 0, 0, 0, 0, idx, 0);
+        rec_push(x, DEMI_REC_UNPARTITION, e->a, e->b, 0, 0, 0, idx, 0);
         x->partitioned &= ~(1ULL << (e->a * 8 + e->b));
         break;
       case DEMI_EV_WAIT_QUIESCENCE: /* :182-184 */
-        rec_push(x, DEMI_REC_BEGIN_WAIT_QUIESCENCE, 0, 0, 0, 0, 0, 0, idx, 0);
+        rec_push(x, DEMI_REC_BEGIN_WAIT_QUIESCENCE, 0, 0, 0, 0, 0, idx, 0);
         loop = 0;
         break;
       default: break;
@@ -664,13 +704,12 @@ static inline void hash_step(uint64_t* h, uint64_t v) { *h = (*h ^ v) * 0x100000
 static void deliver(exec_t* x, uint64_t word) {
   uint32_t me = W_DST(word);
   orc_effect* fx = x->fx; /* DEMI_MAX_CODE rows x at most DEMI_MAX_ACTORS effects each: never full */
-  int n = orc_vm_run(x->m, me, &x->state[model_stw(x->m) * me], (uint8_t)W_TYPE(word), (uint8_t)W_SRC(word),
-                     (uint16_t)WX_P0(x->wide, word), (uint16_t)WX_P1(x->wide, word), x->exists, fx,
-                     DEMI_MAX_CODE * DEMI_MAX_ACTORS, &x->app_rng);
+  int n = orc_vm_run_area(x->m, me, &x->state[model_stw(x->m) * me], (uint8_t)W_TYPE(word), (uint8_t)W_SRC(word),
+                          WX_AREA(x->wide, word), x->exists, fx, DEMI_MAX_CODE * DEMI_MAX_ACTORS, &x->app_rng);
   if (n < 0) { x->flags |= DEMI_V_QUEUE_OVF; return; }
   for (int i = 0; i < n; i++) {
     switch (fx[i].kind) {
-      case 0: event_produced(x, me, fx[i].target, fx[i].msg_type, fx[i].p0, fx[i].p1, 0, 255); break;
+      case 0: event_produced(x, me, fx[i].target, fx[i].msg_type, fx[i].area, 0, 255); break;
       case 1: register_cancellable(x, 0, me, fx[i].msg_type); break;
       case 2: register_cancellable(x, 1, me, fx[i].msg_type); break;
       case 3: cancel_timer(x, me, fx[i].msg_type); break;
@@ -741,8 +780,7 @@ static int schedule_new_message(exec_t* x) {
   }
   x->count++;                                                   /* :462 */
   uint64_t w = e.word;
-  rec_push(x, DEMI_REC_MSG_EVENT, (uint8_t)W_SRC(w), (uint8_t)W_DST(w), (uint8_t)W_TYPE(w), (uint16_t)WX_P0(x->wide, w),
-           (uint16_t)WX_P1(x->wide, w), 0, 255, e.id);
+  rec_push(x, DEMI_REC_MSG_EVENT, (uint8_t)W_SRC(w), (uint8_t)W_DST(w), (uint8_t)W_TYPE(w), WX_AREA(x->wide, w), 0, 255, e.id);
   hash_step(&x->hash, w);
   /* updateRepeatingTimer :405-421; isTimer = timerToCancellable contains (rcv, msg) */
   int is_rep = x->m->msg_class[W_TYPE(w)] == DEMI_MSG_TIMER &&
@@ -808,7 +846,7 @@ static int random_execute_in2(exec_t* x, const demi_model* m, const demi_ext_eve
     if (x->flags & (DEMI_V_PENDING_OVF | DEMI_V_QUEUE_OVF)) break;
     if (x->violation) break;                 /* notify_quiescence :487-500 */
     if (x->trace_idx < n_ev) {
-      rec_push(x, DEMI_REC_QUIESCENCE, 0, 0, 0, 0, 0, 0, 255, 0);
+      rec_push(x, DEMI_REC_QUIESCENCE, 0, 0, 0, 0, 0, 255, 0);
       continue;
     }
     break;
@@ -1019,15 +1057,15 @@ static void sts_deliver(sts_t* x, uint64_t w) {
   /* Instrumenter retrigger of repeating timers (V/Instrumenter.scala:1008-1016), pinned before receive */
   if (m->msg_class[W_TYPE(w)] == DEMI_MSG_TIMER && (x->repeating & timer_bit(m, me, W_TYPE(w))))
     sts_handle_timer(x, me, W_TYPE(w));
-  int n = orc_vm_run(m, me, &x->state[model_stw(m) * me], (uint8_t)W_TYPE(w), (uint8_t)W_SRC(w), (uint16_t)WX_P0(x->wide, w),
-                     (uint16_t)WX_P1(x->wide, w), x->exists, x->fx, DEMI_MAX_CODE * DEMI_MAX_ACTORS, &x->app_rng);
+  int n = orc_vm_run_area(m, me, &x->state[model_stw(m) * me], (uint8_t)W_TYPE(w), (uint8_t)W_SRC(w), WX_AREA(x->wide, w),
+                          x->exists, x->fx, DEMI_MAX_CODE * DEMI_MAX_ACTORS, &x->app_rng);
   if (n < 0) { x->flags |= DEMI_V_QUEUE_OVF; return; }
   for (int i = 0; i < n && !(x->flags & OVF_ANY); i++) {
     const orc_effect* e = &x->fx[i];
     uint32_t bit = e->kind ? timer_bit(m, me, e->msg_type) : 0;
     switch (e->kind) {
       case 0: /* event_produced, internal (:590-607) */
-        if (!sts_crosses(x, me, e->target)) sts_pend_add(x, msg_word_x(x->wide, e->msg_type, me, e->target, e->p0, e->p1));
+        if (!sts_crosses(x, me, e->target)) sts_pend_add(x, msg_word_a(x->wide, e->msg_type, me, e->target, e->area));
         break;
       case 1: case 2: /* registerCancellable + handleTick (V/Instrumenter.scala:1145-1200) */
         if (x->repeating & bit) break;
@@ -1146,7 +1184,7 @@ static int sts_replay_in(sts_t* x, const demi_model* m, const demi_ext_event* ex
         }
         /* external MsgSend: enqueue_message (:509-511) unless its Send was pruned; internal: nothing */
         if ((e->flags & 1) && IN_MASK(e->ext_idx) && ((x->exists >> e->rcv) & 1)) {
-          sts_pend_add(x, msg_word_x(x->wide, e->msg_type, DEMI_DEADLETTERS, e->rcv, e->p0, e->p1));
+          sts_pend_add(x, msg_word_a(x->wide, e->msg_type, DEMI_DEADLETTERS, e->rcv, DEMI_REC_AREA(*e)));
           if (kept && !(x->flags & OVF_ANY)) kept[idx] = 1;
         }
         break;
@@ -1156,7 +1194,7 @@ static int sts_replay_in(sts_t* x, const demi_model* m, const demi_ext_event* ex
         if (s != 255 && !IN_MASK(s)) break; /* pruned together with its Send */
         /* filterKnownAbsentInternals: messageDeliverable(snd, rcv, id) or the event is not part of the projected trace */
         if (fka && !(FK_ALIVE(e->rcv) && !FK_PART(e->snd, e->rcv) && !(e->id < sizeof fk_pruned && fk_pruned[e->id]))) break;
-        uint64_t w = msg_word_x(x->wide, e->msg_type, e->snd, e->rcv, e->p0, e->p1);
+        uint64_t w = msg_word_a(x->wide, e->msg_type, e->snd, e->rcv, DEMI_REC_AREA(*e));
         int k = ((x->blocked >> e->rcv) & 1) ? -1 : sts_pend_find(x, w);   /* messagePending: "double check that the destination isn't currently blocked" (:392-402) */
         if (k < 0) { x->ignored++; break; } /* "Ignoring message" (:528-529) */
         sts_pend_remove(x, k);
@@ -1335,7 +1373,7 @@ static uint32_t dpor_run_external(dpor_t* x, const demi_ext_event* ext, uint32_t
     const demi_ext_event* e = &ext[idx];
     if (e->kind == DEMI_EV_START) x->isolated &= ~(1u << e->a);
     else if (e->kind == DEMI_EV_SEND)
-      dpor_produce(x, msg_word_x(x->wide, e->msg_type, DEMI_DEADLETTERS, e->a, e->p0 | ((uint32_t)e->p0_hi << 8), e->p1 | ((uint32_t)e->p1_hi << 8)));
+      dpor_produce(x, msg_word_a(x->wide, e->msg_type, DEMI_DEADLETTERS, e->a, area_of2(x->m, e->p0 | ((uint32_t)e->p0_hi << 8), e->p1 | ((uint32_t)e->p1_hi << 8))));
     else if (e->kind == DEMI_EV_WAIT_QUIESCENCE) { x->marker_pending = 1; x->marker_ext = idx; await = 1; }
     idx++;
   }
@@ -1366,14 +1404,14 @@ static void dpor_deliver(dpor_t* x, uint64_t w) {
   hash_step(&x->hash, w);
   if (m->msg_class[W_TYPE(w)] == DEMI_MSG_TIMER && (x->repeating & timer_bit(m, me, W_TYPE(w))))
     dpor_produce(x, msg_word(W_TYPE(w), DEMI_DEADLETTERS, me, 0, 0)); /* retrigger -> enqueue_timer = `!` (Scheduler.scala:73) */
-  int n = orc_vm_run(m, me, &x->state[model_stw(m) * me], (uint8_t)W_TYPE(w), (uint8_t)W_SRC(w), (uint16_t)WX_P0(x->wide, w),
-                     (uint16_t)WX_P1(x->wide, w), (1u << m->n_actors) - 1, x->fx, DEMI_MAX_CODE * DEMI_MAX_ACTORS, &x->app_rng);
+  int n = orc_vm_run_area(m, me, &x->state[model_stw(m) * me], (uint8_t)W_TYPE(w), (uint8_t)W_SRC(w), WX_AREA(x->wide, w),
+                          (1u << m->n_actors) - 1, x->fx, DEMI_MAX_CODE * DEMI_MAX_ACTORS, &x->app_rng);
   if (n < 0) { x->flags |= DEMI_V_QUEUE_OVF; return; }
   for (int i = 0; i < n && !(x->flags & OVF_ANY); i++) {
     const orc_effect* e = &x->fx[i];
     uint32_t bit = e->kind ? timer_bit(m, me, e->msg_type) : 0;
     switch (e->kind) {
-      case 0: dpor_produce(x, msg_word_x(x->wide, e->msg_type, me, e->target, e->p0, e->p1)); break;
+      case 0: dpor_produce(x, msg_word_a(x->wide, e->msg_type, me, e->target, e->area)); break;
       case 1: case 2:
         if (x->repeating & bit) break; /* Non-unique timer */
         if (e->kind == 2) x->repeating |= bit;

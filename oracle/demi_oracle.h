@@ -38,11 +38,19 @@ typedef struct {
   uint8_t kind;   /* 0 send, 1 tset, 2 trep, 3 tcancel */
   uint8_t target; /* send: receiver */
   uint8_t msg_type;
-  uint16_t p0, p1; /* 8 bits used unless the model is DEMI_MODEL_WIDE */
-} orc_effect;
+  uint16_t p0, p1; /* the SEND row's two operands (8 bits used unless the model is DEMI_MODEL_WIDE) */
+  uint64_t area;   /* send: the message's whole payload as demi_rec_event stores it (p0 | p1 << 16 | p_hi << 32): the operands
+                      truncated to the model's field width, and the staged fields P2.. of a DEMI_MODEL_PAYLOADS model */
+} orc_effect;      /* 16 bytes */
 /* state: the actor's one word, or its two words for a DEMI_MODEL_WIDE model */
 int orc_vm_run(const demi_model* m, uint32_t me, uint64_t* state, uint8_t msg_type, uint8_t src,
                uint16_t p0, uint16_t p1, uint32_t exists_mask, orc_effect* fx, uint32_t fx_cap, orc_jrandom* app);
+
+/* the same with the delivered message's payload as an area (every field of a DEMI_MODEL_PAYLOADS model); orc_pay_area packs
+ * DEMI_MAX_PAYLOADS field values the way a SEND does */
+int orc_vm_run_area(const demi_model* m, uint32_t me, uint64_t* state, uint8_t msg_type, uint8_t src,
+                    uint64_t area, uint32_t exists_mask, orc_effect* fx, uint32_t fx_cap, orc_jrandom* app);
+uint64_t orc_pay_area(const demi_model* m, const uint16_t* fields);
 
 /* Invariant: returns the fingerprint code (0 = holds). */
 uint32_t orc_invariant(const demi_model* m, const uint64_t* states, uint32_t exists_mask);

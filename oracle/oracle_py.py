@@ -107,6 +107,10 @@ def lib():
                                          C.c_void_p, C.c_uint64, C.POINTER(T.Limits), C.c_void_p, C.c_int]
         L.orc_vm_run.argtypes = [C.POINTER(T.ModelStruct), C.c_uint32, C.c_void_p, C.c_uint8, C.c_uint8,
                                  C.c_uint16, C.c_uint16, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.orc_vm_run_area.argtypes = [C.POINTER(T.ModelStruct), C.c_uint32, C.c_void_p, C.c_uint8, C.c_uint8,
+                                      C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.orc_pay_area.argtypes = [C.POINTER(T.ModelStruct), C.c_void_p]
+        L.orc_pay_area.restype = C.c_uint64
         L.orc_sts_replay_batch.argtypes = [C.POINTER(T.ModelStruct), C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
                                            C.c_void_p, C.c_uint64, C.POINTER(T.Limits), C.c_void_p, C.c_int]
         L.orc_sts_removal_batch.argtypes = [C.POINTER(T.ModelStruct), C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
@@ -122,7 +126,8 @@ def lib():
 
 class Effect(C.Structure):
     """orc_effect (demi_oracle.h): kind 0 send, 1 tset, 2 trep, 3 tcancel, 4 crash."""
-    _fields_ = [("kind", C.c_uint8), ("target", C.c_uint8), ("msg_type", C.c_uint8), ("p0", C.c_uint16), ("p1", C.c_uint16)]
+    _fields_ = [("kind", C.c_uint8), ("target", C.c_uint8), ("msg_type", C.c_uint8), ("p0", C.c_uint16), ("p1", C.c_uint16),
+                ("area", C.c_uint64)]
 
 
 class JRandom:

@@ -12,10 +12,25 @@ struct LaneMem { uint64_t* st; word_t* fxq; };
 static inline uint32_t w_type(word_t w) { return (uint32_t)w & 31u; }
 static inline uint32_t w_dst(word_t w) { return ((uint32_t)w >> 5) & 7u; }
 static inline uint32_t w_src(word_t w) { return ((uint32_t)w >> 8) & 15u; }
-static inline uint32_t w_p0(word_t w) { return (uint32_t)w >> 16; }
-static inline uint32_t w_p1(word_t w) { return (uint32_t)(w >> 32) & 0xFFFFu; }
+// DEMI_MODEL_PAYLOADS (demi_device.hpp): NPAY fields of PAY_BITS bits in the 48-bit payload area above the word's header
+#ifndef DEMI_JIT_NPAY
+#define DEMI_JIT_NPAY 2
+#endif
+constexpr uint32_t NPAY = DEMI_JIT_NPAY, PAY_BITS = NPAY <= 3 ? 16u : 48u / NPAY, PAY_MASK = (1u << PAY_BITS) - 1u;
+static inline uint64_t pay_area(uint32_t p0, uint32_t p1, uint32_t p2 = 0, uint32_t p3 = 0, uint32_t p4 = 0, uint32_t p5 = 0) {
+  const uint32_t p[6] = {p0, p1, p2, p3, p4, p5};
+  uint64_t a = 0;
+  for (uint32_t k = 0; k < NPAY; k++) a |= (uint64_t)(p[k] & PAY_MASK) << (k * PAY_BITS);
+  return a;
+}
+static inline uint32_t w_pay(word_t w, uint32_t k) { return k < NPAY ? (uint32_t)(w >> (16 + k * PAY_BITS)) & PAY_MASK : 0u; }
+static inline uint32_t w_p0(word_t w) { return w_pay(w, 0); }
+static inline uint32_t w_p1(word_t w) { return w_pay(w, 1); }
+static inline word_t fx_pack_area(uint32_t op, uint32_t type, uint32_t target, uint64_t area) {
+  return (word_t)((op & 31u) | (type << 5) | (target << 10)) | ((word_t)area << 14);
+}
 static inline word_t fx_pack(uint32_t op, uint32_t type, uint32_t target, uint32_t p0, uint32_t p1) {
-  return (word_t)((op & 31u) | (type << 5) | (target << 10)) | ((word_t)(p0 & 0xFFFFu) << 14) | ((word_t)(p1 & 0xFFFFu) << 30);
+  return fx_pack_area(op, type, target, pay_area(p0, p1));
 }
 #else
 typedef uint32_t word_t;

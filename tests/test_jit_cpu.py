@@ -59,7 +59,8 @@ def _host_vm(model, tmp_path, k1=False):
                    % (os.path.join(ROOT, "tests", "jit_host_shim.hpp"), src))
     so = tmp_path / (("vm_host_wide" if wide else "vm_host") + ("_k1.so" if k1 else ".so"))
     subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-label"] + (["-DDEMI_WIDE"] if wide else []) +
-                          ["-DDEMI_JIT_ARR_LEN=%d" % getattr(model, "array_len", 0), "-o", str(so), str(cpp)])
+                          ["-DDEMI_JIT_ARR_LEN=%d" % getattr(model, "array_len", 0), "-DDEMI_JIT_NPAY=%d" % getattr(model, "payloads", 2),
+                           "-o", str(so), str(cpp)])
     L = C.CDLL(str(so))
     L.run.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64 if wide else C.c_uint32, C.POINTER(C.c_uint32)]
     L.run.restype = C.c_uint32
@@ -472,6 +473,96 @@ def test_wide_tables_through_the_code_generator(oracle, tmp_path, seed):
         seen_fx += len(got)
         seen_big += any(v > 255 for v in (int(st[(2 * me) * 64]) >> 16 & 0xFFFF, *[g[3] for g in got]))
     assert seen_fx > 200 and seen_big > 100
+
+
+def _random_handler_payloads(rng, n_rows, n_types, npay):
+    """A random wide handler whose rows also read the message's payload fields (LDP, in and out of range) and stage the
+    further fields of what it sends (PSET, registers and constants)."""
+    base = _random_handler_wide(rng, n_rows, n_types)
+    b = M.Asm()
+    regs = [M.Reg(i) for i in range(16)]
+    pre = int(rng.integers(2, 7))
+    for _ in range(pre):
+        if rng.integers(2):
+            b.ldp(regs[int(rng.integers(12))], int(rng.integers(0, 6)))
+        else:
+            b.pset(int(rng.integers(2, 6)), regs[int(rng.integers(16))] if rng.integers(3) else int(rng.integers(0, 256)))
+    b.rows += base.rows
+    b._fix = [(i + pre, lab) for i, lab in base._fix]
+    b._labels = {k: v + pre for k, v in base._labels.items()}
+    return b
+
+
+@pytest.mark.parametrize("npay", [3, 4, 5, 6])
+def test_payload_tables_through_the_code_generator(oracle, tmp_path, npay):
+    """DEMI_MODEL_PAYLOADS(n): the generated handlers - payload fields read with LDP (and P0 / P1), staged with PSET, packed into
+    the 48-bit area of the effect word at the width of the model - equal the oracle's row interpreter on random rows, and on the
+    raft with akka-raft's field sets (n = 5); the kernel source compiles for gfx950."""
+    rng = np.random.default_rng(70 + npay)
+    if npay == 5:
+        model = M.raft_model(5, log_cap=8, real_fields=True)
+        A, NT = 5, model.n_msg_types
+    else:
+        MSGS = [("E", T.MSG_EXTERNAL), ("A", T.MSG_INTERNAL), ("B", T.MSG_INTERNAL), ("Tm", T.MSG_TIMER)]
+        h = {(0, name): _random_handler_payloads(rng, int(rng.integers(4, 40)), len(MSGS), npay) for name, _ in MSGS}
+        A, NT = 4, len(MSGS)
+        model = M.build_model("rand_pay%d" % npay, A, MSGS, h, [[0] * 8] * A, (T.INV_NEVER, 0, 60000, 0), wide=True, payloads=npay)
+    assert model.payloads == npay and oracle.model_validate(model)[0] == 0
+    try:
+        size, kernel = _native.specialize_check(model.to_struct())
+        assert size > 10000 and "k1_random_explore" in kernel and "k2_replay" in kernel and "k3_dpor" in kernel
+    except _native.DemiError as e:
+        if "hiprtc not found" not in str(e):
+            raise
+    L = _host_vm(model, tmp_path)
+    ms = model.to_struct()
+    hs = np.full(T.MAX_CLASSES * T.MAX_MSG_TYPES, 0xFFFF, dtype=np.uint32)
+    hs[:len(model.handler_start)] = model.handler_start
+    sw = model.state_words
+    st = np.zeros(8 * sw * 64, dtype=np.uint64)
+    fxq = np.zeros(FX_CAP * 64, dtype=np.uint64)
+    fx = (Effect * 64)()
+    want_state = (C.c_uint64 * sw)()
+    bits = T.payload_bits(npay)
+    seen_fx = seen_far = 0
+    for it in range(5000):
+        me, typ = int(rng.integers(A)), int(rng.integers(NT))
+        src = int(rng.choice([int(rng.integers(A)), T.DEADLETTERS]))
+        hi = 65536 if it % 2 else 9
+        pay = [int(x) for x in rng.integers(0, hi, 6)]
+        fields = [int(x) for x in rng.integers(0, hi, 8)]
+        if npay == 5:
+            fields[0], fields[2], fields[5] = int(rng.integers(3)), int(rng.choice([M.NOBODY, int(rng.integers(A))])), int(rng.integers(9))
+        words = M.pack_state_wide(fields) + [int(x) for x in rng.integers(0, 1 << 63, sw - 2)]
+        for k in range(sw):
+            st[(sw * me + k) * 64] = words[k]
+            want_state[k] = words[k]
+        area = T.payload_area(pay, npay)
+        w = typ | (me << 5) | (src << 8) | (area << 16)
+        flags = C.c_uint32(0)
+        n = L.run(hs.ctypes.data, 0, NT, st.ctypes.data, fxq.ctypes.data, w, C.byref(flags))
+        wn = oracle.lib().orc_vm_run_area(C.byref(ms), me, want_state, typ, src, area, (1 << A) - 1, fx, 64, C.byref(L.app_rng))
+        if wn < 0:
+            assert flags.value & T.V_QUEUE_OVF
+            continue
+        assert not flags.value
+        assert [int(st[(sw * me + k) * 64]) for k in range(sw)] == list(want_state), (it, me, typ, fields)
+        got = []
+        for k in range(n):
+            f = int(fxq[k * 64])
+            op, t_, target, ar = f & 31, (f >> 5) & 31, (f >> 10) & 15, (f >> 14) & ((1 << 48) - 1)
+            if op == M.OPS["SEND"]:
+                if target < A:
+                    got.append((0, target, t_, ar))
+            elif op == M.OPS["BCAST"]:
+                got += [(0, r, t_, ar) for r in range(A) if r != me]
+            else:
+                got.append((1 + op - M.OPS["TSET"], me, t_, 0))
+        assert got == [(e.kind, e.target, e.msg_type, e.area if e.kind == 0 else 0) for e in fx[:wn]], (it, me, typ)
+        assert all(e.kind != 0 or e.area < (1 << (npay * bits)) for e in fx[:wn])
+        seen_fx += len(got)
+        seen_far += any(g[0] == 0 and (g[3] >> (2 * bits)) for g in got)
+    assert seen_fx > 200 and seen_far > 50, (seen_fx, seen_far)
 
 
 def _vgpr_count(image):

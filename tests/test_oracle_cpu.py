@@ -274,8 +274,175 @@ def test_raft_with_a_real_log_equals_plain_reference(oracle, buggy):
     assert all(v > 50 for v in seen.values()), seen
 
 
+def raft_fields_reference(n_actors, buggy, me, fields, log, msg, src, pay, cap):
+    """raft_model(log_cap = cap, real_fields = True) as the protocol written out: messages are tuples of akka-raft's fields -
+    AppendEntries(term, prevLogIndex, prevLogTerm, entry term or 0, leaderCommit), RequestVote(term, candidateId, lastLogTerm,
+    lastLogIndex), VoteReply(term, granted), AppendReply(term, lastIndex or hint, success) - every field 9 bits on the wire
+    (DEMI_MODEL_PAYLOADS(5)).  Returns (fields, log, effects); a send is ("send", to, type, (f0, .., f4))."""
+    role, term, voted, votes, budget, loglen, commit, booted = fields
+    log = list(log)
+    others = [j for j in range(n_actors) if j != me]
+    at = lambda i: log[i] if 0 <= i < cap else 0                    # LDX: past the end reads 0
+    wire = lambda *f: tuple(v & 511 for v in (list(f) + [0] * 5)[:5])
+    last_term = at(loglen - 1) if loglen else 0
+    fx = []
+
+    def append_entries(k, term, commit):
+        k &= 0xFFFF
+        return wire(term, 0, 0, 0, commit) if k == 0 else wire(term, k - 1, at(k - 2) if k >= 2 else 0, at(k - 1), commit)
+
+    def step_down():
+        if role == M.LEADER:
+            fx.append(("tcancel", M.M_HEARTBEAT))
+
+    if msg == M.M_BOOTSTRAP:
+        if not booted:
+            booted = 1
+            fx.append(("tset", M.M_ELECTION_TIMEOUT))
+    elif msg == M.M_CLIENT:
+        if role == M.LEADER and loglen < cap:
+            log[loglen] = term
+            loglen += 1
+            fx += [("send", j, M.M_APPEND_ENTRIES, append_entries(loglen, term, commit)) for j in others]
+    elif msg == M.M_ELECTION_TIMEOUT:
+        if role != M.LEADER and budget != 0:
+            budget -= 1
+            role, term, voted, votes = M.CANDIDATE, (term + 1) & 0xFFFF, me, 1 << me
+            fx += [("send", j, M.M_REQUEST_VOTE, wire(term, me, last_term, loglen)) for j in others]
+            fx.append(("tset", M.M_ELECTION_TIMEOUT))
+    elif msg == M.M_REQUEST_VOTE:
+        c_term, _cand, c_last_term, c_last_index = pay[:4]
+        if c_term > term:
+            step_down()
+            term, role, voted = c_term, M.FOLLOWER, M.NOBODY
+        up_to_date = c_last_term > last_term or (c_last_term == last_term and c_last_index >= loglen)
+        free = voted == M.NOBODY or voted == src
+        if buggy and role == M.CANDIDATE and ((src - 1) & 0xFFFF) == me:
+            free = True
+        if c_term == term and up_to_date and free:
+            voted = src
+            fx += [("tcancel", M.M_ELECTION_TIMEOUT), ("tset", M.M_ELECTION_TIMEOUT), ("send", src, M.M_VOTE_REPLY, wire(term, 1))]
+        else:
+            fx.append(("send", src, M.M_VOTE_REPLY, wire(term, 0)))
+    elif msg == M.M_VOTE_REPLY:
+        r_term, granted = pay[:2]
+        if r_term > term:
+            step_down()
+            term, role, voted = r_term, M.FOLLOWER, M.NOBODY
+        elif role == M.CANDIDATE and r_term == term and granted & 1:
+            votes = (votes | (1 << (src & 15))) & 0xFFFF
+            if bin(votes).count("1") >= n_actors // 2 + 1:
+                role = M.LEADER
+                fx += [("tcancel", M.M_ELECTION_TIMEOUT), ("trep", M.M_HEARTBEAT)]
+                fx += [("send", j, M.M_APPEND_ENTRIES, append_entries(loglen, term, commit)) for j in others]
+    elif msg == M.M_APPEND_ENTRIES:
+        l_term, prev_index, prev_term, entry_term, leader_commit = pay[:5]
+        if l_term < term:
+            fx.append(("send", src, M.M_APPEND_REPLY, wire(term, 0, 0)))
+        else:
+            if l_term > term:
+                voted = M.NOBODY
+            if l_term > term or role != M.LEADER:
+                step_down()
+                role = M.FOLLOWER
+            term = l_term
+            fx += [("tcancel", M.M_ELECTION_TIMEOUT), ("tset", M.M_ELECTION_TIMEOUT)]
+            index = (prev_index + 1) & 0xFFFF if entry_term else 0
+            if index == 0:
+                fx.append(("send", src, M.M_APPEND_REPLY, wire(term, 0, 1)))
+            elif index >= 2 and not (prev_index <= loglen and at(prev_index - 1) == prev_term):
+                fx.append(("send", src, M.M_APPEND_REPLY, wire(term, min((index - 2) & 0xFFFF, loglen), 0)))
+            else:
+                if (at(index - 1) if index <= loglen else 0) != entry_term:          # append, or overwrite and cut the suffix
+                    if index - 1 < cap:
+                        log[index - 1] = entry_term
+                    loglen = index
+                commit = max(commit, min(leader_commit, index))
+                fx.append(("send", src, M.M_APPEND_REPLY, wire(term, index, 1)))
+    elif msg == M.M_APPEND_REPLY:
+        r_term, index, success = pay[:3]
+        if r_term > term:
+            step_down()
+            term, role, voted = r_term, M.FOLLOWER, M.NOBODY
+        elif role == M.LEADER and r_term == term:
+            go = True
+            if success:
+                if index <= loglen:
+                    commit = max(commit, index)
+                else:
+                    go = False
+            if go and index < loglen:
+                fx.append(("send", src, M.M_APPEND_ENTRIES, append_entries(index + 1, term, commit)))
+    elif msg == M.M_HEARTBEAT:
+        if role != M.LEADER:
+            fx.append(("tcancel", M.M_HEARTBEAT))
+        elif loglen > commit:
+            fx += [("send", j, M.M_APPEND_ENTRIES, append_entries(loglen, term, commit)) for j in others]
+    return [role, term, voted, votes, budget, loglen, commit, booted], log, fx
+
+
+@pytest.mark.parametrize("buggy", [True, False])
+def test_raft_with_akka_raft_field_sets_equals_plain_reference(oracle, buggy):
+    """raft_model(log_cap = 8, real_fields = True): a DEMI_MODEL_PAYLOADS(5) table - the rows (LDP for the fields past P1, PSET
+    in front of the SENDs, the up-to-date rule of RequestVote, leaderCommit) against the protocol in Python, every field of every
+    message sent compared through the 48-bit payload area."""
+    A, cap = 5, 8
+    model = M.raft_model(A, buggy=buggy, log_cap=cap, real_fields=True)
+    assert model.wide and model.payloads == 5 and T.payload_bits(5) == 9 and oracle.model_validate(model)[0] == 0
+    ms = model.to_struct()
+    rnd = random.Random(12)
+    fx = (_Effect * 64)()
+    st = (C.c_uint64 * 4)()
+    seen = {"append": 0, "nack": 0, "over": 0, "next": 0, "stale_log": 0, "granted": 0, "commit": 0}
+    for _ in range(20000):
+        me = rnd.randrange(A)
+        msg = rnd.choice([M.M_CLIENT, M.M_APPEND_ENTRIES, M.M_APPEND_ENTRIES, M.M_APPEND_REPLY, M.M_REQUEST_VOTE, M.M_REQUEST_VOTE,
+                          rnd.randrange(8)])
+        src = T.DEADLETTERS if model.msg_class[msg] != T.MSG_INTERNAL else rnd.choice([j for j in range(A) if j != me])
+        loglen = rnd.randrange(cap + 1)
+        log = [rnd.randrange(1, 6) for _ in range(loglen)] + [rnd.choice([0, 0, rnd.randrange(1, 6)]) for _ in range(cap - loglen)]
+        fields = [rnd.randrange(3), rnd.randrange(1, 7), rnd.choice([M.NOBODY] + list(range(A))), rnd.randrange(32),
+                  rnd.randrange(3), loglen, rnd.randrange(loglen + 1), rnd.randrange(2)]
+        pay = [rnd.randrange(1, 7), rnd.randrange(4), 0, 0, 0]
+        if msg == M.M_APPEND_ENTRIES:
+            prev = rnd.choice([loglen, loglen, rnd.randrange(cap + 1), rnd.randrange(14)])
+            pay[1:] = [prev, rnd.choice([log[prev - 1] if 1 <= prev <= cap else 0, rnd.randrange(6)]), rnd.choice([0, rnd.randrange(1, 6), rnd.randrange(1, 6)]),
+                       rnd.randrange(cap + 2)]
+        elif msg == M.M_APPEND_REPLY:
+            pay[1:3] = [rnd.randrange(cap + 2), rnd.randrange(2)]
+        elif msg == M.M_REQUEST_VOTE:
+            pay[0] = rnd.choice([fields[1], fields[1], rnd.randrange(1, 8)])
+            pay[1:4] = [src, rnd.choice([log[loglen - 1] if loglen else 0, rnd.randrange(6)]), rnd.choice([loglen, rnd.randrange(cap + 1)])]
+        elif msg == M.M_VOTE_REPLY:
+            pay[1] = rnd.randrange(2)
+        words = M.pack_state_wide(fields) + [sum(v << (16 * (i % 4)) for i, v in enumerate(log) if i // 4 == k) for k in range(2)]
+        for k in range(4):
+            st[k] = words[k]
+        area = T.payload_area(pay, 5)
+        assert T.payload_fields(area, 5) == pay
+        n = oracle.lib().orc_vm_run_area(C.byref(ms), me, st, msg, src, area, (1 << A) - 1, fx, 64, C.byref(C.c_uint64(0x5DEECE66D)))
+        want_fields, want_log, want_fx = raft_fields_reference(A, buggy, me, fields, log, msg, src, pay, cap)
+        got_fields = [(st[i // 4] >> (16 * (i % 4))) & 0xFFFF for i in range(8)]
+        got_log = [(st[2 + i // 4] >> (16 * (i % 4))) & 0xFFFF for i in range(cap)]
+        got_fx = [("send", e.target, e.msg_type, tuple(T.payload_fields(e.area, 5))) if e.kind == 0 else (["", "tset", "trep", "tcancel"][e.kind], e.msg_type)
+                  for e in fx[:n]]
+        assert got_fields == want_fields and got_log == want_log, (fields, log, msg, src, pay)
+        assert got_fx == want_fx, (fields, log, msg, src, pay)
+        if msg == M.M_APPEND_ENTRIES and pay[0] >= fields[1]:
+            seen["append"] += want_fields[5] == loglen + 1
+            seen["over"] += want_log != log and want_fields[5] <= loglen
+            seen["nack"] += any(e[0] == "send" and e[3][2] == 0 for e in want_fx)
+            seen["commit"] += want_fields[6] > fields[6]
+        seen["next"] += msg == M.M_APPEND_REPLY and any(e[0] == "send" for e in want_fx)
+        if msg == M.M_REQUEST_VOTE:
+            seen["granted"] += any(e[0] == "send" and e[3][1] == 1 for e in want_fx)
+            seen["stale_log"] += pay[0] >= fields[1] and not any(e[0] == "send" and e[3][1] == 1 for e in want_fx)
+    assert all(v > 50 for v in seen.values()), seen
+
+
 class _Effect(C.Structure):      # orc_effect (oracle/demi_oracle.h)
-    _fields_ = [("kind", C.c_uint8), ("target", C.c_uint8), ("msg_type", C.c_uint8), ("p0", C.c_uint16), ("p1", C.c_uint16)]
+    _fields_ = [("kind", C.c_uint8), ("target", C.c_uint8), ("msg_type", C.c_uint8), ("p0", C.c_uint16), ("p1", C.c_uint16),
+                ("area", C.c_uint64)]
 
 
 @pytest.mark.parametrize("buggy", [True, False])

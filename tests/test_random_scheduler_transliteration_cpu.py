@@ -33,7 +33,8 @@ DEAD = "deadLetters"
 
 
 class _Effect(C.Structure):      # orc_effect (oracle/demi_oracle.h)
-    _fields_ = [("kind", C.c_uint8), ("target", C.c_uint8), ("msg_type", C.c_uint8), ("p0", C.c_uint16), ("p1", C.c_uint16)]
+    _fields_ = [("kind", C.c_uint8), ("target", C.c_uint8), ("msg_type", C.c_uint8), ("p0", C.c_uint16), ("p1", C.c_uint16),
+                ("area", C.c_uint64)]
 
 
 class FullyRandom:
