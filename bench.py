@@ -607,6 +607,9 @@ def main():
     ap.add_argument("--log-cap", type=int, default=0,
                     help="experiment, not the headline: the raft with a REAL log of this many entries in the nodes' arrays "
                          "(DEMI_MODEL_ARRAY, raft_model(log_cap)); parity green on the GPU, not yet timed (DESIGN section 8, item 0)")
+    ap.add_argument("--real-fields", action="store_true",
+                    help="with --log-cap: the messages carry akka-raft's own field sets (DEMI_MODEL_PAYLOADS(5): AppendEntries(term, "
+                         "prevLogIndex, prevLogTerm, entry, leaderCommit), RequestVote(term, candidateId, lastLogTerm, lastLogIndex))")
     ap.add_argument("--strategy", choices=["random", "fifo"], default="random",
                     help="RandomizationStrategy: FullyRandom (the headline workload) or SrcDstFIFO")
     args = ap.parse_args()
@@ -706,7 +709,7 @@ def main():
         model = raft_model(5, term0=args.wide_term0, loglen0=300)
     if args.log_cap:
         from demi_amd.model import raft_model
-        model = raft_model(5, log_cap=args.log_cap)
+        model = raft_model(5, log_cap=args.log_cap, real_fields=args.real_fields)
     limits.p_max = args.p_max
     limits.strategy = T.STRATEGY_SRC_DST_FIFO if args.strategy == "fifo" else T.STRATEGY_FULLY_RANDOM
     n = args.schedules
@@ -886,7 +889,8 @@ def main():
                        "invariant_check_interval": int(limits.invariant_check_interval), "p_max": int(limits.p_max),
                        "randomization_strategy": "SrcDstFIFO" if args.strategy == "fifo" else "FullyRandom",
                        "table_compiled_to_native_code": specialized, "jit_compile_s": jit_compile_s,
-                       "wide_register_window": bool(getattr(model, "wide", False)), "array_elements_per_actor": int(getattr(model, "array_len", 0)), "seed_base": SEED_BASE,
+                       "wide_register_window": bool(getattr(model, "wide", False)), "array_elements_per_actor": int(getattr(model, "array_len", 0)),
+                       "payload_fields_per_message": int(getattr(model, "payloads", 2)), "seed_base": SEED_BASE,
                        "seeds": "timed step i of rank r: schedule indices [(i * %d + r) * n, ... + n) - every timed step evaluates fresh "
                                 "seeds; the untimed last step: [r * n, ... + n)" % world,
                        "parallelism": "schedule-index range sharded, %d rank(s)" % world, "collective": collective,

@@ -29,10 +29,20 @@ def msg_word(msg_type: int, src: int, dst: int, p0: int, p1: int) -> int:
     return msg_type | (dst << 5) | (src << 8) | (p0 << 16) | (p1 << 24)
 
 
-def dpor_initial_trace(trace: EventTrace) -> np.ndarray:
+def rec_msg_word(e, wide: bool = False) -> int:
+    """The message word of a recorded MsgSend / MsgEvent: 32 bits, or the 64 bits of a wide table (header | payload area << 16,
+    the area being the record's p0 | p1 << 16 | p_hi << 32: include/demi_gpu.h)."""
+    if not wide:
+        return msg_word(int(e["msg_type"]), int(e["snd"]), int(e["rcv"]), int(e["p0"]), int(e["p1"]))
+    return int(e["msg_type"]) | (int(e["rcv"]) << 5) | (int(e["snd"]) << 8) | (T.rec_area(e) << 16)
+
+
+def dpor_initial_trace(trace: EventTrace, model=None) -> np.ndarray:
     """DepTracker.getInitialTrace (DepTracker.scala:130-133, 173) of a recorded execution: the root followed by
     every delivery, each identified by the hash chain of its causal path (parent = the delivery during which it
-    was sent; the root for external messages)."""
+    was sent; the root for external messages).  model: needed for a wide table (its node keys hash the 64-bit message word;
+    the trace entry reports the word's low half)."""
+    wide = bool(model is not None and getattr(model, "wide", False))
     ev = trace.events
     key_of_id: Dict[int, Tuple[int, int]] = {}          # Uniq id -> (node key, trace index of its producer)
     out = [(T.DPOR_ROOT_KEY, 0, 0, 0, 0, 0)]
@@ -41,15 +51,15 @@ def dpor_initial_trace(trace: EventTrace) -> np.ndarray:
     for e in ev:
         kind = int(e["kind"])
         if kind == T.REC_MSG_SEND:
-            w = msg_word(int(e["msg_type"]), int(e["snd"]), int(e["rcv"]), int(e["p0"]), int(e["p1"]))
+            w = rec_msg_word(e, wide)
             ext = bool(int(e["flags"]) & 1)
             pk, pi = (T.DPOR_ROOT_KEY, 0) if ext else (cur_key, cur_idx)
             key_of_id[int(e["id"])] = (((pk ^ w) * T.DPOR_PRIME) & 0xFFFFFFFFFFFFFFFF, pi)
         elif kind == T.REC_MSG_EVENT:
-            w = msg_word(int(e["msg_type"]), int(e["snd"]), int(e["rcv"]), int(e["p0"]), int(e["p1"]))
+            w = rec_msg_word(e, wide)
             k, pi = key_of_id[int(e["id"])]
             depth_of.append(depth_of[pi] + 1)
-            out.append((k, w, pi & 0xFF, 0, depth_of[-1] & 0xFF, 1))
+            out.append((k, w & 0xFFFFFFFF, pi & 0xFF, 0, depth_of[-1] & 0xFF, 1))
             cur_key, cur_idx = k, len(out) - 1
     return np.array(out, dtype=T.DPOR_TRACE_DTYPE)
 
@@ -150,7 +160,7 @@ def editDistanceDporDDMin(schedulerConfig: SchedulerConfig, trace: EventTrace, v
     trace.original_externals, stats, the DPOR trace that reproduces the violation on the MCS or None, violation).
     native: every DPOR consultation runs inside the library (demi_dpor_explore with ArvindDistanceOrdering, the distance cap,
     the initial trace and - for a subsequence consulted again at a larger distance - its resumable state)."""
-    initialTrace = dpor_initial_trace(trace)
+    initialTrace = dpor_initial_trace(trace, schedulerConfig.model)
     if native_loop:
         # the whole of this function inside the library (demi_edit_distance_dpor_ddmin, csrc/incddmin_host.hpp): one call
         from . import _native

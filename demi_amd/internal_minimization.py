@@ -36,7 +36,10 @@ def deliveries(trace: EventTrace) -> List[Tuple[int, Key, int]]:
         return cached
     ev = trace.events
     idx = np.nonzero(ev["kind"] == T.REC_MSG_EVENT)[0]
-    out = [(int(i), (int(ev["snd"][i]), int(ev["rcv"][i]), (int(ev["msg_type"][i]), int(ev["p0"][i]), int(ev["p1"][i]))),
+    # (the fingerprint of a message: its type and every payload field - p_hi holds the fields past the second one of a
+    # DEMI_MODEL_PAYLOADS table and is 0 otherwise)
+    out = [(int(i), (int(ev["snd"][i]), int(ev["rcv"][i]), (int(ev["msg_type"][i]), int(ev["p0"][i]), int(ev["p1"][i])) +
+                     ((int(ev["p_hi"][i]),) if int(ev["p_hi"][i]) else ())),
             int(ev["flags"][i])) for i in idx]
     trace._deliveries = out
     return out

@@ -61,7 +61,7 @@ def fuzz(generateFuzzTest: Callable[[int], np.ndarray], schedulerConfig: Schedul
                 replayer.shutdown()
             if not deterministic:
                 continue
-        initialTrace = dpor_initial_trace(trace)
+        initialTrace = dpor_initial_trace(trace, schedulerConfig.model)
         if not computeProvenance:
             filtered = initialTrace[:0]
         elif provenance_device is not None:

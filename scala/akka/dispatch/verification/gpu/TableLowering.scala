@@ -6,11 +6,28 @@ import akka.dispatch.verification._
 case class FlatModel(nActors: Int, msgClass: Array[Byte], actorClass: Array[Byte], nClasses: Int,
                      handlerStart: Array[Short], code: Array[Int], initState: Array[Long],
                      invKind: Int, invFa: Int, invVa: Int, invFb: Int, fpMatchMask: Int = 0xFFFFFFFF,
-                     wide: Boolean = false, arrayLen: Int = 0) {
+                     wide: Boolean = false, arrayLen: Int = 0, payloads: Int = 2) {
   /** demi_model.flags.  wide = DEMI_MODEL_WIDE: 16-bit state fields and payloads (terms / log indices above 255); initState then
    *  holds two words per actor (F0..F3, F4..F7).  arrayLen = DEMI_MODEL_ARRAY(n): every actor owns an array of n elements
    *  beside its eight fields (rows LDX / STX: a replicated log, a vote table), empty at the start (include/demi_gpu.h). */
-  def flags: Int = (if (wide) 1 else 0) | ((arrayLen & 0xFF) << 8)
+  def flags: Int = (if (wide) 1 else 0) | ((arrayLen & 0xFF) << 8) | (if (payloads > 2) payloads << 16 else 0)
+  /** payloads = DEMI_MODEL_PAYLOADS(n), n = 3..6 (wide tables only): a message carries n payload fields, each payloadBits wide
+   *  (16, 12, 9, 8 bits), in the 48-bit payload area of the 64-bit message word; demi_rec_event holds the area as
+   *  p0 | p1 << 16 | p_hi << 32.  A table without the option has two fields: 8 bits each, 16 when wide. */
+  def payloadBits: Int = if (!wide) 8 else if (payloads <= 3) 16 else 48 / payloads
+  def area(fields: Seq[Int]): Long = {
+    val m = (1L << payloadBits) - 1
+    if (!wide) (fields(0) & m) | ((fields(1) & m) << 16)
+    else fields.take(payloads).zipWithIndex.map { case (v, k) => (v.toLong & m) << (k * payloadBits) }.foldLeft(0L)(_ | _)
+  }
+  def fieldsOf(area: Long): Seq[Int] = {
+    val m = (1L << payloadBits) - 1
+    if (!wide) Seq((area & m).toInt, ((area >> 16) & m).toInt) else (0 until payloads).map(k => ((area >> (k * payloadBits)) & m).toInt)
+  }
+  /** the message word (include/demi_gpu.h): 32 bits, or the 64 bits of a wide table */
+  def word(msgType: Int, src: Int, dst: Int, area: Long): Long =
+    if (!wide) (msgType | (dst << 5) | (src << 8)).toLong | ((area & 0xFF) << 16) | (((area >> 16) & 0xFF) << 24)
+    else (msgType | (dst << 5) | (src << 8)).toLong | (area << 16)
   /** Such a table has no interpreter on the device: every scheduler compiles it right after loading it. */
   def compiledOnly: Boolean = wide || arrayLen > 0
 }
@@ -25,6 +42,9 @@ trait TableLowering {
   def actorName(id: Int): String
   def encode(msg: Any): (Int, Int, Int)               // (msg_type, p0, p1) = the message's fingerprint
   def decode(msgType: Int, p0: Int, p1: Int): Any     // a message equal to the original under the app's fingerprinter
+  /** Messages with more than two fields (model.payloads > 2): every field, P0 first.  The defaults serve two-field tables. */
+  def encodeFields(msg: Any): (Int, Seq[Int]) = { val (t, p0, p1) = encode(msg); (t, Seq(p0, p1)) }
+  def decodeFields(msgType: Int, fields: Seq[Int]): Any = decode(msgType, fields(0), fields(1))
   def fingerprintCode(fp: ViolationFingerprint): Int  // 32-bit code of demi_verdict.fingerprint
   def fingerprintOf(code: Int): ViolationFingerprint
 }
@@ -65,11 +85,12 @@ object FlatEvents {
   def toEventTrace(rec: Array[Byte], nRec: Int, externals: Seq[ExternalEvent], lo: TableLowering): EventTrace = {
     val trace = new EventTrace(externals)
     for (i <- 0 until nRec) {
-      // kind, snd, rcv, msg_type, p0 (u16), p1 (u16), flags, ext_idx, reserved (u16), id (u32): include/demi_gpu.h
+      // kind, snd, rcv, msg_type, p0 (u16), p1 (u16), flags, ext_idx, p_hi (u16), id (u32): include/demi_gpu.h
       val o = REC_BYTES * i
       def u(k: Int) = rec(o + k) & 0xFF
       val id = (u(12)) | (u(13) << 8) | (u(14) << 16) | (u(15) << 24)
-      val p0 = u(4) | (u(5) << 8); val p1 = u(6) | (u(7) << 8)
+      val area = (u(4) | (u(5) << 8)).toLong | ((u(6) | (u(7) << 8)).toLong << 16) | ((u(10) | (u(11) << 8)).toLong << 32)   // DEMI_REC_AREA
+      def msg = lo.decodeFields(u(3), lo.model.fieldsOf(area))
       u(0) match {
         case REC_SPAWN => externals(u(9)) match { case Start(ctor, n) => trace += SpawnEvent("", ctor(), n, null) }
         case REC_KILL => trace += KillEvent(lo.actorName(u(2)))
@@ -77,8 +98,8 @@ object FlatEvents {
         case REC_UNPARTITION => trace += UnPartitionEvent((lo.actorName(u(1)), lo.actorName(u(2))))
         case REC_BEGIN_WAIT_QUIESCENCE => trace += BeginWaitQuiescence
         case REC_QUIESCENCE => trace += Quiescence
-        case REC_MSG_SEND => trace += UniqueMsgSend(MsgSend(name(u(1), lo), lo.actorName(u(2)), lo.decode(u(3), p0, p1)), id)
-        case REC_MSG_EVENT => trace += UniqueMsgEvent(MsgEvent(name(u(1), lo), lo.actorName(u(2)), lo.decode(u(3), p0, p1)), id)
+        case REC_MSG_SEND => trace += UniqueMsgSend(MsgSend(name(u(1), lo), lo.actorName(u(2)), msg), id)
+        case REC_MSG_EVENT => trace += UniqueMsgEvent(MsgEvent(name(u(1), lo), lo.actorName(u(2)), msg), id)
       }
     }
     trace
@@ -92,14 +113,15 @@ object FlatEvents {
   val DPOR_PRIME = 0x100000001B3L
   def dporInitialTrace(trace: EventTrace, lo: TableLowering): Array[Byte] = {
     def actor(n: String) = if (n == "deadLetters" || n == "Timer") DEADLETTERS else lo.actorId(n)
-    def word(s: String, r: String, m: Any): Int = { val (t, p0, p1) = lo.encode(m); t | (lo.actorId(r) << 5) | (actor(s) << 8) | ((p0 & 255) << 16) | ((p1 & 255) << 24) }
+    // (a wide table's node keys hash the 64-bit word; the entry reports its low half)
+    def word(s: String, r: String, m: Any): Long = { val (t, f) = lo.encodeFields(m); lo.model.word(t, actor(s), lo.actorId(r), lo.model.area(f)) }
     val keyOfId = scala.collection.mutable.Map[Int, (Long, Int)]()        // Uniq id -> (node key, trace index of its producer)
-    val entries = scala.collection.mutable.ArrayBuffer[(Long, Int, Int, Int, Int)]((DPOR_ROOT_KEY, 0, 0, 0, 0))    // key, word, parent, depth, kind
+    val entries = scala.collection.mutable.ArrayBuffer[(Long, Long, Int, Int, Int)]((DPOR_ROOT_KEY, 0L, 0, 0, 0))    // key, word, parent, depth, kind
     var curKey = DPOR_ROOT_KEY; var curIdx = 0
     for (e <- trace.events) e match {
       case u @ UniqueMsgSend(MsgSend(s, r, m), id) =>
         val (pk, pi) = if (EventTypes.isExternal(u)) (DPOR_ROOT_KEY, 0) else (curKey, curIdx)
-        keyOfId(id) = (((pk ^ (word(s, r, m).toLong & 0xFFFFFFFFL)) * DPOR_PRIME), pi)
+        keyOfId(id) = (((pk ^ word(s, r, m)) * DPOR_PRIME), pi)
       case UniqueMsgEvent(MsgEvent(s, r, m), id) =>
         val (k, pi) = keyOfId(id)
         entries += ((k, word(s, r, m), pi & 0xFF, (entries(pi)._4 + 1) & 0xFF, 1))
@@ -123,28 +145,28 @@ object FlatEvents {
     val sends = trace.original_externals.zipWithIndex.collect { case (Send(_, _), i) => i }.iterator
     val spawns = scala.collection.mutable.Map[String, Int]() ++
       trace.original_externals.zipWithIndex.collect { case (Start(_, n), i) => n -> i }
-    def put(i: Int, kind: Int, snd: Int, rcv: Int, t: Int, p0: Int, p1: Int, fl: Int, ext: Int, id: Int) {
+    def put(i: Int, kind: Int, snd: Int, rcv: Int, t: Int, area: Long, fl: Int, ext: Int, id: Int) {
       val o = REC_BYTES * i
       out(o) = kind.toByte; out(o + 1) = snd.toByte; out(o + 2) = rcv.toByte; out(o + 3) = t.toByte
-      out(o + 4) = p0.toByte; out(o + 5) = (p0 >> 8).toByte; out(o + 6) = p1.toByte; out(o + 7) = (p1 >> 8).toByte
-      out(o + 8) = fl.toByte; out(o + 9) = ext.toByte                                  // (10, 11: reserved, 0)
+      out(o + 4) = area.toByte; out(o + 5) = (area >> 8).toByte; out(o + 6) = (area >> 16).toByte; out(o + 7) = (area >> 24).toByte   // p0, p1
+      out(o + 8) = fl.toByte; out(o + 9) = ext.toByte; out(o + 10) = (area >> 32).toByte; out(o + 11) = (area >> 40).toByte            // p_hi
       out(o + 12) = id.toByte; out(o + 13) = (id >> 8).toByte; out(o + 14) = (id >> 16).toByte; out(o + 15) = (id >> 24).toByte
     }
     def actor(n: String) = if (n == "deadLetters" || n == "Timer") DEADLETTERS else lo.actorId(n)
     for ((e, i) <- evs.zipWithIndex) e match {
-      case SpawnEvent(_, _, n, _) => put(i, REC_SPAWN, 0, lo.actorId(n), 0, 0, 0, 0, spawns.getOrElse(n, 255), 0)
-      case KillEvent(n) => put(i, REC_KILL, 0, lo.actorId(n), 0, 0, 0, 0, 255, 0)
-      case PartitionEvent((a, b)) => put(i, REC_PARTITION, lo.actorId(a), lo.actorId(b), 0, 0, 0, 0, 255, 0)
-      case UnPartitionEvent((a, b)) => put(i, REC_UNPARTITION, lo.actorId(a), lo.actorId(b), 0, 0, 0, 0, 255, 0)
-      case BeginWaitQuiescence => put(i, REC_BEGIN_WAIT_QUIESCENCE, 0, 0, 0, 0, 0, 0, 255, 0)
-      case Quiescence => put(i, REC_QUIESCENCE, 0, 0, 0, 0, 0, 0, 255, 0)
+      case SpawnEvent(_, _, n, _) => put(i, REC_SPAWN, 0, lo.actorId(n), 0, 0L, 0, spawns.getOrElse(n, 255), 0)
+      case KillEvent(n) => put(i, REC_KILL, 0, lo.actorId(n), 0, 0L, 0, 255, 0)
+      case PartitionEvent((a, b)) => put(i, REC_PARTITION, lo.actorId(a), lo.actorId(b), 0, 0L, 0, 255, 0)
+      case UnPartitionEvent((a, b)) => put(i, REC_UNPARTITION, lo.actorId(a), lo.actorId(b), 0, 0L, 0, 255, 0)
+      case BeginWaitQuiescence => put(i, REC_BEGIN_WAIT_QUIESCENCE, 0, 0, 0, 0L, 0, 255, 0)
+      case Quiescence => put(i, REC_QUIESCENCE, 0, 0, 0, 0L, 0, 255, 0)
       case UniqueMsgSend(MsgSend(s, r, m), id) =>
-        val (t, p0, p1) = lo.encode(m)
+        val (t, f) = lo.encodeFields(m)
         val external = EventTypes.isExternal(e)       // the k-th external MsgSend belongs to the k-th Send (EventTrace.scala:382-452)
-        put(i, REC_MSG_SEND, actor(s), lo.actorId(r), t, p0, p1, if (external) 1 else 0, if (external) sends.next() else 255, id)
+        put(i, REC_MSG_SEND, actor(s), lo.actorId(r), t, lo.model.area(f), if (external) 1 else 0, if (external) sends.next() else 255, id)
       case UniqueMsgEvent(MsgEvent(s, r, m), id) =>
-        val (t, p0, p1) = lo.encode(m)
-        put(i, REC_MSG_EVENT, actor(s), lo.actorId(r), t, p0, p1, 0, 255, id)
+        val (t, f) = lo.encodeFields(m)
+        put(i, REC_MSG_EVENT, actor(s), lo.actorId(r), t, lo.model.area(f), 0, 255, id)
       case other => throw new UnsupportedOnGpu(other.getClass.getSimpleName)
     }
     out

@@ -47,6 +47,14 @@ def test_initial_trace_of_a_random_execution_replays_under_dpor(oracle):
     dt = oracle.dpor_batch(model, ev, [init], T.DporParams(0, len(init), 0, 0, 64, 4096, 0))[1][0]
     n = min(len(dt), len(init))
     assert n >= 8 and (dt["key"][:8] == init["key"][:8]).all()
+    # a wide table with five payload fields: the keys chain the 64-bit message words (header | payload area << 16)
+    model = M.raft_model(3, log_cap=4, real_fields=True)
+    v, trace = _execution(oracle, model, ev, want_violation=False, lim=T.Limits(12, 0, 64, 0, 0, 0))
+    init = dpor_initial_trace(trace, model)
+    dt = oracle.dpor_batch(model, ev, [init], T.DporParams(0, len(init), 0, 0, 64, 4096, 0))[1][0]
+    n = min(len(dt), len(init))
+    assert n >= 8 and (dt["key"][:8] == init["key"][:8]).all() and (dt["word"][:8] == init["word"][:8]).all()
+    assert (trace.events["p0"] != 0).any() and (dpor_initial_trace(trace)["key"] != init["key"]).any()     # (the 32-bit layout gives other keys)
 
 
 def test_prioritize_pending_upon_divergence(oracle):

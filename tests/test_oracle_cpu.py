@@ -501,6 +501,46 @@ def test_wide_raft_table_equals_plain_reference(oracle):
         assert got_fx == want_fx, (fields, msg, src, p0, p1)
 
 
+def test_payload_model_rules(oracle):
+    """DEMI_MODEL_PAYLOADS: wide tables only, 3..6 fields; LDP / PSET belong to such tables; the width of a field follows from the
+    count (16, 12, 9, 8 bits) and a SEND truncates to it; an external Send sets P0 / P1, the other fields of the message are 0;
+    a recorded execution carries the fields in p0 / p1 / p_hi and replays."""
+    E = [("E", T.MSG_EXTERNAL), ("A", T.MSG_INTERNAL)]
+    relay = Asm().ldp(M.T0, 1).ldp(M.T1, 2).pset(2, 0x77).pset(3, M.P0).send(1, M.ME, M.P0, M.P1)     # E(p0, p1) -> A(p0, p1, 0x77, p0) to itself
+    sink = Asm().ldp(M.F[0], 0).ldp(M.F[1], 1).ldp(M.F[2], 2).ldp(M.F[3], 3).ldp(M.F[4], 4).ldp(M.F[5], 5)
+    h = {(0, "E"): relay, (0, "A"): sink}
+    for flags_bad, why in (((False, 4), "WIDE"), ((True, 7), "3..6")):
+        m = build_model("m", 2, E, h, [[0] * 8] * 2, (T.INV_NONE, 0, 0, 0), wide=True, payloads=4)
+        ms = m.to_struct()
+        ms.flags = (T.MODEL_WIDE if flags_bad[0] else 0) | (flags_bad[1] << 16)
+        err = C.create_string_buffer(256)
+        assert oracle.lib().orc_model_validate(C.byref(ms), err, 256) == T.ERR_INVALID_MODEL and why in err.value.decode()
+    plain = build_model("p", 2, E, h, [[0] * 8] * 2, (T.INV_NONE, 0, 0, 0), wide=True)
+    rc, msg = oracle.model_validate(plain)
+    assert rc == T.ERR_INVALID_MODEL and "LDP / PSET" in msg
+    assert [T.payload_bits(n) for n in (2, 3, 4, 5, 6)] == [16, 16, 12, 9, 8]
+    ev = events_to_array([start(0), start(1), send(0, 0, 0xABCD, 0x1234)])
+    for n in (3, 4, 5, 6):
+        m = build_model("m%d" % n, 2, E, h, [[0] * 8] * 2, (T.INV_NEVER, 6, 1, 0), wide=True, payloads=n)
+        assert oracle.model_validate(m)[0] == 0
+        v, rec, states = oracle.random_execute(m, ev, 0, T.Limits(0, 0, 16, 0, 0, 0))
+        mask = (1 << T.payload_bits(n)) - 1
+        want = [0xABCD & mask, 0x1234 & mask, 0x77 & mask, (0xABCD & mask) if n > 3 else 0, 0, 0]      # (the relay reads the truncated P0)
+        got = [(int(states[i // 4]) >> (16 * (i % 4))) & 0xFFFF for i in range(6)]
+        assert got == want, (n, got, want)
+        sends = rec[rec["kind"] == T.REC_MSG_SEND]
+        assert T.payload_fields(T.rec_area(sends[0]), n)[:2] == want[:2] and T.payload_fields(T.rec_area(sends[0]), n)[2:] == [0] * (n - 2)
+        assert T.payload_fields(T.rec_area(sends[1]), n) == want[:n]
+        used = ev[:T.verdict_trace_idx(v.flags)]
+        masks = np.array([[7, 0, 0, 0], [3, 0, 0, 0]], dtype=np.uint64)
+        r = oracle.sts_replay_batch(m, used, rec, masks, T.Limits(0, 0, 16, 0, 0, 0))
+        assert int(r[0]["hash"]) == v.hash and not r[0]["flags"] & T.V_DIVERGED and int(r[1]["hash"]) != v.hash
+        bad_rec = rec.copy()
+        bad_rec["p_hi"][np.nonzero(rec["kind"] == T.REC_MSG_EVENT)[0][-1]] ^= 1            # another message: not pending -> ignored
+        r2 = oracle.sts_replay_batch(m, used, bad_rec, masks[:1], T.Limits(0, 0, 16, 0, 0, 0))
+        assert int(r2[0]["hash"]) != v.hash
+
+
 def test_wide_model_rules(oracle):
     """MOVHI and 16-bit payloads belong to wide models only; a wide model executes under the RandomScheduler oracle (terms
     above 255 reach the verdict hash) is recorded with its 16-bit payloads and replays; under SrcDstFIFO it takes the narrow table's schedules."""

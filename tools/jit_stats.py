@@ -39,12 +39,13 @@ def main():
     ap.add_argument("--system", action="store_true", help="compile with /opt/rocm's comgr (LD_PRELOAD) instead of PyTorch's")
     ap.add_argument("--wide", action="store_true", help="the raft lowered as a wide table")
     ap.add_argument("--log-cap", type=int, default=0, help="the raft with a real log of this many entries (DEMI_MODEL_ARRAY)")
+    ap.add_argument("--real-fields", action="store_true", help="with --log-cap: akka-raft's field sets (DEMI_MODEL_PAYLOADS(5))")
     ap.add_argument("--flags", default="", help="DEMI_JIT_FLAGS")
     args = ap.parse_args()
     d = tempfile.mkdtemp()
     code = ("import sys; sys.path.insert(0, %r)\nfrom demi_amd import _native, model as M\n"
-            "m = M.raft_model(5, log_cap=%d) if %d else M.raft_model(5, term0=1000, loglen0=300) if %r else M.raft_model(5)\n"
-            "print(_native.specialize_check(m.to_struct())[0])\n" % (ROOT, args.log_cap, args.log_cap, args.wide))
+            "m = M.raft_model(5, log_cap=%d, real_fields=%r) if %d else M.raft_model(5, term0=1000, loglen0=300) if %r else M.raft_model(5)\n"
+            "print(_native.specialize_check(m.to_struct())[0])\n" % (ROOT, args.log_cap, args.real_fields, args.log_cap, args.wide))
     env = dict(os.environ, DEMI_EXPERIMENT="1", DEMI_JIT_DUMP=os.path.join(d, "img"))
     if args.flags:
         env["DEMI_JIT_FLAGS"] = args.flags
