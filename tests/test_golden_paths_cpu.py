@@ -50,9 +50,9 @@ def test_array_model_fixtures(oracle):
     """DEMI_MODEL_ARRAY: the committed models (rows with LDX / STX, the array length in `flags`) and the oracle's verdicts on
     them, both strategies - the raft with a real log on the bench trace, the replicated log with its hole."""
     import pytest
-    for name in ("raft5_log8", "replog4_6"):
+    for name in ("raft5_log8", "replog4_6", "raft5_log8_fields"):
         model = M.load_model(os.path.join(G, name + "_model.json"))
-        assert model.array_len > 0
+        assert model.array_len > 0 and model.payloads == (5 if name.endswith("fields") else 2)
         z = np.load(os.path.join(G, name + "_verdicts.npz"))
         mm, ic, pm = (int(x) for x in z["limits"])
         for sname, strat in (("random", T.STRATEGY_FULLY_RANDOM), ("fifo", T.STRATEGY_SRC_DST_FIFO)):
@@ -62,4 +62,5 @@ def test_array_model_fixtures(oracle):
             assert (got["flags"] & T.V_VIOLATION).sum() > 10
     # the constructors still produce the committed tables
     assert M.raft_model(5, log_cap=8).code == M.load_model(os.path.join(G, "raft5_log8_model.json")).code
+    assert M.raft_model(5, log_cap=8, real_fields=True).code == M.load_model(os.path.join(G, "raft5_log8_fields_model.json")).code
     assert M.replog_model(4, 6, True, False).code == M.load_model(os.path.join(G, "replog4_6_model.json")).code

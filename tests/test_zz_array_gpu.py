@@ -255,7 +255,7 @@ def test_scheduler_mirror_on_a_table_with_arrays(oracle):
     assert IM.countMsgEvents(out) <= IM.countMsgEvents(verified) and stats.total_replays > 0
 
 
-@pytest.mark.parametrize("name", ["raft5_log8", "replog4_6"])
+@pytest.mark.parametrize("name", ["raft5_log8", "replog4_6", "raft5_log8_fields"])
 def test_array_golden_fixtures_on_gpu(name):
     """The committed fixtures of tools/make_golden.py (models as JSON, the oracle's verdicts for both strategies)."""
     G = os.path.join(os.path.dirname(__file__), "golden")

@@ -113,6 +113,8 @@ from demi_amd.fuzzer import wait_quiescence  # noqa: E402
 
 _, events, limits = raft5_config2()
 arr = {"raft5_log8": (M.raft_model(5, log_cap=8), events, limits, 2048),
+       # DEMI_MODEL_PAYLOADS(5): the same raft with akka-raft's field sets on the wire (AppendEntries with five fields)
+       "raft5_log8_fields": (M.raft_model(5, log_cap=8, real_fields=True), events, limits, 2048),
        "replog4_6": (M.replog_model(4, 6, True, False),
                      events_to_array([start(a) for a in range(4)] + [send(0 if i % 3 else i % 4, M.RL_PUT, 20 + i, 0) for i in range(6)]),
                      T.Limits(400, 7, 64, 0, 0, 0), 1024)}
