@@ -73,7 +73,7 @@ constexpr size_t K3_ANALYSIS_BYTES = DEMI_DPOR_MAX_TRACE * 4 + DEMI_DPOR_MAX_TRA
 __host__ __device__ inline size_t k3_lds_bytes(uint32_t code_len, uint32_t n_ext, uint32_t n_hs, uint32_t n_actors, bool wide = WIDE_TU,
                                                uint32_t hot = PEND_HOT, uint32_t waves = 4, uint32_t arr_words = ARR_WORDS) {
   return tables_lds_bytes(code_len, n_ext, n_hs, wide, arr_words) +
-         waves * (lane_mem_wave_bytes(n_actors, true, hot, wide, DEMI_FX_CAP, arr_words) + K3_ANALYSIS_BYTES);
+         waves * lane_mem_wave_bytes(n_actors, true, hot, wide, DEMI_FX_CAP, arr_words);
 }
 
 __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v, uint32_t lane) {
@@ -212,9 +212,6 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
                                      args.spill, (size_t)blockIdx.x * blockDim.x + threadIdx.x,
                                      (size_t)gridDim.x * blockDim.x);
   uint64_t* const st = mem.st;
-  unsigned char* const an = wave_base + (size_t)(blockDim.x >> 6) * lane_mem_wave_bytes(t.A, true) + (size_t)wave * K3_ANALYSIS_BYTES;
-  uint64_t* const s_anc = reinterpret_cast<uint64_t*>(an);
-  uint32_t* const s_meta = reinterpret_cast<uint32_t*>(an + DEMI_DPOR_MAX_TRACE * 32);
   const uint32_t A = t.A, NE = t.E, PMAX = args.p_max;
   const uint32_t max_messages = args.max_messages ? args.max_messages : 0x7FFFFFFFu;
 
@@ -492,29 +489,9 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
     // ---------------------------------------------------------- finished interleavings
     const bool fin = active && finish;
     const bool aborted = (flags & K3_ABORT) != 0;
-    uint32_t np = 0;
-    bool pairs_ovf = false;
-    {
-      // dpor(): racing pairs (:1122-1139), one finished trace at a time, all lanes helping
-      uint64_t todo = __ballot(fin && !aborted);
-      if (todo) __threadfence();            // the owner lane's trace stores are read back by the other lanes
-      while (todo) {
-        const int src = __builtin_ctzll(todo);
-        todo &= todo - 1;
-        const uint64_t s_sched = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(sched >> 32), src) << 32) |
-                                 (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)sched, src);
-        const uint32_t s_n = (uint32_t)__builtin_amdgcn_readlane((int)n_trace, src);
-        const uint32_t s_shared = args.shared_len ? args.shared_len[s_sched]
-                                  : (args.items && args.items[s_sched].src != 0xFFFFFFFFu) ? (uint32_t)args.items[s_sched].branch + 1u : 0u;
-#ifdef DEMI_K3_NO_PAIRS      // timing experiments only (DEMI_JIT_DEFINES): the interleavings without their racing-pair analysis
-        const uint32_t total = 0; (void)s_n; (void)s_shared;
-#else
-        const uint32_t total = k3_racing_pairs(args.traces + s_sched * DEMI_DPOR_MAX_TRACE, s_n, s_meta, s_anc,
-                                               args.pairs + s_sched * (uint64_t)args.max_pairs, args.max_pairs, lane, s_shared);
-#endif
-        if ((int)lane == src) { np = total < args.max_pairs ? total : args.max_pairs; pairs_ovf = total > args.max_pairs; }
-      }
-    }
+    // dpor()'s racing pairs (:1122-1139) of the finished traces are k3_analyze's, a kernel of its own after this one (round 4):
+    // in here a wave analysed its finished traces one after the other, all lanes helping and every other interleaving of the wave
+    // waiting - 25-39 % of the kernel - and the analysis' 9 KB of LDS per wave halved the number of resident waves
     K3_MARK(7);
     if (fin) {
       uint32_t viol = 0;
@@ -527,14 +504,15 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
       }
       for (uint32_t a = 0; a < A * ST_WORDS; a++) hash_step(hash, st[a * 64]);
       uint4 v;
+      args.n_pairs[sched] = 0;                 // (k3_analyze's to fill, with DEMI_V_PAIRS_OVF in the verdict)
       if (aborted) {
         v.x = flags & K3_ABORT; v.y = 0; v.z = 0; v.w = 0;
-        args.trace_len[sched] = 0; args.n_pairs[sched] = 0;
+        args.trace_len[sched] = 0;
       } else {
-        v.x = (viol ? DEMI_V_VIOLATION : 0u) | (pairs_ovf ? DEMI_V_PAIRS_OVF : 0u) |
+        v.x = (viol ? DEMI_V_VIOLATION : 0u) |
               ((count > max_messages) ? DEMI_V_MAXMSG : 0u) | ((deliveries < 0xFFFFu ? deliveries : 0xFFFFu) << 16);
         v.y = viol; v.z = (uint32_t)hash; v.w = (uint32_t)(hash >> 32);
-        args.trace_len[sched] = n_trace; args.n_pairs[sched] = np;
+        args.trace_len[sched] = n_trace;
       }
       *reinterpret_cast<uint4*>(&args.out[sched]) = v;
       active = false;
@@ -548,8 +526,34 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
     o[14] = ph_iters; o[15] = ph_active;
   }
 #endif
-#undef K3_ABORT
 #undef TIMER_BIT
 }
+
+#ifndef __HIPCC_RTC__      // (a generic kernel of the library: nothing in it depends on the table)
+// dpor()'s pair loop for the n interleavings k3_dpor just finished: one wave per trace, every trace of the round at once (a
+// 16 384-interleaving round is sixteen waves per SIMD: the analysis' dependent LDS reads hide behind one another instead of
+// holding up a wave's simulators).  Writes pairs[s][..] and n_pairs[s], and DEMI_V_PAIRS_OVF into the verdict.
+constexpr int K3A_WAVES = 4;
+__global__ __launch_bounds__(K3A_WAVES * 64) void k3_analyze(const K3Args args) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint64_t s = (uint64_t)blockIdx.x * K3A_WAVES + wave;
+  if (s >= args.n) return;
+  unsigned char* const an = smem + (size_t)wave * K3_ANALYSIS_BYTES;
+  uint64_t* const s_anc = reinterpret_cast<uint64_t*>(an);
+  uint32_t* const s_meta = reinterpret_cast<uint32_t*>(an + DEMI_DPOR_MAX_TRACE * 32);
+  const uint32_t fl = args.out[s].flags, n = args.trace_len[s];
+  if ((fl & K3_ABORT) || n == 0) return;                   // (aborted: k3_dpor left n_pairs = 0)
+  const uint32_t shared = args.shared_len ? args.shared_len[s]
+                          : (args.items && args.items[s].src != 0xFFFFFFFFu) ? (uint32_t)args.items[s].branch + 1u : 0u;
+  const uint32_t total = k3_racing_pairs(args.traces + s * DEMI_DPOR_MAX_TRACE, n, s_meta, s_anc, args.pairs + s * (uint64_t)args.max_pairs,
+                                         args.max_pairs, lane, shared);
+  if (lane == 0) {
+    args.n_pairs[s] = total < args.max_pairs ? total : args.max_pairs;
+    if (total > args.max_pairs) args.out[s].flags = fl | DEMI_V_PAIRS_OVF;
+  }
+}
+#endif
+#undef K3_ABORT
 
 }  // namespace demi

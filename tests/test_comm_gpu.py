@@ -62,14 +62,16 @@ ev3 = events_to_array([start(a) for a in range(3)] + [send(a, M.M_BOOTSTRAP) for
 ctx.comm_destroy()
 ctx.model_load(m3.to_struct()); ctx.dpor_load(ev3)
 par = T.DporParams(30, 0, 0, 0, 64, 4096)
-for batch in (5, 256):
-    srch = T.DporSearch(batch, 5000, 0, 1)
+# (rounds of 5: ragged blocks and padding ids at every world size, a budget of a few hundred interleavings - each round is
+# three collectives over gloo; rounds of 256: the whole exploration, until the queue is empty)
+for batch, budget in ((5, 400), (256, 5000)):
+    srch = T.DporSearch(batch, budget, 0, 1)
     ctx.comm_destroy()
     one = ctx.dpor_explore(par, srch)
     ctx.comm_create_host(rank, world, allgather)
     two = ctx.dpor_explore(par, srch)
     assert len(one[0]) == len(two[0]) and (one[0] == two[0]).all() and (one[1] == two[1]).all() and (one[2] == two[2]).all(), batch
-    assert one[4].exhausted and two[4].exhausted
+    assert len(one[0]) >= 400 and (batch == 5 or (one[4].exhausted and two[4].exhausted))
 ctx.comm_destroy()
 dist.barrier(); dist.destroy_process_group()
 ctx.close()
