@@ -69,11 +69,16 @@ struct K3Args {
 constexpr int K3_WAVES = 4;
 constexpr size_t K3_ANALYSIS_BYTES = DEMI_DPOR_MAX_TRACE * 4 + DEMI_DPOR_MAX_TRACE * 32;   // meta words + ancestor sets
 
+// The key plane (round 4): the node key of every LDS-resident pending message - key(child) = (key(producer) ^ word) * prime,
+// computed when the message is produced, while the producer's key is in a register - beside its word and side word.  The prefix
+// match and the delivery used to fetch the producer's trace entry from HBM for it: a dependent round trip in each of the two
+// longest phases of a scheduling step (slots beyond the LDS-resident ones still do).
+__host__ __device__ inline size_t k3_key_wave_bytes(uint32_t hot) { return (size_t)hot * 64 * 8; }
 // (waves: wavefronts per workgroup of the launch, at most K3_WAVES; the kernel reads it from blockDim)
 __host__ __device__ inline size_t k3_lds_bytes(uint32_t code_len, uint32_t n_ext, uint32_t n_hs, uint32_t n_actors, bool wide = WIDE_TU,
                                                uint32_t hot = PEND_HOT, uint32_t waves = 4, uint32_t arr_words = ARR_WORDS) {
   return tables_lds_bytes(code_len, n_ext, n_hs, wide, arr_words) +
-         waves * lane_mem_wave_bytes(n_actors, true, hot, wide, DEMI_FX_CAP, arr_words);
+         waves * (lane_mem_wave_bytes(n_actors, true, hot, wide, DEMI_FX_CAP, arr_words) + k3_key_wave_bytes(hot));
 }
 
 __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v, uint32_t lane) {
@@ -212,6 +217,8 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
                                      args.spill, (size_t)blockIdx.x * blockDim.x + threadIdx.x,
                                      (size_t)gridDim.x * blockDim.x);
   uint64_t* const st = mem.st;
+  uint64_t* const kp = reinterpret_cast<uint64_t*>(wave_base + (size_t)(blockDim.x >> 6) * lane_mem_wave_bytes(t.A, true) +
+                                                   (size_t)wave * k3_key_wave_bytes(PEND_HOT)) + lane;      // [slot * 64]
   const uint32_t A = t.A, NE = t.E, PMAX = args.p_max;
   const uint32_t max_messages = args.max_messages ? args.max_messages : 0x7FFFFFFFu;
 
@@ -226,6 +233,7 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
     return pf[(args.items && i > it_branch && i >= it_earlier) ? i + 1 : i];
   };
   uint32_t n_pend = 0, next_seq = 0, parent = 0, parent_depth = 0, cur_root = 0, qperiod = 0, next_qperiod = 0;
+  uint64_t parent_key = DPOR_ROOT_KEY;       // key of trace[parent]: what the messages produced now descend from
   uint32_t marker_ext = 0, qmarker_ext = 0, isolated = 0, rep = 0, flags = 0, count = 0, deliveries = 0;
   uint32_t blocked = 0;     // crashed actors (DEMI_OP_CRASH): skipped by getMatchingMessage (:478, 518) and getPendingEvent (:455)
   uint32_t n_trace = 0, ext_idx = 0;
@@ -252,16 +260,33 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
     if (n_pend >= PMAX) { flags |= DEMI_V_PENDING_OVF; return; }
     pend_store(mem, n_pend, word);
     aux_store(mem, n_pend, parent | (qperiod << 8) | (next_seq << 16));
+    if (n_pend < PEND_HOT) kp[n_pend * 64] = (parent_key ^ (uint64_t)word) * DPOR_PRIME;
     next_seq++;
     n_pend++;
   };
+  // the node key of the pending message in slot k (word cw, side word aux)
+  auto key_at = [&](uint32_t k, word_t cw, uint32_t aux) -> uint64_t {
+    return k < PEND_HOT ? kp[k * 64] : (tr[aux & 0xFF].key ^ (uint64_t)cw) * DPOR_PRIME;
+  };
+  // swap-remove of slot k (the last slot's message moves into it)
+  auto pend_remove_at = [&](uint32_t k) {
+    const uint32_t last = n_pend - 1;
+    const word_t lw = pend_load(mem, last);
+    const uint32_t la = aux_load(mem, last);
+    if (k < PEND_HOT && k != last) kp[k * 64] = key_at(last, lw, la);
+    pend_store(mem, k, lw);
+    aux_store(mem, k, la);
+    n_pend--;
+  };
   // (a wide table's trace entry reports the low half of the 64-bit message word: type, dst, src, p0 - include/demi_gpu.h)
   uint32_t pushed_depth = 0;
-  auto trace_push = [&](uint64_t key, word_t word, uint32_t par, uint32_t qp, uint32_t kind) -> int {
+  // (depth_hint >= 0: the entry's depth is known - a delivery matched against the prefix is the same node as the prefix entry, and a
+  // node IS its causal path - and the producer's entry need not be read back)
+  auto trace_push = [&](uint64_t key, word_t word, uint32_t par, uint32_t qp, uint32_t kind, int depth_hint = -1) -> int {
     if (n_trace >= DEMI_DPOR_MAX_TRACE) { flags |= DEMI_V_TRACE_OVF; return -1; }
     demi_dpor_trace_entry e;
     e.key = key; e.word = (uint32_t)word; e.parent = (uint8_t)par; e.qperiod = (uint8_t)qp;
-    e.depth = (uint8_t)(n_trace == 0 ? 0 : tr[par].depth + 1);
+    e.depth = (uint8_t)(n_trace == 0 ? 0 : depth_hint >= 0 ? (uint32_t)depth_hint : tr[par].depth + 1);
     e.kind = (uint8_t)kind;
     tr[n_trace] = e;
     pushed_depth = e.depth;                    // (the caller's setParentEvent: not read back from the trace)
@@ -334,7 +359,7 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
         n_pend = 0; next_seq = 0; qperiod = 0; next_qperiod = 0; rep = 0; flags = 0; count = 0; deliveries = 0; blocked = 0;
         n_trace = 0; ext_idx = 0; awaiting = false; marker_pending = false;
         trace_push(DPOR_ROOT_KEY, 0, 0, 0, 0);   // currentTrace += getRootEvent (:336-343)
-        parent = 0; parent_depth = 0; cur_root = 0;
+        parent = 0; parent_depth = 0; cur_root = 0; parent_key = DPOR_ROOT_KEY;
         run_external();
         K3_MARK(1);
       }
@@ -342,7 +367,7 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
         finish = true;
       } else {
         // ------------------------------------------------------ schedule_new_message (:421-648)
-        int chosen = -1;
+        int chosen = -1, chosen_depth = -1;
         bool chose_marker = false, none = false;
         count++;                                         // messagesScheduledSoFar += 1 (:583)
         if (count > max_messages) none = true;           // (:584-586)
@@ -373,8 +398,8 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
                 if (hit0) hit0 &= hit0 - 1; else hit1 &= hit1 - 1;
                 const word_t cw = pend_load(mem, k);
                 const uint32_t aux = aux_load(mem, k);
-                const uint64_t key = (tr[aux & 0xFF].key ^ (uint64_t)cw) * DPOR_PRIME;
-                if (key == want.key && (aux >> 16) < best_seq) { best_seq = aux >> 16; chosen = (int)k; }
+                const uint64_t key = key_at(k, cw, aux);
+                if (key == want.key && (aux >> 16) < best_seq) { best_seq = aux >> 16; chosen = (int)k; chosen_depth = (int)want.depth; }
               }
             }
           } while (args.prioritize && chosen < 0 && !chose_marker);
@@ -400,20 +425,18 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
         } else if (!none) {
           const word_t pw = pend_load(mem, (uint32_t)chosen);
           const uint32_t aux = aux_load(mem, (uint32_t)chosen);
-          pend_store(mem, (uint32_t)chosen, pend_load(mem, n_pend - 1));
-          aux_store(mem, (uint32_t)chosen, aux_load(mem, n_pend - 1));
-          n_pend--;
+          const uint64_t key = key_at((uint32_t)chosen, pw, aux);
+          pend_remove_at((uint32_t)chosen);
           const uint32_t snd = w_src(pw), rcv = w_dst(pw);
           if ((snd < DEMI_MAX_ACTORS && ((isolated >> snd) & 1)) || ((isolated >> rcv) & 1)) {
             if (snd == rcv) { flags |= DEMI_V_SELFMSG; finish = true; }   // (:631-633)
             // else: discarded, schedule again (:626-635)
           } else {
             const uint32_t par = aux & 0xFF;
-            const uint64_t key = (tr[par].key ^ (uint64_t)pw) * DPOR_PRIME;
-            const int ti = trace_push(key, pw, par, (aux >> 8) & 0xFF, 1);
+            const int ti = trace_push(key, pw, par, (aux >> 8) & 0xFF, 1, chosen_depth);
             if (ti < 0) finish = true;
             else {
-              parent = (uint32_t)ti; parent_depth = pushed_depth;   // setParentEvent
+              parent = (uint32_t)ti; parent_depth = pushed_depth; parent_key = key;   // setParentEvent
               w = pw; deliver = true;
               deliveries++;
               hash_step(hash, w);
@@ -430,7 +453,7 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
             const int ti = trace_push(dpor_marker_key(qmarker_ext), 0, cur_root, qperiod, 2);
             if (ti < 0) finish = true;
             else {
-              cur_root = (uint32_t)ti; parent = (uint32_t)ti; parent_depth = pushed_depth;
+              cur_root = (uint32_t)ti; parent = (uint32_t)ti; parent_depth = pushed_depth; parent_key = dpor_marker_key(qmarker_ext);
               run_external();
             }
           } else {
@@ -470,11 +493,7 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
             const uint32_t sq = aux_load(mem, q) >> 16;
             if (sq < best_seq) { best_seq = sq; best = (int)q; }
           }
-          if (best >= 0) {
-            pend_store(mem, (uint32_t)best, pend_load(mem, n_pend - 1));
-            aux_store(mem, (uint32_t)best, aux_load(mem, n_pend - 1));
-            n_pend--;
-          }
+          if (best >= 0) pend_remove_at((uint32_t)best);
         } else {
           const uint32_t bit = TIMER_BIT(me, type);
           if (!(rep & bit)) {
