@@ -384,12 +384,21 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
             } else {
               // first which pending slots hold this message word (a branch-free pass: its LDS / scratch reads do not wait for
               // one another), then the identity test - producer's key, FIFO order - for those few
+              // (round 4: the LDS-resident slots in ONE unrolled pass - every slot a read at a constant offset, a compare and a
+              // constant bit, slots past n_pend masked off afterwards - instead of a loop with a residency test, a 64-bit
+              // variable shift and a branch per slot: the scan was 40 % of a scheduling step; the slots in the HBM scratch follow)
               uint32_t best_seq = 0xFFFFFFFFu;
               uint64_t hit0 = 0, hit1 = 0;
               if (!((blocked >> w_dst(want.word)) & 1u)) {
-#pragma unroll 4
-                for (uint32_t k = 0; k < n_pend; k++) {
-                  const uint64_t h = ((uint32_t)pend_load(mem, k) == want.word) ? 1ull : 0ull;   // (the entry holds the word's low half)
+#pragma unroll
+                for (uint32_t k = 0; k < PEND_HOT; k++) {
+                  const uint64_t h = ((uint32_t)mem.pend[k * 64] == want.word) ? 1ull : 0ull;   // (the entry holds the word's low half)
+                  if (k < 64) hit0 |= h << k; else hit1 |= h << (k - 64);
+                }
+                if (n_pend < 64) hit0 &= (1ull << n_pend) - 1ull;
+                if (n_pend <= 64) hit1 = 0; else if (n_pend < 128) hit1 &= (1ull << (n_pend - 64)) - 1ull;
+                for (uint32_t k = PEND_HOT; k < n_pend; k++) {
+                  const uint64_t h = ((uint32_t)pend_load(mem, k) == want.word) ? 1ull : 0ull;
                   if (k < 64) hit0 |= h << k; else hit1 |= h << (k - 64);
                 }
               }
@@ -408,11 +417,18 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
         if (!none && chosen < 0 && !chose_marker) {
           // getPendingEvent (:452-472), iteration order pinned: (snd, rcv) ascending, FIFO inside
           uint32_t best = 0xFFFFFFFFu;
-#pragma unroll 4
-          for (uint32_t k = 0; k < n_pend; k++) {                // (branch-free body: the reads of consecutive slots overlap)
+#pragma unroll
+          for (uint32_t k = 0; k < PEND_HOT; k++) {              // (the LDS-resident slots, unrolled: constant offsets, no residency test)
+            const word_t pw = mem.pend[k * 64];
+            const uint32_t ord = (((w_src(pw) << 4) | w_dst(pw)) << 16) | (mem.pend_aux[k * 64] >> 16);
+            const bool ok = k < n_pend && !((blocked >> w_dst(pw)) & 1u) && ord < best;      // !(blockedActors contains k._2) (:455)
+            best = ok ? ord : best;
+            chosen = ok ? (int)k : chosen;
+          }
+          for (uint32_t k = PEND_HOT; k < n_pend; k++) {         // (the slots in the HBM scratch)
             const word_t pw = pend_load(mem, k);
             const uint32_t ord = (((w_src(pw) << 4) | w_dst(pw)) << 16) | (aux_load(mem, k) >> 16);
-            const bool ok = !((blocked >> w_dst(pw)) & 1u) && ord < best;      // !(blockedActors contains k._2) (:455)
+            const bool ok = !((blocked >> w_dst(pw)) & 1u) && ord < best;
             best = ok ? ord : best;
             chosen = ok ? (int)k : chosen;
           }
@@ -488,8 +504,23 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
           const word_t wantw = msg_word(type, DEMI_DEADLETTERS, me, 0, 0);
           int best = -1;
           uint32_t best_seq = 0xFFFFFFFFu;
-          for (uint32_t q = 0; q < n_pend; q++) {
-            if (pend_load(mem, q) != wantw) continue;
+          // (which slots hold the word: one unrolled pass over the LDS-resident slots, as in getMatchingMessage; the side words
+          // only of those - usually none or one)
+          uint64_t hit0 = 0, hit1 = 0;
+#pragma unroll
+          for (uint32_t q = 0; q < PEND_HOT; q++) {
+            const uint64_t h = (mem.pend[q * 64] == wantw) ? 1ull : 0ull;
+            if (q < 64) hit0 |= h << q; else hit1 |= h << (q - 64);
+          }
+          if (n_pend < 64) hit0 &= (1ull << n_pend) - 1ull;
+          if (n_pend <= 64) hit1 = 0; else if (n_pend < 128) hit1 &= (1ull << (n_pend - 64)) - 1ull;
+          for (uint32_t q = PEND_HOT; q < n_pend; q++) {
+            const uint64_t h = (pend_load(mem, q) == wantw) ? 1ull : 0ull;
+            if (q < 64) hit0 |= h << q; else hit1 |= h << (q - 64);
+          }
+          while (hit0 | hit1) {
+            const uint32_t q = hit0 ? (uint32_t)__builtin_ctzll(hit0) : 64u + (uint32_t)__builtin_ctzll(hit1);
+            if (hit0) hit0 &= hit0 - 1; else hit1 &= hit1 - 1;
             const uint32_t sq = aux_load(mem, q) >> 16;
             if (sq < best_seq) { best_seq = sq; best = (int)q; }
           }
