@@ -391,9 +391,14 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
               uint64_t hit0 = 0, hit1 = 0;
               if (!((blocked >> w_dst(want.word)) & 1u)) {
 #pragma unroll
-                for (uint32_t k = 0; k < PEND_HOT; k++) {
-                  const uint64_t h = ((uint32_t)mem.pend[k * 64] == want.word) ? 1ull : 0ull;   // (the entry holds the word's low half)
-                  if (k < 64) hit0 |= h << k; else hit1 |= h << (k - 64);
+                for (uint32_t c = 0; c < PEND_HOT; c += 8) {          // (eight slots at a time, as far as some lane's set reaches)
+                  if (c < n_pend) {
+#pragma unroll
+                    for (uint32_t k = c; k < c + 8 && k < PEND_HOT; k++) {
+                      const uint64_t h = ((uint32_t)mem.pend[k * 64] == want.word) ? 1ull : 0ull;   // (the entry holds the word's low half)
+                      if (k < 64) hit0 |= h << k; else hit1 |= h << (k - 64);
+                    }
+                  }
                 }
                 if (n_pend < 64) hit0 &= (1ull << n_pend) - 1ull;
                 if (n_pend <= 64) hit1 = 0; else if (n_pend < 128) hit1 &= (1ull << (n_pend - 64)) - 1ull;
@@ -418,12 +423,17 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
           // getPendingEvent (:452-472), iteration order pinned: (snd, rcv) ascending, FIFO inside
           uint32_t best = 0xFFFFFFFFu;
 #pragma unroll
-          for (uint32_t k = 0; k < PEND_HOT; k++) {              // (the LDS-resident slots, unrolled: constant offsets, no residency test)
-            const word_t pw = mem.pend[k * 64];
-            const uint32_t ord = (((w_src(pw) << 4) | w_dst(pw)) << 16) | (mem.pend_aux[k * 64] >> 16);
-            const bool ok = k < n_pend && !((blocked >> w_dst(pw)) & 1u) && ord < best;      // !(blockedActors contains k._2) (:455)
-            best = ok ? ord : best;
-            chosen = ok ? (int)k : chosen;
+          for (uint32_t c = 0; c < PEND_HOT; c += 8) {           // (the LDS-resident slots, unrolled by eight: constant offsets, no residency test)
+            if (c < n_pend) {
+#pragma unroll
+              for (uint32_t k = c; k < c + 8 && k < PEND_HOT; k++) {
+                const word_t pw = mem.pend[k * 64];
+                const uint32_t ord = (((w_src(pw) << 4) | w_dst(pw)) << 16) | (mem.pend_aux[k * 64] >> 16);
+                const bool ok = k < n_pend && !((blocked >> w_dst(pw)) & 1u) && ord < best;      // !(blockedActors contains k._2) (:455)
+                best = ok ? ord : best;
+                chosen = ok ? (int)k : chosen;
+              }
+            }
           }
           for (uint32_t k = PEND_HOT; k < n_pend; k++) {         // (the slots in the HBM scratch)
             const word_t pw = pend_load(mem, k);
@@ -508,9 +518,14 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
           // only of those - usually none or one)
           uint64_t hit0 = 0, hit1 = 0;
 #pragma unroll
-          for (uint32_t q = 0; q < PEND_HOT; q++) {
-            const uint64_t h = (mem.pend[q * 64] == wantw) ? 1ull : 0ull;
-            if (q < 64) hit0 |= h << q; else hit1 |= h << (q - 64);
+          for (uint32_t c = 0; c < PEND_HOT; c += 8) {
+            if (c < n_pend) {
+#pragma unroll
+              for (uint32_t q = c; q < c + 8 && q < PEND_HOT; q++) {
+                const uint64_t h = (mem.pend[q * 64] == wantw) ? 1ull : 0ull;
+                if (q < 64) hit0 |= h << q; else hit1 |= h << (q - 64);
+              }
+            }
           }
           if (n_pend < 64) hit0 &= (1ull << n_pend) - 1ull;
           if (n_pend <= 64) hit1 = 0; else if (n_pend < 128) hit1 &= (1ull << (n_pend - 64)) - 1ull;
