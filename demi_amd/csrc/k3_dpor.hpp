@@ -375,9 +375,16 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
           // getMatchingMessage: skip root / id-0 heads (:363-372), then match the head by identity; with
           // prioritizePendingUponDivergence keep popping heads until one is pending (getNextMatchingMessage :537-550)
           do {
-            while (pfx < pfx_len && pf_at(pfx).kind == 0) pfx++;
+            // (one 16-byte read of the head: the kind test used to be a read of its own in front of it - two trips to the arena
+            // in a row; only the root entry at position 0 is ever skipped)
             if (pfx >= pfx_len) break;
-            const demi_dpor_trace_entry want = pf_at(pfx);
+            demi_dpor_trace_entry want = pf_at(pfx);
+            while (want.kind == 0) {
+              pfx++;
+              if (pfx >= pfx_len) break;
+              want = pf_at(pfx);
+            }
+            if (pfx >= pfx_len) break;
             pfx++;
             if (want.kind == 2) {
               if (marker_pending && want.key == dpor_marker_key(marker_ext)) chose_marker = true;

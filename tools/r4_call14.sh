@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 mkdir -p gpurun_out
 {
-for hot in default 16 24 32 40; do
+for hot in ${HOTS:-default 16 24 32 40}; do
   for wl in dpor config5; do
     if [ $hot = default ]; then E="DEMI_X=1"; else E="DEMI_JIT_K3_HOT=$hot"; fi
     env $E DEMI_K3_VERBOSE=1 timeout 300 python bench.py --workload $wl --no-cpu-baseline > gpurun_out/r04_key_${hot}_$wl.json 2> gpurun_out/r04_key_${hot}_$wl.err
@@ -23,4 +23,4 @@ PY
 done
 bash tools/k3_phases.sh 2>&1 | grep 'k3 phases' | head -4
 } 2>&1 | tee gpurun_out/r04_k3_key_plane.txt
-timeout 600 python -m pytest tests/test_k3_gpu.py tests/test_blocked_actors_gpu.py tests/test_payloads_gpu.py tests/test_zz_array_gpu.py tests/test_wide_gpu.py -m gpu -x -q 2>&1 | tail -3 | tee gpurun_out/r04_k3_key_tests.log
+[ -n "$SKIP_TESTS" ] || timeout 600 python -m pytest tests/test_k3_gpu.py tests/test_blocked_actors_gpu.py tests/test_payloads_gpu.py tests/test_zz_array_gpu.py tests/test_wide_gpu.py -m gpu -x -q 2>&1 | tail -3 | tee gpurun_out/r04_k3_key_tests.log
