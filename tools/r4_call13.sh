@@ -6,8 +6,8 @@ cd $R
 mkdir -p gpurun_out
 timeout 900 python -m pytest tests -m gpu -x -q --durations=10 > gpurun_out/r04_gpu_tests_final.log 2>&1
 grep -E 'passed|failed' gpurun_out/r04_gpu_tests_final.log | tail -2
-/usr/bin/time -v timeout 600 python bench.py > gpurun_out/r04_bench_final.json 2> gpurun_out/r04_bench_final.err
-grep -E 'Elapsed|Maximum resident' gpurun_out/r04_bench_final.err
+S0=$(date +%s); timeout 600 python bench.py > gpurun_out/r04_bench_final.json 2> gpurun_out/r04_bench_final.err
+echo "bench wall $(( $(date +%s) - S0 )) s"
 python - <<'PY'
 import json
 d = json.loads(open('gpurun_out/r04_bench_final.json').read().strip().splitlines()[-1])
