@@ -112,6 +112,13 @@ def test_array_tables_through_every_kernel_on_the_cpu():
                   "test_zz_array_gpu.py::test_array_golden_fixtures_on_gpu"])
 
 
+def test_payload_tables_through_every_kernel_on_the_cpu():
+    """DEMI_MODEL_PAYLOADS (LDP / PSET, the 48-bit payload area): the raft with akka-raft's field sets through K1 in every
+    variant, recorded traces, K2, the native DDMin and K3; a random table with four 12-bit fields."""
+    run_emulated(["test_payloads_gpu.py::test_raft_with_akka_raft_field_sets_through_the_kernels",
+                  "test_payloads_gpu.py::test_random_payload_tables_parity[4]"], threads=1)
+
+
 def test_results_do_not_depend_on_the_order_of_the_lanes_within_an_interval():
     run_emulated(["test_k1_gpu.py::test_raft5_parity_all_capacities[32]",
                   "test_k1_gpu.py::test_srcdst_fifo_parity_raft5[64]",
