@@ -258,9 +258,15 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
     if (args.depth_bound && parent_depth + 1 >= args.depth_bound) return;
     if (flags & DEMI_OVF_ANY) return;
     if (n_pend >= PMAX) { flags |= DEMI_V_PENDING_OVF; return; }
-    pend_store(mem, n_pend, word);
-    aux_store(mem, n_pend, parent | (qperiod << 8) | (next_seq << 16));
-    if (n_pend < PEND_HOT) kp[n_pend * 64] = (parent_key ^ (uint64_t)word) * DPOR_PRIME;
+    const uint32_t side = parent | (qperiod << 8) | (next_seq << 16);
+    if (n_pend < PEND_HOT) {          // (the usual case under ONE residency test: word, side word and key into LDS)
+      mem.pend[n_pend * 64] = word;
+      mem.pend_aux[n_pend * 64] = side;
+      kp[n_pend * 64] = (parent_key ^ (uint64_t)word) * DPOR_PRIME;
+    } else {
+      pend_store(mem, n_pend, word);
+      aux_store(mem, n_pend, side);
+    }
     next_seq++;
     n_pend++;
   };
@@ -271,11 +277,17 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
   // swap-remove of slot k (the last slot's message moves into it)
   auto pend_remove_at = [&](uint32_t k) {
     const uint32_t last = n_pend - 1;
-    const word_t lw = pend_load(mem, last);
-    const uint32_t la = aux_load(mem, last);
-    if (k < PEND_HOT && k != last) kp[k * 64] = key_at(last, lw, la);
-    pend_store(mem, k, lw);
-    aux_store(mem, k, la);
+    if (last < PEND_HOT) {            // (the whole set is LDS-resident - the usual case - under ONE test; k <= last)
+      mem.pend[k * 64] = mem.pend[last * 64];
+      mem.pend_aux[k * 64] = mem.pend_aux[last * 64];
+      kp[k * 64] = kp[last * 64];
+    } else {
+      const word_t lw = pend_load(mem, last);
+      const uint32_t la = aux_load(mem, last);
+      if (k < PEND_HOT && k != last) kp[k * 64] = key_at(last, lw, la);
+      pend_store(mem, k, lw);
+      aux_store(mem, k, la);
+    }
     n_pend--;
   };
   // (a wide table's trace entry reports the low half of the 64-bit message word: type, dst, src, p0 - include/demi_gpu.h)
@@ -456,9 +468,12 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
         if (chose_marker) {                              // awaitQuiescenceUpdate (:256-266)
           marker_pending = false; awaiting = true; next_qperiod = marker_ext + 1; qmarker_ext = marker_ext;
         } else if (!none) {
-          const word_t pw = pend_load(mem, (uint32_t)chosen);
-          const uint32_t aux = aux_load(mem, (uint32_t)chosen);
-          const uint64_t key = key_at((uint32_t)chosen, pw, aux);
+          word_t pw; uint32_t aux; uint64_t key;
+          if ((uint32_t)chosen < PEND_HOT) {        // (one residency test for the three reads)
+            pw = mem.pend[chosen * 64]; aux = mem.pend_aux[chosen * 64]; key = kp[chosen * 64];
+          } else {
+            pw = pend_load(mem, (uint32_t)chosen); aux = aux_load(mem, (uint32_t)chosen); key = key_at((uint32_t)chosen, pw, aux);
+          }
           pend_remove_at((uint32_t)chosen);
           const uint32_t snd = w_src(pw), rcv = w_dst(pw);
           if ((snd < DEMI_MAX_ACTORS && ((isolated >> snd) & 1)) || ((isolated >> rcv) & 1)) {
