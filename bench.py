@@ -613,6 +613,8 @@ def main():
     ap.add_argument("--strategy", choices=["random", "fifo"], default="random",
                     help="RandomizationStrategy: FullyRandom (the headline workload) or SrcDstFIFO")
     args = ap.parse_args()
+    if args.real_fields and not args.log_cap:
+        ap.error("--real-fields needs --log-cap N (the field sets include the log's prevLogIndex / prevLogTerm / entry)")
 
     import numpy as np
     import torch
