@@ -26,15 +26,10 @@ namespace demi {
 struct PairEntry {           // 64 bytes, one per UNORDERED pair of node keys: everything dpor() does with a racing pair touches
                              // the ordered pair and its flip, so both live in one line.  Side 0 is (lo, hi), side 1 is (hi, lo).
   unsigned long long lo, hi; // lo < hi; lo == 0 = empty slot (node keys are FNV chains, never 0)
-  uint32_t state[2];         // per side: bit 31 explored; bits 0..8: 1 + highest branch of a queued point flipping into it
-  uint32_t pad0[2];
-  // (round 4: key and state share the entry's first 32-byte sector - most probes of a round meet a pair that is explored
-  // already and need nothing else, and the table is far larger than the caches: config 5's pair kernels moved a 64-byte line
-  // per probe - the candidates, which only unexplored pairs read or write, lie in the second sector)
   unsigned long long cand[2];   // per side: this round's candidate for the points flipping INTO it: round | branch + 1 | ~ordinal
-  uint32_t pad[4];
+  uint32_t state[2];         // per side: bit 31 explored; bits 0..8: 1 + highest branch of a queued point flipping into it
+  uint32_t pad[6];
 };
-static_assert(sizeof(PairEntry) == 64, "one line per unordered pair");
 constexpr uint32_t PE_EXPLORED = 0x80000000u, PE_QMASK = 0x1FFu;
 
 __device__ __forceinline__ uint64_t pair_hash(uint64_t a, uint64_t b) {
@@ -151,9 +146,7 @@ __global__ __launch_bounds__(256) void k3_pairs_insert(const K3PairArgs a) {
       }
     }
     const unsigned long long mine = cand_pack(a.round, p.branch, (unsigned long long)it * a.max_pairs + k);
-    // (s2 is the other side of the same entry.  A flipped pair that is explored already gets no candidate: decide skips its
-    // points before it looks at one - the explored bit is only ever set - and the candidates' sector stays untouched)
-    if (!(e1->state[s2 & 1] & PE_EXPLORED) && e1->cand[(s2 & 1)] < mine) atomicMax(&e1->cand[s2 & 1], mine);
+    if (e1->cand[(s2 & 1)] < mine) atomicMax(&e1->cand[s2 & 1], mine);   // (s2 is the other side of the same entry)
   }
 }
 
@@ -229,7 +222,7 @@ __global__ __launch_bounds__(256) void k3_pairs_insert_rec(const K3PairArgs a) {
       }
     }
     const unsigned long long mine = cand_pack(a.round, r.branch, r.ordinal);
-    if (!(e1->state[s2 & 1] & PE_EXPLORED) && e1->cand[s2 & 1] < mine) atomicMax(&e1->cand[s2 & 1], mine);
+    if (e1->cand[s2 & 1] < mine) atomicMax(&e1->cand[s2 & 1], mine);
   }
 }
 
