@@ -147,6 +147,28 @@ def test_edit_distance_dpor_ddmin_end_to_end(oracle):
     assert len(ddmin.oracle.subseqToDPOR) >= len({c for c, _ in ddmin.ddmin.consulted})
 
 
+def test_edit_distance_dpor_ddmin_on_a_table_with_payload_fields(oracle):
+    """The same search on a wide table whose messages carry four fields (DEMI_MODEL_PAYLOADS(4)): the DPOR initial trace chains
+    64-bit message words, the writer's identity travels in the third field (LDP / PSET), the violation needs the same three
+    externals."""
+    MSGS = [("Go", T.MSG_EXTERNAL), ("Write", T.MSG_INTERNAL)]
+    hnd = {(0, "Go"): Asm().mov(M.T0, 0).ldi16(M.T1, 0x123).send(1, M.T0, M.T1, 7, M.ME, 0xEE),
+           (0, "Write"): Asm().ldp(M.F[0], 2).ldp(M.F[2], 3).add(M.F[1], M.F[1], 1)}
+    model = build_model("race4p", 4, MSGS, hnd, [[0] * 8] * 4, (T.INV_NEVER, 0, 1, 0), wide=True, payloads=4)
+    assert oracle.model_validate(model)[0] == 0
+    ev = events_to_array([start(0), start(1), start(2), start(3), send(2, 0), send(1, 0), send(3, 0), send(2, 0)])
+    v, trace = _execution(oracle, model, ev)
+    writes = trace.events[(trace.events["kind"] == T.REC_MSG_EVENT) & (trace.events["msg_type"] == 1)]
+    assert len(writes) and all(T.payload_fields(T.rec_area(e), 4)[:2] == [0x123, 7] and T.payload_fields(T.rec_area(e), 4)[3] == 0xEE for e in writes)
+    fp = ViolationFingerprint(v.fingerprint)
+    mcs, ddmin, verified, _ = editDistanceDporDDMin(SchedulerConfig(model=model), trace, fp, stopAtSize=2, maxMaxDistance=8,
+                                                    batch=8, backend=oracle.dpor_batch)
+    assert verified is not None
+    kinds = [(int(ev[i]["kind"]), int(ev[i]["a"])) for i in mcs]
+    assert (T.EV_START, 0) in kinds and (T.EV_START, 1) in kinds and (T.EV_SEND, 1) in kinds
+    assert len(mcs) < len(ev) and len(mcs) <= 4 and ddmin.distances[0][0] == 0
+
+
 @pytest.mark.parametrize("which", ["two_writers", "raft3"])
 def test_native_ordered_exploration_equals_the_python_mirror(oracle, which):
     """demi_dpor_explore's plain loop for ArvindDistanceOrdering / setMaxDistance / setInitialTrace (dpor_host.hpp
