@@ -10,6 +10,7 @@ Inputs (transition table, trace) and outputs (verdicts) are resident in HBM duri
   python bench.py --gpus 1 --steps 10 --warmup 2
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
       --master-port P bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N ...          (no launcher: bench.py starts the N ranks itself, the same way, on a free port)
 
 Every timed step evaluates FRESH seeds: step i of rank r runs the schedule indices [(i * W + r) * n, ... + n), so that
 `bugs_per_hr` counts the distinct violating executions (by the 64-bit hash over every delivered message and every final
@@ -585,6 +586,22 @@ def bench_ddmin(ctx_device, cpu_baseline=True, n=1 << 20):
     return out
 
 
+def _self_launch(n_gpus):
+    """Re-run this command as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py <same arguments>`; returns the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -615,6 +632,12 @@ def main():
     args = ap.parse_args()
     if args.real_fields and not args.log_cap:
         ap.error("--real-fields needs --log-cap N (the field sets include the log's prevLogIndex / prevLogTerm / entry)")
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: become the launcher.  One rank per GPU under torch.distributed.run
+        # (the command the contract names), rendezvous on 127.0.0.1 at a port the kernel hands out; rank 0's one JSON line goes
+        # to this process's stdout unchanged.  Under torchrun WORLD_SIZE is set and this branch is never taken.
+        raise SystemExit(_self_launch(args.gpus))
 
     import numpy as np
     import torch

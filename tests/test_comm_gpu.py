@@ -175,6 +175,26 @@ def test_bench_py_two_ranks_on_one_gpu(tmp_path):
     assert d["violations_last_step"] > d1["violations_last_step"] > 0
 
 
+def test_bench_py_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with NO external launcher (the shape of the driver's 1-GPU command, with N = 2): bench.py
+    re-runs itself under torch.distributed.run on a free port and rank 0's one JSON line arrives on the caller's stdout.
+    Same one-GPU plumbing environment as the test above."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DEMI_BENCH_BACKEND="gloo", DEMI_BENCH_ONE_GPU="1", DEMI_BENCH_COMM="host")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--schedules", "65536",
+           "--no-prewarm", "--no-cpu-baseline", "--no-secondary"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and d["timed_region"]["schedules"] == 2 * 2 * 65536
+    assert "demi_comm_allgather_dev" in d["config"]["collective"]
+
+
 # BASELINE configs 4 and 5 over the ranks, exactly as bench.py --gpus N runs them: demi_ddmin with the communicator (every
 # speculative frontier split over the ranks inside the library) and the bounded DPOR exploration of the shuffle pipeline
 # (apps.shuffle8_config5_large; a smaller budget here), each against the single-rank call on the same inputs.
