@@ -17,7 +17,7 @@ EXPORTS = ["demi_ctx_create", "demi_ctx_destroy", "demi_last_error", "demi_versi
            "demi_replay_removal_batch", "demi_replay_get_kept", "demi_replay_recorded_len", "demi_ddmin", "demi_dpor_set_traces", "demi_model_specialize", "demi_model_is_specialized", "demi_model_code_id",
            "demi_specialize_check", "demi_specialize_source", "demi_specialize_source_k1", "demi_provenance_prune", "demi_device_probe", "demi_device_probe_mix", "demi_calib_rw", "demi_random_explore_flagged", "demi_collect_flagged_dev",
            "demi_comm_unique_id", "demi_comm_create", "demi_comm_create_host", "demi_comm_destroy", "demi_comm_rank",
-           "demi_comm_allgather_dev", "demi_random_explore_sharded", "demi_replay_batch_sharded", "demi_abi_version", "demi_replay_externals_len", "demi_edit_distance_dpor_ddmin"]
+           "demi_comm_allgather_dev", "demi_random_explore_sharded", "demi_replay_batch_sharded", "demi_abi_version", "demi_replay_externals_len", "demi_edit_distance_dpor_ddmin", "demi_dpor_explored"]
 
 _lib = None
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)     # demi_allgather_fn
@@ -100,6 +100,8 @@ def lib():
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.demi_dpor_explore.argtypes = [C.c_void_p, C.POINTER(T.DporParams), C.POINTER(T.DporSearch), C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(T.DporStats)]
+    L.demi_dpor_explored.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_void_p,
+                                     C.POINTER(C.c_uint32)]
     L.demi_random_explore_violations.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(T.Limits), C.c_void_p,
                                                  C.c_uint32, C.POINTER(C.c_uint64)]
     L.demi_random_explore_flagged.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(T.Limits), C.c_uint32, C.c_void_p,
@@ -374,6 +376,15 @@ class Context:
                                             plen.ctypes.data, rounds.ctypes.data, vt.ctypes.data, C.byref(vl), C.byref(stats)))
         n = int(stats.interleavings)
         return verdicts[:n].copy(), plen[:n].copy(), rounds[:int(stats.launches)].copy(), vt[:vl.value].copy(), stats
+
+    def dpor_explored(self, index):
+        """Interleaving `index` of the last dpor_explore: (next trace it was started from, shared length, executed trace)."""
+        import numpy as np
+        nt = np.zeros(T.DPOR_MAX_TRACE, dtype=T.DPOR_TRACE_DTYPE)
+        tr = np.zeros(T.DPOR_MAX_TRACE, dtype=T.DPOR_TRACE_DTYPE)
+        nl, sl, tl = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+        self._check(lib().demi_dpor_explored(self._h, C.c_uint64(int(index)), nt.ctypes.data, C.byref(nl), C.byref(sl), tr.ctypes.data, C.byref(tl)))
+        return nt[:nl.value].copy(), int(sl.value), tr[:tl.value].copy()
 
     # ---- multi-GPU (one process and one Context per GPU)
     @staticmethod

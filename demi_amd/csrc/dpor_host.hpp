@@ -1048,13 +1048,24 @@ int explore_reference_order(Run&& run, Fetch&& fetch, uint32_t max_pairs, const 
 // With several GPUs every rank runs this same loop on identical queues (SPMD): dev.round() returns the same verdicts,
 // points and kills on every rank, whatever part of the round and of the explored-pair table that rank worked on.
 
+// What the device-resident explorations remember of every interleaving they return (demi_dpor_explored): the backtrack point
+// it was dequeued as and the arena row that holds the trace it executed.  8 + 4 bytes per interleaving.
+struct ExploredLog {
+  std::vector<demi::DporItem> item;
+  std::vector<uint32_t> id;
+  void clear() { item.clear(); id.clear(); }
+  void add(const demi::DporItem& it, uint32_t arena_id) { item.push_back(it); id.push_back(arena_id); }
+  size_t size() const { return id.size(); }
+};
+
 template <class Dev>
 int explore_rounds_resident(Dev&& dev, const demi_dpor_search* srch, demi_verdict* out_verdicts, uint32_t* out_prefix_len,
                             uint32_t* out_rounds, demi_dpor_trace_entry* first_violation_trace, uint32_t* first_violation_len,
-                            demi_dpor_stats* stats, double* seconds) {
+                            demi_dpor_stats* stats, double* seconds, ExploredLog* log = nullptr) {
   memset(stats, 0, sizeof *stats);
   stats->first_violation = ~0ull;
   if (first_violation_len) *first_violation_len = 0;
+  if (log) log->clear();
   auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   std::deque<demi::DporPoint> bucket[256];
   int top = -1;
@@ -1086,6 +1097,7 @@ int explore_rounds_resident(Dev&& dev, const demi_dpor_search* srch, demi_verdic
       const uint64_t idx = stats->interleavings++;
       out_verdicts[idx] = vd[i];
       out_prefix_len[idx] = items[i].src == 0xFFFFFFFFu ? 0u : (uint32_t)items[i].later;
+      if (log) log->add(items[i], base_id + i);
       if (vd[i].flags & DEMI_V_VIOLATION) {
         stats->violations++;
         found = true;
@@ -1264,10 +1276,11 @@ inline size_t ref_fetch_width() {
 template <class Dev>
 int explore_reference_resident(Dev&& dev, const demi_dpor_search* srch, demi_verdict* out_verdicts, uint32_t* out_prefix_len,
                                uint32_t* out_rounds, demi_dpor_trace_entry* first_violation_trace, uint32_t* first_violation_len,
-                               demi_dpor_stats* stats, double* seconds) {
+                               demi_dpor_stats* stats, double* seconds, ExploredLog* log = nullptr) {
   memset(stats, 0, sizeof *stats);
   stats->first_violation = ~0ull;
   if (first_violation_len) *first_violation_len = 0;
+  if (log) log->clear();
   auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   auto key_of = [](const demi::DporItem& it) -> uint64_t {
     return ((uint64_t)it.src << 24) | ((uint64_t)it.branch << 16) | ((uint64_t)it.later << 8) | (uint64_t)it.earlier;
@@ -1311,6 +1324,7 @@ int explore_reference_resident(Dev&& dev, const demi_dpor_search* srch, demi_ver
       const uint64_t idx = stats->interleavings++;
       out_verdicts[idx] = r.verdict;
       out_prefix_len[idx] = cur.src == 0xFFFFFFFFu ? 0u : (uint32_t)cur.later;
+      if (log) log->add(cur, r.id);
       bool found = false;
       if (r.verdict.flags & DEMI_V_VIOLATION) {
         stats->violations++;

@@ -9,9 +9,13 @@ JSON file, so a JVM (or anything else) can read it without this package:
   mcs.bin                   uint32[]           (indices of the minimal causal sequence, optional)
   meta.json                 fingerprint code, limits, seed, format version, rec_event_size
 
-Format 2 (round 3 on): demi_rec_event is 16 bytes (16-bit payload fields, a reserved half-word).  Format 1 directories hold the
-12-byte record of rounds 1-2 (8-bit payloads); load_experiment reads them with that layout and converts field by field.  A file
-whose size is not a whole number of records of its format is refused, never truncated.
+Format 2: demi_rec_event is 16 bytes (16-bit payload fields, the payload area's high half-word) and meta.json says so
+(rec_event_size).  "format": 1 was written by two generations of this package: rounds 1-2 with the 12-byte record (8-bit
+payloads), and round 3 - before the version was bumped - already with the 16-byte record.  A format-1 directory is therefore
+read by what its bytes are: rec_event_size from meta.json if present, else whichever of the two record sizes divides the file AND
+parses as a recorded execution (kinds and actor ids in range, every MsgEvent preceded by the MsgSend of the same id and
+message); when both or neither do, the directory is refused - never guessed.  A file whose size is not a whole number of
+records of its format is refused, never truncated.
 """
 import json
 import os
@@ -46,6 +50,47 @@ def save_experiment(path: str, model: Model, trace: EventTrace, fingerprint: Vio
         json.dump(meta, f)
 
 
+def _plausible_recording(rec) -> bool:
+    """Is this array a recorded execution?  Kinds and actor ids in range, ids of MsgSend records distinct, every MsgEvent
+    delivers a message a MsgSend with the same id, sender, receiver and type produced earlier (RandomScheduler.scala:319-320,
+    460-463: the two records of one Uniq)."""
+    if len(rec) == 0:
+        return True
+    if int(rec["kind"].max()) > T.REC_MSG_EVENT:
+        return False
+    snd = rec["snd"]
+    if int(rec["rcv"].max()) >= T.MAX_ACTORS or bool(((snd >= T.MAX_ACTORS) & (snd != T.DEADLETTERS)).any()):
+        return False
+    sent = {}
+    for e in rec:
+        k = int(e["kind"])
+        if k == T.REC_MSG_SEND:
+            if int(e["id"]) in sent:
+                return False
+            sent[int(e["id"])] = (int(e["snd"]), int(e["rcv"]), int(e["msg_type"]), int(e["p0"]), int(e["p1"]))
+        elif k == T.REC_MSG_EVENT:
+            if sent.get(int(e["id"])) != (int(e["snd"]), int(e["rcv"]), int(e["msg_type"]), int(e["p0"]), int(e["p1"])):
+                return False
+    return True
+
+
+def _format1_record(trace_path: str, declared_size):
+    """Which record a "format": 1 event_trace.bin holds (see the module docstring)."""
+    by_size = {REC_EVENT_DTYPE_V1.itemsize: REC_EVENT_DTYPE_V1, T.REC_EVENT_DTYPE.itemsize: T.REC_EVENT_DTYPE}
+    if declared_size is not None:
+        if declared_size not in by_size:
+            raise ValueError("event_trace.bin was written with %r-byte records, this build reads 12 or 16" % (declared_size,))
+        return by_size[declared_size]
+    size = os.path.getsize(trace_path)
+    fits = [dt for sz, dt in sorted(by_size.items()) if size % sz == 0]
+    good = [dt for dt in fits if _plausible_recording(np.fromfile(trace_path, dtype=dt))]
+    if len(good) == 1:
+        return good[0]
+    raise ValueError("event_trace.bin (%d bytes, format 1 without rec_event_size): %s - refusing to guess" %
+                     (size, "neither the 12-byte nor the 16-byte record parses as a recorded execution" if not good else
+                      "both the 12-byte and the 16-byte record parse as a recorded execution"))
+
+
 def load_experiment(path: str):
     """Returns (model, EventTrace, ViolationFingerprint, meta dict, mcs or None)."""
     model = load_model(os.path.join(path, "model.json"))
@@ -54,9 +99,13 @@ def load_experiment(path: str):
     fmt = meta.get("format")
     if fmt not in (1, FORMAT_VERSION):
         raise ValueError("unknown experiment format %r" % fmt)
-    rec_dtype = REC_EVENT_DTYPE_V1 if fmt == 1 else T.REC_EVENT_DTYPE
-    if fmt != 1 and meta.get("rec_event_size", rec_dtype.itemsize) != rec_dtype.itemsize:
-        raise ValueError("event_trace.bin was written with %r-byte records, this build reads %d" % (meta.get("rec_event_size"), rec_dtype.itemsize))
+    trace_path = os.path.join(path, "event_trace.bin")
+    if fmt == 1:
+        rec_dtype = _format1_record(trace_path, meta.get("rec_event_size"))
+    else:
+        rec_dtype = T.REC_EVENT_DTYPE
+        if meta.get("rec_event_size", rec_dtype.itemsize) != rec_dtype.itemsize:
+            raise ValueError("event_trace.bin was written with %r-byte records, this build reads %d" % (meta.get("rec_event_size"), rec_dtype.itemsize))
     for name, dt in (("externals.bin", T.EXT_EVENT_DTYPE), ("event_trace.bin", rec_dtype)):
         size = os.path.getsize(os.path.join(path, name))
         if size % dt.itemsize:

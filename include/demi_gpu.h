@@ -591,6 +591,17 @@ int demi_dpor_explore(demi_ctx* ctx, const demi_dpor_params* params, const demi_
                       demi_dpor_trace_entry* first_violation_trace, uint32_t* first_violation_len,
                       demi_dpor_stats* stats);
 
+/* What interleaving `index` of the last demi_dpor_explore of this context WAS (for auditing an exploration against another
+ * implementation of DPORwHeuristics - an exploration hands back verdicts only): the next trace it was started from
+ * (out_next_trace, *out_next_len entries; `trace.take(maxIndex + 1) ++ replayThis` of the backtrack point it was dequeued as,
+ * DPORwHeuristics.scala:1054-1057, 1180; empty for the first interleaving), how many leading entries of it are the take() part
+ * (*out_shared_len, may be NULL: demi_dpor_batch's shared_len), and the trace it executed (out_trace, *out_trace_len).  Both
+ * buffers [DEMI_DPOR_MAX_TRACE].  Available after the explorations whose traces stay in the device's arena - trackHistory with
+ * DefaultBacktrackOrdering, no distance cap, no initial trace, in either order - until the next demi_dpor_explore / demi_dpor_load
+ * of the context; DEMI_ERR_INVALID_ARG otherwise.  With several ranks every rank holds every trace. */
+int demi_dpor_explored(demi_ctx* ctx, uint64_t index, demi_dpor_trace_entry* out_next_trace, uint32_t* out_next_len,
+                       uint32_t* out_shared_len, demi_dpor_trace_entry* out_trace, uint32_t* out_trace_len);
+
 /* ---------------------------------------------------------- DDMin over DPOR with a growing edit-distance bound
  * RunnerUtils.editDistanceDporDDMin (RunnerUtils.scala:810-879) in one call: IncrementalDDMin (minification/
  * IncrementalDeltaDebugging.scala:20-92) - DDMin with the distance cap 0, then 2, 4, ... < max_max_distance, each pass starting

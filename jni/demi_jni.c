@@ -35,6 +35,10 @@
 #define INTS(arr) ((arr) ? (void*)(*e)->GetIntArrayElements(e, (arr), NULL) : NULL)
 #define LONGS(arr) ((arr) ? (void*)(*e)->GetLongArrayElements(e, (arr), NULL) : NULL)
 #define LOST(arr, p) ((arr) != NULL && (p) == NULL)     /* the array exists and its elements could not be obtained */
+/* Results go back through Set*ArrayRegion.  When a Get*ArrayElements failed (LOST) an OutOfMemoryError is pending, and with an
+ * exception pending JNI allows only a short list of calls - the Release* calls among them, Set*ArrayRegion not (-Xcheck:jni
+ * aborts on it): the outputs are skipped then, the caller sees the exception and DEMI_ERR_INVALID_ARG. */
+#define SET_LONGS(arr, n, src) do { if (!(*e)->ExceptionCheck(e)) (*e)->SetLongArrayRegion(e, (arr), 0, (n), (src)); } while (0)
 #define PUT_BYTES(arr, p, mode) do { if ((arr) && (p)) (*e)->ReleaseByteArrayElements(e, (arr), (jbyte*)(p), (mode)); } while (0)
 #define PUT_SHORTS(arr, p, mode) do { if ((arr) && (p)) (*e)->ReleaseShortArrayElements(e, (arr), (jshort*)(p), (mode)); } while (0)
 #define PUT_INTS(arr, p, mode) do { if ((arr) && (p)) (*e)->ReleaseIntArrayElements(e, (arr), (jint*)(p), (mode)); } while (0)
@@ -145,7 +149,7 @@ JNIEXPORT jint JNICALL FN(randomExploreFlagged)(JNIEnv* e, jclass c, jlong h, jl
                                                        &n_flagged, &first);
   PUT_LONGS(out, o, 0);
   const jlong cn[2] = {(jlong)n_flagged, (jlong)first};
-  (*e)->SetLongArrayRegion(e, counts, 0, 2, cn);
+  SET_LONGS(counts, 2, cn);
   return rc;
 }
 /* verdict: long[2]; recorded: byte[16 * cap]; returns the number of recorded events, or a negative demi_status */
@@ -160,7 +164,7 @@ JNIEXPORT jint JNICALL FN(randomGetTrace)(JNIEnv* e, jclass c, jlong h, jlong se
   void* r = BYTES(recorded);
   jint rc = LOST(recorded, r) ? DEMI_ERR_INVALID_ARG : demi_random_get_trace(CTX(h), (uint64_t)seed, &lim, &v, (demi_rec_event*)r, cap, &n_out);
   PUT_BYTES(recorded, r, 0);
-  (*e)->SetLongArrayRegion(e, verdict, 0, 2, (const jlong*)(const void*)&v);
+  SET_LONGS(verdict, 2, (const jlong*)(const void*)&v);
   return rc == DEMI_OK ? (jint)n_out : rc;
 }
 
@@ -178,7 +182,7 @@ JNIEXPORT jint JNICALL FN(randomGetTraceCarried)(JNIEnv* e, jclass c, jlong h, j
   jint rc = LOST(recorded, r) ? DEMI_ERR_INVALID_ARG
                               : demi_random_get_trace_carried(CTX(h), (uint64_t)seed, (uint32_t)execIndex, &lim, &v, (demi_rec_event*)r, cap, &n_out, &ran);
   PUT_BYTES(recorded, r, 0);
-  (*e)->SetLongArrayRegion(e, verdict, 0, 2, (const jlong*)(const void*)&v);
+  SET_LONGS(verdict, 2, (const jlong*)(const void*)&v);
   if (rc == DEMI_OK && ran != (uint32_t)execIndex) return DEMI_ERR_INVALID_ARG;      /* an earlier execution of the chain already violated */
   return rc == DEMI_OK ? (jint)n_out : rc;
 }
@@ -242,7 +246,7 @@ JNIEXPORT jint JNICALL FN(replayGetKept)(JNIEnv* e, jclass c, jlong h, jlongArra
             : demi_replay_get_kept(CTX(h), (const uint64_t*)m, (uint32_t)skip, &lim, &v, (uint8_t*)k);
   PUT_BYTES(kept, k, 0);
   PUT_LONGS(maskOrNull, m, JNI_ABORT);
-  (*e)->SetLongArrayRegion(e, verdict, 0, 2, (const jlong*)(const void*)&v);
+  SET_LONGS(verdict, 2, (const jlong*)(const void*)&v);
   return rc;
 }
 
@@ -275,10 +279,10 @@ JNIEXPORT jint JNICALL FN(ddmin)(JNIEnv* e, jclass c, jlong h, jintArray limits,
   PUT_BYTES(passedOrNull, pa, 0);
   PUT_LONGS(consultedOrNull, co, 0);
   PUT_BYTES(conjoinedOrNull, cj, JNI_ABORT);
-  (*e)->SetLongArrayRegion(e, mcs, 0, 4, (const jlong*)(const void*)out);
+  SET_LONGS(mcs, 4, (const jlong*)(const void*)out);
   jlong o[5];
   o[0] = (jlong)st.consultations; o[1] = (jlong)st.launches; o[2] = (jlong)st.mcs_len; o[3] = (jlong)st.verified; o[4] = (jlong)st.replays;
-  (*e)->SetLongArrayRegion(e, stats, 0, 5, o);
+  SET_LONGS(stats, 5, o);
   return rc;
 }
 
@@ -330,12 +334,12 @@ JNIEXPORT jint JNICALL FN(editDistanceDporDDMin)(JNIEnv* e, jclass c, jlong h, j
   PUT_LONGS(consultedOrNull, co, 0);
   PUT_BYTES(initialTrace, it, JNI_ABORT);
   PUT_BYTES(externals, ex, JNI_ABORT);
-  (*e)->SetLongArrayRegion(e, mcs, 0, 4, (const jlong*)(const void*)out);
+  SET_LONGS(mcs, 4, (const jlong*)(const void*)out);
   jlong o[40];
   o[0] = (jlong)st.replays; o[1] = (jlong)st.interleavings; o[2] = (jlong)st.consultations; o[3] = (jlong)st.instances;
   o[4] = (jlong)st.passes; o[5] = (jlong)st.mcs_len; o[6] = (jlong)st.verified; o[7] = (jlong)st.violation_len;
   for (int i = 0; i < 16; i++) { o[8 + i] = (jlong)st.pass_distance[i]; o[24 + i] = (jlong)st.pass_mcs_len[i]; }
-  (*e)->SetLongArrayRegion(e, stats, 0, 40, o);
+  SET_LONGS(stats, 40, o);
   return rc;
 }
 
@@ -385,8 +389,26 @@ JNIEXPORT jint JNICALL FN(dporExplore)(JNIEnv* e, jclass c, jlong h, jintArray p
   o[4] = (jlong)st.queue_len; o[5] = (jlong)st.exhausted; o[6] = (jlong)st.executed; o[7] = (jlong)st.cache_misses;
   memcpy(&o[8], &st.kernel_ms, sizeof(jlong));
   o[9] = (jlong)st.h2d_bytes; o[10] = (jlong)st.d2h_bytes; o[11] = (jlong)st.backtrack_points; o[12] = (jlong)st.fetches;
-  (*e)->SetLongArrayRegion(e, stats, 0, 13, o);
+  SET_LONGS(stats, 13, o);
   return rc == DEMI_OK ? (jint)vlen : rc;
+}
+
+/* ---- demi_dpor_explored: what interleaving `index` of the last dporExplore was.  nextTrace, trace: byte[16 * 256]
+ *      (demi_dpor_trace_entry); lens: long[3] = next-trace length, shared length, executed-trace length */
+JNIEXPORT jint JNICALL FN(dporExplored)(JNIEnv* e, jclass c, jlong h, jlong index, jbyteArray nextTrace, jbyteArray trace, jlongArray lens) {
+  (void)c;
+  const int64_t need = (int64_t)sizeof(demi_dpor_trace_entry) * DEMI_DPOR_MAX_TRACE;
+  if (index < 0 || !nextTrace || !trace || LEN(nextTrace) < need || LEN(trace) < need || LEN(lens) != 3) return DEMI_ERR_INVALID_ARG;
+  uint32_t nl = 0, sl = 0, tl = 0;
+  void* nt = BYTES(nextTrace);
+  void* tr = BYTES(trace);
+  jint rc = (LOST(nextTrace, nt) || LOST(trace, tr)) ? DEMI_ERR_INVALID_ARG
+            : demi_dpor_explored(CTX(h), (uint64_t)index, (demi_dpor_trace_entry*)nt, &nl, &sl, (demi_dpor_trace_entry*)tr, &tl);
+  PUT_BYTES(trace, tr, 0);
+  PUT_BYTES(nextTrace, nt, 0);
+  jlong o[3] = {(jlong)nl, (jlong)sl, (jlong)tl};
+  SET_LONGS(lens, 3, o);
+  return rc;
 }
 
 /* ---- ProvenanceTracker.pruneConcurrentEvents for a batch of traces: traces byte[16 * stride * n] (demi_dpor_trace_entry),
@@ -458,6 +480,6 @@ JNIEXPORT jint JNICALL FN(randomExploreSharded)(JNIEnv* e, jclass c, jlong h, jl
                          : demi_random_explore_sharded(CTX(h), (uint64_t)seedBase, (uint64_t)nTotal, &lim, (demi_violation*)o, cap, &n);
   PUT_LONGS(out, o, 0);
   const jlong cn = (jlong)n;
-  (*e)->SetLongArrayRegion(e, count, 0, 1, &cn);
+  SET_LONGS(count, 1, &cn);
   return rc;
 }

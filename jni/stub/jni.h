@@ -32,5 +32,6 @@ struct JNINativeInterface_ {
   void (*GetIntArrayRegion)(JNIEnv*, jintArray, jsize, jsize, jint*);
   void (*SetByteArrayRegion)(JNIEnv*, jbyteArray, jsize, jsize, const jbyte*);
   void (*SetLongArrayRegion)(JNIEnv*, jlongArray, jsize, jsize, const jlong*);
+  jboolean (*ExceptionCheck)(JNIEnv*);
 };
 #endif

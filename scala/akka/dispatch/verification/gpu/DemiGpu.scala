@@ -39,6 +39,9 @@ object DemiGpu {
   @native def dporSetTraces(h: Long, originalKeysOrNull: Array[Long], initialTraceOrNull: Array[Byte]): Int
   @native def dporExplore(h: Long, params: Array[Int], search: Array[Int], verdicts: Array[Long], prefixLen: Array[Int],
                           rounds: Array[Int], firstViolationTrace: Array[Byte], stats: Array[Long]): Int
+  /** What interleaving `index` of the last dporExplore was (demi_dpor_explored): nextTrace / trace = byte[16 * 256] (16-byte trace entries),
+   *  lens = long[3] (next-trace length, its shared take() part, executed-trace length).  For diffing an exploration against DPORwHeuristics. */
+  @native def dporExplored(h: Long, index: Long, nextTrace: Array[Byte], trace: Array[Byte], lens: Array[Long]): Int
   /** RunnerUtils.editDistanceDporDDMin in one call (demi_edit_distance_dpor_ddmin: IncrementalDDMin over ResumableDPOR, every DPOR
    *  consultation inside the library).  externals = 8 bytes each; initialTrace = 16-byte entries (FlatEvents.dporInitialTrace);
    *  dporParams = int[7]; params = int[7] (max_max_distance, stop_at_size, check_unmodified, ignore_quiescence, verify_mcs, batch, budget);

@@ -332,7 +332,8 @@ class GpuDPOR(val schedulerConfig: SchedulerConfig, lowering: TableLowering, dep
     val m = lowering.model
     check(h, modelLoad(h, m.nActors, m.msgClass, m.actorClass, m.nClasses, m.handlerStart, m.code, m.initState,
                        Array(m.invKind, m.invFa, m.invVa, m.invFb, m.fpMatchMask, m.flags)))
-    modelSpecialize(h, true)
+    if (m.compiledOnly) check(h, modelSpecialize(h, true))
+    else modelSpecialize(h, true)
     check(h, dporLoad(h, FlatEvents.pack(events, lowering)))      // Start / Send / WaitQuiescence only (DPORwHeuristics.scala:692-710)
     val params = Array(depthBound, maxMessagesToSchedule, 1, lowering.fingerprintCode(fp), 64, 4096, 0)
     val search = Array(batch, maxInterleavings, if (stopIfViolationFound) 1 else 0, 1,
@@ -366,7 +367,8 @@ object GpuEditDistanceDporDDMin {
       val m = lowering.model
       check(h, modelLoad(h, m.nActors, m.msgClass, m.actorClass, m.nClasses, m.handlerStart, m.code, m.initState,
                          Array(m.invKind, m.invFa, m.invVa, m.invFb, m.fpMatchMask, m.flags)))
-      modelSpecialize(h, true)
+      if (m.compiledOnly) check(h, modelSpecialize(h, true))     // a wide table, or one with arrays, runs only as compiled code
+      else modelSpecialize(h, true)                              // optional: a failure keeps the table interpreter
       val ext = trace.original_externals
       val init = FlatEvents.dporInitialTrace(trace, lowering)
       // what the reference's dporConstructor sets (:827-839): prioritizePendingUponDivergence, setMaxMessagesToSchedule(initialTrace.size)
@@ -377,7 +379,13 @@ object GpuEditDistanceDporDDMin {
       val out = stats.getOrElse(new MinimizationStats)
       (0L until st(0)).foreach(_ => out.increment_replays())
       val kept = ext.indices.filter(i => ((mcs(i >> 6) >>> (i & 63)) & 1L) != 0).map(ext)
-      val verified = if (st(6) == 1) Some(GpuDPOR.traceOf(vt, st(7).toInt, kept, lowering)) else None
+      // RunnerUtils.scala:841-878: an MCS no smaller than the externals that took part is not verified at all and the ORIGINAL trace
+      // is returned (st(6) == -1); otherwise Some(reproducing trace) when the MCS verifies (1), None when it does not (0)
+      val verified = st(6) match {
+        case 1L => Some(GpuDPOR.traceOf(vt, st(7).toInt, kept, lowering))
+        case 0L => None
+        case _  => Some(trace)
+      }
       (kept, out, verified, violation)
     } finally ctxDestroy(h)
   }

@@ -88,6 +88,8 @@ def test_k3_and_provenance_sources_against_the_oracle_on_the_cpu():
                   "test_k3_gpu.py::test_native_exploration_loop_equals_the_python_loop[64-3000]",
                   "test_k3_gpu.py::test_reference_order_on_the_gpu_is_the_batch1_sequence[True]",
                   "test_k3_gpu.py::test_config5_shuffle8_bounded_dpor",
+                  "test_k3_gpu.py::test_config5_pipeline_exploration_against_the_oracle",
+                  "test_k3_gpu.py::test_one_job_shuffle_in_reference_order_equals_the_scala_transliteration",
                   "test_provenance_gpu.py"], threads=1)
 
 

@@ -157,6 +157,57 @@ def test_experiment_dir_roundtrip(tmp_path, oracle):
     assert os.path.getsize(str(tmp_path / "e" / "event_trace.bin")) == 16 * len(rec)
 
 
+def test_format1_directories_of_both_generations_load(tmp_path, oracle):
+    """"format": 1 was written with 12-byte records (rounds 1-2) and, before the version was bumped, with 16-byte records
+    (round 3): load_experiment tells them apart by content - also when the byte count is a multiple of both sizes - and refuses
+    what it cannot tell apart."""
+    import json
+    from demi_amd.apps import SEED_BASE, raft3_config1
+    from demi_amd.schedulers import EventTrace, ViolationFingerprint
+    from demi_amd.serialization import REC_EVENT_DTYPE_V1, load_experiment, save_experiment
+    model, events, lim = raft3_config1()
+    v, rec, _ = oracle.random_execute(model, events, SEED_BASE + 1, lim)
+    rec = rec[:len(rec) - len(rec) % 3]                       # 16 n divisible by 12 and 12 n by 16 (n % 12 == 0 below): the ambiguous sizes
+    rec = rec[:len(rec) - len(rec) % 12]
+    assert len(rec) >= 12
+    tr = EventTrace(rec, events[:T.verdict_trace_idx(v.flags)])
+
+    def write(name, dtype, declare):
+        d = str(tmp_path / name)
+        save_experiment(d, model, tr, ViolationFingerprint(7), limits=lim)
+        out = np.zeros(len(rec), dtype=dtype)
+        for f in dtype.names:
+            out[f] = rec[f]
+        out.tofile(os.path.join(d, "event_trace.bin"))
+        meta = json.load(open(os.path.join(d, "meta.json")))
+        meta["format"] = 1
+        if declare:
+            meta["rec_event_size"] = dtype.itemsize
+        else:
+            meta.pop("rec_event_size")
+        json.dump(meta, open(os.path.join(d, "meta.json"), "w"))
+        return d
+
+    for dtype in (REC_EVENT_DTYPE_V1, T.REC_EVENT_DTYPE):        # the round-1/2 writer and the round-3 writer, undeclared and declared
+        for declare in (False, True):
+            _m, t2, _fp, meta, _mcs = load_experiment(write("e%d_%d" % (dtype.itemsize, declare), dtype, declare))
+            assert meta["format"] == 1 and (t2.events == rec).all()
+    # bytes that parse under neither record: refused, not guessed
+    d = write("garbage", T.REC_EVENT_DTYPE, False)
+    raw = np.fromfile(os.path.join(d, "event_trace.bin"), dtype=np.uint8)
+    raw[::16] = 0xEE
+    raw.tofile(os.path.join(d, "event_trace.bin"))
+    with pytest.raises(ValueError, match="refusing to guess"):
+        load_experiment(d)
+    # an unknown declared size is refused too
+    d = write("odd", T.REC_EVENT_DTYPE, True)
+    meta = json.load(open(os.path.join(d, "meta.json")))
+    meta["rec_event_size"] = 20
+    json.dump(meta, open(os.path.join(d, "meta.json"), "w"))
+    with pytest.raises(ValueError):
+        load_experiment(d)
+
+
 def test_jni_shim_compiles_against_the_stub_header_and_covers_the_adapter():
     """jni/demi_jni.c must stay in step with include/demi_gpu.h (no JDK here: a compile-only <jni.h> stands in), and every
     @native method the Scala adapter declares has its Java_..._DemiGpu_<name> function."""

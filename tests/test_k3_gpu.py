@@ -402,3 +402,104 @@ def test_reference_order_resident_equals_the_host_commit(monkeypatch):
     assert (a[0] == b[0]).all() and a[1] == b[1] and len(a[4].violations) == len(b[4].violations) == 1
     ta, tb = a[4].interleavings[a[4].violations[0]].trace, b[4].interleavings[b[4].violations[0]].trace
     assert len(ta) == len(tb) and (np.asarray(ta) == np.asarray(tb)).all()
+
+
+def _seq_digest(verdicts):
+    """bench.py's order-sensitive digest of a verdict sequence (the `sequence_digest` of its dpor / config5 records)."""
+    idx = np.arange(1, len(verdicts) + 1, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        x = (verdicts["hash"] ^ (verdicts["flags"].astype(np.uint64) << np.uint64(32)) ^ verdicts["fingerprint"].astype(np.uint64)) * \
+            (idx * np.uint64(0x9E3779B97F4A7C15) | np.uint64(1))
+    return int(np.bitwise_xor.reduce(x)) if len(verdicts) else 0
+
+
+def test_config5_pipeline_exploration_against_the_oracle(oracle):
+    """BASELINE config 5 as bench.py times it (apps.shuffle8_config5_large: pipeline of three shuffle jobs, depth 40, budget
+    2^20, ROUNDS of 16 384), the WHOLE exploration held against the CPU oracle in two ways:
+      (1) its first 2^17 interleavings verdict for verdict against the oracle's exploration (same order, same prefixes);
+      (2) more than 2 000 interleavings from everywhere in the 2^20 - every round's first and last member, the whole tail of the
+          last round, the rest drawn at random - re-executed ONE BY ONE by the oracle (orc_dpor_execute) from the next trace the
+          exploration started them from (demi_dpor_explored): the verdict the exploration returned, the trace it left in the arena
+          and the racing pairs of that prefix must be the oracle's.  No host bookkeeping is shared in (2): the oracle sees a
+          prefix and nothing else."""
+    import os
+    from demi_amd import _native
+    from demi_amd.apps import shuffle8_config5_large
+    emu = os.environ.get("DEMI_EMU") == "1"
+    model, ev, depth, budget = shuffle8_config5_large()
+    batch, head, n_random = 16384, 1 << 17, 1500
+    if emu:
+        budget, batch, head, n_random = 2500, 256, 800, 40
+    par = T.DporParams(depth, 0, 0, 0, 64, 4096)
+    ctx = _native.Context(0)
+    ctx.model_load(model.to_struct())
+    ctx.model_specialize()
+    ctx.dpor_load(ev)
+    verdicts, plen, rounds, _vt, st = ctx.dpor_explore(par, T.DporSearch(batch, budget, 0, 1, T.DPOR_ORDER_ROUNDS))
+    n = len(verdicts)
+    assert n == budget and not st.exhausted and int(rounds.sum()) == n
+    if not emu:
+        assert "%016x" % _seq_digest(verdicts) == "a8b790d52998a190"          # the sequence bench.py's config5 record reports
+    # (1) the head of the exploration
+    v, pl, _r, _t, _s, _secs = oracle.dpor_explore(model, ev, par, T.DporSearch(batch, head, 0, 1, T.DPOR_ORDER_ROUNDS), n_threads=os.cpu_count() or 1)
+    assert len(v) == head and (v == verdicts[:head]).all() and (pl == plen[:head]).all()
+    # (2) samples from the whole of it
+    starts = np.concatenate([[0], np.cumsum(rounds)[:-1]]).astype(np.int64)
+    ends = (np.cumsum(rounds) - 1).astype(np.int64)
+    last_lo = int(starts[-1])
+    rng = np.random.default_rng(20260922)
+    pick = set(int(x) for x in starts) | set(int(x) for x in ends) | set(range(max(last_lo, n - 400), n)) | \
+        set(int(x) for x in rng.integers(0, n, n_random))
+    pick = sorted(pick)
+    assert emu or (len(pick) >= 2000 and sum(1 for i in pick if i >= head) >= 1500 and sum(1 for i in pick if i >= last_lo) >= 300)
+    prefixes, shared, traces = [], [], []
+    for i in pick:
+        nt, sh, tr = ctx.dpor_explored(i)
+        assert len(nt) == plen[i] and (i == 0) == (len(nt) == 0)
+        ov, otr, _opr = oracle.dpor_batch(model, ev, [nt], par, shared=[sh])
+        assert ov[0] == verdicts[i], i
+        assert len(otr[0]) == len(tr) and (otr[0] == tr).all(), i
+        prefixes.append(nt); shared.append(sh); traces.append(tr)
+    # the racing pairs of those prefixes (the exploration consumes them on the device: the same kernels on the same prefixes)
+    for lo in range(0, len(pick), 512):
+        gv, gt, gp = ctx.dpor_batch(prefixes[lo:lo + 512], par, shared[lo:lo + 512])
+        cv, ct, cp = oracle.dpor_batch(model, ev, prefixes[lo:lo + 512], par, shared[lo:lo + 512])
+        same_batch((gv, gt, gp), (cv, ct, cp))
+        assert all((gv[k] == verdicts[pick[lo + k]]) and (gt[k] == traces[lo + k]).all() for k in range(len(gv)))
+    ctx.close()
+
+
+def test_one_job_shuffle_in_reference_order_equals_the_scala_transliteration(oracle):
+    """A bookkeeping check that shares NOTHING with the product's host loops: the literal transliteration of DPORwHeuristics
+    (tests/test_dpor_scheduler_transliteration_cpu.py - its own id counter, dependency graph, backtrack PriorityQueue and
+    ExploredTacker, Python containers) explores the one-job shuffle8 table (config 5's application, 1 399 interleavings in the
+    reference's own order) to exhaustion, and the GPU exploration in DEMI_DPOR_ORDER_REFERENCE must return the same sequence:
+    every verdict (the hash covers every delivery and final state), every next-trace length, exhaustion."""
+    import os
+    from demi_amd import _native
+    from demi_amd.apps import shuffle8_config5
+    from tests.test_dpor_scheduler_transliteration_cpu import ScalaDPORwHeuristics
+    emu = os.environ.get("DEMI_EMU") == "1"
+    model, ev, _f, _l = shuffle8_config5()
+    cap = 120 if emu else 4000
+    sc = ScalaDPORwHeuristics(oracle, model, ev, depth_bound=40, max_messages=0)
+    exhausted = sc.run(cap)
+    want = np.array(sc.verdicts, dtype=T.VERDICT_DTYPE)
+    assert emu or (exhausted and len(want) == 1399)
+    ctx = _native.Context(0)
+    ctx.model_load(model.to_struct())
+    ctx.model_specialize()
+    ctx.dpor_load(ev)
+    par = T.DporParams(40, 0, 0, 0, 64, 4096)
+    for batch in (256, 1):          # the device speculating 256 wide, and the plain one-at-a-time loop
+        got, plen, _rounds, _vt, st = ctx.dpor_explore(par, T.DporSearch(batch, cap, 0, 1, T.DPOR_ORDER_REFERENCE))
+        assert len(got) == len(want) and bool(st.exhausted) == exhausted
+        assert (got == want).all() and [int(x) for x in plen] == sc.next_trace_lens
+        if batch == 1:
+            break
+        if emu:
+            break
+    # and what the exploration says it started each interleaving from is what the transliteration's getNext() built
+    nt, sh, tr = ctx.dpor_explored(len(want) - 1)
+    assert len(nt) == sc.next_trace_lens[-1]
+    ctx.close()
