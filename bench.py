@@ -122,7 +122,7 @@ def bench_dpor(ctx_device, cpu_baseline=True, batch=16384, orders=("rounds", "re
     n_il = r["interleavings"]
     per_il = 4.0 * r["mean_prefix_len"] + 8.0 + 12.0 * (r["backtrack_points"] / max(1, n_il))
     alg = n_il * per_il
-    traffic = (_counters_profile("r04_dpor_counters.json") or _counters_profile("r03_dpor_counters.json") or {}).get("fabric_bytes_per_exploration")
+    traffic = (_counters_profile("dpor_counters.json") or {}).get("fabric_bytes_per_exploration")
     out["roofline"] = roofline(alg, r["kernel_ms_total"], traffic,
                                "k3_dpor + k3_pairs_mark/insert/decide (specialised, hiprtc), %d rounds" % r["launches"],
                                "ROUNDS order. Algorithmic bytes per SURVEY 8(d): 4 x mean prefix length (%.1f events) + 8 + 12 x r "
@@ -230,12 +230,17 @@ class Ranks:
 
 
 def _counters_profile(name):
-    """fabric-side bytes of a secondary record from its FETCH_SIZE / WRITE_SIZE passes (tools/profile_r4.sh), if committed"""
-    try:
-        with open(os.path.join(ROOT, "profiles", name)) as f:
-            return json.load(f)
-    except (OSError, ValueError):
-        return None
+    """fabric-side bytes of a secondary record from its FETCH_SIZE / WRITE_SIZE passes (tools/profile_r5_k2k3.sh), if committed:
+    `name` is the file's name without its round tag; the newest round's file wins"""
+    for tag in ("r05", "r04", "r03"):
+        try:
+            with open(os.path.join(ROOT, "profiles", "%s_%s" % (tag, name))) as f:
+                d = json.load(f)
+                d["profile_file"] = "profiles/%s_%s" % (tag, name)
+                return d
+        except (OSError, ValueError):
+            continue
+    return None
 
 
 def bench_config5(ctx_device, cpu_baseline=True, max_interleavings=None, batch=16384, ranks=None, small=True):
@@ -273,7 +278,7 @@ def bench_config5(ctx_device, cpu_baseline=True, max_interleavings=None, batch=1
     digest = "%016x" % _seq_digest(verdicts)
     per_il = 4.0 * float(np.mean(plen)) + 8.0 + 12.0 * (int(st.backtrack_points) / max(1, n_il))
     flags, counts = np.unique(verdicts["flags"] & 0xFF, return_counts=True)
-    prof = _counters_profile("r04_config5_counters.json")
+    prof = _counters_profile("config5_counters.json")
     out = {"metric": "interleavings explored/sec, bounded DPOR (shuffle8-synth pipeline of 3 jobs, depth 40, budget %d)" % max_interleavings,
            "unit": "interleavings/s", "value": n_il / dt, "seconds": dt, "interleavings": n_il, "exhausted": bool(st.exhausted),
            "budget": int(max_interleavings), "backtrack_points_still_queued": int(st.queue_len), "launches": int(st.launches),
@@ -469,7 +474,7 @@ def bench_ddmin(ctx_device, cpu_baseline=True, n=1 << 20):
     # is shared by every lane (read once per workgroup into LDS)
     alg = 48 * n + 8 * n_exp * ((n + 255) // 256)
     # (measured fabric-side bytes of one 2^20-candidate launch, when the counters of this round are committed: tools/profile_r4_k2k3.sh)
-    k2_traffic = (_counters_profile("r04_ddmin_counters.json") or {}).get("fabric_bytes_per_launch") if n == (1 << 20) else None
+    k2_traffic = (_counters_profile("ddmin_counters.json") or {}).get("fabric_bytes_per_launch") if n == (1 << 20) else None
     out["roofline"] = roofline(alg, kms, k2_traffic, "k2_replay (specialised, hiprtc)",
                                "32 B mask + 16 B verdict per candidate, the lowered original trace (%d x 8 B) once per workgroup; "
                                "the replay itself is integer / LDS work" % n_exp)

@@ -4,6 +4,7 @@ for the host and compare it, delivery by delivery, with the oracle's row interpr
 import ctypes as C
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -691,3 +692,33 @@ def test_generated_invariant_program_equals_the_oracle(oracle, tmp_path, wide):
             assert (hit != 0) == (r[8] != 0) and (hit == 0 or key.value == r[9]), (trial, it, fields, hit, key.value, r[8], r[9])
             hits += hit != 0
         assert hits > 20 or trial > 0
+
+
+def test_committed_k1_counters_describe_the_kernel_this_tree_compiles(tmp_path):
+    """profiles/k1_counters.json (the rocprofv3 --pmc passes bench.py quotes as roofline.traffic / issue_model) names the code
+    object it was taken on: `code_id` = FNV-1a over .text of the K1 specialised for the default raft5 table, what
+    demi_model_code_id returns on the GPU box.  The same compiler runs here, so the id of what THIS tree compiles is known
+    without a GPU - and a change to the kernel, the code generator or the table that is committed without re-taking the
+    profile (tools/profile_r5.sh) fails here instead of silently nulling the driver line's counters."""
+    import json
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from jit_stats import text_hash
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from demi_amd import _native\n"
+            "from demi_amd.apps import raft5_config2\n"
+            "try:\n"
+            "    print('SIZE', _native.specialize_check(raft5_config2()[0].to_struct())[0])\n"
+            "except _native.DemiError as e:\n"
+            "    print('ERR', e)\n" % ROOT)
+    env = dict(os.environ, DEMI_EXPERIMENT="1", DEMI_JIT_DUMP=str(tmp_path / "img"), DEMI_SPECIALIZE_CHECK_K1_ONLY="1")
+    for k in ("DEMI_JIT_FLAGS", "DEMI_JIT_DEFINES", "DEMI_JIT_K1_HOT", "LD_PRELOAD"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    if "hiprtc not found" in out.stdout:
+        pytest.skip("no hiprtc in this environment")
+    assert "SIZE" in out.stdout, out.stdout + out.stderr
+    here = text_hash(open(str(tmp_path / "img") + ".0", "rb").read())
+    with open(os.path.join(ROOT, "profiles", "k1_counters.json")) as f:
+        prof = json.load(f)
+    assert prof.get("code_id") == here, ("profiles/k1_counters.json was taken on code id %s, this tree compiles %s: "
+                                         "re-run tools/profile_r5.sh on the GPU box and commit its k1_counters.json" % (prof.get("code_id"), here))
