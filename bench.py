@@ -411,7 +411,92 @@ def bench_ddmin_ranks(ctx_device, ranks, n_per_rank=1 << 18):
            "ddmin_end_to_end_single_rank": {"seconds": single_s, "launches": int(st1.launches), "replays_launched": int(st1.replays),
                                             "mcs_len": len(mcs1), "max_candidates": 1024}}
     ctx.close()
+    # randomDDMin with the frontier split over the ranks (demi_random_ddmin with the communicator): the DDMin shape whose launches
+    # have real width - (candidates x 100 executions)
+    try:
+        from demi_amd.schedulers import ViolationFingerprint
+        out["random_ddmin_R100"] = _bench_random_ddmin(ctx_device, model, used, rec, ViolationFingerprint(vv.fingerprint), False, ranks=ranks)
+    except Exception as e:
+        out["random_ddmin_R100"] = {"error": "%s: %s" % (type(e).__name__, e)}
     return out
+
+
+def _bench_random_ddmin(ctx_device, model, used, rec, fp, cpu_baseline, R=100, ranks=None):
+    import numpy as np
+    from demi_amd import _native, types as T
+    from demi_amd.apps import SEED_BASE
+    from demi_amd.minification import randomDDMin
+    from demi_amd.schedulers import EventTrace, SchedulerConfig
+    ranks = ranks or Ranks()
+    ctx = _native.Context(ctx_device)
+    ctx.model_load(model.to_struct())
+    ctx.model_specialize()
+    ctx.trace_load(used)
+    collective = ranks.attach(ctx) if ranks.world > 1 else "none (1 rank)"
+    lim = T.Limits(len(rec), 0, 64, 1, fp.code, 0)          # sched.setMaxMessages(trace.size), lookingFor = the violation
+    best = None
+    for budget in (64 * ranks.world, 256 * ranks.world, 1024 * ranks.world):
+        par = T.RandomDdminParams(R, 0, budget)
+        ctx.random_ddmin(lim, par, seed_base=SEED_BASE)
+        for _ in range(3):
+            ranks.barrier()
+            t = time.perf_counter()
+            mcs, cons, batches, st = ctx.random_ddmin(lim, par, seed_base=SEED_BASE)
+            dt = ranks.max(time.perf_counter() - t)
+            if best is None or dt < best["seconds"]:
+                best = {"seconds": dt, "mcs_len": len(mcs), "oracle_consultations": int(st.consultations), "launches": int(st.launches),
+                        "executions": int(st.consultations) * R, "executions_per_s": int(st.consultations) * R / dt,
+                        "executions_launched": int(st.replays), "executions_launched_per_s": int(st.replays) / dt,
+                        "candidates_per_launch": batches, "max_candidates_all_ranks": budget, "verified": bool(st.verified),
+                        "mcs": [int(i) for i in mcs],
+                        "consulted_digest": __import__("hashlib").sha256(repr([(tuple(int(i) for i in c), bool(p)) for c, p in cons]).encode()).hexdigest()[:16]}
+    # the sequential algorithm on the device: one launch per consultation (what the reference's DDMin does with its oracle)
+    par = T.RandomDdminParams(R, sequential=1)
+    ctx.random_ddmin(lim, par, seed_base=SEED_BASE)
+    t = time.perf_counter()
+    mcs_s, cons_s, _b, st_s = ctx.random_ddmin(lim, par, seed_base=SEED_BASE)
+    dts = ranks.max(time.perf_counter() - t)
+    best["sequential_native"] = {"seconds": dts, "launches": int(st_s.launches), "executions_per_s": int(st_s.consultations) * R / dts,
+                                 "same_mcs": tuple(mcs_s) == tuple(best["mcs"])}
+    best["n_gpus"] = ranks.world
+    best["collective"] = collective
+    if ranks.world > 1:
+        every = ranks.gather({"mcs": best["mcs"], "digest": best["consulted_digest"]})
+        best["same_mcs_and_consultations_on_every_rank"] = all(r["mcs"] == best["mcs"] and r["digest"] == best["consulted_digest"] for r in every)
+        best["same_mcs_as_single_rank_sequential"] = best["sequential_native"]["same_mcs"]
+    ctx.close()
+    if ranks.world == 1:
+        # round 4's path: the Python loop, sequential DDMin, the table interpreted
+        randomDDMin(SchedulerConfig(model=model), EventTrace(rec, used), fp, max_executions=R, seed_base=SEED_BASE)
+        t = time.perf_counter()
+        mcs_r, dd_r, _v = randomDDMin(SchedulerConfig(model=model), EventTrace(rec, used), fp, max_executions=R, seed_base=SEED_BASE)
+        dtr = time.perf_counter() - t
+        best["python_loop_interpreted"] = {"seconds": dtr, "oracle_consultations": len(dd_r.consulted), "executions_per_s": len(dd_r.consulted) * R / dtr,
+                                           "same_mcs": tuple(mcs_r) == tuple(best["mcs"]),
+                                           "same_consultation_sequence": [(tuple(c), p) for c, p in dd_r.consulted] == [(tuple(c), p) for c, p in cons_s]}
+        if cpu_baseline:
+            # the reference's loop around the CPU oracle's RandomScheduler, one host thread per execution batch
+            from oracle import oracle_py as O
+            from demi_amd.minification import DDMin, UnmodifiedEventDag
+            cores = os.cpu_count() or 1
+
+            class _Sched:
+                def getName(self):
+                    return "RandomScheduler"
+
+                def test(self, events, fp_, stats=None):
+                    v = O.random_explore(model, used[list(events)], R, seed_base=SEED_BASE, limits=lim, n_threads=min(cores, R))
+                    return True if (v["flags"] & T.V_VIOLATION).any() else None
+            dd = DDMin(_Sched(), checkUnmodifed=False)
+            t = time.perf_counter()
+            want = dd.minimize(UnmodifiedEventDag(used), fp).get_all_events()
+            dc = time.perf_counter() - t
+            best["cpu_baseline"] = {"value": len(dd.consulted) * R / dc, "unit": "executions/s", "cores": min(cores, R), "kind": "port", "seconds": dc,
+                                    "sample": "the same minimization: the reference's DDMin loop (Python) around oracle/demi_oracle.c, "
+                                              "%d executions per consultation on %d host threads" % (R, min(cores, R)),
+                                    "same_mcs_as_gpu": tuple(want) == tuple(best["mcs"]),
+                                    "same_consultation_sequence_as_gpu": [(tuple(c), p) for c, p in dd.consulted] == [(tuple(c), p) for c, p in cons_s]}
+    return best
 
 
 def bench_ddmin(ctx_device, cpu_baseline=True, n=1 << 20):
@@ -514,16 +599,12 @@ def bench_ddmin(ctx_device, cpu_baseline=True, n=1 << 20):
     out["ddmin_end_to_end"] = best
     ctx.close()
     # RunnerUtils.randomDDMin (RunnerUtils.scala:601-623): DDMin whose oracle is the RandomScheduler itself, R = 100 random
-    # interleavings per candidate: every consultation is one K1 launch of R executions
+    # interleavings per candidate.  demi_random_ddmin: decision tree + speculative frontier in the library, one
+    # launch = (frontier candidates x R) executions of the compiled K1, a workgroup per candidate; beside it round 4's shape - the
+    # Python loop, one interpreted 100-lane launch per consultation.  executions_per_s counts what the SEQUENTIAL algorithm asks for
+    # (consultations x R): speculation that is launched and not consulted is not throughput.
     try:
-        from demi_amd.minification import randomDDMin
-        randomDDMin(SchedulerConfig(model=model), EventTrace(rec, used), fp, max_executions=100, seed_base=SEED_BASE)
-        t = time.perf_counter()
-        mcs_r, dd_r, _v = randomDDMin(SchedulerConfig(model=model), EventTrace(rec, used), fp, max_executions=100, seed_base=SEED_BASE)
-        dtr = time.perf_counter() - t
-        n_cons = len(dd_r.consulted) if hasattr(dd_r, "consulted") else None
-        out["random_ddmin_R100"] = {"seconds": dtr, "mcs_len": len(mcs_r), "oracle_consultations": n_cons,
-                                    "executions": (n_cons or 0) * 100, "executions_per_s": ((n_cons or 0) * 100 / dtr) if dtr else None}
+        out["random_ddmin_R100"] = _bench_random_ddmin(ctx_device, model, used, rec, fp, cpu_baseline)
     except Exception as e:           # never let a side measurement cost the record
         out["random_ddmin_R100"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if cpu_baseline:

@@ -17,7 +17,7 @@ EXPORTS = ["demi_ctx_create", "demi_ctx_destroy", "demi_last_error", "demi_versi
            "demi_replay_removal_batch", "demi_replay_get_kept", "demi_replay_recorded_len", "demi_ddmin", "demi_dpor_set_traces", "demi_model_specialize", "demi_model_is_specialized", "demi_model_code_id",
            "demi_specialize_check", "demi_specialize_source", "demi_specialize_source_k1", "demi_provenance_prune", "demi_device_probe", "demi_device_probe_mix", "demi_calib_rw", "demi_random_explore_flagged", "demi_collect_flagged_dev",
            "demi_comm_unique_id", "demi_comm_create", "demi_comm_create_host", "demi_comm_destroy", "demi_comm_rank",
-           "demi_comm_allgather_dev", "demi_random_explore_sharded", "demi_replay_batch_sharded", "demi_abi_version", "demi_replay_externals_len", "demi_edit_distance_dpor_ddmin", "demi_dpor_explored"]
+           "demi_comm_allgather_dev", "demi_random_explore_sharded", "demi_replay_batch_sharded", "demi_abi_version", "demi_replay_externals_len", "demi_edit_distance_dpor_ddmin", "demi_dpor_explored", "demi_random_ddmin", "demi_random_explore_candidates"]
 
 _lib = None
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)     # demi_allgather_fn
@@ -100,6 +100,9 @@ def lib():
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.demi_dpor_explore.argtypes = [C.c_void_p, C.POINTER(T.DporParams), C.POINTER(T.DporSearch), C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(T.DporStats)]
+    L.demi_random_explore_candidates.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(T.Limits), C.c_void_p, C.c_void_p]
+    L.demi_random_ddmin.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(T.Limits), C.POINTER(T.RandomDdminParams), C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(T.DdminStats)]
     L.demi_dpor_explored.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_void_p,
                                      C.POINTER(C.c_uint32)]
     L.demi_random_explore_violations.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(T.Limits), C.c_void_p,
@@ -287,6 +290,33 @@ class Context:
                                      C.byref(st)))
         return T.mask_to_events(mcs), [(T.mask_to_events(consulted[i]), bool(passed[i])) for i in range(min(cap, st.consultations))], \
             [int(b) for b in batches[:st.launches]], st
+
+    def random_explore_candidates(self, masks, executions, limits, seed_base=0):
+        """K1 over candidate subsequences of the loaded trace: (verdicts [n_cand, executions], flags [n_cand])."""
+        import numpy as np
+        m = np.ascontiguousarray(masks, dtype=np.uint64).reshape(-1, 4)
+        v = np.zeros((len(m), executions), dtype=T.VERDICT_DTYPE)
+        f = np.zeros(len(m), dtype=np.uint32)
+        self._check(lib().demi_random_explore_candidates(self._h, C.c_uint64(seed_base), m.ctypes.data, len(m), executions, C.byref(limits),
+                                                         v.ctypes.data, f.ctypes.data))
+        return v, f
+
+    def random_ddmin(self, limits, params=None, seed_base=0, conjoined=None, cap=4096):
+        """RunnerUtils.randomDDMin on the loaded trace, natively (demi_random_ddmin): (mcs indices, [(candidate indices, passes)]
+        in consultation order, candidates per launch, stats)."""
+        import numpy as np
+        params = params or T.RandomDdminParams()
+        mcs = np.zeros(4, dtype=np.uint64)
+        consulted = np.zeros((cap, 4), dtype=np.uint64)
+        passed = np.zeros(cap, dtype=np.uint8)
+        batches = np.zeros(cap, dtype=np.uint32)
+        st = T.DdminStats()
+        conj = np.ascontiguousarray(conjoined, dtype=np.uint8) if conjoined is not None else None
+        self._check(lib().demi_random_ddmin(self._h, C.c_uint64(seed_base), C.byref(limits), C.byref(params),
+                                            conj.ctypes.data if conj is not None else None, mcs.ctypes.data, consulted.ctypes.data,
+                                            passed.ctypes.data, cap, batches.ctypes.data, cap, C.byref(st)))
+        return T.mask_to_events(mcs), [(T.mask_to_events(consulted[i]), bool(passed[i])) for i in range(min(cap, st.consultations))], \
+            [int(b) for b in batches[:min(cap, st.launches)]], st
 
     def replay_get_kept(self, n_rec, skip, limits, mask=None):
         """(Verdict, uint8[n_rec]) of one candidate: which recorded events make up its executed trace."""

@@ -46,6 +46,17 @@ struct K1Args {
   uint32_t epi;             // CARRY variants: executions per RandomScheduler instance (demi_limits.executions_per_instance)
   uint32_t rec_shared;      // CARRY + REC: every execution of the instance records into rec_out[0 ..] (the last one stays)
 };
+// MULTI variants (demi_random_ddmin): workgroup = one CANDIDATE subsequence of the trace.  Their kernels take this struct; every
+// other variant keeps K1Args as it was (same kernel-argument segment, same instructions as the measured kernels)
+struct K1MultiArgs : K1Args {
+  const uint64_t* cand_masks;   // [n_cand][4]: bit i = external event i of `trace` is part of the candidate
+  uint32_t n_cand;
+  uint32_t epc;                 // executions per candidate: execution k of every candidate uses seed_base + k (or seeds[k])
+  uint32_t* cand_flags;         // [n_cand], zeroed by the host: bit 0 = some execution violated, bit 1 = some execution aborted on a capacity
+  uint32_t populate_all;        // 1 = `exists` as given; 0 = the actors the CANDIDATE Start()s (what trace_load derives)
+};
+template <bool MULTI> struct K1ArgsOf { typedef K1Args type; };
+template <> struct K1ArgsOf<true> { typedef K1MultiArgs type; };
 
 enum : int { PH_IDLE = 0, PH_INJECT = 1, PH_DISPATCH = 2, PH_FINISH = 3 };
 
@@ -152,12 +163,52 @@ __host__ __device__ inline size_t k1_lds_bytes(uint32_t code_len, uint32_t n_ev,
 // directory are LDS columns, the pending set a column of the HBM scratch, all addressable by any lane - so that the lanes of
 // a wave now run (almost) one handler.  A second barrier, and every owner takes its state back.  Which lane runs a
 // delivery changes nothing about it: verdicts are bit-identical with the plain kernel (tests run both).
-template <bool REC, bool FIFO = false, bool CARRY = false, bool REBIN = false>
-__global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
+//
+// MULTI (round 5, demi_random_ddmin = RunnerUtils.randomDDMin's oracle, RunnerUtils.scala:601-623): the launch evaluates a
+// FRONTIER of DDMin candidates, each against `epc` random interleavings.  A candidate is a subsequence of the external trace and
+// everything K1 derives from the trace is workgroup-shared (the trace itself, the per-batch network states, the Send words), so
+// a workgroup IS a candidate (ceil(epc / blockDim) workgroups when epc exceeds one workgroup): thread 0 compacts the trace by
+// the candidate's mask in LDS before it builds the batch table, lane k runs execution k - no refill, a lane has one execution -
+// and a violating execution sets the candidate's flag.  Verdict cand * epc + k is what the plain kernel returns for
+// trace_load(candidate's events) and seed_base + k.
+template <bool REC, bool FIFO = false, bool CARRY = false, bool REBIN = false, bool MULTI = false>
+__global__ K1_LAUNCH_BOUNDS void k1_random_explore(const typename K1ArgsOf<MULTI>::type args) {
   static_assert(!REBIN || (!REC && !FIFO), "the re-binned kernel exists for the non-recording FullyRandom variant");
+  static_assert(!MULTI || (!REC && !CARRY && !REBIN), "a frontier of candidates runs the non-recording, per-execution-seed kernel");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Tables t;
   unsigned char* extra = tables_load(t, smem, args.model, args.trace, args.n_ev, args.exists);
+  // MULTI: which candidate this workgroup evaluates, and which of its executions this lane runs
+  uint32_t m_cand = 0, m_exec = 0;
+  if constexpr (MULTI) {
+    const uint32_t m_wgpc = (args.epc + blockDim.x - 1) / blockDim.x;
+    m_cand = blockIdx.x / m_wgpc;
+    m_exec = (blockIdx.x % m_wgpc) * blockDim.x + threadIdx.x;
+    // the candidate's events: counted by every thread (t.E is a per-thread value), compacted in place by thread 0 below
+    const uint64_t* cm = args.cand_masks + 4 * (size_t)m_cand;
+    uint32_t e_cnt = 0;
+    for (uint32_t wi = 0; wi < 4; wi++) {
+      uint64_t mw = cm[wi];
+      if (args.n_ev < 64 * (wi + 1)) mw &= args.n_ev > 64 * wi ? ((1ull << (args.n_ev - 64 * wi)) - 1ull) : 0ull;
+      e_cnt += (uint32_t)__popcll(mw);
+    }
+    if (threadIdx.x == 0) {
+      uint64_t* tr = const_cast<uint64_t*>(t.trace);
+      uint32_t j = 0;
+      for (uint32_t i = 0; i < args.n_ev; i++)
+        if ((cm[i >> 6] >> (i & 63)) & 1ull) tr[j++] = tr[i];
+    }
+    t.E = e_cnt;
+    __syncthreads();
+    if (!args.populate_all) {                 // populateActorSystem creates the actors the trace Start()s (ExternalEventInjector.scala:371-378)
+      uint32_t ex = 0;
+      for (uint32_t i = 0; i < t.E; i++) {
+        const uint64_t ev = t.trace[i];
+        if (((uint32_t)ev & 0xFF) == DEMI_EV_START) ex |= 1u << ((uint32_t)(ev >> 8) & 0xFF);
+      }
+      t.exists = ex;
+    }
+  }
   // (the word arrays first: 8-byte words in a wide build, and `extra` is 16-byte aligned)
   word_t* const s_sendw = reinterpret_cast<word_t*>(extra);
   word_t* const s_bsend = s_sendw + args.n_ev;       // the deliverable Send words, batch after batch, compacted
@@ -516,6 +567,10 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
         }
         *reinterpret_cast<uint4*>(&args.out[sched]) = v;
         if (REC) args.rec_count[sched] = n_rec;
+        if constexpr (MULTI) {
+          const uint32_t cf = ((v.x & DEMI_V_VIOLATION) ? 1u : 0u) | ((v.x & DEMI_OVF_ANY) ? 2u : 0u);
+          if (cf) atomicOr(&args.cand_flags[m_cand], cf);
+        }
         // reset the simulator for the next schedule
         ph = PH_IDLE;
         if (CARRY && !(v.x & DEMI_V_VIOLATION) && sched + 1 < inst_end) {
@@ -529,7 +584,14 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
       }
       PH_MARK(10);
       // ------------------------------------------------------------ refill idle lanes
-      {
+      if constexpr (MULTI) {
+        // one execution per lane: execution m_exec of this workgroup's candidate, claimed in the first iteration
+        if (!exhausted) {
+          exhausted = true;
+          if (m_exec < args.epc && m_cand < args.n_cand) { ph = PH_INJECT; fresh = true; sched = (uint64_t)m_cand * args.epc + m_exec; }
+        }
+        if (__ballot(ph != PH_IDLE) == 0) break;
+      } else {
         const uint64_t idle = __ballot(ph == PH_IDLE);
         if (idle != 0 && !exhausted) {                     // wave-uniform
           const uint32_t want = (uint32_t)__popcll(idle);
@@ -567,7 +629,7 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const K1Args args) {
           // new execution: `new FullyRandom(seed)`; populateActorSystem isolates every created actor
           // (ExternalEventInjector.scala:371-378)
           if (!CARRY || exec_no == 0) {
-            const uint64_t unit = CARRY ? inst : sched;
+            const uint64_t unit = MULTI ? (uint64_t)m_exec : CARRY ? inst : sched;
             const uint64_t seed = args.seeds ? args.seeds[unit] : args.seed_base + unit;
             rng = jr_seed(seed);
             te_rng = rng;                // SrcDstFIFO: both generators are `new Random(seed)`

@@ -330,20 +330,53 @@ class _SubsequenceOracle:
 
 
 def randomDDMin(schedulerConfig, trace, violation: ViolationFingerprint, max_executions: int = 100, seed_base: int = 0,
-                stats: Optional[MinimizationStats] = None, device: int = 0, p_max: int = 64):
+                stats: Optional[MinimizationStats] = None, device: int = 0, p_max: int = 64, native: bool = False,
+                specialize: Optional[bool] = None, max_candidates: int = 256, sequential: bool = False):
     """RunnerUtils.randomDDMin (RunnerUtils.scala:601-623): DDMin whose oracle is the RandomScheduler itself —
-    a candidate subsequence "fails" iff one of `max_executions` random interleavings of it (one K1 launch; the
-    reference constructs the scheduler with max_executions = 1) reproduces the violation fingerprint.  maxMessages is
-    the length of the recorded trace, as in the reference.  Returns (mcs indices, ddmin, verified trace or None)."""
+    a candidate subsequence "fails" iff one of `max_executions` random interleavings of it (the reference constructs the
+    scheduler with max_executions = 1) reproduces the violation fingerprint.  maxMessages is the length of the recorded trace,
+    as in the reference.  Returns (mcs indices, ddmin, verified trace or None).
+
+    native=False: the reference's loop written out here - sequential DDMin, one K1 launch per consultation (the table
+    interpreted unless `specialize`).  native=True: demi_random_ddmin - decision tree, speculative frontier and launches inside
+    the library, one launch for (frontier candidates x max_executions) with a workgroup per candidate, the table compiled
+    (unless specialize=False); `ddmin` is then a record with the same fields the mirror's DDMin exposes (consulted,
+    total_inputs_pruned is not kept) plus `.stats` (demi_ddmin_stats) and `.batches`."""
     from .schedulers import RandomScheduler
+    if specialize is None:
+        specialize = native
     sched = RandomScheduler(schedulerConfig, max_executions, 0, seed_base=seed_base, device=device, p_max=p_max,
-                            specialize=False)
+                            specialize=specialize)
     sched.setMaxMessages(len(trace.events))
     try:
         externals = trace.original_externals
+        if native:
+            sched._prepare(externals)
+            lim = sched._limits(violation)
+            par = T.RandomDdminParams(executions=max_executions, max_candidates=max_candidates, check_unmodified=0, verify_mcs=1,
+                                      sequential=1 if sequential else 0)
+            mcs_idx, consulted, batches, st = sched._ctx.random_ddmin(lim, par, seed_base=seed_base)
+            if stats is not None:
+                stats.increment_replays(int(st.consultations) * max_executions)
+            ddmin = _NativeDdminRecord(consulted, batches, st)
+            if len(mcs_idx) < len(externals):
+                verified = sched.test(externals[list(mcs_idx)], violation) if st.verified else None
+            else:
+                verified = trace
+            return tuple(mcs_idx), ddmin, verified
         ddmin = DDMin(_SubsequenceOracle(sched, externals), checkUnmodifed=False, stats=stats)
         mcs = ddmin.minimize(UnmodifiedEventDag(externals), violation)
         verified = ddmin.verify_mcs(mcs, violation) if mcs.length < len(externals) else trace
     finally:
         sched.shutdown()
     return mcs.get_all_events(), ddmin, verified
+
+
+class _NativeDdminRecord:
+    """What demi_random_ddmin reports, under the names the mirror's DDMin uses."""
+
+    def __init__(self, consulted, batches, st):
+        self.consulted = [(tuple(int(i) for i in c), bool(p)) for c, p in consulted]
+        self.batches = list(batches)
+        self.stats = st
+        self.total_consultations = int(st.consultations)

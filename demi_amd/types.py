@@ -142,6 +142,15 @@ class DdminParams(C.Structure):
         super().__init__(depth, max_candidates, check_unmodified, verify_mcs)
 
 
+class RandomDdminParams(C.Structure):
+    """demi_random_ddmin_params"""
+    _fields_ = [("executions", C.c_uint32), ("depth", C.c_uint32), ("max_candidates", C.c_uint32), ("check_unmodified", C.c_uint32),
+                ("verify_mcs", C.c_uint32), ("sequential", C.c_uint32), ("reserved", C.c_uint32 * 2)]
+
+    def __init__(self, executions=100, depth=0, max_candidates=256, check_unmodified=0, verify_mcs=1, sequential=0):
+        super().__init__(executions, depth, max_candidates, check_unmodified, verify_mcs, sequential)
+
+
 class DdminStats(C.Structure):
     """demi_ddmin_stats"""
     _fields_ = [("consultations", C.c_uint32), ("launches", C.c_uint32), ("mcs_len", C.c_uint32), ("verified", C.c_uint32),

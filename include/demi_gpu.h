@@ -458,6 +458,41 @@ int demi_ddmin(demi_ctx* ctx, const demi_limits* limits, const demi_ddmin_params
                uint64_t out_mcs[4], uint64_t* out_consulted, uint8_t* out_passed, uint32_t cap, uint32_t* out_batches,
                uint32_t batches_cap, demi_ddmin_stats* stats);
 
+/* ---------------------------------------------------------- randomDDMin: DDMin over the RandomScheduler itself
+ * RunnerUtils.randomDDMin (RunnerUtils.scala:601-623) in one call: DDMin (minification/DeltaDebugging.scala:27-109) whose
+ * TestOracle is RandomScheduler.test (RandomScheduler.scala:597-612) - a candidate subsequence of the external events "fails"
+ * (still triggers the violation) iff one of `executions` random interleavings of it ends in a violation that matches
+ * limits.looking_for.  The externals are those of demi_trace_load (trace.original_externals, WaitQuiescence events included:
+ * :609-610 minimises them as they are); limits as for demi_random_explore (RunnerUtils sets max_messages = the recorded
+ * trace's length); execution k of every candidate runs under java.util.Random(seed_base + k).  The decision tree is evaluated
+ * speculatively as in demi_ddmin: ONE launch runs (frontier candidates x executions) - a workgroup per candidate, whose
+ * projected external trace is workgroup-shared - and the tree then walks through the verdicts; the MCS and the sequence of
+ * consultations are those of the sequential algorithm.  With a communicator (demi_comm_*) every frontier is split over the ranks
+ * in contiguous blocks and the candidates' verdict bits are all-gathered.
+ * stats: consultations, launches, replays (executions run on the device, speculation included), mcs_len, verified (verify_mcs
+ * when the MCS is smaller than the externals, :611-618: 1 = it reproduces). */
+/* RandomScheduler.test for a batch of SUBSEQUENCES of the loaded external trace (what demi_random_ddmin launches per frontier):
+ * masks [n_cand][4], bit i = external event i takes part.  out_verdicts [n_cand * executions] (may be NULL): entry c * executions + k
+ * is demi_random_explore's verdict for demi_trace_load(the events of masks[c]) under seed_base + k.  out_flags [n_cand] (may be
+ * NULL): bit 0 = some execution of the candidate violates (limits.looking_for applies), bit 1 = some execution was aborted on a
+ * capacity (DEMI_V_PENDING_OVF / DEMI_V_QUEUE_OVF). */
+int demi_random_explore_candidates(demi_ctx* ctx, uint64_t seed_base, const uint64_t* masks, uint32_t n_cand, uint32_t executions,
+                                   const demi_limits* limits, demi_verdict* out_verdicts, uint32_t* out_flags);
+typedef struct demi_random_ddmin_params {
+  uint32_t executions;        /* R: RandomScheduler(config, max_executions = R) per consultation (0 = 1, the reference's own value) */
+  uint32_t depth;             /* 0: as many unknown levels of the decision tree per launch as fit max_candidates; k: k levels below the node */
+  uint32_t max_candidates;    /* candidates per launch (0 = 256) */
+  uint32_t check_unmodified;  /* DDMin's checkUnmodifed (RunnerUtils passes false) */
+  uint32_t verify_mcs;
+  uint32_t sequential;        /* 1: no speculation - one launch per consultation, as the reference consults its oracle */
+  uint32_t reserved[2];
+} demi_random_ddmin_params;
+int demi_random_ddmin(demi_ctx* ctx, uint64_t seed_base, const demi_limits* limits, const demi_random_ddmin_params* params,
+                      const uint8_t* conjoined /* [n_ext] or NULL: partner index of explicitly conjoined events, 255 = none */,
+                      uint64_t out_mcs[4], uint64_t* out_consulted /* [cap][4] or NULL */, uint8_t* out_passed /* [cap] or NULL */,
+                      uint32_t cap, uint32_t* out_batches /* candidates per launch, or NULL */, uint32_t batches_cap,
+                      demi_ddmin_stats* stats);
+
 /* ---------------------------------------------------------- K3: DPORwHeuristics interleavings
  * Replaces, per interleaving, DPORwHeuristics.schedule_new_message / event_produced / getMessage /
  * runExternal / notify_quiescence (DPORwHeuristics.scala:421-648, 803-847, 773-801, 684-721,

@@ -286,6 +286,68 @@ JNIEXPORT jint JNICALL FN(ddmin)(JNIEnv* e, jclass c, jlong h, jintArray limits,
   return rc;
 }
 
+/* ---- RunnerUtils.randomDDMin in one call (demi_random_ddmin) on the externals of traceLoad.  params: int[6] = executions, depth,
+ *      max_candidates, check_unmodified, verify_mcs, sequential; conjoinedOrNull: byte[>= n externals]; mcs: long[4]; consultedOrNull:
+ *      long[4 * cap] with passedOrNull: byte[cap]; stats: long[5] = consultations, launches, mcs_len, verified, executions run */
+JNIEXPORT jint JNICALL FN(randomDDMin)(JNIEnv* e, jclass c, jlong h, jlong seedBase, jintArray limits, jintArray params, jint nExternals,
+                                      jbyteArray conjoinedOrNull, jlongArray mcs, jlongArray consultedOrNull, jbyteArray passedOrNull,
+                                      jlongArray stats) {
+  demi_limits lim;
+  demi_random_ddmin_params par;
+  demi_ddmin_stats st;
+  jint pr[6];
+  uint64_t out[4] = {0, 0, 0, 0};
+  (void)c;
+  if (limits_of(e, limits, &lim) || LEN(params) != 6 || LEN(mcs) != 4 || LEN(stats) != 5 || nExternals < 0) return DEMI_ERR_INVALID_ARG;
+  (*e)->GetIntArrayRegion(e, params, 0, 6, pr);
+  memset(&par, 0, sizeof par);
+  par.executions = (uint32_t)pr[0]; par.depth = (uint32_t)pr[1]; par.max_candidates = (uint32_t)pr[2];
+  par.check_unmodified = (uint32_t)pr[3]; par.verify_mcs = (uint32_t)pr[4]; par.sequential = (uint32_t)pr[5];
+  /* demi_random_ddmin reads conjoined[0 .. n externals of the loaded trace): the caller states that count, a shorter array is refused */
+  if (conjoinedOrNull && LEN(conjoinedOrNull) < (int64_t)nExternals) return DEMI_ERR_INVALID_ARG;
+  uint32_t cap = 0;
+  if (consultedOrNull) {
+    if (LEN(consultedOrNull) % 4 || !passedOrNull || LEN(passedOrNull) < LEN(consultedOrNull) / 4) return DEMI_ERR_INVALID_ARG;
+    cap = (uint32_t)(LEN(consultedOrNull) / 4);
+  }
+  memset(&st, 0, sizeof st);
+  void* cj = BYTES(conjoinedOrNull);
+  void* co = LONGS(consultedOrNull);
+  void* pa = BYTES(passedOrNull);
+  jint rc = (LOST(conjoinedOrNull, cj) || LOST(consultedOrNull, co) || LOST(passedOrNull, pa)) ? DEMI_ERR_INVALID_ARG
+            : demi_random_ddmin(CTX(h), (uint64_t)seedBase, &lim, &par, (const uint8_t*)cj, out, (uint64_t*)co, (uint8_t*)pa, cap, NULL, 0, &st);
+  PUT_BYTES(passedOrNull, pa, 0);
+  PUT_LONGS(consultedOrNull, co, 0);
+  PUT_BYTES(conjoinedOrNull, cj, JNI_ABORT);
+  SET_LONGS(mcs, 4, (const jlong*)(const void*)out);
+  jlong o[5];
+  o[0] = (jlong)st.consultations; o[1] = (jlong)st.launches; o[2] = (jlong)st.mcs_len; o[3] = (jlong)st.verified; o[4] = (jlong)st.replays;
+  SET_LONGS(stats, 5, o);
+  return rc;
+}
+
+/* ---- RandomScheduler.test for a batch of subsequences of the loaded trace (demi_random_explore_candidates).  masks: long[4 * n];
+ *      verdictsOrNull: long[2 * n * executions]; flags: int[n] (bit 0: some execution violates, bit 1: some execution aborted) */
+JNIEXPORT jint JNICALL FN(randomExploreCandidates)(JNIEnv* e, jclass c, jlong h, jlong seedBase, jlongArray masks, jint executions,
+                                                  jintArray limits, jlongArray verdictsOrNull, jintArray flags) {
+  demi_limits lim;
+  (void)c;
+  const int64_t n = LEN(masks) / 4;
+  if (limits_of(e, limits, &lim) || LEN(masks) % 4 || executions <= 0 || !flags || LEN(flags) < n ||
+      (verdictsOrNull && LEN(verdictsOrNull) < 2 * n * (int64_t)executions))
+    return DEMI_ERR_INVALID_ARG;
+  void* m = LONGS(masks);
+  void* v = LONGS(verdictsOrNull);
+  void* f = INTS(flags);
+  jint rc = (LOST(masks, m) || LOST(verdictsOrNull, v) || LOST(flags, f)) ? DEMI_ERR_INVALID_ARG
+            : demi_random_explore_candidates(CTX(h), (uint64_t)seedBase, (const uint64_t*)m, (uint32_t)n, (uint32_t)executions, &lim,
+                                             (demi_verdict*)v, (uint32_t*)f);
+  PUT_INTS(flags, f, 0);
+  PUT_LONGS(verdictsOrNull, v, 0);
+  PUT_LONGS(masks, m, JNI_ABORT);
+  return rc;
+}
+
 /* ---- RunnerUtils.editDistanceDporDDMin in one call (demi_edit_distance_dpor_ddmin).  externals: byte[8 * n]; initialTrace: byte[16 * m]
  *      (demi_dpor_trace_entry); dporParams: int[7]; params: int[7] = max_max_distance, stop_at_size, check_unmodified, ignore_quiescence,
  *      verify_mcs, batch, budget; mcs: long[4]; consultedOrNull: long[4 * cap] with passedOrNull: byte[cap] and distanceOrNull: int[cap];

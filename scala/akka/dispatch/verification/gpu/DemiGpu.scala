@@ -32,6 +32,15 @@ object DemiGpu {
    *  stats = long[5] (consultations, launches, mcs_len, verified, replays) */
   @native def ddmin(h: Long, limits: Array[Int], params: Array[Int], conjoinedOrNull: Array[Byte], mcs: Array[Long],
                     consultedOrNull: Array[Long], passedOrNull: Array[Byte], stats: Array[Long]): Int
+  /** RunnerUtils.randomDDMin in one call (demi_random_ddmin) on the externals of traceLoad: params = int[6] (executions, depth, max_candidates,
+   *  check_unmodified, verify_mcs, sequential), nExternals = how many externals traceLoad was given, mcs = long[4], stats = long[5]
+   *  (consultations, launches, mcs_len, verified, executions run) */
+  @native def randomDDMin(h: Long, seedBase: Long, limits: Array[Int], params: Array[Int], nExternals: Int, conjoinedOrNull: Array[Byte],
+                          mcs: Array[Long], consultedOrNull: Array[Long], passedOrNull: Array[Byte], stats: Array[Long]): Int
+  /** RandomScheduler.test for a batch of subsequences of the loaded externals (demi_random_explore_candidates): masks = long[4 * n],
+   *  verdictsOrNull = long[2 * n * executions], flags = int[n] (bit 0 = some execution violates, bit 1 = some execution was aborted) */
+  @native def randomExploreCandidates(h: Long, seedBase: Long, masks: Array[Long], executions: Int, limits: Array[Int],
+                                      verdictsOrNull: Array[Long], flags: Array[Int]): Int
   @native def replayGetKept(h: Long, maskOrNull: Array[Long], skip: Int, limits: Array[Int], verdict: Array[Long], kept: Array[Byte]): Int
   @native def dporLoad(h: Long, externals: Array[Byte]): Int
   /** returns the length of the first violating trace (entries of 16 bytes in firstViolationTrace), or a negative status */

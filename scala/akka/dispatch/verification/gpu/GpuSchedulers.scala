@@ -391,6 +391,49 @@ object GpuEditDistanceDporDDMin {
   }
 }
 
+/** RunnerUtils.randomDDMin (RunnerUtils.scala:601-623) in ONE native call (demi_random_ddmin): DDMin whose TestOracle is the RandomScheduler
+ *  itself - a candidate subsequence "fails" iff one of `maxExecutions` random interleavings of it reproduces `violation` (the reference
+ *  builds its scheduler with max_executions = 1; SURVEY 8d's config 4 asks for 100).  The decision tree, its speculative frontier and the
+ *  launches - (frontier candidates x maxExecutions) executions each, a workgroup per candidate - run inside the library.  Returns what the
+ *  reference returns: (mcs externals, stats, Some(a reproducing trace) if the MCS verifies - the original trace when nothing was removed -,
+ *  the violation).  `sched.setMaxMessages(trace.size)` as in the reference (:608). */
+object GpuRandomDDMin {
+  def apply(schedulerConfig: SchedulerConfig, lowering: TableLowering, trace: EventTrace, violation: ViolationFingerprint,
+            maxExecutions: Int = 100, seed: Long = 0L, stats: Option[MinimizationStats] = None, device: Int = 0, pMax: Int = 64,
+            maxCandidates: Int = 256): (Seq[ExternalEvent], MinimizationStats, Option[EventTrace], ViolationFingerprint) = {
+    if (schedulerConfig.invariant_check.isEmpty) throw new IllegalArgumentException("Must invoke setInvariant before test()")
+    val h = ctxCreate(device)
+    if (h == 0) throw new IllegalStateException("no MI355X visible: use RunnerUtils.randomDDMin")
+    try {
+      val m = lowering.model
+      check(h, modelLoad(h, m.nActors, m.msgClass, m.actorClass, m.nClasses, m.handlerStart, m.code, m.initState,
+                         Array(m.invKind, m.invFa, m.invVa, m.invFb, m.fpMatchMask, m.flags)))
+      if (m.compiledOnly) check(h, modelSpecialize(h, true)) else modelSpecialize(h, true)
+      val ext = trace.original_externals
+      check(h, traceLoad(h, FlatEvents.pack(ext, lowering)))
+      // demi_limits: max_messages = trace.size (:608), no periodic invariant check (RandomScheduler(config, 1, 0)), lookingFor = violation
+      val limits = Array(trace.events.size, 0, pMax, 1, lowering.fingerprintCode(violation), 0, 0, 0, 1)
+      val params = Array(maxExecutions, 0, maxCandidates, 0 /* checkUnmodifed = false (:609) */, 1, 0)
+      val mcs = new Array[Long](4); val st = new Array[Long](5)
+      check(h, DemiGpu.randomDDMin(h, seed, limits, params, ext.size, null, mcs, null, null, st))
+      val out = stats.getOrElse(new MinimizationStats)
+      (0L until st(0) * maxExecutions).foreach(_ => out.increment_replays())      // RandomScheduler counts a replay per execution (:203-205)
+      val kept = ext.indices.filter(i => ((mcs(i >> 6) >>> (i & 63)) & 1L) != 0).map(ext)
+      // (:611-622) the MCS is validated only when it is smaller than the externals; the reproducing trace itself comes from the
+      // recording kernel: the lowest violating execution of the MCS, as RandomScheduler.test returns it
+      val verified: Option[EventTrace] =
+        if (kept.size >= ext.size) Some(trace)
+        else if (st(3) != 1L) None
+        else {
+          val sched = new GpuRandomScheduler(schedulerConfig, maxExecutions, 0, seed, lowering, device, false, pMax)
+          try { sched.setInvariant(schedulerConfig.invariant_check.get); sched.setMaxMessages(trace.events.size); sched.test(kept, violation, out) }
+          finally sched.shutdown()
+        }
+      (kept, out, verified, violation)
+    } finally ctxDestroy(h)
+  }
+}
+
 object GpuDPOR {
   /** demi_dpor_trace_entry[] (key 8, word 4, parent, qperiod, depth, kind) -> the MsgEvents of the violating interleaving */
   def traceOf(vt: Array[Byte], n: Int, externals: Seq[ExternalEvent], lo: TableLowering): EventTrace = {

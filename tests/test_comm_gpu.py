@@ -240,6 +240,22 @@ for budget in (256, 256 * world):
     else:
         assert len(batchesw) <= len(batches1)
 ctx.comm_destroy()
+# ---- config 4 with the RandomScheduler as DDMin's oracle (randomDDMin, R executions per candidate): every frontier's candidates
+# split over the ranks, their verdict bits all-gathered - same MCS, consultations and frontiers as the single-rank call
+R = 24 if emu else 100
+ctx.trace_load(used)
+rl = T.Limits(len(rec), 0, 128, 1, vv.fingerprint, 0)
+r1 = ctx.random_ddmin(rl, T.RandomDdminParams(R, 0, 64), seed_base=SEED_BASE)
+ctx.comm_create_host(rank, world, allgather)
+for budget in (64, 64 * world):
+    rw = ctx.random_ddmin(rl, T.RandomDdminParams(R, 0, budget), seed_base=SEED_BASE)
+    assert tuple(rw[0]) == tuple(r1[0]) and rw[3].verified == r1[3].verified and rw[3].consultations == r1[3].consultations
+    assert [(tuple(c), p) for c, p in rw[1]] == [(tuple(c), p) for c, p in r1[1]]
+    if budget == 64:
+        assert rw[2] == r1[2]
+        # this rank ran its blocks only: fewer executions than the single-rank call launched (odd frontiers: the last rank's block is short)
+        assert rw[3].replays < r1[3].replays or max(r1[2]) == 1
+ctx.comm_destroy()
 # ---- config 5: the shuffle pipeline, bounded DPOR exploration
 model5, ev5, depth, _budget = shuffle8_config5_large()
 budget = int(os.environ.get("CFG5_BUDGET", "3000" if emu else "40000"))

@@ -93,6 +93,13 @@ def test_k3_and_provenance_sources_against_the_oracle_on_the_cpu():
                   "test_provenance_gpu.py"], threads=1)
 
 
+def test_random_ddmin_and_its_kernel_on_the_cpu():
+    """K1 over a frontier of candidate subsequences (a workgroup per candidate) against the oracle per candidate, demi_random_ddmin
+    against the reference's DDMin loop around the oracle's RandomScheduler, and its two-rank form (frontier split over the ranks)."""
+    run_emulated(["test_random_ddmin_gpu.py"], threads=4)
+    run_emulated(["test_comm_gpu.py::test_config4_ddmin_and_config5_dpor_over_the_ranks[2]"], threads=1)
+
+
 def test_sharded_entry_points_two_ranks_on_the_cpu():
     """demi_random_explore_sharded / demi_replay_batch_sharded / the sharded demi_dpor_explore with two processes, gloo and the
     host all-gather: the worker of tests/test_comm_gpu.py as it is, each rank on an emulated device."""
