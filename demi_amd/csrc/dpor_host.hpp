@@ -1144,6 +1144,130 @@ int explore_rounds_resident(Dev&& dev, const demi_dpor_search* srch, demi_verdic
   return 0;
 }
 
+// ------------------------------------------------------------------ ROUNDS order, bookkeeping AND queue on the device
+// explore_rounds_resident with the backtrack queue itself on the device (k3_queue.hpp; single rank).  What is left here: per branch
+// the FIFO of runs (pool offset, points left) - the device sorts every round's points into one run per branch - and the order in
+// which runs are handed to a dequeue: deepest branch first, oldest run first (DefaultBacktrackOrdering with PriorityQueue ties in
+// creation order: the order of explore_rounds_resident's 256 buckets).
+//   dev.q_round(items, n, round, base_id, pool_fill, verdicts, &points, run_len[256])
+//       one launch: K3 for the items, dpor()'s insert / decide, the round's live points sorted into the pool segment at pool_fill
+//   dev.q_pop(ranges, n_ranges, n_cand, want, dequeue_no, items_out, &taken, &consumed)
+//       getNext() for up to `want` items among the candidates of `ranges` (in that order): the first `taken` live ones, `consumed`
+//       candidates used up
+struct QueueRange { unsigned long long start; uint32_t count, prefix; };      // = demi::QRange
+
+template <class Dev>
+int explore_rounds_devqueue(Dev&& dev, const demi_dpor_search* srch, demi_verdict* out_verdicts, uint32_t* out_prefix_len,
+                            uint32_t* out_rounds, demi_dpor_trace_entry* first_violation_trace, uint32_t* first_violation_len,
+                            demi_dpor_stats* stats, double* seconds, ExploredLog* log = nullptr) {
+  memset(stats, 0, sizeof *stats);
+  stats->first_violation = ~0ull;
+  if (first_violation_len) *first_violation_len = 0;
+  if (log) log->clear();
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  struct Run { unsigned long long start; uint32_t left; };
+  std::deque<Run> runs[256];
+  int top = -1;
+  uint64_t queued = 0, pool_fill = 0;
+  std::vector<demi::DporItem> items(1, demi::DporItem{0xFFFFFFFFu, 0, 0, 0, 0});   // first run: nextTrace is empty
+  std::vector<demi_verdict> vd;
+  std::vector<QueueRange> ranges;
+  uint64_t run_len[256];
+  uint32_t base_id = 0, round = 0, dequeue_no = 0;
+  uint64_t first_id = ~0ull;
+  bool exhausted = false;
+  constexpr size_t MAX_RANGES = 4096;
+  while (!items.empty()) {
+    const uint32_t n = (uint32_t)items.size();
+    vd.resize(n);
+    round++;
+    double t0 = now();
+    uint64_t points = 0;
+    int rc = dev.q_round(items.data(), n, round, base_id, pool_fill, vd.data(), &points, run_len);
+    if (rc) return rc;
+    double t1 = now();
+    if (out_rounds) out_rounds[stats->launches] = n;
+    stats->launches++;
+    stats->executed += n;
+    bool found = false;
+    for (uint32_t i = 0; i < n; i++) {
+      const uint64_t idx = stats->interleavings++;
+      out_verdicts[idx] = vd[i];
+      out_prefix_len[idx] = items[i].src == 0xFFFFFFFFu ? 0u : (uint32_t)items[i].later;
+      if (log) log->add(items[i], base_id + i);
+      if (vd[i].flags & DEMI_V_VIOLATION) {
+        stats->violations++;
+        found = true;
+        if (stats->first_violation == ~0ull) { stats->first_violation = idx; first_id = base_id + i; }
+      }
+    }
+    base_id += n;
+    // the round's segment: one run per branch, deepest first
+    {
+      uint64_t acc = 0;
+      for (int b = 255; b >= 0; b--) {
+        if (!run_len[b]) continue;
+        runs[b].push_back(Run{pool_fill + acc, (uint32_t)run_len[b]});
+        acc += run_len[b];
+        if (b > top) top = b;
+      }
+      if (acc != points) return DEMI_ERR_DEVICE;          // (the device's own counts disagree)
+      pool_fill += points;
+      queued += points;
+      stats->backtrack_points += points;
+    }
+    items.clear();
+    double t2 = now();
+    if (seconds) { seconds[0] += t1 - t0; seconds[1] += t2 - t1; }
+    if (srch->stop_if_violation && found) break;
+    if (stats->interleavings >= srch->max_interleavings) break;
+    // getNext (:1142-1162) for up to `batch` points
+    const uint64_t room = srch->max_interleavings - stats->interleavings;
+    const uint32_t want = (uint32_t)(room < srch->batch ? room : srch->batch);
+    while (items.size() < want && queued != 0) {
+      const uint32_t need = want - (uint32_t)items.size();
+      const uint64_t target = (uint64_t)need * 2 > 4096 ? (uint64_t)need * 2 : 4096;
+      ranges.clear();
+      uint32_t n_cand = 0;
+      for (int b = top; b >= 0 && n_cand < target && ranges.size() < MAX_RANGES; b--)
+        for (const Run& r : runs[b]) {
+          if (n_cand >= target || ranges.size() >= MAX_RANGES) break;
+          const uint32_t take = (uint64_t)r.left < target - n_cand ? r.left : (uint32_t)(target - n_cand);
+          ranges.push_back(QueueRange{r.start, take, n_cand});
+          n_cand += take;
+        }
+      if (n_cand == 0) break;
+      uint32_t taken = 0, consumed = 0;
+      const size_t have = items.size();
+      items.resize(have + need);
+      rc = dev.q_pop(ranges.data(), (uint32_t)ranges.size(), n_cand, need, ++dequeue_no, items.data() + have, &taken, &consumed);
+      if (rc) return rc;
+      if (taken > need || consumed > n_cand) return DEMI_ERR_DEVICE;
+      items.resize(have + taken);
+      // the consumed candidates leave the queue, in the order they were offered
+      uint32_t left = consumed;
+      while (left) {
+        while (top >= 0 && runs[top].empty()) top--;
+        Run& r = runs[top].front();
+        const uint32_t c = r.left < left ? r.left : left;
+        r.start += c; r.left -= c; left -= c;
+        if (!r.left) runs[top].pop_front();
+      }
+      queued -= consumed;
+      while (top >= 0 && runs[top].empty()) top--;
+    }
+    if (items.empty() && queued == 0) exhausted = true;
+    if (seconds) seconds[2] += now() - t2;
+  }
+  if (first_id != ~0ull && first_violation_trace && first_violation_len) {
+    int rc = dev.fetch_trace((uint32_t)first_id, first_violation_trace, first_violation_len);
+    if (rc) return rc;
+  }
+  stats->queue_len = queued;
+  stats->exhausted = exhausted ? 1u : 0u;
+  return 0;
+}
+
 // ------------------------------------------------------------------ REFERENCE order, results resident on the device
 // The same committed sequence as explore_reference_order (DPORwHeuristics' own one-at-a-time order), with what made that
 // path slow taken out: every finished trace used to cross PCIe together with all of its racing pairs (1.3 GB for config 3),

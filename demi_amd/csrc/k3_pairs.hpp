@@ -28,8 +28,11 @@ struct PairEntry {           // 64 bytes, one per UNORDERED pair of node keys: e
   unsigned long long lo, hi; // lo < hi; lo == 0 = empty slot (node keys are FNV chains, never 0)
   unsigned long long cand[2];   // per side: this round's candidate for the points flipping INTO it: round | branch + 1 | ~ordinal
   uint32_t state[2];         // per side: bit 31 explored; bits 0..8: 1 + highest branch of a queued point flipping into it
-  uint32_t pad[6];
+  unsigned long long pop[2]; // per side: the dequeue (k3_queue.hpp) that last saw an unexplored candidate with this flipped pair, and
+                             // the lowest such candidate: dequeue number << 32 | ~candidate index (atomicMax)
+  uint32_t pad[2];
 };
+static_assert(sizeof(PairEntry) == 64, "one explored-pair entry is one 64-byte line");
 constexpr uint32_t PE_EXPLORED = 0x80000000u, PE_QMASK = 0x1FFu;
 
 __device__ __forceinline__ uint64_t pair_hash(uint64_t a, uint64_t b) {
@@ -94,6 +97,13 @@ struct K3PairArgs {
   DporPairRec* recs;                   // k3_pairs_records out: [recs_cap]; insert_rec / decide_rec in: [world][recs_stride]
   uint32_t recs_cap, recs_stride;
   const unsigned long long* rec_counts;   // [world] valid records per rank segment
+  // the parent filter of insert (see k3_pairs_insert); complete == nullptr: every reported pair is probed
+  const uint32_t* arena_len;           // [ids]
+  uint8_t* complete;                   // [ids]: invariant (I) of dpor_host.hpp's ParentFilter holds for that interleaving
+  const demi_verdict* verdicts;        // [n] the round's verdicts (DEMI_V_PAIRS_OVF)
+  // the device-resident backtrack queue (k3_queue.hpp)
+  unsigned long long* keep_bits;       // [n][max_pairs / 64]: decide's verdict per racing pair (bit = its backtrack point is emitted)
+  uint32_t* item_points;               // [n]: points emitted per interleaving
 };
 
 __device__ __forceinline__ unsigned long long cand_pack(uint32_t round, uint32_t branch, unsigned long long ordinal) {
@@ -121,14 +131,87 @@ __global__ __launch_bounds__(256) void k3_pairs_mark(const K3PairArgs a) {
   atomicOr(&a.table[s >> 1].state[s & 1], PE_EXPLORED);
 }
 
-// insert: one workgroup per finished interleaving, its threads stride over the racing pairs
+// insert: one workgroup per finished interleaving, its threads stride over the racing pairs.
+//
+// The parent filter (round 5).  Thousands of sibling interleavings of a round report the SAME racing pairs - same node keys -
+// and so did the interleaving they all descend from: config 5 probed the table 6 x 10^8 times for 5 x 10^6 distinct pairs.  What
+// the PARENT of an interleaving C provably applied already is dropped here before it costs a probe: dpor_host.hpp's ParentFilter
+// rule (both events also occur in the parent P - the interleaving whose racing pair produced C's next trace -, with keys unique
+// on both sides and equal quiescent periods, in the same order, and the branch event sits at least as deep in P), evaluated
+// against P's trace in the arena through a hash of its node keys in LDS (the same code as k3_ref_filter's rule (a)).  P's pairs
+// were inserted in an earlier round - C's backtrack point was CREATED by that insert - with a branch at least as deep, so C's
+// instance sets an explored bit that is set, proposes a candidate that cannot be emitted (the flipped pair is explored by now or
+// carries a queued mark above C's branch) and, being unable to win, cannot displace an instance that could: a no-op.  The rule
+// needs invariant (I) for P (every racing pair of P applied with a branch at least as deep): `complete`, kept per arena id -
+// false once a pair list was truncated (DEMI_V_PAIRS_OVF) anywhere up the chain of parents; nothing is dropped then.
+constexpr uint32_t PF_SLOTS = 1024;       // > 2 x DEMI_DPOR_MAX_TRACE
+__device__ __forceinline__ uint32_t pf_key_hash(uint64_t k) { return (uint32_t)((k * 0x9E3779B97F4A7C15ULL) >> 54) & (PF_SLOTS - 1); }
+
 __global__ __launch_bounds__(256) void k3_pairs_insert(const K3PairArgs a) {
-  const uint32_t it = blockIdx.x;
+  __shared__ unsigned long long s_pkey[DEMI_DPOR_MAX_TRACE], s_okey[DEMI_DPOR_MAX_TRACE];
+  __shared__ uint32_t s_pslot[PF_SLOTS], s_oslot[PF_SLOTS];      // 0xFFFFFFFF = empty, else an event index
+  __shared__ uint32_t s_pdup[DEMI_DPOR_MAX_TRACE], s_odup[DEMI_DPOR_MAX_TRACE];
+  __shared__ int s_idx[DEMI_DPOR_MAX_TRACE];
+  __shared__ uint8_t s_pq[DEMI_DPOR_MAX_TRACE];
+  const uint32_t it = blockIdx.x, t = threadIdx.x;
   const demi_dpor_trace_entry* T = a.arena + (size_t)(a.base_id + it) * DEMI_DPOR_MAX_TRACE;
   const demi_dpor_pair* P = a.pairs + (size_t)it * a.max_pairs;
   const uint32_t np = a.n_pairs[it];
-  for (uint32_t k = threadIdx.x; k < np; k += blockDim.x) {
+  bool par = false;
+  if (a.complete) {
+    const DporItem item = a.items[a.item_base + it];
+    par = item.src != 0xFFFFFFFFu && a.complete[item.src] != 0;
+    if (t == 0) a.complete[a.base_id + it] = (!(a.verdicts[it].flags & DEMI_V_PAIRS_OVF) && (item.src == 0xFFFFFFFFu || par)) ? 1 : 0;
+    if (par && np != 0) {                    // where each of this interleaving's events sits in the parent (or -1)
+      const uint32_t n_tr = min(a.arena_len[a.base_id + it], (uint32_t)DEMI_DPOR_MAX_TRACE);
+      const demi_dpor_trace_entry* TP = a.arena + (size_t)item.src * DEMI_DPOR_MAX_TRACE;
+      const uint32_t n_par = min(a.arena_len[item.src], (uint32_t)DEMI_DPOR_MAX_TRACE);
+      for (uint32_t i = t; i < PF_SLOTS; i += blockDim.x) { s_pslot[i] = 0xFFFFFFFFu; s_oslot[i] = 0xFFFFFFFFu; }
+      if (t < DEMI_DPOR_MAX_TRACE) {
+        s_pdup[t] = 0; s_odup[t] = 0; s_idx[t] = -1;
+        if (t < n_par) { s_pkey[t] = TP[t].key; s_pq[t] = TP[t].qperiod; }
+        if (t < n_tr) s_okey[t] = T[t].key;
+      }
+      __syncthreads();
+      if (t < n_par) {                       // equal keys mark each other as duplicates (collapsed siblings)
+        const unsigned long long k = s_pkey[t];
+        for (uint32_t h = pf_key_hash(k);; h = (h + 1) & (PF_SLOTS - 1)) {
+          const uint32_t old = atomicCAS(&s_pslot[h], 0xFFFFFFFFu, t);
+          if (old == 0xFFFFFFFFu) break;
+          if (s_pkey[old] == k) { s_pdup[old] = 1; s_pdup[t] = 1; break; }
+        }
+      }
+      if (t < n_tr) {
+        const unsigned long long k = s_okey[t];
+        for (uint32_t h = pf_key_hash(k);; h = (h + 1) & (PF_SLOTS - 1)) {
+          const uint32_t old = atomicCAS(&s_oslot[h], 0xFFFFFFFFu, t);
+          if (old == 0xFFFFFFFFu) break;
+          if (s_okey[old] == k) { s_odup[old] = 1; s_odup[t] = 1; break; }
+        }
+      }
+      __syncthreads();
+      if (t < n_tr && !s_odup[t]) {          // same key, unique on both sides, same quiescent period
+        const unsigned long long k = s_okey[t];
+        for (uint32_t h = pf_key_hash(k);; h = (h + 1) & (PF_SLOTS - 1)) {
+          const uint32_t j = s_pslot[h];
+          if (j == 0xFFFFFFFFu) break;
+          if (s_pkey[j] == k) { if (!s_pdup[j] && s_pq[j] == T[t].qperiod) s_idx[t] = (int)j; break; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  uint32_t dropped = 0;
+  for (uint32_t k = t; k < np; k += blockDim.x) {
     const demi_dpor_pair p = P[k];
+    if (par) {
+      const int ie = s_idx[p.earlier], il = s_idx[p.later], ib = s_idx[p.branch];
+      if (ie >= 0 && il >= 0 && ie < il && ib >= (int)p.branch) {             // the parent applied it
+        a.pair_slot_of[(size_t)it * a.max_pairs + k] = 0xFFFFFFFFu;
+        dropped++;
+        continue;
+      }
+    }
     const uint64_t ke = T[p.earlier].key, kl = T[p.later].key;
     const uint32_t s1 = pair_slot(a.table, a.mask, ke, kl);                // (earlier, later); its flip is the other side
     const uint32_t s2 = s1 == 0xFFFFFFFFu ? s1 : (s1 ^ 1u);
@@ -140,13 +223,23 @@ __global__ __launch_bounds__(256) void k3_pairs_insert(const K3PairArgs a) {
     PairEntry* const e1 = a.table + (s1 >> 1);
     if (!(e1->state[s1 & 1] & PE_EXPLORED)) {
       const uint32_t old = atomicOr(&e1->state[s1 & 1], PE_EXPLORED);      // setExplored(branch, (earlier, later))
-      if (!(old & PE_EXPLORED) && (old & PE_QMASK)) {                      // queued points flip into this pair: dead now
-        const unsigned long long q = atomicAdd(&a.counters[1], 1ull);
+      if (a.kills && !(old & PE_EXPLORED) && (old & PE_QMASK)) {           // queued points flip into this pair: dead now
+        const unsigned long long q = atomicAdd(&a.counters[1], 1ull);      // (only a HOST queue is told: the device queue reads the table)
         if (q < a.kills_cap) { DporKill kk; kk.a = ke; kk.b = kl; a.kills[q] = kk; }
       }
     }
     const unsigned long long mine = cand_pack(a.round, p.branch, (unsigned long long)it * a.max_pairs + k);
     if (e1->cand[(s2 & 1)] < mine) atomicMax(&e1->cand[s2 & 1], mine);   // (s2 is the other side of the same entry)
+  }
+  // statistics (single-rank rounds: counters[3] is otherwise the sharded rounds' record count): pairs the parent filter dropped
+  if (t == 0 && !a.kills && np) atomicAdd(&a.counters[1], (unsigned long long)np);     // (device-queue rounds: counters[1] = pairs reported)
+  if (a.world <= 1 && par) {               // (par is uniform over the workgroup)
+    __syncthreads();                       // (every thread is done reading the index table: its first word collects the count)
+    if (t == 0) s_idx[0] = 0;
+    __syncthreads();
+    if (dropped) atomicAdd(reinterpret_cast<uint32_t*>(&s_idx[0]), dropped);
+    __syncthreads();
+    if (t == 0 && s_idx[0]) atomicAdd(&a.counters[3], (unsigned long long)(uint32_t)s_idx[0]);
   }
 }
 
@@ -176,6 +269,38 @@ __global__ __launch_bounds__(256) void k3_pairs_decide(const K3PairArgs a) {
       a.points[q] = o;
     }
   }
+}
+
+// decide for the device-resident queue (k3_queue.hpp): the same verdict per racing pair, left as one bit per pair (and the
+// count per interleaving) instead of a point pushed through an atomic counter - k3_q_scan / k3_q_emit then write the round's
+// points in creation order.  max_pairs <= 4096.
+__global__ __launch_bounds__(256) void k3_pairs_decide_q(const K3PairArgs a) {
+  __shared__ unsigned long long s_keep[64];
+  __shared__ uint32_t s_cnt;
+  const uint32_t it = blockIdx.x, t = threadIdx.x;
+  const uint32_t words = (a.max_pairs + 63) / 64;
+  if (t < 64) s_keep[t] = 0;
+  if (t == 0) s_cnt = 0;
+  __syncthreads();
+  const demi_dpor_pair* P = a.pairs + (size_t)it * a.max_pairs;
+  const uint32_t np = a.n_pairs[it];
+  for (uint32_t k = t; k < np; k += blockDim.x) {
+    const uint32_t s2 = a.pair_slot_of[(size_t)it * a.max_pairs + k];
+    if (s2 == 0xFFFFFFFFu) continue;
+    const demi_dpor_pair p = P[k];
+    PairEntry* e = a.table + (s2 >> 1);
+    const uint32_t sd = s2 & 1;
+    const uint32_t st = e->state[sd];
+    if (st & PE_EXPLORED) continue;                                        // getNext would skip it (:1153-1157)
+    if (e->cand[sd] != cand_pack(a.round, p.branch, (unsigned long long)it * a.max_pairs + k)) continue;
+    if ((st & PE_QMASK) > p.branch) continue;                              // a queued point of an earlier round is dequeued first
+    e->state[sd] = (st & ~PE_QMASK) | ((uint32_t)p.branch + 1);            // (the only writer of this side this round)
+    atomicOr(&s_keep[k >> 6], 1ull << (k & 63));
+    atomicAdd(&s_cnt, 1u);
+  }
+  __syncthreads();
+  if (t < words) a.keep_bits[(size_t)it * words + t] = s_keep[t];
+  if (t == 0) a.item_points[it] = s_cnt;
 }
 
 }  // namespace demi

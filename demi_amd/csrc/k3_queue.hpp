@@ -1,0 +1,258 @@
+// k3_queue.hpp — DPORwHeuristics' backtrack queue on the device (round 5; single-rank ROUNDS order).
+//
+// Until round 4 the queue lived on the host (dpor_host.hpp explore_rounds_resident): per round every backtrack point that could
+// still be dequeued (40 bytes) and every pair that became explored under a queued point (16 bytes) crossed PCIe, the host
+// radix-sorted the points into 256 FIFO buckets and kept a hash set of dead flipped pairs - for config 5 that was half the wall
+// time of the exploration (197 MB device-to-host, 66 synchronous rounds, the device idle while the host commits).  But the host's
+// `dead` set is a copy of what the device's explored-pair table already knows - getNext()'s skip (DPORwHeuristics.scala:1153-1157)
+// is `isExplored(flipped pair)`, and both the dequeue (:1170-1172) and dpor() (:1068-1070) mark pairs in that table - so the queue
+// can stay where its inputs and its consumer are:
+//
+//   * decide (k3_pairs.hpp) no longer emits points through an atomic counter: it leaves one keep BIT per racing pair, and
+//     k3_q_scan / k3_q_emit compact the kept pairs in creation order (interleaving by interleaving, pair by pair - what the host's
+//     sort by ordinal produced);
+//   * k3_q_hist / k3_q_offsets / k3_q_scatter are one stable counting-sort pass over the 8-bit branch index, deepest branch first
+//     (DefaultBacktrackOrdering, BacktrackOrdering.scala:58-69), into the next free segment of a pool that holds every queued
+//     point: a segment is 256 runs, one per branch, each in creation order.  The host only learns the 256 run lengths;
+//   * the host keeps, per branch, the FIFO of runs (pool offset, remaining) - PriorityQueue order with ties in creation order is
+//     "deepest branch first, oldest run first, run order" - and for a dequeue hands the device the next ranges of that order;
+//   * k3_q_probe / k3_q_take are getNext() for a whole round: every candidate of the ranges looks its flipped pair up in the
+//     explored-pair table; a candidate is LIVE iff the pair is not explored and no earlier candidate of this dequeue has the same
+//     flipped pair (the first one marks it explored, :1170-1172, the others would be skipped); the first `want` live candidates
+//     become the round's items and mark their pairs; what precedes the last one taken is consumed (the dead ones for good), the
+//     rest stays queued.  The host gets two numbers back.
+// Same dequeue order, same rounds, same verdict sequence as the host queue (tests: both paths on the same explorations).
+#pragma once
+
+#include "k3_pairs.hpp"
+
+namespace demi {
+
+struct QPoint {                          // a queued backtrack point, 24 bytes
+  unsigned long long flip_a, flip_b;     // (later key, earlier key): the pair getNext() tests with isExplored
+  uint32_t src;                          // arena id of the interleaving that found it
+  uint8_t branch, later, earlier, pad;
+};
+
+struct QRange { unsigned long long start; uint32_t count, prefix; };   // pool[start .. start + count): candidates prefix .. prefix + count
+
+constexpr uint32_t Q_TILE = 2048;        // elements a wave sorts (k3_q_hist / k3_q_scatter)
+
+struct K3QueueArgs {
+  // ---- emit + sort (after decide)
+  const demi_dpor_trace_entry* arena;
+  const demi_dpor_pair* pairs;           // [n][max_pairs]
+  const uint32_t* n_pairs;               // [n]
+  const unsigned long long* keep_bits;   // [n][max_pairs / 64]
+  uint32_t* item_points;                 // [n] in: points per interleaving; k3_q_scan turns it into the exclusive prefix
+  uint32_t n, max_pairs, base_id;
+  QPoint* staging;                       // [staging_cap] the round's points in creation order
+  uint32_t staging_cap;
+  uint32_t* tile_hist;                   // [tiles][256]
+  uint32_t* digit_start;                 // [256] where the run of branch d starts within the segment (deepest branch first)
+  QPoint* pool;                          // the queue's pool; the round's segment starts at pool_fill
+  unsigned long long pool_fill;
+  // [0] points of the round, [1] candidates taken by the dequeue, [2] candidates consumed, [3] table-full errors; [4 .. 260) run lengths per branch
+  unsigned long long* out;
+  // ---- dequeue
+  PairEntry* table; uint32_t mask;
+  const QRange* ranges; uint32_t n_ranges;
+  uint32_t n_cand;                       // candidates of this dequeue (the ranges' total)
+  uint32_t want;                         // live candidates to take
+  uint32_t round;                        // stamps the dequeue (1, 2, ...: every k3_q_probe launch has its own)
+  uint32_t* cand_slot;                   // [n_cand] table slot * 2 + side of each candidate's flipped pair
+  DporItem* items;                       // out: the taken candidates, in dequeue order
+};
+
+__device__ __forceinline__ unsigned long long q_stamp(uint32_t round, uint32_t j) {
+  return ((unsigned long long)round << 32) | (unsigned long long)(0xFFFFFFFFu - j);      // max = this dequeue, lowest candidate index
+}
+
+// exclusive prefix of item_points[0 .. n) in place; the total to out[0].  One workgroup.
+__global__ __launch_bounds__(1024) void k3_q_scan(const K3QueueArgs a) {
+  __shared__ uint32_t s_part[1024];
+  __shared__ uint32_t s_carry;
+  const uint32_t t = threadIdx.x;
+  if (t == 0) s_carry = 0;
+  __syncthreads();
+  for (uint32_t lo = 0; lo < a.n; lo += 1024) {
+    const uint32_t i = lo + t;
+    const uint32_t v = i < a.n ? a.item_points[i] : 0u;
+    s_part[t] = v;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {                 // inclusive scan (Hillis-Steele)
+      const uint32_t x = t >= d ? s_part[t - d] : 0u;
+      __syncthreads();
+      s_part[t] += x;
+      __syncthreads();
+    }
+    const uint32_t carry = s_carry;
+    if (i < a.n) a.item_points[i] = carry + s_part[t] - v;
+    __syncthreads();
+    if (t == 1023) s_carry = carry + s_part[1023];
+    __syncthreads();
+  }
+  if (t == 0) a.out[0] = s_carry;
+}
+
+// the kept pairs of interleaving blockIdx.x, in pair order, to staging[item_points[it] ..)
+__global__ __launch_bounds__(256) void k3_q_emit(const K3QueueArgs a) {
+  __shared__ uint32_t s_pre[65];
+  const uint32_t it = blockIdx.x, t = threadIdx.x;
+  const uint32_t words = (a.max_pairs + 63) / 64;
+  const unsigned long long* kb = a.keep_bits + (size_t)it * words;
+  const uint32_t np = a.n_pairs[it];
+  const uint32_t nw = (np + 63) / 64;
+  if (t == 0) {
+    uint32_t tot = 0;
+    for (uint32_t w = 0; w < nw; w++) { s_pre[w] = tot; tot += (uint32_t)__popcll(kb[w]); }
+    s_pre[64] = tot;
+  }
+  __syncthreads();
+  if (s_pre[64] == 0) return;
+  const uint32_t off = a.item_points[it];
+  if ((unsigned long long)off + s_pre[64] > a.staging_cap) return;          // (the host sees out[0] > staging_cap and reports it)
+  const demi_dpor_trace_entry* T = a.arena + (size_t)(a.base_id + it) * DEMI_DPOR_MAX_TRACE;
+  const demi_dpor_pair* P = a.pairs + (size_t)it * a.max_pairs;
+  for (uint32_t k = t; k < np; k += blockDim.x) {
+    const unsigned long long w = kb[k >> 6];
+    if (!((w >> (k & 63)) & 1ull)) continue;
+    const demi_dpor_pair p = P[k];
+    QPoint q;
+    q.flip_a = T[p.later].key; q.flip_b = T[p.earlier].key; q.src = a.base_id + it;
+    q.branch = p.branch; q.later = p.later; q.earlier = p.earlier; q.pad = 0;
+    a.staging[off + s_pre[k >> 6] + (uint32_t)__popcll(w & ((1ull << (k & 63)) - 1ull))] = q;
+  }
+}
+
+// per tile of Q_TILE staged points: how many of each branch.  One wave per tile.
+__global__ __launch_bounds__(64) void k3_q_hist(const K3QueueArgs a) {
+  __shared__ uint32_t s_h[256];
+  const uint32_t tile = blockIdx.x, lane = threadIdx.x;
+  const uint32_t total = (uint32_t)a.out[0];
+  for (uint32_t i = lane; i < 256; i += 64) s_h[i] = 0;
+  __syncthreads();
+  const uint32_t lo = tile * Q_TILE, hi = min(lo + Q_TILE, total);
+  for (uint32_t i = lo + lane; i < hi; i += 64) atomicAdd(&s_h[a.staging[i].branch], 1u);
+  __syncthreads();
+  for (uint32_t i = lane; i < 256; i += 64) a.tile_hist[(size_t)tile * 256 + i] = s_h[i];
+}
+
+// thread d: the tiles' counts of branch d -> exclusive prefix over the tiles, the run length to out[4 + d]; then the runs' starts
+// within the segment, deepest branch first.  One workgroup of 256.
+__global__ __launch_bounds__(256) void k3_q_offsets(const K3QueueArgs a, uint32_t tiles) {
+  __shared__ uint32_t s_tot[256];
+  const uint32_t d = threadIdx.x;
+  uint32_t run = 0;
+  for (uint32_t tl = 0; tl < tiles; tl++) {
+    const uint32_t c = a.tile_hist[(size_t)tl * 256 + d];
+    a.tile_hist[(size_t)tl * 256 + d] = run;
+    run += c;
+  }
+  s_tot[d] = run;
+  a.out[4 + d] = run;
+  __syncthreads();
+  if (d == 0) {
+    uint32_t acc = 0;
+    for (int b = 255; b >= 0; b--) { a.digit_start[b] = acc; acc += s_tot[b]; }
+  }
+}
+
+// stable scatter of a tile into the pool segment: dest = run start of the branch + the tile's base within the run + the rank
+// among the tile's earlier points of that branch.  One wave per tile, 64 points at a time: the lanes that hold the same
+// branch find each other with eight ballots.
+__global__ __launch_bounds__(64) void k3_q_scatter(const K3QueueArgs a) {
+  __shared__ uint32_t s_run[256];
+  const uint32_t tile = blockIdx.x, lane = threadIdx.x;
+  const uint32_t total = (uint32_t)a.out[0];
+  for (uint32_t i = lane; i < 256; i += 64) s_run[i] = a.digit_start[i] + a.tile_hist[(size_t)tile * 256 + i];
+  __syncthreads();
+  const uint32_t lo = tile * Q_TILE, hi = min(lo + Q_TILE, total);
+  for (uint32_t base = lo; base < hi; base += 64) {
+    const uint32_t i = base + lane;
+    const bool on = i < hi;
+    QPoint q;
+    if (on) q = a.staging[i];
+    const uint32_t d = on ? q.branch : 0u;
+    unsigned long long peers = __ballot(on);
+    for (uint32_t b = 0; b < 8; b++) {
+      const unsigned long long m = __ballot(on && ((d >> b) & 1u));
+      peers &= ((d >> b) & 1u) ? m : ~m;
+    }
+    const uint32_t rank = (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));
+    uint32_t dst = 0;
+    if (on) dst = s_run[d] + rank;
+    __syncthreads();                       // (one wave: orders the reads of s_run above against the updates below)
+    if (on && rank == 0) s_run[d] += (uint32_t)__popcll(peers);
+    __syncthreads();
+    if (on) a.pool[a.pool_fill + dst] = q;
+  }
+}
+
+// ------------------------------------------------------------------ getNext() for a round
+// candidate j of the dequeue: the j-th point of the ranges
+__device__ __forceinline__ unsigned long long q_cand_index(const QRange* r, uint32_t n_ranges, uint32_t j) {
+  uint32_t lo = 0, hi = n_ranges;           // the last range with prefix <= j
+  while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (r[mid].prefix <= j) lo = mid; else hi = mid; }
+  return r[lo].start + (j - r[lo].prefix);
+}
+
+__global__ __launch_bounds__(256) void k3_q_probe(const K3QueueArgs a) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= a.n_cand) return;
+  const QPoint q = a.pool[q_cand_index(a.ranges, a.n_ranges, j)];
+  const uint32_t s = pair_slot(a.table, a.mask, q.flip_a, q.flip_b);
+  a.cand_slot[j] = s;
+  if (s == 0xFFFFFFFFu) { atomicAdd(&a.out[3], 1ull); return; }
+  PairEntry* e = a.table + (s >> 1);
+  if (__atomic_load_n(&e->state[s & 1], __ATOMIC_RELAXED) & PE_EXPLORED) return;
+  atomicMax(&e->pop[s & 1], q_stamp(a.round, j));
+}
+
+// One workgroup walks the candidates in order: live = not explored, and the first of this dequeue with its flipped pair; the
+// first `want` live ones are taken.  out[1] = taken, out[2] = consumed (the index after the last one taken, or n_cand).
+__global__ __launch_bounds__(1024) void k3_q_take(const K3QueueArgs a) {
+  __shared__ uint32_t s_part[1024];
+  __shared__ uint32_t s_have, s_consumed;
+  const uint32_t t = threadIdx.x;
+  if (t == 0) { s_have = 0; s_consumed = a.n_cand; }
+  __syncthreads();
+  for (uint32_t lo = 0; lo < a.n_cand; lo += 1024) {
+    const uint32_t have = s_have;
+    if (have >= a.want) break;                               // (workgroup-uniform)
+    const uint32_t j = lo + t;
+    bool live = false;
+    uint32_t s = 0xFFFFFFFFu;
+    if (j < a.n_cand) {
+      s = a.cand_slot[j];
+      if (s != 0xFFFFFFFFu) {
+        PairEntry* e = a.table + (s >> 1);
+        live = !(__atomic_load_n(&e->state[s & 1], __ATOMIC_RELAXED) & PE_EXPLORED) &&
+               __atomic_load_n(&e->pop[s & 1], __ATOMIC_RELAXED) == q_stamp(a.round, j);
+      }
+    }
+    s_part[t] = live ? 1u : 0u;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+      const uint32_t x = t >= d ? s_part[t - d] : 0u;
+      __syncthreads();
+      s_part[t] += x;
+      __syncthreads();
+    }
+    const uint32_t rank = have + s_part[t] - (live ? 1u : 0u);
+    if (live && rank < a.want) {
+      const QPoint q = a.pool[q_cand_index(a.ranges, a.n_ranges, j)];
+      DporItem it;
+      it.src = q.src; it.branch = q.branch; it.later = q.later; it.earlier = q.earlier; it.pad = 0;
+      a.items[rank] = it;
+      atomicOr(&a.table[s >> 1].state[s & 1], PE_EXPLORED);        // setExplored(maxIndex, (e1, e2)) (:1170-1172)
+      if (rank + 1 == a.want) s_consumed = j + 1;
+    }
+    __syncthreads();
+    if (t == 1023) s_have = min(have + s_part[1023], a.want);
+    __syncthreads();
+  }
+  if (t == 0) { a.out[1] = s_have; a.out[2] = s_consumed; }
+}
+
+}  // namespace demi
