@@ -75,6 +75,15 @@ class FlatPairMap {
     }
   }
   size_t size() const { return n_; }
+  // ask the memory system for the line find() / at() will look at first (the commit knows its next pairs in advance)
+  void prefetch(uint64_t a, uint64_t b) const {
+#ifndef DEMI_NO_PREFETCH
+    const bool sw = b < a;
+    __builtin_prefetch(&tab_[slot(sw ? b : a, sw ? a : b)]);
+#else
+    (void)a; (void)b;
+#endif
+  }
 
  private:
   struct Entry { uint64_t lo, hi; uint32_t val[2]; };
@@ -1306,7 +1315,10 @@ class RefBook {
   // dpor() for one committed interleaving (arena id `src`): its surviving racing pairs in pair order
   void absorb(const RefRec* r, uint32_t n, uint32_t src) {
     front_valid_ = false;
+    constexpr uint32_t AHEAD = 8;          // the table is far larger than the caches: the next records' lines are requested while this one is applied
+    for (uint32_t k = 0; k < n && k < AHEAD; k++) map_.prefetch(r[k].ke, r[k].kl);
     for (uint32_t k = 0; k < n; k++) {
+      if (k + AHEAD < n) map_.prefetch(r[k + AHEAD].ke, r[k + AHEAD].kl);
       const FlatPairMap::Ref e = map_.at(r[k].ke, r[k].kl);
       uint32_t* const side0 = r[k].ke < r[k].kl ? e.fwd : e.rev;      // (the entry's first value: where the dirty mark lives)
       if (!(*e.fwd & EXPLORED)) touch(side0, r[k].ke, r[k].kl);
@@ -1329,6 +1341,7 @@ class RefBook {
       const Point p = b.front();
       b.pop_front();
       queued_--;
+      if (b.size() > 3) map_.prefetch(b[3].flip_a, b[3].flip_b);          // (dead points are skipped in runs: the line of the one after next)
       const FlatPairMap::Ref e = map_.at(p.flip_a, p.flip_b);
       if (*e.fwd & EXPLORED) continue;                     // isExplored: skip
       *e.fwd |= EXPLORED;                                  // setExplored(maxIndex, (e1, e2)) (:1170-1172)
