@@ -1397,7 +1397,7 @@ class RefBook {
 //   the device's copy of the commit's table first, and afterwards the commit filter - interleaving i keeps rec_cnt[i] racing
 //   pairs as records, in pair order, WITH THE DEVICE (keyed by its arena id base_id + i); use_parent[i] says whether its
 //   parent's trace may be used for (a).
-// dev.ref_fetch(ids, m, deltas, n_deltas, rec_off, rec_cnt, &recs):
+// dev.ref_fetch_begin(ids, m, deltas, n_deltas) / dev.ref_fetch_end(rec_off, rec_cnt, &recs)   (one fetch in flight at a time):
 //   the commit is about to absorb the interleavings `ids` (arena ids, the first one right now, the others probably next):
 //   their records, filtered AGAIN under the table as it is now (the deltas first) - rule (b) holds for any older state, and a
 //   launch is 10^4 interleavings wide, most of whose pairs the commit has made no-ops by the time it reaches them: a
@@ -1422,7 +1422,8 @@ int explore_reference_resident(Dev&& dev, const demi_dpor_search* srch, demi_ver
   auto key_of = [](const demi::DporItem& it) -> uint64_t {
     return ((uint64_t)it.src << 24) | ((uint64_t)it.branch << 16) | ((uint64_t)it.later << 8) | (uint64_t)it.earlier;
   };
-  struct Result { uint32_t id; demi_verdict verdict; const RefRec* recs; uint32_t rec_cnt; bool fetched; };
+  // fetched: its records have been ASKED for (a fetch names it); ready: they are here (nothing to fetch: both from the start)
+  struct Result { uint32_t id; demi_verdict verdict; const RefRec* recs; uint32_t rec_cnt; bool fetched, ready; };
   std::unordered_map<uint64_t, Result> results;          // every interleaving run so far, by its item; its surviving racing
                                                          // pairs stay where the device's copy put them (dev owns that memory)
   std::vector<uint8_t> complete;                         // per arena id: invariant (I) of ParentFilter holds (see there)
@@ -1444,7 +1445,14 @@ int explore_reference_resident(Dev&& dev, const demi_dpor_search* srch, demi_ver
   std::vector<uint32_t> rec_cnt;
   std::vector<RefDelta> deltas;
   std::vector<uint32_t> fetch_ids;
-  std::vector<Result*> fetch_res;
+  std::vector<Result*> fetch_res, inflight_res;
+  bool inflight = false;                                  // a record fetch has been issued and not yet landed
+  // Measured (round 5, config 3, profiles/r05_call4_reference_prefetch_ab.txt): with the next window's fetch in flight the wait
+  // shrinks 23 -> 19 ms, the records fetched a window early are filtered under an older table and grow 33 -> 63 MB, the commit
+  // 13 -> 17 ms: 59.7 against 59.8 ms.  A window of the commit (25 us) is shorter than a fetch's round trip (40 us: two launches,
+  // a PCIe read of the request, the answer's writes, the event), so ONE fetch ahead cannot hide it and each further one costs more
+  // stale records.  Off by default (DEMI_DPOR_PREFETCH=1 turns it on); the split into begin / end stays.
+  const bool no_prefetch = demi_host::knob("DEMI_DPOR_PREFETCH") == nullptr;
   uint32_t base_id = 0, round = 0;
   uint64_t first_id = ~0ull;
   const size_t fetch_width = ref_fetch_width();
@@ -1456,7 +1464,7 @@ int explore_reference_resident(Dev&& dev, const demi_dpor_search* srch, demi_ver
     while (have_cur) {
       auto it = results.find(key_of(cur));
       if (it == results.end()) break;
-      if (!it->second.fetched) { need_fetch = true; break; }
+      if (!it->second.ready) { need_fetch = true; break; }
       const Result& r = it->second;
       const uint64_t idx = stats->interleavings++;
       out_verdicts[idx] = r.verdict;
@@ -1479,31 +1487,62 @@ int explore_reference_resident(Dev&& dev, const demi_dpor_search* srch, demi_ver
     if (seconds) seconds[2] += t1 - t0;
     if (done) break;
 
-    if (need_fetch) {
-      // ---- the records of the interleaving the commit stands at, and of those its queue will most likely hand out next
+    // A record fetch is two steps: issue() names the interleavings and hands the device the table's changes, land() waits for the
+    // answer.  With DEMI_DPOR_PREFETCH the fetch for the NEXT window of the queue front is issued while the commit works through
+    // this one (records fetched a window early are filtered under a table that is a window older - rule (b) holds for any older
+    // state - so more of them cross PCIe); by default a fetch is waited for when it is issued (see no_prefetch above).
+    auto issue = [&](bool with_cur) -> int {
       fetch_ids.clear(); fetch_res.clear();
-      Result* r0 = &results.find(key_of(cur))->second;         // (no insertion below: the pointers stay valid)
-      fetch_ids.push_back(r0->id); fetch_res.push_back(r0);
-      r0->fetched = true;
-      real.peek(fetch_width, [&](const RefBook::Point& p) {
+      if (with_cur) {
+        Result* r0 = &results.find(key_of(cur))->second;       // (std::unordered_map: element addresses survive insertions)
+        r0->fetched = true;
+        fetch_ids.push_back(r0->id); fetch_res.push_back(r0);
+      }
+      // (with_cur: the window at the queue's front; else the window behind it - the front one has been asked for already)
+      real.peek(with_cur ? fetch_width : 2 * fetch_width, [&](const RefBook::Point& p) {
         auto it = results.find(key_of(demi::DporItem{p.src, p.branch, p.later, p.earlier, 0}));
         if (it == results.end() || it->second.fetched) return;
         it->second.fetched = true;
         fetch_ids.push_back(it->second.id); fetch_res.push_back(&it->second);
       });
+      if (fetch_ids.empty()) return 0;
       real.take_deltas(deltas);
-      const uint32_t m = (uint32_t)fetch_ids.size();
+      int rc = dev.ref_fetch_begin(fetch_ids.data(), (uint32_t)fetch_ids.size(), deltas.data(), (uint32_t)deltas.size());
+      if (rc) return rc;
+      inflight_res = fetch_res;
+      inflight = true;
+      return 0;
+    };
+    auto land = [&]() -> int {
+      if (!inflight) return 0;
+      const uint32_t m = (uint32_t)inflight_res.size();
       rec_off.resize(m); rec_cnt.resize(m);
       const RefRec* recs = nullptr;
-      int rc = dev.ref_fetch(fetch_ids.data(), m, deltas.data(), (uint32_t)deltas.size(), rec_off.data(), rec_cnt.data(), &recs);
+      int rc = dev.ref_fetch_end(rec_off.data(), rec_cnt.data(), &recs);
       if (rc) return rc;
-      for (uint32_t j = 0; j < m; j++) { fetch_res[j]->recs = recs + rec_off[j]; fetch_res[j]->rec_cnt = rec_cnt[j]; }
+      for (uint32_t j = 0; j < m; j++) { inflight_res[j]->recs = recs + rec_off[j]; inflight_res[j]->rec_cnt = rec_cnt[j]; inflight_res[j]->ready = true; }
+      inflight = false;
       stats->fetches++;
+      return 0;
+    };
+    if (need_fetch) {
+      // ---- the records of the interleaving the commit stands at: in the fetch that is in flight (the usual case), or asked for now
+      int rc = land();
+      if (rc) return rc;
+      const Result& r0 = results.find(key_of(cur))->second;
+      if (!r0.ready) {
+        rc = issue(!r0.fetched);
+        if (!rc) rc = land();
+        if (rc) return rc;
+      }
+      // ... and, while the commit absorbs them, those of the interleavings its queue will most likely hand out after this window
+      if (!no_prefetch) { rc = issue(false); if (rc) return rc; }
       if (seconds) seconds[1] += now() - t1;
       continue;
     }
 
     // ---- one launch: what the commit is waiting for + the speculation's next round (minus what has been run already)
+    { int rc = land(); if (rc) return rc; }         // (the launch sends the table's changes too: one stream of deltas, in order)
     stats->cache_misses++;
     items.clear();
     items.push_back(cur);
@@ -1539,7 +1578,7 @@ int explore_reference_resident(Dev&& dev, const demi_dpor_search* srch, demi_ver
     double t2 = now();
     if (complete.size() < (size_t)base_id + n) complete.resize((size_t)base_id + n, 0);
     for (uint32_t i = 0; i < n; i++) {
-      results[key_of(items[i])] = Result{base_id + i, vd[i], nullptr, 0u, rec_cnt[i] == 0};   // (nothing to fetch: as good as fetched)
+      results[key_of(items[i])] = Result{base_id + i, vd[i], nullptr, 0u, rec_cnt[i] == 0, rec_cnt[i] == 0};   // (nothing to fetch: as good as here)
       // (I) holds for this interleaving once it is absorbed iff its own pair list is whole and (I) held for its parent
       complete[(size_t)base_id + i] = !(vd[i].flags & DEMI_V_PAIRS_OVF) && (items[i].src == 0xFFFFFFFFu || use_parent[i]);
     }
@@ -1561,6 +1600,13 @@ int explore_reference_resident(Dev&& dev, const demi_dpor_search* srch, demi_ver
       spec_items.push_back(demi::DporItem{p.src, p.branch, p.later, p.earlier, 0});
     }
     if (seconds) { seconds[0] += t2 - t1; seconds[1] += now() - t2; }
+  }
+  if (inflight) {                                          // (an answer nobody needs any more: still waited for - it writes host memory)
+    rec_off.resize(inflight_res.size()); rec_cnt.resize(inflight_res.size());
+    const RefRec* recs = nullptr;
+    int rc = dev.ref_fetch_end(rec_off.data(), rec_cnt.data(), &recs);
+    if (rc) return rc;
+    inflight = false;
   }
   if (first_id != ~0ull && first_violation_trace && first_violation_len) {
     int rc = dev.fetch_trace((uint32_t)first_id, first_violation_trace, first_violation_len);

@@ -124,6 +124,19 @@ struct SimDev {
     *recs_out = recs.data();
     return 0;
   }
+  // the asynchronous form the host loop uses: the work happens at begin (the table as of THEN), the answer is handed over at end
+  std::vector<uint64_t> pend_off;
+  std::vector<uint32_t> pend_cnt;
+  const demi_host::RefRec* pend_recs = nullptr;
+  int ref_fetch_begin(const uint32_t* ids, uint32_t m, const demi_host::RefDelta* deltas, uint32_t n_deltas) {
+    pend_off.assign(m, 0); pend_cnt.assign(m, 0);
+    return ref_fetch(ids, m, deltas, n_deltas, pend_off.data(), pend_cnt.data(), &pend_recs);
+  }
+  int ref_fetch_end(uint64_t* rec_off, uint32_t* rec_cnt, const demi_host::RefRec** recs_out) {
+    for (size_t j = 0; j < pend_off.size(); j++) { rec_off[j] = pend_off[j]; rec_cnt[j] = pend_cnt[j]; }
+    *recs_out = pend_recs;
+    return 0;
+  }
   std::vector<std::vector<demi_host::RefRec>> held;           // per arena id: the first filter's survivors
   std::deque<std::vector<demi_host::RefRec>> rec_chunks;      // one per fetch, alive until the exploration ends
   unsigned long long pairs_fetched = 0, fetches = 0, fetched_ids = 0;

@@ -503,3 +503,27 @@ def test_one_job_shuffle_in_reference_order_equals_the_scala_transliteration(ora
     nt, sh, tr = ctx.dpor_explored(len(want) - 1)
     assert len(nt) == sc.next_trace_lens[-1]
     ctx.close()
+
+
+def test_reference_order_with_the_record_fetch_in_flight(monkeypatch):
+    """DEMI_DPOR_PREFETCH=1: the commit's record fetch for the next window of its queue front is issued while this window is
+    absorbed (dpor_host.hpp issue() / land()); records fetched early are filtered under an older table, the committed sequence is
+    the same - raft5 (config 3, a budgeted slice) and the writers model, whose violating set depends on the order."""
+    from tests.test_dpor_cpu import writers_model
+    from demi_amd import _native
+    model3, ev3, depth3 = raft5_config3()
+    cases = [(model3, ev3, depth3, 6000), (writers_model(4), events_to_array([start(a) for a in range(5)] + [send(a, 0) for a in range(1, 5)]), 0, 20000)]
+    for model, ev, depth, budget in cases:
+        ctx = _native.Context(0)
+        ctx.model_load(model.to_struct())
+        ctx.dpor_load(ev)
+        par, srch = T.DporParams(depth, 0, 0, 0, 64, 4096), T.DporSearch(256, budget, 0, 1, T.DPOR_ORDER_REFERENCE)
+        monkeypatch.delenv("DEMI_DPOR_PREFETCH", raising=False)
+        one = ctx.dpor_explore(par, srch)
+        monkeypatch.setenv("DEMI_DPOR_PREFETCH", "1")
+        two = ctx.dpor_explore(par, srch)
+        monkeypatch.delenv("DEMI_DPOR_PREFETCH")
+        assert len(one[0]) == len(two[0]) and (one[0] == two[0]).all() and (one[1] == two[1]).all()
+        assert one[4].exhausted == two[4].exhausted and one[4].queue_len == two[4].queue_len
+        assert two[4].d2h_bytes >= one[4].d2h_bytes        # (records fetched a window early: never fewer)
+        ctx.close()
