@@ -209,8 +209,23 @@ __global__ __launch_bounds__(256) void k3_q_probe(const K3QueueArgs a) {
   atomicMax(&e->pop[s & 1], q_stamp(a.round, j));
 }
 
-// One workgroup walks the candidates in order: live = not explored, and the first of this dequeue with its flipped pair; the
-// first `want` live ones are taken.  out[1] = taken, out[2] = consumed (the index after the last one taken, or n_cand).
+// which candidates are LIVE: not explored, and the first of this dequeue with its flipped pair.  Two dependent reads of the
+// explored-pair table per candidate: done by the whole grid, the verdict left in bit 31 of cand_slot (slots are below 2^28), so
+// that the one workgroup of k3_q_take only streams that array.
+constexpr uint32_t Q_LIVE = 0x80000000u;
+__global__ __launch_bounds__(256) void k3_q_live(const K3QueueArgs a) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= a.n_cand) return;
+  const uint32_t s = a.cand_slot[j];
+  if (s == 0xFFFFFFFFu) { a.cand_slot[j] = 0x7FFFFFFFu; return; }        // (table full: reported by k3_q_probe; never live)
+  const PairEntry* e = a.table + (s >> 1);
+  const bool live = !(__atomic_load_n(&e->state[s & 1], __ATOMIC_RELAXED) & PE_EXPLORED) &&
+                    __atomic_load_n(&e->pop[s & 1], __ATOMIC_RELAXED) == q_stamp(a.round, j);
+  if (live) a.cand_slot[j] = s | Q_LIVE;
+}
+
+// One workgroup walks the candidates in order: the first `want` live ones are taken.  out[1] = taken, out[2] = consumed (the
+// index after the last one taken, or n_cand).
 __global__ __launch_bounds__(1024) void k3_q_take(const K3QueueArgs a) {
   __shared__ uint32_t s_part[1024];
   __shared__ uint32_t s_have, s_consumed;
@@ -222,14 +237,11 @@ __global__ __launch_bounds__(1024) void k3_q_take(const K3QueueArgs a) {
     if (have >= a.want) break;                               // (workgroup-uniform)
     const uint32_t j = lo + t;
     bool live = false;
-    uint32_t s = 0xFFFFFFFFu;
+    uint32_t s = 0;
     if (j < a.n_cand) {
-      s = a.cand_slot[j];
-      if (s != 0xFFFFFFFFu) {
-        PairEntry* e = a.table + (s >> 1);
-        live = !(__atomic_load_n(&e->state[s & 1], __ATOMIC_RELAXED) & PE_EXPLORED) &&
-               __atomic_load_n(&e->pop[s & 1], __ATOMIC_RELAXED) == q_stamp(a.round, j);
-      }
+      const uint32_t cs = a.cand_slot[j];
+      live = (cs & Q_LIVE) != 0;
+      s = cs & ~Q_LIVE;
     }
     s_part[t] = live ? 1u : 0u;
     __syncthreads();

@@ -527,3 +527,43 @@ def test_reference_order_with_the_record_fetch_in_flight(monkeypatch):
         assert one[4].exhausted == two[4].exhausted and one[4].queue_len == two[4].queue_len
         assert two[4].d2h_bytes >= one[4].d2h_bytes        # (records fetched a window early: never fewer)
         ctx.close()
+
+
+@pytest.mark.parametrize("cfg", ["config3", "config5"])
+def test_device_queue_and_parent_filter_leave_the_exploration_unchanged(monkeypatch, cfg):
+    """Round 5's two changes of the ROUNDS path - the backtrack queue on the device (k3_queue.hpp) and the parent filter in
+    k3_pairs_insert - against round 4's loop (DEMI_DPOR_HOST_QUEUE: live points and kills to a host queue) and against probing
+    every reported pair (DEMI_K3_NO_PARENT_FILTER): the same rounds, verdicts, prefix lengths, queue and backtrack-point count."""
+    import os
+    from demi_amd import _native
+    from demi_amd.apps import shuffle8_config5_large
+    emu = os.environ.get("DEMI_EMU") == "1"
+    if cfg == "config3":
+        model, ev, depth = raft5_config3()
+        budget, batch = (3000, 256) if emu else (1 << 17, 16384)
+    else:
+        model, ev, depth, _b = shuffle8_config5_large()
+        budget, batch = (2000, 256) if emu else (100000, 16384)
+    ctx = _native.Context(0)
+    ctx.model_load(model.to_struct())
+    ctx.model_specialize()
+    ctx.dpor_load(ev)
+    par, srch = T.DporParams(depth, 0, 0, 0, 64, 4096), T.DporSearch(batch, budget, 0, 1, T.DPOR_ORDER_ROUNDS)
+    runs = {}
+    for name, env in (("default", {}), ("host_queue", {"DEMI_DPOR_HOST_QUEUE": "1"}), ("no_filter", {"DEMI_K3_NO_PARENT_FILTER": "1"}),
+                      ("round4", {"DEMI_DPOR_HOST_QUEUE": "1", "DEMI_K3_NO_PARENT_FILTER": "1"})):
+        for k in ("DEMI_DPOR_HOST_QUEUE", "DEMI_K3_NO_PARENT_FILTER"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        runs[name] = ctx.dpor_explore(par, srch)
+    for k in ("DEMI_DPOR_HOST_QUEUE", "DEMI_K3_NO_PARENT_FILTER"):
+        monkeypatch.delenv(k, raising=False)
+    d = runs["default"]
+    assert len(d[0]) == budget or d[4].exhausted
+    for name, r in runs.items():
+        assert len(r[0]) == len(d[0]) and (r[0] == d[0]).all() and (r[1] == d[1]).all() and (r[2] == d[2]).all(), name
+        assert r[4].queue_len == d[4].queue_len and r[4].backtrack_points == d[4].backtrack_points and r[4].exhausted == d[4].exhausted, name
+    # what no longer crosses PCIe: the host queue is fed 40-byte points and 16-byte kills, the device queue 256 run lengths per round
+    assert d[4].d2h_bytes < runs["host_queue"][4].d2h_bytes
+    ctx.close()
