@@ -147,70 +147,81 @@ __global__ __launch_bounds__(256) void k3_pairs_mark(const K3PairArgs a) {
 constexpr uint32_t PF_SLOTS = 1024;       // > 2 x DEMI_DPOR_MAX_TRACE
 __device__ __forceinline__ uint32_t pf_key_hash(uint64_t k) { return (uint32_t)((k * 0x9E3779B97F4A7C15ULL) >> 54) & (PF_SLOTS - 1); }
 
+// the LDS a workgroup needs for the filter, and its construction: s_idx[i] = where event i of this interleaving sits in its parent
+// (same key, unique on both sides, same quiescent period), or -1.  Returns whether the filter applies (uniform over the workgroup).
+struct ParentIndex {
+  unsigned long long pkey[DEMI_DPOR_MAX_TRACE], okey[DEMI_DPOR_MAX_TRACE];
+  uint32_t pslot[PF_SLOTS], oslot[PF_SLOTS];      // 0xFFFFFFFF = empty, else an event index
+  uint32_t pdup[DEMI_DPOR_MAX_TRACE], odup[DEMI_DPOR_MAX_TRACE];
+  int idx[DEMI_DPOR_MAX_TRACE];
+  uint8_t pq[DEMI_DPOR_MAX_TRACE];
+};
+// it: the interleaving's index within a.pairs / a.n_pairs / a.verdicts (this rank's block); arena id a.base_id + it; its
+// backtrack point a.items[a.item_base + it].  Also records `complete` for the interleaving (thread 0).
+__device__ inline bool parent_index_build(const K3PairArgs& a, uint32_t it, uint32_t np, const demi_dpor_trace_entry* T, ParentIndex& S) {
+  const uint32_t t = threadIdx.x;
+  if (!a.complete) return false;
+  const DporItem item = a.items[a.item_base + it];
+  const bool par = item.src != 0xFFFFFFFFu && a.complete[item.src] != 0;
+  if (t == 0) a.complete[a.base_id + it] = (!(a.verdicts[it].flags & DEMI_V_PAIRS_OVF) && (item.src == 0xFFFFFFFFu || par)) ? 1 : 0;
+  if (!par || np == 0) return false;
+  const uint32_t n_tr = min(a.arena_len[a.base_id + it], (uint32_t)DEMI_DPOR_MAX_TRACE);
+  const demi_dpor_trace_entry* TP = a.arena + (size_t)item.src * DEMI_DPOR_MAX_TRACE;
+  const uint32_t n_par = min(a.arena_len[item.src], (uint32_t)DEMI_DPOR_MAX_TRACE);
+  for (uint32_t i = t; i < PF_SLOTS; i += blockDim.x) { S.pslot[i] = 0xFFFFFFFFu; S.oslot[i] = 0xFFFFFFFFu; }
+  if (t < DEMI_DPOR_MAX_TRACE) {
+    S.pdup[t] = 0; S.odup[t] = 0; S.idx[t] = -1;
+    if (t < n_par) { S.pkey[t] = TP[t].key; S.pq[t] = TP[t].qperiod; }
+    if (t < n_tr) S.okey[t] = T[t].key;
+  }
+  __syncthreads();
+  if (t < n_par) {                       // equal keys mark each other as duplicates (collapsed siblings)
+    const unsigned long long k = S.pkey[t];
+    for (uint32_t h = pf_key_hash(k);; h = (h + 1) & (PF_SLOTS - 1)) {
+      const uint32_t old = atomicCAS(&S.pslot[h], 0xFFFFFFFFu, t);
+      if (old == 0xFFFFFFFFu) break;
+      if (S.pkey[old] == k) { S.pdup[old] = 1; S.pdup[t] = 1; break; }
+    }
+  }
+  if (t < n_tr) {
+    const unsigned long long k = S.okey[t];
+    for (uint32_t h = pf_key_hash(k);; h = (h + 1) & (PF_SLOTS - 1)) {
+      const uint32_t old = atomicCAS(&S.oslot[h], 0xFFFFFFFFu, t);
+      if (old == 0xFFFFFFFFu) break;
+      if (S.okey[old] == k) { S.odup[old] = 1; S.odup[t] = 1; break; }
+    }
+  }
+  __syncthreads();
+  if (t < n_tr && !S.odup[t]) {          // same key, unique on both sides, same quiescent period
+    const unsigned long long k = S.okey[t];
+    for (uint32_t h = pf_key_hash(k);; h = (h + 1) & (PF_SLOTS - 1)) {
+      const uint32_t j = S.pslot[h];
+      if (j == 0xFFFFFFFFu) break;
+      if (S.pkey[j] == k) { if (!S.pdup[j] && S.pq[j] == T[t].qperiod) S.idx[t] = (int)j; break; }
+    }
+  }
+  __syncthreads();
+  return true;
+}
+__device__ __forceinline__ bool parent_applied(const ParentIndex& S, const demi_dpor_pair& p) {
+  const int ie = S.idx[p.earlier], il = S.idx[p.later], ib = S.idx[p.branch];
+  return ie >= 0 && il >= 0 && ie < il && ib >= (int)p.branch;
+}
+
 __global__ __launch_bounds__(256) void k3_pairs_insert(const K3PairArgs a) {
-  __shared__ unsigned long long s_pkey[DEMI_DPOR_MAX_TRACE], s_okey[DEMI_DPOR_MAX_TRACE];
-  __shared__ uint32_t s_pslot[PF_SLOTS], s_oslot[PF_SLOTS];      // 0xFFFFFFFF = empty, else an event index
-  __shared__ uint32_t s_pdup[DEMI_DPOR_MAX_TRACE], s_odup[DEMI_DPOR_MAX_TRACE];
-  __shared__ int s_idx[DEMI_DPOR_MAX_TRACE];
-  __shared__ uint8_t s_pq[DEMI_DPOR_MAX_TRACE];
+  __shared__ ParentIndex S;
   const uint32_t it = blockIdx.x, t = threadIdx.x;
   const demi_dpor_trace_entry* T = a.arena + (size_t)(a.base_id + it) * DEMI_DPOR_MAX_TRACE;
   const demi_dpor_pair* P = a.pairs + (size_t)it * a.max_pairs;
   const uint32_t np = a.n_pairs[it];
-  bool par = false;
-  if (a.complete) {
-    const DporItem item = a.items[a.item_base + it];
-    par = item.src != 0xFFFFFFFFu && a.complete[item.src] != 0;
-    if (t == 0) a.complete[a.base_id + it] = (!(a.verdicts[it].flags & DEMI_V_PAIRS_OVF) && (item.src == 0xFFFFFFFFu || par)) ? 1 : 0;
-    if (par && np != 0) {                    // where each of this interleaving's events sits in the parent (or -1)
-      const uint32_t n_tr = min(a.arena_len[a.base_id + it], (uint32_t)DEMI_DPOR_MAX_TRACE);
-      const demi_dpor_trace_entry* TP = a.arena + (size_t)item.src * DEMI_DPOR_MAX_TRACE;
-      const uint32_t n_par = min(a.arena_len[item.src], (uint32_t)DEMI_DPOR_MAX_TRACE);
-      for (uint32_t i = t; i < PF_SLOTS; i += blockDim.x) { s_pslot[i] = 0xFFFFFFFFu; s_oslot[i] = 0xFFFFFFFFu; }
-      if (t < DEMI_DPOR_MAX_TRACE) {
-        s_pdup[t] = 0; s_odup[t] = 0; s_idx[t] = -1;
-        if (t < n_par) { s_pkey[t] = TP[t].key; s_pq[t] = TP[t].qperiod; }
-        if (t < n_tr) s_okey[t] = T[t].key;
-      }
-      __syncthreads();
-      if (t < n_par) {                       // equal keys mark each other as duplicates (collapsed siblings)
-        const unsigned long long k = s_pkey[t];
-        for (uint32_t h = pf_key_hash(k);; h = (h + 1) & (PF_SLOTS - 1)) {
-          const uint32_t old = atomicCAS(&s_pslot[h], 0xFFFFFFFFu, t);
-          if (old == 0xFFFFFFFFu) break;
-          if (s_pkey[old] == k) { s_pdup[old] = 1; s_pdup[t] = 1; break; }
-        }
-      }
-      if (t < n_tr) {
-        const unsigned long long k = s_okey[t];
-        for (uint32_t h = pf_key_hash(k);; h = (h + 1) & (PF_SLOTS - 1)) {
-          const uint32_t old = atomicCAS(&s_oslot[h], 0xFFFFFFFFu, t);
-          if (old == 0xFFFFFFFFu) break;
-          if (s_okey[old] == k) { s_odup[old] = 1; s_odup[t] = 1; break; }
-        }
-      }
-      __syncthreads();
-      if (t < n_tr && !s_odup[t]) {          // same key, unique on both sides, same quiescent period
-        const unsigned long long k = s_okey[t];
-        for (uint32_t h = pf_key_hash(k);; h = (h + 1) & (PF_SLOTS - 1)) {
-          const uint32_t j = s_pslot[h];
-          if (j == 0xFFFFFFFFu) break;
-          if (s_pkey[j] == k) { if (!s_pdup[j] && s_pq[j] == T[t].qperiod) s_idx[t] = (int)j; break; }
-        }
-      }
-      __syncthreads();
-    }
-  }
+  const bool par = parent_index_build(a, it, np, T, S);
   uint32_t dropped = 0;
   for (uint32_t k = t; k < np; k += blockDim.x) {
     const demi_dpor_pair p = P[k];
-    if (par) {
-      const int ie = s_idx[p.earlier], il = s_idx[p.later], ib = s_idx[p.branch];
-      if (ie >= 0 && il >= 0 && ie < il && ib >= (int)p.branch) {             // the parent applied it
-        a.pair_slot_of[(size_t)it * a.max_pairs + k] = 0xFFFFFFFFu;
-        dropped++;
-        continue;
-      }
+    if (par && parent_applied(S, p)) {
+      a.pair_slot_of[(size_t)it * a.max_pairs + k] = 0xFFFFFFFFu;
+      dropped++;
+      continue;
     }
     const uint64_t ke = T[p.earlier].key, kl = T[p.later].key;
     const uint32_t s1 = pair_slot(a.table, a.mask, ke, kl);                // (earlier, later); its flip is the other side
@@ -235,11 +246,11 @@ __global__ __launch_bounds__(256) void k3_pairs_insert(const K3PairArgs a) {
   if (t == 0 && !a.kills && np) atomicAdd(&a.counters[1], (unsigned long long)np);     // (device-queue rounds: counters[1] = pairs reported)
   if (a.world <= 1 && par) {               // (par is uniform over the workgroup)
     __syncthreads();                       // (every thread is done reading the index table: its first word collects the count)
-    if (t == 0) s_idx[0] = 0;
+    if (t == 0) S.idx[0] = 0;
     __syncthreads();
-    if (dropped) atomicAdd(reinterpret_cast<uint32_t*>(&s_idx[0]), dropped);
+    if (dropped) atomicAdd(reinterpret_cast<uint32_t*>(&S.idx[0]), dropped);
     __syncthreads();
-    if (t == 0 && s_idx[0]) atomicAdd(&a.counters[3], (unsigned long long)(uint32_t)s_idx[0]);
+    if (t == 0 && S.idx[0]) atomicAdd(&a.counters[3], (unsigned long long)(uint32_t)S.idx[0]);
   }
 }
 
@@ -309,13 +320,18 @@ namespace demi {
 
 // ------------------------------------------------------------------ multi-GPU rounds: racing pairs as records
 // this rank's racing pairs of the round, compacted (any order: the ordinal travels with the record)
+// (what the interleaving's parent provably applied is not a record at all: the parent filter of k3_pairs_insert, here before
+// the pairs cost an all-gather - every rank holds every trace and every `complete` flag, both gathered in place)
 __global__ __launch_bounds__(256) void k3_pairs_records(const K3PairArgs a) {
+  __shared__ ParentIndex S;
   const uint32_t it = blockIdx.x;
   const demi_dpor_trace_entry* T = a.arena + (size_t)(a.base_id + it) * DEMI_DPOR_MAX_TRACE;
   const demi_dpor_pair* P = a.pairs + (size_t)it * a.max_pairs;
   const uint32_t np = a.n_pairs[it];
+  const bool par = parent_index_build(a, it, np, T, S);
   for (uint32_t k = threadIdx.x; k < np; k += blockDim.x) {
     const demi_dpor_pair p = P[k];
+    if (par && parent_applied(S, p)) continue;
     const unsigned long long q = atomicAdd(&a.counters[3], 1ull);
     if (q >= a.recs_cap) continue;
     DporPairRec r;
