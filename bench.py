@@ -45,7 +45,7 @@ N_PER_GPU = 1 << 20           # "1M random interleavings on 1 MI355X"
 VIOL_CAP = 1 << 16            # found-violation list capacity per rank and step
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
 PREWARM_S = 1.5               # untimed launches before the warmup steps: the shader clock ramps over ~1 s (DVFS)
-K1_COUNTERS = os.path.join(ROOT, "profiles", "k1_counters.json")   # rocprofv3 --pmc passes of this workload (tools/profile_k1.sh)
+K1_COUNTERS = os.path.join(ROOT, "profiles", "k1_counters.json")   # rocprofv3 --pmc passes of this workload (tools/profile_r5.sh)
 
 
 def roofline(bound_bytes, kernel_ms, traffic, kernel, note, extra=None):
@@ -118,7 +118,7 @@ def bench_dpor(ctx_device, cpu_baseline=True, batch=16384, orders=("rounds", "re
     # backtrack points out), with the MEASURED mean prefix length and r = backtrack points enqueued / interleavings.  What the
     # kernels additionally move inside HBM (finished traces into the arena and back into the pair kernels, racing pairs, one
     # 64-byte explored-pair entry per pair) is working-set traffic, reported beside it as a model and, when a counters profile of
-    # this workload exists (tools/profile_r3.sh dpor passes), as measured `traffic` - never as algorithmic bytes.
+    # this workload exists (tools/profile_r5_k2k3.sh), as measured `traffic` - never as algorithmic bytes.
     n_il = r["interleavings"]
     per_il = 4.0 * r["mean_prefix_len"] + 8.0 + 12.0 * (r["backtrack_points"] / max(1, n_il))
     alg = n_il * per_il

@@ -1,4 +1,4 @@
-// k_probe.hpp — measurement helpers behind demi_device_probe / demi_calib_rw (bench.py, tools/profile_k1.sh).
+// k_probe.hpp — measurement helpers behind demi_device_probe / demi_calib_rw (bench.py, tools/profile_r5.sh).
 // Not on the product path: they exist so that the bench line's clock and issue-rate figures are measured on the box
 // the line is printed on, and so that the rocprofv3 FETCH_SIZE / WRITE_SIZE counters can be calibrated against a known
 // byte count in K1's own access pattern (4 B per lane, one 256-byte row per wave and slot).

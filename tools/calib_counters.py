@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Known-byte-count kernels for calibrating rocprofv3's FETCH_SIZE / WRITE_SIZE (run under rocprofv3 --pmc by
-tools/profile_r2.sh): four dispatches of demi::k_calib_rw in this order - write 4 B/lane, read 4 B/lane, write 16 B/lane,
+tools/profile_r5.sh): four dispatches of demi::k_calib_rw in this order - write 4 B/lane, read 4 B/lane, write 16 B/lane,
 read 16 B/lane - over BYTES each (1 GiB: four times the Infinity Cache, so reads come from HBM)."""
 import os
 import sys
