@@ -1298,6 +1298,48 @@ int explore_rounds_devqueue(Dev&& dev, const demi_dpor_search* srch, demi_verdic
 //     records (keys + indices), in pair order.
 // Committed sequence, verdicts, prefix lengths, first violation: those of batch = 1 (tests: the CPU harness restates the
 // device rules sequentially under this same loop; the GPU suite holds config 3 against the committed golden sequence).
+// 64-bit key -> V, open addressing over indices into a deque of values: an insertion allocates nothing per element and the
+// values keep their addresses (the commit holds pointers to results across insertions).  Key 0 is the empty slot.
+template <class V>
+class FlatKeyMap {
+ public:
+  FlatKeyMap() { slots_.assign(1u << 12, Slot{0, 0}); mask_ = slots_.size() - 1; }
+  V* find(uint64_t key) {
+    for (size_t i = hash(key) & mask_;; i = (i + 1) & mask_) {
+      const Slot& s = slots_[i];
+      if (s.key == key) return &vals_[s.idx];
+      if (s.key == 0) return nullptr;
+    }
+  }
+  bool count(uint64_t key) { return find(key) != nullptr; }
+  // the value of `key`, default-constructed first if absent
+  V& at(uint64_t key) {
+    if ((vals_.size() + 1) * 2 > slots_.size()) grow();
+    for (size_t i = hash(key) & mask_;; i = (i + 1) & mask_) {
+      Slot& s = slots_[i];
+      if (s.key == key) return vals_[s.idx];
+      if (s.key == 0) { s.key = key; s.idx = (uint32_t)vals_.size(); vals_.emplace_back(); return vals_.back(); }
+    }
+  }
+  void prefetch(uint64_t key) const { __builtin_prefetch(&slots_[hash(key) & mask_]); }
+  size_t size() const { return vals_.size(); }
+
+ private:
+  struct Slot { uint64_t key; uint32_t idx; };
+  static size_t hash(uint64_t k) { k *= 0x9E3779B97F4A7C15ULL; return (size_t)(k ^ (k >> 29)); }
+  void grow() {
+    std::vector<Slot> old;
+    old.swap(slots_);
+    slots_.assign(old.size() * 2, Slot{0, 0});
+    mask_ = slots_.size() - 1;
+    for (const Slot& o : old)
+      if (o.key) { size_t i = hash(o.key) & mask_; while (slots_[i].key) i = (i + 1) & mask_; slots_[i] = o; }
+  }
+  std::vector<Slot> slots_;
+  size_t mask_ = 0;
+  std::deque<V> vals_;
+};
+
 struct RefRec {              // one racing pair the commit still has to absorb (device -> host), 24 bytes
   unsigned long long ke, kl;
   uint8_t branch, later, earlier, pad;
@@ -1424,7 +1466,7 @@ int explore_reference_resident(Dev&& dev, const demi_dpor_search* srch, demi_ver
   };
   // fetched: its records have been ASKED for (a fetch names it); ready: they are here (nothing to fetch: both from the start)
   struct Result { uint32_t id; demi_verdict verdict; const RefRec* recs; uint32_t rec_cnt; bool fetched, ready; };
-  std::unordered_map<uint64_t, Result> results;          // every interleaving run so far, by its item; its surviving racing
+  FlatKeyMap<Result> results;                            // every interleaving run so far, by its item; its surviving racing
                                                          // pairs stay where the device's copy put them (dev owns that memory)
   std::vector<uint8_t> complete;                         // per arena id: invariant (I) of ParentFilter holds (see there)
   RefBook real;
@@ -1462,10 +1504,10 @@ int explore_reference_resident(Dev&& dev, const demi_dpor_search* srch, demi_ver
     double t0 = now();
     bool need_fetch = false;
     while (have_cur) {
-      auto it = results.find(key_of(cur));
-      if (it == results.end()) break;
-      if (!it->second.ready) { need_fetch = true; break; }
-      const Result& r = it->second;
+      const Result* it = results.find(key_of(cur));
+      if (!it) break;
+      if (!it->ready) { need_fetch = true; break; }
+      const Result& r = *it;
       const uint64_t idx = stats->interleavings++;
       out_verdicts[idx] = r.verdict;
       out_prefix_len[idx] = cur.src == 0xFFFFFFFFu ? 0u : (uint32_t)cur.later;
@@ -1494,16 +1536,16 @@ int explore_reference_resident(Dev&& dev, const demi_dpor_search* srch, demi_ver
     auto issue = [&](bool with_cur) -> int {
       fetch_ids.clear(); fetch_res.clear();
       if (with_cur) {
-        Result* r0 = &results.find(key_of(cur))->second;       // (std::unordered_map: element addresses survive insertions)
+        Result* r0 = results.find(key_of(cur));                // (FlatKeyMap: element addresses survive insertions)
         r0->fetched = true;
         fetch_ids.push_back(r0->id); fetch_res.push_back(r0);
       }
       // (with_cur: the window at the queue's front; else the window behind it - the front one has been asked for already)
       real.peek(with_cur ? fetch_width : 2 * fetch_width, [&](const RefBook::Point& p) {
-        auto it = results.find(key_of(demi::DporItem{p.src, p.branch, p.later, p.earlier, 0}));
-        if (it == results.end() || it->second.fetched) return;
-        it->second.fetched = true;
-        fetch_ids.push_back(it->second.id); fetch_res.push_back(&it->second);
+        Result* it = results.find(key_of(demi::DporItem{p.src, p.branch, p.later, p.earlier, 0}));
+        if (!it || it->fetched) return;
+        it->fetched = true;
+        fetch_ids.push_back(it->id); fetch_res.push_back(it);
       });
       if (fetch_ids.empty()) return 0;
       real.take_deltas(deltas);
@@ -1529,7 +1571,7 @@ int explore_reference_resident(Dev&& dev, const demi_dpor_search* srch, demi_ver
       // ---- the records of the interleaving the commit stands at: in the fetch that is in flight (the usual case), or asked for now
       int rc = land();
       if (rc) return rc;
-      const Result& r0 = results.find(key_of(cur))->second;
+      const Result& r0 = *results.find(key_of(cur));
       if (!r0.ready) {
         rc = issue(!r0.fetched);
         if (!rc) rc = land();
@@ -1547,7 +1589,8 @@ int explore_reference_resident(Dev&& dev, const demi_dpor_search* srch, demi_ver
     items.clear();
     items.push_back(cur);
     {
-      std::unordered_set<uint64_t> in_launch;
+      FlatKeyMap<uint8_t> in_launch_map;
+      struct { FlatKeyMap<uint8_t>& m; struct R { bool second; }; R insert(uint64_t k) { const size_t n0 = m.size(); m.at(k); return R{m.size() != n0}; } } in_launch{in_launch_map};
       in_launch.insert(key_of(cur));
       // the commit's own queue front: what it will most likely dequeue next (the speculation below explores in rounds and
       // runs out long before the commit does; without this every later interleaving would be a launch of its own)
@@ -1578,7 +1621,7 @@ int explore_reference_resident(Dev&& dev, const demi_dpor_search* srch, demi_ver
     double t2 = now();
     if (complete.size() < (size_t)base_id + n) complete.resize((size_t)base_id + n, 0);
     for (uint32_t i = 0; i < n; i++) {
-      results[key_of(items[i])] = Result{base_id + i, vd[i], nullptr, 0u, rec_cnt[i] == 0, rec_cnt[i] == 0};   // (nothing to fetch: as good as here)
+      results.at(key_of(items[i])) = Result{base_id + i, vd[i], nullptr, 0u, rec_cnt[i] == 0, rec_cnt[i] == 0};   // (nothing to fetch: as good as here)
       // (I) holds for this interleaving once it is absorbed iff its own pair list is whole and (I) held for its parent
       complete[(size_t)base_id + i] = !(vd[i].flags & DEMI_V_PAIRS_OVF) && (items[i].src == 0xFFFFFFFFu || use_parent[i]);
     }
