@@ -64,7 +64,37 @@ struct K3Args {
   const DporItem* items;             // [n] or null (then prefixes / prefix_len / shared_len are used)
   const demi_dpor_trace_entry* arena;
   unsigned long long* phase_out;     // -DDEMI_K3_PHASES builds only (tools/k3_phases.sh): [waves][16] cycle totals per phase
+  // checkpointed interleavings (round 5; `items` launches of one rank; snap == nullptr: off).  See K3Snap below.
+  unsigned char* snap;               // [snap_ids][K3_SNAP_SLOTS] records of snap_stride bytes
+  uint32_t* snap_owner;              // [snap_ids][16]: which interleaving's record holds the state after c = 16 (k + 1) events of this trace
+  uint32_t snap_stride, snap_pend_cap, snap_ids;
+  uint32_t first_id;                 // arena id of interleaving 0 of this launch (traces = arena + first_id rows)
 };
+
+// Checkpointed interleavings.  The next trace of a child C is its parent's trace up to the branch point, then the events to
+// replay (DPORwHeuristics.scala:1054-1057, 1180): C used to re-execute the shared part - 83 of 250 deliveries on average for
+// config 5, 60 of 190 for config 3 - only to arrive at the state its parent P had been in at that point.  An interleaving now
+// leaves a RECORD of its state every 16 trace entries - everything a scheduling step reads: the scalars of the scheduler, the
+// actors' states, the pending set with side words and node keys - and a child starts from the deepest record at or below its
+// branch point, copying the trace entries in front of it from P's row of the arena.
+// What makes that exact: a prefix head that is matched (getMatchingMessage, :474-537) picks the message the original divergent
+// step picked (getPendingEvent, :452-472) - same slot, same swap-remove - so C's state after replaying entries [0, c) IS P's
+// state when it had pushed c entries, as long as P's steps up to there were all deliveries or quiescence markers.  The one step
+// that leaves no trace entry is the discard of a message to or from an isolated actor (:626-635): P removes it from the pending
+// set when it is picked, C - matching prefix heads - never picks it.  An interleaving stops leaving records at its first such
+// step (`asym`), and no record is taken between choosing a quiescence marker and pushing it.  Records P did not make itself -
+// those below the point where P started from ITS parent's record - are found through an owner table (16 arena ids per
+// interleaving, inherited at the start).  Same traces, verdicts and racing pairs (tests run both ways: DEMI_K3_NO_CHECKPOINT).
+constexpr uint32_t K3_SNAP_SLOTS = 15, K3_SNAP_EVERY = 16, K3_SNAP_NONE = 0xFFFFFFFFu, K3_SNAP_MAGIC = 0x4B335350u;
+struct K3SnapHdr {                   // 96 bytes; the actors' states and the pending entries follow
+  unsigned long long hash, app_rng, parent_key;
+  uint32_t magic, c, n_pend, flags, next_seq, count, deliveries, ext_idx, parent, parent_depth, cur_root, qperiod, next_qperiod,
+      marker_ext, qmarker_ext, isolated, rep, blocked;
+};
+__host__ __device__ inline uint32_t k3_snap_pend_bytes(bool wide) { return wide ? 24u : 16u; }       // key 8, word 4 | 8, side word 4 (+ 4 pad)
+__host__ __device__ inline uint32_t k3_snap_stride(uint32_t n_actors, uint32_t st_words, uint32_t pend_cap, bool wide) {
+  return (uint32_t)((sizeof(K3SnapHdr) + 8u * n_actors * st_words + pend_cap * k3_snap_pend_bytes(wide) + 63u) & ~63u);
+}
 
 constexpr int K3_WAVES = 4;
 constexpr size_t K3_ANALYSIS_BYTES = DEMI_DPOR_MAX_TRACE * 4 + DEMI_DPOR_MAX_TRACE * 32;   // meta words + ancestor sets
@@ -240,6 +270,10 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
   bool awaiting = false, marker_pending = false;
   uint64_t b_next = 0, b_end = 0;
   bool exhausted = false;
+  // checkpoints: this interleaving's arena id, the trace length of its last record, "a step left no trace entry"
+  const bool snap_on = args.snap != nullptr && args.items != nullptr;
+  uint32_t my_id = 0, last_snap_c = 0;
+  bool asym = false;
 
 #ifdef DEMI_K3_PHASES
   uint64_t ph_t[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ph_iters = 0, ph_active = 0;
@@ -363,6 +397,53 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
           pf = args.prefixes + sched * (uint64_t)args.stride;
           pfx_len = args.prefix_len[sched];
         }
+        // ---- start from a record of the parent's (or of an ancestor's) state, if there is one at or below the branch point
+        const unsigned char* rec = nullptr;
+        asym = false; last_snap_c = 0;
+        if (snap_on) {
+          my_id = args.first_id + (uint32_t)sched;
+          const DporItem it = args.items[sched];
+          uint32_t* const mine = my_id < args.snap_ids ? args.snap_owner + (size_t)my_id * 16 : nullptr;
+          uint32_t have = 0;                       // records 0 .. have - 1 of the parent are at or below the branch point
+          const uint32_t* theirs = nullptr;
+          if (it.src != 0xFFFFFFFFu && it.src < args.snap_ids) {
+            theirs = args.snap_owner + (size_t)it.src * 16;
+            have = ((uint32_t)it.branch + 1u) / K3_SNAP_EVERY;
+            if (have > K3_SNAP_SLOTS) have = K3_SNAP_SLOTS;
+          }
+          uint32_t use = 0;                        // the deepest of them that exists: record use - 1
+          for (uint32_t k = have; k > 0 && !use; k--) if (theirs[k - 1] != K3_SNAP_NONE) use = k;
+          if (mine) for (uint32_t k = 0; k < 16; k++) mine[k] = (k < use) ? theirs[k] : (k == 15 ? 0u : K3_SNAP_NONE);      // ([15]: statistics)
+          if (use) {
+            const uint32_t owner = theirs[use - 1];
+            rec = args.snap + ((size_t)owner * K3_SNAP_SLOTS + (use - 1)) * args.snap_stride;
+            if (reinterpret_cast<const K3SnapHdr*>(rec)->magic != K3_SNAP_MAGIC || reinterpret_cast<const K3SnapHdr*>(rec)->c != use * K3_SNAP_EVERY) rec = nullptr;
+          }
+        }
+        if (rec) {
+          const K3SnapHdr h = *reinterpret_cast<const K3SnapHdr*>(rec);
+          hash = h.hash; app_rng = h.app_rng; parent_key = h.parent_key;
+          n_pend = h.n_pend; flags = h.flags; next_seq = h.next_seq; count = h.count; deliveries = h.deliveries; ext_idx = h.ext_idx;
+          parent = h.parent; parent_depth = h.parent_depth; cur_root = h.cur_root; qperiod = h.qperiod; next_qperiod = h.next_qperiod;
+          marker_ext = h.marker_ext & 0xFFFFu; marker_pending = (h.marker_ext >> 16) != 0; qmarker_ext = h.qmarker_ext;
+          isolated = h.isolated; rep = h.rep; blocked = h.blocked;
+          awaiting = false;
+          const unsigned long long* sw = reinterpret_cast<const unsigned long long*>(rec + sizeof(K3SnapHdr));
+          for (uint32_t a = 0; a < A * ST_WORDS; a++) st[a * 64] = sw[a];
+          const unsigned char* pe = rec + sizeof(K3SnapHdr) + 8u * A * ST_WORDS;
+          for (uint32_t k = 0; k < n_pend; k++, pe += k3_snap_pend_bytes(WIDE_TU)) {
+            const unsigned long long key = *reinterpret_cast<const unsigned long long*>(pe);
+            const word_t word = *reinterpret_cast<const word_t*>(pe + 8);
+            const uint32_t side = *reinterpret_cast<const uint32_t*>(pe + 8 + sizeof(word_t));
+            if (k < PEND_HOT) { mem.pend[k * 64] = word; mem.pend_aux[k * 64] = side; kp[k * 64] = key; }
+            else { pend_store(mem, k, word); aux_store(mem, k, side); }
+          }
+          if (my_id < args.snap_ids) args.snap_owner[(size_t)my_id * 16 + 15] = h.c;      // (statistics: the entries this interleaving did not execute)
+          n_trace = h.c;                            // the trace in front of the record: the parent's entries (they are below the branch point)
+          for (uint32_t i = 0; i < n_trace; i++) tr[i] = pf[i];
+          pfx = n_trace;                            // ... and as many prefix positions are consumed
+          last_snap_c = n_trace;
+        } else {
         pfx = 0;
         hash = 0xCBF29CE484222325ULL;
         app_rng = jr_seed(0);
@@ -373,7 +454,35 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
         trace_push(DPOR_ROOT_KEY, 0, 0, 0, 0);   // currentTrace += getRootEvent (:336-343)
         parent = 0; parent_depth = 0; cur_root = 0; parent_key = DPOR_ROOT_KEY;
         run_external();
+        }
         K3_MARK(1);
+      }
+      // ---- leave a record of this state (see K3Snap above): the first scheduling step at a multiple of 16 trace entries
+      if (snap_on && !asym && !awaiting && !(flags & K3_ABORT) && n_trace != last_snap_c && n_trace >= K3_SNAP_EVERY &&
+          (n_trace & (K3_SNAP_EVERY - 1)) == 0 && n_trace <= K3_SNAP_EVERY * K3_SNAP_SLOTS && my_id < args.snap_ids) {
+        last_snap_c = n_trace;
+        if (n_pend <= args.snap_pend_cap) {
+          const uint32_t slot = n_trace / K3_SNAP_EVERY - 1;
+          unsigned char* rec = args.snap + ((size_t)my_id * K3_SNAP_SLOTS + slot) * args.snap_stride;
+          K3SnapHdr h;
+          h.hash = hash; h.app_rng = app_rng; h.parent_key = parent_key;
+          h.magic = K3_SNAP_MAGIC; h.c = n_trace; h.n_pend = n_pend; h.flags = flags; h.next_seq = next_seq; h.count = count;
+          h.deliveries = deliveries; h.ext_idx = ext_idx; h.parent = parent; h.parent_depth = parent_depth; h.cur_root = cur_root;
+          h.qperiod = qperiod; h.next_qperiod = next_qperiod; h.marker_ext = marker_ext | (marker_pending ? 1u << 16 : 0u);
+          h.qmarker_ext = qmarker_ext; h.isolated = isolated; h.rep = rep; h.blocked = blocked;
+          *reinterpret_cast<K3SnapHdr*>(rec) = h;
+          unsigned long long* sw = reinterpret_cast<unsigned long long*>(rec + sizeof(K3SnapHdr));
+          for (uint32_t a = 0; a < A * ST_WORDS; a++) sw[a] = st[a * 64];
+          unsigned char* pe = rec + sizeof(K3SnapHdr) + 8u * A * ST_WORDS;
+          for (uint32_t k = 0; k < n_pend; k++, pe += k3_snap_pend_bytes(WIDE_TU)) {
+            const word_t word = pend_load(mem, k);
+            const uint32_t side = aux_load(mem, k);
+            *reinterpret_cast<unsigned long long*>(pe) = key_at(k, word, side);
+            *reinterpret_cast<word_t*>(pe + 8) = word;
+            *reinterpret_cast<uint32_t*>(pe + 8 + sizeof(word_t)) = side;
+          }
+          args.snap_owner[(size_t)my_id * 16 + slot] = my_id;
+        }
       }
       if (flags & K3_ABORT) {
         finish = true;
@@ -479,6 +588,7 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
           if ((snd < DEMI_MAX_ACTORS && ((isolated >> snd) & 1)) || ((isolated >> rcv) & 1)) {
             if (snd == rcv) { flags |= DEMI_V_SELFMSG; finish = true; }   // (:631-633)
             // else: discarded, schedule again (:626-635)
+            asym = true;                        // (a step without a trace entry: no records of this interleaving from here on)
           } else {
             const uint32_t par = aux & 0xFF;
             const int ti = trace_push(key, pw, par, (aux >> 8) & 0xFF, 1, chosen_depth);
