@@ -567,3 +567,63 @@ def test_device_queue_and_parent_filter_leave_the_exploration_unchanged(monkeypa
     # what no longer crosses PCIe: the host queue is fed 40-byte points and 16-byte kills, the device queue 256 run lengths per round
     assert d[4].d2h_bytes < runs["host_queue"][4].d2h_bytes
     ctx.close()
+
+
+@pytest.mark.parametrize("case", ["late_start_two_periods", "two_periods", "writers", "config3", "config5"])
+def test_checkpointed_interleavings_are_the_same_interleavings(oracle, monkeypatch, case):
+    """k3_dpor starts an interleaving from a record of its parent's state at or below the branch point (K3Snap) instead of
+    re-executing the shared prefix.  Against the same exploration without records (DEMI_K3_NO_CHECKPOINT) and against the CPU
+    oracle's exploration: every verdict (the hash covers every delivery and every final state), every next-trace length, the
+    queue; and the traces left in the arena entry by entry.  `late_start_two_periods` has actors that are started in a later
+    quiescent period - messages to them are discarded without a trace entry, the step after which an interleaving must stop
+    leaving records (so early here that the case runs without any) - and a quiescence marker in the middle of the trace;
+    `two_periods` has the marker and no isolated actor: records on both sides of it."""
+    import os
+    from demi_amd import _native
+    from demi_amd.apps import shuffle8_config5_large
+    from tests.test_dpor_cpu import writers_model
+    emu = os.environ.get("DEMI_EMU") == "1"
+    if case == "late_start_two_periods":
+        model, depth = M.raft_model(3), 40
+        ev = events_to_array([start(0), start(1), send(0, M.M_BOOTSTRAP), send(1, M.M_BOOTSTRAP), wait_quiescence(), start(2),
+                              send(2, M.M_BOOTSTRAP), send(0, M.M_BOOTSTRAP)])
+        budget, batch = (1500, 128) if emu else (20000, 1024)
+    elif case == "two_periods":
+        model, depth = M.raft_model(3), 36
+        ev = events_to_array([start(a) for a in range(3)] + [send(0, M.M_BOOTSTRAP), wait_quiescence(), send(1, M.M_BOOTSTRAP), send(2, M.M_BOOTSTRAP)])
+        budget, batch = (1500, 128) if emu else (20000, 1024)
+    elif case == "writers":
+        model, depth = writers_model(4), 0
+        ev = events_to_array([start(a) for a in range(5)] + [send(a, 0) for a in range(1, 5)])
+        budget, batch = (2500, 128) if emu else (20000, 512)
+    elif case == "config3":
+        model, ev, depth = raft5_config3()
+        budget, batch = (1500, 256) if emu else (1 << 17, 16384)
+    else:
+        model, ev, depth, _b = shuffle8_config5_large()
+        budget, batch = (1200, 256) if emu else (60000, 16384)
+    par, srch = T.DporParams(depth, 0, 0, 0, 64, 4096), T.DporSearch(batch, budget, 0, 1, T.DPOR_ORDER_ROUNDS)
+    ctx = _native.Context(0)
+    ctx.model_load(model.to_struct())
+    ctx.model_specialize()
+    ctx.dpor_load(ev)
+    monkeypatch.delenv("DEMI_K3_NO_CHECKPOINT", raising=False)
+    with_records = ctx.dpor_explore(par, srch)
+    n = len(with_records[0])
+    rng = np.random.default_rng(3)
+    probe = sorted(set([0, n - 1] + [int(x) for x in rng.integers(0, n, 40)]))
+    traces = [ctx.dpor_explored(i) for i in probe]
+    monkeypatch.setenv("DEMI_K3_NO_CHECKPOINT", "1")
+    without = ctx.dpor_explore(par, srch)
+    plain = [ctx.dpor_explored(i) for i in probe]
+    monkeypatch.delenv("DEMI_K3_NO_CHECKPOINT")
+    assert len(without[0]) == n and (with_records[0] == without[0]).all() and (with_records[1] == without[1]).all()
+    assert (with_records[2] == without[2]).all() and with_records[4].queue_len == without[4].queue_len
+    assert with_records[4].exhausted == without[4].exhausted and with_records[4].backtrack_points == without[4].backtrack_points
+    for (nt_a, sh_a, tr_a), (nt_b, sh_b, tr_b) in zip(traces, plain):
+        assert sh_a == sh_b and len(nt_a) == len(nt_b) and (nt_a == nt_b).all() and len(tr_a) == len(tr_b) and (tr_a == tr_b).all()
+    # ... and the oracle's exploration (its interleavings run from scratch, by construction)
+    cpu = oracle.dpor_explore(model, ev, par, T.DporSearch(batch, min(budget, 6000 if not emu else budget), 0, 1, T.DPOR_ORDER_ROUNDS), n_threads=os.cpu_count() or 1)
+    m = len(cpu[0])
+    assert (cpu[0] == with_records[0][:m]).all() and (cpu[1] == with_records[1][:m]).all()
+    ctx.close()
