@@ -144,22 +144,24 @@ __global__ __launch_bounds__(256) void k3_pairs_mark(const K3PairArgs a) {
 // carries a queued mark above C's branch) and, being unable to win, cannot displace an instance that could: a no-op.  The rule
 // needs invariant (I) for P (every racing pair of P applied with a branch at least as deep): `complete`, kept per arena id -
 // false once a pair list was truncated (DEMI_V_PAIRS_OVF) anywhere up the chain of parents; nothing is dropped then.
-constexpr uint32_t PF_SLOTS = 1024;       // > 2 x DEMI_DPOR_MAX_TRACE
-__device__ __forceinline__ uint32_t pf_key_hash(uint64_t k) { return (uint32_t)((k * 0x9E3779B97F4A7C15ULL) >> 54) & (PF_SLOTS - 1); }
+constexpr uint32_t PF_SLOTS = 512;        // 2 x DEMI_DPOR_MAX_TRACE (a trace has at most 256 distinct keys)
+__device__ __forceinline__ uint32_t pf_key_hash(uint64_t k) { return (uint32_t)((k * 0x9E3779B97F4A7C15ULL) >> 55) & (PF_SLOTS - 1); }
 
-// the LDS a workgroup needs for the filter, and its construction: s_idx[i] = where event i of this interleaving sits in its parent
-// (same key, unique on both sides, same quiescent period), or -1.  Returns whether the filter applies (uniform over the workgroup).
+// the LDS a workgroup needs for the filter (9.5 KB), and its construction: idx[i] = where event i of this interleaving sits in its
+// parent (same key, unique on both sides, same quiescent period), or -1.  Returns whether the filter applies (uniform over the
+// workgroup).  Written for any workgroup size: the insert / records kernels run ONE WAVE per interleaving - the work of an
+// interleaving is a chain of dependent loads (item, parent's flags and length, the two traces' keys, the pairs, the table), and
+// what hides that latency is the number of interleavings in flight on a CU, which the LDS per workgroup bounds.
 struct ParentIndex {
   unsigned long long pkey[DEMI_DPOR_MAX_TRACE], okey[DEMI_DPOR_MAX_TRACE];
   uint32_t pslot[PF_SLOTS], oslot[PF_SLOTS];      // 0xFFFFFFFF = empty, else an event index
-  uint32_t pdup[DEMI_DPOR_MAX_TRACE], odup[DEMI_DPOR_MAX_TRACE];
-  int idx[DEMI_DPOR_MAX_TRACE];
-  uint8_t pq[DEMI_DPOR_MAX_TRACE];
+  short idx[DEMI_DPOR_MAX_TRACE];
+  uint8_t pdup[DEMI_DPOR_MAX_TRACE], odup[DEMI_DPOR_MAX_TRACE], pq[DEMI_DPOR_MAX_TRACE];
 };
 // it: the interleaving's index within a.pairs / a.n_pairs / a.verdicts (this rank's block); arena id a.base_id + it; its
 // backtrack point a.items[a.item_base + it].  Also records `complete` for the interleaving (thread 0).
 __device__ inline bool parent_index_build(const K3PairArgs& a, uint32_t it, uint32_t np, const demi_dpor_trace_entry* T, ParentIndex& S) {
-  const uint32_t t = threadIdx.x;
+  const uint32_t t = threadIdx.x, nt = blockDim.x;
   if (!a.complete) return false;
   const DporItem item = a.items[a.item_base + it];
   const bool par = item.src != 0xFFFFFFFFu && a.complete[item.src] != 0;
@@ -168,36 +170,37 @@ __device__ inline bool parent_index_build(const K3PairArgs& a, uint32_t it, uint
   const uint32_t n_tr = min(a.arena_len[a.base_id + it], (uint32_t)DEMI_DPOR_MAX_TRACE);
   const demi_dpor_trace_entry* TP = a.arena + (size_t)item.src * DEMI_DPOR_MAX_TRACE;
   const uint32_t n_par = min(a.arena_len[item.src], (uint32_t)DEMI_DPOR_MAX_TRACE);
-  for (uint32_t i = t; i < PF_SLOTS; i += blockDim.x) { S.pslot[i] = 0xFFFFFFFFu; S.oslot[i] = 0xFFFFFFFFu; }
-  if (t < DEMI_DPOR_MAX_TRACE) {
-    S.pdup[t] = 0; S.odup[t] = 0; S.idx[t] = -1;
-    if (t < n_par) { S.pkey[t] = TP[t].key; S.pq[t] = TP[t].qperiod; }
-    if (t < n_tr) S.okey[t] = T[t].key;
+  for (uint32_t i = t; i < PF_SLOTS; i += nt) { S.pslot[i] = 0xFFFFFFFFu; S.oslot[i] = 0xFFFFFFFFu; }
+  for (uint32_t i = t; i < DEMI_DPOR_MAX_TRACE; i += nt) {
+    S.pdup[i] = 0; S.odup[i] = 0; S.idx[i] = -1;
+    if (i < n_par) { S.pkey[i] = TP[i].key; S.pq[i] = TP[i].qperiod; }
+    if (i < n_tr) S.okey[i] = T[i].key;
   }
   __syncthreads();
-  if (t < n_par) {                       // equal keys mark each other as duplicates (collapsed siblings)
-    const unsigned long long k = S.pkey[t];
+  for (uint32_t i = t; i < n_par; i += nt) {       // equal keys mark each other as duplicates (collapsed siblings)
+    const unsigned long long k = S.pkey[i];
     for (uint32_t h = pf_key_hash(k);; h = (h + 1) & (PF_SLOTS - 1)) {
-      const uint32_t old = atomicCAS(&S.pslot[h], 0xFFFFFFFFu, t);
+      const uint32_t old = atomicCAS(&S.pslot[h], 0xFFFFFFFFu, i);
       if (old == 0xFFFFFFFFu) break;
-      if (S.pkey[old] == k) { S.pdup[old] = 1; S.pdup[t] = 1; break; }
+      if (S.pkey[old] == k) { S.pdup[old] = 1; S.pdup[i] = 1; break; }
     }
   }
-  if (t < n_tr) {
-    const unsigned long long k = S.okey[t];
+  for (uint32_t i = t; i < n_tr; i += nt) {
+    const unsigned long long k = S.okey[i];
     for (uint32_t h = pf_key_hash(k);; h = (h + 1) & (PF_SLOTS - 1)) {
-      const uint32_t old = atomicCAS(&S.oslot[h], 0xFFFFFFFFu, t);
+      const uint32_t old = atomicCAS(&S.oslot[h], 0xFFFFFFFFu, i);
       if (old == 0xFFFFFFFFu) break;
-      if (S.okey[old] == k) { S.odup[old] = 1; S.odup[t] = 1; break; }
+      if (S.okey[old] == k) { S.odup[old] = 1; S.odup[i] = 1; break; }
     }
   }
   __syncthreads();
-  if (t < n_tr && !S.odup[t]) {          // same key, unique on both sides, same quiescent period
-    const unsigned long long k = S.okey[t];
+  for (uint32_t i = t; i < n_tr; i += nt) {        // same key, unique on both sides, same quiescent period
+    if (S.odup[i]) continue;
+    const unsigned long long k = S.okey[i];
     for (uint32_t h = pf_key_hash(k);; h = (h + 1) & (PF_SLOTS - 1)) {
       const uint32_t j = S.pslot[h];
       if (j == 0xFFFFFFFFu) break;
-      if (S.pkey[j] == k) { if (!S.pdup[j] && S.pq[j] == T[t].qperiod) S.idx[t] = (int)j; break; }
+      if (S.pkey[j] == k) { if (!S.pdup[j] && S.pq[j] == T[i].qperiod) S.idx[i] = (short)j; break; }
     }
   }
   __syncthreads();
@@ -210,6 +213,7 @@ __device__ __forceinline__ bool parent_applied(const ParentIndex& S, const demi_
 
 __global__ __launch_bounds__(256) void k3_pairs_insert(const K3PairArgs a) {
   __shared__ ParentIndex S;
+  __shared__ uint32_t s_drop;
   const uint32_t it = blockIdx.x, t = threadIdx.x;
   const demi_dpor_trace_entry* T = a.arena + (size_t)(a.base_id + it) * DEMI_DPOR_MAX_TRACE;
   const demi_dpor_pair* P = a.pairs + (size_t)it * a.max_pairs;
@@ -245,12 +249,11 @@ __global__ __launch_bounds__(256) void k3_pairs_insert(const K3PairArgs a) {
   // statistics (single-rank rounds: counters[3] is otherwise the sharded rounds' record count): pairs the parent filter dropped
   if (t == 0 && !a.kills && np) atomicAdd(&a.counters[1], (unsigned long long)np);     // (device-queue rounds: counters[1] = pairs reported)
   if (a.world <= 1 && par) {               // (par is uniform over the workgroup)
-    __syncthreads();                       // (every thread is done reading the index table: its first word collects the count)
-    if (t == 0) S.idx[0] = 0;
+    if (t == 0) s_drop = 0;
     __syncthreads();
-    if (dropped) atomicAdd(reinterpret_cast<uint32_t*>(&S.idx[0]), dropped);
+    if (dropped) atomicAdd(&s_drop, dropped);
     __syncthreads();
-    if (t == 0 && S.idx[0]) atomicAdd(&a.counters[3], (unsigned long long)(uint32_t)S.idx[0]);
+    if (t == 0 && s_drop) atomicAdd(&a.counters[3], (unsigned long long)s_drop);
   }
 }
 
