@@ -102,6 +102,10 @@ struct K3PairArgs {
   uint8_t* complete;                   // [ids]: invariant (I) of dpor_host.hpp's ParentFilter holds for that interleaving
   const demi_verdict* verdicts;        // [n] the round's verdicts (DEMI_V_PAIRS_OVF)
   // the device-resident backtrack queue (k3_queue.hpp)
+  // insert -> decide: the pairs that reached the table, compacted per interleaving (any order): surv_k[it][j] = the pair's index,
+  // pair_slot_of[it][j] = the slot of its flipped pair, j < n_surv[it]
+  uint16_t* surv_k;                    // [n][max_pairs]
+  uint32_t* n_surv;                    // [n]
   unsigned long long* keep_bits;       // [n][max_pairs / 64]: decide's verdict per racing pair (bit = its backtrack point is emitted)
   uint32_t* item_points;               // [n]: points emitted per interleaving
 };
@@ -149,9 +153,7 @@ __device__ __forceinline__ uint32_t pf_key_hash(uint64_t k) { return (uint32_t)(
 
 // the LDS a workgroup needs for the filter (9.5 KB), and its construction: idx[i] = where event i of this interleaving sits in its
 // parent (same key, unique on both sides, same quiescent period), or -1.  Returns whether the filter applies (uniform over the
-// workgroup).  Written for any workgroup size: the insert / records kernels run ONE WAVE per interleaving - the work of an
-// interleaving is a chain of dependent loads (item, parent's flags and length, the two traces' keys, the pairs, the table), and
-// what hides that latency is the number of interleavings in flight on a CU, which the LDS per workgroup bounds.
+// workgroup).  Written for any workgroup size (one wave per interleaving was measured: slower, see k3_pair_threads in demi_gpu.hip).
 struct ParentIndex {
   unsigned long long pkey[DEMI_DPOR_MAX_TRACE], okey[DEMI_DPOR_MAX_TRACE];
   uint32_t pslot[PF_SLOTS], oslot[PF_SLOTS];      // 0xFFFFFFFF = empty, else an event index
@@ -213,24 +215,46 @@ __device__ __forceinline__ bool parent_applied(const ParentIndex& S, const demi_
 
 __global__ __launch_bounds__(256) void k3_pairs_insert(const K3PairArgs a) {
   __shared__ ParentIndex S;
-  __shared__ uint32_t s_drop;
-  const uint32_t it = blockIdx.x, t = threadIdx.x;
+  __shared__ uint16_t s_surv[4096];        // the pairs the filter leaves (their indices), in any order
+  __shared__ uint32_t s_n;
+  const uint32_t it = blockIdx.x, t = threadIdx.x, nt = blockDim.x;
   const demi_dpor_trace_entry* T = a.arena + (size_t)(a.base_id + it) * DEMI_DPOR_MAX_TRACE;
   const demi_dpor_pair* P = a.pairs + (size_t)it * a.max_pairs;
-  const uint32_t np = a.n_pairs[it];
+  const uint32_t np = min(a.n_pairs[it], a.max_pairs);
+  if (t == 0) s_n = 0;
   const bool par = parent_index_build(a, it, np, T, S);
-  uint32_t dropped = 0;
-  for (uint32_t k = t; k < np; k += blockDim.x) {
-    const demi_dpor_pair p = P[k];
-    if (par && parent_applied(S, p)) {
-      a.pair_slot_of[(size_t)it * a.max_pairs + k] = 0xFFFFFFFFu;
-      dropped++;
-      continue;
+  __syncthreads();
+  uint32_t done = 0;                        // survivors written so far (max_pairs may exceed the list: 4096 pairs at a time)
+  for (uint32_t c0 = 0; c0 < np; c0 += 4096) {
+  const uint32_t c1 = min(c0 + 4096u, np);
+  // ---- the filter: four pairs per thread and step, their loads issued together (a step is one round trip to HBM, and the
+  // steps of a thread wait for one another)
+  if (par) {
+    for (uint32_t base = c0; base < c1; base += 4 * nt) {
+      demi_dpor_pair p[4];
+#pragma unroll
+      for (uint32_t j = 0; j < 4; j++) { const uint32_t k = base + j * nt + t; if (k < c1) p[j] = P[k]; }
+#pragma unroll
+      for (uint32_t j = 0; j < 4; j++) {
+        const uint32_t k = base + j * nt + t;
+        if (k < c1 && !parent_applied(S, p[j])) s_surv[atomicAdd(&s_n, 1u)] = (uint16_t)(k - c0);
+      }
     }
+  } else {
+    for (uint32_t k = c0 + t; k < c1; k += nt) s_surv[k - c0] = (uint16_t)(k - c0);
+    if (t == 0) s_n = c1 - c0;
+  }
+  __syncthreads();
+  const uint32_t ns = s_n;
+  // ---- the survivors' table entries
+  for (uint32_t j = t; j < ns; j += nt) {
+    const uint32_t k = c0 + s_surv[j];
+    const demi_dpor_pair p = P[k];
     const uint64_t ke = T[p.earlier].key, kl = T[p.later].key;
     const uint32_t s1 = pair_slot(a.table, a.mask, ke, kl);                // (earlier, later); its flip is the other side
     const uint32_t s2 = s1 == 0xFFFFFFFFu ? s1 : (s1 ^ 1u);
-    a.pair_slot_of[(size_t)it * a.max_pairs + k] = s2;
+    a.surv_k[(size_t)it * a.max_pairs + done + j] = (uint16_t)k;
+    a.pair_slot_of[(size_t)it * a.max_pairs + done + j] = s2;
     if (s1 == 0xFFFFFFFFu) { atomicAdd(&a.counters[2], 1ull); continue; }
     // Thousands of interleavings of a round report the same few pairs, and a read-modify-write on one address is serialised
     // where it executes.  Both updates are monotone (the explored bit is only ever set, the candidate only ever raised), so
@@ -246,14 +270,15 @@ __global__ __launch_bounds__(256) void k3_pairs_insert(const K3PairArgs a) {
     const unsigned long long mine = cand_pack(a.round, p.branch, (unsigned long long)it * a.max_pairs + k);
     if (e1->cand[(s2 & 1)] < mine) atomicMax(&e1->cand[s2 & 1], mine);   // (s2 is the other side of the same entry)
   }
-  // statistics (single-rank rounds: counters[3] is otherwise the sharded rounds' record count): pairs the parent filter dropped
-  if (t == 0 && !a.kills && np) atomicAdd(&a.counters[1], (unsigned long long)np);     // (device-queue rounds: counters[1] = pairs reported)
-  if (a.world <= 1 && par) {               // (par is uniform over the workgroup)
-    if (t == 0) s_drop = 0;
-    __syncthreads();
-    if (dropped) atomicAdd(&s_drop, dropped);
-    __syncthreads();
-    if (t == 0 && s_drop) atomicAdd(&a.counters[3], (unsigned long long)s_drop);
+  done += ns;
+  __syncthreads();
+  if (t == 0) s_n = 0;
+  __syncthreads();
+  }
+  if (t == 0) {
+    a.n_surv[it] = done;
+    if (!a.kills && np) atomicAdd(&a.counters[1], (unsigned long long)np);                 // statistics (device-queue rounds): pairs reported,
+    if (!a.kills && a.world <= 1 && np > done) atomicAdd(&a.counters[3], (unsigned long long)(np - done));   // pairs the filter dropped
   }
 }
 
@@ -262,10 +287,11 @@ __global__ __launch_bounds__(256) void k3_pairs_decide(const K3PairArgs a) {
   const uint32_t it = blockIdx.x;
   const demi_dpor_trace_entry* T = a.arena + (size_t)(a.base_id + it) * DEMI_DPOR_MAX_TRACE;
   const demi_dpor_pair* P = a.pairs + (size_t)it * a.max_pairs;
-  const uint32_t np = a.n_pairs[it];
-  for (uint32_t k = threadIdx.x; k < np; k += blockDim.x) {
-    const uint32_t s2 = a.pair_slot_of[(size_t)it * a.max_pairs + k];
+  const uint32_t ns = a.n_surv[it];
+  for (uint32_t j = threadIdx.x; j < ns; j += blockDim.x) {
+    const uint32_t s2 = a.pair_slot_of[(size_t)it * a.max_pairs + j];
     if (s2 == 0xFFFFFFFFu) continue;
+    const uint32_t k = a.surv_k[(size_t)it * a.max_pairs + j];
     const demi_dpor_pair p = P[k];
     PairEntry* e = a.table + (s2 >> 1);
     const uint32_t sd = s2 & 1;
@@ -297,10 +323,11 @@ __global__ __launch_bounds__(256) void k3_pairs_decide_q(const K3PairArgs a) {
   if (t == 0) s_cnt = 0;
   __syncthreads();
   const demi_dpor_pair* P = a.pairs + (size_t)it * a.max_pairs;
-  const uint32_t np = a.n_pairs[it];
-  for (uint32_t k = t; k < np; k += blockDim.x) {
-    const uint32_t s2 = a.pair_slot_of[(size_t)it * a.max_pairs + k];
+  const uint32_t ns = a.n_surv[it];
+  for (uint32_t j = t; j < ns; j += blockDim.x) {
+    const uint32_t s2 = a.pair_slot_of[(size_t)it * a.max_pairs + j];
     if (s2 == 0xFFFFFFFFu) continue;
+    const uint32_t k = a.surv_k[(size_t)it * a.max_pairs + j];
     const demi_dpor_pair p = P[k];
     PairEntry* e = a.table + (s2 >> 1);
     const uint32_t sd = s2 & 1;
