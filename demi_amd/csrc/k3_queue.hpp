@@ -130,6 +130,7 @@ __global__ __launch_bounds__(64) void k3_q_hist(const K3QueueArgs a) {
   __shared__ uint32_t s_h[256];
   const uint32_t tile = blockIdx.x, lane = threadIdx.x;
   const uint32_t total = (uint32_t)a.out[0];
+  if (tile * Q_TILE >= total || total > a.staging_cap) return;       // (the grid is sized for the largest round)
   for (uint32_t i = lane; i < 256; i += 64) s_h[i] = 0;
   __syncthreads();
   const uint32_t lo = tile * Q_TILE, hi = min(lo + Q_TILE, total);
@@ -140,9 +141,11 @@ __global__ __launch_bounds__(64) void k3_q_hist(const K3QueueArgs a) {
 
 // thread d: the tiles' counts of branch d -> exclusive prefix over the tiles, the run length to out[4 + d]; then the runs' starts
 // within the segment, deepest branch first.  One workgroup of 256.
-__global__ __launch_bounds__(256) void k3_q_offsets(const K3QueueArgs a, uint32_t tiles) {
+__global__ __launch_bounds__(256) void k3_q_offsets(const K3QueueArgs a) {
   __shared__ uint32_t s_tot[256];
   const uint32_t d = threadIdx.x;
+  // (the host launches before it knows the round's point count; more points than the staging area holds: the host reports it)
+  const uint32_t tiles = a.out[0] > a.staging_cap ? 0u : ((uint32_t)a.out[0] + Q_TILE - 1) / Q_TILE;
   uint32_t run = 0;
   for (uint32_t tl = 0; tl < tiles; tl++) {
     const uint32_t c = a.tile_hist[(size_t)tl * 256 + d];
@@ -165,6 +168,7 @@ __global__ __launch_bounds__(64) void k3_q_scatter(const K3QueueArgs a) {
   __shared__ uint32_t s_run[256];
   const uint32_t tile = blockIdx.x, lane = threadIdx.x;
   const uint32_t total = (uint32_t)a.out[0];
+  if (tile * Q_TILE >= total || total > a.staging_cap) return;
   for (uint32_t i = lane; i < 256; i += 64) s_run[i] = a.digit_start[i] + a.tile_hist[(size_t)tile * 256 + i];
   __syncthreads();
   const uint32_t lo = tile * Q_TILE, hi = min(lo + Q_TILE, total);
@@ -227,9 +231,9 @@ __global__ __launch_bounds__(256) void k3_q_live(const K3QueueArgs a) {
 // One workgroup walks the candidates in order: the first `want` live ones are taken.  out[1] = taken, out[2] = consumed (the
 // index after the last one taken, or n_cand).
 __global__ __launch_bounds__(1024) void k3_q_take(const K3QueueArgs a) {
-  __shared__ uint32_t s_part[1024];
+  __shared__ uint32_t s_wave[16];          // live candidates per wave of the current chunk
   __shared__ uint32_t s_have, s_consumed;
-  const uint32_t t = threadIdx.x;
+  const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
   if (t == 0) { s_have = 0; s_consumed = a.n_cand; }
   __syncthreads();
   for (uint32_t lo = 0; lo < a.n_cand; lo += 1024) {
@@ -243,15 +247,13 @@ __global__ __launch_bounds__(1024) void k3_q_take(const K3QueueArgs a) {
       live = (cs & Q_LIVE) != 0;
       s = cs & ~Q_LIVE;
     }
-    s_part[t] = live ? 1u : 0u;
+    // rank of a live candidate among the chunk's live ones: a ballot within the wave, sixteen wave counts through LDS
+    const unsigned long long m = __ballot(live);
+    if (lane == 0) s_wave[wave] = (uint32_t)__popcll(m);
     __syncthreads();
-    for (uint32_t d = 1; d < 1024; d <<= 1) {
-      const uint32_t x = t >= d ? s_part[t - d] : 0u;
-      __syncthreads();
-      s_part[t] += x;
-      __syncthreads();
-    }
-    const uint32_t rank = have + s_part[t] - (live ? 1u : 0u);
+    uint32_t before = 0, chunk = 0;
+    for (uint32_t w = 0; w < 16; w++) { const uint32_t c = s_wave[w]; before += w < wave ? c : 0u; chunk += c; }
+    const uint32_t rank = have + before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
     if (live && rank < a.want) {
       const QPoint q = a.pool[q_cand_index(a.ranges, a.n_ranges, j)];
       DporItem it;
@@ -261,7 +263,7 @@ __global__ __launch_bounds__(1024) void k3_q_take(const K3QueueArgs a) {
       if (rank + 1 == a.want) s_consumed = j + 1;
     }
     __syncthreads();
-    if (t == 1023) s_have = min(have + s_part[1023], a.want);
+    if (t == 0) s_have = min(have + chunk, a.want);
     __syncthreads();
   }
   if (t == 0) { a.out[1] = s_have; a.out[2] = s_consumed; }
