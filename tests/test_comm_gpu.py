@@ -167,6 +167,9 @@ def test_bench_py_two_ranks_on_one_gpu(tmp_path):
     e2e = dd["ddmin_end_to_end"]
     assert dd["n_gpus"] == 2 and e2e["same_mcs_as_single_rank"] and e2e["same_consultation_sequence_as_single_rank"] and e2e["mcs_len"] > 0
     assert dd["every_ranks_block_arrived_everywhere"] and dd["value"] > 0
+    rd = dd["random_ddmin_R100"]         # randomDDMin with every frontier split over the two ranks
+    assert "error" not in rd, rd
+    assert rd["n_gpus"] == 2 and rd["same_mcs_and_consultations_on_every_rank"] and rd["same_mcs_as_single_rank_sequential"] and rd["mcs_len"] > 0
     assert c5["n_gpus"] == 2 and c5["interleavings"] == 40000 and not c5["exhausted"] and c5["same_verdict_sequence_on_every_rank"]
     # both ranks' violations are in the merged set: rank 1 evaluates the indices [65536, 131072)
     one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0", "--schedules", "65536",
