@@ -627,3 +627,35 @@ def test_checkpointed_interleavings_are_the_same_interleavings(oracle, monkeypat
     m = len(cpu[0])
     assert (cpu[0] == with_records[0][:m]).all() and (cpu[1] == with_records[1][:m]).all()
     ctx.close()
+
+
+@pytest.mark.parametrize("max_pairs,stop,batch", [(48, 0, 64), (4096, 1, 128), (4096, 0, 1), (300, 0, 7)])
+def test_device_queue_edge_cases_against_the_host_bookkeeping(monkeypatch, max_pairs, stop, batch):
+    """The device-resident path (queue, parent filter, checkpoints) where its special cases live: racing-pair lists that overflow
+    max_pairs (DEMI_V_PAIRS_OVF ends the parent filter's invariant for the descendants), stopIfViolationFound, rounds of one
+    and of an odd size, a budget that is not a multiple of the batch - against the path that fetches every racing pair and does
+    dpor()'s bookkeeping on host threads (DEMI_DPOR_HOST_BOOKKEEPING), on a model with violations (writers) and on raft3."""
+    from demi_amd import _native
+    from tests.test_dpor_cpu import writers_model
+    cases = [(writers_model(4), events_to_array([start(a) for a in range(5)] + [send(a, 0) for a in range(1, 5)]), 0, 1801),
+             (M.raft_model(3), events_to_array([start(a) for a in range(3)] + [send(a, M.M_BOOTSTRAP) for a in range(3)]), 30, 1203)]
+    for model, ev, depth, budget in cases:
+        if batch == 1:
+            budget = 160
+        ctx = _native.Context(0)
+        ctx.model_load(model.to_struct())
+        ctx.dpor_load(ev)
+        par, srch = T.DporParams(depth, 0, 0, 0, 64, max_pairs), T.DporSearch(batch, budget, stop, 1, T.DPOR_ORDER_ROUNDS)
+        monkeypatch.delenv("DEMI_DPOR_HOST_BOOKKEEPING", raising=False)
+        dev = ctx.dpor_explore(par, srch)
+        monkeypatch.setenv("DEMI_DPOR_HOST_BOOKKEEPING", "1")
+        host = ctx.dpor_explore(par, srch)
+        monkeypatch.delenv("DEMI_DPOR_HOST_BOOKKEEPING")
+        assert len(dev[0]) == len(host[0]) and (dev[0] == host[0]).all() and (dev[1] == host[1]).all() and (dev[2] == host[2]).all()
+        assert dev[4].exhausted == host[4].exhausted and dev[4].violations == host[4].violations and dev[4].first_violation == host[4].first_violation
+        assert len(dev[3]) == len(host[3]) and (dev[3] == host[3]).all()                 # the first violating trace
+        if max_pairs == 48 and depth == 30:                       # (raft3: hundreds of racing pairs per interleaving)
+            assert (dev[0]["flags"] & T.V_PAIRS_OVF).any()
+        if stop:
+            assert (dev[4].violations >= 1) == bool((dev[0]["flags"] & T.V_VIOLATION).any())
+        ctx.close()
