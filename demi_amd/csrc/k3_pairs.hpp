@@ -162,22 +162,30 @@ struct ParentIndex {
 };
 // it: the interleaving's index within a.pairs / a.n_pairs / a.verdicts (this rank's block); arena id a.base_id + it; its
 // backtrack point a.items[a.item_base + it].  Also records `complete` for the interleaving (thread 0).
+// The loads are issued as early and as unconditionally as their addresses allow - a workgroup's time is the chain of its
+// dependent round trips to HBM: the item (1), then the parent's flag, its length and its keys together (2; whole rows are read,
+// entries past a trace's length are never looked at), the own keys beside the item.
 __device__ inline bool parent_index_build(const K3PairArgs& a, uint32_t it, uint32_t np, const demi_dpor_trace_entry* T, ParentIndex& S) {
   const uint32_t t = threadIdx.x, nt = blockDim.x;
   if (!a.complete) return false;
   const DporItem item = a.items[a.item_base + it];
-  const bool par = item.src != 0xFFFFFFFFu && a.complete[item.src] != 0;
-  if (t == 0) a.complete[a.base_id + it] = (!(a.verdicts[it].flags & DEMI_V_PAIRS_OVF) && (item.src == 0xFFFFFFFFu || par)) ? 1 : 0;
-  if (!par || np == 0) return false;
-  const uint32_t n_tr = min(a.arena_len[a.base_id + it], (uint32_t)DEMI_DPOR_MAX_TRACE);
-  const demi_dpor_trace_entry* TP = a.arena + (size_t)item.src * DEMI_DPOR_MAX_TRACE;
-  const uint32_t n_par = min(a.arena_len[item.src], (uint32_t)DEMI_DPOR_MAX_TRACE);
+  const uint32_t n_tr_raw = a.arena_len[a.base_id + it];
+  for (uint32_t i = t; i < DEMI_DPOR_MAX_TRACE; i += nt) S.okey[i] = T[i].key;
   for (uint32_t i = t; i < PF_SLOTS; i += nt) { S.pslot[i] = 0xFFFFFFFFu; S.oslot[i] = 0xFFFFFFFFu; }
-  for (uint32_t i = t; i < DEMI_DPOR_MAX_TRACE; i += nt) {
-    S.pdup[i] = 0; S.odup[i] = 0; S.idx[i] = -1;
-    if (i < n_par) { S.pkey[i] = TP[i].key; S.pq[i] = TP[i].qperiod; }
-    if (i < n_tr) S.okey[i] = T[i].key;
+  for (uint32_t i = t; i < DEMI_DPOR_MAX_TRACE; i += nt) { S.pdup[i] = 0; S.odup[i] = 0; S.idx[i] = -1; }
+  const bool has_src = item.src != 0xFFFFFFFFu;
+  uint32_t comp = 0, n_par_raw = 0;
+  if (has_src) {
+    const demi_dpor_trace_entry* TP = a.arena + (size_t)item.src * DEMI_DPOR_MAX_TRACE;
+    comp = a.complete[item.src];
+    n_par_raw = a.arena_len[item.src];
+    if (np != 0)
+      for (uint32_t i = t; i < DEMI_DPOR_MAX_TRACE; i += nt) { const demi_dpor_trace_entry e = TP[i]; S.pkey[i] = e.key; S.pq[i] = e.qperiod; }
   }
+  const bool par = has_src && comp != 0;
+  if (t == 0) a.complete[a.base_id + it] = (!(a.verdicts[it].flags & DEMI_V_PAIRS_OVF) && (!has_src || par)) ? 1 : 0;
+  if (!par || np == 0) return false;
+  const uint32_t n_tr = min(n_tr_raw, (uint32_t)DEMI_DPOR_MAX_TRACE), n_par = min(n_par_raw, (uint32_t)DEMI_DPOR_MAX_TRACE);
   __syncthreads();
   for (uint32_t i = t; i < n_par; i += nt) {       // equal keys mark each other as duplicates (collapsed siblings)
     const unsigned long long k = S.pkey[i];
@@ -222,6 +230,10 @@ __global__ __launch_bounds__(256) void k3_pairs_insert(const K3PairArgs a) {
   const demi_dpor_pair* P = a.pairs + (size_t)it * a.max_pairs;
   const uint32_t np = min(a.n_pairs[it], a.max_pairs);
   if (t == 0) s_n = 0;
+  // (the first step's pairs are asked for before the index is built: their address depends on nothing)
+  demi_dpor_pair first[4];
+#pragma unroll
+  for (uint32_t j = 0; j < 4; j++) { const uint32_t k = j * nt + t; if (k < a.max_pairs) first[j] = P[k]; }
   const bool par = parent_index_build(a, it, np, T, S);
   __syncthreads();
   uint32_t done = 0;                        // survivors written so far (max_pairs may exceed the list: 4096 pairs at a time)
@@ -233,7 +245,7 @@ __global__ __launch_bounds__(256) void k3_pairs_insert(const K3PairArgs a) {
     for (uint32_t base = c0; base < c1; base += 4 * nt) {
       demi_dpor_pair p[4];
 #pragma unroll
-      for (uint32_t j = 0; j < 4; j++) { const uint32_t k = base + j * nt + t; if (k < c1) p[j] = P[k]; }
+      for (uint32_t j = 0; j < 4; j++) { const uint32_t k = base + j * nt + t; if (base == 0) p[j] = first[j]; else if (k < c1) p[j] = P[k]; }
 #pragma unroll
       for (uint32_t j = 0; j < 4; j++) {
         const uint32_t k = base + j * nt + t;
@@ -250,7 +262,7 @@ __global__ __launch_bounds__(256) void k3_pairs_insert(const K3PairArgs a) {
   for (uint32_t j = t; j < ns; j += nt) {
     const uint32_t k = c0 + s_surv[j];
     const demi_dpor_pair p = P[k];
-    const uint64_t ke = T[p.earlier].key, kl = T[p.later].key;
+    const uint64_t ke = par ? S.okey[p.earlier] : T[p.earlier].key, kl = par ? S.okey[p.later] : T[p.later].key;   // (the index holds the own keys)
     const uint32_t s1 = pair_slot(a.table, a.mask, ke, kl);                // (earlier, later); its flip is the other side
     const uint32_t s2 = s1 == 0xFFFFFFFFu ? s1 : (s1 ^ 1u);
     a.surv_k[(size_t)it * a.max_pairs + done + j] = (uint16_t)k;
