@@ -417,7 +417,7 @@ def test_config5_pipeline_exploration_against_the_oracle(oracle):
     """BASELINE config 5 as bench.py times it (apps.shuffle8_config5_large: pipeline of three shuffle jobs, depth 40, budget
     2^20, ROUNDS of 16 384), the WHOLE exploration held against the CPU oracle in two ways:
       (1) its first 2^17 interleavings verdict for verdict against the oracle's exploration (same order, same prefixes);
-      (2) more than 2 000 interleavings from everywhere in the 2^20 - every round's first and last member, the whole tail of the
+      (2) more than 6 000 interleavings from everywhere in the 2^20 - every round's first and last member, the whole tail of the
           last round, the rest drawn at random - re-executed ONE BY ONE by the oracle (orc_dpor_execute) from the next trace the
           exploration started them from (demi_dpor_explored): the verdict the exploration returned, the trace it left in the arena
           and the racing pairs of that prefix must be the oracle's.  No host bookkeeping is shared in (2): the oracle sees a
@@ -427,7 +427,7 @@ def test_config5_pipeline_exploration_against_the_oracle(oracle):
     from demi_amd.apps import shuffle8_config5_large
     emu = os.environ.get("DEMI_EMU") == "1"
     model, ev, depth, budget = shuffle8_config5_large()
-    batch, head, n_random = 16384, 1 << 17, 1500
+    batch, head, n_random = 16384, 1 << 17, 6000
     if emu:
         budget, batch, head, n_random = 2500, 256, 800, 40
     par = T.DporParams(depth, 0, 0, 0, 64, 4096)
@@ -451,7 +451,7 @@ def test_config5_pipeline_exploration_against_the_oracle(oracle):
     pick = set(int(x) for x in starts) | set(int(x) for x in ends) | set(range(max(last_lo, n - 400), n)) | \
         set(int(x) for x in rng.integers(0, n, n_random))
     pick = sorted(pick)
-    assert emu or (len(pick) >= 2000 and sum(1 for i in pick if i >= head) >= 1500 and sum(1 for i in pick if i >= last_lo) >= 300)
+    assert emu or (len(pick) >= 6000 and sum(1 for i in pick if i >= head) >= 5000 and sum(1 for i in pick if i >= last_lo) >= 300)
     prefixes, shared, traces = [], [], []
     for i in pick:
         nt, sh, tr = ctx.dpor_explored(i)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 5, call 8: the compacted pair kernels - K3 suite, configs 5 and 3, per-kernel stats.
+# Round 5, calls 8 and 10: the pair kernels after a change - K3 suite, configs 5 and 3, per-kernel stats.
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 mkdir -p gpurun_out
