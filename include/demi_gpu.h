@@ -558,9 +558,15 @@ int demi_dpor_batch(demi_ctx* ctx, const demi_dpor_trace_entry* prefixes, const 
 /* The whole bounded exploration in one call: the backtrack priority queue with
  * DefaultBacktrackOrdering (BacktrackOrdering.scala:58-69), the ExploredTacker
  * (AuxilaryTypes.scala:209-246), dpor()'s bookkeeping (:1068-1070, 1134) and getNext() (:1142-1185)
- * run natively on the host around demi_dpor_batch-sized launches.  A round pops up to `batch`
+ * inside the library around demi_dpor_batch-sized launches.  A round pops up to `batch`
  * unexplored backtrack points (batch = 1 is the reference's one-at-a-time order; PriorityQueue ties
- * pop in creation order) and each point carries its own next trace.                                */
+ * pop in creation order) and each point carries its own next trace.
+ * With trackHistory and the default ordering all of it is DEVICE-RESIDENT on one rank (round 5): the traces stay in an arena
+ * (a backtrack point is 8 bytes: the interleaving that found it + three trace indices), the ExploredTacker is a hash table over
+ * pairs of node keys, a racing pair the interleaving's parent provably applied never reaches it, the queue is a pool of points
+ * sorted per round with getNext() as one probe + take over the candidates in dequeue order, and an interleaving starts from a
+ * record of its parent's state below the branch point instead of re-executing the shared prefix.  None of it changes what is
+ * explored: same rounds, verdicts and queue as the bookkeeping on host threads.          */
 /* In which order the backtrack points are explored.
  * ROUNDS: a round pops up to `batch` unexplored points, runs them as one launch and absorbs their racing pairs in pop
  *   order.  batch = 1 is the reference's order; the explored-pair heuristic (ExploredTacker, AuxilaryTypes.scala:209-246)
