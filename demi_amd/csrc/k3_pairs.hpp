@@ -158,7 +158,7 @@ struct ParentIndex {
   unsigned long long pkey[DEMI_DPOR_MAX_TRACE], okey[DEMI_DPOR_MAX_TRACE];
   uint32_t pslot[PF_SLOTS], oslot[PF_SLOTS];      // 0xFFFFFFFF = empty, else an event index
   short idx[DEMI_DPOR_MAX_TRACE];
-  uint8_t pdup[DEMI_DPOR_MAX_TRACE], odup[DEMI_DPOR_MAX_TRACE], pq[DEMI_DPOR_MAX_TRACE];
+  uint8_t pdup[DEMI_DPOR_MAX_TRACE], odup[DEMI_DPOR_MAX_TRACE], pq[DEMI_DPOR_MAX_TRACE], oq[DEMI_DPOR_MAX_TRACE];
 };
 // it: the interleaving's index within a.pairs / a.n_pairs / a.verdicts (this rank's block); arena id a.base_id + it; its
 // backtrack point a.items[a.item_base + it].  Also records `complete` for the interleaving (thread 0).
@@ -170,7 +170,7 @@ __device__ inline bool parent_index_build(const K3PairArgs& a, uint32_t it, uint
   if (!a.complete) return false;
   const DporItem item = a.items[a.item_base + it];
   const uint32_t n_tr_raw = a.arena_len[a.base_id + it];
-  for (uint32_t i = t; i < DEMI_DPOR_MAX_TRACE; i += nt) S.okey[i] = T[i].key;
+  for (uint32_t i = t; i < DEMI_DPOR_MAX_TRACE; i += nt) { const demi_dpor_trace_entry e = T[i]; S.okey[i] = e.key; S.oq[i] = e.qperiod; }
   for (uint32_t i = t; i < PF_SLOTS; i += nt) { S.pslot[i] = 0xFFFFFFFFu; S.oslot[i] = 0xFFFFFFFFu; }
   for (uint32_t i = t; i < DEMI_DPOR_MAX_TRACE; i += nt) { S.pdup[i] = 0; S.odup[i] = 0; S.idx[i] = -1; }
   const bool has_src = item.src != 0xFFFFFFFFu;
@@ -210,7 +210,7 @@ __device__ inline bool parent_index_build(const K3PairArgs& a, uint32_t it, uint
     for (uint32_t h = pf_key_hash(k);; h = (h + 1) & (PF_SLOTS - 1)) {
       const uint32_t j = S.pslot[h];
       if (j == 0xFFFFFFFFu) break;
-      if (S.pkey[j] == k) { if (!S.pdup[j] && S.pq[j] == T[i].qperiod) S.idx[i] = (short)j; break; }
+      if (S.pkey[j] == k) { if (!S.pdup[j] && S.pq[j] == S.oq[i]) S.idx[i] = (short)j; break; }
     }
   }
   __syncthreads();
@@ -231,9 +231,9 @@ __global__ __launch_bounds__(256) void k3_pairs_insert(const K3PairArgs a) {
   const uint32_t np = min(a.n_pairs[it], a.max_pairs);
   if (t == 0) s_n = 0;
   // (the first step's pairs are asked for before the index is built: their address depends on nothing)
-  demi_dpor_pair first[4];
+  demi_dpor_pair first[8];
 #pragma unroll
-  for (uint32_t j = 0; j < 4; j++) { const uint32_t k = j * nt + t; if (k < a.max_pairs) first[j] = P[k]; }
+  for (uint32_t j = 0; j < 8; j++) { const uint32_t k = j * nt + t; if (k < a.max_pairs) first[j] = P[k]; }
   const bool par = parent_index_build(a, it, np, T, S);
   __syncthreads();
   uint32_t done = 0;                        // survivors written so far (max_pairs may exceed the list: 4096 pairs at a time)
@@ -245,7 +245,10 @@ __global__ __launch_bounds__(256) void k3_pairs_insert(const K3PairArgs a) {
     for (uint32_t base = c0; base < c1; base += 4 * nt) {
       demi_dpor_pair p[4];
 #pragma unroll
-      for (uint32_t j = 0; j < 4; j++) { const uint32_t k = base + j * nt + t; if (base == 0) p[j] = first[j]; else if (k < c1) p[j] = P[k]; }
+      for (uint32_t j = 0; j < 4; j++) {
+        const uint32_t k = base + j * nt + t;
+        if (base == 0) p[j] = first[j]; else if (base == 4 * nt) p[j] = first[4 + j]; else if (k < c1) p[j] = P[k];
+      }
 #pragma unroll
       for (uint32_t j = 0; j < 4; j++) {
         const uint32_t k = base + j * nt + t;
@@ -263,7 +266,17 @@ __global__ __launch_bounds__(256) void k3_pairs_insert(const K3PairArgs a) {
     const uint32_t k = c0 + s_surv[j];
     const demi_dpor_pair p = P[k];
     const uint64_t ke = par ? S.okey[p.earlier] : T[p.earlier].key, kl = par ? S.okey[p.later] : T[p.later].key;   // (the index holds the own keys)
-    const uint32_t s1 = pair_slot(a.table, a.mask, ke, kl);                // (earlier, later); its flip is the other side
+    // The entry is usually there already (a sibling inserted it) and at its home position: key, candidates and states of that
+    // position are read TOGETHER - three loads of one 64-byte line in flight instead of three round trips in a row - and used
+    // when the key matches; anything else takes pair_slot()'s path.
+    const uint64_t lo_ = ke < kl ? ke : kl, hi_ = ke < kl ? kl : ke;
+    const uint32_t home = (uint32_t)pair_hash(lo_, hi_) & a.mask;
+    const PairEntry* const eh = a.table + home;
+    const ulonglong2 hk = *reinterpret_cast<const ulonglong2*>(&eh->lo);
+    const ulonglong2 hc = *reinterpret_cast<const ulonglong2*>(&eh->cand[0]);
+    const uint2 hs = *reinterpret_cast<const uint2*>(&eh->state[0]);
+    const bool at_home = hk.x == lo_ && hk.y == hi_;
+    const uint32_t s1 = at_home ? home * 2 + (ke < kl ? 0u : 1u) : pair_slot(a.table, a.mask, ke, kl);   // (earlier, later); its flip is the other side
     const uint32_t s2 = s1 == 0xFFFFFFFFu ? s1 : (s1 ^ 1u);
     a.surv_k[(size_t)it * a.max_pairs + done + j] = (uint16_t)k;
     a.pair_slot_of[(size_t)it * a.max_pairs + done + j] = s2;
@@ -272,7 +285,9 @@ __global__ __launch_bounds__(256) void k3_pairs_insert(const K3PairArgs a) {
     // where it executes.  Both updates are monotone (the explored bit is only ever set, the candidate only ever raised), so
     // an ordinary load that already shows the result makes the atomic redundant; a stale line only means one atomic more.
     PairEntry* const e1 = a.table + (s1 >> 1);
-    if (!(e1->state[s1 & 1] & PE_EXPLORED)) {
+    const uint32_t seen_state = at_home ? ((s1 & 1) ? hs.y : hs.x) : e1->state[s1 & 1];
+    const unsigned long long seen_cand = at_home ? ((s2 & 1) ? hc.y : hc.x) : e1->cand[s2 & 1];
+    if (!(seen_state & PE_EXPLORED)) {
       const uint32_t old = atomicOr(&e1->state[s1 & 1], PE_EXPLORED);      // setExplored(branch, (earlier, later))
       if (a.kills && !(old & PE_EXPLORED) && (old & PE_QMASK)) {           // queued points flip into this pair: dead now
         const unsigned long long q = atomicAdd(&a.counters[1], 1ull);      // (only a HOST queue is told: the device queue reads the table)
@@ -280,7 +295,7 @@ __global__ __launch_bounds__(256) void k3_pairs_insert(const K3PairArgs a) {
       }
     }
     const unsigned long long mine = cand_pack(a.round, p.branch, (unsigned long long)it * a.max_pairs + k);
-    if (e1->cand[(s2 & 1)] < mine) atomicMax(&e1->cand[s2 & 1], mine);   // (s2 is the other side of the same entry)
+    if (seen_cand < mine) atomicMax(&e1->cand[s2 & 1], mine);            // (s2 is the other side of the same entry)
   }
   done += ns;
   __syncthreads();
