@@ -79,7 +79,9 @@ class FlatPairMap {
   void prefetch(uint64_t a, uint64_t b) const {
 #ifndef DEMI_NO_PREFETCH
     const bool sw = b < a;
-    __builtin_prefetch(&tab_[slot(sw ? b : a, sw ? a : b)]);
+    const char* e = reinterpret_cast<const char*>(&tab_[slot(sw ? b : a, sw ? a : b)]);
+    __builtin_prefetch(e);
+    __builtin_prefetch(e + sizeof(Entry) - 1);       // (24-byte entries: one in three lies across two lines)
 #else
     (void)a; (void)b;
 #endif
@@ -118,6 +120,7 @@ class FlatPairSet {
     }
   }
   size_t size() const { return n_; }
+  void prefetch(uint64_t a, uint64_t b) const { __builtin_prefetch(&tab_[slot(a, b)]); }
 
  private:
   struct Entry { uint64_t a, b; };
@@ -1114,7 +1117,15 @@ int explore_rounds_resident(Dev&& dev, const demi_dpor_search* srch, demi_verdic
       }
     }
     base_id += dev.ids_used(n);
-    for (const demi::DporKill& k : kills) dead.insert(k.a, k.b);
+    {
+      constexpr size_t AHEAD = 12;
+      const size_t nk = kills.size();
+      for (size_t i = 0; i < nk && i < AHEAD; i++) dead.prefetch(kills[i].a, kills[i].b);
+      for (size_t i = 0; i < nk; i++) {
+        if (i + AHEAD < nk) dead.prefetch(kills[i + AHEAD].a, kills[i + AHEAD].b);
+        dead.insert(kills[i].a, kills[i].b);
+      }
+    }
     // creation order: the round's interleavings in pop order, then pair order (ordinals are unique within a round)
     ord_key.resize(pts.size());
     for (size_t i = 0; i < pts.size(); i++) ord_key[i] = pts[i].ordinal;
@@ -1298,8 +1309,9 @@ int explore_rounds_devqueue(Dev&& dev, const demi_dpor_search* srch, demi_verdic
 //     records (keys + indices), in pair order.
 // Committed sequence, verdicts, prefix lengths, first violation: those of batch = 1 (tests: the CPU harness restates the
 // device rules sequentially under this same loop; the GPU suite holds config 3 against the committed golden sequence).
-// 64-bit key -> V, open addressing over indices into a deque of values: an insertion allocates nothing per element and the
-// values keep their addresses (the commit holds pointers to results across insertions).  Key 0 is the empty slot.
+// 64-bit key -> V, open addressing over indices into chunks of values: an insertion allocates nothing per element (a chunk of
+// 4096 values now and then) and the values keep their addresses (the commit holds pointers to results across insertions).
+// Key 0 is the empty slot.
 template <class V>
 class FlatKeyMap {
  public:
@@ -1307,26 +1319,34 @@ class FlatKeyMap {
   V* find(uint64_t key) {
     for (size_t i = hash(key) & mask_;; i = (i + 1) & mask_) {
       const Slot& s = slots_[i];
-      if (s.key == key) return &vals_[s.idx];
+      if (s.key == key) return &val(s.idx);
       if (s.key == 0) return nullptr;
     }
   }
   bool count(uint64_t key) { return find(key) != nullptr; }
-  // the value of `key`, default-constructed first if absent
-  V& at(uint64_t key) {
-    if ((vals_.size() + 1) * 2 > slots_.size()) grow();
+  // the value of `key`, value-initialised first if absent (`inserted` says which)
+  V& at(uint64_t key, bool& inserted) {
+    if ((n_ + 1) * 2 > slots_.size()) grow();
     for (size_t i = hash(key) & mask_;; i = (i + 1) & mask_) {
       Slot& s = slots_[i];
-      if (s.key == key) return vals_[s.idx];
-      if (s.key == 0) { s.key = key; s.idx = (uint32_t)vals_.size(); vals_.emplace_back(); return vals_.back(); }
+      if (s.key == key) { inserted = false; return val(s.idx); }
+      if (s.key == 0) {
+        if ((n_ & (CHUNK - 1)) == 0 && n_ / CHUNK == chunks_.size()) chunks_.emplace_back(new V[CHUNK]());
+        s.key = key; s.idx = (uint32_t)n_;
+        inserted = true;
+        return val(n_++);
+      }
     }
   }
+  V& at(uint64_t key) { bool ins; return at(key, ins); }
   void prefetch(uint64_t key) const { __builtin_prefetch(&slots_[hash(key) & mask_]); }
-  size_t size() const { return vals_.size(); }
+  size_t size() const { return n_; }
 
  private:
+  static constexpr size_t CHUNK = 4096;
   struct Slot { uint64_t key; uint32_t idx; };
   static size_t hash(uint64_t k) { k *= 0x9E3779B97F4A7C15ULL; return (size_t)(k ^ (k >> 29)); }
+  V& val(size_t i) { return chunks_[i / CHUNK][i % CHUNK]; }
   void grow() {
     std::vector<Slot> old;
     old.swap(slots_);
@@ -1336,8 +1356,8 @@ class FlatKeyMap {
       if (o.key) { size_t i = hash(o.key) & mask_; while (slots_[i].key) i = (i + 1) & mask_; slots_[i] = o; }
   }
   std::vector<Slot> slots_;
-  size_t mask_ = 0;
-  std::deque<V> vals_;
+  size_t mask_ = 0, n_ = 0;
+  std::vector<std::unique_ptr<V[]>> chunks_;
 };
 
 struct RefRec {              // one racing pair the commit still has to absorb (device -> host), 24 bytes
@@ -1396,23 +1416,40 @@ class RefBook {
   uint64_t queue_len() const { return queued_; }
   uint64_t enqueued() const { return enqueued_; }
   // up to `k` points in dequeue order that are live right now, without dequeuing them: what the commit will most likely ask
-  // for next (a speculation: a point may still die before its turn, and new points may get ahead of it)
+  // for next (a speculation: a point may still die before its turn, and new points may get ahead of it).  The table lines of
+  // the points further down the bucket are requested while this one is looked at.
   template <class F>
   void peek(size_t k, F&& f) const {
-    for (int b = top_; b >= 0 && k; b--)
-      for (const Point& p : bucket_[b]) {
-        if (!k) break;
+    constexpr size_t AHEAD = 12;
+    for (int b = top_; b >= 0 && k; b--) {
+      const std::deque<Point>& q = bucket_[b];
+      const size_t n = q.size();
+      for (size_t j = 0; j < n && j < AHEAD; j++) map_.prefetch(q[j].flip_a, q[j].flip_b);
+      for (size_t i = 0; i < n && k; i++) {
+        if (i + AHEAD < n) map_.prefetch(q[i + AHEAD].flip_a, q[i + AHEAD].flip_b);
+        const Point& p = q[i];
         const uint32_t* v = map_.find(p.flip_a, p.flip_b);
         if (v && (*v & EXPLORED)) continue;
         f(p);
         k--;
       }
+    }
+  }
+  // the point get_next() would look at first (live or not): its result is what the commit most likely needs after this one
+  const Point* front() {
+    while (top_ >= 0 && bucket_[top_].empty()) top_--;
+    return top_ >= 0 ? &bucket_[top_].front() : nullptr;
   }
   // the entries that changed since the last call, with their current states
   void take_deltas(std::vector<RefDelta>& out) {
     out.clear();
     out.reserve(dirty_.size());
-    for (const std::pair<uint64_t, uint64_t>& k : dirty_) {
+    constexpr size_t AHEAD = 12;
+    const size_t n = dirty_.size();
+    for (size_t i = 0; i < n && i < AHEAD; i++) map_.prefetch(dirty_[i].first, dirty_[i].second);
+    for (size_t i = 0; i < n; i++) {
+      if (i + AHEAD < n) map_.prefetch(dirty_[i + AHEAD].first, dirty_[i + AHEAD].second);
+      const std::pair<uint64_t, uint64_t>& k = dirty_[i];
       const FlatPairMap::Ref e = map_.at(k.first, k.second);      // (lo, hi): fwd = side 0
       *e.fwd &= ~DIRTY;
       out.push_back(RefDelta{k.first, k.second, {*e.fwd & ~DIRTY, *e.rev & ~DIRTY}});
@@ -1464,6 +1501,7 @@ int explore_reference_resident(Dev&& dev, const demi_dpor_search* srch, demi_ver
   auto key_of = [](const demi::DporItem& it) -> uint64_t {
     return ((uint64_t)it.src << 24) | ((uint64_t)it.branch << 16) | ((uint64_t)it.later << 8) | (uint64_t)it.earlier;
   };
+  // (`seconds`, a diagnostic, is 8 doubles here: [0..2] as in the other loops, [3] naming the fetches (host), [4] the device's part of them, [5] the host's work after a launch, [6] before one)
   // fetched: its records have been ASKED for (a fetch names it); ready: they are here (nothing to fetch: both from the start)
   struct Result { uint32_t id; demi_verdict verdict; const RefRec* recs; uint32_t rec_cnt; bool fetched, ready; };
   FlatKeyMap<Result> results;                            // every interleaving run so far, by its item; its surviving racing
@@ -1487,7 +1525,9 @@ int explore_reference_resident(Dev&& dev, const demi_dpor_search* srch, demi_ver
   std::vector<uint32_t> rec_cnt;
   std::vector<RefDelta> deltas;
   std::vector<uint32_t> fetch_ids;
-  std::vector<Result*> fetch_res, inflight_res;
+  std::vector<Result*> fetch_res, inflight_res, launch_res;
+  std::vector<uint64_t> peeked;
+  std::vector<demi::DporItem> peeked_items;
   bool inflight = false;                                  // a record fetch has been issued and not yet landed
   // Measured (round 5, config 3, profiles/r05_call4_reference_prefetch_ab.txt): with the next window's fetch in flight the wait
   // shrinks 23 -> 19 ms, the records fetched a window early are filtered under an older table and grow 33 -> 63 MB, the commit
@@ -1518,6 +1558,8 @@ int explore_reference_resident(Dev&& dev, const demi_dpor_search* srch, demi_ver
         found = true;
         if (stats->first_violation == ~0ull) { stats->first_violation = idx; first_id = r.id; }
       }
+      if (const RefBook::Point* f = real.front())           // (most likely the next one: its result's line, while this one's records are absorbed)
+        results.prefetch(key_of(demi::DporItem{f->src, f->branch, f->later, f->earlier, 0}));
       real.absorb(r.recs, r.rec_cnt, r.id);
       if ((srch->stop_if_violation && found) || stats->interleavings >= srch->max_interleavings) { done = true; break; }
       RefBook::Point p;
@@ -1533,6 +1575,7 @@ int explore_reference_resident(Dev&& dev, const demi_dpor_search* srch, demi_ver
     // answer.  With DEMI_DPOR_PREFETCH the fetch for the NEXT window of the queue front is issued while the commit works through
     // this one (records fetched a window early are filtered under a table that is a window older - rule (b) holds for any older
     // state - so more of them cross PCIe); by default a fetch is waited for when it is issued (see no_prefetch above).
+    double t_named = t1;
     auto issue = [&](bool with_cur) -> int {
       fetch_ids.clear(); fetch_res.clear();
       if (with_cur) {
@@ -1541,14 +1584,21 @@ int explore_reference_resident(Dev&& dev, const demi_dpor_search* srch, demi_ver
         fetch_ids.push_back(r0->id); fetch_res.push_back(r0);
       }
       // (with_cur: the window at the queue's front; else the window behind it - the front one has been asked for already)
+      peeked.clear();
       real.peek(with_cur ? fetch_width : 2 * fetch_width, [&](const RefBook::Point& p) {
-        Result* it = results.find(key_of(demi::DporItem{p.src, p.branch, p.later, p.earlier, 0}));
-        if (!it || it->fetched) return;
+        const uint64_t k = key_of(demi::DporItem{p.src, p.branch, p.later, p.earlier, 0});
+        results.prefetch(k);
+        peeked.push_back(k);
+      });
+      for (const uint64_t k : peeked) {
+        Result* it = results.find(k);
+        if (!it || it->fetched) continue;
         it->fetched = true;
         fetch_ids.push_back(it->id); fetch_res.push_back(it);
-      });
+      }
       if (fetch_ids.empty()) return 0;
       real.take_deltas(deltas);
+      t_named = now();
       int rc = dev.ref_fetch_begin(fetch_ids.data(), (uint32_t)fetch_ids.size(), deltas.data(), (uint32_t)deltas.size());
       if (rc) return rc;
       inflight_res = fetch_res;
@@ -1573,9 +1623,11 @@ int explore_reference_resident(Dev&& dev, const demi_dpor_search* srch, demi_ver
       if (rc) return rc;
       const Result& r0 = *results.find(key_of(cur));
       if (!r0.ready) {
+        const double t_i0 = now();
         rc = issue(!r0.fetched);
         if (!rc) rc = land();
         if (rc) return rc;
+        if (seconds) { seconds[3] += t_named - t_i0; seconds[4] += now() - t_named; }      // (diagnostic: naming the fetch / the device's part of it)
       }
       // ... and, while the commit absorbs them, those of the interleavings its queue will most likely hand out after this window
       if (!no_prefetch) { rc = issue(false); if (rc) return rc; }
@@ -1586,23 +1638,31 @@ int explore_reference_resident(Dev&& dev, const demi_dpor_search* srch, demi_ver
     // ---- one launch: what the commit is waiting for + the speculation's next round (minus what has been run already)
     { int rc = land(); if (rc) return rc; }         // (the launch sends the table's changes too: one stream of deltas, in order)
     stats->cache_misses++;
-    items.clear();
-    items.push_back(cur);
+    // every item of the launch gets its entry in `results` right away (filled in when the launch is back): one table
+    // operation per item, and an interleaving that is already there - run earlier, or named twice here - is not run again
+    items.clear(); launch_res.clear();
+    auto add = [&](const demi::DporItem& q) {
+      bool fresh;
+      Result& r = results.at(key_of(q), fresh);
+      if (fresh) { items.push_back(q); launch_res.push_back(&r); }
+    };
+    add(cur);
+    // the commit's own queue front: what it will most likely dequeue next (the speculation below explores in rounds and
+    // runs out long before the commit does; without this every later interleaving would be a launch of its own)
+    peeked_items.clear();
+    real.peek(srch->batch / 4 + 1, [&](const RefBook::Point& p) {
+      const demi::DporItem q{p.src, p.branch, p.later, p.earlier, 0};
+      results.prefetch(key_of(q));
+      peeked_items.push_back(q);
+    });
+    for (const demi::DporItem& q : peeked_items) add(q);
     {
-      FlatKeyMap<uint8_t> in_launch_map;
-      struct { FlatKeyMap<uint8_t>& m; struct R { bool second; }; R insert(uint64_t k) { const size_t n0 = m.size(); m.at(k); return R{m.size() != n0}; } } in_launch{in_launch_map};
-      in_launch.insert(key_of(cur));
-      // the commit's own queue front: what it will most likely dequeue next (the speculation below explores in rounds and
-      // runs out long before the commit does; without this every later interleaving would be a launch of its own)
-      real.peek(srch->batch / 4 + 1, [&](const RefBook::Point& p) {
-        const demi::DporItem q{p.src, p.branch, p.later, p.earlier, 0};
-        const uint64_t k = key_of(q);
-        if (!results.count(k) && in_launch.insert(k).second) items.push_back(q);
-      });
-      for (const demi::DporItem& s : spec_items) {
-        const uint64_t k = key_of(s);
-        if (results.count(k) || !in_launch.insert(k).second) continue;
-        items.push_back(s);
+      constexpr size_t AHEAD = 12;
+      const size_t ns = spec_items.size();
+      for (size_t i = 0; i < ns && i < AHEAD; i++) results.prefetch(key_of(spec_items[i]));
+      for (size_t i = 0; i < ns; i++) {
+        if (i + AHEAD < ns) results.prefetch(key_of(spec_items[i + AHEAD]));
+        add(spec_items[i]);
       }
     }
     const uint32_t n = (uint32_t)items.size();
@@ -1612,6 +1672,8 @@ int explore_reference_resident(Dev&& dev, const demi_dpor_search* srch, demi_ver
     vd.resize(n); rec_off.resize(n); rec_cnt.resize(n);
     pts.clear(); kills.clear();
     round++;
+    const double t_l0 = now();
+    if (seconds) seconds[6] += t_l0 - t1;
     int rc = dev.round_ref(items.data(), use_parent.data(), n, round, base_id, deltas.data(), (uint32_t)deltas.size(), vd.data(), pts, kills,
                            rec_cnt.data());
     if (rc) return rc;
@@ -1621,13 +1683,21 @@ int explore_reference_resident(Dev&& dev, const demi_dpor_search* srch, demi_ver
     double t2 = now();
     if (complete.size() < (size_t)base_id + n) complete.resize((size_t)base_id + n, 0);
     for (uint32_t i = 0; i < n; i++) {
-      results.at(key_of(items[i])) = Result{base_id + i, vd[i], nullptr, 0u, rec_cnt[i] == 0, rec_cnt[i] == 0};   // (nothing to fetch: as good as here)
+      *launch_res[i] = Result{base_id + i, vd[i], nullptr, 0u, rec_cnt[i] == 0, rec_cnt[i] == 0};   // (nothing to fetch: as good as here)
       // (I) holds for this interleaving once it is absorbed iff its own pair list is whole and (I) held for its parent
       complete[(size_t)base_id + i] = !(vd[i].flags & DEMI_V_PAIRS_OVF) && (items[i].src == 0xFFFFFFFFu || use_parent[i]);
     }
     base_id += dev.ids_used(n);
     // the speculation: this round's live points and kills into its queue, then its next round
-    for (const demi::DporKill& k : kills) dead.insert(k.a, k.b);
+    {
+      constexpr size_t AHEAD = 12;
+      const size_t nk = kills.size();
+      for (size_t i = 0; i < nk && i < AHEAD; i++) dead.prefetch(kills[i].a, kills[i].b);
+      for (size_t i = 0; i < nk; i++) {
+        if (i + AHEAD < nk) dead.prefetch(kills[i + AHEAD].a, kills[i + AHEAD].b);
+        dead.insert(kills[i].a, kills[i].b);
+      }
+    }
     std::sort(pts.begin(), pts.end(), [](const demi::DporPoint& x, const demi::DporPoint& y) { return x.ordinal < y.ordinal; });
     for (const demi::DporPoint& p : pts) {
       bucket[p.branch].push_back(p);
@@ -1639,10 +1709,11 @@ int explore_reference_resident(Dev&& dev, const demi_dpor_search* srch, demi_ver
       if (top < 0) break;
       const demi::DporPoint p = bucket[top].front();
       bucket[top].pop_front();
+      if (bucket[top].size() > 8) dead.prefetch(bucket[top][8].flip_a, bucket[top][8].flip_b);
       if (!dead.insert(p.flip_a, p.flip_b)) continue;
       spec_items.push_back(demi::DporItem{p.src, p.branch, p.later, p.earlier, 0});
     }
-    if (seconds) { seconds[0] += t2 - t1; seconds[1] += now() - t2; }
+    if (seconds) { const double t3 = now(); seconds[0] += t2 - t1; seconds[1] += t3 - t2; seconds[5] += t3 - t2; }
   }
   if (inflight) {                                          // (an answer nobody needs any more: still waited for - it writes host memory)
     rec_off.resize(inflight_res.size()); rec_cnt.resize(inflight_res.size());

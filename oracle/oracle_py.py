@@ -40,7 +40,7 @@ def dpor_explore_reference_resident(model, externals, params, search, n_threads=
     vlen = C.c_uint32(0)
     stats = T.DporStats()
     counts = np.zeros(6, dtype=np.uint64)
-    secs = np.zeros(3, dtype=np.float64)
+    secs = np.zeros(8, dtype=np.float64)
     rc = H.harness_dpor_explore_reference_resident(C.byref(ms), ev.ctypes.data, len(ev), C.byref(params), C.byref(search),
                                                    n_threads or (os.cpu_count() or 1), verdicts.ctypes.data, plen.ctypes.data,
                                                    rounds.ctypes.data, vtrace.ctypes.data, C.byref(vlen), C.byref(stats), secs.ctypes.data, counts.ctypes.data)
@@ -69,7 +69,7 @@ def dpor_explore(model, externals, params, search, n_threads=None, resident=Fals
     vt = np.zeros(T.DPOR_MAX_TRACE, dtype=T.DPOR_TRACE_DTYPE)
     vl = C.c_uint32(0)
     stats = T.DporStats()
-    secs = np.zeros(3, dtype=np.float64)
+    secs = np.zeros(8, dtype=np.float64)
     args = [C.byref(ms), ev.ctypes.data, len(ev), C.byref(params), C.byref(search),
             n_threads or (os.cpu_count() or 1), verdicts.ctypes.data, plen.ctypes.data, rounds.ctypes.data,
             vt.ctypes.data, C.byref(vl), C.byref(stats), secs.ctypes.data]

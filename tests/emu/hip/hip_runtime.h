@@ -38,7 +38,7 @@ typedef void* hipModule_t;
 typedef void* hipFunction_t;      // -> a w64_kernel_entry of a module compiled by the emulator's hiprtc (tests/emu/hiprtc_emu.cpp)
 enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
 enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
-enum : unsigned { hipHostMallocDefault = 0, hipEventDisableTiming = 2 };
+enum : unsigned { hipHostMallocDefault = 0, hipHostMallocCoherent = 0x40000000u, hipEventDisableTiming = 2 };
 struct hipDeviceProp_t {
   char name[256];
   char gcnArchName[256];
