@@ -479,15 +479,23 @@ struct K3RefArgs {
   unsigned long long* counters;                       // [0] records wanted (may exceed recs_cap: the host grows and re-runs), [1] table full
 };
 
-// the commit's table: entries are written by k3_ref_apply (one writer per entry and launch) and read by k3_ref_filter
+// A state of the commit's table only grows AS A NUMBER: the explored bit is the top bit and is never cleared, the queued mark
+// below it is only replaced by a higher one (dpor_host.hpp RefBook::absorb).  So a change is merged with a maximum, and the
+// order in which batches of changes arrive - a launch's on its stream, a record fetch's on another - does not matter: an
+// entry never goes back to an older state.
+__device__ __forceinline__ void ref_state_merge(PairEntry* e, const RefDeltaDev& d) {
+  atomicMax(&e->state[0], d.state[0]);
+  atomicMax(&e->state[1], d.state[1]);
+}
+
+// the commit's table: entries are written by k3_ref_apply and by k3_ref_fetch's own blocks, and read by both filters
 __global__ __launch_bounds__(256) void k3_ref_apply(const K3RefArgs a) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.n_deltas) return;
   const RefDeltaDev d = a.deltas[i];
   const uint32_t s = pair_slot(a.real_table, a.real_mask, d.lo, d.hi);        // lo < hi: side 0
   if (s == 0xFFFFFFFFu) { atomicAdd(&a.counters[1], 1ull); return; }
-  a.real_table[s >> 1].state[0] = d.state[0];
-  a.real_table[s >> 1].state[1] = d.state[1];
+  ref_state_merge(a.real_table + (s >> 1), d);
 }
 
 // read-only lookup: the states of (a, b) and of its flip, 0 / 0 when the pair has no entry
@@ -638,8 +646,7 @@ __global__ __launch_bounds__(256) void k3_ref_fetch(const K3FetchArgs a) {
       const RefDeltaDev d = a.deltas[i];
       const uint32_t s = pair_slot(a.real_table, a.real_mask, d.lo, d.hi);        // lo < hi: side 0
       if (s == 0xFFFFFFFFu) { atomicAdd(&a.counter[1], 1ull); continue; }
-      a.real_table[s >> 1].state[0] = d.state[0];
-      a.real_table[s >> 1].state[1] = d.state[1];
+      ref_state_merge(a.real_table + (s >> 1), d);
     }
     if (a.spins) {
       __threadfence();                                   // this block's entries are the device's before it says so

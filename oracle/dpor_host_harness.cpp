@@ -70,8 +70,10 @@ struct SimDev {
   // survivors stay "with the device", per arena id
   void apply_deltas(const demi_host::RefDelta* deltas, uint32_t n_deltas) {
     for (uint32_t i = 0; i < n_deltas; i++) {
-      real_tab[{deltas[i].lo, deltas[i].hi}] = deltas[i].state[0];
-      real_tab[{deltas[i].hi, deltas[i].lo}] = deltas[i].state[1];
+      uint32_t& f = real_tab[{deltas[i].lo, deltas[i].hi}];      // (merged with a maximum, as k3_pairs.hpp ref_state_merge does:
+      uint32_t& r = real_tab[{deltas[i].hi, deltas[i].lo}];      //  a state only grows as a number)
+      f = std::max(f, deltas[i].state[0]);
+      r = std::max(r, deltas[i].state[1]);
     }
   }
   bool noop(uint64_t ke, uint64_t kl, uint32_t branch) const {
@@ -107,6 +109,27 @@ struct SimDev {
     }
     return 0;
   }
+  // the two-step form the host loop uses: the work happens at begin, the results are handed over at end
+  struct PendRound { bool active = false; uint32_t n = 0; int rc = 0; std::vector<demi_verdict> vd; std::vector<demi::DporPoint> pts; std::vector<demi::DporKill> kills; std::vector<uint32_t> rec_cnt; } pend;
+  int round_ref_begin(const demi::DporItem* items, const uint8_t* use_parent, uint32_t n, uint32_t round_no, uint32_t base_id,
+                      const demi_host::RefDelta* deltas, uint32_t n_deltas) {
+    if (pend.active) return DEMI_ERR_INVALID_ARG;
+    pend.vd.assign(n, demi_verdict{}); pend.rec_cnt.assign(n, 0u); pend.pts.clear(); pend.kills.clear();
+    pend.rc = round_ref(items, use_parent, n, round_no, base_id, deltas, n_deltas, pend.vd.data(), pend.pts, pend.kills, pend.rec_cnt.data());
+    pend.active = true; pend.n = n;
+    return 0;
+  }
+  bool round_ref_done() const { return true; }
+  int round_ref_end(demi_verdict* vd, std::vector<demi::DporPoint>& pts, std::vector<demi::DporKill>& kills, uint32_t* rec_cnt) {
+    if (!pend.active) return DEMI_ERR_INVALID_ARG;
+    pend.active = false;
+    if (pend.rc) return pend.rc;
+    memcpy(vd, pend.vd.data(), sizeof(demi_verdict) * pend.n);
+    memcpy(rec_cnt, pend.rec_cnt.data(), 4 * (size_t)pend.n);
+    pts = pend.pts; kills = pend.kills;
+    return 0;
+  }
+  void round_ref_abort() { pend.active = false; }
   // ResidentDev::ref_fetch restated: the held records of `ids`, filtered again under the table as of now
   int ref_fetch(const uint32_t* ids, uint32_t m, const demi_host::RefDelta* deltas, uint32_t n_deltas, uint64_t* rec_off,
                 uint32_t* rec_cnt, const demi_host::RefRec** recs_out) {
