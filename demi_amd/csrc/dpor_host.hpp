@@ -1471,13 +1471,13 @@ class RefBook {
   std::vector<std::pair<uint64_t, uint64_t>> dirty_;
 };
 
-// dev.round_ref_begin(items, use_parent, n, round, base_id, deltas, n_deltas) / dev.round_ref_done() /
+// dev.round_ref_begin(items, use_parent, n, round, base_id, deltas, n_deltas) /
 // dev.round_ref_end(verdicts, points, kills, rec_cnt) / dev.round_ref_abort()          (one launch in flight at a time):
 //   one launch like dev.round() of the ROUNDS path (K3 + the speculation's mark / insert / decide), plus: the deltas applied to
 //   the device's copy of the commit's table first, and afterwards the commit filter - interleaving i keeps rec_cnt[i] racing
 //   pairs as records, in pair order, WITH THE DEVICE (keyed by its arena id base_id + i); use_parent[i] says whether its
-//   parent's trace may be used for (a).  begin starts it and returns; done says, without waiting, whether it has finished; end
-//   waits and hands the results over; abort waits and drops them.  Record fetches may run while a launch is in flight.
+//   parent's trace may be used for (a).  begin enqueues it and returns; end waits and hands the results over; abort waits and
+//   drops them.
 // dev.ref_fetch_begin(ids, m, deltas, n_deltas) / dev.ref_fetch_end(rec_off, rec_cnt, &recs)   (one fetch in flight at a time):
 //   the commit is about to absorb the interleavings `ids` (arena ids, the first one right now, the others probably next):
 //   their records, filtered AGAIN under the table as it is now (the deltas first) - rule (b) holds for any older state, and a
@@ -1505,8 +1505,7 @@ int explore_reference_resident(Dev&& dev, const demi_dpor_search* srch, demi_ver
   };
   // (`seconds`, a diagnostic, is 8 doubles here: [0..2] as in the other loops, [3] naming the fetches (host), [4] the device's part of them, [5] the host's work after a launch, [6] before one)
   // fetched: its records have been ASKED for (a fetch names it); ready: they are here (nothing to fetch: both from the start)
-  // run: the launch that computes it is back (an interleaving is entered when its launch is STARTED)
-  struct Result { uint32_t id; demi_verdict verdict; const RefRec* recs; uint32_t rec_cnt; bool fetched, ready, run; };
+  struct Result { uint32_t id; demi_verdict verdict; const RefRec* recs; uint32_t rec_cnt; bool fetched, ready; };
   FlatKeyMap<Result> results;                            // every interleaving run so far, by its item; its surviving racing
                                                          // pairs stay where the device's copy put them (dev owns that memory)
   std::vector<uint8_t> complete;                         // per arena id: invariant (I) of ParentFilter holds (see there)
@@ -1538,20 +1537,19 @@ int explore_reference_resident(Dev&& dev, const demi_dpor_search* srch, demi_ver
   // a PCIe read of the request, the answer's writes, the event), so ONE fetch ahead cannot hide it and each further one costs more
   // stale records.  Off by default (DEMI_DPOR_PREFETCH=1 turns it on); the split into begin / end stays.
   const bool no_prefetch = demi_host::knob("DEMI_DPOR_PREFETCH") == nullptr;
-  // The speculation does not depend on the commit: its next round is started the moment the last one is back, on the launches'
-  // own stream, and runs while the commit works through what it has (fetching records on another stream).  Off:
-  // DEMI_DPOR_SYNC_LAUNCHES (every launch waited for where it is started - and started only when the commit lacks a result).
-  const bool eager = demi_host::knob("DEMI_DPOR_SYNC_LAUNCHES") == nullptr;
+  // Measured and not kept (round 5, profiles/r05_call15_reference_eager_rounds_ab.txt): the speculation's next round started the
+  // moment the last one is back, on a stream of its own beside the record fetches.  The commit is depth-first - after a handful
+  // of steps it stands at a descendant that only the speculation's LAST rounds produce - so it waits for the rounds one after
+  // the other all the same (13 ms of launches either way), and the rounds' kernels and the fetches slow each other down
+  // (kernels 11.3 -> 13.5 ms): 1.10·10⁶/s against 1.09-1.12.  A launch is started when the commit lacks a result, and waited for.
   uint32_t base_id = 0, round = 0, fl_base = 0;
-  bool fl_active = false;                                 // a launch is in flight: items / use_parent / launch_res are its
   uint64_t first_id = ~0ull;
   const size_t fetch_width = ref_fetch_width();
-  struct Drain { Dev& dev; bool& active; ~Drain() { if (active) dev.round_ref_abort(); } } drain{dev, fl_active};
 
-  // start a launch: (the interleaving the commit stands at + its queue's front, if asked) + the speculation's next round,
-  // minus what has been entered already.  Every item gets its entry in `results` right away (filled in when the launch is
-  // back): one table operation per item, and an interleaving that is already there is not run again.
-  auto begin_launch = [&](bool with_front) -> int {
+  // start a launch: the interleaving the commit stands at + its queue's front + the speculation's next round, minus what has
+  // been run already.  Every item gets its entry in `results` right away (filled in when the launch is back): one table
+  // operation per item, and an interleaving that is already there is not run again.
+  auto begin_launch = [&]() -> int {
     const double tb = now();
     items.clear(); launch_res.clear();
     auto add = [&](const demi::DporItem& q) {
@@ -1559,18 +1557,16 @@ int explore_reference_resident(Dev&& dev, const demi_dpor_search* srch, demi_ver
       Result& r = results.at(key_of(q), fresh);
       if (fresh) { items.push_back(q); launch_res.push_back(&r); }
     };
-    if (with_front) {
-      add(cur);
-      // the commit's own queue front: what it will most likely dequeue next (the speculation explores in rounds and runs out
-      // long before the commit does; without this every later interleaving would be a launch of its own)
-      peeked_items.clear();
-      real.peek(srch->batch / 4 + 1, [&](const RefBook::Point& p) {
-        const demi::DporItem q{p.src, p.branch, p.later, p.earlier, 0};
-        results.prefetch(key_of(q));
-        peeked_items.push_back(q);
-      });
-      for (const demi::DporItem& q : peeked_items) add(q);
-    }
+    add(cur);
+    // the commit's own queue front: what it will most likely dequeue next (the speculation explores in rounds and runs out
+    // long before the commit does; without this every later interleaving would be a launch of its own)
+    peeked_items.clear();
+    real.peek(srch->batch / 4 + 1, [&](const RefBook::Point& p) {
+      const demi::DporItem q{p.src, p.branch, p.later, p.earlier, 0};
+      results.prefetch(key_of(q));
+      peeked_items.push_back(q);
+    });
+    for (const demi::DporItem& q : peeked_items) add(q);
     {
       constexpr size_t AHEAD = 12;
       const size_t ns = spec_items.size();
@@ -1585,9 +1581,7 @@ int explore_reference_resident(Dev&& dev, const demi_dpor_search* srch, demi_ver
     if (!n) return 0;
     use_parent.resize(n);
     for (uint32_t i = 0; i < n; i++) use_parent[i] = items[i].src != 0xFFFFFFFFu && items[i].src < complete.size() && complete[items[i].src];
-    // (the table's changes so far travel with every launch; a round started on its own runs beside the record fetches,
-    // which carry later changes on another stream - the device merges a change with a maximum, so their order is free)
-    real.take_deltas(deltas);
+    real.take_deltas(deltas);                          // (the table's changes so far travel with the launch)
     round++;
     if (seconds) seconds[6] += now() - tb;
     int rc = dev.round_ref_begin(items.data(), use_parent.data(), n, round, base_id, deltas.data(), (uint32_t)deltas.size());
@@ -1595,23 +1589,22 @@ int explore_reference_resident(Dev&& dev, const demi_dpor_search* srch, demi_ver
     if (out_rounds && stats->launches < srch->max_interleavings) out_rounds[stats->launches] = n;
     stats->launches++;
     stats->executed += n;
-    fl_base = base_id; fl_active = true;
+    fl_base = base_id;
     base_id += dev.ids_used(n);
     return 0;
   };
-  // wait for the launch in flight and take its results in; then (next_round) start the speculation's next round right away
-  auto land_launch = [&](bool next_round) -> int {
+  // wait for the launch in flight and take its results in
+  auto land_launch = [&]() -> int {
     const double tl = now();
     const uint32_t n = (uint32_t)items.size();
     vd.resize(n); rec_cnt.resize(n);
     pts.clear(); kills.clear();
     int rc = dev.round_ref_end(vd.data(), pts, kills, rec_cnt.data());
-    fl_active = false;
     if (rc) return rc;
     const double t2 = now();
     if (complete.size() < (size_t)fl_base + n) complete.resize((size_t)fl_base + n, 0);
     for (uint32_t i = 0; i < n; i++) {
-      *launch_res[i] = Result{fl_base + i, vd[i], nullptr, 0u, rec_cnt[i] == 0, rec_cnt[i] == 0, true};   // (nothing to fetch: as good as here)
+      *launch_res[i] = Result{fl_base + i, vd[i], nullptr, 0u, rec_cnt[i] == 0, rec_cnt[i] == 0};   // (nothing to fetch: as good as here)
       // (I) holds for this interleaving once it is absorbed iff its own pair list is whole and (I) held for its parent
       complete[(size_t)fl_base + i] = !(vd[i].flags & DEMI_V_PAIRS_OVF) && (items[i].src == 0xFFFFFFFFu || use_parent[i]);
     }
@@ -1640,19 +1633,16 @@ int explore_reference_resident(Dev&& dev, const demi_dpor_search* srch, demi_ver
       spec_items.push_back(demi::DporItem{p.src, p.branch, p.later, p.earlier, 0});
     }
     if (seconds) { const double t3 = now(); seconds[0] += t2 - tl; seconds[1] += t3 - t2; seconds[5] += t3 - t2; }
-    // (the speculation may run ahead of the commit by a few rounds' worth of arena rows, no further)
-    if (next_round && eager && !spec_items.empty() && stats->executed - stats->interleavings < 8ull * srch->batch) return begin_launch(false);
     return 0;
   };
 
   while (!done) {
     // ---- commit, one interleaving at a time, as far as computed results reach
     double t0 = now();
-    bool need_fetch = false, need_land = false;
+    bool need_fetch = false;
     while (have_cur) {
       const Result* it = results.find(key_of(cur));
       if (!it) break;
-      if (!it->run) { need_land = true; break; }
       if (!it->ready) { need_fetch = true; break; }
       const Result& r = *it;
       const uint64_t idx = stats->interleavings++;
@@ -1699,7 +1689,7 @@ int explore_reference_resident(Dev&& dev, const demi_dpor_search* srch, demi_ver
       });
       for (const uint64_t k : peeked) {
         Result* it = results.find(k);
-        if (!it || !it->run || it->fetched) continue;          // (not run yet, or still running: nothing to fetch)
+        if (!it || it->fetched) continue;
         it->fetched = true;
         fetch_ids.push_back(it->id); fetch_res.push_back(it);
       }
@@ -1739,26 +1729,16 @@ int explore_reference_resident(Dev&& dev, const demi_dpor_search* srch, demi_ver
       // ... and, while the commit absorbs them, those of the interleavings its queue will most likely hand out after this window
       if (!no_prefetch) { rc = issue(false); if (rc) return rc; }
       if (seconds) seconds[1] += now() - t1;
-      // the speculation's round in flight, if it has finished meanwhile: in, and the next one out
-      if (fl_active && dev.round_ref_done()) { rc = land_launch(true); if (rc) return rc; }
       continue;
     }
-    { int rc = land(); if (rc) return rc; }         // (a launch may send the table's changes too: one stream of deltas, in order)
-    if (need_land) {
-      // ---- the commit stands at an interleaving of the launch in flight
-      int rc = land_launch(true);
-      if (rc) return rc;
-      continue;
-    }
-    // ---- the commit stands at an interleaving nobody has entered: a launch of its own (with the queue's front and the
-    // speculation's next round), waited for here
-    if (fl_active) { int rc = land_launch(false); if (rc) return rc; }
+    // ---- one launch: what the commit is waiting for + its queue's front + the speculation's next round (minus what has been
+    // run already)
+    { int rc = land(); if (rc) return rc; }         // (the launch sends the table's changes too)
     stats->cache_misses++;
-    int rc = begin_launch(true);
-    if (!rc) rc = land_launch(true);
-    if (rc) return rc;
+    int rc = begin_launch();
+    if (!rc) rc = land_launch();
+    if (rc) { dev.round_ref_abort(); return rc; }          // (nothing of a failed launch stays in flight)
   }
-  if (fl_active) { dev.round_ref_abort(); fl_active = false; }       // (a round nobody needs any more: still waited for - its kernels use the device's buffers)
   if (inflight) {                                          // (an answer nobody needs any more: still waited for - it writes host memory)
     rec_off.resize(inflight_res.size()); rec_cnt.resize(inflight_res.size());
     const RefRec* recs = nullptr;

@@ -607,29 +607,26 @@ __global__ __launch_bounds__(256) void k3_ref_filter(const K3RefArgs a) {
 // most likely hand out next; rule (b) is applied AGAIN, under the table as the commit has made it by now (the host sends the
 // entries that changed first).  The same monotonicity argument holds, so what is dropped here is a no-op for the commit too -
 // and by now that is most of what a wide launch had to keep.  One workgroup per interleaving; survivors in pair order.
-// ids / out / out_off / out_cnt are pinned host memory mapped into the device's address space: the launch reads its request
-// and writes its answer across PCIe itself - no copies.
-// ONE launch per fetch (round 5): the table's changes used to be a launch of their own (k3_ref_apply) in front of this one.  Now
-// block j applies its slice of the deltas, the blocks meet at a barrier (an arrival counter in device memory; every block of a
-// fetch is resident - at most one per CU - and the wait is BOUNDED: a block that gives up filters under a table that lacks some
-// of this fetch's deltas, which is rule (b) under an older state - more records, the same commit), and then filter.  The
-// answer's last writer (an arrival counter again) raises a flag in host memory that the host polls: no event, no interrupt.
-constexpr uint32_t FETCH_INLINE_IDS = 160;                  // a request this short travels in the kernel's arguments
+// out / out_off / out_cnt are pinned host memory mapped into the device's address space: the launch writes its answer across
+// PCIe itself, so a fetch costs two launches (k3_ref_apply in front of this one) and one synchronisation, no copies; a request
+// of up to FETCH_INLINE_IDS interleavings travels in the kernel's arguments, a longer one is read from pinned memory.
+// Measured and not kept (round 5, profiles/r05_call14_fetch_one_launch_ab.txt, r05_call15_reference_eager_rounds_ab.txt): the
+// table's changes applied by this kernel's own blocks - with a barrier between applying and filtering the fetch's device time
+// goes from 13.7 to 19.0 ms (the barrier's atomics cross the chip), without one to 12.1 ms but a block then filters under a
+// table that lacks other blocks' changes and 11 % more records cross PCIe -; the answer's last block raising a flag the host
+// polls instead of an event (13.7 against 13.5 ms).
+constexpr uint32_t FETCH_INLINE_IDS = 160;
 
 struct K3FetchArgs {
-  PairEntry* real_table; uint32_t real_mask;
+  const PairEntry* real_table; uint32_t real_mask;
   const uint32_t* ids; uint32_t m;                          // arena ids of the interleavings asked for (null: ids_inline)
   const RefRecDev* pool;                                    // every record kept so far
   const unsigned long long* pool_off; const uint32_t* pool_cnt;   // per arena id
   RefRecDev* out;                                           // room for the sum of pool_cnt[ids]
   unsigned long long* out_off; uint32_t* out_cnt;           // [m]
-  unsigned long long* counter; unsigned long long counter_base;   // [0] running total of records handed out, [1] "table full"
-                                                                  // count, [2] barrier arrivals, [3] finished blocks (device memory)
+  unsigned long long* counter; unsigned long long counter_base;   // [0] running total of records handed out, [1] k3_ref_apply's
+                                                                  // "table full" count (device memory)
   unsigned long long* table_full_out;                       // counter[1], passed on to the host
-  const RefDeltaDev* deltas; uint32_t n_deltas;             // applied by this launch (0: k3_ref_apply ran in front of it)
-  uint32_t spins;                                           // how often a block looks for the others at the barrier (0: no barrier)
-  unsigned long long bar_target, done_target;               // counter[2] / counter[3] once every block of this fetch has arrived
-  unsigned long long* flag_out; unsigned long long seq;     // host memory: = seq once the whole answer is there (null: the host waits for the stream)
   uint32_t ids_inline[FETCH_INLINE_IDS];
 };
 
@@ -637,31 +634,13 @@ __global__ __launch_bounds__(256) void k3_ref_fetch(const K3FetchArgs a) {
   __shared__ uint32_t s_keep[128], s_pre[129];
   __shared__ unsigned long long s_off;
   const uint32_t j = blockIdx.x, t = threadIdx.x;
+  if (j == 0 && t == 0) *a.table_full_out = a.counter[1];
   const uint32_t id = a.ids ? a.ids[j] : a.ids_inline[j];
-  const unsigned long long p_off = a.pool_off[id];
+  const RefRecDev* R = a.pool + a.pool_off[id];
   const uint32_t n = min(a.pool_cnt[id], 4096u);
-  for (uint32_t i = t; i < 128; i += blockDim.x) s_keep[i] = 0;
-  if (a.n_deltas) {
-    for (uint32_t i = j * blockDim.x + t; i < a.n_deltas; i += gridDim.x * blockDim.x) {
-      const RefDeltaDev d = a.deltas[i];
-      const uint32_t s = pair_slot(a.real_table, a.real_mask, d.lo, d.hi);        // lo < hi: side 0
-      if (s == 0xFFFFFFFFu) { atomicAdd(&a.counter[1], 1ull); continue; }
-      ref_state_merge(a.real_table + (s >> 1), d);
-    }
-    if (a.spins) {
-      __threadfence();                                   // this block's entries are the device's before it says so
-      __syncthreads();
-      if (t == 0) {
-        atomicAdd(&a.counter[2], 1ull);
-        for (uint32_t k = 0; k < a.spins && __hip_atomic_load(&a.counter[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.bar_target; k++)
-          __builtin_amdgcn_s_sleep(1);
-      }
-      __syncthreads();
-      __threadfence();                                   // ... and the others' entries are read from the device, not from a stale line
-    }
-  }
+  const uint32_t words = (n + 31) >> 5;                     // (an interleaving holds ~10^2 records: a few words of keep bits)
+  for (uint32_t i = t; i < words; i += blockDim.x) s_keep[i] = 0;
   __syncthreads();
-  const RefRecDev* R = a.pool + p_off;
   for (uint32_t k = t; k < n; k += blockDim.x) {
     uint32_t sf, sr;
     pair_states(a.real_table, a.real_mask, R[k].ke, R[k].kl, sf, sr);
@@ -671,8 +650,7 @@ __global__ __launch_bounds__(256) void k3_ref_fetch(const K3FetchArgs a) {
   __syncthreads();
   if (t == 0) {
     uint32_t tot = 0;
-    for (uint32_t w = 0; w < 128; w++) { s_pre[w] = tot; tot += (uint32_t)__popc(s_keep[w]); }
-    s_pre[128] = tot;
+    for (uint32_t w = 0; w < words; w++) { s_pre[w] = tot; tot += (uint32_t)__popc(s_keep[w]); }
     s_off = atomicAdd(a.counter, (unsigned long long)tot) - a.counter_base;
     a.out_off[j] = s_off;
     a.out_cnt[j] = tot;
@@ -683,15 +661,6 @@ __global__ __launch_bounds__(256) void k3_ref_fetch(const K3FetchArgs a) {
     const uint32_t w = s_keep[k >> 5];
     if (!((w >> (k & 31)) & 1u)) continue;
     a.out[off + s_pre[k >> 5] + (uint32_t)__popc(w & ((1u << (k & 31)) - 1u))] = R[k];
-  }
-  if (a.flag_out) __threadfence_system();                // this block's part of the answer is in host memory ...
-  __syncthreads();
-  if (t == 0 && atomicAdd(&a.counter[3], 1ull) + 1 == a.done_target) {           // ... and the last block to get here says so
-    *a.table_full_out = __hip_atomic_load(&a.counter[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (a.flag_out) {
-      __threadfence_system();
-      __hip_atomic_store(a.flag_out, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
   }
 }
 

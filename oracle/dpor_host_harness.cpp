@@ -119,7 +119,6 @@ struct SimDev {
     pend.active = true; pend.n = n;
     return 0;
   }
-  bool round_ref_done() const { return true; }
   int round_ref_end(demi_verdict* vd, std::vector<demi::DporPoint>& pts, std::vector<demi::DporKill>& kills, uint32_t* rec_cnt) {
     if (!pend.active) return DEMI_ERR_INVALID_ARG;
     pend.active = false;

@@ -38,7 +38,7 @@ typedef void* hipModule_t;
 typedef void* hipFunction_t;      // -> a w64_kernel_entry of a module compiled by the emulator's hiprtc (tests/emu/hiprtc_emu.cpp)
 enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
 enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
-enum : unsigned { hipHostMallocDefault = 0, hipHostMallocCoherent = 0x40000000u, hipEventDisableTiming = 2 };
+enum : unsigned { hipHostMallocDefault = 0, hipEventDisableTiming = 2 };
 struct hipDeviceProp_t {
   char name[256];
   char gcnArchName[256];
@@ -83,10 +83,6 @@ static inline hipError_t hipMemset(void* d, int v, size_t n) { if (n) memset(d, 
 static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t = nullptr) { if (n) memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
-enum : unsigned { hipStreamNonBlocking = 1 };
-static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return hipSuccess; }
-static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
-static inline hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned = 0) { return hipSuccess; }
 static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new w64_event{0.0}; return hipSuccess; }
 static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }

@@ -94,8 +94,6 @@ template <class T> static inline T w64_shfl_up_(T v, unsigned d, int line) {
 #define __builtin_amdgcn_fence(ORDER, SCOPE) __atomic_thread_fence(__ATOMIC_SEQ_CST)
 static inline void __threadfence_block() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
-static inline void __threadfence_system() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
-static inline void __builtin_amdgcn_s_sleep(int) {}
 
 // ------------------------------------------------------------------ integer builtins
 template <class T> static inline T min(T a, T b) { return b < a ? b : a; }      // (HIP's global min / max)
