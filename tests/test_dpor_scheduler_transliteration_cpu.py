@@ -342,6 +342,12 @@ class ScalaDPORwHeuristics:
         return False
 
 
+def _config3(cap):
+    from demi_amd.apps import raft5_config3
+    model, ev, depth = raft5_config3()
+    return model, ev, depth, 0, cap
+
+
 CASES = {
     "writers4": lambda: (writers_model(4), events_to_array([start(a) for a in range(5)] + [send(a, 0) for a in range(1, 5)]), 0, 0, 2500),
     "raft3": lambda: (M.raft_model(3), events_to_array([start(a) for a in range(3)] + [send(a, M.M_BOOTSTRAP) for a in range(3)]), 30, 0, 300),
@@ -349,6 +355,9 @@ CASES = {
                                   wait_quiescence(), send(1, M.M_BOOTSTRAP), send(2, M.M_BOOTSTRAP)]), 24, 0, 300),
     # DEMI_MODEL_ARRAY: the replicated log (rows LDX / STX, an invariant program that reads the log)
     "replog3_arrays": lambda: (M.replog_model(3, 4, True, False), events_to_array([start(a) for a in range(3)] + [send(0, M.RL_PUT, 9, 0), send(1, M.RL_PUT, 8, 0), send(0, M.RL_PUT, 7, 0)]), 40, 0, 400),
+    # BASELINE config 3, its first interleavings (the whole exploration - 60 332, most of an hour in this Python - is what
+    # tools/check_golden_dpor_transliteration.py runs; its record: tests/golden/dpor_config3_transliteration.json)
+    "raft5_config3_first_250": lambda: _config3(250),
     "raft3_late_start_and_cap": lambda: (M.raft_model(3), events_to_array([start(0), start(1), send(0, M.M_BOOTSTRAP), send(1, M.M_BOOTSTRAP),
                                          wait_quiescence(), start(2), send(2, M.M_BOOTSTRAP)]), 20, 40, 300),
 }
