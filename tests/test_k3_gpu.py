@@ -659,3 +659,32 @@ def test_device_queue_edge_cases_against_the_host_bookkeeping(monkeypatch, max_p
         if stop:
             assert (dev[4].violations >= 1) == bool((dev[0]["flags"] & T.V_VIOLATION).any())
         ctx.close()
+
+
+@pytest.mark.gpu
+def test_a_round_with_more_points_than_the_staging_area_is_sorted_again(monkeypatch):
+    """The device-resident queue stages a round's backtrack points in an area sized for the largest round so far (2^21 points
+    to begin with); a round that produces more - config 5 past 6 million interleavings leaves 2.3 million in one round - is
+    sorted again into a larger area, from the decision the round has already made.  Here the area starts at two points
+    (DEMI_K3_POINTS_CAP), so it is outgrown many times over: the exploration is the one with the default area."""
+    from demi_amd import _native
+    from tests.test_dpor_cpu import writers_model
+    cases = [(writers_model(4), events_to_array([start(a) for a in range(5)] + [send(a, 0) for a in range(1, 5)]), 0, 900, 64),
+             (M.raft_model(3), events_to_array([start(a) for a in range(3)] + [send(a, M.M_BOOTSTRAP) for a in range(3)]), 30, 700, 37)]
+    monkeypatch.setenv("DEMI_EXPERIMENT", "1")
+    for model, ev, depth, budget, batch in cases:
+        par, srch = T.DporParams(depth, 0, 0, 0, 64, 4096), T.DporSearch(batch, budget, 0, 1, T.DPOR_ORDER_ROUNDS)
+        res = []
+        for cap in (None, "2"):
+            if cap is None:
+                monkeypatch.delenv("DEMI_K3_POINTS_CAP", raising=False)
+            else:
+                monkeypatch.setenv("DEMI_K3_POINTS_CAP", cap)
+            ctx = _native.Context(0)                     # (the area belongs to the context: a fresh one per setting)
+            ctx.model_load(model.to_struct())
+            ctx.dpor_load(ev)
+            res.append(ctx.dpor_explore(par, srch))
+            ctx.close()
+        a, b = res
+        assert len(a[0]) == len(b[0]) > 5 and (a[0] == b[0]).all() and (a[1] == b[1]).all() and (a[2] == b[2]).all()
+        assert a[4].backtrack_points == b[4].backtrack_points > 2 and a[4].queue_len == b[4].queue_len and a[4].exhausted == b[4].exhausted
