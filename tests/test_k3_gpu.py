@@ -688,3 +688,29 @@ def test_a_round_with_more_points_than_the_staging_area_is_sorted_again(monkeypa
         a, b = res
         assert len(a[0]) == len(b[0]) > 5 and (a[0] == b[0]).all() and (a[1] == b[1]).all() and (a[2] == b[2]).all()
         assert a[4].backtrack_points == b[4].backtrack_points > 2 and a[4].queue_len == b[4].queue_len and a[4].exhausted == b[4].exhausted
+
+
+@pytest.mark.gpu
+def test_config5_pipeline_in_reference_order_is_the_one_at_a_time_sequence(oracle):
+    """The three-job shuffle pipeline of config 5 (8 actors, 3 classes, ~1 800 racing pairs per interleaving) in the REFERENCE
+    order with a budget: the device-resident commit (speculation in rounds, record fetches, the commit filter's two passes)
+    returns the verdicts and prefix lengths of the oracle's exploration one backtrack point at a time, for two widths of the
+    speculation - a larger table than config 3's and a shape the commit was not tuned on."""
+    import os
+    from demi_amd import _native
+    from demi_amd.apps import shuffle8_config5_large
+    emu = os.environ.get("DEMI_EMU") == "1"
+    model, ev, depth, _budget = shuffle8_config5_large()
+    budget = 300 if emu else 6000
+    par = T.DporParams(depth, 0, 0, 0, 64, 4096)
+    one = oracle.dpor_explore(model, ev, par, T.DporSearch(1, budget, 0, 1, T.DPOR_ORDER_ROUNDS), n_threads=1)
+    assert len(one[0]) == budget
+    ctx = _native.Context(0)
+    ctx.model_load(model.to_struct())
+    ctx.model_specialize()
+    ctx.dpor_load(ev)
+    for batch in ((64,) if emu else (1024, 16384)):
+        v, pl, _r, _vt, st = ctx.dpor_explore(par, T.DporSearch(batch, budget, 0, 1, T.DPOR_ORDER_REFERENCE))
+        assert len(v) == budget and (v == one[0]).all() and (pl == one[1]).all(), batch
+        assert not st.exhausted and int(st.fetches) >= 1 and int(st.executed) >= budget
+    ctx.close()
