@@ -1471,12 +1471,13 @@ class RefBook {
   std::vector<std::pair<uint64_t, uint64_t>> dirty_;
 };
 
-// dev.round_ref_begin(items, use_parent, n, round, base_id, deltas, n_deltas) /
-// dev.round_ref_end(verdicts, points, kills, rec_cnt) / dev.round_ref_abort()          (one launch in flight at a time):
+// dev.round_ref_begin(items, use_parent, n, round, base_id, deltas, n_deltas, speculate) /
+// dev.round_ref_end(verdicts, points, kills, rec_cnt, &spec_overflow) / dev.round_ref_abort()   (one launch in flight at a time):
 //   one launch like dev.round() of the ROUNDS path (K3 + the speculation's mark / insert / decide), plus: the deltas applied to
 //   the device's copy of the commit's table first, and afterwards the commit filter - interleaving i keeps rec_cnt[i] racing
 //   pairs as records, in pair order, WITH THE DEVICE (keyed by its arena id base_id + i); use_parent[i] says whether its
-//   parent's trace may be used for (a).  begin enqueues it and returns; end waits and hands the results over; abort waits and
+//   parent's trace may be used for (a); speculate = false leaves the speculation's table and points out.  begin enqueues it and returns; end waits and hands the results over (spec_overflow:
+//   the speculation's own table or point area is full - its points are dropped, everything else stands); abort waits and
 //   drops them.
 // dev.ref_fetch_begin(ids, m, deltas, n_deltas) / dev.ref_fetch_end(rec_off, rec_cnt, &recs)   (one fetch in flight at a time):
 //   the commit is about to absorb the interleavings `ids` (arena ids, the first one right now, the others probably next):
@@ -1543,6 +1544,7 @@ int explore_reference_resident(Dev&& dev, const demi_dpor_search* srch, demi_ver
   // the other all the same (13 ms of launches either way), and the rounds' kernels and the fetches slow each other down
   // (kernels 11.3 -> 13.5 ms): 1.10·10⁶/s against 1.09-1.12.  A launch is started when the commit lacks a result, and waited for.
   uint32_t base_id = 0, round = 0, fl_base = 0;
+  bool spec_off = false;                                  // the speculation has stopped for good (its table is full)
   uint64_t first_id = ~0ull;
   const size_t fetch_width = ref_fetch_width();
 
@@ -1584,7 +1586,8 @@ int explore_reference_resident(Dev&& dev, const demi_dpor_search* srch, demi_ver
     real.take_deltas(deltas);                          // (the table's changes so far travel with the launch)
     round++;
     if (seconds) seconds[6] += now() - tb;
-    int rc = dev.round_ref_begin(items.data(), use_parent.data(), n, round, base_id, deltas.data(), (uint32_t)deltas.size());
+    int rc = dev.round_ref_begin(items.data(), use_parent.data(), n, round, base_id, deltas.data(), (uint32_t)deltas.size(),
+                                 !spec_off && stats->executed < srch->max_interleavings);
     if (rc) return rc;
     if (out_rounds && stats->launches < srch->max_interleavings) out_rounds[stats->launches] = n;
     stats->launches++;
@@ -1599,8 +1602,14 @@ int explore_reference_resident(Dev&& dev, const demi_dpor_search* srch, demi_ver
     const uint32_t n = (uint32_t)items.size();
     vd.resize(n); rec_cnt.resize(n);
     pts.clear(); kills.clear();
-    int rc = dev.round_ref_end(vd.data(), pts, kills, rec_cnt.data());
+    bool spec_overflow = false;
+    int rc = dev.round_ref_end(vd.data(), pts, kills, rec_cnt.data(), &spec_overflow);
     if (rc) return rc;
+    if (spec_overflow) {                     // the speculation's own table (or a round's point area) is full: it guesses no further
+      spec_off = true;
+      for (std::deque<demi::DporPoint>& b : bucket) b.clear();
+      top = -1;
+    }
     const double t2 = now();
     if (complete.size() < (size_t)fl_base + n) complete.resize((size_t)fl_base + n, 0);
     for (uint32_t i = 0; i < n; i++) {
@@ -1623,7 +1632,9 @@ int explore_reference_resident(Dev&& dev, const demi_dpor_search* srch, demi_ver
       bucket[p.branch].push_back(p);
       if ((int)p.branch > top) top = (int)p.branch;
     }
-    while (spec_items.size() < srch->batch) {
+    // (a budgeted exploration: once as many interleavings have been run as the commit may take, the speculation stops - what the
+    // commit still lacks comes from its own queue's front)
+    while (!spec_off && spec_items.size() < srch->batch && stats->executed + spec_items.size() < srch->max_interleavings) {
       while (top >= 0 && bucket[top].empty()) top--;
       if (top < 0) break;
       const demi::DporPoint p = bucket[top].front();

@@ -112,14 +112,16 @@ struct SimDev {
   // the two-step form the host loop uses: the work happens at begin, the results are handed over at end
   struct PendRound { bool active = false; uint32_t n = 0; int rc = 0; std::vector<demi_verdict> vd; std::vector<demi::DporPoint> pts; std::vector<demi::DporKill> kills; std::vector<uint32_t> rec_cnt; } pend;
   int round_ref_begin(const demi::DporItem* items, const uint8_t* use_parent, uint32_t n, uint32_t round_no, uint32_t base_id,
-                      const demi_host::RefDelta* deltas, uint32_t n_deltas) {
+                      const demi_host::RefDelta* deltas, uint32_t n_deltas, bool speculate) {
     if (pend.active) return DEMI_ERR_INVALID_ARG;
+    (void)speculate;                                    // (always: this table never fills)
     pend.vd.assign(n, demi_verdict{}); pend.rec_cnt.assign(n, 0u); pend.pts.clear(); pend.kills.clear();
     pend.rc = round_ref(items, use_parent, n, round_no, base_id, deltas, n_deltas, pend.vd.data(), pend.pts, pend.kills, pend.rec_cnt.data());
     pend.active = true; pend.n = n;
     return 0;
   }
-  int round_ref_end(demi_verdict* vd, std::vector<demi::DporPoint>& pts, std::vector<demi::DporKill>& kills, uint32_t* rec_cnt) {
+  int round_ref_end(demi_verdict* vd, std::vector<demi::DporPoint>& pts, std::vector<demi::DporKill>& kills, uint32_t* rec_cnt, bool* spec_overflow) {
+    if (spec_overflow) *spec_overflow = false;          // (this table is a map: it never fills)
     if (!pend.active) return DEMI_ERR_INVALID_ARG;
     pend.active = false;
     if (pend.rc) return pend.rc;

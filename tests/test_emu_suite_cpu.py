@@ -94,6 +94,7 @@ def test_k3_and_provenance_sources_against_the_oracle_on_the_cpu():
                   "test_k3_gpu.py::test_reference_order_with_the_record_fetch_in_flight",
                   "test_k3_gpu.py::test_a_round_with_more_points_than_the_staging_area_is_sorted_again",
                   "test_k3_gpu.py::test_config5_pipeline_in_reference_order_is_the_one_at_a_time_sequence",
+                  "test_k3_gpu.py::test_reference_order_when_the_speculations_table_is_full",
                   "test_k3_gpu.py::test_checkpointed_interleavings_are_the_same_interleavings",
                   "test_k3_gpu.py::test_device_queue_edge_cases_against_the_host_bookkeeping",
                   "test_provenance_gpu.py"], threads=1)

@@ -714,3 +714,30 @@ def test_config5_pipeline_in_reference_order_is_the_one_at_a_time_sequence(oracl
         assert len(v) == budget and (v == one[0]).all() and (pl == one[1]).all(), batch
         assert not st.exhausted and int(st.fetches) >= 1 and int(st.executed) >= budget
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_reference_order_when_the_speculations_table_is_full(oracle, monkeypatch):
+    """In the REFERENCE order the device's explored-pair table only steers the speculation (which interleavings to run before the
+    commit asks for them); the commit has its own.  A budgeted exploration can outrun a table sized for the budget - config 5
+    with a budget of 6 000 did -: the speculation then stops, its table's kernels are left out of the launches, and the commit
+    goes on from its own queue's front.  Here the table has 64 entries (DEMI_K3_TABLE_ENTRIES): the committed sequence is the
+    one-at-a-time exploration's all the same."""
+    from demi_amd import _native
+    model = M.raft_model(3)
+    ev = events_to_array([start(a) for a in range(3)] + [send(a, M.M_BOOTSTRAP) for a in range(3)])
+    par, budget = T.DporParams(30, 0, 0, 0, 64, 4096), 900
+    one = oracle.dpor_explore(model, ev, par, T.DporSearch(1, budget, 0, 1, T.DPOR_ORDER_ROUNDS), n_threads=1)
+    monkeypatch.setenv("DEMI_EXPERIMENT", "1")
+    monkeypatch.setenv("DEMI_K3_TABLE_ENTRIES", "64")
+    ctx = _native.Context(0)
+    ctx.model_load(model.to_struct())
+    ctx.dpor_load(ev)
+    for batch in (16, 256):
+        v, pl, _r, _vt, st = ctx.dpor_explore(par, T.DporSearch(batch, budget, 0, 1, T.DPOR_ORDER_REFERENCE))
+        assert len(v) == len(one[0]) and (v == one[0]).all() and (pl == one[1]).all(), batch
+        assert bool(st.exhausted) == bool(one[4].exhausted)
+    # (the ROUNDS order NEEDS that table: there a full one ends the exploration with an error)
+    with pytest.raises(_native.DemiError, match="table full"):
+        ctx.dpor_explore(par, T.DporSearch(64, budget, 0, 1, T.DPOR_ORDER_ROUNDS))
+    ctx.close()
