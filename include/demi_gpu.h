@@ -626,7 +626,12 @@ typedef struct {
 } demi_dpor_stats;
 
 /* out_verdicts / out_prefix_len: [max_interleavings], in execution order.  first_violation_trace:
- * [DEMI_DPOR_MAX_TRACE] (may be NULL).  out_rounds: launch sizes, [max_interleavings] (may be NULL). */
+ * [DEMI_DPOR_MAX_TRACE] (may be NULL).  out_rounds: launch sizes, [max_interleavings] (may be NULL).
+ * Device memory follows the budget: 4 KB of trace arena per interleaving run, the explored-pair table (128 entries of 64 B per
+ * interleaving of the budget: at most 4 GB up to 2^21 interleavings, 16 GB beyond), checkpoint records for as many interleavings
+ * as a quarter of the free memory holds.  DEMI_ERR_CAPACITY: the explored-pair table is full (ROUNDS order; in the REFERENCE order
+ * the device's table only steers the speculation, which then stops), or - several ranks - a round left more than 2^21 backtrack
+ * points (on one rank the area they are staged in grows).  Measured on one MI355X: 2^24 interleavings of config 5 in 2.9 s. */
 int demi_dpor_explore(demi_ctx* ctx, const demi_dpor_params* params, const demi_dpor_search* search,
                       demi_verdict* out_verdicts, uint32_t* out_prefix_len, uint32_t* out_rounds,
                       demi_dpor_trace_entry* first_violation_trace, uint32_t* first_violation_len,
