@@ -25,3 +25,10 @@ python -c "
 import json
 for w in ('config5','dpor','ddmin'):
     d=json.load(open('gpurun_out/r05_%s_counters.json' % w)); print(w, {k: d[k] for k in d if k.startswith('fabric')})"
+# beyond the sizes the bench line runs (no profile, one line each): 2^24 schedules per K1 launch, config 5 with a budget of 2^23
+timeout 300 python bench.py --schedules 16777216 --steps 2 --warmup 1 --no-secondary --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('K1 2^24 schedules per launch: %.4g/s %.2f ms per step' % (d['value'], d['ms_per_step']))" || echo "K1 2^24: failed"
+timeout 300 python bench.py --workload config5 --no-cpu-baseline --config5-budget 8388608 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('config 5, budget 2^23: %.4g/s %.3f s digest %s' % (d['value'], d['seconds'], d['sequence_digest']))" || echo "config 5 2^23: failed"
