@@ -704,6 +704,9 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="fuzz line only (no dpor / ddmin records)")
     ap.add_argument("--no-specialize", action="store_true", help="interpret the transition table instead of compiling it")
     ap.add_argument("--no-prewarm", action="store_true")
+    ap.add_argument("--launches-in-flight", type=int, choices=[1, 2], default=2,
+                    help="fuzz: 2 = the steps dealt over two contexts, each on a stream of its own (the tail of a launch overlaps "
+                         "the start of the next); 1 = one context, one stream")
     ap.add_argument("--cpu-sample", type=int, default=1 << 20)
     ap.add_argument("--wide-term0", type=int, default=0,
                     help="experiment, not the headline: the same raft lowered as DEMI_MODEL_WIDE with terms starting here (> 255)")
@@ -845,42 +848,64 @@ def main():
     keep_steps = min(args.steps, 256)
     vbuf = torch.empty((max(1, keep_steps), n, 2), dtype=torch.int64, device=dev)     # demi_verdict[n] per step
     verdicts = torch.empty((n, 2), dtype=torch.int64, device=dev)                     # warm-up / fixed-seed step
-    viol = torch.zeros((VIOL_CAP + 1, 2), dtype=torch.int64, device=dev)  # row 0 = count, then demi_violation[]
-    gathered = torch.empty((world, VIOL_CAP + 1, 2), dtype=torch.int64, device=dev) if world > 1 else None
-    # the found-violation sets are all-gathered by the library's own communicator; if RCCL cannot be initialised there,
-    # torch.distributed's all_gather does the exchange (and the line says so)
+    # A K1 launch is a resident grid that drains a work counter: its last schedules run on a thinning device.  With a second
+    # launch queued on another stream the workgroups that retire are replaced by the next launch's, so the timed steps are dealt
+    # over TWO contexts, each on a stream of its own (--launches-in-flight 1: one context on the current stream).  A context runs
+    # one launch at a time - its pending-set scratch is the launch's -, hence two of them (same table, same trace, same code).
+    n_lanes = args.launches_in_flight
+    ctxs = [ctx]
+    if n_lanes == 2:
+        ctx2 = _native.Context(local_rank)
+        ctx2.model_load(model.to_struct())
+        ctx2.trace_load(events)
+        if specialized:
+            ctx2.model_specialize()
+        ctxs.append(ctx2)
+    # the found-violation sets are all-gathered by the library's own communicator (one per context); if RCCL cannot be
+    # initialised there, torch.distributed's all_gather does the exchange (and the line says so)
     collective = "none (1 rank)"
     if world > 1:
         try:
-            collective = attach(ctx) + ": demi_comm_allgather_dev"
+            collective = "; ".join(sorted(set(attach(c) for c in ctxs))) + ": demi_comm_allgather_dev"
         except RuntimeError as e:
             collective = "torch.distributed.all_gather (%s)" % e
-    use_lib_comm = collective.startswith("demi_comm")
-    stream = torch.cuda.current_stream()
-    sp = C.c_void_p(stream.cuda_stream)
+    use_lib_comm = collective.find("demi_comm") >= 0
+
+    class Lane:
+        def __init__(self, c, st):
+            self.ctx, self.stream, self.sp = c, st, C.c_void_p(st.cuda_stream)
+            self.viol = torch.zeros((VIOL_CAP + 1, 2), dtype=torch.int64, device=dev)  # row 0 = count, then demi_violation[]
+            self.gathered = torch.empty((world, VIOL_CAP + 1, 2), dtype=torch.int64, device=dev) if world > 1 else None
+    lanes = [Lane(c, torch.cuda.current_stream() if n_lanes == 1 else torch.cuda.Stream(device=dev)) for c in ctxs]
+    torch.cuda.synchronize()                 # (the buffers above exist before another stream touches them)
+    stream, sp = lanes[0].stream, lanes[0].sp
+    viol, gathered = lanes[0].viol, lanes[0].gathered
 
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
 
     def step(i=None, out=None, index_base=None):
         """one pass of the hot path: K1 over n schedules, the found-violation set compacted, all-gathered with N > 1.
-        Timed step i: fresh indices [(i * W + r) * n, ...); otherwise the fixed indices [r * n, ...)."""
+        Timed step i: fresh indices [(i * W + r) * n, ...), on lane i mod (launches in flight); otherwise the fixed indices
+        [r * n, ...) on lane 0."""
+        ln = lanes[i % n_lanes] if i is not None else lanes[0]
         if index_base is None:
             index_base = ((i * world + rank) if i is not None else rank) * n
         if out is None:
             out = vbuf[i % keep_steps] if i is not None else verdicts
         if i is not None:
-            ev0[i].record(stream)
-        ctx.random_explore_dev(n, limits, out.data_ptr(), seed_base=SEED_BASE + index_base, stream=sp)
+            ev0[i].record(ln.stream)
+        ln.ctx.random_explore_dev(n, limits, out.data_ptr(), seed_base=SEED_BASE + index_base, stream=ln.sp)
         if i is not None:
-            ev1[i].record(stream)
-        ctx.collect_violations_dev(out.data_ptr(), n, index_base, viol[1:].data_ptr(), VIOL_CAP,
-                                   viol[0:1].data_ptr(), stream=sp)
+            ev1[i].record(ln.stream)
+        ln.ctx.collect_violations_dev(out.data_ptr(), n, index_base, ln.viol[1:].data_ptr(), VIOL_CAP,
+                                      ln.viol[0:1].data_ptr(), stream=ln.sp)
         if world > 1:
             if use_lib_comm:
-                ctx.comm_allgather_dev(viol.data_ptr(), gathered.data_ptr(), viol.numel() * 8, stream=sp)
+                ln.ctx.comm_allgather_dev(ln.viol.data_ptr(), ln.gathered.data_ptr(), ln.viol.numel() * 8, stream=ln.sp)
             else:
-                dist.all_gather_into_tensor(gathered.view(-1, 2), viol)
+                with torch.cuda.stream(ln.stream):
+                    dist.all_gather_into_tensor(ln.gathered.view(-1, 2), ln.viol)
 
     def sync():
         if world > 1:
@@ -898,6 +923,27 @@ def main():
         prewarm_s = time.perf_counter() - t0
     for _ in range(args.warmup):
         step()
+    # with two launches in flight a launch's duration includes its wait for the other's workgroups to retire; the same
+    # launches one at a time (one context, one stream), untimed and BEFORE the timed region: what a launch takes with the
+    # device to itself - the duration the committed counters and the issue model below belong to
+    alone = None
+    if n_lanes == 2:
+        ea = [torch.cuda.Event(enable_timing=True) for _ in range(2 * args.steps)]
+        l0 = lanes[0]
+        ta = time.perf_counter()
+        for i in range(args.steps):
+            base_a = (((args.steps + 1 + i) * world) + rank) * n
+            ea[2 * i].record(l0.stream)
+            l0.ctx.random_explore_dev(n, limits, verdicts.data_ptr(), seed_base=SEED_BASE + base_a, stream=l0.sp)
+            ea[2 * i + 1].record(l0.stream)
+            l0.ctx.collect_violations_dev(verdicts.data_ptr(), n, base_a, l0.viol[1:].data_ptr(), VIOL_CAP, l0.viol[0:1].data_ptr(), stream=l0.sp)
+        torch.cuda.synchronize()
+        ta = time.perf_counter() - ta
+        alone = {"contexts": 1, "streams": 1, "steps": args.steps, "ms_per_step": ta / args.steps * 1e3, "value": n * args.steps / ta,
+                 "unit": "schedules/s (this rank)", "kernel_ms": float(np.mean([ea[2 * i].elapsed_time(ea[2 * i + 1]) for i in range(args.steps)]))}
+    if n_lanes == 2:                          # (the second context's first launches: its scratch, its code object)
+        for _ in range(max(1, args.warmup)):
+            lanes[1].ctx.random_explore_dev(n, limits, verdicts.data_ptr(), seed_base=SEED_BASE + rank * n, stream=lanes[1].sp)
     sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -909,6 +955,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
+    kernel_ms_alone = alone["kernel_ms"] if alone else kernel_ms
 
     # ---- what the timed region found: the violating executions of its steps, by delivery-sequence hash and by fingerprint
     # (bugs/hr = distinct violating schedules per wall-clock hour); counted here, after the timed region
@@ -967,7 +1014,7 @@ def main():
             with open(K1_COUNTERS) as f:
                 ctr = json.load(f)
             pms = float(ctr.get("kernel_ms", 0.0))
-            same = (ctr["code_id"] == code_id) if ctr.get("code_id") else (pms > 0 and abs(pms - kernel_ms) / pms <= 0.10)
+            same = (ctr["code_id"] == code_id) if ctr.get("code_id") else (pms > 0 and abs(pms - kernel_ms_alone) / pms <= 0.10)
             if same:
                 traffic = ctr.get("fabric_bytes_per_launch")
                 if probe and "SQ_INSTS_VALU" in ctr:
@@ -976,7 +1023,7 @@ def main():
                     clk = probe["shader_clock_ghz"] * 1e9
                     valu, salu = ctr["SQ_INSTS_VALU"], ctr["SQ_INSTS_SALU"]
                     other = ctr.get("SQ_INSTS_LDS", 0) + ctr.get("SQ_INSTS_VMEM_RD", 0) + ctr.get("SQ_INSTS_VMEM_WR", 0)
-                    cyc = kernel_ms * 1e-3 * clk
+                    cyc = kernel_ms_alone * 1e-3 * clk          # (a launch with the device to itself: what the counters were taken on)
                     issue = {"valu_insts_per_launch": valu, "salu_insts_per_launch": salu,
                              "active_lanes_per_valu_inst": ctr.get("SQ_THREAD_CYCLES_VALU", 0) / valu if valu else None,
                              "valu_alone_frac": valu * probe["simd_cycles_per_int_valu_6_waves"] / (cus * 4) / cyc,
@@ -1005,6 +1052,7 @@ def main():
                        "seeds": "timed step i of rank r: schedule indices [(i * %d + r) * n, ... + n) - every timed step evaluates fresh "
                                 "seeds; the untimed last step: [r * n, ... + n)" % world,
                        "parallelism": "schedule-index range sharded, %d rank(s)" % world, "collective": collective,
+                       "launches_in_flight": "%d (the timed steps dealt over %d context(s), one stream each)" % (n_lanes, n_lanes),
                        "untimed_prewarm_s": prewarm_s},
             # distinct bugs found in the TIMED region per wall-clock hour of it: by delivery-sequence hash - two
             # executions count once only if every delivered message and every final state agree - and by fingerprint
@@ -1023,8 +1071,15 @@ def main():
                                  "HBM; FETCH_SIZE x 2 + WRITE_SIZE as calibrated in profiles/), dominated by the pending sets the "
                                  "specialised build keeps in a [slot][lane] scratch instead of LDS (24 waves per CU): a measured trade, "
                                  "DESIGN.md section 4 K1; that working set (~47 MB) fits the 256 MiB Infinity Cache",
-                                 {"issue_model": issue, "probe": probe, "counters_stale": stale, "kernel_code_id": code_id}),
+                                 {"issue_model": issue, "probe": probe, "counters_stale": stale, "kernel_code_id": code_id,
+                                  "kernel_ms_alone": kernel_ms_alone,
+                                  "kernel_ms_note": "kernel_ms = a launch's duration in the timed region, by events on its stream; with two "
+                                                    "launches in flight that includes its wait for the other launch's workgroups to retire (the "
+                                                    "device's time per launch is ms_per_step); kernel_ms_alone = the same launch with the "
+                                                    "device to itself (one_launch_at_a_time), what the counters and the issue model belong to"}),
         }
+        if alone:
+            out["one_launch_at_a_time"] = alone
         if world == 1:
             # what a JVM host sees through demi_random_explore (caller's pageable host buffer for the verdicts): the same
             # launch plus the copy over PCIe.  Never `value` (inputs / outputs resident in HBM); reported beside it.
@@ -1066,7 +1121,8 @@ def main():
                                    "single_thread": {"value": m1 / t1, "unit": "schedules/s", "cores": 1, "seconds": t1,
                                                      "sample": "first %d schedules, one thread" % m1,
                                                      "bit_identical_to_gpu": bool((cpu1 == verdicts[:m1].cpu().numpy().view(T.VERDICT_DTYPE).reshape(-1)).all())}}
-    ctx.close()
+    for c in ctxs:
+        c.close()
     del vbuf
     torch.cuda.empty_cache()
     if not args.no_secondary:
