@@ -940,7 +940,9 @@ def main():
         torch.cuda.synchronize()
         ta = time.perf_counter() - ta
         alone = {"contexts": 1, "streams": 1, "steps": args.steps, "ms_per_step": ta / args.steps * 1e3, "value": n * args.steps / ta,
-                 "unit": "schedules/s (this rank)", "kernel_ms": float(np.mean([ea[2 * i].elapsed_time(ea[2 * i + 1]) for i in range(args.steps)]))}
+                 "unit": "schedules/s (this rank)", "kernel_ms": float(np.mean([ea[2 * i].elapsed_time(ea[2 * i + 1]) for i in range(args.steps)])),
+                 "note": "untimed side run on lane 0's stream with an event pair per launch; its kernel_ms is what a launch takes with the "
+                         "device to itself.  The one-stream bench line itself (--launches-in-flight 1) runs 4.06-4.08 ms per step on an MI355X"}
     if n_lanes == 2:                          # (the second context's first launches: its scratch, its code object)
         for _ in range(max(1, args.warmup)):
             lanes[1].ctx.random_explore_dev(n, limits, verdicts.data_ptr(), seed_base=SEED_BASE + rank * n, stream=lanes[1].sp)
