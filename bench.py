@@ -861,22 +861,27 @@ def main():
         if specialized:
             ctx2.model_specialize()
         ctxs.append(ctx2)
-    # the found-violation sets are all-gathered by the library's own communicator (one per context); if RCCL cannot be
-    # initialised there, torch.distributed's all_gather does the exchange (and the line says so)
+    # the found-violation sets are all-gathered by the library's own communicator - ONE, the first context's, on a stream of
+    # its own: the exchanges of all steps follow each other in step order on every rank, whatever the lanes do (two
+    # communicators driven from two streams could meet in different orders on different ranks); if RCCL cannot be initialised
+    # there, torch.distributed's all_gather does the exchange (and the line says so)
     collective = "none (1 rank)"
     if world > 1:
         try:
-            collective = "; ".join(sorted(set(attach(c) for c in ctxs))) + ": demi_comm_allgather_dev"
+            collective = attach(ctx) + ": demi_comm_allgather_dev"
         except RuntimeError as e:
             collective = "torch.distributed.all_gather (%s)" % e
-    use_lib_comm = collective.find("demi_comm") >= 0
+    use_lib_comm = collective.startswith("demi_comm")
 
     class Lane:
         def __init__(self, c, st):
             self.ctx, self.stream, self.sp = c, st, C.c_void_p(st.cuda_stream)
             self.viol = torch.zeros((VIOL_CAP + 1, 2), dtype=torch.int64, device=dev)  # row 0 = count, then demi_violation[]
             self.gathered = torch.empty((world, VIOL_CAP + 1, 2), dtype=torch.int64, device=dev) if world > 1 else None
+            self.extracted, self.exchanged = torch.cuda.Event(), torch.cuda.Event()
     lanes = [Lane(c, torch.cuda.current_stream() if n_lanes == 1 else torch.cuda.Stream(device=dev)) for c in ctxs]
+    comm_stream = lanes[0].stream if n_lanes == 1 or world == 1 else torch.cuda.Stream(device=dev)
+    csp = C.c_void_p(comm_stream.cuda_stream)
     torch.cuda.synchronize()                 # (the buffers above exist before another stream touches them)
     stream, sp = lanes[0].stream, lanes[0].sp
     viol, gathered = lanes[0].viol, lanes[0].gathered
@@ -901,11 +906,16 @@ def main():
         ln.ctx.collect_violations_dev(out.data_ptr(), n, index_base, ln.viol[1:].data_ptr(), VIOL_CAP,
                                       ln.viol[0:1].data_ptr(), stream=ln.sp)
         if world > 1:
+            # the exchange waits for this lane's extraction, and the lane's next extraction (which overwrites viol) for the exchange
+            ln.extracted.record(ln.stream)
+            comm_stream.wait_event(ln.extracted)
             if use_lib_comm:
-                ln.ctx.comm_allgather_dev(ln.viol.data_ptr(), ln.gathered.data_ptr(), ln.viol.numel() * 8, stream=ln.sp)
+                ctx.comm_allgather_dev(ln.viol.data_ptr(), ln.gathered.data_ptr(), ln.viol.numel() * 8, stream=csp)
             else:
-                with torch.cuda.stream(ln.stream):
+                with torch.cuda.stream(comm_stream):
                     dist.all_gather_into_tensor(ln.gathered.view(-1, 2), ln.viol)
+            ln.exchanged.record(comm_stream)
+            ln.stream.wait_event(ln.exchanged)
 
     def sync():
         if world > 1:
