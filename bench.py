@@ -855,12 +855,18 @@ def main():
     n_lanes = args.launches_in_flight
     ctxs = [ctx]
     if n_lanes == 2:
-        ctx2 = _native.Context(local_rank)
-        ctx2.model_load(model.to_struct())
-        ctx2.trace_load(events)
-        if specialized:
-            ctx2.model_specialize()
-        ctxs.append(ctx2)
+        try:
+            ctx2 = _native.Context(local_rank)
+            ctx2.model_load(model.to_struct())
+            ctx2.trace_load(events)
+            if specialized:
+                ctx2.model_specialize()
+                if not ctx2.is_specialized():
+                    raise _native.DemiError(-6, "the second context's table did not compile")
+            ctxs.append(ctx2)
+        except _native.DemiError as e:              # (one launch at a time then: the line says so in config.launches_in_flight)
+            print("bench: no second context, one launch at a time: %s" % e, file=sys.stderr)
+            n_lanes = 1
     # the found-violation sets are all-gathered by the library's own communicator - ONE, the first context's, on a stream of
     # its own: the exchanges of all steps follow each other in step order on every rank, whatever the lanes do (two
     # communicators driven from two streams could meet in different orders on different ranks); if RCCL cannot be initialised
