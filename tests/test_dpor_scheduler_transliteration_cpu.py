@@ -348,6 +348,12 @@ def _config3(cap):
     return model, ev, depth, 0, cap
 
 
+def _config5(cap):
+    from demi_amd.apps import shuffle8_config5_large
+    model, ev, depth, _budget = shuffle8_config5_large()
+    return model, ev, depth, 0, cap
+
+
 CASES = {
     "writers4": lambda: (writers_model(4), events_to_array([start(a) for a in range(5)] + [send(a, 0) for a in range(1, 5)]), 0, 0, 2500),
     "raft3": lambda: (M.raft_model(3), events_to_array([start(a) for a in range(3)] + [send(a, M.M_BOOTSTRAP) for a in range(3)]), 30, 0, 300),
@@ -358,6 +364,9 @@ CASES = {
     # BASELINE config 3, its first interleavings (the whole exploration - 60 332, most of an hour in this Python - is what
     # tools/check_golden_dpor_transliteration.py runs; its record: tests/golden/dpor_config3_transliteration.json)
     "raft5_config3_first_250": lambda: _config3(250),
+    # config 5's three-job shuffle pipeline (8 actors, 3 classes, depth 40), its first interleavings (the 6 000 that the GPU's
+    # reference-order test compares: tools/check_golden_dpor_transliteration.py --config5 6000)
+    "shuffle8_pipeline_first_120": lambda: _config5(120),
     "raft3_late_start_and_cap": lambda: (M.raft_model(3), events_to_array([start(0), start(1), send(0, M.M_BOOTSTRAP), send(1, M.M_BOOTSTRAP),
                                          wait_quiescence(), start(2), send(2, M.M_BOOTSTRAP)]), 20, 40, 300),
 }
@@ -396,3 +405,23 @@ def test_config3_golden_record_is_the_transliterations_too():
     for k in ("interleavings", "exhausted", "sha256_verdicts", "sha256_prefix_lens", "violations", "distinct_schedules"):
         assert tr[k] == gold[k], k
     assert gold["interleavings"] == 60332 and gold["exhausted"]
+
+
+def test_config5_pipeline_record_of_the_transliteration_is_the_oracles(oracle):
+    """tests/golden/dpor_config5_transliteration.json: the first 6 000 interleavings of config 5's three-job pipeline in the
+    reference's order as ScalaDPORwHeuristics explored them (tools/check_golden_dpor_transliteration.py --config5 6000, nine
+    minutes).  The C oracle under the product's one-at-a-time loop gives the same bytes - and the GPU suite holds the device's
+    REFERENCE order against both (test_config5_pipeline_in_reference_order_is_the_one_at_a_time_sequence)."""
+    import hashlib
+    import json
+    import os
+    from demi_amd.apps import shuffle8_config5_large
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dpor_config5_transliteration.json")) as f:
+        rec = json.load(f)
+    assert "ScalaDPORwHeuristics" in rec["generator"] and rec["equals_the_oracles_one_at_a_time_exploration"] is True
+    model, ev, depth, _budget = shuffle8_config5_large()
+    n = rec["interleavings"]
+    one = oracle.dpor_explore(model, ev, PAR(depth=depth), T.DporSearch(1, n, 0, 1, T.DPOR_ORDER_ROUNDS), n_threads=1)
+    assert len(one[0]) == n == 6000
+    assert hashlib.sha256(np.ascontiguousarray(one[0], dtype=T.VERDICT_DTYPE).tobytes()).hexdigest() == rec["sha256_verdicts"]
+    assert hashlib.sha256(np.ascontiguousarray(one[1], dtype=np.uint32).tobytes()).hexdigest() == rec["sha256_prefix_lens"]

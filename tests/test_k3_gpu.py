@@ -709,10 +709,17 @@ def test_config5_pipeline_in_reference_order_is_the_one_at_a_time_sequence(oracl
     ctx.model_load(model.to_struct())
     ctx.model_specialize()
     ctx.dpor_load(ev)
+    import hashlib
+    import json
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dpor_config5_transliteration.json")) as f:
+        translit = json.load(f)          # (the same 6 000 interleavings by the Python transliteration of the Scala scheduler)
     for batch in ((64,) if emu else (1024, 16384)):
         v, pl, _r, _vt, st = ctx.dpor_explore(par, T.DporSearch(batch, budget, 0, 1, T.DPOR_ORDER_REFERENCE))
         assert len(v) == budget and (v == one[0]).all() and (pl == one[1]).all(), batch
         assert not st.exhausted and int(st.fetches) >= 1 and int(st.executed) >= budget
+        if budget == translit["interleavings"]:
+            assert hashlib.sha256(np.ascontiguousarray(v, dtype=T.VERDICT_DTYPE).tobytes()).hexdigest() == translit["sha256_verdicts"]
+            assert hashlib.sha256(np.ascontiguousarray(pl, dtype=np.uint32).tobytes()).hexdigest() == translit["sha256_prefix_lens"]
     ctx.close()
 
 

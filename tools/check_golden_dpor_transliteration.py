@@ -21,6 +21,29 @@ from demi_amd.apps import raft5_config3  # noqa: E402
 from oracle import oracle_py as O  # noqa: E402
 from tests.test_dpor_scheduler_transliteration_cpu import ScalaDPORwHeuristics  # noqa: E402
 
+if len(sys.argv) > 2 and sys.argv[1] == "--config5":
+    # config 5's three-job pipeline, its first N interleavings, against the C oracle under the product's one-at-a-time loop
+    # (what tests/test_k3_gpu.py::test_config5_pipeline_in_reference_order_is_the_one_at_a_time_sequence holds the GPU against)
+    from demi_amd.apps import shuffle8_config5_large
+    model, ev, depth, _budget = shuffle8_config5_large()
+    cap = int(sys.argv[2])
+    sc = ScalaDPORwHeuristics(O, model, ev, depth_bound=depth, max_messages=0)
+    t0 = time.perf_counter()
+    exhausted = sc.run(cap)
+    seconds = time.perf_counter() - t0
+    v = np.array(sc.verdicts, dtype=T.VERDICT_DTYPE)
+    plen = np.array(sc.next_trace_lens, dtype=np.uint32)
+    one = O.dpor_explore(model, ev, T.DporParams(depth, 0, 0, 0, 64, 4096), T.DporSearch(1, cap, 0, 1, T.DPOR_ORDER_ROUNDS), n_threads=1)
+    same = len(one[0]) == len(v) and bool((one[0] == v).all()) and bool((one[1] == plen).all())
+    rec = {"generator": "tools/check_golden_dpor_transliteration.py --config5 %d (ScalaDPORwHeuristics, one core, %.0f s)" % (cap, seconds),
+           "interleavings": int(len(v)), "exhausted": bool(exhausted), "sha256_verdicts": hashlib.sha256(v.tobytes()).hexdigest(),
+           "sha256_prefix_lens": hashlib.sha256(plen.tobytes()).hexdigest(),
+           "equals_the_oracles_one_at_a_time_exploration": same}
+    print(rec)
+    with open(os.path.join(ROOT, "tests", "golden", "dpor_config5_transliteration.json"), "w") as f:
+        json.dump(rec, f, indent=1)
+    sys.exit(0 if same else 1)
+
 model, ev, depth = raft5_config3()
 cap = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 17
 sc = ScalaDPORwHeuristics(O, model, ev, depth_bound=depth, max_messages=0)
