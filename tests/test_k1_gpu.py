@@ -269,6 +269,15 @@ def test_full_size_properties_1m(gpu_ctx, oracle):
     b = out.cpu().numpy().view(T.VERDICT_DTYPE).reshape(-1)
     assert_same(a, b)
     gpu_ctx.model_specialize(False)
+    # all 2^20 of them are the verdicts of the Scala RandomScheduler as transliterated (tools/check_fuzz_transliteration.py ran it
+    # over the whole step; the CPU suite holds the C oracle against the same record)
+    import hashlib
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fuzz_config2_transliteration.json")) as f:
+        translit = json.load(f)
+    assert translit["seed_base"] == SEED_BASE and translit["equals_the_oracle"] is True
+    assert hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest() == translit["sha256_verdicts_of_the_first"][str(n)]
     flags = a["flags"]
     assert not (flags & (T.V_PENDING_OVF | T.V_QUEUE_OVF)).any()
     deliveries = (flags >> 16) & 0xFFFF

@@ -415,3 +415,23 @@ def test_a_table_with_arrays_equals_the_scala_transliteration(oracle):
         events = events_to_array(ev)
         checked, violations = _compare(oracle, model, events, list(range(100, 140)), 300, 5)
         assert checked == 40 and (violations > 5) == buggy
+
+
+def test_the_whole_bench_step_by_the_transliteration_is_the_oracles(oracle):
+    """tests/golden/fuzz_config2_transliteration.json: ALL 2^20 schedules of the bench's fixed-seed step (config 2: raft5, the
+    frozen trace, seeds SEED_BASE + i) as ScalaRandomScheduler above executed them (tools/check_fuzz_transliteration.py, eight
+    processes, minutes).  The C oracle gives the same bytes - here for every recorded prefix - and the GPU suite holds the device's
+    2^20 verdicts against the same record (test_full_size_properties_1m)."""
+    import hashlib
+    import json
+    import os
+    from demi_amd.apps import SEED_BASE, raft5_config2
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fuzz_config2_transliteration.json")) as f:
+        rec = json.load(f)
+    assert "ScalaRandomScheduler" in rec["generator"] and rec["equals_the_oracle"] is True and rec["seed_base"] == SEED_BASE
+    assert rec["schedules"] == 1 << 20 and set(rec["sha256_verdicts_of_the_first"]) == {"16384", "131072", "1048576"}
+    model, events, lim = raft5_config2()
+    v = oracle.random_explore(model, events, rec["schedules"], seed_base=SEED_BASE, limits=lim, n_threads=os.cpu_count() or 1)
+    for p, sha in rec["sha256_verdicts_of_the_first"].items():
+        assert hashlib.sha256(np.ascontiguousarray(v[:int(p)]).tobytes()).hexdigest() == sha, p
+    assert int(((v["flags"] & T.V_VIOLATION) != 0).sum()) == rec["violating_executions"]
