@@ -67,6 +67,7 @@ def test_emulator_reports_divergent_cross_lane_operations(tmp_path):
 
 def test_k1_sources_against_the_oracle_on_the_cpu():
     run_emulated(["test_k1_gpu.py::test_raft5_parity_all_capacities[64]",
+                  "test_k1_gpu.py::test_first_schedules_against_the_random_scheduler_transliterations_record",
                   "test_k1_gpu.py::test_recorded_event_traces_are_identical",
                   "test_k1_gpu.py::test_random_programs_interpreter_specialised_and_oracle_agree[1]",
                   "test_blocked_actors_gpu.py::test_k1_parity_with_crashed_actors[0]",
@@ -75,6 +76,7 @@ def test_k1_sources_against_the_oracle_on_the_cpu():
 
 def test_k2_sources_against_the_oracle_on_the_cpu():
     run_emulated(["test_k2_gpu.py::test_replay_parity_random_subsequences_raft5",
+                  "test_k2_gpu.py::test_bench_candidates_against_the_sts_transliterations_record",
                   "test_k2_gpu.py::test_filter_known_absents_parity[auto]",
                   "test_k2_gpu.py::test_removal_batch_and_kept_parity",
                   "test_k2_gpu.py::test_config4_ddmin_200_external_events",

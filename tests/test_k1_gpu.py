@@ -517,3 +517,26 @@ def test_carried_generator_instances(gpu_ctx, oracle, strategy):
         vo, reco, rano = oracle.random_execute_carried(model, events, SEED_BASE + 2, e, lim)
         assert ran == rano and (int(v.flags), int(v.fingerprint), int(v.hash)) == (int(vo.flags), int(vo.fingerprint), int(vo.hash))
         assert len(rec) == len(reco) and (rec == reco).all()
+
+
+@pytest.mark.gpu
+def test_first_schedules_against_the_random_scheduler_transliterations_record(gpu_ctx):
+    """The bench's fixed-seed step again, through the host-buffer entry point and without torch (so that the wave64 emulator runs it
+    too): the first 2^17 schedules (2^14 on the emulator), interpreter and compiled table, are byte for byte the verdicts the
+    transliteration of the Scala RandomScheduler produced (tests/golden/fuzz_config2_transliteration.json,
+    tools/check_fuzz_transliteration.py).  (Checked once by hand on the emulator for all 2^20: both kernels, the same SHA-256.)"""
+    import hashlib
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fuzz_config2_transliteration.json")) as f:
+        rec = json.load(f)
+    n = 1 << 14 if os.environ.get("DEMI_EMU") == "1" else 1 << 17
+    model, events, lim = raft5_config2()
+    gpu_ctx.model_load(model.to_struct())
+    gpu_ctx.trace_load(events)
+    for specialised in (False, True):
+        if specialised:
+            gpu_ctx.model_specialize()
+        v = gpu_ctx.random_explore(n, lim, seed_base=SEED_BASE)
+        assert hashlib.sha256(np.ascontiguousarray(v).tobytes()).hexdigest() == rec["sha256_verdicts_of_the_first"][str(n)], specialised
+    gpu_ctx.model_specialize(False)

@@ -407,3 +407,38 @@ def test_filter_known_absents_parity(gpu_ctx, oracle, k2_mode, monkeypatch):
     assert differs > 0
     with pytest.raises(Exception):
         gpu_ctx.replay_batch(masks, T.Limits(0, 0, 128, 1, fpc, 0, 0, 3))
+
+
+@pytest.mark.gpu
+def test_bench_candidates_against_the_sts_transliterations_record(gpu_ctx):
+    """The bench's replay workload (config 4: the 200-event failing execution, candidates drawn with default_rng(0) at 0.7 per
+    event), all 2^20 candidates: K2's verdicts are the ones the transliteration of the Scala STSScheduler produced
+    (tools/check_replay_transliteration.py; tests/golden/replay_config4_transliteration.json - the CPU suite holds the C oracle
+    against the same record)."""
+    import hashlib
+    import json
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "replay_config4_transliteration.json")) as f:
+        rec_t = json.load(f)
+    model, events, lim = raft5_config4()
+    vv, rec, used = record(gpu_ctx, model, events, lim, n=4000)
+    assert len(used) == rec_t["externals"] and len(rec) == rec_t["recorded_events"]
+    emu = os.environ.get("DEMI_EMU") == "1"
+    n = 1024 if emu else rec_t["candidates"]          # (the emulator: the first candidates only, against the oracle's bytes for them)
+    keep = np.random.default_rng(0).random((n, len(used))) < 0.7
+    masks = np.zeros((n, 4), dtype=np.uint64)
+    for w in range(4):
+        bits = keep[:, 64 * w:64 * (w + 1)]
+        masks[:, w] = (bits.astype(np.uint64) << np.arange(bits.shape[1], dtype=np.uint64)).sum(axis=1)
+    gpu_ctx.replay_load(used, rec)
+    got = gpu_ctx.replay_batch(masks, T.Limits(0, 0, 128, 1, vv.fingerprint, 0))
+    if not emu:
+        f = rec_t["first"]
+        assert hashlib.sha256(masks[:f].tobytes()).hexdigest() == rec_t["sha256_masks"]
+        assert hashlib.sha256(np.ascontiguousarray(got[:f]).tobytes()).hexdigest() == rec_t["sha256_verdicts"]
+        assert hashlib.sha256(masks.tobytes()).hexdigest() == rec_t["sha256_masks_of_all"]
+        assert hashlib.sha256(np.ascontiguousarray(got).tobytes()).hexdigest() == rec_t["sha256_verdicts_of_all"]
+        assert int(((got["flags"] & T.V_VIOLATION) != 0).sum()) == rec_t["still_violating"]
+    else:
+        from oracle import oracle_py as O
+        want = O.sts_replay_batch(model, used, rec, masks, T.Limits(0, 0, 128, 1, vv.fingerprint, 0), n_threads=os.cpu_count() or 1)
+        assert (got == want).all()

@@ -217,3 +217,35 @@ def test_replays_on_a_table_with_arrays_equal_the_scala_transliteration(oracle):
     subseqs = [allx] + [[i for i in allx if rng.random() < p] for p in (0.4, 0.6, 0.8, 0.9) for _ in range(8)]
     checked, diverged = _check(oracle, model, used, rec, vv.fingerprint, subseqs)
     assert checked == len(subseqs) and 0 < diverged < checked
+
+
+def test_the_bench_candidates_by_the_transliteration_are_the_oracles(oracle):
+    """tests/golden/replay_config4_transliteration.json: ALL 2^20 candidate subsequences of the bench's replay workload (config 4)
+    as ScalaSTSScheduler above replayed them (tools/check_replay_transliteration.py, eight processes, a quarter of an hour).  The
+    C oracle gives the same bytes - re-computed here for the first 2^16 -; the GPU suite holds K2's verdicts of all 2^20 against the
+    same record
+    (test_bench_candidates_against_the_sts_transliterations_record)."""
+    import hashlib
+    import json
+    import os
+    from demi_amd.apps import raft5_config4
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "replay_config4_transliteration.json")) as f:
+        rec_t = json.load(f)
+    assert "ScalaSTSScheduler" in rec_t["generator"] and rec_t["equals_the_oracle"] is True
+    assert rec_t["candidates"] == 1 << 20 and rec_t["first"] == 1 << 16      # (all of the bench's candidates; re-computed here: the first 2^16)
+    model, events, lim = raft5_config4()
+    v = oracle.random_explore(model, events, 4000, seed_base=SEED_BASE, limits=lim)
+    i = int(np.nonzero(v["flags"] & T.V_VIOLATION)[0][0])
+    vv, rec, _ = oracle.random_execute(model, events, SEED_BASE + i, lim)
+    used = events[:T.verdict_trace_idx(vv.flags)]
+    assert len(used) == rec_t["externals"] and len(rec) == rec_t["recorded_events"]
+    n = rec_t["first"]
+    keep = np.random.default_rng(0).random((n, len(used))) < 0.7
+    masks = np.zeros((n, 4), dtype=np.uint64)
+    for w in range(4):
+        bits = keep[:, 64 * w:64 * (w + 1)]
+        masks[:, w] = (bits.astype(np.uint64) << np.arange(bits.shape[1], dtype=np.uint64)).sum(axis=1)
+    assert hashlib.sha256(masks.tobytes()).hexdigest() == rec_t["sha256_masks"]
+    got = oracle.sts_replay_batch(model, used, rec, masks, T.Limits(0, 0, 128, 1, vv.fingerprint, 0), n_threads=os.cpu_count() or 1)
+    assert hashlib.sha256(np.ascontiguousarray(got).tobytes()).hexdigest() == rec_t["sha256_verdicts"]
+    assert int(((got["flags"] & T.V_VIOLATION) != 0).sum()) == rec_t["still_violating_of_the_first"]
