@@ -11,6 +11,11 @@
  * tests/golden/jrandom_kat.json).  Everything else restates the Scala sources function by
  * function; each function below cites the file:line it follows (paths relative to
  * /root/reference/src/main/scala/verification/).
+ * What stands in for the missing JVM: literal Python transliterations of the Scala schedulers (tests/test_*_transliteration_cpu.py:
+ * the reference's own containers and control flow, sharing only the actors' row interpreter with this file).  They have executed
+ * every timed workload once - all 2^20 schedules of config 2's step, all 2^20 candidates of config 4, all 60 332 interleavings of
+ * config 3, the first 6 000 of config 5's pipeline - and this oracle gives their bytes (tests/golden/ *_transliteration.json, written
+ * by tools/check_*_transliteration.py; the CPU suite re-checks the oracle against the records).
  */
 #ifndef DEMI_ORACLE_H
 #define DEMI_ORACLE_H
