@@ -25,7 +25,8 @@ configurations, each with its own roofline and CPU baseline:
   ddmin    config 4: DDMin of a 200-event failing execution over the STSSched replay oracle.  N = 1: replays/s of 2^20 resident
            candidates + demi_ddmin end to end.  N > 1: demi_ddmin with every speculative frontier split over the ranks
            (demi_replay_batch_sharded inside the library: all-gather of the verdicts), and the aggregate replay rate;
-  config5  the 8-actor shuffle pipeline, bounded DPOR exploration with a budget of 2^20 interleavings (apps.shuffle8_config5_large).
+  config5  the 8-actor shuffle pipeline, bounded DPOR exploration with a budget of 2^20 interleavings (apps.shuffle8_dpor_config5),
+           in ROUNDS order and (N = 1) in the reference's own order.
            N > 1: demi_dpor_explore with the communicator (rounds dealt over the ranks, explored-pair table owner-sharded).
 `--workload dpor|ddmin|config1|config5` prints that record alone as the line (same contract fields; ddmin and config5 also
 under torch.distributed.run with N ranks).
@@ -70,19 +71,24 @@ def _seq_digest(verdicts):
 
 
 def bench_dpor(ctx_device, cpu_baseline=True, batch=16384, orders=("rounds", "reference_order")):
-    """BASELINE config 3: the whole bounded DPOR exploration of raft5 (depth 30, Start x 5 + Send x 5)."""
+    """BASELINE config 3: the whole bounded DPOR exploration of raft5 (depth 30, Start x 5 + Send x 5) - from round 6 on the
+    workload that FINDS the seeded bug (apps.raft5_dpor_config3 says what changed and why).  `value` is the rate in the
+    REFERENCE order - the order whose explored set and found-violation set are DPORwHeuristics' own - with the ROUNDS order
+    beside it; the record states how the two orders' violating sets relate (`violating_sets`)."""
+    import hashlib
     import numpy as np
     from demi_amd import types as T
-    from demi_amd.apps import raft5_config3
-    from demi_amd.dpor import DPORwHeuristics
-    from demi_amd.schedulers import SchedulerConfig
-    model, ev, depth = raft5_config3()
+    from demi_amd.apps import raft5_dpor_config3
+    model, ev, par = raft5_dpor_config3()
+    depth = int(par.depth_bound)
     out = {"metric": "interleavings explored/sec, DPORwHeuristics bounded exploration (raft5, depth 30)", "unit": "interleavings/s",
-           "config": {"workload": "raft5-synth, Start x 5 + Send(Bootstrap) x 5, depth_bound 30, trackHistory, stopIfViolationFound = false, "
-                                  "explored until the backtrack queue is empty", "batch": batch}}
+           "config": {"workload": "raft5-synth (config 2's rows; election budgets 1,1,1,0,0), Start x 5 + Send(Bootstrap) x 5, depth_bound 30, "
+                                  "prioritizePendingUponDivergence, trackHistory, stopIfViolationFound = false, explored until the "
+                                  "backtrack queue is empty", "batch": batch}}
     runs = {}
+    viol_sets = {}
+    ref_verdicts = None
     from demi_amd import _native
-    par = T.DporParams(depth, 0, 0, 0, 64, 4096)
     for name, ref in (("rounds", False), ("reference_order", True)):
         if name not in orders:
             continue
@@ -92,27 +98,55 @@ def bench_dpor(ctx_device, cpu_baseline=True, batch=16384, orders=("rounds", "re
         ctx.model_load(model.to_struct())
         ctx.model_specialize()
         ctx.dpor_load(ev)
-        srch = T.DporSearch(batch, 1 << 17, 0, 1, T.DPOR_ORDER_REFERENCE if ref else T.DPOR_ORDER_ROUNDS)
+        srch = T.DporSearch(batch, 1 << 20, 0, 1, T.DPOR_ORDER_REFERENCE if ref else T.DPOR_ORDER_ROUNDS)
         # a first whole exploration outside the timing: compilation for this table, the device arenas (a long-lived demi_ctx
         # keeps them); every call is a fresh exploration
         ctx.dpor_explore(par, srch)
         t = time.perf_counter()
         verdicts, plen, rounds, vtrace, st = ctx.dpor_explore(par, srch)
         dt = time.perf_counter() - t
+        vh = np.unique(verdicts["hash"][(verdicts["flags"] & T.V_VIOLATION) != 0])
+        viol_sets[name] = set(vh.tolist())
+        if ref:
+            ref_verdicts = verdicts
         runs[name] = {"value": len(verdicts) / dt, "seconds": dt, "interleavings": len(verdicts),
                       "mean_prefix_len": float(np.mean(plen)) if len(plen) else 0.0, "backtrack_points": int(st.backtrack_points),
                       "sequence_digest": "%016x" % _seq_digest(verdicts),
+                      "sha256_verdicts": hashlib.sha256(np.ascontiguousarray(verdicts).tobytes()).hexdigest(),
                       "executed_on_device": int(st.executed), "launches": int(st.launches), "exhausted": bool(st.exhausted),
                       "violations": int(np.count_nonzero(verdicts["flags"] & T.V_VIOLATION)),
+                      "distinct_violating_schedules": int(len(vh)), "bugs_per_hr": len(vh) / dt * 3600.0,
+                      "sha256_sorted_violating_hashes": hashlib.sha256(vh.tobytes()).hexdigest(),
+                      "first_violation": int(np.nonzero(verdicts["flags"] & T.V_VIOLATION)[0][0]) if len(vh) else None,
                       "distinct_schedules": int(len(np.unique(verdicts["hash"]))),
                       "kernel_ms_total": float(st.kernel_ms), "h2d_bytes": int(st.h2d_bytes), "d2h_bytes": int(st.d2h_bytes)}
         if ref:
             runs[name]["launches_for_results_the_speculation_lacked"] = int(st.cache_misses)
             runs[name]["record_fetches"] = int(st.fetches)
         ctx.close()
+    # the headline of this record is the reference's own order (its explored set and its found-violation set are
+    # DPORwHeuristics'); the ROUNDS order explores another - larger - set, whose violating set is compared below
+    head = "reference_order" if "reference_order" in runs else next(iter(runs))
     first = "rounds" if "rounds" in runs else next(iter(runs))
-    out["value"] = runs[first]["value"]
+    out["value"] = runs[head]["value"]
+    out["value_order"] = head
+    out["violations"] = runs[head]["violations"]
+    out["bugs_per_hr"] = runs[head]["bugs_per_hr"]
     out["orders"] = runs
+    if len(viol_sets) == 2:
+        a, b = viol_sets["rounds"], viol_sets["reference_order"]
+        out["violating_sets"] = {"common": len(a & b), "rounds_only": len(a - b), "reference_order_only": len(b - a),
+                                 "note": "distinct violating executions by the 64-bit hash over every delivery and final state; the "
+                                         "two orders flip each racing pair once but in different contexts (ExploredTacker is global), "
+                                         "so neither explored set contains the other"}
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", "dpor_config3_bug_reference_order.json")) as f:
+            gold = json.load(f)
+        if "reference_order" in runs:
+            out["reference_order_equals_golden_record"] = all(runs["reference_order"][k] == gold[k] for k in
+                                                              ("interleavings", "violations", "sha256_verdicts", "sha256_sorted_violating_hashes"))
+    except (OSError, ValueError, KeyError):
+        pass
     r = runs[first]
     # algorithmic bytes per interleaving = 4 x depth (its prefix in) + 8 (verdict out) + 12 x r (its r new
     # backtrack points out), with the MEASURED mean prefix length and r = backtrack points enqueued / interleavings.  What the
@@ -147,18 +181,27 @@ def bench_dpor(ctx_device, cpu_baseline=True, batch=16384, orders=("rounds", "re
         for name, ref in (("rounds", False), ("reference_order", True)):
             if name not in orders:
                 continue
-            srch = T.DporSearch(batch, 1 << 17, 0, 1, T.DPOR_ORDER_REFERENCE if ref else T.DPOR_ORDER_ROUNDS)
+            # (the oracle's reference order runs one interleaving at a time: a speculation `batch` wide costs a host thousands of
+            # discarded executions per committed one)
+            # discarded executions per committed one) - and a bounded sample of it: the first 2^14 interleavings
+            srch = T.DporSearch(1 if ref else batch, 1 << 14 if ref else 1 << 20, 0, 1, T.DPOR_ORDER_ROUNDS)
             t = time.perf_counter()
-            v, plen, rounds, vt, st, secs = O.dpor_explore(model, ev, par, srch, n_threads=cores)
+            v, plen, rounds, vt, st, secs = O.dpor_explore(model, ev, par, srch, n_threads=1 if ref else cores)
             dt = time.perf_counter() - t
-            base[name] = {"value": len(v) / dt, "seconds": dt, "interleavings": len(v), "sequence_digest": "%016x" % _seq_digest(v)}
-        out["cpu_baseline"] = {"value": base[first]["value"], "unit": "interleavings/s", "cores": cores, "kind": "port",
-                               "sample": "the same whole exploration: oracle/demi_oracle.c interleavings on %d host threads (one next "
-                                         "trace per thread) under the same host bookkeeping (demi_amd/csrc/dpor_host.hpp)" % cores,
+            base[name] = {"value": len(v) / dt, "seconds": dt, "interleavings": len(v), "sequence_digest": "%016x" % _seq_digest(v),
+                          "sha256_verdicts": hashlib.sha256(np.ascontiguousarray(v).tobytes()).hexdigest()}
+            if ref:
+                base[name]["same_as_the_gpus_first_interleavings"] = bool(
+                    hashlib.sha256(np.ascontiguousarray(ref_verdicts[:len(v)]).tobytes()).hexdigest() == base[name]["sha256_verdicts"])
+        out["cpu_baseline"] = {"value": base[head]["value"], "unit": "interleavings/s", "cores": 1 if head == "reference_order" else cores, "kind": "port",
+                               "sample": "the same whole exploration: oracle/demi_oracle.c interleavings under the same host bookkeeping "
+                                         "(demi_amd/csrc/dpor_host.hpp) - the reference's order one interleaving at a time on one thread "
+                                         "(as DPORwHeuristics runs), the ROUNDS order on %d host threads (one next trace per thread)" % cores,
                                "orders": base,
-                               "same_interleaving_count_as_gpu": {k: base[k]["interleavings"] == runs[k]["interleavings"] for k in base},
-                               # every verdict (flags, fingerprint, delivery hash) in exploration order, GPU = oracle
-                               "same_verdict_sequence_as_gpu": {k: base[k]["sequence_digest"] == runs[k]["sequence_digest"] for k in base}}
+                               # every verdict (flags, fingerprint, delivery hash) in exploration order, GPU = oracle (the reference
+                               # order: over the sample's interleavings; the whole sequence is held against the golden record above)
+                               "same_verdict_sequence_as_gpu": {k: (base[k]["same_as_the_gpus_first_interleavings"] if k == "reference_order"
+                                                                    else base[k]["sha256_verdicts"] == runs[k]["sha256_verdicts"]) for k in base}}
     return out
 
 
@@ -232,7 +275,7 @@ class Ranks:
 def _counters_profile(name):
     """fabric-side bytes of a secondary record from its FETCH_SIZE / WRITE_SIZE passes (tools/profile_r5_k2k3.sh), if committed:
     `name` is the file's name without its round tag; the newest round's file wins"""
-    for tag in ("r05", "r04", "r03"):
+    for tag in ("r06", "r05", "r04", "r03"):
         try:
             with open(os.path.join(ROOT, "profiles", "%s_%s" % (tag, name))) as f:
                 d = json.load(f)
@@ -243,20 +286,21 @@ def _counters_profile(name):
     return None
 
 
-def bench_config5(ctx_device, cpu_baseline=True, max_interleavings=None, batch=16384, ranks=None, small=True):
+def bench_config5(ctx_device, cpu_baseline=True, max_interleavings=None, batch=16384, ranks=None, small=True, reference_order=True):
     """BASELINE config 5: shuffle8-synth as a pipeline of three jobs (8 actors, 3 classes), bounded DPOR exploration with a budget
-    of 2^20 interleavings (apps.shuffle8_config5_large says why more externals do not enlarge the one-job exploration and
+    of 2^20 interleavings (apps.shuffle8_dpor_config5; shuffle8_config5_large says why more externals do not enlarge the one-job exploration and
     chained jobs do).  With N ranks: demi_dpor_explore with the communicator - a round's backtrack points dealt over the ranks
     in contiguous blocks, the explored-pair table sharded by owner = hash(unordered pair) mod N, three all-gathers per round
     (DESIGN section 6); every rank ends with the same verdict sequence (checked)."""
+    import hashlib
     import numpy as np
     from demi_amd import _native, types as T
-    from demi_amd.apps import shuffle8_config5, shuffle8_config5_large
+    from demi_amd.apps import shuffle8_config5, shuffle8_dpor_config5
     ranks = ranks or Ranks()
-    model, dpor_events, depth, budget = shuffle8_config5_large()
+    model, dpor_events, par, budget = shuffle8_dpor_config5()
+    depth = int(par.depth_bound)
     if max_interleavings is None:
         max_interleavings = budget
-    par = T.DporParams(depth, 0, 0, 0, 64, 4096)
     srch = T.DporSearch(batch, max_interleavings, 0, 1, T.DPOR_ORDER_ROUNDS)
     ctx = _native.Context(ctx_device)
     ctx.model_load(model.to_struct())
@@ -278,18 +322,24 @@ def bench_config5(ctx_device, cpu_baseline=True, max_interleavings=None, batch=1
     digest = "%016x" % _seq_digest(verdicts)
     per_il = 4.0 * float(np.mean(plen)) + 8.0 + 12.0 * (int(st.backtrack_points) / max(1, n_il))
     flags, counts = np.unique(verdicts["flags"] & 0xFF, return_counts=True)
+    vh = np.unique(verdicts["hash"][(verdicts["flags"] & T.V_VIOLATION) != 0])
     prof = _counters_profile("config5_counters.json")
     out = {"metric": "interleavings explored/sec, bounded DPOR (shuffle8-synth pipeline of 3 jobs, depth 40, budget %d)" % max_interleavings,
            "unit": "interleavings/s", "value": n_il / dt, "seconds": dt, "interleavings": n_il, "exhausted": bool(st.exhausted),
            "budget": int(max_interleavings), "backtrack_points_still_queued": int(st.queue_len), "launches": int(st.launches),
            "n_gpus": ranks.world, "collective": collective, "setup_s_untimed": setup_s,
            "violations": int(np.count_nonzero(verdicts["flags"] & T.V_VIOLATION)), "sequence_digest": digest,
+           "distinct_violating_schedules": int(len(vh)), "bugs_per_hr": len(vh) / dt * 3600.0,
+           "first_violation": int(np.nonzero(verdicts["flags"] & T.V_VIOLATION)[0][0]) if len(vh) else None,
+           "sha256_verdicts": hashlib.sha256(np.ascontiguousarray(verdicts).tobytes()).hexdigest(),
+           "value_order": "rounds",
            "distinct_schedules": int(len(np.unique(verdicts["hash"]))),
            "verdict_flag_histogram": {"0x%02x" % int(f): int(c) for f, c in zip(flags, counts)},
            "mean_prefix_len": float(np.mean(plen)), "kernel_ms_total": float(st.kernel_ms),
            "pcie_bytes": {"h2d": int(st.h2d_bytes), "d2h": int(st.d2h_bytes)},
-           "config": {"workload": "shuffle8-synth pipeline (2-stage shuffle stand-in, 8 actors, 3 actor classes, 3 jobs back to back), "
-                                  "Start x 8 + Submit + Speculate, depth_bound 40, ROUNDS of %d, budget %d interleavings (not exhausted: "
+           "config": {"workload": "shuffle8-synth pipeline (2-stage shuffle stand-in, 8 actors, 3 actor classes, 3 jobs back to back, both "
+                                  "seeded bugs: apps.shuffle8_dpor_config5), Start x 8 + Submit + Speculate, depth_bound 40, "
+                                  "prioritizePendingUponDivergence, ROUNDS of %d, budget %d interleavings (not exhausted: "
                                   "the budget bounds the search, RunnerUtils.boundedDPOR's shape)" % (batch, max_interleavings)},
            "roofline": roofline(n_il * per_il, float(st.kernel_ms), (prof or {}).get("fabric_bytes_per_exploration"),
                                 "k3_dpor + k3_pairs_* (specialised)",
@@ -299,6 +349,39 @@ def bench_config5(ctx_device, cpu_baseline=True, max_interleavings=None, batch=1
         per_rank = ranks.gather({"digest": digest, "interleavings": n_il, "kernel_ms": float(st.kernel_ms)})
         out["per_rank"] = per_rank
         out["same_verdict_sequence_on_every_rank"] = all(r["digest"] == digest and r["interleavings"] == n_il for r in per_rank)
+    if ranks.world == 1 and reference_order:
+        # the same budget in the REFERENCE order: the order whose 2^20 interleavings are the ones DPORwHeuristics itself would
+        # explore under this budget (ROUNDS takes the 2^20 from another frontier), single-rank by construction
+        rs = T.DporSearch(batch, max_interleavings, 0, 1, T.DPOR_ORDER_REFERENCE)
+        try:
+            ctx.dpor_explore(par, rs)
+            t = time.perf_counter()
+            rv, rplen, _rr, _rt, rst = ctx.dpor_explore(par, rs)
+            rdt = time.perf_counter() - t
+            rvh = np.unique(rv["hash"][(rv["flags"] & T.V_VIOLATION) != 0])
+            out["reference_order"] = {"value": len(rv) / rdt, "seconds": rdt, "interleavings": len(rv), "exhausted": bool(rst.exhausted),
+                                      "violations": int(np.count_nonzero(rv["flags"] & T.V_VIOLATION)),
+                                      "distinct_violating_schedules": int(len(rvh)), "bugs_per_hr": len(rvh) / rdt * 3600.0,
+                                      "first_violation": int(np.nonzero(rv["flags"] & T.V_VIOLATION)[0][0]) if len(rvh) else None,
+                                      "sequence_digest": "%016x" % _seq_digest(rv),
+                                      "sha256_verdicts": hashlib.sha256(np.ascontiguousarray(rv).tobytes()).hexdigest(),
+                                      "sha256_first_6000_verdicts": hashlib.sha256(np.ascontiguousarray(rv[:6000]).tobytes()).hexdigest(),
+                                      "executed_on_device": int(rst.executed), "launches": int(rst.launches), "record_fetches": int(rst.fetches),
+                                      "kernel_ms_total": float(rst.kernel_ms),
+                                      "pcie_bytes": {"h2d": int(rst.h2d_bytes), "d2h": int(rst.d2h_bytes)}}
+            a, b = set(vh.tolist()), set(rvh.tolist())
+            out["violating_sets"] = {"common": len(a & b), "rounds_only": len(a - b), "reference_order_only": len(b - a),
+                                     "note": "under a budget the two orders explore different interleavings (the search is not exhausted)"}
+            try:
+                with open(os.path.join(ROOT, "tests", "golden", "dpor_config5_bug_transliteration.json")) as f:
+                    g5 = json.load(f)
+                if g5["interleavings"] == 6000 and len(rv) >= 6000:
+                    out["reference_order"]["first_6000_equal_the_transliterations_record"] = bool(
+                        g5["sha256_verdicts"] == out["reference_order"]["sha256_first_6000_verdicts"])
+            except (OSError, ValueError, KeyError):
+                pass
+        except Exception as e:        # reported, never hidden: the ROUNDS record above stands on its own
+            out["reference_order"] = {"error": str(e)}
     ctx.close()
     if small and ranks.world == 1:
         # the one-job table of rounds 1-3 (1 653 interleavings, exhausted in three launches: launch latency, kept for continuity)
@@ -312,6 +395,7 @@ def bench_config5(ctx_device, cpu_baseline=True, max_interleavings=None, batch=1
         d1 = time.perf_counter() - t
         c1.close()
         out["one_job"] = {"interleavings": len(v1), "seconds": d1, "value": len(v1) / d1, "exhausted": bool(st1.exhausted),
+                          "violations": int(np.count_nonzero(v1["flags"] & T.V_VIOLATION)),
                           "launches": int(st1.launches), "sequence_digest": "%016x" % _seq_digest(v1)}
     if cpu_baseline and ranks.rank == 0:
         from oracle import oracle_py as O
@@ -695,17 +779,17 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", choices=["fuzz", "dpor", "ddmin", "config1", "config5"], default="fuzz")
     ap.add_argument("--dpor-order", choices=["both", "rounds", "reference_order"], default="both",
-                    help="--workload dpor: which exploration order(s) to run (profiling passes use one)")
+                    help="--workload dpor / config5: which exploration order(s) to run (profiling passes use one; config5 always runs ROUNDS)")
     ap.add_argument("--schedules", type=int, default=N_PER_GPU, help="schedules per GPU per step")
     ap.add_argument("--config5-budget", type=int, default=None,
-                    help="interleavings the config 5 record may explore (default: apps.shuffle8_config5_large's 2^20)")
+                    help="interleavings the config 5 record may explore (default: apps.shuffle8_dpor_config5's 2^20)")
     ap.add_argument("--p-max", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="fuzz line only (no dpor / ddmin records)")
     ap.add_argument("--no-specialize", action="store_true", help="interpret the transition table instead of compiling it")
     ap.add_argument("--no-prewarm", action="store_true")
     ap.add_argument("--launches-in-flight", type=int, choices=[1, 2], default=2,
-                    help="fuzz: 2 = the steps dealt over two contexts, each on a stream of its own (the tail of a launch overlaps "
+                    help="fuzz: 2 = the steps dealt over two streams of the one context (the tail of a launch overlaps "
                          "the start of the next); 1 = one context, one stream")
     ap.add_argument("--cpu-sample", type=int, default=1 << 20)
     ap.add_argument("--wide-term0", type=int, default=0,
@@ -804,7 +888,8 @@ def main():
             rec = bench_dpor(local_rank, cpu_baseline=not args.no_cpu_baseline,
                              orders=("rounds", "reference_order") if args.dpor_order == "both" else (args.dpor_order,))
         elif args.workload == "config5":
-            rec = bench_config5(local_rank, cpu_baseline=not args.no_cpu_baseline, ranks=ranks, max_interleavings=args.config5_budget)
+            rec = bench_config5(local_rank, cpu_baseline=not args.no_cpu_baseline, ranks=ranks, max_interleavings=args.config5_budget,
+                                reference_order=args.dpor_order in ("both", "reference_order"))
         elif args.workload == "ddmin" and world > 1:
             rec = bench_ddmin_ranks(local_rank, ranks)
         else:
@@ -849,27 +934,13 @@ def main():
     vbuf = torch.empty((max(1, keep_steps), n, 2), dtype=torch.int64, device=dev)     # demi_verdict[n] per step
     verdicts = torch.empty((n, 2), dtype=torch.int64, device=dev)                     # warm-up / fixed-seed step
     # A K1 launch is a resident grid that drains a work counter: its last schedules run on a thinning device.  With a second
-    # launch queued on another stream the workgroups that retire are replaced by the next launch's, so the timed steps are dealt
-    # over TWO contexts, each on a stream of its own (--launches-in-flight 1: one context on the current stream).  A context runs
-    # one launch at a time - its pending-set scratch is the launch's -, hence two of them (same table, same trace, same code).
+    # launch queued on another stream the workgroups that retire are replaced by the next launch's.  ONE context does that since
+    # round 6 (it holds two sets of K1's per-launch scratch and alternates between them: include/demi_gpu.h): the timed steps
+    # are dealt over two streams of the same context (--launches-in-flight 1: one stream).
     n_lanes = args.launches_in_flight
     ctxs = [ctx]
-    if n_lanes == 2:
-        try:
-            ctx2 = _native.Context(local_rank)
-            ctx2.model_load(model.to_struct())
-            ctx2.trace_load(events)
-            if specialized:
-                ctx2.model_specialize()
-                if not ctx2.is_specialized():
-                    raise _native.DemiError(-6, "the second context's table did not compile")
-            ctxs.append(ctx2)
-        except _native.DemiError as e:              # (one launch at a time then: the line says so in config.launches_in_flight)
-            print("bench: no second context, one launch at a time: %s" % e, file=sys.stderr)
-            n_lanes = 1
-    # the found-violation sets are all-gathered by the library's own communicator - ONE, the first context's, on a stream of
-    # its own: the exchanges of all steps follow each other in step order on every rank, whatever the lanes do (two
-    # communicators driven from two streams could meet in different orders on different ranks); if RCCL cannot be initialised
+    # the found-violation sets are all-gathered by the library's own communicator on a stream of its own: the exchanges of all
+    # steps follow each other in step order on every rank, whatever the lanes do; if RCCL cannot be initialised
     # there, torch.distributed's all_gather does the exchange (and the line says so)
     collective = "none (1 rank)"
     if world > 1:
@@ -885,7 +956,7 @@ def main():
             self.viol = torch.zeros((VIOL_CAP + 1, 2), dtype=torch.int64, device=dev)  # row 0 = count, then demi_violation[]
             self.gathered = torch.empty((world, VIOL_CAP + 1, 2), dtype=torch.int64, device=dev) if world > 1 else None
             self.extracted, self.exchanged = torch.cuda.Event(), torch.cuda.Event()
-    lanes = [Lane(c, torch.cuda.current_stream() if n_lanes == 1 else torch.cuda.Stream(device=dev)) for c in ctxs]
+    lanes = [Lane(ctx, torch.cuda.current_stream() if n_lanes == 1 else torch.cuda.Stream(device=dev)) for _ in range(n_lanes)]
     comm_stream = lanes[0].stream if n_lanes == 1 or world == 1 else torch.cuda.Stream(device=dev)
     csp = C.c_void_p(comm_stream.cuda_stream)
     torch.cuda.synchronize()                 # (the buffers above exist before another stream touches them)
@@ -931,14 +1002,17 @@ def main():
     # a freshly leased GPU idles at a low shader clock and ramps over about a second of load: run the same launches
     # untimed first so that the W warmup steps and the K timed steps see the clock a long-running job sees
     prewarm_s = 0.0
+    k1_launches_before = 0            # K1 launches this process issues before the timed region (tools/summarize_prof.py finds the timed ones by it)
     if not args.no_prewarm:
         t0 = time.perf_counter()
         while time.perf_counter() - t0 < PREWARM_S:
             ctx.random_explore_dev(n, limits, verdicts.data_ptr(), seed_base=SEED_BASE + rank * n, stream=sp)
             torch.cuda.synchronize()
+            k1_launches_before += 1
         prewarm_s = time.perf_counter() - t0
     for _ in range(args.warmup):
         step()
+        k1_launches_before += 1
     # with two launches in flight a launch's duration includes its wait for the other's workgroups to retire; the same
     # launches one at a time (one context, one stream), untimed and BEFORE the timed region: what a launch takes with the
     # device to itself - the duration the committed counters and the issue model below belong to
@@ -955,13 +1029,15 @@ def main():
             l0.ctx.collect_violations_dev(verdicts.data_ptr(), n, base_a, l0.viol[1:].data_ptr(), VIOL_CAP, l0.viol[0:1].data_ptr(), stream=l0.sp)
         torch.cuda.synchronize()
         ta = time.perf_counter() - ta
-        alone = {"contexts": 1, "streams": 1, "steps": args.steps, "ms_per_step": ta / args.steps * 1e3, "value": n * args.steps / ta,
+        k1_launches_before += args.steps
+        alone = {"streams": 1, "steps": args.steps, "ms_per_step": ta / args.steps * 1e3, "value": n * args.steps / ta,
                  "unit": "schedules/s (this rank)", "kernel_ms": float(np.mean([ea[2 * i].elapsed_time(ea[2 * i + 1]) for i in range(args.steps)])),
                  "note": "untimed side run on lane 0's stream with an event pair per launch; its kernel_ms is what a launch takes with the "
                          "device to itself.  The one-stream bench line itself (--launches-in-flight 1) runs 4.06-4.08 ms per step on an MI355X"}
-    if n_lanes == 2:                          # (the second context's first launches: its scratch, its code object)
-        for _ in range(max(1, args.warmup)):
+    if n_lanes == 2:                          # (the second scratch set's first launches: its allocation)
+        for _ in range(max(2, args.warmup)):
             lanes[1].ctx.random_explore_dev(n, limits, verdicts.data_ptr(), seed_base=SEED_BASE + rank * n, stream=lanes[1].sp)
+            k1_launches_before += 1
     sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -1070,13 +1146,14 @@ def main():
                        "seeds": "timed step i of rank r: schedule indices [(i * %d + r) * n, ... + n) - every timed step evaluates fresh "
                                 "seeds; the untimed last step: [r * n, ... + n)" % world,
                        "parallelism": "schedule-index range sharded, %d rank(s)" % world, "collective": collective,
-                       "launches_in_flight": "%d (the timed steps dealt over %d context(s), one stream each)" % (n_lanes, n_lanes),
+                       "launches_in_flight": "%d (ONE demi_ctx; the timed steps dealt over %d stream(s))" % (n_lanes, n_lanes),
                        "untimed_prewarm_s": prewarm_s},
             # distinct bugs found in the TIMED region per wall-clock hour of it: by delivery-sequence hash - two
             # executions count once only if every delivered message and every final state agree - and by fingerprint
             "bugs_per_hr": timed_hashes / counted_frac / dt * 3600.0,
             "bugs_per_hr_by_fingerprint": timed_fps / dt * 3600.0,
             "timed_region": {"schedules": total, "seconds": dt, "violating_executions": timed_viol,
+                             "k1_launches_before": k1_launches_before, "k1_launches": args.steps,
                              "distinct_violating_delivery_hashes": timed_hashes, "distinct_fingerprints": timed_fps,
                              "steps_counted": keep_steps},
             "violations_last_step": int(len(vset)),
@@ -1116,6 +1193,32 @@ def main():
                 out["pcie_inclusive"] = {"entry_point": "demi_random_explore (16 B verdict per schedule copied into a pageable host buffer)",
                                          "ms_per_step": th * 1e3, "value": n / th, "unit": "schedules/s",
                                          "same_verdicts_as_the_resident_path": bool((hv == verdicts.cpu().numpy().view(T.VERDICT_DTYPE).reshape(-1)).all())}
+                # the same through demi_random_explore_submit / _wait - what GpuRandomScheduler.explore calls: two calls in
+                # flight in the one context, (a) every verdict copied into the caller's host buffer, (b) only the flagged
+                # executions (what explore() needs); K steps of fresh seeds each, host wall clock around the whole loop
+                hv2 = [np.zeros(n, dtype=T.VERDICT_DTYPE) for _ in range(2)]
+                for h_ in hv2:
+                    h_["hash"] = 1
+                def piped(with_verdicts, steps):
+                    tk = [ctx.random_explore_submit(n, limits, seed_base=SEED_BASE + index_base)]
+                    found = 0
+                    for j in range(steps):
+                        if j + 1 < steps:
+                            tk.append(ctx.random_explore_submit(n, limits, seed_base=SEED_BASE + (steps + 2 + j) * n))
+                        _h, cnt, _f = ctx.random_explore_wait(tk[j], out=hv2[j & 1] if with_verdicts else None)
+                        found += cnt
+                    return found
+                piped(True, 2)
+                same_p = bool((hv2[0] == hv).all())            # (the first call of the loop runs the fixed seeds)
+                ksteps = max(4, args.steps)
+                tp = time.perf_counter(); piped(True, ksteps); tp = (time.perf_counter() - tp) / ksteps
+                tf = time.perf_counter(); nf = piped(False, ksteps); tf = (time.perf_counter() - tf) / ksteps
+                out["pcie_inclusive"]["pipelined"] = {
+                    "entry_point": "demi_random_explore_submit / demi_random_explore_wait (two calls in flight in one demi_ctx, streams of its own)",
+                    "every_verdict_to_host": {"ms_per_step": tp * 1e3, "value": n / tp, "unit": "schedules/s", "steps": ksteps,
+                                              "same_verdicts_as_the_resident_path": same_p},
+                    "flagged_executions_to_host": {"ms_per_step": tf * 1e3, "value": n / tf, "unit": "schedules/s", "steps": ksteps,
+                                                   "violating_executions_returned": int(nf)}}
             except Exception as e:           # never let a side measurement break the bench line
                 print("bench: host-buffer measurement unavailable: %s" % e, file=sys.stderr)
         if not args.no_cpu_baseline and world == 1:

@@ -15,7 +15,7 @@ EXPORTS = ["demi_ctx_create", "demi_ctx_destroy", "demi_last_error", "demi_versi
            "demi_trace_load", "demi_random_explore", "demi_random_explore_dev", "demi_random_get_trace", "demi_collect_violations_dev",
            "demi_replay_load", "demi_replay_batch", "demi_replay_batch_dev", "demi_dpor_load", "demi_dpor_batch", "demi_dpor_explore", "demi_random_explore_violations", "demi_random_get_trace_carried",
            "demi_replay_removal_batch", "demi_replay_get_kept", "demi_replay_recorded_len", "demi_ddmin", "demi_dpor_set_traces", "demi_model_specialize", "demi_model_is_specialized", "demi_model_code_id",
-           "demi_specialize_check", "demi_specialize_source", "demi_specialize_source_k1", "demi_provenance_prune", "demi_device_probe", "demi_device_probe_mix", "demi_calib_rw", "demi_random_explore_flagged", "demi_collect_flagged_dev",
+           "demi_specialize_check", "demi_specialize_source", "demi_specialize_source_k1", "demi_provenance_prune", "demi_device_probe", "demi_device_probe_mix", "demi_calib_rw", "demi_random_explore_flagged", "demi_collect_flagged_dev", "demi_random_explore_submit", "demi_random_explore_wait",
            "demi_comm_unique_id", "demi_comm_create", "demi_comm_create_host", "demi_comm_destroy", "demi_comm_rank",
            "demi_comm_allgather_dev", "demi_random_explore_sharded", "demi_replay_batch_sharded", "demi_abi_version", "demi_replay_externals_len", "demi_edit_distance_dpor_ddmin", "demi_dpor_explored", "demi_random_ddmin", "demi_random_explore_candidates"]
 
@@ -109,6 +109,9 @@ def lib():
                                                  C.c_uint32, C.POINTER(C.c_uint64)]
     L.demi_random_explore_flagged.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(T.Limits), C.c_uint32, C.c_void_p,
                                               C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.demi_random_explore_submit.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(T.Limits), C.c_uint32, C.POINTER(C.c_uint32)]
+    L.demi_random_explore_wait.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64),
+                                           C.POINTER(C.c_uint64)]
     L.demi_collect_flagged_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint32,
                                            C.c_void_p, C.c_void_p]
     L.demi_comm_unique_id.argtypes = [C.c_void_p]
@@ -226,6 +229,22 @@ class Context:
         self._check(lib().demi_random_explore_flagged(self._h, C.c_uint64(seed_base), n, C.byref(limits), flag_mask,
                                                       out.ctypes.data, cap, C.byref(cnt), C.byref(first)))
         return out[:min(cnt.value, cap)].copy(), int(cnt.value), int(first.value)
+
+    def random_explore_submit(self, n, limits, seed_base=0, flag_mask=0):
+        """explore() in pieces, two in flight: enqueue n executions on a stream of the context's own; returns the ticket."""
+        t = C.c_uint32(0)
+        self._check(lib().demi_random_explore_submit(self._h, C.c_uint64(seed_base), n, C.byref(limits), flag_mask, C.byref(t)))
+        return int(t.value)
+
+    def random_explore_wait(self, ticket, out=None, cap=1 << 16):
+        """-> (flagged entries sorted by index, their exact count, the lowest flagged index or 2^64 - 1); out: a VERDICT_DTYPE
+        array of the call's n entries to receive every verdict, or None"""
+        import numpy as np
+        fl = np.zeros(cap, dtype=T.VIOLATION_DTYPE)
+        cnt, first = C.c_uint64(0), C.c_uint64(0)
+        self._check(lib().demi_random_explore_wait(self._h, ticket, out.ctypes.data if out is not None else None, fl.ctypes.data, cap,
+                                                   C.byref(cnt), C.byref(first)))
+        return fl[:min(cnt.value, cap)].copy(), int(cnt.value), int(first.value)
 
     def random_explore_dev(self, n, limits, d_out_ptr, seed_base=0, d_seeds_ptr=None, stream=None):
         self._check(lib().demi_random_explore_dev(self._h, C.c_uint64(seed_base), d_seeds_ptr, n, C.byref(limits),

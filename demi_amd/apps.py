@@ -41,8 +41,30 @@ def raft5_config4(n_events=200):
     return model, events, limits
 
 
+def raft5_dpor_config3():
+    """BASELINE config 3 as bench.py times it from round 6 on: DPORwHeuristics over raft5-synth - the SAME rows as config 2's
+    table, seeded bug included - depth_bound 30, Start x 5 + Send(Bootstrap) x 5, trackHistory, stopIfViolationFound = false,
+    explored until the backtrack queue is empty.  Two things differ from raft5_config3() below, both so that the exploration
+    FINDS the seeded bug (rounds 1-5 explored 60 332 interleavings and the violating set was empty):
+      * prioritizePendingUponDivergence = true (DPORwHeuristics.scala:65-68, 537-550; what RunnerUtils.editDistanceDporDDMin
+        constructs its DPOR with, RunnerUtils.scala:824-827).  Without it a flipped pair is undone on the spot: the first
+        expected event that is not pending - a reply to the message the flip postponed - makes getMatchingMessage fall back to
+        getPendingEvent (:594-625), whose first queue holds exactly the postponed message.
+      * nodes 3 and 4 never campaign (election budgets 1, 1, 1, 0, 0: initial field values, no row changes).  The invariant is
+        checked on the FINAL state (notify_quiescence, :877-902); with five campaigning nodes every execution ends after the
+        last node's election in a fresh term, which hides an earlier term's two leaders.
+    297 396 interleavings in ROUNDS order, 7 237 of them violating (oracle; the counts of the reference's order are in
+    tests/golden/dpor_config3_bug_reference_order.json).  Returns (model, externals, DporParams)."""
+    from .fuzzer import send, start
+    from .model import M_BOOTSTRAP
+    model = raft_model(5, election_budget=(1, 1, 1, 0, 0))
+    events = events_to_array([start(a) for a in range(5)] + [send(a, M_BOOTSTRAP) for a in range(5)])
+    return model, events, T.DporParams(30, 0, 0, 0, 64, 4096, 1)
+
+
 def raft5_config3(n_sends=5):
-    """BASELINE config 3: DPORwHeuristics, depth_bound 30, Start x 5 + Send x k (DPOR supports only
+    """BASELINE config 3 as rounds 1-5 timed it (kept: a parity workload of the suites, 60 332 interleavings in the reference's
+    order, none violating - see raft5_dpor_config3): DPORwHeuristics, depth_bound 30, Start x 5 + Send x k (DPOR supports only
     Start / Send / WaitQuiescence), stopIfViolationFound=false, trackHistory=true."""
     from .fuzzer import send, start
     from .model import M_BOOTSTRAP
@@ -78,3 +100,18 @@ def shuffle8_config5_large(jobs=3):
     model = shuffle_model(jobs=jobs)
     dpor_events = events_to_array([start(a) for a in range(8)] + [send(0, SH_SUBMIT), send(0, SH_SPECULATE, 1)])
     return model, dpor_events, 40, 1 << 20
+
+
+def shuffle8_dpor_config5(jobs=3):
+    """BASELINE config 5 as bench.py times it from round 6 on: shuffle8_config5_large's pipeline with the pipeline's second
+    seeded bug (model.shuffle_model(early_cleanup=True): reducer 7 frees its map output as soon as it has finished) and
+    prioritizePendingUponDivergence = true (see raft5_dpor_config3).  The duplicate-MapDone bug alone needs the FIRST job's
+    straggler detector - the shallow end of a deepest-first search: with two jobs the first violating interleaving is number
+    1 652 292, with three it lies beyond any budget run here - so the 2^20-interleaving record of rounds 4-5 had an empty
+    violating set.  With the reduce-phase race the search reports its first violation within a few hundred interleavings.
+    Returns (model, externals, DporParams, budget)."""
+    from .fuzzer import send, start
+    from .model import SH_SPECULATE, SH_SUBMIT, shuffle_model
+    model = shuffle_model(jobs=jobs, early_cleanup=True)
+    dpor_events = events_to_array([start(a) for a in range(8)] + [send(0, SH_SUBMIT), send(0, SH_SPECULATE, 1)])
+    return model, dpor_events, T.DporParams(40, 0, 0, 0, 64, 4096, 1), 1 << 20

@@ -558,9 +558,14 @@ def raft_model(n_actors=5, election_budget=1, buggy=True, term0=0, loglen0=0, in
         a.bcast(M_APPEND_ENTRIES, TERM, LOGLEN).label("done")
     h[(0, "Heartbeat")] = a
 
-    init = [[FOLLOWER, term0, NOBODY, 0, election_budget, loglen0, loglen0, 0] for _ in range(n_actors)]
-    return build_model("raft%d-synth%s%s%s%s" % (n_actors, "" if buggy else "-fixed", "-wide" if wide else "", "-log%d" % log_cap if log_cap else "",
-                                                 "-fields" if real_fields else ""),
+    # election_budget: one number, or one per node (the rows do not change, only the nodes' initial BUDGET field: a node with
+    # budget 0 votes and replicates but never campaigns)
+    budgets = list(election_budget) if isinstance(election_budget, (list, tuple)) else [election_budget] * n_actors
+    assert len(budgets) == n_actors
+    init = [[FOLLOWER, term0, NOBODY, 0, b, loglen0, loglen0, 0] for b in budgets]
+    return build_model("raft%d-synth%s%s%s%s%s" % (n_actors, "" if buggy else "-fixed", "-wide" if wide else "", "-log%d" % log_cap if log_cap else "",
+                                                   "-fields" if real_fields else "",
+                                                   "-eb" + "".join(str(b) for b in budgets) if len(set(budgets)) > 1 else ""),
                        n_actors, RAFT_MSGS, h, init, invariant=invariant or (T.INV_AT_MOST_ONE, int(ROLE), LEADER, int(TERM)), wide=wide,
                        array_len=log_cap, payloads=5 if real_fields else 2)
 
@@ -589,7 +594,7 @@ SH_REDUCEDONE = 9      # the pipeline variant only (shuffle_model(jobs > 1))
 CLS_DRIVER, CLS_COORD, CLS_WORKER = 0, 1, 2
 
 
-def shuffle_model(buggy=True, jobs=1) -> Model:
+def shuffle_model(buggy=True, jobs=1, early_cleanup=False) -> Model:
     """Actors: 0 driver, 1 map-stage coordinator, 2 reduce-stage coordinator, 3..7 workers.
 
     jobs > 1 is the PIPELINE variant (BASELINE config 5 at a size worth sharding, apps.shuffle8_config5_large): the reduce stage
@@ -597,9 +602,15 @@ def shuffle_model(buggy=True, jobs=1) -> Model:
     StageDone(2) - and the driver then launches the next job itself, `jobs` of them back to back.  The next job's messages
     descend from the delivery that completed the previous one, so its whole subtree of DPOR nodes is new for every way the
     previous job can end: the space of racing pairs multiplies per job instead of adding up.  jobs = 1 is the table every
-    fixture of rounds 1-3 was taken on, row for row."""
+    fixture of rounds 1-3 was taken on, row for row.
+    early_cleanup (pipeline only): the pipeline's second seeded bug - reducer 7, once it has all its FetchReplies, frees its own
+    map output at once although other reducers may not have fetched it yet (shuffle files removed too early); their Fetch then
+    finds nothing and the invariant's sticky flag F2 is raised.  Unlike the duplicate MapDone (which needs the straggler
+    detector of the FIRST job and so sits at the shallow end of a depth-first exploration) this race lives in every job's
+    reduce phase: a bounded DPOR search meets it within its first few hundred interleavings (round 6)."""
     n_workers = 5
     pipeline = jobs > 1
+    early_cleanup = bool(early_cleanup and buggy and pipeline)
     assert 1 <= jobs <= 255
     h = {}
     # ---- driver: F0 phase (0 idle, 1 map, 2 reduce, 3 done), F1 reports counted, F2 bitmask of workers reported, F6 job number
@@ -661,14 +672,17 @@ def shuffle_model(buggy=True, jobs=1) -> Model:
     a = Asm()          # FetchReply(has_output)
     a.add(F[1], F[1], 1).if_eq(P0, 0, "y").mov(F[2], 1).label("y")
     if pipeline:       # the last of the n_workers - 1 replies: this reducer is done
-        a.if_eq(F[1], n_workers - 1, "x").mov(T0, 2).send(SH_REDUCEDONE, T0, T1, 0).label("x")
+        a.if_eq(F[1], n_workers - 1, "x")
+        if early_cleanup:
+            a.if_eq(ME, 7, "keep").mov(F[0], 0).label("keep")
+        a.mov(T0, 2).send(SH_REDUCEDONE, T0, T1, 0).label("x")
     h[(CLS_WORKER, "FetchReply")] = a
     a = Asm()          # TaskTimeout: a straggler detector re-reports (duplicate MapDone)
     a.if_eq(F[0], 1, "x").if_lt(F[4], 1, "x").add(F[4], F[4], 1).mov(T0, 1).send(SH_MAPDONE, T0, T1, 0).label("x")
     h[(CLS_WORKER, "TaskTimeout")] = a
     # coordinators ignore worker-only messages and vice versa (handler_start 0xFFFF)
     init = [[0] * 8 for _ in range(8)]
-    return build_model("shuffle8-synth%s%s" % ("" if buggy else "-fixed", "-x%d" % jobs if pipeline else ""), 8,
+    return build_model("shuffle8-synth%s%s%s" % ("" if buggy else "-fixed", "-x%d" % jobs if pipeline else "", "-c" if early_cleanup else ""), 8,
                        SH_MSGS + ([("ReduceDone", T.MSG_INTERNAL)] if pipeline else []), h, init,
                        invariant=(T.INV_NEVER, 2, 1, 0), actor_class=[CLS_DRIVER, CLS_COORD, CLS_COORD] + [CLS_WORKER] * 5,
                        n_classes=3)

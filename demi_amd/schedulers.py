@@ -111,6 +111,7 @@ class RandomScheduler:
         self.strategy = T.STRATEGY_SRC_DST_FIFO if isinstance(randomizationStrategy, SrcDstFIFO) else T.STRATEGY_FULLY_RANDOM
         self.maxMessages = 0x7FFFFFFF            # Int.MaxValue (:54)
         self.p_max = p_max
+        self.chunk = 1 << 20                     # executions per device call of explore() (two calls in flight)
         self.stats: Optional[MinimizationStats] = None
         self._model: Optional[Model] = schedulerConfig.model
         self._ctx = _native.Context(device)
@@ -192,6 +193,69 @@ class RandomScheduler:
         # only the violating and the aborted executions cross PCIe (16 B each instead of 16 B per schedule).  An execution
         # aborted on a capacity has no valid verdict: it is re-run alone with the largest pending set before any
         # higher index is believed (the reference has no capacities; its answer is the lowest violating index)
+        # The executions go to the device in calls of `chunk` (BASELINE config 2's step), two of them in flight in the one
+        # context (demi_random_explore_submit / _wait: call k + 1 runs while call k is waited for and its candidates are
+        # examined - GpuRandomScheduler.explore in scala/ is this loop), and nothing beyond the first violating call is submitted.
+        lim = self._limits(_lookingFor)
+        start, i = 0, None
+        self.last_aborted_reruns = 0
+        self.last_calls = 0
+        inflight = [None]                         # (first execution, executions, ticket) of the call already running
+
+        def submit(s):
+            if s >= self.max_executions:
+                return None
+            n = min(self.chunk, self.max_executions - s)
+            self.last_calls += 1
+            return s, n, self._ctx.random_explore_submit(n, self._limits(_lookingFor), seed_base=self.seed_base + s,
+                                                         flag_mask=T.V_VIOLATION | OVF_FLAGS)
+
+        def drain():
+            if inflight[0] is not None:
+                self._ctx.random_explore_wait(inflight[0][2], cap=1)
+                inflight[0] = None
+        try:
+            while start < self.max_executions and i is None:
+                if inflight[0] is not None and inflight[0][0] != start:
+                    drain()
+                cur = inflight[0] or submit(start)
+                span = cur[1]
+                inflight[0] = submit(start + span)
+                hits, n_hits, first = self._ctx.random_explore_wait(cur[2])
+                # a truncated list is an arbitrary subset: only the lowest index (computed on the device) is certain then
+                cand = [(int(h["index"]), int(h["flags"])) for h in hits] if n_hits <= len(hits) else [(first, None)]
+                nxt = start + span
+                for idx, flags in cand:
+                    if flags is not None and not (flags & OVF_FLAGS):
+                        i = start + idx
+                        break
+                    # aborted (or unknown): decide this execution alone
+                    self.last_aborted_reruns += 1
+                    big = self._limits(_lookingFor)
+                    big.p_max = T.MAX_PENDING
+                    v1, _ = self._ctx.random_get_trace(self.seed_base + start + idx, big)
+                    if v1.flags & OVF_FLAGS:
+                        raise CapacityExceeded("schedule %d exceeds the engine's capacities (flags 0x%x)" % (start + idx, v1.flags & 0xFF))
+                    if v1.flags & T.V_VIOLATION:
+                        i = start + idx
+                        lim = big
+                        break
+                    if flags is None:
+                        nxt = start + idx + 1
+                start = nxt
+        finally:
+            drain()
+        if i is None:
+            return None
+        v, rec = self._ctx.random_get_trace(self.seed_base + i, lim)
+        assert v.flags & T.V_VIOLATION
+        # checkIfBugFound prunes the externals that were never injected (:160-163)
+        used = ev[:T.verdict_trace_idx(v.flags)]
+        mask = self._model.fp_match_mask if self._model else 0xFFFFFFFF
+        return EventTrace(rec, used), ViolationFingerprint(int(v.fingerprint), mask)
+
+    def _explore_one_call(self, ev, _lookingFor):
+        """explore() as rounds 1-5 ran it: ONE device call for all the executions (kept for the comparison in the suite)."""
         lim = self._limits(_lookingFor)
         start, i = 0, None
         self.last_aborted_reruns = 0

@@ -16,7 +16,10 @@
  * The *_dev entry points enqueue on the caller's stream and return without synchronising; a ctx runs ONE launch at a
  * time (its work counter and scratch are shared): a launch on a different stream than the ctx's previous one waits for
  * that one on the device, and demi_model_load / demi_trace_load / demi_replay_load wait for the last launch before they
- * replace what the kernels read.  Concurrent launches need one ctx each.
+ * replace what the kernels read.  The exception is the RandomScheduler kernel (demi_random_explore_dev and everything
+ * built on it): a ctx holds TWO sets of its per-launch scratch and alternates between them, so two of its launches on
+ * two streams overlap - the tail of one with the start of the next (demi_random_explore_submit / _wait do that with
+ * two streams of the ctx's own, for hosts that have no HIP streams).  Other concurrent launches need one ctx each.
  * Pointers named d_* are DEVICE pointers; all others are host pointers.
  *
  * Environment.  The library reads exactly two environment variables on its own account:
@@ -727,6 +730,21 @@ int demi_random_explore_violations(demi_ctx* ctx, uint64_t seed_base, uint64_t n
  * the lowest selected index, computed on the device: exact even when the list is truncated.                        */
 int demi_random_explore_flagged(demi_ctx* ctx, uint64_t seed_base, uint64_t n, const demi_limits* limits, uint32_t flag_mask,
                                 demi_violation* out, uint32_t cap, uint64_t* n_flagged, uint64_t* first_index);
+
+/* explore() in pieces, two of them in flight (RandomScheduler.scala:234-272: the loop over executions, here cut into calls of n
+ * executions each).  demi_random_explore_submit enqueues the n executions seeded seed_base .. seed_base + n - 1 and the
+ * compaction of the verdicts whose flags intersect flag_mask (0 = DEMI_V_VIOLATION) on a stream of the ctx's own and returns
+ * at once with a ticket; at most two tickets are outstanding.  demi_random_explore_wait blocks until that call has finished and
+ * returns what demi_random_explore_flagged returns (list sorted by index, truncated to cap <= 65536; *n_flagged and
+ * *first_index exact) and, if `out` is not NULL, all n verdicts.  While a host waits for ticket k the kernel of ticket k + 1
+ * already runs: the thinning tail of a launch is filled by the next launch's workgroups and the copies of k cross PCIe under
+ * it - a JVM loop `submit(k + 1); wait(k)` gets the rate bench.py reports without owning a HIP stream.  A driver that wants
+ * the reference's answer (the lowest violating index) stops submitting at the first call that reports one.
+ * Not for the carried-generator mode (one chain of executions: nothing to overlap). */
+int demi_random_explore_submit(demi_ctx* ctx, uint64_t seed_base, uint64_t n, const demi_limits* limits, uint32_t flag_mask,
+                               uint32_t* ticket);
+int demi_random_explore_wait(demi_ctx* ctx, uint32_t ticket, demi_verdict* out, demi_violation* flagged, uint32_t cap,
+                             uint64_t* n_flagged, uint64_t* first_index);
 
 int demi_collect_violations_dev(demi_ctx* ctx, const demi_verdict* d_verdicts, uint64_t n, uint64_t index_base,
                                 demi_violation* d_out, uint32_t cap, unsigned long long* d_count,

@@ -152,6 +152,29 @@ JNIEXPORT jint JNICALL FN(randomExploreFlagged)(JNIEnv* e, jclass c, jlong h, jl
   SET_LONGS(counts, 2, cn);
   return rc;
 }
+/* explore() in pieces, two calls in flight in one context.  Returns the ticket (> 0) or a negative demi_status. */
+JNIEXPORT jint JNICALL FN(randomExploreSubmit)(JNIEnv* e, jclass c, jlong h, jlong seedBase, jlong n, jintArray limits, jint flagMask) {
+  demi_limits lim;
+  uint32_t ticket = 0;
+  (void)c;
+  if (limits_of(e, limits, &lim) || n <= 0) return DEMI_ERR_INVALID_ARG;
+  const int rc = demi_random_explore_submit(CTX(h), (uint64_t)seedBase, (uint64_t)n, &lim, (uint32_t)flagMask, &ticket);
+  return rc ? rc : (jint)ticket;
+}
+/* out: long[2 * cap] (flagged entries, sorted by index); counts: long[2] = { number flagged, lowest flagged index } */
+JNIEXPORT jint JNICALL FN(randomExploreWait)(JNIEnv* e, jclass c, jlong h, jint ticket, jlongArray out, jlongArray counts) {
+  (void)c;
+  if (ticket <= 0 || LEN(out) < 0 || LEN(out) % 2 || LEN(counts) != 2) return DEMI_ERR_INVALID_ARG;
+  const uint32_t cap = (uint32_t)(LEN(out) / 2);
+  uint64_t n_flagged = 0, first = 0;
+  void* o = LONGS(out);
+  jint rc = LOST(out, o) ? DEMI_ERR_INVALID_ARG
+                         : demi_random_explore_wait(CTX(h), (uint32_t)ticket, NULL, (demi_violation*)o, cap, &n_flagged, &first);
+  PUT_LONGS(out, o, 0);
+  const jlong cn[2] = {(jlong)n_flagged, (jlong)first};
+  SET_LONGS(counts, 2, cn);
+  return rc;
+}
 /* verdict: long[2]; recorded: byte[16 * cap]; returns the number of recorded events, or a negative demi_status */
 JNIEXPORT jint JNICALL FN(randomGetTrace)(JNIEnv* e, jclass c, jlong h, jlong seed, jintArray limits, jlongArray verdict, jbyteArray recorded) {
   demi_limits lim;

@@ -21,6 +21,10 @@ object DemiGpu {
   @native def randomExplore(h: Long, seedBase: Long, n: Long, limits: Array[Int], verdicts: Array[Long]): Int
   @native def randomExploreFlagged(h: Long, seedBase: Long, n: Long, limits: Array[Int], flagMask: Int,
                                    out: Array[Long], counts: Array[Long]): Int
+  /** explore() in pieces, two calls in flight in one context (demi_random_explore_submit / _wait): the ticket (> 0) or a
+   *  negative status; wait fills `out` / `counts` as randomExploreFlagged does */
+  @native def randomExploreSubmit(h: Long, seedBase: Long, n: Long, limits: Array[Int], flagMask: Int): Int
+  @native def randomExploreWait(h: Long, ticket: Int, out: Array[Long], counts: Array[Long]): Int
   /** returns the number of recorded events (16 bytes each in `recorded`: demi_rec_event), or a negative status */
   @native def randomGetTrace(h: Long, seed: Long, limits: Array[Int], verdict: Array[Long], recorded: Array[Byte]): Int
   /** the same for execution number `execIndex` of the instance seeded `seed` (demi_limits.executions_per_instance > 1) */

@@ -77,6 +77,11 @@ object GpuDepTracker {
  *  first violating one is returned - and is what a JVM run with the same seed can be compared with execution by execution
  *  (sequential by nature: use it for that comparison, not for throughput).  The default is "N independent executions with
  *  seeds seed, seed + 1, ...", the lowest violating index returned: RunnerUtils.fuzz's shape, and the parallel one. */
+object GpuRandomScheduler {
+  /** executions per device call of explore() (BASELINE config 2's step: 2^20 schedules) */
+  val CHUNK = 1L << 20
+}
+
 class GpuRandomScheduler(val schedulerConfig: SchedulerConfig, max_executions: Int = 1, invariant_check_interval: Int = 0,
                          seed: Long = System.currentTimeMillis(), lowering: TableLowering, device: Int = 0,
                          srcDstFifo: Boolean = false, pMax: Int = 64, carriedGenerator: Boolean = false)
@@ -125,10 +130,33 @@ class GpuRandomScheduler(val schedulerConfig: SchedulerConfig, max_executions: I
     // Python mirror raises CapacityExceeded): the whole chain - exploration AND the recording re-run - is then repeated with the
     // largest pending set, and if an execution still does not fit the JVM scheduler has to decide the instance.
     var chainPMax = pMax
-    while (start < max_executions) {
+    // Fresh generator per execution (the shape of RunnerUtils.fuzz): the executions go to the device in calls of CHUNK, two
+    // of them in flight - call k + 1 runs while call k is waited for and its candidates are examined (the library overlaps
+    // the tail of one launch with the start of the next), and nothing beyond the first violating call is ever submitted.
+    val pipelined = !carriedGenerator
+    var inflight: Option[(Long, Long, Int)] = None        // the call that is already running: (first execution, executions, ticket)
+    def submit(s: Long): Option[(Long, Long, Int)] =
+      if (s >= max_executions) None
+      else {
+        val n = math.min(GpuRandomScheduler.CHUNK, max_executions - s)
+        Some((s, n, check(h, randomExploreSubmit(h, seed + s, n, limits(lookingFor, pMax), V_VIOLATION | OVF))))
+      }
+    def drain() {
+      inflight.foreach { case (_, _, t) => randomExploreWait(h, t, new Array[Long](0), new Array[Long](2)) }
+      inflight = None
+    }
+    try { while (start < max_executions) {
       val out = new Array[Long](2 * 65536); val counts = new Array[Long](2)
-      check(h, randomExploreFlagged(h, seed + start, max_executions - start, limits(lookingFor, chainPMax), V_VIOLATION | OVF, out, counts))
-      if (counts(0) == 0) return None
+      var span = max_executions - start                    // executions [start, start + span) are decided by this pass
+      if (pipelined) {
+        if (inflight.exists(_._1 != start)) drain()
+        val cur = inflight.orElse(submit(start)).get
+        span = cur._2
+        inflight = submit(start + span)
+        check(h, randomExploreWait(h, cur._3, out, counts))
+      } else
+        check(h, randomExploreFlagged(h, seed + start, max_executions - start, limits(lookingFor, chainPMax), V_VIOLATION | OVF, out, counts))
+      if (counts(0) == 0 && !pipelined) return None
       // (index, flags) in index order; a truncated list is an arbitrary subset: then only the lowest index is certain
       val cand0 = if (counts(0) <= 65536) (0 until counts(0).toInt).map(i => (out(2 * i), ((out(2 * i + 1) >>> 32) & 0xFF).toInt))
                   else Seq((counts(1), -1))
@@ -137,7 +165,7 @@ class GpuRandomScheduler(val schedulerConfig: SchedulerConfig, max_executions: I
       if (chainOvf && chainPMax == MAX_PENDING)
         throw new UnsupportedOnGpu("an execution of the carried-generator instance exceeds the engine's capacities")
       val cand = if (chainOvf) { chainPMax = MAX_PENDING; Seq.empty[(Long, Int)] } else cand0
-      var next = if (chainOvf) 0L else max_executions.toLong          // (0: the same chain again, with the largest pending set)
+      var next = if (chainOvf) 0L else start + span                   // (0: the same chain again, with the largest pending set)
       for ((idx, fl) <- cand) {
         var lim = limits(lookingFor, chainPMax)
         if (fl < 0 || (fl & OVF) != 0) lim = limits(lookingFor, MAX_PENDING)
@@ -155,9 +183,9 @@ class GpuRandomScheduler(val schedulerConfig: SchedulerConfig, max_executions: I
         }
         if (fl < 0) next = start + idx + 1
       }
-      if (counts(0) <= 65536 && !chainOvf) return None
+      if (counts(0) <= 65536 && !chainOvf && start + span >= max_executions) return None
       start = next
-    }
+    } } finally drain()
     None
   }
 

@@ -83,6 +83,10 @@ static inline hipError_t hipMemset(void* d, int v, size_t n) { if (n) memset(d, 
 static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t = nullptr) { if (n) memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+#define hipStreamNonBlocking 1u
+// (every launch of the emulator is synchronous: a stream is a name)
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { static char names[64]; static int next = 0; *s = &names[next++ & 63]; return hipSuccess; }
+static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned = 0) { return hipSuccess; }
 static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new w64_event{0.0}; return hipSuccess; }
 static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }

@@ -37,7 +37,13 @@ class Unique:
 
 
 class ScalaDPORwHeuristics:
-    def __init__(self, oracle, model, externals, depth_bound=0, max_messages=0, trackHistory=True):
+    def __init__(self, oracle, model, externals, depth_bound=0, max_messages=0, trackHistory=True, prioritizePendingUponDivergence=False,
+                 lean=False):
+        self.prioritizePendingUponDivergence = prioritizePendingUponDivergence
+        # lean (tools/check_golden_dpor_transliteration.py --bug: hundreds of thousands of interleavings, ~2 000 racing pairs each):
+        # the backtrack queue holds ONE entry per flipped pair instead of one per report - see dpor() for why that is the same
+        # exploration; test_lean_queue_is_the_literal_queue holds the two against each other
+        self.lean, self.best, self.exploredFlat = lean and trackHistory, {}, set()
         self.oracle, self.model, self.ms = oracle, model, model.to_struct()
         self.should_bound, self.stop_at_depth = bool(depth_bound), depth_bound
         self.should_cap_messages, self.max_messages = bool(max_messages), max_messages
@@ -182,7 +188,12 @@ class ScalaDPORwHeuristics:
             if self.should_cap_messages and self.messagesScheduledSoFar > self.max_messages:
                 return None
             if not self.awaitingQuiescence:
-                result = self.getMatchingMessage()
+                if self.prioritizePendingUponDivergence:           # getNextMatchingMessage (:537-550): pop heads until one matches
+                    result = None
+                    while self.nextTrace and result is None:
+                        result = self.getMatchingMessage()
+                else:
+                    result = self.getMatchingMessage()
                 if result is None:
                     result = self.getPendingEvent()
             else:
@@ -258,9 +269,14 @@ class ScalaDPORwHeuristics:
 
     # ------------------------------------------------------------------ ExploredTacker, dpor(), getNext()
     def setExplored(self, index, pair):
-        self.exploredStack.setdefault(index, set()).add(pair)
+        if self.lean:
+            self.exploredFlat.add(pair)      # (the union of the index sets is all isExplored ever asks for)
+        else:
+            self.exploredStack.setdefault(index, set()).add(pair)
 
     def isExplored(self, pair):
+        if self.lean:
+            return pair in self.exploredFlat
         return any(pair in s for s in self.exploredStack.values())
 
     def dpor(self, trace):
@@ -287,12 +303,32 @@ class ScalaDPORwHeuristics:
                 assert branchI < laterI
                 if self.trackHistory:
                     self.setExplored(branchI, (earlier, later))
+                if self.lean:
+                    # Memory only, not behaviour.  (1) exploredStack never shrinks (trimExplored is commented out in the Scala),
+                    # so a point whose pair is explored NOW would be skipped whenever it is popped: not stored.  (2) of several
+                    # stored points for one pair the queue pops the one with the largest branchI (ties: the oldest) first and
+                    # marks the pair, so the others would be skipped: only that one is kept (the superseded heap entry stays
+                    # behind and is recognised by its sequence number).  The replay list is built at the pop from the trace.
+                    pair = (later, earlier)
+                    if not self.isExplored(pair):
+                        cur = self.best.get(pair)
+                        if cur is None or branchI > cur[0]:
+                            self.best[pair] = (branchI, self.seq)
+                            heapq.heappush(self.backTrack, (-branchI, self.seq, pair, (trace, branchI, laterI, earlier.id)))
+                    self.seq += 1
+                    continue
                 heapq.heappush(self.backTrack, (-branchI, self.seq, (later, earlier), needToReplay))
                 self.seq += 1
         while True:                                                    # getNext
             if not self.backTrack:
                 return None
             negI, _s, (e1, e2), replayThis = heapq.heappop(self.backTrack)
+            if self.lean:
+                if self.best.get((e1, e2), (None, None))[1] != _s:
+                    continue                                           # superseded by a deeper point for the same pair
+                del self.best[(e1, e2)]
+                tr, b, li, eid = replayThis
+                replayThis = [x for x in tr[b + 1:li + 1] if x.id != eid]
             if self.trackHistory and self.isExplored((e1, e2)):
                 continue
             maxIndex = -negI
@@ -354,7 +390,26 @@ def _config5(cap):
     return model, ev, depth, 0, cap
 
 
+def _config3_bug(cap):
+    from demi_amd.apps import raft5_dpor_config3
+    model, ev, par = raft5_dpor_config3()
+    return model, ev, int(par.depth_bound), 0, cap, True
+
+
+def _config5_bug(cap):
+    from demi_amd.apps import shuffle8_dpor_config5
+    model, ev, par, _budget = shuffle8_dpor_config5()
+    return model, ev, int(par.depth_bound), 0, cap, True
+
+
 CASES = {
+    # round 6: the DPOR workloads bench.py times (prioritizePendingUponDivergence; they find the seeded bugs), their first
+    # interleavings (the whole of config 3 - hundreds of thousands - is tools/check_golden_dpor_transliteration.py --bug)
+    "raft5_dpor_config3_first_250": lambda: _config3_bug(250),
+    "shuffle8_dpor_config5_first_250": lambda: _config5_bug(250),
+    # prioritizePendingUponDivergence where a flip decides the verdict: two campaigning nodes of three, exhausted
+    "raft3_two_campaigners_prioritize": lambda: (M.raft_model(3, election_budget=(1, 1, 0)), events_to_array([start(a) for a in range(3)] +
+                                                 [send(a, M.M_BOOTSTRAP) for a in range(3)]), 30, 0, 20000, True),
     "writers4": lambda: (writers_model(4), events_to_array([start(a) for a in range(5)] + [send(a, 0) for a in range(1, 5)]), 0, 0, 2500),
     "raft3": lambda: (M.raft_model(3), events_to_array([start(a) for a in range(3)] + [send(a, M.M_BOOTSTRAP) for a in range(3)]), 30, 0, 300),
     "raft3_two_periods": lambda: (M.raft_model(3), events_to_array([start(a) for a in range(3)] + [send(0, M.M_BOOTSTRAP),
@@ -374,10 +429,13 @@ CASES = {
 
 @pytest.mark.parametrize("case", sorted(CASES))
 def test_whole_exploration_equals_the_scala_transliteration(oracle, case):
-    model, ev, depth, maxm, cap = CASES[case]()
-    sc = ScalaDPORwHeuristics(oracle, model, ev, depth_bound=depth, max_messages=maxm)
+    model, ev, depth, maxm, cap, *pp = CASES[case]()
+    pp = bool(pp and pp[0])
+    sc = ScalaDPORwHeuristics(oracle, model, ev, depth_bound=depth, max_messages=maxm, prioritizePendingUponDivergence=pp)
     exhausted = sc.run(cap)
-    nat = native_explore(model, ev, PAR(depth=depth, maxm=maxm), 1, cap)
+    par = PAR(depth=depth, maxm=maxm)
+    par.prioritize_pending = 1 if pp else 0
+    nat = native_explore(model, ev, par, 1, cap)
     assert len(nat[0]) == len(sc.verdicts) and bool(nat[4].exhausted) == exhausted
     want = np.array(sc.verdicts, dtype=[("flags", "<u4"), ("fingerprint", "<u4"), ("hash", "<u8")])
     for f in ("flags", "fingerprint", "hash"):
@@ -387,6 +445,22 @@ def test_whole_exploration_equals_the_scala_transliteration(oracle, case):
         assert exhausted and 0 < int((want["flags"] & T.V_VIOLATION != 0).sum()) < len(want)
     if case == "raft3_late_start_and_cap":
         assert int((want["flags"] & T.V_MAXMSG != 0).sum()) > 0
+    if case in ("raft3_two_campaigners_prioritize", "shuffle8_dpor_config5_first_250"):
+        assert 0 < int((want["flags"] & T.V_VIOLATION != 0).sum()) < len(want)
+    if case == "raft3_two_campaigners_prioritize":
+        assert exhausted
+
+
+@pytest.mark.parametrize("case", ["raft3_two_campaigners_prioritize", "raft3", "raft5_dpor_config3_first_250", "raft3_two_periods"])
+def test_lean_queue_is_the_literal_queue(oracle, case):
+    """ScalaDPORwHeuristics(lean=True) - one queue entry per flipped pair, what the hours-long run of the tool uses - explores the
+    interleavings of the literal queue, in its order."""
+    model, ev, depth, maxm, cap, *pp = CASES[case]()
+    pp = bool(pp and pp[0])
+    a = ScalaDPORwHeuristics(oracle, model, ev, depth_bound=depth, max_messages=maxm, prioritizePendingUponDivergence=pp)
+    b = ScalaDPORwHeuristics(oracle, model, ev, depth_bound=depth, max_messages=maxm, prioritizePendingUponDivergence=pp, lean=True)
+    assert a.run(cap) == b.run(cap)
+    assert a.verdicts == b.verdicts and a.next_trace_lens == b.next_trace_lens and len(a.verdicts) > 100
 
 
 def test_config3_golden_record_is_the_transliterations_too():

@@ -540,3 +540,72 @@ def test_first_schedules_against_the_random_scheduler_transliterations_record(gp
         v = gpu_ctx.random_explore(n, lim, seed_base=SEED_BASE)
         assert hashlib.sha256(np.ascontiguousarray(v).tobytes()).hexdigest() == rec["sha256_verdicts_of_the_first"][str(n)], specialised
     gpu_ctx.model_specialize(False)
+
+
+def test_two_calls_in_flight_in_one_context(oracle):
+    """demi_random_explore_submit / _wait: explore() in pieces with two of them running in ONE context (a second set of K1's
+    per-launch scratch, two streams of the context's own).  Every call returns what demi_random_explore_flagged returns for its
+    seeds and, on request, all its verdicts = the oracle's; a third submit is refused until a ticket is waited for; tickets
+    are single-use; a (re)load of the trace waits for both calls."""
+    from demi_amd import _native
+    model, events, lim = raft5_config2()
+    ctx = _native.Context(0)
+    try:
+        ctx.model_load(model.to_struct())
+        ctx.trace_load(events)
+        ctx.model_specialize()
+        n, k = (1 << 12, 5) if os.environ.get("DEMI_EMU") == "1" else (1 << 18, 7)
+        mask = T.V_VIOLATION | T.V_PENDING_OVF | T.V_QUEUE_OVF
+        want_flagged = [ctx.random_explore_flagged(n, lim, mask, seed_base=SEED_BASE + j * n) for j in range(k)]
+        tickets = [ctx.random_explore_submit(n, lim, seed_base=SEED_BASE + j * n, flag_mask=mask) for j in range(2)]
+        assert tickets[0] != tickets[1] and all(t > 0 for t in tickets)
+        with pytest.raises(_native.DemiError):
+            ctx.random_explore_submit(n, lim, seed_base=SEED_BASE, flag_mask=mask)
+        for j in range(k):
+            out = np.zeros(n, dtype=T.VERDICT_DTYPE) if j in (0, k - 1) else None
+            hits, cnt, first = ctx.random_explore_wait(tickets[j], out=out)
+            with pytest.raises(_native.DemiError):
+                ctx.random_explore_wait(tickets[j])                  # a ticket is waited for once
+            if j + 2 < k:
+                tickets.append(ctx.random_explore_submit(n, lim, seed_base=SEED_BASE + (j + 2) * n, flag_mask=mask))
+            wh, wc, wf = want_flagged[j]
+            assert cnt == wc and first == wf and len(hits) == len(wh) and (hits == wh).all(), j
+            if out is not None:
+                assert_same(out, oracle.random_explore(model, events, n, seed_base=SEED_BASE + j * n, limits=lim, n_threads=os.cpu_count()))
+        # a call in flight when the trace is replaced: the load waits, the call's answer is the old trace's
+        t = ctx.random_explore_submit(n, lim, seed_base=SEED_BASE, flag_mask=mask)
+        ctx.trace_load(events[:10])
+        hits, cnt, first = ctx.random_explore_wait(t)
+        assert cnt == want_flagged[0][1] and (hits == want_flagged[0][0]).all()
+    finally:
+        ctx.close()
+
+
+def test_explore_in_calls_is_explore_in_one_call(oracle):
+    """RandomScheduler.explore (the loop GpuRandomScheduler.explore in scala/ runs): the executions in calls of `chunk`, two in
+    flight, nothing submitted beyond the first violating call - the same first violating execution, trace and fingerprint as
+    ONE call over all executions (rounds 1-5), on a trace whose first violation lies several calls in, and None alike when
+    there is none."""
+    from demi_amd.schedulers import RandomScheduler, SchedulerConfig
+    model, events, lim = raft5_config2()
+    n = 40000
+    want = oracle.random_explore(model, events, n, seed_base=SEED_BASE + 7000, limits=lim, n_threads=os.cpu_count())
+    viol = np.nonzero(want["flags"] & T.V_VIOLATION)[0]
+    assert len(viol) and viol[0] >= 48
+    chunk = int(viol[0]) // 3                       # the first violating execution is in the fourth call
+    sched = RandomScheduler(SchedulerConfig(model=model), max_executions=n, invariant_check_interval=30, seed_base=SEED_BASE + 7000)
+    sched.setMaxMessages(200)
+    sched.chunk = chunk
+    a = sched.explore(events)
+    assert sched.last_calls in (4, 5)                # (the fourth call, and the fifth already in flight behind it)
+    ev = sched._prepare(events)
+    b = sched._explore_one_call(ev, None)
+    assert a is not None and b is not None
+    assert (a[0].events == b[0].events).all() and a[1].code == b[1].code == int(want["fingerprint"][viol[0]])
+    sched.shutdown()
+    fixed = M.raft_model(5, buggy=False)
+    s2 = RandomScheduler(SchedulerConfig(model=fixed), max_executions=5000, invariant_check_interval=30, seed_base=SEED_BASE)
+    s2.setMaxMessages(200)
+    s2.chunk = 1024
+    assert s2.explore(events) is None and s2.last_calls == 5
+    s2.shutdown()

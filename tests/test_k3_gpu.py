@@ -529,7 +529,7 @@ def test_reference_order_with_the_record_fetch_in_flight(monkeypatch):
         ctx.close()
 
 
-@pytest.mark.parametrize("cfg", ["config3", "config5"])
+@pytest.mark.parametrize("cfg", ["config3", "config5", "config3_bug", "config5_bug"])
 def test_device_queue_and_parent_filter_leave_the_exploration_unchanged(monkeypatch, cfg):
     """Round 5's two changes of the ROUNDS path - the backtrack queue on the device (k3_queue.hpp) and the parent filter in
     k3_pairs_insert - against round 4's loop (DEMI_DPOR_HOST_QUEUE: live points and kills to a host queue) and against probing
@@ -538,17 +538,27 @@ def test_device_queue_and_parent_filter_leave_the_exploration_unchanged(monkeypa
     from demi_amd import _native
     from demi_amd.apps import shuffle8_config5_large
     emu = os.environ.get("DEMI_EMU") == "1"
+    par = None
     if cfg == "config3":
         model, ev, depth = raft5_config3()
         budget, batch = (3000, 256) if emu else (1 << 17, 16384)
-    else:
+    elif cfg == "config5":
         model, ev, depth, _b = shuffle8_config5_large()
+        budget, batch = (2000, 256) if emu else (100000, 16384)
+    elif cfg == "config3_bug":          # round 6's workloads: prioritizePendingUponDivergence, violating interleavings in the rounds
+        from demi_amd.apps import raft5_dpor_config3
+        model, ev, par = raft5_dpor_config3()
+        budget, batch = (3000, 256) if emu else (100000, 16384)
+    else:
+        from demi_amd.apps import shuffle8_dpor_config5
+        model, ev, par, _b = shuffle8_dpor_config5()
         budget, batch = (2000, 256) if emu else (100000, 16384)
     ctx = _native.Context(0)
     ctx.model_load(model.to_struct())
     ctx.model_specialize()
     ctx.dpor_load(ev)
-    par, srch = T.DporParams(depth, 0, 0, 0, 64, 4096), T.DporSearch(batch, budget, 0, 1, T.DPOR_ORDER_ROUNDS)
+    par = par or T.DporParams(depth, 0, 0, 0, 64, 4096)
+    srch = T.DporSearch(batch, budget, 0, 1, T.DPOR_ORDER_ROUNDS)
     runs = {}
     for name, env in (("default", {}), ("host_queue", {"DEMI_DPOR_HOST_QUEUE": "1"}), ("no_filter", {"DEMI_K3_NO_PARENT_FILTER": "1"}),
                       ("round4", {"DEMI_DPOR_HOST_QUEUE": "1", "DEMI_K3_NO_PARENT_FILTER": "1"})):
@@ -561,6 +571,8 @@ def test_device_queue_and_parent_filter_leave_the_exploration_unchanged(monkeypa
         monkeypatch.delenv(k, raising=False)
     d = runs["default"]
     assert len(d[0]) == budget or d[4].exhausted
+    if cfg == "config5_bug" and not emu:
+        assert (d[0]["flags"] & T.V_VIOLATION).any()
     for name, r in runs.items():
         assert len(r[0]) == len(d[0]) and (r[0] == d[0]).all() and (r[1] == d[1]).all() and (r[2] == d[2]).all(), name
         assert r[4].queue_len == d[4].queue_len and r[4].backtrack_points == d[4].backtrack_points and r[4].exhausted == d[4].exhausted, name
@@ -569,7 +581,7 @@ def test_device_queue_and_parent_filter_leave_the_exploration_unchanged(monkeypa
     ctx.close()
 
 
-@pytest.mark.parametrize("case", ["late_start_two_periods", "two_periods", "writers", "config3", "config5"])
+@pytest.mark.parametrize("case", ["late_start_two_periods", "two_periods", "writers", "config3", "config5", "config3_bug", "config5_bug"])
 def test_checkpointed_interleavings_are_the_same_interleavings(oracle, monkeypatch, case):
     """k3_dpor starts an interleaving from a record of its parent's state at or below the branch point (K3Snap) instead of
     re-executing the shared prefix.  Against the same exploration without records (DEMI_K3_NO_CHECKPOINT) and against the CPU
@@ -599,10 +611,19 @@ def test_checkpointed_interleavings_are_the_same_interleavings(oracle, monkeypat
     elif case == "config3":
         model, ev, depth = raft5_config3()
         budget, batch = (1500, 256) if emu else (1 << 17, 16384)
-    else:
+    elif case == "config5":
         model, ev, depth, _b = shuffle8_config5_large()
         budget, batch = (1200, 256) if emu else (60000, 16384)
-    par, srch = T.DporParams(depth, 0, 0, 0, 64, 4096), T.DporSearch(batch, budget, 0, 1, T.DPOR_ORDER_ROUNDS)
+    elif case == "config3_bug":         # (prioritizePendingUponDivergence: expected heads that are skipped, before and after a record)
+        from demi_amd.apps import raft5_dpor_config3
+        model, ev, par3 = raft5_dpor_config3()
+        budget, batch = (1500, 256) if emu else (60000, 16384)
+    else:
+        from demi_amd.apps import shuffle8_dpor_config5
+        model, ev, par3, _b = shuffle8_dpor_config5()
+        budget, batch = (1200, 256) if emu else (60000, 16384)
+    par = par3 if case.endswith("_bug") else T.DporParams(depth, 0, 0, 0, 64, 4096)
+    srch = T.DporSearch(batch, budget, 0, 1, T.DPOR_ORDER_ROUNDS)
     ctx = _native.Context(0)
     ctx.model_load(model.to_struct())
     ctx.model_specialize()

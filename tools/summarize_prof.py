@@ -32,11 +32,19 @@ lines, counters, k1 = [], {}, {}
 cur = db_of("prof_stats")
 if cur:
     lines += stats_lines(cur, "python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-secondary") + [""]
-    # the timed launches (two in flight since round 5's last day) are the 30 in front of the run's last five - the fixed-seed step
-    # and the four host-buffer calls; pre-warm, warm-up and the one-at-a-time launches come before them
+    # the timed launches (two in flight) are named by the traced run's own bench line: timed_region.k1_launches_before /
+    # k1_launches = how many K1 launches the process issued before its timed region, and how many in it (trace order)
     rows = [r[0] for r in cur.execute("select duration from kernels where name like '%k1_random_explore%' order by start")]
+    first, count = None, None
+    try:
+        for line in open(os.path.join(out_dir, "%s_prof_stats.log" % tag)):
+            if line.startswith('{"metric"'):
+                tr = json.loads(line)["timed_region"]
+                first, count = int(tr["k1_launches_before"]), int(tr["k1_launches"])
+    except (OSError, KeyError, ValueError):
+        pass
     if rows:
-        tail = rows[-35:-5] if len(rows) >= 35 else rows[-30:]
+        tail = rows[first:first + count] if first is not None and len(rows) >= first + count else rows[-30:]
         k1["kernel_ms"] = sum(tail) / len(tail) / 1e6
         k1["kernel_ms_all_launches"] = sum(rows) / len(rows) / 1e6
         k1["launches_profiled"] = len(rows)
