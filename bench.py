@@ -174,6 +174,11 @@ def bench_dpor(ctx_device, cpu_baseline=True, batch=16384, orders=("rounds", "re
                                   max(1, runs["reference_order"]["interleavings"])),
                                  "kernel_ms_total": runs["reference_order"]["kernel_ms_total"],
                                  "pcie_bytes": {"h2d": runs["reference_order"]["h2d_bytes"], "d2h": runs["reference_order"]["d2h_bytes"]}}})
+    if "rounds" in runs:
+        pctx = _native.Context(ctx_device)
+        out["roofline"]["issue_model"] = issue_model(pctx, "dpor", runs["rounds"]["kernel_ms_total"],
+                                                     lambda tr: tr.get("sequence_digest") == runs["rounds"]["sequence_digest"])
+        pctx.close()
     if cpu_baseline:
         from oracle import oracle_py as O
         cores = os.cpu_count() or 1
@@ -243,6 +248,48 @@ def bench_config1(ctx_device, cpu_baseline=True):
                                          "'DEMi JVM': no JVM / akka-raft in this image)", "seconds": dc,
                                "bit_identical_to_gpu": bool((cpu == got).all())}
     return out
+
+
+def issue_model(ctx, name, kernel_ms, same_run):
+    """The integer-issue model of a secondary record, as the fuzz line has it for K1: the committed instruction counters of this
+    workload (tools/profile_r6_k2k3.sh -> profiles/<tag>_<name>_insts.json: wave-instructions per launch / per exploration) priced
+    with the SIMD cycles per instruction and the shader clock measured in THIS run (demi_device_probe).  Quoted only when the
+    counters belong to this run's work: same_run(traced_run) must hold (same exploration digest / same candidates) and the traced
+    kernel time must be within 25 % of this run's (a traced process runs slower)."""
+    prof = _counters_profile("%s_insts.json" % name)
+    if not prof:
+        return None
+    tr = prof.get("traced_run", {})
+    try:
+        if not same_run(tr):
+            return {"stale": "%s describes another run (%s)" % (prof["profile_file"], {k: tr.get(k) for k in ("sequence_digest", "interleavings", "still_violating")})}
+        pms = float(tr.get("kernel_ms") or 0.0)
+        if not pms or abs(pms - kernel_ms) / pms > 0.25:
+            return {"stale": "%s: kernel time %.3f ms there, %.3f ms here" % (prof["profile_file"], pms, kernel_ms)}
+        p6 = ctx.device_probe(6, 6000)
+        m6, d6 = ctx.device_probe(6, 6000, 2), ctx.device_probe(6, 6000, 3)
+        s6 = ctx.device_probe(6, 6000, 1)
+        import torch
+        cus = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+        c = prof["counters"]
+        valu, salu = c.get("SQ_INSTS_VALU", 0.0), c.get("SQ_INSTS_SALU", 0.0)
+        other = c.get("SQ_INSTS_LDS", 0.0) + c.get("SQ_INSTS_VMEM_RD", 0.0) + c.get("SQ_INSTS_VMEM_WR", 0.0)
+        clk = p6.shader_clock_ghz * 1e9
+        cyc = kernel_ms * 1e-3 * clk
+        simds = cus * 4
+        return {"valu_insts": valu, "salu_insts": salu, "lds_vmem_insts": other, "unit": prof.get("unit"),
+                "active_lanes_per_valu_inst": (c.get("SQ_THREAD_CYCLES_VALU", 0.0) / valu) if valu else None,
+                "waves": c.get("SQ_WAVES"),
+                "wait_share_of_wave_cycles": (c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"]) if c.get("SQ_WAVE_CYCLES") else None,
+                "valu_alone_frac": valu * p6.cycles_per_valu / simds / cyc, "salu_alone_frac": salu * s6.cycles_per_valu / simds / cyc,
+                "issue_frac_straight_line": (valu + salu + other) * m6.cycles_per_valu / simds / cyc,
+                "issue_frac_branchy": (valu + salu + other) * d6.cycles_per_valu / simds / cyc,
+                "clock_hz": clk, "kernel_ms": kernel_ms, "source": "%s (rocprofv3 --pmc; kernel time %.3f ms in the traced run); clock and SIMD cycles "
+                "per instruction measured in this run. The share of the kernels' duration that issuing their instructions would take on "
+                "ALL SIMDs lies between the straight-line and the branchy figure: far below 1 = the launches do not fill the chip / "
+                "wait on memory, not issue-bound" % (prof["profile_file"], pms)}
+    except Exception as e:          # a model must never cost the record
+        return {"error": "%s: %s" % (type(e).__name__, e)}
 
 
 class Ranks:
@@ -349,12 +396,16 @@ def bench_config5(ctx_device, cpu_baseline=True, max_interleavings=None, batch=1
         per_rank = ranks.gather({"digest": digest, "interleavings": n_il, "kernel_ms": float(st.kernel_ms)})
         out["per_rank"] = per_rank
         out["same_verdict_sequence_on_every_rank"] = all(r["digest"] == digest and r["interleavings"] == n_il for r in per_rank)
+    if ranks.world == 1:
+        out["roofline"]["issue_model"] = issue_model(ctx, "config5", float(st.kernel_ms), lambda tr: tr.get("sequence_digest") == digest)
     if ranks.world == 1 and reference_order:
         # the same budget in the REFERENCE order: the order whose 2^20 interleavings are the ones DPORwHeuristics itself would
         # explore under this budget (ROUNDS takes the 2^20 from another frontier), single-rank by construction
         rs = T.DporSearch(batch, max_interleavings, 0, 1, T.DPOR_ORDER_REFERENCE)
         try:
-            ctx.dpor_explore(par, rs)
+            # (untimed: this order's own staging and kernels with a small budget - the trace arena and the explored-pair table
+            # of the full budget exist since the ROUNDS run above; the whole exploration takes seconds in this order)
+            ctx.dpor_explore(par, T.DporSearch(batch, min(max_interleavings, 1 << 15), 0, 1, T.DPOR_ORDER_REFERENCE))
             t = time.perf_counter()
             rv, rplen, _rr, _rt, rst = ctx.dpor_explore(par, rs)
             rdt = time.perf_counter() - t
@@ -647,6 +698,9 @@ def bench_ddmin(ctx_device, cpu_baseline=True, n=1 << 20):
     out["roofline"] = roofline(alg, kms, k2_traffic, "k2_replay (specialised, hiprtc)",
                                "32 B mask + 16 B verdict per candidate, the lowered original trace (%d x 8 B) once per workgroup; "
                                "the replay itself is integer / LDS work" % n_exp)
+    if n == (1 << 20):
+        nviol = out["still_violating"]
+        out["roofline"]["issue_model"] = issue_model(ctx, "ddmin", kms, lambda tr: tr.get("still_violating") == nviol)
     ctx.close()
     # what the replays are for: RunnerUtils.stsSchedDDMin on this execution, end to end (DDMin's decision tree on the host,
     # every frontier one launch), through the Python mirror of the reference's classes

@@ -15,7 +15,7 @@ EXPORTS = ["demi_ctx_create", "demi_ctx_destroy", "demi_last_error", "demi_versi
            "demi_trace_load", "demi_random_explore", "demi_random_explore_dev", "demi_random_get_trace", "demi_collect_violations_dev",
            "demi_replay_load", "demi_replay_batch", "demi_replay_batch_dev", "demi_dpor_load", "demi_dpor_batch", "demi_dpor_explore", "demi_random_explore_violations", "demi_random_get_trace_carried",
            "demi_replay_removal_batch", "demi_replay_get_kept", "demi_replay_recorded_len", "demi_ddmin", "demi_dpor_set_traces", "demi_model_specialize", "demi_model_is_specialized", "demi_model_code_id",
-           "demi_specialize_check", "demi_specialize_source", "demi_specialize_source_k1", "demi_provenance_prune", "demi_device_probe", "demi_device_probe_mix", "demi_calib_rw", "demi_random_explore_flagged", "demi_collect_flagged_dev", "demi_random_explore_submit", "demi_random_explore_wait",
+           "demi_specialize_check", "demi_specialize_source", "demi_specialize_source_k1", "demi_provenance_prune", "demi_device_probe", "demi_device_probe_mix", "demi_calib_rw", "demi_random_explore_flagged", "demi_collect_flagged_dev", "demi_random_explore_submit", "demi_random_explore_wait", "demi_trace_len",
            "demi_comm_unique_id", "demi_comm_create", "demi_comm_create_host", "demi_comm_destroy", "demi_comm_rank",
            "demi_comm_allgather_dev", "demi_random_explore_sharded", "demi_replay_batch_sharded", "demi_abi_version", "demi_replay_externals_len", "demi_edit_distance_dpor_ddmin", "demi_dpor_explored", "demi_random_ddmin", "demi_random_explore_candidates"]
 
@@ -57,6 +57,8 @@ def lib():
                           % (L.demi_abi_version(), T.ABI_VERSION))
     L.demi_replay_externals_len.argtypes = [C.c_void_p]
     L.demi_replay_externals_len.restype = C.c_uint32
+    L.demi_trace_len.argtypes = [C.c_void_p]
+    L.demi_trace_len.restype = C.c_uint32
     L.demi_model_load.argtypes = [C.c_void_p, C.POINTER(T.ModelStruct)]
     L.demi_model_specialize.argtypes = [C.c_void_p, C.c_int]
     L.demi_model_is_specialized.argtypes = [C.c_void_p]

@@ -424,6 +424,8 @@ int demi_replay_get_kept(demi_ctx* ctx, const uint64_t* mask /* [4] or NULL */, 
 uint32_t demi_replay_recorded_len(const demi_ctx* ctx);
 /* Number of external events of that execution (0 without one): the length demi_ddmin's `conjoined` must have. */
 uint32_t demi_replay_externals_len(const demi_ctx* ctx);
+/* external events of the trace demi_trace_load holds (0: none) - what demi_random_ddmin's `conjoined` array must cover */
+uint32_t demi_trace_len(const demi_ctx* ctx);
 
 /* ---------------------------------------------------------- DDMin over the replay oracle, in one call
  * Replaces RunnerUtils.stsSchedDDMin (RunnerUtils.scala:642-707): DDMin.minimize / ddmin2 (minification/DeltaDebugging.scala:27-109)

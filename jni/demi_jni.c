@@ -326,8 +326,10 @@ JNIEXPORT jint JNICALL FN(randomDDMin)(JNIEnv* e, jclass c, jlong h, jlong seedB
   memset(&par, 0, sizeof par);
   par.executions = (uint32_t)pr[0]; par.depth = (uint32_t)pr[1]; par.max_candidates = (uint32_t)pr[2];
   par.check_unmodified = (uint32_t)pr[3]; par.verify_mcs = (uint32_t)pr[4]; par.sequential = (uint32_t)pr[5];
-  /* demi_random_ddmin reads conjoined[0 .. n externals of the loaded trace): the caller states that count, a shorter array is refused */
-  if (conjoinedOrNull && LEN(conjoinedOrNull) < (int64_t)nExternals) return DEMI_ERR_INVALID_ARG;
+  /* demi_random_ddmin reads conjoined[0 .. n externals of the LOADED trace): the library says how many that is; a caller that
+   * states another count, or passes a shorter array, is refused before anything is read */
+  if ((uint32_t)nExternals != demi_trace_len(CTX(h))) return DEMI_ERR_INVALID_ARG;
+  if (conjoinedOrNull && LEN(conjoinedOrNull) < (int64_t)demi_trace_len(CTX(h))) return DEMI_ERR_INVALID_ARG;
   uint32_t cap = 0;
   if (consultedOrNull) {
     if (LEN(consultedOrNull) % 4 || !passedOrNull || LEN(passedOrNull) < LEN(consultedOrNull) / 4) return DEMI_ERR_INVALID_ARG;

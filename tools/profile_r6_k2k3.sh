@@ -5,6 +5,7 @@
 #   <tag>_dpor_counters.json, <tag>_config5_counters.json  fabric bytes per exploration (FETCH_SIZE x 2048 + WRITE_SIZE x 1024, the
 #                                          calibration of tools/calib_counters.py) = the `traffic` of those records' rooflines
 #   <tag>_ddmin_counters.json               the same per 2^20-candidate launch of k2_replay_fp_hbm (the six largest dispatches)
+#   <tag>_{ddmin,dpor,config5}_insts.json    instruction / wave-cycle counters in the form bench.py's issue model reads
 # Every rocprofv3 call has its own timeout (a pass that asks for too many counters aborts and then hangs in finalisation).
 export TMPDIR=/tmp
 export TAG=${TAG:-r06}
@@ -18,8 +19,9 @@ PRE="--preload $COMGR"
 timeout 300 rocprofv3 $PRE --kernel-trace --stats -d $P/prof_stats_ddmin -o k2 -- python $R/bench.py --workload ddmin --no-cpu-baseline > $OUT/${TAG}_prof_stats_ddmin.log 2>&1
 timeout 300 rocprofv3 $PRE --kernel-trace --stats -d $P/prof_stats_dpor -o k3 -- python $R/bench.py --workload dpor --no-cpu-baseline > $OUT/${TAG}_prof_stats_dpor.log 2>&1
 timeout 300 rocprofv3 $PRE --kernel-trace --stats -d $P/prof_stats_config5 -o k3 -- python $R/bench.py --workload config5 --no-cpu-baseline --dpor-order rounds > $OUT/${TAG}_prof_stats_config5.log 2>&1
-for w in ddmin dpor; do
+for w in ddmin dpor config5; do
   timeout 300 rocprofv3 $PRE --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE -d $P/$w -o c -- python $R/bench.py --workload $w --no-cpu-baseline --dpor-order rounds > $OUT/${TAG}_pmc_$w.log 2>&1
+  timeout 300 rocprofv3 $PRE --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_ANY -d $P/${w}_sq2 -o c -- python $R/bench.py --workload $w --no-cpu-baseline --dpor-order rounds > $OUT/${TAG}_pmc_${w}_sq2.log 2>&1
 done
 for w in dpor ddmin config5; do
   timeout 300 rocprofv3 $PRE --pmc FETCH_SIZE -d $P/${w}_fetch -o c -- python $R/bench.py --workload $w --no-cpu-baseline --dpor-order rounds > $OUT/${TAG}_pmc_${w}_fetch.log 2>&1
@@ -42,6 +44,43 @@ if cur:
         lines.append("%-90s %8d %14.0f %12.0f %7.2f" % (r[0][:90], r[1], r[2] * 1000, r[3] * 1000, r[4]))
     open(os.path.join(out, TAG + "_config5.txt"), "w").write("\n".join(lines) + "\n")
     print("\n".join(lines[:12]))
+# the instruction counters in the form bench.py's issue model reads (<tag>_<workload>_insts.json): totals per exploration (the DPOR
+# workloads: the traced bench runs the exploration twice) / per 2^20-candidate launch (K2: its six largest dispatches), with what
+# identifies the run they belong to (the bench line of the traced process: digest, interleavings, kernel_ms)
+def bench_line(w, suffix=""):
+    try:
+        for line in open(os.path.join(out, "%s_pmc_%s%s.log" % (TAG, w, suffix))):
+            if line.startswith('{"metric"'):
+                return json.loads(line)
+    except (OSError, ValueError):
+        pass
+    return None
+for w in ("ddmin", "dpor", "config5"):
+    tot = {}
+    for d in (w, w + "_sq2"):
+        cur = db(d)
+        if not cur:
+            continue
+        if w == "ddmin":
+            # per counter: the six largest dispatches of the throughput kernel
+            for (cn,) in list(cur.execute("select distinct counter_name from counters_collection where kernel_name like '%k2_replay%'")):
+                vals = [r[0] for r in cur.execute("select sum(value) from counters_collection where kernel_name like '%k2_replay%' and counter_name = ? "
+                                                  "group by dispatch_id order by sum(value) desc limit 6", (cn,))]
+                if vals:
+                    tot[cn] = sum(vals) / len(vals)
+        else:
+            for cn, v in cur.execute("select counter_name, sum(value) from counters_collection where kernel_name like '%demi%' group by counter_name"):
+                tot[cn] = v / 2.0
+    line = bench_line(w)
+    if tot and line:
+        rec = {"counters": tot, "unit": "per 2^20-candidate launch (mean of the six largest k2_replay dispatches)" if w == "ddmin" else "per exploration (all demi kernels; the traced run explores twice)",
+               "traced_run": {"kernel_ms": line.get("roofline", {}).get("kernel_ms"), "value": line.get("value"),
+                              "sequence_digest": (line.get("orders", {}).get("rounds", {}) or line).get("sequence_digest"),
+                              "interleavings": (line.get("orders", {}).get("rounds", {}) or line).get("interleavings"),
+                              "still_violating": line.get("still_violating")},
+               "source": "rocprofv3 --pmc (two passes) over python bench.py --workload %s --no-cpu-baseline --dpor-order rounds" % w}
+        json.dump(rec, open(os.path.join(out, "%s_%s_insts.json" % (TAG, w)), "w"), indent=1)
+        print(w, "instruction counters:", {k: "%.4g" % v for k, v in tot.items()})
 for w in ("ddmin", "dpor"):
     cur = db(w)
     if not cur:
