@@ -41,6 +41,10 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# The HIP runtime multiplexes a process's streams over GPU_MAX_HW_QUEUES (default 4) hardware queues; this process owns torch's
+# streams AND the library's own two (demi_random_explore_submit / _wait, the host-buffer record), which must not end up on one
+# queue (include/demi_gpu.h; profiles/r06_pipeline_ab.txt).  Read by the runtime when it initialises: set before torch is imported.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 N_PER_GPU = 1 << 20           # "1M random interleavings on 1 MI355X"
 VIOL_CAP = 1 << 16            # found-violation list capacity per rank and step
@@ -174,6 +178,29 @@ def bench_dpor(ctx_device, cpu_baseline=True, batch=16384, orders=("rounds", "re
                                   max(1, runs["reference_order"]["interleavings"])),
                                  "kernel_ms_total": runs["reference_order"]["kernel_ms_total"],
                                  "pcie_bytes": {"h2d": runs["reference_order"]["h2d_bytes"], "d2h": runs["reference_order"]["d2h_bytes"]}}})
+    # continuity: the workload rounds 1-5 timed (apps.raft5_config3: 60 332 interleavings in the reference's order, none
+    # violating - flips that getMatchingMessage undoes), both orders, so that the rates of the two workloads can be read side by side
+    try:
+        from demi_amd.apps import raft5_config3
+        m5, e5, d5 = raft5_config3()
+        p5 = T.DporParams(d5, 0, 0, 0, 64, 4096)
+        old = {}
+        for name, ref in (("rounds", False), ("reference_order", True)):
+            if name not in orders:
+                continue
+            c5 = _native.Context(ctx_device)
+            c5.model_load(m5.to_struct()); c5.model_specialize(); c5.dpor_load(e5)
+            s5 = T.DporSearch(batch, 1 << 17, 0, 1, T.DPOR_ORDER_REFERENCE if ref else T.DPOR_ORDER_ROUNDS)
+            c5.dpor_explore(p5, s5)
+            t = time.perf_counter()
+            v5, _pl5, _r5, _t5, st5 = c5.dpor_explore(p5, s5)
+            d = time.perf_counter() - t
+            old[name] = {"value": len(v5) / d, "seconds": d, "interleavings": len(v5), "violations": int(np.count_nonzero(v5["flags"] & T.V_VIOLATION)),
+                         "launches": int(st5.launches), "sequence_digest": "%016x" % _seq_digest(v5), "kernel_ms_total": float(st5.kernel_ms)}
+            c5.close()
+        out["round5_workload"] = {"workload": "apps.raft5_config3 (prioritizePendingUponDivergence = false, five campaigning nodes)", "orders": old}
+    except Exception as e:
+        out["round5_workload"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if "rounds" in runs:
         pctx = _native.Context(ctx_device)
         out["roofline"]["issue_model"] = issue_model(pctx, "dpor", runs["rounds"]["kernel_ms_total"],
@@ -254,8 +281,7 @@ def issue_model(ctx, name, kernel_ms, same_run):
     """The integer-issue model of a secondary record, as the fuzz line has it for K1: the committed instruction counters of this
     workload (tools/profile_r6_k2k3.sh -> profiles/<tag>_<name>_insts.json: wave-instructions per launch / per exploration) priced
     with the SIMD cycles per instruction and the shader clock measured in THIS run (demi_device_probe).  Quoted only when the
-    counters belong to this run's work: same_run(traced_run) must hold (same exploration digest / same candidates) and the traced
-    kernel time must be within 25 % of this run's (a traced process runs slower)."""
+    counters belong to this run's work: same_run(traced_run) must hold (same exploration digest / same candidates)."""
     prof = _counters_profile("%s_insts.json" % name)
     if not prof:
         return None
@@ -263,9 +289,9 @@ def issue_model(ctx, name, kernel_ms, same_run):
     try:
         if not same_run(tr):
             return {"stale": "%s describes another run (%s)" % (prof["profile_file"], {k: tr.get(k) for k in ("sequence_digest", "interleavings", "still_violating")})}
+        # (the counters are COUNTS of the same work - the digest says so - and do not depend on the clock; the traced run's kernel
+        # time, taken with the profiler serialising every dispatch, is quoted for information only)
         pms = float(tr.get("kernel_ms") or 0.0)
-        if not pms or abs(pms - kernel_ms) / pms > 0.25:
-            return {"stale": "%s: kernel time %.3f ms there, %.3f ms here" % (prof["profile_file"], pms, kernel_ms)}
         p6 = ctx.device_probe(6, 6000)
         m6, d6 = ctx.device_probe(6, 6000, 2), ctx.device_probe(6, 6000, 3)
         s6 = ctx.device_probe(6, 6000, 1)
@@ -679,10 +705,33 @@ def bench_ddmin(ctx_device, cpu_baseline=True, n=1 << 20):
         torch.cuda.synchronize(dev)
         res[m] = {"kernel_ms": e0.elapsed_time(e1) / reps, "wall_ms": (time.perf_counter() - t) * 1e3 / reps}
     got = d_out.cpu().numpy().view(T.VERDICT_DTYPE).reshape(-1)
+    # two launches in flight (round 6: a K2 launch has K1's shape - a resident grid that drains a work counter - and a context holds
+    # a second set of K2's per-launch scratch): the 2^20-candidate launches dealt over two streams, each with its own verdict array
+    two = None
+    try:
+        st2 = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+        sp2 = [C.c_void_p(x.cuda_stream) for x in st2]
+        d_out2 = [d_out, torch.empty_like(d_out)]
+        torch.cuda.synchronize(dev)
+        for i in range(4):
+            ctx.replay_batch_dev(d_masks.data_ptr(), n, target, d_out2[i & 1].data_ptr(), stream=sp2[i & 1])
+        torch.cuda.synchronize(dev)
+        reps2 = 10
+        t = time.perf_counter()
+        for i in range(reps2):
+            ctx.replay_batch_dev(d_masks.data_ptr(), n, target, d_out2[i & 1].data_ptr(), stream=sp2[i & 1])
+        torch.cuda.synchronize(dev)
+        two = {"wall_ms": (time.perf_counter() - t) * 1e3 / reps2, "launches": reps2,
+               "same_verdicts": bool(torch.equal(d_out2[0], d_out2[1]))}
+        two["replays_per_s"] = n / (two["wall_ms"] * 1e-3)
+    except Exception as e:
+        two = {"error": "%s: %s" % (type(e).__name__, e)}
     n_exp = int(sum(1 for e in rec if e["kind"] in (0, 1, 2, 3, 7) or (e["kind"] == 6 and e["flags"] & 1)))
     kms = res[n]["kernel_ms"]
     out = {"metric": "candidate subsequences replayed/sec (STSScheduler.test without peek, DDMin's oracle)", "unit": "replays/s",
-           "value": n / (res[n]["wall_ms"] * 1e-3),
+           "value": n / ((two["wall_ms"] if two and "wall_ms" in two else res[n]["wall_ms"]) * 1e-3),
+           "launches_in_flight": 2 if two and "wall_ms" in two else 1, "two_launches_in_flight": two,
+           "one_launch_at_a_time": {"replays_per_s": n / (res[n]["wall_ms"] * 1e-3), "wall_ms": res[n]["wall_ms"], "kernel_ms": res[n]["kernel_ms"]},
            "config": {"workload": "raft5-synth, 200-event failing execution (%d externals used, %d recorded events, %d deliveries), "
                                   "%d random candidate subsequences per launch, masks and verdicts resident in HBM" %
                                   (len(used), len(rec), T.verdict_deliveries(vv.flags), n), "candidates_per_launch": n},
@@ -1201,7 +1250,7 @@ def main():
                                 "seeds; the untimed last step: [r * n, ... + n)" % world,
                        "parallelism": "schedule-index range sharded, %d rank(s)" % world, "collective": collective,
                        "launches_in_flight": "%d (ONE demi_ctx; the timed steps dealt over %d stream(s))" % (n_lanes, n_lanes),
-                       "untimed_prewarm_s": prewarm_s},
+                       "untimed_prewarm_s": prewarm_s, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")},
             # distinct bugs found in the TIMED region per wall-clock hour of it: by delivery-sequence hash - two
             # executions count once only if every delivered message and every final state agree - and by fingerprint
             "bugs_per_hr": timed_hashes / counted_frac / dt * 3600.0,
@@ -1247,18 +1296,21 @@ def main():
                 out["pcie_inclusive"] = {"entry_point": "demi_random_explore (16 B verdict per schedule copied into a pageable host buffer)",
                                          "ms_per_step": th * 1e3, "value": n / th, "unit": "schedules/s",
                                          "same_verdicts_as_the_resident_path": bool((hv == verdicts.cpu().numpy().view(T.VERDICT_DTYPE).reshape(-1)).all())}
-                # the same through demi_random_explore_submit / _wait - what GpuRandomScheduler.explore calls: two calls in
-                # flight in the one context, (a) every verdict copied into the caller's host buffer, (b) only the flagged
+                # the same through demi_random_explore_submit / _wait - what GpuRandomScheduler.explore calls: three calls
+                # outstanding in the one context, (a) every verdict copied into the caller's host buffer, (b) only the flagged
                 # executions (what explore() needs); K steps of fresh seeds each, host wall clock around the whole loop
                 hv2 = [np.zeros(n, dtype=T.VERDICT_DTYPE) for _ in range(2)]
                 for h_ in hv2:
                     h_["hash"] = 1
                 def piped(with_verdicts, steps):
-                    tk = [ctx.random_explore_submit(n, limits, seed_base=SEED_BASE + index_base)]
+                    # submit(k + 2); wait(k): two calls submitted ahead of the one waited for (include/demi_gpu.h says why)
+                    tk = [ctx.random_explore_submit(n, limits, seed_base=SEED_BASE + index_base, want_verdicts=with_verdicts)]
+                    if steps > 1:
+                        tk.append(ctx.random_explore_submit(n, limits, seed_base=SEED_BASE + (steps + 2) * n, want_verdicts=with_verdicts))
                     found = 0
                     for j in range(steps):
-                        if j + 1 < steps:
-                            tk.append(ctx.random_explore_submit(n, limits, seed_base=SEED_BASE + (steps + 2 + j) * n))
+                        if j + 2 < steps:
+                            tk.append(ctx.random_explore_submit(n, limits, seed_base=SEED_BASE + (steps + 3 + j) * n, want_verdicts=with_verdicts))
                         _h, cnt, _f = ctx.random_explore_wait(tk[j], out=hv2[j & 1] if with_verdicts else None)
                         found += cnt
                     return found
@@ -1268,7 +1320,7 @@ def main():
                 tp = time.perf_counter(); piped(True, ksteps); tp = (time.perf_counter() - tp) / ksteps
                 tf = time.perf_counter(); nf = piped(False, ksteps); tf = (time.perf_counter() - tf) / ksteps
                 out["pcie_inclusive"]["pipelined"] = {
-                    "entry_point": "demi_random_explore_submit / demi_random_explore_wait (two calls in flight in one demi_ctx, streams of its own)",
+                    "entry_point": "demi_random_explore_submit / demi_random_explore_wait (submit(k + 2), wait(k): three calls outstanding in one demi_ctx, two streams of its own)",
                     "every_verdict_to_host": {"ms_per_step": tp * 1e3, "value": n / tp, "unit": "schedules/s", "steps": ksteps,
                                               "same_verdicts_as_the_resident_path": same_p},
                     "flagged_executions_to_host": {"ms_per_step": tf * 1e3, "value": n / tf, "unit": "schedules/s", "steps": ksteps,

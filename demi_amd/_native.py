@@ -111,7 +111,7 @@ def lib():
                                                  C.c_uint32, C.POINTER(C.c_uint64)]
     L.demi_random_explore_flagged.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(T.Limits), C.c_uint32, C.c_void_p,
                                               C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
-    L.demi_random_explore_submit.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(T.Limits), C.c_uint32, C.POINTER(C.c_uint32)]
+    L.demi_random_explore_submit.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(T.Limits), C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
     L.demi_random_explore_wait.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64),
                                            C.POINTER(C.c_uint64)]
     L.demi_collect_flagged_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint32,
@@ -232,10 +232,12 @@ class Context:
                                                       out.ctypes.data, cap, C.byref(cnt), C.byref(first)))
         return out[:min(cnt.value, cap)].copy(), int(cnt.value), int(first.value)
 
-    def random_explore_submit(self, n, limits, seed_base=0, flag_mask=0):
-        """explore() in pieces, two in flight: enqueue n executions on a stream of the context's own; returns the ticket."""
+    def random_explore_submit(self, n, limits, seed_base=0, flag_mask=0, want_verdicts=False):
+        """explore() in pieces, up to three outstanding: enqueue n executions on a stream of the context's own; returns the ticket.
+        want_verdicts: every verdict travels to the library's pinned memory behind the call (random_explore_wait(out=...))."""
         t = C.c_uint32(0)
-        self._check(lib().demi_random_explore_submit(self._h, C.c_uint64(seed_base), n, C.byref(limits), flag_mask, C.byref(t)))
+        self._check(lib().demi_random_explore_submit(self._h, C.c_uint64(seed_base), n, C.byref(limits), flag_mask,
+                                                     1 if want_verdicts else 0, C.byref(t)))
         return int(t.value)
 
     def random_explore_wait(self, ticket, out=None, cap=1 << 16):

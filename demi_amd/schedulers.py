@@ -111,7 +111,7 @@ class RandomScheduler:
         self.strategy = T.STRATEGY_SRC_DST_FIFO if isinstance(randomizationStrategy, SrcDstFIFO) else T.STRATEGY_FULLY_RANDOM
         self.maxMessages = 0x7FFFFFFF            # Int.MaxValue (:54)
         self.p_max = p_max
-        self.chunk = 1 << 20                     # executions per device call of explore() (two calls in flight)
+        self.chunk = 1 << 20                     # executions per device call of explore() (two calls submitted ahead of the one waited for)
         self.stats: Optional[MinimizationStats] = None
         self._model: Optional[Model] = schedulerConfig.model
         self._ctx = _native.Context(device)
@@ -193,34 +193,36 @@ class RandomScheduler:
         # only the violating and the aborted executions cross PCIe (16 B each instead of 16 B per schedule).  An execution
         # aborted on a capacity has no valid verdict: it is re-run alone with the largest pending set before any
         # higher index is believed (the reference has no capacities; its answer is the lowest violating index)
-        # The executions go to the device in calls of `chunk` (BASELINE config 2's step), two of them in flight in the one
-        # context (demi_random_explore_submit / _wait: call k + 1 runs while call k is waited for and its candidates are
-        # examined - GpuRandomScheduler.explore in scala/ is this loop), and nothing beyond the first violating call is submitted.
+        # The executions go to the device in calls of `chunk` (BASELINE config 2's step); while the answer of call k is waited
+        # for, calls k + 1 and k + 2 are already submitted in the one context (demi_random_explore_submit / _wait: the tail of
+        # every launch is filled by the next one - GpuRandomScheduler.explore in scala/ is this loop), and nothing beyond the
+        # calls in flight behind the first violating one is ever submitted.
         lim = self._limits(_lookingFor)
         start, i = 0, None
         self.last_aborted_reruns = 0
         self.last_calls = 0
-        inflight = [None]                         # (first execution, executions, ticket) of the call already running
+        ahead = []                                # the calls already submitted, in order: (first execution, executions, ticket)
 
-        def submit(s):
-            if s >= self.max_executions:
-                return None
-            n = min(self.chunk, self.max_executions - s)
-            self.last_calls += 1
-            return s, n, self._ctx.random_explore_submit(n, self._limits(_lookingFor), seed_base=self.seed_base + s,
-                                                         flag_mask=T.V_VIOLATION | OVF_FLAGS)
+        def top_up(frm):
+            """keep the call at `frm` and the two behind it submitted"""
+            nxt = ahead[-1][0] + ahead[-1][1] if ahead else frm
+            while len(ahead) < 3 and nxt < self.max_executions:
+                n = min(self.chunk, self.max_executions - nxt)
+                self.last_calls += 1
+                ahead.append((nxt, n, self._ctx.random_explore_submit(n, self._limits(_lookingFor), seed_base=self.seed_base + nxt,
+                                                                      flag_mask=T.V_VIOLATION | OVF_FLAGS)))
+                nxt += n
 
         def drain():
-            if inflight[0] is not None:
-                self._ctx.random_explore_wait(inflight[0][2], cap=1)
-                inflight[0] = None
+            while ahead:
+                self._ctx.random_explore_wait(ahead.pop(0)[2], cap=1)
         try:
             while start < self.max_executions and i is None:
-                if inflight[0] is not None and inflight[0][0] != start:
-                    drain()
-                cur = inflight[0] or submit(start)
+                if ahead and ahead[0][0] != start:
+                    drain()                       # (a truncated list sent the search back into the middle of a call)
+                top_up(start)
+                cur = ahead.pop(0)
                 span = cur[1]
-                inflight[0] = submit(start + span)
                 hits, n_hits, first = self._ctx.random_explore_wait(cur[2])
                 # a truncated list is an arbitrary subset: only the lowest index (computed on the device) is certain then
                 cand = [(int(h["index"]), int(h["flags"])) for h in hits] if n_hits <= len(hits) else [(first, None)]

@@ -736,15 +736,24 @@ int demi_random_explore_flagged(demi_ctx* ctx, uint64_t seed_base, uint64_t n, c
 /* explore() in pieces, two of them in flight (RandomScheduler.scala:234-272: the loop over executions, here cut into calls of n
  * executions each).  demi_random_explore_submit enqueues the n executions seeded seed_base .. seed_base + n - 1 and the
  * compaction of the verdicts whose flags intersect flag_mask (0 = DEMI_V_VIOLATION) on a stream of the ctx's own and returns
- * at once with a ticket; at most two tickets are outstanding.  demi_random_explore_wait blocks until that call has finished and
- * returns what demi_random_explore_flagged returns (list sorted by index, truncated to cap <= 65536; *n_flagged and
- * *first_index exact) and, if `out` is not NULL, all n verdicts.  While a host waits for ticket k the kernel of ticket k + 1
- * already runs: the thinning tail of a launch is filled by the next launch's workgroups and the copies of k cross PCIe under
- * it - a JVM loop `submit(k + 1); wait(k)` gets the rate bench.py reports without owning a HIP stream.  A driver that wants
- * the reference's answer (the lowest violating index) stops submitting at the first call that reports one.
+ * at once with a ticket; at most THREE tickets are outstanding (call k runs on stream k mod 2).  demi_random_explore_wait
+ * blocks until that call has finished and returns what demi_random_explore_flagged returns (list sorted by index, truncated to
+ * cap <= 65536; *n_flagged and *first_index exact) and, if `out` is not NULL, all n verdicts (want_verdicts != 0 at the submit
+ * sends them to pinned memory of the library behind the call, so that the wait only copies them on with the CPU; otherwise the
+ * wait fetches them).  The loop to write is
+ * `submit(k + 2); wait(k)`: while a host waits for ticket k the kernel of ticket k + 1 runs and that of k + 2 is queued behind
+ * k's compaction, so the thinning tail of every launch is filled by the next launch's workgroups and the answer of k crosses
+ * PCIe under them - a JVM gets the rate bench.py reports without owning a HIP stream.  (`submit(k + 1); wait(k)` is correct
+ * but no faster than one call at a time: the compaction of k only runs in the tail of k + 1, so k + 2 would come too late.)
+ * Hardware queues: the HIP runtime multiplexes a process's streams over GPU_MAX_HW_QUEUES (default 4) hardware queues, and two
+ * streams on one queue do not overlap.  In a process that owns no other streams (a JVM) the library's two streams get queues of
+ * their own; a process that has created three or more streams before its first submit (a PyTorch process) should start with
+ * GPU_MAX_HW_QUEUES=8 in its environment, or it measures one call at a time (profiles/r06_pipeline_ab.txt: 4.18 against 3.23 ms
+ * per 2^20 schedules).
+ * A driver that wants the reference's answer (the lowest violating index) stops submitting at the first call that reports one.
  * Not for the carried-generator mode (one chain of executions: nothing to overlap). */
 int demi_random_explore_submit(demi_ctx* ctx, uint64_t seed_base, uint64_t n, const demi_limits* limits, uint32_t flag_mask,
-                               uint32_t* ticket);
+                               uint32_t want_verdicts, uint32_t* ticket);
 int demi_random_explore_wait(demi_ctx* ctx, uint32_t ticket, demi_verdict* out, demi_violation* flagged, uint32_t cap,
                              uint64_t* n_flagged, uint64_t* first_index);
 

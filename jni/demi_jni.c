@@ -158,7 +158,7 @@ JNIEXPORT jint JNICALL FN(randomExploreSubmit)(JNIEnv* e, jclass c, jlong h, jlo
   uint32_t ticket = 0;
   (void)c;
   if (limits_of(e, limits, &lim) || n <= 0) return DEMI_ERR_INVALID_ARG;
-  const int rc = demi_random_explore_submit(CTX(h), (uint64_t)seedBase, (uint64_t)n, &lim, (uint32_t)flagMask, &ticket);
+  const int rc = demi_random_explore_submit(CTX(h), (uint64_t)seedBase, (uint64_t)n, &lim, (uint32_t)flagMask, 0u, &ticket);
   return rc ? rc : (jint)ticket;
 }
 /* out: long[2 * cap] (flagged entries, sorted by index); counts: long[2] = { number flagged, lowest flagged index } */

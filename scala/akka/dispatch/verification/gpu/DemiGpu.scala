@@ -21,7 +21,7 @@ object DemiGpu {
   @native def randomExplore(h: Long, seedBase: Long, n: Long, limits: Array[Int], verdicts: Array[Long]): Int
   @native def randomExploreFlagged(h: Long, seedBase: Long, n: Long, limits: Array[Int], flagMask: Int,
                                    out: Array[Long], counts: Array[Long]): Int
-  /** explore() in pieces, two calls in flight in one context (demi_random_explore_submit / _wait): the ticket (> 0) or a
+  /** explore() in pieces, up to three calls outstanding in one context (demi_random_explore_submit / _wait; the loop: submit(k + 2), wait(k)): the ticket (> 0) or a
    *  negative status; wait fills `out` / `counts` as randomExploreFlagged does */
   @native def randomExploreSubmit(h: Long, seedBase: Long, n: Long, limits: Array[Int], flagMask: Int): Int
   @native def randomExploreWait(h: Long, ticket: Int, out: Array[Long], counts: Array[Long]): Int

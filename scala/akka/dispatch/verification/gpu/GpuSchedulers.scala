@@ -130,29 +130,30 @@ class GpuRandomScheduler(val schedulerConfig: SchedulerConfig, max_executions: I
     // Python mirror raises CapacityExceeded): the whole chain - exploration AND the recording re-run - is then repeated with the
     // largest pending set, and if an execution still does not fit the JVM scheduler has to decide the instance.
     var chainPMax = pMax
-    // Fresh generator per execution (the shape of RunnerUtils.fuzz): the executions go to the device in calls of CHUNK, two
-    // of them in flight - call k + 1 runs while call k is waited for and its candidates are examined (the library overlaps
-    // the tail of one launch with the start of the next), and nothing beyond the first violating call is ever submitted.
+    // Fresh generator per execution (the shape of RunnerUtils.fuzz): the executions go to the device in calls of CHUNK; while the
+    // answer of call k is waited for, calls k + 1 and k + 2 are already submitted (the library overlaps the tail of every launch
+    // with the start of the next), and nothing beyond the calls in flight behind the first violating one is ever submitted.
     val pipelined = !carriedGenerator
-    var inflight: Option[(Long, Long, Int)] = None        // the call that is already running: (first execution, executions, ticket)
-    def submit(s: Long): Option[(Long, Long, Int)] =
-      if (s >= max_executions) None
-      else {
-        val n = math.min(GpuRandomScheduler.CHUNK, max_executions - s)
-        Some((s, n, check(h, randomExploreSubmit(h, seed + s, n, limits(lookingFor, pMax), V_VIOLATION | OVF))))
+    val ahead = new scala.collection.mutable.Queue[(Long, Long, Int)]   // submitted calls, in order: (first execution, executions, ticket)
+    def topUp(from: Long) {
+      var nxt = if (ahead.isEmpty) from else ahead.last._1 + ahead.last._2
+      while (ahead.size < 3 && nxt < max_executions) {
+        val n = math.min(GpuRandomScheduler.CHUNK, max_executions - nxt)
+        ahead.enqueue((nxt, n, check(h, randomExploreSubmit(h, seed + nxt, n, limits(lookingFor, pMax), V_VIOLATION | OVF))))
+        nxt += n
       }
+    }
     def drain() {
-      inflight.foreach { case (_, _, t) => randomExploreWait(h, t, new Array[Long](0), new Array[Long](2)) }
-      inflight = None
+      while (ahead.nonEmpty) randomExploreWait(h, ahead.dequeue()._3, new Array[Long](0), new Array[Long](2))
     }
     try { while (start < max_executions) {
       val out = new Array[Long](2 * 65536); val counts = new Array[Long](2)
       var span = max_executions - start                    // executions [start, start + span) are decided by this pass
       if (pipelined) {
-        if (inflight.exists(_._1 != start)) drain()
-        val cur = inflight.orElse(submit(start)).get
+        if (ahead.nonEmpty && ahead.head._1 != start) drain()   // (a truncated list sent the search back into the middle of a call)
+        topUp(start)
+        val cur = ahead.dequeue()
         span = cur._2
-        inflight = submit(start + span)
         check(h, randomExploreWait(h, cur._3, out, counts))
       } else
         check(h, randomExploreFlagged(h, seed + start, max_executions - start, limits(lookingFor, chainPMax), V_VIOLATION | OVF, out, counts))

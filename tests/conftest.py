@@ -45,7 +45,7 @@ if os.environ.get("DEMI_EMU") == "1":
 
     # what cannot run there: the tests about the real library file, a torch device, RCCL, or bench.py itself
     _EMU_SKIP = {"test_native_library_is_the_one_running", "test_full_size_properties_1m", "test_launches_of_one_ctx_on_two_streams_are_ordered",
-                 "test_rccl_communicator_world_of_one", "test_bench_py_two_ranks_on_one_gpu"}
+                 "test_rccl_communicator_world_of_one", "test_bench_py_two_ranks_on_one_gpu", "test_replay_launches_of_one_ctx_on_two_streams"}
 
     def pytest_collection_modifyitems(config, items):
         for it in items:

@@ -409,7 +409,7 @@ CASES = {
     "shuffle8_dpor_config5_first_250": lambda: _config5_bug(250),
     # prioritizePendingUponDivergence where a flip decides the verdict: two campaigning nodes of three, exhausted
     "raft3_two_campaigners_prioritize": lambda: (M.raft_model(3, election_budget=(1, 1, 0)), events_to_array([start(a) for a in range(3)] +
-                                                 [send(a, M.M_BOOTSTRAP) for a in range(3)]), 30, 0, 20000, True),
+                                                 [send(a, M.M_BOOTSTRAP) for a in range(3)]), 12, 0, 20000, True),   # (1 552 interleavings, 28 violating)
     "writers4": lambda: (writers_model(4), events_to_array([start(a) for a in range(5)] + [send(a, 0) for a in range(1, 5)]), 0, 0, 2500),
     "raft3": lambda: (M.raft_model(3), events_to_array([start(a) for a in range(3)] + [send(a, M.M_BOOTSTRAP) for a in range(3)]), 30, 0, 300),
     "raft3_two_periods": lambda: (M.raft_model(3), events_to_array([start(a) for a in range(3)] + [send(0, M.M_BOOTSTRAP),
@@ -497,5 +497,36 @@ def test_config5_pipeline_record_of_the_transliteration_is_the_oracles(oracle):
     n = rec["interleavings"]
     one = oracle.dpor_explore(model, ev, PAR(depth=depth), T.DporSearch(1, n, 0, 1, T.DPOR_ORDER_ROUNDS), n_threads=1)
     assert len(one[0]) == n == 6000
+    assert hashlib.sha256(np.ascontiguousarray(one[0], dtype=T.VERDICT_DTYPE).tobytes()).hexdigest() == rec["sha256_verdicts"]
+    assert hashlib.sha256(np.ascontiguousarray(one[1], dtype=np.uint32).tobytes()).hexdigest() == rec["sha256_prefix_lens"]
+
+
+def test_round6_records_of_the_workloads_that_find_the_bugs(oracle):
+    """The records the GPU's REFERENCE order is held against on the workloads bench.py times from round 6 on
+    (tests/test_dpor_bug_workloads_gpu.py): config 3's golden record (the C oracle, one backtrack point at a time) and the
+    transliteration's record of the SAME 258 025 interleavings say the same, and the oracle reproduces the golden record's first
+    2^14 verdicts here; config 5's first 6 000 (1 118 violating) by the transliteration are the oracle's bytes."""
+    import hashlib
+    import json
+    import os
+    from demi_amd.apps import raft5_dpor_config3, shuffle8_dpor_config5
+    g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    with open(os.path.join(g, "dpor_config3_bug_reference_order.json")) as f:
+        gold = json.load(f)
+    with open(os.path.join(g, "dpor_config3_bug_transliteration.json")) as f:
+        tr = json.load(f)
+    assert "ScalaDPORwHeuristics" in tr["generator"] and tr["equals_dpor_config3_bug_reference_order_json"] is True
+    for k in ("interleavings", "exhausted", "sha256_verdicts", "sha256_prefix_lens", "violations", "distinct_schedules"):
+        assert tr[k] == gold[k], k
+    assert gold["interleavings"] == 258025 and gold["exhausted"] and gold["violations"] == 4028 and gold["first_violation"] == 47012
+    model, ev, par = raft5_dpor_config3()
+    one = oracle.dpor_explore(model, ev, par, T.DporSearch(1, 1 << 14, 0, 1, T.DPOR_ORDER_ROUNDS), n_threads=1)
+    assert hashlib.sha256(np.ascontiguousarray(one[0], dtype=T.VERDICT_DTYPE).tobytes()).hexdigest() == gold["sha256_first_16384_verdicts"]
+    with open(os.path.join(g, "dpor_config5_bug_transliteration.json")) as f:
+        rec = json.load(f)
+    assert "ScalaDPORwHeuristics" in rec["generator"] and rec["equals_the_oracles_one_at_a_time_exploration"] is True and rec["violations"] == 1118
+    model, ev, par, _budget = shuffle8_dpor_config5()
+    one = oracle.dpor_explore(model, ev, par, T.DporSearch(1, rec["interleavings"], 0, 1, T.DPOR_ORDER_ROUNDS), n_threads=1)
+    assert len(one[0]) == rec["interleavings"] == 6000
     assert hashlib.sha256(np.ascontiguousarray(one[0], dtype=T.VERDICT_DTYPE).tobytes()).hexdigest() == rec["sha256_verdicts"]
     assert hashlib.sha256(np.ascontiguousarray(one[1], dtype=np.uint32).tobytes()).hexdigest() == rec["sha256_prefix_lens"]

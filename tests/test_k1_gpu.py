@@ -543,10 +543,10 @@ def test_first_schedules_against_the_random_scheduler_transliterations_record(gp
 
 
 def test_two_calls_in_flight_in_one_context(oracle):
-    """demi_random_explore_submit / _wait: explore() in pieces with two of them running in ONE context (a second set of K1's
-    per-launch scratch, two streams of the context's own).  Every call returns what demi_random_explore_flagged returns for its
-    seeds and, on request, all its verdicts = the oracle's; a third submit is refused until a ticket is waited for; tickets
-    are single-use; a (re)load of the trace waits for both calls."""
+    """demi_random_explore_submit / _wait: explore() in pieces, up to three calls outstanding in ONE context, two of their kernels
+    running at a time (a second set of K1's per-launch scratch, two streams of the context's own).  Every call returns what
+    demi_random_explore_flagged returns for its seeds and, on request, all its verdicts = the oracle's; a fourth submit is
+    refused until a ticket is waited for; tickets are single-use; a (re)load of the trace waits for the calls in flight."""
     from demi_amd import _native
     model, events, lim = raft5_config2()
     ctx = _native.Context(0)
@@ -557,17 +557,18 @@ def test_two_calls_in_flight_in_one_context(oracle):
         n, k = (1 << 12, 5) if os.environ.get("DEMI_EMU") == "1" else (1 << 18, 7)
         mask = T.V_VIOLATION | T.V_PENDING_OVF | T.V_QUEUE_OVF
         want_flagged = [ctx.random_explore_flagged(n, lim, mask, seed_base=SEED_BASE + j * n) for j in range(k)]
-        tickets = [ctx.random_explore_submit(n, lim, seed_base=SEED_BASE + j * n, flag_mask=mask) for j in range(2)]
-        assert tickets[0] != tickets[1] and all(t > 0 for t in tickets)
+        # (every verdict asked for at the submit for call 0 only: the last call's are fetched by its wait)
+        tickets = [ctx.random_explore_submit(n, lim, seed_base=SEED_BASE + j * n, flag_mask=mask, want_verdicts=(j == 0)) for j in range(3)]
+        assert len(set(tickets)) == 3 and all(t > 0 for t in tickets)
         with pytest.raises(_native.DemiError):
-            ctx.random_explore_submit(n, lim, seed_base=SEED_BASE, flag_mask=mask)
+            ctx.random_explore_submit(n, lim, seed_base=SEED_BASE, flag_mask=mask)       # three are outstanding
         for j in range(k):
             out = np.zeros(n, dtype=T.VERDICT_DTYPE) if j in (0, k - 1) else None
             hits, cnt, first = ctx.random_explore_wait(tickets[j], out=out)
             with pytest.raises(_native.DemiError):
                 ctx.random_explore_wait(tickets[j])                  # a ticket is waited for once
-            if j + 2 < k:
-                tickets.append(ctx.random_explore_submit(n, lim, seed_base=SEED_BASE + (j + 2) * n, flag_mask=mask))
+            if j + 3 < k:
+                tickets.append(ctx.random_explore_submit(n, lim, seed_base=SEED_BASE + (j + 3) * n, flag_mask=mask))
             wh, wc, wf = want_flagged[j]
             assert cnt == wc and first == wf and len(hits) == len(wh) and (hits == wh).all(), j
             if out is not None:
@@ -582,8 +583,8 @@ def test_two_calls_in_flight_in_one_context(oracle):
 
 
 def test_explore_in_calls_is_explore_in_one_call(oracle):
-    """RandomScheduler.explore (the loop GpuRandomScheduler.explore in scala/ runs): the executions in calls of `chunk`, two in
-    flight, nothing submitted beyond the first violating call - the same first violating execution, trace and fingerprint as
+    """RandomScheduler.explore (the loop GpuRandomScheduler.explore in scala/ runs): the executions in calls of `chunk`, two
+    submitted ahead of the one waited for, nothing submitted beyond those behind the first violating call - the same first violating execution, trace and fingerprint as
     ONE call over all executions (rounds 1-5), on a trace whose first violation lies several calls in, and None alike when
     there is none."""
     from demi_amd.schedulers import RandomScheduler, SchedulerConfig
@@ -597,7 +598,7 @@ def test_explore_in_calls_is_explore_in_one_call(oracle):
     sched.setMaxMessages(200)
     sched.chunk = chunk
     a = sched.explore(events)
-    assert sched.last_calls in (4, 5)                # (the fourth call, and the fifth already in flight behind it)
+    assert sched.last_calls in (4, 5, 6)             # (the fourth call, and the two already submitted behind it)
     ev = sched._prepare(events)
     b = sched._explore_one_call(ev, None)
     assert a is not None and b is not None

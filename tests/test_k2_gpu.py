@@ -442,3 +442,47 @@ def test_bench_candidates_against_the_sts_transliterations_record(gpu_ctx):
         from oracle import oracle_py as O
         want = O.sts_replay_batch(model, used, rec, masks, T.Limits(0, 0, 128, 1, vv.fingerprint, 0), n_threads=os.cpu_count() or 1)
         assert (got == want).all()
+
+
+@pytest.mark.gpu
+def test_replay_launches_of_one_ctx_on_two_streams(oracle):
+    """demi_replay_batch_dev alternates between two sets of K2's per-launch scratch (work counter, spill, word counters in HBM): launches
+    that alternate between two streams overlap and must still each replay exactly their own candidates - against the oracle, for the
+    scanning kernel's table and for one with word counters, with a (re)load in between that has to wait for both."""
+    import ctypes as C
+    import torch
+    from demi_amd import _native
+    model, events, lim = raft5_config4(120)
+    ctx = _native.Context(0)
+    try:
+        ctx.model_load(model.to_struct())
+        ctx.trace_load(events)
+        v = ctx.random_explore(4000, lim, seed_base=SEED_BASE)
+        i = int(np.nonzero(v["flags"] & T.V_VIOLATION)[0][0])
+        vv, rec = ctx.random_get_trace(SEED_BASE + i, lim)
+        used = events[:T.verdict_trace_idx(int(vv.flags))]
+        target = T.Limits(0, 0, 128, 1, vv.fingerprint, 0)
+        rng = np.random.default_rng(7)
+        n, k = 1 << 16, 6
+        masks = [random_masks(rng, len(used), n) for _ in range(k)]
+        for specialise in (False, True):
+            ctx.replay_load(used, rec)
+            if specialise:
+                ctx.model_specialize()
+            want = [oracle.sts_replay_batch(model, used, rec, m, target, n_threads=os.cpu_count()) for m in masks[:2]]
+            streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+            d_masks = [torch.from_numpy(m.view(np.int64)).cuda() for m in masks]
+            outs = [torch.zeros((n, 2), dtype=torch.int64, device="cuda") for _ in range(k)]
+            torch.cuda.synchronize()
+            for j in range(k):
+                ctx.replay_batch_dev(d_masks[j].data_ptr(), n, target, outs[j].data_ptr(), stream=C.c_void_p(streams[j % 2].cuda_stream))
+            ctx.replay_load(used, rec)                 # must wait for the launches in flight on both scratch sets
+            torch.cuda.synchronize()
+            seq = [ctx.replay_batch(m, target) for m in masks]
+            for j in range(k):
+                got = outs[j].cpu().numpy().view(T.VERDICT_DTYPE).reshape(-1)
+                assert (got == seq[j]).all(), (specialise, j)
+                if j < 2:
+                    assert (got == want[j]).all(), (specialise, j)
+    finally:
+        ctx.close()
