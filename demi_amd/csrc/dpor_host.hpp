@@ -1197,6 +1197,11 @@ int explore_rounds_devqueue(Dev&& dev, const demi_dpor_search* srch, demi_verdic
   uint64_t first_id = ~0ull;
   bool exhausted = false;
   constexpr size_t MAX_RANGES = 4096;
+  // (pools below 2^22 points - 100 MB - are not worth a compaction; DEMI_K3_POOL_COMPACT_MIN: a test's way to a small threshold)
+  // (with the knob set a compaction happens as soon as that many points are dead, whatever the live share)
+  uint64_t compact_min = 1ull << 22;
+  bool compact_eager = false;
+  if (const char* e = demi_host::knob("DEMI_K3_POOL_COMPACT_MIN")) { const unsigned long long v = strtoull(e, nullptr, 10); if (v >= 1) { compact_min = v; compact_eager = true; } }
   while (!items.empty()) {
     const uint32_t n = (uint32_t)items.size();
     vd.resize(n);
@@ -1277,6 +1282,36 @@ int explore_rounds_devqueue(Dev&& dev, const demi_dpor_search* srch, demi_verdic
       while (top >= 0 && runs[top].empty()) top--;
     }
     if (items.empty() && queued == 0) exhausted = true;
+    // The pool only ever grew: 24 B for every point ever emitted (advisor, round 5).  Once more than half of a sizeable pool is
+    // dequeued points, the live runs move to the front of a fresh one (deepest bucket first, FIFO order kept within a bucket)
+    // and the runs are rebased.  A failed allocation leaves everything as it was.
+    if (!items.empty() && pool_fill >= compact_min && (compact_eager ? pool_fill - queued >= compact_min : pool_fill - queued > queued)) {
+      if (dev.q_compact_begin(queued) == 0) {
+        uint64_t acc = 0;
+        int crc = 0;
+        ranges.clear();
+        uint64_t block_base = 0;
+        auto flush = [&]() {
+          if (!ranges.empty() && !crc) crc = dev.q_compact_add(ranges.data(), (uint32_t)ranges.size(), block_base);
+          ranges.clear();
+          block_base = acc;
+        };
+        std::vector<std::pair<Run*, uint64_t>> moved;
+        for (int b = top; b >= 0 && !crc; b--)
+          for (Run& r : runs[b]) {
+            if ((uint64_t)(acc - block_base) + r.left > 0xFFFFFFFFull || ranges.size() >= MAX_RANGES) flush();
+            ranges.push_back(QueueRange{r.start, r.left, (uint32_t)(acc - block_base)});
+            moved.emplace_back(&r, acc);
+            acc += r.left;
+          }
+        flush();
+        if (!crc && acc == queued) {
+          crc = dev.q_compact_end();
+          if (!crc) { for (auto& m : moved) m.first->start = m.second; pool_fill = queued; stats->fetches++; }
+        } else dev.q_compact_abort();
+        if (crc) return crc;
+      }
+    }
     if (seconds) seconds[2] += now() - t2;
   }
   if (first_id != ~0ull && first_violation_trace && first_violation_len) {

@@ -230,6 +230,15 @@ __global__ __launch_bounds__(256) void k3_q_live(const K3QueueArgs a) {
 
 // One workgroup walks the candidates in order: the first `want` live ones are taken.  out[1] = taken, out[2] = consumed (the
 // index after the last one taken, or n_cand).
+// compaction of the pool (round 6): range r's points pool[start .. start + count) move to dst[prefix .. prefix + count) - the live
+// runs of the host's FIFOs, in the order the host lists them; one workgroup per range.
+__global__ __launch_bounds__(256) void k3_q_compact(const QRange* ranges, uint32_t n_ranges, const QPoint* src, QPoint* dst, unsigned long long dst_base) {
+  const uint32_t r = blockIdx.x;
+  if (r >= n_ranges) return;
+  const QRange g = ranges[r];
+  for (uint32_t i = threadIdx.x; i < g.count; i += blockDim.x) dst[dst_base + g.prefix + i] = src[g.start + i];
+}
+
 __global__ __launch_bounds__(1024) void k3_q_take(const K3QueueArgs a) {
   __shared__ uint32_t s_wave[16];          // live candidates per wave of the current chunk
   __shared__ uint32_t s_have, s_consumed;

@@ -620,7 +620,8 @@ typedef struct {
   uint64_t first_violation;     /* index into out_verdicts, ~0 if none */
   uint64_t queue_len;           /* backtrack points still queued at return */
   uint32_t exhausted;           /* the queue ran empty */
-  uint32_t fetches;             /* REFERENCE order: how many times the commit asked the device for racing-pair records */
+  uint32_t fetches;             /* REFERENCE order: how many times the commit asked the device for racing-pair records;
+                                   ROUNDS order on one GPU: how many times the device-resident queue's pool was compacted */
   uint64_t executed;            /* interleavings run on the device (REFERENCE order: committed + speculated in vain) */
   uint64_t cache_misses;        /* REFERENCE order: committed interleavings the speculation had not run */
   double kernel_ms;             /* sum of the K3 launches' durations (HIP events on the launch stream) */

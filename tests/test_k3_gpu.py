@@ -769,3 +769,33 @@ def test_reference_order_when_the_speculations_table_is_full(oracle, monkeypatch
     with pytest.raises(_native.DemiError, match="table full"):
         ctx.dpor_explore(par, T.DporSearch(64, budget, 0, 1, T.DPOR_ORDER_ROUNDS))
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_the_device_queues_pool_is_compacted_without_changing_the_exploration(monkeypatch):
+    """The device-resident backtrack queue used to keep every point ever emitted (24 B each, advisor's finding of round 5): once
+    more than half of the pool is dequeued points its live runs now move to the front of a fresh pool.  With the threshold at 64
+    points (DEMI_K3_POOL_COMPACT_MIN) that happens again and again: the exploration - verdicts, next-trace lengths, rounds, queue - is
+    the one without any compaction, on the config-3 workload that finds the seeded bug, in small and in large rounds."""
+    from demi_amd import _native
+    from demi_amd.apps import raft5_dpor_config3
+    emu = __import__("os").environ.get("DEMI_EMU") == "1"
+    m3, e3, p3 = raft5_dpor_config3()
+    cases = [(m3, e3, p3, 1500, 8), (m3, e3, p3, 3000 if emu else 40000, 32 if emu else 2048)]
+    monkeypatch.setenv("DEMI_EXPERIMENT", "1")
+    for model, ev, par, budget, batch in cases:
+        srch = T.DporSearch(batch, budget, 0, 1, T.DPOR_ORDER_ROUNDS)
+        res = []
+        for thr in ("1000000000", "64"):
+            monkeypatch.setenv("DEMI_K3_POOL_COMPACT_MIN", thr)
+            ctx = _native.Context(0)
+            ctx.model_load(model.to_struct())
+            ctx.model_specialize()
+            ctx.dpor_load(ev)
+            res.append(ctx.dpor_explore(par, srch))
+            ctx.close()
+        monkeypatch.delenv("DEMI_K3_POOL_COMPACT_MIN")
+        a, b = res
+        assert int(a[4].fetches) == 0 and int(b[4].fetches) >= 2              # (compactions are counted in stats.fetches in this order)
+        assert len(a[0]) == len(b[0]) > 5 and (a[0] == b[0]).all() and (a[1] == b[1]).all() and (a[2] == b[2]).all()
+        assert a[4].backtrack_points == b[4].backtrack_points and a[4].queue_len == b[4].queue_len and a[4].exhausted == b[4].exhausted
