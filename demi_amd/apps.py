@@ -115,3 +115,35 @@ def shuffle8_dpor_config5(jobs=3):
     model = shuffle_model(jobs=jobs, early_cleanup=True)
     dpor_events = events_to_array([start(a) for a in range(8)] + [send(0, SH_SUBMIT), send(0, SH_SPECULATE, 1)])
     return model, dpor_events, T.DporParams(40, 0, 0, 0, 64, 4096, 1), 1 << 20
+
+
+# ---- more than 8 actors: the BIG layout of include/demi_gpu.h (4-bit receiver / 5-bit sender fields, deadLetters = 31; a wide,
+# compiled table).  The same applications with more nodes - the reference puts no bound on actor names (ExternalEvents.scala:62-91).
+def raft11_config2(n_events=50):
+    """Config 2's shape with 11 raft nodes (majority 6; four of them ever campaign - the seeded bug needs an odd cluster: two
+    leaders in a term take 2 x majority votes, one more than there are nodes): 50-event fuzz trace, maxMessages 1000, invariant
+    every 30 deliveries, pending capacity 128.  About 1 % of the schedules violate (oracle)."""
+    model = raft_model(11, election_budget=[1] * 4 + [0] * 7)
+    events = events_to_array(raft_trace(11, n_events, TRACE_SEED + 11))
+    return model, events, T.Limits(1000, 30, 128, 0, 0, 0)
+
+
+def raft11_dpor(campaigners=2):
+    """DPOR over 11 raft nodes of which `campaigners` ever campaign (see raft5_dpor_config3): Start x 11 + Bootstrap x 11."""
+    from .fuzzer import send, start
+    from .model import M_BOOTSTRAP
+    model = raft_model(11, election_budget=[1] * campaigners + [0] * (11 - campaigners))
+    events = events_to_array([start(a) for a in range(11)] + [send(a, M_BOOTSTRAP) for a in range(11)])
+    return model, events, T.DporParams(30, 0, 0, 0, 128, 4096, 1)
+
+
+def shuffle12_config5(jobs=1, early_cleanup=False):
+    """Config 5's application with nine workers (12 actors, three classes): (model, DPOR externals, fuzz externals, Limits,
+    DporParams)."""
+    from .fuzzer import send, start, wait_quiescence
+    from .model import SH_SPECULATE, SH_SUBMIT, shuffle_model
+    model = shuffle_model(jobs=jobs, early_cleanup=early_cleanup, n_workers=9)
+    dpor_events = events_to_array([start(a) for a in range(12)] + [send(0, SH_SUBMIT), send(0, SH_SPECULATE, 1)])
+    fuzz_events = events_to_array([start(a) for a in range(12)] + [send(0, SH_SUBMIT), send(0, SH_SPECULATE, 1),
+                                                                   send(0, SH_SPECULATE, 7), wait_quiescence()])
+    return model, dpor_events, fuzz_events, T.Limits(600, 0, 128, 0, 0, 0), T.DporParams(40, 0, 0, 0, 128, 4096, 1)

@@ -380,7 +380,7 @@ def raft_model(n_actors=5, election_budget=1, buggy=True, term0=0, loglen0=0, in
     candidate whose log is behind its own), AppendReply(term, lastIndex / hint, success); a follower that appended advances
     its commit index to min(leaderCommit, the entry's index)."""
     assert 0 <= log_cap <= RAFT_LOG_MAX and not (log_cap and (term0 > 50 or loglen0)) and not (real_fields and not log_cap)
-    wide = max(term0, loglen0) > 200 or log_cap > 0
+    wide = max(term0, loglen0) > 200 or log_cap > 0 or n_actors > T.MAX_ACTORS      # (more than 8 actors: the BIG layout, a wide table's)
     majority = n_actors // 2 + 1
     h = {}
 
@@ -594,8 +594,9 @@ SH_REDUCEDONE = 9      # the pipeline variant only (shuffle_model(jobs > 1))
 CLS_DRIVER, CLS_COORD, CLS_WORKER = 0, 1, 2
 
 
-def shuffle_model(buggy=True, jobs=1, early_cleanup=False) -> Model:
-    """Actors: 0 driver, 1 map-stage coordinator, 2 reduce-stage coordinator, 3..7 workers.
+def shuffle_model(buggy=True, jobs=1, early_cleanup=False, n_workers=5) -> Model:
+    """Actors: 0 driver, 1 map-stage coordinator, 2 reduce-stage coordinator, 3..7 workers (n_workers = 5: the table of every
+    fixture; up to 13 workers = 16 actors - more than 8 actors is the BIG layout of include/demi_gpu.h, a wide table).
 
     jobs > 1 is the PIPELINE variant (BASELINE config 5 at a size worth sharding, apps.shuffle8_config5_large): the reduce stage
     reports back - a worker that has all its FetchReplies sends ReduceDone, the reduce coordinator counts them and reports
@@ -608,10 +609,10 @@ def shuffle_model(buggy=True, jobs=1, early_cleanup=False) -> Model:
     finds nothing and the invariant's sticky flag F2 is raised.  Unlike the duplicate MapDone (which needs the straggler
     detector of the FIRST job and so sits at the shallow end of a depth-first exploration) this race lives in every job's
     reduce phase: a bounded DPOR search meets it within its first few hundred interleavings (round 6)."""
-    n_workers = 5
+    n_actors = 3 + n_workers
     pipeline = jobs > 1
     early_cleanup = bool(early_cleanup and buggy and pipeline)
-    assert 1 <= jobs <= 255
+    assert 1 <= jobs <= 255 and 1 <= n_workers <= T.MAX_ACTORS_BIG - 3
     h = {}
     # ---- driver: F0 phase (0 idle, 1 map, 2 reduce, 3 done), F1 reports counted, F2 bitmask of workers reported, F6 job number
     a = Asm()
@@ -633,16 +634,22 @@ def shuffle_model(buggy=True, jobs=1, early_cleanup=False) -> Model:
     a.if_eq(ME, 2, "map")            # on the reduce coordinator: RunTask(reduce) to every worker
     if pipeline:
         a.mov(F[1], 0).mov(F[3], 0)
-    for w in range(n_workers):
-        a.mov(T0, 3 + w).mov(T1, 2).send(SH_RUN, T0, T1, 0)
+    if n_workers == 5:
+        for w in range(n_workers):
+            a.mov(T0, 3 + w).mov(T1, 2).send(SH_RUN, T0, T1, 0)
+    else:              # (one effect row instead of n_workers: a delivery has DEMI_FX_CAP of them; driver and coordinators ignore RunTask)
+        a.mov(T1, 2).bcast(SH_RUN, T1, 0)
     a.halt()
     a.label("map")                   # on the map coordinator: relaunch=0 -> all workers; relaunch=1 -> worker 3+w only
     a.if_eq(P1, 0, "re")
     if pipeline:                     # (a new job number: the coordinator starts over)
         a.if_ne(P0, F[4], "same").mov(F[4], P0).mov(F[0], 0).mov(F[1], 0).mov(F[2], 0).mov(F[3], 0).label("same")
     a.if_eq(F[0], 0, "x").mov(F[0], 1)
-    for w in range(n_workers):
-        a.mov(T0, 3 + w).mov(T1, 1).send(SH_RUN, T0, T1, 0)
+    if n_workers == 5:
+        for w in range(n_workers):
+            a.mov(T0, 3 + w).mov(T1, 1).send(SH_RUN, T0, T1, 0)
+    else:
+        a.mov(T1, 1).bcast(SH_RUN, T1, 0)
     a.halt()
     a.label("re").lt(T2, P0, n_workers).if_ne(T2, 0, "x").add(T0, P0, 3).mov(T1, 1).send(SH_RUN, T0, T1, 0).label("x")
     h[(CLS_COORD, "LaunchStage")] = a
@@ -674,18 +681,18 @@ def shuffle_model(buggy=True, jobs=1, early_cleanup=False) -> Model:
     if pipeline:       # the last of the n_workers - 1 replies: this reducer is done
         a.if_eq(F[1], n_workers - 1, "x")
         if early_cleanup:
-            a.if_eq(ME, 7, "keep").mov(F[0], 0).label("keep")
+            a.if_eq(ME, n_actors - 1, "keep").mov(F[0], 0).label("keep")
         a.mov(T0, 2).send(SH_REDUCEDONE, T0, T1, 0).label("x")
     h[(CLS_WORKER, "FetchReply")] = a
     a = Asm()          # TaskTimeout: a straggler detector re-reports (duplicate MapDone)
     a.if_eq(F[0], 1, "x").if_lt(F[4], 1, "x").add(F[4], F[4], 1).mov(T0, 1).send(SH_MAPDONE, T0, T1, 0).label("x")
     h[(CLS_WORKER, "TaskTimeout")] = a
     # coordinators ignore worker-only messages and vice versa (handler_start 0xFFFF)
-    init = [[0] * 8 for _ in range(8)]
-    return build_model("shuffle8-synth%s%s%s" % ("" if buggy else "-fixed", "-x%d" % jobs if pipeline else "", "-c" if early_cleanup else ""), 8,
+    init = [[0] * 8 for _ in range(n_actors)]
+    return build_model("shuffle%d-synth%s%s%s" % (n_actors, "" if buggy else "-fixed", "-x%d" % jobs if pipeline else "", "-c" if early_cleanup else ""), n_actors,
                        SH_MSGS + ([("ReduceDone", T.MSG_INTERNAL)] if pipeline else []), h, init,
-                       invariant=(T.INV_NEVER, 2, 1, 0), actor_class=[CLS_DRIVER, CLS_COORD, CLS_COORD] + [CLS_WORKER] * 5,
-                       n_classes=3)
+                       invariant=(T.INV_NEVER, 2, 1, 0), actor_class=[CLS_DRIVER, CLS_COORD, CLS_COORD] + [CLS_WORKER] * n_workers,
+                       n_classes=3, wide=n_actors > T.MAX_ACTORS)
 
 
 # --------------------------------------------------------------------------- replicated log (DEMI_MODEL_ARRAY)

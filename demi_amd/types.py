@@ -3,6 +3,8 @@ import ctypes as C
 
 MAX_ACTORS = 8
 DEADLETTERS = 15
+MAX_ACTORS_BIG = 16       # a table with more than MAX_ACTORS actors: the BIG layout (include/demi_gpu.h)
+DEADLETTERS_BIG = 31
 MAX_MSG_TYPES = 32
 MAX_CLASSES = 4
 MAX_CODE = 1024

@@ -43,8 +43,10 @@ extern "C" {
 #endif
 
 /* ------------------------------------------------------------------ limits */
-#define DEMI_MAX_ACTORS      8      /* actor ids 0..7 */
+#define DEMI_MAX_ACTORS      8      /* actor ids 0..7: the layout every table of up to 8 actors uses */
 #define DEMI_DEADLETTERS     15     /* sender id of externals and timers ("deadLetters") */
+#define DEMI_MAX_ACTORS_BIG  16     /* actor ids 0..15: the BIG layout of a table with more than 8 actors (below) */
+#define DEMI_DEADLETTERS_BIG 31     /* its deadLetters id (r14 of a handler run for an external message or a timer) */
 #define DEMI_MAX_MSG_TYPES   32
 #define DEMI_MAX_CLASSES     4
 #define DEMI_MAX_CODE        1024   /* delta-table rows */

@@ -48,6 +48,21 @@ double orc_jrandom_next_double(orc_jrandom* r) {
   return (double)((hi << 27) + lo) * (1.0 / (double)(1LL << 53));
 }
 
+/* ===================================================================== the two message-word layouts (include/demi_gpu.h)
+ * A table with more than DEMI_MAX_ACTORS actors (DEMI_MODEL "big": up to DEMI_MAX_ACTORS_BIG, a wide table) has a 4-bit
+ * receiver and a 5-bit sender field in its message word, deadLetters = DEMI_DEADLETTERS_BIG and 16-bit actor masks in its
+ * fingerprints; every entry point sets the layout of the model it was given (per thread) before it touches a word. */
+#define ORC_MAX_ACTORS DEMI_MAX_ACTORS_BIG
+static _Thread_local int g_big;
+static inline int model_big(const demi_model* m) { return m->n_actors > DEMI_MAX_ACTORS; }
+#define ORC_DL (g_big ? (uint32_t)DEMI_DEADLETTERS_BIG : (uint32_t)(DEMI_DEADLETTERS))      /* sender id of externals and timers */
+#define ORC_IS_ACTOR(a) ((a) < (g_big ? (uint32_t)DEMI_MAX_ACTORS_BIG : (uint32_t)DEMI_MAX_ACTORS))
+/* ordered-pair matrices (partitions): bit a * 16 + b of 256 */
+typedef struct { uint64_t w[4]; } orc_pairset;
+static inline void ps_set(orc_pairset* p, uint32_t a, uint32_t b) { const uint32_t i = a * 16 + b; p->w[i >> 6] |= 1ULL << (i & 63); }
+static inline void ps_clear(orc_pairset* p, uint32_t a, uint32_t b) { const uint32_t i = a * 16 + b; p->w[i >> 6] &= ~(1ULL << (i & 63)); }
+static inline int ps_get(const orc_pairset* p, uint32_t a, uint32_t b) { const uint32_t i = a * 16 + b; return (int)((p->w[i >> 6] >> (i & 63)) & 1); }
+
 /* ===================================================================== model helpers */
 static int timer_index(const demi_model* m, uint32_t type) {
   /* dense index of a TIMER-class type among the model's timer types, ascending */
@@ -57,8 +72,8 @@ static int timer_index(const demi_model* m, uint32_t type) {
   return k;
 }
 
-static uint32_t timer_bit(const demi_model* m, uint32_t rcv, uint32_t type) {
-  return 1u << (rcv * DEMI_MAX_TIMER_TYPES + (uint32_t)timer_index(m, type));
+static uint64_t timer_bit(const demi_model* m, uint32_t rcv, uint32_t type) {
+  return 1ULL << (rcv * DEMI_MAX_TIMER_TYPES + (uint32_t)timer_index(m, type));
 }
 
 /* state words of one actor: its field word(s) - one, two for DEMI_MODEL_WIDE - then its array (DEMI_MODEL_ARRAY: 8 elements
@@ -86,7 +101,9 @@ static void state_init(const demi_model* m, uint64_t* st) {
 
 int orc_model_validate(const demi_model* m, char* err, size_t err_cap) {
   if (!m) FAIL("null model");
-  if (m->n_actors < 1 || m->n_actors > DEMI_MAX_ACTORS) FAIL("n_actors out of range");
+  if (m->n_actors < 1 || m->n_actors > DEMI_MAX_ACTORS_BIG) FAIL("n_actors out of range");
+  if (m->n_actors > DEMI_MAX_ACTORS && !(m->flags & DEMI_MODEL_WIDE))
+    FAIL("more than %d actors need DEMI_MODEL_WIDE (the big layout is a compiled table's)", DEMI_MAX_ACTORS);
   if (m->n_msg_types < 1 || m->n_msg_types > DEMI_MAX_MSG_TYPES) FAIL("n_msg_types out of range");
   if (m->n_classes < 1 || m->n_classes > DEMI_MAX_CLASSES) FAIL("n_classes out of range");
   if (m->code_len < 1 || m->code_len > DEMI_MAX_CODE) FAIL("code_len out of range");
@@ -398,7 +415,9 @@ static void inv_actor(const demi_model* m, const uint64_t* st, uint32_t i, uint3
 
 uint32_t orc_invariant(const demi_model* m, const uint64_t* st, uint32_t exists) {
   const uint32_t A = m->n_actors;
-  uint32_t hit[DEMI_MAX_ACTORS], key[DEMI_MAX_ACTORS], hits = 0;
+  uint32_t hit[ORC_MAX_ACTORS], key[ORC_MAX_ACTORS], hits = 0;
+  /* fingerprint layouts: kind << 24 | key << 8 | actors (8 bits); big tables: kind << 30 | (key & 0x3FFF) << 16 | actors (16 bits) */
+  const int big = model_big(m);
   if ((m->inv_kind & 0xFFu) == DEMI_INV_NONE) return 0;
   for (uint32_t i = 0; i < A; i++) {
     hit[i] = 0; key[i] = 0;
@@ -414,12 +433,12 @@ uint32_t orc_invariant(const demi_model* m, const uint64_t* st, uint32_t exists)
           uint32_t mask = 0;
           for (uint32_t k = 0; k < A; k++)
             if (hit[k] && key[k] == key[i]) mask |= 1u << k;
-          return (1u << 24) | (key[i] << 8) | mask;
+          return big ? (1u << 30) | ((key[i] & 0x3FFFu) << 16) | mask : (1u << 24) | (key[i] << 8) | mask;
         }
       }
       return 0;
     case DEMI_INV_NEVER:
-      return hits ? (2u << 24) | hits : 0;
+      return hits ? (big ? 2u << 30 : 2u << 24) | hits : 0;
     case DEMI_INV_AGREE: {
       uint32_t first = 0xFFFFFFFFu, bad = 0;
       for (uint32_t k = 0; k < A; k++) {
@@ -427,7 +446,7 @@ uint32_t orc_invariant(const demi_model* m, const uint64_t* st, uint32_t exists)
         if (first == 0xFFFFFFFFu) first = key[k];
         else if (key[k] != first) bad = 1;
       }
-      return bad ? (3u << 24) | hits : 0;
+      return bad ? (big ? 3u << 30 : 3u << 24) | hits : 0;
     }
     default:
       return 0;
@@ -441,18 +460,20 @@ uint32_t orc_invariant(const demi_model* m, const uint64_t* st, uint32_t exists)
 typedef struct { uint64_t word; uint32_t id; } pend_entry;
 
 /* message word: type[4:0] | dst[7:5] | src[11:8] | p0[23:16] | p1[31:24]; DEMI_MODEL_WIDE: p0[31:16] | p1[47:32] */
+/* big tables (more than 8 actors): type[4:0] | dst[8:5] | src[13:9] | area[63:16] */
 static inline uint32_t msg_word(uint32_t type, uint32_t src, uint32_t dst, uint32_t p0, uint32_t p1) {
+  if (g_big) return type | (dst << 5) | (src << 9) | (p0 << 16);      /* (only ever called with p0 = p1 = 0 for a wide table) */
   return type | (dst << 5) | (src << 8) | (p0 << 16) | (p1 << 24);
 }
 #define W_TYPE(w) ((uint32_t)(w) & 31u)
-#define W_DST(w) (((uint32_t)(w) >> 5) & 7u)
-#define W_SRC(w) (((uint32_t)(w) >> 8) & 15u)
+#define W_DST(w) (g_big ? (((uint32_t)(w) >> 5) & 15u) : (((uint32_t)(w) >> 5) & 7u))
+#define W_SRC(w) (g_big ? (((uint32_t)(w) >> 9) & 31u) : (((uint32_t)(w) >> 8) & 15u))
 #define W_P0(w) (((w) >> 16) & 255u)
 #define W_P1(w) ((w) >> 24)
 /* the word of a message whose payload is `area`, and the area of a word (see "payload area" above) */
 static inline uint64_t msg_word_a(int wide, uint32_t type, uint32_t src, uint32_t dst, uint64_t area) {
   if (!wide) return msg_word(type, src, dst, (uint32_t)area & 0xFFu, (uint32_t)(area >> 16) & 0xFFu);
-  return (uint64_t)(type | (dst << 5) | (src << 8)) | (area << 16);
+  return (uint64_t)(type | (dst << 5) | (src << (g_big ? 9 : 8))) | (area << 16);
 }
 #define WX_AREA(wide, w) ((wide) ? (uint64_t)(w) >> 16 : (uint64_t)(W_P0(w) | (W_P1(w) << 16)))
 
@@ -465,10 +486,10 @@ typedef struct {
   const demi_limits* lim;
   orc_jrandom rng;
   int wide;                             /* DEMI_MODEL_WIDE */
-  uint64_t state[ORC_MAX_STW * DEMI_MAX_ACTORS];  /* model_stw words per actor: field word(s), then the array */
+  uint64_t state[ORC_MAX_STW * ORC_MAX_ACTORS];  /* model_stw words per actor: field word(s), then the array */
   uint32_t exists, inaccessible, killed;
   uint32_t blocked;     /* Instrumenter().blockedActors (crashed actors), V/Instrumenter.scala:116, 184-199 */
-  uint64_t partitioned; /* bit a*8+b : ordered pair (a,b), V/schedulers/EventOrchestrator.scala:51 */
+  orc_pairset partitioned; /* ordered pair (a,b), V/schedulers/EventOrchestrator.scala:51 */
   uint32_t trace_idx;
   pend_entry pend[PEND_HARD_CAP]; /* RandomizedHashSet.arr, V/schedulers/Util.scala:112 (SrcDstFIFO: timersAndExternals) */
   uint32_t n_pend, p_max;
@@ -477,15 +498,15 @@ typedef struct {
   int fifo;
   pend_entry norm[PEND_HARD_CAP];
   uint32_t n_norm;
-  uint8_t pairs[64];              /* srcDsts: src * 8 + dst, in queue-creation order */
+  uint8_t pairs[256];             /* srcDsts: src * 16 + dst, in queue-creation order */
   uint32_t n_pairs;
   orc_jrandom te_rng;             /* timersAndExternals' RandomizedHashSet generator */
   orc_jrandom app_rng;            /* Instrumenter().seededRandom = scala.util.Random(0), new per ActorSystem (V/Instrumenter.scala:226-229) */
   mts_entry mts[MTS_CAP]; /* messagesToSend, V/schedulers/ExternalEventInjector.scala:109 */
   uint32_t n_mts;
   uint32_t n_mts_timers;  /* timers among them; capacity DEMI_TQ_CAP is part of the spec */
-  uint32_t just_scheduled; /* justScheduledTimers, V/schedulers/RandomScheduler.scala:109 */
-  uint32_t repeating;      /* timerToCancellable of ongoing timers, V/Instrumenter.scala:141 */
+  uint64_t just_scheduled; /* justScheduledTimers, V/schedulers/RandomScheduler.scala:109 */
+  uint64_t repeating;      /* timerToCancellable of ongoing timers, V/Instrumenter.scala:141 */
   uint8_t resend[DEMI_RESEND_CAP][2]; /* timersToResend (rcv, type), RandomScheduler.scala:113 */
   uint32_t n_resend;
   uint32_t count;     /* messagesScheduledSoFar */
@@ -495,7 +516,7 @@ typedef struct {
   uint64_t hash;
   demi_rec_event* rec;
   uint32_t rec_cap, n_rec;
-  orc_effect fx[DEMI_MAX_CODE * DEMI_MAX_ACTORS];
+  orc_effect fx[DEMI_MAX_CODE * ORC_MAX_ACTORS];
 } exec_t;
 
 static void rec_push(exec_t* x, uint8_t kind, uint8_t snd, uint8_t rcv, uint8_t type, uint64_t area,
@@ -513,10 +534,10 @@ static void rec_push(exec_t* x, uint8_t kind, uint8_t snd, uint8_t rcv, uint8_t 
 static int crosses_partition(const exec_t* x, uint32_t snd, uint32_t rcv) {
   if (snd == rcv && !((x->killed >> snd) & 1)) return 0;
   int part = 0;
-  if (snd < DEMI_MAX_ACTORS && rcv < DEMI_MAX_ACTORS)
-    part = (int)(((x->partitioned >> (snd * 8 + rcv)) | (x->partitioned >> (rcv * 8 + snd))) & 1);
-  int inacc_r = rcv < DEMI_MAX_ACTORS ? (int)((x->inaccessible >> rcv) & 1) : 0;
-  int inacc_s = snd < DEMI_MAX_ACTORS ? (int)((x->inaccessible >> snd) & 1) : 0;
+  if (ORC_IS_ACTOR(snd) && ORC_IS_ACTOR(rcv))
+    part = ps_get(&x->partitioned, snd, rcv) | ps_get(&x->partitioned, rcv, snd);
+  int inacc_r = ORC_IS_ACTOR(rcv) ? (int)((x->inaccessible >> rcv) & 1) : 0;
+  int inacc_s = ORC_IS_ACTOR(snd) ? (int)((x->inaccessible >> snd) & 1) : 0;
   return part || inacc_r || inacc_s;
 }
 
@@ -525,9 +546,9 @@ static int crosses_partition(const exec_t* x, uint32_t snd, uint32_t rcv) {
 static void pend_insert(exec_t* x, uint64_t word, uint32_t id) {
   if (x->flags & OVF_ANY) return; /* only the first capacity overflow is reported */
   if (x->n_pend + x->n_norm >= x->p_max) { x->flags |= DEMI_V_PENDING_OVF; return; }
-  if (x->fifo && W_SRC(word) != DEMI_DEADLETTERS) {
+  if (x->fifo && W_SRC(word) != ORC_DL) {
     /* SrcDstFIFO.+= (:791-811): append to the pair's queue, creating it (and its srcDsts entry) if absent */
-    uint8_t pair = (uint8_t)(W_SRC(word) * 8 + W_DST(word));
+    uint8_t pair = (uint8_t)(W_SRC(word) * 16 + W_DST(word));
     int have = 0;
     for (uint32_t i = 0; i < x->n_pairs; i++) have |= (x->pairs[i] == pair);
     if (!have) x->pairs[x->n_pairs++] = pair;
@@ -545,12 +566,12 @@ static void pend_insert(exec_t* x, uint64_t word, uint32_t id) {
 static pend_entry fifo_dequeue(exec_t* x, uint32_t pi) {
   const uint8_t pair = x->pairs[pi];
   uint32_t k = 0;
-  while (W_SRC(x->norm[k].word) * 8 + W_DST(x->norm[k].word) != pair) k++;
+  while (W_SRC(x->norm[k].word) * 16 + W_DST(x->norm[k].word) != pair) k++;
   pend_entry v = x->norm[k];
   memmove(&x->norm[k], &x->norm[k + 1], (x->n_norm - k - 1) * sizeof(pend_entry));
   x->n_norm--;
   int more = 0;
-  for (uint32_t i = k; i < x->n_norm; i++) more |= (W_SRC(x->norm[i].word) * 8 + W_DST(x->norm[i].word) == pair);
+  for (uint32_t i = k; i < x->n_norm; i++) more |= (W_SRC(x->norm[i].word) * 16 + W_DST(x->norm[i].word) == pair);
   if (!more) {
     memmove(&x->pairs[pi], &x->pairs[pi + 1], x->n_pairs - pi - 1);   /* ArrayList.remove(idx) */
     x->n_pairs--;
@@ -590,7 +611,7 @@ static void enqueue_timer(exec_t* x, uint32_t rcv, uint32_t type) {
 /* Instrumenter.registerCancellable + handleTick, V/Instrumenter.scala:1145-1200
  * (WeaveActor.aj:234-279: scheduleOnce -> ongoing=false, schedule -> ongoing=true).            */
 static void register_cancellable(exec_t* x, int ongoing, uint32_t rcv, uint32_t type) {
-  uint32_t bit = timer_bit(x->m, rcv, type);
+  uint64_t bit = timer_bit(x->m, rcv, type);
   if (x->repeating & bit) return; /* "Non-unique timer" (:1154-1157) */
   if (ongoing) x->repeating |= bit;
   enqueue_timer(x, rcv, type);    /* "Schedule it immediately!" */
@@ -625,7 +646,7 @@ static void event_produced(exec_t* x, uint32_t snd, uint32_t rcv, uint32_t type,
   uint32_t id = x->next_id++;
   int is_timer = 0, dropped = 0;
   if (!is_external) {
-    if (snd == DEMI_DEADLETTERS) is_timer = 1;
+    if (snd == ORC_DL) is_timer = 1;
     if (!crosses_partition(x, snd, rcv)) pend_insert(x, msg_word_a(x->wide, type, snd, rcv, area), id);
     else dropped = 1;
   } else {
@@ -639,7 +660,7 @@ static void event_produced(exec_t* x, uint32_t snd, uint32_t rcv, uint32_t type,
 static void send_external_messages(exec_t* x) {
   for (uint32_t i = 0; i < x->n_mts; i++) {
     mts_entry* e = &x->mts[i];
-    event_produced(x, DEMI_DEADLETTERS, e->rcv, e->type, e->area, e->is_external, e->ext_idx);
+    event_produced(x, ORC_DL, e->rcv, e->type, e->area, e->is_external, e->ext_idx);
   }
   x->n_mts = 0;
   x->n_mts_timers = 0;
@@ -671,11 +692,11 @@ static void inject_until_quiescence(exec_t* x) {
         break;
       case DEMI_EV_PARTITION: /* trigger_partition :314-322 */
         rec_push(x, DEMI_REC_PARTITION, e->a, e->b, 0, 0, 0, idx, 0);
-        x->partitioned |= 1ULL << (e->a * 8 + e->b);
+        ps_set(&x->partitioned, e->a, e->b);
         break;
       case DEMI_EV_UNPARTITION: /* trigger_unpartition :324-332 (ordered pair as given) */
         rec_push(x, DEMI_REC_UNPARTITION, e->a, e->b, 0, 0, 0, idx, 0);
-        x->partitioned &= ~(1ULL << (e->a * 8 + e->b));
+        ps_clear(&x->partitioned, e->a, e->b);
         break;
       case DEMI_EV_WAIT_QUIESCENCE: /* :182-184 */
         rec_push(x, DEMI_REC_BEGIN_WAIT_QUIESCENCE, 0, 0, 0, 0, 0, idx, 0);
@@ -705,7 +726,7 @@ static void deliver(exec_t* x, uint64_t word) {
   uint32_t me = W_DST(word);
   orc_effect* fx = x->fx; /* DEMI_MAX_CODE rows x at most DEMI_MAX_ACTORS effects each: never full */
   int n = orc_vm_run_area(x->m, me, &x->state[model_stw(x->m) * me], (uint8_t)W_TYPE(word), (uint8_t)W_SRC(word),
-                          WX_AREA(x->wide, word), x->exists, fx, DEMI_MAX_CODE * DEMI_MAX_ACTORS, &x->app_rng);
+                          WX_AREA(x->wide, word), x->exists, fx, DEMI_MAX_CODE * ORC_MAX_ACTORS, &x->app_rng);
   if (n < 0) { x->flags |= DEMI_V_QUEUE_OVF; return; }
   for (int i = 0; i < n; i++) {
     switch (fx[i].kind) {
@@ -762,7 +783,7 @@ static int schedule_new_message(exec_t* x) {
   } else {
     /* SrcDstFIFO.getNonBlockedMessage (:716-760) */
     int open_pair = 0;                      /* a pair queue whose receiver is not blocked */
-    for (uint32_t i = 0; i < x->n_pairs; i++) open_pair |= !((x->blocked >> (x->pairs[i] & 7)) & 1);
+    for (uint32_t i = 0; i < x->n_pairs; i++) open_pair |= !((x->blocked >> (x->pairs[i] & 15)) & 1);
     if (!open_pair) {
       /* (:717-729) "only timers left" */
       if (!find_non_blocked(x, &x->te_rng, &e)) return 0;
@@ -773,7 +794,7 @@ static int schedule_new_message(exec_t* x) {
         timer = find_non_blocked(x, &x->te_rng, &e);
       if (!timer) {
         uint32_t pi = (uint32_t)orc_jrandom_next_int_bound(&x->rng, (int32_t)x->n_pairs);
-        while ((x->blocked >> (x->pairs[pi] & 7)) & 1) pi = (uint32_t)orc_jrandom_next_int_bound(&x->rng, (int32_t)x->n_pairs);
+        while ((x->blocked >> (x->pairs[pi] & 15)) & 1) pi = (uint32_t)orc_jrandom_next_int_bound(&x->rng, (int32_t)x->n_pairs);
         e = fifo_dequeue(x, pi);
       }
     }
@@ -815,6 +836,7 @@ static int random_execute_in2(exec_t* x, const demi_model* m, const demi_ext_eve
                               uint64_t seed, const demi_limits* lim, demi_verdict* out, demi_rec_event* rec,
                               uint32_t rec_cap, uint32_t* n_rec, uint64_t* final_states, orc_jrandom* carried, int carried_valid) {
   memset(x, 0, offsetof(exec_t, fx));
+  g_big = model_big(m);
   x->m = m; x->trace = trace; x->n_ev = n_ev; x->lim = lim;
   x->wide = (m->flags & DEMI_MODEL_WIDE) != 0;
   x->rec = rec; x->rec_cap = rec_cap;
@@ -986,27 +1008,28 @@ typedef struct { uint64_t word; uint32_t seq; } sts_pend;   /* word: 64 bits for
 typedef struct {
   const demi_model* m;
   int wide;           /* DEMI_MODEL_WIDE: 64-bit message words, two state words per actor */
-  uint64_t state[ORC_MAX_STW * DEMI_MAX_ACTORS];
+  uint64_t state[ORC_MAX_STW * ORC_MAX_ACTORS];
   uint32_t exists, inaccessible, killed;
   uint32_t blocked;   /* crashed actors (Instrumenter().blockedActors): an expected delivery to one is not "pending" (:392-402) */
   orc_jrandom app_rng; /* Instrumenter().seededRandom, new with every replay */
-  uint64_t partitioned;
+  orc_pairset partitioned;
   sts_pend pend[PEND_HARD_CAP];   /* pendingEvents: (snd,rcv) -> fingerprint -> FIFO; seq keeps FIFO order */
   uint32_t n_pend, p_max, next_seq;
   uint8_t mts[DEMI_TQ_CAP][2];    /* messagesToSend timers (rcv, type) */
   uint32_t n_mts;
-  uint32_t repeating, flags, count, ignored;
+  uint64_t repeating;
+  uint32_t flags, count, ignored;
   uint64_t hash;
-  orc_effect fx[DEMI_MAX_CODE * DEMI_MAX_ACTORS];
+  orc_effect fx[DEMI_MAX_CODE * ORC_MAX_ACTORS];
 } sts_t;
 
 static int sts_crosses(const sts_t* x, uint32_t snd, uint32_t rcv) {
   if (snd == rcv && !((x->killed >> snd) & 1)) return 0;
   int part = 0;
-  if (snd < DEMI_MAX_ACTORS && rcv < DEMI_MAX_ACTORS)
-    part = (int)(((x->partitioned >> (snd * 8 + rcv)) | (x->partitioned >> (rcv * 8 + snd))) & 1);
-  int ir = rcv < DEMI_MAX_ACTORS ? (int)((x->inaccessible >> rcv) & 1) : 0;
-  int is = snd < DEMI_MAX_ACTORS ? (int)((x->inaccessible >> snd) & 1) : 0;
+  if (ORC_IS_ACTOR(snd) && ORC_IS_ACTOR(rcv))
+    part = ps_get(&x->partitioned, snd, rcv) | ps_get(&x->partitioned, rcv, snd);
+  int ir = ORC_IS_ACTOR(rcv) ? (int)((x->inaccessible >> rcv) & 1) : 0;
+  int is = ORC_IS_ACTOR(snd) ? (int)((x->inaccessible >> snd) & 1) : 0;
   return part || ir || is;
 }
 
@@ -1044,7 +1067,7 @@ static void sts_handle_timer(sts_t* x, uint32_t rcv, uint32_t type) {
 static void sts_flush(sts_t* x) {
   for (uint32_t i = 0; i < x->n_mts; i++) {
     uint32_t rcv = x->mts[i][0], type = x->mts[i][1];
-    if (!((x->inaccessible >> rcv) & 1)) sts_pend_add(x, msg_word(type, DEMI_DEADLETTERS, rcv, 0, 0));
+    if (!((x->inaccessible >> rcv) & 1)) sts_pend_add(x, msg_word(type, ORC_DL, rcv, 0, 0));
   }
   x->n_mts = 0;
 }
@@ -1058,11 +1081,11 @@ static void sts_deliver(sts_t* x, uint64_t w) {
   if (m->msg_class[W_TYPE(w)] == DEMI_MSG_TIMER && (x->repeating & timer_bit(m, me, W_TYPE(w))))
     sts_handle_timer(x, me, W_TYPE(w));
   int n = orc_vm_run_area(m, me, &x->state[model_stw(m) * me], (uint8_t)W_TYPE(w), (uint8_t)W_SRC(w), WX_AREA(x->wide, w),
-                          x->exists, x->fx, DEMI_MAX_CODE * DEMI_MAX_ACTORS, &x->app_rng);
+                          x->exists, x->fx, DEMI_MAX_CODE * ORC_MAX_ACTORS, &x->app_rng);
   if (n < 0) { x->flags |= DEMI_V_QUEUE_OVF; return; }
   for (int i = 0; i < n && !(x->flags & OVF_ANY); i++) {
     const orc_effect* e = &x->fx[i];
-    uint32_t bit = e->kind ? timer_bit(m, me, e->msg_type) : 0;
+    uint64_t bit = e->kind ? timer_bit(m, me, e->msg_type) : 0;
     switch (e->kind) {
       case 0: /* event_produced, internal (:590-607) */
         if (!sts_crosses(x, me, e->target)) sts_pend_add(x, msg_word_a(x->wide, e->msg_type, me, e->target, e->area));
@@ -1082,7 +1105,7 @@ static void sts_deliver(sts_t* x, uint64_t w) {
           }
         }
         if (!found) {
-          int k = sts_pend_find(x, msg_word(e->msg_type, DEMI_DEADLETTERS, me, 0, 0));
+          int k = sts_pend_find(x, msg_word(e->msg_type, ORC_DL, me, 0, 0));
           if (k >= 0) sts_pend_remove(x, k);
         }
         break;
@@ -1109,6 +1132,7 @@ static int sts_replay_in(sts_t* x, const demi_model* m, const demi_ext_event* ex
    * V/minification/internal_minimization/OneAtATimeRemoval.scala:57-124); kept[i] = 1 iff rec[i] took effect
    * in the replay, i.e. is part of the executed trace test() returns (V/schedulers/STSScheduler.scala:286-292) */
   memset(x, 0, offsetof(sts_t, fx));
+  g_big = model_big(m);
   orc_jrandom_seed(&x->app_rng, 0);
   if (kept) memset(kept, 0, n_rec);
   x->m = m;
@@ -1139,13 +1163,13 @@ static int sts_replay_in(sts_t* x, const demi_model* m, const demi_ext_event* ex
    * ids of MsgSends that were not sendable; their MsgEvents go too.                                                   */
   const uint32_t fka = lim->filter_known_absents;
   uint32_t fk_alive = 0;
-  uint64_t fk_part = 0;
+  orc_pairset fk_part = {{0, 0, 0, 0}};
   static _Thread_local uint8_t fk_pruned[DEMI_MAX_REC_EVENTS * 2];
   if (fka) memset(fk_pruned, 0, sizeof fk_pruned);
-#define FK_ALIVE(who) ((who) >= DEMI_MAX_ACTORS ? 1u : ((fk_alive >> (who)) & 1u))
-#define FK_PART(s, r) (((s) >= DEMI_MAX_ACTORS || (r) >= DEMI_MAX_ACTORS) ? 0u                                       \
-                       : (fka == DEMI_FILTER_ABSENTS_LITERAL) ? (uint32_t)((fk_part >> ((s) * 8 + (r))) & 1u)         \
-                       : (uint32_t)(((fk_part >> ((s) * 8 + (r))) | (fk_part >> ((r) * 8 + (s)))) & 1u))
+#define FK_ALIVE(who) (!ORC_IS_ACTOR(who) ? 1u : ((fk_alive >> (who)) & 1u))
+#define FK_PART(s, r) ((!ORC_IS_ACTOR(s) || !ORC_IS_ACTOR(r)) ? 0u                                                   \
+                       : (fka == DEMI_FILTER_ABSENTS_LITERAL) ? (uint32_t)ps_get(&fk_part, (s), (r))                  \
+                       : (uint32_t)(ps_get(&fk_part, (s), (r)) | ps_get(&fk_part, (r), (s))))
 
   /* cursor over the subsequence's non-Send externals (subsequenceIntersection :299-304) */
   uint32_t cur = 0;
@@ -1164,14 +1188,14 @@ static int sts_replay_in(sts_t* x, const demi_model* m, const demi_ext_event* ex
         if (kept) kept[idx] = 1;
         if (e->kind == DEMI_REC_SPAWN) { x->inaccessible &= ~(1u << a); x->killed &= ~(1u << a); x->blocked &= ~(1u << a); }
         else if (e->kind == DEMI_REC_KILL) { x->killed |= 1u << a; x->inaccessible |= 1u << a; }
-        else if (e->kind == DEMI_REC_PARTITION) x->partitioned |= 1ULL << (a * 8 + b);
-        else x->partitioned &= ~(1ULL << (a * 8 + b));
+        else if (e->kind == DEMI_REC_PARTITION) ps_set(&x->partitioned, a, b);
+        else ps_clear(&x->partitioned, a, b);
         if (e->kind == DEMI_REC_SPAWN) fk_alive |= 1u << a;
         else if (e->kind == DEMI_REC_KILL) fk_alive &= ~(1u << a);
         else {
           /* literal: Partition -> false, UnPartition -> true (sic); corrected: the other way round */
           const int set = (fka == DEMI_FILTER_ABSENTS_LITERAL) ? (e->kind == DEMI_REC_UNPARTITION) : (e->kind == DEMI_REC_PARTITION);
-          if (set) fk_part |= 1ULL << (a * 8 + b); else fk_part &= ~(1ULL << (a * 8 + b));
+          if (set) ps_set(&fk_part, a, b); else ps_clear(&fk_part, a, b);
         }
         break;
       }
@@ -1184,7 +1208,7 @@ static int sts_replay_in(sts_t* x, const demi_model* m, const demi_ext_event* ex
         }
         /* external MsgSend: enqueue_message (:509-511) unless its Send was pruned; internal: nothing */
         if ((e->flags & 1) && IN_MASK(e->ext_idx) && ((x->exists >> e->rcv) & 1)) {
-          sts_pend_add(x, msg_word_a(x->wide, e->msg_type, DEMI_DEADLETTERS, e->rcv, DEMI_REC_AREA(*e)));
+          sts_pend_add(x, msg_word_a(x->wide, e->msg_type, ORC_DL, e->rcv, DEMI_REC_AREA(*e)));
           if (kept && !(x->flags & OVF_ANY)) kept[idx] = 1;
         }
         break;
@@ -1321,7 +1345,7 @@ typedef struct {
   const demi_model* m;
   const demi_dpor_params* par;
   int wide;                             /* DEMI_MODEL_WIDE: 64-bit message words, two state words per actor */
-  uint64_t state[ORC_MAX_STW * DEMI_MAX_ACTORS];
+  uint64_t state[ORC_MAX_STW * ORC_MAX_ACTORS];
   uint32_t isolated;
   uint32_t blocked;    /* crashed actors: skipped by getPendingEvent (:455) and by getMatchingMessage (:478, 518) */
   orc_jrandom app_rng; /* Instrumenter().seededRandom, new with every interleaving */
@@ -1332,9 +1356,10 @@ typedef struct {
   demi_dpor_trace_entry* trace;
   uint32_t n_trace;
   uint32_t parent, cur_root, qperiod, next_qperiod, awaiting, quiescent_marker_ext;
-  uint32_t repeating, flags, count, deliveries;
+  uint64_t repeating;
+  uint32_t flags, count, deliveries;
   uint64_t hash;
-  orc_effect fx[DEMI_MAX_CODE * DEMI_MAX_ACTORS];
+  orc_effect fx[DEMI_MAX_CODE * ORC_MAX_ACTORS];
 } dpor_t;
 
 int orc_dpor_trace_validate(const demi_model* m, const demi_ext_event* ev, uint32_t n, char* err, size_t err_cap) {
@@ -1373,7 +1398,7 @@ static uint32_t dpor_run_external(dpor_t* x, const demi_ext_event* ext, uint32_t
     const demi_ext_event* e = &ext[idx];
     if (e->kind == DEMI_EV_START) x->isolated &= ~(1u << e->a);
     else if (e->kind == DEMI_EV_SEND)
-      dpor_produce(x, msg_word_a(x->wide, e->msg_type, DEMI_DEADLETTERS, e->a, area_of2(x->m, e->p0 | ((uint32_t)e->p0_hi << 8), e->p1 | ((uint32_t)e->p1_hi << 8))));
+      dpor_produce(x, msg_word_a(x->wide, e->msg_type, ORC_DL, e->a, area_of2(x->m, e->p0 | ((uint32_t)e->p0_hi << 8), e->p1 | ((uint32_t)e->p1_hi << 8))));
     else if (e->kind == DEMI_EV_WAIT_QUIESCENCE) { x->marker_pending = 1; x->marker_ext = idx; await = 1; }
     idx++;
   }
@@ -1403,23 +1428,23 @@ static void dpor_deliver(dpor_t* x, uint64_t w) {
   x->deliveries++;
   hash_step(&x->hash, w);
   if (m->msg_class[W_TYPE(w)] == DEMI_MSG_TIMER && (x->repeating & timer_bit(m, me, W_TYPE(w))))
-    dpor_produce(x, msg_word(W_TYPE(w), DEMI_DEADLETTERS, me, 0, 0)); /* retrigger -> enqueue_timer = `!` (Scheduler.scala:73) */
+    dpor_produce(x, msg_word(W_TYPE(w), ORC_DL, me, 0, 0)); /* retrigger -> enqueue_timer = `!` (Scheduler.scala:73) */
   int n = orc_vm_run_area(m, me, &x->state[model_stw(m) * me], (uint8_t)W_TYPE(w), (uint8_t)W_SRC(w), WX_AREA(x->wide, w),
-                          (1u << m->n_actors) - 1, x->fx, DEMI_MAX_CODE * DEMI_MAX_ACTORS, &x->app_rng);
+                          (1u << m->n_actors) - 1, x->fx, DEMI_MAX_CODE * ORC_MAX_ACTORS, &x->app_rng);
   if (n < 0) { x->flags |= DEMI_V_QUEUE_OVF; return; }
   for (int i = 0; i < n && !(x->flags & OVF_ANY); i++) {
     const orc_effect* e = &x->fx[i];
-    uint32_t bit = e->kind ? timer_bit(m, me, e->msg_type) : 0;
+    uint64_t bit = e->kind ? timer_bit(m, me, e->msg_type) : 0;
     switch (e->kind) {
       case 0: dpor_produce(x, msg_word_a(x->wide, e->msg_type, me, e->target, e->area)); break;
       case 1: case 2:
         if (x->repeating & bit) break; /* Non-unique timer */
         if (e->kind == 2) x->repeating |= bit;
-        dpor_produce(x, msg_word(e->msg_type, DEMI_DEADLETTERS, me, 0, 0));
+        dpor_produce(x, msg_word(e->msg_type, ORC_DL, me, 0, 0));
         break;
       case 3: { /* notify_timer_cancel (:961-984): first in the (deadLetters, rcv) queue with this msg */
         x->repeating &= ~bit;
-        uint64_t want = msg_word(e->msg_type, DEMI_DEADLETTERS, me, 0, 0);
+        uint64_t want = msg_word(e->msg_type, ORC_DL, me, 0, 0);
         int best = -1;
         for (uint32_t k = 0; k < x->n_pend; k++)
           if (x->pend[k].word == want && (best < 0 || x->pend[k].seq < x->pend[best].seq)) best = (int)k;
@@ -1436,6 +1461,7 @@ int orc_dpor_execute(const demi_model* m, const demi_ext_event* ext, uint32_t n_
                      demi_dpor_trace_entry* trace, uint32_t* trace_len, demi_dpor_pair* pairs, uint32_t* n_pairs) {
   dpor_t* x = (dpor_t*)calloc(1, sizeof(dpor_t));
   if (!x) return DEMI_ERR_INVALID_ARG;
+  g_big = model_big(m);
   x->m = m; x->par = par; x->trace = trace;
   x->wide = (m->flags & DEMI_MODEL_WIDE) != 0;
   x->p_max = par->p_max ? par->p_max : 64;
@@ -1492,7 +1518,7 @@ int orc_dpor_execute(const demi_model* m, const demi_ext_event* ext, uint32_t n_
       x->pend[chosen] = x->pend[x->n_pend - 1];
       x->n_pend--;
       uint32_t snd = W_SRC(p.word), rcv = W_DST(p.word);
-      if ((snd < DEMI_MAX_ACTORS && ((x->isolated >> snd) & 1)) || ((x->isolated >> rcv) & 1)) {
+      if ((ORC_IS_ACTOR(snd) && ((x->isolated >> snd) & 1)) || ((x->isolated >> rcv) & 1)) {
         if (snd == rcv) { x->flags |= DEMI_V_SELFMSG; break; }  /* (:631-633) */
         continue;                                     /* discarded, schedule again (:626-635) */
       }
