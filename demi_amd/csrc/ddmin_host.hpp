@@ -107,24 +107,24 @@ class DdminDag {
       out.push_back(Atom{(uint8_t)e, (uint8_t)o});
       done[e] = done[o] = 1;
     }
-    int start_of[DEMI_MAX_ACTORS];
-    int part_of[DEMI_MAX_ACTORS * DEMI_MAX_ACTORS];
+    int start_of[DEMI_MAX_ACTORS_BIG];
+    int part_of[DEMI_MAX_ACTORS_BIG * DEMI_MAX_ACTORS_BIG];
     for (int& x : start_of) x = -1;
     for (int& x : part_of) x = -1;
     for (uint32_t e = 0; e < n; e++) {
       if (!given.get(e) || conj_[e] != 255) continue;
       const demi_ext_event& x = ext_[e];
-      const uint32_t a = x.a % DEMI_MAX_ACTORS, b = x.b % DEMI_MAX_ACTORS;
+      const uint32_t a = x.a % DEMI_MAX_ACTORS_BIG, b = x.b % DEMI_MAX_ACTORS_BIG;
       if (x.kind == DEMI_EV_KILL) {
         if (start_of[a] < 0) return false;                 // "Kill without preceding Start"
         out.push_back(Atom{(uint8_t)start_of[a], (uint8_t)e});
         start_of[a] = -1;
       } else if (x.kind == DEMI_EV_PARTITION) {
-        part_of[a * DEMI_MAX_ACTORS + b] = (int)e;         // (a later Partition of the same pair overwrites: caught below)
+        part_of[a * DEMI_MAX_ACTORS_BIG + b] = (int)e;         // (a later Partition of the same pair overwrites: caught below)
       } else if (x.kind == DEMI_EV_START) {
         start_of[a] = (int)e;
       } else if (x.kind == DEMI_EV_UNPARTITION) {
-        int& p = part_of[a * DEMI_MAX_ACTORS + b];
+        int& p = part_of[a * DEMI_MAX_ACTORS_BIG + b];
         if (p < 0) return false;                           // "UnPartition without preceding Partition"
         out.push_back(Atom{(uint8_t)p, (uint8_t)e});
         p = -1;

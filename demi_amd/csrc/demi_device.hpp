@@ -31,6 +31,9 @@ struct DevModel {
   uint64_t init_state_wide[2 * DEMI_MAX_ACTORS];   // DEMI_MODEL_WIDE: two words per actor (init_state is unused then)
   uint64_t tix_packed;      // timer index of message type t in bits 2t, 2t + 1 (what meta[t] >> 8 holds, without the table read)
   uint32_t npay, pad_;      // DEMI_MODEL_PAYLOADS: payload fields per message (2 unless the table says otherwise)
+  // a table with more than DEMI_MAX_ACTORS actors (the BIG layout below; appended, so that every offset above stays what it was)
+  uint32_t actor_class_big[DEMI_MAX_ACTORS_BIG];
+  uint64_t init_state_big[2 * DEMI_MAX_ACTORS_BIG];    // (a big table is a wide table: two words per actor)
 };
 
 // A translation unit compiled for a DEMI_MODEL_WIDE table (-DDEMI_WIDE, only ever by demi_model_specialize) sees 64-bit
@@ -44,6 +47,26 @@ typedef uint32_t word_t;
 constexpr uint32_t FLD_WORDS = 1;
 constexpr bool WIDE_TU = false;
 #endif
+// The BIG layout (-DDEMI_BIG, together with DEMI_WIDE, only ever by demi_model_specialize): a table with 9 .. 16 actors.  The
+// message word's receiver field is 4 bits, its sender field 5 (deadLetters = 31), actor masks are 16 bits, the ordered-pair
+// matrices (partitions, reach) 16 x 16, the timer bits 64.  Everything else compiles to what it compiled to before.
+#ifdef DEMI_BIG
+#ifndef DEMI_WIDE
+#error "DEMI_BIG is a layout of wide tables"
+#endif
+constexpr bool BIG_TU = true;
+constexpr uint32_t MAX_ACT = DEMI_MAX_ACTORS_BIG, DL = DEMI_DEADLETTERS_BIG, W_SRC_SHIFT = 9, W_SRC_MASK = 31;
+typedef uint64_t tmask_t;     // timer bits: actor * DEMI_MAX_TIMER_TYPES + timer index
+typedef uint64_t acpack_t;    // actor classes, 4 bits per actor
+#else
+constexpr bool BIG_TU = false;
+constexpr uint32_t MAX_ACT = DEMI_MAX_ACTORS, DL = DEMI_DEADLETTERS, W_SRC_SHIFT = 8, W_SRC_MASK = 15;
+typedef uint32_t tmask_t;
+typedef uint32_t acpack_t;
+#endif
+constexpr uint32_t ACT_MASK = (1u << MAX_ACT) - 1u;      // every actor
+__host__ __device__ constexpr uint32_t max_act_of(bool big) { return big ? DEMI_MAX_ACTORS_BIG : DEMI_MAX_ACTORS; }
+
 // DEMI_MODEL_ARRAY(n): the actors' arrays (rows LDX / STX) are further state words behind the field word(s) - 8 elements to
 // a word, 4 in a wide table - and, like the wide window, exist only in a translation unit compiled for the table
 // (DEMI_JIT_ARR_LEN, from demi_model_specialize).  ST_WORDS = all the 64-bit words of one actor's state: what is initialised,
@@ -80,14 +103,14 @@ __device__ __forceinline__ uint64_t pay_area(uint32_t p0, uint32_t p1, uint32_t 
   return a;
 }
 __device__ __forceinline__ word_t msg_word_area(uint32_t type, uint32_t src, uint32_t dst, uint64_t area) {
-  return (word_t)(type | (dst << 5) | (src << 8)) | ((word_t)area << 16);
+  return (word_t)(type | (dst << 5) | (src << W_SRC_SHIFT)) | ((word_t)area << 16);
 }
 __device__ __forceinline__ word_t msg_word(uint32_t type, uint32_t src, uint32_t dst, uint32_t p0, uint32_t p1) {
   return msg_word_area(type, src, dst, pay_area(p0, p1));
 }
 __device__ __forceinline__ uint32_t w_type(word_t w) { return (uint32_t)w & 31u; }
-__device__ __forceinline__ uint32_t w_dst(word_t w) { return ((uint32_t)w >> 5) & 7u; }
-__device__ __forceinline__ uint32_t w_src(word_t w) { return ((uint32_t)w >> 8) & 15u; }
+__device__ __forceinline__ uint32_t w_dst(word_t w) { return ((uint32_t)w >> 5) & (MAX_ACT - 1u); }
+__device__ __forceinline__ uint32_t w_src(word_t w) { return ((uint32_t)w >> W_SRC_SHIFT) & W_SRC_MASK; }
 __device__ __forceinline__ uint64_t w_area(word_t w) { return w >> 16; }
 __device__ __forceinline__ uint32_t w_pay(word_t w, uint32_t k) { return k < NPAY ? (uint32_t)(w >> (16 + k * PAY_BITS)) & PAY_MASK : 0u; }
 __device__ __forceinline__ uint32_t w_p0(word_t w) { return w_pay(w, 0); }
@@ -129,16 +152,66 @@ __device__ __forceinline__ uint32_t jr_next_int(uint64_t& s, uint32_t bound, con
 
 // ------------------------------------------------------------------ partitions
 // EventOrchestrator.crosses_partition (schedulers/EventOrchestrator.scala:345-351)
+#ifdef DEMI_BIG
+struct PairSet {         // ordered pairs of actors: bit a * 16 + b of 256
+  uint64_t w[4];
+};
+__device__ __forceinline__ void pairs_clear(PairSet& p) { p.w[0] = 0; p.w[1] = 0; p.w[2] = 0; p.w[3] = 0; }
+// (selected by VALUE, not by address: an indexed register array would live in scratch memory)
+__device__ __forceinline__ uint32_t pairs_get(const PairSet& p, uint32_t a, uint32_t b) {
+  const uint32_t q = a >> 2, sh = ((a & 3u) << 4) | b;
+  const uint64_t v = q == 0 ? p.w[0] : q == 1 ? p.w[1] : q == 2 ? p.w[2] : p.w[3];
+  return (uint32_t)(v >> sh) & 1u;
+}
+__device__ __forceinline__ void pairs_put(PairSet& p, uint32_t a, uint32_t b, bool on) {
+  const uint32_t q = a >> 2;
+  const uint64_t bit = 1ull << (((a & 3u) << 4) | b);
+#pragma unroll
+  for (uint32_t k = 0; k < 4; k++) {
+    const uint64_t m = q == k ? bit : 0ull;
+    p.w[k] = on ? (p.w[k] | m) : (p.w[k] & ~m);
+  }
+}
+#else
+struct PairSet {         // ordered pairs of actors: bit a * 8 + b
+  uint64_t w;
+};
+__device__ __forceinline__ void pairs_clear(PairSet& p) { p.w = 0; }
+__device__ __forceinline__ uint32_t pairs_get(const PairSet& p, uint32_t a, uint32_t b) { return (uint32_t)(p.w >> (a * 8 + b)) & 1u; }
+__device__ __forceinline__ void pairs_put(PairSet& p, uint32_t a, uint32_t b, bool on) {
+  if (on) p.w |= 1ULL << (a * 8 + b); else p.w &= ~(1ULL << (a * 8 + b));
+}
+#endif
 struct Net {
   uint32_t inaccessible, killed;
-  uint64_t partitioned;  // bit a*8+b = ordered pair (a,b)
+  PairSet partitioned;   // the ordered pairs Partition()ed
 };
 __device__ __forceinline__ bool crosses_partition(const Net& n, uint32_t snd, uint32_t rcv) {
-  // snd, rcv < 8 (actor-to-actor)
+  // snd, rcv actors (actor-to-actor)
   if (snd == rcv && !((n.killed >> snd) & 1)) return false;
-  const uint32_t part = (uint32_t)((n.partitioned >> (snd * 8 + rcv)) | (n.partitioned >> (rcv * 8 + snd))) & 1u;
+#ifdef DEMI_BIG
+  const uint32_t part = pairs_get(n.partitioned, snd, rcv) | pairs_get(n.partitioned, rcv, snd);
+#else
+  const uint32_t part = (uint32_t)((n.partitioned.w >> (snd * 8 + rcv)) | (n.partitioned.w >> (rcv * 8 + snd))) & 1u;
+#endif
   return (part | (n.inaccessible >> rcv) | (n.inaccessible >> snd)) & 1u;
 }
+
+// messagesToSend's timers / timersToResend: one byte per entry.  (rcv << 5 | type); BIG: (rcv << 2 | timer index) - four bits
+// of receiver and five of type do not fit - with the type recovered from the table's constants (DEMI_JIT_TYPE_OF_TIX: the
+// message type of timer index k in bits 5k .. 5k + 4; a big table always runs as compiled code)
+#ifdef DEMI_BIG
+#ifndef DEMI_JIT_TYPE_OF_TIX
+#define DEMI_JIT_TYPE_OF_TIX 0u
+#endif
+__device__ __forceinline__ uint32_t tq_pack(uint32_t rcv, uint32_t type, uint32_t tix) { (void)type; return (rcv << 2) | tix; }
+__device__ __forceinline__ uint32_t tq_rcv(uint32_t b) { return b >> 2; }
+__device__ __forceinline__ uint32_t tq_type(uint32_t b) { return ((uint32_t)(DEMI_JIT_TYPE_OF_TIX) >> (5u * (b & 3u))) & 31u; }
+#else
+__device__ __forceinline__ uint32_t tq_pack(uint32_t rcv, uint32_t type, uint32_t tix) { (void)tix; return (rcv << 5) | type; }
+__device__ __forceinline__ uint32_t tq_rcv(uint32_t b) { return b >> 5; }
+__device__ __forceinline__ uint32_t tq_type(uint32_t b) { return b & 31u; }
+#endif
 
 __device__ __forceinline__ void hash_step(uint64_t& h, uint64_t v) { h = (h ^ v) * 0x100000001B3ULL; }
 

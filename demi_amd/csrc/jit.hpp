@@ -411,9 +411,9 @@ inline std::string generate_vm(const demi::DevModel& h, bool sched = false) {
       if (fxs.ok && (fxs.cls[fxs.slot[pc]] >> 16) != FXK_SEND)
         emit("DEMI_FX_MARK(%d)%s\n", fxs.slot[pc], (cw & CW_HALT) ? " goto done;" : "");
       else if (fxs.ok)
-        emit("DEMI_FX_AT(%d, %uu, %uu, %uu, %s > 15u ? 15u : %s, %s)\n", fxs.slot[pc], fxq_of_slot[fxs.slot[pc]], row & 0xFFu, aux, a, a, pay);
-      else
-        emit("DEMI_FX(%uu, %uu, %s > 15u ? 15u : %s, %s)%s\n", row & 0xFFu, aux, a, a, pay, (cw & CW_HALT) ? " goto done;" : "");
+        emit("DEMI_FX_AT(%d, %uu, %uu, %uu, %s > FX_NOBODY ? FX_NOBODY : %s, %s)\n", fxs.slot[pc], fxq_of_slot[fxs.slot[pc]], row & 0xFFu, aux, a, a, pay);
+      else      // (a target beyond the field - sim_core.hpp FX_NOBODY: 15, 31 in the BIG layout - is nobody)
+        emit("DEMI_FX(%uu, %uu, %s > FX_NOBODY ? FX_NOBODY : %s, %s)%s\n", row & 0xFFu, aux, a, a, pay, (cw & CW_HALT) ? " goto done;" : "");
     }
   }
   s += "  done:\n";

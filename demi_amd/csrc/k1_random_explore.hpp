@@ -79,11 +79,15 @@ constexpr int K1_BATCH = 64;         // schedule indices claimed per atomic
 // injection batch (inject_until_quiescence is schedule-independent: the events are applied in trace
 // order whatever the interleaving, so the state after batch j is a function of j alone) and the
 // message word of every Send (0 = not a deliverable Send).
-constexpr uint32_t K1_BATCH_WORDS = 9;   // end index, inaccessible, killed, partitioned lo/hi, sends (offset | count << 16), actors Start()ed, reach lo/hi
+// batch words: end index, inaccessible, killed, partitioned lo/hi, sends (offset | count << 16), actors Start()ed, reach lo/hi
 // reach: byte `snd` = the created actors a message sent by `snd` reaches, i.e. NOT crosses_partition(snd, .)
 // (EventOrchestrator.scala:345-351) under the batch's network state - what every SEND / BCAST of the batch's deliveries asks
-__host__ __device__ inline size_t k1_extra_lds_bytes(uint32_t n_ev, uint32_t n_batches, bool wide = WIDE_TU) {
-  return ((size_t)n_batches * K1_BATCH_WORDS * 4 + 2 * (size_t)n_ev * (wide ? 8 : 4) + 15) & ~(size_t)15;
+// (the BIG layout: words 3 and 4 unused - only the recording variant reads partitions, and it walks the events itself - and the
+// reach matrix is 16 rows of 16 bits, words 7 .. 14, read from LDS where the 8 x 8 one travels in a register pair)
+__host__ __device__ constexpr uint32_t k1_batch_words(bool big) { return big ? 15u : 9u; }
+constexpr uint32_t K1_BATCH_WORDS = k1_batch_words(BIG_TU);
+__host__ __device__ inline size_t k1_extra_lds_bytes(uint32_t n_ev, uint32_t n_batches, bool wide = WIDE_TU, bool big = BIG_TU) {
+  return ((size_t)n_batches * k1_batch_words(big) * 4 + 2 * (size_t)n_ev * (wide ? 8 : 4) + 15) & ~(size_t)15;
 }
 // SrcDstFIFO (RandomScheduler.scala:702-909) keeps the actor-to-actor messages apart from the timers / externals:
 // one array in arrival order (a pair's queue is the sub-sequence with that (src, dst)); its NORM_HOT first slots in
@@ -133,8 +137,8 @@ template <bool REC, bool FIFO>
 __host__ __device__ inline size_t k1_lds_bytes(uint32_t code_len, uint32_t n_ev, uint32_t n_hs, uint32_t n_actors,
                                                uint32_t n_batches, uint32_t n_timer_types, uint32_t hot = K1_HOT, bool wide = WIDE_TU,
                                                uint32_t fxq_slots = K1_FXQ_SLOTS, uint32_t arr_words = ARR_WORDS,
-                                               uint32_t rb_words = 0, uint32_t rb_classes = 0) {
-  return tables_lds_bytes(code_len, n_ev, n_hs, wide, arr_words) + k1_extra_lds_bytes(n_ev, n_batches, wide) +
+                                               uint32_t rb_words = 0, uint32_t rb_classes = 0, bool big = BIG_TU) {
+  return tables_lds_bytes(code_len, n_ev, n_hs, wide, arr_words, big) + k1_extra_lds_bytes(n_ev, n_batches, wide, big) +
          K1_WAVES * (lane_mem_wave_bytes(n_actors, REC, hot, wide, fxq_slots, arr_words) + (FIFO ? k1_fifo_wave_bytes(n_actors, REC, wide) : 0) +
                      k1_tdir_wave_bytes(n_actors, n_timer_types)) + k1_rb_bytes(rb_words, rb_classes);
 }
@@ -175,6 +179,7 @@ template <bool REC, bool FIFO = false, bool CARRY = false, bool REBIN = false, b
 __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const typename K1ArgsOf<MULTI>::type args) {
   static_assert(!REBIN || (!REC && !FIFO), "the re-binned kernel exists for the non-recording FullyRandom variant");
   static_assert(!MULTI || (!REC && !CARRY && !REBIN), "a frontier of candidates runs the non-recording, per-execution-seed kernel");
+  static_assert(!BIG_TU || !REBIN, "the re-binned kernel packs an 8 x 8 reach row: tables of up to 8 actors");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Tables t;
   unsigned char* extra = tables_load(t, smem, args.model, args.trace, args.n_ev, args.exists);
@@ -217,6 +222,25 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const typename K1ArgsOf<MULTI
   if (threadIdx.x == 0) {
     // EventOrchestrator.inject_until_quiescence (:132-189) once per workgroup, for every batch
     uint32_t inacc = t.exists, killed = 0, b_no = 0, n_bs = 0, bs_lo = 0, started = 0;
+#ifdef DEMI_BIG
+    // the 16 x 16 layout: partitions as one 16-bit row per sender; the batch's reach rows go straight into its words 7 .. 14
+    uint32_t prow[MAX_ACT];
+    for (uint32_t i = 0; i < MAX_ACT; i++) prow[i] = 0;
+    auto put_reach = [&](uint32_t* o, uint32_t inacc_, uint32_t killed_) {
+      for (uint32_t k = 0; k < MAX_ACT / 2; k++) o[7 + k] = 0;
+      for (uint32_t snd = 0; snd < MAX_ACT; snd++) {
+        uint32_t col = 0;
+        for (uint32_t r = 0; r < MAX_ACT; r++) col |= ((prow[r] >> snd) & 1u) << r;
+        uint32_t cut = prow[snd] | col | inacc_ | (((inacc_ >> snd) & 1u) ? 0xFFFFu : 0u);
+        if (!((killed_ >> snd) & 1u)) cut &= ~(1u << snd);        // snd == rcv && !killed: never crosses
+        o[7 + (snd >> 1)] |= (t.exists & ~cut & 0xFFFFu) << (16 * (snd & 1u));
+      }
+    };
+    if (t.E == 0) {
+      s_batch[0] = 0; s_batch[1] = inacc; s_batch[2] = 0; s_batch[3] = 0; s_batch[4] = 0; s_batch[5] = 0; s_batch[6] = 0;
+      put_reach(s_batch, inacc, 0);
+    }
+#else
     uint64_t part = 0;
     auto reach_of = [&](uint32_t inacc_, uint32_t killed_, uint64_t part_) -> uint64_t {
       uint64_t r = 0;
@@ -234,6 +258,7 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const typename K1ArgsOf<MULTI
       s_batch[0] = 0; s_batch[1] = inacc; s_batch[2] = 0; s_batch[3] = 0; s_batch[4] = 0; s_batch[5] = 0; s_batch[6] = 0;
       s_batch[7] = (uint32_t)r0; s_batch[8] = (uint32_t)(r0 >> 32);
     }
+#endif
     for (uint32_t i = 0; i < t.E; i++) {
       const uint64_t ev = t.trace[i];
       const uint32_t kind = (uint32_t)ev & 0xFF, a = (uint32_t)(ev >> 8) & 0xFF, b = (uint32_t)(ev >> 16) & 0xFF;
@@ -241,20 +266,33 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const typename K1ArgsOf<MULTI
       const uint32_t ep0 = ((uint32_t)(ev >> 32) & 0xFF) | (WIDE_TU ? ((uint32_t)(ev >> 48) & 0xFF) << 8 : 0u);
       const uint32_t ep1 = ((uint32_t)(ev >> 40) & 0xFF) | (WIDE_TU ? ((uint32_t)(ev >> 56) & 0xFF) << 8 : 0u);
       const word_t sw = (kind == DEMI_EV_SEND && ((t.exists >> a) & 1))
-                            ? msg_word((uint32_t)(ev >> 24) & 0xFF, DEMI_DEADLETTERS, a, ep0, ep1)
+                            ? msg_word((uint32_t)(ev >> 24) & 0xFF, DL, a, ep0, ep1)
                             : (word_t)0;
       s_sendw[i] = sw;
       if (sw != 0) s_bsend[n_bs++] = sw;
       if (kind == DEMI_EV_START) { inacc &= ~(1u << a); killed &= ~(1u << a); started |= 1u << a; }
       else if (kind == DEMI_EV_KILL) { killed |= 1u << a; inacc |= 1u << a; }
+#ifdef DEMI_BIG
+      else if (kind == DEMI_EV_PARTITION) prow[a & (MAX_ACT - 1u)] |= 1u << b;
+      else if (kind == DEMI_EV_UNPARTITION) prow[a & (MAX_ACT - 1u)] &= ~(1u << b);
+#else
       else if (kind == DEMI_EV_PARTITION) part |= 1ULL << (a * 8 + b);
       else if (kind == DEMI_EV_UNPARTITION) part &= ~(1ULL << (a * 8 + b));
+#endif
       if (kind == DEMI_EV_WAIT_QUIESCENCE || i + 1 == t.E) {
         uint32_t* o = s_batch + (size_t)b_no * K1_BATCH_WORDS;
+#ifdef DEMI_BIG
+        o[0] = i + 1; o[1] = inacc; o[2] = killed; o[3] = 0; o[4] = 0;
+#else
         o[0] = i + 1; o[1] = inacc; o[2] = killed; o[3] = (uint32_t)part; o[4] = (uint32_t)(part >> 32);
+#endif
         o[5] = bs_lo | ((n_bs - bs_lo) << 16);
         o[6] = started;
+#ifdef DEMI_BIG
+        put_reach(o, inacc, killed);
+#else
         { const uint64_t r = reach_of(inacc, killed, part); o[7] = (uint32_t)r; o[8] = (uint32_t)(r >> 32); }
+#endif
         bs_lo = n_bs; started = 0;
         b_no++;
       }
@@ -360,7 +398,7 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const typename K1ArgsOf<MULTI
   auto timer_entry = [&](word_t pw, uint32_t& e) -> bool {
     const uint32_t ty = w_type(pw);
     e = w_dst(pw) * NTT + tix_of(ty);
-    return w_src(pw) == DEMI_DEADLETTERS && ((timer_types >> ty) & 1u);
+    return w_src(pw) == DL && ((timer_types >> ty) & 1u);
   };
   const uint32_t E = t.E, exists = t.exists;
   const uint32_t max_messages = args.max_messages ? args.max_messages : 0x7FFFFFFFu;
@@ -379,11 +417,30 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const typename K1ArgsOf<MULTI
   // pairmask bit (src * 8 + dst) = that pair has a queue; te_rng is timersAndExternals' own generator
   uint32_t n_norm = 0, n_pairs = 0;
   uint64_t pairmask = 0, te_rng = 0;
-  Net net = {0, 0, 0};
-  uint64_t reach = 0;                 // !REC: the batch's reach matrix (K1_BATCH_WORDS above)
-  uint64_t tq = 0, resend = 0;        // messagesToSend timers / timersToResend: 1 byte each (rcv<<5 | type)
+  Net net;
+  net.inaccessible = 0; net.killed = 0; pairs_clear(net.partitioned);
+  uint64_t reach = 0;                 // !REC: the batch's reach matrix (K1_BATCH_WORDS above; BIG: read from the batch table instead)
+  uint64_t tq = 0, resend = 0;        // messagesToSend timers / timersToResend: 1 byte each (demi_device.hpp tq_pack)
   uint32_t n_tq = 0, n_resend = 0;
-  uint32_t just = 0, rep = 0;         // justScheduledTimers / registered repeating timers (bit rcv*4+tidx)
+  tmask_t just = 0, rep = 0;          // justScheduledTimers / registered repeating timers (bit rcv*4+tidx)
+  // the created actors a message sent by `snd` reaches under the current batch's network state
+  auto reach_row = [&](uint32_t snd) -> uint32_t {
+#ifdef DEMI_BIG
+    return (s_batch[(size_t)(batch_no - 1u) * K1_BATCH_WORDS + 7u + (snd >> 1)] >> (16u * (snd & 1u))) & 0xFFFFu;
+#else
+    return (uint32_t)(reach >> (snd * 8)) & 0xFFu;
+#endif
+  };
+  // does pair `pr` (src * MAX_ACT + dst) have a SrcDstFIFO queue: a bit of pairmask; BIG (256 pairs): a scan of srcDsts
+  auto pair_has = [&](uint32_t pr) -> bool {
+#ifdef DEMI_BIG
+    bool h = false;
+    for (uint32_t i = 0; i < n_pairs; i++) h |= pair_get(i) == pr;
+    return h;
+#else
+    return (pairmask >> pr) & 1ull;
+#endif
+  };
   uint32_t viol = 0, flags = 0;
   uint32_t blocked = 0;               // Instrumenter().blockedActors: actors that crashed (DEMI_OP_CRASH) and were not Start()ed since
   // a specialised build knows whether the table has a CRASH row at all (jit: DEMI_JIT_NO_CRASH): without one `blocked` is
@@ -452,19 +509,19 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const typename K1ArgsOf<MULTI
     if (n_pend + n_norm >= PMAX) { flags |= DEMI_V_PENDING_OVF; }     \
     else {                                                            \
       const word_t w_ = (WORD);                                       \
-      const uint32_t pr_ = w_src(w_) * 8 + w_dst(w_);                 \
+      const uint32_t pr_ = w_src(w_) * MAX_ACT + w_dst(w_);           \
       norm_store(n_norm, w_);                                         \
       if (REC) norm_aux_store(n_norm, (ID));                          \
-      if (!((pairmask >> pr_) & 1ull)) { pair_set(n_pairs, pr_); n_pairs++; pairmask |= 1ull << pr_; } \
+      if (!pair_has(pr_)) { pair_set(n_pairs, pr_); n_pairs++; if (!BIG_TU) pairmask |= 1ull << pr_; } \
       n_norm++;                                                       \
     }                                                                 \
   } while (0)
 
-#define TIMER_BIT(RCV, TYPE) (1u << ((RCV) * DEMI_MAX_TIMER_TYPES + tix_of(TYPE)))
+#define TIMER_BIT(RCV, TYPE) ((tmask_t)1 << ((RCV) * DEMI_MAX_TIMER_TYPES + tix_of(TYPE)))
 
   // RandomScheduler.enqueue_timer (:549-559) -> handle_timer (ExternalEventInjector.scala:282-297)
-  auto enqueue_timer = [&](uint32_t rcv, uint32_t type, uint32_t tbit) {      // tbit = TIMER_BIT(rcv, type)
-    const uint64_t b = (uint64_t)((rcv << 5) | type);
+  auto enqueue_timer = [&](uint32_t rcv, uint32_t type, tmask_t tbit) {      // tbit = TIMER_BIT(rcv, type)
+    const uint64_t b = (uint64_t)tq_pack(rcv, type, BIG_TU ? tix_of(type) : 0u);
     if (just & tbit) {
       if (n_resend >= DEMI_RESEND_CAP) { flags |= DEMI_V_QUEUE_OVF; return; }
       resend |= b << (8 * n_resend);
@@ -636,7 +693,7 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const typename K1ArgsOf<MULTI
           }
           app_rng = jr_seed(0);
           hash = 0xCBF29CE484222325ULL;
-          net.inaccessible = exists; net.killed = 0; net.partitioned = 0;
+          net.inaccessible = exists; net.killed = 0; pairs_clear(net.partitioned);
           blocked = 0;
           hits = 0;
           for (uint32_t j = 0; j < k1_tdir_words(A, NTT); j++) *reinterpret_cast<uint32_t*>(tdir + (j << 8)) = 0xFFFFFFFFu;   // no timer pending
@@ -653,8 +710,12 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const typename K1ArgsOf<MULTI
           const uint32_t* bt = s_batch + (size_t)batch_no * K1_BATCH_WORDS;
           batch_no++;
           tidx = bt[0];
-          net.inaccessible = bt[1]; net.killed = bt[2]; net.partitioned = (uint64_t)bt[3] | ((uint64_t)bt[4] << 32);
+#ifdef DEMI_BIG
+          net.inaccessible = bt[1]; net.killed = bt[2];      // (partitions and reach: the batch table's, see reach_row)
+#else
+          net.inaccessible = bt[1]; net.killed = bt[2]; net.partitioned.w = (uint64_t)bt[3] | ((uint64_t)bt[4] << 32);
           reach = (uint64_t)bt[7] | ((uint64_t)bt[8] << 32);
+#endif
           fl_off = bt[5] & 0xFFFFu; fl_cnt = bt[5] >> 16;
           blocked &= ~bt[6];            // trigger_start: "allow scheduler to send messages to it again" (EventOrchestrator.scala:224-227)
         }
@@ -670,10 +731,10 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const typename K1ArgsOf<MULTI
             net.killed |= 1u << a; net.inaccessible |= 1u << a;
           } else if (kind == DEMI_EV_PARTITION) {
             REC_PUSH(DEMI_REC_PARTITION, a, b, 0, 0, 0, tidx, 0);
-            net.partitioned |= 1ULL << (a * 8 + b);
+            pairs_put(net.partitioned, a, b, true);
           } else if (kind == DEMI_EV_UNPARTITION) {
             REC_PUSH(DEMI_REC_UNPARTITION, a, b, 0, 0, 0, tidx, 0);
-            net.partitioned &= ~(1ULL << (a * 8 + b));
+            pairs_put(net.partitioned, a, b, false);
           } else if (kind == DEMI_EV_WAIT_QUIESCENCE) {
             REC_PUSH(DEMI_REC_BEGIN_WAIT_QUIESCENCE, 0, 0, 0, 0, 0, tidx, 0);
             loop = false;
@@ -750,7 +811,7 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const typename K1ArgsOf<MULTI
           if (sw != 0) {
             const uint32_t id = next_id; next_id++;
             PEND_APPEND(sw, id, -1);
-            REC_PUSH(DEMI_REC_MSG_SEND, DEMI_DEADLETTERS, w_dst(sw), w_type(sw), w_area(sw), 1, i, id);
+            REC_PUSH(DEMI_REC_MSG_SEND, DL, w_dst(sw), w_type(sw), w_area(sw), 1, i, id);
           }
         }
         inj_lo = inj_hi;
@@ -758,11 +819,11 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const typename K1ArgsOf<MULTI
       // ... then timers: internal messages from deadLetters, dropped when the receiver is
       // inaccessible (crosses_partition(deadLetters, rcv), :287-297)
       for (uint32_t k = 0; k < n_tq; k++) {
-        const uint32_t bt = (uint32_t)(tq >> (8 * k)) & 0xFF, rcv = bt >> 5, type = bt & 31;
+        const uint32_t bt = (uint32_t)(tq >> (8 * k)) & 0xFF, rcv = tq_rcv(bt), type = tq_type(bt);
         const uint32_t id = next_id; if (REC) next_id++;
         const bool drop = (net.inaccessible >> rcv) & 1;
-        if (!drop) PEND_APPEND(msg_word(type, DEMI_DEADLETTERS, rcv, 0, 0), id, (int32_t)(rcv * NTT + tix_of(type)));
-        REC_PUSH(DEMI_REC_MSG_SEND, DEMI_DEADLETTERS, rcv, type, 0, 2 | (drop ? 4 : 0), 255, id);
+        if (!drop) PEND_APPEND(msg_word(type, DL, rcv, 0, 0), id, (int32_t)(rcv * NTT + tix_of(type)));
+        REC_PUSH(DEMI_REC_MSG_SEND, DL, rcv, type, 0, 2 | (drop ? 4 : 0), 255, id);
       }
       tq = 0; n_tq = 0;
       if ((flags & DEMI_OVF_ANY) || n_pend + n_norm == 0) none = true;
@@ -776,13 +837,13 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const typename K1ArgsOf<MULTI
         const uint32_t pr = pair_get(pi);
         uint32_t k = 0;
         word_t cur = norm_load(0);
-        while (k + 1 < n_norm && w_src(cur) * 8 + w_dst(cur) != pr) { k++; cur = norm_load(k); }   // queue.head
+        while (k + 1 < n_norm && w_src(cur) * MAX_ACT + w_dst(cur) != pr) { k++; cur = norm_load(k); }   // queue.head
         w = cur;
         if (REC) wid = norm_aux_load(k);
         bool more = false;
         for (uint32_t j = k; j + 1 < n_norm; j++) {
           const word_t nx = norm_load(j + 1);
-          more |= (w_src(nx) * 8 + w_dst(nx) == pr);
+          more |= (w_src(nx) * MAX_ACT + w_dst(nx) == pr);
           norm_store(j, nx);
           if (REC) norm_aux_store(j, norm_aux_load(j + 1));
         }
@@ -790,7 +851,7 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const typename K1ArgsOf<MULTI
         if (!more) {                                     // srcDstToMessages -= srcDst; srcDsts.remove(idx)
           for (uint32_t j = pi; j + 1 < n_pairs; j++) pair_set(j, pair_get(j + 1));
           n_pairs--;
-          pairmask &= ~(1ull << pr);
+          if (!BIG_TU) pairmask &= ~(1ull << pr);
         }
       };
       bool picked = false;          // the message was already chosen (and removed) by the blocked-actor path
@@ -841,14 +902,14 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const typename K1ArgsOf<MULTI
         } else {
           // SrcDstFIFO.getNonBlockedMessage (:716-760) with blocked receivers
           bool open_pair = false;                        // a pair queue whose receiver is not blocked
-          for (uint32_t i = 0; i < n_pairs; i++) open_pair |= !((blocked >> (pair_get(i) & 7u)) & 1u);
+          for (uint32_t i = 0; i < n_pairs; i++) open_pair |= !((blocked >> (pair_get(i) & (MAX_ACT - 1u))) & 1u);
           if (!open_pair) {
             found = find_non_blocked(te_rng);            // (:717-729) "only timers left"
           } else {
             if (jr_next_int(rng, n_pend + n_norm, t.magic) < n_pend) found = find_non_blocked(te_rng);
             if (!found) {
               uint32_t pi = jr_next_int(rng, n_pairs, t.magic);
-              while ((blocked >> (pair_get(pi) & 7u)) & 1u) pi = jr_next_int(rng, n_pairs, t.magic);
+              while ((blocked >> (pair_get(pi) & (MAX_ACT - 1u))) & 1u) pi = jr_next_int(rng, n_pairs, t.magic);
               fifo_dequeue(pi);
               found = true;
             }
@@ -886,7 +947,7 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const typename K1ArgsOf<MULTI
         REC_PUSH(DEMI_REC_MSG_EVENT, w_src(w), me, type, w_area(w), 0, 255, wid);
         hash_step(hash, w);
         // updateRepeatingTimer (:405-421) and the Instrumenter's retrigger (Instrumenter.scala:1008-1016)
-        const uint32_t tbit = TIMER_BIT(me, type);
+        const tmask_t tbit = TIMER_BIT(me, type);
         const bool is_rep = ((timer_types >> type) & 1u) && (rep & tbit);
         if (is_rep) {
           just |= tbit;
@@ -1003,9 +1064,9 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const typename K1ArgsOf<MULTI
     // column of the ordered-pair matrix, the column gathered by a multiply; inaccessible receivers; isolated sender)
     auto send_targets = [&](uint32_t fx) -> uint32_t {    // (the low word of the effect: op, type, target)
       const bool bc = ((fx & 31u) == DEMI_OP_BCAST);
-      const uint32_t target = (fx >> 10) & 15u;
-      const uint32_t tm = bc ? ~(1u << me) : (1u << target);       // (target 15 = nobody: outside the matrix row)
-      return tm & (uint32_t)(reach >> (me * 8)) & 0xFFu;           // created, and not cut off from `me` (reach_of above)
+      const uint32_t target = fx_target(fx);
+      const uint32_t tm = bc ? ~(1u << me) : (1u << target);       // (target FX_NOBODY: outside the matrix row)
+      return tm & reach_row(me);                                   // created, and not cut off from `me` (reach_of above)
     };
     // event_produced for internal messages (:287-297): dropped at send time when crosses_partition, else appended
     auto apply_send = [&](word_t fxw) {
@@ -1013,7 +1074,7 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const typename K1ArgsOf<MULTI
       const uint32_t type = (fx >> 5) & 31u;
       if (REC) {
         const bool bc = ((fx & 31u) == DEMI_OP_BCAST);
-        const uint32_t target = (fx >> 10) & 15u;
+        const uint32_t target = fx_target(fx);
         const uint32_t first = bc ? 0u : target, last = bc ? A : (target < A ? target + 1 : 0u);
         for (uint32_t r = first; r < last; r++) {
           if ((bc && r == me) || !((exists >> r) & 1)) continue;
@@ -1037,9 +1098,9 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const typename K1ArgsOf<MULTI
       }
     };
     // cancelTimer (Instrumenter.scala:159-168) -> notify_timer_cancel (:525-534)
-    auto apply_cancel = [&](uint32_t type, uint32_t tbit, uint32_t tix) {      // tbit = TIMER_BIT(me, type), tix = its timer index
+    auto apply_cancel = [&](uint32_t type, tmask_t tbit, uint32_t tix) {      // tbit = TIMER_BIT(me, type), tix = its timer index
       rep &= ~tbit;
-      const uint32_t want = (me << 5) | type;
+      const uint32_t want = tq_pack(me, type, tix);
       // handle_timer_cancel: messagesToSend first.  The first of its n_tq bytes equal to `want`, all eight
       // compared at once (zero-byte test on tq ^ want...want; its lowest hit is exact)
       bool found = false;
@@ -1062,7 +1123,7 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const typename K1ArgsOf<MULTI
         unsigned char* const p = td_ptr(me * NTT + tix);
         const uint32_t d = *p;
         if (d != TD_NONE) {
-          const word_t wantw = msg_word(type, DEMI_DEADLETTERS, me, 0, 0);
+          const word_t wantw = msg_word(type, DL, me, 0, 0);
           if (d != TD_MANY) {
             pend_remove(d, wantw, LASTW());
           } else {
@@ -1085,7 +1146,7 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const typename K1ArgsOf<MULTI
       }
     };
     // TSET / TREP: registerCancellable + handleTick (Instrumenter.scala:1145-1200)
-    auto apply_timer_set = [&](bool repeating, uint32_t type, uint32_t bit) {      // bit = TIMER_BIT(me, type)
+    auto apply_timer_set = [&](bool repeating, uint32_t type, tmask_t bit) {      // bit = TIMER_BIT(me, type)
       if (!(rep & bit)) {               // else "Non-unique timer" (:1154-1157)
         if (repeating) rep |= bit;
         enqueue_timer(me, type, bit);
@@ -1099,8 +1160,8 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const typename K1ArgsOf<MULTI
 #define DEMI_FX_SLOT(J, KIND, OP, TYPE, TIDX, Q)                                                                      \
       if (((nfx >> (J)) & 1u) && !(flags & DEMI_OVF_ANY)) {                                                           \
         if ((KIND) == 0u) apply_send(mem.fxq[(Q) * 64]);                     /* (Q: the slot's entry of the effect queue) */ \
-        else if ((KIND) == 1u) apply_cancel((TYPE), 1u << (me * DEMI_MAX_TIMER_TYPES + (TIDX)), (TIDX));               \
-        else if ((KIND) == 2u) apply_timer_set((OP) == DEMI_OP_TREP, (TYPE), 1u << (me * DEMI_MAX_TIMER_TYPES + (TIDX))); \
+        else if ((KIND) == 1u) apply_cancel((TYPE), (tmask_t)1 << (me * DEMI_MAX_TIMER_TYPES + (TIDX)), (TIDX));               \
+        else if ((KIND) == 2u) apply_timer_set((OP) == DEMI_OP_TREP, (TYPE), (tmask_t)1 << (me * DEMI_MAX_TIMER_TYPES + (TIDX))); \
         else if (CRASHES) blocked |= 1u << me;                                                                        \
       }                                                                                                               \
       PH_MARK((KIND) == 0u ? 6 : (KIND) == 1u ? 7 : 8);      /* (after the slot, where the wave has reconverged: every lane's clock) */

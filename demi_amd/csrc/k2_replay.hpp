@@ -103,8 +103,8 @@ __host__ __device__ inline size_t k2_fp_lds_bytes(uint32_t code_len, uint32_t n_
 }
 
 __host__ __device__ inline size_t k2_lds_bytes(uint32_t code_len, uint32_t n_ext, uint32_t n_hs, uint32_t n_actors, bool wide = WIDE_TU,
-                                               uint32_t hot = PEND_HOT, uint32_t arr_words = ARR_WORDS) {
-  return tables_lds_bytes(code_len, n_ext, n_hs, wide, arr_words) + K2_WAVES * lane_mem_wave_bytes(n_actors, false, hot, wide, DEMI_FX_CAP, arr_words);
+                                               uint32_t hot = PEND_HOT, uint32_t arr_words = ARR_WORDS, bool big = BIG_TU) {
+  return tables_lds_bytes(code_len, n_ext, n_hs, wide, arr_words, big) + K2_WAVES * lane_mem_wave_bytes(n_actors, false, hot, wide, DEMI_FX_CAP, arr_words);
 }
 
 template <int MODE>
@@ -196,8 +196,10 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
   uint64_t sched = 0, hash = 0;
   uint64_t m0 = 0, m1 = 0, m2 = 0, m3 = 0;   // candidate mask
   uint64_t app_rng = 0;                      // Instrumenter().seededRandom, restarted with every replay (DEMI_OP_RND)
-  uint32_t idx = 0, cur = 0, n_pend = 0, count = 0, ignored = 0, flags = 0, rep = 0, skip = 0xFFFFFFFFu;
-  Net net = {0, 0, 0};
+  uint32_t idx = 0, cur = 0, n_pend = 0, count = 0, ignored = 0, flags = 0, skip = 0xFFFFFFFFu;
+  tmask_t rep = 0;                           // registered repeating timers (bit rcv * 4 + timer index)
+  Net net;
+  net.inaccessible = 0; net.killed = 0; pairs_clear(net.partitioned);
   uint32_t blocked = 0;     // crashed actors (DEMI_OP_CRASH): an expected delivery to one is not "pending" (STSScheduler.scala:392-402)
   // EventTrace.filterKnownAbsentInternals (EventTrace.scala:458-534) on the fly.  actorToAlive is exists & ~inaccessible (a
   // kept SpawnEvent sets it, a kept KillEvent clears it, default false; deadLetters always alive).  actorsToPartitioned as the
@@ -205,13 +207,20 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
   // fk_part (LITERAL); CORRECTED reads net.partitioned in both directions.  prunedMessageSends is a mask over the slots the
   // lowering gave the in-flight internal messages.
   const uint32_t FK = args.filter_absents;
-  uint64_t fk_part = 0, fk_pruned0 = 0, fk_pruned1 = 0;
+  PairSet fk_part;
+  pairs_clear(fk_part);
+  uint64_t fk_pruned0 = 0, fk_pruned1 = 0;
   auto fk_cut = [&](uint32_t s_, uint32_t r_) __attribute__((always_inline)) -> bool {
-    if (s_ >= DEMI_MAX_ACTORS || r_ >= DEMI_MAX_ACTORS) return false;
-    if (FK == DEMI_FILTER_ABSENTS_LITERAL) return (fk_part >> (s_ * 8 + r_)) & 1ull;
-    return ((net.partitioned >> (s_ * 8 + r_)) | (net.partitioned >> (r_ * 8 + s_))) & 1ull;
+    if (s_ >= MAX_ACT || r_ >= MAX_ACT) return false;
+#ifdef DEMI_BIG
+    if (FK == DEMI_FILTER_ABSENTS_LITERAL) return pairs_get(fk_part, s_, r_);
+    return pairs_get(net.partitioned, s_, r_) | pairs_get(net.partitioned, r_, s_);
+#else
+    if (FK == DEMI_FILTER_ABSENTS_LITERAL) return (fk_part.w >> (s_ * 8 + r_)) & 1ull;
+    return ((net.partitioned.w >> (s_ * 8 + r_)) | (net.partitioned.w >> (r_ * 8 + s_))) & 1ull;
+#endif
   };
-  auto fk_alive = [&](uint32_t who) __attribute__((always_inline)) -> bool { return who >= DEMI_MAX_ACTORS || (((exists & ~net.inaccessible) >> who) & 1u); };
+  auto fk_alive = [&](uint32_t who) __attribute__((always_inline)) -> bool { return who >= MAX_ACT || (((exists & ~net.inaccessible) >> who) & 1u); };
   uint64_t tq = 0;
   uint32_t n_tq = 0;
   // K2_FP_WAVE: the look-ahead window (lane i: expected event win_base + i): class 0 network event / 1 actor's MsgSend (filter
@@ -227,7 +236,7 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
 // step of the walk then waits for two memory round trips (round 3: 240 bytes of scratch per lane, 2 500 cycles per event)
 #define IN_MASK(I) ((uint32_t)((((((I) >> 6) & 3u) == 0u ? m0 : 0ull) | ((((I) >> 6) & 3u) == 1u ? m1 : 0ull) | \
                                 ((((I) >> 6) & 3u) == 2u ? m2 : 0ull) | ((((I) >> 6) & 3u) == 3u ? m3 : 0ull)) >> ((I) & 63u)) & 1u)
-#define TIMER_BIT(RCV, TYPE) (1u << ((RCV) * DEMI_MAX_TIMER_TYPES + (t.meta[(TYPE)] >> 8)))
+#define TIMER_BIT(RCV, TYPE) ((tmask_t)1 << ((RCV) * DEMI_MAX_TIMER_TYPES + (t.meta[(TYPE)] >> 8)))
 // the message word of expected event E at index I, from SRC to DST (a wide table's payload area comes from exp_area)
 #ifdef DEMI_WIDE
 #define EXP_WORD(E, I, SRC, DST) msg_word_area((uint32_t)((E) >> 24) & 0xFF, (SRC), (DST), args.exp_area[(I)])
@@ -257,7 +266,7 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
   // STSScheduler.enqueue_timer = handle_timer: straight into messagesToSend (no parking)
   auto handle_timer = [&](uint32_t rcv, uint32_t type) __attribute__((always_inline)) {
     if (n_tq >= DEMI_TQ_CAP) { flags |= DEMI_V_QUEUE_OVF; return; }
-    tq |= (uint64_t)((rcv << 5) | type) << (8 * n_tq);
+    tq |= (uint64_t)tq_pack(rcv, type, BIG_TU ? (t.meta[type] >> 8) : 0u) << (8 * n_tq);
     n_tq++;
   };
 
@@ -299,11 +308,11 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
         skip = args.skip ? args.skip[sched] : 0xFFFFFFFFu;
         hash = 0xCBF29CE484222325ULL;
         app_rng = jr_seed(0);
-        net.inaccessible = exists; net.killed = 0; net.partitioned = 0;
+        net.inaccessible = exists; net.killed = 0; pairs_clear(net.partitioned);
         for (uint32_t a = 0; a < A * ST_WORDS; a++) st[a * 64] = t.init[a];
         if (FP && !WAVE) for (uint32_t f = 0; f < args.n_fp; f++) cnt[(size_t)f * cnt_stride] = 0;
         cur = 0; n_pend = 0; count = 0; ignored = 0; flags = 0; rep = 0; tq = 0; n_tq = 0; blocked = 0;
-        fk_part = 0; fk_pruned0 = 0; fk_pruned1 = 0;
+        pairs_clear(fk_part); fk_pruned0 = 0; fk_pruned1 = 0;
         cur_skip();
       }
       if (WAVE) {
@@ -370,14 +379,19 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
           bool in_trace = w_static;
           if (FK) {       // (the filter's state, broadcast where control flow is wave-uniform: FK is a kernel argument)
             const uint32_t inacc0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)net.inaccessible);
-            const uint64_t partn0 = bcast64(net.partitioned), part0 = bcast64(fk_part), pr0 = bcast64(fk_pruned0), pr1 = bcast64(fk_pruned1);
+            const uint64_t pr0 = bcast64(fk_pruned0), pr1 = bcast64(fk_pruned1);
             const uint32_t a_ = w_ab & 0xFF, b_ = (w_ab >> 8) & 0xFF, slot = w_ab >> 16;
             const bool sent = slot == 255u || !(((slot & 64u) ? pr1 : pr0) >> (slot & 63u) & 1ull);
-            const bool alive = b_ >= DEMI_MAX_ACTORS || (((exists & ~inacc0) >> b_) & 1u);
+            const bool alive = b_ >= MAX_ACT || (((exists & ~inacc0) >> b_) & 1u);
             bool cut = false;
+#ifdef DEMI_BIG     // (compiled, never launched: a big table is a wide table and replays with the scanning kernel)
+            cut = fk_cut(a_, b_);
+#else
+            const uint64_t partn0 = bcast64(net.partitioned.w), part0 = bcast64(fk_part.w);
             if (a_ < DEMI_MAX_ACTORS && b_ < DEMI_MAX_ACTORS)
               cut = FK == DEMI_FILTER_ABSENTS_LITERAL ? ((part0 >> (a_ * 8 + b_)) & 1ull)
                                                       : (((partn0 >> (a_ * 8 + b_)) | (partn0 >> (b_ * 8 + a_))) & 1ull);
+#endif
             in_trace = in_trace && alive && !cut && sent;
           }
           const bool is_ev = w_kind == 3u;
@@ -418,8 +432,8 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
               if (args.kept) args.kept[sched * NX + idx - 1] = 1;
               if (kind == DEMI_REC_SPAWN) { net.inaccessible &= ~(1u << a); net.killed &= ~(1u << a); blocked &= ~(1u << a); }
               else if (kind == DEMI_REC_KILL) { net.killed |= 1u << a; net.inaccessible |= 1u << a; }
-              else if (kind == DEMI_REC_PARTITION) { net.partitioned |= 1ULL << (a * 8 + b); fk_part &= ~(1ULL << (a * 8 + b)); }
-              else { net.partitioned &= ~(1ULL << (a * 8 + b)); fk_part |= 1ULL << (a * 8 + b); }
+              else if (kind == DEMI_REC_PARTITION) { pairs_put(net.partitioned, a, b, true); pairs_put(fk_part, a, b, false); }
+              else { pairs_put(net.partitioned, a, b, false); pairs_put(fk_part, a, b, true); }
             }
           }
           continue;
@@ -436,7 +450,7 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
         }
         if (kind == DEMI_REC_MSG_SEND) {
           if (active && IN_MASK(ext) && ((exists >> b) & 1)) {
-            PEND_APPEND_ID(EXP_WORD(e, idx - 1, DEMI_DEADLETTERS, b),
+            PEND_APPEND_ID(EXP_WORD(e, idx - 1, DL, b),
                            FP ? fp_cur : K2_FP_NONE);
             if (args.kept && !(flags & DEMI_OVF_ANY)) args.kept[sched * NX + idx - 1] = 1;
             if (flags & DEMI_OVF_ANY) active = false;
@@ -480,7 +494,7 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
           count++;
           hash_step(hash, w);
           const uint32_t meta = t.meta[type];
-          if (((meta & 0xFF) == DEMI_MSG_TIMER) && (rep & (1u << (me * DEMI_MAX_TIMER_TYPES + (meta >> 8)))))
+          if (((meta & 0xFF) == DEMI_MSG_TIMER) && (rep & ((tmask_t)1 << (me * DEMI_MAX_TIMER_TYPES + (meta >> 8)))))
             handle_timer(me, type);
           if (flags & DEMI_OVF_ANY) { deliver = false; active = false; }
         }
@@ -492,7 +506,7 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
           for (uint32_t k = 0; k < nfx && !(flags & DEMI_OVF_ANY); k++) {
             const word_t fxw = mem.fxq[k * 64];
             const uint32_t fx = (uint32_t)fxw;
-            const uint32_t op = fx & 31u, ftype = (fx >> 5) & 31u, target = (fx >> 10) & 15u;
+            const uint32_t op = fx & 31u, ftype = (fx >> 5) & 31u, target = fx_target(fx);
             if (op <= DEMI_OP_BCAST) {
               const bool bc = (op == DEMI_OP_BCAST);
               const uint32_t first = bc ? 0u : target, last = bc ? A : (target < A ? target + 1 : 0u);
@@ -504,7 +518,7 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
               blocked |= 1u << me;
             } else if (op == DEMI_OP_TCANCEL) {
               rep &= ~TIMER_BIT(me, ftype);
-              const uint32_t wantt = (me << 5) | ftype;
+              const uint32_t wantt = tq_pack(me, ftype, BIG_TU ? (t.meta[ftype] >> 8) : 0u);
               bool found = false;
               for (uint32_t q = 0; q < n_tq; q++) {
                 if (((uint32_t)(tq >> (8 * q)) & 0xFF) == wantt) {
@@ -514,7 +528,7 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
                 }
               }
               if (!found) {
-                const word_t wantw = msg_word(ftype, DEMI_DEADLETTERS, me, 0, 0);
+                const word_t wantw = msg_word(ftype, DL, me, 0, 0);
                 if (FP) {
                   const uint32_t f = fp_of((uint32_t)wantw);
                   if (cnt_get(f)) { cnt_add(f, false); n_pend--; }
@@ -528,7 +542,7 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
                 }
               }
             } else {
-              const uint32_t bit = TIMER_BIT(me, ftype);
+              const tmask_t bit = TIMER_BIT(me, ftype);
               if (!(rep & bit)) {
                 if (op == DEMI_OP_TREP) rep |= bit;
                 handle_timer(me, ftype);
@@ -536,8 +550,8 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
             }
           }
           for (uint32_t k = 0; k < n_tq && !(flags & DEMI_OVF_ANY); k++) {
-            const uint32_t bt = (uint32_t)(tq >> (8 * k)) & 0xFF, rcv = bt >> 5, ttype = bt & 31;
-            if (!((net.inaccessible >> rcv) & 1)) PEND_APPEND(msg_word(ttype, DEMI_DEADLETTERS, rcv, 0, 0));
+            const uint32_t bt = (uint32_t)(tq >> (8 * k)) & 0xFF, rcv = tq_rcv(bt), ttype = tq_type(bt);
+            if (!((net.inaccessible >> rcv) & 1)) PEND_APPEND(msg_word(ttype, DL, rcv, 0, 0));
           }
           tq = 0; n_tq = 0;
           if (flags & DEMI_OVF_ANY) active = false;
@@ -610,11 +624,11 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
         skip = args.skip ? args.skip[sched] : 0xFFFFFFFFu;
         hash = 0xCBF29CE484222325ULL;
         app_rng = jr_seed(0);
-        net.inaccessible = exists; net.killed = 0; net.partitioned = 0;
+        net.inaccessible = exists; net.killed = 0; pairs_clear(net.partitioned);
         for (uint32_t a = 0; a < A * ST_WORDS; a++) st[a * 64] = t.init[a];
         if (FP) for (uint32_t f = 0; f < args.n_fp; f++) cnt[(size_t)f * cnt_stride] = 0;
         idx = 0; cur = 0; n_pend = 0; count = 0; ignored = 0; flags = 0; rep = 0; tq = 0; n_tq = 0; blocked = 0;
-        fk_part = 0; fk_pruned0 = 0; fk_pruned1 = 0;
+        pairs_clear(fk_part); fk_pruned0 = 0; fk_pruned1 = 0;
         cur_skip();
       }
       // -------------------------------------------------------- advanceReplay (:405-559)
@@ -638,8 +652,8 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
           if (args.kept) args.kept[sched * NX + idx - 1] = 1;
           if (kind == DEMI_REC_SPAWN) { net.inaccessible &= ~(1u << a); net.killed &= ~(1u << a); blocked &= ~(1u << a); }
           else if (kind == DEMI_REC_KILL) { net.killed |= 1u << a; net.inaccessible |= 1u << a; }
-          else if (kind == DEMI_REC_PARTITION) { net.partitioned |= 1ULL << (a * 8 + b); fk_part &= ~(1ULL << (a * 8 + b)); }
-          else { net.partitioned &= ~(1ULL << (a * 8 + b)); fk_part |= 1ULL << (a * 8 + b); }
+          else if (kind == DEMI_REC_PARTITION) { pairs_put(net.partitioned, a, b, true); pairs_put(fk_part, a, b, false); }
+          else { pairs_put(net.partitioned, a, b, false); pairs_put(fk_part, a, b, true); }
         } else if (kind == DEMI_REC_MSG_SEND && ext == 255) {
           // an actor's MsgSend (only lowered for the filter): `if (messageSendable(snd, rcv)) result += event else
           // prunedMessageSends += id`; the slot is reused, so a sendable one clears the bit
@@ -651,7 +665,7 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
         } else if (kind == DEMI_REC_MSG_SEND) {
           // external MsgSend -> enqueue_message (:509-511) unless its Send was pruned
           if (IN_MASK(ext) && ((exists >> b) & 1)) {
-            PEND_APPEND_ID(EXP_WORD(e, idx - 1, DEMI_DEADLETTERS, b),
+            PEND_APPEND_ID(EXP_WORD(e, idx - 1, DL, b),
                            FP ? (uint32_t)exp_fp[idx - 1] : K2_FP_NONE);
             if (args.kept && !(flags & DEMI_OVF_ANY)) args.kept[sched * NX + idx - 1] = 1;
           }
@@ -690,7 +704,7 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
         // Instrumenter retrigger of a repeating timer (Instrumenter.scala:1008-1016)
         const uint32_t type = w_type(w), me = w_dst(w);
         const uint32_t meta = t.meta[type];
-        if (((meta & 0xFF) == DEMI_MSG_TIMER) && (rep & (1u << (me * DEMI_MAX_TIMER_TYPES + (meta >> 8)))))
+        if (((meta & 0xFF) == DEMI_MSG_TIMER) && (rep & ((tmask_t)1 << (me * DEMI_MAX_TIMER_TYPES + (meta >> 8)))))
           handle_timer(me, type);
         if (flags & DEMI_OVF_ANY) { deliver = false; finish = true; }
       }
@@ -704,7 +718,7 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
       for (uint32_t k = 0; k < nfx && !(flags & DEMI_OVF_ANY); k++) {
         const word_t fxw = mem.fxq[k * 64];
         const uint32_t fx = (uint32_t)fxw;
-        const uint32_t op = fx & 31u, type = (fx >> 5) & 31u, target = (fx >> 10) & 15u;
+        const uint32_t op = fx & 31u, type = (fx >> 5) & 31u, target = fx_target(fx);
         if (op <= DEMI_OP_BCAST) {
           const bool bc = (op == DEMI_OP_BCAST);
           const uint32_t first = bc ? 0u : target, last = bc ? A : (target < A ? target + 1 : 0u);
@@ -717,7 +731,7 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
         } else if (op == DEMI_OP_TCANCEL) {
           // notify_timer_cancel (:828-855): messagesToSend first, then the (deadLetters, rcv) queue
           rep &= ~TIMER_BIT(me, type);
-          const uint32_t want = (me << 5) | type;
+          const uint32_t want = tq_pack(me, type, BIG_TU ? (t.meta[type] >> 8) : 0u);
           bool found = false;
           for (uint32_t q = 0; q < n_tq; q++) {
             if (((uint32_t)(tq >> (8 * q)) & 0xFF) == want) {
@@ -727,7 +741,7 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
             }
           }
           if (!found) {
-            const word_t wantw = msg_word(type, DEMI_DEADLETTERS, me, 0, 0);
+            const word_t wantw = msg_word(type, DL, me, 0, 0);
             if (FP) {
               const uint32_t f = fp_of((uint32_t)wantw);         // every timer word has an id
               if (cnt_get(f)) { cnt_add(f, false); n_pend--; }
@@ -741,7 +755,7 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
             }
           }
         } else {
-          const uint32_t bit = TIMER_BIT(me, type);
+          const tmask_t bit = TIMER_BIT(me, type);
           if (!(rep & bit)) {
             if (op == DEMI_OP_TREP) rep |= bit;
             handle_timer(me, type);
@@ -751,8 +765,8 @@ __device__ __forceinline__ void k2_replay_body(const K2Args& args) {
       // schedule_new_message starts with send_external_messages (:655): timers become pending now,
       // unless the receiver is inaccessible (crosses_partition(deadLetters, rcv))
       for (uint32_t k = 0; k < n_tq && !(flags & DEMI_OVF_ANY); k++) {
-        const uint32_t bt = (uint32_t)(tq >> (8 * k)) & 0xFF, rcv = bt >> 5, type = bt & 31;
-        if (!((net.inaccessible >> rcv) & 1)) PEND_APPEND(msg_word(type, DEMI_DEADLETTERS, rcv, 0, 0));
+        const uint32_t bt = (uint32_t)(tq >> (8 * k)) & 0xFF, rcv = tq_rcv(bt), type = tq_type(bt);
+        if (!((net.inaccessible >> rcv) & 1)) PEND_APPEND(msg_word(type, DL, rcv, 0, 0));
       }
       tq = 0; n_tq = 0;
       if (flags & DEMI_OVF_ANY) finish = true;

@@ -90,10 +90,13 @@ struct K3SnapHdr {                   // 96 bytes; the actors' states and the pen
   unsigned long long hash, app_rng, parent_key;
   uint32_t magic, c, n_pend, flags, next_seq, count, deliveries, ext_idx, parent, parent_depth, cur_root, qperiod, next_qperiod,
       marker_ext, qmarker_ext, isolated, rep, blocked;
+#ifdef DEMI_BIG
+  uint32_t rep_hi, pad_big;          // (64 timer bits; the host sizes the records with k3_snap_stride(..., big))
+#endif
 };
 __host__ __device__ inline uint32_t k3_snap_pend_bytes(bool wide) { return wide ? 24u : 16u; }       // key 8, word 4 | 8, side word 4 (+ 4 pad)
-__host__ __device__ inline uint32_t k3_snap_stride(uint32_t n_actors, uint32_t st_words, uint32_t pend_cap, bool wide) {
-  return (uint32_t)((sizeof(K3SnapHdr) + 8u * n_actors * st_words + pend_cap * k3_snap_pend_bytes(wide) + 63u) & ~63u);
+__host__ __device__ inline uint32_t k3_snap_stride(uint32_t n_actors, uint32_t st_words, uint32_t pend_cap, bool wide, bool big = BIG_TU) {
+  return (uint32_t)(((big ? 104u : 96u) + 8u * n_actors * st_words + pend_cap * k3_snap_pend_bytes(wide) + 63u) & ~63u);
 }
 
 constexpr int K3_WAVES = 4;
@@ -106,8 +109,8 @@ constexpr size_t K3_ANALYSIS_BYTES = DEMI_DPOR_MAX_TRACE * 4 + DEMI_DPOR_MAX_TRA
 __host__ __device__ inline size_t k3_key_wave_bytes(uint32_t hot) { return (size_t)hot * 64 * 8; }
 // (waves: wavefronts per workgroup of the launch, at most K3_WAVES; the kernel reads it from blockDim)
 __host__ __device__ inline size_t k3_lds_bytes(uint32_t code_len, uint32_t n_ext, uint32_t n_hs, uint32_t n_actors, bool wide = WIDE_TU,
-                                               uint32_t hot = PEND_HOT, uint32_t waves = 4, uint32_t arr_words = ARR_WORDS) {
-  return tables_lds_bytes(code_len, n_ext, n_hs, wide, arr_words) +
+                                               uint32_t hot = PEND_HOT, uint32_t waves = 4, uint32_t arr_words = ARR_WORDS, bool big = BIG_TU) {
+  return tables_lds_bytes(code_len, n_ext, n_hs, wide, arr_words, big) +
          waves * (lane_mem_wave_bytes(n_actors, true, hot, wide, DEMI_FX_CAP, arr_words) + k3_key_wave_bytes(hot));
 }
 
@@ -123,14 +126,17 @@ __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v, uint32_t lane
 // dpor()'s pair loop (:1122-1139) for one finished trace T[0..n), executed by all 64 lanes of the wave.
 // Returns the number of racing pairs (wave-uniform) whose later event is at index >= shared; the first max_pairs of them
 // are written to `po` in the order of the sequential loop (later ascending, earlier ascending).
+// BIG (a template parameter here, not the translation unit's layout: k3_analyze is a generic kernel of the library): the trace
+// entries' words carry a 4-bit receiver field
+template <bool BIG>
 __device__ inline uint32_t k3_racing_pairs(const demi_dpor_trace_entry* __restrict__ T, uint32_t n, uint32_t* s_meta,
                                            uint64_t* s_anc, demi_dpor_pair* __restrict__ po, uint32_t max_pairs,
                                            uint32_t lane, uint32_t shared) {
-  constexpr uint32_t MSG = 1u << 19;
-  // meta word: parent | qperiod << 8 | receiver << 16 | (kind == message delivery) << 19
+  constexpr uint32_t MSG = BIG ? 1u << 20 : 1u << 19;
+  // meta word: parent | qperiod << 8 | receiver << 16 | (kind == message delivery) << 19 (BIG: << 20)
   for (uint32_t i = lane; i < n; i += 64) {
     const demi_dpor_trace_entry e = T[i];
-    s_meta[i] = (uint32_t)e.parent | ((uint32_t)e.qperiod << 8) | (w_dst(e.word) << 16) | (e.kind == 1 ? MSG : 0u);
+    s_meta[i] = (uint32_t)e.parent | ((uint32_t)e.qperiod << 8) | (((e.word >> 5) & (BIG ? 15u : 7u)) << 16) | (e.kind == 1 ? MSG : 0u);
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -160,7 +166,7 @@ __device__ inline uint32_t k3_racing_pairs(const demi_dpor_trace_entry* __restri
   // order) and walks only ITS set bits to compute the branch points (analyze_dep, :1043-1077: the highest common bit of two
   // ancestor sets) and write the pairs.  The loop over every (later group, earlier) with its dependent LDS read per step that
   // this replaces took 60-75 % of k3_dpor (tools/k3_phases.sh).
-  constexpr uint32_t CLS = 0xFFF00u;        // quiescent period | receiver | MSG
+  constexpr uint32_t CLS = BIG ? 0x1FFF00u : 0xFFF00u;        // quiescent period | receiver | MSG
   uint32_t mg[4];
 #pragma unroll
   for (uint32_t k = 0; k < 4; k++) mg[k] = (k * 64 + lane < n) ? s_meta[k * 64 + lane] : 0u;
@@ -241,7 +247,7 @@ __device__ inline uint32_t k3_racing_pairs(const demi_dpor_trace_entry* __restri
 __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   Tables t;
-  unsigned char* wave_base = tables_load(t, smem, args.model, args.ext, args.n_ext, (1u << args.model->n_actors) - 1);
+  unsigned char* wave_base = tables_load(t, smem, args.model, args.ext, args.n_ext, (1u << args.model->n_actors) - 1);     // (n_actors <= 16)
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const LaneMem mem = lane_mem_carve(wave_base + (size_t)wave * lane_mem_wave_bytes(t.A, true), t.A, true, lane,
                                      args.spill, (size_t)blockIdx.x * blockDim.x + threadIdx.x,
@@ -264,7 +270,8 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
   };
   uint32_t n_pend = 0, next_seq = 0, parent = 0, parent_depth = 0, cur_root = 0, qperiod = 0, next_qperiod = 0;
   uint64_t parent_key = DPOR_ROOT_KEY;       // key of trace[parent]: what the messages produced now descend from
-  uint32_t marker_ext = 0, qmarker_ext = 0, isolated = 0, rep = 0, flags = 0, count = 0, deliveries = 0;
+  uint32_t marker_ext = 0, qmarker_ext = 0, isolated = 0, flags = 0, count = 0, deliveries = 0;
+  tmask_t rep = 0;          // registered repeating timers (bit rcv * 4 + timer index)
   uint32_t blocked = 0;     // crashed actors (DEMI_OP_CRASH): skipped by getMatchingMessage (:478, 518) and getPendingEvent (:455)
   uint32_t n_trace = 0, ext_idx = 0;
   bool awaiting = false, marker_pending = false;
@@ -284,7 +291,7 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
 #define K3_MARK(I) do {} while (0)
 #endif
 #define K3_ABORT (DEMI_OVF_ANY | DEMI_V_TRACE_OVF | DEMI_V_SELFMSG)
-#define TIMER_BIT(RCV, TYPE) (1u << ((RCV) * DEMI_MAX_TIMER_TYPES + (t.meta[(TYPE)] >> 8)))
+#define TIMER_BIT(RCV, TYPE) ((tmask_t)1 << ((RCV) * DEMI_MAX_TIMER_TYPES + (t.meta[(TYPE)] >> 8)))
 
   // event_produced + getMessage: the node is a child of the current parentEvent; enqueued unless
   // the depth bound is hit (:832-838)
@@ -346,7 +353,7 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
       const uint32_t kind = (uint32_t)ev & 0xFF, a = (uint32_t)(ev >> 8) & 0xFF;
       if (kind == DEMI_EV_START) isolated &= ~(1u << a);
       else if (kind == DEMI_EV_SEND)
-        produce(msg_word((uint32_t)(ev >> 24) & 0xFF, DEMI_DEADLETTERS, a,
+        produce(msg_word((uint32_t)(ev >> 24) & 0xFF, DL, a,
                          ((uint32_t)(ev >> 32) & 0xFF) | (WIDE_TU ? ((uint32_t)(ev >> 48) & 0xFF) << 8 : 0u),
                          ((uint32_t)(ev >> 40) & 0xFF) | (WIDE_TU ? ((uint32_t)(ev >> 56) & 0xFF) << 8 : 0u)));
       else if (kind == DEMI_EV_WAIT_QUIESCENCE) { marker_pending = true; marker_ext = ext_idx; await = true; }
@@ -427,6 +434,9 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
           parent = h.parent; parent_depth = h.parent_depth; cur_root = h.cur_root; qperiod = h.qperiod; next_qperiod = h.next_qperiod;
           marker_ext = h.marker_ext & 0xFFFFu; marker_pending = (h.marker_ext >> 16) != 0; qmarker_ext = h.qmarker_ext;
           isolated = h.isolated; rep = h.rep; blocked = h.blocked;
+#ifdef DEMI_BIG
+          rep |= (tmask_t)h.rep_hi << 32;
+#endif
           awaiting = false;
           const unsigned long long* sw = reinterpret_cast<const unsigned long long*>(rec + sizeof(K3SnapHdr));
           for (uint32_t a = 0; a < A * ST_WORDS; a++) st[a * 64] = sw[a];
@@ -469,7 +479,10 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
           h.magic = K3_SNAP_MAGIC; h.c = n_trace; h.n_pend = n_pend; h.flags = flags; h.next_seq = next_seq; h.count = count;
           h.deliveries = deliveries; h.ext_idx = ext_idx; h.parent = parent; h.parent_depth = parent_depth; h.cur_root = cur_root;
           h.qperiod = qperiod; h.next_qperiod = next_qperiod; h.marker_ext = marker_ext | (marker_pending ? 1u << 16 : 0u);
-          h.qmarker_ext = qmarker_ext; h.isolated = isolated; h.rep = rep; h.blocked = blocked;
+          h.qmarker_ext = qmarker_ext; h.isolated = isolated; h.rep = (uint32_t)rep; h.blocked = blocked;
+#ifdef DEMI_BIG
+          h.rep_hi = (uint32_t)(rep >> 32); h.pad_big = 0;
+#endif
           *reinterpret_cast<K3SnapHdr*>(rec) = h;
           unsigned long long* sw = reinterpret_cast<unsigned long long*>(rec + sizeof(K3SnapHdr));
           for (uint32_t a = 0; a < A * ST_WORDS; a++) sw[a] = st[a * 64];
@@ -585,7 +598,7 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
           }
           pend_remove_at((uint32_t)chosen);
           const uint32_t snd = w_src(pw), rcv = w_dst(pw);
-          if ((snd < DEMI_MAX_ACTORS && ((isolated >> snd) & 1)) || ((isolated >> rcv) & 1)) {
+          if ((snd < MAX_ACT && ((isolated >> snd) & 1)) || ((isolated >> rcv) & 1)) {
             if (snd == rcv) { flags |= DEMI_V_SELFMSG; finish = true; }   // (:631-633)
             // else: discarded, schedule again (:626-635)
             asym = true;                        // (a step without a trace entry: no records of this interleaving from here on)
@@ -599,8 +612,8 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
               deliveries++;
               hash_step(hash, w);
               const uint32_t type = w_type(w), meta = t.meta[type];
-              if (((meta & 0xFF) == DEMI_MSG_TIMER) && (rep & (1u << (rcv * DEMI_MAX_TIMER_TYPES + (meta >> 8)))))
-                produce(msg_word(type, DEMI_DEADLETTERS, rcv, 0, 0));   // retrigger: enqueue_timer = `!`
+              if (((meta & 0xFF) == DEMI_MSG_TIMER) && (rep & ((tmask_t)1 << (rcv * DEMI_MAX_TIMER_TYPES + (meta >> 8)))))
+                produce(msg_word(type, DL, rcv, 0, 0));   // retrigger: enqueue_timer = `!`
             }
           }
         } else {
@@ -630,7 +643,7 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
       for (uint32_t k = 0; k < nfx && !(flags & DEMI_OVF_ANY); k++) {
         const word_t fxw = mem.fxq[k * 64];
         const uint32_t fx = (uint32_t)fxw;
-        const uint32_t op = fx & 31u, type = (fx >> 5) & 31u, target = (fx >> 10) & 15u;
+        const uint32_t op = fx & 31u, type = (fx >> 5) & 31u, target = fx_target(fx);
         if (op <= DEMI_OP_BCAST) {
           const bool bc = (op == DEMI_OP_BCAST);
           const uint32_t first = bc ? 0u : target, last = bc ? A : (target < A ? target + 1 : 0u);
@@ -643,7 +656,7 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
         } else if (op == DEMI_OP_TCANCEL) {
           // notify_timer_cancel (:961-984): first of the (deadLetters, rcv) queue with this message
           rep &= ~TIMER_BIT(me, type);
-          const word_t wantw = msg_word(type, DEMI_DEADLETTERS, me, 0, 0);
+          const word_t wantw = msg_word(type, DL, me, 0, 0);
           int best = -1;
           uint32_t best_seq = 0xFFFFFFFFu;
           // (which slots hold the word: one unrolled pass over the LDS-resident slots, as in getMatchingMessage; the side words
@@ -673,10 +686,10 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
           }
           if (best >= 0) pend_remove_at((uint32_t)best);
         } else {
-          const uint32_t bit = TIMER_BIT(me, type);
+          const tmask_t bit = TIMER_BIT(me, type);
           if (!(rep & bit)) {
             if (op == DEMI_OP_TREP) rep |= bit;
-            produce(msg_word(type, DEMI_DEADLETTERS, me, 0, 0));
+            produce(msg_word(type, DL, me, 0, 0));
           }
         }
       }
@@ -731,7 +744,8 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
 // 16 384-interleaving round is sixteen waves per SIMD: the analysis' dependent LDS reads hide behind one another instead of
 // holding up a wave's simulators).  Writes pairs[s][..] and n_pairs[s], and DEMI_V_PAIRS_OVF into the verdict.
 constexpr int K3A_WAVES = 4;
-__global__ __launch_bounds__(K3A_WAVES * 64) void k3_analyze(const K3Args args) {
+template <bool BIG>
+__device__ __forceinline__ void k3_analyze_body(const K3Args& args) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint64_t s = (uint64_t)blockIdx.x * K3A_WAVES + wave;
@@ -743,13 +757,15 @@ __global__ __launch_bounds__(K3A_WAVES * 64) void k3_analyze(const K3Args args) 
   if ((fl & K3_ABORT) || n == 0) return;                   // (aborted: k3_dpor left n_pairs = 0)
   const uint32_t shared = args.shared_len ? args.shared_len[s]
                           : (args.items && args.items[s].src != 0xFFFFFFFFu) ? (uint32_t)args.items[s].branch + 1u : 0u;
-  const uint32_t total = k3_racing_pairs(args.traces + s * DEMI_DPOR_MAX_TRACE, n, s_meta, s_anc, args.pairs + s * (uint64_t)args.max_pairs,
+  const uint32_t total = k3_racing_pairs<BIG>(args.traces + s * DEMI_DPOR_MAX_TRACE, n, s_meta, s_anc, args.pairs + s * (uint64_t)args.max_pairs,
                                          args.max_pairs, lane, shared);
   if (lane == 0) {
     args.n_pairs[s] = total < args.max_pairs ? total : args.max_pairs;
     if (total > args.max_pairs) args.out[s].flags = fl | DEMI_V_PAIRS_OVF;
   }
 }
+__global__ __launch_bounds__(K3A_WAVES * 64) void k3_analyze(const K3Args args) { k3_analyze_body<false>(args); }
+__global__ __launch_bounds__(K3A_WAVES * 64) void k3_analyze_big(const K3Args args) { k3_analyze_body<true>(args); }      // traces of a table with more than 8 actors
 #endif
 #undef K3_ABORT
 

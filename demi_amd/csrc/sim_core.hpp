@@ -83,15 +83,16 @@ struct Tables {
   const uint32_t* magic;  // [129] nextInt multiply-high magics of the scheduler's bounds (<= p_max <= 128), in LDS
   const uint32_t* gmagic; // [257] the whole table in the model blob (global memory): DEMI_OP_RND's bounds go up to 255 and are rare
   const uint32_t* optab;  // [64] per-op control words (op_control)
-  uint32_t A, NT, code_len, E, exists, ac_packed;
+  uint32_t A, NT, code_len, E, exists;
+  acpack_t ac_packed;                    // actor classes, 4 bits per actor
   uint32_t inv_kind, inv_fa, inv_va, inv_fb, fp_mask;
   uint32_t n_timer_types, timer_types;   // TIMER-class message types: how many, and which (bit t)
   uint64_t tix_packed;                   // their timer indices, two bits per message type
 };
 
 __host__ __device__ inline size_t tables_lds_bytes(uint32_t code_len, uint32_t n_ev, uint32_t n_hs, bool wide = WIDE_TU,
-                                                   uint32_t arr_words = ARR_WORDS) {
-  size_t b = (size_t)n_ev * 8 + DEMI_MAX_ACTORS * 8 * ((wide ? 2 : 1) + arr_words) + (size_t)code_len * 4 + (size_t)n_hs * 4 +
+                                                   uint32_t arr_words = ARR_WORDS, bool big = BIG_TU) {
+  size_t b = (size_t)n_ev * 8 + max_act_of(big) * 8 * ((wide ? 2 : 1) + arr_words) + (size_t)code_len * 4 + (size_t)n_hs * 4 +
              DEMI_MAX_MSG_TYPES * 4 + 132 * 4 + 64 * 4;
   return (b + 15) & ~(size_t)15;
 }
@@ -107,17 +108,19 @@ __device__ inline unsigned char* tables_load(Tables& t, unsigned char* smem, con
   const uint32_t n_hs = gm->n_classes * t.NT;
   uint64_t* s_trace = reinterpret_cast<uint64_t*>(smem);
   uint64_t* s_init = s_trace + n_ev;
-  uint32_t* s_code = reinterpret_cast<uint32_t*>(s_init + DEMI_MAX_ACTORS * ST_WORDS);
+  uint32_t* s_code = reinterpret_cast<uint32_t*>(s_init + MAX_ACT * ST_WORDS);
   uint32_t* s_hs = s_code + t.code_len;
   uint32_t* s_meta = s_hs + n_hs;
   uint32_t* s_magic = s_meta + DEMI_MAX_MSG_TYPES;
   uint32_t* s_optab = s_magic + 132;
   for (uint32_t i = threadIdx.x; i < n_ev; i += blockDim.x) s_trace[i] = g_trace[i];
-  for (uint32_t i = threadIdx.x; i < DEMI_MAX_ACTORS * ST_WORDS; i += blockDim.x) {
-    if (ARR_WORDS == 0) s_init[i] = WIDE_TU ? gm->init_state_wide[i] : gm->init_state[i];
+  // (a big table's fields and actor classes come from the arrays appended to the model blob)
+  const uint64_t* const g_init_wide = BIG_TU ? gm->init_state_big : gm->init_state_wide;
+  for (uint32_t i = threadIdx.x; i < MAX_ACT * ST_WORDS; i += blockDim.x) {
+    if (ARR_WORDS == 0) s_init[i] = WIDE_TU ? g_init_wide[i] : gm->init_state[i];
     else {                                   // (the fields from the model, the arrays empty)
       const uint32_t a = i / ST_WORDS, k = i % ST_WORDS;
-      s_init[i] = k >= FLD_WORDS ? 0ull : WIDE_TU ? gm->init_state_wide[a * FLD_WORDS + k] : gm->init_state[a];
+      s_init[i] = k >= FLD_WORDS ? 0ull : WIDE_TU ? g_init_wide[a * FLD_WORDS + k] : gm->init_state[a];
     }
   }
   for (uint32_t i = threadIdx.x; i < t.code_len; i += blockDim.x) s_code[i] = gm->code[i];
@@ -126,10 +129,10 @@ __device__ inline unsigned char* tables_load(Tables& t, unsigned char* smem, con
   for (uint32_t i = threadIdx.x; i < 129; i += blockDim.x) s_magic[i] = gm->divmagic[i];
   for (uint32_t i = threadIdx.x; i < 64; i += blockDim.x) s_optab[i] = gm->optab[i];
   t.ac_packed = 0;
-  for (uint32_t a = 0; a < t.A; a++) t.ac_packed |= gm->actor_class[a] << (4 * a);
+  for (uint32_t a = 0; a < t.A; a++) t.ac_packed |= (acpack_t)(BIG_TU ? gm->actor_class_big[a] : gm->actor_class[a]) << (4 * a);
   t.trace = s_trace; t.init = s_init; t.code = s_code; t.hs = s_hs; t.meta = s_meta; t.magic = s_magic; t.gmagic = gm->divmagic; t.optab = s_optab;
   __syncthreads();
-  return smem + tables_lds_bytes(t.code_len, n_ev, n_hs);
+  return smem + tables_lds_bytes(t.code_len, n_ev, n_hs);     // (this translation unit's layout: the defaults)
 }
 
 // ------------------------------------------------------------------ per-lane arrays
@@ -230,15 +233,17 @@ __device__ __forceinline__ void aux_store(const LaneMem& m, uint32_t slot, uint3
 // ------------------------------------------------------------------ row interpreter
 // effect word recorded per effect row: op[4:0] | type[9:5] | target[13:10] | p0[21:14] | p1[29:22]
 // wide: op[4:0] | type[9:5] | target[13:10] | payload area[61:14] (demi_device.hpp pay_area: p0[29:14] | p1[45:30] for the two
-// fields of a plain wide table)
+// fields of a plain wide table); BIG: target[14:10] (FX_NOBODY = 31) | payload area[62:15]
+constexpr uint32_t FX_NOBODY = BIG_TU ? 31u : 15u, FX_AREA_SHIFT = BIG_TU ? 15u : 14u;
+__device__ __forceinline__ uint32_t fx_target(uint32_t fx_low) { return (fx_low >> 10) & FX_NOBODY; }
 #ifdef DEMI_WIDE
 __device__ __forceinline__ word_t fx_pack_area(uint32_t op, uint32_t type, uint32_t target, uint64_t area) {
-  return (word_t)((op & 31u) | (type << 5) | (target << 10)) | ((word_t)area << 14);
+  return (word_t)((op & 31u) | (type << 5) | (target << 10)) | ((word_t)area << FX_AREA_SHIFT);
 }
 __device__ __forceinline__ word_t fx_pack(uint32_t op, uint32_t type, uint32_t target, uint32_t p0, uint32_t p1) {
   return fx_pack_area(op, type, target, pay_area(p0, p1));
 }
-__device__ __forceinline__ uint64_t fx_area(word_t fx) { return (fx >> 14) & 0xFFFFFFFFFFFFull; }
+__device__ __forceinline__ uint64_t fx_area(word_t fx) { return (fx >> FX_AREA_SHIFT) & 0xFFFFFFFFFFFFull; }
 // the message an effect word sends: type / payload from the word, sender and receiver from the caller
 __device__ __forceinline__ word_t fx_msg_word(word_t fx, uint32_t type, uint32_t src, uint32_t dst) {
   return msg_word_area(type, src, dst, fx_area(fx));
@@ -445,12 +450,14 @@ __device__ __forceinline__ uint32_t invariant_hit_at(const Tables& t, const uint
 __device__ inline uint32_t invariant_from_hits(const Tables& t, const uint64_t* st, uint32_t vmask, uint32_t A, uint32_t kind, uint32_t fb) {
   vmask &= (1u << A) - 1u;   // (a specialised build knows A: the pair logic below then only exists for real actors)
   const uint32_t comb = kind & 0xFFu;
-  if (comb == DEMI_INV_NEVER) return vmask ? ((2u << 24) | vmask) : 0u;
+  // fingerprints: kind << 24 | key << 8 | actors; BIG: kind << 30 | (key & 0x3FFF) << 16 | actors (include/demi_gpu.h)
+  constexpr uint32_t FPK = BIG_TU ? 30u : 24u;
+  if (comb == DEMI_INV_NEVER) return vmask ? ((2u << FPK) | vmask) : 0u;
   if (comb == DEMI_INV_NONE || (vmask & (vmask - 1)) == 0) return 0u;   // needs at least two hits
   // slow path: group keys of the hit actors
-  uint32_t key[DEMI_MAX_ACTORS];
+  uint32_t key[MAX_ACT];
 #pragma unroll
-  for (uint32_t i = 0; i < DEMI_MAX_ACTORS; i++) {
+  for (uint32_t i = 0; i < MAX_ACT; i++) {
     key[i] = 0u;
     if (i < A) {
       if (kind & DEMI_INV_PROGRAM) { if ((vmask >> i) & 1u) (void)inv_prog(t, st, i, key[i]); }
@@ -461,30 +468,30 @@ __device__ inline uint32_t invariant_from_hits(const Tables& t, const uint64_t* 
     bool have = false, bad = false;
     uint32_t first = 0;
 #pragma unroll
-    for (uint32_t i = 0; i < DEMI_MAX_ACTORS; i++) {
+    for (uint32_t i = 0; i < MAX_ACT; i++) {
       if ((vmask >> i) & 1) {
         if (!have) { have = true; first = key[i]; }
         else if (key[i] != first) bad = true;
       }
     }
-    return bad ? ((3u << 24) | vmask) : 0u;
+    return bad ? ((3u << FPK) | vmask) : 0u;
   }
   // AT_MOST_ONE: lowest (i, j) pair of hits with equal keys
   bool found = false;
   uint32_t k = 0;
 #pragma unroll
-  for (uint32_t i = 0; i < DEMI_MAX_ACTORS; i++) {
+  for (uint32_t i = 0; i < MAX_ACT; i++) {
 #pragma unroll
-    for (uint32_t j = i + 1; j < DEMI_MAX_ACTORS; j++) {
+    for (uint32_t j = i + 1; j < MAX_ACT; j++) {
       if (!found && ((vmask >> i) & 1) && ((vmask >> j) & 1) && key[i] == key[j]) { found = true; k = key[i]; }
     }
   }
   if (!found) return 0u;
   uint32_t mask = 0;
 #pragma unroll
-  for (uint32_t i = 0; i < DEMI_MAX_ACTORS; i++)
+  for (uint32_t i = 0; i < MAX_ACT; i++)
     if (((vmask >> i) & 1) && key[i] == k) mask |= 1u << i;
-  return (1u << 24) | (k << 8) | mask;
+  return BIG_TU ? (1u << 30) | ((k & 0x3FFFu) << 16) | mask : (1u << 24) | (k << 8) | mask;
 }
 
 __device__ inline uint32_t invariant_code(const Tables& t, const uint64_t* st, uint32_t exists,

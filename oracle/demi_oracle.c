@@ -633,7 +633,7 @@ static void cancel_timer(exec_t* x, uint32_t rcv, uint32_t type) {
   }
   for (uint32_t i = 0; i < x->n_pend; i++) {
     uint64_t w = x->pend[i].word;
-    if (W_SRC(w) == DEMI_DEADLETTERS && W_DST(w) == rcv && W_TYPE(w) == type && (w >> 16) == 0) {
+    if (W_SRC(w) == ORC_DL && W_DST(w) == rcv && W_TYPE(w) == type && (w >> 16) == 0) {
       pend_remove_at(x, i);
       return;
     }
