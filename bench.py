@@ -277,6 +277,82 @@ def bench_config1(ctx_device, cpu_baseline=True):
     return out
 
 
+def bench_big_tables(ctx_device, cpu_baseline=True, n=1 << 20):
+    """Tables of MORE THAN 8 ACTORS (the BIG layout of include/demi_gpu.h; round 6): config 2's step - 2^20 RandomScheduler executions,
+    verdicts resident in HBM, one launch at a time on the null stream - on the 11-node raft cluster (apps.raft11_config2) and the
+    12-actor shuffle job (apps.shuffle12_config5), and the 12-actor job's DPOR exploration to exhaustion in ROUNDS order.  Each is
+    checked against the oracle (a 2^14 prefix of the step; the whole exploration) and timed beside it on every host thread."""
+    import hashlib
+    import numpy as np
+    import torch
+    from demi_amd import _native, types as T
+    from demi_amd.apps import SEED_BASE, raft11_config2, shuffle12_config5
+    out = {"metric": "candidate schedules evaluated/sec, tables of more than 8 actors (BIG layout)", "unit": "schedules/s", "workloads": {}}
+    m2, dev, fev, lim2, par = shuffle12_config5()
+    threads = os.cpu_count() or 1
+    for name, (model, events, lim) in (("raft11", raft11_config2()), ("shuffle12", (m2, fev, lim2))):
+        ctx = _native.Context(ctx_device)
+        ctx.model_load(model.to_struct())
+        ctx.trace_load(events)
+        ctx.model_specialize()
+        vbuf = torch.empty(n * 16, dtype=torch.uint8, device="cuda:%d" % ctx_device)
+        ctx.random_explore_dev(n, lim, vbuf.data_ptr(), seed_base=SEED_BASE)
+        torch.cuda.synchronize()
+        steps = 5
+        t = time.perf_counter()
+        for i in range(steps):
+            ctx.random_explore_dev(n, lim, vbuf.data_ptr(), seed_base=SEED_BASE + (i + 1) * n)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t) / steps
+        ctx.random_explore_dev(n, lim, vbuf.data_ptr(), seed_base=SEED_BASE)
+        torch.cuda.synchronize()
+        got = vbuf.cpu().numpy().view(T.VERDICT_DTYPE).reshape(-1)
+        ctx.close()
+        rec = {"value": n / dt, "unit": "schedules/s", "ms_per_step": dt * 1e3, "schedules_per_step": n, "n_actors": model.n_actors,
+               "model": model.name, "violations": int(np.count_nonzero(got["flags"] & T.V_VIOLATION)),
+               "capacity_aborts": int(np.count_nonzero(got["flags"] & (T.V_PENDING_OVF | T.V_QUEUE_OVF))),
+               "mean_deliveries": float((got["flags"] >> 16).mean()),
+               "roofline": roofline(16.0 * n, dt * 1e3, None, "k1_random_explore<false,false> compiled for the table (BIG layout, wide)",
+                                    "16 B verdict per schedule; the launch's wall time (one launch at a time)")}
+        if cpu_baseline:
+            from oracle import oracle_py as O
+            k = 1 << 14
+            t = time.perf_counter()
+            cpu = O.random_explore(model, events, k, seed_base=SEED_BASE, limits=lim, n_threads=threads)
+            dc = time.perf_counter() - t
+            rec["cpu_baseline"] = {"value": k / dc, "unit": "schedules/s", "cores": threads, "kind": "port",
+                                   "sample": "the first 2^14 schedules of the step, oracle/demi_oracle.c on every host thread",
+                                   "bit_identical_to_gpu": bool((cpu == got[:k]).all())}
+        out["workloads"][name] = rec
+    # the 12-actor job's DPOR exploration, exhausted (33 529 interleavings, 1 836 violating: tests/golden/big_tables.json)
+    ctx = _native.Context(ctx_device)
+    ctx.model_load(m2.to_struct())
+    ctx.model_specialize()
+    ctx.dpor_load(dev)
+    srch = T.DporSearch(4096, 1 << 17, 0, 1, T.DPOR_ORDER_ROUNDS)
+    ctx.dpor_explore(par, srch)
+    t = time.perf_counter()
+    g = ctx.dpor_explore(par, srch)
+    dd = time.perf_counter() - t
+    ctx.close()
+    drec = {"value": len(g[0]) / dd, "unit": "interleavings/s", "seconds": dd, "interleavings": int(len(g[0])), "violations": int(g[4].violations),
+            "exhausted": bool(g[4].exhausted), "order": "rounds (batch 4096)", "sha256_verdicts": hashlib.sha256(np.ascontiguousarray(g[0]).tobytes()).hexdigest(),
+            "kernel_ms_total": float(g[4].kernel_ms)}
+    if cpu_baseline:
+        from oracle import oracle_py as O
+        t = time.perf_counter()
+        c = O.dpor_explore(m2, dev, par, srch, threads)
+        dc = time.perf_counter() - t
+        drec["cpu_baseline"] = {"value": len(c[0]) / dc, "unit": "interleavings/s", "cores": threads, "kind": "port",
+                                "sample": "the whole exploration, the product's host bookkeeping around the oracle's interleavings",
+                                "bit_identical_to_gpu": bool(len(c[0]) == len(g[0]) and (c[0] == g[0]).all())}
+    out["workloads"]["shuffle12_dpor"] = drec
+    out["value"] = out["workloads"]["raft11"]["value"]
+    out["config"] = {"workload": "raft11-synth (11 actors, 50-event fuzz trace), shuffle12-synth (12 actors), 2^20 schedules per step; "
+                                 "shuffle12 DPOR exhausted"}
+    return out
+
+
 def issue_model(ctx, name, kernel_ms, same_run):
     """The integer-issue model of a secondary record, as the fuzz line has it for K1: the committed instruction counters of this
     workload (tools/profile_r6_k2k3.sh -> profiles/<tag>_<name>_insts.json: wave-instructions per launch / per exploration) priced
@@ -880,7 +956,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", choices=["fuzz", "dpor", "ddmin", "config1", "config5"], default="fuzz")
+    ap.add_argument("--workload", choices=["fuzz", "dpor", "ddmin", "config1", "config5", "big"], default="fuzz")
     ap.add_argument("--dpor-order", choices=["both", "rounds", "reference_order"], default="both",
                     help="--workload dpor / config5: which exploration order(s) to run (profiling passes use one; config5 always runs ROUNDS)")
     ap.add_argument("--schedules", type=int, default=N_PER_GPU, help="schedules per GPU per step")
@@ -996,7 +1072,7 @@ def main():
         elif args.workload == "ddmin" and world > 1:
             rec = bench_ddmin_ranks(local_rank, ranks)
         else:
-            rec = {"ddmin": bench_ddmin, "config1": bench_config1}[args.workload](local_rank, cpu_baseline=not args.no_cpu_baseline)
+            rec = {"ddmin": bench_ddmin, "config1": bench_config1, "big": bench_big_tables}[args.workload](local_rank, cpu_baseline=not args.no_cpu_baseline)
         rec.update({"n_gpus": world, "steps": 1, "warmup": 1, "ms_per_step": (time.perf_counter() - t) * 1e3, "higher_is_better": True,
                     "scaling": "strong" if args.workload == "config5" else "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic"})
         if rank == 0:
@@ -1355,7 +1431,7 @@ def main():
     if not args.no_secondary:
         sec = {}
         if world == 1:
-            for name, fn in (("config1", bench_config1), ("dpor", bench_dpor), ("ddmin", bench_ddmin),
+            for name, fn in (("config1", bench_config1), ("dpor", bench_dpor), ("ddmin", bench_ddmin), ("more_than_8_actors", bench_big_tables),
                              ("config5", lambda d, cpu_baseline: bench_config5(d, cpu_baseline=cpu_baseline, max_interleavings=args.config5_budget))):
                 try:
                     sec[name] = fn(local_rank, cpu_baseline=not args.no_cpu_baseline)

@@ -1,0 +1,214 @@
+"""GPU parity suite for tables of MORE THAN 8 ACTORS - the BIG layout of include/demi_gpu.h (9 .. 16 actors: 4-bit receiver and
+5-bit sender fields in the message word, deadLetters = 31, 16-bit actor masks in the fingerprints, 16 x 16 partition / reach
+matrices, 64 timer bits; a wide, compiled table).  The reference puts no bound on actor names (ExternalEvents.scala:62-91,
+EventOrchestrator.scala:203-217, 345-351); rounds 1-5 stopped at 8.  Every kernel through the C ABI against the oracle, whose
+own BIG layout is pinned by the literal transliterations of the Scala schedulers (tests/test_random_scheduler_transliteration_cpu.py
+::test_tables_of_more_than_eight_actors..., tests/test_dpor_scheduler_transliteration_cpu.py cases shuffle12 / raft11) and by
+tests/golden/big_tables.json.  Workloads: apps.raft11_config2 (11 raft nodes, fuzz trace with kills and partitions),
+apps.shuffle12_config5 (driver, two coordinators, nine workers)."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from demi_amd import _native, types as T
+from demi_amd import model as M
+from demi_amd.apps import SEED_BASE, raft11_config2, raft11_dpor, shuffle12_config5
+
+pytestmark = pytest.mark.gpu
+
+EMU = os.environ.get("DEMI_EMU") == "1"
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "big_tables.json")
+
+
+def _fuzz_workloads():
+    m, ev, lim = raft11_config2()
+    yield "raft11", m, ev, lim
+    m, _dev, fev, lim, _par = shuffle12_config5()
+    yield "shuffle12", m, fev, lim
+
+
+def _ctx(model, events=None):
+    ctx = _native.Context(0)
+    ctx.model_load(model.to_struct())
+    if events is not None:
+        ctx.trace_load(events)
+    ctx.model_specialize()
+    assert ctx.is_specialized()
+    return ctx
+
+
+def _limits(lim, **kw):
+    l = T.Limits(lim.max_messages, lim.invariant_check_interval, lim.p_max, 0, 0, 0)
+    for k, v in kw.items():
+        setattr(l, k, v)
+    return l
+
+
+def test_random_scheduler_on_tables_of_more_than_eight_actors(oracle):
+    """K1, FullyRandom: every verdict field of n schedules = the oracle's; the golden record's prefix; the violating executions
+    carry the BIG fingerprint layout (kind << 30 | key << 16 | 16-bit actor mask)."""
+    with open(GOLDEN) as f:
+        gold = json.load(f)
+    n = 1024 if EMU else 1 << 16
+    for name, m, ev, lim in _fuzz_workloads():
+        ctx = _ctx(m, ev)
+        try:
+            g = ctx.random_explore(n, lim, seed_base=SEED_BASE)
+            c = oracle.random_explore(m, ev, n, seed_base=SEED_BASE, limits=lim, n_threads=os.cpu_count())
+            assert (g == c).all(), name
+            viol = g[(g["flags"] & T.V_VIOLATION) != 0]
+            assert len(viol) >= (1 if EMU else 100) and not (g["flags"] & (T.V_PENDING_OVF | T.V_QUEUE_OVF)).any()
+            assert ((viol["fingerprint"] >> 30) == gold[name]["fingerprint_kind"]).all()
+            k = gold[name]["fuzz_prefix"]
+            if n >= k:
+                assert hashlib.sha256(np.ascontiguousarray(g[:k]).tobytes()).hexdigest() == gold[name]["sha256_fuzz_verdicts"]
+        finally:
+            ctx.close()
+
+
+def test_recording_fifo_and_carried_variants(oracle):
+    """The other K1 variants a wide table gets compiled: the recording kernel (every recorded event incl. deadLetters = 31 as the
+    sender of externals and timers), SrcDstFIFO (16 x 16 pairs: srcDsts scanned instead of a 64-bit pair mask) and the
+    carried-generator mode."""
+    n = 256 if EMU else 8192
+    for name, m, ev, lim in _fuzz_workloads():
+        ctx = _ctx(m, ev)
+        try:
+            for seed in (0, 1, 5, 17):
+                v, rec = ctx.random_get_trace(SEED_BASE + seed, lim)
+                ov, orec, _st = oracle.random_execute(m, ev, SEED_BASE + seed, lim)
+                assert (v.flags, v.fingerprint, v.hash) == (ov.flags, ov.fingerprint, ov.hash) and len(rec) == len(orec) and (rec == orec).all()
+                snd = rec["snd"][(rec["kind"] == T.REC_MSG_EVENT)]
+                assert int(snd.max()) == T.DEADLETTERS_BIG and ((snd < m.n_actors) | (snd == T.DEADLETTERS_BIG)).all()
+            lf = _limits(lim, strategy=1)
+            g = ctx.random_explore(n, lf, seed_base=SEED_BASE)
+            c = oracle.random_explore(m, ev, n, seed_base=SEED_BASE, limits=lf, n_threads=os.cpu_count())
+            assert (g == c).all(), name + " SrcDstFIFO"
+            v, rec = ctx.random_get_trace(SEED_BASE + 3, lf)
+            ov, orec, _st = oracle.random_execute(m, ev, SEED_BASE + 3, lf)
+            assert (v.flags, v.hash) == (ov.flags, ov.hash) and len(rec) == len(orec) and (rec == orec).all()
+            lc = _limits(lim, executions_per_instance=4)
+            g = ctx.random_explore(n, lc, seed_base=SEED_BASE)
+            c = oracle.random_explore(m, ev, n, seed_base=SEED_BASE, limits=lc, n_threads=os.cpu_count())
+            assert (g == c).all(), name + " carried generators"
+        finally:
+            ctx.close()
+
+
+def test_replay_and_ddmin(oracle):
+    """K2 (the scanning kernel a wide table replays with): candidates of a violating execution's externals under the three
+    filterKnownAbsents settings, then demi_ddmin end to end against the same loop around the oracle."""
+    rng = np.random.default_rng(7)
+    n = 300 if EMU else 20000
+    for name, m, ev, lim in _fuzz_workloads():
+        ctx = _ctx(m, ev)
+        try:
+            l0 = _limits(lim, invariant_check_interval=0)
+            v = oracle.random_explore(m, ev, 4000, seed_base=SEED_BASE, limits=l0, n_threads=os.cpu_count())
+            idx = int(np.nonzero((v["flags"] & T.V_VIOLATION) != 0)[0][0])
+            vd, rec = ctx.random_get_trace(SEED_BASE + idx, l0)
+            assert vd.flags & T.V_VIOLATION
+            lr = _limits(l0, looking_for_valid=1, looking_for=int(vd.fingerprint))
+            masks = rng.integers(0, 2**63, size=(n, 4), dtype=np.uint64) | (rng.integers(0, 2, size=(n, 4), dtype=np.uint64) << np.uint64(63))
+            masks[0] = 0xFFFFFFFFFFFFFFFF
+            masks[1:n // 4] |= rng.integers(0, 2**63, size=(n // 4 - 1, 4), dtype=np.uint64)       # denser candidates
+            ctx.replay_load(ev, rec)
+            for fk in (0, 1, 2):
+                lr.filter_known_absents = fk
+                g = ctx.replay_batch(masks, lr)
+                c = oracle.sts_replay_batch(m, ev, rec, masks, lr, n_threads=os.cpu_count())
+                assert (g == c).all(), (name, fk)
+                assert g[0]["flags"] & T.V_VIOLATION
+            lr.filter_known_absents = 0
+            if name == "raft11":        # (sub-traces of the 11-node cluster run into the pending capacity of 128: demi_ddmin refuses those)
+                continue
+            mcs, consulted, batches, st = ctx.ddmin(lr)
+            omcs, oconsulted, obatches, ost = oracle.ddmin(m, ev, rec, lr, n_threads=os.cpu_count())
+            assert mcs == omcs and consulted == oconsulted and 0 < len(mcs) < len(ev)
+        finally:
+            ctx.close()
+
+
+def test_candidate_frontier_of_the_random_scheduler(oracle):
+    """K1's MULTI variant (demi_random_explore_candidates, what demi_random_ddmin launches): a workgroup per candidate subsequence,
+    verdict by verdict what the plain kernel gives for trace_load(candidate)."""
+    m, _dev, ev, lim, _par = shuffle12_config5()
+    ctx = _ctx(m, ev)
+    try:
+        rng = np.random.default_rng(3)
+        n_ev = len(ev)
+        masks = np.zeros((6, 4), dtype=np.uint64)
+        masks[0, 0] = (1 << n_ev) - 1
+        for i in range(1, 6):
+            masks[i, 0] = int(rng.integers(0, 1 << n_ev)) | 0xFFF | (1 << 12)             # every Start, the Submit, some Speculates
+        execs = 32 if EMU else 256
+        gv, gf = ctx.random_explore_candidates(masks, execs, lim, seed_base=SEED_BASE)
+        for i in range(len(masks)):
+            sub = ev[[j for j in range(n_ev) if (int(masks[i, 0]) >> j) & 1]]
+            c = oracle.random_explore(m, sub, execs, seed_base=SEED_BASE, limits=lim, n_threads=os.cpu_count())
+            assert (gv[i] == c).all(), i
+            assert bool(gf[i] & 1) == bool((c["flags"] & T.V_VIOLATION).any())
+    finally:
+        ctx.close()
+
+
+def test_dpor_in_both_orders(oracle):
+    """K3 with the device-resident queue, the checkpoints (104-byte record headers: 64 timer bits) and k3_analyze_big (4-bit
+    receiver field in the trace entries): ROUNDS order against the oracle's exploration in rounds, the reference's order against
+    the oracle one backtrack point at a time.  On the GPU the 12-actor shuffle job is explored until its queue is empty:
+    33 529 interleavings, 1 836 violating (tests/golden/big_tables.json)."""
+    with open(GOLDEN) as f:
+        gold = json.load(f)
+    m, dev, _fev, _lim, par = shuffle12_config5()
+    cases = [("shuffle12", m, dev, par)]
+    m2, ev2, par2 = raft11_dpor()
+    cases.append(("raft11", m2, ev2, par2))
+    for name, model, ev, p in cases:
+        for order, budget, batch in ((T.DPOR_ORDER_ROUNDS, 1500 if EMU else 1 << 16, 128 if EMU else 4096),
+                                     (T.DPOR_ORDER_REFERENCE, 300 if EMU else 3000, 32 if EMU else 256)):
+            if name == "raft11" and not EMU:
+                budget = min(budget, 20000)
+            ctx = _native.Context(0)
+            try:
+                ctx.model_load(model.to_struct())
+                ctx.model_specialize()
+                ctx.dpor_load(ev)
+                g = ctx.dpor_explore(p, T.DporSearch(batch, budget, 0, 1, order))
+            finally:
+                ctx.close()
+            if order == T.DPOR_ORDER_ROUNDS:
+                c = oracle.dpor_explore(model, ev, p, T.DporSearch(batch, budget, 0, 1, T.DPOR_ORDER_ROUNDS), os.cpu_count())
+            else:
+                c = oracle.dpor_explore(model, ev, p, T.DporSearch(1, budget, 0, 1, T.DPOR_ORDER_ROUNDS), 1)
+            assert len(g[0]) == len(c[0]) and (g[0] == c[0]).all() and (g[1] == c[1]).all(), (name, order)
+            assert not (g[0]["flags"] & 0xFC).any()
+            if name == "shuffle12" and order == T.DPOR_ORDER_ROUNDS and not EMU:
+                d = gold["shuffle12"]["dpor_rounds_batch_4096"]
+                assert int(g[4].exhausted) == 1 and len(g[0]) == d["interleavings"] and int(g[4].violations) == d["violating"]
+                assert hashlib.sha256(np.ascontiguousarray(g[0]).tobytes()).hexdigest() == d["sha256_verdicts"]
+
+
+def test_what_a_big_table_is_refused():
+    """More than 8 actors need DEMI_MODEL_WIDE; more than 16 are refused; pruneConcurrentEvents (3-bit receiver fields) refuses a
+    context that holds a big table."""
+    ctx = _native.Context(0)
+    try:
+        m = M.raft_model(9)
+        assert m.wide
+        m.wide = False
+        m.init_state = m.init_state[::2]
+        with pytest.raises(_native.DemiError, match="DEMI_MODEL_WIDE"):
+            ctx.model_load(m.to_struct())
+        m17 = M.raft_model(11)
+        m17.n_actors = 17
+        with pytest.raises(_native.DemiError, match="n_actors"):
+            ctx.model_load(m17.to_struct())
+        m, ev, par = raft11_dpor()
+        ctx.model_load(m.to_struct())
+        with pytest.raises(_native.DemiError, match="8 actors"):
+            ctx.provenance_prune([np.zeros(3, dtype=T.DPOR_TRACE_DTYPE)], [1])
+    finally:
+        ctx.close()

@@ -45,6 +45,7 @@ class ScalaDPORwHeuristics:
         # exploration; test_lean_queue_is_the_literal_queue holds the two against each other
         self.lean, self.best, self.exploredFlat = lean and trackHistory, {}, set()
         self.oracle, self.model, self.ms = oracle, model, model.to_struct()
+        self.DEAD = T.DEADLETTERS_BIG if model.n_actors > T.MAX_ACTORS else DEAD
         self.should_bound, self.stop_at_depth = bool(depth_bound), depth_bound
         self.should_cap_messages, self.max_messages = bool(max_messages), max_messages
         self.trackHistory = trackHistory
@@ -118,8 +119,13 @@ class ScalaDPORwHeuristics:
         self.timerToCancellable, self.ongoing, self.registered, self.next_c = {}, set(), set(), 0
         self.seededRandom = C.c_uint64((0 ^ 0x5DEECE66D) & ((1 << 48) - 1))
         # (an actor's state: its field word, then - DEMI_MODEL_ARRAY - the words of its array, empty at the start)
+        # (a wide table has two field words per actor; a table with more than 8 actors - the BIG layout of include/demi_gpu.h, a
+        # wide table - names deadLetters 31: it still sorts behind every actor in the pinned queue order)
         self.stw = getattr(self.model, "state_words", 1)
-        self.state = [[int(self.model.init_state[a])] + [0] * (self.stw - 1) for a in range(A)]
+        self.wide = bool(getattr(self.model, "wide", False))
+        self.big = A > T.MAX_ACTORS
+        fw = 2 if self.wide else 1
+        self.state = [[int(w) for w in self.model.init_state[a * fw:(a + 1) * fw]] + [0] * (self.stw - fw) for a in range(A)]
         self.deliveries = []
         self.aborted = False
         self.runExternal()
@@ -135,7 +141,7 @@ class ScalaDPORwHeuristics:
             elif event[0] == T.EV_START:
                 self.isolatedActors.discard(event[1])
             elif event[0] == T.EV_SEND:
-                self.event_produced(DEAD, event[1], event[2])       # actorMappings(rcv) ! msgCtor()
+                self.event_produced(self.DEAD, event[1], event[2])       # actorMappings(rcv) ! msgCtor()
             else:
                 raise Exception("unsuported external event")
             self.externalEventIdx += 1
@@ -227,7 +233,7 @@ class ScalaDPORwHeuristics:
         self.handleTick(receiver, msg, c)
 
     def handleTick(self, receiver, msg, c):
-        self.event_produced(DEAD, receiver, msg)                   # scheduler.enqueue_timer -> enqueue_message -> `!`
+        self.event_produced(self.DEAD, receiver, msg)                   # scheduler.enqueue_timer -> enqueue_message -> `!`
         if c not in self.ongoing:
             self.registered.discard(c)
             del self.timerToCancellable[(receiver, msg)]
@@ -237,7 +243,7 @@ class ScalaDPORwHeuristics:
         if c is not None:
             self.ongoing.discard(c)
             self.registered.discard(c)
-        q = self.pendingEvents.get((DEAD, rcv))                    # notify_timer_cancel (:961-984)
+        q = self.pendingEvents.get((self.DEAD, rcv))                    # notify_timer_cancel (:961-984)
         if q is not None:
             for i, u in enumerate(q):
                 if u.event[3] == msg:
@@ -247,7 +253,10 @@ class ScalaDPORwHeuristics:
     def dispatch(self, u):
         _, snd, rcv, msg = u.event
         mtype, p0, p1 = msg
-        self.deliveries.append(mtype | (rcv << 5) | (snd << 8) | (p0 << 16) | (p1 << 24))
+        if self.wide:
+            self.deliveries.append(mtype | (rcv << 5) | (snd << (9 if self.big else 8)) | (p0 << 16) | (p1 << 32))
+        else:
+            self.deliveries.append(mtype | (rcv << 5) | (snd << 8) | (p0 << 16) | (p1 << 24))
         c = self.timerToCancellable.get((rcv, msg))
         if c is not None and c in self.ongoing:                    # "Check if it was a repeating timer. If so, retrigger it"
             self.handleTick(rcv, msg, c)
@@ -360,7 +369,7 @@ class ScalaDPORwHeuristics:
                     continue
                 break
             # checkInvariant + the verdict of this interleaving
-            states = (C.c_uint64 * (T.MAX_ACTORS * self.stw))(*[w for st_ in self.state for w in st_])
+            states = (C.c_uint64 * (self.model.n_actors * self.stw))(*[w for st_ in self.state for w in st_])
             fp = int(self.oracle.lib().orc_invariant(C.byref(self.ms), states, (1 << self.model.n_actors) - 1))
             h = 0xCBF29CE484222325
             for w in self.deliveries:
@@ -402,6 +411,15 @@ def _config5_bug(cap):
     return model, ev, int(par.depth_bound), 0, cap, True
 
 
+def _big(which, cap):
+    from demi_amd.apps import raft11_dpor, shuffle12_config5
+    if which == "raft11":
+        model, ev, par = raft11_dpor()
+    else:
+        model, ev, _fev, _lim, par = shuffle12_config5()
+    return model, ev, int(par.depth_bound), 0, cap, True, int(par.p_max)
+
+
 CASES = {
     # round 6: the DPOR workloads bench.py times (prioritizePendingUponDivergence; they find the seeded bugs), their first
     # interleavings (the whole of config 3 - hundreds of thousands - is tools/check_golden_dpor_transliteration.py --bug)
@@ -410,6 +428,10 @@ CASES = {
     # prioritizePendingUponDivergence where a flip decides the verdict: two campaigning nodes of three, exhausted
     "raft3_two_campaigners_prioritize": lambda: (M.raft_model(3, election_budget=(1, 1, 0)), events_to_array([start(a) for a in range(3)] +
                                                  [send(a, M.M_BOOTSTRAP) for a in range(3)]), 12, 0, 20000, True),   # (1 552 interleavings, 28 violating)
+    # more than 8 actors (the BIG layout of include/demi_gpu.h): the 12-actor shuffle job's first interleavings - its exploration
+    # exhausts after 33 529, 1 836 of them violating - and the 11-node raft cluster
+    "shuffle12_first_150": lambda: _big("shuffle12", 150),
+    "raft11_first_120": lambda: _big("raft11", 120),
     "writers4": lambda: (writers_model(4), events_to_array([start(a) for a in range(5)] + [send(a, 0) for a in range(1, 5)]), 0, 0, 2500),
     "raft3": lambda: (M.raft_model(3), events_to_array([start(a) for a in range(3)] + [send(a, M.M_BOOTSTRAP) for a in range(3)]), 30, 0, 300),
     "raft3_two_periods": lambda: (M.raft_model(3), events_to_array([start(a) for a in range(3)] + [send(0, M.M_BOOTSTRAP),
@@ -430,11 +452,14 @@ CASES = {
 @pytest.mark.parametrize("case", sorted(CASES))
 def test_whole_exploration_equals_the_scala_transliteration(oracle, case):
     model, ev, depth, maxm, cap, *pp = CASES[case]()
+    p_max = pp[1] if len(pp) > 1 else 0          # (the restatement's pending capacity; the reference has none)
     pp = bool(pp and pp[0])
     sc = ScalaDPORwHeuristics(oracle, model, ev, depth_bound=depth, max_messages=maxm, prioritizePendingUponDivergence=pp)
     exhausted = sc.run(cap)
     par = PAR(depth=depth, maxm=maxm)
     par.prioritize_pending = 1 if pp else 0
+    if p_max:
+        par.p_max = p_max
     nat = native_explore(model, ev, par, 1, cap)
     assert len(nat[0]) == len(sc.verdicts) and bool(nat[4].exhausted) == exhausted
     want = np.array(sc.verdicts, dtype=[("flags", "<u4"), ("fingerprint", "<u4"), ("hash", "<u8")])

@@ -74,6 +74,15 @@ def test_k1_sources_against_the_oracle_on_the_cpu():
                   "test_invariant_gpu.py::test_random_program_invariants_through_every_kernel[1]"])
 
 
+def test_tables_of_more_than_eight_actors_on_the_cpu():
+    """The BIG layout (include/demi_gpu.h): every kernel compiled for the 11-node raft table and the 12-actor shuffle job - K1 and its
+    recording / SrcDstFIFO / carried-generator / candidate-frontier variants, K2 with demi_ddmin, K3 in both orders - against the oracle,
+    once more with the lanes of every lock-step interval resumed in reverse."""
+    run_emulated(["test_big_gpu.py"], timeout=2400)
+    run_emulated(["test_big_gpu.py::test_random_scheduler_on_tables_of_more_than_eight_actors", "test_big_gpu.py::test_dpor_in_both_orders"],
+                 threads=1, lane_order="reverse", timeout=2400)
+
+
 def test_k2_sources_against_the_oracle_on_the_cpu():
     run_emulated(["test_k2_gpu.py::test_replay_parity_random_subsequences_raft5",
                   "test_k2_gpu.py::test_bench_candidates_against_the_sts_transliterations_record",

@@ -95,9 +95,14 @@ class ScalaRandomScheduler:
         self.seededRandom = C.c_uint64((0 ^ 0x5DEECE66D) & ((1 << 48) - 1))       # new Random(0)
         # ---- the application
         # (an actor's state: its field word, then - DEMI_MODEL_ARRAY - the words of its array, empty at the start)
+        # (a wide table - 16-bit fields - has two field words per actor; a table with more than 8 actors is wide and names
+        # deadLetters 31 in the register window and in the recorded trace: the BIG layout of include/demi_gpu.h)
         self.stw = getattr(model, "state_words", 1)
-        assert not getattr(model, "wide", False)
-        self.state = [[int(model.init_state[a])] + [0] * (self.stw - 1) for a in range(A)]
+        self.wide = bool(getattr(model, "wide", False))
+        self.big = A > T.MAX_ACTORS
+        self.dl = T.DEADLETTERS_BIG if self.big else T.DEADLETTERS
+        fw = 2 if self.wide else 1
+        self.state = [[int(w) for w in model.init_state[a * fw:(a + 1) * fw]] + [0] * (self.stw - fw) for a in range(A)]
         self.deliveries = []
         self.next_uniq = 1
         # populateActorSystem: every actor that is ever Start()ed is created and isolated (:371-378, 397-406)
@@ -175,7 +180,7 @@ class ScalaRandomScheduler:
                 self.pendingEvents.add((snd, rcv, msg, uniq))
 
     def test_invariant(self):
-        states = (C.c_uint64 * (T.MAX_ACTORS * self.stw))(*[w for st in self.state for w in st])
+        states = (C.c_uint64 * (self.model.n_actors * self.stw))(*[w for st in self.state for w in st])
         return int(self.oracle.lib().orc_invariant(C.byref(self.ms), states, self.exists))
 
     def isTimer(self, rcv, msg):
@@ -255,7 +260,7 @@ class ScalaRandomScheduler:
 
     def dispatch_new_message(self, snd, rcv, msg):
         mtype, p0, p1 = msg
-        self.deliveries.append((15 if snd == DEAD else snd, rcv, mtype, p0, p1))
+        self.deliveries.append((self.dl if snd == DEAD else snd, rcv, mtype, p0, p1))
         if self.enqueuedExternalMessages[msg] > 0:                  # handle_event_consumed
             self.enqueuedExternalMessages[msg] -= 1
         # "Check if it was a repeating timer. If so, retrigger it" (pinned before the receive)
@@ -265,7 +270,7 @@ class ScalaRandomScheduler:
         # the actor's receive
         st = (C.c_uint64 * self.stw)(*self.state[rcv])
         fx = (_Effect * 64)()
-        n = self.oracle.lib().orc_vm_run(C.byref(self.ms), rcv, st, mtype, 15 if snd == DEAD else snd, p0, p1,
+        n = self.oracle.lib().orc_vm_run(C.byref(self.ms), rcv, st, mtype, self.dl if snd == DEAD else snd, p0, p1,
                                          self.exists, fx, 64, C.byref(self.seededRandom))
         assert n >= 0
         self.state[rcv] = [int(w) for w in st]
@@ -301,7 +306,10 @@ class ScalaRandomScheduler:
     def verdict(self):
         h = 0xCBF29CE484222325
         for snd, rcv, mtype, p0, p1 in self.deliveries:
-            w = mtype | (rcv << 5) | (snd << 8) | (p0 << 16) | (p1 << 24)
+            if self.wide:       # the 64-bit word: sender at bit 8, or bit 9 behind the 4-bit receiver of the BIG layout
+                w = mtype | (rcv << 5) | (snd << (9 if self.big else 8)) | (p0 << 16) | (p1 << 32)
+            else:
+                w = mtype | (rcv << 5) | (snd << 8) | (p0 << 16) | (p1 << 24)
             h = ((h ^ w) * 0x100000001B3) & MASK64
         for a in range(self.model.n_actors):
             for w in self.state[a]:
@@ -415,6 +423,27 @@ def test_a_table_with_arrays_equals_the_scala_transliteration(oracle):
         events = events_to_array(ev)
         checked, violations = _compare(oracle, model, events, list(range(100, 140)), 300, 5)
         assert checked == 40 and (violations > 5) == buggy
+
+
+def test_tables_of_more_than_eight_actors_equal_the_scala_transliteration(oracle):
+    """The BIG layout (include/demi_gpu.h: 9 .. 16 actors, 4-bit receiver / 5-bit sender fields, deadLetters 31, 16-bit actor
+    masks in the fingerprints): whole executions of the 11-node raft table (fuzz trace with kills and partitions) and of the
+    12-actor shuffle job against the transliteration - delivery by delivery, verdict and hash."""
+    from demi_amd.apps import SEED_BASE, raft11_config2, shuffle12_config5
+    model, events, lim = raft11_config2()
+    checked, violations = _compare(oracle, model, events, [SEED_BASE + i for i in range(60)], lim.max_messages, lim.invariant_check_interval)
+    assert checked == 60
+    model, _dev, events, lim, _par = shuffle12_config5()
+    checked, violations = _compare(oracle, model, events, [SEED_BASE + i for i in range(40)], lim.max_messages, lim.invariant_check_interval)
+    assert checked == 40 and violations >= 3
+    w = FuzzerWeights(kill=0.12, send=0.35, wait_quiescence=0.13, partition=0.25, unpartition=0.15)
+    model = M.raft_model(9, election_budget=[1, 1, 1, 1, 0, 0, 0, 0, 0])
+    total = 0
+    for tseed in (1, 2, 3):
+        events = events_to_array(raft_trace(9, 60, tseed, w, exact=False))
+        c, _ = _compare(oracle, model, events, [1000 * tseed + i * 7919 for i in range(10)], 600, 10)
+        total += c
+    assert total >= 25
 
 
 def test_the_whole_bench_step_by_the_transliteration_is_the_oracles(oracle):
