@@ -17,7 +17,7 @@ EXPORTS = ["demi_ctx_create", "demi_ctx_destroy", "demi_last_error", "demi_versi
            "demi_replay_removal_batch", "demi_replay_get_kept", "demi_replay_recorded_len", "demi_ddmin", "demi_dpor_set_traces", "demi_model_specialize", "demi_model_is_specialized", "demi_model_code_id",
            "demi_specialize_check", "demi_specialize_source", "demi_specialize_source_k1", "demi_provenance_prune", "demi_device_probe", "demi_device_probe_mix", "demi_calib_rw", "demi_random_explore_flagged", "demi_collect_flagged_dev", "demi_random_explore_submit", "demi_random_explore_wait", "demi_trace_len",
            "demi_comm_unique_id", "demi_comm_create", "demi_comm_create_host", "demi_comm_destroy", "demi_comm_rank",
-           "demi_comm_allgather_dev", "demi_random_explore_sharded", "demi_replay_batch_sharded", "demi_abi_version", "demi_replay_externals_len", "demi_edit_distance_dpor_ddmin", "demi_dpor_explored", "demi_random_ddmin", "demi_random_explore_candidates"]
+           "demi_comm_allgather_dev", "demi_random_explore_sharded", "demi_replay_batch_sharded", "demi_abi_version", "demi_replay_externals_len", "demi_edit_distance_dpor_ddmin", "demi_dpor_explored", "demi_random_ddmin", "demi_random_explore_candidates", "demi_ext_payload_areas"]
 
 _lib = None
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)     # demi_allgather_fn
@@ -80,6 +80,7 @@ def lib():
     L.demi_specialize_source_k1.argtypes = [C.POINTER(T.ModelStruct), C.c_char_p, C.c_size_t]
     L.demi_specialize_source_k1.restype = C.c_long
     L.demi_trace_load.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+    L.demi_ext_payload_areas.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
     L.demi_random_explore.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(T.Limits), C.c_void_p]
     L.demi_random_explore_dev.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.POINTER(T.Limits),
                                           C.c_void_p, C.c_void_p]
@@ -195,9 +196,21 @@ class Context:
         """64-bit identity of the compiled K1 of the loaded model (0: interpreted)."""
         return int(lib().demi_model_code_id(self._h))
 
-    def trace_load(self, events):
+    def ext_payload_areas(self, areas):
+        """demi_ext_payload_areas: the 48-bit payload areas (T.pay_area) of the external events of the NEXT trace_load / dpor_load -
+        a DEMI_MODEL_PAYLOADS table's external Sends with all their fields.  None forgets a staged array."""
+        import numpy as np
+        if areas is None:
+            self._check(lib().demi_ext_payload_areas(self._h, None, 0))
+            return
+        a = np.ascontiguousarray(areas, dtype=np.uint64)
+        self._check(lib().demi_ext_payload_areas(self._h, a.ctypes.data if len(a) else None, len(a)))
+
+    def trace_load(self, events, areas=None):
         import numpy as np
         ev = np.ascontiguousarray(events, dtype=T.EXT_EVENT_DTYPE)
+        if areas is not None:
+            self.ext_payload_areas(areas)
         self._check(lib().demi_trace_load(self._h, ev.ctypes.data if len(ev) else None, len(ev)))
 
     def random_explore(self, n, limits, seed_base=0, seeds=None):
@@ -354,9 +367,11 @@ class Context:
                                                C.byref(v), kept.ctypes.data))
         return v, kept[:int(n_rec)]
 
-    def dpor_load(self, externals):
+    def dpor_load(self, externals, areas=None):
         import numpy as np
         ev = np.ascontiguousarray(externals, dtype=T.EXT_EVENT_DTYPE)
+        if areas is not None:
+            self.ext_payload_areas(areas)
         self._check(lib().demi_dpor_load(self._h, ev.ctypes.data if len(ev) else None, len(ev)))
 
     def dpor_batch(self, prefixes, params, shared=None):

@@ -90,6 +90,9 @@ constexpr uint32_t NPAY = DEMI_JIT_NPAY;
 #else
 constexpr uint32_t NPAY = 2;
 #endif
+// the payload areas of the external events (demi_ext_payload_areas): behind the events in the same device array, word
+// EXT_AREA_OFFSET + i for event i; read by the kernels compiled for a DEMI_MODEL_PAYLOADS table only (DEMI_JIT_NPAY)
+constexpr uint32_t EXT_AREA_OFFSET = DEMI_MAX_EXT_EVENTS + 1;
 constexpr uint32_t PAY_BITS = DEMI_PAYLOAD_BITS(NPAY);
 constexpr uint32_t PAY_MASK = (1u << PAY_BITS) - 1u;
 #ifdef DEMI_WIDE

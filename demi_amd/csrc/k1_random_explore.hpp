@@ -201,7 +201,12 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const typename K1ArgsOf<MULTI
       uint64_t* tr = const_cast<uint64_t*>(t.trace);
       uint32_t j = 0;
       for (uint32_t i = 0; i < args.n_ev; i++)
-        if ((cm[i >> 6] >> (i & 63)) & 1ull) tr[j++] = tr[i];
+        if ((cm[i >> 6] >> (i & 63)) & 1ull) {
+#ifdef DEMI_JIT_NPAY
+          reinterpret_cast<word_t*>(extra)[j] = (word_t)i;      // (the event's index in the loaded trace: where its payload area is; s_sendw's place, read back below)
+#endif
+          tr[j++] = tr[i];
+        }
     }
     t.E = e_cnt;
     __syncthreads();
@@ -265,9 +270,19 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const typename K1ArgsOf<MULTI
       // (a wide table's Sends carry 16-bit payloads: demi_ext_event.p0_hi / p1_hi, zero otherwise)
       const uint32_t ep0 = ((uint32_t)(ev >> 32) & 0xFF) | (WIDE_TU ? ((uint32_t)(ev >> 48) & 0xFF) << 8 : 0u);
       const uint32_t ep1 = ((uint32_t)(ev >> 40) & 0xFF) | (WIDE_TU ? ((uint32_t)(ev >> 56) & 0xFF) << 8 : 0u);
+#ifdef DEMI_JIT_NPAY
+      // (a table whose messages have more than two fields: the Send's whole payload area, staged by demi_ext_payload_areas or
+      // made of P0 / P1 by the load - behind the events in the same array)
+      const uint32_t orig = MULTI ? (uint32_t)s_sendw[i] : i;
+      const word_t sw = (kind == DEMI_EV_SEND && ((t.exists >> a) & 1))
+                            ? msg_word_area((uint32_t)(ev >> 24) & 0xFF, DL, a, args.trace[EXT_AREA_OFFSET + orig] & 0xFFFFFFFFFFFFull)
+                            : (word_t)0;
+      (void)ep0; (void)ep1;
+#else
       const word_t sw = (kind == DEMI_EV_SEND && ((t.exists >> a) & 1))
                             ? msg_word((uint32_t)(ev >> 24) & 0xFF, DL, a, ep0, ep1)
                             : (word_t)0;
+#endif
       s_sendw[i] = sw;
       if (sw != 0) s_bsend[n_bs++] = sw;
       if (kind == DEMI_EV_START) { inacc &= ~(1u << a); killed &= ~(1u << a); started |= 1u << a; }

@@ -352,10 +352,15 @@ __global__ __launch_bounds__(K3_WAVES * 64) void k3_dpor(const K3Args args) {
       const uint64_t ev = t.trace[ext_idx];
       const uint32_t kind = (uint32_t)ev & 0xFF, a = (uint32_t)(ev >> 8) & 0xFF;
       if (kind == DEMI_EV_START) isolated &= ~(1u << a);
+#ifdef DEMI_JIT_NPAY
+      else if (kind == DEMI_EV_SEND)      // (more than two payload fields: the Send's whole area, behind the events - demi_ext_payload_areas)
+        produce(msg_word_area((uint32_t)(ev >> 24) & 0xFF, DL, a, args.ext[EXT_AREA_OFFSET + ext_idx] & 0xFFFFFFFFFFFFull));
+#else
       else if (kind == DEMI_EV_SEND)
         produce(msg_word((uint32_t)(ev >> 24) & 0xFF, DL, a,
                          ((uint32_t)(ev >> 32) & 0xFF) | (WIDE_TU ? ((uint32_t)(ev >> 48) & 0xFF) << 8 : 0u),
                          ((uint32_t)(ev >> 40) & 0xFF) | (WIDE_TU ? ((uint32_t)(ev >> 56) & 0xFF) << 8 : 0u)));
+#endif
       else if (kind == DEMI_EV_WAIT_QUIESCENCE) { marker_pending = true; marker_ext = ext_idx; await = true; }
       ext_idx++;
     }

@@ -34,14 +34,17 @@ struct ProvArgs {
 
 __host__ __device__ inline size_t prov_wave_bytes() { return (size_t)PROV_MAX * PROV_WORDS * 8 + PROV_MAX * 3 + 9 * 4; }
 
-__global__ __launch_bounds__(PROV_WAVES * 64) void k_provenance(const ProvArgs args) {
+// BIG: the traces of a table with more than 8 actors (a 4-bit receiver field in the entries' words, 16 machines + the root's)
+template <bool BIG>
+__device__ __forceinline__ void k_provenance_body(const ProvArgs& args) {
+  constexpr uint32_t MACHINES = BIG ? DEMI_MAX_ACTORS_BIG : DEMI_MAX_ACTORS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint64_t item = (uint64_t)blockIdx.x * PROV_WAVES + wave;
   if (item >= args.n) return;                                // (no workgroup barrier below: waves are independent)
   unsigned char* base = smem + (size_t)wave * ((prov_wave_bytes() + 15) & ~(size_t)15);
   uint64_t* M = reinterpret_cast<uint64_t*>(base);           // [PROV_MAX][PROV_WORDS]
-  uint8_t* rcv = base + (size_t)PROV_MAX * PROV_WORDS * 8;   // receiver (0..7), 8 = the root's own "machine", 255 = not a receive
+  uint8_t* rcv = base + (size_t)PROV_MAX * PROV_WORDS * 8;   // receiver (0..7; BIG: 0..15), MACHINES = the root's own "machine", 255 = not a receive
   uint8_t* par = rcv + PROV_MAX;
   uint8_t* prev = par + PROV_MAX;                            // previous receive of the same machine (255: none)
   const uint32_t n = args.trace_len[item] < PROV_MAX ? args.trace_len[item] : PROV_MAX;
@@ -51,8 +54,8 @@ __global__ __launch_bounds__(PROV_WAVES * 64) void k_provenance(const ProvArgs a
     uint32_t r = 255, p = 0;
     if (u < n) {
       const demi_dpor_trace_entry e = tr[u];
-      if (u == 0) r = 8;                                     // the root is a MsgEvent("null", "null", null) (:283-285)
-      else if (e.kind == 1) r = (e.word >> 5) & 7u;
+      if (u == 0) r = MACHINES;                              // the root is a MsgEvent("null", "null", null) (:283-285)
+      else if (e.kind == 1) r = (e.word >> 5) & (MACHINES - 1u);
       p = e.parent;
     }
     rcv[u] = (uint8_t)r; par[u] = (uint8_t)p;
@@ -62,8 +65,8 @@ __global__ __launch_bounds__(PROV_WAVES * 64) void k_provenance(const ProvArgs a
   // says so to the compiler, and to the lock-step emulator of the CPU suite, whose lanes really run one after the other)
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  // prev[u]: by one lane per machine (9 of them), in trace order
-  if (lane < 9) {
+  // prev[u]: by one lane per machine (9 of them; BIG: 17), in trace order
+  if (lane < MACHINES + 1u) {
     uint32_t last = 255;
     for (uint32_t u = 0; u < n; u++)
       if (rcv[u] == lane) { prev[u] = (uint8_t)last; last = u; }
@@ -90,10 +93,10 @@ __global__ __launch_bounds__(PROV_WAVES * 64) void k_provenance(const ProvArgs a
   __builtin_amdgcn_wave_barrier();
 
   // the last receive of every affected node
-  uint32_t last_of[DEMI_MAX_ACTORS];
+  uint32_t last_of[MACHINES];
   uint32_t n_last = 0;
   const uint32_t aff = args.affected[item];
-  for (uint32_t a = 0; a < DEMI_MAX_ACTORS; a++) {
+  for (uint32_t a = 0; a < MACHINES; a++) {
     if (!((aff >> a) & 1u)) continue;
     uint32_t l = 0xFFFFu;
     for (uint32_t u = 0; u < n; u++) if (rcv[u] == a) l = u;       // (uniform over the wave; n <= 256)
@@ -115,5 +118,7 @@ __global__ __launch_bounds__(PROV_WAVES * 64) void k_provenance(const ProvArgs a
     if (lane == 0) args.keep[item * PROV_WORDS + w] = bits;
   }
 }
+__global__ __launch_bounds__(PROV_WAVES * 64) void k_provenance(const ProvArgs args) { k_provenance_body<false>(args); }
+__global__ __launch_bounds__(PROV_WAVES * 64) void k_provenance_big(const ProvArgs args) { k_provenance_body<true>(args); }
 
 }  // namespace demi

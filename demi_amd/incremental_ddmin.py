@@ -29,12 +29,13 @@ def msg_word(msg_type: int, src: int, dst: int, p0: int, p1: int) -> int:
     return msg_type | (dst << 5) | (src << 8) | (p0 << 16) | (p1 << 24)
 
 
-def rec_msg_word(e, wide: bool = False) -> int:
+def rec_msg_word(e, wide: bool = False, big: bool = False) -> int:
     """The message word of a recorded MsgSend / MsgEvent: 32 bits, or the 64 bits of a wide table (header | payload area << 16,
     the area being the record's p0 | p1 << 16 | p_hi << 32: include/demi_gpu.h)."""
     if not wide:
         return msg_word(int(e["msg_type"]), int(e["snd"]), int(e["rcv"]), int(e["p0"]), int(e["p1"]))
-    return int(e["msg_type"]) | (int(e["rcv"]) << 5) | (int(e["snd"]) << 8) | (T.rec_area(e) << 16)
+    # (big: the layout of a table with more than 8 actors - the sender field sits behind a 4-bit receiver)
+    return int(e["msg_type"]) | (int(e["rcv"]) << 5) | (int(e["snd"]) << (9 if big else 8)) | (T.rec_area(e) << 16)
 
 
 def dpor_initial_trace(trace: EventTrace, model=None) -> np.ndarray:
@@ -43,6 +44,7 @@ def dpor_initial_trace(trace: EventTrace, model=None) -> np.ndarray:
     was sent; the root for external messages).  model: needed for a wide table (its node keys hash the 64-bit message word;
     the trace entry reports the word's low half)."""
     wide = bool(model is not None and getattr(model, "wide", False))
+    big = bool(model is not None and model.n_actors > T.MAX_ACTORS)
     ev = trace.events
     key_of_id: Dict[int, Tuple[int, int]] = {}          # Uniq id -> (node key, trace index of its producer)
     out = [(T.DPOR_ROOT_KEY, 0, 0, 0, 0, 0)]
@@ -51,12 +53,12 @@ def dpor_initial_trace(trace: EventTrace, model=None) -> np.ndarray:
     for e in ev:
         kind = int(e["kind"])
         if kind == T.REC_MSG_SEND:
-            w = rec_msg_word(e, wide)
+            w = rec_msg_word(e, wide, big)
             ext = bool(int(e["flags"]) & 1)
             pk, pi = (T.DPOR_ROOT_KEY, 0) if ext else (cur_key, cur_idx)
             key_of_id[int(e["id"])] = (((pk ^ w) * T.DPOR_PRIME) & 0xFFFFFFFFFFFFFFFF, pi)
         elif kind == T.REC_MSG_EVENT:
-            w = rec_msg_word(e, wide)
+            w = rec_msg_word(e, wide, big)
             k, pi = key_of_id[int(e["id"])]
             depth_of.append(depth_of[pi] + 1)
             out.append((k, w & 0xFFFFFFFF, pi & 0xFF, 0, depth_of[-1] & 0xFF, 1))

@@ -103,6 +103,7 @@ class OneAtATimeStrategy(RemovalStrategy):
         (msg_type, p0, p1) and the application's external-message filter (msg_class == EXTERNAL,
         EventTypes.setExternalMessageFilter, ExternalEvents.scala:157-166)."""
         self.verified_mcs = verified_mcs
+        self.deadLetters = T.deadletters_of(model.n_actors)       # (31 for a table of more than 8 actors: include/demi_gpu.h)
         # deliveries we have tried ignoring so far; external messages are never ignored (:32-35)
         self.triedIgnoring: Counter = Counter()
         for _, key, _ in deliveries(verified_mcs):
@@ -153,7 +154,7 @@ class SrcDstFIFORemoval(OneAtATimeStrategy):
         super().__init__(verified_mcs, model)
         self.srcDstToMessages = {}
         for _, (snd, rcv, fp), _ in deliveries(verified_mcs):
-            if snd == T.DEADLETTERS:
+            if snd == self.deadLetters:
                 continue
             self.srcDstToMessages.setdefault((snd, rcv), []).append(fp)
         self.previouslyChosenSrcDst: Optional[Tuple[int, int]] = None
@@ -176,7 +177,7 @@ class SrcDstFIFORemoval(OneAtATimeStrategy):
                 self.previouslyChosenSrcDst = k
                 return True
         self.previouslyChosenSrcDst = None
-        return snd == T.DEADLETTERS
+        return snd == self.deadLetters
 
     def next_index(self, trace, alreadyRemoved, violationTriggeredLastRun):
         if not violationTriggeredLastRun and self.previouslyChosenSrcDst is not None:
@@ -187,7 +188,7 @@ class SrcDstFIFORemoval(OneAtATimeStrategy):
             removed = Counter(alreadyRemoved)
             for _, key, _ in reversed(deliveries(self.verified_mcs)):
                 snd, rcv, fp = key
-                if snd == T.DEADLETTERS:
+                if snd == self.deadLetters:
                     continue
                 if removed[key] > 0:
                     removed[key] -= 1

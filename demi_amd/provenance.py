@@ -21,12 +21,13 @@ from . import types as T
 
 
 class ProvenanceTracker:
-    def __init__(self, trace: np.ndarray):
-        """trace: DPOR_TRACE_DTYPE (key, word, parent, kind), index 0 = root."""
+    def __init__(self, trace: np.ndarray, big: bool = False):
+        """trace: DPOR_TRACE_DTYPE (key, word, parent, kind), index 0 = root.  big: the trace of a table with more than 8 actors
+        (the BIG layout of include/demi_gpu.h: a 4-bit receiver field in the entries' words)."""
         self.trace = np.ascontiguousarray(trace, dtype=T.DPOR_TRACE_DTYPE)
         n = len(self.trace)
         word = self.trace["word"].astype(np.int64)
-        rcv = (word >> 5) & 7
+        rcv = (word >> 5) & (15 if big else 7)
         is_msg = (self.trace["kind"] == 1) | (np.arange(n) == 0)         # the root is a MsgEvent("null", "null", null)
         rcv = np.where(np.arange(n) == 0, -1, rcv)
         hb = np.zeros((n, n), dtype=bool)
@@ -73,18 +74,18 @@ class ProvenanceTracker:
         return np.nonzero(~removed)[0]
 
 
-def pruneConcurrentEvents(initialTrace: np.ndarray, affectedNodes: Sequence[int], ctx=None) -> np.ndarray:
+def pruneConcurrentEvents(initialTrace: np.ndarray, affectedNodes: Sequence[int], ctx=None, big: bool = False) -> np.ndarray:
     """RunnerUtils.pruneConcurrentEvents: the initial trace restricted to the provenance of the violation.
-    ctx: a demi_amd._native.Context - the closure and the pruning then run on its device."""
+    ctx: a demi_amd._native.Context - the closure and the pruning then run on its device (in the layout of the table it holds)."""
     if ctx is not None:
         return pruneConcurrentEventsBatch(ctx, [initialTrace], [affectedNodes])[0]
-    keep = ProvenanceTracker(initialTrace).pruneConcurrentEvents(affectedNodes)
+    keep = ProvenanceTracker(initialTrace, big).pruneConcurrentEvents(affectedNodes)
     return np.ascontiguousarray(initialTrace)[keep]
 
 
 def pruneConcurrentEventsBatch(ctx, initialTraces: Sequence[np.ndarray], affectedNodes: Sequence[Sequence[int]]) -> List[np.ndarray]:
     """pruneConcurrentEvents for many executions in one launch (one wavefront per trace)."""
     traces = [np.ascontiguousarray(t, dtype=T.DPOR_TRACE_DTYPE) for t in initialTraces]
-    masks = [sum(1 << int(a) for a in set(nodes) if 0 <= int(a) < T.MAX_ACTORS) for nodes in affectedNodes]
+    masks = [sum(1 << int(a) for a in set(nodes) if 0 <= int(a) < T.MAX_ACTORS_BIG) for nodes in affectedNodes]
     kept = ctx.provenance_prune(traces, masks)
     return [t[k] for t, k in zip(traces, kept)]

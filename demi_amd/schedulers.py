@@ -48,7 +48,7 @@ class ViolationFingerprint:
         return ((self.code ^ other.code) & self.match_mask) == 0
 
     def affectedNodes(self) -> List[int]:
-        return [i for i in range(T.MAX_ACTORS) if (self.code >> i) & 1]
+        return T.fingerprint_actors(self.code)
 
 
 @dataclass

@@ -59,7 +59,10 @@ def _plausible_recording(rec) -> bool:
     if int(rec["kind"].max()) > T.REC_MSG_EVENT:
         return False
     snd = rec["snd"]
-    if int(rec["rcv"].max()) >= T.MAX_ACTORS or bool(((snd >= T.MAX_ACTORS) & (snd != T.DEADLETTERS)).any()):
+    # (either layout: actors 0..7 with deadLetters 15, or - a table of more than 8 actors - 0..15 with deadLetters 31)
+    big = int(rec["rcv"].max()) >= T.MAX_ACTORS or bool((snd == T.DEADLETTERS_BIG).any())
+    cap, dl = (T.MAX_ACTORS_BIG, T.DEADLETTERS_BIG) if big else (T.MAX_ACTORS, T.DEADLETTERS)
+    if int(rec["rcv"].max()) >= cap or bool(((snd >= cap) & (snd != dl)).any()):
         return False
     sent = {}
     for e in rec:

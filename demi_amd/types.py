@@ -5,6 +5,17 @@ MAX_ACTORS = 8
 DEADLETTERS = 15
 MAX_ACTORS_BIG = 16       # a table with more than MAX_ACTORS actors: the BIG layout (include/demi_gpu.h)
 DEADLETTERS_BIG = 31
+
+
+def deadletters_of(n_actors):
+    """The sender id of externals and timers in the layout of a table with n_actors actors."""
+    return DEADLETTERS_BIG if n_actors > MAX_ACTORS else DEADLETTERS
+
+
+def fingerprint_actors(code):
+    """The actors a ViolationFingerprint word names: its low 8 bits, or - the BIG layout, kind in bits 30..31 - its low 16."""
+    n = MAX_ACTORS_BIG if (int(code) >> 30) else MAX_ACTORS
+    return [i for i in range(n) if (int(code) >> i) & 1]
 MAX_MSG_TYPES = 32
 MAX_CLASSES = 4
 MAX_CODE = 1024
@@ -108,6 +119,12 @@ def payload_fields(area, n):
     """The n payload fields of a 48-bit payload area (DEMI_PAYLOAD_OF)."""
     w = payload_bits(n)
     return [(int(area) >> (k * w)) & ((1 << w) - 1) for k in range(n)]
+
+
+def pay_area(fields, n):
+    """The 48-bit payload area of a message with n payload fields (3..6: DEMI_MODEL_PAYLOADS; include/demi_gpu.h), P0 first."""
+    w = payload_bits(n)
+    return sum((int(v) & ((1 << w) - 1)) << (k * w) for k, v in enumerate(list(fields)[:n]))
 
 
 def rec_area(e):

@@ -96,7 +96,7 @@ typedef struct {
  * guarded micro-op over a 16 x u8 register window:
  *   r0..r7  = the receiving actor's state fields F0..F7 (persisted across deliveries)
  *   r8..r11 = temporaries T0..T3 (zero at handler entry)
- *   r12,r13 = message payload P0,P1     r14 = sender id (15 = deadLetters)   r15 = own id
+ *   r12,r13 = message payload P0,P1     r14 = sender id (15 = deadLetters; 31 in the BIG layout)   r15 = own id
  * Row word: op[7:0] | dst[11:8] | a[15:12] | bimm[16] | aux[23:17] | b[31:24]
  *   (bimm=1: b is an 8-bit immediate, else b[3:0] is a register).  All arithmetic mod 256,
  *   comparisons unsigned.  Control flow is forward-only (SKIP*), so a handler terminates.   */
@@ -173,7 +173,7 @@ typedef enum {
 #define DEMI_INV_PROGRAM 0x100u
 
 typedef struct {
-  uint32_t n_actors;        /* 1..DEMI_MAX_ACTORS */
+  uint32_t n_actors;        /* 1..DEMI_MAX_ACTORS; 9..DEMI_MAX_ACTORS_BIG with DEMI_MODEL_WIDE: the BIG layout (below) */
   uint32_t n_msg_types;     /* 1..DEMI_MAX_MSG_TYPES */
   uint32_t n_classes;       /* 1..DEMI_MAX_CLASSES */
   uint32_t code_len;        /* rows in `code` */
@@ -209,6 +209,28 @@ typedef struct {
  * for the table), the replay entry points (the pending-set scan variant of the kernel) and the DPOR entry points.  The 8-bit
  * layout is untouched by the option (same code, same verdict hashes as before). */
 #define DEMI_MODEL_WIDE 0x1u
+
+/* MORE THAN 8 ACTORS - the BIG layout (round 6).  The reference puts no bound on actor names (ExternalEvents.scala:62-91,
+ * EventOrchestrator.scala:203-217, 345-351); a table with n_actors = 9 .. DEMI_MAX_ACTORS_BIG (16) is accepted when it is also
+ * DEMI_MODEL_WIDE (it runs only as compiled code, like every wide table), and everything that names an actor is laid out for 16:
+ *   message word      type[4:0] | dst[8:5] | src[13:9] | payload area[63:16]  (4-bit receiver, 5-bit sender; tables of up to
+ *                     8 actors keep dst[7:5] | src[11:8]).  demi_verdict.hash hashes these words, demi_dpor_trace_entry.word
+ *                     is their low half;
+ *   deadLetters       DEMI_DEADLETTERS_BIG (31): r14 of a handler run for an external message or a timer, demi_rec_event.snd of
+ *                     such a message (15 stays what it is for tables of up to 8 actors - there it could be an actor's id here);
+ *   SEND rows         a target register above 15 addresses nobody, as a target above 7 does in the small layout;
+ *   fingerprints      kind[31:30] | key[29:16] | actors[15:0]: DEMI_INV_AT_MOST_ONE = 1 << 30 | (key & 0x3FFF) << 16 | mask of the
+ *                     actors that share the key, DEMI_INV_NEVER = 2 << 30 | hit actors, DEMI_INV_AGREE = 3 << 30 | hit actors (the
+ *                     small layout: kind << 24 | key << 8 | 8-bit mask).  A key wider than 14 bits is truncated IN THE
+ *                     FINGERPRINT only (the comparison of keys is exact); fp_match_mask applies to this word;
+ *   inside the engine 16 x 16 partition / reach matrices, 64 timer bits (actor x DEMI_MAX_TIMER_TYPES), 256 (src, dst) pairs of
+ *                     SrcDstFIFO - none of it visible at the boundary.
+ * Every entry point takes such a table - the RandomScheduler kernel in all its variants (recording, SrcDstFIFO, carried generators,
+ * candidate frontiers: demi_random_ddmin), the replay kernel with demi_ddmin and the internal-event minimization, DPORwHeuristics
+ * in both orders with the device-resident queue and the checkpoints, demi_provenance_prune (which reads its traces in the layout
+ * of the table the context holds).  Tables of up to 8 actors are untouched: same layout, same
+ * verdict hashes, the same instructions in their kernels (the message word of the small layout has no room for a second
+ * layout's fields, so the big one is a layout of its own rather than a widening of the old).  tests/test_big_gpu.py. */
 
 /* DEMI_MODEL_ARRAY(n): every actor owns, beside its eight state fields, an ARRAY of n elements (1..DEMI_MAX_ARRAY) of the
  * register window's width (u8, or u16 with DEMI_MODEL_WIDE) - the part of an actor's state that eight fields cannot hold: a
@@ -310,7 +332,7 @@ typedef enum {
 
 typedef struct {
   uint8_t kind;            /* demi_rec_kind */
-  uint8_t snd, rcv;        /* MSG_*: sender (15 = deadLetters; timers are recorded as "Timer"), receiver;
+  uint8_t snd, rcv;        /* MSG_*: sender (15 = deadLetters, 31 for a table of more than 8 actors; timers are recorded as "Timer"), receiver;
                               SPAWN/KILL: rcv = actor; (UN)PARTITION: snd = a, rcv = b */
   uint8_t msg_type;
   uint16_t p0, p1;         /* the message's payload fields: below 256 unless the model is DEMI_MODEL_WIDE (with
@@ -365,6 +387,14 @@ long demi_specialize_source(const demi_model* model, char* out, size_t cap);
 long demi_specialize_source_k1(const demi_model* model, char* out, size_t cap);
 /* The external-event trace handed to explore()/test() (RandomScheduler.scala:226-237). */
 int demi_trace_load(demi_ctx* ctx, const demi_ext_event* events, uint32_t n_events);
+/* External Sends of a DEMI_MODEL_PAYLOADS table with ALL their fields (Send(name, messageCtor), ExternalEvents.scala:62-91: the
+ * constructor's message is whatever the application sends; demi_ext_event has room for P0 and P1).  areas[i] = the 48-bit payload
+ * area (DEMI_MODEL_PAYLOADS above: field k in bits [k * w, (k + 1) * w)) of external event i of the trace that the NEXT
+ * demi_trace_load / demi_dpor_load of this context loads - read for its Send events only, n must equal that load's count, the
+ * load consumes it (a later load without a new call takes the fields from the events again: P0, P1, the others 0).  A table with
+ * two payload fields ignores it.  demi_replay_load needs none: the recorded MsgSend of an external message carries its area
+ * (demi_rec_event p0 / p1 / p_hi), and that is what a replay enqueues.  NULL, 0: forget a staged array. */
+int demi_ext_payload_areas(demi_ctx* ctx, const uint64_t* areas, uint32_t n);
 
 /* ---------------------------------------------------------- K1: RandomScheduler
  * Replaces the loop of RandomScheduler.explore (RandomScheduler.scala:234-272) in the
@@ -707,7 +737,8 @@ int demi_edit_distance_dpor_ddmin(demi_ctx* ctx, const demi_ext_event* externals
  * handling") closed transitively, then an event is kept iff it strictly precedes the last receive of at least one actor
  * of affected[i] (bit a = actor a, ViolationFingerprint.affectedNodes).  traces: [n][stride] entries as K3 /
  * dpor_initial_trace produce them (word, parent and kind are read; trace_len[i] <= DEMI_DPOR_MAX_TRACE);
- * out_keep: [n][DEMI_DPOR_MAX_TRACE / 64] words, bit u = event u of trace i is kept.  All host pointers.          */
+ * out_keep: [n][DEMI_DPOR_MAX_TRACE / 64] words, bit u = event u of trace i is kept.  All host pointers.  The receiver of an
+ * entry is read in the layout of the table the context holds (4 bits and up to 16 affected actors for a table of more than 8).  */
 int demi_provenance_prune(demi_ctx* ctx, const demi_dpor_trace_entry* traces, const uint32_t* trace_len,
                           const uint32_t* affected, uint32_t stride, uint64_t n, uint64_t* out_keep);
 

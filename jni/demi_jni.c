@@ -125,6 +125,18 @@ JNIEXPORT jint JNICALL FN(traceLoad)(JNIEnv* e, jclass c, jlong h, jbyteArray ev
   return rc;
 }
 
+/* demi_ext_payload_areas: the payload areas of the external events the next traceLoad / dporLoad loads (null: forget) */
+JNIEXPORT jint JNICALL FN(extPayloadAreas)(JNIEnv* e, jclass c, jlong h, jlongArray areas) {
+  (void)c;
+  if (!areas) return demi_ext_payload_areas(CTX(h), NULL, 0);
+  const int64_t len = LEN(areas);
+  if (len < 0 || len > DEMI_MAX_EXT_EVENTS) return DEMI_ERR_INVALID_ARG;
+  void* p = LONGS(areas);
+  jint rc = LOST(areas, p) ? DEMI_ERR_INVALID_ARG : demi_ext_payload_areas(CTX(h), (const uint64_t*)p, (uint32_t)len);
+  PUT_LONGS(areas, p, JNI_ABORT);
+  return rc;
+}
+
 /* ---- K1 */
 JNIEXPORT jint JNICALL FN(randomExplore)(JNIEnv* e, jclass c, jlong h, jlong seedBase, jlong n, jintArray limits, jlongArray verdicts) {
   demi_limits lim;

@@ -63,6 +63,16 @@ static inline void ps_set(orc_pairset* p, uint32_t a, uint32_t b) { const uint32
 static inline void ps_clear(orc_pairset* p, uint32_t a, uint32_t b) { const uint32_t i = a * 16 + b; p->w[i >> 6] &= ~(1ULL << (i & 63)); }
 static inline int ps_get(const orc_pairset* p, uint32_t a, uint32_t b) { const uint32_t i = a * 16 + b; return (int)((p->w[i >> 6] >> (i & 63)) & 1); }
 
+/* The payload areas of external Sends (include/demi_gpu.h demi_ext_payload_areas): a table with DEMI_MODEL_PAYLOADS has messages
+ * of up to six fields, demi_ext_event room for two.  Set before an entry point is called with the trace the areas belong to
+ * (areas[i] = the area of external event i when it is a Send), cleared with NULL; a process-wide pointer (the worker threads of
+ * the batch entry points read it), test infrastructure like everything here. */
+static const uint64_t* g_ext_areas;
+static uint32_t g_n_ext_areas;
+void orc_set_ext_areas(const uint64_t* areas, uint32_t n) { g_ext_areas = areas; g_n_ext_areas = areas ? n : 0; }
+#define ORC_EXT_AREA(m, e, idx) ((g_ext_areas && (idx) < g_n_ext_areas && DEMI_MODEL_PAYLOADS_N((m)->flags) > 2) ? (g_ext_areas[(idx)] & 0xFFFFFFFFFFFFull) \
+                                 : area_of2((m), (e)->p0 | ((uint32_t)(e)->p0_hi << 8), (e)->p1 | ((uint32_t)(e)->p1_hi << 8)))
+
 /* ===================================================================== model helpers */
 static int timer_index(const demi_model* m, uint32_t type) {
   /* dense index of a TIMER-class type among the model's timer types, ascending */
@@ -687,7 +697,7 @@ static void inject_until_quiescence(exec_t* x) {
       case DEMI_EV_SEND: /* enqueue_message, V/schedulers/ExternalEventInjector.scala:250-279 */
         if ((x->exists >> e->a) & 1) {
           if (x->n_mts >= MTS_CAP) { x->flags |= DEMI_V_QUEUE_OVF; break; }
-          x->mts[x->n_mts++] = (mts_entry){e->a, e->msg_type, area_of2(x->m, e->p0 | ((uint32_t)e->p0_hi << 8), e->p1 | ((uint32_t)e->p1_hi << 8)), 1, idx};
+          x->mts[x->n_mts++] = (mts_entry){e->a, e->msg_type, ORC_EXT_AREA(x->m, e, x->trace_idx), 1, idx};
         } /* else: "Unknown message receiver" (:254) */
         break;
       case DEMI_EV_PARTITION: /* trigger_partition :314-322 */
@@ -1398,7 +1408,7 @@ static uint32_t dpor_run_external(dpor_t* x, const demi_ext_event* ext, uint32_t
     const demi_ext_event* e = &ext[idx];
     if (e->kind == DEMI_EV_START) x->isolated &= ~(1u << e->a);
     else if (e->kind == DEMI_EV_SEND)
-      dpor_produce(x, msg_word_a(x->wide, e->msg_type, ORC_DL, e->a, area_of2(x->m, e->p0 | ((uint32_t)e->p0_hi << 8), e->p1 | ((uint32_t)e->p1_hi << 8))));
+      dpor_produce(x, msg_word_a(x->wide, e->msg_type, ORC_DL, e->a, ORC_EXT_AREA(x->m, e, idx)));
     else if (e->kind == DEMI_EV_WAIT_QUIESCENCE) { x->marker_pending = 1; x->marker_ext = idx; await = 1; }
     idx++;
   }

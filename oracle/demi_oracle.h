@@ -57,6 +57,10 @@ int orc_vm_run_area(const demi_model* m, uint32_t me, uint64_t* state, uint8_t m
                     uint64_t area, uint32_t exists_mask, orc_effect* fx, uint32_t fx_cap, orc_jrandom* app);
 uint64_t orc_pay_area(const demi_model* m, const uint16_t* fields);
 
+/* The payload areas of the external Sends of the trace the NEXT calls are given (a DEMI_MODEL_PAYLOADS table: demi_ext_event has
+ * room for two fields); NULL clears.  Process-wide. */
+void orc_set_ext_areas(const uint64_t* areas, uint32_t n);
+
 /* Invariant: returns the fingerprint code (0 = holds). */
 uint32_t orc_invariant(const demi_model* m, const uint64_t* states, uint32_t exists_mask);
 

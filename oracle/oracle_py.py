@@ -144,6 +144,24 @@ class JRandom:
         return lib().orc_jrandom_next_double(C.byref(self._s))
 
 
+_EXT_AREAS = None       # (kept alive while the oracle holds the pointer)
+
+
+def set_ext_areas(areas):
+    """orc_set_ext_areas: the payload areas of the external Sends of the trace the NEXT calls are given (a DEMI_MODEL_PAYLOADS
+    table); None clears."""
+    global _EXT_AREAS
+    L = lib()
+    L.orc_set_ext_areas.argtypes = [C.c_void_p, C.c_uint32]
+    L.orc_set_ext_areas.restype = None
+    if areas is None:
+        _EXT_AREAS = None
+        L.orc_set_ext_areas(None, 0)
+        return
+    _EXT_AREAS = np.ascontiguousarray(areas, dtype=np.uint64)
+    L.orc_set_ext_areas(_EXT_AREAS.ctypes.data, len(_EXT_AREAS))
+
+
 def model_validate(model):
     err = C.create_string_buffer(256)
     ms = model.to_struct()

@@ -18,6 +18,9 @@ object DemiGpu {
                         handlerStart: Array[Short], code: Array[Int], initState: Array[Long], inv: Array[Int]): Int
   @native def modelSpecialize(h: Long, enable: Boolean): Int
   @native def traceLoad(h: Long, events: Array[Byte]): Int
+  /** demi_ext_payload_areas: the 48-bit payload areas of the external events the NEXT traceLoad / dporLoad loads (a table whose
+   *  messages have more than two fields: FlatEvents.packAreas); null forgets a staged array. */
+  @native def extPayloadAreas(h: Long, areas: Array[Long]): Int
   @native def randomExplore(h: Long, seedBase: Long, n: Long, limits: Array[Int], verdicts: Array[Long]): Int
   @native def randomExploreFlagged(h: Long, seedBase: Long, n: Long, limits: Array[Int], flagMask: Int,
                                    out: Array[Long], counts: Array[Long]): Int

@@ -112,6 +112,7 @@ class GpuRandomScheduler(val schedulerConfig: SchedulerConfig, max_executions: I
       else if (max_executions >= (1 << 16)) modelSpecialize(h, true)   // optional: a failure keeps the table interpreter
       modelLoaded = true
     }
+    if (lowering.model.payloads > 2) check(h, extPayloadAreas(h, FlatEvents.packAreas(trace, lowering)))   // external Sends with all their fields
     check(h, traceLoad(h, FlatEvents.pack(trace, lowering)))
   }
 
@@ -363,6 +364,7 @@ class GpuDPOR(val schedulerConfig: SchedulerConfig, lowering: TableLowering, dep
                        Array(m.invKind, m.invFa, m.invVa, m.invFb, m.fpMatchMask, m.flags)))
     if (m.compiledOnly) check(h, modelSpecialize(h, true))
     else modelSpecialize(h, true)
+    if (lowering.model.payloads > 2) check(h, extPayloadAreas(h, FlatEvents.packAreas(events, lowering)))
     check(h, dporLoad(h, FlatEvents.pack(events, lowering)))      // Start / Send / WaitQuiescence only (DPORwHeuristics.scala:692-710)
     val params = Array(depthBound, maxMessagesToSchedule, 1, lowering.fingerprintCode(fp), 64, 4096, 0)
     val search = Array(batch, maxInterleavings, if (stopIfViolationFound) 1 else 0, 1,
@@ -439,6 +441,7 @@ object GpuRandomDDMin {
                          Array(m.invKind, m.invFa, m.invVa, m.invFb, m.fpMatchMask, m.flags)))
       if (m.compiledOnly) check(h, modelSpecialize(h, true)) else modelSpecialize(h, true)
       val ext = trace.original_externals
+      if (lowering.model.payloads > 2) check(h, extPayloadAreas(h, FlatEvents.packAreas(ext, lowering)))
       check(h, traceLoad(h, FlatEvents.pack(ext, lowering)))
       // demi_limits: max_messages = trace.size (:608), no periodic invariant check (RandomScheduler(config, 1, 0)), lookingFor = violation
       val limits = Array(trace.events.size, 0, pMax, 1, lowering.fingerprintCode(violation), 0, 0, 0, 1)
@@ -472,8 +475,11 @@ object GpuDPOR {
       val kind = vt(o + 15) & 0xFF
       if (kind == 1) {
         val w = (vt(o + 8) & 0xFF) | ((vt(o + 9) & 0xFF) << 8) | ((vt(o + 10) & 0xFF) << 16) | ((vt(o + 11) & 0xFF) << 24)
-        val (ty, dst, src, p0, p1) = (w & 31, (w >> 5) & 7, (w >> 8) & 15, (w >> 16) & 255, (w >>> 24) & 255)
-        t += MsgEvent(if (src == FlatEvents.DEADLETTERS) "deadLetters" else lo.actorName(src), lo.actorName(dst), lo.decode(ty, p0, p1))
+        // (the header in the layout of the lowering's table: 3 + 4 bits of receiver / sender, or 4 + 5 for more than 8 actors; a
+        // wide table's entry reports type, receiver, sender and p0 - p1 is not in the low half of its word)
+        val (ty, dst, src) = lo.model.header(w)
+        val (p0, p1) = if (lo.model.wide) ((w >>> 16) & 0xFFFF, 0) else ((w >> 16) & 255, (w >>> 24) & 255)
+        t += MsgEvent(if (src == lo.model.deadLetters) "deadLetters" else lo.actorName(src), lo.actorName(dst), lo.decode(ty, p0, p1))
       } else if (kind == 2) t += Quiescence
     }
     t

@@ -24,10 +24,16 @@ case class FlatModel(nActors: Int, msgClass: Array[Byte], actorClass: Array[Byte
     val m = (1L << payloadBits) - 1
     if (!wide) Seq((area & m).toInt, ((area >> 16) & m).toInt) else (0 until payloads).map(k => ((area >> (k * payloadBits)) & m).toInt)
   }
+  /** More than 8 actors (9 .. 16): the BIG layout of include/demi_gpu.h - such a table must be wide; its message word has a 4-bit
+   *  receiver and a 5-bit sender field, its deadLetters id is 31, its fingerprints carry 16-bit actor masks. */
+  def big: Boolean = nActors > 8
+  def deadLetters: Int = if (big) 31 else 15
   /** the message word (include/demi_gpu.h): 32 bits, or the 64 bits of a wide table */
   def word(msgType: Int, src: Int, dst: Int, area: Long): Long =
     if (!wide) (msgType | (dst << 5) | (src << 8)).toLong | ((area & 0xFF) << 16) | (((area >> 16) & 0xFF) << 24)
-    else (msgType | (dst << 5) | (src << 8)).toLong | (area << 16)
+    else (msgType | (dst << 5) | (src << (if (big) 9 else 8))).toLong | (area << 16)
+  /** (type, receiver, sender) of the low half of a message word (demi_dpor_trace_entry.word) */
+  def header(w: Int): (Int, Int, Int) = if (big) (w & 31, (w >> 5) & 15, (w >> 9) & 31) else (w & 31, (w >> 5) & 7, (w >> 8) & 15)
   /** Such a table has no interpreter on the device: every scheduler compiles it right after loading it. */
   def compiledOnly: Boolean = wide || arrayLen > 0
 }
@@ -57,7 +63,7 @@ object FlatEvents {
   val REC_SPAWN = 0; val REC_KILL = 1; val REC_PARTITION = 2; val REC_UNPARTITION = 3; val REC_BEGIN_WAIT_QUIESCENCE = 4
   val REC_QUIESCENCE = 5; val REC_MSG_SEND = 6; val REC_MSG_EVENT = 7
   val REC_BYTES = 16           // sizeof(demi_rec_event)
-  val DEADLETTERS = 15
+  val DEADLETTERS = 15         // (tables of up to 8 actors; FlatModel.deadLetters is the id of the lowering's own layout)
 
   def pack(trace: Seq[ExternalEvent], lo: TableLowering): Array[Byte] = {
     val out = new Array[Byte](8 * trace.size)
@@ -79,7 +85,12 @@ object FlatEvents {
     out
   }
 
-  private def name(id: Int, lo: TableLowering) = if (id == DEADLETTERS) "deadLetters" else lo.actorName(id)
+  /** The payload areas of the trace's Sends (demi_ext_payload_areas), for a lowering whose messages have more than two fields:
+   *  every field of the constructor's message, packed as FlatModel.area does; 0 for the events that are not Sends. */
+  def packAreas(trace: Seq[ExternalEvent], lo: TableLowering): Array[Long] =
+    trace.map { case Send(_, ctor) => lo.model.area(lo.encodeFields(ctor())._2); case _ => 0L }.toArray
+
+  private def name(id: Int, lo: TableLowering) = if (id == lo.model.deadLetters) "deadLetters" else lo.actorName(id)
 
   /** demi_rec_event[] -> the records an EventTrace holds (EventTrace.scala:16-18, AuxilaryTypes.scala:34-69). */
   def toEventTrace(rec: Array[Byte], nRec: Int, externals: Seq[ExternalEvent], lo: TableLowering): EventTrace = {
@@ -112,7 +123,7 @@ object FlatEvents {
   val DPOR_ROOT_KEY = 0xCBF29CE484222325L
   val DPOR_PRIME = 0x100000001B3L
   def dporInitialTrace(trace: EventTrace, lo: TableLowering): Array[Byte] = {
-    def actor(n: String) = if (n == "deadLetters" || n == "Timer") DEADLETTERS else lo.actorId(n)
+    def actor(n: String) = if (n == "deadLetters" || n == "Timer") lo.model.deadLetters else lo.actorId(n)
     // (a wide table's node keys hash the 64-bit word; the entry reports its low half)
     def word(s: String, r: String, m: Any): Long = { val (t, f) = lo.encodeFields(m); lo.model.word(t, actor(s), lo.actorId(r), lo.model.area(f)) }
     val keyOfId = scala.collection.mutable.Map[Int, (Long, Int)]()        // Uniq id -> (node key, trace index of its producer)
@@ -152,7 +163,7 @@ object FlatEvents {
       out(o + 8) = fl.toByte; out(o + 9) = ext.toByte; out(o + 10) = (area >> 32).toByte; out(o + 11) = (area >> 40).toByte            // p_hi
       out(o + 12) = id.toByte; out(o + 13) = (id >> 8).toByte; out(o + 14) = (id >> 16).toByte; out(o + 15) = (id >> 24).toByte
     }
-    def actor(n: String) = if (n == "deadLetters" || n == "Timer") DEADLETTERS else lo.actorId(n)
+    def actor(n: String) = if (n == "deadLetters" || n == "Timer") lo.model.deadLetters else lo.actorId(n)
     for ((e, i) <- evs.zipWithIndex) e match {
       case SpawnEvent(_, _, n, _) => put(i, REC_SPAWN, 0, lo.actorId(n), 0, 0L, 0, spawns.getOrElse(n, 255), 0)
       case KillEvent(n) => put(i, REC_KILL, 0, lo.actorId(n), 0, 0L, 0, 255, 0)

@@ -192,8 +192,7 @@ def test_dpor_in_both_orders(oracle):
 
 
 def test_what_a_big_table_is_refused():
-    """More than 8 actors need DEMI_MODEL_WIDE; more than 16 are refused; pruneConcurrentEvents (3-bit receiver fields) refuses a
-    context that holds a big table."""
+    """More than 8 actors need DEMI_MODEL_WIDE; more than 16 are refused."""
     ctx = _native.Context(0)
     try:
         m = M.raft_model(9)
@@ -206,9 +205,37 @@ def test_what_a_big_table_is_refused():
         m17.n_actors = 17
         with pytest.raises(_native.DemiError, match="n_actors"):
             ctx.model_load(m17.to_struct())
-        m, ev, par = raft11_dpor()
-        ctx.model_load(m.to_struct())
-        with pytest.raises(_native.DemiError, match="8 actors"):
-            ctx.provenance_prune([np.zeros(3, dtype=T.DPOR_TRACE_DTYPE)], [1])
+    finally:
+        ctx.close()
+
+
+def test_provenance_of_violations_on_a_big_table():
+    """ProvenanceTracker.pruneConcurrentEvents (k_provenance_big: 4-bit receiver fields, up to 16 affected actors) over violating
+    executions of the 12-actor job - recorded by K1, lowered by DepTracker.getInitialTrace's mirror (64-bit words of the BIG
+    layout in the node keys) - against the host class (the shape of the reference's own)."""
+    from demi_amd.incremental_ddmin import dpor_initial_trace
+    from demi_amd.provenance import ProvenanceTracker, pruneConcurrentEventsBatch
+    from demi_amd.schedulers import EventTrace
+    m, _dev, fev, lim, _par = shuffle12_config5()
+    ctx = _ctx(m, fev)
+    try:
+        v = ctx.random_explore(600 if EMU else 6000, lim, seed_base=SEED_BASE)
+        traces, affected = [], []
+        for i in np.nonzero(v["flags"] & T.V_VIOLATION)[0]:
+            vv, rec = ctx.random_get_trace(SEED_BASE + int(i), lim)
+            it = dpor_initial_trace(EventTrace(rec, fev[:T.verdict_trace_idx(vv.flags)]), m)
+            if len(it) <= T.DPOR_MAX_TRACE:
+                traces.append(it)
+                affected.append(T.fingerprint_actors(vv.fingerprint))
+            if len(traces) >= (10 if EMU else 150):
+                break
+        assert len(traces) >= 5 and max(max(a) for a in affected) >= T.MAX_ACTORS      # workers 8 .. 11 are among the violating actors
+        got = pruneConcurrentEventsBatch(ctx, traces, affected)
+        kept_some = 0
+        for tr, aff, k in zip(traces, affected, got):
+            w = tr[ProvenanceTracker(tr, big=True).pruneConcurrentEvents(aff)]
+            assert len(k) == len(w) and (k == w).all()
+            kept_some += int(0 < len(k) < len(tr))
+        assert kept_some >= len(traces) // 2
     finally:
         ctx.close()

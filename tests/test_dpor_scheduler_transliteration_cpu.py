@@ -122,6 +122,7 @@ class ScalaDPORwHeuristics:
         # (a wide table has two field words per actor; a table with more than 8 actors - the BIG layout of include/demi_gpu.h, a
         # wide table - names deadLetters 31: it still sorts behind every actor in the pinned queue order)
         self.stw = getattr(self.model, "state_words", 1)
+        assert getattr(self.model, "payloads", 2) == 2       # (messages are (type, p0, p1) here: tables of two payload fields)
         self.wide = bool(getattr(self.model, "wide", False))
         self.big = A > T.MAX_ACTORS
         fw = 2 if self.wide else 1

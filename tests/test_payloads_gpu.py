@@ -121,3 +121,109 @@ def test_random_payload_tables_parity(oracle, npay):
             assert len(grec) == len(crec) and (grec == crec).all()
     finally:
         ctx.close()
+
+
+def _ledger_model(n_actors=4):
+    """A table whose EXTERNAL message has five fields: Deposit(account, amount, fee, memo, flags) at a teller, who books the
+    fields into its state and forwards Post(account, amount, fee, memo, flags) to the next teller; a Post is booked and
+    acknowledged.  Invariant: nobody has booked the memo 0x1A5 (a sticky flag in F5) - reachable only when the external Send's
+    fourth field crosses the boundary."""
+    from demi_amd.model import Asm, F, P0, P1, ME, SRC, T0, T1, T2, T3, build_model
+    MSGS = [("Deposit", T.MSG_EXTERNAL), ("Post", T.MSG_INTERNAL), ("Ack", T.MSG_INTERNAL)]
+    h = {}
+    for name in ("Deposit", "Post"):
+        a = Asm()
+        a.ldp(T0, 2).ldp(T1, 3).ldp(T2, 4)
+        a.add(F[0], F[0], P1).add(F[1], F[1], T0).xor(F[2], F[2], T1).or_(F[3], F[3], T2).add(F[4], F[4], 1)
+        a.ldi16(T3, 0x1A5).if_eq(T1, T3, "m").mov(F[5], 1).label("m")
+        if name == "Deposit":       # forward to the next teller, every field as it came
+            a.add(T3, ME, 1).if_ge(T3, n_actors, "w").mov(T3, 0).label("w")
+            a.send(1, T3, P0, P1, T0, T1, T2)
+        else:
+            a.send(2, SRC, F[4], 0)
+        h[(0, name)] = a
+    h[(0, "Ack")] = Asm().add(F[6], F[6], P0)
+    return build_model("ledger%d" % n_actors, n_actors, MSGS, h, [[0] * 8] * n_actors, (T.INV_NEVER, 5, 1, 0), wide=True, payloads=5)
+
+
+def test_external_sends_with_all_their_fields(oracle):
+    """demi_ext_payload_areas (round 6): Send(name, messageCtor) of a message with five fields - demi_ext_event has room for two.
+    The areas staged before the load reach K1 (plain, recording, candidate frontiers), the replay of the recorded execution (K2:
+    the recorded MsgSend carries the area) and K3, each against the oracle given the same areas; without them the other fields
+    are 0 and the memo never arrives."""
+    model = _ledger_model()
+    assert model.payloads == 5 and T.payload_bits(5) == 9
+    rng = np.random.default_rng(11)
+    ev, areas = [start(a) for a in range(4)], [0] * 4
+    for i in range(10):
+        acct, amount = int(rng.integers(0, 512)), int(rng.integers(0, 512))
+        fields = [acct, amount, int(rng.integers(0, 512)), 0x1A5 if i == 6 else int(rng.integers(0, 0x1A0)), int(rng.integers(0, 512))]
+        ev.append(send(int(rng.integers(0, 4)), 0, acct, amount))
+        areas.append(T.pay_area(fields, 5))
+        if i == 4:
+            ev.append(wait_quiescence()); areas.append(0)
+    events = events_to_array(ev)
+    areas = np.array(areas, dtype=np.uint64)
+    lim = T.Limits(200, 0, 64, 0, 0, 0)
+    n = 256 if os.environ.get("DEMI_EMU") == "1" else 4096
+    ctx = _native.Context(0)
+    try:
+        ctx.model_load(model.to_struct())
+        ctx.model_specialize()
+        # ---- K1 with the areas: the memo arrives in every execution; without: never
+        ctx.trace_load(events, areas)
+        g = ctx.random_explore(n, lim, seed_base=SEED_BASE)
+        oracle.set_ext_areas(areas)
+        c = oracle.random_explore(model, events, n, seed_base=SEED_BASE, limits=lim, n_threads=os.cpu_count())
+        assert_same(g, c)
+        assert ((g["flags"] & T.V_VIOLATION) != 0).all() and len(np.unique(g["hash"])) > n // 4
+        vv, rec = ctx.random_get_trace(SEED_BASE + 3, lim)
+        cv, crec, _st = oracle.random_execute(model, events, SEED_BASE + 3, lim)
+        assert vv.hash == cv.hash and (rec == crec).all()
+        sends = rec[(rec["kind"] == T.REC_MSG_SEND) & ((rec["flags"] & 1) != 0)]
+        assert sorted(T.rec_area(e) for e in sends) == sorted(int(a) for a, e in zip(areas, events) if e["kind"] == T.EV_SEND)
+        # candidate frontiers (what demi_random_ddmin launches): the areas follow the events of every candidate
+        masks = np.zeros((3, 4), dtype=np.uint64)
+        masks[0, 0] = (1 << len(events)) - 1
+        masks[1, 0] = ((1 << len(events)) - 1) & ~(1 << 11)                 # without the Send that carries the memo (event 11)
+        masks[2, 0] = 0xF | (1 << 11) | (1 << 12)
+        assert int(areas[11]) >> 27 & 0x1FF == 0x1A5
+        gv, gf = ctx.random_explore_candidates(masks, 64, lim, seed_base=SEED_BASE)
+        for i in range(3):
+            keep = [j for j in range(len(events)) if (int(masks[i, 0]) >> j) & 1]
+            oracle.set_ext_areas(areas[keep])
+            cc = oracle.random_explore(model, events[keep], 64, seed_base=SEED_BASE, limits=lim, n_threads=os.cpu_count())
+            assert (gv[i] == cc).all(), i
+        assert gf[0] & 1 and not gf[1] & 1 and gf[2] & 1
+        # ---- K2: the replay of the recorded execution enqueues the recorded areas
+        oracle.set_ext_areas(areas)
+        lr = T.Limits(200, 0, 64, 1, int(vv.fingerprint), 0)
+        ctx.replay_load(events, rec)
+        km = np.array([[0xFFFFFFFFFFFFFFFF] * 4, [0xFFFFFFFFFFFFFFFF & ~(1 << 11)] + [0xFFFFFFFFFFFFFFFF] * 3], dtype=np.uint64)
+        gr = ctx.replay_batch(km, lr)
+        cr = oracle.sts_replay_batch(model, events, rec, km, lr, n_threads=1)
+        assert (gr == cr).all() and gr[0]["flags"] & T.V_VIOLATION and int(gr[0]["hash"]) == int(vv.hash) and not gr[1]["flags"] & T.V_VIOLATION
+        # ---- K3 (Start / Send only): the same areas
+        keep = [j for j in range(len(events)) if events[j]["kind"] != T.EV_WAIT_QUIESCENCE][:9]
+        dev, dar = events[keep], areas[keep]
+        par = T.DporParams(30, 0, 0, 0, 64, 4096, 1)
+        srch = T.DporSearch(64, 400, 0, 1, T.DPOR_ORDER_ROUNDS)
+        ctx.dpor_load(dev, dar)
+        gd = ctx.dpor_explore(par, srch)
+        oracle.set_ext_areas(dar)
+        cd = oracle.dpor_explore(model, dev, par, srch, os.cpu_count())
+        assert len(gd[0]) == len(cd[0]) > 20 and (gd[0] == cd[0]).all() and (gd[1] == cd[1]).all()
+        # ---- without areas: P0 / P1 only, the memo never arrives; a staged array of the wrong length is refused
+        oracle.set_ext_areas(None)
+        ctx.trace_load(events)
+        g0 = ctx.random_explore(n, lim, seed_base=SEED_BASE)
+        c0 = oracle.random_explore(model, events, n, seed_base=SEED_BASE, limits=lim, n_threads=os.cpu_count())
+        assert_same(g0, c0)
+        assert not (g0["flags"] & T.V_VIOLATION).any()
+        ctx.ext_payload_areas(areas[:5])
+        with pytest.raises(_native.DemiError, match="staged"):
+            ctx.trace_load(events)
+        ctx.trace_load(events)                                                # (the refused load consumed the staging)
+    finally:
+        oracle.set_ext_areas(None)
+        ctx.close()

@@ -98,6 +98,7 @@ class ScalaRandomScheduler:
         # (a wide table - 16-bit fields - has two field words per actor; a table with more than 8 actors is wide and names
         # deadLetters 31 in the register window and in the recorded trace: the BIG layout of include/demi_gpu.h)
         self.stw = getattr(model, "state_words", 1)
+        assert getattr(model, "payloads", 2) == 2       # (messages are (type, p0, p1) here: tables of two payload fields)
         self.wide = bool(getattr(model, "wide", False))
         self.big = A > T.MAX_ACTORS
         self.dl = T.DEADLETTERS_BIG if self.big else T.DEADLETTERS
