@@ -130,6 +130,7 @@ class OneAtATimeStrategy(RemovalStrategy):
 
     def _copy_base(self, other):
         other.verified_mcs = self.verified_mcs
+        other.deadLetters = self.deadLetters
         other.triedIgnoring = Counter(self.triedIgnoring)
         other._unignorable = self._unignorable
 

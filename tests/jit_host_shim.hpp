@@ -5,6 +5,7 @@
 #define DEMI_FX_CAP 8
 #define DEMI_V_QUEUE_OVF 0x8u
 namespace demi {
+constexpr uint32_t FX_NOBODY = 15u;     // (sim_core.hpp: a SEND target beyond the field is nobody; the shim runs tables of up to 8 actors)
 struct Tables { const uint32_t* hs; uint32_t ac_packed, NT; const uint32_t* magic; const uint32_t* gmagic; };
 #ifdef DEMI_WIDE      // a DEMI_MODEL_WIDE table: 64-bit message / effect words, two state words per actor
 typedef uint64_t word_t;
