@@ -93,7 +93,12 @@ __host__ __device__ inline size_t k1_extra_lds_bytes(uint32_t n_ev, uint32_t n_b
 // one array in arrival order (a pair's queue is the sub-sequence with that (src, dst)); its NORM_HOT first slots in
 // LDS, the rest in the HBM spill after the timers-and-externals arrays; srcDsts as a byte list (src * 8 + dst).
 constexpr uint32_t NORM_HOT = 16;
-__host__ __device__ inline uint32_t k1_pair_words(uint32_t n_actors) { return (n_actors * n_actors + 3) / 4; }
+// (a pair is listed while it has a queued message: at most p_max <= DEMI_MAX_PENDING of them at a time - what bounds the list
+// of a table with more than 11 actors)
+__host__ __device__ inline uint32_t k1_pair_words(uint32_t n_actors) {
+  const uint32_t pairs = n_actors * n_actors < DEMI_MAX_PENDING ? n_actors * n_actors : DEMI_MAX_PENDING;
+  return (pairs + 3) / 4;
+}
 // (message words are 8 bytes in a wide build; the ids beside them - recording variant - and the pair list stay 32-bit)
 __host__ __device__ inline size_t k1_fifo_wave_bytes(uint32_t n_actors, bool rec, bool wide = WIDE_TU) {
   return ((size_t)NORM_HOT * ((wide ? 2 : 1) + (rec ? 1 : 0)) + k1_pair_words(n_actors)) * 64 * 4;

@@ -191,6 +191,41 @@ def test_dpor_in_both_orders(oracle):
                 assert hashlib.sha256(np.ascontiguousarray(g[0]).tobytes()).hexdigest() == d["sha256_verdicts"]
 
 
+def test_reference_order_exhausted_is_the_scala_transliterations_record():
+    """tests/golden/big_tables_transliteration.json (tools/check_big_transliteration.py): the literal transliteration of
+    DPORwHeuristics explored the 12-actor job in the reference's own order until its queue was empty - 28 767 interleavings, 1 566
+    violating - and ScalaRandomScheduler executed the first 4 096 schedules of both fuzz steps.  The device returns those bytes."""
+    with open(os.path.join(os.path.dirname(GOLDEN), "big_tables_transliteration.json")) as f:
+        tl = json.load(f)
+    r = tl["shuffle12_dpor_reference_order"]
+    assert r["exhausted"] and r["equals_the_oracles_one_at_a_time_exploration"] and tl["raft11"]["equals_the_oracle"] and tl["shuffle12"]["equals_the_oracle"]
+    for name, m, ev, lim in _fuzz_workloads():
+        ctx = _ctx(m, ev)
+        try:
+            k = 512 if EMU else tl[name]["schedules"]
+            g = ctx.random_explore(k, lim, seed_base=SEED_BASE)
+            if not EMU:
+                assert hashlib.sha256(np.ascontiguousarray(g).tobytes()).hexdigest() == tl[name]["sha256_verdicts"]
+                assert int(((g["flags"] & T.V_VIOLATION) != 0).sum()) == tl[name]["violating_executions"]
+        finally:
+            ctx.close()
+    if EMU:
+        return                  # (the whole exploration under the emulator: tools/emu_full_workloads.py big)
+    m, dev, _fev, _lim, par = shuffle12_config5()
+    ctx = _native.Context(0)
+    try:
+        ctx.model_load(m.to_struct())
+        ctx.model_specialize()
+        ctx.dpor_load(dev)
+        g = ctx.dpor_explore(par, T.DporSearch(512, r["interleavings"] + 64, 0, 1, T.DPOR_ORDER_REFERENCE))
+    finally:
+        ctx.close()
+    assert int(g[4].exhausted) == 1 and len(g[0]) == r["interleavings"] and int(g[4].violations) == r["violations"]
+    assert hashlib.sha256(np.ascontiguousarray(g[0]).tobytes()).hexdigest() == r["sha256_verdicts"]
+    assert hashlib.sha256(np.ascontiguousarray(g[1], dtype=np.uint32).tobytes()).hexdigest() == r["sha256_prefix_lens"]
+    assert int(g[4].first_violation) == r["first_violation"]
+
+
 def test_what_a_big_table_is_refused():
     """More than 8 actors need DEMI_MODEL_WIDE; more than 16 are refused."""
     ctx = _native.Context(0)
@@ -237,5 +272,73 @@ def test_provenance_of_violations_on_a_big_table():
             assert len(k) == len(w) and (k == w).all()
             kept_some += int(0 < len(k) < len(tr))
         assert kept_some >= len(traces) // 2
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("seed", [2, 5])
+def test_random_tables_of_sixteen_actors(oracle, seed):
+    """Random wide tables at the layout's limit - 16 actors in three classes, every op, SENDs to computed targets (an id above 15
+    addresses nobody), timers, RND, 16-bit external payloads - under traces with kills, partitions between any two of the sixteen
+    and quiescence markers: K1 (both strategies, recorded traces), K2 over a recorded execution, K3."""
+    from demi_amd.fuzzer import events_to_array, kill, partition, send, start, unpartition, wait_quiescence
+    from .test_jit_cpu import _random_handler_wide
+    rng = np.random.default_rng(1000 + seed)
+    A = 16
+    MSGS = [("E", T.MSG_EXTERNAL), ("A", T.MSG_INTERNAL), ("B", T.MSG_INTERNAL), ("Tm", T.MSG_TIMER)]
+    h = {}
+    for cls in range(3):
+        for name, _ in MSGS:
+            if rng.integers(6):
+                h[(cls, name)] = _random_handler_wide(rng, int(rng.integers(3, 24)), len(MSGS))
+    model = M.build_model("rand_big%d" % seed, A, MSGS, h, [[int(x) for x in rng.integers(0, 65536, 8)] for _ in range(A)],
+                          (T.INV_AT_MOST_ONE, 1, int(rng.integers(0, 4)), 2), actor_class=[int(x) for x in rng.integers(0, 3, A)], n_classes=3, wide=True)
+    ev = [start(a) for a in range(A)]
+    for i in range(44):
+        k = int(rng.integers(0, 12))
+        if k == 0 and ev[-1][0] != T.EV_WAIT_QUIESCENCE:
+            ev.append(wait_quiescence())
+        elif k == 1:
+            ev.append(partition(int(rng.integers(0, A)), int(rng.integers(0, A))))
+        elif k == 2:
+            ev.append(unpartition(int(rng.integers(0, A)), int(rng.integers(0, A))))
+        elif k == 3:
+            ev.append(kill(int(rng.integers(0, A))) if rng.integers(2) else start(int(rng.integers(0, A))))
+        else:
+            ev.append(send(int(rng.integers(0, A)), 0, int(rng.integers(0, 65536)), int(rng.integers(0, 65536))))
+    events = events_to_array(ev)
+    lim = T.Limits(160, 9, 96, 0, 0, 0)
+    n = 384 if EMU else 6000
+    ctx = _ctx(model, events)
+    try:
+        for strategy in (0, 1):
+            l2 = _limits(lim, strategy=strategy)
+            g = ctx.random_explore(n, l2, seed_base=77)
+            c = oracle.random_explore(model, events, n, seed_base=77, limits=l2, n_threads=os.cpu_count())
+            assert (g == c).all(), strategy
+            assert len(np.unique(g["hash"])) > n // 8
+        rec = None
+        for s in (77, 78, 90):
+            v, rec = ctx.random_get_trace(s, lim)
+            ov, orec, _st = oracle.random_execute(model, events, s, lim)
+            assert (v.flags, v.fingerprint, v.hash) == (ov.flags, ov.fingerprint, ov.hash) and len(rec) == len(orec) and (rec == orec).all()
+        # K2 over the last recorded execution
+        masks = rng.integers(0, 2**63, size=(200, 4), dtype=np.uint64) | rng.integers(0, 2**63, size=(200, 4), dtype=np.uint64)
+        masks[0] = 0xFFFFFFFFFFFFFFFF
+        lr = _limits(lim, invariant_check_interval=0, looking_for_valid=1, looking_for=int(v.fingerprint))
+        ctx.replay_load(events, rec)
+        for fk in (0, 2):
+            lr.filter_known_absents = fk
+            gr = ctx.replay_batch(masks, lr)
+            cr = oracle.sts_replay_batch(model, events, rec, masks, lr, n_threads=os.cpu_count())
+            assert (gr == cr).all(), fk
+        # K3: Start / Send / WaitQuiescence only
+        dev = events_to_array([e for e in ev if e[0] in (T.EV_START, T.EV_SEND, T.EV_WAIT_QUIESCENCE)][:A + 7])
+        par = T.DporParams(24, 120, 0, 0, 96, 4096, int(seed & 1))
+        srch = T.DporSearch(64, 300 if EMU else 3000, 0, 1, T.DPOR_ORDER_ROUNDS)
+        ctx.dpor_load(dev)
+        gd = ctx.dpor_explore(par, srch)
+        cd = oracle.dpor_explore(model, dev, par, srch, os.cpu_count())
+        assert len(gd[0]) == len(cd[0]) and (gd[0] == cd[0]).all() and (gd[1] == cd[1]).all()
     finally:
         ctx.close()

@@ -9,6 +9,8 @@ INFRASTRUCTURE) over the FULL records of the timed workloads - what rounds 4-5 c
   k3bug     config 3 as timed from round 6 on, REFERENCE order (258 025) -> tests/golden/dpor_config3_bug_reference_order.json,
             and ROUNDS order (297 396) -> the oracle's exploration in rounds
   k3c5      config 5 (round 6), REFERENCE order, first 6 000 -> tests/golden/dpor_config5_bug_transliteration.json
+  big       tables of more than 8 actors: raft11 / shuffle12 fuzz prefixes, shuffle12's DPOR exhausted in both orders
+            -> tests/golden/big_tables.json, big_tables_transliteration.json
 
 Usage: python tools/emu_full_workloads.py [k1 k2 k3 k3bug k3c5 ...]   (default: all; W64_THREADS = host threads the emulator's
 workgroups run on, default: all cores).  Writes tests/golden/emu_full_workloads.json (one entry per workload: SHA-256s, whether
@@ -151,7 +153,49 @@ def k3c5():
             "equals_the_record": sha(v, T.VERDICT_DTYPE) == g["sha256_verdicts"] and sha(plen, np.uint32) == g["sha256_prefix_lens"]}
 
 
-WORK = {"k1": k1, "k2": k2, "k3": k3, "k3bug": k3bug, "k3c5": k3c5}
+def big():
+    """Tables of more than 8 actors (the BIG layout): K1 over the fuzz prefixes of raft11 / shuffle12, K3 over the 12-actor job's
+    exploration to exhaustion in both orders -> tests/golden/big_tables.json (the oracle's) and big_tables_transliteration.json
+    (the Scala schedulers' transliterations')."""
+    from demi_amd.apps import raft11_config2, shuffle12_config5
+    g = gold("big_tables.json")
+    try:
+        tl = gold("big_tables_transliteration.json")
+    except OSError:
+        tl = None
+    out = {"workload": "raft11 / shuffle12 fuzz prefixes, shuffle12 DPOR exhausted in both orders", "record": "big_tables.json, big_tables_transliteration.json"}
+    ok = True
+    m, ev, lim = raft11_config2()
+    m2, dev, fev, lim2, par = shuffle12_config5()
+    t0 = time.perf_counter()
+    for name, model, events, limits in (("raft11", m, ev, lim), ("shuffle12", m2, fev, lim2)):
+        ctx = _native.Context(0)
+        ctx.model_load(model.to_struct())
+        ctx.trace_load(events)
+        ctx.model_specialize()
+        v = ctx.random_explore(g[name]["fuzz_prefix"], limits, seed_base=SEED_BASE)
+        ctx.close()
+        out[name + "_sha256_fuzz_verdicts"] = sha(v, T.VERDICT_DTYPE)
+        same = out[name + "_sha256_fuzz_verdicts"] == g[name]["sha256_fuzz_verdicts"]
+        if tl and tl[name]["schedules"] == g[name]["fuzz_prefix"]:
+            same = same and out[name + "_sha256_fuzz_verdicts"] == tl[name]["sha256_verdicts"]
+        ok &= same
+    d = g["shuffle12"]["dpor_rounds_batch_4096"]
+    v, plen, st, dt = _dpor(m2, dev, par, T.DPOR_ORDER_ROUNDS, 1 << 17, 4096)
+    out["dpor_rounds"] = {"interleavings": len(v), "violations": int(((v["flags"] & T.V_VIOLATION) != 0).sum()), "sha256_verdicts": sha(v, T.VERDICT_DTYPE)}
+    ok &= len(v) == d["interleavings"] and out["dpor_rounds"]["sha256_verdicts"] == d["sha256_verdicts"] and sha(plen, np.uint32) == d["sha256_prefix_lengths"]
+    if tl:
+        r = tl["shuffle12_dpor_reference_order"]
+        v, plen, st, dt = _dpor(m2, dev, par, T.DPOR_ORDER_REFERENCE, r["interleavings"] + 64, 512)
+        out["dpor_reference_order"] = {"interleavings": len(v), "executed": int(st.executed), "violations": int(((v["flags"] & T.V_VIOLATION) != 0).sum()),
+                                       "sha256_verdicts": sha(v, T.VERDICT_DTYPE)}
+        ok &= len(v) == r["interleavings"] and out["dpor_reference_order"]["sha256_verdicts"] == r["sha256_verdicts"] and sha(plen, np.uint32) == r["sha256_prefix_lens"]
+    out["seconds"] = time.perf_counter() - t0
+    out["equals_the_record"] = bool(ok)
+    return out
+
+
+WORK = {"k1": k1, "k2": k2, "k3": k3, "k3bug": k3bug, "k3c5": k3c5, "big": big}
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(WORK)
