@@ -72,3 +72,22 @@ def test_validation_of_big_tables(oracle):
     # the 8-actor tables are what they were: narrow, deadLetters 15
     m8 = M.shuffle_model()
     assert m8.n_actors == 8 and not m8.wide and m8.name == "shuffle8-synth"
+
+
+def test_oracle_gives_the_transliterations_record(oracle):
+    """tests/golden/big_tables_transliteration.json (tools/check_big_transliteration.py): ScalaRandomScheduler over the first 4 096
+    schedules of both fuzz steps, ScalaDPORwHeuristics over the 12-actor job in the reference's own order until its queue was
+    empty (28 767 interleavings, 16 minutes of Python).  The C oracle - its batch, and the product's one-at-a-time loop around its
+    interleavings - gives those bytes."""
+    with open(os.path.join(os.path.dirname(GOLDEN), "big_tables_transliteration.json")) as f:
+        tl = json.load(f)
+    m, ev, lim = raft11_config2()
+    m2, dev, fev, lim2, par = shuffle12_config5()
+    for name, model, events, limits in (("raft11", m, ev, lim), ("shuffle12", m2, fev, lim2)):
+        v = oracle.random_explore(model, events, tl[name]["schedules"], seed_base=SEED_BASE, limits=limits, n_threads=os.cpu_count())
+        assert _sha(v) == tl[name]["sha256_verdicts"] and tl[name]["equals_the_oracle"] is True
+    r = tl["shuffle12_dpor_reference_order"]
+    one = oracle.dpor_explore(m2, dev, par, T.DporSearch(1, r["interleavings"] + 64, 0, 1, T.DPOR_ORDER_ROUNDS), 1)
+    assert int(one[4].exhausted) == 1 and len(one[0]) == r["interleavings"] == 28767 and int(one[4].violations) == r["violations"]
+    assert _sha(one[0]) == r["sha256_verdicts"] and _sha(np.ascontiguousarray(one[1], dtype=np.uint32)) == r["sha256_prefix_lens"]
+    assert int(one[4].first_violation) == r["first_violation"]
