@@ -108,6 +108,11 @@ struct K3PairArgs {
   uint32_t* n_surv;                    // [n]
   unsigned long long* keep_bits;       // [n][max_pairs / 64]: decide's verdict per racing pair (bit = its backtrack point is emitted)
   uint32_t* item_points;               // [n]: points emitted per interleaving
+  // diagnostic (DEMI_K3_INSERT_PROBE): a launch of k3_pairs_insert that stops after the index build (1), after the filter (2) or after
+  // the survivors' table loads (3) and changes nothing - the host times it beside the real launch of the same round
+  uint32_t dry;
+  unsigned long long* dbg;             // diagnostic: [0] survivors, [1] not at home, [2] atomicOr, [3] atomicMax (null: not counted)
+  uint32_t fresh;                      // the pre-checks in front of insert's atomics read at agent scope (see k3_pairs_insert)
 };
 
 __device__ __forceinline__ unsigned long long cand_pack(uint32_t round, uint32_t branch, unsigned long long ordinal) {
@@ -236,6 +241,8 @@ __global__ __launch_bounds__(256) void k3_pairs_insert(const K3PairArgs a) {
   for (uint32_t j = 0; j < 8; j++) { const uint32_t k = j * nt + t; if (k < a.max_pairs) first[j] = P[k]; }
   const bool par = parent_index_build(a, it, np, T, S);
   __syncthreads();
+  if (a.dry == 1) return;
+  uint32_t c_nh = 0, c_or = 0, c_max = 0;
   uint32_t done = 0;                        // survivors written so far (max_pairs may exceed the list: 4096 pairs at a time)
   for (uint32_t c0 = 0; c0 < np; c0 += 4096) {
   const uint32_t c1 = min(c0 + 4096u, np);
@@ -261,6 +268,7 @@ __global__ __launch_bounds__(256) void k3_pairs_insert(const K3PairArgs a) {
   }
   __syncthreads();
   const uint32_t ns = s_n;
+  if (a.dry == 2) return;
   // ---- the survivors' table entries
   for (uint32_t j = t; j < ns; j += nt) {
     const uint32_t k = c0 + s_surv[j];
@@ -276,8 +284,10 @@ __global__ __launch_bounds__(256) void k3_pairs_insert(const K3PairArgs a) {
     const ulonglong2 hc = *reinterpret_cast<const ulonglong2*>(&eh->cand[0]);
     const uint2 hs = *reinterpret_cast<const uint2*>(&eh->state[0]);
     const bool at_home = hk.x == lo_ && hk.y == hi_;
+    if (a.dry == 3) { if (hk.x == 1 && hc.x == 1 && hs.x == 1) atomicAdd(&a.counters[2], 1ull); continue; }
     const uint32_t s1 = at_home ? home * 2 + (ke < kl ? 0u : 1u) : pair_slot(a.table, a.mask, ke, kl);   // (earlier, later); its flip is the other side
     const uint32_t s2 = s1 == 0xFFFFFFFFu ? s1 : (s1 ^ 1u);
+    c_nh += !at_home;
     a.surv_k[(size_t)it * a.max_pairs + done + j] = (uint16_t)k;
     a.pair_slot_of[(size_t)it * a.max_pairs + done + j] = s2;
     if (s1 == 0xFFFFFFFFu) { atomicAdd(&a.counters[2], 1ull); continue; }
@@ -285,9 +295,18 @@ __global__ __launch_bounds__(256) void k3_pairs_insert(const K3PairArgs a) {
     // where it executes.  Both updates are monotone (the explored bit is only ever set, the candidate only ever raised), so
     // an ordinary load that already shows the result makes the atomic redundant; a stale line only means one atomic more.
     PairEntry* const e1 = a.table + (s1 >> 1);
-    const uint32_t seen_state = at_home ? ((s1 & 1) ? hs.y : hs.x) : e1->state[s1 & 1];
-    const unsigned long long seen_cand = at_home ? ((s2 & 1) ? hc.y : hc.x) : e1->cand[s2 & 1];
+    uint32_t seen_state = at_home ? ((s1 & 1) ? hs.y : hs.x) : e1->state[s1 & 1];
+    unsigned long long seen_cand = at_home ? ((s2 & 1) ? hc.y : hc.x) : e1->cand[s2 & 1];
+    if (a.fresh) {
+      // An ordinary load is answered by the XCD's own L2, and a line that got there early in the launch stays there while the
+      // other seven XCDs' atomics raise the value in memory: every later instance of the pair on this XCD sees the previous
+      // round's candidate and pays an atomic that changes nothing.  An agent-scope load sees what the atomics have made of it.
+      if (!(seen_state & PE_EXPLORED)) seen_state = __hip_atomic_load(&e1->state[s1 & 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (seen_cand < cand_pack(a.round, p.branch, (unsigned long long)it * a.max_pairs + k))
+        seen_cand = __hip_atomic_load(&e1->cand[s2 & 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if (!(seen_state & PE_EXPLORED)) {
+      c_or++;
       const uint32_t old = atomicOr(&e1->state[s1 & 1], PE_EXPLORED);      // setExplored(branch, (earlier, later))
       if (a.kills && !(old & PE_EXPLORED) && (old & PE_QMASK)) {           // queued points flip into this pair: dead now
         const unsigned long long q = atomicAdd(&a.counters[1], 1ull);      // (only a HOST queue is told: the device queue reads the table)
@@ -295,6 +314,7 @@ __global__ __launch_bounds__(256) void k3_pairs_insert(const K3PairArgs a) {
       }
     }
     const unsigned long long mine = cand_pack(a.round, p.branch, (unsigned long long)it * a.max_pairs + k);
+    c_max += seen_cand < mine;
     if (seen_cand < mine) atomicMax(&e1->cand[s2 & 1], mine);            // (s2 is the other side of the same entry)
   }
   done += ns;
@@ -302,11 +322,18 @@ __global__ __launch_bounds__(256) void k3_pairs_insert(const K3PairArgs a) {
   if (t == 0) s_n = 0;
   __syncthreads();
   }
-  if (t == 0) {
-    a.n_surv[it] = done;
-    if (!a.kills && np) atomicAdd(&a.counters[1], (unsigned long long)np);                 // statistics (device-queue rounds): pairs reported,
-    if (!a.kills && a.world <= 1 && np > done) atomicAdd(&a.counters[3], (unsigned long long)(np - done));   // pairs the filter dropped
+  if (a.dry) return;
+  if (a.dbg) {
+    if (c_nh) atomicAdd(&a.dbg[1], (unsigned long long)c_nh);
+    if (c_or) atomicAdd(&a.dbg[2], (unsigned long long)c_or);
+    if (c_max) atomicAdd(&a.dbg[3], (unsigned long long)c_max);
+    if (t == 0) atomicAdd(&a.dbg[0], (unsigned long long)done);
   }
+  // (The statistics of the device-queue rounds - pairs reported, pairs the filter dropped - are sums over n_pairs / n_surv that
+  // k3_q_scan takes while it scans the round anyway.  They used to be two atomicAdds per workgroup on two fixed addresses: 131 072
+  // same-address atomics of a 65 536-wide round, executed one after the other wherever atomics execute - 1.5 of the launch's
+  // 1.9 ms, profiles/r06_insert_probe.txt.)
+  if (t == 0) a.n_surv[it] = done;
 }
 
 // decide: which pairs' backtrack points can still be dequeued live

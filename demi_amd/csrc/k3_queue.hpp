@@ -43,6 +43,7 @@ struct K3QueueArgs {
   const demi_dpor_trace_entry* arena;
   const demi_dpor_pair* pairs;           // [n][max_pairs]
   const uint32_t* n_pairs;               // [n]
+  const uint32_t* n_surv;                // [n] pairs the parent filter left (k3_pairs_insert), or nullptr: k3_q_scan's statistics
   const unsigned long long* keep_bits;   // [n][max_pairs / 64]
   uint32_t* item_points;                 // [n] in: points per interleaving; k3_q_scan turns it into the exclusive prefix
   uint32_t n, max_pairs, base_id;
@@ -61,6 +62,7 @@ struct K3QueueArgs {
   uint32_t want;                         // live candidates to take
   uint32_t round;                        // stamps the dequeue (1, 2, ...: every k3_q_probe launch has its own)
   uint32_t* cand_slot;                   // [n_cand] table slot * 2 + side of each candidate's flipped pair
+  uint32_t* blk_live;                    // [(n_cand + 255) / 256] live candidates per workgroup of k3_q_live
   DporItem* items;                       // out: the taken candidates, in dequeue order
 };
 
@@ -68,31 +70,43 @@ __device__ __forceinline__ unsigned long long q_stamp(uint32_t round, uint32_t j
   return ((unsigned long long)round << 32) | (unsigned long long)(0xFFFFFFFFu - j);      // max = this dequeue, lowest candidate index
 }
 
-// exclusive prefix of item_points[0 .. n) in place; the total to out[0].  One workgroup.
+// exclusive prefix of item_points[0 .. n) in place; the total to out[0].  One workgroup, a tile of 1 024 interleavings per step (a
+// scan within each wave, the sixteen wave sums through LDS; the next tile's loads are issued before this tile's barriers).  The same
+// pass takes the round's statistics: out[1] += racing pairs reported, out[3] += pairs the parent filter dropped (n_surv != nullptr:
+// the device-queue rounds).
 __global__ __launch_bounds__(1024) void k3_q_scan(const K3QueueArgs a) {
-  __shared__ uint32_t s_part[1024];
-  __shared__ uint32_t s_carry;
-  const uint32_t t = threadIdx.x;
-  if (t == 0) s_carry = 0;
-  __syncthreads();
+  __shared__ uint32_t s_w[16];
+  __shared__ unsigned long long s_rep, s_drop;
+  const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+  if (t == 0) { s_rep = 0; s_drop = 0; }
+  uint32_t carry = 0;
+  unsigned long long rep = 0, drop = 0;
+  uint32_t v_next = t < a.n ? a.item_points[t] : 0u, np_next = 0, ns_next = 0;
+  if (a.n_surv && t < a.n) { np_next = a.n_pairs[t]; ns_next = a.n_surv[t]; }
   for (uint32_t lo = 0; lo < a.n; lo += 1024) {
-    const uint32_t i = lo + t;
-    const uint32_t v = i < a.n ? a.item_points[i] : 0u;
-    s_part[t] = v;
+    const uint32_t i = lo + t, v = v_next;
+    { const uint32_t np = min(np_next, a.max_pairs); rep += np; drop += np > ns_next ? np - ns_next : 0u; }
+    const uint32_t i2 = i + 1024;
+    v_next = i2 < a.n ? a.item_points[i2] : 0u;
+    np_next = 0; ns_next = 0;
+    if (a.n_surv && i2 < a.n) { np_next = a.n_pairs[i2]; ns_next = a.n_surv[i2]; }
+    uint32_t incl = v;
+    for (uint32_t d = 1; d < 64; d <<= 1) { const uint32_t x = __shfl_up(incl, d); if (lane >= d) incl += x; }
+    if (lane == 63) s_w[wave] = incl;
     __syncthreads();
-    for (uint32_t d = 1; d < 1024; d <<= 1) {                 // inclusive scan (Hillis-Steele)
-      const uint32_t x = t >= d ? s_part[t - d] : 0u;
-      __syncthreads();
-      s_part[t] += x;
-      __syncthreads();
-    }
-    const uint32_t carry = s_carry;
-    if (i < a.n) a.item_points[i] = carry + s_part[t] - v;
-    __syncthreads();
-    if (t == 1023) s_carry = carry + s_part[1023];
+    uint32_t before = 0, tile = 0;
+    for (uint32_t w = 0; w < 16; w++) { const uint32_t c = s_w[w]; before += w < wave ? c : 0u; tile += c; }
+    if (i < a.n) a.item_points[i] = carry + before + incl - v;
+    carry += tile;
     __syncthreads();
   }
-  if (t == 0) a.out[0] = s_carry;
+  if (rep) atomicAdd(&s_rep, rep);
+  if (drop) atomicAdd(&s_drop, drop);
+  __syncthreads();
+  if (t == 0) {
+    a.out[0] = carry;
+    if (a.n_surv) { a.out[1] += s_rep; a.out[3] += s_drop; }
+  }
 }
 
 // the kept pairs of interleaving blockIdx.x, in pair order, to staging[item_points[it] ..)
@@ -214,18 +228,27 @@ __global__ __launch_bounds__(256) void k3_q_probe(const K3QueueArgs a) {
 }
 
 // which candidates are LIVE: not explored, and the first of this dequeue with its flipped pair.  Two dependent reads of the
-// explored-pair table per candidate: done by the whole grid, the verdict left in bit 31 of cand_slot (slots are below 2^28), so
-// that the one workgroup of k3_q_take only streams that array.
+// explored-pair table per candidate: done by the whole grid, the verdict left in bit 31 of cand_slot (slots are below 2^28), and
+// the live candidates of every workgroup counted (blk_live), so that k3_q_take's workgroups know their ranks without a walk.
 constexpr uint32_t Q_LIVE = 0x80000000u;
 __global__ __launch_bounds__(256) void k3_q_live(const K3QueueArgs a) {
+  __shared__ uint32_t s_w[4];
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= a.n_cand) return;
-  const uint32_t s = a.cand_slot[j];
-  if (s == 0xFFFFFFFFu) { a.cand_slot[j] = 0x7FFFFFFFu; return; }        // (table full: reported by k3_q_probe; never live)
-  const PairEntry* e = a.table + (s >> 1);
-  const bool live = !(__atomic_load_n(&e->state[s & 1], __ATOMIC_RELAXED) & PE_EXPLORED) &&
-                    __atomic_load_n(&e->pop[s & 1], __ATOMIC_RELAXED) == q_stamp(a.round, j);
-  if (live) a.cand_slot[j] = s | Q_LIVE;
+  bool live = false;
+  if (j < a.n_cand) {
+    const uint32_t s = a.cand_slot[j];
+    if (s == 0xFFFFFFFFu) a.cand_slot[j] = 0x7FFFFFFFu;                  // (table full: reported by k3_q_probe; never live)
+    else {
+      const PairEntry* e = a.table + (s >> 1);
+      live = !(__atomic_load_n(&e->state[s & 1], __ATOMIC_RELAXED) & PE_EXPLORED) &&
+             __atomic_load_n(&e->pop[s & 1], __ATOMIC_RELAXED) == q_stamp(a.round, j);
+      if (live) a.cand_slot[j] = s | Q_LIVE;
+    }
+  }
+  const unsigned long long m = __ballot(live);
+  if ((threadIdx.x & 63u) == 0) s_w[threadIdx.x >> 6] = (uint32_t)__popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) a.blk_live[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
 }
 
 // One workgroup walks the candidates in order: the first `want` live ones are taken.  out[1] = taken, out[2] = consumed (the
@@ -239,43 +262,43 @@ __global__ __launch_bounds__(256) void k3_q_compact(const QRange* ranges, uint32
   for (uint32_t i = threadIdx.x; i < g.count; i += blockDim.x) dst[dst_base + g.prefix + i] = src[g.start + i];
 }
 
-__global__ __launch_bounds__(1024) void k3_q_take(const K3QueueArgs a) {
-  __shared__ uint32_t s_wave[16];          // live candidates per wave of the current chunk
-  __shared__ uint32_t s_have, s_consumed;
+// (same grid as k3_q_live)  The candidates in order: the first `want` live ones are taken.  A workgroup's first rank is the sum of
+// the workgroups' counts before it.  out[1] = taken, out[2] = consumed (the index after the last one taken, or n_cand).
+__global__ __launch_bounds__(256) void k3_q_take(const K3QueueArgs a) {
+  __shared__ uint32_t s_w[4], s_sum[4];
   const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-  if (t == 0) { s_have = 0; s_consumed = a.n_cand; }
-  __syncthreads();
-  for (uint32_t lo = 0; lo < a.n_cand; lo += 1024) {
-    const uint32_t have = s_have;
-    if (have >= a.want) break;                               // (workgroup-uniform)
-    const uint32_t j = lo + t;
-    bool live = false;
-    uint32_t s = 0;
-    if (j < a.n_cand) {
-      const uint32_t cs = a.cand_slot[j];
-      live = (cs & Q_LIVE) != 0;
-      s = cs & ~Q_LIVE;
-    }
-    // rank of a live candidate among the chunk's live ones: a ballot within the wave, sixteen wave counts through LDS
-    const unsigned long long m = __ballot(live);
-    if (lane == 0) s_wave[wave] = (uint32_t)__popcll(m);
-    __syncthreads();
-    uint32_t before = 0, chunk = 0;
-    for (uint32_t w = 0; w < 16; w++) { const uint32_t c = s_wave[w]; before += w < wave ? c : 0u; chunk += c; }
-    const uint32_t rank = have + before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-    if (live && rank < a.want) {
-      const QPoint q = a.pool[q_cand_index(a.ranges, a.n_ranges, j)];
-      DporItem it;
-      it.src = q.src; it.branch = q.branch; it.later = q.later; it.earlier = q.earlier; it.pad = 0;
-      a.items[rank] = it;
-      atomicOr(&a.table[s >> 1].state[s & 1], PE_EXPLORED);        // setExplored(maxIndex, (e1, e2)) (:1170-1172)
-      if (rank + 1 == a.want) s_consumed = j + 1;
-    }
-    __syncthreads();
-    if (t == 0) s_have = min(have + chunk, a.want);
-    __syncthreads();
+  uint32_t part = 0;
+  for (uint32_t b = t; b < blockIdx.x; b += 256) part += a.blk_live[b];
+  for (uint32_t d = 1; d < 64; d <<= 1) { const uint32_t x = __shfl_up(part, d); if (lane >= d) part += x; }      // inclusive, per wave
+  if (lane == 63) s_sum[wave] = part;
+  const uint32_t j = blockIdx.x * 256 + t;
+  bool live = false;
+  uint32_t s = 0;
+  if (j < a.n_cand) {
+    const uint32_t cs = a.cand_slot[j];
+    live = (cs & Q_LIVE) != 0;
+    s = cs & ~Q_LIVE;
   }
-  if (t == 0) { a.out[1] = s_have; a.out[2] = s_consumed; }
+  const unsigned long long m = __ballot(live);
+  if (lane == 0) s_w[wave] = (uint32_t)__popcll(m);
+  __syncthreads();
+  const uint32_t first = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+  uint32_t before = 0, mine = 0;
+  for (uint32_t w = 0; w < 4; w++) { const uint32_t c = s_w[w]; before += w < wave ? c : 0u; mine += c; }
+  const uint32_t rank = first + before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+  if (live && rank < a.want) {
+    const QPoint q = a.pool[q_cand_index(a.ranges, a.n_ranges, j)];
+    DporItem it;
+    it.src = q.src; it.branch = q.branch; it.later = q.later; it.earlier = q.earlier; it.pad = 0;
+    a.items[rank] = it;
+    atomicOr(&a.table[s >> 1].state[s & 1], PE_EXPLORED);        // setExplored(maxIndex, (e1, e2)) (:1170-1172)
+    if (rank + 1 == a.want) a.out[2] = j + 1;
+  }
+  if (t == 0 && blockIdx.x + 1 == gridDim.x) {
+    const uint32_t total = first + mine;
+    a.out[1] = min(total, a.want);
+    if (total < a.want) a.out[2] = a.n_cand;
+  }
 }
 
 }  // namespace demi
