@@ -74,7 +74,7 @@ def _seq_digest(verdicts):
     return int(np.bitwise_xor.reduce(x))
 
 
-def bench_dpor(ctx_device, cpu_baseline=True, batch=16384, orders=("rounds", "reference_order")):
+def bench_dpor(ctx_device, cpu_baseline=True, batch=16384, orders=("rounds", "reference_order"), rounds_batch=32768):
     """BASELINE config 3: the whole bounded DPOR exploration of raft5 (depth 30, Start x 5 + Send x 5) - from round 6 on the
     workload that FINDS the seeded bug (apps.raft5_dpor_config3 says what changed and why).  `value` is the rate in the
     REFERENCE order - the order whose explored set and found-violation set are DPORwHeuristics' own - with the ROUNDS order
@@ -88,7 +88,10 @@ def bench_dpor(ctx_device, cpu_baseline=True, batch=16384, orders=("rounds", "re
     out = {"metric": "interleavings explored/sec, DPORwHeuristics bounded exploration (raft5, depth 30)", "unit": "interleavings/s",
            "config": {"workload": "raft5-synth (config 2's rows; election budgets 1,1,1,0,0), Start x 5 + Send(Bootstrap) x 5, depth_bound 30, "
                                   "prioritizePendingUponDivergence, trackHistory, stopIfViolationFound = false, explored until the "
-                                  "backtrack queue is empty", "batch": batch}}
+                                  "backtrack queue is empty", "batch": batch, "rounds_batch": rounds_batch,
+                       "note": "ROUNDS of rounds_batch backtrack points (the width is the caller's: a k3_dpor launch is as long as one "
+                               "interleaving whatever its width, profiles/r06_config5_round_width_sweep.txt); the reference's order "
+                               "speculates `batch` wide"}}
     runs = {}
     viol_sets = {}
     ref_verdicts = None
@@ -102,7 +105,7 @@ def bench_dpor(ctx_device, cpu_baseline=True, batch=16384, orders=("rounds", "re
         ctx.model_load(model.to_struct())
         ctx.model_specialize()
         ctx.dpor_load(ev)
-        srch = T.DporSearch(batch, 1 << 20, 0, 1, T.DPOR_ORDER_REFERENCE if ref else T.DPOR_ORDER_ROUNDS)
+        srch = T.DporSearch(batch if ref else rounds_batch, 1 << 20, 0, 1, T.DPOR_ORDER_REFERENCE if ref else T.DPOR_ORDER_ROUNDS)
         # a first whole exploration outside the timing: compilation for this table, the device arenas (a long-lived demi_ctx
         # keeps them); every call is a fresh exploration
         ctx.dpor_explore(par, srch)
@@ -216,7 +219,7 @@ def bench_dpor(ctx_device, cpu_baseline=True, batch=16384, orders=("rounds", "re
             # (the oracle's reference order runs one interleaving at a time: a speculation `batch` wide costs a host thousands of
             # discarded executions per committed one)
             # discarded executions per committed one) - and a bounded sample of it: the first 2^14 interleavings
-            srch = T.DporSearch(1 if ref else batch, 1 << 14 if ref else 1 << 20, 0, 1, T.DPOR_ORDER_ROUNDS)
+            srch = T.DporSearch(1 if ref else rounds_batch, 1 << 14 if ref else 1 << 20, 0, 1, T.DPOR_ORDER_ROUNDS)
             t = time.perf_counter()
             v, plen, rounds, vt, st, secs = O.dpor_explore(model, ev, par, srch, n_threads=1 if ref else cores)
             dt = time.perf_counter() - t
@@ -435,7 +438,8 @@ def _counters_profile(name):
     return None
 
 
-def bench_config5(ctx_device, cpu_baseline=True, max_interleavings=None, batch=16384, ranks=None, small=True, reference_order=True):
+def bench_config5(ctx_device, cpu_baseline=True, max_interleavings=None, batch=65536, ranks=None, small=True, reference_order=True,
+                  reference_batch=16384):
     """BASELINE config 5: shuffle8-synth as a pipeline of three jobs (8 actors, 3 classes), bounded DPOR exploration with a budget
     of 2^20 interleavings (apps.shuffle8_dpor_config5; shuffle8_config5_large says why more externals do not enlarge the one-job exploration and
     chained jobs do).  With N ranks: demi_dpor_explore with the communicator - a round's backtrack points dealt over the ranks
@@ -446,6 +450,8 @@ def bench_config5(ctx_device, cpu_baseline=True, max_interleavings=None, batch=1
     from demi_amd import _native, types as T
     from demi_amd.apps import shuffle8_config5, shuffle8_dpor_config5
     ranks = ranks or Ranks()
+    if ranks.world > 1:
+        batch = min(batch, 16384)     # (the multi-rank rounds stage at most 2^21 backtrack points per round - DESIGN section 6)
     model, dpor_events, par, budget = shuffle8_dpor_config5()
     depth = int(par.depth_bound)
     if max_interleavings is None:
@@ -503,11 +509,11 @@ def bench_config5(ctx_device, cpu_baseline=True, max_interleavings=None, batch=1
     if ranks.world == 1 and reference_order:
         # the same budget in the REFERENCE order: the order whose 2^20 interleavings are the ones DPORwHeuristics itself would
         # explore under this budget (ROUNDS takes the 2^20 from another frontier), single-rank by construction
-        rs = T.DporSearch(batch, max_interleavings, 0, 1, T.DPOR_ORDER_REFERENCE)
+        rs = T.DporSearch(reference_batch, max_interleavings, 0, 1, T.DPOR_ORDER_REFERENCE)
         try:
             # (untimed: this order's own staging and kernels with a small budget - the trace arena and the explored-pair table
             # of the full budget exist since the ROUNDS run above; the whole exploration takes seconds in this order)
-            ctx.dpor_explore(par, T.DporSearch(batch, min(max_interleavings, 1 << 15), 0, 1, T.DPOR_ORDER_REFERENCE))
+            ctx.dpor_explore(par, T.DporSearch(reference_batch, min(max_interleavings, 1 << 15), 0, 1, T.DPOR_ORDER_REFERENCE))
             t = time.perf_counter()
             rv, rplen, _rr, _rt, rst = ctx.dpor_explore(par, rs)
             rdt = time.perf_counter() - t

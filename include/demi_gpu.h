@@ -608,7 +608,10 @@ int demi_dpor_batch(demi_ctx* ctx, const demi_dpor_trace_entry* prefixes, const 
  * ROUNDS: a round pops up to `batch` unexplored points, runs them as one launch and absorbs their racing pairs in pop
  *   order.  batch = 1 is the reference's order; the explored-pair heuristic (ExploredTacker, AuxilaryTypes.scala:209-246)
  *   makes the SET of explored interleavings depend on the order, so a wider round explores a slightly different set
- *   (DESIGN.md section 4 K3 has the measured difference).
+ *   (DESIGN.md section 4 K3 has the measured difference).  How wide: a launch takes about as long as ONE interleaving whatever
+ *   its width, so rounds should be as wide as the queue fills them - 32 768 .. 65 536 on an MI355X (config 5's 2^20 interleavings:
+ *   0.103 / 0.074 / 0.065 / 0.079 s in rounds of 16 384 / 32 768 / 65 536 / 131 072); beyond that the
+ *   deepest-first order spends the width on shallow points.
  * REFERENCE: exactly the sequence of interleavings of batch = 1 - DPORwHeuristics' own depth-first order
  *   (:1142-1185) with PriorityQueue ties in creation order - whatever `batch` is.  The device runs ahead speculatively
  *   (a ROUNDS exploration of width `batch` whose results are cached by next-trace identity) and the host commits the

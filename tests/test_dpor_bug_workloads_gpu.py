@@ -91,6 +91,21 @@ def test_config3_in_rounds_is_the_oracles_exploration_in_rounds(config3_runs, or
         assert len(v) == 297396 and st.exhausted and int(np.count_nonzero(v["flags"] & T.V_VIOLATION)) == 7237
 
 
+def test_config3_in_the_rounds_bench_py_times_is_the_oracles_exploration(oracle):
+    """bench.py's ROUNDS record of config 3 uses rounds of 32 768 (round 6's width sweep): the whole exploration against the oracle's
+    with the same width - verdicts, prefix lengths, round sizes."""
+    model, ev, par = raft5_dpor_config3()
+    budget, batch = (1200, 256) if EMU else (1 << 20, 32768)
+    ctx = _ctx(model, ev)
+    v, plen, rr, _vt, st = ctx.dpor_explore(par, T.DporSearch(batch, budget, 0, 1, T.DPOR_ORDER_ROUNDS))
+    ctx.close()
+    cpu = oracle.dpor_explore(model, ev, par, T.DporSearch(batch, budget, 0, 1, T.DPOR_ORDER_ROUNDS), n_threads=os.cpu_count() or 1)
+    assert len(cpu[0]) == len(v) and (cpu[0] == v).all() and (cpu[1] == plen).all() and (cpu[2] == rr).all()
+    assert bool(cpu[4].exhausted) == bool(st.exhausted)
+    if not EMU:
+        assert len(v) == 298255 and st.exhausted and int(np.count_nonzero(v["flags"] & T.V_VIOLATION)) == 6955
+
+
 def test_the_two_orders_found_violation_sets(config3_runs):
     """What relates ROUNDS to the reference's order on the exhausted config 3.  Both flip every racing pair exactly once
     (ExploredTacker is global), but a pair is flipped in the context in which an order happens to reach it first, so the explored
@@ -115,14 +130,16 @@ def test_the_two_orders_found_violation_sets(config3_runs):
 CONFIG3_SETS = (2106, 4727, 1563)
 
 
-def test_config5_in_rounds_against_the_oracle(oracle):
-    """The 2^20-interleaving exploration bench.py times: head against the oracle's exploration, and interleavings from all over it
-    (every round's ends, the last round's tail, random ones) re-executed one by one by the oracle from nothing but their next
-    traces (demi_dpor_explored) - verdict and trace.  Violating interleavings are among the samples."""
+@pytest.mark.parametrize("width", [16384, 65536])
+def test_config5_in_rounds_against_the_oracle(oracle, width):
+    """The 2^20-interleaving exploration bench.py times (in ROUNDS of 65 536 since round 6's width sweep; 16 384 before): head
+    against the oracle's exploration with the same width, and interleavings from all over it (every round's ends, the last round's
+    tail, random ones) re-executed one by one by the oracle from nothing but their next traces (demi_dpor_explored) - verdict and
+    trace.  Violating interleavings are among the samples."""
     model, ev, par, budget = shuffle8_dpor_config5()
-    batch, head, n_random = 16384, 1 << 16, 3000
+    batch, head, n_random = width, (1 << 16) if width <= 16384 else (1 << 17), 3000
     if EMU:
-        budget, batch, head, n_random = 1500, 128, 500, 30
+        budget, batch, head, n_random = 1500, 128 if width <= 16384 else 512, 500, 30
     ctx = _ctx(model, ev)
     v, plen, rounds, _vt, st = ctx.dpor_explore(par, T.DporSearch(batch, budget, 0, 1, T.DPOR_ORDER_ROUNDS))
     n = len(v)
