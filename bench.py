@@ -108,10 +108,13 @@ def bench_dpor(ctx_device, cpu_baseline=True, batch=16384, orders=("rounds", "re
         srch = T.DporSearch(batch if ref else rounds_batch, 1 << 20, 0, 1, T.DPOR_ORDER_REFERENCE if ref else T.DPOR_ORDER_ROUNDS)
         # a first whole exploration outside the timing: compilation for this table, the device arenas (a long-lived demi_ctx
         # keeps them); every call is a fresh exploration
-        ctx.dpor_explore(par, srch)
+        # (the output arrays are the caller's, as a JVM host's are: allocated and touched before the timed call)
+        bufs = _native.Context.dpor_buffers(srch.max_interleavings)
+        ctx.dpor_explore(par, srch, buffers=bufs)
         t = time.perf_counter()
-        verdicts, plen, rounds, vtrace, st = ctx.dpor_explore(par, srch)
+        verdicts, plen, rounds, vtrace, st = ctx.dpor_explore(par, srch, buffers=bufs)
         dt = time.perf_counter() - t
+        verdicts, plen = verdicts.copy(), plen.copy()
         vh = np.unique(verdicts["hash"][(verdicts["flags"] & T.V_VIOLATION) != 0])
         viol_sets[name] = set(vh.tolist())
         if ref:
@@ -467,12 +470,14 @@ def bench_config5(ctx_device, cpu_baseline=True, max_interleavings=None, batch=6
     # explored-pair table are allocated when a call first needs them - the same budget, so that the timed call allocates nothing;
     # every call is a fresh exploration)
     warm = T.DporSearch(batch, max_interleavings, 0, 1, T.DPOR_ORDER_ROUNDS)
-    ctx.dpor_explore(par, warm)
+    bufs = _native.Context.dpor_buffers(max_interleavings)        # (the caller's output arrays, as a JVM host's are: touched before the timed call)
+    ctx.dpor_explore(par, warm, buffers=bufs)
     setup_s = time.perf_counter() - t
     ranks.barrier()
     t = time.perf_counter()
-    verdicts, plen, rounds, vtrace, st = ctx.dpor_explore(par, srch)
+    verdicts, plen, rounds, vtrace, st = ctx.dpor_explore(par, srch, buffers=bufs)
     dt = ranks.max(time.perf_counter() - t)
+    verdicts, plen, rounds = verdicts.copy(), plen.copy(), rounds.copy()
     n_il = len(verdicts)
     digest = "%016x" % _seq_digest(verdicts)
     per_il = 4.0 * float(np.mean(plen)) + 8.0 + 12.0 * (int(st.backtrack_points) / max(1, n_il))
@@ -513,9 +518,9 @@ def bench_config5(ctx_device, cpu_baseline=True, max_interleavings=None, batch=6
         try:
             # (untimed: this order's own staging and kernels with a small budget - the trace arena and the explored-pair table
             # of the full budget exist since the ROUNDS run above; the whole exploration takes seconds in this order)
-            ctx.dpor_explore(par, T.DporSearch(reference_batch, min(max_interleavings, 1 << 15), 0, 1, T.DPOR_ORDER_REFERENCE))
+            ctx.dpor_explore(par, T.DporSearch(reference_batch, min(max_interleavings, 1 << 15), 0, 1, T.DPOR_ORDER_REFERENCE), buffers=bufs)
             t = time.perf_counter()
-            rv, rplen, _rr, _rt, rst = ctx.dpor_explore(par, rs)
+            rv, rplen, _rr, _rt, rst = ctx.dpor_explore(par, rs, buffers=bufs)
             rdt = time.perf_counter() - t
             rvh = np.unique(rv["hash"][(rv["flags"] & T.V_VIOLATION) != 0])
             out["reference_order"] = {"value": len(rv) / rdt, "seconds": rdt, "interleavings": len(rv), "exhausted": bool(rst.exhausted),

@@ -430,19 +430,38 @@ class Context:
             [(int(st.pass_distance[i]), int(st.pass_mcs_len[i])) for i in range(min(16, st.passes))], \
             (vt[:st.violation_len].copy() if st.violation_len else None), st
 
-    def dpor_explore(self, params, search):
-        """The whole exploration natively: returns (verdicts, prefix_len, rounds, first violating trace, stats)."""
+    @staticmethod
+    def dpor_buffers(max_interleavings):
+        """Output arrays for dpor_explore(..., buffers=...) - what a host that calls demi_dpor_explore repeatedly keeps (a JVM's
+        arrays): allocated and touched once, so that a call's time is the library's and not the page faults of fresh arrays."""
+        import numpy as np
+        cap = int(max_interleavings)
+        b = (np.zeros(cap, dtype=T.VERDICT_DTYPE), np.zeros(cap, dtype=np.uint32), np.zeros(cap, dtype=np.uint32),
+             np.zeros(T.DPOR_MAX_TRACE, dtype=T.DPOR_TRACE_DTYPE))
+        for a in b:
+            a.view(np.uint8)[::4096] = 0          # (np.zeros maps its pages lazily)
+        return b
+
+    def dpor_explore(self, params, search, buffers=None):
+        """The whole exploration natively: returns (verdicts, prefix_len, rounds, first violating trace, stats).  With `buffers`
+        (dpor_buffers) the results are VIEWS of those arrays - valid until the next call that uses them."""
         import numpy as np
         cap = search.max_interleavings
-        verdicts = np.zeros(cap, dtype=T.VERDICT_DTYPE)
-        plen = np.zeros(cap, dtype=np.uint32)
-        rounds = np.zeros(cap, dtype=np.uint32)
-        vt = np.zeros(T.DPOR_MAX_TRACE, dtype=T.DPOR_TRACE_DTYPE)
+        if buffers is not None:
+            verdicts, plen, rounds, vt = buffers
+            assert len(verdicts) >= cap and len(plen) >= cap and len(rounds) >= cap
+        else:
+            verdicts = np.zeros(cap, dtype=T.VERDICT_DTYPE)
+            plen = np.zeros(cap, dtype=np.uint32)
+            rounds = np.zeros(cap, dtype=np.uint32)
+            vt = np.zeros(T.DPOR_MAX_TRACE, dtype=T.DPOR_TRACE_DTYPE)
         vl = C.c_uint32(0)
         stats = T.DporStats()
         self._check(lib().demi_dpor_explore(self._h, C.byref(params), C.byref(search), verdicts.ctypes.data,
                                             plen.ctypes.data, rounds.ctypes.data, vt.ctypes.data, C.byref(vl), C.byref(stats)))
         n = int(stats.interleavings)
+        if buffers is not None:
+            return verdicts[:n], plen[:n], rounds[:int(stats.launches)], vt[:vl.value], stats
         return verdicts[:n].copy(), plen[:n].copy(), rounds[:int(stats.launches)].copy(), vt[:vl.value].copy(), stats
 
     def dpor_explored(self, index):

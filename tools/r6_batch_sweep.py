@@ -16,11 +16,12 @@ def run(name, model, events, par, budget, widths):
         ctx.model_load(model.to_struct()); ctx.model_specialize(); ctx.dpor_load(events)
         s = T.DporSearch(batch, budget, 0, 1, T.DPOR_ORDER_ROUNDS)
         try:
-            ctx.dpor_explore(par, s)
+            bufs = _native.Context.dpor_buffers(budget)
+            ctx.dpor_explore(par, s, buffers=bufs)
             best = None
             for _ in range(3):
                 t = time.perf_counter()
-                v, plen, rounds, vt, st = ctx.dpor_explore(par, s)
+                v, plen, rounds, vt, st = ctx.dpor_explore(par, s, buffers=bufs)
                 dt = time.perf_counter() - t
                 if best is None or dt < best[0]:
                     best = (dt, float(st.kernel_ms), int(st.launches))
