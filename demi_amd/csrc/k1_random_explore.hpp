@@ -54,9 +54,19 @@ struct K1MultiArgs : K1Args {
   uint32_t epc;                 // executions per candidate: execution k of every candidate uses seed_base + k (or seeds[k])
   uint32_t* cand_flags;         // [n_cand], zeroed by the host: bit 0 = some execution violated, bit 1 = some execution aborted on a capacity
   uint32_t populate_all;        // 1 = `exists` as given; 0 = the actors the CANDIDATE Start()s (what trace_load derives)
+  uint32_t lanes_per_wave;      // 0 = 64; see SPREAD below: the first lanes_per_wave lanes of every wave run executions
 };
-template <bool MULTI> struct K1ArgsOf { typedef K1Args type; };
-template <> struct K1ArgsOf<true> { typedef K1MultiArgs type; };
+// SPREAD variant (round 6): a launch far smaller than the chip on as many waves as it has executions.  A wave's iteration costs what
+// the UNION of its lanes' paths costs (~780 vector instructions with 56 lanes delivering, ~240 for a lane alone: DESIGN section 4
+// K1), so a launch of 100 executions is faster as 100 waves of one lane than as two full waves.  Only the first lanes_per_wave
+// lanes of a wave ever claim work; the others idle through the wave's cooperative steps.  Its own struct and its own template
+// parameter: every other variant keeps its kernel-argument segment and its instructions.
+struct K1SpreadArgs : K1Args {
+  uint32_t lanes_per_wave;      // 1 .. 64
+};
+template <bool MULTI, bool SPREAD = false> struct K1ArgsOf { typedef K1Args type; };
+template <> struct K1ArgsOf<true, false> { typedef K1MultiArgs type; };
+template <> struct K1ArgsOf<false, true> { typedef K1SpreadArgs type; };
 
 enum : int { PH_IDLE = 0, PH_INJECT = 1, PH_DISPATCH = 2, PH_FINISH = 3 };
 
@@ -180,8 +190,9 @@ __host__ __device__ inline size_t k1_lds_bytes(uint32_t code_len, uint32_t n_ev,
 // the candidate's mask in LDS before it builds the batch table, lane k runs execution k - no refill, a lane has one execution -
 // and a violating execution sets the candidate's flag.  Verdict cand * epc + k is what the plain kernel returns for
 // trace_load(candidate's events) and seed_base + k.
-template <bool REC, bool FIFO = false, bool CARRY = false, bool REBIN = false, bool MULTI = false>
-__global__ K1_LAUNCH_BOUNDS void k1_random_explore(const typename K1ArgsOf<MULTI>::type args) {
+template <bool REC, bool FIFO = false, bool CARRY = false, bool REBIN = false, bool MULTI = false, bool SPREAD = false>
+__global__ K1_LAUNCH_BOUNDS void k1_random_explore(const typename K1ArgsOf<MULTI, SPREAD>::type args) {
+  static_assert(!SPREAD || (!REC && !CARRY && !REBIN && !MULTI), "the spread variant is the plain per-execution kernel");
   static_assert(!REBIN || (!REC && !FIFO), "the re-binned kernel exists for the non-recording FullyRandom variant");
   static_assert(!MULTI || (!REC && !CARRY && !REBIN), "a frontier of candidates runs the non-recording, per-execution-seed kernel");
   static_assert(!BIG_TU || !REBIN, "the re-binned kernel packs an 8 x 8 reach row: tables of up to 8 actors");
@@ -191,9 +202,12 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const typename K1ArgsOf<MULTI
   // MULTI: which candidate this workgroup evaluates, and which of its executions this lane runs
   uint32_t m_cand = 0, m_exec = 0;
   if constexpr (MULTI) {
-    const uint32_t m_wgpc = (args.epc + blockDim.x - 1) / blockDim.x;
+    // (lanes_per_wave < 64: a candidate's executions on the first lanes of more waves - SPREAD above; 64: lane k = execution k)
+    const uint32_t m_lpw = args.lanes_per_wave ? args.lanes_per_wave : 64u;
+    const uint32_t m_eff = (blockDim.x >> 6) * m_lpw;                    // executions per workgroup
+    const uint32_t m_wgpc = (args.epc + m_eff - 1) / m_eff;
     m_cand = blockIdx.x / m_wgpc;
-    m_exec = (blockIdx.x % m_wgpc) * blockDim.x + threadIdx.x;
+    m_exec = (threadIdx.x & 63u) < m_lpw ? (blockIdx.x % m_wgpc) * m_eff + (threadIdx.x >> 6) * m_lpw + (threadIdx.x & 63u) : 0xFFFFFFFFu;
     // the candidate's events: counted by every thread (t.E is a per-thread value), compacted in place by thread 0 below
     const uint64_t* cm = args.cand_masks + 4 * (size_t)m_cand;
     uint32_t e_cnt = 0;
@@ -669,17 +683,21 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const typename K1ArgsOf<MULTI
         }
         if (__ballot(ph != PH_IDLE) == 0) break;
       } else {
-        const uint64_t idle = __ballot(ph == PH_IDLE);
+        // (SPREAD: only the first lanes_per_wave lanes take work, and a claim is as many indices)
+        uint32_t claim = K1_BATCH;
+        bool may_claim = true;
+        if constexpr (SPREAD) { claim = args.lanes_per_wave; may_claim = lane < args.lanes_per_wave; }
+        const uint64_t idle = __ballot(ph == PH_IDLE && may_claim);
         if (idle != 0 && !exhausted) {                     // wave-uniform
           const uint32_t want = (uint32_t)__popcll(idle);
           const uint64_t have = b_end - b_next;
           uint64_t got = 0;
           if (have < want) {
-            // one claim always suffices: at most 64 lanes ask and a batch holds 64 indices
-            if (lane == 0) got = atomicAdd(args.work_counter, (unsigned long long)K1_BATCH);
+            // one claim always suffices: at most 64 (SPREAD: lanes_per_wave) lanes ask and a batch holds as many indices
+            if (lane == 0) got = atomicAdd(args.work_counter, (unsigned long long)claim);
             got = __shfl(got, 0);
           }
-          if (ph == PH_IDLE) {
+          if (ph == PH_IDLE && may_claim) {
             const uint32_t rank = (uint32_t)__popcll(idle & ((1ULL << lane) - 1));
             const uint64_t my = (rank < have) ? (b_next + rank) : (got + (rank - have));
             if (my < n_units) {
@@ -690,7 +708,7 @@ __global__ K1_LAUNCH_BOUNDS void k1_random_explore(const typename K1ArgsOf<MULTI
               } else sched = my;
             }
           }
-          if (have < want) { b_next = got + (want - have); b_end = got + K1_BATCH; }
+          if (have < want) { b_next = got + (want - have); b_end = got + claim; }
           else b_next += want;
           if (b_next >= n_units) exhausted = true;
         }

@@ -112,7 +112,6 @@ struct K3PairArgs {
   // the survivors' table loads (3) and changes nothing - the host times it beside the real launch of the same round
   uint32_t dry;
   unsigned long long* dbg;             // diagnostic: [0] survivors, [1] not at home, [2] atomicOr, [3] atomicMax (null: not counted)
-  uint32_t fresh;                      // the pre-checks in front of insert's atomics read at agent scope (see k3_pairs_insert)
 };
 
 __device__ __forceinline__ unsigned long long cand_pack(uint32_t round, uint32_t branch, unsigned long long ordinal) {
@@ -295,16 +294,8 @@ __global__ __launch_bounds__(256) void k3_pairs_insert(const K3PairArgs a) {
     // where it executes.  Both updates are monotone (the explored bit is only ever set, the candidate only ever raised), so
     // an ordinary load that already shows the result makes the atomic redundant; a stale line only means one atomic more.
     PairEntry* const e1 = a.table + (s1 >> 1);
-    uint32_t seen_state = at_home ? ((s1 & 1) ? hs.y : hs.x) : e1->state[s1 & 1];
-    unsigned long long seen_cand = at_home ? ((s2 & 1) ? hc.y : hc.x) : e1->cand[s2 & 1];
-    if (a.fresh) {
-      // An ordinary load is answered by the XCD's own L2, and a line that got there early in the launch stays there while the
-      // other seven XCDs' atomics raise the value in memory: every later instance of the pair on this XCD sees the previous
-      // round's candidate and pays an atomic that changes nothing.  An agent-scope load sees what the atomics have made of it.
-      if (!(seen_state & PE_EXPLORED)) seen_state = __hip_atomic_load(&e1->state[s1 & 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (seen_cand < cand_pack(a.round, p.branch, (unsigned long long)it * a.max_pairs + k))
-        seen_cand = __hip_atomic_load(&e1->cand[s2 & 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    const uint32_t seen_state = at_home ? ((s1 & 1) ? hs.y : hs.x) : e1->state[s1 & 1];
+    const unsigned long long seen_cand = at_home ? ((s2 & 1) ? hc.y : hc.x) : e1->cand[s2 & 1];
     if (!(seen_state & PE_EXPLORED)) {
       c_or++;
       const uint32_t old = atomicOr(&e1->state[s1 & 1], PE_EXPLORED);      // setExplored(branch, (earlier, later))

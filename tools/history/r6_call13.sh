@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 6, call 13: the K3 rounds after the same-address atomics left k3_pairs_insert, getNext's take became a grid and bench.py moved to
+# Round 6, call 13 (run twice: after the K3 round work, and again - the evidence run - after the reference order's launch reordering, the pinned staging and the callers' output arrays):
 # ROUNDS of 65 536 (config 5) / 32 768 (config 3): GPU suite, smoke, the secondary records' profiles re-taken (new digests), the bench line.
 mkdir -p gpurun_out
 python __graft_entry__.py > gpurun_out/r06_call13_build.log 2>&1
