@@ -25,17 +25,24 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_emulated(ids, threads=4, lane_order=None, timeout=1500):
+def run_emulated(ids, threads=4, lane_order=None, timeout=1500, extra_env=None, only=None):
+    """extra_env: further variables - for the ids listed in `only` (run as a second pytest process), or for all of them."""
     env = dict(os.environ, DEMI_EMU="1", W64_THREADS=str(threads))
     env.pop("DEMI_JIT_DEFINES", None)
     if lane_order:
         env["W64_LANE_ORDER"] = lane_order
-    cmd = [sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-p", "no:cacheprovider", "-x"] + ["tests/" + i for i in ids]
-    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
-    tail = (out.stdout + out.stderr)[-4000:]
-    assert out.returncode == 0, tail
-    m = re.search(r"(\d+) passed", out.stdout)
-    assert m and int(m.group(1)) >= len(ids) and "failed" not in out.stdout and "skipped" not in out.stdout, tail
+    groups = [(ids, dict(env, **(extra_env or {})))]
+    if only:
+        groups = [([i for i in ids if i not in only], env), ([i for i in ids if i in only], dict(env, **(extra_env or {})))]
+    for group, genv in groups:
+        if not group:
+            continue
+        cmd = [sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-p", "no:cacheprovider", "-x"] + ["tests/" + i for i in group]
+        out = subprocess.run(cmd, cwd=ROOT, env=genv, capture_output=True, text=True, timeout=timeout)
+        tail = (out.stdout + out.stderr)[-4000:]
+        assert out.returncode == 0, tail
+        m = re.search(r"(\d+) passed", out.stdout)
+        assert m and int(m.group(1)) >= len(group) and "failed" not in out.stdout and "skipped" not in out.stdout, tail
 
 
 def test_emulator_reports_divergent_cross_lane_operations(tmp_path):
@@ -72,6 +79,13 @@ def test_k1_sources_against_the_oracle_on_the_cpu():
                   "test_k1_gpu.py::test_random_programs_interpreter_specialised_and_oracle_agree[1]",
                   "test_blocked_actors_gpu.py::test_k1_parity_with_crashed_actors[0]",
                   "test_invariant_gpu.py::test_random_program_invariants_through_every_kernel[1]"])
+
+
+def test_k1_spread_variant_on_the_cpu():
+    """K1's SPREAD variant (few lanes of many wavefronts for launches far smaller than the chip) and the frontier kernels with
+    lanes_per_wave < 64, interpreter and compiled table, against the plain launch and the oracle."""
+    run_emulated(["test_k1_gpu.py::test_small_launches_on_few_lanes_of_many_waves",
+                  "test_random_ddmin_gpu.py"], extra_env={"DEMI_K1_LANES_PER_WAVE": "3"}, only=["test_random_ddmin_gpu.py"])
 
 
 def test_tables_of_more_than_eight_actors_on_the_cpu():

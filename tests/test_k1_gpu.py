@@ -74,6 +74,31 @@ def test_raft5_parity_all_capacities(gpu_ctx, oracle, p_max):
         assert (g["flags"] & T.V_PENDING_OVF).sum() > 0      # overflow is a verdict, identical on both sides
 
 
+@pytest.mark.parametrize("lanes", [None, 1, 3, 8])
+def test_small_launches_on_few_lanes_of_many_waves(gpu_ctx, oracle, monkeypatch, lanes):
+    """The SPREAD variant of K1 (k1_random_explore.hpp): a launch far smaller than the chip runs on the first
+    lanes of as many wavefronts as it fills.  lanes = None: as the host picks them for each size (on the MI355X 1 lane up to a few
+    thousand schedules, more beyond, the plain launch from ~32 768 on); otherwise forced.  Interpreter and compiled table, against
+    the plain launch (DEMI_K1_NO_SPREAD) and the oracle: the same verdicts whatever a launch's shape."""
+    model, events, lim = raft5_config2()
+    sizes = (1, 100, 1000, 5000, 20000) if lanes is None else (100, 3000)
+    if os.environ.get("DEMI_EMU") == "1":
+        sizes = sizes[:3]
+    for n in sizes:
+        monkeypatch.delenv("DEMI_K1_NO_SPREAD", raising=False)
+        if lanes is None:
+            monkeypatch.delenv("DEMI_K1_LANES_PER_WAVE", raising=False)
+        else:
+            monkeypatch.setenv("DEMI_K1_LANES_PER_WAVE", str(lanes))
+        g, c = both(gpu_ctx, oracle, model, events, n, lim, jit=True)
+        assert_same(g, c)
+        monkeypatch.setenv("DEMI_K1_NO_SPREAD", "1")
+        gpu_ctx.model_specialize()
+        plain = gpu_ctx.random_explore(n, lim, seed_base=SEED_BASE)
+        gpu_ctx.model_specialize(False)
+        assert_same(plain, c)
+
+
 def test_raft3_config1_and_fixed_model(gpu_ctx, oracle):
     model, events, lim = raft3_config1()
     g, c = both(gpu_ctx, oracle, model, events, 100, lim)
