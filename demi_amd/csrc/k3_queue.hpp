@@ -45,7 +45,8 @@ struct K3QueueArgs {
   const uint32_t* n_pairs;               // [n]
   const uint32_t* n_surv;                // [n] pairs the parent filter left (k3_pairs_insert), or nullptr: k3_q_scan's statistics
   const unsigned long long* keep_bits;   // [n][max_pairs / 64]
-  uint32_t* item_points;                 // [n] in: points per interleaving; k3_q_scan turns it into the exclusive prefix
+  uint32_t* item_points;                 // [n] in: points per interleaving; k3_q_scan turns it into the exclusive prefix within its tile of 1 024
+  uint32_t* tile_sum;                    // [ceil(n / 1024)] the tiles' totals, then (k3_q_scan_tiles) their offsets
   uint32_t n, max_pairs, base_id;
   QPoint* staging;                       // [staging_cap] the round's points in creation order
   uint32_t staging_cap;
@@ -70,43 +71,49 @@ __device__ __forceinline__ unsigned long long q_stamp(uint32_t round, uint32_t j
   return ((unsigned long long)round << 32) | (unsigned long long)(0xFFFFFFFFu - j);      // max = this dequeue, lowest candidate index
 }
 
-// exclusive prefix of item_points[0 .. n) in place; the total to out[0].  One workgroup, a tile of 1 024 interleavings per step (a
-// scan within each wave, the sixteen wave sums through LDS; the next tile's loads are issued before this tile's barriers).  The same
-// pass takes the round's statistics: out[1] += racing pairs reported, out[3] += pairs the parent filter dropped (n_surv != nullptr:
-// the device-queue rounds).
+// exclusive prefix of item_points[0 .. n), in two steps: k3_q_scan - one workgroup per tile of 1 024 interleavings - turns its tile's
+// counts into prefixes WITHIN the tile (a scan within each wave, the sixteen wave sums through LDS) and leaves the tile's total;
+// k3_q_scan_tiles - one wavefront - turns the totals into the tiles' offsets and writes the round's total to out[0].  k3_q_emit adds
+// the two.  (One workgroup walking the tiles one after the other was 72 us of a 65 536-wide round.)  k3_q_scan also takes the round's
+// statistics: out[1] += racing pairs reported, out[3] += pairs the parent filter dropped (n_surv != nullptr: the device-queue rounds).
+constexpr uint32_t Q_SCAN_TILE = 1024;
 __global__ __launch_bounds__(1024) void k3_q_scan(const K3QueueArgs a) {
   __shared__ uint32_t s_w[16];
   __shared__ unsigned long long s_rep, s_drop;
   const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
   if (t == 0) { s_rep = 0; s_drop = 0; }
-  uint32_t carry = 0;
+  const uint32_t i = blockIdx.x * Q_SCAN_TILE + t;
+  const uint32_t v = i < a.n ? a.item_points[i] : 0u;
   unsigned long long rep = 0, drop = 0;
-  uint32_t v_next = t < a.n ? a.item_points[t] : 0u, np_next = 0, ns_next = 0;
-  if (a.n_surv && t < a.n) { np_next = a.n_pairs[t]; ns_next = a.n_surv[t]; }
-  for (uint32_t lo = 0; lo < a.n; lo += 1024) {
-    const uint32_t i = lo + t, v = v_next;
-    { const uint32_t np = min(np_next, a.max_pairs); rep += np; drop += np > ns_next ? np - ns_next : 0u; }
-    const uint32_t i2 = i + 1024;
-    v_next = i2 < a.n ? a.item_points[i2] : 0u;
-    np_next = 0; ns_next = 0;
-    if (a.n_surv && i2 < a.n) { np_next = a.n_pairs[i2]; ns_next = a.n_surv[i2]; }
-    uint32_t incl = v;
-    for (uint32_t d = 1; d < 64; d <<= 1) { const uint32_t x = __shfl_up(incl, d); if (lane >= d) incl += x; }
-    if (lane == 63) s_w[wave] = incl;
-    __syncthreads();
-    uint32_t before = 0, tile = 0;
-    for (uint32_t w = 0; w < 16; w++) { const uint32_t c = s_w[w]; before += w < wave ? c : 0u; tile += c; }
-    if (i < a.n) a.item_points[i] = carry + before + incl - v;
-    carry += tile;
-    __syncthreads();
-  }
+  if (a.n_surv && i < a.n) { const uint32_t np = min(a.n_pairs[i], a.max_pairs), ns = a.n_surv[i]; rep = np; drop = np > ns ? np - ns : 0u; }
+  uint32_t incl = v;
+  for (uint32_t d = 1; d < 64; d <<= 1) { const uint32_t x = __shfl_up(incl, d); if (lane >= d) incl += x; }
+  if (lane == 63) s_w[wave] = incl;
+  __syncthreads();
+  uint32_t before = 0, tile = 0;
+  for (uint32_t w = 0; w < 16; w++) { const uint32_t c = s_w[w]; before += w < wave ? c : 0u; tile += c; }
+  if (i < a.n) a.item_points[i] = before + incl - v;
   if (rep) atomicAdd(&s_rep, rep);
   if (drop) atomicAdd(&s_drop, drop);
   __syncthreads();
   if (t == 0) {
-    a.out[0] = carry;
-    if (a.n_surv) { a.out[1] += s_rep; a.out[3] += s_drop; }
+    a.tile_sum[blockIdx.x] = tile;
+    if (a.n_surv) { if (s_rep) atomicAdd(&a.out[1], s_rep); if (s_drop) atomicAdd(&a.out[3], s_drop); }
   }
+}
+// tile_sum[0 .. tiles) -> exclusive offsets in place, the total to out[0].  One wavefront: lane l owns a contiguous chunk of tiles.
+__global__ __launch_bounds__(64) void k3_q_scan_tiles(const K3QueueArgs a) {
+  const uint32_t lane = threadIdx.x;
+  const uint32_t tiles = (a.n + Q_SCAN_TILE - 1) / Q_SCAN_TILE;
+  const uint32_t per = (tiles + 63) / 64;
+  const uint32_t lo = min(lane * per, tiles), hi = min(lo + per, tiles);
+  uint32_t sum = 0;
+  for (uint32_t b = lo; b < hi; b++) sum += a.tile_sum[b];
+  uint32_t incl = sum;
+  for (uint32_t d = 1; d < 64; d <<= 1) { const uint32_t x = __shfl_up(incl, d); if (lane >= d) incl += x; }
+  uint32_t run = incl - sum;
+  for (uint32_t b = lo; b < hi; b++) { const uint32_t v = a.tile_sum[b]; a.tile_sum[b] = run; run += v; }
+  if (lane == 63) a.out[0] = incl;
 }
 
 // the kept pairs of interleaving blockIdx.x, in pair order, to staging[item_points[it] ..)
@@ -124,7 +131,7 @@ __global__ __launch_bounds__(256) void k3_q_emit(const K3QueueArgs a) {
   }
   __syncthreads();
   if (s_pre[64] == 0) return;
-  const uint32_t off = a.item_points[it];
+  const uint32_t off = a.item_points[it] + a.tile_sum[it / Q_SCAN_TILE];   // (within the tile + the tile's offset: k3_q_scan, k3_q_scan_tiles)
   if ((unsigned long long)off + s_pre[64] > a.staging_cap) return;          // (the host sees out[0] > staging_cap and reports it)
   const demi_dpor_trace_entry* T = a.arena + (size_t)(a.base_id + it) * DEMI_DPOR_MAX_TRACE;
   const demi_dpor_pair* P = a.pairs + (size_t)it * a.max_pairs;
