@@ -497,6 +497,24 @@ struct K3RefArgs {
   unsigned long long* counters;                       // [0] records wanted (may exceed recs_cap: the host grows and re-runs), [1] table full
 };
 
+// A reference-order launch's fixed-size results - the verdicts, the round's and the filter's counters, the record counts - written
+// straight into the launch's pinned host area by ONE kernel behind the filter (they used to be four copies, each a dispatch of its
+// own on a stream where every dispatch waits for the one before it).
+struct K3RefResults {
+  const demi_verdict* verdicts; const unsigned long long* round_counters; const unsigned long long* filter_counters; const uint32_t* rec_cnt;
+  uint32_t n;
+  demi_verdict* h_verdicts; unsigned long long* h_counters /* [0..3] the round's, [4..5] the filter's */; uint32_t* h_rec_cnt;
+};
+__global__ __launch_bounds__(256) void k3_ref_results(const K3RefResults a) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < a.n) {
+    *reinterpret_cast<uint4*>(&a.h_verdicts[i]) = *reinterpret_cast<const uint4*>(&a.verdicts[i]);
+    a.h_rec_cnt[i] = a.rec_cnt[i];
+  }
+  if (i < 4) a.h_counters[i] = a.round_counters[i];
+  else if (i < 6) a.h_counters[i] = a.filter_counters[i - 4];
+}
+
 // A state of the commit's table only grows AS A NUMBER: the explored bit is the top bit and is never cleared, the queued mark
 // below it is only replaced by a higher one (dpor_host.hpp RefBook::absorb).  So a change is merged with a maximum, and the
 // order in which batches of changes arrive - a launch's on its stream, a record fetch's on another - does not matter: an
