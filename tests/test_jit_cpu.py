@@ -352,7 +352,7 @@ def test_array_tables_through_the_code_generator(oracle, tmp_path, seed, wide, a
     if seed in (1, 3):
         try:
             size, kernel = _native.specialize_check(model.to_struct())
-            assert size > 10000 and kernel.count("k1_random_explore") == 12 and "k2_replay" in kernel and "k3_dpor" in kernel
+            assert size > 10000 and kernel.count("k1_random_explore") == 13 and "k2_replay" in kernel and "k3_dpor" in kernel
         except _native.DemiError as e:
             if "hiprtc not found" not in str(e):
                 raise
